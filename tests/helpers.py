@@ -1,0 +1,128 @@
+"""Shared test helpers: ULP distance, f64 closed forms, input generators."""
+import json
+from pathlib import Path
+
+import numpy as np
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def kats():
+    return json.loads((GOLDEN / "ref_kats.json").read_text())
+
+
+def bits_to_f32(bits):
+    return np.array(bits, dtype=np.uint32).view(np.float32)
+
+
+def ulp_diff(a, b):
+    """Element-wise ULP distance between two f32 arrays; +0 == -0; NaN == NaN."""
+    a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+    b = np.ascontiguousarray(b, dtype=np.float32).ravel()
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    d = np.abs(ai - bi)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return np.where(both_nan, 0, d)
+
+
+def assert_ulp(actual, expected, max_ulp, what=""):
+    d = ulp_diff(actual, expected)
+    worst = int(d.max()) if d.size else 0
+    assert worst <= max_ulp, "%s: max ULP distance %d > %d (at flat index %d)" % (
+        what, worst, max_ulp, int(d.argmax()))
+
+
+def bit_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(
+        a.view(np.uint8), b.view(np.uint8))
+
+
+# ---- closed forms (f64) ------------------------------------------------------
+
+def imdct_analytical(x, scale):
+    """mdct.rs:154-175: y[i] = scale * sum_j x[j] cos(pi/(4N) (2i+1+N)(2j+1))."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[-1]
+    i = np.arange(2 * n)[:, None]
+    j = np.arange(n)[None, :]
+    c = np.cos(np.pi / (4 * n) * ((2 * i + 1 + n) * (2 * j + 1)))
+    return scale * (x @ c.T)
+
+
+def dft_naive(x):
+    x = np.asarray(x, dtype=np.complex128)
+    n = x.size
+    k = np.arange(n)
+    w = np.exp(-2j * np.pi * ((k[:, None] * k[None, :]) % n) / n)
+    return w @ x
+
+
+def imdct36_analytical(x):
+    x = np.asarray(x, dtype=np.float64)
+    i = np.arange(36)[:, None]
+    j = np.arange(18)[None, :]
+    return (np.cos(np.pi / 72 * ((2 * i + 19) * (2 * j + 1))) * x).sum(axis=1)
+
+
+def imdct12_analytical(x6):
+    x6 = np.asarray(x6, dtype=np.float64)
+    i = np.arange(12)[:, None]
+    k = np.arange(6)[None, :]
+    return (np.cos(np.pi / 24 * ((2 * i + 7) * (2 * k + 1))) * x6).sum(axis=1)
+
+
+def dct32_analytical(x):
+    x = np.asarray(x, dtype=np.float64)
+    i = np.arange(32)[:, None]
+    j = np.arange(32)[None, :]
+    return (np.cos(np.pi / 32 * i * (j + 0.5)) * x).sum(axis=1)
+
+
+def mdct_forward(x2n):
+    """Forward MDCT (2N -> N) matching imdct_analytical's kernel (for TDAC tests)."""
+    x = np.asarray(x2n, dtype=np.float64)
+    n = x.shape[-1] // 2
+    i = np.arange(2 * n)[None, :]
+    j = np.arange(n)[:, None]
+    c = np.cos(np.pi / (4 * n) * ((2 * i + 1 + n) * (2 * j + 1)))
+    return x @ c.T
+
+
+# ---- input generators --------------------------------------------------------
+
+def aac_spectra(rng, shape_prefix, band_limit=672):
+    """SURVEY 8d config 2 spectra: N(0,1) * 2^u, u ~ U{-8..12} per 16-line band,
+    zero above band_limit, with a few denormals / signed zeros sprinkled in."""
+    shape = tuple(shape_prefix) + (1024,)
+    x = rng.standard_normal(shape).astype(np.float32)
+    u = rng.integers(-8, 13, size=tuple(shape_prefix) + (64,))
+    x *= np.repeat(np.exp2(u).astype(np.float32), 16, axis=-1)
+    x[..., band_limit:] = 0.0
+    flat = x.reshape(-1)
+    idx = rng.integers(0, flat.size, size=max(4, flat.size // 4096))
+    flat[idx[0::4]] = np.float32(1e-41)
+    flat[idx[1::4]] = np.float32(-0.0)
+    flat[idx[2::4]] = np.float32(-3e-39)
+    return x
+
+
+def aac_sequence_chain(rng, n_frames, p_switch=0.25):
+    """Legal window-sequence state machine {0->0/1, 1->2/3, 2->2/3, 3->0/1} plus
+    per-frame window shapes; prev_shape[t] = shape[t-1] (ics/mod.rs:119, 172-177)."""
+    seq = np.zeros(n_frames, dtype=np.uint8)
+    cur = 0
+    for t in range(n_frames):
+        if cur in (0, 3):
+            nxt = 1 if rng.random() < p_switch else 0
+        else:
+            nxt = 2 if rng.random() < 0.5 else 3
+        seq[t] = nxt
+        cur = nxt
+    shape = rng.integers(0, 2, size=n_frames).astype(np.uint8)
+    prev = np.concatenate(([rng.integers(0, 2)], shape[:-1])).astype(np.uint8)
+    return seq, shape, prev
