@@ -1,0 +1,217 @@
+/*
+ * symaccel.h -- C ABI of the MI355X-native batched synthesis backend for Symphonia's DSP hot path.
+ *
+ * This is the drop-in boundary (SURVEY.md 8b / DESIGN.md "Boundary"): every entry point is what a
+ * thin `unsafe extern "C"` block in a Rust shim crate binds in place of one reference call site.
+ * Plain pointers and sizes only; no C++ types, no exceptions, no torch types.  The reference
+ * items replaced are cited per function as <file>:<lines> relative to the Symphonia tree (0.6.1).
+ *
+ * Conventions
+ *  - All `_device` entry points take DEVICE pointers (HBM resident) and only enqueue work on the
+ *    context's stream; call symaccel_sync() (or synchronise the stream you handed in) before
+ *    reading results.  Entry points without the suffix take HOST pointers, stage through HBM and
+ *    return after the results are in the host buffers.
+ *  - "chain" = one channel of one stream: the unit that carries overlap state from one codec
+ *    frame to the next.  Batches are chain-major: x[chain][frame][...].  Chains are independent.
+ *  - State buffers (`*_io`) are read at the first frame of the batch and hold the state after the
+ *    last frame on return, so consecutive calls continue a stream exactly like consecutive
+ *    decode() calls on the reference decoder.  reset() in the reference == zero the state.
+ *  - Return value: SYMACCEL_OK (0) or a negative symaccel_status.  INVALID_ARG corresponds to the
+ *    reference's assert!/panic class, UNSUPPORTED to Error::Unsupported, DEVICE/OOM to
+ *    Error::IoError (symphonia-core/src/errors.rs:38-54).  symaccel_strerror() returns static
+ *    strings (usable as &'static str).  On error no output buffer is partially trusted: the
+ *    caller clears its AudioBuffer as symphonia-core/src/codecs/audio.rs:278 requires.
+ *  - Thread safety: distinct contexts may be used from distinct threads concurrently; one context
+ *    is externally synchronised (matches `&mut self` on AudioDecoder, audio.rs:251-298).
+ *  - There is NO CPU fallback: without a HIP device symaccel_ctx_create() fails with
+ *    SYMACCEL_ERR_DEVICE.
+ */
+#ifndef SYMACCEL_H
+#define SYMACCEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYMACCEL_ABI_VERSION 1
+
+typedef enum symaccel_status {
+    SYMACCEL_OK = 0,
+    SYMACCEL_ERR_INVALID_ARG = -1, /* reference: assert!/panic (e.g. mdct.rs:37-40, 76-78) */
+    SYMACCEL_ERR_UNSUPPORTED = -2, /* reference: Error::Unsupported */
+    SYMACCEL_ERR_DEVICE = -3,      /* HIP error / no device; reference class: Error::IoError */
+    SYMACCEL_ERR_OOM = -4,         /* device or host allocation failed */
+} symaccel_status;
+
+typedef struct symaccel_ctx symaccel_ctx;
+
+int symaccel_abi_version(void);
+const char *symaccel_strerror(int status);
+/* Last HIP error text seen by this context ("" if none); static storage inside the context. */
+const char *symaccel_last_error(const symaccel_ctx *ctx);
+
+/* Create a context on HIP device `device` (ordinal).  Builds every constant table on the host
+ * with the same libm calls the reference uses and uploads them. */
+int symaccel_ctx_create(int device, symaccel_ctx **out);
+void symaccel_ctx_destroy(symaccel_ctx *ctx);
+/* Use an existing hipStream_t (e.g. PyTorch's current stream).  NULL = the context's own stream. */
+int symaccel_ctx_set_stream(symaccel_ctx *ctx, void *hip_stream);
+/* Block until everything enqueued on the context's stream has finished. */
+int symaccel_sync(symaccel_ctx *ctx);
+/* Tuning knob: frames (granules / blocks) one wavefront walks sequentially before the next
+ * segment starts with a one-frame halo recompute.  0 = library default. */
+int symaccel_ctx_set_segment(symaccel_ctx *ctx, int frames_per_segment);
+
+/* ------------------------------------------------------------------ core dsp (symphonia-core) */
+
+/* Fft::fft / Fft::fft_inplace (symphonia-core/src/dsp/fft/no_simd.rs:96-140): `count` forward
+ * complex FFTs of size n (power of two, 2 <= n <= 4096), interleaved (re, im) f32.
+ * d_in == d_out is allowed (fft_inplace). */
+int symaccel_fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count);
+
+/* Imdct::new_scaled(n, scale).imdct(spec, out) (symphonia-core/src/dsp/mdct.rs:35-146), `count`
+ * times: spec[count][n] -> out[count][2n].  n = power of two, 4 <= n <= 8192. */
+int symaccel_imdct_f32_device(symaccel_ctx *ctx, int n, double scale, const float *d_spec,
+                              float *d_out, size_t count);
+int symaccel_imdct_f32(symaccel_ctx *ctx, int n, double scale, const float *h_spec, float *h_out,
+                       size_t count);
+
+/* --------------------------------------------------------------------------------- AAC-LC */
+
+#define SYMACCEL_AAC_ONLY_LONG 0u   /* symphonia-codec-aac/src/aac/common.rs:17-20 */
+#define SYMACCEL_AAC_LONG_START 1u
+#define SYMACCEL_AAC_EIGHT_SHORT 2u
+#define SYMACCEL_AAC_LONG_STOP 3u
+/* one side byte per channel-frame: window_sequence | window_shape<<2 | prev_window_shape<<3 */
+#define SYMACCEL_AAC_SIDE(seq, shape, prev_shape) \
+    ((uint8_t)(((seq) & 3u) | (((shape) & 1u) << 2) | (((prev_shape) & 1u) << 3)))
+
+/* Dsp::synth (symphonia-codec-aac/src/aac/dsp.rs:57-158) for n_chains x frames_per_chain
+ * channel-frames: coeffs[chain][frame][1024] f32 (post pulse/TNS, i.e. what Ics::synth_channel
+ * hands to Dsp::synth, ics/mod.rs:449-468), side[chain][frame], delay_io[chain][1024],
+ * pcm[chain][frame][1024]. */
+int symaccel_aac_synth_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side,
+                              float *d_delay_io, float *d_pcm, size_t n_chains,
+                              size_t frames_per_chain);
+int symaccel_aac_synth(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *h_side,
+                       float *h_delay_io, float *h_pcm, size_t n_chains, size_t frames_per_chain);
+
+/* --------------------------------------------------------------------------------- MP3 */
+
+#define SYMACCEL_MP3_LONG 0u /* BlockType, symphonia-bundle-mp3/src/layer3/common.rs:174-185 */
+#define SYMACCEL_MP3_START 1u
+#define SYMACCEL_MP3_SHORT 2u
+#define SYMACCEL_MP3_END 3u
+
+/* per granule-channel side record: the GranuleChannel fields the synthesis tail reads */
+typedef struct symaccel_mp3_side {
+    uint8_t block_type; /* SYMACCEL_MP3_* */
+    uint8_t is_mixed;   /* BlockType::Short { is_mixed } */
+    uint16_t rzero;     /* GranuleChannel::rzero as left by the parser (<= 576) */
+} symaccel_mp3_side;
+
+/* The per-channel tail of Layer3::decode's granule loop (layer3/mod.rs:440-476): reorder,
+ * antialias, hybrid_synthesis, frequency_inversion (layer3/hybrid_synthesis.rs:153-485) and
+ * synthesis::synthesis with n_frames = 18 (synthesis.rs:158-336).
+ * xr[chain][granule][576] f32 = samples after requantize + stereo; side[chain][granule];
+ * sample_rate_idx 0..8 selects the scale-factor-band table used by reorder.
+ * State per chain: overlap_io[32][18], vvec_io[16][64], vfront_io (int32, 0..15).
+ * pcm[chain][granule][576]. */
+int symaccel_mp3_synth_device(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_side,
+                              int sample_rate_idx, float *d_overlap_io, float *d_vvec_io,
+                              int32_t *d_vfront_io, float *d_pcm, size_t n_chains,
+                              size_t granules_per_chain);
+int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_side *h_side,
+                       int sample_rate_idx, float *h_overlap_io, float *h_vvec_io,
+                       int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
+                       size_t granules_per_chain);
+
+/* --------------------------------------------------------------------------------- Vorbis */
+
+/* DspChannel::synth for every channel of every block (symphonia-codec-vorbis/src/dsp.rs:68-126,
+ * called from lib.rs:296-331).  A chain's spectra (floor x residue, lib.rs:282-292) are packed
+ * back to back: block b with flag f contributes bs_f/2 floats; a chain starts at
+ * d_spectra + chain * spec_stride.  block_flag[chain][block] in {0,1}.  prev_flag_io[chain]:
+ * -1 = no previous block (Dsp::prev_block_flag == None), else 0/1.  overlap_io[chain][bs1/2].
+ * PCM is packed the same way: block b contributes (prev_n + n)/4 floats (lib.rs:303); a chain
+ * starts at d_pcm + chain * pcm_stride.  6 <= bs0_exp <= bs1_exp <= 13. */
+int symaccel_vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra,
+                                 size_t spec_stride, const uint8_t *d_block_flag,
+                                 int32_t *d_prev_flag_io, float *d_overlap_io, float *d_pcm,
+                                 size_t pcm_stride, size_t n_chains, size_t blocks_per_chain);
+int symaccel_vorbis_synth(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *h_spectra,
+                          size_t spec_stride, const uint8_t *h_block_flag, int32_t *h_prev_flag_io,
+                          float *h_overlap_io, float *h_pcm, size_t pcm_stride, size_t n_chains,
+                          size_t blocks_per_chain);
+
+/* Inverse coupling (lib.rs:252-278) of `n_pairs` (magnitude, angle) vector pairs of n floats,
+ * in place: pair p uses d_residue + mag_index[p]*n and d_residue + ang_index[p]*n.  Pairs are
+ * applied in order (coupling steps may chain).  Index arrays are HOST arrays (<= 256 entries). */
+int symaccel_vorbis_inverse_coupling_device(symaccel_ctx *ctx, float *d_residue, size_t n,
+                                            const uint32_t *mag_index, const uint32_t *ang_index,
+                                            size_t n_pairs);
+/* Dot product floor[i] *= residue[i] over `total` floats (lib.rs:282-292). */
+int symaccel_vorbis_dot_product_device(symaccel_ctx *ctx, float *d_floor, const float *d_residue,
+                                       size_t total);
+/* Residue type-2 de-interleave (residue.rs:177-218): type2[count][n2*n_ch] -> planar[count][n_ch][n2]. */
+int symaccel_vorbis_deinterleave2_device(symaccel_ctx *ctx, const float *d_type2, float *d_planar,
+                                         int n_ch, size_t n2, size_t count);
+/* Floor-1 curve synthesis, steps 1 and 2 (floor.rs:568-653, 776-825) for `count` channel-blocks
+ * sharing one floor configuration: x_list[n_posts] (HOST, from the setup header), multiplier
+ * 1..4, y[count][n_posts] (DEVICE, decoded floor1_Y values), floor[count][n] out. */
+int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts,
+                                  int multiplier, const uint32_t *d_y, uint32_t n, float *d_floor,
+                                  size_t count);
+
+/* --------------------------------------------------------------------------------- FLAC */
+
+#define SYMACCEL_FLAC_VERBATIM 0u /* constant / verbatim subframe: predictor is a no-op */
+#define SYMACCEL_FLAC_FIXED 1u    /* fixed_predict, decoder.rs:663-710 */
+#define SYMACCEL_FLAC_LPC 2u      /* lpc_predict, decoder.rs:716-752 */
+
+typedef struct symaccel_flac_desc {
+    uint8_t kind;        /* SYMACCEL_FLAC_* */
+    uint8_t order;       /* fixed: 0..4, lpc: 1..32 (<= blocksize) */
+    uint8_t shift;       /* qlp_coeff_shift, 0..15 (negative shifts: reference returns Unsupported) */
+    uint8_t wasted_bits; /* dropped_bps for samples_shl, decoder.rs:396-409 */
+} symaccel_flac_desc;
+
+/* Predictor restore for n_blocks subframes of `blocksize` samples, in place:
+ * buf[block][blocksize] i32 holds `order` warm-up samples followed by residuals
+ * (decoder.rs:446-511); coeffs[block][32] in bitstream order (first coefficient multiplies the
+ * most recent sample; unused entries ignored).  Bit-exact i64 accumulation, wrapping i32 add. */
+int symaccel_flac_restore_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
+                                 const int32_t *d_coeffs, size_t n_blocks, size_t blocksize);
+int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac_desc *h_desc,
+                          const int32_t *h_coeffs, size_t n_blocks, size_t blocksize);
+/* decorrelate_{left_side,mid_side,right_side} (decoder.rs:32-82) then `<< out_shift`
+ * (decoder.rs:239-242, out_shift = 32 - bits_per_sample, 0 = none) over n_pairs channel pairs:
+ * mode[pair] in {0 independent, 1 left/side, 2 mid/side, 3 right/side}; ch0/ch1[pair][blocksize]. */
+int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, int32_t *d_ch0,
+                                     int32_t *d_ch1, size_t n_pairs, size_t blocksize,
+                                     uint32_t out_shift);
+
+/* ------------------------------------------------------------- table read-back (for tests) */
+
+enum symaccel_table {
+    SYMACCEL_TABLE_AAC_KBD_LONG = 0,   /* 1024 f32, window.rs:37-52 alpha 4 */
+    SYMACCEL_TABLE_AAC_KBD_SHORT = 1,  /* 128 */
+    SYMACCEL_TABLE_AAC_SINE_LONG = 2,  /* 1024, window.rs:30-35 */
+    SYMACCEL_TABLE_AAC_SINE_SHORT = 3, /* 128 */
+    SYMACCEL_TABLE_MP3_SYNTH_D = 4,    /* 512, synthesis.rs:13-142 */
+    SYMACCEL_TABLE_MP3_IMDCT_WIN = 5,  /* 4*36, hybrid_synthesis.rs:53-92 */
+    SYMACCEL_TABLE_VORBIS_FLOOR1_DB = 6 /* 256, vorbis floor.rs:21-112 */
+};
+/* Copies the HOST copy of a constant table; returns the number of floats, or a negative status. */
+int symaccel_table_f32(const symaccel_ctx *ctx, int table, float *dst, size_t capacity);
+/* Imdct twiddles (n/2 complex) and FFT merge twiddles W_n (n/2 complex), as generated on the host. */
+int symaccel_imdct_twiddles(int n, double scale, float *dst);
+int symaccel_fft_twiddles(int n, float *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYMACCEL_H */

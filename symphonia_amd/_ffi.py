@@ -1,0 +1,119 @@
+"""ctypes binding of the symaccel C ABI (include/symaccel.h).
+
+`Library(path)` binds one shared object; `default_library()` binds the hipcc-built
+symphonia_amd/libsymaccel.so and raises if it is missing -- there is no CPU path.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+DEFAULT_SO = HERE / "libsymaccel.so"
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_UNSUPPORTED = -2
+ERR_DEVICE = -3
+ERR_OOM = -4
+
+TABLE_AAC_KBD_LONG, TABLE_AAC_KBD_SHORT, TABLE_AAC_SINE_LONG, TABLE_AAC_SINE_SHORT = 0, 1, 2, 3
+TABLE_MP3_SYNTH_D, TABLE_MP3_IMDCT_WIN, TABLE_VORBIS_FLOOR1_DB = 4, 5, 6
+
+# every symbol include/symaccel.h declares (tests/test_abi.py checks the built library exports all)
+ABI_SYMBOLS = [
+    "symaccel_abi_version", "symaccel_strerror", "symaccel_last_error", "symaccel_ctx_create",
+    "symaccel_ctx_destroy", "symaccel_ctx_set_stream", "symaccel_sync", "symaccel_ctx_set_segment",
+    "symaccel_fft_c32_device", "symaccel_imdct_f32_device", "symaccel_imdct_f32",
+    "symaccel_aac_synth_device", "symaccel_aac_synth", "symaccel_mp3_synth_device", "symaccel_mp3_synth",
+    "symaccel_vorbis_synth_device", "symaccel_vorbis_synth", "symaccel_vorbis_inverse_coupling_device",
+    "symaccel_vorbis_dot_product_device", "symaccel_vorbis_deinterleave2_device",
+    "symaccel_vorbis_floor1_device", "symaccel_flac_restore_device", "symaccel_flac_restore",
+    "symaccel_flac_decorrelate_device", "symaccel_table_f32", "symaccel_imdct_twiddles",
+    "symaccel_fft_twiddles",
+]
+
+_vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
+
+
+class SymaccelError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s (status %d)" % (message, status))
+        self.status = status
+
+
+class Library:
+    def __init__(self, path=None):
+        path = Path(path) if path is not None else DEFAULT_SO
+        if not path.exists():
+            raise FileNotFoundError(
+                "%s is missing: build it with `python -m symphonia_amd.build` (hipcc, gfx950). "
+                "symphonia_amd has no CPU fallback." % path)
+        self.path = path
+        self.dll = C.CDLL(str(path))
+        d = self.dll
+        d.symaccel_strerror.restype = C.c_char_p
+        d.symaccel_strerror.argtypes = [_i]
+        d.symaccel_last_error.restype = C.c_char_p
+        d.symaccel_last_error.argtypes = [_vp]
+        d.symaccel_ctx_create.argtypes = [_i, C.POINTER(_vp)]
+        d.symaccel_ctx_destroy.argtypes = [_vp]
+        d.symaccel_ctx_destroy.restype = None
+        d.symaccel_ctx_set_stream.argtypes = [_vp, _vp]
+        d.symaccel_sync.argtypes = [_vp]
+        d.symaccel_ctx_set_segment.argtypes = [_vp, _i]
+        d.symaccel_fft_c32_device.argtypes = [_vp, _i, _vp, _vp, _sz]
+        d.symaccel_imdct_f32_device.argtypes = [_vp, _i, _d, _vp, _vp, _sz]
+        d.symaccel_imdct_f32.argtypes = [_vp, _i, _d, _vp, _vp, _sz]
+        d.symaccel_aac_synth_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_aac_synth.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_mp3_synth_device.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_mp3_synth.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_vorbis_synth_device.argtypes = [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
+        d.symaccel_vorbis_synth.argtypes = [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
+        d.symaccel_vorbis_inverse_coupling_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz]
+        d.symaccel_vorbis_dot_product_device.argtypes = [_vp, _vp, _vp, _sz]
+        d.symaccel_vorbis_deinterleave2_device.argtypes = [_vp, _vp, _vp, _i, _sz, _sz]
+        d.symaccel_vorbis_floor1_device.argtypes = [_vp, _vp, _i, _i, _vp, _u32, _vp, _sz]
+        d.symaccel_flac_restore_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_flac_restore.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_flac_decorrelate_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz, _u32]
+        d.symaccel_table_f32.argtypes = [_vp, _i, _vp, _sz]
+        d.symaccel_imdct_twiddles.argtypes = [_i, _d, _vp]
+        d.symaccel_fft_twiddles.argtypes = [_i, _vp]
+
+    def check(self, status, ctx=None):
+        if status < 0:
+            msg = self.dll.symaccel_strerror(status).decode()
+            if ctx:
+                extra = self.dll.symaccel_last_error(ctx).decode()
+                if extra:
+                    msg += ": " + extra
+            raise SymaccelError(status, msg)
+        return status
+
+    # table read-back (host copies; no device needed)
+    def table(self, which):
+        buf = np.empty(1024, dtype=np.float32)
+        n = self.check(self.dll.symaccel_table_f32(None, which, buf.ctypes.data, buf.size))
+        return buf[:n].copy()
+
+    def imdct_twiddles(self, n, scale):
+        buf = np.empty(n // 2, dtype=np.complex64)
+        self.check(self.dll.symaccel_imdct_twiddles(n, float(scale), buf.ctypes.data))
+        return buf
+
+    def fft_twiddles(self, n):
+        buf = np.empty(n // 2, dtype=np.complex64)
+        self.check(self.dll.symaccel_fft_twiddles(n, buf.ctypes.data))
+        return buf
+
+
+_default = None
+
+
+def default_library():
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default

@@ -1,0 +1,573 @@
+// Context management and the C-ABI entry points (argument checking, host<->HBM staging, state
+// double-buffering).  The kernels live in the .hip files; nothing here computes audio.
+#include <cstring>
+#include <new>
+
+#include "symaccel_internal.h"
+
+using namespace symaccel;
+
+namespace symaccel {
+
+int ctx_fail(symaccel_ctx *ctx, hipError_t err, const char *where) {
+    if (ctx) {
+        ctx->last_error = std::string(where) + ": " + hipGetErrorString(err);
+    }
+    return err == hipErrorOutOfMemory ? SYMACCEL_ERR_OOM : SYMACCEL_ERR_DEVICE;
+}
+
+int ctx_alloc(symaccel_ctx *ctx, void **out, size_t bytes, bool tracked) {
+    *out = nullptr;
+    if (bytes == 0) bytes = 16;
+    SYM_GPU(ctx, hipMalloc(out, bytes));
+    if (tracked) ctx->allocations.push_back(*out);
+    return SYMACCEL_OK;
+}
+
+int ctx_scratch(symaccel_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) {
+            // earlier work on the stream may still read the old scratch
+            SYM_GPU(ctx, hipStreamSynchronize(ctx->stream));
+            SYM_GPU(ctx, hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+        }
+        size_t want = bytes + bytes / 4 + 4096;
+        SYM_TRY(ctx_alloc(ctx, &ctx->scratch, want, false));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return SYMACCEL_OK;
+}
+
+int ctx_upload(symaccel_ctx *ctx, const void *src, size_t bytes, const void **out) {
+    void *d = nullptr;
+    SYM_TRY(ctx_alloc(ctx, &d, bytes));
+    SYM_GPU(ctx, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    *out = d;
+    return SYMACCEL_OK;
+}
+
+int get_imdct_plan(symaccel_ctx *ctx, int n, double scale, const ImdctPlan **out) {
+    uint64_t bits;
+    std::memcpy(&bits, &scale, 8);
+    auto key = std::make_pair(n, bits);
+    auto it = ctx->imdct_plans.find(key);
+    if (it == ctx->imdct_plans.end()) {
+        std::vector<cpx> tw((size_t)n / 2);
+        make_imdct_twiddles(n, scale, tw.data());
+        const void *d = nullptr;
+        SYM_TRY(ctx_upload(ctx, tw.data(), tw.size() * sizeof(cpx), &d));
+        it = ctx->imdct_plans.emplace(key, ImdctPlan{n, (cpx *)d}).first;
+    }
+    *out = &it->second;
+    return SYMACCEL_OK;
+}
+
+int get_vorbis_window(symaccel_ctx *ctx, int bs, const float **out) {
+    auto it = ctx->vorbis_windows.find(bs);
+    if (it == ctx->vorbis_windows.end()) {
+        std::vector<float> w((size_t)bs / 2);
+        make_vorbis_window(bs, w.data());
+        const void *d = nullptr;
+        SYM_TRY(ctx_upload(ctx, w.data(), w.size() * sizeof(float), &d));
+        it = ctx->vorbis_windows.emplace(bs, (float *)d).first;
+    }
+    *out = it->second;
+    return SYMACCEL_OK;
+}
+
+namespace {
+
+// reorder (hybrid_synthesis.rs:153-215) as a gather: for each (sample-rate, mixed) the source
+// index of every destination line, and for every incoming rzero the index `i` the reference's
+// interleave loop stops at (bands that start at or beyond rzero are skipped).
+void build_reorder_tables(const HostTables &t, std::vector<int32_t> &map, std::vector<int32_t> &end) {
+    map.assign(9 * 2 * 576, 0);
+    end.assign(9 * 2 * 577, 0);
+    for (int sr = 0; sr < 9; ++sr) {
+        for (int mixed = 0; mixed < 2; ++mixed) {
+            const int32_t *bands;
+            int n_bands;
+            if (mixed) {
+                bands = t.mp3_sfb_mixed[sr] + t.mp3_sfb_switch[sr];
+                n_bands = t.mp3_sfb_mixed_len[sr] - t.mp3_sfb_switch[sr];
+            } else {
+                bands = t.mp3_sfb_short[sr];
+                n_bands = 40;
+            }
+            int32_t *m = &map[(size_t)(sr * 2 + mixed) * 576];
+            int32_t *e = &end[(size_t)(sr * 2 + mixed) * 577];
+            for (int i = 0; i < 576; ++i) m[i] = i;
+            const int start = bands[0];
+            for (int rz = 0; rz <= 576; ++rz) e[rz] = start;
+            int i = start;
+            for (int b = 0; b + 3 < n_bands; b += 3) {
+                const int s0 = bands[b], s1 = bands[b + 1], s2 = bands[b + 2], s3 = bands[b + 3];
+                int len = s1 - s0;
+                if (s2 - s1 < len) len = s2 - s1;
+                if (s3 - s2 < len) len = s3 - s2;
+                for (int k = 0; k < len; ++k) {
+                    if (i + 2 < 576) {
+                        m[i + 0] = s0 + k;
+                        m[i + 1] = s1 + k;
+                        m[i + 2] = s2 + k;
+                    }
+                    i += 3;
+                }
+                // this band is processed iff s0 < rzero
+                for (int rz = s0 + 1; rz <= 576; ++rz) e[rz] = i;
+            }
+        }
+    }
+}
+
+int upload_tables(symaccel_ctx *ctx) {
+    const HostTables &t = host_tables();
+    DevTables &d = ctx->dev;
+    const void *p = nullptr;
+#define UP(field, src, bytes)                         \
+    SYM_TRY(ctx_upload(ctx, (src), (bytes), &p));     \
+    d.field = (decltype(d.field))p
+    UP(aac_kbd_long, t.aac_kbd_long.data(), 1024 * 4);
+    UP(aac_kbd_short, t.aac_kbd_short.data(), 128 * 4);
+    UP(aac_sine_long, t.aac_sine_long.data(), 1024 * 4);
+    UP(aac_sine_short, t.aac_sine_short.data(), 128 * 4);
+    UP(aac_tw_long, t.aac_tw_long.data(), 512 * sizeof(cpx));
+    UP(aac_tw_short, t.aac_tw_short.data(), 64 * sizeof(cpx));
+    UP(fft_merge, t.fft_merge.data(), t.fft_merge.size() * sizeof(cpx));
+    UP(small16, t.small16, sizeof t.small16);
+    UP(small32, t.small32, sizeof t.small32);
+    UP(small16_form, t.small16_form, sizeof t.small16_form);
+    UP(small32_form, t.small32_form, sizeof t.small32_form);
+    std::vector<float> mc(MP3C_TOTAL, 0.0f);
+    std::memcpy(&mc[MP3C_IMDCT_WIN], t.mp3_imdct_win, 144 * 4);
+    std::memcpy(&mc[MP3C_COS12], t.mp3_cos12, 36 * 4);
+    std::memcpy(&mc[MP3C_CS], t.mp3_cs, 8 * 4);
+    std::memcpy(&mc[MP3C_CA], t.mp3_ca, 8 * 4);
+    std::memcpy(&mc[MP3C_DCT_IV], t.mp3_dct_iv_scale, 18 * 4);
+    std::memcpy(&mc[MP3C_SDCT18], t.mp3_sdct18_scale, 9 * 4);
+    std::memcpy(&mc[MP3C_SDCT9_D], t.mp3_sdct9_d, 7 * 4);
+    std::memcpy(&mc[MP3C_COS16], t.mp3_cos16, 16 * 4);
+    std::memcpy(&mc[MP3C_COS8], t.mp3_cos8, 8 * 4);
+    std::memcpy(&mc[MP3C_COS4], t.mp3_cos4, 4 * 4);
+    std::memcpy(&mc[MP3C_COS2], t.mp3_cos2, 2 * 4);
+    mc[MP3C_COS1] = t.mp3_cos1;
+    std::memcpy(&mc[MP3C_SYNTH_D], t.mp3_synth_d, 512 * 4);
+    UP(mp3_consts, mc.data(), mc.size() * 4);
+    std::vector<int32_t> rmap, rend;
+    build_reorder_tables(t, rmap, rend);
+    UP(mp3_reorder_map, rmap.data(), rmap.size() * 4);
+    UP(mp3_reorder_end, rend.data(), rend.size() * 4);
+    UP(vorbis_floor1_db, t.vorbis_floor1_db, 256 * 4);
+#undef UP
+    return SYMACCEL_OK;
+}
+
+// Host-pointer convenience wrappers stage through tracked-free temporaries.
+struct DevBuf {
+    symaccel_ctx *ctx;
+    void *p = nullptr;
+    explicit DevBuf(symaccel_ctx *c) : ctx(c) {}
+    ~DevBuf() {
+        if (p) hipFree(p);
+    }
+    int alloc(size_t bytes) { return ctx_alloc(ctx, &p, bytes, false); }
+    int from_host(const void *h, size_t bytes) {
+        SYM_TRY(alloc(bytes));
+        if (bytes) SYM_GPU(ctx, hipMemcpyAsync(p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SYMACCEL_OK;
+    }
+    int to_host(void *h, size_t bytes) {
+        if (bytes) SYM_GPU(ctx, hipMemcpyAsync(h, p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return SYMACCEL_OK;
+    }
+};
+
+bool pow2(long v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+}  // namespace symaccel
+
+// ------------------------------------------------------------------------------------ ABI
+
+extern "C" {
+
+int symaccel_abi_version(void) { return SYMACCEL_ABI_VERSION; }
+
+const char *symaccel_strerror(int status) {
+    switch (status) {
+        case SYMACCEL_OK: return "ok";
+        case SYMACCEL_ERR_INVALID_ARG: return "symaccel: invalid argument";
+        case SYMACCEL_ERR_UNSUPPORTED: return "symaccel: unsupported configuration";
+        case SYMACCEL_ERR_DEVICE: return "symaccel: HIP device error";
+        case SYMACCEL_ERR_OOM: return "symaccel: out of memory";
+        default: return "symaccel: unknown status";
+    }
+}
+
+const char *symaccel_last_error(const symaccel_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int symaccel_ctx_create(int device, symaccel_ctx **out) {
+    if (!out) return SYMACCEL_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SYMACCEL_ERR_DEVICE;  // no CPU path
+    if (device < 0 || device >= count) return SYMACCEL_ERR_INVALID_ARG;
+    symaccel_ctx *ctx = new (std::nothrow) symaccel_ctx();
+    if (!ctx) return SYMACCEL_ERR_OOM;
+    ctx->device = device;
+    int st = SYMACCEL_OK;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
+        st = SYMACCEL_ERR_DEVICE;
+    } else {
+        ctx->stream = ctx->own_stream;
+        st = upload_tables(ctx);
+    }
+    if (st != SYMACCEL_OK) {
+        symaccel_ctx_destroy(ctx);
+        return st;
+    }
+    *out = ctx;
+    return SYMACCEL_OK;
+}
+
+void symaccel_ctx_destroy(symaccel_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->allocations) hipFree(p);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int symaccel_ctx_set_stream(symaccel_ctx *ctx, void *hip_stream) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SYMACCEL_OK;
+}
+
+int symaccel_sync(symaccel_ctx *ctx) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipStreamSynchronize(ctx->stream));
+    return SYMACCEL_OK;
+}
+
+int symaccel_ctx_set_segment(symaccel_ctx *ctx, int frames_per_segment) {
+    if (!ctx || frames_per_segment < 0) return SYMACCEL_ERR_INVALID_ARG;
+    ctx->segment = frames_per_segment;
+    return SYMACCEL_OK;
+}
+
+// ---- core ---------------------------------------------------------------------------------
+
+int symaccel_fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count) {
+    if (!ctx || !pow2(n) || n < 2 || n > 4096) return SYMACCEL_ERR_INVALID_ARG;  // no_simd.rs:77-80
+    if (count == 0) return SYMACCEL_OK;
+    if (!d_in || !d_out) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_fft(ctx, n, d_in, d_out, count);
+}
+
+int symaccel_imdct_f32_device(symaccel_ctx *ctx, int n, double scale, const float *d_spec, float *d_out,
+                              size_t count) {
+    if (!ctx || !pow2(n) || n < 4 || n > 8192) return SYMACCEL_ERR_INVALID_ARG;  // mdct.rs:37-40
+    if (count == 0) return SYMACCEL_OK;
+    if (!d_spec || !d_out) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    const ImdctPlan *plan = nullptr;
+    SYM_TRY(get_imdct_plan(ctx, n, scale, &plan));
+    return launch_imdct(ctx, *plan, d_spec, d_out, count);
+}
+
+int symaccel_imdct_f32(symaccel_ctx *ctx, int n, double scale, const float *h_spec, float *h_out, size_t count) {
+    if (!ctx || !pow2(n) || n < 4 || n > 8192) return SYMACCEL_ERR_INVALID_ARG;
+    if (count == 0) return SYMACCEL_OK;
+    if (!h_spec || !h_out) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DevBuf in(ctx), out(ctx);
+    SYM_TRY(in.from_host(h_spec, count * (size_t)n * 4));
+    SYM_TRY(out.alloc(count * (size_t)n * 8));
+    SYM_TRY(symaccel_imdct_f32_device(ctx, n, scale, (const float *)in.p, (float *)out.p, count));
+    SYM_TRY(out.to_host(h_out, count * (size_t)n * 8));
+    return symaccel_sync(ctx);
+}
+
+// ---- AAC ----------------------------------------------------------------------------------
+
+int symaccel_aac_synth_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, float *d_delay_io,
+                              float *d_pcm, size_t n_chains, size_t frames_per_chain) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
+    if (!d_coeffs || !d_side || !d_delay_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    // Segments of one chain run concurrently: the first reads the incoming delay line while the
+    // last writes the outgoing one, so the new state goes to scratch and is copied back after.
+    void *scratch = nullptr;
+    const size_t state_bytes = n_chains * 1024 * sizeof(float);
+    SYM_TRY(ctx_scratch(ctx, state_bytes, &scratch));
+    SYM_TRY(launch_aac(ctx, d_coeffs, d_side, d_delay_io, (float *)scratch, d_pcm, n_chains, frames_per_chain));
+    SYM_GPU(ctx, hipMemcpyAsync(d_delay_io, scratch, state_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SYMACCEL_OK;
+}
+
+int symaccel_aac_synth(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *h_side, float *h_delay_io,
+                       float *h_pcm, size_t n_chains, size_t frames_per_chain) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
+    if (!h_coeffs || !h_side || !h_delay_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    const size_t nf = n_chains * frames_per_chain;
+    DevBuf coeffs(ctx), side(ctx), delay(ctx), pcm(ctx);
+    SYM_TRY(coeffs.from_host(h_coeffs, nf * 4096));
+    SYM_TRY(side.from_host(h_side, nf));
+    SYM_TRY(delay.from_host(h_delay_io, n_chains * 4096));
+    SYM_TRY(pcm.alloc(nf * 4096));
+    SYM_TRY(symaccel_aac_synth_device(ctx, (const float *)coeffs.p, (const uint8_t *)side.p, (float *)delay.p,
+                                      (float *)pcm.p, n_chains, frames_per_chain));
+    SYM_TRY(pcm.to_host(h_pcm, nf * 4096));
+    SYM_TRY(delay.to_host(h_delay_io, n_chains * 4096));
+    return symaccel_sync(ctx);
+}
+
+// ---- MP3 ----------------------------------------------------------------------------------
+
+int symaccel_mp3_synth_device(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_side,
+                              int sample_rate_idx, float *d_overlap_io, float *d_vvec_io, int32_t *d_vfront_io,
+                              float *d_pcm, size_t n_chains, size_t granules_per_chain) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
+    if (!d_xr || !d_side || !d_overlap_io || !d_vvec_io || !d_vfront_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    const size_t ov_bytes = n_chains * 576 * 4, vv_bytes = n_chains * 1024 * 4, vf_bytes = n_chains * 4;
+    void *scratch = nullptr;
+    SYM_TRY(ctx_scratch(ctx, ov_bytes + vv_bytes + vf_bytes, &scratch));
+    float *ov_out = (float *)scratch;
+    float *vv_out = ov_out + n_chains * 576;
+    int32_t *vf_out = (int32_t *)(vv_out + n_chains * 1024);
+    SYM_TRY(launch_mp3(ctx, d_xr, d_side, sample_rate_idx, d_overlap_io, d_vvec_io, d_vfront_io, ov_out, vv_out,
+                       vf_out, d_pcm, n_chains, granules_per_chain));
+    SYM_GPU(ctx, hipMemcpyAsync(d_overlap_io, ov_out, ov_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(d_vvec_io, vv_out, vv_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(d_vfront_io, vf_out, vf_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SYMACCEL_OK;
+}
+
+int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_side *h_side, int sample_rate_idx,
+                       float *h_overlap_io, float *h_vvec_io, int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
+                       size_t granules_per_chain) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
+    if (!h_xr || !h_side || !h_overlap_io || !h_vvec_io || !h_vfront_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    const size_t ng = n_chains * granules_per_chain;
+    DevBuf xr(ctx), side(ctx), ov(ctx), vv(ctx), vf(ctx), pcm(ctx);
+    SYM_TRY(xr.from_host(h_xr, ng * 576 * 4));
+    SYM_TRY(side.from_host(h_side, ng * sizeof(symaccel_mp3_side)));
+    SYM_TRY(ov.from_host(h_overlap_io, n_chains * 576 * 4));
+    SYM_TRY(vv.from_host(h_vvec_io, n_chains * 1024 * 4));
+    SYM_TRY(vf.from_host(h_vfront_io, n_chains * 4));
+    SYM_TRY(pcm.alloc(ng * 576 * 4));
+    SYM_TRY(symaccel_mp3_synth_device(ctx, (const float *)xr.p, (const symaccel_mp3_side *)side.p, sample_rate_idx,
+                                      (float *)ov.p, (float *)vv.p, (int32_t *)vf.p, (float *)pcm.p, n_chains,
+                                      granules_per_chain));
+    SYM_TRY(pcm.to_host(h_pcm, ng * 576 * 4));
+    SYM_TRY(ov.to_host(h_overlap_io, n_chains * 576 * 4));
+    SYM_TRY(vv.to_host(h_vvec_io, n_chains * 1024 * 4));
+    SYM_TRY(vf.to_host(h_vfront_io, n_chains * 4));
+    return symaccel_sync(ctx);
+}
+
+// ---- Vorbis -------------------------------------------------------------------------------
+
+int symaccel_vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra,
+                                 size_t spec_stride, const uint8_t *d_block_flag, int32_t *d_prev_flag_io,
+                                 float *d_overlap_io, float *d_pcm, size_t pcm_stride, size_t n_chains,
+                                 size_t blocks_per_chain) {
+    // vorbis/lib.rs:404-406, 461-470: block sizes 2^6..2^13, bs0 <= bs1
+    if (!ctx || bs0_exp < 6 || bs1_exp > 13 || bs0_exp > bs1_exp) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
+    if (!d_spectra || !d_block_flag || !d_prev_flag_io || !d_overlap_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    const size_t half1 = (size_t)1 << (bs1_exp - 1);
+    const size_t ov_bytes = n_chains * half1 * 4, pf_bytes = n_chains * 4;
+    void *scratch = nullptr;
+    const size_t off_bytes = n_chains * (blocks_per_chain + 1) * 2 * sizeof(uint32_t);
+    SYM_TRY(ctx_scratch(ctx, ov_bytes + pf_bytes + 256 + off_bytes, &scratch));
+    float *ov_out = (float *)scratch;
+    int32_t *pf_out = (int32_t *)(ov_out + n_chains * half1);
+    SYM_TRY(launch_vorbis(ctx, bs0_exp, bs1_exp, d_spectra, spec_stride, d_block_flag, d_prev_flag_io, pf_out,
+                          d_overlap_io, ov_out, d_pcm, pcm_stride, n_chains, blocks_per_chain));
+    SYM_GPU(ctx, hipMemcpyAsync(d_overlap_io, ov_out, ov_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(d_prev_flag_io, pf_out, pf_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SYMACCEL_OK;
+}
+
+int symaccel_vorbis_synth(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *h_spectra, size_t spec_stride,
+                          const uint8_t *h_block_flag, int32_t *h_prev_flag_io, float *h_overlap_io, float *h_pcm,
+                          size_t pcm_stride, size_t n_chains, size_t blocks_per_chain) {
+    if (!ctx || bs0_exp < 6 || bs1_exp > 13 || bs0_exp > bs1_exp) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
+    if (!h_spectra || !h_block_flag || !h_prev_flag_io || !h_overlap_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    const size_t half1 = (size_t)1 << (bs1_exp - 1);
+    DevBuf sp(ctx), bf(ctx), pf(ctx), ov(ctx), pcm(ctx);
+    SYM_TRY(sp.from_host(h_spectra, n_chains * spec_stride * 4));
+    SYM_TRY(bf.from_host(h_block_flag, n_chains * blocks_per_chain));
+    SYM_TRY(pf.from_host(h_prev_flag_io, n_chains * 4));
+    SYM_TRY(ov.from_host(h_overlap_io, n_chains * half1 * 4));
+    SYM_TRY(pcm.alloc(n_chains * pcm_stride * 4));
+    SYM_GPU(ctx, hipMemsetAsync(pcm.p, 0, n_chains * pcm_stride * 4, ctx->stream));
+    SYM_TRY(symaccel_vorbis_synth_device(ctx, bs0_exp, bs1_exp, (const float *)sp.p, spec_stride,
+                                         (const uint8_t *)bf.p, (int32_t *)pf.p, (float *)ov.p, (float *)pcm.p,
+                                         pcm_stride, n_chains, blocks_per_chain));
+    SYM_TRY(pcm.to_host(h_pcm, n_chains * pcm_stride * 4));
+    SYM_TRY(ov.to_host(h_overlap_io, n_chains * half1 * 4));
+    SYM_TRY(pf.to_host(h_prev_flag_io, n_chains * 4));
+    return symaccel_sync(ctx);
+}
+
+int symaccel_vorbis_inverse_coupling_device(symaccel_ctx *ctx, float *d_residue, size_t n, const uint32_t *mag_index,
+                                            const uint32_t *ang_index, size_t n_pairs) {
+    if (!ctx || n_pairs > 256) return SYMACCEL_ERR_INVALID_ARG;
+    if (n == 0 || n_pairs == 0) return SYMACCEL_OK;
+    if (!d_residue || !mag_index || !ang_index) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    for (size_t p = 0; p < n_pairs; ++p) {  // ordered: coupling steps may chain (lib.rs:252)
+        if (mag_index[p] == ang_index[p]) return SYMACCEL_ERR_INVALID_ARG;  // lib.rs:253 debug_assert
+        SYM_TRY(launch_vorbis_coupling(ctx, d_residue + (size_t)mag_index[p] * n, d_residue + (size_t)ang_index[p] * n, n));
+    }
+    return SYMACCEL_OK;
+}
+
+int symaccel_vorbis_dot_product_device(symaccel_ctx *ctx, float *d_floor, const float *d_residue, size_t total) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (total == 0) return SYMACCEL_OK;
+    if (!d_floor || !d_residue) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_vorbis_dot(ctx, d_floor, d_residue, total);
+}
+
+int symaccel_vorbis_deinterleave2_device(symaccel_ctx *ctx, const float *d_type2, float *d_planar, int n_ch,
+                                         size_t n2, size_t count) {
+    if (!ctx || n_ch < 1 || n_ch > 32) return SYMACCEL_ERR_INVALID_ARG;  // lib.rs:439-441
+    if (n2 == 0 || count == 0) return SYMACCEL_OK;
+    if (!d_type2 || !d_planar || d_type2 == d_planar) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_vorbis_deinterleave(ctx, d_type2, d_planar, n_ch, n2, count);
+}
+
+int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
+                                  const uint32_t *d_y, uint32_t n, float *d_floor, size_t count) {
+    if (!ctx || n_posts < 2 || n_posts > 65 || multiplier < 1 || multiplier > 4) return SYMACCEL_ERR_INVALID_ARG;
+    if (count == 0 || n == 0) return SYMACCEL_OK;
+    if (!x_list || !d_y || !d_floor) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    // Setup-time derivations the reference does once per floor (floor.rs:540-555, 748-773):
+    // neighbours of every post and the x-sorted visiting order.
+    uint32_t setup[65 * 4] = {0};  // x | low neighbour | high neighbour | sort order
+    for (int x = 0; x < n_posts; ++x) {
+        uint32_t bound = x_list[x], low = 0, high = 0xffffffffu, rl = 0, rh = 0;
+        for (int i = 0; i < x; ++i) {
+            const uint32_t xv = x_list[i];
+            if (xv > low && xv < bound) { low = xv; rl = (uint32_t)i; }
+            if (xv < high && xv > bound) { high = xv; rh = (uint32_t)i; }
+        }
+        setup[x] = x_list[x];
+        setup[65 + x] = rl;
+        setup[130 + x] = rh;
+        setup[195 + x] = (uint32_t)x;
+    }
+    for (int i = 1; i < n_posts; ++i) {  // stable, like sort_by_key
+        const uint32_t k = setup[195 + i];
+        int j = i - 1;
+        while (j >= 0 && x_list[setup[195 + j]] > x_list[k]) { setup[195 + j + 1] = setup[195 + j]; --j; }
+        setup[195 + j + 1] = k;
+    }
+    for (int i = 1; i < n_posts; ++i)  // render_line divides by (x1 - x0): equal x would panic in the reference
+        if (x_list[setup[195 + i]] == x_list[setup[195 + i - 1]]) return SYMACCEL_ERR_INVALID_ARG;
+    void *scratch = nullptr;
+    SYM_TRY(ctx_scratch(ctx, sizeof setup, &scratch));
+    SYM_GPU(ctx, hipMemcpyAsync(scratch, setup, sizeof setup, hipMemcpyHostToDevice, ctx->stream));
+    SYM_GPU(ctx, hipStreamSynchronize(ctx->stream));  // `setup` is a stack buffer
+    return launch_vorbis_floor1(ctx, (const uint32_t *)scratch, n_posts, multiplier, d_y, n, d_floor, count);
+}
+
+// ---- FLAC ---------------------------------------------------------------------------------
+
+int symaccel_flac_restore_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
+                                 const int32_t *d_coeffs, size_t n_blocks, size_t blocksize) {
+    if (!ctx || blocksize > 65535) return SYMACCEL_ERR_INVALID_ARG;  // frame.rs:58 (u16 block size)
+    if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!d_buf || !d_desc || !d_coeffs) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_flac_restore(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize);
+}
+
+int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac_desc *h_desc, const int32_t *h_coeffs,
+                          size_t n_blocks, size_t blocksize) {
+    if (!ctx || blocksize > 65535) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!h_buf || !h_desc || !h_coeffs) return SYMACCEL_ERR_INVALID_ARG;
+    for (size_t b = 0; b < n_blocks; ++b) {  // decoder.rs:361, 456-458, 506-508
+        const symaccel_flac_desc &d = h_desc[b];
+        if (d.kind > SYMACCEL_FLAC_LPC || d.order > blocksize || d.shift > 31 || d.wasted_bits > 31) return SYMACCEL_ERR_INVALID_ARG;
+        if (d.kind == SYMACCEL_FLAC_FIXED && d.order > 4) return SYMACCEL_ERR_INVALID_ARG;
+        if (d.kind == SYMACCEL_FLAC_LPC && (d.order < 1 || d.order > 32)) return SYMACCEL_ERR_INVALID_ARG;
+    }
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DevBuf buf(ctx), desc(ctx), co(ctx);
+    SYM_TRY(buf.from_host(h_buf, n_blocks * blocksize * 4));
+    SYM_TRY(desc.from_host(h_desc, n_blocks * sizeof(symaccel_flac_desc)));
+    SYM_TRY(co.from_host(h_coeffs, n_blocks * 32 * 4));
+    SYM_TRY(symaccel_flac_restore_device(ctx, (int32_t *)buf.p, (const symaccel_flac_desc *)desc.p,
+                                         (const int32_t *)co.p, n_blocks, blocksize));
+    SYM_TRY(buf.to_host(h_buf, n_blocks * blocksize * 4));
+    return symaccel_sync(ctx);
+}
+
+int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, int32_t *d_ch0, int32_t *d_ch1,
+                                     size_t n_pairs, size_t blocksize, uint32_t out_shift) {
+    if (!ctx || out_shift > 31) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!d_mode || !d_ch0 || !d_ch1) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_flac_decorrelate(ctx, d_mode, d_ch0, d_ch1, n_pairs, blocksize, out_shift);
+}
+
+// ---- tables -------------------------------------------------------------------------------
+
+int symaccel_table_f32(const symaccel_ctx *, int table, float *dst, size_t capacity) {
+    const HostTables &t = host_tables();
+    const float *src = nullptr;
+    size_t n = 0;
+    switch (table) {
+        case SYMACCEL_TABLE_AAC_KBD_LONG: src = t.aac_kbd_long.data(); n = 1024; break;
+        case SYMACCEL_TABLE_AAC_KBD_SHORT: src = t.aac_kbd_short.data(); n = 128; break;
+        case SYMACCEL_TABLE_AAC_SINE_LONG: src = t.aac_sine_long.data(); n = 1024; break;
+        case SYMACCEL_TABLE_AAC_SINE_SHORT: src = t.aac_sine_short.data(); n = 128; break;
+        case SYMACCEL_TABLE_MP3_SYNTH_D: src = t.mp3_synth_d; n = 512; break;
+        case SYMACCEL_TABLE_MP3_IMDCT_WIN: src = &t.mp3_imdct_win[0][0]; n = 144; break;
+        case SYMACCEL_TABLE_VORBIS_FLOOR1_DB: src = t.vorbis_floor1_db; n = 256; break;
+        default: return SYMACCEL_ERR_INVALID_ARG;
+    }
+    if (!dst || capacity < n) return SYMACCEL_ERR_INVALID_ARG;
+    std::memcpy(dst, src, n * 4);
+    return (int)n;
+}
+
+int symaccel_imdct_twiddles(int n, double scale, float *dst) {
+    if (!pow2(n) || n < 2 || !dst) return SYMACCEL_ERR_INVALID_ARG;
+    make_imdct_twiddles(n, scale, (cpx *)dst);
+    return n / 2;
+}
+
+int symaccel_fft_twiddles(int n, float *dst) {
+    if (!pow2(n) || n < 2 || !dst) return SYMACCEL_ERR_INVALID_ARG;
+    make_fft_twiddles(n, (cpx *)dst);
+    return n / 2;
+}
+
+}  // extern "C"

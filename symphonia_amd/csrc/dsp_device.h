@@ -1,0 +1,76 @@
+// Device-side arithmetic primitives shared by the kernels.
+//
+// ARITHMETIC CONTRACT: the reference never fuses a multiply with an add, so every
+// a*b +/- c*d here must compile to two rounded multiplies and one rounded add/sub.  The build
+// passes -ffp-contract=off (build.py) and keeps f32 denormals on (no
+// -fgpu-flush-denormals-to-zero); tests/test_build.py greps the ISA for v_fma/v_mac/v_mad.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "symaccel_internal.h"
+
+namespace symaccel {
+
+struct c32 {
+    float re, im;
+};
+
+__device__ __forceinline__ c32 c_add(c32 a, c32 b) { return c32{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ c32 c_sub(c32 a, c32 b) { return c32{a.re - b.re, a.im - b.im}; }
+// num-complex `Mul`: (a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re)
+__device__ __forceinline__ c32 c_mul(c32 a, c32 b) {
+    return c32{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
+// One radix-2 DIT butterfly: q already twiddled.  e' = e + q, o' = e - q.
+__device__ __forceinline__ void bfly(c32 &e, c32 &o, c32 q) {
+    const c32 p = e;
+    e = c_add(p, q);
+    o = c_sub(p, q);
+}
+
+#define SYM_FRAC_1_SQRT_2 0.70710678118654752440f
+
+// Twiddles of the unrolled fft4/fft8 combine steps (no_simd.rs:405-447), compile-time forms.
+__device__ __forceinline__ c32 tw_minus_i(c32 v) { return c32{v.im, -v.re}; }          // k = n/4
+__device__ __forceinline__ c32 tw_n8(c32 v) {                                          // k = n/8
+    const float a = SYM_FRAC_1_SQRT_2 * v.re, b = SYM_FRAC_1_SQRT_2 * v.im;
+    return c32{a + b, b - a};
+}
+__device__ __forceinline__ c32 tw_3n8(c32 v) {                                         // k = 3n/8
+    const float a = -SYM_FRAC_1_SQRT_2 * v.re, b = -SYM_FRAC_1_SQRT_2 * v.im;
+    return c32{a - b, a + b};
+}
+
+// fft8 (no_simd.rs:405-454) on 8 values already in bit-reversed order, in registers.
+__device__ __forceinline__ void fft8_regs(c32 (&x)[8]) {
+    bfly(x[0], x[1], x[1]);  // fft2 x4
+    bfly(x[2], x[3], x[3]);
+    bfly(x[4], x[5], x[5]);
+    bfly(x[6], x[7], x[7]);
+    bfly(x[0], x[2], x[2]);  // fft4 x2: k=0 plain, k=1 multiply by -i
+    bfly(x[1], x[3], tw_minus_i(x[3]));
+    bfly(x[4], x[6], x[6]);
+    bfly(x[5], x[7], tw_minus_i(x[7]));
+    bfly(x[0], x[4], x[4]);  // fft8 combine
+    bfly(x[1], x[5], tw_n8(x[5]));
+    bfly(x[2], x[6], tw_minus_i(x[6]));
+    bfly(x[3], x[7], tw_3n8(x[7]));
+}
+
+// Lane-dependent twiddle of the fft16 / fft32 combine step: `form` 0 = complex product with w
+// (w holds the literal, or (+-c,-c) for the k = n/8, 3n/8 strength-reduced forms, which are the
+// same roundings), 1 = k == 0 (no twiddle), 2 = multiply by -i.  Selection, not branching, so a
+// wavefront with mixed k stays converged and every lane gets the reference's exact operations.
+__device__ __forceinline__ c32 tw_small(c32 v, c32 w, int form) {
+    const c32 g = c_mul(w, v);
+    c32 q;
+    q.re = form == 1 ? v.re : (form == 2 ? v.im : g.re);
+    q.im = form == 1 ? v.im : (form == 2 ? -v.re : g.im);
+    return q;
+}
+
+__device__ __forceinline__ unsigned rev_bits(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
+
+}  // namespace symaccel

@@ -1,0 +1,176 @@
+// FLAC integer path: fixed / LPC predictor restore, wasted-bits shift, stereo decorrelation and
+// the final left-justification shift -- bit-exact (i64 accumulation, wrapping i32 adds).
+//
+// Reference: symphonia-bundle-flac/src/decoder.rs:663-710 (fixed_predict), :716-752 (lpc_predict,
+// dispatch :487-504), :403-409 (samples_shl), :32-82 (decorrelate_*), :239-242 (<< (32 - bps)).
+//
+// MI355X mapping (DESIGN.md "flac_restore"): the recurrence is serial inside a subframe and
+// independent across subframes, so one LANE owns one subframe.  A wavefront walks its 64 subframes
+// in tiles of 64 samples: the tile is fetched with 256-byte coalesced row segments into LDS
+// (row stride 65 -> conflict-free column access), every lane then runs its own recurrence over its
+// row with the last 32 samples held in registers (circular, statically indexed by unrolling 32
+// steps), and the tile is written back coalesced.  All orders use one formula
+//   pred_i = sum_{j < order} c_j * s[i-1-j]   (i64),   s[i] += (i32)(pred_i >> shift)
+// which equals the reference's prefill + main loop (its padded taps are zero) and, with the
+// binomial coefficients and shift 0, its fixed predictors.
+// Bound: integer ALU / dependent-chain latency (32 i32xi32->i64 MACs per 8 B), NOT HBM.
+#include <hip/hip_runtime.h>
+
+#include "symaccel_internal.h"
+
+namespace symaccel {
+
+namespace {
+
+constexpr int kTile = 64;
+constexpr int kStride = kTile + 1;
+
+__device__ __forceinline__ int32_t wrap_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+
+__device__ __forceinline__ unsigned wave_max(unsigned v) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, m);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+// 32 recurrence steps with statically indexed circular history: before step u the most recent
+// sample sits in h[(u + 31) & 31].
+template <int TAPS>
+__device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)[32], int32_t *row, int col0,
+                                            int first_pred, int n_valid, uint32_t shift, uint32_t wasted) {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        if (u < n_valid) {
+            int32_t x = row[col0 + u];
+            if (col0 + u >= first_pred) {
+                int64_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < TAPS; ++j) acc += (int64_t)c[j] * (int64_t)h[(u + 31 - j) & 31];
+                x = wrap_add(x, (int32_t)(acc >> shift));
+            }
+            h[u & 31] = x;
+            row[col0 + u] = (int32_t)((uint32_t)x << wasted);  // samples_shl (decoder.rs:403-409)
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void flac_restore_kernel(int32_t *__restrict__ buf,
+                                                          const symaccel_flac_desc *__restrict__ desc,
+                                                          const int32_t *__restrict__ coeffs, size_t n_blocks,
+                                                          unsigned blocksize) {
+    __shared__ int32_t tile[kTile * kStride];
+    const int lane = (int)threadIdx.x;
+    const size_t blk0 = (size_t)blockIdx.x * kTile;
+    const size_t my = blk0 + (size_t)lane;
+    const bool have = my < n_blocks;
+
+    int32_t c[32];
+    int32_t h[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        c[j] = 0;
+        h[j] = 0;
+    }
+    unsigned order = 0, shift = 0, wasted = 0;
+    if (have) {
+        const symaccel_flac_desc d = desc[my];
+        wasted = d.wasted_bits & 31u;
+        if (d.kind == SYMACCEL_FLAC_LPC) {
+            order = d.order > 32u ? 32u : d.order;
+            shift = d.shift & 63u;
+            const int32_t *cp = coeffs + my * 32;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) c[j] = (unsigned)j < order ? cp[j] : 0;
+        } else if (d.kind == SYMACCEL_FLAC_FIXED) {
+            order = d.order > 4u ? 4u : d.order;
+            // decoder.rs:679-707: s(i) = sum binom * s(i-k)
+            c[0] = order == 1 ? 1 : order == 2 ? 2 : order == 3 ? 3 : order == 4 ? 4 : 0;
+            c[1] = order == 2 ? -1 : order == 3 ? -3 : order == 4 ? -6 : 0;
+            c[2] = order == 3 ? 1 : order == 4 ? 4 : 0;
+            c[3] = order == 4 ? -1 : 0;
+        }
+        if (order > blocksize) order = blocksize;  // decoder.rs:456-458 would have rejected the frame
+    }
+    // Does any lane of this wavefront need more than 4 / 12 taps?  (wave-uniform specialisation)
+    const unsigned max_order = wave_max(order);
+
+    for (unsigned t0 = 0; t0 < blocksize; t0 += kTile) {
+        const unsigned cols = min((unsigned)kTile, blocksize - t0);
+        // coalesced fetch: row r = subframe blk0 + r, 64 consecutive samples
+        for (int r = 0; r < kTile; ++r) {
+            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
+                tile[r * kStride + lane] = buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane];
+        }
+        __syncthreads();
+        if (have) {
+            int32_t *row = tile + lane * kStride;
+            for (int half = 0; half < 2; ++half) {
+                const int col0 = 32 * half;
+                const int n_valid = (int)cols - col0;
+                const int first_pred = (int)order - (int)t0;  // column index of the first predicted sample
+                if (n_valid <= 0) break;
+                if (max_order <= 4)
+                    lpc_steps32<4>(h, c, row, col0, first_pred, n_valid, shift, wasted);
+                else if (max_order <= 12)
+                    lpc_steps32<12>(h, c, row, col0, first_pred, n_valid, shift, wasted);
+                else
+                    lpc_steps32<32>(h, c, row, col0, first_pred, n_valid, shift, wasted);
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < kTile; ++r) {
+            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
+                buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane] = tile[r * kStride + lane];
+        }
+        __syncthreads();
+    }
+}
+
+// decoder.rs:32-82 + :239-242
+__global__ void flac_decorrelate_kernel(const uint8_t *__restrict__ mode, int32_t *__restrict__ ch0,
+                                        int32_t *__restrict__ ch1, size_t n_pairs, size_t blocksize,
+                                        uint32_t out_shift) {
+    const size_t total = n_pairs * blocksize;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned m = mode[i / blocksize];
+        int32_t a = ch0[i], b = ch1[i];
+        if (m == 1) {  // left/side: side = left - side
+            b = (int32_t)((uint32_t)a - (uint32_t)b);
+        } else if (m == 2) {  // mid/side
+            const int32_t mid = (int32_t)(((uint32_t)a << 1) | ((uint32_t)b & 1u));
+            const int32_t sd = b;
+            a = (int32_t)((uint32_t)mid + (uint32_t)sd) >> 1;
+            b = (int32_t)((uint32_t)mid - (uint32_t)sd) >> 1;
+        } else if (m == 3) {  // right/side: ch0 = side, ch1 = right: side += right
+            a = wrap_add(a, b);
+        }
+        ch0[i] = (int32_t)((uint32_t)a << out_shift);
+        ch1[i] = (int32_t)((uint32_t)b << out_shift);
+    }
+}
+
+}  // namespace
+
+int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc, const int32_t *d_coeffs,
+                        size_t n_blocks, size_t blocksize) {
+    const size_t grid = (n_blocks + kTile - 1) / kTile;
+    if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(flac_restore_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs,
+                       n_blocks, (unsigned)blocksize);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *d_mode, int32_t *d_ch0, int32_t *d_ch1, size_t n_pairs,
+                            size_t blocksize, uint32_t out_shift) {
+    const size_t total = n_pairs * blocksize;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(flac_decorrelate_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_mode, d_ch0, d_ch1, n_pairs,
+                       blocksize, out_shift);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+}  // namespace symaccel

@@ -1,0 +1,148 @@
+// Internal declarations shared by the host side of libsymaccel (not part of the ABI).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/symaccel.h"
+#include <hip/hip_runtime.h>
+
+namespace symaccel {
+
+struct cpx {
+    float re, im;
+};
+
+// Constant tables, generated on the host with the libm calls the reference uses (tables.cpp).
+struct HostTables {
+    // AAC (symphonia-codec-aac/src/aac/window.rs:28-63, dsp.rs:34-54)
+    std::vector<float> aac_kbd_long, aac_kbd_short, aac_sine_long, aac_sine_short;
+    std::vector<cpx> aac_tw_long, aac_tw_short;  // Imdct twiddles N=1024 (scale 1/2048), N=128 (1/256)
+    // FFT (symphonia-core/src/dsp/fft/no_simd.rs:16-36, 307-324, 374-383)
+    std::vector<cpx> fft_merge;   // W64 | W128 | ... | W4096 back to back (offset of W_n = n/2 - 32)
+    cpx small16[8], small32[16];  // combine constants of fft16 / fft32 in "general form"
+    uint8_t small16_form[8], small32_form[16];  // 0 general, 1 identity, 2 multiply by -i
+    // MP3 (hybrid_synthesis.rs:53-149, 611-630, 668-678, 722-730; synthesis.rs:13-142, 354-396)
+    float mp3_imdct_win[4][36];
+    float mp3_cos12[6][6];
+    float mp3_cs[8], mp3_ca[8];
+    float mp3_dct_iv_scale[18], mp3_sdct18_scale[9], mp3_sdct9_d[7];
+    float mp3_cos16[16], mp3_cos8[8], mp3_cos4[4], mp3_cos2[2], mp3_cos1;
+    float mp3_synth_d[512];
+    int32_t mp3_sfb_short[9][40];
+    int32_t mp3_sfb_mixed[9][40];
+    int32_t mp3_sfb_mixed_len[9];
+    int32_t mp3_sfb_switch[9];
+    // Vorbis (floor.rs:21-112)
+    float vorbis_floor1_db[256];
+};
+
+const HostTables &host_tables();
+void make_imdct_twiddles(int n, double scale, cpx *dst);  // mdct.rs:45-54
+void make_fft_twiddles(int n, cpx *dst);                  // no_simd.rs:16-36
+void make_vorbis_window(int bs, float *dst);              // vorbis window.rs:11-24
+
+inline size_t fft_merge_offset(int n) { return (size_t)(n / 2 - 32); }  // n >= 64
+
+// Device-resident copy of the tables the kernels read (plain pointers, passed by value).
+struct DevTables {
+    const float *aac_kbd_long, *aac_kbd_short, *aac_sine_long, *aac_sine_short;
+    const cpx *aac_tw_long, *aac_tw_short;
+    const cpx *fft_merge;
+    const cpx *small16, *small32;        // 8 + 16 complex
+    const uint8_t *small16_form, *small32_form;
+    const float *mp3_consts;             // packed, see Mp3ConstLayout
+    const int32_t *mp3_reorder_map;      // [9 sample rates][2 (plain, mixed)][576] source index
+    const int32_t *mp3_reorder_end;      // [9][2][577]: reorder end index `i` for each input rzero
+    const float *vorbis_floor1_db;
+};
+
+// Offsets (in floats) inside DevTables::mp3_consts.
+enum Mp3ConstLayout {
+    MP3C_IMDCT_WIN = 0,    // 4*36
+    MP3C_COS12 = 144,      // 36
+    MP3C_CS = 180,         // 8
+    MP3C_CA = 188,         // 8
+    MP3C_DCT_IV = 196,     // 18
+    MP3C_SDCT18 = 214,     // 9
+    MP3C_SDCT9_D = 223,    // 7
+    MP3C_COS16 = 230,      // 16
+    MP3C_COS8 = 246,       // 8
+    MP3C_COS4 = 254,       // 4
+    MP3C_COS2 = 258,       // 2
+    MP3C_COS1 = 260,       // 1
+    MP3C_SYNTH_D = 264,    // 512
+    MP3C_TOTAL = 776
+};
+
+struct ImdctPlan {
+    int n;
+    cpx *d_twiddle;  // n/2 complex on the device
+};
+
+}  // namespace symaccel
+
+struct symaccel_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    int segment = 0;
+    std::string last_error;
+    symaccel::DevTables dev{};
+    std::vector<void *> allocations;  // freed on destroy
+    std::map<std::pair<int, uint64_t>, symaccel::ImdctPlan> imdct_plans;
+    std::map<int, float *> vorbis_windows;  // bs -> device window (bs/2 floats)
+    // growable device scratch (state double-buffering, per-block offsets)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+namespace symaccel {
+
+int ctx_fail(symaccel_ctx *ctx, hipError_t err, const char *where);
+int ctx_alloc(symaccel_ctx *ctx, void **out, size_t bytes, bool tracked = true);
+int ctx_scratch(symaccel_ctx *ctx, size_t bytes, void **out);
+int ctx_upload(symaccel_ctx *ctx, const void *src, size_t bytes, const void **out);
+int get_imdct_plan(symaccel_ctx *ctx, int n, double scale, const ImdctPlan **out);
+int get_vorbis_window(symaccel_ctx *ctx, int bs, const float **out);
+
+#define SYM_TRY(expr)                                                   \
+    do {                                                                \
+        int _st = (expr);                                               \
+        if (_st != SYMACCEL_OK) return _st;                             \
+    } while (0)
+#define SYM_GPU(ctx, expr)                                              \
+    do {                                                                \
+        hipError_t _e = (expr);                                         \
+        if (_e != hipSuccess) return ::symaccel::ctx_fail((ctx), _e, #expr); \
+    } while (0)
+
+// kernel launchers (one per .hip file)
+int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count);
+int launch_imdct(symaccel_ctx *ctx, const ImdctPlan &plan, const float *d_spec, float *d_out, size_t count);
+int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const float *d_delay_in,
+               float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain);
+int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_side, int sr,
+               const float *d_overlap_in, const float *d_vvec_in, const int32_t *d_vfront_in,
+               float *d_overlap_out, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm,
+               size_t n_chains, size_t granules_per_chain);
+int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, size_t spec_stride,
+                  const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out,
+                  const float *d_overlap_in, float *d_overlap_out, float *d_pcm, size_t pcm_stride,
+                  size_t n_chains, size_t blocks_per_chain);
+int launch_vorbis_coupling(symaccel_ctx *ctx, float *d_mag, float *d_ang, size_t n);
+int launch_vorbis_dot(symaccel_ctx *ctx, float *d_floor, const float *d_residue, size_t total);
+int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d_planar, int n_ch, size_t n2,
+                               size_t count);
+int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *d_setup, int n_posts, int multiplier,
+                         const uint32_t *d_y, uint32_t n, float *d_floor, size_t count);
+int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
+                        const int32_t *d_coeffs, size_t n_blocks, size_t blocksize);
+int launch_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *d_mode, int32_t *d_ch0, int32_t *d_ch1,
+                            size_t n_pairs, size_t blocksize, uint32_t out_shift);
+
+}  // namespace symaccel

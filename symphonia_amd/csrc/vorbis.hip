@@ -1,0 +1,395 @@
+// Vorbis synthesis: DspChannel::synth (symphonia-codec-vorbis/src/dsp.rs:68-145) = Imdct of the
+// floor x residue spectrum + the three window/overlap cases, plus the streaming helpers around it:
+// inverse coupling and dot product (lib.rs:252-292), residue type-2 de-interleave
+// (residue.rs:177-218) and floor-1 curve rendering (floor.rs:568-653, 776-825).
+//
+// MI355X mapping (DESIGN.md "vorbis_synth"): one wavefront per (chain, segment of blocks); blocks
+// have two sizes, so a tiny scan kernel first turns the block-flag sequence into packed spectrum /
+// PCM offsets.  Each block: pre-twiddle into LDS (bit-reversed), LDS FFT (fft_lds.h), post-twiddle
+// into an LDS PCM tile, overlap-add against the previous block's right half kept in LDS, coalesced
+// PCM store.  Segments start with a one-block halo that only rebuilds the overlap.
+// Roofline: HBM-bound: 4*(n/2) B in + 4*(prev_n + n)/4 B out per channel-block.
+#include "fft_lds.h"
+
+namespace symaccel {
+
+namespace {
+
+constexpr int kVThreads = 64;
+
+// ---- packed offsets -----------------------------------------------------------------------
+// offs[chain][0 .. nb] (spectrum) and offs[chain][nb+1 .. 2nb+1] (pcm), exclusive prefix sums.
+__global__ __launch_bounds__(256) void vorbis_offsets_kernel(const uint8_t *__restrict__ flags,
+                                                             const int32_t *__restrict__ prev_flag_in,
+                                                             uint32_t *__restrict__ offs, unsigned nb, int bs0,
+                                                             int bs1) {
+    __shared__ uint32_t part_s[256], part_p[256];
+    const unsigned chain = blockIdx.x, tid = threadIdx.x;
+    const uint8_t *f = flags + (size_t)chain * nb;
+    uint32_t *os = offs + (size_t)chain * 2 * (nb + 1), *op = os + (nb + 1);
+    const unsigned per = (nb + 255) / 256;
+    const unsigned b0 = tid * per, b1 = min(b0 + per, nb);
+    const int pf0 = prev_flag_in[chain];
+    uint32_t ss = 0, sp = 0;
+    for (unsigned b = b0; b < b1; ++b) {
+        const int fl = f[b] ? 1 : 0;
+        const int pf = b == 0 ? (pf0 < 0 ? fl : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);
+        const int n = fl ? bs1 : bs0, pn = pf ? bs1 : bs0;
+        ss += (uint32_t)(n / 2);
+        sp += (uint32_t)((pn + n) / 4);  // lib.rs:303
+    }
+    part_s[tid] = ss;
+    part_p[tid] = sp;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = 0, c = 0;
+        for (int i = 0; i < 256; ++i) {
+            const uint32_t ts = part_s[i], tp = part_p[i];
+            part_s[i] = a;
+            part_p[i] = c;
+            a += ts;
+            c += tp;
+        }
+    }
+    __syncthreads();
+    ss = part_s[tid];
+    sp = part_p[tid];
+    for (unsigned b = b0; b < b1; ++b) {
+        const int fl = f[b] ? 1 : 0;
+        const int pf = b == 0 ? (pf0 < 0 ? fl : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);
+        const int n = fl ? bs1 : bs0, pn = pf ? bs1 : bs0;
+        os[b] = ss;
+        op[b] = sp;
+        ss += (uint32_t)(n / 2);
+        sp += (uint32_t)((pn + n) / 4);
+        if (b == nb - 1) {
+            os[nb] = ss;
+            op[nb] = sp;
+        }
+    }
+}
+
+// ---- synthesis ----------------------------------------------------------------------------
+
+template <int MAXBS>
+struct VorbisShared {
+    c32 fft[fft_padded(MAXBS / 4)];
+    float pcm[MAXBS];        // Imdct output of the current block (2N = bs floats)
+    float overlap[MAXBS / 2];  // right half of the previous block's Imdct output (dsp.rs:125)
+};
+
+// Imdct of one block into sh.pcm[0 .. bs) (mdct.rs:67-146).
+template <int MAXBS>
+__device__ __forceinline__ void vorbis_imdct_block(VorbisShared<MAXBS> &sh, const float *__restrict__ spec, int bs,
+                                                   int log2nf, const cpx *__restrict__ tw, const DevTables &tb) {
+    const int n = bs >> 1, nf = bs >> 2, n4 = bs >> 3;
+    for (int i = (int)threadIdx.x; i < nf; i += kVThreads) {
+        const cpx w = tw[i];
+        const float even = spec[2 * i];
+        const float odd = -spec[n - 1 - 2 * i];
+        sh.fft[fft_pad((int)rev_bits((unsigned)i, log2nf))] = c32{odd * w.im - even * w.re, odd * w.re + even * w.im};
+    }
+    wg_fft_lds(sh.fft, nf, nf, tb);
+    float *vec0 = sh.pcm, *vec1 = sh.pcm + nf, *vec2 = sh.pcm + 2 * nf, *vec3 = sh.pcm + 3 * nf;
+    for (int k = (int)threadIdx.x; k < nf; k += kVThreads) {
+        const c32 x = sh.fft[fft_pad(k)];
+        const cpx w = tw[k];
+        const c32 val = c_mul(c32{w.re, w.im}, c32{x.re, -x.im});
+        if (k < n4) {
+            const int fi = 2 * k, ri = nf - 1 - 2 * k;
+            vec0[ri] = -val.im;
+            vec1[fi] = val.im;
+            vec2[ri] = val.re;
+            vec3[fi] = val.re;
+        } else {
+            const int i = k - n4;
+            const int fi = 2 * i, ri = nf - 1 - 2 * i;
+            vec0[fi] = -val.re;
+            vec1[ri] = val.re;
+            vec2[fi] = val.im;
+            vec3[ri] = val.im;
+        }
+    }
+    __syncthreads();
+}
+
+template <int MAXBS>
+__global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
+    DevTables tb, int bs0_exp, int bs1_exp, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
+    const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
+    size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
+    int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in, float *__restrict__ overlap_out,
+    float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs, unsigned nb, unsigned seg_len,
+    unsigned segs_per_chain) {
+    __shared__ VorbisShared<MAXBS> sh;
+    const int tid = (int)threadIdx.x;
+    const unsigned chain = blockIdx.x / segs_per_chain, seg = blockIdx.x % segs_per_chain;
+    const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
+    const int bs0 = 1 << bs0_exp, bs1 = 1 << bs1_exp;
+    const uint8_t *f = flags + (size_t)chain * nb;
+    const uint32_t *os = offs + (size_t)chain * 2 * (nb + 1), *op = os + (nb + 1);
+    const float *sp = spectra + (size_t)chain * spec_stride;
+    float *out = pcm + (size_t)chain * pcm_stride;
+    const int pf0 = prev_flag_in[chain];
+
+    if (b_begin == 0) {
+        for (int i = tid; i < bs1 / 2; i += kVThreads) sh.overlap[i] = overlap_in[(size_t)chain * (size_t)(bs1 / 2) + i];
+    }
+    __syncthreads();
+
+    const long b_first = b_begin == 0 ? 0 : (long)b_begin - 1;  // halo block rebuilds the overlap only
+    for (long b = b_first; b < (long)b_end; ++b) {
+        const int flag = f[b] ? 1 : 0;
+        const int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);  // lib.rs:298
+        const int bs = flag ? bs1 : bs0;
+        vorbis_imdct_block<MAXBS>(sh, sp + os[b], bs, (flag ? bs1_exp : bs0_exp) - 2, flag ? tw_long : tw_short, tb);
+        if (b >= (long)b_begin) {
+            float *o = out + op[b];
+            const float *win = (flag && pflag) ? win_long : win_short;  // dsp.rs:83
+            if (pflag == flag) {  // dsp.rs:85-90
+                const int len = bs / 2;
+                for (int k = tid; k < len; k += kVThreads)
+                    o[k] = sh.overlap[k] * win[len - 1 - k] + sh.pcm[k] * win[k];
+            } else if (pflag && !flag) {  // long -> short, dsp.rs:91-106
+                const int start = (bs1 - bs0) / 4, len = bs0 / 2;
+                for (int k = tid; k < start; k += kVThreads) o[k] = sh.overlap[k];
+                for (int k = tid; k < len; k += kVThreads)
+                    o[start + k] = sh.overlap[start + k] * win[len - 1 - k] + sh.pcm[k] * win[k];
+            } else {  // short -> long, dsp.rs:107-122
+                const int start = (bs1 - bs0) / 4, len = bs0 / 2, end = start + len;
+                for (int k = tid; k < len; k += kVThreads)
+                    o[k] = sh.overlap[k] * win[len - 1 - k] + sh.pcm[start + k] * win[k];
+                for (int k = tid; k < bs1 / 2 - end; k += kVThreads) o[len + k] = sh.pcm[end + k];
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < bs / 2; k += kVThreads) sh.overlap[k] = sh.pcm[bs / 2 + k];  // dsp.rs:125
+        __syncthreads();
+    }
+
+    if (b_end == nb) {
+        for (int i = tid; i < bs1 / 2; i += kVThreads) overlap_out[(size_t)chain * (size_t)(bs1 / 2) + i] = sh.overlap[i];
+        if (tid == 0) prev_flag_out[chain] = f[nb - 1] ? 1 : 0;  // lib.rs:328
+    }
+}
+
+// ---- streaming helpers ----------------------------------------------------------------------
+
+// lib.rs:265-277
+__global__ void vorbis_coupling_kernel(float *__restrict__ mag, float *__restrict__ ang, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float m = mag[i], a = ang[i];
+        float nm, na;
+        if (m > 0.0f) {
+            if (a > 0.0f) {
+                nm = m;
+                na = m - a;
+            } else {
+                nm = m + a;
+                na = m;
+            }
+        } else {
+            if (a > 0.0f) {
+                nm = m;
+                na = m + a;
+            } else {
+                nm = m - a;
+                na = m;
+            }
+        }
+        mag[i] = nm;
+        ang[i] = na;
+    }
+}
+
+// lib.rs:289-291
+__global__ void vorbis_dot_kernel(float *__restrict__ floor, const float *__restrict__ residue, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        floor[i] *= residue[i];
+}
+
+// residue.rs:177-218: planar[c][i] = type2[i * n_ch + c]
+__global__ void vorbis_deinterleave_kernel(const float *__restrict__ type2, float *__restrict__ planar, int n_ch,
+                                           size_t n2, size_t count) {
+    const size_t per = n2 * (size_t)n_ch, total = per * count;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t blk = o / per, r = o % per;
+        const size_t c = r / n2, i = r % n2;
+        planar[o] = type2[blk * per + i * (size_t)n_ch + c];
+    }
+}
+
+// floor.rs:776-782
+__device__ __forceinline__ int32_t floor1_render_point(uint32_t x0, int32_t y0, uint32_t x1, int32_t y1,
+                                                       uint32_t x) {
+    const int32_t dy = y1 - y0;
+    const uint32_t adx = x1 - x0;
+    const uint32_t err = (uint32_t)(dy < 0 ? -dy : dy) * (x - x0);
+    const uint32_t off = err / adx;
+    return dy < 0 ? y0 - (int32_t)off : y0 + (int32_t)off;
+}
+
+// One workgroup per channel-block: step 1 is a short serial recurrence (<= 65 posts, lane 0), step 2
+// renders the line segments in parallel, one thread per x: the integer DDA of render_line
+// (floor.rs:785-825) has the closed form  y(x) = y0 + base*t + sign*floor(ady*t / adx),  t = x - x0.
+__global__ __launch_bounds__(256) void vorbis_floor1_kernel(const uint32_t *__restrict__ setup, int n_posts,
+                                                            int multiplier, const uint32_t *__restrict__ yv,
+                                                            uint32_t n, float *__restrict__ floor_out,
+                                                            const float *__restrict__ db) {
+    __shared__ int32_t final_y[65];
+    __shared__ int32_t flag[65];
+    __shared__ uint32_t seg_x[66];
+    __shared__ int32_t seg_y[66];
+    __shared__ int n_seg;
+    const uint32_t *xl = setup, *lo_n = setup + 65, *hi_n = setup + 130, *order = setup + 195;
+    const uint32_t *y = yv + (size_t)blockIdx.x * (size_t)n_posts;
+    float *out = floor_out + (size_t)blockIdx.x * (size_t)n;
+    if (threadIdx.x == 0) {
+        // synthesis_step1 (floor.rs:568-625)
+        const int32_t range = multiplier == 1 ? 256 : multiplier == 2 ? 128 : multiplier == 3 ? 86 : 64;
+        flag[0] = flag[1] = 1;
+        final_y[0] = (int32_t)y[0];
+        final_y[1] = (int32_t)y[1];
+        for (int i = 2; i < n_posts; ++i) {
+            const int lo = (int)lo_n[i], hi = (int)hi_n[i];
+            const int32_t predicted = floor1_render_point(xl[lo], final_y[lo], xl[hi], final_y[hi], xl[i]);
+            const int32_t val = (int32_t)y[i];
+            const int32_t highroom = range - predicted, lowroom = predicted;
+            if (val != 0) {
+                const int32_t room = 2 * (highroom < lowroom ? highroom : lowroom);
+                flag[lo] = flag[hi] = flag[i] = 1;
+                if (val >= room)
+                    final_y[i] = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
+                else
+                    final_y[i] = (val & 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
+            } else {
+                flag[i] = 0;
+                final_y[i] = predicted;
+            }
+        }
+        // synthesis_step2 (floor.rs:627-653): list of line end points in x order
+        int32_t ly = final_y[order[0]] * multiplier;
+        ly = ly < 0 ? 0 : (ly > 255 ? 255 : ly);
+        int ns = 0;
+        seg_x[0] = 0;
+        seg_y[0] = ly;
+        uint32_t hx = 0;
+        int32_t hy = 0;
+        for (int k = 1; k < n_posts; ++k) {
+            const int i = (int)order[k];
+            if (flag[i]) {
+                hy = final_y[i] * multiplier;
+                hy = hy < 0 ? 0 : (hy > 255 ? 255 : hy);
+                hx = xl[i];
+                ++ns;
+                seg_x[ns] = hx;
+                seg_y[ns] = hy;
+            }
+        }
+        if (hx < n) {  // flat tail (floor.rs:650-652)
+            ++ns;
+            seg_x[ns] = n;
+            seg_y[ns] = hy;
+        }
+        n_seg = ns;
+    }
+    __syncthreads();
+    const int ns = n_seg;
+    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) {
+        // the segment with seg_x[s] <= x < seg_x[s+1]; render_line(x0..x1) writes [x0, min(n, x1))
+        int s = 0;
+        while (s + 1 < ns && seg_x[s + 1] <= x) ++s;
+        if (x >= seg_x[ns]) continue;  // beyond the last rendered point: left untouched like the reference
+        const uint32_t x0 = seg_x[s], x1 = seg_x[s + 1];
+        const int32_t y0 = seg_y[s], y1 = seg_y[s + 1];
+        const int32_t dy = y1 - y0, adx = (int32_t)(x1 - x0);
+        const int32_t base = dy / adx;
+        const int32_t ady = (dy < 0 ? -dy : dy) - (base < 0 ? -base : base) * adx;
+        const int32_t t = (int32_t)(x - x0);
+        const int32_t steps = (int32_t)(((int64_t)ady * t) / adx);  // number of err >= adx events in t steps
+        const int32_t yy = y0 + base * t + (dy < 0 ? -steps : steps);
+        out[x] = db[yy];
+    }
+}
+
+int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, size_t spec_stride,
+                  const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out,
+                  const float *d_overlap_in, float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains,
+                  size_t blocks_per_chain) {
+    if (blocks_per_chain > 0x3fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    const ImdctPlan *ps = nullptr, *pl = nullptr;
+    SYM_TRY(get_imdct_plan(ctx, (1 << bs0_exp) >> 1, 1.0, &ps));  // vorbis/lib.rs:123
+    SYM_TRY(get_imdct_plan(ctx, (1 << bs1_exp) >> 1, 1.0, &pl));  // vorbis/lib.rs:124
+    const float *ws = nullptr, *wl = nullptr;
+    SYM_TRY(get_vorbis_window(ctx, 1 << bs0_exp, &ws));
+    SYM_TRY(get_vorbis_window(ctx, 1 << bs1_exp, &wl));
+    // the ABI wrapper reserved room for the offsets behind the state copies in ctx->scratch
+    const size_t half1 = (size_t)1 << (bs1_exp - 1);
+    const size_t state_bytes = n_chains * half1 * 4 + n_chains * 4;
+    uint32_t *offs = (uint32_t *)((char *)ctx->scratch + ((state_bytes + 255) / 256) * 256);
+    const unsigned nb = (unsigned)blocks_per_chain;
+    hipLaunchKernelGGL(vorbis_offsets_kernel, dim3((unsigned)n_chains), dim3(256), 0, ctx->stream, d_block_flag,
+                       d_prev_in, offs, nb, 1 << bs0_exp, 1 << bs1_exp);
+    SYM_GPU(ctx, hipGetLastError());
+    unsigned seg = ctx->segment > 0 ? (unsigned)ctx->segment : 32u;
+    if (seg > nb) seg = nb;
+    const size_t segs = (nb + seg - 1) / seg;
+    const size_t grid = n_chains * segs;
+    if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    if (bs1_exp <= 11) {
+        hipLaunchKernelGGL(vorbis_synth_kernel<2048>, dim3((unsigned)grid), dim3(kVThreads), 0, ctx->stream, ctx->dev,
+                           bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
+                           spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
+                           pcm_stride, (const uint32_t *)offs, nb, seg, (unsigned)segs);
+    } else {
+        hipLaunchKernelGGL(vorbis_synth_kernel<8192>, dim3((unsigned)grid), dim3(kVThreads), 0, ctx->stream, ctx->dev,
+                           bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
+                           spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
+                           pcm_stride, (const uint32_t *)offs, nb, seg, (unsigned)segs);
+    }
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_vorbis_coupling(symaccel_ctx *ctx, float *d_mag, float *d_ang, size_t n) {
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(vorbis_coupling_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_mag, d_ang, n);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_vorbis_dot(symaccel_ctx *ctx, float *d_floor, const float *d_residue, size_t total) {
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(vorbis_dot_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_floor, d_residue, total);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d_planar, int n_ch, size_t n2,
+                               size_t count) {
+    const size_t total = n2 * (size_t)n_ch * count;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(vorbis_deinterleave_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_type2, d_planar, n_ch, n2,
+                       count);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *d_setup, int n_posts, int multiplier, const uint32_t *d_y,
+                         uint32_t n, float *d_floor, size_t count) {
+    if (count > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(vorbis_floor1_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_setup, n_posts,
+                       multiplier, d_y, n, d_floor, ctx->dev.vorbis_floor1_db);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+}  // namespace symaccel

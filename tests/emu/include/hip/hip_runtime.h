@@ -1,0 +1,149 @@
+// TEST-ONLY stand-in for <hip/hip_runtime.h>: lets g++ compile the product's .hip sources
+// unchanged and run every workgroup on CPU threads, so kernel index math / host logic can be
+// checked against the oracle in the GPU-less container (tests/test_emu_*.py).
+//
+// It is NOT part of the product: libsymaccel.so is only ever built by hipcc for gfx950
+// (symphonia_amd/build.py) and has no CPU path.  Nothing under symphonia_amd/ includes this.
+//
+// Model: one OS thread per work-item of a workgroup, workgroups run one after another,
+// __syncthreads() is a real barrier, `__shared__` is function-scope static storage, and the
+// cross-lane builtins the kernels use are emulated through a per-workgroup exchange buffer.
+#pragma once
+
+#include <pthread.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define SYMACCEL_EMULATED_HIP 1
+
+// ---- qualifiers -------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+// ---- vector types -----------------------------------------------------------------------
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+// ---- runtime API subset -----------------------------------------------------------------
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+typedef struct emu_stream *hipStream_t;
+typedef struct emu_event *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated hip error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) {
+    *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+
+// ---- execution model --------------------------------------------------------------------
+namespace emu {
+struct Idx { unsigned x, y, z; };
+extern thread_local Idx t_threadIdx, t_blockIdx;
+extern Idx g_blockDim, g_gridDim;
+extern pthread_barrier_t g_barrier;
+extern uint32_t g_exchange[1024];
+void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+}  // namespace emu
+
+#define threadIdx (emu::t_threadIdx)
+#define blockIdx (emu::t_blockIdx)
+#define blockDim (emu::g_blockDim)
+#define gridDim (emu::g_gridDim)
+static const int warpSize = 64;
+
+static inline void __syncthreads() { pthread_barrier_wait(&emu::g_barrier); }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+
+// ---- device builtins used by the kernels ------------------------------------------------
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
+static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline void __builtin_amdgcn_wave_barrier() {}
+static inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+
+// dst[lane] = src[(byte_addr / 4) % 64] within the lane's wavefront
+static inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int value) {
+    unsigned tid = emu::t_threadIdx.x;
+    unsigned wave_base = tid & ~63u;
+    emu::g_exchange[tid] = (uint32_t)value;
+    __syncthreads();
+    int r = (int)emu::g_exchange[wave_base + (((unsigned)byte_addr >> 2) & 63u)];
+    __syncthreads();
+    return r;
+}
+static inline int __shfl(int v, int src_lane, int width = 64) {
+    (void)width;
+    return __builtin_amdgcn_ds_bpermute(src_lane * 4, v);
+}
+static inline float __shfl(float v, int src_lane, int width = 64) {
+    return __int_as_float(__shfl(__float_as_int(v), src_lane, width));
+}
+static inline int __shfl_xor(int v, int mask, int width = 64) {
+    return __shfl(v, (int)((emu::t_threadIdx.x & 63u) ^ (unsigned)mask), width);
+}
+static inline float __shfl_xor(float v, int mask, int width = 64) {
+    return __int_as_float(__shfl_xor(__float_as_int(v), mask, width));
+}
+static inline int __shfl_up(int v, unsigned d, int width = 64) {
+    (void)width;
+    unsigned lane = emu::t_threadIdx.x & 63u;
+    int r = __shfl(v, (int)(lane >= d ? lane - d : lane));
+    return r;
+}
+static inline int __shfl_down(int v, unsigned d, int width = 64) {
+    (void)width;
+    unsigned lane = emu::t_threadIdx.x & 63u;
+    return __shfl(v, (int)(lane + d < 64 ? lane + d : lane));
+}
+static inline float __shfl_up(float v, unsigned d, int w = 64) { return __int_as_float(__shfl_up(__float_as_int(v), d, w)); }
+static inline float __shfl_down(float v, unsigned d, int w = 64) { return __int_as_float(__shfl_down(__float_as_int(v), d, w)); }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline unsigned __brev(unsigned x) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
+    return r;
+}

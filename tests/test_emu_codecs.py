@@ -1,0 +1,177 @@
+"""Kernel-logic checks (CPU emulation of the HIP sources, see test_emu_core_aac.py) for the MP3,
+Vorbis and FLAC paths: bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from emu_lib import emu_ctx  # noqa: F401
+from helpers import bit_equal
+from symphonia_amd import FlacPredictor, Mp3Synthesis, VorbisDsp, flac_desc, mp3_side
+from symphonia_amd.backend import FLAC_FIXED, FLAC_LPC, FLAC_VERBATIM
+
+
+def mp3_case(rng, nch, ngr, legal=True):
+    xr = (rng.standard_normal((nch, ngr, 576)) * np.exp2(-rng.integers(0, 12, (nch, ngr, 1)))).astype(np.float32)
+    bt = np.zeros((nch, ngr), np.uint8)
+    mx = np.zeros((nch, ngr), np.uint8)
+    for c in range(nch):
+        g = 0
+        while g < ngr:
+            r = rng.random()
+            if r < 0.45 or g + 3 > ngr:
+                bt[c, g] = 0
+                g += 1
+            else:  # Start -> Short(s) -> End
+                bt[c, g] = 1
+                n_short = int(rng.integers(1, 3))
+                for k in range(n_short):
+                    if g + 1 + k < ngr:
+                        bt[c, g + 1 + k] = 2
+                        mx[c, g + 1 + k] = rng.random() < 0.3
+                if g + 1 + n_short < ngr:
+                    bt[c, g + 1 + n_short] = 3
+                g += 2 + n_short
+    rz = (rng.integers(0, 289, (nch, ngr)) * 2).astype(np.uint16)
+    rz[rng.random((nch, ngr)) < 0.2] = 576
+    for c in range(nch):
+        for g in range(ngr):
+            xr[c, g, rz[c, g]:] = 0.0
+    return xr, bt, mx, rz
+
+
+@pytest.mark.parametrize("seg,sr", [(2, 0), (3, 1), (64, 8), (5, 4)])
+def test_emu_mp3(emu_ctx, seg, sr):
+    rng = np.random.default_rng(10 * seg + sr)
+    nch, ngr = 3, 11
+    xr, bt, mx, rz = mp3_case(rng, nch, ngr)
+    ov = rng.standard_normal((nch, 576)).astype(np.float32)
+    # a consistent polyphase state: run the oracle on a warm-up granule from reset
+    warm = rng.standard_normal((nch, 2, 576)).astype(np.float32)
+    _, _, vv, vf = oracle.mp3_synth(warm, oracle.mp3_side(np.zeros((nch, 2)), np.zeros((nch, 2)), np.full((nch, 2), 576)),
+                                    sr, np.zeros((nch, 576), np.float32), np.zeros((nch, 1024), np.float32),
+                                    np.array([0, 5, 11], np.int32))
+    emu_ctx.set_segment(seg)
+    got = Mp3Synthesis(emu_ctx, sr).synth(xr, mp3_side(bt, mx, rz), ov, vv, vf)
+    want = oracle.mp3_synth(xr, oracle.mp3_side(bt, mx, rz), sr, ov, vv, vf)
+    emu_ctx.set_segment(0)
+    assert bit_equal(got[0], want[0]), "pcm"
+    assert bit_equal(got[1], want[1]), "overlap"
+    assert np.array_equal(got[3], want[3]), "v_front"
+    # v_vec rows: identical up to the sign of zero in entry 16 of a row (the reference stores +0.0 there)
+    assert bit_equal(got[2], want[2]), "v_vec"
+
+
+def test_emu_mp3_single_granule_and_odd_chain_count(emu_ctx):
+    rng = np.random.default_rng(77)
+    for nch, ngr in ((1, 1), (1, 2), (5, 3)):
+        xr, bt, mx, rz = mp3_case(rng, nch, ngr)
+        z = (np.zeros((nch, 576), np.float32), np.zeros((nch, 1024), np.float32), np.zeros(nch, np.int32))
+        got = Mp3Synthesis(emu_ctx, 0).synth(xr, mp3_side(bt, mx, rz), *z)
+        want = oracle.mp3_synth(xr, oracle.mp3_side(bt, mx, rz), 0, *z)
+        for a, b in zip(got, want):
+            assert bit_equal(a, np.asarray(b)), (nch, ngr)
+
+
+def vorbis_case(rng, bs0e, bs1e, nch, nb, p_long=0.6):
+    flags = (rng.random((nch, nb)) < p_long).astype(np.uint8)
+    prev = rng.integers(-1, 2, nch).astype(np.int32)
+    dsp_layout = oracle.vorbis_layout(bs0e, bs1e, flags, prev)
+    spec_stride = int(dsp_layout[0][:, -1].max())
+    pcm_stride = int(dsp_layout[1][:, -1].max())
+    spectra = (rng.standard_normal((nch, spec_stride)) * 0.25).astype(np.float32)
+    overlap = rng.standard_normal((nch, (1 << bs1e) // 2)).astype(np.float32)
+    return flags, prev, spectra, overlap, pcm_stride
+
+
+@pytest.mark.parametrize("bs0e,bs1e,seg", [(8, 11, 3), (6, 6, 2), (6, 9, 64), (7, 12, 4), (8, 8, 1)])
+def test_emu_vorbis_synth(emu_ctx, bs0e, bs1e, seg):
+    rng = np.random.default_rng(bs0e * 100 + bs1e)
+    flags, prev, spectra, overlap, pcm_stride = vorbis_case(rng, bs0e, bs1e, 2, 9)
+    emu_ctx.set_segment(seg)
+    got = VorbisDsp(emu_ctx, bs0e, bs1e).synth(spectra, flags, prev, overlap, pcm_stride)
+    emu_ctx.set_segment(0)
+    want = oracle.vorbis_synth(bs0e, bs1e, spectra, flags, prev, overlap, pcm_stride)
+    assert bit_equal(got[0], want[0]), "pcm"
+    assert bit_equal(got[1], want[1]), "overlap"
+    assert np.array_equal(got[2], want[2]), "prev flag"
+
+
+def test_emu_vorbis_helpers(emu_ctx):
+    rng = np.random.default_rng(5)
+    v = VorbisDsp(emu_ctx, 8, 11)
+    n = 1000
+    res = rng.standard_normal((4, n)).astype(np.float32)
+    res[rng.random((4, n)) < 0.2] = 0.0
+    want = res.copy()
+    for m, a in ((0, 1), (2, 3), (1, 2)):
+        want[m], want[a] = oracle.vorbis_inverse_coupling(want[m], want[a])
+    got = res.copy()
+    v.inverse_coupling(got, n, [0, 2, 1], [1, 3, 2])
+    assert bit_equal(got, want)
+    fl = rng.standard_normal(4 * n).astype(np.float32)
+    want_f = oracle.vorbis_dot_product(fl, got.ravel())
+    v.dot_product(fl, got, 4 * n)
+    assert bit_equal(fl, want_f)
+    t2 = rng.standard_normal((3, 5 * 128)).astype(np.float32)
+    planar = np.empty((3, 5, 128), np.float32)
+    v.deinterleave2(t2, planar, 5, 128, 3)
+    assert bit_equal(planar, np.stack([oracle.vorbis_deinterleave2(t, 5) for t in t2]))
+
+
+def test_emu_vorbis_floor1(emu_ctx):
+    rng = np.random.default_rng(6)
+    v = VorbisDsp(emu_ctx, 8, 11)
+    for n, n_posts, mult in ((1024, 30, 2), (128, 9, 1), (1024, 65, 4), (128, 2, 3)):
+        xs = [0, n] + rng.permutation(np.arange(1, n))[:n_posts - 2].tolist()
+        rr = [256, 128, 86, 64][mult - 1]
+        count = 7
+        ys = rng.integers(0, rr, size=(count, n_posts)).astype(np.uint32)
+        ys[rng.random((count, n_posts)) < 0.3] = 0
+        out = np.zeros((count, n), np.float32)
+        v.floor1(xs, mult, ys, n, out, count)
+        want = np.stack([oracle.vorbis_floor1(xs, y, mult, n) for y in ys])
+        assert bit_equal(out, want), (n, n_posts, mult)
+
+
+def test_emu_flac_restore(emu_ctx):
+    rng = np.random.default_rng(9)
+    for blocksize in (1, 31, 64, 100, 192, 4096 // 8):
+        nb = 70
+        buf = rng.integers(-(1 << 22), 1 << 22, (nb, blocksize)).astype(np.int32)
+        kind = rng.integers(0, 3, nb).astype(np.uint8)
+        order = np.where(kind == FLAC_FIXED, rng.integers(0, 5, nb), rng.integers(1, 33, nb))
+        order = np.minimum(order, blocksize).astype(np.uint8)
+        kind[(kind == FLAC_LPC) & (order == 0)] = FLAC_VERBATIM
+        shift = rng.integers(0, 16, nb).astype(np.uint8)
+        wasted = np.where(rng.random(nb) < 0.2, rng.integers(1, 8, nb), 0).astype(np.uint8)
+        coeffs = rng.integers(-(1 << 14), 1 << 14, (nb, 32)).astype(np.int32)
+        got = FlacPredictor(emu_ctx).restore(buf, flac_desc(kind, order, shift, wasted), coeffs)
+        want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, wasted), coeffs)
+        assert np.array_equal(got, want), blocksize
+
+
+def test_emu_flac_small_orders_only(emu_ctx):
+    rng = np.random.default_rng(19)
+    nb, blocksize = 64, 130
+    buf = rng.integers(-(1 << 15), 1 << 15, (nb, blocksize)).astype(np.int32)
+    for hi in (4, 12):
+        order = rng.integers(1, hi + 1, nb).astype(np.uint8)
+        kind = np.full(nb, FLAC_LPC, np.uint8)
+        coeffs = rng.integers(-2000, 2000, (nb, 32)).astype(np.int32)
+        shift = np.full(nb, 9, np.uint8)
+        got = FlacPredictor(emu_ctx).restore(buf, flac_desc(kind, order, shift, 0 * shift), coeffs)
+        want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, 0 * shift), coeffs)
+        assert np.array_equal(got, want), hi
+
+
+def test_emu_flac_decorrelate(emu_ctx):
+    rng = np.random.default_rng(29)
+    n_pairs, bs = 9, 77
+    a = rng.integers(-(1 << 24), 1 << 24, (n_pairs, bs)).astype(np.int32)
+    b = rng.integers(-(1 << 24), 1 << 24, (n_pairs, bs)).astype(np.int32)
+    mode = rng.integers(0, 4, n_pairs).astype(np.uint8)
+    ga, gb = a.copy(), b.copy()
+    FlacPredictor(emu_ctx).decorrelate(mode, ga, gb, bs, out_shift=8)
+    for p in range(n_pairs):
+        wa, wb = oracle.flac_decorrelate(int(mode[p]), a[p], b[p])
+        assert np.array_equal(ga[p], oracle.flac_shl(wa, 8)) and np.array_equal(gb[p], oracle.flac_shl(wb, 8))
