@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched synthesis hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload aac|mp3|vorbis|flac]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic, HBM-resident input.  Default
+workload = BASELINE config 2: AAC-LC 48 kHz stereo, 65 536 long-block frames (128 chains x 1024
+frames, KBD windows), 1024-pt IMDCT + window + overlap-add.  Rank 0 prints ONE JSON line.
+
+Multi-GPU: one process per GPU, chains sharded across ranks with NO data-path collective (streams are
+independent) -- weak scaling: every rank runs the full per-GPU batch.  RCCL is used only
+for the barrier / max-over-ranks timing.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def make_workload(name, torch, ctx, seed, scale=1.0):
+    """Returns (step_fn, units_per_step, unit_name, algorithmic_bytes_per_step, description, kernel_name)."""
+    import symphonia_amd as sa
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if name == "aac":
+        nch, nfr = int(128 * scale), 1024  # 64 stereo streams x 1024 frames = 65 536 frames
+        coeffs = torch.randn((nch, nfr, 1024), generator=g, device="cuda", dtype=torch.float32)
+        coeffs *= torch.exp2(torch.randint(-8, 13, (nch, nfr, 64), generator=g, device="cuda").float()).repeat_interleave(16, dim=2)
+        coeffs[:, :, 672:] = 0.0  # 48 kHz content: band-limited like a real encoder's output
+        side = torch.full((nch, nfr), int(sa.aac_side(0, 1, 1)), dtype=torch.uint8, device="cuda")
+        delay = torch.zeros((nch, 1024), device="cuda", dtype=torch.float32)
+        pcm = torch.empty_like(coeffs)
+        dsp = sa.AacDsp(ctx)
+
+        def step():
+            dsp.synth(coeffs, side, delay, pcm)
+        frames = nch * nfr // 2
+        return step, frames, "frames", nch * nfr * 8192, {
+            "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d), 1024-pt IMDCT+window+OLA, KBD"
+                        % (frames, nch, nfr), "channel_frames": nch * nfr, "samples_per_frame": 1024}, "aac_synth_kernel"
+    if name == "mp3":
+        nch, ngr = int(128 * scale), 2048  # 64 stereo streams x 2048 granules = 131 072 granules
+        xr = torch.randn((nch, ngr, 576), generator=g, device="cuda", dtype=torch.float32) * 0.05
+        side_np = sa.mp3_side(np.zeros((nch, ngr)), np.zeros((nch, ngr)), np.full((nch, ngr), 576))
+        side = torch.from_numpy(side_np.view(np.uint8).reshape(nch, ngr, 4)).cuda()
+        st = [torch.zeros((nch, 576), device="cuda"), torch.zeros((nch, 1024), device="cuda"),
+              torch.zeros(nch, dtype=torch.int32, device="cuda")]
+        pcm = torch.empty_like(xr)
+        syn = sa.Mp3Synthesis(ctx, 0)
+
+        def step():
+            syn.synth(xr, side, st[0], st[1], st[2], pcm)
+        granules = nch * ngr // 2
+        return step, granules, "granules", nch * ngr * 4608, {
+            "workload": "MP3 Layer III 44.1 kHz stereo, %d long-block granules (%d chains x %d), hybrid synthesis + polyphase"
+                        % (granules, nch, ngr), "granule_channels": nch * ngr, "samples_per_granule": 576}, "mp3_synth_kernel"
+    if name == "vorbis":
+        nch, nb = int(64 * scale), 4096  # one GPU's shard of config 4: 8 streams x 8 ch x 4096 blocks
+        rng = np.random.default_rng(seed)
+        flags = np.zeros((nch, nb), np.uint8)
+        cur = np.ones(nch, bool)
+        for b in range(nb):  # Markov: P(long->long) = 0.9, P(short->short) = 0.7
+            r = rng.random(nch)
+            cur = np.where(cur, r < 0.9, r >= 0.7)
+            flags[:, b] = cur
+        v = sa.VorbisDsp(ctx, 8, 11)
+        so, po = v.layout(flags, np.full(nch, -1))
+        spec_stride, pcm_stride = int(so[:, -1].max()), int(po[:, -1].max())
+        spectra = torch.randn((nch, spec_stride), generator=g, device="cuda", dtype=torch.float32) * 0.1
+        d_flags = torch.from_numpy(flags).cuda()
+        prev = torch.full((nch,), -1, dtype=torch.int32, device="cuda")
+        overlap = torch.zeros((nch, 1024), device="cuda")
+        pcm = torch.zeros((nch, pcm_stride), device="cuda")
+
+        def step():
+            prev.fill_(-1)
+            v.synth(spectra, d_flags, prev, overlap, pcm_stride, pcm)
+        bytes_alg = int(4 * (so[:, -1].sum() + po[:, -1].sum()))
+        return step, nch * nb // 8, "frames", bytes_alg, {
+            "workload": "Vorbis 2048/256 mixed block sizes, 8 ch, %d blocks (%d chains x %d)" % (nch * nb // 8, nch, nb),
+            "channel_blocks": nch * nb}, "vorbis_synth_kernel"
+    if name == "flac":
+        nb, bs = int(65536 * scale), 4096  # 1/16 of config 5 per step (the full 1 M blocks = 16 GiB)
+        buf0 = torch.randint(-(1 << 12), 1 << 12, (nb, bs), generator=g, device="cuda", dtype=torch.int32)
+        buf = buf0.clone()
+        desc_np = sa.flac_desc(np.full(nb, 2), np.full(nb, 32), np.full(nb, 12), np.zeros(nb))
+        desc = torch.from_numpy(desc_np.view(np.uint8).reshape(nb, 4)).cuda()
+        co = torch.randint(-40, 40, (nb, 32), generator=g, device="cuda", dtype=torch.int32)
+        co[:, 0] = int(1.6 * 4096)
+        co[:, 1] = int(-0.7 * 4096)
+        fp = sa.FlacPredictor(ctx)
+
+        def step():
+            buf.copy_(buf0)  # the restore is in place; not counted as algorithmic bytes
+            fp.restore(buf, desc, co)
+        return step, nb, "blocks", nb * bs * 8, {
+            "workload": "FLAC 24-bit, LPC order 32, %d subframe blocks of 4096 samples" % nb, "samples": nb * bs}, "flac_restore_kernel"
+    raise ValueError(name)
+
+
+def cpu_baseline(name, seconds=12.0):
+    """The oracle (C restatement of the reference's scalar path) timed on the host cores on a bounded sample."""
+    import oracle
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    if name == "aac":
+        nch, nfr = 2, 256
+        coeffs = rng.standard_normal((nch, nfr, 1024)).astype(np.float32)
+        side = np.full((nch, nfr), oracle.aac_side(0, 1, 1), np.uint8)
+        delay = np.zeros((nch, 1024), np.float32)
+
+        def work():
+            oracle.aac_synth(coeffs, side, delay)
+        units, unit = nch * nfr / 2, "frames/s"
+        sample = "%d channel-frames (2 chains x 256 long blocks) per task" % (nch * nfr)
+    elif name == "mp3":
+        nch, ngr = 2, 256
+        xr = rng.standard_normal((nch, ngr, 576)).astype(np.float32)
+        side = oracle.mp3_side(np.zeros((nch, ngr)), np.zeros((nch, ngr)), np.full((nch, ngr), 576))
+        z = (np.zeros((nch, 576), np.float32), np.zeros((nch, 1024), np.float32), np.zeros(nch, np.int32))
+
+        def work():
+            oracle.mp3_synth(xr, side, 0, *z)
+        units, unit = nch * ngr / 2, "granules/s"
+        sample = "%d granule-channels per task" % (nch * ngr)
+    elif name == "vorbis":
+        flags = np.ones((8, 64), np.uint8)
+        spectra = rng.standard_normal((8, 64 * 1024)).astype(np.float32)
+
+        def work():
+            oracle.vorbis_synth(8, 11, spectra, flags, np.full(8, -1, np.int32), np.zeros((8, 1024), np.float32), 64 * 1024)
+        units, unit = 64, "frames/s"
+        sample = "8 ch x 64 long blocks per task"
+    else:
+        nb, bs = 16, 4096
+        buf = rng.integers(-4096, 4096, (nb, bs)).astype(np.int32)
+        desc = oracle.flac_desc(np.full(nb, 2), np.full(nb, 32), np.full(nb, 12), np.zeros(nb))
+        co = rng.integers(-40, 40, (nb, 32)).astype(np.int32)
+
+        def work():
+            oracle.flac_restore(buf, desc, co)
+        units, unit = nb, "blocks/s"
+        sample = "16 order-32 blocks of 4096 samples per task"
+    work()  # warm tables
+    t0 = time.perf_counter()
+    work()
+    one = max(time.perf_counter() - t0, 1e-6)
+    reps = max(1, int(seconds / one))  # per thread
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(lambda _: [work() for _ in range(reps)], range(cores)))
+        dt = time.perf_counter() - t0
+    return {"value": units * reps * cores / dt, "unit": unit, "cores": cores, "kind": "port",
+            "sample": "oracle/symoracle.c (scalar restatement of the reference's non-SIMD path, gcc -O2, no FMA), "
+                      + sample + ", %d reps on each of %d threads" % (reps, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac"])
+    ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
+    ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import symphonia_amd as sa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: symphonia_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = sa.Context(local_rank)
+    ctx.use_torch_stream()
+    if args.segment:
+        ctx.set_segment(args.segment)
+    step, units, unit_name, alg_bytes, config, kernel = make_workload(args.workload, torch, ctx, 1234 + rank, args.scale)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()
+        step()
+        ends[i].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dev_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]  # HIP events on the launch stream
+    launch_s = float(np.mean(dev_ms)) / 1e3
+
+    if rank == 0:
+        achieved = alg_bytes / launch_s / 1e9
+        out = {
+            "metric": "decoded audio frames/sec (batch IMDCT+OLA)" if args.workload == "aac" else
+                      "decoded %s/sec (%s synthesis)" % (unit_name, args.workload),
+            "value": units * world * args.steps / elapsed,
+            "unit": unit_name + "/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i32/i64" if args.workload == "flac" else "f32",
+            "data": "synthetic",
+            "config": dict(config, parallelism="chains sharded per GPU, no collective", segment=args.segment or 32),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
+                         "kernel_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if args.workload == "flac":
+            out["roofline"]["note"] = "integer-ALU / dependent-chain bound, not HBM (DESIGN.md)"
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ CSRC = HERE / "csrc"
 OUT = HERE / "libsymaccel.so"
 SOURCES = ["tables.cpp", "ctx.cpp", "imdct_generic.hip", "aac.hip", "mp3.hip", "vorbis.hip", "flac.hip"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 

@@ -6,9 +6,12 @@
 //    delay line stays in 16 VGPRs/lane between frames, so HBM traffic is the algorithmic
 //    4 KiB in + 4 KiB out per channel-frame (+ one halo frame re-read per segment: segments
 //    start by recomputing the previous frame's delay, which depends only on that frame's input);
+//  * a workgroup is four such wavefronts that share only the LDS-resident tables (Imdct twiddles,
+//    KBD and sine long windows, 12 KiB); they never synchronise with each other after start-up --
+//    each wavefront orders its own LDS traffic with wave-local fences;
 //  * the 512-point complex FFT is three radix-8 register passes (stages 1-3, 4-6, 7-9 of the
 //    reference's radix-2 DIT graph -- identical operands and roundings, only the schedule differs)
-//    with conflict-free XOR-swizzled LDS transposes between them (tools/lds_sim.py);
+//    with conflict-free LDS transposes between them whose addresses are lane base + immediate;
 //  * spectrum loads are 8 B/lane coalesced; the bit-reversal is absorbed in the lane mapping
 //    (lane m owns z[m + 64 s]) so the input never round-trips through LDS; the mirrored odd
 //    lines come from lane 63-m via ds_bpermute;
@@ -22,19 +25,40 @@ namespace symaccel {
 
 namespace {
 
-constexpr int kAacLds = 2048;  // floats per wavefront: 512 complex for the long path, pcm_long[2048] for short
+constexpr int kWaves = 4;                 // wavefronts per workgroup
+constexpr int kWaveLds = 2264;            // floats of private LDS per wavefront (FFT work array, see below)
+constexpr int kTabTw = 0;                 // shared LDS tables: Imdct twiddles, 512 complex
+constexpr int kTabKbd = 1024;             //   KBD long window, 1024 f32
+constexpr int kTabSine = 2048;            //   sine long window, 1024 f32
+constexpr int kTabFloats = 3072;
 
 enum : int { ONLY_LONG = 0, LONG_START = 1, EIGHT_SHORT = 2, LONG_STOP = 3 };
 constexpr int kP0 = 512 - 64;  // SHORT_WIN_POINT0 (dsp.rs:19)
 constexpr int kP1 = 512 + 64;  // SHORT_WIN_POINT1 (dsp.rs:20)
 
-// LDS complex index of element (B, j, k) = logical position 64B + 8j + k.
-// T1: pass-1 lanes (B, j) write k = 0..7, pass-2 lanes (B, k) read j = 0..7.
-__device__ __forceinline__ int lds_t1(int B, int j, int k) {
-    return B * 64 + (j & 1) * 32 + ((((j >> 1) ^ (B >> 1)) & 1) * 16) + ((((j >> 2) ^ B) & 1) * 8) + (k ^ B);
+// Order this wavefront's LDS accesses (its lanes exchange data through LDS; the hardware executes
+// one wavefront's DS instructions in order, the fences stop the compiler from reordering them).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// LDS complex index of element (B, j, k) = logical position 64B + 8j + k of the FFT work array.
+// Both layouts are SEPARABLE -- lane base + per-instruction constant on the write AND the read side,
+// so every ds instruction uses one address VGPR plus an immediate offset -- and conflict-free for
+// ds_write_b64 / ds_read_b64 (integer carries do what an XOR swizzle would; tools/aac_wave_model.py).
+// T1: pass-1 lanes (B, j) write k = 0..7, pass-2 lanes (B, k) read j = 0..7.
+__device__ __forceinline__ int lds_t1_lane_w(int B, int j) { return B + 8 * (j >> 2) + 288 * (j & 3); }
+__device__ __forceinline__ constexpr int lds_t1_inst_w(int k) { return 36 * k; }
+__device__ __forceinline__ int lds_t1_lane_r(int B, int k) { return B + 36 * k; }
+__device__ __forceinline__ constexpr int lds_t1_inst_r(int j) { return 8 * (j >> 2) + 288 * (j & 3); }
 // T2: pass-2 lanes (B, k) write j = 0..7, pass-3 lanes k' = 8j + k read B = 0..7.
-__device__ __forceinline__ int lds_t2(int B, int j, int k) { return (B * 64 + j * 8 + k) ^ ((B & 1) << 3); }
+__device__ __forceinline__ int lds_t2_lane_w(int B, int k) { return k + 8 * (B & 1) + 64 * (B >> 1) + 256 * (B & 1); }
+__device__ __forceinline__ constexpr int lds_t2_inst_w(int j) { return 8 * j; }
+__device__ __forceinline__ int lds_t2_lane_r(int j, int k) { return k + 8 * j; }
+__device__ __forceinline__ constexpr int lds_t2_inst_r(int B) { return 8 * (B & 1) + 64 * (B >> 1) + 256 * (B & 1); }
+static_assert(2 * (7 + 8 + 288 * 3 + 36 * 7 + 1) <= kWaveLds, "FFT work array must fit the per-wave LDS");
 
 struct LaneTables {
     // pass 2 (stages 4-6): fft16 combine k, fft32 combine k and k+8, merge W64[8j + k]
@@ -118,118 +142,80 @@ __device__ __forceinline__ c32 pre_twiddle(float even_line, float mirrored_line,
 // mdct.rs:104 / 123: val = w * x.conj()
 __device__ __forceinline__ c32 post_twiddle(c32 x, c32 w) { return c_mul(w, c32{x.re, -x.im}); }
 
-struct LongConsts {
-    c32 tw_pre[8];      // Imdct twiddle tw[lane + 64 s]
-    c32 tw_post[2][4];  // per output slot: tw[255-2m2], tw[254-2m2], tw[256+2m2], tw[257+2m2]
-    float kbd[2][8];    // long windows at the slot's two float4 positions: [h][0..3] = win[4m2+q],
-    float sine[2][8];   //                                                   [h][4..7] = win[1020-4m2+q]
-};
-
-__device__ __forceinline__ void load_long_consts(const DevTables &tb, int lane, LongConsts &c) {
-#pragma unroll
-    for (int s = 0; s < 8; ++s) c.tw_pre[s] = ld_c(tb.aac_tw_long + lane + 64 * s);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int m2 = lane + 64 * h;
-        c.tw_post[h][0] = ld_c(tb.aac_tw_long + 255 - 2 * m2);
-        c.tw_post[h][1] = ld_c(tb.aac_tw_long + 254 - 2 * m2);
-        c.tw_post[h][2] = ld_c(tb.aac_tw_long + 256 + 2 * m2);
-        c.tw_post[h][3] = ld_c(tb.aac_tw_long + 257 + 2 * m2);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            c.kbd[h][q] = tb.aac_kbd_long[4 * m2 + q];
-            c.kbd[h][4 + q] = tb.aac_kbd_long[1020 - 4 * m2 + q];
-            c.sine[h][q] = tb.aac_sine_long[4 * m2 + q];
-            c.sine[h][4 + q] = tb.aac_sine_long[1020 - 4 * m2 + q];
-        }
-    }
-}
-
-// Raw IMDCT output owned by a lane: for slot h (m2 = lane + 64h)
-//   lo[h][q]   = pcm[4*m2 + q]              hi[h][q]   = pcm[1020 - 4*m2 + q]            (first 1024)
-//   lo2[h][q]  = pcm[1024 + 4*m2 + q]       hi2[h][q]  = pcm[1024 + 1020 - 4*m2 + q]     (second 1024)
-struct LanePcm {
-    float lo[2][4], hi[2][4], lo2[2][4], hi2[2][4];
-};
-
-// 1024-line IMDCT of one frame by one wavefront.  `line` holds the lane's 8 coalesced float2
-// loads: line[s] = (spec[2m + 128 s], spec[2m + 128 s + 1]).
-__device__ __forceinline__ void imdct_long_wave(const float2 (&line)[8], int lane, c32 *lds, const LongConsts &lc,
-                                                const LaneTables &lt, LanePcm &out) {
-    // ---- pre-twiddle z[m + 64 s]; the mirrored (odd) line sits in lane 63-m's load 7-s
-    c32 z[8];
-    const int mirror = (63 - lane) * 4;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
-        z[s] = pre_twiddle(line[s].x, mirrored, lc.tw_pre[s]);
-    }
+// 512-point FFT of the pre-twiddled z[m + 64 s] held by lane m; leaves Z[0..512) in natural order
+// in the wavefront's LDS (complex index = position).
+__device__ __forceinline__ void fft512_wave(c32 (&z)[8], int lane, c32 *lds, const LaneTables &lt) {
     // ---- pass 1: fft8 over z[m + 64*rev3(r)] -> a[8*rev6(m) + r], i.e. element (B, j, k=r)
     bitrev8(z);
     fft8_regs(z);
     {
         const int B = (int)rev_bits((unsigned)lane & 7u, 3), j = (int)rev_bits((unsigned)lane >> 3, 3);
+        c32 *w = lds + lds_t1_lane_w(B, j);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) lds[lds_t1(B, j, r)] = z[r];
+        for (int r = 0; r < 8; ++r) w[lds_t1_inst_w(r)] = z[r];
     }
-    __syncthreads();
+    wave_sync();
     // ---- pass 2: lane (B, k) gathers j = 0..7
     const int B2 = lane >> 3, k2 = lane & 7;
-    c32 u[8];
+    {
+        const c32 *r = lds + lds_t1_lane_r(B2, k2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) u[j] = lds[lds_t1(B2, j, k2)];
-    pass2_regs(u, lt);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) lds[lds_t2(B2, j, k2)] = u[j];
-    __syncthreads();
-    // ---- pass 3: lane k' = 8j + k gathers B = 0..7
-#pragma unroll
-    for (int B = 0; B < 8; ++B) u[B] = lds[lds_t2(B, lane >> 3, lane & 7)];
-    pass3_regs(u, lt);
-    __syncthreads();
-#pragma unroll
-    for (int B = 0; B < 8; ++B) lds[64 * B + lane] = u[B];  // natural order Z[64B + k']
-    __syncthreads();
-    // ---- post-twiddle into the lane's output slots (mdct.rs:94-137)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int m2 = lane + 64 * h;
-        const c32 vB = post_twiddle(lds[254 - 2 * m2], lc.tw_post[h][1]);
-        const c32 vA = post_twiddle(lds[255 - 2 * m2], lc.tw_post[h][0]);
-        const c32 vC = post_twiddle(lds[256 + 2 * m2], lc.tw_post[h][2]);
-        const c32 vD = post_twiddle(lds[257 + 2 * m2], lc.tw_post[h][3]);
-        out.lo[h][0] = -vC.re;  // vec0[4m2 .. 4m2+3]
-        out.lo[h][1] = -vA.im;
-        out.lo[h][2] = -vD.re;
-        out.lo[h][3] = -vB.im;
-        out.hi[h][0] = vB.im;   // vec1[508-4m2 .. 511-4m2]
-        out.hi[h][1] = vD.re;
-        out.hi[h][2] = vA.im;
-        out.hi[h][3] = vC.re;
-        out.lo2[h][0] = vC.im;  // vec2[4m2 ..]
-        out.lo2[h][1] = vA.re;
-        out.lo2[h][2] = vD.im;
-        out.lo2[h][3] = vB.re;
-        out.hi2[h][0] = vB.re;  // vec3[508-4m2 ..]
-        out.hi2[h][1] = vD.im;
-        out.hi2[h][2] = vA.re;
-        out.hi2[h][3] = vC.im;
+        for (int j = 0; j < 8; ++j) z[j] = r[lds_t1_inst_r(j)];
     }
-    __syncthreads();  // LDS is reused by the next frame
+    pass2_regs(z, lt);
+    wave_sync();
+    {
+        c32 *w = lds + lds_t2_lane_w(B2, k2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[lds_t2_inst_w(j)] = z[j];
+    }
+    wave_sync();
+    // ---- pass 3: lane k' = 8j + k gathers B = 0..7
+    {
+        const c32 *r = lds + lds_t2_lane_r(lane >> 3, lane & 7);
+#pragma unroll
+        for (int B = 0; B < 8; ++B) z[B] = r[lds_t2_inst_r(B)];
+    }
+    pass3_regs(z, lt);
+    wave_sync();
+#pragma unroll
+    for (int B = 0; B < 8; ++B) lds[64 * B + lane] = z[B];  // natural order Z[64B + k']
+    wave_sync();
 }
 
-// Eight 128-line IMDCTs (dsp.rs:80-83) into pcm_long[2048] in LDS (reference layout).
-__device__ __forceinline__ void imdct_short_wave(const float2 (&line)[8], int lane, float *ldsf, const DevTables &tb,
-                                                 const LaneTables &lt) {
+// Post-twiddle (mdct.rs:94-137) of the four FFT bins that feed output slot m2 = lane + 64h:
+//   x[q]  = pcm[j(q)]         (first half of the 2048-sample IMDCT output)
+//   x2[q] = pcm[1024 + j(q)]  with j(q) = 4*m2 + q for q < 4, 1020 - 4*m2 + (q - 4) for q >= 4.
+// Twiddles tw[254-2m2 .. 255-2m2] and tw[256+2m2 .. 257+2m2] come from the shared LDS table.
+__device__ __forceinline__ void post_slot(const c32 *lds, const c32 *tw, int m2, float (&x)[8], float (&x2)[8]) {
+    const c32 vB = post_twiddle(lds[254 - 2 * m2], tw[254 - 2 * m2]);
+    const c32 vA = post_twiddle(lds[255 - 2 * m2], tw[255 - 2 * m2]);
+    const c32 vC = post_twiddle(lds[256 + 2 * m2], tw[256 + 2 * m2]);
+    const c32 vD = post_twiddle(lds[257 + 2 * m2], tw[257 + 2 * m2]);
+    x[0] = -vC.re;  // vec0[4m2 .. 4m2+3]
+    x[1] = -vA.im;
+    x[2] = -vD.re;
+    x[3] = -vB.im;
+    x[4] = vB.im;   // vec1[508-4m2 .. 511-4m2]
+    x[5] = vD.re;
+    x[6] = vA.im;
+    x[7] = vC.re;
+    x2[0] = vC.im;  // vec2[4m2 ..]
+    x2[1] = vA.re;
+    x2[2] = vD.im;
+    x2[3] = vB.re;
+    x2[4] = vB.re;  // vec3[508-4m2 ..]
+    x2[5] = vD.im;
+    x2[6] = vA.re;
+    x2[7] = vC.im;
+}
+
+// Eight 128-line IMDCTs (dsp.rs:80-83).  The frame's 1024 lines are staged in ldsf[0..1024).  Of each
+// window's 256 outputs v0|v1|v2|v3 only v1 and v2 are kept: H[w][0..64) = v1, H[w][64..128) = v2 in
+// ldsf[128 w ..]; v0[x] = -v1[63-x] and v3[x] = v2[63-x] exactly (mdct.rs:108-136 writes the same
+// value, negated for v0, to both).
+__device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const DevTables &tb, const LaneTables &lt) {
     c32 *lds = reinterpret_cast<c32 *>(ldsf);
-    // stage the frame's 1024 lines in LDS (the short transform indexes them per 128-line window)
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        ldsf[2 * lane + 128 * s] = line[s].x;
-        ldsf[2 * lane + 128 * s + 1] = line[s].y;
-    }
-    __syncthreads();
     // pass 1: lane (w, c) owns z_w[c + 8 s] = pre_twiddle(x_w[2i], x_w[127 - 2i]), i = c + 8 s
     const int w = lane >> 3, c = lane & 7;
     c32 z[8];
@@ -238,103 +224,138 @@ __device__ __forceinline__ void imdct_short_wave(const float2 (&line)[8], int la
         const int i = c + 8 * s;
         z[s] = pre_twiddle(ldsf[128 * w + 2 * i], ldsf[128 * w + 127 - 2 * i], ld_c(tb.aac_tw_short + i));
     }
-    __syncthreads();
+    wave_sync();
     bitrev8(z);
     fft8_regs(z);  // -> a_w[8*rev3(c) + r] = element (B = w, j = rev3(c), k = r)
     {
         const int j = (int)rev_bits((unsigned)c, 3);
+        c32 *wp = lds + lds_t1_lane_w(w, j);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) lds[lds_t1(w, j, r)] = z[r];
+        for (int r = 0; r < 8; ++r) wp[lds_t1_inst_w(r)] = z[r];
     }
-    __syncthreads();
-    c32 u[8];
+    wave_sync();
+    {
+        const c32 *rp = lds + lds_t1_lane_r(w, c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) u[j] = lds[lds_t1(w, j, c)];
-    pass2_regs(u, lt);  // 64-point FFT done: u[j] = Z_w[8j + k], k = c
-    __syncthreads();
-    // post-twiddle (mdct.rs:94-137 with n2 = 64, n4 = 32) into pcm_long[256 w ..]
-    float *o = ldsf + 256 * w;
+        for (int j = 0; j < 8; ++j) z[j] = rp[lds_t1_inst_r(j)];
+    }
+    pass2_regs(z, lt);  // 64-point FFT done: z[j] = Z_w[8j + k], k = c
+    wave_sync();
+    // post-twiddle (mdct.rs:94-137 with n2 = 64, n4 = 32)
+    float *o = ldsf + 128 * w;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = 8 * j + c;
-        const c32 val = post_twiddle(u[j], ld_c(tb.aac_tw_short + i));
+        const c32 val = post_twiddle(z[j], ld_c(tb.aac_tw_short + i));
         if (j < 4) {
-            const int fi = 2 * i, ri = 63 - 2 * i;
-            o[ri] = -val.im;
-            o[64 + fi] = val.im;
-            o[128 + ri] = val.re;
-            o[192 + fi] = val.re;
+            o[2 * i] = val.im;            // v1[fi]   (v0[ri] = -val.im is its mirror)
+            o[64 + 63 - 2 * i] = val.re;  // v2[ri]   (v3[fi] = val.re is its mirror)
         } else {
             const int i2 = i - 32;
-            const int fi = 2 * i2, ri = 63 - 2 * i2;
-            o[fi] = -val.re;
-            o[64 + ri] = val.re;
-            o[128 + fi] = val.im;
-            o[192 + ri] = val.im;
+            o[63 - 2 * i2] = val.re;      // v1[ri]   (v0[fi] = -val.re)
+            o[64 + 2 * i2] = val.im;      // v2[fi]   (v3[ri] = val.im)
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
-// pcm_short[q] of dsp.rs:86-101, rebuilt from pcm_long in LDS with the reference's operation order
-// (including the `0.0 +` of the `+=` onto the zero-filled buffer for windows > 0).
-__device__ __forceinline__ float pcm_short_at(const float *pcm_long, int q, const float *short_win,
+// src_w[i] of dsp.rs:86-101 (i in 0..256) from the half-stored windows.
+__device__ __forceinline__ float short_src(const float *H, int w, int i) {
+    const float *h = H + 128 * w;
+    if (i < 64) return -h[63 - i];
+    if (i < 192) return h[i - 64];
+    return h[319 - i];
+}
+
+// pcm_short[q] of dsp.rs:86-101 with the reference's operation order (including the `0.0 +` of the
+// `+=` onto the zero-filled buffer for windows > 0).
+__device__ __forceinline__ float pcm_short_at(const float *H, int q, const float *short_win,
                                               const float *prev_short_win) {
     const int w = q >> 7, i = q & 127;
     float acc = 0.0f;
     bool have = false;
     if (w >= 1) {  // right half of window w-1: src[i + 128] * short_win[127 - i]
-        const float a = pcm_long[256 * (w - 1) + 128 + i] * short_win[127 - i];
+        const float a = short_src(H, w - 1, 128 + i) * short_win[127 - i];
         acc = (w - 1 == 0) ? a : (0.0f + a);
         have = true;
     }
     if (w <= 7) {  // left half of window w
-        const float b = pcm_long[256 * w + i] * (w == 0 ? prev_short_win[i] : short_win[i]);
+        const float b = short_src(H, w, i) * (w == 0 ? prev_short_win[i] : short_win[i]);
         acc = have ? (acc + b) : b;
     }
     return acc;
 }
 
-__global__ __launch_bounds__(64) void aac_synth_kernel(DevTables tb, const float *__restrict__ coeffs,
-                                                       const uint8_t *__restrict__ side,
-                                                       const float *__restrict__ delay_in,
-                                                       float *__restrict__ delay_out, float *__restrict__ pcm,
-                                                       unsigned frames_per_chain, unsigned seg_len,
-                                                       unsigned segs_per_chain) {
-    __shared__ __attribute__((aligned(16))) float ldsf[kAacLds];
+__device__ __forceinline__ void store_slot(float *frame, int m2, const float (&v)[8]) {
+    float4 *o4 = reinterpret_cast<float4 *>(frame);
+    o4[m2] = make_float4(v[0], v[1], v[2], v[3]);
+    o4[255 - m2] = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void load_slot(const float *frame, int m2, float (&v)[8]) {
+    const float4 *i4 = reinterpret_cast<const float4 *>(frame);
+    const float4 a = i4[m2], b = i4[255 - m2];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// Effective output window of a LONG_STOP frame at sample j (dsp.rs:118-127): j < 448 -> dst = delay
+// (flagged by the caller), 448..575 -> prev_short_win[j-448], >= 576 -> delay + pcm (pcm * 1.0 is exact).
+__device__ __forceinline__ float stop_window(const DevTables &tb, int prev_shape, int j) {
+    const float *psw = prev_shape ? tb.aac_kbd_short : tb.aac_sine_short;
+    return (j >= kP0 && j < kP1) ? psw[j - kP0] : 1.0f;
+}
+// Effective delay window of a LONG_START frame at sample j (dsp.rs:146-155), multiplying pcm[1024 + j]:
+// j < 448 -> copy (x * 1.0 exact), 448..575 -> short_win[127 - (j-448)], >= 576 -> literal 0.0 (caller).
+__device__ __forceinline__ float start_window(const DevTables &tb, int shape, int j) {
+    const float *sw = shape ? tb.aac_kbd_short : tb.aac_sine_short;
+    return (j >= kP0 && j < kP1) ? sw[127 - (j - kP0)] : 1.0f;
+}
+
+__global__ __launch_bounds__(64 * kWaves, 2) void aac_synth_kernel(
+    DevTables tb, const float *__restrict__ coeffs, const uint8_t *__restrict__ side,
+    const float *__restrict__ delay_in, float *__restrict__ delay_out, float *__restrict__ pcm,
+    unsigned frames_per_chain, unsigned seg_len, unsigned segs_per_chain, unsigned n_items) {
+    __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
+    __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
+
+    // ---- shared tables -> LDS (once per workgroup)
+    for (int i = (int)threadIdx.x; i < 1024; i += 64 * kWaves) {
+        tabs[kTabTw + i] = reinterpret_cast<const float *>(tb.aac_tw_long)[i];
+        tabs[kTabKbd + i] = tb.aac_kbd_long[i];
+        tabs[kTabSine + i] = tb.aac_sine_long[i];
+    }
+    __syncthreads();  // the only workgroup-wide barrier; wavefronts are independent from here on
+
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const unsigned item = blockIdx.x * kWaves + (unsigned)wave;
+    if (item >= n_items) return;
+    float *ldsf = wave_lds[wave];
     c32 *lds = reinterpret_cast<c32 *>(ldsf);
-    const int lane = (int)threadIdx.x;
-    const unsigned chain = blockIdx.x / segs_per_chain, seg = blockIdx.x % segs_per_chain;
+    const c32 *tw = reinterpret_cast<const c32 *>(tabs + kTabTw);
+
+    const unsigned chain = item / segs_per_chain, seg = item % segs_per_chain;
     const unsigned t_begin = seg * seg_len;
     const unsigned t_end = min(t_begin + seg_len, frames_per_chain);
     const size_t chain_base = (size_t)chain * frames_per_chain;
 
     LaneTables lt;
-    LongConsts lc;
     load_lane_tables(tb, lane, lt);
-    load_long_consts(tb, lane, lc);
 
     // delay line, in slot layout: dl[h][0..3] = delay[4m2 + q], dl[h][4..7] = delay[1020 - 4m2 + q]
     float dl[2][8];
-    if (t_begin == 0) {
-        const float4 *d4 = reinterpret_cast<const float4 *>(delay_in + (size_t)chain * 1024);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m2 = lane + 64 * h;
-            const float4 a = d4[m2], b = d4[255 - m2];
-            dl[h][0] = a.x; dl[h][1] = a.y; dl[h][2] = a.z; dl[h][3] = a.w;
-            dl[h][4] = b.x; dl[h][5] = b.y; dl[h][6] = b.z; dl[h][7] = b.w;
-        }
-    } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
+        if (t_begin == 0) {
+            load_slot(delay_in + (size_t)chain * 1024, lane + 64 * h, dl[h]);
+        } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) dl[h][q] = 0.0f;
+        }
     }
 
     // frame t_begin-1 is the halo: it only rebuilds the delay line
     const long t_first = t_begin == 0 ? 0 : (long)t_begin - 1;
-    float2 line[8];
+    float2 line[8];  // line[s] = (spec[2m + 128 s], spec[2m + 128 s + 1]), 512 B coalesced per load
     {
         const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t_first) * 1024);
 #pragma unroll
@@ -345,103 +366,108 @@ __global__ __launch_bounds__(64) void aac_synth_kernel(DevTables tb, const float
         const bool emit = t >= (long)t_begin;
         const unsigned sb = side[chain_base + (size_t)t];
         const int seq = (int)(sb & 3u);
-        const bool shape = (sb >> 2) & 1u, prev_shape = (sb >> 3) & 1u;
+        const int shape = (int)((sb >> 2) & 1u), prev_shape = (int)((sb >> 3) & 1u);
+        float *frame_out = pcm + (chain_base + (size_t)t) * 1024;
 
-        float2 cur[8];
+        // ---- consume the prefetched lines
+        c32 z[8];
+        if (seq != EIGHT_SHORT) {
+            // pre-twiddle z[m + 64 s] with tw[m + 64 s]; the mirrored (odd) line sits in lane 63-m's load 7-s
+            const int mirror = (63 - lane) * 4;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) cur[s] = line[s];
-        if (t + 1 < (long)t_end) {  // prefetch the next frame while this one is transformed
+            for (int s = 0; s < 8; ++s) {
+                const float mirrored =
+                    __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
+                z[s] = pre_twiddle(line[s].x, mirrored, tw[lane + 64 * s]);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {  // the short transform indexes lines per 128-line window: stage in LDS
+                ldsf[2 * lane + 128 * s] = line[s].x;
+                ldsf[2 * lane + 128 * s + 1] = line[s].y;
+            }
+            wave_sync();
+        }
+        if (t + 1 < (long)t_end) {  // prefetch the next frame; it lands while this one is transformed
             const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t + 1) * 1024);
 #pragma unroll
             for (int s = 0; s < 8; ++s) line[s] = src[lane + 64 * s];
         }
 
-        float dst[2][8];
         if (seq != EIGHT_SHORT) {
-            LanePcm p;
-            imdct_long_wave(cur, lane, lds, lc, lt, p);
+            fft512_wave(z, lane, lds, lt);
+            const float *wprev = tabs + (prev_shape ? kTabKbd : kTabSine);  // prev_long_win (dsp.rs:71-74)
+            const float *wcur = tabs + (shape ? kTabKbd : kTabSine);        // long_win (dsp.rs:66-69)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int m2 = lane + 64 * h;
+                float x[8], x2[8];
+                post_slot(lds, tw, m2, x, x2);
+                // ---- output samples (dsp.rs:105-129): dst = delay + pcm * w, or delay alone
+                float wo[8], dst[8];
+                if (seq == LONG_STOP) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        wo[q] = stop_window(tb, prev_shape, q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4));
+                } else {
+                    load_slot(wprev, m2, wo);
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int j = q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4);
-                    const float x = q < 4 ? p.lo[h][q] : p.hi[h][q - 4];       // pcm_long[j]
-                    const float x2 = q < 4 ? p.lo2[h][q] : p.hi2[h][q - 4];    // pcm_long[1024 + j]
-                    // window values at j and at 1023 - j (the slot's other float4, reversed)
-                    const int qr = q < 4 ? 7 - q : 3 - (q - 4);
-                    const float wprev = prev_shape ? lc.kbd[h][q] : lc.sine[h][q];
-                    const float wcur_rev = shape ? lc.kbd[h][qr] : lc.sine[h][qr];
-                    // ---- output samples (dsp.rs:105-129)
-                    float d;
-                    if (seq == LONG_STOP) {
-                        if (j < kP0) {
-                            d = dl[h][q];
-                        } else if (j < kP1) {
-                            const float *psw = prev_shape ? tb.aac_kbd_short : tb.aac_sine_short;
-                            d = dl[h][q] + x * psw[j - kP0];
-                        } else {
-                            d = dl[h][q] + x;
-                        }
-                    } else {
-                        d = dl[h][q] + (x * wprev);
-                    }
-                    dst[h][q] = d;
-                    // ---- delay for the next frame (dsp.rs:132-157)
-                    float nd;
-                    if (seq == LONG_START) {
-                        if (j < kP0) {
-                            nd = x2;
-                        } else if (j < kP1) {
-                            const float *sw = shape ? tb.aac_kbd_short : tb.aac_sine_short;
-                            nd = x2 * sw[127 - (j - kP0)];
-                        } else {
-                            nd = 0.0f;
-                        }
-                    } else {
-                        nd = x2 * wcur_rev;
-                    }
-                    dl[h][q] = nd;
+                    const float v = dl[h][q] + (x[q] * wo[q]);
+                    dst[q] = (seq == LONG_STOP && j < kP0) ? dl[h][q] : v;
+                }
+                if (emit) store_slot(frame_out, m2, dst);
+                // ---- delay for the next frame (dsp.rs:132-157): pcm[1024 + j] * long_win[1023 - j] (the
+                // slot's two float4 read backwards), a short-window slope, or literal zero
+                float wd[8];
+                if (seq == LONG_START) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        wd[q] = start_window(tb, shape, q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4));
+                } else {
+                    float wr[8];
+                    load_slot(wcur, m2, wr);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) wd[q] = wr[7 - q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4);
+                    const float v = x2[q] * wd[q];
+                    dl[h][q] = (seq == LONG_START && j >= kP1) ? 0.0f : v;
                 }
             }
+            wave_sync();  // Z in LDS is overwritten by the next frame
         } else {
-            imdct_short_wave(cur, lane, ldsf, tb, lt);
+            // ---- eight short windows (rare): everything through LDS in natural order
+            float *dly = ldsf + 1024;
+            imdct_short_wave(lane, ldsf, tb, lt);  // H[8][128] in ldsf[0..1024)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) store_slot(dly, lane + 64 * h, dl[h]);  // (the FFT work array overlapped dly)
+            wave_sync();
             const float *sw = shape ? tb.aac_kbd_short : tb.aac_sine_short;
             const float *psw = prev_shape ? tb.aac_kbd_short : tb.aac_sine_short;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m2 = lane + 64 * h;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int j = q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4);
-                    // dsp.rs:111-117
-                    dst[h][q] = j < kP0 ? dl[h][q] : dl[h][q] + pcm_short_at(ldsf, j - kP0, sw, psw);
-                    // dsp.rs:138-145
-                    dl[h][q] = j < kP1 ? pcm_short_at(ldsf, j + kP1, sw, psw) : 0.0f;
-                }
+#pragma unroll 1
+            for (int e = 0; e < 16; ++e) {
+                const int j = lane + 64 * e;
+                const float d = dly[j];
+                const float o = j < kP0 ? d : d + pcm_short_at(ldsf, j - kP0, sw, psw);      // dsp.rs:111-117
+                if (emit) frame_out[j] = o;
+                dly[j] = j < kP1 ? pcm_short_at(ldsf, j + kP1, sw, psw) : 0.0f;               // dsp.rs:138-145
             }
-            __syncthreads();  // pcm_long in LDS is overwritten by the next frame
-        }
-
-        if (emit) {
-            float4 *o4 = reinterpret_cast<float4 *>(pcm + (chain_base + (size_t)t) * 1024);
+            wave_sync();
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m2 = lane + 64 * h;
-                o4[m2] = make_float4(dst[h][0], dst[h][1], dst[h][2], dst[h][3]);
-                o4[255 - m2] = make_float4(dst[h][4], dst[h][5], dst[h][6], dst[h][7]);
-            }
+            for (int h = 0; h < 2; ++h) load_slot(dly, lane + 64 * h, dl[h]);
+            wave_sync();  // LDS is overwritten by the next frame
         }
     }
 
     if (t_end == frames_per_chain) {
-        float4 *d4 = reinterpret_cast<float4 *>(delay_out + (size_t)chain * 1024);
+        float *d = delay_out + (size_t)chain * 1024;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m2 = lane + 64 * h;
-            d4[m2] = make_float4(dl[h][0], dl[h][1], dl[h][2], dl[h][3]);
-            d4[255 - m2] = make_float4(dl[h][4], dl[h][5], dl[h][6], dl[h][7]);
-        }
+        for (int h = 0; h < 2; ++h) store_slot(d, lane + 64 * h, dl[h]);
     }
 }
 
@@ -453,10 +479,12 @@ int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, 
     unsigned seg = ctx->segment > 0 ? (unsigned)ctx->segment : 32u;
     if (seg > frames_per_chain) seg = (unsigned)frames_per_chain;
     const size_t segs = (frames_per_chain + seg - 1) / seg;
-    const size_t grid = n_chains * segs;
-    if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(aac_synth_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, ctx->dev, d_coeffs, d_side,
-                       d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, seg, (unsigned)segs);
+    const size_t items = n_chains * segs;
+    const size_t grid = (items + kWaves - 1) / kWaves;
+    if (items > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(aac_synth_kernel, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, d_coeffs,
+                       d_side, d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, seg, (unsigned)segs,
+                       (unsigned)items);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

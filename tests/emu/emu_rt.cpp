@@ -5,6 +5,7 @@ namespace emu {
 thread_local Idx t_threadIdx, t_blockIdx;
 Idx g_blockDim, g_gridDim;
 pthread_barrier_t g_barrier;
+pthread_barrier_t g_wave_barrier[32];
 uint32_t g_exchange[1024];
 
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
@@ -14,6 +15,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     g_blockDim = Idx{block.x, block.y, block.z};
     g_gridDim = Idx{grid.x, grid.y, grid.z};
     pthread_barrier_init(&g_barrier, nullptr, nthreads);
+    const unsigned nwaves = (nthreads + 63) / 64;
+    for (unsigned w = 0; w < nwaves; w++) {
+        unsigned cnt = (w + 1) * 64 <= nthreads ? 64 : nthreads - w * 64;
+        pthread_barrier_init(&g_wave_barrier[w], nullptr, cnt);
+    }
     std::vector<std::thread> pool;
     pool.reserve(nthreads);
     for (unsigned t = 0; t < nthreads; t++) {
@@ -28,5 +34,6 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     }
     for (auto &th : pool) th.join();
     pthread_barrier_destroy(&g_barrier);
+    for (unsigned w = 0; w < nwaves; w++) pthread_barrier_destroy(&g_wave_barrier[w]);
 }
 }  // namespace emu

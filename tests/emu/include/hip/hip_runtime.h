@@ -78,6 +78,7 @@ struct Idx { unsigned x, y, z; };
 extern thread_local Idx t_threadIdx, t_blockIdx;
 extern Idx g_blockDim, g_gridDim;
 extern pthread_barrier_t g_barrier;
+extern pthread_barrier_t g_wave_barrier[32];
 extern uint32_t g_exchange[1024];
 void launch(dim3 grid, dim3 block, const std::function<void()> &body);
 }  // namespace emu
@@ -99,7 +100,12 @@ static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
 static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-static inline void __builtin_amdgcn_wave_barrier() {}
+// A real rendezvous of the wavefront's work-items: the hardware runs them in lock step, the emulation
+// runs them as threads, so every point where the kernel relies on lock step must synchronise.
+static inline void __builtin_amdgcn_wave_barrier() {
+    unsigned linear = emu::t_threadIdx.x + emu::g_blockDim.x * (emu::t_threadIdx.y + emu::g_blockDim.y * emu::t_threadIdx.z);
+    pthread_barrier_wait(&emu::g_wave_barrier[linear >> 6]);
+}
 static inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 
@@ -108,9 +114,9 @@ static inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int value) {
     unsigned tid = emu::t_threadIdx.x;
     unsigned wave_base = tid & ~63u;
     emu::g_exchange[tid] = (uint32_t)value;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     int r = (int)emu::g_exchange[wave_base + (((unsigned)byte_addr >> 2) & 63u)];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     return r;
 }
 static inline int __shfl(int v, int src_lane, int width = 64) {

@@ -1,0 +1,345 @@
+"""GPU parity tests (run on a real MI355X: `pytest -m gpu`).  Every call goes through the C ABI of
+the hipcc-built symphonia_amd/libsymaccel.so; the oracle is only the checker.
+
+Bar (BASELINE.json north_star): PCM within +-1 ULP f32 of the reference CPU path, bit-exact for the
+FLAC integer path.  The kernels reproduce the reference's operation DAG, so we assert the stronger
+property -- bit-exact (signed zeros and NaN payloads aside) -- and report the ULP bound as the
+contract.  Full BASELINE sizes are checked through size-independent properties (segmentation
+invariance, sampled-chain parity against the oracle, analysis->synthesis reconstruction)."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import aac_sequence_chain, aac_spectra, assert_ulp, mdct_forward, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the gpu-marked tests must run on an MI355X (there is no CPU path)")
+    from symphonia_amd import Context
+    c = Context(0)
+    c.use_torch_stream()
+    yield c
+    c.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def assert_parity(got, want, what):
+    """Contract: <= 1 ULP.  Expectation: identical bits (modulo the sign of zero)."""
+    assert_ulp(got, want, 1, what)
+    d = ulp_diff(got, want)
+    assert int(d.max()) == 0, "%s: within 1 ULP but not bit-identical (%d elements differ)" % (what, int((d > 0).sum()))
+
+
+# ------------------------------------------------------------------------------------------ core
+
+@pytest.mark.parametrize("n", [4, 16, 32, 64, 128, 256, 1024, 2048, 4096, 8192])
+def test_imdct_parity(ctx, n):
+    from symphonia_amd import Imdct
+    rng = np.random.default_rng(n)
+    count = 37 if n <= 2048 else 5
+    spec = (rng.standard_normal((count, n)) * np.exp2(rng.integers(-10, 12, (count, n)))).astype(np.float32)
+    spec[0, : n // 2] = np.float32(1e-41)  # denormals must survive (no flush-to-zero)
+    spec[1, ::3] = -0.0
+    for scale in (1.0, 1.0 / (2 * n), -2.0):
+        got = host(Imdct(ctx, n, scale).imdct(dev(spec)))
+        assert_parity(got, oracle.imdct(spec, scale), "imdct n=%d scale=%g" % (n, scale))
+
+
+def test_imdct_reference_kat_on_gpu(ctx):
+    """mdct.rs:177-201 (N=32 ramp vs the f64 closed form, 1e-5) through the GPU path."""
+    import math
+    from helpers import imdct_analytical, kats
+    from symphonia_amd import Imdct
+    x = np.array(kats()["imdct32_input"], dtype=np.float32)
+    scale = math.sqrt(2.0 / 64.0)
+    got = host(Imdct(ctx, 32, scale).imdct(dev(x[None])))[0]
+    assert np.abs(got - imdct_analytical(x, scale)).max() < 1e-5
+
+
+@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 512, 1024, 4096])
+def test_fft_parity(ctx, n):
+    from helpers import dft_naive, kats
+    from symphonia_amd import Fft
+    rng = np.random.default_rng(n + 1)
+    x = (rng.standard_normal((9, n)) + 1j * rng.standard_normal((9, n))).astype(np.complex64)
+    if n == 64:  # dsp/fft/mod.rs:88-186
+        v = np.array(kats()["fft64_input"], dtype=np.float32)
+        x[0] = v[:, 0] + 1j * v[:, 1]
+    xd = torch.view_as_real(dev(x)).contiguous()
+    yd = torch.empty_like(xd)
+    Fft(ctx, n).fft(xd, yd)
+    got = host(yd).view(np.complex64).reshape(9, n)
+    want = np.stack([oracle.fft(r) for r in x])
+    assert_parity(got.view(np.float32), want.view(np.float32), "fft n=%d" % n)
+    if n == 64:
+        assert np.abs(got[0] - dft_naive(x[0])).max() < 1e-5
+    Fft(ctx, n).fft_inplace(xd)
+    assert_parity(host(xd).view(np.complex64).reshape(9, n).view(np.float32), want.view(np.float32), "fft_inplace")
+
+
+# ------------------------------------------------------------------------------------------ AAC
+
+def aac_case(seed, nch, nfr, only_long=False):
+    rng = np.random.default_rng(seed)
+    coeffs = aac_spectra(rng, (nch, nfr))
+    side = np.empty((nch, nfr), np.uint8)
+    for c in range(nch):
+        if only_long:
+            side[c] = oracle.aac_side(0, 1, 1)
+        else:
+            s, sh, pv = aac_sequence_chain(rng, nfr, p_switch=0.35)
+            side[c] = oracle.aac_side(s, sh, pv)
+    delay = rng.standard_normal((nch, 1024)).astype(np.float32)
+    return coeffs, side, delay
+
+
+@pytest.mark.parametrize("seg", [1, 5, 32, 1000])
+@pytest.mark.parametrize("only_long", [True, False])
+def test_aac_parity(ctx, seg, only_long):
+    from symphonia_amd import AacDsp
+    coeffs, side, delay = aac_case(10 + seg, 6, 41, only_long)
+    if not only_long:
+        assert set((side & 3).ravel().tolist()) == {0, 1, 2, 3}
+    ctx.set_segment(seg)
+    d_delay = dev(delay)
+    pcm = host(AacDsp(ctx).synth(dev(coeffs), dev(side), d_delay))
+    ctx.set_segment(0)
+    wp, wd = oracle.aac_synth(coeffs, side, delay)
+    assert_parity(pcm, wp, "aac pcm")
+    assert_parity(host(d_delay), wd, "aac delay")
+
+
+def test_aac_streaming_state(ctx):
+    """Two consecutive calls continue the stream exactly like one call (delay_io contract)."""
+    from symphonia_amd import AacDsp
+    coeffs, side, delay = aac_case(3, 3, 20)
+    d = dev(delay)
+    a = host(AacDsp(ctx).synth(dev(coeffs[:, :9]), dev(side[:, :9]), d))
+    b = host(AacDsp(ctx).synth(dev(coeffs[:, 9:]), dev(side[:, 9:]), d))
+    wp, wd = oracle.aac_synth(coeffs, side, delay)
+    assert_parity(np.concatenate((a, b), axis=1), wp, "aac two calls")
+    assert_parity(host(d), wd, "aac delay after two calls")
+
+
+def test_aac_config2_full_size_properties(ctx):
+    """BASELINE config 2: 65 536 stereo long-block frames = 128 chains x 1024 frames (1 GiB of traffic)."""
+    from symphonia_amd import AacDsp
+    nch, nfr = 128, 1024
+    g = torch.Generator(device="cuda").manual_seed(2)
+    coeffs = torch.randn((nch, nfr, 1024), generator=g, device="cuda", dtype=torch.float32)
+    coeffs *= torch.exp2(torch.randint(-8, 13, (nch, nfr, 1), generator=g, device="cuda").float())
+    coeffs[:, :, 672:] = 0.0
+    side = torch.full((nch, nfr), int(oracle.aac_side(0, 1, 1)), dtype=torch.uint8, device="cuda")
+    delay0 = torch.randn((nch, 1024), generator=g, device="cuda", dtype=torch.float32)
+    outs = []
+    for seg in (16, 64):  # segmentation (halo recompute) must not change a single bit
+        ctx.set_segment(seg)
+        d = delay0.clone()
+        outs.append((AacDsp(ctx).synth(coeffs, side, d), d))
+    ctx.set_segment(0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
+    assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))
+    # sampled chains against the oracle (the oracle finishes 6 x 1024 frames in seconds)
+    pick = [0, 1, 63, 64, 126, 127]
+    wp, wd = oracle.aac_synth(host(coeffs[pick]), host(side[pick]), host(delay0[pick]))
+    assert_parity(host(outs[0][0][pick]), wp, "config-2 sampled chains")
+    assert_parity(host(outs[0][1][pick]), wd, "config-2 sampled delay")
+
+
+def test_aac_tdac_reconstruction_on_gpu(ctx):
+    """analysis (sine windows, long blocks) -> GPU Dsp::synth == 0.25 * x."""
+    from symphonia_amd import AacDsp
+    rng = np.random.default_rng(5)
+    nfr = 12
+    x = rng.standard_normal(1024 * (nfr + 1))
+    x[:1024] = 0
+    w = oracle.aac_window(False, 0.0, 1024).astype(np.float64)
+    win = np.concatenate((w, w[::-1]))
+    coeffs = np.stack([mdct_forward(x[t * 1024:t * 1024 + 2048] * win) for t in range(nfr)]).astype(np.float32)[None]
+    side = np.zeros((1, nfr), np.uint8)
+    pcm = host(AacDsp(ctx).synth(dev(coeffs), dev(side), dev(np.zeros((1, 1024), np.float32))))
+    assert np.abs(pcm[0].reshape(-1)[1024:] - 0.25 * x[1024:1024 * nfr]).max() < 3e-5 * np.abs(x).max()
+
+
+# ------------------------------------------------------------------------------------------ MP3
+
+def mp3_case(seed, nch, ngr):
+    from test_emu_codecs import mp3_case as gen
+    rng = np.random.default_rng(seed)
+    xr, bt, mx, rz = gen(rng, nch, ngr)
+    ov = rng.standard_normal((nch, 576)).astype(np.float32)
+    warm = rng.standard_normal((nch, 2, 576)).astype(np.float32)
+    z = np.zeros((nch, 2))
+    _, _, vv, vf = oracle.mp3_synth(warm, oracle.mp3_side(z, z, z + 576), 0, np.zeros((nch, 576), np.float32),
+                                    np.zeros((nch, 1024), np.float32), rng.integers(0, 16, nch).astype(np.int32))
+    return xr, bt, mx, rz, ov, vv, vf
+
+
+@pytest.mark.parametrize("seg,sr", [(2, 0), (7, 1), (32, 8), (1000, 3)])
+def test_mp3_parity(ctx, seg, sr):
+    from symphonia_amd import Mp3Synthesis, mp3_side
+    xr, bt, mx, rz, ov, vv, vf = mp3_case(seg + sr, 5, 37)
+    side = mp3_side(bt, mx, rz)
+    d_ov, d_vv, d_vf = dev(ov), dev(vv), dev(vf)
+    ctx.set_segment(seg)
+    pcm = host(Mp3Synthesis(ctx, sr).synth(dev(xr), dev(side.view(np.uint8).reshape(5, 37, 4)), d_ov, d_vv, d_vf))
+    ctx.set_segment(0)
+    want = oracle.mp3_synth(xr, oracle.mp3_side(bt, mx, rz), sr, ov, vv, vf)
+    assert set(bt.ravel().tolist()) == {0, 1, 2, 3}
+    assert_parity(pcm, want[0], "mp3 pcm")
+    assert_parity(host(d_ov), want[1], "mp3 overlap")
+    assert_parity(host(d_vv), want[2], "mp3 v_vec")
+    assert np.array_equal(host(d_vf), want[3])
+
+
+def test_mp3_config3_sampled(ctx):
+    """BASELINE config 3 shape (long blocks), reduced chain count: 16 chains x 2048 granules."""
+    from symphonia_amd import Mp3Synthesis, mp3_side
+    nch, ngr = 16, 2048
+    rng = np.random.default_rng(3)
+    xr = (rng.standard_normal((nch, ngr, 576)) * 0.1).astype(np.float32)
+    side = mp3_side(np.zeros((nch, ngr)), np.zeros((nch, ngr)), np.full((nch, ngr), 576))
+    outs = []
+    for seg in (16, 128):
+        ctx.set_segment(seg)
+        st = [dev(np.zeros((nch, 576), np.float32)), dev(np.zeros((nch, 1024), np.float32)), dev(np.zeros(nch, np.int32))]
+        outs.append(Mp3Synthesis(ctx, 0).synth(dev(xr), dev(side.view(np.uint8).reshape(nch, ngr, 4)), *st))
+    ctx.set_segment(0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    pick = [0, 7, 15]
+    z = (np.zeros((3, 576), np.float32), np.zeros((3, 1024), np.float32), np.zeros(3, np.int32))
+    want = oracle.mp3_synth(xr[pick], oracle.mp3_side(np.zeros((3, ngr)), np.zeros((3, ngr)), np.full((3, ngr), 576)), 0, *z)
+    assert_parity(host(outs[0][pick]), want[0], "mp3 config-3 sampled chains")
+
+
+# ------------------------------------------------------------------------------------------ Vorbis
+
+@pytest.mark.parametrize("bs0e,bs1e,seg", [(8, 11, 5), (6, 6, 2), (6, 13, 3), (7, 12, 1000), (11, 11, 4)])
+def test_vorbis_parity(ctx, bs0e, bs1e, seg):
+    from test_emu_codecs import vorbis_case
+    from symphonia_amd import VorbisDsp
+    rng = np.random.default_rng(bs0e * 31 + bs1e)
+    flags, prev, spectra, overlap, pcm_stride = vorbis_case(rng, bs0e, bs1e, 4, 23)
+    d_prev, d_ov = dev(prev), dev(overlap)
+    ctx.set_segment(seg)
+    pcm = host(VorbisDsp(ctx, bs0e, bs1e).synth(dev(spectra), dev(flags), d_prev, d_ov, pcm_stride))
+    ctx.set_segment(0)
+    want = oracle.vorbis_synth(bs0e, bs1e, spectra, flags, prev, overlap, pcm_stride)
+    assert_parity(pcm, want[0], "vorbis pcm")
+    assert_parity(host(d_ov), want[1], "vorbis overlap")
+    assert np.array_equal(host(d_prev), want[2])
+
+
+def test_vorbis_helpers_parity(ctx):
+    from symphonia_amd import VorbisDsp
+    rng = np.random.default_rng(8)
+    v = VorbisDsp(ctx, 8, 11)
+    n = 1024
+    res = rng.standard_normal((8, n)).astype(np.float32)
+    res[rng.random((8, n)) < 0.2] = 0.0
+    want = res.copy()
+    pairs = [(0, 1), (2, 3), (1, 2), (6, 7)]
+    for m, a in pairs:
+        want[m], want[a] = oracle.vorbis_inverse_coupling(want[m], want[a])
+    d = dev(res)
+    v.inverse_coupling(d, n, [p[0] for p in pairs], [p[1] for p in pairs])
+    assert_parity(host(d), want, "coupling")
+    fl = rng.standard_normal(8 * n).astype(np.float32)
+    dfl = dev(fl)
+    v.dot_product(dfl, d, 8 * n)
+    assert_parity(host(dfl), oracle.vorbis_dot_product(fl, want.ravel()), "dot product")
+    t2 = rng.standard_normal((3, 6 * 1024)).astype(np.float32)
+    planar = torch.empty((3, 6, 1024), dtype=torch.float32, device="cuda")
+    v.deinterleave2(dev(t2), planar, 6, 1024, 3)
+    assert_parity(host(planar), np.stack([oracle.vorbis_deinterleave2(t, 6) for t in t2]), "deinterleave")
+    for nn, n_posts, mult in ((1024, 40, 2), (128, 12, 1), (1024, 65, 4)):
+        xs = [0, nn] + rng.permutation(np.arange(1, nn))[:n_posts - 2].tolist()
+        rr = [256, 128, 86, 64][mult - 1]
+        ys = rng.integers(0, rr, size=(50, n_posts)).astype(np.uint32)
+        ys[rng.random((50, n_posts)) < 0.3] = 0
+        out = torch.zeros((50, nn), dtype=torch.float32, device="cuda")
+        v.floor1(xs, mult, dev(ys), nn, out, 50)
+        assert_parity(host(out), np.stack([oracle.vorbis_floor1(xs, y, mult, nn) for y in ys]), "floor1")
+
+
+# ------------------------------------------------------------------------------------------ FLAC
+
+def test_flac_restore_parity(ctx):
+    from symphonia_amd import FlacPredictor, flac_desc
+    rng = np.random.default_rng(4)
+    for blocksize in (1, 33, 192, 1000, 4096):
+        nb = 200
+        buf = rng.integers(-(1 << 23), 1 << 23, (nb, blocksize)).astype(np.int32)
+        kind = rng.integers(0, 3, nb).astype(np.uint8)
+        order = np.where(kind == 1, rng.integers(0, 5, nb), rng.integers(1, 33, nb))
+        order = np.minimum(order, blocksize).astype(np.uint8)
+        kind[(kind == 2) & (order == 0)] = 0
+        shift = rng.integers(0, 16, nb).astype(np.uint8)
+        wasted = np.where(rng.random(nb) < 0.2, rng.integers(1, 8, nb), 0).astype(np.uint8)
+        coeffs = rng.integers(-(1 << 14), 1 << 14, (nb, 32)).astype(np.int32)
+        d = dev(buf)
+        FlacPredictor(ctx).restore(d, dev(flac_desc(kind, order, shift, wasted).view(np.uint8).reshape(nb, 4)), dev(coeffs))
+        want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, wasted), coeffs)
+        assert np.array_equal(host(d), want), blocksize
+
+
+def test_flac_config5_encoder_identity(ctx):
+    """BASELINE config 5 shape (order-32 LPC, 4096-sample blocks, 24-bit), reduced count: a forward
+    encoder's residuals must decode back to the PCM exactly."""
+    from symphonia_amd import FlacPredictor, flac_desc
+    rng = np.random.default_rng(5)
+    nb, bs, order, shift = 512, 4096, 32, 12
+    t = np.arange(bs)
+    pcm = (np.sin(t[None] * rng.uniform(0.01, 0.3, (nb, 1))) * 3e6 + rng.standard_normal((nb, bs)) * 2e4).astype(np.int64)
+    co = np.zeros((nb, 32), np.int64)
+    co[:, 0] = int(1.6 * (1 << shift))
+    co[:, 1] = int(-0.7 * (1 << shift))
+    co[:, 2:] = rng.integers(-60, 60, (nb, 30))
+    res = pcm.copy()
+    hist = np.stack([pcm[:, order - 1 - j: bs - 1 - j] for j in range(order)], axis=2)  # [nb, bs-order, order]
+    pred = (hist * co[:, None, :]).sum(axis=2) >> shift
+    res[:, order:] = pcm[:, order:] - pred
+    assert np.abs(res).max() < (1 << 31)
+    d = dev(res.astype(np.int32))
+    kind = np.full(nb, 2, np.uint8)
+    FlacPredictor(ctx).restore(d, dev(flac_desc(kind, kind * 0 + order, kind * 0 + shift, kind * 0).view(np.uint8).reshape(nb, 4)),
+                               dev(co.astype(np.int32)))
+    assert np.array_equal(host(d), pcm.astype(np.int32))
+
+
+def test_flac_decorrelate_parity(ctx):
+    from symphonia_amd import FlacPredictor
+    rng = np.random.default_rng(6)
+    n_pairs, bs = 40, 1152
+    a = rng.integers(-(1 << 24), 1 << 24, (n_pairs, bs)).astype(np.int32)
+    b = rng.integers(-(1 << 24), 1 << 24, (n_pairs, bs)).astype(np.int32)
+    mode = rng.integers(0, 4, n_pairs).astype(np.uint8)
+    da, db = dev(a), dev(b)
+    FlacPredictor(ctx).decorrelate(dev(mode), da, db, bs, out_shift=8)
+    ga, gb = host(da), host(db)
+    for p in range(n_pairs):
+        wa, wb = oracle.flac_decorrelate(int(mode[p]), a[p], b[p])
+        assert np.array_equal(ga[p], oracle.flac_shl(wa, 8)) and np.array_equal(gb[p], oracle.flac_shl(wb, 8))
+
+
+def test_no_cpu_fallback(ctx):
+    """The product library refuses to exist without HIP: creating a context on a bogus device fails."""
+    from symphonia_amd import Context, SymaccelError
+    with pytest.raises(SymaccelError):
+        Context(99)

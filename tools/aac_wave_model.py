@@ -110,8 +110,9 @@ def butterfly(re, im, a, b, qr, qi):
 # --------------------------------------------------------------------------- LDS layouts
 
 def lds_T1(B, j, k):
-    """complex index of element (B, j, k) for the pass1 -> pass2 transpose."""
-    return B * 64 + (j & 1) * 32 + (((j >> 1) & 1) ^ ((B >> 1) & 1)) * 16 + (((j >> 2) & 1) ^ (B & 1)) * 8 + (k ^ B)
+    """complex index of element (B, j, k) for the pass1 -> pass2 transpose: separable
+    (lane base + per-instruction immediate on both sides) and conflict-free."""
+    return B + 8 * (j >> 2) + 36 * k + 288 * (j & 3)
 
 
 def lds_T2(B, j, k):
@@ -120,7 +121,7 @@ def lds_T2(B, j, k):
 
 
 def lds_T2_impl(B, j, k):
-    return (B * 64 + j * 8 + k) ^ ((B & 1) << 3)
+    return k + 8 * ((B & 1) + j) + 64 * (B >> 1) + 256 * (B & 1)
 
 
 class Lds:
@@ -146,7 +147,7 @@ def run_frame(spec, tw_pre, W16, W32, W64, W128, W256, W512, conflict_log=None):
     re, im = fft8_regs((zr[:, REV3], zi[:, REV3]))
     Bw, jw = REV3[m & 7], REV3[m >> 3]
     # ---- T1 through LDS
-    lds = Lds(1024)
+    lds = Lds(1536)
     for r in range(8):
         a = lds_T1(Bw, jw, r)
         lds.re[a], lds.im[a] = re[:, r], im[:, r]
