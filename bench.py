@@ -17,7 +17,6 @@ import json
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -25,7 +24,12 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+T_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
 def make_workload(name, torch, ctx, seed, scale=1.0):
@@ -108,61 +112,49 @@ def make_workload(name, torch, ctx, seed, scale=1.0):
     raise ValueError(name)
 
 
-def cpu_baseline(name, seconds=12.0):
-    """The oracle (C restatement of the reference's scalar path) timed on the host cores on a bounded sample."""
+def cpu_baseline(name, seconds=10.0):
+    """The oracle (C restatement of the reference's scalar path) timed on the host cores on a bounded sample.
+    Fan-out over cores happens inside oracle/bench_mt.c (pthreads, private outputs per thread)."""
     import oracle
     cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
     if name == "aac":
-        nch, nfr = 2, 256
-        coeffs = rng.standard_normal((nch, nfr, 1024)).astype(np.float32)
-        side = np.full((nch, nfr), oracle.aac_side(0, 1, 1), np.uint8)
-        delay = np.zeros((nch, 1024), np.float32)
-
-        def work():
-            oracle.aac_synth(coeffs, side, delay)
+        nch, nfr = 2, 128
+        in0 = rng.standard_normal((nch, nfr, 1024)).astype(np.float32)
+        in0[:, :, 672:] = 0.0
+        in1 = np.full((nch, nfr), oracle.aac_side(0, 1, 1), np.uint8)
+        kw = dict(n_chains=nch, per_chain=nfr)
         units, unit = nch * nfr / 2, "frames/s"
-        sample = "%d channel-frames (2 chains x 256 long blocks) per task" % (nch * nfr)
+        sample = "%d channel-frames (2 chains x %d long blocks)" % (nch * nfr, nfr)
     elif name == "mp3":
-        nch, ngr = 2, 256
-        xr = rng.standard_normal((nch, ngr, 576)).astype(np.float32)
-        side = oracle.mp3_side(np.zeros((nch, ngr)), np.zeros((nch, ngr)), np.full((nch, ngr), 576))
-        z = (np.zeros((nch, 576), np.float32), np.zeros((nch, 1024), np.float32), np.zeros(nch, np.int32))
-
-        def work():
-            oracle.mp3_synth(xr, side, 0, *z)
+        nch, ngr = 2, 128
+        in0 = rng.standard_normal((nch, ngr, 576)).astype(np.float32)
+        in1 = oracle.mp3_side(np.zeros((nch, ngr)), np.zeros((nch, ngr)), np.full((nch, ngr), 576))
+        kw = dict(n_chains=nch, per_chain=ngr, p0=0)
         units, unit = nch * ngr / 2, "granules/s"
-        sample = "%d granule-channels per task" % (nch * ngr)
+        sample = "%d granule-channels (2 chains x %d long granules)" % (nch * ngr, ngr)
     elif name == "vorbis":
-        flags = np.ones((8, 64), np.uint8)
-        spectra = rng.standard_normal((8, 64 * 1024)).astype(np.float32)
-
-        def work():
-            oracle.vorbis_synth(8, 11, spectra, flags, np.full(8, -1, np.int32), np.zeros((8, 1024), np.float32), 64 * 1024)
-        units, unit = 64, "frames/s"
-        sample = "8 ch x 64 long blocks per task"
+        nch, nb = 8, 32
+        in1 = np.ones((nch, nb), np.uint8)
+        in0 = rng.standard_normal((nch, nb * 1024)).astype(np.float32)
+        kw = dict(n_chains=nch, per_chain=nb, stride_in=nb * 1024, stride_out=nb * 1024, p0=8, p1=11)
+        units, unit = nb, "frames/s"
+        sample = "8 ch x %d long blocks" % nb
     else:
-        nb, bs = 16, 4096
-        buf = rng.integers(-4096, 4096, (nb, bs)).astype(np.int32)
-        desc = oracle.flac_desc(np.full(nb, 2), np.full(nb, 32), np.full(nb, 12), np.zeros(nb))
+        nb, bs = 8, 4096
+        in0 = rng.integers(-4096, 4096, (nb, bs)).astype(np.int32)
+        in1 = oracle.flac_desc(np.full(nb, 2), np.full(nb, 32), np.full(nb, 12), np.zeros(nb))
         co = rng.integers(-40, 40, (nb, 32)).astype(np.int32)
-
-        def work():
-            oracle.flac_restore(buf, desc, co)
+        kw = dict(in2=co, n_chains=nb, per_chain=bs)
         units, unit = nb, "blocks/s"
-        sample = "16 order-32 blocks of 4096 samples per task"
-    work()  # warm tables
-    t0 = time.perf_counter()
-    work()
-    one = max(time.perf_counter() - t0, 1e-6)
-    reps = max(1, int(seconds / one))  # per thread
-    with ThreadPoolExecutor(cores) as ex:
-        t0 = time.perf_counter()
-        list(ex.map(lambda _: [work() for _ in range(reps)], range(cores)))
-        dt = time.perf_counter() - t0
+        sample = "%d order-32 blocks of 4096 samples" % nb
+    one = oracle.bench_mt(name, 1, 3, in0, in1, **kw) / 3  # single-thread calibration
+    reps = max(1, int(seconds / max(one, 1e-6)))
+    dt = oracle.bench_mt(name, cores, reps, in0, in1, **kw)
     return {"value": units * reps * cores / dt, "unit": unit, "cores": cores, "kind": "port",
-            "sample": "oracle/symoracle.c (scalar restatement of the reference's non-SIMD path, gcc -O2, no FMA), "
-                      + sample + ", %d reps on each of %d threads" % (reps, cores)}
+            "single_thread_value": units / one,
+            "sample": "oracle/symoracle.c (scalar restatement of the reference's non-SIMD path, gcc -O2, no FMA): "
+                      + sample + " per task, %d reps on each of %d threads (%.1f s)" % (reps, cores, dt)}
 
 
 def main():
@@ -175,6 +167,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(170, repeat=True, file=sys.stderr)  # a hang leaves a stack in the log
 
     import torch
     import torch.distributed as dist
@@ -195,9 +190,11 @@ def main():
         ctx.set_segment(args.segment)
     step, units, unit_name, alg_bytes, config, kernel = make_workload(args.workload, torch, ctx, 1234 + rank, args.scale)
 
+    log("workload built: %s" % config["workload"])
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    log("warmup done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -219,6 +216,7 @@ def main():
         elapsed = float(t.item())
     dev_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]  # HIP events on the launch stream
     launch_s = float(np.mean(dev_ms)) / 1e3
+    log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))
 
     if rank == 0:
         achieved = alg_bytes / launch_s / 1e9

@@ -16,7 +16,7 @@ _SO = _HERE / "libsymoracle.so"
 
 
 def build(force=False):
-    src_m = max((_HERE / f).stat().st_mtime for f in ("symoracle.c", "symoracle.h", "spec_tables.h"))
+    src_m = max((_HERE / f).stat().st_mtime for f in ("symoracle.c", "bench_mt.c", "symoracle.h", "spec_tables.h"))
     if force or not _SO.exists() or _SO.stat().st_mtime < src_m:
         subprocess.run(["make", "-C", str(_HERE)], check=True, stdout=subprocess.DEVNULL)
     return _SO
@@ -34,6 +34,9 @@ def lib():
         _lib.so_imdct_new.argtypes = [C.c_int, C.c_double]
         _lib.so_flac_rice_signed_to_i32.restype = C.c_int32
         _lib.so_flac_rice_signed_to_i32.argtypes = [C.c_uint32]
+        _lib.so_bench_mt.restype = C.c_double
+        _lib.so_bench_mt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
         _lib.so_mp3_reorder.restype = C.c_int
         _lib.so_mp3_antialias.restype = C.c_int
     return _lib
@@ -356,3 +359,12 @@ def flac_restore(buf, desc, coeffs):
     c = np.ascontiguousarray(coeffs, dtype=np.int32)
     lib().so_flac_restore_batch(_p(b), _p(d), _p(c), C.c_size_t(b.shape[0]), C.c_size_t(b.shape[1]))
     return b
+
+
+# ---- timing driver (bench.py cpu_baseline) ------------------------------------
+
+def bench_mt(kind, threads, reps, in0, in1, in2=None, n_chains=0, per_chain=0, stride_in=0, stride_out=0, p0=0, p1=0):
+    """oracle/bench_mt.c: `threads` pthreads each run the batch `reps` times on private outputs; returns seconds."""
+    k = {"aac": 0, "mp3": 1, "vorbis": 2, "flac": 3}[kind]
+    return float(lib().so_bench_mt(k, int(threads), int(reps), _p(in0), _p(in1), _p(in2) if in2 is not None else None,
+                                   n_chains, per_chain, stride_in, stride_out, p0, p1))
