@@ -112,11 +112,23 @@ def make_workload(name, torch, ctx, seed, scale=1.0):
     raise ValueError(name)
 
 
+def usable_cores():
+    """Threads the CPU baseline uses: the affinity mask, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(name, seconds=10.0):
     """The oracle (C restatement of the reference's scalar path) timed on the host cores on a bounded sample.
     Fan-out over cores happens inside oracle/bench_mt.c (pthreads, private outputs per thread)."""
     import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     rng = np.random.default_rng(0)
     if name == "aac":
         nch, nfr = 2, 128
@@ -148,13 +160,12 @@ def cpu_baseline(name, seconds=10.0):
         kw = dict(in2=co, n_chains=nb, per_chain=bs)
         units, unit = nb, "blocks/s"
         sample = "%d order-32 blocks of 4096 samples" % nb
-    one = oracle.bench_mt(name, 1, 3, in0, in1, **kw) / 3  # single-thread calibration
-    reps = max(1, int(seconds / max(one, 1e-6)))
-    dt = oracle.bench_mt(name, cores, reps, in0, in1, **kw)
-    return {"value": units * reps * cores / dt, "unit": unit, "cores": cores, "kind": "port",
-            "single_thread_value": units / one,
+    dt1, reps1 = oracle.bench_mt(name, 1, 2.0, in0, in1, **kw)  # the reference is single-threaded (BENCHMARKS.md:5)
+    dt, reps = oracle.bench_mt(name, cores, seconds, in0, in1, **kw)
+    return {"value": units * reps / dt, "unit": unit, "cores": cores, "kind": "port",
+            "single_thread_value": units * reps1 / dt1,
             "sample": "oracle/symoracle.c (scalar restatement of the reference's non-SIMD path, gcc -O2, no FMA): "
-                      + sample + " per task, %d reps on each of %d threads (%.1f s)" % (reps, cores, dt)}
+                      + sample + " per task; %d tasks on %d threads in %.1f s" % (reps, cores, dt)}
 
 
 def main():

@@ -35,7 +35,7 @@ def lib():
         _lib.so_flac_rice_signed_to_i32.restype = C.c_int32
         _lib.so_flac_rice_signed_to_i32.argtypes = [C.c_uint32]
         _lib.so_bench_mt.restype = C.c_double
-        _lib.so_bench_mt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+        _lib.so_bench_mt.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_long), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
         _lib.so_mp3_reorder.restype = C.c_int
         _lib.so_mp3_antialias.restype = C.c_int
@@ -363,8 +363,11 @@ def flac_restore(buf, desc, coeffs):
 
 # ---- timing driver (bench.py cpu_baseline) ------------------------------------
 
-def bench_mt(kind, threads, reps, in0, in1, in2=None, n_chains=0, per_chain=0, stride_in=0, stride_out=0, p0=0, p1=0):
-    """oracle/bench_mt.c: `threads` pthreads each run the batch `reps` times on private outputs; returns seconds."""
+def bench_mt(kind, threads, seconds, in0, in1, in2=None, n_chains=0, per_chain=0, stride_in=0, stride_out=0, p0=0, p1=0):
+    """oracle/bench_mt.c: `threads` pthreads each run the batch on private outputs for `seconds`.
+    Returns (elapsed seconds, batches completed by all threads)."""
     k = {"aac": 0, "mp3": 1, "vorbis": 2, "flac": 3}[kind]
-    return float(lib().so_bench_mt(k, int(threads), int(reps), _p(in0), _p(in1), _p(in2) if in2 is not None else None,
-                                   n_chains, per_chain, stride_in, stride_out, p0, p1))
+    reps = C.c_long(0)
+    dt = float(lib().so_bench_mt(k, int(threads), float(seconds), C.byref(reps), _p(in0), _p(in1),
+                                 _p(in2) if in2 is not None else None, n_chains, per_chain, stride_in, stride_out, p0, p1))
+    return dt, int(reps.value)

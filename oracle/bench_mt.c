@@ -4,8 +4,9 @@
  * bench.py's `cpu_baseline` leg times the oracle (the C restatement of the reference's scalar,
  * single-threaded path) on every host core.  Doing the fan-out from Python threads serialises on the
  * allocator / GIL at 256 threads, so the fan-out lives here: `threads` pthreads, each with private
- * state and output buffers, each running the same read-only input `reps` times between two barriers.
- * Returns the wall time in seconds of the timed region (all threads, start barrier -> last finish).
+ * state and output buffers, each running the same read-only input until `seconds` have elapsed
+ * (time-bounded, so an over-subscribed or CPU-quota'd box cannot stretch the run).  Returns the wall
+ * time of the timed region (start barrier -> last finish); *total_reps = batches completed by all threads.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -18,7 +19,9 @@
 
 typedef struct job {
     int kind; /* 0 aac, 1 mp3, 2 vorbis, 3 flac */
-    int reps;
+    double seconds;
+    long *total_reps;
+    pthread_mutex_t *lock;
     const void *in0, *in1, *in2;
     size_t n_chains, per_chain, stride_in, stride_out;
     int p0, p1;
@@ -53,6 +56,12 @@ static void run_once(const job *j, void *state, void *out) {
     }
 }
 
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static void *worker(void *arg) {
     const job *j = (const job *)arg;
     size_t state_bytes, out_bytes;
@@ -65,25 +74,29 @@ static void *worker(void *arg) {
     void *state = calloc(1, state_bytes), *out = calloc(1, out_bytes);
     run_once(j, state, out); /* warm: tables, page faults */
     pthread_barrier_wait(j->start);
-    for (int r = 0; r < j->reps; ++r) run_once(j, state, out);
+    const double deadline = now_s() + j->seconds;
+    long reps = 0;
+    do {
+        run_once(j, state, out);
+        ++reps;
+    } while (now_s() < deadline);
+    pthread_mutex_lock(j->lock);
+    *j->total_reps += reps;
+    pthread_mutex_unlock(j->lock);
     free(state);
     free(out);
     return NULL;
 }
 
-static double now_s(void) {
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
-}
-
 /* kind: 0 aac (in0 coeffs, in1 side), 1 mp3 (in0 xr, in1 side, p0 sample_rate_idx), 2 vorbis (in0 spectra,
  * in1 flags, p0/p1 bs exps, strides), 3 flac (in0 buf, in1 desc, in2 coeffs; per_chain = blocksize). */
-double so_bench_mt(int kind, int threads, int reps, const void *in0, const void *in1, const void *in2,
+double so_bench_mt(int kind, int threads, double seconds, long *total_reps, const void *in0, const void *in1, const void *in2,
                    size_t n_chains, size_t per_chain, size_t stride_in, size_t stride_out, int p0, int p1) {
     pthread_barrier_t start;
     pthread_barrier_init(&start, NULL, (unsigned)threads + 1);
-    job j = {kind, reps, in0, in1, in2, n_chains, per_chain, stride_in, stride_out, p0, p1, &start};
+    pthread_mutex_t lock = PTHREAD_MUTEX_INITIALIZER;
+    *total_reps = 0;
+    job j = {kind, seconds, total_reps, &lock, in0, in1, in2, n_chains, per_chain, stride_in, stride_out, p0, p1, &start};
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
     for (int i = 0; i < threads; ++i) pthread_create(&th[i], NULL, worker, &j);
     pthread_barrier_wait(&start);
