@@ -185,6 +185,7 @@ def main():
     import torch
     import torch.distributed as dist
     import symphonia_amd as sa
+    from symphonia_amd.sharding import max_over_ranks
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -221,10 +222,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist if world > 1 else None, device="cuda")
     dev_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]  # HIP events on the launch stream
     launch_s = float(np.mean(dev_ms)) / 1e3
     log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))

@@ -16,6 +16,9 @@
 // Bound: integer ALU / dependent-chain latency (32 i32xi32->i64 MACs per 8 B), NOT HBM.
 #include <hip/hip_runtime.h>
 
+#include <climits>
+#include <cstdint>
+
 #include "symaccel_internal.h"
 
 namespace symaccel {
@@ -36,7 +39,7 @@ __device__ __forceinline__ unsigned wave_max(unsigned v) {
 }
 
 // 32 recurrence steps with statically indexed circular history: before step u the most recent
-// sample sits in h[(u + 31) & 31].
+// sample sits in h[(u + 31) & 31].  Integer path: any coefficient magnitude.
 template <int TAPS>
 __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)[32], int32_t *row, int col0,
                                             int first_pred, int n_valid, uint32_t shift, uint32_t wasted) {
@@ -53,6 +56,84 @@ __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)
             h[u & 31] = x;
             row[col0 + u] = (int32_t)((uint32_t)x << wasted);  // samples_shl (decoder.rs:403-409)
         }
+    }
+}
+
+// The same recurrence with the dot product carried by the FP64 FMA pipe, which is exact here:
+// |c_j| < 2^16 (checked per wavefront; a valid stream has qlp precision <= 15 bits, decoder.rs:467-471)
+// and |s| <= 2^31, so every product is < 2^47 and every partial sum of <= 32 products is < 2^52 < 2^53:
+// no FMA ever rounds, the sum is the exact integer whatever the association, and the four partial
+// accumulators (which break the 32-deep dependent chain) change nothing.  v_mad_i64_i32 is a
+// quarter-rate instruction on CDNA4, v_fma_f64 is full rate.
+// (acc >> shift) as i32  ==  floor(acc * 2^-shift) mod 2^32: ldexp and floor are exact, the mod is taken
+// by peeling the multiple of 2^32 off in f64 (exact) before the conversion.
+template <int TAPS>
+__device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&c)[32], int32_t *row, int col0,
+                                                int first_pred, int n_valid, int shift, uint32_t wasted) {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        if (u < n_valid) {
+            int32_t x = row[col0 + u];
+            if (col0 + u >= first_pred) {
+                constexpr int P = TAPS >= 8 ? 4 : 1;
+                double part[P];
+#pragma unroll
+                for (int q = 0; q < P; ++q) part[q] = 0.0;
+#pragma unroll
+                for (int j = 0; j < TAPS; ++j) part[j % P] = __builtin_fma(c[j], h[(u + 31 - j) & 31], part[j % P]);
+                double acc = part[0];
+                if constexpr (P == 4) acc = (part[0] + part[1]) + (part[2] + part[3]);
+                const double q = __builtin_floor(__builtin_ldexp(acc, -shift));         // floor(acc / 2^shift)
+                const double hi = __builtin_floor(__builtin_ldexp(q, -32));             // floor(q / 2^32)
+                const double lo = __builtin_fma(hi, -4294967296.0, q);                  // q mod 2^32, in [0, 2^32)
+                x = wrap_add(x, (int32_t)(uint32_t)lo);
+            }
+            h[u & 31] = (double)x;
+            row[col0 + u] = (int32_t)((uint32_t)x << wasted);  // samples_shl (decoder.rs:403-409)
+        }
+    }
+}
+
+__device__ __forceinline__ int iabs_sat(int32_t v) { return v < 0 ? (v == INT32_MIN ? INT32_MAX : -v) : v; }
+
+// Tile loop of the FP64 path (same tiling as the integer path below).
+__device__ __forceinline__ void flac_restore_f64(int32_t *__restrict__ buf, int32_t *tile, const int32_t (&ci)[32],
+                                                 size_t blk0, size_t n_blocks, unsigned blocksize, int lane, bool have,
+                                                 unsigned order, unsigned max_order, int shift, uint32_t wasted) {
+    double c[32], h[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        c[j] = (double)ci[j];
+        h[j] = 0.0;
+    }
+    for (unsigned t0 = 0; t0 < blocksize; t0 += kTile) {
+        const unsigned cols = min((unsigned)kTile, blocksize - t0);
+        for (int r = 0; r < kTile; ++r) {
+            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
+                tile[r * kStride + lane] = buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane];
+        }
+        __syncthreads();
+        if (have) {
+            int32_t *row = tile + lane * kStride;
+            for (int half = 0; half < 2; ++half) {
+                const int col0 = 32 * half;
+                const int n_valid = (int)cols - col0;
+                const int first_pred = (int)order - (int)t0;
+                if (n_valid <= 0) break;
+                if (max_order <= 4)
+                    lpc_steps32_f64<4>(h, c, row, col0, first_pred, n_valid, shift, wasted);
+                else if (max_order <= 12)
+                    lpc_steps32_f64<12>(h, c, row, col0, first_pred, n_valid, shift, wasted);
+                else
+                    lpc_steps32_f64<32>(h, c, row, col0, first_pred, n_valid, shift, wasted);
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < kTile; ++r) {
+            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
+                buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane] = tile[r * kStride + lane];
+        }
+        __syncthreads();
     }
 }
 
@@ -95,6 +176,18 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(int32_t *__restrict__ 
     }
     // Does any lane of this wavefront need more than 4 / 12 taps?  (wave-uniform specialisation)
     const unsigned max_order = wave_max(order);
+    // FP64 path iff every coefficient of the wavefront is below 2^16 in magnitude (always, for valid streams)
+    unsigned cmax = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const unsigned a = (unsigned)iabs_sat(c[j]);
+        cmax = a > cmax ? a : cmax;
+    }
+    const bool use_f64 = wave_max(cmax) < 65536u;
+    if (use_f64) {
+        flac_restore_f64(buf, tile, c, blk0, n_blocks, blocksize, lane, have, order, max_order, (int)shift, wasted);
+        return;
+    }
 
     for (unsigned t0 = 0; t0 < blocksize; t0 += kTile) {
         const unsigned cols = min((unsigned)kTile, blocksize - t0);

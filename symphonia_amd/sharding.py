@@ -1,0 +1,47 @@
+"""Batch sharding across GPUs (one process per GPU).
+
+Chains (one channel of one stream) are independent, so the batch is split by chain with no data-path
+collective; the channels of one stream stay on one rank so a decoder adapter sees whole frames.
+`torch.distributed` (RCCL on the GPU box, gloo in the CPU tests) is used only for barriers, the
+max-over-ranks timing and -- when a caller really wants the PCM in one place -- an all_gather.
+"""
+
+
+def shard_streams(n_streams, world_size, rank):
+    """Contiguous, balanced [begin, end) range of streams for `rank` (first ranks take the remainder)."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError("rank %d out of range for world size %d" % (rank, world_size))
+    base, extra = divmod(int(n_streams), world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_chains(n_chains, channels_per_stream, world_size, rank):
+    """[begin, end) range of chains for `rank`, aligned to whole streams."""
+    if n_chains % channels_per_stream:
+        raise ValueError("n_chains must be a multiple of channels_per_stream")
+    b, e = shard_streams(n_chains // channels_per_stream, world_size, rank)
+    return b * channels_per_stream, e * channels_per_stream
+
+
+def max_over_ranks(seconds, dist=None, device=None):
+    """The bench clock: the slowest rank's time (bench.py contract)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(seconds)
+    import torch
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_chains(local, n_chains, channels_per_stream, dist):
+    """all_gather of chain-major shards (rows = chains) back into the full batch order, on every rank."""
+    import torch
+    world = dist.get_world_size()
+    sizes = [shard_chains(n_chains, channels_per_stream, world, r) for r in range(world)]
+    rows = max(e - b for b, e in sizes)
+    pad = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[: e - b] for o, (b, e) in zip(out, sizes)], dim=0)

@@ -126,3 +126,23 @@ def aac_sequence_chain(rng, n_frames, p_switch=0.25):
     shape = rng.integers(0, 2, size=n_frames).astype(np.uint8)
     prev = np.concatenate(([rng.integers(0, 2)], shape[:-1])).astype(np.uint8)
     return seq, shape, prev
+
+
+def flac_extreme_case(seed, big_coeffs):
+    """Full-range i32 samples (wrapping adds) with coefficients at the edge of the FP64-exact path
+    (|c| < 2^16, big_coeffs=False) or far beyond it (integer path, big_coeffs=True)."""
+    rng = np.random.default_rng(seed)
+    nb, blocksize = 64, 97
+    buf = rng.integers(-(1 << 31), 1 << 31, (nb, blocksize)).astype(np.int32)
+    buf[0, :40] = -(1 << 31)
+    buf[1, :40] = (1 << 31) - 1
+    kind = np.full(nb, 2, np.uint8)
+    order = rng.integers(1, 33, nb).astype(np.uint8)
+    order[:4] = 32
+    shift = rng.integers(0, 32, nb).astype(np.uint8)
+    lim = (1 << 30) if big_coeffs else (1 << 16) - 1
+    coeffs = rng.integers(-lim, lim + 1, (nb, 32)).astype(np.int32)
+    coeffs[0] = -lim
+    coeffs[1] = lim
+    coeffs[2] = np.where(np.arange(32) % 2 == 0, lim, -lim)
+    return buf, kind, order, shift, coeffs

@@ -5,7 +5,7 @@ import pytest
 
 import oracle
 from emu_lib import emu_ctx  # noqa: F401
-from helpers import bit_equal
+from helpers import bit_equal, flac_extreme_case
 from symphonia_amd import FlacPredictor, Mp3Synthesis, VorbisDsp, flac_desc, mp3_side
 from symphonia_amd.backend import FLAC_FIXED, FLAC_LPC, FLAC_VERBATIM
 
@@ -162,6 +162,14 @@ def test_emu_flac_small_orders_only(emu_ctx):
         got = FlacPredictor(emu_ctx).restore(buf, flac_desc(kind, order, shift, 0 * shift), coeffs)
         want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, 0 * shift), coeffs)
         assert np.array_equal(got, want), hi
+
+
+@pytest.mark.parametrize("big_coeffs", [False, True])
+def test_emu_flac_extreme_ranges(emu_ctx, big_coeffs):
+    buf, kind, order, shift, coeffs = flac_extreme_case(23, big_coeffs)
+    got = FlacPredictor(emu_ctx).restore(buf, flac_desc(kind, order, shift, 0 * shift), coeffs)
+    want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, 0 * shift), coeffs)
+    assert np.array_equal(got, want)
 
 
 def test_emu_flac_decorrelate(emu_ctx):

@@ -323,6 +323,18 @@ def test_flac_config5_encoder_identity(ctx):
     assert np.array_equal(host(d), pcm.astype(np.int32))
 
 
+@pytest.mark.parametrize("big_coeffs", [False, True])
+def test_flac_extreme_ranges(ctx, big_coeffs):
+    """Full-range i32 samples with |c| < 2^16 (FP64-exact dot product path) and |c| up to 2^30 (i64 path)."""
+    from helpers import flac_extreme_case
+    from symphonia_amd import FlacPredictor, flac_desc
+    buf, kind, order, shift, coeffs = flac_extreme_case(29, big_coeffs)
+    d = dev(buf)
+    FlacPredictor(ctx).restore(d, dev(flac_desc(kind, order, shift, 0 * shift).view(np.uint8).reshape(-1, 4)), dev(coeffs))
+    want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, 0 * shift), coeffs)
+    assert np.array_equal(host(d), want)
+
+
 def test_flac_decorrelate_parity(ctx):
     from symphonia_amd import FlacPredictor
     rng = np.random.default_rng(6)
