@@ -12,6 +12,14 @@
 
 namespace symaccel {
 
+// Pointer to a host-generated constant table, in the CONSTANT address space: the tables are written
+// once before any launch, so uniform-index reads may use scalar loads (s_load_dword through the
+// scalar cache into SGPRs) instead of per-lane vector loads that each occupy a VGPR.
+using cf32p = const __attribute__((address_space(4))) float *;
+__device__ __forceinline__ cf32p as_const(const float *p) {
+    return (cf32p)p;  // deliberate address-space cast (global -> constant), same 64-bit representation
+}
+
 struct c32 {
     float re, im;
 };

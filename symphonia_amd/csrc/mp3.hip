@@ -4,38 +4,46 @@
 // Reference: symphonia-bundle-mp3/src/layer3/hybrid_synthesis.rs:153-485, 559-779;
 //            symphonia-bundle-mp3/src/synthesis.rs:158-844; caller layer3/mod.rs:440-476.
 //
-// MI355X mapping (DESIGN.md "mp3_synth"): a 64-lane wavefront carries TWO chains (one per
-// 32-lane half).  Each half walks a segment of consecutive granules of its chain:
-//   lane = sub-band for the hybrid stage (the 18-sample overlap of sub-band sb lives in lane sb's
-//   registers across granules), lane = time slot for the 18 dct32s, lane = output sample index
-//   for the 512-tap window (its 16 window coefficients live in registers).
-// LDS per chain: X/S tile (576 f32, the granule in sub-band-major then slot-major order) and the
-// polyphase history H[16 + 18][32] holding dct32 outputs of the previous 16 and the current 18
-// time slots (the reference's V rows are +-copies of those 32 values, synthesis.rs:247-263).
-// Segments other than a chain's first start with a two-granule halo (granule g-2 rebuilds the
-// overlap, granule g-1 rebuilds the 15-slot history); both depend only on those granules' inputs.
-// Roofline: HBM-bound, 2304 B in + 2304 B out per granule-channel, ~32 kflop -> 7 flop/B.
+// MI355X mapping (DESIGN.md "mp3_synth"): a 64-lane wavefront carries TWO chains (one per 32-lane
+// half) and is its own workgroup -- no workgroup barriers, only wave-local LDS ordering.  Each half
+// walks a segment of consecutive granules of its chain, with everything that crosses granules held
+// in REGISTERS:
+//   * lane = sub-band for antialias + hybrid synthesis: the sub-band's 18 lines and its 18-sample
+//     overlap are registers; the 8 antialias butterflies per boundary exchange with lanes sb-1 / sb+1;
+//   * lane = time slot for the 18 dct32s (one LDS transpose in, one out, both conflict-free b128);
+//   * lane = output sample i for the 512-tap window: the lane keeps the two V-vector entries it needs
+//     from each of the last 16 + 18 time slots (V[i] and V[32+i], which are +-copies of dct32 outputs,
+//     synthesis.rs:247-263) in registers, so the 16-tap dot product per sample reads no memory.
+// The next granule's 576 lines are prefetched (8 B/lane, 256 B per half-wave) while the current one
+// is transformed.  Segments other than a chain's first start with a two-granule halo (granule g-2
+// rebuilds the overlap, granule g-1 rebuilds the 16-slot history); both depend only on inputs.
+// LDS: one 5 KiB buffer per wavefront (the granule tile, then the dct32 transpose).
+// Roofline: HBM-bound on paper, 2304 B in + 2304 B out per granule-channel, ~34 kflop (no FMA) -> 7.4 flop/B.
 #include "dsp_device.h"
 
 namespace symaccel {
 
 namespace {
 
-constexpr int kHalf = 32;
-constexpr int kXStride = 19;   // sub-band-major tile X[sb][18], padded: 19 is odd -> conflict-free column reads
-constexpr int kSStride = 33;   // slot-major tile S[slot][32], padded
-constexpr int kHistOld = 16;  // previous slots kept (15 are read by the window, the 16th completes v_vec)
-constexpr int kHistRows = kHistOld + 18;
+constexpr int kSStride = 36;   // row stride (floats) of the slot-major transpose S[slot][32]: b128-aligned and
+                               // conflict-free for one-row-per-lane b128 access (lanes 0..17)
+constexpr int kHistOld = 16;   // previous time slots kept (15 are read by the window, the 16th completes v_vec)
+constexpr int kRows = kHistOld + 18;
+constexpr int kTileFloats = 2 * 576;             // two granule tiles (one per half-wave)
+constexpr int kWaveFloats = kTileFloats + 2 * 18 * kSStride;  // per-wavefront LDS
 
-struct Mp3Shared {
-    float tile[32 * kXStride > 18 * kSStride ? 32 * kXStride : 18 * kSStride];
-    float hist[kHistRows][32];
-};
+// Order this wavefront's LDS accesses: its lanes exchange data through LDS; the hardware executes one
+// wavefront's DS instructions in order, the fences stop the compiler from reordering them.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ---- 36-point IMDCT (Szu-Wei Lee), hybrid_synthesis.rs:559-779 -------------------------------
 
 // sdct_ii_9 (hybrid_synthesis.rs:720-779); writes y[0], y[2], ..., y[16]
-__device__ __forceinline__ void sdct_ii_9(const float (&x)[9], float *y, const float *D) {
+__device__ __forceinline__ void sdct_ii_9(const float (&x)[9], float *y, cf32p D) {
     const float a01 = x[3] + x[5], a02 = x[3] - x[5], a03 = x[6] + x[2], a04 = x[6] - x[2];
     const float a05 = x[1] + x[7], a06 = x[1] - x[7], a07 = x[8] + x[0], a08 = x[8] - x[0];
     const float a09 = x[4] + a05, a10 = a01 + a03, a11 = a10 + a07, a12 = a03 - a07;
@@ -57,7 +65,7 @@ __device__ __forceinline__ void sdct_ii_9(const float (&x)[9], float *y, const f
 }
 
 // dct_iv (hybrid_synthesis.rs:608-660) incl. sdct_ii_18 (:665-716)
-__device__ __forceinline__ void dct_iv_18(const float (&x)[18], float (&y)[19], const float *mc) {
+__device__ __forceinline__ void dct_iv_18(const float (&x)[18], float (&y)[19], cf32p mc) {
     float s[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) s[i] = mc[MP3C_DCT_IV + i] * x[i];
@@ -76,7 +84,7 @@ __device__ __forceinline__ void dct_iv_18(const float (&x)[18], float (&y)[19], 
 }
 
 // imdct36 (hybrid_synthesis.rs:571-603): x[18] in place, overlap[18] in/out
-__device__ __forceinline__ void imdct36(float (&x)[18], float (&overlap)[18], const float *window, const float *mc) {
+__device__ __forceinline__ void imdct36(float (&x)[18], float (&overlap)[18], cf32p window, cf32p mc) {
     float dct[19];
     dct_iv_18(x, dct, mc);
 #pragma unroll
@@ -90,8 +98,8 @@ __device__ __forceinline__ void imdct36(float (&x)[18], float (&overlap)[18], co
 }
 
 // imdct12_win (hybrid_synthesis.rs:363-455)
-__device__ __forceinline__ void imdct12_win(float (&x)[18], float (&overlap)[18], const float *window, const float *mc) {
-    const float *cos12 = mc + MP3C_COS12;
+__device__ __forceinline__ void imdct12_win(float (&x)[18], float (&overlap)[18], cf32p window, cf32p mc) {
+    cf32p cos12 = mc + MP3C_COS12;
     float tmp[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) tmp[i] = 0.0f;
@@ -99,7 +107,7 @@ __device__ __forceinline__ void imdct12_win(float (&x)[18], float (&overlap)[18]
     for (int w = 0; w < 3; ++w) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float *cl = cos12 + 6 * i, *cr = cos12 + 6 * (i + 3);
+            cf32p cl = cos12 + 6 * i, cr = cos12 + 6 * (i + 3);
             const float yl = (x[w] * cl[0]) + (x[3 + w] * cl[1]) + (x[6 + w] * cl[2]) + (x[9 + w] * cl[3]) +
                              (x[12 + w] * cl[4]) + (x[15 + w] * cl[5]);
             const float yr = (x[w] * cr[0]) + (x[3 + w] * cr[1]) + (x[6 + w] * cr[2]) + (x[9 + w] * cr[3]) +
@@ -119,7 +127,7 @@ __device__ __forceinline__ void imdct12_win(float (&x)[18], float (&overlap)[18]
 
 // ---- dct32 (B.G. Lee), synthesis.rs:348-844, as the recursion the reference flattens ---------
 template <int N>
-__device__ __forceinline__ void dct_lee(float *x, const float *mc) {
+__device__ __forceinline__ void dct_lee(float *x, cf32p mc) {
     if constexpr (N == 2) {
         const float a = x[0] + x[1], b = (x[0] - x[1]) * mc[MP3C_COS1];
         x[0] = a;
@@ -160,16 +168,17 @@ __device__ __forceinline__ VMap vmap(int i) {
     return m;
 }
 
-__global__ __launch_bounds__(64) void mp3_synth_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void mp3_synth_kernel(
     DevTables tb, const float *__restrict__ xr, const symaccel_mp3_side *__restrict__ side, int sr,
     const float *__restrict__ overlap_in, const float *__restrict__ vvec_in, const int32_t *__restrict__ vfront_in,
     float *__restrict__ overlap_out, float *__restrict__ vvec_out, int32_t *__restrict__ vfront_out,
     float *__restrict__ pcm, unsigned n_chains, unsigned granules_per_chain, unsigned seg_len,
     unsigned segs_per_chain) {
-    __shared__ Mp3Shared sh[2];
+    __shared__ __attribute__((aligned(16))) float lds[kWaveFloats];
     const int half = (int)threadIdx.x >> 5, hl = (int)threadIdx.x & 31;
-    Mp3Shared &S = sh[half];
-    const float *mc = tb.mp3_consts;
+    float *tile = lds + half * 576;               // the granule's 576 lines, natural order
+    float *S = lds + kTileFloats + half * (18 * kSStride);  // S[slot][32]: dct32 transpose
+    cf32p mc = as_const(tb.mp3_consts);
 
     const unsigned item = blockIdx.x * 2u + (unsigned)half;
     const bool live = item < n_chains * segs_per_chain;
@@ -187,34 +196,40 @@ __global__ __launch_bounds__(64) void mp3_synth_kernel(
     }
     const VMap vm = vmap(hl);
 
-    // ---- incoming state
-    float overlap[18];
+    // ---- incoming state.  oA[16 + r] = V_r[i], oB[16 + r] = V_r[32 + i] for the previous granules' time slots r < 0
+    float overlap[18], oA[kHistOld], oB[kHistOld];
     const bool first_seg = g_begin == 0;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) overlap[i] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < kHistOld; ++r) oA[r] = oB[r] = 0.0f;
     if (live && first_seg) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) overlap[i] = overlap_in[(size_t)chain * 576 + 18 * hl + i];
         const int v_front = vfront_in[chain] & 15;
-        // history rows 0..15 = time slots -16..-1; slot -m sits in FIFO row (v_front + m) & 15
         const float *vv = vvec_in + (size_t)chain * 1024;
-        for (int m = 1; m <= kHistOld; ++m) {
-            const float *row = vv + 64 * ((v_front + m) & 15);
-            // invert synthesis.rs:247-263: d[16+k] = V[k] (k=0..15), d[0] = -V[48], d[k] = -V[48+k]
-            S.hist[kHistOld - m][hl] = hl >= 16 ? row[hl - 16] : -row[48 + hl];
-        }
-    } else {
 #pragma unroll
-        for (int i = 0; i < 18; ++i) overlap[i] = 0.0f;
+        for (int m = 1; m <= kHistOld; ++m) {  // slot -m sits in FIFO row (v_front + m) & 15 (synthesis.rs:335)
+            const float *row = vv + 64 * ((v_front + m) & 15);
+            oA[kHistOld - m] = row[hl];
+            oB[kHistOld - m] = row[32 + hl];
+        }
     }
-    __syncthreads();
 
     // halo: g_begin-2 (overlap only), g_begin-1 (history only)
     const long g_first = first_seg ? 0 : (long)g_begin - 2;
-    long g_stop = (long)g_end;
-    // both halves must run the same number of barrier rounds
-    long rounds = g_stop - g_first;
+    const long g_stop = (long)g_end;
+    long rounds = live ? g_stop - g_first : 0;  // both halves run the same number of rounds (wave-uniform loop)
     {
         const long other = __shfl((int)rounds, (int)(threadIdx.x ^ 32u));
         rounds = rounds > other ? rounds : other;
+    }
+
+    float2 line[9];  // line[q] = src[2 (hl + 32 q) .. +1]: 256 B coalesced per half-wave and load
+    if (live && g_first < g_stop) {
+        const float2 *src = reinterpret_cast<const float2 *>(xr + (chain_base + (size_t)g_first) * 576);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) line[q] = src[hl + 32 * q];
     }
 
     for (long r = 0; r < rounds; ++r) {
@@ -230,52 +245,68 @@ __global__ __launch_bounds__(64) void mp3_synth_kernel(
             mixed = sd.is_mixed ? 1 : 0;
             rzero = sd.rzero > 576 ? 576 : sd.rzero;
         }
-        // ---- load + reorder (hybrid_synthesis.rs:153-215) into X[sb][18]
+        // ---- granule -> LDS tile (natural order), then lane sb gathers its 18 lines
         if (active) {
-            const float *src = xr + (chain_base + (size_t)g) * 576;
-            int r_start = 576, r_end = 576;
-            const int32_t *map = tb.mp3_reorder_map + (size_t)(sr * 2 + mixed) * 576;
-            if (bt == SYMACCEL_MP3_SHORT) {
-                const int32_t *ends = tb.mp3_reorder_end + (size_t)(sr * 2 + mixed) * 577;
-                r_start = ends[0];
-                r_end = ends[rzero];
-                rzero = rzero > r_end ? rzero : r_end;
-            }
+            float2 *t2 = reinterpret_cast<float2 *>(tile);
 #pragma unroll
-            for (int q = 0; q < 18; ++q) {
-                const int i = hl + 32 * q;
-                const int s = (i >= r_start && i < r_end) ? map[i] : i;
-                S.tile[(i / 18) * kXStride + (i % 18)] = src[s];
-            }
+            for (int q = 0; q < 9; ++q) t2[hl + 32 * q] = line[q];
         }
-        __syncthreads();
-        // ---- antialias (hybrid_synthesis.rs:218-277)
-        if (active && !(bt == SYMACCEL_MP3_SHORT && !mixed)) {
-            const int sb_limit = bt == SYMACCEL_MP3_SHORT ? 2 : 32;
-            int lim = rzero / 18 + 2;
-            lim = lim < sb_limit ? lim : sb_limit;
-            lim = lim < 32 ? lim : 32;
-            rzero = 18 * lim;
+        wave_sync();
+        float y[18];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int task = hl + 32 * q;  // 31 boundaries x 8 butterflies
-                const int sb = 1 + (task >> 3), i = task & 7;
-                if (sb < 32 && 18 * sb < rzero) {
-                    float *lo = &S.tile[(sb - 1) * kXStride + 17 - i], *up = &S.tile[sb * kXStride + i];
-                    const float lower = *lo, upper = *up;
-                    const float cs = mc[MP3C_CS + i], ca = mc[MP3C_CA + i];
-                    *lo = lower * cs - upper * ca;
-                    *up = upper * cs + lower * ca;
+        for (int i = 0; i < 18; ++i) y[i] = 0.0f;
+        if (active) {
+            if (bt == SYMACCEL_MP3_SHORT) {
+                // reorder (hybrid_synthesis.rs:153-215) applied as a gather through the precomputed source map
+                const int32_t *map = tb.mp3_reorder_map + (size_t)(sr * 2 + mixed) * 576;
+                const int32_t *ends = tb.mp3_reorder_end + (size_t)(sr * 2 + mixed) * 577;
+                const int r_start = ends[0], r_end = ends[rzero];
+                rzero = rzero > r_end ? rzero : r_end;
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    const int idx = 18 * hl + i;
+                    y[i] = tile[(idx >= r_start && idx < r_end) ? map[idx] : idx];
+                }
+            } else {
+                const float2 *t2 = reinterpret_cast<const float2 *>(tile + 18 * hl);  // 72 B lane stride: conflict-free b64
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float2 v = t2[k];
+                    y[2 * k] = v.x;
+                    y[2 * k + 1] = v.y;
                 }
             }
         }
-        __syncthreads();
+        // ---- antialias (hybrid_synthesis.rs:218-277): boundary sb pairs lane sb-1's y[17-i] with lane sb's y[i]
+        {
+            int lim = 0;  // boundaries 1 .. lim-1 are processed
+            if (active && !(bt == SYMACCEL_MP3_SHORT && !mixed)) {
+                const int sb_limit = bt == SYMACCEL_MP3_SHORT ? 2 : 32;
+                lim = rzero / 18 + 2;
+                lim = lim < sb_limit ? lim : sb_limit;
+                lim = lim < 32 ? lim : 32;
+                rzero = 18 * lim;
+            }
+            const bool below = hl >= 1 && hl < lim;      // boundary hl (with lane hl-1) is active
+            const bool above = hl + 1 < lim;             // boundary hl+1 (with lane hl+1) is active
+            float lo_new[8], up_new[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float cs = mc[MP3C_CS + i], ca = mc[MP3C_CA + i];
+                const float lower_nb = __shfl_up(y[17 - i], 1);   // lane sb-1's lower element
+                const float upper_nb = __shfl_down(y[i], 1);      // lane sb+1's upper element
+                up_new[i] = y[i] * cs + lower_nb * ca;            // upper' = upper * cs + lower * ca
+                lo_new[i] = y[17 - i] * cs - upper_nb * ca;       // lower' = lower * cs - upper * ca
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                y[i] = below ? up_new[i] : y[i];
+                y[17 - i] = above ? lo_new[i] : y[17 - i];
+            }
+        }
         // ---- hybrid synthesis (hybrid_synthesis.rs:280-359): lane = sub-band
-        float y[18];
         if (active) {
             const int sb = hl;
-#pragma unroll
-            for (int i = 0; i < 18; ++i) y[i] = S.tile[sb * kXStride + i];
             const int sb_limit = (rzero + 17) / 18;
             const int sb_split = bt == SYMACCEL_MP3_SHORT ? (mixed ? 2 : 0) : 32;
             if (sb >= sb_limit) {
@@ -296,68 +327,77 @@ __global__ __launch_bounds__(64) void mp3_synth_kernel(
                 for (int i = 1; i < 18; i += 2) y[i] = -y[i];
             }
         }
-        __syncthreads();  // everyone has read X; reuse the tile as S[slot][sb]
+        wave_sync();  // the previous granule's window pass has read S
         if (need_hist) {
 #pragma unroll
-            for (int b = 0; b < 18; ++b) S.tile[b * kSStride + hl] = y[b];
+            for (int b = 0; b < 18; ++b) S[b * kSStride + hl] = y[b];
         }
-        __syncthreads();
-        // ---- 18 x dct32 (synthesis.rs:165-245): lane = time slot
+        wave_sync();
+        // ---- 18 x dct32 (synthesis.rs:165-245): lane = time slot, row in / row out
         if (need_hist && hl < 18) {
             float d[32];
+            float4 *row = reinterpret_cast<float4 *>(S + hl * kSStride);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) d[i] = S.tile[hl * kSStride + i];
+            for (int k = 0; k < 8; ++k) {
+                const float4 v = row[k];
+                d[4 * k] = v.x;
+                d[4 * k + 1] = v.y;
+                d[4 * k + 2] = v.z;
+                d[4 * k + 3] = v.w;
+            }
             dct_lee<32>(d, mc);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) S.hist[kHistOld + hl][i] = d[i];
+            for (int k = 0; k < 8; ++k) row[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
         }
-        __syncthreads();
-        // ---- windowing (synthesis.rs:309-324): lane = sample index i within the 32-sample block
-        if (emit) {
-            float *dst = pcm + (chain_base + (size_t)g) * 576;
-            for (int b = 0; b < 18; ++b) {
-                float acc = 0.0f;
+        wave_sync();
+        if (live && g + 1 < g_stop) {  // prefetch the next granule; it lands during the window pass
+            const float2 *src = reinterpret_cast<const float2 *>(xr + (chain_base + (size_t)(g + 1)) * 576);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float df = S.hist[kHistOld + b - 2 * j][vm.fidx];
-                    const float v0 = vm.fkind == 0 ? df : (vm.fkind == 1 ? -df : 0.0f);  // V[i]
-                    const float v1 = -S.hist[kHistOld + b - 2 * j - 1][vm.sidx];          // V[32 + i]
-                    acc += v0 * dw0[j];
-                    acc += v1 * dw1[j];
-                }
-                dst[32 * b + hl] = acc;
+            for (int q = 0; q < 9; ++q) line[q] = src[hl + 32 * q];
+        }
+        // ---- windowing (synthesis.rs:309-324), one time slot at a time: fetch the slot's two V entries for
+        // this lane's sample index (synthesis.rs:247-263), then 16 taps with every operand in registers.
+        // (Lanes / granules that do not need the history read stale LDS into nA/nB and never use it.)
+        float *dst = pcm + (chain_base + (size_t)g) * 576;
+        float nA[18], nB[18];
+#pragma unroll
+        for (int b = 0; b < 18; ++b) {
+            const float df = S[b * kSStride + vm.fidx];
+            nA[b] = vm.fkind == 0 ? df : (vm.fkind == 1 ? -df : 0.0f);  // V[i]
+            nB[b] = -S[b * kSStride + vm.sidx];                          // V[32 + i]
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ra = b - 2 * j, rb = b - 2 * j - 1;
+                acc += (ra >= 0 ? nA[ra >= 0 ? ra : 0] : oA[ra < 0 ? kHistOld + ra : 0]) * dw0[j];
+                acc += (rb >= 0 ? nB[rb >= 0 ? rb : 0] : oB[rb < 0 ? kHistOld + rb : 0]) * dw1[j];
+            }
+            if (emit) dst[32 * b + hl] = acc;
+        }
+        // ---- slide the history: slots 2..17 of this granule become slots -16..-1
+        if (need_hist) {
+#pragma unroll
+            for (int m = 0; m < kHistOld; ++m) {
+                oA[m] = nA[2 + m];
+                oB[m] = nB[2 + m];
             }
         }
-        __syncthreads();
-        // ---- slide the history: slots 2..17 of this granule become slots -16..-1
-        float keep[kHistOld];
-        if (need_hist) {
-#pragma unroll
-            for (int m = 0; m < kHistOld; ++m) keep[m] = S.hist[18 + m][hl];
-        }
-        __syncthreads();
-        if (need_hist) {
-#pragma unroll
-            for (int m = 0; m < kHistOld; ++m) S.hist[m][hl] = keep[m];
-        }
-        __syncthreads();
     }
 
     // ---- outgoing state (only the segment that ends the chain)
     if (live && g_end == granules_per_chain) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) overlap_out[(size_t)chain * 576 + 18 * hl + i] = overlap[i];
-        // Rebuild v_vec[16][64] + v_front exactly as the reference leaves them: v_front moves back one
-        // row per time slot (synthesis.rs:335) and row (v_front + m) & 15 holds slot -m, m = 1..16.
+        // v_vec[16][64] + v_front exactly as the reference leaves them: v_front moves back one row per time
+        // slot (synthesis.rs:335) and row (v_front + m) & 15 holds slot -m, m = 1..16.
         const int vf0 = vfront_in[chain] & 15;
         const int vf_final = (int)(((unsigned)vf0 + 15u * 18u * granules_per_chain) & 15u);
         float *vv = vvec_out + (size_t)chain * 1024;
+#pragma unroll
         for (int m = 1; m <= kHistOld; ++m) {
             float *row = vv + 64 * ((vf_final + m) & 15);
-            const float *d = S.hist[kHistOld - m];
-            const float df = d[vm.fidx];
-            row[hl] = vm.fkind == 0 ? df : (vm.fkind == 1 ? -df : 0.0f);  // synthesis.rs:247-263
-            row[32 + hl] = -d[vm.sidx];
+            row[hl] = oA[kHistOld - m];
+            row[32 + hl] = oB[kHistOld - m];
         }
         if (hl == 0) vfront_out[chain] = vf_final;
     }
