@@ -26,7 +26,61 @@ namespace symaccel {
 namespace {
 
 constexpr int kTile = 64;
-constexpr int kStride = kTile + 1;
+constexpr int kStride = kTile + 4;  // 68: rows stay 16-byte aligned; one-row-per-lane b128 access is conflict-free
+
+// Tile I/O.  Fast path (full 64 x 64 tile, 16-byte aligned rows): every lane moves int4, a wavefront
+// instruction covers four 256-byte row segments, and all loads of a batch are in flight together.
+__device__ __forceinline__ void tile_fetch(const int32_t *__restrict__ buf, int32_t *tile, size_t blk0, size_t n_blocks,
+                                           unsigned blocksize, unsigned t0, unsigned cols, int lane, bool fast) {
+    if (fast) {
+        const int q = lane & 15, rsub = lane >> 4;
+#pragma unroll
+        for (int it0 = 0; it0 < 16; it0 += 8) {
+            int4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = 4 * (it0 + k) + rsub;
+                v[k] = *reinterpret_cast<const int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = 4 * (it0 + k) + rsub;
+                *reinterpret_cast<int4 *>(tile + r * kStride + 4 * q) = v[k];
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int r0 = 0; r0 < kTile; r0 += 16) {
+            int32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const size_t b = blk0 + (size_t)(r0 + k);
+                v[k] = (b < n_blocks && (unsigned)lane < cols) ? buf[b * blocksize + t0 + (unsigned)lane] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tile[(r0 + k) * kStride + lane] = v[k];
+        }
+    }
+}
+
+__device__ __forceinline__ void tile_store(int32_t *__restrict__ buf, const int32_t *tile, size_t blk0, size_t n_blocks,
+                                           unsigned blocksize, unsigned t0, unsigned cols, int lane, bool fast) {
+    if (fast) {
+        const int q = lane & 15, rsub = lane >> 4;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = 4 * it + rsub;
+            *reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q) =
+                *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q);
+        }
+    } else {
+#pragma unroll 4
+        for (int r = 0; r < kTile; ++r) {
+            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
+                buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane] = tile[r * kStride + lane];
+        }
+    }
+}
 
 __device__ __forceinline__ int32_t wrap_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 
@@ -43,10 +97,15 @@ __device__ __forceinline__ unsigned wave_max(unsigned v) {
 template <int TAPS>
 __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)[32], int32_t *row, int col0,
                                             int first_pred, int n_valid, uint32_t shift, uint32_t wasted) {
+    int32_t xs[4];
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
+        if ((u & 3) == 0) {  // four samples per LDS access (columns past n_valid are padding inside the row)
+            const int4 v = *reinterpret_cast<const int4 *>(row + col0 + u);
+            xs[0] = v.x; xs[1] = v.y; xs[2] = v.z; xs[3] = v.w;
+        }
         if (u < n_valid) {
-            int32_t x = row[col0 + u];
+            int32_t x = xs[u & 3];
             if (col0 + u >= first_pred) {
                 int64_t acc = 0;
 #pragma unroll
@@ -54,8 +113,9 @@ __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)
                 x = wrap_add(x, (int32_t)(acc >> shift));
             }
             h[u & 31] = x;
-            row[col0 + u] = (int32_t)((uint32_t)x << wasted);  // samples_shl (decoder.rs:403-409)
+            xs[u & 3] = (int32_t)((uint32_t)x << wasted);  // samples_shl (decoder.rs:403-409)
         }
+        if ((u & 3) == 3) *reinterpret_cast<int4 *>(row + col0 + u - 3) = make_int4(xs[0], xs[1], xs[2], xs[3]);
     }
 }
 
@@ -70,10 +130,15 @@ __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)
 template <int TAPS>
 __device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&c)[32], int32_t *row, int col0,
                                                 int first_pred, int n_valid, int shift, uint32_t wasted) {
+    int32_t xs[4];
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
+        if ((u & 3) == 0) {
+            const int4 v = *reinterpret_cast<const int4 *>(row + col0 + u);
+            xs[0] = v.x; xs[1] = v.y; xs[2] = v.z; xs[3] = v.w;
+        }
         if (u < n_valid) {
-            int32_t x = row[col0 + u];
+            int32_t x = xs[u & 3];
             if (col0 + u >= first_pred) {
                 constexpr int P = TAPS >= 8 ? 4 : 1;
                 double part[P];
@@ -89,8 +154,9 @@ __device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&
                 x = wrap_add(x, (int32_t)(uint32_t)lo);
             }
             h[u & 31] = (double)x;
-            row[col0 + u] = (int32_t)((uint32_t)x << wasted);  // samples_shl (decoder.rs:403-409)
+            xs[u & 3] = (int32_t)((uint32_t)x << wasted);  // samples_shl (decoder.rs:403-409)
         }
+        if ((u & 3) == 3) *reinterpret_cast<int4 *>(row + col0 + u - 3) = make_int4(xs[0], xs[1], xs[2], xs[3]);
     }
 }
 
@@ -108,10 +174,8 @@ __device__ __forceinline__ void flac_restore_f64(int32_t *__restrict__ buf, int3
     }
     for (unsigned t0 = 0; t0 < blocksize; t0 += kTile) {
         const unsigned cols = min((unsigned)kTile, blocksize - t0);
-        for (int r = 0; r < kTile; ++r) {
-            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
-                tile[r * kStride + lane] = buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane];
-        }
+        const bool fast = cols == (unsigned)kTile && (blocksize & 3u) == 0 && blk0 + kTile <= n_blocks;
+        tile_fetch(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane, fast);
         __syncthreads();
         if (have) {
             int32_t *row = tile + lane * kStride;
@@ -129,10 +193,7 @@ __device__ __forceinline__ void flac_restore_f64(int32_t *__restrict__ buf, int3
             }
         }
         __syncthreads();
-        for (int r = 0; r < kTile; ++r) {
-            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
-                buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane] = tile[r * kStride + lane];
-        }
+        tile_store(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane, fast);
         __syncthreads();
     }
 }
@@ -141,7 +202,7 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(int32_t *__restrict__ 
                                                           const symaccel_flac_desc *__restrict__ desc,
                                                           const int32_t *__restrict__ coeffs, size_t n_blocks,
                                                           unsigned blocksize) {
-    __shared__ int32_t tile[kTile * kStride];
+    __shared__ __attribute__((aligned(16))) int32_t tile[kTile * kStride];
     const int lane = (int)threadIdx.x;
     const size_t blk0 = (size_t)blockIdx.x * kTile;
     const size_t my = blk0 + (size_t)lane;
@@ -191,11 +252,8 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(int32_t *__restrict__ 
 
     for (unsigned t0 = 0; t0 < blocksize; t0 += kTile) {
         const unsigned cols = min((unsigned)kTile, blocksize - t0);
-        // coalesced fetch: row r = subframe blk0 + r, 64 consecutive samples
-        for (int r = 0; r < kTile; ++r) {
-            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
-                tile[r * kStride + lane] = buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane];
-        }
+        const bool fast = cols == (unsigned)kTile && (blocksize & 3u) == 0 && blk0 + kTile <= n_blocks;
+        tile_fetch(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane, fast);
         __syncthreads();
         if (have) {
             int32_t *row = tile + lane * kStride;
@@ -213,10 +271,7 @@ __global__ __launch_bounds__(64) void flac_restore_kernel(int32_t *__restrict__ 
             }
         }
         __syncthreads();
-        for (int r = 0; r < kTile; ++r) {
-            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
-                buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane] = tile[r * kStride + lane];
-        }
+        tile_store(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane, fast);
         __syncthreads();
     }
 }
