@@ -18,6 +18,7 @@
 
 #include <climits>
 #include <cstdint>
+#include <type_traits>
 
 #include "symaccel_internal.h"
 
@@ -162,15 +163,77 @@ __device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&
 
 __device__ __forceinline__ int iabs_sat(int32_t v) { return v < 0 ? (v == INT32_MIN ? INT32_MAX : -v) : v; }
 
-// Tile loop of the FP64 path (same tiling as the integer path below).
-__device__ __forceinline__ void flac_restore_f64(int32_t *__restrict__ buf, int32_t *tile, const int32_t (&ci)[32],
-                                                 size_t blk0, size_t n_blocks, unsigned blocksize, int lane, bool have,
-                                                 unsigned order, unsigned max_order, int shift, uint32_t wasted) {
-    double c[32], h[32];
+// Per-lane subframe parameters, shared by both kernels.
+struct LaneParams {
+    int32_t c[32];
+    unsigned order, shift, wasted, max_order;
+    bool use_f64;
+};
+
+__device__ __forceinline__ void load_params(LaneParams &p, const symaccel_flac_desc *__restrict__ desc,
+                                            const int32_t *__restrict__ coeffs, size_t my, bool have,
+                                            unsigned blocksize) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) p.c[j] = 0;
+    p.order = p.shift = p.wasted = 0;
+    if (have) {
+        const symaccel_flac_desc d = desc[my];
+        p.wasted = d.wasted_bits & 31u;
+        if (d.kind == SYMACCEL_FLAC_LPC) {
+            p.order = d.order > 32u ? 32u : d.order;
+            p.shift = d.shift & 63u;
+            const int4 *cp = reinterpret_cast<const int4 *>(coeffs + my * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int4 v = cp[j];
+                p.c[4 * j] = (unsigned)(4 * j) < p.order ? v.x : 0;
+                p.c[4 * j + 1] = (unsigned)(4 * j + 1) < p.order ? v.y : 0;
+                p.c[4 * j + 2] = (unsigned)(4 * j + 2) < p.order ? v.z : 0;
+                p.c[4 * j + 3] = (unsigned)(4 * j + 3) < p.order ? v.w : 0;
+            }
+        } else if (d.kind == SYMACCEL_FLAC_FIXED) {
+            p.order = d.order > 4u ? 4u : d.order;
+            // decoder.rs:679-707: s(i) = sum binom * s(i-k)
+            p.c[0] = p.order == 1 ? 1 : p.order == 2 ? 2 : p.order == 3 ? 3 : p.order == 4 ? 4 : 0;
+            p.c[1] = p.order == 2 ? -1 : p.order == 3 ? -3 : p.order == 4 ? -6 : 0;
+            p.c[2] = p.order == 3 ? 1 : p.order == 4 ? 4 : 0;
+            p.c[3] = p.order == 4 ? -1 : 0;
+        }
+        if (p.order > blocksize) p.order = blocksize;  // decoder.rs:456-458 would have rejected the frame
+    }
+    // Does any lane of this wavefront need more than 4 / 12 taps?  (wave-uniform specialisation)
+    p.max_order = wave_max(p.order);
+    // FP64 path iff every coefficient of the wavefront is below 2^16 in magnitude (always, for valid streams)
+    unsigned cmax = 0;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        c[j] = (double)ci[j];
-        h[j] = 0.0;
+        const unsigned a = (unsigned)iabs_sat(p.c[j]);
+        cmax = a > cmax ? a : cmax;
+    }
+    p.use_f64 = wave_max(cmax) < 65536u;
+}
+
+// One kernel per arithmetic path, so each is register-allocated for what it keeps live (the FP64
+// path: 32 coefficients + 32 history samples as doubles = 128 VGPRs).  Both are launched over the same
+// grid; a wavefront whose subframes belong to the other path exits after reading its parameters.
+template <bool F64>
+__device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc,
+                                                  const int32_t *__restrict__ coeffs, size_t n_blocks,
+                                                  unsigned blocksize, int32_t *tile) {
+    const int lane = (int)threadIdx.x;
+    const size_t blk0 = (size_t)blockIdx.x * kTile;
+    const size_t my = blk0 + (size_t)lane;
+    const bool have = my < n_blocks;
+    LaneParams p;
+    load_params(p, desc, coeffs, my, have, blocksize);
+    if (p.use_f64 != F64) return;
+
+    using T = typename std::conditional<F64, double, int32_t>::type;
+    T c[32], h[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        c[j] = (T)p.c[j];
+        h[j] = (T)0;
     }
     for (unsigned t0 = 0; t0 < blocksize; t0 += kTile) {
         const unsigned cols = min((unsigned)kTile, blocksize - t0);
@@ -182,14 +245,23 @@ __device__ __forceinline__ void flac_restore_f64(int32_t *__restrict__ buf, int3
             for (int half = 0; half < 2; ++half) {
                 const int col0 = 32 * half;
                 const int n_valid = (int)cols - col0;
-                const int first_pred = (int)order - (int)t0;
+                const int first_pred = (int)p.order - (int)t0;  // column index of the first predicted sample
                 if (n_valid <= 0) break;
-                if (max_order <= 4)
-                    lpc_steps32_f64<4>(h, c, row, col0, first_pred, n_valid, shift, wasted);
-                else if (max_order <= 12)
-                    lpc_steps32_f64<12>(h, c, row, col0, first_pred, n_valid, shift, wasted);
-                else
-                    lpc_steps32_f64<32>(h, c, row, col0, first_pred, n_valid, shift, wasted);
+                if constexpr (F64) {
+                    if (p.max_order <= 4)
+                        lpc_steps32_f64<4>(h, c, row, col0, first_pred, n_valid, (int)p.shift, p.wasted);
+                    else if (p.max_order <= 12)
+                        lpc_steps32_f64<12>(h, c, row, col0, first_pred, n_valid, (int)p.shift, p.wasted);
+                    else
+                        lpc_steps32_f64<32>(h, c, row, col0, first_pred, n_valid, (int)p.shift, p.wasted);
+                } else {
+                    if (p.max_order <= 4)
+                        lpc_steps32<4>(h, c, row, col0, first_pred, n_valid, p.shift, p.wasted);
+                    else if (p.max_order <= 12)
+                        lpc_steps32<12>(h, c, row, col0, first_pred, n_valid, p.shift, p.wasted);
+                    else
+                        lpc_steps32<32>(h, c, row, col0, first_pred, n_valid, p.shift, p.wasted);
+                }
             }
         }
         __syncthreads();
@@ -198,82 +270,18 @@ __device__ __forceinline__ void flac_restore_f64(int32_t *__restrict__ buf, int3
     }
 }
 
-__global__ __launch_bounds__(64) void flac_restore_kernel(int32_t *__restrict__ buf,
-                                                          const symaccel_flac_desc *__restrict__ desc,
-                                                          const int32_t *__restrict__ coeffs, size_t n_blocks,
-                                                          unsigned blocksize) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void flac_restore_f64_kernel(
+    int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
+    size_t n_blocks, unsigned blocksize) {
     __shared__ __attribute__((aligned(16))) int32_t tile[kTile * kStride];
-    const int lane = (int)threadIdx.x;
-    const size_t blk0 = (size_t)blockIdx.x * kTile;
-    const size_t my = blk0 + (size_t)lane;
-    const bool have = my < n_blocks;
+    flac_restore_body<true>(buf, desc, coeffs, n_blocks, blocksize, tile);
+}
 
-    int32_t c[32];
-    int32_t h[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        c[j] = 0;
-        h[j] = 0;
-    }
-    unsigned order = 0, shift = 0, wasted = 0;
-    if (have) {
-        const symaccel_flac_desc d = desc[my];
-        wasted = d.wasted_bits & 31u;
-        if (d.kind == SYMACCEL_FLAC_LPC) {
-            order = d.order > 32u ? 32u : d.order;
-            shift = d.shift & 63u;
-            const int32_t *cp = coeffs + my * 32;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) c[j] = (unsigned)j < order ? cp[j] : 0;
-        } else if (d.kind == SYMACCEL_FLAC_FIXED) {
-            order = d.order > 4u ? 4u : d.order;
-            // decoder.rs:679-707: s(i) = sum binom * s(i-k)
-            c[0] = order == 1 ? 1 : order == 2 ? 2 : order == 3 ? 3 : order == 4 ? 4 : 0;
-            c[1] = order == 2 ? -1 : order == 3 ? -3 : order == 4 ? -6 : 0;
-            c[2] = order == 3 ? 1 : order == 4 ? 4 : 0;
-            c[3] = order == 4 ? -1 : 0;
-        }
-        if (order > blocksize) order = blocksize;  // decoder.rs:456-458 would have rejected the frame
-    }
-    // Does any lane of this wavefront need more than 4 / 12 taps?  (wave-uniform specialisation)
-    const unsigned max_order = wave_max(order);
-    // FP64 path iff every coefficient of the wavefront is below 2^16 in magnitude (always, for valid streams)
-    unsigned cmax = 0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const unsigned a = (unsigned)iabs_sat(c[j]);
-        cmax = a > cmax ? a : cmax;
-    }
-    const bool use_f64 = wave_max(cmax) < 65536u;
-    if (use_f64) {
-        flac_restore_f64(buf, tile, c, blk0, n_blocks, blocksize, lane, have, order, max_order, (int)shift, wasted);
-        return;
-    }
-
-    for (unsigned t0 = 0; t0 < blocksize; t0 += kTile) {
-        const unsigned cols = min((unsigned)kTile, blocksize - t0);
-        const bool fast = cols == (unsigned)kTile && (blocksize & 3u) == 0 && blk0 + kTile <= n_blocks;
-        tile_fetch(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane, fast);
-        __syncthreads();
-        if (have) {
-            int32_t *row = tile + lane * kStride;
-            for (int half = 0; half < 2; ++half) {
-                const int col0 = 32 * half;
-                const int n_valid = (int)cols - col0;
-                const int first_pred = (int)order - (int)t0;  // column index of the first predicted sample
-                if (n_valid <= 0) break;
-                if (max_order <= 4)
-                    lpc_steps32<4>(h, c, row, col0, first_pred, n_valid, shift, wasted);
-                else if (max_order <= 12)
-                    lpc_steps32<12>(h, c, row, col0, first_pred, n_valid, shift, wasted);
-                else
-                    lpc_steps32<32>(h, c, row, col0, first_pred, n_valid, shift, wasted);
-            }
-        }
-        __syncthreads();
-        tile_store(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane, fast);
-        __syncthreads();
-    }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void flac_restore_i64_kernel(
+    int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
+    size_t n_blocks, unsigned blocksize) {
+    __shared__ __attribute__((aligned(16))) int32_t tile[kTile * kStride];
+    flac_restore_body<false>(buf, desc, coeffs, n_blocks, blocksize, tile);
 }
 
 // decoder.rs:32-82 + :239-242
@@ -305,8 +313,11 @@ int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_d
                         size_t n_blocks, size_t blocksize) {
     const size_t grid = (n_blocks + kTile - 1) / kTile;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(flac_restore_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs,
-                       n_blocks, (unsigned)blocksize);
+    hipLaunchKernelGGL(flac_restore_f64_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
+                       d_coeffs, n_blocks, (unsigned)blocksize);
+    SYM_GPU(ctx, hipGetLastError());
+    hipLaunchKernelGGL(flac_restore_i64_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
+                       d_coeffs, n_blocks, (unsigned)blocksize);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }
