@@ -17,7 +17,7 @@ CSRC = HERE / "csrc"
 OUT = HERE / "libsymaccel.so"
 SOURCES = ["tables.cpp", "ctx.cpp", "imdct_generic.hip", "aac.hip", "mp3.hip", "vorbis.hip", "flac.hip"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 
@@ -36,8 +36,13 @@ def needs_build():
     return any(p.stat().st_mtime > t for p in deps)
 
 
+def tuning_defines():
+    """Build-time tuning knobs (development): SYM_<NAME>=<int> in the environment becomes -DSYM_<NAME>=<int>."""
+    return ["-D%s=%d" % (k, int(v)) for k, v in sorted(os.environ.items()) if k.startswith("SYM_") and v.lstrip("-").isdigit()]
+
+
 def build(force=False, verbose=False, save_temps=False):
-    if not force and not needs_build():
+    if not force and not needs_build() and not tuning_defines():
         return OUT
     objdir = HERE / "build"
     objdir.mkdir(exist_ok=True)
@@ -45,7 +50,7 @@ def build(force=False, verbose=False, save_temps=False):
     procs = []
     for src in SOURCES:
         obj = objdir / (src.replace(".", "_") + ".o")
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-x", "hip", *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-x", "hip", *FLAGS, *tuning_defines(), "-c", str(CSRC / src), "-o", str(obj)]
         if save_temps:
             cmd += ["-save-temps=obj"]
         if verbose:

@@ -133,15 +133,6 @@ __device__ __forceinline__ void bitrev8(c32 (&z)[8]) {
     z[6] = t;
 }
 
-// mdct.rs:81-88 for one line pair
-__device__ __forceinline__ c32 pre_twiddle(float even_line, float mirrored_line, c32 w) {
-    const float odd = -mirrored_line;
-    return c32{odd * w.im - even_line * w.re, odd * w.re + even_line * w.im};
-}
-
-// mdct.rs:104 / 123: val = w * x.conj()
-__device__ __forceinline__ c32 post_twiddle(c32 x, c32 w) { return c_mul(w, c32{x.re, -x.im}); }
-
 // 512-point FFT of the pre-twiddled z[m + 64 s] held by lane m; leaves Z[0..512) in natural order
 // in the wavefront's LDS (complex index = position).
 __device__ __forceinline__ void fft512_wave(c32 (&z)[8], int lane, c32 *lds, const LaneTables &lt) {
@@ -192,22 +183,22 @@ __device__ __forceinline__ void post_slot(const c32 *lds, const c32 *tw, int m2,
     const c32 vA = post_twiddle(lds[255 - 2 * m2], tw[255 - 2 * m2]);
     const c32 vC = post_twiddle(lds[256 + 2 * m2], tw[256 + 2 * m2]);
     const c32 vD = post_twiddle(lds[257 + 2 * m2], tw[257 + 2 * m2]);
-    x[0] = -vC.re;  // vec0[4m2 .. 4m2+3]
-    x[1] = -vA.im;
-    x[2] = -vD.re;
-    x[3] = -vB.im;
-    x[4] = vB.im;   // vec1[508-4m2 .. 511-4m2]
-    x[5] = vD.re;
-    x[6] = vA.im;
-    x[7] = vC.re;
-    x2[0] = vC.im;  // vec2[4m2 ..]
-    x2[1] = vA.re;
-    x2[2] = vD.im;
-    x2[3] = vB.re;
-    x2[4] = vB.re;  // vec3[508-4m2 ..]
-    x2[5] = vD.im;
-    x2[6] = vA.re;
-    x2[7] = vC.im;
+    x[0] = -vC.x;  // vec0[4m2 .. 4m2+3]
+    x[1] = -vA.y;
+    x[2] = -vD.x;
+    x[3] = -vB.y;
+    x[4] = vB.y;   // vec1[508-4m2 .. 511-4m2]
+    x[5] = vD.x;
+    x[6] = vA.y;
+    x[7] = vC.x;
+    x2[0] = vC.y;  // vec2[4m2 ..]
+    x2[1] = vA.x;
+    x2[2] = vD.y;
+    x2[3] = vB.x;
+    x2[4] = vB.x;  // vec3[508-4m2 ..]
+    x2[5] = vD.y;
+    x2[6] = vA.x;
+    x2[7] = vC.y;
 }
 
 // Eight 128-line IMDCTs (dsp.rs:80-83).  The frame's 1024 lines are staged in ldsf[0..1024).  Of each
@@ -248,12 +239,12 @@ __device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const De
         const int i = 8 * j + c;
         const c32 val = post_twiddle(z[j], ld_c(tb.aac_tw_short + i));
         if (j < 4) {
-            o[2 * i] = val.im;            // v1[fi]   (v0[ri] = -val.im is its mirror)
-            o[64 + 63 - 2 * i] = val.re;  // v2[ri]   (v3[fi] = val.re is its mirror)
+            o[2 * i] = val.y;            // v1[fi]   (v0[ri] = -val.y is its mirror)
+            o[64 + 63 - 2 * i] = val.x;  // v2[ri]   (v3[fi] = val.x is its mirror)
         } else {
             const int i2 = i - 32;
-            o[63 - 2 * i2] = val.re;      // v1[ri]   (v0[fi] = -val.re)
-            o[64 + 2 * i2] = val.im;      // v2[fi]   (v3[ri] = val.im)
+            o[63 - 2 * i2] = val.x;      // v1[ri]   (v0[fi] = -val.x)
+            o[64 + 2 * i2] = val.y;      // v2[fi]   (v3[ri] = val.y)
         }
     }
     wave_sync();
@@ -311,7 +302,10 @@ __device__ __forceinline__ float start_window(const DevTables &tb, int shape, in
     return (j >= kP0 && j < kP1) ? sw[127 - (j - kP0)] : 1.0f;
 }
 
-__global__ __launch_bounds__(64 * kWaves, 2) void aac_synth_kernel(
+#ifndef SYM_AAC_MIN_WAVES
+#define SYM_AAC_MIN_WAVES 2  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
+#endif
+__global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kernel(
     DevTables tb, const float *__restrict__ coeffs, const uint8_t *__restrict__ side,
     const float *__restrict__ delay_in, float *__restrict__ delay_out, float *__restrict__ pcm,
     unsigned frames_per_chain, unsigned seg_len, unsigned segs_per_chain, unsigned n_items) {

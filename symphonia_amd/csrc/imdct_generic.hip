@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kThreads) void fft_kernel(DevTables tb, int nf, int
         const int t = idx >> log2nf;
         if (first + (size_t)t < count) {
             const c32 v = lds[fft_pad(idx)];
-            out[(first + (size_t)t) * (size_t)nf + (size_t)(idx & (nf - 1))] = make_float2(v.re, v.im);
+            out[(first + (size_t)t) * (size_t)nf + (size_t)(idx & (nf - 1))] = make_float2(v.x, v.y);
         }
     }
 }
@@ -55,10 +55,7 @@ __global__ __launch_bounds__(kThreads) void imdct_kernel(DevTables tb, const cpx
         if (first + (size_t)t < count) {
             const float *s = spec + (first + (size_t)t) * (size_t)n;
             const cpx w = tw[i];
-            const float even = s[2 * i];
-            const float odd = -s[n - 1 - 2 * i];
-            z.re = odd * w.im - even * w.re;
-            z.im = odd * w.re + even * w.im;
+            z = pre_twiddle(s[2 * i], s[n - 1 - 2 * i], c32{w.re, w.im});
         }
         lds[fft_pad((t << log2nf) + (int)rev_bits((unsigned)i, log2nf))] = z;
     }
@@ -71,20 +68,20 @@ __global__ __launch_bounds__(kThreads) void imdct_kernel(DevTables tb, const cpx
         float *vec0 = o, *vec1 = o + nf, *vec2 = o + 2 * nf, *vec3 = o + 3 * nf;
         const c32 x = lds[fft_pad(idx)];
         const cpx w = tw[k];
-        const c32 val = c_mul(c32{w.re, w.im}, c32{x.re, -x.im});  // w * x.conj()
+        const c32 val = post_twiddle(x, c32{w.re, w.im});  // w * x.conj()
         if (k < n4) {
             const int fi = 2 * k, ri = nf - 1 - 2 * k;
-            vec0[ri] = -val.im;
-            vec1[fi] = val.im;
-            vec2[ri] = val.re;
-            vec3[fi] = val.re;
+            vec0[ri] = -val.y;
+            vec1[fi] = val.y;
+            vec2[ri] = val.x;
+            vec3[fi] = val.x;
         } else {
             const int i = k - n4;
             const int fi = 2 * i, ri = nf - 1 - 2 * i;
-            vec0[fi] = -val.re;
-            vec1[ri] = val.re;
-            vec2[fi] = val.im;
-            vec3[ri] = val.im;
+            vec0[fi] = -val.x;
+            vec1[ri] = val.x;
+            vec2[fi] = val.y;
+            vec3[ri] = val.y;
         }
     }
 }

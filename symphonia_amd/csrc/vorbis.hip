@@ -85,29 +85,27 @@ __device__ __forceinline__ void vorbis_imdct_block(VorbisShared<MAXBS> &sh, cons
     const int n = bs >> 1, nf = bs >> 2, n4 = bs >> 3;
     for (int i = (int)threadIdx.x; i < nf; i += kVThreads) {
         const cpx w = tw[i];
-        const float even = spec[2 * i];
-        const float odd = -spec[n - 1 - 2 * i];
-        sh.fft[fft_pad((int)rev_bits((unsigned)i, log2nf))] = c32{odd * w.im - even * w.re, odd * w.re + even * w.im};
+        sh.fft[fft_pad((int)rev_bits((unsigned)i, log2nf))] = pre_twiddle(spec[2 * i], spec[n - 1 - 2 * i], c32{w.re, w.im});
     }
     wg_fft_lds(sh.fft, nf, nf, tb);
     float *vec0 = sh.pcm, *vec1 = sh.pcm + nf, *vec2 = sh.pcm + 2 * nf, *vec3 = sh.pcm + 3 * nf;
     for (int k = (int)threadIdx.x; k < nf; k += kVThreads) {
         const c32 x = sh.fft[fft_pad(k)];
         const cpx w = tw[k];
-        const c32 val = c_mul(c32{w.re, w.im}, c32{x.re, -x.im});
+        const c32 val = post_twiddle(x, c32{w.re, w.im});
         if (k < n4) {
             const int fi = 2 * k, ri = nf - 1 - 2 * k;
-            vec0[ri] = -val.im;
-            vec1[fi] = val.im;
-            vec2[ri] = val.re;
-            vec3[fi] = val.re;
+            vec0[ri] = -val.y;
+            vec1[fi] = val.y;
+            vec2[ri] = val.x;
+            vec3[fi] = val.x;
         } else {
             const int i = k - n4;
             const int fi = 2 * i, ri = nf - 1 - 2 * i;
-            vec0[fi] = -val.re;
-            vec1[ri] = val.re;
-            vec2[fi] = val.im;
-            vec3[ri] = val.im;
+            vec0[fi] = -val.x;
+            vec1[ri] = val.x;
+            vec2[fi] = val.y;
+            vec3[ri] = val.y;
         }
     }
     __syncthreads();
