@@ -8,8 +8,6 @@
 
 #include <hip/hip_runtime.h>
 
-#include <pk_f32.h>
-
 #include "symaccel_internal.h"
 
 namespace symaccel {
@@ -22,52 +20,46 @@ __device__ __forceinline__ cf32p as_const(const float *p) {
     return (cf32p)p;  // deliberate address-space cast (global -> constant), same 64-bit representation
 }
 
-// Complex<f32> as a packed pair (x = re, y = im): one v_pk_* instruction per complex add, three per
-// complex multiply (pk_f32.h).
-using c32 = v2f;
+// Complex<f32>.  Scalar f32 instructions on purpose: on gfx950 v_pk_mul_f32 / v_pk_add_f32 issue at half
+// the wavefront rate of v_mul_f32 / v_add_f32 (measured, tools/ubench/valu_rate.hip: 2.7 vs 5.0 cycles per
+// wave-instruction with >= 2 wavefronts per SIMD), so packing two operations per instruction buys nothing and
+// the register-pair shuffles it needs cost extra -- the packed variant of aac_synth_kernel ran 15 % slower.
+struct c32 {
+    float x, y;  // re, im
+};
 
-__device__ __forceinline__ c32 c_add(c32 a, c32 b) { return a + b; }
-__device__ __forceinline__ c32 c_sub(c32 a, c32 b) { return a - b; }
+__device__ __forceinline__ c32 c_add(c32 a, c32 b) { return c32{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ c32 c_sub(c32 a, c32 b) { return c32{a.x - b.x, a.y - b.y}; }
 // num-complex `Mul`: (a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re)
-__device__ __forceinline__ c32 c_mul(c32 a, c32 b) {
-    return pk_add_neg_lo(pk_mul_xx(a, b), pk_mul_yy_swap(a, b));
-}
-// w * x.conj()  (mdct.rs:104 / 123)
-__device__ __forceinline__ c32 c_mul_conj(c32 w, c32 x) {
-    return pk_add_neg_lo(pk_mul_xx_conj(w, x), pk_mul_yy_swap_conj(w, x));
-}
+__device__ __forceinline__ c32 c_mul(c32 a, c32 b) { return c32{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
 // Imdct pre-twiddle (mdct.rs:81-88): even = spec[2i], odd = -spec[N-1-2i],
 // z = (odd*w.im - even*w.re, odd*w.re + even*w.im).  `mirrored_line` = spec[N-1-2i] (not yet negated).
 __device__ __forceinline__ c32 pre_twiddle(float even_line, float mirrored_line, c32 w) {
-    const v2f em{even_line, mirrored_line};
-    return pk_add_neg_lo(pk_mul_nyy_swap(em, w), pk_mul_xx(em, w));
+    const float odd = -mirrored_line;
+    return c32{odd * w.y - even_line * w.x, odd * w.x + even_line * w.y};
 }
 // Imdct post-twiddle (mdct.rs:104 / 123): val = w * x.conj()
-__device__ __forceinline__ c32 post_twiddle(c32 x, c32 w) { return c_mul_conj(w, x); }
+__device__ __forceinline__ c32 post_twiddle(c32 x, c32 w) { return c_mul(w, c32{x.x, -x.y}); }
 
 // One radix-2 DIT butterfly: q already twiddled.  e' = e + q, o' = e - q.
 __device__ __forceinline__ void bfly(c32 &e, c32 &o, c32 q) {
     const c32 p = e;
-    e = p + q;
-    o = p - q;
-}
-// Butterfly whose twiddle is -i (k = n/4): q = (o.im, -o.re), folded into the adds.
-__device__ __forceinline__ void bfly_minus_i(c32 &e, c32 &o) {
-    const c32 p = e, v = o;
-    e = pk_add_mi(p, v);
-    o = pk_sub_mi(p, v);
+    e = c_add(p, q);
+    o = c_sub(p, q);
 }
 
 #define SYM_FRAC_1_SQRT_2 0.70710678118654752440f
 
 // Twiddles of the unrolled fft4/fft8 combine steps (no_simd.rs:405-447), compile-time forms.
 __device__ __forceinline__ c32 tw_minus_i(c32 v) { return c32{v.y, -v.x}; }            // k = n/4
-__device__ __forceinline__ c32 tw_n8(c32 v) {                                          // k = n/8: (a + b, b - a)
-    return pk_sum_diff(v * c32{SYM_FRAC_1_SQRT_2, SYM_FRAC_1_SQRT_2});
+__device__ __forceinline__ c32 tw_n8(c32 v) {                                          // k = n/8
+    const float a = SYM_FRAC_1_SQRT_2 * v.x, b = SYM_FRAC_1_SQRT_2 * v.y;
+    return c32{a + b, b - a};
 }
-__device__ __forceinline__ c32 tw_3n8(c32 v) {                                         // k = 3n/8: (a - b, a + b)
-    return pk_diff_sum(v * c32{-SYM_FRAC_1_SQRT_2, -SYM_FRAC_1_SQRT_2});
+__device__ __forceinline__ c32 tw_3n8(c32 v) {                                         // k = 3n/8
+    const float a = -SYM_FRAC_1_SQRT_2 * v.x, b = -SYM_FRAC_1_SQRT_2 * v.y;
+    return c32{a - b, a + b};
 }
 
 // fft8 (no_simd.rs:405-454) on 8 values already in bit-reversed order, in registers.
@@ -77,12 +69,12 @@ __device__ __forceinline__ void fft8_regs(c32 (&x)[8]) {
     bfly(x[4], x[5], x[5]);
     bfly(x[6], x[7], x[7]);
     bfly(x[0], x[2], x[2]);  // fft4 x2: k=0 plain, k=1 multiply by -i
-    bfly_minus_i(x[1], x[3]);
+    bfly(x[1], x[3], tw_minus_i(x[3]));
     bfly(x[4], x[6], x[6]);
-    bfly_minus_i(x[5], x[7]);
+    bfly(x[5], x[7], tw_minus_i(x[7]));
     bfly(x[0], x[4], x[4]);  // fft8 combine
     bfly(x[1], x[5], tw_n8(x[5]));
-    bfly_minus_i(x[2], x[6]);
+    bfly(x[2], x[6], tw_minus_i(x[6]));
     bfly(x[3], x[7], tw_3n8(x[7]));
 }
 
