@@ -1,0 +1,250 @@
+// Wavefront-level 1024-line / 128-line Imdct (512-point / 64-point complex FFT) shared by the AAC-LC kernel
+// (Imdct::new_scaled(1024, 1/2048), (128, 1/256)) and the Vorbis 2048/256 kernel (Imdct::new(1024), (128)):
+// symphonia-core/src/dsp/mdct.rs:67-146 over the radix-2 DIT graph of dsp/fft/no_simd.rs.
+//
+// One 64-lane wavefront owns one transform; its lanes exchange data through a private LDS work array of
+// kWaveLds floats with wave-local ordering only (no workgroup barrier).  See aac.hip for the mapping.
+#pragma once
+
+#include "dsp_device.h"
+
+namespace symaccel {
+
+constexpr int kWaveLds = 2264;  // floats of private LDS per wavefront (FFT work array, see the T1/T2 layouts)
+
+// Order this wavefront's LDS accesses (its lanes exchange data through LDS; the hardware executes
+// one wavefront's DS instructions in order, the fences stop the compiler from reordering them).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS complex index of element (B, j, k) = logical position 64B + 8j + k of the FFT work array.
+// Both layouts are SEPARABLE -- lane base + per-instruction constant on the write AND the read side,
+// so every ds instruction uses one address VGPR plus an immediate offset -- and conflict-free for
+// ds_write_b64 / ds_read_b64 (integer carries do what an XOR swizzle would; tools/aac_wave_model.py).
+// T1: pass-1 lanes (B, j) write k = 0..7, pass-2 lanes (B, k) read j = 0..7.
+__device__ __forceinline__ int lds_t1_lane_w(int B, int j) { return B + 8 * (j >> 2) + 288 * (j & 3); }
+__device__ __forceinline__ constexpr int lds_t1_inst_w(int k) { return 36 * k; }
+__device__ __forceinline__ int lds_t1_lane_r(int B, int k) { return B + 36 * k; }
+__device__ __forceinline__ constexpr int lds_t1_inst_r(int j) { return 8 * (j >> 2) + 288 * (j & 3); }
+// T2: pass-2 lanes (B, k) write j = 0..7, pass-3 lanes k' = 8j + k read B = 0..7.
+__device__ __forceinline__ int lds_t2_lane_w(int B, int k) { return k + 8 * (B & 1) + 64 * (B >> 1) + 256 * (B & 1); }
+__device__ __forceinline__ constexpr int lds_t2_inst_w(int j) { return 8 * j; }
+__device__ __forceinline__ int lds_t2_lane_r(int j, int k) { return k + 8 * j; }
+__device__ __forceinline__ constexpr int lds_t2_inst_r(int B) { return 8 * (B & 1) + 64 * (B >> 1) + 256 * (B & 1); }
+static_assert(2 * (7 + 8 + 288 * 3 + 36 * 7 + 1) <= kWaveLds, "FFT work array must fit the per-wave LDS");
+
+struct LaneTables {
+    // pass 2 (stages 4-6): fft16 combine k, fft32 combine k and k+8, merge W64[8j + k]
+    c32 w16;
+    int f16;
+    c32 w32[2];
+    int f32[2];
+    c32 w64[4];
+    // pass 3 (stages 7-9): W128[k'], W256[k' + 64 b], W512[k' + 64 B]
+    c32 w128;
+    c32 w256[2];
+    c32 w512[4];
+};
+
+__device__ __forceinline__ c32 ld_c(const cpx *p) {
+    const cpx v = *p;
+    return c32{v.re, v.im};
+}
+
+__device__ __forceinline__ void load_lane_tables(const DevTables &tb, int lane, LaneTables &t) {
+    const int k = lane & 7;
+    t.w16 = ld_c(tb.small16 + k);
+    t.f16 = tb.small16_form[k];
+    t.w32[0] = ld_c(tb.small32 + k);
+    t.f32[0] = tb.small32_form[k];
+    t.w32[1] = ld_c(tb.small32 + k + 8);
+    t.f32[1] = tb.small32_form[k + 8];
+    const cpx *w64 = tb.fft_merge + 0, *w128 = tb.fft_merge + 32, *w256 = tb.fft_merge + 96,
+              *w512 = tb.fft_merge + 224;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.w64[j] = ld_c(w64 + 8 * j + k);
+    t.w128 = ld_c(w128 + lane);
+    t.w256[0] = ld_c(w256 + lane);
+    t.w256[1] = ld_c(w256 + lane + 64);
+#pragma unroll
+    for (int B = 0; B < 4; ++B) t.w512[B] = ld_c(w512 + lane + 64 * B);
+}
+
+// Stages 4-6 of the radix-2 graph on the eight values u[j] = a[64B + 8j + k] of one lane.
+__device__ __forceinline__ void pass2_regs(c32 (&u)[8], const LaneTables &t) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) bfly(u[j], u[j + 1], tw_small(u[j + 1], t.w16, t.f16));  // fft16 combine
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {                                                          // fft32 combine
+        bfly(u[h + 0], u[h + 2], tw_small(u[h + 2], t.w32[0], t.f32[0]));
+        bfly(u[h + 1], u[h + 3], tw_small(u[h + 3], t.w32[1], t.f32[1]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfly(u[j], u[j + 4], c_mul(u[j + 4], t.w64[j]));             // merge, step 32
+}
+
+// Stages 7-9 on v[B] = a[64B + k'].
+__device__ __forceinline__ void pass3_regs(c32 (&v)[8], const LaneTables &t) {
+#pragma unroll
+    for (int B = 0; B < 8; B += 2) bfly(v[B], v[B + 1], c_mul(v[B + 1], t.w128));            // step 64
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {                                                          // step 128
+        bfly(v[h + 0], v[h + 2], c_mul(v[h + 2], t.w256[0]));
+        bfly(v[h + 1], v[h + 3], c_mul(v[h + 3], t.w256[1]));
+    }
+#pragma unroll
+    for (int B = 0; B < 4; ++B) bfly(v[B], v[B + 4], c_mul(v[B + 4], t.w512[B]));            // step 256
+}
+
+// The u[r] of pass 1 must be presented to fft8 in bit-reversed order: u[r] = z[.. rev3(r)].
+__device__ __forceinline__ void bitrev8(c32 (&z)[8]) {
+    c32 t = z[1];
+    z[1] = z[4];
+    z[4] = t;
+    t = z[3];
+    z[3] = z[6];
+    z[6] = t;
+}
+
+// 512-point FFT of the pre-twiddled z[m + 64 s] held by lane m; leaves Z[0..512) in natural order
+// in the wavefront's LDS (complex index = position).
+__device__ __forceinline__ void fft512_wave(c32 (&z)[8], int lane, c32 *lds, const LaneTables &lt) {
+    // ---- pass 1: fft8 over z[m + 64*rev3(r)] -> a[8*rev6(m) + r], i.e. element (B, j, k=r)
+    bitrev8(z);
+    fft8_regs(z);
+    {
+        const int B = (int)rev_bits((unsigned)lane & 7u, 3), j = (int)rev_bits((unsigned)lane >> 3, 3);
+        c32 *w = lds + lds_t1_lane_w(B, j);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[lds_t1_inst_w(r)] = z[r];
+    }
+    wave_sync();
+    // ---- pass 2: lane (B, k) gathers j = 0..7
+    const int B2 = lane >> 3, k2 = lane & 7;
+    {
+        const c32 *r = lds + lds_t1_lane_r(B2, k2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = r[lds_t1_inst_r(j)];
+    }
+    pass2_regs(z, lt);
+    wave_sync();
+    {
+        c32 *w = lds + lds_t2_lane_w(B2, k2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[lds_t2_inst_w(j)] = z[j];
+    }
+    wave_sync();
+    // ---- pass 3: lane k' = 8j + k gathers B = 0..7
+    {
+        const c32 *r = lds + lds_t2_lane_r(lane >> 3, lane & 7);
+#pragma unroll
+        for (int B = 0; B < 8; ++B) z[B] = r[lds_t2_inst_r(B)];
+    }
+    pass3_regs(z, lt);
+    wave_sync();
+#pragma unroll
+    for (int B = 0; B < 8; ++B) lds[64 * B + lane] = z[B];  // natural order Z[64B + k']
+    wave_sync();
+}
+
+// Post-twiddle (mdct.rs:94-137) of the four FFT bins that feed output slot m2 = lane + 64h:
+//   x[q]  = pcm[j(q)]         (first half of the 2048-sample IMDCT output)
+//   x2[q] = pcm[1024 + j(q)]  with j(q) = 4*m2 + q for q < 4, 1020 - 4*m2 + (q - 4) for q >= 4.
+// Twiddles tw[254-2m2 .. 255-2m2] and tw[256+2m2 .. 257+2m2] come from the shared LDS table.
+__device__ __forceinline__ void post_slot(const c32 *lds, const c32 *tw, int m2, float (&x)[8], float (&x2)[8]) {
+    const c32 vB = post_twiddle(lds[254 - 2 * m2], tw[254 - 2 * m2]);
+    const c32 vA = post_twiddle(lds[255 - 2 * m2], tw[255 - 2 * m2]);
+    const c32 vC = post_twiddle(lds[256 + 2 * m2], tw[256 + 2 * m2]);
+    const c32 vD = post_twiddle(lds[257 + 2 * m2], tw[257 + 2 * m2]);
+    x[0] = -vC.x;  // vec0[4m2 .. 4m2+3]
+    x[1] = -vA.y;
+    x[2] = -vD.x;
+    x[3] = -vB.y;
+    x[4] = vB.y;   // vec1[508-4m2 .. 511-4m2]
+    x[5] = vD.x;
+    x[6] = vA.y;
+    x[7] = vC.x;
+    x2[0] = vC.y;  // vec2[4m2 ..]
+    x2[1] = vA.x;
+    x2[2] = vD.y;
+    x2[3] = vB.x;
+    x2[4] = vB.x;  // vec3[508-4m2 ..]
+    x2[5] = vD.y;
+    x2[6] = vA.x;
+    x2[7] = vC.y;
+}
+
+// Eight 128-line IMDCTs (dsp.rs:80-83).  The frame's 1024 lines are staged in ldsf[0..1024).  Of each
+// window's 256 outputs v0|v1|v2|v3 only v1 and v2 are kept: H[w][0..64) = v1, H[w][64..128) = v2 in
+// ldsf[128 w ..]; v0[x] = -v1[63-x] and v3[x] = v2[63-x] exactly (mdct.rs:108-136 writes the same
+// value, negated for v0, to both).
+__device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const cpx *tw_short, const LaneTables &lt) {
+    c32 *lds = reinterpret_cast<c32 *>(ldsf);
+    // pass 1: lane (w, c) owns z_w[c + 8 s] = pre_twiddle(x_w[2i], x_w[127 - 2i]), i = c + 8 s
+    const int w = lane >> 3, c = lane & 7;
+    c32 z[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int i = c + 8 * s;
+        z[s] = pre_twiddle(ldsf[128 * w + 2 * i], ldsf[128 * w + 127 - 2 * i], ld_c(tw_short + i));
+    }
+    wave_sync();
+    bitrev8(z);
+    fft8_regs(z);  // -> a_w[8*rev3(c) + r] = element (B = w, j = rev3(c), k = r)
+    {
+        const int j = (int)rev_bits((unsigned)c, 3);
+        c32 *wp = lds + lds_t1_lane_w(w, j);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) wp[lds_t1_inst_w(r)] = z[r];
+    }
+    wave_sync();
+    {
+        const c32 *rp = lds + lds_t1_lane_r(w, c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = rp[lds_t1_inst_r(j)];
+    }
+    pass2_regs(z, lt);  // 64-point FFT done: z[j] = Z_w[8j + k], k = c
+    wave_sync();
+    // post-twiddle (mdct.rs:94-137 with n2 = 64, n4 = 32)
+    float *o = ldsf + 128 * w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = 8 * j + c;
+        const c32 val = post_twiddle(z[j], ld_c(tw_short + i));
+        if (j < 4) {
+            o[2 * i] = val.y;            // v1[fi]   (v0[ri] = -val.y is its mirror)
+            o[64 + 63 - 2 * i] = val.x;  // v2[ri]   (v3[fi] = val.x is its mirror)
+        } else {
+            const int i2 = i - 32;
+            o[63 - 2 * i2] = val.x;      // v1[ri]   (v0[fi] = -val.x)
+            o[64 + 2 * i2] = val.y;      // v2[fi]   (v3[ri] = val.y)
+        }
+    }
+    wave_sync();
+}
+
+// src_w[i] of dsp.rs:86-101 (i in 0..256) from the half-stored windows.
+__device__ __forceinline__ float short_src(const float *H, int w, int i) {
+    const float *h = H + 128 * w;
+    if (i < 64) return -h[63 - i];
+    if (i < 192) return h[i - 64];
+    return h[319 - i];
+}
+
+__device__ __forceinline__ void store_slot(float *frame, int m2, const float (&v)[8]) {
+    float4 *o4 = reinterpret_cast<float4 *>(frame);
+    o4[m2] = make_float4(v[0], v[1], v[2], v[3]);
+    o4[255 - m2] = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void load_slot(const float *frame, int m2, float (&v)[8]) {
+    const float4 *i4 = reinterpret_cast<const float4 *>(frame);
+    const float4 a = i4[m2], b = i4[255 - m2];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+
+}  // namespace symaccel

@@ -342,6 +342,12 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     const size_t segs = (nb + seg - 1) / seg;
     const size_t grid = n_chains * segs;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    if (bs0_exp == 8 && bs1_exp == 11) {
+        // the 256 / 2048 pair: wavefront-per-chain-segment kernel with register-resident overlap (vorbis_wave.hip)
+        return launch_vorbis_wave(ctx, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
+                                  spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
+                                  pcm_stride, (const uint32_t *)offs, n_chains, nb, seg);
+    }
     if (bs1_exp <= 11) {
         hipLaunchKernelGGL(vorbis_synth_kernel<2048>, dim3((unsigned)grid), dim3(kVThreads), 0, ctx->stream, ctx->dev,
                            bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,

@@ -1,0 +1,306 @@
+// Vorbis synthesis, fast path for the 256 / 2048 block-size pair (bs0_exp = 8, bs1_exp = 11: what
+// practically every 44.1 / 48 kHz stream uses, and BASELINE config 4): DspChannel::synth
+// (symphonia-codec-vorbis/src/dsp.rs:68-145) with Imdct::new(1024) / Imdct::new(128)
+// (vorbis/lib.rs:123-124, symphonia-core/src/dsp/mdct.rs:67-146).
+//
+// MI355X mapping: the same wavefront-per-chain-segment scheme as aac_synth_kernel (imdct_wave.h): a long
+// block is one 512-point FFT in three radix-8 register passes, a RUN of up to eight consecutive short
+// blocks is eight 64-point FFTs done at once by the same lanes (8 lanes per block).  The right half of the
+// previous block's Imdct output (the `overlap` of dsp.rs:125) stays in 16 VGPRs per lane in the same slot
+// layout the post-twiddle produces, so the common long -> long overlap-add is lane-local:
+//     out[k] = overlap[k] * win[1023 - k] + pcm[k] * win[k]                       (dsp.rs:85-90, 140-144)
+// Block-size transitions and short blocks go through a natural-order LDS staging area (rare path).
+// Packed spectrum / PCM offsets come from vorbis_offsets_kernel (vorbis.hip).
+// HBM traffic per channel-block: 4 * (n/2) B in + 4 * (prev_n + n)/4 B out (+ one halo block per segment).
+#include "imdct_wave.h"
+
+namespace symaccel {
+
+namespace {
+
+constexpr int kWaves = 4;
+constexpr int kTabTw = 0;        // shared LDS tables: Imdct(1024) twiddles, 512 complex
+constexpr int kTabWin = 1024;    //   long window (left half of the 2048-sample window), 1024 f32
+constexpr int kTabFloats = 2048;
+constexpr int kBs0 = 256, kBs1 = 2048;
+constexpr int kStart = (kBs1 - kBs0) / 4;  // 448 (dsp.rs:93, 109)
+
+// y_s[i], i in 0..256: Imdct output of short block `w` of the current run, from the half-stored H (imdct_wave.h)
+__device__ __forceinline__ float ys(const float *H, int w, int i) { return short_src(H, w, i); }
+
+__global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
+    DevTables tb, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
+    const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
+    size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
+    int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in, float *__restrict__ overlap_out,
+    float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs, unsigned nb, unsigned seg_len,
+    unsigned segs_per_chain, unsigned n_items) {
+    __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
+    __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
+
+    for (int i = (int)threadIdx.x; i < 1024; i += 64 * kWaves) {
+        tabs[kTabTw + i] = reinterpret_cast<const float *>(tw_long)[i];
+        tabs[kTabWin + i] = win_long[i];
+    }
+    __syncthreads();  // the only workgroup-wide barrier
+
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const unsigned item = blockIdx.x * kWaves + (unsigned)wave;
+    if (item >= n_items) return;
+    float *ldsf = wave_lds[wave];
+    c32 *lds = reinterpret_cast<c32 *>(ldsf);
+    const c32 *tw = reinterpret_cast<const c32 *>(tabs + kTabTw);
+    const float *wl = tabs + kTabWin;
+
+    const unsigned chain = item / segs_per_chain, seg = item % segs_per_chain;
+    const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
+    const uint8_t *f = flags + (size_t)chain * nb;
+    const uint32_t *os = offs + (size_t)chain * 2 * (nb + 1), *op = os + (nb + 1);
+    const float *sp = spectra + (size_t)chain * spec_stride;
+    float *out = pcm + (size_t)chain * pcm_stride;
+    const int pf0 = prev_flag_in[chain];
+
+    LaneTables lt;
+    load_lane_tables(tb, lane, lt);
+
+    // overlap (dsp.rs:125), slot layout: dl[h][0..3] = overlap[4 m2 + q], dl[h][4..7] = overlap[1020 - 4 m2 + q]
+    float dl[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (b_begin == 0) {
+            load_slot(overlap_in + (size_t)chain * 1024, lane + 64 * h, dl[h]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dl[h][q] = 0.0f;
+        }
+    }
+    bool hi_fresh = b_begin == 0;  // overlap[128..1024) is what the reference would hold at this point
+
+    // A group = one long block, or a run of up to 8 consecutive short blocks (never crossing b_end).
+    auto group_len = [&](long b) -> int {
+        if (f[b]) return 1;
+        int r = 1;
+        while (r < 8 && b + r < (long)b_end && !f[b + r]) ++r;
+        return r;
+    };
+
+    const long b_first = b_begin == 0 ? 0 : (long)b_begin - 1;  // the halo block rebuilds the overlap only
+    long b = b_first;
+    int glen = b < (long)b_end ? group_len(b) : 0;
+    float2 line[8];  // the group's spectral lines: 1024 (long) or 128 per short block, 512 B coalesced per load
+    if (glen > 0) {
+        const float2 *src = reinterpret_cast<const float2 *>(sp + os[b]);
+        const int n_loads = f[b] ? 8 : glen;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s < n_loads) line[s] = src[lane + 64 * s];
+    }
+
+    while (b < (long)b_end) {
+        const int flag = f[b] ? 1 : 0;
+        const int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);  // lib.rs:298
+        const long nb_next = b + glen;
+        const int glen_next = nb_next < (long)b_end ? group_len(nb_next) : 0;
+
+        if (flag) {
+            // ------------------------------------------------------------------ one long block
+            const bool emit = b >= (long)b_begin;
+            c32 z[8];
+            const int mirror = (63 - lane) * 4;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
+                z[s] = pre_twiddle(line[s].x, mirrored, tw[lane + 64 * s]);
+            }
+            if (glen_next > 0) {  // prefetch the next group
+                const float2 *src = reinterpret_cast<const float2 *>(sp + os[nb_next]);
+                const int n_loads = f[nb_next] ? 8 : glen_next;
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    if (s < n_loads) line[s] = src[lane + 64 * s];
+            }
+            fft512_wave(z, lane, lds, lt);
+            float x[2][8], x2[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) post_slot(lds, tw, lane + 64 * h, x[h], x2[h]);
+            float *o = out + op[b];
+            if (pflag) {
+                // long -> long (dsp.rs:85-90): out[k] = overlap[k] * win[1023 - k] + pcm[k] * win[k]
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float w[8], dst[8];
+                    load_slot(wl, lane + 64 * h, w);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) dst[q] = dl[h][q] * w[7 - q] + x[h][q] * w[q];
+                    if (emit) store_slot(o, lane + 64 * h, dst);
+                }
+                wave_sync();  // Z in LDS is overwritten by the next group
+            } else {
+                // short -> long (dsp.rs:107-122): 128 overlap-added samples, then 448 copied ones
+                wave_sync();  // every lane has read Z
+                float *nat = ldsf, *ovn = ldsf + 1024;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    store_slot(nat, lane + 64 * h, x[h]);
+                    store_slot(ovn, lane + 64 * h, dl[h]);
+                }
+                wave_sync();
+                if (emit) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) {
+                        const int k = lane + 64 * e;  // 0..575
+                        float v;
+                        if (k < kBs0 / 2) {
+                            v = ovn[k] * win_short[kBs0 / 2 - 1 - k] + nat[kStart + k] * win_short[k];
+                        } else {
+                            v = nat[kStart + k];  // imdct[end + (k - 128)], end = 576
+                        }
+                        o[k] = v;
+                    }
+                }
+                wave_sync();
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dl[h][q] = x2[h][q];  // overlap = imdct[1024..2048) (dsp.rs:125)
+            }
+            hi_fresh = true;
+        } else {
+            // ------------------------------------------------------------------ a run of `glen` short blocks
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {  // block s of the run -> window s of the eight-way short transform
+                if (s < glen) {
+                    ldsf[2 * lane + 128 * s] = line[s].x;
+                    ldsf[2 * lane + 128 * s + 1] = line[s].y;
+                }
+            }
+            wave_sync();
+            if (glen_next > 0) {
+                const float2 *src = reinterpret_cast<const float2 *>(sp + os[nb_next]);
+                const int n_loads = f[nb_next] ? 8 : glen_next;
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    if (s < n_loads) line[s] = src[lane + 64 * s];
+            }
+            imdct_short_wave(lane, ldsf, tw_short, lt);  // H[8][128] in ldsf[0..1024)
+            float *ovn = ldsf + 1024;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) store_slot(ovn, lane + 64 * h, dl[h]);
+            wave_sync();
+            for (int i = 0; i < glen; ++i) {
+                const long blk = b + i;
+                const bool emit = blk >= (long)b_begin;
+                float *o = out + op[blk];
+                if (i == 0 && pflag) {
+                    // long -> short (dsp.rs:91-106): 448 unity-gain samples, then 128 overlap-added ones
+                    if (emit) {
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) {
+                            const int k = lane + 64 * e;
+                            float v = ovn[k];
+                            if (k >= kStart) {
+                                const int kk = k - kStart;
+                                v = v * win_short[kBs0 / 2 - 1 - kk] + ys(ldsf, 0, kk) * win_short[kk];
+                            }
+                            o[k] = v;
+                        }
+                    }
+                } else if (emit) {
+                    // short -> short (dsp.rs:85-90)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int k = lane + 64 * e;
+                        const float ov = i == 0 ? ovn[k] : ys(ldsf, i - 1, kBs0 / 2 + k);
+                        o[k] = ov * win_short[kBs0 / 2 - 1 - k] + ys(ldsf, i, k) * win_short[k];
+                    }
+                }
+            }
+            wave_sync();
+            // overlap[0..128) = imdct[128..256) of the run's last block (dsp.rs:125); the rest is left as it was
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = lane + 64 * e;
+                ovn[k] = ys(ldsf, glen - 1, kBs0 / 2 + k);
+            }
+            wave_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) load_slot(ovn, lane + 64 * h, dl[h]);
+            wave_sync();
+        }
+        b = nb_next;
+        glen = glen_next;
+    }
+
+    if (b_end == nb) {
+        if (!hi_fresh) {
+            // The chain ends in short blocks and this segment never saw a long one: overlap[128..1024) still
+            // holds what the most recent long block left there (never used for PCM, but part of the state the
+            // reference carries).  Rebuild it from that block's spectrum, or keep the incoming state.
+            long bl = (long)b_begin - 1;
+            while (bl >= 0 && !f[bl]) --bl;
+            float keep[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) keep[h][q] = dl[h][q];
+            if (bl >= 0) {
+                const float2 *src = reinterpret_cast<const float2 *>(sp + os[bl]);
+                c32 z[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) line[s] = src[lane + 64 * s];
+                const int mirror = (63 - lane) * 4;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
+                    z[s] = pre_twiddle(line[s].x, mirrored, tw[lane + 64 * s]);
+                }
+                fft512_wave(z, lane, lds, lt);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float x[8];
+                    post_slot(lds, tw, lane + 64 * h, x, dl[h]);
+                }
+                wave_sync();
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) load_slot(overlap_in + (size_t)chain * 1024, lane + 64 * h, dl[h]);
+            }
+            // overlap[0..128) comes from the short blocks of this segment
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m2 = lane + 64 * h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4);
+                    if (j < kBs0 / 2) dl[h][q] = keep[h][q];
+                }
+            }
+        }
+        float *d = overlap_out + (size_t)chain * 1024;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) store_slot(d, lane + 64 * h, dl[h]);
+        if (lane == 0) prev_flag_out[chain] = f[nb - 1] ? 1 : 0;  // lib.rs:328
+    }
+}
+
+}  // namespace
+
+int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_long, const float *win_short,
+                       const float *win_long, const float *d_spectra, size_t spec_stride, const uint8_t *d_block_flag,
+                       const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out,
+                       float *d_pcm, size_t pcm_stride, const uint32_t *d_offs, size_t n_chains, unsigned nb,
+                       unsigned seg) {
+    const size_t segs = (nb + seg - 1) / seg;
+    const size_t items = n_chains * segs;
+    const size_t grid = (items + kWaves - 1) / kWaves;
+    if (items > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(vorbis_synth_wave_kernel, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev,
+                       tw_short, tw_long, win_short, win_long, d_spectra, spec_stride, d_block_flag, d_prev_in,
+                       d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs,
+                       (unsigned)items);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+}  // namespace symaccel

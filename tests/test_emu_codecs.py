@@ -96,6 +96,34 @@ def test_emu_vorbis_synth(emu_ctx, bs0e, bs1e, seg):
     assert np.array_equal(got[2], want[2]), "prev flag"
 
 
+def vorbis_wave_case(seed, nch, nb, p_long, tail_short=0):
+    """256/2048 case with controllable run structure; `tail_short` forces the last blocks short (state fix-up path)."""
+    rng = np.random.default_rng(seed)
+    flags = (rng.random((nch, nb)) < p_long).astype(np.uint8)
+    if tail_short:
+        flags[:, nb - tail_short:] = 0
+    flags[0, : min(nb, 11)] = 0  # a run longer than the eight-way short transform handles at once
+    prev = rng.integers(-1, 2, nch).astype(np.int32)
+    lay = oracle.vorbis_layout(8, 11, flags, prev)
+    spectra = (rng.standard_normal((nch, int(lay[0][:, -1].max()))) * 0.25).astype(np.float32)
+    overlap = rng.standard_normal((nch, 1024)).astype(np.float32)
+    return flags, prev, spectra, overlap, int(lay[1][:, -1].max())
+
+
+@pytest.mark.parametrize("seed,nb,p_long,tail_short,seg", [(1, 14, 0.5, 0, 4), (2, 13, 0.2, 6, 3), (3, 12, 0.9, 1, 5),
+                                                            (4, 9, 0.0, 0, 2), (5, 10, 1.0, 0, 1), (6, 16, 0.5, 9, 32)])
+def test_emu_vorbis_wave_paths(emu_ctx, seed, nb, p_long, tail_short, seg):
+    """The 256/2048 wavefront kernel: every transition, runs of short blocks, segment halos, the stale-state fix-up."""
+    flags, prev, spectra, overlap, pcm_stride = vorbis_wave_case(seed, 3, nb, p_long, tail_short)
+    emu_ctx.set_segment(seg)
+    got = VorbisDsp(emu_ctx, 8, 11).synth(spectra, flags, prev, overlap, pcm_stride)
+    emu_ctx.set_segment(0)
+    want = oracle.vorbis_synth(8, 11, spectra, flags, prev, overlap, pcm_stride)
+    assert bit_equal(got[0], want[0]), "pcm"
+    assert bit_equal(got[1], want[1]), "overlap"
+    assert np.array_equal(got[2], want[2]), "prev flag"
+
+
 def test_emu_vorbis_helpers(emu_ctx):
     rng = np.random.default_rng(5)
     v = VorbisDsp(emu_ctx, 8, 11)

@@ -246,6 +246,23 @@ def test_vorbis_parity(ctx, bs0e, bs1e, seg):
     assert np.array_equal(host(d_prev), want[2])
 
 
+@pytest.mark.parametrize("seed,nb,p_long,tail_short,seg", [(11, 67, 0.75, 0, 32), (12, 40, 0.3, 13, 7), (13, 33, 0.95, 2, 1),
+                                                            (14, 29, 0.0, 0, 5), (15, 31, 1.0, 0, 1000), (16, 50, 0.5, 20, 16)])
+def test_vorbis_wave_paths(ctx, seed, nb, p_long, tail_short, seg):
+    """The 256/2048 wavefront kernel: transitions, short runs > 8, segment halos, the stale-state fix-up."""
+    from test_emu_codecs import vorbis_wave_case
+    from symphonia_amd import VorbisDsp
+    flags, prev, spectra, overlap, pcm_stride = vorbis_wave_case(seed, 9, nb, p_long, tail_short)
+    d_prev, d_ov = dev(prev), dev(overlap)
+    ctx.set_segment(seg)
+    pcm = host(VorbisDsp(ctx, 8, 11).synth(dev(spectra), dev(flags), d_prev, d_ov, pcm_stride))
+    ctx.set_segment(0)
+    want = oracle.vorbis_synth(8, 11, spectra, flags, prev, overlap, pcm_stride)
+    assert_parity(pcm, want[0], "vorbis pcm")
+    assert_parity(host(d_ov), want[1], "vorbis overlap")
+    assert np.array_equal(host(d_prev), want[2])
+
+
 def test_vorbis_helpers_parity(ctx):
     from symphonia_amd import VorbisDsp
     rng = np.random.default_rng(8)
