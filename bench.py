@@ -245,7 +245,7 @@ def main():
             "vs_baseline": None,
             "dtype": "i32/i64" if args.workload == "flac" else "f32",
             "data": "synthetic",
-            "config": dict(config, parallelism="chains sharded per GPU, no collective", segment=args.segment or 32),
+            "config": dict(config, parallelism="chains sharded per GPU, no collective", segment=args.segment or "auto"),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
                          "kernel_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},

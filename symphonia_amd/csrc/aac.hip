@@ -235,8 +235,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
 int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const float *d_delay_in,
                float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain) {
     if (frames_per_chain > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    unsigned seg = ctx->segment > 0 ? (unsigned)ctx->segment : 32u;
-    if (seg > frames_per_chain) seg = (unsigned)frames_per_chain;
+    const unsigned seg = choose_segment(ctx, n_chains, frames_per_chain, 4 * SYM_AAC_MIN_WAVES, 1, 1, 1);
     const size_t segs = (frames_per_chain + seg - 1) / seg;
     const size_t items = n_chains * segs;
     const size_t grid = (items + kWaves - 1) / kWaves;

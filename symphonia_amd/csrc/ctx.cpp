@@ -49,6 +49,36 @@ int ctx_upload(symaccel_ctx *ctx, const void *src, size_t bytes, const void **ou
     return SYMACCEL_OK;
 }
 
+// Segment length for the chain-walking kernels.  Every item (chain, segment) costs seg + halo frames; the
+// machine runs `slots` items at a time (resident wavefronts x items per wavefront), so a launch takes about
+// ceil(items / slots) rounds of (seg + halo) frames.  Pick the seg that minimises that: it fills the chip
+// with a whole number of rounds (no half-empty tail round) at the smallest halo overhead.
+unsigned choose_segment(const symaccel_ctx *ctx, size_t n_chains, size_t frames_per_chain, unsigned waves_per_cu,
+                        unsigned items_per_wave, unsigned halo, unsigned min_seg) {
+    if (frames_per_chain == 0) return 1;
+    if (ctx->segment > 0) {
+        unsigned s = (unsigned)ctx->segment < min_seg ? min_seg : (unsigned)ctx->segment;
+        return s > frames_per_chain ? (unsigned)frames_per_chain : s;
+    }
+    const double slots = (double)ctx->n_cus * waves_per_cu * items_per_wave;
+    const unsigned lo = min_seg, hi = frames_per_chain < 256 ? (unsigned)frames_per_chain : 256u;
+    if (hi <= lo) return hi < 1 ? 1 : hi;
+    unsigned best = hi;
+    double best_cost = 1e300;
+    for (unsigned seg = lo; seg <= hi; ++seg) {
+        const double items = (double)n_chains * (double)((frames_per_chain + seg - 1) / seg);
+        const double rounds = items <= slots ? 1.0 : (double)(size_t)((items + slots - 1) / slots);
+        // an under-filled single round still runs faster per wavefront; credit half of the idle fraction
+        const double fill = items < slots ? 0.5 + 0.5 * items / slots : 1.0;
+        const double cost = rounds * (double)(seg + halo) * fill;
+        if (cost < best_cost * 0.999 || (cost <= best_cost * 1.001 && seg > best)) {
+            if (cost < best_cost) best_cost = cost;
+            best = seg;
+        }
+    }
+    return best;
+}
+
 int get_imdct_plan(symaccel_ctx *ctx, int n, double scale, const ImdctPlan **out) {
     uint64_t bits;
     std::memcpy(&bits, &scale, 8);
@@ -223,6 +253,9 @@ int symaccel_ctx_create(int device, symaccel_ctx **out) {
         st = SYMACCEL_ERR_DEVICE;
     } else {
         ctx->stream = ctx->own_stream;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            ctx->n_cus = cus;
         st = upload_tables(ctx);
     }
     if (st != SYMACCEL_OK) {

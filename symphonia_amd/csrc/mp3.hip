@@ -168,7 +168,10 @@ __device__ __forceinline__ VMap vmap(int i) {
     return m;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void mp3_synth_kernel(
+#ifndef SYM_MP3_WAVES
+#define SYM_MP3_WAVES 3  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVES, SYM_MP3_WAVES))) void mp3_synth_kernel(
     DevTables tb, const float *__restrict__ xr, const symaccel_mp3_side *__restrict__ side, int sr,
     const float *__restrict__ overlap_in, const float *__restrict__ vvec_in, const int32_t *__restrict__ vfront_in,
     float *__restrict__ overlap_out, float *__restrict__ vvec_out, int32_t *__restrict__ vfront_out,
@@ -409,9 +412,8 @@ int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_
                const float *d_overlap_in, const float *d_vvec_in, const int32_t *d_vfront_in, float *d_overlap_out,
                float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm, size_t n_chains, size_t granules_per_chain) {
     if (granules_per_chain > 0x3fffffffu || n_chains > 0x3fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    unsigned seg = ctx->segment > 0 ? (unsigned)ctx->segment : 32u;
-    if (seg < 2) seg = 2;  // the two-granule halo needs segment starts >= 2
-    if (seg > granules_per_chain) seg = (unsigned)granules_per_chain;
+    // (the two-granule halo needs segment starts >= 2)
+    const unsigned seg = choose_segment(ctx, n_chains, granules_per_chain, 4 * SYM_MP3_WAVES, 2, 2, 2);
     const size_t segs = (granules_per_chain + seg - 1) / seg;
     const size_t items = n_chains * segs;
     const size_t grid = (items + 1) / 2;

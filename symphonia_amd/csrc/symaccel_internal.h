@@ -90,7 +90,8 @@ struct symaccel_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    int segment = 0;
+    int segment = 0;  // 0 = choose per launch (choose_segment)
+    int n_cus = 256;  // compute units of the device (MI355X: 256)
     std::string last_error;
     symaccel::DevTables dev{};
     std::vector<void *> allocations;  // freed on destroy
@@ -108,6 +109,8 @@ int ctx_alloc(symaccel_ctx *ctx, void **out, size_t bytes, bool tracked = true);
 int ctx_scratch(symaccel_ctx *ctx, size_t bytes, void **out);
 int ctx_upload(symaccel_ctx *ctx, const void *src, size_t bytes, const void **out);
 int get_imdct_plan(symaccel_ctx *ctx, int n, double scale, const ImdctPlan **out);
+unsigned choose_segment(const symaccel_ctx *ctx, size_t n_chains, size_t frames_per_chain, unsigned waves_per_cu,
+                        unsigned items_per_wave, unsigned halo, unsigned min_seg);
 int get_vorbis_window(symaccel_ctx *ctx, int bs, const float **out);
 
 #define SYM_TRY(expr)                                                   \

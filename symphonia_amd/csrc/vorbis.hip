@@ -337,12 +337,12 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     hipLaunchKernelGGL(vorbis_offsets_kernel, dim3((unsigned)n_chains), dim3(256), 0, ctx->stream, d_block_flag,
                        d_prev_in, offs, nb, 1 << bs0_exp, 1 << bs1_exp);
     SYM_GPU(ctx, hipGetLastError());
-    unsigned seg = ctx->segment > 0 ? (unsigned)ctx->segment : 32u;
-    if (seg > nb) seg = nb;
+    const bool wave_path = bs0_exp == 8 && bs1_exp == 11;
+    const unsigned seg = choose_segment(ctx, n_chains, nb, wave_path ? 8 : 12, 1, 1, 1);
     const size_t segs = (nb + seg - 1) / seg;
     const size_t grid = n_chains * segs;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    if (bs0_exp == 8 && bs1_exp == 11) {
+    if (wave_path) {
         // the 256 / 2048 pair: wavefront-per-chain-segment kernel with register-resident overlap (vorbis_wave.hip)
         return launch_vorbis_wave(ctx, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
                                   spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
