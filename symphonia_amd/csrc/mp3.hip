@@ -17,7 +17,8 @@
 // The next granule's 576 lines are prefetched (8 B/lane, 256 B per half-wave) while the current one
 // is transformed.  Segments other than a chain's first start with a two-granule halo (granule g-2
 // rebuilds the overlap, granule g-1 rebuilds the 16-slot history); both depend only on inputs.
-// LDS: one 5 KiB buffer per wavefront (the granule tile, then the dct32 transpose).
+// PCM stores are 4 B per lane (128 B per half-wave): transposing the granule through LDS for 16-byte stores was
+// measured and is not faster.  LDS per wavefront: granule tiles 4.5 KiB + dct32 transpose 5 KiB + window rows 2.5 KiB.
 // Roofline: HBM-bound on paper, 2304 B in + 2304 B out per granule-channel, ~34 kflop (no FMA) -> 7.4 flop/B.
 #include "dsp_device.h"
 
@@ -30,7 +31,9 @@ constexpr int kSStride = 36;   // row stride (floats) of the slot-major transpos
 constexpr int kHistOld = 16;   // previous time slots kept (15 are read by the window, the 16th completes v_vec)
 constexpr int kRows = kHistOld + 18;
 constexpr int kTileFloats = 2 * 576;             // two granule tiles (one per half-wave)
-constexpr int kWaveFloats = kTileFloats + 2 * 18 * kSStride;  // per-wavefront LDS
+constexpr int kDwStride = 20;                    // window-coefficient rows [sample i][16], padded: conflict-free b128
+constexpr int kDwFloats = 32 * kDwStride;
+constexpr int kWaveFloats = kTileFloats + 2 * 18 * kSStride + kDwFloats;  // per-wavefront LDS
 
 // Order this wavefront's LDS accesses: its lanes exchange data through LDS; the hardware executes one
 // wavefront's DS instructions in order, the fences stop the compiler from reordering them.
@@ -168,6 +171,13 @@ __device__ __forceinline__ VMap vmap(int i) {
     return m;
 }
 
+__device__ __forceinline__ void fetch_granule(const float *granule, int hl, float4 (&line)[5]) {
+    const float4 *src = reinterpret_cast<const float4 *>(granule);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) line[q] = src[hl + 32 * q];
+    line[4] = src[128 + (hl & 15)];  // lanes 16..31 re-read float4 128..143 (same cache lines) and ignore it
+}
+
 #ifndef SYM_MP3_WAVES
 #define SYM_MP3_WAVES 3  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
 #endif
@@ -190,12 +200,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
     const unsigned g_end = live ? min(g_begin + seg_len, granules_per_chain) : g_begin;
     const size_t chain_base = (size_t)chain * granules_per_chain;
 
-    // per-lane window coefficients: D[64j + i], D[64j + 32 + i]
-    float dw0[8], dw1[8];
+    // Window coefficients of sample index i = hl: D[64j + i] (j = 0..7), D[64j + 32 + i], as one 64-byte LDS row
+    // per i.  They are only live during the window pass, where they are re-read from LDS (4 x b128) every granule.
+    float *dwt = lds + kTileFloats + 2 * 18 * kSStride;
+    if (half == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        dw0[j] = mc[MP3C_SYNTH_D + 64 * j + hl];
-        dw1[j] = mc[MP3C_SYNTH_D + 64 * j + 32 + hl];
+        for (int j = 0; j < 8; ++j) {
+            dwt[hl * kDwStride + j] = tb.mp3_consts[MP3C_SYNTH_D + 64 * j + hl];
+            dwt[hl * kDwStride + 8 + j] = tb.mp3_consts[MP3C_SYNTH_D + 64 * j + 32 + hl];
+        }
     }
     const VMap vm = vmap(hl);
 
@@ -228,12 +241,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
         rounds = rounds > other ? rounds : other;
     }
 
-    float2 line[9];  // line[q] = src[2 (hl + 32 q) .. +1]: 256 B coalesced per half-wave and load
-    if (live && g_first < g_stop) {
-        const float2 *src = reinterpret_cast<const float2 *>(xr + (chain_base + (size_t)g_first) * 576);
+    // The granule's 576 lines as 144 float4: lane hl holds float4 hl + 32 q, q = 0..3, and (hl < 16) float4 128 + hl.
+    // 16 B per lane: 512 B coalesced per half-wave and instruction (narrow accesses are issue-bound, not HBM-bound).
+    float4 line[5];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) line[q] = src[hl + 32 * q];
-    }
+    for (int q = 0; q < 5; ++q) line[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live && g_first < g_stop) fetch_granule(xr + (chain_base + (size_t)g_first) * 576, hl, line);
 
     for (long r = 0; r < rounds; ++r) {
         const long g = g_first + r;
@@ -250,9 +263,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
         }
         // ---- granule -> LDS tile (natural order), then lane sb gathers its 18 lines
         if (active) {
-            float2 *t2 = reinterpret_cast<float2 *>(tile);
+            float4 *t4 = reinterpret_cast<float4 *>(tile);
 #pragma unroll
-            for (int q = 0; q < 9; ++q) t2[hl + 32 * q] = line[q];
+            for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
+            if (hl < 16) t4[128 + hl] = line[4];
         }
         wave_sync();
         float y[18];
@@ -353,15 +367,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
             for (int k = 0; k < 8; ++k) row[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
         }
         wave_sync();
-        if (live && g + 1 < g_stop) {  // prefetch the next granule; it lands during the window pass
-            const float2 *src = reinterpret_cast<const float2 *>(xr + (chain_base + (size_t)(g + 1)) * 576);
-#pragma unroll
-            for (int q = 0; q < 9; ++q) line[q] = src[hl + 32 * q];
-        }
+        if (live && g + 1 < g_stop)  // prefetch the next granule; it lands during the window pass
+            fetch_granule(xr + (chain_base + (size_t)(g + 1)) * 576, hl, line);
         // ---- windowing (synthesis.rs:309-324), one time slot at a time: fetch the slot's two V entries for
         // this lane's sample index (synthesis.rs:247-263), then 16 taps with every operand in registers.
         // (Lanes / granules that do not need the history read stale LDS into nA/nB and never use it.)
-        float *dst = pcm + (chain_base + (size_t)g) * 576;
+        float dw0[8], dw1[8];
+        {
+            const float4 *r4 = reinterpret_cast<const float4 *>(dwt + hl * kDwStride);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float4 a = r4[k], c = r4[2 + k];
+                dw0[4 * k] = a.x; dw0[4 * k + 1] = a.y; dw0[4 * k + 2] = a.z; dw0[4 * k + 3] = a.w;
+                dw1[4 * k] = c.x; dw1[4 * k + 1] = c.y; dw1[4 * k + 2] = c.z; dw1[4 * k + 3] = c.w;
+            }
+        }
         float nA[18], nB[18];
 #pragma unroll
         for (int b = 0; b < 18; ++b) {
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
                 acc += (ra >= 0 ? nA[ra >= 0 ? ra : 0] : oA[ra < 0 ? kHistOld + ra : 0]) * dw0[j];
                 acc += (rb >= 0 ? nB[rb >= 0 ? rb : 0] : oB[rb < 0 ? kHistOld + rb : 0]) * dw1[j];
             }
-            if (emit) dst[32 * b + hl] = acc;
+            if (emit) (pcm + (chain_base + (size_t)g) * 576)[32 * b + hl] = acc;
         }
         // ---- slide the history: slots 2..17 of this granule become slots -16..-1
         if (need_hist) {

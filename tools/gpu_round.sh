@@ -1,22 +1,23 @@
 #!/bin/bash
-# One gpurun call: bench lines for every workload + rocprofv3 kernel stats and PMC passes for the headline kernel.
-# Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tag]
+# One gpurun call: bench lines for every workload (with the CPU baseline) + rocprofv3 kernel stats for every workload
+# + HBM traffic PMC passes for the headline kernel.   bash tools/gpu_round.sh [tag]
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 for w in aac mp3 vorbis flac; do
   timeout 300 python bench.py --workload $w --steps 20 --warmup 3 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
-  echo "bench $w rc=$?"; tail -n 2 $OUT/bench_$w.json | cut -c1-600
+  echo "bench $w rc=$?"; tail -n 1 $OUT/bench_$w.json | cut -c1-400
 done
 REPO=$PWD
 cd /tmp
-for w in aac mp3; do
+for w in aac mp3 vorbis flac; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_$w -o $w -- python $REPO/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_${TAG}_$w.log 2>&1
   echo "rocprof stats $w rc=$?"
 done
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${TAG}_aac_$c -o aac -- python $REPO/bench.py --workload aac --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_${TAG}_aac_$c.log 2>&1
-  echo "rocprof pmc $c rc=$?"
+for w in aac mp3; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${TAG}_${w}_$c -o $w -- python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_${TAG}_${w}_$c.log 2>&1
+    echo "rocprof pmc $w $c rc=$?"
+  done
 done
-find $OUT -name "*.csv" | head -30
