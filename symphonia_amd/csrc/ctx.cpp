@@ -342,7 +342,7 @@ int symaccel_aac_synth_device(symaccel_ctx *ctx, const float *d_coeffs, const ui
     const size_t state_bytes = n_chains * 1024 * sizeof(float);
     SYM_TRY(ctx_scratch(ctx, state_bytes, &scratch));
     SYM_TRY(launch_aac(ctx, d_coeffs, d_side, d_delay_io, (float *)scratch, d_pcm, n_chains, frames_per_chain));
-    SYM_GPU(ctx, hipMemcpyAsync(d_delay_io, scratch, state_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    SYM_TRY(launch_state_copy(ctx, d_delay_io, scratch, state_bytes, nullptr, nullptr, 0, nullptr, nullptr, 0));
     return SYMACCEL_OK;
 }
 
@@ -382,9 +382,8 @@ int symaccel_mp3_synth_device(symaccel_ctx *ctx, const float *d_xr, const symacc
     int32_t *vf_out = (int32_t *)(vv_out + n_chains * 1024);
     SYM_TRY(launch_mp3(ctx, d_xr, d_side, sample_rate_idx, d_overlap_io, d_vvec_io, d_vfront_io, ov_out, vv_out,
                        vf_out, d_pcm, n_chains, granules_per_chain));
-    SYM_GPU(ctx, hipMemcpyAsync(d_overlap_io, ov_out, ov_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    SYM_GPU(ctx, hipMemcpyAsync(d_vvec_io, vv_out, vv_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    SYM_GPU(ctx, hipMemcpyAsync(d_vfront_io, vf_out, vf_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    SYM_TRY(launch_state_copy(ctx, d_overlap_io, ov_out, ov_bytes, d_vvec_io, vv_out, vv_bytes, d_vfront_io, vf_out,
+                              vf_bytes));
     return SYMACCEL_OK;
 }
 
@@ -433,8 +432,7 @@ int symaccel_vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, co
     int32_t *pf_out = (int32_t *)(ov_out + n_chains * half1);
     SYM_TRY(launch_vorbis(ctx, bs0_exp, bs1_exp, d_spectra, spec_stride, d_block_flag, d_prev_flag_io, pf_out,
                           d_overlap_io, ov_out, d_pcm, pcm_stride, n_chains, blocks_per_chain));
-    SYM_GPU(ctx, hipMemcpyAsync(d_overlap_io, ov_out, ov_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    SYM_GPU(ctx, hipMemcpyAsync(d_prev_flag_io, pf_out, pf_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    SYM_TRY(launch_state_copy(ctx, d_overlap_io, ov_out, ov_bytes, d_prev_flag_io, pf_out, pf_bytes, nullptr, nullptr, 0));
     return SYMACCEL_OK;
 }
 
