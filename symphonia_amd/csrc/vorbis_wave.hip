@@ -9,7 +9,9 @@
 // previous block's Imdct output (the `overlap` of dsp.rs:125) stays in 16 VGPRs per lane in the same slot
 // layout the post-twiddle produces, so the common long -> long overlap-add is lane-local:
 //     out[k] = overlap[k] * win[1023 - k] + pcm[k] * win[k]                       (dsp.rs:85-90, 140-144)
-// Block-size transitions and short blocks go through a natural-order LDS staging area (rare path).
+// Block-size transitions stay in registers too: the 128 overlap-added samples of a long <-> short transition live in
+// the slots of lanes 48..63, the short overlap in lanes 0..31 (one ds_bpermute hop), the copied samples are stored
+// straight from the slot registers; short-block output is read from the half-stored LDS result of the short pass.
 // Packed spectrum / PCM offsets come from vorbis_offsets_kernel (vorbis.hip).
 // HBM traffic per channel-block: 4 * (n/2) B in + 4 * (prev_n + n)/4 B out (+ one halo block per segment).
 #include "imdct_wave.h"
@@ -21,12 +23,35 @@ namespace {
 constexpr int kWaves = 4;
 constexpr int kTabTw = 0;        // shared LDS tables: Imdct(1024) twiddles, 512 complex
 constexpr int kTabWin = 1024;    //   long window (left half of the 2048-sample window), 1024 f32
-constexpr int kTabFloats = 2048;
+constexpr int kTabWs = 2048;     //   short window (left half of the 256-sample window), 128 f32
+constexpr int kTabFloats = 2048 + 128;
 constexpr int kBs0 = 256, kBs1 = 2048;
-constexpr int kStart = (kBs1 - kBs0) / 4;  // 448 (dsp.rs:93, 109)
 
-// y_s[i], i in 0..256: Imdct output of short block `w` of the current run, from the half-stored H (imdct_wave.h)
-__device__ __forceinline__ float ys(const float *H, int w, int i) { return short_src(H, w, i); }
+// y_s[i0 .. i0+3] (i0 a multiple of 4, in 0..256): Imdct output of short block `w` of the current run from the
+// half-stored H (imdct_wave.h): v0 = -reverse(v1), v1 = H[0..64), v2 = H[64..128), v3 = reverse(v2).
+__device__ __forceinline__ void ys4(const float *H, int w, int i0, float (&v)[4]) {
+    const float *h = H + 128 * w;
+    if (i0 < 64) {
+        const float4 r = *reinterpret_cast<const float4 *>(h + 60 - i0);
+        v[0] = -r.w; v[1] = -r.z; v[2] = -r.y; v[3] = -r.x;
+    } else if (i0 < 192) {
+        const float4 r = *reinterpret_cast<const float4 *>(h + i0 - 64);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    } else {
+        const float4 r = *reinterpret_cast<const float4 *>(h + 316 - i0);
+        v[0] = r.w; v[1] = r.z; v[2] = r.y; v[3] = r.x;
+    }
+}
+
+// out[q] = ov[q] * ws[127 - (k + q)] + y[q] * ws[k + q], q = 0..3 (vorbis dsp.rs:140-144 with the short window)
+__device__ __forceinline__ void ola_short4(const float *ws, int k, const float (&ov)[4], const float (&y)[4], float4 &o) {
+    const float4 wf = *reinterpret_cast<const float4 *>(ws + k);
+    const float4 wr = *reinterpret_cast<const float4 *>(ws + 124 - k);  // ws[124-k .. 127-k], used back to front
+    o.x = ov[0] * wr.w + y[0] * wf.x;
+    o.y = ov[1] * wr.z + y[1] * wf.y;
+    o.z = ov[2] * wr.y + y[2] * wf.z;
+    o.w = ov[3] * wr.x + y[3] * wf.w;
+}
 
 __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     DevTables tb, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
@@ -41,6 +66,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     for (int i = (int)threadIdx.x; i < 1024; i += 64 * kWaves) {
         tabs[kTabTw + i] = reinterpret_cast<const float *>(tw_long)[i];
         tabs[kTabWin + i] = win_long[i];
+        if (i < 128) tabs[kTabWs + i] = win_short[i];
     }
     __syncthreads();  // the only workgroup-wide barrier
 
@@ -50,7 +76,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     float *ldsf = wave_lds[wave];
     c32 *lds = reinterpret_cast<c32 *>(ldsf);
     const c32 *tw = reinterpret_cast<const c32 *>(tabs + kTabTw);
-    const float *wl = tabs + kTabWin;
+    const float *wl = tabs + kTabWin, *ws = tabs + kTabWs;
 
     const unsigned chain = item / segs_per_chain, seg = item % segs_per_chain;
     const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
@@ -136,29 +162,32 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                 }
                 wave_sync();  // Z in LDS is overwritten by the next group
             } else {
-                // short -> long (dsp.rs:107-122): 128 overlap-added samples, then 448 copied ones
-                wave_sync();  // every lane has read Z
-                float *nat = ldsf, *ovn = ldsf + 1024;
+                // short -> long (dsp.rs:107-122): out[k] = overlap[k] * ws[127-k] + imdct[448+k] * ws[k] for k < 128,
+                // then imdct[576..1024) copied.  imdct[448..576) sits in the slots of lanes 48..63 (m2 = 112 + t);
+                // the short overlap[0..128) sits in dl[0][0..3] of lanes 0..31: lane 48+t takes lane t's (for its
+                // first float4) and lane 31-t's (for its second) through ds_bpermute.
+                const int t = lane >= 48 ? lane - 48 : 0;
+                float ovA[4], ovB[4];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    store_slot(nat, lane + 64 * h, x[h]);
-                    store_slot(ovn, lane + 64 * h, dl[h]);
+                for (int q = 0; q < 4; ++q) {
+                    ovA[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * t, __float_as_int(dl[0][q])));
+                    ovB[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (31 - t), __float_as_int(dl[0][q])));
                 }
-                wave_sync();
                 if (emit) {
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) {
-                        const int k = lane + 64 * e;  // 0..575
-                        float v;
-                        if (k < kBs0 / 2) {
-                            v = ovn[k] * win_short[kBs0 / 2 - 1 - k] + nat[kStart + k] * win_short[k];
-                        } else {
-                            v = nat[kStart + k];  // imdct[end + (k - 128)], end = 576
-                        }
-                        o[k] = v;
+                    float4 *o4 = reinterpret_cast<float4 *>(o);
+                    // copied part: second float4 of every slot with 1020 - 4 m2 >= 576, i.e. m2 <= 111
+                    o4[143 - lane] = make_float4(x[0][4], x[0][5], x[0][6], x[0][7]);           // (572 - 4 lane) / 4
+                    if (lane < 48) o4[79 - lane] = make_float4(x[1][4], x[1][5], x[1][6], x[1][7]);  // (316 - 4 lane) / 4
+                    if (lane >= 48) {
+                        const float ya[4] = {x[1][0], x[1][1], x[1][2], x[1][3]}, yb[4] = {x[1][4], x[1][5], x[1][6], x[1][7]};
+                        float4 ra, rb;
+                        ola_short4(ws, 4 * t, ovA, ya, ra);
+                        ola_short4(ws, 124 - 4 * t, ovB, yb, rb);
+                        o4[t] = ra;
+                        o4[31 - t] = rb;
                     }
                 }
-                wave_sync();
+                wave_sync();  // Z in LDS is overwritten by the next group
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -183,50 +212,53 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                 for (int s = 0; s < 8; ++s)
                     if (s < n_loads) line[s] = src[lane + 64 * s];
             }
-            imdct_short_wave(lane, ldsf, tw_short, lt);  // H[8][128] in ldsf[0..1024)
-            float *ovn = ldsf + 1024;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) store_slot(ovn, lane + 64 * h, dl[h]);
-            wave_sync();
+            imdct_short_wave(lane, ldsf, tw_short, lt);  // H[8][128] in ldsf[0..1024); ends with a wave_sync
             for (int i = 0; i < glen; ++i) {
                 const long blk = b + i;
                 const bool emit = blk >= (long)b_begin;
-                float *o = out + op[blk];
+                float4 *o4 = reinterpret_cast<float4 *>(out + op[blk]);
                 if (i == 0 && pflag) {
-                    // long -> short (dsp.rs:91-106): 448 unity-gain samples, then 128 overlap-added ones
+                    // long -> short (dsp.rs:91-106): overlap[0..448) at unity gain, then 128 overlap-added samples.
+                    // overlap[448..576) sits in the slots of lanes 48..63 (m2 = 112 + t).
                     if (emit) {
-#pragma unroll
-                        for (int e = 0; e < 9; ++e) {
-                            const int k = lane + 64 * e;
-                            float v = ovn[k];
-                            if (k >= kStart) {
-                                const int kk = k - kStart;
-                                v = v * win_short[kBs0 / 2 - 1 - kk] + ys(ldsf, 0, kk) * win_short[kk];
-                            }
-                            o[k] = v;
+                        o4[lane] = make_float4(dl[0][0], dl[0][1], dl[0][2], dl[0][3]);                     // 4 m2, m2 < 64
+                        if (lane < 48) o4[64 + lane] = make_float4(dl[1][0], dl[1][1], dl[1][2], dl[1][3]);  // m2 < 112
+                        if (lane >= 48) {
+                            const int t = lane - 48;
+                            const float oa[4] = {dl[1][0], dl[1][1], dl[1][2], dl[1][3]}, ob[4] = {dl[1][4], dl[1][5], dl[1][6], dl[1][7]};
+                            float ya[4], yb[4];
+                            ys4(ldsf, 0, 4 * t, ya);
+                            ys4(ldsf, 0, 124 - 4 * t, yb);
+                            float4 ra, rb;
+                            ola_short4(ws, 4 * t, oa, ya, ra);
+                            ola_short4(ws, 124 - 4 * t, ob, yb, rb);
+                            o4[112 + t] = ra;        // (448 + 4 t) / 4
+                            o4[143 - t] = rb;        // (448 + 124 - 4 t) / 4
                         }
                     }
-                } else if (emit) {
-                    // short -> short (dsp.rs:85-90)
+                } else if (emit && lane < 32) {
+                    // short -> short (dsp.rs:85-90): lane l produces out[4 l .. 4 l + 3]
+                    float ov[4], y[4];
+                    if (i == 0) {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int k = lane + 64 * e;
-                        const float ov = i == 0 ? ovn[k] : ys(ldsf, i - 1, kBs0 / 2 + k);
-                        o[k] = ov * win_short[kBs0 / 2 - 1 - k] + ys(ldsf, i, k) * win_short[k];
+                        for (int q = 0; q < 4; ++q) ov[q] = dl[0][q];  // overlap[0..128) = first float4 of lanes 0..31
+                    } else {
+                        ys4(ldsf, i - 1, kBs0 / 2 + 4 * lane, ov);
                     }
+                    ys4(ldsf, i, 4 * lane, y);
+                    float4 r;
+                    ola_short4(ws, 4 * lane, ov, y, r);
+                    o4[lane] = r;
                 }
             }
-            wave_sync();
             // overlap[0..128) = imdct[128..256) of the run's last block (dsp.rs:125); the rest is left as it was
+            if (lane < 32) {
+                float v[4];
+                ys4(ldsf, glen - 1, kBs0 / 2 + 4 * lane, v);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int k = lane + 64 * e;
-                ovn[k] = ys(ldsf, glen - 1, kBs0 / 2 + k);
+                for (int q = 0; q < 4; ++q) dl[0][q] = v[q];
             }
-            wave_sync();
-#pragma unroll
-            for (int h = 0; h < 2; ++h) load_slot(ovn, lane + 64 * h, dl[h]);
-            wave_sync();
+            wave_sync();  // H is overwritten by the next group
         }
         b = nb_next;
         glen = glen_next;
