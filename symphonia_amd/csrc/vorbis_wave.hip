@@ -102,31 +102,56 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     }
     bool hi_fresh = b_begin == 0;  // overlap[128..1024) is what the reference would hold at this point
 
+    // Block flags as wave-uniform bit masks (bit = 1: long; blocks past b_end read as long): m0 covers blocks
+    // [wbase, wbase + 64), m1 the next 64.  One coalesced byte load + ballot per 64 blocks replaces a dependent
+    // global load per block in the group bookkeeping; the packed offsets are carried as running sums.
+    const long b_first = b_begin == 0 ? 0 : (long)b_begin - 1;  // the halo block rebuilds the overlap only
+    auto load_mask = [&](long base) -> unsigned long long {
+        const long idx = base + lane;
+        const bool is_long = idx >= (long)b_end || f[idx] != 0;
+        return __ballot(is_long);
+    };
+    long wbase = b_first;
+    unsigned long long m0 = load_mask(wbase), m1 = load_mask(wbase + 64);
     // A group = one long block, or a run of up to 8 consecutive short blocks (never crossing b_end).
-    auto group_len = [&](long b) -> int {
-        if (f[b]) return 1;
-        int r = 1;
-        while (r < 8 && b + r < (long)b_end && !f[b + r]) ++r;
-        return r;
+    auto group_at = [&](long bb, int &flag_out) -> int {
+        if (bb >= (long)b_end) {
+            flag_out = 1;
+            return 0;
+        }
+        while (bb - wbase >= 64) {
+            m0 = m1;
+            wbase += 64;
+            m1 = load_mask(wbase + 64);
+        }
+        const int off = (int)(bb - wbase);
+        const unsigned long long w = off == 0 ? m0 : ((m0 >> off) | (m1 << (64 - off)));
+        flag_out = (int)(w & 1ull);
+        if (flag_out) return 1;
+        const int run = w ? __builtin_ctzll(w) : 64;
+        return run < 8 ? run : 8;
     };
 
-    const long b_first = b_begin == 0 ? 0 : (long)b_begin - 1;  // the halo block rebuilds the overlap only
     long b = b_first;
-    int glen = b < (long)b_end ? group_len(b) : 0;
+    int flag = 1;
+    int glen = group_at(b, flag);
+    // flag of the block before b (lib.rs:298: the first block of a stream pairs with itself)
+    int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);
+    uint32_t os_cur = os[b_first], op_cur = op[b_first];  // packed spectrum / PCM offsets of block b
     float2 line[8];  // the group's spectral lines: 1024 (long) or 128 per short block, 512 B coalesced per load
     if (glen > 0) {
-        const float2 *src = reinterpret_cast<const float2 *>(sp + os[b]);
-        const int n_loads = f[b] ? 8 : glen;
+        const float2 *src = reinterpret_cast<const float2 *>(sp + os_cur);
+        const int n_loads = flag ? 8 : glen;
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             if (s < n_loads) line[s] = src[lane + 64 * s];
     }
 
     while (b < (long)b_end) {
-        const int flag = f[b] ? 1 : 0;
-        const int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);  // lib.rs:298
         const long nb_next = b + glen;
-        const int glen_next = nb_next < (long)b_end ? group_len(nb_next) : 0;
+        int flag_next = 1;
+        const int glen_next = group_at(nb_next, flag_next);
+        const uint32_t os_next = os_cur + (flag ? 1024u : 128u * (uint32_t)glen);
 
         if (flag) {
             // ------------------------------------------------------------------ one long block
@@ -139,8 +164,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                 z[s] = pre_twiddle(line[s].x, mirrored, tw[lane + 64 * s]);
             }
             if (glen_next > 0) {  // prefetch the next group
-                const float2 *src = reinterpret_cast<const float2 *>(sp + os[nb_next]);
-                const int n_loads = f[nb_next] ? 8 : glen_next;
+                const float2 *src = reinterpret_cast<const float2 *>(sp + os_next);
+                const int n_loads = flag_next ? 8 : glen_next;
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
                     if (s < n_loads) line[s] = src[lane + 64 * s];
@@ -149,7 +174,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
             float x[2][8], x2[2][8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) post_slot(lds, tw, lane + 64 * h, x[h], x2[h]);
-            float *o = out + op[b];
+            float *o = out + op_cur;
             if (pflag) {
                 // long -> long (dsp.rs:85-90): out[k] = overlap[k] * win[1023 - k] + pcm[k] * win[k]
 #pragma unroll
@@ -206,8 +231,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
             }
             wave_sync();
             if (glen_next > 0) {
-                const float2 *src = reinterpret_cast<const float2 *>(sp + os[nb_next]);
-                const int n_loads = f[nb_next] ? 8 : glen_next;
+                const float2 *src = reinterpret_cast<const float2 *>(sp + os_next);
+                const int n_loads = flag_next ? 8 : glen_next;
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
                     if (s < n_loads) line[s] = src[lane + 64 * s];
@@ -216,7 +241,9 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
             for (int i = 0; i < glen; ++i) {
                 const long blk = b + i;
                 const bool emit = blk >= (long)b_begin;
-                float4 *o4 = reinterpret_cast<float4 *>(out + op[blk]);
+                // PCM of the run's blocks is packed back to back: the first contributes 576 (after a long) or 128
+                const uint32_t first_len = pflag ? 576u : 128u;
+                float4 *o4 = reinterpret_cast<float4 *>(out + op_cur + (i == 0 ? 0u : first_len + 128u * (uint32_t)(i - 1)));
                 if (i == 0 && pflag) {
                     // long -> short (dsp.rs:91-106): overlap[0..448) at unity gain, then 128 overlap-added samples.
                     // overlap[448..576) sits in the slots of lanes 48..63 (m2 = 112 + t).
@@ -260,8 +287,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
             }
             wave_sync();  // H is overwritten by the next group
         }
+        op_cur += flag ? (pflag ? 1024u : 576u) : ((pflag ? 576u : 128u) + 128u * (uint32_t)(glen - 1));
+        os_cur = os_next;
+        pflag = flag;  // every block of a group has the group's flag
         b = nb_next;
         glen = glen_next;
+        flag = flag_next;
     }
 
     if (b_end == nb) {

@@ -121,6 +121,18 @@ static inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int value) {
     __builtin_amdgcn_wave_barrier();
     return r;
 }
+// mask of the wavefront's lanes whose predicate is non-zero
+static inline unsigned long long __ballot(int pred) {
+    unsigned tid = emu::t_threadIdx.x;
+    unsigned wave_base = tid & ~63u;
+    emu::g_exchange[tid] = pred ? 1u : 0u;
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < 64 && wave_base + l < emu::g_blockDim.x * emu::g_blockDim.y * emu::g_blockDim.z; ++l)
+        if (emu::g_exchange[wave_base + l]) m |= 1ull << l;
+    __builtin_amdgcn_wave_barrier();
+    return m;
+}
 static inline int __shfl(int v, int src_lane, int width = 64) {
     (void)width;
     return __builtin_amdgcn_ds_bpermute(src_lane * 4, v);

@@ -111,7 +111,8 @@ def vorbis_wave_case(seed, nch, nb, p_long, tail_short=0):
 
 
 @pytest.mark.parametrize("seed,nb,p_long,tail_short,seg", [(1, 14, 0.5, 0, 4), (2, 13, 0.2, 6, 3), (3, 12, 0.9, 1, 5),
-                                                            (4, 9, 0.0, 0, 2), (5, 10, 1.0, 0, 1), (6, 16, 0.5, 9, 32)])
+                                                            (4, 9, 0.0, 0, 2), (5, 10, 1.0, 0, 1), (6, 16, 0.5, 9, 32),
+                                                            (7, 150, 0.6, 0, 1000)])
 def test_emu_vorbis_wave_paths(emu_ctx, seed, nb, p_long, tail_short, seg):
     """The 256/2048 wavefront kernel: every transition, runs of short blocks, segment halos, the stale-state fix-up."""
     flags, prev, spectra, overlap, pcm_stride = vorbis_wave_case(seed, 3, nb, p_long, tail_short)

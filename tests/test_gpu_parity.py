@@ -247,7 +247,8 @@ def test_vorbis_parity(ctx, bs0e, bs1e, seg):
 
 
 @pytest.mark.parametrize("seed,nb,p_long,tail_short,seg", [(11, 67, 0.75, 0, 32), (12, 40, 0.3, 13, 7), (13, 33, 0.95, 2, 1),
-                                                            (14, 29, 0.0, 0, 5), (15, 31, 1.0, 0, 1000), (16, 50, 0.5, 20, 16)])
+                                                            (14, 29, 0.0, 0, 5), (15, 31, 1.0, 0, 1000), (16, 50, 0.5, 20, 16),
+                                                            (17, 300, 0.7, 0, 1000), (18, 200, 0.1, 0, 150)])
 def test_vorbis_wave_paths(ctx, seed, nb, p_long, tail_short, seg):
     """The 256/2048 wavefront kernel: transitions, short runs > 8, segment halos, the stale-state fix-up."""
     from test_emu_codecs import vorbis_wave_case
