@@ -121,9 +121,10 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
         for (int s = 0; s < 8; ++s) line[s] = src[lane + 64 * s];
     }
 
+    unsigned sb_next = side[chain_base + (size_t)t_first];  // side bytes are fetched one frame ahead, like the lines
     for (long t = t_first; t < (long)t_end; ++t) {
         const bool emit = t >= (long)t_begin;
-        const unsigned sb = side[chain_base + (size_t)t];
+        const unsigned sb = sb_next;
         const int seq = (int)(sb & 3u);
         const int shape = (int)((sb >> 2) & 1u), prev_shape = (int)((sb >> 3) & 1u);
         float *frame_out = pcm + (chain_base + (size_t)t) * 1024;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
             wave_sync();
         }
         if (t + 1 < (long)t_end) {  // prefetch the next frame; it lands while this one is transformed
+            sb_next = side[chain_base + (size_t)t + 1];
             const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t + 1) * 1024);
 #pragma unroll
             for (int s = 0; s < 8; ++s) line[s] = src[lane + 64 * s];

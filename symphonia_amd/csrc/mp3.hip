@@ -246,7 +246,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
     float4 line[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) line[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (live && g_first < g_stop) fetch_granule(xr + (chain_base + (size_t)g_first) * 576, hl, line);
+    symaccel_mp3_side sd_next{};
+    if (live && g_first < g_stop) {
+        fetch_granule(xr + (chain_base + (size_t)g_first) * 576, hl, line);
+        sd_next = side[chain_base + (size_t)g_first];
+    }
 
     for (long r = 0; r < rounds; ++r) {
         const long g = g_first + r;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
 
         int bt = 0, mixed = 0, rzero = 0;
         if (active) {
-            const symaccel_mp3_side sd = side[chain_base + (size_t)g];
+            const symaccel_mp3_side sd = sd_next;  // fetched one granule ahead, with the lines
             bt = sd.block_type;
             mixed = sd.is_mixed ? 1 : 0;
             rzero = sd.rzero > 576 ? 576 : sd.rzero;
@@ -367,8 +371,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
             for (int k = 0; k < 8; ++k) row[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
         }
         wave_sync();
-        if (live && g + 1 < g_stop)  // prefetch the next granule; it lands during the window pass
+        if (live && g + 1 < g_stop) {  // prefetch the next granule; it lands during the window pass
             fetch_granule(xr + (chain_base + (size_t)(g + 1)) * 576, hl, line);
+            sd_next = side[chain_base + (size_t)(g + 1)];
+        }
         // ---- windowing (synthesis.rs:309-324), one time slot at a time: fetch the slot's two V entries for
         // this lane's sample index (synthesis.rs:247-263), then 16 taps with every operand in registers.
         // (Lanes / granules that do not need the history read stale LDS into nA/nB and never use it.)
