@@ -208,23 +208,26 @@ def test_mp3_parity(ctx, seg, sr):
 
 
 def test_mp3_config3_sampled(ctx):
-    """BASELINE config 3 shape (long blocks), reduced chain count: 16 chains x 2048 granules."""
+    """BASELINE config 3: 131 072 stereo granules = 128 chains x 2048 granules, long blocks.  Segmentation (halo
+    recompute) must not change a bit; sampled chains are checked against the oracle."""
     from symphonia_amd import Mp3Synthesis, mp3_side
-    nch, ngr = 16, 2048
-    rng = np.random.default_rng(3)
-    xr = (rng.standard_normal((nch, ngr, 576)) * 0.1).astype(np.float32)
+    nch, ngr = 128, 2048
+    g = torch.Generator(device="cuda").manual_seed(3)
+    d_xr = torch.randn((nch, ngr, 576), generator=g, device="cuda", dtype=torch.float32) * 0.1
     side = mp3_side(np.zeros((nch, ngr)), np.zeros((nch, ngr)), np.full((nch, ngr), 576))
+    d_side = dev(side.view(np.uint8).reshape(nch, ngr, 4))
     outs = []
     for seg in (16, 128):
         ctx.set_segment(seg)
         st = [dev(np.zeros((nch, 576), np.float32)), dev(np.zeros((nch, 1024), np.float32)), dev(np.zeros(nch, np.int32))]
-        outs.append(Mp3Synthesis(ctx, 0).synth(dev(xr), dev(side.view(np.uint8).reshape(nch, ngr, 4)), *st))
+        outs.append(Mp3Synthesis(ctx, 0).synth(d_xr, d_side, *st))
     ctx.set_segment(0)
     torch.cuda.synchronize()
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
-    pick = [0, 7, 15]
+    pick = [0, 77, 127]
+    xr = host(d_xr[pick])
     z = (np.zeros((3, 576), np.float32), np.zeros((3, 1024), np.float32), np.zeros(3, np.int32))
-    want = oracle.mp3_synth(xr[pick], oracle.mp3_side(np.zeros((3, ngr)), np.zeros((3, ngr)), np.full((3, ngr), 576)), 0, *z)
+    want = oracle.mp3_synth(xr, oracle.mp3_side(np.zeros((3, ngr)), np.zeros((3, ngr)), np.full((3, ngr), 576)), 0, *z)
     assert_parity(host(outs[0][pick]), want[0], "mp3 config-3 sampled chains")
 
 
@@ -262,6 +265,46 @@ def test_vorbis_wave_paths(ctx, seed, nb, p_long, tail_short, seg):
     assert_parity(pcm, want[0], "vorbis pcm")
     assert_parity(host(d_ov), want[1], "vorbis overlap")
     assert np.array_equal(host(d_prev), want[2])
+
+
+def test_vorbis_config4_shard_properties(ctx):
+    """BASELINE config 4, one GPU's shard: 8 streams x 8 ch = 64 chains x 4096 blocks, 2048/256 Markov block flags.
+    Segmentation must not change a bit; sampled chains are checked against the oracle."""
+    from symphonia_amd import VorbisDsp
+    nch, nb = 64, 4096
+    rng = np.random.default_rng(4)
+    flags = np.zeros((nch, nb), np.uint8)
+    cur = np.ones(nch, bool)
+    for b in range(nb):  # P(long -> long) = 0.9, P(short -> short) = 0.7
+        r = rng.random(nch)
+        cur = np.where(cur, r < 0.9, r >= 0.7)
+        flags[:, b] = cur
+    prev = np.full(nch, -1, np.int32)
+    v = VorbisDsp(ctx, 8, 11)
+    so, po = v.layout(flags, prev)
+    spec_stride, pcm_stride = int(so[:, -1].max()), int(po[:, -1].max())
+    g = torch.Generator(device="cuda").manual_seed(4)
+    spectra = torch.randn((nch, spec_stride), generator=g, device="cuda", dtype=torch.float32) * 0.1
+    d_flags = dev(flags)
+    outs = []
+    for seg in (24, 200):
+        ctx.set_segment(seg)
+        d_prev, d_ov = dev(prev), torch.zeros((nch, 1024), device="cuda")
+        pcm = torch.zeros((nch, pcm_stride), device="cuda")
+        v.synth(spectra, d_flags, d_prev, d_ov, pcm_stride, pcm)
+        outs.append((pcm, d_ov, d_prev))
+    ctx.set_segment(0)
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    pick = [0, 31, 63]
+    want = oracle.vorbis_synth(8, 11, host(spectra[pick]), flags[pick], prev[pick], np.zeros((3, 1024), np.float32), pcm_stride)
+    used = po[pick, -1]
+    got = host(outs[0][0][pick])
+    for i in range(3):
+        assert_parity(got[i, : used[i]], want[0][i, : used[i]], "config-4 sampled chain pcm")
+    assert_parity(host(outs[0][1][pick]), want[1], "config-4 sampled overlap")
+    assert np.array_equal(host(outs[0][2][pick]), want[2])
 
 
 def test_vorbis_helpers_parity(ctx):
