@@ -71,6 +71,7 @@ int symaccel_ctx_set_segment(symaccel_ctx *ctx, int frames_per_segment);
  * complex FFTs of size n (power of two, 2 <= n <= 4096), interleaved (re, im) f32.
  * d_in == d_out is allowed (fft_inplace). */
 int symaccel_fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count);
+int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count);
 
 /* Imdct::new_scaled(n, scale).imdct(spec, out) (symphonia-core/src/dsp/mdct.rs:35-146), `count`
  * times: spec[count][n] -> out[count][2n].  n = power of two, 4 <= n <= 8192. */
@@ -193,6 +194,8 @@ int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac
 int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, int32_t *d_ch0,
                                      int32_t *d_ch1, size_t n_pairs, size_t blocksize,
                                      uint32_t out_shift);
+int symaccel_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *h_mode, int32_t *h_ch0, int32_t *h_ch1,
+                              size_t n_pairs, size_t blocksize, uint32_t out_shift);
 
 /* ------------------------------------------------------------- table read-back (for tests) */
 

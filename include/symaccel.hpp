@@ -1,0 +1,308 @@
+// symaccel.hpp -- C++17 host-side mirror of the reference's DSP interfaces on top of the symaccel C ABI.
+//
+// The reference (pdeljanov/Symphonia 0.6.1) is Rust; this image has no Rust toolchain, so the host side
+// above the C ABI is written in C++ (and, for the tests / bench harness, in Python: symphonia_amd/).  Every
+// type below mirrors one reference item -- same name, same argument meaning, same error behaviour:
+//
+//   dsp::mdct::Imdct           symphonia-core/src/dsp/mdct.rs:16-146
+//   dsp::fft::Fft              symphonia-core/src/dsp/fft/no_simd.rs:70-141
+//   aac::Dsp                   symphonia-codec-aac/src/aac/dsp.rs:22-158
+//   mp3::SynthesisState, mp3::GranuleChannel, mp3::synthesize_granule
+//                              symphonia-bundle-mp3/src/synthesis.rs:145-336, layer3/hybrid_synthesis.rs:153-485,
+//                              the per-channel tail of Layer3::decode (layer3/mod.rs:440-476)
+//   vorbis::Windows / Dsp / DspChannel   symphonia-codec-vorbis/src/dsp.rs:12-145, window.rs:11-39
+//   flac::lpc_predict / fixed_predict / decorrelate_*   symphonia-bundle-flac/src/decoder.rs:32-82, 663-752
+//
+// Error behaviour: what the reference asserts / panics on (slice lengths, non power-of-two sizes) throws
+// std::invalid_argument; what it would return as Error::Unsupported throws Error{Kind::Unsupported}; HIP /
+// device / allocation failures throw Error{Kind::IoError} (symphonia-core/src/errors.rs:38-54).  There is no
+// CPU fallback: constructing a Context without an MI355X throws.
+//
+// The per-packet calls here are batches of one and are latency-bound by design (one launch + PCIe round trip
+// per call); the *_batch members are the path the GPU is for.
+#ifndef SYMACCEL_HPP
+#define SYMACCEL_HPP
+
+#include <array>
+#include <complex>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "symaccel.h"
+
+namespace symphonia_accel {
+
+class Error : public std::runtime_error {
+public:
+    enum class Kind { IoError, Unsupported };  // errors.rs:38-54
+    Error(Kind k, int status, const std::string &what) : std::runtime_error(what), kind(k), status(status) {}
+    Kind kind;
+    int status;
+};
+
+inline void check(int status, const symaccel_ctx *ctx = nullptr) {
+    if (status >= 0) return;
+    std::string msg = symaccel_strerror(status);
+    if (ctx) {
+        const char *extra = symaccel_last_error(ctx);
+        if (extra && *extra) msg += std::string(": ") + extra;
+    }
+    if (status == SYMACCEL_ERR_INVALID_ARG) throw std::invalid_argument(msg);  // the reference's assert!/panic class
+    throw Error(status == SYMACCEL_ERR_UNSUPPORTED ? Error::Kind::Unsupported : Error::Kind::IoError, status, msg);
+}
+
+// One context = one HIP device + stream + device-resident constant tables.  Externally synchronised, like
+// `&mut self` on the reference's decoders; distinct contexts may be used from distinct threads.
+class Context {
+public:
+    explicit Context(int device = 0) { check(symaccel_ctx_create(device, &ctx_)); }
+    ~Context() {
+        if (ctx_) symaccel_ctx_destroy(ctx_);
+    }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    Context(Context &&o) noexcept : ctx_(std::exchange(o.ctx_, nullptr)) {}
+    symaccel_ctx *raw() const { return ctx_; }
+    void sync() { check(symaccel_sync(ctx_), ctx_); }
+    void set_segment(int frames) { check(symaccel_ctx_set_segment(ctx_, frames), ctx_); }
+
+private:
+    symaccel_ctx *ctx_ = nullptr;
+};
+
+namespace dsp {
+namespace mdct {
+
+// Imdct (mdct.rs:16-20): N spectral lines in, 2N samples out.
+class Imdct {
+public:
+    // Imdct::new(n) (mdct.rs:27-29)
+    Imdct(Context &ctx, std::size_t n) : Imdct(ctx, n, 1.0) {}
+    // Imdct::new_scaled(n, scale) (mdct.rs:35-60); panics unless n is a power of two (mdct.rs:37-40)
+    static Imdct new_scaled(Context &ctx, std::size_t n, double scale) { return Imdct(ctx, n, scale); }
+
+    // imdct(&mut self, spec: &[f32], out: &mut [f32]) (mdct.rs:67-146); asserts spec.len() == n, out.len() == 2n
+    void imdct(const float *spec, std::size_t spec_len, float *out, std::size_t out_len) {
+        if (spec_len != n_ || out_len != 2 * n_) throw std::invalid_argument("Imdct::imdct: slice lengths (mdct.rs:76-78)");
+        check(symaccel_imdct_f32(ctx_.raw(), (int)n_, scale_, spec, out, 1), ctx_.raw());
+    }
+    // `count` transforms back to back: spec[count][n] -> out[count][2n]
+    void imdct_batch(const float *spec, float *out, std::size_t count) {
+        check(symaccel_imdct_f32(ctx_.raw(), (int)n_, scale_, spec, out, count), ctx_.raw());
+    }
+
+private:
+    Imdct(Context &ctx, std::size_t n, double scale) : ctx_(ctx), n_(n), scale_(scale) {
+        if (n < 4 || (n & (n - 1)) != 0) throw std::invalid_argument("Imdct: n must be a power of two (mdct.rs:37)");
+        if (n > 8192) throw Error(Error::Kind::Unsupported, SYMACCEL_ERR_UNSUPPORTED, "Imdct: n > 8192");
+    }
+    Context &ctx_;
+    std::size_t n_;
+    double scale_;
+};
+
+}  // namespace mdct
+
+namespace fft {
+
+using Complex = std::complex<float>;  // num_complex::Complex<f32>, same (re, im) layout
+
+// Fft (no_simd.rs:70-141).  The reference's MAX_SIZE is 1 << 16; the device path covers what the decoders use.
+class Fft {
+public:
+    static constexpr std::size_t MAX_SIZE = 4096;
+    Fft(Context &ctx, std::size_t n) : ctx_(ctx), n_(n) {
+        if (n < 2 || (n & (n - 1)) != 0) throw std::invalid_argument("Fft: n must be a power of two (no_simd.rs:77)");
+        if (n > MAX_SIZE) throw Error(Error::Kind::Unsupported, SYMACCEL_ERR_UNSUPPORTED, "Fft: n > 4096");
+    }
+    std::size_t size() const { return n_; }
+    // fft_inplace(&mut self, x: &mut [Complex<f32>]) (no_simd.rs:96-118)
+    void fft_inplace(Complex *x, std::size_t len) {
+        if (len != n_) throw std::invalid_argument("Fft::fft_inplace: slice length (no_simd.rs:97)");
+        check(symaccel_fft_c32(ctx_.raw(), (int)n_, reinterpret_cast<const float *>(x), reinterpret_cast<float *>(x), 1),
+              ctx_.raw());
+    }
+    // fft(&mut self, x: &[Complex<f32>], y: &mut [Complex<f32>]) (no_simd.rs:121-140)
+    void fft(const Complex *x, std::size_t x_len, Complex *y, std::size_t y_len) {
+        if (x_len != n_ || y_len != n_) throw std::invalid_argument("Fft::fft: slice lengths (no_simd.rs:122-123)");
+        check(symaccel_fft_c32(ctx_.raw(), (int)n_, reinterpret_cast<const float *>(x), reinterpret_cast<float *>(y), 1),
+              ctx_.raw());
+    }
+
+private:
+    Context &ctx_;
+    std::size_t n_;
+};
+
+}  // namespace fft
+}  // namespace dsp
+
+namespace aac {
+
+// window sequences (aac/common.rs:17-20)
+constexpr std::uint8_t ONLY_LONG_SEQUENCE = 0, LONG_START_SEQUENCE = 1, EIGHT_SHORT_SEQUENCE = 2, LONG_STOP_SEQUENCE = 3;
+
+// aac::dsp::Dsp (aac/dsp.rs:22-158).  The windows, the two Imdcts and the scratch buffers of the reference's
+// struct live in the context (device tables / LDS).
+class Dsp {
+public:
+    explicit Dsp(Context &ctx) : ctx_(ctx) {}
+    // synth(&mut self, coeffs: &[f32; 1024], delay: &mut [f32; 1024], seq: u8, window_shape: bool,
+    //       prev_window_shape: bool, dst: &mut [f32])  (aac/dsp.rs:57-65)
+    void synth(const std::array<float, 1024> &coeffs, std::array<float, 1024> &delay, std::uint8_t seq, bool window_shape,
+               bool prev_window_shape, float *dst, std::size_t dst_len) {
+        if (dst_len < 1024) throw std::invalid_argument("Dsp::synth: dst shorter than 1024 samples");
+        const std::uint8_t side = SYMACCEL_AAC_SIDE(seq, window_shape ? 1u : 0u, prev_window_shape ? 1u : 0u);
+        check(symaccel_aac_synth(ctx_.raw(), coeffs.data(), &side, delay.data(), dst, 1, 1), ctx_.raw());
+    }
+    // chain-major batch: coeffs[chain][frame][1024], side[chain][frame], delay[chain][1024], pcm[chain][frame][1024]
+    void synth_batch(const float *coeffs, const std::uint8_t *side, float *delay_io, float *pcm, std::size_t n_chains,
+                     std::size_t frames_per_chain) {
+        check(symaccel_aac_synth(ctx_.raw(), coeffs, side, delay_io, pcm, n_chains, frames_per_chain), ctx_.raw());
+    }
+
+private:
+    Context &ctx_;
+};
+
+}  // namespace aac
+
+namespace mp3 {
+
+// BlockType (layer3/common.rs:174-185)
+enum class BlockType : std::uint8_t { Long = 0, Start = 1, Short = 2, End = 3 };
+
+// The GranuleChannel fields the synthesis tail reads (layer3/common.rs:187-230)
+struct GranuleChannel {
+    BlockType block_type = BlockType::Long;
+    bool is_mixed = false;   // BlockType::Short { is_mixed }
+    std::uint16_t rzero = 576;
+};
+
+// SynthesisState (synthesis.rs:145-154) plus the hybrid-synthesis overlap of one channel (layer3/mod.rs:258)
+struct SynthesisState {
+    std::array<float, 32 * 18> overlap{};
+    std::array<float, 16 * 64> v_vec{};
+    std::int32_t v_front = 0;
+};
+
+// One channel of one granule: reorder, antialias, hybrid_synthesis, frequency_inversion (hybrid_synthesis.rs:153-485)
+// and synthesis::synthesis with n_frames = 18 (synthesis.rs:158-336).  samples = post requantize + stereo.
+inline void synthesize_granule(Context &ctx, int sample_rate_idx, const GranuleChannel &gc, const std::array<float, 576> &samples,
+                               SynthesisState &state, float *out, std::size_t out_len) {
+    if (out_len < 576) throw std::invalid_argument("synthesize_granule: out shorter than 576 samples");
+    const symaccel_mp3_side side{(std::uint8_t)gc.block_type, (std::uint8_t)(gc.is_mixed ? 1 : 0), gc.rzero};
+    check(symaccel_mp3_synth(ctx.raw(), samples.data(), &side, sample_rate_idx, state.overlap.data(), state.v_vec.data(),
+                             &state.v_front, out, 1, 1),
+          ctx.raw());
+}
+inline void synthesize_batch(Context &ctx, int sample_rate_idx, const float *xr, const symaccel_mp3_side *side, float *overlap_io,
+                             float *v_vec_io, std::int32_t *v_front_io, float *pcm, std::size_t n_chains,
+                             std::size_t granules_per_chain) {
+    check(symaccel_mp3_synth(ctx.raw(), xr, side, sample_rate_idx, overlap_io, v_vec_io, v_front_io, pcm, n_chains,
+                             granules_per_chain),
+          ctx.raw());
+}
+
+}  // namespace mp3
+
+namespace vorbis {
+
+// Dsp + DspChannel (vorbis/dsp.rs:12-66): block sizes, and per channel the overlap of the previous block.
+class Dsp {
+public:
+    // bs0_exp / bs1_exp from the identification header (vorbis/lib.rs:404-406, 461-470)
+    Dsp(Context &ctx, int bs0_exp, int bs1_exp) : ctx_(ctx), bs0_exp_(bs0_exp), bs1_exp_(bs1_exp) {
+        if (bs0_exp < 6 || bs1_exp > 13 || bs0_exp > bs1_exp) throw std::invalid_argument("vorbis::Dsp: block sizes");
+    }
+    int bs0_exp() const { return bs0_exp_; }
+    int bs1_exp() const { return bs1_exp_; }
+    Context &context() { return ctx_; }
+
+private:
+    Context &ctx_;
+    int bs0_exp_, bs1_exp_;
+};
+
+class DspChannel {
+public:
+    explicit DspChannel(Dsp &dsp) : dsp_(dsp), overlap_((std::size_t)1 << (dsp.bs1_exp() - 1), 0.0f) {}
+    // reset (dsp.rs:128-132)
+    void reset() { overlap_.assign(overlap_.size(), 0.0f); }
+    // synth(&mut self, block_flag, prev_block_flag (lib.rs:298: None pairs the first block with itself), ..., buf)
+    // spectrum = floor x residue, bs/2 values; returns the (prev_n + n) / 4 samples of lib.rs:303 in `out`.
+    std::size_t synth(bool block_flag, std::optional<bool> prev_block_flag, const float *spectrum, float *out, std::size_t out_cap) {
+        const int n = 1 << (block_flag ? dsp_.bs1_exp() : dsp_.bs0_exp());
+        const bool pf = prev_block_flag.value_or(block_flag);
+        const int prev_n = 1 << (pf ? dsp_.bs1_exp() : dsp_.bs0_exp());
+        const std::size_t n_out = (std::size_t)(prev_n + n) / 4;
+        if (out_cap < n_out) throw std::invalid_argument("DspChannel::synth: out too short");
+        std::uint8_t flag = block_flag ? 1 : 0;
+        std::int32_t pflag = prev_block_flag ? (*prev_block_flag ? 1 : 0) : -1;
+        check(symaccel_vorbis_synth(dsp_.context().raw(), dsp_.bs0_exp(), dsp_.bs1_exp(), spectrum, (std::size_t)n / 2, &flag,
+                                    &pflag, overlap_.data(), out, n_out, 1, 1),
+              dsp_.context().raw());
+        return n_out;
+    }
+    const std::vector<float> &overlap() const { return overlap_; }
+
+private:
+    Dsp &dsp_;
+    std::vector<float> overlap_;
+};
+
+}  // namespace vorbis
+
+namespace flac {
+
+// lpc_predict::<N>(order, coeffs, coeff_shift, buf) via the dispatch of decode_linear (decoder.rs:487-504, 716-752):
+// coeffs in bitstream order (the first multiplies the most recent sample); buf = warm-up samples then residuals.
+inline void lpc_predict(Context &ctx, std::size_t order, const std::int32_t *coeffs, std::uint32_t coeff_shift, std::int32_t *buf,
+                        std::size_t len) {
+    if (order < 1 || order > 32 || order > len) throw std::invalid_argument("lpc_predict: order (decoder.rs:456-461)");
+    if (coeff_shift > 31) throw Error(Error::Kind::Unsupported, SYMACCEL_ERR_UNSUPPORTED, "lpc_predict: shift");
+    std::int32_t c[32] = {0};
+    for (std::size_t j = 0; j < order; ++j) c[j] = coeffs[j];
+    const symaccel_flac_desc d{SYMACCEL_FLAC_LPC, (std::uint8_t)order, (std::uint8_t)coeff_shift, 0};
+    check(symaccel_flac_restore(ctx.raw(), buf, &d, c, 1, len), ctx.raw());
+}
+// fixed_predict(order, buf) (decoder.rs:663-710)
+inline void fixed_predict(Context &ctx, std::size_t order, std::int32_t *buf, std::size_t len) {
+    if (order > 4) throw std::invalid_argument("fixed_predict: order > 4 (decoder.rs:664)");
+    std::int32_t c[32] = {0};
+    const symaccel_flac_desc d{SYMACCEL_FLAC_FIXED, (std::uint8_t)order, 0, 0};
+    check(symaccel_flac_restore(ctx.raw(), buf, &d, c, 1, len), ctx.raw());
+}
+inline void restore_batch(Context &ctx, std::int32_t *buf, const symaccel_flac_desc *desc, const std::int32_t *coeffs,
+                          std::size_t n_blocks, std::size_t blocksize) {
+    check(symaccel_flac_restore(ctx.raw(), buf, desc, coeffs, n_blocks, blocksize), ctx.raw());
+}
+namespace detail {
+inline void decorrelate(Context &ctx, std::uint8_t mode, std::int32_t *ch0, std::int32_t *ch1, std::size_t len) {
+    check(symaccel_flac_decorrelate(ctx.raw(), &mode, ch0, ch1, 1, len, 0), ctx.raw());
+}
+}  // namespace detail
+// decorrelate_left_side(left, side): side = left - side (decoder.rs:32-41)
+inline void decorrelate_left_side(Context &ctx, const std::int32_t *left, std::int32_t *side, std::size_t len) {
+    std::vector<std::int32_t> l(left, left + len);
+    detail::decorrelate(ctx, 1, l.data(), side, len);
+}
+// decorrelate_mid_side(mid, side) in place (decoder.rs:43-70)
+inline void decorrelate_mid_side(Context &ctx, std::int32_t *mid, std::int32_t *side, std::size_t len) {
+    detail::decorrelate(ctx, 2, mid, side, len);
+}
+// decorrelate_right_side(right, side): side += right (decoder.rs:72-82)
+inline void decorrelate_right_side(Context &ctx, const std::int32_t *right, std::int32_t *side, std::size_t len) {
+    std::vector<std::int32_t> r(right, right + len);
+    detail::decorrelate(ctx, 3, side, r.data(), len);
+}
+
+}  // namespace flac
+
+}  // namespace symphonia_accel
+
+#endif  // SYMACCEL_HPP

@@ -24,12 +24,12 @@ TABLE_MP3_SYNTH_D, TABLE_MP3_IMDCT_WIN, TABLE_VORBIS_FLOOR1_DB = 4, 5, 6
 ABI_SYMBOLS = [
     "symaccel_abi_version", "symaccel_strerror", "symaccel_last_error", "symaccel_ctx_create",
     "symaccel_ctx_destroy", "symaccel_ctx_set_stream", "symaccel_sync", "symaccel_ctx_set_segment",
-    "symaccel_fft_c32_device", "symaccel_imdct_f32_device", "symaccel_imdct_f32",
+    "symaccel_fft_c32_device", "symaccel_fft_c32", "symaccel_imdct_f32_device", "symaccel_imdct_f32",
     "symaccel_aac_synth_device", "symaccel_aac_synth", "symaccel_mp3_synth_device", "symaccel_mp3_synth",
     "symaccel_vorbis_synth_device", "symaccel_vorbis_synth", "symaccel_vorbis_inverse_coupling_device",
     "symaccel_vorbis_dot_product_device", "symaccel_vorbis_deinterleave2_device",
     "symaccel_vorbis_floor1_device", "symaccel_flac_restore_device", "symaccel_flac_restore",
-    "symaccel_flac_decorrelate_device", "symaccel_table_f32", "symaccel_imdct_twiddles",
+    "symaccel_flac_decorrelate_device", "symaccel_flac_decorrelate", "symaccel_table_f32", "symaccel_imdct_twiddles",
     "symaccel_fft_twiddles",
 ]
 
@@ -63,6 +63,8 @@ class Library:
         d.symaccel_sync.argtypes = [_vp]
         d.symaccel_ctx_set_segment.argtypes = [_vp, _i]
         d.symaccel_fft_c32_device.argtypes = [_vp, _i, _vp, _vp, _sz]
+        d.symaccel_fft_c32.argtypes = [_vp, _i, _vp, _vp, _sz]
+        d.symaccel_flac_decorrelate.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz, _u32]
         d.symaccel_imdct_f32_device.argtypes = [_vp, _i, _d, _vp, _vp, _sz]
         d.symaccel_imdct_f32.argtypes = [_vp, _i, _d, _vp, _vp, _sz]
         d.symaccel_aac_synth_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]

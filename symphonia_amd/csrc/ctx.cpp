@@ -315,6 +315,19 @@ int symaccel_imdct_f32_device(symaccel_ctx *ctx, int n, double scale, const floa
     return launch_imdct(ctx, *plan, d_spec, d_out, count);
 }
 
+int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count) {
+    if (!ctx || !pow2(n) || n < 2 || n > 4096) return SYMACCEL_ERR_INVALID_ARG;
+    if (count == 0) return SYMACCEL_OK;
+    if (!h_in || !h_out) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DevBuf buf(ctx);
+    const size_t bytes = count * (size_t)n * 8;
+    SYM_TRY(buf.from_host(h_in, bytes));
+    SYM_TRY(launch_fft(ctx, n, (const float *)buf.p, (float *)buf.p, count));
+    SYM_TRY(buf.to_host(h_out, bytes));
+    return symaccel_sync(ctx);
+}
+
 int symaccel_imdct_f32(symaccel_ctx *ctx, int n, double scale, const float *h_spec, float *h_out, size_t count) {
     if (!ctx || !pow2(n) || n < 4 || n > 8192) return SYMACCEL_ERR_INVALID_ARG;
     if (count == 0) return SYMACCEL_OK;
@@ -556,6 +569,24 @@ int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac
     SYM_TRY(symaccel_flac_restore_device(ctx, (int32_t *)buf.p, (const symaccel_flac_desc *)desc.p,
                                          (const int32_t *)co.p, n_blocks, blocksize));
     SYM_TRY(buf.to_host(h_buf, n_blocks * blocksize * 4));
+    return symaccel_sync(ctx);
+}
+
+int symaccel_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *h_mode, int32_t *h_ch0, int32_t *h_ch1, size_t n_pairs,
+                              size_t blocksize, uint32_t out_shift) {
+    if (!ctx || out_shift > 31) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!h_mode || !h_ch0 || !h_ch1) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DevBuf mode(ctx), c0(ctx), c1(ctx);
+    const size_t bytes = n_pairs * blocksize * 4;
+    SYM_TRY(mode.from_host(h_mode, n_pairs));
+    SYM_TRY(c0.from_host(h_ch0, bytes));
+    SYM_TRY(c1.from_host(h_ch1, bytes));
+    SYM_TRY(launch_flac_decorrelate(ctx, (const uint8_t *)mode.p, (int32_t *)c0.p, (int32_t *)c1.p, n_pairs, blocksize,
+                                    out_shift));
+    SYM_TRY(c0.to_host(h_ch0, bytes));
+    SYM_TRY(c1.to_host(h_ch1, bytes));
     return symaccel_sync(ctx);
 }
 
