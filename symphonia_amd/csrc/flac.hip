@@ -6,14 +6,15 @@
 //
 // MI355X mapping (DESIGN.md "flac_restore"): the recurrence is serial inside a subframe and
 // independent across subframes, so one LANE owns one subframe.  A wavefront walks its 64 subframes
-// in tiles of 64 samples: the tile is fetched with 256-byte coalesced row segments into LDS
-// (row stride 65 -> conflict-free column access), every lane then runs its own recurrence over its
-// row with the last 32 samples held in registers (circular, statically indexed by unrolling 32
-// steps), and the tile is written back coalesced.  All orders use one formula
-//   pred_i = sum_{j < order} c_j * s[i-1-j]   (i64),   s[i] += (i32)(pred_i >> shift)
+// in tiles of 32 samples staged through LDS (16-byte global accesses, eight 128-byte row segments per
+// instruction; rows of 36 words so every lane reads its own row with conflict-free b128); the next tile's
+// loads are in flight while the recurrence runs over the current one; the last 32 samples stay in registers
+// (circular, statically indexed by unrolling 32 steps).  All orders use one formula
+//   pred_i = sum_{j < order} c_j * s[i-1-j]   (exact 64-bit),   s[i] += (i32)(pred_i >> shift)
 // which equals the reference's prefill + main loop (its padded taps are zero) and, with the
-// binomial coefficients and shift 0, its fixed predictors.
-// Bound: integer ALU / dependent-chain latency (32 i32xi32->i64 MACs per 8 B), NOT HBM.
+// binomial coefficients and shift 0, its fixed predictors.  The sum runs on the FP64 FMA pipe when every
+// coefficient of the wavefront is below 2^16 in magnitude (exact, see lpc_steps32_f64), else on v_mad_i64_i32.
+// Bound: FP64 FMA issue (32 FMAs per 8 B), NOT HBM.
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -26,60 +27,65 @@ namespace symaccel {
 
 namespace {
 
-constexpr int kTile = 64;
-constexpr int kStride = kTile + 4;  // 68: rows stay 16-byte aligned; one-row-per-lane b128 access is conflict-free
+constexpr int kRows = 64;           // subframes per wavefront (one per lane)
+constexpr int kCols = 32;           // samples per tile
+constexpr int kStride = kCols + 4;  // 36 words: rows stay 16-byte aligned; one-row-per-lane b128 access is conflict-free
+constexpr int kTileWords = kRows * kStride;
 
-// Tile I/O.  Fast path (full 64 x 64 tile, 16-byte aligned rows): every lane moves int4, a wavefront
-// instruction covers four 256-byte row segments, and all loads of a batch are in flight together.
-__device__ __forceinline__ void tile_fetch(const int32_t *__restrict__ buf, int32_t *tile, size_t blk0, size_t n_blocks,
-                                           unsigned blocksize, unsigned t0, unsigned cols, int lane, bool fast) {
-    if (fast) {
-        const int q = lane & 15, rsub = lane >> 4;
+// Tile I/O.  A tile is 64 subframes x 32 samples.  Fast path (full tile, 16-byte aligned rows): every lane moves
+// int4, one wavefront instruction covers eight 128-byte row segments; the loads of tile k+1 are issued BEFORE the
+// recurrence runs over tile k and land in registers while it computes (the recurrence alone keeps the FP64 pipe at
+// ~90 %; un-overlapped tile traffic cost another 40 % of wall time).  Two LDS tiles alternate.
+struct TilePrefetch {
+    int4 v[8];
+};
+__device__ __forceinline__ void tile_issue_loads(const int32_t *__restrict__ buf, TilePrefetch &p, size_t blk0,
+                                                 unsigned blocksize, unsigned t0, int lane) {
+    const int q = lane & 7, rsub = lane >> 3;
 #pragma unroll
-        for (int it0 = 0; it0 < 16; it0 += 8) {
-            int4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = 4 * (it0 + k) + rsub;
-                v[k] = *reinterpret_cast<const int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = 4 * (it0 + k) + rsub;
-                *reinterpret_cast<int4 *>(tile + r * kStride + 4 * q) = v[k];
-            }
-        }
-    } else {
-#pragma unroll 1
-        for (int r0 = 0; r0 < kTile; r0 += 16) {
-            int32_t v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const size_t b = blk0 + (size_t)(r0 + k);
-                v[k] = (b < n_blocks && (unsigned)lane < cols) ? buf[b * blocksize + t0 + (unsigned)lane] : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tile[(r0 + k) * kStride + lane] = v[k];
-        }
+    for (int k = 0; k < 8; ++k) {
+        const int r = 8 * k + rsub;
+        p.v[k] = *reinterpret_cast<const int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q);
     }
 }
-
-__device__ __forceinline__ void tile_store(int32_t *__restrict__ buf, const int32_t *tile, size_t blk0, size_t n_blocks,
-                                           unsigned blocksize, unsigned t0, unsigned cols, int lane, bool fast) {
-    if (fast) {
-        const int q = lane & 15, rsub = lane >> 4;
+__device__ __forceinline__ void tile_commit(const TilePrefetch &p, int32_t *tile, int lane) {
+    const int q = lane & 7, rsub = lane >> 3;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int r = 4 * it + rsub;
-            *reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q) =
-                *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q);
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<int4 *>(tile + (8 * k + rsub) * kStride + 4 * q) = p.v[k];
+}
+__device__ __forceinline__ void tile_store_fast(int32_t *__restrict__ buf, const int32_t *tile, size_t blk0,
+                                                unsigned blocksize, unsigned t0, int lane) {
+    const int q = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = 8 * k + rsub;
+        *reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q) =
+            *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q);
+    }
+}
+// Ragged tiles (last columns of a block size that is not a multiple of 32, unaligned rows, last subframes).
+__device__ __forceinline__ void tile_fetch_slow(const int32_t *__restrict__ buf, int32_t *tile, size_t blk0, size_t n_blocks,
+                                                unsigned blocksize, unsigned t0, unsigned cols, int lane) {
+    const int c = lane & 31, rsub = lane >> 5;
+#pragma unroll 1
+    for (int r0 = 0; r0 < kRows; r0 += 16) {
+        int32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t b = blk0 + (size_t)(r0 + 2 * k + rsub);
+            v[k] = (b < n_blocks && (unsigned)c < cols) ? buf[b * blocksize + t0 + (unsigned)c] : 0;
         }
-    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[(r0 + 2 * k + rsub) * kStride + c] = v[k];
+    }
+}
+__device__ __forceinline__ void tile_store_slow(int32_t *__restrict__ buf, const int32_t *tile, size_t blk0, size_t n_blocks,
+                                                unsigned blocksize, unsigned t0, unsigned cols, int lane) {
+    const int c = lane & 31, rsub = lane >> 5;
 #pragma unroll 4
-        for (int r = 0; r < kTile; ++r) {
-            if (blk0 + (size_t)r < n_blocks && (unsigned)lane < cols)
-                buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)lane] = tile[r * kStride + lane];
-        }
+    for (int r = rsub; r < kRows; r += 2) {
+        if (blk0 + (size_t)r < n_blocks && (unsigned)c < cols)
+            buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)c] = tile[r * kStride + c];
     }
 }
 
@@ -219,9 +225,9 @@ __device__ __forceinline__ void load_params(LaneParams &p, const symaccel_flac_d
 template <bool F64>
 __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc,
                                                   const int32_t *__restrict__ coeffs, size_t n_blocks,
-                                                  unsigned blocksize, int32_t *tile) {
+                                                  unsigned blocksize, int32_t *tiles) {
     const int lane = (int)threadIdx.x;
-    const size_t blk0 = (size_t)blockIdx.x * kTile;
+    const size_t blk0 = (size_t)blockIdx.x * kRows;
     const size_t my = blk0 + (size_t)lane;
     const bool have = my < n_blocks;
     LaneParams p;
@@ -235,53 +241,64 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
         c[j] = (T)p.c[j];
         h[j] = (T)0;
     }
-    for (unsigned t0 = 0; t0 < blocksize; t0 += kTile) {
-        const unsigned cols = min((unsigned)kTile, blocksize - t0);
-        const bool fast = cols == (unsigned)kTile && (blocksize & 3u) == 0 && blk0 + kTile <= n_blocks;
-        tile_fetch(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane, fast);
+    const bool aligned = (blocksize & 3u) == 0 && blk0 + kRows <= n_blocks;
+    const unsigned n_tiles = (blocksize + kCols - 1) / kCols;
+    TilePrefetch pre;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pre.v[k] = make_int4(0, 0, 0, 0);
+    if (aligned && blocksize >= (unsigned)kCols) tile_issue_loads(buf, pre, blk0, blocksize, 0, lane);
+    for (unsigned t = 0; t < n_tiles; ++t) {
+        const unsigned t0 = t * kCols;
+        const unsigned cols = min((unsigned)kCols, blocksize - t0);
+        const bool fast = aligned && cols == (unsigned)kCols;
+        int32_t *tile = tiles + (t & 1u) * kTileWords;
+        if (fast)
+            tile_commit(pre, tile, lane);
+        else
+            tile_fetch_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
         __syncthreads();
+        if (aligned && t0 + 2u * kCols <= blocksize)  // the next tile is a full one: fetch it while this one computes
+            tile_issue_loads(buf, pre, blk0, blocksize, t0 + kCols, lane);
         if (have) {
             int32_t *row = tile + lane * kStride;
-            for (int half = 0; half < 2; ++half) {
-                const int col0 = 32 * half;
-                const int n_valid = (int)cols - col0;
-                const int first_pred = (int)p.order - (int)t0;  // column index of the first predicted sample
-                if (n_valid <= 0) break;
-                if constexpr (F64) {
-                    if (p.max_order <= 4)
-                        lpc_steps32_f64<4>(h, c, row, col0, first_pred, n_valid, (int)p.shift, p.wasted);
-                    else if (p.max_order <= 12)
-                        lpc_steps32_f64<12>(h, c, row, col0, first_pred, n_valid, (int)p.shift, p.wasted);
-                    else
-                        lpc_steps32_f64<32>(h, c, row, col0, first_pred, n_valid, (int)p.shift, p.wasted);
-                } else {
-                    if (p.max_order <= 4)
-                        lpc_steps32<4>(h, c, row, col0, first_pred, n_valid, p.shift, p.wasted);
-                    else if (p.max_order <= 12)
-                        lpc_steps32<12>(h, c, row, col0, first_pred, n_valid, p.shift, p.wasted);
-                    else
-                        lpc_steps32<32>(h, c, row, col0, first_pred, n_valid, p.shift, p.wasted);
-                }
+            const int first_pred = (int)p.order - (int)t0;  // column index of the first predicted sample
+            if constexpr (F64) {
+                if (p.max_order <= 4)
+                    lpc_steps32_f64<4>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
+                else if (p.max_order <= 12)
+                    lpc_steps32_f64<12>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
+                else
+                    lpc_steps32_f64<32>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
+            } else {
+                if (p.max_order <= 4)
+                    lpc_steps32<4>(h, c, row, 0, first_pred, (int)cols, p.shift, p.wasted);
+                else if (p.max_order <= 12)
+                    lpc_steps32<12>(h, c, row, 0, first_pred, (int)cols, p.shift, p.wasted);
+                else
+                    lpc_steps32<32>(h, c, row, 0, first_pred, (int)cols, p.shift, p.wasted);
             }
         }
         __syncthreads();
-        tile_store(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane, fast);
-        __syncthreads();
+        if (fast)
+            tile_store_fast(buf, tile, blk0, blocksize, t0, lane);
+        else
+            tile_store_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+        // no barrier here: the next round writes the OTHER LDS tile, and its barrier orders these reads
     }
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void flac_restore_f64_kernel(
     int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
     size_t n_blocks, unsigned blocksize) {
-    __shared__ __attribute__((aligned(16))) int32_t tile[kTile * kStride];
-    flac_restore_body<true>(buf, desc, coeffs, n_blocks, blocksize, tile);
+    __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
+    flac_restore_body<true>(buf, desc, coeffs, n_blocks, blocksize, tiles);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void flac_restore_i64_kernel(
     int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
     size_t n_blocks, unsigned blocksize) {
-    __shared__ __attribute__((aligned(16))) int32_t tile[kTile * kStride];
-    flac_restore_body<false>(buf, desc, coeffs, n_blocks, blocksize, tile);
+    __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
+    flac_restore_body<false>(buf, desc, coeffs, n_blocks, blocksize, tiles);
 }
 
 // decoder.rs:32-82 + :239-242
@@ -311,7 +328,7 @@ __global__ void flac_decorrelate_kernel(const uint8_t *__restrict__ mode, int32_
 
 int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc, const int32_t *d_coeffs,
                         size_t n_blocks, size_t blocksize) {
-    const size_t grid = (n_blocks + kTile - 1) / kTile;
+    const size_t grid = (n_blocks + kRows - 1) / kRows;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(flac_restore_f64_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
                        d_coeffs, n_blocks, (unsigned)blocksize);
