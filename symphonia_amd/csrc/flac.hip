@@ -89,6 +89,14 @@ __device__ __forceinline__ void tile_store_slow(int32_t *__restrict__ buf, const
     }
 }
 
+// The workgroup is one wavefront: order its LDS traffic with wavefront-scope fences only.  (__syncthreads() carries a
+// workgroup-scope release, which makes the wavefront wait for its outstanding GLOBAL stores at every tile.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int32_t wrap_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 
 __device__ __forceinline__ unsigned wave_max(unsigned v) {
@@ -256,7 +264,7 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
             tile_commit(pre, tile, lane);
         else
             tile_fetch_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
-        __syncthreads();
+        wave_sync();
         if (aligned && t0 + 2u * kCols <= blocksize)  // the next tile is a full one: fetch it while this one computes
             tile_issue_loads(buf, pre, blk0, blocksize, t0 + kCols, lane);
         if (have) {
@@ -278,7 +286,7 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
                     lpc_steps32<32>(h, c, row, 0, first_pred, (int)cols, p.shift, p.wasted);
             }
         }
-        __syncthreads();
+        wave_sync();
         if (fast)
             tile_store_fast(buf, tile, blk0, blocksize, t0, lane);
         else
