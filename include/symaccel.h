@@ -206,7 +206,8 @@ enum symaccel_table {
     SYMACCEL_TABLE_AAC_SINE_SHORT = 3, /* 128 */
     SYMACCEL_TABLE_MP3_SYNTH_D = 4,    /* 512, synthesis.rs:13-142 */
     SYMACCEL_TABLE_MP3_IMDCT_WIN = 5,  /* 4*36, hybrid_synthesis.rs:53-92 */
-    SYMACCEL_TABLE_VORBIS_FLOOR1_DB = 6 /* 256, vorbis floor.rs:21-112 */
+    SYMACCEL_TABLE_VORBIS_FLOOR1_DB = 6, /* 256, vorbis floor.rs:21-112 */
+    SYMACCEL_TABLE_MP3_CONSTS = 7       /* 264: the hybrid-synthesis / dct32 constants in the kernels' packed order */
 };
 /* Copies the HOST copy of a constant table; returns the number of floats, or a negative status. */
 int symaccel_table_f32(const symaccel_ctx *ctx, int table, float *dst, size_t capacity);

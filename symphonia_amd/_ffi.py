@@ -18,7 +18,7 @@ ERR_DEVICE = -3
 ERR_OOM = -4
 
 TABLE_AAC_KBD_LONG, TABLE_AAC_KBD_SHORT, TABLE_AAC_SINE_LONG, TABLE_AAC_SINE_SHORT = 0, 1, 2, 3
-TABLE_MP3_SYNTH_D, TABLE_MP3_IMDCT_WIN, TABLE_VORBIS_FLOOR1_DB = 4, 5, 6
+TABLE_MP3_SYNTH_D, TABLE_MP3_IMDCT_WIN, TABLE_VORBIS_FLOOR1_DB, TABLE_MP3_CONSTS = 4, 5, 6, 7
 
 # every symbol include/symaccel.h declares (tests/test_abi.py checks the built library exports all)
 ABI_SYMBOLS = [

@@ -153,6 +153,25 @@ void build_reorder_tables(const HostTables &t, std::vector<int32_t> &map, std::v
     }
 }
 
+// DevTables::mp3_consts layout (Mp3ConstLayout) from the host tables.
+static std::vector<float> pack_mp3_consts(const HostTables &t) {
+    std::vector<float> mc(MP3C_TOTAL, 0.0f);
+    std::memcpy(&mc[MP3C_IMDCT_WIN], t.mp3_imdct_win, 144 * 4);
+    std::memcpy(&mc[MP3C_COS12], t.mp3_cos12, 36 * 4);
+    std::memcpy(&mc[MP3C_CS], t.mp3_cs, 8 * 4);
+    std::memcpy(&mc[MP3C_CA], t.mp3_ca, 8 * 4);
+    std::memcpy(&mc[MP3C_DCT_IV], t.mp3_dct_iv_scale, 18 * 4);
+    std::memcpy(&mc[MP3C_SDCT18], t.mp3_sdct18_scale, 9 * 4);
+    std::memcpy(&mc[MP3C_SDCT9_D], t.mp3_sdct9_d, 7 * 4);
+    std::memcpy(&mc[MP3C_COS16], t.mp3_cos16, 16 * 4);
+    std::memcpy(&mc[MP3C_COS8], t.mp3_cos8, 8 * 4);
+    std::memcpy(&mc[MP3C_COS4], t.mp3_cos4, 4 * 4);
+    std::memcpy(&mc[MP3C_COS2], t.mp3_cos2, 2 * 4);
+    mc[MP3C_COS1] = t.mp3_cos1;
+    std::memcpy(&mc[MP3C_SYNTH_D], t.mp3_synth_d, 512 * 4);
+    return mc;
+}
+
 int upload_tables(symaccel_ctx *ctx) {
     const HostTables &t = host_tables();
     DevTables &d = ctx->dev;
@@ -171,20 +190,7 @@ int upload_tables(symaccel_ctx *ctx) {
     UP(small32, t.small32, sizeof t.small32);
     UP(small16_form, t.small16_form, sizeof t.small16_form);
     UP(small32_form, t.small32_form, sizeof t.small32_form);
-    std::vector<float> mc(MP3C_TOTAL, 0.0f);
-    std::memcpy(&mc[MP3C_IMDCT_WIN], t.mp3_imdct_win, 144 * 4);
-    std::memcpy(&mc[MP3C_COS12], t.mp3_cos12, 36 * 4);
-    std::memcpy(&mc[MP3C_CS], t.mp3_cs, 8 * 4);
-    std::memcpy(&mc[MP3C_CA], t.mp3_ca, 8 * 4);
-    std::memcpy(&mc[MP3C_DCT_IV], t.mp3_dct_iv_scale, 18 * 4);
-    std::memcpy(&mc[MP3C_SDCT18], t.mp3_sdct18_scale, 9 * 4);
-    std::memcpy(&mc[MP3C_SDCT9_D], t.mp3_sdct9_d, 7 * 4);
-    std::memcpy(&mc[MP3C_COS16], t.mp3_cos16, 16 * 4);
-    std::memcpy(&mc[MP3C_COS8], t.mp3_cos8, 8 * 4);
-    std::memcpy(&mc[MP3C_COS4], t.mp3_cos4, 4 * 4);
-    std::memcpy(&mc[MP3C_COS2], t.mp3_cos2, 2 * 4);
-    mc[MP3C_COS1] = t.mp3_cos1;
-    std::memcpy(&mc[MP3C_SYNTH_D], t.mp3_synth_d, 512 * 4);
+    std::vector<float> mc = pack_mp3_consts(t);
     UP(mp3_consts, mc.data(), mc.size() * 4);
     std::vector<int32_t> rmap, rend;
     build_reorder_tables(t, rmap, rend);
@@ -613,6 +619,12 @@ int symaccel_table_f32(const symaccel_ctx *, int table, float *dst, size_t capac
         case SYMACCEL_TABLE_MP3_SYNTH_D: src = t.mp3_synth_d; n = 512; break;
         case SYMACCEL_TABLE_MP3_IMDCT_WIN: src = &t.mp3_imdct_win[0][0]; n = 144; break;
         case SYMACCEL_TABLE_VORBIS_FLOOR1_DB: src = t.vorbis_floor1_db; n = 256; break;
+        case SYMACCEL_TABLE_MP3_CONSTS: {
+            static const std::vector<float> mc = pack_mp3_consts(t);
+            src = mc.data();
+            n = MP3C_SYNTH_D;
+            break;
+        }
         default: return SYMACCEL_ERR_INVALID_ARG;
     }
     if (!dst || capacity < n) return SYMACCEL_ERR_INVALID_ARG;

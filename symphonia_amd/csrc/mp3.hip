@@ -21,6 +21,7 @@
 // measured and is not faster.  LDS per wavefront: granule tiles 4.5 KiB + dct32 transpose 5 KiB + window rows 2.5 KiB.
 // Roofline: HBM-bound on paper, 2304 B in + 2304 B out per granule-channel, ~34 kflop (no FMA) -> 7.4 flop/B.
 #include "dsp_device.h"
+#include "mp3_literals.h"
 
 namespace symaccel {
 
@@ -46,7 +47,8 @@ __device__ __forceinline__ void wave_sync() {
 // ---- 36-point IMDCT (Szu-Wei Lee), hybrid_synthesis.rs:559-779 -------------------------------
 
 // sdct_ii_9 (hybrid_synthesis.rs:720-779); writes y[0], y[2], ..., y[16]
-__device__ __forceinline__ void sdct_ii_9(const float (&x)[9], float *y, cf32p D) {
+__device__ __forceinline__ void sdct_ii_9(const float (&x)[9], float *y) {
+    constexpr const float *D = kMp3Lit + MP3C_SDCT9_D;  // compile-time literals (mp3_literals.h)
     const float a01 = x[3] + x[5], a02 = x[3] - x[5], a03 = x[6] + x[2], a04 = x[6] - x[2];
     const float a05 = x[1] + x[7], a06 = x[1] - x[7], a07 = x[8] + x[0], a08 = x[8] - x[0];
     const float a09 = x[4] + a05, a10 = a01 + a03, a11 = a10 + a07, a12 = a03 - a07;
@@ -68,17 +70,18 @@ __device__ __forceinline__ void sdct_ii_9(const float (&x)[9], float *y, cf32p D
 }
 
 // dct_iv (hybrid_synthesis.rs:608-660) incl. sdct_ii_18 (:665-716)
-__device__ __forceinline__ void dct_iv_18(const float (&x)[18], float (&y)[19], cf32p mc) {
+__device__ __forceinline__ void dct_iv_18(const float (&x)[18], float (&y)[19]) {
+    constexpr const float *mc = kMp3Lit;
     float s[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) s[i] = mc[MP3C_DCT_IV + i] * x[i];
     float even[9], odd[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) even[i] = s[i] + s[17 - i];
-    sdct_ii_9(even, &y[0], mc + MP3C_SDCT9_D);
+    sdct_ii_9(even, &y[0]);
 #pragma unroll
     for (int i = 0; i < 9; ++i) odd[i] = mc[MP3C_SDCT18 + i] * (s[i] - s[17 - i]);
-    sdct_ii_9(odd, &y[1], mc + MP3C_SDCT9_D);
+    sdct_ii_9(odd, &y[1]);
 #pragma unroll
     for (int i = 3; i <= 17; i += 2) y[i] -= y[i - 2];
     y[0] /= 2.0f;
@@ -87,9 +90,9 @@ __device__ __forceinline__ void dct_iv_18(const float (&x)[18], float (&y)[19], 
 }
 
 // imdct36 (hybrid_synthesis.rs:571-603): x[18] in place, overlap[18] in/out
-__device__ __forceinline__ void imdct36(float (&x)[18], float (&overlap)[18], cf32p window, cf32p mc) {
+__device__ __forceinline__ void imdct36(float (&x)[18], float (&overlap)[18], cf32p window) {
     float dct[19];
-    dct_iv_18(x, dct, mc);
+    dct_iv_18(x, dct);
 #pragma unroll
     for (int i = 0; i < 9; ++i) x[i] = overlap[i] + dct[9 + i] * window[i];
 #pragma unroll
@@ -101,8 +104,8 @@ __device__ __forceinline__ void imdct36(float (&x)[18], float (&overlap)[18], cf
 }
 
 // imdct12_win (hybrid_synthesis.rs:363-455)
-__device__ __forceinline__ void imdct12_win(float (&x)[18], float (&overlap)[18], cf32p window, cf32p mc) {
-    cf32p cos12 = mc + MP3C_COS12;
+__device__ __forceinline__ void imdct12_win(float (&x)[18], float (&overlap)[18], cf32p window) {
+    constexpr const float *cos12 = kMp3Lit + MP3C_COS12;
     float tmp[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) tmp[i] = 0.0f;
@@ -110,7 +113,7 @@ __device__ __forceinline__ void imdct12_win(float (&x)[18], float (&overlap)[18]
     for (int w = 0; w < 3; ++w) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            cf32p cl = cos12 + 6 * i, cr = cos12 + 6 * (i + 3);
+            const float *cl = cos12 + 6 * i, *cr = cos12 + 6 * (i + 3);
             const float yl = (x[w] * cl[0]) + (x[3 + w] * cl[1]) + (x[6 + w] * cl[2]) + (x[9 + w] * cl[3]) +
                              (x[12 + w] * cl[4]) + (x[15 + w] * cl[5]);
             const float yr = (x[w] * cr[0]) + (x[3 + w] * cr[1]) + (x[6 + w] * cr[2]) + (x[9 + w] * cr[3]) +
@@ -130,7 +133,8 @@ __device__ __forceinline__ void imdct12_win(float (&x)[18], float (&overlap)[18]
 
 // ---- dct32 (B.G. Lee), synthesis.rs:348-844, as the recursion the reference flattens ---------
 template <int N>
-__device__ __forceinline__ void dct_lee(float *x, cf32p mc) {
+__device__ __forceinline__ void dct_lee(float *x) {
+    constexpr const float *mc = kMp3Lit;
     if constexpr (N == 2) {
         const float a = x[0] + x[1], b = (x[0] - x[1]) * mc[MP3C_COS1];
         x[0] = a;
@@ -144,8 +148,8 @@ __device__ __forceinline__ void dct_lee(float *x, cf32p mc) {
             t[i] = x[i] + x[N - 1 - i];
             t[H + i] = (x[i] - x[N - 1 - i]) * mc[cofs + i];
         }
-        dct_lee<H>(t, mc);
-        dct_lee<H>(t + H, mc);
+        dct_lee<H>(t);
+        dct_lee<H>(t + H);
 #pragma unroll
         for (int i = 0; i < H - 1; ++i) {
             x[2 * i] = t[i];
@@ -310,14 +314,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
             }
             const bool below = hl >= 1 && hl < lim;      // boundary hl (with lane hl-1) is active
             const bool above = hl + 1 < lim;             // boundary hl+1 (with lane hl+1) is active
+            // all 16 neighbour exchanges are issued back to back (one wait), then the butterflies
+            float lower_nb[8], upper_nb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                lower_nb[i] = __shfl_up(y[17 - i], 1);   // lane sb-1's lower element
+                upper_nb[i] = __shfl_down(y[i], 1);      // lane sb+1's upper element
+            }
+            __builtin_amdgcn_sched_barrier(0);
             float lo_new[8], up_new[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float cs = mc[MP3C_CS + i], ca = mc[MP3C_CA + i];
-                const float lower_nb = __shfl_up(y[17 - i], 1);   // lane sb-1's lower element
-                const float upper_nb = __shfl_down(y[i], 1);      // lane sb+1's upper element
-                up_new[i] = y[i] * cs + lower_nb * ca;            // upper' = upper * cs + lower * ca
-                lo_new[i] = y[17 - i] * cs - upper_nb * ca;       // lower' = lower * cs - upper * ca
+                constexpr const float *cs_t = kMp3Lit + MP3C_CS, *ca_t = kMp3Lit + MP3C_CA;
+                const float cs = cs_t[i], ca = ca_t[i];
+                up_new[i] = y[i] * cs + lower_nb[i] * ca;       // upper' = upper * cs + lower * ca
+                lo_new[i] = y[17 - i] * cs - upper_nb[i] * ca;  // lower' = lower * cs - upper * ca
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -338,15 +349,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
                 }
             } else if (sb < sb_split) {
                 const int wi = bt == SYMACCEL_MP3_START ? 1 : (bt == SYMACCEL_MP3_END ? 3 : 0);
-                imdct36(y, overlap, mc + MP3C_IMDCT_WIN + 36 * wi, mc);
+                imdct36(y, overlap, mc + MP3C_IMDCT_WIN + 36 * wi);
             } else {
-                imdct12_win(y, overlap, mc + MP3C_IMDCT_WIN + 36 * 2, mc);
+                imdct12_win(y, overlap, mc + MP3C_IMDCT_WIN + 36 * 2);
             }
             // frequency_inversion (hybrid_synthesis.rs:458-485)
             if (sb & 1) {
 #pragma unroll
                 for (int i = 1; i < 18; i += 2) y[i] = -y[i];
             }
+        }
+        if (live && g + 1 < g_stop) {  // prefetch the next granule; it lands during the dct32 and window passes
+            fetch_granule(xr + (chain_base + (size_t)(g + 1)) * 576, hl, line);
+            sd_next = side[chain_base + (size_t)(g + 1)];
         }
         wave_sync();  // the previous granule's window pass has read S
         if (need_hist) {
@@ -366,15 +381,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
                 d[4 * k + 2] = v.z;
                 d[4 * k + 3] = v.w;
             }
-            dct_lee<32>(d, mc);
+            dct_lee<32>(d);
 #pragma unroll
             for (int k = 0; k < 8; ++k) row[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
         }
         wave_sync();
-        if (live && g + 1 < g_stop) {  // prefetch the next granule; it lands during the window pass
-            fetch_granule(xr + (chain_base + (size_t)(g + 1)) * 576, hl, line);
-            sd_next = side[chain_base + (size_t)(g + 1)];
-        }
         // ---- windowing (synthesis.rs:309-324), one time slot at a time: fetch the slot's two V entries for
         // this lane's sample index (synthesis.rs:247-263), then 16 taps with every operand in registers.
         // (Lanes / granules that do not need the history read stale LDS into nA/nB and never use it.)

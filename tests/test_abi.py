@@ -57,6 +57,16 @@ def test_host_tables_match_oracle(lib):
         assert np.array_equal(lib.fft_twiddles(n).view(np.float32), oracle.fft_twiddles(n).view(np.float32))
 
 
+def test_mp3_literal_header_matches_host_table(lib):
+    """csrc/mp3_literals.h (compile-time immediates in mp3_synth_kernel) == the host-generated table, bit for bit."""
+    text = (ROOT / "symphonia_amd" / "csrc" / "mp3_literals.h").read_text()
+    vals = [float.fromhex(m) for m in re.findall(r"(-?0x[0-9a-f.]+p[-+]?\d+)f,", text)]
+    table = lib.table(_ffi.TABLE_MP3_CONSTS)
+    assert len(vals) == 264 == len(table)
+    assert np.array_equal(np.array(vals, dtype=np.float32).view(np.uint32), table.view(np.uint32))
+    assert np.array_equal(table[:144].reshape(4, 36), oracle.mp3_imdct_windows())
+
+
 def test_no_cpu_fallback(lib):
     import torch
     if torch.cuda.is_available():
