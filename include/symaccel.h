@@ -197,6 +197,31 @@ int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, i
 int symaccel_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *h_mode, int32_t *h_ch0, int32_t *h_ch1,
                               size_t n_pairs, size_t blocksize, uint32_t out_shift);
 
+/* --------------------------------------------------------------------------------- ALAC */
+
+/* per element-channel descriptor: the ElementChannel fields predict() reads (symphonia-codec-alac/src/lib.rs:71-80) */
+typedef struct symaccel_alac_desc {
+    uint8_t mode;      /* 0, or 15 (double predictor); 1..14 are invalid (lib.rs:167-169): the block is left as is */
+    uint8_t lpc_order; /* 0..31; 0 = no prediction (lib.rs:173-175) */
+    uint8_t shift;     /* coefficient quantisation shift, 0..15 */
+    uint8_t bps;       /* prediction bit width: outputs are sign-extended from `bps` bits (clip_msbs, lib.rs:659) */
+} symaccel_alac_desc;
+
+/* ElementChannel::predict (lib.rs:165-264) for n_blocks element channels of `blocksize` samples, in place:
+ * buf[block][blocksize] i32 holds the Rice-decoded residuals; coeffs[block][32] as read from the bitstream
+ * (lib.rs:94-98; adapted on a private copy, like the reference's per-packet ElementChannel).
+ * Bit-exact wrapping i32 arithmetic. */
+int symaccel_alac_predict_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc,
+                                 const int32_t *d_coeffs, size_t n_blocks, size_t blocksize);
+int symaccel_alac_predict(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_alac_desc *h_desc,
+                          const int32_t *h_coeffs, size_t n_blocks, size_t blocksize);
+/* decorrelate_mid_side (lib.rs:664-671) over n_pairs channel pairs: weight[pair] (0 = pair left alone, lib.rs:552),
+ * shift[pair] (<= 31, lib.rs:555); ch0/ch1[pair][blocksize]. */
+int symaccel_alac_mid_side_device(symaccel_ctx *ctx, const int32_t *d_weight, const uint8_t *d_shift,
+                                  int32_t *d_ch0, int32_t *d_ch1, size_t n_pairs, size_t blocksize);
+int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uint8_t *h_shift, int32_t *h_ch0,
+                           int32_t *h_ch1, size_t n_pairs, size_t blocksize);
+
 /* ------------------------------------------------------------- table read-back (for tests) */
 
 enum symaccel_table {

@@ -12,6 +12,7 @@
 //                              the per-channel tail of Layer3::decode (layer3/mod.rs:440-476)
 //   vorbis::Windows / Dsp / DspChannel   symphonia-codec-vorbis/src/dsp.rs:12-145, window.rs:11-39
 //   flac::lpc_predict / fixed_predict / decorrelate_*   symphonia-bundle-flac/src/decoder.rs:32-82, 663-752
+//   alac::ElementChannel::predict / decorrelate_mid_side   symphonia-codec-alac/src/lib.rs:165-264, 664-671
 //
 // Error behaviour: what the reference asserts / panics on (slice lengths, non power-of-two sizes) throws
 // std::invalid_argument; what it would return as Error::Unsupported throws Error{Kind::Unsupported}; HIP /
@@ -302,6 +303,34 @@ inline void decorrelate_right_side(Context &ctx, const std::int32_t *right, std:
 }
 
 }  // namespace flac
+
+namespace alac {
+
+// ElementChannel (symphonia-codec-alac/src/lib.rs:71-80): the fields predict() reads.
+struct ElementChannel {
+    std::uint32_t bps = 16, mode = 0, shift = 0, lpc_order = 0;
+    std::array<std::int32_t, 32> lpc_coeffs{};
+
+    // predict(&mut self, out: &mut [i32]) -> Result<()> (lib.rs:165-264); decode_error on an invalid mode
+    void predict(Context &ctx, std::int32_t *out, std::size_t len) const {
+        if (mode > 0 && mode < 15) throw Error(Error::Kind::IoError, SYMACCEL_ERR_INVALID_ARG, "alac: invalid mode");
+        if (lpc_order > 31 || bps == 0 || bps > 32) throw std::invalid_argument("alac::ElementChannel: field range");
+        const symaccel_alac_desc d{(std::uint8_t)mode, (std::uint8_t)lpc_order, (std::uint8_t)shift, (std::uint8_t)bps};
+        check(symaccel_alac_predict(ctx.raw(), out, &d, lpc_coeffs.data(), 1, len), ctx.raw());
+    }
+};
+inline void predict_batch(Context &ctx, std::int32_t *buf, const symaccel_alac_desc *desc, const std::int32_t *coeffs,
+                          std::size_t n_blocks, std::size_t blocksize) {
+    check(symaccel_alac_predict(ctx.raw(), buf, desc, coeffs, n_blocks, blocksize), ctx.raw());
+}
+// decorrelate_mid_side(out0, out1, weight, shift) (lib.rs:664-671)
+inline void decorrelate_mid_side(Context &ctx, std::int32_t *out0, std::int32_t *out1, std::size_t len, std::int32_t weight,
+                                 std::uint8_t shift) {
+    if (shift > 31) throw Error(Error::Kind::IoError, SYMACCEL_ERR_INVALID_ARG, "alac: mid_side_shift is greater than 31 bit");
+    check(symaccel_alac_mid_side(ctx.raw(), &weight, &shift, out0, out1, 1, len), ctx.raw());
+}
+
+}  // namespace alac
 
 }  // namespace symphonia_accel
 

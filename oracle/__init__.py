@@ -361,6 +361,34 @@ def flac_restore(buf, desc, coeffs):
     return b
 
 
+# ---- ALAC ------------------------------------------------------------------
+
+ALAC_DESC_DTYPE = np.dtype([("mode", np.uint8), ("order", np.uint8), ("shift", np.uint8), ("bps", np.uint8)])
+
+
+def alac_desc(mode, order, shift, bps):
+    m = np.asarray(mode)
+    d = np.zeros(m.shape, dtype=ALAC_DESC_DTYPE)
+    d["mode"], d["order"], d["shift"], d["bps"] = m, np.asarray(order), np.asarray(shift), np.asarray(bps)
+    return d
+
+
+def alac_predict(buf, desc, coeffs):
+    """ElementChannel::predict for buf[blocks, blocksize] (copy); desc from alac_desc; coeffs[blocks, 32] i32."""
+    out = np.array(buf, dtype=np.int32, copy=True, order="C")
+    desc = np.ascontiguousarray(desc)
+    co = np.ascontiguousarray(coeffs, dtype=np.int32)
+    lib().so_alac_predict_batch(_p(out), _p(desc), _p(co), C.c_size_t(out.shape[0]), C.c_size_t(out.shape[1]))
+    return out
+
+
+def alac_decorrelate_mid_side(out0, out1, weight, shift):
+    a = np.array(out0, dtype=np.int32, copy=True)
+    b = np.array(out1, dtype=np.int32, copy=True)
+    lib().so_alac_decorrelate_mid_side(_p(a), _p(b), C.c_size_t(a.size), C.c_int32(weight), C.c_uint32(shift))
+    return a, b
+
+
 # ---- timing driver (bench.py cpu_baseline) ------------------------------------
 
 def bench_mt(kind, threads, seconds, in0, in1, in2=None, n_chains=0, per_chain=0, stride_in=0, stride_out=0, p0=0, p1=0):

@@ -1341,3 +1341,78 @@ void so_flac_restore_batch(int32_t *buf, const uint8_t *desc, const int32_t *coe
         so_flac_shl(x, blocksize, d[3]); /* samples_shl(dropped_bps) decoder.rs:396-409 */
     }
 }
+
+/* ========================================================================== */
+/* ALAC (symphonia-codec-alac/src/lib.rs)                                      */
+/* ========================================================================== */
+
+/* clip_msbs (lib.rs:659-661): sign-extend from (32 - num) bits. */
+static inline int32_t alac_clip_msbs(int32_t val, uint32_t num) {
+    return (int32_t)((uint32_t)val << num) >> num;
+}
+static inline int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static inline int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+static inline int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+
+/* ElementChannel::predict (lib.rs:165-264).  coeffs_in[32] as read by try_read (lib.rs:94-98); the sign-LMS
+ * adaptation works on a private copy, as the reference's per-packet ElementChannel does.  Returns 0, or -1 for the
+ * reference's decode_error("alac: invalid mode") (lib.rs:167-169), in which case `out` is left untouched.
+ * Release-mode Rust arithmetic: the plain `+ - *` of the reference wrap. */
+int so_alac_predict(int32_t *out, size_t len, uint32_t mode, uint32_t lpc_order, uint32_t shift, uint32_t bps,
+                    const int32_t *coeffs_in) {
+    if (mode > 0 && mode < 15) return -1;
+    if (lpc_order == 0 || len == 0) return 0;
+    int32_t coeffs[32];
+    memcpy(coeffs, coeffs_in, sizeof coeffs);
+    const uint32_t num_clip_bits = 32 - bps;
+    if (lpc_order == 31 || mode == 15) {
+        for (size_t i = 1; i < len; i++) out[i] = alac_clip_msbs(wadd(out[i], out[i - 1]), num_clip_bits);
+    }
+    const size_t order = lpc_order;
+    const size_t warm_end = 1 + order < len ? 1 + order : len;
+    for (size_t i = 1; i < warm_end; i++) out[i] = alac_clip_msbs(wadd(out[i], out[i - 1]), num_clip_bits);
+    for (size_t i = 1 + order; i < len; i++) {
+        int32_t res = out[i];
+        const int32_t past0 = out[i - order - 1];
+        int32_t sum = 0;
+        /* coeffs[..order].iter().rev().zip(&out[i-order..i]): coeff[order-1-j] with out[i-order+j] */
+        for (size_t j = 0; j < order; j++) sum = wadd(sum, wmul(coeffs[order - 1 - j], wsub(out[i - order + j], past0)));
+        const int32_t val = wadd(sum, (int32_t)((1u << shift) >> 1)) >> shift;
+        out[i] = alac_clip_msbs(wadd(wadd(out[i], past0), val), num_clip_bits);
+        if (res > 0) {
+            for (size_t j = 0; j < order; j++) {
+                const int32_t v = wsub(past0, out[i - order + j]);
+                const int32_t sign = (v > 0) - (v < 0);
+                coeffs[order - 1 - j] = wsub(coeffs[order - 1 - j], sign);
+                res = wsub(res, wmul((int32_t)(1 + j), wmul(sign, v) >> shift));
+                if (res <= 0) break;
+            }
+        } else if (res < 0) {
+            for (size_t j = 0; j < order; j++) {
+                const int32_t v = wsub(past0, out[i - order + j]);
+                const int32_t sign = (v > 0) - (v < 0);
+                coeffs[order - 1 - j] = wadd(coeffs[order - 1 - j], sign);
+                res = wsub(res, wmul((int32_t)(1 + j), wmul(-sign, v) >> shift));
+                if (res >= 0) break;
+            }
+        }
+    }
+    return 0;
+}
+
+/* decorrelate_mid_side (lib.rs:664-671) */
+void so_alac_decorrelate_mid_side(int32_t *out0, int32_t *out1, size_t len, int32_t weight, uint32_t shift) {
+    for (size_t i = 0; i < len; i++) {
+        const int32_t s0 = wsub(wadd(out0[i], out1[i]), wmul(out1[i], weight) >> shift);
+        out0[i] = s0;
+        out1[i] = wsub(s0, out1[i]);
+    }
+}
+
+/* n_blocks element-channels of `blocksize` samples, in place.  desc[block] = {mode u8, lpc_order u8, shift u8,
+ * bps u8}; coeffs[block][32].  Blocks with an invalid mode are left untouched. */
+void so_alac_predict_batch(int32_t *buf, const uint8_t *desc, const int32_t *coeffs, size_t n_blocks, size_t blocksize) {
+    for (size_t b = 0; b < n_blocks; b++)
+        so_alac_predict(buf + b * blocksize, blocksize, desc[4 * b], desc[4 * b + 1], desc[4 * b + 2], desc[4 * b + 3],
+                        coeffs + 32 * b);
+}

@@ -154,6 +154,16 @@ int32_t so_flac_rice_signed_to_i32(uint32_t word);
 void so_flac_restore_batch(int32_t *buf, const uint8_t *desc, const int32_t *coeffs,
                            size_t n_blocks, size_t blocksize);
 
+/* ---- ALAC (symphonia-codec-alac/src/lib.rs) ------------------------------- */
+
+/* ElementChannel::predict (lib.rs:165-264).  Returns -1 for an invalid mode (lib.rs:167-169). */
+int so_alac_predict(int32_t *out, size_t len, uint32_t mode, uint32_t lpc_order, uint32_t shift, uint32_t bps,
+                    const int32_t *coeffs_in);
+/* decorrelate_mid_side (lib.rs:664-671) */
+void so_alac_decorrelate_mid_side(int32_t *out0, int32_t *out1, size_t len, int32_t weight, uint32_t shift);
+/* desc[block] = {mode u8, lpc_order u8, shift u8, bps u8}; coeffs[block][32]. */
+void so_alac_predict_batch(int32_t *buf, const uint8_t *desc, const int32_t *coeffs, size_t n_blocks, size_t blocksize);
+
 #ifdef __cplusplus
 }
 #endif

@@ -306,3 +306,47 @@ class FlacPredictor:
         n_pairs = (ch0.numel() if _is_torch(ch0) else ch0.size) // int(blocksize)
         self.ctx._call(self.ctx.lib.dll.symaccel_flac_decorrelate_device, _ptr(mode), _ptr(ch0), _ptr(ch1), n_pairs,
                        int(blocksize), int(out_shift))
+
+
+ALAC_DESC_DTYPE = np.dtype([("mode", np.uint8), ("lpc_order", np.uint8), ("shift", np.uint8), ("bps", np.uint8)])
+
+
+def alac_desc(mode, lpc_order, shift, bps):
+    m = np.asarray(mode)
+    d = np.zeros(m.shape, dtype=ALAC_DESC_DTYPE)
+    d["mode"], d["lpc_order"], d["shift"], d["bps"] = m, np.asarray(lpc_order), np.asarray(shift), np.asarray(bps)
+    return d
+
+
+class AlacPredictor:
+    """ElementChannel::predict and decorrelate_mid_side of symphonia-codec-alac/src/lib.rs (165-264, 664-671)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def predict(self, buf, desc, coeffs):
+        """buf[n_blocks, blocksize] i32 residuals -> samples.  numpy: returns a new array; torch: in place."""
+        d = self.ctx.lib.dll
+        nb, bs = int(buf.shape[0]), int(buf.shape[1])
+        if _is_torch(buf):
+            self.ctx._call(d.symaccel_alac_predict_device, _ptr(buf), _ptr(desc), _ptr(coeffs), nb, bs)
+            return buf
+        res = np.array(buf, dtype=np.int32, copy=True, order="C")
+        dsc = np.ascontiguousarray(desc)
+        co = _np(coeffs, np.int32)
+        assert dsc.nbytes == nb * 4 and co.shape == (nb, 32)
+        self.ctx._call(d.symaccel_alac_predict, _ptr(res), _ptr(dsc), _ptr(co), nb, bs)
+        return res
+
+    def mid_side(self, weight, shift, ch0, ch1):
+        """ch0/ch1[n_pairs, blocksize]; weight[n_pairs] i32, shift[n_pairs] u8.  numpy: returns new arrays; torch: in place."""
+        d = self.ctx.lib.dll
+        n_pairs, bs = int(ch0.shape[0]), int(ch0.shape[1])
+        if _is_torch(ch0):
+            self.ctx._call(d.symaccel_alac_mid_side_device, _ptr(weight), _ptr(shift), _ptr(ch0), _ptr(ch1), n_pairs, bs)
+            return ch0, ch1
+        a = np.array(ch0, dtype=np.int32, copy=True, order="C")
+        b = np.array(ch1, dtype=np.int32, copy=True, order="C")
+        self.ctx._call(d.symaccel_alac_mid_side, _ptr(_np(weight, np.int32)), _ptr(_np(shift, np.uint8)), _ptr(a), _ptr(b),
+                       n_pairs, bs)
+        return a, b

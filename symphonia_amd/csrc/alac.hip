@@ -1,0 +1,201 @@
+// ALAC integer path: the adaptive (sign-LMS) linear predictor of an element channel and the mid/side
+// decorrelation -- bit-exact, wrapping i32 arithmetic as the reference's release build computes it.
+//
+// Reference: symphonia-codec-alac/src/lib.rs:165-264 (ElementChannel::predict), :659-661 (clip_msbs),
+// :664-671 (decorrelate_mid_side).
+//
+// MI355X mapping: the same one-lane-per-block tiling as flac.hip (lane_tiles.h): the recurrence -- a FIR over the
+// previous `order` outputs relative to out[i - order - 1], then a data-dependent coefficient update that stops as
+// soon as the residual changes sign -- is serial inside an element channel and independent across them.  The last
+// 32 outputs are a statically indexed register ring; out[i - order - 1] (a per-lane distance) is read back from the
+// lane's LDS row; the early `break` of the update loop is a per-lane predicate; both prediction passes of the
+// mode-15 / order-31 case are fused into the one streaming pass.  Bound: integer ALU (about 13 x order operations
+// per sample), not HBM.
+#include "lane_tiles.h"
+
+namespace symaccel {
+
+namespace {
+
+__device__ __forceinline__ int32_t wrap_sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int32_t wrap_mul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+// clip_msbs (lib.rs:659-661)
+__device__ __forceinline__ int32_t clip_msbs(int32_t v, uint32_t num) { return (int32_t)((uint32_t)v << num) >> num; }
+
+struct AlacLane {
+    int32_t c[32];      // lpc_coeffs (lib.rs:79), adapted in place; entries >= order stay 0
+    int32_t h[32];      // ring of the last 32 outputs: before step u the newest sits in h[(u + 31) & 31]
+    int32_t p1_prev;    // previous output of the first (order-1) pass of the double predictor (lib.rs:185-189)
+    unsigned order, shift, clip;
+    bool enabled, twice;
+};
+
+// 32 samples of one tile.  `row` = this tile's LDS row of the lane, `prev_row` = the previous tile's (still intact in
+// the other LDS buffer); t0 = absolute index of column 0.
+template <int TAPS>
+__device__ __forceinline__ void alac_steps32(AlacLane &L, int32_t *row, const int32_t *prev_row, unsigned t0, int n_valid) {
+    int32_t xs[4];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        if ((u & 3) == 0) {
+            const int4 v = *reinterpret_cast<const int4 *>(row + u);
+            xs[0] = v.x; xs[1] = v.y; xs[2] = v.z; xs[3] = v.w;
+        }
+        if (u < n_valid) {
+            const unsigned i = t0 + (unsigned)u;
+            int32_t x = xs[u & 3];
+            if (L.enabled) {
+                // first pass of the double predictor: out[i] = clip(out[i] + out[i-1]) over the whole block
+                if (L.twice && i >= 1) x = clip_msbs(wrap_add(x, L.p1_prev), L.clip);
+                L.p1_prev = x;
+                const int32_t newest = L.h[(u + 31) & 31];
+                if (i >= 1 && i <= L.order) {
+                    x = clip_msbs(wrap_add(x, newest), L.clip);  // warm-up samples (lib.rs:196-198)
+                } else if (i > L.order) {
+                    int32_t res = x;
+                    // past0 = out[i - order - 1]: the two nearest distances from the ring, the rest from LDS (rows are
+                    // written back four samples at a time, so anything older than three samples is there)
+                    const int idx = u - (int)L.order - 1;
+                    const int32_t far = idx >= 0 ? row[idx >= 0 ? idx : 0] : prev_row[32 + idx];
+                    const int32_t past0 = L.order == 1 ? L.h[(u + 30) & 31] : (L.order == 2 ? L.h[(u + 29) & 31] : far);
+                    int32_t sum = 0;
+#pragma unroll
+                    for (int k = 0; k < TAPS; ++k) sum = wrap_add(sum, wrap_mul(L.c[k], wrap_sub(L.h[(u + 31 - k) & 31], past0)));
+                    const int32_t val = wrap_add(sum, (int32_t)((1u << L.shift) >> 1)) >> L.shift;
+                    x = clip_msbs(wrap_add(wrap_add(x, past0), val), L.clip);
+                    // sign-LMS update (lib.rs:224-260): from the oldest sample (coefficient order-1) to the newest,
+                    // until the residual reaches or crosses zero
+                    const bool pos = res > 0;
+                    bool active = res != 0;
+#pragma unroll
+                    for (int k = TAPS - 1; k >= 0; --k) {
+                        const bool on = active && (unsigned)k < L.order;
+                        const int32_t v = wrap_sub(past0, L.h[(u + 31 - k) & 31]);
+                        const int32_t sign = (v > 0) - (v < 0);
+                        const int32_t step = wrap_mul(pos ? sign : -sign, v) >> L.shift;
+                        const int32_t j1 = (int32_t)L.order - k;  // 1 + j
+                        const int32_t nres = wrap_sub(res, wrap_mul(j1, step));
+                        L.c[k] = on ? (pos ? wrap_sub(L.c[k], sign) : wrap_add(L.c[k], sign)) : L.c[k];
+                        res = on ? nres : res;
+                        active = on ? (pos ? res > 0 : res < 0) : active;
+                    }
+                }
+            }
+            L.h[u & 31] = x;
+            xs[u & 3] = x;
+        }
+        if ((u & 3) == 3) *reinterpret_cast<int4 *>(row + u - 3) = make_int4(xs[0], xs[1], xs[2], xs[3]);
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void alac_predict_kernel(
+    int32_t *__restrict__ buf, const symaccel_alac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
+    size_t n_blocks, unsigned blocksize) {
+    __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
+    const int lane = (int)threadIdx.x;
+    const size_t blk0 = (size_t)blockIdx.x * kRows;
+    const size_t my = blk0 + (size_t)lane;
+    const bool have = my < n_blocks;
+
+    AlacLane L;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) L.c[j] = L.h[j] = 0;
+    L.p1_prev = 0;
+    L.order = L.shift = L.clip = 0;
+    L.enabled = L.twice = false;
+    if (have) {
+        const symaccel_alac_desc d = desc[my];
+        const bool valid_mode = d.mode == 0 || d.mode >= 15;  // lib.rs:167-169 (mode is a 4-bit field)
+        L.order = d.lpc_order > 31u ? 31u : d.lpc_order;
+        L.shift = d.shift & 31u;
+        L.clip = 32u - (d.bps < 1u ? 1u : (d.bps > 32u ? 32u : d.bps));
+        L.enabled = valid_mode && L.order != 0;                // lib.rs:173-175
+        L.twice = L.order == 31 || d.mode == 15;               // lib.rs:185
+        const int4 *cp = reinterpret_cast<const int4 *>(coeffs + my * 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int4 v = cp[j];
+            L.c[4 * j] = (unsigned)(4 * j) < L.order ? v.x : 0;
+            L.c[4 * j + 1] = (unsigned)(4 * j + 1) < L.order ? v.y : 0;
+            L.c[4 * j + 2] = (unsigned)(4 * j + 2) < L.order ? v.z : 0;
+            L.c[4 * j + 3] = (unsigned)(4 * j + 3) < L.order ? v.w : 0;
+        }
+    }
+    const unsigned max_order = wave_max(L.enabled ? L.order : 0u);
+
+    const bool aligned = (blocksize & 3u) == 0 && blk0 + kRows <= n_blocks;
+    const unsigned n_tiles = (blocksize + kCols - 1) / kCols;
+    TilePrefetch pre;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pre.v[k] = make_int4(0, 0, 0, 0);
+    if (aligned && blocksize >= (unsigned)kCols) tile_issue_loads(buf, pre, blk0, blocksize, 0, lane);
+    for (unsigned t = 0; t < n_tiles; ++t) {
+        const unsigned t0 = t * kCols;
+        const unsigned cols = min((unsigned)kCols, blocksize - t0);
+        const bool fast = aligned && cols == (unsigned)kCols;
+        int32_t *tile = tiles + (t & 1u) * kTileWords;
+        const int32_t *prev_tile = tiles + ((t & 1u) ^ 1u) * kTileWords;
+        if (fast)
+            tile_commit(pre, tile, lane);
+        else
+            tile_fetch_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+        wave_sync();
+        if (aligned && t0 + 2u * kCols <= blocksize) tile_issue_loads(buf, pre, blk0, blocksize, t0 + kCols, lane);
+        if (have) {
+            int32_t *row = tile + lane * kStride;
+            const int32_t *prow = prev_tile + lane * kStride;
+            if (max_order <= 4)
+                alac_steps32<4>(L, row, prow, t0, (int)cols);
+            else if (max_order <= 8)
+                alac_steps32<8>(L, row, prow, t0, (int)cols);
+            else if (max_order <= 16)
+                alac_steps32<16>(L, row, prow, t0, (int)cols);
+            else
+                alac_steps32<32>(L, row, prow, t0, (int)cols);
+        }
+        wave_sync();
+        if (fast)
+            tile_store_fast(buf, tile, blk0, blocksize, t0, lane);
+        else
+            tile_store_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+    }
+}
+
+// lib.rs:664-671, pair p: out0 = ch0[p][..], out1 = ch1[p][..]; weight == 0 leaves the pair alone (lib.rs:552)
+__global__ void alac_mid_side_kernel(const int32_t *__restrict__ weight, const uint8_t *__restrict__ shift,
+                                     int32_t *__restrict__ ch0, int32_t *__restrict__ ch1, size_t n_pairs, size_t blocksize) {
+    const size_t total = n_pairs * blocksize;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / blocksize;
+        const int32_t w = weight[p];
+        if (w == 0) continue;
+        const int32_t a = ch0[i], b = ch1[i];
+        const int32_t s0 = wrap_sub(wrap_add(a, b), wrap_mul(b, w) >> (shift[p] & 31u));
+        ch0[i] = s0;
+        ch1[i] = wrap_sub(s0, b);
+    }
+}
+
+}  // namespace
+
+int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc, const int32_t *d_coeffs,
+                        size_t n_blocks, size_t blocksize) {
+    const size_t grid = (n_blocks + kRows - 1) / kRows;
+    if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(alac_predict_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs,
+                       n_blocks, (unsigned)blocksize);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_alac_mid_side(symaccel_ctx *ctx, const int32_t *d_weight, const uint8_t *d_shift, int32_t *d_ch0, int32_t *d_ch1,
+                         size_t n_pairs, size_t blocksize) {
+    const size_t total = n_pairs * blocksize;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(alac_mid_side_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_weight, d_shift, d_ch0, d_ch1, n_pairs,
+                       blocksize);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+}  // namespace symaccel

@@ -607,6 +607,60 @@ int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, i
 
 // ---- tables -------------------------------------------------------------------------------
 
+int symaccel_alac_predict_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc,
+                                 const int32_t *d_coeffs, size_t n_blocks, size_t blocksize) {
+    if (!ctx || blocksize > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!d_buf || !d_desc || !d_coeffs) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_alac_predict(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize);
+}
+
+int symaccel_alac_predict(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_alac_desc *h_desc, const int32_t *h_coeffs,
+                          size_t n_blocks, size_t blocksize) {
+    if (!ctx || blocksize > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!h_buf || !h_desc || !h_coeffs) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DevBuf buf(ctx), desc(ctx), co(ctx);
+    const size_t bytes = n_blocks * blocksize * 4;
+    SYM_TRY(buf.from_host(h_buf, bytes));
+    SYM_TRY(desc.from_host(h_desc, n_blocks * sizeof(symaccel_alac_desc)));
+    SYM_TRY(co.from_host(h_coeffs, n_blocks * 32 * 4));
+    SYM_TRY(launch_alac_predict(ctx, (int32_t *)buf.p, (const symaccel_alac_desc *)desc.p, (const int32_t *)co.p, n_blocks,
+                                blocksize));
+    SYM_TRY(buf.to_host(h_buf, bytes));
+    return symaccel_sync(ctx);
+}
+
+int symaccel_alac_mid_side_device(symaccel_ctx *ctx, const int32_t *d_weight, const uint8_t *d_shift, int32_t *d_ch0,
+                                  int32_t *d_ch1, size_t n_pairs, size_t blocksize) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!d_weight || !d_shift || !d_ch0 || !d_ch1) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_alac_mid_side(ctx, d_weight, d_shift, d_ch0, d_ch1, n_pairs, blocksize);
+}
+
+int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uint8_t *h_shift, int32_t *h_ch0,
+                           int32_t *h_ch1, size_t n_pairs, size_t blocksize) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!h_weight || !h_shift || !h_ch0 || !h_ch1) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DevBuf w(ctx), sh(ctx), c0(ctx), c1(ctx);
+    const size_t bytes = n_pairs * blocksize * 4;
+    SYM_TRY(w.from_host(h_weight, n_pairs * 4));
+    SYM_TRY(sh.from_host(h_shift, n_pairs));
+    SYM_TRY(c0.from_host(h_ch0, bytes));
+    SYM_TRY(c1.from_host(h_ch1, bytes));
+    SYM_TRY(launch_alac_mid_side(ctx, (const int32_t *)w.p, (const uint8_t *)sh.p, (int32_t *)c0.p, (int32_t *)c1.p, n_pairs,
+                                 blocksize));
+    SYM_TRY(c0.to_host(h_ch0, bytes));
+    SYM_TRY(c1.to_host(h_ch1, bytes));
+    return symaccel_sync(ctx);
+}
+
 int symaccel_table_f32(const symaccel_ctx *, int table, float *dst, size_t capacity) {
     const HostTables &t = host_tables();
     const float *src = nullptr;

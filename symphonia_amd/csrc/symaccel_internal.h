@@ -148,6 +148,10 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
                                size_t count);
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *d_setup, int n_posts, int multiplier,
                          const uint32_t *d_y, uint32_t n, float *d_floor, size_t count);
+int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc, const int32_t *d_coeffs,
+                        size_t n_blocks, size_t blocksize);
+int launch_alac_mid_side(symaccel_ctx *ctx, const int32_t *d_weight, const uint8_t *d_shift, int32_t *d_ch0, int32_t *d_ch1,
+                         size_t n_pairs, size_t blocksize);
 int launch_state_copy(symaccel_ctx *ctx, void *dst0, const void *src0, size_t bytes0, void *dst1, const void *src1,
                       size_t bytes1, void *dst2, const void *src2, size_t bytes2);
 int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,

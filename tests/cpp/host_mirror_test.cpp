@@ -202,6 +202,37 @@ static void verify_flac(Context &ctx) {  // decode_linear / decode_fixed_linear 
     EXPECT(threw, "lpc_predict accepted order 33");
 }
 
+static void verify_alac(Context &ctx) {  // decode_element (alac/lib.rs:540-560)
+    std::mt19937 rng(17);
+    for (std::uint32_t order : {4u, 8u, 31u}) {
+        alac::ElementChannel e;
+        e.bps = 16, e.mode = order == 8 ? 15u : 0u, e.shift = 9, e.lpc_order = order;
+        for (std::uint32_t j = 0; j < order; ++j) e.lpc_coeffs[j] = (std::int32_t)(rng() % 1001) - 500;
+        std::vector<std::int32_t> buf(4096), ref;
+        for (auto &v : buf) v = (std::int32_t)(rng() % 2001) - 1000;
+        ref = buf;
+        e.predict(ctx, buf.data(), buf.size());
+        so_alac_predict(ref.data(), ref.size(), e.mode, e.lpc_order, e.shift, e.bps, e.lpc_coeffs.data());
+        EXPECT(buf == ref, "alac predict order %u", order);
+    }
+    std::vector<std::int32_t> a(500), b(500), ra, rb;
+    for (auto &v : a) v = (std::int32_t)rng();
+    for (auto &v : b) v = (std::int32_t)rng();
+    ra = a, rb = b;
+    alac::decorrelate_mid_side(ctx, a.data(), b.data(), a.size(), 3, 2);
+    so_alac_decorrelate_mid_side(ra.data(), rb.data(), ra.size(), 3, 2);
+    EXPECT(a == ra && b == rb, "alac decorrelate_mid_side");
+    bool threw = false;
+    try {
+        alac::ElementChannel bad;
+        bad.mode = 7, bad.lpc_order = 4;
+        bad.predict(ctx, a.data(), a.size());
+    } catch (const Error &) {
+        threw = true;
+    }
+    EXPECT(threw, "alac accepted mode 7");
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && std::strcmp(argv[1], "--expect-no-device") == 0) {
         // there is no CPU path: without an MI355X the context constructor must fail with the IoError class
@@ -220,6 +251,7 @@ int main(int argc, char **argv) {
     verify_mp3(ctx);
     verify_vorbis(ctx);
     verify_flac(ctx);
+    verify_alac(ctx);
     std::printf(g_failures ? "%d failure(s)\n" : "host mirror: all checks passed\n", g_failures);
     return g_failures ? 1 : 0;
 }

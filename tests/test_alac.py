@@ -1,0 +1,168 @@
+"""ALAC predictor (symphonia-codec-alac/src/lib.rs:165-264, 664-671).
+
+The reference has no unit tests or vectors for it -- PARITY UNPINNED BY THE REFERENCE -- so the oracle is pinned by an
+independent forward encoder written here (pure Python, textbook form of the adaptive predictor): residuals produced by
+running the predictor over known PCM must decode back to that PCM exactly.  The kernel is then checked bit-for-bit
+against the oracle: in CPU emulation (logic) and, gpu-marked, on the MI355X."""
+import numpy as np
+import pytest
+
+import oracle
+from emu_lib import emu_ctx  # noqa: F401
+
+
+def sext(v, bits):
+    v &= (1 << bits) - 1
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+def w32(v):
+    return sext(v, 32)
+
+
+def alac_encode(pcm, mode, order, shift, bps, coeffs):
+    """Forward pass: the residual stream whose decode is `pcm` (values must fit `bps` bits)."""
+    n = len(pcm)
+    co = [int(c) for c in coeffs[:order]] + [0] * (32 - order)
+    out = [int(v) for v in pcm]            # decoder-side reconstruction (== pcm by construction)
+    stage = [0] * n                        # what predict() must see after its first pass (or the residuals themselves)
+    clip = lambda v: sext(v, bps)
+    stage[0] = out[0]
+    for i in range(1, min(1 + order, n)):
+        stage[i] = clip(out[i] - out[i - 1])
+    for i in range(1 + order, n):
+        past0 = out[i - order - 1]
+        s = 0
+        for j in range(order):
+            s = w32(s + w32(co[order - 1 - j] * w32(out[i - order + j] - past0)))
+        val = w32(s + ((1 << shift) >> 1)) >> shift
+        res = clip(out[i] - past0 - val)
+        stage[i] = res
+        assert clip(w32(w32(res + past0) + val)) == out[i]
+        if res > 0:
+            for j in range(order):
+                v = w32(past0 - out[i - order + j])
+                sg = (v > 0) - (v < 0)
+                co[order - 1 - j] -= sg
+                res -= (1 + j) * (w32(sg * v) >> shift)
+                if res <= 0:
+                    break
+        elif res < 0:
+            for j in range(order):
+                v = w32(past0 - out[i - order + j])
+                sg = (v > 0) - (v < 0)
+                co[order - 1 - j] += sg
+                res -= (1 + j) * (w32(-sg * v) >> shift)
+                if res >= 0:
+                    break
+    if order == 31 or mode == 15:          # undo the decoder's first pass: stage[i] = clip(r[i] + stage[i-1])
+        r = [stage[0]] + [clip(stage[i] - stage[i - 1]) for i in range(1, n)]
+        return np.array(r, dtype=np.int64).astype(np.int32)
+    return np.array(stage, dtype=np.int64).astype(np.int32)
+
+
+def smooth_pcm(rng, n, bps):
+    t = np.arange(n)
+    amp = (1 << (bps - 2))
+    x = amp * 0.6 * np.sin(t * rng.uniform(0.01, 0.2)) + rng.standard_normal(n) * amp * 0.01
+    return np.clip(np.round(x), -(1 << (bps - 1)), (1 << (bps - 1)) - 1).astype(np.int64)
+
+
+@pytest.mark.parametrize("mode,order,shift,bps", [(0, 4, 9, 16), (0, 8, 9, 16), (15, 4, 9, 16), (0, 31, 9, 24), (0, 1, 4, 16),
+                                                   (0, 2, 0, 20), (0, 12, 9, 32), (0, 0, 9, 16)])
+def test_oracle_decodes_what_an_encoder_produced(mode, order, shift, bps):
+    rng = np.random.default_rng(order * 31 + bps + mode)
+    n = 300
+    pcm = smooth_pcm(rng, n, min(bps, 24))
+    coeffs = np.zeros(32, np.int32)
+    coeffs[:order] = rng.integers(-300, 300, order)
+    if order:
+        coeffs[0] = 1 << shift if shift < 15 else 1 << 14
+    res = alac_encode(pcm, mode, order, shift, bps, coeffs) if order else pcm.astype(np.int32)
+    got = oracle.alac_predict(res[None], oracle.alac_desc([mode], [order], [shift], [bps]), coeffs[None])[0]
+    assert np.array_equal(got, pcm.astype(np.int32))
+
+
+def test_oracle_rejects_invalid_modes_like_the_reference():
+    buf = np.arange(20, dtype=np.int32)[None]
+    out = oracle.alac_predict(buf, oracle.alac_desc([7], [4], [9], [16]), np.ones((1, 32), np.int32))
+    assert np.array_equal(out, buf)  # lib.rs:167-169: decode_error, nothing written
+
+
+def alac_case(seed, nb, blocksize):
+    rng = np.random.default_rng(seed)
+    bps = rng.choice([16, 20, 24, 32], nb).astype(np.uint8)
+    buf = np.stack([rng.integers(-(1 << 10), 1 << 10, blocksize) for _ in range(nb)]).astype(np.int32)
+    buf[0] = rng.integers(-(1 << 31), 1 << 31, blocksize)      # wrapping arithmetic everywhere
+    mode = rng.choice([0, 0, 0, 15, 7], nb).astype(np.uint8)   # 7 = invalid: block must stay untouched
+    order = rng.choice([0, 1, 2, 3, 4, 8, 12, 16, 31], nb).astype(np.uint8)
+    order[:9] = [0, 1, 2, 3, 4, 8, 12, 16, 31][:min(9, nb)] if nb >= 9 else order[:9]
+    shift = rng.integers(0, 16, nb).astype(np.uint8)
+    coeffs = rng.integers(-(1 << 15), 1 << 15, (nb, 32)).astype(np.int32)
+    return buf, mode, order, shift, bps, coeffs
+
+
+@pytest.mark.parametrize("blocksize", [1, 5, 31, 32, 100, 352])
+def test_emu_alac_predict(emu_ctx, blocksize):
+    from symphonia_amd import AlacPredictor, alac_desc
+    buf, mode, order, shift, bps, coeffs = alac_case(blocksize, 70, blocksize)
+    got = AlacPredictor(emu_ctx).predict(buf, alac_desc(mode, order, shift, bps), coeffs)
+    want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
+    assert np.array_equal(got, want)
+
+
+def test_emu_alac_uniform_small_orders(emu_ctx):
+    """Whole wavefronts of order <= 4 / <= 8 take the short-tap specialisations."""
+    from symphonia_amd import AlacPredictor, alac_desc
+    rng = np.random.default_rng(3)
+    for hi in (4, 8, 16):
+        nb, bs = 64, 96
+        buf = rng.integers(-(1 << 14), 1 << 14, (nb, bs)).astype(np.int32)
+        order = rng.integers(1, hi + 1, nb).astype(np.uint8)
+        d = (np.zeros(nb, np.uint8), order, np.full(nb, 9, np.uint8), np.full(nb, 16, np.uint8))
+        coeffs = rng.integers(-2000, 2000, (nb, 32)).astype(np.int32)
+        got = AlacPredictor(emu_ctx).predict(buf, alac_desc(*d), coeffs)
+        assert np.array_equal(got, oracle.alac_predict(buf, oracle.alac_desc(*d), coeffs)), hi
+
+
+def test_emu_alac_mid_side(emu_ctx):
+    from symphonia_amd import AlacPredictor
+    rng = np.random.default_rng(4)
+    a = rng.integers(-(1 << 31), 1 << 31, (5, 77)).astype(np.int32)
+    b = rng.integers(-(1 << 31), 1 << 31, (5, 77)).astype(np.int32)
+    weight = np.array([0, 1, 2, 3, -5], np.int32)
+    shift = np.array([0, 1, 2, 31, 4], np.uint8)
+    ga, gb = AlacPredictor(emu_ctx).mid_side(weight, shift, a, b)
+    for p in range(5):
+        wa, wb = (a[p], b[p]) if weight[p] == 0 else oracle.alac_decorrelate_mid_side(a[p], b[p], int(weight[p]), int(shift[p]))
+        assert np.array_equal(ga[p], wa) and np.array_equal(gb[p], wb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocksize", [1, 33, 352, 4096])
+def test_gpu_alac_predict(blocksize):
+    import torch
+    from symphonia_amd import AlacPredictor, Context, alac_desc
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    buf, mode, order, shift, bps, coeffs = alac_case(100 + blocksize, 200, blocksize)
+    with Context(0) as ctx:
+        ctx.use_torch_stream()
+        d = torch.from_numpy(buf.copy()).cuda()
+        desc = torch.from_numpy(alac_desc(mode, order, shift, bps).view(np.uint8).reshape(-1, 4)).cuda()
+        AlacPredictor(ctx).predict(d, desc, torch.from_numpy(coeffs).cuda())
+        torch.cuda.synchronize()
+        got = d.cpu().numpy()
+        a = torch.from_numpy(buf[:100].copy()).cuda()
+        b = torch.from_numpy(buf[100:].copy()).cuda()
+        w = torch.arange(-50, 50, dtype=torch.int32).cuda()
+        s = (torch.arange(100) % 32).to(torch.uint8).cuda()
+        AlacPredictor(ctx).mid_side(w, s, a, b)
+        torch.cuda.synchronize()
+        ga, gb = a.cpu().numpy(), b.cpu().numpy()
+    want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
+    assert np.array_equal(got, want)
+    for p in range(100):
+        wgt, sh = p - 50, p % 32
+        wa, wb = (buf[p], buf[100 + p]) if wgt == 0 else oracle.alac_decorrelate_mid_side(buf[p], buf[100 + p], wgt, sh)
+        assert np.array_equal(ga[p], wa) and np.array_equal(gb[p], wb), p
