@@ -111,6 +111,19 @@ def make_workload(name, torch, ctx, seed, scale=1.0):
         return step, nb, "blocks", nb * bs * 8, {
             "workload": "FLAC 24-bit, LPC order 32 (15-bit coefficients, shift 12), %d subframe blocks of 4096 samples, "
                         "in place" % nb, "samples": nb * bs}, "flac_restore_kernel"
+    if name == "alac":
+        nb, bs = int(262144 * scale), 4096  # 16-bit ALAC frames of 4096 samples, adaptive predictor of order 8
+        buf = torch.randint(-(1 << 9), 1 << 9, (nb, bs), generator=g, device="cuda", dtype=torch.int32)
+        desc_np = sa.alac_desc(np.zeros(nb), np.full(nb, 8), np.full(nb, 9), np.full(nb, 16))
+        desc = torch.from_numpy(desc_np.view(np.uint8).reshape(nb, 4)).cuda()
+        co = torch.randint(-200, 200, (nb, 32), generator=g, device="cuda", dtype=torch.int32)
+        ap = sa.AlacPredictor(ctx)
+
+        def step():
+            ap.predict(buf, desc, co)  # in place, like the FLAC workload: every pass costs the same
+        return step, nb, "blocks", nb * bs * 8, {
+            "workload": "ALAC 16-bit, adaptive LPC order 8 (shift 9), %d element-channel blocks of 4096 samples, in place" % nb,
+            "samples": nb * bs}, "alac_predict_kernel"
     raise ValueError(name)
 
 
@@ -154,6 +167,14 @@ def cpu_baseline(name, seconds=10.0):
         kw = dict(n_chains=nch, per_chain=nb, stride_in=nb * 1024, stride_out=nb * 1024, p0=8, p1=11)
         units, unit = nb, "frames/s"
         sample = "8 ch x %d long blocks" % nb
+    elif name == "alac":
+        nb, bs = 8, 4096
+        in0 = rng.integers(-512, 512, (nb, bs)).astype(np.int32)
+        in1 = oracle.alac_desc(np.zeros(nb), np.full(nb, 8), np.full(nb, 9), np.full(nb, 16))
+        co = rng.integers(-200, 200, (nb, 32)).astype(np.int32)
+        kw = dict(in2=co, n_chains=nb, per_chain=bs)
+        units, unit = nb, "blocks/s"
+        sample = "%d order-8 blocks of 4096 samples" % nb
     else:
         nb, bs = 8, 4096
         in0 = rng.integers(-4096, 4096, (nb, bs)).astype(np.int32)
@@ -175,7 +196,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac"])
+    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac"])
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -243,7 +264,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "i32/i64" if args.workload == "flac" else "f32",
+            "dtype": "i32/i64" if args.workload == "flac" else ("i32" if args.workload == "alac" else "f32"),
             "data": "synthetic",
             "config": dict(config, parallelism="chains sharded per GPU, no collective", segment=args.segment or "auto"),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -259,8 +280,10 @@ def main():
             pass
         out["roofline"]["copy_ceiling_note"] = ("a plain copy of the same 1:1 read/write footprint reaches 5.1-5.9 TB/s on "
                                                 "this part (profiles/r01_ubench_hbm_copy.txt); peak = HBM3E spec")
+        if args.workload == "alac":
+            out["roofline"]["note"] = "integer-ALU bound (adaptive predictor, ~13 x order operations per sample), not HBM"
         if args.workload == "flac":
-            out["roofline"]["note"] = "integer-ALU / dependent-chain bound, not HBM (DESIGN.md)"
+            out["roofline"]["note"] = "FP64-FMA-issue bound (32 exact FMAs per 8 B), not HBM (DESIGN.md 4.5)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))

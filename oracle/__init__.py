@@ -394,7 +394,7 @@ def alac_decorrelate_mid_side(out0, out1, weight, shift):
 def bench_mt(kind, threads, seconds, in0, in1, in2=None, n_chains=0, per_chain=0, stride_in=0, stride_out=0, p0=0, p1=0):
     """oracle/bench_mt.c: `threads` pthreads each run the batch on private outputs for `seconds`.
     Returns (elapsed seconds, batches completed by all threads)."""
-    k = {"aac": 0, "mp3": 1, "vorbis": 2, "flac": 3}[kind]
+    k = {"aac": 0, "mp3": 1, "vorbis": 2, "flac": 3, "alac": 4}[kind]
     reps = C.c_long(0)
     dt = float(lib().so_bench_mt(k, int(threads), float(seconds), C.byref(reps), _p(in0), _p(in1),
                                  _p(in2) if in2 is not None else None, n_chains, per_chain, stride_in, stride_out, p0, p1))

@@ -18,7 +18,7 @@
 #include "symoracle.h"
 
 typedef struct job {
-    int kind; /* 0 aac, 1 mp3, 2 vorbis, 3 flac */
+    int kind; /* 0 aac, 1 mp3, 2 vorbis, 3 flac, 4 alac */
     double seconds;
     long *total_reps;
     pthread_mutex_t *lock;
@@ -49,6 +49,10 @@ static void run_once(const job *j, void *state, void *out) {
                               (float *)out, j->stride_out, j->n_chains, j->per_chain);
         break;
     }
+    case 4:
+        memcpy(out, j->in0, j->n_chains * j->per_chain * sizeof(int32_t));
+        so_alac_predict_batch((int32_t *)out, (const uint8_t *)j->in1, (const int32_t *)j->in2, j->n_chains, j->per_chain);
+        break;
     default:
         memcpy(out, j->in0, j->n_chains * j->per_chain * sizeof(int32_t));
         so_flac_restore_batch((int32_t *)out, (const uint8_t *)j->in1, (const int32_t *)j->in2, j->n_chains, j->per_chain);
