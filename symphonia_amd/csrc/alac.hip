@@ -6,11 +6,11 @@
 //
 // MI355X mapping: the same one-lane-per-block tiling as flac.hip (lane_tiles.h): the recurrence -- a FIR over the
 // previous `order` outputs relative to out[i - order - 1], then a data-dependent coefficient update that stops as
-// soon as the residual changes sign -- is serial inside an element channel and independent across them.  The last
-// 32 outputs are a statically indexed register ring; out[i - order - 1] (a per-lane distance) is read back from the
-// lane's LDS row; the early `break` of the update loop is a per-lane predicate; both prediction passes of the
-// mode-15 / order-31 case are fused into the one streaming pass.  Bound: integer ALU (about 13 x order operations
-// per sample), not HBM.
+// soon as the residual changes sign -- is serial inside an element channel and independent across them.  The
+// latest outputs are a short per-lane shift register (as long as the largest order in the wavefront: 4, 8, 16 or
+// 32 taps); out[i - order - 1], a per-lane distance, is read back from the lane's LDS row; the early `break` of the
+// update loop is a per-lane predicate; both prediction passes of the mode-15 / order-31 case are fused into the one
+// streaming pass.  Bound: integer ALU (about 13 x order operations per sample), not HBM.
 #include "lane_tiles.h"
 
 namespace symaccel {
@@ -24,67 +24,71 @@ __device__ __forceinline__ int32_t clip_msbs(int32_t v, uint32_t num) { return (
 
 struct AlacLane {
     int32_t c[32];      // lpc_coeffs (lib.rs:79), adapted in place; entries >= order stay 0
-    int32_t h[32];      // ring of the last 32 outputs: before step u the newest sits in h[(u + 31) & 31]
+    int32_t h[32];      // shift register of the latest outputs: h[k] = out[i - 1 - k] (only the first TAPS are kept)
     int32_t p1_prev;    // previous output of the first (order-1) pass of the double predictor (lib.rs:185-189)
     unsigned order, shift, clip;
     bool enabled, twice;
 };
 
+// One sample.  `past_far` = out[i - order - 1] as read back from LDS (valid for order >= 3).
+template <int TAPS>
+__device__ __forceinline__ int32_t alac_step(AlacLane &L, int32_t x, unsigned i, int32_t past_far) {
+    if (L.enabled) {
+        // first pass of the double predictor: out[i] = clip(out[i] + out[i-1]) over the whole block
+        if (L.twice && i >= 1) x = clip_msbs(wrap_add(x, L.p1_prev), L.clip);
+        L.p1_prev = x;
+        if (i >= 1 && i <= L.order) {
+            x = clip_msbs(wrap_add(x, L.h[0]), L.clip);  // warm-up samples (lib.rs:196-198)
+        } else if (i > L.order) {
+            int32_t res = x;
+            const int32_t past0 = L.order == 1 ? L.h[1] : (L.order == 2 ? L.h[2] : past_far);
+            int32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) sum = wrap_add(sum, wrap_mul(L.c[k], wrap_sub(L.h[k], past0)));
+            const int32_t val = wrap_add(sum, (int32_t)((1u << L.shift) >> 1)) >> L.shift;
+            x = clip_msbs(wrap_add(wrap_add(x, past0), val), L.clip);
+            // sign-LMS update (lib.rs:224-260): from the oldest sample (coefficient order-1) to the newest, until the
+            // residual reaches or crosses zero (the reference's `break`, here a per-lane predicate)
+            const bool pos = res > 0;
+            bool active = res != 0;
+#pragma unroll
+            for (int k = TAPS - 1; k >= 0; --k) {
+                const bool on = active && (unsigned)k < L.order;
+                const int32_t v = wrap_sub(past0, L.h[k]);
+                const int32_t sign = (v > 0) - (v < 0);
+                const int32_t step = wrap_mul(pos ? sign : -sign, v) >> L.shift;
+                const int32_t nres = wrap_sub(res, wrap_mul((int32_t)L.order - k, step));  // (1 + j) = order - k
+                L.c[k] = on ? (pos ? wrap_sub(L.c[k], sign) : wrap_add(L.c[k], sign)) : L.c[k];
+                res = on ? nres : res;
+                active = on ? (pos ? res > 0 : res < 0) : active;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = TAPS - 1; k >= 1; --k) L.h[k] = L.h[k - 1];
+    L.h[0] = x;
+    return x;
+}
+
 // 32 samples of one tile.  `row` = this tile's LDS row of the lane, `prev_row` = the previous tile's (still intact in
-// the other LDS buffer); t0 = absolute index of column 0.
+// the other LDS buffer); t0 = absolute index of column 0.  Rows are written back four samples at a time, so anything
+// older than three samples can be read back from LDS: that is where out[i - order - 1] comes from for order >= 3.
 template <int TAPS>
 __device__ __forceinline__ void alac_steps32(AlacLane &L, int32_t *row, const int32_t *prev_row, unsigned t0, int n_valid) {
-    int32_t xs[4];
+#pragma unroll 1
+    for (int u0 = 0; u0 < 32; u0 += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(row + u0);
+        int32_t xs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-        if ((u & 3) == 0) {
-            const int4 v = *reinterpret_cast<const int4 *>(row + u);
-            xs[0] = v.x; xs[1] = v.y; xs[2] = v.z; xs[3] = v.w;
-        }
-        if (u < n_valid) {
-            const unsigned i = t0 + (unsigned)u;
-            int32_t x = xs[u & 3];
-            if (L.enabled) {
-                // first pass of the double predictor: out[i] = clip(out[i] + out[i-1]) over the whole block
-                if (L.twice && i >= 1) x = clip_msbs(wrap_add(x, L.p1_prev), L.clip);
-                L.p1_prev = x;
-                const int32_t newest = L.h[(u + 31) & 31];
-                if (i >= 1 && i <= L.order) {
-                    x = clip_msbs(wrap_add(x, newest), L.clip);  // warm-up samples (lib.rs:196-198)
-                } else if (i > L.order) {
-                    int32_t res = x;
-                    // past0 = out[i - order - 1]: the two nearest distances from the ring, the rest from LDS (rows are
-                    // written back four samples at a time, so anything older than three samples is there)
-                    const int idx = u - (int)L.order - 1;
-                    const int32_t far = idx >= 0 ? row[idx >= 0 ? idx : 0] : prev_row[32 + idx];
-                    const int32_t past0 = L.order == 1 ? L.h[(u + 30) & 31] : (L.order == 2 ? L.h[(u + 29) & 31] : far);
-                    int32_t sum = 0;
-#pragma unroll
-                    for (int k = 0; k < TAPS; ++k) sum = wrap_add(sum, wrap_mul(L.c[k], wrap_sub(L.h[(u + 31 - k) & 31], past0)));
-                    const int32_t val = wrap_add(sum, (int32_t)((1u << L.shift) >> 1)) >> L.shift;
-                    x = clip_msbs(wrap_add(wrap_add(x, past0), val), L.clip);
-                    // sign-LMS update (lib.rs:224-260): from the oldest sample (coefficient order-1) to the newest,
-                    // until the residual reaches or crosses zero
-                    const bool pos = res > 0;
-                    bool active = res != 0;
-#pragma unroll
-                    for (int k = TAPS - 1; k >= 0; --k) {
-                        const bool on = active && (unsigned)k < L.order;
-                        const int32_t v = wrap_sub(past0, L.h[(u + 31 - k) & 31]);
-                        const int32_t sign = (v > 0) - (v < 0);
-                        const int32_t step = wrap_mul(pos ? sign : -sign, v) >> L.shift;
-                        const int32_t j1 = (int32_t)L.order - k;  // 1 + j
-                        const int32_t nres = wrap_sub(res, wrap_mul(j1, step));
-                        L.c[k] = on ? (pos ? wrap_sub(L.c[k], sign) : wrap_add(L.c[k], sign)) : L.c[k];
-                        res = on ? nres : res;
-                        active = on ? (pos ? res > 0 : res < 0) : active;
-                    }
-                }
+        for (int q = 0; q < 4; ++q) {
+            const int u = u0 + q;
+            if (u < n_valid) {
+                const int idx = u - (int)L.order - 1;
+                const int32_t far = idx >= 0 ? row[idx >= 0 ? idx : 0] : prev_row[32 + (idx < -32 ? -32 : idx)];
+                xs[q] = alac_step<TAPS>(L, xs[q], t0 + (unsigned)u, far);
             }
-            L.h[u & 31] = x;
-            xs[u & 3] = x;
         }
-        if ((u & 3) == 3) *reinterpret_cast<int4 *>(row + u - 3) = make_int4(xs[0], xs[1], xs[2], xs[3]);
+        *reinterpret_cast<int4 *>(row + u0) = make_int4(xs[0], xs[1], xs[2], xs[3]);
     }
 }
 
