@@ -56,7 +56,8 @@ __device__ __forceinline__ int32_t alac_step(AlacLane &L, int32_t x, unsigned i,
                 const bool on = active && (unsigned)k < L.order;
                 const int32_t v = wrap_sub(past0, L.h[k]);
                 const int32_t sign = (v > 0) - (v < 0);
-                const int32_t step = wrap_mul(pos ? sign : -sign, v) >> L.shift;
+                const int32_t mag = v < 0 ? wrap_sub(0, v) : v;                        // sign * v (wraps like the reference)
+                const int32_t step = (pos ? mag : wrap_sub(0, mag)) >> L.shift;        // (+-sign * val) >> shift
                 const int32_t nres = wrap_sub(res, wrap_mul((int32_t)L.order - k, step));  // (1 + j) = order - k
                 L.c[k] = on ? (pos ? wrap_sub(L.c[k], sign) : wrap_add(L.c[k], sign)) : L.c[k];
                 res = on ? nres : res;
