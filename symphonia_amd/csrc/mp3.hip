@@ -18,7 +18,7 @@
 // is transformed.  Segments other than a chain's first start with a two-granule halo (granule g-2
 // rebuilds the overlap, granule g-1 rebuilds the 16-slot history); both depend only on inputs.
 // PCM stores are 4 B per lane (128 B per half-wave): transposing the granule through LDS for 16-byte stores was
-// measured and is not faster.  LDS per wavefront: granule tiles 4.5 KiB + dct32 transpose 5 KiB + window rows 2.5 KiB.
+// measured and is not faster.  LDS per wavefront: 5 KiB (granule tiles, then the dct32 transpose) + window rows 2.5 KiB.
 // Roofline: HBM-bound on paper, 2304 B in + 2304 B out per granule-channel, ~34 kflop (no FMA) -> 7.4 flop/B.
 #include "dsp_device.h"
 #include "mp3_literals.h"
@@ -34,7 +34,9 @@ constexpr int kRows = kHistOld + 18;
 constexpr int kTileFloats = 2 * 576;             // two granule tiles (one per half-wave)
 constexpr int kDwStride = 20;                    // window-coefficient rows [sample i][16], padded: conflict-free b128
 constexpr int kDwFloats = 32 * kDwStride;
-constexpr int kWaveFloats = kTileFloats + 2 * 18 * kSStride + kDwFloats;  // per-wavefront LDS
+constexpr int kSBase = 0;  // the dct32 transpose reuses the granule tiles' LDS (the tiles are dead by then)
+constexpr int kWaveFloats = kSBase + 2 * 18 * kSStride + kDwFloats;  // per-wavefront LDS (>= the two tiles)
+static_assert(2 * 18 * kSStride >= kTileFloats, "the transpose area must hold the two granule tiles");
 
 // Order this wavefront's LDS accesses: its lanes exchange data through LDS; the hardware executes one
 // wavefront's DS instructions in order, the fences stop the compiler from reordering them.
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
     __shared__ __attribute__((aligned(16))) float lds[kWaveFloats];
     const int half = (int)threadIdx.x >> 5, hl = (int)threadIdx.x & 31;
     float *tile = lds + half * 576;               // the granule's 576 lines, natural order
-    float *S = lds + kTileFloats + half * (18 * kSStride);  // S[slot][32]: dct32 transpose
+    float *S = lds + kSBase + half * (18 * kSStride);  // S[slot][32]: dct32 transpose
     cf32p mc = as_const(tb.mp3_consts);
 
     const unsigned item = blockIdx.x * 2u + (unsigned)half;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
 
     // Window coefficients of sample index i = hl: D[64j + i] (j = 0..7), D[64j + 32 + i], as one 64-byte LDS row
     // per i.  They are only live during the window pass, where they are re-read from LDS (4 x b128) every granule.
-    float *dwt = lds + kTileFloats + 2 * 18 * kSStride;
+    float *dwt = lds + kSBase + 2 * 18 * kSStride;
     if (half == 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
             }
             if (emit) (pcm + (chain_base + (size_t)g) * 576)[32 * b + hl] = acc;
         }
+        wave_sync();  // the window pass has read S; the next round's tile goes to the same LDS
         // ---- slide the history: slots 2..17 of this granule become slots -16..-1
         if (need_hist) {
 #pragma unroll
