@@ -5,13 +5,13 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-for w in aac mp3 vorbis flac; do
+for w in aac mp3 vorbis flac alac; do
   timeout 300 python bench.py --workload $w --steps 20 --warmup 3 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
   echo "bench $w rc=$?"; tail -n 1 $OUT/bench_$w.json | cut -c1-400
 done
 REPO=$PWD
 cd /tmp
-for w in aac mp3 vorbis flac; do
+for w in aac mp3 vorbis flac alac; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_$w -o $w -- python $REPO/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_${TAG}_$w.log 2>&1
   echo "rocprof stats $w rc=$?"
 done
