@@ -130,6 +130,15 @@ int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_
                        int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
                        size_t granules_per_chain);
 
+/* synthesis::synthesis alone (synthesis.rs:158-336) as Layer I and Layer II use it: n_frames = 12
+ * (layer1/mod.rs:193) or 36 (layer2/mod.rs:383) time slots per packet and channel.  in[chain][packet][32 * n_frames]
+ * sub-band-major (in[n_frames * i + b], synthesis.rs:168-170); pcm[chain][packet][32 * n_frames]; state per chain:
+ * vvec_io[16][64], vfront_io (the reference's SynthesisState).  Other n_frames: SYMACCEL_ERR_UNSUPPORTED. */
+int symaccel_mpa_polyphase_device(symaccel_ctx *ctx, int n_frames, const float *d_in, float *d_vvec_io,
+                                  int32_t *d_vfront_io, float *d_pcm, size_t n_chains, size_t packets_per_chain);
+int symaccel_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *h_in, float *h_vvec_io,
+                           int32_t *h_vfront_io, float *h_pcm, size_t n_chains, size_t packets_per_chain);
+
 /* --------------------------------------------------------------------------------- Vorbis */
 
 /* DspChannel::synth for every channel of every block (symphonia-codec-vorbis/src/dsp.rs:68-126,

@@ -209,6 +209,13 @@ inline void synthesize_batch(Context &ctx, int sample_rate_idx, const float *xr,
           ctx.raw());
 }
 
+// synthesis(state, n_frames, in_samples, out) (synthesis.rs:158-336) as Layer I (n_frames 12) and Layer II (36) call it
+inline void synthesis(Context &ctx, SynthesisState &state, std::size_t n_frames, const float *in_samples, std::size_t in_len,
+                      float *out, std::size_t out_len) {
+    if (in_len != 32 * n_frames || out_len < 32 * n_frames) throw std::invalid_argument("synthesis: slice lengths (synthesis.rs:162)");
+    check(symaccel_mpa_polyphase(ctx.raw(), (int)n_frames, in_samples, state.v_vec.data(), &state.v_front, out, 1, 1), ctx.raw());
+}
+
 }  // namespace mp3
 
 namespace vorbis {

@@ -206,6 +206,35 @@ class Mp3Synthesis:
         return res, ov, vv, vf
 
 
+class MpaPolyphase:
+    """synthesis::synthesis for Layer I (n_frames 12) / Layer II (n_frames 36) (synthesis.rs:158-336)."""
+
+    def __init__(self, ctx, n_frames):
+        if n_frames not in (12, 36):
+            raise ValueError("n_frames must be 12 (Layer I) or 36 (Layer II)")
+        self.ctx, self.n_frames = ctx, int(n_frames)
+
+    def synth(self, samples, v_vec, v_front, pcm=None):
+        """samples[chains, packets, 32 * n_frames] sub-band-major; state v_vec[chains, 1024], v_front[chains] i32.
+        numpy: returns (pcm, v_vec, v_front); torch: state updated in place, returns pcm."""
+        d = self.ctx.lib.dll
+        nch, npk = int(samples.shape[0]), int(samples.shape[1])
+        assert samples.shape[2] == 32 * self.n_frames
+        if _is_torch(samples):
+            import torch
+            if pcm is None:
+                pcm = torch.empty_like(samples)
+            self.ctx._call(d.symaccel_mpa_polyphase_device, self.n_frames, _ptr(samples), _ptr(v_vec), _ptr(v_front), _ptr(pcm),
+                           nch, npk)
+            return pcm
+        x = _np(samples, np.float32)
+        vv = np.array(v_vec, dtype=np.float32, copy=True, order="C")
+        vf = np.array(v_front, dtype=np.int32, copy=True, order="C")
+        res = np.empty_like(x)
+        self.ctx._call(d.symaccel_mpa_polyphase, self.n_frames, _ptr(x), _ptr(vv), _ptr(vf), _ptr(res), nch, npk)
+        return res, vv, vf
+
+
 class VorbisDsp:
     """dsp::Dsp / DspChannel::synth (vorbis/dsp.rs:12-145) for chains of mixed-size blocks."""
 

@@ -607,6 +607,45 @@ int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, i
 
 // ---- tables -------------------------------------------------------------------------------
 
+int symaccel_mpa_polyphase_device(symaccel_ctx *ctx, int n_frames, const float *d_in, float *d_vvec_io,
+                                  int32_t *d_vfront_io, float *d_pcm, size_t n_chains, size_t packets_per_chain) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_frames != 12 && n_frames != 36) return SYMACCEL_ERR_UNSUPPORTED;  // Layer I / Layer II (Layer III: mp3_synth)
+    if (n_chains == 0 || packets_per_chain == 0) return SYMACCEL_OK;
+    if (!d_in || !d_vvec_io || !d_vfront_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    const size_t vv_bytes = n_chains * 1024 * 4, vf_bytes = n_chains * 4;
+    void *scratch = nullptr;
+    SYM_TRY(ctx_scratch(ctx, vv_bytes + vf_bytes, &scratch));
+    float *vv_out = (float *)scratch;
+    int32_t *vf_out = (int32_t *)(vv_out + n_chains * 1024);
+    SYM_TRY(launch_mpa_polyphase(ctx, n_frames, d_in, d_vvec_io, d_vfront_io, vv_out, vf_out, d_pcm, n_chains,
+                                 packets_per_chain));
+    SYM_TRY(launch_state_copy(ctx, d_vvec_io, vv_out, vv_bytes, d_vfront_io, vf_out, vf_bytes, nullptr, nullptr, 0));
+    return SYMACCEL_OK;
+}
+
+int symaccel_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *h_in, float *h_vvec_io, int32_t *h_vfront_io,
+                           float *h_pcm, size_t n_chains, size_t packets_per_chain) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_frames != 12 && n_frames != 36) return SYMACCEL_ERR_UNSUPPORTED;
+    if (n_chains == 0 || packets_per_chain == 0) return SYMACCEL_OK;
+    if (!h_in || !h_vvec_io || !h_vfront_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = n_chains * packets_per_chain * 32 * (size_t)n_frames * 4;
+    DevBuf in(ctx), vv(ctx), vf(ctx), pcm(ctx);
+    SYM_TRY(in.from_host(h_in, bytes));
+    SYM_TRY(vv.from_host(h_vvec_io, n_chains * 1024 * 4));
+    SYM_TRY(vf.from_host(h_vfront_io, n_chains * 4));
+    SYM_TRY(pcm.alloc(bytes));
+    SYM_TRY(symaccel_mpa_polyphase_device(ctx, n_frames, (const float *)in.p, (float *)vv.p, (int32_t *)vf.p, (float *)pcm.p,
+                                          n_chains, packets_per_chain));
+    SYM_TRY(pcm.to_host(h_pcm, bytes));
+    SYM_TRY(vv.to_host(h_vvec_io, n_chains * 1024 * 4));
+    SYM_TRY(vf.to_host(h_vfront_io, n_chains * 4));
+    return symaccel_sync(ctx);
+}
+
 int symaccel_alac_predict_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc,
                                  const int32_t *d_coeffs, size_t n_blocks, size_t blocksize) {
     if (!ctx || blocksize > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;

@@ -148,6 +148,9 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
                                size_t count);
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *d_setup, int n_posts, int multiplier,
                          const uint32_t *d_y, uint32_t n, float *d_floor, size_t count);
+int launch_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *d_in, const float *d_vvec_in,
+                         const int32_t *d_vfront_in, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm, size_t n_chains,
+                         size_t packets_per_chain);
 int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc, const int32_t *d_coeffs,
                         size_t n_blocks, size_t blocksize);
 int launch_alac_mid_side(symaccel_ctx *ctx, const int32_t *d_weight, const uint8_t *d_shift, int32_t *d_ch0, int32_t *d_ch1,
