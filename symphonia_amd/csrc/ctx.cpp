@@ -538,11 +538,11 @@ int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int
     }
     for (int i = 1; i < n_posts; ++i)  // render_line divides by (x1 - x0): equal x would panic in the reference
         if (x_list[setup[195 + i]] == x_list[setup[195 + i - 1]]) return SYMACCEL_ERR_INVALID_ARG;
-    void *scratch = nullptr;
-    SYM_TRY(ctx_scratch(ctx, sizeof setup, &scratch));
-    SYM_GPU(ctx, hipMemcpyAsync(scratch, setup, sizeof setup, hipMemcpyHostToDevice, ctx->stream));
-    SYM_GPU(ctx, hipStreamSynchronize(ctx->stream));  // `setup` is a stack buffer
-    return launch_vorbis_floor1(ctx, (const uint32_t *)scratch, n_posts, multiplier, d_y, n, d_floor, count);
+    for (int i = 0; i < n_posts; ++i)
+        if (x_list[i] > 0xffffu) return SYMACCEL_ERR_INVALID_ARG;  // floor1_X values have at most 15 bits (rangebits)
+    if (n > (1u << 16)) return SYMACCEL_ERR_INVALID_ARG;
+    // the derived tables travel as a kernel argument: no staging copy, no stream synchronisation
+    return launch_vorbis_floor1(ctx, setup, n_posts, multiplier, d_y, n, d_floor, count);
 }
 
 // ---- FLAC ---------------------------------------------------------------------------------

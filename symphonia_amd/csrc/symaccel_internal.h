@@ -146,7 +146,7 @@ int launch_vorbis_coupling(symaccel_ctx *ctx, float *d_mag, float *d_ang, size_t
 int launch_vorbis_dot(symaccel_ctx *ctx, float *d_floor, const float *d_residue, size_t total);
 int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d_planar, int n_ch, size_t n2,
                                size_t count);
-int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *d_setup, int n_posts, int multiplier,
+int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier,
                          const uint32_t *d_y, uint32_t n, float *d_floor, size_t count);
 int launch_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *d_in, const float *d_vvec_in,
                          const int32_t *d_vfront_in, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm, size_t n_chains,

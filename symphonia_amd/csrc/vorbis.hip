@@ -227,86 +227,133 @@ __device__ __forceinline__ int32_t floor1_render_point(uint32_t x0, int32_t y0, 
     return dy < 0 ? y0 - (int32_t)off : y0 + (int32_t)off;
 }
 
-// One workgroup per channel-block: step 1 is a short serial recurrence (<= 65 posts, lane 0), step 2
-// renders the line segments in parallel, one thread per x: the integer DDA of render_line
-// (floor.rs:785-825) has the closed form  y(x) = y0 + base*t + sign*floor(ady*t / adx),  t = x - x0.
-__global__ __launch_bounds__(256) void vorbis_floor1_kernel(const uint32_t *__restrict__ setup, int n_posts,
-                                                            int multiplier, const uint32_t *__restrict__ yv,
-                                                            uint32_t n, float *__restrict__ floor_out,
-                                                            const float *__restrict__ db) {
-    __shared__ int32_t final_y[65];
-    __shared__ int32_t flag[65];
-    __shared__ uint32_t seg_x[66];
-    __shared__ int32_t seg_y[66];
-    __shared__ int n_seg;
-    const uint32_t *xl = setup, *lo_n = setup + 65, *hi_n = setup + 130, *order = setup + 195;
-    const uint32_t *y = yv + (size_t)blockIdx.x * (size_t)n_posts;
-    float *out = floor_out + (size_t)blockIdx.x * (size_t)n;
-    if (threadIdx.x == 0) {
-        // synthesis_step1 (floor.rs:568-625)
-        const int32_t range = multiplier == 1 ? 256 : multiplier == 2 ? 128 : multiplier == 3 ? 86 : 64;
-        flag[0] = flag[1] = 1;
-        final_y[0] = (int32_t)y[0];
-        final_y[1] = (int32_t)y[1];
-        for (int i = 2; i < n_posts; ++i) {
-            const int lo = (int)lo_n[i], hi = (int)hi_n[i];
-            const int32_t predicted = floor1_render_point(xl[lo], final_y[lo], xl[hi], final_y[hi], xl[i]);
-            const int32_t val = (int32_t)y[i];
-            const int32_t highroom = range - predicted, lowroom = predicted;
-            if (val != 0) {
-                const int32_t room = 2 * (highroom < lowroom ? highroom : lowroom);
-                flag[lo] = flag[hi] = flag[i] = 1;
-                if (val >= room)
-                    final_y[i] = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
-                else
-                    final_y[i] = (val & 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
-            } else {
-                flag[i] = 0;
-                final_y[i] = predicted;
-            }
+// Floor-1 curve synthesis (floor.rs:568-653, 776-825).  A wavefront takes 64 channel-blocks:
+//   step 1 (the post-value recurrence over <= 65 posts, with the setup's neighbour tables) runs one LANE per block
+//   -- the post index, neighbours and x values are wave-uniform (kernel arguments, scalar), only the y values differ;
+//   step 2 builds each block's list of line end points (x-sorted, flagged posts only) in LDS;
+//   rendering takes the blocks one after the other with all 64 lanes on consecutive x (coalesced 256-byte stores):
+//   a lane keeps the segment that contains its x and walks forward through the list (entries are fetched from
+//   the lane that holds them with ds_bpermute); the integer DDA of render_line (floor.rs:785-825) has the closed form
+//       y(x) = y0 + base * t + sign * floor(ady * t / adx),   t = x - x0,   ady = |dy| - |base| * adx.
+struct Floor1Setup {  // per floor configuration, derived on the host like the setup parser does (floor.rs:540-555)
+    uint16_t x[65];
+    uint8_t lo[65], hi[65], order[65];
+};
+
+constexpr int kF1Stride = 65;  // LDS row stride of the per-block lists [entry][block]: conflict-free both ways
+
+__global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n_posts, int multiplier,
+                                                           const uint32_t *__restrict__ yv, uint32_t n,
+                                                           float *__restrict__ floor_out, const float *__restrict__ db,
+                                                           size_t count) {
+    __shared__ int32_t fy[65 * 64];               // final_y[post][lane]
+    __shared__ uint32_t seg[67 * kF1Stride];      // first the y values [post][block], then the points (x << 8 | y)
+    __shared__ float dbl[256];
+    const int lane = (int)threadIdx.x;
+    const size_t blk0 = (size_t)blockIdx.x * 64;
+    const int nb = (int)(count - blk0 < 64 ? count - blk0 : 64);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dbl[lane + 64 * e] = db[lane + 64 * e];
+    // the y rows of the 64 blocks are contiguous: coalesced load, transposed into LDS
+    {
+        const uint32_t *src = yv + blk0 * (size_t)n_posts;
+        const int total = nb * n_posts;
+        for (int e = lane; e < total; e += 64) seg[(e % n_posts) * kF1Stride + (e / n_posts)] = src[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- synthesis_step1 (floor.rs:568-625): lane = block
+    const int32_t range = multiplier == 1 ? 256 : multiplier == 2 ? 128 : multiplier == 3 ? 86 : 64;
+    uint32_t flag[3] = {3u, 0u, 0u};  // floor_step2_flag as bits; posts 0 and 1 are always used
+    fy[0 * 64 + lane] = (int32_t)seg[0 * kF1Stride + lane];
+    fy[1 * 64 + lane] = (int32_t)seg[1 * kF1Stride + lane];
+    for (int i = 2; i < n_posts; ++i) {
+        const int lo = st.lo[i], hi = st.hi[i];
+        const int32_t predicted = floor1_render_point(st.x[lo], fy[lo * 64 + lane], st.x[hi], fy[hi * 64 + lane], st.x[i]);
+        const int32_t val = (int32_t)seg[i * kF1Stride + lane];
+        const int32_t highroom = range - predicted, lowroom = predicted;
+        int32_t fin = predicted;
+        if (val != 0) {
+            const int32_t room = 2 * (highroom < lowroom ? highroom : lowroom);
+            flag[lo >> 5] |= 1u << (lo & 31);
+            flag[hi >> 5] |= 1u << (hi & 31);
+            flag[i >> 5] |= 1u << (i & 31);
+            if (val >= room)
+                fin = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
+            else
+                fin = (val & 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
         }
-        // synthesis_step2 (floor.rs:627-653): list of line end points in x order
-        int32_t ly = final_y[order[0]] * multiplier;
+        fy[i * 64 + lane] = fin;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every lane has consumed its y values: `seg` becomes the point lists
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- synthesis_step2 (floor.rs:627-653), first half: the x-sorted list of line end points of this lane's block
+    int ns = 0;
+    {
+        int32_t ly = fy[st.order[0] * 64 + lane] * multiplier;
         ly = ly < 0 ? 0 : (ly > 255 ? 255 : ly);
-        int ns = 0;
-        seg_x[0] = 0;
-        seg_y[0] = ly;
+        seg[0 * kF1Stride + lane] = (uint32_t)ly;  // (x = 0, y = ly)
         uint32_t hx = 0;
         int32_t hy = 0;
         for (int k = 1; k < n_posts; ++k) {
-            const int i = (int)order[k];
-            if (flag[i]) {
-                hy = final_y[i] * multiplier;
+            const int i = st.order[k];
+            if ((flag[i >> 5] >> (i & 31)) & 1u) {
+                hy = fy[i * 64 + lane] * multiplier;
                 hy = hy < 0 ? 0 : (hy > 255 ? 255 : hy);
-                hx = xl[i];
+                hx = st.x[i];
                 ++ns;
-                seg_x[ns] = hx;
-                seg_y[ns] = hy;
+                seg[ns * kF1Stride + lane] = (hx << 8) | (uint32_t)hy;
             }
         }
         if (hx < n) {  // flat tail (floor.rs:650-652)
             ++ns;
-            seg_x[ns] = n;
-            seg_y[ns] = hy;
+            seg[ns * kF1Stride + lane] = (n << 8) | (uint32_t)hy;
         }
-        n_seg = ns;
     }
-    __syncthreads();
-    const int ns = n_seg;
-    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) {
-        // the segment with seg_x[s] <= x < seg_x[s+1]; render_line(x0..x1) writes [x0, min(n, x1))
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- render_line for every segment (floor.rs:785-825), block after block, lane = x
+    for (int b = 0; b < nb; ++b) {
+        const int nsb = __shfl(ns, b);  // points 0 .. nsb of block b
+        // lane k holds points k and 64 + k of the block (beyond the list: x = "infinity")
+        const uint32_t e_lo = lane <= nsb ? seg[lane * kF1Stride + b] : 0xffffffffu;
+        const uint32_t e_hi = 64 + lane <= nsb ? seg[(64 + lane) * kF1Stride + b] : 0xffffffffu;
+        auto point = [&](int k) -> uint32_t {  // k may differ per lane
+            const uint32_t a = (uint32_t)__shfl((int)e_lo, k & 63), c = (uint32_t)__shfl((int)e_hi, k & 63);
+            return k < 64 ? a : c;
+        };
+        float *out = floor_out + (blk0 + (size_t)b) * (size_t)n;
         int s = 0;
-        while (s + 1 < ns && seg_x[s + 1] <= x) ++s;
-        if (x >= seg_x[ns]) continue;  // beyond the last rendered point: left untouched like the reference
-        const uint32_t x0 = seg_x[s], x1 = seg_x[s + 1];
-        const int32_t y0 = seg_y[s], y1 = seg_y[s + 1];
-        const int32_t dy = y1 - y0, adx = (int32_t)(x1 - x0);
-        const int32_t base = dy / adx;
-        const int32_t ady = (dy < 0 ? -dy : dy) - (base < 0 ? -base : base) * adx;
-        const int32_t t = (int32_t)(x - x0);
-        const int32_t steps = (int32_t)(((int64_t)ady * t) / adx);  // number of err >= adx events in t steps
-        const int32_t yy = y0 + base * t + (dy < 0 ? -steps : steps);
-        out[x] = db[yy];
+        uint32_t cur = point(0), nxt = point(1);
+        for (uint32_t x = (uint32_t)lane; x < ((n + 63u) & ~63u); x += 64) {
+            // advance to the segment with x_s <= x < x_{s+1}
+            while (__any((nxt >> 8) <= x && s + 1 < nsb)) {
+                const bool step = (nxt >> 8) <= x && s + 1 < nsb;
+                const uint32_t far = point(s + 2);
+                if (step) {
+                    cur = nxt;
+                    nxt = far;
+                    ++s;
+                }
+            }
+            if (x < n && x < (nxt >> 8)) {
+                const uint32_t x0 = cur >> 8, x1 = nxt >> 8;
+                const int32_t y0 = (int32_t)(cur & 255u), y1 = (int32_t)(nxt & 255u);
+                const int32_t dy = y1 - y0, adx = (int32_t)(x1 - x0);
+                const int32_t base = dy / adx;
+                const int32_t ady = (dy < 0 ? -dy : dy) - (base < 0 ? -base : base) * adx;
+                const int32_t t = (int32_t)(x - x0);
+                const int32_t steps = (int32_t)((uint32_t)(ady * t) / (uint32_t)adx);  // err >= adx events in t steps
+                const int32_t yy = y0 + base * t + (dy < 0 ? -steps : steps);
+                out[x] = dbl[yy];
+            }
+        }
     }
 }
 
@@ -387,11 +434,19 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
     return SYMACCEL_OK;
 }
 
-int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *d_setup, int n_posts, int multiplier, const uint32_t *d_y,
+int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier, const uint32_t *d_y,
                          uint32_t n, float *d_floor, size_t count) {
-    if (count > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(vorbis_floor1_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_setup, n_posts,
-                       multiplier, d_y, n, d_floor, ctx->dev.vorbis_floor1_db);
+    const size_t grid = (count + 63) / 64;
+    if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    Floor1Setup st{};  // passed by value: the kernel reads it with scalar loads (wave-uniform indices)
+    for (int i = 0; i < n_posts; ++i) {
+        st.x[i] = (uint16_t)h_setup[i];
+        st.lo[i] = (uint8_t)h_setup[65 + i];
+        st.hi[i] = (uint8_t)h_setup[130 + i];
+        st.order[i] = (uint8_t)h_setup[195 + i];
+    }
+    hipLaunchKernelGGL(vorbis_floor1_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, st, n_posts, multiplier, d_y, n,
+                       d_floor, ctx->dev.vorbis_floor1_db, count);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -133,6 +133,7 @@ static inline unsigned long long __ballot(int pred) {
     __builtin_amdgcn_wave_barrier();
     return m;
 }
+static inline int __any(int pred) { return __ballot(pred) != 0ull; }
 static inline int __shfl(int v, int src_lane, int width = 64) {
     (void)width;
     return __builtin_amdgcn_ds_bpermute(src_lane * 4, v);

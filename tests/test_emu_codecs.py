@@ -150,12 +150,12 @@ def test_emu_vorbis_helpers(emu_ctx):
 def test_emu_vorbis_floor1(emu_ctx):
     rng = np.random.default_rng(6)
     v = VorbisDsp(emu_ctx, 8, 11)
-    for n, n_posts, mult in ((1024, 30, 2), (128, 9, 1), (1024, 65, 4), (128, 2, 3)):
+    for n, n_posts, mult, count, p_zero in ((1024, 30, 2, 7, 0.3), (128, 9, 1, 7, 0.3), (1024, 65, 4, 7, 0.3), (128, 2, 3, 7, 0.3),
+                                             (2048, 65, 1, 70, 0.02), (32, 5, 2, 130, 0.5), (4096, 40, 2, 3, 0.9)):
         xs = [0, n] + rng.permutation(np.arange(1, n))[:n_posts - 2].tolist()
         rr = [256, 128, 86, 64][mult - 1]
-        count = 7
         ys = rng.integers(0, rr, size=(count, n_posts)).astype(np.uint32)
-        ys[rng.random((count, n_posts)) < 0.3] = 0
+        ys[rng.random((count, n_posts)) < p_zero] = 0
         out = np.zeros((count, n), np.float32)
         v.floor1(xs, mult, ys, n, out, count)
         want = np.stack([oracle.vorbis_floor1(xs, y, mult, n) for y in ys])

@@ -329,13 +329,14 @@ def test_vorbis_helpers_parity(ctx):
     planar = torch.empty((3, 6, 1024), dtype=torch.float32, device="cuda")
     v.deinterleave2(dev(t2), planar, 6, 1024, 3)
     assert_parity(host(planar), np.stack([oracle.vorbis_deinterleave2(t, 6) for t in t2]), "deinterleave")
-    for nn, n_posts, mult in ((1024, 40, 2), (128, 12, 1), (1024, 65, 4)):
+    for nn, n_posts, mult, cnt, p_zero in ((1024, 40, 2, 50, 0.3), (128, 12, 1, 50, 0.3), (1024, 65, 4, 50, 0.3),
+                                           (2048, 65, 1, 333, 0.02), (32, 5, 2, 1000, 0.5), (4096, 33, 3, 65, 0.9)):
         xs = [0, nn] + rng.permutation(np.arange(1, nn))[:n_posts - 2].tolist()
         rr = [256, 128, 86, 64][mult - 1]
-        ys = rng.integers(0, rr, size=(50, n_posts)).astype(np.uint32)
-        ys[rng.random((50, n_posts)) < 0.3] = 0
-        out = torch.zeros((50, nn), dtype=torch.float32, device="cuda")
-        v.floor1(xs, mult, dev(ys), nn, out, 50)
+        ys = rng.integers(0, rr, size=(cnt, n_posts)).astype(np.uint32)
+        ys[rng.random((cnt, n_posts)) < p_zero] = 0
+        out = torch.zeros((cnt, nn), dtype=torch.float32, device="cuda")
+        v.floor1(xs, mult, dev(ys), nn, out, cnt)
         assert_parity(host(out), np.stack([oracle.vorbis_floor1(xs, y, mult, nn) for y in ys]), "floor1")
 
 

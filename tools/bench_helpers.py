@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Throughput of the streaming helper kernels (SURVEY 8a rows a22, a23, a27 and the ALAC mid/side): GB/s of algorithmic
+traffic, HIP events around 10 launches each.  Development tool: python tools/bench_helpers.py (on the GPU box)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import symphonia_amd as sa  # noqa: E402
+
+
+def timeit(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps / 1e3
+
+
+def main():
+    ctx = sa.Context(0)
+    ctx.use_torch_stream()
+    v = sa.VorbisDsp(ctx, 8, 11)
+    n, ch, blocks = 1024, 8, 32768  # 32768 blocks x 8 channels x 1024 lines = 1 GiB of residue
+    res = torch.randn((blocks * ch, n), device="cuda")
+    flo = torch.randn(blocks * ch * n, device="cuda")
+    out = {}
+    t = timeit(lambda: v.dot_product(flo, res, blocks * ch * n))
+    out["vorbis dot product (floor *= residue)"] = 3 * flo.numel() * 4 / t
+    pairs_m, pairs_a = list(range(0, 64, 2)), list(range(1, 64, 2))
+    big = torch.randn((64, 1 << 22), device="cuda")
+    t = timeit(lambda: v.inverse_coupling(big, 1 << 22, pairs_m, pairs_a))
+    out["vorbis inverse coupling (32 pairs x 4 Mi lines)"] = 4 * big.numel() * 4 / 2 / t * 1.0
+    t2 = torch.randn((4096, ch * n), device="cuda")
+    planar = torch.empty((4096, ch, n), device="cuda")
+    t = timeit(lambda: v.deinterleave2(t2, planar, ch, n, 4096))
+    out["vorbis residue type-2 de-interleave"] = 2 * t2.numel() * 4 / t
+    xs = [0, n] + list(range(16, 1008, 16))
+    ys = torch.randint(0, 128, (262144, len(xs)), device="cuda", dtype=torch.int32)  # same bits as u32 for values < 2^31
+    fl = torch.empty((262144, n), device="cuda")
+    t = timeit(lambda: v.floor1(xs, 2, ys, n, fl, 262144))
+    out["vorbis floor-1 render (64 posts -> 1024 lines)"] = fl.numel() * 4 / t
+    fp = sa.FlacPredictor(ctx)
+    a = torch.randint(-1000, 1000, (65536, 4096), device="cuda", dtype=torch.int32)
+    b = torch.randint(-1000, 1000, (65536, 4096), device="cuda", dtype=torch.int32)
+    mode = torch.randint(0, 4, (65536,), device="cuda", dtype=torch.uint8)
+    t = timeit(lambda: fp.decorrelate(mode, a, b, 4096, 8))
+    out["flac decorrelate + shift (65536 pairs x 4096)"] = 4 * a.numel() * 4 / t
+    ap = sa.AlacPredictor(ctx)
+    w = torch.randint(1, 4, (65536,), device="cuda", dtype=torch.int32)
+    sh = torch.full((65536,), 2, device="cuda", dtype=torch.uint8)
+    t = timeit(lambda: ap.mid_side(w, sh, a, b))
+    out["alac mid/side (65536 pairs x 4096)"] = 4 * a.numel() * 4 / t
+    for k, gbps in out.items():
+        print("%-52s %8.1f GB/s  (%.1f %% of 8 TB/s)" % (k, gbps / 1e9, gbps / 8e12 * 100))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

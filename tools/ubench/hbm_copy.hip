@@ -25,6 +25,24 @@ __global__ void copy_frames(const float4 *__restrict__ in, float4 *__restrict__ 
         for (int q = 0; q < 4; ++q) d[lane + 64 * q] = v[q];
     }
 }
+// the same, with each wavefront's run of frames starting at a staggered offset (tests channel hot-spotting when all
+// wavefronts advance in lockstep through addresses that differ by a large power of two)
+__global__ void copy_frames_staggered(const float4 *__restrict__ in, float4 *__restrict__ out, size_t frames, int per_wave,
+                                      int stagger) {
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const size_t start = (wave * per_wave + (wave * 5 % stagger)) % frames;
+    for (int f = 0; f < per_wave; ++f) {
+        const size_t fr = (start + f) % frames;
+        const float4 *s = in + fr * 256;
+        float4 *d = out + fr * 256;
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = s[lane + 64 * q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[lane + 64 * q] = v[q];
+    }
+}
 __global__ void read_k(const float4 *__restrict__ in, float *out, size_t n) {
     float acc = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -76,6 +94,12 @@ int main() {
         const unsigned blocks = (unsigned)((waves + 3) / 4);
         float ms = time_ms([&] { hipLaunchKernelGGL(copy_frames, dim3(blocks), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, frames, per_wave); }, 10);
         printf("copy 4 KiB frames, %2d consecutive frames per wavefront (%u blocks)  %.3f ms  %.2f TB/s\n", per_wave, blocks, ms, 2.0 * bytes / ms / 1e9);
+    }
+    for (int stagger : {1, 7, 16, 61}) {
+        const int per_wave = 64;
+        const unsigned blocks = (unsigned)((frames / per_wave + 3) / 4);
+        float msx = time_ms([&] { hipLaunchKernelGGL(copy_frames_staggered, dim3(blocks), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, frames, per_wave, stagger); }, 10);
+        printf("copy 4 KiB frames, 64 per wavefront, start staggered mod %2d  %.3f ms  %.2f TB/s\n", stagger, msx, 2.0 * bytes / msx / 1e9);
     }
     float ms = time_ms([&] { hipLaunchKernelGGL(read_k, dim3(8192), dim3(256), 0, 0, (const float4 *)a, (float *)b, n4); }, 10);
     printf("read-only  float4  %.3f ms  %.2f TB/s\n", ms, 1.0 * bytes / ms / 1e9);
