@@ -246,8 +246,10 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
                                                            const uint32_t *__restrict__ yv, uint32_t n,
                                                            float *__restrict__ floor_out, const float *__restrict__ db,
                                                            size_t count) {
-    __shared__ int32_t fy[65 * 64];               // final_y[post][lane]
-    __shared__ uint32_t seg[67 * kF1Stride];      // first the y values [post][block], then the points (x << 8 | y)
+    // 22 KiB of LDS per wavefront (7 wavefronts per CU): 16-bit tables
+    __shared__ int16_t fy[65 * 64];               // final_y[post][lane] (|final_y| < 2^9)
+    __shared__ uint16_t segx[67 * kF1Stride];     // first the y values [post][block], then the points' x
+    __shared__ uint8_t segy[67 * kF1Stride];      //                                               ... and y (0..255)
     __shared__ float dbl[256];
     const int lane = (int)threadIdx.x;
     const size_t blk0 = (size_t)blockIdx.x * 64;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
     {
         const uint32_t *src = yv + blk0 * (size_t)n_posts;
         const int total = nb * n_posts;
-        for (int e = lane; e < total; e += 64) seg[(e % n_posts) * kF1Stride + (e / n_posts)] = src[e];
+        for (int e = lane; e < total; e += 64) segx[(e % n_posts) * kF1Stride + (e / n_posts)] = (uint16_t)src[e];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -267,12 +269,12 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
     // ---- synthesis_step1 (floor.rs:568-625): lane = block
     const int32_t range = multiplier == 1 ? 256 : multiplier == 2 ? 128 : multiplier == 3 ? 86 : 64;
     uint32_t flag[3] = {3u, 0u, 0u};  // floor_step2_flag as bits; posts 0 and 1 are always used
-    fy[0 * 64 + lane] = (int32_t)seg[0 * kF1Stride + lane];
-    fy[1 * 64 + lane] = (int32_t)seg[1 * kF1Stride + lane];
+    fy[0 * 64 + lane] = (int16_t)segx[0 * kF1Stride + lane];
+    fy[1 * 64 + lane] = (int16_t)segx[1 * kF1Stride + lane];
     for (int i = 2; i < n_posts; ++i) {
         const int lo = st.lo[i], hi = st.hi[i];
         const int32_t predicted = floor1_render_point(st.x[lo], fy[lo * 64 + lane], st.x[hi], fy[hi * 64 + lane], st.x[i]);
-        const int32_t val = (int32_t)seg[i * kF1Stride + lane];
+        const int32_t val = (int32_t)segx[i * kF1Stride + lane];
         const int32_t highroom = range - predicted, lowroom = predicted;
         int32_t fin = predicted;
         if (val != 0) {
@@ -285,10 +287,10 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
             else
                 fin = (val & 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
         }
-        fy[i * 64 + lane] = fin;
+        fy[i * 64 + lane] = (int16_t)fin;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // every lane has consumed its y values: `seg` becomes the point lists
+    __builtin_amdgcn_wave_barrier();  // every lane has consumed its y values: segx / segy become the point lists
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- synthesis_step2 (floor.rs:627-653), first half: the x-sorted list of line end points of this lane's block
@@ -296,7 +298,8 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
     {
         int32_t ly = fy[st.order[0] * 64 + lane] * multiplier;
         ly = ly < 0 ? 0 : (ly > 255 ? 255 : ly);
-        seg[0 * kF1Stride + lane] = (uint32_t)ly;  // (x = 0, y = ly)
+        segx[0 * kF1Stride + lane] = 0;  // (x = 0, y = ly)
+        segy[0 * kF1Stride + lane] = (uint8_t)ly;
         uint32_t hx = 0;
         int32_t hy = 0;
         for (int k = 1; k < n_posts; ++k) {
@@ -306,12 +309,14 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
                 hy = hy < 0 ? 0 : (hy > 255 ? 255 : hy);
                 hx = st.x[i];
                 ++ns;
-                seg[ns * kF1Stride + lane] = (hx << 8) | (uint32_t)hy;
+                segx[ns * kF1Stride + lane] = (uint16_t)hx;
+                segy[ns * kF1Stride + lane] = (uint8_t)hy;
             }
         }
         if (hx < n) {  // flat tail (floor.rs:650-652)
             ++ns;
-            seg[ns * kF1Stride + lane] = (n << 8) | (uint32_t)hy;
+            segx[ns * kF1Stride + lane] = (uint16_t)n;
+            segy[ns * kF1Stride + lane] = (uint8_t)hy;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -321,9 +326,10 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
     // ---- render_line for every segment (floor.rs:785-825), block after block, lane = x
     for (int b = 0; b < nb; ++b) {
         const int nsb = __shfl(ns, b);  // points 0 .. nsb of block b
-        // lane k holds points k and 64 + k of the block (beyond the list: x = "infinity")
-        const uint32_t e_lo = lane <= nsb ? seg[lane * kF1Stride + b] : 0xffffffffu;
-        const uint32_t e_hi = 64 + lane <= nsb ? seg[(64 + lane) * kF1Stride + b] : 0xffffffffu;
+        // lane k holds points k and 64 + k of the block as (x << 8 | y) (beyond the list: x = "infinity")
+        const uint32_t e_lo = lane <= nsb ? ((uint32_t)segx[lane * kF1Stride + b] << 8) | segy[lane * kF1Stride + b] : 0xffffffffu;
+        const uint32_t e_hi =
+            64 + lane <= nsb ? ((uint32_t)segx[(64 + lane) * kF1Stride + b] << 8) | segy[(64 + lane) * kF1Stride + b] : 0xffffffffu;
         auto point = [&](int k) -> uint32_t {  // k may differ per lane
             const uint32_t a = (uint32_t)__shfl((int)e_lo, k & 63), c = (uint32_t)__shfl((int)e_hi, k & 63);
             return k < 64 ? a : c;
@@ -331,6 +337,10 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
         float *out = floor_out + (blk0 + (size_t)b) * (size_t)n;
         int s = 0;
         uint32_t cur = point(0), nxt = point(1);
+        // per-segment constants of the DDA, recomputed only when the lane moves to another segment
+        int32_t x0 = 0, y0 = 0, base = 0, ady = 0, adx = 1, sgn = 1;
+        float inv = 1.0f;
+        bool fresh = true;
         for (uint32_t x = (uint32_t)lane; x < ((n + 63u) & ~63u); x += 64) {
             // advance to the segment with x_s <= x < x_{s+1}
             while (__any((nxt >> 8) <= x && s + 1 < nsb)) {
@@ -340,18 +350,32 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
                     cur = nxt;
                     nxt = far;
                     ++s;
+                    fresh = true;
                 }
             }
+            if (fresh) {
+                x0 = (int32_t)(cur >> 8);
+                y0 = (int32_t)(cur & 255u);
+                const int32_t dy = (int32_t)(nxt & 255u) - y0;
+                adx = (int32_t)(nxt >> 8) - x0;
+                adx = adx > 0 ? adx : 1;
+                base = dy / adx;
+                ady = (dy < 0 ? -dy : dy) - (base < 0 ? -base : base) * adx;
+                sgn = dy < 0 ? -1 : 1;
+                inv = 1.0f / (float)adx;
+                fresh = false;
+            }
             if (x < n && x < (nxt >> 8)) {
-                const uint32_t x0 = cur >> 8, x1 = nxt >> 8;
-                const int32_t y0 = (int32_t)(cur & 255u), y1 = (int32_t)(nxt & 255u);
-                const int32_t dy = y1 - y0, adx = (int32_t)(x1 - x0);
-                const int32_t base = dy / adx;
-                const int32_t ady = (dy < 0 ? -dy : dy) - (base < 0 ? -base : base) * adx;
-                const int32_t t = (int32_t)(x - x0);
-                const int32_t steps = (int32_t)((uint32_t)(ady * t) / (uint32_t)adx);  // err >= adx events in t steps
-                const int32_t yy = y0 + base * t + (dy < 0 ? -steps : steps);
-                out[x] = dbl[yy];
+                const int32_t t = (int32_t)x - x0;
+                // steps = floor(ady * t / adx): the number of err >= adx events in t steps.  ady * t < 2^21 is exact in
+                // f32; the reciprocal estimate is off by at most one, corrected with the exact integer remainder.
+                const int32_t num = ady * t;
+                int32_t steps = (int32_t)((float)num * inv);
+                int32_t rem = num - steps * adx;
+                steps += rem >= adx ? 1 : 0;
+                rem -= rem >= adx ? adx : 0;
+                steps -= rem < 0 ? 1 : 0;
+                out[x] = dbl[y0 + base * t + sgn * steps];
             }
         }
     }
