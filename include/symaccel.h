@@ -171,7 +171,8 @@ int symaccel_vorbis_deinterleave2_device(symaccel_ctx *ctx, const float *d_type2
                                          int n_ch, size_t n2, size_t count);
 /* Floor-1 curve synthesis, steps 1 and 2 (floor.rs:568-653, 776-825) for `count` channel-blocks
  * sharing one floor configuration: x_list[n_posts] (HOST, from the setup header), multiplier
- * 1..4, y[count][n_posts] (DEVICE, decoded floor1_Y values), floor[count][n] out. */
+ * 1..4, y[count][n_posts] (DEVICE, decoded floor1_Y values, each < 2^16), n = blocksize / 2 (a multiple of 16,
+ * <= 4096), floor[count][n] out. */
 int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts,
                                   int multiplier, const uint32_t *d_y, uint32_t n, float *d_floor,
                                   size_t count);

@@ -540,7 +540,7 @@ int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int
         if (x_list[setup[195 + i]] == x_list[setup[195 + i - 1]]) return SYMACCEL_ERR_INVALID_ARG;
     for (int i = 0; i < n_posts; ++i)
         if (x_list[i] > 0xffffu) return SYMACCEL_ERR_INVALID_ARG;  // floor1_X values have at most 15 bits (rangebits)
-    if (n > (1u << 16)) return SYMACCEL_ERR_INVALID_ARG;
+    if (n > 4096u || (n & 15u)) return SYMACCEL_ERR_INVALID_ARG;  // n = blocksize / 2, blocksize = 2^6 .. 2^13 (lib.rs:404-406)
     // the derived tables travel as a kernel argument: no staging copy, no stream synchronisation
     return launch_vorbis_floor1(ctx, setup, n_posts, multiplier, d_y, n, d_floor, count);
 }

@@ -231,10 +231,15 @@ __device__ __forceinline__ int32_t floor1_render_point(uint32_t x0, int32_t y0, 
 //   step 1 (the post-value recurrence over <= 65 posts, with the setup's neighbour tables) runs one LANE per block
 //   -- the post index, neighbours and x values are wave-uniform (kernel arguments, scalar), only the y values differ;
 //   step 2 builds each block's list of line end points (x-sorted, flagged posts only) in LDS;
-//   rendering takes the blocks one after the other with all 64 lanes on consecutive x (coalesced 256-byte stores):
-//   a lane keeps the segment that contains its x and walks forward through the list (entries are fetched from
-//   the lane that holds them with ds_bpermute); the integer DDA of render_line (floor.rs:785-825) has the closed form
+//   rendering takes the blocks one after the other, every lane on 16 consecutive x (see the render loop); the integer
+//   DDA of render_line (floor.rs:785-825) has the closed form
 //       y(x) = y0 + base * t + sign * floor(ady * t / adx),   t = x - x0,   ady = |dy| - |base| * adx.
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct Floor1Setup {  // per floor configuration, derived on the host like the setup parser does (floor.rs:540-555)
     uint16_t x[65];
     uint8_t lo[65], hi[65], order[65];
@@ -251,6 +256,8 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
     __shared__ uint16_t segx[67 * kF1Stride];     // first the y values [post][block], then the points' x
     __shared__ uint8_t segy[67 * kF1Stride];      //                                               ... and y (0..255)
     __shared__ float dbl[256];
+    __shared__ __attribute__((aligned(16))) uint8_t mark[4096];  // segment-start map of the block being rendered
+    __shared__ __attribute__((aligned(16))) float line[1024];    // one pass of rendered lines
     const int lane = (int)threadIdx.x;
     const size_t blk0 = (size_t)blockIdx.x * 64;
     const int nb = (int)(count - blk0 < 64 ? count - blk0 : 64);
@@ -323,60 +330,100 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- render_line for every segment (floor.rs:785-825), block after block, lane = x
+    // ---- render_line for every segment (floor.rs:785-825), block after block.  Lane l renders 16 consecutive x of
+    // each 1024-line pass; which segment an x belongs to comes from a byte map of the segment starts (scattered by the
+    // lanes that hold the points, then a prefix-max: 6 cross-lane steps per pass instead of a dependent list walk per
+    // x); the pass is staged in LDS and stored with 16-byte, fully coalesced stores.
     for (int b = 0; b < nb; ++b) {
         const int nsb = __shfl(ns, b);  // points 0 .. nsb of block b
-        // lane k holds points k and 64 + k of the block as (x << 8 | y) (beyond the list: x = "infinity")
-        const uint32_t e_lo = lane <= nsb ? ((uint32_t)segx[lane * kF1Stride + b] << 8) | segy[lane * kF1Stride + b] : 0xffffffffu;
-        const uint32_t e_hi =
-            64 + lane <= nsb ? ((uint32_t)segx[(64 + lane) * kF1Stride + b] << 8) | segy[(64 + lane) * kF1Stride + b] : 0xffffffffu;
-        auto point = [&](int k) -> uint32_t {  // k may differ per lane
-            const uint32_t a = (uint32_t)__shfl((int)e_lo, k & 63), c = (uint32_t)__shfl((int)e_hi, k & 63);
-            return k < 64 ? a : c;
-        };
         float *out = floor_out + (blk0 + (size_t)b) * (size_t)n;
-        int s = 0;
-        uint32_t cur = point(0), nxt = point(1);
-        // per-segment constants of the DDA, recomputed only when the lane moves to another segment
-        int32_t x0 = 0, y0 = 0, base = 0, ady = 0, adx = 1, sgn = 1;
-        float inv = 1.0f;
-        bool fresh = true;
-        for (uint32_t x = (uint32_t)lane; x < ((n + 63u) & ~63u); x += 64) {
-            // advance to the segment with x_s <= x < x_{s+1}
-            while (__any((nxt >> 8) <= x && s + 1 < nsb)) {
-                const bool step = (nxt >> 8) <= x && s + 1 < nsb;
-                const uint32_t far = point(s + 2);
-                if (step) {
-                    cur = nxt;
-                    nxt = far;
-                    ++s;
-                    fresh = true;
+        // segment-start map: mark[x_k] = k + 1 for the points with x_k < n (x values are distinct)
+        for (uint32_t i = (uint32_t)lane; i < (n + 3u) / 4u; i += 64) reinterpret_cast<uint32_t *>(mark)[i] = 0u;
+        wave_sync_lds();
+        for (int k = lane; k <= nsb; k += 64) {
+            const uint32_t xk = segx[k * kF1Stride + b];
+            if (xk < n) mark[xk] = (uint8_t)(k + 1);
+        }
+        wave_sync_lds();
+        int carry = 1;  // segment (index + 1) in force before the current pass; x = 0 always starts segment 0
+        for (uint32_t p0 = 0; p0 < n; p0 += 1024) {
+            const uint32_t xb = p0 + 16u * (uint32_t)lane;  // this lane's 16 lines
+            uint32_t m[4] = {0u, 0u, 0u, 0u};
+            if (xb < n) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(mark + xb);  // (n is a multiple of 16: a power of two >= 32)
+                m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
+            }
+            // highest mark in the lane's 16 bytes (marks grow with x), then an exclusive prefix-max across the lanes
+            int mine = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int v = (int)((m[q >> 2] >> (8 * (q & 3))) & 255u);
+                mine = v > mine ? v : mine;
+            }
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, (unsigned)d);
+                incl = (lane >= d && o > incl) ? o : incl;
+            }
+            int before = __shfl_up(incl, 1u);
+            before = lane == 0 ? 0 : before;
+            int seg_id = before > carry ? before : carry;  // (index + 1) of the segment in force just before x = xb
+            const int last = __shfl(incl, 63);
+            carry = last > carry ? last : carry;
+            // per-segment constants of the DDA: y(x) = y0 + base * t + sign * floor(ady * t / adx), t = x - x0
+            int32_t x0 = 0, y0 = 0, base = 0, ady = 0, adx = 1, sgn = 1, x1 = 0;
+            float inv = 1.0f;
+            int loaded = 0;
+            float res[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int v = (int)((m[q >> 2] >> (8 * (q & 3))) & 255u);
+                seg_id = v ? v : seg_id;
+                if (seg_id != loaded) {
+                    const int k = seg_id - 1, k1 = k + 1 <= nsb ? k + 1 : k;
+                    x0 = (int32_t)segx[k * kF1Stride + b];
+                    y0 = (int32_t)segy[k * kF1Stride + b];
+                    x1 = (int32_t)segx[k1 * kF1Stride + b];
+                    const int32_t dy = (int32_t)segy[k1 * kF1Stride + b] - y0;
+                    adx = x1 - x0;
+                    adx = adx > 0 ? adx : 1;
+                    base = dy / adx;
+                    ady = (dy < 0 ? -dy : dy) - (base < 0 ? -base : base) * adx;
+                    sgn = dy < 0 ? -1 : 1;
+                    inv = 1.0f / (float)adx;
+                    loaded = seg_id;
                 }
-            }
-            if (fresh) {
-                x0 = (int32_t)(cur >> 8);
-                y0 = (int32_t)(cur & 255u);
-                const int32_t dy = (int32_t)(nxt & 255u) - y0;
-                adx = (int32_t)(nxt >> 8) - x0;
-                adx = adx > 0 ? adx : 1;
-                base = dy / adx;
-                ady = (dy < 0 ? -dy : dy) - (base < 0 ? -base : base) * adx;
-                sgn = dy < 0 ? -1 : 1;
-                inv = 1.0f / (float)adx;
-                fresh = false;
-            }
-            if (x < n && x < (nxt >> 8)) {
-                const int32_t t = (int32_t)x - x0;
-                // steps = floor(ady * t / adx): the number of err >= adx events in t steps.  ady * t < 2^21 is exact in
-                // f32; the reciprocal estimate is off by at most one, corrected with the exact integer remainder.
+                const int32_t t = (int32_t)(xb + (uint32_t)q) - x0;
+                // steps = floor(ady * t / adx): ady * t < 2^21 is exact in f32; the reciprocal estimate is off by at most
+                // one, corrected with the exact integer remainder
                 const int32_t num = ady * t;
                 int32_t steps = (int32_t)((float)num * inv);
                 int32_t rem = num - steps * adx;
                 steps += rem >= adx ? 1 : 0;
                 rem -= rem >= adx ? adx : 0;
                 steps -= rem < 0 ? 1 : 0;
-                out[x] = dbl[y0 + base * t + sgn * steps];
+                int32_t yy = y0 + base * t + sgn * steps;
+                yy = yy < 0 ? 0 : (yy > 255 ? 255 : yy);  // (in range for every rendered x; guards the lanes past the list)
+                res[q] = dbl[yy];
             }
+            if (xb < n) {
+                float4 *o4 = reinterpret_cast<float4 *>(line + 16 * lane);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o4[q] = make_float4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
+            }
+            wave_sync_lds();
+            {
+                const uint32_t span = n - p0 < 1024u ? n - p0 : 1024u;  // lines of this pass
+                const float4 *l4 = reinterpret_cast<const float4 *>(line);
+                float4 *d4 = reinterpret_cast<float4 *>(out + p0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i4 = (uint32_t)lane + 64u * (uint32_t)q;
+                    if (4u * i4 < span) d4[i4] = l4[i4];
+                }
+            }
+            wave_sync_lds();
         }
     }
 }
