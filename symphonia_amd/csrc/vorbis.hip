@@ -251,13 +251,14 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
                                                            const uint32_t *__restrict__ yv, uint32_t n,
                                                            float *__restrict__ floor_out, const float *__restrict__ db,
                                                            size_t count) {
-    // 22 KiB of LDS per wavefront (7 wavefronts per CU): 16-bit tables
-    __shared__ int16_t fy[65 * 64];               // final_y[post][lane] (|final_y| < 2^9)
+    // 22 KiB of LDS per wavefront (7 wavefronts per CU): 16-bit tables; the render stage reuses final_y's storage
+    __shared__ __attribute__((aligned(16))) int16_t fy[65 * 64];  // final_y[post][lane] (|final_y| < 2^9)
     __shared__ uint16_t segx[67 * kF1Stride];     // first the y values [post][block], then the points' x
     __shared__ uint8_t segy[67 * kF1Stride];      //                                               ... and y (0..255)
     __shared__ float dbl[256];
-    __shared__ __attribute__((aligned(16))) uint8_t mark[4096];  // segment-start map of the block being rendered
-    __shared__ __attribute__((aligned(16))) float line[1024];    // one pass of rendered lines
+    static_assert(sizeof(int16_t) * 65 * 64 >= 4096 + 4096, "the render buffers alias final_y");
+    uint8_t *mark = reinterpret_cast<uint8_t *>(fy);            // segment-start map of the block being rendered (n bytes)
+    float *line = reinterpret_cast<float *>(fy) + 1024;         // one pass of rendered lines (1024 floats)
     const int lane = (int)threadIdx.x;
     const size_t blk0 = (size_t)blockIdx.x * 64;
     const int nb = (int)(count - blk0 < 64 ? count - blk0 : 64);
