@@ -80,8 +80,11 @@ def test_fft_parity(ctx, n):
         v = np.array(kats()["fft64_input"], dtype=np.float32)
         x[0] = v[:, 0] + 1j * v[:, 1]
     xd = torch.view_as_real(dev(x)).contiguous()
-    yd = torch.empty_like(xd)
+    guard = torch.full((2 * xd.numel(),), 12345.0, device="cuda")  # the output sits in front of a sentinel region
+    yd = guard[: xd.numel()].view(xd.shape)
     Fft(ctx, n).fft(xd, yd)
+    torch.cuda.synchronize()
+    assert bool((guard[xd.numel():] == 12345.0).all()), "Fft wrote past the end of its output"
     got = host(yd).view(np.complex64).reshape(9, n)
     want = np.stack([oracle.fft(r) for r in x])
     assert_parity(got.view(np.float32), want.view(np.float32), "fft n=%d" % n)
