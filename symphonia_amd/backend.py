@@ -120,15 +120,16 @@ class Fft:
         self.ctx, self.n = ctx, int(n)
 
     def fft(self, x, y):
-        """x, y: CUDA tensors holding count * n complex values -- complex64 [..., n], or float32 [..., n, 2]
-        (torch.view_as_real layout)."""
-        import torch
-        if x.dtype == torch.complex64:
-            values = x.numel()
+        """x, y: device buffers holding count * n complex values -- complex64 [..., n], or float32 [..., n, 2]
+        (torch.view_as_real layout).  (numpy arrays are accepted for the CPU-emulated test library, whose "device"
+        memory is host memory.)"""
+        total = x.numel() if _is_torch(x) else x.size
+        if str(x.dtype).endswith("complex64"):
+            values = total
         else:
-            assert x.dtype == torch.float32 and x.shape[-1] == 2, "interleaved (re, im) float32 expected"
-            values = x.numel() // 2
-        assert x.is_contiguous() and y.is_contiguous() and y.numel() == x.numel() and y.dtype == x.dtype
+            assert str(x.dtype).endswith("float32") and x.shape[-1] == 2, "interleaved (re, im) float32 expected"
+            values = total // 2
+        assert (y.numel() if _is_torch(y) else y.size) == total and y.dtype == x.dtype
         assert values % self.n == 0  # no_simd.rs:97, 122-123: slice lengths must equal the transform size
         self.ctx._call(self.ctx.lib.dll.symaccel_fft_c32_device, self.n, _ptr(x), _ptr(y), values // self.n)
         return y

@@ -5,6 +5,7 @@
 // Reference: symphonia-core/src/dsp/fft/no_simd.rs:70-141, 221-454; dsp/mdct.rs:67-146.
 // Bound: HBM (n*4 B in, n*8 B out per transform; ~5 flop/B without FMA).
 #include "fft_lds.h"
+#include "imdct_wave.h"
 
 namespace symaccel {
 
@@ -86,6 +87,96 @@ __global__ __launch_bounds__(kThreads) void imdct_kernel(DevTables tb, const cpx
     }
 }
 
+// ---- wavefront-per-transform fast paths for the two sizes the AAC and Vorbis 256/2048 decoders use (imdct_wave.h):
+// n = 1024 (one 512-point FFT in three radix-8 register passes) and n = 128 (eight 64-point FFTs at once).
+constexpr int kWaveWaves = 4;
+
+__global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct1024_wave_kernel(DevTables tb, const cpx *__restrict__ tw_g,
+                                                                             const float *__restrict__ spec,
+                                                                             float *__restrict__ out, size_t count,
+                                                                             unsigned per_wave) {
+    __shared__ __attribute__((aligned(16))) float tw_lds[1024];
+    __shared__ __attribute__((aligned(16))) float wave_lds[kWaveWaves][kWaveLds];
+    for (int i = (int)threadIdx.x; i < 1024; i += 64 * kWaveWaves) tw_lds[i] = reinterpret_cast<const float *>(tw_g)[i];
+    __syncthreads();
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const size_t first = ((size_t)blockIdx.x * kWaveWaves + (size_t)wave) * per_wave;
+    if (first >= count) return;
+    const size_t last = first + per_wave < count ? first + per_wave : count;
+    c32 *lds = reinterpret_cast<c32 *>(wave_lds[wave]);
+    const c32 *tw = reinterpret_cast<const c32 *>(tw_lds);
+    LaneTables lt;
+    load_lane_tables(tb, lane, lt);
+    float2 line[8];
+    {
+        const float2 *src = reinterpret_cast<const float2 *>(spec + first * 1024);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) line[s] = src[lane + 64 * s];
+    }
+    for (size_t t = first; t < last; ++t) {
+        c32 z[8];
+        const int mirror = (63 - lane) * 4;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
+            z[s] = pre_twiddle(line[s].x, mirrored, tw[lane + 64 * s]);
+        }
+        if (t + 1 < last) {
+            const float2 *src = reinterpret_cast<const float2 *>(spec + (t + 1) * 1024);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) line[s] = src[lane + 64 * s];
+        }
+        fft512_wave(z, lane, lds, lt);
+        float *o = out + t * 2048;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float x[8], x2[8];
+            post_slot(lds, tw, lane + 64 * h, x, x2);
+            store_slot(o, lane + 64 * h, x);
+            store_slot(o + 1024, lane + 64 * h, x2);
+        }
+        wave_sync();  // Z in LDS is overwritten by the next transform
+    }
+}
+
+__global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct128_wave_kernel(DevTables tb, const cpx *__restrict__ tw_g,
+                                                                            const float *__restrict__ spec,
+                                                                            float *__restrict__ out, size_t count,
+                                                                            unsigned groups_per_wave) {
+    __shared__ __attribute__((aligned(16))) float wave_lds[kWaveWaves][kWaveLds];
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    float *ldsf = wave_lds[wave];
+    LaneTables lt;
+    load_lane_tables(tb, lane, lt);
+    const size_t g0 = ((size_t)blockIdx.x * kWaveWaves + (size_t)wave) * groups_per_wave;  // groups of 8 transforms
+    for (size_t g = g0; g < g0 + groups_per_wave && g * 8 < count; ++g) {
+        const size_t t0 = g * 8;
+        const int nt = (int)(count - t0 < 8 ? count - t0 : 8);
+        const float2 *src = reinterpret_cast<const float2 *>(spec + t0 * 128);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s < nt) {
+                const float2 v = src[lane + 64 * s];
+                ldsf[2 * lane + 128 * s] = v.x;
+                ldsf[2 * lane + 128 * s + 1] = v.y;
+            }
+        }
+        wave_sync();
+        imdct_short_wave(lane, ldsf, tw_g, lt);  // H[8][128] in ldsf[0..1024); ends with a wave_sync
+        const int w = lane >> 3, c = lane & 7;
+        if (w < nt) {
+            float4 *o4 = reinterpret_cast<float4 *>(out + (t0 + (size_t)w) * 256);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v[4];
+                ys4(ldsf, w, 4 * (c + 8 * e), v);
+                o4[c + 8 * e] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        wave_sync();
+    }
+}
+
 int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -106,6 +197,23 @@ int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t
 }
 
 int launch_imdct(symaccel_ctx *ctx, const ImdctPlan &plan, const float *d_spec, float *d_out, size_t count) {
+    if (plan.n == 1024 || plan.n == 128) {
+        // enough wavefronts to fill the chip several times over, several transforms per wavefront
+        const size_t units = plan.n == 1024 ? count : (count + 7) / 8;
+        size_t per_wave = units / ((size_t)ctx->n_cus * 8 * 4);
+        per_wave = per_wave < 1 ? 1 : (per_wave > 32 ? 32 : per_wave);
+        const size_t waves = (units + per_wave - 1) / per_wave;
+        const size_t grid = (waves + kWaveWaves - 1) / kWaveWaves;
+        if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+        if (plan.n == 1024)
+            hipLaunchKernelGGL(imdct1024_wave_kernel, dim3((unsigned)grid), dim3(64 * kWaveWaves), 0, ctx->stream, ctx->dev,
+                               (const cpx *)plan.d_twiddle, d_spec, d_out, count, (unsigned)per_wave);
+        else
+            hipLaunchKernelGGL(imdct128_wave_kernel, dim3((unsigned)grid), dim3(64 * kWaveWaves), 0, ctx->stream, ctx->dev,
+                               (const cpx *)plan.d_twiddle, d_spec, d_out, count, (unsigned)per_wave);
+        SYM_GPU(ctx, hipGetLastError());
+        return SYMACCEL_OK;
+    }
     const int nf = plan.n / 2;
     const int points = nf >= 2048 ? nf : 2048;
     const size_t per_wg = (size_t)(points / nf);

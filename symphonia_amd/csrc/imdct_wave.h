@@ -247,4 +247,20 @@ __device__ __forceinline__ void load_slot(const float *frame, int m2, float (&v)
 }
 
 
+// y_s[i0 .. i0+3] (i0 a multiple of 4, in 0..256): Imdct output of short block `w` from the half-stored H of imdct_short_wave: v0 = -reverse(v1), v1 = H[0..64), v2 = H[64..128), v3 = reverse(v2).
+__device__ __forceinline__ void ys4(const float *H, int w, int i0, float (&v)[4]) {
+    const float *h = H + 128 * w;
+    if (i0 < 64) {
+        const float4 r = *reinterpret_cast<const float4 *>(h + 60 - i0);
+        v[0] = -r.w; v[1] = -r.z; v[2] = -r.y; v[3] = -r.x;
+    } else if (i0 < 192) {
+        const float4 r = *reinterpret_cast<const float4 *>(h + i0 - 64);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    } else {
+        const float4 r = *reinterpret_cast<const float4 *>(h + 316 - i0);
+        v[0] = r.w; v[1] = r.z; v[2] = r.y; v[3] = r.x;
+    }
+}
+
+
 }  // namespace symaccel

@@ -27,22 +27,6 @@ constexpr int kTabWs = 2048;     //   short window (left half of the 256-sample 
 constexpr int kTabFloats = 2048 + 128;
 constexpr int kBs0 = 256, kBs1 = 2048;
 
-// y_s[i0 .. i0+3] (i0 a multiple of 4, in 0..256): Imdct output of short block `w` of the current run from the
-// half-stored H (imdct_wave.h): v0 = -reverse(v1), v1 = H[0..64), v2 = H[64..128), v3 = reverse(v2).
-__device__ __forceinline__ void ys4(const float *H, int w, int i0, float (&v)[4]) {
-    const float *h = H + 128 * w;
-    if (i0 < 64) {
-        const float4 r = *reinterpret_cast<const float4 *>(h + 60 - i0);
-        v[0] = -r.w; v[1] = -r.z; v[2] = -r.y; v[3] = -r.x;
-    } else if (i0 < 192) {
-        const float4 r = *reinterpret_cast<const float4 *>(h + i0 - 64);
-        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
-    } else {
-        const float4 r = *reinterpret_cast<const float4 *>(h + 316 - i0);
-        v[0] = r.w; v[1] = r.z; v[2] = r.y; v[3] = r.x;
-    }
-}
-
 // out[q] = ov[q] * ws[127 - (k + q)] + y[q] * ws[k + q], q = 0..3 (vorbis dsp.rs:140-144 with the short window)
 __device__ __forceinline__ void ola_short4(const float *ws, int k, const float (&ov)[4], const float (&y)[4], float4 &o) {
     const float4 wf = *reinterpret_cast<const float4 *>(ws + k);
