@@ -33,7 +33,7 @@ def log(msg):
 
 
 def make_workload(name, torch, ctx, seed, scale=1.0):
-    """Returns (step_fn, units_per_step, unit_name, algorithmic_bytes_per_step, description, kernel_name)."""
+    """Returns (step_fn, units_per_step, unit_name, algorithmic_bytes_per_step, description, kernel_name, output tensor)."""
     import symphonia_amd as sa
     g = torch.Generator(device="cuda").manual_seed(seed)
     if name == "aac":
@@ -51,7 +51,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0):
         frames = nch * nfr // 2
         return step, frames, "frames", nch * nfr * 8192, {
             "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d), 1024-pt IMDCT+window+OLA, KBD"
-                        % (frames, nch, nfr), "channel_frames": nch * nfr, "samples_per_frame": 1024}, "aac_synth_kernel"
+                        % (frames, nch, nfr), "channel_frames": nch * nfr, "samples_per_frame": 1024}, "aac_synth_kernel", pcm
     if name == "mp3":
         nch, ngr = int(128 * scale), 2048  # 64 stereo streams x 2048 granules = 131 072 granules
         xr = torch.randn((nch, ngr, 576), generator=g, device="cuda", dtype=torch.float32) * 0.05
@@ -67,7 +67,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0):
         granules = nch * ngr // 2
         return step, granules, "granules", nch * ngr * 4608, {
             "workload": "MP3 Layer III 44.1 kHz stereo, %d long-block granules (%d chains x %d), hybrid synthesis + polyphase"
-                        % (granules, nch, ngr), "granule_channels": nch * ngr, "samples_per_granule": 576}, "mp3_synth_kernel"
+                        % (granules, nch, ngr), "granule_channels": nch * ngr, "samples_per_granule": 576}, "mp3_synth_kernel", pcm
     if name == "vorbis":
         nch, nb = int(64 * scale), 4096  # one GPU's shard of config 4: 8 streams x 8 ch x 4096 blocks
         rng = np.random.default_rng(seed)
@@ -92,7 +92,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0):
         bytes_alg = int(4 * (so[:, -1].sum() + po[:, -1].sum()))
         return step, nch * nb // 8, "frames", bytes_alg, {
             "workload": "Vorbis 2048/256 mixed block sizes, 8 ch, %d blocks (%d chains x %d)" % (nch * nb // 8, nch, nb),
-            "channel_blocks": nch * nb}, "vorbis_synth_kernel"
+            "channel_blocks": nch * nb}, "vorbis_synth_wave_kernel", pcm
     if name == "flac":
         nb, bs = int(262144 * scale), 4096  # 1/4 of config 5 per step (4 GiB in place; the full 1 M blocks = 16 GiB)
         buf = torch.randint(-(1 << 12), 1 << 12, (nb, bs), generator=g, device="cuda", dtype=torch.int32)
@@ -110,7 +110,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0):
             fp.restore(buf, desc, co)
         return step, nb, "blocks", nb * bs * 8, {
             "workload": "FLAC 24-bit, LPC order 32 (15-bit coefficients, shift 12), %d subframe blocks of 4096 samples, "
-                        "in place" % nb, "samples": nb * bs}, "flac_restore_kernel"
+                        "in place" % nb, "samples": nb * bs}, "flac_restore_f64_kernel", buf
     if name == "alac":
         nb, bs = int(262144 * scale), 4096  # 16-bit ALAC frames of 4096 samples, adaptive predictor of order 8
         buf = torch.randint(-(1 << 9), 1 << 9, (nb, bs), generator=g, device="cuda", dtype=torch.int32)
@@ -123,7 +123,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0):
             ap.predict(buf, desc, co)  # in place, like the FLAC workload: every pass costs the same
         return step, nb, "blocks", nb * bs * 8, {
             "workload": "ALAC 16-bit, adaptive LPC order 8 (shift 9), %d element-channel blocks of 4096 samples, in place" % nb,
-            "samples": nb * bs}, "alac_predict_kernel"
+            "samples": nb * bs}, "alac_predict_kernel", buf
     raise ValueError(name)
 
 
@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1 only: also time an RCCL all_gather of the PCM shards (reported beside, never inside, `value`)")
     args = ap.parse_args()
     import faulthandler
     faulthandler.enable()
@@ -223,7 +225,7 @@ def main():
     ctx.use_torch_stream()
     if args.segment:
         ctx.set_segment(args.segment)
-    step, units, unit_name, alg_bytes, config, kernel = make_workload(args.workload, torch, ctx, 1234 + rank, args.scale)
+    step, units, unit_name, alg_bytes, config, kernel, result = make_workload(args.workload, torch, ctx, 1234 + rank, args.scale)
 
     log("workload built: %s" % config["workload"])
     for _ in range(args.warmup):
@@ -249,6 +251,13 @@ def main():
     elapsed = max_over_ranks(elapsed, dist if world > 1 else None, device="cuda")
     launch_s = ev0.elapsed_time(ev1) / 1e3 / args.steps  # mean launch period of the hot-path kernel(s)
     log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))
+
+    gather = None
+    if args.gather and world > 1:
+        from symphonia_amd.sharding import timed_all_gather
+        secs, nbytes = timed_all_gather(result, dist)
+        gather = {"op": "all_gather of every rank's PCM shard (RCCL over xGMI)", "ms": secs * 1e3, "bytes_per_rank": nbytes,
+                  "algbw_GBps": nbytes * world / secs / 1e9}
 
     if rank == 0:
         achieved = alg_bytes / launch_s / 1e9
@@ -284,6 +293,8 @@ def main():
             out["roofline"]["note"] = "integer-ALU bound (adaptive predictor, ~13 x order operations per sample), not HBM"
         if args.workload == "flac":
             out["roofline"]["note"] = "FP64-FMA-issue bound (32 exact FMAs per 8 B), not HBM (DESIGN.md 4.5)"
+        if gather:
+            out["collective"] = gather
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))

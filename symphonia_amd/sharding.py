@@ -45,3 +45,24 @@ def gather_chains(local, n_chains, channels_per_stream, dist):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
     return torch.cat([o[: e - b] for o, (b, e) in zip(out, sizes)], dim=0)
+
+
+def timed_all_gather(local, dist, reps=3):
+    """Optional collection step of a sharded batch: all_gather of every rank's (equal-shape) PCM shard.  Returns
+    (seconds per all_gather, max over ranks; bytes contributed per rank).  This is the only data-path collective the
+    backend ever needs, and only when a caller wants every shard in one place (BASELINE config 4's "split / gather")."""
+    import time
+    import torch
+    world = dist.get_world_size()
+    out = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(out, local)  # warm-up (connection set-up)
+    if local.is_cuda:
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_gather(out, local)
+    if local.is_cuda:
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return max_over_ranks(dt, dist, device=local.device if local.is_cuda else None), local.numel() * local.element_size()

@@ -52,6 +52,9 @@ def _worker(rank, world, port, q):
         full_delay = gather_chains(torch.from_numpy(new_delay), n_chains, 2, dist).numpy()
         want, want_delay = oracle.aac_synth(coeffs, side, delay)
         ok = np.array_equal(full, want) and np.array_equal(full_delay, want_delay)
+        from symphonia_amd.sharding import timed_all_gather
+        secs, nbytes = timed_all_gather(torch.from_numpy(pcm[:2].copy()), dist, reps=2)
+        ok = ok and secs > 0 and nbytes == pcm[:2].nbytes
         slowest = max_over_ranks(1.0 + rank, dist)
         dist.barrier()
         dist.destroy_process_group()
