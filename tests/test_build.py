@@ -1,0 +1,75 @@
+"""Arithmetic contract at the ISA level: the f32 synthesis kernels must not contain a single fused
+multiply-add -- the reference (Rust) never contracts a*b+c, and one FMA changes the rounding of a PCM sample.  The
+device assembly of every f32 kernel file is checked for FMA / MAC / MAD mnemonics; flac.hip is allowed its FP64 FMAs
+(exact by construction) but no f32 ones either."""
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "symphonia_amd" / "csrc"
+F32_FUSED = re.compile(r"\b(v_fma_f32|v_fmac_f32|v_mac_f32|v_mad_f32|v_pk_fma_f32|v_fma_mix\w*|v_mad_mix\w*|v_fma_legacy_f32|"
+                       r"v_mad_legacy_f32|v_mac_legacy_f32|v_dot2c?_f32\w*)\b")
+F64_FUSED = re.compile(r"\b(v_fma_f64|v_fmac_f64)\b")
+SOURCES = ["aac.hip", "mp3.hip", "mpa_polyphase.hip", "vorbis.hip", "vorbis_wave.hip", "imdct_generic.hip", "flac.hip", "alac.hip"]
+
+
+def device_asm(src):
+    from symphonia_amd import build
+    out = ROOT / "symphonia_amd" / "build" / (src.replace(".", "_") + ".s")
+    out.parent.mkdir(exist_ok=True)
+    cmd = [build.hipcc(), "--offload-arch=" + build.ARCH, "-x", "hip", *build.FLAGS, "--cuda-device-only", "-S",
+           str(CSRC / src), "-o", str(out)]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def asm():
+    if not (shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists()):
+        pytest.skip("hipcc not available")
+    with ThreadPoolExecutor(8) as ex:
+        return dict(zip(SOURCES, ex.map(device_asm, SOURCES)))
+
+
+def kernels(text):
+    """{mangled kernel name: body} from a device assembly listing."""
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)^\.Lfunc_end\d+:", text, flags=re.S | re.M):
+        out[m.group(1)] = m.group(2)
+    return out
+
+
+# Kernels with no f32 signal arithmetic at all: the only FMAs they may contain belong to the compiler's expansion of
+# integer and IEEE float DIVISION (index math, the floor-1 DDA reciprocal), which is correctly rounded by construction.
+INDEX_MATH_ONLY = re.compile(r"floor1|offsets|deinterleave|flac_|alac_|state_copy")
+
+
+def test_no_f32_fma_in_any_synthesis_kernel(asm):
+    seen = 0
+    for src, text in asm.items():
+        for name, body in kernels(text).items():
+            if INDEX_MATH_ONLY.search(name):
+                continue
+            seen += 1
+            hits = sorted(set(F32_FUSED.findall(body)))
+            assert not hits, "%s: %s contains fused f32 arithmetic: %s" % (src, name, hits)
+    assert seen >= 8  # aac, mp3, mpa x2, vorbis synth x2 + wave, imdct / fft x4, coupling, dot
+
+
+def test_fp64_fma_only_in_the_flac_kernel(asm):
+    for src, text in asm.items():
+        if src == "flac.hip":
+            assert F64_FUSED.search(text), "flac.hip lost its exact FP64 dot product"
+        else:
+            assert not F64_FUSED.search(text), src
+
+
+def test_build_flags_pin_the_contract():
+    from symphonia_amd import build
+    assert "-ffp-contract=off" in build.FLAGS and "-fno-fast-math" in build.FLAGS
+    assert not any("flush-denormals" in f or f == "-ffast-math" for f in build.FLAGS)
