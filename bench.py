@@ -32,7 +32,7 @@ def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
-def make_workload(name, torch, ctx, seed, scale=1.0):
+def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0):
     """Returns (step_fn, units_per_step, unit_name, algorithmic_bytes_per_step, description, kernel_name, output tensor)."""
     import symphonia_amd as sa
     g = torch.Generator(device="cuda").manual_seed(seed)
@@ -42,6 +42,17 @@ def make_workload(name, torch, ctx, seed, scale=1.0):
         coeffs *= torch.exp2(torch.randint(-8, 13, (nch, nfr, 64), generator=g, device="cuda").float()).repeat_interleave(16, dim=2)
         coeffs[:, :, 672:] = 0.0  # 48 kHz content: band-limited like a real encoder's output
         side = torch.full((nch, nfr), int(sa.aac_side(0, 1, 1)), dtype=torch.uint8, device="cuda")
+        if mix > 0.0:  # development: a legal window-sequence walk with block switching (the headline is all ONLY_LONG)
+            rng = np.random.default_rng(seed)
+            sd = np.empty((nch, nfr), np.uint8)
+            for c in range(nch):
+                cur, prev_shape = 0, 1
+                for t in range(nfr):
+                    cur = (1 if rng.random() < mix else 0) if cur in (0, 3) else (2 if rng.random() < 0.5 else 3)
+                    shape = int(rng.integers(0, 2))
+                    sd[c, t] = int(sa.aac_side(cur, shape, prev_shape))
+                    prev_shape = shape
+            side = torch.from_numpy(sd).cuda()
         delay = torch.zeros((nch, 1024), device="cuda", dtype=torch.float32)
         pcm = torch.empty_like(coeffs)
         dsp = sa.AacDsp(ctx)
@@ -200,6 +211,8 @@ def main():
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--aac-mix", type=float, default=0.0,
+                    help="development: probability of a block switch per long frame in the AAC workload (headline: 0)")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1 only: also time an RCCL all_gather of the PCM shards (reported beside, never inside, `value`)")
     args = ap.parse_args()
@@ -225,7 +238,7 @@ def main():
     ctx.use_torch_stream()
     if args.segment:
         ctx.set_segment(args.segment)
-    step, units, unit_name, alg_bytes, config, kernel, result = make_workload(args.workload, torch, ctx, 1234 + rank, args.scale)
+    step, units, unit_name, alg_bytes, config, kernel, result = make_workload(args.workload, torch, ctx, 1234 + rank, args.scale, args.aac_mix)
 
     log("workload built: %s" % config["workload"])
     for _ in range(args.warmup):

@@ -29,42 +29,55 @@ constexpr int kWaves = 4;                 // wavefronts per workgroup
 constexpr int kTabTw = 0;                 // shared LDS tables: Imdct twiddles, 512 complex
 constexpr int kTabKbd = 1024;             //   KBD long window, 1024 f32
 constexpr int kTabSine = 2048;            //   sine long window, 1024 f32
-constexpr int kTabFloats = 3072;
+constexpr int kTabKbdShort = 3072;        //   KBD short window, 128 f32
+constexpr int kTabSineShort = 3200;       //   sine short window, 128 f32
+constexpr int kTabFloats = 3328;
 
 enum : int { ONLY_LONG = 0, LONG_START = 1, EIGHT_SHORT = 2, LONG_STOP = 3 };
 constexpr int kP0 = 512 - 64;  // SHORT_WIN_POINT0 (dsp.rs:19)
 constexpr int kP1 = 512 + 64;  // SHORT_WIN_POINT1 (dsp.rs:20)
 
-// pcm_short[q] of dsp.rs:86-101 with the reference's operation order (including the `0.0 +` of the
-// `+=` onto the zero-filled buffer for windows > 0).
-__device__ __forceinline__ float pcm_short_at(const float *H, int q, const float *short_win,
-                                              const float *prev_short_win) {
-    const int w = q >> 7, i = q & 127;
-    float acc = 0.0f;
+// pcm_short[q0 .. q0+3] of dsp.rs:86-101 (q0 a multiple of 4) with the reference's operation order, including the
+// `0.0 +` of the `+=` onto the zero-filled buffer for windows > 0.  H = the eight half-stored short transforms.
+__device__ __forceinline__ void pcm_short4(const float *H, int q0, const float *short_win, const float *prev_short_win,
+                                           float (&acc)[4]) {
+    const int w = q0 >> 7, i0 = q0 & 127;
     bool have = false;
-    if (w >= 1) {  // right half of window w-1: src[i + 128] * short_win[127 - i]
-        const float a = short_src(H, w - 1, 128 + i) * short_win[127 - i];
-        acc = (w - 1 == 0) ? a : (0.0f + a);
+    if (w >= 1) {  // right half of window w-1: src[128 + i] * short_win[127 - i]
+        float a[4];
+        ys4(H, w - 1, 128 + i0, a);
+        const float4 wr = *reinterpret_cast<const float4 *>(short_win + 124 - i0);  // short_win[124-i0 .. 127-i0], reversed
+        a[0] *= wr.w; a[1] *= wr.z; a[2] *= wr.y; a[3] *= wr.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = (w - 1 == 0) ? a[q] : (0.0f + a[q]);
         have = true;
     }
     if (w <= 7) {  // left half of window w
-        const float b = short_src(H, w, i) * (w == 0 ? prev_short_win[i] : short_win[i]);
-        acc = have ? (acc + b) : b;
+        float bq[4];
+        ys4(H, w, i0, bq);
+        const float4 wf = *reinterpret_cast<const float4 *>((w == 0 ? prev_short_win : short_win) + i0);
+        bq[0] *= wf.x; bq[1] *= wf.y; bq[2] *= wf.z; bq[3] *= wf.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = have ? (acc[q] + bq[q]) : bq[q];
     }
-    return acc;
 }
 
-// Effective output window of a LONG_STOP frame at sample j (dsp.rs:118-127): j < 448 -> dst = delay
+// Effective output window of a LONG_STOP frame for the float4 at sample j0 (dsp.rs:118-127): j < 448 -> dst = delay
 // (flagged by the caller), 448..575 -> prev_short_win[j-448], >= 576 -> delay + pcm (pcm * 1.0 is exact).
-__device__ __forceinline__ float stop_window(const DevTables &tb, int prev_shape, int j) {
-    const float *psw = prev_shape ? tb.aac_kbd_short : tb.aac_sine_short;
-    return (j >= kP0 && j < kP1) ? psw[j - kP0] : 1.0f;
+__device__ __forceinline__ void stop_window4(const float *psw, int j0, float *w) {
+    float4 v = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (j0 >= kP0 && j0 < kP1) v = *reinterpret_cast<const float4 *>(psw + j0 - kP0);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
-// Effective delay window of a LONG_START frame at sample j (dsp.rs:146-155), multiplying pcm[1024 + j]:
-// j < 448 -> copy (x * 1.0 exact), 448..575 -> short_win[127 - (j-448)], >= 576 -> literal 0.0 (caller).
-__device__ __forceinline__ float start_window(const DevTables &tb, int shape, int j) {
-    const float *sw = shape ? tb.aac_kbd_short : tb.aac_sine_short;
-    return (j >= kP0 && j < kP1) ? sw[127 - (j - kP0)] : 1.0f;
+// Effective delay window of a LONG_START frame for the float4 at sample j0 (dsp.rs:146-155), multiplying
+// pcm[1024 + j]: j < 448 -> copy (x * 1.0 exact), 448..575 -> short_win[127 - (j-448)], >= 576 -> literal 0.0 (caller).
+__device__ __forceinline__ void start_window4(const float *sw, int j0, float *w) {
+    float4 v = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (j0 >= kP0 && j0 < kP1) {
+        const float4 r = *reinterpret_cast<const float4 *>(sw + 124 - (j0 - kP0));  // sw[127-(j-448)], j = j0..j0+3
+        v = make_float4(r.w, r.z, r.y, r.x);
+    }
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
 
 #ifndef SYM_AAC_MIN_WAVES
@@ -82,6 +95,10 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
         tabs[kTabTw + i] = reinterpret_cast<const float *>(tb.aac_tw_long)[i];
         tabs[kTabKbd + i] = tb.aac_kbd_long[i];
         tabs[kTabSine + i] = tb.aac_sine_long[i];
+        if (i < 128) {
+            tabs[kTabKbdShort + i] = tb.aac_kbd_short[i];
+            tabs[kTabSineShort + i] = tb.aac_sine_short[i];
+        }
     }
     __syncthreads();  // the only workgroup-wide barrier; wavefronts are independent from here on
 
@@ -167,9 +184,9 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
                 // ---- output samples (dsp.rs:105-129): dst = delay + pcm * w, or delay alone
                 float wo[8], dst[8];
                 if (seq == LONG_STOP) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        wo[q] = stop_window(tb, prev_shape, q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4));
+                    const float *psw = tabs + (prev_shape ? kTabKbdShort : kTabSineShort);
+                    stop_window4(psw, 4 * m2, wo);
+                    stop_window4(psw, 1020 - 4 * m2, wo + 4);
                 } else {
                     load_slot(wprev, m2, wo);
                 }
@@ -184,9 +201,9 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
                 // slot's two float4 read backwards), a short-window slope, or literal zero
                 float wd[8];
                 if (seq == LONG_START) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        wd[q] = start_window(tb, shape, q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4));
+                    const float *sw = tabs + (shape ? kTabKbdShort : kTabSineShort);
+                    start_window4(sw, 4 * m2, wd);
+                    start_window4(sw, 1020 - 4 * m2, wd + 4);
                 } else {
                     float wr[8];
                     load_slot(wcur, m2, wr);
@@ -208,15 +225,24 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
 #pragma unroll
             for (int h = 0; h < 2; ++h) store_slot(dly, lane + 64 * h, dl[h]);  // (the FFT work array overlapped dly)
             wave_sync();
-            const float *sw = shape ? tb.aac_kbd_short : tb.aac_sine_short;
-            const float *psw = prev_shape ? tb.aac_kbd_short : tb.aac_sine_short;
+            const float *sw = tabs + (shape ? kTabKbdShort : kTabSineShort);
+            const float *psw = tabs + (prev_shape ? kTabKbdShort : kTabSineShort);
 #pragma unroll 1
-            for (int e = 0; e < 16; ++e) {
-                const int j = lane + 64 * e;
-                const float d = dly[j];
-                const float o = j < kP0 ? d : d + pcm_short_at(ldsf, j - kP0, sw, psw);      // dsp.rs:111-117
-                if (emit) frame_out[j] = o;
-                dly[j] = j < kP1 ? pcm_short_at(ldsf, j + kP1, sw, psw) : 0.0f;               // dsp.rs:138-145
+            for (int e = 0; e < 4; ++e) {  // four consecutive samples per lane and round
+                const int j0 = 4 * lane + 256 * e;
+                float4 *d4 = reinterpret_cast<float4 *>(dly + j0);
+                const float4 d = *d4;
+                float o[4] = {d.x, d.y, d.z, d.w};
+                if (j0 >= kP0) {  // dsp.rs:111-117
+                    float ps[4];
+                    pcm_short4(ldsf, j0 - kP0, sw, psw, ps);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = o[q] + ps[q];
+                }
+                if (emit) *reinterpret_cast<float4 *>(frame_out + j0) = make_float4(o[0], o[1], o[2], o[3]);
+                float nd[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // dsp.rs:138-145
+                if (j0 < kP1) pcm_short4(ldsf, j0 + kP1, sw, psw, nd);
+                *d4 = make_float4(nd[0], nd[1], nd[2], nd[3]);
             }
             wave_sync();
 #pragma unroll

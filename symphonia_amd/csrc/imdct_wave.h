@@ -226,14 +226,6 @@ __device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const cp
     wave_sync();
 }
 
-// src_w[i] of dsp.rs:86-101 (i in 0..256) from the half-stored windows.
-__device__ __forceinline__ float short_src(const float *H, int w, int i) {
-    const float *h = H + 128 * w;
-    if (i < 64) return -h[63 - i];
-    if (i < 192) return h[i - 64];
-    return h[319 - i];
-}
-
 __device__ __forceinline__ void store_slot(float *frame, int m2, const float (&v)[8]) {
     float4 *o4 = reinterpret_cast<float4 *>(frame);
     o4[m2] = make_float4(v[0], v[1], v[2], v[3]);
