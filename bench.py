@@ -66,7 +66,24 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0):
     if name == "mp3":
         nch, ngr = int(128 * scale), 2048  # 64 stereo streams x 2048 granules = 131 072 granules
         xr = torch.randn((nch, ngr, 576), generator=g, device="cuda", dtype=torch.float32) * 0.05
-        side_np = sa.mp3_side(np.zeros((nch, ngr)), np.zeros((nch, ngr)), np.full((nch, ngr), 576))
+        bt, mx, rz = np.zeros((nch, ngr), np.uint8), np.zeros((nch, ngr), np.uint8), np.full((nch, ngr), 576)
+        if mix > 0.0:  # development: Long -> Start -> Short... -> End walks (a quarter of the short runs mixed), random rzero
+            rng = np.random.default_rng(seed)
+            for c in range(nch):
+                g = 0
+                while g < ngr:
+                    if rng.random() < mix and g + 3 < ngr:
+                        run = int(rng.integers(1, 4))
+                        mixed = rng.random() < 0.25
+                        bt[c, g] = 1
+                        bt[c, g + 1:g + 1 + run] = 2
+                        mx[c, g + 1:g + 1 + run] = mixed
+                        bt[c, min(g + 1 + run, ngr - 1)] = 3
+                        g += run + 2
+                    else:
+                        g += 1
+            rz = 2 * rng.integers(100, 289, (nch, ngr))
+        side_np = sa.mp3_side(bt, mx, rz)
         side = torch.from_numpy(side_np.view(np.uint8).reshape(nch, ngr, 4)).cuda()
         st = [torch.zeros((nch, 576), device="cuda"), torch.zeros((nch, 1024), device="cuda"),
               torch.zeros(nch, dtype=torch.int32, device="cuda")]
@@ -211,8 +228,8 @@ def main():
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--aac-mix", type=float, default=0.0,
-                    help="development: probability of a block switch per long frame in the AAC workload (headline: 0)")
+    ap.add_argument("--mix", dest="aac_mix", type=float, default=0.0,
+                    help="development: probability of a block switch per long frame / granule in the AAC and MP3 workloads (headline: 0)")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1 only: also time an RCCL all_gather of the PCM shards (reported beside, never inside, `value`)")
     args = ap.parse_args()

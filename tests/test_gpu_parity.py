@@ -70,6 +70,20 @@ def test_imdct_reference_kat_on_gpu(ctx):
     assert np.abs(got - imdct_analytical(x, scale)).max() < 1e-5
 
 
+def test_config1_imdct1024_one_frame_host_path(ctx):
+    """BASELINE config 1: Imdct::new_scaled(1024, 1/2048), one frame, through the host-pointer entry point
+    (symaccel_imdct_f32: stage to HBM, transform, copy back): bit-identical to the oracle, 1e-5 from the closed form."""
+    from helpers import imdct_analytical
+    from symphonia_amd import Imdct
+    rng = np.random.default_rng(0)
+    spec = rng.standard_normal((1, 1024)).astype(np.float32)
+    got = Imdct(ctx, 1024, 1.0 / 2048.0).imdct(spec)  # numpy in -> numpy out
+    assert got.shape == (1, 2048)
+    assert_parity(got, oracle.imdct(spec, 1.0 / 2048.0), "config 1")
+    ref = imdct_analytical(spec[0], 1.0 / 2048.0)
+    assert np.abs(got[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 512, 1024, 4096])
 def test_fft_parity(ctx, n):
     from helpers import dft_naive, kats
