@@ -402,6 +402,28 @@ def test_flac_config5_encoder_identity(ctx):
     assert np.array_equal(host(d), pcm.astype(np.int32))
 
 
+def test_flac_config5_step_sampled(ctx):
+    """BASELINE config 5 at the size of one bench step and beyond what the oracle could redo in full: 65 536 order-32
+    subframes of 4096 samples (1 GiB, 24-bit residual range, 15-bit coefficients, mixed shifts) restored on the GPU;
+    128 sampled subframes, including the first and last wavefront's, are checked bit-for-bit against the oracle."""
+    from symphonia_amd import FlacPredictor, flac_desc
+    nb, bs = 65536, 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
+    buf = torch.randint(-(1 << 14), 1 << 14, (nb, bs), generator=g, device="cuda", dtype=torch.int32)
+    co = torch.randint(-900, 900, (nb, 32), generator=g, device="cuda", dtype=torch.int32)
+    co[:, 0] = 6553
+    co[:, 1] = -2867
+    rng = np.random.default_rng(5)
+    shift = rng.integers(10, 15, nb).astype(np.uint8)
+    desc = flac_desc(np.full(nb, 2, np.uint8), np.full(nb, 32, np.uint8), shift, np.zeros(nb, np.uint8))
+    pick = np.unique(np.concatenate(([0, 1, 63, 64, nb - 64, nb - 1], rng.integers(0, nb, 122))))
+    before = host(buf[pick])
+    FlacPredictor(ctx).restore(buf, dev(desc.view(np.uint8).reshape(nb, 4)), co)
+    want = oracle.flac_restore(before, oracle.flac_desc(np.full(pick.size, 2), np.full(pick.size, 32), shift[pick],
+                                                        np.zeros(pick.size)), host(co[pick]))
+    assert np.array_equal(host(buf[pick]), want)
+
+
 @pytest.mark.parametrize("big_coeffs", [False, True])
 def test_flac_extreme_ranges(ctx, big_coeffs):
     """Full-range i32 samples with |c| < 2^16 (FP64-exact dot product path) and |c| up to 2^30 (i64 path)."""
