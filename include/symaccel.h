@@ -152,6 +152,13 @@ int symaccel_vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, co
                                  size_t spec_stride, const uint8_t *d_block_flag,
                                  int32_t *d_prev_flag_io, float *d_overlap_io, float *d_pcm,
                                  size_t pcm_stride, size_t n_chains, size_t blocks_per_chain);
+/* The same with the dot product fused (lib.rs:282-292 + dsp.rs:68-126): the spectrum of every channel-block is
+ * d_floor[i] * d_residue[i], multiplied as the lines are loaded -- both arrays packed like d_spectra.  Saves the
+ * separate pass of symaccel_vorbis_dot_product_device over HBM. */
+int symaccel_vorbis_synth_fr_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_floor,
+                                    const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
+                                    int32_t *d_prev_flag_io, float *d_overlap_io, float *d_pcm, size_t pcm_stride,
+                                    size_t n_chains, size_t blocks_per_chain);
 int symaccel_vorbis_synth(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *h_spectra,
                           size_t spec_stride, const uint8_t *h_block_flag, int32_t *h_prev_flag_io,
                           float *h_overlap_io, float *h_pcm, size_t pcm_stride, size_t n_chains,

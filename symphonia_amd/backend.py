@@ -289,6 +289,14 @@ class VorbisDsp:
                        _ptr(ov), _ptr(res), int(pcm_stride), nch, nb)
         return res, ov, pf
 
+    def synth_floor_residue(self, floor, residue, block_flag, prev_flag, overlap, pcm_stride, pcm):
+        """synth() with the dot product of lib.rs:282-292 fused: spectrum = floor * residue, multiplied on load.
+        Device buffers (torch tensors, or raw arrays with the CPU-emulated test library); state updated in place."""
+        nch, nb = int(block_flag.shape[0]), int(block_flag.shape[1])
+        self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_synth_fr_device, self.bs0_exp, self.bs1_exp, _ptr(floor), _ptr(residue),
+                       int(floor.shape[1]), _ptr(block_flag), _ptr(prev_flag), _ptr(overlap), _ptr(pcm), int(pcm_stride), nch, nb)
+        return pcm
+
     # device-pointer helpers (torch tensors, or raw arrays when the library treats host memory as device)
     def inverse_coupling(self, residue, n, mag_index, ang_index):
         mi = _np(mag_index, np.uint32)

@@ -433,7 +433,7 @@ int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_
 
 // ---- Vorbis -------------------------------------------------------------------------------
 
-int symaccel_vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra,
+static int vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
                                  size_t spec_stride, const uint8_t *d_block_flag, int32_t *d_prev_flag_io,
                                  float *d_overlap_io, float *d_pcm, size_t pcm_stride, size_t n_chains,
                                  size_t blocks_per_chain) {
@@ -449,10 +449,27 @@ int symaccel_vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, co
     SYM_TRY(ctx_scratch(ctx, ov_bytes + pf_bytes + 256 + off_bytes, &scratch));
     float *ov_out = (float *)scratch;
     int32_t *pf_out = (int32_t *)(ov_out + n_chains * half1);
-    SYM_TRY(launch_vorbis(ctx, bs0_exp, bs1_exp, d_spectra, spec_stride, d_block_flag, d_prev_flag_io, pf_out,
+    SYM_TRY(launch_vorbis(ctx, bs0_exp, bs1_exp, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_flag_io, pf_out,
                           d_overlap_io, ov_out, d_pcm, pcm_stride, n_chains, blocks_per_chain));
     SYM_TRY(launch_state_copy(ctx, d_overlap_io, ov_out, ov_bytes, d_prev_flag_io, pf_out, pf_bytes, nullptr, nullptr, 0));
     return SYMACCEL_OK;
+}
+
+int symaccel_vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra,
+                                 size_t spec_stride, const uint8_t *d_block_flag, int32_t *d_prev_flag_io,
+                                 float *d_overlap_io, float *d_pcm, size_t pcm_stride, size_t n_chains,
+                                 size_t blocks_per_chain) {
+    return vorbis_synth_device(ctx, bs0_exp, bs1_exp, d_spectra, nullptr, spec_stride, d_block_flag, d_prev_flag_io,
+                               d_overlap_io, d_pcm, pcm_stride, n_chains, blocks_per_chain);
+}
+
+int symaccel_vorbis_synth_fr_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_floor,
+                                    const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
+                                    int32_t *d_prev_flag_io, float *d_overlap_io, float *d_pcm, size_t pcm_stride,
+                                    size_t n_chains, size_t blocks_per_chain) {
+    if (!d_residue) return SYMACCEL_ERR_INVALID_ARG;
+    return vorbis_synth_device(ctx, bs0_exp, bs1_exp, d_floor, d_residue, spec_stride, d_block_flag, d_prev_flag_io,
+                               d_overlap_io, d_pcm, pcm_stride, n_chains, blocks_per_chain);
 }
 
 int symaccel_vorbis_synth(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *h_spectra, size_t spec_stride,

@@ -133,12 +133,14 @@ int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_
                const float *d_overlap_in, const float *d_vvec_in, const int32_t *d_vfront_in,
                float *d_overlap_out, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm,
                size_t n_chains, size_t granules_per_chain);
-int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, size_t spec_stride,
+int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
+                  size_t spec_stride,
                   const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out,
                   const float *d_overlap_in, float *d_overlap_out, float *d_pcm, size_t pcm_stride,
                   size_t n_chains, size_t blocks_per_chain);
 int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_long, const float *win_short,
-                       const float *win_long, const float *d_spectra, size_t spec_stride, const uint8_t *d_block_flag,
+                       const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride,
+                       const uint8_t *d_block_flag,
                        const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out,
                        float *d_pcm, size_t pcm_stride, const uint32_t *d_offs, size_t n_chains, unsigned nb,
                        unsigned seg);

@@ -80,12 +80,18 @@ struct VorbisShared {
 
 // Imdct of one block into sh.pcm[0 .. bs) (mdct.rs:67-146).
 template <int MAXBS>
-__device__ __forceinline__ void vorbis_imdct_block(VorbisShared<MAXBS> &sh, const float *__restrict__ spec, int bs,
+__device__ __forceinline__ void vorbis_imdct_block(VorbisShared<MAXBS> &sh, const float *__restrict__ spec,
+                                                   const float *__restrict__ res, int bs,
                                                    int log2nf, const cpx *__restrict__ tw, const DevTables &tb) {
     const int n = bs >> 1, nf = bs >> 2, n4 = bs >> 3;
     for (int i = (int)threadIdx.x; i < nf; i += kVThreads) {
         const cpx w = tw[i];
-        sh.fft[fft_pad((int)rev_bits((unsigned)i, log2nf))] = pre_twiddle(spec[2 * i], spec[n - 1 - 2 * i], c32{w.re, w.im});
+        float even = spec[2 * i], mirrored = spec[n - 1 - 2 * i];
+        if (res) {  // fused dot product (lib.rs:289-291): *f *= r
+            even *= res[2 * i];
+            mirrored *= res[n - 1 - 2 * i];
+        }
+        sh.fft[fft_pad((int)rev_bits((unsigned)i, log2nf))] = pre_twiddle(even, mirrored, c32{w.re, w.im});
     }
     wg_fft_lds(sh.fft, nf, nf, tb);
     float *vec0 = sh.pcm, *vec1 = sh.pcm + nf, *vec2 = sh.pcm + 2 * nf, *vec3 = sh.pcm + 3 * nf;
@@ -115,10 +121,10 @@ template <int MAXBS>
 __global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
     DevTables tb, int bs0_exp, int bs1_exp, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
-    size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
-    int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in, float *__restrict__ overlap_out,
-    float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs, unsigned nb, unsigned seg_len,
-    unsigned segs_per_chain) {
+    const float *__restrict__ residue, size_t spec_stride, const uint8_t *__restrict__ flags,
+    const int32_t *__restrict__ prev_flag_in, int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in,
+    float *__restrict__ overlap_out, float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs,
+    unsigned nb, unsigned seg_len, unsigned segs_per_chain) {
     __shared__ VorbisShared<MAXBS> sh;
     const int tid = (int)threadIdx.x;
     const unsigned chain = blockIdx.x / segs_per_chain, seg = blockIdx.x % segs_per_chain;
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
     const uint8_t *f = flags + (size_t)chain * nb;
     const uint32_t *os = offs + (size_t)chain * 2 * (nb + 1), *op = os + (nb + 1);
     const float *sp = spectra + (size_t)chain * spec_stride;
+    const float *rp = residue ? residue + (size_t)chain * spec_stride : nullptr;
     float *out = pcm + (size_t)chain * pcm_stride;
     const int pf0 = prev_flag_in[chain];
 
@@ -140,7 +147,8 @@ __global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
         const int flag = f[b] ? 1 : 0;
         const int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);  // lib.rs:298
         const int bs = flag ? bs1 : bs0;
-        vorbis_imdct_block<MAXBS>(sh, sp + os[b], bs, (flag ? bs1_exp : bs0_exp) - 2, flag ? tw_long : tw_short, tb);
+        vorbis_imdct_block<MAXBS>(sh, sp + os[b], rp ? rp + os[b] : nullptr, bs, (flag ? bs1_exp : bs0_exp) - 2,
+                                  flag ? tw_long : tw_short, tb);
         if (b >= (long)b_begin) {
             float *o = out + op[b];
             const float *win = (flag && pflag) ? win_long : win_short;  // dsp.rs:83
@@ -437,7 +445,8 @@ int ilog2(int v) {
 
 }  // namespace
 
-int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, size_t spec_stride,
+int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
+                  size_t spec_stride,
                   const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out,
                   const float *d_overlap_in, float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains,
                   size_t blocks_per_chain) {
@@ -464,18 +473,18 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     if (wave_path) {
         // the 256 / 2048 pair: wavefront-per-chain-segment kernel with register-resident overlap (vorbis_wave.hip)
         return launch_vorbis_wave(ctx, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
-                                  spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
+                                  d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
                                   pcm_stride, (const uint32_t *)offs, n_chains, nb, seg);
     }
     if (bs1_exp <= 11) {
         hipLaunchKernelGGL(vorbis_synth_kernel<2048>, dim3((unsigned)grid), dim3(kVThreads), 0, ctx->stream, ctx->dev,
                            bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
-                           spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
+                           d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
                            pcm_stride, (const uint32_t *)offs, nb, seg, (unsigned)segs);
     } else {
         hipLaunchKernelGGL(vorbis_synth_kernel<8192>, dim3((unsigned)grid), dim3(kVThreads), 0, ctx->stream, ctx->dev,
                            bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
-                           spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
+                           d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
                            pcm_stride, (const uint32_t *)offs, nb, seg, (unsigned)segs);
     }
     SYM_GPU(ctx, hipGetLastError());

@@ -20,6 +20,32 @@ namespace symaccel {
 
 namespace {
 
+// the group's spectral lines (and, fused, the residue lines they are multiplied with): 512 B coalesced per load
+template <bool FUSED>
+__device__ __forceinline__ void fetch_lines(const float *sp, const float *rp, uint32_t off, int n_loads, int lane,
+                                            float2 (&line)[8], float2 (&res)[8]) {
+    const float2 *src = reinterpret_cast<const float2 *>(sp + off);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        if (s < n_loads) line[s] = src[lane + 64 * s];
+    if constexpr (FUSED) {
+        const float2 *rs = reinterpret_cast<const float2 *>(rp + off);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s < n_loads) res[s] = rs[lane + 64 * s];
+    }
+}
+template <bool FUSED>
+__device__ __forceinline__ void apply_residue(float2 (&line)[8], const float2 (&res)[8]) {
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            line[s].x *= res[s].x;  // lib.rs:289-291: *f *= r
+            line[s].y *= res[s].y;
+        }
+    }
+}
+
 constexpr int kWaves = 4;
 constexpr int kTabTw = 0;        // shared LDS tables: Imdct(1024) twiddles, 512 complex
 constexpr int kTabWin = 1024;    //   long window (left half of the 2048-sample window), 1024 f32
@@ -37,10 +63,13 @@ __device__ __forceinline__ void ola_short4(const float *ws, int k, const float (
     o.w = ov[3] * wr.x + y[3] * wf.w;
 }
 
+// FUSED: the spectrum is floor[i] * residue[i] (the dot product of lib.rs:282-292), multiplied as the lines are consumed --
+// one rounded multiply per line, exactly the reference's `*f *= r`, without a separate pass over HBM.
+template <bool FUSED>
 __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     DevTables tb, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
-    size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
+    const float *__restrict__ residue, size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
     int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in, float *__restrict__ overlap_out,
     float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs, unsigned nb, unsigned seg_len,
     unsigned segs_per_chain, unsigned n_items) {
@@ -67,6 +96,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     const uint8_t *f = flags + (size_t)chain * nb;
     const uint32_t *os = offs + (size_t)chain * 2 * (nb + 1), *op = os + (nb + 1);
     const float *sp = spectra + (size_t)chain * spec_stride;
+    const float *rp = FUSED ? residue + (size_t)chain * spec_stride : nullptr;
     float *out = pcm + (size_t)chain * pcm_stride;
     const int pf0 = prev_flag_in[chain];
 
@@ -122,14 +152,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     // flag of the block before b (lib.rs:298: the first block of a stream pairs with itself)
     int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);
     uint32_t os_cur = os[b_first], op_cur = op[b_first];  // packed spectrum / PCM offsets of block b
-    float2 line[8];  // the group's spectral lines: 1024 (long) or 128 per short block, 512 B coalesced per load
-    if (glen > 0) {
-        const float2 *src = reinterpret_cast<const float2 *>(sp + os_cur);
-        const int n_loads = flag ? 8 : glen;
+    float2 line[8], res[8];  // the group's lines: 1024 (long) or 128 per short block
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-            if (s < n_loads) line[s] = src[lane + 64 * s];
-    }
+    for (int s = 0; s < 8; ++s) line[s] = res[s] = make_float2(0.0f, 0.0f);
+    if (glen > 0) fetch_lines<FUSED>(sp, rp, os_cur, flag ? 8 : glen, lane, line, res);
 
     while (b < (long)b_end) {
         const long nb_next = b + glen;
@@ -142,18 +168,13 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
             const bool emit = b >= (long)b_begin;
             c32 z[8];
             const int mirror = (63 - lane) * 4;
+            apply_residue<FUSED>(line, res);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
                 z[s] = pre_twiddle(line[s].x, mirrored, tw[lane + 64 * s]);
             }
-            if (glen_next > 0) {  // prefetch the next group
-                const float2 *src = reinterpret_cast<const float2 *>(sp + os_next);
-                const int n_loads = flag_next ? 8 : glen_next;
-#pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    if (s < n_loads) line[s] = src[lane + 64 * s];
-            }
+            if (glen_next > 0) fetch_lines<FUSED>(sp, rp, os_next, flag_next ? 8 : glen_next, lane, line, res);  // prefetch
             fft512_wave(z, lane, lds, lt);
             float x[2][8], x2[2][8];
 #pragma unroll
@@ -206,6 +227,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
             hi_fresh = true;
         } else {
             // ------------------------------------------------------------------ a run of `glen` short blocks
+            apply_residue<FUSED>(line, res);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {  // block s of the run -> window s of the eight-way short transform
                 if (s < glen) {
@@ -214,13 +236,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                 }
             }
             wave_sync();
-            if (glen_next > 0) {
-                const float2 *src = reinterpret_cast<const float2 *>(sp + os_next);
-                const int n_loads = flag_next ? 8 : glen_next;
-#pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    if (s < n_loads) line[s] = src[lane + 64 * s];
-            }
+            if (glen_next > 0) fetch_lines<FUSED>(sp, rp, os_next, flag_next ? 8 : glen_next, lane, line, res);
             imdct_short_wave(lane, ldsf, tw_short, lt);  // H[8][128] in ldsf[0..1024); ends with a wave_sync
             for (int i = 0; i < glen; ++i) {
                 const long blk = b + i;
@@ -292,10 +308,9 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
 #pragma unroll
                 for (int q = 0; q < 8; ++q) keep[h][q] = dl[h][q];
             if (bl >= 0) {
-                const float2 *src = reinterpret_cast<const float2 *>(sp + os[bl]);
                 c32 z[8];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) line[s] = src[lane + 64 * s];
+                fetch_lines<FUSED>(sp, rp, os[bl], 8, lane, line, res);
+                apply_residue<FUSED>(line, res);
                 const int mirror = (63 - lane) * 4;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
@@ -334,7 +349,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
 }  // namespace
 
 int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_long, const float *win_short,
-                       const float *win_long, const float *d_spectra, size_t spec_stride, const uint8_t *d_block_flag,
+                       const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride,
+                       const uint8_t *d_block_flag,
                        const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out,
                        float *d_pcm, size_t pcm_stride, const uint32_t *d_offs, size_t n_chains, unsigned nb,
                        unsigned seg) {
@@ -342,10 +358,16 @@ int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_lon
     const size_t items = n_chains * segs;
     const size_t grid = (items + kWaves - 1) / kWaves;
     if (items > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(vorbis_synth_wave_kernel, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev,
-                       tw_short, tw_long, win_short, win_long, d_spectra, spec_stride, d_block_flag, d_prev_in,
-                       d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs,
-                       (unsigned)items);
+    if (d_residue)
+        hipLaunchKernelGGL(vorbis_synth_wave_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev,
+                           tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in,
+                           d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs,
+                           (unsigned)items);
+    else
+        hipLaunchKernelGGL(vorbis_synth_wave_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev,
+                           tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in,
+                           d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs,
+                           (unsigned)items);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -125,6 +125,22 @@ def test_emu_vorbis_wave_paths(emu_ctx, seed, nb, p_long, tail_short, seg):
     assert np.array_equal(got[2], want[2]), "prev flag"
 
 
+@pytest.mark.parametrize("bs0e,bs1e,seg", [(8, 11, 3), (6, 9, 4)])
+def test_emu_vorbis_fused_dot_product(emu_ctx, bs0e, bs1e, seg):
+    """synth on floor x residue (fused multiply on load) == dot product, then synth -- wave kernel and generic kernel."""
+    rng = np.random.default_rng(77 + bs0e)
+    flags, prev, floor, overlap, pcm_stride = vorbis_case(rng, bs0e, bs1e, 3, 11)
+    residue = rng.standard_normal(floor.shape).astype(np.float32)
+    v = VorbisDsp(emu_ctx, bs0e, bs1e)
+    emu_ctx.set_segment(seg)
+    pf, ov = prev.copy(), overlap.copy()
+    pcm = np.zeros((flags.shape[0], pcm_stride), np.float32)
+    v.synth_floor_residue(floor, residue, flags, pf, ov, pcm_stride, pcm)
+    emu_ctx.set_segment(0)
+    want = oracle.vorbis_synth(bs0e, bs1e, floor * residue, flags, prev, overlap, pcm_stride)
+    assert bit_equal(pcm, want[0]) and bit_equal(ov, want[1]) and np.array_equal(pf, want[2])
+
+
 def test_emu_vorbis_helpers(emu_ctx):
     rng = np.random.default_rng(5)
     v = VorbisDsp(emu_ctx, 8, 11)

@@ -324,6 +324,24 @@ def test_vorbis_config4_shard_properties(ctx):
     assert np.array_equal(host(outs[0][2][pick]), want[2])
 
 
+@pytest.mark.parametrize("bs0e,bs1e,seg", [(8, 11, 0), (7, 10, 0)])
+def test_vorbis_fused_dot_product(ctx, bs0e, bs1e, seg):
+    """symaccel_vorbis_synth_fr_device: floor x residue multiplied on load == dot product kernel + synth."""
+    from test_emu_codecs import vorbis_case
+    from symphonia_amd import VorbisDsp
+    rng = np.random.default_rng(91 + bs0e)
+    flags, prev, floor, overlap, pcm_stride = vorbis_case(rng, bs0e, bs1e, 10, 70)
+    residue = rng.standard_normal(floor.shape).astype(np.float32)
+    v = VorbisDsp(ctx, bs0e, bs1e)
+    d_prev, d_ov = dev(prev), dev(overlap)
+    pcm = torch.zeros((flags.shape[0], pcm_stride), device="cuda")
+    v.synth_floor_residue(dev(floor), dev(residue), dev(flags), d_prev, d_ov, pcm_stride, pcm)
+    want = oracle.vorbis_synth(bs0e, bs1e, floor * residue, flags, prev, overlap, pcm_stride)
+    assert_parity(host(pcm), want[0], "fused pcm")
+    assert_parity(host(d_ov), want[1], "fused overlap")
+    assert np.array_equal(host(d_prev), want[2])
+
+
 def test_vorbis_helpers_parity(ctx):
     from symphonia_amd import VorbisDsp
     rng = np.random.default_rng(8)

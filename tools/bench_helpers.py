@@ -62,7 +62,7 @@ def main():
     ctx.close()
 
 
-if __name__ == "__main__" and "--core" not in sys.argv:
+if __name__ == "__main__" and "--core" not in sys.argv and "--vorbis-fused" not in sys.argv:
     main()
 
 
@@ -89,3 +89,49 @@ def core_transforms():
 
 if __name__ == "__main__" and "--core" in sys.argv:
     core_transforms()
+
+
+def vorbis_fused():
+    """Config-4 shard: dot product kernel + synth versus synth with the dot product fused."""
+    ctx = sa.Context(0)
+    ctx.use_torch_stream()
+    nch, nb = 64, 4096
+    rng = np.random.default_rng(4)
+    flags = np.zeros((nch, nb), np.uint8)
+    cur = np.ones(nch, bool)
+    for b in range(nb):
+        r = rng.random(nch)
+        cur = np.where(cur, r < 0.9, r >= 0.7)
+        flags[:, b] = cur
+    v = sa.VorbisDsp(ctx, 8, 11)
+    so, po = v.layout(flags, np.full(nch, -1))
+    spec_stride, pcm_stride = int(so[:, -1].max()), int(po[:, -1].max())
+    floor = torch.randn((nch, spec_stride), device="cuda")
+    residue = torch.randn((nch, spec_stride), device="cuda")
+    work = torch.empty_like(floor)
+    d_flags = torch.from_numpy(flags).cuda()
+    prev = torch.full((nch,), -1, dtype=torch.int32, device="cuda")
+    overlap = torch.zeros((nch, 1024), device="cuda")
+    pcm = torch.zeros((nch, pcm_stride), device="cuda")
+
+    def separate():
+        work.copy_(floor)  # the dot product is in place on the floor (lib.rs:289-291)
+        v.dot_product(work, residue, work.numel())
+        prev.fill_(-1)
+        v.synth(work, d_flags, prev, overlap, pcm_stride, pcm)
+
+    def separate_no_copy():
+        v.dot_product(work, residue, work.numel())
+        prev.fill_(-1)
+        v.synth(work, d_flags, prev, overlap, pcm_stride, pcm)
+
+    def fused():
+        prev.fill_(-1)
+        v.synth_floor_residue(floor, residue, d_flags, prev, overlap, pcm_stride, pcm)
+
+    print("vorbis config-4 shard: dot product + synth  %.3f ms   fused  %.3f ms" % (timeit(separate_no_copy) * 1e3, timeit(fused) * 1e3))
+    ctx.close()
+
+
+if __name__ == "__main__" and "--vorbis-fused" in sys.argv:
+    vorbis_fused()
