@@ -143,10 +143,12 @@ __global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
     __syncthreads();
 
     const long b_first = b_begin == 0 ? 0 : (long)b_begin - 1;  // halo block rebuilds the overlap only
+    bool hi_fresh = b_begin == 0 || bs0 == bs1;  // overlap[bs0/2 .. bs1/2) is what the reference would hold here
     for (long b = b_first; b < (long)b_end; ++b) {
         const int flag = f[b] ? 1 : 0;
         const int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);  // lib.rs:298
         const int bs = flag ? bs1 : bs0;
+        hi_fresh = hi_fresh || flag;
         vorbis_imdct_block<MAXBS>(sh, sp + os[b], rp ? rp + os[b] : nullptr, bs, (flag ? bs1_exp : bs0_exp) - 2,
                                   flag ? tw_long : tw_short, tb);
         if (b >= (long)b_begin) {
@@ -174,6 +176,22 @@ __global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
     }
 
     if (b_end == nb) {
+        if (!hi_fresh) {
+            // The chain ends in short blocks and this segment never saw a long one: overlap[bs0/2 .. bs1/2) still holds
+            // what the most recent long block left there (dsp.rs:125 only rewrites the first bs/2 entries; never used
+            // for PCM, but part of the state the reference carries).  Rebuild it from that block, or keep the incoming
+            // state if the batch has no long block before this segment.
+            long bl = (long)b_begin - 1;
+            while (bl >= 0 && !f[bl]) --bl;
+            if (bl >= 0) {
+                vorbis_imdct_block<MAXBS>(sh, sp + os[bl], rp ? rp + os[bl] : nullptr, bs1, bs1_exp - 2, tw_long, tb);
+                for (int k = bs0 / 2 + tid; k < bs1 / 2; k += kVThreads) sh.overlap[k] = sh.pcm[bs1 / 2 + k];
+            } else {
+                for (int k = bs0 / 2 + tid; k < bs1 / 2; k += kVThreads)
+                    sh.overlap[k] = overlap_in[(size_t)chain * (size_t)(bs1 / 2) + k];
+            }
+            __syncthreads();
+        }
         for (int i = tid; i < bs1 / 2; i += kVThreads) overlap_out[(size_t)chain * (size_t)(bs1 / 2) + i] = sh.overlap[i];
         if (tid == 0) prev_flag_out[chain] = f[nb - 1] ? 1 : 0;  // lib.rs:328
     }

@@ -125,6 +125,24 @@ def test_emu_vorbis_wave_paths(emu_ctx, seed, nb, p_long, tail_short, seg):
     assert np.array_equal(got[2], want[2]), "prev flag"
 
 
+@pytest.mark.parametrize("bs0e,bs1e,seg,tail", [(6, 9, 2, 5), (7, 10, 3, 9), (6, 8, 1, 12)])
+def test_emu_vorbis_generic_state_after_short_tail(emu_ctx, bs0e, bs1e, seg, tail):
+    """Generic kernel: a chain that ends in more short blocks than a segment holds -- the part of `overlap` the short
+    blocks do not rewrite must still be what the last long block left (or the incoming state)."""
+    rng = np.random.default_rng(31 + bs1e)
+    flags, prev, spectra, overlap, pcm_stride = vorbis_case(rng, bs0e, bs1e, 3, 14)
+    flags[:, 14 - tail:] = 0
+    flags[2, :] = 0  # a chain with no long block at all keeps the incoming state
+    lay = oracle.vorbis_layout(bs0e, bs1e, flags, prev)
+    spectra = (rng.standard_normal((3, int(lay[0][:, -1].max()))) * 0.25).astype(np.float32)
+    pcm_stride = int(lay[1][:, -1].max())
+    emu_ctx.set_segment(seg)
+    got = VorbisDsp(emu_ctx, bs0e, bs1e).synth(spectra, flags, prev, overlap, pcm_stride)
+    emu_ctx.set_segment(0)
+    want = oracle.vorbis_synth(bs0e, bs1e, spectra, flags, prev, overlap, pcm_stride)
+    assert bit_equal(got[0], want[0]) and bit_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+
+
 @pytest.mark.parametrize("bs0e,bs1e,seg", [(8, 11, 3), (6, 9, 4)])
 def test_emu_vorbis_fused_dot_product(emu_ctx, bs0e, bs1e, seg):
     """synth on floor x residue (fused multiply on load) == dot product, then synth -- wave kernel and generic kernel."""
