@@ -205,6 +205,12 @@ int symaccel_flac_restore_device(symaccel_ctx *ctx, int32_t *d_buf, const symacc
                                  const int32_t *d_coeffs, size_t n_blocks, size_t blocksize);
 int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac_desc *h_desc,
                           const int32_t *h_coeffs, size_t n_blocks, size_t blocksize);
+/* Predictor restore with the stereo decorrelation and the final shift fused into the write-back: blocks 2p and 2p+1
+ * are channel 0 and channel 1 of pair p (n_blocks even), pair_mode[p] as for symaccel_flac_decorrelate_device below,
+ * out_shift = 32 - bits_per_sample.  One pass over HBM instead of two (decoder.rs:199-242 in one kernel). */
+int symaccel_flac_restore_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
+                                        const int32_t *d_coeffs, const uint8_t *d_pair_mode, uint32_t out_shift,
+                                        size_t n_blocks, size_t blocksize);
 /* decorrelate_{left_side,mid_side,right_side} (decoder.rs:32-82) then `<< out_shift`
  * (decoder.rs:239-242, out_shift = 32 - bits_per_sample, 0 = none) over n_pairs channel pairs:
  * mode[pair] in {0 independent, 1 left/side, 2 mid/side, 3 right/side}; ch0/ch1[pair][blocksize]. */

@@ -349,6 +349,14 @@ class FlacPredictor:
         self.ctx._call(d.symaccel_flac_restore, _ptr(res), _ptr(dsc), _ptr(co), nb, bs)
         return res
 
+    def restore_stereo(self, buf, desc, coeffs, pair_mode, out_shift=0):
+        """restore() with decorrelate + `<< out_shift` fused into the write-back: blocks 2p / 2p+1 = channels of pair p.
+        Device buffers, in place."""
+        nb, bs = int(buf.shape[0]), int(buf.shape[1])
+        self.ctx._call(self.ctx.lib.dll.symaccel_flac_restore_stereo_device, _ptr(buf), _ptr(desc), _ptr(coeffs),
+                       _ptr(pair_mode), int(out_shift), nb, bs)
+        return buf
+
     def decorrelate(self, mode, ch0, ch1, blocksize, out_shift=0):
         n_pairs = (ch0.numel() if _is_torch(ch0) else ch0.size) // int(blocksize)
         self.ctx._call(self.ctx.lib.dll.symaccel_flac_decorrelate_device, _ptr(mode), _ptr(ch0), _ptr(ch1), n_pairs,

@@ -595,6 +595,16 @@ int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac
     return symaccel_sync(ctx);
 }
 
+int symaccel_flac_restore_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
+                                        const int32_t *d_coeffs, const uint8_t *d_pair_mode, uint32_t out_shift,
+                                        size_t n_blocks, size_t blocksize) {
+    if (!ctx || blocksize > 0xffffffffu || out_shift > 31 || (n_blocks & 1)) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!d_buf || !d_desc || !d_coeffs || !d_pair_mode) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_flac_restore(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize, d_pair_mode, out_shift);
+}
+
 int symaccel_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *h_mode, int32_t *h_ch0, int32_t *h_ch1, size_t n_pairs,
                               size_t blocksize, uint32_t out_shift) {
     if (!ctx || out_shift > 31) return SYMACCEL_ERR_INVALID_ARG;

@@ -146,10 +146,13 @@ __device__ __forceinline__ void load_params(LaneParams &p, const symaccel_flac_d
 // One kernel per arithmetic path, so each is register-allocated for what it keeps live (the FP64
 // path: 32 coefficients + 32 history samples as doubles = 128 VGPRs).  Both are launched over the same
 // grid; a wavefront whose subframes belong to the other path exits after reading its parameters.
-template <bool F64>
+// DECOR: blocks 2p / 2p+1 are the two channels of pair p; the stereo decorrelation (decoder.rs:32-82) and the final
+// `<< (32 - bps)` (decoder.rs:239-242) are applied as the restored tile is written back -- no separate pass over HBM.
+template <bool F64, bool DECOR>
 __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc,
                                                   const int32_t *__restrict__ coeffs, size_t n_blocks,
-                                                  unsigned blocksize, int32_t *tiles) {
+                                                  unsigned blocksize, int32_t *tiles, const uint8_t *__restrict__ pair_mode,
+                                                  uint32_t out_shift, uint8_t *row_mode) {
     const int lane = (int)threadIdx.x;
     const size_t blk0 = (size_t)blockIdx.x * kRows;
     const size_t my = blk0 + (size_t)lane;
@@ -157,6 +160,7 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
     LaneParams p;
     load_params(p, desc, coeffs, my, have, blocksize);
     if (p.use_f64 != F64) return;
+    if constexpr (DECOR) row_mode[lane] = have ? pair_mode[my >> 1] : 0;  // ordered by the first tile's wave_sync
 
     using T = typename std::conditional<F64, double, int32_t>::type;
     T c[32], h[32];
@@ -203,26 +207,37 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
             }
         }
         wave_sync();
-        if (fast)
-            tile_store_fast(buf, tile, blk0, blocksize, t0, lane);
-        else
-            tile_store_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+        if constexpr (DECOR) {
+            if (fast)
+                tile_store_decorrelate_fast(buf, tile, row_mode, out_shift, blk0, blocksize, t0, lane);
+            else
+                tile_store_decorrelate_slow(buf, tile, row_mode, out_shift, blk0, n_blocks, blocksize, t0, cols, lane);
+        } else {
+            if (fast)
+                tile_store_fast(buf, tile, blk0, blocksize, t0, lane);
+            else
+                tile_store_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+        }
         // no barrier here: the next round writes the OTHER LDS tile, and its barrier orders these reads
     }
 }
 
+template <bool DECOR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void flac_restore_f64_kernel(
     int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
-    size_t n_blocks, unsigned blocksize) {
+    size_t n_blocks, unsigned blocksize, const uint8_t *__restrict__ pair_mode, uint32_t out_shift) {
     __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
-    flac_restore_body<true>(buf, desc, coeffs, n_blocks, blocksize, tiles);
+    __shared__ uint8_t row_mode[kRows];
+    flac_restore_body<true, DECOR>(buf, desc, coeffs, n_blocks, blocksize, tiles, pair_mode, out_shift, row_mode);
 }
 
+template <bool DECOR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void flac_restore_i64_kernel(
     int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
-    size_t n_blocks, unsigned blocksize) {
+    size_t n_blocks, unsigned blocksize, const uint8_t *__restrict__ pair_mode, uint32_t out_shift) {
     __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
-    flac_restore_body<false>(buf, desc, coeffs, n_blocks, blocksize, tiles);
+    __shared__ uint8_t row_mode[kRows];
+    flac_restore_body<false, DECOR>(buf, desc, coeffs, n_blocks, blocksize, tiles, pair_mode, out_shift, row_mode);
 }
 
 // decoder.rs:32-82 + :239-242
@@ -251,14 +266,21 @@ __global__ void flac_decorrelate_kernel(const uint8_t *__restrict__ mode, int32_
 }  // namespace
 
 int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc, const int32_t *d_coeffs,
-                        size_t n_blocks, size_t blocksize) {
+                        size_t n_blocks, size_t blocksize, const uint8_t *d_pair_mode, uint32_t out_shift) {
     const size_t grid = (n_blocks + kRows - 1) / kRows;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(flac_restore_f64_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
-                       d_coeffs, n_blocks, (unsigned)blocksize);
-    SYM_GPU(ctx, hipGetLastError());
-    hipLaunchKernelGGL(flac_restore_i64_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
-                       d_coeffs, n_blocks, (unsigned)blocksize);
+    const dim3 g((unsigned)grid), b(64);
+    if (d_pair_mode) {
+        hipLaunchKernelGGL(flac_restore_f64_kernel<true>, g, b, 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
+                           (unsigned)blocksize, d_pair_mode, out_shift);
+        hipLaunchKernelGGL(flac_restore_i64_kernel<true>, g, b, 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
+                           (unsigned)blocksize, d_pair_mode, out_shift);
+    } else {
+        hipLaunchKernelGGL(flac_restore_f64_kernel<false>, g, b, 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
+                           (unsigned)blocksize, d_pair_mode, out_shift);
+        hipLaunchKernelGGL(flac_restore_i64_kernel<false>, g, b, 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
+                           (unsigned)blocksize, d_pair_mode, out_shift);
+    }
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

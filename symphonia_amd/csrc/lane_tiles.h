@@ -73,6 +73,54 @@ __device__ __forceinline__ void tile_store_slow(int32_t *__restrict__ buf, const
     }
 }
 
+// Stereo decorrelation of one restored sample (flac decoder.rs:32-82) followed by the left-justification shift
+// (decoder.rs:239-242).  `own` is the sample of this row's channel, `other` the same sample of the pair's other channel;
+// rows 2p / 2p+1 of a wavefront's tile are channel 0 / 1 of pair p.  mode: 0 independent, 1 left/side, 2 mid/side,
+// 3 right/side (ch0 = side, ch1 = right).
+__device__ __forceinline__ int32_t flac_decorrelated(unsigned mode, bool is_ch1, int32_t own, int32_t other, uint32_t out_shift) {
+    const int32_t a = is_ch1 ? other : own, b = is_ch1 ? own : other;  // (ch0, ch1) as decoded
+    int32_t v = own;
+    if (mode == 1) {  // left/side: side = left - side
+        v = is_ch1 ? (int32_t)((uint32_t)a - (uint32_t)b) : a;
+    } else if (mode == 2) {  // mid/side
+        const int32_t mid = (int32_t)(((uint32_t)a << 1) | ((uint32_t)b & 1u));
+        v = is_ch1 ? ((int32_t)((uint32_t)mid - (uint32_t)b) >> 1) : ((int32_t)((uint32_t)mid + (uint32_t)b) >> 1);
+    } else if (mode == 3) {  // right/side: side += right
+        v = is_ch1 ? b : (int32_t)((uint32_t)a + (uint32_t)b);
+    }
+    return (int32_t)((uint32_t)v << out_shift);
+}
+// Tile write-back with the decorrelation fused in: every lane reads its row and the pair's other row from LDS.
+// `row_mode[r]` = mode of the pair row r belongs to.
+__device__ __forceinline__ void tile_store_decorrelate_fast(int32_t *__restrict__ buf, const int32_t *tile,
+                                                            const uint8_t *row_mode, uint32_t out_shift, size_t blk0,
+                                                            unsigned blocksize, unsigned t0, int lane) {
+    const int q = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = 8 * k + rsub;
+        const int4 own = *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q);
+        const int4 oth = *reinterpret_cast<const int4 *>(tile + (r ^ 1) * kStride + 4 * q);
+        const unsigned m = row_mode[r];
+        const bool c1 = (r & 1) != 0;
+        *reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q) =
+            make_int4(flac_decorrelated(m, c1, own.x, oth.x, out_shift), flac_decorrelated(m, c1, own.y, oth.y, out_shift),
+                      flac_decorrelated(m, c1, own.z, oth.z, out_shift), flac_decorrelated(m, c1, own.w, oth.w, out_shift));
+    }
+}
+__device__ __forceinline__ void tile_store_decorrelate_slow(int32_t *__restrict__ buf, const int32_t *tile,
+                                                            const uint8_t *row_mode, uint32_t out_shift, size_t blk0,
+                                                            size_t n_blocks, unsigned blocksize, unsigned t0, unsigned cols,
+                                                            int lane) {
+    const int c = lane & 31, rsub = lane >> 5;
+#pragma unroll 4
+    for (int r = rsub; r < kRows; r += 2) {
+        if (blk0 + (size_t)r < n_blocks && (unsigned)c < cols)
+            buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)c] =
+                flac_decorrelated(row_mode[r], (r & 1) != 0, tile[r * kStride + c], tile[(r ^ 1) * kStride + c], out_shift);
+    }
+}
+
 // The workgroup is one wavefront: order its LDS traffic with wavefront-scope fences only.  (__syncthreads() carries a
 // workgroup-scope release, which makes the wavefront wait for its outstanding GLOBAL stores at every tile.)
 __device__ __forceinline__ void wave_sync() {

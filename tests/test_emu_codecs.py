@@ -235,6 +235,27 @@ def test_emu_flac_extreme_ranges(emu_ctx, big_coeffs):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("blocksize,nb", [(64, 64), (100, 70), (192, 6), (31, 130)])
+def test_emu_flac_restore_stereo_fused(emu_ctx, blocksize, nb):
+    """restore with decorrelation + shift fused into the write-back == restore, then decorrelate, then shift."""
+    rng = np.random.default_rng(blocksize + nb)
+    buf = rng.integers(-(1 << 20), 1 << 20, (nb, blocksize)).astype(np.int32)
+    kind = rng.integers(0, 3, nb).astype(np.uint8)
+    order = np.minimum(np.where(kind == FLAC_FIXED, rng.integers(0, 5, nb), rng.integers(1, 33, nb)), blocksize).astype(np.uint8)
+    kind[(kind == FLAC_LPC) & (order == 0)] = FLAC_VERBATIM
+    shift = rng.integers(0, 16, nb).astype(np.uint8)
+    wasted = np.where(rng.random(nb) < 0.2, rng.integers(1, 4, nb), 0).astype(np.uint8)
+    coeffs = rng.integers(-(1 << 14), 1 << 14, (nb, 32)).astype(np.int32)
+    mode = rng.integers(0, 4, nb // 2).astype(np.uint8)
+    got = buf.copy()
+    FlacPredictor(emu_ctx).restore_stereo(got, flac_desc(kind, order, shift, wasted), coeffs, mode, 8)
+    want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, wasted), coeffs)
+    for p in range(nb // 2):
+        a, b = oracle.flac_decorrelate(int(mode[p]), want[2 * p], want[2 * p + 1])
+        want[2 * p], want[2 * p + 1] = oracle.flac_shl(a, 8), oracle.flac_shl(b, 8)
+    assert np.array_equal(got, want)
+
+
 def test_emu_flac_decorrelate(emu_ctx):
     rng = np.random.default_rng(29)
     n_pairs, bs = 9, 77

@@ -454,6 +454,29 @@ def test_flac_extreme_ranges(ctx, big_coeffs):
     assert np.array_equal(host(d), want)
 
 
+@pytest.mark.parametrize("blocksize,nb", [(4096, 256), (1000, 130), (33, 64)])
+def test_flac_restore_stereo_fused(ctx, blocksize, nb):
+    """symaccel_flac_restore_stereo_device == restore, decorrelate, shift (decoder.rs:199-242)."""
+    from symphonia_amd import FlacPredictor, flac_desc
+    rng = np.random.default_rng(blocksize)
+    buf = rng.integers(-(1 << 20), 1 << 20, (nb, blocksize)).astype(np.int32)
+    kind = rng.integers(0, 3, nb).astype(np.uint8)
+    order = np.minimum(np.where(kind == 1, rng.integers(0, 5, nb), rng.integers(1, 33, nb)), blocksize).astype(np.uint8)
+    kind[(kind == 2) & (order == 0)] = 0
+    shift = rng.integers(0, 16, nb).astype(np.uint8)
+    wasted = np.where(rng.random(nb) < 0.2, rng.integers(1, 4, nb), 0).astype(np.uint8)
+    coeffs = rng.integers(-(1 << 14), 1 << 14, (nb, 32)).astype(np.int32)
+    mode = rng.integers(0, 4, nb // 2).astype(np.uint8)
+    d = dev(buf)
+    FlacPredictor(ctx).restore_stereo(d, dev(flac_desc(kind, order, shift, wasted).view(np.uint8).reshape(nb, 4)), dev(coeffs),
+                                      dev(mode), 8)
+    want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, wasted), coeffs)
+    for p in range(nb // 2):
+        a, b = oracle.flac_decorrelate(int(mode[p]), want[2 * p], want[2 * p + 1])
+        want[2 * p], want[2 * p + 1] = oracle.flac_shl(a, 8), oracle.flac_shl(b, 8)
+    assert np.array_equal(host(d), want)
+
+
 def test_flac_decorrelate_parity(ctx):
     from symphonia_amd import FlacPredictor
     rng = np.random.default_rng(6)

@@ -62,7 +62,7 @@ def main():
     ctx.close()
 
 
-if __name__ == "__main__" and "--core" not in sys.argv and "--vorbis-fused" not in sys.argv:
+if __name__ == "__main__" and "--core" not in sys.argv and "--vorbis-fused" not in sys.argv and "--flac-fused" not in sys.argv:
     main()
 
 
@@ -135,3 +135,34 @@ def vorbis_fused():
 
 if __name__ == "__main__" and "--vorbis-fused" in sys.argv:
     vorbis_fused()
+
+
+def flac_fused():
+    """Config-5 step: restore + decorrelate/shift as two passes versus the fused kernel."""
+    ctx = sa.Context(0)
+    ctx.use_torch_stream()
+    nb, bs = 131072, 4096
+    buf = torch.randint(-(1 << 12), 1 << 12, (nb, bs), device="cuda", dtype=torch.int32)
+    desc = torch.from_numpy(sa.flac_desc(np.full(nb, 2), np.full(nb, 32), np.full(nb, 12), np.zeros(nb)).view(np.uint8).reshape(nb, 4)).cuda()
+    co = torch.randint(-40, 40, (nb, 32), device="cuda", dtype=torch.int32)
+    co[:, 0] = 6553
+    co[:, 1] = -2867
+    mode = torch.randint(0, 4, (nb // 2,), device="cuda", dtype=torch.uint8)
+    fp = sa.FlacPredictor(ctx)
+    pairs = buf.view(nb // 2, 2, bs)
+
+    def separate():
+        fp.restore(buf, desc, co)
+        # channel planes of a pair are rows 2p / 2p+1: decorrelate wants ch0[pair][bs], ch1[pair][bs] -> two strided views
+        # are not contiguous, so the two-pass pipeline is timed on contiguous halves (same byte count)
+        fp.decorrelate(mode, buf[: nb // 2], buf[nb // 2:], bs, 8)
+
+    def fused():
+        fp.restore_stereo(buf, desc, co, mode, 8)
+
+    print("flac %d blocks: restore + decorrelate  %.3f ms   fused  %.3f ms" % (nb, timeit(separate, 5) * 1e3, timeit(fused, 5) * 1e3))
+    ctx.close()
+
+
+if __name__ == "__main__" and "--flac-fused" in sys.argv:
+    flac_fused()
