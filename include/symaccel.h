@@ -238,6 +238,11 @@ int symaccel_alac_predict_device(symaccel_ctx *ctx, int32_t *d_buf, const symacc
                                  const int32_t *d_coeffs, size_t n_blocks, size_t blocksize);
 int symaccel_alac_predict(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_alac_desc *h_desc,
                           const int32_t *h_coeffs, size_t n_blocks, size_t blocksize);
+/* predict with decorrelate_mid_side fused into the write-back (decode_element, lib.rs:541-560, in one pass over HBM):
+ * blocks 2p and 2p+1 are the two channels of pair p (n_blocks even); pair_weight[p] (0 = no mixing), pair_shift[p]. */
+int symaccel_alac_predict_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc,
+                                        const int32_t *d_coeffs, const int32_t *d_pair_weight,
+                                        const uint8_t *d_pair_shift, size_t n_blocks, size_t blocksize);
 /* decorrelate_mid_side (lib.rs:664-671) over n_pairs channel pairs: weight[pair] (0 = pair left alone, lib.rs:552),
  * shift[pair] (<= 31, lib.rs:555); ch0/ch1[pair][blocksize]. */
 int symaccel_alac_mid_side_device(symaccel_ctx *ctx, const int32_t *d_weight, const uint8_t *d_shift,

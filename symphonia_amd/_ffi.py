@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "symaccel_vorbis_dot_product_device", "symaccel_vorbis_deinterleave2_device",
     "symaccel_vorbis_floor1_device", "symaccel_flac_restore_device", "symaccel_flac_restore", "symaccel_flac_restore_stereo_device",
     "symaccel_flac_decorrelate_device", "symaccel_flac_decorrelate", "symaccel_alac_predict_device",
-    "symaccel_alac_predict", "symaccel_alac_mid_side_device", "symaccel_alac_mid_side", "symaccel_table_f32", "symaccel_imdct_twiddles",
+    "symaccel_alac_predict", "symaccel_alac_predict_stereo_device", "symaccel_alac_mid_side_device", "symaccel_alac_mid_side", "symaccel_table_f32", "symaccel_imdct_twiddles",
     "symaccel_fft_twiddles",
 ]
 
@@ -86,6 +86,7 @@ class Library:
         d.symaccel_flac_restore.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_flac_decorrelate_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz, _u32]
         d.symaccel_alac_predict_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_alac_predict_stereo_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_predict.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_mid_side_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_mid_side.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]

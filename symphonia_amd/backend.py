@@ -393,6 +393,14 @@ class AlacPredictor:
         self.ctx._call(d.symaccel_alac_predict, _ptr(res), _ptr(dsc), _ptr(co), nb, bs)
         return res
 
+    def predict_stereo(self, buf, desc, coeffs, pair_weight, pair_shift):
+        """predict() with decorrelate_mid_side fused into the write-back: blocks 2p / 2p+1 = channels of pair p.
+        Device buffers, in place."""
+        nb, bs = int(buf.shape[0]), int(buf.shape[1])
+        self.ctx._call(self.ctx.lib.dll.symaccel_alac_predict_stereo_device, _ptr(buf), _ptr(desc), _ptr(coeffs),
+                       _ptr(pair_weight), _ptr(pair_shift), nb, bs)
+        return buf
+
     def mid_side(self, weight, shift, ch0, ch1):
         """ch0/ch1[n_pairs, blocksize]; weight[n_pairs] i32, shift[n_pairs] u8.  numpy: returns new arrays; torch: in place."""
         d = self.ctx.lib.dll

@@ -93,14 +93,60 @@ __device__ __forceinline__ void alac_steps32(AlacLane &L, int32_t *row, const in
     }
 }
 
+// decorrelate_mid_side (lib.rs:664-671) for one sample of a pair: out0 = s0 + s1 - ((s1 * weight) >> shift),
+// out1 = out0 - s1; weight == 0 leaves the pair alone (lib.rs:552).  `own` / `other`: this row's and the pair's other
+// row's predicted sample; rows 2p / 2p+1 are channels 0 / 1 of pair p.
+__device__ __forceinline__ int32_t alac_mixed(int32_t weight, uint32_t shift, bool is_ch1, int32_t own, int32_t other) {
+    if (weight == 0) return own;
+    const int32_t s0 = is_ch1 ? other : own, s1 = is_ch1 ? own : other;
+    const int32_t o0 = wrap_sub(wrap_add(s0, s1), wrap_mul(s1, weight) >> shift);
+    return is_ch1 ? wrap_sub(o0, s1) : o0;
+}
+__device__ __forceinline__ void alac_store_mixed(int32_t *__restrict__ buf, const int32_t *tile, const int32_t *row_weight,
+                                                 const uint8_t *row_shift, size_t blk0, size_t n_blocks, unsigned blocksize,
+                                                 unsigned t0, unsigned cols, int lane, bool fast) {
+    if (fast) {
+        const int q = lane & 7, rsub = lane >> 3;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = 8 * k + rsub;
+            const int4 own = *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q);
+            const int4 oth = *reinterpret_cast<const int4 *>(tile + (r ^ 1) * kStride + 4 * q);
+            const int32_t w = row_weight[r];
+            const uint32_t sh = row_shift[r];
+            const bool c1 = (r & 1) != 0;
+            *reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q) =
+                make_int4(alac_mixed(w, sh, c1, own.x, oth.x), alac_mixed(w, sh, c1, own.y, oth.y),
+                          alac_mixed(w, sh, c1, own.z, oth.z), alac_mixed(w, sh, c1, own.w, oth.w));
+        }
+    } else {
+        const int c = lane & 31, rsub = lane >> 5;
+#pragma unroll 4
+        for (int r = rsub; r < kRows; r += 2) {
+            if (blk0 + (size_t)r < n_blocks && (unsigned)c < cols)
+                buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)c] =
+                    alac_mixed(row_weight[r], row_shift[r], (r & 1) != 0, tile[r * kStride + c], tile[(r ^ 1) * kStride + c]);
+        }
+    }
+}
+
+// MIX: blocks 2p / 2p+1 are the two channels of element pair p; decorrelate_mid_side runs as the predicted tile is
+// written back (decode_element, lib.rs:541-560, in one pass).
+template <bool MIX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void alac_predict_kernel(
     int32_t *__restrict__ buf, const symaccel_alac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
-    size_t n_blocks, unsigned blocksize) {
+    size_t n_blocks, unsigned blocksize, const int32_t *__restrict__ pair_weight, const uint8_t *__restrict__ pair_shift) {
     __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
+    __shared__ int32_t row_weight[kRows];
+    __shared__ uint8_t row_shift[kRows];
     const int lane = (int)threadIdx.x;
     const size_t blk0 = (size_t)blockIdx.x * kRows;
     const size_t my = blk0 + (size_t)lane;
     const bool have = my < n_blocks;
+    if constexpr (MIX) {  // ordered by the first tile's wave_sync
+        row_weight[lane] = have ? pair_weight[my >> 1] : 0;
+        row_shift[lane] = have ? (uint8_t)(pair_shift[my >> 1] & 31u) : 0;
+    }
 
     AlacLane L;
 #pragma unroll
@@ -159,10 +205,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 alac_steps32<32>(L, row, prow, t0, (int)cols);
         }
         wave_sync();
-        if (fast)
-            tile_store_fast(buf, tile, blk0, blocksize, t0, lane);
-        else
-            tile_store_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+        if constexpr (MIX) {
+            alac_store_mixed(buf, tile, row_weight, row_shift, blk0, n_blocks, blocksize, t0, cols, lane, fast);
+        } else {
+            if (fast)
+                tile_store_fast(buf, tile, blk0, blocksize, t0, lane);
+            else
+                tile_store_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+        }
     }
 }
 
@@ -184,11 +234,15 @@ __global__ void alac_mid_side_kernel(const int32_t *__restrict__ weight, const u
 }  // namespace
 
 int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc, const int32_t *d_coeffs,
-                        size_t n_blocks, size_t blocksize) {
+                        size_t n_blocks, size_t blocksize, const int32_t *d_pair_weight, const uint8_t *d_pair_shift) {
     const size_t grid = (n_blocks + kRows - 1) / kRows;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(alac_predict_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs,
-                       n_blocks, (unsigned)blocksize);
+    if (d_pair_weight)
+        hipLaunchKernelGGL(alac_predict_kernel<true>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs,
+                           n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift);
+    else
+        hipLaunchKernelGGL(alac_predict_kernel<false>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs,
+                           n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

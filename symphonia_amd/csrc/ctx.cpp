@@ -682,6 +682,16 @@ int symaccel_alac_predict_device(symaccel_ctx *ctx, int32_t *d_buf, const symacc
     return launch_alac_predict(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize);
 }
 
+int symaccel_alac_predict_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc,
+                                        const int32_t *d_coeffs, const int32_t *d_pair_weight, const uint8_t *d_pair_shift,
+                                        size_t n_blocks, size_t blocksize) {
+    if (!ctx || blocksize > 0xffffffffu || (n_blocks & 1)) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!d_buf || !d_desc || !d_coeffs || !d_pair_weight || !d_pair_shift) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_alac_predict(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize, d_pair_weight, d_pair_shift);
+}
+
 int symaccel_alac_predict(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_alac_desc *h_desc, const int32_t *h_coeffs,
                           size_t n_blocks, size_t blocksize) {
     if (!ctx || blocksize > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;

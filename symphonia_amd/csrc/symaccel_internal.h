@@ -154,7 +154,8 @@ int launch_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *d_in, con
                          const int32_t *d_vfront_in, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm, size_t n_chains,
                          size_t packets_per_chain);
 int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc, const int32_t *d_coeffs,
-                        size_t n_blocks, size_t blocksize);
+                        size_t n_blocks, size_t blocksize, const int32_t *d_pair_weight = nullptr,
+                        const uint8_t *d_pair_shift = nullptr);
 int launch_alac_mid_side(symaccel_ctx *ctx, const int32_t *d_weight, const uint8_t *d_shift, int32_t *d_ch0, int32_t *d_ch1,
                          size_t n_pairs, size_t blocksize);
 int launch_state_copy(symaccel_ctx *ctx, void *dst0, const void *src0, size_t bytes0, void *dst1, const void *src1,

@@ -125,6 +125,23 @@ def test_emu_alac_uniform_small_orders(emu_ctx):
         assert np.array_equal(got, oracle.alac_predict(buf, oracle.alac_desc(*d), coeffs)), hi
 
 
+@pytest.mark.parametrize("blocksize,nb", [(64, 64), (100, 70), (31, 130)])
+def test_emu_alac_predict_stereo_fused(emu_ctx, blocksize, nb):
+    """predict with decorrelate_mid_side fused into the write-back == predict, then decorrelate_mid_side."""
+    from symphonia_amd import AlacPredictor, alac_desc
+    buf, mode, order, shift, bps, coeffs = alac_case(7 * blocksize, nb, blocksize)
+    rng = np.random.default_rng(blocksize)
+    weight = rng.integers(-3, 4, nb // 2).astype(np.int32)
+    msh = rng.integers(0, 32, nb // 2).astype(np.uint8)
+    got = buf.copy()
+    AlacPredictor(emu_ctx).predict_stereo(got, alac_desc(mode, order, shift, bps), coeffs, weight, msh)
+    want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
+    for p in range(nb // 2):
+        if weight[p]:
+            want[2 * p], want[2 * p + 1] = oracle.alac_decorrelate_mid_side(want[2 * p], want[2 * p + 1], int(weight[p]), int(msh[p]))
+    assert np.array_equal(got, want)
+
+
 def test_emu_alac_mid_side(emu_ctx):
     from symphonia_amd import AlacPredictor
     rng = np.random.default_rng(4)
@@ -153,6 +170,11 @@ def test_gpu_alac_predict(blocksize):
         AlacPredictor(ctx).predict(d, desc, torch.from_numpy(coeffs).cuda())
         torch.cuda.synchronize()
         got = d.cpu().numpy()
+        d2 = torch.from_numpy(buf.copy()).cuda()
+        AlacPredictor(ctx).predict_stereo(d2, desc, torch.from_numpy(coeffs).cuda(), torch.arange(-50, 50, dtype=torch.int32).cuda(),
+                                          (torch.arange(100) % 32).to(torch.uint8).cuda())
+        torch.cuda.synchronize()
+        got_fused = d2.cpu().numpy()
         a = torch.from_numpy(buf[:100].copy()).cuda()
         b = torch.from_numpy(buf[100:].copy()).cuda()
         w = torch.arange(-50, 50, dtype=torch.int32).cuda()
@@ -162,6 +184,12 @@ def test_gpu_alac_predict(blocksize):
         ga, gb = a.cpu().numpy(), b.cpu().numpy()
     want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
     assert np.array_equal(got, want)
+    wq = np.arange(-50, 50, dtype=np.int32)
+    sq = (np.arange(100) % 32).astype(np.uint8)
+    for p in range(100):
+        if wq[p]:
+            want[2 * p], want[2 * p + 1] = oracle.alac_decorrelate_mid_side(want[2 * p], want[2 * p + 1], int(wq[p]), int(sq[p]))
+    assert np.array_equal(got_fused, want)
     for p in range(100):
         wgt, sh = p - 50, p % 32
         wa, wb = (buf[p], buf[100 + p]) if wgt == 0 else oracle.alac_decorrelate_mid_side(buf[p], buf[100 + p], wgt, sh)
