@@ -475,25 +475,27 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     const float *ws = nullptr, *wl = nullptr;
     SYM_TRY(get_vorbis_window(ctx, 1 << bs0_exp, &ws));
     SYM_TRY(get_vorbis_window(ctx, 1 << bs1_exp, &wl));
-    // the ABI wrapper reserved room for the offsets behind the state copies in ctx->scratch
-    const size_t half1 = (size_t)1 << (bs1_exp - 1);
-    const size_t state_bytes = n_chains * half1 * 4 + n_chains * 4;
-    uint32_t *offs = (uint32_t *)((char *)ctx->scratch + ((state_bytes + 255) / 256) * 256);
     const unsigned nb = (unsigned)blocks_per_chain;
-    hipLaunchKernelGGL(vorbis_offsets_kernel, dim3((unsigned)n_chains), dim3(256), 0, ctx->stream, d_block_flag,
-                       d_prev_in, offs, nb, 1 << bs0_exp, 1 << bs1_exp);
-    SYM_GPU(ctx, hipGetLastError());
     const bool wave_path = bs0_exp == 8 && bs1_exp == 11;
     const unsigned seg = choose_segment(ctx, n_chains, nb, wave_path ? 8 : 12, 1, 1, 1);
     const size_t segs = (nb + seg - 1) / seg;
     const size_t grid = n_chains * segs;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     if (wave_path) {
-        // the 256 / 2048 pair: wavefront-per-chain-segment kernel with register-resident overlap (vorbis_wave.hip)
+        // the 256 / 2048 pair: wavefront-per-chain-segment kernel with register-resident overlap (vorbis_wave.hip);
+        // it derives the packed offsets itself
         return launch_vorbis_wave(ctx, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
                                   d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
-                                  pcm_stride, (const uint32_t *)offs, n_chains, nb, seg);
+                                  pcm_stride, n_chains, nb, seg);
     }
+    // generic path: a scan kernel turns the flag sequence into packed offsets (the ABI wrapper reserved room for them
+    // behind the state copies in ctx->scratch)
+    const size_t half1 = (size_t)1 << (bs1_exp - 1);
+    const size_t state_bytes = n_chains * half1 * 4 + n_chains * 4;
+    uint32_t *offs = (uint32_t *)((char *)ctx->scratch + ((state_bytes + 255) / 256) * 256);
+    hipLaunchKernelGGL(vorbis_offsets_kernel, dim3((unsigned)n_chains), dim3(256), 0, ctx->stream, d_block_flag,
+                       d_prev_in, offs, nb, 1 << bs0_exp, 1 << bs1_exp);
+    SYM_GPU(ctx, hipGetLastError());
     if (bs1_exp <= 11) {
         hipLaunchKernelGGL(vorbis_synth_kernel<2048>, dim3((unsigned)grid), dim3(kVThreads), 0, ctx->stream, ctx->dev,
                            bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,

@@ -12,7 +12,8 @@
 // Block-size transitions stay in registers too: the 128 overlap-added samples of a long <-> short transition live in
 // the slots of lanes 48..63, the short overlap in lanes 0..31 (one ds_bpermute hop), the copied samples are stored
 // straight from the slot registers; short-block output is read from the half-stored LDS result of the short pass.
-// Packed spectrum / PCM offsets come from vorbis_offsets_kernel (vorbis.hip).
+// The packed spectrum / PCM offsets of a segment's first block follow from the number of long blocks before it, which
+// every wavefront counts itself (16 flags per lane and step); no separate scan kernel runs for this block-size pair.
 // HBM traffic per channel-block: 4 * (n/2) B in + 4 * (prev_n + n)/4 B out (+ one halo block per segment).
 #include "imdct_wave.h"
 
@@ -46,6 +47,33 @@ __device__ __forceinline__ void apply_residue(float2 (&line)[8], const float2 (&
     }
 }
 
+// Number of long blocks among the first `b` blocks of a chain (flags: one byte per block, non-zero = long).
+// 1024 flags per step: each lane takes 16 (flags before the 16-byte alignment point of the row are masked off).
+__device__ __forceinline__ unsigned count_long_before(const uint8_t *f, long b, int lane) {
+    unsigned total = 0;
+    const long mis = (long)(reinterpret_cast<uintptr_t>(f) & 15u);  // f - mis is 16-byte aligned
+    const uint4 *base = reinterpret_cast<const uint4 *>(f - mis);
+    for (long i0 = -mis; i0 < b; i0 += 1024) {
+        const long i = i0 + 16 * lane;  // index of this lane's first flag
+        unsigned cnt = 0;
+        if (i >= 0 && i + 16 <= b) {  // all 16 flags belong to [0, b): one 16-byte load
+            const uint4 v = base[(i + mis) >> 4];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cnt += ((w[q >> 2] >> (8 * (q & 3))) & 255u) ? 1u : 0u;
+        } else if (i < b && i + 16 > 0) {  // the ragged first / last group: byte loads, nothing outside [0, b) is touched
+            for (int q = 0; q < 16; ++q) {
+                const long idx = i + q;
+                if (idx >= 0 && idx < b) cnt += f[idx] ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) cnt += (unsigned)__shfl_xor((int)cnt, m);
+        total += cnt;
+    }
+    return total;
+}
+
 constexpr int kWaves = 4;
 constexpr int kTabTw = 0;        // shared LDS tables: Imdct(1024) twiddles, 512 complex
 constexpr int kTabWin = 1024;    //   long window (left half of the 2048-sample window), 1024 f32
@@ -71,7 +99,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
     const float *__restrict__ residue, size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
     int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in, float *__restrict__ overlap_out,
-    float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs, unsigned nb, unsigned seg_len,
+    float *__restrict__ pcm, size_t pcm_stride, unsigned nb, unsigned seg_len,
     unsigned segs_per_chain, unsigned n_items) {
     __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
@@ -94,7 +122,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     const unsigned chain = item / segs_per_chain, seg = item % segs_per_chain;
     const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
     const uint8_t *f = flags + (size_t)chain * nb;
-    const uint32_t *os = offs + (size_t)chain * 2 * (nb + 1), *op = os + (nb + 1);
     const float *sp = spectra + (size_t)chain * spec_stride;
     const float *rp = FUSED ? residue + (size_t)chain * spec_stride : nullptr;
     float *out = pcm + (size_t)chain * pcm_stride;
@@ -151,7 +178,18 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     int glen = group_at(b, flag);
     // flag of the block before b (lib.rs:298: the first block of a stream pairs with itself)
     int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);
-    uint32_t os_cur = os[b_first], op_cur = op[b_first];  // packed spectrum / PCM offsets of block b
+    // Packed offsets of block b: with S(b) = sum of the first b block sizes = 256 b + 1792 L(b), L(b) = long blocks before b,
+    //   spectrum offset = S(b) / 2,   PCM offset = (S(b) + n_{-1} + S(b-1)) / 4  (lib.rs:303: block k yields (n_{k-1} + n_k) / 4),
+    // where n_{-1} is the size the first block is paired with (its own when there is no previous block, lib.rs:298).
+    auto sizes_before = [&](long bb) -> uint32_t { return 256u * (uint32_t)bb + 1792u * count_long_before(f, bb, lane); };
+    uint32_t os_cur = 0, op_cur = 0;
+    if (b_first > 0) {
+        const uint32_t s_b = sizes_before(b_first);
+        const uint32_t n_prev = f[b_first - 1] ? 2048u : 256u;                  // size of block b_first - 1
+        const uint32_t n_m1 = pf0 < 0 ? (f[0] ? 2048u : 256u) : (pf0 ? 2048u : 256u);
+        os_cur = s_b / 2;
+        op_cur = (s_b + n_m1 + (s_b - n_prev)) / 4;
+    }
     float2 line[8], res[8];  // the group's lines: 1024 (long) or 128 per short block
 #pragma unroll
     for (int s = 0; s < 8; ++s) line[s] = res[s] = make_float2(0.0f, 0.0f);
@@ -309,7 +347,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                 for (int q = 0; q < 8; ++q) keep[h][q] = dl[h][q];
             if (bl >= 0) {
                 c32 z[8];
-                fetch_lines<FUSED>(sp, rp, os[bl], 8, lane, line, res);
+                fetch_lines<FUSED>(sp, rp, sizes_before(bl) / 2, 8, lane, line, res);
                 apply_residue<FUSED>(line, res);
                 const int mirror = (63 - lane) * 4;
 #pragma unroll
@@ -352,7 +390,7 @@ int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_lon
                        const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride,
                        const uint8_t *d_block_flag,
                        const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out,
-                       float *d_pcm, size_t pcm_stride, const uint32_t *d_offs, size_t n_chains, unsigned nb,
+                       float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb,
                        unsigned seg) {
     const size_t segs = (nb + seg - 1) / seg;
     const size_t items = n_chains * segs;
@@ -361,12 +399,12 @@ int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_lon
     if (d_residue)
         hipLaunchKernelGGL(vorbis_synth_wave_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev,
                            tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in,
-                           d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs,
+                           d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, nb, seg, (unsigned)segs,
                            (unsigned)items);
     else
         hipLaunchKernelGGL(vorbis_synth_wave_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev,
                            tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in,
-                           d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs,
+                           d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, nb, seg, (unsigned)segs,
                            (unsigned)items);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
