@@ -50,12 +50,11 @@ __device__ __forceinline__ void apply_residue(float2 (&line)[8], const float2 (&
 // Number of long blocks among the first `b` blocks of a chain (flags: one byte per block, non-zero = long).
 // 1024 flags per step: each lane takes 16 (flags before the 16-byte alignment point of the row are masked off).
 __device__ __forceinline__ unsigned count_long_before(const uint8_t *f, long b, int lane) {
-    unsigned total = 0;
+    unsigned cnt = 0;  // per-lane partial count, reduced once at the end
     const long mis = (long)(reinterpret_cast<uintptr_t>(f) & 15u);  // f - mis is 16-byte aligned
     const uint4 *base = reinterpret_cast<const uint4 *>(f - mis);
     for (long i0 = -mis; i0 < b; i0 += 1024) {
         const long i = i0 + 16 * lane;  // index of this lane's first flag
-        unsigned cnt = 0;
         if (i >= 0 && i + 16 <= b) {  // all 16 flags belong to [0, b): one 16-byte load
             const uint4 v = base[(i + mis) >> 4];
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -67,11 +66,10 @@ __device__ __forceinline__ unsigned count_long_before(const uint8_t *f, long b, 
                 if (idx >= 0 && idx < b) cnt += f[idx] ? 1u : 0u;
             }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) cnt += (unsigned)__shfl_xor((int)cnt, m);
-        total += cnt;
     }
-    return total;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cnt += (unsigned)__shfl_xor((int)cnt, m);
+    return cnt;
 }
 
 constexpr int kWaves = 4;
