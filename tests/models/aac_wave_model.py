@@ -4,18 +4,19 @@
 Emulates the 64 lanes of one wavefront with numpy float32 arithmetic (IEEE, no FMA), using the
 exact lane <-> data mapping, twiddle forms and LDS transposes the HIP kernel uses, and checks
 the result bit-for-bit against the CPU oracle.  Also feeds the LDS address functions to
-tools/lds_sim.py to count bank-conflict cycles of the chosen layout.
+tests/models/lds_sim.py to count bank-conflict cycles of the chosen layout.
 
-This is a dev tool (not shipped, not imported by the product).
+Test infrastructure (tests/test_models.py runs it); not shipped, not imported by the product.
 """
 import sys
 from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-import oracle  # noqa: E402  (dev tool: allowed to use the oracle)
-from tools import lds_sim  # noqa: E402
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import oracle  # noqa: E402  (test infrastructure: the oracle is the checker)
+import lds_sim  # noqa: E402
 
 F = np.float32
 LANES = np.arange(64)
@@ -257,8 +258,8 @@ def main():
         print("trial", trial, "bit-exact vs oracle:", same)
     for (name, instr), (c, ideal) in totals.items():
         print("%-10s %-10s LDS cycles %3d (ideal %3d)" % (name, instr, c, ideal))
-    sys.exit(0 if ok else 1)
+    return ok, totals
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(0 if main()[0] else 1)
