@@ -28,7 +28,8 @@ namespace {
 
 constexpr int kTileFloats = 2 * 576;             // two granule tiles (one per half-wave)
 constexpr int kSBase = 0;  // the dct32 transpose reuses the granule tiles' LDS (the tiles are dead by then)
-constexpr int kWaveFloats = kSBase + 2 * 18 * kSStride + kDwFloats;  // per-wavefront LDS (>= the two tiles)
+constexpr int kWinBase = kSBase + 2 * 18 * kSStride + kDwFloats;
+constexpr int kWaveFloats = kWinBase + 4 * 36;  // per-wavefront LDS: tiles / transpose, synthesis window rows, IMDCT windows
 static_assert(2 * 18 * kSStride >= kTileFloats, "the transpose area must hold the two granule tiles");
 
 // ---- 36-point IMDCT (Szu-Wei Lee), hybrid_synthesis.rs:559-779 -------------------------------
@@ -77,7 +78,9 @@ __device__ __forceinline__ void dct_iv_18(const float (&x)[18], float (&y)[19]) 
 }
 
 // imdct36 (hybrid_synthesis.rs:571-603): x[18] in place, overlap[18] in/out
-__device__ __forceinline__ void imdct36(float (&x)[18], float (&overlap)[18], cf32p window) {
+// `window`: the block type's 36-entry window in LDS (the block type differs between the two chains of a
+// wavefront, so the window is per lane: LDS broadcast reads instead of per-lane global loads)
+__device__ __forceinline__ void imdct36(float (&x)[18], float (&overlap)[18], const float *window) {
     float dct[19];
     dct_iv_18(x, dct);
 #pragma unroll
@@ -157,6 +160,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
             dwt[hl * kDwStride + 8 + j] = tb.mp3_consts[MP3C_SYNTH_D + 64 * j + 32 + hl];
         }
     }
+    float *imdct_win = lds + kWinBase;  // the four 36-entry IMDCT windows (hybrid_synthesis.rs:31-101)
+    for (int i = (int)threadIdx.x; i < 4 * 36; i += 64) imdct_win[i] = tb.mp3_consts[MP3C_IMDCT_WIN + i];
     const VMap vm = vmap(hl);
 
     // ---- incoming state.  oA[16 + r] = V_r[i], oB[16 + r] = V_r[32 + i] for the previous granules' time slots r < 0
@@ -190,13 +195,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
 
     // The granule's 576 lines as 144 float4: lane hl holds float4 hl + 32 q, q = 0..3, and (hl < 16) float4 128 + hl.
     // 16 B per lane: 512 B coalesced per half-wave and instruction (narrow accesses are issue-bound, not HBM-bound).
+    // side info of the next granule, kept as the raw 32-bit word: any arithmetic on it here would make the
+    // compiler wait for the load (and every line load issued before it) right after issuing them
+    static_assert(sizeof(symaccel_mp3_side) == 4, "side info is fetched as one dword");
+    const uint32_t *side_raw = reinterpret_cast<const uint32_t *>(side);
+    uint32_t sd_next = 0;
     float4 line[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) line[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    symaccel_mp3_side sd_next{};
     if (live && g_first < g_stop) {
         fetch_granule(xr + (chain_base + (size_t)g_first) * 576, hl, line);
-        sd_next = side[chain_base + (size_t)g_first];
+        sd_next = side_raw[chain_base + (size_t)g_first];
     }
 
     for (long r = 0; r < rounds; ++r) {
@@ -207,10 +216,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
 
         int bt = 0, mixed = 0, rzero = 0;
         if (active) {
-            const symaccel_mp3_side sd = sd_next;  // fetched one granule ahead, with the lines
-            bt = sd.block_type;
-            mixed = sd.is_mixed ? 1 : 0;
-            rzero = sd.rzero > 576 ? 576 : sd.rzero;
+            const uint32_t sd = sd_next;  // fetched one granule ahead, with the lines (little-endian struct layout)
+            bt = (int)(sd & 0xffu);
+            mixed = (sd & 0xff00u) ? 1 : 0;
+            rzero = (int)(sd >> 16) > 576 ? 576 : (int)(sd >> 16);
         }
         // ---- granule -> LDS tile (natural order), then lane sb gathers its 18 lines
         if (active) {
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
                 }
             } else if (sb < sb_split) {
                 const int wi = bt == SYMACCEL_MP3_START ? 1 : (bt == SYMACCEL_MP3_END ? 3 : 0);
-                imdct36(y, overlap, mc + MP3C_IMDCT_WIN + 36 * wi);
+                imdct36(y, overlap, imdct_win + 36 * wi);
             } else {
                 imdct12_win(y, overlap, mc + MP3C_IMDCT_WIN + 36 * 2);
             }
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
         }
         if (live && g + 1 < g_stop) {  // prefetch the next granule; it lands during the dct32 and window passes
             fetch_granule(xr + (chain_base + (size_t)(g + 1)) * 576, hl, line);
-            sd_next = side[chain_base + (size_t)(g + 1)];
+            sd_next = side_raw[chain_base + (size_t)(g + 1)];
         }
         wave_sync();  // the previous granule's window pass has read S
         if (need_hist) {

@@ -111,6 +111,7 @@ static inline void __builtin_amdgcn_wave_barrier() {
 }
 static inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
 
 // dst[lane] = src[(byte_addr / 4) % 64] within the lane's wavefront
 static inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int value) {
