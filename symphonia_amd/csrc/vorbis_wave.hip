@@ -48,22 +48,23 @@ __device__ __forceinline__ void apply_residue(float2 (&line)[8], const float2 (&
 }
 
 // Number of long blocks among the first `b` blocks of a chain (flags: one byte per block, non-zero = long).
-// 1024 flags per step: each lane takes 16 (flags before the 16-byte alignment point of the row are masked off).
+// 1024 flags per step: each lane takes an aligned group of 16 (flags outside [0, b) are masked off).
 __device__ __forceinline__ unsigned count_long_before(const uint8_t *f, long b, int lane) {
     unsigned cnt = 0;  // per-lane partial count, reduced once at the end
     const long mis = (long)(reinterpret_cast<uintptr_t>(f) & 15u);  // f - mis is 16-byte aligned
     const uint4 *base = reinterpret_cast<const uint4 *>(f - mis);
     for (long i0 = -mis; i0 < b; i0 += 1024) {
         const long i = i0 + 16 * lane;  // index of this lane's first flag
-        if (i >= 0 && i + 16 <= b) {  // all 16 flags belong to [0, b): one 16-byte load
+        if (i < b && i + 16 > 0) {
+            // One aligned 16-byte load per lane.  In the ragged first / last group the load also covers bytes outside
+            // [0, b): they share an aligned 16-byte unit with a byte that is inside, so the access cannot fault, and
+            // they are masked off below (a byte-wise tail would be 16 dependent loads, each waited for in turn).
             const uint4 v = base[(i + mis) >> 4];
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int q = 0; q < 16; ++q) cnt += ((w[q >> 2] >> (8 * (q & 3))) & 255u) ? 1u : 0u;
-        } else if (i < b && i + 16 > 0) {  // the ragged first / last group: byte loads, nothing outside [0, b) is touched
             for (int q = 0; q < 16; ++q) {
-                const long idx = i + q;
-                if (idx >= 0 && idx < b) cnt += f[idx] ? 1u : 0u;
+                const bool inside = i + q >= 0 && i + q < b;
+                cnt += (inside && ((w[q >> 2] >> (8 * (q & 3))) & 255u)) ? 1u : 0u;
             }
         }
     }
