@@ -130,6 +130,34 @@ int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_
                        int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
                        size_t granules_per_chain);
 
+/* Requantisation, the stage in front of stereo + the synthesis tail: the value mapping of
+ * read_huffman_samples (layer3/requantize.rs:117-147, 172-205, 234: a decoded Huffman sample s becomes
+ * (1 - 2 sign) * POW43[|s|], 0.0 for s == 0 and from rzero on; POW43: requantize.rs:28-31) followed by requantize
+ * (requantize.rs:239-380: every scale-factor band times `f64::powf(2.0, 0.25 * (A - B)) as f32`, long / short /
+ * mixed band tables of layer3/common.rs:9-172 -- including the reference's handling of a mixed block's last long
+ * band, whose edge list stops one band short of the first short band, requantize.rs:368-372).
+ * quant[n][576]: the signed quantised samples (|s| <= 8206; larger magnitudes are clamped to the table end);
+ * desc[n]; xr[n][576] in the layout symaccel_mp3_synth_device consumes.  Both tables come from the host's libm.
+ * Domain: subblock_gain < 8, scalefacs[i] + 3 <= 255 (every value the bitstream can code); exponents outside the
+ * table (unreachable inside the domain) are clamped. */
+#define SYMACCEL_MP3_RQ_SCALEFAC_SCALE 1u /* GranuleChannel::scalefac_scale */
+#define SYMACCEL_MP3_RQ_PREFLAG 2u        /* GranuleChannel::preflag */
+typedef struct symaccel_mp3_requant { /* the GranuleChannel fields requantize reads (layer3/mod.rs) */
+    uint8_t global_gain;
+    uint8_t flags;            /* SYMACCEL_MP3_RQ_* */
+    uint8_t block_type;       /* SYMACCEL_MP3_* */
+    uint8_t is_mixed;
+    uint8_t subblock_gain[3];
+    uint8_t reserved;
+    uint16_t rzero;           /* first sample of the rzero partition (<= 576) */
+    uint8_t scalefacs[39];
+    uint8_t pad[3];
+} symaccel_mp3_requant;       /* 52 bytes */
+int symaccel_mp3_requantize_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_desc,
+                                   int sample_rate_idx, float *d_xr, size_t n_granule_channels);
+int symaccel_mp3_requantize(symaccel_ctx *ctx, const int16_t *h_quant, const symaccel_mp3_requant *h_desc,
+                            int sample_rate_idx, float *h_xr, size_t n_granule_channels);
+
 /* synthesis::synthesis alone (synthesis.rs:158-336) as Layer I and Layer II use it: n_frames = 12
  * (layer1/mod.rs:193) or 36 (layer2/mod.rs:383) time slots per packet and channel.  in[chain][packet][32 * n_frames]
  * sub-band-major (in[n_frames * i + b], synthesis.rs:168-170); pcm[chain][packet][32 * n_frames]; state per chain:
@@ -260,7 +288,9 @@ enum symaccel_table {
     SYMACCEL_TABLE_MP3_SYNTH_D = 4,    /* 512, synthesis.rs:13-142 */
     SYMACCEL_TABLE_MP3_IMDCT_WIN = 5,  /* 4*36, hybrid_synthesis.rs:53-92 */
     SYMACCEL_TABLE_VORBIS_FLOOR1_DB = 6, /* 256, vorbis floor.rs:21-112 */
-    SYMACCEL_TABLE_MP3_CONSTS = 7       /* 264: the hybrid-synthesis / dct32 constants in the kernels' packed order */
+    SYMACCEL_TABLE_MP3_CONSTS = 7,      /* 264: the hybrid-synthesis / dct32 constants in the kernels' packed order */
+    SYMACCEL_TABLE_MP3_POW43 = 8,       /* 8207, requantize.rs:28-31 */
+    SYMACCEL_TABLE_MP3_POW2AB = 9       /* 1346: 2^(0.25 e), e = -1300 .. 45 (requantize.rs:280, 343) */
 };
 /* Copies the HOST copy of a constant table; returns the number of floats, or a negative status. */
 int symaccel_table_f32(const symaccel_ctx *ctx, int table, float *dst, size_t capacity);

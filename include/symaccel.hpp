@@ -209,6 +209,38 @@ inline void synthesize_batch(Context &ctx, int sample_rate_idx, const float *xr,
           ctx.raw());
 }
 
+// requantize(header, channel, buf) (requantize.rs:356-380) together with the sample mapping of read_huffman_samples
+// (requantize.rs:117-147): `quant` holds the signed quantised Huffman samples, `buf` receives xr.
+struct RequantizeChannel {  // the GranuleChannel fields requantize reads (layer3/common.rs:187-230)
+    std::uint8_t global_gain = 210;
+    bool scalefac_scale = false, preflag = false;
+    BlockType block_type = BlockType::Long;
+    bool is_mixed = false;
+    std::array<std::uint8_t, 3> subblock_gain{};
+    std::uint16_t rzero = 576;
+    std::array<std::uint8_t, 39> scalefacs{};
+};
+inline symaccel_mp3_requant to_abi(const RequantizeChannel &c) {
+    symaccel_mp3_requant d{};
+    d.global_gain = c.global_gain;
+    d.flags = (std::uint8_t)((c.scalefac_scale ? SYMACCEL_MP3_RQ_SCALEFAC_SCALE : 0u) | (c.preflag ? SYMACCEL_MP3_RQ_PREFLAG : 0u));
+    d.block_type = (std::uint8_t)c.block_type;
+    d.is_mixed = c.is_mixed ? 1 : 0;
+    for (int w = 0; w < 3; ++w) d.subblock_gain[w] = c.subblock_gain[(std::size_t)w];
+    d.rzero = c.rzero;
+    for (int i = 0; i < 39; ++i) d.scalefacs[i] = c.scalefacs[(std::size_t)i];
+    return d;
+}
+inline void requantize(Context &ctx, int sample_rate_idx, const RequantizeChannel &channel, const std::array<std::int16_t, 576> &quant,
+                       std::array<float, 576> &buf) {
+    const symaccel_mp3_requant d = to_abi(channel);
+    check(symaccel_mp3_requantize(ctx.raw(), quant.data(), &d, sample_rate_idx, buf.data(), 1), ctx.raw());
+}
+inline void requantize_batch(Context &ctx, int sample_rate_idx, const std::int16_t *quant, const symaccel_mp3_requant *desc, float *xr,
+                             std::size_t n_granule_channels) {
+    check(symaccel_mp3_requantize(ctx.raw(), quant, desc, sample_rate_idx, xr, n_granule_channels), ctx.raw());
+}
+
 // synthesis(state, n_frames, in_samples, out) (synthesis.rs:158-336) as Layer I (n_frames 12) and Layer II (36) call it
 inline void synthesis(Context &ctx, SynthesisState &state, std::size_t n_frames, const float *in_samples, std::size_t in_len,
                       float *out, std::size_t out_len) {

@@ -389,6 +389,44 @@ def alac_decorrelate_mid_side(out0, out1, weight, shift):
     return a, b
 
 
+# ---- MP3 requantisation (layer3/requantize.rs) ---------------------------------
+
+MP3_REQUANT_DTYPE = np.dtype([("global_gain", np.uint8), ("flags", np.uint8), ("block_type", np.uint8),
+                              ("is_mixed", np.uint8), ("subblock_gain", np.uint8, (3,)), ("reserved", np.uint8),
+                              ("rzero", np.uint16), ("scalefacs", np.uint8, (39,)), ("pad", np.uint8, (3,))])
+assert MP3_REQUANT_DTYPE.itemsize == 52
+MP3_RQ_SCALEFAC_SCALE, MP3_RQ_PREFLAG = 1, 2
+MP3_POW2AB_MIN_E, MP3_POW2AB_LEN = -1300, 1346
+
+
+def mp3_sfb_long(sr):
+    out = np.zeros(23, np.int32)
+    lib().so_mp3_sfb_long(int(sr), _p(out))
+    return out
+
+
+def mp3_pow43():
+    out = np.zeros(8207, np.float32)
+    lib().so_mp3_pow43(_p(out))
+    return out
+
+
+def mp3_pow2ab():
+    out = np.zeros(MP3_POW2AB_LEN, np.float32)
+    lib().so_mp3_pow2ab(_p(out))
+    return out
+
+
+def mp3_requantize(quant, desc, sr):
+    """read_huffman_samples' value mapping + requantize for quant[n, 576] int16, desc[n] MP3_REQUANT_DTYPE."""
+    q = np.ascontiguousarray(quant, dtype=np.int16).reshape(-1, 576)
+    d = np.ascontiguousarray(desc, dtype=MP3_REQUANT_DTYPE).reshape(-1)
+    assert d.shape[0] == q.shape[0]
+    out = np.zeros(q.shape, np.float32)
+    lib().so_mp3_requantize_batch(_p(q), _p(d), int(sr), _p(out), C.c_size_t(q.shape[0]))
+    return out
+
+
 # ---- timing driver (bench.py cpu_baseline) ------------------------------------
 
 def bench_mt(kind, threads, seconds, in0, in1, in2=None, n_chains=0, per_chain=0, stride_in=0, stride_out=0, p0=0, p1=0):

@@ -482,6 +482,9 @@ typedef struct {
     int sfb_mixed[9][40];
     int sfb_mixed_len[9];
     int sfb_mixed_switch[9];
+    int sfb_long[9][23];
+    float pow43[8207];                 /* requantize.rs:28-31 */
+    float pow2ab[SO_MP3_POW2AB_LEN];   /* 2^(0.25 e), e = SO_MP3_POW2AB_MIN_E .. (requantize.rs:280, 343) */
 } mp3_tables;
 
 static mp3_tables g_mp3;
@@ -500,6 +503,21 @@ static const unsigned char MP3_SHORT_WIDTHS[9][13] = {
     {4, 4, 4, 6, 8, 10, 12, 14, 18, 24, 30, 40, 18},  /* 12k   */
     {8, 8, 8, 12, 16, 20, 24, 28, 36, 2, 2, 2, 26},   /* 8k    */
 };
+/* Long scale-factor band widths (ISO/IEC 11172-3 Table B.8, 13818-3 Table B.2; the 8 kHz row as the
+ * reference has it); SFB_LONG_BANDS (layer3/common.rs:9-56) is their running sum. */
+static const unsigned char MP3_LONG_WIDTHS[9][22] = {
+    {4, 4, 4, 4, 4, 4, 6, 6, 8, 8, 10, 12, 16, 20, 24, 28, 34, 42, 50, 54, 76, 158},
+    {4, 4, 4, 4, 4, 4, 6, 6, 6, 8, 10, 12, 16, 18, 22, 28, 34, 40, 46, 54, 54, 192},
+    {4, 4, 4, 4, 4, 4, 6, 6, 8, 10, 12, 16, 20, 24, 30, 38, 46, 56, 68, 84, 102, 26},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 38, 46, 52, 60, 68, 58, 54},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 18, 22, 26, 32, 38, 46, 54, 62, 70, 76, 36},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 38, 46, 52, 60, 68, 58, 54},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 38, 46, 52, 60, 68, 58, 54},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 38, 46, 52, 60, 68, 58, 54},
+    {12, 12, 12, 12, 12, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64, 76, 90, 2, 2, 2, 2, 2},
+};
+/* Pre-emphasis (ISO/IEC 11172-3 Table B.6; requantize.rs:256-257) */
+static const unsigned char MP3_PRE_EMPHASIS[22] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 3, 2, 0};
 /* Long-band prefix of SFB_MIXED_BANDS (layer3/common.rs:108-168), up to and
  * including the boundary at 36; the short bands that follow start at 36. */
 static const unsigned char MP3_MIXED_PREFIX[9][9] = {
@@ -606,7 +624,16 @@ static void mp3_init(void)
         }
         t->sfb_mixed_len[sr] = m;
         t->sfb_mixed_switch[sr] = MP3_MIXED_PREFIX_LEN[sr] - 1; /* SFB_MIXED_SWITCH_POINT */
+        t->sfb_long[sr][0] = 0;
+        for (int b = 0; b < 22; b++)
+            t->sfb_long[sr][b + 1] = t->sfb_long[sr][b] + MP3_LONG_WIDTHS[sr][b];
     }
+    /* POW43 (requantize.rs:28-31): f32::powf(i as f32, 4.0 / 3.0) */
+    for (int i = 0; i < 8207; i++)
+        t->pow43[i] = powf((float)i, 4.0f / 3.0f);
+    /* f64::powf(2.0, 0.25 * f64::from(a - b)) as f32 (requantize.rs:280, 343) for every exponent reachable */
+    for (int i = 0; i < SO_MP3_POW2AB_LEN; i++)
+        t->pow2ab[i] = (float)pow(2.0, 0.25 * (double)(SO_MP3_POW2AB_MIN_E + i));
     t->ready = 1;
 }
 static mp3_tables *mp3_get(void)
@@ -641,6 +668,83 @@ void so_mp3_sfb_tables(int sr, int32_t *dst81)
         dst81[40 + i] = i < t->sfb_mixed_len[sr] ? t->sfb_mixed[sr][i] : -1;
     }
     dst81[80] = t->sfb_mixed_switch[sr];
+}
+
+/* SFB_LONG_BANDS[sr][23] (layer3/common.rs:9-56) */
+void so_mp3_sfb_long(int sr, int32_t *dst23)
+{
+    for (int i = 0; i < 23; i++)
+        dst23[i] = mp3_get()->sfb_long[sr][i];
+}
+void so_mp3_pow43(float *dst8207) { memcpy(dst8207, mp3_get()->pow43, 8207 * 4); }
+void so_mp3_pow2ab(float *dst) { memcpy(dst, mp3_get()->pow2ab, SO_MP3_POW2AB_LEN * 4); }
+
+/* requantize_long (requantize.rs:239-293) over the band edges bands[0..n_edges) */
+static void mp3_requantize_long(const so_mp3_requant *ch, const int *bands, int n_edges, float *buf)
+{
+    mp3_tables *t = mp3_get();
+    const int a = (int)ch->global_gain - 210;
+    const int scalefac_shift = (ch->flags & SO_MP3_RQ_SCALEFAC_SCALE) ? 2 : 1;
+    for (int i = 0; i + 1 < n_edges; i++) {
+        const int start = bands[i], end = bands[i + 1];
+        if (start >= (int)ch->rzero)
+            break;
+        const int pre = (ch->flags & SO_MP3_RQ_PREFLAG) ? MP3_PRE_EMPHASIS[i] : 0;
+        const int b = ((int)ch->scalefacs[i] + pre) << scalefac_shift;
+        const float pow2ab = t->pow2ab[(a - b) - SO_MP3_POW2AB_MIN_E];
+        const int band_end = end < (int)ch->rzero ? end : (int)ch->rzero;
+        for (int k = start; k < band_end; k++)
+            buf[k] *= pow2ab;
+    }
+}
+/* requantize_short (requantize.rs:296-353) */
+static void mp3_requantize_short(const so_mp3_requant *ch, const int *bands, int n_edges, int sw, float *buf)
+{
+    mp3_tables *t = mp3_get();
+    const int gain = (int)ch->global_gain - 210;
+    const int a[3] = {gain - 8 * (int)ch->subblock_gain[0], gain - 8 * (int)ch->subblock_gain[1],
+                      gain - 8 * (int)ch->subblock_gain[2]};
+    const int scalefac_shift = (ch->flags & SO_MP3_RQ_SCALEFAC_SCALE) ? 2 : 1;
+    for (int i = 0; i + 1 < n_edges; i++) {
+        const int start = bands[i], end = bands[i + 1];
+        if (start >= (int)ch->rzero)
+            break;
+        const int b = (int)ch->scalefacs[sw + i] << scalefac_shift;
+        const float pow2ab = t->pow2ab[(a[i % 3] - b) - SO_MP3_POW2AB_MIN_E];
+        const int win_end = end < (int)ch->rzero ? end : (int)ch->rzero;
+        for (int k = start; k < win_end; k++)
+            buf[k] *= pow2ab;
+    }
+}
+/* The sample values read_huffman_samples leaves in buf (requantize.rs:117-147, 172-205, 234):
+ * (1 - 2 sign) * POW43[|s|] for a non-zero quantised sample, 0.0 otherwise and from rzero on;
+ * then requantize (requantize.rs:356-380). */
+void so_mp3_requantize(const int16_t *is576, const so_mp3_requant *ch, int sr, float *xr576)
+{
+    mp3_tables *t = mp3_get();
+    for (int i = 0; i < 576; i++) {
+        const int s = is576[i];
+        if (i >= (int)ch->rzero || s == 0)
+            xr576[i] = 0.0f;
+        else
+            xr576[i] = (1.0f - 2.0f * (s < 0 ? 1.0f : 0.0f)) * t->pow43[s < 0 ? -s : s];
+    }
+    if (ch->block_type == SO_MP3_SHORT && !ch->is_mixed) {
+        mp3_requantize_short(ch, t->sfb_short[sr], 40, 0, xr576);
+    } else if (ch->block_type == SO_MP3_SHORT) {
+        /* the mixed table is split at the switch point; the long part takes the edges bands[..switch], i.e. it
+         * stops one band short of the first short band: the lines in between stay unscaled (requantize.rs:368-372) */
+        const int sw = t->sfb_mixed_switch[sr];
+        mp3_requantize_long(ch, t->sfb_mixed[sr], sw, xr576);
+        mp3_requantize_short(ch, t->sfb_mixed[sr] + sw, t->sfb_mixed_len[sr] - sw, sw, xr576);
+    } else {
+        mp3_requantize_long(ch, t->sfb_long[sr], 23, xr576);
+    }
+}
+void so_mp3_requantize_batch(const int16_t *is, const so_mp3_requant *ch, int sr, float *xr, size_t n)
+{
+    for (size_t g = 0; g < n; g++)
+        so_mp3_requantize(is + g * 576, ch + g, sr, xr + g * 576);
 }
 
 void so_mp3_imdct_windows(float *dst144) { memcpy(dst144, mp3_get()->imdct_windows, 144 * 4); }

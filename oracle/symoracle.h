@@ -59,6 +59,31 @@ void so_fft_twiddles(int n, float *tw_out);
 void so_fft_small_twiddles(int n, float *tw_out);
 void so_mp3_constants(float *dst117);
 void so_mp3_sfb_tables(int sample_rate_idx, int32_t *dst81);
+void so_mp3_sfb_long(int sample_rate_idx, int32_t *dst23);
+
+/* Requantisation (layer3/requantize.rs).  NO test in the reference: parity unpinned by the reference; pinned in
+ * tests/ by the ISO 11172-3 closed form xr = sign(s) |s|^(4/3) 2^(0.25 (A - B)) in f64 and by the band tables
+ * recorded in tests/golden/ref_kats.json. */
+#define SO_MP3_RQ_SCALEFAC_SCALE 1
+#define SO_MP3_RQ_PREFLAG 2
+#define SO_MP3_POW2AB_MIN_E (-1300) /* >= -210 - 8*7 - ((255 + 3) << 2) */
+#define SO_MP3_POW2AB_LEN 1346      /* up to e = 45 = 255 - 210 */
+typedef struct so_mp3_requant {     /* the GranuleChannel fields requantize reads (layer3/mod.rs) */
+    uint8_t global_gain;
+    uint8_t flags;                  /* SO_MP3_RQ_* */
+    uint8_t block_type;             /* SO_MP3_* */
+    uint8_t is_mixed;
+    uint8_t subblock_gain[3];
+    uint8_t reserved;
+    uint16_t rzero;
+    uint8_t scalefacs[39];
+    uint8_t pad[3];
+} so_mp3_requant;                   /* 52 bytes */
+void so_mp3_pow43(float *dst8207);
+void so_mp3_pow2ab(float *dst /* SO_MP3_POW2AB_LEN */);
+/* is576: the signed quantised samples the Huffman stage decodes (|s| <= 8206); xr576 out. */
+void so_mp3_requantize(const int16_t *is576, const so_mp3_requant *ch, int sample_rate_idx, float *xr576);
+void so_mp3_requantize_batch(const int16_t *is, const so_mp3_requant *ch, int sample_rate_idx, float *xr, size_t n);
 void so_vorbis_floor1_table(float *dst256);
 
 /* ---- AAC-LC (symphonia-codec-aac/src/aac/{dsp,window}.rs) ---------------- */

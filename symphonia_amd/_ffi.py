@@ -19,6 +19,7 @@ ERR_OOM = -4
 
 TABLE_AAC_KBD_LONG, TABLE_AAC_KBD_SHORT, TABLE_AAC_SINE_LONG, TABLE_AAC_SINE_SHORT = 0, 1, 2, 3
 TABLE_MP3_SYNTH_D, TABLE_MP3_IMDCT_WIN, TABLE_VORBIS_FLOOR1_DB, TABLE_MP3_CONSTS = 4, 5, 6, 7
+TABLE_MP3_POW43, TABLE_MP3_POW2AB = 8, 9
 
 # every symbol include/symaccel.h declares (tests/test_abi.py checks the built library exports all)
 ABI_SYMBOLS = [
@@ -26,6 +27,7 @@ ABI_SYMBOLS = [
     "symaccel_ctx_destroy", "symaccel_ctx_set_stream", "symaccel_sync", "symaccel_ctx_set_segment",
     "symaccel_fft_c32_device", "symaccel_fft_c32", "symaccel_imdct_f32_device", "symaccel_imdct_f32",
     "symaccel_aac_synth_device", "symaccel_aac_synth", "symaccel_mp3_synth_device", "symaccel_mp3_synth", "symaccel_mpa_polyphase_device", "symaccel_mpa_polyphase",
+    "symaccel_mp3_requantize_device", "symaccel_mp3_requantize",
     "symaccel_vorbis_synth_device", "symaccel_vorbis_synth_fr_device", "symaccel_vorbis_synth", "symaccel_vorbis_inverse_coupling_device",
     "symaccel_vorbis_dot_product_device", "symaccel_vorbis_deinterleave2_device",
     "symaccel_vorbis_floor1_device", "symaccel_flac_restore_device", "symaccel_flac_restore", "symaccel_flac_restore_stereo_device",
@@ -74,6 +76,8 @@ class Library:
         d.symaccel_mp3_synth.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_mpa_polyphase_device.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_mpa_polyphase.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_mp3_requantize_device.argtypes = [_vp, _vp, _vp, _i, _vp, _sz]
+        d.symaccel_mp3_requantize.argtypes = [_vp, _vp, _vp, _i, _vp, _sz]
         d.symaccel_vorbis_synth_device.argtypes = [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_vorbis_synth_fr_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_vorbis_synth.argtypes = [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]

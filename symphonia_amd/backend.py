@@ -245,6 +245,39 @@ class MpaPolyphase:
         return res, vv, vf
 
 
+MP3_REQUANT_DTYPE = np.dtype([("global_gain", np.uint8), ("flags", np.uint8), ("block_type", np.uint8),
+                              ("is_mixed", np.uint8), ("subblock_gain", np.uint8, (3,)), ("reserved", np.uint8),
+                              ("rzero", np.uint16), ("scalefacs", np.uint8, (39,)), ("pad", np.uint8, (3,))])
+MP3_RQ_SCALEFAC_SCALE, MP3_RQ_PREFLAG = 1, 2
+
+
+class Mp3Requantize:
+    """read_huffman_samples' sample mapping + requantize (layer3/requantize.rs:28-31, 117-147, 239-380)."""
+
+    def __init__(self, ctx, sample_rate_idx):
+        if not 0 <= int(sample_rate_idx) <= 8:
+            raise ValueError("sample_rate_idx")
+        self.ctx, self.sr = ctx, int(sample_rate_idx)
+
+    def requantize(self, quant, desc, xr=None):
+        """quant[..., 576] int16, desc[...] MP3_REQUANT_DTYPE (torch: uint8[..., 52]); returns xr[..., 576] f32."""
+        d = self.ctx.lib.dll
+        if _is_torch(quant):
+            import torch
+            n = quant.numel() // 576
+            assert desc.numel() * desc.element_size() == 52 * n
+            if xr is None:
+                xr = torch.empty(quant.shape, dtype=torch.float32, device=quant.device)
+            self.ctx._call(d.symaccel_mp3_requantize_device, _ptr(quant), _ptr(desc), self.sr, _ptr(xr), n)
+            return xr
+        q = _np(quant, np.int16)
+        dd = np.ascontiguousarray(desc, dtype=MP3_REQUANT_DTYPE)
+        assert dd.size * 576 == q.size
+        res = np.empty(q.shape, np.float32)
+        self.ctx._call(d.symaccel_mp3_requantize, _ptr(q), _ptr(dd), self.sr, _ptr(res), dd.size)
+        return res
+
+
 class VorbisDsp:
     """dsp::Dsp / DspChannel::synth (vorbis/dsp.rs:12-145) for chains of mixed-size blocks."""
 

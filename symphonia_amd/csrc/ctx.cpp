@@ -197,6 +197,9 @@ int upload_tables(symaccel_ctx *ctx) {
     UP(mp3_reorder_map, rmap.data(), rmap.size() * 4);
     UP(mp3_reorder_end, rend.data(), rend.size() * 4);
     UP(vorbis_floor1_db, t.vorbis_floor1_db, 256 * 4);
+    UP(mp3_pow43, t.mp3_pow43, sizeof t.mp3_pow43);
+    UP(mp3_pow2ab, t.mp3_pow2ab, sizeof t.mp3_pow2ab);
+    UP(mp3_band_map, t.mp3_band_map, sizeof t.mp3_band_map);
 #undef UP
     return SYMACCEL_OK;
 }
@@ -207,7 +210,7 @@ struct DevBuf {
     void *p = nullptr;
     explicit DevBuf(symaccel_ctx *c) : ctx(c) {}
     ~DevBuf() {
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     }
     int alloc(size_t bytes) { return ctx_alloc(ctx, &p, bytes, false); }
     int from_host(const void *h, size_t bytes) {
@@ -274,11 +277,11 @@ int symaccel_ctx_create(int device, symaccel_ctx **out) {
 
 void symaccel_ctx_destroy(symaccel_ctx *ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    for (void *p : ctx->allocations) hipFree(p);
-    if (ctx->scratch) hipFree(ctx->scratch);
-    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->allocations) (void)hipFree(p);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -634,6 +637,30 @@ int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, i
 
 // ---- tables -------------------------------------------------------------------------------
 
+int symaccel_mp3_requantize_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_desc,
+                                   int sample_rate_idx, float *d_xr, size_t n) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n == 0) return SYMACCEL_OK;
+    if (!d_quant || !d_desc || !d_xr) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_mp3_requantize(ctx, d_quant, d_desc, sample_rate_idx, d_xr, n);
+}
+
+int symaccel_mp3_requantize(symaccel_ctx *ctx, const int16_t *h_quant, const symaccel_mp3_requant *h_desc,
+                            int sample_rate_idx, float *h_xr, size_t n) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n == 0) return SYMACCEL_OK;
+    if (!h_quant || !h_desc || !h_xr) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DevBuf q(ctx), d(ctx), x(ctx);
+    SYM_TRY(q.from_host(h_quant, n * 576 * sizeof(int16_t)));
+    SYM_TRY(d.from_host(h_desc, n * sizeof(symaccel_mp3_requant)));
+    SYM_TRY(x.alloc(n * 576 * 4));
+    SYM_TRY(launch_mp3_requantize(ctx, (const int16_t *)q.p, (const symaccel_mp3_requant *)d.p, sample_rate_idx, (float *)x.p, n));
+    SYM_TRY(x.to_host(h_xr, n * 576 * 4));
+    return symaccel_sync(ctx);
+}
+
 int symaccel_mpa_polyphase_device(symaccel_ctx *ctx, int n_frames, const float *d_in, float *d_vvec_io,
                                   int32_t *d_vfront_io, float *d_pcm, size_t n_chains, size_t packets_per_chain) {
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
@@ -749,6 +776,8 @@ int symaccel_table_f32(const symaccel_ctx *, int table, float *dst, size_t capac
         case SYMACCEL_TABLE_MP3_SYNTH_D: src = t.mp3_synth_d; n = 512; break;
         case SYMACCEL_TABLE_MP3_IMDCT_WIN: src = &t.mp3_imdct_win[0][0]; n = 144; break;
         case SYMACCEL_TABLE_VORBIS_FLOOR1_DB: src = t.vorbis_floor1_db; n = 256; break;
+        case SYMACCEL_TABLE_MP3_POW43: src = t.mp3_pow43; n = 8207; break;
+        case SYMACCEL_TABLE_MP3_POW2AB: src = t.mp3_pow2ab; n = kMp3Pow2abLen; break;
         case SYMACCEL_TABLE_MP3_CONSTS: {
             static const std::vector<float> mc = pack_mp3_consts(t);
             src = mc.data();

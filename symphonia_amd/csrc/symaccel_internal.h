@@ -17,6 +17,9 @@ struct cpx {
     float re, im;
 };
 
+constexpr int kMp3Pow2abMinE = -1300, kMp3Pow2abLen = 1346;  // exponents a - b of requantize.rs:280, 343
+constexpr int kMp3Unscaled = 39;                             // band-map value of lines no band covers
+
 // Constant tables, generated on the host with the libm calls the reference uses (tables.cpp).
 struct HostTables {
     // AAC (symphonia-codec-aac/src/aac/window.rs:28-63, dsp.rs:34-54)
@@ -37,6 +40,11 @@ struct HostTables {
     int32_t mp3_sfb_mixed[9][40];
     int32_t mp3_sfb_mixed_len[9];
     int32_t mp3_sfb_switch[9];
+    // MP3 requantisation (requantize.rs:28-31, 256-257, 280, 343; layer3/common.rs:9-56)
+    int32_t mp3_sfb_long[9][23];
+    float mp3_pow43[8207];
+    float mp3_pow2ab[kMp3Pow2abLen];
+    uint8_t mp3_band_map[9][3][576];  // [sample rate][long, short, mixed][line] -> scale index, kMp3Unscaled = none
     // Vorbis (floor.rs:21-112)
     float vorbis_floor1_db[256];
 };
@@ -59,6 +67,8 @@ struct DevTables {
     const int32_t *mp3_reorder_map;      // [9 sample rates][2 (plain, mixed)][576] source index
     const int32_t *mp3_reorder_end;      // [9][2][577]: reorder end index `i` for each input rzero
     const float *vorbis_floor1_db;
+    const float *mp3_pow43, *mp3_pow2ab;
+    const uint8_t *mp3_band_map;         // [9][3][576]
 };
 
 // Offsets (in floats) inside DevTables::mp3_consts.
@@ -149,6 +159,8 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
                                size_t count);
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier,
                          const uint32_t *d_y, uint32_t n, float *d_floor, size_t count);
+int launch_mp3_requantize(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_desc, int sr,
+                          float *d_xr, size_t n);
 int launch_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *d_in, const float *d_vvec_in,
                          const int32_t *d_vfront_in, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm, size_t n_chains,
                          size_t packets_per_chain);

@@ -83,6 +83,19 @@ const unsigned char kShortWidths[9][13] = {
     {4, 4, 4, 6, 8, 10, 12, 14, 18, 24, 30, 40, 18}, {4, 4, 4, 6, 8, 10, 12, 14, 18, 24, 30, 40, 18},
     {8, 8, 8, 12, 16, 20, 24, 28, 36, 2, 2, 2, 26},
 };
+// Long scale-factor band widths (ISO/IEC 11172-3 Table B.8, 13818-3 Table B.2; 8 kHz as the reference has it):
+// the band edge table (layer3/common.rs:9-56) is their running sum.
+const unsigned char kLongWidths[9][22] = {
+    {4, 4, 4, 4, 4, 4, 6, 6, 8, 8, 10, 12, 16, 20, 24, 28, 34, 42, 50, 54, 76, 158},
+    {4, 4, 4, 4, 4, 4, 6, 6, 6, 8, 10, 12, 16, 18, 22, 28, 34, 40, 46, 54, 54, 192},
+    {4, 4, 4, 4, 4, 4, 6, 6, 8, 10, 12, 16, 20, 24, 30, 38, 46, 56, 68, 84, 102, 26},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 38, 46, 52, 60, 68, 58, 54},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 18, 22, 26, 32, 38, 46, 54, 62, 70, 76, 36},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 38, 46, 52, 60, 68, 58, 54},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 38, 46, 52, 60, 68, 58, 54},
+    {6, 6, 6, 6, 6, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 38, 46, 52, 60, 68, 58, 54},
+    {12, 12, 12, 12, 12, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64, 76, 90, 2, 2, 2, 2, 2},
+};
 // Long-band edges in front of the short bands of a mixed block (layer3/common.rs:108-168).
 const unsigned char kMixedLong[9][9] = {
     {0, 4, 8, 12, 16, 20, 24, 30, 36}, {0, 4, 8, 12, 16, 20, 24, 30, 36}, {0, 4, 8, 12, 16, 20, 24, 30, 36},
@@ -173,7 +186,26 @@ void build(HostTables &t) {
         t.mp3_sfb_mixed_len[sr] = m;
         for (; m < 40; ++m) t.mp3_sfb_mixed[sr][m] = -1;
         t.mp3_sfb_switch[sr] = kMixedLongLen[sr] - 1;  // SFB_MIXED_SWITCH_POINT
+        t.mp3_sfb_long[sr][0] = 0;
+        for (int b = 0; b < 22; ++b) t.mp3_sfb_long[sr][b + 1] = t.mp3_sfb_long[sr][b] + kLongWidths[sr][b];
+        // line -> scale index.  Long: the band; short: the (band, window) slot = scalefacs index; mixed: the long
+        // bands of requantize_long(bands[..switch]) (one fewer than the edges), then scalefacs[switch + i] for the
+        // short slots; lines in between are covered by no band (requantize.rs:368-372).
+        uint8_t(*map)[576] = t.mp3_band_map[sr];
+        std::memset(map, kMp3Unscaled, 3 * 576);
+        for (int b = 0; b < 22; ++b)
+            for (int i = t.mp3_sfb_long[sr][b]; i < t.mp3_sfb_long[sr][b + 1]; ++i) map[0][i] = (uint8_t)b;
+        for (int b = 0; b < 39; ++b)
+            for (int i = t.mp3_sfb_short[sr][b]; i < t.mp3_sfb_short[sr][b + 1]; ++i) map[1][i] = (uint8_t)b;
+        const int sw = t.mp3_sfb_switch[sr], len = t.mp3_sfb_mixed_len[sr];
+        for (int b = 0; b + 1 < sw; ++b)
+            for (int i = t.mp3_sfb_mixed[sr][b]; i < t.mp3_sfb_mixed[sr][b + 1]; ++i) map[2][i] = (uint8_t)b;
+        for (int b = sw; b + 1 < len; ++b)
+            for (int i = t.mp3_sfb_mixed[sr][b]; i < t.mp3_sfb_mixed[sr][b + 1]; ++i) map[2][i] = (uint8_t)b;
     }
+    // requantize.rs:28-31: f32::powf(i as f32, 4.0 / 3.0); requantize.rs:280, 343: f64::powf(2.0, 0.25 * e) as f32
+    for (int i = 0; i < 8207; ++i) t.mp3_pow43[i] = ::powf((float)i, 4.0f / 3.0f);
+    for (int i = 0; i < kMp3Pow2abLen; ++i) t.mp3_pow2ab[i] = (float)::pow(2.0, 0.25 * (double)(kMp3Pow2abMinE + i));
     for (int i = 0; i < 256; ++i) std::memcpy(&t.vorbis_floor1_db[i], &SYM_VORBIS_FLOOR1_DB_BITS[i], 4);
 }
 

@@ -134,6 +134,34 @@ static void verify_mp3(Context &ctx) {  // Layer3::decode granule loop tail (lay
     }
 }
 
+static void verify_mp3_requantize(Context &ctx) {  // Layer3::decode: read_huffman_samples' values + requantize (layer3/mod.rs:393-400)
+    std::mt19937 rng(21);
+    for (int g = 0; g < 6; ++g) {
+        mp3::RequantizeChannel ch;
+        ch.global_gain = (std::uint8_t)(120 + rng() % 100);
+        ch.scalefac_scale = g & 1;
+        ch.preflag = g & 2;
+        ch.block_type = g < 3 ? mp3::BlockType::Long : mp3::BlockType::Short;
+        ch.is_mixed = g == 5;
+        for (auto &v : ch.subblock_gain) v = (std::uint8_t)(rng() % 8);
+        for (auto &v : ch.scalefacs) v = (std::uint8_t)(rng() % 16);
+        ch.rzero = (std::uint16_t)(g == 0 ? 576 : rng() % 577);
+        std::array<std::int16_t, 576> q{};
+        for (int i = 0; i < 576; ++i) q[(size_t)i] = (std::int16_t)((int)(rng() % 61) - 30);
+        q[7] = 8206;
+        q[8] = -8206;
+        std::array<float, 576> got{};
+        float want[576];
+        mp3::requantize(ctx, g % 3, ch, q, got);
+        so_mp3_requant d{};
+        const symaccel_mp3_requant abi = mp3::to_abi(ch);
+        static_assert(sizeof(d) == sizeof(abi), "the oracle's record mirrors the ABI record");
+        std::memcpy(&d, &abi, sizeof d);
+        so_mp3_requantize(q.data(), &d, g % 3, want);
+        EXPECT(same_bits(got.data(), want, 576), "mp3 requantize case %d differs from the oracle", g);
+    }
+}
+
 static void verify_vorbis(Context &ctx) {  // Decoder::decode_inner channel loop (vorbis/lib.rs:296-331)
     std::mt19937 rng(11);
     std::normal_distribution<float> nd(0.f, 0.25f);
@@ -249,6 +277,7 @@ int main(int argc, char **argv) {
     verify_fft(ctx);
     verify_aac(ctx);
     verify_mp3(ctx);
+    verify_mp3_requantize(ctx);
     verify_vorbis(ctx);
     verify_flac(ctx);
     verify_alac(ctx);

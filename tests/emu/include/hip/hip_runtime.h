@@ -39,6 +39,8 @@ struct int2 { int x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(8) short4 { short x, y, z, w; };
+struct alignas(4) uchar4 { unsigned char x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }

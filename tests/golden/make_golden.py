@@ -12,6 +12,7 @@ Sources (relative to the Symphonia tree):
   symphonia-bundle-mp3/src/layer3/hybrid_synthesis.rs:512-516, 804-808   18 literals
   symphonia-bundle-mp3/src/synthesis.rs:868-873   32 literals for dct32
   symphonia-bundle-flac/src/decoder.rs:646-661    rice sign map cases
+  symphonia-bundle-mp3/src/layer3/common.rs:9-172, requantize.rs:256-257   band-edge / pre-emphasis tables
 and the literal twiddle / scale constants (as IEEE-754 bit patterns) of
   dsp/fft/no_simd.rs:307-324, 374-383; hybrid_synthesis.rs:611-630, 668-678,
   722-730; synthesis.rs:13-142, 354-396; vorbis floor.rs:21-112.
@@ -99,6 +100,25 @@ def main():
         ws = "u32::max_value()" if w == 4294967295 else str(w)
         es = "-2_147_483_648" if e == -2147483648 else str(e)
         assert "rice_signed_to_i32(%s), %s)" % (ws, es) in src, (w, e)
+    # scale-factor band edge tables and the pre-emphasis table (standards data; the repo states them as band widths)
+    src = (REF / "symphonia-bundle-mp3/src/layer3/common.rs").read_text()
+    def int_rows(block):
+        block = re.sub(r"//[^\n]*", "", block)
+        return [[int(v) for v in re.findall(r"\d+", row)] for row in re.findall(r"\[([^\[\]]*)\]", block)]
+    m = re.search(r"pub static SFB_LONG_BANDS: \[\[usize; 23\]; 9\] = \[(.*?)\n\];", src, re.S)
+    kat["mp3_sfb_long"] = int_rows(m.group(1))
+    m = re.search(r"pub static SFB_SHORT_BANDS: \[\[usize; 40\]; 9\] = \[(.*?)\n\];", src, re.S)
+    kat["mp3_sfb_short"] = int_rows(m.group(1))
+    m = re.search(r"pub const SFB_MIXED_BANDS: \[&\[usize\]; 9\] = \[(.*?)\n\];", src, re.S)
+    kat["mp3_sfb_mixed"] = int_rows(m.group(1))
+    m = re.search(r"pub const SFB_MIXED_SWITCH_POINT: \[usize; 9\] = \[(.*?)\];", src)
+    kat["mp3_sfb_mixed_switch"] = [int(v) for v in m.group(1).split(",")]
+    assert [len(r) for r in kat["mp3_sfb_long"]] == [23] * 9 and [len(r) for r in kat["mp3_sfb_short"]] == [40] * 9
+    assert len(kat["mp3_sfb_mixed"]) == 9
+    src = (REF / "symphonia-bundle-mp3/src/layer3/requantize.rs").read_text()
+    m = re.search(r"const PRE_EMPHASIS: \[u8; 22\] =\s*\[(.*?)\];", src, re.S)
+    kat["mp3_pre_emphasis"] = [int(v) for v in m.group(1).split(",")]
+    assert len(kat["mp3_pre_emphasis"]) == 22
     kat["literal_bits"] = lit
     OUT.write_text(json.dumps(kat, indent=1))
     print("wrote", OUT)

@@ -57,6 +57,18 @@ def main():
     sh = torch.full((65536,), 2, device="cuda", dtype=torch.uint8)
     t = timeit(lambda: ap.mid_side(w, sh, a, b))
     out["alac mid/side (65536 pairs x 4096)"] = 4 * a.numel() * 4 / t
+    rq = sa.Mp3Requantize(ctx, 0)
+    ngc = 262144  # config 3: 131072 granules x 2 channels
+    rng = np.random.default_rng(0)
+    quant = torch.from_numpy(np.rint(rng.laplace(0, 6, (ngc, 576))).astype(np.int16)).cuda()
+    dnp = np.zeros(ngc, sa.MP3_REQUANT_DTYPE)
+    dnp["global_gain"], dnp["rzero"] = rng.integers(120, 200, ngc), rng.integers(300, 577, ngc)
+    dnp["scalefacs"] = rng.integers(0, 16, (ngc, 39))
+    dnp["block_type"] = rng.choice([0, 0, 0, 0, 0, 0, 0, 1, 2, 3], ngc)
+    desc = torch.from_numpy(dnp.view(np.uint8).reshape(ngc, 52)).cuda()
+    xr = torch.empty((ngc, 576), device="cuda")
+    t = timeit(lambda: rq.requantize(quant, desc, xr))
+    out["mp3 requantize (262144 granule-channels, i16 -> f32)"] = ngc * (576 * 6 + 52) / t
     for k, gbps in out.items():
         print("%-52s %8.1f GB/s  (%.1f %% of 8 TB/s)" % (k, gbps / 1e9, gbps / 8e12 * 100))
     ctx.close()
