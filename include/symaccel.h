@@ -100,6 +100,48 @@ int symaccel_aac_synth_device(symaccel_ctx *ctx, const float *d_coeffs, const ui
 int symaccel_aac_synth(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *h_side,
                        float *h_delay_io, float *h_pcm, size_t n_chains, size_t frames_per_chain);
 
+/* Spectral tools between the spectrum decoder and Dsp::synth, in place on coeffs[chain][frame][1024].
+ *
+ * Joint-stereo decoding of channel pairs (aac/cpe.rs:110-157).  pair_chains[p] = {left chain, right chain};
+ * desc[p][frame]: per scale-factor band of every window the tool to apply -- index [sfb] for one long window,
+ * [w * 16 + sfb] for eight short windows (the host expands window groups to windows, cpe.rs:116-119):
+ * SYMACCEL_AAC_JS_MS = (m, s) -> (m + s, m - s); SYMACCEL_AAC_JS_INTENSITY = right = scale * left with
+ * scale = dir * factor * ics1.scales[g][sfb] exactly as cpe.rs:127-131 forms it; 0 = neither (which is also how the
+ * noise-substitution bands of cpe.rs:140-143 are expressed).  swb_long / swb_short: HOST arrays, the swb offsets of
+ * the stream's sample rate (ICS get_bands(), ics/mod.rs:361-363), n_swb + 1 entries each, multiples of four.
+ * Frames carrying pulse data are decoded on the host (Pulse::synth sits between the two stages, ics/mod.rs:452-454):
+ * give them mode 0 everywhere. */
+#define SYMACCEL_AAC_JS_MS 1u
+#define SYMACCEL_AAC_JS_INTENSITY 2u
+typedef struct symaccel_aac_js_frame {
+    uint8_t num_windows; /* 1, or 8 for EIGHT_SHORT_SEQUENCE */
+    uint8_t max_sfb;
+    uint8_t pad[2];
+    uint8_t mode[128];
+    float scale[128];
+} symaccel_aac_js_frame; /* 644 bytes */
+int symaccel_aac_joint_stereo_device(symaccel_ctx *ctx, float *d_coeffs, size_t frames_per_chain,
+                                     const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs,
+                                     const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short,
+                                     int n_swb_short);
+
+/* The filtering loops of Tns::synth (aac/ics/tns.rs:180-195) for a flat list of filters.  The host keeps the
+ * bitstream-side work (coefficient decoding with `sin`, tns.rs:39-106, and the band arithmetic of tns.rs:149-175) and
+ * passes, per filter, the line range [start, end) it computed, the order, the direction and coef[0..order).
+ * frame = index of the channel-frame in coeffs[n_frames][1024].  The filters of one frame cover disjoint ranges
+ * (tns.rs:163-166), so the list order is free.  Entries with frame >= n_frames, start >= end, end > 1024 or an order
+ * outside 1..20 are skipped. */
+typedef struct symaccel_aac_tns_filter {
+    uint32_t frame;
+    uint16_t start, end;
+    uint8_t order;     /* 1 ..= TNS_MAX_ORDER (20) */
+    uint8_t direction; /* TnsCoeffs::direction: 0 = towards higher lines */
+    uint8_t pad[2];
+    float lpc[20];
+} symaccel_aac_tns_filter; /* 92 bytes */
+int symaccel_aac_tns_device(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames,
+                            const symaccel_aac_tns_filter *d_filters, size_t n_filters);
+
 /* --------------------------------------------------------------------------------- MP3 */
 
 #define SYMACCEL_MP3_LONG 0u /* BlockType, symphonia-bundle-mp3/src/layer3/common.rs:174-185 */

@@ -389,6 +389,28 @@ def alac_decorrelate_mid_side(out0, out1, weight, shift):
     return a, b
 
 
+# ---- AAC spectral tools (aac/cpe.rs:110-157, aac/ics/tns.rs:180-195) -----------
+
+def aac_joint_stereo(left, right, num_windows, max_sfb, bands, mode, scale):
+    """One channel-pair frame; mode[128] u8 (0 none, 1 M/S, 2 intensity), scale[128] f32. Returns (left', right')."""
+    l = np.array(left, dtype=np.float32, copy=True)
+    r = np.array(right, dtype=np.float32, copy=True)
+    b = np.ascontiguousarray(bands, dtype=np.uint16)
+    m = np.ascontiguousarray(mode, dtype=np.uint8)
+    sc = np.ascontiguousarray(scale, dtype=np.float32)
+    assert l.size == 1024 and r.size == 1024 and m.size == 128 and sc.size == 128 and b.size > max_sfb
+    lib().so_aac_joint_stereo(_p(l), _p(r), int(num_windows), int(max_sfb), _p(b), _p(m), _p(sc))
+    return l, r
+
+
+def aac_tns_filter(coeffs, start, end, order, direction, lpc):
+    c = np.array(coeffs, dtype=np.float32, copy=True)
+    lp = np.zeros(20, np.float32)
+    lp[:len(lpc)] = lpc
+    lib().so_aac_tns_filter(_p(c), int(start), int(end), int(order), int(direction), _p(lp))
+    return c
+
+
 # ---- MP3 requantisation (layer3/requantize.rs) ---------------------------------
 
 MP3_REQUANT_DTYPE = np.dtype([("global_gain", np.uint8), ("flags", np.uint8), ("block_type", np.uint8),

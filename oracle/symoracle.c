@@ -466,6 +466,52 @@ void so_aac_synth_batch(const float *coeffs, const uint8_t *side, float *delay, 
     so_imdct_free(is);
 }
 
+/* ---- AAC spectral tools in front of Dsp::synth ---------- */
+
+/* Joint-stereo decoding of one channel pair (aac/cpe.rs:110-157).  bands: the swb offsets of the window length in
+ * use (ICS get_bands), mode/scale per [w * 16 + sfb] for eight short windows or [sfb] for one long window:
+ * mode 2 = intensity (right = scale * left, scale = dir * factor * scales[g][sfb] as cpe.rs:131 forms it),
+ * mode 1 = mid/side, 0 = neither (incl. the noise-substitution bands cpe.rs:140-143 skips). */
+void so_aac_joint_stereo(float *left, float *right, int num_windows, int max_sfb, const uint16_t *bands,
+                         const uint8_t *mode, const float *scale)
+{
+    for (int w = 0; w < num_windows; w++) {
+        for (int sfb = 0; sfb < max_sfb; sfb++) {
+            const int start = w * 128 + bands[sfb], end = w * 128 + bands[sfb + 1];
+            const int slot = num_windows == 1 ? sfb : w * 16 + sfb;
+            if (mode[slot] == 2) {
+                for (int i = start; i < end; i++)
+                    right[i] = scale[slot] * left[i];
+            } else if (mode[slot] == 1) {
+                for (int i = start; i < end; i++) {
+                    const float tmp = left[i] - right[i];
+                    left[i] += right[i];
+                    right[i] = tmp;
+                }
+            }
+        }
+    }
+}
+
+/* One TNS filter of Tns::synth (aac/ics/tns.rs:180-195) over coeffs[start..end): the all-pole filter runs up
+ * (direction 0) or down the spectrum and only reaches back to samples inside its own range (j < min(order, m)). */
+void so_aac_tns_filter(float *coeffs, int start, int end, int order, int direction, const float *lpc)
+{
+    if (!direction) {
+        for (int m = 0, i = start; i < end; i++, m++) {
+            const int lim = order < m ? order : m;
+            for (int j = 0; j < lim; j++)
+                coeffs[i] -= coeffs[i - j - 1] * lpc[j];
+        }
+    } else {
+        for (int m = 0, i = end - 1; i >= start; i--, m++) {
+            const int lim = order < m ? order : m;
+            for (int j = 0; j < lim; j++)
+                coeffs[i] -= coeffs[i + j + 1] * lpc[j];
+        }
+    }
+}
+
 /* ======================================================================== */
 /* MP3: symphonia-bundle-mp3/src/layer3/hybrid_synthesis.rs, synthesis.rs    */
 /* ======================================================================== */

@@ -93,6 +93,13 @@ void so_aac_window(int kbd, float alpha, int size, float *dst);
 /* Dsp::synth (dsp.rs:57-158) for one channel-frame. */
 void so_aac_synth(const float *coeffs, float *delay, int seq, int window_shape,
                   int prev_window_shape, float *dst);
+/* AAC spectral tools in front of Dsp::synth: joint stereo (aac/cpe.rs:110-157) and one TNS filter
+ * (aac/ics/tns.rs:180-195).  NO test in the reference: parity unpinned by the reference; pinned in tests/ by the
+ * defining arithmetic (sum/difference, scalar multiply) and by scipy's all-pole filter in f64. */
+void so_aac_joint_stereo(float *left1024, float *right1024, int num_windows, int max_sfb, const uint16_t *bands,
+                         const uint8_t *mode128, const float *scale128);
+void so_aac_tns_filter(float *coeffs1024, int start, int end, int order, int direction, const float *lpc);
+
 /* n_chains independent channels, frames_per_chain consecutive frames each.
  * coeffs[chain][frame][1024], side[chain][frame] = seq | shape<<2 | prev<<3,
  * delay[chain][1024] in/out, pcm[chain][frame][1024]. */

@@ -183,6 +183,41 @@ def mp3_side(block_type, is_mixed, rzero):
     return s
 
 
+AAC_JS_DTYPE = np.dtype([("num_windows", np.uint8), ("max_sfb", np.uint8), ("pad", np.uint8, (2,)), ("mode", np.uint8, (128,)),
+                         ("scale", np.float32, (128,))])
+AAC_TNS_DTYPE = np.dtype([("frame", np.uint32), ("start", np.uint16), ("end", np.uint16), ("order", np.uint8),
+                          ("direction", np.uint8), ("pad", np.uint8, (2,)), ("lpc", np.float32, (20,))])
+AAC_JS_MS, AAC_JS_INTENSITY = 1, 2
+
+
+class AacSpectralTools:
+    """Joint-stereo decoding (aac/cpe.rs:110-157) and the TNS filters (aac/ics/tns.rs:180-195), in place on the
+    chain-major coefficient array AacDsp.synth consumes.  Device-pointer entry points only: pass torch CUDA tensors
+    (descriptors as uint8 views of AAC_JS_DTYPE / AAC_TNS_DTYPE records)."""
+
+    def __init__(self, ctx, swb_long, swb_short):
+        self.ctx = ctx
+        self.swb_long, self.swb_short = _np(swb_long, np.uint16), _np(swb_short, np.uint16)
+
+    def joint_stereo(self, coeffs, pair_chains, desc):
+        """coeffs[chains, frames, 1024]; pair_chains[pairs, 2] i32; desc[pairs, frames] AAC_JS_DTYPE."""
+        frames = int(coeffs.shape[1])
+        n_pairs = int(pair_chains.shape[0])
+        self.ctx._call(self.ctx.lib.dll.symaccel_aac_joint_stereo_device, _ptr(coeffs), frames, _ptr(pair_chains), _ptr(desc),
+                       n_pairs, _ptr(self.swb_long), self.swb_long.size - 1, _ptr(self.swb_short), self.swb_short.size - 1)
+        return coeffs
+
+    def tns(self, coeffs, filters, n_filters=None):
+        """coeffs[..., 1024] (any leading shape = n_frames); filters[n] AAC_TNS_DTYPE."""
+        n_frames = 1
+        for d in coeffs.shape[:-1]:
+            n_frames *= int(d)
+        if n_filters is None:
+            n_filters = filters.shape[0]
+        self.ctx._call(self.ctx.lib.dll.symaccel_aac_tns_device, _ptr(coeffs), n_frames, _ptr(filters), int(n_filters))
+        return coeffs
+
+
 class Mp3Synthesis:
     """Layer III synthesis tail (layer3/mod.rs:440-476): reorder, antialias, hybrid_synthesis,
     frequency_inversion, synthesis::synthesis."""

@@ -1,0 +1,171 @@
+// AAC spectral tools between the spectrum decoder and Dsp::synth:
+//   joint-stereo decoding of a channel pair   symphonia-codec-aac/src/aac/cpe.rs:110-157
+//   the filtering loops of Tns::synth         symphonia-codec-aac/src/aac/ics/tns.rs:180-195
+// Both work in place on the chain-major coefficient array aac_synth_kernel consumes.
+//
+// Joint stereo is a streaming pass: one workgroup per channel-pair frame, one thread per four lines (the swb offsets
+// of every AAC sample rate are multiples of four, so a float4 never straddles a band); only bands that are coded
+// mid/side or intensity are touched, so the traffic is proportional to their share.
+// TNS is an all-pole filter running along the spectrum -- a serial recurrence of up to 20 taps per line.  The
+// parallel axis is the filter: one lane per filter of a flat list, the tap history in registers, sixteen lines
+// (one 64-byte sector) per lane and round, the next sixteen fetched while the current ones are filtered.  The taps are applied in the reference's order, each as a
+// rounded multiply and a rounded subtract, and only `min(order, lines filtered so far)` of them (tns.rs:184, 191).
+#include <hip/hip_runtime.h>
+
+#include "symaccel_internal.h"
+
+namespace symaccel {
+
+namespace {
+
+__global__ __launch_bounds__(256) void aac_joint_stereo_kernel(AacBandMaps maps, float *__restrict__ coeffs,
+                                                               unsigned frames_per_chain, const int32_t *__restrict__ pair_chains,
+                                                               const symaccel_aac_js_frame *__restrict__ desc) {
+    const unsigned pf = blockIdx.x, pair = pf / frames_per_chain, f = pf % frames_per_chain;
+    const symaccel_aac_js_frame &d = desc[pf];
+    const int t = (int)threadIdx.x;
+    int sfb, slot;
+    if (d.num_windows == 1) {
+        sfb = maps.long4[t];
+        slot = sfb;
+    } else {
+        sfb = maps.short4[t & 31];
+        slot = (t >> 5) * 16 + sfb;
+    }
+    if (sfb >= (int)d.max_sfb || slot >= 128) return;  // (slot < 128 always holds for valid descriptors)
+    const int mode = d.mode[slot];
+    if (mode != SYMACCEL_AAC_JS_MS && mode != SYMACCEL_AAC_JS_INTENSITY) return;
+    float4 *lp = reinterpret_cast<float4 *>(coeffs + ((size_t)pair_chains[2 * pair] * frames_per_chain + f) * 1024) + t;
+    float4 *rp = reinterpret_cast<float4 *>(coeffs + ((size_t)pair_chains[2 * pair + 1] * frames_per_chain + f) * 1024) + t;
+    const float4 l = *lp;
+    if (mode == SYMACCEL_AAC_JS_INTENSITY) {  // cpe.rs:124-139: right = scale * left
+        const float s = d.scale[slot];
+        *rp = make_float4(s * l.x, s * l.y, s * l.z, s * l.w);
+    } else {  // cpe.rs:144-154: (m, s) -> (m + s, m - s)
+        const float4 r = *rp;
+        *lp = make_float4(l.x + r.x, l.y + r.y, l.z + r.z, l.w + r.w);
+        *rp = make_float4(l.x - r.x, l.y - r.y, l.z - r.z, l.w - r.w);
+    }
+}
+
+constexpr int kTnsMaxOrder = 20;  // TNS_MAX_ORDER, tns.rs:22
+constexpr int kTnsGroup = 16;     // lines per lane and round
+
+__global__ __launch_bounds__(64) void aac_tns_kernel(float *__restrict__ coeffs, unsigned n_frames,
+                                                     const symaccel_aac_tns_filter *__restrict__ filters, unsigned n_filters) {
+    const unsigned idx = blockIdx.x * 64u + threadIdx.x;
+    int len = 0, order = 0, step = 1;
+    float *x = coeffs;
+    float lpc[kTnsMaxOrder], h[kTnsMaxOrder];
+#pragma unroll
+    for (int j = 0; j < kTnsMaxOrder; ++j) lpc[j] = h[j] = 0.0f;
+    if (idx < n_filters) {
+        const symaccel_aac_tns_filter &f = filters[idx];
+        const int start = f.start, end = f.end;
+        if (f.frame < n_frames && start < end && end <= 1024 && f.order >= 1 && f.order <= kTnsMaxOrder) {
+            order = f.order;
+            len = end - start;
+            step = f.direction ? -1 : 1;
+            x = coeffs + (size_t)f.frame * 1024 + (f.direction ? end - 1 : start);
+#pragma unroll
+            for (int j = 0; j < kTnsMaxOrder; ++j) lpc[j] = f.lpc[j];
+        }
+    }
+    // wave-uniform bounds: the longest range and the highest order among the wavefront's filters
+    int max_len = len, max_order = order;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int a = __shfl_xor(max_len, m), b = __shfl_xor(max_order, m);
+        max_len = a > max_len ? a : max_len;
+        max_order = b > max_order ? b : max_order;
+    }
+    // Sixteen lines (64 bytes) per lane and round: the filter walks its range in groups of sixteen -- four 16-byte
+    // loads and stores when the range is 16-byte aligned, as every range built from swb offsets is; scalar accesses
+    // otherwise and for a ragged last group -- so every 64-byte sector a lane touches crosses the L2 -> L1 path once
+    // (lane-private 16-byte accesses re-fetched each sector four times and were bound by exactly that).  The next
+    // group is fetched while the current one is filtered: the inputs are the unfiltered lines, independent of the outputs.
+    const bool down = step < 0;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) + (down ? 4 : 0)) & 15u) == 0;  // x = first line (up) / last line (down)
+    auto fetch = [&](int m0, float (&v)[kTnsGroup]) {
+        if (m0 >= len) return;
+        if (aligned && m0 + kTnsGroup <= len) {
+#pragma unroll
+            for (int q = 0; q < kTnsGroup / 4; ++q) {
+                const float4 f4 = *reinterpret_cast<const float4 *>(down ? x - m0 - 4 * q - 3 : x + m0 + 4 * q);
+                v[4 * q + 0] = down ? f4.w : f4.x;
+                v[4 * q + 1] = down ? f4.z : f4.y;
+                v[4 * q + 2] = down ? f4.y : f4.z;
+                v[4 * q + 3] = down ? f4.x : f4.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTnsGroup; ++k)
+                if (m0 + k < len) v[k] = x[(long)(m0 + k) * step];
+        }
+    };
+    float cur[kTnsGroup], nxt[kTnsGroup];
+#pragma unroll
+    for (int k = 0; k < kTnsGroup; ++k) cur[k] = nxt[k] = 0.0f;
+    fetch(0, cur);
+    for (int m0 = 0; m0 < max_len; m0 += kTnsGroup) {
+        fetch(m0 + kTnsGroup, nxt);
+        // Lines past a lane's range are computed too (their results are never stored and the lane's history no longer
+        // matters), so the history shift is an unconditional register renaming.
+#pragma unroll
+        for (int k = 0; k < kTnsGroup; ++k) {
+            const int m = m0 + k;
+            float acc = cur[k];
+            const int lim = order < m ? order : m;  // taps that reach a line of this filter's own range
+#pragma unroll
+            for (int j = 0; j < kTnsMaxOrder; ++j) {
+                if (j < max_order) {  // wave-uniform
+                    const float term = h[j] * lpc[j];
+                    acc = j < lim ? acc - term : acc;  // coeffs[i] -= coeffs[i -+ (j + 1)] * lpc[j], in tap order
+                }
+            }
+            cur[k] = acc;
+#pragma unroll
+            for (int j = kTnsMaxOrder - 1; j >= 1; --j) h[j] = h[j - 1];
+            h[0] = acc;
+        }
+        if (m0 < len) {
+            if (aligned && m0 + kTnsGroup <= len) {
+#pragma unroll
+                for (int q = 0; q < kTnsGroup / 4; ++q)
+                    *reinterpret_cast<float4 *>(down ? x - m0 - 4 * q - 3 : x + m0 + 4 * q) =
+                        down ? make_float4(cur[4 * q + 3], cur[4 * q + 2], cur[4 * q + 1], cur[4 * q])
+                             : make_float4(cur[4 * q], cur[4 * q + 1], cur[4 * q + 2], cur[4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kTnsGroup; ++k)
+                    if (m0 + k < len) x[(long)(m0 + k) * step] = cur[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kTnsGroup; ++k) cur[k] = nxt[k];
+    }
+}
+
+}  // namespace
+
+int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d_coeffs, size_t frames_per_chain,
+                            const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs) {
+    const size_t grid = n_pairs * frames_per_chain;
+    if (grid > 0x7fffffffu || frames_per_chain > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(aac_joint_stereo_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, maps, d_coeffs,
+                       (unsigned)frames_per_chain, d_pair_chains, d_desc);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
+                   size_t n_filters) {
+    const size_t grid = (n_filters + 63) / 64;
+    if (n_frames > 0xffffffffu || n_filters > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(aac_tns_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_coeffs, (unsigned)n_frames, d_filters,
+                       (unsigned)n_filters);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+}  // namespace symaccel

@@ -637,6 +637,40 @@ int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, i
 
 // ---- tables -------------------------------------------------------------------------------
 
+// line/4 -> band map of one swb offset table; false if the table is not what ICS get_bands() can return
+static bool build_band_map(const uint16_t *swb, int n_swb, int lines, int max_bands, uint8_t *map4) {
+    if (!swb || n_swb < 1 || n_swb > max_bands || swb[0] != 0) return false;
+    std::memset(map4, 255, (size_t)lines / 4);
+    for (int b = 0; b < n_swb; ++b) {
+        if (swb[b + 1] <= swb[b] || swb[b + 1] > lines || (swb[b] & 3) || (swb[b + 1] & 3)) return false;
+        for (int i = swb[b] / 4; i < swb[b + 1] / 4; ++i) map4[i] = (uint8_t)b;
+    }
+    return true;
+}
+
+int symaccel_aac_joint_stereo_device(symaccel_ctx *ctx, float *d_coeffs, size_t frames_per_chain,
+                                     const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs,
+                                     const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short, int n_swb_short) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    AacBandMaps maps;
+    // long windows have at most 51 bands (ISO/IEC 14496-3 Table 4.139: 8 kHz... 49/51), short ones at most 15
+    if (!build_band_map(swb_long, n_swb_long, 1024, 64, maps.long4) || !build_band_map(swb_short, n_swb_short, 128, 16, maps.short4))
+        return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs == 0 || frames_per_chain == 0) return SYMACCEL_OK;
+    if (!d_coeffs || !d_pair_chains || !d_desc) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_aac_joint_stereo(ctx, maps, d_coeffs, frames_per_chain, d_pair_chains, d_desc, n_pairs);
+}
+
+int symaccel_aac_tns_device(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
+                            size_t n_filters) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_filters == 0 || n_frames == 0) return SYMACCEL_OK;
+    if (!d_coeffs || !d_filters) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_aac_tns(ctx, d_coeffs, n_frames, d_filters, n_filters);
+}
+
 int symaccel_mp3_requantize_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_desc,
                                    int sample_rate_idx, float *d_xr, size_t n) {
     if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;

@@ -134,6 +134,12 @@ int get_vorbis_window(symaccel_ctx *ctx, int bs, const float **out);
         if (_e != hipSuccess) return ::symaccel::ctx_fail((ctx), _e, #expr); \
     } while (0)
 
+// line / 4 -> scale-factor band of the caller's swb offset tables (255 = past the last band), passed by value
+struct AacBandMaps {
+    uint8_t long4[256];
+    uint8_t short4[32];
+};
+
 // kernel launchers (one per .hip file)
 int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count);
 int launch_imdct(symaccel_ctx *ctx, const ImdctPlan &plan, const float *d_spec, float *d_out, size_t count);
@@ -159,6 +165,10 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
                                size_t count);
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier,
                          const uint32_t *d_y, uint32_t n, float *d_floor, size_t count);
+int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d_coeffs, size_t frames_per_chain,
+                            const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs);
+int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
+                   size_t n_filters);
 int launch_mp3_requantize(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_desc, int sr,
                           float *d_xr, size_t n);
 int launch_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *d_in, const float *d_vvec_in,

@@ -69,6 +69,26 @@ def main():
     xr = torch.empty((ngc, 576), device="cuda")
     t = timeit(lambda: rq.requantize(quant, desc, xr))
     out["mp3 requantize (262144 granule-channels, i16 -> f32)"] = ngc * (576 * 6 + 52) / t
+    # AAC spectral tools at config-2 size: 64 pairs x 1024 frames, every band of every frame mid/side coded;
+    # one order-12 TNS filter over lines 96..896 in every channel-frame
+    swb_long = [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216,
+                240, 264, 292, 320, 352, 384, 416, 448, 480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800, 832, 864, 896,
+                928, 1024]
+    swb_short = [0, 4, 8, 12, 16, 20, 28, 36, 44, 56, 68, 80, 96, 112, 128]
+    tools = sa.AacSpectralTools(ctx, swb_long, swb_short)
+    coeffs = torch.randn((128, 1024, 1024), device="cuda") * 0.01
+    pairs = torch.arange(128, dtype=torch.int32, device="cuda").reshape(64, 2)
+    jd = np.zeros((64, 1024), sa.AAC_JS_DTYPE)
+    jd["num_windows"], jd["max_sfb"], jd["mode"] = 1, 49, 1
+    jdesc = torch.from_numpy(jd.view(np.uint8).reshape(64, 1024, 644)).cuda()
+    t = timeit(lambda: tools.joint_stereo(coeffs, pairs, jdesc))
+    out["aac mid/side, all bands (64 pairs x 1024 frames)"] = (4 * 65536 * 4096 + jd.nbytes) / t
+    tf = np.zeros(131072, sa.AAC_TNS_DTYPE)
+    tf["frame"], tf["start"], tf["end"], tf["order"] = np.arange(131072), 96, 896, 12
+    tf["lpc"][:, :12] = (rng.standard_normal((131072, 12)) * 0.05).astype(np.float32)
+    tfilt = torch.from_numpy(tf.view(np.uint8).reshape(-1, 92)).cuda()
+    t = timeit(lambda: tools.tns(coeffs, tfilt), reps=3)
+    out["aac TNS order 12 x 800 lines in 131072 frames (%.2f ms)" % (t * 1e3)] = 131072 * 800 * 8 / t
     for k, gbps in out.items():
         print("%-52s %8.1f GB/s  (%.1f %% of 8 TB/s)" % (k, gbps / 1e9, gbps / 8e12 * 100))
     ctx.close()
