@@ -170,6 +170,22 @@ private:
     Context &ctx_;
 };
 
+// The stages between the spectrum decoder and Dsp::synth, batched and in place on DEVICE memory (the array
+// Dsp::synth_batch's device twin consumes): joint-stereo decoding of ChannelPair::decode (aac/cpe.rs:110-157) and the
+// filtering loops of Tns::synth (aac/ics/tns.rs:180-195).  Descriptors: see symaccel.h.
+inline void joint_stereo_device(Context &ctx, float *d_coeffs, std::size_t frames_per_chain, const std::int32_t *d_pair_chains,
+                                const symaccel_aac_js_frame *d_desc, std::size_t n_pairs, const std::vector<std::uint16_t> &swb_long,
+                                const std::vector<std::uint16_t> &swb_short) {
+    if (swb_long.size() < 2 || swb_short.size() < 2) throw std::invalid_argument("joint_stereo: swb offset tables");
+    check(symaccel_aac_joint_stereo_device(ctx.raw(), d_coeffs, frames_per_chain, d_pair_chains, d_desc, n_pairs, swb_long.data(),
+                                           (int)swb_long.size() - 1, swb_short.data(), (int)swb_short.size() - 1),
+          ctx.raw());
+}
+inline void tns_device(Context &ctx, float *d_coeffs, std::size_t n_frames, const symaccel_aac_tns_filter *d_filters,
+                       std::size_t n_filters) {
+    check(symaccel_aac_tns_device(ctx.raw(), d_coeffs, n_frames, d_filters, n_filters), ctx.raw());
+}
+
 }  // namespace aac
 
 namespace mp3 {
