@@ -200,6 +200,30 @@ int symaccel_mp3_requantize_device(symaccel_ctx *ctx, const int16_t *d_quant, co
 int symaccel_mp3_requantize(symaccel_ctx *ctx, const int16_t *h_quant, const symaccel_mp3_requant *h_desc,
                             int sample_rate_idx, float *h_xr, size_t n_granule_channels);
 
+/* Joint stereo, the stage between requantisation and the synthesis tail: stereo() (layer3/stereo.rs:485-556) with the
+ * intensity-stereo band scans process_intensity_long_block (:196-260) and process_intensity_short_block (:264-483) --
+ * which bands are intensity coded is decided from the requantised values of channel 1 (zero bands from the top,
+ * per window for short blocks), exactly as the reference does -- mid/side everywhere below the intensity bound, and
+ * the ratio tables of stereo.rs:31-118 (host libm: tan / powf).  In place on xr[chain][granule][576];
+ * pair_chains[p] = {channel-0 chain, channel-1 chain}; desc[p][granule].  The caller keeps the reference's check
+ * that both channels carry the same block type (stereo.rs:502-504) and afterwards gives both channels
+ * rzero = max(rzero0, rzero1) (stereo.rs:549-553) in the side records of symaccel_mp3_synth. */
+#define SYMACCEL_MP3_ST_MID_SIDE 1u  /* Mode::Layer3 { mid_side, .. } */
+#define SYMACCEL_MP3_ST_INTENSITY 2u /* Mode::Layer3 { .., intensity } */
+#define SYMACCEL_MP3_ST_MPEG1 4u     /* FrameHeader::is_mpeg1() */
+#define SYMACCEL_MP3_ST_IS_SCALE 8u  /* channels[1].scalefac_compress & 1 (selects the MPEG-2 / 2.5 ratio table) */
+typedef struct symaccel_mp3_stereo {
+    uint8_t flags;          /* SYMACCEL_MP3_ST_* */
+    uint8_t block_type;     /* SYMACCEL_MP3_*, of both channels */
+    uint8_t is_mixed;
+    uint8_t reserved;
+    uint16_t rzero0, rzero1;
+    uint8_t scalefacs1[39]; /* channels[1].scalefacs: the intensity positions */
+    uint8_t pad;
+} symaccel_mp3_stereo;      /* 48 bytes */
+int symaccel_mp3_stereo_device(symaccel_ctx *ctx, float *d_xr, size_t granules_per_chain, const int32_t *d_pair_chains,
+                               const symaccel_mp3_stereo *d_desc, int sample_rate_idx, size_t n_pairs);
+
 /* synthesis::synthesis alone (synthesis.rs:158-336) as Layer I and Layer II use it: n_frames = 12
  * (layer1/mod.rs:193) or 36 (layer2/mod.rs:383) time slots per packet and channel.  in[chain][packet][32 * n_frames]
  * sub-band-major (in[n_frames * i + b], synthesis.rs:168-170); pcm[chain][packet][32 * n_frames]; state per chain:

@@ -257,6 +257,12 @@ inline void requantize_batch(Context &ctx, int sample_rate_idx, const std::int16
     check(symaccel_mp3_requantize(ctx.raw(), quant, desc, sample_rate_idx, xr, n_granule_channels), ctx.raw());
 }
 
+// stereo(header, granule, ch) (stereo.rs:485-556), batched and in place on DEVICE memory: xr[chain][granule][576]
+inline void stereo_device(Context &ctx, int sample_rate_idx, float *d_xr, std::size_t granules_per_chain,
+                          const std::int32_t *d_pair_chains, const symaccel_mp3_stereo *d_desc, std::size_t n_pairs) {
+    check(symaccel_mp3_stereo_device(ctx.raw(), d_xr, granules_per_chain, d_pair_chains, d_desc, sample_rate_idx, n_pairs), ctx.raw());
+}
+
 // synthesis(state, n_frames, in_samples, out) (synthesis.rs:158-336) as Layer I (n_frames 12) and Layer II (36) call it
 inline void synthesis(Context &ctx, SynthesisState &state, std::size_t n_frames, const float *in_samples, std::size_t in_len,
                       float *out, std::size_t out_len) {

@@ -449,6 +449,27 @@ def mp3_requantize(quant, desc, sr):
     return out
 
 
+MP3_STEREO_DTYPE = np.dtype([("flags", np.uint8), ("block_type", np.uint8), ("is_mixed", np.uint8), ("reserved", np.uint8),
+                             ("rzero0", np.uint16), ("rzero1", np.uint16), ("scalefacs1", np.uint8, (39,)), ("pad", np.uint8)])
+assert MP3_STEREO_DTYPE.itemsize == 48
+MP3_ST_MID_SIDE, MP3_ST_INTENSITY, MP3_ST_MPEG1, MP3_ST_IS_SCALE = 1, 2, 4, 8
+
+
+def mp3_intensity_ratios():
+    m1, m2 = np.zeros((7, 2), np.float32), np.zeros((2, 32, 2), np.float32)
+    lib().so_mp3_intensity_ratios(_p(m1), _p(m2))
+    return m1, m2
+
+
+def mp3_stereo(ch0, ch1, desc, sr):
+    """stereo() for one granule: ch0/ch1[576], desc: MP3_STEREO_DTYPE scalar.  Returns (ch0', ch1')."""
+    a = np.array(ch0, dtype=np.float32, copy=True)
+    b = np.array(ch1, dtype=np.float32, copy=True)
+    d = np.ascontiguousarray(desc, dtype=MP3_STEREO_DTYPE).reshape(1)
+    lib().so_mp3_stereo(_p(a), _p(b), _p(d), int(sr))
+    return a, b
+
+
 # ---- timing driver (bench.py cpu_baseline) ------------------------------------
 
 def bench_mt(kind, threads, seconds, in0, in1, in2=None, n_chains=0, per_chain=0, stride_in=0, stride_out=0, p0=0, p1=0):

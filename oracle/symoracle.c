@@ -531,6 +531,8 @@ typedef struct {
     int sfb_long[9][23];
     float pow43[8207];                 /* requantize.rs:28-31 */
     float pow2ab[SO_MP3_POW2AB_LEN];   /* 2^(0.25 e), e = SO_MP3_POW2AB_MIN_E .. (requantize.rs:280, 343) */
+    float is_mpeg1[7][2];              /* INTENSITY_STEREO_RATIOS_MPEG1 (stereo.rs:83-118) */
+    float is_mpeg2[2][32][2];          /* INTENSITY_STEREO_RATIOS_MPEG2 (stereo.rs:31-81) */
 } mp3_tables;
 
 static mp3_tables g_mp3;
@@ -680,6 +682,26 @@ static void mp3_init(void)
     /* f64::powf(2.0, 0.25 * f64::from(a - b)) as f32 (requantize.rs:280, 343) for every exponent reachable */
     for (int i = 0; i < SO_MP3_POW2AB_LEN; i++)
         t->pow2ab[i] = (float)pow(2.0, 0.25 * (double)(SO_MP3_POW2AB_MIN_E + i));
+    /* stereo.rs:105-116: is_ratio = tan(is_pos PI/12); (is_ratio / (1 + is_ratio), 1 / (1 + is_ratio)); [6] = (1, 0) */
+    for (int is_pos = 0; is_pos < 7; is_pos++) {
+        const double is_ratio = tan((M_PI / 12.0) * (double)is_pos);
+        t->is_mpeg1[is_pos][0] = (float)(is_ratio / (1.0 + is_ratio));
+        t->is_mpeg1[is_pos][1] = (float)(1.0 / (1.0 + is_ratio));
+    }
+    t->is_mpeg1[6][0] = 1.0f;
+    t->is_mpeg1[6][1] = 0.0f;
+    /* stereo.rs:60-79: i0 = 1 / sqrt(SQRT_2) or FRAC_1_SQRT_2; odd: (i0^((is_pos + 1) / 2), 1), even: (1, i0^(is_pos / 2)) */
+    const double is_scale[2] = {1.0 / sqrt(M_SQRT2), M_SQRT1_2};
+    for (int k = 0; k < 2; k++)
+        for (int is_pos = 0; is_pos < 32; is_pos++) {
+            if (is_pos & 1) {
+                t->is_mpeg2[k][is_pos][0] = (float)pow(is_scale[k], (double)(is_pos + 1) / 2.0);
+                t->is_mpeg2[k][is_pos][1] = 1.0f;
+            } else {
+                t->is_mpeg2[k][is_pos][0] = 1.0f;
+                t->is_mpeg2[k][is_pos][1] = (float)pow(is_scale[k], (double)is_pos / 2.0);
+            }
+        }
     t->ready = 1;
 }
 static mp3_tables *mp3_get(void)
@@ -791,6 +813,134 @@ void so_mp3_requantize_batch(const int16_t *is, const so_mp3_requant *ch, int sr
 {
     for (size_t g = 0; g < n; g++)
         so_mp3_requantize(is + g * 576, ch + g, sr, xr + g * 576);
+}
+
+/* ---- joint stereo (layer3/stereo.rs) ---------------------------------------------------------------------------- */
+
+void so_mp3_intensity_ratios(float *mpeg1_14, float *mpeg2_128)
+{
+    memcpy(mpeg1_14, mp3_get()->is_mpeg1, sizeof(mp3_get()->is_mpeg1));
+    memcpy(mpeg2_128, mp3_get()->is_mpeg2, sizeof(mp3_get()->is_mpeg2));
+}
+/* process_mid_side (stereo.rs:139-148) */
+static void mp3_mid_side(float *mid, float *side, int n)
+{
+    for (int i = 0; i < n; i++) {
+        const float left = (mid[i] + side[i]) * 0.70710678118654752440f;
+        const float right = (mid[i] - side[i]) * 0.70710678118654752440f;
+        mid[i] = left;
+        side[i] = right;
+    }
+}
+/* process_intensity (stereo.rs:165-186) */
+static void mp3_intensity(int is_pos, const float (*table)[2], int is_max, int mid_side, float *ch0, float *ch1, int n)
+{
+    if (is_pos < is_max) {
+        const float ratio_l = table[is_pos][0], ratio_r = table[is_pos][1];
+        for (int i = 0; i < n; i++) {
+            const float is = ch0[i];
+            ch0[i] = ratio_l * is;
+            ch1[i] = ratio_r * is;
+        }
+    } else if (mid_side) {
+        mp3_mid_side(ch0, ch1, n);
+    }
+}
+static int mp3_zero_band(const float *band, int n) /* is_zero_band (stereo.rs:189-192) */
+{
+    for (int i = 0; i < n; i++)
+        if (band[i] != 0.0f)
+            return 0;
+    return 1;
+}
+/* stereo (stereo.rs:485-556) with process_intensity_long_block (:196-260) and process_intensity_short_block (:264-483).
+ * The caller has checked that both channels carry the same block type (stereo.rs:502-504) and sets both channels'
+ * rzero to max(rzero0, rzero1) afterwards (:549-553). */
+void so_mp3_stereo(float *ch0, float *ch1, const so_mp3_stereo_desc *d, int sr)
+{
+    mp3_tables *t = mp3_get();
+    const int mid_side = (d->flags & SO_MP3_ST_MID_SIDE) != 0, intensity = (d->flags & SO_MP3_ST_INTENSITY) != 0;
+    if (!mid_side && !intensity)
+        return;
+    const int end = d->rzero0 > d->rzero1 ? d->rzero0 : d->rzero1;
+    int bound = end;
+    if (intensity) {
+        const float (*table)[2];
+        int inv_pos;
+        if (d->flags & SO_MP3_ST_MPEG1) {
+            table = t->is_mpeg1;
+            inv_pos = 7;
+        } else {
+            table = t->is_mpeg2[(d->flags & SO_MP3_ST_IS_SCALE) ? 1 : 0];
+            inv_pos = 31;
+        }
+        if (d->block_type == SO_MP3_SHORT) {
+            const int *bands;
+            int n_edges, sw = 0;
+            if (d->is_mixed) {
+                bands = t->sfb_mixed[sr];
+                n_edges = t->sfb_mixed_len[sr];
+                sw = t->sfb_mixed_switch[sr];
+            } else {
+                bands = t->sfb_short[sr];
+                n_edges = 40;
+            }
+            int is_pos[39]; /* stereo.rs:369-371 */
+            for (int i = 0; i < 36; i++)
+                is_pos[i] = d->scalefacs1[i];
+            for (int i = 0; i < 3; i++)
+                is_pos[36 + i] = d->scalefacs1[33 + i];
+            const int *sb = bands + sw;
+            const int n_short = n_edges - sw;
+            int sfi = d->is_mixed ? n_edges - 1 : 39;
+            int window_is_zero[3] = {1, 1, 1}, found_bound = 0;
+            /* groups of four consecutive edges at every third position, from the top (stereo.rs:379-386) */
+            int n_groups = 0;
+            for (int g = 0; g + 3 < n_short; g += 3)
+                n_groups++;
+            for (int gi = n_groups - 1; gi >= 0; gi--) {
+                const int s[4] = {sb[3 * gi], sb[3 * gi + 1], sb[3 * gi + 2], sb[3 * gi + 3]};
+                for (int w = 2; w >= 0; w--) { /* stereo.rs:392-448, windows 2, 1, 0 */
+                    const int a = s[w], b = s[w + 1];
+                    window_is_zero[w] = window_is_zero[w] && mp3_zero_band(ch1 + a, b - a);
+                    if (window_is_zero[w])
+                        mp3_intensity(is_pos[sfi - 1], table, inv_pos, mid_side, ch0 + a, ch1 + a, b - a);
+                    else if (mid_side)
+                        mp3_mid_side(ch0 + a, ch1 + a, b - a);
+                    sfi--;
+                }
+                bound = s[0];
+                found_bound = !window_is_zero[0] && !window_is_zero[1] && !window_is_zero[2];
+                if (found_bound)
+                    break;
+            }
+            if (!found_bound && d->is_mixed) { /* the long bands bands[..switch + 1], stereo.rs:450-478 */
+                for (int i = sw - 1; i >= 0; i--) {
+                    const int a = bands[i], b = bands[i + 1];
+                    if (!mp3_zero_band(ch1 + a, b - a))
+                        break;
+                    mp3_intensity(is_pos[sfi - 1], table, inv_pos, mid_side, ch0 + a, ch1 + a, b - a);
+                    sfi--;
+                    bound = a;
+                }
+            }
+        } else {
+            const int *bands = t->sfb_long[sr];
+            int is_pos[22]; /* stereo.rs:226-228 */
+            for (int i = 0; i < 22; i++)
+                is_pos[i] = d->scalefacs1[i];
+            is_pos[21] = is_pos[20];
+            for (int i = 21; i >= 0; i--) {
+                const int a = bands[i], b = bands[i + 1];
+                if (!(a >= (int)d->rzero1 || mp3_zero_band(ch1 + a, b - a)))
+                    break;
+                mp3_intensity(is_pos[i], table, inv_pos, mid_side, ch0 + a, ch1 + a, b - a);
+                bound = a;
+            }
+        }
+    }
+    if (mid_side && bound > 0)
+        mp3_mid_side(ch0, ch1, bound);
 }
 
 void so_mp3_imdct_windows(float *dst144) { memcpy(dst144, mp3_get()->imdct_windows, 144 * 4); }

@@ -79,6 +79,23 @@ typedef struct so_mp3_requant {     /* the GranuleChannel fields requantize read
     uint8_t scalefacs[39];
     uint8_t pad[3];
 } so_mp3_requant;                   /* 52 bytes */
+/* Joint stereo (layer3/stereo.rs:485-556).  NO test in the reference: parity unpinned by the reference; pinned in
+ * tests/ by an independent numpy restatement of the band scan and the ISO ratio closed forms. */
+#define SO_MP3_ST_MID_SIDE 1   /* Mode::Layer3 { mid_side, .. } */
+#define SO_MP3_ST_INTENSITY 2  /* Mode::Layer3 { .., intensity } */
+#define SO_MP3_ST_MPEG1 4      /* FrameHeader::is_mpeg1() */
+#define SO_MP3_ST_IS_SCALE 8   /* channels[1].scalefac_compress & 1 (MPEG-2 / 2.5 ratio table select) */
+typedef struct so_mp3_stereo_desc {
+    uint8_t flags;       /* SO_MP3_ST_* */
+    uint8_t block_type;  /* of both channels (stereo.rs:502-504) */
+    uint8_t is_mixed;
+    uint8_t reserved;
+    uint16_t rzero0, rzero1;
+    uint8_t scalefacs1[39]; /* channels[1].scalefacs: the intensity positions */
+    uint8_t pad;
+} so_mp3_stereo_desc;    /* 48 bytes */
+void so_mp3_intensity_ratios(float *mpeg1_7x2, float *mpeg2_2x32x2);
+void so_mp3_stereo(float *ch0_576, float *ch1_576, const so_mp3_stereo_desc *d, int sample_rate_idx);
 void so_mp3_pow43(float *dst8207);
 void so_mp3_pow2ab(float *dst /* SO_MP3_POW2AB_LEN */);
 /* is576: the signed quantised samples the Huffman stage decodes (|s| <= 8206); xr576 out. */

@@ -313,6 +313,26 @@ class Mp3Requantize:
         return res
 
 
+MP3_STEREO_DTYPE = np.dtype([("flags", np.uint8), ("block_type", np.uint8), ("is_mixed", np.uint8), ("reserved", np.uint8),
+                             ("rzero0", np.uint16), ("rzero1", np.uint16), ("scalefacs1", np.uint8, (39,)), ("pad", np.uint8)])
+MP3_ST_MID_SIDE, MP3_ST_INTENSITY, MP3_ST_MPEG1, MP3_ST_IS_SCALE = 1, 2, 4, 8
+
+
+class Mp3Stereo:
+    """stereo() (layer3/stereo.rs:485-556), in place on xr[chains, granules, 576] (device-pointer entry point)."""
+
+    def __init__(self, ctx, sample_rate_idx):
+        if not 0 <= int(sample_rate_idx) <= 8:
+            raise ValueError("sample_rate_idx")
+        self.ctx, self.sr = ctx, int(sample_rate_idx)
+
+    def stereo(self, xr, pair_chains, desc):
+        """pair_chains[pairs, 2] i32; desc[pairs, granules] MP3_STEREO_DTYPE (torch: uint8[pairs, granules, 48])."""
+        self.ctx._call(self.ctx.lib.dll.symaccel_mp3_stereo_device, _ptr(xr), int(xr.shape[1]), _ptr(pair_chains), _ptr(desc),
+                       self.sr, int(pair_chains.shape[0]))
+        return xr
+
+
 class VorbisDsp:
     """dsp::Dsp / DspChannel::synth (vorbis/dsp.rs:12-145) for chains of mixed-size blocks."""
 

@@ -15,7 +15,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libsymaccel.so"
-SOURCES = ["tables.cpp", "ctx.cpp", "imdct_generic.hip", "aac.hip", "aac_tools.hip", "mp3.hip", "mpa_polyphase.hip", "mp3_requant.hip", "vorbis.hip", "vorbis_wave.hip", "flac.hip", "alac.hip", "state_copy.hip"]
+SOURCES = ["tables.cpp", "ctx.cpp", "imdct_generic.hip", "aac.hip", "aac_tools.hip", "mp3.hip", "mpa_polyphase.hip", "mp3_requant.hip", "mp3_stereo.hip", "vorbis.hip", "vorbis_wave.hip", "flac.hip", "alac.hip", "state_copy.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]

@@ -200,6 +200,7 @@ int upload_tables(symaccel_ctx *ctx) {
     UP(mp3_pow43, t.mp3_pow43, sizeof t.mp3_pow43);
     UP(mp3_pow2ab, t.mp3_pow2ab, sizeof t.mp3_pow2ab);
     UP(mp3_band_map, t.mp3_band_map, sizeof t.mp3_band_map);
+    UP(mp3_is_ratios, t.mp3_is_ratios, sizeof t.mp3_is_ratios);
 #undef UP
     return SYMACCEL_OK;
 }
@@ -669,6 +670,15 @@ int symaccel_aac_tns_device(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames,
     if (!d_coeffs || !d_filters) return SYMACCEL_ERR_INVALID_ARG;
     SYM_GPU(ctx, hipSetDevice(ctx->device));
     return launch_aac_tns(ctx, d_coeffs, n_frames, d_filters, n_filters);
+}
+
+int symaccel_mp3_stereo_device(symaccel_ctx *ctx, float *d_xr, size_t granules_per_chain, const int32_t *d_pair_chains,
+                               const symaccel_mp3_stereo *d_desc, int sample_rate_idx, size_t n_pairs) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs == 0 || granules_per_chain == 0) return SYMACCEL_OK;
+    if (!d_xr || !d_pair_chains || !d_desc) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_mp3_stereo(ctx, d_xr, granules_per_chain, d_pair_chains, d_desc, sample_rate_idx, n_pairs);
 }
 
 int symaccel_mp3_requantize_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_desc,

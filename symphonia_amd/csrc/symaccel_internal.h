@@ -44,7 +44,9 @@ struct HostTables {
     int32_t mp3_sfb_long[9][23];
     float mp3_pow43[8207];
     float mp3_pow2ab[kMp3Pow2abLen];
-    uint8_t mp3_band_map[9][3][576];  // [sample rate][long, short, mixed][line] -> scale index, kMp3Unscaled = none
+    uint8_t mp3_band_map[9][4][576];  // [sample rate][long, short, mixed (requantize), mixed (stereo)][line] -> band / slot
+                                      // index; kMp3Unscaled = no band (requantize's mixed map only)
+    float mp3_is_ratios[7 + 64][2];   // INTENSITY_STEREO_RATIOS_MPEG1[7] | _MPEG2[2][32] as (left, right) (stereo.rs:31-118)
     // Vorbis (floor.rs:21-112)
     float vorbis_floor1_db[256];
 };
@@ -68,7 +70,8 @@ struct DevTables {
     const int32_t *mp3_reorder_end;      // [9][2][577]: reorder end index `i` for each input rzero
     const float *vorbis_floor1_db;
     const float *mp3_pow43, *mp3_pow2ab;
-    const uint8_t *mp3_band_map;         // [9][3][576]
+    const uint8_t *mp3_band_map;         // [9][4][576]
+    const float *mp3_is_ratios;          // [71][2]
 };
 
 // Offsets (in floats) inside DevTables::mp3_consts.
@@ -169,6 +172,8 @@ int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d
                             const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs);
 int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
                    size_t n_filters);
+int launch_mp3_stereo(symaccel_ctx *ctx, float *d_xr, size_t granules_per_chain, const int32_t *d_pair_chains,
+                      const symaccel_mp3_stereo *d_desc, int sr, size_t n_pairs);
 int launch_mp3_requantize(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_desc, int sr,
                           float *d_xr, size_t n);
 int launch_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *d_in, const float *d_vvec_in,

@@ -192,7 +192,7 @@ void build(HostTables &t) {
         // bands of requantize_long(bands[..switch]) (one fewer than the edges), then scalefacs[switch + i] for the
         // short slots; lines in between are covered by no band (requantize.rs:368-372).
         uint8_t(*map)[576] = t.mp3_band_map[sr];
-        std::memset(map, kMp3Unscaled, 3 * 576);
+        std::memset(map, kMp3Unscaled, 4 * 576);
         for (int b = 0; b < 22; ++b)
             for (int i = t.mp3_sfb_long[sr][b]; i < t.mp3_sfb_long[sr][b + 1]; ++i) map[0][i] = (uint8_t)b;
         for (int b = 0; b < 39; ++b)
@@ -202,8 +202,31 @@ void build(HostTables &t) {
             for (int i = t.mp3_sfb_mixed[sr][b]; i < t.mp3_sfb_mixed[sr][b + 1]; ++i) map[2][i] = (uint8_t)b;
         for (int b = sw; b + 1 < len; ++b)
             for (int i = t.mp3_sfb_mixed[sr][b]; i < t.mp3_sfb_mixed[sr][b + 1]; ++i) map[2][i] = (uint8_t)b;
+        // stereo's view of a mixed block: every interval of the edge table (long bands bands[..switch + 1], stereo.rs:357)
+        for (int b = 0; b + 1 < len; ++b)
+            for (int i = t.mp3_sfb_mixed[sr][b]; i < t.mp3_sfb_mixed[sr][b + 1]; ++i) map[3][i] = (uint8_t)b;
     }
     // requantize.rs:28-31: f32::powf(i as f32, 4.0 / 3.0); requantize.rs:280, 343: f64::powf(2.0, 0.25 * e) as f32
+    // stereo.rs:105-116 (MPEG-1: tan) and :60-79 (MPEG-2 / 2.5: powf of 1/sqrt(sqrt 2) or 1/sqrt 2)
+    for (int is_pos = 0; is_pos < 7; ++is_pos) {
+        const double is_ratio = std::tan((kPi / 12.0) * (double)is_pos);
+        t.mp3_is_ratios[is_pos][0] = (float)(is_ratio / (1.0 + is_ratio));
+        t.mp3_is_ratios[is_pos][1] = (float)(1.0 / (1.0 + is_ratio));
+    }
+    t.mp3_is_ratios[6][0] = 1.0f;
+    t.mp3_is_ratios[6][1] = 0.0f;
+    const double is_scale[2] = {1.0 / std::sqrt(1.41421356237309504880168872420969808), 0.707106781186547524400844362104849039};
+    for (int k = 0; k < 2; ++k)
+        for (int is_pos = 0; is_pos < 32; ++is_pos) {
+            float *r = t.mp3_is_ratios[7 + 32 * k + is_pos];
+            if (is_pos & 1) {
+                r[0] = (float)::pow(is_scale[k], (double)(is_pos + 1) / 2.0);
+                r[1] = 1.0f;
+            } else {
+                r[0] = 1.0f;
+                r[1] = (float)::pow(is_scale[k], (double)is_pos / 2.0);
+            }
+        }
     for (int i = 0; i < 8207; ++i) t.mp3_pow43[i] = ::powf((float)i, 4.0f / 3.0f);
     for (int i = 0; i < kMp3Pow2abLen; ++i) t.mp3_pow2ab[i] = (float)::pow(2.0, 0.25 * (double)(kMp3Pow2abMinE + i));
     for (int i = 0; i < 256; ++i) std::memcpy(&t.vorbis_floor1_db[i], &SYM_VORBIS_FLOOR1_DB_BITS[i], 4);

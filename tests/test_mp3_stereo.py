@@ -1,0 +1,241 @@
+"""MP3 Layer III joint stereo (layer3/stereo.rs:485-556).
+
+The reference has no test for this stage: the oracle's restatement is "parity unpinned by the reference".  It is pinned
+here by (a) the closed forms of the two ratio tables (ISO/IEC 11172-3 2.4.3.4.9.3, 13818-3 2.4.3.2), (b) an
+independent numpy restatement of the band walk written from the standard's description (intensity-coded = the zero
+part of channel 1 from the top, per window for short blocks; mid/side below the bound), using the band tables
+recorded from the reference, and (c) invertibility of mid/side.  The kernel is compared bit for bit with the oracle:
+CPU emulation here, MI355X under -m gpu."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from emu_lib import emu_ctx  # noqa: F401
+from helpers import bit_equal
+
+KATS = json.loads((Path(__file__).parent / "golden" / "ref_kats.json").read_text())
+SHORT = 2
+F = np.float32
+C = F(0.70710678118654752440)
+
+
+def ms(a, b):
+    return ((a + b) * C).astype(F), ((a - b) * C).astype(F)
+
+
+def numpy_stereo(ch0, ch1, d, sr):
+    """Independent restatement: decide an action per band first, then apply."""
+    ch0, ch1 = ch0.copy(), ch1.copy()
+    mid_side, intensity = bool(d["flags"] & 1), bool(d["flags"] & 2)
+    if not (mid_side or intensity):
+        return ch0, ch1
+    end = max(int(d["rzero0"]), int(d["rzero1"]))
+    m1, m2 = oracle.mp3_intensity_ratios()
+    table, inv = (m1, 7) if d["flags"] & 4 else (m2[1 if d["flags"] & 8 else 0], 31)
+    sf = d["scalefacs1"]
+    actions = {}  # (start, end) -> ("is", kl, kr) | "ms"
+    bound = end
+
+    def zero(a, b):
+        return not np.any(ch1[a:b] != 0)
+
+    def intensity_or_ms(pos):
+        if pos < inv:
+            return ("is", table[pos][0], table[pos][1])
+        return "ms" if mid_side else None
+
+    if intensity:
+        if d["block_type"] == SHORT:
+            mixed = bool(d["is_mixed"])
+            edges = KATS["mp3_sfb_mixed"][sr] if mixed else KATS["mp3_sfb_short"][sr]
+            sw = KATS["mp3_sfb_mixed_switch"][sr] if mixed else 0
+            pos = list(sf[:36]) + list(sf[33:36])
+            n_win = (len(edges) - 1 - sw) // 3 * 3  # the short part, whole bands of three windows
+            alive = [True, True, True]
+            found = False
+            for band_top in range(sw + n_win, sw, -3):  # bands from the top, windows 2, 1, 0
+                for w in (2, 1, 0):
+                    k = band_top - 3 + w
+                    alive[w] = alive[w] and zero(edges[k], edges[k + 1])
+                    actions[(edges[k], edges[k + 1])] = intensity_or_ms(pos[k]) if alive[w] else ("ms" if mid_side else None)
+                bound = edges[band_top - 3]
+                if not any(alive):
+                    found = True
+                    break
+            if not found and mixed:
+                for k in range(sw - 1, -1, -1):
+                    if not zero(edges[k], edges[k + 1]):
+                        break
+                    actions[(edges[k], edges[k + 1])] = intensity_or_ms(pos[k])
+                    bound = edges[k]
+        else:
+            edges = KATS["mp3_sfb_long"][sr]
+            pos = list(sf[:21]) + [sf[20]]
+            for k in range(21, -1, -1):
+                if not (edges[k] >= int(d["rzero1"]) or zero(edges[k], edges[k + 1])):
+                    break
+                actions[(edges[k], edges[k + 1])] = intensity_or_ms(pos[k])
+                bound = edges[k]
+    o0, o1 = ch0.copy(), ch1.copy()
+    for (a, b), act in actions.items():
+        if act == "ms":
+            o0[a:b], o1[a:b] = ms(ch0[a:b], ch1[a:b])
+        elif act is not None:
+            o0[a:b], o1[a:b] = (F(act[1]) * ch0[a:b]).astype(F), (F(act[2]) * ch0[a:b]).astype(F)
+    if mid_side and bound > 0:
+        o0[:bound], o1[:bound] = ms(ch0[:bound], ch1[:bound])
+    return o0, o1
+
+
+def make_granule(rng, sr, kind, flags):
+    d = np.zeros((), oracle.MP3_STEREO_DTYPE)
+    d["flags"] = flags
+    d["block_type"] = SHORT if kind in ("short", "mixed") else rng.choice([0, 1, 3])
+    d["is_mixed"] = kind == "mixed"
+    inv = 7 if flags & 4 else 31
+    d["scalefacs1"] = rng.integers(0, inv + 1 if rng.random() < 0.7 else 8, 39)
+    ch0 = rng.standard_normal(576).astype(F)
+    ch1 = rng.standard_normal(576).astype(F)
+    rz0 = int(rng.integers(0, 289)) * 2
+    style = rng.integers(0, 4)
+    if style == 0:      # channel 1 stops early: the classic intensity layout
+        rz1 = int(rng.integers(0, rz0 // 2 + 1)) * 2
+    elif style == 1:    # channel 1 longer than channel 0
+        rz1 = int(rng.integers(rz0 // 2, 289)) * 2
+    else:
+        rz1 = rz0
+    ch0[rz0:] = 0
+    ch1[rz1:] = 0
+    if style == 3 and kind != "long":  # holes in single windows of short bands
+        edges = KATS["mp3_sfb_mixed" if kind == "mixed" else "mp3_sfb_short"][sr]
+        for k in rng.integers(0, len(edges) - 1, 6):
+            ch1[edges[k]:edges[k + 1]] = 0
+    if style == 3 and kind == "long":
+        edges = KATS["mp3_sfb_long"][sr]
+        for k in rng.integers(10, 22, 4):
+            ch1[edges[k]:edges[k + 1]] = 0
+    d["rzero0"], d["rzero1"] = rz0, rz1
+    return ch0, ch1, d
+
+
+def cases(seed, n, sr):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        kind = ("long", "short", "mixed")[i % 3]
+        flags = int(rng.choice([0, 1, 2, 3, 3, 3])) | (4 if rng.random() < 0.5 else 0) | (8 if rng.random() < 0.5 else 0)
+        out.append(make_granule(rng, sr, kind, flags))
+    return out
+
+
+# ---------------------------------------------------------------- oracle pins
+
+def test_ratio_tables_closed_form():
+    m1, m2 = oracle.mp3_intensity_ratios()
+    for p in range(6):
+        r = np.tan(p * np.pi / 12)
+        np.testing.assert_allclose(m1[p], [r / (1 + r), 1 / (1 + r)], rtol=2e-7, atol=1e-8)
+    assert m1[6, 0] == 1 and m1[6, 1] == 0 and m1[0, 0] == 0 and m1[0, 1] == 1
+    for k, i0 in enumerate((2 ** -0.25, 2 ** -0.5)):
+        for p in range(32):
+            want = (i0 ** ((p + 1) // 2), 1.0) if p & 1 else (1.0, i0 ** (p // 2))
+            np.testing.assert_allclose(m2[k, p], want, rtol=2e-7)
+
+
+@pytest.mark.parametrize("sr", [0, 2, 3, 8])
+def test_oracle_stereo_matches_the_band_walk(sr):
+    for ch0, ch1, d in cases(sr, 90, sr):
+        got = oracle.mp3_stereo(ch0, ch1, d, sr)
+        want = numpy_stereo(ch0, ch1, d, sr)
+        assert bit_equal(got[0], want[0]) and bit_equal(got[1], want[1]), d
+
+
+def test_mid_side_round_trip():
+    rng = np.random.default_rng(3)
+    l, r = rng.standard_normal(576).astype(F), rng.standard_normal(576).astype(F)
+    m, s = ms(l, r)  # the encoder's (l + r) / sqrt 2, (l - r) / sqrt 2
+    d = np.zeros((), oracle.MP3_STEREO_DTYPE)
+    d["flags"], d["rzero0"], d["rzero1"] = 1, 576, 576
+    o0, o1 = oracle.mp3_stereo(m, s, d, 0)
+    np.testing.assert_allclose(o0, l, atol=1e-6)
+    np.testing.assert_allclose(o1, r, atol=1e-6)
+
+
+# ---------------------------------------------------------------- kernel vs oracle
+
+def batch(seed, sr, n_pairs, granules):
+    cs = cases(seed, n_pairs * granules, sr)
+    chains = 2 * n_pairs + 1  # one mono chain in the middle stays untouched
+    xr = np.random.default_rng(seed).standard_normal((chains, granules, 576)).astype(F)
+    order = np.random.default_rng(seed + 1).permutation(chains)
+    pairs = np.array([[order[2 * p], order[2 * p + 1]] for p in range(n_pairs)], np.int32)
+    desc = np.zeros((n_pairs, granules), oracle.MP3_STEREO_DTYPE)
+    want = xr.copy()
+    for p in range(n_pairs):
+        for g in range(granules):
+            ch0, ch1, d = cs[p * granules + g]
+            xr[pairs[p, 0], g], xr[pairs[p, 1], g], desc[p, g] = ch0, ch1, d
+            want[pairs[p, 0], g], want[pairs[p, 1], g] = oracle.mp3_stereo(ch0, ch1, d, sr)
+    want[order[-1]] = xr[order[-1]]
+    return xr, pairs, desc, want
+
+
+@pytest.mark.parametrize("sr,n_pairs,granules", [(0, 3, 7), (3, 1, 1), (8, 2, 5), (1, 4, 6)])
+def test_emu_mp3_stereo(emu_ctx, sr, n_pairs, granules):
+    from symphonia_amd import Mp3Stereo
+    xr, pairs, desc, want = batch(sr + n_pairs, sr, n_pairs, granules)
+    got = xr.copy()
+    Mp3Stereo(emu_ctx, sr).stereo(got, pairs, desc)
+    assert bit_equal(got, want)
+
+
+def test_emu_requantize_stereo_synth_chain(emu_ctx):
+    """The tail of Layer3::decode for a stereo stream (layer3/mod.rs:393-476): requantize both channels, stereo, then the
+    synthesis tail with both channels' rzero = max(rzero0, rzero1) (stereo.rs:549-553)."""
+    from symphonia_amd import Mp3Requantize, Mp3Stereo, Mp3Synthesis
+    import test_mp3_requantize as rq
+    granules, sr = 5, 0
+    q, d = rq.make_case(42, 2 * granules, kinds=("long",))
+    d["block_type"][:] = np.tile([0, 2, 2, 1, 3], 2)         # same block type in both channels of a granule
+    d["is_mixed"][:] = np.tile([0, 0, 1, 0, 0], 2)
+    q = q.reshape(2, granules, 576)
+    q[1, :, 300:] = 0                                         # channel 1 ends early: intensity-coded top
+    d = d.reshape(2, granules)
+    d["rzero"][1] = 300
+    sd = np.zeros((1, granules), oracle.MP3_STEREO_DTYPE)
+    sd["flags"], sd["block_type"], sd["is_mixed"] = 3 | 4, d["block_type"][1], d["is_mixed"][1]
+    sd["rzero0"], sd["rzero1"], sd["scalefacs1"] = d["rzero"][0], d["rzero"][1], d["scalefacs"][1] % 8
+    pairs = np.array([[0, 1]], np.int32)
+    # oracle chain
+    xr_ref = oracle.mp3_requantize(q, d, sr).reshape(2, granules, 576)
+    for g in range(granules):
+        xr_ref[0, g], xr_ref[1, g] = oracle.mp3_stereo(xr_ref[0, g], xr_ref[1, g], sd[0, g], sr)
+    end = np.maximum(d["rzero"][0], d["rzero"][1])
+    side = oracle.mp3_side(d["block_type"], d["is_mixed"], np.stack([end, end]))
+    ov, vv, vf = np.zeros((2, 576), F), np.zeros((2, 1024), F), np.zeros(2, np.int32)
+    want = oracle.mp3_synth(xr_ref, side, sr, ov, vv, vf)[0]
+    # product chain
+    xr = Mp3Requantize(emu_ctx, sr).requantize(q, d).reshape(2, granules, 576)
+    Mp3Stereo(emu_ctx, sr).stereo(xr, pairs, sd)
+    assert bit_equal(xr, xr_ref)
+    got = Mp3Synthesis(emu_ctx, sr).synth(xr, side, ov, vv, vf)[0]
+    assert bit_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,n_pairs,granules", [(0, 16, 64), (4, 5, 33), (8, 3, 20)])
+def test_gpu_mp3_stereo(sr, n_pairs, granules):
+    import torch
+    from symphonia_amd import Context, Mp3Stereo
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    xr, pairs, desc, want = batch(100 + sr, sr, n_pairs, granules)
+    with Context(0) as ctx:
+        d = torch.from_numpy(xr).cuda()
+        Mp3Stereo(ctx, sr).stereo(d, torch.from_numpy(pairs).cuda(),
+                                  torch.from_numpy(desc.view(np.uint8).reshape(n_pairs, granules, 48)).cuda())
+        ctx.sync()
+        assert bit_equal(d.cpu().numpy(), want)

@@ -69,6 +69,16 @@ def main():
     xr = torch.empty((ngc, 576), device="cuda")
     t = timeit(lambda: rq.requantize(quant, desc, xr))
     out["mp3 requantize (262144 granule-channels, i16 -> f32)"] = ngc * (576 * 6 + 52) / t
+    st = sa.Mp3Stereo(ctx, 0)
+    xr2 = torch.randn((128, 2048, 576), device="cuda") * 0.1   # config 3: 64 stereo streams x 2048 granules
+    xr2[1::2, :, 342:] = 0                                       # channel 1 ends at band 20: the top two bands are intensity coded
+    sdn = np.zeros((64, 2048), sa.MP3_STEREO_DTYPE)
+    sdn["flags"], sdn["rzero0"], sdn["rzero1"] = 3 | 4, 576, 342
+    sdn["scalefacs1"] = rng.integers(0, 7, (64, 2048, 39))
+    sdesc = torch.from_numpy(sdn.view(np.uint8).reshape(64, 2048, 48)).cuda()
+    spairs = torch.arange(128, dtype=torch.int32, device="cuda").reshape(64, 2)
+    t = timeit(lambda: st.stereo(xr2, spairs, sdesc))
+    out["mp3 joint stereo (131072 granules, m/s + intensity)"] = 131072 * (4 * 2304 + 48) / t
     # AAC spectral tools at config-2 size: 64 pairs x 1024 frames, every band of every frame mid/side coded;
     # one order-12 TNS filter over lines 96..896 in every channel-frame
     swb_long = [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216,
