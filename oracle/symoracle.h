@@ -20,9 +20,11 @@
  *   imdct36 / imdct12_win (hybrid_synthesis.rs:510-556, 802-822),
  *   dct32 (synthesis.rs:866-882), rice sign map (flac/decoder.rs:646-661).
  * AAC Dsp::synth + windows, MP3 antialias/reorder/polyphase windowing, Vorbis
- * synth/overlap/coupling/floor render and the FLAC predictors have NO test in
- * the reference: for those the oracle is "parity unpinned by the reference"
- * and is pinned instead by f64 closed forms and invertibility properties in
+ * synth/overlap/coupling/floor render, the FLAC and ALAC predictors, and the
+ * stages in front of the path (MP3 requantize + stereo, AAC joint stereo + TNS)
+ * have NO test in the reference: for those the oracle is "parity unpinned by
+ * the reference" and is pinned instead by f64 closed forms, invertibility
+ * properties, independent restatements and the reference's band tables in
  * tests/ (see DESIGN.md section "Oracle").
  */
 #ifndef SYMORACLE_H
