@@ -224,6 +224,15 @@ typedef struct symaccel_mp3_stereo {
 int symaccel_mp3_stereo_device(symaccel_ctx *ctx, float *d_xr, size_t granules_per_chain, const int32_t *d_pair_chains,
                                const symaccel_mp3_stereo *d_desc, int sample_rate_idx, size_t n_pairs);
 
+/* symaccel_mp3_requantize_device followed by symaccel_mp3_stereo_device for the channel pairs of a batch in one pass:
+ * the requantised spectra stay in registers between the two stages.  quant / rq_desc / xr are indexed
+ * [chain][granule] like d_xr above; only the chains named in pair_chains are read and written (mono chains go through
+ * symaccel_mp3_requantize_device).  Granules whose desc has neither joint-stereo flag are requantised only. */
+int symaccel_mp3_requantize_stereo_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc,
+                                          size_t granules_per_chain, const int32_t *d_pair_chains,
+                                          const symaccel_mp3_stereo *d_desc, int sample_rate_idx, float *d_xr,
+                                          size_t n_pairs);
+
 /* synthesis::synthesis alone (synthesis.rs:158-336) as Layer I and Layer II use it: n_frames = 12
  * (layer1/mod.rs:193) or 36 (layer2/mod.rs:383) time slots per packet and channel.  in[chain][packet][32 * n_frames]
  * sub-band-major (in[n_frames * i + b], synthesis.rs:168-170); pcm[chain][packet][32 * n_frames]; state per chain:

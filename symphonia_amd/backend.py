@@ -332,6 +332,13 @@ class Mp3Stereo:
                        self.sr, int(pair_chains.shape[0]))
         return xr
 
+    def requantize_stereo(self, quant, rq_desc, pair_chains, desc, xr):
+        """Mp3Requantize.requantize + stereo for the paired chains in one pass: quant[chains, granules, 576] i16,
+        rq_desc[chains, granules] MP3_REQUANT_DTYPE, xr[chains, granules, 576] f32 (only the paired chains are written)."""
+        self.ctx._call(self.ctx.lib.dll.symaccel_mp3_requantize_stereo_device, _ptr(quant), _ptr(rq_desc), int(quant.shape[1]),
+                       _ptr(pair_chains), _ptr(desc), self.sr, _ptr(xr), int(pair_chains.shape[0]))
+        return xr
+
 
 class VorbisDsp:
     """dsp::Dsp / DspChannel::synth (vorbis/dsp.rs:12-145) for chains of mixed-size blocks."""

@@ -681,6 +681,16 @@ int symaccel_mp3_stereo_device(symaccel_ctx *ctx, float *d_xr, size_t granules_p
     return launch_mp3_stereo(ctx, d_xr, granules_per_chain, d_pair_chains, d_desc, sample_rate_idx, n_pairs);
 }
 
+int symaccel_mp3_requantize_stereo_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc,
+                                          size_t granules_per_chain, const int32_t *d_pair_chains,
+                                          const symaccel_mp3_stereo *d_desc, int sample_rate_idx, float *d_xr, size_t n_pairs) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs == 0 || granules_per_chain == 0) return SYMACCEL_OK;
+    if (!d_quant || !d_rq_desc || !d_xr || !d_pair_chains || !d_desc) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    return launch_mp3_stereo(ctx, d_xr, granules_per_chain, d_pair_chains, d_desc, sample_rate_idx, n_pairs, d_quant, d_rq_desc);
+}
+
 int symaccel_mp3_requantize_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_desc,
                                    int sample_rate_idx, float *d_xr, size_t n) {
     if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;

@@ -2,15 +2,19 @@
 //   symphonia-bundle-mp3/src/layer3/stereo.rs:485-556 (stereo), 196-260 (process_intensity_long_block),
 //   264-483 (process_intensity_short_block), 139-186 (process_mid_side / process_intensity), 31-118 (ratio tables).
 //
-// One wavefront per granule (both channels, 2 x 576 lines in registers, nine lines per lane and channel, coalesced).
+// One wavefront per granule (both channels, 2 x 576 lines in registers as groups of four lines, 16-byte accesses).
 // Which bands are intensity coded depends on the data: the reference walks the scale-factor bands of channel 1 from
 // the top while they are all zero (per window for short blocks).  Here every lane flags the band of each non-zero
 // line it holds in LDS, then the wavefront runs the reference's band walk on those <= 39 flags (wave-uniform scalar
 // work) and leaves one action per band -- none, mid/side, or intensity with its (left, right) ratios -- plus the
 // intensity bound in LDS; finally every lane applies the action of its lines' bands, or mid/side below the bound.
+//
+// FUSED: the wavefront first requantises both channels from the quantised Huffman samples (mp3_requant.h: the
+// arithmetic of mp3_requant.hip) into those registers, so the f32 spectra make no round trip through HBM between
+// the two stages: 2 B in + 4 B out per line instead of 2 + 4 + 4 + 4.
 #include <hip/hip_runtime.h>
 
-#include "symaccel_internal.h"
+#include "mp3_requant.h"
 
 namespace symaccel {
 
@@ -30,12 +34,20 @@ __device__ __forceinline__ void wave_sync() {  // order this wavefront's own LDS
 constexpr int kNone = 0, kMidSide = 1, kIntensity = 2;
 constexpr int kWaves = 4;
 
+template <bool FUSED>
 __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, float *__restrict__ xr, unsigned granules_per_chain,
                                                                  const int32_t *__restrict__ pair_chains,
                                                                  const symaccel_mp3_stereo *__restrict__ desc, int sr, SfbEdges e,
-                                                                 unsigned n_items) {
+                                                                 unsigned n_items, const int16_t *__restrict__ quant,
+                                                                 const symaccel_mp3_requant *__restrict__ rq_desc) {
     __shared__ int nz_all[kWaves][40], act_all[kWaves][40];
     __shared__ float kl_all[kWaves][40], kr_all[kWaves][40];
+    __shared__ float scale_all[FUSED ? kWaves : 1][2][kMp3Slots];
+    __shared__ float pow43_lo[FUSED ? kMp3PowLds : 1];
+    if (FUSED) {
+        for (int k = (int)threadIdx.x; k < kMp3PowLds; k += 64 * kWaves) pow43_lo[k] = tb.mp3_pow43[k];
+        __syncthreads();  // the only workgroup-wide barrier, before any wavefront leaves
+    }
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     const unsigned item = blockIdx.x * kWaves + (unsigned)wave;
     if (item >= n_items) return;
@@ -44,22 +56,72 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
     const unsigned pair = item / granules_per_chain, g = item % granules_per_chain;
     const symaccel_mp3_stereo &d = desc[item];
     const bool mid_side = d.flags & SYMACCEL_MP3_ST_MID_SIDE, intensity = d.flags & SYMACCEL_MP3_ST_INTENSITY;
-    if (!mid_side && !intensity) return;  // stereo.rs:491-500: not joint stereo
-    float *ch0 = xr + ((size_t)pair_chains[2 * pair] * granules_per_chain + g) * 576;
-    float *ch1 = xr + ((size_t)pair_chains[2 * pair + 1] * granules_per_chain + g) * 576;
+    if (!FUSED && !mid_side && !intensity) return;  // stereo.rs:491-500: not joint stereo
+    const size_t gc0 = (size_t)pair_chains[2 * pair] * granules_per_chain + g, gc1 = (size_t)pair_chains[2 * pair + 1] * granules_per_chain + g;
+    float *ch0 = xr + gc0 * 576, *ch1 = xr + gc1 * 576;
     const int rzero1 = d.rzero1 > 576 ? 576 : (int)d.rzero1;
     int end = d.rzero0 > d.rzero1 ? d.rzero0 : d.rzero1;  // stereo.rs:522
     end = end > 576 ? 576 : end;
     const bool is_short = d.block_type == SYMACCEL_MP3_SHORT, is_mixed = is_short && d.is_mixed;
     const uint8_t *map = tb.mp3_band_map + (size_t)(sr * 4 + (is_short ? (is_mixed ? 3 : 1) : 0)) * 576;
 
-    float a[9], b[9];
-    int band[9];
+    // The granule as 144 groups of four lines: lane l holds groups l, l + 64 and (l < 16) l + 128 -- 16-byte loads and
+    // stores of the spectra, 8-byte loads of the quantised samples, 4-byte loads of the band maps.
+    constexpr int kQ = 3;
+    float a[4 * kQ], b[4 * kQ];
+    int band[4 * kQ];
+    bool have[kQ];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        a[q] = ch0[lane + 64 * q];
-        b[q] = ch1[lane + 64 * q];
-        band[q] = map[lane + 64 * q];
+    for (int qq = 0; qq < kQ; ++qq) have[qq] = lane + 64 * qq < 144;
+#pragma unroll
+    for (int i = 0; i < 4 * kQ; ++i) {
+        a[i] = b[i] = 0.0f;
+        band[i] = 0;
+    }
+    auto unpack_map = [&](const uint8_t *m, int grp, int *dst) {
+        const uchar4 v = reinterpret_cast<const uchar4 *>(m)[grp];
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    };
+    if (FUSED) {
+        // read_huffman_samples' values + requantize for both channels (requantize.rs:117-147, 239-380)
+        const symaccel_mp3_requant &r0 = rq_desc[gc0], &r1 = rq_desc[gc1];
+        float(*scale)[kMp3Slots] = scale_all[FUSED ? wave : 0];
+        if (lane < kMp3Slots) {
+            scale[0][lane] = mp3_slot_scale(tb, r0, lane, e.mixed_switch);
+            scale[1][lane] = mp3_slot_scale(tb, r1, lane, e.mixed_switch);
+        }
+        wave_sync();
+        const uint8_t *m0 = tb.mp3_band_map + (size_t)(sr * 4 + mp3_requant_kind(r0)) * 576;
+        const uint8_t *m1 = tb.mp3_band_map + (size_t)(sr * 4 + mp3_requant_kind(r1)) * 576;
+        const int rq0 = r0.rzero > 576 ? 576 : (int)r0.rzero, rq1 = r1.rzero > 576 ? 576 : (int)r1.rzero;
+#pragma unroll
+        for (int qq = 0; qq < kQ; ++qq) {
+            if (!have[qq]) continue;
+            const int grp = lane + 64 * qq;
+            const short4 s0 = reinterpret_cast<const short4 *>(quant + gc0 * 576)[grp];
+            const short4 s1 = reinterpret_cast<const short4 *>(quant + gc1 * 576)[grp];
+            const int v0[4] = {s0.x, s0.y, s0.z, s0.w}, v1[4] = {s1.x, s1.y, s1.z, s1.w};
+            int k0[4], k1[4];
+            unpack_map(m0, grp, k0);
+            unpack_map(m1, grp, k1);
+            unpack_map(map, grp, band + 4 * qq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int line = 4 * grp + j;
+                a[4 * qq + j] = mp3_sample_value(tb, pow43_lo, v0[j], line >= rq0) * scale[0][k0[j]];
+                b[4 * qq + j] = mp3_sample_value(tb, pow43_lo, v1[j], line >= rq1) * scale[1][k1[j]];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int qq = 0; qq < kQ; ++qq) {
+            if (!have[qq]) continue;
+            const int grp = lane + 64 * qq;
+            const float4 x0 = reinterpret_cast<const float4 *>(ch0)[grp], x1 = reinterpret_cast<const float4 *>(ch1)[grp];
+            a[4 * qq] = x0.x; a[4 * qq + 1] = x0.y; a[4 * qq + 2] = x0.z; a[4 * qq + 3] = x0.w;
+            b[4 * qq] = x1.x; b[4 * qq + 1] = x1.y; b[4 * qq + 2] = x1.z; b[4 * qq + 3] = x1.w;
+            unpack_map(map, grp, band + 4 * qq);
+        }
     }
 
     int bound = end;
@@ -70,8 +132,8 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
         }
         wave_sync();
 #pragma unroll
-        for (int q = 0; q < 9; ++q)
-            if (b[q] != 0.0f) nz[band[q]] = 1;  // is_zero_band (stereo.rs:189-192), one flag per band
+        for (int i = 0; i < 4 * kQ; ++i)
+            if (have[i / 4] && b[i] != 0.0f) nz[band[i]] = 1;  // is_zero_band (stereo.rs:189-192), one flag per band
         wave_sync();
         // ---- the band walk (identical in every lane; lane 0 records the decisions)
         const int table = (d.flags & SYMACCEL_MP3_ST_MPEG1) ? 0 : 7 + 32 * ((d.flags & SYMACCEL_MP3_ST_IS_SCALE) ? 1 : 0);
@@ -131,20 +193,33 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
     // ---- apply: mid/side below the intensity bound (stereo.rs:541-543), the band's action from it on
     constexpr float kFrac1Sqrt2 = 0.70710678118654752440f;  // f32::consts::FRAC_1_SQRT_2
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        const int line = lane + 64 * q;
-        int action = kNone;
-        if (line < bound)
-            action = mid_side ? kMidSide : kNone;
-        else if (intensity)
-            action = act[band[q]];
-        if (action == kMidSide) {  // process_mid_side (stereo.rs:139-148)
-            const float left = (a[q] + b[q]) * kFrac1Sqrt2, right = (a[q] - b[q]) * kFrac1Sqrt2;
-            ch0[line] = left;
-            ch1[line] = right;
-        } else if (action == kIntensity) {
-            ch0[line] = kl[band[q]] * a[q];
-            ch1[line] = kr[band[q]] * a[q];
+    for (int qq = 0; qq < kQ; ++qq) {
+        if (!have[qq]) continue;
+        const int grp = lane + 64 * qq;
+        bool touched = FUSED;  // fused: xr is this kernel's output, untouched lines are stored too
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * qq + j, line = 4 * grp + j;
+            int action = kNone;
+            if (line < bound)
+                action = mid_side ? kMidSide : kNone;
+            else if (intensity)
+                action = act[band[i]];
+            if (action == kMidSide) {  // process_mid_side (stereo.rs:139-148)
+                const float left = (a[i] + b[i]) * kFrac1Sqrt2, right = (a[i] - b[i]) * kFrac1Sqrt2;
+                a[i] = left;
+                b[i] = right;
+                touched = true;
+            } else if (action == kIntensity) {  // process_intensity (stereo.rs:174-180)
+                const float is = a[i];
+                a[i] = kl[band[i]] * is;
+                b[i] = kr[band[i]] * is;
+                touched = true;
+            }
+        }
+        if (touched) {
+            reinterpret_cast<float4 *>(ch0)[grp] = make_float4(a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]);
+            reinterpret_cast<float4 *>(ch1)[grp] = make_float4(b[4 * qq], b[4 * qq + 1], b[4 * qq + 2], b[4 * qq + 3]);
         }
     }
 }
@@ -152,7 +227,8 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
 }  // namespace
 
 int launch_mp3_stereo(symaccel_ctx *ctx, float *d_xr, size_t granules_per_chain, const int32_t *d_pair_chains,
-                      const symaccel_mp3_stereo *d_desc, int sr, size_t n_pairs) {
+                      const symaccel_mp3_stereo *d_desc, int sr, size_t n_pairs, const int16_t *d_quant,
+                      const symaccel_mp3_requant *d_rq_desc) {
     const size_t items = n_pairs * granules_per_chain, grid = (items + kWaves - 1) / kWaves;
     if (items > 0xffffffffu || granules_per_chain > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     const HostTables &t = host_tables();
@@ -164,8 +240,12 @@ int launch_mp3_stereo(symaccel_ctx *ctx, float *d_xr, size_t granules_per_chain,
     }
     e.mixed_len = (int16_t)t.mp3_sfb_mixed_len[sr];
     e.mixed_switch = (int16_t)t.mp3_sfb_switch[sr];
-    hipLaunchKernelGGL(mp3_stereo_kernel, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, d_xr,
-                       (unsigned)granules_per_chain, d_pair_chains, d_desc, sr, e, (unsigned)items);
+    if (d_quant)
+        hipLaunchKernelGGL(mp3_stereo_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, d_xr,
+                           (unsigned)granules_per_chain, d_pair_chains, d_desc, sr, e, (unsigned)items, d_quant, d_rq_desc);
+    else
+        hipLaunchKernelGGL(mp3_stereo_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, d_xr,
+                           (unsigned)granules_per_chain, d_pair_chains, d_desc, sr, e, (unsigned)items, d_quant, d_rq_desc);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -173,7 +173,8 @@ int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d
 int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
                    size_t n_filters);
 int launch_mp3_stereo(symaccel_ctx *ctx, float *d_xr, size_t granules_per_chain, const int32_t *d_pair_chains,
-                      const symaccel_mp3_stereo *d_desc, int sr, size_t n_pairs);
+                      const symaccel_mp3_stereo *d_desc, int sr, size_t n_pairs, const int16_t *d_quant = nullptr,
+                      const symaccel_mp3_requant *d_rq_desc = nullptr);
 int launch_mp3_requantize(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_desc, int sr,
                           float *d_xr, size_t n);
 int launch_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *d_in, const float *d_vvec_in,

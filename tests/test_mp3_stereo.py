@@ -225,6 +225,63 @@ def test_emu_requantize_stereo_synth_chain(emu_ctx):
     assert bit_equal(got, want)
 
 
+def fused_case(seed, sr, n_pairs, granules):
+    """Quantised samples + side info for 2 * n_pairs + 1 chains; the oracle's requantize -> stereo as the expectation."""
+    import test_mp3_requantize as rq
+    rng = np.random.default_rng(seed)
+    chains = 2 * n_pairs + 1
+    q, rd = rq.make_case(seed, chains * granules, big=True)
+    q, rd = q.reshape(chains, granules, 576), rd.reshape(chains, granules)
+    order = rng.permutation(chains)
+    pairs = np.array([[order[2 * p], order[2 * p + 1]] for p in range(n_pairs)], np.int32)
+    sd = np.zeros((n_pairs, granules), oracle.MP3_STEREO_DTYPE)
+    for p, (c0, c1) in enumerate(pairs):
+        rd["block_type"][c1], rd["is_mixed"][c1] = rd["block_type"][c0], rd["is_mixed"][c0]  # stereo.rs:502-504
+        cut = rng.integers(0, 577, granules)
+        for g in range(granules):
+            if rng.random() < 0.6:
+                q[c1, g, cut[g]:] = 0  # channel 1 ends early: intensity-coded top
+        sd["flags"][p] = rng.choice([0, 1, 2, 3, 3], granules) | rng.choice([0, 4], granules) | rng.choice([0, 8], granules)
+        sd["block_type"][p], sd["is_mixed"][p] = rd["block_type"][c1], rd["is_mixed"][c1]
+        sd["rzero0"][p], sd["rzero1"][p] = rd["rzero"][c0], rd["rzero"][c1]
+        sd["scalefacs1"][p] = rng.integers(0, 9, (granules, 39))
+    want = oracle.mp3_requantize(q, rd, sr).reshape(chains, granules, 576)
+    for p, (c0, c1) in enumerate(pairs):
+        for g in range(granules):
+            want[c0, g], want[c1, g] = oracle.mp3_stereo(want[c0, g], want[c1, g], sd[p, g], sr)
+    return q, rd, pairs, sd, want, int(order[-1])
+
+
+@pytest.mark.parametrize("sr,n_pairs,granules", [(0, 2, 6), (3, 1, 3), (8, 3, 4)])
+def test_emu_requantize_stereo_fused(emu_ctx, sr, n_pairs, granules):
+    from symphonia_amd import Mp3Stereo
+    q, rd, pairs, sd, want, mono = fused_case(50 + sr, sr, n_pairs, granules)
+    xr = np.full(want.shape, np.float32(123.0))
+    Mp3Stereo(emu_ctx, sr).requantize_stereo(q, rd, pairs, sd, xr)
+    paired = sorted(pairs.reshape(-1))
+    assert bit_equal(xr[paired], want[paired])
+    assert (xr[mono] == 123.0).all()  # chains outside every pair are not this call's business
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,n_pairs,granules", [(0, 9, 40), (8, 2, 17)])
+def test_gpu_requantize_stereo_fused(sr, n_pairs, granules):
+    import torch
+    from symphonia_amd import Context, Mp3Stereo
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    q, rd, pairs, sd, want, mono = fused_case(150 + sr, sr, n_pairs, granules)
+    with Context(0) as ctx:
+        xr = torch.full(want.shape, 123.0, device="cuda")
+        Mp3Stereo(ctx, sr).requantize_stereo(torch.from_numpy(q).cuda(), torch.from_numpy(rd.view(np.uint8).reshape(rd.shape + (52,))).cuda(),
+                                             torch.from_numpy(pairs).cuda(), torch.from_numpy(sd.view(np.uint8).reshape(sd.shape + (48,))).cuda(), xr)
+        ctx.sync()
+        got = xr.cpu().numpy()
+    paired = sorted(pairs.reshape(-1))
+    assert bit_equal(got[paired], want[paired])
+    assert (got[mono] == 123.0).all()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("sr,n_pairs,granules", [(0, 16, 64), (4, 5, 33), (8, 3, 20)])
 def test_gpu_mp3_stereo(sr, n_pairs, granules):

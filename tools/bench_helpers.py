@@ -79,6 +79,10 @@ def main():
     spairs = torch.arange(128, dtype=torch.int32, device="cuda").reshape(64, 2)
     t = timeit(lambda: st.stereo(xr2, spairs, sdesc))
     out["mp3 joint stereo (131072 granules, m/s + intensity)"] = 131072 * (4 * 2304 + 48) / t
+    quant2 = quant.reshape(128, 2048, 576)
+    quant2[1::2, :, 342:] = 0
+    t = timeit(lambda: st.requantize_stereo(quant2, desc.reshape(128, 2048, 52), spairs, sdesc, xr2))
+    out["mp3 requantize + stereo fused (131072 granules; %.3f ms)" % (t * 1e3)] = 131072 * (2 * (1152 + 2304 + 52) + 48) / t
     # AAC spectral tools at config-2 size: 64 pairs x 1024 frames, every band of every frame mid/side coded;
     # one order-12 TNS filter over lines 96..896 in every channel-frame
     swb_long = [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216,
