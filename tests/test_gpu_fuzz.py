@@ -1,0 +1,120 @@
+"""Randomised shape / segment sweep of the chain kernels on the MI355X against the oracle: chains x frames x segment
+length combinations no hand-picked test lists (odd counts, one-frame chains, segments longer than the chain, a last
+workgroup that is only partly populated ...).  SYM_FUZZ_ITERS scales the number of random cases (default 6 per codec)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import bit_equal
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ITERS = int(os.environ.get("SYM_FUZZ_ITERS", "6"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from symphonia_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def shape(rng):
+    nch = int(rng.choice([1, 2, 3, 5, 8, 13, 31]))
+    n = int(rng.choice([1, 2, 3, 4, 7, 16, 33, 64, 97]))
+    seg = int(rng.choice([0, 1, 2, 3, 5, 8, 31, 64, 1000]))
+    return nch, n, seg
+
+
+@pytest.mark.parametrize("it", range(ITERS))
+def test_fuzz_aac(ctx, it):
+    from symphonia_amd import AacDsp
+    from test_gpu_parity import aac_case
+    rng = np.random.default_rng(1000 + it)
+    nch, nfr, seg = shape(rng)
+    coeffs, side, delay = aac_case(2000 + it, nch, nfr, only_long=bool(it % 3 == 0))
+    ctx.set_segment(seg)
+    d_delay = dev(delay)
+    pcm = host(AacDsp(ctx).synth(dev(coeffs), dev(side), d_delay))
+    ctx.set_segment(0)
+    wp, wd = oracle.aac_synth(coeffs, side, delay)
+    assert bit_equal(pcm, wp) and bit_equal(host(d_delay), wd), (nch, nfr, seg)
+
+
+@pytest.mark.parametrize("it", range(ITERS))
+def test_fuzz_mp3(ctx, it):
+    from symphonia_amd import Mp3Synthesis, mp3_side
+    from test_gpu_parity import mp3_case
+    rng = np.random.default_rng(3000 + it)
+    nch, ngr, seg = shape(rng)
+    sr = int(rng.integers(0, 9))
+    xr, bt, mx, rz, ov, vv, vf = mp3_case(4000 + it, nch, ngr)
+    side = mp3_side(bt, mx, rz)
+    d_ov, d_vv, d_vf = dev(ov), dev(vv), dev(vf)
+    ctx.set_segment(seg)
+    pcm = host(Mp3Synthesis(ctx, sr).synth(dev(xr), dev(side.view(np.uint8).reshape(nch, ngr, 4)), d_ov, d_vv, d_vf))
+    ctx.set_segment(0)
+    want = oracle.mp3_synth(xr, oracle.mp3_side(bt, mx, rz), sr, ov, vv, vf)
+    assert bit_equal(pcm, want[0]) and bit_equal(host(d_ov), want[1]) and bit_equal(host(d_vv), want[2]), (nch, ngr, seg, sr)
+    assert np.array_equal(host(d_vf), want[3])
+
+
+@pytest.mark.parametrize("it", range(ITERS))
+def test_fuzz_vorbis(ctx, it):
+    from symphonia_amd import VorbisDsp
+    from test_emu_codecs import vorbis_case, vorbis_wave_case
+    rng = np.random.default_rng(5000 + it)
+    nch, nb, seg = shape(rng)
+    if it % 2 == 0:  # the 256 / 2048 wavefront kernel
+        bs0e, bs1e = 8, 11
+        flags, prev, spectra, overlap, pcm_stride = vorbis_wave_case(6000 + it, nch, nb, float(rng.choice([0.0, 0.3, 0.75, 1.0])),
+                                                                    int(rng.integers(0, nb)))
+    else:
+        bs0e = int(rng.integers(6, 11))
+        bs1e = int(rng.integers(bs0e, 13))
+        flags, prev, spectra, overlap, pcm_stride = vorbis_case(rng, bs0e, bs1e, nch, nb)
+    d_prev, d_ov = dev(prev), dev(overlap)
+    ctx.set_segment(seg)
+    pcm = host(VorbisDsp(ctx, bs0e, bs1e).synth(dev(spectra), dev(flags), d_prev, d_ov, pcm_stride))
+    ctx.set_segment(0)
+    want = oracle.vorbis_synth(bs0e, bs1e, spectra, flags, prev, overlap, pcm_stride)
+    assert bit_equal(pcm, want[0]) and bit_equal(host(d_ov), want[1]), (bs0e, bs1e, nch, nb, seg)
+    assert np.array_equal(host(d_prev), want[2])
+
+
+@pytest.mark.parametrize("it", range(ITERS))
+def test_fuzz_flac_alac(ctx, it):
+    from symphonia_amd import AlacPredictor, FlacPredictor, alac_desc, flac_desc
+    rng = np.random.default_rng(7000 + it)
+    nb = int(rng.choice([1, 2, 63, 64, 65, 130, 257]))
+    bs = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 576, 1152, 4096, 4608]))
+    kind = rng.integers(0, 3, nb).astype(np.uint8)
+    order = np.where(kind == 1, rng.integers(0, 5, nb), rng.integers(1, 33, nb))
+    order = np.minimum(order, bs).astype(np.uint8)
+    kind[(kind == 2) & (order == 0)] = 0
+    shift = rng.integers(0, 16, nb).astype(np.uint8)
+    wasted = np.where(rng.random(nb) < 0.2, rng.integers(1, 8, nb), 0).astype(np.uint8)
+    buf = rng.integers(-(1 << 23), 1 << 23, (nb, bs)).astype(np.int32)
+    coeffs = rng.integers(-(1 << 14), 1 << 14, (nb, 32)).astype(np.int32)
+    d_buf = dev(buf)
+    FlacPredictor(ctx).restore(d_buf, dev(flac_desc(kind, order, shift, wasted).view(np.uint8).reshape(nb, 4)), dev(coeffs))
+    assert bit_equal(host(d_buf), oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, wasted), coeffs)), (nb, bs)
+    from test_alac import alac_case
+    res, mode, aorder, ashift, bps, acoef = alac_case(8000 + it, nb, bs)
+    d_res = dev(res)
+    AlacPredictor(ctx).predict(d_res, dev(alac_desc(mode, aorder, ashift, bps).view(np.uint8).reshape(nb, 4)), dev(acoef))
+    assert bit_equal(host(d_res), oracle.alac_predict(res, oracle.alac_desc(mode, aorder, ashift, bps), acoef)), (nb, bs)
