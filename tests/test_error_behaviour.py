@@ -53,6 +53,30 @@ def test_codec_entry_points_reject_bad_arguments(emu_ctx):
     assert call(emu_ctx, "symaccel_ctx_set_segment", -1) == _ffi.ERR_INVALID_ARG
 
 
+def test_front_stage_entry_points_reject_bad_arguments(emu_ctx):
+    """The rank-1 stages: requantize / stereo (MP3), joint stereo / TNS (AAC)."""
+    f, i8, i16, i32 = buf(4096), buf(4096, np.uint8), buf(4096, np.int16), buf(64, np.int32)
+    p = lambda a: a.ctypes.data  # noqa: E731
+    for sr in (-1, 9):
+        assert call(emu_ctx, "symaccel_mp3_requantize_device", p(i16), p(i8), sr, p(f), 1) == _ffi.ERR_INVALID_ARG
+        assert call(emu_ctx, "symaccel_mp3_stereo_device", p(f), 1, p(i32), p(i8), sr, 1) == _ffi.ERR_INVALID_ARG
+        assert call(emu_ctx, "symaccel_mp3_requantize_stereo_device", p(i16), p(i8), 1, p(i32), p(i8), sr, p(f), 1) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_mp3_requantize_device", None, p(i8), 0, p(f), 1) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_mp3_requantize_device", None, None, 0, None, 0) == _ffi.OK
+    assert call(emu_ctx, "symaccel_mp3_requantize", p(i16), None, 0, p(f), 1) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_mp3_stereo_device", None, 1, p(i32), p(i8), 0, 1) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_mp3_stereo_device", None, 1, None, None, 0, 0) == _ffi.OK
+    assert call(emu_ctx, "symaccel_mp3_requantize_stereo_device", p(i16), p(i8), 1, p(i32), p(i8), 0, None, 1) == _ffi.ERR_INVALID_ARG
+    swb_l, swb_s = np.array([0, 4, 1024], np.uint16), np.array([0, 4, 128], np.uint16)
+    assert call(emu_ctx, "symaccel_aac_joint_stereo_device", p(f), 1, p(i32), p(i8), 1, None, 2, p(swb_s), 2) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_aac_joint_stereo_device", p(f), 1, p(i32), p(i8), 1, p(swb_l), 2, p(swb_s), 17) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_aac_joint_stereo_device", None, 1, p(i32), p(i8), 1, p(swb_l), 2, p(swb_s), 2) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_aac_joint_stereo_device", None, 1, None, None, 0, p(swb_l), 2, p(swb_s), 2) == _ffi.OK
+    assert call(emu_ctx, "symaccel_aac_tns_device", None, 4, p(i8), 1) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_aac_tns_device", p(f), 4, None, 1) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_aac_tns_device", None, 4, None, 0) == _ffi.OK
+
+
 def test_null_context_and_error_strings():
     lib = emu_library()
     assert lib.dll.symaccel_sync(None) == _ffi.ERR_INVALID_ARG
