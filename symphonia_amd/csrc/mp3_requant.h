@@ -38,12 +38,122 @@ __device__ __forceinline__ int mp3_requant_kind(const symaccel_mp3_requant &d) {
     return d.block_type == SYMACCEL_MP3_SHORT ? (d.is_mixed ? 2 : 1) : 0;
 }
 
-// (1.0 - 2.0 * sign_bit) * POW43[|s|] is +-POW43[|s|] exactly; zeros and the rzero partition are +0.0
-__device__ __forceinline__ float mp3_sample_value(const DevTables &tb, const float *pow43_lo, int s, bool in_rzero) {
+// (1.0 - 2.0 * sign_bit) * POW43[|s|] is +-POW43[|s|] exactly; zeros and the rzero partition are +0.0.
+// pow43_lo: the first `lds_n` table entries in LDS.
+__device__ __forceinline__ float mp3_sample_value(const DevTables &tb, const float *pow43_lo, int s, bool in_rzero,
+                                                  int lds_n = kMp3PowLds) {
     int mag = s < 0 ? -s : s;
     mag = mag > 8206 ? 8206 : mag;
-    const float p = mag < kMp3PowLds ? pow43_lo[mag] : tb.mp3_pow43[mag];
+    const float p = mag < lds_n ? pow43_lo[mag] : tb.mp3_pow43[mag];
     return (in_rzero || s == 0) ? 0.0f : (s < 0 ? -p : p);
+}
+
+// ---- joint stereo (layer3/stereo.rs): shared by mp3_stereo.hip and the fused front of mp3.hip -------------------
+
+struct SfbEdges {  // band edge tables of one sample rate (layer3/common.rs:9-172), passed to kernels by value
+    int16_t longb[23], shortb[40], mixed[40];
+    int16_t mixed_len, mixed_switch;
+};
+inline SfbEdges make_sfb_edges(const HostTables &t, int sr) {
+    SfbEdges e;
+    for (int i = 0; i < 23; ++i) e.longb[i] = (int16_t)t.mp3_sfb_long[sr][i];
+    for (int i = 0; i < 40; ++i) {
+        e.shortb[i] = (int16_t)t.mp3_sfb_short[sr][i];
+        e.mixed[i] = (int16_t)t.mp3_sfb_mixed[sr][i];
+    }
+    e.mixed_len = (int16_t)t.mp3_sfb_mixed_len[sr];
+    e.mixed_switch = (int16_t)t.mp3_sfb_switch[sr];
+    return e;
+}
+
+constexpr int kMp3StNone = 0, kMp3StMidSide = 1, kMp3StIntensity = 2;
+constexpr float kMp3Frac1Sqrt2 = 0.70710678118654752440f;  // f32::consts::FRAC_1_SQRT_2 (stereo.rs:143-144)
+
+// The intensity-stereo band walk of process_intensity_long_block (stereo.rs:196-260) and
+// process_intensity_short_block (:264-483) on per-band "channel 1 is non-zero" flags nz[0..39]: every lane of the
+// wavefront runs it identically; the lane with writer == true records one action per band it visits in act[] (bands
+// it does not visit keep what the caller initialised, kMp3StNone) and the (left, right) ratios of intensity bands in
+// kl[] / kr[].  Returns the intensity bound (mid/side applies below it).  Band k of the block's edge table uses
+// is_pos[k]: for short / mixed blocks is_pos[..36] = scalefacs[..36], is_pos[36..39] = scalefacs[33..36] (:369-371),
+// for long blocks is_pos[21] = is_pos[20] (:226-228).
+__device__ __forceinline__ int mp3_stereo_walk(const DevTables &tb, const symaccel_mp3_stereo &d, const SfbEdges &e, const int *nz,
+                                               int *act, float *kl, float *kr, bool writer, int end, int rzero1) {
+    const bool mid_side = d.flags & SYMACCEL_MP3_ST_MID_SIDE;
+    const bool is_short = d.block_type == SYMACCEL_MP3_SHORT, is_mixed = is_short && d.is_mixed;
+    const int table = (d.flags & SYMACCEL_MP3_ST_MPEG1) ? 0 : 7 + 32 * ((d.flags & SYMACCEL_MP3_ST_IS_SCALE) ? 1 : 0);
+    const int inv_pos = (d.flags & SYMACCEL_MP3_ST_MPEG1) ? 7 : 31;  // INTENSITY_INV_POS_* (stereo.rs:19-29)
+    int bound = end;
+    auto zero_band = [&](int k, int is_pos) {  // process_intensity (stereo.rs:165-186) as an action for band k
+        if (!writer) return;
+        if (is_pos < inv_pos) {
+            act[k] = kMp3StIntensity;
+            kl[k] = tb.mp3_is_ratios[2 * (table + is_pos)];
+            kr[k] = tb.mp3_is_ratios[2 * (table + is_pos) + 1];
+        } else {
+            act[k] = mid_side ? kMp3StMidSide : kMp3StNone;
+        }
+    };
+    if (!is_short) {
+        for (int i = 21; i >= 0; --i) {
+            const int start = e.longb[i];
+            if (!(start >= rzero1 || nz[i] == 0)) break;
+            zero_band(i, d.scalefacs1[i < 21 ? i : 20]);
+            bound = start;
+        }
+    } else {
+        const int16_t *bands = is_mixed ? e.mixed : e.shortb;
+        const int n_edges = is_mixed ? e.mixed_len : 40, sw = is_mixed ? e.mixed_switch : 0;
+        const int n_groups = (n_edges - sw - 3 + 2) / 3;  // groups of three windows (stereo.rs:379-386)
+        bool wz0 = true, wz1 = true, wz2 = true, found_bound = false;
+        for (int gi = n_groups - 1; gi >= 0; --gi) {
+            const int k0 = sw + 3 * gi;  // bands k0, k0 + 1, k0 + 2 = windows 0, 1, 2
+#pragma unroll
+            for (int w = 2; w >= 0; --w) {
+                const int k = k0 + w;
+                bool &wz = w == 2 ? wz2 : (w == 1 ? wz1 : wz0);
+                wz = wz && nz[k] == 0;
+                if (wz)
+                    zero_band(k, d.scalefacs1[k < 36 ? k : k - 3]);
+                else if (mid_side && writer)
+                    act[k] = kMp3StMidSide;
+            }
+            bound = bands[k0];
+            found_bound = !wz0 && !wz1 && !wz2;
+            if (found_bound) break;
+        }
+        if (!found_bound && is_mixed) {  // the long bands of a mixed block, stereo.rs:450-478
+            for (int i = sw - 1; i >= 0; --i) {
+                if (nz[i] != 0) break;
+                zero_band(i, d.scalefacs1[i]);
+                bound = bands[i];
+            }
+        }
+    }
+    return bound;
+}
+
+// One line of the pair: mid/side below the intensity bound (stereo.rs:541-543), the band's action from it on.
+// Returns true when (a, b) changed.
+__device__ __forceinline__ bool mp3_stereo_apply(float &a, float &b, int line, int bound, bool mid_side, bool intensity, int band,
+                                                 const int *act, const float *kl, const float *kr) {
+    int action = kMp3StNone;
+    if (line < bound)
+        action = mid_side ? kMp3StMidSide : kMp3StNone;
+    else if (intensity)
+        action = act[band];
+    if (action == kMp3StMidSide) {  // process_mid_side (stereo.rs:139-148)
+        const float left = (a + b) * kMp3Frac1Sqrt2, right = (a - b) * kMp3Frac1Sqrt2;
+        a = left;
+        b = right;
+        return true;
+    }
+    if (action == kMp3StIntensity) {  // process_intensity (stereo.rs:174-180)
+        const float is = a;
+        a = kl[band] * is;
+        b = kr[band] * is;
+        return true;
+    }
+    return false;
 }
 
 }  // namespace symaccel

@@ -20,18 +20,12 @@ namespace symaccel {
 
 namespace {
 
-struct SfbEdges {  // band edge tables of one sample rate (layer3/common.rs:9-172), by value
-    int16_t longb[23], shortb[40], mixed[40];
-    int16_t mixed_len, mixed_switch;
-};
-
 __device__ __forceinline__ void wave_sync() {  // order this wavefront's own LDS traffic (no workgroup barrier needed)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kNone = 0, kMidSide = 1, kIntensity = 2;
 constexpr int kWaves = 4;
 
 template <bool FUSED>
@@ -128,7 +122,7 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
     if (intensity) {
         if (lane < 40) {
             nz[lane] = 0;
-            act[lane] = kNone;
+            act[lane] = kMp3StNone;
         }
         wave_sync();
 #pragma unroll
@@ -136,62 +130,11 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
             if (have[i / 4] && b[i] != 0.0f) nz[band[i]] = 1;  // is_zero_band (stereo.rs:189-192), one flag per band
         wave_sync();
         // ---- the band walk (identical in every lane; lane 0 records the decisions)
-        const int table = (d.flags & SYMACCEL_MP3_ST_MPEG1) ? 0 : 7 + 32 * ((d.flags & SYMACCEL_MP3_ST_IS_SCALE) ? 1 : 0);
-        const int inv_pos = (d.flags & SYMACCEL_MP3_ST_MPEG1) ? 7 : 31;  // INTENSITY_INV_POS_* (stereo.rs:19-29)
-        auto zero_band = [&](int k, int is_pos) {  // process_intensity (stereo.rs:165-186) as an action for band k
-            if (lane != 0) return;
-            if (is_pos < inv_pos) {
-                act[k] = kIntensity;
-                kl[k] = tb.mp3_is_ratios[2 * (table + is_pos)];
-                kr[k] = tb.mp3_is_ratios[2 * (table + is_pos) + 1];
-            } else {
-                act[k] = mid_side ? kMidSide : kNone;
-            }
-        };
-        if (!is_short) {
-            // process_intensity_long_block (stereo.rs:196-260); is_pos[21] = is_pos[20] (:226-228)
-            for (int i = 21; i >= 0; --i) {
-                const int start = e.longb[i];
-                if (!(start >= rzero1 || nz[i] == 0)) break;
-                zero_band(i, d.scalefacs1[i < 21 ? i : 20]);
-                bound = start;
-            }
-        } else {
-            // process_intensity_short_block (stereo.rs:264-483).  Band k of the edge table uses is_pos[k], where
-            // is_pos[..36] = scalefacs[..36] and is_pos[36..39] = scalefacs[33..36] (:369-371).
-            const int16_t *bands = is_mixed ? e.mixed : e.shortb;
-            const int n_edges = is_mixed ? e.mixed_len : 40, sw = is_mixed ? e.mixed_switch : 0;
-            const int n_groups = (n_edges - sw - 3 + 2) / 3;  // groups of three windows (stereo.rs:379-386)
-            bool wz0 = true, wz1 = true, wz2 = true, found_bound = false;
-            for (int gi = n_groups - 1; gi >= 0; --gi) {
-                const int k0 = sw + 3 * gi;  // bands k0, k0 + 1, k0 + 2 = windows 0, 1, 2
-#pragma unroll
-                for (int w = 2; w >= 0; --w) {
-                    const int k = k0 + w;
-                    bool &wz = w == 2 ? wz2 : (w == 1 ? wz1 : wz0);
-                    wz = wz && nz[k] == 0;
-                    if (wz)
-                        zero_band(k, d.scalefacs1[k < 36 ? k : k - 3]);
-                    else if (mid_side && lane == 0)
-                        act[k] = kMidSide;
-                }
-                bound = bands[k0];
-                found_bound = !wz0 && !wz1 && !wz2;
-                if (found_bound) break;
-            }
-            if (!found_bound && is_mixed) {  // the long bands of a mixed block, stereo.rs:450-478
-                for (int i = sw - 1; i >= 0; --i) {
-                    if (nz[i] != 0) break;
-                    zero_band(i, d.scalefacs1[i]);
-                    bound = bands[i];
-                }
-            }
-        }
+        bound = mp3_stereo_walk(tb, d, e, nz, act, kl, kr, lane == 0, end, rzero1);
         wave_sync();
     }
 
-    // ---- apply: mid/side below the intensity bound (stereo.rs:541-543), the band's action from it on
-    constexpr float kFrac1Sqrt2 = 0.70710678118654752440f;  // f32::consts::FRAC_1_SQRT_2
+    // ---- apply
 #pragma unroll
     for (int qq = 0; qq < kQ; ++qq) {
         if (!have[qq]) continue;
@@ -199,23 +142,8 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
         bool touched = FUSED;  // fused: xr is this kernel's output, untouched lines are stored too
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = 4 * qq + j, line = 4 * grp + j;
-            int action = kNone;
-            if (line < bound)
-                action = mid_side ? kMidSide : kNone;
-            else if (intensity)
-                action = act[band[i]];
-            if (action == kMidSide) {  // process_mid_side (stereo.rs:139-148)
-                const float left = (a[i] + b[i]) * kFrac1Sqrt2, right = (a[i] - b[i]) * kFrac1Sqrt2;
-                a[i] = left;
-                b[i] = right;
-                touched = true;
-            } else if (action == kIntensity) {  // process_intensity (stereo.rs:174-180)
-                const float is = a[i];
-                a[i] = kl[band[i]] * is;
-                b[i] = kr[band[i]] * is;
-                touched = true;
-            }
+            const int i = 4 * qq + j;
+            touched |= mp3_stereo_apply(a[i], b[i], 4 * grp + j, bound, mid_side, intensity, band[i], act, kl, kr);
         }
         if (touched) {
             reinterpret_cast<float4 *>(ch0)[grp] = make_float4(a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]);
@@ -231,15 +159,7 @@ int launch_mp3_stereo(symaccel_ctx *ctx, float *d_xr, size_t granules_per_chain,
                       const symaccel_mp3_requant *d_rq_desc) {
     const size_t items = n_pairs * granules_per_chain, grid = (items + kWaves - 1) / kWaves;
     if (items > 0xffffffffu || granules_per_chain > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    const HostTables &t = host_tables();
-    SfbEdges e;
-    for (int i = 0; i < 23; ++i) e.longb[i] = (int16_t)t.mp3_sfb_long[sr][i];
-    for (int i = 0; i < 40; ++i) {
-        e.shortb[i] = (int16_t)t.mp3_sfb_short[sr][i];
-        e.mixed[i] = (int16_t)t.mp3_sfb_mixed[sr][i];
-    }
-    e.mixed_len = (int16_t)t.mp3_sfb_mixed_len[sr];
-    e.mixed_switch = (int16_t)t.mp3_sfb_switch[sr];
+    const SfbEdges e = make_sfb_edges(host_tables(), sr);
     if (d_quant)
         hipLaunchKernelGGL(mp3_stereo_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, d_xr,
                            (unsigned)granules_per_chain, d_pair_chains, d_desc, sr, e, (unsigned)items, d_quant, d_rq_desc);
