@@ -233,19 +233,6 @@ int symaccel_mp3_requantize_stereo_device(symaccel_ctx *ctx, const int16_t *d_qu
                                           const symaccel_mp3_stereo *d_desc, int sample_rate_idx, float *d_xr,
                                           size_t n_pairs);
 
-/* The whole DSP tail of Layer3::decode for stereo streams in ONE kernel (layer3/mod.rs:393-476): requantisation of both
- * channels, stereo, then reorder / antialias / hybrid synthesis / frequency inversion / polyphase synthesis --
- * symaccel_mp3_requantize_stereo_device followed by symaccel_mp3_synth_device, with the f32 spectra never written to
- * HBM (a wavefront of the synthesis kernel carries the two channels of a pair; both get rzero = max(rzero0, rzero1)
- * when the granule is joint-stereo coded, stereo.rs:549-553).  quant / rq_desc / pcm are indexed [chain][granule],
- * st_desc [pair][granule]; the state arrays cover n_chains chains, of which only those named in pair_chains are read
- * and advanced.  Mono chains: symaccel_mp3_requantize_device + symaccel_mp3_synth_device. */
-int symaccel_mp3_decode_tail_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc,
-                                    size_t granules_per_chain, const int32_t *d_pair_chains,
-                                    const symaccel_mp3_stereo *d_st_desc, int sample_rate_idx, float *d_overlap_io,
-                                    float *d_vvec_io, int32_t *d_vfront_io, float *d_pcm, size_t n_pairs,
-                                    size_t n_chains);
-
 /* synthesis::synthesis alone (synthesis.rs:158-336) as Layer I and Layer II use it: n_frames = 12
  * (layer1/mod.rs:193) or 36 (layer2/mod.rs:383) time slots per packet and channel.  in[chain][packet][32 * n_frames]
  * sub-band-major (in[n_frames * i + b], synthesis.rs:168-170); pcm[chain][packet][32 * n_frames]; state per chain:

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "symaccel_ctx_destroy", "symaccel_ctx_set_stream", "symaccel_sync", "symaccel_ctx_set_segment",
     "symaccel_fft_c32_device", "symaccel_fft_c32", "symaccel_imdct_f32_device", "symaccel_imdct_f32",
     "symaccel_aac_synth_device", "symaccel_aac_synth", "symaccel_aac_joint_stereo_device", "symaccel_aac_tns_device", "symaccel_mp3_synth_device", "symaccel_mp3_synth", "symaccel_mpa_polyphase_device", "symaccel_mpa_polyphase",
-    "symaccel_mp3_requantize_device", "symaccel_mp3_requantize", "symaccel_mp3_stereo_device", "symaccel_mp3_requantize_stereo_device", "symaccel_mp3_decode_tail_device",
+    "symaccel_mp3_requantize_device", "symaccel_mp3_requantize", "symaccel_mp3_stereo_device", "symaccel_mp3_requantize_stereo_device",
     "symaccel_vorbis_synth_device", "symaccel_vorbis_synth_fr_device", "symaccel_vorbis_synth", "symaccel_vorbis_inverse_coupling_device",
     "symaccel_vorbis_dot_product_device", "symaccel_vorbis_deinterleave2_device",
     "symaccel_vorbis_floor1_device", "symaccel_flac_restore_device", "symaccel_flac_restore", "symaccel_flac_restore_stereo_device",
@@ -80,7 +80,6 @@ class Library:
         d.symaccel_aac_tns_device.argtypes = [_vp, _vp, _sz, _vp, _sz]
         d.symaccel_mp3_stereo_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _i, _sz]
         d.symaccel_mp3_requantize_stereo_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp, _sz]
-        d.symaccel_mp3_decode_tail_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_mp3_requantize_device.argtypes = [_vp, _vp, _vp, _i, _vp, _sz]
         d.symaccel_mp3_requantize.argtypes = [_vp, _vp, _vp, _i, _vp, _sz]
         d.symaccel_vorbis_synth_device.argtypes = [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]

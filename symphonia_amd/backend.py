@@ -332,15 +332,6 @@ class Mp3Stereo:
                        self.sr, int(pair_chains.shape[0]))
         return xr
 
-    def decode_tail(self, quant, rq_desc, pair_chains, desc, overlap, v_vec, v_front, pcm):
-        """requantize + stereo + the synthesis tail for the paired chains in one kernel (device-pointer entry point):
-        quant[chains, granules, 576] i16, rq_desc[chains, granules], desc[pairs, granules]; state arrays of all `chains`
-        chains (only the paired ones advance), pcm[chains, granules, 576]."""
-        self.ctx._call(self.ctx.lib.dll.symaccel_mp3_decode_tail_device, _ptr(quant), _ptr(rq_desc), int(quant.shape[1]),
-                       _ptr(pair_chains), _ptr(desc), self.sr, _ptr(overlap), _ptr(v_vec), _ptr(v_front), _ptr(pcm),
-                       int(pair_chains.shape[0]), int(quant.shape[0]))
-        return pcm
-
     def requantize_stereo(self, quant, rq_desc, pair_chains, desc, xr):
         """Mp3Requantize.requantize + stereo for the paired chains in one pass: quant[chains, granules, 576] i16,
         rq_desc[chains, granules] MP3_REQUANT_DTYPE, xr[chains, granules, 576] f32 (only the paired chains are written)."""

@@ -410,30 +410,6 @@ int symaccel_mp3_synth_device(symaccel_ctx *ctx, const float *d_xr, const symacc
     return SYMACCEL_OK;
 }
 
-int symaccel_mp3_decode_tail_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc,
-                                    size_t granules_per_chain, const int32_t *d_pair_chains, const symaccel_mp3_stereo *d_st_desc,
-                                    int sample_rate_idx, float *d_overlap_io, float *d_vvec_io, int32_t *d_vfront_io, float *d_pcm,
-                                    size_t n_pairs, size_t n_chains) {
-    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8 || n_chains < 2 * n_pairs) return SYMACCEL_ERR_INVALID_ARG;
-    if (n_pairs == 0 || granules_per_chain == 0) return SYMACCEL_OK;
-    if (!d_quant || !d_rq_desc || !d_pair_chains || !d_st_desc || !d_overlap_io || !d_vvec_io || !d_vfront_io || !d_pcm)
-        return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
-    const size_t ov_bytes = n_chains * 576 * 4, vv_bytes = n_chains * 1024 * 4, vf_bytes = n_chains * 4;
-    void *scratch = nullptr;
-    SYM_TRY(ctx_scratch(ctx, ov_bytes + vv_bytes + vf_bytes, &scratch));
-    float *ov_out = (float *)scratch;
-    float *vv_out = ov_out + n_chains * 576;
-    int32_t *vf_out = (int32_t *)(vv_out + n_chains * 1024);
-    // the kernel writes the outgoing state of the paired chains only: start the scratch copy from the incoming state,
-    // so that chains outside every pair come back unchanged
-    SYM_TRY(launch_state_copy(ctx, ov_out, d_overlap_io, ov_bytes, vv_out, d_vvec_io, vv_bytes, vf_out, d_vfront_io, vf_bytes));
-    SYM_TRY(launch_mp3_front(ctx, d_quant, d_rq_desc, d_st_desc, d_pair_chains, sample_rate_idx, d_overlap_io, d_vvec_io, d_vfront_io,
-                             ov_out, vv_out, vf_out, d_pcm, n_pairs, granules_per_chain));
-    SYM_TRY(launch_state_copy(ctx, d_overlap_io, ov_out, ov_bytes, d_vvec_io, vv_out, vv_bytes, d_vfront_io, vf_out, vf_bytes));
-    return SYMACCEL_OK;
-}
-
 int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_side *h_side, int sample_rate_idx,
                        float *h_overlap_io, float *h_vvec_io, int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
                        size_t granules_per_chain) {

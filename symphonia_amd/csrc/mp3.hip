@@ -21,7 +21,6 @@
 // measured and is not faster.  LDS per wavefront: 5 KiB (granule tiles, then the dct32 transpose) + window rows 2.5 KiB.
 // Roofline: HBM-bound on paper, 2304 B in + 2304 B out per granule-channel, ~34 kflop (no FMA) -> 7.4 flop/B.
 #include "mp3_common.h"
-#include "mp3_requant.h"
 
 namespace symaccel {
 
@@ -129,58 +128,24 @@ __device__ __forceinline__ void fetch_granule(const float *granule, int hl, floa
     line[4] = src[128 + (hl & 15)];  // lanes 16..31 re-read float4 128..143 (same cache lines) and ignore it
 }
 
-// ---- the fused front (FRONT = true): requantisation (layer3/requantize.rs) and joint stereo (layer3/stereo.rs) run inside
-// the synthesis kernel.  The wavefront's two halves are the two channels of one stream; the granule arrives as int16
-// quantised samples (1152 B per channel instead of 2304 B of f32) plus the 52-byte requantize record per channel and the
-// 48-byte stereo record per pair, all prefetched one granule ahead; the requantised lines go straight into the LDS tiles
-// the hybrid stage gathers from, joint stereo is applied on those tiles by all 64 lanes, and the f32 spectra never exist
-// in HBM.  (mp3_requant.h holds the arithmetic shared with the stand-alone kernels of mp3_requant.hip / mp3_stereo.hip.)
-struct Mp3Front {
-    const int16_t *quant;                // [chain][granule][576]
-    const symaccel_mp3_requant *rq;      // [chain][granule]
-    const symaccel_mp3_stereo *st;       // [pair][granule]
-    const int32_t *pair_chains;          // [pair][2]
-    SfbEdges e;
-};
-constexpr int kFrontPow = 256;  // POW43 entries kept in LDS per wavefront
-// LDS words: requantize records (2 x 13) | stereo record (12) | slot scales (2 x 40) | nz, act, kl, kr (4 x 40) | POW43 head
-constexpr int kFrontRq = 0, kFrontSt = 26, kFrontScale = 38, kFrontNz = 118, kFrontAct = 158, kFrontKl = 198, kFrontKr = 238,
-              kFrontPowBase = 278, kFrontFloats = kFrontPowBase + kFrontPow;
-
-__device__ __forceinline__ void fetch_front(const Mp3Front &fr, size_t gc, size_t pair_granule, int half, int hl, int4 (&qline)[3],
-                                            uint32_t &dw) {
-    const int4 *src = reinterpret_cast<const int4 *>(fr.quant + gc * 576);  // 72 x 16 B
-    qline[0] = src[hl];
-    qline[1] = src[32 + hl];
-    qline[2] = src[64 + (hl & 7)];  // lanes 8..31 re-read groups 64..71 and ignore them
-    if (hl < 13)
-        dw = reinterpret_cast<const uint32_t *>(fr.rq + gc)[hl];
-    else if (half == 0 && hl < 25)
-        dw = reinterpret_cast<const uint32_t *>(fr.st + pair_granule)[hl - 13];
-}
-
 #ifndef SYM_MP3_WAVES
 #define SYM_MP3_WAVES 3  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
 #endif
-template <bool FRONT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVES, SYM_MP3_WAVES))) void mp3_synth_kernel(
     DevTables tb, const float *__restrict__ xr, const symaccel_mp3_side *__restrict__ side, int sr,
     const float *__restrict__ overlap_in, const float *__restrict__ vvec_in, const int32_t *__restrict__ vfront_in,
     float *__restrict__ overlap_out, float *__restrict__ vvec_out, int32_t *__restrict__ vfront_out,
     float *__restrict__ pcm, unsigned n_chains, unsigned granules_per_chain, unsigned seg_len,
-    unsigned segs_per_chain, Mp3Front fr) {
+    unsigned segs_per_chain) {
     __shared__ __attribute__((aligned(16))) float lds[kWaveFloats];
-    __shared__ __attribute__((aligned(16))) float front_lds[FRONT ? kFrontFloats : 4];
     const int half = (int)threadIdx.x >> 5, hl = (int)threadIdx.x & 31;
     float *tile = lds + half * 576;               // the granule's 576 lines, natural order
     float *S = lds + kSBase + half * (18 * kSStride);  // S[slot][32]: dct32 transpose
     cf32p mc = as_const(tb.mp3_consts);
 
-    // FRONT: one wavefront per (channel pair, segment), n_chains counts pairs and the halves take the pair's two chains
-    const unsigned item = FRONT ? blockIdx.x : blockIdx.x * 2u + (unsigned)half;
+    const unsigned item = blockIdx.x * 2u + (unsigned)half;
     const bool live = item < n_chains * segs_per_chain;
-    const unsigned unit = live ? item / segs_per_chain : 0, seg = live ? item % segs_per_chain : 0;  // chain, or pair
-    const unsigned chain = FRONT ? (live ? (unsigned)fr.pair_chains[2 * unit + half] : 0u) : unit;
+    const unsigned chain = live ? item / segs_per_chain : 0, seg = live ? item % segs_per_chain : 0;
     const unsigned g_begin = seg * seg_len;
     const unsigned g_end = live ? min(g_begin + seg_len, granules_per_chain) : g_begin;
     const size_t chain_base = (size_t)chain * granules_per_chain;
@@ -198,12 +163,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
     float *imdct_win = lds + kWinBase;  // the four 36-entry IMDCT windows (hybrid_synthesis.rs:31-101)
     for (int i = (int)threadIdx.x; i < 4 * 36; i += 64) imdct_win[i] = tb.mp3_consts[MP3C_IMDCT_WIN + i];
     const VMap vm = vmap(hl);
-    uint32_t *rqw = reinterpret_cast<uint32_t *>(front_lds) + kFrontRq + 13 * half, *stw = reinterpret_cast<uint32_t *>(front_lds) + kFrontSt;
-    float *slot_scale = front_lds + kFrontScale + kMp3Slots * half, *pow_lo = front_lds + kFrontPowBase;
-    int *nz = reinterpret_cast<int *>(front_lds) + kFrontNz, *act = reinterpret_cast<int *>(front_lds) + kFrontAct;
-    float *kl = front_lds + kFrontKl, *kr = front_lds + kFrontKr;
-    if (FRONT)
-        for (int i = (int)threadIdx.x; i < kFrontPow; i += 64) pow_lo[i] = tb.mp3_pow43[i];
 
     // ---- incoming state.  oA[16 + r] = V_r[i], oB[16 + r] = V_r[32 + i] for the previous granules' time slots r < 0
     float overlap[18], oA[kHistOld], oB[kHistOld];
@@ -242,20 +201,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
     const uint32_t *side_raw = reinterpret_cast<const uint32_t *>(side);
     uint32_t sd_next = 0;
     float4 line[5];
-    int4 qline[3];
-    uint32_t dw_next = 0;
 #pragma unroll
     for (int q = 0; q < 5; ++q) line[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) qline[q] = make_int4(0, 0, 0, 0);
-    const size_t pair_base = (size_t)unit * granules_per_chain;  // FRONT: index of the pair's first stereo record
     if (live && g_first < g_stop) {
-        if (FRONT) {
-            fetch_front(fr, chain_base + (size_t)g_first, pair_base + (size_t)g_first, half, hl, qline, dw_next);
-        } else {
-            fetch_granule(xr + (chain_base + (size_t)g_first) * 576, hl, line);
-            sd_next = side_raw[chain_base + (size_t)g_first];
-        }
+        fetch_granule(xr + (chain_base + (size_t)g_first) * 576, hl, line);
+        sd_next = side_raw[chain_base + (size_t)g_first];
     }
 
     for (long r = 0; r < rounds; ++r) {
@@ -265,97 +215,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
         const bool emit = active && g >= (long)g_begin;
 
         int bt = 0, mixed = 0, rzero = 0;
-        if (FRONT) {
-            // ---- the records fetched one granule ahead -> LDS, then the 40 slot scales of this half's channel
-            if (active) {
-                if (hl < 13)
-                    rqw[hl] = dw_next;
-                else if (half == 0 && hl < 25)
-                    stw[hl - 13] = dw_next;
-            }
-            if (threadIdx.x < 40) {
-                nz[threadIdx.x] = 0;
-                act[threadIdx.x] = kMp3StNone;
-            }
-            wave_sync();
-            const symaccel_mp3_requant &rqd = *reinterpret_cast<const symaccel_mp3_requant *>(rqw);
-            const symaccel_mp3_stereo &std_ = *reinterpret_cast<const symaccel_mp3_stereo *>(stw);
-            if (active) {
-                slot_scale[hl] = mp3_slot_scale(tb, rqd, hl, fr.e.mixed_switch);
-                if (hl < 8) slot_scale[32 + hl] = mp3_slot_scale(tb, rqd, 32 + hl, fr.e.mixed_switch);
-            }
-            wave_sync();
-            bool mid_side = false, intensity = false;
-            const uint8_t *mst = tb.mp3_band_map;
-            if (active) {
-                bt = rqd.block_type;
-                mixed = rqd.is_mixed ? 1 : 0;
-                rzero = rqd.rzero > 576 ? 576 : (int)rqd.rzero;
-                mid_side = std_.flags & SYMACCEL_MP3_ST_MID_SIDE;
-                intensity = std_.flags & SYMACCEL_MP3_ST_INTENSITY;
-                const bool st_short = std_.block_type == SYMACCEL_MP3_SHORT;
-                mst = tb.mp3_band_map + (size_t)(sr * 4 + (st_short ? (std_.is_mixed ? 3 : 1) : 0)) * 576;
-                const uint8_t *mrq = tb.mp3_band_map + (size_t)(sr * 4 + mp3_requant_kind(rqd)) * 576;
-                // ---- quantised samples -> requantised lines in the LDS tile (natural order): read_huffman_samples'
-                // values + requantize (requantize.rs:117-147, 239-380); channel 1 flags its non-zero bands on the way
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (q == 2 && hl >= 8) continue;
-                    const int n0 = 8 * (q < 2 ? hl + 32 * q : 64 + hl);
-                    const int4 v = qline[q];
-                    const int w[4] = {v.x, v.y, v.z, v.w};
-                    const uint2 mr = *reinterpret_cast<const uint2 *>(mrq + n0), ms = *reinterpret_cast<const uint2 *>(mst + n0);
-                    float o[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int s = (int)(short)((unsigned)w[j >> 1] >> (16 * (j & 1)));
-                        const int slot = (int)(((j < 4 ? mr.x : mr.y) >> (8 * (j & 3))) & 255u);
-                        o[j] = mp3_sample_value(tb, pow_lo, s, n0 + j >= rzero, kFrontPow) * slot_scale[slot];
-                        if (half == 1 && intensity && o[j] != 0.0f) nz[((j < 4 ? ms.x : ms.y) >> (8 * (j & 3))) & 255u] = 1;
-                    }
-                    float4 *t4 = reinterpret_cast<float4 *>(tile + n0);
-                    t4[0] = make_float4(o[0], o[1], o[2], o[3]);
-                    t4[1] = make_float4(o[4], o[5], o[6], o[7]);
-                }
-            }
-            wave_sync();
-            // ---- stereo (stereo.rs:485-556) on the two tiles, all 64 lanes; both halves then carry rzero = end (:549-553)
-            if (active && (mid_side || intensity)) {  // wave-uniform: the halves share the pair's record
-                int end = std_.rzero0 > std_.rzero1 ? std_.rzero0 : std_.rzero1;
-                end = end > 576 ? 576 : end;
-                int bound = end;
-                if (intensity) {
-                    bound = mp3_stereo_walk(tb, std_, fr.e, nz, act, kl, kr, threadIdx.x == 0, end, std_.rzero1 > 576 ? 576 : (int)std_.rzero1);
-                    wave_sync();
-                }
-#pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    const int n = (int)threadIdx.x + 64 * q;
-                    float a = lds[n], b = lds[576 + n];
-                    if (mp3_stereo_apply(a, b, n, bound, mid_side, intensity, mst[n], act, kl, kr)) {
-                        lds[n] = a;
-                        lds[576 + n] = b;
-                    }
-                }
-                wave_sync();
-                rzero = end;
-            }
-        } else {
-            if (active) {
-                const uint32_t sd = sd_next;  // fetched one granule ahead, with the lines (little-endian struct layout)
-                bt = (int)(sd & 0xffu);
-                mixed = (sd & 0xff00u) ? 1 : 0;
-                rzero = (int)(sd >> 16) > 576 ? 576 : (int)(sd >> 16);
-            }
-            // ---- granule -> LDS tile (natural order), then lane sb gathers its 18 lines
-            if (active) {
-                float4 *t4 = reinterpret_cast<float4 *>(tile);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
-                if (hl < 16) t4[128 + hl] = line[4];
-            }
-            wave_sync();
+        if (active) {
+            const uint32_t sd = sd_next;  // fetched one granule ahead, with the lines (little-endian struct layout)
+            bt = (int)(sd & 0xffu);
+            mixed = (sd & 0xff00u) ? 1 : 0;
+            rzero = (int)(sd >> 16) > 576 ? 576 : (int)(sd >> 16);
         }
+        // ---- granule -> LDS tile (natural order), then lane sb gathers its 18 lines
+        if (active) {
+            float4 *t4 = reinterpret_cast<float4 *>(tile);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
+            if (hl < 16) t4[128 + hl] = line[4];
+        }
+        wave_sync();
         float y[18];
 #pragma unroll
         for (int i = 0; i < 18; ++i) y[i] = 0.0f;
@@ -439,12 +312,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
             }
         }
         if (live && g + 1 < g_stop) {  // prefetch the next granule; it lands during the dct32 and window passes
-            if (FRONT) {
-                fetch_front(fr, chain_base + (size_t)(g + 1), pair_base + (size_t)(g + 1), half, hl, qline, dw_next);
-            } else {
-                fetch_granule(xr + (chain_base + (size_t)(g + 1)) * 576, hl, line);
-                sd_next = side_raw[chain_base + (size_t)(g + 1)];
-            }
+            fetch_granule(xr + (chain_base + (size_t)(g + 1)) * 576, hl, line);
+            sd_next = side_raw[chain_base + (size_t)(g + 1)];
         }
         wave_sync();  // the previous granule's window pass has read S
         if (need_hist) {
@@ -539,27 +408,9 @@ int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_
     const size_t items = n_chains * segs;
     const size_t grid = (items + 1) / 2;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(mp3_synth_kernel<false>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, ctx->dev, d_xr, d_side, sr,
+    hipLaunchKernelGGL(mp3_synth_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, ctx->dev, d_xr, d_side, sr,
                        d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out, d_vfront_out, d_pcm,
-                       (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs, Mp3Front{});
-    SYM_GPU(ctx, hipGetLastError());
-    return SYMACCEL_OK;
-}
-
-// requantize + stereo + synthesis tail for channel pairs (the FRONT instantiation): one wavefront per (pair, segment)
-int launch_mp3_front(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq, const symaccel_mp3_stereo *d_st,
-                     const int32_t *d_pair_chains, int sr, const float *d_overlap_in, const float *d_vvec_in,
-                     const int32_t *d_vfront_in, float *d_overlap_out, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm,
-                     size_t n_pairs, size_t granules_per_chain) {
-    if (granules_per_chain > 0x3fffffffu || n_pairs > 0x3fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    const unsigned seg = choose_segment(ctx, 2 * n_pairs, granules_per_chain, 4 * SYM_MP3_WAVES, 2, 2, 2);
-    const size_t segs = (granules_per_chain + seg - 1) / seg;
-    const size_t grid = n_pairs * segs;
-    if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    Mp3Front fr{d_quant, d_rq, d_st, d_pair_chains, make_sfb_edges(host_tables(), sr)};
-    hipLaunchKernelGGL(mp3_synth_kernel<true>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, ctx->dev, (const float *)nullptr,
-                       (const symaccel_mp3_side *)nullptr, sr, d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out,
-                       d_vfront_out, d_pcm, (unsigned)n_pairs, (unsigned)granules_per_chain, seg, (unsigned)segs, fr);
+                       (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

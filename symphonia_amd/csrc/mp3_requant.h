@@ -66,39 +66,43 @@ inline SfbEdges make_sfb_edges(const HostTables &t, int sr) {
     return e;
 }
 
-constexpr int kMp3StNone = 0, kMp3StMidSide = 1, kMp3StIntensity = 2;
 constexpr float kMp3Frac1Sqrt2 = 0.70710678118654752440f;  // f32::consts::FRAC_1_SQRT_2 (stereo.rs:143-144)
 
+// What stereo() does to a granule, decided per scale-factor band: bands in is_mask are intensity coded, bands in
+// ms_mask (and every line below `bound`, when mid/side is on) are mid/side coded, the rest is left alone.
+struct Mp3StereoPlan {
+    int bound;
+    unsigned long long ms_mask, is_mask;
+};
+
+// is_pos of band k (stereo.rs:226-228, 369-371): long blocks copy band 20 into band 21, short / mixed blocks copy
+// scalefacs[33..36] into positions 36..39
+__device__ __forceinline__ int mp3_is_pos(const symaccel_mp3_stereo &d, bool is_short, int k) {
+    return d.scalefacs1[is_short ? (k < 36 ? k : k - 3) : (k < 21 ? k : 20)];
+}
+
 // The intensity-stereo band walk of process_intensity_long_block (stereo.rs:196-260) and
-// process_intensity_short_block (:264-483) on per-band "channel 1 is non-zero" flags nz[0..39]: every lane of the
-// wavefront runs it identically; the lane with writer == true records one action per band it visits in act[] (bands
-// it does not visit keep what the caller initialised, kMp3StNone) and the (left, right) ratios of intensity bands in
-// kl[] / kr[].  Returns the intensity bound (mid/side applies below it).  Band k of the block's edge table uses
-// is_pos[k]: for short / mixed blocks is_pos[..36] = scalefacs[..36], is_pos[36..39] = scalefacs[33..36] (:369-371),
-// for long blocks is_pos[21] = is_pos[20] (:226-228).
-__device__ __forceinline__ int mp3_stereo_walk(const DevTables &tb, const symaccel_mp3_stereo &d, const SfbEdges &e, const int *nz,
-                                               int *act, float *kl, float *kr, bool writer, int end, int rzero1) {
+// process_intensity_short_block (:264-483) on a bit mask of the bands in which channel 1 is non-zero (bit k = band k
+// of the block's edge table).  Pure scalar work on wave-uniform values: every lane computes the same plan.
+__device__ __forceinline__ Mp3StereoPlan mp3_stereo_walk(const symaccel_mp3_stereo &d, const SfbEdges &e, unsigned long long nzmask,
+                                                         int end, int rzero1) {
     const bool mid_side = d.flags & SYMACCEL_MP3_ST_MID_SIDE;
     const bool is_short = d.block_type == SYMACCEL_MP3_SHORT, is_mixed = is_short && d.is_mixed;
-    const int table = (d.flags & SYMACCEL_MP3_ST_MPEG1) ? 0 : 7 + 32 * ((d.flags & SYMACCEL_MP3_ST_IS_SCALE) ? 1 : 0);
     const int inv_pos = (d.flags & SYMACCEL_MP3_ST_MPEG1) ? 7 : 31;  // INTENSITY_INV_POS_* (stereo.rs:19-29)
-    int bound = end;
-    auto zero_band = [&](int k, int is_pos) {  // process_intensity (stereo.rs:165-186) as an action for band k
-        if (!writer) return;
-        if (is_pos < inv_pos) {
-            act[k] = kMp3StIntensity;
-            kl[k] = tb.mp3_is_ratios[2 * (table + is_pos)];
-            kr[k] = tb.mp3_is_ratios[2 * (table + is_pos) + 1];
-        } else {
-            act[k] = mid_side ? kMp3StMidSide : kMp3StNone;
-        }
+    Mp3StereoPlan plan{end, 0ull, 0ull};
+    auto zero_band = [&](int k) {  // process_intensity (stereo.rs:165-186) as an action for band k
+        if (mp3_is_pos(d, is_short, k) < inv_pos)
+            plan.is_mask |= 1ull << k;
+        else if (mid_side)
+            plan.ms_mask |= 1ull << k;
     };
+    auto nz = [&](int k) { return (nzmask >> k) & 1ull; };
     if (!is_short) {
         for (int i = 21; i >= 0; --i) {
             const int start = e.longb[i];
-            if (!(start >= rzero1 || nz[i] == 0)) break;
-            zero_band(i, d.scalefacs1[i < 21 ? i : 20]);
-            bound = start;
+            if (!(start >= rzero1 || !nz(i))) break;
+            zero_band(i);
+            plan.bound = start;
         }
     } else {
         const int16_t *bands = is_mixed ? e.mixed : e.shortb;
@@ -111,25 +115,45 @@ __device__ __forceinline__ int mp3_stereo_walk(const DevTables &tb, const symacc
             for (int w = 2; w >= 0; --w) {
                 const int k = k0 + w;
                 bool &wz = w == 2 ? wz2 : (w == 1 ? wz1 : wz0);
-                wz = wz && nz[k] == 0;
+                wz = wz && !nz(k);
                 if (wz)
-                    zero_band(k, d.scalefacs1[k < 36 ? k : k - 3]);
-                else if (mid_side && writer)
-                    act[k] = kMp3StMidSide;
+                    zero_band(k);
+                else if (mid_side)
+                    plan.ms_mask |= 1ull << k;
             }
-            bound = bands[k0];
+            plan.bound = bands[k0];
             found_bound = !wz0 && !wz1 && !wz2;
             if (found_bound) break;
         }
         if (!found_bound && is_mixed) {  // the long bands of a mixed block, stereo.rs:450-478
             for (int i = sw - 1; i >= 0; --i) {
-                if (nz[i] != 0) break;
-                zero_band(i, d.scalefacs1[i]);
-                bound = bands[i];
+                if (nz(i)) break;
+                zero_band(i);
+                plan.bound = bands[i];
             }
         }
     }
-    return bound;
+    return plan;
+}
+
+constexpr int kMp3StNone = 0, kMp3StMidSide = 1, kMp3StIntensity = 2;
+
+// Lane k < 40 turns the plan's bit k into band k's action and, for an intensity band, its (left, right) ratios
+// (process_intensity, stereo.rs:165-186), for mp3_stereo_apply to read back per line.  `ratios`: DevTables::mp3_is_ratios.
+__device__ __forceinline__ void mp3_stereo_expand(const Mp3StereoPlan &plan, const symaccel_mp3_stereo &d, const float *ratios, int k,
+                                                  int *act, float *kl, float *kr) {
+    const unsigned long long bit = 1ull << k;
+    int a = kMp3StNone;
+    if (plan.is_mask & bit) {
+        const int table = (d.flags & SYMACCEL_MP3_ST_MPEG1) ? 0 : 7 + 32 * ((d.flags & SYMACCEL_MP3_ST_IS_SCALE) ? 1 : 0);
+        const int is_pos = mp3_is_pos(d, d.block_type == SYMACCEL_MP3_SHORT, k);
+        kl[k] = ratios[2 * (table + is_pos)];
+        kr[k] = ratios[2 * (table + is_pos) + 1];
+        a = kMp3StIntensity;
+    } else if (plan.ms_mask & bit) {
+        a = kMp3StMidSide;
+    }
+    act[k] = a;
 }
 
 // One line of the pair: mid/side below the intensity bound (stereo.rs:541-543), the band's action from it on.

@@ -5,9 +5,9 @@
 // One wavefront per granule (both channels, 2 x 576 lines in registers as groups of four lines, 16-byte accesses).
 // Which bands are intensity coded depends on the data: the reference walks the scale-factor bands of channel 1 from
 // the top while they are all zero (per window for short blocks).  Here every lane flags the band of each non-zero
-// line it holds in LDS, then the wavefront runs the reference's band walk on those <= 39 flags (wave-uniform scalar
-// work) and leaves one action per band -- none, mid/side, or intensity with its (left, right) ratios -- plus the
-// intensity bound in LDS; finally every lane applies the action of its lines' bands, or mid/side below the bound.
+// line it holds in a 40-bit mask (two LDS atomic ORs per lane), then every lane runs the reference's band walk on that
+// mask -- scalar work on wave-uniform values, no memory -- which yields the intensity bound and two band masks
+// (intensity coded / mid-side coded); finally every lane applies its lines' bands' action, or mid/side below the bound.
 //
 // FUSED: the wavefront first requantises both channels from the quantised Huffman samples (mp3_requant.h: the
 // arithmetic of mp3_requant.hip) into those registers, so the f32 spectra make no round trip through HBM between
@@ -34,7 +34,8 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
                                                                  const symaccel_mp3_stereo *__restrict__ desc, int sr, SfbEdges e,
                                                                  unsigned n_items, const int16_t *__restrict__ quant,
                                                                  const symaccel_mp3_requant *__restrict__ rq_desc) {
-    __shared__ int nz_all[kWaves][40], act_all[kWaves][40];
+    __shared__ unsigned nz_all[kWaves][2];  // bit mask of the bands in which channel 1 is non-zero
+    __shared__ int act_all[kWaves][40];     // per band: what the plan says (mp3_stereo_expand)
     __shared__ float kl_all[kWaves][40], kr_all[kWaves][40];
     __shared__ float scale_all[FUSED ? kWaves : 1][2][kMp3Slots];
     __shared__ float pow43_lo[FUSED ? kMp3PowLds : 1];
@@ -45,7 +46,8 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     const unsigned item = blockIdx.x * kWaves + (unsigned)wave;
     if (item >= n_items) return;
-    int *nz = nz_all[wave], *act = act_all[wave];
+    unsigned *nzw = nz_all[wave];
+    int *act = act_all[wave];
     float *kl = kl_all[wave], *kr = kr_all[wave];
     const unsigned pair = item / granules_per_chain, g = item % granules_per_chain;
     const symaccel_mp3_stereo &d = desc[item];
@@ -118,19 +120,21 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
         }
     }
 
-    int bound = end;
+    Mp3StereoPlan plan{end, 0ull, 0ull};
     if (intensity) {
-        if (lane < 40) {
-            nz[lane] = 0;
-            act[lane] = kMp3StNone;
-        }
+        if (lane < 2) nzw[lane] = 0u;
         wave_sync();
+        unsigned long long mine = 0ull;  // is_zero_band (stereo.rs:189-192): one bit per band
 #pragma unroll
         for (int i = 0; i < 4 * kQ; ++i)
-            if (have[i / 4] && b[i] != 0.0f) nz[band[i]] = 1;  // is_zero_band (stereo.rs:189-192), one flag per band
+            if (have[i / 4] && b[i] != 0.0f) mine |= 1ull << band[i];
+        if ((unsigned)mine) atomicOr(&nzw[0], (unsigned)mine);
+        if ((unsigned)(mine >> 32)) atomicOr(&nzw[1], (unsigned)(mine >> 32));
         wave_sync();
-        // ---- the band walk (identical in every lane; lane 0 records the decisions)
-        bound = mp3_stereo_walk(tb, d, e, nz, act, kl, kr, lane == 0, end, rzero1);
+        // ---- the band walk: scalar work on the 40-bit mask, identical in every lane
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)nzw[0]), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)nzw[1]);
+        plan = mp3_stereo_walk(d, e, (unsigned long long)lo | ((unsigned long long)hi << 32), end, rzero1);
+        if (lane < 40) mp3_stereo_expand(plan, d, tb.mp3_is_ratios, lane, act, kl, kr);
         wave_sync();
     }
 
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = 4 * qq + j;
-            touched |= mp3_stereo_apply(a[i], b[i], 4 * grp + j, bound, mid_side, intensity, band[i], act, kl, kr);
+            touched |= mp3_stereo_apply(a[i], b[i], 4 * grp + j, plan.bound, mid_side, intensity, band[i], act, kl, kr);
         }
         if (touched) {
             reinterpret_cast<float4 *>(ch0)[grp] = make_float4(a[4 * qq], a[4 * qq + 1], a[4 * qq + 2], a[4 * qq + 3]);

@@ -44,6 +44,7 @@ struct alignas(4) uchar4 { unsigned char x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 struct dim3 {
     unsigned x, y, z;
@@ -114,6 +115,8 @@ static inline void __builtin_amdgcn_wave_barrier() {
 static inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only used on values every lane already agrees on
+static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 
 // dst[lane] = src[(byte_addr / 4) % 64] within the lane's wavefront
 static inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int value) {

@@ -90,9 +90,7 @@ def main():
     pcm2 = torch.empty_like(xr2)
     t3 = timeit(lambda: (st.requantize_stereo(quant2, desc.reshape(128, 2048, 52), spairs, sdesc, xr2),
                          syn.synth(xr2, side, sst[0], sst[1], sst[2], pcm2)))
-    t1 = timeit(lambda: st.decode_tail(quant2, desc.reshape(128, 2048, 52), spairs, sdesc, sst[0], sst[1], sst[2], pcm2))
     out["mp3 requantize+stereo, then synth: two launches (%.3f ms)" % (t3 * 1e3)] = 131072 * (2 * (1152 + 52 + 2304) + 48) / t3
-    out["mp3 decode tail, one kernel (131072 granules; %.3f ms)" % (t1 * 1e3)] = 131072 * (2 * (1152 + 52 + 2304) + 48) / t1
     # AAC spectral tools at config-2 size: 64 pairs x 1024 frames, every band of every frame mid/side coded;
     # one order-12 TNS filter over lines 96..896 in every channel-frame
     swb_long = [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216,
