@@ -247,9 +247,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: symphonia_amd has no CPU path")
+    # Development smoke test of the N > 1 control flow on a one-GPU box (SYM_BENCH_ONE_GPU_SMOKE=1): every rank shares
+    # cuda:0 and the two tiny reductions go through gloo on the host.  Never set by the driver; its numbers mean nothing.
+    one_gpu_smoke = os.environ.get("SYM_BENCH_ONE_GPU_SMOKE") == "1"
+    if one_gpu_smoke:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu_smoke:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = sa.Context(local_rank)
     ctx.use_torch_stream()
@@ -278,7 +286,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dist if world > 1 else None, device="cuda")
+    elapsed = max_over_ranks(elapsed, dist if world > 1 else None, device="cpu" if one_gpu_smoke else "cuda")
     launch_s = ev0.elapsed_time(ev1) / 1e3 / args.steps  # mean launch period of the hot-path kernel(s)
     log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))
 
