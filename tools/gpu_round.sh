@@ -1,23 +1,26 @@
 #!/bin/bash
-# One gpurun call: bench lines for every workload (with the CPU baseline) + rocprofv3 kernel stats for every workload
-# + HBM traffic PMC passes for the headline kernel.   bash tools/gpu_round.sh [tag]
+# One gpurun call: rocprofv3 kernel stats + HBM traffic PMC passes for every workload, then the bench lines (with the CPU
+# baseline), which pick up the traffic just measured.   bash tools/gpu_round.sh [tag];  afterwards, locally:
+# python tools/collect_round.py <tag>
 TAG=${1:-r01}
+REPO=$PWD
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-for w in aac mp3 vorbis flac alac; do
-  timeout 300 python bench.py --workload $w --steps 20 --warmup 3 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
-  echo "bench $w rc=$?"; tail -n 1 $OUT/bench_$w.json | cut -c1-400
-done
-REPO=$PWD
 cd /tmp
 for w in aac mp3 vorbis flac alac; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_$w -o $w -- python $REPO/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_${TAG}_$w.log 2>&1
   echo "rocprof stats $w rc=$?"
 done
-for w in aac mp3; do
+for w in aac mp3 vorbis flac alac; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${TAG}_${w}_$c -o $w -- python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_${TAG}_${w}_$c.log 2>&1
     echo "rocprof pmc $w $c rc=$?"
   done
+done
+cd $REPO
+python tools/collect_round.py $TAG --traffic-only
+for w in aac mp3 vorbis flac alac; do
+  timeout 300 python bench.py --workload $w --steps 20 --warmup 3 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+  echo "bench $w rc=$?"; tail -n 1 $OUT/bench_$w.json | cut -c1-300
 done
