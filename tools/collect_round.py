@@ -6,7 +6,9 @@
 writes profiles/<tag>_bench_<workload>.json (the bench lines), profiles/<tag>_<workload>_rocprofv3.txt (kernel stats +
 PMC passes, via tools/rocpd_summary.py) and profiles/hbm_traffic.json (HBM bytes per launch of each workload's
 dominant kernel: FETCH_SIZE x 2 -- the gfx950 correction of MI355X_MICROARCH.md, HBM section -- + WRITE_SIZE, in KiB).
-Removes the same files of older tags."""
+Removes the same files of older tags.  The rocpd databases of a round exceed what gpurun copies back, so gpu_round.sh
+runs this on the GPU box with --stage (artifacts are copied to gpurun_out/profiles_<tag>/) and deletes the databases;
+locally: cp gpurun_out/profiles_<tag>/* profiles/ (and git rm the previous tag's files)."""
 import io
 import json
 import sqlite3
@@ -78,3 +80,9 @@ def main(tag, traffic_only=False):
 
 if __name__ == "__main__":
     main(sys.argv[1] if len(sys.argv) > 1 else "r01", traffic_only="--traffic-only" in sys.argv)
+    if "--stage" in sys.argv:  # on the GPU box: leave the artifacts under gpurun_out/ (the only directory copied back)
+        import shutil
+        stage = ROOT / "gpurun_out" / ("profiles_" + sys.argv[1])
+        stage.mkdir(exist_ok=True)
+        for f in list((ROOT / "profiles").glob(sys.argv[1] + "_*")) + [ROOT / "profiles" / "hbm_traffic.json"]:
+            shutil.copy(f, stage / f.name)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: rocprofv3 kernel stats + HBM traffic PMC passes for every workload, then the bench lines (with the CPU
-# baseline), which pick up the traffic just measured.   bash tools/gpu_round.sh [tag];  afterwards, locally:
-# python tools/collect_round.py <tag>
+# baseline), which pick up the traffic just measured, then the artifacts (tools/collect_round.py) into
+# gpurun_out/profiles_<tag>/.   bash tools/gpu_round.sh [tag];  afterwards, locally: cp gpurun_out/profiles_<tag>/* profiles/
 TAG=${1:-r01}
 REPO=$PWD
 OUT=$PWD/gpurun_out
@@ -24,3 +24,5 @@ for w in aac mp3 vorbis flac alac; do
   timeout 300 python bench.py --workload $w --steps 20 --warmup 3 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
   echo "bench $w rc=$?"; tail -n 1 $OUT/bench_$w.json | cut -c1-300
 done
+python tools/collect_round.py $TAG --stage
+rm -rf $OUT/prof_${TAG}_*/ $OUT/pmc_${TAG}_*/   # the rocpd databases: too large to copy back
