@@ -14,12 +14,15 @@
 //   * lane = output sample i for the 512-tap window: the lane keeps the two V-vector entries it needs
 //     from each of the last 16 + 18 time slots (V[i] and V[32+i], which are +-copies of dct32 outputs,
 //     synthesis.rs:247-263) in registers, so the 16-tap dot product per sample reads no memory.
-// The next granule's 576 lines are prefetched (8 B/lane, 256 B per half-wave) while the current one
-// is transformed.  Segments other than a chain's first start with a two-granule halo (granule g-2
-// rebuilds the overlap, granule g-1 rebuilds the 16-slot history); both depend only on inputs.
+// The next granule's 576 lines and its side word are prefetched (16 B/lane, 512 B per half-wave) while the current
+// one is transformed; the side word is decoded only when its round starts (touching it earlier makes the compiler
+// wait for the whole prefetch right after issuing it).  Segments other than a chain's first start with a two-granule
+// halo (granule g-2 rebuilds the overlap, granule g-1 rebuilds the 16-slot history); both depend only on inputs.
 // PCM stores are 4 B per lane (128 B per half-wave): transposing the granule through LDS for 16-byte stores was
-// measured and is not faster.  LDS per wavefront: 5 KiB (granule tiles, then the dct32 transpose) + window rows 2.5 KiB.
-// Roofline: HBM-bound on paper, 2304 B in + 2304 B out per granule-channel, ~34 kflop (no FMA) -> 7.4 flop/B.
+// measured and is not faster.  LDS per wavefront: 5 KiB (granule tiles, then the dct32 transpose) + synthesis-window
+// rows 2.5 KiB + the four IMDCT windows 0.6 KiB (per-lane block types: LDS broadcast instead of vector global loads).
+// Roofline: HBM-bound on paper, 2304 B in + 2304 B out per granule-channel, ~34 kflop (no FMA) -> 7.4 flop/B; in
+// practice latency / VALU-issue bound at three wavefronts per SIMD.
 #include "mp3_common.h"
 
 namespace symaccel {
