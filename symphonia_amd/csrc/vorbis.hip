@@ -181,8 +181,16 @@ __global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
             // what the most recent long block left there (dsp.rs:125 only rewrites the first bs/2 entries; never used
             // for PCM, but part of the state the reference carries).  Rebuild it from that block, or keep the incoming
             // state if the batch has no long block before this segment.
-            long bl = (long)b_begin - 1;
-            while (bl >= 0 && !f[bl]) --bl;
+            static_assert(kVThreads == 64, "the search below is one wavefront wide");
+            long bl = -1;  // searched 64 flags at a time: one coalesced byte load + ballot per step
+            for (long base = ((long)b_begin - 1) & ~63l; base >= 0; base -= 64) {
+                const long idx = base + tid;
+                const unsigned long long m = __ballot(idx < (long)b_begin && f[idx] != 0);
+                if (m) {
+                    bl = base + 63 - __builtin_clzll(m);
+                    break;
+                }
+            }
             if (bl >= 0) {
                 vorbis_imdct_block<MAXBS>(sh, sp + os[bl], rp ? rp + os[bl] : nullptr, bs1, bs1_exp - 2, tw_long, tb);
                 for (int k = bs0 / 2 + tid; k < bs1 / 2; k += kVThreads) sh.overlap[k] = sh.pcm[bs1 / 2 + k];

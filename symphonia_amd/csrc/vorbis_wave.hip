@@ -73,6 +73,34 @@ __device__ __forceinline__ unsigned count_long_before(const uint8_t *f, long b, 
     return cnt;
 }
 
+// Index of the last long block among the first `b` blocks of a chain, or -1: the same 1024-flags-per-step scan, from
+// the top (the answer can be thousands of blocks back; a flag-by-flag walk would be that many dependent loads).
+__device__ __forceinline__ long last_long_before(const uint8_t *f, long b, int lane) {
+    const long mis = (long)(reinterpret_cast<uintptr_t>(f) & 15u);
+    const uint4 *base = reinterpret_cast<const uint4 *>(f - mis);
+    for (long i0 = ((b - 1 + mis) / 1024) * 1024 - mis; i0 >= -mis; i0 -= 1024) {
+        const long i = i0 + 16 * lane;
+        long best = -1;
+        if (i < b && i + 16 > 0) {
+            const uint4 v = base[(i + mis) >> 4];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool inside = i + q >= 0 && i + q < b;
+                if (inside && ((w[q >> 2] >> (8 * (q & 3))) & 255u)) best = i + q;  // ascending q: the last hit stays
+            }
+        }
+        int hi = (int)best;  // < 2^31 blocks per chain (launch_vorbis_wave)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int o = __shfl_xor(hi, m);
+            hi = o > hi ? o : hi;
+        }
+        if (hi >= 0) return hi;
+    }
+    return -1;
+}
+
 constexpr int kWaves = 4;
 constexpr int kTabTw = 0;        // shared LDS tables: Imdct(1024) twiddles, 512 complex
 constexpr int kTabWin = 1024;    //   long window (left half of the 2048-sample window), 1024 f32
@@ -337,8 +365,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
             // The chain ends in short blocks and this segment never saw a long one: overlap[128..1024) still
             // holds what the most recent long block left there (never used for PCM, but part of the state the
             // reference carries).  Rebuild it from that block's spectrum, or keep the incoming state.
-            long bl = (long)b_begin - 1;
-            while (bl >= 0 && !f[bl]) --bl;
+            const long bl = b_begin > 0 ? last_long_before(f, (long)b_begin, lane) : -1;
             float keep[2][8];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
