@@ -105,7 +105,8 @@ constexpr int kWaves = 4;
 constexpr int kTabTw = 0;        // shared LDS tables: Imdct(1024) twiddles, 512 complex
 constexpr int kTabWin = 1024;    //   long window (left half of the 2048-sample window), 1024 f32
 constexpr int kTabWs = 2048;     //   short window (left half of the 256-sample window), 128 f32
-constexpr int kTabFloats = 2048 + 128;
+constexpr int kTabTws = 2048 + 128;  //   Imdct(128) twiddles, 64 complex
+constexpr int kTabFloats = 2048 + 128 + 128;
 constexpr int kBs0 = 256, kBs1 = 2048;
 
 // out[q] = ov[q] * ws[127 - (k + q)] + y[q] * ws[k + q], q = 0..3 (vorbis dsp.rs:140-144 with the short window)
@@ -134,7 +135,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     for (int i = (int)threadIdx.x; i < 1024; i += 64 * kWaves) {
         tabs[kTabTw + i] = reinterpret_cast<const float *>(tw_long)[i];
         tabs[kTabWin + i] = win_long[i];
-        if (i < 128) tabs[kTabWs + i] = win_short[i];
+        if (i < 128) {
+            tabs[kTabWs + i] = win_short[i];
+            tabs[kTabTws + i] = reinterpret_cast<const float *>(tw_short)[i];
+        }
     }
     __syncthreads();  // the only workgroup-wide barrier
 
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     c32 *lds = reinterpret_cast<c32 *>(ldsf);
     const c32 *tw = reinterpret_cast<const c32 *>(tabs + kTabTw);
     const float *wl = tabs + kTabWin, *ws = tabs + kTabWs;
+    const cpx *tws = reinterpret_cast<const cpx *>(tabs + kTabTws);
 
     const unsigned chain = item / segs_per_chain, seg = item % segs_per_chain;
     const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
@@ -302,14 +307,13 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
             }
             wave_sync();
             if (glen_next > 0) fetch_lines<FUSED>(sp, rp, os_next, flag_next ? 8 : glen_next, lane, line, res);
-            imdct_short_wave(lane, ldsf, tw_short, lt);  // H[8][128] in ldsf[0..1024); ends with a wave_sync
-            for (int i = 0; i < glen; ++i) {
-                const long blk = b + i;
-                const bool emit = blk >= (long)b_begin;
-                // PCM of the run's blocks is packed back to back: the first contributes 576 (after a long) or 128
-                const uint32_t first_len = pflag ? 576u : 128u;
-                float4 *o4 = reinterpret_cast<float4 *>(out + op_cur + (i == 0 ? 0u : first_len + 128u * (uint32_t)(i - 1)));
-                if (i == 0 && pflag) {
+            imdct_short_wave(lane, ldsf, tws, lt);  // H[8][128] in ldsf[0..1024); ends with a wave_sync
+            // PCM of the run's blocks is packed back to back: the first contributes 576 (after a long) or 128
+            const uint32_t first_len = pflag ? 576u : 128u;
+            {   // ---- the run's first block
+                const bool emit = b >= (long)b_begin;
+                float4 *o4 = reinterpret_cast<float4 *>(out + op_cur);
+                if (pflag) {
                     // long -> short (dsp.rs:91-106): overlap[0..448) at unity gain, then 128 overlap-added samples.
                     // overlap[448..576) sits in the slots of lanes 48..63 (m2 = 112 + t).
                     if (emit) {
@@ -329,18 +333,29 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                         }
                     }
                 } else if (emit && lane < 32) {
-                    // short -> short (dsp.rs:85-90): lane l produces out[4 l .. 4 l + 3]
-                    float ov[4], y[4];
-                    if (i == 0) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) ov[q] = dl[0][q];  // overlap[0..128) = first float4 of lanes 0..31
-                    } else {
-                        ys4(ldsf, i - 1, kBs0 / 2 + 4 * lane, ov);
-                    }
-                    ys4(ldsf, i, 4 * lane, y);
+                    // short -> short (dsp.rs:85-90) against the carried overlap[0..128) = first float4 of lanes 0..31
+                    const float ov[4] = {dl[0][0], dl[0][1], dl[0][2], dl[0][3]};
+                    float y[4];
+                    ys4(ldsf, 0, 4 * lane, y);
                     float4 r;
                     ola_short4(ws, 4 * lane, ov, y, r);
                     o4[lane] = r;
+                }
+            }
+            // ---- the rest, two blocks per round (one per half-wavefront): short -> short (dsp.rs:85-90), lane l of a
+            // half produces out[4 l .. 4 l + 3] of its block from the two neighbouring transforms in LDS
+            {
+                const int l32 = lane & 31;
+                for (int i0 = 1; i0 < glen; i0 += 2) {
+                    const int i = i0 + (lane >> 5);
+                    if (i < glen && b + i >= (long)b_begin) {
+                        float ov[4], y[4];
+                        ys4(ldsf, i - 1, kBs0 / 2 + 4 * l32, ov);
+                        ys4(ldsf, i, 4 * l32, y);
+                        float4 r;
+                        ola_short4(ws, 4 * l32, ov, y, r);
+                        reinterpret_cast<float4 *>(out + op_cur + first_len + 128u * (uint32_t)(i - 1))[l32] = r;
+                    }
                 }
             }
             // overlap[0..128) = imdct[128..256) of the run's last block (dsp.rs:125); the rest is left as it was
