@@ -43,6 +43,23 @@ __global__ void copy_frames_staggered(const float4 *__restrict__ in, float4 *__r
         for (int q = 0; q < 4; ++q) d[lane + 64 * q] = v[q];
     }
 }
+// frame-major layout: frame f of chain c at (f * chains + c); wavefront (c, seg) walks `per_wave` frames of its chain,
+// so wavefronts that run side by side touch neighbouring 4 KiB frames
+__global__ void copy_frames_fm(const float4 *__restrict__ in, float4 *__restrict__ out, int chains, int per_wave) {
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const size_t c = wave % chains, seg = wave / chains;
+    for (int f = 0; f < per_wave; ++f) {
+        const size_t fr = (seg * per_wave + f) * chains + c;
+        const float4 *s = in + fr * 256;
+        float4 *d = out + fr * 256;
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = s[lane + 64 * q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[lane + 64 * q] = v[q];
+    }
+}
 __global__ void read_k(const float4 *__restrict__ in, float *out, size_t n) {
     float acc = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -94,6 +111,12 @@ int main() {
         const unsigned blocks = (unsigned)((waves + 3) / 4);
         float ms = time_ms([&] { hipLaunchKernelGGL(copy_frames, dim3(blocks), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, frames, per_wave); }, 10);
         printf("copy 4 KiB frames, %2d consecutive frames per wavefront (%u blocks)  %.3f ms  %.2f TB/s\n", per_wave, blocks, ms, 2.0 * bytes / ms / 1e9);
+    }
+    for (int per_wave : {32, 64}) {  // config 2: 128 chains x 1024 frames
+        const int chains = 128;
+        const unsigned blocks = (unsigned)(frames / per_wave / 4);
+        float msf = time_ms([&] { hipLaunchKernelGGL(copy_frames_fm, dim3(blocks), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, chains, per_wave); }, 10);
+        printf("copy 4 KiB frames, frame-major [frame][128 chains], %2d frames per wavefront  %.3f ms  %.2f TB/s\n", per_wave, msf, 2.0 * bytes / msf / 1e9);
     }
     for (int stagger : {1, 7, 16, 61}) {
         const int per_wave = 64;
