@@ -160,8 +160,8 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
         } else {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {  // the short transform indexes lines per 128-line window: stage in LDS
-                ldsf[2 * lane + 128 * s] = line[s].x;
-                ldsf[2 * lane + 128 * s + 1] = line[s].y;
+                ldsf[short_row(s) + 2 * lane] = line[s].x;
+                ldsf[short_row(s) + 2 * lane + 1] = line[s].y;
             }
             wave_sync();
         }
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
             wave_sync();  // Z in LDS is overwritten by the next frame
         } else {
             // ---- eight short windows (rare): everything through LDS in natural order
-            float *dly = ldsf + 1024;
-            imdct_short_wave(lane, ldsf, tb.aac_tw_short, lt);  // H[8][128] in ldsf[0..1024)
+            float *dly = ldsf + kShortRowsEnd;  // after the eight (skewed) short-window rows
+            imdct_short_wave(lane, ldsf, tb.aac_tw_short, lt);  // H[w] = ldsf[short_row(w) ..]
 #pragma unroll
             for (int h = 0; h < 2; ++h) store_slot(dly, lane + 64 * h, dl[h]);  // (the FFT work array overlapped dly)
             wave_sync();

@@ -157,12 +157,12 @@ __global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct128_wave_kernel(DevTa
         for (int s = 0; s < 8; ++s) {
             if (s < nt) {
                 const float2 v = src[lane + 64 * s];
-                ldsf[2 * lane + 128 * s] = v.x;
-                ldsf[2 * lane + 128 * s + 1] = v.y;
+                ldsf[short_row(s) + 2 * lane] = v.x;
+                ldsf[short_row(s) + 2 * lane + 1] = v.y;
             }
         }
         wave_sync();
-        imdct_short_wave(lane, ldsf, tw_g, lt);  // H[8][128] in ldsf[0..1024); ends with a wave_sync
+        imdct_short_wave(lane, ldsf, tw_g, lt);  // H[w] = ldsf[short_row(w) ..]; ends with a wave_sync
         const int w = lane >> 3, c = lane & 7;
         if (w < nt) {
             float4 *o4 = reinterpret_cast<float4 *>(out + (t0 + (size_t)w) * 256);

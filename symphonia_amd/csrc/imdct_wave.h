@@ -35,6 +35,7 @@ __device__ __forceinline__ constexpr int lds_t2_inst_w(int j) { return 8 * j; }
 __device__ __forceinline__ int lds_t2_lane_r(int j, int k) { return k + 8 * j; }
 __device__ __forceinline__ constexpr int lds_t2_inst_r(int B) { return 8 * (B & 1) + 64 * (B >> 1) + 256 * (B & 1); }
 static_assert(2 * (7 + 8 + 288 * 3 + 36 * 7 + 1) <= kWaveLds, "FFT work array must fit the per-wave LDS");
+static_assert(128 * 7 + 96 + 128 + 1024 <= kWaveLds, "the skewed short-window rows and a parked 1024-float delay line must fit the per-wave LDS");
 
 struct LaneTables {
     // pass 2 (stages 4-6): fft16 combine k, fft32 combine k and k+8, merge W64[8j + k]
@@ -177,9 +178,24 @@ __device__ __forceinline__ void post_slot(const c32 *lds, const c32 *tw, int m2,
     x2[7] = vC.y;
 }
 
-// Eight 128-line IMDCTs (dsp.rs:80-83).  The frame's 1024 lines are staged in ldsf[0..1024).  Of each
+// Start of short window w's 128 floats in the per-wave LDS area, for the staged lines and for the half-stored output H.
+// Rows exactly 128 floats apart would put the eight windows on the same banks: the transform's strided per-window
+// reads and writes (32 ds_*_b32 instructions, lanes = (window, column)) would then be 4-way conflicted in each 32-lane
+// group -- measured: 65 % of imdct128_wave_kernel's LDS cycles (57 % with the skew).  These multiples of four (rows stay 16-byte aligned
+// for ys4; non-decreasing, so rows do not overlap; bank offsets 0, 16, 24, 8, 8, 24, 16, 0 mod 32) halve that;
+// tests/models/lds_sim.py finds nothing better among aligned skews (tests/test_models.py).
+__device__ __forceinline__ constexpr int short_row(int w) {
+    // skews {0, 16, 24, 40, 40, 56, 80, 96} = 8 x the nibbles of 0xCA755320 (arithmetic, not a table: w is often a
+    // per-lane run-time value, and a table would be a memory lookup in the middle of the transform)
+    return 128 * w + 8 * (int)((0xCA755320u >> (4 * (w & 7))) & 15u);
+}
+static_assert(short_row(0) == 0 && short_row(1) == 144 && short_row(2) == 280 && short_row(3) == 424 && short_row(4) == 552 &&
+              short_row(5) == 696 && short_row(6) == 848 && short_row(7) == 992, "short_row skews");
+constexpr int kShortRowsEnd = 128 * 7 + 96 + 128;  // floats of per-wave LDS the eight rows span
+
+// Eight 128-line IMDCTs (dsp.rs:80-83).  The frame's 1024 lines are staged at ldsf[short_row(w) ..].  Of each
 // window's 256 outputs v0|v1|v2|v3 only v1 and v2 are kept: H[w][0..64) = v1, H[w][64..128) = v2 in
-// ldsf[128 w ..]; v0[x] = -v1[63-x] and v3[x] = v2[63-x] exactly (mdct.rs:108-136 writes the same
+// ldsf[short_row(w) ..]; v0[x] = -v1[63-x] and v3[x] = v2[63-x] exactly (mdct.rs:108-136 writes the same
 // value, negated for v0, to both).
 __device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const cpx *tw_short, const LaneTables &lt) {
     c32 *lds = reinterpret_cast<c32 *>(ldsf);
@@ -189,7 +205,7 @@ __device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const cp
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int i = c + 8 * s;
-        z[s] = pre_twiddle(ldsf[128 * w + 2 * i], ldsf[128 * w + 127 - 2 * i], ld_c(tw_short + i));
+        z[s] = pre_twiddle(ldsf[short_row(w) + 2 * i], ldsf[short_row(w) + 127 - 2 * i], ld_c(tw_short + i));
     }
     wave_sync();
     bitrev8(z);
@@ -209,7 +225,7 @@ __device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const cp
     pass2_regs(z, lt);  // 64-point FFT done: z[j] = Z_w[8j + k], k = c
     wave_sync();
     // post-twiddle (mdct.rs:94-137 with n2 = 64, n4 = 32)
-    float *o = ldsf + 128 * w;
+    float *o = ldsf + short_row(w);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = 8 * j + c;
@@ -241,7 +257,7 @@ __device__ __forceinline__ void load_slot(const float *frame, int m2, float (&v)
 
 // y_s[i0 .. i0+3] (i0 a multiple of 4, in 0..256): Imdct output of short block `w` from the half-stored H of imdct_short_wave: v0 = -reverse(v1), v1 = H[0..64), v2 = H[64..128), v3 = reverse(v2).
 __device__ __forceinline__ void ys4(const float *H, int w, int i0, float (&v)[4]) {
-    const float *h = H + 128 * w;
+    const float *h = H + short_row(w);
     if (i0 < 64) {
         const float4 r = *reinterpret_cast<const float4 *>(h + 60 - i0);
         v[0] = -r.w; v[1] = -r.z; v[2] = -r.y; v[3] = -r.x;

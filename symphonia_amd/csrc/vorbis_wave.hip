@@ -301,13 +301,13 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
 #pragma unroll
             for (int s = 0; s < 8; ++s) {  // block s of the run -> window s of the eight-way short transform
                 if (s < glen) {
-                    ldsf[2 * lane + 128 * s] = line[s].x;
-                    ldsf[2 * lane + 128 * s + 1] = line[s].y;
+                    ldsf[short_row(s) + 2 * lane] = line[s].x;
+                    ldsf[short_row(s) + 2 * lane + 1] = line[s].y;
                 }
             }
             wave_sync();
             if (glen_next > 0) fetch_lines<FUSED>(sp, rp, os_next, flag_next ? 8 : glen_next, lane, line, res);
-            imdct_short_wave(lane, ldsf, tws, lt);  // H[8][128] in ldsf[0..1024); ends with a wave_sync
+            imdct_short_wave(lane, ldsf, tws, lt);  // H[w] = ldsf[short_row(w) ..]; ends with a wave_sync
             // PCM of the run's blocks is packed back to back: the first contributes 576 (after a long) or 128
             const uint32_t first_len = pflag ? 576u : 128u;
             {   // ---- the run's first block
