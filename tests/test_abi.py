@@ -86,3 +86,19 @@ def test_product_never_imports_the_oracle():
             assert "symoracle" not in text, path
     code = "import sys; import symphonia_amd; sys.exit(1 if 'oracle' in sys.modules else 0)"
     assert subprocess.run([sys.executable, "-c", code], cwd=str(ROOT)).returncode == 0
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/symaccel.h is the boundary a C (or Rust bindgen / cgo-style) binding consumes: it must compile as strict C99
+    on its own, and the record sizes the bindings rely on must be what the documentation says."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "symaccel.h"\n'
+                   '#define SIZE_IS(t, n) typedef char size_of_##t[(sizeof(t) == (n)) ? 1 : -1]\n'
+                   'SIZE_IS(symaccel_mp3_side, 4);\nSIZE_IS(symaccel_mp3_requant, 52);\nSIZE_IS(symaccel_mp3_stereo, 48);\n'
+                   'SIZE_IS(symaccel_flac_desc, 4);\nSIZE_IS(symaccel_alac_desc, 4);\nSIZE_IS(symaccel_aac_js_frame, 644);\n'
+                   'SIZE_IS(symaccel_aac_tns_filter, 92);\n'
+                   'int use(void) { return SYMACCEL_ABI_VERSION + (int)SYMACCEL_ERR_OOM; }\n')
+    out = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"), "-c", str(src),
+                          "-o", str(tmp_path / "abi.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
