@@ -118,3 +118,50 @@ def test_fuzz_flac_alac(ctx, it):
     d_res = dev(res)
     AlacPredictor(ctx).predict(d_res, dev(alac_desc(mode, aorder, ashift, bps).view(np.uint8).reshape(nb, 4)), dev(acoef))
     assert bit_equal(host(d_res), oracle.alac_predict(res, oracle.alac_desc(mode, aorder, ashift, bps), acoef)), (nb, bs)
+
+
+@pytest.mark.parametrize("it", range(ITERS))
+def test_fuzz_mp3_front(ctx, it):
+    """requantize (+ stereo, separately and fused) for random shapes / sample rates."""
+    from symphonia_amd import Mp3Requantize, Mp3Stereo
+    from test_mp3_stereo import fused_case
+    rng = np.random.default_rng(9000 + it)
+    sr = int(rng.integers(0, 9))
+    n_pairs, granules = int(rng.choice([1, 2, 5, 17])), int(rng.choice([1, 2, 3, 16, 33]))
+    q, rd, pairs, sd, want, mono = fused_case(9100 + it, sr, n_pairs, granules)
+    d_q = dev(q)
+    d_rd = dev(rd.view(np.uint8).reshape(rd.shape + (52,)))
+    d_sd = dev(sd.view(np.uint8).reshape(sd.shape + (48,)))
+    d_pairs = dev(pairs)
+    paired = sorted(pairs.reshape(-1))
+    # two launches
+    xr = Mp3Requantize(ctx, sr).requantize(d_q, d_rd)
+    Mp3Stereo(ctx, sr).stereo(xr, d_pairs, d_sd)
+    assert bit_equal(host(xr)[paired], want[paired]), (sr, n_pairs, granules)
+    # one launch
+    xr2 = torch.full(q.shape, 7.0, device="cuda")
+    Mp3Stereo(ctx, sr).requantize_stereo(d_q, d_rd, d_pairs, d_sd, xr2)
+    got = host(xr2)
+    assert bit_equal(got[paired], want[paired]) and (got[mono] == 7.0).all(), (sr, n_pairs, granules)
+
+
+@pytest.mark.parametrize("it", range(ITERS))
+def test_fuzz_aac_tools(ctx, it):
+    from symphonia_amd import AacSpectralTools
+    import test_aac_tools as T
+    rng = np.random.default_rng(9500 + it)
+    n_pairs, frames = int(rng.choice([1, 2, 7])), int(rng.choice([1, 3, 20]))
+    chains = 2 * n_pairs + 1
+    coeffs = rng.standard_normal((chains, frames, 1024)).astype(np.float32)
+    order = rng.permutation(chains)
+    pairs = np.array([[order[2 * p], order[2 * p + 1]] for p in range(n_pairs)], np.int32)
+    desc = np.array([[T.js_frame(rng, short=bool(rng.integers(0, 3) == 0)) for _ in range(frames)] for _ in pairs])
+    _, filt = T.tns_case(rng, chains * frames, int(rng.choice([1, 10, 200])))
+    want_js = T.js_reference(coeffs, pairs, desc)
+    want = T.tns_reference(want_js.reshape(-1, 1024), filt, chains * frames).reshape(coeffs.shape)
+    tools = AacSpectralTools(ctx, T.SWB_LONG, T.SWB_SHORT)
+    d = dev(coeffs)
+    tools.joint_stereo(d, dev(pairs), dev(desc.view(np.uint8).reshape(n_pairs, frames, 644)))
+    assert bit_equal(host(d), want_js), (n_pairs, frames)
+    tools.tns(d, dev(filt.view(np.uint8).reshape(-1, 92)))
+    assert bit_equal(host(d), want), (n_pairs, frames, len(filt))
