@@ -24,6 +24,22 @@ def shard_chains(n_chains, channels_per_stream, world_size, rank):
     return b * channels_per_stream, e * channels_per_stream
 
 
+def local_pairs(pair_chains, chain_begin, chain_end):
+    """The channel pairs (rows of pair_chains, global chain indices) that live on a rank owning chains
+    [chain_begin, chain_end), re-indexed to that rank's local chain numbers, plus their row indices in the global
+    list (to slice the per-pair descriptors).  shard_chains keeps the channels of a stream together, so a pair is
+    either wholly inside or wholly outside the range; anything else is a caller error."""
+    rows, local = [], []
+    for i, (c0, c1) in enumerate(pair_chains):
+        inside = (chain_begin <= c0 < chain_end, chain_begin <= c1 < chain_end)
+        if inside[0] != inside[1]:
+            raise ValueError("pair (%d, %d) straddles the shard [%d, %d)" % (c0, c1, chain_begin, chain_end))
+        if inside[0]:
+            rows.append(i)
+            local.append((int(c0) - chain_begin, int(c1) - chain_begin))
+    return rows, local
+
+
 def max_over_ranks(seconds, dist=None, device=None):
     """The bench clock: the slowest rank's time (bench.py contract)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

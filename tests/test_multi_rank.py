@@ -11,7 +11,7 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 
-from symphonia_amd.sharding import shard_chains, shard_streams  # noqa: E402
+from symphonia_amd.sharding import local_pairs, shard_chains, shard_streams  # noqa: E402
 
 
 def test_shard_arithmetic():
@@ -26,6 +26,42 @@ def test_shard_arithmetic():
         shard_chains(7, 2, 2, 0)
     with pytest.raises(ValueError):
         shard_streams(4, 2, 2)
+
+
+def test_channel_pairs_follow_their_streams():
+    """The joint-stereo stages take (left chain, right chain) pairs: sharding by whole streams keeps every pair on one
+    rank, and local_pairs re-indexes them (and says which descriptor rows go with them)."""
+    pairs = [(2 * s, 2 * s + 1) for s in range(7)]  # 7 stereo streams = 14 chains
+    seen = []
+    for r in range(3):
+        b, e = shard_chains(14, 2, 3, r)
+        rows, local = local_pairs(pairs, b, e)
+        assert all(0 <= c0 < e - b and c1 == c0 + 1 for c0, c1 in local)
+        assert [pairs[i][0] - b for i in rows] == [c0 for c0, _ in local]
+        seen += rows
+    assert sorted(seen) == list(range(7))
+    with pytest.raises(ValueError):
+        local_pairs([(3, 4)], 0, 4)  # a pair cut by the shard boundary
+
+
+def test_two_ranks_shard_the_mp3_front_stage():
+    """requantize + stereo on two 'ranks' (shards run one after the other through the CPU emulation): the union of the
+    shards equals the whole batch -- no rank needs anything from another."""
+    from emu_lib import emu_library
+    from symphonia_amd import Context, Mp3Stereo
+    from test_mp3_stereo import fused_case
+    q, rd, pairs, sd, want, _ = fused_case(5, 0, 3, 4)          # 7 chains, 3 pairs in scrambled order
+    flat = pairs.reshape(-1)                                    # lay the batch out stream by stream: (L, R) adjacent
+    q2, rd2, want2 = q[flat], rd[flat], want[flat]              # chains 0..5 = pair 0 L, R, pair 1 L, R, ...
+    pairs2 = [(2 * p, 2 * p + 1) for p in range(3)]
+    with Context(0, library=emu_library()) as ctx:
+        for r in range(2):
+            b, e = shard_chains(6, 2, 2, r)
+            rows, local = local_pairs(pairs2, b, e)
+            xr = np.zeros((e - b,) + q2.shape[1:], np.float32)
+            Mp3Stereo(ctx, 0).requantize_stereo(np.ascontiguousarray(q2[b:e]), np.ascontiguousarray(rd2[b:e]),
+                                                np.array(local, np.int32), np.ascontiguousarray(sd[rows]), xr)
+            assert np.array_equal(xr.view(np.uint32), want2[b:e].view(np.uint32)), r
 
 
 def _worker(rank, world, port, q):
