@@ -32,16 +32,17 @@ def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
-def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0):
+def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
     """Returns (step_fn, units_per_step, unit_name, algorithmic_bytes_per_step, description, kernel_name, output tensor)."""
     import symphonia_amd as sa
-    g = torch.Generator(device="cuda").manual_seed(seed)
+    dev = "cpu" if emulate else "cuda"
+    g = torch.Generator(device=dev).manual_seed(seed)
     if name == "aac":
-        nch, nfr = int(128 * scale), 1024  # 64 stereo streams x 1024 frames = 65 536 frames
-        coeffs = torch.randn((nch, nfr, 1024), generator=g, device="cuda", dtype=torch.float32)
-        coeffs *= torch.exp2(torch.randint(-8, 13, (nch, nfr, 64), generator=g, device="cuda").float()).repeat_interleave(16, dim=2)
+        nch, nfr = int(128 * scale), (6 if emulate else 1024)  # 64 stereo streams x 1024 frames = 65 536 frames
+        coeffs = torch.randn((nch, nfr, 1024), generator=g, device=dev, dtype=torch.float32)
+        coeffs *= torch.exp2(torch.randint(-8, 13, (nch, nfr, 64), generator=g, device=dev).float()).repeat_interleave(16, dim=2)
         coeffs[:, :, 672:] = 0.0  # 48 kHz content: band-limited like a real encoder's output
-        side = torch.full((nch, nfr), int(sa.aac_side(0, 1, 1)), dtype=torch.uint8, device="cuda")
+        side = torch.full((nch, nfr), int(sa.aac_side(0, 1, 1)), dtype=torch.uint8, device=dev)
         if mix > 0.0:  # development: a legal window-sequence walk with block switching (the headline is all ONLY_LONG)
             rng = np.random.default_rng(seed)
             sd = np.empty((nch, nfr), np.uint8)
@@ -52,20 +53,22 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0):
                     shape = int(rng.integers(0, 2))
                     sd[c, t] = int(sa.aac_side(cur, shape, prev_shape))
                     prev_shape = shape
-            side = torch.from_numpy(sd).cuda()
-        delay = torch.zeros((nch, 1024), device="cuda", dtype=torch.float32)
+            side = torch.from_numpy(sd).to(dev)
+        delay = [torch.zeros((nch, 1024), device=dev, dtype=torch.float32) for _ in range(2)]  # ping-pong state buffers
         pcm = torch.empty_like(coeffs)
         dsp = sa.AacDsp(ctx)
 
         def step():
-            dsp.synth(coeffs, side, delay, pcm)
+            dsp.synth(coeffs, side, delay[0], pcm, delay_out=delay[1])  # one launch; the next call continues from delay[1]
+            delay.reverse()
+        step.input = coeffs
         frames = nch * nfr // 2
         return step, frames, "frames", nch * nfr * 8192, {
             "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d), 1024-pt IMDCT+window+OLA, KBD"
                         % (frames, nch, nfr), "channel_frames": nch * nfr, "samples_per_frame": 1024}, "aac_synth_kernel", pcm
     if name == "mp3":
-        nch, ngr = int(128 * scale), 2048  # 64 stereo streams x 2048 granules = 131 072 granules
-        xr = torch.randn((nch, ngr, 576), generator=g, device="cuda", dtype=torch.float32) * 0.05
+        nch, ngr = int(128 * scale), (6 if emulate else 2048)  # 64 stereo streams x 2048 granules = 131 072 granules
+        xr = torch.randn((nch, ngr, 576), generator=g, device=dev, dtype=torch.float32) * 0.05
         bt, mx, rz = np.zeros((nch, ngr), np.uint8), np.zeros((nch, ngr), np.uint8), np.full((nch, ngr), 576)
         if mix > 0.0:  # development: Long -> Start -> Short... -> End walks (a quarter of the short runs mixed), random rzero
             rng = np.random.default_rng(seed)
@@ -84,20 +87,22 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0):
                         g += 1
             rz = 2 * rng.integers(100, 289, (nch, ngr))
         side_np = sa.mp3_side(bt, mx, rz)
-        side = torch.from_numpy(side_np.view(np.uint8).reshape(nch, ngr, 4)).cuda()
-        st = [torch.zeros((nch, 576), device="cuda"), torch.zeros((nch, 1024), device="cuda"),
-              torch.zeros(nch, dtype=torch.int32, device="cuda")]
+        side = torch.from_numpy(side_np.view(np.uint8).reshape(nch, ngr, 4)).to(dev)
+        st = [[torch.zeros((nch, 576), device=dev), torch.zeros((nch, 1024), device=dev),
+               torch.zeros(nch, dtype=torch.int32, device=dev)] for _ in range(2)]  # ping-pong state buffers
         pcm = torch.empty_like(xr)
         syn = sa.Mp3Synthesis(ctx, 0)
 
         def step():
-            syn.synth(xr, side, st[0], st[1], st[2], pcm)
+            syn.synth(xr, side, st[0][0], st[0][1], st[0][2], pcm, state_out=st[1])
+            st.reverse()
+        step.input = xr
         granules = nch * ngr // 2
         return step, granules, "granules", nch * ngr * 4608, {
             "workload": "MP3 Layer III 44.1 kHz stereo, %d long-block granules (%d chains x %d), hybrid synthesis + polyphase"
                         % (granules, nch, ngr), "granule_channels": nch * ngr, "samples_per_granule": 576}, "mp3_synth_kernel", pcm
     if name == "vorbis":
-        nch, nb = int(64 * scale), 4096  # one GPU's shard of config 4: 8 streams x 8 ch x 4096 blocks
+        nch, nb = int(64 * scale), (16 if emulate else 4096)  # one GPU's shard of config 4: 8 streams x 8 ch x 4096 blocks
         rng = np.random.default_rng(seed)
         flags = np.zeros((nch, nb), np.uint8)
         cur = np.ones(nch, bool)
@@ -108,43 +113,41 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0):
         v = sa.VorbisDsp(ctx, 8, 11)
         so, po = v.layout(flags, np.full(nch, -1))
         spec_stride, pcm_stride = int(so[:, -1].max()), int(po[:, -1].max())
-        spectra = torch.randn((nch, spec_stride), generator=g, device="cuda", dtype=torch.float32) * 0.1
-        d_flags = torch.from_numpy(flags).cuda()
-        prev = torch.full((nch,), -1, dtype=torch.int32, device="cuda")
-        overlap = torch.zeros((nch, 1024), device="cuda")
-        pcm = torch.zeros((nch, pcm_stride), device="cuda")
+        spectra = torch.randn((nch, spec_stride), generator=g, device=dev, dtype=torch.float32) * 0.1
+        d_flags = torch.from_numpy(flags).to(dev)
+        # every step decodes the same packed batch from a fresh stream start (prev flag -1 fixes the packed layout), so the
+        # incoming state is constant and the outgoing state goes to the second buffer: one launch per step
+        prev = [torch.full((nch,), -1, dtype=torch.int32, device=dev), torch.zeros((nch,), dtype=torch.int32, device=dev)]
+        overlap = [torch.zeros((nch, 1024), device=dev) for _ in range(2)]
+        pcm = torch.zeros((nch, pcm_stride), device=dev)
 
         def step():
-            prev.fill_(-1)
-            v.synth(spectra, d_flags, prev, overlap, pcm_stride, pcm)
+            v.synth(spectra, d_flags, prev[0], overlap[0], pcm_stride, pcm, state_out=(prev[1], overlap[1]))
+        step.input = spectra
         bytes_alg = int(4 * (so[:, -1].sum() + po[:, -1].sum()))
         return step, nch * nb // 8, "frames", bytes_alg, {
             "workload": "Vorbis 2048/256 mixed block sizes, 8 ch, %d blocks (%d chains x %d)" % (nch * nb // 8, nch, nb),
             "channel_blocks": nch * nb}, "vorbis_synth_wave_kernel", pcm
     if name == "flac":
-        nb, bs = int(262144 * scale), 4096  # 1/4 of config 5 per step (4 GiB in place; the full 1 M blocks = 16 GiB)
-        buf = torch.randint(-(1 << 12), 1 << 12, (nb, bs), generator=g, device="cuda", dtype=torch.int32)
-        desc_np = sa.flac_desc(np.full(nb, 2), np.full(nb, 32), np.full(nb, 12), np.zeros(nb))
-        desc = torch.from_numpy(desc_np.view(np.uint8).reshape(nb, 4)).cuda()
-        co = torch.randint(-40, 40, (nb, 32), generator=g, device="cuda", dtype=torch.int32)
-        co[:, 0] = int(1.6 * 4096)
-        co[:, 1] = int(-0.7 * 4096)
+        nb, bs = int(1048576 * scale) & ~1, 4096  # config 5: 1 M subframe blocks of 4096 samples = 16 GiB, in place
+        buf, desc, co, pair_mode, _ = flac_config5(torch, nb, bs, seed, dev)
         fp = sa.FlacPredictor(ctx)
 
         def step():
-            # The restore is in place, so every step after the first predicts over the previous step's
-            # output.  That is still one full pass of the recurrence over the batch: the kernel has no
-            # data-dependent control flow and the arithmetic wraps, so the time per pass is the same.
-            fp.restore(buf, desc, co)
+            # In place, so every step after the first predicts over the previous step's output.  That is still one full
+            # pass of the recurrence + decorrelation over the batch: the kernel has no data-dependent control flow (the
+            # f64 / i64 path is chosen from the coefficients alone) and the arithmetic wraps, so every pass costs the same.
+            fp.restore_stereo(buf, desc, co, pair_mode, 8)
         return step, nb, "blocks", nb * bs * 8, {
-            "workload": "FLAC 24-bit, LPC order 32 (15-bit coefficients, shift 12), %d subframe blocks of 4096 samples, "
-                        "in place" % nb, "samples": nb * bs}, "flac_restore_f64_kernel", buf
+            "workload": "FLAC 24-bit 192 kHz, LPC order 32 (15-bit quantised coefficients of random AR models, shift 10..14), "
+                        "%d subframe blocks of 4096 samples, half the channel pairs mid/side (side channel 25 bits), "
+                        "restore + decorrelate + left-justify fused, in place" % nb, "samples": nb * bs}, "flac_restore_f64_kernel", buf
     if name == "alac":
         nb, bs = int(262144 * scale), 4096  # 16-bit ALAC frames of 4096 samples, adaptive predictor of order 8
-        buf = torch.randint(-(1 << 9), 1 << 9, (nb, bs), generator=g, device="cuda", dtype=torch.int32)
+        buf = torch.randint(-(1 << 9), 1 << 9, (nb, bs), generator=g, device=dev, dtype=torch.int32)
         desc_np = sa.alac_desc(np.zeros(nb), np.full(nb, 8), np.full(nb, 9), np.full(nb, 16))
-        desc = torch.from_numpy(desc_np.view(np.uint8).reshape(nb, 4)).cuda()
-        co = torch.randint(-200, 200, (nb, 32), generator=g, device="cuda", dtype=torch.int32)
+        desc = torch.from_numpy(desc_np.view(np.uint8).reshape(nb, 4)).to(dev)
+        co = torch.randint(-200, 200, (nb, 32), generator=g, device=dev, dtype=torch.int32)
         ap = sa.AlacPredictor(ctx)
 
         def step():
@@ -153,6 +156,71 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0):
             "workload": "ALAC 16-bit, adaptive LPC order 8 (shift 9), %d element-channel blocks of 4096 samples, in place" % nb,
             "samples": nb * bs}, "alac_predict_kernel", buf
     raise ValueError(name)
+
+
+def flac_config5(torch, nb, bs, seed, dev, chunk=32768):
+    """SURVEY 8d config 5 data, generated on the device: per block a 24-bit signal (25-bit for the side channel of a
+    mid/side pair), the 15-bit quantised coefficients of a random stable AR(32) model with shift 10..14, and the
+    residual of the forward predictor (FIR over the signal: decoder.rs:716-752 run backwards), so that restoring the
+    block must give the signal back exactly.  Blocks 2p / 2p+1 are the channels of pair p; odd pairs are mid/side.
+    Returns (buf[nb, bs] i32 = 32 warm-up samples then residuals, desc[nb, 4] u8, coeffs[nb, 32] i32, pair_mode[nb/2] u8,
+    expect(b0, b1) -> the i32 samples blocks [b0, b1) must decode to after decorrelation and `<< 8`)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    order = 32
+    shift = torch.randint(10, 15, (nb,), generator=g, device=dev, dtype=torch.int64)
+    # random stable AR(32): reflection coefficients shrinking with the order, stepped up to direct form (Levinson)
+    k = (torch.rand((nb, order), generator=g, device=dev, dtype=torch.float64) * 2 - 1) * 0.9 * (0.8 ** torch.arange(order, device=dev, dtype=torch.float64))
+    a = torch.zeros((nb, order), device=dev, dtype=torch.float64)
+    for i in range(order):
+        prev = a[:, :i].clone()
+        a[:, :i] = prev - k[:, i:i + 1] * prev.flip(1)
+        a[:, i] = k[:, i]
+    # the AR model x[i] = -sum a[j] x[i-1-j] + e[i] predicts with coefficients -a
+    co = torch.clamp(torch.round(-a * torch.exp2(shift.double())[:, None]), -16383, 16383).to(torch.int64)  # qlp precision 15
+    pair_mode = torch.zeros(nb // 2, dtype=torch.uint8, device=dev)
+    pair_mode[1::2] = 2  # decorrelate_mid_side
+    t = torch.arange(bs, device=dev, dtype=torch.float32)
+    buf = torch.empty((nb, bs), dtype=torch.int32, device=dev)
+
+    def signal(b0, b1):
+        """the PCM of blocks [b0, b1) as the subframes carry it (mid / side for the odd pairs), int64"""
+        gs = torch.Generator(device=dev).manual_seed(seed * 1000003 + b0)
+        n = b1 - b0
+        f = torch.rand((n, 3), generator=gs, device=dev) * 0.2 + 0.001
+        ph = torch.rand((n, 3), generator=gs, device=dev) * 6.2831853
+        amp = torch.tensor([0.55, 0.3, 0.1], device=dev) * float(1 << 23)
+        x = sum(amp[j] * torch.sin(f[:, j:j + 1] * t[None, :] + ph[:, j:j + 1]) for j in range(3))
+        x = x + torch.randn((n, bs), generator=gs, device=dev) * 3000.0
+        x = torch.clamp(torch.round(x), -(1 << 23), (1 << 23) - 1).to(torch.int64)  # left / right, 24 bit
+        ms = (torch.arange(b0, b1, device=dev) // 2) % 2 == 1
+        left, right = x[0::2].clone(), x[1::2].clone()
+        mid, side = (left + right) >> 1, left - right
+        msp = ms[0::2]
+        x[0::2] = torch.where(msp[:, None], mid, left)
+        x[1::2] = torch.where(msp[:, None], side, right)
+        return x, left, right
+
+    assert chunk % 2 == 0
+    for b0 in range(0, nb, chunk):
+        b1 = min(nb, b0 + chunk)
+        x, _, _ = signal(b0, b1)
+        pred = torch.zeros_like(x)
+        for j in range(order):  # pred[i] = sum_j co[j] * x[i - 1 - j]
+            pred[:, order:] += co[b0:b1, j:j + 1] * x[:, order - 1 - j:bs - 1 - j]
+        res = x - (pred >> shift[b0:b1, None])
+        res[:, :order] = x[:, :order]  # warm-up samples are stored verbatim
+        buf[b0:b1] = ((res + (1 << 31)) % (1 << 32) - (1 << 31)).to(torch.int32)
+    desc = torch.zeros((nb, 4), dtype=torch.uint8, device=dev)
+    desc[:, 0], desc[:, 1], desc[:, 2] = 2, order, shift.to(torch.uint8)
+
+    def expect(b0, b1):
+        assert b0 % chunk == 0 and b1 <= min(nb, b0 + chunk)  # signal() is seeded per generation chunk
+        _, left, right = signal(b0, min(nb, b0 + chunk))
+        out = torch.empty((2 * left.shape[0], bs), dtype=torch.int64, device=dev)
+        out[0::2], out[1::2] = left, right
+        return ((out[: b1 - b0] << 8) + (1 << 31)) % (1 << 32) - (1 << 31)
+
+    return buf, desc, co.to(torch.int32), pair_mode, expect
 
 
 def usable_cores():
@@ -219,6 +287,36 @@ def cpu_baseline(name, seconds=10.0):
                       + sample + " per task; %d tasks on %d threads in %.1f s" % (reps, cores, dt)}
 
 
+def workload_input(name, step):
+    """The spectra tensor a step consumes (what a one-to-all scatter would have to move)."""
+    return step.input
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with no launcher in the environment: start N ranks ourselves (one process per GPU) with
+    torch.distributed.run on the loopback address and hand its exit status back.  (The driver may also start the ranks
+    itself -- `python -m torch.distributed.run ... bench.py --gpus N` -- in which case WORLD_SIZE is set and we are a rank.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    log("no launcher in the environment: starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def device_identity(torch, local_rank, emulate):
+    """Something that differs between two physical GPUs (PCI bus id via the UUID when the runtime gives one)."""
+    if emulate:
+        return "emulated-%d" % local_rank
+    props = torch.cuda.get_device_properties(local_rank)
+    uuid = getattr(props, "uuid", None)
+    return "%s|%s|%s" % (props.name, uuid if uuid is not None else "no-uuid", getattr(props, "pci_bus_id", local_rank))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,7 +330,17 @@ def main():
                     help="development: probability of a block switch per long frame / granule in the AAC and MP3 workloads (headline: 0)")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1 only: also time an RCCL all_gather of the PCM shards (reported beside, never inside, `value`)")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N > 1: skip the scatter -> synthesis -> gather leg (reported beside, never inside, `value`)")
+    ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the extra BASELINE config-4 (Vorbis shard) line")
+    ap.add_argument("--emulate", action="store_true",
+                    help="TEST ONLY: run the control flow on CPU tensors through the CPU emulation build of the kernels "
+                         "(tests/emu) with gloo; its numbers mean nothing")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     import faulthandler
     faulthandler.enable()
     faulthandler.dump_traceback_later(170, repeat=True, file=sys.stderr)  # a hang leaves a stack in the log
@@ -240,55 +348,97 @@ def main():
     import torch
     import torch.distributed as dist
     import symphonia_amd as sa
-    from symphonia_amd.sharding import max_over_ranks
+    from symphonia_amd.sharding import max_over_ranks, timed_exchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: symphonia_amd has no CPU path")
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: the launcher must start one rank per GPU" % (args.gpus, world))
+    emulate = args.emulate
     # Development smoke test of the N > 1 control flow on a one-GPU box (SYM_BENCH_ONE_GPU_SMOKE=1): every rank shares
-    # cuda:0 and the two tiny reductions go through gloo on the host.  Never set by the driver; its numbers mean nothing.
+    # cuda:0 and the collectives go through gloo on the host.  Never set by the driver; its numbers mean nothing.
     one_gpu_smoke = os.environ.get("SYM_BENCH_ONE_GPU_SMOKE") == "1"
-    if one_gpu_smoke:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+    if emulate:
+        sys.path.insert(0, str(ROOT / "tests"))
+        from emu_lib import emu_library
+        library = emu_library()
+        args.scale = min(args.scale, 1.0 / 32)
+    else:
+        library = None
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs an MI355X: symphonia_amd has no CPU path")
         if one_gpu_smoke:
+            local_rank = 0
+        elif torch.cuda.device_count() < world:
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (world, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+    host_collectives = emulate or one_gpu_smoke
+    if world > 1:
+        if host_collectives:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    red_dev = "cpu" if host_collectives else "cuda"
 
-    ctx = sa.Context(local_rank)
-    ctx.use_torch_stream()
+    def sync():
+        if not emulate:
+            torch.cuda.synchronize()
+
+    # every rank must sit on its own GPU
+    ident = device_identity(torch, local_rank, emulate)
+    idents = [ident]
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if len(set(idents)) != world and not one_gpu_smoke:
+            sys.exit("bench.py: ranks share a device: %r" % (idents,))
+
+    ctx = sa.Context(0 if emulate else local_rank, library=library)  # (the emulation has one 'device')
+    if not emulate:
+        ctx.use_torch_stream()
     if args.segment:
         ctx.set_segment(args.segment)
-    step, units, unit_name, alg_bytes, config, kernel, result = make_workload(args.workload, torch, ctx, 1234 + rank, args.scale, args.aac_mix)
 
+    def timed(step, steps, warmup):
+        """(wall seconds for `steps` steps = max over ranks, mean launch period on this rank's launch stream, this rank's wall)"""
+        for _ in range(warmup):
+            step()
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        # One HIP event pair around the K launches (on the launch stream; the context uses torch's current stream).
+        # Per-step event pairs would put ~40 us of signal traffic between consecutive launches.
+        if not emulate:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        if not emulate:
+            ev0.record()
+        for _ in range(steps):
+            step()
+        if not emulate:
+            ev1.record()
+        sync()
+        mine = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        sync()
+        elapsed = time.perf_counter() - t0
+        elapsed = max_over_ranks(elapsed, dist if world > 1 else None, device=red_dev)
+        launch_s = (ev0.elapsed_time(ev1) / 1e3 if not emulate else mine) / steps
+        return elapsed, launch_s, mine
+
+    step, units, unit_name, alg_bytes, config, kernel, result = make_workload(args.workload, torch, ctx, 1234 + rank, args.scale,
+                                                                              args.aac_mix, emulate)
     log("workload built: %s" % config["workload"])
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    log("warmup done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # One HIP event pair around the K launches (on the launch stream; the context uses torch's current stream).
-    # Per-step event pairs would put ~40 us of signal traffic between consecutive launches.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dist if world > 1 else None, device="cpu" if one_gpu_smoke else "cuda")
-    launch_s = ev0.elapsed_time(ev1) / 1e3 / args.steps  # mean launch period of the hot-path kernel(s)
+    elapsed, launch_s, mine = timed(step, args.steps, args.warmup)
     log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))
+    per_rank_ms = [mine / args.steps * 1e3]
+    if world > 1:
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, mine / args.steps * 1e3)
 
     gather = None
     if args.gather and world > 1:
@@ -296,6 +446,27 @@ def main():
         secs, nbytes = timed_all_gather(result, dist)
         gather = {"op": "all_gather of every rank's PCM shard (RCCL over xGMI)", "ms": secs * 1e3, "bytes_per_rank": nbytes,
                   "algbw_GBps": nbytes * world / secs / 1e9}
+
+    # the same batch when it starts and ends on ONE rank -- scatter of the input shards from rank 0, the
+    # synthesis step, gather of the PCM shards on rank 0.  Reported beside `value` (which is (i): shards resident per GPU).
+    exchange = None
+    if world > 1 and not args.no_exchange and args.workload in ("aac", "mp3", "vorbis"):
+        src = workload_input(args.workload, step)
+        secs = timed_exchange(src, result, step, dist, sync, device=red_dev, reps=2 if emulate else 3)
+        exchange = {"op": "scatter of input shards from rank 0 + synthesis + gather of PCM shards on rank 0 (RCCL over xGMI)",
+                    "ms": {k: v * 1e3 for k, v in secs.items()},
+                    "bytes_per_rank": {"in": src.numel() * src.element_size(), "out": result.numel() * result.element_size()},
+                    "value_inclusive": units * world / secs["total"], "unit": unit_name + "/s"}
+
+    # BASELINE config 4 is the one the north star phrases as an 8-GPU job (64 streams x 8 ch sharded 8 streams per GPU):
+    # with N > 1 and another headline workload, add its line (same timing discipline, fewer steps) beside the headline.
+    config4 = None
+    if world > 1 and not args.no_config4 and args.workload != "vorbis":
+        st4, units4, unit4, bytes4, cfg4, kernel4, _ = make_workload("vorbis", torch, ctx, 4321 + rank, args.scale, 0.0, emulate)
+        e4, l4, _ = timed(st4, max(2, args.steps // 2), 1 if emulate else 2)
+        n4 = max(2, args.steps // 2)
+        config4 = {"value": units4 * world * n4 / e4, "unit": unit4 + "/s", "ms_per_step": e4 / n4 * 1e3, "steps": n4,
+                   "config": cfg4, "roofline_frac_rank0": bytes4 / l4 / 1e9 / HBM_PEAK_GBS, "kernel": kernel4}
 
     if rank == 0:
         achieved = alg_bytes / launch_s / 1e9
@@ -313,16 +484,23 @@ def main():
             "vs_baseline": None,
             "dtype": "i32/i64" if args.workload == "flac" else ("i32" if args.workload == "alac" else "f32"),
             "data": "synthetic",
-            "config": dict(config, parallelism="chains sharded per GPU, no collective", segment=args.segment or "auto"),
+            "config": dict(config, parallelism="chains sharded per GPU, no data-path collective", segment=args.segment or "auto"),
+            "ranks": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
+                      "devices": idents, "ms_per_step_per_rank": per_rank_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,
-                         "kernel_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms_note": "mean launch period over the timed region, HIP events on the launch stream; "
+                                           "one kernel launch per step (ping-pong state buffers)"},
+            "library": {"path": str(ctx.lib.path), "build": ctx.lib.build_flags()},
         }
+        if emulate:
+            out["data"] = "synthetic (EMULATED on CPU: control-flow test, not a measurement)"
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json), if measured
             tr = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text()).get(args.workload)
             if tr and tr["algorithmic_bytes_per_launch"] == alg_bytes:
                 out["roofline"]["traffic"] = tr["bytes_per_launch"]
-                out["roofline"]["traffic_source"] = tr["source"]
+                out["roofline"]["traffic_source"] = tr["source"] + " (a committed rocprofv3 PMC measurement of this command, not taken in this run)"
         except (OSError, ValueError, KeyError):
             pass
         out["roofline"]["copy_ceiling_note"] = ("a plain copy of the same 1:1 read/write footprint reaches 5.1-5.9 TB/s on "
@@ -333,7 +511,11 @@ def main():
             out["roofline"]["note"] = "FP64-FMA-issue bound (32 exact FMAs per 8 B), not HBM (DESIGN.md 4.5)"
         if gather:
             out["collective"] = gather
-        if world == 1 and not args.no_cpu_baseline:
+        if exchange:
+            out["exchange"] = exchange
+        if config4:
+            out["config4_vorbis"] = config4
+        if world == 1 and not args.no_cpu_baseline and not emulate:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))
     ctx.close()

@@ -16,6 +16,13 @@
  *  - State buffers (`*_io`) are read at the first frame of the batch and hold the state after the
  *    last frame on return, so consecutive calls continue a stream exactly like consecutive
  *    decode() calls on the reference decoder.  reset() in the reference == zero the state.
+ *    The `_pp_device` ("ping-pong") variants take the incoming and the outgoing state as two
+ *    DISTINCT buffers (aliasing is rejected): a streaming caller keeps two state buffers and swaps
+ *    them after every call.  They are a single kernel launch; the `_io` variants, whose segments of
+ *    one chain run concurrently while one reads and another writes the state, stage the new state in
+ *    context scratch and add one small copy kernel.
+ *  - A context is bound to ONE stream at a time: symaccel_ctx_set_stream() drains the previous
+ *    stream before switching.  Entry points leave the calling thread's current HIP device unchanged.
  *  - Return value: SYMACCEL_OK (0) or a negative symaccel_status.  INVALID_ARG corresponds to the
  *    reference's assert!/panic class, UNSUPPORTED to Error::Unsupported, DEVICE/OOM to
  *    Error::IoError (symphonia-core/src/errors.rs:38-54).  symaccel_strerror() returns static
@@ -36,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SYMACCEL_ABI_VERSION 1
+#define SYMACCEL_ABI_VERSION 2 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging */
 
 typedef enum symaccel_status {
     SYMACCEL_OK = 0,
@@ -69,12 +76,14 @@ int symaccel_ctx_set_segment(symaccel_ctx *ctx, int frames_per_segment);
 
 /* Fft::fft / Fft::fft_inplace (symphonia-core/src/dsp/fft/no_simd.rs:96-140): `count` forward
  * complex FFTs of size n (power of two, 2 <= n <= 4096), interleaved (re, im) f32.
- * d_in == d_out is allowed (fft_inplace). */
+ * d_in == d_out is allowed (fft_inplace).  4096 < n <= 65536 (legal in the reference, unused by its codecs):
+ * SYMACCEL_ERR_UNSUPPORTED. */
 int symaccel_fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count);
 int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count);
 
 /* Imdct::new_scaled(n, scale).imdct(spec, out) (symphonia-core/src/dsp/mdct.rs:35-146), `count`
- * times: spec[count][n] -> out[count][2n].  n = power of two, 4 <= n <= 8192. */
+ * times: spec[count][n] -> out[count][2n].  n = power of two, 4 <= n <= 8192 (8192 < n <= 131072:
+ * SYMACCEL_ERR_UNSUPPORTED). */
 int symaccel_imdct_f32_device(symaccel_ctx *ctx, int n, double scale, const float *d_spec,
                               float *d_out, size_t count);
 int symaccel_imdct_f32(symaccel_ctx *ctx, int n, double scale, const float *h_spec, float *h_out,
@@ -99,6 +108,10 @@ int symaccel_aac_synth_device(symaccel_ctx *ctx, const float *d_coeffs, const ui
                               size_t frames_per_chain);
 int symaccel_aac_synth(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *h_side,
                        float *h_delay_io, float *h_pcm, size_t n_chains, size_t frames_per_chain);
+/* The same with the delay lines as separate in / out buffers (d_delay_in != d_delay_out): one launch. */
+int symaccel_aac_synth_pp_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side,
+                                 const float *d_delay_in, float *d_delay_out, float *d_pcm,
+                                 size_t n_chains, size_t frames_per_chain);
 
 /* Spectral tools between the spectrum decoder and Dsp::synth, in place on coeffs[chain][frame][1024].
  *
@@ -171,6 +184,12 @@ int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_
                        int sample_rate_idx, float *h_overlap_io, float *h_vvec_io,
                        int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
                        size_t granules_per_chain);
+/* The same with SynthesisState / overlap as separate in / out buffers (pairwise distinct): one launch. */
+int symaccel_mp3_synth_pp_device(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_side,
+                                 int sample_rate_idx, const float *d_overlap_in, const float *d_vvec_in,
+                                 const int32_t *d_vfront_in, float *d_overlap_out, float *d_vvec_out,
+                                 int32_t *d_vfront_out, float *d_pcm, size_t n_chains,
+                                 size_t granules_per_chain);
 
 /* Requantisation, the stage in front of stereo + the synthesis tail: the value mapping of
  * read_huffman_samples (layer3/requantize.rs:117-147, 172-205, 234: a decoded Huffman sample s becomes
@@ -241,6 +260,9 @@ int symaccel_mpa_polyphase_device(symaccel_ctx *ctx, int n_frames, const float *
                                   int32_t *d_vfront_io, float *d_pcm, size_t n_chains, size_t packets_per_chain);
 int symaccel_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *h_in, float *h_vvec_io,
                            int32_t *h_vfront_io, float *h_pcm, size_t n_chains, size_t packets_per_chain);
+int symaccel_mpa_polyphase_pp_device(symaccel_ctx *ctx, int n_frames, const float *d_in, const float *d_vvec_in,
+                                     const int32_t *d_vfront_in, float *d_vvec_out, int32_t *d_vfront_out,
+                                     float *d_pcm, size_t n_chains, size_t packets_per_chain);
 
 /* --------------------------------------------------------------------------------- Vorbis */
 
@@ -266,6 +288,13 @@ int symaccel_vorbis_synth(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const flo
                           size_t spec_stride, const uint8_t *h_block_flag, int32_t *h_prev_flag_io,
                           float *h_overlap_io, float *h_pcm, size_t pcm_stride, size_t n_chains,
                           size_t blocks_per_chain);
+/* Either of the two above with the state as separate in / out buffers (pairwise distinct): d_residue == NULL means
+ * d_spectra holds floor x residue already, otherwise d_spectra is the floor and the dot product is fused. */
+int symaccel_vorbis_synth_pp_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra,
+                                    const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
+                                    const int32_t *d_prev_flag_in, int32_t *d_prev_flag_out,
+                                    const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
+                                    size_t pcm_stride, size_t n_chains, size_t blocks_per_chain);
 
 /* Inverse coupling (lib.rs:252-278) of `n_pairs` (magnitude, angle) vector pairs of n floats,
  * in place: pair p uses d_residue + mag_index[p]*n and d_residue + ang_index[p]*n.  Pairs are

@@ -4,6 +4,8 @@
 symphonia_amd/libsymaccel.so and raises if it is missing -- there is no CPU path.
 """
 import ctypes as C
+import json
+import os
 from pathlib import Path
 
 import numpy as np
@@ -34,6 +36,7 @@ ABI_SYMBOLS = [
     "symaccel_flac_decorrelate_device", "symaccel_flac_decorrelate", "symaccel_alac_predict_device",
     "symaccel_alac_predict", "symaccel_alac_predict_stereo_device", "symaccel_alac_mid_side_device", "symaccel_alac_mid_side", "symaccel_table_f32", "symaccel_imdct_twiddles",
     "symaccel_fft_twiddles",
+    "symaccel_aac_synth_pp_device", "symaccel_mp3_synth_pp_device", "symaccel_vorbis_synth_pp_device", "symaccel_mpa_polyphase_pp_device",
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
@@ -98,9 +101,20 @@ class Library:
         d.symaccel_alac_predict.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_mid_side_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_mid_side.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_aac_synth_pp_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_mp3_synth_pp_device.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_vorbis_synth_pp_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
+        d.symaccel_mpa_polyphase_pp_device.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_table_f32.argtypes = [_vp, _i, _vp, _sz]
         d.symaccel_imdct_twiddles.argtypes = [_i, _d, _vp]
         d.symaccel_fft_twiddles.argtypes = [_i, _vp]
+
+    def build_flags(self):
+        """The flags stamp symphonia_amd.build wrote beside this library (None if it has none)."""
+        try:
+            return json.loads(Path(str(self.path) + ".flags.json").read_text())
+        except (OSError, ValueError):
+            return None
 
     def check(self, status, ctx=None):
         if status < 0:
@@ -114,7 +128,7 @@ class Library:
 
     # table read-back (host copies; no device needed)
     def table(self, which):
-        buf = np.empty(1024, dtype=np.float32)
+        buf = np.empty(8207, dtype=np.float32)  # the largest table (TABLE_MP3_POW43)
         n = self.check(self.dll.symaccel_table_f32(None, which, buf.ctypes.data, buf.size))
         return buf[:n].copy()
 
@@ -135,5 +149,6 @@ _default = None
 def default_library():
     global _default
     if _default is None:
-        _default = Library()
+        # SYMACCEL_LIB: bind another build of the same ABI (a tuned side build, symphonia_amd/build.py); never a fallback
+        _default = Library(os.environ.get("SYMACCEL_LIB") or None)
     return _default

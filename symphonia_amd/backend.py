@@ -150,9 +150,11 @@ class AacDsp:
     def __init__(self, ctx):
         self.ctx = ctx
 
-    def synth(self, coeffs, side, delay, pcm=None):
+    def synth(self, coeffs, side, delay, pcm=None, delay_out=None):
         """coeffs[chains, frames, 1024], side[chains, frames] u8, delay[chains, 1024] (updated).
-        numpy: returns (pcm, new_delay).  torch: writes pcm / delay in place, returns pcm."""
+        numpy: returns (pcm, new_delay).  torch: writes pcm / delay in place, returns pcm.
+        delay_out (torch, a second state buffer): the ping-pong entry point -- `delay` is only read, the new delay
+        lines go to `delay_out`, one kernel launch; the caller swaps the two buffers for the next call."""
         d = self.ctx.lib.dll
         nch, nfr = int(coeffs.shape[0]), int(coeffs.shape[1])
         assert coeffs.shape[2] == 1024
@@ -162,6 +164,11 @@ class AacDsp:
             assert side.dtype == torch.uint8 and tuple(side.shape) == (nch, nfr) and tuple(delay.shape) == (nch, 1024)
             if pcm is None:
                 pcm = torch.empty_like(coeffs)
+            if delay_out is not None:
+                assert delay_out.is_contiguous() and tuple(delay_out.shape) == (nch, 1024)
+                self.ctx._call(d.symaccel_aac_synth_pp_device, _ptr(coeffs), _ptr(side), _ptr(delay), _ptr(delay_out), _ptr(pcm),
+                               nch, nfr)
+                return pcm
             self.ctx._call(d.symaccel_aac_synth_device, _ptr(coeffs), _ptr(side), _ptr(delay), _ptr(pcm), nch, nfr)
             return pcm
         coeffs = _np(coeffs, np.float32)
@@ -227,7 +234,8 @@ class Mp3Synthesis:
             raise ValueError("sample_rate_idx")
         self.ctx, self.sr = ctx, int(sample_rate_idx)
 
-    def synth(self, xr, side, overlap, v_vec, v_front, pcm=None):
+    def synth(self, xr, side, overlap, v_vec, v_front, pcm=None, state_out=None):
+        """state_out = (overlap_out, v_vec_out, v_front_out): the ping-pong entry point (device buffers only)."""
         d = self.ctx.lib.dll
         nch, ngr = int(xr.shape[0]), int(xr.shape[1])
         assert xr.shape[2] == 576
@@ -235,6 +243,10 @@ class Mp3Synthesis:
             import torch
             if pcm is None:
                 pcm = torch.empty_like(xr)
+            if state_out is not None:
+                self.ctx._call(d.symaccel_mp3_synth_pp_device, _ptr(xr), _ptr(side), self.sr, _ptr(overlap), _ptr(v_vec),
+                               _ptr(v_front), _ptr(state_out[0]), _ptr(state_out[1]), _ptr(state_out[2]), _ptr(pcm), nch, ngr)
+                return pcm
             self.ctx._call(d.symaccel_mp3_synth_device, _ptr(xr), _ptr(side), self.sr, _ptr(overlap), _ptr(v_vec),
                            _ptr(v_front), _ptr(pcm), nch, ngr)
             return pcm
@@ -259,9 +271,10 @@ class MpaPolyphase:
             raise ValueError("n_frames must be 12 (Layer I) or 36 (Layer II)")
         self.ctx, self.n_frames = ctx, int(n_frames)
 
-    def synth(self, samples, v_vec, v_front, pcm=None):
+    def synth(self, samples, v_vec, v_front, pcm=None, state_out=None):
         """samples[chains, packets, 32 * n_frames] sub-band-major; state v_vec[chains, 1024], v_front[chains] i32.
-        numpy: returns (pcm, v_vec, v_front); torch: state updated in place, returns pcm."""
+        numpy: returns (pcm, v_vec, v_front); torch: state updated in place, returns pcm.
+        state_out = (v_vec_out, v_front_out): the ping-pong entry point (device buffers only)."""
         d = self.ctx.lib.dll
         nch, npk = int(samples.shape[0]), int(samples.shape[1])
         assert samples.shape[2] == 32 * self.n_frames
@@ -269,6 +282,10 @@ class MpaPolyphase:
             import torch
             if pcm is None:
                 pcm = torch.empty_like(samples)
+            if state_out is not None:
+                self.ctx._call(d.symaccel_mpa_polyphase_pp_device, self.n_frames, _ptr(samples), _ptr(v_vec), _ptr(v_front),
+                               _ptr(state_out[0]), _ptr(state_out[1]), _ptr(pcm), nch, npk)
+                return pcm
             self.ctx._call(d.symaccel_mpa_polyphase_device, self.n_frames, _ptr(samples), _ptr(v_vec), _ptr(v_front), _ptr(pcm),
                            nch, npk)
             return pcm
@@ -364,7 +381,9 @@ class VorbisDsp:
         po[:, 1:] = np.cumsum((prev_n + bs) // 4, axis=1)
         return so, po
 
-    def synth(self, spectra, block_flag, prev_flag, overlap, pcm_stride, pcm=None):
+    def synth(self, spectra, block_flag, prev_flag, overlap, pcm_stride, pcm=None, state_out=None, residue=None):
+        """state_out = (prev_flag_out, overlap_out): the ping-pong entry point (device buffers only; `residue` fuses the dot
+        product there: spectra is then the floor)."""
         d = self.ctx.lib.dll
         nch, nb = int(block_flag.shape[0]), int(block_flag.shape[1])
         spec_stride = int(spectra.shape[1])
@@ -372,6 +391,12 @@ class VorbisDsp:
             import torch
             if pcm is None:
                 pcm = torch.zeros((nch, pcm_stride), dtype=torch.float32, device=spectra.device)
+            if state_out is not None:
+                self.ctx._call(d.symaccel_vorbis_synth_pp_device, self.bs0_exp, self.bs1_exp, _ptr(spectra),
+                               _ptr(residue) if residue is not None else None, spec_stride, _ptr(block_flag), _ptr(prev_flag),
+                               _ptr(state_out[0]), _ptr(overlap), _ptr(state_out[1]), _ptr(pcm), int(pcm_stride), nch, nb)
+                return pcm
+            assert residue is None
             self.ctx._call(d.symaccel_vorbis_synth_device, self.bs0_exp, self.bs1_exp, _ptr(spectra), spec_stride,
                            _ptr(block_flag), _ptr(prev_flag), _ptr(overlap), _ptr(pcm), int(pcm_stride), nch, nb)
             return pcm

@@ -5,7 +5,15 @@
 hipcc cross-compiles without a GPU.  Flags that matter for parity (DESIGN.md "Arithmetic contract"):
   -ffp-contract=off   no FMA contraction anywhere (Rust never contracts)
   (no fast-math, no -fgpu-flush-denormals-to-zero: f32 denormals stay enabled)
+
+Tuning knobs (development only).  SYMACCEL_TUNE_<NAME>=<int> in the environment becomes -DSYM_<NAME>=<int> for the
+names in TUNING_KNOBS, nothing else in the environment is looked at.  A tuned build never replaces the product library:
+it is written to symphonia_amd/build/tuned/libsymaccel.so (bind it with SYMACCEL_LIB=<path>; bench.py reports the
+flags of whatever library it loaded).  The flags of every build are stamped beside the .so (<so>.flags.json) and are
+part of needs_build().
 """
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -15,10 +23,14 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libsymaccel.so"
-SOURCES = ["tables.cpp", "ctx.cpp", "imdct_generic.hip", "aac.hip", "aac_tools.hip", "mp3.hip", "mpa_polyphase.hip", "mp3_requant.hip", "mp3_stereo.hip", "vorbis.hip", "vorbis_wave.hip", "flac.hip", "alac.hip", "state_copy.hip"]
+TUNED_OUT = HERE / "build" / "tuned" / "libsymaccel.so"
+SOURCES = ["tables.cpp", "ctx.cpp", "imdct_generic.hip", "aac.hip", "aac_tools.hip", "mp3.hip", "mpa_polyphase.hip", "mp3_requant.hip",
+           "mp3_stereo.hip", "vorbis.hip", "vorbis_wave.hip", "flac.hip", "alac.hip", "state_copy.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_NT", "MP3_WAVES", "MP3_VARIANT", "VORBIS_WAVES", "TNS_TILE")
+TUNE_PREFIX = "SYMACCEL_TUNE_"
 
 
 def hipcc():
@@ -28,29 +40,69 @@ def hipcc():
     return exe
 
 
-def needs_build():
-    if not OUT.exists():
+def tuning_defines(env=None):
+    """-DSYM_<NAME>=<int> for every allow-listed SYMACCEL_TUNE_<NAME> in the environment."""
+    env = os.environ if env is None else env
+    out = []
+    for name in TUNING_KNOBS:
+        v = env.get(TUNE_PREFIX + name)
+        if v is None:
+            continue
+        if not v.lstrip("-").isdigit():
+            raise ValueError("%s%s must be an integer, got %r" % (TUNE_PREFIX, name, v))
+        out.append("-DSYM_%s=%d" % (name, int(v)))
+    return out
+
+
+def source_files():
+    return sorted(CSRC.glob("*")) + [HERE.parent / "include" / "symaccel.h"]
+
+
+def flags_record(defines):
+    h = hashlib.sha256()
+    for p in source_files():
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return {"arch": ARCH, "flags": [f for f in FLAGS if f != str(CSRC)], "tuning": list(defines), "sources": SOURCES,
+            "source_sha256": h.hexdigest()}
+
+
+def stamp_path(so):
+    return Path(str(so) + ".flags.json")
+
+
+def read_stamp(so):
+    try:
+        return json.loads(stamp_path(so).read_text())
+    except (OSError, ValueError):
+        return None
+
+
+def needs_build(out=OUT, defines=()):
+    if not Path(out).exists():
         return True
-    t = OUT.stat().st_mtime
-    deps = list(CSRC.glob("*")) + [HERE.parent / "include" / "symaccel.h", Path(__file__)]
-    return any(p.stat().st_mtime > t for p in deps)
-
-
-def tuning_defines():
-    """Build-time tuning knobs (development): SYM_<NAME>=<int> in the environment becomes -DSYM_<NAME>=<int>."""
-    return ["-D%s=%d" % (k, int(v)) for k, v in sorted(os.environ.items()) if k.startswith("SYM_") and v.lstrip("-").isdigit()]
+    have = read_stamp(out)
+    if have is None:
+        # a library without a stamp (built before stamps existed, or shipped alone): fall back to modification times
+        t = Path(out).stat().st_mtime
+        return any(p.stat().st_mtime > t for p in source_files() + [Path(__file__)])
+    return have != flags_record(defines)
 
 
 def build(force=False, verbose=False, save_temps=False):
-    if not force and not needs_build() and not tuning_defines():
-        return OUT
-    objdir = HERE / "build"
-    objdir.mkdir(exist_ok=True)
+    """Build (if needed) and return the path of the library: the product library, or the tuned side build when
+    SYMACCEL_TUNE_* knobs are set."""
+    defines = tuning_defines()
+    out = TUNED_OUT if defines else OUT
+    if not force and not needs_build(out, defines):
+        return out
+    objdir = (HERE / "build" / "tuned" / "obj") if defines else (HERE / "build")
+    objdir.mkdir(parents=True, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         obj = objdir / (src.replace(".", "_") + ".o")
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-x", "hip", *FLAGS, *tuning_defines(), "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-x", "hip", *FLAGS, *defines, "-c", str(CSRC / src), "-o", str(obj)]
         if save_temps:
             cmd += ["-save-temps=obj"]
         if verbose:
@@ -59,8 +111,7 @@ def build(force=False, verbose=False, save_temps=False):
         objs.append(str(obj))
     failed = False
     for src, p in procs:
-        out, _ = p.communicate()
-        text = out.decode(errors="replace")
+        text = p.communicate()[0].decode(errors="replace")
         if p.returncode != 0:
             failed = True
             sys.stderr.write("==== %s failed ====\n%s\n" % (src, text))
@@ -68,9 +119,11 @@ def build(force=False, verbose=False, save_temps=False):
             print(text)
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(OUT), *objs]
-    subprocess.run(cmd, check=True)
-    return OUT
+    tmp = Path(str(out) + ".tmp")  # link beside the target, then rename: a process that has the old file mapped keeps it
+    subprocess.run([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(tmp), *objs], check=True)
+    os.replace(tmp, out)
+    stamp_path(out).write_text(json.dumps(flags_record(defines), indent=1) + "\n")
+    return out
 
 
 if __name__ == "__main__":

@@ -83,6 +83,32 @@ __device__ __forceinline__ void start_window4(const float *sw, int j0, float *w)
 #ifndef SYM_AAC_MIN_WAVES
 #define SYM_AAC_MIN_WAVES 2  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
 #endif
+#ifndef SYM_AAC_PREFETCH
+#define SYM_AAC_PREFETCH 1  // frames of spectral lines in flight ahead of the one being transformed (1 or 2)
+#endif
+#ifndef SYM_AAC_NT
+#define SYM_AAC_NT 0  // 1: non-temporal (streaming) loads of the spectra and stores of the PCM
+#endif
+
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float2 ld_line(const float2 *p) {
+#if SYM_AAC_NT
+    const nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2 *>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_slot(float *frame, int m2, const float (&v)[8]) {
+#if SYM_AAC_NT
+    nt_f4 *o4 = reinterpret_cast<nt_f4 *>(frame);
+    __builtin_nontemporal_store(nt_f4{v[0], v[1], v[2], v[3]}, o4 + m2);
+    __builtin_nontemporal_store(nt_f4{v[4], v[5], v[6], v[7]}, o4 + 255 - m2);
+#else
+    store_slot(frame, m2, v);
+#endif
+}
 __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kernel(
     DevTables tb, const float *__restrict__ coeffs, const uint8_t *__restrict__ side,
     const float *__restrict__ delay_in, float *__restrict__ delay_out, float *__restrict__ pcm,
@@ -135,8 +161,17 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
     {
         const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t_first) * 1024);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) line[s] = src[lane + 64 * s];
+        for (int s = 0; s < 8; ++s) line[s] = ld_line(src + lane + 64 * s);
     }
+#if SYM_AAC_PREFETCH == 2
+    float2 line2[8];  // the frame after that
+    {
+        const long t2 = t_first + 1 < (long)t_end ? t_first + 1 : t_first;
+        const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t2) * 1024);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) line2[s] = ld_line(src + lane + 64 * s);
+    }
+#endif
 
     unsigned sb_next = side[chain_base + (size_t)t_first];  // side bytes are fetched one frame ahead, like the lines
     for (long t = t_first; t < (long)t_end; ++t) {
@@ -165,12 +200,24 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
             }
             wave_sync();
         }
+#if SYM_AAC_PREFETCH == 2
+        // two frames in flight: frame t + 1 (loaded during frame t - 1) moves up, frame t + 2 is requested now
+        if (t + 1 < (long)t_end) sb_next = side[chain_base + (size_t)t + 1];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) line[s] = line2[s];
+        if (t + 2 < (long)t_end) {
+            const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t + 2) * 1024);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) line2[s] = ld_line(src + lane + 64 * s);
+        }
+#else
         if (t + 1 < (long)t_end) {  // prefetch the next frame; it lands while this one is transformed
             sb_next = side[chain_base + (size_t)t + 1];
             const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t + 1) * 1024);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) line[s] = src[lane + 64 * s];
+            for (int s = 0; s < 8; ++s) line[s] = ld_line(src + lane + 64 * s);
         }
+#endif
 
         if (seq != EIGHT_SHORT) {
             fft512_wave(z, lane, lds, lt);
@@ -196,7 +243,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
                     const float v = dl[h][q] + (x[q] * wo[q]);
                     dst[q] = (seq == LONG_STOP && j < kP0) ? dl[h][q] : v;
                 }
-                if (emit) store_slot(frame_out, m2, dst);
+                if (emit) st_slot(frame_out, m2, dst);
                 // ---- delay for the next frame (dsp.rs:132-157): pcm[1024 + j] * long_win[1023 - j] (the
                 // slot's two float4 read backwards), a short-window slope, or literal zero
                 float wd[8];

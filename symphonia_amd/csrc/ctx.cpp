@@ -226,6 +226,7 @@ struct DevBuf {
 };
 
 bool pow2(long v) { return v > 0 && (v & (v - 1)) == 0; }
+constexpr int kMaxFft = 4096;  // largest Fft the generic LDS kernel holds (Imdct: twice that); the reference's limit is 65536
 
 }  // namespace
 }  // namespace symaccel
@@ -259,6 +260,8 @@ int symaccel_ctx_create(int device, symaccel_ctx **out) {
     if (!ctx) return SYMACCEL_ERR_OOM;
     ctx->device = device;
     int st = SYMACCEL_OK;
+    int prev_device = -1;
+    if (hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
         st = SYMACCEL_ERR_DEVICE;
     } else {
@@ -270,25 +273,37 @@ int symaccel_ctx_create(int device, symaccel_ctx **out) {
     }
     if (st != SYMACCEL_OK) {
         symaccel_ctx_destroy(ctx);
-        return st;
+    } else {
+        *out = ctx;
     }
-    *out = ctx;
-    return SYMACCEL_OK;
+    if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);  // the caller's current device stays put
+    return st;
 }
 
 void symaccel_ctx_destroy(symaccel_ctx *ctx) {
     if (!ctx) return;
+    int prev_device = -1;
+    if (hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->allocations) (void)hipFree(p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (prev_device >= 0 && prev_device != ctx->device) (void)hipSetDevice(prev_device);
     delete ctx;
 }
 
 int symaccel_ctx_set_stream(symaccel_ctx *ctx, void *hip_stream) {
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next != ctx->stream) {
+        // The context's scratch (state double buffers of the *_io entry points) is ordered by the stream alone:
+        // work still queued on the old stream must not overlap work on the new one.
+        DeviceGuard dev(ctx);
+        if (!dev.ok()) return dev.status();
+        if (ctx->stream) SYM_GPU(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->stream = next;
+    }
     return SYMACCEL_OK;
 }
 
@@ -307,29 +322,35 @@ int symaccel_ctx_set_segment(symaccel_ctx *ctx, int frames_per_segment) {
 // ---- core ---------------------------------------------------------------------------------
 
 int symaccel_fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count) {
-    if (!ctx || !pow2(n) || n < 2 || n > 4096) return SYMACCEL_ERR_INVALID_ARG;  // no_simd.rs:77-80
+    if (!ctx || !pow2(n) || n < 2 || n > 65536) return SYMACCEL_ERR_INVALID_ARG;  // no_simd.rs:77-80
+    if (n > kMaxFft) return SYMACCEL_ERR_UNSUPPORTED;
     if (count == 0) return SYMACCEL_OK;
     if (!d_in || !d_out) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_fft(ctx, n, d_in, d_out, count);
 }
 
 int symaccel_imdct_f32_device(symaccel_ctx *ctx, int n, double scale, const float *d_spec, float *d_out,
                               size_t count) {
-    if (!ctx || !pow2(n) || n < 4 || n > 8192) return SYMACCEL_ERR_INVALID_ARG;  // mdct.rs:37-40
+    if (!ctx || !pow2(n) || n < 4 || n > 131072) return SYMACCEL_ERR_INVALID_ARG;  // mdct.rs:37-40
+    if (n > 2 * kMaxFft) return SYMACCEL_ERR_UNSUPPORTED;
     if (count == 0) return SYMACCEL_OK;
     if (!d_spec || !d_out) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     const ImdctPlan *plan = nullptr;
     SYM_TRY(get_imdct_plan(ctx, n, scale, &plan));
     return launch_imdct(ctx, *plan, d_spec, d_out, count);
 }
 
 int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count) {
-    if (!ctx || !pow2(n) || n < 2 || n > 4096) return SYMACCEL_ERR_INVALID_ARG;
+    if (!ctx || !pow2(n) || n < 2 || n > 65536) return SYMACCEL_ERR_INVALID_ARG;
+    if (n > kMaxFft) return SYMACCEL_ERR_UNSUPPORTED;
     if (count == 0) return SYMACCEL_OK;
     if (!h_in || !h_out) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     DevBuf buf(ctx);
     const size_t bytes = count * (size_t)n * 8;
     SYM_TRY(buf.from_host(h_in, bytes));
@@ -339,10 +360,12 @@ int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, 
 }
 
 int symaccel_imdct_f32(symaccel_ctx *ctx, int n, double scale, const float *h_spec, float *h_out, size_t count) {
-    if (!ctx || !pow2(n) || n < 4 || n > 8192) return SYMACCEL_ERR_INVALID_ARG;
+    if (!ctx || !pow2(n) || n < 4 || n > 131072) return SYMACCEL_ERR_INVALID_ARG;
+    if (n > 2 * kMaxFft) return SYMACCEL_ERR_UNSUPPORTED;
     if (count == 0) return SYMACCEL_OK;
     if (!h_spec || !h_out) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     DevBuf in(ctx), out(ctx);
     SYM_TRY(in.from_host(h_spec, count * (size_t)n * 4));
     SYM_TRY(out.alloc(count * (size_t)n * 8));
@@ -353,14 +376,27 @@ int symaccel_imdct_f32(symaccel_ctx *ctx, int n, double scale, const float *h_sp
 
 // ---- AAC ----------------------------------------------------------------------------------
 
+int symaccel_aac_synth_pp_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const float *d_delay_in,
+                                 float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
+    if (!d_coeffs || !d_side || !d_delay_in || !d_delay_out || !d_pcm || d_delay_in == d_delay_out) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    // one launch, nothing else: the first segment of a chain reads delay_in, the last one writes delay_out
+    return launch_aac(ctx, d_coeffs, d_side, d_delay_in, d_delay_out, d_pcm, n_chains, frames_per_chain);
+}
+
 int symaccel_aac_synth_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, float *d_delay_io,
                               float *d_pcm, size_t n_chains, size_t frames_per_chain) {
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
     if (!d_coeffs || !d_side || !d_delay_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     // Segments of one chain run concurrently: the first reads the incoming delay line while the
-    // last writes the outgoing one, so the new state goes to scratch and is copied back after.
+    // last writes the outgoing one, so the new state goes to scratch and is copied back after
+    // (callers that keep two state buffers use the _pp_ entry point and skip the copy).
     void *scratch = nullptr;
     const size_t state_bytes = n_chains * 1024 * sizeof(float);
     SYM_TRY(ctx_scratch(ctx, state_bytes, &scratch));
@@ -374,7 +410,8 @@ int symaccel_aac_synth(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
     if (!h_coeffs || !h_side || !h_delay_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     const size_t nf = n_chains * frames_per_chain;
     DevBuf coeffs(ctx), side(ctx), delay(ctx), pcm(ctx);
     SYM_TRY(coeffs.from_host(h_coeffs, nf * 4096));
@@ -390,13 +427,29 @@ int symaccel_aac_synth(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *
 
 // ---- MP3 ----------------------------------------------------------------------------------
 
+int symaccel_mp3_synth_pp_device(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_side, int sample_rate_idx,
+                                 const float *d_overlap_in, const float *d_vvec_in, const int32_t *d_vfront_in,
+                                 float *d_overlap_out, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm, size_t n_chains,
+                                 size_t granules_per_chain) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
+    if (!d_xr || !d_side || !d_overlap_in || !d_vvec_in || !d_vfront_in || !d_overlap_out || !d_vvec_out || !d_vfront_out || !d_pcm)
+        return SYMACCEL_ERR_INVALID_ARG;
+    if (d_overlap_in == d_overlap_out || d_vvec_in == d_vvec_out || d_vfront_in == d_vfront_out) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_mp3(ctx, d_xr, d_side, sample_rate_idx, d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out,
+                      d_vfront_out, d_pcm, n_chains, granules_per_chain);
+}
+
 int symaccel_mp3_synth_device(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_side,
                               int sample_rate_idx, float *d_overlap_io, float *d_vvec_io, int32_t *d_vfront_io,
                               float *d_pcm, size_t n_chains, size_t granules_per_chain) {
     if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
     if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
     if (!d_xr || !d_side || !d_overlap_io || !d_vvec_io || !d_vfront_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     const size_t ov_bytes = n_chains * 576 * 4, vv_bytes = n_chains * 1024 * 4, vf_bytes = n_chains * 4;
     void *scratch = nullptr;
     SYM_TRY(ctx_scratch(ctx, ov_bytes + vv_bytes + vf_bytes, &scratch));
@@ -416,7 +469,8 @@ int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_
     if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
     if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
     if (!h_xr || !h_side || !h_overlap_io || !h_vvec_io || !h_vfront_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     const size_t ng = n_chains * granules_per_chain;
     DevBuf xr(ctx), side(ctx), ov(ctx), vv(ctx), vf(ctx), pcm(ctx);
     SYM_TRY(xr.from_host(h_xr, ng * 576 * 4));
@@ -437,26 +491,49 @@ int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_
 
 // ---- Vorbis -------------------------------------------------------------------------------
 
+static int vorbis_check(symaccel_ctx *ctx, int bs0_exp, int bs1_exp) {
+    // vorbis/lib.rs:404-406, 461-470: block sizes 2^6..2^13, bs0 <= bs1
+    if (!ctx || bs0_exp < 6 || bs1_exp > 13 || bs0_exp > bs1_exp) return SYMACCEL_ERR_INVALID_ARG;
+    return SYMACCEL_OK;
+}
+
 static int vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
                                  size_t spec_stride, const uint8_t *d_block_flag, int32_t *d_prev_flag_io,
                                  float *d_overlap_io, float *d_pcm, size_t pcm_stride, size_t n_chains,
                                  size_t blocks_per_chain) {
-    // vorbis/lib.rs:404-406, 461-470: block sizes 2^6..2^13, bs0 <= bs1
-    if (!ctx || bs0_exp < 6 || bs1_exp > 13 || bs0_exp > bs1_exp) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_TRY(vorbis_check(ctx, bs0_exp, bs1_exp));
     if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
     if (!d_spectra || !d_block_flag || !d_prev_flag_io || !d_overlap_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     const size_t half1 = (size_t)1 << (bs1_exp - 1);
     const size_t ov_bytes = n_chains * half1 * 4, pf_bytes = n_chains * 4;
     void *scratch = nullptr;
     const size_t off_bytes = n_chains * (blocks_per_chain + 1) * 2 * sizeof(uint32_t);
-    SYM_TRY(ctx_scratch(ctx, ov_bytes + pf_bytes + 256 + off_bytes, &scratch));
+    SYM_TRY(ctx_scratch(ctx, ov_bytes + pf_bytes + 512 + off_bytes, &scratch));
     float *ov_out = (float *)scratch;
     int32_t *pf_out = (int32_t *)(ov_out + n_chains * half1);
     SYM_TRY(launch_vorbis(ctx, bs0_exp, bs1_exp, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_flag_io, pf_out,
-                          d_overlap_io, ov_out, d_pcm, pcm_stride, n_chains, blocks_per_chain));
+                          d_overlap_io, ov_out, d_pcm, pcm_stride, n_chains, blocks_per_chain, (char *)scratch + ov_bytes + pf_bytes));
     SYM_TRY(launch_state_copy(ctx, d_overlap_io, ov_out, ov_bytes, d_prev_flag_io, pf_out, pf_bytes, nullptr, nullptr, 0));
     return SYMACCEL_OK;
+}
+
+int symaccel_vorbis_synth_pp_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
+                                    size_t spec_stride, const uint8_t *d_block_flag, const int32_t *d_prev_flag_in,
+                                    int32_t *d_prev_flag_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
+                                    size_t pcm_stride, size_t n_chains, size_t blocks_per_chain) {
+    SYM_TRY(vorbis_check(ctx, bs0_exp, bs1_exp));
+    if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
+    if (!d_spectra || !d_block_flag || !d_prev_flag_in || !d_prev_flag_out || !d_overlap_in || !d_overlap_out || !d_pcm)
+        return SYMACCEL_ERR_INVALID_ARG;
+    if (d_prev_flag_in == d_prev_flag_out || d_overlap_in == d_overlap_out) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    void *scratch = nullptr;  // per-block offsets of the generic block-size pairs
+    SYM_TRY(ctx_scratch(ctx, n_chains * (blocks_per_chain + 1) * 2 * sizeof(uint32_t) + 256, &scratch));
+    return launch_vorbis(ctx, bs0_exp, bs1_exp, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_flag_in, d_prev_flag_out,
+                         d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, blocks_per_chain, scratch);
 }
 
 int symaccel_vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra,
@@ -482,7 +559,8 @@ int symaccel_vorbis_synth(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const flo
     if (!ctx || bs0_exp < 6 || bs1_exp > 13 || bs0_exp > bs1_exp) return SYMACCEL_ERR_INVALID_ARG;
     if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
     if (!h_spectra || !h_block_flag || !h_prev_flag_io || !h_overlap_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     const size_t half1 = (size_t)1 << (bs1_exp - 1);
     DevBuf sp(ctx), bf(ctx), pf(ctx), ov(ctx), pcm(ctx);
     SYM_TRY(sp.from_host(h_spectra, n_chains * spec_stride * 4));
@@ -505,7 +583,8 @@ int symaccel_vorbis_inverse_coupling_device(symaccel_ctx *ctx, float *d_residue,
     if (!ctx || n_pairs > 256) return SYMACCEL_ERR_INVALID_ARG;
     if (n == 0 || n_pairs == 0) return SYMACCEL_OK;
     if (!d_residue || !mag_index || !ang_index) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     for (size_t p = 0; p < n_pairs; ++p) {  // ordered: coupling steps may chain (lib.rs:252)
         if (mag_index[p] == ang_index[p]) return SYMACCEL_ERR_INVALID_ARG;  // lib.rs:253 debug_assert
         SYM_TRY(launch_vorbis_coupling(ctx, d_residue + (size_t)mag_index[p] * n, d_residue + (size_t)ang_index[p] * n, n));
@@ -517,7 +596,8 @@ int symaccel_vorbis_dot_product_device(symaccel_ctx *ctx, float *d_floor, const 
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (total == 0) return SYMACCEL_OK;
     if (!d_floor || !d_residue) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_vorbis_dot(ctx, d_floor, d_residue, total);
 }
 
@@ -526,7 +606,8 @@ int symaccel_vorbis_deinterleave2_device(symaccel_ctx *ctx, const float *d_type2
     if (!ctx || n_ch < 1 || n_ch > 32) return SYMACCEL_ERR_INVALID_ARG;  // lib.rs:439-441
     if (n2 == 0 || count == 0) return SYMACCEL_OK;
     if (!d_type2 || !d_planar || d_type2 == d_planar) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_vorbis_deinterleave(ctx, d_type2, d_planar, n_ch, n2, count);
 }
 
@@ -535,7 +616,8 @@ int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int
     if (!ctx || n_posts < 2 || n_posts > 65 || multiplier < 1 || multiplier > 4) return SYMACCEL_ERR_INVALID_ARG;
     if (count == 0 || n == 0) return SYMACCEL_OK;
     if (!x_list || !d_y || !d_floor) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     // Setup-time derivations the reference does once per floor (floor.rs:540-555, 748-773):
     // neighbours of every post and the x-sorted visiting order.
     uint32_t setup[65 * 4] = {0};  // x | low neighbour | high neighbour | sort order
@@ -573,7 +655,8 @@ int symaccel_flac_restore_device(symaccel_ctx *ctx, int32_t *d_buf, const symacc
     if (!ctx || blocksize > 65535) return SYMACCEL_ERR_INVALID_ARG;  // frame.rs:58 (u16 block size)
     if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
     if (!d_buf || !d_desc || !d_coeffs) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_flac_restore(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize);
 }
 
@@ -588,7 +671,8 @@ int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac
         if (d.kind == SYMACCEL_FLAC_FIXED && d.order > 4) return SYMACCEL_ERR_INVALID_ARG;
         if (d.kind == SYMACCEL_FLAC_LPC && (d.order < 1 || d.order > 32)) return SYMACCEL_ERR_INVALID_ARG;
     }
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     DevBuf buf(ctx), desc(ctx), co(ctx);
     SYM_TRY(buf.from_host(h_buf, n_blocks * blocksize * 4));
     SYM_TRY(desc.from_host(h_desc, n_blocks * sizeof(symaccel_flac_desc)));
@@ -605,7 +689,8 @@ int symaccel_flac_restore_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const
     if (!ctx || blocksize > 0xffffffffu || out_shift > 31 || (n_blocks & 1)) return SYMACCEL_ERR_INVALID_ARG;
     if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
     if (!d_buf || !d_desc || !d_coeffs || !d_pair_mode) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_flac_restore(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize, d_pair_mode, out_shift);
 }
 
@@ -614,7 +699,8 @@ int symaccel_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *h_mode, int32_t 
     if (!ctx || out_shift > 31) return SYMACCEL_ERR_INVALID_ARG;
     if (n_pairs == 0 || blocksize == 0) return SYMACCEL_OK;
     if (!h_mode || !h_ch0 || !h_ch1) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     DevBuf mode(ctx), c0(ctx), c1(ctx);
     const size_t bytes = n_pairs * blocksize * 4;
     SYM_TRY(mode.from_host(h_mode, n_pairs));
@@ -632,7 +718,8 @@ int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, i
     if (!ctx || out_shift > 31) return SYMACCEL_ERR_INVALID_ARG;
     if (n_pairs == 0 || blocksize == 0) return SYMACCEL_OK;
     if (!d_mode || !d_ch0 || !d_ch1) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_flac_decorrelate(ctx, d_mode, d_ch0, d_ch1, n_pairs, blocksize, out_shift);
 }
 
@@ -659,7 +746,8 @@ int symaccel_aac_joint_stereo_device(symaccel_ctx *ctx, float *d_coeffs, size_t 
         return SYMACCEL_ERR_INVALID_ARG;
     if (n_pairs == 0 || frames_per_chain == 0) return SYMACCEL_OK;
     if (!d_coeffs || !d_pair_chains || !d_desc) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_aac_joint_stereo(ctx, maps, d_coeffs, frames_per_chain, d_pair_chains, d_desc, n_pairs);
 }
 
@@ -668,7 +756,8 @@ int symaccel_aac_tns_device(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames,
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (n_filters == 0 || n_frames == 0) return SYMACCEL_OK;
     if (!d_coeffs || !d_filters) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_aac_tns(ctx, d_coeffs, n_frames, d_filters, n_filters);
 }
 
@@ -677,7 +766,8 @@ int symaccel_mp3_stereo_device(symaccel_ctx *ctx, float *d_xr, size_t granules_p
     if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
     if (n_pairs == 0 || granules_per_chain == 0) return SYMACCEL_OK;
     if (!d_xr || !d_pair_chains || !d_desc) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_mp3_stereo(ctx, d_xr, granules_per_chain, d_pair_chains, d_desc, sample_rate_idx, n_pairs);
 }
 
@@ -687,7 +777,8 @@ int symaccel_mp3_requantize_stereo_device(symaccel_ctx *ctx, const int16_t *d_qu
     if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
     if (n_pairs == 0 || granules_per_chain == 0) return SYMACCEL_OK;
     if (!d_quant || !d_rq_desc || !d_xr || !d_pair_chains || !d_desc) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_mp3_stereo(ctx, d_xr, granules_per_chain, d_pair_chains, d_desc, sample_rate_idx, n_pairs, d_quant, d_rq_desc);
 }
 
@@ -696,7 +787,8 @@ int symaccel_mp3_requantize_device(symaccel_ctx *ctx, const int16_t *d_quant, co
     if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
     if (n == 0) return SYMACCEL_OK;
     if (!d_quant || !d_desc || !d_xr) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_mp3_requantize(ctx, d_quant, d_desc, sample_rate_idx, d_xr, n);
 }
 
@@ -705,7 +797,8 @@ int symaccel_mp3_requantize(symaccel_ctx *ctx, const int16_t *h_quant, const sym
     if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
     if (n == 0) return SYMACCEL_OK;
     if (!h_quant || !h_desc || !h_xr) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     DevBuf q(ctx), d(ctx), x(ctx);
     SYM_TRY(q.from_host(h_quant, n * 576 * sizeof(int16_t)));
     SYM_TRY(d.from_host(h_desc, n * sizeof(symaccel_mp3_requant)));
@@ -715,13 +808,28 @@ int symaccel_mp3_requantize(symaccel_ctx *ctx, const int16_t *h_quant, const sym
     return symaccel_sync(ctx);
 }
 
+int symaccel_mpa_polyphase_pp_device(symaccel_ctx *ctx, int n_frames, const float *d_in, const float *d_vvec_in,
+                                     const int32_t *d_vfront_in, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm,
+                                     size_t n_chains, size_t packets_per_chain) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_frames != 12 && n_frames != 36) return SYMACCEL_ERR_UNSUPPORTED;
+    if (n_chains == 0 || packets_per_chain == 0) return SYMACCEL_OK;
+    if (!d_in || !d_vvec_in || !d_vfront_in || !d_vvec_out || !d_vfront_out || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    if (d_vvec_in == d_vvec_out || d_vfront_in == d_vfront_out) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_mpa_polyphase(ctx, n_frames, d_in, d_vvec_in, d_vfront_in, d_vvec_out, d_vfront_out, d_pcm, n_chains,
+                                packets_per_chain);
+}
+
 int symaccel_mpa_polyphase_device(symaccel_ctx *ctx, int n_frames, const float *d_in, float *d_vvec_io,
                                   int32_t *d_vfront_io, float *d_pcm, size_t n_chains, size_t packets_per_chain) {
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (n_frames != 12 && n_frames != 36) return SYMACCEL_ERR_UNSUPPORTED;  // Layer I / Layer II (Layer III: mp3_synth)
     if (n_chains == 0 || packets_per_chain == 0) return SYMACCEL_OK;
     if (!d_in || !d_vvec_io || !d_vfront_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     const size_t vv_bytes = n_chains * 1024 * 4, vf_bytes = n_chains * 4;
     void *scratch = nullptr;
     SYM_TRY(ctx_scratch(ctx, vv_bytes + vf_bytes, &scratch));
@@ -739,7 +847,8 @@ int symaccel_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *h_in, f
     if (n_frames != 12 && n_frames != 36) return SYMACCEL_ERR_UNSUPPORTED;
     if (n_chains == 0 || packets_per_chain == 0) return SYMACCEL_OK;
     if (!h_in || !h_vvec_io || !h_vfront_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     const size_t bytes = n_chains * packets_per_chain * 32 * (size_t)n_frames * 4;
     DevBuf in(ctx), vv(ctx), vf(ctx), pcm(ctx);
     SYM_TRY(in.from_host(h_in, bytes));
@@ -759,7 +868,8 @@ int symaccel_alac_predict_device(symaccel_ctx *ctx, int32_t *d_buf, const symacc
     if (!ctx || blocksize > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
     if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
     if (!d_buf || !d_desc || !d_coeffs) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_alac_predict(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize);
 }
 
@@ -769,7 +879,8 @@ int symaccel_alac_predict_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const
     if (!ctx || blocksize > 0xffffffffu || (n_blocks & 1)) return SYMACCEL_ERR_INVALID_ARG;
     if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
     if (!d_buf || !d_desc || !d_coeffs || !d_pair_weight || !d_pair_shift) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_alac_predict(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize, d_pair_weight, d_pair_shift);
 }
 
@@ -778,7 +889,8 @@ int symaccel_alac_predict(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_alac
     if (!ctx || blocksize > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
     if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
     if (!h_buf || !h_desc || !h_coeffs) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     DevBuf buf(ctx), desc(ctx), co(ctx);
     const size_t bytes = n_blocks * blocksize * 4;
     SYM_TRY(buf.from_host(h_buf, bytes));
@@ -795,7 +907,8 @@ int symaccel_alac_mid_side_device(symaccel_ctx *ctx, const int32_t *d_weight, co
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (n_pairs == 0 || blocksize == 0) return SYMACCEL_OK;
     if (!d_weight || !d_shift || !d_ch0 || !d_ch1) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     return launch_alac_mid_side(ctx, d_weight, d_shift, d_ch0, d_ch1, n_pairs, blocksize);
 }
 
@@ -804,7 +917,8 @@ int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uin
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (n_pairs == 0 || blocksize == 0) return SYMACCEL_OK;
     if (!h_weight || !h_shift || !h_ch0 || !h_ch1) return SYMACCEL_ERR_INVALID_ARG;
-    SYM_GPU(ctx, hipSetDevice(ctx->device));
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
     DevBuf w(ctx), sh(ctx), c0(ctx), c1(ctx);
     const size_t bytes = n_pairs * blocksize * 4;
     SYM_TRY(w.from_host(h_weight, n_pairs * 4));

@@ -32,7 +32,8 @@ namespace {
 constexpr int kTileFloats = 2 * 576;             // two granule tiles (one per half-wave)
 constexpr int kSBase = 0;  // the dct32 transpose reuses the granule tiles' LDS (the tiles are dead by then)
 constexpr int kWinBase = kSBase + 2 * 18 * kSStride + kDwFloats;
-constexpr int kWaveFloats = kWinBase + 4 * 36;  // per-wavefront LDS: tiles / transpose, synthesis window rows, IMDCT windows
+constexpr int kMetaBase = kWinBase + 4 * 36;   // 4 words: (chain, ends-its-chain flag) of each half-wave, for the epilogue
+constexpr int kWaveFloats = kMetaBase + 4;  // per-wavefront LDS: tiles / transpose, synthesis window rows, IMDCT windows, meta
 static_assert(2 * 18 * kSStride >= kTileFloats, "the transpose area must hold the two granule tiles");
 
 // ---- 36-point IMDCT (Szu-Wei Lee), hybrid_synthesis.rs:559-779 -------------------------------
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
     }
     float *imdct_win = lds + kWinBase;  // the four 36-entry IMDCT windows (hybrid_synthesis.rs:31-101)
     for (int i = (int)threadIdx.x; i < 4 * 36; i += 64) imdct_win[i] = tb.mp3_consts[MP3C_IMDCT_WIN + i];
-    const VMap vm = vmap(hl);
+    const VMapX vm = vmapx(hl);
 
     // ---- incoming state.  oA[16 + r] = V_r[i], oB[16 + r] = V_r[32 + i] for the previous granules' time slots r < 0
     float overlap[18], oA[kHistOld], oB[kHistOld];
@@ -194,6 +195,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
     {
         const long other = __shfl((int)rounds, (int)(threadIdx.x ^ 32u));
         rounds = rounds > other ? rounds : other;
+    }
+
+    if (hl == 0) {  // what the epilogue needs of the above, parked in LDS (see there)
+        unsigned *meta_w = reinterpret_cast<unsigned *>(lds + kMetaBase) + 2 * half;
+        meta_w[0] = chain;
+        meta_w[1] = (live && g_end == granules_per_chain) ? 1u : 0u;
     }
 
     // The granule's 576 lines as 144 float4: lane hl holds float4 hl + 32 q, q = 0..3, and (hl < 16) float4 128 + hl.
@@ -339,6 +346,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
             dct_lee<32>(d);
 #pragma unroll
             for (int k = 0; k < 8; ++k) row[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+            row[8] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // the zero column V[16] reads (the granule tile overwrote it)
         }
         wave_sync();
         // ---- windowing (synthesis.rs:309-324), one time slot at a time: fetch the slot's two V entries for
@@ -357,9 +365,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
         float nA[18], nB[18];
 #pragma unroll
         for (int b = 0; b < 18; ++b) {
-            const float df = S[b * kSStride + vm.fidx];
-            nA[b] = vm.fkind == 0 ? df : (vm.fkind == 1 ? -df : 0.0f);  // V[i]
-            nB[b] = -S[b * kSStride + vm.sidx];                          // V[32 + i]
+            nA[b] = __uint_as_float(__float_as_uint(S[b * kSStride + vm.fcol]) ^ vm.fsign);  // V[i]
+            nB[b] = -S[b * kSStride + vm.scol];                                               // V[32 + i]
             float acc = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -380,22 +387,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
         }
     }
 
-    // ---- outgoing state (only the segment that ends the chain)
-    if (live && g_end == granules_per_chain) {
+    // ---- outgoing state (only the segment that ends the chain).  The chain index and the addresses derived from it are
+    // re-read here from LDS through an opaque copy of the thread index: kept live across the main loop they (and the
+    // reciprocal of the division that produced them) cost seven VGPRs, which at the 168-register budget of three
+    // wavefronts per SIMD were spilled to scratch around the loop.
+    wave_sync();
+    unsigned tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int hl2 = (int)(tid2 & 31u);
+    const unsigned *meta = reinterpret_cast<const unsigned *>(lds + kMetaBase) + 2 * (tid2 >> 5);
+    const unsigned chain2 = meta[0];
+    if (meta[1] != 0u) {
 #pragma unroll
-        for (int i = 0; i < 18; ++i) overlap_out[(size_t)chain * 576 + 18 * hl + i] = overlap[i];
+        for (int i = 0; i < 18; ++i) overlap_out[(size_t)chain2 * 576 + 18 * hl2 + i] = overlap[i];
         // v_vec[16][64] + v_front exactly as the reference leaves them: v_front moves back one row per time
         // slot (synthesis.rs:335) and row (v_front + m) & 15 holds slot -m, m = 1..16.
-        const int vf0 = vfront_in[chain] & 15;
+        const int vf0 = vfront_in[chain2] & 15;
         const int vf_final = (int)(((unsigned)vf0 + 15u * 18u * granules_per_chain) & 15u);
-        float *vv = vvec_out + (size_t)chain * 1024;
+        float *vv = vvec_out + (size_t)chain2 * 1024;
 #pragma unroll
         for (int m = 1; m <= kHistOld; ++m) {
             float *row = vv + 64 * ((vf_final + m) & 15);
-            row[hl] = oA[kHistOld - m];
-            row[32 + hl] = oB[kHistOld - m];
+            row[hl2] = oA[kHistOld - m];
+            row[32 + hl2] = oB[kHistOld - m];
         }
-        if (hl == 0) vfront_out[chain] = vf_final;
+        if (hl2 == 0) vfront_out[chain2] = vf_final;
     }
 }
 

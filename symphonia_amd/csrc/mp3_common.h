@@ -65,4 +65,22 @@ __device__ __forceinline__ VMap vmap(int i) {
     return m;
 }
 
+// The same mapping with the sign as an XOR mask and the literal 0.0 of V[16] as a read of a zero column: the dct32
+// pass stores 0.0 in columns 32..35 of every row it writes (kSStride = 36 leaves them free), so
+//   V[i]      = bits(S[row][fcol]) ^ fsign      (negation is exact; +0.0 ^ 0 is the reference's literal +0.0)
+//   V[32 + i] = bits(S[row][scol]) ^ 0x80000000
+// -- one VALU instruction per entry instead of a compare/select chain, and two live registers less per lane.
+struct VMapX {
+    int fcol, scol;
+    unsigned fsign;
+};
+__device__ __forceinline__ VMapX vmapx(int i) {
+    const VMap m = vmap(i);
+    VMapX x;
+    x.fcol = m.fkind == 2 ? 32 : m.fidx;
+    x.scol = m.sidx;
+    x.fsign = m.fkind == 1 ? 0x80000000u : 0u;
+    return x;
+}
+
 }  // namespace symaccel

@@ -126,6 +126,36 @@ unsigned choose_segment(const symaccel_ctx *ctx, size_t n_chains, size_t frames_
                         unsigned items_per_wave, unsigned halo, unsigned min_seg);
 int get_vorbis_window(symaccel_ctx *ctx, int bs, const float **out);
 
+// Entry points run on the context's device and leave the caller's current device as they found it (a process that
+// drives several GPUs through one thread must not have its "current device" moved by a library call).
+class DeviceGuard {
+public:
+    explicit DeviceGuard(symaccel_ctx *ctx) {
+        if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+        if (prev_ != ctx->device) {
+            const hipError_t e = hipSetDevice(ctx->device);
+            if (e != hipSuccess) {
+                status_ = ctx_fail(ctx, e, "hipSetDevice");
+                prev_ = -1;
+            } else {
+                switched_ = true;
+            }
+        }
+    }
+    ~DeviceGuard() {
+        if (switched_ && prev_ >= 0) (void)hipSetDevice(prev_);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+    bool ok() const { return status_ == SYMACCEL_OK; }
+    int status() const { return status_; }
+
+private:
+    int prev_ = -1;
+    int status_ = SYMACCEL_OK;
+    bool switched_ = false;
+};
+
 #define SYM_TRY(expr)                                                   \
     do {                                                                \
         int _st = (expr);                                               \
@@ -156,7 +186,7 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
                   size_t spec_stride,
                   const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out,
                   const float *d_overlap_in, float *d_overlap_out, float *d_pcm, size_t pcm_stride,
-                  size_t n_chains, size_t blocks_per_chain);
+                  size_t n_chains, size_t blocks_per_chain, void *d_offsets);
 int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                        const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride,
                        const uint8_t *d_block_flag,

@@ -310,7 +310,14 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
 
     // ---- synthesis_step1 (floor.rs:568-625): lane = block
     const int32_t range = multiplier == 1 ? 256 : multiplier == 2 ? 128 : multiplier == 3 ? 86 : 64;
-    uint32_t flag[3] = {3u, 0u, 0u};  // floor_step2_flag as bits; posts 0 and 1 are always used
+    // floor_step2_flag as bits (posts 0 and 1 are always used): 64 bits + one for post 64, set and tested without
+    // indexing an array by a run-time value (that would put the array in scratch memory)
+    unsigned long long flag_lo = 3ull;
+    unsigned flag_hi = 0u;
+    auto set_flag = [&](int i) {
+        flag_lo |= i < 64 ? (1ull << (i & 63)) : 0ull;
+        flag_hi |= i == 64 ? 1u : 0u;
+    };
     fy[0 * 64 + lane] = (int16_t)segx[0 * kF1Stride + lane];
     fy[1 * 64 + lane] = (int16_t)segx[1 * kF1Stride + lane];
     for (int i = 2; i < n_posts; ++i) {
@@ -321,9 +328,9 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
         int32_t fin = predicted;
         if (val != 0) {
             const int32_t room = 2 * (highroom < lowroom ? highroom : lowroom);
-            flag[lo >> 5] |= 1u << (lo & 31);
-            flag[hi >> 5] |= 1u << (hi & 31);
-            flag[i >> 5] |= 1u << (i & 31);
+            set_flag(lo);
+            set_flag(hi);
+            set_flag(i);
             if (val >= room)
                 fin = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
             else
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
         int32_t hy = 0;
         for (int k = 1; k < n_posts; ++k) {
             const int i = st.order[k];
-            if ((flag[i >> 5] >> (i & 31)) & 1u) {
+            if (i < 64 ? (unsigned)((flag_lo >> (i & 63)) & 1ull) : flag_hi) {
                 hy = fy[i * 64 + lane] * multiplier;
                 hy = hy < 0 ? 0 : (hy > 255 ? 255 : hy);
                 hx = st.x[i];
@@ -475,7 +482,7 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
                   size_t spec_stride,
                   const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out,
                   const float *d_overlap_in, float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains,
-                  size_t blocks_per_chain) {
+                  size_t blocks_per_chain, void *d_offsets) {
     if (blocks_per_chain > 0x3fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     const ImdctPlan *ps = nullptr, *pl = nullptr;
     SYM_TRY(get_imdct_plan(ctx, (1 << bs0_exp) >> 1, 1.0, &ps));  // vorbis/lib.rs:123
@@ -496,11 +503,9 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
                                   d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
                                   pcm_stride, n_chains, nb, seg);
     }
-    // generic path: a scan kernel turns the flag sequence into packed offsets (the ABI wrapper reserved room for them
-    // behind the state copies in ctx->scratch)
-    const size_t half1 = (size_t)1 << (bs1_exp - 1);
-    const size_t state_bytes = n_chains * half1 * 4 + n_chains * 4;
-    uint32_t *offs = (uint32_t *)((char *)ctx->scratch + ((state_bytes + 255) / 256) * 256);
+    // generic path: a scan kernel turns the flag sequence into packed offsets (room for them comes from the ABI wrapper:
+    // n_chains * (blocks_per_chain + 1) * 2 words)
+    uint32_t *offs = (uint32_t *)(((uintptr_t)d_offsets + 255) & ~(uintptr_t)255);
     hipLaunchKernelGGL(vorbis_offsets_kernel, dim3((unsigned)n_chains), dim3(256), 0, ctx->stream, d_block_flag,
                        d_prev_in, offs, nb, 1 << bs0_exp, 1 << bs1_exp);
     SYM_GPU(ctx, hipGetLastError());

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     unsigned segs_per_chain, unsigned n_items) {
     __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
+    __shared__ unsigned wave_chain[kWaves];  // the wavefront's chain index, parked for the epilogue (see there)
 
     for (int i = (int)threadIdx.x; i < 1024; i += 64 * kWaves) {
         tabs[kTabTw + i] = reinterpret_cast<const float *>(tw_long)[i];
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     const cpx *tws = reinterpret_cast<const cpx *>(tabs + kTabTws);
 
     const unsigned chain = item / segs_per_chain, seg = item % segs_per_chain;
+    if (lane == 0) wave_chain[wave] = chain;
     const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
     const uint8_t *f = flags + (size_t)chain * nb;
     const float *sp = spectra + (size_t)chain * spec_stride;
@@ -376,11 +378,21 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     }
 
     if (b_end == nb) {
+        // The chain index and the addresses derived from it are re-derived here from LDS through an opaque copy of the
+        // thread index: kept live across the main loop they were spilled to scratch (the loop runs at the full 256-VGPR
+        // budget of two wavefronts per SIMD).
+        wave_sync();
+        unsigned tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const unsigned chain2 = wave_chain[tid2 >> 6];
+        const uint8_t *f2 = flags + (size_t)chain2 * nb;
+        const float *sp2 = spectra + (size_t)chain2 * spec_stride;
+        const float *rp2 = FUSED ? residue + (size_t)chain2 * spec_stride : nullptr;
         if (!hi_fresh) {
             // The chain ends in short blocks and this segment never saw a long one: overlap[128..1024) still
             // holds what the most recent long block left there (never used for PCM, but part of the state the
             // reference carries).  Rebuild it from that block's spectrum, or keep the incoming state.
-            const long bl = b_begin > 0 ? last_long_before(f, (long)b_begin, lane) : -1;
+            const long bl = b_begin > 0 ? last_long_before(f2, (long)b_begin, lane) : -1;
             float keep[2][8];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                 for (int q = 0; q < 8; ++q) keep[h][q] = dl[h][q];
             if (bl >= 0) {
                 c32 z[8];
-                fetch_lines<FUSED>(sp, rp, sizes_before(bl) / 2, 8, lane, line, res);
+                fetch_lines<FUSED>(sp2, rp2, (256u * (uint32_t)bl + 1792u * count_long_before(f2, bl, lane)) / 2, 8, lane, line, res);
                 apply_residue<FUSED>(line, res);
                 const int mirror = (63 - lane) * 4;
 #pragma unroll
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                 wave_sync();
             } else {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) load_slot(overlap_in + (size_t)chain * 1024, lane + 64 * h, dl[h]);
+                for (int h = 0; h < 2; ++h) load_slot(overlap_in + (size_t)chain2 * 1024, lane + 64 * h, dl[h]);
             }
             // overlap[0..128) comes from the short blocks of this segment
 #pragma unroll
@@ -418,10 +430,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                 }
             }
         }
-        float *d = overlap_out + (size_t)chain * 1024;
+        float *d = overlap_out + (size_t)chain2 * 1024;
 #pragma unroll
         for (int h = 0; h < 2; ++h) store_slot(d, lane + 64 * h, dl[h]);
-        if (lane == 0) prev_flag_out[chain] = f[nb - 1] ? 1 : 0;  // lib.rs:328
+        if (lane == 0) prev_flag_out[chain2] = f2[nb - 1] ? 1 : 0;  // lib.rs:328
     }
 }
 

@@ -82,3 +82,41 @@ def timed_all_gather(local, dist, reps=3):
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     return max_over_ranks(dt, dist, device=local.device if local.is_cuda else None), local.numel() * local.element_size()
+
+
+def timed_exchange(local_in, local_out, step, dist, sync, device=None, reps=3):
+    """a batch that starts and ends on rank 0.  Per repetition: rank 0 scatters one input shard to every
+    rank (dist.scatter: point-to-point sends over xGMI under RCCL), every rank runs `step` on its shard (in `local_in`,
+    result in `local_out`), rank 0 gathers the PCM shards (dist.gather).  Returns seconds per repetition, max over
+    ranks, as {"scatter", "step", "gather", "total"}.  One-to-all traffic is bounded by rank 0's links, which is why this
+    is never the headline number."""
+    import time
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    src = [torch.empty_like(local_in).copy_(local_in) for _ in range(world)] if rank == 0 else None
+    dst = [torch.empty_like(local_out) for _ in range(world)] if rank == 0 else None
+
+    def once():
+        t = [time.perf_counter()]
+        dist.scatter(local_in, src, src=0)
+        sync()
+        t.append(time.perf_counter())
+        step()
+        sync()
+        t.append(time.perf_counter())
+        dist.gather(local_out, dst, dst=0)
+        sync()
+        t.append(time.perf_counter())
+        return t
+
+    once()  # warm-up: connection set-up
+    acc = [0.0, 0.0, 0.0, 0.0]
+    for _ in range(reps):
+        dist.barrier()
+        sync()
+        t = once()
+        for i in range(3):
+            acc[i] += t[i + 1] - t[i]
+        acc[3] += t[3] - t[0]
+    names = ("scatter", "step", "gather", "total")
+    return {n: max_over_ranks(a / reps, dist, device=device) for n, a in zip(names, acc)}

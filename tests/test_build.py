@@ -15,17 +15,13 @@ CSRC = ROOT / "symphonia_amd" / "csrc"
 F32_FUSED = re.compile(r"\b(v_fma_f32|v_fmac_f32|v_mac_f32|v_mad_f32|v_pk_fma_f32|v_fma_mix\w*|v_mad_mix\w*|v_fma_legacy_f32|"
                        r"v_mad_legacy_f32|v_mac_legacy_f32|v_dot2c?_f32\w*)\b")
 F64_FUSED = re.compile(r"\b(v_fma_f64|v_fmac_f64)\b")
-SOURCES = ["aac.hip", "mp3.hip", "mpa_polyphase.hip", "vorbis.hip", "vorbis_wave.hip", "imdct_generic.hip", "flac.hip", "alac.hip"]
+SOURCES = ["aac.hip", "aac_tools.hip", "mp3.hip", "mp3_requant.hip", "mp3_stereo.hip", "mpa_polyphase.hip", "vorbis.hip", "vorbis_wave.hip",
+           "imdct_generic.hip", "flac.hip", "alac.hip", "state_copy.hip"]
 
 
-def device_asm(src):
-    from symphonia_amd import build
-    out = ROOT / "symphonia_amd" / "build" / (src.replace(".", "_") + ".s")
-    out.parent.mkdir(exist_ok=True)
-    cmd = [build.hipcc(), "--offload-arch=" + build.ARCH, "-x", "hip", *build.FLAGS, "--cuda-device-only", "-S",
-           str(CSRC / src), "-o", str(out)]
-    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return out.read_text()
+import sys
+sys.path.insert(0, str(ROOT))
+from tools.kernel_resources import device_asm, kernel_resources  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -46,7 +42,7 @@ def kernels(text):
 
 # Kernels with no f32 signal arithmetic at all: the only FMAs they may contain belong to the compiler's expansion of
 # integer and IEEE float DIVISION (index math, the floor-1 DDA reciprocal), which is correctly rounded by construction.
-INDEX_MATH_ONLY = re.compile(r"floor1|offsets|deinterleave|flac_|alac_|state_copy")
+INDEX_MATH_ONLY = re.compile(r"floor1|offsets|deinterleave|flac_|alac_|state_copy|mp3_requantize_kernel")
 
 
 def test_no_f32_fma_in_any_synthesis_kernel(asm):
@@ -59,6 +55,22 @@ def test_no_f32_fma_in_any_synthesis_kernel(asm):
             hits = sorted(set(F32_FUSED.findall(body)))
             assert not hits, "%s: %s contains fused f32 arithmetic: %s" % (src, name, hits)
     assert seen >= 8  # aac, mp3, mpa x2, vorbis synth x2 + wave, imdct / fft x4, coupling, dot
+
+
+def test_every_source_of_the_library_is_checked():
+    from symphonia_amd import build
+    assert sorted(SOURCES) == sorted(s for s in build.SOURCES if s.endswith(".hip"))
+
+
+def test_no_kernel_spills(asm):
+    """A spilled register is a scratch (HBM-backed) access in the middle of a latency-bound loop: every kernel must
+    fit its register budget.  ScratchSize is the compiler's own figure (.amdhsa_private_segment_fixed_size)."""
+    seen = 0
+    for src, text in asm.items():
+        for name, r in kernel_resources(text).items():
+            seen += 1
+            assert r.get("ScratchSize") == 0, "%s: %s uses %s bytes of scratch (VGPRs %s)" % (src, name, r.get("ScratchSize"), r.get("NumVgprs"))
+    assert seen >= 30
 
 
 def test_fp64_fma_only_in_the_flac_kernel(asm):

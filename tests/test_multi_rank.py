@@ -116,3 +116,42 @@ def test_two_ranks_shard_by_chain_gloo():
     assert [r[1] for r in results] == [True, True], results
     assert [r[2] for r in results] == [2.0, 2.0]  # max over ranks of (1.0, 2.0)
     assert [r[3] for r in results] == [(0, 4), (4, 6)]
+
+
+def _bench(args, env_extra=None, timeout=900):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env,
+                       cwd=str(ROOT))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher in the environment (how the driver calls it) must start two ranks and
+    report a two-rank line.  Runs the real control flow -- self-launch under torch.distributed.run on 127.0.0.1, rank /
+    device checks, barrier + max-over-ranks clock, scatter -> step -> gather leg, config-4 line -- on CPU tensors through
+    the emulation build with gloo (--emulate, test only)."""
+    r, d = _bench(["--gpus", "2", "--emulate", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0 and d is not None, r.stderr[-3000:]
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo"
+    assert len(set(d["ranks"]["devices"])) == 2 and len(d["ranks"]["ms_per_step_per_rank"]) == 2
+    assert d["ms_per_step"] * 1.001 >= max(d["ranks"]["ms_per_step_per_rank"])  # the clock is the slowest rank's
+    # value = units of ALL ranks / max-over-ranks time
+    frames_per_rank = d["config"]["channel_frames"] / 2
+    assert abs(d["value"] - 2 * frames_per_rank * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
+    ex = d["exchange"]
+    assert set(ex["ms"]) == {"scatter", "step", "gather", "total"} and ex["ms"]["total"] >= ex["ms"]["step"]
+    assert ex["value_inclusive"] > 0
+    assert d["config4_vorbis"]["value"] > 0 and "Vorbis" in d["config4_vorbis"]["config"]["workload"]
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_bench_refuses_a_launcher_with_the_wrong_world_size():
+    r, d = _bench(["--gpus", "2", "--emulate", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"},
+                  timeout=300)
+    assert r.returncode != 0 and d is None
+    assert "one rank per GPU" in r.stderr
