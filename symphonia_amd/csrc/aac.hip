@@ -86,29 +86,14 @@ __device__ __forceinline__ void start_window4(const float *sw, int j0, float *w)
 #ifndef SYM_AAC_PREFETCH
 #define SYM_AAC_PREFETCH 1  // frames of spectral lines in flight ahead of the one being transformed (1 or 2)
 #endif
-#ifndef SYM_AAC_NT
-#define SYM_AAC_NT 0  // 1: non-temporal (streaming) loads of the spectra and stores of the PCM
-#endif
-
-typedef float nt_f2 __attribute__((ext_vector_type(2)));
-typedef float nt_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float2 ld_line(const float2 *p) {
-#if SYM_AAC_NT
-    const nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2 *>(p));
-    return make_float2(v.x, v.y);
-#else
-    return *p;
-#endif
-}
+__device__ __forceinline__ float2 ld_line(const float2 *p) { return ld_stream(p); }
+// PCM of one output slot (the two float4 of store_slot), streamed
 __device__ __forceinline__ void st_slot(float *frame, int m2, const float (&v)[8]) {
-#if SYM_AAC_NT
-    nt_f4 *o4 = reinterpret_cast<nt_f4 *>(frame);
-    __builtin_nontemporal_store(nt_f4{v[0], v[1], v[2], v[3]}, o4 + m2);
-    __builtin_nontemporal_store(nt_f4{v[4], v[5], v[6], v[7]}, o4 + 255 - m2);
-#else
-    store_slot(frame, m2, v);
-#endif
+    float4 *o4 = reinterpret_cast<float4 *>(frame);
+    st_stream(o4 + m2, make_float4(v[0], v[1], v[2], v[3]));
+    st_stream(o4 + 255 - m2, make_float4(v[4], v[5], v[6], v[7]));
 }
+
 __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kernel(
     DevTables tb, const float *__restrict__ coeffs, const uint8_t *__restrict__ side,
     const float *__restrict__ delay_in, float *__restrict__ delay_out, float *__restrict__ pcm,
@@ -286,7 +271,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o[q] = o[q] + ps[q];
                 }
-                if (emit) *reinterpret_cast<float4 *>(frame_out + j0) = make_float4(o[0], o[1], o[2], o[3]);
+                if (emit) st_stream(reinterpret_cast<float4 *>(frame_out + j0), make_float4(o[0], o[1], o[2], o[3]));
                 float nd[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // dsp.rs:138-145
                 if (j0 < kP1) pcm_short4(ldsf, j0 + kP1, sw, psw, nd);
                 *d4 = make_float4(nd[0], nd[1], nd[2], nd[3]);

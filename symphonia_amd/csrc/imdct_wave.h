@@ -247,6 +247,11 @@ __device__ __forceinline__ void store_slot(float *frame, int m2, const float (&v
     o4[m2] = make_float4(v[0], v[1], v[2], v[3]);
     o4[255 - m2] = make_float4(v[4], v[5], v[6], v[7]);
 }
+__device__ __forceinline__ void store_slot_stream(float *frame, int m2, const float (&v)[8]) {
+    float4 *o4 = reinterpret_cast<float4 *>(frame);
+    st_stream(o4 + m2, make_float4(v[0], v[1], v[2], v[3]));
+    st_stream(o4 + 255 - m2, make_float4(v[4], v[5], v[6], v[7]));
+}
 __device__ __forceinline__ void load_slot(const float *frame, int m2, float (&v)[8]) {
     const float4 *i4 = reinterpret_cast<const float4 *>(frame);
     const float4 a = i4[m2], b = i4[255 - m2];

@@ -7,7 +7,7 @@
 #include <climits>
 #include <cstdint>
 
-#include "symaccel_internal.h"
+#include "dsp_device.h"
 
 namespace symaccel {
 
@@ -29,7 +29,7 @@ __device__ __forceinline__ void tile_issue_loads(const int32_t *__restrict__ buf
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = 8 * k + rsub;
-        p.v[k] = *reinterpret_cast<const int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q);
+        p.v[k] = ld_stream(reinterpret_cast<const int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q));
     }
 }
 __device__ __forceinline__ void tile_commit(const TilePrefetch &p, int32_t *tile, int lane) {
@@ -43,8 +43,8 @@ __device__ __forceinline__ void tile_store_fast(int32_t *__restrict__ buf, const
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = 8 * k + rsub;
-        *reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q) =
-            *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q);
+        st_stream(reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q),
+                  *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q));
     }
 }
 // Ragged tiles (last columns of a block size that is not a multiple of 32, unaligned rows, last subframes).
@@ -103,9 +103,9 @@ __device__ __forceinline__ void tile_store_decorrelate_fast(int32_t *__restrict_
         const int4 oth = *reinterpret_cast<const int4 *>(tile + (r ^ 1) * kStride + 4 * q);
         const unsigned m = row_mode[r];
         const bool c1 = (r & 1) != 0;
-        *reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q) =
-            make_int4(flac_decorrelated(m, c1, own.x, oth.x, out_shift), flac_decorrelated(m, c1, own.y, oth.y, out_shift),
-                      flac_decorrelated(m, c1, own.z, oth.z, out_shift), flac_decorrelated(m, c1, own.w, oth.w, out_shift));
+        st_stream(reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q),
+                  make_int4(flac_decorrelated(m, c1, own.x, oth.x, out_shift), flac_decorrelated(m, c1, own.y, oth.y, out_shift),
+                            flac_decorrelated(m, c1, own.z, oth.z, out_shift), flac_decorrelated(m, c1, own.w, oth.w, out_shift)));
     }
 }
 __device__ __forceinline__ void tile_store_decorrelate_slow(int32_t *__restrict__ buf, const int32_t *tile,

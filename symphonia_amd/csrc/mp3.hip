@@ -128,8 +128,8 @@ __device__ __forceinline__ void imdct12_win(float (&x)[18], float (&overlap)[18]
 __device__ __forceinline__ void fetch_granule(const float *granule, int hl, float4 (&line)[5]) {
     const float4 *src = reinterpret_cast<const float4 *>(granule);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) line[q] = src[hl + 32 * q];
-    line[4] = src[128 + (hl & 15)];  // lanes 16..31 re-read float4 128..143 (same cache lines) and ignore it
+    for (int q = 0; q < 4; ++q) line[q] = ld_stream(src + hl + 32 * q);
+    line[4] = ld_stream(src + 128 + (hl & 15));  // lanes 16..31 re-read float4 128..143 (same cache lines) and ignore it
 }
 
 #ifndef SYM_MP3_WAVES
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
                 acc += (ra >= 0 ? nA[ra >= 0 ? ra : 0] : oA[ra < 0 ? kHistOld + ra : 0]) * dw0[j];
                 acc += (rb >= 0 ? nB[rb >= 0 ? rb : 0] : oB[rb < 0 ? kHistOld + rb : 0]) * dw1[j];
             }
-            if (emit) (pcm + (chain_base + (size_t)g) * 576)[32 * b + hl] = acc;
+            if (emit) st_stream(pcm + (chain_base + (size_t)g) * 576 + 32 * b + hl, acc);
         }
         wave_sync();  // the window pass has read S; the next round's tile goes to the same LDS
         // ---- slide the history: slots 2..17 of this granule become slots -16..-1

@@ -28,12 +28,12 @@ __device__ __forceinline__ void fetch_lines(const float *sp, const float *rp, ui
     const float2 *src = reinterpret_cast<const float2 *>(sp + off);
 #pragma unroll
     for (int s = 0; s < 8; ++s)
-        if (s < n_loads) line[s] = src[lane + 64 * s];
+        if (s < n_loads) line[s] = ld_stream(src + lane + 64 * s);
     if constexpr (FUSED) {
         const float2 *rs = reinterpret_cast<const float2 *>(rp + off);
 #pragma unroll
         for (int s = 0; s < 8; ++s)
-            if (s < n_loads) res[s] = rs[lane + 64 * s];
+            if (s < n_loads) res[s] = ld_stream(rs + lane + 64 * s);
     }
 }
 template <bool FUSED>
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                     load_slot(wl, lane + 64 * h, w);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) dst[q] = dl[h][q] * w[7 - q] + x[h][q] * w[q];
-                    if (emit) store_slot(o, lane + 64 * h, dst);
+                    if (emit) store_slot_stream(o, lane + 64 * h, dst);
                 }
                 wave_sync();  // Z in LDS is overwritten by the next group
             } else {
@@ -278,15 +278,15 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                 if (emit) {
                     float4 *o4 = reinterpret_cast<float4 *>(o);
                     // copied part: second float4 of every slot with 1020 - 4 m2 >= 576, i.e. m2 <= 111
-                    o4[143 - lane] = make_float4(x[0][4], x[0][5], x[0][6], x[0][7]);           // (572 - 4 lane) / 4
-                    if (lane < 48) o4[79 - lane] = make_float4(x[1][4], x[1][5], x[1][6], x[1][7]);  // (316 - 4 lane) / 4
+                    st_stream(o4 + (143 - lane), make_float4(x[0][4], x[0][5], x[0][6], x[0][7]));           // (572 - 4 lane) / 4
+                    if (lane < 48) st_stream(o4 + (79 - lane), make_float4(x[1][4], x[1][5], x[1][6], x[1][7]));  // (316 - 4 lane) / 4
                     if (lane >= 48) {
                         const float ya[4] = {x[1][0], x[1][1], x[1][2], x[1][3]}, yb[4] = {x[1][4], x[1][5], x[1][6], x[1][7]};
                         float4 ra, rb;
                         ola_short4(ws, 4 * t, ovA, ya, ra);
                         ola_short4(ws, 124 - 4 * t, ovB, yb, rb);
-                        o4[t] = ra;
-                        o4[31 - t] = rb;
+                        st_stream(o4 + (t), ra);
+                        st_stream(o4 + (31 - t), rb);
                     }
                 }
                 wave_sync();  // Z in LDS is overwritten by the next group
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                     // long -> short (dsp.rs:91-106): overlap[0..448) at unity gain, then 128 overlap-added samples.
                     // overlap[448..576) sits in the slots of lanes 48..63 (m2 = 112 + t).
                     if (emit) {
-                        o4[lane] = make_float4(dl[0][0], dl[0][1], dl[0][2], dl[0][3]);                     // 4 m2, m2 < 64
-                        if (lane < 48) o4[64 + lane] = make_float4(dl[1][0], dl[1][1], dl[1][2], dl[1][3]);  // m2 < 112
+                        st_stream(o4 + (lane), make_float4(dl[0][0], dl[0][1], dl[0][2], dl[0][3]));                     // 4 m2, m2 < 64
+                        if (lane < 48) st_stream(o4 + (64 + lane), make_float4(dl[1][0], dl[1][1], dl[1][2], dl[1][3]));  // m2 < 112
                         if (lane >= 48) {
                             const int t = lane - 48;
                             const float oa[4] = {dl[1][0], dl[1][1], dl[1][2], dl[1][3]}, ob[4] = {dl[1][4], dl[1][5], dl[1][6], dl[1][7]};
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                             float4 ra, rb;
                             ola_short4(ws, 4 * t, oa, ya, ra);
                             ola_short4(ws, 124 - 4 * t, ob, yb, rb);
-                            o4[112 + t] = ra;        // (448 + 4 t) / 4
-                            o4[143 - t] = rb;        // (448 + 124 - 4 t) / 4
+                            st_stream(o4 + (112 + t), ra);        // (448 + 4 t) / 4
+                            st_stream(o4 + (143 - t), rb);        // (448 + 124 - 4 t) / 4
                         }
                     }
                 } else if (emit && lane < 32) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                     ys4(ldsf, 0, 4 * lane, y);
                     float4 r;
                     ola_short4(ws, 4 * lane, ov, y, r);
-                    o4[lane] = r;
+                    st_stream(o4 + (lane), r);
                 }
             }
             // ---- the rest, two blocks per round (one per half-wavefront): short -> short (dsp.rs:85-90), lane l of a
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                         ys4(ldsf, i, 4 * l32, y);
                         float4 r;
                         ola_short4(ws, 4 * l32, ov, y, r);
-                        reinterpret_cast<float4 *>(out + op_cur + first_len + 128u * (uint32_t)(i - 1))[l32] = r;
+                        st_stream(reinterpret_cast<float4 *>(out + op_cur + first_len + 128u * (uint32_t)(i - 1)) + l32, r);
                     }
                 }
             }
