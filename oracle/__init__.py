@@ -411,6 +411,52 @@ def aac_tns_filter(coeffs, start, end, order, direction, lpc):
     return c
 
 
+def aac_iquant_requant(val, scale):
+    """iquant(val) and requant(val, scale) of aac/ics/pulse.rs:19-33 for an array of values."""
+    v = _f32(val)
+    iq, rq = np.empty_like(v), np.empty_like(v)
+    lib().so_aac_iquant_requant(_p(v), C.c_float(scale), _p(iq), _p(rq), C.c_size_t(v.size))
+    return iq, rq
+
+
+def aac_pulse(coeffs, bands, scales0, number_pulse, pulse_start_sfb, pulse_offset, pulse_amp):
+    """Pulse::synth (aac/ics/pulse.rs:64-105) on one channel-frame; bands = swb offsets (n_swb + 1), scales0 = scales[0]."""
+    c = np.array(coeffs, dtype=np.float32, copy=True)
+    b = np.ascontiguousarray(bands, dtype=np.int32)
+    sc = _f32(scales0)
+    off = np.ascontiguousarray(pulse_offset, dtype=np.int32)
+    amp = np.ascontiguousarray(pulse_amp, dtype=np.int32)
+    lib().so_aac_pulse(_p(c), _p(b), C.c_int(b.size), _p(sc), C.c_int(int(number_pulse)), C.c_int(int(pulse_start_sfb)), _p(off), _p(amp))
+    return c
+
+
+# ---- Vorbis floor 0 (floor.rs:246-248, 262-340, 353-390) --------------------------
+
+def vorbis_bark_map(n, rate, map_size):
+    out = np.zeros(int(n), np.int32)
+    lib().so_vorbis_bark_map(C.c_uint32(int(n)), C.c_uint32(int(rate)), C.c_uint32(int(map_size)), _p(out))
+    return out
+
+
+def vorbis_floor0_coeffs(angles):
+    c = np.array(angles, dtype=np.float32, copy=True)
+    lib().so_vorbis_floor0_coeffs(_p(c), C.c_int(c.size))
+    return c
+
+
+def vorbis_floor0(coeffs, bark_map, map_size, amplitude_bits, amplitude_offset, amplitude):
+    """Floor0::synthesis for one channel-block: coeffs = 2 cos(lsp) values, bark_map = the map of this block size."""
+    c = _f32(coeffs)
+    m = np.ascontiguousarray(bark_map, dtype=np.int32)
+    out = np.zeros(m.size, np.float32)
+    lib().so_vorbis_floor0.restype = C.c_int
+    st = lib().so_vorbis_floor0(_p(c), C.c_int(c.size), _p(m), C.c_uint32(m.size), C.c_uint32(int(map_size)), C.c_uint32(int(amplitude_bits)),
+                                C.c_uint32(int(amplitude_offset)), C.c_uint64(int(amplitude)), _p(out))
+    if st != 0:
+        raise ValueError("vorbis: invalid floor0 coefficients")
+    return out
+
+
 # ---- MP3 requantisation (layer3/requantize.rs) ---------------------------------
 
 MP3_REQUANT_DTYPE = np.dtype([("global_gain", np.uint8), ("flags", np.uint8), ("block_type", np.uint8),

@@ -512,6 +512,55 @@ void so_aac_tns_filter(float *coeffs, int start, int end, int order, int directi
     }
 }
 
+/* Pulse::synth with iquant / requant (symphonia-codec-aac/src/aac/ics/pulse.rs:19-33, 64-105).  f32 `powf` is the C
+ * library's powf, as it is for the reference (Rust's f32::powf lowers to the same libm call).  `requant` really does
+ * raise `val`, not `val / scale`, to the 3/4 power (pulse.rs:27-33: bval only decides the sign branch); the exponents
+ * 4.0 / 3.0 and 3.0 / 4.0 are f32 divisions. */
+static float aac_iquant(float val)
+{
+    const float e = 4.0f / 3.0f;
+    return val < 0.0f ? -powf(-val, e) : powf(val, e);
+}
+static float aac_requant(float val, float scale)
+{
+    if (scale == 0.0f)
+        return 0.0f;
+    const float bval = val / scale;
+    const float e = 3.0f / 4.0f;
+    return bval >= 0.0f ? powf(val, e) : -powf(-val, e);
+}
+void so_aac_iquant_requant(const float *val, float scale, float *iq, float *rq, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        iq[i] = aac_iquant(val[i]);
+        rq[i] = aac_requant(val[i], scale);
+    }
+}
+void so_aac_pulse(float *coeffs, const int32_t *bands, int n_bands_plus_1, const float *scales0, int number_pulse,
+                  int pulse_start_sfb, const int32_t *pulse_offset, const int32_t *pulse_amp)
+{
+    if (pulse_start_sfb >= n_bands_plus_1 - 1) /* pulse.rs:70-72 */
+        return;
+    int k = bands[pulse_start_sfb];
+    int band = pulse_start_sfb;
+    for (int pno = 0; pno < number_pulse; pno++) {
+        k += pulse_offset[pno];
+        if (k >= 1024)
+            return;
+        while (bands[band + 1] <= k)
+            band++;
+        const float scale = scales0[band];
+        float base = coeffs[k];
+        if (base != 0.0f)
+            base = aac_requant(coeffs[k], scale);
+        if (base > 0.0f)
+            base += (float)pulse_amp[pno];
+        else
+            base -= (float)pulse_amp[pno];
+        coeffs[k] = aac_iquant(base) * scale;
+    }
+}
+
 /* ======================================================================== */
 /* MP3: symphonia-bundle-mp3/src/layer3/hybrid_synthesis.rs, synthesis.rs    */
 /* ======================================================================== */
@@ -1370,6 +1419,73 @@ static void floor1_render_line(uint32_t x0, int32_t y0, uint32_t x1, int32_t y1,
     }
 }
 
+/* Floor 0 (symphonia-codec-vorbis/src/floor.rs).  bark / bark_map: :353-376 (f64 atan / floor from libm); the
+ * `2 cos(coeff)` step that ends read_channel: :246-248 (f32 cos = cosf); synthesis: :262-340; linear_floor0_value: :379-390
+ * (f32 sqrt, expf; the literal 0.11512925 is an f32). */
+static double vorbis_bark(double x)
+{
+    return (13.1 * atan(0.00074 * x)) + (2.24 * atan(0.0000000185 * x * x)) + (0.0001 * x);
+}
+void so_vorbis_bark_map(uint32_t n, uint32_t rate16, uint32_t map_size16, int32_t *map)
+{
+    const int32_t foobar_min = (int32_t)map_size16 - 1;
+    const double rate = (double)rate16;
+    const double rate_by_2n = rate / (2.0 * (double)n);
+    const double c = (double)map_size16 / vorbis_bark(0.5 * rate);
+    for (uint32_t i = 0; i < n; i++) {
+        const double v = floor(vorbis_bark(rate_by_2n * (double)i) * c);
+        int32_t foobar = v >= 2147483647.0 ? INT32_MAX : v <= -2147483648.0 ? INT32_MIN : (int32_t)v; /* `as i32` saturates */
+        map[i] = foobar < foobar_min ? foobar : foobar_min;
+    }
+}
+void so_vorbis_floor0_coeffs(float *coeffs, int order)
+{
+    for (int i = 0; i < order; i++)
+        coeffs[i] = 2.0f * cosf(coeffs[i]);
+}
+/* coeffs = the 2 cos(..) values; map = the bark map of this block size (n entries); returns 0, or -1 for the
+ * reference's decode_error("vorbis: invalid floor0 coefficients") (floor.rs:315-317). */
+int so_vorbis_floor0(const float *coeffs, int order, const int32_t *map, uint32_t n, uint32_t bark_map_size,
+                     uint32_t amplitude_bits, uint32_t amplitude_offset, uint64_t amplitude, float *floor_out)
+{
+    const float pi_f = 3.14159265358979323846264338327950288f;
+    const float omega_step = pi_f / (float)bark_map_size;
+    uint32_t i = 0;
+    for (;;) {
+        const int32_t iter_cond = map[i];
+        const float omega = omega_step * (float)iter_cond;
+        const float cos_omega = cosf(omega);
+        const float two_cos_omega = 2.0f * cos_omega;
+        float p = 1.0f, q = 1.0f;
+        int j = 0;
+        for (; j + 1 < order; j += 2) {
+            p *= coeffs[j + 1] - two_cos_omega;
+            q *= coeffs[j] - two_cos_omega;
+        }
+        if (j < order) { /* odd order: the chunks_exact(2) remainder */
+            q *= coeffs[j] - two_cos_omega;
+            p = p * p * (1.0f - (cos_omega * cos_omega));
+            q = q * q * 0.25f;
+        } else {
+            p = p * p * ((1.0f - cos_omega) / 2.0f);
+            q = q * q * ((1.0f + cos_omega) / 2.0f);
+        }
+        if (p + q == 0.0f)
+            return -1;
+        /* linear_floor0_value */
+        const float a = (float)(amplitude * (uint64_t)amplitude_offset); /* wrapping_mul, then `as f32` */
+        const float b = sqrtf(p + q) * (float)((UINT64_C(1) << amplitude_bits) - 1);
+        const float value = expf(0.11512925f * ((a / b) - (float)amplitude_offset));
+        while (i < n && map[i] == iter_cond) {
+            floor_out[i] = value;
+            i++;
+        }
+        if (i >= n)
+            break;
+    }
+    return 0;
+}
+
 void so_vorbis_floor1(const uint32_t *x_list, const uint32_t *yv, int n_posts, int multiplier,
                       uint32_t n, float *floor_out)
 {
@@ -1560,19 +1676,21 @@ static void flac_lpc_n(int n_max, size_t order, const int32_t *coeffs_n, uint32_
 {
     size_t N = (size_t)n_max;
     size_t n_prefill = (N < len ? N : len) - order;
+    /* The i64 sum of the reference (`.sum::<i64>()`, release build) wraps; signed overflow is undefined in C, so the
+     * accumulation is done in uint64_t (same bits) and reinterpreted for the arithmetic shift. */
     for (size_t i = order; i < order + n_prefill; i++) {
-        int64_t predicted = 0;
+        uint64_t predicted = 0;
         for (size_t j = 0; j < order; j++)
-            predicted += (int64_t)coeffs_n[N - order + j] * (int64_t)buf[i - order + j];
-        buf[i] = wrap_add32(buf[i], (int32_t)(predicted >> shift));
+            predicted += (uint64_t)((int64_t)coeffs_n[N - order + j] * (int64_t)buf[i - order + j]);
+        buf[i] = wrap_add32(buf[i], (int32_t)((int64_t)predicted >> shift));
     }
     if (len <= N)
         return;
     for (size_t i = N; i < len; i++) {
-        int64_t predicted = 0;
+        uint64_t predicted = 0;
         for (size_t j = 0; j < N; j++)
-            predicted += (int64_t)coeffs_n[j] * (int64_t)buf[i - N + j];
-        buf[i] = wrap_add32(buf[i], (int32_t)(predicted >> shift));
+            predicted += (uint64_t)((int64_t)coeffs_n[j] * (int64_t)buf[i - N + j]);
+        buf[i] = wrap_add32(buf[i], (int32_t)((int64_t)predicted >> shift));
     }
 }
 

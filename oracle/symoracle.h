@@ -218,4 +218,13 @@ void so_alac_predict_batch(int32_t *buf, const uint8_t *desc, const int32_t *coe
 #ifdef __cplusplus
 }
 #endif
+/* ---- added in round 2: AAC pulse tool, Vorbis floor 0 (both libm-dependent) ---- */
+void so_aac_iquant_requant(const float *val, float scale, float *iq, float *rq, size_t n);
+void so_aac_pulse(float *coeffs, const int32_t *bands, int n_bands_plus_1, const float *scales0, int number_pulse,
+                  int pulse_start_sfb, const int32_t *pulse_offset, const int32_t *pulse_amp);
+void so_vorbis_bark_map(uint32_t n, uint32_t rate16, uint32_t map_size16, int32_t *map);
+void so_vorbis_floor0_coeffs(float *coeffs, int order);
+int so_vorbis_floor0(const float *coeffs, int order, const int32_t *map, uint32_t n, uint32_t bark_map_size,
+                     uint32_t amplitude_bits, uint32_t amplitude_offset, uint64_t amplitude, float *floor_out);
+
 #endif

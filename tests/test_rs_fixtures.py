@@ -36,7 +36,7 @@ def same(a, b):
 
 
 def test_manifest_covers_the_hot_path():
-    assert {"fft", "imdct", "aac", "mp3", "vorbis", "flac", "alac"} <= set(MANIFEST)
+    assert {"fft", "imdct", "aac", "mp3", "vorbis", "flac", "alac", "mp3_front", "aac_tools"} <= set(MANIFEST)
     for g, m in MANIFEST.items():
         assert m["cases"] and m["sources"], g
     # plain `+ - *` of the reference never wrapped while the fixtures were generated (a debug build would have run the
@@ -196,3 +196,119 @@ def test_oracle_alac():
         o0, o1 = oracle.alac_decorrelate_mid_side(f["ms_%d_in0" % ci], f["ms_%d_in1" % ci], int(w), int(s))
         assert same(o0, f["ms_%d_out0" % ci]) and same(o1, f["ms_%d_out1" % ci]), ci
         ci += 1
+
+
+def rq_desc(row):
+    d = np.zeros(1, oracle.MP3_REQUANT_DTYPE)
+    d["global_gain"], d["flags"], d["block_type"], d["is_mixed"] = row[0], row[1], row[2], row[3]
+    d["subblock_gain"], d["rzero"], d["scalefacs"] = row[4:7], row[7] | (row[8] << 8), row[9:48]
+    return d
+
+
+def st_desc(r):
+    d = np.zeros(1, oracle.MP3_STEREO_DTYPE)
+    d["flags"] = (1 if r[3] else 0) | (2 if r[4] else 0) | (4 if r[0] else 0) | (8 if r[8] else 0)
+    d["block_type"], d["is_mixed"], d["rzero0"], d["rzero1"], d["scalefacs1"] = r[1], r[2], r[6], r[7], r[9:48]
+    return d
+
+
+def test_oracle_mp3_front():
+    f = load("mp3_front")
+    assert same(oracle.mp3_pow43(), f["POW43"])
+    m1, m2 = oracle.mp3_intensity_ratios()
+    assert same(m1, f["IS_RATIOS_MPEG1"]) and same(m2, f["IS_RATIOS_MPEG2"])
+    for sr in range(9):
+        assert np.array_equal(oracle.mp3_sfb_long(sr), f["SFB_LONG_BANDS"][sr])
+        short, mixed, switch = oracle.mp3_sfb_tables(sr)
+        assert np.array_equal(short, f["SFB_SHORT_BANDS"][sr]) and switch == f["SFB_MIXED_SWITCH_POINT"][sr]
+        row = f["SFB_MIXED_BANDS"][sr]
+        assert np.array_equal(mixed, row[row >= 0])
+    for ci in range(f["rq_quant"].shape[0]):
+        got = oracle.mp3_requantize(f["rq_quant"][ci][None], rq_desc(f["rq_desc"][ci]), int(f["rq_sr"][ci]))[0]
+        assert same(got, f["rq_out"][ci]), ci
+    for ci in range(f["st_in"].shape[0]):
+        r = f["st_desc"][ci]
+        a, b = oracle.mp3_stereo(f["st_in"][ci, 0], f["st_in"][ci, 1], st_desc(r)[0], int(r[5]))
+        assert same(np.stack([a, b]), f["st_out"][ci]), ci
+        if r[3] or r[4]:
+            assert (f["st_rzero_out"][ci] == max(r[6], r[7])).all()
+
+
+def tns_filters_of(f, ci):
+    """(start, end, order, direction, lpc) per filter, by the band arithmetic of tns.rs:149-175 (what the host keeps)."""
+    k = "tns_%d_" % ci
+    long_win, nwin, max_sfb = (int(v) for v in f[k + "info"])
+    bands = f["swb_long_48k"] if long_win else f["swb_short_48k"]
+    rate_idx = int(f["rate_idx_48k"][0])
+    tmax = min(int((f["TNS_MAX_LONG_BANDS"] if long_win else f["TNS_MAX_SHORT_BANDS"])[rate_idx]), max_sfb)
+    out = []
+    for w in range(nwin):
+        bottom = len(bands) - 1
+        for fi in range(int(f[k + "n_filt"][w])):
+            ln, order, direction = (int(v) for v in f[k + "filters"][w, fi, :3])
+            top = bottom
+            bottom = max(0, top - ln)
+            if order == 0:
+                continue
+            out.append((w * 128 + int(bands[min(bottom, tmax)]), w * 128 + int(bands[min(top, tmax)]), order, direction,
+                        f[k + "filters"][w, fi, 3:3 + order]))
+    return out
+
+
+def js_modes_of(f, ci):
+    """per-window-band tool + scale, by the group -> window expansion of cpe.rs:110-143 (what the host keeps)."""
+    k = "js_%d_" % ci
+    long_win, nwin, max_sfb, ms_mask_present = (int(v) for v in f[k + "info"])
+    mode, scale = np.zeros(128, np.uint8), np.zeros(128, np.float32)
+    g = 0
+    for w in range(nwin):
+        if w > 0 and not f[k + "grouping"][w - 1]:
+            g += 1
+        for sfb in range(max_sfb):
+            idx = sfb if long_win else w * 16 + sfb
+            cb0, cb1 = int(f[k + "sfb_cb0"][g, sfb]), int(f[k + "sfb_cb1"][g, sfb])
+            if cb1 in (14, 15):
+                invert = ms_mask_present == 1 and f[k + "ms_used"][g, sfb]
+                mode[idx] = 2
+                scale[idx] = np.float32(1.0 if cb1 == 15 else -1.0) * np.float32(-1.0 if invert else 1.0) * f[k + "scales1"][g, sfb]
+            elif cb0 == 13 or cb1 == 13:
+                pass
+            elif f[k + "ms_used"][g, sfb]:
+                mode[idx] = 1
+    return long_win, nwin, max_sfb, mode, scale
+
+
+def test_oracle_aac_tools():
+    f = load("aac_tools")
+    for ci in range(6):
+        c = f["tns_%d_in" % ci].copy()
+        for start, end, order, direction, lpc in tns_filters_of(f, ci):
+            c = oracle.aac_tns_filter(c, start, end, order, direction, lpc)
+        assert same(c, f["tns_%d_out" % ci]), ci
+    for ci in range(4):
+        long_win, nwin, max_sfb, mode, scale = js_modes_of(f, ci)
+        bands = (f["swb_long_48k"] if long_win else f["swb_short_48k"]).astype(np.uint16)
+        l, r = oracle.aac_joint_stereo(f["js_%d_left_in" % ci], f["js_%d_right_in" % ci], nwin, max_sfb, bands, mode, scale)
+        assert same(l, f["js_%d_left_out" % ci]) and same(r, f["js_%d_right_out" % ci]), ci
+    for ci in range(5):
+        p = f["pulse_%d_params" % ci]
+        got = oracle.aac_pulse(f["pulse_%d_in" % ci], f["swb_long_48k"], f["pulse_%d_scales0" % ci], int(p[0]), int(p[1]), p[2:6], p[6:10])
+        assert same(got, f["pulse_%d_out" % ci]), ci
+
+
+def test_oracle_vorbis_floor0():
+    f = load("vorbis")
+    n_cases = 0
+    for c in MANIFEST["vorbis"]["cases"]:
+        if "Floor0" not in c["fn"]:
+            continue
+        n_cases += 1
+        k = "floor0_%d_" % c["case"]
+        b0, b1, order, rate, map_size, amp_bits, amp_off, amp_s, amp_l = (int(v) for v in f[k + "params"])
+        assert np.array_equal(oracle.vorbis_bark_map(1 << (b0 - 1), rate, map_size), f[k + "map_short"])
+        assert np.array_equal(oracle.vorbis_bark_map(1 << (b1 - 1), rate, map_size), f[k + "map_long"])
+        assert same(oracle.vorbis_floor0_coeffs(f[k + "angles"]), f[k + "coeffs"])
+        for which, bexp, amp in (("short", b0, amp_s), ("long", b1, amp_l)):
+            got = oracle.vorbis_floor0(f[k + "coeffs"], f[k + "map_" + which], map_size, amp_bits, amp_off, amp)
+            assert same(got, f[k + "out_" + which]), (c["case"], which)
+    assert n_cases >= 4

@@ -362,10 +362,10 @@ class Builtin:
 
 class RIter:
     """A Rust iterator: a Python iterator, or a materialised list (double-ended / exact-size)."""
-    __slots__ = ('it', 'lst')
+    __slots__ = ('it', 'lst', 'rem')
 
-    def __init__(self, it=None, lst=None):
-        self.it, self.lst = it, lst
+    def __init__(self, it=None, lst=None, rem=None):
+        self.it, self.lst, self.rem = it, lst, rem
 
     def __iter__(self):
         if self.lst is not None:
@@ -754,8 +754,12 @@ class Interp:
                         walk(st)
                         if len(found) == inner_before and pred(repr(st)):
                             found.append(st)
-                    if node[2] is not None:
+                    if node[2] is not None:  # the block's tail expression counts as its last statement
+                        st = ('expr', node[2])
+                        inner_before = len(found)
                         walk(node[2])
+                        if len(found) == inner_before and pred(repr(st)):
+                            found.append(st)
                     return
                 for x in node:
                     walk(x)
@@ -2588,7 +2592,7 @@ class Interp:
                     break
                 out.append(Slice(a, o + i, ln, name.endswith('_mut')))
                 i += c
-            return RIter(lst=out)
+            return RIter(lst=out, rem=Slice(a, o + i, n - i if exact and i < n else 0, name.endswith('_mut')))
         if name == 'windows':
             c = deref(args[0]).v
             return RIter(lst=[Slice(a, o + i, c) for i in range(0, n - c + 1)])
@@ -2675,6 +2679,8 @@ class Interp:
     def iter_method(self, it, name, args, env, gargs):
         if name in ('iter', 'into_iter', 'by_ref', 'iter_mut', 'fuse', 'peekable'):
             return it
+        if name in ('remainder', 'into_remainder'):
+            return it.rem
         if name == 'rev':
             return RIter(lst=it.tolist()[::-1])
         if name == 'enumerate':
