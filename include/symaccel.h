@@ -51,6 +51,7 @@ typedef enum symaccel_status {
     SYMACCEL_ERR_UNSUPPORTED = -2, /* reference: Error::Unsupported */
     SYMACCEL_ERR_DEVICE = -3,      /* HIP error / no device; reference class: Error::IoError */
     SYMACCEL_ERR_OOM = -4,         /* device or host allocation failed */
+    SYMACCEL_ERR_DECODE = -5,      /* reference: Error::DecodeError -- malformed stream data: discard the packet, keep going */
 } symaccel_status;
 
 typedef struct symaccel_ctx symaccel_ctx;
@@ -154,6 +155,29 @@ typedef struct symaccel_aac_tns_filter {
 } symaccel_aac_tns_filter; /* 92 bytes */
 int symaccel_aac_tns_device(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames,
                             const symaccel_aac_tns_filter *d_filters, size_t n_filters);
+
+/* Pulse::synth (aac/ics/pulse.rs:64-105, with iquant / requant :19-33), the tool between joint stereo and TNS
+ * (Ics::synth_channel, ics/mod.rs:452-454).  HOST function on HOST memory: the tool raises values to the 4/3 and 3/4
+ * power with f32 `powf`, which the reference takes from libm; this library calls the same libm so the values are the
+ * reference's.  It is part of the CPU front end (it runs on the dequantised spectra before they are uploaded), not a
+ * fallback for a kernel.  h_coeffs[n_frames][1024]; one record per channel-frame that carries pulse data (long windows
+ * only, as in the reference); scales0 = Ics::scales[0] (one scale per scale-factor band); swb_long: n_swb_long + 1 offsets. */
+typedef struct symaccel_aac_pulse {
+    uint32_t frame;           /* index into h_coeffs */
+    uint8_t number_pulse;     /* 1..4 */
+    uint8_t pulse_start_sfb;
+    uint8_t pulse_offset[4];
+    uint8_t pulse_amp[4];
+    uint8_t pad[2];
+    float scales0[64];
+} symaccel_aac_pulse; /* 272 bytes */
+int symaccel_host_aac_pulse(float *h_coeffs, size_t n_frames, const symaccel_aac_pulse *h_pulse, size_t n_pulse,
+                            const uint16_t *swb_long, int n_swb_long);
+
+/* Per-filter status of symaccel_aac_tns_device's list (what the kernel skips): 0, or SYMACCEL_ERR_INVALID_ARG for an
+ * entry with frame >= n_frames, start >= end, end > 1024 or an order outside 1..20.  d_status[n_filters] int8. */
+int symaccel_aac_tns_status_device(symaccel_ctx *ctx, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
+                                   size_t n_filters, int8_t *d_status);
 
 /* --------------------------------------------------------------------------------- MP3 */
 
@@ -316,6 +340,19 @@ int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int
                                   int multiplier, const uint32_t *d_y, uint32_t n, float *d_floor,
                                   size_t count);
 
+/* Floor 0 (floor.rs:124-397) -- HOST functions on HOST memory, for the same reason as symaccel_host_aac_pulse: f64
+ * atan / floor and f32 cos / sqrt / exp from libm, in the reference's operation order.  Floor-0 streams are rare (the
+ * reference encoder never produces them); the curve is computed on the host and uploaded like a floor-1 curve.
+ *  - bark_map (floor.rs:358-376): the map of one block size, n = blocksize / 2 entries.
+ *  - floor0_coeffs: the `coeff = 2 cos(coeff)` step that ends Floor0::read_channel (floor.rs:246-248), in place.
+ *  - floor0: Floor0::synthesis + linear_floor0_value (floor.rs:262-340, 379-390) for one channel-block; returns
+ *    SYMACCEL_ERR_DECODE where the reference returns decode_error("vorbis: invalid floor0 coefficients"). */
+int symaccel_host_vorbis_bark_map(uint32_t n, uint16_t floor0_rate, uint16_t floor0_bark_map_size, int32_t *h_map);
+int symaccel_host_vorbis_floor0_coeffs(float *h_coeffs, int order);
+int symaccel_host_vorbis_floor0(const float *h_coeffs, int order, const int32_t *h_map, uint32_t n,
+                                uint16_t floor0_bark_map_size, uint8_t amplitude_bits, uint8_t amplitude_offset,
+                                uint64_t amplitude, float *h_floor);
+
 /* --------------------------------------------------------------------------------- FLAC */
 
 #define SYMACCEL_FLAC_VERBATIM 0u /* constant / verbatim subframe: predictor is a no-op */
@@ -337,6 +374,13 @@ int symaccel_flac_restore_device(symaccel_ctx *ctx, int32_t *d_buf, const symacc
                                  const int32_t *d_coeffs, size_t n_blocks, size_t blocksize);
 int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac_desc *h_desc,
                           const int32_t *h_coeffs, size_t n_blocks, size_t blocksize);
+/* Per-block status of a descriptor array, as the reference would have judged each subframe (d_status[n_blocks] int8):
+ * 0 = decodable; SYMACCEL_ERR_DECODE = predictor order greater than the block size (decoder.rs:431-433, 456-458), an
+ * unknown kind, a fixed order above 4 or an LPC order outside 1..32; SYMACCEL_ERR_UNSUPPORTED = shift > 31, the
+ * encoding of a negative qlp shift (decoder.rs:506-508 returns Unsupported).  The restore kernels clamp such blocks
+ * instead of faulting; a shim uses this array to fail exactly the packets the reference fails. */
+int symaccel_flac_block_status_device(symaccel_ctx *ctx, const symaccel_flac_desc *d_desc, size_t n_blocks,
+                                      size_t blocksize, int8_t *d_status);
 /* Predictor restore with the stereo decorrelation and the final shift fused into the write-back: blocks 2p and 2p+1
  * are channel 0 and channel 1 of pair p (n_blocks even), pair_mode[p] as for symaccel_flac_decorrelate_device below,
  * out_shift = 32 - bits_per_sample.  One pass over HBM instead of two (decoder.rs:199-242 in one kernel). */
@@ -370,6 +414,10 @@ int symaccel_alac_predict_device(symaccel_ctx *ctx, int32_t *d_buf, const symacc
                                  const int32_t *d_coeffs, size_t n_blocks, size_t blocksize);
 int symaccel_alac_predict(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_alac_desc *h_desc,
                           const int32_t *h_coeffs, size_t n_blocks, size_t blocksize);
+/* Per-block status (d_status[n_blocks] int8): 0, or SYMACCEL_ERR_DECODE for modes 1..14, which the reference rejects
+ * with decode_error("alac: invalid mode") (lib.rs:167-169) and the predict kernels leave untouched. */
+int symaccel_alac_block_status_device(symaccel_ctx *ctx, const symaccel_alac_desc *d_desc, size_t n_blocks,
+                                      int8_t *d_status);
 /* predict with decorrelate_mid_side fused into the write-back (decode_element, lib.rs:541-560, in one pass over HBM):
  * blocks 2p and 2p+1 are the two channels of pair p (n_blocks even); pair_weight[p] (0 = no mixing), pair_shift[p]. */
 int symaccel_alac_predict_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc,

@@ -18,6 +18,7 @@ ERR_INVALID_ARG = -1
 ERR_UNSUPPORTED = -2
 ERR_DEVICE = -3
 ERR_OOM = -4
+ERR_DECODE = -5
 
 TABLE_AAC_KBD_LONG, TABLE_AAC_KBD_SHORT, TABLE_AAC_SINE_LONG, TABLE_AAC_SINE_SHORT = 0, 1, 2, 3
 TABLE_MP3_SYNTH_D, TABLE_MP3_IMDCT_WIN, TABLE_VORBIS_FLOOR1_DB, TABLE_MP3_CONSTS = 4, 5, 6, 7
@@ -36,6 +37,8 @@ ABI_SYMBOLS = [
     "symaccel_flac_decorrelate_device", "symaccel_flac_decorrelate", "symaccel_alac_predict_device",
     "symaccel_alac_predict", "symaccel_alac_predict_stereo_device", "symaccel_alac_mid_side_device", "symaccel_alac_mid_side", "symaccel_table_f32", "symaccel_imdct_twiddles",
     "symaccel_fft_twiddles",
+    "symaccel_host_aac_pulse", "symaccel_host_vorbis_bark_map", "symaccel_host_vorbis_floor0_coeffs", "symaccel_host_vorbis_floor0",
+    "symaccel_flac_block_status_device", "symaccel_alac_block_status_device", "symaccel_aac_tns_status_device",
     "symaccel_aac_synth_pp_device", "symaccel_mp3_synth_pp_device", "symaccel_vorbis_synth_pp_device", "symaccel_mpa_polyphase_pp_device",
 ]
 
@@ -105,6 +108,13 @@ class Library:
         d.symaccel_mp3_synth_pp_device.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_vorbis_synth_pp_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_mpa_polyphase_pp_device.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_host_aac_pulse.argtypes = [_vp, _sz, _vp, _sz, _vp, _i]
+        d.symaccel_host_vorbis_bark_map.argtypes = [_u32, C.c_uint16, C.c_uint16, _vp]
+        d.symaccel_host_vorbis_floor0_coeffs.argtypes = [_vp, _i]
+        d.symaccel_host_vorbis_floor0.argtypes = [_vp, _i, _vp, _u32, C.c_uint16, C.c_uint8, C.c_uint8, C.c_uint64, _vp]
+        d.symaccel_flac_block_status_device.argtypes = [_vp, _vp, _sz, _sz, _vp]
+        d.symaccel_alac_block_status_device.argtypes = [_vp, _vp, _sz, _vp]
+        d.symaccel_aac_tns_status_device.argtypes = [_vp, _sz, _vp, _sz, _vp]
         d.symaccel_table_f32.argtypes = [_vp, _i, _vp, _sz]
         d.symaccel_imdct_twiddles.argtypes = [_i, _d, _vp]
         d.symaccel_fft_twiddles.argtypes = [_i, _vp]

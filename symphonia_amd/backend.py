@@ -533,3 +533,68 @@ class AlacPredictor:
         self.ctx._call(d.symaccel_alac_mid_side, _ptr(_np(weight, np.int32)), _ptr(_np(shift, np.uint8)), _ptr(a), _ptr(b),
                        n_pairs, bs)
         return a, b
+
+
+# ---- host-side tools (libm-dependent stages that stay on the CPU) and per-record status arrays ----------------------
+
+AAC_PULSE_DTYPE = np.dtype([("frame", np.uint32), ("number_pulse", np.uint8), ("pulse_start_sfb", np.uint8), ("pulse_offset", np.uint8, (4,)),
+                            ("pulse_amp", np.uint8, (4,)), ("pad", np.uint8, (2,)), ("scales0", np.float32, (64,))])
+assert AAC_PULSE_DTYPE.itemsize == 272
+
+
+def aac_pulse(coeffs, pulses, swb_long, library=None):
+    """Pulse::synth (aac/ics/pulse.rs:64-105) on HOST spectra coeffs[n_frames, 1024] (in place; numpy float32, C order).
+    pulses: AAC_PULSE_DTYPE records; swb_long: n_swb + 1 offsets."""
+    lib = library if library is not None else _ffi.default_library()
+    assert isinstance(coeffs, np.ndarray) and coeffs.dtype == np.float32 and coeffs.flags.c_contiguous and coeffs.shape[-1] == 1024
+    p = np.ascontiguousarray(pulses, dtype=AAC_PULSE_DTYPE)
+    swb = _np(swb_long, np.uint16)
+    lib.check(lib.dll.symaccel_host_aac_pulse(_ptr(coeffs), coeffs.size // 1024, _ptr(p), p.size, _ptr(swb), swb.size - 1))
+    return coeffs
+
+
+def vorbis_bark_map(n, rate, bark_map_size, library=None):
+    """bark_map (vorbis floor.rs:358-376), n = blocksize / 2."""
+    lib = library if library is not None else _ffi.default_library()
+    out = np.zeros(int(n), np.int32)
+    lib.check(lib.dll.symaccel_host_vorbis_bark_map(int(n), int(rate), int(bark_map_size), _ptr(out)))
+    return out
+
+
+def vorbis_floor0_coeffs(angles, library=None):
+    """coeff = 2 cos(coeff) (the end of Floor0::read_channel, floor.rs:246-248)."""
+    lib = library if library is not None else _ffi.default_library()
+    c = np.array(angles, dtype=np.float32, copy=True)
+    lib.check(lib.dll.symaccel_host_vorbis_floor0_coeffs(_ptr(c), c.size))
+    return c
+
+
+def vorbis_floor0(coeffs, bark_map, bark_map_size, amplitude_bits, amplitude_offset, amplitude, library=None):
+    """Floor0::synthesis (floor.rs:262-340) for one channel-block on the host; raises SymaccelError (status ERR_DECODE)
+    where the reference returns decode_error("vorbis: invalid floor0 coefficients")."""
+    lib = library if library is not None else _ffi.default_library()
+    c = _np(coeffs, np.float32)
+    m = _np(bark_map, np.int32)
+    out = np.zeros(m.size, np.float32)
+    lib.check(lib.dll.symaccel_host_vorbis_floor0(_ptr(c), c.size, _ptr(m), m.size, int(bark_map_size), int(amplitude_bits),
+                                                  int(amplitude_offset), int(amplitude), _ptr(out)))
+    return out
+
+
+def flac_block_status(ctx, desc, blocksize, status):
+    """desc[n] FLAC_DESC_DTYPE (device), status[n] int8 (device): what the reference would have answered per subframe."""
+    n = (desc.numel() * desc.element_size() if _is_torch(desc) else desc.nbytes) // 4
+    ctx._call(ctx.lib.dll.symaccel_flac_block_status_device, _ptr(desc), n, int(blocksize), _ptr(status))
+    return status
+
+
+def alac_block_status(ctx, desc, status):
+    n = (desc.numel() * desc.element_size() if _is_torch(desc) else desc.nbytes) // 4
+    ctx._call(ctx.lib.dll.symaccel_alac_block_status_device, _ptr(desc), n, _ptr(status))
+    return status
+
+
+def aac_tns_status(ctx, n_frames, filters, status):
+    n = (filters.numel() * filters.element_size() if _is_torch(filters) else filters.nbytes) // 92
+    ctx._call(ctx.lib.dll.symaccel_aac_tns_status_device, int(n_frames), _ptr(filters), n, _ptr(status))
+    return status

@@ -244,6 +244,7 @@ const char *symaccel_strerror(int status) {
         case SYMACCEL_ERR_UNSUPPORTED: return "symaccel: unsupported configuration";
         case SYMACCEL_ERR_DEVICE: return "symaccel: HIP device error";
         case SYMACCEL_ERR_OOM: return "symaccel: out of memory";
+        case SYMACCEL_ERR_DECODE: return "symaccel: malformed stream data";
         default: return "symaccel: unknown status";
     }
 }
@@ -721,6 +722,37 @@ int symaccel_flac_decorrelate_device(symaccel_ctx *ctx, const uint8_t *d_mode, i
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     return launch_flac_decorrelate(ctx, d_mode, d_ch0, d_ch1, n_pairs, blocksize, out_shift);
+}
+
+// ---- per-record status arrays --------------------------------------------------------------
+
+int symaccel_flac_block_status_device(symaccel_ctx *ctx, const symaccel_flac_desc *d_desc, size_t n_blocks, size_t blocksize,
+                                      int8_t *d_status) {
+    if (!ctx || blocksize > 65535) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0) return SYMACCEL_OK;
+    if (!d_desc || !d_status) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_flac_status(ctx, d_desc, n_blocks, blocksize, d_status);
+}
+
+int symaccel_alac_block_status_device(symaccel_ctx *ctx, const symaccel_alac_desc *d_desc, size_t n_blocks, int8_t *d_status) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0) return SYMACCEL_OK;
+    if (!d_desc || !d_status) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_alac_status(ctx, d_desc, n_blocks, d_status);
+}
+
+int symaccel_aac_tns_status_device(symaccel_ctx *ctx, size_t n_frames, const symaccel_aac_tns_filter *d_filters, size_t n_filters,
+                                   int8_t *d_status) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_filters == 0) return SYMACCEL_OK;
+    if (!d_filters || !d_status) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_tns_status(ctx, d_filters, n_filters, n_frames, d_status);
 }
 
 // ---- tables -------------------------------------------------------------------------------

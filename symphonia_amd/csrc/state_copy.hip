@@ -25,7 +25,57 @@ __global__ __launch_bounds__(256) void state_copy_kernel(CopyJob job) {
     }
 }
 
+// Per-record status arrays (what a reference decoder would have answered for each block / filter): pure functions of
+// the descriptors, one thread per record.
+__global__ __launch_bounds__(256) void flac_status_kernel(const symaccel_flac_desc *__restrict__ desc, size_t n, unsigned blocksize,
+                                                          int8_t *__restrict__ status) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const symaccel_flac_desc d = desc[i];
+        int st = SYMACCEL_OK;
+        if (d.kind > SYMACCEL_FLAC_LPC || d.order > blocksize) st = SYMACCEL_ERR_DECODE;                  // decoder.rs:431-433, 456-458
+        else if (d.kind == SYMACCEL_FLAC_FIXED && d.order > 4) st = SYMACCEL_ERR_DECODE;                  // fixed orders are 0..4
+        else if (d.kind == SYMACCEL_FLAC_LPC && (d.order < 1 || d.order > 32)) st = SYMACCEL_ERR_DECODE;  // decoder.rs:361
+        else if (d.kind == SYMACCEL_FLAC_LPC && d.shift > 31) st = SYMACCEL_ERR_UNSUPPORTED;              // decoder.rs:506-508
+        status[i] = (int8_t)st;
+    }
+}
+__global__ __launch_bounds__(256) void alac_status_kernel(const symaccel_alac_desc *__restrict__ desc, size_t n, int8_t *__restrict__ status) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned mode = desc[i].mode;
+        status[i] = (int8_t)((mode > 0 && mode < 15) ? SYMACCEL_ERR_DECODE : SYMACCEL_OK);  // lib.rs:167-169
+    }
+}
+__global__ __launch_bounds__(256) void tns_status_kernel(const symaccel_aac_tns_filter *__restrict__ f, size_t n, unsigned n_frames,
+                                                         int8_t *__restrict__ status) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const symaccel_aac_tns_filter x = f[i];
+        const bool ok = x.frame < n_frames && x.start < x.end && x.end <= 1024 && x.order >= 1 && x.order <= 20;
+        status[i] = (int8_t)(ok ? SYMACCEL_OK : SYMACCEL_ERR_INVALID_ARG);
+    }
+}
+
 }  // namespace
+
+static unsigned status_grid(size_t n) {
+    const size_t b = (n + 255) / 256;
+    return (unsigned)(b < 4096 ? (b ? b : 1) : 4096);
+}
+int launch_flac_status(symaccel_ctx *ctx, const symaccel_flac_desc *d_desc, size_t n, size_t blocksize, int8_t *d_status) {
+    hipLaunchKernelGGL(flac_status_kernel, dim3(status_grid(n)), dim3(256), 0, ctx->stream, d_desc, n, (unsigned)blocksize, d_status);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+int launch_alac_status(symaccel_ctx *ctx, const symaccel_alac_desc *d_desc, size_t n, int8_t *d_status) {
+    hipLaunchKernelGGL(alac_status_kernel, dim3(status_grid(n)), dim3(256), 0, ctx->stream, d_desc, n, d_status);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+int launch_tns_status(symaccel_ctx *ctx, const symaccel_aac_tns_filter *d_filters, size_t n, size_t n_frames, int8_t *d_status) {
+    hipLaunchKernelGGL(tns_status_kernel, dim3(status_grid(n)), dim3(256), 0, ctx->stream, d_filters, n,
+                       (unsigned)(n_frames > 0xffffffffu ? 0xffffffffu : n_frames), d_status);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
 
 // bytes must be multiples of 4 (all state arrays are f32 / i32).
 int launch_state_copy(symaccel_ctx *ctx, void *dst0, const void *src0, size_t bytes0, void *dst1, const void *src1,

@@ -217,6 +217,9 @@ int launch_alac_mid_side(symaccel_ctx *ctx, const int32_t *d_weight, const uint8
                          size_t n_pairs, size_t blocksize);
 int launch_state_copy(symaccel_ctx *ctx, void *dst0, const void *src0, size_t bytes0, void *dst1, const void *src1,
                       size_t bytes1, void *dst2, const void *src2, size_t bytes2);
+int launch_flac_status(symaccel_ctx *ctx, const symaccel_flac_desc *d_desc, size_t n, size_t blocksize, int8_t *d_status);
+int launch_alac_status(symaccel_ctx *ctx, const symaccel_alac_desc *d_desc, size_t n, int8_t *d_status);
+int launch_tns_status(symaccel_ctx *ctx, const symaccel_aac_tns_filter *d_filters, size_t n, size_t n_frames, int8_t *d_status);
 int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
                         const int32_t *d_coeffs, size_t n_blocks, size_t blocksize, const uint8_t *d_pair_mode = nullptr,
                         uint32_t out_shift = 0);
