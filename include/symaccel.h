@@ -73,6 +73,14 @@ int symaccel_sync(symaccel_ctx *ctx);
  * segment starts with a one-frame halo recompute.  0 = library default. */
 int symaccel_ctx_set_segment(symaccel_ctx *ctx, int frames_per_segment);
 
+/* ------------------------------------------------------------------ host memory and staged batches
+ * Page-locked host memory for the batch buffers a shim hands to the host-pointer entry points: with it the
+ * `_pipelined` entry points below overlap H2D, kernels and D2H (pageable memory works too, without the overlap). */
+int symaccel_host_alloc(size_t bytes, void **out);
+int symaccel_host_free(void *p);
+int symaccel_host_register(void *p, size_t bytes);   /* pin memory the caller already owns */
+int symaccel_host_unregister(void *p);
+
 /* ------------------------------------------------------------------ core dsp (symphonia-core) */
 
 /* Fft::fft / Fft::fft_inplace (symphonia-core/src/dsp/fft/no_simd.rs:96-140): `count` forward
@@ -109,6 +117,11 @@ int symaccel_aac_synth_device(symaccel_ctx *ctx, const float *d_coeffs, const ui
                               size_t frames_per_chain);
 int symaccel_aac_synth(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *h_side,
                        float *h_delay_io, float *h_pcm, size_t n_chains, size_t frames_per_chain);
+/* symaccel_aac_synth with pinned / chunked / double-buffered staging: the batch is cut into chunks of `chunk_frames`
+ * frames per chain (0 = library default, ~32 MiB of spectra per chunk); chunk k+1 is copied in and chunk k-1 copied out
+ * while chunk k is transformed.  Same arguments and results as symaccel_aac_synth (which routes here for big batches). */
+int symaccel_aac_synth_pipelined(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *h_side, float *h_delay_io,
+                                 float *h_pcm, size_t n_chains, size_t frames_per_chain, size_t chunk_frames);
 /* The same with the delay lines as separate in / out buffers (d_delay_in != d_delay_out): one launch. */
 int symaccel_aac_synth_pp_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side,
                                  const float *d_delay_in, float *d_delay_out, float *d_pcm,
@@ -208,6 +221,9 @@ int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_
                        int sample_rate_idx, float *h_overlap_io, float *h_vvec_io,
                        int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
                        size_t granules_per_chain);
+int symaccel_mp3_synth_pipelined(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_side *h_side,
+                                 int sample_rate_idx, float *h_overlap_io, float *h_vvec_io, int32_t *h_vfront_io,
+                                 float *h_pcm, size_t n_chains, size_t granules_per_chain, size_t chunk_granules);
 /* The same with SynthesisState / overlap as separate in / out buffers (pairwise distinct): one launch. */
 int symaccel_mp3_synth_pp_device(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_side,
                                  int sample_rate_idx, const float *d_overlap_in, const float *d_vvec_in,
@@ -374,6 +390,8 @@ int symaccel_flac_restore_device(symaccel_ctx *ctx, int32_t *d_buf, const symacc
                                  const int32_t *d_coeffs, size_t n_blocks, size_t blocksize);
 int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac_desc *h_desc,
                           const int32_t *h_coeffs, size_t n_blocks, size_t blocksize);
+int symaccel_flac_restore_pipelined(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac_desc *h_desc,
+                                    const int32_t *h_coeffs, size_t n_blocks, size_t blocksize, size_t chunk_blocks);
 /* Per-block status of a descriptor array, as the reference would have judged each subframe (d_status[n_blocks] int8):
  * 0 = decodable; SYMACCEL_ERR_DECODE = predictor order greater than the block size (decoder.rs:431-433, 456-458), an
  * unknown kind, a fixed order above 4 or an LPC order outside 1..32; SYMACCEL_ERR_UNSUPPORTED = shift > 31, the

@@ -37,6 +37,8 @@ ABI_SYMBOLS = [
     "symaccel_flac_decorrelate_device", "symaccel_flac_decorrelate", "symaccel_alac_predict_device",
     "symaccel_alac_predict", "symaccel_alac_predict_stereo_device", "symaccel_alac_mid_side_device", "symaccel_alac_mid_side", "symaccel_table_f32", "symaccel_imdct_twiddles",
     "symaccel_fft_twiddles",
+    "symaccel_host_alloc", "symaccel_host_free", "symaccel_host_register", "symaccel_host_unregister",
+    "symaccel_aac_synth_pipelined", "symaccel_mp3_synth_pipelined", "symaccel_flac_restore_pipelined",
     "symaccel_host_aac_pulse", "symaccel_host_vorbis_bark_map", "symaccel_host_vorbis_floor0_coeffs", "symaccel_host_vorbis_floor0",
     "symaccel_flac_block_status_device", "symaccel_alac_block_status_device", "symaccel_aac_tns_status_device",
     "symaccel_aac_synth_pp_device", "symaccel_mp3_synth_pp_device", "symaccel_vorbis_synth_pp_device", "symaccel_mpa_polyphase_pp_device",
@@ -108,6 +110,13 @@ class Library:
         d.symaccel_mp3_synth_pp_device.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_vorbis_synth_pp_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_mpa_polyphase_pp_device.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_host_alloc.argtypes = [_sz, C.POINTER(_vp)]
+        d.symaccel_host_free.argtypes = [_vp]
+        d.symaccel_host_register.argtypes = [_vp, _sz]
+        d.symaccel_host_unregister.argtypes = [_vp]
+        d.symaccel_aac_synth_pipelined.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
+        d.symaccel_mp3_synth_pipelined.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
+        d.symaccel_flac_restore_pipelined.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_host_aac_pulse.argtypes = [_vp, _sz, _vp, _sz, _vp, _i]
         d.symaccel_host_vorbis_bark_map.argtypes = [_u32, C.c_uint16, C.c_uint16, _vp]
         d.symaccel_host_vorbis_floor0_coeffs.argtypes = [_vp, _i]

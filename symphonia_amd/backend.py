@@ -150,7 +150,7 @@ class AacDsp:
     def __init__(self, ctx):
         self.ctx = ctx
 
-    def synth(self, coeffs, side, delay, pcm=None, delay_out=None):
+    def synth(self, coeffs, side, delay, pcm=None, delay_out=None, chunk_frames=None):
         """coeffs[chains, frames, 1024], side[chains, frames] u8, delay[chains, 1024] (updated).
         numpy: returns (pcm, new_delay).  torch: writes pcm / delay in place, returns pcm.
         delay_out (torch, a second state buffer): the ping-pong entry point -- `delay` is only read, the new delay
@@ -176,7 +176,10 @@ class AacDsp:
         new_delay = np.array(delay, dtype=np.float32, copy=True, order="C")
         assert side.shape == (nch, nfr) and new_delay.shape == (nch, 1024)
         res = np.empty((nch, nfr, 1024), dtype=np.float32)
-        self.ctx._call(d.symaccel_aac_synth, _ptr(coeffs), _ptr(side), _ptr(new_delay), _ptr(res), nch, nfr)
+        if chunk_frames is not None:  # the staged (chunked, overlapped) host path, explicitly
+            self.ctx._call(d.symaccel_aac_synth_pipelined, _ptr(coeffs), _ptr(side), _ptr(new_delay), _ptr(res), nch, nfr, int(chunk_frames))
+        else:
+            self.ctx._call(d.symaccel_aac_synth, _ptr(coeffs), _ptr(side), _ptr(new_delay), _ptr(res), nch, nfr)
         return res, new_delay
 
 
@@ -234,7 +237,7 @@ class Mp3Synthesis:
             raise ValueError("sample_rate_idx")
         self.ctx, self.sr = ctx, int(sample_rate_idx)
 
-    def synth(self, xr, side, overlap, v_vec, v_front, pcm=None, state_out=None):
+    def synth(self, xr, side, overlap, v_vec, v_front, pcm=None, state_out=None, chunk_granules=None):
         """state_out = (overlap_out, v_vec_out, v_front_out): the ping-pong entry point (device buffers only)."""
         d = self.ctx.lib.dll
         nch, ngr = int(xr.shape[0]), int(xr.shape[1])
@@ -258,8 +261,12 @@ class Mp3Synthesis:
         vf = np.array(v_front, dtype=np.int32, copy=True, order="C")
         assert ov.size == nch * 576 and vv.size == nch * 1024 and vf.size == nch
         res = np.empty((nch, ngr, 576), dtype=np.float32)
-        self.ctx._call(d.symaccel_mp3_synth, _ptr(xr), _ptr(side), self.sr, _ptr(ov), _ptr(vv), _ptr(vf), _ptr(res),
-                       nch, ngr)
+        if chunk_granules is not None:
+            self.ctx._call(d.symaccel_mp3_synth_pipelined, _ptr(xr), _ptr(side), self.sr, _ptr(ov), _ptr(vv), _ptr(vf), _ptr(res),
+                           nch, ngr, int(chunk_granules))
+        else:
+            self.ctx._call(d.symaccel_mp3_synth, _ptr(xr), _ptr(side), self.sr, _ptr(ov), _ptr(vv), _ptr(vf), _ptr(res),
+                           nch, ngr)
         return res, ov, vv, vf
 
 
@@ -454,7 +461,7 @@ class FlacPredictor:
     def __init__(self, ctx):
         self.ctx = ctx
 
-    def restore(self, buf, desc, coeffs):
+    def restore(self, buf, desc, coeffs, chunk_blocks=None):
         """buf[n_blocks, blocksize] i32 (warm-up + residuals) -> samples.  numpy: returns a new array;
         torch: in place."""
         d = self.ctx.lib.dll
@@ -466,7 +473,10 @@ class FlacPredictor:
         dsc = np.ascontiguousarray(desc)
         co = _np(coeffs, np.int32)
         assert dsc.nbytes == nb * 4 and co.shape == (nb, 32)
-        self.ctx._call(d.symaccel_flac_restore, _ptr(res), _ptr(dsc), _ptr(co), nb, bs)
+        if chunk_blocks is not None:
+            self.ctx._call(d.symaccel_flac_restore_pipelined, _ptr(res), _ptr(dsc), _ptr(co), nb, bs, int(chunk_blocks))
+        else:
+            self.ctx._call(d.symaccel_flac_restore, _ptr(res), _ptr(dsc), _ptr(co), nb, bs)
         return res
 
     def restore_stereo(self, buf, desc, coeffs, pair_mode, out_shift=0):
@@ -598,3 +608,22 @@ def aac_tns_status(ctx, n_frames, filters, status):
     n = (filters.numel() * filters.element_size() if _is_torch(filters) else filters.nbytes) // 92
     ctx._call(ctx.lib.dll.symaccel_aac_tns_status_device, int(n_frames), _ptr(filters), n, _ptr(status))
     return status
+
+
+class PinnedBuffer:
+    """Page-locked host memory from symaccel_host_alloc, exposed as a numpy array (for the staged host entry points)."""
+
+    def __init__(self, shape, dtype, library=None):
+        self.lib = library if library is not None else _ffi.default_library()
+        self.shape, self.dtype = tuple(int(v) for v in shape), np.dtype(dtype)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        self.lib.check(self.lib.dll.symaccel_host_alloc(max(nbytes, 16), C.byref(p)))
+        self.ptr = p
+        self.array = np.frombuffer((C.c_char * max(nbytes, 1)).from_address(p.value), dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def free(self):
+        if self.ptr is not None:
+            self.array = None
+            self.lib.dll.symaccel_host_free(self.ptr)
+            self.ptr = None

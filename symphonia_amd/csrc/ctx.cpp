@@ -226,6 +226,7 @@ struct DevBuf {
 };
 
 bool pow2(long v) { return v > 0 && (v & (v - 1)) == 0; }
+constexpr size_t kPipelineBytes = (size_t)64 << 20;  // host batches from this size on are staged in overlapped chunks (stage.cpp)
 constexpr int kMaxFft = 4096;  // largest Fft the generic LDS kernel holds (Imdct: twice that); the reference's limit is 65536
 
 }  // namespace
@@ -411,6 +412,8 @@ int symaccel_aac_synth(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
     if (!h_coeffs || !h_side || !h_delay_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains * frames_per_chain * 4096 >= kPipelineBytes && frames_per_chain >= 16)
+        return symaccel_aac_synth_pipelined(ctx, h_coeffs, h_side, h_delay_io, h_pcm, n_chains, frames_per_chain, 0);
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     const size_t nf = n_chains * frames_per_chain;
@@ -470,6 +473,9 @@ int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_
     if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
     if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
     if (!h_xr || !h_side || !h_overlap_io || !h_vvec_io || !h_vfront_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains * granules_per_chain * 2304 >= kPipelineBytes && granules_per_chain >= 16)
+        return symaccel_mp3_synth_pipelined(ctx, h_xr, h_side, sample_rate_idx, h_overlap_io, h_vvec_io, h_vfront_io, h_pcm, n_chains,
+                                            granules_per_chain, 0);
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     const size_t ng = n_chains * granules_per_chain;
@@ -672,6 +678,8 @@ int symaccel_flac_restore(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac
         if (d.kind == SYMACCEL_FLAC_FIXED && d.order > 4) return SYMACCEL_ERR_INVALID_ARG;
         if (d.kind == SYMACCEL_FLAC_LPC && (d.order < 1 || d.order > 32)) return SYMACCEL_ERR_INVALID_ARG;
     }
+    if (n_blocks * blocksize * 4 >= kPipelineBytes && n_blocks >= 256)
+        return symaccel_flac_restore_pipelined(ctx, h_buf, h_desc, h_coeffs, n_blocks, blocksize, 0);
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     DevBuf buf(ctx), desc(ctx), co(ctx);

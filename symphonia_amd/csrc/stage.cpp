@@ -1,0 +1,249 @@
+// Host-pointer entry points: pinned, chunked, double-buffered staging.
+//
+// The device entry points assume the batch is resident in HBM.  A decoder adapter (AudioDecoder::decode gets a packet
+// in host memory and must hand back a buffer in host memory) pays PCIe both ways: for a config-2 AAC batch that is 1 GiB
+// each way against a quarter of a millisecond of kernel time.  The `*_pipelined` entry points -- which the plain
+// host-pointer entry points of ctx.cpp route to for large batches -- cut the batch into chunks along the frame axis and
+// keep three queues busy at once:
+//
+//      copy-in stream :  H2D(k+1) ..........
+//      compute stream :  kernel(k) ......        (state carried chunk to chunk in two ping-pong device buffers)
+//      copy-out stream:  D2H(k-1) ..........
+//
+// with two device buffer sets, so the wall time tends to max(H2D, D2H, kernel) instead of their sum.  The overlap needs
+// page-locked host memory: allocate the batch buffers with symaccel_host_alloc() or pin existing ones with
+// symaccel_host_register(); pageable memory still works (the runtime stages it) but serialises.
+#include <algorithm>
+#include <cstring>
+
+#include "symaccel_internal.h"
+
+using namespace symaccel;
+
+namespace {
+
+struct Pipe {
+    symaccel_ctx *ctx;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    std::vector<void *> bufs;
+    explicit Pipe(symaccel_ctx *c) : ctx(c) {}
+    ~Pipe() {
+        for (void *p : bufs) (void)hipFree(p);
+        for (int b = 0; b < 2; ++b) {
+            if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
+            if (ev_k[b]) (void)hipEventDestroy(ev_k[b]);
+            if (ev_out[b]) (void)hipEventDestroy(ev_out[b]);
+        }
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_out) (void)hipStreamDestroy(s_out);
+    }
+    int init() {
+        SYM_GPU(ctx, hipStreamCreate(&s_in));
+        SYM_GPU(ctx, hipStreamCreate(&s_out));
+        for (int b = 0; b < 2; ++b) {
+            SYM_GPU(ctx, hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming));
+            SYM_GPU(ctx, hipEventCreateWithFlags(&ev_k[b], hipEventDisableTiming));
+            SYM_GPU(ctx, hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming));
+        }
+        return SYMACCEL_OK;
+    }
+    int alloc(void **p, size_t bytes) {
+        SYM_TRY(ctx_alloc(ctx, p, bytes, false));
+        bufs.push_back(*p);
+        return SYMACCEL_OK;
+    }
+    // everything queued so far, on all three streams
+    int drain() {
+        SYM_GPU(ctx, hipStreamSynchronize(s_in));
+        SYM_GPU(ctx, hipStreamSynchronize(ctx->stream));
+        SYM_GPU(ctx, hipStreamSynchronize(s_out));
+        return SYMACCEL_OK;
+    }
+};
+
+// rows x width bytes between a [rows][src_pitch] and a [rows][dst_pitch] layout
+int copy_rows(symaccel_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipMemcpyKind kind,
+              hipStream_t s) {
+    if (width == 0 || rows == 0) return SYMACCEL_OK;
+    if (dpitch == width && spitch == width) {
+        SYM_GPU(ctx, hipMemcpyAsync(dst, src, width * rows, kind, s));
+    } else {
+        SYM_GPU(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, s));
+    }
+    return SYMACCEL_OK;
+}
+
+size_t pick_chunk(size_t units_per_chain, size_t bytes_per_unit_all_chains, size_t requested) {
+    if (requested > 0) return std::min(requested, units_per_chain);
+    // ~32 MiB of input per chunk: large enough to fill the GPU (hundreds of wavefront segments) and to amortise the
+    // per-copy latency, small enough that the first kernel starts early and the last copy-out finishes soon after the last kernel
+    size_t c = ((size_t)32 << 20) / std::max<size_t>(1, bytes_per_unit_all_chains);
+    c = std::max<size_t>(c, 8);
+    return std::min(c, units_per_chain);
+}
+
+}  // namespace
+
+extern "C" {
+
+int symaccel_host_alloc(size_t bytes, void **out) {
+    if (!out) return SYMACCEL_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (bytes == 0) bytes = 16;
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return e == hipErrorOutOfMemory ? SYMACCEL_ERR_OOM : SYMACCEL_ERR_DEVICE;
+    return SYMACCEL_OK;
+}
+
+int symaccel_host_free(void *p) {
+    if (!p) return SYMACCEL_OK;
+    return hipHostFree(p) == hipSuccess ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+}
+
+int symaccel_host_register(void *p, size_t bytes) {
+    if (!p || bytes == 0) return SYMACCEL_ERR_INVALID_ARG;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+}
+
+int symaccel_host_unregister(void *p) {
+    if (!p) return SYMACCEL_ERR_INVALID_ARG;
+    return hipHostUnregister(p) == hipSuccess ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+}
+
+int symaccel_aac_synth_pipelined(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *h_side, float *h_delay_io, float *h_pcm,
+                                 size_t n_chains, size_t frames_per_chain, size_t chunk_frames) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
+    if (!h_coeffs || !h_side || !h_delay_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    const size_t cf = pick_chunk(frames_per_chain, n_chains * 4096, chunk_frames);
+    Pipe pp(ctx);
+    SYM_TRY(pp.init());
+    float *d_in[2], *d_out[2], *d_state[2];
+    uint8_t *d_side[2];
+    for (int b = 0; b < 2; ++b) {
+        SYM_TRY(pp.alloc((void **)&d_in[b], n_chains * cf * 4096));
+        SYM_TRY(pp.alloc((void **)&d_out[b], n_chains * cf * 4096));
+        SYM_TRY(pp.alloc((void **)&d_side[b], n_chains * cf));
+        SYM_TRY(pp.alloc((void **)&d_state[b], n_chains * 4096));
+    }
+    SYM_GPU(ctx, hipMemcpyAsync(d_state[0], h_delay_io, n_chains * 4096, hipMemcpyHostToDevice, ctx->stream));
+    size_t k = 0;
+    for (size_t t0 = 0; t0 < frames_per_chain; t0 += cf, ++k) {
+        const size_t nf = std::min(cf, frames_per_chain - t0);
+        const int b = (int)(k & 1);
+        if (k >= 2) {  // buffer set b is free once chunk k-2's kernel has read its input and its PCM has left
+            SYM_GPU(ctx, hipStreamWaitEvent(pp.s_in, pp.ev_k[b], 0));
+            SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_out[b], 0));
+        }
+        SYM_TRY(copy_rows(ctx, d_in[b], nf * 4096, h_coeffs + t0 * 1024, frames_per_chain * 4096, nf * 4096, n_chains, hipMemcpyHostToDevice,
+                          pp.s_in));
+        SYM_TRY(copy_rows(ctx, d_side[b], nf, h_side + t0, frames_per_chain, nf, n_chains, hipMemcpyHostToDevice, pp.s_in));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_in[b], pp.s_in));
+        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_in[b], 0));
+        SYM_TRY(launch_aac(ctx, d_in[b], d_side[b], d_state[k & 1], d_state[(k + 1) & 1], d_out[b], n_chains, nf));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_k[b], ctx->stream));
+        SYM_GPU(ctx, hipStreamWaitEvent(pp.s_out, pp.ev_k[b], 0));
+        SYM_TRY(copy_rows(ctx, h_pcm + t0 * 1024, frames_per_chain * 4096, d_out[b], nf * 4096, nf * 4096, n_chains, hipMemcpyDeviceToHost,
+                          pp.s_out));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_out[b], pp.s_out));
+    }
+    SYM_GPU(ctx, hipMemcpyAsync(h_delay_io, d_state[k & 1], n_chains * 4096, hipMemcpyDeviceToHost, ctx->stream));
+    return pp.drain();
+}
+
+int symaccel_mp3_synth_pipelined(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_side *h_side, int sample_rate_idx,
+                                 float *h_overlap_io, float *h_vvec_io, int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
+                                 size_t granules_per_chain, size_t chunk_granules) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
+    if (!h_xr || !h_side || !h_overlap_io || !h_vvec_io || !h_vfront_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    size_t cg = pick_chunk(granules_per_chain, n_chains * 2304, chunk_granules);
+    if (cg < 2 && granules_per_chain >= 2) cg = 2;  // the kernel's two-granule halo wants segments of at least two
+    Pipe pp(ctx);
+    SYM_TRY(pp.init());
+    float *d_in[2], *d_out[2], *d_ov[2], *d_vv[2];
+    symaccel_mp3_side *d_side[2];
+    int32_t *d_vf[2];
+    for (int b = 0; b < 2; ++b) {
+        SYM_TRY(pp.alloc((void **)&d_in[b], n_chains * cg * 2304));
+        SYM_TRY(pp.alloc((void **)&d_out[b], n_chains * cg * 2304));
+        SYM_TRY(pp.alloc((void **)&d_side[b], n_chains * cg * sizeof(symaccel_mp3_side)));
+        SYM_TRY(pp.alloc((void **)&d_ov[b], n_chains * 2304));
+        SYM_TRY(pp.alloc((void **)&d_vv[b], n_chains * 4096));
+        SYM_TRY(pp.alloc((void **)&d_vf[b], n_chains * 4));
+    }
+    SYM_GPU(ctx, hipMemcpyAsync(d_ov[0], h_overlap_io, n_chains * 2304, hipMemcpyHostToDevice, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(d_vv[0], h_vvec_io, n_chains * 4096, hipMemcpyHostToDevice, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(d_vf[0], h_vfront_io, n_chains * 4, hipMemcpyHostToDevice, ctx->stream));
+    size_t k = 0;
+    for (size_t g0 = 0; g0 < granules_per_chain; g0 += cg, ++k) {
+        const size_t ng = std::min(cg, granules_per_chain - g0);
+        const int b = (int)(k & 1);
+        if (k >= 2) {
+            SYM_GPU(ctx, hipStreamWaitEvent(pp.s_in, pp.ev_k[b], 0));
+            SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_out[b], 0));
+        }
+        SYM_TRY(copy_rows(ctx, d_in[b], ng * 2304, h_xr + g0 * 576, granules_per_chain * 2304, ng * 2304, n_chains, hipMemcpyHostToDevice,
+                          pp.s_in));
+        SYM_TRY(copy_rows(ctx, d_side[b], ng * 4, h_side + g0, granules_per_chain * 4, ng * 4, n_chains, hipMemcpyHostToDevice, pp.s_in));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_in[b], pp.s_in));
+        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_in[b], 0));
+        const int si = (int)(k & 1), so = (int)((k + 1) & 1);
+        SYM_TRY(launch_mp3(ctx, d_in[b], d_side[b], sample_rate_idx, d_ov[si], d_vv[si], d_vf[si], d_ov[so], d_vv[so], d_vf[so], d_out[b],
+                           n_chains, ng));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_k[b], ctx->stream));
+        SYM_GPU(ctx, hipStreamWaitEvent(pp.s_out, pp.ev_k[b], 0));
+        SYM_TRY(copy_rows(ctx, h_pcm + g0 * 576, granules_per_chain * 2304, d_out[b], ng * 2304, ng * 2304, n_chains, hipMemcpyDeviceToHost,
+                          pp.s_out));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_out[b], pp.s_out));
+    }
+    const int sf = (int)(k & 1);
+    SYM_GPU(ctx, hipMemcpyAsync(h_overlap_io, d_ov[sf], n_chains * 2304, hipMemcpyDeviceToHost, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(h_vvec_io, d_vv[sf], n_chains * 4096, hipMemcpyDeviceToHost, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(h_vfront_io, d_vf[sf], n_chains * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return pp.drain();
+}
+
+int symaccel_flac_restore_pipelined(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_flac_desc *h_desc, const int32_t *h_coeffs,
+                                    size_t n_blocks, size_t blocksize, size_t chunk_blocks) {
+    if (!ctx || blocksize > 65535) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!h_buf || !h_desc || !h_coeffs) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    size_t cb = chunk_blocks ? chunk_blocks : std::max<size_t>(64, ((size_t)32 << 20) / (blocksize * 4));
+    cb = std::min(cb, n_blocks);
+    Pipe pp(ctx);
+    SYM_TRY(pp.init());
+    int32_t *d_buf[2], *d_co[2];
+    symaccel_flac_desc *d_desc[2];
+    for (int b = 0; b < 2; ++b) {
+        SYM_TRY(pp.alloc((void **)&d_buf[b], cb * blocksize * 4));
+        SYM_TRY(pp.alloc((void **)&d_co[b], cb * 32 * 4));
+        SYM_TRY(pp.alloc((void **)&d_desc[b], cb * sizeof(symaccel_flac_desc)));
+    }
+    size_t k = 0;
+    for (size_t b0 = 0; b0 < n_blocks; b0 += cb, ++k) {
+        const size_t nb = std::min(cb, n_blocks - b0);
+        const int b = (int)(k & 1);
+        if (k >= 2) SYM_GPU(ctx, hipStreamWaitEvent(pp.s_in, pp.ev_out[b], 0));  // in place: the buffer is free once its result has left
+        SYM_GPU(ctx, hipMemcpyAsync(d_buf[b], h_buf + b0 * blocksize, nb * blocksize * 4, hipMemcpyHostToDevice, pp.s_in));
+        SYM_GPU(ctx, hipMemcpyAsync(d_co[b], h_coeffs + b0 * 32, nb * 32 * 4, hipMemcpyHostToDevice, pp.s_in));
+        SYM_GPU(ctx, hipMemcpyAsync(d_desc[b], h_desc + b0, nb * sizeof(symaccel_flac_desc), hipMemcpyHostToDevice, pp.s_in));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_in[b], pp.s_in));
+        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_in[b], 0));
+        SYM_TRY(launch_flac_restore(ctx, d_buf[b], d_desc[b], d_co[b], nb, blocksize));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_k[b], ctx->stream));
+        SYM_GPU(ctx, hipStreamWaitEvent(pp.s_out, pp.ev_k[b], 0));
+        SYM_GPU(ctx, hipMemcpyAsync(h_buf + b0 * blocksize, d_buf[b], nb * blocksize * 4, hipMemcpyDeviceToHost, pp.s_out));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_out[b], pp.s_out));
+    }
+    return pp.drain();
+}
+
+}  // extern "C"
