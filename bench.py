@@ -311,7 +311,8 @@ def host_to_host_aac(sa, ctx, torch, pcm, coeffs, frames, reps=3):
                   nch, nfr, 0)
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
-    same = bool(np.array_equal(h_out.array[:2, :64].view(np.uint32), pcm[:2, :64].cpu().numpy().view(np.uint32)))
+    # (frame 0 depends on the incoming delay line, which the resident steps carry on from step to step: compare from frame 1)
+    same = bool(np.array_equal(h_out.array[:2, 1:64].view(np.uint32), pcm[:2, 1:64].cpu().numpy().view(np.uint32)))
     nbytes = h_in.array.nbytes
     h_in.free()
     h_out.free()
