@@ -25,7 +25,9 @@
 #define SYMACCEL_HPP
 
 #include <array>
+#include <algorithm>
 #include <complex>
+#include <functional>
 #include <cstdint>
 #include <optional>
 #include <stdexcept>
@@ -392,6 +394,224 @@ inline void decorrelate_mid_side(Context &ctx, std::int32_t *out0, std::int32_t 
 }
 
 }  // namespace alac
+
+
+// --------------------------------------------------------------------------------------------- codecs: the trait side
+//
+// symphonia_core::codecs::audio::AudioDecoder (symphonia-core/src/codecs/audio.rs:251-298):
+//     fn reset(&mut self);  fn decode(&mut self, packet: &Packet) -> Result<GenericAudioBufferRef<'_>>;
+//     fn finalize(&mut self) -> FinalizeResult;  fn last_decoded(&self) -> GenericAudioBufferRef<'_>;
+// A GPU pays a launch and a PCIe round trip per call, so a drop-in decoder cannot transform one packet per decode():
+// LookaheadDecoder keeps the trait's method set and its ownership rules (the decoder owns the buffer it returns a
+// borrow of; the borrow is valid until the next &mut call; the buffer is cleared on error, audio.rs:278) and batches
+// underneath: when decode(packet) finds nothing pre-computed for `packet`, it takes that packet plus up to K-1 packets
+// the demuxer side can already see (the `peek` source: the shim wraps the FormatReader so that it reads ahead), runs ONE
+// batch call over all of them -- every channel is a chain, the K packets are K consecutive frames of each chain, the
+// state (delay lines, overlap, V FIFO) enters and leaves through the *_io buffers -- and hands the frames back one per
+// call.  A packet that is not the one expected next (the caller seeked or dropped packets) invalidates the look-ahead.
+// `Codec` supplies the packet type and the batch call (AacLc, Mp3 below); the entropy decode that produces the packets'
+// spectra stays in the reference's CPU code.
+namespace codecs {
+
+struct AudioBufferRef {  // GenericAudioBufferRef::F32 (audio/generic.rs:381-401): planar, one slice per channel
+    std::vector<const float *> planes;
+    std::size_t frames = 0;
+    bool is_empty() const { return frames == 0; }
+};
+
+struct FinalizeResult {  // codecs/audio.rs:230-236
+    std::optional<bool> verify_ok;
+};
+
+template <class Codec>
+class LookaheadDecoder {
+public:
+    using Packet = typename Codec::Packet;
+    using Peek = std::function<std::optional<Packet>()>;  // the next packet of the same track the demuxer can see, if any
+
+    LookaheadDecoder(Context &ctx, const typename Codec::Params &params, std::size_t lookahead, Peek peek)
+        : ctx_(ctx), codec_(params), lookahead_(lookahead < 1 ? 1 : lookahead), peek_(std::move(peek)) {
+        reset();
+    }
+
+    // AudioDecoder::reset (audio.rs:252-257): "must be called after a seek"; state as after construction
+    void reset() {
+        codec_.reset_state();
+        ready_.clear();
+        head_ = 0;
+        have_last_packet_ = false;
+        clear_last();
+    }
+
+    // AudioDecoder::decode (audio.rs:259-281)
+    const AudioBufferRef &decode(const Packet &packet) {
+        if (head_ < ready_.size() && ready_[head_] != Codec::id(packet)) {
+            // Not the packet the look-ahead was computed for: the caller skipped packets without reset().  A
+            // frame-by-frame decoder would now continue from the state the LAST RETURNED packet left, but the carried
+            // state here is already that of the end of the batch.  Every codec on this path has a one-packet memory
+            // (the delay line / overlap / V FIFO after a packet depend on that packet's input alone -- the same property
+            // the kernels' segment halo uses), so replaying the last returned packet rebuilds exactly that state.
+            drop_lookahead();
+            if (have_last_packet_) {
+                std::vector<Packet> one(1, last_packet_);
+                std::vector<float> scratch;
+                codec_.decode_batch(ctx_, one, scratch);
+            }
+        }
+        if (head_ >= ready_.size()) {
+            try {
+                fill(packet);
+            } catch (...) {
+                clear_last();  // audio.rs:278: "implementors of this function must clear the internal buffer if an error occurs"
+                ready_.clear();
+                head_ = 0;
+                throw;
+            }
+        }
+        publish(head_++);
+        last_packet_ = packet;
+        have_last_packet_ = true;
+        return last_;
+    }
+
+    FinalizeResult finalize() { return FinalizeResult{}; }  // (the f32 codecs verify nothing, like the reference's)
+    const AudioBufferRef &last_decoded() const { return last_; }
+    std::size_t lookahead() const { return lookahead_; }
+    std::size_t batches_run() const { return batches_; }
+
+private:
+    void fill(const Packet &first) {
+        std::vector<Packet> batch;
+        batch.push_back(first);
+        // packets pulled earlier whose frames were dropped by a discontinuity are not replayed: the demuxer moved on
+        while (batch.size() < lookahead_) {
+            std::optional<Packet> nxt = peek_ ? peek_() : std::nullopt;
+            if (!nxt) break;
+            batch.push_back(std::move(*nxt));
+        }
+        codec_.decode_batch(ctx_, batch, pcm_);
+        ++batches_;
+        ready_.clear();
+        for (const Packet &p : batch) ready_.push_back(Codec::id(p));
+        batch_len_ = batch.size();
+        head_ = 0;
+    }
+    void drop_lookahead() {
+        ready_.clear();
+        head_ = 0;
+    }
+    void publish(std::size_t i) {
+        const std::size_t fpp = codec_.frames_per_packet(), nch = codec_.channels();
+        last_.planes.resize(nch);
+        for (std::size_t c = 0; c < nch; ++c) last_.planes[c] = pcm_.data() + (c * batch_len_ + i) * fpp;
+        last_.frames = fpp;
+    }
+    void clear_last() {
+        last_.planes.assign(codec_.channels(), nullptr);
+        last_.frames = 0;
+    }
+
+    Context &ctx_;
+    Codec codec_;
+    std::size_t lookahead_;
+    Peek peek_;
+    std::vector<float> pcm_;                 // [channel][packet of the batch][frames_per_packet]: planar per packet
+    std::vector<std::uint64_t> ready_;       // ids of the batch's packets, in order
+    Packet last_packet_{};                   // the packet decode() returned last (replayed after a discontinuity)
+    bool have_last_packet_ = false;
+    std::size_t head_ = 0, batch_len_ = 0, batches_ = 0;
+    AudioBufferRef last_;
+};
+
+// AAC-LC: one packet = one raw_data_block = 1024 frames per channel.  What the CPU side (reference parser + spectral
+// tools) hands over per channel: the dequantised coefficients Ics::synth_channel would give Dsp::synth, the window
+// sequence and the window shapes (ics/mod.rs:449-468).
+struct AacLc {
+    struct Params {
+        std::size_t channels = 2;
+    };
+    struct Packet {
+        std::uint64_t ts = 0;                // Packet::ts: identifies the packet
+        std::vector<float> coeffs;           // [channel][1024]
+        std::vector<std::uint8_t> side;      // [channel]: SYMACCEL_AAC_SIDE(seq, shape, prev_shape)
+    };
+    explicit AacLc(const Params &p) : nch_(p.channels), delay_(p.channels * 1024, 0.0f) {}
+    static std::uint64_t id(const Packet &p) { return p.ts; }
+    std::size_t channels() const { return nch_; }
+    std::size_t frames_per_packet() const { return 1024; }
+    void reset_state() { std::fill(delay_.begin(), delay_.end(), 0.0f); }  // AacDecoder::reset: delay lines zeroed
+    void decode_batch(Context &ctx, const std::vector<Packet> &batch, std::vector<float> &pcm) {
+        const std::size_t k = batch.size();
+        in_.resize(nch_ * k * 1024);
+        side_.resize(nch_ * k);
+        pcm.resize(nch_ * k * 1024);
+        for (std::size_t i = 0; i < k; ++i) {
+            if (batch[i].coeffs.size() != nch_ * 1024 || batch[i].side.size() != nch_) throw std::invalid_argument("AacLc: packet shape");
+            for (std::size_t c = 0; c < nch_; ++c) {
+                std::copy_n(batch[i].coeffs.data() + c * 1024, 1024, in_.data() + (c * k + i) * 1024);
+                side_[c * k + i] = batch[i].side[c];
+            }
+        }
+        check(symaccel_aac_synth(ctx.raw(), in_.data(), side_.data(), delay_.data(), pcm.data(), nch_, k), ctx.raw());
+    }
+
+private:
+    std::size_t nch_;
+    std::vector<float> delay_, in_;
+    std::vector<std::uint8_t> side_;
+};
+
+// MPEG-1/2 Layer III: one packet = one frame = `granules` granules of 576 frames per channel (2 for MPEG-1, 1 for
+// MPEG-2 / 2.5, common.rs:173-178).  Per granule-channel: the requantised, stereo-processed samples and the side fields
+// the synthesis tail reads (layer3/mod.rs:440-476).
+struct Mp3 {
+    struct Params {
+        std::size_t channels = 2;
+        std::size_t granules = 2;
+        int sample_rate_idx = 0;
+    };
+    struct Packet {
+        std::uint64_t ts = 0;
+        std::vector<float> xr;                 // [granule][channel][576]
+        std::vector<symaccel_mp3_side> side;   // [granule][channel]
+    };
+    explicit Mp3(const Params &p)
+        : nch_(p.channels), ngr_(p.granules), sr_(p.sample_rate_idx), overlap_(p.channels * 576, 0.0f), vvec_(p.channels * 1024, 0.0f),
+          vfront_(p.channels, 0) {}
+    static std::uint64_t id(const Packet &p) { return p.ts; }
+    std::size_t channels() const { return nch_; }
+    std::size_t frames_per_packet() const { return 576 * ngr_; }
+    void reset_state() {  // MpaDecoder::reset: fresh State (overlap and SynthesisState::default())
+        std::fill(overlap_.begin(), overlap_.end(), 0.0f);
+        std::fill(vvec_.begin(), vvec_.end(), 0.0f);
+        std::fill(vfront_.begin(), vfront_.end(), 0);
+    }
+    void decode_batch(Context &ctx, const std::vector<Packet> &batch, std::vector<float> &pcm) {
+        const std::size_t k = batch.size(), g = k * ngr_;
+        in_.resize(nch_ * g * 576);
+        side_.resize(nch_ * g);
+        pcm.resize(nch_ * g * 576);
+        for (std::size_t i = 0; i < k; ++i) {
+            if (batch[i].xr.size() != ngr_ * nch_ * 576 || batch[i].side.size() != ngr_ * nch_) throw std::invalid_argument("Mp3: packet shape");
+            for (std::size_t gr = 0; gr < ngr_; ++gr)
+                for (std::size_t c = 0; c < nch_; ++c) {
+                    std::copy_n(batch[i].xr.data() + (gr * nch_ + c) * 576, 576, in_.data() + (c * g + i * ngr_ + gr) * 576);
+                    side_[c * g + i * ngr_ + gr] = batch[i].side[gr * nch_ + c];
+                }
+        }
+        check(symaccel_mp3_synth(ctx.raw(), in_.data(), side_.data(), sr_, overlap_.data(), vvec_.data(), vfront_.data(), pcm.data(), nch_, g),
+              ctx.raw());
+    }
+
+private:
+    std::size_t nch_, ngr_;
+    int sr_;
+    std::vector<float> overlap_, vvec_, in_;
+    std::vector<std::int32_t> vfront_;
+    std::vector<symaccel_mp3_side> side_;
+};
+
+}  // namespace codecs
 
 }  // namespace symphonia_accel
 

@@ -1,0 +1,173 @@
+// LookaheadDecoder (include/symaccel.hpp): the AudioDecoder method set over batched device calls.  A synthetic track of
+// parsed packets is decoded through decode() one packet at a time; every returned buffer must be bit-identical to what a
+// frame-by-frame decoder (the CPU oracle, linked as the checker only) produces -- across batch boundaries, across a
+// reset() (seek) and across a discontinuity without reset().  Built against the real library on the GPU box and against
+// the CPU emulation build elsewhere (tests/test_lookahead.py).
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "symaccel.hpp"
+#include "symoracle.h"
+
+using namespace symphonia_accel;
+using namespace symphonia_accel::codecs;
+
+static int g_failures = 0;
+#define EXPECT(cond, ...)                                    \
+    do {                                                     \
+        if (!(cond)) {                                       \
+            ++g_failures;                                    \
+            std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::printf(__VA_ARGS__);                        \
+            std::printf("\n");                               \
+        }                                                    \
+    } while (0)
+
+static bool same_bits(const float *a, const float *b, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (!(a[i] == b[i])) return false;  // (+0 == -0; the tests use no NaN)
+    return true;
+}
+
+// ---- AAC: a legal window-sequence walk per packet, both channels share it (like a common_window CPE)
+static std::vector<AacLc::Packet> aac_track(size_t n, size_t nch, unsigned seed) {
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nd(0.0f, 50.0f);
+    std::vector<AacLc::Packet> t(n);
+    int cur = 0, prev_shape = 1;
+    for (size_t i = 0; i < n; ++i) {
+        cur = (cur == 0 || cur == 3) ? ((rng() % 4 == 0) ? 1 : 0) : ((rng() % 2) ? 2 : 3);
+        const int shape = (int)(rng() % 2);
+        t[i].ts = 1000 + 1024 * i;
+        t[i].coeffs.resize(nch * 1024);
+        for (auto &v : t[i].coeffs) v = nd(rng);
+        t[i].side.assign(nch, SYMACCEL_AAC_SIDE((unsigned)cur, (unsigned)shape, (unsigned)prev_shape));
+        prev_shape = shape;
+    }
+    return t;
+}
+
+struct AacOracle {  // a frame-by-frame decoder: one so_aac_synth_batch call per packet and channel
+    size_t nch;
+    std::vector<float> delay;
+    explicit AacOracle(size_t c) : nch(c), delay(c * 1024, 0.0f) {}
+    void reset() { std::fill(delay.begin(), delay.end(), 0.0f); }
+    std::vector<float> decode(const AacLc::Packet &p) {
+        std::vector<float> pcm(nch * 1024);
+        for (size_t c = 0; c < nch; ++c) so_aac_synth_batch(p.coeffs.data() + c * 1024, &p.side[c], delay.data() + c * 1024, pcm.data() + c * 1024, 1, 1);
+        return pcm;
+    }
+};
+
+static void test_aac(Context &ctx, size_t lookahead) {
+    const size_t nch = 2, n = 41;
+    auto track = aac_track(n, nch, 7 + (unsigned)lookahead);
+    size_t cursor = 0;  // the demuxer's read position: decode(track[i]) is called with cursor == i + 1
+    LookaheadDecoder<AacLc> dec(ctx, AacLc::Params{nch}, lookahead, [&]() -> std::optional<AacLc::Packet> {
+        if (cursor >= track.size()) return std::nullopt;
+        return track[cursor++];
+    });
+    AacOracle ref(nch);
+    EXPECT(dec.last_decoded().is_empty(), "last_decoded() must be empty before the first decode");
+    auto step = [&](size_t i) {
+        if (cursor <= i) cursor = i + 1;
+        const AudioBufferRef &buf = dec.decode(track[i]);
+        const std::vector<float> want = ref.decode(track[i]);
+        EXPECT(buf.frames == 1024 && buf.planes.size() == nch, "buffer shape at packet %zu", i);
+        for (size_t c = 0; c < nch; ++c)
+            EXPECT(same_bits(buf.planes[c], want.data() + c * 1024, 1024), "AAC K=%zu packet %zu channel %zu differs from the frame-by-frame decoder", lookahead, i, c);
+        EXPECT(dec.last_decoded().planes == buf.planes && dec.last_decoded().frames == 1024, "last_decoded() != what decode() returned");
+    };
+    for (size_t i = 0; i < 17; ++i) step(i);
+    // seek: the caller resets the decoder and continues somewhere else (audio.rs:252-257)
+    dec.reset();
+    ref.reset();
+    EXPECT(dec.last_decoded().is_empty(), "reset() must clear the buffer");
+    cursor = 23;
+    for (size_t i = 23; i < 30; ++i) step(i);
+    // a discontinuity WITHOUT reset (packets dropped): both decoders just carry their state on
+    cursor = 33;
+    for (size_t i = 33; i < n; ++i) step(i);
+    if (lookahead > 1) EXPECT(dec.batches_run() < n, "no batching happened (%zu batches)", dec.batches_run());
+}
+
+// ---- MP3
+static std::vector<Mp3::Packet> mp3_track(size_t n, size_t nch, size_t ngr, unsigned seed) {
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nd(0.0f, 0.1f);
+    std::vector<Mp3::Packet> t(n);
+    int state = 0;  // 0 long, 1 after start (short run), 2 end pending
+    for (size_t i = 0; i < n; ++i) {
+        t[i].ts = 5000 + 1152 * i;
+        t[i].xr.resize(ngr * nch * 576);
+        t[i].side.resize(ngr * nch);
+        for (size_t gr = 0; gr < ngr; ++gr) {
+            int bt;
+            if (state == 0) bt = (rng() % 5 == 0) ? 1 : 0;
+            else if (state == 1) bt = 2;
+            else bt = 3;
+            state = bt == 1 ? 1 : (bt == 2 ? ((rng() % 2) ? 1 : 2) : 0);
+            const unsigned rz = 2 * (unsigned)(rng() % 289);
+            for (size_t c = 0; c < nch; ++c) {
+                float *x = t[i].xr.data() + (gr * nch + c) * 576;
+                for (unsigned k = 0; k < 576; ++k) x[k] = k < rz ? nd(rng) : 0.0f;
+                t[i].side[gr * nch + c] = symaccel_mp3_side{(uint8_t)bt, (uint8_t)(bt == 2 && rng() % 3 == 0), (uint16_t)rz};
+            }
+        }
+    }
+    return t;
+}
+
+static void test_mp3(Context &ctx, size_t lookahead) {
+    const size_t nch = 2, ngr = 2, n = 25;
+    const int sr = 1;
+    auto track = mp3_track(n, nch, ngr, 11 + (unsigned)lookahead);
+    size_t cursor = 0;
+    LookaheadDecoder<Mp3> dec(ctx, Mp3::Params{nch, ngr, sr}, lookahead, [&]() -> std::optional<Mp3::Packet> {
+        if (cursor >= track.size()) return std::nullopt;
+        return track[cursor++];
+    });
+    std::vector<float> ov(nch * 576, 0.0f), vv(nch * 1024, 0.0f);
+    std::vector<int32_t> vf(nch, 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (i == 12) {  // seek
+            dec.reset();
+            std::fill(ov.begin(), ov.end(), 0.0f);
+            std::fill(vv.begin(), vv.end(), 0.0f);
+            std::fill(vf.begin(), vf.end(), 0);
+            cursor = i;
+        }
+        if (cursor <= i) cursor = i + 1;
+        const AudioBufferRef &buf = dec.decode(track[i]);
+        EXPECT(buf.frames == 1152, "mp3 frames per packet");
+        for (size_t c = 0; c < nch; ++c) {
+            float want[1152];
+            for (size_t gr = 0; gr < ngr; ++gr) {
+                const symaccel_mp3_side &sd = track[i].side[gr * nch + c];
+                const uint8_t side[4] = {sd.block_type, sd.is_mixed, (uint8_t)(sd.rzero & 255), (uint8_t)(sd.rzero >> 8)};
+                so_mp3_synth_batch(track[i].xr.data() + (gr * nch + c) * 576, side, sr, ov.data() + c * 576, vv.data() + c * 1024, &vf[c], want + gr * 576, 1, 1);
+            }
+            EXPECT(same_bits(buf.planes[c], want, 1152), "MP3 K=%zu packet %zu channel %zu differs from the frame-by-frame decoder", lookahead, i, c);
+        }
+    }
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && std::strcmp(argv[1], "--expect-no-device") == 0) {
+        try {
+            Context ctx(0);
+        } catch (const std::exception &) {
+            std::printf("no device: refused as expected\n");
+            return 0;
+        }
+        std::printf("a context was created without a device\n");
+        return 1;
+    }
+    Context ctx(0);
+    for (size_t k : {size_t(1), size_t(4), size_t(9), size_t(64)}) test_aac(ctx, k);
+    for (size_t k : {size_t(1), size_t(3), size_t(8)}) test_mp3(ctx, k);
+    if (g_failures == 0) std::printf("all checks passed\n");
+    return g_failures ? 1 : 0;
+}
