@@ -38,3 +38,37 @@ def test_record_sizes_match_the_ctypes_side():
     assert sizes["symaccel_aac_tns_filter"] == backend.AAC_TNS_DTYPE.itemsize == 92
     assert sizes["symaccel_flac_desc"] == backend.FLAC_DESC_DTYPE.itemsize == 4
     assert sizes["symaccel_mp3_side"] == sizes["symaccel_alac_desc"] == 4
+
+
+def test_shim_crate_sources_use_only_symbols_and_arities_of_the_abi():
+    """bindings/rust/symphonia-accel-hip/ cannot be compiled here; at least every `ffi::symaccel_*` call in it must name
+    an exported symbol and pass as many arguments as the C prototype takes, and every status constant must exist."""
+    _, _, funcs = gen_rust_ffi.generate()
+    arity = {name: len(params) for name, _, params in funcs}
+    crate = ROOT / "bindings" / "rust" / "symphonia-accel-hip" / "src"
+    seen = set()
+    for path in sorted(crate.glob("*.rs")):
+        text = re.sub(r"//.*", "", path.read_text())
+        for m in re.finditer(r"ffi::(symaccel_\w+)\s*\(", text):
+            name = m.group(1)
+            assert name in arity, "%s: %s is not in include/symaccel.h" % (path.name, name)
+            depth, i, args, cur = 1, m.end(), 0, ""
+            while depth:
+                ch = text[i]
+                if ch in "([{":
+                    depth += 1
+                elif ch in ")]}":
+                    depth -= 1
+                if depth == 1 and ch == ",":
+                    args += 1 if cur.strip() else 0
+                    cur = ""
+                elif depth >= 1:
+                    cur += ch
+                i += 1
+            args += 1 if cur.strip().rstrip(")").strip() else 0
+            assert args == arity[name], "%s: %s called with %d arguments, the ABI takes %d" % (path.name, name, args, arity[name])
+            seen.add(name)
+        for const in re.findall(r"ffi::(SYMACCEL_\w+)", text):
+            assert ("pub const %s:" % const) in (ROOT / "bindings" / "rust" / "symaccel_sys.rs").read_text(), const
+    assert {"symaccel_ctx_create", "symaccel_ctx_destroy", "symaccel_aac_synth", "symaccel_host_alloc", "symaccel_host_free",
+            "symaccel_strerror", "symaccel_last_error"} <= seen
