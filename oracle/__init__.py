@@ -15,14 +15,53 @@ _HERE = Path(__file__).resolve().parent
 _SO = _HERE / "libsymoracle.so"
 
 
+_SO_NATIVE = _HERE / "libsymoracle_native.so"
+
+
 def build(force=False):
-    src_m = max((_HERE / f).stat().st_mtime for f in ("symoracle.c", "bench_mt.c", "symoracle.h", "spec_tables.h"))
-    if force or not _SO.exists() or _SO.stat().st_mtime < src_m:
-        subprocess.run(["make", "-C", str(_HERE)], check=True, stdout=subprocess.DEVNULL)
+    src_m = max((_HERE / f).stat().st_mtime for f in ("symoracle.c", "bench_mt.c", "cpu_simd.c", "symoracle.h", "spec_tables.h", "Makefile"))
+    if force or not _SO.exists() or _SO.stat().st_mtime < src_m or not _SO_NATIVE.exists() or _SO_NATIVE.stat().st_mtime < src_m:
+        subprocess.run(["make", "-C", str(_HERE)] + (["-B"] if force else []), check=True, stdout=subprocess.DEVNULL)
     return _SO
 
 
 _lib = None
+
+
+def _bind(path):
+    l = C.CDLL(str(path))
+    l.so_bench_mt.restype = C.c_double
+    l.so_bench_mt.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_long), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                              C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+    return l
+
+
+_native = None
+
+
+def native_lib():
+    """The -O3 -march=native build of the same sources (CPU baseline only).  Built ON the machine it runs on: a library
+    built for another CPU model is rebuilt (the GPU box is not the build container)."""
+    global _native
+    if _native is None:
+        build()
+        stamp = _HERE / "libsymoracle_native.cpu"
+        model = cpu_model()
+        if not stamp.exists() or stamp.read_text() != model:
+            subprocess.run(["make", "-C", str(_HERE), "-B", "libsymoracle_native.so"], check=True, stdout=subprocess.DEVNULL)
+            stamp.write_text(model)
+        _native = _bind(_SO_NATIVE)
+    return _native
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def lib():
@@ -518,11 +557,21 @@ def mp3_stereo(ch0, ch1, desc, sr):
 
 # ---- timing driver (bench.py cpu_baseline) ------------------------------------
 
-def bench_mt(kind, threads, seconds, in0, in1, in2=None, n_chains=0, per_chain=0, stride_in=0, stride_out=0, p0=0, p1=0):
+def aac_long_kbd_batch_simd(coeffs, delay, native=False):
+    """cpu_simd.c: ONLY_LONG / KBD frames, 16 chains per vector.  coeffs[chains, frames, 1024], chains % 16 == 0."""
+    c = _f32(coeffs)
+    d = np.array(delay, dtype=np.float32, copy=True, order="C")
+    pcm = np.empty_like(c)
+    l = native_lib() if native else lib()
+    l.so_aac_long_kbd_batch_simd(_p(c), _p(d), _p(pcm), C.c_size_t(c.shape[0]), C.c_size_t(c.shape[1]))
+    return pcm, d
+
+
+def bench_mt(kind, threads, seconds, in0, in1, in2=None, n_chains=0, per_chain=0, stride_in=0, stride_out=0, p0=0, p1=0, native=False):
     """oracle/bench_mt.c: `threads` pthreads each run the batch on private outputs for `seconds`.
     Returns (elapsed seconds, batches completed by all threads)."""
-    k = {"aac": 0, "mp3": 1, "vorbis": 2, "flac": 3, "alac": 4}[kind]
+    k = {"aac": 0, "mp3": 1, "vorbis": 2, "flac": 3, "alac": 4, "aac_simd": 5}[kind]
     reps = C.c_long(0)
-    dt = float(lib().so_bench_mt(k, int(threads), float(seconds), C.byref(reps), _p(in0), _p(in1),
+    dt = float((native_lib() if native else lib()).so_bench_mt(k, int(threads), float(seconds), C.byref(reps), _p(in0), _p(in1),
                                  _p(in2) if in2 is not None else None, n_chains, per_chain, stride_in, stride_out, p0, p1))
     return dt, int(reps.value)

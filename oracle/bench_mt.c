@@ -18,7 +18,7 @@
 #include "symoracle.h"
 
 typedef struct job {
-    int kind; /* 0 aac, 1 mp3, 2 vorbis, 3 flac, 4 alac */
+    int kind; /* 0 aac, 1 mp3, 2 vorbis, 3 flac, 4 alac, 5 aac (ONLY_LONG / KBD) vectorised across chains (cpu_simd.c) */
     double seconds;
     long *total_reps;
     pthread_mutex_t *lock;
@@ -49,6 +49,9 @@ static void run_once(const job *j, void *state, void *out) {
                               (float *)out, j->stride_out, j->n_chains, j->per_chain);
         break;
     }
+    case 5:
+        so_aac_long_kbd_batch_simd((const float *)j->in0, (float *)state, (float *)out, j->n_chains, j->per_chain);
+        break;
     case 4:
         memcpy(out, j->in0, j->n_chains * j->per_chain * sizeof(int32_t));
         so_alac_predict_batch((int32_t *)out, (const uint8_t *)j->in1, (const int32_t *)j->in2, j->n_chains, j->per_chain);
@@ -70,7 +73,8 @@ static void *worker(void *arg) {
     const job *j = (const job *)arg;
     size_t state_bytes, out_bytes;
     switch (j->kind) {
-    case 0: state_bytes = j->n_chains * 1024 * 4; out_bytes = j->n_chains * j->per_chain * 1024 * 4; break;
+    case 0:
+    case 5: state_bytes = j->n_chains * 1024 * 4; out_bytes = j->n_chains * j->per_chain * 1024 * 4; break;
     case 1: state_bytes = j->n_chains * (576 + 1024 + 1) * 4; out_bytes = j->n_chains * j->per_chain * 576 * 4; break;
     case 2: state_bytes = j->n_chains * (((size_t)1 << (j->p1 - 1)) + 1) * 4; out_bytes = j->n_chains * j->stride_out * 4; break;
     default: state_bytes = 4; out_bytes = j->n_chains * j->per_chain * 4; break;

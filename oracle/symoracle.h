@@ -227,4 +227,8 @@ void so_vorbis_floor0_coeffs(float *coeffs, int order);
 int so_vorbis_floor0(const float *coeffs, int order, const int32_t *map, uint32_t n, uint32_t bark_map_size,
                      uint32_t amplitude_bits, uint32_t amplitude_offset, uint64_t amplitude, float *floor_out);
 
+/* cpu_simd.c: the headline workload (AAC-LC ONLY_LONG / KBD) with 16 chains per vector; n_chains % 16 == 0.  Same bits as
+ * so_aac_synth_batch. */
+void so_aac_long_kbd_batch_simd(const float *coeffs, float *delay, float *pcm, size_t n_chains, size_t frames_per_chain);
+
 #endif
