@@ -19,13 +19,28 @@
 //    (slots m2 and 255-m2), the same positions for dst and for the next delay line, so PCM
 //    stores are 1 KiB-coalesced and the overlap-add is lane-local.
 // Roofline: HBM-bound, 8192 B algorithmic per channel-frame, ~27 kflop (no FMA) -> 3.3 flop/B.
+#include <type_traits>
+
 #include "imdct_wave.h"
 
 namespace symaccel {
 
 namespace {
 
+// Build variants (tuning knob SYM_AAC_VARIANT, see build.py):
+//   0  four wavefronts per workgroup, lane twiddles in 31 VGPRs, two wavefronts per SIMD;
+//   1  six wavefronts per workgroup, lane twiddles read from a 4 KiB LDS copy, the halo frame peeled out of the
+//      frame loop (its PCM stores and their address arithmetic disappear at compile time) -- sized for THREE
+//      wavefronts per SIMD (<= 168 VGPRs, 2 workgroups x 71.6 KiB of LDS per CU).
+#ifndef SYM_AAC_VARIANT
+#define SYM_AAC_VARIANT 0
+#endif
+#if SYM_AAC_VARIANT == 1
+constexpr int kWaves = 6;
+#define SYM_AAC_WAVES_PER_SIMD 3
+#else
 constexpr int kWaves = 4;                 // wavefronts per workgroup
+#endif
 constexpr int kTabTw = 0;                 // shared LDS tables: Imdct twiddles, 512 complex
 constexpr int kTabKbd = 1024;             //   KBD long window, 1024 f32
 constexpr int kTabSine = 2048;            //   sine long window, 1024 f32
@@ -80,6 +95,9 @@ __device__ __forceinline__ void start_window4(const float *sw, int j0, float *w)
     w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
 
+#if defined(SYM_AAC_WAVES_PER_SIMD) && !defined(SYM_AAC_MIN_WAVES)
+#define SYM_AAC_MIN_WAVES SYM_AAC_WAVES_PER_SIMD
+#endif
 #ifndef SYM_AAC_MIN_WAVES
 #define SYM_AAC_MIN_WAVES 2  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
 #endif
@@ -100,6 +118,10 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
     unsigned frames_per_chain, unsigned seg_len, unsigned segs_per_chain, unsigned n_items) {
     __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
+#if SYM_AAC_VARIANT == 1
+    __shared__ __attribute__((aligned(16))) c32 lane_tab[kLaneTabComplex];
+    fill_lane_tables_lds(tb, lane_tab, (int)threadIdx.x, 64 * kWaves);
+#endif
 
     // ---- shared tables -> LDS (once per workgroup)
     for (int i = (int)threadIdx.x; i < 1024; i += 64 * kWaves) {
@@ -125,8 +147,12 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
     const unsigned t_end = min(t_begin + seg_len, frames_per_chain);
     const size_t chain_base = (size_t)chain * frames_per_chain;
 
+#if SYM_AAC_VARIANT == 1
+    const LaneTablesLds lt = lane_tables_lds(tb, lane_tab, lane);
+#else
     LaneTables lt;
     load_lane_tables(tb, lane, lt);
+#endif
 
     // delay line, in slot layout: dl[h][0..3] = delay[4m2 + q], dl[h][4..7] = delay[1020 - 4m2 + q]
     float dl[2][8];
@@ -159,8 +185,15 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
 #endif
 
     unsigned sb_next = side[chain_base + (size_t)t_first];  // side bytes are fetched one frame ahead, like the lines
+    // one frame of the walk.  Variant 1 wraps the body in a lambda whose `emit_c` is a compile-time true/false so that
+    // the halo frame can be peeled; variant 0 keeps the plain loop (its register allocation is the measured one).
+#if SYM_AAC_VARIANT == 1
+    auto do_frame = [&](long t, auto emit_c) {
+        const bool emit = emit_c;
+#else
     for (long t = t_first; t < (long)t_end; ++t) {
         const bool emit = t >= (long)t_begin;
+#endif
         const unsigned sb = sb_next;
         const int seq = (int)(sb & 3u);
         const int shape = (int)((sb >> 2) & 1u), prev_shape = (int)((sb >> 3) & 1u);
@@ -281,7 +314,15 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
             for (int h = 0; h < 2; ++h) load_slot(dly, lane + 64 * h, dl[h]);
             wave_sync();  // LDS is overwritten by the next frame
         }
+#if SYM_AAC_VARIANT == 1
+    };
+    long t = t_first;
+    if (t < (long)t_begin) do_frame(t++, std::false_type{});
+#pragma unroll 1
+    for (; t < (long)t_end; ++t) do_frame(t, std::true_type{});
+#else
     }
+#endif
 
     if (t_end == frames_per_chain) {
         float *d = delay_out + (size_t)chain * 1024;

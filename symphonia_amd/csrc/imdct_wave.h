@@ -37,6 +37,11 @@ __device__ __forceinline__ constexpr int lds_t2_inst_r(int B) { return 8 * (B & 
 static_assert(2 * (7 + 8 + 288 * 3 + 36 * 7 + 1) <= kWaveLds, "FFT work array must fit the per-wave LDS");
 static_assert(128 * 7 + 96 + 128 + 1024 <= kWaveLds, "the skewed short-window rows and a parked 1024-float delay line must fit the per-wave LDS");
 
+__device__ __forceinline__ c32 ld_c(const cpx *p) {
+    const cpx v = *p;
+    return c32{v.re, v.im};
+}
+
 struct LaneTables {
     // pass 2 (stages 4-6): fft16 combine k, fft32 combine k and k+8, merge W64[8j + k]
     c32 w16;
@@ -48,12 +53,48 @@ struct LaneTables {
     c32 w128;
     c32 w256[2];
     c32 w512[4];
+    __device__ __forceinline__ c32 W16() const { return w16; }
+    __device__ __forceinline__ int F16() const { return f16; }
+    __device__ __forceinline__ c32 W32(int i) const { return w32[i]; }
+    __device__ __forceinline__ int F32(int i) const { return f32[i]; }
+    __device__ __forceinline__ c32 W64(int j) const { return w64[j]; }
+    __device__ __forceinline__ c32 W128() const { return w128; }
+    __device__ __forceinline__ c32 W256(int b) const { return w256[b]; }
+    __device__ __forceinline__ c32 W512(int B) const { return w512[B]; }
 };
 
-__device__ __forceinline__ c32 ld_c(const cpx *p) {
-    const cpx v = *p;
-    return c32{v.re, v.im};
+// The same twiddles read from an LDS copy at the point of use (504 complex values per workgroup): 31 VGPRs per lane less
+// than LaneTables, for 14 conflict-free ds_read_b64 per 512-point transform -- what lets a kernel built around
+// fft512_wave fit three wavefronts per SIMD.  Layout: small16[8] | small32[16] | W64[32] | W128[64] | W256[128] | W512[256].
+constexpr int kLaneTabComplex = 8 + 16 + 32 + 64 + 128 + 256;
+struct LaneTablesLds {
+    const c32 *t;
+    int lane, k, forms;  // forms: f16 | f32[0] << 2 | f32[1] << 4
+    __device__ __forceinline__ c32 W16() const { return t[k]; }
+    __device__ __forceinline__ int F16() const { return forms & 3; }
+    __device__ __forceinline__ c32 W32(int i) const { return t[8 + k + 8 * i]; }
+    __device__ __forceinline__ int F32(int i) const { return (forms >> (2 + 2 * i)) & 3; }
+    __device__ __forceinline__ c32 W64(int j) const { return t[24 + 8 * j + k]; }
+    __device__ __forceinline__ c32 W128() const { return t[56 + lane]; }
+    __device__ __forceinline__ c32 W256(int b) const { return t[120 + lane + 64 * b]; }
+    __device__ __forceinline__ c32 W512(int B) const { return t[248 + lane + 64 * B]; }
+};
+// workgroup-cooperative fill of the LDS copy (call before a __syncthreads)
+__device__ __forceinline__ void fill_lane_tables_lds(const DevTables &tb, c32 *t, int tid, int n_threads) {
+    for (int i = tid; i < kLaneTabComplex; i += n_threads) {
+        const cpx *src = i < 8 ? tb.small16 + i : (i < 24 ? tb.small32 + (i - 8) : tb.fft_merge + (i - 24));
+        t[i] = ld_c(src);
+    }
 }
+__device__ __forceinline__ LaneTablesLds lane_tables_lds(const DevTables &tb, const c32 *t, int lane) {
+    LaneTablesLds lt;
+    lt.t = t;
+    lt.lane = lane;
+    lt.k = lane & 7;
+    lt.forms = (int)tb.small16_form[lt.k] | ((int)tb.small32_form[lt.k] << 2) | ((int)tb.small32_form[lt.k + 8] << 4);
+    return lt;
+}
+
 
 __device__ __forceinline__ void load_lane_tables(const DevTables &tb, int lane, LaneTables &t) {
     const int k = lane & 7;
@@ -75,29 +116,45 @@ __device__ __forceinline__ void load_lane_tables(const DevTables &tb, int lane, 
 }
 
 // Stages 4-6 of the radix-2 graph on the eight values u[j] = a[64B + 8j + k] of one lane.
-__device__ __forceinline__ void pass2_regs(c32 (&u)[8], const LaneTables &t) {
+template <class LT>
+__device__ __forceinline__ void pass2_regs(c32 (&u)[8], const LT &t) {
+    {
+        const c32 w16 = t.W16();
+        const int f16 = t.F16();
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) bfly(u[j], u[j + 1], tw_small(u[j + 1], t.w16, t.f16));  // fft16 combine
+        for (int j = 0; j < 8; j += 2) bfly(u[j], u[j + 1], tw_small(u[j + 1], w16, f16));  // fft16 combine
+    }
+    {
+        const c32 wa = t.W32(0), wb = t.W32(1);
+        const int fa = t.F32(0), fb = t.F32(1);
 #pragma unroll
-    for (int h = 0; h < 8; h += 4) {                                                          // fft32 combine
-        bfly(u[h + 0], u[h + 2], tw_small(u[h + 2], t.w32[0], t.f32[0]));
-        bfly(u[h + 1], u[h + 3], tw_small(u[h + 3], t.w32[1], t.f32[1]));
+        for (int h = 0; h < 8; h += 4) {                                                      // fft32 combine
+            bfly(u[h + 0], u[h + 2], tw_small(u[h + 2], wa, fa));
+            bfly(u[h + 1], u[h + 3], tw_small(u[h + 3], wb, fb));
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfly(u[j], u[j + 4], c_mul(u[j + 4], t.w64[j]));             // merge, step 32
+    for (int j = 0; j < 4; ++j) bfly(u[j], u[j + 4], c_mul(u[j + 4], t.W64(j)));             // merge, step 32
 }
 
 // Stages 7-9 on v[B] = a[64B + k'].
-__device__ __forceinline__ void pass3_regs(c32 (&v)[8], const LaneTables &t) {
+template <class LT>
+__device__ __forceinline__ void pass3_regs(c32 (&v)[8], const LT &t) {
+    {
+        const c32 w128 = t.W128();
 #pragma unroll
-    for (int B = 0; B < 8; B += 2) bfly(v[B], v[B + 1], c_mul(v[B + 1], t.w128));            // step 64
+        for (int B = 0; B < 8; B += 2) bfly(v[B], v[B + 1], c_mul(v[B + 1], w128));          // step 64
+    }
+    {
+        const c32 wa = t.W256(0), wb = t.W256(1);
 #pragma unroll
-    for (int h = 0; h < 8; h += 4) {                                                          // step 128
-        bfly(v[h + 0], v[h + 2], c_mul(v[h + 2], t.w256[0]));
-        bfly(v[h + 1], v[h + 3], c_mul(v[h + 3], t.w256[1]));
+        for (int h = 0; h < 8; h += 4) {                                                      // step 128
+            bfly(v[h + 0], v[h + 2], c_mul(v[h + 2], wa));
+            bfly(v[h + 1], v[h + 3], c_mul(v[h + 3], wb));
+        }
     }
 #pragma unroll
-    for (int B = 0; B < 4; ++B) bfly(v[B], v[B + 4], c_mul(v[B + 4], t.w512[B]));            // step 256
+    for (int B = 0; B < 4; ++B) bfly(v[B], v[B + 4], c_mul(v[B + 4], t.W512(B)));            // step 256
 }
 
 // The u[r] of pass 1 must be presented to fft8 in bit-reversed order: u[r] = z[.. rev3(r)].
@@ -112,7 +169,8 @@ __device__ __forceinline__ void bitrev8(c32 (&z)[8]) {
 
 // 512-point FFT of the pre-twiddled z[m + 64 s] held by lane m; leaves Z[0..512) in natural order
 // in the wavefront's LDS (complex index = position).
-__device__ __forceinline__ void fft512_wave(c32 (&z)[8], int lane, c32 *lds, const LaneTables &lt) {
+template <class LT>
+__device__ __forceinline__ void fft512_wave(c32 (&z)[8], int lane, c32 *lds, const LT &lt) {
     // ---- pass 1: fft8 over z[m + 64*rev3(r)] -> a[8*rev6(m) + r], i.e. element (B, j, k=r)
     bitrev8(z);
     fft8_regs(z);
@@ -197,7 +255,8 @@ constexpr int kShortRowsEnd = 128 * 7 + 96 + 128;  // floats of per-wave LDS the
 // window's 256 outputs v0|v1|v2|v3 only v1 and v2 are kept: H[w][0..64) = v1, H[w][64..128) = v2 in
 // ldsf[short_row(w) ..]; v0[x] = -v1[63-x] and v3[x] = v2[63-x] exactly (mdct.rs:108-136 writes the same
 // value, negated for v0, to both).
-__device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const cpx *tw_short, const LaneTables &lt) {
+template <class LT>
+__device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const cpx *tw_short, const LT &lt) {
     c32 *lds = reinterpret_cast<c32 *>(ldsf);
     // pass 1: lane (w, c) owns z_w[c + 8 s] = pre_twiddle(x_w[2i], x_w[127 - 2i]), i = c + 8 s
     const int w = lane >> 3, c = lane & 7;

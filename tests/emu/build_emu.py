@@ -14,37 +14,54 @@ SOURCES = ["tables.cpp", "ctx.cpp", "host_tools.cpp", "stage.cpp", "imdct_generi
 FLAGS = ["-O1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-w"]
 
 
-def needs_build():
-    if not OUT.exists():
+def needs_build(out=None):
+    out = OUT if out is None else out
+    if not out.exists():
         return True
-    t = OUT.stat().st_mtime
+    t = out.stat().st_mtime
     deps = list(CSRC.glob("*")) + list(HERE.glob("*.cpp")) + list((HERE / "include" / "hip").glob("*")) + [
         ROOT / "include" / "symaccel.h", Path(__file__)]
     return any(p.stat().st_mtime > t for p in deps)
 
 
+def tuned():
+    """The allow-listed SYMACCEL_TUNE_* knobs of the product build (symphonia_amd/build.py), so a kernel variant can be
+    parity-tested on CPU threads before it is taken to the GPU.  A tuned emulation build has its own output path."""
+    sys.path.insert(0, str(ROOT))
+    from symphonia_amd.build import tuning_defines
+    return list(tuning_defines())
+
+
 def build(force=False):
-    if not force and not needs_build():
-        return OUT
-    objdir = HERE / "build"
-    objdir.mkdir(exist_ok=True)
+    defines = tuned()
+    if defines:
+        tag = "_".join(d[2:].replace("=", "") for d in defines)
+        out = HERE / ("libsymaccel_emu_%s.so" % tag)
+        objdir = HERE / "build" / tag
+        if not force and out.exists() and not needs_build(out):
+            return out
+    else:
+        out, objdir = OUT, HERE / "build"
+        if not force and not needs_build():
+            return OUT
+    objdir.mkdir(exist_ok=True, parents=True)
     procs, objs = [], []
     for src in SOURCES + ["../../tests/emu/emu_rt.cpp"]:
         path = (CSRC / src).resolve()
         obj = objdir / (path.name.replace(".", "_") + ".o")
-        cmd = ["g++", "-x", "c++", *FLAGS, "-I", str(HERE / "include"), "-I", str(CSRC), "-c", str(path), "-o", str(obj)]
+        cmd = ["g++", "-x", "c++", *FLAGS, *defines, "-I", str(HERE / "include"), "-I", str(CSRC), "-c", str(path), "-o", str(obj)]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(str(obj))
     bad = False
     for src, p in procs:
-        out, _ = p.communicate()
+        log, _ = p.communicate()
         if p.returncode != 0:
             bad = True
-            sys.stderr.write("==== %s ====\n%s\n" % (src, out.decode(errors="replace")[-6000:]))
+            sys.stderr.write("==== %s ====\n%s\n" % (src, log.decode(errors="replace")[-6000:]))
     if bad:
         raise RuntimeError("emulation build failed")
-    subprocess.run(["g++", "-shared", "-pthread", "-o", str(OUT), *objs], check=True)
-    return OUT
+    subprocess.run(["g++", "-shared", "-pthread", "-o", str(out), *objs], check=True)
+    return out
 
 
 if __name__ == "__main__":
