@@ -132,6 +132,9 @@ __device__ __forceinline__ void fetch_granule(const float *granule, int hl, floa
     line[4] = ld_stream(src + 128 + (hl & 15));  // lanes 16..31 re-read float4 128..143 (same cache lines) and ignore it
 }
 
+#ifndef SYM_MP3_VARIANT
+#define SYM_MP3_VARIANT 0
+#endif
 #ifndef SYM_MP3_WAVES
 #define SYM_MP3_WAVES 3  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
 #endif
@@ -363,16 +366,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
             }
         }
         float nA[18], nB[18];
+#if SYM_MP3_VARIANT == 1
+        // the two LDS reads of slot b + 1 are issued before the taps of slot b (the store's branch per slot otherwise
+        // pins each read directly in front of its first use: 18 exposed LDS round trips per granule)
+        float ra = S[vm.fcol], rb = S[vm.scol];
+#endif
 #pragma unroll
         for (int b = 0; b < 18; ++b) {
+#if SYM_MP3_VARIANT == 1
+            nA[b] = __uint_as_float(__float_as_uint(ra) ^ vm.fsign);
+            nB[b] = -rb;
+            if (b + 1 < 18) {
+                ra = S[(b + 1) * kSStride + vm.fcol];
+                rb = S[(b + 1) * kSStride + vm.scol];
+            }
+#else
             nA[b] = __uint_as_float(__float_as_uint(S[b * kSStride + vm.fcol]) ^ vm.fsign);  // V[i]
             nB[b] = -S[b * kSStride + vm.scol];                                               // V[32 + i]
+#endif
             float acc = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int ra = b - 2 * j, rb = b - 2 * j - 1;
-                acc += (ra >= 0 ? nA[ra >= 0 ? ra : 0] : oA[ra < 0 ? kHistOld + ra : 0]) * dw0[j];
-                acc += (rb >= 0 ? nB[rb >= 0 ? rb : 0] : oB[rb < 0 ? kHistOld + rb : 0]) * dw1[j];
+                const int ra_ = b - 2 * j, rb_ = b - 2 * j - 1;
+                acc += (ra_ >= 0 ? nA[ra_ >= 0 ? ra_ : 0] : oA[ra_ < 0 ? kHistOld + ra_ : 0]) * dw0[j];
+                acc += (rb_ >= 0 ? nB[rb_ >= 0 ? rb_ : 0] : oB[rb_ < 0 ? kHistOld + rb_ : 0]) * dw1[j];
             }
             if (emit) st_stream(pcm + (chain_base + (size_t)g) * 576 + 32 * b + hl, acc);
         }

@@ -6,7 +6,7 @@
 writes profiles/<tag>_bench_<workload>.json (the bench lines), profiles/<tag>_<workload>_rocprofv3.txt (kernel stats +
 PMC passes, via tools/rocpd_summary.py) and profiles/hbm_traffic.json (HBM bytes per launch of each workload's
 dominant kernel: FETCH_SIZE x 2 -- the gfx950 correction of MI355X_MICROARCH.md, HBM section -- + WRITE_SIZE, in KiB).
-Removes the same files of older tags.  The rocpd databases of a round exceed what gpurun copies back, so gpu_round.sh
+Removes the same files of older tags of the same round (r02a when r02b arrives; r01* stay).  The rocpd databases of a round exceed what gpurun copies back, so gpu_round.sh
 runs this on the GPU box with --stage (artifacts are copied to gpurun_out/profiles_<tag>/) and deletes the databases;
 locally: cp gpurun_out/profiles_<tag>/* profiles/ (and git rm the previous tag's files)."""
 import io
@@ -49,7 +49,7 @@ def main(tag, traffic_only=False):
                         "torch's exp2 kernel (32 MiB read reports 16 400 KB). bench.py copies bytes_per_launch into roofline.traffic."}
     if not traffic_only:
         for old in list(prof.glob("r0*_bench_*.json")) + list(prof.glob("r0*_rocprofv3.txt")):
-            if not old.name.startswith(tag + "_"):
+            if old.name.startswith(tag[:3]) and not old.name.startswith(tag + "_"):  # older tags of the SAME round only
                 old.unlink()
     for w in WORKLOADS:
         if traffic_only:  # on the GPU box, before the bench lines exist: the PMC run's own bench line has the byte count

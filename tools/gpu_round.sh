@@ -2,19 +2,19 @@
 # One gpurun call: rocprofv3 kernel stats + HBM traffic PMC passes for every workload, then the bench lines (with the CPU
 # baseline), which pick up the traffic just measured, then the artifacts (tools/collect_round.py) into
 # gpurun_out/profiles_<tag>/.   bash tools/gpu_round.sh [tag];  afterwards, locally: cp gpurun_out/profiles_<tag>/* profiles/
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=$PWD
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for w in aac mp3 vorbis flac alac; do
-  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_$w -o $w -- python $REPO/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_${TAG}_$w.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_$w -o $w -- python $REPO/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-host-path > $OUT/prof_${TAG}_$w.log 2>&1
   echo "rocprof stats $w rc=$?"
 done
 for w in aac mp3 vorbis flac alac; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${TAG}_${w}_$c -o $w -- python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_${TAG}_${w}_$c.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${TAG}_${w}_$c -o $w -- python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path > $OUT/pmc_${TAG}_${w}_$c.log 2>&1
     echo "rocprof pmc $w $c rc=$?"
   done
 done
