@@ -20,6 +20,16 @@ __device__ __forceinline__ cf32p as_const(const float *p) {
     return (cf32p)p;  // deliberate address-space cast (global -> constant), same 64-bit representation
 }
 
+// Explicit counter waits around LDS-DMA loads (global_load_lds): hipcc neither orders a ds_read behind a pending LDS-DMA
+// write nor an LDS-DMA write behind pending ds_reads of the same bytes -- both waits are the kernel's.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SYM_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SYM_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define SYM_WAIT_VMCNT0() ((void)0)
+#define SYM_WAIT_LGKMCNT0() ((void)0)
+#endif
+
 // Streaming accesses.  The batch is read once and written once, so the big loads and stores carry the non-temporal
 // hint (`nt` on the global_load / global_store): measured on config 2, +4 % (0.239 -> 0.229 ms; mostly the stores,
 // which otherwise allocate in the memory-side cache on their way to HBM).  SYM_NT bit 0: loads, bit 1: stores.

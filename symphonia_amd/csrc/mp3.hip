@@ -29,11 +29,31 @@ namespace symaccel {
 
 namespace {
 
+#ifndef SYM_MP3_VARIANT
+#define SYM_MP3_VARIANT 0
+#endif
+// Build variants (tuning knob SYM_MP3_VARIANT, see build.py; DESIGN.md 4.2 has the measurements -- all within 3 % of
+// each other, which is the finding):
+//   0  one wavefront per workgroup; one granule of spectral lines in flight; the window pass stores each PCM sample as
+//      it is produced (4 B per lane, 128 B per half-wave and instruction);
+//   2  the granule's PCM is collected in an LDS tile and stored as float4 (16 B per lane) when the window pass is done;
+//      four wavefronts per workgroup share the window tables, which pays for the extra 4.5 KiB of LDS per wavefront;
+//   3  two granules of spectral lines in flight instead of one.
+#define SYM_MP3_OTILE (SYM_MP3_VARIANT == 2)
+#define SYM_MP3_PREFETCH2 (SYM_MP3_VARIANT == 3)
+#ifndef SYM_MP3_WG_WAVES
+#define SYM_MP3_WG_WAVES (SYM_MP3_OTILE ? 4 : 1)
+#endif
+constexpr int kWgWaves = SYM_MP3_WG_WAVES;       // wavefronts per workgroup
 constexpr int kTileFloats = 2 * 576;             // two granule tiles (one per half-wave)
-constexpr int kSBase = 0;  // the dct32 transpose reuses the granule tiles' LDS (the tiles are dead by then)
-constexpr int kWinBase = kSBase + 2 * 18 * kSStride + kDwFloats;
-constexpr int kMetaBase = kWinBase + 4 * 36;   // 4 words: (chain, ends-its-chain flag) of each half-wave, for the epilogue
-constexpr int kWaveFloats = kMetaBase + 4;  // per-wavefront LDS: tiles / transpose, synthesis window rows, IMDCT windows, meta
+// per-wavefront LDS: the granule tiles, overlaid by the dct32 transpose S (the tiles are dead before S is written);
+// variant 2: + the PCM tiles
+constexpr int kSBase = 0;
+constexpr int kOBase = kSBase + 2 * 18 * kSStride;
+constexpr int kMetaBase = kOBase + (SYM_MP3_OTILE ? kTileFloats : 0);  // 4 words: (chain, ends-its-chain flag) of each half-wave, for the epilogue
+constexpr int kWaveFloats = kMetaBase + 4;
+// per-workgroup LDS tables: synthesis window rows, then the four 36-entry IMDCT windows
+constexpr int kTabFloats = kDwFloats + 4 * 36;
 static_assert(2 * 18 * kSStride >= kTileFloats, "the transpose area must hold the two granule tiles");
 
 // ---- 36-point IMDCT (Szu-Wei Lee), hybrid_synthesis.rs:559-779 -------------------------------
@@ -135,40 +155,47 @@ __device__ __forceinline__ void fetch_granule(const float *granule, int hl, floa
 #ifndef SYM_MP3_VARIANT
 #define SYM_MP3_VARIANT 0
 #endif
+
 #ifndef SYM_MP3_WAVES
 #define SYM_MP3_WAVES 3  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVES, SYM_MP3_WAVES))) void mp3_synth_kernel(
+__global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVES, SYM_MP3_WAVES))) void mp3_synth_kernel(
     DevTables tb, const float *__restrict__ xr, const symaccel_mp3_side *__restrict__ side, int sr,
     const float *__restrict__ overlap_in, const float *__restrict__ vvec_in, const int32_t *__restrict__ vfront_in,
     float *__restrict__ overlap_out, float *__restrict__ vvec_out, int32_t *__restrict__ vfront_out,
     float *__restrict__ pcm, unsigned n_chains, unsigned granules_per_chain, unsigned seg_len,
     unsigned segs_per_chain) {
-    __shared__ __attribute__((aligned(16))) float lds[kWaveFloats];
-    const int half = (int)threadIdx.x >> 5, hl = (int)threadIdx.x & 31;
+    __shared__ __attribute__((aligned(16))) float lds_tab[kTabFloats];
+    __shared__ __attribute__((aligned(16))) float lds_wave[kWgWaves][kWaveFloats];
+    const int wave = (int)threadIdx.x >> 6;
+    const int half = ((int)threadIdx.x >> 5) & 1, hl = (int)threadIdx.x & 31;
+    float *lds = lds_wave[wave];
     float *tile = lds + half * 576;               // the granule's 576 lines, natural order
     float *S = lds + kSBase + half * (18 * kSStride);  // S[slot][32]: dct32 transpose
+#if SYM_MP3_OTILE
+    float *O = lds + kOBase + half * 576;              // the granule's PCM, natural order
+#endif
     cf32p mc = as_const(tb.mp3_consts);
-
-    const unsigned item = blockIdx.x * 2u + (unsigned)half;
-    const bool live = item < n_chains * segs_per_chain;
-    const unsigned chain = live ? item / segs_per_chain : 0, seg = live ? item % segs_per_chain : 0;
-    const unsigned g_begin = seg * seg_len;
-    const unsigned g_end = live ? min(g_begin + seg_len, granules_per_chain) : g_begin;
-    const size_t chain_base = (size_t)chain * granules_per_chain;
 
     // Window coefficients of sample index i = hl: D[64j + i] (j = 0..7), D[64j + 32 + i], as one 64-byte LDS row
     // per i.  They are only live during the window pass, where they are re-read from LDS (4 x b128) every granule.
-    float *dwt = lds + kSBase + 2 * 18 * kSStride;
-    if (half == 0) {
+    float *dwt = lds_tab;
+    if ((int)threadIdx.x < 32) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             dwt[hl * kDwStride + j] = tb.mp3_consts[MP3C_SYNTH_D + 64 * j + hl];
             dwt[hl * kDwStride + 8 + j] = tb.mp3_consts[MP3C_SYNTH_D + 64 * j + 32 + hl];
         }
     }
-    float *imdct_win = lds + kWinBase;  // the four 36-entry IMDCT windows (hybrid_synthesis.rs:31-101)
-    for (int i = (int)threadIdx.x; i < 4 * 36; i += 64) imdct_win[i] = tb.mp3_consts[MP3C_IMDCT_WIN + i];
+    float *imdct_win = lds_tab + kDwFloats;  // the four 36-entry IMDCT windows (hybrid_synthesis.rs:31-101)
+    for (int i = (int)threadIdx.x; i < 4 * 36; i += 64 * kWgWaves) imdct_win[i] = tb.mp3_consts[MP3C_IMDCT_WIN + i];
+    if (kWgWaves > 1) __syncthreads();  // the only workgroup-wide barrier; wavefronts are independent from here on
+
+    const unsigned item = (blockIdx.x * (unsigned)kWgWaves + (unsigned)wave) * 2u + (unsigned)half;
+    const bool live = item < n_chains * segs_per_chain;
+    const unsigned chain = live ? item / segs_per_chain : 0, seg = live ? item % segs_per_chain : 0;
+    const unsigned g_begin = seg * seg_len;
+    const unsigned g_end = live ? min(g_begin + seg_len, granules_per_chain) : g_begin;
     const VMapX vm = vmapx(hl);
 
     // ---- incoming state.  oA[16 + r] = V_r[i], oB[16 + r] = V_r[32 + i] for the previous granules' time slots r < 0
@@ -191,14 +218,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
         }
     }
 
-    // halo: g_begin-2 (overlap only), g_begin-1 (history only)
-    const long g_first = first_seg ? 0 : (long)g_begin - 2;
-    const long g_stop = (long)g_end;
-    long rounds = live ? g_stop - g_first : 0;  // both halves run the same number of rounds (wave-uniform loop)
+    // halo: g_begin-2 (overlap only), g_begin-1 (history only).  Per half-wave the walk is described by three small
+    // integers (rounds of its own, first round that rebuilds the history, first round that emits) and ONE running
+    // 32-bit granule index `gi` = chain * granules_per_chain + g (launch_mp3 checks that it fits); every global
+    // address is formed from it where it is used -- 64-bit pointers carried through the loop cost two VGPRs each.
+    const unsigned g_first = first_seg ? 0u : g_begin - 2u;
+    const int my_rounds = live ? (int)(g_end - g_first) : 0;
+    const int hist_from = first_seg ? 0 : 1, emit_from = first_seg ? 0 : 2;
+    int rounds = my_rounds;  // both halves run the same number of rounds (wave-uniform loop)
     {
-        const long other = __shfl((int)rounds, (int)(threadIdx.x ^ 32u));
+        const int other = __shfl(rounds, (int)((threadIdx.x & 63u) ^ 32u));
         rounds = rounds > other ? rounds : other;
     }
+    rounds = __builtin_amdgcn_readfirstlane(rounds);
+    unsigned gi = chain * granules_per_chain + g_first;
 
     if (hl == 0) {  // what the epilogue needs of the above, parked in LDS (see there)
         unsigned *meta_w = reinterpret_cast<unsigned *>(lds + kMetaBase) + 2 * half;
@@ -216,16 +249,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
     float4 line[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) line[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (live && g_first < g_stop) {
-        fetch_granule(xr + (chain_base + (size_t)g_first) * 576, hl, line);
-        sd_next = side_raw[chain_base + (size_t)g_first];
+    if (my_rounds > 0) {
+        fetch_granule(xr + (size_t)gi * 576, hl, line);
+        sd_next = side_raw[gi];
     }
+#if SYM_MP3_PREFETCH2
+    // two granules in flight: round r consumes `line` (granule r), `line2` holds granule r + 1 and granule r + 2 is
+    // requested into it once it has moved up -- a granule then has two rounds, not ~60 % of one, to arrive
+    uint32_t sd_next2 = 0;
+    float4 line2[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) line2[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (my_rounds > 1) {
+        fetch_granule(xr + (size_t)(gi + 1u) * 576, hl, line2);
+        sd_next2 = side_raw[gi + 1u];
+    }
+#endif
 
-    for (long r = 0; r < rounds; ++r) {
-        const long g = g_first + r;
-        const bool active = live && g < g_stop;
-        const bool need_hist = active && g >= (long)g_begin - 1;  // halo granule g_begin-2 only rebuilds overlap
-        const bool emit = active && g >= (long)g_begin;
+    for (int r = 0; r < rounds; ++r, ++gi) {
+        unsigned hlg = (unsigned)hl;  // the lane's offset in global addresses, opaque for the same reason as gi:
+        asm volatile("" : "+v"(gi), "+v"(hlg));  // keeps the address arithmetic in the loop (see above)
+        const bool active = r < my_rounds;
+        const bool need_hist = active && r >= hist_from;  // halo granule g_begin-2 only rebuilds overlap
+        const bool emit = active && r >= emit_from;
 
         int bt = 0, mixed = 0, rzero = 0;
         if (active) {
@@ -252,9 +298,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
                 const int32_t *ends = tb.mp3_reorder_end + (size_t)(sr * 2 + mixed) * 577;
                 const int r_start = ends[0], r_end = ends[rzero];
                 rzero = rzero > r_end ? rzero : r_end;
+                int hls = hl;  // (opaque: the 18 line indices are formed here, in the rare path, not kept in VGPRs across the loop)
+                asm volatile("" : "+v"(hls));
 #pragma unroll
                 for (int i = 0; i < 18; ++i) {
-                    const int idx = 18 * hl + i;
+                    const int idx = 18 * hls + i;
                     y[i] = tile[(idx >= r_start && idx < r_end) ? map[idx] : idx];
                 }
             } else {
@@ -324,10 +372,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
                 for (int i = 1; i < 18; i += 2) y[i] = -y[i];
             }
         }
-        if (live && g + 1 < g_stop) {  // prefetch the next granule; it lands during the dct32 and window passes
-            fetch_granule(xr + (chain_base + (size_t)(g + 1)) * 576, hl, line);
-            sd_next = side_raw[chain_base + (size_t)(g + 1)];
+#if SYM_MP3_PREFETCH2
+#pragma unroll
+        for (int q = 0; q < 5; ++q) line[q] = line2[q];
+        sd_next = sd_next2;
+        if (r + 2 < my_rounds) {
+            fetch_granule(xr + (size_t)(gi + 2u) * 576, (int)hlg, line2);
+            sd_next2 = side_raw[gi + 2u];
         }
+#else
+        if (r + 1 < my_rounds) {  // prefetch the next granule; it lands during the dct32 and window passes
+            fetch_granule(xr + (size_t)(gi + 1u) * 576, (int)hlg, line);
+            sd_next = side_raw[gi + 1u];
+        }
+#endif
         wave_sync();  // the previous granule's window pass has read S
         if (need_hist) {
 #pragma unroll
@@ -366,24 +424,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
             }
         }
         float nA[18], nB[18];
-#if SYM_MP3_VARIANT == 1
         // the two LDS reads of slot b + 1 are issued before the taps of slot b (the store's branch per slot otherwise
         // pins each read directly in front of its first use: 18 exposed LDS round trips per granule)
         float ra = S[vm.fcol], rb = S[vm.scol];
-#endif
 #pragma unroll
         for (int b = 0; b < 18; ++b) {
-#if SYM_MP3_VARIANT == 1
-            nA[b] = __uint_as_float(__float_as_uint(ra) ^ vm.fsign);
-            nB[b] = -rb;
+            nA[b] = __uint_as_float(__float_as_uint(ra) ^ vm.fsign);  // V[i]
+            nB[b] = -rb;                                               // V[32 + i]
             if (b + 1 < 18) {
                 ra = S[(b + 1) * kSStride + vm.fcol];
                 rb = S[(b + 1) * kSStride + vm.scol];
             }
-#else
-            nA[b] = __uint_as_float(__float_as_uint(S[b * kSStride + vm.fcol]) ^ vm.fsign);  // V[i]
-            nB[b] = -S[b * kSStride + vm.scol];                                               // V[32 + i]
-#endif
             float acc = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -391,8 +442,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
                 acc += (ra_ >= 0 ? nA[ra_ >= 0 ? ra_ : 0] : oA[ra_ < 0 ? kHistOld + ra_ : 0]) * dw0[j];
                 acc += (rb_ >= 0 ? nB[rb_ >= 0 ? rb_ : 0] : oB[rb_ < 0 ? kHistOld + rb_ : 0]) * dw1[j];
             }
-            if (emit) st_stream(pcm + (chain_base + (size_t)g) * 576 + 32 * b + hl, acc);
+#if SYM_MP3_OTILE
+            O[32 * b + hl] = acc;
+#else
+            if (emit) st_stream(pcm + (size_t)gi * 576 + 32 * b + hlg, acc);
+#endif
         }
+#if SYM_MP3_OTILE
+        wave_sync();
+        if (emit) {  // the granule's 144 float4, lane hl stores float4 hl + 32 q (and 128 + hl for hl < 16)
+            const float4 *o4 = reinterpret_cast<const float4 *>(O);
+            float4 *dst = reinterpret_cast<float4 *>(pcm + (size_t)gi * 576) + hlg;
+            float4 v[5];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = o4[hl + 32 * q];
+            v[4] = o4[128 + (hl & 15)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st_stream(dst + 32 * q, v[q]);
+            if (hl < 16) st_stream(dst + 128, v[4]);
+        }
+#endif
         wave_sync();  // the window pass has read S; the next round's tile goes to the same LDS
         // ---- slide the history: slots 2..17 of this granule become slots -16..-1
         if (need_hist) {
@@ -412,7 +481,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
     unsigned tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));
     const int hl2 = (int)(tid2 & 31u);
-    const unsigned *meta = reinterpret_cast<const unsigned *>(lds + kMetaBase) + 2 * (tid2 >> 5);
+    const unsigned *meta = reinterpret_cast<const unsigned *>(lds_wave[tid2 >> 6] + kMetaBase) + 2 * ((tid2 >> 5) & 1u);
     const unsigned chain2 = meta[0];
     if (meta[1] != 0u) {
 #pragma unroll
@@ -437,14 +506,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVE
 int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_side, int sr,
                const float *d_overlap_in, const float *d_vvec_in, const int32_t *d_vfront_in, float *d_overlap_out,
                float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm, size_t n_chains, size_t granules_per_chain) {
-    if (granules_per_chain > 0x3fffffffu || n_chains > 0x3fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    // (the kernel indexes granules of the whole batch with 32 bits: 2^32 granules are 9.9 TB of spectra)
+    if (granules_per_chain > 0x3fffffffu || n_chains > 0x3fffffffu || n_chains * granules_per_chain > 0xffffffffu)
+        return SYMACCEL_ERR_INVALID_ARG;
     // (the two-granule halo needs segment starts >= 2)
     const unsigned seg = choose_segment(ctx, n_chains, granules_per_chain, 4 * SYM_MP3_WAVES, 2, 2, 2);
     const size_t segs = (granules_per_chain + seg - 1) / seg;
     const size_t items = n_chains * segs;
-    const size_t grid = (items + 1) / 2;
+    const size_t grid = (items + 2 * kWgWaves - 1) / (2 * kWgWaves);
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(mp3_synth_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, ctx->dev, d_xr, d_side, sr,
+    hipLaunchKernelGGL(mp3_synth_kernel, dim3((unsigned)grid), dim3(64 * kWgWaves), 0, ctx->stream, ctx->dev, d_xr, d_side, sr,
                        d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out, d_vfront_out, d_pcm,
                        (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs);
     SYM_GPU(ctx, hipGetLastError());

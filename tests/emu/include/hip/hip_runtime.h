@@ -128,6 +128,13 @@ static inline void __builtin_amdgcn_wave_barrier() {
     pthread_barrier_wait(&emu::g_wave_barrier[linear >> 6]);
 }
 static inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
+// LDS-DMA load (global_load_lds): lane L's `size` bytes land at the wave-uniform LDS base + offset + L * size.  Done at
+// the point of issue here; on the GPU it lands some time before the kernel's vmcnt wait -- a kernel that still reads the
+// old bytes after issuing the load is wrong on both.
+static inline void __builtin_amdgcn_global_load_lds(const void *g, void *l, unsigned size, int offset, int /*aux*/) {
+    const unsigned lane = emu::t_threadIdx.x & 63u;
+    std::memcpy(static_cast<char *>(l) + offset + (size_t)lane * size, g, size);
+}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only used on values every lane already agrees on

@@ -1,0 +1,26 @@
+"""The build variants kept behind tuning knobs (SYMACCEL_TUNE_*, symphonia_amd/build.py) are bit-exact too: each one is
+compiled into its own CPU-emulation library (tests/emu/build_emu.py honours the same knobs) and runs the emulation
+parity tests of its kernel in a subprocess.  (The GPU A/B of the same variants is in profiles/r02*_ab.txt.)"""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+CASES = [
+    ({"SYMACCEL_TUNE_AAC_VARIANT": "1"}, "tests/test_emu_core_aac.py", "aac_all_sequences or imdct_bit_exact"),
+    ({"SYMACCEL_TUNE_MP3_VARIANT": "2"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_VARIANT": "3"}, "tests/test_emu_codecs.py", "emu_mp3"),
+]
+
+
+@pytest.mark.parametrize("knobs,module,select", CASES, ids=lambda v: "_".join("%s%s" % kv for kv in v.items()) if isinstance(v, dict) else None)
+def test_tuned_variant_is_bit_exact_in_emulation(knobs, module, select):
+    env = dict(os.environ, **knobs)
+    r = subprocess.run([sys.executable, "-m", "pytest", module, "-x", "-q", "-k", select, "-p", "no:cacheprovider"],
+                       cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
