@@ -28,6 +28,15 @@
  *    Error::IoError (symphonia-core/src/errors.rs:38-54).  symaccel_strerror() returns static
  *    strings (usable as &'static str).  On error no output buffer is partially trusted: the
  *    caller clears its AudioBuffer as symphonia-core/src/codecs/audio.rs:278 requires.
+ *  - What is validated: sizes, counts, null pointers, aliasing of ping-pong state, the ranges of
+ *    scalar parameters, and -- where the describing data is in HOST memory (every host-pointer entry
+ *    point; index lists such as mag_index / ang_index) -- the layout it implies against the strides
+ *    given (symaccel_vorbis_synth checks the packed spectrum / PCM sizes that follow from the block
+ *    flags).  Data that lives in DEVICE memory is trusted like the device pointers themselves: the
+ *    block flags and pair_chains[] of the *_device entry points index the caller's own buffers, and
+ *    a caller that builds them from an untrusted stream bounds them first (the reference's readers
+ *    do: vorbis/lib.rs:461-470, aac/cpe.rs:53-74).  *_device Vorbis calls still reject a spec_stride
+ *    below the all-short-blocks minimum.
  *  - Thread safety: distinct contexts may be used from distinct threads concurrently; one context
  *    is externally synchronised (matches `&mut self` on AudioDecoder, audio.rs:251-298).
  *  - There is NO CPU fallback: without a HIP device symaccel_ctx_create() fails with

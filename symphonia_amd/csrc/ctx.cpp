@@ -503,6 +503,11 @@ static int vorbis_check(symaccel_ctx *ctx, int bs0_exp, int bs1_exp) {
     if (!ctx || bs0_exp < 6 || bs1_exp > 13 || bs0_exp > bs1_exp) return SYMACCEL_ERR_INVALID_ARG;
     return SYMACCEL_OK;
 }
+// What can be said about the strides of a device-pointer call without reading the (device-resident) flags: even a chain
+// of short blocks only needs blocks * bs0/2 lines.  The exact check is the host-pointer entry point's (and the caller's).
+static int vorbis_stride_floor(int bs0_exp, size_t spec_stride, size_t blocks_per_chain) {
+    return spec_stride < blocks_per_chain * ((size_t)1 << (bs0_exp - 1)) ? SYMACCEL_ERR_INVALID_ARG : SYMACCEL_OK;
+}
 
 static int vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
                                  size_t spec_stride, const uint8_t *d_block_flag, int32_t *d_prev_flag_io,
@@ -511,6 +516,7 @@ static int vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, cons
     SYM_TRY(vorbis_check(ctx, bs0_exp, bs1_exp));
     if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
     if (!d_spectra || !d_block_flag || !d_prev_flag_io || !d_overlap_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_TRY(vorbis_stride_floor(bs0_exp, spec_stride, blocks_per_chain));
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     const size_t half1 = (size_t)1 << (bs1_exp - 1);
@@ -535,6 +541,7 @@ int symaccel_vorbis_synth_pp_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp,
     if (!d_spectra || !d_block_flag || !d_prev_flag_in || !d_prev_flag_out || !d_overlap_in || !d_overlap_out || !d_pcm)
         return SYMACCEL_ERR_INVALID_ARG;
     if (d_prev_flag_in == d_prev_flag_out || d_overlap_in == d_overlap_out) return SYMACCEL_ERR_INVALID_ARG;
+    SYM_TRY(vorbis_stride_floor(bs0_exp, spec_stride, blocks_per_chain));
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     void *scratch = nullptr;  // per-block offsets of the generic block-size pairs
@@ -566,6 +573,22 @@ int symaccel_vorbis_synth(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const flo
     if (!ctx || bs0_exp < 6 || bs1_exp > 13 || bs0_exp > bs1_exp) return SYMACCEL_ERR_INVALID_ARG;
     if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
     if (!h_spectra || !h_block_flag || !h_prev_flag_io || !h_overlap_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    // The flags are on the host here: check the packed layout they imply against the caller's strides before anything
+    // is launched (a block of n samples reads n/2 lines and owns (prev_n + n)/4 PCM slots -- see the layout note in
+    // symaccel.h; a first block without a previous one owns n/2 slots and leaves them untouched).  Strides that are too
+    // small would make one chain's blocks overwrite the next chain's.
+    for (size_t c = 0; c < n_chains; ++c) {
+        size_t lines = 0, samples = 0;
+        int prev = h_prev_flag_io[c];  // -1: no previous block (lapping state empty)
+        for (size_t b = 0; b < blocks_per_chain; ++b) {
+            const int flag = h_block_flag[c * blocks_per_chain + b] ? 1 : 0;
+            const size_t n = (size_t)1 << (flag ? bs1_exp : bs0_exp);
+            lines += n / 2;
+            samples += (prev >= 0 ? (((size_t)1 << (prev ? bs1_exp : bs0_exp)) + n) / 4 : n / 2);
+            prev = flag;
+        }
+        if (lines > spec_stride || samples > pcm_stride) return SYMACCEL_ERR_INVALID_ARG;
+    }
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     const size_t half1 = (size_t)1 << (bs1_exp - 1);

@@ -42,6 +42,29 @@ def bit_equal(a, b):
         a.view(np.uint8), b.view(np.uint8))
 
 
+def equal_mod_nan(a, b):
+    """Bit-equal wherever neither side is NaN (so +-Inf, signed zeros and denormals must match exactly), NaN exactly
+    where the other is NaN.  (The NaN a GPU and an x86 produce for inf - inf differ in sign and payload; WHERE a NaN
+    appears is a property of the operation graph and must agree.)"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    if a.shape != b.shape:
+        return False
+    na, nb = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb]))
+
+
+def sprinkle_specials(x, rng, units, per_unit=3):
+    """+Inf, -Inf and NaN lines in the given units (frames / granules: indices into x reshaped to [-1, x.shape[-1]]):
+    the non-finite inputs a corrupt stream can hand the synthesis stage (the reference does no range check)."""
+    flat = x.reshape(-1, x.shape[-1])
+    vals = np.array([np.inf, -np.inf, np.nan], np.float32)
+    for u in units:
+        pos = rng.integers(0, x.shape[-1], size=per_unit)
+        flat[u, pos] = vals[np.arange(per_unit) % 3]
+    return x
+
+
 # ---- closed forms (f64) ------------------------------------------------------
 
 def imdct_analytical(x, scale):

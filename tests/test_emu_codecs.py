@@ -61,6 +61,26 @@ def test_emu_mp3(emu_ctx, seg, sr):
     assert bit_equal(got[2], want[2]), "v_vec"
 
 
+def test_emu_mp3_non_finite_lines(emu_ctx):
+    """+-Inf / NaN lines in a few granules: NaN appears in the PCM, the overlap and the polyphase FIFO exactly where the
+    reference's operation graph puts it (the FIFO keeps it for 16 time slots), and the halo recompute walks through it."""
+    from helpers import equal_mod_nan, sprinkle_specials
+    rng = np.random.default_rng(405)
+    nch, ngr = 3, 9
+    xr, bt, mx, rz = mp3_case(rng, nch, ngr)
+    sprinkle_specials(xr, rng, [1, 4, ngr + 2, 2 * ngr + 8])
+    z = (np.zeros((nch, 576), np.float32), np.zeros((nch, 1024), np.float32), np.zeros(nch, np.int32))
+    want = oracle.mp3_synth(xr, oracle.mp3_side(bt, mx, rz), 0, *z)
+    assert np.isnan(want[0]).any() and np.isnan(want[2]).any()
+    for seg in (2, 3, 64):
+        emu_ctx.set_segment(seg)
+        got = Mp3Synthesis(emu_ctx, 0).synth(xr, mp3_side(bt, mx, rz), *z)
+        for a, b, what in zip(got[:3], want[:3], ("pcm", "overlap", "v_vec")):
+            assert equal_mod_nan(a, np.asarray(b)), (seg, what)
+        assert np.array_equal(got[3], want[3])
+    emu_ctx.set_segment(0)
+
+
 def test_emu_mp3_single_granule_and_odd_chain_count(emu_ctx):
     rng = np.random.default_rng(77)
     for nch, ngr in ((1, 1), (1, 2), (5, 3)):

@@ -63,3 +63,25 @@ def test_emu_aac_all_sequences(emu_ctx, seg):
     assert bit_equal(pcm, wp)
     assert bit_equal(nd, wd)
     emu_ctx.set_segment(0)
+
+
+def test_emu_aac_non_finite_lines(emu_ctx):
+    """+-Inf / NaN spectral lines (a corrupt stream): the frame and the delay line it feeds turn NaN exactly where the
+    reference's operation graph makes them NaN, the frames after recover, and the halo recompute walks through it."""
+    from helpers import equal_mod_nan, sprinkle_specials
+    rng = np.random.default_rng(404)
+    nch, nfr = 2, 10
+    coeffs = aac_spectra(rng, (nch, nfr))
+    sprinkle_specials(coeffs, rng, [2, 5, nfr + 3, nfr + 4])
+    side = np.empty((nch, nfr), np.uint8)
+    for c in range(nch):
+        s, sh, pv = aac_sequence_chain(rng, nfr, p_switch=0.5)
+        side[c] = aac_side(s, sh, pv)
+    delay = rng.standard_normal((nch, 1024)).astype(np.float32)
+    wp, wd = oracle.aac_synth(coeffs, side, delay)
+    assert np.isnan(wp).any() and np.isfinite(wp[0, 8]).all()
+    for seg in (3, 64):
+        emu_ctx.set_segment(seg)
+        pcm, nd = AacDsp(emu_ctx).synth(coeffs, side, delay)
+        assert equal_mod_nan(pcm, wp) and equal_mod_nan(nd, wd), seg
+    emu_ctx.set_segment(0)

@@ -90,3 +90,23 @@ def test_null_context_and_error_strings():
         lib.check(_ffi.ERR_UNSUPPORTED)
     assert e.value.status == _ffi.ERR_UNSUPPORTED and "unsupported" in str(e.value).lower()
     assert lib.dll.symaccel_table_f32(None, 99, None, 0) == _ffi.ERR_INVALID_ARG
+
+
+def test_vorbis_strides_are_checked_against_the_block_flags(emu_ctx):
+    """Host-pointer entry point: the packed layout implied by the flags must fit the strides (a stride that is too small
+    would let one chain's blocks overwrite the next chain's); device-pointer entry points can only apply the
+    all-short-blocks lower bound, the flags being on the device."""
+    p = lambda a: a.ctypes.data  # noqa: E731
+    flags = np.array([[1, 0, 1, 1]], np.uint8)            # long short long long, 256 / 2048
+    prev = np.array([1], np.int32)
+    lines = 1024 + 128 + 1024 + 1024
+    samples = (2048 + 2048) // 4 + (2048 + 256) // 4 + (256 + 2048) // 4 + (2048 + 2048) // 4
+    spec, ov, pcm = buf(lines), buf(1024), buf(samples)
+    args = lambda ss, ps: (8, 11, p(spec), ss, p(flags), p(prev), p(ov), p(pcm), ps, 1, 4)  # noqa: E731
+    assert call(emu_ctx, "symaccel_vorbis_synth", *args(lines, samples)) == _ffi.OK
+    assert call(emu_ctx, "symaccel_vorbis_synth", *args(lines - 1, samples)) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_vorbis_synth", *args(lines, samples - 1)) == _ffi.ERR_INVALID_ARG
+    prev[0] = -1  # no previous block: the first block still owns (n + n) / 4 slots of the packed layout (symaccel.h)
+    assert call(emu_ctx, "symaccel_vorbis_synth", *args(lines, samples - 1)) == _ffi.ERR_INVALID_ARG
+    assert call(emu_ctx, "symaccel_vorbis_synth", *args(lines, samples)) == _ffi.OK
+    assert call(emu_ctx, "symaccel_vorbis_synth_device", 8, 11, p(spec), 4 * 128 - 1, p(flags), p(prev), p(ov), p(pcm), samples, 1, 4) == _ffi.ERR_INVALID_ARG

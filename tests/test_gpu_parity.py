@@ -140,6 +140,22 @@ def test_aac_parity(ctx, seg, only_long):
     assert_parity(host(d_delay), wd, "aac delay")
 
 
+@pytest.mark.parametrize("seg", [3, 64])
+def test_aac_non_finite_lines(ctx, seg):
+    """+-Inf / NaN spectral lines: NaN exactly where the reference's operation graph makes it, everything else bit-equal."""
+    from helpers import equal_mod_nan, sprinkle_specials
+    from symphonia_amd import AacDsp
+    coeffs, side, delay = aac_case(77, 4, 21, False)
+    sprinkle_specials(coeffs, np.random.default_rng(78), [2, 9, 21 + 3, 21 + 4, 3 * 21 + 20])
+    wp, wd = oracle.aac_synth(coeffs, side, delay)
+    assert np.isnan(wp).any() and np.isnan(wd[3]).any() and np.isfinite(wp[0, 15]).all()
+    ctx.set_segment(seg)
+    d_delay = dev(delay)
+    pcm = host(AacDsp(ctx).synth(dev(coeffs), dev(side), d_delay))
+    ctx.set_segment(0)
+    assert equal_mod_nan(pcm, wp) and equal_mod_nan(host(d_delay), wd)
+
+
 def test_aac_streaming_state(ctx):
     """Two consecutive calls continue the stream exactly like one call (delay_io contract)."""
     from symphonia_amd import AacDsp
@@ -221,6 +237,23 @@ def test_mp3_parity(ctx, seg, sr):
     assert_parity(pcm, want[0], "mp3 pcm")
     assert_parity(host(d_ov), want[1], "mp3 overlap")
     assert_parity(host(d_vv), want[2], "mp3 v_vec")
+    assert np.array_equal(host(d_vf), want[3])
+
+
+@pytest.mark.parametrize("seg", [2, 5, 64])
+def test_mp3_non_finite_lines(ctx, seg):
+    from helpers import equal_mod_nan, sprinkle_specials
+    from symphonia_amd import Mp3Synthesis, mp3_side
+    xr, bt, mx, rz, ov, vv, vf = mp3_case(90, 5, 23)
+    sprinkle_specials(xr, np.random.default_rng(91), [1, 7, 23 + 2, 2 * 23 + 22, 4 * 23 + 11])
+    want = oracle.mp3_synth(xr, oracle.mp3_side(bt, mx, rz), 0, ov, vv, vf)
+    assert np.isnan(want[0]).any() and np.isnan(want[2]).any()
+    side = mp3_side(bt, mx, rz)
+    d_ov, d_vv, d_vf = dev(ov), dev(vv), dev(vf)
+    ctx.set_segment(seg)
+    pcm = host(Mp3Synthesis(ctx, 0).synth(dev(xr), dev(side.view(np.uint8).reshape(5, 23, 4)), d_ov, d_vv, d_vf))
+    ctx.set_segment(0)
+    assert equal_mod_nan(pcm, want[0]) and equal_mod_nan(host(d_ov), want[1]) and equal_mod_nan(host(d_vv), want[2])
     assert np.array_equal(host(d_vf), want[3])
 
 
