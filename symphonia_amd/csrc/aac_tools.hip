@@ -8,8 +8,12 @@
 // mid/side or intensity are touched, so the traffic is proportional to their share.
 // TNS is an all-pole filter running along the spectrum -- a serial recurrence of up to 20 taps per line.  The
 // parallel axis is the filter: one lane per filter of a flat list, the tap history in registers, sixteen lines
-// (one 64-byte sector) per lane and round, the next sixteen fetched while the current ones are filtered.  The taps are applied in the reference's order, each as a
-// rounded multiply and a rounded subtract, and only `min(order, lines filtered so far)` of them (tns.rs:184, 191).
+// (one 64-byte sector) per lane and round, the next sixteen fetched while the current ones are filtered.  The taps are
+// applied in the reference's order, each as a rounded multiply and a rounded subtract, and only `min(order, lines
+// filtered so far)` of them (tns.rs:184, 191).  (Staging the lines through an LDS tile of 64 filters x 32 lines, as the
+// integer predictors do, was measured: 128-byte row segments on the HBM side, but 0.50 ms instead of 0.38 ms for 131 072
+// order-12 filters -- the kernel is bound by the serial chain per line and two wavefronts per SIMD, not by its access
+// pattern; profiles/r02n_tns_alac_ab.txt.)
 #include <hip/hip_runtime.h>
 
 #include "symaccel_internal.h"
@@ -119,8 +123,11 @@ __global__ __launch_bounds__(64) void aac_tns_kernel(float *__restrict__ coeffs,
 #pragma unroll
             for (int j = 0; j < kTnsMaxOrder; ++j) {
                 if (j < max_order) {  // wave-uniform
-                    const float term = h[j] * lpc[j];
-                    acc = j < lim ? acc - term : acc;  // coeffs[i] -= coeffs[i -+ (j + 1)] * lpc[j], in tap order
+                    // coeffs[i] -= coeffs[i -+ (j + 1)] * lpc[j], in tap order.  A tap that does not apply subtracts
+                    // +0.0 instead (x - +0.0 == x for every x, -0.0 and NaN included): the select is on the product,
+                    // off the serial chain, and one subtract per tap is all that is serial.
+                    const float term = j < lim ? h[j] * lpc[j] : 0.0f;
+                    acc = acc - term;
                 }
             }
             cur[k] = acc;

@@ -19,6 +19,15 @@ namespace {
 
 __device__ __forceinline__ int32_t wrap_sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 __device__ __forceinline__ int32_t wrap_mul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+// The two multiplies of a predictor tap.  v_mul_lo_u32 issues at a quarter of the rate of the other integer operations;
+// v_mul_i32_i24 (the low 32 bits of a signed 24 x 24-bit product) at the full rate, and it IS wrap_mul whenever both
+// operands are representable in 24 signed bits.  The kernel exists in both forms; each wavefront proves or fails a bound
+// on its 64 blocks before the first sample (alac_predict_kernel, "narrow") and only the matching form processes it.
+template <bool M24>
+__device__ __forceinline__ int32_t tap_mul(int32_t a, int32_t b) {
+    if constexpr (M24) return __mul24(a, b);
+    else return wrap_mul(a, b);
+}
 // clip_msbs (lib.rs:659-661)
 __device__ __forceinline__ int32_t clip_msbs(int32_t v, uint32_t num) { return (int32_t)((uint32_t)v << num) >> num; }
 
@@ -31,7 +40,8 @@ struct AlacLane {
 };
 
 // One sample.  `past_far` = out[i - order - 1] as read back from LDS (valid for order >= 3).
-template <int TAPS>
+// FULL: every lane's order equals TAPS (wave-uniform), so no tap needs neutralising.
+template <int TAPS, bool M24, bool FULL>
 __device__ __forceinline__ int32_t alac_step(AlacLane &L, int32_t x, unsigned i, int32_t past_far) {
     if (L.enabled) {
         // first pass of the double predictor: out[i] = clip(out[i] + out[i-1]) over the whole block
@@ -44,24 +54,36 @@ __device__ __forceinline__ int32_t alac_step(AlacLane &L, int32_t x, unsigned i,
             const int32_t past0 = L.order == 1 ? L.h[1] : (L.order == 2 ? L.h[2] : past_far);
             int32_t sum = 0;
 #pragma unroll
-            for (int k = 0; k < TAPS; ++k) sum = wrap_add(sum, wrap_mul(L.c[k], wrap_sub(L.h[k], past0)));
+            for (int k = 0; k < TAPS; ++k) sum = wrap_add(sum, tap_mul<M24>(L.c[k], wrap_sub(L.h[k], past0)));
             const int32_t val = wrap_add(sum, (int32_t)((1u << L.shift) >> 1)) >> L.shift;
             x = clip_msbs(wrap_add(wrap_add(x, past0), val), L.clip);
             // sign-LMS update (lib.rs:224-260): from the oldest sample (coefficient order-1) to the newest, until the
-            // residual reaches or crosses zero (the reference's `break`, here a per-lane predicate)
-            const bool pos = res > 0;
-            bool active = res != 0;
+            // residual reaches or crosses zero (the reference's `break`, here a per-lane predicate).
+            // Shape of the code (it decides the kernel's speed; one lane per block means every predicate is per lane):
+            //  * predicates are 0 / -1 words in VGPRs and applied with AND / XOR / BFI, never `?:` on a bool that lives
+            //    across taps -- hipcc keeps such bools as SGPR-pair masks, ran out of SGPRs at 32 taps, spilled them
+            //    into VGPR lanes and branched around every coefficient update;
+            //  * tap k subtracts t_k = (1 + j) * step_k from the residual, and neither t_k nor the direction the
+            //    coefficient moves in depends on the residual, so the residual after tap k is res - (t_{order-1} + ... +
+            //    t_k) (wrapping sums re-associate freely): only the running sum and "still active" are serial;
+            //  * a tap beyond the lane's own order (TAPS is the wavefront's maximum) is neutralised by zeroing its
+            //    difference v: step, t_k and the coefficient move are then 0, and since those taps come first, while the
+            //    running sum is still 0, the activity test sees the untouched residual and changes nothing.
+            const int32_t pm = res > 0 ? 0 : -1;      // 0: the residual is positive, -1: negative (zero: never active)
+            int32_t act = res != 0 ? -1 : 0;
+            int32_t run = 0;                          // t_{order-1} + ... + t_k so far
 #pragma unroll
             for (int k = TAPS - 1; k >= 0; --k) {
-                const bool on = active && (unsigned)k < L.order;
-                const int32_t v = wrap_sub(past0, L.h[k]);
-                const int32_t sign = (v > 0) - (v < 0);
-                const int32_t mag = v < 0 ? wrap_sub(0, v) : v;                        // sign * v (wraps like the reference)
-                const int32_t step = (pos ? mag : wrap_sub(0, mag)) >> L.shift;        // (+-sign * val) >> shift
-                const int32_t nres = wrap_sub(res, wrap_mul((int32_t)L.order - k, step));  // (1 + j) = order - k
-                L.c[k] = on ? (pos ? wrap_sub(L.c[k], sign) : wrap_add(L.c[k], sign)) : L.c[k];
-                res = on ? nres : res;
-                active = on ? (pos ? res > 0 : res < 0) : active;
+                const int32_t nk = (int32_t)L.order - k;                                   // (1 + j); <= 0 beyond the order
+                int32_t v = wrap_sub(past0, L.h[k]);
+                if constexpr (!FULL) v &= wrap_sub(0, nk) >> 31;                           // 0 beyond the lane's order
+                const int32_t m2 = pm ^ (v >> 31);                                         // v and the residual differ in sign
+                const int32_t step = wrap_sub(v ^ m2, m2) >> L.shift;                      // (+-sign(v) * v) >> shift = +-|v| >> shift
+                const int32_t sg = v > 1 ? 1 : (v < -1 ? -1 : v);                          // signum(v) (v_med3_i32)
+                run = wrap_add(run, tap_mul<M24>(nk, step));
+                const int32_t r = wrap_sub(res, run);                                      // the residual after this tap
+                L.c[k] = wrap_sub(L.c[k], wrap_sub(sg ^ pm, pm) & act);                    // c -= +-sign, while still active
+                act = (r ^ pm) > pm ? act : 0;                                             // r > 0 resp. r < 0: still on the residual's side
             }
         }
     }
@@ -74,7 +96,7 @@ __device__ __forceinline__ int32_t alac_step(AlacLane &L, int32_t x, unsigned i,
 // 32 samples of one tile.  `row` = this tile's LDS row of the lane, `prev_row` = the previous tile's (still intact in
 // the other LDS buffer); t0 = absolute index of column 0.  Rows are written back four samples at a time, so anything
 // older than three samples can be read back from LDS: that is where out[i - order - 1] comes from for order >= 3.
-template <int TAPS>
+template <int TAPS, bool M24, bool FULL>
 __device__ __forceinline__ void alac_steps32(AlacLane &L, int32_t *row, const int32_t *prev_row, unsigned t0, int n_valid) {
 #pragma unroll 1
     for (int u0 = 0; u0 < 32; u0 += 4) {
@@ -86,7 +108,7 @@ __device__ __forceinline__ void alac_steps32(AlacLane &L, int32_t *row, const in
             if (u < n_valid) {
                 const int idx = u - (int)L.order - 1;
                 const int32_t far = idx >= 0 ? row[idx >= 0 ? idx : 0] : prev_row[32 + (idx < -32 ? -32 : idx)];
-                xs[q] = alac_step<TAPS>(L, xs[q], t0 + (unsigned)u, far);
+                xs[q] = alac_step<TAPS, M24, FULL>(L, xs[q], t0 + (unsigned)u, far);
             }
         }
         *reinterpret_cast<int4 *>(row + u0) = make_int4(xs[0], xs[1], xs[2], xs[3]);
@@ -132,10 +154,53 @@ __device__ __forceinline__ void alac_store_mixed(int32_t *__restrict__ buf, cons
 
 // MIX: blocks 2p / 2p+1 are the two channels of element pair p; decorrelate_mid_side runs as the predicted tile is
 // written back (decode_element, lib.rs:541-560, in one pass).
-template <bool MIX>
+// "narrow": every multiply of a block has operands of at most 24 signed bits, so that v_mul_i32_i24 computes what the
+// reference's wrapping i32 multiply computes.  The operands are (coefficient, difference of two earlier outputs) and
+// (1..32, a shifted-down such difference):
+//  * every output but a block's first is clip_msbs'd to the channel's bit depth (lib.rs:196-198, 221); with a depth of
+//    at most 23 bits and a first sample inside [-2^22, 2^22) any difference of two outputs is inside +-(2^23 - 1);
+//  * a coefficient moves by at most one per sample (lib.rs:236-257): starting inside +-2^22, a block of at most 2^21
+//    samples keeps it inside +-2^23.
+// Anything else (24-bit channels -- 25 bits on a side channel --, a caller's arbitrary i32 data) takes the full 32-bit
+// multiply.  One flag per wavefront of 64 blocks, computed BEFORE the in-place prediction touches the buffer.
+__global__ __launch_bounds__(64) void alac_narrow_kernel(const int32_t *__restrict__ buf, const symaccel_alac_desc *__restrict__ desc,
+                                                         const int32_t *__restrict__ coeffs, size_t n_blocks, unsigned blocksize,
+                                                         uint8_t *__restrict__ narrow_flag) {
+    const size_t my = (size_t)blockIdx.x * kRows + threadIdx.x;
+    bool narrow = true;
+    if (my < n_blocks) {
+        const symaccel_alac_desc d = desc[my];
+        const unsigned order = d.lpc_order > 31u ? 31u : d.lpc_order;
+        const bool enabled = (d.mode == 0 || d.mode >= 15) && order != 0;
+        if (enabled) {
+            const unsigned bps = d.bps < 1u ? 1u : (d.bps > 32u ? 32u : d.bps);
+            const int32_t first = buf[my * (size_t)blocksize];
+            narrow = bps <= 23u && blocksize <= (1u << 21) && first >= -(1 << 22) && first < (1 << 22);
+            const int4 *cp = reinterpret_cast<const int4 *>(coeffs + my * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int4 v = cp[j];
+                const int32_t c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((unsigned)(4 * j + q) < order) narrow = narrow && c[q] > -(1 << 22) && c[q] < (1 << 22);
+            }
+        }
+    }
+    const bool all = __all(narrow) != 0;
+    if (threadIdx.x == 0) narrow_flag[blockIdx.x] = all ? 1 : 0;
+}
+
+// M24: the instantiation for wavefronts whose blocks are all "narrow" (see there); the other instantiation takes the
+// rest.  Both are launched over the whole grid and a wavefront returns at once from the one that is not its own (the two
+// loops in one kernel cost the register allocator its second wavefront per SIMD; and the choice cannot be re-derived by
+// the second launch, the buffer being predicted in place by the first).
+template <bool MIX, bool M24>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void alac_predict_kernel(
     int32_t *__restrict__ buf, const symaccel_alac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
-    size_t n_blocks, unsigned blocksize, const int32_t *__restrict__ pair_weight, const uint8_t *__restrict__ pair_shift) {
+    size_t n_blocks, unsigned blocksize, const int32_t *__restrict__ pair_weight, const uint8_t *__restrict__ pair_shift,
+    const uint8_t *__restrict__ narrow_flag) {
+    if ((narrow_flag[blockIdx.x] != 0) != M24) return;  // the other instantiation's wavefront (alac_narrow_kernel)
     __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
     __shared__ int32_t row_weight[kRows];
     __shared__ uint8_t row_shift[kRows];
@@ -173,6 +238,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
     }
     const unsigned max_order = wave_max(L.enabled ? L.order : 0u);
+    const bool full8 = __all(!have || !L.enabled || L.order == 8u) != 0 && max_order == 8u;
 
     const bool aligned = (blocksize & 3u) == 0 && blk0 + kRows <= n_blocks;
     const unsigned n_tiles = (blocksize + kCols - 1) / kCols;
@@ -195,14 +261,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if (have) {
             int32_t *row = tile + lane * kStride;
             const int32_t *prow = prev_tile + lane * kStride;
-            if (max_order <= 4)
-                alac_steps32<4>(L, row, prow, t0, (int)cols);
+            if (full8)  // the common stream: every block of the wavefront has order 8
+                alac_steps32<8, M24, true>(L, row, prow, t0, (int)cols);
+            else if (max_order <= 4)
+                alac_steps32<4, M24, false>(L, row, prow, t0, (int)cols);
             else if (max_order <= 8)
-                alac_steps32<8>(L, row, prow, t0, (int)cols);
+                alac_steps32<8, M24, false>(L, row, prow, t0, (int)cols);
             else if (max_order <= 16)
-                alac_steps32<16>(L, row, prow, t0, (int)cols);
+                alac_steps32<16, M24, false>(L, row, prow, t0, (int)cols);
             else
-                alac_steps32<32>(L, row, prow, t0, (int)cols);
+                alac_steps32<32, M24, false>(L, row, prow, t0, (int)cols);
         }
         wave_sync();
         if constexpr (MIX) {
@@ -237,12 +305,22 @@ int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_d
                         size_t n_blocks, size_t blocksize, const int32_t *d_pair_weight, const uint8_t *d_pair_shift) {
     const size_t grid = (n_blocks + kRows - 1) / kRows;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    if (d_pair_weight)
-        hipLaunchKernelGGL(alac_predict_kernel<true>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs,
-                           n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift);
-    else
-        hipLaunchKernelGGL(alac_predict_kernel<false>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs,
-                           n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift);
+    void *flags = nullptr;  // one byte per wavefront: 24-bit multiplies are exact for its 64 blocks
+    SYM_TRY(ctx_scratch(ctx, grid, &flags));
+    hipLaunchKernelGGL(alac_narrow_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
+                       (unsigned)blocksize, (uint8_t *)flags);
+    // two launches over the same grid: the 24-bit-multiply wavefronts, then the rest (each wavefront runs in exactly one)
+    if (d_pair_weight) {
+        hipLaunchKernelGGL((alac_predict_kernel<true, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
+                           d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags);
+        hipLaunchKernelGGL((alac_predict_kernel<true, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
+                           d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags);
+    } else {
+        hipLaunchKernelGGL((alac_predict_kernel<false, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
+                           d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags);
+        hipLaunchKernelGGL((alac_predict_kernel<false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
+                           d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags);
+    }
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -163,6 +163,13 @@ static inline unsigned long long __ballot(int pred) {
     return m;
 }
 static inline int __any(int pred) { return __ballot(pred) != 0ull; }
+// every ACTIVE lane's predicate is non-zero (a wavefront that is only partly populated is still "all")
+static inline int __all(int pred) { return __ballot(!pred) == 0ull; }
+// v_mul_i32_i24: the low 32 bits of the product of the operands' low 24 bits, each taken as a signed number
+static inline int __mul24(int a, int b) {
+    const int64_t sa = (int64_t)((int32_t)((uint32_t)a << 8) >> 8), sb = (int64_t)((int32_t)((uint32_t)b << 8) >> 8);
+    return (int)(uint32_t)(uint64_t)(sa * sb);
+}
 static inline int __shfl(int v, int src_lane, int width = 64) {
     (void)width;
     return __builtin_amdgcn_ds_bpermute(src_lane * 4, v);

@@ -125,6 +125,63 @@ def test_emu_alac_uniform_small_orders(emu_ctx):
         assert np.array_equal(got, oracle.alac_predict(buf, oracle.alac_desc(*d), coeffs)), hi
 
 
+@pytest.mark.parametrize("bps", [16, 24])
+def test_emu_alac_uniform_order_8(emu_ctx, bps):
+    """Every block of the wavefront at order 8 (what Apple's encoder writes): the instantiation without per-tap order
+    masks, with 24-bit multiplies (16-bit channels) and with full ones (24-bit channels)."""
+    from symphonia_amd import AlacPredictor, alac_desc
+    rng = np.random.default_rng(80 + bps)
+    nb, bs = 128, 200
+    buf = rng.integers(-(1 << (bps - 3)), 1 << (bps - 3), (nb, bs)).astype(np.int32)
+    buf[::7] = rng.integers(-(1 << 31), 1 << 31, (len(buf[::7]), bs))
+    buf[:, 0] = rng.integers(-(1 << 15), 1 << 15, nb)
+    d = (rng.choice([0, 15], nb).astype(np.uint8), np.full(nb, 8, np.uint8), rng.integers(0, 12, nb).astype(np.uint8), np.full(nb, bps, np.uint8))
+    coeffs = rng.integers(-(1 << 15), 1 << 15, (nb, 32)).astype(np.int32)
+    got = AlacPredictor(emu_ctx).predict(buf, alac_desc(*d), coeffs)
+    assert np.array_equal(got, oracle.alac_predict(buf, oracle.alac_desc(*d), coeffs))
+
+
+def narrow_case(seed, blocksize):
+    """Five wavefronts of 64 blocks around the bound that selects the 24-bit-multiply instantiation (alac.hip, "narrow"):
+    wavefronts 0 and 4 sit exactly ON the bound (23-bit channels, first samples -2^22 and 2^22 - 1, coefficients
+    +-(2^22 - 1), residuals that drive the outputs to the rails), wavefronts 1, 2, 3 each have ONE block just outside it
+    (first sample 2^22; a coefficient of 2^22; a 24-bit channel) and must take the full multiply."""
+    rng = np.random.default_rng(seed)
+    nb = 5 * 64
+    bps = np.full(nb, 23, np.uint8)
+    bps[64:256] = rng.choice([16, 20, 23], 192)
+    buf = rng.integers(-(1 << 21), 1 << 21, (nb, blocksize)).astype(np.int32)
+    buf[::3] = rng.integers(-(1 << 31), 1 << 31, (len(buf[::3]), blocksize))   # wrapping residuals
+    buf[:, 0] = rng.choice([-(1 << 22), (1 << 22) - 1, 0, 12345], nb)
+    mode = rng.choice([0, 0, 15], nb).astype(np.uint8)
+    order = rng.choice([1, 2, 3, 4, 8, 16, 31], nb).astype(np.uint8)
+    shift = rng.integers(0, 12, nb).astype(np.uint8)
+    coeffs = rng.integers(-(1 << 15), 1 << 15, (nb, 32)).astype(np.int32)
+    coeffs[::5] = rng.choice([-(1 << 22) + 1, (1 << 22) - 1], (len(coeffs[::5]), 32))
+    buf[64 + 7, 0] = 1 << 22
+    order[128 + 9] = 8
+    coeffs[128 + 9, 3] = 1 << 22
+    bps[192 + 11] = 24
+    return buf, mode, order, shift, bps, coeffs
+
+
+@pytest.mark.parametrize("blocksize", [40, 352])
+def test_emu_alac_24_bit_multiply_bound(emu_ctx, blocksize):
+    from symphonia_amd import AlacPredictor, alac_desc
+    buf, mode, order, shift, bps, coeffs = narrow_case(blocksize, blocksize)
+    want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
+    got = AlacPredictor(emu_ctx).predict(buf, alac_desc(mode, order, shift, bps), coeffs)
+    assert np.array_equal(got, want)
+    rng = np.random.default_rng(1)
+    weight, msh = rng.integers(-3, 4, 160).astype(np.int32), rng.integers(0, 32, 160).astype(np.uint8)
+    got = buf.copy()
+    AlacPredictor(emu_ctx).predict_stereo(got, alac_desc(mode, order, shift, bps), coeffs, weight, msh)
+    for p in range(160):
+        if weight[p]:
+            want[2 * p], want[2 * p + 1] = oracle.alac_decorrelate_mid_side(want[2 * p], want[2 * p + 1], int(weight[p]), int(msh[p]))
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("blocksize,nb", [(64, 64), (100, 70), (31, 130)])
 def test_emu_alac_predict_stereo_fused(emu_ctx, blocksize, nb):
     """predict with decorrelate_mid_side fused into the write-back == predict, then decorrelate_mid_side."""
@@ -194,3 +251,45 @@ def test_gpu_alac_predict(blocksize):
         wgt, sh = p - 50, p % 32
         wa, wb = (buf[p], buf[100 + p]) if wgt == 0 else oracle.alac_decorrelate_mid_side(buf[p], buf[100 + p], wgt, sh)
         assert np.array_equal(ga[p], wa) and np.array_equal(gb[p], wb), p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bps", [16, 24])
+def test_gpu_alac_uniform_order_8(bps):
+    import torch
+    from symphonia_amd import AlacPredictor, Context, alac_desc
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    rng = np.random.default_rng(180 + bps)
+    nb, bs = 640, 4096
+    buf = rng.integers(-(1 << (bps - 3)), 1 << (bps - 3), (nb, bs)).astype(np.int32)
+    buf[::7] = rng.integers(-(1 << 31), 1 << 31, (len(buf[::7]), bs))
+    buf[:, 0] = rng.integers(-(1 << 15), 1 << 15, nb)
+    d = (rng.choice([0, 15], nb).astype(np.uint8), np.full(nb, 8, np.uint8), rng.integers(0, 12, nb).astype(np.uint8), np.full(nb, bps, np.uint8))
+    coeffs = rng.integers(-(1 << 15), 1 << 15, (nb, 32)).astype(np.int32)
+    want = oracle.alac_predict(buf, oracle.alac_desc(*d), coeffs)
+    with Context(0) as ctx:
+        ctx.use_torch_stream()
+        t = torch.from_numpy(buf.copy()).cuda()
+        AlacPredictor(ctx).predict(t, torch.from_numpy(alac_desc(*d).view(np.uint8).reshape(-1, 4)).cuda(), torch.from_numpy(coeffs).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(t.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocksize", [40, 4096])
+def test_gpu_alac_24_bit_multiply_bound(blocksize):
+    """On the bound and just outside it (narrow_case), long blocks included: the coefficient drift of 4096 updates."""
+    import torch
+    from symphonia_amd import AlacPredictor, Context, alac_desc
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    buf, mode, order, shift, bps, coeffs = narrow_case(1000 + blocksize, blocksize)
+    want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
+    with Context(0) as ctx:
+        ctx.use_torch_stream()
+        d = torch.from_numpy(buf.copy()).cuda()
+        desc = torch.from_numpy(alac_desc(mode, order, shift, bps).view(np.uint8).reshape(-1, 4)).cuda()
+        AlacPredictor(ctx).predict(d, desc, torch.from_numpy(coeffs).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), want)

@@ -94,6 +94,25 @@ def test_mp3_build_variants_fit_three_waves_per_simd(variant):
     assert not F32_FUSED.search(text)
 
 
+def test_alac_has_both_multiply_forms(asm):
+    """alac_predict_kernel<., true> multiplies with v_mul_i32_i24 (full rate), <., false> with v_mul_lo_u32; which one a
+    wavefront runs is decided by alac_narrow_kernel from a proven operand bound (tests/test_alac.py, narrow_case)."""
+    text = asm["alac.hip"]
+    bodies = {}
+    for chunk in re.split(r"^\s*\.globl\s+", text, flags=re.M)[1:]:
+        name = chunk.split(None, 1)[0]
+        if "alac_predict_kernel" in name:
+            bodies[name] = chunk
+    assert len(bodies) == 4
+    fast = 0
+    for name, body in bodies.items():
+        n24, nlo = len(re.findall(r"v_mul_i32_i24", body)), len(re.findall(r"v_mul_lo_u32", body))
+        # (the few v_mul_lo_u32 of the 24-bit form are address arithmetic and the mid/side weight of the fused store)
+        assert (n24 > 100 and nlo < 60) or (nlo > 100 and n24 == 0), (name, n24, nlo)
+        fast += n24 > 100
+    assert fast == 2
+
+
 def test_fp64_fma_only_in_the_flac_kernel(asm):
     for src, text in asm.items():
         if src == "flac.hip":

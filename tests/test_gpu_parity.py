@@ -475,6 +475,38 @@ def test_flac_config5_step_sampled(ctx):
     assert np.array_equal(host(buf[pick]), want)
 
 
+def test_flac_config5_full_size(ctx):
+    """BASELINE config 5 at its full size -- 1 048 576 order-32 subframe blocks of 4096 24-bit samples (16 GiB in place),
+    SURVEY 8d's generator (bench.flac_config5: quantised random AR(32) models, forward-predictor residuals, half the pairs
+    mid/side) -- restored, decorrelated and left-justified (<< 8) by the fused stereo entry point in one call.  Checked
+    two ways: the encoder identity (three whole 32 768-block generation chunks, first / middle / last, must come back as
+    the PCM the residuals were made from) and the oracle on 96 sampled pairs spread over the batch."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    from symphonia_amd import FlacPredictor
+    free, _ = torch.cuda.mem_get_info()
+    nb, bs, chunk = 1048576, 4096, 32768
+    if free < 40 << 30:
+        pytest.skip("needs 40 GiB of free HBM")
+    buf, desc, co, pair_mode, expect = bench.flac_config5(torch, nb, bs, 5, "cuda", chunk)
+    rng = np.random.default_rng(55)
+    pairs = np.unique(np.concatenate(([0, 1, nb // 2 - 1], rng.integers(0, nb // 2, 93))))
+    rows = np.stack([2 * pairs, 2 * pairs + 1], axis=1).ravel()
+    before, d_h, c_h, pm_h = host(buf[rows]), host(desc[rows]), host(co[rows]), host(pair_mode[pairs])
+    FlacPredictor(ctx).restore_stereo(buf, desc, co, pair_mode, 8)
+    torch.cuda.synchronize()
+    for b0 in (0, nb // 2, nb - chunk):
+        assert torch.equal(buf[b0:b0 + chunk].to(torch.int64), expect(b0, b0 + chunk)), b0
+    want = oracle.flac_restore(before, d_h, c_h)
+    got = host(buf[rows])
+    for i, p in enumerate(pairs):
+        left, right = oracle.flac_decorrelate(int(pm_h[i]), want[2 * i], want[2 * i + 1])  # decoder.rs:557-571
+        assert np.array_equal(got[2 * i], oracle.flac_shl(left, 8)) and np.array_equal(got[2 * i + 1], oracle.flac_shl(right, 8)), p
+    del buf
+
+
 @pytest.mark.parametrize("big_coeffs", [False, True])
 def test_flac_extreme_ranges(ctx, big_coeffs):
     """Full-range i32 samples with |c| < 2^16 (FP64-exact dot product path) and |c| up to 2^30 (i64 path)."""
