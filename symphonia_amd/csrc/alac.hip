@@ -13,6 +13,17 @@
 // streaming pass.  Bound: integer ALU (about 13 x order operations per sample), not HBM.
 #include "lane_tiles.h"
 
+// (the attribute's argument is an expression of a template parameter: hidden from the host-only emulation build, whose
+// compiler does not know the attribute and cannot parse that)
+#ifndef SYM_ALAC_SMALL_WAVES
+#define SYM_ALAC_SMALL_WAVES 3  // wavefronts per SIMD of the orders-<=-8 instantiations (build-time tuning knob)
+#endif
+#if defined(__HIPCC__)
+#define SYM_ALAC_OCCUPANCY(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#else
+#define SYM_ALAC_OCCUPANCY(n)
+#endif
+
 namespace symaccel {
 
 namespace {
@@ -31,9 +42,13 @@ __device__ __forceinline__ int32_t tap_mul(int32_t a, int32_t b) {
 // clip_msbs (lib.rs:659-661)
 __device__ __forceinline__ int32_t clip_msbs(int32_t v, uint32_t num) { return (int32_t)((uint32_t)v << num) >> num; }
 
+// NC = 32: any order; out[i - order - 1] is read back from the LDS tiles.  NC = 8: the instantiation for wavefronts whose
+// orders are all <= 8 -- a ninth history register holds out[i - order - 1], there is no LDS read-back, no second tile,
+// and the kernel fits four wavefronts per SIMD instead of two.
+template <int NC>
 struct AlacLane {
-    int32_t c[32];      // lpc_coeffs (lib.rs:79), adapted in place; entries >= order stay 0
-    int32_t h[32];      // shift register of the latest outputs: h[k] = out[i - 1 - k] (only the first TAPS are kept)
+    int32_t c[NC];      // lpc_coeffs (lib.rs:79), adapted in place; entries >= order stay 0
+    int32_t h[NC == 32 ? 32 : NC + 1];  // shift register of the latest outputs: h[k] = out[i - 1 - k]
     int32_t p1_prev;    // previous output of the first (order-1) pass of the double predictor (lib.rs:185-189)
     unsigned order, shift, clip;
     bool enabled, twice;
@@ -41,8 +56,8 @@ struct AlacLane {
 
 // One sample.  `past_far` = out[i - order - 1] as read back from LDS (valid for order >= 3).
 // FULL: every lane's order equals TAPS (wave-uniform), so no tap needs neutralising.
-template <int TAPS, bool M24, bool FULL>
-__device__ __forceinline__ int32_t alac_step(AlacLane &L, int32_t x, unsigned i, int32_t past_far) {
+template <int TAPS, bool M24, bool FULL, int NC>
+__device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigned i, int32_t past_far) {
     if (L.enabled) {
         // first pass of the double predictor: out[i] = clip(out[i] + out[i-1]) over the whole block
         if (L.twice && i >= 1) x = clip_msbs(wrap_add(x, L.p1_prev), L.clip);
@@ -51,7 +66,16 @@ __device__ __forceinline__ int32_t alac_step(AlacLane &L, int32_t x, unsigned i,
             x = clip_msbs(wrap_add(x, L.h[0]), L.clip);  // warm-up samples (lib.rs:196-198)
         } else if (i > L.order) {
             int32_t res = x;
-            const int32_t past0 = L.order == 1 ? L.h[1] : (L.order == 2 ? L.h[2] : past_far);
+            int32_t past0;
+            if constexpr (NC == 32) {
+                past0 = L.order == 1 ? L.h[1] : (L.order == 2 ? L.h[2] : past_far);
+            } else if constexpr (FULL) {
+                past0 = L.h[TAPS];
+            } else {
+                past0 = L.h[1];
+#pragma unroll
+                for (int k = 2; k <= TAPS; ++k) past0 = L.order == (unsigned)k ? L.h[k] : past0;
+            }
             int32_t sum = 0;
 #pragma unroll
             for (int k = 0; k < TAPS; ++k) sum = wrap_add(sum, tap_mul<M24>(L.c[k], wrap_sub(L.h[k], past0)));
@@ -88,7 +112,7 @@ __device__ __forceinline__ int32_t alac_step(AlacLane &L, int32_t x, unsigned i,
         }
     }
 #pragma unroll
-    for (int k = TAPS - 1; k >= 1; --k) L.h[k] = L.h[k - 1];
+    for (int k = (NC == 32 ? TAPS - 1 : TAPS); k >= 1; --k) L.h[k] = L.h[k - 1];
     L.h[0] = x;
     return x;
 }
@@ -96,8 +120,8 @@ __device__ __forceinline__ int32_t alac_step(AlacLane &L, int32_t x, unsigned i,
 // 32 samples of one tile.  `row` = this tile's LDS row of the lane, `prev_row` = the previous tile's (still intact in
 // the other LDS buffer); t0 = absolute index of column 0.  Rows are written back four samples at a time, so anything
 // older than three samples can be read back from LDS: that is where out[i - order - 1] comes from for order >= 3.
-template <int TAPS, bool M24, bool FULL>
-__device__ __forceinline__ void alac_steps32(AlacLane &L, int32_t *row, const int32_t *prev_row, unsigned t0, int n_valid) {
+template <int TAPS, bool M24, bool FULL, int NC>
+__device__ __forceinline__ void alac_steps32(AlacLane<NC> &L, int32_t *row, const int32_t *prev_row, unsigned t0, int n_valid) {
 #pragma unroll 1
     for (int u0 = 0; u0 < 32; u0 += 4) {
         const int4 v = *reinterpret_cast<const int4 *>(row + u0);
@@ -106,9 +130,12 @@ __device__ __forceinline__ void alac_steps32(AlacLane &L, int32_t *row, const in
         for (int q = 0; q < 4; ++q) {
             const int u = u0 + q;
             if (u < n_valid) {
-                const int idx = u - (int)L.order - 1;
-                const int32_t far = idx >= 0 ? row[idx >= 0 ? idx : 0] : prev_row[32 + (idx < -32 ? -32 : idx)];
-                xs[q] = alac_step<TAPS, M24, FULL>(L, xs[q], t0 + (unsigned)u, far);
+                int32_t far = 0;
+                if constexpr (NC == 32) {
+                    const int idx = u - (int)L.order - 1;
+                    far = idx >= 0 ? row[idx >= 0 ? idx : 0] : prev_row[32 + (idx < -32 ? -32 : idx)];
+                }
+                xs[q] = alac_step<TAPS, M24, FULL, NC>(L, xs[q], t0 + (unsigned)u, far);
             }
         }
         *reinterpret_cast<int4 *>(row + u0) = make_int4(xs[0], xs[1], xs[2], xs[3]);
@@ -167,12 +194,13 @@ __global__ __launch_bounds__(64) void alac_narrow_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ coeffs, size_t n_blocks, unsigned blocksize,
                                                          uint8_t *__restrict__ narrow_flag) {
     const size_t my = (size_t)blockIdx.x * kRows + threadIdx.x;
-    bool narrow = true;
+    bool narrow = true, small = true;  // small: order <= 8 (the register-only instantiation, AlacLane<8>)
     if (my < n_blocks) {
         const symaccel_alac_desc d = desc[my];
         const unsigned order = d.lpc_order > 31u ? 31u : d.lpc_order;
         const bool enabled = (d.mode == 0 || d.mode >= 15) && order != 0;
         if (enabled) {
+            small = order <= 8u;
             const unsigned bps = d.bps < 1u ? 1u : (d.bps > 32u ? 32u : d.bps);
             const int32_t first = buf[my * (size_t)blocksize];
             narrow = bps <= 23u && blocksize <= (1u << 21) && first >= -(1 << 22) && first < (1 << 22);
@@ -187,21 +215,26 @@ __global__ __launch_bounds__(64) void alac_narrow_kernel(const int32_t *__restri
             }
         }
     }
-    const bool all = __all(narrow) != 0;
-    if (threadIdx.x == 0) narrow_flag[blockIdx.x] = all ? 1 : 0;
+    const bool all = __all(narrow) != 0, all_small = __all(small) != 0;
+    if (threadIdx.x == 0) narrow_flag[blockIdx.x] = (uint8_t)((all ? 1 : 0) | (all_small ? 2 : 0));
 }
 
-// M24: the instantiation for wavefronts whose blocks are all "narrow" (see there); the other instantiation takes the
-// rest.  Both are launched over the whole grid and a wavefront returns at once from the one that is not its own (the two
-// loops in one kernel cost the register allocator its second wavefront per SIMD; and the choice cannot be re-derived by
-// the second launch, the buffer being predicted in place by the first).
-template <bool MIX, bool M24>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void alac_predict_kernel(
+// M24: the instantiation for wavefronts whose blocks are all "narrow" (see there); SMALL: for wavefronts whose orders are
+// all <= 8 (AlacLane<8>: half the LDS, under 128 VGPRs -- four wavefronts per SIMD instead of two).  All four
+// instantiations are launched over the whole grid and a wavefront returns at once from those that are not its own (the
+// loops in one kernel cost the register allocator its occupancy; and the choice cannot be re-derived by a later launch,
+// the buffer being predicted in place by an earlier one).
+template <bool MIX, bool M24, bool SMALL>
+__global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES : 2) void alac_predict_kernel(
     int32_t *__restrict__ buf, const symaccel_alac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
     size_t n_blocks, unsigned blocksize, const int32_t *__restrict__ pair_weight, const uint8_t *__restrict__ pair_shift,
     const uint8_t *__restrict__ narrow_flag) {
-    if ((narrow_flag[blockIdx.x] != 0) != M24) return;  // the other instantiation's wavefront (alac_narrow_kernel)
-    __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
+    {
+        const unsigned f = narrow_flag[blockIdx.x];  // alac_narrow_kernel
+        if (((f & 1u) != 0) != M24 || ((f & 2u) != 0) != SMALL) return;  // another instantiation's wavefront
+    }
+    constexpr int NC = SMALL ? 8 : 32;
+    __shared__ __attribute__((aligned(16))) int32_t tiles[(SMALL ? 1 : 2) * kTileWords];
     __shared__ int32_t row_weight[kRows];
     __shared__ uint8_t row_shift[kRows];
     const int lane = (int)threadIdx.x;
@@ -213,9 +246,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         row_shift[lane] = have ? (uint8_t)(pair_shift[my >> 1] & 31u) : 0;
     }
 
-    AlacLane L;
+    AlacLane<NC> L;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) L.c[j] = L.h[j] = 0;
+    for (int j = 0; j < NC; ++j) L.c[j] = 0;
+#pragma unroll
+    for (int j = 0; j < (NC == 32 ? 32 : NC + 1); ++j) L.h[j] = 0;
     L.p1_prev = 0;
     L.order = L.shift = L.clip = 0;
     L.enabled = L.twice = false;
@@ -229,7 +264,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         L.twice = L.order == 31 || d.mode == 15;               // lib.rs:185
         const int4 *cp = reinterpret_cast<const int4 *>(coeffs + my * 32);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NC / 4; ++j) {
             const int4 v = cp[j];
             L.c[4 * j] = (unsigned)(4 * j) < L.order ? v.x : 0;
             L.c[4 * j + 1] = (unsigned)(4 * j + 1) < L.order ? v.y : 0;
@@ -250,8 +285,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const unsigned t0 = t * kCols;
         const unsigned cols = min((unsigned)kCols, blocksize - t0);
         const bool fast = aligned && cols == (unsigned)kCols;
-        int32_t *tile = tiles + (t & 1u) * kTileWords;
-        const int32_t *prev_tile = tiles + ((t & 1u) ^ 1u) * kTileWords;
+        int32_t *tile = tiles + (SMALL ? 0u : (t & 1u) * kTileWords);
+        const int32_t *prev_tile = tiles + (SMALL ? 0u : ((t & 1u) ^ 1u) * kTileWords);
+        if constexpr (SMALL) wave_sync();  // one tile: the previous round's write-back has read it
         if (fast)
             tile_commit(pre, tile, lane);
         else
@@ -261,16 +297,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if (have) {
             int32_t *row = tile + lane * kStride;
             const int32_t *prow = prev_tile + lane * kStride;
-            if (full8)  // the common stream: every block of the wavefront has order 8
-                alac_steps32<8, M24, true>(L, row, prow, t0, (int)cols);
-            else if (max_order <= 4)
-                alac_steps32<4, M24, false>(L, row, prow, t0, (int)cols);
-            else if (max_order <= 8)
-                alac_steps32<8, M24, false>(L, row, prow, t0, (int)cols);
-            else if (max_order <= 16)
-                alac_steps32<16, M24, false>(L, row, prow, t0, (int)cols);
-            else
-                alac_steps32<32, M24, false>(L, row, prow, t0, (int)cols);
+            if constexpr (SMALL) {
+                if (full8)  // the common stream: every block of the wavefront has order 8
+                    alac_steps32<8, M24, true>(L, row, prow, t0, (int)cols);
+                else if (max_order <= 4)
+                    alac_steps32<4, M24, false>(L, row, prow, t0, (int)cols);
+                else
+                    alac_steps32<8, M24, false>(L, row, prow, t0, (int)cols);
+            } else {
+                if (max_order <= 16)
+                    alac_steps32<16, M24, false>(L, row, prow, t0, (int)cols);
+                else
+                    alac_steps32<32, M24, false>(L, row, prow, t0, (int)cols);
+            }
         }
         wave_sync();
         if constexpr (MIX) {
@@ -309,18 +348,22 @@ int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_d
     SYM_TRY(ctx_scratch(ctx, grid, &flags));
     hipLaunchKernelGGL(alac_narrow_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
                        (unsigned)blocksize, (uint8_t *)flags);
-    // two launches over the same grid: the 24-bit-multiply wavefronts, then the rest (each wavefront runs in exactly one)
+    // four launches over the same grid, one per (24-bit multiplies, orders <= 8) class: each wavefront runs in exactly one
+#define SYM_ALAC_LAUNCH(MIX, M24, SMALL)                                                                                     \
+    hipLaunchKernelGGL((alac_predict_kernel<MIX, M24, SMALL>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, \
+                       d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags)
     if (d_pair_weight) {
-        hipLaunchKernelGGL((alac_predict_kernel<true, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
-                           d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags);
-        hipLaunchKernelGGL((alac_predict_kernel<true, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
-                           d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags);
+        SYM_ALAC_LAUNCH(true, true, true);
+        SYM_ALAC_LAUNCH(true, true, false);
+        SYM_ALAC_LAUNCH(true, false, true);
+        SYM_ALAC_LAUNCH(true, false, false);
     } else {
-        hipLaunchKernelGGL((alac_predict_kernel<false, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
-                           d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags);
-        hipLaunchKernelGGL((alac_predict_kernel<false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc,
-                           d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags);
+        SYM_ALAC_LAUNCH(false, true, true);
+        SYM_ALAC_LAUNCH(false, true, false);
+        SYM_ALAC_LAUNCH(false, false, true);
+        SYM_ALAC_LAUNCH(false, false, false);
     }
+#undef SYM_ALAC_LAUNCH
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -95,22 +95,26 @@ def test_mp3_build_variants_fit_three_waves_per_simd(variant):
 
 
 def test_alac_has_both_multiply_forms(asm):
-    """alac_predict_kernel<., true> multiplies with v_mul_i32_i24 (full rate), <., false> with v_mul_lo_u32; which one a
-    wavefront runs is decided by alac_narrow_kernel from a proven operand bound (tests/test_alac.py, narrow_case)."""
+    """alac_predict_kernel<., true, .> multiplies with v_mul_i32_i24 / v_mad_i32_i24 (full rate), <., false, .> with
+    v_mul_lo_u32; which one a wavefront runs is decided by alac_narrow_kernel from a proven operand bound
+    (tests/test_alac.py, narrow_case).  The orders-<=-8 instantiations fit three wavefronts per SIMD."""
     text = asm["alac.hip"]
     bodies = {}
     for chunk in re.split(r"^\s*\.globl\s+", text, flags=re.M)[1:]:
         name = chunk.split(None, 1)[0]
         if "alac_predict_kernel" in name:
             bodies[name] = chunk
-    assert len(bodies) == 4
+    assert len(bodies) == 8
     fast = 0
     for name, body in bodies.items():
-        n24, nlo = len(re.findall(r"v_mul_i32_i24", body)), len(re.findall(r"v_mul_lo_u32", body))
+        n24, nlo = len(re.findall(r"v_m(?:ul|ad)_i32_i24", body)), len(re.findall(r"v_mul_lo_u32", body))
         # (the few v_mul_lo_u32 of the 24-bit form are address arithmetic and the mid/side weight of the fused store)
         assert (n24 > 100 and nlo < 60) or (nlo > 100 and n24 == 0), (name, n24, nlo)
         fast += n24 > 100
-    assert fast == 2
+    assert fast == 4
+    res = kernel_resources(text)
+    small = [r for n, r in res.items() if "alac_predict_kernel" in n and n.split("alac_predict_kernel")[1].startswith("ILb") and "ELb1EEE" in n]
+    assert len(small) == 4 and all(r["Occupancy"] >= 3 and r["LDSByteSize"] < 10240 for r in small), small
 
 
 def test_fp64_fma_only_in_the_flac_kernel(asm):
