@@ -98,6 +98,12 @@ int symaccel_host_unregister(void *p);
  * SYMACCEL_ERR_UNSUPPORTED. */
 int symaccel_fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count);
 int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count);
+/* Ifft::ifft / Ifft::ifft_inplace (no_simd.rs:143-219): the forward transform() between a re <-> im swap of the permuted
+ * input and a swap of the output scaled by 1.0 / n.  Same sizes and layout as the forward entry points.  As in the
+ * reference, an inverse transform of fewer than 32 points only permutes, swaps and scales: transform() has no case for
+ * them (Fft::fft dispatches fft2 .. fft16 before calling it, Ifft does not). */
+int symaccel_ifft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count);
+int symaccel_ifft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count);
 
 /* Imdct::new_scaled(n, scale).imdct(spec, out) (symphonia-core/src/dsp/mdct.rs:35-146), `count`
  * times: spec[count][n] -> out[count][2n].  n = power of two, 4 <= n <= 8192 (8192 < n <= 131072:

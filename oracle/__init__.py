@@ -99,6 +99,14 @@ def fft(x):
     return y
 
 
+def ifft(x):
+    """Ifft::ifft on a complex64 vector (power-of-two length; below 32 points the reference only permutes and scales)."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    y = np.empty_like(x)
+    lib().so_ifft(_p(x), _p(y), C.c_int(x.size))
+    return y
+
+
 def fft_inplace(x):
     y = np.array(x, dtype=np.complex64, copy=True)
     lib().so_fft_inplace(_p(y), C.c_int(y.size))

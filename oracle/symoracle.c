@@ -187,6 +187,31 @@ void so_fft(const float *xf, float *yf, int n)
     fft_transform(y, n);
 }
 
+/* Ifft::ifft / ifft_inplace (no_simd.rs:143-219): y[i] = swap(x[perm[i]]); transform(y, n); y[i] = (c * y[i].im,
+ * c * y[i].re) with c = 1.0 / n as f32.  NOTE transform() itself (no_simd.rs:221-281) handles exactly 32 points and
+ * >= 64 points; called with fewer than 32 -- which only Ifft does, Fft::fft dispatching fft2..fft16 before it -- its
+ * chunks_exact_mut(64) loop has nothing to iterate over: an Ifft of 2..16 points permutes, swaps and scales, nothing more.
+ * The in-place form swaps while permuting (i <= j) and gives the same values. */
+void so_ifft(const float *xf, float *yf, int n)
+{
+    const cpx *x = (const cpx *)xf;
+    cpx *y = (cpx *)yf;
+    for (int i = 0; i < n; i++) {
+        cpx v = x[bitrev((unsigned)i, n)];
+        y[i].re = v.im;
+        y[i].im = v.re;
+    }
+    if (n >= 32)
+        fft_transform(y, n);
+    const float c = 1.0f / (float)n;
+    for (int i = 0; i < n; i++) {
+        cpx v = y[i];
+        y[i].re = c * v.im;
+        y[i].im = c * v.re;
+    }
+}
+
+
 /* ======================================================================== */
 /* IMDCT: symphonia-core/src/dsp/mdct.rs                                     */
 /* ======================================================================== */

@@ -43,6 +43,7 @@ extern "C" {
 void so_fft_inplace(float *x, int n);
 /* Fft::fft (fft/no_simd.rs:121-140). */
 void so_fft(const float *x, float *y, int n);
+void so_ifft(const float *x, float *y, int n);
 
 typedef struct so_imdct so_imdct;
 /* Imdct::new_scaled (mdct.rs:35-60). */

@@ -28,7 +28,7 @@ TABLE_MP3_POW43, TABLE_MP3_POW2AB = 8, 9
 ABI_SYMBOLS = [
     "symaccel_abi_version", "symaccel_strerror", "symaccel_last_error", "symaccel_ctx_create",
     "symaccel_ctx_destroy", "symaccel_ctx_set_stream", "symaccel_sync", "symaccel_ctx_set_segment",
-    "symaccel_fft_c32_device", "symaccel_fft_c32", "symaccel_imdct_f32_device", "symaccel_imdct_f32",
+    "symaccel_fft_c32_device", "symaccel_fft_c32", "symaccel_ifft_c32_device", "symaccel_ifft_c32", "symaccel_imdct_f32_device", "symaccel_imdct_f32",
     "symaccel_aac_synth_device", "symaccel_aac_synth", "symaccel_aac_joint_stereo_device", "symaccel_aac_tns_device", "symaccel_mp3_synth_device", "symaccel_mp3_synth", "symaccel_mpa_polyphase_device", "symaccel_mpa_polyphase",
     "symaccel_mp3_requantize_device", "symaccel_mp3_requantize", "symaccel_mp3_stereo_device", "symaccel_mp3_requantize_stereo_device",
     "symaccel_vorbis_synth_device", "symaccel_vorbis_synth_fr_device", "symaccel_vorbis_synth", "symaccel_vorbis_inverse_coupling_device",
@@ -75,6 +75,8 @@ class Library:
         d.symaccel_ctx_set_segment.argtypes = [_vp, _i]
         d.symaccel_fft_c32_device.argtypes = [_vp, _i, _vp, _vp, _sz]
         d.symaccel_fft_c32.argtypes = [_vp, _i, _vp, _vp, _sz]
+        d.symaccel_ifft_c32_device.argtypes = [_vp, _i, _vp, _vp, _sz]
+        d.symaccel_ifft_c32.argtypes = [_vp, _i, _vp, _vp, _sz]
         d.symaccel_flac_decorrelate.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz, _u32]
         d.symaccel_imdct_f32_device.argtypes = [_vp, _i, _d, _vp, _vp, _sz]
         d.symaccel_imdct_f32.argtypes = [_vp, _i, _d, _vp, _vp, _sz]

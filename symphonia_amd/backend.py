@@ -114,6 +114,8 @@ class Imdct:
 class Fft:
     """Fft::new(n) (no_simd.rs:75-88); device tensors only (complex64, interleaved)."""
 
+    _entry = "symaccel_fft_c32_device"
+
     def __init__(self, ctx, n):
         if n < 2 or n & (n - 1) or n > 4096:
             raise ValueError("n must be a power of two <= 4096")
@@ -131,10 +133,22 @@ class Fft:
             values = total // 2
         assert (y.numel() if _is_torch(y) else y.size) == total and y.dtype == x.dtype
         assert values % self.n == 0  # no_simd.rs:97, 122-123: slice lengths must equal the transform size
-        self.ctx._call(self.ctx.lib.dll.symaccel_fft_c32_device, self.n, _ptr(x), _ptr(y), values // self.n)
+        self.ctx._call(getattr(self.ctx.lib.dll, self._entry), self.n, _ptr(x), _ptr(y), values // self.n)
         return y
 
     def fft_inplace(self, x):
+        return self.fft(x, x)
+
+
+class Ifft(Fft):
+    """Ifft::new(n) (no_simd.rs:143-158): ifft / ifft_inplace, same buffers as Fft."""
+
+    _entry = "symaccel_ifft_c32_device"
+
+    def ifft(self, x, y):
+        return self.fft(x, y)
+
+    def ifft_inplace(self, x):
         return self.fft(x, x)
 
 

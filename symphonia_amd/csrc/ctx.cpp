@@ -323,14 +323,20 @@ int symaccel_ctx_set_segment(symaccel_ctx *ctx, int frames_per_segment) {
 
 // ---- core ---------------------------------------------------------------------------------
 
-int symaccel_fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count) {
-    if (!ctx || !pow2(n) || n < 2 || n > 65536) return SYMACCEL_ERR_INVALID_ARG;  // no_simd.rs:77-80
+static int fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count, bool inverse) {
+    if (!ctx || !pow2(n) || n < 2 || n > 65536) return SYMACCEL_ERR_INVALID_ARG;  // no_simd.rs:77-80, 152-156
     if (n > kMaxFft) return SYMACCEL_ERR_UNSUPPORTED;
     if (count == 0) return SYMACCEL_OK;
     if (!d_in || !d_out) return SYMACCEL_ERR_INVALID_ARG;
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
-    return launch_fft(ctx, n, d_in, d_out, count);
+    return launch_fft(ctx, n, d_in, d_out, count, inverse);
+}
+int symaccel_fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count) {
+    return fft_c32_device(ctx, n, d_in, d_out, count, false);
+}
+int symaccel_ifft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count) {
+    return fft_c32_device(ctx, n, d_in, d_out, count, true);
 }
 
 int symaccel_imdct_f32_device(symaccel_ctx *ctx, int n, double scale, const float *d_spec, float *d_out,
@@ -346,7 +352,7 @@ int symaccel_imdct_f32_device(symaccel_ctx *ctx, int n, double scale, const floa
     return launch_imdct(ctx, *plan, d_spec, d_out, count);
 }
 
-int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count) {
+static int fft_c32_host(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count, bool inverse) {
     if (!ctx || !pow2(n) || n < 2 || n > 65536) return SYMACCEL_ERR_INVALID_ARG;
     if (n > kMaxFft) return SYMACCEL_ERR_UNSUPPORTED;
     if (count == 0) return SYMACCEL_OK;
@@ -356,9 +362,15 @@ int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, 
     DevBuf buf(ctx);
     const size_t bytes = count * (size_t)n * 8;
     SYM_TRY(buf.from_host(h_in, bytes));
-    SYM_TRY(launch_fft(ctx, n, (const float *)buf.p, (float *)buf.p, count));
+    SYM_TRY(launch_fft(ctx, n, (const float *)buf.p, (float *)buf.p, count, inverse));
     SYM_TRY(buf.to_host(h_out, bytes));
     return symaccel_sync(ctx);
+}
+int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count) {
+    return fft_c32_host(ctx, n, h_in, h_out, count, false);
+}
+int symaccel_ifft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count) {
+    return fft_c32_host(ctx, n, h_in, h_out, count, true);
 }
 
 int symaccel_imdct_f32(symaccel_ctx *ctx, int n, double scale, const float *h_spec, float *h_out, size_t count) {

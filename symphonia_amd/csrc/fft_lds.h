@@ -58,8 +58,11 @@ __device__ __forceinline__ void fft_chunk_phase(c32 *lds, int points, const DevT
 }
 
 // In-place FFTs of every transform in the workgroup's LDS tile.  Ends with a barrier.
-__device__ __forceinline__ void wg_fft_lds(c32 *lds, int nf, int points, const DevTables &tb) {
+// `small_cases`: Fft::fft dispatches fft2 .. fft16 itself before transform(); Ifft calls transform() directly, which has no
+// case below 32 points (no_simd.rs:221-281: its 64-point chunk loop is empty) -- such an Ifft runs no butterflies at all.
+__device__ __forceinline__ void wg_fft_lds(c32 *lds, int nf, int points, const DevTables &tb, bool small_cases = true) {
     __syncthreads();
+    if (nf < 32 && !small_cases) return;
     switch (nf) {
         case 2: fft_chunk_phase<2>(lds, points, tb); break;
         case 4: fft_chunk_phase<4>(lds, points, tb); break;

@@ -16,8 +16,10 @@ constexpr int kMaxPoints = 4096;
 
 __device__ __forceinline__ int tile_points(int nf) { return nf >= 2048 ? nf : 2048; }
 
+// inverse: Ifft::ifft (no_simd.rs:143-219) = the same forward transform between a re <-> im swap on the way in and a swap
+// with the 1/n scale on the way out.
 __global__ __launch_bounds__(kThreads) void fft_kernel(DevTables tb, int nf, int log2nf, const float2 *in,
-                                                       float2 *out, size_t count) {
+                                                       float2 *out, size_t count, int inverse) {
     __shared__ c32 lds[fft_padded(kMaxPoints)];
     const int points = tile_points(nf);
     const int per_wg = points / nf;
@@ -28,16 +30,17 @@ __global__ __launch_bounds__(kThreads) void fft_kernel(DevTables tb, int nf, int
         c32 v{0.0f, 0.0f};
         if (first + (size_t)t < count) {
             const float2 x = in[(first + (size_t)t) * (size_t)nf + (size_t)i];
-            v = c32{x.x, x.y};
+            v = inverse ? c32{x.y, x.x} : c32{x.x, x.y};
         }
         lds[fft_pad((t << log2nf) + (int)rev_bits((unsigned)i, log2nf))] = v;
     }
-    wg_fft_lds(lds, nf, points, tb);
+    wg_fft_lds(lds, nf, points, tb, !inverse);
+    const float c = 1.0f / (float)nf;  // no_simd.rs:181, 212
     for (int idx = (int)threadIdx.x; idx < points; idx += kThreads) {
         const int t = idx >> log2nf;
         if (first + (size_t)t < count) {
             const c32 v = lds[fft_pad(idx)];
-            out[(first + (size_t)t) * (size_t)nf + (size_t)(idx & (nf - 1))] = make_float2(v.x, v.y);
+            out[(first + (size_t)t) * (size_t)nf + (size_t)(idx & (nf - 1))] = inverse ? make_float2(c * v.y, c * v.x) : make_float2(v.x, v.y);
         }
     }
 }
@@ -185,13 +188,13 @@ int ilog2(int v) {
 
 }  // namespace
 
-int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count) {
+int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count, bool inverse) {
     const int points = n >= 2048 ? n : 2048;
     const size_t per_wg = (size_t)(points / n);
     const size_t grid = (count + per_wg - 1) / per_wg;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(fft_kernel, dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, ctx->dev, n, ilog2(n),
-                       (const float2 *)d_in, (float2 *)d_out, count);
+                       (const float2 *)d_in, (float2 *)d_out, count, inverse ? 1 : 0);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -174,7 +174,7 @@ struct AacBandMaps {
 };
 
 // kernel launchers (one per .hip file)
-int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count);
+int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count, bool inverse = false);
 int launch_imdct(symaccel_ctx *ctx, const ImdctPlan &plan, const float *d_spec, float *d_out, size_t count);
 int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const float *d_delay_in,
                float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain);

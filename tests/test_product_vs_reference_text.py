@@ -70,6 +70,14 @@ def check_fft(r):
         assert same(r.host(y)[0], f["out_%d" % n]), n
         Fft(r.ctx, n).fft_inplace(x)
         assert same(r.host(x)[0], f["out_%d" % n]), n
+    from symphonia_amd import Ifft
+    for n in (2, 8, 16, 32, 64, 256, 1024, 4096):  # (below 32 points the reference's Ifft only permutes, swaps and scales)
+        x = r.dev(np.stack([f["iin_%d" % n]] * 3))
+        y = r.dev(np.zeros((3, n, 2), np.float32))
+        Ifft(r.ctx, n).ifft(x, y)
+        assert all(same(row, f["iout_%d" % n]) for row in r.host(y)), n
+        Ifft(r.ctx, n).ifft_inplace(x)
+        assert all(same(row, f["iout_%d" % n]) for row in r.host(x)), n
 
 
 def check_imdct(r, manifest_cases):

@@ -54,6 +54,10 @@ def test_oracle_fft():
         want = f["out_%d" % n]
         got = oracle.fft((x[:, 0] + 1j * x[:, 1]).astype(np.complex64))
         assert same(np.stack([got.real, got.imag], 1), want), n
+    for n in (2, 8, 16, 32, 64, 256, 1024, 4096):
+        x = f["iin_%d" % n]
+        got = oracle.ifft((x[:, 0] + 1j * x[:, 1]).astype(np.complex64))
+        assert same(np.stack([got.real, got.imag], 1), f["iout_%d" % n]), n
     for n in (64, 128, 256, 512, 1024, 2048):
         w = oracle.fft_twiddles(n)
         assert same(np.stack([w.real, w.imag], 1), f["twiddle_%d" % n]), n
