@@ -16,11 +16,18 @@
 
 mod aac;
 mod ctx;
+pub mod decoder;
 mod ffi;
+mod flac;
 pub mod frontends;
 mod lookahead;
+mod mpa;
+mod vorbis;
 
 pub use aac::{AacFrontEnd, HipAacDecoder, ParsedAac};
+pub use flac::{FlacFrontEnd, HipFlacDecoder, ParsedFlac};
+pub use mpa::{HipMpaDecoder, MpaFrontEnd, ParsedMpa};
+pub use vorbis::{HipVorbisDecoder, ParsedVorbis, VorbisFrontEnd};
 pub use ctx::{Context, Pinned};
 pub use lookahead::{track_queue, BatchCodec, Lookahead, LookaheadReader, TrackQueue};
 
@@ -31,8 +38,9 @@ pub const DEFAULT_LOOKAHEAD: usize = 256;
 
 /// Register the accelerated decoders at `Tier::Preferred` (symphonia-core/src/codecs/registry.rs:252-269): the registry
 /// looks preferred -> standard -> fallback (`:152-154`), so the CPU decoders stay available underneath.
-/// HipMpaDecoder / HipVorbisDecoder / HipFlacDecoder follow the pattern of `aac.rs` over symaccel_mp3_synth,
-/// symaccel_vorbis_synth (+ floor / coupling helpers) and symaccel_flac_restore (+ per-block status); see INTEGRATION.md.
 pub fn register(registry: &mut CodecRegistry) {
     registry.register_audio_decoder_at_tier::<HipAacDecoder>(Tier::Preferred);
+    registry.register_audio_decoder_at_tier::<HipMpaDecoder>(Tier::Preferred);
+    registry.register_audio_decoder_at_tier::<HipVorbisDecoder>(Tier::Preferred);
+    registry.register_audio_decoder_at_tier::<HipFlacDecoder>(Tier::Preferred);
 }
