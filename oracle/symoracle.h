@@ -13,19 +13,21 @@
  * tree, workspace version 0.6.1).
  *
  * Pinning status: the reference (Rust) cannot be compiled in this image, so no
- * oracle/_ref exists.  The oracle is pinned by the reference's own in-source
- * known-answer tests (tests/golden/ref_kats.json, extracted by
- * tests/golden/make_golden.py) at the reference's own tolerance (1e-5 abs):
- *   Imdct N=32 (mdct.rs:177-201), Fft 64-pt (dsp/fft/mod.rs:88-186),
- *   imdct36 / imdct12_win (hybrid_synthesis.rs:510-556, 802-822),
- *   dct32 (synthesis.rs:866-882), rice sign map (flac/decoder.rs:646-661).
- * AAC Dsp::synth + windows, MP3 antialias/reorder/polyphase windowing, Vorbis
- * synth/overlap/coupling/floor render, the FLAC and ALAC predictors, and the
- * stages in front of the path (MP3 requantize + stereo, AAC joint stereo + TNS)
- * have NO test in the reference: for those the oracle is "parity unpinned by
- * the reference" and is pinned instead by f64 closed forms, invertibility
- * properties, independent restatements and the reference's band tables in
- * tests/ (see DESIGN.md section "Oracle").
+ * oracle/_ref exists.  Instead the reference's own source TEXT is executed:
+ * tools/rsinterp (an interpreter for the subset of Rust the DSP code is written
+ * in) runs the functions of every hot-path row from /root/reference on seeded
+ * inputs, and tools/rs2fixtures.py commits inputs and outputs as bit patterns
+ * under tests/golden/rs_fixtures/ (manifest.json lists the reference file:line
+ * of every entry).  tests/test_rs_fixtures.py holds every function below to
+ * those fixtures BIT FOR BIT: Fft / Ifft / Imdct, AAC Dsp::synth and windows,
+ * MP3 imdct36 / imdct12_win / antialias / reorder / dct32 / synthesis /
+ * requantize / stereo, Vorbis synth / overlap_add / coupling / floor-0 /
+ * floor-1, FLAC and ALAC predictors and decorrelation, AAC joint stereo / TNS /
+ * pulse.  The reference's in-source known-answer tests (tests/golden/
+ * ref_kats.json, at the reference's own 1e-5 tolerance), f64 closed forms and
+ * encoder identities remain as an independent second pin.
+ * Not pinned: the reference's `opt-simd` build, which delegates to rustfft
+ * (un-vendored): against that build only the 1e-5 criterion is meaningful.
  */
 #ifndef SYMORACLE_H
 #define SYMORACLE_H
