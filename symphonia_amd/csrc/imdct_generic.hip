@@ -19,7 +19,7 @@ __device__ __forceinline__ int tile_points(int nf) { return nf >= 2048 ? nf : 20
 // inverse: Ifft::ifft (no_simd.rs:143-219) = the same forward transform between a re <-> im swap on the way in and a swap
 // with the 1/n scale on the way out.
 __global__ __launch_bounds__(kThreads) void fft_kernel(DevTables tb, int nf, int log2nf, const float2 *in,
-                                                       float2 *out, size_t count, int inverse) {
+                                                       float2 *out, size_t count, int inverse, float c) {
     __shared__ c32 lds[fft_padded(kMaxPoints)];
     const int points = tile_points(nf);
     const int per_wg = points / nf;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kThreads) void fft_kernel(DevTables tb, int nf, int
         lds[fft_pad((t << log2nf) + (int)rev_bits((unsigned)i, log2nf))] = v;
     }
     wg_fft_lds(lds, nf, points, tb, !inverse);
-    const float c = 1.0f / (float)nf;  // no_simd.rs:181, 212
+    // c = 1.0 / n as f32 (no_simd.rs:181, 212), formed on the host: a device division expands into fused operations
     for (int idx = (int)threadIdx.x; idx < points; idx += kThreads) {
         const int t = idx >> log2nf;
         if (first + (size_t)t < count) {
@@ -194,7 +194,7 @@ int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t
     const size_t grid = (count + per_wg - 1) / per_wg;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     hipLaunchKernelGGL(fft_kernel, dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, ctx->dev, n, ilog2(n),
-                       (const float2 *)d_in, (float2 *)d_out, count, inverse ? 1 : 0);
+                       (const float2 *)d_in, (float2 *)d_out, count, inverse ? 1 : 0, 1.0f / (float)n);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }
