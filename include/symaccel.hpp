@@ -501,10 +501,12 @@ private:
         head_ = 0;
     }
     void publish(std::size_t i) {
-        const std::size_t fpp = codec_.frames_per_packet(), nch = codec_.channels();
+        // where packet i of the last batch lies in a channel's plane is the codec's business: fixed-size frames are
+        // [channel][packet][frames]; Vorbis packs (prev_n + n) / 4 samples per packet and none for the first one
+        const std::size_t nch = codec_.channels();
         last_.planes.resize(nch);
-        for (std::size_t c = 0; c < nch; ++c) last_.planes[c] = pcm_.data() + (c * batch_len_ + i) * fpp;
-        last_.frames = fpp;
+        for (std::size_t c = 0; c < nch; ++c) last_.planes[c] = pcm_.data() + codec_.plane_offset(c, i, batch_len_);
+        last_.frames = codec_.packet_frames(i);
     }
     void clear_last() {
         last_.planes.assign(codec_.channels(), nullptr);
@@ -539,6 +541,8 @@ struct AacLc {
     static std::uint64_t id(const Packet &p) { return p.ts; }
     std::size_t channels() const { return nch_; }
     std::size_t frames_per_packet() const { return 1024; }
+    std::size_t packet_frames(std::size_t) const { return 1024; }
+    std::size_t plane_offset(std::size_t c, std::size_t i, std::size_t k) const { return (c * k + i) * 1024; }
     void reset_state() { std::fill(delay_.begin(), delay_.end(), 0.0f); }  // AacDecoder::reset: delay lines zeroed
     void decode_batch(Context &ctx, const std::vector<Packet> &batch, std::vector<float> &pcm) {
         const std::size_t k = batch.size();
@@ -581,6 +585,8 @@ struct Mp3 {
     static std::uint64_t id(const Packet &p) { return p.ts; }
     std::size_t channels() const { return nch_; }
     std::size_t frames_per_packet() const { return 576 * ngr_; }
+    std::size_t packet_frames(std::size_t) const { return 576 * ngr_; }
+    std::size_t plane_offset(std::size_t c, std::size_t i, std::size_t k) const { return (c * k + i) * 576 * ngr_; }
     void reset_state() {  // MpaDecoder::reset: fresh State (overlap and SynthesisState::default())
         std::fill(overlap_.begin(), overlap_.end(), 0.0f);
         std::fill(vvec_.begin(), vvec_.end(), 0.0f);
@@ -609,6 +615,76 @@ private:
     std::vector<float> overlap_, vvec_, in_;
     std::vector<std::int32_t> vfront_;
     std::vector<symaccel_mp3_side> side_;
+};
+
+// Vorbis: one packet = one audio block of the size its mode's block flag selects.  What the CPU side hands over per
+// channel: floor x residue, the n / 2 lines DspChannel::synth receives (lib.rs:282-331).  A packet yields
+// (prev_n + n) / 4 frames -- none for the first block after a reset (dsp.rs:77-80) -- so the batch's PCM is packed
+// (include/symaccel.h, "Vorbis") and the per-packet spans are what publish() asks for.
+struct Vorbis {
+    struct Params {
+        std::size_t channels = 2;
+        int bs0_exp = 8, bs1_exp = 11;
+    };
+    struct Packet {
+        std::uint64_t ts = 0;
+        bool long_block = false;
+        std::vector<float> spectra;  // [channel][n / 2]
+    };
+    explicit Vorbis(const Params &p)
+        : nch_(p.channels), e0_(p.bs0_exp), e1_(p.bs1_exp), prev_(p.channels, -1), overlap_(p.channels * ((std::size_t)1 << (p.bs1_exp - 1)), 0.0f) {}
+    static std::uint64_t id(const Packet &p) { return p.ts; }
+    std::size_t channels() const { return nch_; }
+    std::size_t packet_frames(std::size_t i) const { return emits_[i] ? off_[i + 1] - off_[i] : 0; }
+    std::size_t plane_offset(std::size_t c, std::size_t i, std::size_t) const { return c * stride_ + off_[i]; }
+    void reset_state() {  // Dsp::reset (dsp.rs:45-56): no block to lap with, overlap zeroed
+        std::fill(prev_.begin(), prev_.end(), -1);
+        std::fill(overlap_.begin(), overlap_.end(), 0.0f);
+    }
+    void decode_batch(Context &ctx, const std::vector<Packet> &batch, std::vector<float> &pcm) {
+        const std::size_t k = batch.size();
+        const std::size_t bs[2] = {(std::size_t)1 << e0_, (std::size_t)1 << e1_};
+        std::vector<std::size_t> spec_off(k);
+        off_.assign(k + 1, 0);
+        emits_.assign(k, false);
+        std::size_t lines = 0, samples = 0;
+        int prev = prev_[0];
+        for (std::size_t i = 0; i < k; ++i) {
+            const std::size_t n = bs[batch[i].long_block ? 1 : 0];
+            if (batch[i].spectra.size() != nch_ * n / 2) throw std::invalid_argument("Vorbis: packet shape");
+            spec_off[i] = lines;
+            off_[i] = samples;
+            emits_[i] = prev >= 0;
+            lines += n / 2;
+            samples += prev >= 0 ? (bs[prev] + n) / 4 : n / 2;  // a first block owns n / 2 untouched slots
+            prev = batch[i].long_block ? 1 : 0;
+        }
+        off_[k] = samples;
+        stride_ = samples;
+        in_.resize(nch_ * lines);
+        flags_.resize(nch_ * k);
+        pcm.assign(nch_ * samples, 0.0f);
+        for (std::size_t i = 0; i < k; ++i) {
+            const std::size_t half = bs[batch[i].long_block ? 1 : 0] / 2;
+            for (std::size_t c = 0; c < nch_; ++c) {
+                std::copy_n(batch[i].spectra.data() + c * half, half, in_.data() + c * lines + spec_off[i]);
+                flags_[c * k + i] = batch[i].long_block ? 1 : 0;
+            }
+        }
+        check(symaccel_vorbis_synth(ctx.raw(), e0_, e1_, in_.data(), lines, flags_.data(), prev_.data(), overlap_.data(), pcm.data(), samples,
+                                    nch_, k),
+              ctx.raw());
+    }
+
+private:
+    std::size_t nch_;
+    int e0_, e1_;
+    std::vector<std::int32_t> prev_;
+    std::vector<float> overlap_, in_;
+    std::vector<std::uint8_t> flags_;
+    std::vector<std::size_t> off_;
+    std::vector<bool> emits_;
+    std::size_t stride_ = 0;
 };
 
 }  // namespace codecs

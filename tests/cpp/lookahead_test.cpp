@@ -1,4 +1,4 @@
-// LookaheadDecoder (include/symaccel.hpp): the AudioDecoder method set over batched device calls.  A synthetic track of
+// LookaheadDecoder (include/symaccel.hpp): the AudioDecoder method set over batched device calls (AAC-LC, MP3, Vorbis).  A synthetic track of
 // parsed packets is decoded through decode() one packet at a time; every returned buffer must be bit-identical to what a
 // frame-by-frame decoder (the CPU oracle, linked as the checker only) produces -- across batch boundaries, across a
 // reset() (seek) and across a discontinuity without reset().  Built against the real library on the GPU box and against
@@ -154,6 +154,51 @@ static void test_mp3(Context &ctx, size_t lookahead) {
     }
 }
 
+// ---- Vorbis: mixed block sizes, a variable number of frames per packet (none for the first block after a reset)
+static void test_vorbis(Context &ctx, size_t lookahead, int e0, int e1) {
+    const size_t nch = 2, n = 37;
+    const size_t bs[2] = {(size_t)1 << e0, (size_t)1 << e1};
+    std::mt19937 rng(100 + (unsigned)lookahead + (unsigned)e1);
+    std::normal_distribution<float> nd(0.0f, 0.25f);
+    std::vector<Vorbis::Packet> track(n);
+    for (size_t i = 0; i < n; ++i) {
+        track[i].ts = 9000 + 7 * i;
+        track[i].long_block = rng() % 3 != 0;
+        track[i].spectra.resize(nch * bs[track[i].long_block] / 2);
+        for (auto &v : track[i].spectra) v = nd(rng);
+    }
+    size_t cursor = 0;
+    LookaheadDecoder<Vorbis> dec(ctx, Vorbis::Params{nch, e0, e1}, lookahead, [&]() -> std::optional<Vorbis::Packet> {
+        if (cursor >= track.size()) return std::nullopt;
+        return track[cursor++];
+    });
+    // the frame-by-frame decoder: one oracle call per packet and channel, state carried like DspChannel does
+    std::vector<int32_t> prev(nch, -1);
+    std::vector<float> ov(nch * bs[1] / 2, 0.0f);
+    auto step = [&](size_t i) {
+        if (cursor <= i) cursor = i + 1;
+        const AudioBufferRef &buf = dec.decode(track[i]);
+        const size_t nb = bs[track[i].long_block];
+        for (size_t c = 0; c < nch; ++c) {
+            const bool emits = prev[c] >= 0;
+            const size_t frames = emits ? (bs[prev[c]] + nb) / 4 : 0, slots = emits ? frames : nb / 2;
+            std::vector<float> want(slots, 0.0f);
+            const uint8_t flag = track[i].long_block ? 1 : 0;
+            so_vorbis_synth_batch(e0, e1, track[i].spectra.data() + c * nb / 2, nb / 2, &flag, &prev[c], ov.data() + c * bs[1] / 2, want.data(), slots, 1, 1);
+            EXPECT(buf.frames == frames, "Vorbis K=%zu packet %zu: %zu frames, expected %zu", lookahead, i, buf.frames, frames);
+            EXPECT(buf.frames != frames || same_bits(buf.planes[c], want.data(), frames), "Vorbis %d/%d K=%zu packet %zu channel %zu differs from the frame-by-frame decoder", e0, e1, lookahead, i, c);
+        }
+    };
+    for (size_t i = 0; i < 15; ++i) step(i);
+    dec.reset();  // seek
+    std::fill(prev.begin(), prev.end(), -1);
+    std::fill(ov.begin(), ov.end(), 0.0f);
+    cursor = 19;
+    for (size_t i = 19; i < 27; ++i) step(i);
+    cursor = 30;  // packets dropped without reset()
+    for (size_t i = 30; i < n; ++i) step(i);
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && std::strcmp(argv[1], "--expect-no-device") == 0) {
         try {
@@ -168,6 +213,8 @@ int main(int argc, char **argv) {
     Context ctx(0);
     for (size_t k : {size_t(1), size_t(4), size_t(9), size_t(64)}) test_aac(ctx, k);
     for (size_t k : {size_t(1), size_t(3), size_t(8)}) test_mp3(ctx, k);
+    for (size_t k : {size_t(1), size_t(5), size_t(16)}) test_vorbis(ctx, k, 8, 11);
+    test_vorbis(ctx, 6, 6, 9);
     if (g_failures == 0) std::printf("all checks passed\n");
     return g_failures ? 1 : 0;
 }

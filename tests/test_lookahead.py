@@ -1,5 +1,5 @@
 """codecs::LookaheadDecoder (include/symaccel.hpp): the reference's AudioDecoder method set (codecs/audio.rs:251-298) over
-batched calls.  tests/cpp/lookahead_test.cpp decodes synthetic AAC and MP3 tracks packet by packet and compares every
+batched calls.  tests/cpp/lookahead_test.cpp decodes synthetic AAC, MP3 and Vorbis tracks packet by packet and compares every
 returned buffer with a frame-by-frame decoder (the oracle), across batch boundaries, a reset() and a discontinuity.
 CPU: linked against the emulation build of the kernels; GPU: against libsymaccel.so."""
 import subprocess
