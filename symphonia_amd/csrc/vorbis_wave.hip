@@ -101,7 +101,13 @@ __device__ __forceinline__ long last_long_before(const uint8_t *f, long b, int l
     return -1;
 }
 
-constexpr int kWaves = 4;
+// Build variant (tuning knob SYM_VORBIS_WAVES, see build.py): 2 = four wavefronts per workgroup, lane twiddles in 31 VGPRs,
+// two wavefronts per SIMD (the default); 3 = six wavefronts per workgroup, lane twiddles read from a 4 KiB LDS copy,
+// register budget of three wavefronts per SIMD.
+#ifndef SYM_VORBIS_WAVES
+#define SYM_VORBIS_WAVES 2
+#endif
+constexpr int kWaves = SYM_VORBIS_WAVES == 3 ? 6 : 4;
 constexpr int kTabTw = 0;        // shared LDS tables: Imdct(1024) twiddles, 512 complex
 constexpr int kTabWin = 1024;    //   long window (left half of the 2048-sample window), 1024 f32
 constexpr int kTabWs = 2048;     //   short window (left half of the 256-sample window), 128 f32
@@ -122,7 +128,7 @@ __device__ __forceinline__ void ola_short4(const float *ws, int k, const float (
 // FUSED: the spectrum is floor[i] * residue[i] (the dot product of lib.rs:282-292), multiplied as the lines are consumed --
 // one rounded multiply per line, exactly the reference's `*f *= r`, without a separate pass over HBM.
 template <bool FUSED>
-__global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
+__global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wave_kernel(
     DevTables tb, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
     const float *__restrict__ residue, size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
@@ -132,6 +138,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
     __shared__ unsigned wave_chain[kWaves];  // the wavefront's chain index, parked for the epilogue (see there)
+#if SYM_VORBIS_WAVES == 3
+    __shared__ __attribute__((aligned(16))) c32 lane_tab[kLaneTabComplex];
+    fill_lane_tables_lds(tb, lane_tab, (int)threadIdx.x, 64 * kWaves);
+#endif
 
     for (int i = (int)threadIdx.x; i < 1024; i += 64 * kWaves) {
         tabs[kTabTw + i] = reinterpret_cast<const float *>(tw_long)[i];
@@ -161,8 +171,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
     float *out = pcm + (size_t)chain * pcm_stride;
     const int pf0 = prev_flag_in[chain];
 
+#if SYM_VORBIS_WAVES == 3
+    const LaneTablesLds lt = lane_tables_lds(tb, lane_tab, lane);
+#else
     LaneTables lt;
     load_lane_tables(tb, lane, lt);
+#endif
 
     // overlap (dsp.rs:125), slot layout: dl[h][0..3] = overlap[4 m2 + q], dl[h][4..7] = overlap[1020 - 4 m2 + q]
     float dl[2][8];
@@ -248,19 +262,21 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
             }
             if (glen_next > 0) fetch_lines<FUSED>(sp, rp, os_next, flag_next ? 8 : glen_next, lane, line, res);  // prefetch
             fft512_wave(z, lane, lds, lt);
-            float x[2][8], x2[2][8];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) post_slot(lds, tw, lane + 64 * h, x[h], x2[h]);
+            // (the two slot halves h = 0, 1 are post-twiddled, overlap-added, stored and turned into the new overlap one
+            // after the other: 16 instead of 32 live outputs)
             float *o = out + op_cur;
             if (pflag) {
                 // long -> long (dsp.rs:85-90): out[k] = overlap[k] * win[1023 - k] + pcm[k] * win[k]
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    float w[8], dst[8];
+                    float x[8], x2[8], w[8], dst[8];
+                    post_slot(lds, tw, lane + 64 * h, x, x2);
                     load_slot(wl, lane + 64 * h, w);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) dst[q] = dl[h][q] * w[7 - q] + x[h][q] * w[q];
+                    for (int q = 0; q < 8; ++q) dst[q] = dl[h][q] * w[7 - q] + x[q] * w[q];
                     if (emit) store_slot_stream(o, lane + 64 * h, dst);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) dl[h][q] = x2[q];  // overlap = imdct[1024..2048) (dsp.rs:125)
                 }
                 wave_sync();  // Z in LDS is overwritten by the next group
             } else {
@@ -275,26 +291,33 @@ __global__ __launch_bounds__(64 * kWaves, 2) void vorbis_synth_wave_kernel(
                     ovA[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * t, __float_as_int(dl[0][q])));
                     ovB[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (31 - t), __float_as_int(dl[0][q])));
                 }
-                if (emit) {
-                    float4 *o4 = reinterpret_cast<float4 *>(o);
+                float4 *o4 = reinterpret_cast<float4 *>(o);
+                {
+                    float x[8], x2[8];
+                    post_slot(lds, tw, lane, x, x2);
                     // copied part: second float4 of every slot with 1020 - 4 m2 >= 576, i.e. m2 <= 111
-                    st_stream(o4 + (143 - lane), make_float4(x[0][4], x[0][5], x[0][6], x[0][7]));           // (572 - 4 lane) / 4
-                    if (lane < 48) st_stream(o4 + (79 - lane), make_float4(x[1][4], x[1][5], x[1][6], x[1][7]));  // (316 - 4 lane) / 4
-                    if (lane >= 48) {
-                        const float ya[4] = {x[1][0], x[1][1], x[1][2], x[1][3]}, yb[4] = {x[1][4], x[1][5], x[1][6], x[1][7]};
-                        float4 ra, rb;
-                        ola_short4(ws, 4 * t, ovA, ya, ra);
-                        ola_short4(ws, 124 - 4 * t, ovB, yb, rb);
-                        st_stream(o4 + (t), ra);
-                        st_stream(o4 + (31 - t), rb);
+                    if (emit) st_stream(o4 + (143 - lane), make_float4(x[4], x[5], x[6], x[7]));           // (572 - 4 lane) / 4
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) dl[0][q] = x2[q];
+                }
+                {
+                    float x[8], x2[8];
+                    post_slot(lds, tw, lane + 64, x, x2);
+                    if (emit) {
+                        if (lane < 48) st_stream(o4 + (79 - lane), make_float4(x[4], x[5], x[6], x[7]));  // (316 - 4 lane) / 4
+                        if (lane >= 48) {
+                            const float ya[4] = {x[0], x[1], x[2], x[3]}, yb[4] = {x[4], x[5], x[6], x[7]};
+                            float4 ra, rb;
+                            ola_short4(ws, 4 * t, ovA, ya, ra);
+                            ola_short4(ws, 124 - 4 * t, ovB, yb, rb);
+                            st_stream(o4 + (t), ra);
+                            st_stream(o4 + (31 - t), rb);
+                        }
                     }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) dl[1][q] = x2[q];
                 }
                 wave_sync();  // Z in LDS is overwritten by the next group
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) dl[h][q] = x2[h][q];  // overlap = imdct[1024..2048) (dsp.rs:125)
             }
             hi_fresh = true;
         } else {
