@@ -93,9 +93,9 @@ int symaccel_host_unregister(void *p);
 /* ------------------------------------------------------------------ core dsp (symphonia-core) */
 
 /* Fft::fft / Fft::fft_inplace (symphonia-core/src/dsp/fft/no_simd.rs:96-140): `count` forward
- * complex FFTs of size n (power of two, 2 <= n <= 4096), interleaved (re, im) f32.
- * d_in == d_out is allowed (fft_inplace).  4096 < n <= 65536 (legal in the reference, unused by its codecs):
- * SYMACCEL_ERR_UNSUPPORTED. */
+ * complex FFTs of size n (power of two, 2 <= n <= 65536: the reference's own limit, no_simd.rs:77-80),
+ * interleaved (re, im) f32.  d_in == d_out is allowed (fft_inplace).  More than 4096 points (used by none of the
+ * reference's codecs) take a global-memory path through count * n * 8 bytes of context scratch. */
 int symaccel_fft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count);
 int symaccel_fft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count);
 /* Ifft::ifft / Ifft::ifft_inplace (no_simd.rs:143-219): the forward transform() between a re <-> im swap of the permuted
@@ -106,8 +106,8 @@ int symaccel_ifft_c32_device(symaccel_ctx *ctx, int n, const float *d_in, float 
 int symaccel_ifft_c32(symaccel_ctx *ctx, int n, const float *h_in, float *h_out, size_t count);
 
 /* Imdct::new_scaled(n, scale).imdct(spec, out) (symphonia-core/src/dsp/mdct.rs:35-146), `count`
- * times: spec[count][n] -> out[count][2n].  n = power of two, 4 <= n <= 8192 (8192 < n <= 131072:
- * SYMACCEL_ERR_UNSUPPORTED). */
+ * times: spec[count][n] -> out[count][2n].  n = power of two, 4 <= n <= 131072 (mdct.rs:37-40); above 8192 the
+ * global-memory path of the large Fft (count * n * 4 bytes of context scratch). */
 int symaccel_imdct_f32_device(symaccel_ctx *ctx, int n, double scale, const float *d_spec,
                               float *d_out, size_t count);
 int symaccel_imdct_f32(symaccel_ctx *ctx, int n, double scale, const float *h_spec, float *h_out,

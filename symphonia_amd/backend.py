@@ -117,8 +117,8 @@ class Fft:
     _entry = "symaccel_fft_c32_device"
 
     def __init__(self, ctx, n):
-        if n < 2 or n & (n - 1) or n > 4096:
-            raise ValueError("n must be a power of two <= 4096")
+        if n < 2 or n & (n - 1) or n > 65536:
+            raise ValueError("n must be a power of two <= 65536")  # no_simd.rs:77-80
         self.ctx, self.n = ctx, int(n)
 
     def fft(self, x, y):

@@ -227,7 +227,7 @@ struct DevBuf {
 
 bool pow2(long v) { return v > 0 && (v & (v - 1)) == 0; }
 constexpr size_t kPipelineBytes = (size_t)64 << 20;  // host batches from this size on are staged in overlapped chunks (stage.cpp)
-constexpr int kMaxFft = 4096;  // largest Fft the generic LDS kernel holds (Imdct: twice that); the reference's limit is 65536
+constexpr int kMaxFft = 65536;  // the reference's limit (no_simd.rs:77-80); above 4096 points: imdct_generic.hip, "big" path
 
 }  // namespace
 }  // namespace symaccel

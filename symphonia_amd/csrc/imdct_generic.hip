@@ -90,6 +90,93 @@ __global__ __launch_bounds__(kThreads) void imdct_kernel(DevTables tb, const cpx
     }
 }
 
+// ---- Transforms of more than 4096 complex points (Fft 8192 .. 65536, Imdct 16384 .. 131072: legal in the reference,
+// no_simd.rs:77-80 / mdct.rs:37-40, used by none of its codecs).  The reference's breadth-first schedule is kept: the
+// permuted input is transformed in 4096-point tiles in LDS (stages up to step 2048, exactly wg_fft_lds), the remaining
+// merge stages (step 4096 .. nf / 2, no_simd.rs:247-279) run as one global-memory pass each over a scratch copy.  Every
+// butterfly is the reference's; correctness over speed (these sizes are nobody's hot path).
+enum : int { kBigFft = 0, kBigIfft = 1, kBigImdct = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void fft_big_tile_kernel(DevTables tb, int nf, int log2nf, const void *src_v, const cpx *tw,
+                                                                c32 *work, size_t count) {
+    __shared__ c32 lds[fft_padded(kMaxPoints)];
+    const unsigned tiles = (unsigned)(nf >> 12);
+    const size_t t = blockIdx.x / tiles;
+    const unsigned j = blockIdx.x % tiles;
+    for (int idx = (int)threadIdx.x; idx < 4096; idx += kThreads) {
+        // y[pos] = x[perm[pos]] (no_simd.rs:101-107, 126-128; Ifft :167-169 with the re <-> im swap; Imdct: the
+        // pre-twiddled z of mdct.rs:81-88)
+        const unsigned pos = (j << 12) + (unsigned)idx;
+        const unsigned i = rev_bits(pos, log2nf);
+        c32 v;
+        if constexpr (MODE == kBigImdct) {
+            const int n = nf << 1;
+            const float *s = static_cast<const float *>(src_v) + t * (size_t)n;
+            const cpx w = tw[i];
+            v = pre_twiddle(s[2 * i], s[n - 1 - 2 * (int)i], c32{w.re, w.im});
+        } else {
+            const float2 x = static_cast<const float2 *>(src_v)[t * (size_t)nf + i];
+            v = MODE == kBigIfft ? c32{x.y, x.x} : c32{x.x, x.y};
+        }
+        lds[fft_pad(idx)] = v;
+    }
+    wg_fft_lds(lds, 4096, 4096, tb);
+    for (int idx = (int)threadIdx.x; idx < 4096; idx += kThreads) work[t * (size_t)nf + ((size_t)j << 12) + (size_t)idx] = lds[fft_pad(idx)];
+}
+
+// one merge stage (no_simd.rs:222-238): q = o * w; e' = e + q; o' = e - q.  `scale_swap`: the last stage of an Ifft
+// writes (c * im, c * re) (no_simd.rs:181-186).
+__global__ __launch_bounds__(kThreads) void fft_big_merge_kernel(DevTables tb, int nf, int step, const c32 *src, c32 *dst, size_t count,
+                                                                 int scale_swap, float c) {
+    const size_t half = (size_t)nf >> 1, total = count * half;
+    for (size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x; g < total; g += (size_t)gridDim.x * kThreads) {
+        const size_t t = g / half;
+        const unsigned b = (unsigned)(g % half);
+        const unsigned k = b & (unsigned)(step - 1);
+        const size_t e = t * (size_t)nf + (((size_t)(b - k)) << 1) + k, o = e + (size_t)step;
+        const cpx wk = tb.fft_merge[(size_t)(step - 32) + k];  // W_{2 * step}
+        c32 ev = src[e], ov = src[o];
+        const c32 q = c_mul(ov, c32{wk.re, wk.im});
+        bfly(ev, ov, q);
+        if (scale_swap) {
+            ev = c32{c * ev.y, c * ev.x};
+            ov = c32{c * ov.y, c * ov.x};
+        }
+        dst[e] = ev;
+        dst[o] = ov;
+    }
+}
+
+// post-FFT twiddle and expansion into the four quarter vectors (mdct.rs:94-137), from the scratch copy
+__global__ __launch_bounds__(kThreads) void imdct_big_post_kernel(const cpx *tw, int n, const c32 *work, float *out, size_t count) {
+    const int nf = n >> 1, n4 = n >> 2;
+    const size_t total = count * (size_t)nf;
+    for (size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x; g < total; g += (size_t)gridDim.x * kThreads) {
+        const size_t t = g / (size_t)nf;
+        const int k = (int)(g % (size_t)nf);
+        float *o = out + t * 2 * (size_t)n;
+        float *vec0 = o, *vec1 = o + nf, *vec2 = o + 2 * nf, *vec3 = o + 3 * nf;
+        const c32 x = work[g];
+        const cpx w = tw[k];
+        const c32 val = post_twiddle(x, c32{w.re, w.im});  // w * x.conj()
+        if (k < n4) {
+            const int fi = 2 * k, ri = nf - 1 - 2 * k;
+            vec0[ri] = -val.y;
+            vec1[fi] = val.y;
+            vec2[ri] = val.x;
+            vec3[fi] = val.x;
+        } else {
+            const int i = k - n4;
+            const int fi = 2 * i, ri = nf - 1 - 2 * i;
+            vec0[fi] = -val.x;
+            vec1[ri] = val.x;
+            vec2[fi] = val.y;
+            vec3[ri] = val.y;
+        }
+    }
+}
+
 // ---- wavefront-per-transform fast paths for the two sizes the AAC and Vorbis 256/2048 decoders use (imdct_wave.h):
 // n = 1024 (one 512-point FFT in three radix-8 register passes) and n = 128 (eight 64-point FFTs at once).
 constexpr int kWaveWaves = 4;
@@ -188,7 +275,34 @@ int ilog2(int v) {
 
 }  // namespace
 
+// The big-transform driver: src -> scratch (tiles), merge stages in scratch, the last one into `final_dst` (Fft / Ifft) or,
+// for Imdct (final_dst == nullptr), staying in scratch for the post-twiddle.  Returns the scratch pointer in *work_out.
+template <int MODE>
+static int run_big_fft(symaccel_ctx *ctx, int nf, const void *src, const cpx *tw, c32 *final_dst, size_t count, c32 **work_out) {
+    const size_t tiles = (size_t)(nf >> 12);
+    if (count * tiles > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    void *scratch = nullptr;
+    SYM_TRY(ctx_scratch(ctx, count * (size_t)nf * sizeof(c32), &scratch));
+    c32 *work = static_cast<c32 *>(scratch);
+    hipLaunchKernelGGL(fft_big_tile_kernel<MODE>, dim3((unsigned)(count * tiles)), dim3(kThreads), 0, ctx->stream, ctx->dev, nf, ilog2(nf),
+                       src, tw, work, count);
+    const size_t pairs = count * (size_t)(nf >> 1);
+    const unsigned grid = (unsigned)((pairs + kThreads - 1) / kThreads < 65536 ? (pairs + kThreads - 1) / kThreads : 65536);
+    for (int step = 4096; step < nf; step <<= 1) {
+        const bool last = (step << 1) == nf;
+        c32 *dst = last && final_dst ? final_dst : work;
+        hipLaunchKernelGGL(fft_big_merge_kernel, dim3(grid), dim3(kThreads), 0, ctx->stream, ctx->dev, nf, step, (const c32 *)work, dst, count,
+                           (last && MODE == kBigIfft) ? 1 : 0, 1.0f / (float)nf);
+    }
+    SYM_GPU(ctx, hipGetLastError());
+    if (work_out) *work_out = work;
+    return SYMACCEL_OK;
+}
+
 int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count, bool inverse) {
+    if (n > kMaxPoints)  // (reads everything of d_in before the last stage writes d_out: d_in == d_out is fine)
+        return inverse ? run_big_fft<kBigIfft>(ctx, n, d_in, nullptr, reinterpret_cast<c32 *>(d_out), count, nullptr)
+                       : run_big_fft<kBigFft>(ctx, n, d_in, nullptr, reinterpret_cast<c32 *>(d_out), count, nullptr);
     const int points = n >= 2048 ? n : 2048;
     const size_t per_wg = (size_t)(points / n);
     const size_t grid = (count + per_wg - 1) / per_wg;
@@ -218,6 +332,16 @@ int launch_imdct(symaccel_ctx *ctx, const ImdctPlan &plan, const float *d_spec, 
         return SYMACCEL_OK;
     }
     const int nf = plan.n / 2;
+    if (nf > kMaxPoints) {
+        c32 *work = nullptr;
+        SYM_TRY((run_big_fft<kBigImdct>(ctx, nf, d_spec, (const cpx *)plan.d_twiddle, nullptr, count, &work)));
+        const size_t total = count * (size_t)nf;
+        const unsigned g = (unsigned)((total + kThreads - 1) / kThreads < 65536 ? (total + kThreads - 1) / kThreads : 65536);
+        hipLaunchKernelGGL(imdct_big_post_kernel, dim3(g), dim3(kThreads), 0, ctx->stream, (const cpx *)plan.d_twiddle, plan.n,
+                           (const c32 *)work, d_out, count);
+        SYM_GPU(ctx, hipGetLastError());
+        return SYMACCEL_OK;
+    }
     const int points = nf >= 2048 ? nf : 2048;
     const size_t per_wg = (size_t)(points / nf);
     const size_t grid = (count + per_wg - 1) / per_wg;

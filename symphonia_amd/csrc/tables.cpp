@@ -117,8 +117,9 @@ void build(HostTables &t) {
     make_imdct_twiddles(1024, 1.0 / 2048.0, t.aac_tw_long.data());  // aac/dsp.rs:49
     make_imdct_twiddles(128, 1.0 / 256.0, t.aac_tw_short.data());   // aac/dsp.rs:50
 
-    t.fft_merge.resize(fft_merge_offset(8192));
-    for (int n = 64; n <= 4096; n <<= 1) make_fft_twiddles(n, t.fft_merge.data() + fft_merge_offset(n));
+    // W64 .. W65536 (no_simd.rs:16-67 generates them lazily per size; the largest legal Fft has 65536 points)
+    t.fft_merge.resize(fft_merge_offset(131072));
+    for (int n = 64; n <= 65536; n <<= 1) make_fft_twiddles(n, t.fft_merge.data() + fft_merge_offset(n));
     build_small(16, t.small16, t.small16_form);
     build_small(32, t.small32, t.small32_form);
 

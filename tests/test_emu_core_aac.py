@@ -34,6 +34,34 @@ def test_emu_fft_bit_exact(emu_ctx, n):
     assert bit_equal(z, want)
 
 
+@pytest.mark.parametrize("n", [8192, 32768])
+def test_emu_large_fft_and_ifft(emu_ctx, n):
+    """More than 4096 points (legal in the reference up to 65 536, used by none of its codecs): 4096-point tiles in LDS,
+    then the remaining merge stages in global memory -- the same butterflies, in and out of place."""
+    from symphonia_amd import Ifft
+    rng = np.random.default_rng(200 + n)
+    x = (rng.standard_normal((2, n)) * np.exp2(rng.integers(-4, 5, (2, n))) + 1j * rng.standard_normal((2, n))).astype(np.complex64)
+    y = np.empty_like(x)
+    Fft(emu_ctx, n).fft(x, y)
+    assert bit_equal(y, np.stack([oracle.fft(v) for v in x]))
+    z = x.copy()
+    Fft(emu_ctx, n).fft_inplace(z)
+    assert bit_equal(z, y)
+    Ifft(emu_ctx, n).ifft(x, y)
+    assert bit_equal(y, np.stack([oracle.ifft(v) for v in x]))
+    z = x.copy()
+    Ifft(emu_ctx, n).ifft_inplace(z)
+    assert bit_equal(z, y)
+
+
+@pytest.mark.parametrize("n", [16384, 65536])
+def test_emu_large_imdct(emu_ctx, n):
+    rng = np.random.default_rng(300 + n)
+    spec = (rng.standard_normal((2, n)) * np.exp2(rng.integers(-6, 8, (2, n)))).astype(np.float32)
+    for scale in (1.0, -1.0 / 3):
+        assert bit_equal(Imdct(emu_ctx, n, scale).imdct(spec), oracle.imdct(spec, scale)), (n, scale)
+
+
 def test_emu_aac_only_long(emu_ctx):
     rng = np.random.default_rng(1)
     coeffs = aac_spectra(rng, (2, 5))

@@ -46,11 +46,11 @@ def assert_parity(got, want, what):
 
 # ------------------------------------------------------------------------------------------ core
 
-@pytest.mark.parametrize("n", [4, 16, 32, 64, 128, 256, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("n", [4, 16, 32, 64, 128, 256, 1024, 2048, 4096, 8192, 16384, 131072])
 def test_imdct_parity(ctx, n):
     from symphonia_amd import Imdct
     rng = np.random.default_rng(n)
-    count = 37 if n <= 2048 else 5
+    count = 37 if n <= 2048 else (5 if n <= 8192 else 3)
     spec = (rng.standard_normal((count, n)) * np.exp2(rng.integers(-10, 12, (count, n)))).astype(np.float32)
     spec[0, : n // 2] = np.float32(1e-41)  # denormals must survive (no flush-to-zero)
     spec[1, ::3] = -0.0
@@ -84,7 +84,7 @@ def test_config1_imdct1024_one_frame_host_path(ctx):
     assert np.abs(got[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 512, 1024, 4096])
+@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 512, 1024, 4096, 8192, 65536])
 def test_fft_parity(ctx, n):
     from helpers import dft_naive, kats
     from symphonia_amd import Fft
@@ -104,6 +104,11 @@ def test_fft_parity(ctx, n):
     assert_parity(got.view(np.float32), want.view(np.float32), "fft n=%d" % n)
     if n == 64:
         assert np.abs(got[0] - dft_naive(x[0])).max() < 1e-5
+    from symphonia_amd import Ifft
+    Ifft(ctx, n).ifft_inplace(xd)  # (in place: the large sizes go through a scratch copy)
+    got = host(xd).view(np.complex64).reshape(9, n)
+    want = np.stack([oracle.ifft(r) for r in x])
+    assert_parity(got.view(np.float32), want.view(np.float32), "ifft n=%d" % n)
     Fft(ctx, n).fft_inplace(xd)
     assert_parity(host(xd).view(np.complex64).reshape(9, n).view(np.float32), want.view(np.float32), "fft_inplace")
 

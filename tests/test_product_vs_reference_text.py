@@ -63,7 +63,7 @@ def gpu_ctx():
 def check_fft(r):
     from symphonia_amd import Fft
     f = load("fft")
-    for n in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
+    for n in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
         x = r.dev(f["in_%d" % n][None])          # [1, n, 2] interleaved (re, im)
         y = r.dev(np.zeros((1, n, 2), np.float32))
         Fft(r.ctx, n).fft(x, y)

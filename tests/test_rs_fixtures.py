@@ -49,7 +49,7 @@ def test_manifest_covers_the_hot_path():
 
 def test_oracle_fft():
     f = load("fft")
-    for n in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
+    for n in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
         x = f["in_%d" % n]
         want = f["out_%d" % n]
         got = oracle.fft((x[:, 0] + 1j * x[:, 1]).astype(np.complex64))
