@@ -15,7 +15,12 @@ namespace symaccel {
 
 namespace {
 
-constexpr int kVThreads = 64;
+// Threads of the generic kernel's workgroup (one workgroup per (chain, segment); its wavefronts share every block's FFT):
+// one wavefront for block sizes up to 2048 -- their FFTs are at most 512 points, four wavefronts would mostly wait at the
+// barriers (128 / 1024: 2.6 ms with one, 3.8 ms with four) --, four for the 4096 and 8192 blocks (512 / 4096: 5.0 ms
+// with one, 2.0 ms with four; profiles/r02w_vorbis_pairs.txt).
+template <int MAXBS>
+constexpr int vorbis_threads() { return MAXBS > 2048 ? 256 : 64; }
 
 // ---- packed offsets -----------------------------------------------------------------------
 // offs[chain][0 .. nb] (spectrum) and offs[chain][nb+1 .. 2nb+1] (pcm), exclusive prefix sums.
@@ -78,27 +83,62 @@ struct VorbisShared {
     float overlap[MAXBS / 2];  // right half of the previous block's Imdct output (dsp.rs:125)
 };
 
-// Imdct of one block into sh.pcm[0 .. bs) (mdct.rs:67-146).
+// A block's inputs as the lanes consume them: lane `tid` owns the FFT points i = tid + kVT * j.  Fetching a block is
+// separate from transforming it so that block b + 1 is in flight while block b is transformed: with a run-time trip count
+// and dependent 4-byte loads the pre-twiddle loop used to wait for HBM once per iteration (27 us per 2048-sample block).
 template <int MAXBS>
-__device__ __forceinline__ void vorbis_imdct_block(VorbisShared<MAXBS> &sh, const float *__restrict__ spec,
-                                                   const float *__restrict__ res, int bs,
-                                                   int log2nf, const cpx *__restrict__ tw, const DevTables &tb) {
-    const int n = bs >> 1, nf = bs >> 2, n4 = bs >> 3;
-    for (int i = (int)threadIdx.x; i < nf; i += kVThreads) {
-        const cpx w = tw[i];
-        float even = spec[2 * i], mirrored = spec[n - 1 - 2 * i];
-        if (res) {  // fused dot product (lib.rs:289-291): *f *= r
-            even *= res[2 * i];
-            mirrored *= res[n - 1 - 2 * i];
+struct VorbisLines {
+    static constexpr int J = MAXBS / 4 / vorbis_threads<MAXBS>();  // points per lane of the largest block
+    float even[J], mirrored[J];  // spec[2 i], spec[n - 1 - 2 i] (already multiplied by the residue when fused)
+    c32 w[J];                    // the block size's Imdct twiddles tw[i] (pre- and post-twiddle use the same ones)
+};
+
+template <int MAXBS>
+__device__ __forceinline__ void vorbis_fetch_block(VorbisLines<MAXBS> &L, const float *__restrict__ spec,
+                                                   const float *__restrict__ res, int bs, const cpx *__restrict__ tw) {
+    constexpr int kVT = vorbis_threads<MAXBS>();
+    const int n = bs >> 1, nf = bs >> 2;
+    float re[VorbisLines<MAXBS>::J], rm[VorbisLines<MAXBS>::J];
+#pragma unroll
+    for (int j = 0; j < VorbisLines<MAXBS>::J; ++j) {
+        const int i = (int)threadIdx.x + kVT * j;
+        const bool in = i < nf;
+        const int ii = in ? i : 0;
+        const cpx w = tw[ii];
+        L.w[j] = c32{w.re, w.im};
+        L.even[j] = in ? spec[2 * ii] : 0.0f;
+        L.mirrored[j] = in ? spec[n - 1 - 2 * ii] : 0.0f;
+        re[j] = (res && in) ? res[2 * ii] : 1.0f;
+        rm[j] = (res && in) ? res[n - 1 - 2 * ii] : 1.0f;
+    }
+    if (res) {  // fused dot product (lib.rs:289-291): *f *= r
+#pragma unroll
+        for (int j = 0; j < VorbisLines<MAXBS>::J; ++j) {
+            L.even[j] *= re[j];
+            L.mirrored[j] *= rm[j];
         }
-        sh.fft[fft_pad((int)rev_bits((unsigned)i, log2nf))] = pre_twiddle(even, mirrored, c32{w.re, w.im});
+    }
+}
+
+// Imdct of one fetched block into sh.pcm[0 .. bs) (mdct.rs:67-146).
+template <int MAXBS>
+__device__ __forceinline__ void vorbis_imdct_block(VorbisShared<MAXBS> &sh, const VorbisLines<MAXBS> &L, int bs, int log2nf,
+                                                   const DevTables &tb) {
+    constexpr int kVT = vorbis_threads<MAXBS>();
+    const int nf = bs >> 2, n4 = bs >> 3;
+#pragma unroll
+    for (int j = 0; j < VorbisLines<MAXBS>::J; ++j) {
+        const int i = (int)threadIdx.x + kVT * j;
+        if (i < nf) sh.fft[fft_pad((int)rev_bits((unsigned)i, log2nf))] = pre_twiddle(L.even[j], L.mirrored[j], L.w[j]);
     }
     wg_fft_lds(sh.fft, nf, nf, tb);
     float *vec0 = sh.pcm, *vec1 = sh.pcm + nf, *vec2 = sh.pcm + 2 * nf, *vec3 = sh.pcm + 3 * nf;
-    for (int k = (int)threadIdx.x; k < nf; k += kVThreads) {
+#pragma unroll
+    for (int j = 0; j < VorbisLines<MAXBS>::J; ++j) {
+        const int k = (int)threadIdx.x + kVT * j;
+        if (k >= nf) continue;
         const c32 x = sh.fft[fft_pad(k)];
-        const cpx w = tw[k];
-        const c32 val = post_twiddle(x, c32{w.re, w.im});
+        const c32 val = post_twiddle(x, L.w[j]);
         if (k < n4) {
             const int fi = 2 * k, ri = nf - 1 - 2 * k;
             vec0[ri] = -val.y;
@@ -118,13 +158,14 @@ __device__ __forceinline__ void vorbis_imdct_block(VorbisShared<MAXBS> &sh, cons
 }
 
 template <int MAXBS>
-__global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
+__global__ __launch_bounds__(vorbis_threads<MAXBS>()) void vorbis_synth_kernel(
     DevTables tb, int bs0_exp, int bs1_exp, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
     const float *__restrict__ residue, size_t spec_stride, const uint8_t *__restrict__ flags,
     const int32_t *__restrict__ prev_flag_in, int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in,
     float *__restrict__ overlap_out, float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs,
     unsigned nb, unsigned seg_len, unsigned segs_per_chain) {
+    constexpr int kVT = vorbis_threads<MAXBS>();
     __shared__ VorbisShared<MAXBS> sh;
     const int tid = (int)threadIdx.x;
     const unsigned chain = blockIdx.x / segs_per_chain, seg = blockIdx.x % segs_per_chain;
@@ -138,40 +179,59 @@ __global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
     const int pf0 = prev_flag_in[chain];
 
     if (b_begin == 0) {
-        for (int i = tid; i < bs1 / 2; i += kVThreads) sh.overlap[i] = overlap_in[(size_t)chain * (size_t)(bs1 / 2) + i];
+        for (int i = tid; i < bs1 / 2; i += kVT) sh.overlap[i] = overlap_in[(size_t)chain * (size_t)(bs1 / 2) + i];
     }
     __syncthreads();
 
     const long b_first = b_begin == 0 ? 0 : (long)b_begin - 1;  // halo block rebuilds the overlap only
     bool hi_fresh = b_begin == 0 || bs0 == bs1;  // overlap[bs0/2 .. bs1/2) is what the reference would hold here
+    VorbisLines<MAXBS> cur, nxt;
+    int flag_next = b_first < (long)b_end ? (f[b_first] ? 1 : 0) : 0;
+    if (b_first < (long)b_end) {
+        const uint32_t o0 = os[b_first];
+        vorbis_fetch_block<MAXBS>(nxt, sp + o0, rp ? rp + o0 : nullptr, flag_next ? bs1 : bs0, flag_next ? tw_long : tw_short);
+    }
     for (long b = b_first; b < (long)b_end; ++b) {
-        const int flag = f[b] ? 1 : 0;
+        const int flag = flag_next;
         const int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);  // lib.rs:298
         const int bs = flag ? bs1 : bs0;
         hi_fresh = hi_fresh || flag;
-        vorbis_imdct_block<MAXBS>(sh, sp + os[b], rp ? rp + os[b] : nullptr, bs, (flag ? bs1_exp : bs0_exp) - 2,
-                                  flag ? tw_long : tw_short, tb);
+        cur = nxt;
+        if (b + 1 < (long)b_end) {  // the next block's lines and twiddles travel while this one is transformed
+            flag_next = f[b + 1] ? 1 : 0;
+            const uint32_t o1 = os[b + 1];
+            vorbis_fetch_block<MAXBS>(nxt, sp + o1, rp ? rp + o1 : nullptr, flag_next ? bs1 : bs0, flag_next ? tw_long : tw_short);
+        }
+        vorbis_imdct_block<MAXBS>(sh, cur, bs, (flag ? bs1_exp : bs0_exp) - 2, tb);
         if (b >= (long)b_begin) {
-            float *o = out + op[b];
-            const float *win = (flag && pflag) ? win_long : win_short;  // dsp.rs:83
+            float *__restrict__ o = out + op[b];
+            const float *__restrict__ win = (flag && pflag) ? win_long : win_short;  // dsp.rs:83
+            // (the loops below are unrolled by four so that the window loads of four iterations are in flight together:
+            // with a run-time trip count the compiler otherwise waits for each iteration's pair of loads in turn)
             if (pflag == flag) {  // dsp.rs:85-90
                 const int len = bs / 2;
-                for (int k = tid; k < len; k += kVThreads)
+#pragma unroll 4
+                for (int k = tid; k < len; k += kVT)
                     o[k] = sh.overlap[k] * win[len - 1 - k] + sh.pcm[k] * win[k];
             } else if (pflag && !flag) {  // long -> short, dsp.rs:91-106
                 const int start = (bs1 - bs0) / 4, len = bs0 / 2;
-                for (int k = tid; k < start; k += kVThreads) o[k] = sh.overlap[k];
-                for (int k = tid; k < len; k += kVThreads)
+#pragma unroll 4
+                for (int k = tid; k < start; k += kVT) o[k] = sh.overlap[k];
+#pragma unroll 4
+                for (int k = tid; k < len; k += kVT)
                     o[start + k] = sh.overlap[start + k] * win[len - 1 - k] + sh.pcm[k] * win[k];
             } else {  // short -> long, dsp.rs:107-122
                 const int start = (bs1 - bs0) / 4, len = bs0 / 2, end = start + len;
-                for (int k = tid; k < len; k += kVThreads)
+#pragma unroll 4
+                for (int k = tid; k < len; k += kVT)
                     o[k] = sh.overlap[k] * win[len - 1 - k] + sh.pcm[start + k] * win[k];
-                for (int k = tid; k < bs1 / 2 - end; k += kVThreads) o[len + k] = sh.pcm[end + k];
+#pragma unroll 4
+                for (int k = tid; k < bs1 / 2 - end; k += kVT) o[len + k] = sh.pcm[end + k];
             }
         }
         __syncthreads();
-        for (int k = tid; k < bs / 2; k += kVThreads) sh.overlap[k] = sh.pcm[bs / 2 + k];  // dsp.rs:125
+#pragma unroll 4
+        for (int k = tid; k < bs / 2; k += kVT) sh.overlap[k] = sh.pcm[bs / 2 + k];  // dsp.rs:125
         __syncthreads();
     }
 
@@ -181,26 +241,32 @@ __global__ __launch_bounds__(kVThreads) void vorbis_synth_kernel(
             // what the most recent long block left there (dsp.rs:125 only rewrites the first bs/2 entries; never used
             // for PCM, but part of the state the reference carries).  Rebuild it from that block, or keep the incoming
             // state if the batch has no long block before this segment.
-            static_assert(kVThreads == 64, "the search below is one wavefront wide");
-            long bl = -1;  // searched 64 flags at a time: one coalesced byte load + ballot per step
-            for (long base = ((long)b_begin - 1) & ~63l; base >= 0; base -= 64) {
-                const long idx = base + tid;
-                const unsigned long long m = __ballot(idx < (long)b_begin && f[idx] != 0);
-                if (m) {
-                    bl = base + 63 - __builtin_clzll(m);
-                    break;
+            __shared__ long bl_shared;
+            if (tid < 64) {  // the first wavefront searches 64 flags at a time: one coalesced byte load + ballot per step
+                long found = -1;
+                for (long base = ((long)b_begin - 1) & ~63l; base >= 0; base -= 64) {
+                    const long idx = base + tid;
+                    const unsigned long long m = __ballot(idx < (long)b_begin && f[idx] != 0);
+                    if (m) {
+                        found = base + 63 - __builtin_clzll(m);
+                        break;
+                    }
                 }
+                if (tid == 0) bl_shared = found;
             }
+            __syncthreads();
+            const long bl = bl_shared;
             if (bl >= 0) {
-                vorbis_imdct_block<MAXBS>(sh, sp + os[bl], rp ? rp + os[bl] : nullptr, bs1, bs1_exp - 2, tw_long, tb);
-                for (int k = bs0 / 2 + tid; k < bs1 / 2; k += kVThreads) sh.overlap[k] = sh.pcm[bs1 / 2 + k];
+                vorbis_fetch_block<MAXBS>(cur, sp + os[bl], rp ? rp + os[bl] : nullptr, bs1, tw_long);
+                vorbis_imdct_block<MAXBS>(sh, cur, bs1, bs1_exp - 2, tb);
+                for (int k = bs0 / 2 + tid; k < bs1 / 2; k += kVT) sh.overlap[k] = sh.pcm[bs1 / 2 + k];
             } else {
-                for (int k = bs0 / 2 + tid; k < bs1 / 2; k += kVThreads)
+                for (int k = bs0 / 2 + tid; k < bs1 / 2; k += kVT)
                     sh.overlap[k] = overlap_in[(size_t)chain * (size_t)(bs1 / 2) + k];
             }
             __syncthreads();
         }
-        for (int i = tid; i < bs1 / 2; i += kVThreads) overlap_out[(size_t)chain * (size_t)(bs1 / 2) + i] = sh.overlap[i];
+        for (int i = tid; i < bs1 / 2; i += kVT) overlap_out[(size_t)chain * (size_t)(bs1 / 2) + i] = sh.overlap[i];
         if (tid == 0) prev_flag_out[chain] = f[nb - 1] ? 1 : 0;  // lib.rs:328
     }
 }
@@ -492,7 +558,9 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     SYM_TRY(get_vorbis_window(ctx, 1 << bs1_exp, &wl));
     const unsigned nb = (unsigned)blocks_per_chain;
     const bool wave_path = bs0_exp == 8 && bs1_exp == 11;
-    const unsigned seg = choose_segment(ctx, n_chains, nb, wave_path ? 8 : 12, 1, 1, 1);
+    // resident items per CU: eight wavefronts of the wavefront kernel; of the generic one, eight one-wavefront workgroups
+    // (226 VGPRs: two per SIMD) or two 256-thread workgroups (66 KiB of LDS each)
+    const unsigned seg = choose_segment(ctx, n_chains, nb, wave_path ? 8 : (bs1_exp > 11 ? 2 : 8), 1, 1, 1);
     const size_t segs = (nb + seg - 1) / seg;
     const size_t grid = n_chains * segs;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
@@ -510,12 +578,12 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
                        d_prev_in, offs, nb, 1 << bs0_exp, 1 << bs1_exp);
     SYM_GPU(ctx, hipGetLastError());
     if (bs1_exp <= 11) {
-        hipLaunchKernelGGL(vorbis_synth_kernel<2048>, dim3((unsigned)grid), dim3(kVThreads), 0, ctx->stream, ctx->dev,
+        hipLaunchKernelGGL(vorbis_synth_kernel<2048>, dim3((unsigned)grid), dim3(vorbis_threads<2048>()), 0, ctx->stream, ctx->dev,
                            bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
                            d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
                            pcm_stride, (const uint32_t *)offs, nb, seg, (unsigned)segs);
     } else {
-        hipLaunchKernelGGL(vorbis_synth_kernel<8192>, dim3((unsigned)grid), dim3(kVThreads), 0, ctx->stream, ctx->dev,
+        hipLaunchKernelGGL(vorbis_synth_kernel<8192>, dim3((unsigned)grid), dim3(vorbis_threads<8192>()), 0, ctx->stream, ctx->dev,
                            bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
                            d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
                            pcm_stride, (const uint32_t *)offs, nb, seg, (unsigned)segs);

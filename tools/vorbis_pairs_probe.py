@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Throughput of symaccel_vorbis_synth_device for every block-size pair class: the wavefront kernel (256 / 2048) and the
+generic LDS kernel (everything else).  Development tool, run on the GPU box: python tools/vorbis_pairs_probe.py"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import symphonia_amd as sa  # noqa: E402
+
+ctx = sa.Context(0)
+ctx.use_torch_stream()
+
+
+def run(e0, e1, p_ll=0.9, p_ss=0.7):
+    nch = 64
+    nb = max(64, (4096 * 2048) >> e1)  # about the same number of lines per chain for every pair
+    rng = np.random.default_rng(1)
+    flags = np.zeros((nch, nb), np.uint8)
+    cur = np.ones(nch, bool)
+    for b in range(nb):
+        r = rng.random(nch)
+        cur = np.where(cur, r < p_ll, r >= p_ss)
+        flags[:, b] = cur
+    v = sa.VorbisDsp(ctx, e0, e1)
+    so, po = v.layout(flags, np.full(nch, -1))
+    ss, ps = int(so[:, -1].max()), int(po[:, -1].max())
+    spectra = torch.randn((nch, ss), device="cuda") * 0.1
+    dfl = torch.from_numpy(flags).cuda()
+    prev = torch.full((nch,), -1, dtype=torch.int32, device="cuda")
+    ov = torch.zeros((nch, (1 << e1) // 2), device="cuda")
+    pcm = torch.zeros((nch, ps), device="cuda")
+
+    def step():
+        prev.fill_(-1)
+        v.synth(spectra, dfl, prev, ov, ps, pcm)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        step()
+    b.record()
+    torch.cuda.synchronize()
+    t = a.elapsed_time(b) / 10
+    byts = 4 * (so[:, -1].sum() + po[:, -1].sum())
+    print("%4d / %-5d  %6d blocks/chain  long share %.2f  %.3f ms  %.2f TB/s (%.1f %% of 8 TB/s)" % (
+        1 << e0, 1 << e1, nb, flags.mean(), t, byts / t / 1e9, byts / t / 1e9 / 80))
+
+
+for e0, e1 in ((8, 11), (7, 10), (9, 12), (6, 9), (8, 10), (10, 13), (11, 11)):
+    run(e0, e1)
