@@ -1514,8 +1514,8 @@ int so_vorbis_floor0(const float *coeffs, int order, const int32_t *map, uint32_
 void so_vorbis_floor1(const uint32_t *x_list, const uint32_t *yv, int n_posts, int multiplier,
                       uint32_t n, float *floor_out)
 {
-    int lo_n[65], hi_n[65], order[65], flag[65];
-    int32_t final_y[65];
+    int lo_n[65], hi_n[65], order[65] = {0}, flag[65];  /* (order[0] is read below even for an empty post list) */
+    int32_t final_y[65] = {0};
     /* find_neighbors (floor.rs:748-773) for every post; sort order (floor.rs:547-554) */
     for (int x = 0; x < n_posts; x++) {
         uint32_t bound = x_list[x], low = 0, high = 0xffffffffu;
