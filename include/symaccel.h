@@ -370,6 +370,13 @@ int symaccel_vorbis_deinterleave2_device(symaccel_ctx *ctx, const float *d_type2
 int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts,
                                   int multiplier, const uint32_t *d_y, uint32_t n, float *d_floor,
                                   size_t count);
+/* The same with the dot product of lib.rs:282-292 fused into the curve's store: spectrum[i] = floor[i] * residue[i], one
+ * rounded multiply per line (the reference's `*f *= r`), for channels whose residue is decoded.  The curve never goes to
+ * HBM and the separate dot-product pass disappears: feed the result to symaccel_vorbis_synth_*.  d_spectrum may be
+ * d_residue (in place). */
+int symaccel_vorbis_floor1_dot_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
+                                      const uint32_t *d_y, uint32_t n, const float *d_residue, float *d_spectrum,
+                                      size_t count);
 
 /* Floor 0 (floor.rs:124-397) -- HOST functions on HOST memory, for the same reason as symaccel_host_aac_pulse: f64
  * atan / floor and f32 cos / sqrt / exp from libm, in the reference's operation order.  Floor-0 streams are rare (the

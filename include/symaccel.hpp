@@ -114,13 +114,13 @@ namespace fft {
 
 using Complex = std::complex<float>;  // num_complex::Complex<f32>, same (re, im) layout
 
-// Fft (no_simd.rs:70-141).  The reference's MAX_SIZE is 1 << 16; the device path covers what the decoders use.
+// Fft (no_simd.rs:70-141).  MAX_SIZE is the reference's (1 << 16: its permutation table is u16).
 class Fft {
 public:
-    static constexpr std::size_t MAX_SIZE = 4096;
+    static constexpr std::size_t MAX_SIZE = 65536;
     Fft(Context &ctx, std::size_t n) : ctx_(ctx), n_(n) {
         if (n < 2 || (n & (n - 1)) != 0) throw std::invalid_argument("Fft: n must be a power of two (no_simd.rs:77)");
-        if (n > MAX_SIZE) throw Error(Error::Kind::Unsupported, SYMACCEL_ERR_UNSUPPORTED, "Fft: n > 4096");
+        if (n > MAX_SIZE) throw std::invalid_argument("Fft: n > MAX_SIZE (no_simd.rs:80)");
     }
     std::size_t size() const { return n_; }
     // fft_inplace(&mut self, x: &mut [Complex<f32>]) (no_simd.rs:96-118)
@@ -134,6 +134,33 @@ public:
         if (x_len != n_ || y_len != n_) throw std::invalid_argument("Fft::fft: slice lengths (no_simd.rs:122-123)");
         check(symaccel_fft_c32(ctx_.raw(), (int)n_, reinterpret_cast<const float *>(x), reinterpret_cast<float *>(y), 1),
               ctx_.raw());
+    }
+
+private:
+    Context &ctx_;
+    std::size_t n_;
+};
+
+// Ifft (no_simd.rs:143-219): the forward transform between a re <-> im swap on the way in and a swap with the 1 / n scale
+// on the way out.  (As in the reference, fewer than 32 points only permute, swap and scale: its transform() has no case
+// for them.)
+class Ifft {
+public:
+    static constexpr std::size_t MAX_SIZE = 65536;
+    Ifft(Context &ctx, std::size_t n) : ctx_(ctx), n_(n) {
+        if (n < 2 || (n & (n - 1)) != 0) throw std::invalid_argument("Ifft: n must be a power of two (no_simd.rs:152)");
+        if (n > MAX_SIZE) throw std::invalid_argument("Ifft: n > MAX_SIZE (no_simd.rs:155)");
+    }
+    std::size_t size() const { return n_; }
+    // ifft_inplace(&mut self, x: &mut [Complex<f32>]) (no_simd.rs:189-218)
+    void ifft_inplace(Complex *x, std::size_t len) {
+        if (len != n_) throw std::invalid_argument("Ifft::ifft_inplace: slice length (no_simd.rs:191)");
+        check(symaccel_ifft_c32(ctx_.raw(), (int)n_, reinterpret_cast<const float *>(x), reinterpret_cast<float *>(x), 1), ctx_.raw());
+    }
+    // ifft(&mut self, x: &[Complex<f32>], y: &mut [Complex<f32>]) (no_simd.rs:166-187)
+    void ifft(const Complex *x, std::size_t x_len, Complex *y, std::size_t y_len) {
+        if (x_len != n_ || y_len != n_) throw std::invalid_argument("Ifft::ifft: slice lengths (no_simd.rs:168-169)");
+        check(symaccel_ifft_c32(ctx_.raw(), (int)n_, reinterpret_cast<const float *>(x), reinterpret_cast<float *>(y), 1), ctx_.raw());
     }
 
 private:

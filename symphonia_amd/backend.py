@@ -452,10 +452,16 @@ class VorbisDsp:
         self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_deinterleave2_device, _ptr(type2), _ptr(planar), int(n_ch),
                        int(n2), int(count))
 
-    def floor1(self, x_list, multiplier, y, n, floor, count):
+    def floor1(self, x_list, multiplier, y, n, floor, count, residue=None):
+        """floor[count][n] = the floor-1 curve; with `residue`, floor = curve * residue (the dot product fused into the
+        curve's store; `floor` may be `residue`)."""
         xl = _np(x_list, np.uint32)
-        self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_floor1_device, _ptr(xl), xl.size, int(multiplier), _ptr(y),
-                       int(n), _ptr(floor), int(count))
+        if residue is None:
+            self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_floor1_device, _ptr(xl), xl.size, int(multiplier), _ptr(y),
+                           int(n), _ptr(floor), int(count))
+        else:
+            self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_floor1_dot_device, _ptr(xl), xl.size, int(multiplier), _ptr(y),
+                           int(n), _ptr(residue), _ptr(floor), int(count))
 
 
 FLAC_DESC_DTYPE = np.dtype([("kind", np.uint8), ("order", np.uint8), ("shift", np.uint8), ("wasted_bits", np.uint8)])

@@ -653,8 +653,8 @@ int symaccel_vorbis_deinterleave2_device(symaccel_ctx *ctx, const float *d_type2
     return launch_vorbis_deinterleave(ctx, d_type2, d_planar, n_ch, n2, count);
 }
 
-int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
-                                  const uint32_t *d_y, uint32_t n, float *d_floor, size_t count) {
+static int vorbis_floor1(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier, const uint32_t *d_y, uint32_t n,
+                         float *d_floor, size_t count, const float *d_residue) {
     if (!ctx || n_posts < 2 || n_posts > 65 || multiplier < 1 || multiplier > 4) return SYMACCEL_ERR_INVALID_ARG;
     if (count == 0 || n == 0) return SYMACCEL_OK;
     if (!x_list || !d_y || !d_floor) return SYMACCEL_ERR_INVALID_ARG;
@@ -687,7 +687,17 @@ int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int
         if (x_list[i] > 0xffffu) return SYMACCEL_ERR_INVALID_ARG;  // floor1_X values have at most 15 bits (rangebits)
     if (n > 4096u || (n & 15u)) return SYMACCEL_ERR_INVALID_ARG;  // n = blocksize / 2, blocksize = 2^6 .. 2^13 (lib.rs:404-406)
     // the derived tables travel as a kernel argument: no staging copy, no stream synchronisation
-    return launch_vorbis_floor1(ctx, setup, n_posts, multiplier, d_y, n, d_floor, count);
+    return launch_vorbis_floor1(ctx, setup, n_posts, multiplier, d_y, n, d_floor, count, d_residue);
+}
+
+int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
+                                  const uint32_t *d_y, uint32_t n, float *d_floor, size_t count) {
+    return vorbis_floor1(ctx, x_list, n_posts, multiplier, d_y, n, d_floor, count, nullptr);
+}
+int symaccel_vorbis_floor1_dot_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
+                                      const uint32_t *d_y, uint32_t n, const float *d_residue, float *d_spectrum, size_t count) {
+    if (count != 0 && n != 0 && !d_residue) return SYMACCEL_ERR_INVALID_ARG;
+    return vorbis_floor1(ctx, x_list, n_posts, multiplier, d_y, n, d_spectrum, count, d_residue);
 }
 
 // ---- FLAC ---------------------------------------------------------------------------------

@@ -197,7 +197,7 @@ int launch_vorbis_dot(symaccel_ctx *ctx, float *d_floor, const float *d_residue,
 int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d_planar, int n_ch, size_t n2,
                                size_t count);
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier,
-                         const uint32_t *d_y, uint32_t n, float *d_floor, size_t count);
+                         const uint32_t *d_y, uint32_t n, float *d_floor, size_t count, const float *d_residue = nullptr);
 int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d_coeffs, size_t frames_per_chain,
                             const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs);
 int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,

@@ -347,10 +347,11 @@ struct Floor1Setup {  // per floor configuration, derived on the host like the s
 
 constexpr int kF1Stride = 65;  // LDS row stride of the per-block lists [entry][block]: conflict-free both ways
 
+template <bool DOT>
 __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n_posts, int multiplier,
                                                            const uint32_t *__restrict__ yv, uint32_t n,
-                                                           float *__restrict__ floor_out, const float *__restrict__ db,
-                                                           size_t count) {
+                                                           float *floor_out, const float *__restrict__ db,
+                                                           size_t count, const float *residue) {
     // 22 KiB of LDS per wavefront (7 wavefronts per CU): 16-bit tables; the render stage reuses final_y's storage
     __shared__ __attribute__((aligned(16))) int16_t fy[65 * 64];  // final_y[post][lane] (|final_y| < 2^9)
     __shared__ uint16_t segx[67 * kF1Stride];     // first the y values [post][block], then the points' x
@@ -445,6 +446,9 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
     for (int b = 0; b < nb; ++b) {
         const int nsb = __shfl(ns, b);  // points 0 .. nsb of block b
         float *out = floor_out + (blk0 + (size_t)b) * (size_t)n;
+        // fused dot product (lib.rs:282-292): the curve is multiplied by the block's residue as it is stored -- one rounded
+        // multiply per line, the reference's `*f *= r` -- so the curve itself never goes to HBM (residue may be `out`)
+        const float *rin = DOT ? residue + (blk0 + (size_t)b) * (size_t)n : nullptr;
         // segment-start map: mark[x_k] = k + 1 for the points with x_k < n (x values are distinct)
         for (uint32_t i = (uint32_t)lane; i < (n + 3u) / 4u; i += 64) reinterpret_cast<uint32_t *>(mark)[i] = 0u;
         wave_sync_lds();
@@ -456,6 +460,16 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
         int carry = 1;  // segment (index + 1) in force before the current pass; x = 0 always starts segment 0
         for (uint32_t p0 = 0; p0 < n; p0 += 1024) {
             const uint32_t xb = p0 + 16u * (uint32_t)lane;  // this lane's 16 lines
+            // the residue of the float4s this lane will store at the end of the pass, requested now: the render hides the latency
+            float4 rr[4];
+            if constexpr (DOT) {
+                const uint32_t span_p = n - p0 < 1024u ? n - p0 : 1024u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i4 = (uint32_t)lane + 64u * (uint32_t)q;
+                    rr[q] = 4u * i4 < span_p ? reinterpret_cast<const float4 *>(rin + p0)[i4] : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                }
+            }
             uint32_t m[4] = {0u, 0u, 0u, 0u};
             if (xb < n) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(mark + xb);  // (n is a multiple of 16: a power of two >= 32)
@@ -528,7 +542,11 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t i4 = (uint32_t)lane + 64u * (uint32_t)q;
-                    if (4u * i4 < span) d4[i4] = l4[i4];
+                    if (4u * i4 < span) {
+                        float4 v = l4[i4];
+                        if constexpr (DOT) v = make_float4(v.x * rr[q].x, v.y * rr[q].y, v.z * rr[q].z, v.w * rr[q].w);
+                        d4[i4] = v;
+                    }
                 }
             }
             wave_sync_lds();
@@ -617,7 +635,7 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
 }
 
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier, const uint32_t *d_y,
-                         uint32_t n, float *d_floor, size_t count) {
+                         uint32_t n, float *d_floor, size_t count, const float *d_residue) {
     const size_t grid = (count + 63) / 64;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     Floor1Setup st{};  // passed by value: the kernel reads it with scalar loads (wave-uniform indices)
@@ -627,8 +645,12 @@ int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts
         st.hi[i] = (uint8_t)h_setup[130 + i];
         st.order[i] = (uint8_t)h_setup[195 + i];
     }
-    hipLaunchKernelGGL(vorbis_floor1_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, st, n_posts, multiplier, d_y, n,
-                       d_floor, ctx->dev.vorbis_floor1_db, count);
+    if (d_residue)
+        hipLaunchKernelGGL(vorbis_floor1_kernel<true>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, st, n_posts, multiplier, d_y, n,
+                           d_floor, ctx->dev.vorbis_floor1_db, count, d_residue);
+    else
+        hipLaunchKernelGGL(vorbis_floor1_kernel<false>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, st, n_posts, multiplier, d_y, n,
+                           d_floor, ctx->dev.vorbis_floor1_db, count, d_residue);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -85,6 +85,22 @@ static void verify_fft(Context &ctx) {  // dsp/fft/mod.rs:155-186
     float ref[128];
     so_fft(reinterpret_cast<const float *>(x.data()), ref, 64);
     EXPECT(same_bits(ref, reinterpret_cast<const float *>(y.data()), 128), "fft differs from the oracle");
+    // Ifft (no_simd.rs:143-219): against the oracle bit for bit, and ifft(fft(x)) == x to the reference's own 1e-5
+    dsp::fft::Ifft ifft(ctx, 64);
+    ifft.ifft(x.data(), 64, z.data(), 64);
+    so_ifft(reinterpret_cast<const float *>(x.data()), ref, 64);
+    EXPECT(same_bits(ref, reinterpret_cast<const float *>(z.data()), 128), "ifft differs from the oracle");
+    z = y;
+    ifft.ifft_inplace(z.data(), 64);
+    for (int k = 0; k < 64; ++k) EXPECT(std::abs(z[k] - x[k]) < 1e-5f * 32.0f, "ifft(fft(x))[%d]", k);
+    // the reference's limit (1 << 16 points) is the mirror's limit
+    bool threw = false;
+    try {
+        dsp::fft::Fft too_big(ctx, 1u << 17);
+    } catch (const std::invalid_argument &) {
+        threw = true;
+    }
+    EXPECT(threw, "Fft::new accepted more than MAX_SIZE points");
 }
 
 static void verify_aac(Context &ctx) {  // decoder-style: one Dsp::synth per frame (aac/mod.rs:217-220)

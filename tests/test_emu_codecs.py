@@ -214,6 +214,16 @@ def test_emu_vorbis_floor1(emu_ctx):
         v.floor1(xs, mult, ys, n, out, count)
         want = np.stack([oracle.vorbis_floor1(xs, y, mult, n) for y in ys])
         assert bit_equal(out, want), (n, n_posts, mult)
+        # the dot product of lib.rs:282-292 fused into the curve's store: one rounded multiply per line, out of place and
+        # in place on the residue
+        res = (rng.standard_normal((count, n)) * np.exp2(rng.integers(-8, 9, (count, n)))).astype(np.float32)
+        res[0, ::5] = -0.0
+        prod = np.zeros((count, n), np.float32)
+        v.floor1(xs, mult, ys, n, prod, count, residue=res)
+        assert bit_equal(prod, want * res), (n, n_posts, mult)
+        inplace = res.copy()
+        v.floor1(xs, mult, ys, n, inplace, count, residue=inplace)
+        assert bit_equal(inplace, want * res), (n, n_posts, mult)
 
 
 def test_emu_flac_restore(emu_ctx):

@@ -411,7 +411,12 @@ def test_vorbis_helpers_parity(ctx):
         ys[rng.random((cnt, n_posts)) < p_zero] = 0
         out = torch.zeros((cnt, nn), dtype=torch.float32, device="cuda")
         v.floor1(xs, mult, dev(ys), nn, out, cnt)
-        assert_parity(host(out), np.stack([oracle.vorbis_floor1(xs, y, mult, nn) for y in ys]), "floor1")
+        curve = np.stack([oracle.vorbis_floor1(xs, y, mult, nn) for y in ys])
+        assert_parity(host(out), curve, "floor1")
+        res = (rng.standard_normal((cnt, nn)) * np.exp2(rng.integers(-8, 9, (cnt, nn)))).astype(np.float32)
+        d_res = dev(res)
+        v.floor1(xs, mult, dev(ys), nn, d_res, cnt, residue=d_res)  # floor x residue, in place on the residue
+        assert np.array_equal(host(d_res).view(np.uint32), (curve * res).view(np.uint32)), "floor1 x residue"
 
 
 # ------------------------------------------------------------------------------------------ FLAC

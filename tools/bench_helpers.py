@@ -46,6 +46,11 @@ def main():
     fl = torch.empty((262144, n), device="cuda")
     t = timeit(lambda: v.floor1(xs, 2, ys, n, fl, 262144))
     out["vorbis floor-1 render (64 posts -> 1024 lines)"] = fl.numel() * 4 / t
+    rs = torch.randn((262144, n), device="cuda")
+    t = timeit(lambda: v.floor1(xs, 2, ys, n, fl, 262144, residue=rs))
+    out["vorbis floor-1 x residue fused (read 4 B + write 4 B per line; %.2f ms)" % (t * 1e3)] = 2 * fl.numel() * 4 / t
+    t = timeit(lambda: (v.floor1(xs, 2, ys, n, fl, 262144), v.dot_product(fl.view(-1), rs, fl.numel())))
+    out["vorbis floor-1, then dot product: two launches (%.2f ms)" % (t * 1e3)] = 2 * fl.numel() * 4 / t
     fp = sa.FlacPredictor(ctx)
     a = torch.randint(-1000, 1000, (65536, 4096), device="cuda", dtype=torch.int32)
     b = torch.randint(-1000, 1000, (65536, 4096), device="cuda", dtype=torch.int32)
