@@ -345,7 +345,14 @@ struct Floor1Setup {  // per floor configuration, derived on the host like the s
     uint8_t lo[65], hi[65], order[65];
 };
 
-constexpr int kF1Stride = 65;  // LDS row stride of the per-block lists [entry][block]: conflict-free both ways
+// Channel-blocks per wavefront.  Steps 1 and 2a run one lane per block (half the lanes with 32), the render uses all 64
+// lanes on one block at a time either way; what 32 buys is LDS -- 11.8 KiB instead of 22.4 -- i.e. 13 instead of 7
+// wavefronts per CU for a kernel that spends half its time waiting.
+#ifndef SYM_FLOOR1_BLOCKS
+#define SYM_FLOOR1_BLOCKS 32
+#endif
+constexpr int kF1B = SYM_FLOOR1_BLOCKS;
+constexpr int kF1Stride = kF1B + 1;  // LDS row stride of the per-block lists [entry][block]: conflict-free both ways
 
 template <bool DOT>
 __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n_posts, int multiplier,
@@ -353,16 +360,16 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
                                                            float *floor_out, const float *__restrict__ db,
                                                            size_t count, const float *residue) {
     // 22 KiB of LDS per wavefront (7 wavefronts per CU): 16-bit tables; the render stage reuses final_y's storage
-    __shared__ __attribute__((aligned(16))) int16_t fy[65 * 64];  // final_y[post][lane] (|final_y| < 2^9)
+    __shared__ __attribute__((aligned(16))) int16_t fy[65 * kF1B];  // final_y[post][lane] (|final_y| < 2^9)
     __shared__ uint16_t segx[67 * kF1Stride];     // first the y values [post][block], then the points' x
     __shared__ uint8_t segy[67 * kF1Stride];      //                                               ... and y (0..255)
     __shared__ float dbl[256];
-    static_assert(sizeof(int16_t) * 65 * 64 >= 4096 + 4096, "the render buffers alias final_y");
+    static_assert(sizeof(int16_t) * 65 * kF1B >= 4096, "the segment-start map aliases final_y");
     uint8_t *mark = reinterpret_cast<uint8_t *>(fy);            // segment-start map of the block being rendered (n bytes)
-    float *line = reinterpret_cast<float *>(fy) + 1024;         // one pass of rendered lines (1024 floats)
     const int lane = (int)threadIdx.x;
-    const size_t blk0 = (size_t)blockIdx.x * 64;
-    const int nb = (int)(count - blk0 < 64 ? count - blk0 : 64);
+    const size_t blk0 = (size_t)blockIdx.x * kF1B;
+    const int nb = (int)(count - blk0 < (size_t)kF1B ? count - blk0 : (size_t)kF1B);
+    const bool owner = lane < nb;  // this lane runs steps 1 and 2a of block blk0 + lane
 #pragma unroll
     for (int e = 0; e < 4; ++e) dbl[lane + 64 * e] = db[lane + 64 * e];
     // the y rows of the 64 blocks are contiguous: coalesced load, transposed into LDS
@@ -385,11 +392,12 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
         flag_lo |= i < 64 ? (1ull << (i & 63)) : 0ull;
         flag_hi |= i == 64 ? 1u : 0u;
     };
-    fy[0 * 64 + lane] = (int16_t)segx[0 * kF1Stride + lane];
-    fy[1 * 64 + lane] = (int16_t)segx[1 * kF1Stride + lane];
+    if (lane < kF1B) {
+    fy[0 * kF1B + lane] = (int16_t)segx[0 * kF1Stride + lane];
+    fy[1 * kF1B + lane] = (int16_t)segx[1 * kF1Stride + lane];
     for (int i = 2; i < n_posts; ++i) {
         const int lo = st.lo[i], hi = st.hi[i];
-        const int32_t predicted = floor1_render_point(st.x[lo], fy[lo * 64 + lane], st.x[hi], fy[hi * 64 + lane], st.x[i]);
+        const int32_t predicted = floor1_render_point(st.x[lo], fy[lo * kF1B + lane], st.x[hi], fy[hi * kF1B + lane], st.x[i]);
         const int32_t val = (int32_t)segx[i * kF1Stride + lane];
         const int32_t highroom = range - predicted, lowroom = predicted;
         int32_t fin = predicted;
@@ -403,7 +411,8 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
             else
                 fin = (val & 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
         }
-        fy[i * 64 + lane] = (int16_t)fin;
+        fy[i * kF1B + lane] = (int16_t)fin;
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every lane has consumed its y values: segx / segy become the point lists
@@ -411,8 +420,8 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
 
     // ---- synthesis_step2 (floor.rs:627-653), first half: the x-sorted list of line end points of this lane's block
     int ns = 0;
-    {
-        int32_t ly = fy[st.order[0] * 64 + lane] * multiplier;
+    if (lane < kF1B) {
+        int32_t ly = fy[st.order[0] * kF1B + lane] * multiplier;
         ly = ly < 0 ? 0 : (ly > 255 ? 255 : ly);
         segx[0 * kF1Stride + lane] = 0;  // (x = 0, y = ly)
         segy[0 * kF1Stride + lane] = (uint8_t)ly;
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
         for (int k = 1; k < n_posts; ++k) {
             const int i = st.order[k];
             if (i < 64 ? (unsigned)((flag_lo >> (i & 63)) & 1ull) : flag_hi) {
-                hy = fy[i * 64 + lane] * multiplier;
+                hy = fy[i * kF1B + lane] * multiplier;
                 hy = hy < 0 ? 0 : (hy > 255 ? 255 : hy);
                 hx = st.x[i];
                 ++ns;
@@ -460,15 +469,11 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
         int carry = 1;  // segment (index + 1) in force before the current pass; x = 0 always starts segment 0
         for (uint32_t p0 = 0; p0 < n; p0 += 1024) {
             const uint32_t xb = p0 + 16u * (uint32_t)lane;  // this lane's 16 lines
-            // the residue of the float4s this lane will store at the end of the pass, requested now: the render hides the latency
-            float4 rr[4];
+            float4 rr[4];  // their residue, requested now: the render hides the latency
             if constexpr (DOT) {
-                const uint32_t span_p = n - p0 < 1024u ? n - p0 : 1024u;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t i4 = (uint32_t)lane + 64u * (uint32_t)q;
-                    rr[q] = 4u * i4 < span_p ? reinterpret_cast<const float4 *>(rin + p0)[i4] : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-                }
+                for (int q = 0; q < 4; ++q)
+                    rr[q] = xb < n ? reinterpret_cast<const float4 *>(rin + xb)[q] : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             }
             uint32_t m[4] = {0u, 0u, 0u, 0u};
             if (xb < n) {
@@ -529,28 +534,19 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
                 yy = yy < 0 ? 0 : (yy > 255 ? 255 : yy);  // (in range for every rendered x; guards the lanes past the list)
                 res[q] = dbl[yy];
             }
+            // the lane's 16 lines are four float4 of the output (n is a multiple of 16): stored straight from registers --
+            // 64 contiguous bytes per lane, the wavefront's four instructions fill 4 KiB between them (no LDS staging pass)
             if (xb < n) {
-                float4 *o4 = reinterpret_cast<float4 *>(line + 16 * lane);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o4[q] = make_float4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
-            }
-            wave_sync_lds();
-            {
-                const uint32_t span = n - p0 < 1024u ? n - p0 : 1024u;  // lines of this pass
-                const float4 *l4 = reinterpret_cast<const float4 *>(line);
-                float4 *d4 = reinterpret_cast<float4 *>(out + p0);
+                float4 *o4 = reinterpret_cast<float4 *>(out + xb);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint32_t i4 = (uint32_t)lane + 64u * (uint32_t)q;
-                    if (4u * i4 < span) {
-                        float4 v = l4[i4];
-                        if constexpr (DOT) v = make_float4(v.x * rr[q].x, v.y * rr[q].y, v.z * rr[q].z, v.w * rr[q].w);
-                        d4[i4] = v;
-                    }
+                    float4 v = make_float4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
+                    if constexpr (DOT) v = make_float4(v.x * rr[q].x, v.y * rr[q].y, v.z * rr[q].z, v.w * rr[q].w);
+                    o4[q] = v;
                 }
             }
-            wave_sync_lds();
         }
+        wave_sync_lds();  // the next block's segment-start map overwrites this one's
     }
 }
 
@@ -636,7 +632,7 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
 
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier, const uint32_t *d_y,
                          uint32_t n, float *d_floor, size_t count, const float *d_residue) {
-    const size_t grid = (count + 63) / 64;
+    const size_t grid = (count + kF1B - 1) / kF1B;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     Floor1Setup st{};  // passed by value: the kernel reads it with scalar loads (wave-uniform indices)
     for (int i = 0; i < n_posts; ++i) {
