@@ -68,12 +68,60 @@ __device__ __forceinline__ void wg_fft_lds(c32 *lds, int nf, int points, const D
         case 4: fft_chunk_phase<4>(lds, points, tb); break;
         case 8: fft_chunk_phase<8>(lds, points, tb); break;
         case 16: fft_chunk_phase<16>(lds, points, tb); break;
-        default: fft_chunk_phase<32>(lds, points, tb); break;
+        default:
+            // 32 points and more: fft8 on every 8-group with one thread per group, then the fft16 and fft32 combine steps
+            // of every 32-chunk as one pass with eight threads per chunk (k, k + 8, k + 16, k + 24 each) -- the same
+            // butterflies as fft_small_regs<32>, which kept 32 values per thread and only points / 32 threads busy.
+            fft_chunk_phase<8>(lds, points, tb);
+            __syncthreads();
+#pragma unroll 2
+            for (int g = (int)threadIdx.x; g < points / 4; g += (int)blockDim.x) {
+                const int k = g & 7, base = ((g >> 3) << 5) + k;
+                const int i0 = fft_pad(base), i1 = fft_pad(base + 8), i2 = fft_pad(base + 16), i3 = fft_pad(base + 24);
+                const cpx wa = tb.small16[k], wb = tb.small32[k], wc = tb.small32[k + 8];
+                const int fa = tb.small16_form[k], fb = tb.small32_form[k], fc = tb.small32_form[k + 8];
+                c32 a0 = lds[i0], a1 = lds[i1], a2 = lds[i2], a3 = lds[i3];
+                bfly(a0, a1, tw_small(a1, c32{wa.re, wa.im}, fa));  // fft16 combine (no_simd.rs:307-345), both halves of the chunk
+                bfly(a2, a3, tw_small(a3, c32{wa.re, wa.im}, fa));
+                bfly(a0, a2, tw_small(a2, c32{wb.re, wb.im}, fb));  // fft32 combine (no_simd.rs:374-405)
+                bfly(a1, a3, tw_small(a3, c32{wc.re, wc.im}, fc));
+                lds[i0] = a0;
+                lds[i1] = a1;
+                lds[i2] = a2;
+                lds[i3] = a3;
+            }
+            break;
     }
-    // merge passes, step = 32, 64, ..., nf/2 (no_simd.rs:247-279)
-    for (int step = 32; step < nf; step <<= 1) {
+    // merge passes, step = 32, 64, ..., nf/2 (no_simd.rs:247-279).  Two consecutive stages are done per pass through LDS
+    // where two remain: a thread takes the four elements k, k + step, k + 2 step, k + 3 step of a 4 * step block, runs the
+    // two `step` butterflies and then the two `2 * step` butterflies on them in registers -- the reference's operations on
+    // the reference's operands, half the LDS round trips and barriers.
+    int step = 32;
+    for (; 2 * step < nf; step <<= 2) {
+        __syncthreads();
+        const cpx *w1 = tb.fft_merge + (step - 32);      // W_{2 * step}
+        const cpx *w2 = tb.fft_merge + (2 * step - 32);  // W_{4 * step}
+#pragma unroll 2
+        for (int g = (int)threadIdx.x; g < points / 4; g += (int)blockDim.x) {
+            const int k = g & (step - 1);
+            const int base = ((g - k) << 2) + k;
+            const int i0 = fft_pad(base), i1 = fft_pad(base + step), i2 = fft_pad(base + 2 * step), i3 = fft_pad(base + 3 * step);
+            const cpx wa = w1[k], wb = w2[k], wc = w2[k + step];
+            c32 a0 = lds[i0], a1 = lds[i1], a2 = lds[i2], a3 = lds[i3];
+            bfly(a0, a1, c_mul(a1, c32{wa.re, wa.im}));  // stage `step`, blocks of 2 * step
+            bfly(a2, a3, c_mul(a3, c32{wa.re, wa.im}));
+            bfly(a0, a2, c_mul(a2, c32{wb.re, wb.im}));  // stage `2 * step`, blocks of 4 * step
+            bfly(a1, a3, c_mul(a3, c32{wc.re, wc.im}));
+            lds[i0] = a0;
+            lds[i1] = a1;
+            lds[i2] = a2;
+            lds[i3] = a3;
+        }
+    }
+    for (; step < nf; step <<= 1) {  // an odd stage left over
         __syncthreads();
         const cpx *w = tb.fft_merge + (step - 32);  // W_{2*step}: offset (2*step)/2 - 32
+#pragma unroll 4
         for (int b = (int)threadIdx.x; b < points / 2; b += (int)blockDim.x) {
             const int k = b & (step - 1);
             const int e = ((b - k) << 1) + k;  // block start * 2 + k
