@@ -85,7 +85,7 @@ def test_fuzz_vorbis(ctx, it):
                                                                     int(rng.integers(0, nb)))
     else:
         bs0e = int(rng.integers(6, 11))
-        bs1e = int(rng.integers(bs0e, 13))
+        bs1e = int(rng.integers(bs0e, 14))  # up to 8192-sample blocks (lib.rs:404-406)
         flags, prev, spectra, overlap, pcm_stride = vorbis_case(rng, bs0e, bs1e, nch, nb)
     d_prev, d_ov = dev(prev), dev(overlap)
     ctx.set_segment(seg)
@@ -118,6 +118,18 @@ def test_fuzz_flac_alac(ctx, it):
     d_res = dev(res)
     AlacPredictor(ctx).predict(d_res, dev(alac_desc(mode, aorder, ashift, bps).view(np.uint8).reshape(nb, 4)), dev(acoef))
     assert bit_equal(host(d_res), oracle.alac_predict(res, oracle.alac_desc(mode, aorder, ashift, bps), acoef)), (nb, bs)
+    # the instantiation classes of the ALAC kernel: uniform channel depth (24-bit multiplies below 24 bits) x orders <= 8 / any
+    depth = int(rng.choice([16, 20, 23, 24]))
+    small = bool(rng.integers(0, 2))
+    res2 = rng.integers(-(1 << (depth - 2)), 1 << (depth - 2), (nb, bs)).astype(np.int32)
+    res2[::5] = rng.integers(-(1 << 31), 1 << 31, (len(res2[::5]), bs))
+    res2[:, 0] = rng.integers(-(1 << 15), 1 << 15, nb)
+    order2 = (rng.integers(1, 9, nb) if small else rng.choice([4, 8, 12, 16, 31], nb)).astype(np.uint8)
+    d2 = (rng.choice([0, 0, 15], nb).astype(np.uint8), order2, rng.integers(0, 12, nb).astype(np.uint8), np.full(nb, depth, np.uint8))
+    coef2 = rng.integers(-(1 << 15), 1 << 15, (nb, 32)).astype(np.int32)
+    d_res2 = dev(res2)
+    AlacPredictor(ctx).predict(d_res2, dev(alac_desc(*d2).view(np.uint8).reshape(nb, 4)), dev(coef2))
+    assert bit_equal(host(d_res2), oracle.alac_predict(res2, oracle.alac_desc(*d2), coef2)), (nb, bs, depth, small)
 
 
 @pytest.mark.parametrize("it", range(ITERS))
