@@ -317,23 +317,12 @@ __global__ void vorbis_deinterleave_kernel(const float *__restrict__ type2, floa
     }
 }
 
-// floor.rs:776-782
-__device__ __forceinline__ int32_t floor1_render_point(uint32_t x0, int32_t y0, uint32_t x1, int32_t y1,
-                                                       uint32_t x) {
-    const int32_t dy = y1 - y0;
-    const uint32_t adx = x1 - x0;
-    const uint32_t err = (uint32_t)(dy < 0 ? -dy : dy) * (x - x0);
-    const uint32_t off = err / adx;
-    return dy < 0 ? y0 - (int32_t)off : y0 + (int32_t)off;
-}
-
 // Floor-1 curve synthesis (floor.rs:568-653, 776-825).  A wavefront takes 64 channel-blocks:
 //   step 1 (the post-value recurrence over <= 65 posts, with the setup's neighbour tables) runs one LANE per block
 //   -- the post index, neighbours and x values are wave-uniform (kernel arguments, scalar), only the y values differ;
 //   step 2 builds each block's list of line end points (x-sorted, flagged posts only) in LDS;
-//   rendering takes the blocks one after the other, every lane on 16 consecutive x (see the render loop); the integer
-//   DDA of render_line (floor.rs:785-825) has the closed form
-//       y(x) = y0 + base * t + sign * floor(ady * t / adx),   t = x - x0,   ady = |dy| - |base| * adx.
+//   rendering takes the blocks one after the other: one lane per SEGMENT derives the segment's constants once (LDS table),
+//   then every lane renders 16 consecutive x through the closed form of render_line's integer DDA (see the render loop).
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -341,98 +330,114 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 struct Floor1Setup {  // per floor configuration, derived on the host like the setup parser does (floor.rs:540-555)
-    uint16_t x[65];
-    uint8_t lo[65], hi[65], order[65];
+    // Everything a loop iteration needs sits at an address that depends on the loop counter only: the scalar loads of
+    // several iterations go out together instead of lo -> x[lo] chains of dependent round trips.
+    uint32_t nb[65];    // post i: lo | hi << 8 | (x[i] - x[lo]) << 16
+    uint32_t adx[65];   //         x[hi] - x[lo], render_point's divisor ...
+    float inv_adx[65];  //         ... and its reciprocal
+    uint32_t ord[65];   // x-sorted position k: order[k] | x[order[k]] << 16
 };
 
-// Channel-blocks per wavefront.  Steps 1 and 2a run one lane per block (half the lanes with 32), the render uses all 64
-// lanes on one block at a time either way; what 32 buys is LDS -- 11.8 KiB instead of 22.4 -- i.e. 13 instead of 7
-// wavefronts per CU for a kernel that spends half its time waiting.
-#ifndef SYM_FLOOR1_BLOCKS
-#define SYM_FLOOR1_BLOCKS 32
+// A workgroup of four wavefronts takes 64 channel-blocks.  Steps 1 and 2a are a chain of <= 65 dependent posts per block
+// whose instruction count does not depend on how many lanes are busy, so ONE wavefront runs them, a lane per block, for all
+// 64 blocks (the other three wait at the barrier and cost no issue slots); then every wavefront renders 16 of the blocks.
+// Measured (profiles/r02zb_floor1_ab.txt): a wavefront per 16 or 32 blocks doing everything itself spends as many
+// instructions in the post chain as in the render, and the kernel is bound by instruction issue and dependent latency, not
+// by HBM.
+#ifndef SYM_FLOOR1_PROBE
+#define SYM_FLOOR1_PROBE 0
 #endif
-constexpr int kF1B = SYM_FLOOR1_BLOCKS;
-constexpr int kF1Stride = kF1B + 1;  // LDS row stride of the per-block lists [entry][block]: conflict-free both ways
+constexpr int kF1B = 64;                 // channel-blocks per workgroup
+constexpr int kF1Waves = 4;              // wavefronts per workgroup
+constexpr int kF1Stride = kF1B + 1;      // LDS row stride of the per-block lists [entry][block]: conflict-free both ways
 
-template <bool DOT>
-__global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n_posts, int multiplier,
-                                                           const uint32_t *__restrict__ yv, uint32_t n,
-                                                           float *floor_out, const float *__restrict__ db,
-                                                           size_t count, const float *residue) {
-    // 22 KiB of LDS per wavefront (7 wavefronts per CU): 16-bit tables; the render stage reuses final_y's storage
-    __shared__ __attribute__((aligned(16))) int16_t fy[65 * kF1B];  // final_y[post][lane] (|final_y| < 2^9)
+template <bool DOT, int NMAX>
+__global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setup st, int n_posts, int multiplier,
+                                                                      const uint32_t *__restrict__ yv, uint32_t n,
+                                                                      float *floor_out, const float *__restrict__ db,
+                                                                      size_t count, const float *residue) {
+    // LDS per workgroup: 22.4 KiB of shared lists + per wavefront a segment table and a segment-start map (n bytes)
+    __shared__ __attribute__((aligned(16))) int16_t fy[65 * kF1B];  // final_y[post][block] (|final_y| < 2^9)
     __shared__ uint16_t segx[67 * kF1Stride];     // first the y values [post][block], then the points' x
     __shared__ uint8_t segy[67 * kF1Stride];      //                                               ... and y (0..255)
+    __shared__ uint8_t ns_of[kF1B];               // points 0 .. ns_of[b] of block b
     __shared__ float dbl[256];
-    static_assert(sizeof(int16_t) * 65 * kF1B >= 4096, "the segment-start map aliases final_y");
-    uint8_t *mark = reinterpret_cast<uint8_t *>(fy);            // segment-start map of the block being rendered (n bytes)
-    const int lane = (int)threadIdx.x;
+    __shared__ uint4 segc_w[kF1Waves][67];  // per wavefront, of the block it renders: x0 | 4 y0 << 16, +-|dy| / adx, +-0.5 / adx
+    __shared__ __attribute__((aligned(16))) uint8_t mark_w[kF1Waves][NMAX];  // ... and its segment-start map
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint4 *segc = segc_w[wave];
+    uint8_t *mark = mark_w[wave];
     const size_t blk0 = (size_t)blockIdx.x * kF1B;
     const int nb = (int)(count - blk0 < (size_t)kF1B ? count - blk0 : (size_t)kF1B);
-    const bool owner = lane < nb;  // this lane runs steps 1 and 2a of block blk0 + lane
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dbl[lane + 64 * e] = db[lane + 64 * e];
-    // the y rows of the 64 blocks are contiguous: coalesced load, transposed into LDS
+    dbl[tid] = db[tid];
+    // the y rows of the 64 blocks are contiguous: coalesced load by the whole workgroup, transposed into LDS
     {
         const uint32_t *src = yv + blk0 * (size_t)n_posts;
         const int total = nb * n_posts;
-        for (int e = lane; e < total; e += 64) segx[(e % n_posts) * kF1Stride + (e / n_posts)] = (uint16_t)src[e];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- synthesis_step1 (floor.rs:568-625): lane = block
-    const int32_t range = multiplier == 1 ? 256 : multiplier == 2 ? 128 : multiplier == 3 ? 86 : 64;
-    // floor_step2_flag as bits (posts 0 and 1 are always used): 64 bits + one for post 64, set and tested without
-    // indexing an array by a run-time value (that would put the array in scratch memory)
-    unsigned long long flag_lo = 3ull;
-    unsigned flag_hi = 0u;
-    auto set_flag = [&](int i) {
-        flag_lo |= i < 64 ? (1ull << (i & 63)) : 0ull;
-        flag_hi |= i == 64 ? 1u : 0u;
-    };
-    if (lane < kF1B) {
-    fy[0 * kF1B + lane] = (int16_t)segx[0 * kF1Stride + lane];
-    fy[1 * kF1B + lane] = (int16_t)segx[1 * kF1Stride + lane];
-    for (int i = 2; i < n_posts; ++i) {
-        const int lo = st.lo[i], hi = st.hi[i];
-        const int32_t predicted = floor1_render_point(st.x[lo], fy[lo * kF1B + lane], st.x[hi], fy[hi * kF1B + lane], st.x[i]);
-        const int32_t val = (int32_t)segx[i * kF1Stride + lane];
-        const int32_t highroom = range - predicted, lowroom = predicted;
-        int32_t fin = predicted;
-        if (val != 0) {
-            const int32_t room = 2 * (highroom < lowroom ? highroom : lowroom);
-            set_flag(lo);
-            set_flag(hi);
-            set_flag(i);
-            if (val >= room)
-                fin = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
-            else
-                fin = (val & 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
+        // element e = block * n_posts + post; (block, post) advance by 256 elements without a division per element
+        const int dq = 256 / n_posts, dr = 256 % n_posts;
+        int blk = tid / n_posts, post = tid % n_posts;
+        for (int e = tid; e < total; e += 256) {
+            segx[post * kF1Stride + blk] = (uint16_t)src[e];
+            post += dr;
+            blk += dq + (post >= n_posts ? 1 : 0);
+            post -= post >= n_posts ? n_posts : 0;
         }
-        fy[i * kF1B + lane] = (int16_t)fin;
     }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // every lane has consumed its y values: segx / segy become the point lists
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
+#if SYM_FLOOR1_PROBE == 2
+    if (n_posts < 1000) n_posts = 2;
+#endif
+    if (wave == 0) {
+        // ---- synthesis_step1 (floor.rs:568-625): lane = block
+        const int32_t range = multiplier == 1 ? 256 : multiplier == 2 ? 128 : multiplier == 3 ? 86 : 64;
+        // floor_step2_flag as bits (posts 0 and 1 are always used): 64 bits + one for post 64, set and tested without
+        // indexing an array by a run-time value (that would put the array in scratch memory)
+        unsigned long long flag_lo = 3ull;
+        unsigned flag_hi = 0u;
+        fy[0 * kF1B + lane] = (int16_t)segx[0 * kF1Stride + lane];
+        fy[1 * kF1B + lane] = (int16_t)segx[1 * kF1Stride + lane];
+        for (int i = 2; i < n_posts; ++i) {
+            const uint32_t pn = st.nb[i];
+            const int lo = (int)(pn & 255u), hi = (int)((pn >> 8) & 255u);
+            // render_point (floor.rs:776-782): y0 +- |dy| * (x - x0) / adx.  The product is below 2^22 (|dy| < 2^9, x < 2^13), exact
+            // in f32, so the quotient comes from the host's reciprocal, corrected by the exact remainder (off by one at most)
+            const int32_t py0 = fy[lo * kF1B + lane], dy = fy[hi * kF1B + lane] - py0;
+            const int32_t adx = (int32_t)st.adx[i];
+            const int32_t err = __mul24(dy < 0 ? -dy : dy, (int32_t)(pn >> 16));
+            int32_t off = (int32_t)((float)err * st.inv_adx[i]);
+            const int32_t rem = err - __mul24(off, adx);
+            off += (rem >= adx ? 1 : 0) - (rem < 0 ? 1 : 0);
+            const int32_t predicted = dy < 0 ? py0 - off : py0 + off;
+            const int32_t val = (int32_t)segx[i * kF1Stride + lane];
+            // floor.rs:596-621 as selects (the lanes of a wavefront take all the branches anyway)
+            const int32_t highroom = range - predicted, lowroom = predicted;
+            const int32_t room = 2 * (highroom < lowroom ? highroom : lowroom);
+            const int32_t far = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
+            const int32_t near = (val & 1) ? predicted - ((val + 1) >> 1) : predicted + (val >> 1);
+            const int32_t fin = val == 0 ? predicted : (val >= room ? far : near);
+            const unsigned long long used = (lo < 64 ? 1ull << lo : 0ull) | (hi < 64 ? 1ull << hi : 0ull) | (i < 64 ? 1ull << i : 0ull);
+            flag_lo |= val != 0 ? used : 0ull;
+            flag_hi |= (val != 0 && (lo == 64 || hi == 64 || i == 64)) ? 1u : 0u;
+            fy[i * kF1B + lane] = (int16_t)fin;
+        }
+        wave_sync_lds();  // every lane has consumed its y values: segx / segy become the point lists
 
-    // ---- synthesis_step2 (floor.rs:627-653), first half: the x-sorted list of line end points of this lane's block
-    int ns = 0;
-    if (lane < kF1B) {
-        int32_t ly = fy[st.order[0] * kF1B + lane] * multiplier;
+        // ---- synthesis_step2 (floor.rs:627-653), first half: the x-sorted list of line end points of this lane's block
+        int ns = 0;
+        int32_t ly = fy[(st.ord[0] & 255u) * kF1B + lane] * multiplier;
         ly = ly < 0 ? 0 : (ly > 255 ? 255 : ly);
         segx[0 * kF1Stride + lane] = 0;  // (x = 0, y = ly)
         segy[0 * kF1Stride + lane] = (uint8_t)ly;
         uint32_t hx = 0;
         int32_t hy = 0;
         for (int k = 1; k < n_posts; ++k) {
-            const int i = st.order[k];
+            const uint32_t po = st.ord[k];
+            const int i = (int)(po & 255u);
             if (i < 64 ? (unsigned)((flag_lo >> (i & 63)) & 1ull) : flag_hi) {
                 hy = fy[i * kF1B + lane] * multiplier;
                 hy = hy < 0 ? 0 : (hy > 255 ? 255 : hy);
-                hx = st.x[i];
+                hx = po >> 16;
                 ++ns;
                 segx[ns * kF1Stride + lane] = (uint16_t)hx;
                 segy[ns * kF1Stride + lane] = (uint8_t)hy;
@@ -443,17 +448,18 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
             segx[ns * kF1Stride + lane] = (uint16_t)n;
             segy[ns * kF1Stride + lane] = (uint8_t)hy;
         }
+        ns_of[lane] = (uint8_t)ns;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
 
-    // ---- render_line for every segment (floor.rs:785-825), block after block.  Lane l renders 16 consecutive x of
-    // each 1024-line pass; which segment an x belongs to comes from a byte map of the segment starts (scattered by the
-    // lanes that hold the points, then a prefix-max: 6 cross-lane steps per pass instead of a dependent list walk per
-    // x); the pass is staged in LDS and stored with 16-byte, fully coalesced stores.
-    for (int b = 0; b < nb; ++b) {
-        const int nsb = __shfl(ns, b);  // points 0 .. nsb of block b
+    // ---- render_line for every segment (floor.rs:785-825): wavefront w takes blocks w, w + 4, ... one after the other.
+    // Which segment an x belongs to comes from a byte map of the segment starts (scattered by the lanes that hold the
+    // points); the segments' constants from a table built one lane per segment.
+#if SYM_FLOOR1_PROBE == 1
+    if (n_posts < 1000) { if (tid < nb) floor_out[(blk0 + tid) * (size_t)n] = (float)ns_of[tid]; return; }
+#endif
+    for (int b = wave; b < nb; b += kF1Waves) {
+        const int nsb = (int)ns_of[b];  // points 0 .. nsb of block b
         float *out = floor_out + (blk0 + (size_t)b) * (size_t)n;
         // fused dot product (lib.rs:282-292): the curve is multiplied by the block's residue as it is stored -- one rounded
         // multiply per line, the reference's `*f *= r` -- so the curve itself never goes to HBM (residue may be `out`)
@@ -461,89 +467,82 @@ __global__ __launch_bounds__(64) void vorbis_floor1_kernel(Floor1Setup st, int n
         // segment-start map: mark[x_k] = k + 1 for the points with x_k < n (x values are distinct)
         for (uint32_t i = (uint32_t)lane; i < (n + 3u) / 4u; i += 64) reinterpret_cast<uint32_t *>(mark)[i] = 0u;
         wave_sync_lds();
+        // ... and the constants of segment k (point k to point k + 1), one lane per segment.  The integer DDA of render_line
+        // (floor.rs:785-825: y += base every x, one more step of sign(dy) whenever err overflows adx) has the closed form
+        //     y(x) = y0 + sign(dy) * floor(|dy| * t / adx),   t = x - x0 < adx
+        // (base * t + sign * floor(ady * t / adx) with base = sign * floor(|dy| / adx), ady = |dy| mod adx), and the floor is
+        //     trunc(f32(t) * slope + half),   slope = f32(|dy|) / f32(adx),   half = 0.5f / f32(adx)      (both rounded)
+        // EXACTLY: |dy| * t / adx + 0.5 / adx is at least 0.5 / adx away from an integer on either side, the three roundings
+        // move the value by less than 255 * 3 * 2^-24 < 0.5 / 8192.  tests/cpp/floor1_division_check.c walks every
+        // (adx <= 4096, |dy| <= 255, t < adx).  The sign goes into slope and half (the conversion truncates towards zero).
         for (int k = lane; k <= nsb; k += 64) {
+            const int k1 = k + 1 <= nsb ? k + 1 : k;
             const uint32_t xk = segx[k * kF1Stride + b];
             if (xk < n) mark[xk] = (uint8_t)(k + 1);
+            const int32_t y0 = (int32_t)segy[k * kF1Stride + b];
+            const int32_t dy = (int32_t)segy[k1 * kF1Stride + b] - y0;
+            int32_t adx = (int32_t)segx[k1 * kF1Stride + b] - (int32_t)xk;
+            adx = adx > 0 ? adx : 1;
+#if SYM_FLOOR1_PROBE == 4
+            const float fadx = 1.0f;
+#else
+            const float fadx = (float)adx;
+#endif
+            segc[k] = make_uint4(xk | ((uint32_t)y0 << 18), __float_as_uint((float)dy / fadx),
+                                 __float_as_uint((dy < 0 ? -0.5f : 0.5f) / fadx), 0u);
         }
         wave_sync_lds();
         int carry = 1;  // segment (index + 1) in force before the current pass; x = 0 always starts segment 0
-        for (uint32_t p0 = 0; p0 < n; p0 += 1024) {
-            const uint32_t xb = p0 + 16u * (uint32_t)lane;  // this lane's 16 lines
-            float4 rr[4];  // their residue, requested now: the render hides the latency
+        // 256 lines per step: lane l renders x = p0 + 4 l .. + 3, so that a store instruction writes 1 KiB without a gap
+        // (16 consecutive x per lane left every 64-byte unit of a store three quarters empty: four times the write requests)
+#pragma unroll 4
+        for (uint32_t p0 = 0; p0 < n; p0 += 256) {
+            const uint32_t xb = p0 + 4u * (uint32_t)lane;  // this lane's four lines (n is a multiple of 16)
+            const bool inside = xb < n;
+            float4 rr = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // their residue, requested now: the render hides the latency
             if constexpr (DOT) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    rr[q] = xb < n ? reinterpret_cast<const float4 *>(rin + xb)[q] : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                if (inside) rr = *reinterpret_cast<const float4 *>(rin + xb);
             }
-            uint32_t m[4] = {0u, 0u, 0u, 0u};
-            if (xb < n) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(mark + xb);  // (n is a multiple of 16: a power of two >= 32)
-                m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
+            const uint32_t m = inside ? *reinterpret_cast<const uint32_t *>(mark + xb) : 0u;
+            // the segment in force just before the lane's first x: the highest mark below it.  Marks grow with x, so that is
+            // the last mark of the nearest lower lane that holds one -- a ballot and one lane read, no scan
+            const int v0 = (int)(m & 255u), v1 = (int)((m >> 8) & 255u), v2 = (int)((m >> 16) & 255u), v3 = (int)(m >> 24);
+            const int mine = max(max(v0, v1), max(v2, v3));
+            const unsigned long long holders = __ballot(mine != 0);
+            const unsigned long long below = holders & ((1ull << lane) - 1ull);
+            const int before = __shfl(mine, below ? 63 - __builtin_clzll(below) : lane);
+            int seg_id = (below && before > carry) ? before : carry;  // (index + 1) of the segment
+            if (holders) {
+                const int last = __shfl(mine, 63 - __builtin_clzll(holders));
+                carry = last > carry ? last : carry;
             }
-            // highest mark in the lane's 16 bytes (marks grow with x), then an exclusive prefix-max across the lanes
-            int mine = 0;
+            // The lane keeps its segment's constants in registers and re-reads the table only at an x that starts a segment
+            // (an exec-masked LDS read of the few lanes concerned)
+            seg_id = v0 > seg_id ? v0 : seg_id;
+            uint4 c = segc[seg_id - 1];
+            float res[4];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int v = (int)((m[q >> 2] >> (8 * (q & 3))) & 255u);
-                mine = v > mine ? v : mine;
+            for (int q = 0; q < 4; ++q) {
+                const int v = q == 1 ? v1 : (q == 2 ? v2 : v3);
+                if (q > 0 && v != 0) c = segc[v - 1];
+                const int32_t t = (int32_t)(xb + (uint32_t)q) - (int32_t)(c.x & 0xffffu);
+                const int32_t steps = (int32_t)((float)t * __uint_as_float(c.y) + __uint_as_float(c.z));
+                int32_t y4 = (int32_t)(c.x >> 16) + (steps << 2);  // byte offset of the table entry (y0 sits at bit 18)
+                y4 = y4 < 0 ? 0 : (y4 > 1020 ? 1020 : y4);        // (in range for every rendered x; guards the lanes past the list)
+#if SYM_FLOOR1_PROBE == 6
+                res[q] = __int_as_float(y4);
+#else
+                res[q] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dbl) + y4);
+#endif
             }
-            int incl = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(incl, (unsigned)d);
-                incl = (lane >= d && o > incl) ? o : incl;
-            }
-            int before = __shfl_up(incl, 1u);
-            before = lane == 0 ? 0 : before;
-            int seg_id = before > carry ? before : carry;  // (index + 1) of the segment in force just before x = xb
-            const int last = __shfl(incl, 63);
-            carry = last > carry ? last : carry;
-            // per-segment constants of the DDA: y(x) = y0 + base * t + sign * floor(ady * t / adx), t = x - x0
-            int32_t x0 = 0, y0 = 0, base = 0, ady = 0, adx = 1, sgn = 1, x1 = 0;
-            float inv = 1.0f;
-            int loaded = 0;
-            float res[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int v = (int)((m[q >> 2] >> (8 * (q & 3))) & 255u);
-                seg_id = v ? v : seg_id;
-                if (seg_id != loaded) {
-                    const int k = seg_id - 1, k1 = k + 1 <= nsb ? k + 1 : k;
-                    x0 = (int32_t)segx[k * kF1Stride + b];
-                    y0 = (int32_t)segy[k * kF1Stride + b];
-                    x1 = (int32_t)segx[k1 * kF1Stride + b];
-                    const int32_t dy = (int32_t)segy[k1 * kF1Stride + b] - y0;
-                    adx = x1 - x0;
-                    adx = adx > 0 ? adx : 1;
-                    base = dy / adx;
-                    ady = (dy < 0 ? -dy : dy) - (base < 0 ? -base : base) * adx;
-                    sgn = dy < 0 ? -1 : 1;
-                    inv = 1.0f / (float)adx;
-                    loaded = seg_id;
-                }
-                const int32_t t = (int32_t)(xb + (uint32_t)q) - x0;
-                // steps = floor(ady * t / adx): ady * t < 2^21 is exact in f32; the reciprocal estimate is off by at most
-                // one, corrected with the exact integer remainder
-                const int32_t num = ady * t;
-                int32_t steps = (int32_t)((float)num * inv);
-                int32_t rem = num - steps * adx;
-                steps += rem >= adx ? 1 : 0;
-                rem -= rem >= adx ? adx : 0;
-                steps -= rem < 0 ? 1 : 0;
-                int32_t yy = y0 + base * t + sgn * steps;
-                yy = yy < 0 ? 0 : (yy > 255 ? 255 : yy);  // (in range for every rendered x; guards the lanes past the list)
-                res[q] = dbl[yy];
-            }
-            // the lane's 16 lines are four float4 of the output (n is a multiple of 16): stored straight from registers --
-            // 64 contiguous bytes per lane, the wavefront's four instructions fill 4 KiB between them (no LDS staging pass)
-            if (xb < n) {
-                float4 *o4 = reinterpret_cast<float4 *>(out + xb);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v = make_float4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
-                    if constexpr (DOT) v = make_float4(v.x * rr[q].x, v.y * rr[q].y, v.z * rr[q].z, v.w * rr[q].w);
-                    o4[q] = v;
-                }
+#if SYM_FLOOR1_PROBE == 3
+            if (inside && res[0] == 12345.0f) {
+#else
+            if (inside) {
+#endif
+                float4 v = make_float4(res[0], res[1], res[2], res[3]);
+                if constexpr (DOT) v = make_float4(v.x * rr.x, v.y * rr.y, v.z * rr.z, v.w * rr.w);
+                *reinterpret_cast<float4 *>(out + xb) = v;
             }
         }
         wave_sync_lds();  // the next block's segment-start map overwrites this one's
@@ -635,18 +634,27 @@ int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts
     const size_t grid = (count + kF1B - 1) / kF1B;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     Floor1Setup st{};  // passed by value: the kernel reads it with scalar loads (wave-uniform indices)
-    for (int i = 0; i < n_posts; ++i) {
-        st.x[i] = (uint16_t)h_setup[i];
-        st.lo[i] = (uint8_t)h_setup[65 + i];
-        st.hi[i] = (uint8_t)h_setup[130 + i];
-        st.order[i] = (uint8_t)h_setup[195 + i];
+    for (int k = 0; k < n_posts; ++k) {
+        const uint32_t i = h_setup[195 + k] & 255u;
+        st.ord[k] = i | (h_setup[i] & 0xffffu) << 16;
     }
-    if (d_residue)
-        hipLaunchKernelGGL(vorbis_floor1_kernel<true>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, st, n_posts, multiplier, d_y, n,
-                           d_floor, ctx->dev.vorbis_floor1_db, count, d_residue);
-    else
-        hipLaunchKernelGGL(vorbis_floor1_kernel<false>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, st, n_posts, multiplier, d_y, n,
-                           d_floor, ctx->dev.vorbis_floor1_db, count, d_residue);
+    for (int i = 2; i < n_posts; ++i) {
+        const uint32_t lo = h_setup[65 + i] & 255u, hi = h_setup[130 + i] & 255u;
+        const int adx = (int)h_setup[hi] - (int)h_setup[lo];  // > 0: the wrapper checked that the x values are distinct
+        st.nb[i] = lo | hi << 8 | ((h_setup[i] - h_setup[lo]) & 0xffffu) << 16;
+        st.adx[i] = (uint32_t)(adx > 0 ? adx : 1);
+        st.inv_adx[i] = 1.0f / (float)(adx > 0 ? adx : 1);
+    }
+    // instantiated per block class: the segment-start map is n bytes of LDS, and LDS is what bounds the resident wavefronts
+#define SYM_F1_LAUNCH(DOT, NMAX)                                                                                                     \
+    hipLaunchKernelGGL((vorbis_floor1_kernel<DOT, NMAX>), dim3((unsigned)grid), dim3(64 * kF1Waves), 0, ctx->stream, st, n_posts, multiplier, d_y, \
+                       n, d_floor, ctx->dev.vorbis_floor1_db, count, d_residue)
+    if (d_residue) {
+        if (n <= 1024) SYM_F1_LAUNCH(true, 1024); else SYM_F1_LAUNCH(true, 4096);
+    } else {
+        if (n <= 1024) SYM_F1_LAUNCH(false, 1024); else SYM_F1_LAUNCH(false, 4096);
+    }
+#undef SYM_F1_LAUNCH
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

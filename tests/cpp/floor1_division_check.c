@@ -1,0 +1,33 @@
+/* Exhaustive check of the closed form the floor-1 render kernel uses for render_line's integer DDA (vorbis.hip,
+ * vorbis_floor1_kernel; reference: symphonia-codec-vorbis/src/floor.rs:785-825):
+ *     floor(|dy| * t / adx) == trunc(f32(t) * slope + half),  slope = f32(|dy|) / f32(adx),  half = 0.5f / f32(adx)
+ * for every adx <= maxadx (argv[1], default 4096 = the largest n the ABI accepts), |dy| <= 255, 0 <= t < adx, and for the
+ * negated slope / half (dy < 0: the conversion truncates towards zero).  Plain IEEE f32 operations, no contraction: the
+ * same arithmetic the device executes.  tests/test_vorbis_floor1_closed_form.py builds and runs it.  */
+#include <stdio.h>
+#include <stdlib.h>
+int main(int argc, char **argv) {
+    int maxadx = argc > 1 ? atoi(argv[1]) : 4096;
+    long bad = 0, total = 0;
+    for (int adx = 1; adx <= maxadx; ++adx) {
+        volatile float fadx = (float)adx;
+        float hinv = 0.5f / fadx;
+        for (int ady = 0; ady <= 255; ++ady) {
+            float slope = (float)ady / fadx;
+            for (int t = 0; t < adx; ++t) {
+                volatile float p = (float)t * slope;
+                volatile float q = p + hinv;
+                int s = (int)q;
+                int want = (int)(((long)ady * t) / adx);
+                bad += s != want;
+                ++total;
+                // negative direction: trunc toward zero of the negated expression
+                volatile float pn = (float)t * (-slope);
+                volatile float qn = pn + (-hinv);
+                bad += (int)qn != -want;
+            }
+        }
+    }
+    printf("maxadx %d total %ld bad %ld\n", maxadx, total, bad);
+    return bad != 0;
+}

@@ -46,6 +46,11 @@ def main():
     fl = torch.empty((262144, n), device="cuda")
     t = timeit(lambda: v.floor1(xs, 2, ys, n, fl, 262144))
     out["vorbis floor-1 render (64 posts -> 1024 lines)"] = fl.numel() * 4 / t
+    rng = np.random.default_rng(5)
+    xs_irr = [0, n] + sorted(rng.permutation(np.arange(1, n))[:62].tolist())  # 64 posts at irregular x (the usual case)
+    ys_irr = torch.randint(0, 128, (262144, len(xs_irr)), device="cuda", dtype=torch.int32)
+    t = timeit(lambda: v.floor1(xs_irr, 2, ys_irr, n, fl, 262144))
+    out["vorbis floor-1 render, irregular post positions"] = fl.numel() * 4 / t
     rs = torch.randn((262144, n), device="cuda")
     t = timeit(lambda: v.floor1(xs, 2, ys, n, fl, 262144, residue=rs))
     out["vorbis floor-1 x residue fused (read 4 B + write 4 B per line; %.2f ms)" % (t * 1e3)] = 2 * fl.numel() * 4 / t
