@@ -332,9 +332,9 @@ __device__ __forceinline__ void wave_sync_lds() {
 struct Floor1Setup {  // per floor configuration, derived on the host like the setup parser does (floor.rs:540-555)
     // Everything a loop iteration needs sits at an address that depends on the loop counter only: the scalar loads of
     // several iterations go out together instead of lo -> x[lo] chains of dependent round trips.
-    uint32_t nb[65];    // post i: lo | hi << 8 | (x[i] - x[lo]) << 16
-    uint32_t adx[65];   //         x[hi] - x[lo], render_point's divisor ...
-    float inv_adx[65];  //         ... and its reciprocal
+    uint32_t nb[65];    // post i: lo | hi << 8 (floor1_x_list_neighbors)
+    float ratio[65];    //         (x[i] - x[lo]) / (x[hi] - x[lo]) and
+    float half[65];     //         0.5 / (x[hi] - x[lo]), both rounded to f32: render_point in closed form (see step 1)
     uint32_t ord[65];   // x-sorted position k: order[k] | x[order[k]] << 16
 };
 
@@ -356,17 +356,22 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
                                                                       const uint32_t *__restrict__ yv, uint32_t n,
                                                                       float *floor_out, const float *__restrict__ db,
                                                                       size_t count, const float *residue) {
-    // LDS per workgroup: 22.4 KiB of shared lists + per wavefront a segment table and a segment-start map (n bytes)
-    __shared__ __attribute__((aligned(16))) int16_t fy[65 * kF1B];  // final_y[post][block] (|final_y| < 2^9)
+    // LDS per workgroup: 13 KiB of point lists + 8.2 KiB (n <= 1024; 20 KiB otherwise) that first hold final_y and then, per
+    // wavefront, a segment table and a segment-start map (n bytes): 22.6 KiB, seven workgroups per CU
+    constexpr int kPerWave = 67 * 16 + NMAX;  // bytes
+    constexpr int kOverlay = 65 * kF1B * 2 > kF1Waves * kPerWave ? 65 * kF1B * 2 : kF1Waves * kPerWave;
+    __shared__ __attribute__((aligned(16))) uint8_t overlay[kOverlay];
     __shared__ uint16_t segx[67 * kF1Stride];     // first the y values [post][block], then the points' x
     __shared__ uint8_t segy[67 * kF1Stride];      //                                               ... and y (0..255)
     __shared__ uint8_t ns_of[kF1B];               // points 0 .. ns_of[b] of block b
+    __shared__ unsigned long long used_lo[kF1B];  // floor_step2_flag of posts 0..63 ...
+    __shared__ uint8_t used_hi[kF1B];             // ... and of post 64
     __shared__ float dbl[256];
-    __shared__ uint4 segc_w[kF1Waves][67];  // per wavefront, of the block it renders: x0 | 4 y0 << 16, +-|dy| / adx, +-0.5 / adx
-    __shared__ __attribute__((aligned(16))) uint8_t mark_w[kF1Waves][NMAX];  // ... and its segment-start map
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint4 *segc = segc_w[wave];
-    uint8_t *mark = mark_w[wave];
+    int16_t *fy = reinterpret_cast<int16_t *>(overlay);  // final_y[post][block] (|final_y| < 2^9), steps 1 and 2a
+    // the render's: constants of the segments of the block being rendered (x0 | 4 y0 << 16, +-|dy| / adx, +-0.5 / adx) ...
+    uint4 *segc = reinterpret_cast<uint4 *>(overlay + wave * kPerWave);
+    uint8_t *mark = overlay + wave * kPerWave + 67 * 16;  // ... and its segment-start map
     const size_t blk0 = (size_t)blockIdx.x * kF1B;
     const int nb = (int)(count - blk0 < (size_t)kF1B ? count - blk0 : (size_t)kF1B);
     dbl[tid] = db[tid];
@@ -388,40 +393,67 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
 #if SYM_FLOOR1_PROBE == 2
     if (n_posts < 1000) n_posts = 2;
 #endif
-    if (wave == 0) {
-        // ---- synthesis_step1 (floor.rs:568-625): lane = block
-        const int32_t range = multiplier == 1 ? 256 : multiplier == 2 ? 128 : multiplier == 3 ? 86 : 64;
-        // floor_step2_flag as bits (posts 0 and 1 are always used): 64 bits + one for post 64, set and tested without
+    if (wave == 1) {
+        // floor_step2_flag (floor.rs:599-601): a property of the y values alone, so a second wavefront derives it while the
+        // first walks the post chain.  Bits (posts 0 and 1 are always used): 64 + one for post 64, set and tested without
         // indexing an array by a run-time value (that would put the array in scratch memory)
         unsigned long long flag_lo = 3ull;
         unsigned flag_hi = 0u;
-        fy[0 * kF1B + lane] = (int16_t)segx[0 * kF1Stride + lane];
-        fy[1 * kF1B + lane] = (int16_t)segx[1 * kF1Stride + lane];
+#pragma unroll 4
         for (int i = 2; i < n_posts; ++i) {
             const uint32_t pn = st.nb[i];
             const int lo = (int)(pn & 255u), hi = (int)((pn >> 8) & 255u);
-            // render_point (floor.rs:776-782): y0 +- |dy| * (x - x0) / adx.  The product is below 2^22 (|dy| < 2^9, x < 2^13), exact
-            // in f32, so the quotient comes from the host's reciprocal, corrected by the exact remainder (off by one at most)
-            const int32_t py0 = fy[lo * kF1B + lane], dy = fy[hi * kF1B + lane] - py0;
-            const int32_t adx = (int32_t)st.adx[i];
-            const int32_t err = __mul24(dy < 0 ? -dy : dy, (int32_t)(pn >> 16));
-            int32_t off = (int32_t)((float)err * st.inv_adx[i]);
-            const int32_t rem = err - __mul24(off, adx);
-            off += (rem >= adx ? 1 : 0) - (rem < 0 ? 1 : 0);
-            const int32_t predicted = dy < 0 ? py0 - off : py0 + off;
-            const int32_t val = (int32_t)segx[i * kF1Stride + lane];
-            // floor.rs:596-621 as selects (the lanes of a wavefront take all the branches anyway)
+            const bool coded = segx[i * kF1Stride + lane] != 0;
+            const unsigned long long used = (lo < 64 ? 1ull << lo : 0ull) | (hi < 64 ? 1ull << hi : 0ull) | (i < 64 ? 1ull << i : 0ull);
+            flag_lo |= coded ? used : 0ull;
+            flag_hi |= (coded && (lo == 64 || hi == 64 || i == 64)) ? 1u : 0u;
+        }
+        used_lo[lane] = flag_lo;
+        used_hi[lane] = (uint8_t)flag_hi;
+    }
+    if (wave == 0) {
+        // ---- synthesis_step1 (floor.rs:568-625): lane = block.  The chain from one post to the next is what this phase costs
+        // (each post needs final_y of two earlier ones), so what does not depend on it -- the post's constants (scalar loads)
+        // and its y value -- is requested one post ahead, and the chain itself is as short as it gets:
+        // render_point (floor.rs:776-782) is y0 +- floor(|dy| * (x - x0) / adx), and
+        //     floor(|dy| * dx / adx) == trunc(f32(|dy|) * ratio + half),   ratio = f32(dx) / f32(adx), half = 0.5f / f32(adx)
+        // exactly for |dy| <= 511 (final_y stays within -42 .. 255) and adx <= 4096 (tests/cpp/floor1_division_check.c);
+        // the sign of dy goes into both terms (the conversion truncates towards zero).
+        const int32_t range = multiplier == 1 ? 256 : multiplier == 2 ? 128 : multiplier == 3 ? 86 : 64;
+        fy[0 * kF1B + lane] = (int16_t)segx[0 * kF1Stride + lane];
+        fy[1 * kF1B + lane] = (int16_t)segx[1 * kF1Stride + lane];
+        uint32_t pn_next = st.nb[2];
+        float ratio_next = st.ratio[2], half_next = st.half[2];
+        int32_t val_next = (int32_t)segx[2 * kF1Stride + lane];
+        for (int i = 2; i < n_posts; ++i) {
+            const uint32_t pn = pn_next;
+            const int32_t val = val_next;
+            const float ratio = ratio_next, half = half_next;
+            {
+                const int j = i + 1 < n_posts ? i + 1 : i;
+                pn_next = st.nb[j];
+                ratio_next = st.ratio[j];
+                half_next = st.half[j];
+                val_next = (int32_t)segx[j * kF1Stride + lane];
+            }
+            const int lo = (int)(pn & 255u), hi = (int)((pn >> 8) & 255u);
+            const int32_t py0 = fy[lo * kF1B + lane];
+            const float fdy = (float)(fy[hi * kF1B + lane] - py0);
+            const int32_t predicted = py0 + (int32_t)(fdy * ratio + __builtin_copysignf(half, fdy));
+            // floor.rs:596-621 as selects (the lanes of a wavefront take all the branches anyway); lowroom = predicted, so
+            // `val - lowroom + predicted` is val and `predicted - val + highroom - 1` is range - val - 1
             const int32_t highroom = range - predicted, lowroom = predicted;
             const int32_t room = 2 * (highroom < lowroom ? highroom : lowroom);
-            const int32_t far = highroom > lowroom ? val - lowroom + predicted : predicted - val + highroom - 1;
+            const int32_t far = highroom > lowroom ? val : range - val - 1;
             const int32_t near = (val & 1) ? predicted - ((val + 1) >> 1) : predicted + (val >> 1);
             const int32_t fin = val == 0 ? predicted : (val >= room ? far : near);
-            const unsigned long long used = (lo < 64 ? 1ull << lo : 0ull) | (hi < 64 ? 1ull << hi : 0ull) | (i < 64 ? 1ull << i : 0ull);
-            flag_lo |= val != 0 ? used : 0ull;
-            flag_hi |= (val != 0 && (lo == 64 || hi == 64 || i == 64)) ? 1u : 0u;
             fy[i * kF1B + lane] = (int16_t)fin;
         }
-        wave_sync_lds();  // every lane has consumed its y values: segx / segy become the point lists
+    }
+    __syncthreads();  // final_y and the flags are complete; every lane has consumed its y values: segx / segy become the point lists
+    if (wave == 0) {
+        const unsigned long long flag_lo = used_lo[lane];
+        const unsigned flag_hi = used_hi[lane];
 
         // ---- synthesis_step2 (floor.rs:627-653), first half: the x-sorted list of line end points of this lane's block
         int ns = 0;
@@ -431,12 +463,15 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
         segy[0 * kF1Stride + lane] = (uint8_t)ly;
         uint32_t hx = 0;
         int32_t hy = 0;
+        // (the reads do not depend on the list being built: unrolled, their latencies overlap)
+#pragma unroll 4
         for (int k = 1; k < n_posts; ++k) {
             const uint32_t po = st.ord[k];
             const int i = (int)(po & 255u);
+            int32_t py = fy[i * kF1B + lane] * multiplier;
+            py = py < 0 ? 0 : (py > 255 ? 255 : py);
             if (i < 64 ? (unsigned)((flag_lo >> (i & 63)) & 1ull) : flag_hi) {
-                hy = fy[i * kF1B + lane] * multiplier;
-                hy = hy < 0 ? 0 : (hy > 255 ? 255 : hy);
+                hy = py;
                 hx = po >> 16;
                 ++ns;
                 segx[ns * kF1Stride + lane] = (uint16_t)hx;
@@ -493,56 +528,64 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
         }
         wave_sync_lds();
         int carry = 1;  // segment (index + 1) in force before the current pass; x = 0 always starts segment 0
-        // 256 lines per step: lane l renders x = p0 + 4 l .. + 3, so that a store instruction writes 1 KiB without a gap
-        // (16 consecutive x per lane left every 64-byte unit of a store three quarters empty: four times the write requests)
-#pragma unroll 4
-        for (uint32_t p0 = 0; p0 < n; p0 += 256) {
-            const uint32_t xb = p0 + 4u * (uint32_t)lane;  // this lane's four lines (n is a multiple of 16)
-            const bool inside = xb < n;
-            float4 rr = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // their residue, requested now: the render hides the latency
-            if constexpr (DOT) {
-                if (inside) rr = *reinterpret_cast<const float4 *>(rin + xb);
-            }
-            const uint32_t m = inside ? *reinterpret_cast<const uint32_t *>(mark + xb) : 0u;
-            // the segment in force just before the lane's first x: the highest mark below it.  Marks grow with x, so that is
-            // the last mark of the nearest lower lane that holds one -- a ballot and one lane read, no scan
-            const int v0 = (int)(m & 255u), v1 = (int)((m >> 8) & 255u), v2 = (int)((m >> 16) & 255u), v3 = (int)(m >> 24);
-            const int mine = max(max(v0, v1), max(v2, v3));
-            const unsigned long long holders = __ballot(mine != 0);
-            const unsigned long long below = holders & ((1ull << lane) - 1ull);
-            const int before = __shfl(mine, below ? 63 - __builtin_clzll(below) : lane);
-            int seg_id = (below && before > carry) ? before : carry;  // (index + 1) of the segment
-            if (holders) {
-                const int last = __shfl(mine, 63 - __builtin_clzll(holders));
-                carry = last > carry ? last : carry;
-            }
-            // The lane keeps its segment's constants in registers and re-reads the table only at an x that starts a segment
-            // (an exec-masked LDS read of the few lanes concerned)
-            seg_id = v0 > seg_id ? v0 : seg_id;
-            uint4 c = segc[seg_id - 1];
-            float res[4];
+        // 1024 lines per pass in four groups of 256: in group j lane l renders x = p0 + 256 j + 4 l .. + 3, so that a store
+        // instruction writes 1 KiB without a gap (16 consecutive x per lane left every 64-byte unit of a store three quarters
+        // empty: four times the write requests).  The pass is straight-line code -- every LDS round trip (map, lane reads,
+        // table, dB values) is issued for all four groups before the first result is needed.
+        for (uint32_t p0 = 0; p0 < n; p0 += 1024) {
+            uint32_t xb[4], m[4];
+            float4 rr[4];  // the lines' residue, requested now: the render hides the latency
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int v = q == 1 ? v1 : (q == 2 ? v2 : v3);
-                if (q > 0 && v != 0) c = segc[v - 1];
-                const int32_t t = (int32_t)(xb + (uint32_t)q) - (int32_t)(c.x & 0xffffu);
-                const int32_t steps = (int32_t)((float)t * __uint_as_float(c.y) + __uint_as_float(c.z));
-                int32_t y4 = (int32_t)(c.x >> 16) + (steps << 2);  // byte offset of the table entry (y0 sits at bit 18)
-                y4 = y4 < 0 ? 0 : (y4 > 1020 ? 1020 : y4);        // (in range for every rendered x; guards the lanes past the list)
-#if SYM_FLOOR1_PROBE == 6
-                res[q] = __int_as_float(y4);
-#else
-                res[q] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dbl) + y4);
-#endif
+            for (int j = 0; j < 4; ++j) {
+                xb[j] = p0 + 256u * (uint32_t)j + 4u * (uint32_t)lane;  // (n is a multiple of 16)
+                rr[j] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                if constexpr (DOT) {
+                    if (xb[j] < n) rr[j] = *reinterpret_cast<const float4 *>(rin + xb[j]);
+                }
+                m[j] = xb[j] < n ? *reinterpret_cast<const uint32_t *>(mark + xb[j]) : 0u;
             }
+            // the segment in force just before a lane's first x: the highest mark below it.  Marks grow with x, so that is
+            // the last mark of the nearest lower lane that holds one (a ballot and one lane read, no scan), or else the
+            // highest mark of the groups before
+            int before[4], last[4];
+            unsigned long long below[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mine = (int)max(max(m[j] & 255u, (m[j] >> 8) & 255u), max((m[j] >> 16) & 255u, m[j] >> 24));
+                const unsigned long long holders = __ballot(mine != 0);
+                below[j] = holders & ((1ull << lane) - 1ull);
+                before[j] = __shfl(mine, below[j] ? 63 - __builtin_clzll(below[j]) : lane);
+                last[j] = __shfl(mine, holders ? 63 - __builtin_clzll(holders) : 0);
+                last[j] = holders ? last[j] : 0;
+            }
+            float res[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int seg_id = (below[j] && before[j] > carry) ? before[j] : carry;  // (index + 1) of the segment
+                carry = last[j] > carry ? last[j] : carry;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int v = (int)((m[j] >> (8 * q)) & 255u);
+                    seg_id = v > seg_id ? v : seg_id;
+                    const uint4 c = segc[seg_id - 1];
+                    const int32_t t = (int32_t)(xb[j] + (uint32_t)q) - (int32_t)(c.x & 0xffffu);
+                    const int32_t steps = (int32_t)((float)t * __uint_as_float(c.y) + __uint_as_float(c.z));
+                    int32_t y4 = (int32_t)(c.x >> 16) + (steps << 2);  // byte offset of the table entry (y0 sits at bit 18)
+                    y4 = y4 < 0 ? 0 : (y4 > 1020 ? 1020 : y4);        // (in range for every rendered x; guards the lanes past the list)
+                    res[j][q] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dbl) + y4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
 #if SYM_FLOOR1_PROBE == 3
-            if (inside && res[0] == 12345.0f) {
+                if (xb[j] < n && res[j][0] == 12345.0f) {
 #else
-            if (inside) {
+                if (xb[j] < n) {
 #endif
-                float4 v = make_float4(res[0], res[1], res[2], res[3]);
-                if constexpr (DOT) v = make_float4(v.x * rr.x, v.y * rr.y, v.z * rr.z, v.w * rr.w);
-                *reinterpret_cast<float4 *>(out + xb) = v;
+                    float4 v = make_float4(res[j][0], res[j][1], res[j][2], res[j][3]);
+                    if constexpr (DOT) v = make_float4(v.x * rr[j].x, v.y * rr[j].y, v.z * rr[j].z, v.w * rr[j].w);
+                    *reinterpret_cast<float4 *>(out + xb[j]) = v;
+                }
             }
         }
         wave_sync_lds();  // the next block's segment-start map overwrites this one's
@@ -641,9 +684,10 @@ int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts
     for (int i = 2; i < n_posts; ++i) {
         const uint32_t lo = h_setup[65 + i] & 255u, hi = h_setup[130 + i] & 255u;
         const int adx = (int)h_setup[hi] - (int)h_setup[lo];  // > 0: the wrapper checked that the x values are distinct
-        st.nb[i] = lo | hi << 8 | ((h_setup[i] - h_setup[lo]) & 0xffffu) << 16;
-        st.adx[i] = (uint32_t)(adx > 0 ? adx : 1);
-        st.inv_adx[i] = 1.0f / (float)(adx > 0 ? adx : 1);
+        const float fadx = (float)(adx > 0 ? adx : 1);
+        st.nb[i] = lo | hi << 8;
+        st.ratio[i] = (float)((int)h_setup[i] - (int)h_setup[lo]) / fadx;
+        st.half[i] = 0.5f / fadx;
     }
     // instantiated per block class: the segment-start map is n bytes of LDS, and LDS is what bounds the resident wavefronts
 #define SYM_F1_LAUNCH(DOT, NMAX)                                                                                                     \

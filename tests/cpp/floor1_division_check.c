@@ -6,9 +6,32 @@
  * same arithmetic the device executes.  tests/test_vorbis_floor1_closed_form.py builds and runs it.  */
 #include <stdio.h>
 #include <stdlib.h>
+/* render_point (floor.rs:776-782) in step 1 of the same kernel: the divisor and dx = x - x0 belong to the setup, |dy| varies:
+ *     floor(|dy| * dx / adx) == trunc(f32(|dy|) * ratio + half),  ratio = f32(dx) / f32(adx),  for |dy| <= 511, dx < adx  */
+static long check_render_point(int maxadx) {
+    long bad = 0;
+    for (int adx = 1; adx <= maxadx; ++adx) {
+        float fadx = (float)adx, hinv = 0.5f / fadx;
+        for (int dx = 0; dx < adx; ++dx) {
+            float ratio = (float)dx / fadx;
+            for (int ady = 0; ady <= 511; ++ady) {
+                volatile float p = (float)ady * ratio;
+                volatile float q = p + hinv;
+                volatile float pn = (float)(-ady) * ratio;
+                volatile float qn = pn + (-hinv);
+                int want = (int)(((long)ady * dx) / adx);
+                bad += (int)q != want;
+                bad += (int)qn != -want;
+            }
+        }
+    }
+    return bad;
+}
+
 int main(int argc, char **argv) {
     int maxadx = argc > 1 ? atoi(argv[1]) : 4096;
-    long bad = 0, total = 0;
+    long bad = check_render_point(maxadx), total = 0;
+    printf("render_point: bad %ld\n", bad);
     for (int adx = 1; adx <= maxadx; ++adx) {
         volatile float fadx = (float)adx;
         float hinv = 0.5f / fadx;
