@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "symaccel_host_alloc", "symaccel_host_free", "symaccel_host_register", "symaccel_host_unregister",
     "symaccel_aac_synth_pipelined", "symaccel_mp3_synth_pipelined", "symaccel_flac_restore_pipelined",
     "symaccel_host_aac_pulse", "symaccel_host_vorbis_bark_map", "symaccel_host_vorbis_floor0_coeffs", "symaccel_host_vorbis_floor0",
-    "symaccel_flac_block_status_device", "symaccel_alac_block_status_device", "symaccel_aac_tns_status_device",
+    "symaccel_flac_block_status_device", "symaccel_alac_block_status_device", "symaccel_vorbis_floor1_status_device", "symaccel_aac_tns_status_device",
     "symaccel_aac_synth_pp_device", "symaccel_mp3_synth_pp_device", "symaccel_vorbis_synth_pp_device", "symaccel_mpa_polyphase_pp_device",
 ]
 
@@ -126,6 +126,7 @@ class Library:
         d.symaccel_host_vorbis_floor0.argtypes = [_vp, _i, _vp, _u32, C.c_uint16, C.c_uint8, C.c_uint8, C.c_uint64, _vp]
         d.symaccel_flac_block_status_device.argtypes = [_vp, _vp, _sz, _sz, _vp]
         d.symaccel_alac_block_status_device.argtypes = [_vp, _vp, _sz, _vp]
+        d.symaccel_vorbis_floor1_status_device.argtypes = [_vp, _i, _vp, _sz, _vp]
         d.symaccel_aac_tns_status_device.argtypes = [_vp, _sz, _vp, _sz, _vp]
         d.symaccel_table_f32.argtypes = [_vp, _i, _vp, _sz]
         d.symaccel_imdct_twiddles.argtypes = [_i, _d, _vp]

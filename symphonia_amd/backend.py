@@ -618,6 +618,13 @@ def flac_block_status(ctx, desc, blocksize, status):
     return status
 
 
+def vorbis_floor1_status(ctx, n_posts, y, count, status):
+    """y[count][n_posts] uint32 (device), status[count] int8 (device): 0, or ERR_UNSUPPORTED for a block with a y value above
+    255 (outside the floor-1 kernels' arithmetic; the reference's i32 arithmetic still covers it)."""
+    ctx._call(ctx.lib.dll.symaccel_vorbis_floor1_status_device, int(n_posts), _ptr(y), int(count), _ptr(status))
+    return status
+
+
 def alac_block_status(ctx, desc, status):
     n = (desc.numel() * desc.element_size() if _is_torch(desc) else desc.nbytes) // 4
     ctx._call(ctx.lib.dll.symaccel_alac_block_status_device, _ptr(desc), n, _ptr(status))

@@ -789,6 +789,15 @@ int symaccel_flac_block_status_device(symaccel_ctx *ctx, const symaccel_flac_des
     return launch_flac_status(ctx, d_desc, n_blocks, blocksize, d_status);
 }
 
+int symaccel_vorbis_floor1_status_device(symaccel_ctx *ctx, int n_posts, const uint32_t *d_y, size_t count, int8_t *d_status) {
+    if (!ctx || n_posts < 2 || n_posts > 65) return SYMACCEL_ERR_INVALID_ARG;
+    if (count == 0) return SYMACCEL_OK;
+    if (!d_y || !d_status) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_floor1_status(ctx, d_y, count, n_posts, d_status);
+}
+
 int symaccel_alac_block_status_device(symaccel_ctx *ctx, const symaccel_alac_desc *d_desc, size_t n_blocks, int8_t *d_status) {
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (n_blocks == 0) return SYMACCEL_OK;

@@ -45,6 +45,18 @@ __global__ __launch_bounds__(256) void alac_status_kernel(const symaccel_alac_de
         status[i] = (int8_t)((mode > 0 && mode < 15) ? SYMACCEL_ERR_DECODE : SYMACCEL_OK);  // lib.rs:167-169
     }
 }
+// a wavefront per channel-block's y row (<= 65 values): any value the floor-1 kernel's arithmetic does not cover?
+__global__ __launch_bounds__(256) void floor1_status_kernel(const uint32_t *__restrict__ y, size_t count, unsigned n_posts,
+                                                            int8_t *__restrict__ status) {
+    const unsigned lane = threadIdx.x & 63u;
+    for (size_t b = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6); b < count; b += (size_t)gridDim.x * 4u) {
+        const uint32_t *row = y + b * n_posts;
+        uint32_t worst = lane < n_posts ? row[lane] : 0u;
+        if (lane == 0 && n_posts > 64) worst = worst > row[64] ? worst : row[64];
+        const bool big = __any(worst > 255u) != 0;
+        if (lane == 0) status[b] = (int8_t)(big ? SYMACCEL_ERR_UNSUPPORTED : SYMACCEL_OK);
+    }
+}
 __global__ __launch_bounds__(256) void tns_status_kernel(const symaccel_aac_tns_filter *__restrict__ f, size_t n, unsigned n_frames,
                                                          int8_t *__restrict__ status) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -67,6 +79,13 @@ int launch_flac_status(symaccel_ctx *ctx, const symaccel_flac_desc *d_desc, size
 }
 int launch_alac_status(symaccel_ctx *ctx, const symaccel_alac_desc *d_desc, size_t n, int8_t *d_status) {
     hipLaunchKernelGGL(alac_status_kernel, dim3(status_grid(n)), dim3(256), 0, ctx->stream, d_desc, n, d_status);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+int launch_floor1_status(symaccel_ctx *ctx, const uint32_t *d_y, size_t count, int n_posts, int8_t *d_status) {
+    const size_t b = (count + 3) / 4;
+    hipLaunchKernelGGL(floor1_status_kernel, dim3((unsigned)(b < 16384 ? b : 16384)), dim3(256), 0, ctx->stream, d_y, count,
+                       (unsigned)n_posts, d_status);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -219,6 +219,7 @@ int launch_state_copy(symaccel_ctx *ctx, void *dst0, const void *src0, size_t by
                       size_t bytes1, void *dst2, const void *src2, size_t bytes2);
 int launch_flac_status(symaccel_ctx *ctx, const symaccel_flac_desc *d_desc, size_t n, size_t blocksize, int8_t *d_status);
 int launch_alac_status(symaccel_ctx *ctx, const symaccel_alac_desc *d_desc, size_t n, int8_t *d_status);
+int launch_floor1_status(symaccel_ctx *ctx, const uint32_t *d_y, size_t count, int n_posts, int8_t *d_status);
 int launch_tns_status(symaccel_ctx *ctx, const symaccel_aac_tns_filter *d_filters, size_t n, size_t n_frames, int8_t *d_status);
 int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
                         const int32_t *d_coeffs, size_t n_blocks, size_t blocksize, const uint8_t *d_pair_mode = nullptr,

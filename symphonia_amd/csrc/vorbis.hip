@@ -344,9 +344,6 @@ struct Floor1Setup {  // per floor configuration, derived on the host like the s
 // Measured (profiles/r02zb_floor1_ab.txt): a wavefront per 16 or 32 blocks doing everything itself spends as many
 // instructions in the post chain as in the render, and the kernel is bound by instruction issue and dependent latency, not
 // by HBM.
-#ifndef SYM_FLOOR1_PROBE
-#define SYM_FLOOR1_PROBE 0
-#endif
 constexpr int kF1B = 64;                 // channel-blocks per workgroup
 constexpr int kF1Waves = 4;              // wavefronts per workgroup
 constexpr int kF1Stride = kF1B + 1;      // LDS row stride of the per-block lists [entry][block]: conflict-free both ways
@@ -390,9 +387,6 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
         }
     }
     __syncthreads();
-#if SYM_FLOOR1_PROBE == 2
-    if (n_posts < 1000) n_posts = 2;
-#endif
     if (wave == 1) {
         // floor_step2_flag (floor.rs:599-601): a property of the y values alone, so a second wavefront derives it while the
         // first walks the post chain.  Bits (posts 0 and 1 are always used): 64 + one for post 64, set and tested without
@@ -490,9 +484,6 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
     // ---- render_line for every segment (floor.rs:785-825): wavefront w takes blocks w, w + 4, ... one after the other.
     // Which segment an x belongs to comes from a byte map of the segment starts (scattered by the lanes that hold the
     // points); the segments' constants from a table built one lane per segment.
-#if SYM_FLOOR1_PROBE == 1
-    if (n_posts < 1000) { if (tid < nb) floor_out[(blk0 + tid) * (size_t)n] = (float)ns_of[tid]; return; }
-#endif
     for (int b = wave; b < nb; b += kF1Waves) {
         const int nsb = (int)ns_of[b];  // points 0 .. nsb of block b
         float *out = floor_out + (blk0 + (size_t)b) * (size_t)n;
@@ -518,11 +509,7 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
             const int32_t dy = (int32_t)segy[k1 * kF1Stride + b] - y0;
             int32_t adx = (int32_t)segx[k1 * kF1Stride + b] - (int32_t)xk;
             adx = adx > 0 ? adx : 1;
-#if SYM_FLOOR1_PROBE == 4
-            const float fadx = 1.0f;
-#else
             const float fadx = (float)adx;
-#endif
             segc[k] = make_uint4(xk | ((uint32_t)y0 << 18), __float_as_uint((float)dy / fadx),
                                  __float_as_uint((dy < 0 ? -0.5f : 0.5f) / fadx), 0u);
         }
@@ -577,11 +564,7 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-#if SYM_FLOOR1_PROBE == 3
-                if (xb[j] < n && res[j][0] == 12345.0f) {
-#else
                 if (xb[j] < n) {
-#endif
                     float4 v = make_float4(res[j][0], res[j][1], res[j][2], res[j][3]);
                     if constexpr (DOT) v = make_float4(v.x * rr[j].x, v.y * rr[j].y, v.z * rr[j].z, v.w * rr[j].w);
                     *reinterpret_cast<float4 *>(out + xb[j]) = v;

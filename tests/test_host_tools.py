@@ -80,6 +80,14 @@ def test_status_arrays(emu_ctx):
     st3 = np.full(4, 99, np.int8)
     sa.alac_block_status(emu_ctx, ad, st3)
     assert st3.tolist() == [0, D, D, 0]
+    ys = np.zeros((5, 65), np.uint32)
+    ys[1, 64], ys[2, 0], ys[3, 30], ys[4, 63] = 256, 255, 70000, 255
+    st5 = np.full(5, 99, np.int8)
+    sa.vorbis_floor1_status(emu_ctx, 65, ys, 5, st5)
+    assert st5.tolist() == [0, U, 0, U, 0]
+    st6 = np.full(3, 99, np.int8)
+    sa.vorbis_floor1_status(emu_ctx, 7, np.array([[0, 1, 2, 3, 4, 5, 300], [255] * 7, [0, 0, 0, 0, 0, 0, 0]], np.uint32), 3, st6)
+    assert st6.tolist() == [U, 0, 0]
     filt = np.zeros(5, sa.AAC_TNS_DTYPE)
     filt["frame"], filt["start"], filt["end"], filt["order"] = [0, 9, 0, 0, 1], [0, 0, 8, 0, 4], [16, 16, 8, 1028, 1024], [3, 3, 3, 3, 21]
     filt[0]["order"] = 20
