@@ -169,3 +169,28 @@ def flac_extreme_case(seed, big_coeffs):
     coeffs[1] = lim
     coeffs[2] = np.where(np.arange(32) % 2 == 0, lim, -lim)
     return buf, kind, order, shift, coeffs
+
+
+def floor1_case(rng):
+    """A random floor-1 configuration and y rows: (x_list, multiplier, n, ys).  Post positions are spread or clustered
+    (runs of adjacent x: one-line segments), y values up to 255 whatever the range (what a non-conforming but accepted
+    stream can carry, symaccel_vorbis_floor1_status_device), zero densities from almost none to almost all."""
+    import numpy as np
+    n = int(rng.choice([32, 64, 128, 256, 512, 1024, 2048, 4096]))
+    n_posts = int(rng.integers(2, min(65, n) + 1))
+    mult = int(rng.integers(1, 5))
+    count = int(rng.choice([1, 3, 17, 64, 65, 130]))
+    if rng.random() < 0.4:
+        base = int(rng.integers(1, max(2, n - n_posts)))
+        rest = rng.permutation(np.arange(base, min(n, base + n_posts + 5)))[:n_posts - 2].tolist()
+        while len(rest) < n_posts - 2:
+            x = int(rng.integers(1, n))
+            if x not in rest:
+                rest.append(x)
+    else:
+        rest = rng.permutation(np.arange(1, n))[:n_posts - 2].tolist()
+    xs = [0, n] + rest
+    top = 256 if rng.random() < 0.3 else [256, 128, 86, 64][mult - 1]
+    ys = rng.integers(0, top, size=(count, n_posts)).astype(np.uint32)
+    ys[rng.random((count, n_posts)) < rng.choice([0.02, 0.3, 0.9])] = 0
+    return xs, mult, n, ys

@@ -226,6 +226,18 @@ def test_emu_vorbis_floor1(emu_ctx):
         assert bit_equal(inplace, want * res), (n, n_posts, mult)
 
 
+def test_emu_vorbis_floor1_random(emu_ctx):
+    from helpers import floor1_case
+    rng = np.random.default_rng(61)
+    v = VorbisDsp(emu_ctx, 8, 11)
+    for _ in range(25):
+        xs, mult, n, ys = floor1_case(rng)
+        out = np.zeros((len(ys), n), np.float32)
+        v.floor1(xs, mult, ys, n, out, len(ys))
+        want = np.stack([oracle.vorbis_floor1(xs, y, mult, n) for y in ys])
+        assert bit_equal(out, want), (n, len(xs), mult, len(ys))
+
+
 def test_emu_flac_restore(emu_ctx):
     rng = np.random.default_rng(9)
     for blocksize in (1, 31, 64, 100, 192, 4096 // 8):

@@ -177,3 +177,20 @@ def test_fuzz_aac_tools(ctx, it):
     assert bit_equal(host(d), want_js), (n_pairs, frames)
     tools.tns(d, dev(filt.view(np.uint8).reshape(-1, 92)))
     assert bit_equal(host(d), want), (n_pairs, frames, len(filt))
+
+
+@pytest.mark.parametrize("it", range(4 * ITERS))
+def test_fuzz_vorbis_floor1(ctx, it):
+    from symphonia_amd import VorbisDsp
+    from helpers import floor1_case
+    rng = np.random.default_rng(7000 + it)
+    xs, mult, n, ys = floor1_case(rng)
+    v = VorbisDsp(ctx, 8, 11)
+    out = torch.zeros((len(ys), n), dtype=torch.float32, device="cuda")
+    v.floor1(xs, mult, dev(ys), n, out, len(ys))
+    curve = np.stack([oracle.vorbis_floor1(xs, y, mult, n) for y in ys])
+    assert bit_equal(host(out), curve), (n, len(xs), mult, len(ys))
+    res = (rng.standard_normal(curve.shape) * np.exp2(rng.integers(-8, 9, curve.shape))).astype(np.float32)
+    d_res = dev(res)
+    v.floor1(xs, mult, dev(ys), n, d_res, len(ys), residue=d_res)
+    assert bit_equal(host(d_res), curve * res), (n, len(xs), mult, len(ys))
