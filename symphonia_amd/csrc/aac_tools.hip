@@ -8,12 +8,13 @@
 // mid/side or intensity are touched, so the traffic is proportional to their share.
 // TNS is an all-pole filter running along the spectrum -- a serial recurrence of up to 20 taps per line.  The
 // parallel axis is the filter: one lane per filter of a flat list, the tap history in registers, sixteen lines
-// (one 64-byte sector) per lane and round, the next sixteen fetched while the current ones are filtered.  The taps are
+// (one 64-byte sector) per lane and round, the next sixteen requested while the current ones are filtered; the four lanes
+// of a quad move their four groups together (64-byte requests) and transpose them among themselves.  The taps are
 // applied in the reference's order, each as a rounded multiply and a rounded subtract, and only `min(order, lines
 // filtered so far)` of them (tns.rs:184, 191).  (Staging the lines through an LDS tile of 64 filters x 32 lines, as the
 // integer predictors do -- 128-byte row segments on the HBM side -- was built and measured twice, before and after the
 // tap loop became compile-time: 0.50 against 0.38 ms, then 0.33 against 0.30 ms for 131 072 order-12 filters.  Not kept;
-// profiles/r02n_tns_alac_ab.txt.)
+// profiles/r02n_tns_alac_ab.txt, profiles/r02zc_tns_ab.txt.)
 #include <hip/hip_runtime.h>
 
 #include "symaccel_internal.h"
@@ -62,19 +63,99 @@ struct TnsLane {
     bool down, aligned;
 };
 
-// Sixteen lines (64 bytes) per lane and round: the filter walks its range in groups of sixteen -- four 16-byte loads and
-// stores when the range is 16-byte aligned, as every range built from swb offsets is; scalar accesses otherwise and for a
-// ragged last group -- so every 64-byte sector a lane touches crosses the L2 -> L1 path once.
-__device__ __forceinline__ void tns_fetch(const TnsLane &L, int m0, float (&v)[kTnsGroup]) {
+// Value of lane (lane ^ S) of the same quad, S = 1 or 2: one DPP move (quad_perm), no LDS.
+template <int S>
+__device__ __forceinline__ uint32_t quad_xor(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, S == 1 ? 0xB1 : 0x4E, 0xf, 0xf, true);  // quad_perm [1,0,3,2] / [2,3,0,1]
+#else
+    return (uint32_t)__shfl_xor((int)v, S);
+#endif
+}
+// Value of lane J of the caller's quad.
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xf, 0xf, true);  // quad_perm [J,J,J,J]
+#else
+    return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 60u) | (unsigned)J));
+#endif
+}
+// Transpose of a 4 x 4 matrix of 16-byte elements held one row per lane of a quad: afterwards element j of lane i is what
+// was element i of lane j.  Two butterfly steps (lane bit 0 with index bit 0, lane bit 1 with index bit 1).
+__device__ __forceinline__ void quad_transpose(uint4 (&e)[4], int lane) {
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+    auto swap_step = [](uint4 &lo, uint4 &hi, bool b, auto xchg) {
+        uint32_t *l = &lo.x, *h = &hi.x;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t r = xchg(b ? l[d] : h[d]);  // the lower lane sends its upper element, the upper lane its lower one
+            l[d] = b ? r : l[d];
+            h[d] = b ? h[d] : r;
+        }
+    };
+    swap_step(e[0], e[1], b0, [](uint32_t v) { return quad_xor<1>(v); });
+    swap_step(e[2], e[3], b0, [](uint32_t v) { return quad_xor<1>(v); });
+    swap_step(e[0], e[2], b1, [](uint32_t v) { return quad_xor<2>(v); });
+    swap_step(e[1], e[3], b1, [](uint32_t v) { return quad_xor<2>(v); });
+}
+
+// The four filters of a quad, as every lane of the quad sees them: filter j's first line (element index into coeffs),
+// length and whether a full group of it can be moved as four aligned 16-byte pieces.
+struct TnsQuad {
+    size_t idx[4];
+    int len[4];
+    bool down[4], aligned[4];
+};
+__device__ __forceinline__ TnsQuad tns_quad(const TnsLane &L, const float *coeffs) {
+    TnsQuad Q;
+    const uint64_t p = (uint64_t)(L.x - coeffs);
+    const uint32_t lo = (uint32_t)p, hi = (uint32_t)(p >> 32), meta = (uint32_t)L.len | (L.down ? 1u << 16 : 0u) | (L.aligned ? 1u << 17 : 0u);
+    auto take = [&](auto bc, int j) {
+        const uint32_t m = bc(meta);
+        Q.idx[j] = (size_t)((uint64_t)bc(lo) | (uint64_t)bc(hi) << 32);
+        Q.len[j] = (int)(m & 0xffffu);
+        Q.down[j] = (m >> 16 & 1u) != 0;
+        Q.aligned[j] = (m >> 17 & 1u) != 0;
+    };
+    take([](uint32_t v) { return quad_bcast<0>(v); }, 0);
+    take([](uint32_t v) { return quad_bcast<1>(v); }, 1);
+    take([](uint32_t v) { return quad_bcast<2>(v); }, 2);
+    take([](uint32_t v) { return quad_bcast<3>(v); }, 3);
+    return Q;
+}
+
+// Sixteen lines (64 bytes) per lane and round.  A lane on its own would move them as four 16-byte accesses, each to a line of
+// its own: 64 separate requests per wavefront instruction -- the address unit was busy 84 % of the kernel and the L2 saw the
+// stores as 16-byte writes (profiles/r02z_tns_sq_counters.txt).  So the four lanes of a quad move their four filters'
+// groups TOGETHER: instruction j covers the 64-byte group of filter j, a quarter per lane (one contiguous 64-byte request),
+// and a 4 x 4 transpose inside the quad (DPP moves, no LDS) hands every lane its own filter's sixteen lines.
+//  * tns_request only ISSUES the loads (unconditionally: a filter with no full aligned group at m0 reads coeffs[0..3]
+//    instead, which is discarded) -- no branch, no use of the data, so they stay in flight while the previous group is
+//    filtered; tns_take transposes them when the group's turn comes.
+//  * A filter whose group is ragged or unaligned is moved by its own lane, scalar, when its turn comes.
+struct TnsRaw {
+    uint4 e[4];
+};
+__device__ __forceinline__ void tns_request(const float *coeffs, const TnsQuad &Q, int lane, int m0, TnsRaw &raw) {
+    const int i = lane & 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool full = Q.aligned[j] && m0 + kTnsGroup <= Q.len[j];
+        const size_t at = Q.down[j] ? Q.idx[j] - (size_t)(m0 + 4 * i + 3) : Q.idx[j] + (size_t)(m0 + 4 * i);
+        raw.e[j] = *reinterpret_cast<const uint4 *>(coeffs + (full ? at : (size_t)0));
+    }
+}
+__device__ __forceinline__ void tns_take(const TnsLane &L, TnsRaw &raw, int lane, int m0, float (&v)[kTnsGroup]) {
+    quad_transpose(raw.e, lane);
     if (m0 >= L.len) return;
     if (L.aligned && m0 + kTnsGroup <= L.len) {
 #pragma unroll
         for (int q = 0; q < kTnsGroup / 4; ++q) {
-            const float4 f4 = *reinterpret_cast<const float4 *>(L.down ? L.x - m0 - 4 * q - 3 : L.x + m0 + 4 * q);
-            v[4 * q + 0] = L.down ? f4.w : f4.x;
-            v[4 * q + 1] = L.down ? f4.z : f4.y;
-            v[4 * q + 2] = L.down ? f4.y : f4.z;
-            v[4 * q + 3] = L.down ? f4.x : f4.w;
+            v[4 * q + 0] = __uint_as_float(L.down ? raw.e[q].w : raw.e[q].x);
+            v[4 * q + 1] = __uint_as_float(L.down ? raw.e[q].z : raw.e[q].y);
+            v[4 * q + 2] = __uint_as_float(L.down ? raw.e[q].y : raw.e[q].z);
+            v[4 * q + 3] = __uint_as_float(L.down ? raw.e[q].x : raw.e[q].w);
         }
     } else {
 #pragma unroll
@@ -82,14 +163,20 @@ __device__ __forceinline__ void tns_fetch(const TnsLane &L, int m0, float (&v)[k
             if (m0 + k < L.len) v[k] = L.x[L.down ? -(long)(m0 + k) : (long)(m0 + k)];
     }
 }
-__device__ __forceinline__ void tns_store(const TnsLane &L, int m0, const float (&v)[kTnsGroup]) {
-    if (m0 >= L.len) return;
-    if (L.aligned && m0 + kTnsGroup <= L.len) {
+__device__ __forceinline__ void tns_store(float *coeffs, const TnsLane &L, const TnsQuad &Q, int lane, int m0, const float (&v)[kTnsGroup]) {
+    const int i = lane & 3;
+    uint4 e[4];
 #pragma unroll
-        for (int q = 0; q < kTnsGroup / 4; ++q)
-            *reinterpret_cast<float4 *>(L.down ? L.x - m0 - 4 * q - 3 : L.x + m0 + 4 * q) =
-                L.down ? make_float4(v[4 * q + 3], v[4 * q + 2], v[4 * q + 1], v[4 * q]) : make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    } else {
+    for (int q = 0; q < kTnsGroup / 4; ++q)
+        e[q] = L.down ? make_uint4(__float_as_uint(v[4 * q + 3]), __float_as_uint(v[4 * q + 2]), __float_as_uint(v[4 * q + 1]), __float_as_uint(v[4 * q]))
+                      : make_uint4(__float_as_uint(v[4 * q]), __float_as_uint(v[4 * q + 1]), __float_as_uint(v[4 * q + 2]), __float_as_uint(v[4 * q + 3]));
+    quad_transpose(e, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (Q.aligned[j] && m0 + kTnsGroup <= Q.len[j])
+            *reinterpret_cast<uint4 *>(coeffs + (Q.down[j] ? Q.idx[j] - (size_t)(m0 + 4 * i + 3) : Q.idx[j] + (size_t)(m0 + 4 * i))) = e[j];
+    }
+    if (m0 < L.len && !(L.aligned && m0 + kTnsGroup <= L.len)) {
 #pragma unroll
         for (int k = 0; k < kTnsGroup; ++k)
             if (m0 + k < L.len) L.x[L.down ? -(long)(m0 + k) : (long)(m0 + k)] = v[k];
@@ -130,7 +217,8 @@ __device__ __forceinline__ void tns_lines16(float (&cur)[kTnsGroup], float (&h)[
 }
 
 template <int TAPS>
-__device__ __forceinline__ void tns_walk(const TnsLane &L, const float *lpc_all, int max_len) {
+__device__ __forceinline__ void tns_walk(float *coeffs, const TnsLane &L, const float *lpc_all, int max_len, int lane) {
+    const TnsQuad Q = tns_quad(L, coeffs);
     float lpc[TAPS], h[TAPS];
     unsigned mask[TAPS];
 #pragma unroll
@@ -139,61 +227,76 @@ __device__ __forceinline__ void tns_walk(const TnsLane &L, const float *lpc_all,
         h[j] = 0.0f;
         mask[j] = j < L.order ? 0xffffffffu : 0u;
     }
-    // The next group is fetched while the current one is filtered: the inputs are the unfiltered lines, independent of the outputs.
-    float cur[kTnsGroup], nxt[kTnsGroup];
+    // The inputs are the unfiltered lines, independent of the outputs: the next group is requested before the current one
+    // is filtered (two alternating register groups, the round loop unrolled by two so that every index is static).
+    TnsRaw raw[2];
+    float cur[kTnsGroup];
 #pragma unroll
-    for (int k = 0; k < kTnsGroup; ++k) cur[k] = nxt[k] = 0.0f;
-    tns_fetch(L, 0, cur);
-    for (int m0 = 0; m0 < max_len; m0 += kTnsGroup) {
-        tns_fetch(L, m0 + kTnsGroup, nxt);
-        if (m0 < TAPS)  // (wave-uniform) the groups that contain a range's first TAPS lines
-            tns_lines16<TAPS, true>(cur, h, lpc, mask, L.order, m0);
-        else
-            tns_lines16<TAPS, false>(cur, h, lpc, mask, L.order, m0);
-        tns_store(L, m0, cur);
+    for (int k = 0; k < kTnsGroup; ++k) cur[k] = 0.0f;
+    tns_request(coeffs, Q, lane, 0, raw[0]);
+    for (int m0 = 0; m0 < max_len; m0 += 2 * kTnsGroup) {
 #pragma unroll
-        for (int k = 0; k < kTnsGroup; ++k) cur[k] = nxt[k];
+        for (int r = 0; r < 2; ++r) {
+            const int m = m0 + r * kTnsGroup;
+            if (m < max_len) {  // (wave-uniform)
+                tns_request(coeffs, Q, lane, m + kTnsGroup, raw[r ^ 1]);
+                tns_take(L, raw[r], lane, m, cur);
+                if (m < TAPS)  // (wave-uniform) the groups that contain a range's first TAPS lines
+                    tns_lines16<TAPS, true>(cur, h, lpc, mask, L.order, m);
+                else
+                    tns_lines16<TAPS, false>(cur, h, lpc, mask, L.order, m);
+                tns_store(coeffs, L, Q, lane, m, cur);
+            }
+        }
     }
 }
 
+// One kernel per tap class (TAPS = 4, 8, 12, 20), all launched over the same grid: a wavefront runs in the kernel of its
+// highest order and leaves the others at once.  As ONE kernel the five walks shared a register allocation -- that of the
+// largest -- and the ring of groups in flight did not fit two wavefronts per SIMD.
+template <int TAPS>
 __global__ __launch_bounds__(64) void aac_tns_kernel(float *__restrict__ coeffs, unsigned n_frames,
                                                      const symaccel_aac_tns_filter *__restrict__ filters, unsigned n_filters) {
     const unsigned idx = blockIdx.x * 64u + threadIdx.x;
-    TnsLane L{coeffs, 0, 0, false, false};
-    float lpc[kTnsMaxOrder];
-#pragma unroll
-    for (int j = 0; j < kTnsMaxOrder; ++j) lpc[j] = 0.0f;
+    // the wavefront's class first: only the order bytes (one 4-byte word per filter)
+    int order = 0;
+    bool valid = false;
     if (idx < n_filters) {
         const symaccel_aac_tns_filter &f = filters[idx];
         const int start = f.start, end = f.end;
-        if (f.frame < n_frames && start < end && end <= 1024 && f.order >= 1 && f.order <= kTnsMaxOrder) {
-            L.order = f.order;
-            L.len = end - start;
-            L.down = f.direction != 0;
-            L.x = coeffs + (size_t)f.frame * 1024 + (L.down ? end - 1 : start);
-            L.aligned = ((reinterpret_cast<uintptr_t>(L.x) + (L.down ? 4 : 0)) & 15u) == 0;  // x = first line (up) / last line (down)
-#pragma unroll
-            for (int j = 0; j < kTnsMaxOrder; ++j) lpc[j] = f.lpc[j];
-        }
+        valid = f.frame < n_frames && start < end && end <= 1024 && f.order >= 1 && f.order <= kTnsMaxOrder;
+        order = valid ? (int)f.order : 0;
     }
-    // wave-uniform bounds: the longest range and the highest order among the wavefront's filters
-    int max_len = L.len, max_order = L.order;
+    int max_order = order;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-        const int a = __shfl_xor(max_len, m), b = __shfl_xor(max_order, m);
-        max_len = a > max_len ? a : max_len;
+        const int b = __shfl_xor(max_order, m);
         max_order = b > max_order ? b : max_order;
     }
-    if (max_order <= 4)
-        tns_walk<4>(L, lpc, max_len);
-    else if (max_order <= 8)
-        tns_walk<8>(L, lpc, max_len);
-    else if (max_order <= 12)
-        tns_walk<12>(L, lpc, max_len);
-    else if (max_order <= 16)
-        tns_walk<16>(L, lpc, max_len);
-    else
-        tns_walk<20>(L, lpc, max_len);
+    constexpr int kLower = TAPS == 20 ? 12 : TAPS - 4;  // this kernel's orders: kLower < max_order <= TAPS
+    if (max_order <= kLower || max_order > TAPS) return;
+    TnsLane L{coeffs, 0, 0, false, false};
+    float lpc[TAPS];
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) lpc[j] = 0.0f;
+    if (valid) {
+        const symaccel_aac_tns_filter &f = filters[idx];
+        const int start = f.start, end = f.end;
+        L.order = order;
+        L.len = end - start;
+        L.down = f.direction != 0;
+        L.x = coeffs + (size_t)f.frame * 1024 + (L.down ? end - 1 : start);
+        L.aligned = ((reinterpret_cast<uintptr_t>(L.x) + (L.down ? 4 : 0)) & 15u) == 0;  // x = first line (up) / last line (down)
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) lpc[j] = f.lpc[j];
+    }
+    int max_len = L.len;  // wave-uniform bound: the longest range among the wavefront's filters
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int a = __shfl_xor(max_len, m);
+        max_len = a > max_len ? a : max_len;
+    }
+    tns_walk<TAPS>(coeffs, L, lpc, max_len, (int)threadIdx.x);
 }
 
 }  // namespace
@@ -212,8 +315,13 @@ int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const sy
                    size_t n_filters) {
     const size_t grid = (n_filters + 63) / 64;
     if (n_frames > 0xffffffffu || n_filters > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(aac_tns_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_coeffs, (unsigned)n_frames, d_filters,
-                       (unsigned)n_filters);
+#define SYM_TNS_LAUNCH(TAPS) \
+    hipLaunchKernelGGL(aac_tns_kernel<TAPS>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_coeffs, (unsigned)n_frames, d_filters, (unsigned)n_filters)
+    SYM_TNS_LAUNCH(12);  // (AAC-LC long windows: the common class first)
+    SYM_TNS_LAUNCH(8);
+    SYM_TNS_LAUNCH(4);
+    SYM_TNS_LAUNCH(20);
+#undef SYM_TNS_LAUNCH
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

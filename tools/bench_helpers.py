@@ -121,6 +121,18 @@ def main():
     tfilt = torch.from_numpy(tf.view(np.uint8).reshape(-1, 92)).cuda()
     t = timeit(lambda: tools.tns(coeffs, tfilt), reps=3)
     out["aac TNS order 12 x 800 lines in 131072 frames (%.2f ms)" % (t * 1e3)] = 131072 * 800 * 8 / t
+    # the same filters with their ranges staggered (start 0, 32, ... 224 in turn): the lanes of a wavefront are no longer at the
+    # same offset of their 4 KiB frames at the same time
+    tf["start"] = 32 * (np.arange(131072) % 8)
+    tf["end"] = tf["start"] + 800
+    tfilt2 = torch.from_numpy(tf.view(np.uint8).reshape(-1, 92)).cuda()
+    t = timeit(lambda: tools.tns(coeffs, tfilt2), reps=3)
+    out["aac TNS, ranges staggered by 32 lines (%.2f ms)" % (t * 1e3)] = 131072 * 800 * 8 / t
+    tf["start"] = 32 * ((np.arange(131072) // 64) % 8)
+    tf["end"] = tf["start"] + 800
+    tfilt3 = torch.from_numpy(tf.view(np.uint8).reshape(-1, 92)).cuda()
+    t = timeit(lambda: tools.tns(coeffs, tfilt3), reps=3)
+    out["aac TNS, ranges staggered per wavefront (%.2f ms)" % (t * 1e3)] = 131072 * 800 * 8 / t
     for k, gbps in out.items():
         print("%-52s %8.1f GB/s  (%.1f %% of 8 TB/s)" % (k, gbps / 1e9, gbps / 8e12 * 100))
     ctx.close()
