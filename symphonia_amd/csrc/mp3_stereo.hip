@@ -74,13 +74,18 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
         a[i] = b[i] = 0.0f;
         band[i] = 0;
     }
-    auto unpack_map = [&](const uint8_t *m, int grp, int *dst) {
-        const uchar4 v = reinterpret_cast<const uchar4 *>(m)[grp];
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    };
     if (FUSED) {
         // read_huffman_samples' values + requantize for both channels (requantize.rs:117-147, 239-380)
         const symaccel_mp3_requant &r0 = rq_desc[gc0], &r1 = rq_desc[gc1];
+        // the quantised samples only need the granule's address: requested before the scale factors are turned into
+        // scales (descriptor fields -> table look-up -> LDS), so that the two trips to HBM overlap
+        short4 s0[kQ], s1[kQ];
+#pragma unroll
+        for (int qq = 0; qq < kQ; ++qq) {
+            const int grp = have[qq] ? lane + 64 * qq : 0;
+            s0[qq] = reinterpret_cast<const short4 *>(quant + gc0 * 576)[grp];
+            s1[qq] = reinterpret_cast<const short4 *>(quant + gc1 * 576)[grp];
+        }
         float(*scale)[kMp3Slots] = scale_all[FUSED ? wave : 0];
         if (lane < kMp3Slots) {
             scale[0][lane] = mp3_slot_scale(tb, r0, lane, e.mixed_switch);
@@ -90,33 +95,47 @@ __global__ __launch_bounds__(64 * kWaves) void mp3_stereo_kernel(DevTables tb, f
         const uint8_t *m0 = tb.mp3_band_map + (size_t)(sr * 4 + mp3_requant_kind(r0)) * 576;
         const uint8_t *m1 = tb.mp3_band_map + (size_t)(sr * 4 + mp3_requant_kind(r1)) * 576;
         const int rq0 = r0.rzero > 576 ? 576 : (int)r0.rzero, rq1 = r1.rzero > 576 ? 576 : (int)r1.rzero;
+        // every load of the granule first, the arithmetic after: the sample mapping below has a (rare) global table read
+        // behind a branch per sample, and a load placed after such a branch is not issued before it -- as one loop this
+        // was three dependent trips to HBM per granule instead of one
+        uchar4 k0[kQ], k1[kQ], kb[kQ];
+#pragma unroll
+        for (int qq = 0; qq < kQ; ++qq) {
+            const int grp = have[qq] ? lane + 64 * qq : 0;
+            k0[qq] = reinterpret_cast<const uchar4 *>(m0)[grp];
+            k1[qq] = reinterpret_cast<const uchar4 *>(m1)[grp];
+            kb[qq] = reinterpret_cast<const uchar4 *>(map)[grp];
+        }
 #pragma unroll
         for (int qq = 0; qq < kQ; ++qq) {
             if (!have[qq]) continue;
             const int grp = lane + 64 * qq;
-            const short4 s0 = reinterpret_cast<const short4 *>(quant + gc0 * 576)[grp];
-            const short4 s1 = reinterpret_cast<const short4 *>(quant + gc1 * 576)[grp];
-            const int v0[4] = {s0.x, s0.y, s0.z, s0.w}, v1[4] = {s1.x, s1.y, s1.z, s1.w};
-            int k0[4], k1[4];
-            unpack_map(m0, grp, k0);
-            unpack_map(m1, grp, k1);
-            unpack_map(map, grp, band + 4 * qq);
+            const int v0[4] = {s0[qq].x, s0[qq].y, s0[qq].z, s0[qq].w}, v1[4] = {s1[qq].x, s1[qq].y, s1[qq].z, s1[qq].w};
+            const int i0[4] = {k0[qq].x, k0[qq].y, k0[qq].z, k0[qq].w}, i1[4] = {k1[qq].x, k1[qq].y, k1[qq].z, k1[qq].w};
+            band[4 * qq] = kb[qq].x; band[4 * qq + 1] = kb[qq].y; band[4 * qq + 2] = kb[qq].z; band[4 * qq + 3] = kb[qq].w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int line = 4 * grp + j;
-                a[4 * qq + j] = mp3_sample_value(tb, pow43_lo, v0[j], line >= rq0) * scale[0][k0[j]];
-                b[4 * qq + j] = mp3_sample_value(tb, pow43_lo, v1[j], line >= rq1) * scale[1][k1[j]];
+                a[4 * qq + j] = mp3_sample_value(tb, pow43_lo, v0[j], line >= rq0) * scale[0][i0[j]];
+                b[4 * qq + j] = mp3_sample_value(tb, pow43_lo, v1[j], line >= rq1) * scale[1][i1[j]];
             }
         }
     } else {
+        float4 x0[kQ], x1[kQ];
+        uchar4 kb[kQ];
+#pragma unroll
+        for (int qq = 0; qq < kQ; ++qq) {  // (all the loads before the first use, as above)
+            const int grp = have[qq] ? lane + 64 * qq : 0;
+            x0[qq] = reinterpret_cast<const float4 *>(ch0)[grp];
+            x1[qq] = reinterpret_cast<const float4 *>(ch1)[grp];
+            kb[qq] = reinterpret_cast<const uchar4 *>(map)[grp];
+        }
 #pragma unroll
         for (int qq = 0; qq < kQ; ++qq) {
             if (!have[qq]) continue;
-            const int grp = lane + 64 * qq;
-            const float4 x0 = reinterpret_cast<const float4 *>(ch0)[grp], x1 = reinterpret_cast<const float4 *>(ch1)[grp];
-            a[4 * qq] = x0.x; a[4 * qq + 1] = x0.y; a[4 * qq + 2] = x0.z; a[4 * qq + 3] = x0.w;
-            b[4 * qq] = x1.x; b[4 * qq + 1] = x1.y; b[4 * qq + 2] = x1.z; b[4 * qq + 3] = x1.w;
-            unpack_map(map, grp, band + 4 * qq);
+            a[4 * qq] = x0[qq].x; a[4 * qq + 1] = x0[qq].y; a[4 * qq + 2] = x0[qq].z; a[4 * qq + 3] = x0[qq].w;
+            b[4 * qq] = x1[qq].x; b[4 * qq + 1] = x1[qq].y; b[4 * qq + 2] = x1[qq].z; b[4 * qq + 3] = x1[qq].w;
+            band[4 * qq] = kb[qq].x; band[4 * qq + 1] = kb[qq].y; band[4 * qq + 2] = kb[qq].z; band[4 * qq + 3] = kb[qq].w;
         }
     }
 
