@@ -34,6 +34,13 @@ __global__ void k(float *out, int iters, float seed) {
         if constexpr (KIND == 8) BODY("v_pk_fma_f32 %0, %0, %8, %8\n v_pk_fma_f32 %1, %1, %8, %8\n v_pk_fma_f32 %2, %2, %8, %8\n v_pk_fma_f32 %3, %3, %8, %8\n v_pk_fma_f32 %4, %4, %8, %8\n v_pk_fma_f32 %5, %5, %8, %8\n v_pk_fma_f32 %6, %6, %8, %8\n v_pk_fma_f32 %7, %7, %8, %8")
         const v2f r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
         out[blockIdx.x * blockDim.x + threadIdx.x] = r.x + r.y;
+    } else if constexpr (KIND >= 9) {
+        int a0 = (int)s, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7, c = 0x00030005;
+        if constexpr (KIND == 9) BODY("v_dot2_i32_i16 %0, %8, %8, %0\n v_dot2_i32_i16 %1, %8, %8, %1\n v_dot2_i32_i16 %2, %8, %8, %2\n v_dot2_i32_i16 %3, %8, %8, %3\n v_dot2_i32_i16 %4, %8, %8, %4\n v_dot2_i32_i16 %5, %8, %8, %5\n v_dot2_i32_i16 %6, %8, %8, %6\n v_dot2_i32_i16 %7, %8, %8, %7")
+        if constexpr (KIND == 10) BODY("v_mad_i32_i24 %0, %8, %8, %0\n v_mad_i32_i24 %1, %8, %8, %1\n v_mad_i32_i24 %2, %8, %8, %2\n v_mad_i32_i24 %3, %8, %8, %3\n v_mad_i32_i24 %4, %8, %8, %4\n v_mad_i32_i24 %5, %8, %8, %5\n v_mad_i32_i24 %6, %8, %8, %6\n v_mad_i32_i24 %7, %8, %8, %7")
+        if constexpr (KIND == 11) BODY("v_dot4_i32_i8 %0, %8, %8, %0\n v_dot4_i32_i8 %1, %8, %8, %1\n v_dot4_i32_i8 %2, %8, %8, %2\n v_dot4_i32_i8 %3, %8, %8, %3\n v_dot4_i32_i8 %4, %8, %8, %4\n v_dot4_i32_i8 %5, %8, %8, %5\n v_dot4_i32_i8 %6, %8, %8, %6\n v_dot4_i32_i8 %7, %8, %8, %7")
+        if constexpr (KIND == 12) BODY("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8")
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
     } else {
         double a0 = s, a1 = s + 1, a2 = s + 2, a3 = s + 3, a4 = s + 4, a5 = s + 5, a6 = s + 6, a7 = s + 7, c = 1.0000001;
         BODY("v_fma_f64 %0, %0, %8, %8\n v_fma_f64 %1, %1, %8, %8\n v_fma_f64 %2, %2, %8, %8\n v_fma_f64 %3, %3, %8, %8\n v_fma_f64 %4, %4, %8, %8\n v_fma_f64 %5, %5, %8, %8\n v_fma_f64 %6, %6, %8, %8\n v_fma_f64 %7, %7, %8, %8")
@@ -78,5 +85,9 @@ int main() {
     run<8>("v_pk_fma_f32", d, p.multiProcessorCount, ghz);
     run<5>("v_mov_b32", d, p.multiProcessorCount, ghz);
     run<4>("v_fma_f64", d, p.multiProcessorCount, ghz);
+    run<9>("v_dot2_i32_i16", d, p.multiProcessorCount, ghz);
+    run<11>("v_dot4_i32_i8", d, p.multiProcessorCount, ghz);
+    run<10>("v_mad_i32_i24", d, p.multiProcessorCount, ghz);
+    run<12>("v_mul_lo_u32", d, p.multiProcessorCount, ghz);
     return 0;
 }
