@@ -1,5 +1,5 @@
 #!/bin/bash
-# (every pass under its own `timeout`: a pass with the TCP *_LATENCY counters did not come back in ten minutes)
+# (every pass under its own `timeout`: rocprofv3 has died at start-up on a fresh box twice and then sat until the gpurun limit)
 # SQ / LDS / L1-L2 counter passes over tools/bench_helpers.py, filtered to the kernels matching <pattern>:
 #   bash tools/gpu_helpers_pmc.sh <tag> <pattern>      -> gpurun_out/<tag>_helper_counters.txt
 TAG=$1; PAT=$2
