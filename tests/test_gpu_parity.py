@@ -568,6 +568,22 @@ def test_flac_decorrelate_parity(ctx):
         assert np.array_equal(ga[p], oracle.flac_shl(wa, 8)) and np.array_equal(gb[p], oracle.flac_shl(wb, 8))
 
 
+def test_status_arrays_on_gpu(ctx):
+    """symaccel_{flac,alac}_block_status_device, symaccel_aac_tns_status_device, symaccel_vorbis_floor1_status_device on
+    the device (tests/test_host_tools.py runs the same cases through the CPU emulation)."""
+    from test_host_tools import check_status_arrays
+
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        return torch.from_numpy(a.view(np.uint8).reshape(-1) if a.dtype.fields else a).cuda()
+
+    def to_host(t):
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+
+    check_status_arrays(ctx, to_dev, to_host)
+
+
 def test_no_cpu_fallback(ctx):
     """The product library refuses to exist without HIP: creating a context on a bogus device fails."""
     from symphonia_amd import Context, SymaccelError

@@ -65,32 +65,37 @@ def test_floor0_reports_the_reference_s_decode_error():
     assert e.value.status == sa._ffi.ERR_DECODE
 
 
-def test_status_arrays(emu_ctx):
+def check_status_arrays(ctx, dev, host):
+    """The per-block status kernels (ABI v2) against what the reference would have answered; `dev` / `host` move arrays."""
     desc = sa.flac_desc(np.array([0, 1, 1, 2, 2, 2, 3, 2, 2]), np.array([0, 4, 5, 32, 33, 0, 0, 9, 8]), np.array([0, 0, 0, 14, 3, 3, 0, 32, 31]),
                         np.zeros(9))
     st = np.full(9, 99, np.int8)
-    sa.flac_block_status(emu_ctx, desc, 8, st)
+    st = host(sa.flac_block_status(ctx, dev(desc), 8, dev(st)))
     D, U = sa._ffi.ERR_DECODE, sa._ffi.ERR_UNSUPPORTED
     #           verbatim fixed4 fixed5 lpc32>8 lpc33 lpc0 kind3 order9>8 ok
     assert st.tolist() == [0, 0, D, D, D, D, D, D, 0]
     st2 = np.full(2, 99, np.int8)
-    sa.flac_block_status(emu_ctx, sa.flac_desc(np.array([2, 2]), np.array([4, 4]), np.array([32, 15]), np.zeros(2)), 4096, st2)
+    st2 = host(sa.flac_block_status(ctx, dev(sa.flac_desc(np.array([2, 2]), np.array([4, 4]), np.array([32, 15]), np.zeros(2))), 4096, dev(st2)))
     assert st2.tolist() == [U, 0]
     ad = sa.alac_desc(np.array([0, 1, 14, 15]), np.array([4, 4, 4, 4]), np.array([9, 9, 9, 9]), np.array([16, 16, 16, 16]))
     st3 = np.full(4, 99, np.int8)
-    sa.alac_block_status(emu_ctx, ad, st3)
+    st3 = host(sa.alac_block_status(ctx, dev(ad), dev(st3)))
     assert st3.tolist() == [0, D, D, 0]
     ys = np.zeros((5, 65), np.uint32)
     ys[1, 64], ys[2, 0], ys[3, 30], ys[4, 63] = 256, 255, 70000, 255
     st5 = np.full(5, 99, np.int8)
-    sa.vorbis_floor1_status(emu_ctx, 65, ys, 5, st5)
+    st5 = host(sa.vorbis_floor1_status(ctx, 65, dev(ys), 5, dev(st5)))
     assert st5.tolist() == [0, U, 0, U, 0]
     st6 = np.full(3, 99, np.int8)
-    sa.vorbis_floor1_status(emu_ctx, 7, np.array([[0, 1, 2, 3, 4, 5, 300], [255] * 7, [0, 0, 0, 0, 0, 0, 0]], np.uint32), 3, st6)
+    st6 = host(sa.vorbis_floor1_status(ctx, 7, dev(np.array([[0, 1, 2, 3, 4, 5, 300], [255] * 7, [0, 0, 0, 0, 0, 0, 0]], np.uint32)), 3, dev(st6)))
     assert st6.tolist() == [U, 0, 0]
     filt = np.zeros(5, sa.AAC_TNS_DTYPE)
     filt["frame"], filt["start"], filt["end"], filt["order"] = [0, 9, 0, 0, 1], [0, 0, 8, 0, 4], [16, 16, 8, 1028, 1024], [3, 3, 3, 3, 21]
     filt[0]["order"] = 20
     st4 = np.full(5, 99, np.int8)
-    sa.aac_tns_status(emu_ctx, 2, filt, st4)
+    st4 = host(sa.aac_tns_status(ctx, 2, dev(filt), dev(st4)))
     assert st4.tolist() == [0, -1, -1, -1, -1]
+
+
+def test_status_arrays(emu_ctx):
+    check_status_arrays(emu_ctx, lambda a: a, lambda a: a)
