@@ -193,6 +193,41 @@ def test_emu_tns_unaligned_ranges(emu_ctx):
     assert bit_equal(got, want)
 
 
+def tns_case_ragged(rng, n_frames):
+    """One filter per frame over an arbitrary range (any start, any length, both directions, every order): quads of
+    lanes then mix ranges whose groups are aligned, unaligned, ragged or already finished."""
+    from symphonia_amd import AAC_TNS_DTYPE
+    coeffs = (rng.standard_normal((n_frames, 1024)) * np.exp2(rng.integers(-6, 8, (n_frames, 1)))).astype(np.float32)
+    filt = np.zeros(n_frames, AAC_TNS_DTYPE)
+    for k in range(n_frames):
+        kind = rng.integers(0, 4)
+        if kind == 0:    # aligned start, any length
+            lo = 4 * int(rng.integers(0, 255))
+            hi = int(rng.integers(lo + 1, 1025))
+        elif kind == 1:  # anything
+            lo = int(rng.integers(0, 1023))
+            hi = int(rng.integers(lo + 1, 1025))
+        elif kind == 2:  # short
+            lo = int(rng.integers(0, 1000))
+            hi = lo + int(rng.integers(1, 24))
+        else:            # whole multiples of sixteen lines
+            lo = 16 * int(rng.integers(0, 32))
+            hi = lo + 16 * int(rng.integers(1, (1024 - lo) // 16 + 1))
+        order = int(rng.integers(1, 21))
+        filt[k] = (k, lo, hi, order, int(rng.integers(0, 2)), 0, tns_lpc(rng, order, coef_res=bool(rng.integers(0, 2))))
+    return coeffs, filt[rng.permutation(n_frames)]
+
+
+@pytest.mark.parametrize("seed,n_frames", [(3, 64), (4, 130), (5, 7)])
+def test_emu_tns_ragged_quads(emu_ctx, seed, n_frames):
+    from symphonia_amd import AacSpectralTools
+    coeffs, filt = tns_case_ragged(np.random.default_rng(seed), n_frames)
+    want = tns_reference(coeffs, filt, n_frames)
+    got = coeffs.copy()
+    AacSpectralTools(emu_ctx, SWB_LONG, SWB_SHORT).tns(got, filt)
+    assert bit_equal(got, want)
+
+
 def test_emu_tools_feed_synth(emu_ctx):
     """joint stereo -> TNS -> Dsp::synth: the order of ChannelPair::decode + Ics::synth_channel (cpe.rs:109-157, ics/mod.rs:449-468)."""
     from symphonia_amd import AacDsp, AacSpectralTools
@@ -247,5 +282,21 @@ def test_gpu_aac_tools():
         ctx.sync()
         assert bit_equal(d.cpu().numpy(), want_js)
         tools.tns(d, torch.from_numpy(filt.view(np.uint8).reshape(-1, 92)).cuda())
+        ctx.sync()
+        assert bit_equal(d.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_frames", [(13, 64), (14, 1000), (15, 333)])
+def test_gpu_tns_ragged_quads(seed, n_frames):
+    import torch
+    from symphonia_amd import AacSpectralTools, Context
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    coeffs, filt = tns_case_ragged(np.random.default_rng(seed), n_frames)
+    want = tns_reference(coeffs, filt, n_frames)
+    with Context(0) as ctx:
+        d = torch.from_numpy(coeffs).cuda()
+        AacSpectralTools(ctx, SWB_LONG, SWB_SHORT).tns(d, torch.from_numpy(filt.view(np.uint8).reshape(-1, 92)).cuda())
         ctx.sync()
         assert bit_equal(d.cpu().numpy(), want)
