@@ -51,13 +51,32 @@ __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)
 }
 
 // The same recurrence with the dot product carried by the FP64 FMA pipe, which is exact here:
-// |c_j| < 2^16 (checked per wavefront; a valid stream has qlp precision <= 15 bits, decoder.rs:467-471)
-// and |s| <= 2^31, so every product is < 2^47 and every partial sum of <= 32 products is < 2^52 < 2^53:
-// no FMA ever rounds, the sum is the exact integer whatever the association, and the four partial
-// accumulators (which break the 32-deep dependent chain) change nothing.  v_mad_i64_i32 is a
-// quarter-rate instruction on CDNA4, v_fma_f64 is full rate.
-// (acc >> shift) as i32  ==  floor(acc * 2^-shift) mod 2^32: ldexp and floor are exact, the mod is taken
-// by peeling the multiple of 2^32 off in f64 (exact) before the conversion.
+// sum |c_j| < 2^20 (checked per wavefront; a valid stream has <= 32 coefficients of qlp precision <= 15 bits,
+// decoder.rs:467-471) and |s| <= 2^31, so every partial sum is below 2^51 in magnitude (2^53 with the offset below):
+// no FMA ever rounds and the sum is the exact integer whatever the association.  v_mad_i64_i32 is a
+// slower instruction on CDNA4 than v_fma_f64.
+// (acc >> shift) as i32 without leaving the integer domain: the sum is started from 2^52 + 2^51 instead of 0, so the f64
+// that comes out is 2^52 + (2^51 + acc), whose 52 mantissa bits ARE the integer 2^51 + acc (|acc| < 2^51 because a lane only
+// takes this path when the magnitudes of its coefficients sum to less than 2^20, load_params).  Its low word is acc mod 2^32,
+// its high word minus 0x43380000 (exponent field and the 2^51) is floor(acc / 2^32), and the wanted 32 bits of the arithmetic
+// shift are one v_alignbit_b32 of the two.  (Round 1 took floor(ldexp(acc, -shift)) mod 2^32 in f64: six more FP64-rate
+// instructions per sample, a tenth of the loop.)
+// Partial accumulators of the 32-tap sum (build-time knob).  Four, to break the dependent FMA chain, was round 1's guess;
+// measured in round 2 (profiles/r02zh_flac_ab.txt): 4 -> 9.85 ms, 2 -> 9.79 ms, 1 -> 8.60 ms for config 5 -- with two wavefronts
+// per SIMD the chain's latency is covered anyway, and the extra accumulators cost FP64-rate adds and registers.
+#ifndef SYM_FLAC_PARTS
+#define SYM_FLAC_PARTS 1
+#endif
+constexpr double kFlacMagic = 6755399441055744.0;  // 2^52 + 2^51
+__device__ __forceinline__ int32_t flac_shifted(double acc_plus_magic, int shift) {
+    const uint64_t bits = __builtin_bit_cast(uint64_t, acc_plus_magic);
+    const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32) - 0x43380000u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int32_t)__builtin_amdgcn_alignbit(hi, lo, (uint32_t)shift);
+#else
+    return (int32_t)(uint32_t)((((uint64_t)hi << 32) | lo) >> (shift & 31));
+#endif
+}
 template <int TAPS>
 __device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&c)[32], int32_t *row, int col0,
                                                 int first_pred, int n_valid, int shift, uint32_t wasted) {
@@ -71,18 +90,16 @@ __device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&
         if (u < n_valid) {
             int32_t x = xs[u & 3];
             if (col0 + u >= first_pred) {
-                constexpr int P = TAPS >= 8 ? 4 : 1;
+                constexpr int P = TAPS >= 8 ? SYM_FLAC_PARTS : 1;
                 double part[P];
 #pragma unroll
-                for (int q = 0; q < P; ++q) part[q] = 0.0;
+                for (int q = 0; q < P; ++q) part[q] = q == 0 ? kFlacMagic : 0.0;
 #pragma unroll
                 for (int j = 0; j < TAPS; ++j) part[j % P] = __builtin_fma(c[j], h[(u + 31 - j) & 31], part[j % P]);
                 double acc = part[0];
                 if constexpr (P == 4) acc = (part[0] + part[1]) + (part[2] + part[3]);
-                const double q = __builtin_floor(__builtin_ldexp(acc, -shift));         // floor(acc / 2^shift)
-                const double hi = __builtin_floor(__builtin_ldexp(q, -32));             // floor(q / 2^32)
-                const double lo = __builtin_fma(hi, -4294967296.0, q);                  // q mod 2^32, in [0, 2^32)
-                x = wrap_add(x, (int32_t)(uint32_t)lo);
+                if constexpr (P == 2) acc = part[0] + part[1];
+                x = wrap_add(x, flac_shifted(acc, shift));
             }
             h[u & 31] = (double)x;
             xs[u & 3] = (int32_t)((uint32_t)x << wasted);  // samples_shl (decoder.rs:403-409)
@@ -133,14 +150,13 @@ __device__ __forceinline__ void load_params(LaneParams &p, const symaccel_flac_d
     }
     // Does any lane of this wavefront need more than 4 / 12 taps?  (wave-uniform specialisation)
     p.max_order = wave_max(p.order);
-    // FP64 path iff every coefficient of the wavefront is below 2^16 in magnitude (always, for valid streams)
-    unsigned cmax = 0;
+    // FP64 path iff in every lane of the wavefront the coefficient magnitudes sum to less than 2^20 (always, for valid
+    // streams: <= 32 coefficients of <= 15 bits): with |sample| <= 2^31 every partial sum then stays below 2^51 in
+    // magnitude -- exact in f64 whatever the association, and inside what flac_shifted can take apart
+    unsigned long long csum = 0;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const unsigned a = (unsigned)iabs_sat(p.c[j]);
-        cmax = a > cmax ? a : cmax;
-    }
-    p.use_f64 = wave_max(cmax) < 65536u;
+    for (int j = 0; j < 32; ++j) csum += (unsigned)iabs_sat(p.c[j]);
+    p.use_f64 = wave_max(csum < (1ull << 20) ? 0u : 1u) == 0u;
 }
 
 // One kernel per arithmetic path, so each is register-allocated for what it keeps live (the FP64

@@ -152,8 +152,8 @@ def aac_sequence_chain(rng, n_frames, p_switch=0.25):
 
 
 def flac_extreme_case(seed, big_coeffs):
-    """Full-range i32 samples (wrapping adds) with coefficients at the edge of the FP64-exact path
-    (|c| < 2^16, big_coeffs=False) or far beyond it (integer path, big_coeffs=True)."""
+    """Full-range i32 samples (wrapping adds) with coefficients at the edge of the FP64-exact path (the magnitudes of a
+    block's coefficients sum to at most 2^20 - 1, big_coeffs=False) or far beyond it (integer path, big_coeffs=True)."""
     rng = np.random.default_rng(seed)
     nb, blocksize = 64, 97
     buf = rng.integers(-(1 << 31), 1 << 31, (nb, blocksize)).astype(np.int32)
@@ -163,11 +163,18 @@ def flac_extreme_case(seed, big_coeffs):
     order = rng.integers(1, 33, nb).astype(np.uint8)
     order[:4] = 32
     shift = rng.integers(0, 32, nb).astype(np.uint8)
-    lim = (1 << 30) if big_coeffs else (1 << 16) - 1
+    shift[:4] = (0, 31, 19, 20)
+    lim = (1 << 30) if big_coeffs else 32767
     coeffs = rng.integers(-lim, lim + 1, (nb, 32)).astype(np.int32)
     coeffs[0] = -lim
     coeffs[1] = lim
     coeffs[2] = np.where(np.arange(32) % 2 == 0, lim, -lim)
+    if not big_coeffs:  # 32 * 32767 + 31 = 2^20 - 1: the largest sum of magnitudes the FP64 path takes
+        coeffs[0, 5] -= 31
+        coeffs[1, 9] += 31
+        coeffs[2, 0] += 31
+        coeffs[3] = 0
+        coeffs[3, 7] = (1 << 20) - 1  # ... as one coefficient
     return buf, kind, order, shift, coeffs
 
 
