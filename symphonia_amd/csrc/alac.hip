@@ -99,14 +99,15 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
             //    across taps -- hipcc keeps such bools as SGPR-pair masks, ran out of SGPRs at 32 taps, spilled them
             //    into VGPR lanes and branched around every coefficient update;
             //  * tap k subtracts t_k = (1 + j) * step_k from the residual, and neither t_k nor the direction the
-            //    coefficient moves in depends on the residual, so the residual after tap k is res - (t_{order-1} + ... +
-            //    t_k) (wrapping sums re-associate freely): only the running sum and "still active" are serial;
+            //    coefficient moves in depends on the residual: only the residual itself and "still active" are serial (the
+            //    residual keeps being updated after the reference's `break`, where nothing reads it any more).  Round 2 first
+            //    carried a separate running sum of the t_k to shorten that chain; one instruction per tap more and, with three
+            //    or four wavefronts per SIMD, nothing gained (profiles/r02zg_alac_med3_ab.txt);
             //  * a tap beyond the lane's own order (TAPS is the wavefront's maximum) is neutralised by zeroing its
             //    difference v: step, t_k and the coefficient move are then 0, and since those taps come first, while the
             //    running sum is still 0, the activity test sees the untouched residual and changes nothing.
             const int32_t pm = res > 0 ? 0 : -1;      // 0: the residual is positive, -1: negative (zero: never active)
             int32_t act = res != 0 ? -1 : 0;
-            int32_t run = 0;                          // t_{order-1} + ... + t_k so far
 #pragma unroll
             for (int k = TAPS - 1; k >= 0; --k) {
                 const int32_t nk = (int32_t)L.order - k;                                   // (1 + j); <= 0 beyond the order
@@ -115,10 +116,9 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
                 const int32_t m2 = pm ^ (v >> 31);                                         // v and the residual differ in sign
                 const int32_t step = wrap_sub(v ^ m2, m2) >> L.shift;                      // (+-sign(v) * v) >> shift = +-|v| >> shift
                 const int32_t sg = signum_i32(v);
-                run = wrap_add(run, tap_mul<M24>(nk, step));
-                const int32_t r = wrap_sub(res, run);                                      // the residual after this tap
-                L.c[k] = wrap_sub(L.c[k], wrap_sub(sg ^ pm, pm) & act);                    // c -= +-sign, while still active
-                act = (r ^ pm) > pm ? act : 0;                                             // r > 0 resp. r < 0: still on the residual's side
+                L.c[k] = wrap_sub(L.c[k], wrap_sub(sg ^ pm, pm) & act);                    // c -= +-sign, while still active (as AND + v_mad_i32_i24: 4 % slower)
+                res = wrap_sub(res, tap_mul<M24>(nk, step));                               // the residual after this tap
+                act = (res ^ pm) > pm ? act : 0;                                           // > 0 resp. < 0: still on the residual's side
             }
         }
     }
