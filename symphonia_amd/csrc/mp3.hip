@@ -156,6 +156,9 @@ __device__ __forceinline__ void fetch_granule(const float *granule, int hl, floa
 #define SYM_MP3_VARIANT 0
 #endif
 
+#ifndef SYM_MP3_SLOT_GROUP
+#define SYM_MP3_SLOT_GROUP 3
+#endif
 #ifndef SYM_MP3_WAVES
 #define SYM_MP3_WAVES 3  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
 #endif
@@ -427,25 +430,39 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
         // the two LDS reads of slot b + 1 are issued before the taps of slot b (the store's branch per slot otherwise
         // pins each read directly in front of its first use: 18 exposed LDS round trips per granule)
         float ra = S[vm.fcol], rb = S[vm.scol];
+        // kSlotGroup time slots per store branch: the 16-tap sums of a group are independent chains in ONE basic block (the
+        // per-slot `if (emit)` used to fence every chain off from the next)
+        constexpr int kSlotGroup = SYM_MP3_SLOT_GROUP;
+        static_assert(18 % kSlotGroup == 0, "whole groups");
 #pragma unroll
-        for (int b = 0; b < 18; ++b) {
-            nA[b] = __uint_as_float(__float_as_uint(ra) ^ vm.fsign);  // V[i]
-            nB[b] = -rb;                                               // V[32 + i]
-            if (b + 1 < 18) {
-                ra = S[(b + 1) * kSStride + vm.fcol];
-                rb = S[(b + 1) * kSStride + vm.scol];
-            }
-            float acc = 0.0f;
+        for (int b0 = 0; b0 < 18; b0 += kSlotGroup) {
+            float accs[kSlotGroup];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ra_ = b - 2 * j, rb_ = b - 2 * j - 1;
-                acc += (ra_ >= 0 ? nA[ra_ >= 0 ? ra_ : 0] : oA[ra_ < 0 ? kHistOld + ra_ : 0]) * dw0[j];
-                acc += (rb_ >= 0 ? nB[rb_ >= 0 ? rb_ : 0] : oB[rb_ < 0 ? kHistOld + rb_ : 0]) * dw1[j];
+            for (int g = 0; g < kSlotGroup; ++g) {
+                const int b = b0 + g;
+                nA[b] = __uint_as_float(__float_as_uint(ra) ^ vm.fsign);  // V[i]
+                nB[b] = -rb;                                               // V[32 + i]
+                if (b + 1 < 18) {
+                    ra = S[(b + 1) * kSStride + vm.fcol];
+                    rb = S[(b + 1) * kSStride + vm.scol];
+                }
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ra_ = b - 2 * j, rb_ = b - 2 * j - 1;
+                    acc += (ra_ >= 0 ? nA[ra_ >= 0 ? ra_ : 0] : oA[ra_ < 0 ? kHistOld + ra_ : 0]) * dw0[j];
+                    acc += (rb_ >= 0 ? nB[rb_ >= 0 ? rb_ : 0] : oB[rb_ < 0 ? kHistOld + rb_ : 0]) * dw1[j];
+                }
+                accs[g] = acc;
             }
 #if SYM_MP3_OTILE
-            O[32 * b + hl] = acc;
+#pragma unroll
+            for (int g = 0; g < kSlotGroup; ++g) O[32 * (b0 + g) + hl] = accs[g];
 #else
-            if (emit) st_stream(pcm + (size_t)gi * 576 + 32 * b + hlg, acc);
+            if (emit) {
+#pragma unroll
+                for (int g = 0; g < kSlotGroup; ++g) st_stream(pcm + (size_t)gi * 576 + 32 * (b0 + g) + hlg, accs[g]);
+            }
 #endif
         }
 #if SYM_MP3_OTILE
