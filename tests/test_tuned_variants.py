@@ -14,6 +14,9 @@ CASES = [
     ({"SYMACCEL_TUNE_AAC_VARIANT": "1"}, "tests/test_emu_core_aac.py", "aac_all_sequences or imdct_bit_exact"),
     ({"SYMACCEL_TUNE_MP3_VARIANT": "2"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_VARIANT": "3"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "18"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_FLAC_PARTS": "4"}, "tests/test_emu_codecs.py", "emu_flac"),
 ]
 
 
