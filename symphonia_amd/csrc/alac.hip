@@ -67,15 +67,21 @@ struct AlacLane {
 
 // One sample.  `past_far` = out[i - order - 1] as read back from LDS (valid for order >= 3).
 // FULL: every lane's order equals TAPS (wave-uniform), so no tap needs neutralising.
-template <int TAPS, bool M24, bool FULL, int NC>
+// STEADY: every lane of the wavefront is enabled and past its warm-up samples (i > order): no per-sample conditions.
+template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false>
 __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigned i, int32_t past_far) {
-    if (L.enabled) {
+    if (STEADY || L.enabled) {
         // first pass of the double predictor: out[i] = clip(out[i] + out[i-1]) over the whole block
-        if (L.twice && i >= 1) x = clip_msbs(wrap_add(x, L.p1_prev), L.clip);
+        if constexpr (STEADY) {
+            const int32_t x2 = clip_msbs(wrap_add(x, L.p1_prev), L.clip);
+            x = L.twice ? x2 : x;
+        } else {
+            if (L.twice && i >= 1) x = clip_msbs(wrap_add(x, L.p1_prev), L.clip);
+        }
         L.p1_prev = x;
-        if (i >= 1 && i <= L.order) {
+        if (!STEADY && i >= 1 && i <= L.order) {
             x = clip_msbs(wrap_add(x, L.h[0]), L.clip);  // warm-up samples (lib.rs:196-198)
-        } else if (i > L.order) {
+        } else if (STEADY || i > L.order) {
             int32_t res = x;
             int32_t past0;
             if constexpr (NC == 32) {
@@ -131,7 +137,7 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
 // 32 samples of one tile.  `row` = this tile's LDS row of the lane, `prev_row` = the previous tile's (still intact in
 // the other LDS buffer); t0 = absolute index of column 0.  Rows are written back four samples at a time, so anything
 // older than three samples can be read back from LDS: that is where out[i - order - 1] comes from for order >= 3.
-template <int TAPS, bool M24, bool FULL, int NC>
+template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false>
 __device__ __forceinline__ void alac_steps32(AlacLane<NC> &L, int32_t *row, const int32_t *prev_row, unsigned t0, int n_valid) {
 #pragma unroll 1
     for (int u0 = 0; u0 < 32; u0 += 4) {
@@ -140,13 +146,13 @@ __device__ __forceinline__ void alac_steps32(AlacLane<NC> &L, int32_t *row, cons
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int u = u0 + q;
-            if (u < n_valid) {
+            if (STEADY || u < n_valid) {
                 int32_t far = 0;
                 if constexpr (NC == 32) {
                     const int idx = u - (int)L.order - 1;
                     far = idx >= 0 ? row[idx >= 0 ? idx : 0] : prev_row[32 + (idx < -32 ? -32 : idx)];
                 }
-                xs[q] = alac_step<TAPS, M24, FULL, NC>(L, xs[q], t0 + (unsigned)u, far);
+                xs[q] = alac_step<TAPS, M24, FULL, NC, STEADY>(L, xs[q], t0 + (unsigned)u, far);
             }
         }
         *reinterpret_cast<int4 *>(row + u0) = make_int4(xs[0], xs[1], xs[2], xs[3]);
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
     }
     const unsigned max_order = wave_max(L.enabled ? L.order : 0u);
     const bool full8 = __all(!have || !L.enabled || L.order == 8u) != 0 && max_order == 8u;
+    const bool steady_ok = __all(!have || L.enabled) != 0;  // (with full8: past sample 8 no lane has a per-sample condition left)
 
     const bool aligned = (blocksize & 3u) == 0 && blk0 + kRows <= n_blocks;
     const unsigned n_tiles = (blocksize + kCols - 1) / kCols;
@@ -309,7 +316,9 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
             int32_t *row = tile + lane * kStride;
             const int32_t *prow = prev_tile + lane * kStride;
             if constexpr (SMALL) {
-                if (full8)  // the common stream: every block of the wavefront has order 8
+                if (full8 && steady_ok && cols == (unsigned)kCols && t0 > 8u)
+                    alac_steps32<8, M24, true, 8, true>(L, row, prow, t0, (int)cols);
+                else if (full8)  // the common stream: every block of the wavefront has order 8
                     alac_steps32<8, M24, true>(L, row, prow, t0, (int)cols);
                 else if (max_order <= 4)
                     alac_steps32<4, M24, false>(L, row, prow, t0, (int)cols);
