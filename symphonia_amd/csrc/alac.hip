@@ -315,16 +315,22 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
         if (have) {
             int32_t *row = tile + lane * kStride;
             const int32_t *prow = prev_tile + lane * kStride;
+            // steady: a full tile past every lane's warm-up samples, every block of the wavefront enabled
+            const bool steady = steady_ok && cols == (unsigned)kCols && t0 > max_order;
             if constexpr (SMALL) {
-                if (full8 && steady_ok && cols == (unsigned)kCols && t0 > 8u)
-                    alac_steps32<8, M24, true, 8, true>(L, row, prow, t0, (int)cols);
-                else if (full8)  // the common stream: every block of the wavefront has order 8
-                    alac_steps32<8, M24, true>(L, row, prow, t0, (int)cols);
-                else if (max_order <= 4)
-                    alac_steps32<4, M24, false>(L, row, prow, t0, (int)cols);
-                else
-                    alac_steps32<8, M24, false>(L, row, prow, t0, (int)cols);
+                if (full8) {  // the common stream: every block of the wavefront has order 8
+                    if (steady) alac_steps32<8, M24, true, 8, true>(L, row, prow, t0, (int)cols);
+                    else alac_steps32<8, M24, true>(L, row, prow, t0, (int)cols);
+                } else if (max_order <= 4) {
+                    if (steady) alac_steps32<4, M24, false, 8, true>(L, row, prow, t0, (int)cols);
+                    else alac_steps32<4, M24, false>(L, row, prow, t0, (int)cols);
+                } else {
+                    if (steady) alac_steps32<8, M24, false, 8, true>(L, row, prow, t0, (int)cols);
+                    else alac_steps32<8, M24, false>(L, row, prow, t0, (int)cols);
+                }
             } else {
+                // (no steady variant here: a second copy of the 16- / 32-tap step beside the first does not fit the register
+                // file -- 284 to 336 bytes of scratch)
                 if (max_order <= 16)
                     alac_steps32<16, M24, false>(L, row, prow, t0, (int)cols);
                 else
