@@ -38,7 +38,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
     dev = "cpu" if emulate else "cuda"
     g = torch.Generator(device=dev).manual_seed(seed)
     if name == "aac":
-        nch, nfr = int(128 * scale), (6 if emulate else 1024)  # 64 stereo streams x 1024 frames = 65 536 frames
+        nch, nfr = max(2, int(128 * scale)), (6 if emulate else 1024)  # 64 stereo streams x 1024 frames = 65 536 frames
         coeffs = torch.randn((nch, nfr, 1024), generator=g, device=dev, dtype=torch.float32)
         coeffs *= torch.exp2(torch.randint(-8, 13, (nch, nfr, 64), generator=g, device=dev).float()).repeat_interleave(16, dim=2)
         coeffs[:, :, 672:] = 0.0  # 48 kHz content: band-limited like a real encoder's output
@@ -67,7 +67,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d), 1024-pt IMDCT+window+OLA, KBD"
                         % (frames, nch, nfr), "channel_frames": nch * nfr, "samples_per_frame": 1024}, "aac_synth_kernel", pcm
     if name == "mp3":
-        nch, ngr = int(128 * scale), (6 if emulate else 2048)  # 64 stereo streams x 2048 granules = 131 072 granules
+        nch, ngr = max(2, int(128 * scale)), (6 if emulate else 2048)  # 64 stereo streams x 2048 granules = 131 072 granules
         xr = torch.randn((nch, ngr, 576), generator=g, device=dev, dtype=torch.float32) * 0.05
         bt, mx, rz = np.zeros((nch, ngr), np.uint8), np.zeros((nch, ngr), np.uint8), np.full((nch, ngr), 576)
         if mix > 0.0:  # development: Long -> Start -> Short... -> End walks (a quarter of the short runs mixed), random rzero
@@ -102,7 +102,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             "workload": "MP3 Layer III 44.1 kHz stereo, %d long-block granules (%d chains x %d), hybrid synthesis + polyphase"
                         % (granules, nch, ngr), "granule_channels": nch * ngr, "samples_per_granule": 576}, "mp3_synth_kernel", pcm
     if name == "vorbis":
-        nch, nb = int(64 * scale), (16 if emulate else 4096)  # one GPU's shard of config 4: 8 streams x 8 ch x 4096 blocks
+        nch, nb = max(1, int(64 * scale)), (16 if emulate else 4096)  # one GPU's shard of config 4: 8 streams x 8 ch x 4096 blocks
         rng = np.random.default_rng(seed)
         flags = np.zeros((nch, nb), np.uint8)
         cur = np.ones(nch, bool)
@@ -129,7 +129,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             "workload": "Vorbis 2048/256 mixed block sizes, 8 ch, %d blocks (%d chains x %d)" % (nch * nb // 8, nch, nb),
             "channel_blocks": nch * nb}, "vorbis_synth_wave_kernel", pcm
     if name == "flac":
-        nb, bs = int(1048576 * scale) & ~1, 4096  # config 5: 1 M subframe blocks of 4096 samples = 16 GiB, in place
+        nb, bs = max(2, int(1048576 * scale) & ~1), 4096  # config 5: 1 M subframe blocks of 4096 samples = 16 GiB, in place
         buf, desc, co, pair_mode, _ = flac_config5(torch, nb, bs, seed, dev)
         fp = sa.FlacPredictor(ctx)
 
@@ -143,7 +143,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
                         "%d subframe blocks of 4096 samples, half the channel pairs mid/side (side channel 25 bits), "
                         "restore + decorrelate + left-justify fused, in place" % nb, "samples": nb * bs}, "flac_restore_f64_kernel", buf
     if name == "alac":
-        nb, bs = int(262144 * scale), 4096  # 16-bit ALAC frames of 4096 samples, adaptive predictor of order 8
+        nb, bs = max(1, int(262144 * scale)), 4096  # 16-bit ALAC frames of 4096 samples, adaptive predictor of order 8
         buf = torch.randint(-(1 << 9), 1 << 9, (nb, bs), generator=g, device=dev, dtype=torch.int32)
         desc_np = sa.alac_desc(np.zeros(nb), np.full(nb, 8), np.full(nb, 9), np.full(nb, 16))
         desc = torch.from_numpy(desc_np.view(np.uint8).reshape(nb, 4)).to(dev)
@@ -334,6 +334,32 @@ def host_to_host_aac(sa, ctx, torch, pcm, coeffs, frames, reps=3):
             "path": "symaccel_aac_synth_pipelined on page-locked host buffers: chunked H2D || kernel || D2H on three streams"}
 
 
+def copy_ceiling(ctx, torch, seg_len, reps=10):
+    """the copy rates THIS run reaches with the synthesis kernels' traffic shape (1 byte read : 1 byte
+    written, config 2's footprint: 512 MiB in, 512 MiB out), through symaccel_probe_copy_device on the launch stream:
+    a plain 16 B/lane grid-stride copy, and the copy in which every wavefront streams `seg_len` consecutive 4 KiB frames
+    (aac_synth_kernel's own access pattern).  HIP events around `reps` launches each, after one untimed launch."""
+    nbytes = 512 << 20
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
+    b = torch.empty_like(a)
+    d = ctx.lib.dll
+    out = {"bytes_read": nbytes, "bytes_written": nbytes, "unit": "GB/s", "reps": reps}
+    for key, fpw, flags in (("plain_float4", 0, 0), ("plain_float4_nt", 0, 1), ("frames_per_wavefront_1_nt", 1, 1),
+                            ("frames_per_wavefront_%d_nt" % seg_len, seg_len, 1), ("frames_per_wavefront_%d" % seg_len, seg_len, 0)):
+        ctx._call(d.symaccel_probe_copy_device, a.data_ptr(), b.data_ptr(), nbytes, fpw, flags)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            ctx._call(d.symaccel_probe_copy_device, a.data_ptr(), b.data_ptr(), nbytes, fpw, flags)
+        ev1.record()
+        torch.cuda.synchronize()
+        out[key] = 2.0 * nbytes / (ev0.elapsed_time(ev1) / 1e3 / reps) / 1e9
+    if not bool(torch.equal(a, b)):
+        raise RuntimeError("probe copy did not copy")
+    del a, b
+    return out
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` with no launcher in the environment: start N ranks ourselves (one process per GPU) with
     torch.distributed.run on the loopback address and hand its exit status back.  (The driver may also start the ranks
@@ -376,6 +402,10 @@ def main():
                     help="N > 1: skip the scatter -> synthesis -> gather leg (reported beside, never inside, `value`)")
     ap.add_argument("--no-host-path", action="store_true",
                     help="N = 1, aac: skip the host-to-host line (pinned, chunked, overlapped staging through symaccel_aac_synth_pipelined)")
+    ap.add_argument("--no-others", action="store_true",
+                    help="N = 1, aac: skip the `other_workloads` object (BASELINE configs 3, 4 (one GPU's shard), 5 and the ALAC "
+                         "predictor: 5 steps each with the same event timing)")
+    ap.add_argument("--no-copy-ceiling", action="store_true", help="N = 1: skip the same-run copy probes")
     ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the extra BASELINE config-4 (Vorbis shard) line")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: run the control flow on CPU tensors through the CPU emulation build of the kernels "
@@ -520,6 +550,32 @@ def main():
         except Exception as e:  # noqa: BLE001
             config4 = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # The same run's copy ceilings and the other BASELINE configs under the same clock: optional legs, each in
+    # its own try so that nothing here can cost the headline line.
+    ceiling = None
+    if world == 1 and not emulate and not args.no_copy_ceiling:
+        try:
+            ceiling = copy_ceiling(ctx, torch, 64)
+        except Exception as e:  # noqa: BLE001
+            ceiling = {"error": "%s: %s" % (type(e).__name__, e)}
+        log("copy probes done")
+    others = None
+    if world == 1 and args.workload == "aac" and not args.no_others:
+        others = {}
+        for w in ("mp3", "vorbis", "flac", "alac"):
+            try:
+                stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, 0.0, emulate)
+                nw, ww = 5, 2
+                ew, lw, _ = timed(stw, nw, ww)
+                others[w] = {"value": unitsw * nw / ew, "unit": unitw + "/s", "ms_per_step": ew / nw * 1e3, "steps": nw, "warmup": ww,
+                             "kernel": kernelw, "kernel_ms": lw * 1e3, "algorithmic_bytes_per_launch": bytesw,
+                             "roofline_frac": bytesw / lw / 1e9 / HBM_PEAK_GBS, "workload": cfgw["workload"]}
+                del stw, resw
+            except Exception as e:  # noqa: BLE001
+                others[w] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+            log("other workload %s done" % w)
+
     if rank == 0:
         achieved = alg_bytes / launch_s / 1e9
         out = {
@@ -555,8 +611,19 @@ def main():
                 out["roofline"]["traffic_source"] = tr["source"] + " (a committed rocprofv3 PMC measurement of this command, not taken in this run)"
         except (OSError, ValueError, KeyError):
             pass
-        out["roofline"]["copy_ceiling_note"] = ("a plain copy of the same 1:1 read/write footprint reaches 5.1-5.9 TB/s on "
-                                                "this part (profiles/r01_ubench_hbm_copy.txt); peak = HBM3E spec")
+        if ceiling:
+            out["roofline"]["copy_ceiling"] = ceiling
+            best = max((v for k, v in ceiling.items() if k.startswith(("plain", "frames")) and isinstance(v, float)), default=None)
+            same = ceiling.get("frames_per_wavefront_64_nt")
+            if best:
+                out["roofline"]["frac_of_best_copy"] = achieved / best
+            if same:
+                out["roofline"]["frac_of_same_pattern_copy"] = achieved / same
+            out["roofline"]["copy_ceiling_note"] = ("symaccel_probe_copy_device in THIS run: 512 MiB read + 512 MiB written per launch; "
+                                                    "frames_per_wavefront_64 = every wavefront streams 64 consecutive 4 KiB frames, "
+                                                    "the headline kernel's access pattern; `peak` stays the HBM3E spec")
+        if others:
+            out["other_workloads"] = others
         if args.workload == "alac":
             out["roofline"]["note"] = "integer-ALU bound (adaptive predictor, ~13 x order operations per sample), not HBM"
         if args.workload == "flac":

@@ -476,6 +476,16 @@ int symaccel_alac_mid_side_device(symaccel_ctx *ctx, const int32_t *d_weight, co
 int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uint8_t *h_shift, int32_t *h_ch0,
                            int32_t *h_ch1, size_t n_pairs, size_t blocksize);
 
+/* ------------------------------------------------------------------ measurement probe */
+
+/* Device-to-device copy of `bytes` (a multiple of 4096; distinct, 16-byte-aligned buffers) with the traffic shape of the
+ * synthesis kernels -- every byte read once and written once -- so that a benchmark can quote a workload against the copy
+ * rate the SAME run reaches.  frames_per_wavefront 0: a plain grid-stride 16 B/lane copy; k > 0: every
+ * wavefront streams k consecutive 4 KiB frames, the access pattern of a wavefront that walks a k-frame segment of one
+ * chain.  flags bit 0: non-temporal loads and stores (what the synthesis kernels use).  Not part of any decode path. */
+int symaccel_probe_copy_device(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes,
+                               uint32_t frames_per_wavefront, uint32_t flags);
+
 /* ------------------------------------------------------------- table read-back (for tests) */
 
 enum symaccel_table {

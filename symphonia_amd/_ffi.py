@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "symaccel_host_aac_pulse", "symaccel_host_vorbis_bark_map", "symaccel_host_vorbis_floor0_coeffs", "symaccel_host_vorbis_floor0",
     "symaccel_flac_block_status_device", "symaccel_alac_block_status_device", "symaccel_vorbis_floor1_status_device", "symaccel_aac_tns_status_device",
     "symaccel_aac_synth_pp_device", "symaccel_mp3_synth_pp_device", "symaccel_vorbis_synth_pp_device", "symaccel_mpa_polyphase_pp_device",
+    "symaccel_probe_copy_device",
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
@@ -107,6 +108,7 @@ class Library:
         d.symaccel_alac_predict_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_predict_stereo_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_predict.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_probe_copy_device.argtypes = [_vp, _vp, _vp, _sz, _u32, _u32]
         d.symaccel_alac_mid_side_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_mid_side.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_aac_synth_pp_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]

@@ -1,0 +1,65 @@
+// Copy probes: the practical HBM ceiling for the synthesis kernels' traffic shape (every byte read once, every byte
+// written once), measured by the SAME library in the SAME run as a workload ("also report against a measured
+// copy ceiling from the same run").  bench.py launches them next to the timed step and quotes the workload's rate as a
+// fraction of what they reach; they are not on any decode path.
+//   frames_per_wavefront == 0: grid-stride float4 copy, 65 536 workgroups (the best plain copy on this part);
+//   frames_per_wavefront == k: every wavefront streams k consecutive 4 KiB frames (aac_synth_kernel's own shape: a
+//                              wavefront walks a segment of one chain; k = its segment length).
+#include "dsp_device.h"
+
+namespace symaccel {
+
+namespace {
+
+template <bool NT>
+__global__ __launch_bounds__(256) void probe_copy_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (NT) st_stream(out + i, ld_stream(in + i));
+        else out[i] = in[i];
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void probe_copy_frames_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t frames,
+                                                                unsigned per_wave) {
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned lane = threadIdx.x & 63u;
+    for (unsigned f = 0; f < per_wave; ++f) {
+        const size_t fr = wave * per_wave + f;
+        if (fr >= frames) return;
+        const float4 *s = in + fr * 256;
+        float4 *d = out + fr * 256;
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = NT ? ld_stream(s + lane + 64 * q) : s[lane + 64 * q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (NT) st_stream(d + lane + 64 * q, v[q]);
+            else d[lane + 64 * q] = v[q];
+        }
+    }
+}
+
+}  // namespace
+
+int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, unsigned frames_per_wavefront, bool nt) {
+    const float4 *in = static_cast<const float4 *>(d_src);
+    float4 *out = static_cast<float4 *>(d_dst);
+    if (frames_per_wavefront == 0) {
+        const size_t n = bytes / 16;
+        const unsigned grid = (unsigned)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+        if (nt) hipLaunchKernelGGL(probe_copy_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, in, out, n);
+        else hipLaunchKernelGGL(probe_copy_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, in, out, n);
+    } else {
+        const size_t frames = bytes / 4096;
+        const size_t waves = (frames + frames_per_wavefront - 1) / frames_per_wavefront;
+        const size_t grid = (waves + 3) / 4;
+        if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+        if (nt) hipLaunchKernelGGL(probe_copy_frames_kernel<true>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, frames, frames_per_wavefront);
+        else hipLaunchKernelGGL(probe_copy_frames_kernel<false>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, frames, frames_per_wavefront);
+    }
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+}  // namespace symaccel
