@@ -370,8 +370,20 @@ int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_d
                         size_t n_blocks, size_t blocksize, const int32_t *d_pair_weight, const uint8_t *d_pair_shift) {
     const size_t grid = (n_blocks + kRows - 1) / kRows;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    void *flags = nullptr;  // one byte per wavefront: 24-bit multiplies are exact for its 64 blocks
-    SYM_TRY(ctx_scratch(ctx, grid, &flags));
+    // one byte per wavefront: 24-bit multiplies are exact for its 64 blocks.  A buffer of its own: the context's shared scratch
+    // synchronises the stream when it grows, and another entry point interleaved on the same context may hold it.
+    if (ctx->alac_flags_bytes < grid) {
+        const size_t want = grid < 4096 ? 4096 : grid + grid / 2;
+        void *nf = nullptr;
+        SYM_TRY(ctx_alloc(ctx, &nf, want, false));
+        if (ctx->alac_flags) {
+            SYM_GPU(ctx, hipStreamSynchronize(ctx->stream));  // (launches queued earlier still read the old buffer)
+            SYM_GPU(ctx, hipFree(ctx->alac_flags));
+        }
+        ctx->alac_flags = nf;
+        ctx->alac_flags_bytes = want;
+    }
+    void *flags = ctx->alac_flags;
     hipLaunchKernelGGL(alac_narrow_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
                        (unsigned)blocksize, (uint8_t *)flags);
     // four launches over the same grid, one per (24-bit multiplies, orders <= 8) class: each wavefront runs in exactly one

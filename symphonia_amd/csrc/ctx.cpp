@@ -290,6 +290,14 @@ void symaccel_ctx_destroy(symaccel_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->allocations) (void)hipFree(p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->stage_in) (void)hipStreamSynchronize(ctx->stage_in);
+    if (ctx->stage_out) (void)hipStreamSynchronize(ctx->stage_out);
+    if (ctx->stage_arena) (void)hipFree(ctx->stage_arena);
+    if (ctx->alac_flags) (void)hipFree(ctx->alac_flags);
+    for (hipEvent_t e : ctx->stage_events)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stage_in) (void)hipStreamDestroy(ctx->stage_in);
+    if (ctx->stage_out) (void)hipStreamDestroy(ctx->stage_out);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (prev_device >= 0 && prev_device != ctx->device) (void)hipSetDevice(prev_device);
     delete ctx;

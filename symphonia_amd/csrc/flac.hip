@@ -128,7 +128,10 @@ __device__ __forceinline__ void load_params(LaneParams &p, const symaccel_flac_d
         p.wasted = d.wasted_bits & 31u;
         if (d.kind == SYMACCEL_FLAC_LPC) {
             p.order = d.order > 32u ? 32u : d.order;
-            p.shift = d.shift & 63u;
+            // a shift above 31 encodes a negative qlp shift, which the reference refuses (decoder.rs:506-508; the status kernel
+            // flags the block): clamped, so that such a block's (meaningless) output does not depend on whether its wavefront
+            // took the f64 path (v_alignbit uses shift & 31) or the i64 path (a full 64-bit shift)
+            p.shift = d.shift > 31u ? 31u : d.shift;
             const int4 *cp = reinterpret_cast<const int4 *>(coeffs + my * 32);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

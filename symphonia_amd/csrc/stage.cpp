@@ -26,31 +26,58 @@ struct Pipe {
     symaccel_ctx *ctx;
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    std::vector<void *> bufs;
+    std::vector<std::pair<void **, size_t>> wanted;
+    bool queued = false;
     explicit Pipe(symaccel_ctx *c) : ctx(c) {}
+    // An early (error) return must not leave copies to or from the caller's host buffers in flight: whatever was queued is
+    // waited for before the call returns.  The streams, events and the arena belong to the context and stay.
     ~Pipe() {
-        for (void *p : bufs) (void)hipFree(p);
-        for (int b = 0; b < 2; ++b) {
-            if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
-            if (ev_k[b]) (void)hipEventDestroy(ev_k[b]);
-            if (ev_out[b]) (void)hipEventDestroy(ev_out[b]);
-        }
-        if (s_in) (void)hipStreamDestroy(s_in);
-        if (s_out) (void)hipStreamDestroy(s_out);
+        if (!queued) return;
+        if (s_in) (void)hipStreamSynchronize(s_in);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        if (s_out) (void)hipStreamSynchronize(s_out);
     }
     int init() {
-        SYM_GPU(ctx, hipStreamCreate(&s_in));
-        SYM_GPU(ctx, hipStreamCreate(&s_out));
+        if (!ctx->stage_in) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_in));
+        if (!ctx->stage_out) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_out));
+        for (hipEvent_t &e : ctx->stage_events)
+            if (!e) SYM_GPU(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s_in = ctx->stage_in;
+        s_out = ctx->stage_out;
         for (int b = 0; b < 2; ++b) {
-            SYM_GPU(ctx, hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming));
-            SYM_GPU(ctx, hipEventCreateWithFlags(&ev_k[b], hipEventDisableTiming));
-            SYM_GPU(ctx, hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming));
+            ev_in[b] = ctx->stage_events[b];
+            ev_k[b] = ctx->stage_events[2 + b];
+            ev_out[b] = ctx->stage_events[4 + b];
         }
         return SYMACCEL_OK;
     }
+    // chunk buffers: requested one by one, carved from the context's arena by commit() (which grows it if needed; the
+    // previous call drained everything, so a smaller arena can be freed at once)
     int alloc(void **p, size_t bytes) {
-        SYM_TRY(ctx_alloc(ctx, p, bytes, false));
-        bufs.push_back(*p);
+        *p = nullptr;
+        wanted.emplace_back(p, bytes);
+        return SYMACCEL_OK;
+    }
+    int commit() {
+        size_t total = 0;
+        for (auto &w : wanted) total += (w.second + 255) & ~(size_t)255;
+        if (total > ctx->stage_arena_bytes) {
+            if (ctx->stage_arena) {
+                SYM_GPU(ctx, hipFree(ctx->stage_arena));
+                ctx->stage_arena = nullptr;
+                ctx->stage_arena_bytes = 0;
+            }
+            void *a = nullptr;
+            SYM_TRY(ctx_alloc(ctx, &a, total, false));
+            ctx->stage_arena = a;
+            ctx->stage_arena_bytes = total;
+        }
+        size_t off = 0;
+        for (auto &w : wanted) {
+            *w.first = static_cast<char *>(ctx->stage_arena) + off;
+            off += (w.second + 255) & ~(size_t)255;
+        }
+        queued = true;  // from here on work may be in flight
         return SYMACCEL_OK;
     }
     // everything queued so far, on all three streams
@@ -58,6 +85,7 @@ struct Pipe {
         SYM_GPU(ctx, hipStreamSynchronize(s_in));
         SYM_GPU(ctx, hipStreamSynchronize(ctx->stream));
         SYM_GPU(ctx, hipStreamSynchronize(s_out));
+        queued = false;
         return SYMACCEL_OK;
     }
 };
@@ -129,6 +157,7 @@ int symaccel_aac_synth_pipelined(symaccel_ctx *ctx, const float *h_coeffs, const
         SYM_TRY(pp.alloc((void **)&d_side[b], n_chains * cf));
         SYM_TRY(pp.alloc((void **)&d_state[b], n_chains * 4096));
     }
+    SYM_TRY(pp.commit());
     SYM_GPU(ctx, hipMemcpyAsync(d_state[0], h_delay_io, n_chains * 4096, hipMemcpyHostToDevice, ctx->stream));
     size_t k = 0;
     for (size_t t0 = 0; t0 < frames_per_chain; t0 += cf, ++k) {
@@ -177,6 +206,7 @@ int symaccel_mp3_synth_pipelined(symaccel_ctx *ctx, const float *h_xr, const sym
         SYM_TRY(pp.alloc((void **)&d_vv[b], n_chains * 4096));
         SYM_TRY(pp.alloc((void **)&d_vf[b], n_chains * 4));
     }
+    SYM_TRY(pp.commit());
     SYM_GPU(ctx, hipMemcpyAsync(d_ov[0], h_overlap_io, n_chains * 2304, hipMemcpyHostToDevice, ctx->stream));
     SYM_GPU(ctx, hipMemcpyAsync(d_vv[0], h_vvec_io, n_chains * 4096, hipMemcpyHostToDevice, ctx->stream));
     SYM_GPU(ctx, hipMemcpyAsync(d_vf[0], h_vfront_io, n_chains * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -227,6 +257,7 @@ int symaccel_flac_restore_pipelined(symaccel_ctx *ctx, int32_t *h_buf, const sym
         SYM_TRY(pp.alloc((void **)&d_co[b], cb * 32 * 4));
         SYM_TRY(pp.alloc((void **)&d_desc[b], cb * sizeof(symaccel_flac_desc)));
     }
+    SYM_TRY(pp.commit());
     size_t k = 0;
     for (size_t b0 = 0; b0 < n_blocks; b0 += cb, ++k) {
         const size_t nb = std::min(cb, n_blocks - b0);

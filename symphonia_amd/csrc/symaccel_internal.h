@@ -113,6 +113,15 @@ struct symaccel_ctx {
     // growable device scratch (state double-buffering, per-block offsets)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // host <-> device staging of the *_pipelined entry points (stage.cpp), created on first use and kept: two copy streams,
+    // six events, one growable device arena the chunk buffers are carved from
+    hipStream_t stage_in = nullptr, stage_out = nullptr;
+    hipEvent_t stage_events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *stage_arena = nullptr;
+    size_t stage_arena_bytes = 0;
+    // small dedicated device buffers (not shared with `scratch`, whose growth synchronises the stream)
+    void *alac_flags = nullptr;
+    size_t alac_flags_bytes = 0;
 };
 
 namespace symaccel {

@@ -332,9 +332,11 @@ __device__ __forceinline__ void wave_sync_lds() {
 struct Floor1Setup {  // per floor configuration, derived on the host like the setup parser does (floor.rs:540-555)
     // Everything a loop iteration needs sits at an address that depends on the loop counter only: the scalar loads of
     // several iterations go out together instead of lo -> x[lo] chains of dependent round trips.
-    uint32_t nb[65];    // post i: lo | hi << 8 (floor1_x_list_neighbors)
+    uint32_t nb[65];    // post i: lo | hi << 8 (floor1_x_list_neighbors) | wide << 16 (neighbour span above 4096, see `wide`)
     float ratio[65];    //         (x[i] - x[lo]) / (x[hi] - x[lo]) and
     float half[65];     //         0.5 / (x[hi] - x[lo]), both rounded to f32: render_point in closed form (see step 1)
+    uint32_t wide[65];  //         (x[i] - x[lo]) | (x[hi] - x[lo]) << 16 for the posts whose span is outside the closed form's
+                        //         proven range: render_point in integers, as the reference writes it
     uint32_t ord[65];   // x-sorted position k: order[k] | x[order[k]] << 16
 };
 
@@ -432,8 +434,18 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
             }
             const int lo = (int)(pn & 255u), hi = (int)((pn >> 8) & 255u);
             const int32_t py0 = fy[lo * kF1B + lane];
-            const float fdy = (float)(fy[hi * kF1B + lane] - py0);
-            const int32_t predicted = py0 + (int32_t)(fdy * ratio + __builtin_copysignf(half, fdy));
+            const int32_t dy = fy[hi * kF1B + lane] - py0;
+            const float fdy = (float)dy;
+            int32_t predicted = py0 + (int32_t)(fdy * ratio + __builtin_copysignf(half, fdy));
+            if (pn & 0x10000u) {
+                // neighbours more than 4096 apart (a floor whose posts reach past every block size: rangebits up to 15 are
+                // legal): outside the closed form's proven range -- it first fails at adx = 17019 --, so the integer form of
+                // floor.rs:776-782 itself.  A property of the setup: the branch is wave-uniform and no conforming
+                // encoder's setup takes it.
+                const uint32_t w = st.wide[i];
+                const uint32_t off = ((uint32_t)(dy < 0 ? -dy : dy) * (w & 0xffffu)) / (w >> 16);
+                predicted = dy < 0 ? py0 - (int32_t)off : py0 + (int32_t)off;
+            }
             // floor.rs:596-621 as selects (the lanes of a wavefront take all the branches anyway); lowroom = predicted, so
             // `val - lowroom + predicted` is val and `predicted - val + highroom - 1` is range - val - 1
             const int32_t highroom = range - predicted, lowroom = predicted;
@@ -501,6 +513,10 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
         // EXACTLY: |dy| * t / adx + 0.5 / adx is at least 0.5 / adx away from an integer on either side, the three roundings
         // move the value by less than 255 * 3 * 2^-24 < 0.5 / 8192.  tests/cpp/floor1_division_check.c walks every
         // (adx <= 4096, |dy| <= 255, t < adx).  The sign goes into slope and half (the conversion truncates towards zero).
+        // Segments LONGER than 4096 exist (posts past the block, or few flagged posts under a large rangebits: adx up to
+        // 65535), but only their first n <= 4096 lines are rendered: the value is below 255 * 4096 / adx there, the three
+        // roundings move it by less than 3 * 255 * 4096 * 2^-24 / adx = 0.19 / adx < 0.5 / adx -- exact again; the same
+        // program walks (4096 < adx <= 65535, |dy| <= 255, t < 4096) (every adx with SYM_SLOW_TESTS=1, every 16th otherwise).
         for (int k = lane; k <= nsb; k += 64) {
             const int k1 = k + 1 <= nsb ? k + 1 : k;
             const uint32_t xk = segx[k * kF1Stride + b];
@@ -668,9 +684,11 @@ int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts
         const uint32_t lo = h_setup[65 + i] & 255u, hi = h_setup[130 + i] & 255u;
         const int adx = (int)h_setup[hi] - (int)h_setup[lo];  // > 0: the wrapper checked that the x values are distinct
         const float fadx = (float)(adx > 0 ? adx : 1);
-        st.nb[i] = lo | hi << 8;
+        const bool wide = adx > 4096;  // tests/cpp/floor1_division_check.c proves the closed form up to here
+        st.nb[i] = lo | hi << 8 | (wide ? 0x10000u : 0u);
         st.ratio[i] = (float)((int)h_setup[i] - (int)h_setup[lo]) / fadx;
         st.half[i] = 0.5f / fadx;
+        st.wide[i] = wide ? ((h_setup[i] - h_setup[lo]) & 0xffffu) | (uint32_t)adx << 16 : 0u;
     }
     // instantiated per block class: the segment-start map is n bytes of LDS, and LDS is what bounds the resident wavefronts
 #define SYM_F1_LAUNCH(DOT, NMAX)                                                                                                     \

@@ -197,6 +197,18 @@ def floor1_case(rng):
     else:
         rest = rng.permutation(np.arange(1, n))[:n_posts - 2].tolist()
     xs = [0, n] + rest
+    if rng.random() < 0.25:
+        # a floor whose range reaches past the block (rangebits up to 15 are legal, floor.rs:494-497): posts beyond n and
+        # neighbour spans above 4096, where render_point runs in integers (vorbis.hip `wide`) and render_line's segments
+        # are longer than the block
+        top_x = 1 << int(rng.integers(max(6, int(np.log2(n)) + 1), 16))
+        inside = sorted(set(int(v) for v in rng.integers(1, n, size=int(rng.integers(0, n_posts - 1)))))
+        rest = inside[:n_posts - 2]
+        while len(rest) < n_posts - 2:
+            x = int(rng.integers(1, top_x))
+            if x not in rest:
+                rest.append(x)
+        xs = [0, top_x] + [int(v) for v in rng.permutation(rest)]
     top = 256 if rng.random() < 0.3 else [256, 128, 86, 64][mult - 1]
     ys = rng.integers(0, top, size=(count, n_posts)).astype(np.uint32)
     ys[rng.random((count, n_posts)) < rng.choice([0.02, 0.3, 0.9])] = 0
