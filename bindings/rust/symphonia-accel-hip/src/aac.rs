@@ -1,11 +1,11 @@
 //! `HipAacDecoder`: AAC-LC with the synthesis tail (Dsp::synth, symphonia-codec-aac/src/aac/dsp.rs:57-158) on the MI355X.
-use symphonia_core::audio::{AudioBuffer, AudioSpec, GenericAudioBufferRef};
+use symphonia_core::audio::{Audio, AudioBuffer, AudioMut, AudioSpec, GenericAudioBufferRef};
 use symphonia_core::codecs::audio::well_known::CODEC_ID_AAC;
 use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoder, AudioDecoderOptions, FinalizeResult};
 use symphonia_core::codecs::registry::{RegisterableAudioDecoder, SupportedAudioCodec};
 use symphonia_core::codecs::CodecInfo;
 use symphonia_core::errors::{unsupported_error, Result};
-use symphonia_core::packet::{Packet, PacketRef};
+use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
 use crate::ctx::{check, Context, Pinned};
@@ -23,7 +23,7 @@ pub struct ParsedAac {
 /// (symphonia-codec-aac/src/aac/mod.rs:170-225), vendored because `mod aac` is private to its crate.
 pub trait AacFrontEnd: Send + Sync {
     fn channels(&self) -> usize;
-    fn parse(&mut self, packet: &Packet) -> Result<ParsedAac>;
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedAac>;
 }
 
 struct AacBatch {
@@ -42,7 +42,7 @@ struct AacBatch {
 impl BatchCodec for AacBatch {
     type Parsed = ParsedAac;
 
-    fn parse(&mut self, packet: &Packet) -> Result<ParsedAac> {
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedAac> {
         self.front.parse(packet)
     }
 
@@ -97,7 +97,7 @@ impl BatchCodec for AacBatch {
 pub struct HipAacDecoder {
     params: AudioCodecParameters,
     batch: AacBatch,
-    la: Lookahead,
+    la: Lookahead<ParsedAac>,
 }
 
 impl HipAacDecoder {
@@ -141,11 +141,8 @@ impl AudioDecoder for HipAacDecoder {
     }
 
     fn decode_ref(&mut self, packet: &PacketRef<'_>) -> Result<GenericAudioBufferRef<'_>> {
-        let owned = packet.to_packet();
-        if let Err(e) = self.la.decode(&mut self.batch, &owned) {
-            self.batch.clear(); // codecs/audio.rs:278
-            return Err(e);
-        }
+        // (Lookahead::decode clears the buffer on every error path: codecs/audio.rs:278)
+        self.la.decode(&mut self.batch, packet)?;
         Ok(self.batch.buf.as_generic_audio_buffer_ref())
     }
 
@@ -160,8 +157,11 @@ impl AudioDecoder for HipAacDecoder {
 
 impl RegisterableAudioDecoder for HipAacDecoder {
     fn try_registry_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Box<dyn AudioDecoder>> {
-        let front = crate::frontends::aac_front_end(params)?;
-        Ok(Box::new(HipAacDecoder::try_new(params, opts, front, crate::DEFAULT_LOOKAHEAD)?))
+        // no front end, no device, no memory: the decoder that was registered below this one takes the track
+        match crate::frontends::aac_front_end(params).and_then(|front| HipAacDecoder::try_new(params, opts, front, crate::DEFAULT_LOOKAHEAD)) {
+            Ok(decoder) => Ok(Box::new(decoder)),
+            Err(e) => crate::fallback::make(params, opts, e),
+        }
     }
 
     fn supported_codecs() -> &'static [SupportedAudioCodec] {

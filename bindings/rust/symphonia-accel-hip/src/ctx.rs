@@ -25,7 +25,8 @@ pub(crate) fn check(status: i32, ctx: *const ffi::SymaccelCtx) -> Result<()> {
             }
             else {
                 // SAFETY: the context outlives this call; the string lives inside it.
-                unsafe { CStr::from_ptr(ffi::symaccel_last_error(ctx)) }.to_string_lossy().into_owned()
+                let text = unsafe { CStr::from_ptr(ffi::symaccel_last_error(ctx)) };
+                text.to_string_lossy().into_owned()
             };
             Err(Error::IoError(std::io::Error::other(format!("{msg}: {detail}"))))
         }

@@ -19,12 +19,12 @@ pub trait DecoderBatch: BatchCodec {
 
 #[macro_export]
 macro_rules! hip_decoder {
-    ($name:ident, $batch:ty, $front_end:path, $codecs:expr, $doc:literal) => {
+    ($name:ident, $batch:ty, $parsed:ty, $front_end:path, $codecs:expr, $doc:literal) => {
         #[doc = $doc]
         pub struct $name {
             params: symphonia_core::codecs::audio::AudioCodecParameters,
             batch: $batch,
-            la: $crate::lookahead::Lookahead,
+            la: $crate::lookahead::Lookahead<$parsed>,
         }
 
         impl symphonia_core::codecs::audio::AudioDecoder for $name {
@@ -46,11 +46,8 @@ macro_rules! hip_decoder {
                 &mut self,
                 packet: &symphonia_core::packet::PacketRef<'_>,
             ) -> symphonia_core::errors::Result<symphonia_core::audio::GenericAudioBufferRef<'_>> {
-                let owned = packet.to_packet();
-                if let Err(e) = self.la.decode(&mut self.batch, &owned) {
-                    $crate::lookahead::BatchCodec::clear(&mut self.batch); // codecs/audio.rs:278
-                    return Err(e);
-                }
+                // (Lookahead::decode clears the buffer on every error path: codecs/audio.rs:278)
+                self.la.decode(&mut self.batch, packet)?;
                 Ok($crate::decoder::DecoderBatch::buffer(&self.batch))
             }
 
@@ -68,8 +65,11 @@ macro_rules! hip_decoder {
                 params: &symphonia_core::codecs::audio::AudioCodecParameters,
                 opts: &symphonia_core::codecs::audio::AudioDecoderOptions,
             ) -> symphonia_core::errors::Result<Box<dyn symphonia_core::codecs::audio::AudioDecoder>> {
-                let front = $front_end(params)?;
-                Ok(Box::new(Self::try_new(params, opts, front, $crate::DEFAULT_LOOKAHEAD)?))
+                // no front end, no device, no memory: the decoder that was registered below this one takes the track
+                match $front_end(params).and_then(|front| Self::try_new(params, opts, front, $crate::DEFAULT_LOOKAHEAD)) {
+                    Ok(decoder) => Ok(Box::new(decoder)),
+                    Err(e) => $crate::fallback::make(params, opts, e),
+                }
             }
 
             fn supported_codecs() -> &'static [symphonia_core::codecs::registry::SupportedAudioCodec] {

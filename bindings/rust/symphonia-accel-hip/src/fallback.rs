@@ -1,0 +1,48 @@
+//! The decoders this crate was registered above.
+//!
+//! The registry answers with the most preferred entry and calls its factory; when that factory fails the error goes to
+//! the application -- there is no fall-through to the next tier (codecs/registry.rs:152-154, 330-341).  A `Tier::Preferred`
+//! decoder that cannot be built on this machine (no GPU, no memory, no parse stage for the codec) would therefore turn a
+//! decodable track into an error.  So `register` remembers, per codec id, the factory the registry would have used
+//! without this crate, and `try_registry_new` hands the track to it when the accelerated decoder cannot be constructed.
+use std::collections::HashMap;
+use std::sync::Mutex;
+
+use symphonia_core::codecs::audio::{AudioCodecId, AudioCodecParameters, AudioDecoder, AudioDecoderOptions};
+use symphonia_core::codecs::registry::{AudioDecoderFactoryFn, CodecRegistry};
+use symphonia_core::errors::{Error, Result};
+
+static BELOW: Mutex<Option<HashMap<AudioCodecId, AudioDecoderFactoryFn>>> = Mutex::new(None);
+
+/// Record what `registry` answers for `ids` right now (call before registering above it).  The first registration wins:
+/// a second `register` call would otherwise record this crate's own factory and recurse.
+pub fn remember(registry: &CodecRegistry, ids: &[AudioCodecId]) {
+    let mut below = BELOW.lock().expect("fallback table poisoned");
+    let map = below.get_or_insert_with(HashMap::new);
+    for id in ids {
+        if let Some(found) = registry.get_audio_decoder(*id) {
+            map.entry(*id).or_insert(found.factory);
+        }
+    }
+}
+
+/// The factory recorded for `id`, if any.
+pub fn factory_below(id: AudioCodecId) -> Option<AudioDecoderFactoryFn> {
+    let below = BELOW.lock().expect("fallback table poisoned");
+    match below.as_ref() {
+        Some(map) => map.get(&id).copied(),
+        None => None,
+    }
+}
+
+/// Build the decoder that was registered below this crate for `params.codec`; `why` (the reason the accelerated decoder
+/// could not be built) is returned when there is none.
+pub fn make(params: &AudioCodecParameters, opts: &AudioDecoderOptions, why: Error) -> Result<Box<dyn AudioDecoder>> {
+    match factory_below(params.codec) {
+        Some(factory) => {
+            log::warn!("symphonia-accel-hip: {why}; the CPU decoder takes this track");
+            factory(params, opts)
+        }
+        None => Err(why),
+    }
+}

@@ -1,11 +1,11 @@
 //! `HipFlacDecoder`: the predictor stage of every subframe (fixed and LPC, symphonia-bundle-flac/src/decoder.rs:663-752),
 //! the stereo decorrelation (:32-82) and the left-justification shift (:239-242) on the MI355X.  FLAC carries no state
 //! from frame to frame, so a batch is simply many frames' subframes side by side.
-use symphonia_core::audio::{AudioBuffer, AudioSpec, GenericAudioBufferRef};
+use symphonia_core::audio::{Audio, AudioBuffer, AudioMut, AudioSpec, GenericAudioBufferRef};
 use symphonia_core::codecs::audio::well_known::CODEC_ID_FLAC;
 use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoderOptions};
 use symphonia_core::errors::{decode_error, unsupported_error, Result};
-use symphonia_core::packet::Packet;
+use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
 use crate::ctx::{check, Context, Pinned};
@@ -28,7 +28,7 @@ pub struct ParsedFlac {
 pub trait FlacFrontEnd: Send + Sync {
     fn channels(&self) -> usize;
     fn max_blocksize(&self) -> usize;
-    fn parse(&mut self, packet: &Packet) -> Result<ParsedFlac>;
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedFlac>;
 }
 
 pub struct FlacBatch {
@@ -48,7 +48,7 @@ pub struct FlacBatch {
 impl BatchCodec for FlacBatch {
     type Parsed = ParsedFlac;
 
-    fn parse(&mut self, packet: &Packet) -> Result<ParsedFlac> {
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedFlac> {
         let p = self.front.parse(packet)?;
         if p.blocksize == 0 || p.blocksize > self.front.max_blocksize() {
             return decode_error("flac: block size outside the stream's bounds");
@@ -138,6 +138,7 @@ impl DecoderBatch for FlacBatch {
 crate::hip_decoder!(
     HipFlacDecoder,
     FlacBatch,
+    ParsedFlac,
     crate::frontends::flac_front_end,
     &[support_audio_codec!(CODEC_ID_FLAC, "flac", "Free Lossless Audio Codec (MI355X predictors)")],
     "FLAC decoder with the same observable behaviour as `symphonia_bundle_flac::FlacDecoder` (verification off)."

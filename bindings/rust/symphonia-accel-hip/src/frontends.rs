@@ -10,6 +10,10 @@
 //!  * FLAC: `FlacDecoder::decode_inner` (symphonia-bundle-flac/src/decoder.rs:200-300) with `read_subframe` stopped
 //!    before `fixed_predict` / `lpc_predict` (:456-520), returning warm-up + residual words, the subframe descriptor
 //!    and the quantised coefficients.
+//!
+//! None of the four copies is part of this source drop, and the crate is honest about it: `AVAILABLE` says so per codec,
+//! `register` (lib.rs) does not put a decoder above the CPU one for a codec whose front end is absent, and a decoder
+//! built directly through `try_registry_new` hands the track to the CPU decoder it was registered above (fallback.rs).
 use symphonia_core::codecs::audio::AudioCodecParameters;
 use symphonia_core::errors::{unsupported_error, Result};
 
@@ -17,6 +21,16 @@ use crate::aac::AacFrontEnd;
 use crate::flac::FlacFrontEnd;
 use crate::mpa::MpaFrontEnd;
 use crate::vorbis::VorbisFrontEnd;
+
+/// Which vendored parse stages this build contains.
+pub struct Available {
+    pub aac: bool,
+    pub mpa: bool,
+    pub vorbis: bool,
+    pub flac: bool,
+}
+
+pub const AVAILABLE: Available = Available { aac: false, mpa: false, vorbis: false, flac: false };
 
 const NOT_IN_DROP: &str = "symphonia-accel-hip: the vendored parse stage of this codec is not part of this source drop";
 

@@ -3,13 +3,17 @@
 //! ```ignore
 //! let mut registry = symphonia::default::get_codecs().clone();   // or CodecRegistry::new() + your own set
 //! symphonia_accel_hip::register(&mut registry);                  // Tier::Preferred: wins over the CPU decoders
-//! let reader = symphonia_accel_hip::LookaheadReader::new(format_reader, 256);
+//! let reader: Box<dyn FormatReader> = Box::new(symphonia_accel_hip::LookaheadReader::new(format_reader, 256));
 //! ```
 //! Everything above the decoders -- demuxers, probe, symphonia-check, symphonia-play -- is untouched: they only see
-//! `Box<dyn AudioDecoder>` (symphonia-check/src/main.rs:144-147).
+//! `Box<dyn AudioDecoder>` and `Box<dyn FormatReader>` (symphonia-check/src/main.rs:144-147).
 //!
-//! Status: this crate is NOT compiled in the repository's build image (no Rust toolchain).  Its compiled and tested twin
-//! is `codecs::LookaheadDecoder` in include/symaccel.hpp (tests/cpp/lookahead_test.cpp).  The parse stages
+//! Status: this crate is NOT compiled in the repository's build image (no Rust toolchain).  What IS checked there
+//! (tests/test_rust_shim.py): every file parses (tools/rsinterp/parser.py), every `use symphonia_core::...` names an item
+//! the reference tree defines, every `impl AudioDecoder / RegisterableAudioDecoder / FormatReader` matches the trait text
+//! of the reference (method names, receivers, arity), and `lookahead.rs` + `fallback.rs` are EXECUTED under the
+//! repository's Rust interpreter with a mock codec, a mock demuxer and a mock registry on the packet script of the
+//! compiled C++ twin (`codecs::LookaheadDecoder`, include/symaccel.hpp, tests/cpp/lookahead_test.cpp).  The parse stages
 //! (`frontends`) have to be vendored from the reference's codec crates because their `mod`s are private
 //! (symphonia-codec-aac/src/aac/mod.rs:29-34, symphonia-codec-vorbis/src/lib.rs:37-42, symphonia-bundle-mp3/src/lib.rs:18-40).
 #![allow(clippy::needless_range_loop)]
@@ -17,6 +21,7 @@
 mod aac;
 mod ctx;
 pub mod decoder;
+pub mod fallback;
 mod ffi;
 mod flac;
 pub mod frontends;
@@ -25,22 +30,39 @@ mod mpa;
 mod vorbis;
 
 pub use aac::{AacFrontEnd, HipAacDecoder, ParsedAac};
+pub use ctx::{Context, Pinned};
 pub use flac::{FlacFrontEnd, HipFlacDecoder, ParsedFlac};
+pub use lookahead::{find_reader, BatchCodec, Lookahead, LookaheadReader, PacketKey, Shared, SharedHandle, TrackQueue};
 pub use mpa::{HipMpaDecoder, MpaFrontEnd, ParsedMpa};
 pub use vorbis::{HipVorbisDecoder, ParsedVorbis, VorbisFrontEnd};
-pub use ctx::{Context, Pinned};
-pub use lookahead::{track_queue, BatchCodec, Lookahead, LookaheadReader, TrackQueue};
 
-use symphonia_core::codecs::registry::{CodecRegistry, Tier};
+use symphonia_core::codecs::audio::AudioCodecId;
+use symphonia_core::codecs::registry::{CodecRegistry, RegisterableAudioDecoder};
+use symphonia_core::common::Tier;
 
 /// Packets per batch when a `LookaheadReader` feeds the decoder.
 pub const DEFAULT_LOOKAHEAD: usize = 256;
 
-/// Register the accelerated decoders at `Tier::Preferred` (symphonia-core/src/codecs/registry.rs:252-269): the registry
-/// looks preferred -> standard -> fallback (`:152-154`), so the CPU decoders stay available underneath.
+/// Register the accelerated decoders at `Tier::Preferred` (symphonia-core/src/codecs/registry.rs:252-269).
+///
+/// The registry does NOT fall through to the next tier when a preferred factory fails (`:152-154`, `:330-341`), so
+///  * a codec whose parse stage is not in this build (`frontends::AVAILABLE`) is not registered at all -- the CPU decoder
+///    keeps the codec --, and
+///  * for the codecs that are registered, the factory that was in force before is remembered (`fallback::remember`) and
+///    `try_registry_new` delegates to it when the device decoder cannot be built (no GPU, out of memory).
 pub fn register(registry: &mut CodecRegistry) {
-    registry.register_audio_decoder_at_tier::<HipAacDecoder>(Tier::Preferred);
-    registry.register_audio_decoder_at_tier::<HipMpaDecoder>(Tier::Preferred);
-    registry.register_audio_decoder_at_tier::<HipVorbisDecoder>(Tier::Preferred);
-    registry.register_audio_decoder_at_tier::<HipFlacDecoder>(Tier::Preferred);
+    register_one::<HipAacDecoder>(registry, frontends::AVAILABLE.aac);
+    register_one::<HipMpaDecoder>(registry, frontends::AVAILABLE.mpa);
+    register_one::<HipVorbisDecoder>(registry, frontends::AVAILABLE.vorbis);
+    register_one::<HipFlacDecoder>(registry, frontends::AVAILABLE.flac);
+}
+
+/// Register one decoder type above whatever the registry holds for its codecs, if its front end is present.
+pub fn register_one<D: RegisterableAudioDecoder>(registry: &mut CodecRegistry, front_end_present: bool) {
+    if !front_end_present {
+        return;
+    }
+    let ids: Vec<AudioCodecId> = D::supported_codecs().iter().map(|c| c.id).collect();
+    fallback::remember(registry, &ids);
+    registry.register_audio_decoder_at_tier::<D>(Tier::Preferred);
 }

@@ -1,52 +1,111 @@
 //! Look-ahead batching behind the `AudioDecoder` method set (the Rust twin of `codecs::LookaheadDecoder` in
-//! include/symaccel.hpp, which is the version that is compiled and tested in the repository).
+//! include/symaccel.hpp; tests/test_rust_shim.py executes THIS file under tools/rsinterp with a mock codec and a mock
+//! demuxer, on the packet script of tests/cpp/lookahead_test.cpp).
 //!
 //! `AudioDecoder::decode_ref(&mut self, &PacketRef)` (codecs/audio.rs:281-285) sees one packet; a GPU wants thousands of
-//! frames per call.  The bridge is a reader-side look-ahead: `LookaheadReader` wraps the application's `FormatReader`,
-//! reads K packets ahead and publishes the packets of each track in a queue the track's decoder can see.  When
-//! `decode_ref(p)` finds nothing pre-computed for `p`, the decoder parses `p` and the queued packets that follow it (CPU,
-//! the reference's own parser), transforms all of them in ONE batch call, and serves the following `decode_ref` calls
-//! from the result.  Without a `LookaheadReader` the queue is empty and every call is a batch of one: correct, slow.
+//! frames per call.  The bridge is a reader-side look-ahead: `LookaheadReader` wraps the application's `FormatReader`
+//! (it IS a `FormatReader`, so the application keeps calling `next_packet` / `seek` on a `Box<dyn FormatReader>`), reads
+//! `depth` packets ahead and keeps the packets of each track in a queue the track's decoder can see.  When `decode_ref(p)`
+//! finds nothing pre-computed for `p`, the decoder parses `p` and the queued packets that follow it (CPU, the reference's
+//! own parser), transforms all of them in ONE batch call, and serves the following `decode_ref` calls from the result.
+//! Without a `LookaheadReader` there is no queue and every call is a batch of one: correct, slow.
+//!
+//! Decoders are created by the registry from `(params, opts)` alone (codecs/registry.rs:34-44), so a decoder cannot be
+//! handed its reader.  It finds it: the reader records the identity of the packet it returned last for each track
+//! (track id, pts, address and length of the payload), and a decoder that is asked to decode a packet looks for the
+//! live reader that handed out exactly that packet.  Two open containers with equal track ids therefore never share
+//! a queue; an application that clones packets before decoding simply gets batches of one.
 use std::collections::{HashMap, VecDeque};
-use std::sync::{Arc, Mutex, OnceLock};
+use std::sync::{Arc, Mutex, Weak};
 
 use symphonia_core::errors::Result;
-use symphonia_core::formats::{FormatReader, SeekMode, SeekTo, SeekedTo, Track};
-use symphonia_core::packet::Packet;
+use symphonia_core::formats::{Attachment, FormatInfo, FormatReader, MediaInfo, SeekMode, SeekTo, SeekedTo, Track};
+use symphonia_core::io::MediaSourceStream;
+use symphonia_core::meta::{ChapterGroup, Metadata};
+use symphonia_core::packet::{Packet, PacketRef};
 
-/// Packets of one track the demuxer has already read but the application has not yet handed to the decoder.
-#[derive(Default)]
-pub struct TrackQueue {
-    pub packets: VecDeque<Packet>,
+/// Identity of a packet in the hands of the application.
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
+pub struct PacketKey {
+    pub track_id: u32,
+    pub pts: i64,
+    pub data: usize,
+    pub len: usize,
 }
 
-static QUEUES: OnceLock<Mutex<HashMap<u32, Arc<Mutex<TrackQueue>>>>> = OnceLock::new();
+impl PacketKey {
+    pub fn of(packet: &PacketRef<'_>) -> PacketKey {
+        PacketKey { track_id: packet.track_id, pts: packet.pts.get(), data: packet.data.as_ptr() as usize, len: packet.data.len() }
+    }
+}
 
-/// The queue of a track (created on first use).  Keyed by track id: one look-ahead reader per process and container is
-/// the expected shape; applications with several open containers give each its own id space through `LookaheadReader::with_id_base`.
-pub fn track_queue(track_id: u32) -> Arc<Mutex<TrackQueue>> {
-    let map = QUEUES.get_or_init(|| Mutex::new(HashMap::new()));
-    map.lock().expect("queue map poisoned").entry(track_id).or_default().clone()
+/// Packets of one track the demuxer has already read but the application has not yet been given.
+#[derive(Default)]
+pub struct TrackQueue {
+    /// oldest first; the front is what `next_packet` returns next for this track
+    pub packets: VecDeque<Packet>,
+    /// the packet `next_packet` returned last for this track
+    pub last_out: Option<PacketKey>,
+}
+
+/// What one `LookaheadReader` shares with the decoders of its tracks.
+#[derive(Default)]
+pub struct Shared {
+    pub tracks: HashMap<u32, TrackQueue>,
+}
+
+pub type SharedHandle = Arc<Mutex<Shared>>;
+
+/// Every live reader (weak: a dropped reader disappears from the list at the next lookup).
+static READERS: Mutex<Vec<Weak<Mutex<Shared>>>> = Mutex::new(Vec::new());
+
+/// The live reader that handed out the packet `key`, if any.
+pub fn find_reader(key: &PacketKey) -> Option<SharedHandle> {
+    let mut readers = READERS.lock().expect("reader list poisoned");
+    readers.retain(|w| w.strong_count() > 0);
+    for w in readers.iter() {
+        if let Some(handle) = w.upgrade() {
+            let hit = match handle.lock().expect("look-ahead state poisoned").tracks.get(&key.track_id) {
+                Some(q) => q.last_out == Some(*key),
+                None => false,
+            };
+            if hit {
+                return Some(handle);
+            }
+        }
+    }
+    None
 }
 
 /// A `FormatReader` that stays `depth` packets ahead of what it returns.
 pub struct LookaheadReader {
     inner: Box<dyn FormatReader>,
     depth: usize,
+    /// everything read ahead, in container order (clones of what sits in the track queues)
     pending: VecDeque<Packet>,
+    shared: SharedHandle,
     eof: bool,
 }
 
 impl LookaheadReader {
     pub fn new(inner: Box<dyn FormatReader>, depth: usize) -> Self {
-        LookaheadReader { inner, depth: depth.max(1), pending: VecDeque::new(), eof: false }
+        let shared: SharedHandle = Arc::new(Mutex::new(Shared::default()));
+        READERS.lock().expect("reader list poisoned").push(Arc::downgrade(&shared));
+        LookaheadReader { inner, depth: depth.max(1), pending: VecDeque::new(), shared, eof: false }
+    }
+
+    /// The state the decoders of this reader's tracks look at (tests; an application never needs it).
+    pub fn shared(&self) -> SharedHandle {
+        self.shared.clone()
     }
 
     fn refill(&mut self) -> Result<()> {
         while !self.eof && self.pending.len() < self.depth {
             match self.inner.next_packet()? {
                 Some(p) => {
-                    track_queue(p.track_id).lock().expect("track queue poisoned").packets.push_back(p.clone());
+                    let mut shared = self.shared.lock().expect("look-ahead state poisoned");
+                    shared.tracks.entry(p.track_id).or_default().packets.push_back(p.clone());
+                    drop(shared);
                     self.pending.push_back(p);
                 }
                 None => self.eof = true,
@@ -56,36 +115,69 @@ impl LookaheadReader {
     }
 
     fn drop_lookahead(&mut self) {
-        for p in self.pending.drain(..) {
-            track_queue(p.track_id).lock().expect("track queue poisoned").packets.clear();
+        self.pending.clear();
+        let mut shared = self.shared.lock().expect("look-ahead state poisoned");
+        for q in shared.tracks.values_mut() {
+            q.packets.clear();
+            q.last_out = None;
         }
+        drop(shared);
         self.eof = false;
     }
+}
 
-    pub fn tracks(&self) -> &[Track] {
+impl FormatReader for LookaheadReader {
+    fn format_info(&self) -> &FormatInfo {
+        self.inner.format_info()
+    }
+
+    fn media_info(&self) -> &MediaInfo {
+        self.inner.media_info()
+    }
+
+    fn attachments(&self) -> &[Attachment] {
+        self.inner.attachments()
+    }
+
+    fn chapters(&self) -> Option<&ChapterGroup> {
+        self.inner.chapters()
+    }
+
+    fn metadata(&mut self) -> Metadata<'_> {
+        self.inner.metadata()
+    }
+
+    /// formats/mod.rs:591: everything read ahead is stale.  The application resets the decoders afterwards, as the
+    /// reference requires (codecs/audio.rs:252-257).
+    fn seek(&mut self, mode: SeekMode, to: SeekTo) -> Result<SeekedTo> {
+        self.drop_lookahead();
+        self.inner.seek(mode, to)
+    }
+
+    fn tracks(&self) -> &[Track] {
         self.inner.tracks()
     }
 
-    /// `FormatReader::next_packet` (formats/mod.rs:646): the oldest pre-read packet.
-    pub fn next_packet(&mut self) -> Result<Option<Packet>> {
+    /// formats/mod.rs:646: the oldest packet read ahead.  It leaves its track's queue (the queue holds what FOLLOWS the
+    /// packet the application is about to decode) and becomes the track's `last_out`.  An error of the inner reader is
+    /// returned when it occurs, like the inner reader would have returned it `depth` packets later.
+    fn next_packet(&mut self) -> Result<Option<Packet>> {
         self.refill()?;
         let next = self.pending.pop_front();
         if let Some(p) = &next {
-            // the application now owns this packet: it leaves the decoder-visible queue when the decoder consumes it
-            let q = track_queue(p.track_id);
-            let mut q = q.lock().expect("track queue poisoned");
-            if q.packets.front().map(|f| f.pts == p.pts) == Some(true) {
-                q.packets.pop_front();
-            }
+            let mut shared = self.shared.lock().expect("look-ahead state poisoned");
+            let q = shared.tracks.entry(p.track_id).or_default();
+            q.packets.pop_front();
+            q.last_out = Some(PacketKey::of(&p.as_packet_ref()));
         }
         Ok(next)
     }
 
-    /// `FormatReader::seek` (formats/mod.rs:591): everything read ahead is stale.  The application resets the decoder
-    /// afterwards, as the reference requires (codecs/audio.rs:252-257).
-    pub fn seek(&mut self, mode: SeekMode, to: SeekTo) -> Result<SeekedTo> {
-        self.drop_lookahead();
-        self.inner.seek(mode, to)
+    fn into_inner<'s>(self: Box<Self>) -> MediaSourceStream<'s>
+    where
+        Self: 's,
+    {
+        self.inner.into_inner()
     }
 }
 
@@ -95,7 +187,7 @@ pub trait BatchCodec {
     type Parsed;
     /// Entropy decode + dequantise one packet with the reference's CPU code (vendored: the parse modules of the
     /// reference's codec crates are private).  Errors here are the reference's `DecodeError`s.
-    fn parse(&mut self, packet: &Packet) -> Result<Self::Parsed>;
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<Self::Parsed>;
     /// Transform `batch` (consecutive packets of this track) in one call; the state (delay lines / overlap / V FIFO)
     /// enters and leaves through the codec's `*_io` buffers.  Writes planar PCM: `pcm[ch][i]` = packet i of channel ch.
     fn transform(&mut self, batch: &[Self::Parsed]) -> Result<()>;
@@ -108,59 +200,94 @@ pub trait BatchCodec {
 }
 
 /// Batching state shared by the four decoders.
-pub struct Lookahead {
-    /// pts of the packets of the last batch, in order; `head` = the next one to hand out.
-    ready: Vec<u64>,
+pub struct Lookahead<P> {
+    /// the packets of the last batch, parsed, and their pts, in order; `head` = the next one to hand out
+    parsed: Vec<P>,
+    ready: Vec<i64>,
     head: usize,
     max_batch: usize,
+    /// the reader this decoder's packets come from, once found
+    reader: Option<SharedHandle>,
 }
 
-impl Lookahead {
+impl<P> Lookahead<P> {
     pub fn new(max_batch: usize) -> Self {
-        Lookahead { ready: Vec::new(), head: 0, max_batch: max_batch.max(1) }
+        Lookahead { parsed: Vec::new(), ready: Vec::new(), head: 0, max_batch: max_batch.max(1), reader: None }
     }
 
+    /// `AudioDecoder::reset` (audio.rs:252-257): nothing pre-computed survives.
     pub fn reset(&mut self) {
+        self.parsed.clear();
         self.ready.clear();
         self.head = 0;
     }
 
+    /// Batches transformed so far would be a counter in the C++ twin; here: packets waiting in the current batch.
+    pub fn precomputed(&self) -> usize {
+        self.ready.len() - self.head
+    }
+
     /// The body of `decode_ref`: returns after `codec.publish` has filled the decoder's buffer with `packet`'s audio.
-    pub fn decode<C: BatchCodec>(&mut self, codec: &mut C, packet: &Packet) -> Result<()> {
+    /// On error the codec's buffer is cleared (audio.rs:278) and nothing pre-computed is kept.
+    pub fn decode<C: BatchCodec<Parsed = P>>(&mut self, codec: &mut C, packet: &PacketRef<'_>) -> Result<()> {
         if self.head < self.ready.len() && self.ready[self.head] != packet.pts.get() {
-            // discontinuity without reset(): drop the pre-computed frames (the C++ twin also replays the last returned
-            // packet to rebuild the exact state; the same one-packet-memory argument applies here)
+            // Not the packet the look-ahead was computed for: the caller skipped packets without reset().  A frame-by-frame
+            // decoder would continue from the state the LAST RETURNED packet left, but the carried state is already that of
+            // the end of the batch.  Every codec on this path has a one-packet memory (the delay line / overlap / V FIFO after
+            // a packet depend on that packet's input alone), so replaying the last returned packet rebuilds exactly that
+            // state (include/symaccel.hpp, LookaheadDecoder::decode, does the same).
+            let replay = if self.head >= 1 { Some(self.head - 1) } else { None };
+            if let Some(i) = replay {
+                if let Err(e) = codec.transform(&self.parsed[i..i + 1]) {
+                    codec.clear();
+                    self.reset();
+                    return Err(e);
+                }
+            }
             self.reset();
         }
         if self.head >= self.ready.len() {
-            let mut parsed = Vec::with_capacity(self.max_batch);
-            let mut ids = Vec::with_capacity(self.max_batch);
-            parsed.push(codec.parse(packet)?);
-            ids.push(packet.pts.get());
-            {
-                let q = track_queue(packet.track_id);
-                let q = q.lock().expect("track queue poisoned");
-                for p in q.packets.iter().take(self.max_batch - 1) {
-                    match codec.parse(p) {
-                        Ok(x) => {
-                            parsed.push(x);
-                            ids.push(p.pts.get());
-                        }
-                        // a corrupt packet further ahead ends the batch: it fails when its own decode_ref comes
-                        Err(_) => break,
-                    }
-                }
-            }
-            if let Err(e) = codec.transform(&parsed) {
+            if let Err(e) = self.fill(codec, packet) {
                 codec.clear();
                 self.reset();
                 return Err(e);
             }
-            self.ready = ids;
-            self.head = 0;
         }
         codec.publish(self.head);
         self.head += 1;
+        Ok(())
+    }
+
+    fn fill<C: BatchCodec<Parsed = P>>(&mut self, codec: &mut C, packet: &PacketRef<'_>) -> Result<()> {
+        let mut parsed = Vec::with_capacity(self.max_batch);
+        let mut ids = Vec::with_capacity(self.max_batch);
+        parsed.push(codec.parse(packet)?);
+        ids.push(packet.pts.get());
+        if self.reader.is_none() {
+            self.reader = find_reader(&PacketKey::of(packet));
+        }
+        if let Some(reader) = &self.reader {
+            let shared = reader.lock().expect("look-ahead state poisoned");
+            // only if `packet` is the one this reader handed out last for the track do the queued packets follow it
+            if let Some(q) = shared.tracks.get(&packet.track_id) {
+                if q.last_out == Some(PacketKey::of(packet)) {
+                    for p in q.packets.iter().take(self.max_batch - 1) {
+                        match codec.parse(&p.as_packet_ref()) {
+                            Ok(x) => {
+                                parsed.push(x);
+                                ids.push(p.pts.get());
+                            }
+                            // a corrupt packet further ahead ends the batch: it fails when its own decode_ref comes
+                            Err(_) => break,
+                        }
+                    }
+                }
+            }
+        }
+        codec.transform(&parsed)?;
+        self.parsed = parsed;
+        self.ready = ids;
+        self.head = 0;
         Ok(())
     }
 }

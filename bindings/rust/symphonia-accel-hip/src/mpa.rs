@@ -1,11 +1,11 @@
 //! `HipMpaDecoder`: MPEG-1/2/2.5 Layer III with the synthesis tail -- reorder, antialias, hybrid synthesis, frequency
 //! inversion and the polyphase filterbank (symphonia-bundle-mp3/src/layer3/hybrid_synthesis.rs:153-485,
 //! synthesis.rs:158-336; caller layer3/mod.rs:440-476) -- on the MI355X.
-use symphonia_core::audio::{AudioBuffer, AudioSpec, GenericAudioBufferRef};
+use symphonia_core::audio::{Audio, AudioBuffer, AudioMut, AudioSpec, GenericAudioBufferRef};
 use symphonia_core::codecs::audio::well_known::CODEC_ID_MP3;
 use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoderOptions};
 use symphonia_core::errors::{unsupported_error, Result};
-use symphonia_core::packet::Packet;
+use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
 use crate::ctx::{check, Context, Pinned};
@@ -27,7 +27,7 @@ pub struct ParsedMpa {
 pub trait MpaFrontEnd: Send + Sync {
     fn channels(&self) -> usize;
     fn sample_rate_idx(&self) -> i32;
-    fn parse(&mut self, packet: &Packet) -> Result<ParsedMpa>;
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedMpa>;
 }
 
 pub struct MpaBatch {
@@ -47,7 +47,7 @@ pub struct MpaBatch {
 impl BatchCodec for MpaBatch {
     type Parsed = ParsedMpa;
 
-    fn parse(&mut self, packet: &Packet) -> Result<ParsedMpa> {
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedMpa> {
         self.front.parse(packet)
     }
 
@@ -125,6 +125,7 @@ impl DecoderBatch for MpaBatch {
 crate::hip_decoder!(
     HipMpaDecoder,
     MpaBatch,
+    ParsedMpa,
     crate::frontends::mpa_front_end,
     &[support_audio_codec!(CODEC_ID_MP3, "mp3", "MPEG Audio Layer 3 (MI355X synthesis)")],
     "MP3 decoder with the same observable behaviour as `symphonia_bundle_mp3::MpaDecoder` for Layer III streams."

@@ -1,10 +1,10 @@
 //! `HipVorbisDecoder`: the per-channel synthesis of every audio packet -- Imdct, windowing and the lapped overlap-add of
 //! `DspChannel::synth` (symphonia-codec-vorbis/src/dsp.rs:68-145, called from lib.rs:296-331) -- on the MI355X.
-use symphonia_core::audio::{AudioBuffer, AudioSpec, GenericAudioBufferRef};
+use symphonia_core::audio::{Audio, AudioBuffer, AudioMut, AudioSpec, GenericAudioBufferRef};
 use symphonia_core::codecs::audio::well_known::CODEC_ID_VORBIS;
 use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoderOptions};
 use symphonia_core::errors::{unsupported_error, Result};
-use symphonia_core::packet::Packet;
+use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
 use crate::ctx::{check, Context, Pinned};
@@ -24,7 +24,7 @@ pub trait VorbisFrontEnd: Send + Sync {
     fn channels(&self) -> usize;
     /// (bs0_exp, bs1_exp) of the identification header (lib.rs:404-406)
     fn block_exps(&self) -> (i32, i32);
-    fn parse(&mut self, packet: &Packet) -> Result<ParsedVorbis>;
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedVorbis>;
 }
 
 pub struct VorbisBatch {
@@ -47,7 +47,7 @@ pub struct VorbisBatch {
 impl BatchCodec for VorbisBatch {
     type Parsed = ParsedVorbis;
 
-    fn parse(&mut self, packet: &Packet) -> Result<ParsedVorbis> {
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedVorbis> {
         self.front.parse(packet)
     }
 
@@ -135,6 +135,7 @@ impl DecoderBatch for VorbisBatch {
 crate::hip_decoder!(
     HipVorbisDecoder,
     VorbisBatch,
+    ParsedVorbis,
     crate::frontends::vorbis_front_end,
     &[support_audio_codec!(CODEC_ID_VORBIS, "vorbis", "Vorbis (MI355X synthesis)")],
     "Vorbis decoder with the same observable behaviour as `symphonia_codec_vorbis::VorbisDecoder`."

@@ -440,11 +440,14 @@ inline void decorrelate_mid_side(Context &ctx, std::int32_t *out0, std::int32_t 
 // spectra stays in the reference's CPU code.
 namespace codecs {
 
-struct AudioBufferRef {  // GenericAudioBufferRef::F32 (audio/generic.rs:381-401): planar, one slice per channel
-    std::vector<const float *> planes;
+template <class S>
+struct AudioBufferRefT {  // GenericAudioBufferRef::F32 / ::S32 (audio/generic.rs:381-401): planar, one slice per channel
+    std::vector<const S *> planes;
     std::size_t frames = 0;
     bool is_empty() const { return frames == 0; }
 };
+using AudioBufferRef = AudioBufferRefT<float>;          // the transform codecs
+using AudioBufferRefS32 = AudioBufferRefT<std::int32_t>;  // FLAC (AudioBuffer<i32>, flac/decoder.rs:103)
 
 struct FinalizeResult {  // codecs/audio.rs:230-236
     std::optional<bool> verify_ok;
@@ -454,6 +457,8 @@ template <class Codec>
 class LookaheadDecoder {
 public:
     using Packet = typename Codec::Packet;
+    using Sample = typename Codec::Sample;                // f32 for the transform codecs, i32 for FLAC
+    using Buffer = AudioBufferRefT<Sample>;
     using Peek = std::function<std::optional<Packet>()>;  // the next packet of the same track the demuxer can see, if any
 
     LookaheadDecoder(Context &ctx, const typename Codec::Params &params, std::size_t lookahead, Peek peek)
@@ -471,7 +476,7 @@ public:
     }
 
     // AudioDecoder::decode (audio.rs:259-281)
-    const AudioBufferRef &decode(const Packet &packet) {
+    const Buffer &decode(const Packet &packet) {
         if (head_ < ready_.size() && ready_[head_] != Codec::id(packet)) {
             // Not the packet the look-ahead was computed for: the caller skipped packets without reset().  A
             // frame-by-frame decoder would now continue from the state the LAST RETURNED packet left, but the carried
@@ -481,7 +486,7 @@ public:
             drop_lookahead();
             if (have_last_packet_) {
                 std::vector<Packet> one(1, last_packet_);
-                std::vector<float> scratch;
+                std::vector<Sample> scratch;
                 codec_.decode_batch(ctx_, one, scratch);
             }
         }
@@ -502,7 +507,7 @@ public:
     }
 
     FinalizeResult finalize() { return FinalizeResult{}; }  // (the f32 codecs verify nothing, like the reference's)
-    const AudioBufferRef &last_decoded() const { return last_; }
+    const Buffer &last_decoded() const { return last_; }
     std::size_t lookahead() const { return lookahead_; }
     std::size_t batches_run() const { return batches_; }
 
@@ -544,18 +549,19 @@ private:
     Codec codec_;
     std::size_t lookahead_;
     Peek peek_;
-    std::vector<float> pcm_;                 // [channel][packet of the batch][frames_per_packet]: planar per packet
+    std::vector<Sample> pcm_;                // [channel][packet of the batch][frames_per_packet]: planar per packet
     std::vector<std::uint64_t> ready_;       // ids of the batch's packets, in order
     Packet last_packet_{};                   // the packet decode() returned last (replayed after a discontinuity)
     bool have_last_packet_ = false;
     std::size_t head_ = 0, batch_len_ = 0, batches_ = 0;
-    AudioBufferRef last_;
+    Buffer last_;
 };
 
 // AAC-LC: one packet = one raw_data_block = 1024 frames per channel.  What the CPU side (reference parser + spectral
 // tools) hands over per channel: the dequantised coefficients Ics::synth_channel would give Dsp::synth, the window
 // sequence and the window shapes (ics/mod.rs:449-468).
 struct AacLc {
+    using Sample = float;
     struct Params {
         std::size_t channels = 2;
     };
@@ -596,6 +602,7 @@ private:
 // MPEG-2 / 2.5, common.rs:173-178).  Per granule-channel: the requantised, stereo-processed samples and the side fields
 // the synthesis tail reads (layer3/mod.rs:440-476).
 struct Mp3 {
+    using Sample = float;
     struct Params {
         std::size_t channels = 2;
         std::size_t granules = 2;
@@ -649,6 +656,7 @@ private:
 // (prev_n + n) / 4 frames -- none for the first block after a reset (dsp.rs:77-80) -- so the batch's PCM is packed
 // (include/symaccel.h, "Vorbis") and the per-packet spans are what publish() asks for.
 struct Vorbis {
+    using Sample = float;
     struct Params {
         std::size_t channels = 2;
         int bs0_exp = 8, bs1_exp = 11;
@@ -712,6 +720,90 @@ private:
     std::vector<std::size_t> off_;
     std::vector<bool> emits_;
     std::size_t stride_ = 0;
+};
+
+// FLAC: one packet = one frame = one subframe per channel.  What the CPU side (frame / subframe headers, Rice decode:
+// flac/decoder.rs:381-660) hands over per channel: `blocksize` words -- the warm-up samples followed by the residuals,
+// exactly what fixed_predict / lpc_predict receive --, the subframe descriptor and its quantised coefficients, and per
+// frame the channel assignment.  The predictor restore of every subframe of the batch runs in one device call
+// (decoder.rs:663-752), then the stereo decorrelation and the `<< (32 - bps)` of decoder.rs:199-242.  FLAC carries no
+// state from frame to frame, so reset() has nothing to zero; block sizes may differ from packet to packet (the last
+// frame; variable-block-size streams): every subframe gets a slot of the batch's largest block size.
+struct Flac {
+    using Sample = std::int32_t;
+    struct Params {
+        std::size_t channels = 2;
+        std::uint32_t bits_per_sample = 16;
+    };
+    struct Packet {
+        std::uint64_t ts = 0;
+        std::size_t blocksize = 0;
+        std::vector<std::int32_t> words;        // [channel][blocksize]
+        std::vector<symaccel_flac_desc> desc;   // [channel]
+        std::vector<std::int32_t> coeffs;       // [channel][32], reference order (decoder.rs:716-752)
+        std::uint8_t pair_mode = 0;             // 0 independent, 1 left/side, 2 mid/side, 3 right/side (two-channel frames)
+    };
+    explicit Flac(const Params &p) : nch_(p.channels), shift_(32u - p.bits_per_sample) {
+        if (p.channels == 0 || p.bits_per_sample == 0 || p.bits_per_sample > 32) throw std::invalid_argument("Flac: parameters");
+    }
+    static std::uint64_t id(const Packet &p) { return p.ts; }
+    std::size_t channels() const { return nch_; }
+    std::size_t packet_frames(std::size_t i) const { return lens_[i]; }
+    std::size_t plane_offset(std::size_t c, std::size_t i, std::size_t) const { return (i * nch_ + c) * stride_; }
+    void reset_state() {}
+    void decode_batch(Context &ctx, const std::vector<Packet> &batch, std::vector<std::int32_t> &pcm) {
+        const std::size_t k = batch.size();
+        stride_ = 0;
+        lens_.assign(k, 0);
+        for (std::size_t i = 0; i < k; ++i) {
+            const Packet &p = batch[i];
+            if (p.blocksize == 0 || p.blocksize > 65535 || p.words.size() != nch_ * p.blocksize || p.desc.size() != nch_ ||
+                p.coeffs.size() != nch_ * 32 || p.pair_mode > 3 || (p.pair_mode != 0 && nch_ != 2))
+                throw std::invalid_argument("Flac: packet shape");
+            lens_[i] = p.blocksize;
+            stride_ = std::max(stride_, p.blocksize);
+        }
+        pcm.assign(k * nch_ * stride_, 0);
+        desc_.resize(k * nch_);
+        coeffs_.resize(k * nch_ * 32);
+        modes_.resize(k);
+        for (std::size_t i = 0; i < k; ++i) {
+            const Packet &p = batch[i];
+            for (std::size_t c = 0; c < nch_; ++c) {
+                std::copy_n(p.words.data() + c * p.blocksize, p.blocksize, pcm.data() + (i * nch_ + c) * stride_);
+                desc_[i * nch_ + c] = p.desc[c];
+                // a slot longer than its block: the restore runs over `stride_` words, the tail is zero residual and is never published
+                std::copy_n(p.coeffs.data() + c * 32, 32, coeffs_.data() + (i * nch_ + c) * 32);
+            }
+            modes_[i] = p.pair_mode;
+        }
+        check(symaccel_flac_restore(ctx.raw(), pcm.data(), desc_.data(), coeffs_.data(), k * nch_, stride_), ctx.raw());
+        if (nch_ == 2) {
+            // pair i = (channel 0, channel 1) of packet i: rows 2 i and 2 i + 1 of the batch
+            ch0_.resize(k * stride_);
+            ch1_.resize(k * stride_);
+            for (std::size_t i = 0; i < k; ++i) {
+                std::copy_n(pcm.data() + (2 * i) * stride_, stride_, ch0_.data() + i * stride_);
+                std::copy_n(pcm.data() + (2 * i + 1) * stride_, stride_, ch1_.data() + i * stride_);
+            }
+            check(symaccel_flac_decorrelate(ctx.raw(), modes_.data(), ch0_.data(), ch1_.data(), k, stride_, shift_), ctx.raw());
+            for (std::size_t i = 0; i < k; ++i) {
+                std::copy_n(ch0_.data() + i * stride_, stride_, pcm.data() + (2 * i) * stride_);
+                std::copy_n(ch1_.data() + i * stride_, stride_, pcm.data() + (2 * i + 1) * stride_);
+            }
+        } else {
+            for (std::int32_t &v : pcm) v = (std::int32_t)((std::uint32_t)v << shift_);  // decoder.rs:239-242
+        }
+    }
+
+private:
+    std::size_t nch_;
+    std::uint32_t shift_;
+    std::size_t stride_ = 0;
+    std::vector<std::size_t> lens_;
+    std::vector<symaccel_flac_desc> desc_;
+    std::vector<std::int32_t> coeffs_, ch0_, ch1_;
+    std::vector<std::uint8_t> modes_;
 };
 
 }  // namespace codecs

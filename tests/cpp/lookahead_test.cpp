@@ -1,4 +1,4 @@
-// LookaheadDecoder (include/symaccel.hpp): the AudioDecoder method set over batched device calls (AAC-LC, MP3, Vorbis).  A synthetic track of
+// LookaheadDecoder (include/symaccel.hpp): the AudioDecoder method set over batched device calls (AAC-LC, MP3, Vorbis, FLAC).  A synthetic track of
 // parsed packets is decoded through decode() one packet at a time; every returned buffer must be bit-identical to what a
 // frame-by-frame decoder (the CPU oracle, linked as the checker only) produces -- across batch boundaries, across a
 // reset() (seek) and across a discontinuity without reset().  Built against the real library on the GPU box and against
@@ -199,6 +199,61 @@ static void test_vorbis(Context &ctx, size_t lookahead, int e0, int e1) {
     for (size_t i = 30; i < n; ++i) step(i);
 }
 
+// ---- FLAC: integer samples, no carried state, block sizes that differ from packet to packet
+static void test_flac(Context &ctx, size_t lookahead, size_t nch, uint32_t bps) {
+    const size_t n = 23;
+    std::mt19937 rng(77 + (unsigned)lookahead + (unsigned)nch);
+    std::vector<Flac::Packet> track(n);
+    for (size_t i = 0; i < n; ++i) {
+        Flac::Packet &p = track[i];
+        p.ts = 900 + 4096 * i;
+        p.blocksize = i + 1 == n ? 777 : (rng() % 4 == 0 ? 1152 : 4096);
+        p.words.resize(nch * p.blocksize);
+        p.desc.resize(nch);
+        p.coeffs.assign(nch * 32, 0);
+        p.pair_mode = nch == 2 ? (uint8_t)(rng() % 4) : 0;
+        for (size_t c = 0; c < nch; ++c) {
+            const unsigned kind = rng() % 3;
+            const unsigned order = kind == 0 ? 0 : (kind == 1 ? rng() % 5 : 1 + rng() % 32);
+            const unsigned shift = kind == 2 ? 8 + rng() % 6 : 0;
+            const unsigned wasted = rng() % 5 == 0 ? 1 + rng() % 3 : 0;
+            p.desc[c] = symaccel_flac_desc{(uint8_t)kind, (uint8_t)order, (uint8_t)shift, (uint8_t)wasted};
+            if (kind == 2)
+                for (unsigned j = 0; j < order; ++j) p.coeffs[c * 32 + j] = (int32_t)(rng() % 2001) - 1000;
+            for (size_t k = 0; k < p.blocksize; ++k) p.words[c * p.blocksize + k] = (int32_t)(rng() % 4001) - 2000;
+        }
+    }
+    size_t cursor = 0;
+    LookaheadDecoder<Flac> dec(ctx, Flac::Params{nch, bps}, lookahead, [&]() -> std::optional<Flac::Packet> {
+        if (cursor >= track.size()) return std::nullopt;
+        return track[cursor++];
+    });
+    for (size_t i = 0; i < n; ++i) {
+        if (i == 9) {  // seek
+            dec.reset();
+            EXPECT(dec.last_decoded().is_empty(), "reset() must clear the buffer");
+            cursor = i;
+        }
+        if (i == 15) cursor = i;  // (i == 14 is skipped below: packets dropped without reset())
+        if (i == 14) continue;
+        if (cursor <= i) cursor = i + 1;
+        const AudioBufferRefS32 &buf = dec.decode(track[i]);
+        const Flac::Packet &p = track[i];
+        EXPECT(buf.frames == p.blocksize, "flac frames per packet: %zu vs %zu", buf.frames, p.blocksize);
+        std::vector<int32_t> want(p.words);
+        for (size_t c = 0; c < nch; ++c) {
+            const uint8_t d[4] = {p.desc[c].kind, p.desc[c].order, p.desc[c].shift, p.desc[c].wasted_bits};
+            so_flac_restore_batch(want.data() + c * p.blocksize, d, p.coeffs.data() + c * 32, 1, p.blocksize);
+        }
+        if (nch == 2) so_flac_decorrelate(p.pair_mode, want.data(), want.data() + p.blocksize, p.blocksize);
+        for (size_t c = 0; c < nch; ++c) {
+            so_flac_shl(want.data() + c * p.blocksize, p.blocksize, 32 - bps);
+            EXPECT(std::memcmp(buf.planes[c], want.data() + c * p.blocksize, p.blocksize * 4) == 0,
+                   "FLAC K=%zu packet %zu channel %zu differs from the frame-by-frame decoder", lookahead, i, c);
+        }
+    }
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && std::strcmp(argv[1], "--expect-no-device") == 0) {
         try {
@@ -215,6 +270,9 @@ int main(int argc, char **argv) {
     for (size_t k : {size_t(1), size_t(3), size_t(8)}) test_mp3(ctx, k);
     for (size_t k : {size_t(1), size_t(5), size_t(16)}) test_vorbis(ctx, k, 8, 11);
     test_vorbis(ctx, 6, 6, 9);
+    for (size_t k : {size_t(1), size_t(4), size_t(32)}) test_flac(ctx, k, 2, 16);
+    test_flac(ctx, 5, 1, 24);
+    test_flac(ctx, 7, 3, 20);
     if (g_failures == 0) std::printf("all checks passed\n");
     return g_failures ? 1 : 0;
 }

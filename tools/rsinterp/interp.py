@@ -407,6 +407,12 @@ def deepclone(v):
         return Arr([deepclone(x) for x in v.a[v.o:v.o + v.n]], True)
     if isinstance(v, Place):
         return deepclone(v.get())
+    if isinstance(v, Struct):  # (a derived Clone clones the Vec / Box fields too; copyval would move them)
+        return Struct(v.name, {k: deepclone(x) for k, x in v.f.items()})
+    if isinstance(v, Enum) and v.f is not None:
+        return Enum(v.enum, v.variant, {k: deepclone(x) for k, x in v.f.items()})
+    if isinstance(v, tuple):
+        return tuple(deepclone(x) for x in v)
     return copyval(v)
 
 
@@ -1647,6 +1653,9 @@ class Interp:
         if name in INT_BITS:
             if isinstance(v, Int):
                 return Int(wrap_int(v.v, name), name)
+            if isinstance(v, (Arr, Slice)):  # `slice.as_ptr() as usize`: an address -- the identity of the storage
+                a, o, _ = seq_view(v)
+                return Int(id(a) + o, name)
             if isinstance(v, (bool, np.bool_)):
                 return Int(int(v), name)
             if isinstance(v, ULit):
@@ -1964,6 +1973,10 @@ class Interp:
     def builtin_fn(self, segs):
         name = segs[-1]
         head = segs[-2] if len(segs) >= 2 else None
+        from . import stdext
+        ext = stdext.path_builtin(self, segs)
+        if ext is not None:
+            return ext
         if head == 'consts' and len(segs) >= 3 and segs[-3] in FLOAT_TYPES:
             return self.prim_const(segs[-3], name)
         if head in FLOAT_TYPES or head in INT_BITS:
@@ -2105,6 +2118,12 @@ class Interp:
         _, recv_e, name, gargs, arg_es = e
         recv = self.evr(recv_e, env)
         base = deref(recv)
+        from . import stdext
+        while stdext.is_std(base):
+            done, val = stdext.method(self, base, name, [self.ev(a, env) for a in arg_es] if not isinstance(base, stdext.Cell) or base.kind != 'Arc' or name == 'clone' else [], env)
+            if done:
+                return val
+            base = recv = val  # Arc<T>: the method is T's
         # user-defined methods
         if isinstance(base, (Struct, Enum)):
             tname = base.name if isinstance(base, Struct) else base.enum
@@ -2634,11 +2653,23 @@ class Interp:
             return UNIT
         # Vec
         if isinstance(v, Arr):
-            if name == 'push':
+            if name in ('push', 'push_back'):
                 v.a.append(args[0])
                 return UNIT
-            if name == 'pop':
+            if name in ('pop', 'pop_back'):
                 return some(v.a.pop()) if v.a else NONE
+            if name == 'pop_front':
+                return some(v.a.pop(0)) if v.a else NONE
+            if name == 'push_front':
+                v.a.insert(0, args[0])
+                return UNIT
+            if name in ('front', 'front_mut'):
+                return some(v.a[0]) if v.a else NONE
+            if name in ('back', 'back_mut'):
+                return some(v.a[-1]) if v.a else NONE
+            if name == 'retain':
+                v.a[:] = [x for x in v.a if truth(self.call_value(args[0], [x]))]
+                return UNIT
             if name == 'clear':
                 v.a.clear()
                 return UNIT
@@ -2923,6 +2954,12 @@ class Interp:
             if name in ('filter',):
                 return v if good and truth(self.call_value(args[0], [v.f['0']])) else NONE
             if name == 'unwrap_unchecked':
+                return v.f['0']
+            if name in ('get_or_insert_with', 'get_or_insert') and v.enum == 'Option':
+                if not good:
+                    if v is NONE:
+                        raise InterpError('Option::%s on a temporary' % name)
+                    v.variant, v.f = 'Some', {'0': self.call_value(args[0], []) if name == 'get_or_insert_with' else args[0]}
                 return v.f['0']
         if name == 'clone':
             return copyval(v)

@@ -1163,7 +1163,8 @@ class Parser:
                         self.i += 1
                         guard = self.expr()
                     self.expect('=>')
-                    body = self.expr()
+                    # an arm whose body is a block ends at the block's brace (`{ .. } (3, 0) => ..` is two arms, not a call)
+                    body = self.block_expr() if self.at('{') else self.expr()
                     arms.append((pat, guard, body))
                     if not self.eat(','):
                         if self.at('}'):
