@@ -482,7 +482,9 @@ int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uin
  * synthesis kernels -- every byte read once and written once -- so that a benchmark can quote a workload against the copy
  * rate the SAME run reaches.  frames_per_wavefront 0: a plain grid-stride 16 B/lane copy; k > 0: every
  * wavefront streams k consecutive 4 KiB frames, the access pattern of a wavefront that walks a k-frame segment of one
- * chain.  flags bit 0: non-temporal loads and stores (what the synthesis kernels use).  Not part of any decode path. */
+ * chain.  flags bit 0: non-temporal loads and stores (what the synthesis kernels use); bits 1-2 (k > 0 only): 0 copy, 1 read
+ * only, 2 write only; bit 3 (k > 0 only): the four wavefronts of a workgroup share 4 k consecutive frames round-robin
+ * (16 KiB contiguous per workgroup and step).  Not part of any decode path. */
 int symaccel_probe_copy_device(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes,
                                uint32_t frames_per_wavefront, uint32_t flags);
 

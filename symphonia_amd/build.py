@@ -29,7 +29,7 @@ SOURCES = ["tables.cpp", "ctx.cpp", "host_tools.cpp", "stage.cpp", "imdct_generi
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
-TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_VARIANT", "NT", "MP3_WAVES", "MP3_VARIANT", "MP3_WG_WAVES", "VORBIS_WAVES", "ALAC_SMALL_WAVES", "FLAC_PARTS", "MP3_SLOT_GROUP")
+TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_VARIANT", "NT", "MP3_WAVES", "MP3_VARIANT", "MP3_WG_WAVES", "VORBIS_WAVES", "ALAC_SMALL_WAVES", "FLAC_PARTS", "MP3_SLOT_GROUP", "AAC_ABLATE", "AAC_QUAD")
 TUNE_PREFIX = "SYMACCEL_TUNE_"
 
 
@@ -100,7 +100,18 @@ def build(force=False, verbose=False, save_temps=False):
     objdir.mkdir(parents=True, exist_ok=True)
     objs = []
     procs = []
+    # A tuned build only recompiles the sources a knob can reach (the knob's macro appears in the file, or in a header -- then
+    # everything); the rest links the product build's objects, which are current when the product library is.
+    reuse = set()
+    if defines and not force and not needs_build(OUT, ()):
+        macros = [d[2:].split("=")[0] for d in defines]
+        if not any(m in h.read_text() for h in CSRC.glob("*.h") for m in macros):
+            reuse = {s for s in SOURCES if not any(m in (CSRC / s).read_text() for m in macros)
+                     and (HERE / "build" / (s.replace(".", "_") + ".o")).exists()}
     for src in SOURCES:
+        if src in reuse:
+            objs.append(str(HERE / "build" / (src.replace(".", "_") + ".o")))
+            continue
         obj = objdir / (src.replace(".", "_") + ".o")
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-x", "hip", *FLAGS, *defines, "-c", str(CSRC / src), "-o", str(obj)]
         if save_temps:

@@ -104,6 +104,19 @@ __device__ __forceinline__ void start_window4(const float *sw, int j0, float *w)
 #ifndef SYM_AAC_PREFETCH
 #define SYM_AAC_PREFETCH 1  // frames of spectral lines in flight ahead of the one being transformed (1 or 2)
 #endif
+// MEASUREMENT ONLY (results are wrong by construction; never set in the product build, profiles/r03*_aac_ablate*.txt):
+// bit 0: no PCM stores; bit 1: every frame's lines are read from the chain's first frame (an L2-resident 512 KiB instead of
+// 512 MiB from HBM); bit 2: no transform -- the pre-twiddled lines are stored as they are (the kernel's load / prefetch /
+// store skeleton at its own occupancy).  Which direction, or whether the arithmetic between them, binds the kernel.
+#ifndef SYM_AAC_ABLATE
+#define SYM_AAC_ABLATE 0
+#endif
+// Which walk (build knob): 0 = the wavefront walk, 1 = the workgroup walk (two LDS-only barriers per step).  A third form --
+// dedicated delay slots and point-to-point LDS flags instead of barriers -- measured the same as 1 and was removed
+// (profiles/r03f_aac_quad2_ab.txt).
+#ifndef SYM_AAC_QUAD
+#define SYM_AAC_QUAD 0
+#endif
 __device__ __forceinline__ float2 ld_line(const float2 *p) { return ld_stream(p); }
 // PCM of one output slot (the two float4 of store_slot), streamed
 __device__ __forceinline__ void st_slot(float *frame, int m2, const float (&v)[8]) {
@@ -231,12 +244,28 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
 #else
         if (t + 1 < (long)t_end) {  // prefetch the next frame; it lands while this one is transformed
             sb_next = side[chain_base + (size_t)t + 1];
-            const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t + 1) * 1024);
+            const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + ((SYM_AAC_ABLATE & 2) ? (size_t)0 : (size_t)t + 1)) * 1024);
 #pragma unroll
             for (int s = 0; s < 8; ++s) line[s] = ld_line(src + lane + 64 * s);
         }
 #endif
 
+#if SYM_AAC_ABLATE & 4
+        if (true) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float dst[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dst[2 * q] = z[4 * h + q].x + dl[h][2 * q];
+                    dst[2 * q + 1] = z[4 * h + q].y + dl[h][2 * q + 1];
+                }
+                if (emit && !(SYM_AAC_ABLATE & 1)) st_slot(frame_out, lane + 64 * h, dst);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dl[h][q] = dst[q] * 0.5f;
+            }
+        } else
+#endif
         if (seq != EIGHT_SHORT) {
             fft512_wave(z, lane, lds, lt);
             const float *wprev = tabs + (prev_shape ? kTabKbd : kTabSine);  // prev_long_win (dsp.rs:71-74)
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
                     const float v = dl[h][q] + (x[q] * wo[q]);
                     dst[q] = (seq == LONG_STOP && j < kP0) ? dl[h][q] : v;
                 }
-                if (emit) st_slot(frame_out, m2, dst);
+                if (emit && !(SYM_AAC_ABLATE & 1)) st_slot(frame_out, m2, dst);
                 // ---- delay for the next frame (dsp.rs:132-157): pcm[1024 + j] * long_win[1023 - j] (the
                 // slot's two float4 read backwards), a short-window slope, or literal zero
                 float wd[8];
@@ -331,11 +360,250 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
     }
 }
 
+
+// ---- the workgroup walk -------------------------------------------------------------------------------------------------
+// The four wavefronts of a workgroup take FOUR CONSECUTIVE frames of one chain per step (wave j: frame t0 + 4 i + j), so a
+// workgroup reads and writes 16 KiB of contiguous memory per step instead of four 4 KiB pieces 256 KiB apart.  Measured with
+// the copy probe of the same shapes (profiles/r03c_probe_patterns.txt): 5.3 TB/s against 4.6 TB/s, and the ablation of
+// profiles/r03b_aac_ablate_ab.txt says the wavefront walk above sits exactly on the slower of the two.
+// What makes it possible: the delay line a frame leaves behind depends on THAT frame's input alone (the second half of its
+// IMDCT output, windowed: dsp.rs:132-157), so the four transforms of a step are independent; only the overlap-add needs
+// the neighbour's result.  Every wavefront writes its frame's delay line into an LDS slot (natural sample order), the
+// workgroup meets at a barrier, every wavefront adds its predecessor's slot to its own first half and stores the PCM.
+// Wave 0's predecessor is wave 3 of the step before: that slot is a double-buffered 4 KiB carry buffer of its own (the
+// other three live in the owners' FFT work areas, which the next transform overwrites -- hence the second barrier).
+// A segment starts with a step in which only wave 3 runs: the halo frame (or the chain's incoming delay) fills the carry.
+constexpr int kSlotOff = kShortRowsEnd;  // floats: the slot lies behind the eight short-window rows, inside the FFT work area
+static_assert(kSlotOff + 1024 <= kWaveLds, "delay slot must fit the per-wave LDS behind the short-window rows");
+
+__global__ __launch_bounds__(256, SYM_AAC_MIN_WAVES) void aac_synth_quad_kernel(
+    DevTables tb, const float *__restrict__ coeffs, const uint8_t *__restrict__ side,
+    const float *__restrict__ delay_in, float *__restrict__ delay_out, float *__restrict__ pcm,
+    unsigned frames_per_chain, unsigned seg_steps, unsigned segs_per_chain) {
+    __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
+    __shared__ __attribute__((aligned(16))) float wave_lds[4][kWaveLds];
+    __shared__ __attribute__((aligned(16))) float carry[2][1024];
+    for (int i = (int)threadIdx.x; i < 1024; i += 256) {
+        tabs[kTabTw + i] = reinterpret_cast<const float *>(tb.aac_tw_long)[i];
+        tabs[kTabKbd + i] = tb.aac_kbd_long[i];
+        tabs[kTabSine + i] = tb.aac_sine_long[i];
+        if (i < 128) {
+            tabs[kTabKbdShort + i] = tb.aac_kbd_short[i];
+            tabs[kTabSineShort + i] = tb.aac_sine_short[i];
+        }
+    }
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    float *ldsf = wave_lds[wave];
+    c32 *lds = reinterpret_cast<c32 *>(ldsf);
+    const c32 *tw = reinterpret_cast<const c32 *>(tabs + kTabTw);
+    const unsigned chain = blockIdx.x / segs_per_chain, seg = blockIdx.x % segs_per_chain;
+    const long t_begin = (long)seg * seg_steps * 4;
+    const long t_end = t_begin + (long)seg_steps * 4 < (long)frames_per_chain ? t_begin + (long)seg_steps * 4 : (long)frames_per_chain;
+    const long n_steps = (t_end - t_begin + 3) / 4;
+    const size_t chain_base = (size_t)chain * frames_per_chain;
+    LaneTables lt;
+    load_lane_tables(tb, lane, lt);
+
+    // the carry in front of the segment: the caller's delay line at a chain's start, else what the halo frame leaves (step -1)
+    if (t_begin == 0 && wave == 3) {
+        const float4 *src = reinterpret_cast<const float4 *>(delay_in + (size_t)chain * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4 *>(carry[1])[lane + 64 * q] = src[lane + 64 * q];
+    }
+    // `line` always holds the lines of frame t_loaded: the halo frame for wave 3 of a later segment, else the frame of step 0
+    long t_loaded = (wave == 3 && t_begin > 0) ? t_begin - 1 : t_begin + wave;
+    float2 line[8];
+    unsigned sb_next = 0;
+    if (t_loaded < t_end) {
+        const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t_loaded) * 1024);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) line[s] = ld_line(src + lane + 64 * s);
+        sb_next = side[chain_base + (size_t)t_loaded];
+    } else {
+        t_loaded = -100;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) line[s] = make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();  // tables and the carry are in place
+
+    long t = t_begin - 4 + wave;  // this wavefront's frame of step i
+    for (long i = -1; i < n_steps; ++i, t += 4) {
+        const bool active = t == t_loaded;  // (step -1: only a wave 3 with a halo frame)
+        const bool emit = i >= 0;
+        const unsigned sb = sb_next;
+        const int seq = (int)(sb & 3u);
+        const int shape = (int)((sb >> 2) & 1u), prev_shape = (int)((sb >> 3) & 1u);
+        float *my_slot = wave == 3 ? carry[i & 1] : ldsf + kSlotOff;
+        const float *prev_slot = wave == 0 ? carry[(i + 1) & 1] : wave_lds[wave - 1] + kSlotOff;
+        float xw[2][8];  // long frames: first half of the IMDCT output times its window, waiting for the predecessor's delay
+
+        // ---------------- phase 1: transform this wavefront's frame, publish the delay line it leaves behind
+        if (active) {
+            c32 z[8];
+            if (seq != EIGHT_SHORT) {
+                const int mirror = (63 - lane) * 4;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
+                    z[s] = pre_twiddle(line[s].x, mirrored, tw[lane + 64 * s]);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {  // the short transform indexes lines per 128-line window: stage in LDS
+                    ldsf[short_row(s) + 2 * lane] = line[s].x;
+                    ldsf[short_row(s) + 2 * lane + 1] = line[s].y;
+                }
+                wave_sync();
+            }
+            // this wavefront's frame of the next step lands while this one is transformed
+            const long tn = t < t_begin ? t_begin + 3 : t + 4;  // (after the halo frame t_begin - 1 wave 3 continues with t_begin + 3)
+            if (tn < t_end) {
+                sb_next = side[chain_base + (size_t)tn];
+                const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + ((SYM_AAC_ABLATE & 2) ? (size_t)0 : (size_t)tn)) * 1024);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) line[s] = ld_line(src + lane + 64 * s);
+                t_loaded = tn;
+            } else {
+                t_loaded = -100;
+            }
+#if SYM_AAC_ABLATE & 4
+            if (true) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float nd[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        xw[h][2 * q] = z[4 * h + q].x;
+                        xw[h][2 * q + 1] = z[4 * h + q].y;
+                        nd[2 * q] = z[4 * h + q].y * 0.5f;
+                        nd[2 * q + 1] = z[4 * h + q].x * 0.5f;
+                    }
+                    store_slot(my_slot, lane + 64 * h, nd);
+                }
+            } else
+#endif
+            if (seq != EIGHT_SHORT) {
+                fft512_wave(z, lane, lds, lt);
+                const float *wprev = tabs + (prev_shape ? kTabKbd : kTabSine);  // prev_long_win (dsp.rs:71-74)
+                const float *wcur = tabs + (shape ? kTabKbd : kTabSine);        // long_win (dsp.rs:66-69)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m2 = lane + 64 * h;
+                    float x[8], x2[8];
+                    post_slot(lds, tw, m2, x, x2);
+                    float wo[8];
+                    if (seq == LONG_STOP) {
+                        const float *psw = tabs + (prev_shape ? kTabKbdShort : kTabSineShort);
+                        stop_window4(psw, 4 * m2, wo);
+                        stop_window4(psw, 1020 - 4 * m2, wo + 4);
+                    } else {
+                        load_slot(wprev, m2, wo);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) xw[h][q] = x[q] * wo[q];
+                    // the delay this frame leaves (dsp.rs:132-157): pcm[1024 + j] * long_win[1023 - j], a short-window slope,
+                    // or literal zero
+                    float wd[8], nd[8];
+                    if (seq == LONG_START) {
+                        const float *sw = tabs + (shape ? kTabKbdShort : kTabSineShort);
+                        start_window4(sw, 4 * m2, wd);
+                        start_window4(sw, 1020 - 4 * m2, wd + 4);
+                    } else {
+                        float wr[8];
+                        load_slot(wcur, m2, wr);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) wd[q] = wr[7 - q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4);
+                        const float v = x2[q] * wd[q];
+                        nd[q] = (seq == LONG_START && j >= kP1) ? 0.0f : v;
+                    }
+                    store_slot(my_slot, m2, nd);
+                }
+            } else {
+                imdct_short_wave(lane, ldsf, tb.aac_tw_short, lt);  // H[w] = ldsf[short_row(w) ..]
+                const float *sw = tabs + (shape ? kTabKbdShort : kTabSineShort);
+                const float *psw = tabs + (prev_shape ? kTabKbdShort : kTabSineShort);
+#pragma unroll 1
+                for (int e = 0; e < 4; ++e) {  // dsp.rs:138-145
+                    const int j0 = 4 * lane + 256 * e;
+                    float nd[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (j0 < kP1) pcm_short4(ldsf, j0 + kP1, sw, psw, nd);
+                    *reinterpret_cast<float4 *>(my_slot + j0) = make_float4(nd[0], nd[1], nd[2], nd[3]);
+                }
+            }
+        }
+        wg_sync_lds();  // every delay line of this step is in its slot (LDS-only: the prefetch and the PCM stores stay in flight)
+
+        // ---------------- phase 2: overlap-add with the predecessor's delay line, PCM out
+        if (active && emit) {
+            float *frame_out = pcm + (chain_base + (size_t)t) * 1024;
+            if (seq != EIGHT_SHORT) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m2 = lane + 64 * h;
+                    float dl[8], dst[8];
+                    load_slot(prev_slot, m2, dl);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {  // dsp.rs:105-129: dst = delay + pcm * w, or delay alone
+                        const int j = q < 4 ? 4 * m2 + q : 1020 - 4 * m2 + (q - 4);
+                        const float v = dl[q] + xw[h][q];
+                        dst[q] = (seq == LONG_STOP && j < kP0) ? dl[q] : v;
+                    }
+                    if (!(SYM_AAC_ABLATE & 1)) st_slot(frame_out, m2, dst);
+                    else if (dst[0] == 12345.678f) frame_out[0] = dst[1];  // (keeps the overlap-add alive)
+                }
+            } else {
+                const float *sw = tabs + (shape ? kTabKbdShort : kTabSineShort);
+                const float *psw = tabs + (prev_shape ? kTabKbdShort : kTabSineShort);
+#pragma unroll 1
+                for (int e = 0; e < 4; ++e) {  // dsp.rs:111-117
+                    const int j0 = 4 * lane + 256 * e;
+                    const float4 d = *reinterpret_cast<const float4 *>(prev_slot + j0);
+                    float o[4] = {d.x, d.y, d.z, d.w};
+                    if (j0 >= kP0) {
+                        float ps[4];
+                        pcm_short4(ldsf, j0 - kP0, sw, psw, ps);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = o[q] + ps[q];
+                    }
+                    st_stream(reinterpret_cast<float4 *>(frame_out + j0), make_float4(o[0], o[1], o[2], o[3]));
+                }
+            }
+            if (t + 1 == (long)frames_per_chain) {  // the chain's last frame: its delay line is the outgoing state
+                float4 *d = reinterpret_cast<float4 *>(delay_out + (size_t)chain * 1024);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d[lane + 64 * q] = reinterpret_cast<const float4 *>(my_slot)[lane + 64 * q];
+            }
+        }
+        wg_sync_lds();  // the slots are free: the next transforms overwrite them
+    }
+}
+
 }  // namespace
 
 int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const float *d_delay_in,
                float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain) {
     if (frames_per_chain > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+#if SYM_AAC_QUAD
+    {
+        // a workgroup walks seg_steps steps of four frames; two workgroups per CU (one wavefront per SIMD each)
+        const size_t steps_per_chain = (frames_per_chain + 3) / 4;
+        unsigned seg_steps;
+        if (ctx->segment > 0) seg_steps = (unsigned)((ctx->segment + 3) / 4);
+        else seg_steps = choose_segment(ctx, n_chains, steps_per_chain, SYM_AAC_MIN_WAVES, 1, 1, 1);
+        if (seg_steps > steps_per_chain) seg_steps = (unsigned)steps_per_chain;
+        const size_t segs = (steps_per_chain + seg_steps - 1) / seg_steps;
+        const size_t grid = n_chains * segs;
+        if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+        hipLaunchKernelGGL(aac_synth_quad_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->dev, d_coeffs, d_side,
+                           d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, seg_steps, (unsigned)segs);
+        SYM_GPU(ctx, hipGetLastError());
+        return SYMACCEL_OK;
+    }
+#endif
     const unsigned seg = choose_segment(ctx, n_chains, frames_per_chain, 4 * SYM_AAC_MIN_WAVES, 1, 1, 1);
     const size_t segs = (frames_per_chain + seg - 1) / seg;
     const size_t items = n_chains * segs;

@@ -20,6 +20,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope fence over every address space: hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the s_barrier, i.e. every wavefront first waits for its outstanding global loads (the
+// prefetched next frame) and for its PCM stores to reach the L2 -- a round trip to memory per barrier.  Wavefronts that exchange
+// data through LDS alone need the LDS counter, nothing else.
+__device__ __forceinline__ void wg_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // LDS complex index of element (B, j, k) = logical position 64B + 8j + k of the FFT work array.
 // Both layouts are SEPARABLE -- lane base + per-instruction constant on the write AND the read side,
 // so every ds instruction uses one address VGPR plus an immediate offset -- and conflict-free for

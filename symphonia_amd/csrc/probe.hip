@@ -19,33 +19,46 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const float4 *__restric
     }
 }
 
-template <bool NT>
+// MODE 0 copy, 1 read only (the values feed a compare that never holds), 2 write only.  GROUP 1: a wavefront streams `per_wave`
+// consecutive frames; GROUP 4: the four wavefronts of a workgroup share 4 * per_wave consecutive frames and take them
+// round-robin (wave j: frames j, j + 4, ...), so that a workgroup's accesses of one step are 16 KiB contiguous.
+template <bool NT, int MODE, int GROUP>
 __global__ __launch_bounds__(256) void probe_copy_frames_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t frames,
                                                                 unsigned per_wave) {
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned lane = threadIdx.x & 63u;
+    float acc = 0.0f;
     for (unsigned f = 0; f < per_wave; ++f) {
-        const size_t fr = wave * per_wave + f;
-        if (fr >= frames) return;
+        const size_t fr = GROUP == 1 ? wave * per_wave + f : ((wave / GROUP) * per_wave + f) * GROUP + wave % GROUP;
+        if (fr >= frames) break;
         const float4 *s = in + fr * 256;
         float4 *d = out + fr * 256;
         float4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = NT ? ld_stream(s + lane + 64 * q) : s[lane + 64 * q];
+        for (int q = 0; q < 4; ++q) v[q] = MODE == 2 ? make_float4((float)f, 1.0f, 2.0f, (float)lane) : (NT ? ld_stream(s + lane + 64 * q) : s[lane + 64 * q]);
+        if (MODE == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += v[q].x + v[q].y + v[q].z + v[q].w;
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (NT) st_stream(d + lane + 64 * q, v[q]);
             else d[lane + 64 * q] = v[q];
         }
     }
+    if (MODE == 1 && acc == 12345.678f) out[0] = make_float4(acc, acc, acc, acc);
 }
 
 }  // namespace
 
-int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, unsigned frames_per_wavefront, bool nt) {
+int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, unsigned frames_per_wavefront, unsigned flags) {
+    const bool nt = (flags & 1u) != 0;
+    const unsigned mode = (flags >> 1) & 3u, group = (flags & 8u) ? 4u : 1u;
     const float4 *in = static_cast<const float4 *>(d_src);
     float4 *out = static_cast<float4 *>(d_dst);
     if (frames_per_wavefront == 0) {
+        if (mode != 0 || group != 1) return SYMACCEL_ERR_INVALID_ARG;
         const size_t n = bytes / 16;
         const unsigned grid = (unsigned)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
         if (nt) hipLaunchKernelGGL(probe_copy_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, in, out, n);
@@ -54,9 +67,15 @@ int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t 
         const size_t frames = bytes / 4096;
         const size_t waves = (frames + frames_per_wavefront - 1) / frames_per_wavefront;
         const size_t grid = (waves + 3) / 4;
-        if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-        if (nt) hipLaunchKernelGGL(probe_copy_frames_kernel<true>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, frames, frames_per_wavefront);
-        else hipLaunchKernelGGL(probe_copy_frames_kernel<false>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, frames, frames_per_wavefront);
+        if (grid > 0x7fffffffu || mode > 2) return SYMACCEL_ERR_INVALID_ARG;
+#define SYM_PROBE(NT, MODE, GROUP) \
+    hipLaunchKernelGGL((probe_copy_frames_kernel<NT, MODE, GROUP>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, frames, frames_per_wavefront)
+#define SYM_PROBE_G(NT, MODE) do { if (group == 4) SYM_PROBE(NT, MODE, 4); else SYM_PROBE(NT, MODE, 1); } while (0)
+#define SYM_PROBE_M(NT) do { if (mode == 0) SYM_PROBE_G(NT, 0); else if (mode == 1) SYM_PROBE_G(NT, 1); else SYM_PROBE_G(NT, 2); } while (0)
+        if (nt) SYM_PROBE_M(true); else SYM_PROBE_M(false);
+#undef SYM_PROBE_M
+#undef SYM_PROBE_G
+#undef SYM_PROBE
     }
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;

@@ -11,6 +11,7 @@
 #pragma once
 
 #include <pthread.h>
+#include <sched.h>
 
 #include <cmath>
 #include <cstdint>
@@ -121,7 +122,8 @@ static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; 
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
 static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(order, ...) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
 // A real rendezvous of the wavefront's work-items: the hardware runs them in lock step, the emulation
 // runs them as threads, so every point where the kernel relies on lock step must synchronise.
 static inline void __builtin_amdgcn_wave_barrier() {

@@ -8,7 +8,7 @@ from symphonia_amd import SymaccelError, _ffi
 
 
 def _modes():
-    return [(0, 0), (0, 1), (1, 1), (3, 0), (64, 1)]
+    return [(0, 0), (0, 1), (1, 1), (3, 0), (64, 1), (2, 9), (5, 8)]
 
 
 def test_emu_probe_copy(emu_ctx):
@@ -24,7 +24,7 @@ def test_emu_probe_copy(emu_ctx):
     for args in ((src.ctypes.data, dst.ctypes.data, 4095, 0, 0),            # not whole frames
                  (src.ctypes.data + 4, dst.ctypes.data, 4096, 0, 0),        # unaligned
                  (src.ctypes.data, src.ctypes.data + 4096, 8192, 0, 0),     # overlapping
-                 (src.ctypes.data, dst.ctypes.data, 4096, 0, 2),            # unknown flag
+                 (src.ctypes.data, dst.ctypes.data, 4096, 0, 16),           # unknown flag
                  (0, dst.ctypes.data, 4096, 0, 0)):
         with pytest.raises(SymaccelError) as e:
             emu_ctx._call(d.symaccel_probe_copy_device, *args)

@@ -12,6 +12,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 CASES = [
     ({"SYMACCEL_TUNE_AAC_VARIANT": "1"}, "tests/test_emu_core_aac.py", "aac_all_sequences or imdct_bit_exact"),
+    ({"SYMACCEL_TUNE_AAC_QUAD": "1"}, "tests/test_emu_core_aac.py", "aac"),
     ({"SYMACCEL_TUNE_MP3_VARIANT": "2"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_VARIANT": "3"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
