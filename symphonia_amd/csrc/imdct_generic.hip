@@ -12,6 +12,11 @@ namespace symaccel {
 namespace {
 
 constexpr int kThreads = 256;
+// SYM_MULTI_WAVE (build knob): 1 = transforms of 16 .. 512 points run on the register-pass kernels (fft_wave_multi), 0 = on the LDS-staged
+// generic kernels as before (kept for the A/B and for every larger size).
+#ifndef SYM_MULTI_WAVE
+#define SYM_MULTI_WAVE 1
+#endif
 constexpr int kMaxPoints = 4096;
 
 __device__ __forceinline__ int tile_points(int nf) { return nf >= 2048 ? nf : 2048; }
@@ -177,8 +182,9 @@ __global__ __launch_bounds__(kThreads) void imdct_big_post_kernel(const cpx *tw,
     }
 }
 
-// ---- wavefront-per-transform fast paths for the two sizes the AAC and Vorbis 256/2048 decoders use (imdct_wave.h):
-// n = 1024 (one 512-point FFT in three radix-8 register passes) and n = 128 (eight 64-point FFTs at once).
+// ---- wavefront-per-transform fast path for n = 1024 (one 512-point FFT in three radix-8 register passes, imdct_wave.h; every other
+// size up to 1024 lines runs the multi-transform kernel below -- n = 128 used to have a kernel of its own here, 3.7 TB/s against the
+// 4.9 TB/s of the general one, profiles/r03g_core_transforms_ab.txt).
 constexpr int kWaveWaves = 4;
 
 __global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct1024_wave_kernel(DevTables tb, const cpx *__restrict__ tw_g,
@@ -229,38 +235,125 @@ __global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct1024_wave_kernel(DevT
     }
 }
 
-__global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct128_wave_kernel(DevTables tb, const cpx *__restrict__ tw_g,
-                                                                            const float *__restrict__ spec,
-                                                                            float *__restrict__ out, size_t count,
-                                                                            unsigned groups_per_wave) {
+// ---- every size from 16 to 512 points on the register-pass FFT: 512 / P transforms per wavefront pass (fft_wave_multi, imdct_wave.h).
+// A group = 512 / P consecutive transforms = 1024 input floats (Imdct: lines; Fft: 512 complex points) and, for Imdct, 2048 output
+// floats, both contiguous in the batch: loads and stores are 16 B per lane, 1 KiB per instruction.
+// Sizes whose per-lane input pieces would be shorter than 128 B (P <= 64) go through an LDS staging copy of the group's input.
+__device__ __forceinline__ void multi_fetch(const float *src, size_t valid_floats, int lane, float4 (&v)[4]) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i4 = lane + 64 * q;
+        v[q] = (size_t)(4 * i4) < valid_floats ? ld_stream(s4 + i4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct_multi_wave_kernel(DevTables tb, const cpx *__restrict__ tw_g, int logp,
+                                                                               const float *__restrict__ spec, float *__restrict__ out,
+                                                                               size_t count, unsigned groups_per_wave) {
+    __shared__ __attribute__((aligned(16))) float tw_lds[1024];
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaveWaves][kWaveLds];
+    const int P = 1 << logp;
+    for (int i = (int)threadIdx.x; i < 2 * P; i += 64 * kWaveWaves) tw_lds[i] = reinterpret_cast<const float *>(tw_g)[i];
+    __syncthreads();
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     float *ldsf = wave_lds[wave];
+    c32 *lds = reinterpret_cast<c32 *>(ldsf);
+    const c32 *tw = reinterpret_cast<const c32 *>(tw_lds);
     LaneTables lt;
     load_lane_tables(tb, lane, lt);
-    const size_t g0 = ((size_t)blockIdx.x * kWaveWaves + (size_t)wave) * groups_per_wave;  // groups of 8 transforms
-    for (size_t g = g0; g < g0 + groups_per_wave && g * 8 < count; ++g) {
-        const size_t t0 = g * 8;
-        const int nt = (int)(count - t0 < 8 ? count - t0 : 8);
-        const float2 *src = reinterpret_cast<const float2 *>(spec + t0 * 128);
+    const size_t per_group = (size_t)512 >> logp;  // transforms per group
+    const size_t n_groups = (count + per_group - 1) / per_group;
+    const size_t g0 = ((size_t)blockIdx.x * kWaveWaves + (size_t)wave) * groups_per_wave;
+    if (g0 >= n_groups) return;
+    const size_t g1 = g0 + groups_per_wave < n_groups ? g0 + groups_per_wave : n_groups;
+    float4 v[4];
+    multi_fetch(spec + g0 * 1024, (count - g0 * per_group) * (size_t)(2 * P), lane, v);
+    for (size_t g = g0; g < g1; ++g) {
+        // the group's 1024 lines -> LDS (natural order), from there each lane's pairs and their mirrored odd lines
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (s < nt) {
-                const float2 v = src[lane + 64 * s];
-                ldsf[short_row(s) + 2 * lane] = v.x;
-                ldsf[short_row(s) + 2 * lane + 1] = v.y;
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4 *>(ldsf)[lane + 64 * q] = v[q];
+        wave_sync();
+        if (g + 1 < g1) multi_fetch(spec + (g + 1) * 1024, (count - (g + 1) * per_group) * (size_t)(2 * P), lane, v);
+        c32 z[8];
+        {
+            const int gbits = logp - 3, G = 1 << gbits;
+            const int T = lane >> gbits, u = lane & (G - 1);
+            const float *sT = ldsf + ((size_t)T << (logp + 1));
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int i = u + (s << gbits);
+                const float2 pr = *reinterpret_cast<const float2 *>(sT + 2 * i);
+                z[s] = pre_twiddle(pr.x, sT[2 * P - 1 - 2 * i], tw[i]);
             }
         }
         wave_sync();
-        imdct_short_wave(lane, ldsf, tw_g, lt);  // H[w] = ldsf[short_row(w) ..]; ends with a wave_sync
-        const int w = lane >> 3, c = lane & 7;
-        if (w < nt) {
-            float4 *o4 = reinterpret_cast<float4 *>(out + (t0 + (size_t)w) * 256);
+        fft_wave_multi(z, lane, lds, lt, logp);
+        multi_post_twiddle(z, lane, logp, tw, ldsf);
+        wave_sync();
+        {
+            float4 *o4 = reinterpret_cast<float4 *>(out + g * 2048);
+            const size_t valid = (count - g * per_group) * (size_t)(4 * P);  // output floats of this group that exist
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v[4];
-                ys4(ldsf, w, 4 * (c + 8 * e), v);
-                o4[c + 8 * e] = make_float4(v[0], v[1], v[2], v[3]);
+            for (int q = 0; q < 8; ++q) {
+                const int i4 = lane + 64 * q;
+                if ((size_t)(4 * i4) < valid) st_stream(o4 + i4, reinterpret_cast<const float4 *>(ldsf)[i4]);
+            }
+        }
+        wave_sync();
+    }
+}
+
+// Fft::fft / Ifft::ifft (no_simd.rs:96-219) for 16 .. 512 points: a group = 512 points = 512 / n transforms.
+__global__ __launch_bounds__(64 * kWaveWaves, 2) void fft_multi_wave_kernel(DevTables tb, int logp, const float *__restrict__ in,
+                                                                             float *__restrict__ out, size_t count, unsigned groups_per_wave,
+                                                                             int inverse, float c) {
+    __shared__ __attribute__((aligned(16))) float wave_lds[kWaveWaves][kWaveLds];
+    const int P = 1 << logp;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    float *ldsf = wave_lds[wave];
+    c32 *lds = reinterpret_cast<c32 *>(ldsf);
+    LaneTables lt;
+    load_lane_tables(tb, lane, lt);
+    const size_t per_group = (size_t)512 >> logp;
+    const size_t n_groups = (count + per_group - 1) / per_group;
+    const size_t g0 = ((size_t)blockIdx.x * kWaveWaves + (size_t)wave) * groups_per_wave;
+    if (g0 >= n_groups) return;
+    const size_t g1 = g0 + groups_per_wave < n_groups ? g0 + groups_per_wave : n_groups;
+    float4 v[4];
+    multi_fetch(in + g0 * 1024, (count - g0 * per_group) * (size_t)(2 * P), lane, v);
+    for (size_t g = g0; g < g1; ++g) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4 *>(ldsf)[lane + 64 * q] = v[q];
+        wave_sync();
+        if (g + 1 < g1) multi_fetch(in + (g + 1) * 1024, (count - (g + 1) * per_group) * (size_t)(2 * P), lane, v);
+        c32 z[8];
+        {
+            const int gbits = logp - 3, G = 1 << gbits;
+            const int T = lane >> gbits, u = lane & (G - 1);
+            const c32 *xT = lds + ((size_t)T << logp);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const c32 x = xT[u + (s << gbits)];
+                z[s] = inverse ? c32{x.y, x.x} : x;  // Ifft: re <-> im on the way in (no_simd.rs:160-166)
+            }
+        }
+        wave_sync();
+        fft_wave_multi(z, lane, lds, lt, logp);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = logp <= 6 ? 64 * (lane >> 3) + 8 * q + (lane & 7) : 64 * q + lane;
+            // c = 1.0 / n as f32 (no_simd.rs:181, 212), formed on the host
+            lds[p] = inverse ? c32{c * z[q].y, c * z[q].x} : z[q];
+        }
+        wave_sync();
+        {
+            float4 *o4 = reinterpret_cast<float4 *>(out + g * 1024);
+            const size_t valid = (count - g * per_group) * (size_t)(2 * P);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i4 = lane + 64 * q;
+                if ((size_t)(4 * i4) < valid) st_stream(o4 + i4, reinterpret_cast<const float4 *>(ldsf)[i4]);
             }
         }
         wave_sync();
@@ -303,6 +396,20 @@ int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t
     if (n > kMaxPoints)  // (reads everything of d_in before the last stage writes d_out: d_in == d_out is fine)
         return inverse ? run_big_fft<kBigIfft>(ctx, n, d_in, nullptr, reinterpret_cast<c32 *>(d_out), count, nullptr)
                        : run_big_fft<kBigFft>(ctx, n, d_in, nullptr, reinterpret_cast<c32 *>(d_out), count, nullptr);
+    // (an Ifft of fewer than 32 points runs no butterflies in the reference, no_simd.rs:221-281: left to the generic kernel)
+    if (n >= 16 && n <= 512 && !(inverse && n < 32) && (SYM_MULTI_WAVE & 3)) {
+        const int logp = ilog2(n);
+        const size_t groups = (count + (size_t)(512 >> logp) - 1) / (size_t)(512 >> logp);
+        size_t per_wave = groups / ((size_t)ctx->n_cus * 8 * 4);
+        per_wave = per_wave < 1 ? 1 : (per_wave > 32 ? 32 : per_wave);
+        const size_t waves = (groups + per_wave - 1) / per_wave;
+        const size_t grid = (waves + kWaveWaves - 1) / kWaveWaves;
+        if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+        hipLaunchKernelGGL(fft_multi_wave_kernel, dim3((unsigned)grid), dim3(64 * kWaveWaves), 0, ctx->stream, ctx->dev, logp, d_in, d_out,
+                           count, (unsigned)per_wave, inverse ? 1 : 0, 1.0f / (float)n);
+        SYM_GPU(ctx, hipGetLastError());
+        return SYMACCEL_OK;
+    }
     const int points = n >= 2048 ? n : 2048;
     const size_t per_wg = (size_t)(points / n);
     const size_t grid = (count + per_wg - 1) / per_wg;
@@ -314,24 +421,32 @@ int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t
 }
 
 int launch_imdct(symaccel_ctx *ctx, const ImdctPlan &plan, const float *d_spec, float *d_out, size_t count) {
-    if (plan.n == 1024 || plan.n == 128) {
+    if (plan.n == 1024 && !(SYM_MULTI_WAVE & 2)) {
         // enough wavefronts to fill the chip several times over, several transforms per wavefront
-        const size_t units = plan.n == 1024 ? count : (count + 7) / 8;
-        size_t per_wave = units / ((size_t)ctx->n_cus * 8 * 4);
+        size_t per_wave = count / ((size_t)ctx->n_cus * 8 * 4);
         per_wave = per_wave < 1 ? 1 : (per_wave > 32 ? 32 : per_wave);
-        const size_t waves = (units + per_wave - 1) / per_wave;
+        const size_t waves = (count + per_wave - 1) / per_wave;
         const size_t grid = (waves + kWaveWaves - 1) / kWaveWaves;
         if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-        if (plan.n == 1024)
-            hipLaunchKernelGGL(imdct1024_wave_kernel, dim3((unsigned)grid), dim3(64 * kWaveWaves), 0, ctx->stream, ctx->dev,
-                               (const cpx *)plan.d_twiddle, d_spec, d_out, count, (unsigned)per_wave);
-        else
-            hipLaunchKernelGGL(imdct128_wave_kernel, dim3((unsigned)grid), dim3(64 * kWaveWaves), 0, ctx->stream, ctx->dev,
-                               (const cpx *)plan.d_twiddle, d_spec, d_out, count, (unsigned)per_wave);
+        hipLaunchKernelGGL(imdct1024_wave_kernel, dim3((unsigned)grid), dim3(64 * kWaveWaves), 0, ctx->stream, ctx->dev,
+                           (const cpx *)plan.d_twiddle, d_spec, d_out, count, (unsigned)per_wave);
         SYM_GPU(ctx, hipGetLastError());
         return SYMACCEL_OK;
     }
     const int nf = plan.n / 2;
+    if (nf >= 16 && nf <= 512 && (SYM_MULTI_WAVE & 3)) {
+        const int logp = ilog2(nf);
+        const size_t groups = (count + (size_t)(512 >> logp) - 1) / (size_t)(512 >> logp);
+        size_t per_wave = groups / ((size_t)ctx->n_cus * 8 * 4);
+        per_wave = per_wave < 1 ? 1 : (per_wave > 32 ? 32 : per_wave);
+        const size_t waves = (groups + per_wave - 1) / per_wave;
+        const size_t grid = (waves + kWaveWaves - 1) / kWaveWaves;
+        if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+        hipLaunchKernelGGL(imdct_multi_wave_kernel, dim3((unsigned)grid), dim3(64 * kWaveWaves), 0, ctx->stream, ctx->dev,
+                           (const cpx *)plan.d_twiddle, logp, d_spec, d_out, count, (unsigned)per_wave);
+        SYM_GPU(ctx, hipGetLastError());
+        return SYMACCEL_OK;
+    }
     if (nf > kMaxPoints) {
         c32 *work = nullptr;
         SYM_TRY((run_big_fft<kBigImdct>(ctx, nf, d_spec, (const cpx *)plan.d_twiddle, nullptr, count, &work)));

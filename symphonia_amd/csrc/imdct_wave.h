@@ -219,6 +219,134 @@ __device__ __forceinline__ void fft512_wave(c32 (&z)[8], int lane, c32 *lds, con
     wave_sync();
 }
 
+// ---- any power-of-two size from 16 to 512 points: 512 / P transforms in ONE pass of the same three register passes --------------
+// A 512-point pass over the work array IS 512 / P independent P-point transforms laid side by side (transform T at positions
+// T P .. T P + P - 1) as long as the radix-2 stages stop after log2 P of them: stages 1-3 and 4-6 work inside 64-position blocks,
+// stages 7, 8, 9 pair positions 64, 128, 256 apart.  What changes with P is only (a) which inputs a lane brings: the DIT input order
+// is the bit reversal over log2 P bits INSIDE a transform, so lane l = (T, u), u < P / 8, owns x_T[u + (P / 8) s], s = 0..7, and its
+// fft8 lands at positions 8 g .. 8 g + 7 with g = T P / 8 + rev(u); and (b) where the passes stop.  Every butterfly is the one
+// the reference's fft16 / fft32 / transform() does for that size (no_simd.rs:221-454): same operands, same twiddle values.
+// In:  z[s] = x_T[u + (P / 8) s] for lane (T, u).
+// Out: logp <= 6: z[j] = X at position 64 (lane >> 3) + 8 j + (lane & 7);   logp >= 7: z[B] = X at position 64 B + lane.
+//      Position p belongs to transform p >> logp, bin p & (P - 1).  The work array is free again on return (after a wave_sync).
+template <class LT>
+__device__ __forceinline__ void fft_wave_multi(c32 (&z)[8], int lane, c32 *lds, const LT &lt, int logp) {
+    bitrev8(z);
+    fft8_regs(z);
+    {
+        const int gbits = logp - 3;  // 1 .. 6
+        const int T = lane >> gbits, u = lane & ((1 << gbits) - 1);
+        const int g = (T << gbits) + (int)rev_bits((unsigned)u, gbits);
+        c32 *w = lds + lds_t1_lane_w(g >> 3, g & 7);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[lds_t1_inst_w(r)] = z[r];
+    }
+    wave_sync();
+    const int B2 = lane >> 3, k2 = lane & 7;
+    {
+        const c32 *r = lds + lds_t1_lane_r(B2, k2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = r[lds_t1_inst_r(j)];
+    }
+    {   // stages 4-6, as many as the size has (wave-uniform branches)
+        const c32 w16 = lt.W16();
+        const int f16 = lt.F16();
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) bfly(z[j], z[j + 1], tw_small(z[j + 1], w16, f16));  // fft16 combine
+    }
+    if (logp >= 5) {
+        const c32 wa = lt.W32(0), wb = lt.W32(1);
+        const int fa = lt.F32(0), fb = lt.F32(1);
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {  // fft32 combine
+            bfly(z[h + 0], z[h + 2], tw_small(z[h + 2], wa, fa));
+            bfly(z[h + 1], z[h + 3], tw_small(z[h + 3], wb, fb));
+        }
+    }
+    if (logp >= 6) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfly(z[j], z[j + 4], c_mul(z[j + 4], lt.W64(j)));  // merge, step 32
+    }
+    wave_sync();
+    if (logp <= 6) return;
+    {
+        c32 *w = lds + lds_t2_lane_w(B2, k2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[lds_t2_inst_w(j)] = z[j];
+    }
+    wave_sync();
+    {
+        const c32 *r = lds + lds_t2_lane_r(lane >> 3, lane & 7);
+#pragma unroll
+        for (int B = 0; B < 8; ++B) z[B] = r[lds_t2_inst_r(B)];
+    }
+    {
+        const c32 w128 = lt.W128();
+#pragma unroll
+        for (int B = 0; B < 8; B += 2) bfly(z[B], z[B + 1], c_mul(z[B + 1], w128));  // step 64
+    }
+    if (logp >= 8) {
+        const c32 wa = lt.W256(0), wb = lt.W256(1);
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {  // step 128
+            bfly(z[h + 0], z[h + 2], c_mul(z[h + 2], wa));
+            bfly(z[h + 1], z[h + 3], c_mul(z[h + 3], wb));
+        }
+    }
+    if (logp >= 9) {
+#pragma unroll
+        for (int B = 0; B < 4; ++B) bfly(z[B], z[B + 4], c_mul(z[B + 4], lt.W512(B)));  // step 256
+    }
+    wave_sync();
+}
+
+// The lines of 512 / P consecutive Imdct inputs of N = 2 P lines each (P = 1 << logp), pre-twiddled (mdct.rs:81-88) into the
+// lane order fft_wave_multi takes: lane (T, u) loads the pairs (spec_T[2 i], spec_T[2 i + 1]), i = u + (P / 8) s, 8 B each; the
+// mirrored odd line spec_T[N - 1 - 2 i] is the second half of pair P - 1 - i, which lane (T, P / 8 - 1 - u) holds in load 7 - s.
+// `line` = those loads (issued by the caller, possibly one group ahead); `tw` = the size's Imdct twiddles (P complex, LDS).
+__device__ __forceinline__ int multi_line_index(int lane, int logp, int s) {  // pair index inside the group's 1024-float input
+    const int gbits = logp - 3;
+    const int T = lane >> gbits, u = lane & ((1 << gbits) - 1);
+    return (T << logp) + u + (s << gbits);
+}
+__device__ __forceinline__ void multi_pre_twiddle(const float2 (&line)[8], c32 (&z)[8], int lane, int logp, const c32 *tw) {
+    const int gbits = logp - 3, G = 1 << gbits;
+    const int u = lane & (G - 1);
+    const int mirror = ((lane & ~(G - 1)) + (G - 1 - u)) * 4;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
+        z[s] = pre_twiddle(line[s].x, mirrored, tw[u + (s << gbits)]);
+    }
+}
+// Post-twiddle (mdct.rs:94-137) of what fft_wave_multi left in the registers, scattered into `pcm`: transform T's 4 P output
+// samples at pcm[4 P T ..] in natural order (vec0 | vec1 | vec2 | vec3 of P samples each).
+__device__ __forceinline__ void multi_post_twiddle(const c32 (&z)[8], int lane, int logp, const c32 *tw, float *pcm) {
+    const int P = 1 << logp, n4 = P >> 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int p = logp <= 6 ? 64 * (lane >> 3) + 8 * q + (lane & 7) : 64 * q + lane;
+        const int T = p >> logp, k = p & (P - 1);
+        const c32 val = post_twiddle(z[q], tw[k]);
+        float *vec0 = pcm + ((size_t)T << (logp + 2)), *vec1 = vec0 + P, *vec2 = vec1 + P, *vec3 = vec2 + P;
+        if (k < n4) {
+            const int fi = 2 * k, ri = P - 1 - 2 * k;
+            vec0[ri] = -val.y;
+            vec1[fi] = val.y;
+            vec2[ri] = val.x;
+            vec3[fi] = val.x;
+        } else {
+            const int i = k - n4;
+            const int fi = 2 * i, ri = P - 1 - 2 * i;
+            vec0[fi] = -val.x;
+            vec1[ri] = val.x;
+            vec2[fi] = val.y;
+            vec3[ri] = val.y;
+        }
+    }
+}
+static_assert(2048 <= kWaveLds, "the Imdct output of a 512-point pass (2048 samples) must fit the per-wave LDS");
+
 // Post-twiddle (mdct.rs:94-137) of the four FFT bins that feed output slot m2 = lane + 64h:
 //   x[q]  = pcm[j(q)]         (first half of the 2048-sample IMDCT output)
 //   x2[q] = pcm[1024 + j(q)]  with j(q) = 4*m2 + q for q < 4, 1020 - 4*m2 + (q - 4) for q >= 4.

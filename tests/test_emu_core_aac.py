@@ -10,7 +10,7 @@ from helpers import aac_sequence_chain, aac_spectra, bit_equal
 from symphonia_amd import AacDsp, Fft, Imdct, aac_side
 
 
-@pytest.mark.parametrize("n", [4, 8, 16, 32, 64, 128, 256, 1024, 2048, 4096])
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096])
 def test_emu_imdct_bit_exact(emu_ctx, n):
     rng = np.random.default_rng(n)
     count = 5 if n <= 1024 else 2
@@ -20,7 +20,7 @@ def test_emu_imdct_bit_exact(emu_ctx, n):
         assert bit_equal(got, oracle.imdct(spec, scale)), (n, scale)
 
 
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 512, 2048, 4096])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 2048, 4096])
 def test_emu_fft_bit_exact(emu_ctx, n):
     rng = np.random.default_rng(100 + n)
     count = 3
@@ -32,6 +32,26 @@ def test_emu_fft_bit_exact(emu_ctx, n):
     z = x.copy()
     Fft(emu_ctx, n).fft_inplace(z)
     assert bit_equal(z, want)
+
+
+@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512])
+def test_emu_register_pass_kernels_over_several_groups(emu_ctx, n):
+    """Transforms of 16 .. 512 points run 512 / n at a time per wavefront pass (fft_wave_multi): whole groups, a ragged last
+    group, several groups per wavefront, Fft / Ifft in and out of place, Imdct of 2 n lines."""
+    from symphonia_amd import Ifft
+    rng = np.random.default_rng(300 + n)
+    per_group = 512 // n
+    for count in (1, per_group, per_group + 1, 5 * per_group + max(1, per_group // 2)):
+        x = (rng.standard_normal((count, n)) * np.exp2(rng.integers(-6, 7, (count, n))) + 1j * rng.standard_normal((count, n))).astype(np.complex64)
+        y = np.empty_like(x)
+        Fft(emu_ctx, n).fft(x, y)
+        assert bit_equal(y, np.stack([oracle.fft(v) for v in x])), (n, count)
+        z = x.copy()
+        Ifft(emu_ctx, n).ifft_inplace(z)
+        assert bit_equal(z, np.stack([oracle.ifft(v) for v in x])), (n, count)
+        spec = (rng.standard_normal((count, 2 * n)) * np.exp2(rng.integers(-6, 8, (count, 2 * n)))).astype(np.float32)
+        if 2 * n not in (128, 1024):  # (those two sizes have kernels of their own)
+            assert bit_equal(Imdct(emu_ctx, 2 * n, 1.0 / n).imdct(spec), oracle.imdct(spec, 1.0 / n)), (n, count)
 
 
 @pytest.mark.parametrize("n", [8192, 32768])
