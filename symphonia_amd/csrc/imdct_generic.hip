@@ -239,15 +239,6 @@ __global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct1024_wave_kernel(DevT
 // A group = 512 / P consecutive transforms = 1024 input floats (Imdct: lines; Fft: 512 complex points) and, for Imdct, 2048 output
 // floats, both contiguous in the batch: loads and stores are 16 B per lane, 1 KiB per instruction.
 // Sizes whose per-lane input pieces would be shorter than 128 B (P <= 64) go through an LDS staging copy of the group's input.
-__device__ __forceinline__ void multi_fetch(const float *src, size_t valid_floats, int lane, float4 (&v)[4]) {
-    const float4 *s4 = reinterpret_cast<const float4 *>(src);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i4 = lane + 64 * q;
-        v[q] = (size_t)(4 * i4) < valid_floats ? ld_stream(s4 + i4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-}
-
 __global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct_multi_wave_kernel(DevTables tb, const cpx *__restrict__ tw_g, int logp,
                                                                                const float *__restrict__ spec, float *__restrict__ out,
                                                                                size_t count, unsigned groups_per_wave) {

@@ -319,6 +319,16 @@ __device__ __forceinline__ void multi_pre_twiddle(const float2 (&line)[8], c32 (
         z[s] = pre_twiddle(line[s].x, mirrored, tw[u + (s << gbits)]);
     }
 }
+// a group's input: 1024 floats, 16 B per lane and load (floats past `valid_floats` read as zero)
+__device__ __forceinline__ void multi_fetch(const float *src, size_t valid_floats, int lane, float4 (&v)[4]) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i4 = lane + 64 * q;
+        v[q] = (size_t)(4 * i4) < valid_floats ? ld_stream(s4 + i4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
 // Post-twiddle (mdct.rs:94-137) of what fft_wave_multi left in the registers, scattered into `pcm`: transform T's 4 P output
 // samples at pcm[4 P T ..] in natural order (vec0 | vec1 | vec2 | vec3 of P samples each).
 __device__ __forceinline__ void multi_post_twiddle(const c32 (&z)[8], int lane, int logp, const c32 *tw, float *pcm) {

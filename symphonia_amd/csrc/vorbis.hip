@@ -599,6 +599,12 @@ int ilog2(int v) {
 
 }  // namespace
 
+// SYM_VORBIS_WAVE2 (build knob): 1 = block-size pairs other than 256 / 2048 with bs1 <= 2048 run vorbis_synth_wave2_kernel, 0 = the
+// LDS-staged generic kernel as before (kept for the A/B and for 4096 / 8192-sample blocks).
+#ifndef SYM_VORBIS_WAVE2
+#define SYM_VORBIS_WAVE2 1
+#endif
+
 int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
                   size_t spec_stride,
                   const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out,
@@ -615,7 +621,12 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     const bool wave_path = bs0_exp == 8 && bs1_exp == 11;
     // resident items per CU: eight wavefronts of the wavefront kernel; of the generic one, eight one-wavefront workgroups
     // (226 VGPRs: two per SIMD) or two 256-thread workgroups (66 KiB of LDS each)
-    const unsigned seg = choose_segment(ctx, n_chains, nb, wave_path ? 8 : (bs1_exp > 11 ? 2 : 8), 1, 1, 1);
+    // every other pair with long blocks of up to 2048 samples: the multi-transform wavefront kernel (vorbis_wave2.hip; 16-byte
+    // accesses: the strides must keep every chain 16-byte aligned), unless the build knob keeps the LDS-staged generic kernel
+    const bool wave2_path = !wave_path && bs1_exp <= 11 && spec_stride % 4 == 0 && pcm_stride % 4 == 0 &&
+                            ((uintptr_t)d_spectra | (uintptr_t)d_residue | (uintptr_t)d_pcm | (uintptr_t)d_overlap_in | (uintptr_t)d_overlap_out) % 16 == 0 &&
+                            SYM_VORBIS_WAVE2;
+    const unsigned seg = choose_segment(ctx, n_chains, nb, wave2_path && bs1_exp <= 10 ? 12 : ((wave_path || wave2_path) ? 8 : (bs1_exp > 11 ? 2 : 8)), 1, 1, 1);
     const size_t segs = (nb + seg - 1) / seg;
     const size_t grid = n_chains * segs;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
@@ -632,6 +643,10 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     hipLaunchKernelGGL(vorbis_offsets_kernel, dim3((unsigned)n_chains), dim3(256), 0, ctx->stream, d_block_flag,
                        d_prev_in, offs, nb, 1 << bs0_exp, 1 << bs1_exp);
     SYM_GPU(ctx, hipGetLastError());
+    if (wave2_path)
+        return launch_vorbis_wave2(ctx, bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra, d_residue,
+                                   spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride,
+                                   (const uint32_t *)offs, n_chains, nb, seg);
     if (bs1_exp <= 11) {
         hipLaunchKernelGGL(vorbis_synth_kernel<2048>, dim3((unsigned)grid), dim3(vorbis_threads<2048>()), 0, ctx->stream, ctx->dev,
                            bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,

@@ -116,6 +116,33 @@ def test_emu_vorbis_synth(emu_ctx, bs0e, bs1e, seg):
     assert np.array_equal(got[2], want[2]), "prev flag"
 
 
+@pytest.mark.parametrize("bs0e,bs1e,nb,p_long,seg", [(7, 10, 150, 0.6, 1000), (6, 9, 140, 0.3, 37), (8, 10, 70, 0.75, 5), (6, 7, 200, 0.5, 64),
+                                                      (9, 11, 40, 0.5, 7), (10, 11, 33, 0.2, 1), (11, 11, 20, 0.5, 3), (6, 11, 90, 0.1, 13),
+                                                      (7, 7, 77, 0.5, 10), (9, 9, 30, 1.0, 4), (6, 10, 100, 0.0, 33)])
+def test_emu_vorbis_register_pass_kernel_pairs(emu_ctx, bs0e, bs1e, nb, p_long, seg):
+    """vorbis_synth_wave2_kernel (every pair with long blocks of up to 2048 samples except 256 / 2048): runs longer than a group
+    holds (2048 / bs blocks), runs across the 64-block flag masks, every transition, segment halos, equal sizes, chains of one
+    flag only, the stale-state fix-up after a short tail, arbitrary incoming overlap."""
+    rng = np.random.default_rng(1000 * bs0e + 10 * bs1e + nb)
+    nch = 3
+    flags = (rng.random((nch, nb)) < p_long).astype(np.uint8)
+    flags[0, : min(nb, 45)] = 0                  # a run longer than thirty-two short blocks
+    flags[1, nb // 2: nb // 2 + 40] = 1          # ... and a long run of long blocks
+    flags[2, nb - min(nb, 50):] = 0              # a short tail longer than most segments (state fix-up)
+    prev = rng.integers(-1, 2, nch).astype(np.int32)
+    lay = oracle.vorbis_layout(bs0e, bs1e, flags, prev)
+    spectra = (rng.standard_normal((nch, int(lay[0][:, -1].max()))) * np.exp2(rng.integers(-4, 4, (nch, 1)))).astype(np.float32)
+    overlap = rng.standard_normal((nch, (1 << bs1e) // 2)).astype(np.float32)
+    pcm_stride = int(lay[1][:, -1].max())
+    emu_ctx.set_segment(seg)
+    got = VorbisDsp(emu_ctx, bs0e, bs1e).synth(spectra, flags, prev, overlap, pcm_stride)
+    emu_ctx.set_segment(0)
+    want = oracle.vorbis_synth(bs0e, bs1e, spectra, flags, prev, overlap, pcm_stride)
+    assert bit_equal(got[0], want[0]), "pcm"
+    assert bit_equal(got[1], want[1]), "overlap"
+    assert np.array_equal(got[2], want[2]), "prev flag"
+
+
 def vorbis_wave_case(seed, nch, nb, p_long, tail_short=0):
     """256/2048 case with controllable run structure; `tail_short` forces the last blocks short (state fix-up path)."""
     rng = np.random.default_rng(seed)
