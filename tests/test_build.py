@@ -77,7 +77,7 @@ def test_aac_three_wave_variant_fits_its_register_budget():
     """SYMACCEL_TUNE_AAC_VARIANT=1 (six wavefronts per workgroup, lane twiddles in LDS, peeled halo) is sized for three
     wavefronts per SIMD: <= 168 VGPRs, no scratch, two 71.6 KiB workgroups per CU -- and contains no fused multiply-add."""
     text = device_asm("aac.hip", ["-DSYM_AAC_VARIANT=1"])
-    (r,) = kernel_resources(text).values()
+    (r,) = [v for k, v in kernel_resources(text).items() if "quad" not in k]  # (aac.hip also holds the workgroup walk, SYM_AAC_QUAD)
     assert r["ScratchSize"] == 0 and r["NumVgprs"] <= 168 and r["Occupancy"] == 3, r
     assert 2 * r["LDSByteSize"] <= 160 * 1024
     assert not F32_FUSED.search(text)
