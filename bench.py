@@ -360,6 +360,80 @@ def copy_ceiling(ctx, torch, seg_len, reps=10):
     return out
 
 
+def exchange_c_api(ctx, torch, dist, world, rank, local_in, local_out, step, units, unit_name, sync, reps=3):
+    """The scatter -> synthesis -> gather leg again, through the C ABI a Rust / C++ host would use (csrc/multi.cpp):
+    symaccel_comm_unique_id on rank 0, the id handed round with torch.distributed, symaccel_comm_init on every rank (its own
+    RCCL communicator, nothing borrowed from torch), then symaccel_scatter_streams / symaccel_gather_streams with every rank's
+    shard as one "stream".  Returns the same keys as the torch leg."""
+    import ctypes as C
+    d = ctx.lib.dll
+    uid = (C.c_char * 128)()
+    if rank == 0:
+        assert d.symaccel_comm_unique_id(C.addressof(uid)) == 0  # (no context argument)
+    box = [uid.raw]
+    dist.broadcast_object_list(box, src=0)
+    uid = C.create_string_buffer(box[0], 128)
+    comm = C.c_void_p()
+    ctx._call(d.symaccel_comm_init, C.addressof(uid), world, rank, C.byref(comm))
+    try:
+        in_bytes, out_bytes = local_in.numel() * local_in.element_size(), local_out.numel() * local_out.element_size()
+        all_in = torch.empty((world,) + tuple(local_in.shape), dtype=local_in.dtype, device=local_in.device) if rank == 0 else None
+        all_out = torch.empty((world,) + tuple(local_out.shape), dtype=local_out.dtype, device=local_out.device) if rank == 0 else None
+        if rank == 0:
+            all_in[:] = local_in
+        p_in, p_out = (all_in.data_ptr(), all_out.data_ptr()) if rank == 0 else (None, None)
+
+        def once():
+            ts = [time.perf_counter()]
+            ctx._call(d.symaccel_scatter_streams, comm, world, rank, 0, p_in, local_in.data_ptr(), world, in_bytes)
+            sync()
+            ts.append(time.perf_counter())
+            step()
+            sync()
+            ts.append(time.perf_counter())
+            ctx._call(d.symaccel_gather_streams, comm, world, rank, 0, local_out.data_ptr(), p_out, world, out_bytes)
+            sync()
+            ts.append(time.perf_counter())
+            return ts
+
+        once()  # connection set-up
+        acc = [0.0, 0.0, 0.0, 0.0]
+        for _ in range(reps):
+            dist.barrier()
+            sync()
+            ts = once()
+            for i in range(3):
+                acc[i] += ts[i + 1] - ts[i]
+            acc[3] += ts[3] - ts[0]
+        from symphonia_amd.sharding import max_over_ranks
+        secs = {k: max_over_ranks(a / reps, dist, device="cuda") for k, a in zip(("scatter", "step", "gather", "total"), acc)}
+        same = bool(torch.equal(all_out[0], local_out)) if rank == 0 else None  # (the root's own slice came back through the local copy)
+        return {"op": "symaccel_scatter_streams + synthesis + symaccel_gather_streams on a communicator of its own (RCCL over xGMI, C ABI)",
+                "ms": {k: v * 1e3 for k, v in secs.items()}, "bytes_per_rank": {"in": in_bytes, "out": out_bytes},
+                "value_inclusive": units * world / secs["total"], "unit": unit_name + "/s", "root_slice_round_trip": same}
+    finally:
+        d.symaccel_comm_destroy(comm)
+
+
+def guarded(fn, seconds):
+    """Run an optional leg on a watchdog: (result, hung).  A leg that never returns (a collective that cannot complete) must not
+    cost the line: the caller reports the timeout and leaves with os._exit once the line is out."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["result"] = fn()
+        except Exception as e:  # noqa: BLE001
+            box["result"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": "timed out after %d s" % seconds}, True
+    return box["result"], False
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` with no launcher in the environment: start N ranks ourselves (one process per GPU) with
     torch.distributed.run on the loopback address and hand its exit status back.  (The driver may also start the ranks
@@ -576,6 +650,22 @@ def main():
             torch.cuda.empty_cache()
             log("other workload %s done" % w)
 
+    # N > 1, real GPUs: (a) the deployment shape DESIGN.md section 7 argues for -- every rank stages ITS shard from its own
+    # page-locked host memory (per-GPU producers: no rank-0 bottleneck) --, (b) the exchange leg once more through the C ABI.
+    # Both last, (b) on a watchdog: nothing here can cost what was measured above.
+    producers, exchange_c, hung = None, None, False
+    if world > 1 and not emulate and not one_gpu_smoke and args.workload == "aac" and not args.no_host_path:
+        try:
+            h2h = host_to_host_aac(sa, ctx, torch, result, step.input, units)
+            worst = max_over_ranks(h2h["ms"] / 1e3, dist, device=red_dev)
+            producers = {"op": "every rank: its shard from page-locked host memory through symaccel_aac_synth_pipelined and back (no inter-GPU traffic)",
+                         "ms": worst * 1e3, "value": units * world / worst, "unit": unit_name + "/s", "GBps_each_way_per_rank": h2h["GBps_each_way"]}
+        except Exception as e:  # noqa: BLE001
+            producers = {"error": "%s: %s" % (type(e).__name__, e)}
+    if world > 1 and not host_collectives and not args.no_exchange and args.workload in ("aac", "mp3", "vorbis"):
+        exchange_c, hung = guarded(lambda: exchange_c_api(ctx, torch, dist, world, rank, workload_input(args.workload, step), result, step, units,
+                                                          unit_name, sync), 150)
+
     if rank == 0:
         achieved = alg_bytes / launch_s / 1e9
         out = {
@@ -634,11 +724,17 @@ def main():
             out["exchange"] = exchange
         if config4:
             out["config4_vorbis"] = config4
+        if producers:
+            out["per_gpu_producers"] = producers
+        if exchange_c:
+            out["exchange_c_api"] = exchange_c
         if world == 1 and args.workload == "aac" and not args.no_host_path and not emulate:
             out["host_to_host"] = host_to_host_aac(sa, ctx, torch, result, step.input, units)
         if world == 1 and not args.no_cpu_baseline and not emulate:
             out["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if hung:
+        os._exit(0)  # a leg is still stuck in a collective: the line is out, do not wait for it
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SYMACCEL_ABI_VERSION 2 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging */
+#define SYMACCEL_ABI_VERSION 3 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe */
 
 typedef enum symaccel_status {
     SYMACCEL_OK = 0,
@@ -475,6 +475,47 @@ int symaccel_alac_mid_side_device(symaccel_ctx *ctx, const int32_t *d_weight, co
                                   int32_t *d_ch0, int32_t *d_ch1, size_t n_pairs, size_t blocksize);
 int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uint8_t *h_shift, int32_t *h_ch0,
                            int32_t *h_ch1, size_t n_pairs, size_t blocksize);
+
+/* ------------------------------------------------------------------------- multi-GPU */
+
+/* Chains are independent, so a batch shards across GPUs by whole streams with no data-path collective (the unit is
+ * the packet loop of symphonia-codec-vorbis/src/lib.rs:296-331, one stream's channels).  One process (or thread) per GPU, one
+ * context each.  symaccel_shard_range gives rank's contiguous, balanced slice [first, first + count) of n_streams streams (the
+ * first n_streams % world ranks take one more). */
+int symaccel_shard_range(size_t n_streams, int world, int rank, size_t *first, size_t *count);
+
+/* For a batch that starts and ends on ONE rank (BASELINE config 4's "batch split / gather"): the root sends every rank its slice
+ * of a stream-major device buffer d_all[n_streams][bytes_per_stream] (scatter), or receives the slices back (gather); every
+ * rank's own slice is d_mine[count][bytes_per_stream].  ncclSend / ncclRecv inside one group on `comm` (an ncclComm_t of RCCL,
+ * one per rank) and the context's stream: the root's world - 1 transfers run over its xGMI links side by side, its own slice is
+ * a device-to-device copy.  Asynchronous like every *_device call.  world == 1 needs no communicator.  One-to-all traffic is
+ * bounded by the root's links (7 x ~153 GB/s): a deployment that can keeps producers per GPU instead.
+ * librccl.so is loaded at first use (SYMACCEL_RCCL_LIB overrides the name); SYMACCEL_ERR_UNSUPPORTED if there is none. */
+int symaccel_scatter_streams(symaccel_ctx *ctx, void *comm, int world, int rank, int root, const void *d_all, void *d_mine,
+                             size_t n_streams, size_t bytes_per_stream);
+int symaccel_gather_streams(symaccel_ctx *ctx, void *comm, int world, int rank, int root, const void *d_mine, void *d_all,
+                            size_t n_streams, size_t bytes_per_stream);
+
+/* Communicator set-up without RCCL's headers: rank 0 makes an id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by
+ * whatever means the host has (a pipe, MPI, torch.distributed); every rank then creates its communicator on its context's device
+ * (ncclCommInitRank: collective, call it on all ranks) and destroys it at the end. */
+typedef struct symaccel_unique_id {
+    char internal[128];
+} symaccel_unique_id;
+int symaccel_comm_unique_id(symaccel_unique_id *id);
+int symaccel_comm_init(symaccel_ctx *ctx, const symaccel_unique_id *id, int world, int rank, void **comm);
+int symaccel_comm_destroy(void *comm);
+
+/* A caller-supplied point-to-point transport instead of RCCL (MPI, shared memory, a test double): send / recv move `bytes`
+ * bytes of DEVICE memory to / from rank `peer` on `stream` and return 0 on success; `comm` is passed through untouched;
+ * group_start / group_end may be null.  NULL restores RCCL.  Process-wide; set it before the first exchange. */
+typedef struct symaccel_transport {
+    int (*group_start)(void);
+    int (*group_end)(void);
+    int (*send)(const void *d_buf, size_t bytes, int peer, void *comm, void *stream);
+    int (*recv)(void *d_buf, size_t bytes, int peer, void *comm, void *stream);
+} symaccel_transport;
+int symaccel_multi_set_transport(const symaccel_transport *transport);
 
 /* ------------------------------------------------------------------ measurement probe */
 

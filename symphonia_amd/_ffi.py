@@ -43,6 +43,8 @@ ABI_SYMBOLS = [
     "symaccel_flac_block_status_device", "symaccel_alac_block_status_device", "symaccel_vorbis_floor1_status_device", "symaccel_aac_tns_status_device",
     "symaccel_aac_synth_pp_device", "symaccel_mp3_synth_pp_device", "symaccel_vorbis_synth_pp_device", "symaccel_mpa_polyphase_pp_device",
     "symaccel_probe_copy_device",
+    "symaccel_shard_range", "symaccel_scatter_streams", "symaccel_gather_streams", "symaccel_comm_unique_id", "symaccel_comm_init",
+    "symaccel_comm_destroy", "symaccel_multi_set_transport",
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
@@ -108,6 +110,13 @@ class Library:
         d.symaccel_alac_predict_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_predict_stereo_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_predict.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_shard_range.argtypes = [_sz, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]
+        d.symaccel_scatter_streams.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _sz]
+        d.symaccel_gather_streams.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _sz]
+        d.symaccel_comm_unique_id.argtypes = [_vp]
+        d.symaccel_comm_init.argtypes = [_vp, _vp, _i, _i, C.POINTER(_vp)]
+        d.symaccel_comm_destroy.argtypes = [_vp]
+        d.symaccel_multi_set_transport.argtypes = [_vp]
         d.symaccel_probe_copy_device.argtypes = [_vp, _vp, _vp, _sz, _u32, _u32]
         d.symaccel_alac_mid_side_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_mid_side.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]

@@ -1,0 +1,215 @@
+// Multi-GPU at the C level: what a Rust / C++ host needs to do BASELINE config 4's "batch split / gather" without Python --
+// shard arithmetic, and one-to-all scatter / all-to-one gather of chain-major shards over RCCL (xGMI) with ncclSend / ncclRecv
+// inside one group.  Chains (one channel of one stream) are independent: the split is by whole streams, the data
+// path of the synthesis itself never communicates; these two calls exist for callers whose batch starts and ends on one rank.
+//
+// RCCL is resolved at first use (dlopen of librccl.so: a process that never touches these entry points does not need the
+// library), or replaced by a caller-supplied transport (symaccel_multi_set_transport): MPI, shared memory, or the in-process
+// mailbox of tests/test_multi_c.py.
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "symaccel_internal.h"
+
+namespace symaccel {
+
+namespace {
+
+// the RCCL entry points used, with their C signatures (rccl.h: ncclResult_t == int, ncclDataType_t ncclInt8 == 0)
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *id) = nullptr;
+    int (*CommInitRank)(void **comm, int nranks, symaccel_unique_id id, int rank) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t stream) = nullptr;
+    int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t stream) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+symaccel_transport g_transport{};  // all null: RCCL
+bool g_have_transport = false;
+
+void load_rccl() {
+    const char *names[] = {std::getenv("SYMACCEL_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        void *h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        Rccl r;
+        r.handle = h;
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        if (r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv) {
+            g_rccl = r;
+            return;
+        }
+        dlclose(h);
+    }
+}
+
+const Rccl *rccl() {
+    std::call_once(g_rccl_once, load_rccl);
+    return g_rccl.handle ? &g_rccl : nullptr;
+}
+
+int rccl_fail(symaccel_ctx *ctx, int rc, const char *where) {
+    if (ctx) {
+        const Rccl *r = rccl();
+        ctx->last_error = std::string(where) + ": " + ((r && r->GetErrorString) ? r->GetErrorString(rc) : "RCCL error");
+    }
+    return SYMACCEL_ERR_DEVICE;
+}
+
+// one peer-to-peer transfer through the transport in force
+int xfer_send(symaccel_ctx *ctx, const void *buf, size_t bytes, int peer, void *comm) {
+    if (g_have_transport) return g_transport.send(buf, bytes, peer, comm, (void *)ctx->stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+    const int rc = rccl()->Send(buf, bytes, 0, peer, comm, ctx->stream);
+    return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclSend");
+}
+int xfer_recv(symaccel_ctx *ctx, void *buf, size_t bytes, int peer, void *comm) {
+    if (g_have_transport) return g_transport.recv(buf, bytes, peer, comm, (void *)ctx->stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+    const int rc = rccl()->Recv(buf, bytes, 0, peer, comm, ctx->stream);
+    return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclRecv");
+}
+int group_start(symaccel_ctx *ctx) {
+    if (g_have_transport) return g_transport.group_start ? (g_transport.group_start() == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE) : SYMACCEL_OK;
+    const int rc = rccl()->GroupStart();
+    return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclGroupStart");
+}
+int group_end(symaccel_ctx *ctx) {
+    if (g_have_transport) return g_transport.group_end ? (g_transport.group_end() == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE) : SYMACCEL_OK;
+    const int rc = rccl()->GroupEnd();
+    return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclGroupEnd");
+}
+
+bool have_backend() { return g_have_transport || rccl() != nullptr; }
+
+struct Slice {
+    size_t first, count;  // in streams
+};
+Slice slice_of(size_t n_streams, int world, int rank) {
+    const size_t base = n_streams / (size_t)world, extra = n_streams % (size_t)world;
+    const size_t r = (size_t)rank;
+    return Slice{r * base + (r < extra ? r : extra), base + (r < extra ? 1u : 0u)};
+}
+
+// scatter (to_root == false) or gather (to_root == true) of the ranks' stream slices; `d_all` is read / written on the root only
+int exchange(symaccel_ctx *ctx, void *comm, int world, int rank, int root, void *d_all, void *d_mine, size_t n_streams,
+             size_t bytes_per_stream, bool to_root) {
+    if (!ctx || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_streams == 0 || bytes_per_stream == 0) return SYMACCEL_OK;
+    const Slice mine = slice_of(n_streams, world, rank);
+    if ((mine.count && !d_mine) || (rank == root && !d_all)) return SYMACCEL_ERR_INVALID_ARG;
+    if (world > 1 && !comm) return SYMACCEL_ERR_INVALID_ARG;
+    if (world > 1 && !have_backend()) {
+        ctx->last_error = "librccl.so not found (set SYMACCEL_RCCL_LIB or install a transport)";
+        return SYMACCEL_ERR_UNSUPPORTED;
+    }
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    char *all = static_cast<char *>(d_all);
+    if (rank == root && mine.count) {
+        // the root's own slice never leaves the device
+        void *a = all + mine.first * bytes_per_stream;
+        if (to_root) SYM_GPU(ctx, hipMemcpyAsync(a, d_mine, mine.count * bytes_per_stream, hipMemcpyDeviceToDevice, ctx->stream));
+        else SYM_GPU(ctx, hipMemcpyAsync(d_mine, a, mine.count * bytes_per_stream, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (world == 1) return SYMACCEL_OK;
+    // one group: the root posts world - 1 transfers (each over its own xGMI link), every other rank one
+    SYM_TRY(group_start(ctx));
+    int st = SYMACCEL_OK;
+    if (rank == root) {
+        for (int p = 0; p < world && st == SYMACCEL_OK; ++p) {
+            if (p == root) continue;
+            const Slice s = slice_of(n_streams, world, p);
+            if (!s.count) continue;
+            void *a = all + s.first * bytes_per_stream;
+            st = to_root ? xfer_recv(ctx, a, s.count * bytes_per_stream, p, comm) : xfer_send(ctx, a, s.count * bytes_per_stream, p, comm);
+        }
+    } else if (mine.count) {
+        st = to_root ? xfer_send(ctx, d_mine, mine.count * bytes_per_stream, root, comm) : xfer_recv(ctx, d_mine, mine.count * bytes_per_stream, root, comm);
+    }
+    const int ge = group_end(ctx);  // (always closed, also after a failed post)
+    return st != SYMACCEL_OK ? st : ge;
+}
+
+}  // namespace
+
+}  // namespace symaccel
+
+using namespace symaccel;
+
+extern "C" {
+
+int symaccel_shard_range(size_t n_streams, int world, int rank, size_t *first, size_t *count) {
+    if (world < 1 || rank < 0 || rank >= world || !first || !count) return SYMACCEL_ERR_INVALID_ARG;
+    const Slice s = slice_of(n_streams, world, rank);
+    *first = s.first;
+    *count = s.count;
+    return SYMACCEL_OK;
+}
+
+int symaccel_multi_set_transport(const symaccel_transport *t) {
+    if (!t) {
+        g_have_transport = false;
+        g_transport = symaccel_transport{};
+        return SYMACCEL_OK;
+    }
+    if (!t->send || !t->recv) return SYMACCEL_ERR_INVALID_ARG;
+    g_transport = *t;
+    g_have_transport = true;
+    return SYMACCEL_OK;
+}
+
+int symaccel_comm_unique_id(symaccel_unique_id *id) {
+    if (!id) return SYMACCEL_ERR_INVALID_ARG;
+    const Rccl *r = rccl();
+    if (!r) return SYMACCEL_ERR_UNSUPPORTED;
+    return r->GetUniqueId(id) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+}
+
+int symaccel_comm_init(symaccel_ctx *ctx, const symaccel_unique_id *id, int world, int rank, void **comm) {
+    if (!ctx || !id || !comm || world < 1 || rank < 0 || rank >= world) return SYMACCEL_ERR_INVALID_ARG;
+    *comm = nullptr;
+    const Rccl *r = rccl();
+    if (!r) {
+        ctx->last_error = "librccl.so not found (set SYMACCEL_RCCL_LIB)";
+        return SYMACCEL_ERR_UNSUPPORTED;
+    }
+    DeviceGuard dev(ctx);  // a communicator belongs to the device that is current when it is created
+    if (!dev.ok()) return dev.status();
+    const int rc = r->CommInitRank(comm, world, *id, rank);
+    return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclCommInitRank");
+}
+
+int symaccel_comm_destroy(void *comm) {
+    if (!comm) return SYMACCEL_OK;
+    const Rccl *r = rccl();
+    if (!r) return SYMACCEL_ERR_UNSUPPORTED;
+    return r->CommDestroy(comm) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+}
+
+int symaccel_scatter_streams(symaccel_ctx *ctx, void *comm, int world, int rank, int root, const void *d_all, void *d_mine,
+                             size_t n_streams, size_t bytes_per_stream) {
+    return exchange(ctx, comm, world, rank, root, const_cast<void *>(d_all), d_mine, n_streams, bytes_per_stream, false);
+}
+
+int symaccel_gather_streams(symaccel_ctx *ctx, void *comm, int world, int rank, int root, const void *d_mine, void *d_all,
+                            size_t n_streams, size_t bytes_per_stream) {
+    return exchange(ctx, comm, world, rank, root, d_all, const_cast<void *>(d_mine), n_streams, bytes_per_stream, true);
+}
+
+}  // extern "C"
