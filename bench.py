@@ -434,6 +434,50 @@ def guarded(fn, seconds):
     return box["result"], False
 
 
+def host_to_host_mp3(sa, ctx, torch, nch, ngr, granules, reps=3):
+    """Config 3 from and to page-locked HOST memory, two ways: the f32 spectra through symaccel_mp3_synth_pipelined (576 MiB in),
+    and what the entropy decoder actually produces -- int16 Huffman samples + side records -- through
+    symaccel_mp3_decode_pipelined (requantize + joint stereo + synthesis on the device: 288 MiB + records in).  Synthetic long
+    blocks, every stream a mid/side pair.  Reported beside -- never inside -- `value`."""
+    from symphonia_amd import backend
+    d = ctx.lib.dll
+    rng = np.random.default_rng(5)
+    h_q = sa.PinnedBuffer((nch, ngr, 576), np.int16)
+    h_x = sa.PinnedBuffer((nch, ngr, 576), np.float32)
+    h_out = sa.PinnedBuffer((nch, ngr, 576), np.float32)
+    h_q.array[:] = rng.integers(-40, 41, (nch, ngr, 576), dtype=np.int16)
+    h_x.array[:] = (h_q.array * np.float32(0.01))
+    rq = np.zeros((nch, ngr), backend.MP3_REQUANT_DTYPE)
+    rq["global_gain"], rq["rzero"] = 150, 576
+    rq["scalefacs"] = rng.integers(0, 4, (nch, ngr, 39))
+    st = np.zeros((nch // 2, ngr), backend.MP3_STEREO_DTYPE)
+    st["flags"], st["rzero0"], st["rzero1"] = 1 | 4, 576, 576  # mid/side, MPEG-1
+    pairs = np.arange(nch, dtype=np.int32).reshape(-1, 2)
+    side = sa.mp3_side(np.zeros((nch, ngr), np.uint8), np.zeros((nch, ngr), np.uint8), np.full((nch, ngr), 576))
+    side = np.ascontiguousarray(side)
+    out = {}
+    for key, call in (("f32_spectra", lambda o, v, f: ctx._call(d.symaccel_mp3_synth_pipelined, h_x.array.ctypes.data, side.ctypes.data, 0, o.ctypes.data,
+                                                              v.ctypes.data, f.ctypes.data, h_out.array.ctypes.data, nch, ngr, 0)),
+                      ("int16_samples", lambda o, v, f: ctx._call(d.symaccel_mp3_decode_pipelined, h_q.array.ctypes.data, rq.ctypes.data, pairs.ctypes.data,
+                                                                st.ctypes.data, nch // 2, side.ctypes.data, 0, o.ctypes.data, v.ctypes.data, f.ctypes.data,
+                                                                h_out.array.ctypes.data, nch, ngr, 0))):
+        times = []
+        for _ in range(reps + 1):
+            o, v, f = np.zeros((nch, 576), np.float32), np.zeros((nch, 1024), np.float32), np.zeros(nch, np.int32)
+            t0 = time.perf_counter()
+            call(o, v, f)
+            times.append(time.perf_counter() - t0)
+        best = min(times[1:])
+        bytes_in = h_x.array.nbytes if key == "f32_spectra" else h_q.array.nbytes + rq.nbytes + st.nbytes
+        out[key] = {"value": granules / best, "unit": "granules/s", "ms": best * 1e3, "bytes_in": int(bytes_in) + side.nbytes,
+                    "bytes_out": h_out.array.nbytes, "finite": bool(np.isfinite(h_out.array[:2, :8]).all())}
+    out["path"] = ("symaccel_mp3_synth_pipelined (f32 spectra) and symaccel_mp3_decode_pipelined (int16 samples + records; requantize + joint "
+                   "stereo + synthesis on the device) on page-locked host buffers, chunked H2D || kernels || D2H")
+    for b in (h_q, h_x, h_out):
+        b.free()
+    return out
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` with no launcher in the environment: start N ranks ourselves (one process per GPU) with
     torch.distributed.run on the loopback address and hand its exit status back.  (The driver may also start the ranks
@@ -730,6 +774,11 @@ def main():
             out["exchange_c_api"] = exchange_c
         if world == 1 and args.workload == "aac" and not args.no_host_path and not emulate:
             out["host_to_host"] = host_to_host_aac(sa, ctx, torch, result, step.input, units)
+        if world == 1 and args.workload == "mp3" and not args.no_host_path and not emulate:
+            try:
+                out["host_to_host"] = host_to_host_mp3(sa, ctx, torch, int(step.input.shape[0]), int(step.input.shape[1]), units)
+            except Exception as e:  # noqa: BLE001
+                out["host_to_host"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline and not emulate:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

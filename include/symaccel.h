@@ -307,6 +307,19 @@ int symaccel_mp3_requantize_stereo_device(symaccel_ctx *ctx, const int16_t *d_qu
                                           const symaccel_mp3_stereo *d_desc, int sample_rate_idx, float *d_xr,
                                           size_t n_pairs);
 
+/* The whole Layer III tail from what the entropy decoder produces, HOST memory in and out (layer3/mod.rs:421-477: requantize,
+ * stereo, then the per-channel synthesis): quant[chain][granule][576] int16 Huffman samples and rq_desc[chain][granule];
+ * pair_chains[n_pairs][2] + st_desc[pair][granule] for the joint-stereo channel pairs (n_pairs may be 0; a chain appears in at
+ * most one pair); side[chain][granule] as symaccel_mp3_synth takes it (with the rzero the reference has AFTER stereo,
+ * stereo.rs:549-553); state and pcm as symaccel_mp3_synth_pipelined.  Chunked like the other *_pipelined entry points: what
+ * crosses PCIe on the way in is 2 bytes per line plus the records -- half the bytes of the f32 spectra -- and the requantised
+ * spectra never leave the device. */
+int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, const symaccel_mp3_requant *h_rq_desc,
+                                  const int32_t *h_pair_chains, const symaccel_mp3_stereo *h_st_desc, size_t n_pairs,
+                                  const symaccel_mp3_side *h_side, int sample_rate_idx, float *h_overlap_io, float *h_vvec_io,
+                                  int32_t *h_vfront_io, float *h_pcm, size_t n_chains, size_t granules_per_chain,
+                                  size_t chunk_granules);
+
 /* synthesis::synthesis alone (synthesis.rs:158-336) as Layer I and Layer II use it: n_frames = 12
  * (layer1/mod.rs:193) or 36 (layer2/mod.rs:383) time slots per packet and channel.  in[chain][packet][32 * n_frames]
  * sub-band-major (in[n_frames * i + b], synthesis.rs:168-170); pcm[chain][packet][32 * n_frames]; state per chain:

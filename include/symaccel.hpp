@@ -651,6 +651,77 @@ private:
     std::vector<symaccel_mp3_side> side_;
 };
 
+// The same Layer III packets one stage earlier: what the entropy decoder produces (layer3/mod.rs:393-420) -- the Huffman samples as
+// int16, the GranuleChannel fields requantize reads, one stereo record per granule for a two-channel stream -- handed to
+// symaccel_mp3_decode_pipelined, which runs requantize + joint stereo + the synthesis tail on the device (layer3/mod.rs:421-477).
+// Half the bytes of Mp3's f32 spectra cross PCIe, and the host keeps neither POW43 nor the band loops.
+struct Mp3Huffman {
+    using Sample = float;
+    struct Params {
+        std::size_t channels = 2;  // 1, or 2 (one joint-stereo pair)
+        std::size_t granules = 2;
+        int sample_rate_idx = 0;
+    };
+    struct Packet {
+        std::uint64_t ts = 0;
+        std::vector<std::int16_t> quant;            // [granule][channel][576]
+        std::vector<symaccel_mp3_requant> rq;       // [granule][channel]
+        std::vector<symaccel_mp3_stereo> stereo;    // [granule] (two-channel streams)
+        std::vector<symaccel_mp3_side> side;        // [granule][channel], rzero as it is AFTER stereo (stereo.rs:549-553)
+    };
+    explicit Mp3Huffman(const Params &p)
+        : nch_(p.channels), ngr_(p.granules), sr_(p.sample_rate_idx), overlap_(p.channels * 576, 0.0f), vvec_(p.channels * 1024, 0.0f),
+          vfront_(p.channels, 0) {
+        if (p.channels < 1 || p.channels > 2) throw std::invalid_argument("Mp3Huffman: one or two channels");
+    }
+    static std::uint64_t id(const Packet &p) { return p.ts; }
+    std::size_t channels() const { return nch_; }
+    std::size_t packet_frames(std::size_t) const { return 576 * ngr_; }
+    std::size_t plane_offset(std::size_t c, std::size_t i, std::size_t k) const { return (c * k + i) * 576 * ngr_; }
+    void reset_state() {
+        std::fill(overlap_.begin(), overlap_.end(), 0.0f);
+        std::fill(vvec_.begin(), vvec_.end(), 0.0f);
+        std::fill(vfront_.begin(), vfront_.end(), 0);
+    }
+    void decode_batch(Context &ctx, const std::vector<Packet> &batch, std::vector<float> &pcm) {
+        const std::size_t k = batch.size(), g = k * ngr_;
+        q_.resize(nch_ * g * 576);
+        rq_.resize(nch_ * g);
+        side_.resize(nch_ * g);
+        st_.resize(nch_ == 2 ? g : 0);
+        pcm.resize(nch_ * g * 576);
+        for (std::size_t i = 0; i < k; ++i) {
+            const Packet &p = batch[i];
+            if (p.quant.size() != ngr_ * nch_ * 576 || p.rq.size() != ngr_ * nch_ || p.side.size() != ngr_ * nch_ ||
+                p.stereo.size() != (nch_ == 2 ? ngr_ : 0))
+                throw std::invalid_argument("Mp3Huffman: packet shape");
+            for (std::size_t gr = 0; gr < ngr_; ++gr) {
+                for (std::size_t c = 0; c < nch_; ++c) {
+                    const std::size_t dst = c * g + i * ngr_ + gr;
+                    std::copy_n(p.quant.data() + (gr * nch_ + c) * 576, 576, q_.data() + dst * 576);
+                    rq_[dst] = p.rq[gr * nch_ + c];
+                    side_[dst] = p.side[gr * nch_ + c];
+                }
+                if (nch_ == 2) st_[i * ngr_ + gr] = p.stereo[gr];
+            }
+        }
+        const std::int32_t pair[2] = {0, 1};
+        check(symaccel_mp3_decode_pipelined(ctx.raw(), q_.data(), rq_.data(), nch_ == 2 ? pair : nullptr, nch_ == 2 ? st_.data() : nullptr,
+                                            nch_ == 2 ? 1 : 0, side_.data(), sr_, overlap_.data(), vvec_.data(), vfront_.data(), pcm.data(), nch_, g, 0),
+              ctx.raw());
+    }
+
+private:
+    std::size_t nch_, ngr_;
+    int sr_;
+    std::vector<float> overlap_, vvec_;
+    std::vector<std::int32_t> vfront_;
+    std::vector<std::int16_t> q_;
+    std::vector<symaccel_mp3_requant> rq_;
+    std::vector<symaccel_mp3_stereo> st_;
+    std::vector<symaccel_mp3_side> side_;
+};
+
 // Vorbis: one packet = one audio block of the size its mode's block flag selects.  What the CPU side hands over per
 // channel: floor x residue, the n / 2 lines DspChannel::synth receives (lib.rs:282-331).  A packet yields
 // (prev_n + n) / 4 frames -- none for the first block after a reset (dsp.rs:77-80) -- so the batch's PCM is packed

@@ -15,6 +15,7 @@
 // symaccel_host_register(); pageable memory still works (the runtime stages it) but serialises.
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "symaccel_internal.h"
 
@@ -230,6 +231,91 @@ int symaccel_mp3_synth_pipelined(symaccel_ctx *ctx, const float *h_xr, const sym
         SYM_GPU(ctx, hipStreamWaitEvent(pp.s_out, pp.ev_k[b], 0));
         SYM_TRY(copy_rows(ctx, h_pcm + g0 * 576, granules_per_chain * 2304, d_out[b], ng * 2304, ng * 2304, n_chains, hipMemcpyDeviceToHost,
                           pp.s_out));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_out[b], pp.s_out));
+    }
+    const int sf = (int)(k & 1);
+    SYM_GPU(ctx, hipMemcpyAsync(h_overlap_io, d_ov[sf], n_chains * 2304, hipMemcpyDeviceToHost, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(h_vvec_io, d_vv[sf], n_chains * 4096, hipMemcpyDeviceToHost, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(h_vfront_io, d_vf[sf], n_chains * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return pp.drain();
+}
+
+int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, const symaccel_mp3_requant *h_rq_desc,
+                                  const int32_t *h_pair_chains, const symaccel_mp3_stereo *h_st_desc, size_t n_pairs,
+                                  const symaccel_mp3_side *h_side, int sample_rate_idx, float *h_overlap_io, float *h_vvec_io,
+                                  int32_t *h_vfront_io, float *h_pcm, size_t n_chains, size_t granules_per_chain, size_t chunk_granules) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
+    if (!h_quant || !h_rq_desc || !h_side || !h_overlap_io || !h_vvec_io || !h_vfront_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs && (!h_pair_chains || !h_st_desc)) return SYMACCEL_ERR_INVALID_ARG;
+    // pair_chains is in host memory: check it (every chain at most once, inside the batch) and learn whether every chain is paired
+    std::vector<uint8_t> paired(n_chains, 0);
+    for (size_t p = 0; p < 2 * n_pairs; ++p) {
+        const int32_t c = h_pair_chains[p];
+        if (c < 0 || (size_t)c >= n_chains || paired[(size_t)c]) return SYMACCEL_ERR_INVALID_ARG;
+        paired[(size_t)c] = 1;
+    }
+    const bool all_paired = 2 * n_pairs == n_chains;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    size_t cg = pick_chunk(granules_per_chain, n_chains * 1152, chunk_granules);
+    if (cg < 2 && granules_per_chain >= 2) cg = 2;  // the synthesis kernel's two-granule halo wants segments of at least two
+    Pipe pp(ctx);
+    SYM_TRY(pp.init());
+    int16_t *d_q[2];
+    symaccel_mp3_requant *d_rq[2];
+    symaccel_mp3_stereo *d_st[2];
+    symaccel_mp3_side *d_side[2];
+    float *d_out[2], *d_ov[2], *d_vv[2], *d_xr;
+    int32_t *d_vf[2], *d_pairs;
+    for (int b = 0; b < 2; ++b) {
+        SYM_TRY(pp.alloc((void **)&d_q[b], n_chains * cg * 1152));
+        SYM_TRY(pp.alloc((void **)&d_rq[b], n_chains * cg * sizeof(symaccel_mp3_requant)));
+        SYM_TRY(pp.alloc((void **)&d_st[b], (n_pairs ? n_pairs : 1) * cg * sizeof(symaccel_mp3_stereo)));
+        SYM_TRY(pp.alloc((void **)&d_side[b], n_chains * cg * sizeof(symaccel_mp3_side)));
+        SYM_TRY(pp.alloc((void **)&d_out[b], n_chains * cg * 2304));
+        SYM_TRY(pp.alloc((void **)&d_ov[b], n_chains * 2304));
+        SYM_TRY(pp.alloc((void **)&d_vv[b], n_chains * 4096));
+        SYM_TRY(pp.alloc((void **)&d_vf[b], n_chains * 4));
+    }
+    SYM_TRY(pp.alloc((void **)&d_xr, n_chains * cg * 2304));  // the requantised spectra never leave the device (one buffer:
+    SYM_TRY(pp.alloc((void **)&d_pairs, (n_pairs ? n_pairs : 1) * 8));  // its writer and its reader are ordered by the stream)
+    SYM_TRY(pp.commit());
+    if (n_pairs) SYM_GPU(ctx, hipMemcpyAsync(d_pairs, h_pair_chains, n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(d_ov[0], h_overlap_io, n_chains * 2304, hipMemcpyHostToDevice, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(d_vv[0], h_vvec_io, n_chains * 4096, hipMemcpyHostToDevice, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(d_vf[0], h_vfront_io, n_chains * 4, hipMemcpyHostToDevice, ctx->stream));
+    size_t k = 0;
+    for (size_t g0 = 0; g0 < granules_per_chain; g0 += cg, ++k) {
+        const size_t ng = std::min(cg, granules_per_chain - g0);
+        const int b = (int)(k & 1);
+        if (k >= 2) {
+            SYM_GPU(ctx, hipStreamWaitEvent(pp.s_in, pp.ev_k[b], 0));
+            SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_out[b], 0));
+        }
+        // what the entropy decoder produced: 2 bytes per line + 52-byte records (+ one 48-byte record per pair), a quarter of
+        // the f32 spectra's bytes plus the side words
+        SYM_TRY(copy_rows(ctx, d_q[b], ng * 1152, h_quant + g0 * 576, granules_per_chain * 1152, ng * 1152, n_chains, hipMemcpyHostToDevice, pp.s_in));
+        SYM_TRY(copy_rows(ctx, d_rq[b], ng * sizeof(symaccel_mp3_requant), h_rq_desc + g0, granules_per_chain * sizeof(symaccel_mp3_requant),
+                          ng * sizeof(symaccel_mp3_requant), n_chains, hipMemcpyHostToDevice, pp.s_in));
+        if (n_pairs)
+            SYM_TRY(copy_rows(ctx, d_st[b], ng * sizeof(symaccel_mp3_stereo), h_st_desc + g0, granules_per_chain * sizeof(symaccel_mp3_stereo),
+                              ng * sizeof(symaccel_mp3_stereo), n_pairs, hipMemcpyHostToDevice, pp.s_in));
+        SYM_TRY(copy_rows(ctx, d_side[b], ng * 4, h_side + g0, granules_per_chain * 4, ng * 4, n_chains, hipMemcpyHostToDevice, pp.s_in));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_in[b], pp.s_in));
+        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_in[b], 0));
+        // requantize (+ joint stereo) -> synthesis tail, layer3/mod.rs:421-477 in that order
+        if (all_paired) {
+            SYM_TRY(launch_mp3_stereo(ctx, d_xr, ng, d_pairs, d_st[b], sample_rate_idx, n_pairs, d_q[b], d_rq[b]));
+        } else {
+            SYM_TRY(launch_mp3_requantize(ctx, d_q[b], d_rq[b], sample_rate_idx, d_xr, n_chains * ng));
+            if (n_pairs) SYM_TRY(launch_mp3_stereo(ctx, d_xr, ng, d_pairs, d_st[b], sample_rate_idx, n_pairs));
+        }
+        const int si = (int)(k & 1), so = (int)((k + 1) & 1);
+        SYM_TRY(launch_mp3(ctx, d_xr, d_side[b], sample_rate_idx, d_ov[si], d_vv[si], d_vf[si], d_ov[so], d_vv[so], d_vf[so], d_out[b], n_chains, ng));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_k[b], ctx->stream));
+        SYM_GPU(ctx, hipStreamWaitEvent(pp.s_out, pp.ev_k[b], 0));
+        SYM_TRY(copy_rows(ctx, h_pcm + g0 * 576, granules_per_chain * 2304, d_out[b], ng * 2304, ng * 2304, n_chains, hipMemcpyDeviceToHost, pp.s_out));
         SYM_GPU(ctx, hipEventRecord(pp.ev_out[b], pp.s_out));
     }
     const int sf = (int)(k & 1);

@@ -154,6 +154,78 @@ static void test_mp3(Context &ctx, size_t lookahead) {
     }
 }
 
+// ---- MP3 one stage earlier: int16 Huffman samples + records in, the device requantises and runs the joint stereo
+static void test_mp3_huffman(Context &ctx, size_t lookahead) {
+    const size_t nch = 2, ngr = 2, n = 19;
+    const int sr = 0;
+    std::mt19937 rng(501 + (unsigned)lookahead);
+    std::vector<Mp3Huffman::Packet> track(n);
+    for (size_t i = 0; i < n; ++i) {
+        Mp3Huffman::Packet &p = track[i];
+        p.ts = 7000 + 1152 * i;
+        p.quant.resize(ngr * nch * 576);
+        p.rq.resize(ngr * nch);
+        p.stereo.resize(ngr);
+        p.side.resize(ngr * nch);
+        for (size_t gr = 0; gr < ngr; ++gr) {
+            const unsigned rz0 = 2 * (unsigned)(rng() % 289), rz1 = 2 * (unsigned)(rng() % 289);
+            const unsigned flags = (unsigned)(rng() % 4) | SYMACCEL_MP3_ST_MPEG1;
+            symaccel_mp3_stereo &sd = p.stereo[gr];
+            std::memset(&sd, 0, sizeof sd);
+            sd.flags = (uint8_t)flags;
+            sd.rzero0 = (uint16_t)rz0;
+            sd.rzero1 = (uint16_t)rz1;
+            for (int s = 0; s < 39; ++s) sd.scalefacs1[s] = (uint8_t)(rng() % 8);
+            const unsigned end = rz0 > rz1 ? rz0 : rz1;
+            for (size_t c = 0; c < nch; ++c) {
+                const unsigned rz = c == 0 ? rz0 : rz1;
+                int16_t *q = p.quant.data() + (gr * nch + c) * 576;
+                for (unsigned k = 0; k < 576; ++k) q[k] = k < rz ? (int16_t)((int)(rng() % 61) - 30) : (int16_t)0;
+                symaccel_mp3_requant &r = p.rq[gr * nch + c];
+                std::memset(&r, 0, sizeof r);
+                r.global_gain = (uint8_t)(140 + rng() % 40);
+                r.flags = (uint8_t)(rng() % 4);
+                r.rzero = (uint16_t)rz;
+                for (int s = 0; s < 39; ++s) r.scalefacs[s] = (uint8_t)(rng() % 4);
+                p.side[gr * nch + c] = symaccel_mp3_side{0, 0, (uint16_t)((flags & 3u) ? end : rz)};
+            }
+        }
+    }
+    size_t cursor = 0;
+    LookaheadDecoder<Mp3Huffman> dec(ctx, Mp3Huffman::Params{nch, ngr, sr}, lookahead, [&]() -> std::optional<Mp3Huffman::Packet> {
+        if (cursor >= track.size()) return std::nullopt;
+        return track[cursor++];
+    });
+    std::vector<float> ov(nch * 576, 0.0f), vv(nch * 1024, 0.0f);
+    std::vector<int32_t> vf(nch, 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (i == 8) {  // seek
+            dec.reset();
+            std::fill(ov.begin(), ov.end(), 0.0f);
+            std::fill(vv.begin(), vv.end(), 0.0f);
+            std::fill(vf.begin(), vf.end(), 0);
+            cursor = i;
+        }
+        if (cursor <= i) cursor = i + 1;
+        const AudioBufferRef &buf = dec.decode(track[i]);
+        const Mp3Huffman::Packet &p = track[i];
+        float want[2][1152];
+        for (size_t gr = 0; gr < ngr; ++gr) {
+            float xr[2][576];
+            for (size_t c = 0; c < nch; ++c)
+                so_mp3_requantize(p.quant.data() + (gr * nch + c) * 576, reinterpret_cast<const so_mp3_requant *>(&p.rq[gr * nch + c]), sr, xr[c]);
+            so_mp3_stereo(xr[0], xr[1], reinterpret_cast<const so_mp3_stereo_desc *>(&p.stereo[gr]), sr);
+            for (size_t c = 0; c < nch; ++c) {
+                const symaccel_mp3_side &sd = p.side[gr * nch + c];
+                const uint8_t side[4] = {sd.block_type, sd.is_mixed, (uint8_t)(sd.rzero & 255), (uint8_t)(sd.rzero >> 8)};
+                so_mp3_synth_batch(xr[c], side, sr, ov.data() + c * 576, vv.data() + c * 1024, &vf[c], want[c] + gr * 576, 1, 1);
+            }
+        }
+        for (size_t c = 0; c < nch; ++c)
+            EXPECT(same_bits(buf.planes[c], want[c], 1152), "MP3 (Huffman in) K=%zu packet %zu channel %zu differs from the frame-by-frame decoder", lookahead, i, c);
+    }
+}
+
 // ---- Vorbis: mixed block sizes, a variable number of frames per packet (none for the first block after a reset)
 static void test_vorbis(Context &ctx, size_t lookahead, int e0, int e1) {
     const size_t nch = 2, n = 37;
@@ -268,6 +340,7 @@ int main(int argc, char **argv) {
     Context ctx(0);
     for (size_t k : {size_t(1), size_t(4), size_t(9), size_t(64)}) test_aac(ctx, k);
     for (size_t k : {size_t(1), size_t(3), size_t(8)}) test_mp3(ctx, k);
+    for (size_t k : {size_t(1), size_t(6)}) test_mp3_huffman(ctx, k);
     for (size_t k : {size_t(1), size_t(5), size_t(16)}) test_vorbis(ctx, k, 8, 11);
     test_vorbis(ctx, 6, 6, 9);
     for (size_t k : {size_t(1), size_t(4), size_t(32)}) test_flac(ctx, k, 2, 16);

@@ -341,3 +341,57 @@ def test_gpu_mp3_stereo(sr, n_pairs, granules):
                                   torch.from_numpy(desc.view(np.uint8).reshape(n_pairs, granules, 48)).cuda())
         ctx.sync()
         assert bit_equal(d.cpu().numpy(), want)
+
+
+def decode_pipelined_case(seed, sr, n_pairs, granules, with_mono):
+    """fused_case (2 n_pairs + 1 chains: one mono) or its paired chains alone; expectation = oracle requantize -> stereo -> synth."""
+    q, rd, pairs, sd, xr_want, mono = fused_case(seed, sr, n_pairs, granules)
+    side = side_of(rd, pairs, sd)
+    if not with_mono:  # drop the mono chain and renumber
+        keep = [c for c in range(q.shape[0]) if c != mono]
+        remap = {c: i for i, c in enumerate(keep)}
+        q, rd, xr_want, side = q[keep], rd[keep], xr_want[keep], side[keep]
+        pairs = np.array([[remap[int(a)], remap[int(b)]] for a, b in pairs], np.int32)
+    rng = np.random.default_rng(seed + 11)
+    chains = q.shape[0]
+    ov = rng.standard_normal((chains, 576)).astype(F)
+    vv = rng.standard_normal((chains, 1024)).astype(F)
+    vf = rng.integers(0, 16, chains).astype(np.int32)
+    want = oracle.mp3_synth(xr_want, side, sr, ov, vv, vf)
+    return q, rd, pairs, sd, side, ov, vv, vf, want
+
+
+def run_decode_pipelined(ctx, sr, n_pairs, granules, with_mono, chunks):
+    q, rd, pairs, sd, side, ov, vv, vf, want = decode_pipelined_case(90 + sr + n_pairs, sr, n_pairs, granules, with_mono)
+    d = ctx.lib.dll
+    chains = q.shape[0]
+    q, rd, sd, side = (np.ascontiguousarray(a) for a in (q, rd, sd, side))
+    for ch in chunks:
+        o, v, f = ov.copy(), vv.copy(), vf.copy()
+        pcm = np.zeros((chains, granules, 576), F)
+        ctx._call(d.symaccel_mp3_decode_pipelined, q.ctypes.data, rd.ctypes.data, pairs.ctypes.data if len(pairs) else None,
+                  sd.ctypes.data if len(pairs) else None, len(pairs), side.ctypes.data, sr, o.ctypes.data, v.ctypes.data, f.ctypes.data,
+                  pcm.ctypes.data, chains, granules, ch)
+        assert bit_equal(pcm, want[0]), ("pcm", ch)
+        assert bit_equal(o, want[1]) and bit_equal(v, want[2]) and np.array_equal(f, want[3]), ("state", ch)
+
+
+@pytest.mark.parametrize("sr,n_pairs,granules,with_mono", [(0, 2, 9, True), (3, 1, 5, False), (8, 3, 7, False), (1, 0, 4, True)])
+def test_emu_mp3_decode_pipelined(emu_ctx, sr, n_pairs, granules, with_mono):
+    """symaccel_mp3_decode_pipelined: int16 Huffman samples + records in host memory -> PCM in host memory (requantize, joint
+    stereo, synthesis: layer3/mod.rs:421-477), in chunks of every size, with and without chains outside the pairs."""
+    run_decode_pipelined(emu_ctx, sr, n_pairs, granules, with_mono, [2, 3, granules, 0])
+    pairs_bad = np.array([[0, 0]], np.int32)
+    z = np.zeros(8, np.uint8)
+    with pytest.raises(Exception):
+        emu_ctx._call(emu_ctx.lib.dll.symaccel_mp3_decode_pipelined, z.ctypes.data, z.ctypes.data, pairs_bad.ctypes.data, z.ctypes.data, 1,
+                      z.ctypes.data, 0, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, 2, 1, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,n_pairs,granules,with_mono", [(0, 4, 33, True), (8, 5, 20, False)])
+def test_gpu_mp3_decode_pipelined(sr, n_pairs, granules, with_mono):
+    from symphonia_amd import Context
+    ctx = Context(0)
+    run_decode_pipelined(ctx, sr, n_pairs, granules, with_mono, [4, 0])
+    ctx.close()
