@@ -378,7 +378,7 @@ int symaccel_vorbis_deinterleave2_device(symaccel_ctx *ctx, const float *d_type2
                                          int n_ch, size_t n2, size_t count);
 /* Floor-1 curve synthesis, steps 1 and 2 (floor.rs:568-653, 776-825) for `count` channel-blocks
  * sharing one floor configuration: x_list[n_posts] (HOST, from the setup header), multiplier
- * 1..4, y[count][n_posts] (DEVICE, decoded floor1_Y values, each <= 255: see symaccel_vorbis_floor1_status_device; a block
+ * 1..4, y[count][n_posts] (DEVICE, decoded floor1_Y values, each <= 511: see symaccel_vorbis_floor1_status_device; a block
  * with a larger value gets an unspecified curve), n = blocksize / 2 (a multiple of 16, <= 4096), floor[count][n] out. */
 int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts,
                                   int multiplier, const uint32_t *d_y, uint32_t n, float *d_floor,
@@ -391,9 +391,10 @@ int symaccel_vorbis_floor1_dot_device(symaccel_ctx *ctx, const uint32_t *x_list,
                                       const uint32_t *d_y, uint32_t n, const float *d_residue, float *d_spectrum,
                                       size_t count);
 /* Per-block status of the y rows (d_status[count] int8): 0, or SYMACCEL_ERR_UNSUPPORTED for a block with a value above
- * 255.  floor1_Y values are codebook entry numbers (floor.rs:698-712) that a conforming stream keeps below the floor's
- * range (<= 256); the reference computes whatever a larger value implies in i32, the kernels above do not (their closed
- * forms hold for |final_y| <= 511): such a block is the caller's to render on the CPU. */
+ * 511.  floor1_Y values are codebook entry numbers (floor.rs:698-712) that a conforming stream keeps below the floor's
+ * range (<= 256); the reference computes whatever a larger value implies in i32.  Up to 511 the kernels above reproduce
+ * it exactly (render_point in integers wherever a difference of final_y values leaves the closed form's proven range;
+ * the final_y stay inside 16 bits); beyond, a block is the caller's to render on the CPU. */
 int symaccel_vorbis_floor1_status_device(symaccel_ctx *ctx, int n_posts, const uint32_t *d_y, size_t count,
                                          int8_t *d_status);
 

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void floor1_status_kernel(const uint32_t *__re
         const uint32_t *row = y + b * n_posts;
         uint32_t worst = lane < n_posts ? row[lane] : 0u;
         if (lane == 0 && n_posts > 64) worst = worst > row[64] ? worst : row[64];
-        const bool big = __any(worst > 255u) != 0;
+        const bool big = __any(worst > 511u) != 0;  // (up to 511 the kernel is exact: integer render_point above |dy| 511, final_y inside int16)
         if (lane == 0) status[b] = (int8_t)(big ? SYMACCEL_ERR_UNSUPPORTED : SYMACCEL_OK);
     }
 }

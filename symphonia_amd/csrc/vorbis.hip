@@ -335,8 +335,8 @@ struct Floor1Setup {  // per floor configuration, derived on the host like the s
     uint32_t nb[65];    // post i: lo | hi << 8 (floor1_x_list_neighbors) | wide << 16 (neighbour span above 4096, see `wide`)
     float ratio[65];    //         (x[i] - x[lo]) / (x[hi] - x[lo]) and
     float half[65];     //         0.5 / (x[hi] - x[lo]), both rounded to f32: render_point in closed form (see step 1)
-    uint32_t wide[65];  //         (x[i] - x[lo]) | (x[hi] - x[lo]) << 16 for the posts whose span is outside the closed form's
-                        //         proven range: render_point in integers, as the reference writes it
+    uint32_t wide[65];  //         (x[i] - x[lo]) | (x[hi] - x[lo]) << 16: render_point in integers, as the reference writes it, for the
+                        //         posts and lanes outside the closed form's proven range (spans above 4096, |dy| above 511)
     uint32_t ord[65];   // x-sorted position k: order[k] | x[order[k]] << 16
 };
 
@@ -437,13 +437,17 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
             const int32_t dy = fy[hi * kF1B + lane] - py0;
             const float fdy = (float)dy;
             int32_t predicted = py0 + (int32_t)(fdy * ratio + __builtin_copysignf(half, fdy));
-            if (pn & 0x10000u) {
-                // neighbours more than 4096 apart (a floor whose posts reach past every block size: rangebits up to 15 are
-                // legal): outside the closed form's proven range -- it first fails at adx = 17019 --, so the integer form of
-                // floor.rs:776-782 itself.  A property of the setup: the branch is wave-uniform and no conforming
-                // encoder's setup takes it.
+            const uint32_t ady = (uint32_t)(dy < 0 ? -dy : dy);
+            if ((pn & 0x10000u) || ady > 511u) {
+                // Outside the closed form's proven range, the integer form of floor.rs:776-782 itself:
+                //  * neighbours more than 4096 apart (a floor whose posts reach past every block size: rangebits up to 15 are
+                //    legal; the closed form first fails at adx = 17019) -- a property of the setup, wave-uniform, and no
+                //    conforming encoder's setup has it;
+                //  * |dy| above 511: only y values beyond the floor's range produce it (they are codebook entry numbers,
+                //    floor.rs:698-712, so a hostile stream can carry them; up to 511 the final_y stay inside int16) -- per lane,
+                //    and no lane of a conforming stream takes it.
                 const uint32_t w = st.wide[i];
-                const uint32_t off = ((uint32_t)(dy < 0 ? -dy : dy) * (w & 0xffffu)) / (w >> 16);
+                const uint32_t off = (ady * (w & 0xffffu)) / (w >> 16);
                 predicted = dy < 0 ? py0 - (int32_t)off : py0 + (int32_t)off;
             }
             // floor.rs:596-621 as selects (the lanes of a wavefront take all the branches anyway); lowroom = predicted, so
@@ -703,7 +707,7 @@ int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts
         st.nb[i] = lo | hi << 8 | (wide ? 0x10000u : 0u);
         st.ratio[i] = (float)((int)h_setup[i] - (int)h_setup[lo]) / fadx;
         st.half[i] = 0.5f / fadx;
-        st.wide[i] = wide ? ((h_setup[i] - h_setup[lo]) & 0xffffu) | (uint32_t)adx << 16 : 0u;
+        st.wide[i] = ((h_setup[i] - h_setup[lo]) & 0xffffu) | (uint32_t)(adx > 0 ? adx : 1) << 16;  // (x[i] - x[lo]) | adx << 16
     }
     // instantiated per block class: the segment-start map is n bytes of LDS, and LDS is what bounds the resident wavefronts
 #define SYM_F1_LAUNCH(DOT, NMAX)                                                                                                     \

@@ -209,7 +209,8 @@ def floor1_case(rng):
             if x not in rest:
                 rest.append(x)
         xs = [0, top_x] + [int(v) for v in rng.permutation(rest)]
-    top = 256 if rng.random() < 0.3 else [256, 128, 86, 64][mult - 1]
+    # (values beyond the range are legal codebook entries: up to 511 the kernel reproduces the reference's i32 arithmetic)
+    top = 512 if rng.random() < 0.2 else (256 if rng.random() < 0.3 else [256, 128, 86, 64][mult - 1])
     ys = rng.integers(0, top, size=(count, n_posts)).astype(np.uint32)
     ys[rng.random((count, n_posts)) < rng.choice([0.02, 0.3, 0.9])] = 0
     return xs, mult, n, ys

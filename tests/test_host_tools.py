@@ -82,12 +82,12 @@ def check_status_arrays(ctx, dev, host):
     st3 = host(sa.alac_block_status(ctx, dev(ad), dev(st3)))
     assert st3.tolist() == [0, D, D, 0]
     ys = np.zeros((5, 65), np.uint32)
-    ys[1, 64], ys[2, 0], ys[3, 30], ys[4, 63] = 256, 255, 70000, 255
+    ys[1, 64], ys[2, 0], ys[3, 30], ys[4, 63] = 512, 511, 70000, 255
     st5 = np.full(5, 99, np.int8)
     st5 = host(sa.vorbis_floor1_status(ctx, 65, dev(ys), 5, dev(st5)))
     assert st5.tolist() == [0, U, 0, U, 0]
     st6 = np.full(3, 99, np.int8)
-    st6 = host(sa.vorbis_floor1_status(ctx, 7, dev(np.array([[0, 1, 2, 3, 4, 5, 300], [255] * 7, [0, 0, 0, 0, 0, 0, 0]], np.uint32)), 3, dev(st6)))
+    st6 = host(sa.vorbis_floor1_status(ctx, 7, dev(np.array([[0, 1, 2, 3, 4, 5, 600], [511] * 7, [0, 0, 0, 0, 0, 0, 0]], np.uint32)), 3, dev(st6)))
     assert st6.tolist() == [U, 0, 0]
     filt = np.zeros(5, sa.AAC_TNS_DTYPE)
     filt["frame"], filt["start"], filt["end"], filt["order"] = [0, 9, 0, 0, 1], [0, 0, 8, 0, 4], [16, 16, 8, 1028, 1024], [3, 3, 3, 3, 21]

@@ -98,7 +98,7 @@ def check_aac(r, seg):
     from symphonia_amd import AacDsp
     f = load("aac")
     r.ctx.set_segment(seg)
-    for walk in ("a", "b"):
+    for walk in ("a", "b", "c", "d"):
         coeffs = f["coeffs_" + walk]
         side = np.tile(np.array([oracle.aac_side(s, sh, pv) for s, sh, pv in f["side_" + walk]], np.uint8), (coeffs.shape[0], 1))
         if isinstance(r, Emu):
@@ -115,7 +115,7 @@ def check_mp3(r, seg):
     from symphonia_amd import Mp3Synthesis, MpaPolyphase, mp3_side
     f = load("mp3")
     r.ctx.set_segment(seg)
-    for chain in ("long", "switch", "sr3", "sr8"):
+    for chain in ("long", "switch", "sr3", "sr8") + tuple("mix%d" % i for i in range(9)):
         k = "chain_%s_" % chain
         xr, g = f[k + "xr"], f[k + "side"]
         n = xr.shape[0]

@@ -84,7 +84,7 @@ def test_oracle_aac():
     for nm, (kbd, alpha, size) in {"kbd_long_win": (1, 4.0, 1024), "kbd_short_win": (1, 6.0, 128), "sine_long_win": (0, 0, 1024),
                                    "sine_short_win": (0, 0, 128)}.items():
         assert same(oracle.aac_window(kbd, alpha, size), f[nm]), nm
-    for walk in ("a", "b"):
+    for walk in ("a", "b", "c", "d"):
         coeffs = f["coeffs_" + walk]
         pcm, delay = oracle.aac_synth(coeffs, aac_side_of(f, walk, coeffs.shape[0]), f["delay_in_" + walk])
         assert same(pcm, f["pcm_" + walk]) and same(delay, f["delay_out_" + walk]), walk
@@ -105,7 +105,7 @@ def test_oracle_mp3():
             assert same(o, f["imdct36_out_w%d" % wi][l]) and same(oo, f["imdct36_ovout_w%d" % wi][l]), (l, wi)
         o, oo = oracle.mp3_imdct12_win(f["imdct36_x"][l], f["IMDCT_WINDOWS"][2], f["imdct36_overlap"][l])
         assert same(o, f["imdct12_out"][l]) and same(oo, f["imdct12_ovout"][l]), l
-    for chain in ("long", "switch", "sr3", "sr8"):
+    for chain in ("long", "switch", "sr3", "sr8") + tuple("mix%d" % i for i in range(9)):
         k = "chain_%s_" % chain
         xr = f[k + "xr"]
         g = f[k + "side"]
