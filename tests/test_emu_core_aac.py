@@ -20,7 +20,7 @@ def test_emu_imdct_bit_exact(emu_ctx, n):
         assert bit_equal(got, oracle.imdct(spec, scale)), (n, scale)
 
 
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 2048, 4096])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096])
 def test_emu_fft_bit_exact(emu_ctx, n):
     rng = np.random.default_rng(100 + n)
     count = 3
@@ -32,6 +32,24 @@ def test_emu_fft_bit_exact(emu_ctx, n):
     z = x.copy()
     Fft(emu_ctx, n).fft_inplace(z)
     assert bit_equal(z, want)
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_emu_big_register_pass_kernels(emu_ctx, n):
+    """1024 / 2048 points: two / four 512-point sub-transforms per wavefront, the last stages in registers; Fft, Ifft (in place),
+    Imdct of 2 n lines, several transforms per wavefront."""
+    from symphonia_amd import Ifft
+    rng = np.random.default_rng(400 + n)
+    for count in (1, 3, 9):
+        x = (rng.standard_normal((count, n)) * np.exp2(rng.integers(-6, 7, (count, n))) + 1j * rng.standard_normal((count, n))).astype(np.complex64)
+        y = np.empty_like(x)
+        Fft(emu_ctx, n).fft(x, y)
+        assert bit_equal(y, np.stack([oracle.fft(v) for v in x])), (n, count)
+        z = x.copy()
+        Ifft(emu_ctx, n).ifft_inplace(z)
+        assert bit_equal(z, np.stack([oracle.ifft(v) for v in x])), (n, count)
+        spec = (rng.standard_normal((count, 2 * n)) * np.exp2(rng.integers(-6, 8, (count, 2 * n)))).astype(np.float32)
+        assert bit_equal(Imdct(emu_ctx, 2 * n, -1.0 / 3).imdct(spec), oracle.imdct(spec, -1.0 / 3)), (n, count)
 
 
 @pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512])

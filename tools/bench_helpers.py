@@ -146,14 +146,14 @@ def core_transforms():
     """Generic Imdct / Fft kernels (any power-of-two size): algorithmic GB/s."""
     ctx = sa.Context(0)
     ctx.use_torch_stream()
-    for n in (32, 64, 128, 256, 512, 1024, 2048, 8192):
+    for n in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
         count = (1 << 27) // n  # 512 MiB of spectra
         spec = torch.randn((count, n), device="cuda")
         out = torch.empty((count, 2 * n), device="cuda")
         im = sa.Imdct(ctx, n, 1.0 / (2 * n))
         t = timeit(lambda: im.imdct(spec, out))
         print("Imdct n=%-5d x %-8d %8.1f GB/s (in + out)  %.3f ms" % (n, count, 3 * spec.numel() * 4 / t / 1e9, t * 1e3))
-    for n in (16, 64, 128, 256, 512, 4096):
+    for n in (16, 64, 128, 256, 512, 1024, 2048, 4096):
         count = (1 << 26) // n  # 512 MiB of complex values
         x = torch.randn((count, n, 2), device="cuda")
         y = torch.empty_like(x)
