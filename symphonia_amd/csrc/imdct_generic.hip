@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64 * kWaveWaves, 2) void imdct_big_wave_kernel(DevT
         // post-twiddle (mdct.rs:94-137): val = tw[p] * conj(X[p]); every value goes to one place in each of the four output
         // vectors (P samples each): one vector per round through the LDS work area, stored 16 B per lane
         float *o = out + t * (size_t)(2 * N);
-#pragma unroll 1
+#pragma unroll
         for (int round = 0; round < 4; ++round) {
 #pragma unroll
             for (int r = 0; r < R; ++r)

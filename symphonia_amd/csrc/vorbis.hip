@@ -627,10 +627,10 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     // (226 VGPRs: two per SIMD) or two 256-thread workgroups (66 KiB of LDS each)
     // every other pair with long blocks of up to 2048 samples: the multi-transform wavefront kernel (vorbis_wave2.hip; 16-byte
     // accesses: the strides must keep every chain 16-byte aligned), unless the build knob keeps the LDS-staged generic kernel
-    const bool wave2_path = !wave_path && bs1_exp <= 11 && spec_stride % 4 == 0 && pcm_stride % 4 == 0 &&
+    const bool wave2_path = !wave_path && spec_stride % 4 == 0 && pcm_stride % 4 == 0 &&
                             ((uintptr_t)d_spectra | (uintptr_t)d_residue | (uintptr_t)d_pcm | (uintptr_t)d_overlap_in | (uintptr_t)d_overlap_out) % 16 == 0 &&
                             SYM_VORBIS_WAVE2;
-    const unsigned seg = choose_segment(ctx, n_chains, nb, wave2_path && bs1_exp <= 10 ? 12 : ((wave_path || wave2_path) ? 8 : (bs1_exp > 11 ? 2 : 8)), 1, 1, 1);
+    const unsigned seg = choose_segment(ctx, n_chains, nb, wave2_path && bs1_exp <= 10 ? 12 : (wave2_path && bs1_exp == 13 ? 6 : ((wave_path || wave2_path) ? 8 : (bs1_exp > 11 ? 2 : 8))), 1, 1, 1);
     const size_t segs = (nb + seg - 1) / seg;
     const size_t grid = n_chains * segs;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;

@@ -18,7 +18,9 @@ namespace symaccel {
 
 namespace {
 
-constexpr int kWaves = 4;
+// wavefronts per workgroup: four; two for long blocks of 4096 / 8192 samples (their overlap arrays are 8 / 16 KiB each)
+template <int MAXE1>
+constexpr int vw2_waves() { return MAXE1 > 11 ? 2 : 4; }
 
 // out[k .. k+3] = ov[k ..] * win[len - 1 - k ..] + y[k ..] * win[k ..], k = 4 c, c = lane, lane + 64, ...  (dsp.rs:140-144)
 __device__ __forceinline__ void ola_span(float *__restrict__ o, const float *ov, const float *y, const float *win, int len, int lane, bool emit) {
@@ -36,12 +38,192 @@ __device__ __forceinline__ void copy_span(float *__restrict__ o, const float *sr
     for (int k = 4 * lane; k < len; k += 256) st_stream(reinterpret_cast<float4 *>(o + k), *reinterpret_cast<const float4 *>(src + k));
 }
 
+// ---- blocks of 4096 and 8192 samples (P = bs / 4 = 1024 or 2048 FFT points): R = P / 512 sub-transforms of 512 points through the
+// register passes, the last log2 R stages in registers (the scheme of imdct_big_wave_kernel, imdct_generic.hip).  The block's output
+// is four vectors of P samples (left half = vec0 | vec1, right half = vec2 | vec3); they pass through the LDS work area ONE AT A
+// TIME: the two left vectors are overlap-added / copied out as they appear (against `overlap`, whose old contents they need), the
+// two right vectors then replace overlap[0 .. bs / 2).  Tables (twiddles, windows, W_1024 | W_2048) are read from global memory:
+// two wavefronts of this size class keep 50 KiB of LDS busy as it is.
+// `keep_below`: overlap[k] for k < keep_below is left as it is (the stale-state rebuild after a short tail; 0 otherwise).
+template <int R, bool FUSED, class LT>
+__device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec, const float *__restrict__ res, const cpx *__restrict__ tw_g,
+                                                 const cpx *__restrict__ w_merge_g, const float *__restrict__ win_long,
+                                                 const float *__restrict__ win_short, int flag, int pflag, int bs0, int bs1, float *ldsf,
+                                                 float *ovl, const LT &lt, int lane_i, float *__restrict__ o, bool emit, int keep_below) {
+    constexpr int P = 512 * R, N = 2 * P;
+    // (every global index below is UNSIGNED and 32 bits wide: a uniform base pointer plus a zero-extended lane offset is one SGPR pair +
+    // one VGPR + an immediate in the instruction; signed 64-bit indices made the compiler keep a 64-bit address per access live across
+    // the whole block loop -- 150 bytes of scratch and no second wavefront per SIMD)
+    const unsigned lane = (unsigned)lane_i;
+    // The table pointers are the same for every block, so the compiler forms the 64-bit address of every table access ONCE, in front of
+    // the block loop, and keeps them all: ~100 address pairs, parked in AGPRs, one wavefront per SIMD.  Passing the (uniform) bases
+    // through an empty asm per block makes the addresses per-block values: a few VALU adds per access instead of 200 registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(tw_g), "+s"(w_merge_g), "+s"(win_long), "+s"(win_short));
+#endif
+    c32 *lds = reinterpret_cast<c32 *>(ldsf);
+    const c32 *tw = reinterpret_cast<const c32 *>(tw_g);
+    c32 x[R][8];
+    {
+        // Lines 2 R m .. 2 R m + 2 R - 1 of m = lane + 64 s are the (even, odd) pairs of the FFT inputs R m + c.  Loads s and 7 - s
+        // are consumed together (the mirrored odd line of load s sits in load 7 - s of lane 63 - lane), one such pair of loads ahead
+        // of the arithmetic: 2 x 2 x R / 2 float4 live instead of all sixteen, and at most 2 R twiddles from global memory at a time.
+        const float4 *src = reinterpret_cast<const float4 *>(spec);
+        const float4 *rs = reinterpret_cast<const float4 *>(res);
+        auto load_pair = [&](int sp, float4 (&a)[R / 2], float4 (&b)[R / 2]) {
+#pragma unroll
+            for (int h = 0; h < R / 2; ++h) {
+                a[h] = ld_stream((src + ((lane + 64u * (unsigned)sp) * (unsigned)(R / 2) + (unsigned)h)));
+                b[h] = ld_stream((src + ((lane + 64u * (unsigned)(7 - sp)) * (unsigned)(R / 2) + (unsigned)h)));
+            }
+            if constexpr (FUSED) {  // lib.rs:289-291: *f *= r
+#pragma unroll
+                for (int h = 0; h < R / 2; ++h) {
+                    const float4 qa = ld_stream((rs + ((lane + 64u * (unsigned)sp) * (unsigned)(R / 2) + (unsigned)h))), qb = ld_stream((rs + ((lane + 64u * (unsigned)(7 - sp)) * (unsigned)(R / 2) + (unsigned)h)));
+                    a[h].x *= qa.x; a[h].y *= qa.y; a[h].z *= qa.z; a[h].w *= qa.w;
+                    b[h].x *= qb.x; b[h].y *= qb.y; b[h].z *= qb.z; b[h].w *= qb.w;
+                }
+            }
+        };
+        const int mirror = (int)((63u - lane) * 4u);
+        float4 a[R / 2], b[R / 2], na[R / 2], nb[R / 2];
+        load_pair(0, a, b);
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            if (sp + 1 < 4) load_pair(sp + 1, na, nb);
+#pragma unroll
+            for (int cc = 0; cc < R; ++cc) {
+                const int cm = R - 1 - cc;
+                // load s = sp: its mirror is in load 7 - sp (b) of lane 63 - lane; load s = 7 - sp: its mirror is in load sp (a)
+                const float odd_b = (cm & 1) ? b[cm >> 1].w : b[cm >> 1].y, odd_a = (cm & 1) ? a[cm >> 1].w : a[cm >> 1].y;
+                const float mir_lo = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(odd_b)));
+                const float mir_hi = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(odd_a)));
+                const float ev_lo = (cc & 1) ? a[cc >> 1].z : a[cc >> 1].x, ev_hi = (cc & 1) ? b[cc >> 1].z : b[cc >> 1].x;
+                x[cc][sp] = pre_twiddle(ev_lo, mir_lo, tw[(unsigned)R * (lane + 64u * (unsigned)sp) + (unsigned)cc]);
+                x[cc][7 - sp] = pre_twiddle(ev_hi, mir_hi, tw[(unsigned)R * (lane + 64u * (unsigned)(7 - sp)) + (unsigned)cc]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < R / 2; ++h) {
+                a[h] = na[h];
+                b[h] = nb[h];
+            }
+        }
+    }
+    // the R sub-transforms and the last stages (imdct_generic.hip: fft_big_regs, restated here on the global twiddle table)
+#pragma unroll
+    for (int r = 0; r < R; ++r) fft_wave_multi(x[R == 2 ? r : ((r & 1) << 1 | (r >> 1))], lane_i, lds, lt, 9);
+    auto blk = [](int r) { return R == 2 ? r : ((r & 1) << 1 | (r >> 1)); };
+    const c32 *wm = reinterpret_cast<const c32 *>(w_merge_g);
+    // (the merge twiddles come from global memory; left alone the scheduler requests all 8 + 16 of them at once and keeps them in
+    // 48 more registers next to the transform: four at a time, with a scheduling fence between the groups)
+#pragma unroll
+    for (int r = 0; r < R; r += 2)
+#pragma unroll
+        for (int B0 = 0; B0 < 8; B0 += 4) {
+#pragma unroll
+            for (int B = B0; B < B0 + 4; ++B) bfly(x[blk(r)][B], x[blk(r + 1)][B], c_mul(x[blk(r + 1)][B], wm[64u * (unsigned)B + lane]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    if constexpr (R == 4) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int B0 = 0; B0 < 8; B0 += 4) {
+#pragma unroll
+                for (int B = B0; B < B0 + 4; ++B) bfly(x[blk(r)][B], x[blk(r + 2)][B], c_mul(x[blk(r + 2)][B], wm[512u + 512u * (unsigned)r + 64u * (unsigned)B + lane]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    // post-twiddle once, in place (mdct.rs:104 / 123): the rounds below only pick components
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int B0 = 0; B0 < 8; B0 += 4) {
+#pragma unroll
+            for (int B = B0; B < B0 + 4; ++B) x[blk(r)][B] = post_twiddle(x[blk(r)][B], tw[512u * (unsigned)r + 64u * (unsigned)B + lane]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    const int bs = 4 * P;
+    const float *win = (flag && pflag) ? win_long : win_short;  // dsp.rs:83
+    const int start = (bs1 - bs0) / 4;
+    // long -> short with a short block of this size: the unity part of the old overlap goes out first (dsp.rs:97)
+    if (emit && pflag && !flag) {
+        for (unsigned k = 4u * lane; k < (unsigned)start; k += 256u) st_stream(reinterpret_cast<float4 *>((o + (k))), *reinterpret_cast<const float4 *>(ovl + k));
+    }
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        // vector `round` -> the work area (mdct.rs:94-137: every FFT bin gives one sample to each of the four vectors)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int B = 0; B < 8; ++B) {
+                const int p = 512 * r + 64 * B + lane_i;
+                const c32 val = x[blk(r)][B];
+                constexpr int n4 = P / 2;
+                float f;
+                int at;
+                if (p < n4) {
+                    f = round == 0 ? -val.y : (round == 1 ? val.y : val.x);
+                    at = (round == 0 || round == 2) ? P - 1 - 2 * p : 2 * p;
+                } else {
+                    const int i = p - n4;
+                    f = round == 0 ? -val.x : (round == 1 ? val.x : val.y);
+                    at = (round == 0 || round == 2) ? 2 * i : P - 1 - 2 * i;
+                }
+                ldsf[at] = f;
+            }
+        wave_sync();
+        if (round < 2) {
+            if (emit) {
+                const int k0 = round * P;  // the work area holds left[k0 .. k0 + P)
+                for (unsigned kk = 4u * lane; kk < (unsigned)P; kk += 256u) {
+                    const unsigned k = (unsigned)k0 + kk;
+                    const float4 y = *reinterpret_cast<const float4 *>(ldsf + kk);
+                    if (pflag == flag) {  // dsp.rs:85-90 over bs / 2 samples
+                        const float4 a = *reinterpret_cast<const float4 *>(ovl + k);
+                        const float4 wf = *reinterpret_cast<const float4 *>((win + (k))), wr = *reinterpret_cast<const float4 *>((win + ((unsigned)(N - 4) - k)));
+                        st_stream(reinterpret_cast<float4 *>((o + (k))),
+                                  make_float4(a.x * wr.w + y.x * wf.x, a.y * wr.z + y.y * wf.y, a.z * wr.y + y.z * wf.z, a.w * wr.x + y.w * wf.w));
+                    } else if (pflag) {  // long -> short (dsp.rs:91-106): out[start + k] = overlap[start + k] * ws[len-1-k] + imdct[k] * ws[k]
+                        const unsigned len = (unsigned)bs0 / 2u;
+                        const float4 a = *reinterpret_cast<const float4 *>(ovl + (unsigned)start + k);
+                        const float4 wf = *reinterpret_cast<const float4 *>((win + (k))), wr = *reinterpret_cast<const float4 *>((win + (len - 4u - k)));
+                        st_stream(reinterpret_cast<float4 *>((o + ((unsigned)start + k))),
+                                  make_float4(a.x * wr.w + y.x * wf.x, a.y * wr.z + y.y * wf.y, a.z * wr.y + y.z * wf.z, a.w * wr.x + y.w * wf.w));
+                    } else {  // short -> long (dsp.rs:107-122): imdct[start .. end) laps with overlap[0 .. len), imdct[end ..) is copied
+                        const unsigned len = (unsigned)bs0 / 2u, end = (unsigned)start + len;
+                        if (k >= (unsigned)start && k < end) {
+                            const unsigned j = k - (unsigned)start;
+                            const float4 a = *reinterpret_cast<const float4 *>(ovl + j);
+                            const float4 wf = *reinterpret_cast<const float4 *>((win + (j))), wr = *reinterpret_cast<const float4 *>((win + (len - 4u - j)));
+                            st_stream(reinterpret_cast<float4 *>((o + (j))),
+                                      make_float4(a.x * wr.w + y.x * wf.x, a.y * wr.z + y.y * wf.y, a.z * wr.y + y.z * wf.z, a.w * wr.x + y.w * wf.w));
+                        } else if (k >= end) {
+                            st_stream(reinterpret_cast<float4 *>((o + (len + (k - end)))), y);
+                        }
+                    }
+                }
+            }
+        } else {
+            const int k0 = (round - 2) * P;  // overlap[k0 .. k0 + P) = this vector (dsp.rs:125)
+            for (int kk = 4 * lane_i; kk < P; kk += 256)
+                if (k0 + kk >= keep_below) *reinterpret_cast<float4 *>(ovl + k0 + kk) = *reinterpret_cast<const float4 *>(ldsf + kk);
+        }
+        wave_sync();
+    }
+    (void)bs;
+}
+
 // MAXE1: the largest long-block exponent the instantiation serves.  Up to 1024-sample long blocks the tables and the overlap
 // arrays are half the size and three workgroups fit a CU (52 KiB of LDS each, <= 168 VGPRs): the kernel is bound by the latency
 // of a group's dependent steps, and a third wavefront per SIMD is worth more than anything else here.  (The fused variant carries
 // sixteen more registers -- the prefetched residue lines -- and would spill at 168: it stays at two wavefronts per SIMD.)
-template <bool FUSED, int MAXE1>
-__global__ __launch_bounds__(64 * kWaves, (MAXE1 <= 10 && !FUSED) ? 3 : 2) void vorbis_synth_wave2_kernel(
+// BIG0 (big-block instantiations): 0 = the short blocks are at most 2048 samples (group path), 2 / 4 = they are 4096 / 8192 samples
+// themselves.  One instantiation per case so that a kernel holds one copy of each block routine it needs and no other: everything a
+// routine keeps loop-invariant (addresses, table pointers) is live across the block loop, and the copies add up.
+template <bool FUSED, int MAXE1, int BIG0 = 0>
+__global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void vorbis_synth_wave2_kernel(
     DevTables tb, int e0, int e1, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
     const float *__restrict__ residue, size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
@@ -49,22 +231,41 @@ __global__ __launch_bounds__(64 * kWaves, (MAXE1 <= 10 && !FUSED) ? 3 : 2) void 
     float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs, unsigned nb, unsigned seg_len,
     unsigned segs_per_chain, unsigned n_items) {
     // shared tables: Imdct twiddles and left window halves of both block sizes (bs / 2 floats each)
-    __shared__ __attribute__((aligned(16))) float tabs[2 << MAXE1];
+    constexpr bool kBig = MAXE1 > 11;  // long blocks of 4096 / 8192 samples: tables stay in global memory, see vorbis_big_block
+    constexpr int kWaves = vw2_waves<MAXE1>();
+    __shared__ __attribute__((aligned(16))) float tabs[kBig ? 4 : (2 << MAXE1)];
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
     __shared__ __attribute__((aligned(16))) float wave_ovl[kWaves][(1 << MAXE1) / 2];
     const int bs0 = 1 << e0, bs1 = 1 << e1;
-    float *t_twl = tabs, *t_wl = tabs + bs1 / 2, *t_tws = tabs + bs1, *t_ws = tabs + bs1 + bs0 / 2;
-    for (int i = (int)threadIdx.x; i < bs1 / 2; i += 64 * kWaves) {
-        t_twl[i] = reinterpret_cast<const float *>(tw_long)[i];
-        t_wl[i] = win_long[i];
-        if (i < bs0 / 2) {
-            t_tws[i] = reinterpret_cast<const float *>(tw_short)[i];
-            t_ws[i] = win_short[i];
+    const float *t_twl, *t_wl, *t_tws, *t_ws;
+    __shared__ __attribute__((aligned(16))) c32 lane_tab[kBig ? kLaneTabComplex : 1];
+    if constexpr (kBig) {
+        t_twl = reinterpret_cast<const float *>(tw_long);
+        t_wl = win_long;
+        t_tws = reinterpret_cast<const float *>(tw_short);
+        t_ws = win_short;
+        fill_lane_tables_lds(tb, lane_tab, (int)threadIdx.x, 64 * kWaves);
+        __syncthreads();
+    } else {
+        float *l_twl = tabs, *l_wl = tabs + bs1 / 2, *l_tws = tabs + bs1, *l_ws = tabs + bs1 + bs0 / 2;
+        for (int i = (int)threadIdx.x; i < bs1 / 2; i += 64 * kWaves) {
+            l_twl[i] = reinterpret_cast<const float *>(tw_long)[i];
+            l_wl[i] = win_long[i];
+            if (i < bs0 / 2) {
+                l_tws[i] = reinterpret_cast<const float *>(tw_short)[i];
+                l_ws[i] = win_short[i];
+            }
         }
+        t_twl = l_twl;
+        t_wl = l_wl;
+        t_tws = l_tws;
+        t_ws = l_ws;
+        __syncthreads();  // the only workgroup-wide barrier
     }
-    __syncthreads();  // the only workgroup-wide barrier
 
-    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    // (the wavefront index through readfirstlane: the compiler then knows that the chain, and every pointer derived from it, is
+    // wave-uniform and keeps them in SGPRs instead of a 64-bit VGPR pair each)
+    const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const unsigned item = blockIdx.x * kWaves + (unsigned)wave;
     if (item >= n_items) return;
     float *ldsf = wave_lds[wave];
@@ -78,8 +279,17 @@ __global__ __launch_bounds__(64 * kWaves, (MAXE1 <= 10 && !FUSED) ? 3 : 2) void 
     const float *rp = FUSED ? residue + (size_t)chain * spec_stride : nullptr;
     float *out = pcm + (size_t)chain * pcm_stride;
     const int pf0 = prev_flag_in[chain];
-    LaneTables lt;
-    load_lane_tables(tb, lane, lt);
+    // (the big-block instantiations read the FFT's lane twiddles from an LDS copy: 31 VGPRs less in a kernel that holds a whole
+    // 2048-point transform in registers)
+    auto lt = [&]() {
+        if constexpr (kBig) {
+            return lane_tables_lds(tb, lane_tab, lane);
+        } else {
+            LaneTables l;
+            load_lane_tables(tb, lane, l);
+            return l;
+        }
+    }();
 
     // overlap (dsp.rs:125): the caller's state at a chain's start; zero in front of a later segment, whose halo block rebuilds
     // the part the next block reads
@@ -97,7 +307,7 @@ __global__ __launch_bounds__(64 * kWaves, (MAXE1 <= 10 && !FUSED) ? 3 : 2) void 
     };
     long wbase = b_first;
     unsigned long long m0 = load_mask(wbase), m1 = load_mask(wbase + 64);
-    const int cap0 = 2048 >> e0, cap1 = 2048 >> e1;  // blocks per group
+    const int cap0 = e0 > 11 ? 1 : 2048 >> e0, cap1 = e1 > 11 ? 1 : 2048 >> e1;  // blocks per group (one of 4096 / 8192 samples)
     // A group = a run of consecutive blocks with one flag, at most 2048 / bs of them, never crossing b_end.
     auto group_at = [&](long bb, int &flag_out) -> int {
         if (bb >= (long)b_end) {
@@ -132,18 +342,74 @@ __global__ __launch_bounds__(64 * kWaves, (MAXE1 <= 10 && !FUSED) ? 3 : 2) void 
         multi_fetch(sp + off, valid, lane, v);
         if constexpr (FUSED) multi_fetch(rp + off, valid, lane, r);
     };
-    if (glen > 0) fetch(os_cur, flag, glen);
+    // (the big-block instantiations do not prefetch: 16 / 32 registers that would be live across a 2048-point transform)
+    if (!kBig && glen > 0) fetch(os_cur, flag, glen);
 
-    while (b < (long)b_end) {
+    // The walk, then -- at a chain's end, if no long block refreshed overlap[bs0/2 .. bs1/2) in this segment -- ONE more trip through
+    // the same loop body for the most recent long block in front of the segment (`rebuild`: nothing is emitted, only the upper part
+    // of `overlap` is taken from it): dsp.rs:125 rewrites only the first bs / 2 entries, so that part is still what that block left,
+    // never used for PCM but part of the state the reference carries.  With no such block the incoming state is kept.
+    bool rebuild = false;
+    int keep_below = 0;
+    while (true) {
+        if (b >= (long)b_end) {
+            if (rebuild || b_end != nb || hi_fresh) break;
+            long bl = -1;
+            for (long base = ((long)b_begin - 1) & ~63l; base >= 0; base -= 64) {
+                const long idx = base + lane;
+                const unsigned long long m = __ballot(idx < (long)b_begin && f[idx] != 0);
+                if (m) {
+                    bl = base + 63 - __builtin_clzll(m);
+                    break;
+                }
+            }
+            if (bl < 0) {
+                for (int k = bs0 / 2 + 4 * lane; k < bs1 / 2; k += 256)
+                    *reinterpret_cast<float4 *>(ovl + k) = *reinterpret_cast<const float4 *>(overlap_in + (size_t)chain * (size_t)(bs1 / 2) + k);
+                wave_sync();
+                break;
+            }
+            rebuild = true;
+            keep_below = bs0 / 2;
+            b = bl;
+            glen = 1;
+            flag = pflag = 1;
+            os_cur = os[bl];
+            if constexpr (!kBig) fetch(os_cur, 1, 1);
+        }
         const int e = flag ? e1 : e0, bs = 1 << e, logp = e - 2, P = 1 << logp;
         const long nb_next = b + glen;
         int flag_next = 1;
-        const int glen_next = group_at(nb_next, flag_next);
+        const int glen_next = rebuild ? 0 : group_at(nb_next, flag_next);
         const uint32_t os_next = os_cur + ((uint32_t)glen << (e - 1));
         const c32 *tw = reinterpret_cast<const c32 *>(flag ? t_twl : t_tws);
         hi_fresh = hi_fresh || flag;
+        const bool emit = !rebuild && b >= (long)b_begin;
+        if constexpr (kBig) {
+            if (e > 11) {
+                // ---- one block of 4096 / 8192 samples (a group of its own)
+                const cpx *twg = flag ? tw_long : tw_short;
+                constexpr int R1 = MAXE1 == 12 ? 2 : 4;
+                if (BIG0 == 0 || BIG0 == R1 || flag)
+                    vorbis_big_block<R1, FUSED>(sp + os_cur, FUSED ? rp + os_cur : nullptr, twg, tb.fft_merge + 480, win_long, win_short, flag, pflag, bs0,
+                                                bs1, ldsf, ovl, lt, lane, out + op_cur, emit, keep_below);
+                else if constexpr (BIG0 != 0 && BIG0 != R1)
+                    vorbis_big_block<BIG0, FUSED>(sp + os_cur, FUSED ? rp + os_cur : nullptr, twg, tb.fft_merge + 480, win_long, win_short, flag, pflag, bs0,
+                                                  bs1, ldsf, ovl, lt, lane, out + op_cur, emit, keep_below);
+                if (rebuild) break;
+                op_cur += (uint32_t)((pflag ? bs1 : bs0) + bs) >> 2;
+                os_cur = os_next;
+                pflag = flag;
+                b = nb_next;
+                glen = glen_next;
+                flag = flag_next;
+                continue;
+            }
+        }
+        if constexpr (BIG0 == 0) {
 
         // ---- the group's lines -> LDS (natural order), multiplied by the residue on the way (lib.rs:289-291: *f *= r)
+        if constexpr (kBig) fetch(os_cur, flag, glen);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 x = v[q];
@@ -156,7 +422,7 @@ __global__ __launch_bounds__(64 * kWaves, (MAXE1 <= 10 && !FUSED) ? 3 : 2) void 
             reinterpret_cast<float4 *>(ldsf)[lane + 64 * q] = x;
         }
         wave_sync();
-        if (glen_next > 0) fetch(os_next, flag_next, glen_next);  // the next group travels while this one is transformed
+        if (!kBig && glen_next > 0) fetch(os_next, flag_next, glen_next);  // the next group travels while this one is transformed
         c32 z[8];
         {
             const int gbits = logp - 3, G = 1 << gbits;
@@ -176,7 +442,6 @@ __global__ __launch_bounds__(64 * kWaves, (MAXE1 <= 10 && !FUSED) ? 3 : 2) void 
 
         // ---- the group's first block against `overlap` (dsp.rs:85-122)
         {
-            const bool emit = b >= (long)b_begin;
             float *o = out + op_cur;
             const float *left = ldsf;
             if (pflag == flag) {
@@ -211,73 +476,20 @@ __global__ __launch_bounds__(64 * kWaves, (MAXE1 <= 10 && !FUSED) ? 3 : 2) void 
         // overlap[..bs / 2) = right half of the run's last block (dsp.rs:125); what lies above stays
         {
             const float *right = ldsf + (size_t)(glen - 1) * bs + (bs >> 1);
-            for (int k = 4 * lane; k < bs / 2; k += 256) *reinterpret_cast<float4 *>(ovl + k) = *reinterpret_cast<const float4 *>(right + k);
+            for (int k = keep_below + 4 * lane; k < bs / 2; k += 256) *reinterpret_cast<float4 *>(ovl + k) = *reinterpret_cast<const float4 *>(right + k);
         }
         wave_sync();  // the work area is overwritten by the next group
+        if (rebuild) break;
         op_cur += first_len + (uint32_t)(glen - 1) * (uint32_t)(bs >> 1);
         os_cur = os_next;
         pflag = flag;
         b = nb_next;
         glen = glen_next;
         flag = flag_next;
+        }  // BIG0 == 0
     }
 
     if (b_end == nb) {
-        if (!hi_fresh) {
-            // The chain ends in short blocks and this segment never saw a long one: overlap[bs0/2 .. bs1/2) still holds what the
-            // most recent long block left there (dsp.rs:125 only rewrites the first bs / 2 entries; never used for PCM, but part
-            // of the state the reference carries).  Rebuild it from that block, or keep the incoming state if the batch has no
-            // long block in front of this segment.
-            long bl = -1;
-            for (long base = ((long)b_begin - 1) & ~63l; base >= 0; base -= 64) {
-                const long idx = base + lane;
-                const unsigned long long m = __ballot(idx < (long)b_begin && f[idx] != 0);
-                if (m) {
-                    bl = base + 63 - __builtin_clzll(m);
-                    break;
-                }
-            }
-            if (bl >= 0) {
-                const int logp = e1 - 2, P = 1 << logp;
-                const c32 *tw = reinterpret_cast<const c32 *>(t_twl);
-                multi_fetch(sp + os[bl], (size_t)bs1 / 2, lane, v);
-                if constexpr (FUSED) multi_fetch(rp + os[bl], (size_t)bs1 / 2, lane, r);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 x = v[q];
-                    if constexpr (FUSED) {
-                        x.x *= r[q].x;
-                        x.y *= r[q].y;
-                        x.z *= r[q].z;
-                        x.w *= r[q].w;
-                    }
-                    reinterpret_cast<float4 *>(ldsf)[lane + 64 * q] = x;
-                }
-                wave_sync();
-                c32 z[8];
-                {
-                    const int gbits = logp - 3, G = 1 << gbits;
-                    const int T = lane >> gbits, u = lane & (G - 1);
-                    const float *sT = ldsf + ((size_t)T << (logp + 1));
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        const int i = u + (s << gbits);
-                        const float2 pr = *reinterpret_cast<const float2 *>(sT + 2 * i);
-                        z[s] = pre_twiddle(pr.x, sT[2 * P - 1 - 2 * i], tw[i]);
-                    }
-                }
-                wave_sync();
-                fft_wave_multi(z, lane, lds, lt, logp);
-                multi_post_twiddle(z, lane, logp, tw, ldsf);
-                wave_sync();
-                for (int k = bs0 / 2 + 4 * lane; k < bs1 / 2; k += 256)
-                    *reinterpret_cast<float4 *>(ovl + k) = *reinterpret_cast<const float4 *>(ldsf + bs1 / 2 + k);
-            } else {
-                for (int k = bs0 / 2 + 4 * lane; k < bs1 / 2; k += 256)
-                    *reinterpret_cast<float4 *>(ovl + k) = *reinterpret_cast<const float4 *>(overlap_in + (size_t)chain * (size_t)(bs1 / 2) + k);
-            }
-            wave_sync();
-        }
         for (int k = 4 * lane; k < bs1 / 2; k += 256)
             *reinterpret_cast<float4 *>(overlap_out + (size_t)chain * (size_t)(bs1 / 2) + k) = *reinterpret_cast<const float4 *>(ovl + k);
         if (lane == 0) prev_flag_out[chain] = f[nb - 1] ? 1 : 0;  // lib.rs:328
@@ -293,18 +505,37 @@ int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *
                         unsigned seg) {
     const size_t segs = (nb + seg - 1) / seg;
     const size_t items = n_chains * segs;
+    const size_t kWaves = bs1_exp > 11 ? 2 : 4;
     const size_t grid = (items + kWaves - 1) / kWaves;
     if (items > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+#define SYM_VW2_LAUNCH3(FUSED, MAXE1, BIG0)                                                                                                  \
+    hipLaunchKernelGGL((vorbis_synth_wave2_kernel<FUSED, MAXE1, BIG0>), dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, bs0_exp, \
+                       bs1_exp, tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, \
+                       d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs, (unsigned)items)
 #define SYM_VW2_LAUNCH(FUSED, MAXE1)                                                                                                        \
     hipLaunchKernelGGL((vorbis_synth_wave2_kernel<FUSED, MAXE1>), dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, bs0_exp, \
                        bs1_exp, tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, \
                        d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs, (unsigned)items)
     if (bs1_exp <= 10) {
         if (d_residue) SYM_VW2_LAUNCH(true, 10); else SYM_VW2_LAUNCH(false, 10);
-    } else {
+    } else if (bs1_exp == 11) {
         if (d_residue) SYM_VW2_LAUNCH(true, 11); else SYM_VW2_LAUNCH(false, 11);
+    } else {
+        // the big-block instantiations: by long size and by whether the short size is big as well
+        const int big0 = bs0_exp <= 11 ? 0 : (bs0_exp == 12 ? 2 : 4);
+#define SYM_VW2_BIG(FUSED)                                                                      \
+    do {                                                                                        \
+        if (bs1_exp == 12) {                                                                    \
+            if (big0 == 0) SYM_VW2_LAUNCH3(FUSED, 12, 0); else SYM_VW2_LAUNCH3(FUSED, 12, 2);   \
+        } else if (big0 == 0) SYM_VW2_LAUNCH3(FUSED, 13, 0);                                    \
+        else if (big0 == 2) SYM_VW2_LAUNCH3(FUSED, 13, 2);                                      \
+        else SYM_VW2_LAUNCH3(FUSED, 13, 4);                                                     \
+    } while (0)
+        if (d_residue) SYM_VW2_BIG(true); else SYM_VW2_BIG(false);
+#undef SYM_VW2_BIG
     }
 #undef SYM_VW2_LAUNCH
+#undef SYM_VW2_LAUNCH3
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -118,9 +118,11 @@ def test_emu_vorbis_synth(emu_ctx, bs0e, bs1e, seg):
 
 @pytest.mark.parametrize("bs0e,bs1e,nb,p_long,seg", [(7, 10, 150, 0.6, 1000), (6, 9, 140, 0.3, 37), (8, 10, 70, 0.75, 5), (6, 7, 200, 0.5, 64),
                                                       (9, 11, 40, 0.5, 7), (10, 11, 33, 0.2, 1), (11, 11, 20, 0.5, 3), (6, 11, 90, 0.1, 13),
-                                                      (7, 7, 77, 0.5, 10), (9, 9, 30, 1.0, 4), (6, 10, 100, 0.0, 33)])
+                                                      (7, 7, 77, 0.5, 10), (9, 9, 30, 1.0, 4), (6, 10, 100, 0.0, 33),
+                                                      (9, 12, 40, 0.6, 6), (10, 13, 24, 0.5, 5), (12, 12, 12, 0.5, 3), (12, 13, 14, 0.5, 4),
+                                                      (13, 13, 7, 0.4, 2), (6, 13, 60, 0.3, 9), (11, 12, 30, 0.7, 1000), (8, 12, 50, 0.2, 3)])
 def test_emu_vorbis_register_pass_kernel_pairs(emu_ctx, bs0e, bs1e, nb, p_long, seg):
-    """vorbis_synth_wave2_kernel (every pair with long blocks of up to 2048 samples except 256 / 2048): runs longer than a group
+    """vorbis_synth_wave2_kernel (every pair except 256 / 2048; blocks of 4096 / 8192 samples on its big-block path): runs longer than a group
     holds (2048 / bs blocks), runs across the 64-block flag masks, every transition, segment halos, equal sizes, chains of one
     flag only, the stale-state fix-up after a short tail, arbitrary incoming overlap."""
     rng = np.random.default_rng(1000 * bs0e + 10 * bs1e + nb)

@@ -48,7 +48,7 @@ def run(e0, e1, p_ll=0.9, p_ss=0.7):
     t = a.elapsed_time(b) / 10
     byts = 4 * (so[:, -1].sum() + po[:, -1].sum())
     print("%4d / %-5d  %6d blocks/chain  long share %.2f  %.3f ms  %.2f TB/s (%.1f %% of 8 TB/s)" % (
-        1 << e0, 1 << e1, nb, flags.mean(), t, byts / t / 1e9, byts / t / 1e9 / 8000 * 100))
+        1 << e0, 1 << e1, nb, flags.mean(), t, byts / t / 1e9, byts / t / 1e9 / 8 * 100))
 
 
 for e0, e1 in ((8, 11), (7, 10), (9, 12), (6, 9), (8, 10), (10, 13), (11, 11)):
