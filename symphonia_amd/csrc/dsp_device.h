@@ -57,9 +57,29 @@ __device__ __forceinline__ float2 ld_stream(const float2 *p) { return *p; }
 __device__ __forceinline__ float4 ld_stream(const float4 *p) { return *p; }
 __device__ __forceinline__ int4 ld_stream(const int4 *p) { return *p; }
 #endif
+// SYM_ST_POLICY (build knob, measurement): the cache-policy bits of the 16-byte PCM stores -- 0: nt (the default, what
+// __builtin_nontemporal_store emits), 1: sc1 nt, 2: sc0 sc1 nt, 3: sc0 sc1 (system scope, temporal), 4: sc1.
+#ifndef SYM_ST_POLICY
+#define SYM_ST_POLICY 0
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && (SYM_NT & 2)
 __device__ __forceinline__ void st_stream(float4 *p, float4 v) {
+#if SYM_ST_POLICY == 0
     __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4 *>(p));
+#else
+    const nt_f4 x{v.x, v.y, v.z, v.w};
+#if SYM_ST_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(x) : "memory");
+#elif SYM_ST_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(x) : "memory");
+#elif SYM_ST_POLICY == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+#elif SYM_ST_POLICY == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+#else  // 5: nt again, through the same inline asm (the control for 1..4: the compiler's waitcnt bookkeeping does not see asm stores)
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(x) : "memory");
+#endif
+#endif
 }
 __device__ __forceinline__ void st_stream(int4 *p, int4 v) {
     __builtin_nontemporal_store(nt_i4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_i4 *>(p));
