@@ -294,6 +294,7 @@ void symaccel_ctx_destroy(symaccel_ctx *ctx) {
     if (ctx->stage_out) (void)hipStreamSynchronize(ctx->stage_out);
     if (ctx->stage_arena) (void)hipFree(ctx->stage_arena);
     if (ctx->alac_flags) (void)hipFree(ctx->alac_flags);
+    if (ctx->mp3_sink) (void)hipFree(ctx->mp3_sink);
     for (hipEvent_t e : ctx->stage_events)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stage_in) (void)hipStreamDestroy(ctx->stage_in);

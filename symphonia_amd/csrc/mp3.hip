@@ -38,7 +38,15 @@ namespace {
 //      it is produced (4 B per lane, 128 B per half-wave and instruction);
 //   2  the granule's PCM is collected in an LDS tile and stored as float4 (16 B per lane) when the window pass is done;
 //      four wavefronts per workgroup share the window tables, which pays for the extra 4.5 KiB of LDS per wavefront;
-//   3  two granules of spectral lines in flight instead of one.
+//   3  two granules of spectral lines in flight instead of one;
+//   4  prefetch and PCM stores issued unconditionally, the prefetched lines consumed at the end of the round (SYM_MP3_SINK
+//      below): the waits are for the lines only -- measured equal (profiles/r03k_mp3_sink_ab.txt), i.e. the write
+//      acknowledgements were not what the kernel waits for.
+// Round 3's measurements (tools/ubench/valu_clock.hip, tools/mp3_clock_probe.py): the loads and stores alone
+// run at 5.3-5.6 TB/s (SYM_MP3_ABLATE); a wavefront issues one instruction per ~4.9 cycles, a SIMD's VALU port accepts one
+// plain f32 instruction per ~2.5 cycles, so two wavefronts saturate it and the third of a SIMD gets the leftovers (walks of 45
+// rounds finish after 212 / 231 / 315 us on every SIMD); under this kernel's VALU + LDS + HBM load the part clocks at 1.7 GHz
+// (2.3 GHz for the same loads and stores without the arithmetic).  The kernel is bound by VALU issue at a throttled clock.
 #define SYM_MP3_OTILE (SYM_MP3_VARIANT == 2)
 #define SYM_MP3_PREFETCH2 (SYM_MP3_VARIANT == 3)
 #ifndef SYM_MP3_WG_WAVES
@@ -152,21 +160,50 @@ __device__ __forceinline__ void fetch_granule(const float *granule, int hl, floa
     line[4] = ld_stream(src + 128 + (hl & 15));  // lanes 16..31 re-read float4 128..143 (same cache lines) and ignore it
 }
 
-#ifndef SYM_MP3_VARIANT
-#define SYM_MP3_VARIANT 0
+#ifndef SYM_MP3_PACKED
+#define SYM_MP3_PACKED 0
 #endif
-
+// SYM_MP3_PACKED 1: the window pass computes TWO time slots per instruction stream with v_pk_mul_f32 / v_pk_add_f32 (the two
+// 16-tap sums of slots 2p and 2p + 1 are independent and use the same coefficients).  A wavefront issues at most one
+// instruction per ~4.9 cycles whatever the instruction is (tools/ubench/valu_clock.hip), a packed instruction costs one
+// such slot and ~1.7 plain ones on the SIMD's VALU port: 288 issue slots instead of 576 per granule pair.  The V history
+// is kept as register PAIRS of raw dct32 outputs: HA[t] / HB[t], t = 16 + slot (t < 16: the previous granule), with
+//   PA[k] = (HA[2k], HA[2k + 1]),  PB[k] = (HB[2k - 1], HB[2k]),
+// so that both operand pairs of slot pair p and tap j are the aligned pairs PA[8 + p - j], PB[8 + p - j].  The signs of
+// synthesis.rs:247-263 (V[i] = +-d[..], V[32 + i] = -d[..]) are folded into the lane's window coefficients -- (-a) * d and
+// a * (-d) are the same bits -- and applied to the history only where it enters or leaves the kernel.
+typedef float v2f __attribute__((vector_size(8)));  // (GCC / clang vector extension: the emulation build is g++)
+#ifndef SYM_MP3_PAIR_GROUP
+#define SYM_MP3_PAIR_GROUP 3
+#endif
+#ifndef SYM_MP3_CLOCK
+#define SYM_MP3_CLOCK 0
+#endif
+#ifndef SYM_MP3_ABLATE
+#define SYM_MP3_ABLATE 0
+#endif
 #ifndef SYM_MP3_SLOT_GROUP
 #define SYM_MP3_SLOT_GROUP 3
 #endif
 #ifndef SYM_MP3_WAVES
 #define SYM_MP3_WAVES 3  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
 #endif
+// SYM_MP3_SINK (variant 4): gfx950 has ONE in-order counter for vector loads and stores (vmcnt).  With the PCM stores inside
+// `if (emit)` and the prefetch inside `if (r + 1 < my_rounds)` the compiler cannot know how many stores follow the prefetch,
+// and at the loop header it also has to honour the state of the loop's entry (the first fetch, no store behind it): it waits
+// with vmcnt(5) ... vmcnt(0), i.e. until the stores issued a few instructions earlier are acknowledged by memory as well --
+// the write latency was exposed once per round.  Here every round issues its prefetch and its 18 stores unconditionally
+// (lanes that must not emit -- halo rounds, an idle half-wave -- aim at a per-wavefront slot of a sink buffer; a half-wave
+// without a next granule re-reads granule 0), and the prefetched lines are consumed at the END of the round body, in the
+// same straight-line region: the waits become vmcnt(22) ... vmcnt(18), for the lines only.
+#define SYM_MP3_SINK (SYM_MP3_VARIANT == 4)
+constexpr int kSinkSlotFloats = 2048;  // 8 KiB per wavefront slot: two half-waves x 18 rows of 128 B
+constexpr int kSinkSlots = 256;
 __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVES, SYM_MP3_WAVES))) void mp3_synth_kernel(
     DevTables tb, const float *__restrict__ xr, const symaccel_mp3_side *__restrict__ side, int sr,
     const float *__restrict__ overlap_in, const float *__restrict__ vvec_in, const int32_t *__restrict__ vfront_in,
     float *__restrict__ overlap_out, float *__restrict__ vvec_out, int32_t *__restrict__ vfront_out,
-    float *__restrict__ pcm, unsigned n_chains, unsigned granules_per_chain, unsigned seg_len,
+    float *__restrict__ pcm, float *__restrict__ sink, unsigned n_chains, unsigned granules_per_chain, unsigned seg_len,
     unsigned segs_per_chain) {
     __shared__ __attribute__((aligned(16))) float lds_tab[kTabFloats];
     __shared__ __attribute__((aligned(16))) float lds_wave[kWgWaves][kWaveFloats];
@@ -186,8 +223,13 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
     if ((int)threadIdx.x < 32) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+#if SYM_MP3_PACKED
+            dwt[hl * kDwStride + j] = __uint_as_float(__float_as_uint(tb.mp3_consts[MP3C_SYNTH_D + 64 * j + hl]) ^ vmapx(hl).fsign);
+            dwt[hl * kDwStride + 8 + j] = -tb.mp3_consts[MP3C_SYNTH_D + 64 * j + 32 + hl];
+#else
             dwt[hl * kDwStride + j] = tb.mp3_consts[MP3C_SYNTH_D + 64 * j + hl];
             dwt[hl * kDwStride + 8 + j] = tb.mp3_consts[MP3C_SYNTH_D + 64 * j + 32 + hl];
+#endif
         }
     }
     float *imdct_win = lds_tab + kDwFloats;  // the four 36-entry IMDCT windows (hybrid_synthesis.rs:31-101)
@@ -200,14 +242,28 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
     const unsigned g_begin = seg * seg_len;
     const unsigned g_end = live ? min(g_begin + seg_len, granules_per_chain) : g_begin;
     const VMapX vm = vmapx(hl);
+#if SYM_MP3_CLOCK
+    const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
+#endif
 
     // ---- incoming state.  oA[16 + r] = V_r[i], oB[16 + r] = V_r[32 + i] for the previous granules' time slots r < 0
-    float overlap[18], oA[kHistOld], oB[kHistOld];
+    float overlap[18];
+#if SYM_MP3_PACKED
+    v2f PA[17], PB[18];
+#define SYM_HA(t) PA[(t) / 2][(t) & 1]              /* HA[t], t = 0..33 */
+#define SYM_HB(t) PB[((t) + 1) / 2][((t) + 1) & 1]  /* HB[t], t = -1..34 */
+#pragma unroll
+    for (int k = 0; k < 17; ++k) PA[k] = v2f{0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 18; ++k) PB[k] = v2f{0.0f, 0.0f};
+#else
+    float oA[kHistOld], oB[kHistOld];
+#pragma unroll
+    for (int r = 0; r < kHistOld; ++r) oA[r] = oB[r] = 0.0f;
+#endif
     const bool first_seg = g_begin == 0;
 #pragma unroll
     for (int i = 0; i < 18; ++i) overlap[i] = 0.0f;
-#pragma unroll
-    for (int r = 0; r < kHistOld; ++r) oA[r] = oB[r] = 0.0f;
     if (live && first_seg) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) overlap[i] = overlap_in[(size_t)chain * 576 + 18 * hl + i];
@@ -216,8 +272,13 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
 #pragma unroll
         for (int m = 1; m <= kHistOld; ++m) {  // slot -m sits in FIFO row (v_front + m) & 15 (synthesis.rs:335)
             const float *row = vv + 64 * ((v_front + m) & 15);
+#if SYM_MP3_PACKED
+            SYM_HA(kHistOld - m) = __uint_as_float(__float_as_uint(row[hl]) ^ vm.fsign);
+            SYM_HB(kHistOld - m) = -row[32 + hl];
+#else
             oA[kHistOld - m] = row[hl];
             oB[kHistOld - m] = row[32 + hl];
+#endif
         }
     }
 
@@ -269,27 +330,76 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
     }
 #endif
 
+#if SYM_MP3_SINK
+    {   // round 0's granule -> LDS tile (later rounds: at the end of the round before)
+        float4 *t4 = reinterpret_cast<float4 *>(tile);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
+        if (hl < 16) t4[128 + hl] = line[4];
+    }
+    uint32_t sd_cur = sd_next;
+    asm volatile("" : "+v"(sd_cur));
+#endif
     for (int r = 0; r < rounds; ++r, ++gi) {
         unsigned hlg = (unsigned)hl;  // the lane's offset in global addresses, opaque for the same reason as gi:
         asm volatile("" : "+v"(gi), "+v"(hlg));  // keeps the address arithmetic in the loop (see above)
         const bool active = r < my_rounds;
         const bool need_hist = active && r >= hist_from;  // halo granule g_begin-2 only rebuilds overlap
         const bool emit = active && r >= emit_from;
+#if SYM_MP3_ABLATE
+        {   // measurement only (results wrong by construction): the loads and the stores of a round, nothing else.
+            // 1: 18 four-byte stores per lane (the product's store pattern); 2: five 16-byte stores
+            float4 cur[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) cur[q] = line[q];
+            const unsigned gn = r + 1 < my_rounds ? gi + 1u : 0u;
+            fetch_granule(xr + (size_t)gn * 576, (int)hlg, line);
+            sd_next = side_raw[gn];
+            unsigned tid3 = threadIdx.x;
+            asm volatile("" : "+v"(tid3));
+            float *sink_lane = sink + (size_t)((blockIdx.x * (unsigned)kWgWaves + (tid3 >> 6)) % (unsigned)kSinkSlots) * kSinkSlotFloats +
+                               ((tid3 >> 5) & 1u) * 576u;
+            float *base = emit ? pcm + (size_t)gi * 576 : sink_lane;
+            if (SYM_MP3_ABLATE == 1) {
+#pragma unroll
+                for (int b = 0; b < 18; ++b) {
+                    const float4 v = cur[b % 5];
+                    st_stream(base + 32 * b + hlg, (b / 5) == 0 ? v.x : ((b / 5) == 1 ? v.y : ((b / 5) == 2 ? v.z : v.w)));
+                }
+            } else {
+                float4 *dst = reinterpret_cast<float4 *>(base) + hlg;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st_stream(dst + 32 * q, cur[q]);
+                if (hl < 16) st_stream(dst + 128, cur[4]);
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(line[q].x), "+v"(line[q].y), "+v"(line[q].z), "+v"(line[q].w));
+            asm volatile("" : "+v"(sd_next));
+            overlap[0] += cur[0].x;  // (keeps the epilogue's stores dependent on the walk)
+            continue;
+        }
+#endif
 
         int bt = 0, mixed = 0, rzero = 0;
         if (active) {
+#if SYM_MP3_SINK
+            const uint32_t sd = sd_cur;
+#else
             const uint32_t sd = sd_next;  // fetched one granule ahead, with the lines (little-endian struct layout)
+#endif
             bt = (int)(sd & 0xffu);
             mixed = (sd & 0xff00u) ? 1 : 0;
             rzero = (int)(sd >> 16) > 576 ? 576 : (int)(sd >> 16);
         }
         // ---- granule -> LDS tile (natural order), then lane sb gathers its 18 lines
+#if !SYM_MP3_SINK
         if (active) {
             float4 *t4 = reinterpret_cast<float4 *>(tile);
 #pragma unroll
             for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
             if (hl < 16) t4[128 + hl] = line[4];
         }
+#endif
         wave_sync();
         float y[18];
 #pragma unroll
@@ -383,6 +493,12 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
             fetch_granule(xr + (size_t)(gi + 2u) * 576, (int)hlg, line2);
             sd_next2 = side_raw[gi + 2u];
         }
+#elif SYM_MP3_SINK
+        {   // prefetch the next granule (granule 0 where there is none: always a valid address, never used)
+            const unsigned gn = r + 1 < my_rounds ? gi + 1u : 0u;
+            fetch_granule(xr + (size_t)gn * 576, (int)hlg, line);
+            sd_next = side_raw[gn];
+        }
 #else
         if (r + 1 < my_rounds) {  // prefetch the next granule; it lands during the dct32 and window passes
             fetch_granule(xr + (size_t)(gi + 1u) * 576, (int)hlg, line);
@@ -426,6 +542,65 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
                 dw1[4 * k] = c.x; dw1[4 * k + 1] = c.y; dw1[4 * k + 2] = c.z; dw1[4 * k + 3] = c.w;
             }
         }
+#if SYM_MP3_SINK && !SYM_MP3_OTILE
+        float *outp;
+        {
+            unsigned tid3 = threadIdx.x;
+            asm volatile("" : "+v"(tid3));  // (formed here, not carried through the loop)
+            float *sink_lane = sink + (size_t)((blockIdx.x * (unsigned)kWgWaves + (tid3 >> 6)) % (unsigned)kSinkSlots) * kSinkSlotFloats +
+                               ((tid3 >> 5) & 1u) * 576u + (tid3 & 31u);
+            outp = emit ? pcm + (size_t)gi * 576 + hlg : sink_lane;
+        }
+#endif
+#if SYM_MP3_PACKED
+        // this granule's 18 slots: HA[16 + b] = S[b][fcol], HB[16 + b] = S[b][scol], read as the pairs they are kept in (one
+        // ds_read2_b32 each, all issued up front; the sums below wait for them pair by pair)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) PA[8 + q] = v2f{S[(2 * q) * kSStride + vm.fcol], S[(2 * q + 1) * kSStride + vm.fcol]};
+        PB[8][1] = S[vm.scol];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) PB[8 + q] = v2f{S[(2 * q - 1) * kSStride + vm.scol], S[(2 * q) * kSStride + vm.scol]};
+        PB[17][0] = S[17 * kSStride + vm.scol];
+        // kPairGroup slot pairs advance together: a packed instruction that reads the result of the instruction right before it
+        // costs a wait state (the compiler pads with s_nop, an issue slot each); interleaved chains never are back to back
+        constexpr int kPairGroup = SYM_MP3_PAIR_GROUP;
+        static_assert(9 % kPairGroup == 0, "whole groups");
+#pragma unroll
+        for (int q0 = 0; q0 < 9; q0 += kPairGroup) {  // time slots 2q and 2q + 1
+            v2f acc[kPairGroup];
+#pragma unroll
+            for (int g = 0; g < kPairGroup; ++g) acc[g] = v2f{0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const v2f d0 = {dw0[j], dw0[j]}, d1 = {dw1[j], dw1[j]};
+                v2f pa[kPairGroup], pb[kPairGroup];
+#pragma unroll
+                for (int g = 0; g < kPairGroup; ++g) pa[g] = PA[8 + q0 + g - j] * d0;
+#pragma unroll
+                for (int g = 0; g < kPairGroup; ++g) acc[g] += pa[g];
+#pragma unroll
+                for (int g = 0; g < kPairGroup; ++g) pb[g] = PB[8 + q0 + g - j] * d1;
+#pragma unroll
+                for (int g = 0; g < kPairGroup; ++g) acc[g] += pb[g];
+            }
+#pragma unroll
+            for (int g = 0; g < kPairGroup; ++g) {
+                const int q = q0 + g;
+#if SYM_MP3_OTILE
+                O[32 * (2 * q) + hl] = acc[g][0];
+                O[32 * (2 * q + 1) + hl] = acc[g][1];
+#elif SYM_MP3_SINK
+                st_stream(outp + 32 * (2 * q), acc[g][0]);
+                st_stream(outp + 32 * (2 * q + 1), acc[g][1]);
+#else
+                if (emit) {
+                    st_stream(pcm + (size_t)gi * 576 + 32 * (2 * q) + hlg, acc[g][0]);
+                    st_stream(pcm + (size_t)gi * 576 + 32 * (2 * q + 1) + hlg, acc[g][1]);
+                }
+#endif
+            }
+        }
+#else
         float nA[18], nB[18];
         // the two LDS reads of slot b + 1 are issued before the taps of slot b (the store's branch per slot otherwise
         // pins each read directly in front of its first use: 18 exposed LDS round trips per granule)
@@ -458,6 +633,9 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
 #if SYM_MP3_OTILE
 #pragma unroll
             for (int g = 0; g < kSlotGroup; ++g) O[32 * (b0 + g) + hl] = accs[g];
+#elif SYM_MP3_SINK
+#pragma unroll
+            for (int g = 0; g < kSlotGroup; ++g) st_stream(outp + 32 * (b0 + g), accs[g]);
 #else
             if (emit) {
 #pragma unroll
@@ -465,6 +643,7 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
             }
 #endif
         }
+#endif
 #if SYM_MP3_OTILE
         wave_sync();
         if (emit) {  // the granule's 144 float4, lane hl stores float4 hl + 32 q (and 128 + hl for hl < 16)
@@ -480,16 +659,49 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
         }
 #endif
         wave_sync();  // the window pass has read S; the next round's tile goes to the same LDS
+#if SYM_MP3_SINK
+        {
+            float4 *t4 = reinterpret_cast<float4 *>(tile);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
+            if (hl < 16) t4[128 + hl] = line[4];
+            sd_cur = sd_next;
+            asm volatile("" : "+v"(sd_cur));  // (the side word is waited for HERE, behind the lines, not at the loop header)
+        }
+#endif
         // ---- slide the history: slots 2..17 of this granule become slots -16..-1
         if (need_hist) {
+#if SYM_MP3_PACKED
+#pragma unroll
+            for (int k = 0; k < 8; ++k) PA[k] = PA[k + 9];   // HA[t] <- HA[t + 18]
+#pragma unroll
+            for (int k = 0; k < 9; ++k) PB[k] = PB[k + 9];   // HB[t] <- HB[t + 18], up to HB[15] = PB[8].x
+#else
 #pragma unroll
             for (int m = 0; m < kHistOld; ++m) {
                 oA[m] = nA[2 + m];
                 oB[m] = nB[2 + m];
             }
+#endif
         }
     }
 
+#if SYM_MP3_CLOCK
+    if (live && hl == 0) {  // measurement build (corrupts the PCM): shader cycles, 100 MHz ticks and rounds of this walk
+        const unsigned long long dc = __builtin_readcyclecounter() - clk_t0, dw = wall_clock64() - clk_w0;
+        unsigned *o = reinterpret_cast<unsigned *>(pcm + ((size_t)chain * granules_per_chain + g_begin) * 576);
+        o[0] = 0x51a7c10cu;
+        o[1] = (unsigned)dc;
+        o[2] = (unsigned)dw;
+        o[3] = (unsigned)rounds;
+        o[4] = (unsigned)(clk_w0 & 0xffffffffu);
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[5] = hw;
+        o[6] = xcc;
+    }
+#endif
     // ---- outgoing state (only the segment that ends the chain).  The chain index and the addresses derived from it are
     // re-read here from LDS through an opaque copy of the thread index: kept live across the main loop they (and the
     // reciprocal of the division that produced them) cost seven VGPRs, which at the 168-register budget of three
@@ -511,8 +723,13 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
 #pragma unroll
         for (int m = 1; m <= kHistOld; ++m) {
             float *row = vv + 64 * ((vf_final + m) & 15);
+#if SYM_MP3_PACKED
+            row[hl2] = __uint_as_float(__float_as_uint(SYM_HA(kHistOld - m)) ^ vmapx(hl2).fsign);
+            row[32 + hl2] = -SYM_HB(kHistOld - m);
+#else
             row[hl2] = oA[kHistOld - m];
             row[32 + hl2] = oB[kHistOld - m];
+#endif
         }
         if (hl2 == 0) vfront_out[chain2] = vf_final;
     }
@@ -532,9 +749,10 @@ int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_
     const size_t items = n_chains * segs;
     const size_t grid = (items + 2 * kWgWaves - 1) / (2 * kWgWaves);
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    if (!ctx->mp3_sink) SYM_TRY(ctx_alloc(ctx, &ctx->mp3_sink, (size_t)kSinkSlots * kSinkSlotFloats * sizeof(float), false));
     hipLaunchKernelGGL(mp3_synth_kernel, dim3((unsigned)grid), dim3(64 * kWgWaves), 0, ctx->stream, ctx->dev, d_xr, d_side, sr,
                        d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out, d_vfront_out, d_pcm,
-                       (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs);
+                       static_cast<float *>(ctx->mp3_sink), (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

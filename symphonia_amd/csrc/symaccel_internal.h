@@ -120,6 +120,7 @@ struct symaccel_ctx {
     void *stage_arena = nullptr;
     size_t stage_arena_bytes = 0;
     // small dedicated device buffers (not shared with `scratch`, whose growth synchronises the stream)
+    void *mp3_sink = nullptr;  // target of the PCM stores of lanes that must not emit (mp3.hip, SYM_MP3_SINK)
     void *alac_flags = nullptr;
     size_t alac_flags_bytes = 0;
 };

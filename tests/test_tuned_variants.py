@@ -15,6 +15,9 @@ CASES = [
     ({"SYMACCEL_TUNE_AAC_QUAD": "1"}, "tests/test_emu_core_aac.py", "aac"),
     ({"SYMACCEL_TUNE_MP3_VARIANT": "2"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_VARIANT": "3"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_VARIANT": "4"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_PACKED": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_PACKED": "1", "SYMACCEL_TUNE_MP3_VARIANT": "4", "SYMACCEL_TUNE_MP3_PAIR_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "18"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_FLAC_PARTS": "4"}, "tests/test_emu_codecs.py", "emu_flac"),
