@@ -117,6 +117,28 @@ __device__ __forceinline__ void start_window4(const float *sw, int j0, float *w)
 #ifndef SYM_AAC_QUAD
 #define SYM_AAC_QUAD 0
 #endif
+// SYM_AAC_SINK 1 (the wavefront walk, one frame in flight): gfx950 counts vector loads and stores with ONE in-order counter
+// (vmcnt).  With the PCM stores under `if (emit)`, the prefetch under `if (t + 1 < t_end)` and the prefetched lines consumed
+// at the top of the loop, the compiler has to assume "no store followed the prefetch" and waits with vmcnt(0) at the loop
+// header: every frame the wavefront stood still until the four stores it had issued a moment earlier were acknowledged by
+// memory, with nothing of its own in flight meanwhile.  Here the prefetch and the stores are unconditional (the halo frame's
+// stores go to a per-wavefront slot of the context's sink buffer, the last frame re-reads itself) and the prefetched registers
+// are touched at the END of the frame, behind the stores, in straight-line code: the wait becomes vmcnt(4) -- for the lines,
+// not for the stores -- and the loop header needs none.
+#ifndef SYM_AAC_SINK
+#define SYM_AAC_SINK 0
+#endif
+// MEASUREMENT ONLY (needs SYM_AAC_SINK; corrupts the first PCM frame of every segment): shader cycles, 100 MHz ticks and the
+// cycles spent in the wait for the prefetched frame, per wavefront (tools/kernel_clock_probe.py)
+#ifndef SYM_AAC_CLOCK
+#define SYM_AAC_CLOCK 0
+#endif
+// the wait for the prefetched frame, placed where it is called (the registers must be valid from here on)
+__device__ __forceinline__ void touch_prefetch(float2 (&line)[8], unsigned &sb) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(line[s].x), "+v"(line[s].y));
+    asm volatile("" : "+v"(sb));
+}
 __device__ __forceinline__ float2 ld_line(const float2 *p) { return ld_stream(p); }
 // PCM of one output slot (the two float4 of store_slot), streamed
 __device__ __forceinline__ void st_slot(float *frame, int m2, const float (&v)[8]) {
@@ -127,7 +149,7 @@ __device__ __forceinline__ void st_slot(float *frame, int m2, const float (&v)[8
 
 __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kernel(
     DevTables tb, const float *__restrict__ coeffs, const uint8_t *__restrict__ side,
-    const float *__restrict__ delay_in, float *__restrict__ delay_out, float *__restrict__ pcm,
+    const float *__restrict__ delay_in, float *__restrict__ delay_out, float *__restrict__ pcm, float *__restrict__ sink,
     unsigned frames_per_chain, unsigned seg_len, unsigned segs_per_chain, unsigned n_items) {
     __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
@@ -198,6 +220,14 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
 #endif
 
     unsigned sb_next = side[chain_base + (size_t)t_first];  // side bytes are fetched one frame ahead, like the lines
+#if SYM_AAC_CLOCK
+    const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
+    unsigned long long clk_wait = 0;
+#endif
+#if SYM_AAC_SINK
+    touch_prefetch(line, sb_next);  // (nothing pending at the loop header, from either side)
+    float *const sink_frame = sink + (size_t)(item % (unsigned)(kSinkBytes / 4096)) * 1024;
+#endif
     // one frame of the walk.  Variant 1 wraps the body in a lambda whose `emit_c` is a compile-time true/false so that
     // the halo frame can be peeled; variant 0 keeps the plain loop (its register allocation is the measured one).
 #if SYM_AAC_VARIANT == 1
@@ -207,10 +237,23 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
     for (long t = t_first; t < (long)t_end; ++t) {
         const bool emit = t >= (long)t_begin;
 #endif
+#if SYM_AAC_SINK
+        // the side byte is the same for the whole wavefront: as a scalar the window-sequence branches are uniform branches, of
+        // which exactly one runs (an exec-masked if / else has a static path through neither arm, and on that path no store
+        // follows the prefetch: the bookkeeping described above would be back to vmcnt(0))
+        const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)sb_next);
+#else
         const unsigned sb = sb_next;
+#endif
         const int seq = (int)(sb & 3u);
         const int shape = (int)((sb >> 2) & 1u), prev_shape = (int)((sb >> 3) & 1u);
+#if SYM_AAC_SINK
+        float *frame_out = emit ? pcm + (chain_base + (size_t)t) * 1024 : sink_frame;  // (wave-uniform)
+#define SYM_AAC_EMIT true
+#else
         float *frame_out = pcm + (chain_base + (size_t)t) * 1024;
+#define SYM_AAC_EMIT emit
+#endif
 
         // ---- consume the prefetched lines
         c32 z[8];
@@ -241,6 +284,14 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
 #pragma unroll
             for (int s = 0; s < 8; ++s) line2[s] = ld_line(src + lane + 64 * s);
         }
+#elif SYM_AAC_SINK
+        {   // prefetch the next frame (the last frame of the walk re-reads itself: a valid address, never used)
+            const size_t tn = t + 1 < (long)t_end ? (size_t)t + 1 : (size_t)t;
+            sb_next = side[chain_base + tn];
+            const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + ((SYM_AAC_ABLATE & 2) ? (size_t)0 : tn)) * 1024);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) line[s] = ld_line(src + lane + 64 * s);
+        }
 #else
         if (t + 1 < (long)t_end) {  // prefetch the next frame; it lands while this one is transformed
             sb_next = side[chain_base + (size_t)t + 1];
@@ -260,7 +311,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
                     dst[2 * q] = z[4 * h + q].x + dl[h][2 * q];
                     dst[2 * q + 1] = z[4 * h + q].y + dl[h][2 * q + 1];
                 }
-                if (emit && !(SYM_AAC_ABLATE & 1)) st_slot(frame_out, lane + 64 * h, dst);
+                if (SYM_AAC_EMIT && !(SYM_AAC_ABLATE & 1)) st_slot(frame_out, lane + 64 * h, dst);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) dl[h][q] = dst[q] * 0.5f;
             }
@@ -290,7 +341,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
                     const float v = dl[h][q] + (x[q] * wo[q]);
                     dst[q] = (seq == LONG_STOP && j < kP0) ? dl[h][q] : v;
                 }
-                if (emit && !(SYM_AAC_ABLATE & 1)) st_slot(frame_out, m2, dst);
+                if (SYM_AAC_EMIT && !(SYM_AAC_ABLATE & 1)) st_slot(frame_out, m2, dst);
                 // ---- delay for the next frame (dsp.rs:132-157): pcm[1024 + j] * long_win[1023 - j] (the
                 // slot's two float4 read backwards), a short-window slope, or literal zero
                 float wd[8];
@@ -311,6 +362,15 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
                     dl[h][q] = (seq == LONG_START && j >= kP1) ? 0.0f : v;
                 }
             }
+#if SYM_AAC_SINK
+#if SYM_AAC_CLOCK
+            const unsigned long long cw0 = __builtin_readcyclecounter();
+#endif
+            touch_prefetch(line, sb_next);  // vmcnt(4): the next frame's lines, not this frame's stores
+#if SYM_AAC_CLOCK
+            clk_wait += __builtin_readcyclecounter() - cw0;
+#endif
+#endif
             wave_sync();  // Z in LDS is overwritten by the next frame
         } else {
             // ---- eight short windows (rare): everything through LDS in natural order
@@ -333,7 +393,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o[q] = o[q] + ps[q];
                 }
-                if (emit) st_stream(reinterpret_cast<float4 *>(frame_out + j0), make_float4(o[0], o[1], o[2], o[3]));
+                if (SYM_AAC_EMIT) st_stream(reinterpret_cast<float4 *>(frame_out + j0), make_float4(o[0], o[1], o[2], o[3]));
                 float nd[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // dsp.rs:138-145
                 if (j0 < kP1) pcm_short4(ldsf, j0 + kP1, sw, psw, nd);
                 *d4 = make_float4(nd[0], nd[1], nd[2], nd[3]);
@@ -341,6 +401,9 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
             wave_sync();
 #pragma unroll
             for (int h = 0; h < 2; ++h) load_slot(dly, lane + 64 * h, dl[h]);
+#if SYM_AAC_SINK
+            touch_prefetch(line, sb_next);
+#endif
             wave_sync();  // LDS is overwritten by the next frame
         }
 #if SYM_AAC_VARIANT == 1
@@ -353,6 +416,23 @@ __global__ __launch_bounds__(64 * kWaves, SYM_AAC_MIN_WAVES) void aac_synth_kern
     }
 #endif
 
+#if SYM_AAC_CLOCK
+    if (lane == 0) {
+        const unsigned long long dc = __builtin_readcyclecounter() - clk_t0, dw = wall_clock64() - clk_w0;
+        unsigned *o = reinterpret_cast<unsigned *>(pcm + (chain_base + (size_t)t_begin) * 1024);
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[0] = 0x51a7c10cu;
+        o[1] = (unsigned)dc;
+        o[2] = (unsigned)dw;
+        o[3] = (unsigned)(t_end - (unsigned)t_first);
+        o[4] = (unsigned)(clk_w0 & 0xffffffffu);
+        o[5] = hw;
+        o[6] = xcc;
+        o[7] = (unsigned)clk_wait;
+    }
+#endif
     if (t_end == frames_per_chain) {
         float *d = delay_out + (size_t)chain * 1024;
 #pragma unroll
@@ -609,8 +689,10 @@ int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, 
     const size_t items = n_chains * segs;
     const size_t grid = (items + kWaves - 1) / kWaves;
     if (items > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    void *sink = nullptr;
+    SYM_TRY(ctx_sink(ctx, &sink));
     hipLaunchKernelGGL(aac_synth_kernel, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, d_coeffs,
-                       d_side, d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, seg, (unsigned)segs,
+                       d_side, d_delay_in, d_delay_out, d_pcm, static_cast<float *>(sink), (unsigned)frames_per_chain, seg, (unsigned)segs,
                        (unsigned)items);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;

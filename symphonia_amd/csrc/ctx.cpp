@@ -24,6 +24,12 @@ int ctx_alloc(symaccel_ctx *ctx, void **out, size_t bytes, bool tracked) {
     return SYMACCEL_OK;
 }
 
+int ctx_sink(symaccel_ctx *ctx, void **out) {
+    if (!ctx->sink) SYM_TRY(ctx_alloc(ctx, &ctx->sink, kSinkBytes, false));
+    *out = ctx->sink;
+    return SYMACCEL_OK;
+}
+
 int ctx_scratch(symaccel_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->scratch_bytes) {
         if (ctx->scratch) {
@@ -294,7 +300,7 @@ void symaccel_ctx_destroy(symaccel_ctx *ctx) {
     if (ctx->stage_out) (void)hipStreamSynchronize(ctx->stage_out);
     if (ctx->stage_arena) (void)hipFree(ctx->stage_arena);
     if (ctx->alac_flags) (void)hipFree(ctx->alac_flags);
-    if (ctx->mp3_sink) (void)hipFree(ctx->mp3_sink);
+    if (ctx->sink) (void)hipFree(ctx->sink);
     for (hipEvent_t e : ctx->stage_events)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stage_in) (void)hipStreamDestroy(ctx->stage_in);

@@ -91,10 +91,121 @@ __device__ __forceinline__ void st_stream(int4 *p, int4 v) { *p = v; }
 __device__ __forceinline__ void st_stream(float *p, float v) { *p = v; }
 #endif
 
-// Complex<f32>.  Scalar f32 instructions on purpose: on gfx950 v_pk_mul_f32 / v_pk_add_f32 issue at half
-// the wavefront rate of v_mul_f32 / v_add_f32 (measured, tools/ubench/valu_rate.hip: 2.7 vs 5.0 cycles per
-// wave-instruction with >= 2 wavefronts per SIMD), so packing two operations per instruction buys nothing and
-// the register-pair shuffles it needs cost extra -- the packed variant of aac_synth_kernel ran 15 % slower.
+// Complex<f32>.  Two builds of the same arithmetic (every operation rounds exactly as num-complex's scalar code does):
+//   SYM_PACKED_C32 0: scalar v_mul_f32 / v_add_f32 (rounds 1-2, and the emulation build);
+//   SYM_PACKED_C32 1: a complex value is an aligned register pair and the butterflies are v_pk_mul_f32 / v_pk_add_f32 with
+//     op_sel / neg modifiers: a complex product is 3 instructions instead of 6, a butterfly's sum and difference 2 instead of 4.
+// Round 1 measured packed f32 at half the issue rate of scalar f32 on the SIMD's VALU port and dropped it.  Round 3's
+// tools/ubench/valu_clock.hip shows the other half of the picture: a WAVEFRONT issues at most one instruction per ~4.9 cycles
+// whatever it is, so at one or two wavefronts per SIMD -- where the transform kernels run, for their registers -- the instruction
+// count, not the port, is what the arithmetic costs.
+// Chosen per source file (a file defines SYM_PACKED_C32_DEFAULT 1 in front of its includes; the build knob SYM_PACKED_C32 overrides
+// every file): measured in one call (profiles/r03s_packed_c32.txt) the packed form wins where the kernel has the registers for it
+// (Vorbis 256 / 2048 +7 %, the 2048-point Fft +16 %) and loses where the aligned pairs push a kernel over its register budget
+// (Vorbis 4096 / 8192-sample blocks -16 / -23 %, AAC -2 %).
+#ifndef SYM_PACKED_C32_DEFAULT
+#define SYM_PACKED_C32_DEFAULT 0
+#endif
+#ifndef SYM_PACKED_C32
+#define SYM_PACKED_C32 SYM_PACKED_C32_DEFAULT
+#endif
+#if SYM_PACKED_C32 && !defined(SYMACCEL_EMULATED_HIP)
+#define SYM_C32_IS_PACKED 1
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+struct c32 {
+    union {
+        struct {
+            float x, y;  // re, im
+        };
+        v2f_t v;
+    };
+};
+__device__ __forceinline__ c32 c_pack(v2f_t v) {
+    c32 r;
+    r.v = v;
+    return r;
+}
+// v_pk_add_f32 with source modifiers the compiler's instruction selection does not produce from generic vector code
+#define SYM_PK_ADD(name, mods)                                                \
+    __device__ __forceinline__ v2f_t name(v2f_t a, v2f_t b) {                 \
+        v2f_t r;                                                              \
+        asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(r) : "v"(a), "v"(b));      \
+        return r;                                                             \
+    }
+SYM_PK_ADD(pk_sub_add, "neg_lo:[0,1]")                                    // (a.x - b.x, a.y + b.y)
+SYM_PK_ADD(pk_add_rsub, "neg_hi:[1,0]")                                   // (a.x + b.x, b.y - a.y)
+SYM_PK_ADD(pk_add_swap_sub, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")  // (a.x + b.y, a.y - b.x)
+SYM_PK_ADD(pk_sub_swap_add, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")  // (a.x - b.y, a.y + b.x)
+SYM_PK_ADD(pk_lolo_sub_add, "op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1]")  // (a.x - b.y, a.x + b.y)
+#undef SYM_PK_ADD
+
+__device__ __forceinline__ c32 c_add(c32 a, c32 b) { return c_pack(a.v + b.v); }
+__device__ __forceinline__ c32 c_sub(c32 a, c32 b) { return c_pack(a.v - b.v); }
+// num-complex `Mul`: (a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re)
+__device__ __forceinline__ c32 c_mul(c32 a, c32 b) {
+    const v2f_t t1 = v2f_t{a.x, a.x} * b.v;              // (a.x b.x, a.x b.y)
+    const v2f_t t2 = v2f_t{a.y, a.y} * v2f_t{b.y, b.x};  // (a.y b.y, a.y b.x)
+    return c_pack(pk_sub_add(t1, t2));
+}
+// Imdct pre-twiddle (mdct.rs:81-88): even = spec[2i], odd = -spec[N-1-2i],
+// z = (odd*w.im - even*w.re, odd*w.re + even*w.im).  `mirrored_line` = spec[N-1-2i] (not yet negated).
+__device__ __forceinline__ c32 pre_twiddle(float even_line, float mirrored_line, c32 w) {
+    const float odd = -mirrored_line;
+    const v2f_t t1 = v2f_t{odd, odd} * v2f_t{w.y, w.x};
+    const v2f_t t2 = v2f_t{even_line, even_line} * w.v;
+    return c_pack(pk_sub_add(t1, t2));
+}
+// Imdct post-twiddle (mdct.rs:104 / 123): val = w * x.conj() = (w.x x.x - w.y (-x.y), w.x (-x.y) + w.y x.x); negating a factor
+// negates the product exactly, so this is (w.x x.x + w.y x.y, w.y x.x - w.x x.y) with the same four roundings
+__device__ __forceinline__ c32 post_twiddle(c32 x, c32 w) {
+    const v2f_t t1 = v2f_t{w.x, w.x} * x.v;              // (w.x x.x, w.x x.y)
+    const v2f_t t2 = v2f_t{w.y, w.y} * v2f_t{x.y, x.x};  // (w.y x.y, w.y x.x)
+    return c_pack(pk_add_rsub(t1, t2));
+}
+
+// One radix-2 DIT butterfly: q already twiddled.  e' = e + q, o' = e - q.
+__device__ __forceinline__ void bfly(c32 &e, c32 &o, c32 q) {
+    const c32 p = e;
+    e = c_add(p, q);
+    o = c_sub(p, q);
+}
+
+#define SYM_FRAC_1_SQRT_2 0.70710678118654752440f
+
+// Twiddles of the unrolled fft4/fft8 combine steps (no_simd.rs:405-447), compile-time forms, fused with their butterfly:
+// q = -i v = (v.y, -v.x):  e' = (p.x + v.y, p.y - v.x), o' = (p.x - v.y, p.y + v.x)
+__device__ __forceinline__ void bfly_minus_i(c32 &e, c32 &o) {
+    const c32 p = e, v = o;
+    e = c_pack(pk_add_swap_sub(p.v, v.v));
+    o = c_pack(pk_sub_swap_add(p.v, v.v));
+}
+__device__ __forceinline__ c32 tw_minus_i(c32 v) { return c32{v.y, -v.x}; }            // k = n/4
+__device__ __forceinline__ c32 tw_n8(c32 v) {                                          // k = n/8: (a + b, b - a)
+    const v2f_t t = v.v * v2f_t{SYM_FRAC_1_SQRT_2, SYM_FRAC_1_SQRT_2};
+    return c_pack(pk_add_swap_sub(t, t));
+}
+__device__ __forceinline__ c32 tw_3n8(c32 v) {                                         // k = 3n/8: (a - b, a + b)
+    const v2f_t t = v.v * v2f_t{-SYM_FRAC_1_SQRT_2, -SYM_FRAC_1_SQRT_2};
+    return c_pack(pk_lolo_sub_add(t, t));
+}
+
+// fft8 (no_simd.rs:405-454) on 8 values already in bit-reversed order, in registers.
+__device__ __forceinline__ void fft8_regs(c32 (&x)[8]) {
+    bfly(x[0], x[1], x[1]);  // fft2 x4
+    bfly(x[2], x[3], x[3]);
+    bfly(x[4], x[5], x[5]);
+    bfly(x[6], x[7], x[7]);
+    bfly(x[0], x[2], x[2]);  // fft4 x2: k=0 plain, k=1 multiply by -i
+    bfly_minus_i(x[1], x[3]);
+    bfly(x[4], x[6], x[6]);
+    bfly_minus_i(x[5], x[7]);
+    bfly(x[0], x[4], x[4]);  // fft8 combine
+    bfly(x[1], x[5], tw_n8(x[5]));
+    bfly_minus_i(x[2], x[6]);
+    bfly(x[3], x[7], tw_3n8(x[7]));
+}
+#else
+#define SYM_C32_IS_PACKED 0
 struct c32 {
     float x, y;  // re, im
 };
@@ -148,6 +259,7 @@ __device__ __forceinline__ void fft8_regs(c32 (&x)[8]) {
     bfly(x[2], x[6], tw_minus_i(x[6]));
     bfly(x[3], x[7], tw_3n8(x[7]));
 }
+#endif
 
 // Lane-dependent twiddle of the fft16 / fft32 combine step: `form` 0 = complex product with w
 // (w holds the literal, or (+-c,-c) for the k = n/8, 3n/8 strength-reduced forms, which are the

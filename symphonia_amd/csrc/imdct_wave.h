@@ -89,6 +89,25 @@ struct LaneTablesLds {
     __device__ __forceinline__ c32 W256(int b) const { return t[120 + lane + 64 * b]; }
     __device__ __forceinline__ c32 W512(int B) const { return t[248 + lane + 64 * B]; }
 };
+// Stages 4-6 from registers (17 VGPRs), stages 7-9 from the LDS copy (seven ds_read_b64 per 512-point transform): 14 VGPRs
+// per lane less than LaneTables.  What the packed build of the Vorbis 256 / 2048 kernel needs to stay inside 256 VGPRs.
+struct LaneTablesMixed {
+    c32 w16;
+    int f16;
+    c32 w32[2];
+    int f32[2];
+    c32 w64[4];
+    const c32 *t;
+    int lane;
+    __device__ __forceinline__ c32 W16() const { return w16; }
+    __device__ __forceinline__ int F16() const { return f16; }
+    __device__ __forceinline__ c32 W32(int i) const { return w32[i]; }
+    __device__ __forceinline__ int F32(int i) const { return f32[i]; }
+    __device__ __forceinline__ c32 W64(int j) const { return w64[j]; }
+    __device__ __forceinline__ c32 W128() const { return t[56 + lane]; }
+    __device__ __forceinline__ c32 W256(int b) const { return t[120 + lane + 64 * b]; }
+    __device__ __forceinline__ c32 W512(int B) const { return t[248 + lane + 64 * B]; }
+};
 // workgroup-cooperative fill of the LDS copy (call before a __syncthreads)
 __device__ __forceinline__ void fill_lane_tables_lds(const DevTables &tb, c32 *t, int tid, int n_threads) {
     for (int i = tid; i < kLaneTabComplex; i += n_threads) {
@@ -123,6 +142,20 @@ __device__ __forceinline__ void load_lane_tables(const DevTables &tb, int lane, 
     t.w256[1] = ld_c(w256 + lane + 64);
 #pragma unroll
     for (int B = 0; B < 4; ++B) t.w512[B] = ld_c(w512 + lane + 64 * B);
+}
+
+__device__ __forceinline__ void load_lane_tables_mixed(const DevTables &tb, const c32 *lds_copy, int lane, LaneTablesMixed &t) {
+    const int k = lane & 7;
+    t.w16 = ld_c(tb.small16 + k);
+    t.f16 = tb.small16_form[k];
+    t.w32[0] = ld_c(tb.small32 + k);
+    t.f32[0] = tb.small32_form[k];
+    t.w32[1] = ld_c(tb.small32 + k + 8);
+    t.f32[1] = tb.small32_form[k + 8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.w64[j] = ld_c(tb.fft_merge + 8 * j + k);
+    t.t = lds_copy;
+    t.lane = lane;
 }
 
 // Stages 4-6 of the radix-2 graph on the eight values u[j] = a[64B + 8j + k] of one lane.

@@ -42,7 +42,7 @@ namespace {
 //   4  prefetch and PCM stores issued unconditionally, the prefetched lines consumed at the end of the round (SYM_MP3_SINK
 //      below): the waits are for the lines only -- measured equal (profiles/r03k_mp3_sink_ab.txt), i.e. the write
 //      acknowledgements were not what the kernel waits for.
-// Round 3's measurements (tools/ubench/valu_clock.hip, tools/mp3_clock_probe.py): the loads and stores alone
+// Round 3's measurements (tools/ubench/valu_clock.hip, tools/kernel_clock_probe.py): the loads and stores alone
 // run at 5.3-5.6 TB/s (SYM_MP3_ABLATE); a wavefront issues one instruction per ~4.9 cycles, a SIMD's VALU port accepts one
 // plain f32 instruction per ~2.5 cycles, so two wavefronts saturate it and the third of a SIMD gets the leftovers (walks of 45
 // rounds finish after 212 / 231 / 315 us on every SIMD); under this kernel's VALU + LDS + HBM load the part clocks at 1.7 GHz
@@ -749,10 +749,12 @@ int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_
     const size_t items = n_chains * segs;
     const size_t grid = (items + 2 * kWgWaves - 1) / (2 * kWgWaves);
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    if (!ctx->mp3_sink) SYM_TRY(ctx_alloc(ctx, &ctx->mp3_sink, (size_t)kSinkSlots * kSinkSlotFloats * sizeof(float), false));
+    static_assert((size_t)kSinkSlots * kSinkSlotFloats * sizeof(float) <= kSinkBytes, "sink slots");
+    void *sink = nullptr;
+    SYM_TRY(ctx_sink(ctx, &sink));
     hipLaunchKernelGGL(mp3_synth_kernel, dim3((unsigned)grid), dim3(64 * kWgWaves), 0, ctx->stream, ctx->dev, d_xr, d_side, sr,
                        d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out, d_vfront_out, d_pcm,
-                       static_cast<float *>(ctx->mp3_sink), (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs);
+                       static_cast<float *>(sink), (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -120,7 +120,7 @@ struct symaccel_ctx {
     void *stage_arena = nullptr;
     size_t stage_arena_bytes = 0;
     // small dedicated device buffers (not shared with `scratch`, whose growth synchronises the stream)
-    void *mp3_sink = nullptr;  // target of the PCM stores of lanes that must not emit (mp3.hip, SYM_MP3_SINK)
+    void *sink = nullptr;  // 2 MiB nobody reads: target of the stores of wavefronts / lanes that must not emit (ctx_sink)
     void *alac_flags = nullptr;
     size_t alac_flags_bytes = 0;
 };
@@ -130,6 +130,10 @@ namespace symaccel {
 int ctx_fail(symaccel_ctx *ctx, hipError_t err, const char *where);
 int ctx_alloc(symaccel_ctx *ctx, void **out, size_t bytes, bool tracked = true);
 int ctx_scratch(symaccel_ctx *ctx, size_t bytes, void **out);
+// The context's sink buffer (kSinkBytes, allocated on first use, never read).  Kernels whose loops must issue a FIXED number of
+// stores per round (the vmcnt bookkeeping of aac.hip / mp3.hip) aim the stores of halo rounds at a slot of it.
+constexpr size_t kSinkBytes = 2u << 20;
+int ctx_sink(symaccel_ctx *ctx, void **out);
 int ctx_upload(symaccel_ctx *ctx, const void *src, size_t bytes, const void **out);
 int get_imdct_plan(symaccel_ctx *ctx, int n, double scale, const ImdctPlan **out);
 unsigned choose_segment(const symaccel_ctx *ctx, size_t n_chains, size_t frames_per_chain, unsigned waves_per_cu,

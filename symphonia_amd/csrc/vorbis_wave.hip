@@ -15,6 +15,7 @@
 // The packed spectrum / PCM offsets of a segment's first block follow from the number of long blocks before it, which
 // every wavefront counts itself (16 flags per lane and step); no separate scan kernel runs for this block-size pair.
 // HBM traffic per channel-block: 4 * (n/2) B in + 4 * (prev_n + n)/4 B out (+ one halo block per segment).
+#define SYM_PACKED_C32_DEFAULT 1  // complex arithmetic as v_pk_*_f32 on register pairs: +7 % here (dsp_device.h)
 #include "imdct_wave.h"
 
 namespace symaccel {
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
     __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
     __shared__ unsigned wave_chain[kWaves];  // the wavefront's chain index, parked for the epilogue (see there)
-#if SYM_VORBIS_WAVES == 3
+#if SYM_VORBIS_WAVES == 3 || SYM_C32_IS_PACKED
     __shared__ __attribute__((aligned(16))) c32 lane_tab[kLaneTabComplex];
     fill_lane_tables_lds(tb, lane_tab, (int)threadIdx.x, 64 * kWaves);
 #endif
@@ -173,6 +174,9 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
 
 #if SYM_VORBIS_WAVES == 3
     const LaneTablesLds lt = lane_tables_lds(tb, lane_tab, lane);
+#elif SYM_C32_IS_PACKED
+    LaneTablesMixed lt;  // (complex values as aligned register pairs need the 14 VGPRs the last three stages' twiddles took)
+    load_lane_tables_mixed(tb, lane_tab, lane, lt);
 #else
     LaneTables lt;
     load_lane_tables(tb, lane, lt);

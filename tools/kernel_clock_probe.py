@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Development tool: the shader clock and the cycles per round inside mp3_synth_kernel, from a library built with
-SYMACCEL_TUNE_MP3_CLOCK=1 (each half-wave's walk leaves its cycle / 100 MHz tick counts in its first PCM granule).
-  SYMACCEL_LIB=build_ab/mp3_clock.so python tools/mp3_clock_probe.py"""
+"""Development tool: the shader clock and the cycles per round inside mp3_synth_kernel / aac_synth_kernel, from a library built with
+SYMACCEL_TUNE_MP3_CLOCK=1 (or SYMACCEL_TUNE_AAC_SINK=1 SYMACCEL_TUNE_AAC_CLOCK=1; argument: mp3 | aac) (each half-wave's walk leaves its cycle / 100 MHz tick counts in its first PCM granule).
+  SYMACCEL_LIB=build_ab/mp3_clock.so python tools/kernel_clock_probe.py"""
 import sys
 from pathlib import Path
 
@@ -16,7 +16,9 @@ import symphonia_amd as sa  # noqa: E402
 def main():
     ctx = sa.Context(0)
     ctx.use_torch_stream()
-    step, *_rest, pcm = bench.make_workload("mp3", torch, ctx, 0)
+    name = sys.argv[1] if len(sys.argv) > 1 else "mp3"
+    unit = {"mp3": 576, "aac": 1024}[name]
+    step, *_rest, pcm = bench.make_workload(name, torch, ctx, 0)
     for _ in range(30):  # sustained: the clock follows the load
         step()
     torch.cuda.synchronize()
@@ -25,7 +27,7 @@ def main():
     step()
     e1.record()
     torch.cuda.synchronize()
-    words = pcm.view(torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 576)
+    words = pcm.view(torch.int32).cpu().numpy().view(np.uint32).reshape(-1, unit)
     tagged = words[words[:, 0] == 0x51A7C10C]
     cyc, ticks, rounds, start = (tagged[:, i].astype(np.float64) for i in (1, 2, 3, 4))
     us = ticks / 100.0
@@ -34,6 +36,9 @@ def main():
         rounds.mean(), us.mean(), us.min(), us.max(), cyc.mean(), (cyc / (ticks * 10.0)).mean()))
     print("cycles per round: %.0f mean (min %.0f, max %.0f); us per round %.2f" % (
         (cyc / rounds).mean(), (cyc / rounds).min(), (cyc / rounds).max(), (us / rounds).mean()))
+    if name == "aac":
+        wait = tagged[:, 7].astype(np.float64)
+        print("cycles in the wait for the prefetched frame: %.1f %% of the walk (%.0f per round)" % (100 * (wait / cyc).mean(), (wait / rounds).mean()))
     span = (start.max() - start.min()) / 100.0
     print("walk starts spread over %.1f us" % span)
     # HW_ID (gfx9): wave_id [3:0], simd_id [5:4], pipe [7:6], cu_id [11:8], sh [12], se_id [15:13]; XCC_ID [3:0]
@@ -48,7 +53,7 @@ def main():
         per.setdefault(int(k), []).append(u)
     ranks = {}
     for k, v in per.items():
-        v = sorted(v)[::2]  # (the two halves of a wavefront stamp the same walk)
+        v = sorted(v)[::2] if name == "mp3" else sorted(v)  # (mp3: the two halves of a wavefront stamp the same walk)
         for i, u in enumerate(v):
             ranks.setdefault((len(v), i), []).append(u)
     for (n, i), v in sorted(ranks.items()):
