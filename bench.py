@@ -65,7 +65,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
         frames = nch * nfr // 2
         return step, frames, "frames", nch * nfr * 8192, {
             "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d), 1024-pt IMDCT+window+OLA, KBD"
-                        % (frames, nch, nfr), "channel_frames": nch * nfr, "samples_per_frame": 1024}, "aac_synth_kernel", pcm
+                        % (frames, nch, nfr), "channel_frames": nch * nfr, "samples_per_frame": 1024}, "aac_synth_quad_kernel", pcm
     if name == "mp3":
         nch, ngr = max(2, int(128 * scale)), (6 if emulate else 2048)  # 64 stereo streams x 2048 granules = 131 072 granules
         xr = torch.randn((nch, ngr, 576), generator=g, device=dev, dtype=torch.float32) * 0.05
@@ -338,15 +338,17 @@ def copy_ceiling(ctx, torch, seg_len, reps=10):
     """the copy rates THIS run reaches with the synthesis kernels' traffic shape (1 byte read : 1 byte
     written, config 2's footprint: 512 MiB in, 512 MiB out), through symaccel_probe_copy_device on the launch stream:
     a plain 16 B/lane grid-stride copy, and the copy in which every wavefront streams `seg_len` consecutive 4 KiB frames
-    (aac_synth_kernel's own access pattern).  HIP events around `reps` launches each, after one untimed launch."""
+    (the wavefront walk's access pattern), and the workgroup walk's (aac_synth_quad_kernel: four wavefronts share consecutive frames round-robin).  HIP events around `reps` launches each, after `reps` untimed ones."""
     nbytes = 512 << 20
     a = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
     b = torch.empty_like(a)
     d = ctx.lib.dll
     out = {"bytes_read": nbytes, "bytes_written": nbytes, "unit": "GB/s", "reps": reps}
     for key, fpw, flags in (("plain_float4", 0, 0), ("plain_float4_nt", 0, 1), ("frames_per_wavefront_1_nt", 1, 1),
-                            ("frames_per_wavefront_%d_nt" % seg_len, seg_len, 1), ("frames_per_wavefront_%d" % seg_len, seg_len, 0)):
-        ctx._call(d.symaccel_probe_copy_device, a.data_ptr(), b.data_ptr(), nbytes, fpw, flags)
+                            ("frames_per_wavefront_%d_nt" % seg_len, seg_len, 1), ("frames_per_wavefront_%d" % seg_len, seg_len, 0),
+                            ("frames_per_workgroup_walk_%d_nt" % (4 * seg_len), seg_len, 9)):
+        for _ in range(reps):  # (untimed: the same sustained state as the headline's timed region)
+            ctx._call(d.symaccel_probe_copy_device, a.data_ptr(), b.data_ptr(), nbytes, fpw, flags)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(reps):
@@ -524,6 +526,8 @@ def main():
                     help="N = 1, aac: skip the `other_workloads` object (BASELINE configs 3, 4 (one GPU's shard), 5 and the ALAC "
                          "predictor: 5 steps each with the same event timing)")
     ap.add_argument("--no-copy-ceiling", action="store_true", help="N = 1: skip the same-run copy probes")
+    ap.add_argument("--spinup-ms", type=int, default=60, help="milliseconds of back-to-back steps in front of the W warm-up steps (sustained clocks)")
+    ap.add_argument("--no-spinup", action="store_true", help="measure W + K from an idle board only (the clock ramp)")
     ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the extra BASELINE config-4 (Vorbis shard) line")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: run the control flow on CPU tensors through the CPU emulation build of the kernels "
@@ -595,8 +599,17 @@ def main():
     if args.segment:
         ctx.set_segment(args.segment)
 
-    def timed(step, steps, warmup):
-        """(wall seconds for `steps` steps = max over ranks, mean launch period on this rank's launch stream, this rank's wall)"""
+    def timed(step, steps, warmup, spinup_s=0.0):
+        """(wall seconds for `steps` steps = max over ranks, mean launch period on this rank's launch stream, this rank's wall).
+        `spinup_s`: seconds of back-to-back steps BEFORE the W warm-up steps.  The board's clock / power management needs
+        ~25 ms of load to leave its idle state (profiles/r03w_step_timeline.txt: mp3 0.43 -> 0.31 ms per step, vorbis 0.59 ->
+        0.38 over the first 25 ms, flat for the next second); W + K short steps from idle measure that ramp, not the kernel."""
+        if spinup_s > 0.0 and not emulate:
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < spinup_s:
+                for _ in range(8):
+                    step()
+                sync()
         for _ in range(warmup):
             step()
         sync()
@@ -627,7 +640,16 @@ def main():
     step, units, unit_name, alg_bytes, config, kernel, result = make_workload(args.workload, torch, ctx, 1234 + rank, args.scale,
                                                                               args.aac_mix, emulate)
     log("workload built: %s" % config["workload"])
-    elapsed, launch_s, mine = timed(step, args.steps, args.warmup)
+    # the same W + K twice: from idle (reported as `cold_start`), then at the sustained clocks (the line's `value`)
+    spin = 0.0 if (args.no_spinup or emulate) else args.spinup_ms / 1e3
+    cold = None
+    if spin > 0.0:
+        e_c, l_c, _ = timed(step, args.steps, args.warmup)
+        cold = {"ms_per_step": e_c / args.steps * 1e3, "kernel_ms": l_c * 1e3, "steps": args.steps, "warmup": args.warmup,
+                "note": "the same W warm-up + K timed steps started from an idle board (clock ramp of ~25 ms, "
+                        "profiles/r03w_step_timeline.txt); `value` is measured after %d ms of back-to-back steps" % args.spinup_ms}
+        log("cold-start region done: %.3f ms/step" % (e_c / args.steps * 1e3))
+    elapsed, launch_s, mine = timed(step, args.steps, args.warmup, spin)
     log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))
     per_rank_ms = [mine / args.steps * 1e3]
     if world > 1:
@@ -661,7 +683,7 @@ def main():
     if world > 1 and not args.no_config4 and args.workload != "vorbis":
         try:
             st4, units4, unit4, bytes4, cfg4, kernel4, _ = make_workload("vorbis", torch, ctx, 4321 + rank, args.scale, 0.0, emulate)
-            e4, l4, _ = timed(st4, max(2, args.steps // 2), 1 if emulate else 2)
+            e4, l4, _ = timed(st4, max(2, args.steps // 2), 1 if emulate else 2, spin)
             n4 = max(2, args.steps // 2)
             config4 = {"value": units4 * world * n4 / e4, "unit": unit4 + "/s", "ms_per_step": e4 / n4 * 1e3, "steps": n4,
                        "config": cfg4, "roofline_frac_rank0": bytes4 / l4 / 1e9 / HBM_PEAK_GBS, "kernel": kernel4}
@@ -684,7 +706,7 @@ def main():
             try:
                 stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, 0.0, emulate)
                 nw, ww = 5, 2
-                ew, lw, _ = timed(stw, nw, ww)
+                ew, lw, _ = timed(stw, nw, ww, spin)
                 others[w] = {"value": unitsw * nw / ew, "unit": unitw + "/s", "ms_per_step": ew / nw * 1e3, "steps": nw, "warmup": ww,
                              "kernel": kernelw, "kernel_ms": lw * 1e3, "algorithmic_bytes_per_launch": bytesw,
                              "roofline_frac": bytesw / lw / 1e9 / HBM_PEAK_GBS, "workload": cfgw["workload"]}
@@ -721,6 +743,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "spinup_ms": (args.spinup_ms if spin > 0.0 else 0),
+            "cold_start": cold,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -748,14 +772,16 @@ def main():
         if ceiling:
             out["roofline"]["copy_ceiling"] = ceiling
             best = max((v for k, v in ceiling.items() if k.startswith(("plain", "frames")) and isinstance(v, float)), default=None)
-            same = ceiling.get("frames_per_wavefront_64_nt")
+            same = ceiling.get("frames_per_workgroup_walk_256_nt")
             if best:
                 out["roofline"]["frac_of_best_copy"] = achieved / best
             if same:
                 out["roofline"]["frac_of_same_pattern_copy"] = achieved / same
             out["roofline"]["copy_ceiling_note"] = ("symaccel_probe_copy_device in THIS run: 512 MiB read + 512 MiB written per launch; "
-                                                    "frames_per_wavefront_64 = every wavefront streams 64 consecutive 4 KiB frames, "
-                                                    "the headline kernel's access pattern; `peak` stays the HBM3E spec")
+                                                    "frames_per_wavefront_64 = every wavefront streams 64 consecutive 4 KiB frames (the "
+                                                    "wavefront walk's pattern); frames_per_workgroup_walk_256 = the four wavefronts of a "
+                                                    "workgroup share 256 consecutive frames round-robin, 16 KiB contiguous per step (the "
+                                                    "headline kernel's pattern: `frac_of_same_pattern_copy`); `peak` stays the HBM3E spec")
         if others:
             out["other_workloads"] = others
         if args.workload == "alac":

@@ -111,11 +111,13 @@ __device__ __forceinline__ void start_window4(const float *sw, int j0, float *w)
 #ifndef SYM_AAC_ABLATE
 #define SYM_AAC_ABLATE 0
 #endif
-// Which walk (build knob): 0 = the wavefront walk, 1 = the workgroup walk (two LDS-only barriers per step).  A third form --
-// dedicated delay slots and point-to-point LDS flags instead of barriers -- measured the same as 1 and was removed
-// (profiles/r03f_aac_quad2_ab.txt).
+// Which walk (build knob): 0 = the wavefront walk, 1 = the workgroup walk (two LDS-only barriers per step; the product).  A third
+// form -- dedicated delay slots and point-to-point LDS flags instead of barriers -- measured the same as 1 and was removed
+// (profiles/r03f_aac_quad2_ab.txt).  Which of the two is faster depends on the clock the board runs at: during the ~25 ms after
+// an idle period (1.4 GHz under this kernel) the arithmetic binds and the wavefront walk is 4-7 % ahead; at the sustained clock
+// the access pattern binds and the workgroup walk is 5-9 % ahead (0.210 against 0.222-0.234 ms, profiles/r03y_aac_sustained.txt).
 #ifndef SYM_AAC_QUAD
-#define SYM_AAC_QUAD 0
+#define SYM_AAC_QUAD 1
 #endif
 // SYM_AAC_SINK 1 (the wavefront walk, one frame in flight): gfx950 counts vector loads and stores with ONE in-order counter
 // (vmcnt).  With the PCM stores under `if (emit)`, the prefetch under `if (t + 1 < t_end)` and the prefetched lines consumed

@@ -30,7 +30,7 @@ namespace symaccel {
 namespace {
 
 #ifndef SYM_MP3_VARIANT
-#define SYM_MP3_VARIANT 0
+#define SYM_MP3_VARIANT 4
 #endif
 // Build variants (tuning knob SYM_MP3_VARIANT, see build.py; DESIGN.md 4.2 has the measurements -- all within 3 % of
 // each other, which is the finding):
@@ -40,8 +40,9 @@ namespace {
 //      four wavefronts per workgroup share the window tables, which pays for the extra 4.5 KiB of LDS per wavefront;
 //   3  two granules of spectral lines in flight instead of one;
 //   4  prefetch and PCM stores issued unconditionally, the prefetched lines consumed at the end of the round (SYM_MP3_SINK
-//      below): the waits are for the lines only -- measured equal (profiles/r03k_mp3_sink_ab.txt), i.e. the write
-//      acknowledgements were not what the kernel waits for.
+//      below): the waits are for the lines only -- measured equal during the clock ramp (profiles/r03k_mp3_sink_ab.txt: the
+//      write acknowledgements were not what the kernel waits for), 1 % ahead at the sustained clock together with the packed
+//      window pass (profiles/r03x_sustained_ab.txt): the product.
 // Round 3's measurements (tools/ubench/valu_clock.hip, tools/kernel_clock_probe.py): the loads and stores alone
 // run at 5.3-5.6 TB/s (SYM_MP3_ABLATE); a wavefront issues one instruction per ~4.9 cycles, a SIMD's VALU port accepts one
 // plain f32 instruction per ~2.5 cycles, so two wavefronts saturate it and the third of a SIMD gets the leftovers (walks of 45
@@ -161,7 +162,7 @@ __device__ __forceinline__ void fetch_granule(const float *granule, int hl, floa
 }
 
 #ifndef SYM_MP3_PACKED
-#define SYM_MP3_PACKED 0
+#define SYM_MP3_PACKED 1
 #endif
 // SYM_MP3_PACKED 1: the window pass computes TWO time slots per instruction stream with v_pk_mul_f32 / v_pk_add_f32 (the two
 // 16-tap sums of slots 2p and 2p + 1 are independent and use the same coefficients).  A wavefront issues at most one

@@ -12,12 +12,12 @@ ROOT = Path(__file__).resolve().parent.parent
 
 CASES = [
     ({"SYMACCEL_TUNE_AAC_VARIANT": "1"}, "tests/test_emu_core_aac.py", "aac_all_sequences or imdct_bit_exact"),
-    ({"SYMACCEL_TUNE_AAC_QUAD": "1"}, "tests/test_emu_core_aac.py", "aac"),
-    ({"SYMACCEL_TUNE_MP3_VARIANT": "2"}, "tests/test_emu_codecs.py", "emu_mp3"),
-    ({"SYMACCEL_TUNE_MP3_VARIANT": "3"}, "tests/test_emu_codecs.py", "emu_mp3"),
-    ({"SYMACCEL_TUNE_MP3_VARIANT": "4"}, "tests/test_emu_codecs.py", "emu_mp3"),
-    ({"SYMACCEL_TUNE_MP3_PACKED": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
-    ({"SYMACCEL_TUNE_MP3_PACKED": "1", "SYMACCEL_TUNE_MP3_VARIANT": "4", "SYMACCEL_TUNE_MP3_PAIR_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_AAC_QUAD": "0"}, "tests/test_emu_core_aac.py", "aac"),
+    ({"SYMACCEL_TUNE_MP3_VARIANT": "2", "SYMACCEL_TUNE_MP3_PACKED": "0"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_VARIANT": "3", "SYMACCEL_TUNE_MP3_PACKED": "0"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_VARIANT": "0", "SYMACCEL_TUNE_MP3_PACKED": "0"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_VARIANT": "0"}, "tests/test_emu_codecs.py", "emu_mp3"),
+    ({"SYMACCEL_TUNE_MP3_PACKED": "0", "SYMACCEL_TUNE_MP3_PAIR_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "18"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_FLAC_PARTS": "4"}, "tests/test_emu_codecs.py", "emu_flac"),

@@ -11,9 +11,15 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import symphonia_amd as sa  # noqa: E402
 
 
-def timeit(fn, reps=10):
+def timeit(fn, reps=10, spinup_s=0.05):
+    import time
     fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()  # sustained clocks: the board needs ~25 ms of load to leave its idle state
+    while time.perf_counter() - t0 < spinup_s:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):

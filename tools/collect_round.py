@@ -30,7 +30,7 @@ def pmc_avg(db, kernel, counter):
     return None if row is None or row[0] is None else float(row[0])
 
 
-KERNELS = {"aac": "aac_synth_kernel", "mp3": "mp3_synth_kernel", "vorbis": "vorbis_synth_wave_kernel",
+KERNELS = {"aac": "aac_synth_quad_kernel", "mp3": "mp3_synth_kernel", "vorbis": "vorbis_synth_wave_kernel",
            "flac": "flac_restore_f64_kernel",
            # (four instantiations are launched per step and three return at once: count the one the workload's wavefronts run in)
            "alac": "alac_predict_kernel<false, true, true>"}

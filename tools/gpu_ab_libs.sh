@@ -5,6 +5,6 @@ TAG=$1; W=$2; REPS=$3; shift 3
 OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 for rep in $(seq $REPS); do
   for lib in "$@"; do
-    SYMACCEL_LIB=$lib timeout 120 python bench.py --workload $W --steps 40 --warmup 5 --no-cpu-baseline --no-others --no-host-path --no-copy-ceiling 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$W', '$(basename $lib)', 'ms_per_step', round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms'],4), 'frac', round(d['roofline']['frac'],4))" | tee -a $OUT/${TAG}_ab.log
+    SYMACCEL_LIB=$lib timeout 120 python bench.py --workload $W --steps ${STEPS:-400} --warmup ${WARMUP:-100} --no-cpu-baseline --no-others --no-host-path --no-copy-ceiling 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$W', '$(basename $lib)', 'ms_per_step', round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms'],4), 'frac', round(d['roofline']['frac'],4))" | tee -a $OUT/${TAG}_ab.log
   done
 done

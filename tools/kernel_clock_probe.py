@@ -19,7 +19,7 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "mp3"
     unit = {"mp3": 576, "aac": 1024}[name]
     step, *_rest, pcm = bench.make_workload(name, torch, ctx, 0)
-    for _ in range(30):  # sustained: the clock follows the load
+    for _ in range(600):  # sustained: the board needs ~25 ms of load to leave its idle state, the clock then follows the load
         step()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
