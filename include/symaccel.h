@@ -539,7 +539,8 @@ int symaccel_multi_set_transport(const symaccel_transport *transport);
  * wavefront streams k consecutive 4 KiB frames, the access pattern of a wavefront that walks a k-frame segment of one
  * chain.  flags bit 0: non-temporal loads and stores (what the synthesis kernels use); bits 1-2 (k > 0 only): 0 copy, 1 read
  * only, 2 write only; bit 3 (k > 0 only): the four wavefronts of a workgroup share 4 k consecutive frames round-robin
- * (16 KiB contiguous per workgroup and step).  Not part of any decode path. */
+ * (16 KiB contiguous per workgroup and step); bit 4: eight wavefronts (two neighbouring workgroups) share 8 k frames, bits 3 + 4:
+ * sixteen.  Not part of any decode path. */
 int symaccel_probe_copy_device(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes,
                                uint32_t frames_per_wavefront, uint32_t flags);
 

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const float4 *__restric
 
 // MODE 0 copy, 1 read only (the values feed a compare that never holds), 2 write only.  GROUP 1: a wavefront streams `per_wave`
 // consecutive frames; GROUP 4: the four wavefronts of a workgroup share 4 * per_wave consecutive frames and take them
-// round-robin (wave j: frames j, j + 4, ...), so that a workgroup's accesses of one step are 16 KiB contiguous.
+// round-robin (wave j: frames j, j + 4, ...), so that a workgroup's accesses of one step are 16 KiB contiguous; GROUP 8 / 16: the same
+// over the wavefronts of two / four neighbouring workgroups (32 / 64 KiB per step).
 template <bool NT, int MODE, int GROUP>
 __global__ __launch_bounds__(256) void probe_copy_frames_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t frames,
                                                                 unsigned per_wave) {
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void probe_copy_frames_kernel(const float4 *__
 
 int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, unsigned frames_per_wavefront, unsigned flags) {
     const bool nt = (flags & 1u) != 0;
-    const unsigned mode = (flags >> 1) & 3u, group = (flags & 8u) ? 4u : 1u;
+    const unsigned mode = (flags >> 1) & 3u, group = (flags & 24u) == 24u ? 16u : ((flags & 16u) ? 8u : ((flags & 8u) ? 4u : 1u));
     const float4 *in = static_cast<const float4 *>(d_src);
     float4 *out = static_cast<float4 *>(d_dst);
     if (frames_per_wavefront == 0) {
@@ -65,12 +66,13 @@ int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t 
         else hipLaunchKernelGGL(probe_copy_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, in, out, n);
     } else {
         const size_t frames = bytes / 4096;
-        const size_t waves = (frames + frames_per_wavefront - 1) / frames_per_wavefront;
+        size_t waves = (frames + frames_per_wavefront - 1) / frames_per_wavefront;
+        waves = (waves + group - 1) / group * group;  // (whole groups: a group's wavefronts interleave over its frames)
         const size_t grid = (waves + 3) / 4;
         if (grid > 0x7fffffffu || mode > 2) return SYMACCEL_ERR_INVALID_ARG;
 #define SYM_PROBE(NT, MODE, GROUP) \
     hipLaunchKernelGGL((probe_copy_frames_kernel<NT, MODE, GROUP>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, frames, frames_per_wavefront)
-#define SYM_PROBE_G(NT, MODE) do { if (group == 4) SYM_PROBE(NT, MODE, 4); else SYM_PROBE(NT, MODE, 1); } while (0)
+#define SYM_PROBE_G(NT, MODE) do { if (group == 16) SYM_PROBE(NT, MODE, 16); else if (group == 8) SYM_PROBE(NT, MODE, 8); else if (group == 4) SYM_PROBE(NT, MODE, 4); else SYM_PROBE(NT, MODE, 1); } while (0)
 #define SYM_PROBE_M(NT) do { if (mode == 0) SYM_PROBE_G(NT, 0); else if (mode == 1) SYM_PROBE_G(NT, 1); else SYM_PROBE_G(NT, 2); } while (0)
         if (nt) SYM_PROBE_M(true); else SYM_PROBE_M(false);
 #undef SYM_PROBE_M

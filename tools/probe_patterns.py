@@ -20,7 +20,8 @@ b = torch.empty_like(a)
 
 
 def run(k, flags, reps=10):
-    ctx._call(d.symaccel_probe_copy_device, a.data_ptr(), b.data_ptr(), nbytes, k, flags)
+    for _ in range(reps):  # (untimed: sustained clocks)
+        ctx._call(d.symaccel_probe_copy_device, a.data_ptr(), b.data_ptr(), nbytes, k, flags)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -35,12 +36,12 @@ for rnd in range(2):
     print("# round", rnd)
     for mode, name, moved in ((0, "copy ", 2), (1, "read ", 1), (2, "write", 1)):
         for nt in (1, 0):
-            for group in (0, 8):
+            for group in (0, 8, 16, 24):
                 row = []
                 for k in (1, 4, 16, 64):
                     ms = run(k, nt | (mode << 1) | group)
                     row.append("k=%-2d %.3f ms %.2f" % (k, ms, moved * nbytes / ms / 1e9))
-                print("%s %s %s | %s" % (name, "nt   " if nt else "plain", "wg-interleaved" if group else "per-wavefront ", " | ".join(row)))
+                print("%s %s %s | %s" % (name, "nt   " if nt else "plain", {0: "per-wavefront   ", 8: "4 waves together ", 16: "8 waves together ", 24: "16 waves together"}[group], " | ".join(row)))
     ms = run(0, 0)
     print("copy  plain grid-stride float4: %.3f ms %.2f" % (ms, 2 * nbytes / ms / 1e9))
     ms = run(0, 1)
