@@ -14,17 +14,20 @@ for w in aac mp3 vorbis flac alac; do
 done
 for w in aac mp3 vorbis flac alac; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${TAG}_${w}_$c -o $w -- python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path --no-others --no-copy-ceiling > $OUT/pmc_${TAG}_${w}_$c.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${TAG}_${w}_$c -o $w -- python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-spinup --no-cpu-baseline --no-host-path --no-others --no-copy-ceiling > $OUT/pmc_${TAG}_${w}_$c.log 2>&1
     echo "rocprof pmc $w $c rc=$?"
   done
 done
 cd $REPO
+python -m pytest tests -m gpu -q 2>&1 | grep -v -E "^(RCCL|HIP|ROCm|Hostname|Librccl)" | tail -n 5 > $OUT/gputest_${TAG}.log
+cat $OUT/gputest_${TAG}.log
 python tools/collect_round.py $TAG --traffic-only
 for w in aac mp3 vorbis flac alac; do
   timeout 300 python bench.py --workload $w --steps 20 --warmup 3 --no-others > $OUT/bench_$w.json 2> $OUT/bench_$w.err
   echo "bench $w rc=$?"; tail -n 1 $OUT/bench_$w.json | cut -c1-300
 done
 python tools/collect_round.py $TAG --stage
+cp $OUT/gputest_${TAG}.log $OUT/profiles_${TAG}/${TAG}_gputest.log
 # the exact default command (what the driver runs): headline + other_workloads + same-run copy ceilings
 timeout 600 python bench.py > $OUT/profiles_${TAG}/${TAG}_default_bench.json 2> $OUT/bench_default.err
 echo "default bench rc=$?"; cut -c1-600 $OUT/profiles_${TAG}/${TAG}_default_bench.json
