@@ -404,6 +404,7 @@ int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t
         return SYMACCEL_OK;
     }
     if ((n == 1024 || n == 2048) && (SYM_MULTI_WAVE & 1)) return launch_fft_big_wave(ctx, n, d_in, d_out, count, inverse);
+    if (n == 4096 && (SYM_MULTI_WAVE & 1)) return launch_fft4096_wg(ctx, d_in, d_out, count, inverse);
     const int points = n >= 2048 ? n : 2048;
     const size_t per_wg = (size_t)(points / n);
     const size_t grid = (count + per_wg - 1) / per_wg;
@@ -443,6 +444,7 @@ int launch_imdct(symaccel_ctx *ctx, const ImdctPlan &plan, const float *d_spec, 
     }
     if ((nf == 1024 || nf == 2048) && (SYM_MULTI_WAVE & 1))
         return launch_imdct_big_wave(ctx, (const cpx *)plan.d_twiddle, nf, d_spec, d_out, count);
+    if (nf == 4096 && (SYM_MULTI_WAVE & 1)) return launch_imdct8192_wg(ctx, (const cpx *)plan.d_twiddle, d_spec, d_out, count);
     if (nf > kMaxPoints) {
         c32 *work = nullptr;
         SYM_TRY((run_big_fft<kBigImdct>(ctx, nf, d_spec, (const cpx *)plan.d_twiddle, nullptr, count, &work)));

@@ -189,6 +189,8 @@ struct AacBandMaps {
 
 // kernel launchers (one per .hip file)
 int launch_fft_big_wave(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count, bool inverse);            // imdct_big.hip
+int launch_fft4096_wg(symaccel_ctx *ctx, const float *d_in, float *d_out, size_t count, bool inverse);                         // imdct_big.hip
+int launch_imdct8192_wg(symaccel_ctx *ctx, const cpx *d_twiddle, const float *d_spec, float *d_out, size_t count);              // imdct_big.hip
 int launch_imdct_big_wave(symaccel_ctx *ctx, const cpx *d_twiddle, int nf, const float *d_spec, float *d_out, size_t count);  // imdct_big.hip
 int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count, bool inverse = false);
 int launch_imdct(symaccel_ctx *ctx, const ImdctPlan &plan, const float *d_spec, float *d_out, size_t count);

@@ -34,10 +34,11 @@ def test_emu_fft_bit_exact(emu_ctx, n):
     assert bit_equal(z, want)
 
 
-@pytest.mark.parametrize("n", [1024, 2048])
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
 def test_emu_big_register_pass_kernels(emu_ctx, n):
-    """1024 / 2048 points: two / four 512-point sub-transforms per wavefront, the last stages in registers; Fft, Ifft (in place),
-    Imdct of 2 n lines, several transforms per wavefront."""
+    """1024 / 2048 points: two / four 512-point sub-transforms per wavefront, the last stages in registers; 4096 points: the four
+    wavefronts of a workgroup take a quarter each and meet in LDS for the last two stages; Fft, Ifft (in place), Imdct of 2 n
+    lines, several transforms per wavefront / workgroup."""
     from symphonia_amd import Ifft
     rng = np.random.default_rng(400 + n)
     for count in (1, 3, 9):
