@@ -605,6 +605,11 @@ int ilog2(int v) {
 
 // SYM_VORBIS_WAVE2 (build knob): 1 = block-size pairs other than 256 / 2048 with bs1 <= 2048 run vorbis_synth_wave2_kernel, 0 = the
 // LDS-staged generic kernel as before (kept for the A/B and for 4096 / 8192-sample blocks).
+// SYM_VORBIS_WG (build knob): 1 = pairs with long blocks of 8192 samples run the workgroup-cooperative vorbis_synth_wg_kernel, 2 = those
+// with 4096-sample long blocks too, 0 = vorbis_synth_wave2_kernel's one-wavefront-per-block form for all of them (kept for the A/B).
+#ifndef SYM_VORBIS_WG
+#define SYM_VORBIS_WG 1
+#endif
 #ifndef SYM_VORBIS_WAVE2
 #define SYM_VORBIS_WAVE2 1
 #endif
@@ -630,7 +635,11 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     const bool wave2_path = !wave_path && spec_stride % 4 == 0 && pcm_stride % 4 == 0 &&
                             ((uintptr_t)d_spectra | (uintptr_t)d_residue | (uintptr_t)d_pcm | (uintptr_t)d_overlap_in | (uintptr_t)d_overlap_out) % 16 == 0 &&
                             SYM_VORBIS_WAVE2;
-    const unsigned seg = choose_segment(ctx, n_chains, nb, wave2_path && bs1_exp <= 10 ? 12 : (wave2_path && bs1_exp == 13 ? 6 : ((wave_path || wave2_path) ? 8 : (bs1_exp > 11 ? 2 : 8))), 1, 1, 1);
+    // long blocks of 8192 samples: the workgroup-cooperative kernel (vorbis_wg.hip), two workgroups resident per CU.  (SYM_VORBIS_WG 2
+    // sends the 4096-sample pairs there as well: measured slower than the one-wavefront-per-block form, 1.85 against 2.2 TB/s -- only
+    // two of its four wavefronts have a sub-transform to do.  The 4096 / 8192 pair would need both block routines in one kernel.)
+    const bool wg_path = wave2_path && !(bs0_exp == 12 && bs1_exp == 13) && ((bs1_exp == 13 && SYM_VORBIS_WG) || (bs1_exp == 12 && SYM_VORBIS_WG == 2));
+    const unsigned seg = choose_segment(ctx, n_chains, nb, wg_path ? 2 : (wave2_path && bs1_exp <= 10 ? 12 : (wave2_path && bs1_exp == 13 ? 6 : ((wave_path || wave2_path) ? 8 : (bs1_exp > 11 ? 2 : 8)))), 1, 1, 1);
     const size_t segs = (nb + seg - 1) / seg;
     const size_t grid = n_chains * segs;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
@@ -647,6 +656,10 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
     hipLaunchKernelGGL(vorbis_offsets_kernel, dim3((unsigned)n_chains), dim3(256), 0, ctx->stream, d_block_flag,
                        d_prev_in, offs, nb, 1 << bs0_exp, 1 << bs1_exp);
     SYM_GPU(ctx, hipGetLastError());
+    if (wg_path)
+        return launch_vorbis_wg(ctx, bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra, d_residue,
+                                spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride,
+                                (const uint32_t *)offs, n_chains, nb, seg);
     if (wave2_path)
         return launch_vorbis_wave2(ctx, bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra, d_residue,
                                    spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride,

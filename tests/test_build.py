@@ -15,7 +15,7 @@ CSRC = ROOT / "symphonia_amd" / "csrc"
 F32_FUSED = re.compile(r"\b(v_fma_f32|v_fmac_f32|v_mac_f32|v_mad_f32|v_pk_fma_f32|v_fma_mix\w*|v_mad_mix\w*|v_fma_legacy_f32|"
                        r"v_mad_legacy_f32|v_mac_legacy_f32|v_dot2c?_f32\w*)\b")
 F64_FUSED = re.compile(r"\b(v_fma_f64|v_fmac_f64)\b")
-SOURCES = ["aac.hip", "aac_tools.hip", "mp3.hip", "mp3_requant.hip", "mp3_stereo.hip", "mpa_polyphase.hip", "vorbis.hip", "vorbis_wave.hip", "vorbis_wave2.hip",
+SOURCES = ["aac.hip", "aac_tools.hip", "mp3.hip", "mp3_requant.hip", "mp3_stereo.hip", "mpa_polyphase.hip", "vorbis.hip", "vorbis_wave.hip", "vorbis_wave2.hip", "vorbis_wg.hip",
            "imdct_generic.hip", "imdct_big.hip", "flac.hip", "alac.hip", "state_copy.hip", "probe.hip"]
 
 

@@ -21,6 +21,8 @@ CASES = [
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "18"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_FLAC_PARTS": "4"}, "tests/test_emu_codecs.py", "emu_flac"),
+    ({"SYMACCEL_TUNE_VORBIS_WG": "0"}, "tests/test_emu_codecs.py", "register_pass_kernel_pairs"),
+    ({"SYMACCEL_TUNE_VORBIS_WG": "2"}, "tests/test_emu_codecs.py", "register_pass_kernel_pairs or emu_vorbis_synth"),
 ]
 
 
