@@ -323,6 +323,68 @@ def test_vorbis_wave_paths(ctx, seed, nb, p_long, tail_short, seg):
     assert np.array_equal(host(d_prev), want[2])
 
 
+@pytest.mark.parametrize("bs0e,bs1e,nb,p_long", [(10, 13, 36, 0.7), (6, 13, 60, 0.4), (13, 13, 20, 1.0), (9, 12, 48, 0.7)])
+def test_vorbis_big_blocks_under_load(ctx, bs0e, bs1e, nb, p_long):
+    """Long blocks of 8192 samples (the workgroup-cooperative kernel: four wavefronts per block, LDS exchange between them) and 4096
+    samples with the whole chip busy: 256 chains = 4 distinct chains x 64 copies, several segments each.  Every copy must equal its
+    original bit for bit (chains are independent: anything else is a race or a stray address), the originals are checked against
+    the oracle."""
+    from symphonia_amd import VorbisDsp
+    rng = np.random.default_rng(17 * bs0e + bs1e)
+    kinds, copies = 4, 64
+    flags0 = (rng.random((kinds, nb)) < p_long).astype(np.uint8)
+    flags0[0, : nb // 3] = 0   # a long run of short blocks (several groups at once)
+    flags0[1, nb // 2:] = 1    # ... and of long ones
+    prev0 = rng.integers(-1, 2, kinds).astype(np.int32)
+    lay = oracle.vorbis_layout(bs0e, bs1e, flags0, prev0)
+    spec_stride, pcm_stride = int(lay[0][:, -1].max()), int(lay[1][:, -1].max())
+    spec_stride += (-spec_stride) % 4
+    pcm_stride += (-pcm_stride) % 4
+    spectra0 = (rng.standard_normal((kinds, spec_stride)) * 0.25).astype(np.float32)
+    overlap0 = rng.standard_normal((kinds, (1 << bs1e) // 2)).astype(np.float32)
+    rep = lambda a: np.ascontiguousarray(np.tile(a, (copies,) + (1,) * (a.ndim - 1)))  # chain c = original c % kinds
+    d_prev, d_ov = dev(rep(prev0)), dev(rep(overlap0))
+    ctx.set_segment(7)
+    pcm = VorbisDsp(ctx, bs0e, bs1e).synth(dev(rep(spectra0)), dev(rep(flags0)), d_prev, d_ov, pcm_stride)
+    ctx.set_segment(0)
+    torch.cuda.synchronize()
+    pcm_k = pcm.view(copies, kinds, -1)
+    ov_k = d_ov.view(copies, kinds, -1)
+    assert torch.equal(pcm_k.view(torch.int32), pcm_k[:1].expand_as(pcm_k).contiguous().view(torch.int32)), "copies of a chain differ"
+    assert torch.equal(ov_k.view(torch.int32), ov_k[:1].expand_as(ov_k).contiguous().view(torch.int32)), "copies of a chain's state differ"
+    want = oracle.vorbis_synth(bs0e, bs1e, spectra0, flags0, prev0, overlap0, pcm_stride)
+    assert_parity(host(pcm[:kinds]), want[0], "vorbis pcm")
+    assert_parity(host(d_ov[:kinds]), want[1], "vorbis overlap")
+    assert np.array_equal(host(d_prev[:kinds]), want[2])
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_workgroup_transforms_under_load(ctx, n):
+    """Fft of 4096 points / Imdct of 8192 lines (four wavefronts per transform) with every CU busy and several transforms per
+    workgroup: 4096 transforms = 16 distinct ones x 256 copies; copies bit-equal, the originals against the oracle."""
+    from symphonia_amd import Fft, Imdct
+    rng = np.random.default_rng(n)
+    kinds, copies = 16, 256
+    if n == 4096:
+        x0 = (rng.standard_normal((kinds, n)) + 1j * rng.standard_normal((kinds, n))).astype(np.complex64)
+        xd = torch.view_as_real(dev(np.ascontiguousarray(np.tile(x0, (copies, 1))))).contiguous()
+        yd = torch.empty_like(xd)
+        Fft(ctx, n).fft(xd, yd)
+        torch.cuda.synchronize()
+        y = yd.view(copies, kinds, -1)
+        assert torch.equal(y.view(torch.int32), y[:1].expand_as(y).contiguous().view(torch.int32))
+        got = host(yd[:kinds].contiguous()).reshape(kinds, -1)  # (re, im) pairs as f32
+        want = np.ascontiguousarray(np.stack([oracle.fft(v) for v in x0]).astype(np.complex64)).view(np.float32).reshape(kinds, -1)
+        assert_parity(got, want, "fft 4096")
+    else:
+        spec0 = (rng.standard_normal((kinds, n)) * np.exp2(rng.integers(-8, 8, (kinds, n)))).astype(np.float32)
+        out = Imdct(ctx, n, -1.0 / 7).imdct(dev(np.ascontiguousarray(np.tile(spec0, (copies, 1)))))
+        torch.cuda.synchronize()
+        o = out.view(copies, kinds, -1)
+        assert torch.equal(o.view(torch.int32), o[:1].expand_as(o).contiguous().view(torch.int32))
+        assert_parity(host(out[:kinds]), oracle.imdct(spec0, -1.0 / 7), "imdct 8192")
+
+
 def test_vorbis_config4_shard_properties(ctx):
     """BASELINE config 4, one GPU's shard: 8 streams x 8 ch = 64 chains x 4096 blocks, 2048/256 Markov block flags.
     Segmentation must not change a bit; sampled chains are checked against the oracle."""
