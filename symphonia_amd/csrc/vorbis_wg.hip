@@ -26,9 +26,9 @@ constexpr int kWgWaves = 4;
 template <int S>
 __device__ __forceinline__ int wgv_slot(int e) { return e + e / S; }
 
-// One block of bs = 2048 S samples, by the whole workgroup.  `area`: >= 512 S + 512 complex slots (staging with padding, then the
-// exchange); `left`: 1024 S floats for the left half of the output -- the four FFT work areas taken as one array: they are idle once
-// the sub-transforms are done --; `ldsf`: this wavefront's FFT work area; `ovl`: dsp.rs:125.
+// One block of bs = 2048 S samples, by the whole workgroup.  `area`: >= 512 S + 512 complex slots (staging with padding, later the
+// left half of the output: 1024 S floats); `work`: the four FFT work areas (kWaveLds floats each; a sub-transform's results are
+// exchanged through its own work area, idle by then); `ldsf`: this wavefront's work area; `ovl`: dsp.rs:125.  Four barriers.
 // Every table value the block needs is requested FIRST, in front of the staging: the loads then travel while the workgroup stages
 // and meets, instead of being exposed one barrier interval at a time (the kernel is bound by the latency of a block's steps).
 // Barriers inside: every wavefront of the workgroup must call this with the same arguments.
@@ -37,12 +37,14 @@ template <int S, bool FUSED, class LT>
 __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float *__restrict__ spec, const float *__restrict__ res,
                                                 const cpx *__restrict__ tw_g, const float *__restrict__ win_long,
                                                 const float *__restrict__ win_short, int flag, int pflag, int bs0, int bs1, c32 *area,
-                                                float *left, float *ldsf, float *ovl, const LT &lt, int tid, float *__restrict__ o, bool emit,
-                                                int keep_below) {
+                                                float *work, float *ldsf, float *ovl, const LT &lt, int tid, float *__restrict__ o, bool emit,
+                                                int keep_below, float4 (&pre)[S], bool pre_valid, const float *__restrict__ next_spec,
+                                                const float *__restrict__ next_res) {
     static_assert(S == 2 || S == 4, "two or four 512-point sub-transforms");
     constexpr int P = 512 * S, N = 2 * P;  // FFT points; lines = samples of one half of the block
     const int lane = tid & 63, wave = tid >> 6;
     float *af = reinterpret_cast<float *>(area);
+    float *left = af;  // (the staging area again, once the gathers are done: see the barriers below)
     c32 *lds = reinterpret_cast<c32 *>(ldsf);
     const int rq = S == 2 ? (wave & 1) : (((wave & 1) << 1) | ((wave >> 1) & 1));
     // the pre-twiddles first: they are needed right behind the first barrier
@@ -54,12 +56,11 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
     const bool same = pflag == flag;
     const float *win = (flag && pflag) ? win_long : win_short;  // dsp.rs:83
     // ---- the block's N lines, coalesced, times the residue (lib.rs:289-291: *f *= r), staged as pairs e = (line 2 e, line 2 e + 1)
-    // (prefetching the next block's lines during this block's transform was measured and bought nothing: the loads above are what
-    // the block waits for at its barriers, not these)
-    {
-        const float4 *s4 = reinterpret_cast<const float4 *>(spec);
-        const float4 *r4 = reinterpret_cast<const float4 *>(res);
-        float4 v[S];
+    // (`pre`: the lines, already multiplied, if the block before prefetched them; `next_spec`: the block to prefetch now, or null.
+    // With the table loads out of the way the block's own lines are the longest wait left in its chain of steps.)
+    auto fetch = [&](const float *sp_, const float *rs_, float4 (&v)[S]) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(sp_);
+        const float4 *r4 = reinterpret_cast<const float4 *>(rs_);
 #pragma unroll
         for (int j = 0; j < S; ++j) v[j] = ld_stream(s4 + tid + 256 * j);
         if constexpr (FUSED) {
@@ -72,13 +73,15 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
                 v[j].w *= q.w;
             }
         }
+    };
+    if (!pre_valid) fetch(spec, res, pre);
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
-            const int e = 2 * (tid + 256 * j);  // (e and e + 1 share a group of S: adjacent slots)
-            area[wgv_slot<S>(e)] = c32{v[j].x, v[j].y};
-            area[wgv_slot<S>(e) + 1] = c32{v[j].z, v[j].w};
-        }
+    for (int j = 0; j < S; ++j) {
+        const int e = 2 * (tid + 256 * j);  // (e and e + 1 share a group of S: adjacent slots)
+        area[wgv_slot<S>(e)] = c32{pre[j].x, pre[j].y};
+        area[wgv_slot<S>(e) + 1] = c32{pre[j].z, pre[j].w};
     }
+    if (next_spec) fetch(next_spec, next_res, pre);  // lands during this block's transform
     wg_sync_lds();
     // ---- wavefront q < S: the 512-point transform of the z-indices S m + rev(q) (mdct.rs:81-88 on the way in)
     c32 x[8];
@@ -114,19 +117,19 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
             wrv[it] = *reinterpret_cast<const float4 *>(win + ((unsigned)(N - 4) - k));
         }
     }
-    wg_sync_lds();  // every gather is done: the area becomes the exchange area
+    // the sub-transform's results go into its own (now idle) work area: no barrier between the gathers and the exchange
     if (wave < S) {
 #pragma unroll
-        for (int B = 0; B < 8; ++B) area[512 * wave + 64 * B + lane] = x[B];
+        for (int B = 0; B < 8; ++B) lds[64 * B + lane] = x[B];
     }
-    wg_sync_lds();
+    wg_sync_lds();  // every sub-transform is published (and every gather done: the staging area is free)
     // ---- the last log2 S stages (no_simd.rs:247-279) and the post-twiddle (mdct.rs:104 / 123) on positions p = 128 wave + 64 i + lane
     c32 val[2][S];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int p = 128 * wave + 64 * i + lane;
 #pragma unroll
-        for (int j = 0; j < S; ++j) val[i][j] = area[512 * j + p];
+        for (int j = 0; j < S; ++j) val[i][j] = reinterpret_cast<const c32 *>(work + (size_t)j * kWaveLds)[p];
         if constexpr (S == 2) {
             bfly(val[i][0], val[i][1], c_mul(val[i][1], w1[i]));  // X[p], X[p + 512]
         } else {
@@ -302,6 +305,10 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     // of `overlap` is taken from it; vorbis_wave2.hip has the reasoning).
     bool rebuild = false;
     int keep_below = 0;
+    float4 pre[S1];  // the next long block's lines, requested while the block before it is transformed
+    bool pre_valid = false;
+#pragma unroll
+    for (int j = 0; j < S1; ++j) pre[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     while (true) {
         if (b >= (long)b_end) {
             if (rebuild || b_end != nb || hi_fresh) break;
@@ -337,12 +344,19 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
         if (e > 11) {
             // ---- one block of 4096 / 8192 samples, by the whole workgroup
             const cpx *twg = flag ? tw_long : tw_short;
-            if (BIG0 == 0 || BIG0 == S1 || flag)
+            if (BIG0 == 0 || BIG0 == S1 || flag) {
+                // (a block of the long size; the next one is prefetched if it has the same size -- the common case)
+                const bool next_same = glen_next > 0 && (flag_next ? e1 : e0) == e;
                 vorbis_wg_block<S1, FUSED>(tb, sp + os_cur, FUSED ? rp + os_cur : nullptr, twg, win_long, win_short, flag, pflag, bs0, bs1, area,
-                                           &wave_lds[0][0], ldsf, ovl, lt, tid, out + op_cur, emit, keep_below);
-            else if constexpr (BIG0 != 0 && BIG0 != S1)
+                                           &wave_lds[0][0], ldsf, ovl, lt, tid, out + op_cur, emit, keep_below, pre, pre_valid,
+                                           next_same ? sp + os_next : nullptr, (FUSED && next_same) ? rp + os_next : nullptr);
+                pre_valid = next_same;
+            } else if constexpr (BIG0 != 0 && BIG0 != S1) {
+                float4 tmp[BIG0];
                 vorbis_wg_block<BIG0, FUSED>(tb, sp + os_cur, FUSED ? rp + os_cur : nullptr, twg, win_long, win_short, flag, pflag, bs0, bs1, area,
-                                             &wave_lds[0][0], ldsf, ovl, lt, tid, out + op_cur, emit, keep_below);
+                                             &wave_lds[0][0], ldsf, ovl, lt, tid, out + op_cur, emit, keep_below, tmp, false, nullptr, nullptr);
+                pre_valid = false;
+            }
             if (rebuild) break;
             op_cur += (uint32_t)((pflag ? bs1 : bs0) + bs) >> 2;
         } else if constexpr (BIG0 == 0) {
