@@ -210,6 +210,11 @@ int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_lon
                        const uint8_t *d_block_flag,
                        const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out,
                        float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg);
+// SYM_VORBIS_WG (build knob): 1 = pairs with long blocks of 8192 samples run the workgroup-cooperative vorbis_synth_wg_kernel, 2 = those
+// with 4096-sample long blocks too, 0 = vorbis_synth_wave2_kernel's one-wavefront-per-block form for all of them (kept for the A/B).
+#ifndef SYM_VORBIS_WG
+#define SYM_VORBIS_WG 1
+#endif
 int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                      const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
                      const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,

@@ -605,11 +605,6 @@ int ilog2(int v) {
 
 // SYM_VORBIS_WAVE2 (build knob): 1 = block-size pairs other than 256 / 2048 with bs1 <= 2048 run vorbis_synth_wave2_kernel, 0 = the
 // LDS-staged generic kernel as before (kept for the A/B and for 4096 / 8192-sample blocks).
-// SYM_VORBIS_WG (build knob): 1 = pairs with long blocks of 8192 samples run the workgroup-cooperative vorbis_synth_wg_kernel, 2 = those
-// with 4096-sample long blocks too, 0 = vorbis_synth_wave2_kernel's one-wavefront-per-block form for all of them (kept for the A/B).
-#ifndef SYM_VORBIS_WG
-#define SYM_VORBIS_WG 1
-#endif
 #ifndef SYM_VORBIS_WAVE2
 #define SYM_VORBIS_WAVE2 1
 #endif

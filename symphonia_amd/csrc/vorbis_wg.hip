@@ -490,6 +490,9 @@ int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_
     // (the 4096 / 8192 pair would need both cooperative block routines in one kernel: 256 VGPRs and scratch -- it stays on
     // vorbis_synth_wave2_kernel, launch_vorbis in vorbis.hip)
     if ((bs1_exp != 12 && bs1_exp != 13) || (bs0_exp == 12 && bs1_exp == 13)) return SYMACCEL_ERR_INVALID_ARG;
+#if SYM_VORBIS_WG != 2
+    if (bs1_exp == 12) return SYMACCEL_ERR_INVALID_ARG;  // (those instantiations exist in the SYM_VORBIS_WG = 2 build only)
+#endif
     const size_t segs = (nb + seg - 1) / seg;
     const size_t grid = n_chains * segs;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
@@ -498,15 +501,21 @@ int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_
                        bs1_exp, tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, \
                        d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs)
     const int big0 = bs0_exp <= 11 ? 0 : (bs0_exp == 12 ? 2 : 4);
+#if SYM_VORBIS_WG == 2
+#define SYM_VWG_12(FUSED) do { if (big0 == 0) SYM_VWG_LAUNCH(FUSED, 12, 0); else SYM_VWG_LAUNCH(FUSED, 12, 2); } while (0)
+#else
+#define SYM_VWG_12(FUSED) do { } while (0)
+#endif
 #define SYM_VWG_BIG(FUSED)                                                                    \
     do {                                                                                      \
         if (bs1_exp == 12) {                                                                  \
-            if (big0 == 0) SYM_VWG_LAUNCH(FUSED, 12, 0); else SYM_VWG_LAUNCH(FUSED, 12, 2);   \
+            SYM_VWG_12(FUSED);                                                                \
         } else if (big0 == 0) SYM_VWG_LAUNCH(FUSED, 13, 0);                                   \
         else SYM_VWG_LAUNCH(FUSED, 13, 4);                                                    \
     } while (0)
     if (d_residue) SYM_VWG_BIG(true); else SYM_VWG_BIG(false);
 #undef SYM_VWG_BIG
+#undef SYM_VWG_12
 #undef SYM_VWG_LAUNCH
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
