@@ -524,7 +524,7 @@ def main():
                     help="N = 1, aac: skip the host-to-host line (pinned, chunked, overlapped staging through symaccel_aac_synth_pipelined)")
     ap.add_argument("--no-others", action="store_true",
                     help="N = 1, aac: skip the `other_workloads` object (BASELINE configs 3, 4 (one GPU's shard), 5 and the ALAC "
-                         "predictor: 5 steps each with the same event timing)")
+                         "predictor: 20 / 20 / 8 / 8 steps each with the same event timing)")
     ap.add_argument("--no-copy-ceiling", action="store_true", help="N = 1: skip the same-run copy probes")
     ap.add_argument("--spinup-ms", type=int, default=60, help="milliseconds of back-to-back steps in front of the W warm-up steps (sustained clocks)")
     ap.add_argument("--no-spinup", action="store_true", help="measure W + K from an idle board only (the clock ramp)")
@@ -644,6 +644,8 @@ def main():
     spin = 0.0 if (args.no_spinup or emulate) else args.spinup_ms / 1e3
     cold = None
     if spin > 0.0:
+        sync()
+        time.sleep(0.25)  # (an idle board: the workload's construction has just run kernels of its own)
         e_c, l_c, _ = timed(step, args.steps, args.warmup)
         cold = {"ms_per_step": e_c / args.steps * 1e3, "kernel_ms": l_c * 1e3, "steps": args.steps, "warmup": args.warmup,
                 "note": "the same W warm-up + K timed steps started from an idle board (clock ramp of ~25 ms, "
@@ -705,7 +707,7 @@ def main():
         for w in ("mp3", "vorbis", "flac", "alac"):
             try:
                 stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, 0.0, emulate)
-                nw, ww = 5, 2
+                nw, ww = (20, 3) if w in ("mp3", "vorbis") else (8, 2)  # (a few milliseconds each for the short ones)
                 ew, lw, _ = timed(stw, nw, ww, spin)
                 others[w] = {"value": unitsw * nw / ew, "unit": unitw + "/s", "ms_per_step": ew / nw * 1e3, "steps": nw, "warmup": ww,
                              "kernel": kernelw, "kernel_ms": lw * 1e3, "algorithmic_bytes_per_launch": bytesw,
