@@ -30,6 +30,9 @@ def test_imdct_and_fft_size_checks(emu_ctx):
     assert call(emu_ctx, "symaccel_fft_c32_device", 6, x.ctypes.data, y.ctypes.data, 1) == _ffi.ERR_INVALID_ARG
     assert call(emu_ctx, "symaccel_imdct_f32_device", 64, 1.0, None, y.ctypes.data, 1) == _ffi.ERR_INVALID_ARG
     assert call(emu_ctx, "symaccel_imdct_f32_device", 64, 1.0, None, None, 0) == _ffi.OK  # empty batch: nothing to do
+    # ... also for the sizes that run the workgroup-cooperative kernels
+    assert call(emu_ctx, "symaccel_imdct_f32_device", 8192, 1.0, None, None, 0) == _ffi.OK
+    assert call(emu_ctx, "symaccel_fft_c32_device", 4096, None, None, 0) == _ffi.OK
 
 
 def test_codec_entry_points_reject_bad_arguments(emu_ctx):
@@ -44,6 +47,10 @@ def test_codec_entry_points_reject_bad_arguments(emu_ctx):
     # vorbis/lib.rs:404-406, 461-470: 2^6 <= bs0 <= bs1 <= 2^13
     for bs0, bs1 in ((5, 11), (8, 14), (11, 8)):
         assert call(emu_ctx, "symaccel_vorbis_synth_device", bs0, bs1, p(f), 1024, p(i8), p(i32), p(f), p(f), 1024, 1, 1) == _ffi.ERR_INVALID_ARG
+    # empty batches (no chains / no blocks), also for the pair with 8192-sample long blocks (its own kernel)
+    for bs0, bs1 in ((8, 11), (10, 13), (7, 10)):
+        assert call(emu_ctx, "symaccel_vorbis_synth_device", bs0, bs1, None, 0, None, None, None, None, 0, 0, 5) == _ffi.OK
+        assert call(emu_ctx, "symaccel_vorbis_synth_device", bs0, bs1, None, 0, None, None, None, None, 0, 3, 0) == _ffi.OK
     assert call(emu_ctx, "symaccel_vorbis_synth_fr_device", 8, 11, p(f), None, 1024, p(i8), p(i32), p(f), p(f), 1024, 1, 1) == _ffi.ERR_INVALID_ARG
     xs = np.array([0, 128, 64, 64], np.uint32)  # duplicate x: render_line would divide by zero in the reference
     assert call(emu_ctx, "symaccel_vorbis_floor1_device", p(xs), 4, 1, p(i32), 128, p(f), 1) == _ffi.ERR_INVALID_ARG
