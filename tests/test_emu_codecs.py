@@ -120,7 +120,8 @@ def test_emu_vorbis_synth(emu_ctx, bs0e, bs1e, seg):
                                                       (9, 11, 40, 0.5, 7), (10, 11, 33, 0.2, 1), (11, 11, 20, 0.5, 3), (6, 11, 90, 0.1, 13),
                                                       (7, 7, 77, 0.5, 10), (9, 9, 30, 1.0, 4), (6, 10, 100, 0.0, 33),
                                                       (9, 12, 40, 0.6, 6), (10, 13, 24, 0.5, 5), (12, 12, 12, 0.5, 3), (12, 13, 14, 0.5, 4),
-                                                      (13, 13, 7, 0.4, 2), (6, 13, 60, 0.3, 9), (11, 12, 30, 0.7, 1000), (8, 12, 50, 0.2, 3)])
+                                                      (13, 13, 7, 0.4, 2), (6, 13, 60, 0.3, 9), (11, 12, 30, 0.7, 1000), (8, 12, 50, 0.2, 3),
+                                                      (10, 13, 1, 1.0, 1), (10, 13, 2, 0.5, 1), (9, 13, 3, 0.5, 2), (11, 13, 5, 0.6, 1)])
 def test_emu_vorbis_register_pass_kernel_pairs(emu_ctx, bs0e, bs1e, nb, p_long, seg):
     """vorbis_synth_wave2_kernel (every pair except 256 / 2048; blocks of 4096 / 8192 samples on its big-block path): runs longer than a group
     holds (2048 / bs blocks), runs across the 64-block flag masks, every transition, segment halos, equal sizes, chains of one
