@@ -9,7 +9,7 @@ PASS_B="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_
 for w in "$@"; do
   for p in A B; do
     eval "C=\$PASS_$p"
-    timeout 200 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_${TAG}_${w}_$p -o $w -- python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path > $OUT/pmc_${TAG}_${w}_$p.log 2>&1
+    timeout 200 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_${TAG}_${w}_$p -o $w -- python $REPO/bench.py --workload $w --steps 3 --warmup 1 --spinup-ms 40 --no-cpu-baseline --no-host-path --no-others --no-copy-ceiling > $OUT/pmc_${TAG}_${w}_$p.log 2>&1
     echo "pmc $w pass $p rc=$?"
   done
 done
