@@ -62,10 +62,22 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             dsp.synth(coeffs, side, delay[0], pcm, delay_out=delay[1])  # one launch; the next call continues from delay[1]
             delay.reverse()
         step.input = coeffs
+        step.aac = (coeffs, side)
+
+        def verify_step():
+            z = torch.zeros_like(delay[0])
+            dsp.synth(coeffs, side, z, pcm, delay_out=delay[1])
+            return pcm
+        step.verify_step = verify_step
         frames = nch * nfr // 2
-        return step, frames, "frames", nch * nfr * 8192, {
-            "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d), 1024-pt IMDCT+window+OLA, KBD"
-                        % (frames, nch, nfr), "channel_frames": nch * nfr, "samples_per_frame": 1024}, "aac_synth_quad_kernel", pcm
+        cfg = {"workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d), 1024-pt IMDCT+window+OLA, KBD"
+                           % (frames, nch, nfr), "channel_frames": nch * nfr, "samples_per_frame": 1024}
+        if mix > 0.0:
+            hist = np.bincount((sd & 3).ravel(), minlength=4) / float(sd.size)
+            cfg["workload"] = ("AAC-LC 48 kHz stereo, %d frames (%d chains x %d) on legal window-sequence walks, random window shapes, "
+                               "1024-pt / 8 x 128-pt IMDCT+window+OLA" % (frames, nch, nfr))
+            cfg["mix"] = {"p_switch": mix, "only_long": hist[0], "long_start": hist[1], "eight_short": hist[2], "long_stop": hist[3]}
+        return step, frames, "frames", nch * nfr * 8192, cfg, "aac_synth_quad_kernel", pcm
     if name == "mp3":
         nch, ngr = max(2, int(128 * scale)), (6 if emulate else 2048)  # 64 stereo streams x 2048 granules = 131 072 granules
         xr = torch.randn((nch, ngr, 576), generator=g, device=dev, dtype=torch.float32) * 0.05
@@ -97,10 +109,23 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             syn.synth(xr, side, st[0][0], st[0][1], st[0][2], pcm, state_out=st[1])
             st.reverse()
         step.input = xr
+        step.mp3 = (xr, side)
+
+        def verify_step():
+            z = [torch.zeros_like(t) for t in st[0]]
+            syn.synth(xr, side, z[0], z[1], z[2], pcm, state_out=st[1])
+            return pcm
+        step.verify_step = verify_step
         granules = nch * ngr // 2
-        return step, granules, "granules", nch * ngr * 4608, {
-            "workload": "MP3 Layer III 44.1 kHz stereo, %d long-block granules (%d chains x %d), hybrid synthesis + polyphase"
-                        % (granules, nch, ngr), "granule_channels": nch * ngr, "samples_per_granule": 576}, "mp3_synth_kernel", pcm
+        cfg = {"workload": "MP3 Layer III 44.1 kHz stereo, %d long-block granules (%d chains x %d), hybrid synthesis + polyphase"
+                           % (granules, nch, ngr), "granule_channels": nch * ngr, "samples_per_granule": 576}
+        if mix > 0.0:
+            hist = np.bincount(bt.ravel(), minlength=4) / float(bt.size)
+            cfg["workload"] = ("MP3 Layer III 44.1 kHz stereo, %d granules (%d chains x %d) on Long / Start -> Short.. -> End walks, a quarter of "
+                               "the short runs mixed, rzero uniform in 200..576, hybrid synthesis + polyphase" % (granules, nch, ngr))
+            cfg["mix"] = {"p_switch": mix, "long": hist[0], "start": hist[1], "short": hist[2], "end": hist[3],
+                          "mixed_share_of_short": float(mx[bt == 2].mean()) if (bt == 2).any() else 0.0}
+        return step, granules, "granules", nch * ngr * 4608, cfg, "mp3_synth_kernel", pcm
     if name == "vorbis":
         nch, nb = max(1, int(64 * scale)), (16 if emulate else 4096)  # one GPU's shard of config 4: 8 streams x 8 ch x 4096 blocks
         rng = np.random.default_rng(seed)
@@ -298,6 +323,44 @@ def cpu_baseline(name, seconds=10.0):
             "cpu": "%s, %d logical CPUs online, %d usable" % (oracle.cpu_model(), os.cpu_count() or 0, cores),
             "sample": build + ": " + sample + " per task; %d tasks on %d threads in %.1f s (scalar -O2 restatement on one thread: "
                       "%.3g %s)" % (reps, cores, dt, units * reps1 / dt1, unit)}
+
+
+def verify_sampled_chains(name, step, torch, sync):
+    """Tie the timed batch to a verified result: one more step of THE SAME batch (outside every timed region) from a zero
+    carried state, then sampled chains x frame windows of its output compared bit for bit with the oracle (the checker,
+    oracle/ -- test infrastructure).  A window that does not start at frame 0 is recomputed from `halo` frames earlier with
+    a zero state: the carried state of these codecs depends on the previous frame's (MP3: two granules') INPUT alone
+    (SURVEY 8e).  Windows: the chain's start, the 256-frame workgroup-walk boundary, a segment boundary, the chain's end."""
+    import oracle
+    if name == "aac":
+        (coeffs, side), halo = step.aac, 1
+    elif name == "mp3":
+        (coeffs, side), halo = step.mp3, 2
+    else:
+        return None
+    nch, nfr = int(coeffs.shape[0]), int(coeffs.shape[1])
+    pcm = step.verify_step()
+    sync()
+    chains = sorted({0, nch // 2 - 1, nch // 2, nch - 1})
+    wins = [(a, min(b, nfr)) for a, b in ((0, 24), (60, 70), (250, 262), (nfr - 12, nfr)) if a < nfr and a >= 0]
+    checked, bad = 0, 0
+    for c in chains:
+        for a, b in wins:
+            a0 = max(0, a - halo)
+            x = coeffs[c:c + 1, a0:b].cpu().numpy()
+            sd = side[c:c + 1, a0:b].cpu().numpy()
+            if name == "aac":
+                want, _ = oracle.aac_synth(x, sd, np.zeros((1, 1024), np.float32))
+            else:
+                want, _, _, _ = oracle.mp3_synth(x, sd, 0, np.zeros((1, 576), np.float32), np.zeros((1, 1024), np.float32), np.zeros(1, np.int32))
+            got = pcm[c, a:b].cpu().numpy()
+            w = want[0, a - a0:]
+            bad += int((got != w).sum())  # (value comparison: the sign of a zero is not part of the contract, DESIGN section 2)
+            checked += got.size
+    if bad:
+        raise RuntimeError("bench: the timed %s batch differs from the oracle in %d of %d sampled samples" % (name, bad, checked))
+    return {"checker": "oracle/symoracle.c (CPU restatement), outside the timed region", "chains": chains, "frame_windows": wins,
+            "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
 
 
 def workload_input(name, step):
@@ -653,6 +716,10 @@ def main():
         log("cold-start region done: %.3f ms/step" % (e_c / args.steps * 1e3))
     elapsed, launch_s, mine = timed(step, args.steps, args.warmup, spin)
     log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))
+    verified = None
+    if rank == 0 and args.workload in ("aac", "mp3"):
+        verified = verify_sampled_chains(args.workload, step, torch, sync)  # raises on a mismatch: no line for a wrong result
+        log("timed batch verified against the oracle: %d samples" % verified["samples_compared"])
     per_rank_ms = [mine / args.steps * 1e3]
     if world > 1:
         per_rank_ms = [None] * world
@@ -704,19 +771,28 @@ def main():
     others = None
     if world == 1 and args.workload == "aac" and not args.no_others:
         others = {}
-        for w in ("mp3", "vorbis", "flac", "alac"):
+        # (key, workload, block-switch probability): the BASELINE configs at their headline settings, then what a REAL stream
+        # costs -- AAC with legal window-sequence walks (5 % / 25 % of the long frames start a LONG_START -> EIGHT_SHORT.. ->
+        # LONG_STOP run, random window shapes) and MP3 with Start -> Short.. -> End runs (a quarter of them mixed) and random
+        # rzero: SURVEY 8d's correctness mixes, timed
+        for key, w, mixw in (("mp3", "mp3", 0.0), ("vorbis", "vorbis", 0.0), ("flac", "flac", 0.0), ("alac", "alac", 0.0),
+                             ("aac_mix_0.05", "aac", 0.05), ("aac_mix_0.25", "aac", 0.25), ("mp3_mix_0.06", "mp3", 0.06)):
             try:
-                stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, 0.0, emulate)
-                nw, ww = (20, 3) if w in ("mp3", "vorbis") else (8, 2)  # (a few milliseconds each for the short ones)
+                stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, mixw, emulate)
+                nw, ww = (20, 3) if w in ("aac", "mp3", "vorbis") else (8, 2)  # (a few milliseconds each for the short ones)
                 ew, lw, _ = timed(stw, nw, ww, spin)
-                others[w] = {"value": unitsw * nw / ew, "unit": unitw + "/s", "ms_per_step": ew / nw * 1e3, "steps": nw, "warmup": ww,
-                             "kernel": kernelw, "kernel_ms": lw * 1e3, "algorithmic_bytes_per_launch": bytesw,
-                             "roofline_frac": bytesw / lw / 1e9 / HBM_PEAK_GBS, "workload": cfgw["workload"]}
+                others[key] = {"value": unitsw * nw / ew, "unit": unitw + "/s", "ms_per_step": ew / nw * 1e3, "steps": nw, "warmup": ww,
+                               "kernel": kernelw, "kernel_ms": lw * 1e3, "algorithmic_bytes_per_launch": bytesw,
+                               "roofline_frac": bytesw / lw / 1e9 / HBM_PEAK_GBS, "workload": cfgw["workload"]}
+                if mixw:
+                    others[key]["mix"] = cfgw.get("mix")
+                if w in ("aac", "mp3"):
+                    others[key]["verified"] = verify_sampled_chains(w, stw, torch, sync)
                 del stw, resw
             except Exception as e:  # noqa: BLE001
-                others[w] = {"error": "%s: %s" % (type(e).__name__, e)}
+                others[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
-            log("other workload %s done" % w)
+            log("other workload %s done" % key)
 
     # N > 1, real GPUs: (a) the deployment shape DESIGN.md section 7 argues for -- every rank stages ITS shard from its own
     # page-locked host memory (per-GPU producers: no rank-0 bottleneck) --, (b) the exchange leg once more through the C ABI.
@@ -745,8 +821,12 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "schema": 4,
+            "protocol": ("sustained (spinup %d ms of back-to-back steps, then W warm-up + K timed steps); `cold_start` = the same W + K "
+                         "from an idle board, the protocol of BENCH_r01 / r02" % args.spinup_ms) if spin > 0.0 else "cold (W + K from an idle board)",
             "spinup_ms": (args.spinup_ms if spin > 0.0 else 0),
             "cold_start": cold,
+            "verified": verified,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
