@@ -192,6 +192,9 @@ def test_a5_every_fft_size_within_1e5_of_the_closed_form(ctx, e):
         full = np.fft.fft(x[r].astype(np.complex128))
         assert np.abs(full[bins] - want).max() < 1e-9 * max(1.0, np.abs(full).max())  # (the sampled closed form is the DFT)
         assert np.abs(got[r] - full).max() <= 1e-5 * max(1.0, np.abs(full).max()), n
+    if n < 32:
+        return  # the reference's Ifft runs no butterflies below 32 points (`transform`, no_simd.rs:221-281, has no case for them:
+        # its output there is NOT the inverse DFT -- the product reproduces that bit for bit, test_fft_parity / fixtures `ifft_*`)
     zi = xd.clone()
     Ifft(ctx, n).ifft_inplace(zi)
     back = host(zi).reshape(3, n, 2)
