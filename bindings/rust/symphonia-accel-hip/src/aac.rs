@@ -1,10 +1,13 @@
 //! `HipAacDecoder`: AAC-LC with the synthesis tail (Dsp::synth, symphonia-codec-aac/src/aac/dsp.rs:57-158) on the MI355X.
+use std::sync::{Arc, Mutex};
+
+use symphonia_codec_aac::{AacDecoder, SynthBackend};
 use symphonia_core::audio::{Audio, AudioBuffer, AudioMut, AudioSpec, GenericAudioBufferRef};
 use symphonia_core::codecs::audio::well_known::CODEC_ID_AAC;
 use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoder, AudioDecoderOptions, FinalizeResult};
 use symphonia_core::codecs::registry::{RegisterableAudioDecoder, SupportedAudioCodec};
 use symphonia_core::codecs::CodecInfo;
-use symphonia_core::errors::{unsupported_error, Result};
+use symphonia_core::errors::{decode_error, unsupported_error, Result};
 use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
@@ -22,8 +25,96 @@ pub struct ParsedAac {
 /// The CPU front end: the reference's `AacDecoder::decode_inner` up to (not including) `synth_audio`
 /// (symphonia-codec-aac/src/aac/mod.rs:170-225), vendored because `mod aac` is private to its crate.
 pub trait AacFrontEnd: Send + Sync {
+    /// The stream's parameters as the reference's decoder amends them (sample rate and channels from the
+    /// AudioSpecificConfig, aac/mod.rs:99-102).
+    fn params(&self) -> &AudioCodecParameters;
     fn channels(&self) -> usize;
     fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedAac>;
+}
+
+/// What the reference's decoder hands its `SynthBackend` for one packet (bindings/rust/patches/symphonia-codec-aac.diff).
+#[derive(Default)]
+pub struct AacRecord {
+    pub coeffs: Vec<f32>, // [channel][1024]
+    pub side: Vec<u8>,    // [channel]
+    pub seen: Vec<bool>,  // [channel]: the packet carried this channel
+}
+
+impl AacRecord {
+    fn begin_packet(&mut self, nch: usize) {
+        self.coeffs.clear();
+        self.coeffs.resize(nch * 1024, 0.0);
+        self.side.clear();
+        self.side.resize(nch, 0);
+        self.seen.clear();
+        self.seen.resize(nch, false);
+    }
+}
+
+/// The `SynthBackend` handed to the reference's `AacDecoder`: the coefficients `Dsp::synth` would transform (after
+/// joint stereo, pulse data and TNS -- all of that is the reference's code) are recorded, nothing is synthesized.
+pub struct Recorder(pub Arc<Mutex<AacRecord>>);
+
+impl SynthBackend for Recorder {
+    fn synth(
+        &mut self,
+        channel: usize,
+        coeffs: &[f32; 1024],
+        _delay: &mut [f32; 1024],
+        window_sequence: u8,
+        window_shape: bool,
+        prev_window_shape: bool,
+        _dst: &mut [f32],
+    ) {
+        let mut rec = self.0.lock().expect("aac record poisoned");
+        if channel < rec.seen.len() {
+            rec.coeffs[channel * 1024..(channel + 1) * 1024].copy_from_slice(coeffs);
+            // SYMACCEL_AAC_SIDE(seq, shape, prev_shape), include/symaccel.h
+            rec.side[channel] = (window_sequence & 3) | ((window_shape as u8) << 2) | ((prev_window_shape as u8) << 3);
+            rec.seen[channel] = true;
+        }
+    }
+}
+
+/// `AacFrontEnd` over the reference's own decoder with the recording backend installed: element parsing, Huffman decoding,
+/// dequantisation, M/S and intensity stereo, PNS, pulse data and TNS are symphonia-codec-aac's code, unmodified.
+pub struct SeamFrontEnd {
+    dec: AacDecoder,
+    rec: Arc<Mutex<AacRecord>>,
+    nch: usize,
+}
+
+impl SeamFrontEnd {
+    pub fn try_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Self> {
+        let rec: Arc<Mutex<AacRecord>> = Arc::new(Mutex::new(AacRecord::default()));
+        let dec = AacDecoder::try_new_with_backend(params, opts, Box::new(Recorder(rec.clone())))?;
+        // the decoder amends its parameters from the AudioSpecificConfig (aac/mod.rs:99-102)
+        let Some(channels) = dec.codec_params().channels.clone() else {
+            return unsupported_error("aac: channels are required");
+        };
+        Ok(SeamFrontEnd { dec, rec, nch: channels.count() })
+    }
+}
+
+impl AacFrontEnd for SeamFrontEnd {
+    fn params(&self) -> &AudioCodecParameters {
+        self.dec.codec_params()
+    }
+
+    fn channels(&self) -> usize {
+        self.nch
+    }
+
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedAac> {
+        self.rec.lock().expect("aac record poisoned").begin_packet(self.nch);
+        self.dec.decode_ref(packet)?;
+        let rec = self.rec.lock().expect("aac record poisoned");
+        if rec.seen.iter().any(|s| !*s) {
+            // the reference would have left the missing channel's plane as it was rendered: not a stream this path takes
+            return decode_error("aac: the packet does not carry every channel of the stream");
+        }
+        Ok(ParsedAac { coeffs: rec.coeffs.clone(), side: rec.side.clone() })
+    }
 }
 
 struct AacBatch {
@@ -101,14 +192,15 @@ pub struct HipAacDecoder {
 }
 
 impl HipAacDecoder {
-    pub fn try_new(params: &AudioCodecParameters, _opts: &AudioDecoderOptions, front: Box<dyn AacFrontEnd>, max_batch: usize) -> Result<Self> {
+    pub fn try_new(_params: &AudioCodecParameters, _opts: &AudioDecoderOptions, front: Box<dyn AacFrontEnd>, max_batch: usize) -> Result<Self> {
+        let params = front.params().clone();
         let (Some(rate), Some(channels)) = (params.sample_rate, params.channels.clone()) else {
             return unsupported_error("aac: sample rate and channels are required");
         };
         let nch = front.channels();
         let max_batch = max_batch.max(1);
         Ok(HipAacDecoder {
-            params: params.clone(),
+            params,
             batch: AacBatch {
                 ctx: Context::new(0)?,
                 front,
@@ -158,7 +250,7 @@ impl AudioDecoder for HipAacDecoder {
 impl RegisterableAudioDecoder for HipAacDecoder {
     fn try_registry_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Box<dyn AudioDecoder>> {
         // no front end, no device, no memory: the decoder that was registered below this one takes the track
-        match crate::frontends::aac_front_end(params).and_then(|front| HipAacDecoder::try_new(params, opts, front, crate::DEFAULT_LOOKAHEAD)) {
+        match crate::frontends::aac_front_end(params, opts).and_then(|front| HipAacDecoder::try_new(params, opts, front, crate::DEFAULT_LOOKAHEAD)) {
             Ok(decoder) => Ok(Box::new(decoder)),
             Err(e) => crate::fallback::make(params, opts, e),
         }

@@ -66,7 +66,7 @@ macro_rules! hip_decoder {
                 opts: &symphonia_core::codecs::audio::AudioDecoderOptions,
             ) -> symphonia_core::errors::Result<Box<dyn symphonia_core::codecs::audio::AudioDecoder>> {
                 // no front end, no device, no memory: the decoder that was registered below this one takes the track
-                match $front_end(params).and_then(|front| Self::try_new(params, opts, front, $crate::DEFAULT_LOOKAHEAD)) {
+                match $front_end(params, opts).and_then(|front| Self::try_new(params, opts, front, $crate::DEFAULT_LOOKAHEAD)) {
                     Ok(decoder) => Ok(Box::new(decoder)),
                     Err(e) => $crate::fallback::make(params, opts, e),
                 }

@@ -12,16 +12,19 @@ use symphonia_core::codecs::audio::{AudioCodecId, AudioCodecParameters, AudioDec
 use symphonia_core::codecs::registry::{AudioDecoderFactoryFn, CodecRegistry};
 use symphonia_core::errors::{Error, Result};
 
-static BELOW: Mutex<Option<HashMap<AudioCodecId, AudioDecoderFactoryFn>>> = Mutex::new(None);
+/// Per codec id: `Some(factory)` = the decoder that was in force when this crate registered above it, `None` = there was none.
+static BELOW: Mutex<Option<HashMap<AudioCodecId, Option<AudioDecoderFactoryFn>>>> = Mutex::new(None);
 
-/// Record what `registry` answers for `ids` right now (call before registering above it).  The first registration wins:
-/// a second `register` call would otherwise record this crate's own factory and recurse.
+/// Record what `registry` answers for `ids` right now (call before registering above it).  The FIRST lookup wins, also when
+/// it finds nothing: a second `register` call on the same registry would otherwise find this crate's own factory there, and
+/// `make` would call it, which calls `make` again.
 pub fn remember(registry: &CodecRegistry, ids: &[AudioCodecId]) {
     let mut below = BELOW.lock().expect("fallback table poisoned");
     let map = below.get_or_insert_with(HashMap::new);
     for id in ids {
-        if let Some(found) = registry.get_audio_decoder(*id) {
-            map.entry(*id).or_insert(found.factory);
+        if !map.contains_key(id) {
+            let found = registry.get_audio_decoder(*id).map(|r| r.factory);
+            map.insert(*id, found);
         }
     }
 }
@@ -30,7 +33,10 @@ pub fn remember(registry: &CodecRegistry, ids: &[AudioCodecId]) {
 pub fn factory_below(id: AudioCodecId) -> Option<AudioDecoderFactoryFn> {
     let below = BELOW.lock().expect("fallback table poisoned");
     match below.as_ref() {
-        Some(map) => map.get(&id).copied(),
+        Some(map) => match map.get(&id) {
+            Some(entry) => *entry,
+            None => None,
+        },
         None => None,
     }
 }

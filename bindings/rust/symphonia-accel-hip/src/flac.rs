@@ -1,9 +1,12 @@
 //! `HipFlacDecoder`: the predictor stage of every subframe (fixed and LPC, symphonia-bundle-flac/src/decoder.rs:663-752),
 //! the stereo decorrelation (:32-82) and the left-justification shift (:239-242) on the MI355X.  FLAC carries no state
 //! from frame to frame, so a batch is simply many frames' subframes side by side.
+use std::sync::{Arc, Mutex};
+
+use symphonia_bundle_flac::{Decorrelation, FlacDecoder, SynthBackend};
 use symphonia_core::audio::{Audio, AudioBuffer, AudioMut, AudioSpec, GenericAudioBufferRef};
 use symphonia_core::codecs::audio::well_known::CODEC_ID_FLAC;
-use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoderOptions};
+use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoder, AudioDecoderOptions};
 use symphonia_core::errors::{decode_error, unsupported_error, Result};
 use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
@@ -20,15 +23,137 @@ pub struct ParsedFlac {
     pub blocksize: usize,
     pub words: Vec<i32>,                 // [channel][blocksize]
     pub desc: Vec<ffi::SymaccelFlacDesc>, // [channel]
-    pub coeffs: Vec<i32>,                // [channel][32], reference order (decoder.rs:716-752)
+    pub coeffs: Vec<i32>,                // [channel][32], bitstream order (the first coefficient multiplies the most recent sample)
     pub pair_mode: u8,                   // 0 independent, 1 left/side, 2 mid/side, 3 right/side (stereo frames only)
     pub out_shift: u32,                  // 32 - bits per sample (decoder.rs:239-242)
 }
 
 pub trait FlacFrontEnd: Send + Sync {
+    /// The stream's parameters as the reference's decoder amends them from STREAMINFO (decoder.rs:110-118): sample rate,
+    /// channels, bits per sample, maximum block size.
+    fn params(&self) -> &AudioCodecParameters;
     fn channels(&self) -> usize;
     fn max_blocksize(&self) -> usize;
     fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedFlac>;
+}
+
+/// What the reference's decoder tells its `SynthBackend` about one frame (bindings/rust/patches/symphonia-bundle-flac.diff):
+/// the recording backend below stores it instead of computing anything, so the decoder's `AudioBuffer` is left holding
+/// every subframe's warm-up samples and residuals -- the input of the batched device call.
+#[derive(Default)]
+pub struct FlacRecord {
+    pub desc: Vec<ffi::SymaccelFlacDesc>, // [channel]
+    pub coeffs: Vec<i32>,                 // [channel][32], bitstream order
+    pub pair_mode: u8,
+    pub out_shift: u32,
+}
+
+impl FlacRecord {
+    fn begin_frame(&mut self, nch: usize) {
+        self.desc.clear();
+        self.desc.resize(nch, ffi::SymaccelFlacDesc { kind: 0, order: 0, shift: 0, wasted_bits: 0 });
+        self.coeffs.clear();
+        self.coeffs.resize(nch * 32, 0);
+        self.pair_mode = 0;
+        self.out_shift = 0;
+    }
+}
+
+/// The `SynthBackend` handed to the reference's `FlacDecoder`: every operation after entropy decoding is recorded, none
+/// is performed.
+pub struct Recorder(pub Arc<Mutex<FlacRecord>>);
+
+impl SynthBackend for Recorder {
+    fn fixed_predict(&mut self, channel: usize, order: u32, _buf: &mut [i32]) {
+        let mut rec = self.0.lock().expect("flac record poisoned");
+        rec.desc[channel].kind = ffi::SYMACCEL_FLAC_FIXED as u8;
+        rec.desc[channel].order = order as u8;
+    }
+
+    fn lpc_predict(&mut self, channel: usize, order: u32, qlp_coeffs: &[i32; 32], qlp_coeff_shift: u32, _buf: &mut [i32]) {
+        let mut rec = self.0.lock().expect("flac record poisoned");
+        rec.desc[channel].kind = ffi::SYMACCEL_FLAC_LPC as u8;
+        rec.desc[channel].order = order as u8;
+        rec.desc[channel].shift = qlp_coeff_shift as u8;
+        // the decoder stores the first coefficient it reads at index 31 (decoder.rs:477-481); the C ABI wants bitstream order
+        for j in 0..order as usize {
+            rec.coeffs[channel * 32 + j] = qlp_coeffs[31 - j];
+        }
+    }
+
+    fn samples_shl(&mut self, channel: usize, shift: u32, _buf: &mut [i32]) {
+        let mut rec = self.0.lock().expect("flac record poisoned");
+        rec.desc[channel].wasted_bits = shift as u8;
+    }
+
+    fn decorrelate(&mut self, mode: Decorrelation, _plane0: &mut [i32], _plane1: &mut [i32]) {
+        let mut rec = self.0.lock().expect("flac record poisoned");
+        rec.pair_mode = match mode {
+            Decorrelation::LeftSide => 1,
+            Decorrelation::MidSide => 2,
+            Decorrelation::RightSide => 3,
+        };
+    }
+
+    fn left_justify(&mut self, shift: u32, _buf: &mut AudioBuffer<i32>) {
+        let mut rec = self.0.lock().expect("flac record poisoned");
+        rec.out_shift = shift;
+    }
+}
+
+/// `FlacFrontEnd` over the reference's own decoder with the recording backend installed: frame sync, frame header, subframe
+/// headers and Rice decoding are symphonia-bundle-flac's code, unmodified.
+pub struct SeamFrontEnd {
+    dec: FlacDecoder,
+    rec: Arc<Mutex<FlacRecord>>,
+    nch: usize,
+    max_bs: usize,
+}
+
+impl SeamFrontEnd {
+    pub fn try_new(params: &AudioCodecParameters) -> Result<Self> {
+        let rec: Arc<Mutex<FlacRecord>> = Arc::new(Mutex::new(FlacRecord::default()));
+        // (verification is the caller's: the MD5 would be fed the residuals)
+        let opts = AudioDecoderOptions { verify: false, ..Default::default() };
+        let dec = FlacDecoder::try_new_with_backend(params, &opts, Box::new(Recorder(rec.clone())))?;
+        // the decoder amends its parameters from STREAMINFO (decoder.rs:110-118)
+        let (Some(channels), Some(max_bs)) = (dec.codec_params().channels.clone(), dec.codec_params().max_frames_per_packet) else {
+            return unsupported_error("flac: stream info is required");
+        };
+        Ok(SeamFrontEnd { dec, rec, nch: channels.count(), max_bs: max_bs as usize })
+    }
+}
+
+impl FlacFrontEnd for SeamFrontEnd {
+    fn params(&self) -> &AudioCodecParameters {
+        self.dec.codec_params()
+    }
+
+    fn channels(&self) -> usize {
+        self.nch
+    }
+
+    fn max_blocksize(&self) -> usize {
+        self.max_bs
+    }
+
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedFlac> {
+        self.rec.lock().expect("flac record poisoned").begin_frame(self.nch);
+        let planes = match self.dec.decode_ref(packet)? {
+            GenericAudioBufferRef::S32(planes) => planes,
+            _ => return decode_error("flac: the front end's buffer is not 32-bit"),
+        };
+        let blocksize = planes.frames();
+        let mut words = Vec::with_capacity(self.nch * blocksize);
+        for c in 0..self.nch {
+            match planes.plane(c) {
+                Some(plane) => words.extend_from_slice(plane),
+                None => return decode_error("flac: missing audio plane"),
+            }
+        }
+        let rec = self.rec.lock().expect("flac record poisoned");
+        Ok(ParsedFlac { blocksize, words, desc: rec.desc.clone(), coeffs: rec.coeffs.clone(), pair_mode: rec.pair_mode, out_shift: rec.out_shift })
+    }
 }
 
 pub struct FlacBatch {
@@ -145,7 +270,12 @@ crate::hip_decoder!(
 );
 
 impl HipFlacDecoder {
-    pub fn try_new(params: &AudioCodecParameters, _opts: &AudioDecoderOptions, front: Box<dyn FlacFrontEnd>, max_batch: usize) -> Result<Self> {
+    pub fn try_new(_params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn FlacFrontEnd>, max_batch: usize) -> Result<Self> {
+        if opts.verify {
+            // the MD5 of STREAMINFO is computed over the decoded audio inside the reference's decoder; here the caller verifies
+            return unsupported_error("flac: verification is not available with the batched predictors");
+        }
+        let params = front.params().clone();
         let (Some(rate), Some(channels)) = (params.sample_rate, params.channels.clone()) else {
             return unsupported_error("flac: sample rate and channels are required");
         };
@@ -153,7 +283,7 @@ impl HipFlacDecoder {
         let max_batch = max_batch.max(1);
         let max_bs = front.max_blocksize();
         Ok(HipFlacDecoder {
-            params: params.clone(),
+            params,
             batch: FlacBatch {
                 ctx: Context::new(0)?,
                 front,

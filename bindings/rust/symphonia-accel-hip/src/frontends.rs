@@ -1,28 +1,30 @@
-//! CPU front ends: bitstream parse, Huffman / VQ / Rice decode, dequantisation -- the reference's own code, up to the
-//! point where the synthesis stage starts.  The reference keeps these in private modules, so a shim has to carry a copy
-//! of the parse stage (or the reference has to grow a `pub trait SynthBackend`).  The copy is mechanical:
-//!  * AAC: `AacDecoder::decode_inner` (symphonia-codec-aac/src/aac/mod.rs:170-225), stopped before `synth_audio`,
-//!    returning `ics.coeffs` + `info.window_sequence / window_shape / prev_window_shape` per channel;
-//!  * MP3: `Layer3::decode` (symphonia-bundle-mp3/src/layer3/mod.rs:300-440) up to the per-channel tail, returning the
-//!    requantized + stereo-processed samples and `block_type / is_mixed / rzero` per granule-channel;
-//!  * Vorbis: `VorbisDecoder::decode_inner` (symphonia-codec-vorbis/src/lib.rs:186-292) up to `dsp.channels[..].synth`,
-//!    returning floor x residue per channel and the mode's block flag;
-//!  * FLAC: `FlacDecoder::decode_inner` (symphonia-bundle-flac/src/decoder.rs:200-300) with `read_subframe` stopped
-//!    before `fixed_predict` / `lpc_predict` (:456-520), returning warm-up + residual words, the subframe descriptor
-//!    and the quantised coefficients.
+//! CPU front ends: bitstream parse, Huffman / VQ / Rice decode, dequantisation, joint stereo -- the reference's own code, up to
+//! the point where the synthesis stage starts.
 //!
-//! None of the four copies is part of this source drop, and the crate is honest about it: `AVAILABLE` says so per codec,
-//! `register` (lib.rs) does not put a decoder above the CPU one for a codec whose front end is absent, and a decoder
-//! built directly through `try_registry_new` hands the track to the CPU decoder it was registered above (fallback.rs).
-use symphonia_core::codecs::audio::AudioCodecParameters;
-use symphonia_core::errors::{unsupported_error, Result};
+//! The reference keeps those stages in private modules (symphonia-codec-aac/src/aac/mod.rs:29-34,
+//! symphonia-codec-vorbis/src/lib.rs:37-42, symphonia-bundle-mp3/src/lib.rs:18-40), so this crate does not carry a copy of
+//! them: it builds against codec crates with the SEAM PATCHES of `bindings/rust/patches/` applied
+//! (`symphonia-bundle-flac.diff`, `symphonia-codec-aac.diff`, `symphonia-bundle-mp3.diff`, `symphonia-codec-vorbis.diff`).
+//! Each patch adds a `pub trait SynthBackend` at the place where the decoder calls its DSP
+//! (flac decoder.rs:199-242 + 446-511, aac ics/mod.rs:449-468, mp3 layer3/mod.rs:421-477, vorbis lib.rs:316-331) with the
+//! crate's own CPU code as the default, and a `try_new_with_backend` constructor.  The front ends below are the reference's
+//! decoders with a RECORDING backend installed: `parse(packet)` runs the reference's `decode_ref` -- which now stops short
+//! of the DSP -- and returns what the backend was handed.  The batched device call then does the DSP for many packets.
+//!
+//! tests/test_seam_patches.py applies the patches to a copy of the reference tree and checks that every patched file still
+//! parses and that the `SynthBackend` impls in this crate match the patched traits; tests/test_flac_packets.py EXECUTES the
+//! patched FLAC decoder + this crate's FLAC path on packet bytes (under the repository's Rust interpreter) against the
+//! unpatched reference decoder.
+use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoderOptions};
+use symphonia_core::errors::Result;
 
 use crate::aac::AacFrontEnd;
 use crate::flac::FlacFrontEnd;
 use crate::mpa::MpaFrontEnd;
 use crate::vorbis::VorbisFrontEnd;
 
-/// Which vendored parse stages this build contains.
+/// Which front ends this build contains: all four, through the seam patches (kept as a table so that a build against an
+/// unpatched codec crate can switch a codec off instead of failing to link; see `register`).
 pub struct Available {
     pub aac: bool,
     pub mpa: bool,
@@ -30,23 +32,20 @@ pub struct Available {
     pub flac: bool,
 }
 
-pub const AVAILABLE: Available = Available { aac: false, mpa: false, vorbis: false, flac: false };
+pub const AVAILABLE: Available = Available { aac: true, mpa: true, vorbis: true, flac: true };
 
-const NOT_IN_DROP: &str = "symphonia-accel-hip: the vendored parse stage of this codec is not part of this source drop";
-
-/// Build the AAC-LC front end for a track.  (Vendored parser goes here; see the module comment.)
-pub fn aac_front_end(_params: &AudioCodecParameters) -> Result<Box<dyn AacFrontEnd>> {
-    unsupported_error(NOT_IN_DROP)
+pub fn aac_front_end(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Box<dyn AacFrontEnd>> {
+    Ok(Box::new(crate::aac::SeamFrontEnd::try_new(params, opts)?))
 }
 
-pub fn mpa_front_end(_params: &AudioCodecParameters) -> Result<Box<dyn MpaFrontEnd>> {
-    unsupported_error(NOT_IN_DROP)
+pub fn mpa_front_end(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Box<dyn MpaFrontEnd>> {
+    Ok(Box::new(crate::mpa::SeamFrontEnd::try_new(params, opts)?))
 }
 
-pub fn vorbis_front_end(_params: &AudioCodecParameters) -> Result<Box<dyn VorbisFrontEnd>> {
-    unsupported_error(NOT_IN_DROP)
+pub fn vorbis_front_end(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Box<dyn VorbisFrontEnd>> {
+    Ok(Box::new(crate::vorbis::SeamFrontEnd::try_new(params, opts)?))
 }
 
-pub fn flac_front_end(_params: &AudioCodecParameters) -> Result<Box<dyn FlacFrontEnd>> {
-    unsupported_error(NOT_IN_DROP)
+pub fn flac_front_end(params: &AudioCodecParameters, _opts: &AudioDecoderOptions) -> Result<Box<dyn FlacFrontEnd>> {
+    Ok(Box::new(crate::flac::SeamFrontEnd::try_new(params)?))
 }

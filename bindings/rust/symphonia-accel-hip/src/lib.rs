@@ -8,14 +8,18 @@
 //! Everything above the decoders -- demuxers, probe, symphonia-check, symphonia-play -- is untouched: they only see
 //! `Box<dyn AudioDecoder>` and `Box<dyn FormatReader>` (symphonia-check/src/main.rs:144-147).
 //!
-//! Status: this crate is NOT compiled in the repository's build image (no Rust toolchain).  What IS checked there
-//! (tests/test_rust_shim.py): every file parses (tools/rsinterp/parser.py), every `use symphonia_core::...` names an item
-//! the reference tree defines, every `impl AudioDecoder / RegisterableAudioDecoder / FormatReader` matches the trait text
-//! of the reference (method names, receivers, arity), and `lookahead.rs` + `fallback.rs` are EXECUTED under the
-//! repository's Rust interpreter with a mock codec, a mock demuxer and a mock registry on the packet script of the
-//! compiled C++ twin (`codecs::LookaheadDecoder`, include/symaccel.hpp, tests/cpp/lookahead_test.cpp).  The parse stages
-//! (`frontends`) have to be vendored from the reference's codec crates because their `mod`s are private
-//! (symphonia-codec-aac/src/aac/mod.rs:29-34, symphonia-codec-vorbis/src/lib.rs:37-42, symphonia-bundle-mp3/src/lib.rs:18-40).
+//! The parse stages are the reference's own decoders: this crate builds against codec crates with the seam patches of
+//! `bindings/rust/patches/` applied (a `pub trait SynthBackend` where each decoder calls its DSP; `frontends.rs`).
+//!
+//! Status: this crate is NOT compiled in the repository's build image (no Rust toolchain).  What IS checked there: every
+//! file parses, every `use symphonia_core::...` names an item the reference tree defines, every `impl AudioDecoder /
+//! RegisterableAudioDecoder / FormatReader` matches the trait text of the reference (tests/test_rust_shim.py); the patches
+//! apply to the reference tree, the patched files parse and this crate's `SynthBackend` impls match the patched traits
+//! (tests/test_seam_patches.py); and the crate is EXECUTED under the repository's Rust interpreter (tools/rsinterp) with its
+//! `extern "C"` block bound to libsymaccel through ctypes: `lookahead.rs` + `fallback.rs` with mocks (test_rust_shim.py), the
+//! four codec adapters + `ctx.rs` with front ends that replay the reference-text fixtures (tests/test_rust_adapters.py), and
+//! the whole FLAC path -- the patched reference decoder as front end, `flac.rs`, `decoder.rs`, `lookahead.rs`, `ctx.rs` -- on
+//! packet bytes against the unpatched reference decoder (tests/test_flac_packets.py).
 #![allow(clippy::needless_range_loop)]
 
 mod aac;
@@ -30,6 +34,7 @@ mod mpa;
 mod vorbis;
 
 pub use aac::{AacFrontEnd, HipAacDecoder, ParsedAac};
+pub use decoder::DecoderBatch;
 pub use ctx::{Context, Pinned};
 pub use flac::{FlacFrontEnd, HipFlacDecoder, ParsedFlac};
 pub use lookahead::{find_reader, BatchCodec, Lookahead, LookaheadReader, PacketKey, Shared, SharedHandle, TrackQueue};

@@ -85,13 +85,16 @@ pub struct LookaheadReader {
     pending: VecDeque<Packet>,
     shared: SharedHandle,
     eof: bool,
+    /// an error of the inner reader that occurred while reading AHEAD: returned once every packet read before it has been
+    /// handed out, exactly where the inner reader would have returned it
+    deferred: Option<symphonia_core::errors::Error>,
 }
 
 impl LookaheadReader {
     pub fn new(inner: Box<dyn FormatReader>, depth: usize) -> Self {
         let shared: SharedHandle = Arc::new(Mutex::new(Shared::default()));
         READERS.lock().expect("reader list poisoned").push(Arc::downgrade(&shared));
-        LookaheadReader { inner, depth: depth.max(1), pending: VecDeque::new(), shared, eof: false }
+        LookaheadReader { inner, depth: depth.max(1), pending: VecDeque::new(), shared, eof: false, deferred: None }
     }
 
     /// The state the decoders of this reader's tracks look at (tests; an application never needs it).
@@ -99,19 +102,20 @@ impl LookaheadReader {
         self.shared.clone()
     }
 
-    fn refill(&mut self) -> Result<()> {
-        while !self.eof && self.pending.len() < self.depth {
-            match self.inner.next_packet()? {
-                Some(p) => {
+    fn refill(&mut self) {
+        while !self.eof && self.deferred.is_none() && self.pending.len() < self.depth {
+            match self.inner.next_packet() {
+                Ok(Some(p)) => {
                     let mut shared = self.shared.lock().expect("look-ahead state poisoned");
                     shared.tracks.entry(p.track_id).or_default().packets.push_back(p.clone());
                     drop(shared);
                     self.pending.push_back(p);
                 }
-                None => self.eof = true,
+                Ok(None) => self.eof = true,
+                // reading stops here; the packets already read are still delivered, then the error (next_packet)
+                Err(e) => self.deferred = Some(e),
             }
         }
-        Ok(())
     }
 
     fn drop_lookahead(&mut self) {
@@ -123,6 +127,7 @@ impl LookaheadReader {
         }
         drop(shared);
         self.eof = false;
+        self.deferred = None;
     }
 }
 
@@ -160,9 +165,15 @@ impl FormatReader for LookaheadReader {
 
     /// formats/mod.rs:646: the oldest packet read ahead.  It leaves its track's queue (the queue holds what FOLLOWS the
     /// packet the application is about to decode) and becomes the track's `last_out`.  An error of the inner reader is
-    /// returned when it occurs, like the inner reader would have returned it `depth` packets later.
+    /// returned where the inner reader would have returned it: after every packet that was read before it (a damaged file
+    /// still plays up to the damage); the call after that reads on, like a second call on the inner reader would.
     fn next_packet(&mut self) -> Result<Option<Packet>> {
-        self.refill()?;
+        self.refill();
+        if self.pending.is_empty() {
+            if let Some(e) = self.deferred.take() {
+                return Err(e);
+            }
+        }
         let next = self.pending.pop_front();
         if let Some(p) = &next {
             let mut shared = self.shared.lock().expect("look-ahead state poisoned");

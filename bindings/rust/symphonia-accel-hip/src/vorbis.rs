@@ -1,9 +1,13 @@
 //! `HipVorbisDecoder`: the per-channel synthesis of every audio packet -- Imdct, windowing and the lapped overlap-add of
 //! `DspChannel::synth` (symphonia-codec-vorbis/src/dsp.rs:68-145, called from lib.rs:296-331) -- on the MI355X.
+use std::sync::{Arc, Mutex};
+
+use symphonia_codec_vorbis::backend::SynthBackend;
+use symphonia_codec_vorbis::VorbisDecoder;
 use symphonia_core::audio::{Audio, AudioBuffer, AudioMut, AudioSpec, GenericAudioBufferRef};
 use symphonia_core::codecs::audio::well_known::CODEC_ID_VORBIS;
-use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoderOptions};
-use symphonia_core::errors::{unsupported_error, Result};
+use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoder, AudioDecoderOptions};
+use symphonia_core::errors::{decode_error, unsupported_error, Result};
 use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
@@ -16,6 +20,7 @@ use crate::lookahead::{BatchCodec, Lookahead};
 /// floor x residue product: lib.rs:186-292): per channel the n/2 spectral lines `DspChannel::synth` receives.
 /// Channels whose floor is unused ("do not decode") carry zeros, as `synth` sees them (dsp.rs:72-75).
 pub struct ParsedVorbis {
+    pub trim: (usize, usize), // frames to trim from the start / end of the decoded packet (lib.rs:333-342; the decoder is gapless)
     pub long_block: bool,  // block_flag of the packet's mode (lib.rs:203-214)
     pub spectra: Vec<f32>, // [channel][n / 2], n = the block size the flag selects
 }
@@ -25,6 +30,86 @@ pub trait VorbisFrontEnd: Send + Sync {
     /// (bs0_exp, bs1_exp) of the identification header (lib.rs:404-406)
     fn block_exps(&self) -> (i32, i32);
     fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedVorbis>;
+}
+
+/// What the reference's decoder hands its `SynthBackend` (bindings/rust/patches/symphonia-codec-vorbis.diff).
+#[derive(Default)]
+pub struct VorbisRecord {
+    pub n_channels: usize,
+    pub bs0_exp: i32,
+    pub bs1_exp: i32,
+    pub long_block: bool,
+    pub spectra: Vec<f32>, // [channel][n / 2]
+    pub seen: usize,
+}
+
+/// The `SynthBackend` handed to the reference's `VorbisDecoder`: every channel's floor x residue spectrum is recorded,
+/// nothing is synthesized.
+pub struct Recorder(pub Arc<Mutex<VorbisRecord>>);
+
+impl SynthBackend for Recorder {
+    fn configure(&mut self, n_channels: usize, bs0_exp: u8, bs1_exp: u8) {
+        let mut rec = self.0.lock().expect("vorbis record poisoned");
+        rec.n_channels = n_channels;
+        rec.bs0_exp = bs0_exp as i32;
+        rec.bs1_exp = bs1_exp as i32;
+    }
+
+    fn synth(&mut self, channel: usize, block_flag: bool, _prev_block_flag: bool, spectrum: &[f32], _out: &mut [f32]) {
+        let mut rec = self.0.lock().expect("vorbis record poisoned");
+        let half = spectrum.len();
+        if rec.spectra.len() != rec.n_channels * half {
+            rec.spectra.clear();
+            rec.spectra.resize(rec.n_channels * half, 0.0);
+        }
+        rec.long_block = block_flag;
+        rec.spectra[channel * half..(channel + 1) * half].copy_from_slice(spectrum);
+        rec.seen += 1;
+    }
+
+    fn reset(&mut self) {}
+}
+
+/// `VorbisFrontEnd` over the reference's own decoder with the recording backend installed: setup headers, codebooks, floor
+/// and residue decoding, inverse coupling and the dot product are symphonia-codec-vorbis's code, unmodified.
+pub struct SeamFrontEnd {
+    dec: VorbisDecoder,
+    rec: Arc<Mutex<VorbisRecord>>,
+}
+
+impl SeamFrontEnd {
+    pub fn try_new(params: &AudioCodecParameters, _opts: &AudioDecoderOptions) -> Result<Self> {
+        let rec: Arc<Mutex<VorbisRecord>> = Arc::new(Mutex::new(VorbisRecord::default()));
+        // the front end never silences or trims: both are applied to what the device produced (VorbisBatch::publish)
+        let opts = AudioDecoderOptions { gapless: false, ..Default::default() };
+        let dec = VorbisDecoder::try_new_with_backend(params, &opts, Box::new(Recorder(rec.clone())))?;
+        Ok(SeamFrontEnd { dec, rec })
+    }
+}
+
+impl VorbisFrontEnd for SeamFrontEnd {
+    fn channels(&self) -> usize {
+        self.rec.lock().expect("vorbis record poisoned").n_channels
+    }
+
+    fn block_exps(&self) -> (i32, i32) {
+        let rec = self.rec.lock().expect("vorbis record poisoned");
+        (rec.bs0_exp, rec.bs1_exp)
+    }
+
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedVorbis> {
+        self.rec.lock().expect("vorbis record poisoned").seen = 0;
+        self.dec.decode_ref(packet)?;
+        let rec = self.rec.lock().expect("vorbis record poisoned");
+        if rec.seen != rec.n_channels {
+            return decode_error("vorbis: the packet did not reach the synthesis stage for every channel");
+        }
+        Ok(ParsedVorbis {
+            trim: (packet.trim_start.get() as usize, packet.trim_end.get() as usize),
+            long_block: rec.long_block,
+            spectra: rec.spectra.clone(),
+        })
+    }
 }
 
 pub struct VorbisBatch {
@@ -40,7 +125,8 @@ pub struct VorbisBatch {
     spec_stride: usize,
     pcm_stride: usize,
     pcm_off: Vec<usize>,      // per packet of the batch: offset of its samples in a channel's PCM; one extra = total
-    emits: Vec<bool>,         // per packet: false for the first block after a reset (dsp.rs:77-80: nothing to lap with)
+    emits: Vec<bool>,         // per packet: false for the first block after a reset (lib.rs:335-338: silenced when gapless)
+    trims: Vec<(usize, usize)>, // per packet of the batch
     buf: AudioBuffer<f32>,
 }
 
@@ -60,7 +146,9 @@ impl BatchCodec for VorbisBatch {
         let mut spec_off = Vec::with_capacity(k);
         self.pcm_off.clear();
         self.emits.clear();
+        self.trims.clear();
         for p in batch {
+            self.trims.push(p.trim);
             let n = self.bs[p.long_block as usize];
             spec_off.push(lines);
             self.pcm_off.push(samples);
@@ -113,6 +201,10 @@ impl BatchCodec for VorbisBatch {
                 plane[..frames].copy_from_slice(&self.pcm.as_slice()[src..src + frames]);
             }
         }
+        // lib.rs:333-342 (gapless): the first packet after a reset is silenced (`emits`), every other one is trimmed
+        if self.emits[i] {
+            self.buf.trim(self.trims[i].0, self.trims[i].1);
+        }
     }
 
     fn reset_state(&mut self) {
@@ -142,7 +234,13 @@ crate::hip_decoder!(
 );
 
 impl HipVorbisDecoder {
-    pub fn try_new(params: &AudioCodecParameters, _opts: &AudioDecoderOptions, front: Box<dyn VorbisFrontEnd>, max_batch: usize) -> Result<Self> {
+    pub fn try_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn VorbisFrontEnd>, max_batch: usize) -> Result<Self> {
+        if !opts.gapless {
+            // Without gapless support the reference returns the first block after a reset windowed against silence
+            // (lib.rs:316-331 with an all-zero overlap); the batched call does not compute that half block.  The decoder
+            // registered below this one takes such tracks (fallback.rs).
+            return unsupported_error("vorbis: the batched decoder implements the gapless (default) behaviour only");
+        }
         let (Some(rate), Some(channels)) = (params.sample_rate, params.channels.clone()) else {
             return unsupported_error("vorbis: sample rate and channels are required");
         };
@@ -166,6 +264,7 @@ impl HipVorbisDecoder {
                 pcm_stride: 0,
                 pcm_off: Vec::with_capacity(max_batch + 1),
                 emits: Vec::with_capacity(max_batch),
+                trims: Vec::with_capacity(max_batch),
                 buf: AudioBuffer::new(AudioSpec::new(rate, channels), bs[1] / 2),
             },
             la: Lookahead::new(max_batch),

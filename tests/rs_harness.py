@@ -1,0 +1,157 @@
+"""TEST ONLY.  Builds a tools/rsinterp interpreter in which the Rust shim crate (bindings/rust/symphonia-accel-hip) can be EXECUTED:
+its sources, the generated FFI declarations bound to a libsymaccel through ctypes (tools/rsinterp/ffi.py: the CPU-emulation build
+in the CPU suite, the hipcc-built library in the `-m gpu` suite), stand-ins for symphonia-core's container types
+(tests/rust/core_stubs.rs, audio_stubs.rs) -- or, with `reference=True` (needs /root/reference), the reference's own io / checksum /
+packet modules and a codec crate with the repository's seam patch applied."""
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+
+from rsinterp import Interp  # noqa: E402
+from rsinterp import ffi as F  # noqa: E402
+from rsinterp import interp as I  # noqa: E402
+from rsinterp import parser as P  # noqa: E402
+
+CRATE = ROOT / "bindings" / "rust" / "symphonia-accel-hip" / "src"
+PATCHES = ROOT / "bindings" / "rust" / "patches"
+REF = Path("/root/reference")
+CODEC_CRATES = ("symphonia-bundle-flac", "symphonia-codec-aac", "symphonia-bundle-mp3", "symphonia-codec-vorbis")
+CORE_IO = ("errors.rs", "util.rs", "io/mod.rs", "io/buf_reader.rs", "io/monitor_stream.rs", "checksum/crc8.rs", "checksum/crc16.rs",
+           "units.rs", "packet.rs")
+
+
+def usize(v):
+    return I.Int(int(v), "usize")
+
+
+def u8_vec(data):
+    return I.Arr([I.Int(int(b), "u8") for b in data], True)
+
+
+def f32_vec(a):
+    return I.Arr([I.F32(x) for x in np.asarray(a, np.float32).ravel()], True)
+
+
+def i32_vec(a):
+    return I.Arr([I.Int(int(x), "i32") for x in np.asarray(a).ravel()], True)
+
+
+def patched_tree(crates=CODEC_CRATES):
+    """A temporary copy of the reference's codec crates with bindings/rust/patches/*.diff applied; returns its root."""
+    tmp = Path(tempfile.mkdtemp(prefix="seam_"))
+    for c in crates:
+        shutil.copytree(REF / c / "src", tmp / c / "src")
+        r = subprocess.run(["patch", "-p1", "-s", "-i", str(PATCHES / (c + ".diff"))], cwd=tmp, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("patch %s does not apply: %s%s" % (c, r.stdout, r.stderr))
+    return tmp
+
+
+def strip_vlc_entries(src):
+    # `decl_entry!(/// doc ...)` matches its `#[doc = $expr]` arm through the doc comment, which the lexer drops with the other
+    # comments: the codebook entry types are not on the FLAC path
+    return re.sub(r"decl_entry!\((?:.|\n)*?\);\n", "", src)
+
+
+class Harness:
+    def __init__(self, dll, reference=False, flac_tree=None):
+        self.it = it = Interp()
+        self.dll = dll
+        self.reference = reference
+        if reference:
+            for f in CORE_IO:
+                it.load_file(REF / "symphonia-core" / "src" / f)
+            it.load_source(strip_vlc_entries((REF / "symphonia-core/src/io/bit.rs").read_text()), "io/bit.rs")
+        else:
+            it.load_file(ROOT / "tests" / "rust" / "core_stubs.rs")
+        it.load_file(ROOT / "tests" / "rust" / "audio_stubs.rs")
+        it.native_methods[("AudioBuffer", "as_generic_audio_buffer_ref")] = self._generic_ref
+        if flac_tree is not None:  # the FLAC crate (patched or not) + STREAMINFO
+            for f in ("frame.rs", "decoder.rs") + (("backend.rs",) if (flac_tree / "backend.rs").exists() else ()):
+                it.load_file(flac_tree / f)
+            it.load_file(REF / "symphonia-common/src/xiph/audio/flac/mod.rs")
+            # (symphonia-core's Position bit flags are outside the stand-in Channels)
+            it.load_source("pub fn flac_channels_to_channels(channels: u32) -> Channels { Channels::Discrete(channels as u16) }", "stub")
+        self.bridge = F.Bridge(it, (ROOT / "bindings" / "rust" / "symaccel_sys.rs").read_text(), dll) if dll is not None else None
+        bad = it.globals.get("__unparsed__")
+        assert not bad, bad
+
+    @staticmethod
+    def _generic_ref(buf, args):
+        planes = buf.f["planes"].a
+        first = planes[0].a[0] if planes and planes[0].a else None
+        kind = "S32" if isinstance(first, I.Int) and first.t == "i32" else "F32"
+        return I.Enum("GenericAudioBufferRef", kind, {"0": buf})
+
+    def load_shim(self, *names):
+        """crate files with `hip_decoder!` invocations expanded (decoder.rs defines the macro and must come first)"""
+        for name in names:
+            path = CRATE / name
+            out = []
+            for item in P.parse_source(path.read_text(), str(path)):
+                if item[0] == "macro_item" and item[1] == "hip_decoder":
+                    toks = self.it.expand_macro("hip_decoder", item[2])
+                    toks = [tk for i, tk in enumerate(toks) if not (tk.s == "$" and i + 1 < len(toks) and toks[i + 1].s == "crate")]
+                    out.extend(P.parse_tokens_as_items(toks, str(path)))
+                else:
+                    out.append(item)
+            self.it.register_items(out, str(path))
+        bad = self.it.globals.get("__unparsed__")
+        assert not bad, bad
+
+    # ---- values
+    def params(self, codec, rate=None, nch=None, extra=None, bps=None):
+        it = self.it
+        return I.Struct("AudioCodecParameters", {
+            "codec": it.resolve_value([codec], I.Env(), None),
+            "sample_rate": I.some(I.Int(rate, "u32")) if rate else I.NONE,
+            "bits_per_sample": I.some(I.Int(bps, "u32")) if bps else I.NONE,
+            "channels": I.some(I.Enum("Channels", "Discrete", {"0": I.Int(nch, "u16")})) if nch else I.NONE,
+            "max_frames_per_packet": I.NONE,
+            "extra_data": I.some(u8_vec(extra)) if extra is not None else I.NONE})
+
+    def opts(self, gapless=True, verify=False):
+        return I.Struct("AudioDecoderOptions", {"verify": bool(verify), "gapless": bool(gapless)})
+
+    def packet(self, data, pts, track=0, owned=False):
+        """a PacketRef (or, owned=True, a Packet a MockReader can hand out)"""
+        arr = u8_vec(data)
+        ts = I.Struct("Timestamp", {"0": I.Int(int(pts), "i64")})
+        if owned and self.reference:  # symphonia-core's own Packet (packet.rs:50-89)
+            zero = I.Struct("Duration", {"0": I.Int(0, "u64")})
+            return I.Struct("Packet", {"track_id": I.Int(track, "u32"), "pts": ts, "dts": ts, "dur": zero, "trim_start": zero, "trim_end": zero,
+                                       "data": arr})
+        if owned:
+            return self.it.call("Packet::new", I.Int(track, "u32"), ts, arr)
+        return I.Struct("PacketRef", {"track_id": I.Int(track, "u32"), "pts": ts, "data": I.Slice(arr.a, 0, len(arr.a), False)})
+
+    def decode(self, type_name, dec, pkt):
+        """decode_ref: ('ok', planes as a numpy array [channel][frames]) or ('err', variant name); checks the buffer is cleared on error"""
+        r = self.it.call_method(type_name, "decode_ref", dec, pkt)
+        last = self.it.call_method(type_name, "last_decoded", dec)
+        if r.variant == "Err":
+            assert last.f["0"].f["num_frames"].v == 0, "the buffer must be cleared on error (codecs/audio.rs:278)"
+            return "err", r.f["0"].variant
+        buf = r.f["0"].f["0"]
+        assert buf is last.f["0"], "last_decoded() must be the buffer decode_ref returned (codecs/audio.rs:291-297)"
+        return "ok", self.planes(buf)
+
+    @staticmethod
+    def planes(buf):
+        n = buf.f["num_frames"].v
+        rows = []
+        for p in buf.f["planes"].a:
+            vals = p.a[:n]
+            if vals and isinstance(vals[0], I.Int):
+                rows.append(np.array([x.v for x in vals], np.int64))
+            else:
+                rows.append(np.array([np.float32(x) if not isinstance(x, I.Int) else np.float32(x.v) for x in vals], np.float32))
+        return np.stack(rows) if rows else np.zeros((0, 0))

@@ -521,7 +521,23 @@ def test_a_read_error_of_the_inner_reader_is_reported_and_reading_continues(rig)
         seen.append(st if st != "ok" else p.f["data"].a[0].v)
         if st == "eof":
             break
-    assert seen == [1, 2, "err", 3, 4, 5, "eof"] or seen == [1, "err", 2, 3, 4, 5, "eof"]
+    # the inner reader fails in front of its fourth packet: the three packets read before that are all delivered, THEN the error
+    # (where the inner reader itself would have returned it), then reading goes on -- ADVICE r3: an error met while reading
+    # AHEAD must not swallow the packets already read
+    assert seen == [1, 2, 3, "err", 4, 5, "eof"]
+
+
+def test_a_failing_inner_reader_loses_no_packet_at_any_depth(rig):
+    for depth in (1, 2, 3, 8):
+        reader, inner = rig.reader(rig.packets(list(range(1, 11))), depth=depth)
+        inner.f["fail_at"] = i64(6)
+        seen = []
+        for _ in range(14):
+            st, p = rig.next_packet(reader)
+            seen.append(st if st != "ok" else p.f["data"].a[0].v)
+            if st == "eof":
+                break
+        assert seen == [1, 2, 3, 4, 5, 6, "err", 7, 8, 9, 10, "eof"], (depth, seen)
 
 
 def test_registry_has_no_fall_through_and_the_shim_delegates(rig):
@@ -554,3 +570,10 @@ def test_registry_has_no_fall_through_and_the_shim_delegates(rig):
     fb = it.call("factory_below", aac)
     assert fb.variant == "Some"
     assert it.call("factory_below", mp3).variant == "None"
+    # a codec with NOTHING below: the first lookup (nothing) wins, so a second register() cannot record the shim's own factory
+    flac = I.Struct("AudioCodecId", {"0": u32(3)})
+    it.call("remember", reg, I.Arr([flac], True))
+    it.call_method("CodecRegistry", "register_at_tier", reg, pref, flac, hip)
+    it.call("remember", reg, I.Arr([flac], True))
+    assert it.call("factory_below", flac).variant == "None"
+    assert make(flac) == "Unsupported"  # the reason the accelerated decoder could not be built, not a recursion

@@ -1,0 +1,303 @@
+"""`unsafe extern "C"` for the interpreter: the raw-pointer idioms of bindings/rust/symphonia-accel-hip/src/ctx.rs and the calls
+of its codec adapters into libsymaccel, bound through ctypes (tests/test_rust_adapters.py, tests/test_flac_packets.py).
+
+What the crate does with raw pointers is little, and all of it is modelled by value:
+  ptr::null_mut() / ptr::null()         NULL (is_null() is true)
+  out-pointer to an opaque handle       `symaccel_ctx_create(device, &mut raw)`: the place receives a `Handle` (the C pointer)
+  symaccel_host_alloc(bytes, &mut p)    the place receives a `RawMem`: an element list created on first use
+  p as *mut T                           the same object (casts between pointer types do nothing)
+  ptr.add(i).write(v)                   stores element i
+  slice::from_raw_parts(_mut)(ptr, n)   a slice over the first n elements
+  v.as_ptr() / v.as_mut_ptr()           the Vec / slice itself (interp.builtin_method)
+  CStr::from_ptr(p)                     the Python str a `*const c_char` result was turned into
+
+A call of a bound function marshals every pointer argument into a numpy array of the element type the DECLARATION in
+bindings/rust/symaccel_sys.rs gives it (scalars, or #[repr(C)] structs as structured dtypes), calls the C function, and copies
+`*mut` arrays back element by element.  The calls the crate makes are synchronous host-pointer entry points, so copy-in /
+copy-out is exactly their contract."""
+import ctypes as C
+import re
+
+import numpy as np
+
+from . import interp as I
+
+SCALARS = {'u8': np.uint8, 'i8': np.int8, 'u16': np.uint16, 'i16': np.int16, 'u32': np.uint32, 'i32': np.int32, 'u64': np.uint64,
+           'i64': np.int64, 'usize': np.uint64, 'isize': np.int64, 'f32': np.float32, 'f64': np.float64, 'c_int': np.int32, 'c_uint': np.uint32,
+           'c_char': np.int8, 'bool': np.uint8}
+CT = {'u8': C.c_uint8, 'i8': C.c_int8, 'u16': C.c_uint16, 'i16': C.c_int16, 'u32': C.c_uint32, 'i32': C.c_int32, 'u64': C.c_uint64,
+      'i64': C.c_int64, 'usize': C.c_size_t, 'isize': C.c_ssize_t, 'f32': C.c_float, 'f64': C.c_double, 'c_int': C.c_int, 'c_uint': C.c_uint}
+
+
+class Null:
+    def __repr__(self):
+        return 'null'
+
+    def rs_method(self, it, name, args):
+        if name == 'is_null':
+            return True
+        raise I.InterpError('no method %s on a null pointer' % name)
+
+
+NULL = Null()
+
+
+class Handle:
+    """an opaque C pointer (symaccel_ctx *, a communicator)"""
+
+    def __init__(self, p):
+        self.p = p
+
+    def __repr__(self):
+        return 'Handle(%#x)' % (self.p or 0)
+
+    def rs_method(self, it, name, args):
+        if name == 'is_null':
+            return not self.p
+        raise I.InterpError('no method %s on an opaque pointer' % name)
+
+
+class RawMem:
+    """memory from symaccel_host_alloc: `nbytes` bytes seen as elements of whatever the crate stores in it"""
+
+    def __init__(self, nbytes):
+        self.nbytes, self.arr, self.off = nbytes, I.Arr([], True), 0
+
+    def __repr__(self):
+        return 'RawMem(%d B, %d elements)' % (self.nbytes, len(self.arr.a))
+
+    def need(self, n):
+        a = self.arr.a
+        if len(a) < n:
+            a.extend([I.Int(0)] * (n - len(a)))
+
+    def rs_method(self, it, name, args):
+        if name == 'is_null':
+            return False
+        if name in ('add', 'offset'):
+            view = RawMem(self.nbytes)
+            view.arr, view.off = self.arr, self.off + int(I.deref(args[0]).v)
+            return view
+        if name == 'write':
+            self.need(self.off + 1)
+            self.arr.a[self.off] = args[0]
+            return I.UNIT
+        if name == 'read':
+            self.need(self.off + 1)
+            return self.arr.a[self.off]
+        if name in ('cast', 'cast_mut', 'cast_const'):
+            return self
+        raise I.InterpError('no method %s on a raw pointer' % name)
+
+
+def from_raw_parts(ptr, n, mut):
+    ptr = I.deref(ptr)
+    n = int(I.deref(n).v)
+    if isinstance(ptr, RawMem):
+        ptr.need(ptr.off + n)
+        return I.Slice(ptr.arr.a, ptr.off, n, mut)
+    if isinstance(ptr, (I.Arr, I.Slice)):
+        a, o, _ = I.seq_view(ptr)
+        return I.Slice(a, o, n, mut)
+    raise I.InterpError('slice::from_raw_parts of %r' % (ptr,))
+
+
+def path_builtin(segs):
+    name, head = segs[-1], (segs[-2] if len(segs) >= 2 else None)
+    if head == 'ptr' and name in ('null', 'null_mut'):
+        return I.Builtin(lambda: NULL, 'ptr::' + name)
+    if head == 'slice' and name in ('from_raw_parts', 'from_raw_parts_mut'):
+        return I.Builtin(lambda p, n, _m=name.endswith('mut'): from_raw_parts(p, n, _m), 'slice::' + name)
+    if head == 'CStr' and name == 'from_ptr':
+        return I.Builtin(lambda p: CStrVal(p if isinstance(p, str) else ''), 'CStr::from_ptr')
+    return None
+
+
+class CStrVal:
+    def __init__(self, s):
+        self.s = s
+
+    def rs_method(self, it, name, args):
+        if name == 'to_str':
+            return I.ok(self.s)
+        if name in ('to_string_lossy', 'into_owned', 'to_owned', 'to_string'):
+            return self.s
+        raise I.InterpError('no method %s on CStr' % name)
+
+
+# ---------------------------------------------------------------------------------------------- declarations
+
+def parse_extern_block(text):
+    """(text without the extern block, {fn name: ([(param, type text)], return type text or None)})"""
+    m = re.search(r'extern\s+"C"\s*\{', text)
+    if not m:
+        return text, {}
+    depth, i = 1, m.end()
+    while depth:
+        depth += {'{': 1, '}': -1}.get(text[i], 0)
+        i += 1
+    block = text[m.end():i - 1]
+    decls = {}
+    for fm in re.finditer(r'pub fn (\w+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;', block):
+        params = []
+        for prm in [x for x in fm.group(2).split(',') if x.strip()]:
+            pn, pt = prm.split(':', 1)
+            params.append((pn.strip(), ' '.join(pt.split())))
+        decls[fm.group(1)] = (params, fm.group(3).strip() if fm.group(3) else None)
+    head = re.sub(r'(#\[link[^\]]*\]\s*)?(unsafe)?\s*$', '', text[:m.start()])
+    return head + '\n' + text[i:], decls
+
+
+class Bridge:
+    """binds the `extern "C"` declarations of a bindings file to a ctypes library inside one interpreter"""
+
+    def __init__(self, it, sys_rs_text, dll):
+        self.it, self.dll = it, dll
+        rest, self.decls = parse_extern_block(sys_rs_text)
+        it.load_source(rest, 'symaccel_sys.rs')
+        self.calls = []  # (name) log, for the tests
+        for name in self.decls:
+            it.globals[name] = I.Builtin(lambda *a, _n=name: self.call(_n, *a), name)
+            it.globals['ffi::' + name] = it.globals[name]
+
+    # -- element types
+    def dtype(self, ty):
+        ty = ty.strip()
+        base = ty.split('::')[-1]
+        if base in SCALARS:
+            return np.dtype(SCALARS[base])
+        item = self.it.types.get(base)
+        if item is None or item[0] != 'struct':
+            raise I.InterpError('ffi: no layout for %s' % ty)
+        fields = []
+        for fname, fty in item[3]:
+            fields.append((fname,) + self.field_dtype(fty))
+        return np.dtype(fields)
+
+    def field_dtype(self, fty):
+        if fty[0] == 'tarray':
+            n = int(self.it.ev(fty[2], I.Env()).v) if not isinstance(fty[2], int) else fty[2]
+            inner = self.field_dtype(fty[1])
+            return (inner[0], (n,) + (inner[1] if len(inner) > 1 else ()))
+        return (self.dtype(self.it.type_name(fty)),)
+
+    def to_np(self, v, dt):
+        if isinstance(v, I.Struct):
+            out = []
+            for fname in dt.names:
+                sub = dt.fields[fname][0]
+                x = v.f[fname]
+                out.append(self.to_np_seq(x, sub.base, sub.shape) if sub.shape else self.to_np(x, sub))
+            return tuple(out)
+        if isinstance(v, I.Int):
+            return v.v
+        if v is I.UNINIT or v is None:
+            return 0
+        if isinstance(v, (bool, np.bool_)):
+            return int(v)
+        return v
+
+    def to_np_seq(self, v, dt, shape=None):
+        a, o, n = I.seq_view(I.deref(v))
+        if dt.names:
+            arr = np.array([self.to_np(x, dt) for x in a[o:o + n]], dtype=dt)
+        else:
+            arr = np.array([self.to_np(x, dt) for x in a[o:o + n]]).astype(dt) if n else np.zeros(0, dt)
+        return arr
+
+    def from_np(self, x, dt, like):
+        if dt.names:
+            f = {}
+            for fname in dt.names:
+                sub = dt.fields[fname][0]
+                if sub.shape:
+                    f[fname] = I.Arr([self.from_np(y, sub.base, None) for y in np.asarray(x[fname]).reshape(-1)])
+                else:
+                    f[fname] = self.from_np(x[fname], sub, None)
+            return I.Struct(like.name if isinstance(like, I.Struct) else '?', f)
+        if dt.kind == 'f':
+            return I.F32(x) if dt.itemsize == 4 else float(x)
+        name = {v: k for k, v in SCALARS.items() if k[0] in 'iu' and k not in ('usize', 'isize')}.get(dt.type, 'i32')
+        return I.Int(int(x), name)
+
+    # -- one call
+    def call(self, name, *args):
+        params, ret = self.decls[name]
+        fn = getattr(self.dll, name)
+        cargs, after, keep = [], [], []
+        if len(args) != len(params):
+            raise I.InterpError('ffi: %s takes %d arguments, got %d' % (name, len(params), len(args)))
+        for (pn, pt), v in zip(params, args):
+            m = re.fullmatch(r'\*(const|mut) (.+)', pt)
+            if not m:
+                base = pt.split('::')[-1]
+                x = I.deref(v)
+                if base in ('f32', 'f64'):
+                    cargs.append(CT[base](float(x)))
+                else:
+                    cargs.append(CT[base](int(x.v) if isinstance(x, I.Int) else int(x)))
+                continue
+            mut, elem = m.group(1) == 'mut', m.group(2)
+            m2 = re.fullmatch(r'\*(const|mut) (.+)', elem)
+            if m2:  # pointer to pointer: an out-parameter for a handle or for host memory
+                if not isinstance(v, I.Place):
+                    raise I.InterpError('ffi: %s: %s must be `&mut` of a pointer variable' % (name, pn))
+                slot = C.c_void_p()
+                cargs.append(C.byref(slot))
+                after.append(('handle', v, slot, m2.group(2), args))
+                continue
+            x = I.deref(v)
+            if isinstance(x, Null):
+                cargs.append(None)
+            elif isinstance(x, Handle):
+                cargs.append(C.c_void_p(x.p))
+            elif isinstance(x, RawMem) and elem.split('::')[-1] == 'c_void':
+                cargs.append(None)  # symaccel_host_free(ptr): the emulated allocation has no C counterpart
+            elif isinstance(v, I.Place) and not isinstance(x, (I.Arr, I.Slice, RawMem)):  # `&mut scalar`
+                dt = self.dtype(elem)
+                arr = np.array([self.to_np(x, dt)], dtype=dt)
+                keep.append(arr)
+                cargs.append(arr.ctypes.data_as(C.c_void_p))
+                if mut:
+                    after.append(('scalar', v, arr, dt, x))
+            else:
+                if isinstance(x, RawMem):
+                    x = I.Slice(x.arr.a, x.off, len(x.arr.a) - x.off, True)
+                dt = self.dtype(elem)
+                arr = np.ascontiguousarray(self.to_np_seq(x, dt))
+                keep.append(arr)
+                cargs.append(arr.ctypes.data_as(C.c_void_p) if arr.size else None)
+                if mut:
+                    after.append(('seq', x, arr, dt, None))
+        rbase = ret.split('::')[-1] if ret else None
+        if ret is None:
+            fn.restype = None
+        elif ret.startswith('*'):
+            fn.restype = C.c_char_p if 'c_char' in ret else C.c_void_p
+        else:
+            fn.restype = CT[rbase]
+        fn.argtypes = None
+        self.calls.append(name)
+        r = fn(*cargs)
+        for kind, dst, arr, dt, extra in after:
+            if kind == 'seq':
+                a, o, n = I.seq_view(dst)
+                for i in range(n):
+                    a[o + i] = self.from_np(arr[i], dt, a[o + i])
+            elif kind == 'scalar':
+                dst.set(self.from_np(arr[0], dt, extra))
+            else:  # an out-pointer
+                if 'c_void' in dt and name.endswith('host_alloc'):
+                    nbytes = int(I.deref(extra[0]).v)
+                    if arr.value:
+                        self.dll.symaccel_host_free(C.c_void_p(arr.value))  # the crate's buffer lives in the interpreter
+                    dst.set(RawMem(nbytes) if arr.value else NULL)
+                else:
+                    dst.set(Handle(arr.value) if arr.value else NULL)
+        if ret is None:
+            return I.UNIT
+        if ret.startswith('*'):
+            return r.decode() if isinstance(r, bytes) else (Handle(r) if r else NULL)
+        if rbase in ('f32', 'f64'):
+            return I.F32(r) if rbase == 'f32' else float(r)
+        return I.Int(int(r), 'i32' if rbase == 'c_int' else ('u32' if rbase == 'c_uint' else rbase))

@@ -456,11 +456,17 @@ class Parser:
         else:
             self.expect('{')
             s, e = self.skip_balanced('{', '}')
-            body = (s, e)  # token range of the body, parsed on first call
+            # the body's tokens up to and including the closing brace, parsed on first call.  A COPY, not an index range:
+            # parsing a body can split a `>>` token in two (split_shr), which would shift every range recorded behind it
+            body = self.t[s:e + 1]
         return ('fn', name, gen, params, self_kind, ret, body, attrs, self)
 
     def parse_body(self, rng):
-        """Parse a function body from its token range (lazily, on first call)."""
+        """Parse a function body from its tokens (lazily, on first call)."""
+        if isinstance(rng, list):
+            sub = Parser(rng + [Tok('eof', '', rng[-1].line)], self.fname)
+            sub.uses = self.uses
+            return sub.block_body()
         save = self.i
         self.i = rng[0]
         try:

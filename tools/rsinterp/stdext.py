@@ -94,6 +94,15 @@ def default_of(it, ty):
 def path_builtin(it, segs):
     name = segs[-1]
     head = segs[-2] if len(segs) >= 2 else None
+    from . import ffi
+    raw = ffi.path_builtin(segs)
+    if raw is not None:
+        return raw
+    # std::io::Error: modelled as the symphonia Error it becomes at the first `?` (errors.rs `impl From<io::Error> for Error`)
+    if head == 'ErrorKind' and 'io' in segs:
+        return name
+    if head == 'Error' and 'io' in segs and name in ('other', 'new', 'from'):
+        return I.Builtin(lambda *a: I.Enum('Error', 'IoError', {'0': a[-1] if a else ''}), 'io::Error::' + name)
     if head in ('Arc', 'Rc') and name == 'new':
         return I.Builtin(lambda v: Cell('Arc', v), 'Arc::new')
     if head in ('Arc', 'Rc') and name == 'downgrade':
