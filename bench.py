@@ -126,6 +126,50 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             cfg["mix"] = {"p_switch": mix, "long": hist[0], "start": hist[1], "short": hist[2], "end": hist[3],
                           "mixed_share_of_short": float(mx[bt == 2].mean()) if (bt == 2).any() else 0.0}
         return step, granules, "granules", nch * ngr * 4608, cfg, "mp3_synth_kernel", pcm
+    if name in ("mp3q", "mp3q2"):
+        # config 3 from what the ENTROPY DECODER produces: int16 Huffman samples + the 52-byte requantize record per granule-channel
+        # + one 48-byte joint-stereo record per granule of a pair, every stream a mid/side pair, long blocks.
+        #   mp3q : requantize + stereo + synthesis in ONE kernel (symaccel_mp3_decode_pp_device: the front lives in the load path)
+        #   mp3q2: the same work as TWO kernels (requantize + stereo -> f32 spectra in HBM -> synthesis), the round-3 pipeline
+        from symphonia_amd import backend
+        nch, ngr = max(2, int(128 * scale)) & ~1, (6 if emulate else 2048)
+        rng = np.random.default_rng(seed)
+        q = torch.randint(-40, 41, (nch, ngr, 576), generator=g, device=dev, dtype=torch.int16)
+        rq = np.zeros((nch, ngr), backend.MP3_REQUANT_DTYPE)
+        rq["global_gain"], rq["rzero"] = 150, 576
+        rq["scalefacs"] = rng.integers(0, 4, (nch, ngr, 39))
+        st = np.zeros((nch // 2, ngr), backend.MP3_STEREO_DTYPE)
+        st["flags"], st["rzero0"], st["rzero1"] = 1 | 4, 576, 576  # mid/side, MPEG-1
+        units = np.arange(nch, dtype=np.int32).reshape(-1, 2)
+        side_np = sa.mp3_side(np.zeros((nch, ngr), np.uint8), np.zeros((nch, ngr), np.uint8), np.full((nch, ngr), 576))
+        as_bytes = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(a.shape + (-1,))).to(dev)  # noqa: E731
+        d_rq, d_st, d_units, side = as_bytes(rq), as_bytes(st), torch.from_numpy(units).to(dev), as_bytes(side_np)
+        stt = [[torch.zeros((nch, 576), device=dev), torch.zeros((nch, 1024), device=dev), torch.zeros(nch, dtype=torch.int32, device=dev)]
+               for _ in range(2)]
+        pcm = torch.empty((nch, ngr, 576), device=dev, dtype=torch.float32)
+        syn = sa.Mp3Synthesis(ctx, 0)
+        if name == "mp3q":
+            def step():
+                syn.decode(q, d_rq, d_units, d_st, side, stt[0][0], stt[0][1], stt[0][2], pcm, state_out=stt[1])
+                stt.reverse()
+            kernel = "mp3_synth_kernel<4, true>"
+        else:
+            xr = torch.empty((nch, ngr, 576), device=dev, dtype=torch.float32)
+            ste = sa.Mp3Stereo(ctx, 0)
+
+            def step():
+                ste.requantize_stereo(q, d_rq, d_units, d_st, xr)
+                syn.synth(xr, side, stt[0][0], stt[0][1], stt[0][2], pcm, state_out=stt[1])
+                stt.reverse()
+            kernel = "mp3_stereo_kernel<true> + mp3_synth_kernel<1, false>"
+        step.input = q
+        granules = nch * ngr // 2
+        per_gc = 1152 + 52 + 24 + 4 + 2304  # samples + requantize record + half a stereo record + side word in, PCM out
+        return step, granules, "granules", nch * ngr * per_gc, {
+            "workload": "MP3 Layer III 44.1 kHz stereo from int16 Huffman samples + side records, %d long-block mid/side granules (%d chains x %d): "
+                        "requantize + joint stereo + hybrid synthesis + polyphase, %s" % (granules, nch, ngr, "one kernel" if name == "mp3q" else
+                                                                                      "two kernels (f32 spectra through HBM)"),
+            "granule_channels": nch * ngr, "algorithmic_bytes_per_granule_channel": per_gc}, kernel, pcm
     if name == "vorbis":
         nch, nb = max(1, int(64 * scale)), (16 if emulate else 4096)  # one GPU's shard of config 4: 8 streams x 8 ch x 4096 blocks
         rng = np.random.default_rng(seed)
@@ -573,7 +617,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac"])
+    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2"])
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -776,7 +820,8 @@ def main():
         # LONG_STOP run, random window shapes) and MP3 with Start -> Short.. -> End runs (a quarter of them mixed) and random
         # rzero: SURVEY 8d's correctness mixes, timed
         for key, w, mixw in (("mp3", "mp3", 0.0), ("vorbis", "vorbis", 0.0), ("flac", "flac", 0.0), ("alac", "alac", 0.0),
-                             ("aac_mix_0.05", "aac", 0.05), ("aac_mix_0.25", "aac", 0.25), ("mp3_mix_0.06", "mp3", 0.06)):
+                             ("aac_mix_0.05", "aac", 0.05), ("aac_mix_0.25", "aac", 0.25), ("mp3_mix_0.06", "mp3", 0.06),
+                             ("mp3_int16_one_kernel", "mp3q", 0.0), ("mp3_int16_two_kernels", "mp3q2", 0.0)):
             try:
                 stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, mixw, emulate)
                 nw, ww = (20, 3) if w in ("aac", "mp3", "vorbis") else (8, 2)  # (a few milliseconds each for the short ones)

@@ -320,6 +320,22 @@ int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, con
                                   int32_t *h_vfront_io, float *h_pcm, size_t n_chains, size_t granules_per_chain,
                                   size_t chunk_granules);
 
+/* The same tail in ONE kernel on device buffers (layer3/mod.rs:421-477 fused: requantize + stereo happen in the synthesis
+ * kernel's load path -- csrc/mp3.hip `mp3_front` -- so the requantised spectra never exist in HBM: 2 bytes per line + the
+ * records in, 4 bytes per sample out).  unit_chains[n_units][2]: the chains of every stream of the batch, {channel 0,
+ * channel 1} or {chain, -1} for a mono stream; every chain appears exactly once.  st_desc[n_units][granule] (read, but
+ * ignored, for mono units); quant / rq_desc / side / pcm / state indexed by chain as above.  `_pp_`: separate state in /
+ * out buffers (pairwise distinct), one launch; the plain form updates the state in place. */
+int symaccel_mp3_decode_pp_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc,
+                                  const int32_t *d_unit_chains, const symaccel_mp3_stereo *d_st_desc, size_t n_units,
+                                  const symaccel_mp3_side *d_side, int sample_rate_idx, const float *d_overlap_in,
+                                  const float *d_vvec_in, const int32_t *d_vfront_in, float *d_overlap_out, float *d_vvec_out,
+                                  int32_t *d_vfront_out, float *d_pcm, size_t n_chains, size_t granules_per_chain);
+int symaccel_mp3_decode_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc,
+                               const int32_t *d_unit_chains, const symaccel_mp3_stereo *d_st_desc, size_t n_units,
+                               const symaccel_mp3_side *d_side, int sample_rate_idx, float *d_overlap_io, float *d_vvec_io,
+                               int32_t *d_vfront_io, float *d_pcm, size_t n_chains, size_t granules_per_chain);
+
 /* synthesis::synthesis alone (synthesis.rs:158-336) as Layer I and Layer II use it: n_frames = 12
  * (layer1/mod.rs:193) or 36 (layer2/mod.rs:383) time slots per packet and channel.  in[chain][packet][32 * n_frames]
  * sub-band-major (in[n_frames * i + b], synthesis.rs:168-170); pcm[chain][packet][32 * n_frames]; state per chain:

@@ -45,6 +45,7 @@ ABI_SYMBOLS = [
     "symaccel_probe_copy_device",
     "symaccel_shard_range", "symaccel_scatter_streams", "symaccel_gather_streams", "symaccel_comm_unique_id", "symaccel_comm_init",
     "symaccel_comm_destroy", "symaccel_multi_set_transport", "symaccel_mp3_decode_pipelined",
+    "symaccel_mp3_decode_pp_device", "symaccel_mp3_decode_device",
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
@@ -111,6 +112,8 @@ class Library:
         d.symaccel_alac_predict_stereo_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_predict.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_mp3_decode_pipelined.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
+        d.symaccel_mp3_decode_pp_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_mp3_decode_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_shard_range.argtypes = [_sz, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]
         d.symaccel_scatter_streams.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _sz]
         d.symaccel_gather_streams.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _sz]

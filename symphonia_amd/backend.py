@@ -284,6 +284,26 @@ class Mp3Synthesis:
         return res, ov, vv, vf
 
 
+    def decode(self, quant, rq_desc, unit_chains, st_desc, side, overlap, v_vec, v_front, pcm=None, state_out=None):
+        """The whole tail from the entropy decoder's output in ONE kernel (symaccel_mp3_decode_*_device; device buffers):
+        quant[chains, granules, 576] i16, rq_desc[chains, granules] (52-byte records), unit_chains[units, 2] i32 (second
+        -1 for a mono stream), st_desc[units, granules] (48-byte records), side as synth() takes it."""
+        d = self.ctx.lib.dll
+        nch, ngr = int(quant.shape[0]), int(quant.shape[1])
+        nu = int(unit_chains.shape[0])
+        if pcm is None:
+            import torch
+            pcm = torch.empty((nch, ngr, 576), dtype=torch.float32, device=quant.device)
+        if state_out is not None:
+            self.ctx._call(d.symaccel_mp3_decode_pp_device, _ptr(quant), _ptr(rq_desc), _ptr(unit_chains), _ptr(st_desc), nu, _ptr(side),
+                           self.sr, _ptr(overlap), _ptr(v_vec), _ptr(v_front), _ptr(state_out[0]), _ptr(state_out[1]), _ptr(state_out[2]),
+                           _ptr(pcm), nch, ngr)
+            return pcm
+        self.ctx._call(d.symaccel_mp3_decode_device, _ptr(quant), _ptr(rq_desc), _ptr(unit_chains), _ptr(st_desc), nu, _ptr(side), self.sr,
+                       _ptr(overlap), _ptr(v_vec), _ptr(v_front), _ptr(pcm), nch, ngr)
+        return pcm
+
+
 class MpaPolyphase:
     """synthesis::synthesis for Layer I (n_frames 12) / Layer II (n_frames 36) (synthesis.rs:158-336)."""
 

@@ -494,6 +494,45 @@ int symaccel_mp3_synth_device(symaccel_ctx *ctx, const float *d_xr, const symacc
     return SYMACCEL_OK;
 }
 
+int symaccel_mp3_decode_pp_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc,
+                                  const int32_t *d_unit_chains, const symaccel_mp3_stereo *d_st_desc, size_t n_units,
+                                  const symaccel_mp3_side *d_side, int sample_rate_idx, const float *d_overlap_in,
+                                  const float *d_vvec_in, const int32_t *d_vfront_in, float *d_overlap_out, float *d_vvec_out,
+                                  int32_t *d_vfront_out, float *d_pcm, size_t n_chains, size_t granules_per_chain) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
+    if (!d_quant || !d_rq_desc || !d_unit_chains || !d_st_desc || !d_side || !d_overlap_in || !d_vvec_in || !d_vfront_in ||
+        !d_overlap_out || !d_vvec_out || !d_vfront_out || !d_pcm)
+        return SYMACCEL_ERR_INVALID_ARG;
+    if (n_units == 0 || n_units > n_chains || 2 * n_units < n_chains) return SYMACCEL_ERR_INVALID_ARG;  // every chain in exactly one unit
+    if (d_overlap_in == d_overlap_out || d_vvec_in == d_vvec_out || d_vfront_in == d_vfront_out) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_mp3_decode(ctx, d_quant, d_rq_desc, d_unit_chains, d_st_desc, n_units, d_side, sample_rate_idx, d_overlap_in,
+                             d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out, d_vfront_out, d_pcm, n_chains, granules_per_chain);
+}
+
+int symaccel_mp3_decode_device(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc,
+                               const int32_t *d_unit_chains, const symaccel_mp3_stereo *d_st_desc, size_t n_units,
+                               const symaccel_mp3_side *d_side, int sample_rate_idx, float *d_overlap_io, float *d_vvec_io,
+                               int32_t *d_vfront_io, float *d_pcm, size_t n_chains, size_t granules_per_chain) {
+    if (!ctx || sample_rate_idx < 0 || sample_rate_idx > 8) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || granules_per_chain == 0) return SYMACCEL_OK;
+    if (!d_overlap_io || !d_vvec_io || !d_vfront_io) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    const size_t ov_bytes = n_chains * 576 * 4, vv_bytes = n_chains * 1024 * 4, vf_bytes = n_chains * 4;
+    void *scratch = nullptr;
+    SYM_TRY(ctx_scratch(ctx, ov_bytes + vv_bytes + vf_bytes, &scratch));
+    float *ov_out = (float *)scratch;
+    float *vv_out = ov_out + n_chains * 576;
+    int32_t *vf_out = (int32_t *)(vv_out + n_chains * 1024);
+    SYM_TRY(symaccel_mp3_decode_pp_device(ctx, d_quant, d_rq_desc, d_unit_chains, d_st_desc, n_units, d_side, sample_rate_idx, d_overlap_io,
+                                          d_vvec_io, d_vfront_io, ov_out, vv_out, vf_out, d_pcm, n_chains, granules_per_chain));
+    SYM_TRY(launch_state_copy(ctx, d_overlap_io, ov_out, ov_bytes, d_vvec_io, vv_out, vv_bytes, d_vfront_io, vf_out, vf_bytes));
+    return SYMACCEL_OK;
+}
+
 int symaccel_mp3_synth(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_side *h_side, int sample_rate_idx,
                        float *h_overlap_io, float *h_vvec_io, int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
                        size_t granules_per_chain) {

@@ -24,6 +24,7 @@
 // Roofline: HBM-bound on paper, 2304 B in + 2304 B out per granule-channel, ~34 kflop (no FMA) -> 7.4 flop/B; in
 // practice latency / VALU-issue bound at three wavefronts per SIMD.
 #include "mp3_common.h"
+#include "mp3_requant.h"
 
 namespace symaccel {
 
@@ -189,6 +190,9 @@ typedef float v2f __attribute__((vector_size(8)));  // (GCC / clang vector exten
 #ifndef SYM_MP3_WAVES
 #define SYM_MP3_WAVES 3  // wavefronts per SIMD the register allocation must allow (build-time tuning knob)
 #endif
+#ifndef SYM_MP3_FUSED_WG_WAVES
+#define SYM_MP3_FUSED_WG_WAVES 4  // wavefronts per workgroup of the fused (int16 -> PCM) kernel
+#endif
 // SYM_MP3_SINK (variant 4): gfx950 has ONE in-order counter for vector loads and stores (vmcnt).  With the PCM stores inside
 // `if (emit)` and the prefetch inside `if (r + 1 < my_rounds)` the compiler cannot know how many stores follow the prefetch,
 // and at the loop header it also has to honour the state of the loop's entry (the first fetch, no store behind it): it waits
@@ -200,14 +204,115 @@ typedef float v2f __attribute__((vector_size(8)));  // (GCC / clang vector exten
 #define SYM_MP3_SINK (SYM_MP3_VARIANT == 4)
 constexpr int kSinkSlotFloats = 2048;  // 8 KiB per wavefront slot: two half-waves x 18 rows of 128 B
 constexpr int kSinkSlots = 256;
-__global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVES, SYM_MP3_WAVES))) void mp3_synth_kernel(
+// ---- the fused front (FUSED = true; symaccel_mp3_decode_device): the wavefront's two half-waves are the two CHANNELS of one
+// stream (half 0 = channel 0), walking the same segment of the same granules, and what they load is what the entropy
+// decoder produced -- 576 quantised Huffman samples (int16) and the 52-byte requantize record per granule-channel, one
+// 48-byte joint-stereo record per granule -- instead of the f32 spectra.  At the end of round r the front turns granule
+// r + 1 into the LDS tile the round starts from: requantize (requantize.rs:117-147, 239-380: POW43 look-up, the band's
+// 2^(0.25 (A - B)), one rounded multiply; mp3_requant.h, the arithmetic of mp3_requantize_kernel) with lane = sub-band
+// (lines 18 hl .. 18 hl + 17, the layout the hybrid synthesis wants), then joint stereo (stereo.rs:485-556) against the
+// other half-wave's lines (ds_bpermute with lane ^ 32) -- mid/side below the intensity bound, the band walk of
+// process_intensity_* on the channel-1 zero-band mask when the frame uses intensity stereo (mp3_requant.h, shared with
+// mp3_stereo_kernel).  The f32 spectra never exist in HBM: int16 in, PCM out, one pass.
+constexpr int kFrontPow = kMp3PowLds;                   // POW43 head in LDS (floats)
+constexpr int kFrontMapFloats = 4 * 576 / 4;            // the four line -> band maps of this sample rate (bytes)
+constexpr int kFrontTabFloats = kFrontPow + kFrontMapFloats;
+constexpr int kFwScale = 0;                             // per wavefront: scale[2][40]
+constexpr int kFwRq = kFwScale + 2 * kMp3Slots;         //   the two requantize records (13 dwords each, padded to 14)
+constexpr int kFwSt = kFwRq + 2 * 14;                   //   the joint-stereo record (12 dwords)
+constexpr int kFwNz = kFwSt + 12;                       //   zero-band mask of channel 1 (2 words)
+constexpr int kFwAct = kFwNz + 2;                       //   per band: action, left ratio, right ratio
+constexpr int kFwKl = kFwAct + 40;
+constexpr int kFwKr = kFwKl + 40;
+constexpr int kFrontWaveFloats = kFwKr + 40;
+static_assert(sizeof(symaccel_mp3_requant) == 52 && sizeof(symaccel_mp3_stereo) == 48, "records are fetched as 13 / 12 dwords");
+
+// the 18 quantised samples of lane hl's sub-band (36 bytes, 4-byte aligned: 9 dwords)
+__device__ __forceinline__ void fetch_quant(const int16_t *granule, int hl, uint32_t (&qw)[9]) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(granule) + 9 * hl;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) qw[k] = src[k];
+}
+
+// Granule in registers -> the half-wave's LDS tile (natural line order).  Every lane of the wavefront calls this together.
+__device__ __forceinline__ void mp3_front(const DevTables &tb, const SfbEdges &e, int sr, const uint32_t (&qw)[9], uint32_t dq, int hl, int half,
+                                          bool pair_live, const float *pow43_lo, const uint8_t *maps, float *fw, float *tile) {
+    float *scale = fw + kFwScale + half * kMp3Slots;
+    uint32_t *rqw = reinterpret_cast<uint32_t *>(fw + kFwRq) + 14 * half;
+    uint32_t *stw = reinterpret_cast<uint32_t *>(fw + kFwSt);
+    unsigned *nzw = reinterpret_cast<unsigned *>(fw + kFwNz);
+    int *act = reinterpret_cast<int *>(fw + kFwAct);
+    float *kl = fw + kFwKl, *kr = fw + kFwKr;
+    wave_sync();  // (the records and tables of the previous granule are no longer read)
+    if (hl < 13) rqw[hl] = dq;
+    else if (hl < 25 && half == 0) stw[hl - 13] = dq;
+    if (hl < 2 && half == 0) nzw[hl] = 0u;
+    wave_sync();
+    const symaccel_mp3_requant &rd = *reinterpret_cast<const symaccel_mp3_requant *>(rqw);
+    const symaccel_mp3_stereo &sd = *reinterpret_cast<const symaccel_mp3_stereo *>(stw);
+    scale[hl] = mp3_slot_scale(tb, rd, hl, e.mixed_switch);
+    if (hl < kMp3Slots - 32) scale[32 + hl] = mp3_slot_scale(tb, rd, 32 + hl, e.mixed_switch);
+    wave_sync();
+    const int rz = rd.rzero > 576 ? 576 : (int)rd.rzero;
+    const uint8_t *smap = maps + 576 * mp3_requant_kind(rd) + 18 * hl;
+    float a[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        const uint32_t w = qw[i >> 1];
+        const int sv = (i & 1) ? (int)w >> 16 : (int)(w << 16) >> 16;  // little endian: the even sample is the low half
+        a[i] = mp3_sample_value(tb, pow43_lo, sv, 18 * hl + i >= rz) * scale[smap[i]];
+    }
+    // ---- joint stereo (both half-waves hold the same lines of their channel)
+    const bool mid_side = pair_live && (sd.flags & SYMACCEL_MP3_ST_MID_SIDE), intensity = pair_live && (sd.flags & SYMACCEL_MP3_ST_INTENSITY);
+    if (mid_side || intensity) {  // (wave-uniform: one record per pair and granule)
+        const bool is_short = sd.block_type == SYMACCEL_MP3_SHORT, is_mixed = is_short && sd.is_mixed;
+        const uint8_t *bmap = maps + 576 * (is_short ? (is_mixed ? 3 : 1) : 0) + 18 * hl;
+        const int rzero1 = sd.rzero1 > 576 ? 576 : (int)sd.rzero1;
+        int end = sd.rzero0 > sd.rzero1 ? sd.rzero0 : sd.rzero1;  // stereo.rs:522
+        end = end > 576 ? 576 : end;
+        float b[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) b[i] = __shfl_xor(a[i], 32);
+        Mp3StereoPlan plan{end, 0ull, 0ull};
+        if (intensity) {
+            if (half == 1) {  // is_zero_band (stereo.rs:189-192) of channel 1: one bit per band
+                unsigned long long mine = 0ull;
+#pragma unroll
+                for (int i = 0; i < 18; ++i)
+                    if (a[i] != 0.0f) mine |= 1ull << bmap[i];
+                if ((unsigned)mine) atomicOr(&nzw[0], (unsigned)mine);
+                if ((unsigned)(mine >> 32)) atomicOr(&nzw[1], (unsigned)(mine >> 32));
+            }
+            wave_sync();
+            plan = mp3_stereo_walk(sd, e, (unsigned long long)nzw[0] | ((unsigned long long)nzw[1] << 32), end, rzero1);
+            const int k = half == 0 ? hl : 32 + hl;
+            if (k < 40) mp3_stereo_expand(plan, sd, tb.mp3_is_ratios, k, act, kl, kr);
+            wave_sync();
+        }
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            float c0 = half == 0 ? a[i] : b[i], c1 = half == 0 ? b[i] : a[i];
+            mp3_stereo_apply(c0, c1, 18 * hl + i, plan.bound, mid_side, intensity, bmap[i], act, kl, kr);
+            a[i] = half == 0 ? c0 : c1;
+        }
+    }
+    float2 *t2 = reinterpret_cast<float2 *>(tile + 18 * hl);  // 72 B lane stride: conflict-free b64
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t2[k] = make_float2(a[2 * k], a[2 * k + 1]);
+}
+
+template <int WGW, bool FUSED>
+__global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVES, SYM_MP3_WAVES))) void mp3_synth_kernel(
     DevTables tb, const float *__restrict__ xr, const symaccel_mp3_side *__restrict__ side, int sr,
     const float *__restrict__ overlap_in, const float *__restrict__ vvec_in, const int32_t *__restrict__ vfront_in,
     float *__restrict__ overlap_out, float *__restrict__ vvec_out, int32_t *__restrict__ vfront_out,
     float *__restrict__ pcm, float *__restrict__ sink, unsigned n_chains, unsigned granules_per_chain, unsigned seg_len,
-    unsigned segs_per_chain) {
-    __shared__ __attribute__((aligned(16))) float lds_tab[kTabFloats];
-    __shared__ __attribute__((aligned(16))) float lds_wave[kWgWaves][kWaveFloats];
+    unsigned segs_per_chain, const int16_t *__restrict__ quant, const symaccel_mp3_requant *__restrict__ rq_desc,
+    const symaccel_mp3_stereo *__restrict__ st_desc, const int32_t *__restrict__ pair_chains, SfbEdges edges) {
+    constexpr int kWgWaves = WGW;  // (shadows the file-level constant: wavefronts per workgroup of THIS instantiation)
+    constexpr int kWaveFloatsT = kWaveFloats + (FUSED ? kFrontWaveFloats : 0);
+    __shared__ __attribute__((aligned(16))) float lds_tab[kTabFloats + (FUSED ? kFrontTabFloats : 0)];
+    __shared__ __attribute__((aligned(16))) float lds_wave[WGW][kWaveFloatsT];
     const int wave = (int)threadIdx.x >> 6;
     const int half = ((int)threadIdx.x >> 5) & 1, hl = (int)threadIdx.x & 31;
     float *lds = lds_wave[wave];
@@ -235,11 +340,27 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
     }
     float *imdct_win = lds_tab + kDwFloats;  // the four 36-entry IMDCT windows (hybrid_synthesis.rs:31-101)
     for (int i = (int)threadIdx.x; i < 4 * 36; i += 64 * kWgWaves) imdct_win[i] = tb.mp3_consts[MP3C_IMDCT_WIN + i];
-    if (kWgWaves > 1) __syncthreads();  // the only workgroup-wide barrier; wavefronts are independent from here on
+    float *pow43_lo = lds_tab + kTabFloats;                                                 // (FUSED only)
+    uint8_t *front_maps = reinterpret_cast<uint8_t *>(lds_tab + kTabFloats + kFrontPow);    // (FUSED only)
+    float *fw = lds + kWaveFloats;                                                          // (FUSED only)
+    if (FUSED) {
+        for (int i = (int)threadIdx.x; i < kFrontPow; i += 64 * kWgWaves) pow43_lo[i] = tb.mp3_pow43[i];
+        const uint32_t *msrc = reinterpret_cast<const uint32_t *>(tb.mp3_band_map + (size_t)sr * 4 * 576);
+        for (int i = (int)threadIdx.x; i < kFrontMapFloats; i += 64 * kWgWaves) reinterpret_cast<uint32_t *>(front_maps)[i] = msrc[i];
+    }
+    if (kWgWaves > 1 || FUSED) __syncthreads();  // the only workgroup-wide barrier; wavefronts are independent from here on
 
-    const unsigned item = (blockIdx.x * (unsigned)kWgWaves + (unsigned)wave) * 2u + (unsigned)half;
-    const bool live = item < n_chains * segs_per_chain;
-    const unsigned chain = live ? item / segs_per_chain : 0, seg = live ? item % segs_per_chain : 0;
+    // unfused: every half-wave takes its own (chain, segment); fused: the wavefront takes a (pair, segment), half = channel
+    const unsigned witem = blockIdx.x * (unsigned)kWgWaves + (unsigned)wave;
+    const unsigned item = FUSED ? witem : witem * 2u + (unsigned)half;
+    const bool in_range = item < n_chains * segs_per_chain;  // (fused: n_chains is the number of pairs)
+    const unsigned unit = in_range ? item / segs_per_chain : 0, seg = in_range ? item % segs_per_chain : 0;
+    int fchain = 0;
+    if (FUSED && in_range) fchain = pair_chains[2 * unit + (unsigned)half];  // -1: a mono stream's missing second channel
+    const bool live = in_range && fchain >= 0;
+    const unsigned chain = FUSED ? (live ? (unsigned)fchain : 0u) : unit;
+    bool pair_live = false;  // both channels present: joint stereo can apply
+    if (FUSED) pair_live = in_range && pair_chains[2 * unit] >= 0 && pair_chains[2 * unit + 1] >= 0;
     const unsigned g_begin = seg * seg_len;
     const unsigned g_end = live ? min(g_begin + seg_len, granules_per_chain) : g_begin;
     const VMapX vm = vmapx(hl);
@@ -314,8 +435,23 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
     float4 line[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) line[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // fused: the granule's quantised samples (9 dwords per lane) and one dword of its records (lanes 0..12: the channel's
+    // requantize record, lanes 13..24: the pair's joint-stereo record), fetched like the lines -- one granule ahead
+    uint32_t qw[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t dq = 0u;
+    unsigned sti = FUSED ? unit * granules_per_chain + g_first : 0u;  // index of the pair's joint-stereo record of granule gi
+    auto fetch_front = [&](unsigned g_idx, unsigned st_idx, int lane) {
+        fetch_quant(quant + (size_t)g_idx * 576, lane, qw);
+        if (lane < 13)
+            dq = reinterpret_cast<const uint32_t *>(rq_desc + g_idx)[lane];
+        else if (lane < 25)
+            dq = reinterpret_cast<const uint32_t *>(st_desc + st_idx)[lane - 13];
+    };
     if (my_rounds > 0) {
-        fetch_granule(xr + (size_t)gi * 576, hl, line);
+        if (FUSED)
+            fetch_front(gi, sti, hl);
+        else
+            fetch_granule(xr + (size_t)gi * 576, hl, line);
         sd_next = side_raw[gi];
     }
 #if SYM_MP3_PREFETCH2
@@ -332,7 +468,9 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
 #endif
 
 #if SYM_MP3_SINK
-    {   // round 0's granule -> LDS tile (later rounds: at the end of the round before)
+    if (FUSED) {  // round 0's granule -> LDS tile through the front (requantize + joint stereo)
+        mp3_front(tb, edges, sr, qw, dq, hl, half, pair_live, pow43_lo, front_maps, fw, tile);
+    } else {   // round 0's granule -> LDS tile (later rounds: at the end of the round before)
         float4 *t4 = reinterpret_cast<float4 *>(tile);
 #pragma unroll
         for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
@@ -497,7 +635,12 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
 #elif SYM_MP3_SINK
         {   // prefetch the next granule (granule 0 where there is none: always a valid address, never used)
             const unsigned gn = r + 1 < my_rounds ? gi + 1u : 0u;
-            fetch_granule(xr + (size_t)gn * 576, (int)hlg, line);
+            if (FUSED) {
+                ++sti;
+                fetch_front(gn, r + 1 < my_rounds ? sti : 0u, (int)hlg);
+            } else {
+                fetch_granule(xr + (size_t)gn * 576, (int)hlg, line);
+            }
             sd_next = side_raw[gn];
         }
 #else
@@ -661,7 +804,11 @@ __global__ __launch_bounds__(64 * kWgWaves) __attribute__((amdgpu_waves_per_eu(S
 #endif
         wave_sync();  // the window pass has read S; the next round's tile goes to the same LDS
 #if SYM_MP3_SINK
-        {
+        if (FUSED) {
+            mp3_front(tb, edges, sr, qw, dq, hl, half, pair_live, pow43_lo, front_maps, fw, tile);
+            sd_cur = sd_next;
+            asm volatile("" : "+v"(sd_cur));
+        } else {
             float4 *t4 = reinterpret_cast<float4 *>(tile);
 #pragma unroll
             for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
@@ -753,11 +900,45 @@ int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_
     static_assert((size_t)kSinkSlots * kSinkSlotFloats * sizeof(float) <= kSinkBytes, "sink slots");
     void *sink = nullptr;
     SYM_TRY(ctx_sink(ctx, &sink));
-    hipLaunchKernelGGL(mp3_synth_kernel, dim3((unsigned)grid), dim3(64 * kWgWaves), 0, ctx->stream, ctx->dev, d_xr, d_side, sr,
+    hipLaunchKernelGGL((mp3_synth_kernel<kWgWaves, false>), dim3((unsigned)grid), dim3(64 * kWgWaves), 0, ctx->stream, ctx->dev, d_xr, d_side, sr,
                        d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out, d_vfront_out, d_pcm,
-                       static_cast<float *>(sink), (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs);
+                       static_cast<float *>(sink), (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs,
+                       (const int16_t *)nullptr, (const symaccel_mp3_requant *)nullptr, (const symaccel_mp3_stereo *)nullptr,
+                       (const int32_t *)nullptr, SfbEdges{});
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
+}
+
+// int16 Huffman samples + records -> PCM in one kernel (the fused front, see mp3_front).  d_pair_chains[n_pairs][2]: the two
+// chains of each stream (the second may be -1: a mono stream); every chain of the batch appears exactly once.
+int launch_mp3_decode(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc, const int32_t *d_pair_chains,
+                      const symaccel_mp3_stereo *d_st_desc, size_t n_pairs, const symaccel_mp3_side *d_side, int sr,
+                      const float *d_overlap_in, const float *d_vvec_in, const int32_t *d_vfront_in, float *d_overlap_out,
+                      float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm, size_t n_chains, size_t granules_per_chain) {
+#if SYM_MP3_SINK && !SYM_MP3_OTILE && !SYM_MP3_PREFETCH2
+    if (granules_per_chain > 0x3fffffffu || n_chains > 0x3fffffffu || n_chains * granules_per_chain > 0xffffffffu || n_pairs > n_chains)
+        return SYMACCEL_ERR_INVALID_ARG;
+    constexpr int kFw = SYM_MP3_FUSED_WG_WAVES;  // wavefronts per workgroup: they share the 6.4 KiB of front tables
+    // (a wavefront carries one pair: twice the units of work per chain-segment of the unfused kernel)
+    const unsigned seg = choose_segment(ctx, n_pairs, granules_per_chain, 2 * SYM_MP3_WAVES, 2, 2, 2);
+    const size_t segs = (granules_per_chain + seg - 1) / seg;
+    const size_t items = n_pairs * segs;
+    const size_t grid = (items + kFw - 1) / kFw;
+    if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    void *sink = nullptr;
+    SYM_TRY(ctx_sink(ctx, &sink));
+    const SfbEdges e = make_sfb_edges(host_tables(), sr);
+    hipLaunchKernelGGL((mp3_synth_kernel<kFw, true>), dim3((unsigned)grid), dim3(64 * kFw), 0, ctx->stream, ctx->dev, (const float *)nullptr, d_side,
+                       sr, d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out, d_vfront_out, d_pcm, static_cast<float *>(sink),
+                       (unsigned)n_pairs, (unsigned)granules_per_chain, seg, (unsigned)segs, d_quant, d_rq_desc, d_st_desc, d_pair_chains, e);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+#else
+    (void)ctx; (void)d_quant; (void)d_rq_desc; (void)d_pair_chains; (void)d_st_desc; (void)n_pairs; (void)d_side; (void)sr; (void)d_overlap_in;
+    (void)d_vvec_in; (void)d_vfront_in; (void)d_overlap_out; (void)d_vvec_out; (void)d_vfront_out; (void)d_pcm; (void)n_chains;
+    (void)granules_per_chain;
+    return SYMACCEL_ERR_UNSUPPORTED;  // (the fused front is written for the product's schedule, SYM_MP3_VARIANT 4)
+#endif
 }
 
 }  // namespace symaccel

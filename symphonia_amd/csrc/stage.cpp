@@ -255,7 +255,14 @@ int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, con
         if (c < 0 || (size_t)c >= n_chains || paired[(size_t)c]) return SYMACCEL_ERR_INVALID_ARG;
         paired[(size_t)c] = 1;
     }
-    const bool all_paired = 2 * n_pairs == n_chains;
+    // the fused kernel takes every stream as a unit: the pairs, then {chain, -1} for every chain no pair names (mono)
+    std::vector<int32_t> units(h_pair_chains ? h_pair_chains : nullptr, h_pair_chains ? h_pair_chains + 2 * n_pairs : nullptr);
+    for (size_t c = 0; c < n_chains; ++c)
+        if (!paired[c]) {
+            units.push_back((int32_t)c);
+            units.push_back(-1);
+        }
+    const size_t n_units = units.size() / 2;
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     size_t cg = pick_chunk(granules_per_chain, n_chains * 1152, chunk_granules);
@@ -266,22 +273,24 @@ int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, con
     symaccel_mp3_requant *d_rq[2];
     symaccel_mp3_stereo *d_st[2];
     symaccel_mp3_side *d_side[2];
-    float *d_out[2], *d_ov[2], *d_vv[2], *d_xr;
+    float *d_out[2], *d_ov[2], *d_vv[2];
     int32_t *d_vf[2], *d_pairs;
     for (int b = 0; b < 2; ++b) {
         SYM_TRY(pp.alloc((void **)&d_q[b], n_chains * cg * 1152));
         SYM_TRY(pp.alloc((void **)&d_rq[b], n_chains * cg * sizeof(symaccel_mp3_requant)));
-        SYM_TRY(pp.alloc((void **)&d_st[b], (n_pairs ? n_pairs : 1) * cg * sizeof(symaccel_mp3_stereo)));
+        SYM_TRY(pp.alloc((void **)&d_st[b], n_units * cg * sizeof(symaccel_mp3_stereo)));
         SYM_TRY(pp.alloc((void **)&d_side[b], n_chains * cg * sizeof(symaccel_mp3_side)));
         SYM_TRY(pp.alloc((void **)&d_out[b], n_chains * cg * 2304));
         SYM_TRY(pp.alloc((void **)&d_ov[b], n_chains * 2304));
         SYM_TRY(pp.alloc((void **)&d_vv[b], n_chains * 4096));
         SYM_TRY(pp.alloc((void **)&d_vf[b], n_chains * 4));
     }
-    SYM_TRY(pp.alloc((void **)&d_xr, n_chains * cg * 2304));  // the requantised spectra never leave the device (one buffer:
-    SYM_TRY(pp.alloc((void **)&d_pairs, (n_pairs ? n_pairs : 1) * 8));  // its writer and its reader are ordered by the stream)
+    SYM_TRY(pp.alloc((void **)&d_pairs, n_units * 8));
     SYM_TRY(pp.commit());
-    if (n_pairs) SYM_GPU(ctx, hipMemcpyAsync(d_pairs, h_pair_chains, n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
+    // (the requantised spectra exist in registers and LDS only: csrc/mp3.hip mp3_front)
+    SYM_GPU(ctx, hipMemcpy(d_pairs, units.data(), n_units * 8, hipMemcpyHostToDevice));  // (`units` is a local: a blocking copy)
+    for (int b = 0; b < 2; ++b)  // the records of mono units stay zero: no joint-stereo flag
+        SYM_GPU(ctx, hipMemsetAsync(d_st[b], 0, n_units * cg * sizeof(symaccel_mp3_stereo), pp.s_in));
     SYM_GPU(ctx, hipMemcpyAsync(d_ov[0], h_overlap_io, n_chains * 2304, hipMemcpyHostToDevice, ctx->stream));
     SYM_GPU(ctx, hipMemcpyAsync(d_vv[0], h_vvec_io, n_chains * 4096, hipMemcpyHostToDevice, ctx->stream));
     SYM_GPU(ctx, hipMemcpyAsync(d_vf[0], h_vfront_io, n_chains * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -304,15 +313,10 @@ int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, con
         SYM_TRY(copy_rows(ctx, d_side[b], ng * 4, h_side + g0, granules_per_chain * 4, ng * 4, n_chains, hipMemcpyHostToDevice, pp.s_in));
         SYM_GPU(ctx, hipEventRecord(pp.ev_in[b], pp.s_in));
         SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_in[b], 0));
-        // requantize (+ joint stereo) -> synthesis tail, layer3/mod.rs:421-477 in that order
-        if (all_paired) {
-            SYM_TRY(launch_mp3_stereo(ctx, d_xr, ng, d_pairs, d_st[b], sample_rate_idx, n_pairs, d_q[b], d_rq[b]));
-        } else {
-            SYM_TRY(launch_mp3_requantize(ctx, d_q[b], d_rq[b], sample_rate_idx, d_xr, n_chains * ng));
-            if (n_pairs) SYM_TRY(launch_mp3_stereo(ctx, d_xr, ng, d_pairs, d_st[b], sample_rate_idx, n_pairs));
-        }
+        // requantize, joint stereo and the synthesis tail (layer3/mod.rs:421-477) in one kernel
         const int si = (int)(k & 1), so = (int)((k + 1) & 1);
-        SYM_TRY(launch_mp3(ctx, d_xr, d_side[b], sample_rate_idx, d_ov[si], d_vv[si], d_vf[si], d_ov[so], d_vv[so], d_vf[so], d_out[b], n_chains, ng));
+        SYM_TRY(launch_mp3_decode(ctx, d_q[b], d_rq[b], d_pairs, d_st[b], n_units, d_side[b], sample_rate_idx, d_ov[si], d_vv[si], d_vf[si],
+                                  d_ov[so], d_vv[so], d_vf[so], d_out[b], n_chains, ng));
         SYM_GPU(ctx, hipEventRecord(pp.ev_k[b], ctx->stream));
         SYM_GPU(ctx, hipStreamWaitEvent(pp.s_out, pp.ev_k[b], 0));
         SYM_TRY(copy_rows(ctx, h_pcm + g0 * 576, granules_per_chain * 2304, d_out[b], ng * 2304, ng * 2304, n_chains, hipMemcpyDeviceToHost, pp.s_out));

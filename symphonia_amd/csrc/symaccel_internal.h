@@ -234,6 +234,10 @@ int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d
                             const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs);
 int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
                    size_t n_filters);
+int launch_mp3_decode(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc, const int32_t *d_pair_chains,
+                      const symaccel_mp3_stereo *d_st_desc, size_t n_pairs, const symaccel_mp3_side *d_side, int sr,
+                      const float *d_overlap_in, const float *d_vvec_in, const int32_t *d_vfront_in, float *d_overlap_out,
+                      float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm, size_t n_chains, size_t granules_per_chain);
 int launch_mp3_stereo(symaccel_ctx *ctx, float *d_xr, size_t granules_per_chain, const int32_t *d_pair_chains,
                       const symaccel_mp3_stereo *d_desc, int sr, size_t n_pairs, const int16_t *d_quant = nullptr,
                       const symaccel_mp3_requant *d_rq_desc = nullptr);

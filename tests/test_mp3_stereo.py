@@ -395,3 +395,62 @@ def test_gpu_mp3_decode_pipelined(sr, n_pairs, granules, with_mono):
     ctx = Context(0)
     run_decode_pipelined(ctx, sr, n_pairs, granules, with_mono, [4, 0])
     ctx.close()
+
+
+# ---------------------------------------------------------------- the fused kernel on device buffers (int16 -> PCM, one launch)
+
+def units_of(pairs, chains):
+    """unit_chains of symaccel_mp3_decode_*_device: the pairs, then {chain, -1} for every chain no pair names"""
+    named = set(int(c) for c in np.asarray(pairs).ravel())
+    rows = [[int(a), int(b)] for a, b in pairs] + [[c, -1] for c in range(chains) if c not in named]
+    return np.array(rows, np.int32)
+
+
+def run_decode_device(ctx, dev, host, sr, n_pairs, granules, with_mono, seg, seed=0):
+    from symphonia_amd import Mp3Synthesis
+    q, rd, pairs, sd, side, ov, vv, vf, want = decode_pipelined_case(70 + seed + sr + n_pairs, sr, n_pairs, granules, with_mono)
+    chains = q.shape[0]
+    units = units_of(pairs, chains)
+    sdu = np.zeros((len(units), granules), oracle.MP3_STEREO_DTYPE)
+    sdu[: len(pairs)] = sd
+    as_bytes = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(a.shape + (-1,))  # noqa: E731
+    d_ov, d_vv, d_vf = dev(ov), dev(vv), dev(vf)
+    pcm = dev(np.zeros((chains, granules, 576), F))
+    ctx.set_segment(seg)
+    Mp3Synthesis(ctx, sr).decode(dev(q), dev(as_bytes(rd)), dev(units), dev(as_bytes(sdu)), dev(as_bytes(np.ascontiguousarray(side))), d_ov, d_vv,
+                                 d_vf, pcm)
+    ctx.set_segment(0)
+    assert bit_equal(host(pcm), want[0]), ("pcm", seg)
+    assert bit_equal(host(d_ov), want[1]) and bit_equal(host(d_vv), want[2]) and np.array_equal(host(d_vf), want[3]), ("state", seg)
+    # the ping-pong form: state in untouched, state out written
+    o2, v2, f2 = dev(np.zeros_like(ov)), dev(np.zeros_like(vv)), dev(np.zeros_like(vf))
+    d_ov, d_vv, d_vf = dev(ov), dev(vv), dev(vf)
+    pcm2 = dev(np.zeros((chains, granules, 576), F))
+    Mp3Synthesis(ctx, sr).decode(dev(q), dev(as_bytes(rd)), dev(units), dev(as_bytes(sdu)), dev(as_bytes(np.ascontiguousarray(side))), d_ov, d_vv,
+                                 d_vf, pcm2, state_out=(o2, v2, f2))
+    assert bit_equal(host(pcm2), want[0]) and bit_equal(host(o2), want[1]) and bit_equal(host(v2), want[2]) and np.array_equal(host(f2), want[3])
+    assert bit_equal(host(d_ov), ov) and bit_equal(host(d_vv), vv)
+
+
+@pytest.mark.parametrize("sr,n_pairs,granules,with_mono,seg", [(0, 2, 9, True, 0), (3, 1, 5, False, 2), (8, 3, 11, False, 3), (1, 0, 4, True, 0),
+                                                                (4, 5, 1, True, 0), (2, 2, 13, True, 4)])
+def test_emu_mp3_decode_device(emu_ctx, sr, n_pairs, granules, with_mono, seg):
+    """symaccel_mp3_decode_device / _pp_device: requantize + joint stereo inside the synthesis kernel's load path (csrc/mp3.hip
+    mp3_front) == oracle requantize -> stereo -> synthesis, bit for bit; segments with their two-granule halo included."""
+    run_decode_device(emu_ctx, lambda a: np.array(a, copy=True, order="C"), lambda a: a, sr, n_pairs, granules, with_mono, seg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,n_pairs,granules,with_mono,seg", [(0, 9, 40, True, 0), (8, 5, 33, False, 7), (3, 33, 17, True, 2), (0, 1, 1, False, 0),
+                                                                (5, 70, 24, True, 0)])
+def test_gpu_mp3_decode_device(sr, n_pairs, granules, with_mono, seg):
+    import torch
+    from symphonia_amd import Context
+    ctx = Context(0)
+    ctx.use_torch_stream()
+
+    def host(t):
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+    run_decode_device(ctx, lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(), host, sr, n_pairs, granules, with_mono, seg, seed=3)
+    ctx.close()
