@@ -193,6 +193,9 @@ typedef float v2f __attribute__((vector_size(8)));  // (GCC / clang vector exten
 #ifndef SYM_MP3_FUSED_WG_WAVES
 #define SYM_MP3_FUSED_WG_WAVES 4  // wavefronts per workgroup of the fused (int16 -> PCM) kernel
 #endif
+#ifndef SYM_MP3_FUSED_WAVES
+#define SYM_MP3_FUSED_WAVES 2     // wavefronts per SIMD its register allocation must allow (build-time tuning knob)
+#endif
 // SYM_MP3_SINK (variant 4): gfx950 has ONE in-order counter for vector loads and stores (vmcnt).  With the PCM stores inside
 // `if (emit)` and the prefetch inside `if (r + 1 < my_rounds)` the compiler cannot know how many stores follow the prefetch,
 // and at the loop header it also has to honour the state of the loop's entry (the first fetch, no store behind it): it waits
@@ -214,9 +217,16 @@ constexpr int kSinkSlots = 256;
 // other half-wave's lines (ds_bpermute with lane ^ 32) -- mid/side below the intensity bound, the band walk of
 // process_intensity_* on the channel-1 zero-band mask when the frame uses intensity stereo (mp3_requant.h, shared with
 // mp3_stereo_kernel).  The f32 spectra never exist in HBM: int16 in, PCM out, one pass.
-constexpr int kFrontPow = kMp3PowLds;                   // POW43 head in LDS (floats)
+// Both look-up tables of requantize live in LDS IN FULL (POW43: 8207 entries, 32 KiB; 2^(0.25 e): 1346 entries, 5.3 KiB), shared by
+// the workgroup's four wavefronts.  A global load anywhere in the front -- even in a branch that is never taken: the compiler
+// places the wait where the paths join -- makes the wavefront wait for its own 18 PCM stores of the round (gfx950 counts
+// loads and stores with one in-order counter); 69 KiB of LDS per workgroup still leaves two workgroups (two wavefronts per
+// SIMD) per CU.
+constexpr int kFrontPow = 8208;                         // POW43 (8207 entries, padded)
 constexpr int kFrontMapFloats = 4 * 576 / 4;            // the four line -> band maps of this sample rate (bytes)
-constexpr int kFrontTabFloats = kFrontPow + kFrontMapFloats;
+constexpr int kP2MinE = kMp3Pow2abMinE, kP2Len = kMp3Pow2abLen;
+constexpr int kFrontEdgeFloats = (sizeof(SfbEdges) + 3) / 4;  // the band edge tables (the intensity walk reads them through a pointer)
+constexpr int kFrontTabFloats = kFrontPow + kFrontMapFloats + kP2Len + kFrontEdgeFloats;
 constexpr int kFwScale = 0;                             // per wavefront: scale[2][40]
 constexpr int kFwRq = kFwScale + 2 * kMp3Slots;         //   the two requantize records (13 dwords each, padded to 14)
 constexpr int kFwSt = kFwRq + 2 * 14;                   //   the joint-stereo record (12 dwords)
@@ -227,6 +237,24 @@ constexpr int kFwKr = kFwKl + 40;
 constexpr int kFrontWaveFloats = kFwKr + 40;
 static_assert(sizeof(symaccel_mp3_requant) == 52 && sizeof(symaccel_mp3_stereo) == 48, "records are fetched as 13 / 12 dwords");
 
+// The exponent A - B of mp3_slot_scale (mp3_requant.h; requantize.rs:260-352) of scale slot `slot` (< kMp3Unscaled), without a
+// memory table: the pre-emphasis values of ISO/IEC 11172-3 Table B.6 are two bits per band in a constant.
+__device__ __forceinline__ int front_slot_exponent(const symaccel_mp3_requant &d, int slot, int switch_point) {
+    // bands 0..21: 0 0 0 0 0 0 0 0 0 0 0 1 1 1 1 2 2 3 3 3 2 0
+    constexpr unsigned long long kPre2 = (1ull << 22) | (1ull << 24) | (1ull << 26) | (1ull << 28) | (2ull << 30) | (2ull << 32) | (3ull << 34) |
+                                         (3ull << 36) | (3ull << 38) | (2ull << 40);
+    const bool is_short = d.block_type == SYMACCEL_MP3_SHORT;
+    const int sw = is_short ? (d.is_mixed ? switch_point : 0) : 64;
+    const int shift = (d.flags & SYMACCEL_MP3_RQ_SCALEFAC_SCALE) ? 2 : 1;
+    const int gain = (int)d.global_gain - 210;
+    if (slot < sw) {
+        const int pre = ((d.flags & SYMACCEL_MP3_RQ_PREFLAG) && slot < 22) ? (int)((kPre2 >> (2 * slot)) & 3ull) : 0;
+        return gain - (((int)d.scalefacs[slot] + pre) << shift);
+    }
+    const int win = (slot - sw) % 3;
+    return gain - 8 * (int)d.subblock_gain[win] - ((int)d.scalefacs[slot] << shift);
+}
+
 // the 18 quantised samples of lane hl's sub-band (36 bytes, 4-byte aligned: 9 dwords)
 __device__ __forceinline__ void fetch_quant(const int16_t *granule, int hl, uint32_t (&qw)[9]) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(granule) + 9 * hl;
@@ -234,15 +262,56 @@ __device__ __forceinline__ void fetch_quant(const int16_t *granule, int hl, uint
     for (int k = 0; k < 9; ++k) qw[k] = src[k];
 }
 
+// The intensity-stereo plan of one granule (stereo.rs:196-483): which bands are intensity coded is decided from the zero bands of
+// channel 1 (the half-wave 1 lanes flag the bands of their non-zero lines), then every lane runs the reference's band walk
+// on that mask and lanes 0..39 turn it into per-band actions and ratios.  Rare (low bit rate streams), long, branchy:
+// kept OUT of the synthesis loop's instruction stream.
+// Works on the two half-waves' LDS tiles (the requantised lines of channel 0 and channel 1, natural order), in place; every argument
+// is a scalar or a pointer into LDS -- an array passed by reference would live in scratch memory in the CALLER too.
+__device__ __attribute__((noinline)) void mp3_front_intensity(const float *is_ratios, const SfbEdges *e, const symaccel_mp3_stereo *sd, float *tiles,
+                                                               const uint8_t *bmap_row, int hl, int half, float *fw) {
+    unsigned *nzw = reinterpret_cast<unsigned *>(fw + kFwNz);
+    int *act = reinterpret_cast<int *>(fw + kFwAct);
+    float *kl = fw + kFwKl, *kr = fw + kFwKr;
+    const bool mid_side = sd->flags & SYMACCEL_MP3_ST_MID_SIDE;
+    const int rzero1 = sd->rzero1 > 576 ? 576 : (int)sd->rzero1;
+    int end = sd->rzero0 > sd->rzero1 ? sd->rzero0 : sd->rzero1;  // stereo.rs:522
+    end = end > 576 ? 576 : end;
+    const uint8_t *bmap = bmap_row + 18 * hl;
+    float c0[18], c1[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        c0[i] = tiles[18 * hl + i];
+        c1[i] = tiles[576 + 18 * hl + i];
+    }
+    if (half == 1) {  // is_zero_band (stereo.rs:189-192) of channel 1: one bit per band
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int i = 0; i < 18; ++i)
+            if (c1[i] != 0.0f) mine |= 1ull << bmap[i];
+        if ((unsigned)mine) atomicOr(&nzw[0], (unsigned)mine);
+        if ((unsigned)(mine >> 32)) atomicOr(&nzw[1], (unsigned)(mine >> 32));
+    }
+    wave_sync();  // (also: every lane has read its lines of both tiles)
+    const Mp3StereoPlan plan = mp3_stereo_walk(*sd, *e, (unsigned long long)nzw[0] | ((unsigned long long)nzw[1] << 32), end, rzero1);
+    const int k = half == 0 ? hl : 32 + hl;
+    if (k < 40) mp3_stereo_expand(plan, *sd, is_ratios, k, act, kl, kr);
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        mp3_stereo_apply(c0[i], c1[i], 18 * hl + i, plan.bound, mid_side, true, bmap[i], act, kl, kr);
+        tiles[576 * half + 18 * hl + i] = half == 0 ? c0[i] : c1[i];
+    }
+}
+
 // Granule in registers -> the half-wave's LDS tile (natural line order).  Every lane of the wavefront calls this together.
-__device__ __forceinline__ void mp3_front(const DevTables &tb, const SfbEdges &e, int sr, const uint32_t (&qw)[9], uint32_t dq, int hl, int half,
-                                          bool pair_live, const float *pow43_lo, const uint8_t *maps, float *fw, float *tile) {
+__device__ __forceinline__ void mp3_front(const DevTables &tb, const SfbEdges *e_lds, int mixed_switch, const uint32_t (&qw)[9], uint32_t dq, int hl,
+                                          int half, bool pair_live, const float *pow43_lo, const uint8_t *maps, const float *p2_lo, float *fw,
+                                          float *tile) {
     float *scale = fw + kFwScale + half * kMp3Slots;
     uint32_t *rqw = reinterpret_cast<uint32_t *>(fw + kFwRq) + 14 * half;
     uint32_t *stw = reinterpret_cast<uint32_t *>(fw + kFwSt);
     unsigned *nzw = reinterpret_cast<unsigned *>(fw + kFwNz);
-    int *act = reinterpret_cast<int *>(fw + kFwAct);
-    float *kl = fw + kFwKl, *kr = fw + kFwKr;
     wave_sync();  // (the records and tables of the previous granule are no longer read)
     if (hl < 13) rqw[hl] = dq;
     else if (hl < 25 && half == 0) stw[hl - 13] = dq;
@@ -250,59 +319,77 @@ __device__ __forceinline__ void mp3_front(const DevTables &tb, const SfbEdges &e
     wave_sync();
     const symaccel_mp3_requant &rd = *reinterpret_cast<const symaccel_mp3_requant *>(rqw);
     const symaccel_mp3_stereo &sd = *reinterpret_cast<const symaccel_mp3_stereo *>(stw);
-    scale[hl] = mp3_slot_scale(tb, rd, hl, e.mixed_switch);
-    if (hl < kMp3Slots - 32) scale[32 + hl] = mp3_slot_scale(tb, rd, 32 + hl, e.mixed_switch);
+    {   // the slots' 2^(0.25 (A - B)) (mp3_slot_scale, mp3_requant.h): lane hl has slot hl and, lanes 0..7, slot 32 + hl
+        auto slot_scale = [&](int slot) {
+            if (slot >= kMp3Unscaled) return 1.0f;  // lines no band covers: x * 1.0f == x
+            int idx = front_slot_exponent(rd, slot, mixed_switch) - kP2MinE;
+            idx = idx < 0 ? 0 : (idx >= kP2Len ? kP2Len - 1 : idx);
+            return p2_lo[idx];
+        };
+        scale[hl] = slot_scale(hl);
+        if (hl < kMp3Slots - 32) scale[32 + hl] = slot_scale(32 + hl);
+    }
     wave_sync();
     const int rz = rd.rzero > 576 ? 576 : (int)rd.rzero;
     const uint8_t *smap = maps + 576 * mp3_requant_kind(rd) + 18 * hl;
-    float a[18];
+    // mp3_sample_value (mp3_requant.h) x the band's scale, with every table in LDS and NO conditional around a load: the
+    // compiler turns `cond ? table[i] : 0` into a branch per line with the LDS round trip inside it -- 54 dependent round trips
+    // per granule.  Here the index is made harmless instead (a zeroed sample reads POW43[0] = +0.0), the 18 + 9 + 18 reads
+    // of a phase are independent of each other, and the sign is OR-ed in (POW43 >= 0).
+    int mag[18];
+    unsigned sgn[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
         const uint32_t w = qw[i >> 1];
-        const int sv = (i & 1) ? (int)w >> 16 : (int)(w << 16) >> 16;  // little endian: the even sample is the low half
-        a[i] = mp3_sample_value(tb, pow43_lo, sv, 18 * hl + i >= rz) * scale[smap[i]];
+        int sv = (i & 1) ? (int)w >> 16 : (int)(w << 16) >> 16;  // little endian: the even sample is the low half
+        sv = 18 * hl + i < rz ? sv : 0;                           // the rzero partition: literal +0.0 (requantize.rs:117-147)
+        const int m = sv < 0 ? -sv : sv;
+        mag[i] = m > 8206 ? 8206 : m;
+        sgn[i] = (unsigned)sv & 0x80000000u;
+    }
+    float pw[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) pw[i] = pow43_lo[mag[i]];
+    unsigned sm[9];  // the 18 slot indices of the lane's lines, two per 16-bit read (18 hl is even)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sm[k] = reinterpret_cast<const uint16_t *>(smap)[k];
+    float a[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        const float sc = scale[(sm[i >> 1] >> (8 * (i & 1))) & 255u];
+        a[i] = __uint_as_float(__float_as_uint(pw[i]) | sgn[i]) * sc;
     }
     // ---- joint stereo (both half-waves hold the same lines of their channel)
     const bool mid_side = pair_live && (sd.flags & SYMACCEL_MP3_ST_MID_SIDE), intensity = pair_live && (sd.flags & SYMACCEL_MP3_ST_INTENSITY);
-    if (mid_side || intensity) {  // (wave-uniform: one record per pair and granule)
-        const bool is_short = sd.block_type == SYMACCEL_MP3_SHORT, is_mixed = is_short && sd.is_mixed;
-        const uint8_t *bmap = maps + 576 * (is_short ? (is_mixed ? 3 : 1) : 0) + 18 * hl;
-        const int rzero1 = sd.rzero1 > 576 ? 576 : (int)sd.rzero1;
+    if (mid_side && !intensity) {  // (wave-uniform: one record per pair and granule) mid/side alone, stereo.rs:139-148, 541-543
         int end = sd.rzero0 > sd.rzero1 ? sd.rzero0 : sd.rzero1;  // stereo.rs:522
         end = end > 576 ? 576 : end;
-        float b[18];
-#pragma unroll
-        for (int i = 0; i < 18; ++i) b[i] = __shfl_xor(a[i], 32);
-        Mp3StereoPlan plan{end, 0ull, 0ull};
-        if (intensity) {
-            if (half == 1) {  // is_zero_band (stereo.rs:189-192) of channel 1: one bit per band
-                unsigned long long mine = 0ull;
-#pragma unroll
-                for (int i = 0; i < 18; ++i)
-                    if (a[i] != 0.0f) mine |= 1ull << bmap[i];
-                if ((unsigned)mine) atomicOr(&nzw[0], (unsigned)mine);
-                if ((unsigned)(mine >> 32)) atomicOr(&nzw[1], (unsigned)(mine >> 32));
-            }
-            wave_sync();
-            plan = mp3_stereo_walk(sd, e, (unsigned long long)nzw[0] | ((unsigned long long)nzw[1] << 32), end, rzero1);
-            const int k = half == 0 ? hl : 32 + hl;
-            if (k < 40) mp3_stereo_expand(plan, sd, tb.mp3_is_ratios, k, act, kl, kr);
-            wave_sync();
-        }
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
-            float c0 = half == 0 ? a[i] : b[i], c1 = half == 0 ? b[i] : a[i];
-            mp3_stereo_apply(c0, c1, 18 * hl + i, plan.bound, mid_side, intensity, bmap[i], act, kl, kr);
-            a[i] = half == 0 ? c0 : c1;
+            const float b = __shfl_xor(a[i], 32);
+            const float c0 = half == 0 ? a[i] : b, c1 = half == 0 ? b : a[i];
+            const float v = (half == 0 ? c0 + c1 : c0 - c1) * kMp3Frac1Sqrt2;
+            a[i] = 18 * hl + i < end ? v : a[i];
         }
     }
     float2 *t2 = reinterpret_cast<float2 *>(tile + 18 * hl);  // 72 B lane stride: conflict-free b64
 #pragma unroll
     for (int k = 0; k < 9; ++k) t2[k] = make_float2(a[2 * k], a[2 * k + 1]);
+    if (intensity) {  // rare (low bit rates): the band walk and its application, on the two tiles, out of line
+        const bool is_short = sd.block_type == SYMACCEL_MP3_SHORT, is_mixed = is_short && sd.is_mixed;
+        wave_sync();
+        mp3_front_intensity(tb.mp3_is_ratios, e_lds, &sd, tile - 576 * half, maps + 576 * (is_short ? (is_mixed ? 3 : 1) : 0), hl, half, fw);
+    }
 }
 
+#ifdef SYMACCEL_EMULATED_HIP
+#define SYM_MP3_WAVES_ATTR(fused)
+#else
+#define SYM_MP3_WAVES_ATTR(fused) \
+    __attribute__((amdgpu_waves_per_eu((fused) ? SYM_MP3_FUSED_WAVES : SYM_MP3_WAVES, (fused) ? SYM_MP3_FUSED_WAVES : SYM_MP3_WAVES)))
+#endif
 template <int WGW, bool FUSED>
-__global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(SYM_MP3_WAVES, SYM_MP3_WAVES))) void mp3_synth_kernel(
+__global__ __launch_bounds__(64 * WGW) SYM_MP3_WAVES_ATTR(FUSED) void mp3_synth_kernel(
     DevTables tb, const float *__restrict__ xr, const symaccel_mp3_side *__restrict__ side, int sr,
     const float *__restrict__ overlap_in, const float *__restrict__ vvec_in, const int32_t *__restrict__ vfront_in,
     float *__restrict__ overlap_out, float *__restrict__ vvec_out, int32_t *__restrict__ vfront_out,
@@ -342,11 +429,16 @@ __global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(SYM_MP
     for (int i = (int)threadIdx.x; i < 4 * 36; i += 64 * kWgWaves) imdct_win[i] = tb.mp3_consts[MP3C_IMDCT_WIN + i];
     float *pow43_lo = lds_tab + kTabFloats;                                                 // (FUSED only)
     uint8_t *front_maps = reinterpret_cast<uint8_t *>(lds_tab + kTabFloats + kFrontPow);    // (FUSED only)
+    float *p2_lo = lds_tab + kTabFloats + kFrontPow + kFrontMapFloats;                      // (FUSED only)
+    SfbEdges *e_lds = reinterpret_cast<SfbEdges *>(lds_tab + kTabFloats + kFrontPow + kFrontMapFloats + kP2Len);  // (FUSED only)
+    const int mixed_switch = edges.mixed_switch;
     float *fw = lds + kWaveFloats;                                                          // (FUSED only)
     if (FUSED) {
-        for (int i = (int)threadIdx.x; i < kFrontPow; i += 64 * kWgWaves) pow43_lo[i] = tb.mp3_pow43[i];
+        for (int i = (int)threadIdx.x; i < 8207; i += 64 * kWgWaves) pow43_lo[i] = tb.mp3_pow43[i];
         const uint32_t *msrc = reinterpret_cast<const uint32_t *>(tb.mp3_band_map + (size_t)sr * 4 * 576);
         for (int i = (int)threadIdx.x; i < kFrontMapFloats; i += 64 * kWgWaves) reinterpret_cast<uint32_t *>(front_maps)[i] = msrc[i];
+        for (int i = (int)threadIdx.x; i < kP2Len; i += 64 * kWgWaves) p2_lo[i] = tb.mp3_pow2ab[i];
+        if (threadIdx.x == 0) *e_lds = edges;
     }
     if (kWgWaves > 1 || FUSED) __syncthreads();  // the only workgroup-wide barrier; wavefronts are independent from here on
 
@@ -468,9 +560,7 @@ __global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(SYM_MP
 #endif
 
 #if SYM_MP3_SINK
-    if (FUSED) {  // round 0's granule -> LDS tile through the front (requantize + joint stereo)
-        mp3_front(tb, edges, sr, qw, dq, hl, half, pair_live, pow43_lo, front_maps, fw, tile);
-    } else {   // round 0's granule -> LDS tile (later rounds: at the end of the round before)
+    if (!FUSED) {   // round 0's granule -> LDS tile (later rounds: at the end of the round before; fused: by the pre-round below)
         float4 *t4 = reinterpret_cast<float4 *>(tile);
 #pragma unroll
         for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
@@ -479,7 +569,10 @@ __global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(SYM_MP
     uint32_t sd_cur = sd_next;
     asm volatile("" : "+v"(sd_cur));
 #endif
-    for (int r = 0; r < rounds; ++r, ++gi) {
+    // fused: the loop starts with a PRE-ROUND (r = -1) that runs nothing but the front on granule 0 -- the front is a few hundred
+    // instructions and has exactly one copy in the instruction stream this way
+    if (FUSED) --gi;
+    for (int r = FUSED ? -1 : 0; r < rounds; ++r, ++gi) {
         unsigned hlg = (unsigned)hl;  // the lane's offset in global addresses, opaque for the same reason as gi:
         asm volatile("" : "+v"(gi), "+v"(hlg));  // keeps the address arithmetic in the loop (see above)
         const bool active = r < my_rounds;
@@ -519,6 +612,8 @@ __global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(SYM_MP
         }
 #endif
 
+        do {  // (the round proper; skipped by the fused kernel's pre-round)
+        if (FUSED && r < 0) break;
         int bt = 0, mixed = 0, rzero = 0;
         if (active) {
 #if SYM_MP3_SINK
@@ -803,9 +898,10 @@ __global__ __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(SYM_MP
         }
 #endif
         wave_sync();  // the window pass has read S; the next round's tile goes to the same LDS
+        } while (0);
 #if SYM_MP3_SINK
         if (FUSED) {
-            mp3_front(tb, edges, sr, qw, dq, hl, half, pair_live, pow43_lo, front_maps, fw, tile);
+            mp3_front(tb, e_lds, mixed_switch, qw, dq, hl, half, pair_live, pow43_lo, front_maps, p2_lo, fw, tile);
             sd_cur = sd_next;
             asm volatile("" : "+v"(sd_cur));
         } else {
@@ -920,7 +1016,7 @@ int launch_mp3_decode(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_
         return SYMACCEL_ERR_INVALID_ARG;
     constexpr int kFw = SYM_MP3_FUSED_WG_WAVES;  // wavefronts per workgroup: they share the 6.4 KiB of front tables
     // (a wavefront carries one pair: twice the units of work per chain-segment of the unfused kernel)
-    const unsigned seg = choose_segment(ctx, n_pairs, granules_per_chain, 2 * SYM_MP3_WAVES, 2, 2, 2);
+    const unsigned seg = choose_segment(ctx, n_pairs, granules_per_chain, 4 * SYM_MP3_FUSED_WAVES, 1, 2, 2);
     const size_t segs = (granules_per_chain + seg - 1) / seg;
     const size_t items = n_pairs * segs;
     const size_t grid = (items + kFw - 1) / kFw;
