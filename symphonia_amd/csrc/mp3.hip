@@ -898,21 +898,6 @@ __global__ __launch_bounds__(64 * WGW) SYM_MP3_WAVES_ATTR(FUSED) void mp3_synth_
         }
 #endif
         wave_sync();  // the window pass has read S; the next round's tile goes to the same LDS
-        } while (0);
-#if SYM_MP3_SINK
-        if (FUSED) {
-            mp3_front(tb, e_lds, mixed_switch, qw, dq, hl, half, pair_live, pow43_lo, front_maps, p2_lo, fw, tile);
-            sd_cur = sd_next;
-            asm volatile("" : "+v"(sd_cur));
-        } else {
-            float4 *t4 = reinterpret_cast<float4 *>(tile);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
-            if (hl < 16) t4[128 + hl] = line[4];
-            sd_cur = sd_next;
-            asm volatile("" : "+v"(sd_cur));  // (the side word is waited for HERE, behind the lines, not at the loop header)
-        }
-#endif
         // ---- slide the history: slots 2..17 of this granule become slots -16..-1
         if (need_hist) {
 #if SYM_MP3_PACKED
@@ -928,6 +913,21 @@ __global__ __launch_bounds__(64 * WGW) SYM_MP3_WAVES_ATTR(FUSED) void mp3_synth_
             }
 #endif
         }
+        } while (0);
+#if SYM_MP3_SINK
+        if (FUSED) {
+            mp3_front(tb, e_lds, mixed_switch, qw, dq, hl, half, pair_live, pow43_lo, front_maps, p2_lo, fw, tile);
+            sd_cur = sd_next;
+            asm volatile("" : "+v"(sd_cur));
+        } else {
+            float4 *t4 = reinterpret_cast<float4 *>(tile);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t4[hl + 32 * q] = line[q];
+            if (hl < 16) t4[128 + hl] = line[4];
+            sd_cur = sd_next;
+            asm volatile("" : "+v"(sd_cur));  // (the side word is waited for HERE, behind the lines, not at the loop header)
+        }
+#endif
     }
 
 #if SYM_MP3_CLOCK
