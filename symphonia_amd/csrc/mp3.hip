@@ -45,7 +45,7 @@ namespace {
 //      write acknowledgements were not what the kernel waits for), 1 % ahead at the sustained clock together with the packed
 //      window pass (profiles/r03x_sustained_ab.txt): the product.
 // Round 3's measurements (tools/ubench/valu_clock.hip, tools/kernel_clock_probe.py): the loads and stores alone
-// run at 5.3-5.6 TB/s (SYM_MP3_ABLATE); a wavefront issues one instruction per ~4.9 cycles, a SIMD's VALU port accepts one
+// run at 5.3-5.6 TB/s (a loads-and-stores-only build, profiles/r03*_mp3_ablate*; removed from this file in round 4); a wavefront issues one instruction per ~4.9 cycles, a SIMD's VALU port accepts one
 // plain f32 instruction per ~2.5 cycles, so two wavefronts saturate it and the third of a SIMD gets the leftovers (walks of 45
 // rounds finish after 212 / 231 / 315 us on every SIMD); under this kernel's VALU + LDS + HBM load the part clocks at 1.7 GHz
 // (2.3 GHz for the same loads and stores without the arithmetic).  The kernel is bound by VALU issue at a throttled clock.
@@ -177,12 +177,6 @@ __device__ __forceinline__ void fetch_granule(const float *granule, int hl, floa
 typedef float v2f __attribute__((vector_size(8)));  // (GCC / clang vector extension: the emulation build is g++)
 #ifndef SYM_MP3_PAIR_GROUP
 #define SYM_MP3_PAIR_GROUP 3
-#endif
-#ifndef SYM_MP3_CLOCK
-#define SYM_MP3_CLOCK 0
-#endif
-#ifndef SYM_MP3_ABLATE
-#define SYM_MP3_ABLATE 0
 #endif
 #ifndef SYM_MP3_SLOT_GROUP
 #define SYM_MP3_SLOT_GROUP 3
@@ -456,9 +450,6 @@ __global__ __launch_bounds__(64 * WGW) SYM_MP3_WAVES_ATTR(FUSED) void mp3_synth_
     const unsigned g_begin = seg * seg_len;
     const unsigned g_end = live ? min(g_begin + seg_len, granules_per_chain) : g_begin;
     const VMapX vm = vmapx(hl);
-#if SYM_MP3_CLOCK
-    const unsigned long long clk_t0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
-#endif
 
     // ---- incoming state.  oA[16 + r] = V_r[i], oB[16 + r] = V_r[32 + i] for the previous granules' time slots r < 0
     float overlap[18];
@@ -578,39 +569,6 @@ __global__ __launch_bounds__(64 * WGW) SYM_MP3_WAVES_ATTR(FUSED) void mp3_synth_
         const bool active = r < my_rounds;
         const bool need_hist = active && r >= hist_from;  // halo granule g_begin-2 only rebuilds overlap
         const bool emit = active && r >= emit_from;
-#if SYM_MP3_ABLATE
-        {   // measurement only (results wrong by construction): the loads and the stores of a round, nothing else.
-            // 1: 18 four-byte stores per lane (the product's store pattern); 2: five 16-byte stores
-            float4 cur[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) cur[q] = line[q];
-            const unsigned gn = r + 1 < my_rounds ? gi + 1u : 0u;
-            fetch_granule(xr + (size_t)gn * 576, (int)hlg, line);
-            sd_next = side_raw[gn];
-            unsigned tid3 = threadIdx.x;
-            asm volatile("" : "+v"(tid3));
-            float *sink_lane = sink + (size_t)((blockIdx.x * (unsigned)kWgWaves + (tid3 >> 6)) % (unsigned)kSinkSlots) * kSinkSlotFloats +
-                               ((tid3 >> 5) & 1u) * 576u;
-            float *base = emit ? pcm + (size_t)gi * 576 : sink_lane;
-            if (SYM_MP3_ABLATE == 1) {
-#pragma unroll
-                for (int b = 0; b < 18; ++b) {
-                    const float4 v = cur[b % 5];
-                    st_stream(base + 32 * b + hlg, (b / 5) == 0 ? v.x : ((b / 5) == 1 ? v.y : ((b / 5) == 2 ? v.z : v.w)));
-                }
-            } else {
-                float4 *dst = reinterpret_cast<float4 *>(base) + hlg;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) st_stream(dst + 32 * q, cur[q]);
-                if (hl < 16) st_stream(dst + 128, cur[4]);
-            }
-#pragma unroll
-            for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(line[q].x), "+v"(line[q].y), "+v"(line[q].z), "+v"(line[q].w));
-            asm volatile("" : "+v"(sd_next));
-            overlap[0] += cur[0].x;  // (keeps the epilogue's stores dependent on the walk)
-            continue;
-        }
-#endif
 
         do {  // (the round proper; skipped by the fused kernel's pre-round)
         if (FUSED && r < 0) break;
@@ -930,22 +888,6 @@ __global__ __launch_bounds__(64 * WGW) SYM_MP3_WAVES_ATTR(FUSED) void mp3_synth_
 #endif
     }
 
-#if SYM_MP3_CLOCK
-    if (live && hl == 0) {  // measurement build (corrupts the PCM): shader cycles, 100 MHz ticks and rounds of this walk
-        const unsigned long long dc = __builtin_readcyclecounter() - clk_t0, dw = wall_clock64() - clk_w0;
-        unsigned *o = reinterpret_cast<unsigned *>(pcm + ((size_t)chain * granules_per_chain + g_begin) * 576);
-        o[0] = 0x51a7c10cu;
-        o[1] = (unsigned)dc;
-        o[2] = (unsigned)dw;
-        o[3] = (unsigned)rounds;
-        o[4] = (unsigned)(clk_w0 & 0xffffffffu);
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        o[5] = hw;
-        o[6] = xcc;
-    }
-#endif
     // ---- outgoing state (only the segment that ends the chain).  The chain index and the addresses derived from it are
     // re-read here from LDS through an opaque copy of the thread index: kept live across the main loop they (and the
     // reciprocal of the division that produced them) cost seven VGPRs, which at the 168-register budget of three

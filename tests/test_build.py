@@ -76,8 +76,8 @@ def test_no_kernel_spills(asm):
 def test_aac_three_wave_variant_fits_its_register_budget():
     """SYMACCEL_TUNE_AAC_VARIANT=1 (six wavefronts per workgroup, lane twiddles in LDS, peeled halo) is sized for three
     wavefronts per SIMD: <= 168 VGPRs, no scratch, two 71.6 KiB workgroups per CU -- and contains no fused multiply-add."""
-    text = device_asm("aac.hip", ["-DSYM_AAC_VARIANT=1"])
-    (r,) = [v for k, v in kernel_resources(text).items() if "quad" not in k]  # (aac.hip also holds the workgroup walk, SYM_AAC_QUAD)
+    text = device_asm("aac.hip", ["-DSYM_AAC_VARIANT=1", "-DSYM_AAC_QUAD=0"])  # (the wavefront walk: csrc/experiments/aac_wave_walk.h)
+    (r,) = [v for k, v in kernel_resources(text).items() if "quad" not in k]  # (aac.hip also holds the workgroup walk, the product)
     assert r["ScratchSize"] == 0 and r["NumVgprs"] <= 168 and r["Occupancy"] == 3, r
     assert 2 * r["LDSByteSize"] <= 160 * 1024
     assert not F32_FUSED.search(text)
@@ -129,3 +129,17 @@ def test_build_flags_pin_the_contract():
     from symphonia_amd import build
     assert "-ffp-contract=off" in build.FLAGS and "-fno-fast-math" in build.FLAGS
     assert not any("flush-denormals" in f or f == "-ffast-math" for f in build.FLAGS)
+
+
+def test_the_product_translation_units_carry_no_measurement_only_code():
+    """VERDICT r3 hygiene: the ablation / cycle-counter / alternative-walk code of the AAC kernel lives in csrc/experiments/ and is
+    only compiled into TUNED builds (symphonia_amd/build/tuned/): the default build neither includes the file nor defines its knobs."""
+    from symphonia_amd import build
+    aac = (build.CSRC / "aac.hip").read_text()
+    assert "SYM_AAC_ABLATE" not in aac and "SYM_AAC_CLOCK" not in aac and "SYM_AAC_SINK" not in aac
+    assert '#if !SYM_AAC_QUAD\n#include "experiments/aac_wave_walk.h"' in aac
+    assert "__global__" in (build.CSRC / "experiments" / "aac_wave_walk.h").read_text()
+    assert all(p.parent == build.CSRC or p.name == "symaccel.h" for p in build.source_files())  # the product's sources: csrc/* only
+    text = device_asm("aac.hip", [])
+    kernels = [k for k in kernel_resources(text)]
+    assert len(kernels) == 1 and "aac_synth_quad_kernel" in kernels[0], kernels

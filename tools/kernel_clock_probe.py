@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Development tool: the shader clock and the cycles per round inside mp3_synth_kernel / aac_synth_kernel, from a library built with
+"""NOTE (round 4): the MP3 cycle-counter build (SYMACCEL_TUNE_MP3_CLOCK) was removed from csrc/mp3.hip with the other measurement-only
+branches; check out a round-3 tree to reproduce profiles/r03*_mp3_clock*.  The AAC form lives on in csrc/experiments/aac_wave_walk.h.
+
+Development tool: the shader clock and the cycles per round inside mp3_synth_kernel / aac_synth_kernel, from a library built with
 SYMACCEL_TUNE_MP3_CLOCK=1 (or SYMACCEL_TUNE_AAC_SINK=1 SYMACCEL_TUNE_AAC_CLOCK=1; argument: mp3 | aac) (each half-wave's walk leaves its cycle / 100 MHz tick counts in its first PCM granule).
   SYMACCEL_LIB=build_ab/mp3_clock.so python tools/kernel_clock_probe.py"""
 import sys
