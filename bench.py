@@ -603,6 +603,13 @@ def relaunch_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_version(torch):
+    try:
+        return list(torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def device_identity(torch, local_rank, emulate):
     """Something that differs between two physical GPUs (PCI bus id via the UUID when the runtime gives one)."""
     if emulate:
@@ -636,10 +643,17 @@ def main():
     ap.add_argument("--spinup-ms", type=int, default=60, help="milliseconds of back-to-back steps in front of the W warm-up steps (sustained clocks)")
     ap.add_argument("--no-spinup", action="store_true", help="measure W + K from an idle board only (the clock ramp)")
     ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the extra BASELINE config-4 (Vorbis shard) line")
+    ap.add_argument("--selftest-multi", type=int, nargs="?", const=4, default=0, metavar="WORLD",
+                    help="one GPU: exercise the N > 1 C path (RCCL binding at world size 1; scatter -> synthesis -> gather with WORLD "
+                         "in-process ranks over a mailbox transport), print its JSON and exit")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: run the control flow on CPU tensors through the CPU emulation build of the kernels "
                          "(tests/emu) with gloo; its numbers mean nothing")
     args = ap.parse_args()
+    if args.selftest_multi:
+        from symphonia_amd.selftest import multi_selftest
+        print(json.dumps({"selftest_multi": multi_selftest(args.selftest_multi)}), flush=True)
+        return
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -879,6 +893,7 @@ def main():
             "data": "synthetic",
             "config": dict(config, parallelism="chains sharded per GPU, no data-path collective", segment=args.segment or "auto"),
             "ranks": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
+                      "rccl_version": rccl_version(torch) if (world > 1 and not host_collectives) else None,
                       "devices": idents, "ms_per_step_per_rank": per_rank_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel,

@@ -8,6 +8,7 @@
 // mailbox of tests/test_multi_c.py.
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -33,8 +34,12 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_rccl_once;
-symaccel_transport g_transport{};  // all null: RCCL
-bool g_have_transport = false;
+// The caller-supplied transport: published with release / read with acquire, so that rank threads started after
+// symaccel_multi_set_transport see a complete table (setting it while an exchange is in flight is still the caller's bug).
+symaccel_transport g_transport_slots[2]{};
+std::atomic<const symaccel_transport *> g_transport_ptr{nullptr};  // null: RCCL
+#define g_have_transport (g_transport_ptr.load(std::memory_order_acquire) != nullptr)
+#define g_transport (*g_transport_ptr.load(std::memory_order_acquire))
 
 void load_rccl() {
     const char *names[] = {std::getenv("SYMACCEL_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -113,7 +118,8 @@ int exchange(symaccel_ctx *ctx, void *comm, int world, int rank, int root, void 
     if (n_streams == 0 || bytes_per_stream == 0) return SYMACCEL_OK;
     const Slice mine = slice_of(n_streams, world, rank);
     if ((mine.count && !d_mine) || (rank == root && !d_all)) return SYMACCEL_ERR_INVALID_ARG;
-    if (world > 1 && !comm) return SYMACCEL_ERR_INVALID_ARG;
+    // (`comm` is RCCL's communicator; a caller-supplied transport gets it passed through untouched and may not need one)
+    if (world > 1 && !comm && !g_have_transport) return SYMACCEL_ERR_INVALID_ARG;
     if (world > 1 && !have_backend()) {
         ctx->last_error = "librccl.so not found (set SYMACCEL_RCCL_LIB or install a transport)";
         return SYMACCEL_ERR_UNSUPPORTED;
@@ -164,13 +170,16 @@ int symaccel_shard_range(size_t n_streams, int world, int rank, size_t *first, s
 
 int symaccel_multi_set_transport(const symaccel_transport *t) {
     if (!t) {
-        g_have_transport = false;
-        g_transport = symaccel_transport{};
+        g_transport_ptr.store(nullptr, std::memory_order_release);
         return SYMACCEL_OK;
     }
     if (!t->send || !t->recv) return SYMACCEL_ERR_INVALID_ARG;
-    g_transport = *t;
-    g_have_transport = true;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    // write the slot that is NOT published, then publish it
+    symaccel_transport *slot = g_transport_ptr.load(std::memory_order_acquire) == &g_transport_slots[0] ? &g_transport_slots[1] : &g_transport_slots[0];
+    *slot = *t;
+    g_transport_ptr.store(slot, std::memory_order_release);
     return SYMACCEL_OK;
 }
 

@@ -143,3 +143,21 @@ def test_the_product_translation_units_carry_no_measurement_only_code():
     text = device_asm("aac.hip", [])
     kernels = [k for k in kernel_resources(text)]
     assert len(kernels) == 1 and "aac_synth_quad_kernel" in kernels[0], kernels
+
+
+def test_rccl_constants_the_c_glue_hard_codes():
+    """csrc/multi.cpp binds RCCL through dlsym without its header: the two facts it hard-codes are checked against rccl.h here --
+    ncclUniqueId is 128 opaque bytes passed BY VALUE to ncclCommInitRank (symaccel_unique_id), and ncclInt8 == 0 (the dtype of
+    every ncclSend / ncclRecv: counts are bytes)."""
+    hdr = Path("/opt/rocm/include/rccl/rccl.h")
+    if not hdr.exists():
+        pytest.skip("no rccl.h in this image")
+    text = hdr.read_text()
+    assert re.search(r"#define\s+NCCL_UNIQUE_ID_BYTES\s+128\b", text)
+    assert re.search(r"typedef struct \{ char internal\[NCCL_UNIQUE_ID_BYTES\];", text)
+    assert re.search(r"ncclInt8\s*=\s*0\b", text)
+    assert re.search(r"ncclCommInitRank\(ncclComm_t\*\s*comm,\s*int nranks,\s*ncclUniqueId commId,\s*int rank\)", text)
+    sym = (ROOT / "include" / "symaccel.h").read_text()
+    assert re.search(r"typedef struct symaccel_unique_id \{\s*char internal\[128\];", sym)
+    multi = (CSRC / "multi.cpp").read_text()
+    assert "int (*CommInitRank)(void **comm, int nranks, symaccel_unique_id id, int rank)" in multi and "rccl()->Send(buf, bytes, 0, peer" in multi

@@ -155,3 +155,14 @@ def test_rccl_path_at_world_size_one():
     assert torch.equal(full, mine) and torch.equal(full, back)
     assert d.symaccel_comm_destroy(comm) == 0
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_multi_selftest_on_one_gpu(world):
+    """symphonia_amd/selftest.py (also `python bench.py --selftest-multi WORLD`): the RCCL binding at world size 1 and the scatter ->
+    synthesis -> gather leg with `world` in-process ranks (one context + one HIP stream each on cuda:0) over a caller-supplied
+    transport on DEVICE buffers; the gathered PCM equals the PCM of the whole batch decoded in one call."""
+    from symphonia_amd.selftest import multi_selftest
+    r = multi_selftest(world)
+    assert r["rccl_world1"]["ok"] and r["in_process_ranks"]["ok"] and len(r["in_process_ranks"]["per_rank"]) == world
