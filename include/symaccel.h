@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SYMACCEL_ABI_VERSION 3 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe */
+#define SYMACCEL_ABI_VERSION 4 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device */
 
 typedef enum symaccel_status {
     SYMACCEL_OK = 0,
