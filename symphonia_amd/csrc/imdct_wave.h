@@ -262,6 +262,15 @@ __device__ __forceinline__ void fft512_wave(c32 (&z)[8], int lane, c32 *lds, con
 // In:  z[s] = x_T[u + (P / 8) s] for lane (T, u).
 // Out: logp <= 6: z[j] = X at position 64 (lane >> 3) + 8 j + (lane & 7);   logp >= 7: z[B] = X at position 64 B + lane.
 //      Position p belongs to transform p >> logp, bin p & (P - 1).  The work array is free again on return (after a wave_sync).
+// T1M, the pass-1 -> pass-2 exchange layout of fft_wave_multi: element (B, j, k) at B + fj(j) + 36 k with
+// fj(j) = 18 j0 + 100 j1 + 344 j2 (j's bits).  T1 is conflict-free only for the lane order of the 512-point transform; with P < 512
+// the sixteen lanes of a ds_write_b64 group hold (2 B) x (8 j), (4 B) x (4 j of one parity) or (8 B) x (j, j + 4), and all three
+// need fj(j) = 2 j (mod 16).  The weights are the smallest that keep the layout injective (largest index 7 + 462 + 252 = 721);
+// tools/vorbis_lds_model.py: 32 + 16 LDS cycles per exchange for every P (T1: 128 + 16 for P <= 128, 64 + 16 for P = 256).
+__device__ __forceinline__ int lds_t1m_lane_w(int B, int j) { return B + 18 * (j & 1) + 100 * ((j >> 1) & 1) + 344 * (j >> 2); }
+__device__ __forceinline__ constexpr int lds_t1m_inst_r(int j) { return 18 * (j & 1) + 100 * ((j >> 1) & 1) + 344 * (j >> 2); }
+static_assert(2 * (7 + 462 + 36 * 7 + 1) <= kWaveLds, "T1M must fit the per-wave LDS");
+
 template <class LT>
 __device__ __forceinline__ void fft_wave_multi(c32 (&z)[8], int lane, c32 *lds, const LT &lt, int logp) {
     bitrev8(z);
@@ -270,7 +279,7 @@ __device__ __forceinline__ void fft_wave_multi(c32 (&z)[8], int lane, c32 *lds, 
         const int gbits = logp - 3;  // 1 .. 6
         const int T = lane >> gbits, u = lane & ((1 << gbits) - 1);
         const int g = (T << gbits) + (int)rev_bits((unsigned)u, gbits);
-        c32 *w = lds + lds_t1_lane_w(g >> 3, g & 7);
+        c32 *w = lds + lds_t1m_lane_w(g >> 3, g & 7);
 #pragma unroll
         for (int r = 0; r < 8; ++r) w[lds_t1_inst_w(r)] = z[r];
     }
@@ -279,7 +288,7 @@ __device__ __forceinline__ void fft_wave_multi(c32 (&z)[8], int lane, c32 *lds, 
     {
         const c32 *r = lds + lds_t1_lane_r(B2, k2);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = r[lds_t1_inst_r(j)];
+        for (int j = 0; j < 8; ++j) z[j] = r[lds_t1m_inst_r(j)];
     }
     {   // stages 4-6, as many as the size has (wave-uniform branches)
         const c32 w16 = lt.W16();
@@ -385,6 +394,48 @@ __device__ __forceinline__ void multi_post_twiddle(const c32 (&z)[8], int lane, 
             vec1[ri] = val.x;
             vec2[fi] = val.y;
             vec3[ri] = val.y;
+        }
+    }
+}
+// Padding of the work area for transforms of up to 64 points (blocks of up to 256 samples), in floats per transform (input: 2 P
+// lines) and per block (output: 4 P samples): 4 for P = 16, 8 for P = 32 and 64 (multiples of four keep the 16-byte accesses
+// aligned).  tools/vorbis_lds_model.py: pre-twiddle reads 384 -> 48 LDS cycles (P = 16), output scatter 256 -> 128.
+__device__ __forceinline__ constexpr int multi_pad(int logp) { return logp == 4 ? 4 : (logp <= 6 ? 8 : 0); }
+static_assert(32 * (64 + multi_pad(4)) <= kWaveLds && 16 * (128 + multi_pad(5)) <= kWaveLds && 8 * (256 + multi_pad(6)) <= kWaveLds,
+              "the padded outputs of a group must fit the per-wave LDS");
+
+// The same scatter with the size known at compile time.  Position p = (part that depends on q) + (part that depends on the lane),
+// and the two never carry into each other: for P >= 128, p = 64 q + lane; for P <= 64, p = 8 q + (64 (lane >> 3) + (lane & 7)).
+// So T = Tq + Tl and k = kq + kl with Tq, kq compile-time, and `k < n4` is decided by kq alone: every store below is one
+// ds_write_b32 from one of two per-lane base addresses (index rising / falling with the lane) plus an immediate offset.
+// OPAD: floats between the blocks' outputs (block T at pcm + T (4 P + OPAD)): for P <= 64 the lanes of a store belong to several
+// blocks, and with a stride of 4 P floats they all meet in the same banks (multi_pad below).
+template <int LOGP, int OPAD = 0>
+__device__ __forceinline__ void multi_post_twiddle_ct(const c32 (&z)[8], int lane, const c32 *tw, float *pcm) {
+    constexpr int P = 1 << LOGP, n4 = P >> 1, g = LOGP <= 6 ? 8 : 64, ST = 4 * P + OPAD;
+    const int kl = LOGP <= 6 ? (lane & 7) : lane;
+    const int Tl = LOGP <= 6 ? ((lane >> 3) << (6 - LOGP)) : 0;
+    float *up = pcm + Tl * ST + 2 * kl;                  // index 2 kl + c
+    float *down = pcm + Tl * ST + (2 * g - 1 - 2 * kl);  // index c - 2 kl, rebased so that c - (2 g - 1) >= 0 below
+    const c32 *twl = tw + kl;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int pq = LOGP <= 6 ? 8 * q : 64 * q;
+        const int kq = pq & (P - 1), Tq = pq >> LOGP;
+        const c32 val = post_twiddle(z[q], twl[kq]);
+        const int base = Tq * ST;
+        if (kq < n4) {  // vec0[ri] = -y, vec1[fi] = y, vec2[ri] = x, vec3[fi] = x with fi = 2 k, ri = P - 1 - 2 k
+            const int fi = 2 * kq, ri = P - 1 - 2 * kq - (2 * g - 1);
+            down[base + ri] = -val.y;
+            up[base + P + fi] = val.y;
+            down[base + 2 * P + ri] = val.x;
+            up[base + 3 * P + fi] = val.x;
+        } else {        // vec0[fi] = -x, vec1[ri] = x, vec2[fi] = y, vec3[ri] = y with fi = 2 (k - n4)
+            const int fi = 2 * (kq - n4), ri = P - 1 - 2 * (kq - n4) - (2 * g - 1);
+            up[base + fi] = -val.x;
+            down[base + P + ri] = val.x;
+            up[base + 2 * P + fi] = val.y;
+            down[base + 3 * P + ri] = val.y;
         }
     }
 }

@@ -218,12 +218,11 @@ int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_lon
 int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                      const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
                      const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
-                     size_t pcm_stride, const uint32_t *d_offs, size_t n_chains, unsigned nb, unsigned seg);  // vorbis_wg.hip
+                     size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg);  // vorbis_wg.hip
 int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                         const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride,
                         const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in,
-                        float *d_overlap_out, float *d_pcm, size_t pcm_stride, const uint32_t *d_offs, size_t n_chains, unsigned nb,
-                        unsigned seg);
+                        float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg);
 int launch_vorbis_coupling(symaccel_ctx *ctx, float *d_mag, float *d_ang, size_t n);
 int launch_vorbis_dot(symaccel_ctx *ctx, float *d_floor, const float *d_residue, size_t total);
 int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d_planar, int n_ch, size_t n2,

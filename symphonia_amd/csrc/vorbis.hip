@@ -645,20 +645,19 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
                                   d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
                                   pcm_stride, n_chains, nb, seg);
     }
-    // generic path: a scan kernel turns the flag sequence into packed offsets (room for them comes from the ABI wrapper:
-    // n_chains * (blocks_per_chain + 1) * 2 words)
+    // (both derive the packed offsets from the flags themselves, vorbis_offsets.h)
+    if (wg_path)
+        return launch_vorbis_wg(ctx, bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra, d_residue,
+                                spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, nb, seg);
+    if (wave2_path)
+        return launch_vorbis_wave2(ctx, bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra, d_residue,
+                                   spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, nb, seg);
+    // the LDS-staged generic kernel (unaligned strides / pointers): a scan kernel turns the flag sequence into packed offsets (room for
+    // them comes from the ABI wrapper: n_chains * (blocks_per_chain + 1) * 2 words)
     uint32_t *offs = (uint32_t *)(((uintptr_t)d_offsets + 255) & ~(uintptr_t)255);
     hipLaunchKernelGGL(vorbis_offsets_kernel, dim3((unsigned)n_chains), dim3(256), 0, ctx->stream, d_block_flag,
                        d_prev_in, offs, nb, 1 << bs0_exp, 1 << bs1_exp);
     SYM_GPU(ctx, hipGetLastError());
-    if (wg_path)
-        return launch_vorbis_wg(ctx, bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra, d_residue,
-                                spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride,
-                                (const uint32_t *)offs, n_chains, nb, seg);
-    if (wave2_path)
-        return launch_vorbis_wave2(ctx, bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra, d_residue,
-                                   spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride,
-                                   (const uint32_t *)offs, n_chains, nb, seg);
     if (bs1_exp <= 11) {
         hipLaunchKernelGGL(vorbis_synth_kernel<2048>, dim3((unsigned)grid), dim3(vorbis_threads<2048>()), 0, ctx->stream, ctx->dev,
                            bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,

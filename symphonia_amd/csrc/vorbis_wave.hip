@@ -17,6 +17,7 @@
 // HBM traffic per channel-block: 4 * (n/2) B in + 4 * (prev_n + n)/4 B out (+ one halo block per segment).
 #define SYM_PACKED_C32_DEFAULT 1  // complex arithmetic as v_pk_*_f32 on register pairs: +7 % here (dsp_device.h)
 #include "imdct_wave.h"
+#include "vorbis_offsets.h"
 
 namespace symaccel {
 
@@ -46,60 +47,6 @@ __device__ __forceinline__ void apply_residue(float2 (&line)[8], const float2 (&
             line[s].y *= res[s].y;
         }
     }
-}
-
-// Number of long blocks among the first `b` blocks of a chain (flags: one byte per block, non-zero = long).
-// 1024 flags per step: each lane takes an aligned group of 16 (flags outside [0, b) are masked off).
-__device__ __forceinline__ unsigned count_long_before(const uint8_t *f, long b, int lane) {
-    unsigned cnt = 0;  // per-lane partial count, reduced once at the end
-    const long mis = (long)(reinterpret_cast<uintptr_t>(f) & 15u);  // f - mis is 16-byte aligned
-    const uint4 *base = reinterpret_cast<const uint4 *>(f - mis);
-    for (long i0 = -mis; i0 < b; i0 += 1024) {
-        const long i = i0 + 16 * lane;  // index of this lane's first flag
-        if (i < b && i + 16 > 0) {
-            // One aligned 16-byte load per lane.  In the ragged first / last group the load also covers bytes outside
-            // [0, b): they share an aligned 16-byte unit with a byte that is inside, so the access cannot fault, and
-            // they are masked off below (a byte-wise tail would be 16 dependent loads, each waited for in turn).
-            const uint4 v = base[(i + mis) >> 4];
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const bool inside = i + q >= 0 && i + q < b;
-                cnt += (inside && ((w[q >> 2] >> (8 * (q & 3))) & 255u)) ? 1u : 0u;
-            }
-        }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) cnt += (unsigned)__shfl_xor((int)cnt, m);
-    return cnt;
-}
-
-// Index of the last long block among the first `b` blocks of a chain, or -1: the same 1024-flags-per-step scan, from
-// the top (the answer can be thousands of blocks back; a flag-by-flag walk would be that many dependent loads).
-__device__ __forceinline__ long last_long_before(const uint8_t *f, long b, int lane) {
-    const long mis = (long)(reinterpret_cast<uintptr_t>(f) & 15u);
-    const uint4 *base = reinterpret_cast<const uint4 *>(f - mis);
-    for (long i0 = ((b - 1 + mis) / 1024) * 1024 - mis; i0 >= -mis; i0 -= 1024) {
-        const long i = i0 + 16 * lane;
-        long best = -1;
-        if (i < b && i + 16 > 0) {
-            const uint4 v = base[(i + mis) >> 4];
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const bool inside = i + q >= 0 && i + q < b;
-                if (inside && ((w[q >> 2] >> (8 * (q & 3))) & 255u)) best = i + q;  // ascending q: the last hit stays
-            }
-        }
-        int hi = (int)best;  // < 2^31 blocks per chain (launch_vorbis_wave)
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const int o = __shfl_xor(hi, m);
-            hi = o > hi ? o : hi;
-        }
-        if (hi >= 0) return hi;
-    }
-    return -1;
 }
 
 // Build variant (tuning knob SYM_VORBIS_WAVES, see build.py): 2 = four wavefronts per workgroup, lane twiddles in 31 VGPRs,

@@ -10,9 +10,10 @@
 // block, natural order) lands in the wavefront's LDS work area; `overlap` (dsp.rs:125) is a per-wavefront LDS array with
 // exactly the reference's contents, so the three window cases of dsp.rs:85-122 are loops over LDS with 16-byte accesses and
 // the stale upper part a short block leaves behind needs no special case.  Blocks after the first of a group lap with their
-// predecessor inside the work area.  Packed offsets: from the scan kernel at the segment start, running sums after that.
+// predecessor inside the work area.  Packed offsets: counted from the flags at the segment start (vorbis_offsets.h), running sums after that.
 // HBM traffic per channel-block: 4 * (n / 2) B in + 4 * (prev_n + n) / 4 B out (+ one halo block per segment).
 #include "imdct_wave.h"
+#include "vorbis_offsets.h"
 
 namespace symaccel {
 
@@ -215,6 +216,54 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
     (void)bs;
 }
 
+// One group's transform with the block size known at compile time: the lines (natural order, in the work area) -> pre-twiddle ->
+// 512 / P transforms of P = 2^LOGP points -> post-twiddle -> the blocks' 4 P output samples each, natural order, in the work area.
+// (With LOGP a constant every LDS address is a per-lane base plus an immediate and the stage count of the FFT is fixed: ~250 VALU
+// instructions per group less than the run-time form -- the kernel is bound by VALU issue, profiles/r04i_vorbis_pairs.txt.)
+template <int LOGP, class LT>
+__device__ __forceinline__ void vw2_transform(int lane, float *ldsf, const c32 *tw, const LT &lt) {
+    constexpr int P = 1 << LOGP, gbits = LOGP - 3, G = 1 << gbits, PAD = multi_pad(LOGP);
+    c32 z[8];
+    {
+        const int T = lane >> gbits, u = lane & (G - 1);
+        const float *sT = ldsf + T * (2 * P + PAD);
+        const float *fwd = sT + 2 * u, *bwd = sT + (2 * P - 1) - 2 * u;
+        const c32 *twu = tw + u;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float2 pr = *reinterpret_cast<const float2 *>(fwd + 2 * (s << gbits));
+            z[s] = pre_twiddle(pr.x, bwd[-2 * (s << gbits)], twu[s << gbits]);
+        }
+    }
+    wave_sync();
+    fft_wave_multi(z, lane, reinterpret_cast<c32 *>(ldsf), lt, LOGP);
+    multi_post_twiddle_ct<LOGP, PAD>(z, lane, tw, ldsf);  // block i of the group: ldsf[i * (bs + PAD) ..)
+    wave_sync();
+}
+
+// (the run-time form: the big-block instantiations, which hold a 1024- or 2048-point transform in registers as well, have no room
+// for six copies of the group routine)
+template <class LT>
+__device__ __forceinline__ void vw2_transform_rt(int lane, float *ldsf, const c32 *tw, const LT &lt, int logp) {
+    const int P = 1 << logp;
+    c32 z[8];
+    {
+        const int gbits = logp - 3, G = 1 << gbits;
+        const int T = lane >> gbits, u = lane & (G - 1);
+        const float *sT = ldsf + ((size_t)T << (logp + 1));
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int i = u + (s << gbits);
+            const float2 pr = *reinterpret_cast<const float2 *>(sT + 2 * i);
+            z[s] = pre_twiddle(pr.x, sT[2 * P - 1 - 2 * i], tw[i]);
+        }
+    }
+    wave_sync();
+    fft_wave_multi(z, lane, reinterpret_cast<c32 *>(ldsf), lt, logp);
+    multi_post_twiddle(z, lane, logp, tw, ldsf);
+    wave_sync();
+}
+
 // MAXE1: the largest long-block exponent the instantiation serves.  Up to 1024-sample long blocks the tables and the overlap
 // arrays are half the size and three workgroups fit a CU (52 KiB of LDS each, <= 168 VGPRs): the kernel is bound by the latency
 // of a group's dependent steps, and a third wavefront per SIMD is worth more than anything else here.  (The fused variant carries
@@ -228,8 +277,7 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
     const float *__restrict__ residue, size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
     int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in, float *__restrict__ overlap_out,
-    float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs, unsigned nb, unsigned seg_len,
-    unsigned segs_per_chain, unsigned n_items) {
+    float *__restrict__ pcm, size_t pcm_stride, unsigned nb, unsigned seg_len, unsigned segs_per_chain, unsigned n_items) {
     // shared tables: Imdct twiddles and left window halves of both block sizes (bs / 2 floats each)
     constexpr bool kBig = MAXE1 > 11;  // long blocks of 4096 / 8192 samples: tables stay in global memory, see vorbis_big_block
     constexpr int kWaves = vw2_waves<MAXE1>();
@@ -274,7 +322,6 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
     const unsigned chain = item / segs_per_chain, seg = item % segs_per_chain;
     const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
     const uint8_t *f = flags + (size_t)chain * nb;
-    const uint32_t *os = offs + (size_t)chain * 2 * (nb + 1), *op = os + (nb + 1);
     const float *sp = spectra + (size_t)chain * spec_stride;
     const float *rp = FUSED ? residue + (size_t)chain * spec_stride : nullptr;
     float *out = pcm + (size_t)chain * pcm_stride;
@@ -335,7 +382,8 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
     int glen = group_at(b, flag);
     // flag of the block before b (lib.rs:298: the first block of a stream pairs with itself)
     int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);
-    uint32_t os_cur = glen > 0 ? os[b] : 0u, op_cur = glen > 0 ? op[b] : 0u;
+    const VorbisPackedAt at0 = vorbis_packed_at(f, b, pf0, bs0, bs1, lane);
+    uint32_t os_cur = at0.spec, op_cur = at0.pcm;
     float4 v[4], r[4];
     auto fetch = [&](uint32_t off, int fl, int n_blocks) {
         const size_t valid = (size_t)n_blocks << ((fl ? e1 : e0) - 1);
@@ -374,7 +422,7 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
             b = bl;
             glen = 1;
             flag = pflag = 1;
-            os_cur = os[bl];
+            os_cur = vorbis_sizes_before(f, bl, bs0, bs1, lane) / 2u;
             if constexpr (!kBig) fetch(os_cur, 1, 1);
         }
         const int e = flag ? e1 : e0, bs = 1 << e, logp = e - 2, P = 1 << logp;
@@ -409,6 +457,7 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
         if constexpr (BIG0 == 0) {
 
         // ---- the group's lines -> LDS (natural order), multiplied by the residue on the way (lib.rs:289-291: *f *= r)
+        const int pad = kBig ? 0 : multi_pad(logp), ostride = bs + pad;  // (the run-time form of the big-block instantiations is unpadded)
         if constexpr (kBig) fetch(os_cur, flag, glen);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -419,26 +468,23 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
                 x.z *= r[q].z;
                 x.w *= r[q].w;
             }
-            reinterpret_cast<float4 *>(ldsf)[lane + 64 * q] = x;
+            // (transforms of up to 64 points: multi_pad(logp) floats between the transforms' lines, see imdct_wave.h)
+            const int e4 = 4 * (lane + 64 * q);
+            *reinterpret_cast<float4 *>(ldsf + e4 + pad * (e4 >> (logp + 1))) = x;
         }
         wave_sync();
         if (!kBig && glen_next > 0) fetch(os_next, flag_next, glen_next);  // the next group travels while this one is transformed
-        c32 z[8];
-        {
-            const int gbits = logp - 3, G = 1 << gbits;
-            const int T = lane >> gbits, u = lane & (G - 1);
-            const float *sT = ldsf + ((size_t)T << (logp + 1));
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int i = u + (s << gbits);
-                const float2 pr = *reinterpret_cast<const float2 *>(sT + 2 * i);
-                z[s] = pre_twiddle(pr.x, sT[2 * P - 1 - 2 * i], tw[i]);
-            }
+        if constexpr (kBig) vw2_transform_rt(lane, ldsf, tw, lt, logp);
+        else switch (logp) {  // (wave-uniform; an instantiation holds the sizes it can meet)
+            case 4: vw2_transform<4>(lane, ldsf, tw, lt); break;
+            case 5: vw2_transform<5>(lane, ldsf, tw, lt); break;
+            case 6: vw2_transform<6>(lane, ldsf, tw, lt); break;
+            case 7: vw2_transform<7>(lane, ldsf, tw, lt); break;
+            case 8: vw2_transform<8>(lane, ldsf, tw, lt); break;
+            default:
+                if constexpr (MAXE1 >= 11) vw2_transform<9>(lane, ldsf, tw, lt);
+                break;
         }
-        wave_sync();
-        fft_wave_multi(z, lane, lds, lt, logp);
-        multi_post_twiddle(z, lane, logp, tw, ldsf);  // block i of the group: ldsf[i * bs .. (i + 1) * bs)
-        wave_sync();
 
         // ---- the group's first block against `overlap` (dsp.rs:85-122)
         {
@@ -463,8 +509,8 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
             const float *win = flag ? t_wl : t_ws;
             // (all of them are emitted: only a halo block precedes b_begin, and a halo block is its group's first)
             for (int c = lane; c < (glen - 1) * per_block; c += 64) {
-                const int i = 1 + c / per_block, k = 4 * (c % per_block);
-                const float *ov = ldsf + (size_t)(i - 1) * bs + half, *y = ldsf + (size_t)i * bs;
+                const int i = 1 + (c >> (e - 3)), k = 4 * (c & (per_block - 1));  // (per_block = 1 << (e - 3): no integer division)
+                const float *ov = ldsf + (i - 1) * ostride + half, *y = ldsf + i * ostride;
                 const float4 a = *reinterpret_cast<const float4 *>(ov + k), bq = *reinterpret_cast<const float4 *>(y + k);
                 const float4 wf = *reinterpret_cast<const float4 *>(win + k);
                 const float4 wr = *reinterpret_cast<const float4 *>(win + half - 4 - k);
@@ -475,7 +521,7 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
         wave_sync();  // `overlap` has been read
         // overlap[..bs / 2) = right half of the run's last block (dsp.rs:125); what lies above stays
         {
-            const float *right = ldsf + (size_t)(glen - 1) * bs + (bs >> 1);
+            const float *right = ldsf + (glen - 1) * ostride + (bs >> 1);
             for (int k = keep_below + 4 * lane; k < bs / 2; k += 256) *reinterpret_cast<float4 *>(ovl + k) = *reinterpret_cast<const float4 *>(right + k);
         }
         wave_sync();  // the work area is overwritten by the next group
@@ -501,8 +547,7 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
 int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                         const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride,
                         const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in,
-                        float *d_overlap_out, float *d_pcm, size_t pcm_stride, const uint32_t *d_offs, size_t n_chains, unsigned nb,
-                        unsigned seg) {
+                        float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg) {
     const size_t segs = (nb + seg - 1) / seg;
     const size_t items = n_chains * segs;
     const size_t kWaves = bs1_exp > 11 ? 2 : 4;
@@ -511,11 +556,11 @@ int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *
 #define SYM_VW2_LAUNCH3(FUSED, MAXE1, BIG0)                                                                                                  \
     hipLaunchKernelGGL((vorbis_synth_wave2_kernel<FUSED, MAXE1, BIG0>), dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, bs0_exp, \
                        bs1_exp, tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, \
-                       d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs, (unsigned)items)
+                       d_overlap_in, d_overlap_out, d_pcm, pcm_stride, nb, seg, (unsigned)segs, (unsigned)items)
 #define SYM_VW2_LAUNCH(FUSED, MAXE1)                                                                                                        \
     hipLaunchKernelGGL((vorbis_synth_wave2_kernel<FUSED, MAXE1>), dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, bs0_exp, \
                        bs1_exp, tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, \
-                       d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs, (unsigned)items)
+                       d_overlap_in, d_overlap_out, d_pcm, pcm_stride, nb, seg, (unsigned)segs, (unsigned)items)
     if (bs1_exp <= 10) {
         if (d_residue) SYM_VW2_LAUNCH(true, 10); else SYM_VW2_LAUNCH(false, 10);
     } else if (bs1_exp == 11) {

@@ -16,6 +16,7 @@
 // 8192-sample blocks -- 2.2 / 1.3 TB/s.
 // HBM traffic per channel-block: 4 * (n / 2) B in + 4 * (prev_n + n) / 4 B out (+ one halo block per segment).
 #include "imdct_wave.h"
+#include "vorbis_offsets.h"
 
 namespace symaccel {
 
@@ -231,8 +232,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
     const float *__restrict__ residue, size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
     int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in, float *__restrict__ overlap_out,
-    float *__restrict__ pcm, size_t pcm_stride, const uint32_t *__restrict__ offs, unsigned nb, unsigned seg_len,
-    unsigned segs_per_chain) {
+    float *__restrict__ pcm, size_t pcm_stride, unsigned nb, unsigned seg_len, unsigned segs_per_chain) {
     constexpr int S1 = (1 << MAXE1) / 2048;  // 2 / 4
     constexpr int PL = 512 * S1;
     __shared__ __attribute__((aligned(16))) c32 area[PL + PL / 2];  // staging (P + P / S slots, S >= 2) -> exchange -> left half
@@ -248,7 +248,6 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     const unsigned chain = item / segs_per_chain, seg = item % segs_per_chain;
     const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
     const uint8_t *f = flags + (size_t)chain * nb;
-    const uint32_t *os = offs + (size_t)chain * 2 * (nb + 1), *op = os + (nb + 1);
     const float *sp = spectra + (size_t)chain * spec_stride;
     const float *rp = FUSED ? residue + (size_t)chain * spec_stride : nullptr;
     float *out = pcm + (size_t)chain * pcm_stride;
@@ -298,7 +297,9 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     int glen = group_at(b, flag);
     // flag of the block before b (lib.rs:298: the first block of a stream pairs with itself)
     int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);
-    uint32_t os_cur = glen > 0 ? os[b] : 0u, op_cur = glen > 0 ? op[b] : 0u;
+    // packed offsets of the segment's first block: counted from the flags by every wavefront (vorbis_offsets.h), running sums after that
+    const VorbisPackedAt at0 = vorbis_packed_at(f, b, pf0, bs0, bs1, lane);
+    uint32_t os_cur = at0.spec, op_cur = at0.pcm;
 
     // The walk, then -- at a chain's end, if no long block refreshed overlap[bs0/2 .. bs1/2) in this segment -- ONE more trip through
     // the same loop body for the most recent long block in front of the segment (`rebuild`: nothing is emitted, only the upper part
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
             b = bl;
             glen = 1;
             flag = pflag = 1;
-            os_cur = os[bl];
+            os_cur = vorbis_sizes_before(f, bl, bs0, bs1, lane) / 2u;
         }
         const int e = flag ? e1 : e0, bs = 1 << e, logp = e - 2, P = 1 << logp;
         long nb_next = b + glen;
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
 int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                      const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
                      const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
-                     size_t pcm_stride, const uint32_t *d_offs, size_t n_chains, unsigned nb, unsigned seg) {
+                     size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg) {
     // (the 4096 / 8192 pair would need both cooperative block routines in one kernel: 256 VGPRs and scratch -- it stays on
     // vorbis_synth_wave2_kernel, launch_vorbis in vorbis.hip)
     if ((bs1_exp != 12 && bs1_exp != 13) || (bs0_exp == 12 && bs1_exp == 13)) return SYMACCEL_ERR_INVALID_ARG;
@@ -499,7 +500,7 @@ int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_
 #define SYM_VWG_LAUNCH(FUSED, MAXE1, BIG0)                                                                                                      \
     hipLaunchKernelGGL((vorbis_synth_wg_kernel<FUSED, MAXE1, BIG0>), dim3((unsigned)grid), dim3(64 * kWgWaves), 0, ctx->stream, ctx->dev, bs0_exp, \
                        bs1_exp, tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, \
-                       d_overlap_in, d_overlap_out, d_pcm, pcm_stride, d_offs, nb, seg, (unsigned)segs)
+                       d_overlap_in, d_overlap_out, d_pcm, pcm_stride, nb, seg, (unsigned)segs)
     const int big0 = bs0_exp <= 11 ? 0 : (bs0_exp == 12 ? 2 : 4);
 #if SYM_VORBIS_WG == 2
 #define SYM_VWG_12(FUSED) do { if (big0 == 0) SYM_VWG_LAUNCH(FUSED, 12, 0); else SYM_VWG_LAUNCH(FUSED, 12, 2); } while (0)

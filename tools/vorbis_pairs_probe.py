@@ -29,13 +29,15 @@ def run(e0, e1, p_ll=0.9, p_ss=0.7):
     ss, ps = int(so[:, -1].max()), int(po[:, -1].max())
     spectra = torch.randn((nch, ss), device="cuda") * 0.1
     dfl = torch.from_numpy(flags).cuda()
+    # ping-pong state like bench.py's Vorbis step (symaccel_vorbis_synth_pp_device: one launch per step, no state copy in front);
+    # every step starts from the same state (prev = -1, empty overlap)
     prev = torch.full((nch,), -1, dtype=torch.int32, device="cuda")
     ov = torch.zeros((nch, (1 << e1) // 2), device="cuda")
+    prev_out, ov_out = torch.empty_like(prev), torch.empty_like(ov)
     pcm = torch.zeros((nch, ps), device="cuda")
 
     def step():
-        prev.fill_(-1)
-        v.synth(spectra, dfl, prev, ov, ps, pcm)
+        v.synth(spectra, dfl, prev, ov, ps, pcm, state_out=(prev_out, ov_out))
     import time
     t0 = time.perf_counter()  # sustained clocks: ~25 ms of load take the board out of its idle state (profiles/r03w_step_timeline.txt)
     while time.perf_counter() - t0 < 0.06:
@@ -54,5 +56,8 @@ def run(e0, e1, p_ll=0.9, p_ss=0.7):
         1 << e0, 1 << e1, nb, flags.mean(), t, byts / t / 1e9, byts / t / 1e9 / 8 * 100))
 
 
-for e0, e1 in ((8, 11), (7, 10), (9, 12), (6, 9), (8, 10), (10, 13), (11, 11)):
+PAIRS = ((8, 11), (7, 10), (9, 12), (6, 9), (8, 10), (10, 13), (11, 11))
+if len(sys.argv) > 1:  # python tools/vorbis_pairs_probe.py 7,10 9,12
+    PAIRS = tuple(tuple(int(x) for x in a.split(",")) for a in sys.argv[1:])
+for e0, e1 in PAIRS:
     run(e0, e1)
