@@ -70,13 +70,17 @@ __device__ __forceinline__ long last_long_before(const uint8_t *f, long b, int l
 struct VorbisPackedAt {
     uint32_t spec, pcm;
 };
+// (out of line for the kernels that have no registers to spare -- it runs once per segment, in front of everything else)
+__device__ __attribute__((noinline)) unsigned count_long_before_call(const uint8_t *f, long b, int lane) { return count_long_before(f, b, lane); }
+template <bool INLINE = true>
 __device__ __forceinline__ uint32_t vorbis_sizes_before(const uint8_t *f, long b, int bs0, int bs1, int lane) {
-    return (uint32_t)bs0 * (uint32_t)b + (uint32_t)(bs1 - bs0) * count_long_before(f, b, lane);
+    return (uint32_t)bs0 * (uint32_t)b + (uint32_t)(bs1 - bs0) * (INLINE ? count_long_before(f, b, lane) : count_long_before_call(f, b, lane));
 }
+template <bool INLINE = true>
 __device__ __forceinline__ VorbisPackedAt vorbis_packed_at(const uint8_t *f, long b, int pf0, int bs0, int bs1, int lane) {
     VorbisPackedAt at = {0u, 0u};
     if (b > 0) {
-        const uint32_t s_b = vorbis_sizes_before(f, b, bs0, bs1, lane);
+        const uint32_t s_b = vorbis_sizes_before<INLINE>(f, b, bs0, bs1, lane);
         const uint32_t n_prev = (uint32_t)(f[b - 1] ? bs1 : bs0);
         const uint32_t n_m1 = (uint32_t)(pf0 < 0 ? (f[0] ? bs1 : bs0) : (pf0 ? bs1 : bs0));
         at.spec = s_b / 2u;

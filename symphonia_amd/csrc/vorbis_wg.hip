@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     // flag of the block before b (lib.rs:298: the first block of a stream pairs with itself)
     int pflag = b == 0 ? (pf0 < 0 ? flag : (pf0 ? 1 : 0)) : (f[b - 1] ? 1 : 0);
     // packed offsets of the segment's first block: counted from the flags by every wavefront (vorbis_offsets.h), running sums after that
-    const VorbisPackedAt at0 = vorbis_packed_at(f, b, pf0, bs0, bs1, lane);
+    const VorbisPackedAt at0 = vorbis_packed_at<false>(f, b, pf0, bs0, bs1, lane);
     uint32_t os_cur = at0.spec, op_cur = at0.pcm;
 
     // The walk, then -- at a chain's end, if no long block refreshed overlap[bs0/2 .. bs1/2) in this segment -- ONE more trip through
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
             b = bl;
             glen = 1;
             flag = pflag = 1;
-            os_cur = vorbis_sizes_before(f, bl, bs0, bs1, lane) / 2u;
+            os_cur = vorbis_sizes_before<false>(f, bl, bs0, bs1, lane) / 2u;
         }
         const int e = flag ? e1 : e0, bs = 1 << e, logp = e - 2, P = 1 << logp;
         long nb_next = b + glen;
