@@ -197,6 +197,57 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
         return step, nch * nb // 8, "frames", bytes_alg, {
             "workload": "Vorbis 2048/256 mixed block sizes, 8 ch, %d blocks (%d chains x %d)" % (nch * nb // 8, nch, nb),
             "channel_blocks": nch * nb}, "vorbis_synth_wave_kernel", pcm
+    if name in ("vorbisf", "vorbisf2"):
+        # config 4's shard from what the floor-1 and residue decoders produce: posts per channel-block + residue lines -> PCM.
+        # vorbisf: floor-1 curve as dB-table indices (1 B / line, one call per block-size class) + synthesis that looks the table up and
+        # multiplies as it loads the residue; vorbisf2: curve x residue written as an f32 spectrum, then plain synthesis (round 3).
+        nch, nb = max(1, int(64 * scale)), (16 if emulate else 4096)
+        rng = np.random.default_rng(seed)
+        flags = np.zeros((nch, nb), np.uint8)
+        cur = np.ones(nch, bool)
+        for b in range(nb):
+            r = rng.random(nch)
+            cur = np.where(cur, r < 0.9, r >= 0.7)
+            flags[:, b] = cur
+        v = sa.VorbisDsp(ctx, 8, 11)
+        so, po = v.layout(flags, np.full(nch, -1))
+        spec_stride, pcm_stride = int(so[:, -1].max()), int(po[:, -1].max())
+        spec_stride += (-spec_stride) % 4
+        pcm_stride += (-pcm_stride) % 4
+        residue = torch.randn((nch, spec_stride), generator=g, device=dev, dtype=torch.float32) * 0.1
+        d_flags = torch.from_numpy(flags).to(dev)
+        classes, n_post_words = [], 0
+        for flag, n, n_posts, mult in ((1, 1024, 40, 2), (0, 128, 12, 2)):
+            xs = [0, n] + rng.permutation(np.arange(1, n))[:n_posts - 2].tolist()
+            where = np.argwhere(flags == flag)
+            ys = rng.integers(0, 128, size=(len(where), n_posts)).astype(np.uint32)
+            ys[rng.random(ys.shape) < 0.2] = 0
+            offs = np.array([c * spec_stride + so[c, b] for c, b in where], np.uint32)
+            classes.append((xs, mult, torch.from_numpy(ys).to(dev), n, torch.from_numpy(offs).to(dev), len(where)))
+            n_post_words += ys.size + offs.size
+        plane = torch.zeros((nch, spec_stride), dtype=torch.uint8, device=dev)
+        spectrum = torch.zeros((nch, spec_stride), device=dev)
+        prev = [torch.full((nch,), -1, dtype=torch.int32, device=dev), torch.zeros((nch,), dtype=torch.int32, device=dev)]
+        overlap = [torch.zeros((nch, 1024), device=dev) for _ in range(2)]
+        pcm = torch.zeros((nch, pcm_stride), device=dev)
+
+        def step():
+            for xs, mult, ys, n, offs, cnt in classes:
+                if name == "vorbisf":
+                    v.floor1(xs, mult, ys, n, None, cnt, y_plane=plane, line_offsets=offs)
+                else:
+                    v.floor1(xs, mult, ys, n, spectrum, cnt, residue=residue, line_offsets=offs)
+            if name == "vorbisf":
+                v.synth_floor_y(plane, residue, d_flags, prev[0], overlap[0], pcm_stride, pcm, state_out=(prev[1], overlap[1]))
+            else:
+                v.synth(spectrum, d_flags, prev[0], overlap[0], pcm_stride, pcm, state_out=(prev[1], overlap[1]))
+        step.input = residue
+        bytes_alg = int(4 * (so[:, -1].sum() + po[:, -1].sum()) + 4 * n_post_words)  # residue lines + PCM samples + posts and offsets
+        return step, nch * nb // 8, "frames", bytes_alg, {
+            "workload": "Vorbis 2048/256, 8 ch, %d blocks (%d chains x %d) from floor-1 posts + residue: %s" % (
+                nch * nb // 8, nch, nb, "byte plane of dB-table indices, multiplied in the synthesis load path" if name == "vorbisf" else
+                "curve x residue as an f32 spectrum, then synthesis"),
+            "channel_blocks": nch * nb}, "vorbis_floor1_kernel x2 + vorbis_synth_wave_kernel", pcm
     if name == "flac":
         nb, bs = max(2, int(1048576 * scale) & ~1), 4096  # config 5: 1 M subframe blocks of 4096 samples = 16 GiB, in place
         buf, desc, co, pair_mode, _ = flac_config5(torch, nb, bs, seed, dev)
@@ -624,7 +675,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2"])
+    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2", "vorbisf", "vorbisf2"])
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -835,10 +886,11 @@ def main():
         # rzero: SURVEY 8d's correctness mixes, timed
         for key, w, mixw in (("mp3", "mp3", 0.0), ("vorbis", "vorbis", 0.0), ("flac", "flac", 0.0), ("alac", "alac", 0.0),
                              ("aac_mix_0.05", "aac", 0.05), ("aac_mix_0.25", "aac", 0.25), ("mp3_mix_0.06", "mp3", 0.06),
-                             ("mp3_int16_one_kernel", "mp3q", 0.0), ("mp3_int16_two_kernels", "mp3q2", 0.0)):
+                             ("mp3_int16_one_kernel", "mp3q", 0.0), ("mp3_int16_two_kernels", "mp3q2", 0.0),
+                             ("vorbis_posts_byte_plane", "vorbisf", 0.0), ("vorbis_posts_f32_spectrum", "vorbisf2", 0.0)):
             try:
                 stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, mixw, emulate)
-                nw, ww = (20, 3) if w in ("aac", "mp3", "vorbis") else (8, 2)  # (a few milliseconds each for the short ones)
+                nw, ww = (20, 3) if w in ("aac", "mp3", "vorbis", "vorbisf", "vorbisf2") else (8, 2)  # (a few milliseconds each for the short ones)
                 ew, lw, _ = timed(stw, nw, ww, spin)
                 others[key] = {"value": unitsw * nw / ew, "unit": unitw + "/s", "ms_per_step": ew / nw * 1e3, "steps": nw, "warmup": ww,
                                "kernel": kernelw, "kernel_ms": lw * 1e3, "algorithmic_bytes_per_launch": bytesw,
@@ -950,7 +1002,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not emulate:
             # (the int16 MP3 lines are timed against the same CPU restatement as config 3: its synthesis tail; the CPU side of
             # requantize + stereo is a few per cent of that)
-            out["cpu_baseline"] = cpu_baseline("mp3" if args.workload in ("mp3q", "mp3q2") else args.workload)
+            out["cpu_baseline"] = cpu_baseline({"mp3q": "mp3", "mp3q2": "mp3", "vorbisf": "vorbis", "vorbisf2": "vorbis"}.get(args.workload, args.workload))
         print(json.dumps(out), flush=True)
     if hung:
         os._exit(0)  # a leg is still stuck in a collective: the line is out, do not wait for it

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SYMACCEL_ABI_VERSION 4 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device */
+#define SYMACCEL_ABI_VERSION 4 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device, vorbis floor_y */
 
 typedef enum symaccel_status {
     SYMACCEL_OK = 0,
@@ -380,6 +380,23 @@ int symaccel_vorbis_synth_pp_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp,
                                     const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
                                     size_t pcm_stride, size_t n_chains, size_t blocks_per_chain);
 
+/* The same with the floor curve as dB-table INDICES, one byte per line (symaccel_vorbis_floor1_y_device; floor.rs:785-825 writes
+ * FLOOR1_INVERSE_DB_TABLE[y] and nothing else): floor_y[chain][spec_stride] bytes in the spectrum's packed layout, residue as
+ * d_spectra would be.  The kernels look the table up as they load the residue -- spectrum[i] = table[y[i]] * residue[i], the
+ * value floor.rs:822 stores times lib.rs:289-291's `*f *= r`, one rounded multiply -- so a floor-1 stream costs 1 byte per line
+ * written + 5 bytes per line read in front of the PCM instead of a curve (or a multiplied spectrum) in f32.  A channel marked
+ * do-not-decode (lib.rs:284-287: floor all zero) is a zero residue with any y.  spec_stride and pcm_stride multiples of 4,
+ * d_floor_y and d_residue 16-byte aligned (other layouts: SYMACCEL_ERR_INVALID_ARG / SYMACCEL_ERR_UNSUPPORTED). */
+int symaccel_vorbis_synth_fy_pp_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const uint8_t *d_floor_y,
+                                       const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
+                                       const int32_t *d_prev_flag_in, int32_t *d_prev_flag_out, const float *d_overlap_in,
+                                       float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains,
+                                       size_t blocks_per_chain);
+int symaccel_vorbis_synth_fy_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const uint8_t *d_floor_y,
+                                    const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
+                                    int32_t *d_prev_flag_io, float *d_overlap_io, float *d_pcm, size_t pcm_stride,
+                                    size_t n_chains, size_t blocks_per_chain);
+
 /* Inverse coupling (lib.rs:252-278) of `n_pairs` (magnitude, angle) vector pairs of n floats,
  * in place: pair p uses d_residue + mag_index[p]*n and d_residue + ang_index[p]*n.  Pairs are
  * applied in order (coupling steps may chain).  Index arrays are HOST arrays (<= 256 entries). */
@@ -406,6 +423,19 @@ int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int
 int symaccel_vorbis_floor1_dot_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
                                       const uint32_t *d_y, uint32_t n, const float *d_residue, float *d_spectrum,
                                       size_t count);
+/* symaccel_vorbis_floor1_dot_device for the blocks of one size class of a MIXED stream: block b's lines are at line
+ * d_line_offsets[b] (multiples of 4) of d_residue / d_spectrum -- the packed layout of symaccel_vorbis_synth_*. */
+int symaccel_vorbis_floor1_dot_at_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
+                                         const uint32_t *d_y, uint32_t n, const uint32_t *d_line_offsets,
+                                         const float *d_residue, float *d_spectrum, size_t count);
+/* The curve as dB-table INDICES, one byte per line (floor.rs:785-825: every value render_line writes is
+ * FLOOR1_INVERSE_DB_TABLE[y], y = 0..255): floor_y[.. + i] = the y of line i, block b at byte offset d_line_offsets[b] (multiples
+ * of 4; NULL: b * n).  With the offsets of a stream's blocks in the packed spectrum layout of symaccel_vorbis_synth_* this
+ * writes the plane symaccel_vorbis_synth_fy_* reads -- one call per block-size class of a mixed stream.  1 byte per line to
+ * HBM instead of a 4-byte curve (or a read-multiply-write pass over the residue); d_floor_y 4-byte aligned. */
+int symaccel_vorbis_floor1_y_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
+                                    const uint32_t *d_y, uint32_t n, const uint32_t *d_line_offsets, uint8_t *d_floor_y,
+                                    size_t count);
 /* Per-block status of the y rows (d_status[count] int8): 0, or SYMACCEL_ERR_UNSUPPORTED for a block with a value above
  * 511.  floor1_Y values are codebook entry numbers (floor.rs:698-712) that a conforming stream keeps below the floor's
  * range (<= 256); the reference computes whatever a larger value implies in i32.  Up to 511 the kernels above reproduce

@@ -33,7 +33,8 @@ ABI_SYMBOLS = [
     "symaccel_mp3_requantize_device", "symaccel_mp3_requantize", "symaccel_mp3_stereo_device", "symaccel_mp3_requantize_stereo_device",
     "symaccel_vorbis_synth_device", "symaccel_vorbis_synth_fr_device", "symaccel_vorbis_synth", "symaccel_vorbis_inverse_coupling_device",
     "symaccel_vorbis_dot_product_device", "symaccel_vorbis_deinterleave2_device",
-    "symaccel_vorbis_floor1_device", "symaccel_vorbis_floor1_dot_device", "symaccel_flac_restore_device", "symaccel_flac_restore", "symaccel_flac_restore_stereo_device",
+    "symaccel_vorbis_floor1_device", "symaccel_vorbis_floor1_dot_device", "symaccel_vorbis_floor1_y_device", "symaccel_vorbis_floor1_dot_at_device",
+    "symaccel_vorbis_synth_fy_pp_device", "symaccel_vorbis_synth_fy_device", "symaccel_flac_restore_device", "symaccel_flac_restore", "symaccel_flac_restore_stereo_device",
     "symaccel_flac_decorrelate_device", "symaccel_flac_decorrelate", "symaccel_alac_predict_device",
     "symaccel_alac_predict", "symaccel_alac_predict_stereo_device", "symaccel_alac_mid_side_device", "symaccel_alac_mid_side", "symaccel_table_f32", "symaccel_imdct_twiddles",
     "symaccel_fft_twiddles",
@@ -104,6 +105,10 @@ class Library:
         d.symaccel_vorbis_deinterleave2_device.argtypes = [_vp, _vp, _vp, _i, _sz, _sz]
         d.symaccel_vorbis_floor1_device.argtypes = [_vp, _vp, _i, _i, _vp, _u32, _vp, _sz]
         d.symaccel_vorbis_floor1_dot_device.argtypes = [_vp, _vp, _i, _i, _vp, C.c_uint32, _vp, _vp, _sz]
+        d.symaccel_vorbis_floor1_y_device.argtypes = [_vp, _vp, _i, _i, _vp, C.c_uint32, _vp, _vp, _sz]
+        d.symaccel_vorbis_floor1_dot_at_device.argtypes = [_vp, _vp, _i, _i, _vp, C.c_uint32, _vp, _vp, _vp, _sz]
+        d.symaccel_vorbis_synth_fy_pp_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
+        d.symaccel_vorbis_synth_fy_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_flac_restore_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_flac_restore_stereo_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _u32, _sz, _sz]
         d.symaccel_flac_restore.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]

@@ -458,6 +458,21 @@ class VorbisDsp:
                        int(floor.shape[1]), _ptr(block_flag), _ptr(prev_flag), _ptr(overlap), _ptr(pcm), int(pcm_stride), nch, nb)
         return pcm
 
+    def synth_floor_y(self, floor_y, residue, block_flag, prev_flag, overlap, pcm_stride, pcm, state_out=None):
+        """synth() from the floor curve as dB-table indices (one byte per line, floor1(..., y_plane=)) and the residue: the table
+        look-up and the dot product happen in the synthesis kernel's load path.  state_out = (prev_flag_out, overlap_out): the
+        ping-pong entry point; otherwise the state is updated in place."""
+        d = self.ctx.lib.dll
+        nch, nb = int(block_flag.shape[0]), int(block_flag.shape[1])
+        if state_out is not None:
+            self.ctx._call(d.symaccel_vorbis_synth_fy_pp_device, self.bs0_exp, self.bs1_exp, _ptr(floor_y), _ptr(residue),
+                           int(residue.shape[1]), _ptr(block_flag), _ptr(prev_flag), _ptr(state_out[0]), _ptr(overlap),
+                           _ptr(state_out[1]), _ptr(pcm), int(pcm_stride), nch, nb)
+        else:
+            self.ctx._call(d.symaccel_vorbis_synth_fy_device, self.bs0_exp, self.bs1_exp, _ptr(floor_y), _ptr(residue),
+                           int(residue.shape[1]), _ptr(block_flag), _ptr(prev_flag), _ptr(overlap), _ptr(pcm), int(pcm_stride), nch, nb)
+        return pcm
+
     # device-pointer helpers (torch tensors, or raw arrays when the library treats host memory as device)
     def inverse_coupling(self, residue, n, mag_index, ang_index):
         mi = _np(mag_index, np.uint32)
@@ -472,13 +487,20 @@ class VorbisDsp:
         self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_deinterleave2_device, _ptr(type2), _ptr(planar), int(n_ch),
                        int(n2), int(count))
 
-    def floor1(self, x_list, multiplier, y, n, floor, count, residue=None):
+    def floor1(self, x_list, multiplier, y, n, floor, count, residue=None, y_plane=None, line_offsets=None):
         """floor[count][n] = the floor-1 curve; with `residue`, floor = curve * residue (the dot product fused into the
-        curve's store; `floor` may be `residue`)."""
+        curve's store; `floor` may be `residue`); with `y_plane` (uint8), the curve's dB-table indices, one byte per line, block b
+        at byte offset line_offsets[b] (None: b * n) -- what synth_floor_y() reads."""
         xl = _np(x_list, np.uint32)
-        if residue is None:
+        if y_plane is not None:
+            self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_floor1_y_device, _ptr(xl), xl.size, int(multiplier), _ptr(y), int(n),
+                           _ptr(line_offsets) if line_offsets is not None else None, _ptr(y_plane), int(count))
+        elif residue is None:
             self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_floor1_device, _ptr(xl), xl.size, int(multiplier), _ptr(y),
                            int(n), _ptr(floor), int(count))
+        elif line_offsets is not None:
+            self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_floor1_dot_at_device, _ptr(xl), xl.size, int(multiplier), _ptr(y),
+                           int(n), _ptr(line_offsets), _ptr(residue), _ptr(floor), int(count))
         else:
             self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_floor1_dot_device, _ptr(xl), xl.size, int(multiplier), _ptr(y),
                            int(n), _ptr(residue), _ptr(floor), int(count))

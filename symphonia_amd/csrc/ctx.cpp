@@ -578,7 +578,7 @@ static int vorbis_stride_floor(int bs0_exp, size_t spec_stride, size_t blocks_pe
 static int vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
                                  size_t spec_stride, const uint8_t *d_block_flag, int32_t *d_prev_flag_io,
                                  float *d_overlap_io, float *d_pcm, size_t pcm_stride, size_t n_chains,
-                                 size_t blocks_per_chain) {
+                                 size_t blocks_per_chain, const uint8_t *d_floor_y = nullptr) {
     SYM_TRY(vorbis_check(ctx, bs0_exp, bs1_exp));
     if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
     if (!d_spectra || !d_block_flag || !d_prev_flag_io || !d_overlap_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
@@ -593,15 +593,15 @@ static int vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, cons
     float *ov_out = (float *)scratch;
     int32_t *pf_out = (int32_t *)(ov_out + n_chains * half1);
     SYM_TRY(launch_vorbis(ctx, bs0_exp, bs1_exp, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_flag_io, pf_out,
-                          d_overlap_io, ov_out, d_pcm, pcm_stride, n_chains, blocks_per_chain, (char *)scratch + ov_bytes + pf_bytes));
+                          d_overlap_io, ov_out, d_pcm, pcm_stride, n_chains, blocks_per_chain, (char *)scratch + ov_bytes + pf_bytes, d_floor_y));
     SYM_TRY(launch_state_copy(ctx, d_overlap_io, ov_out, ov_bytes, d_prev_flag_io, pf_out, pf_bytes, nullptr, nullptr, 0));
     return SYMACCEL_OK;
 }
 
-int symaccel_vorbis_synth_pp_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
-                                    size_t spec_stride, const uint8_t *d_block_flag, const int32_t *d_prev_flag_in,
-                                    int32_t *d_prev_flag_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
-                                    size_t pcm_stride, size_t n_chains, size_t blocks_per_chain) {
+static int vorbis_synth_pp(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
+                           size_t spec_stride, const uint8_t *d_block_flag, const int32_t *d_prev_flag_in,
+                           int32_t *d_prev_flag_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
+                           size_t pcm_stride, size_t n_chains, size_t blocks_per_chain, const uint8_t *d_floor_y) {
     SYM_TRY(vorbis_check(ctx, bs0_exp, bs1_exp));
     if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
     if (!d_spectra || !d_block_flag || !d_prev_flag_in || !d_prev_flag_out || !d_overlap_in || !d_overlap_out || !d_pcm)
@@ -613,7 +613,40 @@ int symaccel_vorbis_synth_pp_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp,
     void *scratch = nullptr;  // per-block offsets of the generic block-size pairs
     SYM_TRY(ctx_scratch(ctx, n_chains * (blocks_per_chain + 1) * 2 * sizeof(uint32_t) + 256, &scratch));
     return launch_vorbis(ctx, bs0_exp, bs1_exp, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_flag_in, d_prev_flag_out,
-                         d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, blocks_per_chain, scratch);
+                         d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, blocks_per_chain, scratch, d_floor_y);
+}
+
+int symaccel_vorbis_synth_pp_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra, const float *d_residue,
+                                    size_t spec_stride, const uint8_t *d_block_flag, const int32_t *d_prev_flag_in,
+                                    int32_t *d_prev_flag_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
+                                    size_t pcm_stride, size_t n_chains, size_t blocks_per_chain) {
+    return vorbis_synth_pp(ctx, bs0_exp, bs1_exp, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_flag_in, d_prev_flag_out,
+                           d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, blocks_per_chain, nullptr);
+}
+
+// floor curve as table indices (one byte per line) x residue, multiplied in the synthesis kernels' load path
+static int vorbis_fy_check(const uint8_t *d_floor_y, const float *d_residue, size_t spec_stride, size_t pcm_stride, size_t n_chains,
+                           size_t blocks_per_chain) {
+    if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
+    if (!d_floor_y || !d_residue) return SYMACCEL_ERR_INVALID_ARG;
+    // 16-byte accesses on the residue and the PCM, 4-byte accesses on the byte plane, every chain aligned alike
+    if (spec_stride % 4 || pcm_stride % 4 || ((uintptr_t)d_floor_y | (uintptr_t)d_residue) % 16) return SYMACCEL_ERR_INVALID_ARG;
+    return SYMACCEL_OK;
+}
+int symaccel_vorbis_synth_fy_pp_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const uint8_t *d_floor_y, const float *d_residue,
+                                       size_t spec_stride, const uint8_t *d_block_flag, const int32_t *d_prev_flag_in,
+                                       int32_t *d_prev_flag_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
+                                       size_t pcm_stride, size_t n_chains, size_t blocks_per_chain) {
+    SYM_TRY(vorbis_fy_check(d_floor_y, d_residue, spec_stride, pcm_stride, n_chains, blocks_per_chain));
+    return vorbis_synth_pp(ctx, bs0_exp, bs1_exp, d_residue, nullptr, spec_stride, d_block_flag, d_prev_flag_in, d_prev_flag_out,
+                           d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, blocks_per_chain, d_floor_y);
+}
+int symaccel_vorbis_synth_fy_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const uint8_t *d_floor_y, const float *d_residue,
+                                    size_t spec_stride, const uint8_t *d_block_flag, int32_t *d_prev_flag_io, float *d_overlap_io,
+                                    float *d_pcm, size_t pcm_stride, size_t n_chains, size_t blocks_per_chain) {
+    SYM_TRY(vorbis_fy_check(d_floor_y, d_residue, spec_stride, pcm_stride, n_chains, blocks_per_chain));
+    return vorbis_synth_device(ctx, bs0_exp, bs1_exp, d_residue, nullptr, spec_stride, d_block_flag, d_prev_flag_io, d_overlap_io,
+                               d_pcm, pcm_stride, n_chains, blocks_per_chain, d_floor_y);
 }
 
 int symaccel_vorbis_synth_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_spectra,
@@ -708,10 +741,11 @@ int symaccel_vorbis_deinterleave2_device(symaccel_ctx *ctx, const float *d_type2
 }
 
 static int vorbis_floor1(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier, const uint32_t *d_y, uint32_t n,
-                         float *d_floor, size_t count, const float *d_residue) {
+                         float *d_floor, size_t count, const float *d_residue, uint8_t *d_floor_y = nullptr,
+                         const uint32_t *d_line_offs = nullptr) {
     if (!ctx || n_posts < 2 || n_posts > 65 || multiplier < 1 || multiplier > 4) return SYMACCEL_ERR_INVALID_ARG;
     if (count == 0 || n == 0) return SYMACCEL_OK;
-    if (!x_list || !d_y || !d_floor) return SYMACCEL_ERR_INVALID_ARG;
+    if (!x_list || !d_y || (!d_floor && !d_floor_y)) return SYMACCEL_ERR_INVALID_ARG;
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     // Setup-time derivations the reference does once per floor (floor.rs:540-555, 748-773):
@@ -741,7 +775,7 @@ static int vorbis_floor1(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts,
         if (x_list[i] > 0xffffu) return SYMACCEL_ERR_INVALID_ARG;  // floor1_X values have at most 15 bits (rangebits)
     if (n > 4096u || (n & 15u)) return SYMACCEL_ERR_INVALID_ARG;  // n = blocksize / 2, blocksize = 2^6 .. 2^13 (lib.rs:404-406)
     // the derived tables travel as a kernel argument: no staging copy, no stream synchronisation
-    return launch_vorbis_floor1(ctx, setup, n_posts, multiplier, d_y, n, d_floor, count, d_residue);
+    return launch_vorbis_floor1(ctx, setup, n_posts, multiplier, d_y, n, d_floor, count, d_residue, d_floor_y, d_line_offs);
 }
 
 int symaccel_vorbis_floor1_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
@@ -752,6 +786,17 @@ int symaccel_vorbis_floor1_dot_device(symaccel_ctx *ctx, const uint32_t *x_list,
                                       const uint32_t *d_y, uint32_t n, const float *d_residue, float *d_spectrum, size_t count) {
     if (count != 0 && n != 0 && !d_residue) return SYMACCEL_ERR_INVALID_ARG;
     return vorbis_floor1(ctx, x_list, n_posts, multiplier, d_y, n, d_spectrum, count, d_residue);
+}
+int symaccel_vorbis_floor1_dot_at_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier, const uint32_t *d_y,
+                                         uint32_t n, const uint32_t *d_line_offsets, const float *d_residue, float *d_spectrum,
+                                         size_t count) {
+    if (count != 0 && n != 0 && (!d_residue || !d_line_offsets)) return SYMACCEL_ERR_INVALID_ARG;
+    return vorbis_floor1(ctx, x_list, n_posts, multiplier, d_y, n, d_spectrum, count, d_residue, nullptr, d_line_offsets);
+}
+int symaccel_vorbis_floor1_y_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier, const uint32_t *d_y,
+                                    uint32_t n, const uint32_t *d_line_offsets, uint8_t *d_floor_y, size_t count) {
+    if (count != 0 && n != 0 && (!d_floor_y || ((uintptr_t)d_floor_y & 3u))) return SYMACCEL_ERR_INVALID_ARG;
+    return vorbis_floor1(ctx, x_list, n_posts, multiplier, d_y, n, nullptr, count, nullptr, d_floor_y, d_line_offsets);
 }
 
 // ---- FLAC ---------------------------------------------------------------------------------

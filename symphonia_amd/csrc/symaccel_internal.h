@@ -204,12 +204,12 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
                   size_t spec_stride,
                   const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out,
                   const float *d_overlap_in, float *d_overlap_out, float *d_pcm, size_t pcm_stride,
-                  size_t n_chains, size_t blocks_per_chain, void *d_offsets);
+                  size_t n_chains, size_t blocks_per_chain, void *d_offsets, const uint8_t *d_floor_y = nullptr);
 int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                        const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride,
                        const uint8_t *d_block_flag,
                        const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out,
-                       float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg);
+                       float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg, int floor_mode);
 // SYM_VORBIS_WG (build knob): 1 = pairs with long blocks of 8192 samples run the workgroup-cooperative vorbis_synth_wg_kernel, 2 = those
 // with 4096-sample long blocks too, 0 = vorbis_synth_wave2_kernel's one-wavefront-per-block form for all of them (kept for the A/B).
 #ifndef SYM_VORBIS_WG
@@ -218,17 +218,18 @@ int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_lon
 int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                      const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
                      const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
-                     size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg);  // vorbis_wg.hip
+                     size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg, int floor_mode);  // vorbis_wg.hip
 int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                         const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride,
                         const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in,
-                        float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg);
+                        float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg, int floor_mode);
 int launch_vorbis_coupling(symaccel_ctx *ctx, float *d_mag, float *d_ang, size_t n);
 int launch_vorbis_dot(symaccel_ctx *ctx, float *d_floor, const float *d_residue, size_t total);
 int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d_planar, int n_ch, size_t n2,
                                size_t count);
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier,
-                         const uint32_t *d_y, uint32_t n, float *d_floor, size_t count, const float *d_residue = nullptr);
+                         const uint32_t *d_y, uint32_t n, float *d_floor, size_t count, const float *d_residue = nullptr,
+                         uint8_t *d_floor_y = nullptr, const uint32_t *d_line_offs = nullptr);
 int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d_coeffs, size_t frames_per_chain,
                             const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs);
 int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,

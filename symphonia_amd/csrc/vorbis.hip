@@ -350,11 +350,18 @@ constexpr int kF1B = 64;                 // channel-blocks per workgroup
 constexpr int kF1Waves = 4;              // wavefronts per workgroup
 constexpr int kF1Stride = kF1B + 1;      // LDS row stride of the per-block lists [entry][block]: conflict-free both ways
 
-template <bool DOT, int NMAX>
+// MODE 0: the curve (f32) -> floor_out[block][n];  1: curve * residue -> floor_out (the dot product of lib.rs:282-292);
+//      2: the curve's dB-table INDICES, one byte per line -> (uint8_t *)floor_out + line_offs[block] (or block * n): every value
+//         render_line writes is FLOOR1_INVERSE_DB_TABLE[y], y in 0..255 (floor.rs:785-825), so one byte per line carries the whole
+//         curve; the synthesis kernels look the table up as they load the residue (symaccel_vorbis_synth_fy_*): 1 B / line
+//         written here and read there instead of 4 + 4 + 4 B / line for a multiplied spectrum.
+template <int MODE, int NMAX>
 __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setup st, int n_posts, int multiplier,
                                                                       const uint32_t *__restrict__ yv, uint32_t n,
                                                                       float *floor_out, const float *__restrict__ db,
-                                                                      size_t count, const float *residue) {
+                                                                      size_t count, const float *residue,
+                                                                      const uint32_t *__restrict__ line_offs) {
+    constexpr bool DOT = MODE == 1;
     // LDS per workgroup: 13 KiB of point lists + 8.2 KiB (n <= 1024; 20 KiB otherwise) that first hold final_y and then, per
     // wavefront, a segment table and a segment-start map (n bytes): 22.6 KiB, seven workgroups per CU
     constexpr int kPerWave = 67 * 16 + NMAX;  // bytes
@@ -502,10 +509,15 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
     // points); the segments' constants from a table built one lane per segment.
     for (int b = wave; b < nb; b += kF1Waves) {
         const int nsb = (int)ns_of[b];  // points 0 .. nsb of block b
-        float *out = floor_out + (blk0 + (size_t)b) * (size_t)n;
+        // (line_offs: block b's lines start at line line_offs[b] of the plane instead of b * n -- a block-size class of a mixed stream
+        // rendered straight into the packed layout the synthesis kernels read)
+        const size_t line0 = line_offs ? (size_t)line_offs[blk0 + (size_t)b] : (blk0 + (size_t)b) * (size_t)n;
+        float *out = floor_out + line0;
+        uint8_t *yout = nullptr;
+        if constexpr (MODE == 2) yout = reinterpret_cast<uint8_t *>(floor_out) + line0;
         // fused dot product (lib.rs:282-292): the curve is multiplied by the block's residue as it is stored -- one rounded
         // multiply per line, the reference's `*f *= r` -- so the curve itself never goes to HBM (residue may be `out`)
-        const float *rin = DOT ? residue + (blk0 + (size_t)b) * (size_t)n : nullptr;
+        const float *rin = DOT ? residue + line0 : nullptr;
         // segment-start map: mark[x_k] = k + 1 for the points with x_k < n (x values are distinct)
         for (uint32_t i = (uint32_t)lane; i < (n + 3u) / 4u; i += 64) reinterpret_cast<uint32_t *>(mark)[i] = 0u;
         wave_sync_lds();
@@ -566,6 +578,7 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
                 last[j] = holders ? last[j] : 0;
             }
             float res[4][4];
+            uint32_t ybytes[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int seg_id = (below[j] && before[j] > carry) ? before[j] : carry;  // (index + 1) of the segment
@@ -579,12 +592,15 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
                     const int32_t steps = (int32_t)((float)t * __uint_as_float(c.y) + __uint_as_float(c.z));
                     int32_t y4 = (int32_t)(c.x >> 16) + (steps << 2);  // byte offset of the table entry (y0 sits at bit 18)
                     y4 = y4 < 0 ? 0 : (y4 > 1020 ? 1020 : y4);        // (in range for every rendered x; guards the lanes past the list)
-                    res[j][q] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dbl) + y4);
+                    if constexpr (MODE == 2) ybytes[j] |= (uint32_t)(y4 >> 2) << (8 * q);
+                    else res[j][q] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dbl) + y4);
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (xb[j] < n) {
+                if constexpr (MODE == 2) {
+                    if (xb[j] < n) *reinterpret_cast<uint32_t *>(yout + xb[j]) = ybytes[j];  // 256 B per store instruction
+                } else if (xb[j] < n) {
                     float4 v = make_float4(res[j][0], res[j][1], res[j][2], res[j][3]);
                     if constexpr (DOT) v = make_float4(v.x * rr[j].x, v.y * rr[j].y, v.z * rr[j].z, v.w * rr[j].w);
                     *reinterpret_cast<float4 *>(out + xb[j]) = v;
@@ -613,8 +629,12 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
                   size_t spec_stride,
                   const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out,
                   const float *d_overlap_in, float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains,
-                  size_t blocks_per_chain, void *d_offsets) {
+                  size_t blocks_per_chain, void *d_offsets, const uint8_t *d_floor_y) {
     if (blocks_per_chain > 0x3fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    // d_floor_y: the floor curve as dB-table indices, one byte per line in the spectrum's packed layout (symaccel_vorbis_floor1_y_device);
+    // d_spectra is then the RESIDUE.  The kernels take the plane through their `residue` argument (FUSED = 2).
+    const int floor_mode = d_floor_y ? 2 : (d_residue ? 1 : 0);
+    if (d_floor_y) d_residue = reinterpret_cast<const float *>(d_floor_y);
     const ImdctPlan *ps = nullptr, *pl = nullptr;
     SYM_TRY(get_imdct_plan(ctx, (1 << bs0_exp) >> 1, 1.0, &ps));  // vorbis/lib.rs:123
     SYM_TRY(get_imdct_plan(ctx, (1 << bs1_exp) >> 1, 1.0, &pl));  // vorbis/lib.rs:124
@@ -643,15 +663,17 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
         // it derives the packed offsets itself
         return launch_vorbis_wave(ctx, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra,
                                   d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
-                                  pcm_stride, n_chains, nb, seg);
+                                  pcm_stride, n_chains, nb, seg, floor_mode);
     }
     // (both derive the packed offsets from the flags themselves, vorbis_offsets.h)
     if (wg_path)
         return launch_vorbis_wg(ctx, bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra, d_residue,
-                                spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, nb, seg);
+                                spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, nb, seg, floor_mode);
     if (wave2_path)
         return launch_vorbis_wave2(ctx, bs0_exp, bs1_exp, (const cpx *)ps->d_twiddle, (const cpx *)pl->d_twiddle, ws, wl, d_spectra, d_residue,
-                                   spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, nb, seg);
+                                   spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, n_chains, nb, seg, floor_mode);
+    // the byte plane needs the 16-byte-aligned kernels above
+    if (floor_mode == 2) return SYMACCEL_ERR_UNSUPPORTED;
     // the LDS-staged generic kernel (unaligned strides / pointers): a scan kernel turns the flag sequence into packed offsets (room for
     // them comes from the ABI wrapper: n_chains * (blocks_per_chain + 1) * 2 words)
     uint32_t *offs = (uint32_t *)(((uintptr_t)d_offsets + 255) & ~(uintptr_t)255);
@@ -698,7 +720,8 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
 }
 
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier, const uint32_t *d_y,
-                         uint32_t n, float *d_floor, size_t count, const float *d_residue) {
+                         uint32_t n, float *d_floor, size_t count, const float *d_residue, uint8_t *d_floor_y,
+                         const uint32_t *d_line_offs) {
     const size_t grid = (count + kF1B - 1) / kF1B;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     Floor1Setup st{};  // passed by value: the kernel reads it with scalar loads (wave-uniform indices)
@@ -717,13 +740,15 @@ int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts
         st.wide[i] = ((h_setup[i] - h_setup[lo]) & 0xffffu) | (uint32_t)(adx > 0 ? adx : 1) << 16;  // (x[i] - x[lo]) | adx << 16
     }
     // instantiated per block class: the segment-start map is n bytes of LDS, and LDS is what bounds the resident wavefronts
-#define SYM_F1_LAUNCH(DOT, NMAX)                                                                                                     \
-    hipLaunchKernelGGL((vorbis_floor1_kernel<DOT, NMAX>), dim3((unsigned)grid), dim3(64 * kF1Waves), 0, ctx->stream, st, n_posts, multiplier, d_y, \
-                       n, d_floor, ctx->dev.vorbis_floor1_db, count, d_residue)
-    if (d_residue) {
-        if (n <= 1024) SYM_F1_LAUNCH(true, 1024); else SYM_F1_LAUNCH(true, 4096);
+#define SYM_F1_LAUNCH(MODE, NMAX)                                                                                                    \
+    hipLaunchKernelGGL((vorbis_floor1_kernel<MODE, NMAX>), dim3((unsigned)grid), dim3(64 * kF1Waves), 0, ctx->stream, st, n_posts, multiplier, d_y, \
+                       n, d_floor_y ? reinterpret_cast<float *>(d_floor_y) : d_floor, ctx->dev.vorbis_floor1_db, count, d_residue, d_line_offs)
+    if (d_floor_y) {  // the curve as table indices, one byte per line
+        if (n <= 1024) SYM_F1_LAUNCH(2, 1024); else SYM_F1_LAUNCH(2, 4096);
+    } else if (d_residue) {
+        if (n <= 1024) SYM_F1_LAUNCH(1, 1024); else SYM_F1_LAUNCH(1, 4096);
     } else {
-        if (n <= 1024) SYM_F1_LAUNCH(false, 1024); else SYM_F1_LAUNCH(false, 4096);
+        if (n <= 1024) SYM_F1_LAUNCH(0, 1024); else SYM_F1_LAUNCH(0, 4096);
     }
 #undef SYM_F1_LAUNCH
     SYM_GPU(ctx, hipGetLastError());

@@ -1,3 +1,5 @@
+// Shared by the three Vorbis synthesis kernels: the packed offsets and the fused floor x residue load.
+//
 // Packed Vorbis offsets from the block flags alone (lib.rs:296-331: block k reads n_k / 2 lines and yields (n_{k-1} + n_k) / 4
 // samples): every wavefront derives the offsets of its segment's first block itself, so no scan kernel runs in front of the
 // synthesis kernels (vorbis_wave.hip, vorbis_wave2.hip, vorbis_wg.hip; the LDS-staged generic kernel of vorbis.hip keeps its scan).
@@ -87,6 +89,28 @@ __device__ __forceinline__ VorbisPackedAt vorbis_packed_at(const uint8_t *f, lon
         at.pcm = (s_b + n_m1 + (s_b - n_prev)) / 4u;
     }
     return at;
+}
+
+// FUSED (all three synthesis kernels): 0 = `spectra` is the spectrum; 1 = `spectra` is the floor curve and `residue` the residue, both
+// f32 (lib.rs:289-291: *f *= r as the lines are loaded); 2 = `spectra` is the RESIDUE and `residue` the floor curve as dB-table
+// indices, one byte per line (symaccel_vorbis_floor1_y_device): the four bytes that belong to a lane's float4 are one 32-bit load.
+template <int FUSED>
+__device__ __forceinline__ const float *res_at(const float *rp, size_t lines) {
+    if constexpr (FUSED == 2) return reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(rp) + lines);
+    else return FUSED ? rp + lines : nullptr;
+}
+// x *= table[y] for the four lines of a float4 (floor.rs:822 + lib.rs:289-291)
+__device__ __forceinline__ void mul_floor_y(float4 &x, uint32_t yb, const float *dbt) {
+    x.x = dbt[yb & 255u] * x.x;
+    x.y = dbt[(yb >> 8) & 255u] * x.y;
+    x.z = dbt[(yb >> 16) & 255u] * x.z;
+    x.w = dbt[yb >> 24] * x.w;
+}
+
+// (out of line, values in registers both ways: for the instantiations that have no registers left for the inlined form's temporaries)
+__device__ __attribute__((noinline)) float4 mul_floor_y_call(float4 x, uint32_t yb, const float *dbt) {
+    mul_floor_y(x, yb, dbt);
+    return x;
 }
 
 }  // namespace

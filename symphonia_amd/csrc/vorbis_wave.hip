@@ -23,28 +23,45 @@ namespace symaccel {
 
 namespace {
 
-// the group's spectral lines (and, fused, the residue lines they are multiplied with): 512 B coalesced per load
-template <bool FUSED>
+// the group's spectral lines (and, fused, the residue lines they are multiplied with): 512 B coalesced per load.
+// FUSED 0: `sp` is the spectrum.  1: `sp` is the floor curve, `rp` the residue (f32 both).  2: `sp` is the RESIDUE and `rp` the
+// floor curve as dB-table indices, one byte per line (symaccel_vorbis_floor1_y_device): a lane's pair of lines is one 16-bit load,
+// carried in res[s].x as a bit pattern; apply_residue looks the two table values up in LDS (`dbt`, 256 floats).
+template <int FUSED>
 __device__ __forceinline__ void fetch_lines(const float *sp, const float *rp, uint32_t off, int n_loads, int lane,
                                             float2 (&line)[8], float2 (&res)[8]) {
     const float2 *src = reinterpret_cast<const float2 *>(sp + off);
 #pragma unroll
     for (int s = 0; s < 8; ++s)
         if (s < n_loads) line[s] = ld_stream(src + lane + 64 * s);
-    if constexpr (FUSED) {
+    if constexpr (FUSED == 1) {
         const float2 *rs = reinterpret_cast<const float2 *>(rp + off);
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             if (s < n_loads) res[s] = ld_stream(rs + lane + 64 * s);
     }
+    if constexpr (FUSED == 2) {
+        const uint16_t *ys = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(rp) + off);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s < n_loads) res[s].x = __uint_as_float((unsigned)ys[lane + 64 * s]);
+    }
 }
-template <bool FUSED>
-__device__ __forceinline__ void apply_residue(float2 (&line)[8], const float2 (&res)[8]) {
-    if constexpr (FUSED) {
+template <int FUSED>
+__device__ __forceinline__ void apply_residue(float2 (&line)[8], const float2 (&res)[8], const float *dbt) {
+    if constexpr (FUSED == 1) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             line[s].x *= res[s].x;  // lib.rs:289-291: *f *= r
             line[s].y *= res[s].y;
+        }
+    }
+    if constexpr (FUSED == 2) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const unsigned yy = __float_as_uint(res[s].x);
+            line[s].x = dbt[yy & 255u] * line[s].x;  // floor.rs:822 (the curve's value) and lib.rs:289-291 (*f *= r) in one step
+            line[s].y = dbt[yy >> 8] * line[s].y;
         }
     }
 }
@@ -75,7 +92,7 @@ __device__ __forceinline__ void ola_short4(const float *ws, int k, const float (
 
 // FUSED: the spectrum is floor[i] * residue[i] (the dot product of lib.rs:282-292), multiplied as the lines are consumed --
 // one rounded multiply per line, exactly the reference's `*f *= r`, without a separate pass over HBM.
-template <bool FUSED>
+template <int FUSED>
 __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wave_kernel(
     DevTables tb, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
     int32_t *__restrict__ prev_flag_out, const float *__restrict__ overlap_in, float *__restrict__ overlap_out,
     float *__restrict__ pcm, size_t pcm_stride, unsigned nb, unsigned seg_len,
     unsigned segs_per_chain, unsigned n_items) {
-    __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
+    __shared__ __attribute__((aligned(16))) float tabs[kTabFloats + (FUSED == 2 ? 256 : 0)];  // (+ FLOOR1_INVERSE_DB_TABLE)
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
     __shared__ unsigned wave_chain[kWaves];  // the wavefront's chain index, parked for the epilogue (see there)
 #if SYM_VORBIS_WAVES == 3 || SYM_C32_IS_PACKED
@@ -99,6 +116,8 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
             tabs[kTabTws + i] = reinterpret_cast<const float *>(tw_short)[i];
         }
     }
+    if constexpr (FUSED == 2) tabs[kTabFloats + ((int)threadIdx.x & 255)] = tb.vorbis_floor1_db[(int)threadIdx.x & 255];
+    const float *dbt = tabs + kTabFloats;
     __syncthreads();  // the only workgroup-wide barrier
 
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
@@ -115,7 +134,9 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
     const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
     const uint8_t *f = flags + (size_t)chain * nb;
     const float *sp = spectra + (size_t)chain * spec_stride;
-    const float *rp = FUSED ? residue + (size_t)chain * spec_stride : nullptr;
+    // (FUSED 2: `residue` is the byte plane of table indices, `spectra` the residue)
+    const float *rp = FUSED == 2 ? reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(residue) + (size_t)chain * spec_stride)
+                                 : (FUSED ? residue + (size_t)chain * spec_stride : nullptr);
     float *out = pcm + (size_t)chain * pcm_stride;
     const int pf0 = prev_flag_in[chain];
 
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
             const bool emit = b >= (long)b_begin;
             c32 z[8];
             const int mirror = (63 - lane) * 4;
-            apply_residue<FUSED>(line, res);
+            apply_residue<FUSED>(line, res, dbt);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
@@ -273,7 +294,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
             hi_fresh = true;
         } else {
             // ------------------------------------------------------------------ a run of `glen` short blocks
-            apply_residue<FUSED>(line, res);
+            apply_residue<FUSED>(line, res, dbt);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {  // block s of the run -> window s of the eight-way short transform
                 if (s < glen) {
@@ -361,7 +382,8 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
         const unsigned chain2 = wave_chain[tid2 >> 6];
         const uint8_t *f2 = flags + (size_t)chain2 * nb;
         const float *sp2 = spectra + (size_t)chain2 * spec_stride;
-        const float *rp2 = FUSED ? residue + (size_t)chain2 * spec_stride : nullptr;
+        const float *rp2 = FUSED == 2 ? reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(residue) + (size_t)chain2 * spec_stride)
+                                      : (FUSED ? residue + (size_t)chain2 * spec_stride : nullptr);
         if (!hi_fresh) {
             // The chain ends in short blocks and this segment never saw a long one: overlap[128..1024) still
             // holds what the most recent long block left there (never used for PCM, but part of the state the
@@ -375,7 +397,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
             if (bl >= 0) {
                 c32 z[8];
                 fetch_lines<FUSED>(sp2, rp2, (256u * (uint32_t)bl + 1792u * count_long_before(f2, bl, lane)) / 2, 8, lane, line, res);
-                apply_residue<FUSED>(line, res);
+                apply_residue<FUSED>(line, res, dbt);
                 const int mirror = (63 - lane) * 4;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
@@ -418,21 +440,19 @@ int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_lon
                        const uint8_t *d_block_flag,
                        const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out,
                        float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb,
-                       unsigned seg) {
+                       unsigned seg, int floor_mode) {
     const size_t segs = (nb + seg - 1) / seg;
     const size_t items = n_chains * segs;
     const size_t grid = (items + kWaves - 1) / kWaves;
     if (items > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    if (d_residue)
-        hipLaunchKernelGGL(vorbis_synth_wave_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev,
-                           tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in,
-                           d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, nb, seg, (unsigned)segs,
-                           (unsigned)items);
-    else
-        hipLaunchKernelGGL(vorbis_synth_wave_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev,
-                           tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in,
-                           d_prev_out, d_overlap_in, d_overlap_out, d_pcm, pcm_stride, nb, seg, (unsigned)segs,
-                           (unsigned)items);
+#define SYM_VW_LAUNCH(MODE)                                                                                                           \
+    hipLaunchKernelGGL(vorbis_synth_wave_kernel<MODE>, dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, tw_short, tw_long, \
+                       win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in,       \
+                       d_overlap_out, d_pcm, pcm_stride, nb, seg, (unsigned)segs, (unsigned)items)
+    if (floor_mode == 2) SYM_VW_LAUNCH(2);
+    else if (d_residue) SYM_VW_LAUNCH(1);
+    else SYM_VW_LAUNCH(0);
+#undef SYM_VW_LAUNCH
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -46,15 +46,20 @@ __device__ __forceinline__ void copy_span(float *__restrict__ o, const float *sr
 // two right vectors then replace overlap[0 .. bs / 2).  Tables (twiddles, windows, W_1024 | W_2048) are read from global memory:
 // two wavefronts of this size class keep 50 KiB of LDS busy as it is.
 // `keep_below`: overlap[k] for k < keep_below is left as it is (the stale-state rebuild after a short tail; 0 otherwise).
-template <int R, bool FUSED, class LT>
+template <int R, int FUSED, class LT>
 __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec, const float *__restrict__ res, const cpx *__restrict__ tw_g,
                                                  const cpx *__restrict__ w_merge_g, const float *__restrict__ win_long,
                                                  const float *__restrict__ win_short, int flag, int pflag, int bs0, int bs1, float *ldsf,
-                                                 float *ovl, const LT &lt, int lane_i, float *__restrict__ o, bool emit, int keep_below) {
+                                                 float *ovl, const LT &lt, int lane_i, float *__restrict__ o, bool emit, int keep_below,
+                                                 const float *dbt) {
     constexpr int P = 512 * R, N = 2 * P;
     // (every global index below is UNSIGNED and 32 bits wide: a uniform base pointer plus a zero-extended lane offset is one SGPR pair +
     // one VGPR + an immediate in the instruction; signed 64-bit indices made the compiler keep a 64-bit address per access live across
     // the whole block loop -- 150 bytes of scratch and no second wavefront per SIMD)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (and everything derived from the lane index is a per-block value too, not a loop invariant held across the block loop)
+    asm volatile("" : "+v"(lane_i));
+#endif
     const unsigned lane = (unsigned)lane_i;
     // The table pointers are the same for every block, so the compiler forms the 64-bit address of every table access ONCE, in front of
     // the block loop, and keeps them all: ~100 address pairs, parked in AGPRs, one wavefront per SIMD.  Passing the (uniform) bases
@@ -71,13 +76,23 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
         // of the arithmetic: 2 x 2 x R / 2 float4 live instead of all sixteen, and at most 2 R twiddles from global memory at a time.
         const float4 *src = reinterpret_cast<const float4 *>(spec);
         const float4 *rs = reinterpret_cast<const float4 *>(res);
-        auto load_pair = [&](int sp, float4 (&a)[R / 2], float4 (&b)[R / 2]) {
+        // (FUSED 2: the table indices travel with the lines -- ya / yb, four bytes per float4 -- and the multiply happens where the
+        // pair is consumed, so the loads of the next pair stay in flight during this pair's arithmetic)
+        auto load_pair = [&](int sp, float4 (&a)[R / 2], float4 (&b)[R / 2], uint32_t (&ya)[R / 2], uint32_t (&yb)[R / 2]) {
 #pragma unroll
             for (int h = 0; h < R / 2; ++h) {
                 a[h] = ld_stream((src + ((lane + 64u * (unsigned)sp) * (unsigned)(R / 2) + (unsigned)h)));
                 b[h] = ld_stream((src + ((lane + 64u * (unsigned)(7 - sp)) * (unsigned)(R / 2) + (unsigned)h)));
             }
-            if constexpr (FUSED) {  // lib.rs:289-291: *f *= r
+            if constexpr (FUSED == 2) {
+                const uint32_t *ry = reinterpret_cast<const uint32_t *>(res);
+#pragma unroll
+                for (int h = 0; h < R / 2; ++h) {
+                    ya[h] = ry[(lane + 64u * (unsigned)sp) * (unsigned)(R / 2) + (unsigned)h];
+                    yb[h] = ry[(lane + 64u * (unsigned)(7 - sp)) * (unsigned)(R / 2) + (unsigned)h];
+                }
+            }
+            if constexpr (FUSED == 1) {  // lib.rs:289-291: *f *= r
 #pragma unroll
                 for (int h = 0; h < R / 2; ++h) {
                     const float4 qa = ld_stream((rs + ((lane + 64u * (unsigned)sp) * (unsigned)(R / 2) + (unsigned)h))), qb = ld_stream((rs + ((lane + 64u * (unsigned)(7 - sp)) * (unsigned)(R / 2) + (unsigned)h)));
@@ -88,10 +103,18 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
         };
         const int mirror = (int)((63u - lane) * 4u);
         float4 a[R / 2], b[R / 2], na[R / 2], nb[R / 2];
-        load_pair(0, a, b);
+        uint32_t ya[R / 2], yb[R / 2], nya[R / 2], nyb[R / 2];
+        load_pair(0, a, b, ya, yb);
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp) {
-            if (sp + 1 < 4) load_pair(sp + 1, na, nb);
+            if (sp + 1 < 4) load_pair(sp + 1, na, nb, nya, nyb);
+            if constexpr (FUSED == 2) {
+#pragma unroll
+                for (int h = 0; h < R / 2; ++h) {
+                    mul_floor_y(a[h], ya[h], dbt);
+                    mul_floor_y(b[h], yb[h], dbt);
+                }
+            }
 #pragma unroll
             for (int cc = 0; cc < R; ++cc) {
                 const int cm = R - 1 - cc;
@@ -108,6 +131,8 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
             for (int h = 0; h < R / 2; ++h) {
                 a[h] = na[h];
                 b[h] = nb[h];
+                ya[h] = nya[h];
+                yb[h] = nyb[h];
             }
         }
     }
@@ -271,7 +296,7 @@ __device__ __forceinline__ void vw2_transform_rt(int lane, float *ldsf, const c3
 // BIG0 (big-block instantiations): 0 = the short blocks are at most 2048 samples (group path), 2 / 4 = they are 4096 / 8192 samples
 // themselves.  One instantiation per case so that a kernel holds one copy of each block routine it needs and no other: everything a
 // routine keeps loop-invariant (addresses, table pointers) is live across the block loop, and the copies add up.
-template <bool FUSED, int MAXE1, int BIG0 = 0>
+template <int FUSED, int MAXE1, int BIG0 = 0>
 __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void vorbis_synth_wave2_kernel(
     DevTables tb, int e0, int e1, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
@@ -285,6 +310,11 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
     __shared__ __attribute__((aligned(16))) float wave_lds[kWaves][kWaveLds];
     __shared__ __attribute__((aligned(16))) float wave_ovl[kWaves][(1 << MAXE1) / 2];
     const int bs0 = 1 << e0, bs1 = 1 << e1;
+    __shared__ float db_lds[FUSED == 2 ? 256 : 1];  // FLOOR1_INVERSE_DB_TABLE (floor.rs:785-825), read where the residue is multiplied
+    if constexpr (FUSED == 2) {
+        for (int i = (int)threadIdx.x; i < 256; i += 64 * kWaves) db_lds[i] = tb.vorbis_floor1_db[i];  // (in front of the barriers below)
+    }
+    const float *dbt = db_lds;
     const float *t_twl, *t_wl, *t_tws, *t_ws;
     __shared__ __attribute__((aligned(16))) c32 lane_tab[kBig ? kLaneTabComplex : 1];
     if constexpr (kBig) {
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
     const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
     const uint8_t *f = flags + (size_t)chain * nb;
     const float *sp = spectra + (size_t)chain * spec_stride;
-    const float *rp = FUSED ? residue + (size_t)chain * spec_stride : nullptr;
+    const float *rp = res_at<FUSED>(residue, (size_t)chain * spec_stride);
     float *out = pcm + (size_t)chain * pcm_stride;
     const int pf0 = prev_flag_in[chain];
     // (the big-block instantiations read the FFT's lane twiddles from an LDS copy: 31 VGPRs less in a kernel that holds a whole
@@ -385,10 +415,33 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
     const VorbisPackedAt at0 = vorbis_packed_at(f, b, pf0, bs0, bs1, lane);
     uint32_t os_cur = at0.spec, op_cur = at0.pcm;
     float4 v[4], r[4];
+    const int lane_of_wave = lane;
     auto fetch = [&](uint32_t off, int fl, int n_blocks) {
         const size_t valid = (size_t)n_blocks << ((fl ? e1 : e0) - 1);
+        int lane = lane_of_wave;
+        if constexpr (kBig) {
+            // (the big-block instantiations: what the group path derives from the lane index -- load addresses, 64-bit -- would be
+            // kept as loop invariants across the block routine, which has no registers for them: recomputed per group instead)
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(lane));
+#endif
+        }
         multi_fetch(sp + off, valid, lane, v);
-        if constexpr (FUSED) multi_fetch(rp + off, valid, lane, r);
+        if constexpr (FUSED == 1) multi_fetch(rp + off, valid, lane, r);
+        if constexpr (FUSED == 2) {
+            const uint32_t *ry = reinterpret_cast<const uint32_t *>(res_at<2>(rp, off));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i4 = lane + 64 * q;
+                const uint32_t yw = (size_t)(4 * i4) < valid ? ry[i4] : 0u;
+                if constexpr (kBig) {  // (no prefetch in the big-block instantiations: multiplied here, one float4 at a time)
+                    mul_floor_y(v[q], yw, dbt);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    r[q].x = __uint_as_float(yw);
+                }
+            }
+        }
     };
     // (the big-block instantiations do not prefetch: 16 / 32 registers that would be live across a 2048-point transform)
     if (!kBig && glen > 0) fetch(os_cur, flag, glen);
@@ -439,11 +492,11 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
                 const cpx *twg = flag ? tw_long : tw_short;
                 constexpr int R1 = MAXE1 == 12 ? 2 : 4;
                 if (BIG0 == 0 || BIG0 == R1 || flag)
-                    vorbis_big_block<R1, FUSED>(sp + os_cur, FUSED ? rp + os_cur : nullptr, twg, tb.fft_merge + 480, win_long, win_short, flag, pflag, bs0,
-                                                bs1, ldsf, ovl, lt, lane, out + op_cur, emit, keep_below);
+                    vorbis_big_block<R1, FUSED>(sp + os_cur, res_at<FUSED>(rp, os_cur), twg, tb.fft_merge + 480, win_long, win_short, flag, pflag, bs0,
+                                                bs1, ldsf, ovl, lt, lane, out + op_cur, emit, keep_below, dbt);
                 else if constexpr (BIG0 != 0 && BIG0 != R1)
-                    vorbis_big_block<BIG0, FUSED>(sp + os_cur, FUSED ? rp + os_cur : nullptr, twg, tb.fft_merge + 480, win_long, win_short, flag, pflag, bs0,
-                                                  bs1, ldsf, ovl, lt, lane, out + op_cur, emit, keep_below);
+                    vorbis_big_block<BIG0, FUSED>(sp + os_cur, res_at<FUSED>(rp, os_cur), twg, tb.fft_merge + 480, win_long, win_short, flag, pflag, bs0,
+                                                  bs1, ldsf, ovl, lt, lane, out + op_cur, emit, keep_below, dbt);
                 if (rebuild) break;
                 op_cur += (uint32_t)((pflag ? bs1 : bs0) + bs) >> 2;
                 os_cur = os_next;
@@ -462,7 +515,8 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 x = v[q];
-            if constexpr (FUSED) {
+            if constexpr (FUSED == 2 && !kBig) mul_floor_y(x, __float_as_uint(r[q].x), dbt);
+            if constexpr (FUSED == 1) {
                 x.x *= r[q].x;
                 x.y *= r[q].y;
                 x.z *= r[q].z;
@@ -547,7 +601,7 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
 int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                         const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride,
                         const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in,
-                        float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg) {
+                        float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg, int floor_mode) {
     const size_t segs = (nb + seg - 1) / seg;
     const size_t items = n_chains * segs;
     const size_t kWaves = bs1_exp > 11 ? 2 : 4;
@@ -561,10 +615,16 @@ int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *
     hipLaunchKernelGGL((vorbis_synth_wave2_kernel<FUSED, MAXE1>), dim3((unsigned)grid), dim3(64 * kWaves), 0, ctx->stream, ctx->dev, bs0_exp, \
                        bs1_exp, tw_short, tw_long, win_short, win_long, d_spectra, d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, \
                        d_overlap_in, d_overlap_out, d_pcm, pcm_stride, nb, seg, (unsigned)segs, (unsigned)items)
+    const int mode = floor_mode == 2 ? 2 : (d_residue ? 1 : 0);
+#define SYM_VW2_MODES(LAUNCH) do { if (mode == 2) { LAUNCH(2); } else if (mode == 1) { LAUNCH(1); } else { LAUNCH(0); } } while (0)
     if (bs1_exp <= 10) {
-        if (d_residue) SYM_VW2_LAUNCH(true, 10); else SYM_VW2_LAUNCH(false, 10);
+#define SYM_VW2_10(FUSED) SYM_VW2_LAUNCH(FUSED, 10)
+        SYM_VW2_MODES(SYM_VW2_10);
+#undef SYM_VW2_10
     } else if (bs1_exp == 11) {
-        if (d_residue) SYM_VW2_LAUNCH(true, 11); else SYM_VW2_LAUNCH(false, 11);
+#define SYM_VW2_11(FUSED) SYM_VW2_LAUNCH(FUSED, 11)
+        SYM_VW2_MODES(SYM_VW2_11);
+#undef SYM_VW2_11
     } else {
         // the big-block instantiations: by long size and by whether the short size is big as well
         const int big0 = bs0_exp <= 11 ? 0 : (bs0_exp == 12 ? 2 : 4);
@@ -576,9 +636,10 @@ int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *
         else if (big0 == 2) SYM_VW2_LAUNCH3(FUSED, 13, 2);                                      \
         else SYM_VW2_LAUNCH3(FUSED, 13, 4);                                                     \
     } while (0)
-        if (d_residue) SYM_VW2_BIG(true); else SYM_VW2_BIG(false);
+        SYM_VW2_MODES(SYM_VW2_BIG);
 #undef SYM_VW2_BIG
     }
+#undef SYM_VW2_MODES
 #undef SYM_VW2_LAUNCH
 #undef SYM_VW2_LAUNCH3
     SYM_GPU(ctx, hipGetLastError());

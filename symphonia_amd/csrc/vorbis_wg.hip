@@ -23,25 +23,35 @@ namespace symaccel {
 namespace {
 
 constexpr int kWgWaves = 4;
+// floats of FFT / group work area per wavefront: a group's 2048 output samples, or the exchange layouts of fft_wave_multi (T1M: 722
+// complex values, T2: 520) -- less than the kWaveLds of the kernels that run the 512-point T1 layout, which makes room for the
+// dB table of the fused floor x residue load inside this kernel's 2 x 80 KiB
+constexpr int kWgWaveLds = 2176;
+static_assert(2 * (7 + 462 + 36 * 7 + 1) <= kWgWaveLds && 2048 <= kWgWaveLds, "work area");
 
 template <int S>
 __device__ __forceinline__ int wgv_slot(int e) { return e + e / S; }
 
 // One block of bs = 2048 S samples, by the whole workgroup.  `area`: >= 512 S + 512 complex slots (staging with padding, later the
-// left half of the output: 1024 S floats); `work`: the four FFT work areas (kWaveLds floats each; a sub-transform's results are
+// left half of the output: 1024 S floats); `work`: the four FFT work areas (kWgWaveLds floats each; a sub-transform's results are
 // exchanged through its own work area, idle by then); `ldsf`: this wavefront's work area; `ovl`: dsp.rs:125.  Four barriers.
 // Every table value the block needs is requested FIRST, in front of the staging: the loads then travel while the workgroup stages
 // and meets, instead of being exposed one barrier interval at a time (the kernel is bound by the latency of a block's steps).
 // Barriers inside: every wavefront of the workgroup must call this with the same arguments.
 // `keep_below`: overlap[k] for k < keep_below is left as it is (the stale-state rebuild after a short tail; 0 otherwise).
-template <int S, bool FUSED, class LT>
+template <int S, int FUSED, class LT>
 __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float *__restrict__ spec, const float *__restrict__ res,
                                                 const cpx *__restrict__ tw_g, const float *__restrict__ win_long,
                                                 const float *__restrict__ win_short, int flag, int pflag, int bs0, int bs1, c32 *area,
                                                 float *work, float *ldsf, float *ovl, const LT &lt, int tid, float *__restrict__ o, bool emit,
                                                 int keep_below, float4 (&pre)[S], bool pre_valid, const float *__restrict__ next_spec,
-                                                const float *__restrict__ next_res) {
+                                                const float *__restrict__ next_res, const float *dbt) {
     static_assert(S == 2 || S == 4, "two or four 512-point sub-transforms");
+    // (what the routine derives from the thread index -- 64-bit load / store addresses, LDS offsets -- would be kept across the
+    // block loop as loop invariants, and the routine has no registers for them: recomputed per block, a dozen VALU instructions)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(tid));
+#endif
     constexpr int P = 512 * S, N = 2 * P;  // FFT points; lines = samples of one half of the block
     const int lane = tid & 63, wave = tid >> 6;
     float *af = reinterpret_cast<float *>(area);
@@ -64,7 +74,7 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
         const float4 *r4 = reinterpret_cast<const float4 *>(rs_);
 #pragma unroll
         for (int j = 0; j < S; ++j) v[j] = ld_stream(s4 + tid + 256 * j);
-        if constexpr (FUSED) {
+        if constexpr (FUSED == 1) {
 #pragma unroll
             for (int j = 0; j < S; ++j) {
                 const float4 q = ld_stream(r4 + tid + 256 * j);
@@ -72,6 +82,14 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
                 v[j].y *= q.y;
                 v[j].z *= q.z;
                 v[j].w *= q.w;
+            }
+        }
+        if constexpr (FUSED == 2) {
+            const uint32_t *ry = reinterpret_cast<const uint32_t *>(rs_);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                mul_floor_y(v[j], ry[tid + 256 * j], dbt);
+                __builtin_amdgcn_sched_barrier(0);  // (one float4's table values at a time: 256 VGPRs are in use)
             }
         }
     };
@@ -130,7 +148,7 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
     for (int i = 0; i < 2; ++i) {
         const int p = 128 * wave + 64 * i + lane;
 #pragma unroll
-        for (int j = 0; j < S; ++j) val[i][j] = reinterpret_cast<const c32 *>(work + (size_t)j * kWaveLds)[p];
+        for (int j = 0; j < S; ++j) val[i][j] = reinterpret_cast<const c32 *>(work + (size_t)j * kWgWaveLds)[p];
         if constexpr (S == 2) {
             bfly(val[i][0], val[i][1], c_mul(val[i][1], w1[i]));  // X[p], X[p + 512]
         } else {
@@ -226,7 +244,7 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
 
 // MAXE1: the long-block exponent (12 / 13).  BIG0: 0 = the short blocks have at most 2048 samples (groups, wavefront 0), 2 / 4 = they
 // have 4096 / 8192 samples themselves (S of their cooperative transform).
-template <bool FUSED, int MAXE1, int BIG0>
+template <int FUSED, int MAXE1, int BIG0>
 __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     DevTables tb, int e0, int e1, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
@@ -236,7 +254,9 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     constexpr int S1 = (1 << MAXE1) / 2048;  // 2 / 4
     constexpr int PL = 512 * S1;
     __shared__ __attribute__((aligned(16))) c32 area[PL + PL / 2];  // staging (P + P / S slots, S >= 2) -> exchange -> left half
-    __shared__ __attribute__((aligned(16))) float wave_lds[kWgWaves][kWaveLds];
+    __shared__ __attribute__((aligned(16))) float wave_lds[kWgWaves][kWgWaveLds];
+    __shared__ float db_lds[FUSED == 2 ? 256 : 1];  // FLOOR1_INVERSE_DB_TABLE for the fused floor x residue load
+    if constexpr (FUSED == 2) db_lds[threadIdx.x] = tb.vorbis_floor1_db[threadIdx.x];  // (256 threads; the barriers of the first block come first)
     __shared__ __attribute__((aligned(16))) float ovl[(1 << MAXE1) / 2];
     __shared__ __attribute__((aligned(16))) c32 lane_tab[kLaneTabComplex];  // the FFT's lane twiddles, read at the point of use (31 VGPRs)
     fill_lane_tables_lds(tb, lane_tab, (int)threadIdx.x, 64 * kWgWaves);
@@ -249,7 +269,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     const unsigned b_begin = seg * seg_len, b_end = min(b_begin + seg_len, nb);
     const uint8_t *f = flags + (size_t)chain * nb;
     const float *sp = spectra + (size_t)chain * spec_stride;
-    const float *rp = FUSED ? residue + (size_t)chain * spec_stride : nullptr;
+    const float *rp = res_at<FUSED>(residue, (size_t)chain * spec_stride);
     float *out = pcm + (size_t)chain * pcm_stride;
     const int pf0 = prev_flag_in[chain];
     const LaneTablesLds lt = lane_tables_lds(tb, lane_tab, lane);
@@ -348,14 +368,14 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
             if (BIG0 == 0 || BIG0 == S1 || flag) {
                 // (a block of the long size; the next one is prefetched if it has the same size -- the common case)
                 const bool next_same = glen_next > 0 && (flag_next ? e1 : e0) == e;
-                vorbis_wg_block<S1, FUSED>(tb, sp + os_cur, FUSED ? rp + os_cur : nullptr, twg, win_long, win_short, flag, pflag, bs0, bs1, area,
+                vorbis_wg_block<S1, FUSED>(tb, sp + os_cur, res_at<FUSED>(rp, os_cur), twg, win_long, win_short, flag, pflag, bs0, bs1, area,
                                            &wave_lds[0][0], ldsf, ovl, lt, tid, out + op_cur, emit, keep_below, pre, pre_valid,
-                                           next_same ? sp + os_next : nullptr, (FUSED && next_same) ? rp + os_next : nullptr);
+                                           next_same ? sp + os_next : nullptr, next_same ? res_at<FUSED>(rp, os_next) : nullptr, db_lds);
                 pre_valid = next_same;
             } else if constexpr (BIG0 != 0 && BIG0 != S1) {
                 float4 tmp[BIG0];
-                vorbis_wg_block<BIG0, FUSED>(tb, sp + os_cur, FUSED ? rp + os_cur : nullptr, twg, win_long, win_short, flag, pflag, bs0, bs1, area,
-                                             &wave_lds[0][0], ldsf, ovl, lt, tid, out + op_cur, emit, keep_below, tmp, false, nullptr, nullptr);
+                vorbis_wg_block<BIG0, FUSED>(tb, sp + os_cur, res_at<FUSED>(rp, os_cur), twg, win_long, win_short, flag, pflag, bs0, bs1, area,
+                                             &wave_lds[0][0], ldsf, ovl, lt, tid, out + op_cur, emit, keep_below, tmp, false, nullptr, nullptr, db_lds);
                 pre_valid = false;
             }
             if (rebuild) break;
@@ -396,7 +416,15 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
                 float4 v[4];
                 const size_t valid = (size_t)mine << (e - 1);
                 multi_fetch(sp + os_mine, valid, lane, v);
-                if constexpr (FUSED) {
+                if constexpr (FUSED == 2) {
+                    const uint32_t *ry = reinterpret_cast<const uint32_t *>(res_at<2>(rp, os_mine));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i4 = lane + 64 * q;
+                        mul_floor_y(v[q], (size_t)(4 * i4) < valid ? ry[i4] : 0u, db_lds);
+                    }
+                }
+                if constexpr (FUSED == 1) {
                     float4 r[4];
                     multi_fetch(rp + os_mine, valid, lane, r);
 #pragma unroll
@@ -487,7 +515,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
 int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                      const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
                      const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
-                     size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg) {
+                     size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg, int floor_mode) {
     // (the 4096 / 8192 pair would need both cooperative block routines in one kernel: 256 VGPRs and scratch -- it stays on
     // vorbis_synth_wave2_kernel, launch_vorbis in vorbis.hip)
     if ((bs1_exp != 12 && bs1_exp != 13) || (bs0_exp == 12 && bs1_exp == 13)) return SYMACCEL_ERR_INVALID_ARG;
@@ -514,7 +542,7 @@ int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_
         } else if (big0 == 0) SYM_VWG_LAUNCH(FUSED, 13, 0);                                   \
         else SYM_VWG_LAUNCH(FUSED, 13, 4);                                                    \
     } while (0)
-    if (d_residue) SYM_VWG_BIG(true); else SYM_VWG_BIG(false);
+    if (floor_mode == 2) SYM_VWG_BIG(2); else if (d_residue) SYM_VWG_BIG(1); else SYM_VWG_BIG(0);
 #undef SYM_VWG_BIG
 #undef SYM_VWG_12
 #undef SYM_VWG_LAUNCH
