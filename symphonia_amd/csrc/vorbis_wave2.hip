@@ -104,10 +104,24 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
         const int mirror = (int)((63u - lane) * 4u);
         float4 a[R / 2], b[R / 2], na[R / 2], nb[R / 2];
         uint32_t ya[R / 2], yb[R / 2], nya[R / 2], nyb[R / 2];
+        // (the pre-twiddles of a pair come from global memory as well: requested one pair ahead, with the lines.  Requesting the first
+        // pair of the NEXT block from inside this one as well was measured: no gain, 18 registers -- profiles/r04m_vorbis_big_blocks.txt)
+        c32 pta[R], ptb[R], npta[R], nptb[R];
+        auto load_tw = [&](int sp, c32 (&ta)[R], c32 (&tb_)[R]) {
+#pragma unroll
+            for (int cc = 0; cc < R; ++cc) {
+                ta[cc] = tw[(unsigned)R * (lane + 64u * (unsigned)sp) + (unsigned)cc];
+                tb_[cc] = tw[(unsigned)R * (lane + 64u * (unsigned)(7 - sp)) + (unsigned)cc];
+            }
+        };
         load_pair(0, a, b, ya, yb);
+        load_tw(0, pta, ptb);
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp) {
-            if (sp + 1 < 4) load_pair(sp + 1, na, nb, nya, nyb);
+            if (sp + 1 < 4) {
+                load_pair(sp + 1, na, nb, nya, nyb);
+                load_tw(sp + 1, npta, nptb);
+            }
             if constexpr (FUSED == 2) {
 #pragma unroll
                 for (int h = 0; h < R / 2; ++h) {
@@ -123,8 +137,8 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
                 const float mir_lo = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(odd_b)));
                 const float mir_hi = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(odd_a)));
                 const float ev_lo = (cc & 1) ? a[cc >> 1].z : a[cc >> 1].x, ev_hi = (cc & 1) ? b[cc >> 1].z : b[cc >> 1].x;
-                x[cc][sp] = pre_twiddle(ev_lo, mir_lo, tw[(unsigned)R * (lane + 64u * (unsigned)sp) + (unsigned)cc]);
-                x[cc][7 - sp] = pre_twiddle(ev_hi, mir_hi, tw[(unsigned)R * (lane + 64u * (unsigned)(7 - sp)) + (unsigned)cc]);
+                x[cc][sp] = pre_twiddle(ev_lo, mir_lo, pta[cc]);
+                x[cc][7 - sp] = pre_twiddle(ev_hi, mir_hi, ptb[cc]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -134,24 +148,56 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
                 ya[h] = nya[h];
                 yb[h] = nyb[h];
             }
+#pragma unroll
+            for (int cc = 0; cc < R; ++cc) {
+                pta[cc] = npta[cc];
+                ptb[cc] = nptb[cc];
+            }
         }
     }
     // the R sub-transforms and the last stages (imdct_generic.hip: fft_big_regs, restated here on the global twiddle table)
-#pragma unroll
-    for (int r = 0; r < R; ++r) fft_wave_multi(x[R == 2 ? r : ((r & 1) << 1 | (r >> 1))], lane_i, lds, lt, 9);
     auto blk = [](int r) { return R == 2 ? r : ((r & 1) << 1 | (r >> 1)); };
     const c32 *wm = reinterpret_cast<const c32 *>(w_merge_g);
-    // (the merge twiddles come from global memory; left alone the scheduler requests all 8 + 16 of them at once and keeps them in
-    // 48 more registers next to the transform: four at a time, with a scheduling fence between the groups)
+    if constexpr (R == 2) {
+        // 4096-sample blocks have the registers to software-pipeline the table loads: the merge twiddles are requested in front of the
+        // sub-transforms, the post-twiddles of sub-block 0 in front of the merge arithmetic, those of sub-block 1 in front of the first
+        // post-twiddle -- every round trip to the L2 runs under arithmetic instead of being waited for (this kernel runs two wavefronts
+        // per SIMD: what one wavefront waits for is not hidden by others).
+        c32 wmv[8], pt0[8], pt1[8];
 #pragma unroll
-    for (int r = 0; r < R; r += 2)
+        for (int B = 0; B < 8; ++B) wmv[B] = wm[64u * (unsigned)B + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        fft_wave_multi(x[0], lane_i, lds, lt, 9);
+        fft_wave_multi(x[1], lane_i, lds, lt, 9);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int B0 = 0; B0 < 8; B0 += 4) {
+        for (int B = 0; B < 8; ++B) pt0[B] = tw[64u * (unsigned)B + lane];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int B = B0; B < B0 + 4; ++B) bfly(x[blk(r)][B], x[blk(r + 1)][B], c_mul(x[blk(r + 1)][B], wm[64u * (unsigned)B + lane]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    if constexpr (R == 4) {
+        for (int B = 0; B < 8; ++B) bfly(x[0][B], x[1][B], c_mul(x[1][B], wmv[B]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int B = 0; B < 8; ++B) pt1[B] = tw[512u + 64u * (unsigned)B + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int B = 0; B < 8; ++B) x[0][B] = post_twiddle(x[0][B], pt0[B]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int B = 0; B < 8; ++B) x[1][B] = post_twiddle(x[1][B], pt1[B]);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) fft_wave_multi(x[blk(r)], lane_i, lds, lt, 9);
+        // (the merge twiddles come from global memory; left alone the scheduler requests all 8 + 16 of them at once and keeps them in
+        // 48 more registers next to the transform: four at a time, with a scheduling fence between the groups)
+#pragma unroll
+        for (int r = 0; r < R; r += 2)
+#pragma unroll
+            for (int B0 = 0; B0 < 8; B0 += 4) {
+#pragma unroll
+                for (int B = B0; B < B0 + 4; ++B) bfly(x[blk(r)][B], x[blk(r + 1)][B], c_mul(x[blk(r + 1)][B], wm[64u * (unsigned)B + lane]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -160,16 +206,16 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
                 for (int B = B0; B < B0 + 4; ++B) bfly(x[blk(r)][B], x[blk(r + 2)][B], c_mul(x[blk(r + 2)][B], wm[512u + 512u * (unsigned)r + 64u * (unsigned)B + lane]));
                 __builtin_amdgcn_sched_barrier(0);
             }
+        // post-twiddle once, in place (mdct.rs:104 / 123): the rounds below only pick components
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int B0 = 0; B0 < 8; B0 += 4) {
+#pragma unroll
+                for (int B = B0; B < B0 + 4; ++B) x[blk(r)][B] = post_twiddle(x[blk(r)][B], tw[512u * (unsigned)r + 64u * (unsigned)B + lane]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
     }
-    // post-twiddle once, in place (mdct.rs:104 / 123): the rounds below only pick components
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int B0 = 0; B0 < 8; B0 += 4) {
-#pragma unroll
-            for (int B = B0; B < B0 + 4; ++B) x[blk(r)][B] = post_twiddle(x[blk(r)][B], tw[512u * (unsigned)r + 64u * (unsigned)B + lane]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
     const int bs = 4 * P;
     const float *win = (flag && pflag) ? win_long : win_short;  // dsp.rs:83
     const int start = (bs1 - bs0) / 4;
@@ -177,8 +223,23 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
     if (emit && pflag && !flag) {
         for (unsigned k = 4u * lane; k < (unsigned)start; k += 256u) st_stream(reinterpret_cast<float4 *>((o + (k))), *reinterpret_cast<const float4 *>(ovl + k));
     }
+    // The common window case (the block and its predecessor have this size), R = 2: a round's window values -- 4 + 4 float4 per
+    // lane, from global memory -- are requested in front of the round's scatter and arrive while it runs; the generic loop below
+    // waits for every chunk's two loads in turn (eight exposed round trips to the L2 per block).
+    const bool same_fast = R == 2 && emit && pflag == flag;
+    float4 wfv[R == 2 ? 4 : 1], wrv[R == 2 ? 4 : 1];
 #pragma unroll
     for (int round = 0; round < 4; ++round) {
+        if constexpr (R == 2) {
+            if (same_fast && round < 2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned k = (unsigned)(round * P) + 4u * lane + 256u * (unsigned)c;
+                    wfv[c] = *reinterpret_cast<const float4 *>(win + k);
+                    wrv[c] = *reinterpret_cast<const float4 *>(win + ((unsigned)(N - 4) - k));
+                }
+            }
+        }
         // vector `round` -> the work area (mdct.rs:94-137: every FFT bin gives one sample to each of the four vectors)
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -201,7 +262,18 @@ __device__ __forceinline__ void vorbis_big_block(const float *__restrict__ spec,
             }
         wave_sync();
         if (round < 2) {
-            if (emit) {
+            if (same_fast) {
+                if constexpr (R == 2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned kk = 4u * lane + 256u * (unsigned)c, k = (unsigned)(round * P) + kk;
+                        const float4 y = *reinterpret_cast<const float4 *>(ldsf + kk), a = *reinterpret_cast<const float4 *>(ovl + k);
+                        const float4 wf = wfv[c], wr = wrv[c];
+                        st_stream(reinterpret_cast<float4 *>(o + k),
+                                  make_float4(a.x * wr.w + y.x * wf.x, a.y * wr.z + y.y * wf.y, a.z * wr.y + y.z * wf.z, a.w * wr.x + y.w * wf.w));
+                    }
+                }
+            } else if (emit) {
                 const int k0 = round * P;  // the work area holds left[k0 .. k0 + P)
                 for (unsigned kk = 4u * lane; kk < (unsigned)P; kk += 256u) {
                     const unsigned k = (unsigned)k0 + kk;
@@ -509,6 +581,12 @@ __global__ __launch_bounds__(64 * vw2_waves<MAXE1>(), MAXE1 <= 10 ? 3 : 2) void 
         }
         if constexpr (BIG0 == 0) {
 
+        // (big-block instantiations: the group path's lane-derived addresses are per-group values, not loop invariants that sit in
+        // registers through the block routine -- see `fetch`)
+        int lane = lane_of_wave;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (kBig) asm volatile("" : "+v"(lane));
+#endif
         // ---- the group's lines -> LDS (natural order), multiplied by the residue on the way (lib.rs:289-291: *f *= r)
         const int pad = kBig ? 0 : multi_pad(logp), ostride = bs + pad;  // (the run-time form of the big-block instantiations is unpadded)
         if constexpr (kBig) fetch(os_cur, flag, glen);
