@@ -215,6 +215,9 @@ int launch_vorbis_wave(symaccel_ctx *ctx, const cpx *tw_short, const cpx *tw_lon
 #ifndef SYM_VORBIS_WG
 #define SYM_VORBIS_WG 1
 #endif
+#ifndef SYM_VORBIS_WG_SHARED
+#define SYM_VORBIS_WG_SHARED 1  // vorbis_wg.hip: exchange / group work areas inside the staging area, three workgroups per CU
+#endif
 int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_short, const cpx *tw_long, const float *win_short,
                      const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
                      const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,

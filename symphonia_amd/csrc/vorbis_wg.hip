@@ -28,6 +28,14 @@ constexpr int kWgWaves = 4;
 // dB table of the fused floor x residue load inside this kernel's 2 x 80 KiB
 constexpr int kWgWaveLds = 2176;
 static_assert(2 * (7 + 462 + 36 * 7 + 1) <= kWgWaveLds && 2048 <= kWgWaveLds, "work area");
+// SYM_VORBIS_WG_SHARED (build knob) 1: the wavefronts' FFT exchange areas and the short-block groups' work areas live INSIDE the
+// block's staging area (two more barriers per block: between the gathers and the first exchange, between the merge's reads and
+// the left half's writes; three groups of short blocks in flight instead of four): 46 KiB of LDS instead of 80, three workgroups
+// per CU instead of two.  0: separate arrays, as measured in rounds 3-4 (profiles/r04m_vorbis_big_blocks.txt).
+// (default in symaccel_internal.h)
+constexpr int kWgGroupWaves = SYM_VORBIS_WG_SHARED ? 3 : 4;          // groups of short blocks in flight
+constexpr int kWgFftWork = SYM_VORBIS_WG_SHARED ? 1456 : kWgWaveLds;  // floats of FFT exchange area per wavefront (T1M: 1444)
+static_assert(2 * (7 + 462 + 36 * 7 + 1) <= kWgFftWork && 1024 <= kWgFftWork, "exchange area");
 
 template <int S>
 __device__ __forceinline__ int wgv_slot(int e) { return e + e / S; }
@@ -111,6 +119,7 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
             x[s] = pre_twiddle(af[2 * wgv_slot<S>(e)], af[2 * wgv_slot<S>(P - 1 - e) + 1], twp[s]);
         }
     }
+    if constexpr (SYM_VORBIS_WG_SHARED) wg_sync_lds();  // every gather is done: the exchange areas (inside the staging area) may be written
     // the twiddles of the last stages and of the post-twiddle: requested here, they travel during the sub-transform
     c32 tpost[2][S], w1[2], w2a[2], w2b[2];
 #pragma unroll
@@ -148,7 +157,11 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
     for (int i = 0; i < 2; ++i) {
         const int p = 128 * wave + 64 * i + lane;
 #pragma unroll
-        for (int j = 0; j < S; ++j) val[i][j] = reinterpret_cast<const c32 *>(work + (size_t)j * kWgWaveLds)[p];
+        for (int j = 0; j < S; ++j) val[i][j] = reinterpret_cast<const c32 *>(work + (size_t)j * kWgFftWork)[p];
+    }
+    if constexpr (SYM_VORBIS_WG_SHARED) wg_sync_lds();  // every operand is in registers: the left half may overwrite the exchange areas
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
         if constexpr (S == 2) {
             bfly(val[i][0], val[i][1], c_mul(val[i][1], w1[i]));  // X[p], X[p + 512]
         } else {
@@ -245,7 +258,7 @@ __device__ __forceinline__ void vorbis_wg_block(const DevTables &tb, const float
 // MAXE1: the long-block exponent (12 / 13).  BIG0: 0 = the short blocks have at most 2048 samples (groups, wavefront 0), 2 / 4 = they
 // have 4096 / 8192 samples themselves (S of their cooperative transform).
 template <int FUSED, int MAXE1, int BIG0>
-__global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
+__global__ __launch_bounds__(64 * kWgWaves, SYM_VORBIS_WG_SHARED ? 3 : 2) void vorbis_synth_wg_kernel(
     DevTables tb, int e0, int e1, const cpx *__restrict__ tw_short, const cpx *__restrict__ tw_long,
     const float *__restrict__ win_short, const float *__restrict__ win_long, const float *__restrict__ spectra,
     const float *__restrict__ residue, size_t spec_stride, const uint8_t *__restrict__ flags, const int32_t *__restrict__ prev_flag_in,
@@ -253,8 +266,18 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     float *__restrict__ pcm, size_t pcm_stride, unsigned nb, unsigned seg_len, unsigned segs_per_chain) {
     constexpr int S1 = (1 << MAXE1) / 2048;  // 2 / 4
     constexpr int PL = 512 * S1;
+#if SYM_VORBIS_WG_SHARED
+    // staging (P + P / S slots, S >= 2) -> the wavefronts' exchange areas -> left half; or the work areas of three groups of short blocks
+    constexpr int kAreaFloats = 2 * (PL + PL / 2) > kWgGroupWaves * kWgWaveLds ? 2 * (PL + PL / 2) : kWgGroupWaves * kWgWaveLds;
+    static_assert(kWgWaves * kWgFftWork <= kAreaFloats, "exchange areas inside the staging area");
+    __shared__ __attribute__((aligned(16))) float area_f[kAreaFloats];
+    c32 *area = reinterpret_cast<c32 *>(area_f);
+    float *wave_base = area_f;
+#else
     __shared__ __attribute__((aligned(16))) c32 area[PL + PL / 2];  // staging (P + P / S slots, S >= 2) -> exchange -> left half
-    __shared__ __attribute__((aligned(16))) float wave_lds[kWgWaves][kWgWaveLds];
+    __shared__ __attribute__((aligned(16))) float wave_lds_arr[kWgWaves][kWgWaveLds];
+    float *wave_base = &wave_lds_arr[0][0];
+#endif
     __shared__ float db_lds[FUSED == 2 ? 256 : 1];  // FLOOR1_INVERSE_DB_TABLE for the fused floor x residue load
     if constexpr (FUSED == 2) db_lds[threadIdx.x] = tb.vorbis_floor1_db[threadIdx.x];  // (256 threads; the barriers of the first block come first)
     __shared__ __attribute__((aligned(16))) float ovl[(1 << MAXE1) / 2];
@@ -262,7 +285,8 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
     fill_lane_tables_lds(tb, lane_tab, (int)threadIdx.x, 64 * kWgWaves);
     const int bs0 = 1 << e0, bs1 = 1 << e1;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *ldsf = wave_lds[wave];
+    float *ldsf = wave_base + wave * kWgWaveLds;    // a group's work area (wave < kWgGroupWaves)
+    float *fft_ldsf = wave_base + wave * kWgFftWork;  // the wavefront's FFT exchange area inside a cooperative block
     c32 *lds = reinterpret_cast<c32 *>(ldsf);
     const unsigned item = blockIdx.x;
     const unsigned chain = item / segs_per_chain, seg = item % segs_per_chain;
@@ -369,13 +393,13 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
                 // (a block of the long size; the next one is prefetched if it has the same size -- the common case)
                 const bool next_same = glen_next > 0 && (flag_next ? e1 : e0) == e;
                 vorbis_wg_block<S1, FUSED>(tb, sp + os_cur, res_at<FUSED>(rp, os_cur), twg, win_long, win_short, flag, pflag, bs0, bs1, area,
-                                           &wave_lds[0][0], ldsf, ovl, lt, tid, out + op_cur, emit, keep_below, pre, pre_valid,
+                                           wave_base, fft_ldsf, ovl, lt, tid, out + op_cur, emit, keep_below, pre, pre_valid,
                                            next_same ? sp + os_next : nullptr, next_same ? res_at<FUSED>(rp, os_next) : nullptr, db_lds);
                 pre_valid = next_same;
             } else if constexpr (BIG0 != 0 && BIG0 != S1) {
                 float4 tmp[BIG0];
                 vorbis_wg_block<BIG0, FUSED>(tb, sp + os_cur, res_at<FUSED>(rp, os_cur), twg, win_long, win_short, flag, pflag, bs0, bs1, area,
-                                             &wave_lds[0][0], ldsf, ovl, lt, tid, out + op_cur, emit, keep_below, tmp, false, nullptr, nullptr, db_lds);
+                                             wave_base, fft_ldsf, ovl, lt, tid, out + op_cur, emit, keep_below, tmp, false, nullptr, nullptr, db_lds);
                 pre_valid = false;
             }
             if (rebuild) break;
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
             // transform FFT), one per wavefront.  The groups' transforms and the overlap-adds inside a group are independent; a
             // group's FIRST block laps with the last block of the group before it, which sits in the neighbour's work area.
             int gl0 = glen, gl1 = 0, gl2 = 0, gl3 = 0, ng = 1, run_blocks = glen;
-            while (ng < kWgWaves && glen_next > 0 && flag_next == 0) {
+            while (ng < kWgGroupWaves && glen_next > 0 && flag_next == 0) {
                 if (ng == 1) gl1 = glen_next; else if (ng == 2) gl2 = glen_next; else gl3 = glen_next;
                 ++ng;
                 run_blocks += glen_next;
@@ -483,7 +507,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 2) void vorbis_synth_wg_kernel(
                 }
             } else if (wave < ng) {
                 // a later group's first block against the last block of the group before it (short -> short)
-                const float *prev_right = &wave_lds[wave - 1][0] + (size_t)(prev_len - 1) * bs + half;
+                const float *prev_right = wave_base + (wave - 1) * kWgWaveLds + (size_t)(prev_len - 1) * bs + half;
                 ola(out + op_cur + first_len + (size_t)(before - 1) * half, prev_right, ldsf, win_short, half, true);
             }
             wg_sync_lds();  // `overlap` and the neighbours' right halves have been read
