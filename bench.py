@@ -193,6 +193,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
         def step():
             v.synth(spectra, d_flags, prev[0], overlap[0], pcm_stride, pcm, state_out=(prev[1], overlap[1]))
         step.input = spectra
+        step.vorbis = {"flags": flags, "spectrum": lambda: spectra, "pcm": pcm, "pcm_stride": pcm_stride, "used": po[:, -1]}
         bytes_alg = int(4 * (so[:, -1].sum() + po[:, -1].sum()))
         return step, nch * nb // 8, "frames", bytes_alg, {
             "workload": "Vorbis 2048/256 mixed block sizes, 8 ch, %d blocks (%d chains x %d)" % (nch * nb // 8, nch, nb),
@@ -242,6 +243,8 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             else:
                 v.synth(spectrum, d_flags, prev[0], overlap[0], pcm_stride, pcm, state_out=(prev[1], overlap[1]))
         step.input = residue
+        step.vorbis = {"flags": flags, "pcm": pcm, "pcm_stride": pcm_stride, "used": po[:, -1], "residue": residue, "so": so,
+                       "classes": [(xs, mult, ys, n, flag) for (xs, mult, ys, n, offs, cnt), flag in zip(classes, (1, 0))]}
         bytes_alg = int(4 * (so[:, -1].sum() + po[:, -1].sum()) + 4 * n_post_words)  # residue lines + PCM samples + posts and offsets
         return step, nch * nb // 8, "frames", bytes_alg, {
             "workload": "Vorbis 2048/256, 8 ch, %d blocks (%d chains x %d) from floor-1 posts + residue: %s" % (
@@ -427,6 +430,8 @@ def verify_sampled_chains(name, step, torch, sync):
     a zero state: the carried state of these codecs depends on the previous frame's (MP3: two granules') INPUT alone
     (SURVEY 8e).  Windows: the chain's start, the 256-frame workgroup-walk boundary, a segment boundary, the chain's end."""
     import oracle
+    if name in ("vorbis", "vorbisf", "vorbisf2"):
+        return verify_vorbis_chains(name, step, torch, sync)
     if name == "aac":
         (coeffs, side), halo = step.aac, 1
     elif name == "mp3":
@@ -455,6 +460,44 @@ def verify_sampled_chains(name, step, torch, sync):
     if bad:
         raise RuntimeError("bench: the timed %s batch differs from the oracle in %d of %d sampled samples" % (name, bad, checked))
     return {"checker": "oracle/symoracle.c (CPU restatement), outside the timed region", "chains": chains, "frame_windows": wins,
+            "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
+
+
+def verify_vorbis_chains(name, step, torch, sync):
+    """The Vorbis workloads: every step decodes the batch from a fresh stream start, so the PCM the timed steps left IS the result to
+    check -- whole sampled chains against the oracle (floor-1 curve x residue for the posts pipelines, lib.rs:289-291, then
+    DspChannel::synth).  Packed layouts make frame windows awkward; a chain is 4096 blocks and takes the oracle a fraction of a second."""
+    import oracle
+    v = step.vorbis
+    step()
+    sync()
+    flags = v["flags"]
+    nch = flags.shape[0]
+    chains = sorted({0, nch - 1})
+    checked, bad = 0, 0
+    for c in chains:
+        if "classes" in v:
+            res = v["residue"][c].cpu().numpy()
+            spec = np.zeros_like(res)
+            so = v["so"][c]
+            for xs, mult, ys, n, flag in v["classes"]:
+                where = np.argwhere(flags == flag)
+                mine = np.nonzero(where[:, 0] == c)[0]
+                ys_c = ys[torch.from_numpy(mine).to(ys.device)].cpu().numpy() if len(mine) else np.zeros((0, len(xs)), np.uint32)
+                for y, (_, b) in zip(ys_c, where[mine]):
+                    o = int(so[b])
+                    spec[o:o + n] = oracle.vorbis_floor1(xs, y, mult, n) * res[o:o + n]
+        else:
+            spec = v["spectrum"]()[c].cpu().numpy()
+        want = oracle.vorbis_synth(8, 11, spec[None], flags[c:c + 1], np.full(1, -1, np.int32), np.zeros((1, 1024), np.float32), v["pcm_stride"])[0][0]
+        used = int(v["used"][c])
+        first = (2048 if flags[c, 0] else 256) // 2  # a stream's first block owns n / 2 slots and leaves them untouched (lib.rs:298-303)
+        got = v["pcm"][c, first:used].cpu().numpy()
+        bad += int((got != want[first:used]).sum())
+        checked += got.size
+    if bad:
+        raise RuntimeError("bench: the timed %s batch differs from the oracle in %d of %d sampled samples" % (name, bad, checked))
+    return {"checker": "oracle/symoracle.c (CPU restatement), outside the timed region", "chains": chains, "frame_windows": "whole chains",
             "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
 
 
@@ -826,7 +869,7 @@ def main():
     elapsed, launch_s, mine = timed(step, args.steps, args.warmup, spin)
     log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))
     verified = None
-    if rank == 0 and args.workload in ("aac", "mp3"):
+    if rank == 0 and args.workload in ("aac", "mp3", "vorbis", "vorbisf", "vorbisf2"):
         verified = verify_sampled_chains(args.workload, step, torch, sync)  # raises on a mismatch: no line for a wrong result
         log("timed batch verified against the oracle: %d samples" % verified["samples_compared"])
     per_rank_ms = [mine / args.steps * 1e3]
@@ -890,14 +933,14 @@ def main():
                              ("vorbis_posts_byte_plane", "vorbisf", 0.0), ("vorbis_posts_f32_spectrum", "vorbisf2", 0.0)):
             try:
                 stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, mixw, emulate)
-                nw, ww = (20, 3) if w in ("aac", "mp3", "vorbis", "vorbisf", "vorbisf2") else (8, 2)  # (a few milliseconds each for the short ones)
+                nw, ww = (8, 2) if w in ("flac", "alac") else (20, 3)  # (a few milliseconds each for the short ones)
                 ew, lw, _ = timed(stw, nw, ww, spin)
                 others[key] = {"value": unitsw * nw / ew, "unit": unitw + "/s", "ms_per_step": ew / nw * 1e3, "steps": nw, "warmup": ww,
                                "kernel": kernelw, "kernel_ms": lw * 1e3, "algorithmic_bytes_per_launch": bytesw,
                                "roofline_frac": bytesw / lw / 1e9 / HBM_PEAK_GBS, "workload": cfgw["workload"]}
                 if mixw:
                     others[key]["mix"] = cfgw.get("mix")
-                if w in ("aac", "mp3"):
+                if w in ("aac", "mp3", "vorbis", "vorbisf", "vorbisf2"):
                     others[key]["verified"] = verify_sampled_chains(w, stw, torch, sync)
                 del stw, resw
             except Exception as e:  # noqa: BLE001

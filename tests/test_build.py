@@ -94,6 +94,17 @@ def test_mp3_build_variants_fit_three_waves_per_simd(variant):
     assert not F32_FUSED.search(text)
 
 
+def test_vorbis_wg_kernel_fits_three_workgroups_per_cu():
+    """vorbis_synth_wg_kernel (8192-sample blocks): exchange and group work areas inside the staging area -- at most 168 VGPRs and a
+    third of the CU's 160 KiB of LDS, no scratch; the round-3 layout (SYMACCEL_TUNE_VORBIS_WG_SHARED=0) stays buildable."""
+    res = kernel_resources(device_asm("vorbis_wg.hip", []))
+    assert len(res) == 6
+    for name, r in res.items():
+        assert r["ScratchSize"] == 0 and r["NumVgprs"] <= 168 and 3 * r["LDSByteSize"] <= 160 * 1024, (name, r)
+    old = kernel_resources(device_asm("vorbis_wg.hip", ["-DSYM_VORBIS_WG_SHARED=0"]))
+    assert all(r["ScratchSize"] == 0 and 2 * r["LDSByteSize"] <= 160 * 1024 for r in old.values()), old
+
+
 def test_alac_has_both_multiply_forms(asm):
     """alac_predict_kernel<., true, .> multiplies with v_mul_i32_i24 / v_mad_i32_i24 (full rate), <., false, .> with
     v_mul_lo_u32; which one a wavefront runs is decided by alac_narrow_kernel from a proven operand bound
