@@ -217,7 +217,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
         pcm_stride += (-pcm_stride) % 4
         residue = torch.randn((nch, spec_stride), generator=g, device=dev, dtype=torch.float32) * 0.1
         d_flags = torch.from_numpy(flags).to(dev)
-        classes, n_post_words = [], 0
+        classes, n_post_words, host_ys = [], 0, []
         for flag, n, n_posts, mult in ((1, 1024, 40, 2), (0, 128, 12, 2)):
             xs = [0, n] + rng.permutation(np.arange(1, n))[:n_posts - 2].tolist()
             where = np.argwhere(flags == flag)
@@ -225,6 +225,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             ys[rng.random(ys.shape) < 0.2] = 0
             offs = np.array([c * spec_stride + so[c, b] for c, b in where], np.uint32)
             classes.append((xs, mult, torch.from_numpy(ys).to(dev), n, torch.from_numpy(offs).to(dev), len(where)))
+            host_ys.append(ys)
             n_post_words += ys.size + offs.size
         plane = torch.zeros((nch, spec_stride), dtype=torch.uint8, device=dev)
         spectrum = torch.zeros((nch, spec_stride), device=dev)
@@ -244,7 +245,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
                 v.synth(spectrum, d_flags, prev[0], overlap[0], pcm_stride, pcm, state_out=(prev[1], overlap[1]))
         step.input = residue
         step.vorbis = {"flags": flags, "pcm": pcm, "pcm_stride": pcm_stride, "used": po[:, -1], "residue": residue, "so": so,
-                       "classes": [(xs, mult, ys, n, flag) for (xs, mult, ys, n, offs, cnt), flag in zip(classes, (1, 0))]}
+                       "classes": [(xs, mult, hy, n, flag) for (xs, mult, _, n, offs, cnt), hy, flag in zip(classes, host_ys, (1, 0))]}
         bytes_alg = int(4 * (so[:, -1].sum() + po[:, -1].sum()) + 4 * n_post_words)  # residue lines + PCM samples + posts and offsets
         return step, nch * nb // 8, "frames", bytes_alg, {
             "workload": "Vorbis 2048/256, 8 ch, %d blocks (%d chains x %d) from floor-1 posts + residue: %s" % (
@@ -483,7 +484,7 @@ def verify_vorbis_chains(name, step, torch, sync):
             for xs, mult, ys, n, flag in v["classes"]:
                 where = np.argwhere(flags == flag)
                 mine = np.nonzero(where[:, 0] == c)[0]
-                ys_c = ys[torch.from_numpy(mine).to(ys.device)].cpu().numpy() if len(mine) else np.zeros((0, len(xs)), np.uint32)
+                ys_c = ys[mine]
                 for y, (_, b) in zip(ys_c, where[mine]):
                     o = int(so[b])
                     spec[o:o + n] = oracle.vorbis_floor1(xs, y, mult, n) * res[o:o + n]
