@@ -64,6 +64,11 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
         step.input = coeffs
         step.aac = (coeffs, side)
 
+        def chunk_step(first, count):  # chains [first, first + count) from a zero state (symaccel_exchange_pipelined's callback)
+            dsp.synth(coeffs[first:first + count], side[first:first + count], torch.zeros((count, 1024), device=dev), pcm[first:first + count],
+                      delay_out=delay[1][first:first + count])
+        step.chunk_step = chunk_step
+
         def verify_step():
             z = torch.zeros_like(delay[0])
             dsp.synth(coeffs, side, z, pcm, delay_out=delay[1])
@@ -612,9 +617,48 @@ def exchange_c_api(ctx, torch, dist, world, rank, local_in, local_out, step, uni
         from symphonia_amd.sharding import max_over_ranks
         secs = {k: max_over_ranks(a / reps, dist, device="cuda") for k, a in zip(("scatter", "step", "gather", "total"), acc)}
         same = bool(torch.equal(all_out[0], local_out)) if rank == 0 else None  # (the root's own slice came back through the local copy)
-        return {"op": "symaccel_scatter_streams + synthesis + symaccel_gather_streams on a communicator of its own (RCCL over xGMI, C ABI)",
-                "ms": {k: v * 1e3 for k, v in secs.items()}, "bytes_per_rank": {"in": in_bytes, "out": out_bytes},
-                "value_inclusive": units * world / secs["total"], "unit": unit_name + "/s", "root_slice_round_trip": same}
+        out = {"op": "symaccel_scatter_streams + synthesis + symaccel_gather_streams on a communicator of its own (RCCL over xGMI, C ABI)",
+               "ms": {k: v * 1e3 for k, v in secs.items()}, "bytes_per_rank": {"in": in_bytes, "out": out_bytes},
+               "value_inclusive": units * world / secs["total"], "unit": unit_name + "/s", "root_slice_round_trip": same}
+        # the same leg chunked and overlapped (symaccel_exchange_pipelined): streams = chains, the step = the synthesis of a chunk of
+        # this rank's chains from a zero state; the root's link carries chunk c + 1 out and chunk c - 1's PCM back while chunk c is decoded
+        try:
+            if not (hasattr(step, "chunk_step") and local_in.dim() == 3):
+                return out
+            chains = int(local_in.shape[0])
+            per_chain_in, per_chain_out = in_bytes // chains, out_bytes // chains
+            STEP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t)
+            failed = []
+
+            def cb(user, first, count):
+                try:
+                    step.chunk_step(int(first), int(count))
+                    return 0
+                except Exception as e:  # noqa: BLE001
+                    failed.append(repr(e))
+                    return 1
+            cbf = STEP(cb)
+            n_chunks = 4
+
+            def piped():
+                t0 = time.perf_counter()
+                ctx._call(d.symaccel_exchange_pipelined, comm, world, rank, 0, p_in, local_in.data_ptr(), per_chain_in, p_out, local_out.data_ptr(),
+                          per_chain_out, world * chains, n_chunks, cbf, None)
+                sync()
+                return time.perf_counter() - t0
+            piped()
+            tp = 0.0
+            for _ in range(reps):
+                dist.barrier()
+                sync()
+                tp += piped()
+            tp = max_over_ranks(tp / reps, dist, device="cuda")
+            out["pipelined"] = {"op": "symaccel_exchange_pipelined: %d chunks of chains, scatter / synthesis / gather overlapped on two streams" % n_chunks,
+                                "ms": tp * 1e3, "value_inclusive": units * world / tp, "errors": failed or None,
+                                "root_slice_round_trip": bool(torch.equal(all_out[0], local_out)) if rank == 0 else None}
+        except Exception as e:  # noqa: BLE001  (what was measured above stays)
+            out["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        return out
     finally:
         d.symaccel_comm_destroy(comm)
 

@@ -556,6 +556,19 @@ int symaccel_scatter_streams(symaccel_ctx *ctx, void *comm, int world, int rank,
 int symaccel_gather_streams(symaccel_ctx *ctx, void *comm, int world, int rank, int root, const void *d_mine, void *d_all,
                             size_t n_streams, size_t bytes_per_stream);
 
+/* scatter -> step -> gather, chunked and overlapped.  Every rank's slice (symaccel_shard_range) is cut into n_chunks pieces of whole
+ * streams; on a second stream of the context chunk c + 1 travels from the root to the ranks while `step(user, first, count)` --
+ * the caller's synthesis calls on streams [first, first + count) of ITS slice, queued on the context's stream -- processes chunk
+ * c and chunk c - 1's result travels back.  With the root's link busy in both directions at once the exchange costs about
+ * max(scatter, gather) + one chunk instead of scatter + step + gather.  d_all_in / d_all_out: the whole batch on the root
+ * (ignored elsewhere); d_mine_in / d_mine_out: this rank's slice, in_bytes_per_stream / out_bytes_per_stream each stream.  The
+ * result is complete once the context's stream is synchronised.  A step that returns non-zero aborts with SYMACCEL_ERR_DEVICE. */
+typedef int (*symaccel_step_fn)(void *user, size_t first_local_stream, size_t n_local_streams);
+int symaccel_exchange_pipelined(symaccel_ctx *ctx, void *comm, int world, int rank, int root, const void *d_all_in,
+                                void *d_mine_in, size_t in_bytes_per_stream, void *d_all_out, void *d_mine_out,
+                                size_t out_bytes_per_stream, size_t n_streams, int n_chunks, symaccel_step_fn step,
+                                void *user);
+
 /* Communicator set-up without RCCL's headers: rank 0 makes an id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by
  * whatever means the host has (a pipe, MPI, torch.distributed); every rank then creates its communicator on its context's device
  * (ncclCommInitRank: collective, call it on all ranks) and destroys it at the end. */

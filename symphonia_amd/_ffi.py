@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "symaccel_flac_block_status_device", "symaccel_alac_block_status_device", "symaccel_vorbis_floor1_status_device", "symaccel_aac_tns_status_device",
     "symaccel_aac_synth_pp_device", "symaccel_mp3_synth_pp_device", "symaccel_vorbis_synth_pp_device", "symaccel_mpa_polyphase_pp_device",
     "symaccel_probe_copy_device",
-    "symaccel_shard_range", "symaccel_scatter_streams", "symaccel_gather_streams", "symaccel_comm_unique_id", "symaccel_comm_init",
+    "symaccel_shard_range", "symaccel_scatter_streams", "symaccel_gather_streams", "symaccel_exchange_pipelined", "symaccel_comm_unique_id", "symaccel_comm_init",
     "symaccel_comm_destroy", "symaccel_multi_set_transport", "symaccel_mp3_decode_pipelined",
     "symaccel_mp3_decode_pp_device", "symaccel_mp3_decode_device",
 ]
@@ -122,6 +122,7 @@ class Library:
         d.symaccel_shard_range.argtypes = [_sz, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]
         d.symaccel_scatter_streams.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _sz]
         d.symaccel_gather_streams.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _sz]
+        d.symaccel_exchange_pipelined.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _sz, _sz, _i, _vp, _vp]
         d.symaccel_comm_unique_id.argtypes = [_vp]
         d.symaccel_comm_init.argtypes = [_vp, _vp, _i, _i, C.POINTER(_vp)]
         d.symaccel_comm_destroy.argtypes = [_vp]

@@ -342,25 +342,6 @@ __device__ __forceinline__ void fft_wave_multi(c32 (&z)[8], int lane, c32 *lds, 
     wave_sync();
 }
 
-// The lines of 512 / P consecutive Imdct inputs of N = 2 P lines each (P = 1 << logp), pre-twiddled (mdct.rs:81-88) into the
-// lane order fft_wave_multi takes: lane (T, u) loads the pairs (spec_T[2 i], spec_T[2 i + 1]), i = u + (P / 8) s, 8 B each; the
-// mirrored odd line spec_T[N - 1 - 2 i] is the second half of pair P - 1 - i, which lane (T, P / 8 - 1 - u) holds in load 7 - s.
-// `line` = those loads (issued by the caller, possibly one group ahead); `tw` = the size's Imdct twiddles (P complex, LDS).
-__device__ __forceinline__ int multi_line_index(int lane, int logp, int s) {  // pair index inside the group's 1024-float input
-    const int gbits = logp - 3;
-    const int T = lane >> gbits, u = lane & ((1 << gbits) - 1);
-    return (T << logp) + u + (s << gbits);
-}
-__device__ __forceinline__ void multi_pre_twiddle(const float2 (&line)[8], c32 (&z)[8], int lane, int logp, const c32 *tw) {
-    const int gbits = logp - 3, G = 1 << gbits;
-    const int u = lane & (G - 1);
-    const int mirror = ((lane & ~(G - 1)) + (G - 1 - u)) * 4;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
-        z[s] = pre_twiddle(line[s].x, mirrored, tw[u + (s << gbits)]);
-    }
-}
 // a group's input: 1024 floats, 16 B per lane and load (floats past `valid_floats` read as zero)
 __device__ __forceinline__ void multi_fetch(const float *src, size_t valid_floats, int lane, float4 (&v)[4]) {
     const float4 *s4 = reinterpret_cast<const float4 *>(src);

@@ -79,14 +79,14 @@ int rccl_fail(symaccel_ctx *ctx, int rc, const char *where) {
 }
 
 // one peer-to-peer transfer through the transport in force
-int xfer_send(symaccel_ctx *ctx, const void *buf, size_t bytes, int peer, void *comm) {
-    if (g_have_transport) return g_transport.send(buf, bytes, peer, comm, (void *)ctx->stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
-    const int rc = rccl()->Send(buf, bytes, 0, peer, comm, ctx->stream);
+int xfer_send(symaccel_ctx *ctx, const void *buf, size_t bytes, int peer, void *comm, hipStream_t stream) {
+    if (g_have_transport) return g_transport.send(buf, bytes, peer, comm, (void *)stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+    const int rc = rccl()->Send(buf, bytes, 0, peer, comm, stream);
     return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclSend");
 }
-int xfer_recv(symaccel_ctx *ctx, void *buf, size_t bytes, int peer, void *comm) {
-    if (g_have_transport) return g_transport.recv(buf, bytes, peer, comm, (void *)ctx->stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
-    const int rc = rccl()->Recv(buf, bytes, 0, peer, comm, ctx->stream);
+int xfer_recv(symaccel_ctx *ctx, void *buf, size_t bytes, int peer, void *comm, hipStream_t stream) {
+    if (g_have_transport) return g_transport.recv(buf, bytes, peer, comm, (void *)stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+    const int rc = rccl()->Recv(buf, bytes, 0, peer, comm, stream);
     return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclRecv");
 }
 int group_start(symaccel_ctx *ctx) {
@@ -143,12 +143,49 @@ int exchange(symaccel_ctx *ctx, void *comm, int world, int rank, int root, void 
             const Slice s = slice_of(n_streams, world, p);
             if (!s.count) continue;
             void *a = all + s.first * bytes_per_stream;
-            st = to_root ? xfer_recv(ctx, a, s.count * bytes_per_stream, p, comm) : xfer_send(ctx, a, s.count * bytes_per_stream, p, comm);
+            st = to_root ? xfer_recv(ctx, a, s.count * bytes_per_stream, p, comm, ctx->stream) : xfer_send(ctx, a, s.count * bytes_per_stream, p, comm, ctx->stream);
         }
     } else if (mine.count) {
-        st = to_root ? xfer_send(ctx, d_mine, mine.count * bytes_per_stream, root, comm) : xfer_recv(ctx, d_mine, mine.count * bytes_per_stream, root, comm);
+        st = to_root ? xfer_send(ctx, d_mine, mine.count * bytes_per_stream, root, comm, ctx->stream) : xfer_recv(ctx, d_mine, mine.count * bytes_per_stream, root, comm, ctx->stream);
     }
     const int ge = group_end(ctx);  // (always closed, also after a failed post)
+    return st != SYMACCEL_OK ? st : ge;
+}
+
+// chunk c of n of a slice of `count` streams: [first, first + len) in the slice's own numbering
+Slice chunk_of(size_t count, int n_chunks, int c) {
+    const size_t a = count * (size_t)c / (size_t)n_chunks, b = count * (size_t)(c + 1) / (size_t)n_chunks;
+    return Slice{a, b - a};
+}
+
+// One direction of one chunk on `stream`: the root posts world - 1 transfers in one group, every other rank one; the root's own
+// piece is a device copy on the same stream.
+int exchange_chunk(symaccel_ctx *ctx, void *comm, int world, int rank, int root, char *all, char *mine_buf, size_t n_streams,
+                   size_t bytes_per_stream, int n_chunks, int c, bool to_root, hipStream_t stream) {
+    const Slice mine = slice_of(n_streams, world, rank);
+    const Slice mc = chunk_of(mine.count, n_chunks, c);
+    if (rank == root && mc.count) {
+        char *a = all + (mine.first + mc.first) * bytes_per_stream, *m = mine_buf + mc.first * bytes_per_stream;
+        if (to_root) SYM_GPU(ctx, hipMemcpyAsync(a, m, mc.count * bytes_per_stream, hipMemcpyDeviceToDevice, stream));
+        else SYM_GPU(ctx, hipMemcpyAsync(m, a, mc.count * bytes_per_stream, hipMemcpyDeviceToDevice, stream));
+    }
+    if (world == 1) return SYMACCEL_OK;
+    SYM_TRY(group_start(ctx));
+    int st = SYMACCEL_OK;
+    if (rank == root) {
+        for (int p = 0; p < world && st == SYMACCEL_OK; ++p) {
+            if (p == root) continue;
+            const Slice s = slice_of(n_streams, world, p);
+            const Slice pc = chunk_of(s.count, n_chunks, c);
+            if (!pc.count) continue;
+            char *a = all + (s.first + pc.first) * bytes_per_stream;
+            st = to_root ? xfer_recv(ctx, a, pc.count * bytes_per_stream, p, comm, stream) : xfer_send(ctx, a, pc.count * bytes_per_stream, p, comm, stream);
+        }
+    } else if (mc.count) {
+        char *m = mine_buf + mc.first * bytes_per_stream;
+        st = to_root ? xfer_send(ctx, m, mc.count * bytes_per_stream, root, comm, stream) : xfer_recv(ctx, m, mc.count * bytes_per_stream, root, comm, stream);
+    }
+    const int ge = group_end(ctx);
     return st != SYMACCEL_OK ? st : ge;
 }
 
@@ -209,6 +246,61 @@ int symaccel_comm_destroy(void *comm) {
     const Rccl *r = rccl();
     if (!r) return SYMACCEL_ERR_UNSUPPORTED;
     return r->CommDestroy(comm) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+}
+
+int symaccel_exchange_pipelined(symaccel_ctx *ctx, void *comm, int world, int rank, int root, const void *d_all_in, void *d_mine_in,
+                                size_t in_bytes_per_stream, void *d_all_out, void *d_mine_out, size_t out_bytes_per_stream,
+                                size_t n_streams, int n_chunks, symaccel_step_fn step, void *user) {
+    if (!ctx || !step || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || n_chunks < 1) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_streams == 0) return SYMACCEL_OK;
+    if (in_bytes_per_stream == 0 || out_bytes_per_stream == 0) return SYMACCEL_ERR_INVALID_ARG;
+    const Slice mine = slice_of(n_streams, world, rank);
+    if ((mine.count && (!d_mine_in || !d_mine_out)) || (rank == root && (!d_all_in || !d_all_out))) return SYMACCEL_ERR_INVALID_ARG;
+    if (world > 1 && !comm && !g_have_transport) return SYMACCEL_ERR_INVALID_ARG;
+    if (world > 1 && !have_backend()) {
+        ctx->last_error = "librccl.so not found (set SYMACCEL_RCCL_LIB or install a transport)";
+        return SYMACCEL_ERR_UNSUPPORTED;
+    }
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    // The transfers run on a second stream of the context (the one the pinned host paths use for their uploads), the steps on the
+    // context's own: chunk c + 1 travels to the ranks while chunk c is processed and chunk c - 1's result travels back.  Every
+    // rank posts the same sequence on its transfer stream -- S0, S1, G0, S2, G1, ... -- so the sends and receives pair up.
+    if (!ctx->stage_in) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_in));
+    for (hipEvent_t &e : ctx->stage_events)
+        if (!e) SYM_GPU(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipStream_t xs = ctx->stage_in;
+    hipEvent_t *ev_in = &ctx->stage_events[0], *ev_k = &ctx->stage_events[2], ev_done = ctx->stage_events[4], ev_start = ctx->stage_events[5];
+    char *all_in = static_cast<char *>(const_cast<void *>(d_all_in)), *all_out = static_cast<char *>(d_all_out);
+    char *mine_in = static_cast<char *>(d_mine_in), *mine_out = static_cast<char *>(d_mine_out);
+    // the transfer stream starts behind whatever the caller queued on the context's stream (the buffers' producers)
+    SYM_GPU(ctx, hipEventRecord(ev_start, ctx->stream));
+    SYM_GPU(ctx, hipStreamWaitEvent(xs, ev_start, 0));
+    auto scatter = [&](int c) -> int {
+        SYM_TRY(exchange_chunk(ctx, comm, world, rank, root, all_in, mine_in, n_streams, in_bytes_per_stream, n_chunks, c, false, xs));
+        SYM_GPU(ctx, hipEventRecord(ev_in[c & 1], xs));
+        return SYMACCEL_OK;
+    };
+    int st = scatter(0);
+    for (int c = 0; c < n_chunks && st == SYMACCEL_OK; ++c) {
+        if (c + 1 < n_chunks) st = scatter(c + 1);
+        if (st != SYMACCEL_OK) break;
+        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, ev_in[c & 1], 0));
+        const Slice mc = chunk_of(mine.count, n_chunks, c);
+        if (mc.count && step(user, mc.first, mc.count) != 0) {
+            ctx->last_error = "symaccel_exchange_pipelined: the step callback failed";
+            st = SYMACCEL_ERR_DEVICE;
+            break;
+        }
+        SYM_GPU(ctx, hipEventRecord(ev_k[c & 1], ctx->stream));
+        SYM_GPU(ctx, hipStreamWaitEvent(xs, ev_k[c & 1], 0));
+        st = exchange_chunk(ctx, comm, world, rank, root, all_out, mine_out, n_streams, out_bytes_per_stream, n_chunks, c, true, xs);
+    }
+    // whoever synchronises the context's stream afterwards has the gathered result (also after an error: nothing stays in flight
+    // behind the caller's back)
+    (void)hipEventRecord(ev_done, xs);
+    (void)hipStreamWaitEvent(ctx->stream, ev_done, 0);
+    return st;
 }
 
 int symaccel_scatter_streams(symaccel_ctx *ctx, void *comm, int world, int rank, int root, const void *d_all, void *d_mine,

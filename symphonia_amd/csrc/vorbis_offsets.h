@@ -107,12 +107,6 @@ __device__ __forceinline__ void mul_floor_y(float4 &x, uint32_t yb, const float 
     x.w = dbt[yb >> 24] * x.w;
 }
 
-// (out of line, values in registers both ways: for the instantiations that have no registers left for the inlined form's temporaries)
-__device__ __attribute__((noinline)) float4 mul_floor_y_call(float4 x, uint32_t yb, const float *dbt) {
-    mul_floor_y(x, yb, dbt);
-    return x;
-}
-
 }  // namespace
 
 }  // namespace symaccel

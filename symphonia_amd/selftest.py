@@ -141,5 +141,60 @@ def multi_selftest(world=4, streams=None, frames=24):
         raise RuntimeError("unexpected transfers: %r" % (mb.log,))
     out["in_process_ranks"] = {"ok": True, "streams": streams, "transfers": len(mb.log), "per_rank": per_rank,
                                "transport": "symaccel_multi_set_transport: device buffers through a host mailbox (no xGMI on a one-GPU box)"}
+    # ---- 3. the same leg chunked and overlapped: symaccel_exchange_pipelined, the step = the product's AAC synthesis on a chunk
+    # of the rank's streams (chains are independent, so a chunk needs no state from the one before it)
+    n_chunks = 3
+    gathered2 = torch.zeros_like(coeffs)
+    mb2 = DeviceMailbox(hip)
+    assert d.symaccel_multi_set_transport(C.byref(mb2.struct)) == 0
+    STEP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t)
+    errors, steps_seen = [], [0] * world
+    try:
+        def rank_main2(rank):
+            try:
+                torch.cuda.set_device(0)
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    c = sa.Context(0)
+                    c.use_torch_stream()
+                    me = C.c_int(rank)
+                    b, e = shard_streams(streams, world, rank)
+                    n = max(e - b, 1)
+                    my_in = torch.zeros((n, nch, frames, 1024), device="cuda")
+                    my_out = torch.zeros((n, nch, frames, 1024), device="cuda")
+                    my_side = side[b:b + n].contiguous() if e > b else torch.zeros((n, nch, frames), dtype=torch.uint8, device="cuda")
+                    dsp = sa.AacDsp(c)
+
+                    def step(user, first, count):
+                        try:
+                            with torch.cuda.stream(s):
+                                dsp.synth(my_in[first:first + count].view(count * nch, frames, 1024), my_side[first:first + count].view(count * nch, frames),
+                                          torch.zeros((count * nch, 1024), device="cuda"), pcm=my_out[first:first + count].view(count * nch, frames, 1024))
+                            steps_seen[rank] += 1
+                            return 0
+                        except Exception as exc:  # noqa: BLE001
+                            errors.append((rank, "step: " + repr(exc)))
+                            return 1
+                    cb = STEP(step)
+                    c._call(d.symaccel_exchange_pipelined, C.addressof(me), world, rank, 0, coeffs.data_ptr() if rank == 0 else None,
+                            my_in.data_ptr(), bytes_per_stream, gathered2.data_ptr() if rank == 0 else None, my_out.data_ptr(), bytes_per_stream,
+                            streams, n_chunks, cb, None)
+                    s.synchronize()
+                    c.close()
+            except Exception as exc:  # noqa: BLE001
+                errors.append((rank, repr(exc)))
+        threads = [threading.Thread(target=rank_main2, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        if errors or any(t.is_alive() for t in threads):
+            raise RuntimeError("pipelined exchange: rank threads failed: %r" % (errors or "timeout",))
+    finally:
+        assert d.symaccel_multi_set_transport(None) == 0
+    torch.cuda.synchronize()
+    if not torch.equal(gathered2.view(streams * nch, frames, 1024).view(torch.int32), want.view(torch.int32)):
+        raise RuntimeError("the PCM gathered by symaccel_exchange_pipelined differs from the one-call PCM")
+    out["pipelined_exchange"] = {"ok": True, "chunks": n_chunks, "steps_per_rank": steps_seen, "transfers": len(mb2.log)}
     ctx.close()
     return out

@@ -97,6 +97,32 @@ def test_fuzz_vorbis(ctx, it):
 
 
 @pytest.mark.parametrize("it", range(ITERS))
+def test_fuzz_vorbis_floor_y(ctx, it):
+    """symaccel_vorbis_synth_fy_*: random block-size pairs (every kernel: 256 / 2048, the group kernel, 4096- and 8192-sample blocks),
+    batch shapes and segment lengths; spectrum = FLOOR1_INVERSE_DB_TABLE[y] * residue (floor.rs:822, lib.rs:289-291)."""
+    from symphonia_amd import VorbisDsp
+    from test_vorbis_floor_y import db_table, fy_case
+    rng = np.random.default_rng(5500 + it)
+    nch, nb, seg = shape(rng)
+    if it % 3 == 0:
+        bs0e, bs1e = 8, 11
+    else:
+        bs0e = int(rng.integers(6, 12))
+        bs1e = int(rng.integers(bs0e, 14))
+    if bs1e > 11:
+        nb = min(nb, 12)
+    flags, prev, residue, overlap, pcm_stride, ypl = fy_case(rng, bs0e, bs1e, nch, nb)
+    d_prev, d_ov = dev(prev), dev(overlap)
+    pcm = torch.zeros((nch, pcm_stride), device="cuda")
+    ctx.set_segment(seg)
+    VorbisDsp(ctx, bs0e, bs1e).synth_floor_y(dev(ypl), dev(residue), dev(flags), d_prev, d_ov, pcm_stride, pcm)
+    ctx.set_segment(0)
+    want = oracle.vorbis_synth(bs0e, bs1e, db_table()[ypl] * residue, flags, prev, overlap, pcm_stride)
+    assert bit_equal(host(pcm), want[0]) and bit_equal(host(d_ov), want[1]), (bs0e, bs1e, nch, nb, seg)
+    assert np.array_equal(host(d_prev), want[2])
+
+
+@pytest.mark.parametrize("it", range(ITERS))
 def test_fuzz_flac_alac(ctx, it):
     from symphonia_amd import AlacPredictor, FlacPredictor, alac_desc, flac_desc
     rng = np.random.default_rng(7000 + it)
