@@ -131,6 +131,68 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             cfg["mix"] = {"p_switch": mix, "long": hist[0], "start": hist[1], "short": hist[2], "end": hist[3],
                           "mixed_share_of_short": float(mx[bt == 2].mean()) if (bt == 2).any() else 0.0}
         return step, granules, "granules", nch * ngr * 4608, cfg, "mp3_synth_kernel", pcm
+    if name in ("aacjs", "aacjs2"):
+        # config 2 from what the spectrum decoder produces for mid/side-coded stereo: coded spectra + the pairs' stereo maps -> PCM.
+        # aacjs: joint stereo on load inside the synthesis kernel (one launch + the map expansion); aacjs2: aac_joint_stereo_kernel
+        # in place, then the synthesis (round 3's two passes; the coded spectra are rewritten every step, their magnitudes drift --
+        # timing only).
+        nch, nfr = max(2, int(128 * scale)) & ~1, (6 if emulate else 1024)
+        coeffs = torch.randn((nch, nfr, 1024), generator=g, device=dev, dtype=torch.float32)
+        coeffs *= torch.exp2(torch.randint(-8, 13, (nch, nfr, 64), generator=g, device=dev).float()).repeat_interleave(16, dim=2)
+        coeffs[:, :, 672:] = 0.0
+        side = torch.full((nch, nfr), int(sa.aac_side(0, 1, 1)), dtype=torch.uint8, device=dev)
+        swb_long = [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216, 240, 264, 292, 320,
+                    352, 384, 416, 448, 480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800, 832, 864, 896, 928, 1024]  # 44.1 / 48 kHz
+        swb_short = [0, 4, 8, 12, 16, 20, 28, 36, 44, 56, 68, 80, 96, 112, 128]
+        rng = np.random.default_rng(seed)
+        n_pairs = nch // 2
+        desc = np.zeros((n_pairs, nfr), sa.AAC_JS_DTYPE)
+        desc["num_windows"], desc["max_sfb"] = 1, 40  # bands up to line 672
+        desc["mode"] = rng.choice([0, 1, 1, 1, 1, 1, 1, 2, 2, 0], (n_pairs, nfr, 128)).astype(np.uint8)  # 60 % mid/side, 20 % intensity
+        desc["scale"] = (rng.standard_normal((n_pairs, nfr, 128)) * 0.5).astype(np.float32)
+        d_desc = torch.from_numpy(desc.view(np.uint8).reshape(n_pairs, nfr, 644)).to(dev)
+        pairs = np.arange(nch, dtype=np.int32).reshape(n_pairs, 2)
+        d_pairs = torch.from_numpy(pairs).to(dev)
+        delay = [torch.zeros((nch, 1024), device=dev, dtype=torch.float32) for _ in range(2)]
+        pcm = torch.empty_like(coeffs)
+        tools, dsp = sa.AacSpectralTools(ctx, swb_long, swb_short), sa.AacDsp(ctx)
+
+        def step():
+            if name == "aacjs":
+                tools.synth_joint_stereo(coeffs, side, delay[0], d_pairs, d_desc, pcm, delay_out=delay[1])
+            else:
+                tools.joint_stereo(coeffs, d_pairs, d_desc)
+                dsp.synth(coeffs, side, delay[0], pcm, delay_out=delay[1])
+            delay.reverse()
+        step.input = coeffs
+        if name == "aacjs":
+            def verify():
+                import oracle
+                z = torch.zeros_like(delay[0])
+                tools.synth_joint_stereo(coeffs, side, z, d_pairs, d_desc, pcm, delay_out=delay[1])
+                bad = checked = 0
+                for p_ in sorted({0, n_pairs - 1}):
+                    l, r = int(pairs[p_, 0]), int(pairs[p_, 1])
+                    fr = slice(0, min(nfr, 24))
+                    cl, cr = coeffs[l, fr].cpu().numpy(), coeffs[r, fr].cpu().numpy()
+                    dl, dr = cl.copy(), cr.copy()
+                    for f in range(cl.shape[0]):
+                        dl[f], dr[f] = oracle.aac_joint_stereo(cl[f], cr[f], 1, 40, swb_long, desc[p_, f]["mode"], desc[p_, f]["scale"])
+                    want, _ = oracle.aac_synth(np.stack([dl, dr]), side[[l, r], fr].cpu().numpy(), np.zeros((2, 1024), np.float32))
+                    got = pcm[[l, r], fr].cpu().numpy()
+                    bad += int((got != want).sum())
+                    checked += got.size
+                if bad:
+                    raise RuntimeError("bench: the aacjs batch differs from the oracle in %d of %d sampled samples" % (bad, checked))
+                return {"checker": "oracle/symoracle.c (joint stereo, then Dsp::synth), outside the timed region", "pairs": sorted({0, n_pairs - 1}),
+                        "frame_windows": [[0, min(nfr, 24)]], "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
+            step.verify = verify
+        frames = nch * nfr // 2
+        bytes_alg = nch * nfr * 8192 + n_pairs * nfr * 644
+        return step, frames, "frames", bytes_alg, {
+            "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d) from mid/side- and intensity-coded spectra (60 %% / 20 %% of the bands): %s"
+                        % (frames, nch, nfr, "joint stereo on load in the synthesis kernel" if name == "aacjs" else "joint-stereo kernel in place, then synthesis"),
+            "channel_frames": nch * nfr}, "aac_synth_quad_kernel<true>" if name == "aacjs" else "aac_joint_stereo_kernel + aac_synth_quad_kernel", pcm
     if name in ("mp3q", "mp3q2"):
         # config 3 from what the ENTROPY DECODER produces: int16 Huffman samples + the 52-byte requantize record per granule-channel
         # + one 48-byte joint-stereo record per granule of a pair, every stream a mid/side pair, long blocks.
@@ -763,7 +825,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2", "vorbisf", "vorbisf2"])
+    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2", "vorbisf", "vorbisf2", "aacjs", "aacjs2"])
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -914,6 +976,8 @@ def main():
     elapsed, launch_s, mine = timed(step, args.steps, args.warmup, spin)
     log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))
     verified = None
+    if rank == 0 and hasattr(step, "verify"):
+        verified = step.verify()
     if rank == 0 and args.workload in ("aac", "mp3", "vorbis", "vorbisf", "vorbisf2"):
         verified = verify_sampled_chains(args.workload, step, torch, sync)  # raises on a mismatch: no line for a wrong result
         log("timed batch verified against the oracle: %d samples" % verified["samples_compared"])
@@ -975,7 +1039,8 @@ def main():
         for key, w, mixw in (("mp3", "mp3", 0.0), ("vorbis", "vorbis", 0.0), ("flac", "flac", 0.0), ("alac", "alac", 0.0),
                              ("aac_mix_0.05", "aac", 0.05), ("aac_mix_0.25", "aac", 0.25), ("mp3_mix_0.06", "mp3", 0.06),
                              ("mp3_int16_one_kernel", "mp3q", 0.0), ("mp3_int16_two_kernels", "mp3q2", 0.0),
-                             ("vorbis_posts_byte_plane", "vorbisf", 0.0), ("vorbis_posts_f32_spectrum", "vorbisf2", 0.0)):
+                             ("vorbis_posts_byte_plane", "vorbisf", 0.0), ("vorbis_posts_f32_spectrum", "vorbisf2", 0.0),
+                             ("aac_joint_stereo_on_load", "aacjs", 0.0), ("aac_joint_stereo_two_kernels", "aacjs2", 0.0)):
             try:
                 stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, mixw, emulate)
                 nw, ww = (8, 2) if w in ("flac", "alac") else (20, 3)  # (a few milliseconds each for the short ones)
@@ -987,6 +1052,8 @@ def main():
                     others[key]["mix"] = cfgw.get("mix")
                 if w in ("aac", "mp3", "vorbis", "vorbisf", "vorbisf2"):
                     others[key]["verified"] = verify_sampled_chains(w, stw, torch, sync)
+                elif hasattr(stw, "verify"):
+                    others[key]["verified"] = stw.verify()
                 del stw, resw
             except Exception as e:  # noqa: BLE001
                 others[key] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -1090,7 +1157,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not emulate:
             # (the int16 MP3 lines are timed against the same CPU restatement as config 3: its synthesis tail; the CPU side of
             # requantize + stereo is a few per cent of that)
-            out["cpu_baseline"] = cpu_baseline({"mp3q": "mp3", "mp3q2": "mp3", "vorbisf": "vorbis", "vorbisf2": "vorbis"}.get(args.workload, args.workload))
+            out["cpu_baseline"] = cpu_baseline({"mp3q": "mp3", "mp3q2": "mp3", "vorbisf": "vorbis", "vorbisf2": "vorbis", "aacjs": "aac", "aacjs2": "aac"}.get(args.workload, args.workload))
         print(json.dumps(out), flush=True)
     if hung:
         os._exit(0)  # a leg is still stuck in a collective: the line is out, do not wait for it

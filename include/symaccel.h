@@ -167,6 +167,23 @@ int symaccel_aac_joint_stereo_device(symaccel_ctx *ctx, float *d_coeffs, size_t 
                                      const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short,
                                      int n_swb_short);
 
+/* symaccel_aac_synth_*_device with the joint-stereo decoding of the channel pairs done AS THE LINES ARE LOADED (cpe.rs:110-157 +
+ * dsp.rs:57-158 in one kernel): d_coeffs holds what the spectrum decoder produced (mid / side or intensity-coded where the
+ * descriptors say so), pair_chains / js_desc / swb tables as symaccel_aac_joint_stereo_device takes them; chains that belong to
+ * no pair are synthesised as they are.  A chain of a pair reads its partner's lines beside its own, so the decoded spectra never
+ * go to HBM and the separate read-modify-write pass disappears.  Frames that also carry TNS filters (ics/mod.rs:452-468: TNS
+ * runs between joint stereo and the transform) must be decoded by symaccel_aac_joint_stereo_device + symaccel_aac_tns_device
+ * first and get an all-zero mode row here.  `_pp_`: state in / state out, one synthesis launch. */
+int symaccel_aac_synth_js_pp_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side,
+                                    const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_js_desc, size_t n_pairs,
+                                    const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short, int n_swb_short,
+                                    const float *d_delay_in, float *d_delay_out, float *d_pcm, size_t n_chains,
+                                    size_t frames_per_chain);
+int symaccel_aac_synth_js_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side,
+                                 const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_js_desc, size_t n_pairs,
+                                 const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short, int n_swb_short,
+                                 float *d_delay_io, float *d_pcm, size_t n_chains, size_t frames_per_chain);
+
 /* The filtering loops of Tns::synth (aac/ics/tns.rs:180-195) for a flat list of filters.  The host keeps the
  * bitstream-side work (coefficient decoding with `sin`, tns.rs:39-106, and the band arithmetic of tns.rs:149-175) and
  * passes, per filter, the line range [start, end) it computed, the order, the direction and coef[0..order).

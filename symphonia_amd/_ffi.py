@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "symaccel_aac_synth_pipelined", "symaccel_mp3_synth_pipelined", "symaccel_flac_restore_pipelined",
     "symaccel_host_aac_pulse", "symaccel_host_vorbis_bark_map", "symaccel_host_vorbis_floor0_coeffs", "symaccel_host_vorbis_floor0",
     "symaccel_flac_block_status_device", "symaccel_alac_block_status_device", "symaccel_vorbis_floor1_status_device", "symaccel_aac_tns_status_device",
-    "symaccel_aac_synth_pp_device", "symaccel_mp3_synth_pp_device", "symaccel_vorbis_synth_pp_device", "symaccel_mpa_polyphase_pp_device",
+    "symaccel_aac_synth_pp_device", "symaccel_aac_synth_js_pp_device", "symaccel_aac_synth_js_device", "symaccel_mp3_synth_pp_device", "symaccel_vorbis_synth_pp_device", "symaccel_mpa_polyphase_pp_device",
     "symaccel_probe_copy_device",
     "symaccel_shard_range", "symaccel_scatter_streams", "symaccel_gather_streams", "symaccel_exchange_pipelined", "symaccel_comm_unique_id", "symaccel_comm_init",
     "symaccel_comm_destroy", "symaccel_multi_set_transport", "symaccel_mp3_decode_pipelined",
@@ -131,6 +131,8 @@ class Library:
         d.symaccel_alac_mid_side_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_alac_mid_side.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_aac_synth_pp_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_aac_synth_js_pp_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _sz]
+        d.symaccel_aac_synth_js_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _i, _vp, _vp, _sz, _sz]
         d.symaccel_mp3_synth_pp_device.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_vorbis_synth_pp_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_mpa_polyphase_pp_device.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]

@@ -231,6 +231,22 @@ class AacSpectralTools:
                        n_pairs, _ptr(self.swb_long), self.swb_long.size - 1, _ptr(self.swb_short), self.swb_short.size - 1)
         return coeffs
 
+    def synth_joint_stereo(self, coeffs, side, delay, pair_chains, desc, pcm, delay_out=None):
+        """Dsp::synth with the joint-stereo decoding of `pair_chains` done as the lines are loaded (one kernel; the decoded spectra never
+        go to memory).  coeffs[chains, frames, 1024] as the spectrum decoder left them, side / delay / pcm as AacDsp.synth takes them;
+        delay_out: the ping-pong entry point (delay is then only read)."""
+        d = self.ctx.lib.dll
+        nch, frames = int(coeffs.shape[0]), int(coeffs.shape[1])
+        n_pairs = int(pair_chains.shape[0]) if pair_chains is not None else 0
+        swb = (_ptr(self.swb_long), self.swb_long.size - 1, _ptr(self.swb_short), self.swb_short.size - 1)
+        if delay_out is not None:
+            self.ctx._call(d.symaccel_aac_synth_js_pp_device, _ptr(coeffs), _ptr(side), _ptr(pair_chains) if n_pairs else None,
+                           _ptr(desc) if n_pairs else None, n_pairs, *swb, _ptr(delay), _ptr(delay_out), _ptr(pcm), nch, frames)
+        else:
+            self.ctx._call(d.symaccel_aac_synth_js_device, _ptr(coeffs), _ptr(side), _ptr(pair_chains) if n_pairs else None,
+                           _ptr(desc) if n_pairs else None, n_pairs, *swb, _ptr(delay), _ptr(pcm), nch, frames)
+        return pcm
+
     def tns(self, coeffs, filters, n_filters=None):
         """coeffs[..., 1024] (any leading shape = n_frames); filters[n] AAC_TNS_DTYPE."""
         n_frames = 1

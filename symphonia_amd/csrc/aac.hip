@@ -142,13 +142,38 @@ __device__ __forceinline__ void st_slot(float *frame, int m2, const float (&v)[8
 constexpr int kSlotOff = kShortRowsEnd;  // floats: the slot lies behind the eight short-window rows, inside the FFT work area
 static_assert(kSlotOff + 1024 <= kWaveLds, "delay slot must fit the per-wave LDS behind the short-window rows");
 
+// JS (symaccel_aac_synth_js_*): joint-stereo decoding (cpe.rs:110-157) happens as the lines are loaded, with a channel PAIR per
+// workgroup.  Wave j still owns frame t0 + 4 i + j of a step, but of BOTH channels: it loads the left and the right channel's
+// lines (each line of the batch is read exactly once, and every channel keeps its 16 KiB-contiguous steps), the frame's stereo
+// map in line-aligned form (`mode4` / `scale4`: one entry per group of four lines, what aac_js_expand_kernel makes of the
+// 644-byte descriptor), decodes in registers what aac_joint_stereo_kernel would have written back --
+//     mid/side (cpe.rs:144-154):  left = m + s, right = m - s;     intensity (cpe.rs:124-139):  right = scale * left --
+// and then runs the two phases of the walk for the left channel and again for the right one (own carry buffers, the same two
+// barriers per channel).  The decoded spectra never go to HBM: 4 B per line read (+ 5 B per four lines of map) and 4 B per
+// sample written, instead of a read-modify-write pass over both channels in front of the synthesis.  Frames with TNS still
+// take the separate kernels (joint stereo, then TNS) and an all-zero map here.  Chains that belong to no pair are taken by
+// the plain instantiation, launched over all chains: a workgroup whose chain is in `chain` (the index the expansion fills)
+// returns at once.  The lane-index trick of the Vorbis big-block kernels (an empty asm per step) keeps the pair instantiation
+// inside 256 registers.
+struct AacJsArgs {
+    const int2 *chain;                  // per chain: .x = the partner chain (-1: not part of a pair) -- the plain kernel's skip list
+    const int32_t *pair_chains;         // [pair][2]: the left and the right chain
+    const symaccel_aac_js_frame *desc;  // [pair][frame]
+    AacBandMaps maps;                   // line / 4 -> scale-factor band (long / short windows)
+};
+
+template <bool JS>
 __global__ __launch_bounds__(256, SYM_AAC_MIN_WAVES) void aac_synth_quad_kernel(
     DevTables tb, const float *__restrict__ coeffs, const uint8_t *__restrict__ side,
     const float *__restrict__ delay_in, float *__restrict__ delay_out, float *__restrict__ pcm,
-    unsigned frames_per_chain, unsigned seg_steps, unsigned segs_per_chain) {
+    unsigned frames_per_chain, unsigned seg_steps, unsigned segs_per_chain, AacJsArgs js) {
     __shared__ __attribute__((aligned(16))) float tabs[kTabFloats];
     __shared__ __attribute__((aligned(16))) float wave_lds[4][kWaveLds];
-    __shared__ __attribute__((aligned(16))) float carry[2][1024];
+    constexpr int CH = JS ? 2 : 1;  // channels a workgroup walks
+    __shared__ __attribute__((aligned(16))) float carry[CH][2][1024];
+    if constexpr (!JS) {
+        if (js.chain && js.chain[blockIdx.x / segs_per_chain].x >= 0) return;  // a paired chain: the pair instantiation's
+    }
     for (int i = (int)threadIdx.x; i < 1024; i += 256) {
         tabs[kTabTw + i] = reinterpret_cast<const float *>(tb.aac_tw_long)[i];
         tabs[kTabKbd + i] = tb.aac_kbd_long[i];
@@ -162,46 +187,133 @@ __global__ __launch_bounds__(256, SYM_AAC_MIN_WAVES) void aac_synth_quad_kernel(
     float *ldsf = wave_lds[wave];
     c32 *lds = reinterpret_cast<c32 *>(ldsf);
     const c32 *tw = reinterpret_cast<const c32 *>(tabs + kTabTw);
-    const unsigned chain = blockIdx.x / segs_per_chain, seg = blockIdx.x % segs_per_chain;
+    const unsigned unit = blockIdx.x / segs_per_chain, seg = blockIdx.x % segs_per_chain;
+    // the chain of channel 0 (the only one of the plain instantiation) and of channel 1
+    const unsigned chain = JS ? (unsigned)js.pair_chains[2 * unit] : unit, chain1 = JS ? (unsigned)js.pair_chains[2 * unit + 1] : unit;
     const long t_begin = (long)seg * seg_steps * 4;
     const long t_end = t_begin + (long)seg_steps * 4 < (long)frames_per_chain ? t_begin + (long)seg_steps * 4 : (long)frames_per_chain;
     const long n_steps = (t_end - t_begin + 3) / 4;
-    const size_t chain_base = (size_t)chain * frames_per_chain;
+    const size_t chain_base0 = (size_t)chain * frames_per_chain, chain_base1 = (size_t)chain1 * frames_per_chain;
     LaneTables lt;
     load_lane_tables(tb, lane, lt);
 
     // the carry in front of the segment: the caller's delay line at a chain's start, else what the halo frame leaves (step -1)
     if (t_begin == 0 && wave == 3) {
-        const float4 *src = reinterpret_cast<const float4 *>(delay_in + (size_t)chain * 1024);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) reinterpret_cast<float4 *>(carry[1])[lane + 64 * q] = src[lane + 64 * q];
+        for (int ch = 0; ch < CH; ++ch) {
+            const float4 *src = reinterpret_cast<const float4 *>(delay_in + (size_t)(ch ? chain1 : chain) * 1024);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<float4 *>(carry[ch][1])[lane + 64 * q] = src[lane + 64 * q];
+        }
     }
     // `line` always holds the lines of frame t_loaded: the halo frame for wave 3 of a later segment, else the frame of step 0
     long t_loaded = (wave == 3 && t_begin > 0) ? t_begin - 1 : t_begin + wave;
     float2 line[8];
     unsigned sb_next = 0;
+    // JS: channel 1's lines and side byte, and the stereo map of frame t_loaded
+    float2 line1[8];
+    // The frame's 644-byte stereo descriptor travels with the lines as three dwords per lane (161 in all) and is laid down in the
+    // wavefront's LDS area at the top of the step (the area is idle there), where the lanes look up mode[] and scale[] of their
+    // eight line pairs: which (window group, band) a pair belongs to depends on the frame's window sequence, and reading the map
+    // from LDS at decode time keeps that dependency out of the loads.
+    uint32_t dq[3] = {0u, 0u, 0u};
+    unsigned sb1_next = 0;
+    uint32_t sfb_long[2] = {0u, 0u};  // the band of the lane's eight line pairs in a long window, a byte each
+    unsigned sfb_short = 0;           //   ... in a short window (the same for all eight: pair s lies in window s)
+    auto fetch1 = [&](long tf, int ln) {  // the right channel's lines + the frame's stereo descriptor
+        if constexpr (JS) {
+            const float2 *ps = reinterpret_cast<const float2 *>(coeffs + (chain_base1 + (size_t)tf) * 1024);
+            const uint32_t *d = reinterpret_cast<const uint32_t *>(js.desc + (size_t)unit * frames_per_chain + (size_t)tf);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) line1[s] = ld_line(ps + ln + 64 * s);
+            dq[0] = d[ln];
+            dq[1] = d[ln + 64];
+            dq[2] = ln < 33 ? d[ln + 128] : 0u;
+            sb1_next = side[chain_base1 + (size_t)tf];
+        }
+    };
+    if constexpr (JS) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sfb_long[s >> 2] |= (uint32_t)js.maps.long4[(lane >> 1) + 32 * s] << (8 * (s & 3));
+        sfb_short = js.maps.short4[(lane >> 1) & 31];
+    }
     if (t_loaded < t_end) {
-        const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)t_loaded) * 1024);
+        const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base0 + (size_t)t_loaded) * 1024);
 #pragma unroll
         for (int s = 0; s < 8; ++s) line[s] = ld_line(src + lane + 64 * s);
-        sb_next = side[chain_base + (size_t)t_loaded];
+        sb_next = side[chain_base0 + (size_t)t_loaded];
+        fetch1(t_loaded, lane);
     } else {
         t_loaded = -100;
 #pragma unroll
         for (int s = 0; s < 8; ++s) line[s] = make_float2(0.0f, 0.0f);
+        if constexpr (JS) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) line1[s] = make_float2(0.0f, 0.0f);
+        }
     }
     __syncthreads();  // tables and the carry are in place
 
     long t = t_begin - 4 + wave;  // this wavefront's frame of step i
+    const int lane_of_wave = lane;
     for (long i = -1; i < n_steps; ++i, t += 4) {
+        int lane = lane_of_wave;
+        if constexpr (JS) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(lane));  // (what the step derives from the lane index is recomputed per step, not held in ~70 registers)
+#endif
+        }
         const bool active = t == t_loaded;  // (step -1: only a wave 3 with a halo frame)
         const bool emit = i >= 0;
-        const unsigned sb = sb_next;
+        const unsigned sb0 = sb_next, sb1 = sb1_next;
+        if constexpr (JS) {
+            if (active) {  // both channels of the frame, decoded in registers (cpe.rs:110-157)
+                uint32_t *dl = reinterpret_cast<uint32_t *>(ldsf);  // the descriptor: num_windows | max_sfb << 8 | .. ; mode[128]; scale[128]
+                dl[lane] = dq[0];
+                dl[lane + 64] = dq[1];
+                if (lane < 33) dl[lane + 128] = dq[2];
+                wave_sync();
+                const unsigned hdr = dl[0];
+                const bool one = (hdr & 255u) == 1u;
+                const int max_sfb = (int)((hdr >> 8) & 255u);
+                const uint8_t *mode = reinterpret_cast<const uint8_t *>(dl + 1);
+                const float *scale = reinterpret_cast<const float *>(dl + 33);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float2 l = line[s], r = line1[s];
+                    // (window group, band) of the pair; bands at or above max_sfb are not coded (cpe.rs:113-122, aac_joint_stereo_kernel)
+                    const int sfb = one ? (int)((sfb_long[s >> 2] >> (8 * (s & 3))) & 255u) : (int)sfb_short;
+                    const int slot = one ? sfb : 16 * s + sfb;
+                    const bool coded = sfb < max_sfb && slot < 128;
+                    const int sl = slot < 127 ? slot : 127;
+                    const unsigned m = mode[sl];
+                    const float sc = scale[sl];
+                    const bool ms = coded && m == SYMACCEL_AAC_JS_MS, is = coded && m == SYMACCEL_AAC_JS_INTENSITY;
+                    line[s] = ms ? make_float2(l.x + r.x, l.y + r.y) : l;
+                    line1[s] = ms ? make_float2(l.x - r.x, l.y - r.y) : (is ? make_float2(sc * l.x, sc * l.y) : r);
+                }
+                wave_sync();  // (the area is the transform's again)
+            }
+        }
+        const long tn = t < t_begin ? t_begin + 3 : t + 4;  // (after the halo frame t_begin - 1 wave 3 continues with t_begin + 3)
+#pragma unroll 1
+        for (int ch = 0; ch < CH; ++ch) {
+        if constexpr (JS) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(lane));  // (per channel too)
+#endif
+        }
+        const unsigned sb = ch ? sb1 : sb0;
+        const size_t chain_base = ch ? chain_base1 : chain_base0;
         const int seq = (int)(sb & 3u);
         const int shape = (int)((sb >> 2) & 1u), prev_shape = (int)((sb >> 3) & 1u);
-        float *my_slot = wave == 3 ? carry[i & 1] : ldsf + kSlotOff;
-        const float *prev_slot = wave == 0 ? carry[(i + 1) & 1] : wave_lds[wave - 1] + kSlotOff;
+        float *my_slot = wave == 3 ? carry[ch][i & 1] : ldsf + kSlotOff;
+        const float *prev_slot = wave == 0 ? carry[ch][(i + 1) & 1] : wave_lds[wave - 1] + kSlotOff;
         float xw[2][8];  // long frames: first half of the IMDCT output times its window, waiting for the predecessor's delay
+        auto ln_at = [&](int s) -> float2 {
+            if constexpr (JS) return ch ? line1[s] : line[s];
+            else return line[s];
+        };
 
         // ---------------- phase 1: transform this wavefront's frame, publish the delay line it leaves behind
         if (active) {
@@ -210,27 +322,29 @@ __global__ __launch_bounds__(256, SYM_AAC_MIN_WAVES) void aac_synth_quad_kernel(
                 const int mirror = (63 - lane) * 4;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
-                    z[s] = pre_twiddle(line[s].x, mirrored, tw[lane + 64 * s]);
+                    const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(ln_at(7 - s).y)));
+                    z[s] = pre_twiddle(ln_at(s).x, mirrored, tw[lane + 64 * s]);
                 }
             } else {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {  // the short transform indexes lines per 128-line window: stage in LDS
-                    ldsf[short_row(s) + 2 * lane] = line[s].x;
-                    ldsf[short_row(s) + 2 * lane + 1] = line[s].y;
+                    ldsf[short_row(s) + 2 * lane] = ln_at(s).x;
+                    ldsf[short_row(s) + 2 * lane + 1] = ln_at(s).y;
                 }
                 wave_sync();
             }
-            // this wavefront's frame of the next step lands while this one is transformed
-            const long tn = t < t_begin ? t_begin + 3 : t + 4;  // (after the halo frame t_begin - 1 wave 3 continues with t_begin + 3)
+            // this wavefront's frame of the next step lands while this one is transformed (pairs: the left channel's lines during the
+            // left channel's transform, the right channel's and the descriptor during the right channel's -- `line1` holds the frame
+            // being decoded until then; requesting all of it during the left channel's transform, through a second register set,
+            // measured slower: 0.283 against 0.257 ms)
             if (tn < t_end) {
-                sb_next = side[chain_base + (size_t)tn];
-                const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base + (size_t)tn) * 1024);
+                if (ch == 0) {
+                    sb_next = side[chain_base0 + (size_t)tn];
+                    const float2 *src = reinterpret_cast<const float2 *>(coeffs + (chain_base0 + (size_t)tn) * 1024);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) line[s] = ld_line(src + lane + 64 * s);
-                t_loaded = tn;
-            } else {
-                t_loaded = -100;
+                    for (int s = 0; s < 8; ++s) line[s] = ld_line(src + lane + 64 * s);
+                }
+                if (ch == CH - 1) fetch1(tn, lane);
             }
             if (seq != EIGHT_SHORT) {
                 fft512_wave(z, lane, lds, lt);
@@ -322,19 +436,29 @@ __global__ __launch_bounds__(256, SYM_AAC_MIN_WAVES) void aac_synth_quad_kernel(
                 }
             }
             if (t + 1 == (long)frames_per_chain) {  // the chain's last frame: its delay line is the outgoing state
-                float4 *d = reinterpret_cast<float4 *>(delay_out + (size_t)chain * 1024);
+                float4 *d = reinterpret_cast<float4 *>(delay_out + (size_t)(ch ? chain1 : chain) * 1024);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) d[lane + 64 * q] = reinterpret_cast<const float4 *>(my_slot)[lane + 64 * q];
             }
         }
         wg_sync_lds();  // the slots are free: the next transforms overwrite them
+        }  // ch
+        if (active) t_loaded = tn < t_end ? tn : -100;
     }
+}
+
+// The per-chain index of a batch with channel pairs: .x = the partner chain, or -1 (after the memset) for a chain outside every
+// pair -- what tells the plain instantiation which chains are not its own.
+__global__ void aac_js_index_kernel(const int32_t *__restrict__ pair_chains, unsigned n_pairs, int2 *__restrict__ chain_index) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * n_pairs) chain_index[pair_chains[i]] = make_int2(pair_chains[i ^ 1u], (int)i);
 }
 
 }  // namespace
 
 int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const float *d_delay_in,
-               float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain) {
+               float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain, const AacBandMaps *maps,
+               const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_js_desc, size_t n_pairs, void *d_js_scratch) {
     if (frames_per_chain > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
 #if SYM_AAC_QUAD
     {
@@ -347,8 +471,33 @@ int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, 
         const size_t segs = (steps_per_chain + seg_steps - 1) / seg_steps;
         const size_t grid = n_chains * segs;
         if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-        hipLaunchKernelGGL(aac_synth_quad_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->dev, d_coeffs, d_side,
-                           d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, seg_steps, (unsigned)segs);
+        AacJsArgs js{nullptr, nullptr, nullptr, AacBandMaps{}};
+        if (n_pairs == 0 || !maps) {
+            hipLaunchKernelGGL(aac_synth_quad_kernel<false>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->dev, d_coeffs, d_side,
+                               d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, seg_steps, (unsigned)segs, js);
+        } else {
+            // scratch: chain_index[n_chains] int2
+            if (n_pairs * frames_per_chain > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+            int2 *chain_index = reinterpret_cast<int2 *>(d_js_scratch);
+            SYM_GPU(ctx, hipMemsetAsync(chain_index, 0xff, n_chains * sizeof(int2), ctx->stream));  // partner -1: not part of a pair
+            hipLaunchKernelGGL(aac_js_index_kernel, dim3((unsigned)((2 * n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, d_pair_chains,
+                               (unsigned)n_pairs, chain_index);
+            SYM_GPU(ctx, hipGetLastError());
+            js = AacJsArgs{chain_index, d_pair_chains, d_js_desc, *maps};
+            // the pairs: a workgroup per (pair, segment) -- half as many walks as chains, so the segments are chosen for n_pairs walks
+            unsigned pseg_steps;
+            if (ctx->segment > 0) pseg_steps = (unsigned)((ctx->segment + 3) / 4);
+            else pseg_steps = choose_segment(ctx, n_pairs, steps_per_chain, SYM_AAC_MIN_WAVES, 1, 1, 1);
+            if (pseg_steps > steps_per_chain) pseg_steps = (unsigned)steps_per_chain;
+            const size_t psegs = (steps_per_chain + pseg_steps - 1) / pseg_steps;
+            if (n_pairs * psegs > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+            hipLaunchKernelGGL(aac_synth_quad_kernel<true>, dim3((unsigned)(n_pairs * psegs)), dim3(256), 0, ctx->stream, ctx->dev, d_coeffs, d_side,
+                               d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, pseg_steps, (unsigned)psegs, js);
+            SYM_GPU(ctx, hipGetLastError());
+            if (2 * n_pairs < n_chains)  // the chains outside every pair: the plain walk over all chains, paired ones return at once
+                hipLaunchKernelGGL(aac_synth_quad_kernel<false>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->dev, d_coeffs, d_side,
+                                   d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, seg_steps, (unsigned)segs, js);
+        }
         SYM_GPU(ctx, hipGetLastError());
         return SYMACCEL_OK;
     }

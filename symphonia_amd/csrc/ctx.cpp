@@ -405,6 +405,56 @@ int symaccel_imdct_f32(symaccel_ctx *ctx, int n, double scale, const float *h_sp
 
 // ---- AAC ----------------------------------------------------------------------------------
 
+static bool build_band_map(const uint16_t *swb, int n_swb, int lines, int max_bands, uint8_t *map4);
+
+// Dsp::synth with the channel pairs' joint-stereo decoding (cpe.rs:110-157) done as the lines are loaded
+static int aac_synth_js(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const int32_t *d_pair_chains,
+                        const symaccel_aac_js_frame *d_js_desc, size_t n_pairs, const uint16_t *swb_long, int n_swb_long,
+                        const uint16_t *swb_short, int n_swb_short, const float *d_delay_in, float *d_delay_out, float *d_pcm,
+                        size_t n_chains, size_t frames_per_chain, void **scratch_tail, size_t tail_bytes) {
+    AacBandMaps maps;
+    if (!build_band_map(swb_long, n_swb_long, 1024, 64, maps.long4) || !build_band_map(swb_short, n_swb_short, 128, 16, maps.short4))
+        return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs && (!d_pair_chains || !d_js_desc)) return SYMACCEL_ERR_INVALID_ARG;
+    if (2 * n_pairs > n_chains) return SYMACCEL_ERR_INVALID_ARG;
+    void *scratch = nullptr;
+    const size_t js_bytes = aac_js_scratch_bytes(n_chains, n_pairs, frames_per_chain);
+    SYM_TRY(ctx_scratch(ctx, js_bytes + tail_bytes, &scratch));
+    if (scratch_tail) *scratch_tail = static_cast<char *>(scratch) + js_bytes;
+    float *out_state = d_delay_out ? d_delay_out : reinterpret_cast<float *>(static_cast<char *>(scratch) + js_bytes);
+    return launch_aac(ctx, d_coeffs, d_side, d_delay_in, out_state, d_pcm, n_chains, frames_per_chain, &maps, d_pair_chains, d_js_desc, n_pairs,
+                      scratch);
+}
+
+int symaccel_aac_synth_js_pp_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const int32_t *d_pair_chains,
+                                    const symaccel_aac_js_frame *d_js_desc, size_t n_pairs, const uint16_t *swb_long, int n_swb_long,
+                                    const uint16_t *swb_short, int n_swb_short, const float *d_delay_in, float *d_delay_out,
+                                    float *d_pcm, size_t n_chains, size_t frames_per_chain) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
+    if (!d_coeffs || !d_side || !d_delay_in || !d_delay_out || !d_pcm || d_delay_in == d_delay_out) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return aac_synth_js(ctx, d_coeffs, d_side, d_pair_chains, d_js_desc, n_pairs, swb_long, n_swb_long, swb_short, n_swb_short, d_delay_in,
+                        d_delay_out, d_pcm, n_chains, frames_per_chain, nullptr, 0);
+}
+
+int symaccel_aac_synth_js_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const int32_t *d_pair_chains,
+                                 const symaccel_aac_js_frame *d_js_desc, size_t n_pairs, const uint16_t *swb_long, int n_swb_long,
+                                 const uint16_t *swb_short, int n_swb_short, float *d_delay_io, float *d_pcm, size_t n_chains,
+                                 size_t frames_per_chain) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
+    if (!d_coeffs || !d_side || !d_delay_io || !d_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    const size_t state_bytes = n_chains * 1024 * sizeof(float);
+    void *tail = nullptr;  // the new state goes to scratch and is copied back (segments of a chain run concurrently)
+    SYM_TRY(aac_synth_js(ctx, d_coeffs, d_side, d_pair_chains, d_js_desc, n_pairs, swb_long, n_swb_long, swb_short, n_swb_short, d_delay_io,
+                         nullptr, d_pcm, n_chains, frames_per_chain, &tail, state_bytes));
+    return launch_state_copy(ctx, d_delay_io, tail, state_bytes, nullptr, nullptr, 0, nullptr, nullptr, 0);
+}
+
 int symaccel_aac_synth_pp_device(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const float *d_delay_in,
                                  float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain) {
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;

@@ -194,8 +194,17 @@ int launch_imdct8192_wg(symaccel_ctx *ctx, const cpx *d_twiddle, const float *d_
 int launch_imdct_big_wave(symaccel_ctx *ctx, const cpx *d_twiddle, int nf, const float *d_spec, float *d_out, size_t count);  // imdct_big.hip
 int launch_fft(symaccel_ctx *ctx, int n, const float *d_in, float *d_out, size_t count, bool inverse = false);
 int launch_imdct(symaccel_ctx *ctx, const ImdctPlan &plan, const float *d_spec, float *d_out, size_t count);
+// (maps / d_pair_chains / d_js_desc / n_pairs / d_js_scratch: joint stereo on load, symaccel_aac_synth_js_*; scratch of
+// aac_js_scratch_bytes(n_chains, n_pairs, frames_per_chain) bytes)
 int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, const float *d_delay_in,
-               float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain);
+               float *d_delay_out, float *d_pcm, size_t n_chains, size_t frames_per_chain, const AacBandMaps *maps = nullptr,
+               const int32_t *d_pair_chains = nullptr, const symaccel_aac_js_frame *d_js_desc = nullptr, size_t n_pairs = 0,
+               void *d_js_scratch = nullptr);
+inline size_t aac_js_scratch_bytes(size_t n_chains, size_t n_pairs, size_t frames_per_chain) {
+    (void)n_pairs;
+    (void)frames_per_chain;
+    return ((n_chains * 8 + 255) & ~(size_t)255) + 256;
+}
 int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_side, int sr,
                const float *d_overlap_in, const float *d_vvec_in, const int32_t *d_vfront_in,
                float *d_overlap_out, float *d_vvec_out, int32_t *d_vfront_out, float *d_pcm,

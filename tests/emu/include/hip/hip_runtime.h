@@ -46,6 +46,7 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 struct dim3 {

@@ -77,7 +77,7 @@ def test_aac_three_wave_variant_fits_its_register_budget():
     """SYMACCEL_TUNE_AAC_VARIANT=1 (six wavefronts per workgroup, lane twiddles in LDS, peeled halo) is sized for three
     wavefronts per SIMD: <= 168 VGPRs, no scratch, two 71.6 KiB workgroups per CU -- and contains no fused multiply-add."""
     text = device_asm("aac.hip", ["-DSYM_AAC_VARIANT=1", "-DSYM_AAC_QUAD=0"])  # (the wavefront walk: csrc/experiments/aac_wave_walk.h)
-    (r,) = [v for k, v in kernel_resources(text).items() if "quad" not in k]  # (aac.hip also holds the workgroup walk, the product)
+    (r,) = [v for k, v in kernel_resources(text).items() if "quad" not in k and "aac_js_" not in k]  # (aac.hip also holds the product's kernels)
     assert r["ScratchSize"] == 0 and r["NumVgprs"] <= 168 and r["Occupancy"] == 3, r
     assert 2 * r["LDSByteSize"] <= 160 * 1024
     assert not F32_FUSED.search(text)
@@ -152,8 +152,8 @@ def test_the_product_translation_units_carry_no_measurement_only_code():
     assert "__global__" in (build.CSRC / "experiments" / "aac_wave_walk.h").read_text()
     assert all(p.parent == build.CSRC or p.name == "symaccel.h" for p in build.source_files())  # the product's sources: csrc/* only
     text = device_asm("aac.hip", [])
-    kernels = [k for k in kernel_resources(text)]
-    assert len(kernels) == 1 and "aac_synth_quad_kernel" in kernels[0], kernels
+    kernels = [k for k in kernel_resources(text)]  # the walk (plain / a channel pair with joint stereo on load) and the pair index, nothing else
+    assert len(kernels) == 3 and sum("aac_synth_quad_kernel" in k for k in kernels) == 2 and sum("aac_js_index_kernel" in k for k in kernels) == 1, kernels
 
 
 def test_rccl_constants_the_c_glue_hard_codes():

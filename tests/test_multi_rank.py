@@ -164,11 +164,12 @@ def test_bench_line_carries_the_other_workloads():
     assert r.returncode == 0 and d is not None, r.stderr[-3000:]
     ow = d["other_workloads"]
     assert set(ow) == {"mp3", "vorbis", "flac", "alac", "aac_mix_0.05", "aac_mix_0.25", "mp3_mix_0.06", "mp3_int16_one_kernel", "mp3_int16_two_kernels",
-                       "vorbis_posts_byte_plane", "vorbis_posts_f32_spectrum"}
+                       "vorbis_posts_byte_plane", "vorbis_posts_f32_spectrum",
+                       "aac_joint_stereo_on_load", "aac_joint_stereo_two_kernels"}
     for name, line in ow.items():
         assert "error" not in line, (name, line)
         assert line["steps"] == (8 if name in ("flac", "alac") else 20) and line["value"] > 0 and line["algorithmic_bytes_per_launch"] > 0
-        if name.startswith(("aac", "mp3", "vorbis")) and "int16" not in name:  # the timed batch itself is compared with the oracle (sampled chains), mixes included
+        if name.startswith(("aac", "mp3", "vorbis")) and "int16" not in name and "two_kernels" not in name:  # the timed batch itself is compared with the oracle (sampled chains), mixes included
             assert line["verified"]["mismatches"] == 0 and line["verified"]["samples_compared"] > 0
         if "mix" in name:
             assert abs(sum(v for k, v in line["mix"].items() if k not in ("p_switch", "mixed_share_of_short")) - 1.0) < 1e-9
