@@ -6,6 +6,7 @@ symphonia_amd/libsymaccel.so and raises if it is missing -- there is no CPU path
 import ctypes as C
 import json
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -66,6 +67,16 @@ class Library:
                 "%s is missing: build it with `python -m symphonia_amd.build` (hipcc, gfx950). "
                 "symphonia_amd has no CPU fallback." % path)
         self.path = path
+        # One HIP runtime per process: libsymaccel.so is linked against the system's libamdhip64, PyTorch-ROCm ships its own.  When
+        # torch is loaded first the library binds to torch's copy and the two share the device; the other way round both runtimes
+        # are live and symaccel_ctx_create fails with a device error (seen on the MI355X box: build() followed by smoke() in one
+        # process).  The harness uses torch for device memory anyway, so the real library pulls it in first when it is installed
+        # (SYMACCEL_NO_TORCH_PRELOAD=1: a host that never loads torch; the CPU-emulation library of the tests does not link HIP).
+        if "emu" not in path.name and "torch" not in sys.modules and not os.environ.get("SYMACCEL_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:  # noqa: BLE001
+                pass
         self.dll = C.CDLL(str(path))
         d = self.dll
         d.symaccel_strerror.restype = C.c_char_p
