@@ -579,7 +579,9 @@ int symaccel_gather_streams(symaccel_ctx *ctx, void *comm, int world, int rank, 
  * c and chunk c - 1's result travels back.  With the root's link busy in both directions at once the exchange costs about
  * max(scatter, gather) + one chunk instead of scatter + step + gather.  d_all_in / d_all_out: the whole batch on the root
  * (ignored elsewhere); d_mine_in / d_mine_out: this rank's slice, in_bytes_per_stream / out_bytes_per_stream each stream.  The
- * result is complete once the context's stream is synchronised.  A step that returns non-zero aborts with SYMACCEL_ERR_DEVICE. */
+ * result is complete once the context's stream is synchronised.  A step that returns non-zero aborts THIS rank's call with
+ * SYMACCEL_ERR_DEVICE; the other ranks are not told (their transfers with it never complete: tear the communicator down).  Uses the
+ * context's staging stream and events: not concurrently with a *_pipelined host-memory call on the same context. */
 typedef int (*symaccel_step_fn)(void *user, size_t first_local_stream, size_t n_local_streams);
 int symaccel_exchange_pipelined(symaccel_ctx *ctx, void *comm, int world, int rank, int root, const void *d_all_in,
                                 void *d_mine_in, size_t in_bytes_per_stream, void *d_all_out, void *d_mine_out,
