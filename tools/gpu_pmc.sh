@@ -13,3 +13,8 @@ for w in "$@"; do
     echo "pmc $w pass $p rc=$?"
   done
 done
+# text summaries (kernels of the workload only) next to the databases, then drop the databases (too large to copy back)
+for w in "$@"; do
+  python $REPO/tools/rocpd_summary.py $(find $OUT/pmc_${TAG}_${w}_A $OUT/pmc_${TAG}_${w}_B -name '*.db') 2>&1 | grep -v 'at::native\|rocclr\|elementwise' > $OUT/${TAG}_${w}_sq_counters.txt
+  rm -rf $OUT/pmc_${TAG}_${w}_A $OUT/pmc_${TAG}_${w}_B
+done
