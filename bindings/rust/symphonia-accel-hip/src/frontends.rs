@@ -4,9 +4,11 @@
 //! The reference keeps those stages in private modules (symphonia-codec-aac/src/aac/mod.rs:29-34,
 //! symphonia-codec-vorbis/src/lib.rs:37-42, symphonia-bundle-mp3/src/lib.rs:18-40), so this crate does not carry a copy of
 //! them: it builds against codec crates with the SEAM PATCHES of `bindings/rust/patches/` applied
-//! (`symphonia-bundle-flac.diff`, `symphonia-codec-aac.diff`, `symphonia-bundle-mp3.diff`, `symphonia-codec-vorbis.diff`).
+//! (`symphonia-bundle-flac.diff`, `symphonia-codec-aac.diff`, `symphonia-bundle-mp3.diff`, `symphonia-codec-vorbis.diff`,
+//! `symphonia-codec-alac.diff`).
 //! Each patch adds a `pub trait SynthBackend` at the place where the decoder calls its DSP
-//! (flac decoder.rs:199-242 + 446-511, aac ics/mod.rs:449-468, mp3 layer3/mod.rs:421-477, vorbis lib.rs:316-331) with the
+//! (flac decoder.rs:199-242 + 446-511, aac ics/mod.rs:449-468, mp3 layer3/mod.rs:421-477, vorbis lib.rs:316-331, alac lib.rs:541-598)
+//! with the
 //! crate's own CPU code as the default, and a `try_new_with_backend` constructor.  The front ends below are the reference's
 //! decoders with a RECORDING backend installed: `parse(packet)` runs the reference's `decode_ref` -- which now stops short
 //! of the DSP -- and returns what the backend was handed.  The batched device call then does the DSP for many packets.
@@ -19,20 +21,22 @@ use symphonia_core::codecs::audio::{AudioCodecParameters, AudioDecoderOptions};
 use symphonia_core::errors::Result;
 
 use crate::aac::AacFrontEnd;
+use crate::alac::AlacFrontEnd;
 use crate::flac::FlacFrontEnd;
 use crate::mpa::MpaFrontEnd;
 use crate::vorbis::VorbisFrontEnd;
 
-/// Which front ends this build contains: all four, through the seam patches (kept as a table so that a build against an
+/// Which front ends this build contains: all five, through the seam patches (kept as a table so that a build against an
 /// unpatched codec crate can switch a codec off instead of failing to link; see `register`).
 pub struct Available {
     pub aac: bool,
     pub mpa: bool,
     pub vorbis: bool,
     pub flac: bool,
+    pub alac: bool,
 }
 
-pub const AVAILABLE: Available = Available { aac: true, mpa: true, vorbis: true, flac: true };
+pub const AVAILABLE: Available = Available { aac: true, mpa: true, vorbis: true, flac: true, alac: true };
 
 pub fn aac_front_end(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Box<dyn AacFrontEnd>> {
     Ok(Box::new(crate::aac::SeamFrontEnd::try_new(params, opts)?))
@@ -48,4 +52,8 @@ pub fn vorbis_front_end(params: &AudioCodecParameters, opts: &AudioDecoderOption
 
 pub fn flac_front_end(params: &AudioCodecParameters, _opts: &AudioDecoderOptions) -> Result<Box<dyn FlacFrontEnd>> {
     Ok(Box::new(crate::flac::SeamFrontEnd::try_new(params)?))
+}
+
+pub fn alac_front_end(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Box<dyn AlacFrontEnd>> {
+    Ok(Box::new(crate::alac::SeamFrontEnd::try_new(params, opts)?))
 }

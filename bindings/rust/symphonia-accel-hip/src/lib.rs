@@ -17,9 +17,10 @@
 //! apply to the reference tree, the patched files parse and this crate's `SynthBackend` impls match the patched traits
 //! (tests/test_seam_patches.py); and the crate is EXECUTED under the repository's Rust interpreter (tools/rsinterp) with its
 //! `extern "C"` block bound to libsymaccel through ctypes: `lookahead.rs` + `fallback.rs` with mocks (test_rust_shim.py), the
-//! four codec adapters + `ctx.rs` with front ends that replay the reference-text fixtures (tests/test_rust_adapters.py), and
-//! the whole FLAC path -- the patched reference decoder as front end, `flac.rs`, `decoder.rs`, `lookahead.rs`, `ctx.rs` -- on
-//! packet bytes against the unpatched reference decoder (tests/test_flac_packets.py).
+//! five codec adapters + `ctx.rs` with front ends that replay the reference-text fixtures (tests/test_rust_adapters.py), and
+//! the whole FLAC and ALAC paths -- the patched reference decoder as front end, `flac.rs` / `alac.rs`, `decoder.rs`,
+//! `lookahead.rs`, `ctx.rs` -- on packet bytes against the unpatched reference decoder (tests/test_flac_packets.py,
+//! tests/test_alac_packets.py).
 #![allow(clippy::needless_range_loop)]
 
 mod aac;
@@ -27,6 +28,7 @@ mod ctx;
 pub mod decoder;
 pub mod fallback;
 mod ffi;
+mod alac;
 mod flac;
 pub mod frontends;
 mod lookahead;
@@ -34,6 +36,7 @@ mod mpa;
 mod vorbis;
 
 pub use aac::{AacFrontEnd, HipAacDecoder, ParsedAac};
+pub use alac::{AlacFrontEnd, HipAlacDecoder, ParsedAlac};
 pub use decoder::DecoderBatch;
 pub use ctx::{Context, Pinned};
 pub use flac::{FlacFrontEnd, HipFlacDecoder, ParsedFlac};
@@ -60,6 +63,7 @@ pub fn register(registry: &mut CodecRegistry) {
     register_one::<HipMpaDecoder>(registry, frontends::AVAILABLE.mpa);
     register_one::<HipVorbisDecoder>(registry, frontends::AVAILABLE.vorbis);
     register_one::<HipFlacDecoder>(registry, frontends::AVAILABLE.flac);
+    register_one::<HipAlacDecoder>(registry, frontends::AVAILABLE.alac);
 }
 
 /// Register one decoder type above whatever the registry holds for its codecs, if its front end is present.

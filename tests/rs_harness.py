@@ -23,7 +23,7 @@ from rsinterp import parser as P  # noqa: E402
 CRATE = ROOT / "bindings" / "rust" / "symphonia-accel-hip" / "src"
 PATCHES = ROOT / "bindings" / "rust" / "patches"
 REF = Path("/root/reference")
-CODEC_CRATES = ("symphonia-bundle-flac", "symphonia-codec-aac", "symphonia-bundle-mp3", "symphonia-codec-vorbis")
+CODEC_CRATES = ("symphonia-bundle-flac", "symphonia-codec-aac", "symphonia-bundle-mp3", "symphonia-codec-vorbis", "symphonia-codec-alac")
 CORE_IO = ("errors.rs", "util.rs", "io/mod.rs", "io/buf_reader.rs", "io/monitor_stream.rs", "checksum/crc8.rs", "checksum/crc16.rs",
            "units.rs", "packet.rs")
 
@@ -62,7 +62,7 @@ def strip_vlc_entries(src):
 
 
 class Harness:
-    def __init__(self, dll, reference=False, flac_tree=None):
+    def __init__(self, dll, reference=False, flac_tree=None, alac_tree=None):
         self.it = it = Interp()
         self.dll = dll
         self.reference = reference
@@ -80,6 +80,10 @@ class Harness:
             it.load_file(REF / "symphonia-common/src/xiph/audio/flac/mod.rs")
             # (symphonia-core's Position bit flags are outside the stand-in Channels)
             it.load_source("pub fn flac_channels_to_channels(channels: u32) -> Channels { Channels::Discrete(channels as u16) }", "stub")
+        if alac_tree is not None:  # the ALAC crate (patched or not) + the magic cookie
+            for f in (("backend.rs",) if (alac_tree / "backend.rs").exists() else ()) + ("lib.rs",):
+                it.load_file(alac_tree / f)
+            it.load_file(REF / "symphonia-common/src/apple/audio/alac.rs")
         self.bridge = F.Bridge(it, (ROOT / "bindings" / "rust" / "symaccel_sys.rs").read_text(), dll) if dll is not None else None
         bad = it.globals.get("__unparsed__")
         assert not bad, bad

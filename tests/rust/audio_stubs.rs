@@ -20,6 +20,18 @@ impl Channels {
     }
 }
 
+/// audio/channels.rs: the layouts Apple Lossless names (symphonia-common/src/apple/audio/alac.rs:152-161); the stand-in keeps the count
+pub mod layouts {
+    pub const CHANNEL_LAYOUT_MONO: Channels = Channels::Discrete(1);
+    pub const CHANNEL_LAYOUT_STEREO: Channels = Channels::Discrete(2);
+    pub const CHANNEL_LAYOUT_MPEG_3P0_B: Channels = Channels::Discrete(3);
+    pub const CHANNEL_LAYOUT_MPEG_4P0_B: Channels = Channels::Discrete(4);
+    pub const CHANNEL_LAYOUT_MPEG_5P0_D: Channels = Channels::Discrete(5);
+    pub const CHANNEL_LAYOUT_MPEG_5P1_D: Channels = Channels::Discrete(6);
+    pub const CHANNEL_LAYOUT_AAC_6P1: Channels = Channels::Discrete(7);
+    pub const CHANNEL_LAYOUT_MPEG_7P1_B: Channels = Channels::Discrete(8);
+}
+
 pub struct AudioSpec {
     rate: u32,
     channels: Channels,
@@ -68,6 +80,16 @@ impl<S> AudioBuffer<S> {
         assert!(self.num_frames + num_new_frames <= self.capacity(), "capacity will be exceeded");
         self.num_frames += num_new_frames;
         num_new_frames
+    }
+    /// audio/buf.rs render_silence: the new frames are the sample format's mid-point (0 for the i32 buffer of the one caller, ALAC)
+    pub fn render_silence(&mut self, num_frames: Option<usize>) {
+        let start = self.num_frames;
+        let num_new_frames = self.render_uninit(num_frames);
+        for plane in &mut self.planes {
+            for i in start..start + num_new_frames {
+                plane[i] = 0;
+            }
+        }
     }
     pub fn shift(&mut self, shift: usize) {
         if shift >= self.num_frames {
@@ -160,6 +182,7 @@ pub const CODEC_ID_VORBIS: AudioCodecId = AudioCodecId(0x1000);
 pub const CODEC_ID_MP3: AudioCodecId = AudioCodecId(0x1003);
 pub const CODEC_ID_AAC: AudioCodecId = AudioCodecId(0x1004);
 pub const CODEC_ID_FLAC: AudioCodecId = AudioCodecId(0x2000);
+pub const CODEC_ID_ALAC: AudioCodecId = AudioCodecId(0x2003);
 
 /// codecs/audio.rs:300-400 (the fields the decoders on the path read or amend)
 pub struct AudioCodecParameters {

@@ -108,3 +108,37 @@ impl FlacFrontEnd for ScriptedFlacFront {
         })
     }
 }
+
+pub struct ScriptedAlacFront {
+    pub params: AudioCodecParameters,
+    pub nch: usize,
+    pub max_frames: usize,
+    pub script: Vec<ParsedAlac>,
+    pub parses: usize,
+}
+
+impl AlacFrontEnd for ScriptedAlacFront {
+    fn params(&self) -> &AudioCodecParameters {
+        &self.params
+    }
+    fn channels(&self) -> usize {
+        self.nch
+    }
+    fn max_frames(&self) -> usize {
+        self.max_frames
+    }
+    fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedAlac> {
+        let i = script_index(packet)?;
+        self.parses += 1;
+        let p = &self.script[i];
+        Ok(ParsedAlac {
+            frames: p.frames,
+            words: p.words.clone(),
+            desc: p.desc.clone(),
+            coeffs: p.coeffs.clone(),
+            pairs: p.pairs.clone(),
+            tails: p.tails.clone(),
+            out_shift: p.out_shift,
+        })
+    }
+}

@@ -1,4 +1,4 @@
-"""The codec adapters of the Rust shim crate -- bindings/rust/symphonia-accel-hip/src/{aac,mpa,vorbis,flac,ctx,decoder,lookahead}.rs --
+"""The codec adapters of the Rust shim crate -- bindings/rust/symphonia-accel-hip/src/{aac,mpa,vorbis,flac,alac,ctx,decoder,lookahead}.rs --
 EXECUTED under the repository's Rust interpreter with their `unsafe extern "C"` calls bound through ctypes to libsymaccel
 (tools/rsinterp/ffi.py): the CPU-emulation build of the kernels here, the hipcc-built library in the `-m gpu` twin of every test.
 
@@ -274,3 +274,81 @@ def test_flac_adapter_restores_the_pcm(make_dll, bps, blocksize, max_batch):
     r = h.it.call("HipFlacDecoder::try_new", params, h.opts(verify=True), front, usize(2))
     assert r.variant == "Err" and r.f["0"].variant == "Unsupported"  # the MD5 check is the caller's with this decoder
     assert "symaccel_flac_restore" in h.bridge.calls
+
+
+# ------------------------------------------------------------------------------------------------ ALAC
+
+def wrap32(v):
+    return ((np.asarray(v, np.int64) + (1 << 31)) % (1 << 32)) - (1 << 31)
+
+
+@pytest.mark.parametrize("make_dll", LIBS)
+@pytest.mark.parametrize("depth,frames,max_batch", [(16, 160, 4), (24, 352, 1), (20, 64, 8)])
+def test_alac_adapter_restores_the_pcm(make_dll, depth, frames, max_batch):
+    """compressed and uncompressed elements, both predictor modes, orders up to 31, mid-side pairs, separately coded low bits and the
+    final left-justification through AlacBatch::transform / publish: the device predicts (symaccel_alac_predict), the adapter does
+    what follows on the copy out, in the decoder's order (symphonia-codec-alac/src/lib.rs:541-598, 409-414)"""
+    h = harness(make_dll, "alac.rs")
+    rng = np.random.default_rng(depth * 1000 + frames)
+    npk, nch = 9, 2
+    script, want = [], []
+    for t in range(npk):
+        n = frames if t != npk - 1 else frames - 37  # the last packet of a stream is short
+        tail_shift = 8 if (t % 3 == 1 and depth > 16) else 0
+        is_pair = t % 4 != 3
+        bps = depth - tail_shift + (1 if is_pair else 0)
+        uncompressed = t % 5 == 4
+        words, descs, coeffs, planes = [], [], np.zeros((nch, 32), np.int64), []
+        for c in range(nch):
+            if uncompressed:
+                mode, order, qshift = 0, 0, 0
+                res = rng.integers(-(1 << (depth - 1)), 1 << (depth - 1), n)
+            else:
+                mode = 15 if (t + c) % 4 == 2 else 0
+                order = int(rng.choice([0, 1, 4, 8, 12, 31]))
+                qshift = int(rng.integers(4, 10))
+                co = (rng.integers(-300, 300, 32) * (0.7 ** np.arange(32))).astype(np.int64)
+                co[order:] = 0
+                coeffs[c] = co
+                res = rng.integers(-200, 200, n)
+                res[rng.random(n) < 0.15] = 0
+            d = oracle.alac_desc(np.array([mode]), np.array([order]), np.array([qshift]), np.array([bps if not uncompressed else 32]))
+            planes.append(oracle.alac_predict(res.astype(np.int32)[None], d, coeffs[c].astype(np.int32)[None])[0].astype(np.int64))
+            words.append(res)
+            descs.append(I.Struct("SymaccelAlacDesc", {"mode": I.Int(mode, "u8"), "lpc_order": I.Int(order, "u8"), "shift": I.Int(qshift, "u8"),
+                                                         "bps": I.Int(bps if not uncompressed else 32, "u8")}))
+        pairs, tails = [], []
+        if is_pair and not uncompressed and t % 2 == 0:
+            w, s = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+            pairs.append(I.Struct("AlacPair", {"plane0": usize(0), "plane1": usize(1), "weight": I.Int(w, "i32"), "shift": I.Int(s, "u8")}))
+            left = planes[0] + planes[1] - ((planes[1] * w) >> s)
+            planes = [left, left - planes[1]]
+        if tail_shift and not uncompressed:
+            bits = rng.integers(0, 1 << tail_shift, 2 * n if is_pair else n)
+            if is_pair:
+                tails.append(I.Struct("AlacTail", {"plane0": usize(0), "plane1": I.some(usize(1)), "shift": I.Int(tail_shift, "u8"),
+                                                   "bits": I.Arr([I.Int(int(b), "u16") for b in bits], True)}))
+                planes = [(planes[0] << tail_shift) | bits[0::2], (planes[1] << tail_shift) | bits[1::2]]
+            else:
+                tails.append(I.Struct("AlacTail", {"plane0": usize(0), "plane1": I.NONE, "shift": I.Int(tail_shift, "u8"),
+                                                   "bits": I.Arr([I.Int(int(b), "u16") for b in bits], True)}))
+                planes = [(planes[0] << tail_shift) | bits, planes[1]]
+        script.append(I.Struct("ParsedAlac", {"frames": usize(n), "words": i32_vec(np.array(words)), "desc": I.Arr(descs, True),
+                                               "coeffs": i32_vec(coeffs), "pairs": I.Arr(pairs, True), "tails": I.Arr(tails, True),
+                                               "out_shift": I.Int(32 - depth, "u32")}))
+        want.append(wrap32(np.stack([wrap32(p) for p in planes]) << (32 - depth)))
+    params = h.params("CODEC_ID_ALAC", 44100, nch, bps=depth)
+    front = I.Struct("ScriptedAlacFront", {"params": params, "nch": usize(nch), "max_frames": usize(frames), "script": I.Arr(script, True),
+                                            "parses": usize(0)})
+    r = h.it.call("HipAlacDecoder::try_new", params, h.opts(), front, usize(max_batch))
+    assert r.variant == "Ok", r
+    dec = r.f["0"]
+    for t in range(npk):
+        st, got = h.decode("HipAlacDecoder", dec, h.packet(key(t), frames * t))
+        assert st == "ok" and np.array_equal(got, want[t]), (t, got.shape, want[t].shape)
+    st, err = h.decode("HipAlacDecoder", dec, h.packet(bytes([255, 0]), 0))
+    assert (st, err) == ("err", "DecodeError")
+    h.it.call_method("HipAlacDecoder", "reset", dec)
+    st, got = h.decode("HipAlacDecoder", dec, h.packet(key(2), 0))
+    assert st == "ok" and np.array_equal(got, want[2])
+    assert "symaccel_alac_predict" in h.bridge.calls

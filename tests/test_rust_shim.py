@@ -172,6 +172,19 @@ def test_every_symphonia_core_import_names_an_item_the_reference_defines():
     assert checked >= 40
 
 
+@localref
+def test_the_alac_cookie_import_names_what_symphonia_common_exports():
+    """alac.rs reads the frame length and channel count from symphonia_common::apple::audio::alac::MagicCookie"""
+    src = (CRATE / "alac.rs").read_text()
+    assert "use symphonia_common::apple::audio::alac::MagicCookie;" in src
+    ref = (REF / "symphonia-common/src/apple/audio/alac.rs").read_text()
+    assert re.search(r"pub struct MagicCookie\b", ref) and re.search(r"pub fn read\(mut buf: &\[u8\]\) -> Result<MagicCookie>", ref)
+    for field in ("frame_length: u32", "num_channels: u8"):
+        assert "pub " + field in ref
+    for mod in ("apple", "audio", "alac"):
+        assert re.search(r"pub mod %s\b" % mod, "\n".join(q.read_text() for q in (REF / "symphonia-common/src").rglob("*.rs") if q.name in ("lib.rs", "mod.rs")))
+
+
 # ------------------------------------------------------------------------------------------------ traits
 
 TRAIT_FILES = {"AudioDecoder": "codecs/audio.rs", "RegisterableAudioDecoder": "codecs/registry.rs", "FormatReader": "formats/mod.rs"}
@@ -228,7 +241,7 @@ def test_trait_impls_match_the_trait_text_of_the_reference():
                     assert type_shape(ta) == type_shape(tb), "%s::%s parameter %s vs %s" % (who, n, type_shape(ta), type_shape(tb))
                 assert type_shape(m[5]) == type_shape(w[5]), "%s::%s returns %s, the trait %s" % (who, n, type_shape(m[5]), type_shape(w[5]))
             seen.setdefault(tname, []).append(type_shape(it[1]))
-    assert sorted(seen["AudioDecoder"]) == ["HipAacDecoder", "HipFlacDecoder", "HipMpaDecoder", "HipVorbisDecoder"]
+    assert sorted(seen["AudioDecoder"]) == ["HipAacDecoder", "HipAlacDecoder", "HipFlacDecoder", "HipMpaDecoder", "HipVorbisDecoder"]
     assert sorted(seen["RegisterableAudioDecoder"]) == sorted(seen["AudioDecoder"])
     assert seen["FormatReader"] == ["LookaheadReader"]
 

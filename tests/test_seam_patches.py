@@ -32,6 +32,7 @@ SEAM = {  # crate -> (file defining the trait, shim file with the recording back
     "symphonia-codec-aac": ("src/aac/backend.rs", "aac.rs", "AacDecoder", "src/aac/mod.rs"),
     "symphonia-bundle-mp3": ("src/backend.rs", "mpa.rs", "MpaDecoder", "src/decoder.rs"),
     "symphonia-codec-vorbis": ("src/backend.rs", "vorbis.rs", "VorbisDecoder", "src/lib.rs"),
+    "symphonia-codec-alac": ("src/backend.rs", "alac.rs", "AlacDecoder", "src/lib.rs"),
 }
 
 
@@ -85,6 +86,8 @@ def test_the_seam_is_a_public_trait_with_the_cpu_code_as_default(tree, crate):
         assert "impl SynthBackend for CpuBackend" in text and "decoder::fixed_predict(order, buf)" in text and "decoder::lpc_dispatch(" in text
     elif crate == "symphonia-codec-aac":
         assert "impl SynthBackend for Dsp" in text and "Dsp::synth(self, coeffs, delay" in text
+    elif crate == "symphonia-codec-alac":
+        assert "impl SynthBackend for CpuBackend" in text and "crate::predict(pred, out)" in text and "crate::decorrelate_mid_side(" in text
     else:
         assert "if let Some(backend) = self.backend.as_mut()" in diff and "continue;" in diff
     # the seam is reachable from outside the crate
@@ -114,14 +117,14 @@ def test_the_shim_recorders_implement_the_patched_traits(tree, crate):
     assert "try_new_with_backend(" in shim and "struct SeamFrontEnd" in shim
 
 
-def test_register_registers_all_four_decoders():
+def test_register_registers_all_five_decoders():
     fe = (CRATE / "frontends.rs").read_text()
-    assert "Available { aac: true, mpa: true, vorbis: true, flac: true }" in fe
+    assert "Available { aac: true, mpa: true, vorbis: true, flac: true, alac: true }" in fe
     assert "unsupported_error" not in fe  # no stub front end is left
-    for codec in ("aac", "mpa", "vorbis", "flac"):
+    for codec in ("aac", "mpa", "vorbis", "flac", "alac"):
         assert re.search(r"pub fn %s_front_end\(.*\) -> Result<Box<dyn \w+FrontEnd>> \{\s*Ok\(Box::new\(crate::%s::SeamFrontEnd::try_new\(" % (codec, codec), fe), codec
     lib = (CRATE / "lib.rs").read_text()
-    for dec in ("HipAacDecoder", "HipMpaDecoder", "HipVorbisDecoder", "HipFlacDecoder"):
+    for dec in ("HipAacDecoder", "HipMpaDecoder", "HipVorbisDecoder", "HipFlacDecoder", "HipAlacDecoder"):
         assert "register_one::<%s>(registry, frontends::AVAILABLE." % dec in lib
 
 

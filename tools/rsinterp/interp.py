@@ -1351,7 +1351,11 @@ class Interp:
         return e[1]
 
     def e_str(self, e, env):
-        return e[1]
+        s = e[1]
+        if s.startswith('b"'):  # a byte-string literal is a `&[u8; N]`
+            raw = s[2:-1].encode('ascii').decode('unicode_escape').encode('latin-1')
+            return Arr([Int(b, 'u8') for b in raw], False)
+        return s
 
     def e_char(self, e, env):
         return Int(e[1], 'u8' if e[2] else 'char')
@@ -2414,6 +2418,12 @@ class Interp:
         if name == 'trailing_zeros':
             bits = INT_BITS[ty()]
             v = x.v & ((1 << bits) - 1)
+            return Int(bits if v == 0 else (v & -v).bit_length() - 1, 'u32')
+        if name in ('leading_ones', 'trailing_ones'):
+            bits = INT_BITS[ty()]
+            v = ~x.v & ((1 << bits) - 1)
+            if name == 'leading_ones':
+                return Int(bits - v.bit_length(), 'u32')
             return Int(bits if v == 0 else (v & -v).bit_length() - 1, 'u32')
         if name in ('count_ones', 'count_zeros'):
             bits = INT_BITS[ty()]
