@@ -55,21 +55,39 @@ def patched_tree(crates=CODEC_CRATES):
     return tmp
 
 
-def strip_vlc_entries(src):
-    # `decl_entry!(/// doc ...)` matches its `#[doc = $expr]` arm through the doc comment, which the lexer drops with the other
-    # comments: the codebook entry types are not on the FLAC path
-    return re.sub(r"decl_entry!\((?:.|\n)*?\);\n", "", src)
+def expand_vlc_entries(src):
+    """`decl_entry!(/// doc ...)` matches its `#[doc = $expr]` arm through the doc comment, which the lexer drops with the other
+    comments: write the nine invocations out as the items the macro produces (io/bit.rs:52-66)"""
+    def item(m):
+        name, value_type, index_type = [s.strip() for s in re.sub(r"///[^\n]*\n", "", m.group(1)).strip().rstrip(",").split(",")]
+        return "pub struct %s;\nimpl CodebookEntry for %s { type IndexType = %s; type ValueType = %s; }\n" % (name, name, index_type, value_type)
+    return re.sub(r"decl_entry!\(((?:.|\n)*?)\);\n", item, src)
+
+
+def aac_codebooks_for_the_interpreter(src):
+    """symphonia-codec-aac/src/aac/codebooks.rs with two spellings changed, neither of which changes what it computes:
+      * `make_basic_codebook` / `make_value_codebook` are generic in their RETURN type, which rustc infers from the declared types
+        of the statics they initialise (codebooks.rs:627-650); a dynamically typed interpreter needs the type named at the call;
+      * the private `iquant(usize)` shares its name with ics/pulse.rs's private `iquant(f32)`; the interpreter has one namespace."""
+    src = src.replace("make_basic_codebook(&SPECTRUM_TABLES", "make_basic_codebook::<QuadsCodebook>(&SPECTRUM_TABLES")
+    src = re.sub(r"make_value_codebook\(&SPECTRUM_TABLES\[(\d)\]", r"make_value_codebook::<PairsCodebook, _>(&SPECTRUM_TABLES[\1]", src)
+    src = src.replace("make_value_codebook(&SPECTRUM_TABLES[10]", "make_value_codebook::<EscapeCodebook, _>(&SPECTRUM_TABLES[10]")
+    return re.sub(r"\biquant\(", "codebook_iquant(", src)
+
+
+AAC_FILES = ("common.rs", "window.rs", "dsp.rs", "ics/gain.rs", "ics/ltp.rs", "ics/pulse.rs", "ics/tns.rs", "ics/mod.rs", "cpe.rs", "mod.rs")
+CORE_DSP = ("dsp/fft/mod.rs", "dsp/fft/no_simd.rs", "dsp/mdct.rs")  # the in-tree transform: what the product reproduces (SURVEY 8c)
 
 
 class Harness:
-    def __init__(self, dll, reference=False, flac_tree=None, alac_tree=None):
+    def __init__(self, dll, reference=False, flac_tree=None, alac_tree=None, aac_tree=None):
         self.it = it = Interp()
         self.dll = dll
         self.reference = reference
         if reference:
             for f in CORE_IO:
                 it.load_file(REF / "symphonia-core" / "src" / f)
-            it.load_source(strip_vlc_entries((REF / "symphonia-core/src/io/bit.rs").read_text()), "io/bit.rs")
+            it.load_source(expand_vlc_entries((REF / "symphonia-core/src/io/bit.rs").read_text()), "io/bit.rs")
         else:
             it.load_file(ROOT / "tests" / "rust" / "core_stubs.rs")
         it.load_file(ROOT / "tests" / "rust" / "audio_stubs.rs")
@@ -84,6 +102,13 @@ class Harness:
             for f in (("backend.rs",) if (alac_tree / "backend.rs").exists() else ()) + ("lib.rs",):
                 it.load_file(alac_tree / f)
             it.load_file(REF / "symphonia-common/src/apple/audio/alac.rs")
+        if aac_tree is not None:  # the AAC crate's `aac` module (patched or not), the transforms it calls, the AudioSpecificConfig
+            for f in CORE_DSP:
+                it.load_file(REF / "symphonia-core" / "src" / f)
+            it.load_file(REF / "symphonia-common/src/mpeg/audio/mod.rs")
+            it.load_source(aac_codebooks_for_the_interpreter((aac_tree / "aac" / "codebooks.rs").read_text()), "aac/codebooks.rs")
+            for f in AAC_FILES + (("backend.rs",) if (aac_tree / "aac" / "backend.rs").exists() else ()):
+                it.load_file(aac_tree / "aac" / f)
         self.bridge = F.Bridge(it, (ROOT / "bindings" / "rust" / "symaccel_sys.rs").read_text(), dll) if dll is not None else None
         bad = it.globals.get("__unparsed__")
         assert not bad, bad
@@ -136,6 +161,30 @@ class Harness:
         if owned:
             return self.it.call("Packet::new", I.Int(track, "u32"), ts, arr)
         return I.Struct("PacketRef", {"track_id": I.Int(track, "u32"), "pts": ts, "data": I.Slice(arr.a, 0, len(arr.a), False)})
+
+    @staticmethod
+    def f32_buffers(value):
+        """the stand-in AudioBuffer<S>::new cannot know S and fills its planes with untyped zeros; a decoder that hands plane slices
+        to functions declared `&mut [f32]` (the reference's AAC decoder) needs them typed: walk `value`, retype every AudioBuffer"""
+        from rsinterp import stdext
+        seen, todo = set(), [value]
+        while todo:
+            v = I.deref(todo.pop())
+            if id(v) in seen:
+                continue
+            seen.add(id(v))
+            if isinstance(v, I.Struct) and v.name == "AudioBuffer":
+                for plane in v.f["planes"].a:
+                    plane.a[:] = [I.F32(0.0)] * len(plane.a)
+            elif isinstance(v, (I.Struct, I.Enum)):
+                todo.extend((v.f or {}).values())
+            elif isinstance(v, I.Arr):
+                todo.extend(x for x in v.a if not isinstance(x, (I.Int, float, bool, str)))
+            elif isinstance(v, stdext.Cell):
+                todo.append(v.v)
+            elif isinstance(v, tuple):
+                todo.extend(v)
+        return value
 
     def decode(self, type_name, dec, pkt):
         """decode_ref: ('ok', planes as a numpy array [channel][frames]) or ('err', variant name); checks the buffer is cleared on error"""

@@ -24,10 +24,13 @@ class Cell:
 
 
 class HMap:
-    __slots__ = ('d', 'vty')
+    __slots__ = ('d', 'vty', 'ordered')
 
-    def __init__(self, vty=None):
-        self.d, self.vty = {}, vty  # image of key -> (key, value)
+    def __init__(self, vty=None, ordered=False):
+        self.d, self.vty, self.ordered = {}, vty, ordered  # image of key -> (key, value); ordered: a BTreeMap (iterates by key)
+
+    def items(self):
+        return [self.d[h] for h in sorted(self.d)] if self.ordered else list(self.d.values())
 
     def __repr__(self):
         return 'HashMap(%d)' % len(self.d)
@@ -80,9 +83,9 @@ def default_of(it, ty):
             return I.Enum('Option', 'None')
         if name in ('Vec', 'VecDeque'):
             return I.Arr([], True)
-        if name == 'HashMap':
+        if name in ('HashMap', 'BTreeMap'):
             vty = gargs[1][1] if len(gargs) >= 2 and gargs[1][0] == 'gtype' else None
-            return HMap(vty)
+            return HMap(vty, name == 'BTreeMap')
         if name in it.types and it.types[name][0] == 'struct':
             item = it.types[name]
             return I.Struct(name, {f: default_of(it, t) for f, t in item[3]})
@@ -117,6 +120,10 @@ def path_builtin(it, segs):
         return I.Builtin(mutex_new, 'Mutex::new')
     if head == 'HashMap' and name in ('new', 'with_capacity', 'default'):
         return I.Builtin(lambda *a: HMap(), 'HashMap::new')
+    if head == 'BTreeMap' and name in ('new', 'default'):
+        return I.Builtin(lambda *a: HMap(None, True), 'BTreeMap::new')
+    if head == 'NonZero' and name == 'new':  # NonZero<T> is its integer; `get()` gives it back (interp.int_method)
+        return I.Builtin(lambda v: I.some(I.deref(v)) if I.deref(v).v != 0 else I.NONE, 'NonZero::new')
     if head == 'VecDeque' and name in ('new', 'with_capacity', 'default'):
         return I.Builtin(lambda *a: I.Arr([], True), 'VecDeque::new')
     if name == 'default' and head in it.types and it.types[head][0] == 'struct' and 'default' not in it.impls.get(head, {}):
@@ -174,13 +181,13 @@ def method(it, base, name, args, env):
             d.clear()
             return True, I.UNIT
         if name in ('values', 'values_mut', 'into_values'):
-            return True, I.RIter(lst=[v for _, v in d.values()])
+            return True, I.RIter(lst=[v for _, v in base.items()])
         if name in ('keys', 'into_keys'):
-            return True, I.RIter(lst=[k for k, _ in d.values()])
+            return True, I.RIter(lst=[k for k, _ in base.items()])
         if name in ('iter', 'iter_mut', 'into_iter'):
-            return True, I.RIter(lst=[(k, v) for k, v in d.values()])
+            return True, I.RIter(lst=[(k, v) for k, v in base.items()])
         if name == 'clone':
-            m = HMap(base.vty)
+            m = HMap(base.vty, base.ordered)
             m.d = {h: (I.copyval(k), I.deepclone(v) if I.is_agg(v) else v) for h, (k, v) in d.items()}
             return True, m
         raise I.InterpError('no method %s on HashMap' % name)
