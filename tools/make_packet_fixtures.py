@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/packets/*.npz (needs /root/reference): whole-decoder golden vectors.
+
+For each stream, packets from the writers under tests/ are decoded by the REFERENCE's own decoder, executed from /root/reference by
+tools/rsinterp (tests/test_aac_packets.py describes the set-up): `pcm` is what it returns -- outputs of the reference itself.  The same
+packets are parsed by the shim's front end (the patched reference decoder with the recording backend): `coeffs` / `side` are what the
+reference hands to its synthesis stage, packet by packet.  tests/test_packet_fixtures.py replays them through libsymaccel -- on the
+CPU-emulation build and, `-m gpu`, on the MI355X, where /root/reference does not exist -- and compares with `pcm` bit for bit.
+
+    python tools/make_packet_fixtures.py            # rewrites the files (deterministic: the same arrays every time)
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import test_aac_packets as A  # noqa: E402
+from rs_harness import REF, Harness, patched_tree  # noqa: E402
+from rsinterp import interp as I  # noqa: E402
+
+OUT = ROOT / "tests" / "golden" / "packets"
+AAC_STREAMS = {"aac_mono": (1, 7, 1), "aac_stereo": (2, 8, 2)}  # name -> (seed, packets, channels): two of test_aac_packets.STREAMS
+
+
+def aac(name, seed, n_packets, nch, tree):
+    packets = [p for p, _ in A.stream(seed, n_packets, nch)]
+    ref = Harness(None, reference=True, aac_tree=REF / A.CRATE / "src")
+    ref_dec = A.cpu_decoder(ref, nch)
+    h, _ = A.hip_decoder(tree, nch)  # (loads the shim; the decoder itself is not used: the front end is driven directly)
+    front = h.it.call("aac_front_end", h.params("CODEC_ID_AAC", 44100, nch), h.opts())
+    assert front.variant == "Ok", front
+    front = h.f32_buffers(front.f["0"])
+    pcm, coeffs, side = [], [], []
+    for i, pk in enumerate(packets):
+        st, planes = ref.decode("AacDecoder", ref_dec, ref.packet(pk, i * 1024))
+        assert st == "ok"
+        pcm.append(planes)
+        r = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(pk, i * 1024))
+        assert r.variant == "Ok", r
+        parsed = r.f["0"]
+        coeffs.append(np.array([np.float32(x) for x in parsed.f["coeffs"].a], np.float32).reshape(nch, 1024))
+        side.append(np.array([x.v for x in parsed.f["side"].a], np.uint8))
+    lens = np.array([len(p) for p in packets], np.int32)
+    np.savez_compressed(OUT / (name + ".npz"), packet_bytes=np.frombuffer(b"".join(packets), np.uint8), packet_lens=lens,
+                        coeffs=np.stack(coeffs), side=np.stack(side), pcm=np.stack(pcm).astype(np.float32))
+    print(name, "packets", len(packets), "bytes", int(lens.sum()), "peak", float(np.abs(np.stack(pcm)).max()))
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    tree = patched_tree((A.CRATE,)) / A.CRATE / "src"
+    for name, (seed, n, nch) in AAC_STREAMS.items():
+        aac(name, seed, n, nch, tree)
+
+
+if __name__ == "__main__":
+    main()
