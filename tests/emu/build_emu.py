@@ -1,6 +1,7 @@
 """TEST-ONLY: compile the product's .hip/.cpp sources with g++ against the stand-in HIP header
 (tests/emu/include) into tests/emu/libsymaccel_emu.so, so kernel logic can run on CPU threads.
 The product library (symphonia_amd/libsymaccel.so) is never built this way."""
+import os
 import subprocess
 import sys
 from pathlib import Path
@@ -60,7 +61,9 @@ def build(force=False):
             sys.stderr.write("==== %s ====\n%s\n" % (src, log.decode(errors="replace")[-6000:]))
     if bad:
         raise RuntimeError("emulation build failed")
-    subprocess.run(["g++", "-shared", "-pthread", "-o", str(out), *objs], check=True)
+    tmp = out.with_suffix(".so.%d.tmp" % os.getpid())  # linked aside and renamed: a process that races this one never maps half a file
+    subprocess.run(["g++", "-shared", "-pthread", "-o", str(tmp), *objs], check=True)
+    os.replace(tmp, out)
     return out
 
 

@@ -3,6 +3,7 @@ its sources, the generated FFI declarations bound to a libsymaccel through ctype
 in the CPU suite, the hipcc-built library in the `-m gpu` suite), stand-ins for symphonia-core's container types
 (tests/rust/core_stubs.rs, audio_stubs.rs) -- or, with `reference=True` (needs /root/reference), the reference's own io / checksum /
 packet modules and a codec crate with the repository's seam patch applied."""
+import os
 import re
 import shutil
 import subprocess
@@ -26,6 +27,15 @@ REF = Path("/root/reference")
 CODEC_CRATES = ("symphonia-bundle-flac", "symphonia-codec-aac", "symphonia-bundle-mp3", "symphonia-codec-vorbis", "symphonia-codec-alac")
 CORE_IO = ("errors.rs", "util.rs", "io/mod.rs", "io/buf_reader.rs", "io/monitor_stream.rs", "checksum/crc8.rs", "checksum/crc16.rs",
            "units.rs", "packet.rs")
+
+
+# The packet-level tests run whole decoders under the interpreter (1-2 s per frame and decoder).  By default they run a subset sized
+# for the every-round CPU suite; SYMACCEL_PACKET_TESTS=full runs every stream (profiles/r04_packet_tests_full.log is such a run).
+FULL_PACKET_TESTS = os.environ.get("SYMACCEL_PACKET_TESTS", "") == "full"
+
+
+def sized(full, quick):
+    return full if FULL_PACKET_TESTS else quick
 
 
 def usize(v):
@@ -75,15 +85,50 @@ def aac_codebooks_for_the_interpreter(src):
     return re.sub(r"\biquant\(", "codebook_iquant(", src)
 
 
+def cfg_features(src, enabled):
+    """what rustc's cfg-stripping does to a file whose items, enum variants, match arms and array elements carry
+    `#[cfg(feature = "...")]` on a line of their own (symphonia-bundle-mp3/src/decoder.rs): the attribute line goes, and with a
+    feature that is off so does the element behind it (the parser reads attributes in those places and drops them)"""
+    out, lines, i = [], src.split("\n"), 0
+    while i < len(lines):
+        m = re.match(r'\s*#\[cfg\(feature = "(\w+)"\)\]\s*$', lines[i])
+        if not m:
+            out.append(lines[i])
+            i += 1
+            continue
+        i += 1
+        if m.group(1) in enabled:
+            continue
+        depth = 0
+        while True:
+            ln = lines[i]
+            i += 1
+            depth += sum(ln.count(c) for c in "{([") - sum(ln.count(c) for c in "})]")
+            if depth <= 0 and re.search(r"[,;}]\s*$", ln):
+                break
+    return "\n".join(out)
+
+
+MP3_FILES = ("common.rs", "header.rs", "layer3/common.rs", "layer3/codebooks.rs", "layer3/bitstream.rs", "layer3/requantize.rs",
+             "layer3/stereo.rs", "layer3/hybrid_synthesis.rs", "synthesis.rs", "layer3/mod.rs")
 AAC_FILES = ("common.rs", "window.rs", "dsp.rs", "ics/gain.rs", "ics/ltp.rs", "ics/pulse.rs", "ics/tns.rs", "ics/mod.rs", "cpe.rs", "mod.rs")
 CORE_DSP = ("dsp/fft/mod.rs", "dsp/fft/no_simd.rs", "dsp/mdct.rs")  # the in-tree transform: what the product reproduces (SURVEY 8c)
 
 
+_SHARED_STATICS = {}  # the reference's lazily built tables (VLC codebooks, pow43, windows): built once per process and source text
+
+
 class Harness:
-    def __init__(self, dll, reference=False, flac_tree=None, alac_tree=None, aac_tree=None):
+    def __init__(self, dll, reference=False, flac_tree=None, alac_tree=None, aac_tree=None, mp3_tree=None, sample=None):
         self.it = it = Interp()
+        # the silence value of new AudioBuffers: untyped unless the decoder under test hands plane slices to functions declared
+        # `&mut [f32]` (the reference's AAC and MP3 decoders; sample="f32")
+        zero = {None: lambda: I.Int(0, None), "i32": lambda: I.Int(0, "i32"), "f32": lambda: I.F32(0.0)}["f32" if (aac_tree or mp3_tree) and sample is None else sample]
+        it.globals["audio_stub_sample_mid"] = I.Builtin(zero, "audio_stub_sample_mid")
         self.dll = dll
         self.reference = reference
+        if reference:
+            it.shared_statics = _SHARED_STATICS
         if reference:
             for f in CORE_IO:
                 it.load_file(REF / "symphonia-core" / "src" / f)
@@ -109,6 +154,10 @@ class Harness:
             it.load_source(aac_codebooks_for_the_interpreter((aac_tree / "aac" / "codebooks.rs").read_text()), "aac/codebooks.rs")
             for f in AAC_FILES + (("backend.rs",) if (aac_tree / "aac" / "backend.rs").exists() else ()):
                 it.load_file(aac_tree / "aac" / f)
+        if mp3_tree is not None:  # the MP3 crate (patched or not) built with `features = ["mp3"]`, as the shim's Cargo.toml asks
+            for f in MP3_FILES + (("backend.rs",) if (mp3_tree / "backend.rs").exists() else ()):
+                it.load_file(mp3_tree / f)
+            it.load_source(cfg_features((mp3_tree / "decoder.rs").read_text(), {"mp3"}), "decoder.rs")
         self.bridge = F.Bridge(it, (ROOT / "bindings" / "rust" / "symaccel_sys.rs").read_text(), dll) if dll is not None else None
         bad = it.globals.get("__unparsed__")
         assert not bad, bad
@@ -160,6 +209,10 @@ class Harness:
                                        "data": arr})
         if owned:
             return self.it.call("Packet::new", I.Int(track, "u32"), ts, arr)
+        if self.reference:  # symphonia-core's own PacketRef (packet.rs:146-171)
+            zero = I.Struct("Duration", {"0": I.Int(0, "u64")})
+            return I.Struct("PacketRef", {"track_id": I.Int(track, "u32"), "pts": ts, "dts": ts, "dur": zero, "trim_start": zero, "trim_end": zero,
+                                          "data": I.Slice(arr.a, 0, len(arr.a), False)})
         return I.Struct("PacketRef", {"track_id": I.Int(track, "u32"), "pts": ts, "data": I.Slice(arr.a, 0, len(arr.a), False)})
 
     @staticmethod

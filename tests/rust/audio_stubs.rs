@@ -62,7 +62,9 @@ impl<S> AudioBuffer<S> {
         let num_channels = spec.channels().count();
         let mut planes = Vec::new();
         for _ in 0..num_channels {
-            planes.push(vec![0; capacity]);
+            // `S::MID`: the harness supplies it (tests/rs_harness.py `sample=`), since `S` is inferred from the declared type of the
+            // field the buffer is stored in, which the interpreter does not track
+            planes.push(vec![audio_stub_sample_mid(); capacity]);
         }
         AudioBuffer { spec, planes, num_frames: 0, capacity }
     }

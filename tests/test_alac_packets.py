@@ -25,7 +25,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 
 import alac_writer as W  # noqa: E402
-from rs_harness import REF, Harness, patched_tree, usize  # noqa: E402
+from rs_harness import REF, Harness, patched_tree, sized, usize  # noqa: E402
 from rsinterp import interp as I  # noqa: E402
 
 pytestmark = pytest.mark.localref
@@ -70,7 +70,8 @@ def cpu_decoder(h, nch, depth, frame_length):
     return r.f["0"]
 
 
-STREAMS = [(1, 7, 2, 16, 256), (2, 7, 1, 24, 160), (3, 6, 3, 24, 96), (4, 6, 6, 20, 64)]
+ALL_STREAMS = [(1, 7, 2, 16, 256), (2, 7, 1, 24, 160), (3, 6, 3, 24, 96), (4, 6, 6, 20, 64)]
+STREAMS = sized(ALL_STREAMS, [(1, 7, 2, 16, 128), (4, 6, 6, 20, 64)])  # (SYMACCEL_PACKET_TESTS=full: all of them)
 
 
 @pytest.mark.parametrize("seed,n_packets,nch,depth,frame_length", STREAMS)

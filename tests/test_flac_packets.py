@@ -26,7 +26,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 
 import flac_writer as W  # noqa: E402
-from rs_harness import REF, Harness, patched_tree, u8_vec, usize  # noqa: E402
+from rs_harness import REF, Harness, patched_tree, sized, u8_vec, usize  # noqa: E402
 from rsinterp import interp as I  # noqa: E402
 
 pytestmark = pytest.mark.localref
@@ -95,7 +95,7 @@ def hip_decoder(tree, nch, bps, blocksize, max_batch=None):
     return h, r.f["0"]
 
 
-@pytest.mark.parametrize("seed,n_frames,nch,bps,blocksize", STREAMS[:3])
+@pytest.mark.parametrize("seed,n_frames,nch,bps,blocksize", sized(STREAMS[:3], STREAMS[2:3]))  # (SYMACCEL_PACKET_TESTS=full: three streams)
 def test_the_accelerated_decoder_equals_the_reference_on_packet_bytes(trees, seed, n_frames, nch, bps, blocksize):
     frames, pcm = W.random_stream(seed, n_frames, nch, bps, blocksize)
     ref = Harness(None, reference=True, flac_tree=trees[0])

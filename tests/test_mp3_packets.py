@@ -1,0 +1,206 @@
+"""Packet bytes -> PCM for MPEG-1 / MPEG-2 Layer III, symphonia-check style (symphonia-check/src/main.rs:289-295), through the WHOLE
+decoder:
+
+  frames written by tests/mp3_writer.py (every Huffman table with and without linbits, both count1 tables, all block types incl.
+  mixed blocks, scfsi, MPEG-1 and MPEG-2 scale factors, mono / stereo / dual channel / joint stereo with mid-side and intensity,
+  variable bit rate, main data reaching up to 511 bytes back into earlier frames)
+     |
+     +--> the REFERENCE: symphonia-bundle-mp3's MpaDecoder (decoder.rs, header.rs, layer3/*.rs, synthesis.rs; built with
+     |    `features = ["mp3"]`) on symphonia-core's own BufReader, BitReaderLtr and VLC codebook builder -- all EXECUTED from
+     |    /root/reference by tools/rsinterp  ........................................................................  PCM_ref (f32)
+     |
+     +--> the same decoder with bindings/rust/patches/symphonia-bundle-mp3.diff applied, default (CPU) backend  ......  == PCM_ref, bit for bit
+     |
+     +--> HipMpaDecoder (frontends.rs -> mpa.rs SeamFrontEnd = the patched decoder with the recording backend: header, side
+          information, bit reservoir, scale factors, Huffman decoding, requantisation and joint stereo stay the reference's code;
+          MpaBatch, decoder.rs, lookahead.rs, ctx.rs) with its extern "C" calls bound to libsymaccel (the CPU-emulation build of
+          the kernels): symaccel_mp3_synth does reorder, alias reduction, IMDCT, overlap, frequency inversion and the polyphase
+          filterbank  .................................................................................................  == PCM_ref, bit for bit
+
+What the writer wrote is compared with what the reference's parser hands on: `rzero` of every granule, and -- where no joint stereo
+mixes the channels -- the positions of the non-zero samples.  Needs /root/reference (`localref`); the `-m gpu` twin of the accelerated
+path is tests/test_rust_adapters.py::test_mpa_adapter_* (same adapter code, hipcc-built library, scripted front end)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+
+import mp3_writer as W  # noqa: E402
+from rs_harness import REF, Harness, patched_tree, sized, usize  # noqa: E402
+from rsinterp import interp as I  # noqa: E402
+
+pytestmark = pytest.mark.localref
+
+CRATE = "symphonia-bundle-mp3"
+# (seed, frames, channel mode, MPEG-1?, sample rate code)
+ALL_STREAMS = [(1, 6, "stereo", True, 0), (2, 6, "joint", True, 1), (3, 5, "mono", True, 2), (4, 6, "joint", False, 0), (5, 5, "dual", False, 1)]
+STREAMS = sized(ALL_STREAMS, [(2, 3, "joint", True, 1), (4, 4, "joint", False, 0)])  # (SYMACCEL_PACKET_TESTS=full: all of them)
+
+# None: the decoder is built as the registry builds it (try_registry_new: the default batch, whose pinned buffers the interpreter
+# takes 20 s to zero); the default set builds it through try_new with a small batch instead
+BATCH_OF_THE_PLAIN_TESTS = sized(None, 2)
+
+
+@pytest.fixture(scope="module")
+def trees():
+    return REF / CRATE / "src", patched_tree((CRATE,)) / CRATE / "src"
+
+
+def stream(seed, n, mode, mpeg1, sr_code):
+    s = W.Stream(REF, seed, mode, mpeg1=mpeg1, sr_code=sr_code)
+    return s, s.packets(n)
+
+
+def cpu_decoder(h, s):
+    r = h.it.call("MpaDecoder::try_new", h.params("CODEC_ID_MP3", s.rate, s.nch), h.opts())
+    assert r.variant == "Ok", r
+    return r.f["0"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("seed,n,mode,mpeg1,sr_code", STREAMS)
+def test_the_reference_decoder_and_its_patched_twin_decode_the_frames(trees, seed, n, mode, mpeg1, sr_code):
+    s, packets = stream(seed, n, mode, mpeg1, sr_code)
+    per_frame = 1152 if mpeg1 else 576
+    outs = []
+    for tree in trees:
+        h = Harness(None, reference=True, mp3_tree=tree)
+        dec = cpu_decoder(h, s)
+        got = []
+        for i, (pk, _) in enumerate(packets):
+            st, planes = h.decode("MpaDecoder", dec, h.packet(pk, i * per_frame))
+            assert st == "ok", (i, planes)
+            assert planes.shape == (s.nch, per_frame) and np.isfinite(planes).all()
+            got.append(planes)
+        outs.append(np.stack(got))
+    assert np.abs(outs[0]).max() > 1e-3  # (not a stream of silence)
+    assert np.array_equal(bits(outs[0]), bits(outs[1])), "the seam patch changed what the decoder computes"
+
+
+def shim(tree):
+    from emu_lib import emu_library
+    h = Harness(emu_library().dll, reference=True, mp3_tree=tree)
+    h.it.load_file(ROOT / "tests" / "rust" / "registry_stubs.rs")
+    h.load_shim("lib.rs", "ctx.rs", "decoder.rs", "lookahead.rs", "fallback.rs", "mpa.rs", "frontends.rs")
+    return h
+
+
+def hip_decoder(tree, s, max_batch=None):
+    h = shim(tree)
+    p = h.params("CODEC_ID_MP3", s.rate, s.nch)
+    if max_batch is None:
+        r = h.it.call("HipMpaDecoder::try_registry_new", p, h.opts())  # what the registry calls (registry.rs:34-44)
+    else:
+        front = h.it.call("mpa_front_end", p, h.opts())
+        assert front.variant == "Ok", front
+        r = h.it.call("HipMpaDecoder::try_new", p, h.opts(), front.f["0"], usize(max_batch))
+    assert r.variant == "Ok", r
+    return h, r.f["0"]
+
+
+@pytest.mark.parametrize("seed,n,mode,mpeg1,sr_code", sized(ALL_STREAMS[:2] + ALL_STREAMS[3:4], [(1, 3, "stereo", True, 0)]))
+def test_the_parser_hands_on_what_was_written(trees, seed, n, mode, mpeg1, sr_code):
+    """the shim's front end (the patched decoder with the recording backend) on the writer's frames: side information and spectra"""
+    s, packets = stream(seed, n, mode, mpeg1, sr_code)
+    h = shim(trees[1])
+    front = h.it.call("mpa_front_end", h.params("CODEC_ID_MP3", s.rate, s.nch), h.opts())
+    assert front.variant == "Ok", front
+    front = front.f["0"]
+    ngr = 2 if mpeg1 else 1
+    for i, (pk, rec) in enumerate(packets):
+        r = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(pk, 0))
+        assert r.variant == "Ok", (i, r)
+        parsed = r.f["0"]
+        assert parsed.f["n_granules"].v == ngr
+        xr = np.array([np.float32(x) for x in parsed.f["xr"].a], np.float32).reshape(ngr * s.nch, 576)
+        for k, ((f, q), side) in enumerate(zip(rec["granules"], parsed.f["side"].a)):
+            plain = mode != "joint" or rec["mode_ext"] == 0
+            # (joint stereo processing widens the non-zero range of a channel to its partner's: stereo.rs)
+            assert (side.f["rzero"].v == f["rzero"]) if plain else (side.f["rzero"].v >= f["rzero"]), (i, k)
+            assert side.f["block_type"].v == f["block"] and bool(side.f["is_mixed"].v) == bool(f["mixed"] and f["block"] == W.SHORT), (i, k)
+            if plain:
+                assert np.array_equal(xr[k] != 0, q != 0), (i, k)
+
+
+# (a call into the CPU-emulation library costs seconds whatever the batch: the default set keeps the number of calls down)
+@pytest.mark.parametrize("seed,n,mode,mpeg1,sr_code", sized(ALL_STREAMS, [(4, 3, "joint", False, 0)]))
+def test_the_accelerated_decoder_equals_the_reference_on_packet_bytes(trees, seed, n, mode, mpeg1, sr_code):
+    s, packets = stream(seed, n, mode, mpeg1, sr_code)
+    per_frame = 1152 if mpeg1 else 576
+    ref = Harness(None, reference=True, mp3_tree=trees[0])
+    ref_dec = cpu_decoder(ref, s)
+    h, dec = hip_decoder(trees[1], s, max_batch=BATCH_OF_THE_PLAIN_TESTS)
+    for i, (pk, _) in enumerate(packets):
+        st_r, want = ref.decode("MpaDecoder", ref_dec, ref.packet(pk, i * per_frame))
+        st, got = h.decode("HipMpaDecoder", dec, h.packet(pk, i * per_frame))
+        assert st == st_r == "ok"
+        assert np.array_equal(bits(got), bits(want)), (i, float(np.abs(got - want).max()))
+    assert h.bridge.calls.count("symaccel_mp3_synth") == n  # no look-ahead reader: batches of one
+
+
+def test_damaged_packets_fail_like_the_reference_and_the_stream_goes_on(trees):
+    mpeg1 = sized(True, False)
+    per_frame = 1152 if mpeg1 else 576
+    s, packets = stream(7, sized(7, 5), "stereo", mpeg1, 0)
+    data = [p for p, _ in packets]
+    data[1] = data[1][:-5]                                   # the packet is shorter than the header says
+    bad = bytearray(data[3])
+    bad[2] = (bad[2] & 0x0F) | 0xF0                          # an invalid bit-rate index: the header does not check out
+    data[3] = bytes(bad)
+    ref = Harness(None, reference=True, mp3_tree=trees[0])
+    ref_dec = cpu_decoder(ref, s)
+    h, dec = hip_decoder(trees[1], s, max_batch=BATCH_OF_THE_PLAIN_TESTS)
+    outcomes = []
+    for i, pk in enumerate(data):
+        st_r, want = ref.decode("MpaDecoder", ref_dec, ref.packet(pk, i * per_frame))
+        st, got = h.decode("HipMpaDecoder", dec, h.packet(pk, i * per_frame))
+        assert st == st_r, (i, st, st_r, got, want)
+        if st == "ok":
+            assert np.array_equal(bits(got), bits(want)), i
+        else:
+            assert got == want, (i, got, want)
+        outcomes.append(st)
+    assert outcomes.count("err") >= 2 and outcomes[-1] == "ok"
+
+
+def test_look_ahead_batches_and_reset(trees):
+    mpeg1, n, batch = sized((True, 9, 4), (True, 4, 4))
+    per_frame = 1152 if mpeg1 else 576
+    s, packets = stream(8, n, "joint", mpeg1, 0)
+    data = [p for p, _ in packets]
+    ref = Harness(None, reference=True, mp3_tree=trees[0])
+    ref_dec = cpu_decoder(ref, s)
+    want = [ref.decode("MpaDecoder", ref_dec, ref.packet(pk, i * per_frame))[1] for i, pk in enumerate(data)]
+    ref.it.call_method("MpaDecoder", "reset", ref_dec)
+    again = [ref.decode("MpaDecoder", ref_dec, ref.packet(pk, i * per_frame)) for i, pk in enumerate(data[:3])]
+    h, dec = hip_decoder(trees[1], s, max_batch=batch)
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    pk = I.Arr([h.packet(d, i * per_frame, track=1, owned=True) for i, d in enumerate(data)], True)
+    reader = h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(8))
+
+    def run(first, count):
+        out = []
+        for i in range(first, first + count):
+            r = h.it.call_method("LookaheadReader", "next_packet", reader)
+            p = r.f["0"].f["0"]
+            assert p.f["pts"].f["0"].v == i * per_frame
+            out.append(h.decode("HipMpaDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p)))
+        return out
+
+    n0 = h.bridge.calls.count("symaccel_mp3_synth")
+    for i, (st, got) in enumerate(run(0, n)):
+        assert st == "ok" and np.array_equal(bits(got), bits(want[i])), i
+    assert h.bridge.calls.count("symaccel_mp3_synth") - n0 == -(-n // batch)  # overlap and the V FIFO carry across the batches
+    # seek back to the start + reset: the reference drops overlap, FIFO and the bit reservoir (decoder.rs:149-152); packet 0 does not
+    # reach back, packets 1 and 2 do -- into packet 0's slot, which both decoders have again
+    h.it.call_method("LookaheadReader", "seek", reader, I.Int(0, "i64"), usize(0))
+    h.it.call_method("HipMpaDecoder", "reset", dec)
+    for i, ((st, got), (st_r, want_r)) in enumerate(zip(run(0, 3), again)):  # (one batch: the reader is three or more packets ahead)
+        assert st == st_r == "ok" and np.array_equal(bits(got), bits(want_r)), i

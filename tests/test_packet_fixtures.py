@@ -3,12 +3,16 @@ decoder returns for packets written by tests/aac_writer.py (its whole decoder, e
 made), `coeffs` / `side` what the reference's parse stage hands to its synthesis stage for the same packets.  Here the product does
 the synthesis and must give `pcm` back, bit for bit -- no oracle in between, nothing read from /root/reference:
 
-  * through the C ABI (symaccel_aac_synth, one chain per channel, the packets as its frames), in several segmentations;
-  * through the Rust shim's HipAacDecoder (run by tools/rsinterp, `extern "C"` bound to the library) with a front end that replays
-    the parse results, packet by packet and in look-ahead batches.
+  * through the C ABI (symaccel_aac_synth / symaccel_mp3_synth, one chain per channel, the packets as its frames / granules), in
+    several segmentations;
+  * through the Rust shim's HipAacDecoder / HipMpaDecoder (run by tools/rsinterp, `extern "C"` bound to the library) with a front
+    end that replays the parse results, packet by packet and in look-ahead batches.
+
+AAC-LC: mono and stereo streams with every tool (tests/aac_writer.py).  MP3: an MPEG-1 joint-stereo stream at 48 kHz and an MPEG-2
+(LSF) joint-stereo stream at 22.05 kHz, variable bit rate, all block types, main data through the bit reservoir (tests/mp3_writer.py).
 
 `-m gpu`: the hipcc-built library on the MI355X.  Without a GPU the same checks run on the CPU emulation build of the kernel sources.
-tests/test_aac_packets.py (localref) is where the fixture's two halves are shown to belong together."""
+tests/test_aac_packets.py / test_mp3_packets.py (localref) are where the fixtures' two halves are shown to belong together."""
 from pathlib import Path
 
 import numpy as np
@@ -91,3 +95,78 @@ def test_the_shim_decoder_gives_the_reference_decoders_pcm(make_dll, name, max_b
         assert st == "ok" and np.array_equal(bits(got), bits(pcm[t])), (name, t)
     assert h.bridge.calls.count("symaccel_aac_synth") - calls0 == -(-n // max_batch)
     assert front.f["parses"].v == n
+
+
+# ------------------------------------------------------------------------------------------------ MP3
+
+MP3 = ["mp3_joint", "mp3_lsf"]
+MP3_SIDE = np.dtype([("block_type", np.uint8), ("is_mixed", np.uint8), ("rzero", "<u2")])  # symaccel_mp3_side
+
+
+def load_mp3(name):
+    f = np.load(PACKETS / (name + ".npz"))
+    xr, side, pcm = f["xr"], f["side"], f["pcm"]    # [packet][granule][channel][576], [packet][granule][channel][3], [packet][channel][576 g]
+    assert xr.dtype == np.float32 and pcm.dtype == np.float32 and len(xr) == len(pcm) == len(f["packet_lens"])
+    return xr, side, pcm, int(f["sample_rate_idx"][0]), int(f["sample_rate"][0])
+
+
+def check_mp3_c_abi(r, name, seg):
+    from symphonia_amd import Mp3Synthesis
+    xr, side, pcm, sr_idx, _ = load_mp3(name)
+    npk, ngr, nch = xr.shape[:3]
+    chains = np.ascontiguousarray(xr.transpose(2, 0, 1, 3).reshape(nch, npk * ngr, 576))   # a channel's granules are one chain
+    rec = np.zeros((nch, npk * ngr), MP3_SIDE)
+    s = side.transpose(2, 0, 1, 3).reshape(nch, npk * ngr, 3)
+    rec["block_type"], rec["is_mixed"], rec["rzero"] = s[..., 0], s[..., 1], s[..., 2]
+    want = pcm.reshape(npk, nch, ngr, 576).transpose(1, 0, 2, 3).reshape(nch, npk * ngr, 576)
+    zero = (np.zeros((nch, 576), np.float32), np.zeros((nch, 1024), np.float32), np.zeros(nch, np.int32))  # a fresh Layer3 (mod.rs:226-233)
+    r.ctx.set_segment(seg)
+    if isinstance(r, Emu):
+        got = Mp3Synthesis(r.ctx, sr_idx).synth(chains, rec, *zero)[0]
+    else:
+        got = r.host(Mp3Synthesis(r.ctx, sr_idx).synth(r.dev(chains), r.dev(rec), *[r.dev(z) for z in zero]))
+    assert np.array_equal(bits(got), bits(want)), (name, seg, float(np.abs(got - want).max()))
+
+
+@pytest.mark.parametrize("seg", [0, 1, 3])
+@pytest.mark.parametrize("name", MP3)
+def test_emulated_c_abi_gives_the_reference_mp3_decoders_pcm(emu_ctx, name, seg):  # noqa: F811
+    check_mp3_c_abi(Emu(emu_ctx), name, seg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seg", [0, 1, 3])
+@pytest.mark.parametrize("name", MP3)
+def test_gpu_c_abi_gives_the_reference_mp3_decoders_pcm(gpu_ctx, name, seg):  # noqa: F811
+    check_mp3_c_abi(Gpu(gpu_ctx), name, seg)
+
+
+@pytest.mark.parametrize("make_dll", LIBS)
+@pytest.mark.parametrize("name,max_batch", [("mp3_joint", 4), ("mp3_lsf", 1)])
+def test_the_shim_mp3_decoder_gives_the_reference_decoders_pcm(make_dll, name, max_batch):
+    from rs_harness import f32_vec, usize
+    from rsinterp import interp as I
+    xr, side, pcm, sr_idx, rate = load_mp3(name)
+    npk, ngr, nch = xr.shape[:3]
+    h = harness(make_dll, "mpa.rs")
+    h.it.load_file(Path(__file__).resolve().parent / "rust" / "mocks.rs")
+
+    def parsed(p):
+        rows = [I.Struct("SymaccelMp3Side", {"block_type": I.Int(int(side[p, g, c, 0]), "u8"), "is_mixed": I.Int(int(side[p, g, c, 1]), "u8"),
+                                             "rzero": I.Int(int(side[p, g, c, 2]), "u16")}) for g in range(ngr) for c in range(nch)]
+        return I.Struct("ParsedMpa", {"trim": (usize(0), usize(0)), "n_granules": usize(ngr), "xr": f32_vec(xr[p]), "side": I.Arr(rows, True)})
+
+    front = I.Struct("ScriptedMpaFront", {"nch": usize(nch), "sr_idx": I.Int(sr_idx, "i32"), "script": I.Arr([parsed(p) for p in range(npk)], True),
+                                          "parses": usize(0)})
+    r = h.it.call("HipMpaDecoder::try_new", h.params("CODEC_ID_MP3", rate, nch), h.opts(), front, usize(max_batch))
+    assert r.variant == "Ok", r
+    dec = r.f["0"]
+    per = 576 * ngr
+    packets = I.Arr([h.packet(key(t), per * t, track=2, owned=True) for t in range(npk)], True)
+    reader = h.it.call("LookaheadReader::new", h.it.call("MockReader::new", packets), usize(16))
+    calls0 = h.bridge.calls.count("symaccel_mp3_synth")
+    for t in range(npk):
+        p = h.it.call_method("LookaheadReader", "next_packet", reader).f["0"].f["0"]
+        st, got = h.decode("HipMpaDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p))
+        assert st == "ok" and np.array_equal(bits(got), bits(pcm[t])), (name, t)
+    assert h.bridge.calls.count("symaccel_mp3_synth") - calls0 == -(-npk // max_batch)

@@ -7,7 +7,7 @@ packets are parsed by the shim's front end (the patched reference decoder with t
 reference hands to its synthesis stage, packet by packet.  tests/test_packet_fixtures.py replays them through libsymaccel -- on the
 CPU-emulation build and, `-m gpu`, on the MI355X, where /root/reference does not exist -- and compares with `pcm` bit for bit.
 
-    python tools/make_packet_fixtures.py            # rewrites the files (deterministic: the same arrays every time)
+    python tools/make_packet_fixtures.py [aac] [mp3]   # rewrites the files (deterministic: the same arrays every time)
 """
 import sys
 from pathlib import Path
@@ -19,6 +19,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 import test_aac_packets as A  # noqa: E402
+import test_mp3_packets as M  # noqa: E402
 from rs_harness import REF, Harness, patched_tree  # noqa: E402
 from rsinterp import interp as I  # noqa: E402
 
@@ -50,11 +51,48 @@ def aac(name, seed, n_packets, nch, tree):
     print(name, "packets", len(packets), "bytes", int(lens.sum()), "peak", float(np.abs(np.stack(pcm)).max()))
 
 
+MP3_STREAMS = {"mp3_joint": (2, 6, "joint", True, 1), "mp3_lsf": (4, 6, "joint", False, 0)}  # two of test_mp3_packets.ALL_STREAMS
+
+
+def mp3(name, seed, n, mode, mpeg1, sr_code, tree):
+    s, packets = M.stream(seed, n, mode, mpeg1, sr_code)
+    per_frame = 1152 if mpeg1 else 576
+    ref = Harness(None, reference=True, mp3_tree=REF / M.CRATE / "src")
+    ref_dec = M.cpu_decoder(ref, s)
+    h = M.shim(tree)
+    front = h.it.call("mpa_front_end", h.params("CODEC_ID_MP3", s.rate, s.nch), h.opts())
+    assert front.variant == "Ok", front
+    front = front.f["0"]
+    pcm, xr, side = [], [], []
+    for i, (pk, _) in enumerate(packets):
+        st, planes = ref.decode("MpaDecoder", ref_dec, ref.packet(pk, i * per_frame))
+        assert st == "ok"
+        pcm.append(planes)
+        r = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(pk, i * per_frame))
+        assert r.variant == "Ok", r
+        parsed = r.f["0"]
+        ngr = parsed.f["n_granules"].v
+        xr.append(np.array([np.float32(x) for x in parsed.f["xr"].a], np.float32).reshape(ngr, s.nch, 576))      # [granule][channel][576]
+        side.append(np.array([[q.f["block_type"].v, q.f["is_mixed"].v, q.f["rzero"].v] for q in parsed.f["side"].a], np.int32).reshape(ngr, s.nch, 3))
+    data = [p for p, _ in packets]
+    lens = np.array([len(p) for p in data], np.int32)
+    np.savez_compressed(OUT / (name + ".npz"), packet_bytes=np.frombuffer(b"".join(data), np.uint8), packet_lens=lens, xr=np.stack(xr),
+                        side=np.stack(side), pcm=np.stack(pcm).astype(np.float32), sample_rate_idx=np.array([s.sr_idx], np.int32),
+                        sample_rate=np.array([s.rate], np.int32))
+    print(name, "packets", len(data), "bytes", int(lens.sum()), "peak", float(np.abs(np.stack(pcm)).max()))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
-    tree = patched_tree((A.CRATE,)) / A.CRATE / "src"
-    for name, (seed, n, nch) in AAC_STREAMS.items():
-        aac(name, seed, n, nch, tree)
+    which = set(sys.argv[1:]) or {"aac", "mp3"}
+    if "aac" in which:
+        tree = patched_tree((A.CRATE,)) / A.CRATE / "src"
+        for name, (seed, n, nch) in AAC_STREAMS.items():
+            aac(name, seed, n, nch, tree)
+    if "mp3" in which:
+        tree = patched_tree((M.CRATE,)) / M.CRATE / "src"
+        for name, args in MP3_STREAMS.items():
+            mp3(name, *args, tree)
 
 
 if __name__ == "__main__":

@@ -152,7 +152,9 @@ class Bridge:
     """binds the `extern "C"` declarations of a bindings file to a ctypes library inside one interpreter"""
 
     def __init__(self, it, sys_rs_text, dll):
-        self.it, self.dll = it, dll
+        # a CDLL object of its own on the same loaded library: call() sets restype / argtypes per function, and ctypes keeps those on
+        # the CDLL's function objects -- the caller's handle (symphonia_amd._ffi, which declares argtypes) must not see them change
+        self.it, self.dll = it, C.CDLL(dll._name)
         rest, self.decls = parse_extern_block(sys_rs_text)
         it.load_source(rest, 'symaccel_sys.rs')
         self.calls = []  # (name) log, for the tests

@@ -531,23 +531,29 @@ class Env:
 
 class Lazy:
     """A static / const: evaluated on first use."""
-    __slots__ = ('item', 'interp', 'value', 'state', 'env')
+    __slots__ = ('item', 'interp', 'value', 'state', 'env', 'key')
 
-    def __init__(self, item, interp, env=None):
-        self.item, self.interp, self.value, self.state, self.env = item, interp, None, 0, env
+    def __init__(self, item, interp, env=None, key=None):
+        self.item, self.interp, self.value, self.state, self.env, self.key = item, interp, None, 0, env, key
 
     def get(self):
         if self.state == 2:
             return self.value
         if self.state == 1:
             raise InterpError('cyclic static ' + self.item[1])
-        self.state = 1
         it = self.interp
+        shared = it.shared_statics if self.key is not None and self.item[0] == 'static' else None
+        if shared is not None and self.key in shared:  # an immutable `static` another interpreter built from the same source text
+            self.value, self.state = shared[self.key], 2
+            return self.value
+        self.state = 1
         env = self.env if self.env is not None else Env(uses=self.item[5].uses if len(self.item) > 5 and self.item[5] is not None else None)
         v = it.ev(self.item[3], env)
         if self.item[2] is not None:
             v = it.coerce(v, self.item[2], env)
         self.value, self.state = v, 2
+        if shared is not None:
+            shared[self.key] = v
         return v
 
 
@@ -558,6 +564,8 @@ class Interp:
         self.globals = {}      # value namespace: name -> ('fn', ...) item | Lazy | struct/enum item
         self.types = {}        # type namespace: name -> struct / enum item
         self.impls = {}        # type name -> {method name -> fn item}
+        self.shared_statics = None  # optional dict shared between interpreters: (sha1 of the source text, name) -> value of a `static`
+        self.src_hash = {}     # file name -> sha1 of its text
         self.alt_methods = {}  # (type name, method name) -> [fn items] when an inherent and a trait method share a name
         self.macros = {}       # macro_rules
         self.trait_impls = {}  # type name -> [trait names it implements]
@@ -578,6 +586,8 @@ class Interp:
         self.load_source(Path(path).read_text(), str(path))
 
     def load_source(self, src, fname):
+        import hashlib
+        self.src_hash[fname] = hashlib.sha1(src.encode()).hexdigest()
         self.register_items(P.parse_source(src, fname), fname)
 
     def register_items(self, items, fname, module=None):
@@ -588,7 +598,7 @@ class Interp:
                 if module:
                     self.globals[module + '::' + it[1]] = it
             elif k in ('const', 'static'):
-                lz = Lazy(it, self)
+                lz = Lazy(it, self, key=(self.src_hash[fname], it[1]) if fname in self.src_hash else None)
                 self.globals[it[1]] = lz
                 if module:
                     self.globals[module + '::' + it[1]] = lz
@@ -1201,6 +1211,9 @@ class Interp:
                             env.bind(pat[1], UNINIT)
                         continue
                     v = self.ev(init, env)
+                    if v is UNINIT and ty is not None:  # `let x: T = Default::default();`
+                        from . import stdext
+                        v = stdext.default_of(self, ty, env)
                     if ty is not None:
                         v = self.coerce(v, ty, env)
                     if not self.match(pat, v, env, True):
@@ -1414,7 +1427,7 @@ class Interp:
                 if fname in fields:
                     if fields[fname] is UNINIT:  # `field: Default::default()`: the declared type says of what
                         from . import stdext
-                        d = stdext.default_of(self, fty)
+                        d = stdext.default_of(self, fty, env)
                         if d is not UNINIT:
                             fields[fname] = d
                             continue

@@ -65,10 +65,16 @@ def inner(v):
     return v
 
 
-def default_of(it, ty):
+def default_of(it, ty, env=None):
     if ty is None:
         return I.UNINIT
     k = ty[0]
+    if k == 'tarray':  # [T; N]: N defaults (Default is implemented for arrays of up to 32 elements)
+        n = I.deref(it.ev(ty[2], env or I.Env()))
+        first = default_of(it, ty[1], env)
+        if first is I.UNINIT:
+            return I.UNINIT
+        return I.Arr([first] + [default_of(it, ty[1], env) for _ in range(n.v - 1)])
     if k == 'tpath':
         name, gargs = ty[1][-1], ty[2]
         if name in I.INT_BITS:
@@ -86,11 +92,15 @@ def default_of(it, ty):
         if name in ('HashMap', 'BTreeMap'):
             vty = gargs[1][1] if len(gargs) >= 2 and gargs[1][0] == 'gtype' else None
             return HMap(vty, name == 'BTreeMap')
+        if name in it.types and 'default' in it.impls.get(name, {}):  # a hand-written `impl Default`
+            m = it.impls[name]['default']
+            if isinstance(m, tuple) and m[0] == 'fn':
+                return it.call_fn(m, [], None, name, None)
         if name in it.types and it.types[name][0] == 'struct':
             item = it.types[name]
-            return I.Struct(name, {f: default_of(it, t) for f, t in item[3]})
+            return I.Struct(name, {f: default_of(it, t, env) for f, t in item[3]})
     if k == 'ttuple':
-        return tuple(default_of(it, t) for t in ty[1])
+        return tuple(default_of(it, t, env) for t in ty[1])
     return I.UNINIT
 
 
