@@ -18,9 +18,9 @@
 //! (tests/test_seam_patches.py); and the crate is EXECUTED under the repository's Rust interpreter (tools/rsinterp) with its
 //! `extern "C"` block bound to libsymaccel through ctypes: `lookahead.rs` + `fallback.rs` with mocks (test_rust_shim.py), the
 //! five codec adapters + `ctx.rs` with front ends that replay the reference-text fixtures (tests/test_rust_adapters.py), and
-//! the whole AAC-LC, MP3, FLAC and ALAC paths -- the patched reference decoder as front end, `aac.rs` / `mpa.rs` / `flac.rs` /
+//! all five paths whole -- the patched reference decoder as front end, `aac.rs` / `mpa.rs` / `vorbis.rs` / `flac.rs` /
 //! `alac.rs`, `decoder.rs`, `lookahead.rs`, `ctx.rs` -- on packet bytes against the unpatched reference decoder
-//! (tests/test_{aac,mp3,flac,alac}_packets.py).
+//! (tests/test_{aac,mp3,vorbis,flac,alac}_packets.py).
 #![allow(clippy::needless_range_loop)]
 
 mod aac;

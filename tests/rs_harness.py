@@ -119,11 +119,11 @@ _SHARED_STATICS = {}  # the reference's lazily built tables (VLC codebooks, pow4
 
 
 class Harness:
-    def __init__(self, dll, reference=False, flac_tree=None, alac_tree=None, aac_tree=None, mp3_tree=None, sample=None):
+    def __init__(self, dll, reference=False, flac_tree=None, alac_tree=None, aac_tree=None, mp3_tree=None, vorbis_tree=None, sample=None):
         self.it = it = Interp()
         # the silence value of new AudioBuffers: untyped unless the decoder under test hands plane slices to functions declared
         # `&mut [f32]` (the reference's AAC and MP3 decoders; sample="f32")
-        zero = {None: lambda: I.Int(0, None), "i32": lambda: I.Int(0, "i32"), "f32": lambda: I.F32(0.0)}["f32" if (aac_tree or mp3_tree) and sample is None else sample]
+        zero = {None: lambda: I.Int(0, None), "i32": lambda: I.Int(0, "i32"), "f32": lambda: I.F32(0.0)}["f32" if (aac_tree or mp3_tree or vorbis_tree) and sample is None else sample]
         it.globals["audio_stub_sample_mid"] = I.Builtin(zero, "audio_stub_sample_mid")
         self.dll = dll
         self.reference = reference
@@ -158,6 +158,14 @@ class Harness:
             for f in MP3_FILES + (("backend.rs",) if (mp3_tree / "backend.rs").exists() else ()):
                 it.load_file(mp3_tree / f)
             it.load_source(cfg_features((mp3_tree / "decoder.rs").read_text(), {"mp3"}), "decoder.rs")
+        if vorbis_tree is not None:  # the Vorbis crate (patched or not), the transform it calls, the Xiph helpers
+            for f in CORE_DSP:
+                it.load_file(REF / "symphonia-core" / "src" / f)
+            it.load_file(REF / "symphonia-common/src/xiph/audio/vorbis/mod.rs")
+            # (symphonia-core's Position bit flags are outside the stand-in Channels)
+            it.load_source("pub fn vorbis_channels_to_channels(num_channels: u8) -> Option<Channels> { Some(Channels::Discrete(num_channels as u16)) }", "stub")
+            for f in ("common.rs", "window.rs", "codebook.rs", "floor.rs", "residue.rs", "dsp.rs") + (("backend.rs",) if (vorbis_tree / "backend.rs").exists() else ()) + ("lib.rs",):
+                it.load_file(vorbis_tree / f)
         self.bridge = F.Bridge(it, (ROOT / "bindings" / "rust" / "symaccel_sys.rs").read_text(), dll) if dll is not None else None
         bad = it.globals.get("__unparsed__")
         assert not bad, bad

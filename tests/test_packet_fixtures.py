@@ -3,12 +3,13 @@ decoder returns for packets written by tests/aac_writer.py (its whole decoder, e
 made), `coeffs` / `side` what the reference's parse stage hands to its synthesis stage for the same packets.  Here the product does
 the synthesis and must give `pcm` back, bit for bit -- no oracle in between, nothing read from /root/reference:
 
-  * through the C ABI (symaccel_aac_synth / symaccel_mp3_synth, one chain per channel, the packets as its frames / granules), in
+  * through the C ABI (symaccel_aac_synth / symaccel_mp3_synth / symaccel_vorbis_synth, one chain per channel, the packets as its frames / granules), in
     several segmentations;
-  * through the Rust shim's HipAacDecoder / HipMpaDecoder (run by tools/rsinterp, `extern "C"` bound to the library) with a front
+  * through the Rust shim's HipAacDecoder / HipMpaDecoder / HipVorbisDecoder (run by tools/rsinterp, `extern "C"` bound to the library) with a front
     end that replays the parse results, packet by packet and in look-ahead batches.
 
-AAC-LC: mono and stereo streams with every tool (tests/aac_writer.py).  MP3: an MPEG-1 joint-stereo stream at 48 kHz and an MPEG-2
+Vorbis: two stereo streams (64 / 512 and 256 / 2048 -- config 4's block sizes), every block-size transition, residue types 1 and 2,
+coupling (tests/vorbis_writer.py).  AAC-LC: mono and stereo streams with every tool (tests/aac_writer.py).  MP3: an MPEG-1 joint-stereo stream at 48 kHz and an MPEG-2
 (LSF) joint-stereo stream at 22.05 kHz, variable bit rate, all block types, main data through the bit reservoir (tests/mp3_writer.py).
 
 `-m gpu`: the hipcc-built library on the MI355X.  Without a GPU the same checks run on the CPU emulation build of the kernel sources.
@@ -170,3 +171,75 @@ def test_the_shim_mp3_decoder_gives_the_reference_decoders_pcm(make_dll, name, m
         st, got = h.decode("HipMpaDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p))
         assert st == "ok" and np.array_equal(bits(got), bits(pcm[t])), (name, t)
     assert h.bridge.calls.count("symaccel_mp3_synth") - calls0 == -(-npk // max_batch)
+
+
+# ------------------------------------------------------------------------------------------------ Vorbis
+
+VORBIS = ["vorbis_small", "vorbis_256_2048"]
+
+
+def load_vorbis(name):
+    f = np.load(PACKETS / (name + ".npz"))
+    flags, spectra, pcm, frames = f["long_block"], f["spectra"], f["pcm"], f["frames"]   # [packet], [channel][sum n/2], [channel][sum frames]
+    b0, b1 = (int(x) for x in f["block_exps"])
+    n2 = np.where(flags > 0, 1 << b1, 1 << b0) // 2
+    assert spectra.shape[1] == n2.sum() and pcm.shape[1] == frames.sum() and frames[0] == 0
+    return flags, spectra, pcm, frames, b0, b1, n2
+
+
+def check_vorbis_c_abi(r, name, seg):
+    from symphonia_amd import VorbisDsp
+    flags, spectra, pcm, frames, b0, b1, n2 = load_vorbis(name)
+    nch, nb = spectra.shape[0], len(flags)
+    dsp = VorbisDsp(r.ctx, b0, b1)
+    bf = np.tile(flags.astype(np.uint8), (nch, 1))
+    so, po = dsp.layout(bf, np.full(nch, -1))
+    assert so[0, -1] == spectra.shape[1]
+    # packet 0 primes the overlap: the reference (gapless) returns no samples for it (lib.rs:333-336), the batched call computes the
+    # block against a zero overlap in its place; from packet 1 on the outputs are the reference's
+    assert np.array_equal(np.diff(po[0])[1:], frames[1:])
+    zero = np.zeros((nch, (1 << b1) >> 1), np.float32)
+    r.ctx.set_segment(seg)
+    if isinstance(r, Emu):
+        got = dsp.synth(np.ascontiguousarray(spectra), bf, np.full(nch, -1, np.int32), zero, int(po[0, -1]))[0]
+    else:
+        got = r.host(dsp.synth(r.dev(np.ascontiguousarray(spectra)), r.dev(bf), r.dev(np.full(nch, -1, np.int32)), r.dev(zero), int(po[0, -1])))
+    assert np.array_equal(bits(got[:, po[0, 1]:]), bits(pcm)), (name, seg)
+
+
+@pytest.mark.parametrize("seg", [0, 1, 2])
+@pytest.mark.parametrize("name", VORBIS)
+def test_emulated_c_abi_gives_the_reference_vorbis_decoders_pcm(emu_ctx, name, seg):  # noqa: F811
+    check_vorbis_c_abi(Emu(emu_ctx), name, seg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seg", [0, 1, 2])
+@pytest.mark.parametrize("name", VORBIS)
+def test_gpu_c_abi_gives_the_reference_vorbis_decoders_pcm(gpu_ctx, name, seg):  # noqa: F811
+    check_vorbis_c_abi(Gpu(gpu_ctx), name, seg)
+
+
+@pytest.mark.parametrize("make_dll", LIBS)
+@pytest.mark.parametrize("name,max_batch", [("vorbis_small", 4), ("vorbis_256_2048", 2)])
+def test_the_shim_vorbis_decoder_gives_the_reference_decoders_pcm(make_dll, name, max_batch):
+    from rs_harness import f32_vec, usize
+    from rsinterp import interp as I
+    flags, spectra, pcm, frames, b0, b1, n2 = load_vorbis(name)
+    nch, nb = spectra.shape[0], len(flags)
+    h = harness(make_dll, "vorbis.rs")
+    h.it.load_file(Path(__file__).resolve().parent / "rust" / "mocks.rs")
+    so = np.concatenate([[0], np.cumsum(n2)])
+    script = I.Arr([I.Struct("ParsedVorbis", {"trim": (usize(0), usize(0)), "long_block": bool(flags[b]), "spectra": f32_vec(spectra[:, so[b]:so[b + 1]])})
+                    for b in range(nb)], True)
+    front = I.Struct("ScriptedVorbisFront", {"nch": usize(nch), "bs0_exp": I.Int(b0, "i32"), "bs1_exp": I.Int(b1, "i32"), "script": script, "parses": usize(0)})
+    r = h.it.call("HipVorbisDecoder::try_new", h.params("CODEC_ID_VORBIS", 44100, nch), h.opts(), front, usize(max_batch))
+    assert r.variant == "Ok", r
+    dec = r.f["0"]
+    packets = I.Arr([h.packet(key(t), t, track=2, owned=True) for t in range(nb)], True)
+    reader = h.it.call("LookaheadReader::new", h.it.call("MockReader::new", packets), usize(16))
+    po = np.concatenate([[0], np.cumsum(frames)])
+    for t in range(nb):
+        p = h.it.call_method("LookaheadReader", "next_packet", reader).f["0"].f["0"]
+        st, got = h.decode("HipVorbisDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p))
+        assert st == "ok" and got.shape == (nch, frames[t]) and np.array_equal(bits(got), bits(pcm[:, po[t]:po[t + 1]])), (name, t)

@@ -7,7 +7,7 @@ packets are parsed by the shim's front end (the patched reference decoder with t
 reference hands to its synthesis stage, packet by packet.  tests/test_packet_fixtures.py replays them through libsymaccel -- on the
 CPU-emulation build and, `-m gpu`, on the MI355X, where /root/reference does not exist -- and compares with `pcm` bit for bit.
 
-    python tools/make_packet_fixtures.py [aac] [mp3]   # rewrites the files (deterministic: the same arrays every time)
+    python tools/make_packet_fixtures.py [aac] [mp3] [vorbis]   # rewrites the files (deterministic: the same arrays every time)
 """
 import sys
 from pathlib import Path
@@ -20,6 +20,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 import test_aac_packets as A  # noqa: E402
 import test_mp3_packets as M  # noqa: E402
+import test_vorbis_packets as V  # noqa: E402
 from rs_harness import REF, Harness, patched_tree  # noqa: E402
 from rsinterp import interp as I  # noqa: E402
 
@@ -82,9 +83,40 @@ def mp3(name, seed, n, mode, mpeg1, sr_code, tree):
     print(name, "packets", len(data), "bytes", int(lens.sum()), "peak", float(np.abs(np.stack(pcm)).max()))
 
 
+# the second stream has config 4's block sizes (256 / 2048)
+VORBIS_STREAMS = {"vorbis_small": (1, 9, 2, 6, 9, (2, 1), True), "vorbis_256_2048": (4, 7, 2, 8, 11, (2, 2), True)}
+
+
+def vorbis(name, args, tree):
+    s, packets = V.stream(*args)
+    ref = Harness(None, reference=True, vorbis_tree=REF / V.CRATE / "src")
+    ref_dec = V.cpu_decoder(ref, s)
+    h, _ = V.hip_decoder(tree, s, max_batch=1)
+    front = h.it.call("vorbis_front_end", h.params("CODEC_ID_VORBIS", 44100, s.nch, extra=s.extra_data()), h.opts())
+    assert front.variant == "Ok", front
+    front = front.f["0"]
+    flags, spectra, pcm, counts = [], [], [], []
+    for pk, _ in packets:
+        st, planes = ref.decode("VorbisDecoder", ref_dec, ref.packet(pk, 0))
+        assert st == "ok"
+        pcm.append(planes.astype(np.float32).reshape(s.nch, -1))
+        counts.append(planes.shape[1] if planes.size else 0)
+        r = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(pk, 0))
+        assert r.variant == "Ok", r
+        parsed = r.f["0"]
+        flags.append(int(bool(parsed.f["long_block"])))
+        spectra.append(np.array([np.float32(x) for x in parsed.f["spectra"].a], np.float32).reshape(s.nch, -1))
+    data = [p for p, _ in packets]
+    lens = np.array([len(p) for p in data], np.int32)
+    np.savez_compressed(OUT / (name + ".npz"), packet_bytes=np.frombuffer(b"".join(data), np.uint8), packet_lens=lens,
+                        long_block=np.array(flags, np.uint8), spectra=np.concatenate(spectra, axis=1), pcm=np.concatenate(pcm, axis=1),
+                        frames=np.array(counts, np.int32), block_exps=np.array([s.bs0_exp, s.bs1_exp], np.int32))
+    print(name, "packets", len(data), "bytes", int(lens.sum()), "frames", counts, "peak", float(np.abs(np.concatenate(pcm, axis=1)).max()))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
-    which = set(sys.argv[1:]) or {"aac", "mp3"}
+    which = set(sys.argv[1:]) or {"aac", "mp3", "vorbis"}
     if "aac" in which:
         tree = patched_tree((A.CRATE,)) / A.CRATE / "src"
         for name, (seed, n, nch) in AAC_STREAMS.items():
@@ -93,6 +125,10 @@ def main():
         tree = patched_tree((M.CRATE,)) / M.CRATE / "src"
         for name, args in MP3_STREAMS.items():
             mp3(name, *args, tree)
+    if "vorbis" in which:
+        tree = patched_tree((V.CRATE,)) / V.CRATE / "src"
+        for name, args in VORBIS_STREAMS.items():
+            vorbis(name, args, tree)
 
 
 if __name__ == "__main__":

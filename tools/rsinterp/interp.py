@@ -2105,6 +2105,8 @@ class Interp:
                 return Builtin(replace, 'mem::replace')
             if name == 'take':
                 raise InterpError('mem::take needs a type')
+        if head == 'iter' and name == 'repeat_n':
+            return Builtin(lambda v, n: RIter(lst=[deref(v)] * deref(n).v), 'iter::repeat_n')
         if head == 'iter' and name == 'repeat':
             def rep(v):
                 def g():
@@ -2962,7 +2964,18 @@ class Interp:
             l.clear()
             return NONE
         if name == 'collect':
-            return Arr([x for x in it], True)
+            out = []
+            for x in it:  # an iterator of `Result`s collects into `Result<Vec<_>, E>` (the only use in the texts run here): the
+                xv = deref(x)  # first Err ends it, as FromIterator for Result does
+                if isinstance(xv, Enum) and xv.enum == 'Result':
+                    if xv.variant == 'Err':
+                        return xv
+                    out.append(('ok', xv.f['0']))
+                else:
+                    out.append(('v', x))
+            if out and all(k == 'ok' for k, _ in out):
+                return ok(Arr([v for _, v in out], True))
+            return Arr([x if k == 'v' else ok(x) for k, x in out], True)
         if name in ('min', 'max'):
             l = [deref(x) for x in it]
             if not l:

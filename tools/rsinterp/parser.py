@@ -1019,8 +1019,8 @@ class Parser:
                 return ('ref', False, e) if c.s == '&&' else e
         return self.postfix(no_struct)
 
-    def postfix(self, no_struct):
-        e = self.primary(no_struct)
+    def postfix(self, no_struct, start=None):
+        e = self.primary(no_struct) if start is None else start
         while True:
             c = self.cur
             if c.k != 'punct':
@@ -1323,8 +1323,8 @@ class Parser:
             if (c.k == 'ident' and c.s in ('if', 'match', 'loop', 'while', 'for', 'unsafe')) or (c.k == 'punct' and c.s == '{') or \
                     (c.k == 'lifetime' and self.peek().s == ':'):
                 e = self.primary(False)
-                if self.at('.') or self.at('?'):
-                    self.err('method call on a block-like statement is not supported')
+                if self.at('.') or self.at('?'):  # `match x { .. }?;` / `if c { a } else { b }.f();`: the statement goes on
+                    e = self.postfix(False, start=e)
             else:
                 e = self.expr()
             if self.eat(';'):

@@ -24,10 +24,11 @@ class Cell:
 
 
 class HMap:
-    __slots__ = ('d', 'vty', 'ordered')
+    __slots__ = ('d', 'vty', 'ordered', 'is_set')
 
-    def __init__(self, vty=None, ordered=False):
-        self.d, self.vty, self.ordered = {}, vty, ordered  # image of key -> (key, value); ordered: a BTreeMap (iterates by key)
+    def __init__(self, vty=None, ordered=False, is_set=False):
+        # image of key -> (key, value); ordered: a BTreeMap (iterates by key); is_set: a HashSet (the values are unit)
+        self.d, self.vty, self.ordered, self.is_set = {}, vty, ordered, is_set
 
     def items(self):
         return [self.d[h] for h in sorted(self.d)] if self.ordered else list(self.d.values())
@@ -130,6 +131,8 @@ def path_builtin(it, segs):
         return I.Builtin(mutex_new, 'Mutex::new')
     if head == 'HashMap' and name in ('new', 'with_capacity', 'default'):
         return I.Builtin(lambda *a: HMap(), 'HashMap::new')
+    if head == 'HashSet' and name in ('new', 'with_capacity', 'default'):
+        return I.Builtin(lambda *a: HMap(None, False, True), 'HashSet::new')
     if head == 'BTreeMap' and name in ('new', 'default'):
         return I.Builtin(lambda *a: HMap(None, True), 'BTreeMap::new')
     if head == 'NonZero' and name == 'new':  # NonZero<T> is its integer; `get()` gives it back (interp.int_method)
@@ -171,8 +174,13 @@ def method(it, base, name, args, env):
         if name in ('get', 'get_mut'):
             e = d.get(hkey(args[0]))
             return True, (I.some(e[1]) if e is not None else I.NONE)
-        if name == 'contains_key':
+        if name == 'contains_key' or (name == 'contains' and base.is_set):
             return True, hkey(args[0]) in d
+        if name == 'insert' and base.is_set:  # HashSet::insert: true if the value was not there
+            k = I.copyval(I.deref(args[0]))
+            fresh = hkey(k) not in d
+            d[hkey(k)] = (k, I.UNIT)
+            return True, fresh
         if name == 'insert':
             k = I.copyval(I.deref(args[0]))
             old = d.get(hkey(k))
