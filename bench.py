@@ -329,6 +329,29 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             # pass of the recurrence + decorrelation over the batch: the kernel has no data-dependent control flow (the
             # f64 / i64 path is chosen from the coefficients alone) and the arithmetic wraps, so every pass costs the same.
             fp.restore_stereo(buf, desc, co, pair_mode, 8)
+
+        def verify():
+            """one more pass over the batch (outside every timed region): sampled channel pairs, their words saved in front of it,
+            compared with the oracle's restore + decorrelate + shift of those words (the checker: oracle/, test infrastructure)"""
+            import oracle
+            pairs = sorted({0, min(1, nb // 2 - 1), max(0, nb // 4 - 1), nb // 4, nb // 2 - 1})
+            rows = [r for p_ in pairs for r in (2 * p_, 2 * p_ + 1)]
+            before = buf[rows].cpu().numpy()
+            step()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            got = buf[rows].cpu().numpy()
+            want = oracle.flac_restore(before, desc[rows].cpu().numpy(), co[rows].cpu().numpy())
+            pm = pair_mode[pairs].cpu().numpy()
+            for k in range(len(pairs)):
+                a, b = oracle.flac_decorrelate(int(pm[k]), want[2 * k], want[2 * k + 1])
+                want[2 * k], want[2 * k + 1] = oracle.flac_shl(a, 8), oracle.flac_shl(b, 8)
+            bad = int((got != want).sum())
+            if bad:
+                raise RuntimeError("bench: the FLAC batch differs from the oracle in %d of %d sampled samples" % (bad, got.size))
+            return {"checker": "oracle/symoracle.c (CPU restatement), outside the timed region", "channel_pairs": pairs,
+                    "samples_compared": int(got.size), "mismatches": bad, "criterion": "bit-identical i32"}
+        step.verify = verify
         return step, nb, "blocks", nb * bs * 8, {
             "workload": "FLAC 24-bit 192 kHz, LPC order 32 (15-bit quantised coefficients of random AR models, shift 10..14), "
                         "%d subframe blocks of 4096 samples, half the channel pairs mid/side (side channel 25 bits), "
@@ -343,6 +366,23 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
 
         def step():
             ap.predict(buf, desc, co)  # in place, like the FLAC workload: every pass costs the same
+
+        def verify():
+            """as for FLAC: sampled blocks of one more pass against the oracle's predictor on the words saved in front of it"""
+            import oracle
+            rows = sorted({0, min(1, nb - 1), min(63, nb - 1), min(64, nb - 1), nb // 2, nb - 1})
+            before = buf[rows].cpu().numpy()
+            step()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            got = buf[rows].cpu().numpy()
+            want = oracle.alac_predict(before, desc_np[rows], co[rows].cpu().numpy())
+            bad = int((got != want).sum())
+            if bad:
+                raise RuntimeError("bench: the ALAC batch differs from the oracle in %d of %d sampled samples" % (bad, got.size))
+            return {"checker": "oracle/symoracle.c (CPU restatement), outside the timed region", "blocks": rows,
+                    "samples_compared": int(got.size), "mismatches": bad, "criterion": "bit-identical i32"}
+        step.verify = verify
         return step, nb, "blocks", nb * bs * 8, {
             "workload": "ALAC 16-bit, adaptive LPC order 8 (shift 9), %d element-channel blocks of 4096 samples, in place" % nb,
             "samples": nb * bs}, "alac_predict_kernel", buf
