@@ -169,7 +169,7 @@ def test_bench_line_carries_the_other_workloads():
     for name, line in ow.items():
         assert "error" not in line, (name, line)
         assert line["steps"] == (8 if name in ("flac", "alac") else 20) and line["value"] > 0 and line["algorithmic_bytes_per_launch"] > 0
-        if name.startswith(("aac", "mp3", "vorbis")) and "int16" not in name and "two_kernels" not in name:  # the timed batch itself is compared with the oracle (sampled chains), mixes included
+        if name.startswith(("aac", "mp3", "vorbis", "flac", "alac")) and "int16" not in name and "two_kernels" not in name:  # the timed batch itself is compared with the oracle (sampled chains / blocks), mixes included
             assert line["verified"]["mismatches"] == 0 and line["verified"]["samples_compared"] > 0
         if "mix" in name:
             assert abs(sum(v for k, v in line["mix"].items() if k not in ("p_switch", "mixed_share_of_short")) - 1.0) < 1e-9
