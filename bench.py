@@ -531,6 +531,36 @@ def cpu_baseline(name, seconds=10.0):
                       "%.3g %s)" % (reps, cores, dt, units * reps1 / dt1, unit)}
 
 
+def sample_clocks(step, sync):
+    """What the board's clocks are WHILE the workload runs (boards of this pool differ in the clock they hold under load, which
+    moves the issue-bound lines by 20-30 %: profiles/HISTORY.md, "the final tree on two boards"): about half a second of steps is
+    queued, `rocm-smi --showclocks` is asked while they execute.  Outside every timed region; None if rocm-smi is not there."""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        t0 = time.perf_counter()
+        step()
+        sync()
+        per = max(time.perf_counter() - t0, 1e-5)
+        for _ in range(int(min(20000, max(10, 0.6 / per)))):
+            step()
+        r = subprocess.run([exe, "--showclocks"], capture_output=True, text=True, timeout=20)
+        sync()
+        found = {}
+        for name in ("sclk", "mclk", "fclk", "socclk"):
+            m = re.search(r"%s clock level:?\s*\S*\s*\((\d+)\s*Mhz\)" % name, r.stdout, re.I)
+            if m:
+                found[name + "_mhz"] = int(m.group(1))
+        if not found:
+            return None
+        found["source"] = "rocm-smi --showclocks while ~0.6 s of steps execute, outside the timed region"
+        return found
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def verify_sampled_chains(name, step, torch, sync):
     """Tie the timed batch to a verified result: one more step of THE SAME batch (outside every timed region) from a zero
     carried state, then sampled chains x frame windows of its output compared bit for bit with the oracle (the checker,
@@ -1069,6 +1099,9 @@ def main():
         except Exception as e:  # noqa: BLE001
             ceiling = {"error": "%s: %s" % (type(e).__name__, e)}
         log("copy probes done")
+    clocks = None
+    if world == 1 and not emulate and not args.no_copy_ceiling:
+        clocks = sample_clocks(step, sync)
     others = None
     if world == 1 and args.workload == "aac" and not args.no_others:
         others = {}
@@ -1158,6 +1191,8 @@ def main():
                 out["roofline"]["traffic_source"] = tr["source"] + " (a committed rocprofv3 PMC measurement of this command, not taken in this run)"
         except (OSError, ValueError, KeyError):
             pass
+        if clocks:
+            out["clocks_under_load"] = clocks
         if ceiling:
             out["roofline"]["copy_ceiling"] = ceiling
             best = max((v for k, v in ceiling.items() if k.startswith(("plain", "frames")) and isinstance(v, float)), default=None)
