@@ -210,7 +210,7 @@ pub trait BatchCodec {
     fn clear(&mut self);
 }
 
-/// Batching state shared by the four decoders.
+/// Batching state shared by the five decoders.
 pub struct Lookahead<P> {
     /// the packets of the last batch, parsed, and their pts, in order; `head` = the next one to hand out
     parsed: Vec<P>,

@@ -1,5 +1,5 @@
 """Packet bytes -> PCM, symphonia-check style (symphonia-check/src/main.rs:289-295: decode the same packets two ways, compare the
-samples), for FLAC -- the first codec for which the whole chain can be run here without a Rust toolchain (missing 3):
+samples), for FLAC -- the first codec for which the whole chain was run here without a Rust toolchain (the other four: test_{aac,mp3,vorbis,alac}_packets.py):
 
   frames written by tests/flac_writer.py (every subframe type, Rice / Rice2 / escaped partitions, wasted bits, all four channel
   assignments, 16- and 24-bit, frame CRC-8 / CRC-16)
