@@ -8,7 +8,8 @@ the synthesis and must give `pcm` back, bit for bit -- no oracle in between, not
   * through the Rust shim's HipAacDecoder / HipMpaDecoder / HipVorbisDecoder (run by tools/rsinterp, `extern "C"` bound to the library) with a front
     end that replays the parse results, packet by packet and in look-ahead batches.
 
-Vorbis: two stereo streams (64 / 512 and 256 / 2048 -- config 4's block sizes), every block-size transition, residue types 1 and 2,
+FLAC / ALAC (integer paths): 16- and 24-bit FLAC frames of every subframe type and channel assignment, 24-bit stereo and 20-bit 6-channel ALAC
+packets (tests/flac_writer.py, tests/alac_writer.py), through the shim decoders.  Vorbis: two stereo streams (64 / 512 and 256 / 2048 -- config 4's block sizes), every block-size transition, residue types 1 and 2,
 coupling (tests/vorbis_writer.py).  AAC-LC: mono and stereo streams with every tool (tests/aac_writer.py).  MP3: an MPEG-1 joint-stereo stream at 48 kHz and an MPEG-2
 (LSF) joint-stereo stream at 22.05 kHz, variable bit rate, all block types, main data through the bit reservoir (tests/mp3_writer.py).
 
@@ -243,3 +244,71 @@ def test_the_shim_vorbis_decoder_gives_the_reference_decoders_pcm(make_dll, name
         p = h.it.call_method("LookaheadReader", "next_packet", reader).f["0"].f["0"]
         st, got = h.decode("HipVorbisDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p))
         assert st == "ok" and got.shape == (nch, frames[t]) and np.array_equal(bits(got), bits(pcm[:, po[t]:po[t + 1]])), (name, t)
+
+
+# ------------------------------------------------------------------------------------------------ FLAC, ALAC (through the shim decoders)
+
+@pytest.mark.parametrize("make_dll", LIBS)
+@pytest.mark.parametrize("name,max_batch", [("flac_24bit", 2), ("flac_16bit", 8)])
+def test_the_shim_flac_decoder_gives_the_reference_decoders_pcm(make_dll, name, max_batch):
+    from rs_harness import i32_vec, usize
+    from rsinterp import interp as I
+    f = np.load(PACKETS / (name + ".npz"))
+    pcm, words, desc, coeffs = f["pcm"], f["words"], f["desc"], f["coeffs"]     # [frame][channel][blocksize], ..., [frame][channel][4], [frame][channel][32]
+    nfr, nch, bs = words.shape
+    bps = int(f["bps"][0])
+    h = harness(make_dll, "flac.rs")
+    h.it.load_file(Path(__file__).resolve().parent / "rust" / "mocks.rs")
+    script = []
+    for t_ in range(nfr):
+        descs = [I.Struct("SymaccelFlacDesc", {"kind": I.Int(int(d[0]), "u8"), "order": I.Int(int(d[1]), "u8"), "shift": I.Int(int(d[2]), "u8"),
+                                              "wasted_bits": I.Int(int(d[3]), "u8")}) for d in desc[t_]]
+        script.append(I.Struct("ParsedFlac", {"blocksize": usize(bs), "words": i32_vec(words[t_]), "desc": I.Arr(descs, True), "coeffs": i32_vec(coeffs[t_]),
+                                               "pair_mode": I.Int(int(f["pair_mode"][t_]), "u8"), "out_shift": I.Int(int(f["out_shift"][t_]), "u32")}))
+    params = h.params("CODEC_ID_FLAC", 44100, nch, bps=bps)
+    front = I.Struct("ScriptedFlacFront", {"params": params, "nch": usize(nch), "max_bs": usize(bs), "script": I.Arr(script, True), "parses": usize(0)})
+    r = h.it.call("HipFlacDecoder::try_new", params, h.opts(), front, usize(max_batch))
+    assert r.variant == "Ok", r
+    dec = r.f["0"]
+    packets = I.Arr([h.packet(key(t_), bs * t_, track=2, owned=True) for t_ in range(nfr)], True)
+    reader = h.it.call("LookaheadReader::new", h.it.call("MockReader::new", packets), usize(16))
+    for t_ in range(nfr):
+        p = h.it.call_method("LookaheadReader", "next_packet", reader).f["0"].f["0"]
+        st, got = h.decode("HipFlacDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p))
+        assert st == "ok" and np.array_equal(got, pcm[t_]), (name, t_)
+    assert "symaccel_flac_restore" in h.bridge.calls
+
+
+@pytest.mark.parametrize("make_dll", LIBS)
+@pytest.mark.parametrize("name,max_batch", [("alac_24bit_stereo", 3), ("alac_20bit_6ch", 1)])
+def test_the_shim_alac_decoder_gives_the_reference_decoders_pcm(make_dll, name, max_batch):
+    from rs_harness import i32_vec, usize
+    from rsinterp import interp as I
+    f = np.load(PACKETS / (name + ".npz"))
+    pcm, words, desc, coeffs, pairs, tails, tail_bits = f["pcm"], f["words"], f["desc"], f["coeffs"], f["pairs"], f["tails"], f["tail_bits"]
+    npk, nch, n = words.shape
+    depth = int(f["depth"][0])
+    h = harness(make_dll, "alac.rs")
+    h.it.load_file(Path(__file__).resolve().parent / "rust" / "mocks.rs")
+    script = []
+    for t_ in range(npk):
+        descs = [I.Struct("SymaccelAlacDesc", {"mode": I.Int(int(d[0]), "u8"), "lpc_order": I.Int(int(d[1]), "u8"), "shift": I.Int(int(d[2]), "u8"),
+                                              "bps": I.Int(int(d[3]), "u8")}) for d in desc[t_]]
+        prs = [I.Struct("AlacPair", {"plane0": usize(q[1]), "plane1": usize(q[2]), "weight": I.Int(int(q[3]), "i32"), "shift": I.Int(int(q[4]), "u8")})
+               for q in pairs if q[0] == t_]
+        tls = [I.Struct("AlacTail", {"plane0": usize(q[1]), "plane1": I.some(usize(q[2])) if q[2] >= 0 else I.NONE, "shift": I.Int(int(q[3]), "u8"),
+                                     "bits": I.Arr([I.Int(int(b), "u16") for b in tail_bits[q[4]:q[4] + q[5]]], True)}) for q in tails if q[0] == t_]
+        script.append(I.Struct("ParsedAlac", {"frames": usize(n), "words": i32_vec(words[t_]), "desc": I.Arr(descs, True), "coeffs": i32_vec(coeffs[t_]),
+                                               "pairs": I.Arr(prs, True), "tails": I.Arr(tls, True), "out_shift": I.Int(int(f["out_shift"][t_]), "u32")}))
+    params = h.params("CODEC_ID_ALAC", 44100, nch, bps=depth)
+    front = I.Struct("ScriptedAlacFront", {"params": params, "nch": usize(nch), "max_frames": usize(n), "script": I.Arr(script, True), "parses": usize(0)})
+    r = h.it.call("HipAlacDecoder::try_new", params, h.opts(), front, usize(max_batch))
+    assert r.variant == "Ok", r
+    dec = r.f["0"]
+    packets = I.Arr([h.packet(key(t_), n * t_, track=2, owned=True) for t_ in range(npk)], True)
+    reader = h.it.call("LookaheadReader::new", h.it.call("MockReader::new", packets), usize(16))
+    for t_ in range(npk):
+        p = h.it.call_method("LookaheadReader", "next_packet", reader).f["0"].f["0"]
+        st, got = h.decode("HipAlacDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p))
+        assert st == "ok" and np.array_equal(got, pcm[t_]), (name, t_)
+    assert "symaccel_alac_predict" in h.bridge.calls

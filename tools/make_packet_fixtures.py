@@ -7,7 +7,7 @@ packets are parsed by the shim's front end (the patched reference decoder with t
 reference hands to its synthesis stage, packet by packet.  tests/test_packet_fixtures.py replays them through libsymaccel -- on the
 CPU-emulation build and, `-m gpu`, on the MI355X, where /root/reference does not exist -- and compares with `pcm` bit for bit.
 
-    python tools/make_packet_fixtures.py [aac] [mp3] [vorbis]   # rewrites the files (deterministic: the same arrays every time)
+    python tools/make_packet_fixtures.py [aac] [mp3] [vorbis] [flac] [alac]   # rewrites the files (deterministic: the same arrays every time)
 """
 import sys
 from pathlib import Path
@@ -21,6 +21,9 @@ sys.path.insert(0, str(ROOT / "tests"))
 import test_aac_packets as A  # noqa: E402
 import test_mp3_packets as M  # noqa: E402
 import test_vorbis_packets as V  # noqa: E402
+import test_flac_packets as F  # noqa: E402
+import test_alac_packets as L  # noqa: E402
+import flac_writer  # noqa: E402
 from rs_harness import REF, Harness, patched_tree  # noqa: E402
 from rsinterp import interp as I  # noqa: E402
 
@@ -114,9 +117,81 @@ def vorbis(name, args, tree):
     print(name, "packets", len(data), "bytes", int(lens.sum()), "frames", counts, "peak", float(np.abs(np.concatenate(pcm, axis=1)).max()))
 
 
+def ints(arr):
+    return np.array([x.v for x in arr.a], np.int64)
+
+
+def flac(name, seed, n_frames, nch, bps, blocksize):
+    frames, _ = flac_writer.random_stream(seed, n_frames, nch, bps, blocksize)
+    tree = patched_tree(("symphonia-bundle-flac",)) / "symphonia-bundle-flac" / "src"
+    ref = Harness(None, reference=True, flac_tree=REF / "symphonia-bundle-flac" / "src")
+    ref_dec = F.cpu_decoder(ref, nch, bps, blocksize)
+    h, _ = F.hip_decoder(tree, nch, bps, blocksize, max_batch=1)
+    front = h.it.call("flac_front_end", h.params("CODEC_ID_FLAC", extra=F.streaminfo(blocksize, 44100, nch, bps)), h.opts())
+    assert front.variant == "Ok", front
+    front = front.f["0"]
+    out = {"pcm": [], "words": [], "desc": [], "coeffs": [], "pair_mode": [], "out_shift": []}
+    for i, fr in enumerate(frames):
+        st, planes = ref.decode("FlacDecoder", ref_dec, ref.packet(fr, i * blocksize))
+        assert st == "ok"
+        out["pcm"].append(planes)
+        r = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(fr, i * blocksize))
+        assert r.variant == "Ok", r
+        q = r.f["0"]
+        assert q.f["blocksize"].v == blocksize
+        out["words"].append(ints(q.f["words"]).reshape(nch, blocksize))
+        out["desc"].append(np.array([[d.f[k].v for k in ("kind", "order", "shift", "wasted_bits")] for d in q.f["desc"].a], np.uint8))
+        out["coeffs"].append(ints(q.f["coeffs"]).reshape(nch, 32))
+        out["pair_mode"].append(q.f["pair_mode"].v)
+        out["out_shift"].append(q.f["out_shift"].v)
+    np.savez_compressed(OUT / (name + ".npz"), pcm=np.stack(out["pcm"]).astype(np.int32), words=np.stack(out["words"]).astype(np.int32),
+                        desc=np.stack(out["desc"]), coeffs=np.stack(out["coeffs"]).astype(np.int32), pair_mode=np.array(out["pair_mode"], np.uint8),
+                        out_shift=np.array(out["out_shift"], np.uint32), packet_bytes=np.frombuffer(b"".join(frames), np.uint8),
+                        packet_lens=np.array([len(f) for f in frames], np.int32), bps=np.array([bps], np.int32))
+    print(name, "frames", len(frames), "bytes", sum(len(f) for f in frames))
+
+
+def alac(name, args):
+    seed, n_packets, nch, depth, frame_length = args
+    packets, _ = L.stream(seed, n_packets, nch, depth, frame_length)
+    packets, n_frames = packets[:-1], frame_length   # (without the partial last packet: one shape for every array)
+    tree = patched_tree((L.CRATE,)) / L.CRATE / "src"
+    ref = Harness(None, reference=True, alac_tree=REF / L.CRATE / "src")
+    ref_dec = L.cpu_decoder(ref, nch, depth, frame_length)
+    h, _ = L.hip_decoder(tree, nch, depth, frame_length, max_batch=1)
+    front = h.it.call("alac_front_end", h.params("CODEC_ID_ALAC", extra=L.W.cookie(frame_length, depth, nch)), h.opts())
+    assert front.variant == "Ok", front
+    front = front.f["0"]
+    out = {"pcm": [], "words": [], "desc": [], "coeffs": [], "pairs": [], "tails": [], "tail_bits": [], "out_shift": []}
+    for i, pk in enumerate(packets):
+        st, planes = ref.decode("AlacDecoder", ref_dec, ref.packet(pk, i * frame_length))
+        assert st == "ok" and planes.shape[1] == n_frames
+        out["pcm"].append(planes)
+        r = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(pk, i * frame_length))
+        assert r.variant == "Ok", r
+        q = r.f["0"]
+        out["words"].append(ints(q.f["words"]).reshape(nch, n_frames))
+        out["desc"].append(np.array([[d.f[k].v for k in ("mode", "lpc_order", "shift", "bps")] for d in q.f["desc"].a], np.uint8))
+        out["coeffs"].append(ints(q.f["coeffs"]).reshape(nch, 32))
+        out["out_shift"].append(q.f["out_shift"].v)
+        for pr in q.f["pairs"].a:
+            out["pairs"].append([i, pr.f["plane0"].v, pr.f["plane1"].v, pr.f["weight"].v, pr.f["shift"].v])
+        for tl in q.f["tails"].a:
+            p1 = tl.f["plane1"]
+            out["tails"].append([i, tl.f["plane0"].v, p1.f["0"].v if p1.variant == "Some" else -1, tl.f["shift"].v, len(out["tail_bits"]), len(tl.f["bits"].a)])
+            out["tail_bits"].extend(x.v for x in tl.f["bits"].a)
+    np.savez_compressed(OUT / (name + ".npz"), pcm=np.stack(out["pcm"]).astype(np.int32), words=np.stack(out["words"]).astype(np.int32),
+                        desc=np.stack(out["desc"]), coeffs=np.stack(out["coeffs"]).astype(np.int32),
+                        pairs=np.array(out["pairs"], np.int32).reshape(-1, 5), tails=np.array(out["tails"], np.int32).reshape(-1, 6),
+                        tail_bits=np.array(out["tail_bits"], np.uint16), out_shift=np.array(out["out_shift"], np.uint32),
+                        packet_bytes=np.frombuffer(b"".join(packets), np.uint8), packet_lens=np.array([len(p) for p in packets], np.int32),
+                        depth=np.array([depth], np.int32))
+    print(name, "packets", len(packets), "bytes", sum(len(p) for p in packets), "pairs", len(out["pairs"]), "tails", len(out["tails"]))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
-    which = set(sys.argv[1:]) or {"aac", "mp3", "vorbis"}
+    which = set(sys.argv[1:]) or {"aac", "mp3", "vorbis", "flac", "alac"}
     if "aac" in which:
         tree = patched_tree((A.CRATE,)) / A.CRATE / "src"
         for name, (seed, n, nch) in AAC_STREAMS.items():
@@ -125,6 +200,12 @@ def main():
         tree = patched_tree((M.CRATE,)) / M.CRATE / "src"
         for name, args in MP3_STREAMS.items():
             mp3(name, *args, tree)
+    if "flac" in which:
+        flac("flac_24bit", 3, 5, 2, 24, 100)
+        flac("flac_16bit", 1, 6, 2, 16, 192)
+    if "alac" in which:
+        alac("alac_24bit_stereo", (5, 7, 2, 24, 160))
+        alac("alac_20bit_6ch", (4, 6, 6, 20, 64))
     if "vorbis" in which:
         tree = patched_tree((V.CRATE,)) / V.CRATE / "src"
         for name, args in VORBIS_STREAMS.items():
