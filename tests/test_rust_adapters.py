@@ -352,3 +352,20 @@ def test_alac_adapter_restores_the_pcm(make_dll, depth, frames, max_batch):
     st, got = h.decode("HipAlacDecoder", dec, h.packet(key(2), 0))
     assert st == "ok" and np.array_equal(got, want[2])
     assert "symaccel_alac_predict" in h.bridge.calls
+
+
+def test_the_ffi_bridge_leaves_the_bindings_ctypes_declarations_alone():
+    """the interpreter's bridge sets restype / argtypes per call; it must do so on a CDLL object of its own -- the Python binding
+    declares argtypes on ITS handle of the same library, and a later call through it with undeclared arguments truncates pointers
+    (a serial run of the CPU suite crashed that way: a shim test first, a plain emulation test after it)"""
+    from emu_lib import emu_library
+    lib = emu_library()
+    before = {n: getattr(lib.dll, n).argtypes for n in ("symaccel_aac_synth", "symaccel_ctx_create", "symaccel_host_alloc")}
+    assert all(v is not None for v in before.values())
+    h = harness(emu_dll, "aac.rs")
+    coeffs = np.zeros((1, 2, 1024), np.float32)
+    dec, _ = aac_decoder(h, coeffs, np.zeros((2, 1), np.uint8), 2)
+    st, _ = h.decode("HipAacDecoder", dec, h.packet(key(0), 0))
+    assert st == "ok" and "symaccel_aac_synth" in h.bridge.calls
+    assert h.bridge.dll is not lib.dll
+    assert {n: getattr(lib.dll, n).argtypes for n in before} == before
