@@ -1,9 +1,12 @@
-//! `HipMpaDecoder`: MPEG-1/2/2.5 Layer III with the synthesis tail -- reorder, antialias, hybrid synthesis, frequency
-//! inversion and the polyphase filterbank (symphonia-bundle-mp3/src/layer3/hybrid_synthesis.rs:153-485,
-//! synthesis.rs:158-336; caller layer3/mod.rs:440-476) -- on the MI355X.
-use std::sync::{Arc, Mutex};
+//! `HipMpaDecoder`: MPEG-1/2/2.5 Layer III with everything behind the entropy decoder on the MI355X -- requantization and
+//! joint stereo (symphonia-bundle-mp3/src/layer3/requantize.rs:240-380, stereo.rs:485-556), then the synthesis tail: reorder,
+//! antialias, hybrid synthesis, frequency inversion and the polyphase filterbank (layer3/hybrid_synthesis.rs:153-485,
+//! synthesis.rs:158-336; caller layer3/mod.rs:421-476).  The front end hands over what `read_huffman_samples` produced as
+//! 16-bit integers + the side records (`symaccel_mp3_decode_pipelined`: 2 bytes per spectral line across PCIe instead of 4,
+//! one kernel); a front end that delivers requantized f32 spectra (`ParsedMpa::fused == None`) takes `symaccel_mp3_synth`.
+use std::sync::{Arc, Mutex, OnceLock};
 
-use symphonia_bundle_mp3::backend::{GranuleSide, SynthBackend};
+use symphonia_bundle_mp3::backend::{GranuleQuant, GranuleSide, GranuleStereo, SynthBackend};
 use symphonia_bundle_mp3::MpaDecoder;
 use symphonia_core::audio::{Audio, AudioBuffer, AudioMut, AudioSpec, GenericAudioBufferRef};
 use symphonia_core::codecs::audio::well_known::CODEC_ID_MP3;
@@ -23,8 +26,18 @@ use crate::lookahead::{BatchCodec, Lookahead};
 pub struct ParsedMpa {
     pub trim: (usize, usize), // frames to trim from the start / end of the decoded packet when gapless (decoder.rs:128-131)
     pub n_granules: usize, // 2 for MPEG-1, 1 for MPEG-2 / 2.5
-    pub xr: Vec<f32>,
+    pub xr: Vec<f32>,      // empty when `fused` is there
     pub side: Vec<ffi::SymaccelMp3Side>,
+    pub fused: Option<FusedMpa>,
+}
+
+/// One frame as the ENTROPY decoder leaves it (`Layer3::decode` up to, not including, `requantize` at layer3/mod.rs:421-428):
+/// the Huffman samples as integers and what requantize (requantize.rs:240-380) and stereo (stereo.rs:485-556) read of the
+/// side information.  `ParsedMpa::side` then carries the rzero the reference has AFTER stereo (stereo.rs:549-553).
+pub struct FusedMpa {
+    pub quant: Vec<i16>,                  // [granule][channel][576]
+    pub rq: Vec<ffi::SymaccelMp3Requant>, // [granule][channel]
+    pub st: Vec<ffi::SymaccelMp3Stereo>,  // [granule]; flags 0 where the frame is not joint-stereo coded
 }
 
 /// The reference's bitstream reader, Huffman decoder, requantizer and stereo processor, vendored (they are private to
@@ -33,6 +46,8 @@ pub trait MpaFrontEnd: Send + Sync {
     fn channels(&self) -> usize;
     fn sample_rate_idx(&self) -> i32;
     fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedMpa>;
+    /// `AudioDecoder::reset` (decoder.rs:149-152): the parse stage forgets the bit reservoir.
+    fn reset(&mut self);
 }
 
 /// What the reference's decoder hands its `SynthBackend` for one packet (bindings/rust/patches/symphonia-bundle-mp3.diff).
@@ -40,13 +55,48 @@ pub trait MpaFrontEnd: Send + Sync {
 pub struct MpaRecord {
     pub xr: Vec<f32>,                    // [granule][channel][576], in call order
     pub side: Vec<ffi::SymaccelMp3Side>, // [granule][channel]
+    pub quant: Vec<i16>,                  // the fused form (decode_granule): [granule][channel][576]
+    pub rq: Vec<ffi::SymaccelMp3Requant>, // [granule][channel]
+    pub st: Vec<ffi::SymaccelMp3Stereo>,  // [granule]
+    pub bad_sample: bool,                 // a sample that is not sign * s^(4/3) of an integer s (cannot happen: see quantised)
     pub sample_rate_idx: i32,
     pub resets: usize,
 }
 
+/// `POW43` of the reference (requantize.rs:22-31): `f32::powf(i as f32, 4.0 / 3.0)` for i in 0..8207, the values
+/// `read_huffman_samples` stores for a Huffman sample i (requantize.rs:126, 139; +-1.0 in the count1 partition).
+static SAMPLE_VALUES: OnceLock<Vec<f32>> = OnceLock::new();
+
+fn pow43() -> &'static Vec<f32> {
+    SAMPLE_VALUES.get_or_init(|| (0..8207).map(|i| f32::powf(i as f32, 4.0 / 3.0)).collect())
+}
+
+/// The Huffman sample behind a value of `read_huffman_samples`: the s with `POW43[s] == |x|`, signed.  The table is strictly
+/// increasing, so the s is unique; it is found from the rounded 3/4 power and CHECKED against the table (`None`: x is not a
+/// table value, which the reference's Huffman decoder cannot produce).  A seam that handed the integers over directly would
+/// save this step; it keeps the patch to the reference at one `if` in the granule loop instead.
+fn quantised(x: f32) -> Option<i16> {
+    if x == 0.0 {
+        return Some(0);
+    }
+    let table = pow43();
+    let a = x.abs();
+    let guess = (f32::powf(a, 0.75) + 0.5) as usize;
+    for s in [guess, guess + 1, guess.saturating_sub(1)] {
+        if s < table.len() && table[s] == a {
+            return Some(if x < 0.0 { -(s as i16) } else { s as i16 });
+        }
+    }
+    None
+}
+
+fn block_type_of(side: &GranuleSide) -> (u8, u8) {
+    (side.block_type, side.is_mixed as u8)
+}
+
 /// The `SynthBackend` handed to the reference's `MpaDecoder`: the samples of every granule-channel after requantisation
 /// and joint-stereo processing are recorded, nothing is synthesized.
-pub struct Recorder(pub Arc<Mutex<MpaRecord>>);
+pub struct Recorder(pub Arc<Mutex<MpaRecord>>, pub bool);
 
 impl SynthBackend for Recorder {
     fn synth_granule(&mut self, _channel: usize, side: &GranuleSide, samples: &mut [f32; 576], _out: &mut [f32]) {
@@ -60,6 +110,83 @@ impl SynthBackend for Recorder {
     fn reset(&mut self) {
         self.0.lock().expect("mp3 record poisoned").resets += 1;
     }
+
+    /// `Recorder(_, true)`: take the granules in front of requantize (the second seam of the patch).
+    fn takes_granules(&self) -> bool {
+        self.1
+    }
+
+    fn decode_granule(
+        &mut self,
+        _gr: usize,
+        quant: &[GranuleQuant],
+        stereo: Option<GranuleStereo>,
+        samples: &[[f32; 576]; 2],
+        _out: &mut AudioBuffer<f32>,
+    ) {
+        let mut rec = self.0.lock().expect("mp3 record poisoned");
+        // stereo.rs:549-553: with either joint-stereo tool on, both channels end at the larger rzero
+        let joint = match stereo {
+            Some(st) => st.mid_side || st.intensity,
+            None => false,
+        };
+        let end = quant.iter().map(|q| q.side.rzero).max().unwrap_or(0).min(576);
+        for (ch, q) in quant.iter().enumerate() {
+            for x in samples[ch].iter() {
+                match quantised(*x) {
+                    Some(v) => rec.quant.push(v),
+                    None => {
+                        rec.quant.push(0);
+                        rec.bad_sample = true;
+                    }
+                }
+            }
+            let (block_type, is_mixed) = block_type_of(&q.side);
+            let rzero = q.side.rzero.min(576) as u16;
+            let mut flags = 0u8;
+            if q.scalefac_scale {
+                flags |= ffi::SYMACCEL_MP3_RQ_SCALEFAC_SCALE as u8;
+            }
+            if q.preflag {
+                flags |= ffi::SYMACCEL_MP3_RQ_PREFLAG as u8;
+            }
+            rec.rq.push(ffi::SymaccelMp3Requant {
+                global_gain: q.global_gain,
+                flags,
+                block_type,
+                is_mixed,
+                subblock_gain: q.subblock_gain,
+                reserved: 0,
+                rzero,
+                scalefacs: q.scalefacs,
+                pad: [0; 3],
+            });
+            rec.side.push(ffi::SymaccelMp3Side { block_type, is_mixed, rzero: if joint { end as u16 } else { rzero } });
+            rec.sample_rate_idx = q.side.sample_rate_idx as i32;
+        }
+        let mut st = ffi::SymaccelMp3Stereo { flags: 0, block_type: 0, is_mixed: 0, reserved: 0, rzero0: 0, rzero1: 0, scalefacs1: [0; 39], pad: 0 };
+        if let (Some(mode), 2) = (stereo, quant.len()) {
+            if mode.mid_side {
+                st.flags |= ffi::SYMACCEL_MP3_ST_MID_SIDE as u8;
+            }
+            if mode.intensity {
+                st.flags |= ffi::SYMACCEL_MP3_ST_INTENSITY as u8;
+            }
+            if mode.is_mpeg1 {
+                st.flags |= ffi::SYMACCEL_MP3_ST_MPEG1 as u8;
+            }
+            if quant[1].scalefac_compress & 1 != 0 {
+                st.flags |= ffi::SYMACCEL_MP3_ST_IS_SCALE as u8;
+            }
+            let (block_type, is_mixed) = block_type_of(&quant[1].side);
+            st.block_type = block_type;
+            st.is_mixed = is_mixed;
+            st.rzero0 = quant[0].side.rzero.min(576) as u16;
+            st.rzero1 = quant[1].side.rzero.min(576) as u16;
+            st.scalefacs1 = quant[1].scalefacs;
+        }
+        rec.st.push(st);
+    }
 }
 
 /// Index of `rate` in the order the reference's frame header uses (common.rs: 44100, 48000, 32000, 22050, 24000, 16000,
@@ -69,17 +196,25 @@ fn sample_rate_index(rate: u32) -> Option<i32> {
     RATES.iter().position(|r| *r == rate).map(|i| i as i32)
 }
 
-/// `MpaFrontEnd` over the reference's own decoder with the recording backend installed: header, side info, bit reservoir,
-/// scale factors, Huffman decoding, requantisation and joint stereo are symphonia-bundle-mp3's code, unmodified.
+/// `MpaFrontEnd` over the reference's own decoder with the recording backend installed: header, side information, bit reservoir,
+/// scale factors and Huffman decoding are symphonia-bundle-mp3's code, unmodified.  `fused` (the default) stops there -- the
+/// recorder takes the granules in front of requantize and `parse` returns integers + records (`ParsedMpa::fused`); without
+/// it the reference's requantize and stereo run too and `parse` returns f32 spectra.
 pub struct SeamFrontEnd {
     dec: MpaDecoder,
     rec: Arc<Mutex<MpaRecord>>,
     nch: usize,
     sr_idx: i32,
+    fused: bool,
 }
 
 impl SeamFrontEnd {
-    pub fn try_new(params: &AudioCodecParameters, _opts: &AudioDecoderOptions) -> Result<Self> {
+    pub fn try_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Self> {
+        Self::try_new_at(params, opts, true)
+    }
+
+    /// `fused == false`: the first-generation seam (behind requantize + stereo), f32 spectra across PCIe.
+    pub fn try_new_at(params: &AudioCodecParameters, _opts: &AudioDecoderOptions, fused: bool) -> Result<Self> {
         let (Some(rate), Some(channels)) = (params.sample_rate, params.channels.clone()) else {
             return unsupported_error("mp3: sample rate and channels are required");
         };
@@ -89,8 +224,8 @@ impl SeamFrontEnd {
         let rec: Arc<Mutex<MpaRecord>> = Arc::new(Mutex::new(MpaRecord::default()));
         // the front end never trims: the trim of a packet is applied to what the device produced (MpaBatch::publish)
         let opts = AudioDecoderOptions { gapless: false, ..Default::default() };
-        let dec = MpaDecoder::try_new_with_backend(params, &opts, Box::new(Recorder(rec.clone())))?;
-        Ok(SeamFrontEnd { dec, rec, nch: channels.count(), sr_idx })
+        let dec = MpaDecoder::try_new_with_backend(params, &opts, Box::new(Recorder(rec.clone(), fused)))?;
+        Ok(SeamFrontEnd { dec, rec, nch: channels.count(), sr_idx, fused })
     }
 }
 
@@ -108,6 +243,10 @@ impl MpaFrontEnd for SeamFrontEnd {
             let mut rec = self.rec.lock().expect("mp3 record poisoned");
             rec.xr.clear();
             rec.side.clear();
+            rec.quant.clear();
+            rec.rq.clear();
+            rec.st.clear();
+            rec.bad_sample = false;
         }
         self.dec.decode_ref(packet)?;
         let rec = self.rec.lock().expect("mp3 record poisoned");
@@ -116,12 +255,23 @@ impl MpaFrontEnd for SeamFrontEnd {
             // (decoder.rs:105-110, "invalid audio buffer signal spec for packet")
             return decode_error("mp3: the frame does not match the stream's channels or sample rate");
         }
+        if rec.bad_sample {
+            return decode_error("mp3: a spectral sample is not a Huffman table value");
+        }
+        let fused = if self.fused { Some(FusedMpa { quant: rec.quant.clone(), rq: rec.rq.clone(), st: rec.st.clone() }) } else { None };
         Ok(ParsedMpa {
             trim: (packet.trim_start.get() as usize, packet.trim_end.get() as usize),
             n_granules: rec.side.len() / self.nch,
             xr: rec.xr.clone(),
             side: rec.side.clone(),
+            fused,
         })
+    }
+
+    fn reset(&mut self) {
+        // MpaDecoder::reset (decoder.rs:149-152, through the seam patch): a new Layer3 state -- empty bit reservoir -- around
+        // the same backend
+        self.dec.reset();
     }
 }
 
@@ -135,6 +285,9 @@ pub struct MpaBatch {
     vvec: Vec<f32>,                   // [channel][16][64]
     vfront: Vec<i32>,                 // [channel]
     pcm: Pinned<f32>,                 // [channel][granule of the batch][576]
+    quant: Pinned<i16>,               // the fused form: [channel][granule of the batch][576] Huffman samples,
+    rq: Vec<ffi::SymaccelMp3Requant>, //   [channel][granule of the batch],
+    st: Vec<ffi::SymaccelMp3Stereo>,  //   [granule of the batch] (the one channel pair of a stereo stream)
     first_granule: Vec<usize>,        // per packet of the batch: index of its first granule; one extra entry = total
     trims: Vec<(usize, usize)>,       // per packet of the batch
     gapless: bool,
@@ -158,6 +311,10 @@ impl BatchCodec for MpaBatch {
             total += p.n_granules;
         }
         self.first_granule.push(total);
+        // (every packet of a batch comes from the same front end: all fused, or none)
+        if batch.iter().all(|p| p.fused.is_some()) && !batch.is_empty() {
+            return self.transform_fused(batch, total);
+        }
         for (i, p) in batch.iter().enumerate() {
             for g in 0..p.n_granules {
                 for c in 0..self.nch {
@@ -208,6 +365,8 @@ impl BatchCodec for MpaBatch {
     }
 
     fn reset_state(&mut self) {
+        // the parse stage: bit reservoir (a seek lands in the middle of a stream whose main data reaches back)
+        self.front.reset();
         // Layer3::reset + synthesis state (layer3/mod.rs, synthesis.rs:140-156): overlap, V vector and its front index
         self.overlap.fill(0.0);
         self.vvec.fill(0.0);
@@ -216,6 +375,55 @@ impl BatchCodec for MpaBatch {
 
     fn clear(&mut self) {
         self.buf.clear();
+    }
+}
+
+impl MpaBatch {
+    /// layer3/mod.rs:421-477 for the whole batch in one call: requantize, stereo and the synthesis tail on the device from the
+    /// entropy decoder's integers (2 bytes per line in, 4 bytes per sample out).
+    fn transform_fused(&mut self, batch: &[ParsedMpa], total: usize) -> Result<()> {
+        let zero_st = ffi::SymaccelMp3Stereo { flags: 0, block_type: 0, is_mixed: 0, reserved: 0, rzero0: 0, rzero1: 0, scalefacs1: [0; 39], pad: 0 };
+        for (i, p) in batch.iter().enumerate() {
+            let Some(f) = &p.fused else { continue };
+            for g in 0..p.n_granules {
+                let at = self.first_granule[i] + g;
+                for c in 0..self.nch {
+                    let dst = c * total + at;
+                    let src = (g * self.nch + c) * 576;
+                    self.quant.as_mut_slice()[dst * 576..(dst + 1) * 576].copy_from_slice(&f.quant[src..src + 576]);
+                    self.rq[dst] = f.rq[g * self.nch + c];
+                    self.side[dst] = p.side[g * self.nch + c];
+                }
+                self.st[at] = if self.nch == 2 { f.st[g] } else { zero_st };
+            }
+        }
+        let pair: [i32; 2] = [0, 1];
+        let n_pairs = if self.nch == 2 { 1 } else { 0 };
+        // SAFETY: every buffer covers nch * total (* 576) elements and st covers `total` records (sized for max_batch frames of
+        // two granules); pair names the two chains of the batch; the call returns after the PCM and the updated state are back in
+        // host memory.
+        check(
+            unsafe {
+                ffi::symaccel_mp3_decode_pipelined(
+                    self.ctx.raw(),
+                    self.quant.as_slice().as_ptr(),
+                    self.rq.as_ptr(),
+                    pair.as_ptr(),
+                    self.st.as_ptr(),
+                    n_pairs,
+                    self.side.as_ptr(),
+                    self.front.sample_rate_idx(),
+                    self.overlap.as_mut_ptr(),
+                    self.vvec.as_mut_ptr(),
+                    self.vfront.as_mut_ptr(),
+                    self.pcm.as_mut_slice().as_mut_ptr(),
+                    self.nch,
+                    total,
+                    0,
+                )
+            },
+            self.ctx.raw(),
+        )
     }
 }
 
@@ -254,6 +462,12 @@ impl HipMpaDecoder {
                 vvec: vec![0.0; nch * 1024],
                 vfront: vec![0; nch],
                 pcm: Pinned::new(nch * granules * 576)?,
+                quant: Pinned::new(nch * granules * 576)?,
+                rq: vec![
+                    ffi::SymaccelMp3Requant { global_gain: 0, flags: 0, block_type: 0, is_mixed: 0, subblock_gain: [0; 3], reserved: 0, rzero: 0, scalefacs: [0; 39], pad: [0; 3] };
+                    nch * granules
+                ],
+                st: vec![ffi::SymaccelMp3Stereo { flags: 0, block_type: 0, is_mixed: 0, reserved: 0, rzero0: 0, rzero1: 0, scalefacs1: [0; 39], pad: 0 }; granules],
                 first_granule: Vec::with_capacity(max_batch + 1),
                 trims: Vec::with_capacity(max_batch),
                 gapless: opts.gapless,

@@ -36,6 +36,7 @@ pub struct ScriptedMpaFront {
     pub sr_idx: i32,
     pub script: Vec<ParsedMpa>,
     pub parses: usize,
+    pub resets: usize,
 }
 
 impl MpaFrontEnd for ScriptedMpaFront {
@@ -49,7 +50,10 @@ impl MpaFrontEnd for ScriptedMpaFront {
         let i = script_index(packet)?;
         self.parses += 1;
         let p = &self.script[i];
-        Ok(ParsedMpa { trim: p.trim, n_granules: p.n_granules, xr: p.xr.clone(), side: p.side.clone() })
+        Ok(ParsedMpa { trim: p.trim, n_granules: p.n_granules, xr: p.xr.clone(), side: p.side.clone(), fused: None })
+    }
+    fn reset(&mut self) {
+        self.resets += 1;
     }
 }
 

@@ -119,14 +119,42 @@ def test_the_parser_hands_on_what_was_written(trees, seed, n, mode, mpeg1, sr_co
         assert r.variant == "Ok", (i, r)
         parsed = r.f["0"]
         assert parsed.f["n_granules"].v == ngr
-        xr = np.array([np.float32(x) for x in parsed.f["xr"].a], np.float32).reshape(ngr * s.nch, 576)
-        for k, ((f, q), side) in enumerate(zip(rec["granules"], parsed.f["side"].a)):
+        # the FUSED front end (the default): what the entropy decoder produced, as integers, in front of requantize and stereo --
+        # exactly the samples the writer coded, whatever the stereo mode
+        fused = parsed.f["fused"]
+        assert fused.variant == "Some" and len(parsed.f["xr"].a) == 0
+        fused = fused.f["0"]
+        quant = np.array([x.v for x in fused.f["quant"].a], np.int64).reshape(ngr * s.nch, 576)
+        assert len(fused.f["rq"].a) == ngr * s.nch and len(fused.f["st"].a) == ngr
+        for k, ((f, q), side, rq) in enumerate(zip(rec["granules"], parsed.f["side"].a, fused.f["rq"].a)):
             plain = mode != "joint" or rec["mode_ext"] == 0
-            # (joint stereo processing widens the non-zero range of a channel to its partner's: stereo.rs)
+            # (joint stereo processing widens the non-zero range of a channel to its partner's: stereo.rs:549-553)
             assert (side.f["rzero"].v == f["rzero"]) if plain else (side.f["rzero"].v >= f["rzero"]), (i, k)
+            assert rq.f["rzero"].v == f["rzero"] and rq.f["global_gain"].v == f["global_gain"], (i, k)
             assert side.f["block_type"].v == f["block"] and bool(side.f["is_mixed"].v) == bool(f["mixed"] and f["block"] == W.SHORT), (i, k)
-            if plain:
-                assert np.array_equal(xr[k] != 0, q != 0), (i, k)
+            assert np.array_equal(quant[k], np.asarray(q, np.int64)), (i, k)
+        for g, st in enumerate(fused.f["st"].a):
+            want_flags = ((rec["mode_ext"] >> 1) & 1) | ((rec["mode_ext"] & 1) << 1) if mode == "joint" else 0
+            assert (st.f["flags"].v & 3) == want_flags, (i, g)
+
+
+def test_the_unfused_front_end_hands_on_requantized_spectra(trees):
+    """the first-generation seam (behind requantize + stereo) stays available: SeamFrontEnd::try_new_at(.., false)"""
+    seed, n, mode, mpeg1, sr_code = 1, 2, "stereo", True, 0
+    s, packets = stream(seed, n, mode, mpeg1, sr_code)
+    h = shim(trees[1])
+    front = h.it.call("SeamFrontEnd::try_new_at", h.params("CODEC_ID_MP3", s.rate, s.nch), h.opts(), False)
+    assert front.variant == "Ok", front
+    front = front.f["0"]
+    for i, (pk, rec) in enumerate(packets):
+        r = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(pk, 0))
+        assert r.variant == "Ok", (i, r)
+        parsed = r.f["0"]
+        assert parsed.f["fused"].variant == "None"
+        xr = np.array([np.float32(x) for x in parsed.f["xr"].a], np.float32).reshape(2 * s.nch, 576)
+        for k, ((f, q), side) in enumerate(zip(rec["granules"], parsed.f["side"].a)):
+            assert side.f["rzero"].v == f["rzero"], (i, k)
+            assert np.array_equal(xr[k] != 0, np.asarray(q) != 0), (i, k)
 
 
 # (a call into the CPU-emulation library costs seconds whatever the batch: the default set keeps the number of calls down)
@@ -142,7 +170,8 @@ def test_the_accelerated_decoder_equals_the_reference_on_packet_bytes(trees, see
         st, got = h.decode("HipMpaDecoder", dec, h.packet(pk, i * per_frame))
         assert st == st_r == "ok"
         assert np.array_equal(bits(got), bits(want)), (i, float(np.abs(got - want).max()))
-    assert h.bridge.calls.count("symaccel_mp3_synth") == n  # no look-ahead reader: batches of one
+    # no look-ahead reader: batches of one, each through the FUSED entry point (int16 Huffman samples + records in, PCM out)
+    assert h.bridge.calls.count("symaccel_mp3_decode_pipelined") == n and h.bridge.calls.count("symaccel_mp3_synth") == 0
 
 
 def test_damaged_packets_fail_like_the_reference_and_the_stream_goes_on(trees):
@@ -194,13 +223,54 @@ def test_look_ahead_batches_and_reset(trees):
             out.append(h.decode("HipMpaDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p)))
         return out
 
-    n0 = h.bridge.calls.count("symaccel_mp3_synth")
+    n0 = h.bridge.calls.count("symaccel_mp3_decode_pipelined")
     for i, (st, got) in enumerate(run(0, n)):
         assert st == "ok" and np.array_equal(bits(got), bits(want[i])), i
-    assert h.bridge.calls.count("symaccel_mp3_synth") - n0 == -(-n // batch)  # overlap and the V FIFO carry across the batches
+    assert h.bridge.calls.count("symaccel_mp3_decode_pipelined") - n0 == -(-n // batch)  # overlap and the V FIFO carry across the batches
+    assert h.bridge.calls.count("symaccel_mp3_synth") == 0
     # seek back to the start + reset: the reference drops overlap, FIFO and the bit reservoir (decoder.rs:149-152); packet 0 does not
     # reach back, packets 1 and 2 do -- into packet 0's slot, which both decoders have again
     h.it.call_method("LookaheadReader", "seek", reader, I.Int(0, "i64"), usize(0))
     h.it.call_method("HipMpaDecoder", "reset", dec)
     for i, ((st, got), (st_r, want_r)) in enumerate(zip(run(0, 3), again)):  # (one batch: the reader is three or more packets ahead)
         assert st == st_r == "ok" and np.array_equal(bits(got), bits(want_r)), i
+
+
+def test_seek_into_the_middle_of_the_stream_and_reset(trees):
+    """A seek that lands on a packet whose main data reaches BACK into earlier packets (main_data_begin > 0), followed by reset():
+    the reference rebuilds its whole state, bit reservoir included (decoder.rs:149-152), so the granules that would have started
+    in the missing bytes are handled as an underflow.  The accelerated decoder's front end parsed AHEAD of what the caller had been
+    given when the seek came; `reset` must reach the reference decoder inside the front end (`MpaFrontEnd::reset`), or the stale
+    reservoir decodes those granules from the wrong bytes."""
+    mpeg1, n, batch = True, sized(8, 5), 4
+    per_frame = 1152
+    s, packets = stream(11, n, "joint", mpeg1, 0)
+    data = [p for p, _ in packets]
+    backs = [rec["main_data_begin"] for _, rec in packets]
+    k = next(i for i in range(2, n) if backs[i] > 0)  # the seek target reaches back
+    ref = Harness(None, reference=True, mp3_tree=trees[0])
+    ref_dec = cpu_decoder(ref, s)
+    for i, pk in enumerate(data[:k + 2]):  # the reference plays on past the target, like the accelerated decoder's look-ahead does
+        ref.decode("MpaDecoder", ref_dec, ref.packet(pk, i * per_frame))
+    ref.it.call_method("MpaDecoder", "reset", ref_dec)
+    want = [ref.decode("MpaDecoder", ref_dec, ref.packet(pk, (k + i) * per_frame)) for i, pk in enumerate(data[k:])]
+    h, dec = hip_decoder(trees[1], s, max_batch=batch)
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    pk = I.Arr([h.packet(d, i * per_frame, track=1, owned=True) for i, d in enumerate(data)], True)
+    reader = h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(8))
+
+    def run(first, count):
+        out = []
+        for i in range(first, first + count):
+            p = h.it.call_method("LookaheadReader", "next_packet", reader).f["0"].f["0"]
+            assert p.f["pts"].f["0"].v == i * per_frame
+            out.append(h.decode("HipMpaDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p)))
+        return out
+
+    assert all(st == "ok" for st, _ in run(0, 2))  # (the first batch has parsed packets 0 .. batch - 1 by now)
+    h.it.call_method("LookaheadReader", "seek", reader, I.Int(0, "i64"), usize(k))
+    h.it.call_method("HipMpaDecoder", "reset", dec)
+    got = run(k, n - k)
+    assert [st for st, _ in got] == [st for st, _ in want]
+    for i, ((st, a), (_, b)) in enumerate(zip(got, want)):
+        assert (np.array_equal(bits(a), bits(b)) if st == "ok" else a == b), (k + i, st)

@@ -156,10 +156,10 @@ def test_the_shim_mp3_decoder_gives_the_reference_decoders_pcm(make_dll, name, m
     def parsed(p):
         rows = [I.Struct("SymaccelMp3Side", {"block_type": I.Int(int(side[p, g, c, 0]), "u8"), "is_mixed": I.Int(int(side[p, g, c, 1]), "u8"),
                                              "rzero": I.Int(int(side[p, g, c, 2]), "u16")}) for g in range(ngr) for c in range(nch)]
-        return I.Struct("ParsedMpa", {"trim": (usize(0), usize(0)), "n_granules": usize(ngr), "xr": f32_vec(xr[p]), "side": I.Arr(rows, True)})
+        return I.Struct("ParsedMpa", {"trim": (usize(0), usize(0)), "n_granules": usize(ngr), "xr": f32_vec(xr[p]), "side": I.Arr(rows, True), "fused": I.NONE})
 
     front = I.Struct("ScriptedMpaFront", {"nch": usize(nch), "sr_idx": I.Int(sr_idx, "i32"), "script": I.Arr([parsed(p) for p in range(npk)], True),
-                                          "parses": usize(0)})
+                                          "parses": usize(0), "resets": usize(0)})
     r = h.it.call("HipMpaDecoder::try_new", h.params("CODEC_ID_MP3", rate, nch), h.opts(), front, usize(max_batch))
     assert r.variant == "Ok", r
     dec = r.f["0"]

@@ -68,7 +68,7 @@ def aac_decoder(h, coeffs, side, max_batch):
     nch, nfr = coeffs.shape[0], coeffs.shape[1]
     script = I.Arr([I.Struct("ParsedAac", {"coeffs": f32_vec(coeffs[:, t]), "side": u8_vec(side[t])}) for t in range(nfr)], True)
     params = h.params("CODEC_ID_AAC", 48000, nch)
-    front = I.Struct("ScriptedAacFront", {"params": params, "nch": usize(nch), "script": script, "parses": usize(0)})
+    front = I.Struct("ScriptedAacFront", {"params": params, "nch": usize(nch), "script": script, "parses": usize(0), "resets": usize(0)})
     r = h.it.call("HipAacDecoder::try_new", params, h.opts(), front, usize(max_batch))
     assert r.variant == "Ok", r
     return r.f["0"], r.f["0"].f["batch"].f["front"]  # (the decoder owns the front end: `front` was moved into it)
@@ -150,10 +150,10 @@ def test_mpa_adapter_publishes_the_fixture_pcm(make_dll, chain, max_batch):
                 rows.append(I.Struct("SymaccelMp3Side", {"block_type": I.Int(int(sd[g, 0]), "u8"), "is_mixed": I.Int(int(sd[g, 1]), "u8"),
                                                          "rzero": I.Int(int(sd[g, 2]), "u16")}))
         lines = np.stack([xr[c, g] for g in range(gpp * p, gpp * p + gpp) for c in range(nch)])
-        return I.Struct("ParsedMpa", {"trim": (usize(0), usize(0)), "n_granules": usize(gpp), "xr": f32_vec(lines), "side": I.Arr(rows, True)})
+        return I.Struct("ParsedMpa", {"trim": (usize(0), usize(0)), "n_granules": usize(gpp), "xr": f32_vec(lines), "side": I.Arr(rows, True), "fused": I.NONE})
 
     script = I.Arr([parsed(p) for p in range(ngr // gpp)], True)
-    front = I.Struct("ScriptedMpaFront", {"nch": usize(nch), "sr_idx": I.Int(sr, "i32"), "script": script, "parses": usize(0)})
+    front = I.Struct("ScriptedMpaFront", {"nch": usize(nch), "sr_idx": I.Int(sr, "i32"), "script": script, "parses": usize(0), "resets": usize(0)})
     r = h.it.call("HipMpaDecoder::try_new", h.params("CODEC_ID_MP3", 44100, nch), h.opts(), front, usize(max_batch))
     assert r.variant == "Ok", r
     dec = r.f["0"]

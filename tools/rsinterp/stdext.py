@@ -1,5 +1,5 @@
 """std::sync and std::collections for the interpreter: what the trait-side shim (bindings/rust/symphonia-accel-hip) needs to
-be EXECUTED by tests/test_rust_shim.py -- Arc / Weak / Mutex, HashMap with the entry API, VecDeque, #[derive(Default)].
+be EXECUTED by tests/test_rust_shim.py -- Arc / Weak / Mutex / OnceLock, HashMap with the entry API, VecDeque, #[derive(Default)].
 The DSP fixtures (tools/rs2fixtures.py) use none of it.
 
   Arc<T> / Mutex<T>   `Cell` wrappers with reference identity: `clone()` of an Arc is the same Arc, `lock()` yields the inner
@@ -129,6 +129,8 @@ def path_builtin(it, segs):
                 v = I.Enum(v.enum, v.variant, dict(v.f) if v.f else None)
             return Cell('Mutex', v)
         return I.Builtin(mutex_new, 'Mutex::new')
+    if head == 'OnceLock' and name == 'new':  # std::sync::OnceLock: an empty slot; get_or_init fills it once
+        return I.Builtin(lambda: Cell('OnceLock', None), 'OnceLock::new')
     if head == 'HashMap' and name in ('new', 'with_capacity', 'default'):
         return I.Builtin(lambda *a: HMap(), 'HashMap::new')
     if head == 'HashSet' and name in ('new', 'with_capacity', 'default'):
@@ -161,6 +163,14 @@ def method(it, base, name, args, env):
             if name in ('get_mut', 'into_inner'):
                 return True, I.ok(base.v)
             raise I.InterpError('no method %s on Mutex' % name)
+        if base.kind == 'OnceLock':
+            if name == 'get_or_init':
+                if base.v is None:
+                    base.v = it.call_value(args[0], [])
+                return True, base.v
+            if name == 'get':
+                return True, (I.some(base.v) if base.v is not None else I.NONE)
+            raise I.InterpError('no method %s on OnceLock' % name)
         if base.kind == 'Weak':
             if name == 'upgrade':
                 return True, I.some(base.v)
