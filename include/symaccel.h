@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SYMACCEL_ABI_VERSION 4 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device, vorbis floor_y */
+#define SYMACCEL_ABI_VERSION 5 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device, vorbis floor_y; 5: aac_decode_pipelined, aac_joint_stereo_list, vorbis_decode */
 
 typedef enum symaccel_status {
     SYMACCEL_OK = 0,
@@ -167,6 +167,14 @@ int symaccel_aac_joint_stereo_device(symaccel_ctx *ctx, float *d_coeffs, size_t 
                                      const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short,
                                      int n_swb_short);
 
+/* symaccel_aac_joint_stereo_device for a LIST of channel-pair frames only: d_pair_frames[i] = pair * frames_per_chain + frame
+ * (entries outside the batch are skipped; an entry listed twice is decoded twice).  What the frames that carry TNS filters need in
+ * front of symaccel_aac_tns_device when everything else takes the fused walk below; traffic proportional to the list. */
+int symaccel_aac_joint_stereo_list_device(symaccel_ctx *ctx, float *d_coeffs, size_t frames_per_chain,
+                                          const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs,
+                                          const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short, int n_swb_short,
+                                          const uint32_t *d_pair_frames, size_t n_pair_frames);
+
 /* symaccel_aac_synth_*_device with the joint-stereo decoding of the channel pairs done AS THE LINES ARE LOADED (cpe.rs:110-157 +
  * dsp.rs:57-158 in one kernel): d_coeffs holds what the spectrum decoder produced (mid / side or intensity-coded where the
  * descriptors say so), pair_chains / js_desc / swb tables as symaccel_aac_joint_stereo_device takes them; chains that belong to
@@ -200,6 +208,21 @@ typedef struct symaccel_aac_tns_filter {
 } symaccel_aac_tns_filter; /* 92 bytes */
 int symaccel_aac_tns_device(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames,
                             const symaccel_aac_tns_filter *d_filters, size_t n_filters);
+
+/* The AAC-LC tail from what the spectrum decoder produces, HOST memory in and out (cpe.rs:110-157 joint stereo, then per channel
+ * ics/mod.rs:449-468: TNS and Dsp::synth): coeffs[chain][frame][1024] as decoded (mid / side or intensity coded where js_desc says
+ * so), side[chain][frame], pair_chains[n_pairs][2] + js_desc[pair][frame] (n_pairs may be 0; a chain in at most one pair), the swb
+ * tables as symaccel_aac_joint_stereo_device takes them, and the TNS filters of the whole batch as a flat list (frame = chain *
+ * frames_per_chain + frame; n_tns may be 0).  Chunked like the other *_pipelined entry points.  Per chunk: the channel-pair frames
+ * that carry a TNS filter in either channel get their joint stereo decoded in place first (a list pass over those frames only),
+ * then the filters run (one lane per filter -- the recurrence is serial along the spectrum, so it stays a pass of its own), then
+ * ONE walk decodes the joint stereo of every other frame as it loads the lines and synthesizes all of them.  Frames carrying pulse
+ * data (Pulse::synth sits between joint stereo and TNS, ics/mod.rs:452-454) are the caller's: joint stereo + pulse on the host,
+ * mode 0 everywhere here.  delay_io / pcm as symaccel_aac_synth_pipelined. */
+int symaccel_aac_decode_pipelined(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *h_side, const int32_t *h_pair_chains,
+                                  const symaccel_aac_js_frame *h_js_desc, size_t n_pairs, const uint16_t *swb_long, int n_swb_long,
+                                  const uint16_t *swb_short, int n_swb_short, const symaccel_aac_tns_filter *h_tns, size_t n_tns,
+                                  float *h_delay_io, float *h_pcm, size_t n_chains, size_t frames_per_chain, size_t chunk_frames);
 
 /* Pulse::synth (aac/ics/pulse.rs:64-105, with iquant / requant :19-33), the tool between joint stereo and TNS
  * (Ics::synth_channel, ics/mod.rs:452-454).  HOST function on HOST memory: the tool raises values to the 4/3 and 3/4

@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "symaccel_shard_range", "symaccel_scatter_streams", "symaccel_gather_streams", "symaccel_exchange_pipelined", "symaccel_comm_unique_id", "symaccel_comm_init",
     "symaccel_comm_destroy", "symaccel_multi_set_transport", "symaccel_mp3_decode_pipelined",
     "symaccel_mp3_decode_pp_device", "symaccel_mp3_decode_device",
+    "symaccel_aac_joint_stereo_list_device", "symaccel_aac_decode_pipelined",
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
@@ -57,6 +58,14 @@ class SymaccelError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("%s (status %d)" % (message, status))
         self.status = status
+
+
+def _links_hip(path):
+    """does this shared object name the HIP runtime among its dependencies? (a scan of the file for the DT_NEEDED string)"""
+    try:
+        return b"libamdhip64" in Path(path).read_bytes()
+    except OSError:
+        return False
 
 
 class Library:
@@ -70,13 +79,20 @@ class Library:
         # One HIP runtime per process: libsymaccel.so is linked against the system's libamdhip64, PyTorch-ROCm ships its own.  When
         # torch is loaded first the library binds to torch's copy and the two share the device; the other way round both runtimes
         # are live and symaccel_ctx_create fails with a device error (seen on the MI355X box: build() followed by smoke() in one
-        # process).  The harness uses torch for device memory anyway, so the real library pulls it in first when it is installed
-        # (SYMACCEL_NO_TORCH_PRELOAD=1: a host that never loads torch; the CPU-emulation library of the tests does not link HIP).
-        if "emu" not in path.name and "torch" not in sys.modules and not os.environ.get("SYMACCEL_NO_TORCH_PRELOAD"):
+        # process).  The harness (tests, bench.py, smoke) uses torch for device memory, so a library that links the HIP runtime
+        # pulls torch in first when torch is installed but not yet imported -- and SAYS so; a host that never loads torch sets
+        # SYMACCEL_NO_TORCH_PRELOAD=1.  (The CPU-emulation library of the tests does not link HIP: nothing to preload.)
+        self.torch_preload = None
+        if "torch" not in sys.modules and not os.environ.get("SYMACCEL_NO_TORCH_PRELOAD") and _links_hip(path):
+            import warnings
             try:
                 import torch  # noqa: F401
-            except Exception:  # noqa: BLE001
-                pass
+                self.torch_preload = "imported torch before %s (one HIP runtime per process)" % path.name
+            except Exception as e:  # noqa: BLE001
+                self.torch_preload = "torch could not be imported before %s: %s: %s" % (path.name, type(e).__name__, e)
+                warnings.warn("symphonia_amd: " + self.torch_preload)
+            if os.environ.get("SYMACCEL_VERBOSE"):
+                print("symphonia_amd: " + self.torch_preload, file=sys.stderr)
         self.dll = C.CDLL(str(path))
         d = self.dll
         d.symaccel_strerror.restype = C.c_char_p
@@ -104,6 +120,8 @@ class Library:
         d.symaccel_mpa_polyphase.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_aac_joint_stereo_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _i, _vp, _i]
         d.symaccel_aac_tns_device.argtypes = [_vp, _vp, _sz, _vp, _sz]
+        d.symaccel_aac_joint_stereo_list_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _i, _vp, _i, _vp, _sz]
+        d.symaccel_aac_decode_pipelined.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_mp3_stereo_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _i, _sz]
         d.symaccel_mp3_requantize_stereo_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp, _sz]
         d.symaccel_mp3_requantize_device.argtypes = [_vp, _vp, _vp, _i, _vp, _sz]

@@ -247,6 +247,26 @@ class AacSpectralTools:
                            _ptr(desc) if n_pairs else None, n_pairs, *swb, _ptr(delay), _ptr(pcm), nch, frames)
         return pcm
 
+    def joint_stereo_list(self, coeffs, pair_chains, desc, pair_frames):
+        """joint_stereo for the listed channel-pair frames only (pair * frames + frame each): the frames that carry TNS filters."""
+        frames = int(coeffs.shape[1])
+        self.ctx._call(self.ctx.lib.dll.symaccel_aac_joint_stereo_list_device, _ptr(coeffs), frames, _ptr(pair_chains), _ptr(desc),
+                       int(pair_chains.shape[0]), _ptr(self.swb_long), self.swb_long.size - 1, _ptr(self.swb_short), self.swb_short.size - 1,
+                       _ptr(pair_frames), int(pair_frames.shape[0]))
+        return coeffs
+
+    def decode(self, coeffs, side, delay, pair_chains, desc, tns_filters, pcm, chunk_frames=0):
+        """The whole AAC-LC tail HOST to HOST (symaccel_aac_decode_pipelined): coded spectra + joint-stereo descriptors + TNS filters
+        (frame = chain * frames + frame) in numpy arrays -> pcm; delay is updated in place."""
+        nch, frames = int(coeffs.shape[0]), int(coeffs.shape[1])
+        n_pairs = int(pair_chains.shape[0]) if pair_chains is not None else 0
+        n_tns = int(tns_filters.shape[0]) if tns_filters is not None else 0
+        self.ctx._call(self.ctx.lib.dll.symaccel_aac_decode_pipelined, _ptr(coeffs), _ptr(side), _ptr(pair_chains) if n_pairs else None,
+                       _ptr(desc) if n_pairs else None, n_pairs, _ptr(self.swb_long), self.swb_long.size - 1, _ptr(self.swb_short),
+                       self.swb_short.size - 1, _ptr(tns_filters) if n_tns else None, n_tns, _ptr(delay), _ptr(pcm), nch, frames,
+                       int(chunk_frames))
+        return pcm
+
     def tns(self, coeffs, filters, n_filters=None):
         """coeffs[..., 1024] (any leading shape = n_frames); filters[n] AAC_TNS_DTYPE."""
         n_frames = 1

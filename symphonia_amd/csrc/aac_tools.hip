@@ -23,10 +23,15 @@ namespace symaccel {
 
 namespace {
 
+// `list` (optional): the channel-pair frames to decode, pair * frames_per_chain + frame each -- the workgroups of a launch over
+// a list touch nothing else (the frames that carry TNS filters in front of the fused pair walk: symaccel_aac_decode_pipelined).
 __global__ __launch_bounds__(256) void aac_joint_stereo_kernel(AacBandMaps maps, float *__restrict__ coeffs,
                                                                unsigned frames_per_chain, const int32_t *__restrict__ pair_chains,
-                                                               const symaccel_aac_js_frame *__restrict__ desc) {
-    const unsigned pf = blockIdx.x, pair = pf / frames_per_chain, f = pf % frames_per_chain;
+                                                               const symaccel_aac_js_frame *__restrict__ desc,
+                                                               const uint32_t *__restrict__ list, unsigned n_pair_frames) {
+    const unsigned pf = list ? list[blockIdx.x] : blockIdx.x;
+    if (pf >= n_pair_frames) return;  // (a list entry outside the batch)
+    const unsigned pair = pf / frames_per_chain, f = pf % frames_per_chain;
     const symaccel_aac_js_frame &d = desc[pf];
     const int t = (int)threadIdx.x;
     int sfb, slot;
@@ -51,6 +56,14 @@ __global__ __launch_bounds__(256) void aac_joint_stereo_kernel(AacBandMaps maps,
         *lp = make_float4(l.x + r.x, l.y + r.y, l.z + r.z, l.w + r.w);
         *rp = make_float4(l.x - r.x, l.y - r.y, l.z - r.z, l.w - r.w);
     }
+}
+
+// The descriptors of the listed pair frames become "nothing coded": what the fused pair walk must see for frames whose joint
+// stereo was decoded in place by the list pass above.
+__global__ void aac_js_consume_kernel(symaccel_aac_js_frame *__restrict__ desc, const uint32_t *__restrict__ list, unsigned n_list,
+                                      unsigned n_pair_frames) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_list && list[i] < n_pair_frames) desc[list[i]].max_sfb = 0;
 }
 
 constexpr int kTnsMaxOrder = 20;  // TNS_MAX_ORDER, tns.rs:22
@@ -302,11 +315,23 @@ __global__ __launch_bounds__(64) void aac_tns_kernel(float *__restrict__ coeffs,
 }  // namespace
 
 int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d_coeffs, size_t frames_per_chain,
-                            const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs) {
-    const size_t grid = n_pairs * frames_per_chain;
-    if (grid > 0x7fffffffu || frames_per_chain > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
+                            const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs, const uint32_t *d_list,
+                            size_t n_list) {
+    const size_t all = n_pairs * frames_per_chain;
+    const size_t grid = d_list ? n_list : all;
+    if (all > 0x7fffffffu || grid > 0x7fffffffu || frames_per_chain > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    if (grid == 0) return SYMACCEL_OK;
     hipLaunchKernelGGL(aac_joint_stereo_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, maps, d_coeffs,
-                       (unsigned)frames_per_chain, d_pair_chains, d_desc);
+                       (unsigned)frames_per_chain, d_pair_chains, d_desc, d_list, (unsigned)all);
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_aac_js_consume(symaccel_ctx *ctx, symaccel_aac_js_frame *d_desc, const uint32_t *d_list, size_t n_list, size_t n_pair_frames) {
+    if (n_list == 0) return SYMACCEL_OK;
+    if (n_list > 0x7fffffffu || n_pair_frames > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(aac_js_consume_kernel, dim3((unsigned)((n_list + 255) / 256)), dim3(256), 0, ctx->stream, d_desc, d_list,
+                       (unsigned)n_list, (unsigned)n_pair_frames);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

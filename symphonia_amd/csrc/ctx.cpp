@@ -994,6 +994,20 @@ int symaccel_aac_joint_stereo_device(symaccel_ctx *ctx, float *d_coeffs, size_t 
     return launch_aac_joint_stereo(ctx, maps, d_coeffs, frames_per_chain, d_pair_chains, d_desc, n_pairs);
 }
 
+int symaccel_aac_joint_stereo_list_device(symaccel_ctx *ctx, float *d_coeffs, size_t frames_per_chain, const int32_t *d_pair_chains,
+                                          const symaccel_aac_js_frame *d_desc, size_t n_pairs, const uint16_t *swb_long, int n_swb_long,
+                                          const uint16_t *swb_short, int n_swb_short, const uint32_t *d_pair_frames,
+                                          size_t n_pair_frames) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    AacBandMaps maps;
+    if (!aac_band_maps(swb_long, n_swb_long, swb_short, n_swb_short, &maps)) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_pairs == 0 || frames_per_chain == 0 || n_pair_frames == 0) return SYMACCEL_OK;
+    if (!d_coeffs || !d_pair_chains || !d_desc || !d_pair_frames) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_aac_joint_stereo(ctx, maps, d_coeffs, frames_per_chain, d_pair_chains, d_desc, n_pairs, d_pair_frames, n_pair_frames);
+}
+
 int symaccel_aac_tns_device(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
                             size_t n_filters) {
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
@@ -1228,3 +1242,10 @@ int symaccel_fft_twiddles(int n, float *dst) {
 }
 
 }  // extern "C"
+
+namespace symaccel {
+bool aac_band_maps(const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short, int n_swb_short, AacBandMaps *maps) {
+    // long windows have at most 51 bands (ISO/IEC 14496-3 Table 4.139: 8 kHz... 49/51), short ones at most 15
+    return build_band_map(swb_long, n_swb_long, 1024, 64, maps->long4) && build_band_map(swb_short, n_swb_short, 128, 16, maps->short4);
+}
+}  // namespace symaccel

@@ -184,6 +184,111 @@ int symaccel_aac_synth_pipelined(symaccel_ctx *ctx, const float *h_coeffs, const
     return pp.drain();
 }
 
+int symaccel_aac_decode_pipelined(symaccel_ctx *ctx, const float *h_coeffs, const uint8_t *h_side, const int32_t *h_pair_chains,
+                                  const symaccel_aac_js_frame *h_js_desc, size_t n_pairs, const uint16_t *swb_long, int n_swb_long,
+                                  const uint16_t *swb_short, int n_swb_short, const symaccel_aac_tns_filter *h_tns, size_t n_tns,
+                                  float *h_delay_io, float *h_pcm, size_t n_chains, size_t frames_per_chain, size_t chunk_frames) {
+    if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
+    AacBandMaps maps;
+    if (!aac_band_maps(swb_long, n_swb_long, swb_short, n_swb_short, &maps)) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains == 0 || frames_per_chain == 0) return SYMACCEL_OK;
+    if (!h_coeffs || !h_side || !h_delay_io || !h_pcm) return SYMACCEL_ERR_INVALID_ARG;
+    if ((n_pairs && (!h_pair_chains || !h_js_desc)) || (n_tns && !h_tns) || 2 * n_pairs > n_chains) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_chains * frames_per_chain > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    // pair_chains is in host memory: every chain at most once, inside the batch; pair_of[chain] = its pair
+    std::vector<int32_t> pair_of(n_chains, -1);
+    for (size_t p = 0; p < 2 * n_pairs; ++p) {
+        const int32_t c = h_pair_chains[p];
+        if (c < 0 || (size_t)c >= n_chains || pair_of[(size_t)c] >= 0) return SYMACCEL_ERR_INVALID_ARG;
+        pair_of[(size_t)c] = (int32_t)(p / 2);
+    }
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    const size_t cf = pick_chunk(frames_per_chain, n_chains * 4096, chunk_frames);
+    const size_t n_chunks = (frames_per_chain + cf - 1) / cf;
+    // TNS runs between joint stereo and the transform (ics/mod.rs:452-468), and it is a serial recurrence along the spectrum: it
+    // stays a pass of its own (one lane per filter, csrc/aac_tools.hip).  The filters are sorted into the chunks of the pipeline
+    // (frame indices re-based to the chunk's [chain][frame] layout); a channel-pair frame with a filter in either channel has its
+    // joint stereo decoded in place IN FRONT of the filters (a list pass over those frames only) and is marked "nothing coded"
+    // for the fused pair walk.  Frames without TNS -- the bulk of a stream -- are read once, by the walk.
+    std::vector<std::vector<symaccel_aac_tns_filter>> tns(n_chunks);
+    std::vector<std::vector<uint32_t>> tns_pf(n_chunks);
+    for (size_t i = 0; i < n_tns; ++i) {
+        symaccel_aac_tns_filter f = h_tns[i];
+        if ((size_t)f.frame >= n_chains * frames_per_chain) continue;  // (what symaccel_aac_tns_device skips)
+        const size_t chain = f.frame / frames_per_chain, t = f.frame % frames_per_chain, k = t / cf;
+        const size_t nf = std::min(cf, frames_per_chain - k * cf);
+        f.frame = (uint32_t)(chain * nf + (t - k * cf));
+        tns[k].push_back(f);
+        if (pair_of[chain] >= 0) tns_pf[k].push_back((uint32_t)((size_t)pair_of[chain] * nf + (t - k * cf)));
+    }
+    size_t max_tns = 0, max_pf = 0;
+    for (size_t k = 0; k < n_chunks; ++k) {
+        std::sort(tns_pf[k].begin(), tns_pf[k].end());
+        tns_pf[k].erase(std::unique(tns_pf[k].begin(), tns_pf[k].end()), tns_pf[k].end());
+        max_tns = std::max(max_tns, tns[k].size());
+        max_pf = std::max(max_pf, tns_pf[k].size());
+    }
+    Pipe pp(ctx);
+    SYM_TRY(pp.init());
+    float *d_in[2], *d_out[2], *d_state[2];
+    uint8_t *d_side[2];
+    symaccel_aac_js_frame *d_js[2];
+    symaccel_aac_tns_filter *d_tns[2];
+    uint32_t *d_pf[2];
+    int32_t *d_pairs;
+    void *d_index;
+    for (int b = 0; b < 2; ++b) {
+        SYM_TRY(pp.alloc((void **)&d_in[b], n_chains * cf * 4096));
+        SYM_TRY(pp.alloc((void **)&d_out[b], n_chains * cf * 4096));
+        SYM_TRY(pp.alloc((void **)&d_side[b], n_chains * cf));
+        SYM_TRY(pp.alloc((void **)&d_state[b], n_chains * 4096));
+        SYM_TRY(pp.alloc((void **)&d_js[b], std::max<size_t>(1, n_pairs * cf) * sizeof(symaccel_aac_js_frame)));
+        SYM_TRY(pp.alloc((void **)&d_tns[b], std::max<size_t>(1, max_tns) * sizeof(symaccel_aac_tns_filter)));
+        SYM_TRY(pp.alloc((void **)&d_pf[b], std::max<size_t>(1, max_pf) * 4));
+    }
+    SYM_TRY(pp.alloc((void **)&d_pairs, std::max<size_t>(1, n_pairs) * 8));
+    SYM_TRY(pp.alloc(&d_index, aac_js_scratch_bytes(n_chains, n_pairs, cf)));
+    SYM_TRY(pp.commit());
+    if (n_pairs) SYM_GPU(ctx, hipMemcpyAsync(d_pairs, h_pair_chains, n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
+    SYM_GPU(ctx, hipMemcpyAsync(d_state[0], h_delay_io, n_chains * 4096, hipMemcpyHostToDevice, ctx->stream));
+    size_t k = 0;
+    for (size_t t0 = 0; t0 < frames_per_chain; t0 += cf, ++k) {
+        const size_t nf = std::min(cf, frames_per_chain - t0);
+        const int b = (int)(k & 1);
+        if (k >= 2) {  // buffer set b is free once chunk k-2's kernels have read its input and its PCM has left
+            SYM_GPU(ctx, hipStreamWaitEvent(pp.s_in, pp.ev_k[b], 0));
+            SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_out[b], 0));
+        }
+        SYM_TRY(copy_rows(ctx, d_in[b], nf * 4096, h_coeffs + t0 * 1024, frames_per_chain * 4096, nf * 4096, n_chains, hipMemcpyHostToDevice,
+                          pp.s_in));
+        SYM_TRY(copy_rows(ctx, d_side[b], nf, h_side + t0, frames_per_chain, nf, n_chains, hipMemcpyHostToDevice, pp.s_in));
+        if (n_pairs)
+            SYM_TRY(copy_rows(ctx, d_js[b], nf * sizeof(symaccel_aac_js_frame), h_js_desc + t0, frames_per_chain * sizeof(symaccel_aac_js_frame),
+                              nf * sizeof(symaccel_aac_js_frame), n_pairs, hipMemcpyHostToDevice, pp.s_in));
+        if (!tns[k].empty())
+            SYM_GPU(ctx, hipMemcpyAsync(d_tns[b], tns[k].data(), tns[k].size() * sizeof(symaccel_aac_tns_filter), hipMemcpyHostToDevice, pp.s_in));
+        if (!tns_pf[k].empty())
+            SYM_GPU(ctx, hipMemcpyAsync(d_pf[b], tns_pf[k].data(), tns_pf[k].size() * 4, hipMemcpyHostToDevice, pp.s_in));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_in[b], pp.s_in));
+        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_in[b], 0));
+        if (!tns_pf[k].empty()) {  // cpe.rs:110-157 for the pair frames that carry TNS, in place; then they are plain frames for the walk
+            SYM_TRY(launch_aac_joint_stereo(ctx, maps, d_in[b], nf, d_pairs, d_js[b], n_pairs, d_pf[b], tns_pf[k].size()));
+            SYM_TRY(launch_aac_js_consume(ctx, d_js[b], d_pf[b], tns_pf[k].size(), n_pairs * nf));
+        }
+        if (!tns[k].empty()) SYM_TRY(launch_aac_tns(ctx, d_in[b], n_chains * nf, d_tns[b], tns[k].size()));  // tns.rs:180-195
+        SYM_TRY(launch_aac(ctx, d_in[b], d_side[b], d_state[k & 1], d_state[(k + 1) & 1], d_out[b], n_chains, nf, n_pairs ? &maps : nullptr,
+                           d_pairs, d_js[b], n_pairs, d_index));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_k[b], ctx->stream));
+        SYM_GPU(ctx, hipStreamWaitEvent(pp.s_out, pp.ev_k[b], 0));
+        SYM_TRY(copy_rows(ctx, h_pcm + t0 * 1024, frames_per_chain * 4096, d_out[b], nf * 4096, nf * 4096, n_chains, hipMemcpyDeviceToHost,
+                          pp.s_out));
+        SYM_GPU(ctx, hipEventRecord(pp.ev_out[b], pp.s_out));
+    }
+    SYM_GPU(ctx, hipMemcpyAsync(h_delay_io, d_state[k & 1], n_chains * 4096, hipMemcpyDeviceToHost, ctx->stream));
+    return pp.drain();
+}
+
 int symaccel_mp3_synth_pipelined(symaccel_ctx *ctx, const float *h_xr, const symaccel_mp3_side *h_side, int sample_rate_idx,
                                  float *h_overlap_io, float *h_vvec_io, int32_t *h_vfront_io, float *h_pcm, size_t n_chains,
                                  size_t granules_per_chain, size_t chunk_granules) {
@@ -289,8 +394,8 @@ int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, con
     SYM_TRY(pp.commit());
     // (the requantised spectra exist in registers and LDS only: csrc/mp3.hip mp3_front)
     SYM_GPU(ctx, hipMemcpy(d_pairs, units.data(), n_units * 8, hipMemcpyHostToDevice));  // (`units` is a local: a blocking copy)
-    for (int b = 0; b < 2; ++b)  // the records of mono units stay zero: no joint-stereo flag
-        SYM_GPU(ctx, hipMemsetAsync(d_st[b], 0, n_units * cg * sizeof(symaccel_mp3_stereo), pp.s_in));
+    for (int b = 0; b < 2; ++b)  // the records of mono units are zero (no joint-stereo flag): rows [n_pairs, n_units) at stride cg here,
+        SYM_GPU(ctx, hipMemsetAsync(d_st[b], 0, n_units * cg * sizeof(symaccel_mp3_stereo), pp.s_in));  // re-zeroed at stride ng for a short last chunk
     SYM_GPU(ctx, hipMemcpyAsync(d_ov[0], h_overlap_io, n_chains * 2304, hipMemcpyHostToDevice, ctx->stream));
     SYM_GPU(ctx, hipMemcpyAsync(d_vv[0], h_vvec_io, n_chains * 4096, hipMemcpyHostToDevice, ctx->stream));
     SYM_GPU(ctx, hipMemcpyAsync(d_vf[0], h_vfront_io, n_chains * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -311,6 +416,8 @@ int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, con
             SYM_TRY(copy_rows(ctx, d_st[b], ng * sizeof(symaccel_mp3_stereo), h_st_desc + g0, granules_per_chain * sizeof(symaccel_mp3_stereo),
                               ng * sizeof(symaccel_mp3_stereo), n_pairs, hipMemcpyHostToDevice, pp.s_in));
         SYM_TRY(copy_rows(ctx, d_side[b], ng * 4, h_side + g0, granules_per_chain * 4, ng * 4, n_chains, hipMemcpyHostToDevice, pp.s_in));
+        if (n_units > n_pairs && ng != cg)  // a short last chunk: the kernel indexes st_desc with stride ng, so the mono units' rows move
+            SYM_GPU(ctx, hipMemsetAsync(d_st[b] + n_pairs * ng, 0, (n_units - n_pairs) * ng * sizeof(symaccel_mp3_stereo), pp.s_in));
         SYM_GPU(ctx, hipEventRecord(pp.ev_in[b], pp.s_in));
         SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_in[b], 0));
         // requantize, joint stereo and the synthesis tail (layer3/mod.rs:421-477) in one kernel

@@ -243,7 +243,10 @@ int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts
                          const uint32_t *d_y, uint32_t n, float *d_floor, size_t count, const float *d_residue = nullptr,
                          uint8_t *d_floor_y = nullptr, const uint32_t *d_line_offs = nullptr);
 int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d_coeffs, size_t frames_per_chain,
-                            const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs);
+                            const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs,
+                            const uint32_t *d_list = nullptr, size_t n_list = 0);
+int launch_aac_js_consume(symaccel_ctx *ctx, symaccel_aac_js_frame *d_desc, const uint32_t *d_list, size_t n_list, size_t n_pair_frames);
+bool aac_band_maps(const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short, int n_swb_short, AacBandMaps *maps);
 int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
                    size_t n_filters);
 int launch_mp3_decode(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_mp3_requant *d_rq_desc, const int32_t *d_pair_chains,

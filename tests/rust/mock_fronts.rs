@@ -15,6 +15,7 @@ pub struct ScriptedAacFront {
     pub nch: usize,
     pub script: Vec<ParsedAac>,
     pub parses: usize,
+    pub resets: usize,
 }
 
 impl AacFrontEnd for ScriptedAacFront {
@@ -27,7 +28,10 @@ impl AacFrontEnd for ScriptedAacFront {
     fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedAac> {
         let i = script_index(packet)?;
         self.parses += 1;
-        Ok(ParsedAac { coeffs: self.script[i].coeffs.clone(), side: self.script[i].side.clone() })
+        Ok(ParsedAac { coeffs: self.script[i].coeffs.clone(), side: self.script[i].side.clone(), fused: None })
+    }
+    fn reset(&mut self) {
+        self.resets += 1;
     }
 }
 

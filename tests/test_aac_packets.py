@@ -128,7 +128,8 @@ def hip_decoder(tree, nch, max_batch=None):
     return h, h.f32_buffers(r.f["0"])
 
 
-@pytest.mark.parametrize("seed,n_packets,nch", sized(ALL_STREAMS[:2], [(2, 3, 2)]))
+# (the quick set reaches packet 6 of stream 2: the first one whose TNS filters cover a non-empty range of lines)
+@pytest.mark.parametrize("seed,n_packets,nch", sized(ALL_STREAMS[:2], [(2, 7, 2)]))
 def test_the_accelerated_decoder_equals_the_reference_on_packet_bytes(trees, seed, n_packets, nch):
     packets = stream(seed, n_packets, nch)
     ref = Harness(None, reference=True, aac_tree=trees[0])
@@ -139,7 +140,12 @@ def test_the_accelerated_decoder_equals_the_reference_on_packet_bytes(trees, see
         st, got = h.decode("HipAacDecoder", dec, h.packet(pk, i * 1024))
         assert st == st_r == "ok"
         assert np.array_equal(bits(got), bits(want)), (i, np.abs(got - want).max())
-    assert h.bridge.calls.count("symaccel_aac_synth") == n_packets  # no look-ahead reader: batches of one
+    # no look-ahead reader: batches of one, each through the FUSED entry point (coefficients as decoded + joint-stereo descriptors +
+    # TNS filters in, PCM out) -- the reference's M/S, intensity and TNS code did not run
+    assert h.bridge.calls.count("symaccel_aac_decode_pipelined") == n_packets and h.bridge.calls.count("symaccel_aac_synth") == 0
+    fused = [a for name, a in h.bridge.scalars if name == "symaccel_aac_decode_pipelined"]
+    if nch == 2:  # the writer's streams use M/S, intensity stereo and TNS: they reached the device as descriptors, not as arithmetic
+        assert any(a["n_pairs"] == 1 for a in fused) and any(a["n_tns"] > 0 for a in fused), fused
     cp = I.deref(h.it.call_method("HipAacDecoder", "codec_params", dec))
     assert cp.f["sample_rate"].f["0"].v == 44100 and cp.f["channels"].f["0"].f["0"].v == nch
 
@@ -195,12 +201,51 @@ def test_look_ahead_batches_and_reset(trees):
             out.append(h.decode("HipAacDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p)))
         return out
 
-    n0 = h.bridge.calls.count("symaccel_aac_synth")
+    n0 = h.bridge.calls.count("symaccel_aac_decode_pipelined")
     for i, (st, got) in enumerate(run(0, n)):
         assert st == "ok" and np.array_equal(bits(got), bits(want[i])), i
-    assert h.bridge.calls.count("symaccel_aac_synth") - n0 == -(-n // batch)  # the delay lines carry across the batches
+    assert h.bridge.calls.count("symaccel_aac_decode_pipelined") - n0 == -(-n // batch)  # the delay lines carry across the batches
+    assert h.bridge.calls.count("symaccel_aac_synth") == 0
     # seek back to the start and reset both: the overlap state is cleared (aac/mod.rs:244-248, ics/mod.rs:223-226)
     h.it.call_method("LookaheadReader", "seek", reader, I.Int(0, "i64"), usize(0))
     h.it.call_method("HipAacDecoder", "reset", dec)
     for i, (st, got) in zip(range(0, 3), run(0, 3)):
         assert st == "ok" and np.array_equal(bits(got), bits(again[i])), i
+
+
+def test_seek_into_the_middle_of_the_stream_and_reset(trees):
+    """reset() after a seek must reach the reference decoder inside the front end (`AacFrontEnd::reset`): its pairs remember the
+    window shape of the frame parsed last (ics/mod.rs:229-232 forgets it) -- and the front end parsed AHEAD of what the caller had been
+    given when the seek came."""
+    nch, n, batch, k = 2, sized(8, 5), 4, 2
+    written = stream(10, n, nch)
+    packets = [p for p, _ in written]
+    # the last packet the look-ahead parses before the seek carries KBD windows: a front end that is not reset hands packet k on with
+    # prev_window_shape = KBD where the reference, reset, says sine
+    assert all(m["shape"] == 1 for m in written[batch - 1][1])
+    ref = Harness(None, reference=True, aac_tree=trees[0])
+    ref_dec = cpu_decoder(ref, nch)
+    for i, pk in enumerate(packets[:batch]):  # the reference plays on past the target, like the accelerated decoder's look-ahead does
+        ref.decode("AacDecoder", ref_dec, ref.packet(pk, i * 1024))
+    ref.it.call_method("AacDecoder", "reset", ref_dec)
+    want = [ref.decode("AacDecoder", ref_dec, ref.packet(pk, (k + i) * 1024)) for i, pk in enumerate(packets[k:])]
+    h, dec = hip_decoder(trees[1], nch, max_batch=batch)
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    pk = I.Arr([h.packet(d, i * 1024, track=1, owned=True) for i, d in enumerate(packets)], True)
+    reader = h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(8))
+
+    def run(first, count):
+        out = []
+        for i in range(first, first + count):
+            p = h.it.call_method("LookaheadReader", "next_packet", reader).f["0"].f["0"]
+            assert p.f["pts"].f["0"].v == i * 1024
+            out.append(h.decode("HipAacDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p)))
+        return out
+
+    assert all(st == "ok" for st, _ in run(0, 1))  # (the first batch has parsed packets 0 .. batch - 1 by now)
+    h.it.call_method("LookaheadReader", "seek", reader, I.Int(0, "i64"), usize(k))
+    h.it.call_method("HipAacDecoder", "reset", dec)
+    got = run(k, n - k)
+    assert [st for st, _ in got] == [st for st, _ in want]
+    for i, ((st, a), (_, b)) in enumerate(zip(got, want)):
+        assert (np.array_equal(bits(a), bits(b)) if st == "ok" else a == b), (k + i, st)

@@ -66,7 +66,7 @@ def same(got, want):
 def aac_decoder(h, coeffs, side, max_batch):
     """coeffs[channel][frame][1024], side[frame][channel] -> a HipAacDecoder over a scripted front end"""
     nch, nfr = coeffs.shape[0], coeffs.shape[1]
-    script = I.Arr([I.Struct("ParsedAac", {"coeffs": f32_vec(coeffs[:, t]), "side": u8_vec(side[t])}) for t in range(nfr)], True)
+    script = I.Arr([I.Struct("ParsedAac", {"coeffs": f32_vec(coeffs[:, t]), "side": u8_vec(side[t]), "fused": I.NONE}) for t in range(nfr)], True)
     params = h.params("CODEC_ID_AAC", 48000, nch)
     front = I.Struct("ScriptedAacFront", {"params": params, "nch": usize(nch), "script": script, "parses": usize(0), "resets": usize(0)})
     r = h.it.call("HipAacDecoder::try_new", params, h.opts(), front, usize(max_batch))

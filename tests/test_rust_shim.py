@@ -253,7 +253,7 @@ STD_METHODS = set("""
     lock push push_back pop_front pop_back front back clear fill max min as_ptr as_mut_ptr as_slice as_mut_slice as_ref as_mut
     copy_from_slice to_str to_string_lossy into_owned is_null add write get get_mut insert remove entry or_default or_insert
     or_insert_with values_mut values retain upgrade strong_count is_none is_some and_then or_else ok_or first last to_vec
-    with_capacity extend extend_from_slice contains_key get_or_insert_with last_mut chunks chunks_exact zip rev sum fold any all
+    with_capacity extend extend_from_slice contains_key contains sort get_or_insert_with get_or_init last_mut chunks chunks_exact zip rev sum fold any all
     position find filter resize truncate drain swap split_at split_at_mut reserve capacity saturating_sub checked_sub
     wrapping_add wrapping_sub wrapping_shl wrapping_shr wrapping_mul leading_zeros trailing_zeros abs signum min_by max_by count skip step_by flat_map keys
     ok err map_err unwrap_or_else is_ok is_err then then_some into try_into from iter_chunks other pow

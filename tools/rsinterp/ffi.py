@@ -158,6 +158,7 @@ class Bridge:
         rest, self.decls = parse_extern_block(sys_rs_text)
         it.load_source(rest, 'symaccel_sys.rs')
         self.calls = []  # (name) log, for the tests
+        self.scalars = []  # per call: (name, {parameter: value}) for the integer arguments passed by value
         for name in self.decls:
             it.globals[name] = I.Builtin(lambda *a, _n=name: self.call(_n, *a), name)
             it.globals['ffi::' + name] = it.globals[name]
@@ -280,6 +281,7 @@ class Bridge:
             fn.restype = CT[rbase]
         fn.argtypes = None
         self.calls.append(name)
+        self.scalars.append((name, {pn: int(c.value) for (pn, pt), c in zip(params, cargs) if hasattr(c, 'value') and isinstance(c.value, int) and not pt.startswith('*')}))
         r = fn(*cargs)
         for kind, dst, arr, dt, extra in after:
             if kind == 'seq':
