@@ -34,6 +34,10 @@ def log(msg):
 
 def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
     """Returns (step_fn, units_per_step, unit_name, algorithmic_bytes_per_step, description, kernel_name, output tensor)."""
+    def sync_dev():
+        if not emulate:
+            torch.cuda.synchronize()
+
     import symphonia_amd as sa
     dev = "cpu" if emulate else "cuda"
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -220,6 +224,33 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
                 syn.decode(q, d_rq, d_units, d_st, side, stt[0][0], stt[0][1], stt[0][2], pcm, state_out=stt[1])
                 stt.reverse()
             kernel = "mp3_synth_kernel<4, true>"
+
+            def verify():
+                """the timed batch itself, from a zero state: sampled streams x the first granules against the oracle chain requantize ->
+                stereo -> synthesis (layer3/mod.rs:421-477)"""
+                import oracle
+                z = [torch.zeros_like(t) for t in stt[0]]
+                syn.decode(q, d_rq, d_units, d_st, side, z[0], z[1], z[2], pcm, state_out=stt[1])
+                sync_dev()
+                bad = checked = 0
+                gw = min(ngr, 24)
+                picked = sorted({0, nch // 2 - 1})
+                for u in picked:
+                    c0, c1 = int(units[u, 0]), int(units[u, 1])
+                    qs = q[[c0, c1], :gw].cpu().numpy()
+                    xr_ = oracle.mp3_requantize(qs.reshape(-1, 576), np.ascontiguousarray(rq[[c0, c1], :gw]).reshape(-1), 0).reshape(2, gw, 576)
+                    for gi in range(gw):
+                        xr_[0, gi], xr_[1, gi] = oracle.mp3_stereo(xr_[0, gi], xr_[1, gi], st[u, gi], 0)
+                    want = oracle.mp3_synth(xr_, np.ascontiguousarray(side_np[[c0, c1], :gw]), 0, np.zeros((2, 576), np.float32),
+                                            np.zeros((2, 1024), np.float32), np.zeros(2, np.int32))[0]
+                    got = pcm[[c0, c1], :gw].cpu().numpy()
+                    bad += int((got != want).sum())
+                    checked += got.size
+                if bad:
+                    raise RuntimeError("bench: the mp3q batch differs from the oracle in %d of %d sampled samples" % (bad, checked))
+                return {"checker": "oracle/symoracle.c (requantize, stereo, then the synthesis tail), outside the timed region", "streams": picked,
+                        "granule_windows": [[0, gw]], "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
+            step.verify = verify
         else:
             xr = torch.empty((nch, ngr, 576), device=dev, dtype=torch.float32)
             ste = sa.Mp3Stereo(ctx, 0)
@@ -913,6 +944,9 @@ def main():
     ap.add_argument("--no-copy-ceiling", action="store_true", help="N = 1: skip the same-run copy probes")
     ap.add_argument("--spinup-ms", type=int, default=60, help="milliseconds of back-to-back steps in front of the W warm-up steps (sustained clocks)")
     ap.add_argument("--no-spinup", action="store_true", help="measure W + K from an idle board only (the clock ramp)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="further W + K regions timed right after the line's own (same protocol, back to back): `repeats` reports every "
+                         "region's ms per step, the median value and the spread; 0 = none")
     ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the extra BASELINE config-4 (Vorbis shard) line")
     ap.add_argument("--selftest-multi", type=int, nargs="?", const=4, default=0, metavar="WORLD",
                     help="one GPU: exercise the N > 1 C path (RCCL binding at world size 1; scatter -> synthesis -> gather with WORLD "
@@ -1045,6 +1079,22 @@ def main():
         log("cold-start region done: %.3f ms/step" % (e_c / args.steps * 1e3))
     elapsed, launch_s, mine = timed(step, args.steps, args.warmup, spin)
     log("timed region done: %.3f ms/step (device), %.3f ms/step (wall)" % (launch_s * 1e3, elapsed / args.steps * 1e3))
+    # the same W + K region again, `--repeats` times back to back: the line's `value` stays the first region (the contract's "exactly
+    # K steps"); the repeats say how far one 4 ms region is from the next on this board (`repeats.value_median`, `spread_frac`)
+    repeats = None
+    if args.repeats > 0 and not emulate:
+        per, dev_ms = [elapsed / args.steps * 1e3], [launch_s * 1e3]
+        for _ in range(args.repeats):
+            e_r, l_r, _ = timed(step, args.steps, args.warmup)
+            per.append(e_r / args.steps * 1e3)
+            dev_ms.append(l_r * 1e3)
+        med = float(np.median(per))
+        repeats = {"regions": len(per), "ms_per_step": per, "kernel_ms": dev_ms, "ms_per_step_median": med,
+                   "value_median": units * world / (med / 1e3), "value_min": units * world / (max(per) / 1e3),
+                   "value_max": units * world / (min(per) / 1e3), "spread_frac": (max(per) - min(per)) / med,
+                   "roofline_frac_median": alg_bytes / (float(np.median(dev_ms)) / 1e3) / 1e9 / HBM_PEAK_GBS,
+                   "note": "region 0 is the line's own timed region (`value`); the others follow it back to back, W warm-up + K timed steps each"}
+        log("repeats done: median %.4f ms/step, spread %.1f %%" % (med, repeats["spread_frac"] * 100))
     verified = None
     if rank == 0 and hasattr(step, "verify"):
         verified = step.verify()
@@ -1160,11 +1210,12 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "schema": 4,
+            "schema": 5,
             "protocol": ("sustained (spinup %d ms of back-to-back steps, then W warm-up + K timed steps); `cold_start` = the same W + K "
                          "from an idle board, the protocol of BENCH_r01 / r02" % args.spinup_ms) if spin > 0.0 else "cold (W + K from an idle board)",
             "spinup_ms": (args.spinup_ms if spin > 0.0 else 0),
             "cold_start": cold,
+            "repeats": repeats,
             "verified": verified,
             "higher_is_better": True,
             "scaling": "weak",
