@@ -241,7 +241,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
                     xr_ = oracle.mp3_requantize(qs.reshape(-1, 576), np.ascontiguousarray(rq[[c0, c1], :gw]).reshape(-1), 0).reshape(2, gw, 576)
                     for gi in range(gw):
                         xr_[0, gi], xr_[1, gi] = oracle.mp3_stereo(xr_[0, gi], xr_[1, gi], st[u, gi], 0)
-                    want = oracle.mp3_synth(xr_, np.ascontiguousarray(side_np[[c0, c1], :gw]), 0, np.zeros((2, 576), np.float32),
+                    want = oracle.mp3_synth(xr_, np.ascontiguousarray(side_np[[c0, c1], :gw]).view(np.uint8).reshape(2, gw, 4), 0, np.zeros((2, 576), np.float32),
                                             np.zeros((2, 1024), np.float32), np.zeros(2, np.int32))[0]
                     got = pcm[[c0, c1], :gw].cpu().numpy()
                     bad += int((got != want).sum())

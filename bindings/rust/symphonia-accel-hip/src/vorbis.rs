@@ -1,8 +1,11 @@
-//! `HipVorbisDecoder`: the per-channel synthesis of every audio packet -- Imdct, windowing and the lapped overlap-add of
-//! `DspChannel::synth` (symphonia-codec-vorbis/src/dsp.rs:68-145, called from lib.rs:296-331) -- on the MI355X.
+//! `HipVorbisDecoder`: everything behind the packet decoder on the MI355X -- inverse coupling, floor-1 curve synthesis and the dot
+//! product (symphonia-codec-vorbis/src/lib.rs:250-292, floor.rs:568-653), then the per-channel synthesis of every audio packet:
+//! Imdct, windowing and the lapped overlap-add of `DspChannel::synth` (dsp.rs:68-145, called from lib.rs:296-331).  The front end
+//! hands over residue vectors + floor posts + the coupling steps of the packet (`symaccel_vorbis_decode`); a front end that delivers
+//! finished spectra (`ParsedVorbis::fused == None`; any stream with a floor of type 0) takes `symaccel_vorbis_synth`.
 use std::sync::{Arc, Mutex};
 
-use symphonia_codec_vorbis::backend::SynthBackend;
+use symphonia_codec_vorbis::backend::{CodedChannel, Floor1Config, SynthBackend};
 use symphonia_codec_vorbis::VorbisDecoder;
 use symphonia_core::audio::{Audio, AudioBuffer, AudioMut, AudioSpec, GenericAudioBufferRef};
 use symphonia_core::codecs::audio::well_known::CODEC_ID_VORBIS;
@@ -22,14 +25,30 @@ use crate::lookahead::{BatchCodec, Lookahead};
 pub struct ParsedVorbis {
     pub trim: (usize, usize), // frames to trim from the start / end of the decoded packet (lib.rs:333-342; the decoder is gapless)
     pub long_block: bool,  // block_flag of the packet's mode (lib.rs:203-214)
-    pub spectra: Vec<f32>, // [channel][n / 2], n = the block size the flag selects
+    pub spectra: Vec<f32>, // [channel][n / 2], n = the block size the flag selects; with `fused`: the RESIDUE vectors
+    pub fused: Option<FusedVorbis>,
 }
+
+/// What is still to be done to `ParsedVorbis::spectra` when they are the packet decoder's residue vectors (lib.rs:230-248; zeros
+/// for a do-not-decode channel): the inverse coupling steps, the floor curves and the dot product (lib.rs:250-292).
+pub struct FusedVorbis {
+    pub floor: Vec<u8>,    // [channel]: index into `VorbisFrontEnd::floors`, or SYMACCEL_VORBIS_FLOOR_UNUSED
+    pub posts: Vec<u32>,   // [channel][POSTS]: floor1_Y as read from the packet
+    pub coupling: Vec<u8>, // [(magnitude channel, angle channel)], in the mapping's order
+}
+
+/// Posts per channel-block in the batch arrays (floor1_values <= 65: floor.rs:510-520).
+pub const POSTS: usize = 65;
 
 pub trait VorbisFrontEnd: Send + Sync {
     fn channels(&self) -> usize;
     /// (bs0_exp, bs1_exp) of the identification header (lib.rs:404-406)
     fn block_exps(&self) -> (i32, i32);
     fn parse(&mut self, packet: &PacketRef<'_>) -> Result<ParsedVorbis>;
+    /// The floor-1 configurations `FusedVorbis::floor` indexes (empty: this front end never returns `fused`).
+    fn floors(&self) -> Vec<ffi::SymaccelVorbisFloor1Cfg>;
+    /// `AudioDecoder::reset`: nothing in the Vorbis parse stage outlives a packet (the lapping state is the batch's).
+    fn reset(&mut self);
 }
 
 /// What the reference's decoder hands its `SynthBackend` (bindings/rust/patches/symphonia-codec-vorbis.diff).
@@ -41,11 +60,15 @@ pub struct VorbisRecord {
     pub long_block: bool,
     pub spectra: Vec<f32>, // [channel][n / 2]
     pub seen: usize,
+    pub floors: Vec<ffi::SymaccelVorbisFloor1Cfg>, // the fused form (configure_floors, synth_block): see FusedVorbis
+    pub floor: Vec<u8>,
+    pub posts: Vec<u32>,
+    pub coupling: Vec<u8>,
 }
 
 /// The `SynthBackend` handed to the reference's `VorbisDecoder`: every channel's floor x residue spectrum is recorded,
 /// nothing is synthesized.
-pub struct Recorder(pub Arc<Mutex<VorbisRecord>>);
+pub struct Recorder(pub Arc<Mutex<VorbisRecord>>, pub bool);
 
 impl SynthBackend for Recorder {
     fn configure(&mut self, n_channels: usize, bs0_exp: u8, bs1_exp: u8) {
@@ -68,21 +91,87 @@ impl SynthBackend for Recorder {
     }
 
     fn reset(&mut self) {}
+
+    /// `Recorder(_, true)`: take the blocks in front of the inverse coupling (the second seam of the patch).
+    fn takes_blocks(&self) -> bool {
+        self.1
+    }
+
+    fn configure_floors(&mut self, floors: &[Option<Floor1Config>]) {
+        let mut rec = self.0.lock().expect("vorbis record poisoned");
+        rec.floors.clear();
+        for f in floors.iter() {
+            let mut cfg = ffi::SymaccelVorbisFloor1Cfg { multiplier: 1, n_posts: 0, pad: [0; 2], x_list: [0; 65] };
+            if let Some(f) = f {
+                cfg.multiplier = f.multiplier;
+                cfg.n_posts = f.x_list.len().min(POSTS) as u8;
+                for (dst, x) in cfg.x_list.iter_mut().zip(f.x_list.iter()) {
+                    *dst = *x;
+                }
+            }
+            rec.floors.push(cfg);
+        }
+    }
+
+    fn synth_block(&mut self, block_flag: bool, _prev_block_flag: bool, couplings: &[(u8, u8)], channels: &[CodedChannel<'_>], _out: &mut AudioBuffer<f32>) {
+        let mut rec = self.0.lock().expect("vorbis record poisoned");
+        let nch = rec.n_channels;
+        let half = channels.first().map(|c| c.residue.len()).unwrap_or(0);
+        rec.long_block = block_flag;
+        rec.spectra.clear();
+        rec.spectra.resize(nch * half, 0.0);
+        rec.floor.clear();
+        rec.floor.resize(nch, ffi::SYMACCEL_VORBIS_FLOOR_UNUSED as u8);
+        rec.posts.clear();
+        rec.posts.resize(nch * POSTS, 0);
+        rec.coupling.clear();
+        for ch in channels.iter() {
+            let c = ch.plane;
+            if c >= nch {
+                continue;
+            }
+            // a do-not-decode channel's residue buffer is stale (residue.rs:253-259 returns before touching it): its spectrum is 0
+            if !ch.do_not_decode {
+                rec.spectra[c * half..(c + 1) * half].copy_from_slice(ch.residue);
+            }
+            if let Some((index, posts)) = ch.floor {
+                rec.floor[c] = index as u8;
+                for (dst, y) in rec.posts[c * POSTS..(c + 1) * POSTS].iter_mut().zip(posts.iter()) {
+                    *dst = *y;
+                }
+            }
+            rec.seen += 1;
+        }
+        // the steps name channels by their position in `channels`: the batch keeps channels by audio plane
+        for (m, a) in couplings.iter() {
+            if let (Some(mc), Some(ac)) = (channels.get(*m as usize), channels.get(*a as usize)) {
+                rec.coupling.push(mc.plane as u8);
+                rec.coupling.push(ac.plane as u8);
+            }
+        }
+    }
 }
 
 /// `VorbisFrontEnd` over the reference's own decoder with the recording backend installed: setup headers, codebooks, floor
-/// and residue decoding, inverse coupling and the dot product are symphonia-codec-vorbis's code, unmodified.
+/// and residue decoding are symphonia-codec-vorbis's code, unmodified.  `fused` (the default, for streams whose floors are all of
+/// type 1) stops there -- the recorder takes the blocks in front of the inverse coupling and `parse` returns residue vectors + posts
+/// + coupling steps (`ParsedVorbis::fused`); without it the reference's coupling, floor synthesis and dot product run too.
 pub struct SeamFrontEnd {
     dec: VorbisDecoder,
     rec: Arc<Mutex<VorbisRecord>>,
 }
 
 impl SeamFrontEnd {
-    pub fn try_new(params: &AudioCodecParameters, _opts: &AudioDecoderOptions) -> Result<Self> {
+    pub fn try_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Self> {
+        Self::try_new_at(params, opts, true)
+    }
+
+    /// `fused == false`: the first-generation seam (behind the dot product).
+    pub fn try_new_at(params: &AudioCodecParameters, _opts: &AudioDecoderOptions, fused: bool) -> Result<Self> {
         let rec: Arc<Mutex<VorbisRecord>> = Arc::new(Mutex::new(VorbisRecord::default()));
         // the front end never silences or trims: both are applied to what the device produced (VorbisBatch::publish)
         let opts = AudioDecoderOptions { gapless: false, ..Default::default() };
-        let dec = VorbisDecoder::try_new_with_backend(params, &opts, Box::new(Recorder(rec.clone())))?;
+        let dec = VorbisDecoder::try_new_with_backend(params, &opts, Box::new(Recorder(rec.clone(), fused)))?;
         Ok(SeamFrontEnd { dec, rec })
     }
 }
@@ -104,11 +193,29 @@ impl VorbisFrontEnd for SeamFrontEnd {
         if rec.seen != rec.n_channels {
             return decode_error("vorbis: the packet did not reach the synthesis stage for every channel");
         }
+        // (the decoder hands blocks over only if the recorder takes them AND every floor is of type 1: then `floors` is filled)
+        let fused = if rec.floors.is_empty() {
+            None
+        }
+        else {
+            Some(FusedVorbis { floor: rec.floor.clone(), posts: rec.posts.clone(), coupling: rec.coupling.clone() })
+        };
         Ok(ParsedVorbis {
             trim: (packet.trim_start.get() as usize, packet.trim_end.get() as usize),
             long_block: rec.long_block,
             spectra: rec.spectra.clone(),
+            fused,
         })
+    }
+
+    fn floors(&self) -> Vec<ffi::SymaccelVorbisFloor1Cfg> {
+        self.rec.lock().expect("vorbis record poisoned").floors.clone()
+    }
+
+    fn reset(&mut self) {
+        // VorbisDecoder::reset (lib.rs:367-374): Dsp::reset -- the reference's own lapping state, which the recording backend
+        // never reads -- kept in step anyway
+        self.dec.reset();
     }
 }
 
@@ -127,6 +234,9 @@ pub struct VorbisBatch {
     pcm_off: Vec<usize>,      // per packet of the batch: offset of its samples in a channel's PCM; one extra = total
     emits: Vec<bool>,         // per packet: false for the first block after a reset (lib.rs:335-338: silenced when gapless)
     trims: Vec<(usize, usize)>, // per packet of the batch
+    floors: Vec<ffi::SymaccelVorbisFloor1Cfg>, // the fused form: the stream's floor-1 configurations,
+    floor: Vec<u8>,           //   [channel][packet] floor index or SYMACCEL_VORBIS_FLOOR_UNUSED,
+    posts: Vec<u32>,          //   [channel][packet][POSTS]
     buf: AudioBuffer<f32>,
 }
 
@@ -169,6 +279,9 @@ impl BatchCodec for VorbisBatch {
             }
         }
         let (bs0_exp, bs1_exp) = self.front.block_exps();
+        if k > 0 && batch.iter().all(|p| p.fused.is_some()) {
+            return self.transform_fused(batch, lines, samples);
+        }
         // SAFETY: the buffers cover nch chains of `lines` / `samples` / `k` elements (sized for max_batch long blocks).
         check(
             unsafe {
@@ -208,6 +321,7 @@ impl BatchCodec for VorbisBatch {
     }
 
     fn reset_state(&mut self) {
+        self.front.reset();
         // Dsp::reset (dsp.rs:45-56): lapping state empty, overlap zeroed
         self.prev_flag.fill(-1);
         self.overlap.fill(0.0);
@@ -215,6 +329,58 @@ impl BatchCodec for VorbisBatch {
 
     fn clear(&mut self) {
         self.buf.clear();
+    }
+}
+
+impl VorbisBatch {
+    /// lib.rs:250-331 for the whole batch in one call: inverse coupling, floor curves, dot product and synthesis on the device from
+    /// the packet decoder's residue vectors (already packed into `spectra` by `transform`) and posts.
+    fn transform_fused(&mut self, batch: &[ParsedVorbis], lines: usize, samples: usize) -> Result<()> {
+        let k = batch.len();
+        let mut coupling: Vec<u8> = Vec::new();
+        let mut first: Vec<u32> = Vec::with_capacity(k + 1);
+        first.push(0);
+        for (i, p) in batch.iter().enumerate() {
+            let Some(f) = &p.fused else { continue };
+            for c in 0..self.nch {
+                self.floor[c * k + i] = f.floor[c];
+                let dst = (c * k + i) * POSTS;
+                self.posts[dst..dst + POSTS].copy_from_slice(&f.posts[c * POSTS..(c + 1) * POSTS]);
+            }
+            coupling.extend_from_slice(&f.coupling);
+            first.push((coupling.len() / 2) as u32);
+        }
+        let (bs0_exp, bs1_exp) = self.front.block_exps();
+        // SAFETY: residue / flags / floor / posts / pcm cover nch chains of `lines` / k / k / k * POSTS / `samples` elements (sized for
+        // max_batch long blocks), `first` k + 1 entries, `coupling` two bytes per step; null stands for an empty step list.  The
+        // call returns after the PCM and the updated state are back in host memory.
+        check(
+            unsafe {
+                ffi::symaccel_vorbis_decode(
+                    self.ctx.raw(),
+                    bs0_exp,
+                    bs1_exp,
+                    self.spectra.as_slice().as_ptr(),
+                    lines,
+                    self.flags.as_ptr(),
+                    self.floor.as_ptr(),
+                    self.posts.as_ptr(),
+                    POSTS,
+                    self.floors.as_ptr(),
+                    self.floors.len(),
+                    self.nch,
+                    if coupling.is_empty() { std::ptr::null() } else { coupling.as_ptr() },
+                    first.as_ptr(),
+                    self.prev_flag.as_mut_ptr(),
+                    self.overlap.as_mut_ptr(),
+                    self.pcm.as_mut_slice().as_mut_ptr(),
+                    samples,
+                    self.nch,
+                    k,
+                )
+            },
+            self.ctx.raw(),
+        )
     }
 }
 
@@ -248,6 +414,7 @@ impl HipVorbisDecoder {
         let max_batch = max_batch.max(1);
         let (bs0_exp, bs1_exp) = front.block_exps();
         let bs = [1usize << bs0_exp, 1usize << bs1_exp];
+        let floors = front.floors();
         Ok(HipVorbisDecoder {
             params: params.clone(),
             batch: VorbisBatch {
@@ -265,6 +432,9 @@ impl HipVorbisDecoder {
                 pcm_off: Vec::with_capacity(max_batch + 1),
                 emits: Vec::with_capacity(max_batch),
                 trims: Vec::with_capacity(max_batch),
+                floors,
+                floor: vec![0; nch * max_batch],
+                posts: vec![0; nch * max_batch * POSTS],
                 buf: AudioBuffer::new(AudioSpec::new(rate, channels), bs[1] / 2),
             },
             la: Lookahead::new(max_batch),

@@ -437,6 +437,36 @@ int symaccel_vorbis_synth_fy_device(symaccel_ctx *ctx, int bs0_exp, int bs1_exp,
                                     int32_t *d_prev_flag_io, float *d_overlap_io, float *d_pcm, size_t pcm_stride,
                                     size_t n_chains, size_t blocks_per_chain);
 
+/* The Vorbis tail from what the packet decoder produces, HOST memory in and out (lib.rs:250-331: inverse coupling, floor-1 curve
+ * synthesis, dot product, inverse MDCT + windowing + overlap-add).  The channels of a stream are `channels_per_stream` consecutive
+ * chains with equal block flags (one mode per packet, lib.rs:170-178).
+ *   residue[chain][spec_stride]   the decoded residue vectors, packed like the spectra of symaccel_vorbis_synth; all zeros for a
+ *                                 channel the reference marks do-not-decode (lib.rs:196-228)
+ *   floor[chain][block]           index into `floors`, or SYMACCEL_VORBIS_FLOOR_UNUSED: the channel's floor is unused in this packet
+ *                                 (floor.rs:660-668), its curve is all zeros (lib.rs:206-209) -- the spectrum is 0.0 * residue
+ *   posts[chain][block][posts_stride]   the floor1_Y values read from the packet (floor.rs:680-740), each <= 511
+ *                                 (SYMACCEL_ERR_UNSUPPORTED otherwise: symaccel_vorbis_floor1_status_device's domain)
+ *   floors[n_floors]              the floor-1 configurations of the setup header the batch uses (x list, multiplier)
+ *   coupling[][2], coupling_first[n_streams * blocks_per_chain + 1]   the (magnitude, angle) channel pairs of block b of stream s are
+ *                                 coupling[coupling_first[s * blocks + b] .. coupling_first[s * blocks + b + 1]), applied in order
+ *                                 (the mapping of the packet's mode, lib.rs:252-278; channel indices inside the stream)
+ * prev_flag_io / overlap_io / pcm as symaccel_vorbis_synth.  On the device: one pass applies the coupling steps in place (and the
+ * zero floors), the floor curves are rendered as one byte per line (symaccel_vorbis_floor1_y_device, one launch per floor
+ * configuration and block size), and the synthesis kernel multiplies table[y] * residue as it loads the lines
+ * (symaccel_vorbis_synth_fy_device).  Floor-0 streams take symaccel_host_vorbis_floor0 + symaccel_vorbis_synth instead. */
+#define SYMACCEL_VORBIS_FLOOR_UNUSED 255u
+typedef struct symaccel_vorbis_floor1_cfg {
+    uint8_t multiplier; /* floor1_multiplier, 1..4 */
+    uint8_t n_posts;    /* 2..65 */
+    uint8_t pad[2];
+    uint32_t x_list[65]; /* floor1_X_list, in bitstream order */
+} symaccel_vorbis_floor1_cfg; /* 264 bytes */
+int symaccel_vorbis_decode(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *h_residue, size_t spec_stride,
+                           const uint8_t *h_block_flag, const uint8_t *h_floor, const uint32_t *h_posts, size_t posts_stride,
+                           const symaccel_vorbis_floor1_cfg *h_floors, size_t n_floors, size_t channels_per_stream,
+                           const uint8_t *h_coupling, const uint32_t *h_coupling_first, int32_t *h_prev_flag_io, float *h_overlap_io,
+                           float *h_pcm, size_t pcm_stride, size_t n_chains, size_t blocks_per_chain);
+
 /* Inverse coupling (lib.rs:252-278) of `n_pairs` (magnitude, angle) vector pairs of n floats,
  * in place: pair p uses d_residue + mag_index[p]*n and d_residue + ang_index[p]*n.  Pairs are
  * applied in order (coupling steps may chain).  Index arrays are HOST arrays (<= 256 entries). */

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "symaccel_shard_range", "symaccel_scatter_streams", "symaccel_gather_streams", "symaccel_exchange_pipelined", "symaccel_comm_unique_id", "symaccel_comm_init",
     "symaccel_comm_destroy", "symaccel_multi_set_transport", "symaccel_mp3_decode_pipelined",
     "symaccel_mp3_decode_pp_device", "symaccel_mp3_decode_device",
-    "symaccel_aac_joint_stereo_list_device", "symaccel_aac_decode_pipelined",
+    "symaccel_aac_joint_stereo_list_device", "symaccel_aac_decode_pipelined", "symaccel_vorbis_decode",
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
@@ -129,6 +129,7 @@ class Library:
         d.symaccel_vorbis_synth_device.argtypes = [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_vorbis_synth_fr_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_vorbis_synth.argtypes = [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
+        d.symaccel_vorbis_decode.argtypes = [_vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_vorbis_inverse_coupling_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz]
         d.symaccel_vorbis_dot_product_device.argtypes = [_vp, _vp, _vp, _sz]
         d.symaccel_vorbis_deinterleave2_device.argtypes = [_vp, _vp, _vp, _i, _sz, _sz]

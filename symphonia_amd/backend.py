@@ -207,6 +207,7 @@ def mp3_side(block_type, is_mixed, rzero):
     return s
 
 
+VORBIS_FLOOR1_DTYPE = np.dtype([("multiplier", np.uint8), ("n_posts", np.uint8), ("pad", np.uint8, (2,)), ("x_list", np.uint32, (65,))])
 AAC_JS_DTYPE = np.dtype([("num_windows", np.uint8), ("max_sfb", np.uint8), ("pad", np.uint8, (2,)), ("mode", np.uint8, (128,)),
                          ("scale", np.float32, (128,))])
 AAC_TNS_DTYPE = np.dtype([("frame", np.uint32), ("start", np.uint16), ("end", np.uint16), ("order", np.uint8),
@@ -507,6 +508,18 @@ class VorbisDsp:
         else:
             self.ctx._call(d.symaccel_vorbis_synth_fy_device, self.bs0_exp, self.bs1_exp, _ptr(floor_y), _ptr(residue),
                            int(residue.shape[1]), _ptr(block_flag), _ptr(prev_flag), _ptr(overlap), _ptr(pcm), int(pcm_stride), nch, nb)
+        return pcm
+
+    def decode(self, residue, block_flag, floor, posts, floors, channels_per_stream, coupling, coupling_first, prev_flag, overlap,
+               pcm_stride, pcm):
+        """The Vorbis tail HOST to HOST (symaccel_vorbis_decode): residue[chains, spec_stride] f32, block_flag / floor[chains, blocks] u8
+        (floor: index into `floors` or 255 = unused), posts[chains, blocks, posts_stride] u32, floors[n] VORBIS_FLOOR1_DTYPE,
+        coupling[steps, 2] u8 + coupling_first[streams * blocks + 1] u32; prev_flag / overlap are updated in place; numpy arrays."""
+        nch, nb = int(block_flag.shape[0]), int(block_flag.shape[1])
+        self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_decode, self.bs0_exp, self.bs1_exp, _ptr(residue), int(residue.shape[1]),
+                       _ptr(block_flag), _ptr(floor), _ptr(posts), int(posts.shape[2]), _ptr(floors), int(floors.shape[0]),
+                       int(channels_per_stream), _ptr(coupling) if coupling.size else None, _ptr(coupling_first), _ptr(prev_flag),
+                       _ptr(overlap), _ptr(pcm), int(pcm_stride), nch, nb)
         return pcm
 
     # device-pointer helpers (torch tensors, or raw arrays when the library treats host memory as device)

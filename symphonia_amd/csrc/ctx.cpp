@@ -757,6 +757,123 @@ int symaccel_vorbis_synth(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const flo
     return symaccel_sync(ctx);
 }
 
+int symaccel_vorbis_decode(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *h_residue, size_t spec_stride,
+                           const uint8_t *h_block_flag, const uint8_t *h_floor, const uint32_t *h_posts, size_t posts_stride,
+                           const symaccel_vorbis_floor1_cfg *h_floors, size_t n_floors, size_t channels_per_stream,
+                           const uint8_t *h_coupling, const uint32_t *h_coupling_first, int32_t *h_prev_flag_io, float *h_overlap_io,
+                           float *h_pcm, size_t pcm_stride, size_t n_chains, size_t blocks_per_chain) {
+    SYM_TRY(vorbis_check(ctx, bs0_exp, bs1_exp));
+    if (n_chains == 0 || blocks_per_chain == 0) return SYMACCEL_OK;
+    if (!h_residue || !h_block_flag || !h_floor || !h_prev_flag_io || !h_overlap_io || !h_pcm || !h_coupling_first) return SYMACCEL_ERR_INVALID_ARG;
+    const size_t cps = channels_per_stream, nb = blocks_per_chain;
+    if (cps == 0 || cps > 255 || n_chains % cps || n_floors > 255 || (n_floors && (!h_floors || !h_posts))) return SYMACCEL_ERR_INVALID_ARG;
+    if (spec_stride % 4 || pcm_stride % 4) return SYMACCEL_ERR_INVALID_ARG;
+    const size_t n_streams = n_chains / cps;
+    for (size_t f = 0; f < n_floors; ++f)
+        if (h_floors[f].n_posts < 2 || h_floors[f].n_posts > 65 || h_floors[f].n_posts > posts_stride || h_floors[f].multiplier < 1 ||
+            h_floors[f].multiplier > 4)
+            return SYMACCEL_ERR_INVALID_ARG;
+    // Everything that describes the batch is in host memory: check it.  The channels of a stream share their block flags and
+    // their previous flag (one mode per packet, lib.rs:170-178); the packed layout must fit the strides (as symaccel_vorbis_synth);
+    // a floor index names a configuration; coupling steps name two different channels of the stream, in range.
+    std::vector<uint32_t> block_off(n_streams * (nb + 1));
+    for (size_t st = 0; st < n_streams; ++st) {
+        const size_t c0 = st * cps;
+        for (size_t c = c0; c < c0 + cps; ++c) {
+            if (h_prev_flag_io[c] != h_prev_flag_io[c0]) return SYMACCEL_ERR_INVALID_ARG;
+            for (size_t b = 0; b < nb; ++b)
+                if ((h_block_flag[c * nb + b] != 0) != (h_block_flag[c0 * nb + b] != 0)) return SYMACCEL_ERR_INVALID_ARG;
+        }
+        size_t lines = 0, samples = 0;
+        int prev = h_prev_flag_io[c0];
+        for (size_t b = 0; b < nb; ++b) {
+            const int flag = h_block_flag[c0 * nb + b] ? 1 : 0;
+            const size_t n = (size_t)1 << (flag ? bs1_exp : bs0_exp);
+            block_off[st * (nb + 1) + b] = (uint32_t)lines;
+            lines += n / 2;
+            samples += (prev >= 0 ? (((size_t)1 << (prev ? bs1_exp : bs0_exp)) + n) / 4 : n / 2);
+            prev = flag;
+        }
+        block_off[st * (nb + 1) + nb] = (uint32_t)lines;
+        if (lines > spec_stride || samples > pcm_stride || lines > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    }
+    if (n_chains * spec_stride > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;  // (line offsets into the plane are 32-bit)
+    const size_t n_sb = n_streams * nb;
+    if (h_coupling_first[0] != 0) return SYMACCEL_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n_sb; ++i)
+        if (h_coupling_first[i + 1] < h_coupling_first[i]) return SYMACCEL_ERR_INVALID_ARG;
+    const size_t n_steps = h_coupling_first[n_sb];
+    if (n_steps && !h_coupling) return SYMACCEL_ERR_INVALID_ARG;
+    for (size_t s = 0; s < n_steps; ++s)
+        if (h_coupling[2 * s] >= cps || h_coupling[2 * s + 1] >= cps || h_coupling[2 * s] == h_coupling[2 * s + 1]) return SYMACCEL_ERR_INVALID_ARG;
+    // the channel-blocks of every (floor configuration, block size) class: their floor1_Y rows and where their lines are
+    std::vector<std::vector<uint32_t>> ys(n_floors * 2), offs(n_floors * 2);
+    std::vector<uint8_t> kill(n_chains * nb, 0);
+    bool any_kill = false;
+    for (size_t c = 0; c < n_chains; ++c) {
+        const size_t st = c / cps;
+        for (size_t b = 0; b < nb; ++b) {
+            const unsigned f = h_floor[c * nb + b];
+            if (f == SYMACCEL_VORBIS_FLOOR_UNUSED) {
+                kill[c * nb + b] = 1;
+                any_kill = true;
+                continue;
+            }
+            if (f >= n_floors) return SYMACCEL_ERR_INVALID_ARG;
+            const size_t k = 2 * f + (h_block_flag[c * nb + b] ? 1 : 0);
+            const uint32_t *y = h_posts + (c * nb + b) * posts_stride;
+            for (unsigned i = 0; i < h_floors[f].n_posts; ++i) {
+                if (y[i] > 511u) return SYMACCEL_ERR_UNSUPPORTED;  // (symaccel_vorbis_floor1_status_device's domain)
+                ys[k].push_back(y[i]);
+            }
+            offs[k].push_back((uint32_t)(c * spec_stride + block_off[st * (nb + 1) + b]));
+        }
+    }
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    const size_t half1 = (size_t)1 << (bs1_exp - 1);
+    DevBuf res(ctx), bf(ctx), pf(ctx), ov(ctx), pcm(ctx), plane(ctx), d_off(ctx), d_steps(ctx), d_first(ctx), d_kill(ctx);
+    SYM_TRY(res.from_host(h_residue, n_chains * spec_stride * 4));
+    SYM_TRY(bf.from_host(h_block_flag, n_chains * nb));
+    SYM_TRY(pf.from_host(h_prev_flag_io, n_chains * 4));
+    SYM_TRY(ov.from_host(h_overlap_io, n_chains * half1 * 4));
+    SYM_TRY(pcm.alloc(n_chains * pcm_stride * 4));
+    SYM_TRY(plane.alloc(n_chains * spec_stride));
+    SYM_GPU(ctx, hipMemsetAsync(pcm.p, 0, n_chains * pcm_stride * 4, ctx->stream));
+    SYM_GPU(ctx, hipMemsetAsync(plane.p, 0, n_chains * spec_stride, ctx->stream));
+    if (n_steps || any_kill) {  // lib.rs:250-278 + the zero floors of lib.rs:206-209 under lib.rs:289-291
+        SYM_TRY(d_off.from_host(block_off.data(), block_off.size() * 4));
+        SYM_TRY(d_first.from_host(h_coupling_first, (n_sb + 1) * 4));
+        SYM_TRY(d_kill.from_host(kill.data(), kill.size()));
+        if (n_steps) SYM_TRY(d_steps.from_host(h_coupling, n_steps * 2));
+        SYM_TRY(launch_vorbis_prepare(ctx, (float *)res.p, spec_stride, (unsigned)cps, n_streams, nb, (const uint32_t *)d_off.p,
+                                      (const uint8_t *)d_steps.p, (const uint32_t *)d_first.p, (const uint8_t *)d_kill.p));
+    }
+    // floor.rs:568-653 + 776-825 as one byte per line, one launch per class
+    std::vector<DevBuf> keep;
+    keep.reserve(4 * n_floors);
+    for (size_t k = 0; k < 2 * n_floors; ++k) {
+        if (offs[k].empty()) continue;
+        const symaccel_vorbis_floor1_cfg &cfg = h_floors[k / 2];
+        keep.emplace_back(ctx);
+        DevBuf &dy = keep.back();
+        SYM_TRY(dy.from_host(ys[k].data(), ys[k].size() * 4));
+        keep.emplace_back(ctx);
+        DevBuf &dof = keep.back();
+        SYM_TRY(dof.from_host(offs[k].data(), offs[k].size() * 4));
+        const uint32_t n2 = (uint32_t)1 << ((k & 1 ? bs1_exp : bs0_exp) - 1);
+        SYM_TRY(symaccel_vorbis_floor1_y_device(ctx, cfg.x_list, cfg.n_posts, cfg.multiplier, (const uint32_t *)dy.p, n2,
+                                                (const uint32_t *)dof.p, (uint8_t *)plane.p, offs[k].size()));
+    }
+    // lib.rs:282-292 (one rounded multiply per line, in the load path) + dsp.rs:68-126
+    SYM_TRY(symaccel_vorbis_synth_fy_device(ctx, bs0_exp, bs1_exp, (const uint8_t *)plane.p, (const float *)res.p, spec_stride,
+                                            (const uint8_t *)bf.p, (int32_t *)pf.p, (float *)ov.p, (float *)pcm.p, pcm_stride, n_chains, nb));
+    SYM_TRY(pcm.to_host(h_pcm, n_chains * pcm_stride * 4));
+    SYM_TRY(ov.to_host(h_overlap_io, n_chains * half1 * 4));
+    SYM_TRY(pf.to_host(h_prev_flag_io, n_chains * 4));
+    return symaccel_sync(ctx);
+}
+
 int symaccel_vorbis_inverse_coupling_device(symaccel_ctx *ctx, float *d_residue, size_t n, const uint32_t *mag_index,
                                             const uint32_t *ang_index, size_t n_pairs) {
     if (!ctx || n_pairs > 256) return SYMACCEL_ERR_INVALID_ARG;

@@ -236,6 +236,9 @@ int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *
                         const uint8_t *d_block_flag, const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in,
                         float *d_overlap_out, float *d_pcm, size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg, int floor_mode);
 int launch_vorbis_coupling(symaccel_ctx *ctx, float *d_mag, float *d_ang, size_t n);
+int launch_vorbis_prepare(symaccel_ctx *ctx, float *d_residue, size_t spec_stride, unsigned channels_per_stream, size_t n_streams,
+                          size_t blocks, const uint32_t *d_block_off, const uint8_t *d_steps, const uint32_t *d_step_first,
+                          const uint8_t *d_kill);
 int launch_vorbis_dot(symaccel_ctx *ctx, float *d_floor, const float *d_residue, size_t total);
 int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d_planar, int n_ch, size_t n2,
                                size_t count);

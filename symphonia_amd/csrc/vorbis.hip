@@ -273,6 +273,53 @@ __global__ __launch_bounds__(vorbis_threads<MAXBS>()) void vorbis_synth_kernel(
 
 // ---- streaming helpers ----------------------------------------------------------------------
 
+// What stands between the residue decoder and the dot product for a whole batch in the packed layout, in place (lib.rs:250-292):
+// the inverse coupling steps of every block in their order (steps may chain, lib.rs:252), then -- for the channels whose floor is
+// unused but whose residue was decoded because a coupling partner's floor is in use (lib.rs:215-228) -- the product with the
+// all-zero floor, `0.0 * r` (lib.rs:289-291: the sign of the zero, and a NaN from an infinite residue, are the reference's).
+// A workgroup per (stream, block): the channels of a stream share the block flags, so block b's lines sit at the same offset of
+// every channel's row.  block_off[stream][blocks + 1] in lines; steps[][2] = (magnitude, angle) channel of the stream;
+// step_first[stream * blocks + block] .. [+ 1) = the block's steps; kill[chain][block] != 0: times +0.0.
+__global__ __launch_bounds__(256) void vorbis_prepare_kernel(float *__restrict__ residue, size_t spec_stride, unsigned cps, unsigned blocks,
+                                                             const uint32_t *__restrict__ block_off, const uint8_t *__restrict__ steps,
+                                                             const uint32_t *__restrict__ step_first, const uint8_t *__restrict__ kill) {
+    const unsigned sb = blockIdx.x, stream = sb / blocks, b = sb % blocks;
+    const uint32_t off = block_off[(size_t)stream * (blocks + 1) + b], n2 = block_off[(size_t)stream * (blocks + 1) + b + 1] - off;
+    const uint32_t s0 = step_first[sb], s1 = step_first[sb + 1];
+    float *base = residue + (size_t)stream * cps * spec_stride + off;
+    for (uint32_t i = threadIdx.x; i < n2; i += 256) {
+        for (uint32_t s = s0; s < s1; ++s) {
+            float *mp = base + (size_t)steps[2 * s] * spec_stride + i, *ap = base + (size_t)steps[2 * s + 1] * spec_stride + i;
+            const float m = *mp, a = *ap;
+            float nm, na;
+            if (m > 0.0f) {
+                if (a > 0.0f) {
+                    nm = m;
+                    na = m - a;
+                } else {
+                    nm = m + a;
+                    na = m;
+                }
+            } else {
+                if (a > 0.0f) {
+                    nm = m;
+                    na = m + a;
+                } else {
+                    nm = m - a;
+                    na = m;
+                }
+            }
+            *mp = nm;
+            *ap = na;
+        }
+        for (unsigned c = 0; c < cps; ++c)
+            if (kill[((size_t)stream * cps + c) * blocks + b]) {
+                float *p = base + (size_t)c * spec_stride + i;
+                *p = 0.0f * *p;
+            }
+    }
+}
+
 // lib.rs:265-277
 __global__ void vorbis_coupling_kernel(float *__restrict__ mag, float *__restrict__ ang, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -691,6 +738,18 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
                            d_residue, spec_stride, d_block_flag, d_prev_in, d_prev_out, d_overlap_in, d_overlap_out, d_pcm,
                            pcm_stride, (const uint32_t *)offs, nb, seg, (unsigned)segs);
     }
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_vorbis_prepare(symaccel_ctx *ctx, float *d_residue, size_t spec_stride, unsigned channels_per_stream, size_t n_streams,
+                          size_t blocks, const uint32_t *d_block_off, const uint8_t *d_steps, const uint32_t *d_step_first,
+                          const uint8_t *d_kill) {
+    const size_t grid = n_streams * blocks;
+    if (grid == 0) return SYMACCEL_OK;
+    if (grid > 0x7fffffffu || blocks > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(vorbis_prepare_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, d_residue, spec_stride, channels_per_stream,
+                       (unsigned)blocks, d_block_off, d_steps, d_step_first, d_kill);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

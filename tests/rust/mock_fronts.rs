@@ -67,6 +67,7 @@ pub struct ScriptedVorbisFront {
     pub bs1_exp: i32,
     pub script: Vec<ParsedVorbis>,
     pub parses: usize,
+    pub resets: usize,
 }
 
 impl VorbisFrontEnd for ScriptedVorbisFront {
@@ -80,7 +81,13 @@ impl VorbisFrontEnd for ScriptedVorbisFront {
         let i = script_index(packet)?;
         self.parses += 1;
         let p = &self.script[i];
-        Ok(ParsedVorbis { trim: p.trim, long_block: p.long_block, spectra: p.spectra.clone() })
+        Ok(ParsedVorbis { trim: p.trim, long_block: p.long_block, spectra: p.spectra.clone(), fused: None })
+    }
+    fn floors(&self) -> Vec<SymaccelVorbisFloor1Cfg> {
+        Vec::new()
+    }
+    fn reset(&mut self) {
+        self.resets += 1;
     }
 }
 

@@ -231,9 +231,9 @@ def test_the_shim_vorbis_decoder_gives_the_reference_decoders_pcm(make_dll, name
     h = harness(make_dll, "vorbis.rs")
     h.it.load_file(Path(__file__).resolve().parent / "rust" / "mocks.rs")
     so = np.concatenate([[0], np.cumsum(n2)])
-    script = I.Arr([I.Struct("ParsedVorbis", {"trim": (usize(0), usize(0)), "long_block": bool(flags[b]), "spectra": f32_vec(spectra[:, so[b]:so[b + 1]])})
+    script = I.Arr([I.Struct("ParsedVorbis", {"trim": (usize(0), usize(0)), "long_block": bool(flags[b]), "spectra": f32_vec(spectra[:, so[b]:so[b + 1]]), "fused": I.NONE})
                     for b in range(nb)], True)
-    front = I.Struct("ScriptedVorbisFront", {"nch": usize(nch), "bs0_exp": I.Int(b0, "i32"), "bs1_exp": I.Int(b1, "i32"), "script": script, "parses": usize(0)})
+    front = I.Struct("ScriptedVorbisFront", {"nch": usize(nch), "bs0_exp": I.Int(b0, "i32"), "bs1_exp": I.Int(b1, "i32"), "script": script, "parses": usize(0), "resets": usize(0)})
     r = h.it.call("HipVorbisDecoder::try_new", h.params("CODEC_ID_VORBIS", 44100, nch), h.opts(), front, usize(max_batch))
     assert r.variant == "Ok", r
     dec = r.f["0"]

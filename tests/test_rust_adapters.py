@@ -186,9 +186,9 @@ def test_vorbis_adapter_publishes_the_fixture_pcm(make_dll, pair, max_batch):
     nch, nb = spectra.shape[0], flags.size
     so, po = oracle.vorbis_layout(b0, b1, np.tile(flags, (nch, 1)), np.full(nch, prev0))
     script = I.Arr([I.Struct("ParsedVorbis", {"trim": (usize(0), usize(0)), "long_block": bool(flags[b]),
-                                               "spectra": f32_vec(spectra[:, so[0, b]:so[0, b + 1]])}) for b in range(nb)], True)
+                                               "spectra": f32_vec(spectra[:, so[0, b]:so[0, b + 1]]), "fused": I.NONE}) for b in range(nb)], True)
     front = I.Struct("ScriptedVorbisFront", {"nch": usize(nch), "bs0_exp": I.Int(b0, "i32"), "bs1_exp": I.Int(b1, "i32"), "script": script,
-                                              "parses": usize(0)})
+                                              "parses": usize(0), "resets": usize(0)})
     r = h.it.call("HipVorbisDecoder::try_new", h.params("CODEC_ID_VORBIS", 44100, nch), h.opts(gapless=True), front, usize(max_batch))
     assert r.variant == "Ok", r
     dec = r.f["0"]

@@ -137,7 +137,11 @@ def test_the_accelerated_decoder_equals_the_reference_on_packet_bytes(trees, see
         st, got = h.decode("HipVorbisDecoder", dec, h.packet(pk, i))
         assert st == st_r == "ok"
         assert got.shape == want.shape and np.array_equal(bits(got), bits(want)), (i, got.shape, want.shape)
-    assert h.bridge.calls.count("symaccel_vorbis_synth") == n
+    # no look-ahead reader: batches of one, each through the FUSED entry point (residue vectors + floor posts + coupling steps in,
+    # PCM out) -- the reference's inverse coupling, floor synthesis and dot product did not run
+    assert h.bridge.calls.count("symaccel_vorbis_decode") == n and h.bridge.calls.count("symaccel_vorbis_synth") == 0
+    fused = [a for name, a in h.bridge.scalars if name == "symaccel_vorbis_decode"]
+    assert all(a["n_floors"] >= 1 and a["channels_per_stream"] == nch for a in fused), fused
 
 
 def test_damaged_packets_fail_like_the_reference_and_the_stream_goes_on(trees):
@@ -184,10 +188,11 @@ def test_look_ahead_batches_and_reset(trees):
             out.append(h.decode("HipVorbisDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p)))
         return out
 
-    n0 = h.bridge.calls.count("symaccel_vorbis_synth")
+    n0 = h.bridge.calls.count("symaccel_vorbis_decode")
     for i, (st, got) in enumerate(run(0, n)):
         assert st == "ok" and got.shape == want[i].shape and np.array_equal(bits(got), bits(want[i])), i
-    assert h.bridge.calls.count("symaccel_vorbis_synth") - n0 == -(-n // batch)  # the overlap halves carry across the batches
+    assert h.bridge.calls.count("symaccel_vorbis_decode") - n0 == -(-n // batch)  # the overlap halves carry across the batches
+    assert h.bridge.calls.count("symaccel_vorbis_synth") == 0
     # seek back + reset: the next packet primes the overlap again and gives no samples (dsp.rs:13-19, lib.rs:333-336)
     h.it.call_method("LookaheadReader", "seek", reader, I.Int(0, "i64"), usize(0))
     h.it.call_method("HipVorbisDecoder", "reset", dec)
