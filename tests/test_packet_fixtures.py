@@ -312,3 +312,119 @@ def test_the_shim_alac_decoder_gives_the_reference_decoders_pcm(make_dll, name, 
         st, got = h.decode("HipAlacDecoder", dec, h.it.call_method("Packet", "as_packet_ref", p))
         assert st == "ok" and np.array_equal(got, pcm[t_]), (name, t_)
     assert "symaccel_alac_predict" in h.bridge.calls
+
+
+# ------------------------------------------------------------------------------------------------ the second-generation seams
+# <name>_fused.npz: the same packets, the same reference `pcm`, but what the reference's decoders hand over ONE STAGE EARLIER -- the
+# entropy decoder's integers + side records (MP3), the spectrum decoder's coefficients + joint-stereo descriptors + TNS filters (AAC),
+# residue vectors + floor posts + coupling steps (Vorbis).  The host-pointer entry points the shim decoders call
+# (symaccel_mp3_decode_pipelined, symaccel_aac_decode_pipelined, symaccel_vorbis_decode) must give `pcm` back, bit for bit.
+
+def lib_ctx(r):
+    return r.ctx
+
+
+def check_aac_fused(ctx, name, chunk):
+    from symphonia_amd import AAC_JS_DTYPE, AAC_TNS_DTYPE, AacSpectralTools
+    f = np.load(PACKETS / (name + "_fused.npz"))
+    coded, side, pcm = f["coded"], f["side"], f["pcm"]           # [packet][channel][1024], [packet][channel], [packet][channel][1024]
+    npk, nch = coded.shape[:2]
+    chains = np.ascontiguousarray(coded.transpose(1, 0, 2))
+    sides = np.ascontiguousarray(side.T)
+    lefts = sorted(set(int(x) for x in f["joint_where"][:, 1]))
+    pairs = np.array([[l, l + 1] for l in lefts], np.int32).reshape(-1, 2)
+    desc = np.zeros((len(lefts), npk), AAC_JS_DTYPE)
+    desc["num_windows"] = 1
+    for (pk, left), d in zip(f["joint_where"], f["joint_desc"].view(AAC_JS_DTYPE).reshape(-1)):
+        desc[lefts.index(int(left)), pk] = d
+    tns = f["tns"].view(AAC_TNS_DTYPE).reshape(-1).copy()
+    tns["frame"] = f["tns_where"][:, 1].astype(np.uint32) * npk + f["tns_where"][:, 0].astype(np.uint32)  # [channel][packet]
+    swb_long = f["swb_long"] if f["swb_long"].size else np.array([0, 1024], np.uint16)
+    swb_short = f["swb_short"] if f["swb_short"].size else np.array([0, 128], np.uint16)
+    got, delay = np.zeros_like(chains), np.zeros((nch, 1024), np.float32)
+    AacSpectralTools(ctx, swb_long, swb_short).decode(chains, sides, delay, pairs if len(lefts) else None, desc if len(lefts) else None,
+                                                      tns if len(tns) else None, got, chunk_frames=chunk)
+    want = pcm.transpose(1, 0, 2)
+    assert np.array_equal(bits(got), bits(want)), (name, chunk, float(np.abs(got - want).max()))
+    return len(lefts), len(tns)
+
+
+def check_mp3_fused(ctx, name, chunk):
+    f = np.load(PACKETS / (name + "_fused.npz"))
+    quant, pcm, sr_idx = f["quant"], f["pcm"], int(f["sample_rate_idx"][0])   # [packet][granule][channel][576]
+    npk, ngr, nch = quant.shape[:3]
+    to_chain = lambda a: np.ascontiguousarray(a.transpose(2, 0, 1, *range(3, a.ndim)).reshape((nch, npk * ngr) + a.shape[3:]))  # noqa: E731
+    q, rq = to_chain(quant), to_chain(f["rq"])
+    st = np.ascontiguousarray(f["st"].reshape(1, npk * ngr, 48))
+    s = to_chain(f["side"])
+    side = np.zeros((nch, npk * ngr), MP3_SIDE)
+    side["block_type"], side["is_mixed"], side["rzero"] = s[..., 0], s[..., 1], s[..., 2]
+    want = pcm.reshape(npk, nch, ngr, 576).transpose(1, 0, 2, 3).reshape(nch, npk * ngr, 576)
+    ov, vv, vf = np.zeros((nch, 576), np.float32), np.zeros((nch, 1024), np.float32), np.zeros(nch, np.int32)
+    got = np.zeros((nch, npk * ngr, 576), np.float32)
+    pairs = np.array([[0, 1]], np.int32)
+    ctx._call(ctx.lib.dll.symaccel_mp3_decode_pipelined, q.ctypes.data, rq.ctypes.data, pairs.ctypes.data if nch == 2 else None,
+              st.ctypes.data if nch == 2 else None, 1 if nch == 2 else 0, side.ctypes.data, sr_idx, ov.ctypes.data, vv.ctypes.data, vf.ctypes.data,
+              got.ctypes.data, nch, npk * ngr, chunk)
+    assert np.array_equal(bits(got), bits(want)), (name, chunk, float(np.abs(got - want).max()))
+
+
+def check_vorbis_fused(ctx, name):
+    from symphonia_amd import VORBIS_FLOOR1_DTYPE, VorbisDsp
+    f = np.load(PACKETS / (name + "_fused.npz"))
+    flags, residue, pcm = f["long_block"], f["residue"], f["pcm"]
+    b0, b1 = (int(x) for x in f["block_exps"])
+    nch, nb = residue.shape[0], len(flags)
+    dsp = VorbisDsp(ctx, b0, b1)
+    bf = np.tile(flags.astype(np.uint8), (nch, 1))
+    so, po = dsp.layout(bf, np.full(nch, -1))
+    spec_stride, pcm_stride = (int(so[0, -1]) + 3) & ~3, (int(po[0, -1]) + 3) & ~3
+    res = np.zeros((nch, spec_stride), np.float32)
+    res[:, :residue.shape[1]] = residue
+    floor = np.ascontiguousarray(f["floor"].T)                     # [channel][packet]
+    posts = np.ascontiguousarray(f["posts"].transpose(1, 0, 2))    # [channel][packet][65]
+    floors = np.ascontiguousarray(f["floors"]).view(VORBIS_FLOOR1_DTYPE).reshape(-1)
+    prev, ov = np.full(nch, -1, np.int32), np.zeros((nch, (1 << b1) >> 1), np.float32)
+    got = np.zeros((nch, pcm_stride), np.float32)
+    dsp.decode(res, bf, floor, posts, floors, nch, np.ascontiguousarray(f["coupling"]), np.ascontiguousarray(f["coupling_first"]), prev, ov,
+               pcm_stride, got)
+    # (packet 0 primes the overlap: check_vorbis_c_abi)
+    assert np.array_equal(bits(got[:, po[0, 1]:po[0, -1]]), bits(pcm)), name
+    return int(f["coupling_first"][-1]), int((floor == 255).sum())
+
+
+@pytest.mark.parametrize("name", AAC)
+def test_emulated_fused_entry_point_gives_the_reference_aac_decoders_pcm(emu_ctx, name):  # noqa: F811
+    for chunk in (0, 3):
+        n_pairs, n_tns = check_aac_fused(emu_ctx, name, chunk)
+    assert n_tns >= 1 and (n_pairs >= 1 or name == "aac_mono")  # (the fixtures exercise what the entry point is for)
+
+
+@pytest.mark.parametrize("name", MP3)
+def test_emulated_fused_entry_point_gives_the_reference_mp3_decoders_pcm(emu_ctx, name):  # noqa: F811
+    for chunk in (0, 4):
+        check_mp3_fused(emu_ctx, name, chunk)
+
+
+@pytest.mark.parametrize("name", VORBIS)
+def test_emulated_fused_entry_point_gives_the_reference_vorbis_decoders_pcm(emu_ctx, name):  # noqa: F811
+    steps, unused = check_vorbis_fused(emu_ctx, name)
+    assert steps >= 1 and unused >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", AAC + MP3 + VORBIS)
+def test_gpu_fused_entry_points_give_the_reference_decoders_pcm(name):
+    from symphonia_amd import Context
+    ctx = Context(0)
+    try:
+        if name in AAC:
+            for chunk in (0, 3):
+                check_aac_fused(ctx, name, chunk)
+        elif name in MP3:
+            for chunk in (0, 4):
+                check_mp3_fused(ctx, name, chunk)
+        else:
+            check_vorbis_fused(ctx, name)
+    finally:
+        ctx.close()

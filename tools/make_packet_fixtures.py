@@ -36,7 +36,7 @@ def aac(name, seed, n_packets, nch, tree):
     ref = Harness(None, reference=True, aac_tree=REF / A.CRATE / "src")
     ref_dec = A.cpu_decoder(ref, nch)
     h, _ = A.hip_decoder(tree, nch)  # (loads the shim; the decoder itself is not used: the front end is driven directly)
-    front = h.it.call("aac_front_end", h.params("CODEC_ID_AAC", 44100, nch), h.opts())
+    front = h.it.call("SeamFrontEnd::try_new_at", h.params("CODEC_ID_AAC", 44100, nch), h.opts(), False)  # the first-generation seam
     assert front.variant == "Ok", front
     front = h.f32_buffers(front.f["0"])
     pcm, coeffs, side = [], [], []
@@ -64,7 +64,7 @@ def mp3(name, seed, n, mode, mpeg1, sr_code, tree):
     ref = Harness(None, reference=True, mp3_tree=REF / M.CRATE / "src")
     ref_dec = M.cpu_decoder(ref, s)
     h = M.shim(tree)
-    front = h.it.call("mpa_front_end", h.params("CODEC_ID_MP3", s.rate, s.nch), h.opts())
+    front = h.it.call("SeamFrontEnd::try_new_at", h.params("CODEC_ID_MP3", s.rate, s.nch), h.opts(), False)  # the first-generation seam
     assert front.variant == "Ok", front
     front = front.f["0"]
     pcm, xr, side = [], [], []
@@ -95,7 +95,7 @@ def vorbis(name, args, tree):
     ref = Harness(None, reference=True, vorbis_tree=REF / V.CRATE / "src")
     ref_dec = V.cpu_decoder(ref, s)
     h, _ = V.hip_decoder(tree, s, max_batch=1)
-    front = h.it.call("vorbis_front_end", h.params("CODEC_ID_VORBIS", 44100, s.nch, extra=s.extra_data()), h.opts())
+    front = h.it.call("SeamFrontEnd::try_new_at", h.params("CODEC_ID_VORBIS", 44100, s.nch, extra=s.extra_data()), h.opts(), False)  # first generation
     assert front.variant == "Ok", front
     front = front.f["0"]
     flags, spectra, pcm, counts = [], [], [], []
@@ -119,6 +119,101 @@ def vorbis(name, args, tree):
 
 def ints(arr):
     return np.array([x.v for x in arr.a], np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The SECOND-generation seams (the decoders hand over what the entropy / spectrum / packet decoder produced; requantize + stereo,
+# joint stereo + TNS, coupling + floor + dot product run on the device): <name>_fused.npz beside <name>.npz, same packets, same `pcm`.
+
+def records(values, dtype):
+    """interpreter structs (#[repr(C)] records of bindings/rust/symaccel_sys.rs) -> a numpy structured array of the ABI's layout"""
+    out = np.zeros(len(values), dtype)
+    for i, v in enumerate(values):
+        v = I.deref(v)
+        for name in dtype.names:
+            f = I.deref(v.f[name])
+            if dtype[name].shape:
+                out[i][name] = [x.v if isinstance(x, I.Int) else np.float32(x) for x in f.a]
+            else:
+                out[i][name] = f.v if isinstance(f, I.Int) else np.float32(f)
+    return out
+
+
+def aac_fused(name, seed, n_packets, nch, tree):
+    from symphonia_amd import AAC_JS_DTYPE, AAC_TNS_DTYPE
+    packets = [p for p, _ in A.stream(seed, n_packets, nch)]
+    h, _ = A.hip_decoder(tree, nch)
+    front = h.it.call("aac_front_end", h.params("CODEC_ID_AAC", 44100, nch), h.opts())
+    front = h.f32_buffers(front.f["0"])
+    coded, side, joint, tns, swb = [], [], [], [], {"long": np.zeros(0, np.uint16), "short": np.zeros(0, np.uint16)}
+    for i, pk in enumerate(packets):
+        parsed = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(pk, i * 1024)).f["0"]
+        fused = parsed.f["fused"].f["0"]
+        coded.append(np.array([np.float32(x) for x in parsed.f["coeffs"].a], np.float32).reshape(nch, 1024))
+        side.append(np.array([x.v for x in parsed.f["side"].a], np.uint8))
+        for left, d in (I.deref(e) for e in fused.f["joint"].a):
+            joint.append((i, I.deref(left).v, records([d], AAC_JS_DTYPE)[0]))
+        t = records(fused.f["tns"].a, AAC_TNS_DTYPE)
+        tns.append(np.stack([np.full(len(t), i, np.uint32), t["frame"]], axis=1) if len(t) else np.zeros((0, 2), np.uint32))
+        tns.append(t)
+        for key in ("long", "short"):
+            tab = np.array([x.v for x in fused.f["swb_" + key].a], np.uint16)
+            if tab.size:
+                swb[key] = tab
+    where = np.concatenate(tns[0::2])
+    filters = np.concatenate(tns[1::2])
+    ref = np.load(OUT / (name + ".npz"))
+    np.savez_compressed(OUT / (name + "_fused.npz"), coded=np.stack(coded), side=np.stack(side), pcm=ref["pcm"],
+                        joint_where=np.array([(i, left) for i, left, _ in joint], np.int32).reshape(-1, 2),
+                        joint_desc=np.array([d for _, _, d in joint], AAC_JS_DTYPE).view(np.uint8).reshape(-1, 644),
+                        tns_where=where.astype(np.int32), tns=filters.view(np.uint8).reshape(-1, 92), swb_long=swb["long"], swb_short=swb["short"])
+    print(name + "_fused", "packets", len(packets), "jointly coded pairs", len(joint), "tns filters", len(filters))
+
+
+def mp3_fused(name, seed, n, mode, mpeg1, sr_code, tree):
+    from symphonia_amd.backend import MP3_REQUANT_DTYPE, MP3_STEREO_DTYPE
+    s, packets = M.stream(seed, n, mode, mpeg1, sr_code)
+    per_frame = 1152 if mpeg1 else 576
+    h = M.shim(tree)
+    front = h.it.call("mpa_front_end", h.params("CODEC_ID_MP3", s.rate, s.nch), h.opts()).f["0"]
+    quant, rq, st, side = [], [], [], []
+    for i, (pk, _) in enumerate(packets):
+        parsed = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(pk, i * per_frame)).f["0"]
+        fused = parsed.f["fused"].f["0"]
+        ngr = parsed.f["n_granules"].v
+        quant.append(np.array([x.v for x in fused.f["quant"].a], np.int16).reshape(ngr, s.nch, 576))
+        rq.append(records(fused.f["rq"].a, MP3_REQUANT_DTYPE).reshape(ngr, s.nch))
+        st.append(records(fused.f["st"].a, MP3_STEREO_DTYPE).reshape(ngr))
+        side.append(np.array([[q.f["block_type"].v, q.f["is_mixed"].v, q.f["rzero"].v] for q in parsed.f["side"].a], np.int32).reshape(ngr, s.nch, 3))
+    ref = np.load(OUT / (name + ".npz"))
+    np.savez_compressed(OUT / (name + "_fused.npz"), quant=np.stack(quant), rq=np.stack(rq).view(np.uint8).reshape(len(packets), -1, s.nch, 52),
+                        st=np.stack(st).view(np.uint8).reshape(len(packets), -1, 48), side=np.stack(side), pcm=ref["pcm"],
+                        sample_rate_idx=ref["sample_rate_idx"])
+    print(name + "_fused", "packets", len(packets), "joint-stereo granules", int((np.stack(st)["flags"] & 3 != 0).sum()))
+
+
+def vorbis_fused(name, args, tree):
+    from symphonia_amd import VORBIS_FLOOR1_DTYPE
+    s, packets = V.stream(*args)
+    h, _ = V.hip_decoder(tree, s, max_batch=1)
+    front = h.it.call("vorbis_front_end", h.params("CODEC_ID_VORBIS", 44100, s.nch, extra=s.extra_data()), h.opts()).f["0"]
+    floors = records(h.it.call_method("SeamFrontEnd", "floors", front).a, VORBIS_FLOOR1_DTYPE)
+    flags, residue, floor, posts, coupling, first = [], [], [], [], [], [0]
+    for pk, _ in packets:
+        parsed = h.it.call_method("SeamFrontEnd", "parse", front, h.packet(pk, 0)).f["0"]
+        fused = parsed.f["fused"].f["0"]
+        flags.append(int(bool(parsed.f["long_block"])))
+        residue.append(np.array([np.float32(x) for x in parsed.f["spectra"].a], np.float32).reshape(s.nch, -1))
+        floor.append(np.array([x.v for x in fused.f["floor"].a], np.uint8))
+        posts.append(np.array([x.v for x in fused.f["posts"].a], np.uint32).reshape(s.nch, 65))
+        coupling.extend(x.v for x in fused.f["coupling"].a)
+        first.append(len(coupling) // 2)
+    ref = np.load(OUT / (name + ".npz"))
+    np.savez_compressed(OUT / (name + "_fused.npz"), long_block=np.array(flags, np.uint8), residue=np.concatenate(residue, axis=1),
+                        floor=np.stack(floor), posts=np.stack(posts), coupling=np.array(coupling, np.uint8).reshape(-1, 2),
+                        coupling_first=np.array(first, np.uint32), floors=floors.view(np.uint8).reshape(-1, 264), pcm=ref["pcm"],
+                        frames=ref["frames"], block_exps=ref["block_exps"])
+    print(name + "_fused", "packets", len(packets), "coupling steps", len(coupling) // 2, "unused floors", int((np.stack(floor) == 255).sum()))
 
 
 def flac(name, seed, n_frames, nch, bps, blocksize):
@@ -191,11 +286,23 @@ def alac(name, args):
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
-    which = set(sys.argv[1:]) or {"aac", "mp3", "vorbis", "flac", "alac"}
+    which = set(sys.argv[1:]) or {"aac", "mp3", "vorbis", "flac", "alac", "aac_fused", "mp3_fused", "vorbis_fused"}
     if "aac" in which:
         tree = patched_tree((A.CRATE,)) / A.CRATE / "src"
         for name, (seed, n, nch) in AAC_STREAMS.items():
             aac(name, seed, n, nch, tree)
+    if "aac_fused" in which:
+        tree = patched_tree((A.CRATE,)) / A.CRATE / "src"
+        for name, (seed, n, nch) in AAC_STREAMS.items():
+            aac_fused(name, seed, n, nch, tree)
+    if "mp3_fused" in which:
+        tree = patched_tree((M.CRATE,)) / M.CRATE / "src"
+        for name, args in MP3_STREAMS.items():
+            mp3_fused(name, *args, tree)
+    if "vorbis_fused" in which:
+        tree = patched_tree((V.CRATE,)) / V.CRATE / "src"
+        for name, args in VORBIS_STREAMS.items():
+            vorbis_fused(name, args, tree)
     if "mp3" in which:
         tree = patched_tree((M.CRATE,)) / M.CRATE / "src"
         for name, args in MP3_STREAMS.items():

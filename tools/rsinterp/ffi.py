@@ -198,6 +198,8 @@ class Bridge:
             return 0
         if isinstance(v, (bool, np.bool_)):
             return int(v)
+        if isinstance(v, I.ULit):  # an untyped float literal that never met a typed operand (`vec.resize(n, 0.0)`): the array gives the type
+            return v.resolve('f64' if dt == np.float64 else 'f32')
         return v
 
     def to_np_seq(self, v, dt, shape=None):
