@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SYMACCEL_ABI_VERSION 5 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device, vorbis floor_y; 5: aac_decode_pipelined, aac_joint_stereo_list, vorbis_decode */
+#define SYMACCEL_ABI_VERSION 6 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device, vorbis floor_y; 5: aac_decode_pipelined, aac_joint_stereo_list, vorbis_decode; 6: batcher */
 
 typedef enum symaccel_status {
     SYMACCEL_OK = 0,
@@ -605,6 +605,73 @@ int symaccel_alac_mid_side_device(symaccel_ctx *ctx, const int32_t *d_weight, co
                                   int32_t *d_ch0, int32_t *d_ch1, size_t n_pairs, size_t blocksize);
 int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uint8_t *h_shift, int32_t *h_ch0,
                            int32_t *h_ch1, size_t n_pairs, size_t blocksize);
+
+/* ------------------------------------------------------------------ cross-stream batcher (csrc/batcher.cpp)
+ * AudioDecoder::decode_ref (symphonia-core/src/codecs/audio.rs:279-297) sees one packet of one track and the registry builds
+ * every decoder from (params, opts) alone (codecs/registry.rs:330-341): a decoder cannot see its siblings, so N decoders
+ * batching their own look-ahead are N small launches and N PCIe round trips.  The batcher is the coalescing point below the
+ * trait: decoders of one process share it, SUBMIT their batches and come back for the results; whatever is pending when
+ * somebody needs a result -- or once `flush_bytes` of input have piled up -- goes to the device as ONE batch per
+ * (kind, param, units_per_chain) group, the chains of all submissions side by side in the chain-major layout of the entry
+ * points above.  Results are bit-identical to the per-stream calls (chains are independent).
+ *
+ * A submission has the planes of the entry point its kind names, all chain-major over the submission's own chains:
+ *   SYMACCEL_BATCH_AAC_SYNTH   symaccel_aac_synth:  in = { coeffs[chain][unit][1024] f32, side[chain][unit] u8 };
+ *                              state = { delay[chain][1024] }; out = pcm[chain][unit][1024]; param ignored
+ *   SYMACCEL_BATCH_MP3_SYNTH   symaccel_mp3_synth:  in = { xr[chain][unit][576] f32, side[chain][unit] (symaccel_mp3_side) };
+ *                              state = { overlap[chain][576], vvec[chain][1024], vfront[chain] i32 }; out = pcm[chain][unit][576];
+ *                              param = sample_rate_idx
+ *   SYMACCEL_BATCH_MP3_DECODE  symaccel_mp3_decode_pipelined for ONE stream (n_chains = 1, or 2 = one channel pair):
+ *                              in = { quant[chain][unit][576] i16, rq_desc[chain][unit], side[chain][unit], st_desc[unit] (one row
+ *                              per SUBMISSION; ignored for n_chains = 1) }; state / out / param as MP3_SYNTH
+ * `units_per_chain` = frames (AAC) / granules (MP3) per chain.  Two forms:
+ *   zero-copy:  reserve() hands out a slot of page-locked staging memory (the front end writes its output straight into the DMA
+ *               source), commit() says it is filled, wait() blocks until slot.out / slot.state hold the PCM and the state AFTER
+ *               the batch, release() gives the slot back.  Commit a reservation before waiting for anything on the same thread.
+ *   copy:       submit() = reserve + memcpy + commit from caller memory; collect() = wait + memcpy into the `state_io` / `out`
+ *               pointers given to submit() + release.  The `in` planes are free again when submit() returns; `state_io` and `out`
+ *               must stay valid until collect().
+ * A stream submits batch n + 1 only after batch n was collected (the state it starts from).  Thread-safe; the context is driven
+ * through the batcher only while one exists.  A failed launch fails every ticket of its group with the same status. */
+#define SYMACCEL_BATCH_AAC_SYNTH 1
+#define SYMACCEL_BATCH_MP3_SYNTH 2
+#define SYMACCEL_BATCH_MP3_DECODE 3
+typedef struct symaccel_batcher symaccel_batcher;
+typedef struct symaccel_batch_slot {
+    void *input[4];
+    void *state[3];
+    void *out;
+    size_t input_bytes[4]; /* sizes of this submission's planes */
+    size_t state_bytes[3];
+    size_t out_bytes;
+} symaccel_batch_slot;
+typedef struct symaccel_batcher_stats {
+    uint64_t submissions;           /* reserve() / submit() calls */
+    uint64_t launches;              /* groups sent to the device */
+    uint64_t chunks;                /* kernel launches (a group is cut into chunks of submissions for the copy / compute overlap) */
+    uint64_t chains_launched;       /* sum of chains over all launches */
+    uint64_t max_chains_per_launch;
+    uint64_t staging_bytes;         /* page-locked memory held */
+    uint64_t pending;               /* submissions not yet launched */
+} symaccel_batcher_stats;
+/* flush_bytes: input bytes of one group after which it is launched without anybody waiting (0 = 64 MiB); also sizes the
+ * staging memory of a group (input + output + state, page-locked, pooled and reused). */
+int symaccel_batcher_create(symaccel_ctx *ctx, size_t flush_bytes, symaccel_batcher **out);
+int symaccel_batcher_destroy(symaccel_batcher *b);
+int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_chains, size_t units_per_chain,
+                             symaccel_batch_slot *slot, uint64_t *ticket);
+int symaccel_batcher_commit(symaccel_batcher *b, uint64_t ticket);
+/* slot may be NULL; otherwise it is filled in again (same pointers as reserve() gave) */
+int symaccel_batcher_wait(symaccel_batcher *b, uint64_t ticket, symaccel_batch_slot *slot);
+int symaccel_batcher_release(symaccel_batcher *b, uint64_t ticket);
+int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_chains, size_t units_per_chain,
+                            const void **input, void **state_io, void *out, uint64_t *ticket); /* input[4], state_io[3] */
+int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket);
+/* launch everything pending now (nobody has to wait for it) */
+int symaccel_batcher_flush(symaccel_batcher *b);
+/* bytes per chain of every plane of a kind (per submission for MP3_DECODE's input[3]); unused planes 0 */
+int symaccel_batcher_plane_bytes(int kind, size_t units_per_chain, size_t *input_bytes, size_t *state_bytes, size_t *out_bytes); /* [4], [3] */
+int symaccel_batcher_get_stats(symaccel_batcher *b, symaccel_batcher_stats *out);
 
 /* ------------------------------------------------------------------------- multi-GPU */
 

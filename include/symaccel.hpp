@@ -33,6 +33,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <cstring>
 #include <vector>
 
 #include "symaccel.h"
@@ -75,6 +76,30 @@ public:
 
 private:
     symaccel_ctx *ctx_ = nullptr;
+};
+
+// The cross-stream batcher (symaccel_batcher_*, csrc/batcher.cpp): one per process and context, shared by every decoder of the
+// process.  Decoders submit their look-ahead batches; one launch per (kind, units) group serves all of them.  Thread-safe.
+class Batcher {
+public:
+    explicit Batcher(Context &ctx, std::size_t flush_bytes = 0) : ctx_(ctx) { check(symaccel_batcher_create(ctx.raw(), flush_bytes, &b_), ctx.raw()); }
+    ~Batcher() {
+        if (b_) symaccel_batcher_destroy(b_);
+    }
+    Batcher(const Batcher &) = delete;
+    Batcher &operator=(const Batcher &) = delete;
+    symaccel_batcher *raw() const { return b_; }
+    Context &context() const { return ctx_; }
+    void flush() { check(symaccel_batcher_flush(b_), ctx_.raw()); }
+    symaccel_batcher_stats stats() const {
+        symaccel_batcher_stats s{};
+        check(symaccel_batcher_get_stats(b_, &s), ctx_.raw());
+        return s;
+    }
+
+private:
+    Context &ctx_;
+    symaccel_batcher *b_ = nullptr;
 };
 
 namespace dsp {
@@ -453,6 +478,12 @@ struct FinalizeResult {  // codecs/audio.rs:230-236
     std::optional<bool> verify_ok;
 };
 
+// With a `Batcher` (second constructor) the same decoder coalesces ACROSS streams: its batches are submitted to the process-wide
+// batcher instead of being transformed by a call of their own, and the next batch is submitted early -- as soon as half of the
+// current one has been handed out -- so that by the time this stream needs it, the decoders of the other streams have submitted
+// theirs and one launch (one PCIe round trip) serves all of them.  The returned planes then point into the batcher's page-locked
+// result slot (valid, like every buffer of the trait, until the next &mut call).  Codecs without a batch kind (Vorbis, FLAC)
+// ignore the batcher and keep batching per stream.
 template <class Codec>
 class LookaheadDecoder {
 public:
@@ -465,9 +496,18 @@ public:
         : ctx_(ctx), codec_(params), lookahead_(lookahead < 1 ? 1 : lookahead), peek_(std::move(peek)) {
         reset();
     }
+    LookaheadDecoder(Batcher &batcher, const typename Codec::Params &params, std::size_t lookahead, Peek peek)
+        : ctx_(batcher.context()), codec_(params), lookahead_(lookahead < 1 ? 1 : lookahead), peek_(std::move(peek)),
+          batcher_(Codec::kBatchKind ? &batcher : nullptr) {
+        reset();
+    }
+    ~LookaheadDecoder() { drop_tickets(); }
+    LookaheadDecoder(const LookaheadDecoder &) = delete;
+    LookaheadDecoder &operator=(const LookaheadDecoder &) = delete;
 
     // AudioDecoder::reset (audio.rs:252-257): "must be called after a seek"; state as after construction
     void reset() {
+        drop_tickets();
         codec_.reset_state();
         ready_.clear();
         head_ = 0;
@@ -484,17 +524,21 @@ public:
             // (the delay line / overlap / V FIFO after a packet depend on that packet's input alone -- the same property
             // the kernels' segment halo uses), so replaying the last returned packet rebuilds exactly that state.
             drop_lookahead();
-            if (have_last_packet_) {
-                std::vector<Packet> one(1, last_packet_);
-                std::vector<Sample> scratch;
-                codec_.decode_batch(ctx_, one, scratch);
-            }
+            if (have_last_packet_) replay_last();
         }
         if (head_ >= ready_.size()) {
             try {
-                fill(packet);
+                if (next_live_ && !next_ids_.empty() && next_ids_[0] == Codec::id(packet)) {
+                    take_next();  // the batch submitted ahead starts with this packet
+                } else {
+                    // (a batch submitted ahead for packets the caller then skipped is dropped unseen: the carried state is still
+                    // the one the last returned packet left, because the current batch was handed out to its end)
+                    if (next_live_) drop_lookahead();
+                    fill(packet);
+                }
             } catch (...) {
                 clear_last();  // audio.rs:278: "implementors of this function must clear the internal buffer if an error occurs"
+                drop_tickets();
                 ready_.clear();
                 head_ = 0;
                 throw;
@@ -503,6 +547,16 @@ public:
         publish(head_++);
         last_packet_ = packet;
         have_last_packet_ = true;
+        if (batcher_) {
+            // half of the batch handed out: the next one is submitted (the other streams' decoders do the same around now); a
+            // quarter left: whatever is pending goes to the device, so that the copies and the kernels run while the rest is consumed
+            const std::size_t left = ready_.size() - head_;
+            if (!next_live_ && 2 * left <= ready_.size()) submit_ahead();
+            if (next_live_ && !hinted_ && 4 * left <= ready_.size()) {
+                hinted_ = true;
+                batcher_->flush();
+            }
+        }
         return last_;
     }
 
@@ -512,23 +566,117 @@ public:
     std::size_t batches_run() const { return batches_; }
 
 private:
-    void fill(const Packet &first) {
+    std::vector<Packet> gather(const Packet *first) {
         std::vector<Packet> batch;
-        batch.push_back(first);
+        if (first) batch.push_back(*first);
         // packets pulled earlier whose frames were dropped by a discontinuity are not replayed: the demuxer moved on
         while (batch.size() < lookahead_) {
             std::optional<Packet> nxt = peek_ ? peek_() : std::nullopt;
             if (!nxt) break;
             batch.push_back(std::move(*nxt));
         }
+        return batch;
+    }
+    void fill(const Packet &first) {
+        std::vector<Packet> batch = gather(&first);
+        if (batcher_) {
+            if constexpr (Codec::kBatchKind != 0) {
+                submit(batch);
+                take_next();
+                return;
+            }
+        }
         codec_.decode_batch(ctx_, batch, pcm_);
+        pcm_base_ = pcm_.data();
         ++batches_;
         ready_.clear();
         for (const Packet &p : batch) ready_.push_back(Codec::id(p));
         batch_len_ = batch.size();
         head_ = 0;
     }
+    // ---- batcher mode
+    void submit(const std::vector<Packet> &batch) {
+        if constexpr (Codec::kBatchKind != 0) {
+            symaccel_batch_slot slot;
+            check(symaccel_batcher_reserve(batcher_->raw(), Codec::kBatchKind, codec_.batch_param(), codec_.channels(),
+                                           batch.size() * codec_.units_per_packet(), &slot, &next_ticket_),
+                  ctx_.raw());
+            next_live_ = true;
+            try {
+                codec_.fill_slot(batch, slot);  // the parsed packets and the carried state go into the page-locked slot
+            } catch (...) {
+                symaccel_batcher_release(batcher_->raw(), next_ticket_);
+                next_live_ = false;
+                throw;
+            }
+            check(symaccel_batcher_commit(batcher_->raw(), next_ticket_), ctx_.raw());
+            next_ids_.clear();
+            for (const Packet &p : batch) next_ids_.push_back(Codec::id(p));
+            hinted_ = false;
+        }
+    }
+    void replay_last() {
+        std::vector<Packet> one(1, last_packet_);
+        if (batcher_) {
+            if constexpr (Codec::kBatchKind != 0) {  // (through the batcher: the context is not ours to call while a batcher drives it)
+                submit(one);
+                symaccel_batch_slot slot;
+                const int st = symaccel_batcher_wait(batcher_->raw(), next_ticket_, &slot);
+                if (st == SYMACCEL_OK) codec_.take_state(slot);
+                symaccel_batcher_release(batcher_->raw(), next_ticket_);
+                next_live_ = false;
+                next_ids_.clear();
+                check(st, ctx_.raw());
+                return;
+            }
+        }
+        std::vector<Sample> scratch;
+        codec_.decode_batch(ctx_, one, scratch);
+    }
+    void submit_ahead() {
+        // the state the next batch starts from is the one the current batch left: known since take_next() copied it out
+        std::vector<Packet> batch = gather(nullptr);
+        if (!batch.empty()) submit(batch);
+    }
+    void take_next() {
+        if constexpr (Codec::kBatchKind != 0) {
+            symaccel_batch_slot slot;
+            const int st = symaccel_batcher_wait(batcher_->raw(), next_ticket_, &slot);
+            if (st != SYMACCEL_OK) {
+                symaccel_batcher_release(batcher_->raw(), next_ticket_);
+                next_live_ = false;
+                check(st, ctx_.raw());
+            }
+            if (cur_live_) symaccel_batcher_release(batcher_->raw(), cur_ticket_);
+            cur_ticket_ = next_ticket_;
+            cur_live_ = true;
+            next_live_ = false;
+            codec_.take_state(slot);
+            pcm_base_ = static_cast<const Sample *>(slot.out);
+            ready_.swap(next_ids_);
+            next_ids_.clear();
+            batch_len_ = ready_.size();
+            head_ = 0;
+            ++batches_;
+        }
+    }
+    void drop_tickets() {
+        if (!batcher_) return;
+        if (next_live_) {
+            symaccel_batcher_wait(batcher_->raw(), next_ticket_, nullptr);  // (its result is not wanted, its slot must be idle)
+            symaccel_batcher_release(batcher_->raw(), next_ticket_);
+            next_live_ = false;
+        }
+        if (cur_live_) {
+            symaccel_batcher_release(batcher_->raw(), cur_ticket_);
+            cur_live_ = false;
+        }
+        next_ids_.clear();
+        pcm_base_ = nullptr;
+    }
     void drop_lookahead() {
+        drop_tickets();
+        clear_last();
         ready_.clear();
         head_ = 0;
     }
@@ -537,7 +685,7 @@ private:
         // [channel][packet][frames]; Vorbis packs (prev_n + n) / 4 samples per packet and none for the first one
         const std::size_t nch = codec_.channels();
         last_.planes.resize(nch);
-        for (std::size_t c = 0; c < nch; ++c) last_.planes[c] = pcm_.data() + codec_.plane_offset(c, i, batch_len_);
+        for (std::size_t c = 0; c < nch; ++c) last_.planes[c] = pcm_base_ + codec_.plane_offset(c, i, batch_len_);
         last_.frames = codec_.packet_frames(i);
     }
     void clear_last() {
@@ -549,8 +697,13 @@ private:
     Codec codec_;
     std::size_t lookahead_;
     Peek peek_;
+    Batcher *batcher_ = nullptr;
     std::vector<Sample> pcm_;                // [channel][packet of the batch][frames_per_packet]: planar per packet
+    const Sample *pcm_base_ = nullptr;       // pcm_.data(), or the batcher's result slot of the current batch
     std::vector<std::uint64_t> ready_;       // ids of the batch's packets, in order
+    std::vector<std::uint64_t> next_ids_;    // ... of the batch submitted ahead
+    std::uint64_t cur_ticket_ = 0, next_ticket_ = 0;
+    bool cur_live_ = false, next_live_ = false, hinted_ = false;
     Packet last_packet_{};                   // the packet decode() returned last (replayed after a discontinuity)
     bool have_last_packet_ = false;
     std::size_t head_ = 0, batch_len_ = 0, batches_ = 0;
@@ -582,17 +735,30 @@ struct AacLc {
         in_.resize(nch_ * k * 1024);
         side_.resize(nch_ * k);
         pcm.resize(nch_ * k * 1024);
+        gather(batch, in_.data(), side_.data());
+        check(symaccel_aac_synth(ctx.raw(), in_.data(), side_.data(), delay_.data(), pcm.data(), nch_, k), ctx.raw());
+    }
+    // the cross-stream batcher's view of the same batch (LookaheadDecoder's second constructor)
+    static constexpr int kBatchKind = SYMACCEL_BATCH_AAC_SYNTH;
+    int batch_param() const { return 0; }
+    std::size_t units_per_packet() const { return 1; }
+    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
+        gather(batch, static_cast<float *>(slot.input[0]), static_cast<std::uint8_t *>(slot.input[1]));
+        std::memcpy(slot.state[0], delay_.data(), delay_.size() * sizeof(float));
+    }
+    void take_state(const symaccel_batch_slot &slot) { std::memcpy(delay_.data(), slot.state[0], delay_.size() * sizeof(float)); }
+
+private:
+    void gather(const std::vector<Packet> &batch, float *in, std::uint8_t *side) const {
+        const std::size_t k = batch.size();
         for (std::size_t i = 0; i < k; ++i) {
             if (batch[i].coeffs.size() != nch_ * 1024 || batch[i].side.size() != nch_) throw std::invalid_argument("AacLc: packet shape");
             for (std::size_t c = 0; c < nch_; ++c) {
-                std::copy_n(batch[i].coeffs.data() + c * 1024, 1024, in_.data() + (c * k + i) * 1024);
-                side_[c * k + i] = batch[i].side[c];
+                std::copy_n(batch[i].coeffs.data() + c * 1024, 1024, in + (c * k + i) * 1024);
+                side[c * k + i] = batch[i].side[c];
             }
         }
-        check(symaccel_aac_synth(ctx.raw(), in_.data(), side_.data(), delay_.data(), pcm.data(), nch_, k), ctx.raw());
     }
-
-private:
     std::size_t nch_;
     std::vector<float> delay_, in_;
     std::vector<std::uint8_t> side_;
@@ -631,19 +797,37 @@ struct Mp3 {
         in_.resize(nch_ * g * 576);
         side_.resize(nch_ * g);
         pcm.resize(nch_ * g * 576);
+        gather(batch, in_.data(), side_.data());
+        check(symaccel_mp3_synth(ctx.raw(), in_.data(), side_.data(), sr_, overlap_.data(), vvec_.data(), vfront_.data(), pcm.data(), nch_, g),
+              ctx.raw());
+    }
+    static constexpr int kBatchKind = SYMACCEL_BATCH_MP3_SYNTH;
+    int batch_param() const { return sr_; }
+    std::size_t units_per_packet() const { return ngr_; }
+    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
+        gather(batch, static_cast<float *>(slot.input[0]), static_cast<symaccel_mp3_side *>(slot.input[1]));
+        std::memcpy(slot.state[0], overlap_.data(), overlap_.size() * sizeof(float));
+        std::memcpy(slot.state[1], vvec_.data(), vvec_.size() * sizeof(float));
+        std::memcpy(slot.state[2], vfront_.data(), vfront_.size() * sizeof(std::int32_t));
+    }
+    void take_state(const symaccel_batch_slot &slot) {
+        std::memcpy(overlap_.data(), slot.state[0], overlap_.size() * sizeof(float));
+        std::memcpy(vvec_.data(), slot.state[1], vvec_.size() * sizeof(float));
+        std::memcpy(vfront_.data(), slot.state[2], vfront_.size() * sizeof(std::int32_t));
+    }
+
+private:
+    void gather(const std::vector<Packet> &batch, float *in, symaccel_mp3_side *side) const {
+        const std::size_t k = batch.size(), g = k * ngr_;
         for (std::size_t i = 0; i < k; ++i) {
             if (batch[i].xr.size() != ngr_ * nch_ * 576 || batch[i].side.size() != ngr_ * nch_) throw std::invalid_argument("Mp3: packet shape");
             for (std::size_t gr = 0; gr < ngr_; ++gr)
                 for (std::size_t c = 0; c < nch_; ++c) {
-                    std::copy_n(batch[i].xr.data() + (gr * nch_ + c) * 576, 576, in_.data() + (c * g + i * ngr_ + gr) * 576);
-                    side_[c * g + i * ngr_ + gr] = batch[i].side[gr * nch_ + c];
+                    std::copy_n(batch[i].xr.data() + (gr * nch_ + c) * 576, 576, in + (c * g + i * ngr_ + gr) * 576);
+                    side[c * g + i * ngr_ + gr] = batch[i].side[gr * nch_ + c];
                 }
         }
-        check(symaccel_mp3_synth(ctx.raw(), in_.data(), side_.data(), sr_, overlap_.data(), vvec_.data(), vfront_.data(), pcm.data(), nch_, g),
-              ctx.raw());
     }
-
-private:
     std::size_t nch_, ngr_;
     int sr_;
     std::vector<float> overlap_, vvec_, in_;
@@ -690,6 +874,33 @@ struct Mp3Huffman {
         side_.resize(nch_ * g);
         st_.resize(nch_ == 2 ? g : 0);
         pcm.resize(nch_ * g * 576);
+        gather(batch, q_.data(), rq_.data(), side_.data(), st_.data());
+        const std::int32_t pair[2] = {0, 1};
+        check(symaccel_mp3_decode_pipelined(ctx.raw(), q_.data(), rq_.data(), nch_ == 2 ? pair : nullptr, nch_ == 2 ? st_.data() : nullptr,
+                                            nch_ == 2 ? 1 : 0, side_.data(), sr_, overlap_.data(), vvec_.data(), vfront_.data(), pcm.data(), nch_, g, 0),
+              ctx.raw());
+    }
+
+    static constexpr int kBatchKind = SYMACCEL_BATCH_MP3_DECODE;  // one stream per submission: exactly what this codec is
+    int batch_param() const { return sr_; }
+    std::size_t units_per_packet() const { return ngr_; }
+    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
+        gather(batch, static_cast<std::int16_t *>(slot.input[0]), static_cast<symaccel_mp3_requant *>(slot.input[1]),
+               static_cast<symaccel_mp3_side *>(slot.input[2]), static_cast<symaccel_mp3_stereo *>(slot.input[3]));
+        if (nch_ != 2) std::memset(slot.input[3], 0, slot.input_bytes[3]);
+        std::memcpy(slot.state[0], overlap_.data(), overlap_.size() * sizeof(float));
+        std::memcpy(slot.state[1], vvec_.data(), vvec_.size() * sizeof(float));
+        std::memcpy(slot.state[2], vfront_.data(), vfront_.size() * sizeof(std::int32_t));
+    }
+    void take_state(const symaccel_batch_slot &slot) {
+        std::memcpy(overlap_.data(), slot.state[0], overlap_.size() * sizeof(float));
+        std::memcpy(vvec_.data(), slot.state[1], vvec_.size() * sizeof(float));
+        std::memcpy(vfront_.data(), slot.state[2], vfront_.size() * sizeof(std::int32_t));
+    }
+
+private:
+    void gather(const std::vector<Packet> &batch, std::int16_t *q, symaccel_mp3_requant *rq, symaccel_mp3_side *side, symaccel_mp3_stereo *st) const {
+        const std::size_t k = batch.size(), g = k * ngr_;
         for (std::size_t i = 0; i < k; ++i) {
             const Packet &p = batch[i];
             if (p.quant.size() != ngr_ * nch_ * 576 || p.rq.size() != ngr_ * nch_ || p.side.size() != ngr_ * nch_ ||
@@ -698,20 +909,14 @@ struct Mp3Huffman {
             for (std::size_t gr = 0; gr < ngr_; ++gr) {
                 for (std::size_t c = 0; c < nch_; ++c) {
                     const std::size_t dst = c * g + i * ngr_ + gr;
-                    std::copy_n(p.quant.data() + (gr * nch_ + c) * 576, 576, q_.data() + dst * 576);
-                    rq_[dst] = p.rq[gr * nch_ + c];
-                    side_[dst] = p.side[gr * nch_ + c];
+                    std::copy_n(p.quant.data() + (gr * nch_ + c) * 576, 576, q + dst * 576);
+                    rq[dst] = p.rq[gr * nch_ + c];
+                    side[dst] = p.side[gr * nch_ + c];
                 }
-                if (nch_ == 2) st_[i * ngr_ + gr] = p.stereo[gr];
+                if (nch_ == 2) st[i * ngr_ + gr] = p.stereo[gr];
             }
         }
-        const std::int32_t pair[2] = {0, 1};
-        check(symaccel_mp3_decode_pipelined(ctx.raw(), q_.data(), rq_.data(), nch_ == 2 ? pair : nullptr, nch_ == 2 ? st_.data() : nullptr,
-                                            nch_ == 2 ? 1 : 0, side_.data(), sr_, overlap_.data(), vvec_.data(), vfront_.data(), pcm.data(), nch_, g, 0),
-              ctx.raw());
     }
-
-private:
     std::size_t nch_, ngr_;
     int sr_;
     std::vector<float> overlap_, vvec_;
@@ -739,6 +944,7 @@ struct Vorbis {
     };
     explicit Vorbis(const Params &p)
         : nch_(p.channels), e0_(p.bs0_exp), e1_(p.bs1_exp), prev_(p.channels, -1), overlap_(p.channels * ((std::size_t)1 << (p.bs1_exp - 1)), 0.0f) {}
+    static constexpr int kBatchKind = 0;  // (packed, per-stream block sizes: batches per stream)
     static std::uint64_t id(const Packet &p) { return p.ts; }
     std::size_t channels() const { return nch_; }
     std::size_t packet_frames(std::size_t i) const { return emits_[i] ? off_[i + 1] - off_[i] : 0; }
@@ -817,6 +1023,7 @@ struct Flac {
     explicit Flac(const Params &p) : nch_(p.channels), shift_(32u - p.bits_per_sample) {
         if (p.channels == 0 || p.bits_per_sample == 0 || p.bits_per_sample > 32) throw std::invalid_argument("Flac: parameters");
     }
+    static constexpr int kBatchKind = 0;  // (block sizes differ from stream to stream: batches per stream)
     static std::uint64_t id(const Packet &p) { return p.ts; }
     std::size_t channels() const { return nch_; }
     std::size_t packet_frames(std::size_t i) const { return lens_[i]; }

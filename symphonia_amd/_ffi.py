@@ -49,6 +49,9 @@ ABI_SYMBOLS = [
     "symaccel_comm_destroy", "symaccel_multi_set_transport", "symaccel_mp3_decode_pipelined",
     "symaccel_mp3_decode_pp_device", "symaccel_mp3_decode_device",
     "symaccel_aac_joint_stereo_list_device", "symaccel_aac_decode_pipelined", "symaccel_vorbis_decode",
+    "symaccel_batcher_create", "symaccel_batcher_destroy", "symaccel_batcher_reserve", "symaccel_batcher_commit", "symaccel_batcher_wait",
+    "symaccel_batcher_release", "symaccel_batcher_submit", "symaccel_batcher_collect", "symaccel_batcher_flush", "symaccel_batcher_plane_bytes",
+    "symaccel_batcher_get_stats",
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
@@ -121,6 +124,17 @@ class Library:
         d.symaccel_aac_joint_stereo_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _i, _vp, _i]
         d.symaccel_aac_tns_device.argtypes = [_vp, _vp, _sz, _vp, _sz]
         d.symaccel_aac_joint_stereo_list_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _i, _vp, _i, _vp, _sz]
+        d.symaccel_batcher_create.argtypes = [_vp, _sz, C.POINTER(_vp)]
+        d.symaccel_batcher_destroy.argtypes = [_vp]
+        d.symaccel_batcher_reserve.argtypes = [_vp, _i, _i, _sz, _sz, _vp, C.POINTER(C.c_uint64)]
+        d.symaccel_batcher_commit.argtypes = [_vp, C.c_uint64]
+        d.symaccel_batcher_wait.argtypes = [_vp, C.c_uint64, _vp]
+        d.symaccel_batcher_release.argtypes = [_vp, C.c_uint64]
+        d.symaccel_batcher_submit.argtypes = [_vp, _i, _i, _sz, _sz, _vp, _vp, _vp, C.POINTER(C.c_uint64)]
+        d.symaccel_batcher_collect.argtypes = [_vp, C.c_uint64]
+        d.symaccel_batcher_flush.argtypes = [_vp]
+        d.symaccel_batcher_plane_bytes.argtypes = [_i, _sz, _vp, _vp, _vp]
+        d.symaccel_batcher_get_stats.argtypes = [_vp, _vp]
         d.symaccel_aac_decode_pipelined.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_mp3_stereo_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _i, _sz]
         d.symaccel_mp3_requantize_stereo_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp, _sz]

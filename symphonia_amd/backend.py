@@ -745,3 +745,111 @@ class PinnedBuffer:
             self.array = None
             self.lib.dll.symaccel_host_free(self.ptr)
             self.ptr = None
+
+
+BATCH_AAC_SYNTH, BATCH_MP3_SYNTH, BATCH_MP3_DECODE = 1, 2, 3
+
+
+class BatchSlot(C.Structure):
+    """symaccel_batch_slot (include/symaccel.h)"""
+    _fields_ = [("input", C.c_void_p * 4), ("state", C.c_void_p * 3), ("out", C.c_void_p), ("input_bytes", C.c_size_t * 4),
+                ("state_bytes", C.c_size_t * 3), ("out_bytes", C.c_size_t)]
+
+
+class BatcherStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("submissions", "launches", "chunks", "chains_launched", "max_chains_per_launch", "staging_bytes",
+                                           "pending")]
+
+
+def _slot_view(ptr, nbytes, dtype, shape):
+    if not ptr or not nbytes:
+        return None
+    return np.frombuffer((C.c_char * nbytes).from_address(ptr), dtype=dtype).reshape(shape)
+
+
+class Batcher:
+    """The cross-stream batcher (csrc/batcher.cpp, `symaccel_batcher_*`): decoders of one process submit their look-ahead
+    batches, one launch per (kind, units per chain) group serves all of them.  `submit` / `collect` copy from and into the
+    caller's arrays; `reserve` / `commit` / `wait` / `release` expose the page-locked slot itself."""
+
+    _PLANES = {  # kind -> (input dtypes/shapes per unit, state dtypes/shapes, out shape per unit)
+        BATCH_AAC_SYNTH: ([(np.float32, (1024,)), (np.uint8, ())], [(np.float32, (1024,))], (np.float32, (1024,))),
+        BATCH_MP3_SYNTH: ([(np.float32, (576,)), (np.dtype("u1,u1,u2"), ())], [(np.float32, (576,)), (np.float32, (1024,)), (np.int32, ())],
+                          (np.float32, (576,))),
+    }
+
+    def __init__(self, ctx, flush_bytes=0):
+        self.ctx = ctx
+        self.dll = ctx.lib.dll
+        h = C.c_void_p()
+        ctx.lib.check(self.dll.symaccel_batcher_create(ctx.handle, int(flush_bytes), C.byref(h)), ctx.handle)
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.dll.symaccel_batcher_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _check(self, st):
+        return self.ctx.lib.check(st, self.ctx.handle)
+
+    def submit(self, kind, param, inputs, states, out):
+        """inputs / states / out: C-contiguous numpy arrays ([chain][unit]... / [chain]...); the states are updated and `out` is
+        filled by collect()."""
+        n_chains, units = int(out.shape[0]), int(out.shape[1])
+        ins = (C.c_void_p * 4)(*[a.ctypes.data if a is not None else None for a in list(inputs) + [None] * (4 - len(inputs))])
+        sts = (C.c_void_p * 3)(*[a.ctypes.data for a in list(states)] + [None] * (3 - len(states)))
+        for a in list(inputs) + list(states) + [out]:
+            assert a is None or a.flags["C_CONTIGUOUS"]
+        t = C.c_uint64()
+        self._check(self.dll.symaccel_batcher_submit(self.handle, int(kind), int(param), n_chains, units, ins, sts, out.ctypes.data, C.byref(t)))
+        return int(t.value)
+
+    def collect(self, ticket):
+        self._check(self.dll.symaccel_batcher_collect(self.handle, int(ticket)))
+
+    def reserve(self, kind, param, n_chains, units):
+        slot, t = BatchSlot(), C.c_uint64()
+        self._check(self.dll.symaccel_batcher_reserve(self.handle, int(kind), int(param), int(n_chains), int(units), C.byref(slot), C.byref(t)))
+        return int(t.value), slot
+
+    def commit(self, ticket):
+        self._check(self.dll.symaccel_batcher_commit(self.handle, int(ticket)))
+
+    def wait(self, ticket):
+        slot = BatchSlot()
+        self._check(self.dll.symaccel_batcher_wait(self.handle, int(ticket), C.byref(slot)))
+        return slot
+
+    def release(self, ticket):
+        self._check(self.dll.symaccel_batcher_release(self.handle, int(ticket)))
+
+    def flush(self):
+        self._check(self.dll.symaccel_batcher_flush(self.handle))
+
+    def stats(self):
+        s = BatcherStats()
+        self._check(self.dll.symaccel_batcher_get_stats(self.handle, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in BatcherStats._fields_}
+
+    @staticmethod
+    def slot_arrays(slot, kind, n_chains, units):
+        """numpy views of a slot's planes (no copies): (inputs, states, out)"""
+        if kind == BATCH_MP3_DECODE:
+            ins = [_slot_view(slot.input[0], slot.input_bytes[0], np.int16, (n_chains, units, 576)),
+                   _slot_view(slot.input[1], slot.input_bytes[1], MP3_REQUANT_DTYPE, (n_chains, units)),
+                   _slot_view(slot.input[2], slot.input_bytes[2], np.dtype("u1,u1,u2"), (n_chains, units)),
+                   _slot_view(slot.input[3], slot.input_bytes[3], MP3_STEREO_DTYPE, (units,))]
+            sts_spec, out_spec = Batcher._PLANES[BATCH_MP3_SYNTH][1], Batcher._PLANES[BATCH_MP3_SYNTH][2]
+        else:
+            in_spec, sts_spec, out_spec = Batcher._PLANES[kind]
+            ins = [_slot_view(slot.input[i], slot.input_bytes[i], dt, (n_chains, units) + sh) for i, (dt, sh) in enumerate(in_spec)]
+        sts = [_slot_view(slot.state[i], slot.state_bytes[i], dt, (n_chains,) + sh) for i, (dt, sh) in enumerate(sts_spec)]
+        out = _slot_view(slot.out, slot.out_bytes, out_spec[0], (n_chains, units) + out_spec[1])
+        return ins, sts, out

@@ -24,7 +24,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libsymaccel.so"
 TUNED_OUT = HERE / "build" / "tuned" / "libsymaccel.so"
-SOURCES = ["tables.cpp", "ctx.cpp", "host_tools.cpp", "stage.cpp", "multi.cpp", "imdct_generic.hip", "imdct_big.hip", "aac.hip", "aac_tools.hip", "mp3.hip", "mpa_polyphase.hip", "mp3_requant.hip",
+SOURCES = ["tables.cpp", "ctx.cpp", "host_tools.cpp", "stage.cpp", "batcher.cpp", "multi.cpp", "imdct_generic.hip", "imdct_big.hip", "aac.hip", "aac_tools.hip", "mp3.hip", "mpa_polyphase.hip", "mp3_requant.hip",
            "mp3_stereo.hip", "vorbis.hip", "vorbis_wave.hip", "vorbis_wave2.hip", "vorbis_wg.hip", "flac.hip", "alac.hip", "state_copy.hip", "probe.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",

@@ -1,0 +1,616 @@
+// Cross-stream batcher: many decoders, one launch.
+//
+// A `Hip*Decoder` (bindings/rust) or a `codecs::LookaheadDecoder` (include/symaccel.hpp) batches the look-ahead of ITS stream:
+// 256 packets x 2 channels is 2 MiB per call, and N decoders are N small calls, each paying its own launch and its own PCIe
+// round trip.  The reference's trait gives a decoder no view of its siblings (AudioDecoder::decode_ref sees one packet of one
+// track, symphonia-core/src/codecs/audio.rs:279-297; the registry builds decoders from (params, opts) alone, registry.rs:330-341),
+// so the coalescing point is below the trait, here: decoders SUBMIT their batches to a batcher shared by the process and come
+// back for the result later; whatever is pending when somebody needs a result (or when `flush_bytes` of input have piled up)
+// goes to the device as ONE batch per (kind, units per chain) group -- the chains of every submission side by side in the
+// chain-major layout the kernels already take, so nothing in the kernels knows about streams.
+//
+//   reserve()  -> a slot of page-locked staging memory the front end writes its spectra / samples / records into (no copy
+//                 between the parser's output and the DMA source) + a ticket
+//   commit()   -> the slot is filled
+//   wait()     -> launches the ticket's group if nobody has yet (and everything else that is pending), blocks until the
+//                 group's results are in page-locked memory; slot.out / slot.state now hold PCM and the carried state
+//   release()  -> the slot may be reused
+//
+// A group is transferred and transformed in chunks of submissions: H2D(c + 1) || kernel(c) || D2H(c - 1) on the context's three
+// streams (the chunks are chains, which are independent: no carried state between chunks, unlike stage.cpp's frame-axis
+// chunks).  Groups are pooled: in the steady state nothing is allocated.  Thread-safe: submissions may come from any thread; a
+// flush waits for reservations of the group that are still being filled.  A context that has a batcher is driven through the
+// batcher only (the context itself is externally synchronised, include/symaccel.h "Thread safety").
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "symaccel_internal.h"
+
+using namespace symaccel;
+
+namespace {
+
+constexpr int kMaxIn = 4, kMaxState = 3;
+
+// what a kind's planes weigh: bytes per chain (per ticket for `in_per_ticket`) for `units` frames / granules per chain
+struct PlaneSizes {
+    size_t in[kMaxIn] = {0, 0, 0, 0};
+    bool in_per_ticket[kMaxIn] = {false, false, false, false};
+    size_t state[kMaxState] = {0, 0, 0};
+    size_t out = 0;
+    int n_in = 0, n_state = 0;
+};
+
+bool plane_sizes(int kind, size_t units, PlaneSizes *ps) {
+    *ps = PlaneSizes();
+    switch (kind) {
+    case SYMACCEL_BATCH_AAC_SYNTH:  // symaccel_aac_synth: coeffs, side | delay | pcm
+        ps->n_in = 2;
+        ps->in[0] = units * 4096;
+        ps->in[1] = units;
+        ps->n_state = 1;
+        ps->state[0] = 4096;
+        ps->out = units * 4096;
+        return true;
+    case SYMACCEL_BATCH_MP3_SYNTH:  // symaccel_mp3_synth: xr, side | overlap, vvec, vfront | pcm
+        ps->n_in = 2;
+        ps->in[0] = units * 2304;
+        ps->in[1] = units * sizeof(symaccel_mp3_side);
+        ps->n_state = 3;
+        ps->state[0] = 2304;
+        ps->state[1] = 4096;
+        ps->state[2] = 4;
+        ps->out = units * 2304;
+        return true;
+    case SYMACCEL_BATCH_MP3_DECODE:  // symaccel_mp3_decode_pipelined, one stream per submission: quant, rq_desc, side, st_desc (per stream)
+        ps->n_in = 4;
+        ps->in[0] = units * 1152;
+        ps->in[1] = units * sizeof(symaccel_mp3_requant);
+        ps->in[2] = units * sizeof(symaccel_mp3_side);
+        ps->in[3] = units * sizeof(symaccel_mp3_stereo);
+        ps->in_per_ticket[3] = true;
+        ps->n_state = 3;
+        ps->state[0] = 2304;
+        ps->state[1] = 4096;
+        ps->state[2] = 4;
+        ps->out = units * 2304;
+        return true;
+    default:
+        return false;
+    }
+}
+
+size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Group;
+
+struct Ticket {
+    Group *group = nullptr;
+    uint32_t gen = 0;
+    uint32_t first_chain = 0, n_chains = 0, ordinal = 0;
+    bool live = false, committed = false;
+    // copy form (symaccel_batcher_submit): where collect() puts the results
+    void *user_state[kMaxState] = {nullptr, nullptr, nullptr};
+    void *user_out = nullptr;
+};
+
+enum class GroupState { Free, Open, Closed, Launched };
+
+struct Group {
+    int kind = 0, param = 0;
+    size_t units = 0;
+    PlaneSizes ps;
+    size_t cap_chains = 0, cap_tickets = 0;
+    size_t chains = 0, tickets = 0, uncommitted = 0, live = 0;
+    GroupState state = GroupState::Free;
+    int status = SYMACCEL_OK;
+    std::vector<uint32_t> ticket_first;  // first chain of every submission, in order (chunk boundaries, the MP3 unit list)
+    std::vector<uint32_t> ticket_chains;
+    // page-locked staging and its device twin: one allocation each, planes carved out
+    char *h_base = nullptr, *d_base = nullptr;
+    size_t h_bytes = 0, d_bytes = 0;
+    char *h_in[kMaxIn] = {}, *h_state[kMaxState] = {}, *h_out = nullptr;
+    char *d_in[kMaxIn] = {}, *d_state_in[kMaxState] = {}, *d_state_out[kMaxState] = {}, *d_out = nullptr;
+    int32_t *d_units = nullptr;  // MP3_DECODE: unit_chains of every chunk, relative to the chunk's first chain
+    int32_t *h_units = nullptr;  // (page-locked: the copy is asynchronous)
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, done = nullptr;
+};
+
+}  // namespace
+
+struct symaccel_batcher {
+    symaccel_ctx *ctx = nullptr;
+    size_t flush_bytes = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<Group>> groups;
+    std::vector<Ticket> tickets;
+    std::vector<uint32_t> free_tickets;
+    symaccel_batcher_stats stats{};
+    std::string last_error;
+};
+
+namespace {
+
+int group_alloc(symaccel_batcher *b, Group *g, size_t cap_chains) {
+    symaccel_ctx *ctx = b->ctx;
+    const PlaneSizes &ps = g->ps;
+    const size_t cap_tickets = cap_chains;  // a submission has at least one chain
+    size_t h_total = 0, d_total = 0;
+    size_t h_off_in[kMaxIn], h_off_state[kMaxState], h_off_out, d_off_in[kMaxIn], d_off_si[kMaxState], d_off_so[kMaxState], d_off_out;
+    for (int i = 0; i < ps.n_in; ++i) {
+        const size_t bytes = round256(ps.in[i] * (ps.in_per_ticket[i] ? cap_tickets : cap_chains));
+        h_off_in[i] = h_total;
+        h_total += bytes;
+        d_off_in[i] = d_total;
+        d_total += bytes;
+    }
+    for (int i = 0; i < ps.n_state; ++i) {
+        const size_t bytes = round256(ps.state[i] * cap_chains);
+        h_off_state[i] = h_total;
+        h_total += bytes;
+        d_off_si[i] = d_total;
+        d_total += bytes;
+        d_off_so[i] = d_total;
+        d_total += bytes;
+    }
+    h_off_out = h_total;
+    h_total += round256(ps.out * cap_chains);
+    d_off_out = d_total;
+    d_total += round256(ps.out * cap_chains);
+    const size_t units_bytes = round256(cap_tickets * 8);
+    const size_t h_units_off = h_total, d_units_off = d_total;
+    h_total += units_bytes;
+    d_total += units_bytes;
+    if (g->h_base) {
+        (void)hipHostFree(g->h_base);
+        g->h_base = nullptr;
+    }
+    if (g->d_base) {
+        (void)hipFree(g->d_base);
+        g->d_base = nullptr;
+    }
+    g->cap_chains = g->cap_tickets = 0;
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, h_total, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return SYMACCEL_ERR_OOM;
+    }
+    g->h_base = static_cast<char *>(h);
+    g->h_bytes = h_total;
+    SYM_TRY(ctx_alloc(ctx, &d, d_total, false));
+    g->d_base = static_cast<char *>(d);
+    g->d_bytes = d_total;
+    for (int i = 0; i < ps.n_in; ++i) {
+        g->h_in[i] = g->h_base + h_off_in[i];
+        g->d_in[i] = g->d_base + d_off_in[i];
+    }
+    for (int i = 0; i < ps.n_state; ++i) {
+        g->h_state[i] = g->h_base + h_off_state[i];
+        g->d_state_in[i] = g->d_base + d_off_si[i];
+        g->d_state_out[i] = g->d_base + d_off_so[i];
+    }
+    g->h_out = g->h_base + h_off_out;
+    g->d_out = g->d_base + d_off_out;
+    g->h_units = reinterpret_cast<int32_t *>(g->h_base + h_units_off);
+    g->d_units = reinterpret_cast<int32_t *>(g->d_base + d_units_off);
+    for (hipEvent_t *e : {&g->ev_in[0], &g->ev_in[1], &g->ev_k[0], &g->ev_k[1], &g->done})
+        if (!*e) SYM_GPU(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    g->cap_chains = cap_chains;
+    g->cap_tickets = cap_tickets;
+    return SYMACCEL_OK;
+}
+
+void group_free(Group *g) {
+    if (g->h_base) (void)hipHostFree(g->h_base);
+    if (g->d_base) (void)hipFree(g->d_base);
+    for (hipEvent_t e : {g->ev_in[0], g->ev_in[1], g->ev_k[0], g->ev_k[1], g->done})
+        if (e) (void)hipEventDestroy(e);
+    g->h_base = g->d_base = nullptr;
+}
+
+size_t in_bytes_per_chain(const PlaneSizes &ps) {
+    size_t s = 0;
+    for (int i = 0; i < ps.n_in; ++i) s += ps.in[i];
+    return s;
+}
+
+// the kernels of one chunk: chains [c0, c0 + nc), submissions [t0, t0 + nt)
+int launch_chunk(symaccel_batcher *b, Group *g, size_t c0, size_t nc, size_t t0, size_t nt) {
+    symaccel_ctx *ctx = b->ctx;
+    const PlaneSizes &ps = g->ps;
+    auto in = [&](int i) { return g->d_in[i] + (ps.in_per_ticket[i] ? t0 : c0) * ps.in[i]; };
+    auto si = [&](int i) { return g->d_state_in[i] + c0 * ps.state[i]; };
+    auto so = [&](int i) { return g->d_state_out[i] + c0 * ps.state[i]; };
+    char *out = g->d_out + c0 * ps.out;
+    switch (g->kind) {
+    case SYMACCEL_BATCH_AAC_SYNTH:
+        return launch_aac(ctx, (const float *)in(0), (const uint8_t *)in(1), (const float *)si(0), (float *)so(0), (float *)out, nc, g->units);
+    case SYMACCEL_BATCH_MP3_SYNTH:
+        return launch_mp3(ctx, (const float *)in(0), (const symaccel_mp3_side *)in(1), g->param, (const float *)si(0), (const float *)si(1),
+                          (const int32_t *)si(2), (float *)so(0), (float *)so(1), (int32_t *)so(2), (float *)out, nc, g->units);
+    case SYMACCEL_BATCH_MP3_DECODE:
+        return launch_mp3_decode(ctx, (const int16_t *)in(0), (const symaccel_mp3_requant *)in(1), g->d_units + 2 * t0,
+                                 (const symaccel_mp3_stereo *)in(3), nt, (const symaccel_mp3_side *)in(2), g->param, (const float *)si(0),
+                                 (const float *)si(1), (const int32_t *)si(2), (float *)so(0), (float *)so(1), (int32_t *)so(2), (float *)out, nc,
+                                 g->units);
+    default:
+        return SYMACCEL_ERR_INVALID_ARG;
+    }
+}
+
+// Everything of a closed group: chunked copies in, kernels, copies out; `done` is recorded behind the last copy out.
+int launch_group_inner(symaccel_batcher *b, Group *g) {
+    symaccel_ctx *ctx = b->ctx;
+    const PlaneSizes &ps = g->ps;
+    if (!ctx->stage_in) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_in));
+    if (!ctx->stage_out) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_out));
+    hipStream_t s_in = ctx->stage_in, s_out = ctx->stage_out;
+    const size_t per_chain = in_bytes_per_chain(ps);
+    // ~1/6 of the group per chunk, 2 .. 32 MiB of input: long enough copies for the link, enough chunks for the overlap
+    size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)2 << 20, g->chains * per_chain / 6));
+    size_t chunk_chains = std::max<size_t>(1, chunk_bytes / std::max<size_t>(1, per_chain));
+    // (MP3_DECODE: the unit_chains of every submission are relative to the first chain of the chunk it falls into)
+    size_t t0 = 0, k = 0;
+    while (t0 < g->tickets) {
+        const size_t c0 = g->ticket_first[t0];
+        size_t t1 = t0, nc = 0;
+        while (t1 < g->tickets && (nc == 0 || nc + g->ticket_chains[t1] <= chunk_chains)) nc += g->ticket_chains[t1++];
+        const size_t nt = t1 - t0;
+        const int e = (int)(k & 1);
+        if (g->kind == SYMACCEL_BATCH_MP3_DECODE) {
+            for (size_t t = t0; t < t1; ++t) {
+                const int32_t rel = (int32_t)(g->ticket_first[t] - c0);
+                g->h_units[2 * t] = rel;
+                g->h_units[2 * t + 1] = g->ticket_chains[t] == 2 ? rel + 1 : -1;
+            }
+            SYM_GPU(ctx, hipMemcpyAsync(g->d_units + 2 * t0, g->h_units + 2 * t0, nt * 8, hipMemcpyHostToDevice, s_in));
+        }
+        for (int i = 0; i < ps.n_in; ++i) {
+            const size_t first = ps.in_per_ticket[i] ? t0 : c0, n = ps.in_per_ticket[i] ? nt : nc;
+            if (ps.in[i] * n)
+                SYM_GPU(ctx, hipMemcpyAsync(g->d_in[i] + first * ps.in[i], g->h_in[i] + first * ps.in[i], ps.in[i] * n, hipMemcpyHostToDevice, s_in));
+        }
+        for (int i = 0; i < ps.n_state; ++i)
+            SYM_GPU(ctx, hipMemcpyAsync(g->d_state_in[i] + c0 * ps.state[i], g->h_state[i] + c0 * ps.state[i], ps.state[i] * nc,
+                                        hipMemcpyHostToDevice, s_in));
+        SYM_GPU(ctx, hipEventRecord(g->ev_in[e], s_in));
+        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, g->ev_in[e], 0));
+        SYM_TRY(launch_chunk(b, g, c0, nc, t0, nt));
+        SYM_GPU(ctx, hipEventRecord(g->ev_k[e], ctx->stream));
+        SYM_GPU(ctx, hipStreamWaitEvent(s_out, g->ev_k[e], 0));
+        SYM_GPU(ctx, hipMemcpyAsync(g->h_out + c0 * ps.out, g->d_out + c0 * ps.out, ps.out * nc, hipMemcpyDeviceToHost, s_out));
+        for (int i = 0; i < ps.n_state; ++i)
+            SYM_GPU(ctx, hipMemcpyAsync(g->h_state[i] + c0 * ps.state[i], g->d_state_out[i] + c0 * ps.state[i], ps.state[i] * nc,
+                                        hipMemcpyDeviceToHost, s_out));
+        b->stats.chunks += 1;
+        t0 = t1;
+        ++k;
+    }
+    return SYMACCEL_OK;
+}
+
+// mu held.  Close the group, wait until every reservation of it is filled, launch.  On return the group is Launched (its status
+// says whether the launch worked) -- or somebody else has launched it meanwhile.
+void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lock) {
+    if (g->state != GroupState::Open) return;
+    g->state = GroupState::Closed;
+    b->cv.wait(lock, [&] { return g->uncommitted == 0; });
+    if (g->state != GroupState::Closed) return;
+    int st = SYMACCEL_OK;
+    if (g->tickets) {
+        DeviceGuard dev(b->ctx);
+        st = dev.ok() ? launch_group_inner(b, g) : dev.status();
+        if (st != SYMACCEL_OK) {
+            // a launch that failed half way: nothing of this group may still be in flight when its staging memory is reused, and the
+            // copy-out stream does not follow what the other two were left with -- drain all three (error path only)
+            b->last_error = b->ctx->last_error;
+            if (b->ctx->stage_in) (void)hipStreamSynchronize(b->ctx->stage_in);
+            if (b->ctx->stream) (void)hipStreamSynchronize(b->ctx->stream);
+            if (b->ctx->stage_out) (void)hipStreamSynchronize(b->ctx->stage_out);
+        }
+        // `done` sits behind the last copy out, which follows the last kernel, which follows the last copy in
+        if (dev.ok() && b->ctx->stage_out) (void)hipEventRecord(g->done, b->ctx->stage_out);
+    }
+    g->status = st;
+    g->state = GroupState::Launched;
+    b->stats.launches += 1;
+    b->stats.chains_launched += g->chains;
+    b->stats.max_chains_per_launch = std::max<uint64_t>(b->stats.max_chains_per_launch, g->chains);
+    b->cv.notify_all();
+}
+
+Group *open_group(symaccel_batcher *b, int kind, int param, size_t units, const PlaneSizes &ps, size_t n_chains, int *st) {
+    *st = SYMACCEL_OK;
+    Group *spare = nullptr;
+    for (auto &up : b->groups) {
+        Group *g = up.get();
+        if (g->state == GroupState::Open && g->kind == kind && g->param == param && g->units == units) return g;
+        if (g->state == GroupState::Free) {
+            const bool fits = g->kind == kind && g->units == units;
+            if (fits && !(spare && spare->kind == kind && spare->units == units && spare->cap_chains >= g->cap_chains)) spare = g;
+            if (!fits && !spare && b->groups.size() >= 8) spare = g;  // a pool of eight shapes: beyond that the stalest shape is re-cut
+        }
+    }
+    const size_t per_chain = std::max<size_t>(1, in_bytes_per_chain(ps));
+    const size_t want = std::max<size_t>(n_chains, std::max<size_t>(2, b->flush_bytes / per_chain));
+    if (!spare) {
+        b->groups.emplace_back(new Group());
+        spare = b->groups.back().get();
+    }
+    Group *g = spare;
+    if (!(g->kind == kind && g->units == units && g->cap_chains >= want)) {
+        g->kind = kind;
+        g->units = units;
+        g->ps = ps;
+        b->stats.staging_bytes -= std::min<uint64_t>(b->stats.staging_bytes, g->h_bytes);
+        g->h_bytes = 0;
+        DeviceGuard dev(b->ctx);
+        *st = dev.ok() ? group_alloc(b, g, want) : dev.status();
+        if (*st != SYMACCEL_OK) {
+            g->kind = 0;
+            g->cap_chains = 0;
+            return nullptr;
+        }
+        b->stats.staging_bytes += g->h_bytes;
+    }
+    g->param = param;
+    g->chains = g->tickets = g->uncommitted = g->live = 0;
+    g->ticket_first.clear();
+    g->ticket_chains.clear();
+    g->status = SYMACCEL_OK;
+    g->state = GroupState::Open;
+    return g;
+}
+
+Ticket *find_ticket(symaccel_batcher *b, uint64_t id) {
+    const uint32_t idx = (uint32_t)(id & 0xffffffffu), gen = (uint32_t)(id >> 32);
+    if (idx >= b->tickets.size()) return nullptr;
+    Ticket *t = &b->tickets[idx];
+    return t->live && t->gen == gen ? t : nullptr;
+}
+
+void fill_slot(const Group *g, const Ticket *t, symaccel_batch_slot *slot) {
+    const PlaneSizes &ps = g->ps;
+    std::memset(slot, 0, sizeof(*slot));
+    for (int i = 0; i < ps.n_in; ++i) {
+        slot->input[i] = g->h_in[i] + (ps.in_per_ticket[i] ? (size_t)t->ordinal : (size_t)t->first_chain) * ps.in[i];
+        slot->input_bytes[i] = ps.in[i] * (ps.in_per_ticket[i] ? 1 : t->n_chains);
+    }
+    for (int i = 0; i < ps.n_state; ++i) {
+        slot->state[i] = g->h_state[i] + (size_t)t->first_chain * ps.state[i];
+        slot->state_bytes[i] = ps.state[i] * t->n_chains;
+    }
+    slot->out = g->h_out + (size_t)t->first_chain * ps.out;
+    slot->out_bytes = ps.out * t->n_chains;
+}
+
+}  // namespace
+
+extern "C" {
+
+int symaccel_batcher_create(symaccel_ctx *ctx, size_t flush_bytes, symaccel_batcher **out) {
+    if (!ctx || !out) return SYMACCEL_ERR_INVALID_ARG;
+    *out = nullptr;
+    symaccel_batcher *b = new (std::nothrow) symaccel_batcher();
+    if (!b) return SYMACCEL_ERR_OOM;
+    b->ctx = ctx;
+    b->flush_bytes = flush_bytes ? flush_bytes : (size_t)64 << 20;
+    *out = b;
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_destroy(symaccel_batcher *b) {
+    if (!b) return SYMACCEL_OK;
+    {
+        DeviceGuard dev(b->ctx);
+        // nothing of ours may still be in flight when the staging memory goes
+        if (b->ctx->stage_in) (void)hipStreamSynchronize(b->ctx->stage_in);
+        if (b->ctx->stream) (void)hipStreamSynchronize(b->ctx->stream);
+        if (b->ctx->stage_out) (void)hipStreamSynchronize(b->ctx->stage_out);
+        for (auto &g : b->groups) group_free(g.get());
+    }
+    delete b;
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_chains, size_t units_per_chain, symaccel_batch_slot *slot,
+                             uint64_t *ticket) {
+    if (!b || !slot || !ticket || n_chains == 0 || units_per_chain == 0 || n_chains > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    PlaneSizes ps;
+    if (!plane_sizes(kind, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
+    if (kind == SYMACCEL_BATCH_AAC_SYNTH) param = 0;
+    if (kind != SYMACCEL_BATCH_AAC_SYNTH && (param < 0 || param > 8)) return SYMACCEL_ERR_INVALID_ARG;  // sample_rate_idx
+    if (kind == SYMACCEL_BATCH_MP3_DECODE && n_chains > 2) return SYMACCEL_ERR_INVALID_ARG;            // one stream per submission
+    std::unique_lock<std::mutex> lock(b->mu);
+    int st = SYMACCEL_OK;
+    Group *g = open_group(b, kind, param, units_per_chain, ps, n_chains, &st);
+    if (g && g->chains + n_chains > g->cap_chains) {  // full: it goes, a fresh one opens
+        flush_group(b, g, lock);
+        g = open_group(b, kind, param, units_per_chain, ps, n_chains, &st);
+    }
+    if (!g) return st;
+    uint32_t idx;
+    if (!b->free_tickets.empty()) {
+        idx = b->free_tickets.back();
+        b->free_tickets.pop_back();
+    } else {
+        idx = (uint32_t)b->tickets.size();
+        b->tickets.emplace_back();
+    }
+    Ticket *t = &b->tickets[idx];
+    const uint32_t gen = t->gen + 1;
+    *t = Ticket();
+    t->gen = gen;
+    t->group = g;
+    t->first_chain = (uint32_t)g->chains;
+    t->n_chains = (uint32_t)n_chains;
+    t->ordinal = (uint32_t)g->tickets;
+    t->live = true;
+    g->ticket_first.push_back(t->first_chain);
+    g->ticket_chains.push_back(t->n_chains);
+    g->chains += n_chains;
+    g->tickets += 1;
+    g->uncommitted += 1;
+    g->live += 1;
+    b->stats.submissions += 1;
+    fill_slot(g, t, slot);
+    *ticket = ((uint64_t)gen << 32) | idx;
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_commit(symaccel_batcher *b, uint64_t ticket) {
+    if (!b) return SYMACCEL_ERR_INVALID_ARG;
+    std::unique_lock<std::mutex> lock(b->mu);
+    Ticket *t = find_ticket(b, ticket);
+    if (!t || t->committed) return SYMACCEL_ERR_INVALID_ARG;
+    t->committed = true;
+    Group *g = t->group;
+    g->uncommitted -= 1;
+    if (g->uncommitted == 0) b->cv.notify_all();
+    // enough input has piled up: to the device, nobody has to ask
+    if (g->state == GroupState::Open && g->chains * in_bytes_per_chain(g->ps) >= b->flush_bytes) flush_group(b, g, lock);
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_flush(symaccel_batcher *b) {
+    if (!b) return SYMACCEL_ERR_INVALID_ARG;
+    std::unique_lock<std::mutex> lock(b->mu);
+    for (size_t i = 0; i < b->groups.size(); ++i)  // (index loop: flush_group drops the lock while it waits for commits)
+        if (b->groups[i]->state == GroupState::Open && b->groups[i]->tickets) flush_group(b, b->groups[i].get(), lock);
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_wait(symaccel_batcher *b, uint64_t ticket, symaccel_batch_slot *slot) {
+    if (!b) return SYMACCEL_ERR_INVALID_ARG;
+    Group *g;
+    {
+        std::unique_lock<std::mutex> lock(b->mu);
+        Ticket *t = find_ticket(b, ticket);
+        if (!t || !t->committed) return SYMACCEL_ERR_INVALID_ARG;
+        g = t->group;
+        if (g->state == GroupState::Open) {
+            // somebody needs a result: everything pending goes now -- the waiter's group first, then its siblings of other shapes,
+            // which would otherwise each cost their first waiter a round trip of their own
+            flush_group(b, g, lock);
+            for (size_t i = 0; i < b->groups.size(); ++i)
+                if (b->groups[i]->state == GroupState::Open && b->groups[i]->tickets) flush_group(b, b->groups[i].get(), lock);
+        }
+        b->cv.wait(lock, [&] { return g->state == GroupState::Launched; });
+        if (slot) fill_slot(g, find_ticket(b, ticket), slot);
+    }
+    if (g->tickets && g->done) {
+        DeviceGuard dev(b->ctx);
+        if (!dev.ok()) return dev.status();
+        const hipError_t e = hipEventSynchronize(g->done);
+        if (e != hipSuccess) return ctx_fail(b->ctx, e, "hipEventSynchronize(batch done)");
+    }
+    return g->status;
+}
+
+int symaccel_batcher_release(symaccel_batcher *b, uint64_t ticket) {
+    if (!b) return SYMACCEL_ERR_INVALID_ARG;
+    std::unique_lock<std::mutex> lock(b->mu);
+    Ticket *t = find_ticket(b, ticket);
+    if (!t) return SYMACCEL_ERR_INVALID_ARG;
+    Group *g = t->group;
+    if (!t->committed) {  // abandoned before it was filled: the slot's content is whatever it is, nobody reads the result
+        t->committed = true;
+        g->uncommitted -= 1;
+        if (g->uncommitted == 0) b->cv.notify_all();
+    }
+    t->live = false;
+    b->free_tickets.push_back((uint32_t)(ticket & 0xffffffffu));
+    g->live -= 1;
+    if (g->live == 0) {
+        if (g->state == GroupState::Open) flush_group(b, g, lock);  // (its submissions were all abandoned: still a defined state)
+        b->cv.wait(lock, [&] { return g->state == GroupState::Launched; });
+        if (g->live == 0 && g->state == GroupState::Launched) {
+            // released without a wait (or after one): either way nothing of the group may be in flight when it is reused
+            if (g->tickets && g->done) {
+                DeviceGuard dev(b->ctx);
+                if (dev.ok()) (void)hipEventSynchronize(g->done);
+            }
+            g->state = GroupState::Free;
+        }
+    }
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_plane_bytes(int kind, size_t units_per_chain, size_t *in_bytes, size_t *state_bytes, size_t *out_bytes) {
+    PlaneSizes ps;
+    if (!plane_sizes(kind, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
+    for (int i = 0; i < kMaxIn; ++i)
+        if (in_bytes) in_bytes[i] = ps.in[i];
+    for (int i = 0; i < kMaxState; ++i)
+        if (state_bytes) state_bytes[i] = ps.state[i];
+    if (out_bytes) *out_bytes = ps.out;
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_chains, size_t units_per_chain, const void **in,
+                            void **state_io, void *out, uint64_t *ticket) {
+    if (!b || !in || !state_io || !out || !ticket) return SYMACCEL_ERR_INVALID_ARG;
+    PlaneSizes ps;
+    if (!plane_sizes(kind, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
+    for (int i = 0; i < ps.n_in; ++i)
+        if (!in[i] && !(kind == SYMACCEL_BATCH_MP3_DECODE && i == 3 && n_chains == 1)) return SYMACCEL_ERR_INVALID_ARG;
+    for (int i = 0; i < ps.n_state; ++i)
+        if (!state_io[i]) return SYMACCEL_ERR_INVALID_ARG;
+    symaccel_batch_slot slot;
+    uint64_t id = 0;
+    SYM_TRY(symaccel_batcher_reserve(b, kind, param, n_chains, units_per_chain, &slot, &id));
+    for (int i = 0; i < ps.n_in; ++i) {
+        if (in[i])
+            std::memcpy(slot.input[i], in[i], slot.input_bytes[i]);
+        else
+            std::memset(slot.input[i], 0, slot.input_bytes[i]);
+    }
+    for (int i = 0; i < ps.n_state; ++i) std::memcpy(slot.state[i], state_io[i], slot.state_bytes[i]);
+    {
+        std::unique_lock<std::mutex> lock(b->mu);
+        Ticket *t = find_ticket(b, id);
+        for (int i = 0; i < ps.n_state; ++i) t->user_state[i] = state_io[i];
+        t->user_out = out;
+    }
+    *ticket = id;
+    return symaccel_batcher_commit(b, id);
+}
+
+int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket) {
+    if (!b) return SYMACCEL_ERR_INVALID_ARG;
+    symaccel_batch_slot slot;
+    void *user_state[kMaxState], *user_out;
+    {
+        std::unique_lock<std::mutex> lock(b->mu);
+        Ticket *t = find_ticket(b, ticket);
+        if (!t || !t->user_out) return SYMACCEL_ERR_INVALID_ARG;
+        for (int i = 0; i < kMaxState; ++i) user_state[i] = t->user_state[i];
+        user_out = t->user_out;
+    }
+    const int st = symaccel_batcher_wait(b, ticket, &slot);
+    if (st == SYMACCEL_OK) {
+        std::memcpy(user_out, slot.out, slot.out_bytes);
+        for (int i = 0; i < kMaxState; ++i)
+            if (user_state[i] && slot.state[i]) std::memcpy(user_state[i], slot.state[i], slot.state_bytes[i]);
+    }
+    const int rel = symaccel_batcher_release(b, ticket);
+    return st != SYMACCEL_OK ? st : rel;
+}
+
+int symaccel_batcher_get_stats(symaccel_batcher *b, symaccel_batcher_stats *out) {
+    if (!b || !out) return SYMACCEL_ERR_INVALID_ARG;
+    std::unique_lock<std::mutex> lock(b->mu);
+    *out = b->stats;
+    uint64_t pending = 0;
+    for (auto &g : b->groups)
+        if (g->state == GroupState::Open || g->state == GroupState::Closed) pending += g->tickets;
+    out->pending = pending;
+    return SYMACCEL_OK;
+}
+
+}  // extern "C"

@@ -5,6 +5,7 @@
 // the CPU emulation build elsewhere (tests/test_lookahead.py).
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <random>
 #include <vector>
 
@@ -61,14 +62,18 @@ struct AacOracle {  // a frame-by-frame decoder: one so_aac_synth_batch call per
     }
 };
 
-static void test_aac(Context &ctx, size_t lookahead) {
+static void test_aac(Context &ctx, size_t lookahead, Batcher *batcher = nullptr) {
     const size_t nch = 2, n = 41;
     auto track = aac_track(n, nch, 7 + (unsigned)lookahead);
     size_t cursor = 0;  // the demuxer's read position: decode(track[i]) is called with cursor == i + 1
-    LookaheadDecoder<AacLc> dec(ctx, AacLc::Params{nch}, lookahead, [&]() -> std::optional<AacLc::Packet> {
+    auto peek = [&]() -> std::optional<AacLc::Packet> {
         if (cursor >= track.size()) return std::nullopt;
         return track[cursor++];
-    });
+    };
+    std::optional<LookaheadDecoder<AacLc>> holder;
+    if (batcher) holder.emplace(*batcher, AacLc::Params{nch}, lookahead, peek);
+    else holder.emplace(ctx, AacLc::Params{nch}, lookahead, peek);
+    LookaheadDecoder<AacLc> &dec = *holder;
     AacOracle ref(nch);
     EXPECT(dec.last_decoded().is_empty(), "last_decoded() must be empty before the first decode");
     auto step = [&](size_t i) {
@@ -120,15 +125,19 @@ static std::vector<Mp3::Packet> mp3_track(size_t n, size_t nch, size_t ngr, unsi
     return t;
 }
 
-static void test_mp3(Context &ctx, size_t lookahead) {
+static void test_mp3(Context &ctx, size_t lookahead, Batcher *batcher = nullptr) {
     const size_t nch = 2, ngr = 2, n = 25;
     const int sr = 1;
     auto track = mp3_track(n, nch, ngr, 11 + (unsigned)lookahead);
     size_t cursor = 0;
-    LookaheadDecoder<Mp3> dec(ctx, Mp3::Params{nch, ngr, sr}, lookahead, [&]() -> std::optional<Mp3::Packet> {
+    auto peek = [&]() -> std::optional<Mp3::Packet> {
         if (cursor >= track.size()) return std::nullopt;
         return track[cursor++];
-    });
+    };
+    std::optional<LookaheadDecoder<Mp3>> holder;
+    if (batcher) holder.emplace(*batcher, Mp3::Params{nch, ngr, sr}, lookahead, peek);
+    else holder.emplace(ctx, Mp3::Params{nch, ngr, sr}, lookahead, peek);
+    LookaheadDecoder<Mp3> &dec = *holder;
     std::vector<float> ov(nch * 576, 0.0f), vv(nch * 1024, 0.0f);
     std::vector<int32_t> vf(nch, 0);
     for (size_t i = 0; i < n; ++i) {
@@ -155,7 +164,7 @@ static void test_mp3(Context &ctx, size_t lookahead) {
 }
 
 // ---- MP3 one stage earlier: int16 Huffman samples + records in, the device requantises and runs the joint stereo
-static void test_mp3_huffman(Context &ctx, size_t lookahead) {
+static void test_mp3_huffman(Context &ctx, size_t lookahead, Batcher *batcher = nullptr) {
     const size_t nch = 2, ngr = 2, n = 19;
     const int sr = 0;
     std::mt19937 rng(501 + (unsigned)lookahead);
@@ -192,10 +201,14 @@ static void test_mp3_huffman(Context &ctx, size_t lookahead) {
         }
     }
     size_t cursor = 0;
-    LookaheadDecoder<Mp3Huffman> dec(ctx, Mp3Huffman::Params{nch, ngr, sr}, lookahead, [&]() -> std::optional<Mp3Huffman::Packet> {
+    auto peek = [&]() -> std::optional<Mp3Huffman::Packet> {
         if (cursor >= track.size()) return std::nullopt;
         return track[cursor++];
-    });
+    };
+    std::optional<LookaheadDecoder<Mp3Huffman>> holder;
+    if (batcher) holder.emplace(*batcher, Mp3Huffman::Params{nch, ngr, sr}, lookahead, peek);
+    else holder.emplace(ctx, Mp3Huffman::Params{nch, ngr, sr}, lookahead, peek);
+    LookaheadDecoder<Mp3Huffman> &dec = *holder;
     std::vector<float> ov(nch * 576, 0.0f), vv(nch * 1024, 0.0f);
     std::vector<int32_t> vf(nch, 0);
     for (size_t i = 0; i < n; ++i) {
@@ -326,6 +339,50 @@ static void test_flac(Context &ctx, size_t lookahead, size_t nch, uint32_t bps) 
     }
 }
 
+// ---- many streams, one batcher: S AAC decoders called round-robin like a server's worker would; every buffer equals the
+// frame-by-frame decoder's, and the batcher ran far fewer launches than the decoders ran batches
+static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead) {
+    const size_t n = 37;
+    Batcher batcher(ctx);
+    struct Stream {
+        std::vector<AacLc::Packet> track;
+        size_t cursor = 0, nch = 2;
+        std::unique_ptr<LookaheadDecoder<AacLc>> dec;
+        std::unique_ptr<AacOracle> ref;
+    };
+    std::vector<std::unique_ptr<Stream>> streams;
+    for (size_t s = 0; s < n_streams; ++s) {
+        streams.emplace_back(new Stream());
+        Stream *st = streams.back().get();
+        st->nch = 1 + s % 2;
+        st->track = aac_track(n, st->nch, 900 + (unsigned)s);
+        st->dec.reset(new LookaheadDecoder<AacLc>(batcher, AacLc::Params{st->nch}, lookahead, [st]() -> std::optional<AacLc::Packet> {
+            if (st->cursor >= st->track.size()) return std::nullopt;
+            return st->track[st->cursor++];
+        }));
+        st->ref.reset(new AacOracle(st->nch));
+    }
+    size_t batches = 0;
+    for (size_t i = 0; i < n; ++i)
+        for (auto &up : streams) {
+            Stream &st = *up;
+            if (st.cursor <= i) st.cursor = i + 1;
+            const AudioBufferRef &buf = st.dec->decode(st.track[i]);
+            const std::vector<float> want = st.ref->decode(st.track[i]);
+            for (size_t c = 0; c < st.nch; ++c)
+                EXPECT(same_bits(buf.planes[c], want.data() + c * 1024, 1024), "cross-stream S=%zu K=%zu packet %zu differs", n_streams, lookahead, i);
+        }
+    for (auto &up : streams) batches += up->dec->batches_run();
+    const symaccel_batcher_stats stats = batcher.stats();
+    EXPECT(stats.submissions >= batches, "submissions %llu < batches %zu", (unsigned long long)stats.submissions, batches);
+    if (lookahead >= 4 && n_streams >= 4)
+        EXPECT(stats.launches * 2 <= stats.submissions, "the batcher did not coalesce: %llu launches for %llu submissions", (unsigned long long)stats.launches,
+               (unsigned long long)stats.submissions);
+    std::printf("cross-stream S=%zu K=%zu: %llu submissions in %llu launches (largest: %llu chains)\n", n_streams, lookahead,
+                (unsigned long long)stats.submissions, (unsigned long long)stats.launches, (unsigned long long)stats.max_chains_per_launch);
+    streams.clear();  // (decoders release their tickets before the batcher goes)
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && std::strcmp(argv[1], "--expect-no-device") == 0) {
         try {
@@ -346,6 +403,15 @@ int main(int argc, char **argv) {
     for (size_t k : {size_t(1), size_t(4), size_t(32)}) test_flac(ctx, k, 2, 16);
     test_flac(ctx, 5, 1, 24);
     test_flac(ctx, 7, 3, 20);
+    {  // the same single-stream scripts (seek, discontinuity) through the cross-stream batcher
+        Batcher batcher(ctx);
+        for (size_t k : {size_t(1), size_t(4), size_t(9), size_t(64)}) test_aac(ctx, k, &batcher);
+        for (size_t k : {size_t(1), size_t(3), size_t(8)}) test_mp3(ctx, k, &batcher);
+        for (size_t k : {size_t(1), size_t(6)}) test_mp3_huffman(ctx, k, &batcher);
+    }
+    test_cross_stream(ctx, 1, 8);
+    test_cross_stream(ctx, 7, 8);
+    test_cross_stream(ctx, 16, 3);
     if (g_failures == 0) std::printf("all checks passed\n");
     return g_failures ? 1 : 0;
 }

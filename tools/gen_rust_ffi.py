@@ -17,7 +17,7 @@ OUT = ROOT / "bindings" / "rust" / "symaccel_sys.rs"
 
 SCALARS = {"int": "i32", "double": "f64", "float": "f32", "size_t": "usize", "int32_t": "i32", "uint32_t": "u32",
            "int16_t": "i16", "uint16_t": "u16", "uint8_t": "u8", "int8_t": "i8", "uint64_t": "u64", "int64_t": "i64", "char": "core::ffi::c_char", "void": "core::ffi::c_void"}
-SIZES = {"core::ffi::c_char": 1, "u8": 1, "i8": 1, "u64": 8, "i64": 8, "i16": 2, "u16": 2, "i32": 4, "u32": 4, "f32": 4, "f64": 8}
+SIZES = {"usize": 8, "core::ffi::c_char": 1, "u8": 1, "i8": 1, "u64": 8, "i64": 8, "i16": 2, "u16": 2, "i32": 4, "u32": 4, "f32": 4, "f64": 8}
 
 
 # records that hold function pointers (the generator only understands scalar fields)
@@ -72,8 +72,11 @@ def parse(text):
             first, *rest = [n.strip() for n in (decl.split(" ", 1)[1]).split(",")]
             ctype = decl.split(" ", 1)[0]
             for n in [first] + rest:
+                ft = ctype
+                while n.startswith("*"):  # `void *in[4]`: a pointer field
+                    ft, n = ft + " *", n[1:].strip()
                 am = re.fullmatch(r"(\w+)\[(\d+)\]", n)
-                fields.append((am.group(1), ctype, int(am.group(2))) if am else (n, ctype, None))
+                fields.append((am.group(1), ft, int(am.group(2))) if am else (n, ft, None))
         structs.append((m.group(3), fields))
     funcs = []
     for m in re.finditer(r"^(int|void|const char \*)\s*(symaccel_\w+)\(([^;{]*?)\);", text, flags=re.S | re.M):
@@ -95,7 +98,7 @@ def parse(text):
 def struct_size(fields):
     size, align = 0, 1
     for _, ctype, count in fields:
-        s = SIZES[SCALARS[ctype]]
+        s = 8 if ctype.endswith("*") else SIZES[SCALARS[ctype]]
         align = max(align, s)
         size = (size + s - 1) // s * s + s * (count or 1)
     return (size + align - 1) // align * align
@@ -107,14 +110,15 @@ def generate():
            "// Raw FFI of libsymaccel for a `symphonia-accel-hip` shim crate (INTEGRATION.md section 2).",
            "// Not compiled in the repository's image (no Rust toolchain); checked structurally by tests/test_bindings.py.",
            "#![allow(non_camel_case_types, dead_code)]", "",
-           "#[repr(C)]", "pub struct SymaccelCtx {", "    _private: [u8; 0],", "}", ""]
+           "#[repr(C)]", "pub struct SymaccelCtx {", "    _private: [u8; 0],", "}", "",
+           "#[repr(C)]", "pub struct SymaccelBatcher {", "    _private: [u8; 0],", "}", ""]
     for name, value in enums + consts:
         out.append("pub const %s: %s = %d;" % (name, "i32" if value < 0 or name.startswith("SYMACCEL_ERR") or name == "SYMACCEL_OK" else "u32", value))
     out.append("")
     for name, fields in structs:
         out += ["#[repr(C)]", "#[derive(Clone, Copy)]", "pub struct %s {" % camel(name)]
         for fname, ctype, count in fields:
-            rt = SCALARS[ctype]
+            rt = rust_type(ctype) if ctype.endswith("*") else SCALARS[ctype]
             out.append("    pub %s: %s," % (fname, "[%s; %d]" % (rt, count) if count else rt))
         out += ["}", "const _: () = assert!(core::mem::size_of::<%s>() == %d);" % (camel(name), struct_size(fields)), ""]
     out += CALLBACK_STRUCTS
