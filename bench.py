@@ -716,7 +716,8 @@ def copy_ceiling(ctx, torch, seg_len, reps=10):
     out = {"bytes_read": nbytes, "bytes_written": nbytes, "unit": "GB/s", "reps": reps}
     for key, fpw, flags in (("plain_float4", 0, 0), ("plain_float4_nt", 0, 1), ("frames_per_wavefront_1_nt", 1, 1),
                             ("frames_per_wavefront_%d_nt" % seg_len, seg_len, 1), ("frames_per_wavefront_%d" % seg_len, seg_len, 0),
-                            ("frames_per_workgroup_walk_%d_nt" % (4 * seg_len), seg_len, 9)):
+                            ("frames_per_workgroup_walk_%d_nt" % (4 * seg_len), seg_len, 9),
+                            ("frames_per_workgroup_walk_%d_window_major_nt" % (4 * seg_len), seg_len, 9 | 32)):
         for _ in range(reps):  # (untimed: the same sustained state as the headline's timed region)
             ctx._call(d.symaccel_probe_copy_device, a.data_ptr(), b.data_ptr(), nbytes, fpw, flags)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -889,6 +890,71 @@ def host_to_host_mp3(sa, ctx, torch, nch, ngr, granules, reps=3):
     return out
 
 
+def decoders_workload(quick=False, seconds_cpu=3.0, lookahead=64):
+    """Trait-level throughput (`--workload decoders`, and a short form in the default line's `other_workloads`): S AAC-LC stereo
+    streams decoded packet by packet through the compiled C++ twin of the shim's decoders (codecs::LookaheadDecoder,
+    include/symaccel.hpp; tools/decoders_bench.cpp) with ONE process-wide cross-stream batcher (symaccel_batcher_*,
+    csrc/batcher.cpp) -- host memory in, host memory out, T = min(S, cores) caller threads -- beside the CPU port decoding the same
+    packets frame by frame on the same number of threads (oracle/bench_mt.c: one so_aac_synth call per packet and channel, what
+    AudioDecoder::decode_ref does per call, codecs/audio.rs:279-297) and beside the decoders batching per stream (no batcher).
+    PCIe-inclusive by construction: never the headline `value`."""
+    import subprocess
+    import oracle
+    from symphonia_amd import build as sa_build
+    exe = sa_build.build_decoders_bench()
+    cores = usable_cores()
+    rng = np.random.default_rng(0)
+    sweep = [256] if quick else [1, 4, 16, 64, 256, 1024]
+    packets = 256 if quick else 512
+    out = {"harness": "tools/decoders_bench.cpp (g++, links libsymaccel.so only)", "lookahead": lookahead, "cores": cores, "sweep": []}
+
+    def run(codec, streams, threads, per_stream=False, pk=packets):
+        cmd = [str(exe), "--codec", codec, "--streams", str(streams), "--lookahead", str(lookahead), "--packets", str(pk), "--threads", str(threads)]
+        if per_stream:
+            cmd.append("--per-stream")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    def cpu(threads):
+        in0 = rng.standard_normal((2, 1, 1024)).astype(np.float32)
+        in0[:, :, 672:] = 0.0
+        in1 = np.full((2, 1), oracle.aac_side(0, 1, 1), np.uint8)
+        dt, reps = oracle.bench_mt("aac", threads, seconds_cpu, in0, in1, native=True, n_chains=2, per_chain=1)
+        return reps / dt
+    cpu_cache = {}
+    for s_ in sweep:
+        t_ = max(1, min(s_, cores))
+        if t_ not in cpu_cache:
+            cpu_cache[t_] = cpu(t_)
+        g = run("aac", s_, t_, pk=packets if s_ <= 256 else 128)
+        row = {"streams": s_, "threads": t_, "gpu_batcher": g, "cpu_port_packets_per_s": cpu_cache[t_],
+               "gpu_over_cpu": (g.get("packets_per_s", 0.0) / cpu_cache[t_]) if "error" not in g else None}
+        if not quick and s_ in (16, 256):
+            row["gpu_per_stream_batches"] = run("aac", s_, t_, per_stream=True, pk=128)
+        out["sweep"].append(row)
+        log("decoders: S = %d done" % s_)
+    if not quick:
+        out["mp3_int16_S256"] = run("mp3h", 256, max(1, min(256, cores)))
+        out["mp3_f32_S256"] = run("mp3", 256, max(1, min(256, cores)))
+        in0 = rng.standard_normal((16, 32, 1024)).astype(np.float32)
+        in0[:, :, 672:] = 0.0
+        in1 = np.full((16, 32), oracle.aac_side(0, 1, 1), np.uint8)
+        dt, reps = oracle.bench_mt("aac_simd", cores, seconds_cpu, in0, in1, native=True, n_chains=16, per_chain=32)
+        out["cpu_port_across_streams_simd_packets_per_s"] = 8 * 32 * reps / dt
+        out["cpu_port_across_streams_simd_note"] = ("oracle/cpu_simd.c on %d threads: 16 chains (8 stereo streams) per vector, 32 frames per call -- "
+                                                    "a CPU decoder would need the same cross-stream batcher to run this schedule" % cores)
+    best = max((r for r in out["sweep"] if "error" not in r["gpu_batcher"]), key=lambda r: r["gpu_batcher"]["packets_per_s"], default=None)
+    if best:
+        out["best"] = {"streams": best["streams"], "packets_per_s": best["gpu_batcher"]["packets_per_s"], "gpu_over_cpu": best["gpu_over_cpu"]}
+        over = [r["streams"] for r in out["sweep"] if r["gpu_over_cpu"] and r["gpu_over_cpu"] > 1.0]
+        out["gpu_overtakes_cpu_port_from_streams"] = min(over) if over else None
+    out["note"] = ("packets/s through decode(): one packet = one AAC-LC stereo frame (2 x 1024 lines in, 2 x 1024 samples out, f32); the CPU port "
+                   "runs native (-O3 -march=native) frame by frame on the same number of threads")
+    return out
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` with no launcher in the environment: start N ranks ourselves (one process per GPU) with
     torch.distributed.run on the loopback address and hand its exit status back.  (The driver may also start the ranks
@@ -926,7 +992,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2", "vorbisf", "vorbisf2", "aacjs", "aacjs2"])
+    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2", "vorbisf", "vorbisf2", "aacjs", "aacjs2", "decoders"])
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -958,6 +1024,16 @@ def main():
     if args.selftest_multi:
         from symphonia_amd.selftest import multi_selftest
         print(json.dumps({"selftest_multi": multi_selftest(args.selftest_multi)}), flush=True)
+        return
+    if args.workload == "decoders":
+        # (host memory in -> host memory out through the C++ twin of the shim's decoders: its own harness, its own JSON)
+        d = decoders_workload()
+        best = d.get("best") or {}
+        print(json.dumps({"metric": "decoded packets/sec through AudioDecoder-shaped decode() (host memory in and out, cross-stream batcher)",
+                          "value": best.get("packets_per_s"), "unit": "packets/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": "S AAC-LC 48 kHz stereo streams x look-ahead %d through codecs::LookaheadDecoder + "
+                                                          "symaccel_batcher, S = %s" % (d["lookahead"], best.get("streams"))},
+                          "vs_baseline": None, "decoders": d}), flush=True)
         return
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")

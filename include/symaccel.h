@@ -669,6 +669,9 @@ int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_c
 int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket);
 /* launch everything pending now (nobody has to wait for it) */
 int symaccel_batcher_flush(symaccel_batcher *b);
+/* "results will be wanted soon": launch the pending groups that are worth a launch of their own (4 MiB of input, or flush_bytes / 8),
+ * leave smaller ones to grow -- what a decoder calls when a quarter of its current batch is left */
+int symaccel_batcher_hint(symaccel_batcher *b);
 /* bytes per chain of every plane of a kind (per submission for MP3_DECODE's input[3]); unused planes 0 */
 int symaccel_batcher_plane_bytes(int kind, size_t units_per_chain, size_t *input_bytes, size_t *state_bytes, size_t *out_bytes); /* [4], [3] */
 int symaccel_batcher_get_stats(symaccel_batcher *b, symaccel_batcher_stats *out);
@@ -738,7 +741,8 @@ int symaccel_multi_set_transport(const symaccel_transport *transport);
  * chain.  flags bit 0: non-temporal loads and stores (what the synthesis kernels use); bits 1-2 (k > 0 only): 0 copy, 1 read
  * only, 2 write only; bit 3 (k > 0 only): the four wavefronts of a workgroup share 4 k consecutive frames round-robin
  * (16 KiB contiguous per workgroup and step); bit 4: eight wavefronts (two neighbouring workgroups) share 8 k frames, bits 3 + 4:
- * sixteen.  Not part of any decode path. */
+ * sixteen; bit 5 (with bit 3 alone, copy): the workgroup walk over a window-major layout, [step][workgroup][4 frames] -- the grid-wide
+ * footprint of a step is one contiguous window.  Not part of any decode path. */
 int symaccel_probe_copy_device(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes,
                                uint32_t frames_per_wavefront, uint32_t flags);
 

@@ -91,6 +91,7 @@ public:
     symaccel_batcher *raw() const { return b_; }
     Context &context() const { return ctx_; }
     void flush() { check(symaccel_batcher_flush(b_), ctx_.raw()); }
+    void hint() { check(symaccel_batcher_hint(b_), ctx_.raw()); }
     symaccel_batcher_stats stats() const {
         symaccel_batcher_stats s{};
         check(symaccel_batcher_get_stats(b_, &s), ctx_.raw());
@@ -554,7 +555,7 @@ public:
             if (!next_live_ && 2 * left <= ready_.size()) submit_ahead();
             if (next_live_ && !hinted_ && 4 * left <= ready_.size()) {
                 hinted_ = true;
-                batcher_->flush();
+                batcher_->hint();
             }
         }
         return last_;

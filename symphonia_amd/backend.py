@@ -48,8 +48,14 @@ class Context:
         self.lib.check(self.lib.dll.symaccel_ctx_create(int(device), C.byref(h)))
         self.handle = h
         self.device = device
+        self._batchers = []  # weak references: a batcher must go before its context does
 
     def close(self):
+        for ref in getattr(self, "_batchers", []):
+            b = ref()
+            if b is not None:
+                b.close()
+        self._batchers = []
         if getattr(self, "handle", None):
             self.lib.dll.symaccel_ctx_destroy(self.handle)
             self.handle = None
@@ -784,6 +790,8 @@ class Batcher:
         h = C.c_void_p()
         ctx.lib.check(self.dll.symaccel_batcher_create(ctx.handle, int(flush_bytes), C.byref(h)), ctx.handle)
         self.handle = h
+        import weakref
+        ctx._batchers.append(weakref.ref(self))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -25,7 +25,7 @@ CSRC = HERE / "csrc"
 OUT = HERE / "libsymaccel.so"
 TUNED_OUT = HERE / "build" / "tuned" / "libsymaccel.so"
 SOURCES = ["tables.cpp", "ctx.cpp", "host_tools.cpp", "stage.cpp", "batcher.cpp", "multi.cpp", "imdct_generic.hip", "imdct_big.hip", "aac.hip", "aac_tools.hip", "mp3.hip", "mpa_polyphase.hip", "mp3_requant.hip",
-           "mp3_stereo.hip", "vorbis.hip", "vorbis_wave.hip", "vorbis_wave2.hip", "vorbis_wg.hip", "flac.hip", "alac.hip", "state_copy.hip", "probe.hip"]
+           "mp3_stereo.hip", "vorbis.hip", "vorbis_wave.hip", "vorbis_wave2.hip", "vorbis_wg.hip", "flac.hip", "alac.hip", "state_copy.hip", "batch_copy.hip", "probe.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-missing-braces"]
@@ -138,5 +138,25 @@ def build(force=False, verbose=False, save_temps=False):
     return out
 
 
+DECODERS_BENCH = HERE / "build" / "decoders_bench"
+
+
+def build_decoders_bench(force=False):
+    """tools/decoders_bench.cpp: S streams through codecs::LookaheadDecoder and the cross-stream batcher, host memory in -> host
+    memory out (`bench.py --workload decoders` runs it).  g++ against the built libsymaccel.so; the binary sits beside the objects
+    (it travels to the GPU box with them) and finds the library through an $ORIGIN-relative rpath."""
+    so = build()
+    root = HERE.parent
+    srcs = [root / "tools" / "decoders_bench.cpp", root / "include" / "symaccel.hpp", root / "include" / "symaccel.h"]
+    if not force and DECODERS_BENCH.exists() and all(DECODERS_BENCH.stat().st_mtime >= p.stat().st_mtime for p in srcs + [so]):
+        return DECODERS_BENCH
+    DECODERS_BENCH.parent.mkdir(parents=True, exist_ok=True)
+    cxx = shutil.which("g++") or "g++"
+    subprocess.run([cxx, "-std=c++17", "-O2", "-Wall", "-I", str(root / "include"), str(srcs[0]), "-o", str(DECODERS_BENCH), "-L", str(so.parent),
+                    "-lsymaccel", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib", "-pthread"], check=True)
+    return DECODERS_BENCH
+
+
 if __name__ == "__main__":
+    print(build_decoders_bench(force="--force" in sys.argv))
     print(build(force="--force" in sys.argv, verbose=True, save_temps="--save-temps" in sys.argv))

@@ -86,6 +86,38 @@ bool plane_sizes(int kind, size_t units, PlaneSizes *ps) {
 
 size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+size_t in_bytes_per_chain(const PlaneSizes &ps) {
+    size_t s = 0;
+    for (int i = 0; i < ps.n_in; ++i)
+        if (!ps.in_per_ticket[i]) s += ps.in[i];
+    return s;
+}
+
+// a submission's page-locked slot: [in 0 | .. | state 0 | .. | out], every plane on a 256-byte boundary
+struct SlotLayout {
+    size_t in[kMaxIn] = {}, state[kMaxState] = {}, out = 0, bytes = 0;
+    size_t in_bytes[kMaxIn] = {}, state_bytes[kMaxState] = {}, out_bytes = 0;
+};
+SlotLayout slot_layout(const PlaneSizes &ps, size_t n_chains) {
+    SlotLayout l;
+    size_t off = 0;
+    for (int i = 0; i < ps.n_in; ++i) {
+        l.in[i] = off;
+        l.in_bytes[i] = ps.in[i] * (ps.in_per_ticket[i] ? 1 : n_chains);
+        off += round256(l.in_bytes[i]);
+    }
+    for (int i = 0; i < ps.n_state; ++i) {
+        l.state[i] = off;
+        l.state_bytes[i] = ps.state[i] * n_chains;
+        off += round256(l.state_bytes[i]);
+    }
+    l.out = off;
+    l.out_bytes = ps.out * n_chains;
+    off += round256(l.out_bytes);
+    l.bytes = off;
+    return l;
+}
+
 struct Group;
 
 struct Ticket {
@@ -93,6 +125,8 @@ struct Ticket {
     uint32_t gen = 0;
     uint32_t first_chain = 0, n_chains = 0, ordinal = 0;
     bool live = false, committed = false;
+    char *slot = nullptr;  // page-locked, slot_layout(group's planes, n_chains)
+    size_t slot_bytes = 0;
     // copy form (symaccel_batcher_submit): where collect() puts the results
     void *user_state[kMaxState] = {nullptr, nullptr, nullptr};
     void *user_out = nullptr;
@@ -100,23 +134,24 @@ struct Ticket {
 
 enum class GroupState { Free, Open, Closed, Launched };
 
+// One launch: the submissions of one shape that were pending together.  Host side: the submissions' own slots.  Device side: one
+// allocation, cut at launch time (when the number of chains is known) and kept with the group object for the next launch it serves.
 struct Group {
     int kind = 0, param = 0;
     size_t units = 0;
     PlaneSizes ps;
-    size_t cap_chains = 0, cap_tickets = 0;
+    size_t cap_chains = 0;  // reservations accepted before the group is launched and a fresh one opened
     size_t chains = 0, tickets = 0, uncommitted = 0, live = 0;
     GroupState state = GroupState::Free;
     int status = SYMACCEL_OK;
-    std::vector<uint32_t> ticket_first;  // first chain of every submission, in order (chunk boundaries, the MP3 unit list)
-    std::vector<uint32_t> ticket_chains;
-    // page-locked staging and its device twin: one allocation each, planes carved out
-    char *h_base = nullptr, *d_base = nullptr;
-    size_t h_bytes = 0, d_bytes = 0;
-    char *h_in[kMaxIn] = {}, *h_state[kMaxState] = {}, *h_out = nullptr;
+    std::vector<uint32_t> ticket_ids;  // the submissions, in order (index into symaccel_batcher::tickets)
+    char *d_base = nullptr;
+    size_t d_bytes = 0;
     char *d_in[kMaxIn] = {}, *d_state_in[kMaxState] = {}, *d_state_out[kMaxState] = {}, *d_out = nullptr;
     int32_t *d_units = nullptr;  // MP3_DECODE: unit_chains of every chunk, relative to the chunk's first chain
-    int32_t *h_units = nullptr;  // (page-locked: the copy is asynchronous)
+    // page-locked: the copy descriptors of the launch (read by batch_copy_kernel straight from here) and the unit list
+    char *h_desc = nullptr;
+    size_t h_desc_bytes = 0;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, done = nullptr;
 };
 
@@ -132,91 +167,117 @@ struct symaccel_batcher {
     std::vector<uint32_t> free_tickets;
     symaccel_batcher_stats stats{};
     std::string last_error;
+    // page-locked slot memory: slabs, carved into slots by size; a released slot goes to the free list of its size (the shapes of a
+    // running service repeat: in the steady state nothing is allocated)
+    struct Slab {
+        char *base;
+        size_t bytes, used;
+    };
+    std::vector<Slab> slabs;
+    std::vector<std::pair<size_t, std::vector<char *>>> free_slots;
 };
 
 namespace {
 
-int group_alloc(symaccel_batcher *b, Group *g, size_t cap_chains) {
-    symaccel_ctx *ctx = b->ctx;
-    const PlaneSizes &ps = g->ps;
-    const size_t cap_tickets = cap_chains;  // a submission has at least one chain
-    size_t h_total = 0, d_total = 0;
-    size_t h_off_in[kMaxIn], h_off_state[kMaxState], h_off_out, d_off_in[kMaxIn], d_off_si[kMaxState], d_off_so[kMaxState], d_off_out;
-    for (int i = 0; i < ps.n_in; ++i) {
-        const size_t bytes = round256(ps.in[i] * (ps.in_per_ticket[i] ? cap_tickets : cap_chains));
-        h_off_in[i] = h_total;
-        h_total += bytes;
-        d_off_in[i] = d_total;
-        d_total += bytes;
-    }
-    for (int i = 0; i < ps.n_state; ++i) {
-        const size_t bytes = round256(ps.state[i] * cap_chains);
-        h_off_state[i] = h_total;
-        h_total += bytes;
-        d_off_si[i] = d_total;
-        d_total += bytes;
-        d_off_so[i] = d_total;
-        d_total += bytes;
-    }
-    h_off_out = h_total;
-    h_total += round256(ps.out * cap_chains);
-    d_off_out = d_total;
-    d_total += round256(ps.out * cap_chains);
-    const size_t units_bytes = round256(cap_tickets * 8);
-    const size_t h_units_off = h_total, d_units_off = d_total;
-    h_total += units_bytes;
-    d_total += units_bytes;
-    if (g->h_base) {
-        (void)hipHostFree(g->h_base);
-        g->h_base = nullptr;
-    }
-    if (g->d_base) {
-        (void)hipFree(g->d_base);
-        g->d_base = nullptr;
-    }
-    g->cap_chains = g->cap_tickets = 0;
-    void *h = nullptr, *d = nullptr;
-    if (hipHostMalloc(&h, h_total, hipHostMallocDefault) != hipSuccess) {
+constexpr size_t kSlabBytes = (size_t)32 << 20;
+
+int slot_alloc(symaccel_batcher *b, size_t bytes, char **out) {
+    for (auto &cls : b->free_slots)
+        if (cls.first == bytes && !cls.second.empty()) {
+            *out = cls.second.back();
+            cls.second.pop_back();
+            return SYMACCEL_OK;
+        }
+    for (auto &sl : b->slabs)
+        if (sl.bytes - sl.used >= bytes) {
+            *out = sl.base + sl.used;
+            sl.used += bytes;
+            return SYMACCEL_OK;
+        }
+    const size_t want = std::max(kSlabBytes, bytes);
+    void *h = nullptr;
+    DeviceGuard dev(b->ctx);
+    if (!dev.ok()) return dev.status();
+    if (hipHostMalloc(&h, want, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         return SYMACCEL_ERR_OOM;
     }
-    g->h_base = static_cast<char *>(h);
-    g->h_bytes = h_total;
-    SYM_TRY(ctx_alloc(ctx, &d, d_total, false));
-    g->d_base = static_cast<char *>(d);
-    g->d_bytes = d_total;
-    for (int i = 0; i < ps.n_in; ++i) {
-        g->h_in[i] = g->h_base + h_off_in[i];
-        g->d_in[i] = g->d_base + d_off_in[i];
-    }
-    for (int i = 0; i < ps.n_state; ++i) {
-        g->h_state[i] = g->h_base + h_off_state[i];
-        g->d_state_in[i] = g->d_base + d_off_si[i];
-        g->d_state_out[i] = g->d_base + d_off_so[i];
-    }
-    g->h_out = g->h_base + h_off_out;
-    g->d_out = g->d_base + d_off_out;
-    g->h_units = reinterpret_cast<int32_t *>(g->h_base + h_units_off);
-    g->d_units = reinterpret_cast<int32_t *>(g->d_base + d_units_off);
-    for (hipEvent_t *e : {&g->ev_in[0], &g->ev_in[1], &g->ev_k[0], &g->ev_k[1], &g->done})
-        if (!*e) SYM_GPU(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    g->cap_chains = cap_chains;
-    g->cap_tickets = cap_tickets;
+    b->slabs.push_back({static_cast<char *>(h), want, bytes});
+    b->stats.staging_bytes += want;
+    *out = static_cast<char *>(h);
     return SYMACCEL_OK;
 }
 
-void group_free(Group *g) {
-    if (g->h_base) (void)hipHostFree(g->h_base);
-    if (g->d_base) (void)hipFree(g->d_base);
-    for (hipEvent_t e : {g->ev_in[0], g->ev_in[1], g->ev_k[0], g->ev_k[1], g->done})
-        if (e) (void)hipEventDestroy(e);
-    g->h_base = g->d_base = nullptr;
+void slot_free(symaccel_batcher *b, char *p, size_t bytes) {
+    if (!p) return;
+    for (auto &cls : b->free_slots)
+        if (cls.first == bytes) {
+            cls.second.push_back(p);
+            return;
+        }
+    b->free_slots.push_back({bytes, {p}});
 }
 
-size_t in_bytes_per_chain(const PlaneSizes &ps) {
-    size_t s = 0;
-    for (int i = 0; i < ps.n_in; ++i) s += ps.in[i];
-    return s;
+void group_free(Group *g) {
+    if (g->d_base) (void)hipFree(g->d_base);
+    if (g->h_desc) (void)hipHostFree(g->h_desc);
+    for (hipEvent_t e : {g->ev_in[0], g->ev_in[1], g->ev_k[0], g->ev_k[1], g->done})
+        if (e) (void)hipEventDestroy(e);
+    g->d_base = nullptr;
+    g->h_desc = nullptr;
+}
+
+// the device side of a closed group: sized for the chains it holds, planes carved out; grown (never shrunk) across reuses
+int group_device(symaccel_batcher *b, Group *g, size_t n_pieces_bound) {
+    symaccel_ctx *ctx = b->ctx;
+    const PlaneSizes &ps = g->ps;
+    size_t total = 0, off_in[kMaxIn], off_si[kMaxState], off_so[kMaxState], off_out, off_units;
+    for (int i = 0; i < ps.n_in; ++i) {
+        off_in[i] = total;
+        total += round256(ps.in[i] * (ps.in_per_ticket[i] ? g->tickets : g->chains));
+    }
+    for (int i = 0; i < ps.n_state; ++i) {
+        off_si[i] = total;
+        total += round256(ps.state[i] * g->chains);
+        off_so[i] = total;
+        total += round256(ps.state[i] * g->chains);
+    }
+    off_out = total;
+    total += round256(ps.out * g->chains);
+    off_units = total;
+    total += round256(g->tickets * 8);
+    if (total > g->d_bytes) {
+        if (g->d_base) SYM_GPU(ctx, hipFree(g->d_base));
+        g->d_base = nullptr;
+        g->d_bytes = 0;
+        void *d = nullptr;
+        SYM_TRY(ctx_alloc(ctx, &d, total + total / 4, false));
+        g->d_base = static_cast<char *>(d);
+        g->d_bytes = total + total / 4;
+    }
+    for (int i = 0; i < ps.n_in; ++i) g->d_in[i] = g->d_base + off_in[i];
+    for (int i = 0; i < ps.n_state; ++i) {
+        g->d_state_in[i] = g->d_base + off_si[i];
+        g->d_state_out[i] = g->d_base + off_so[i];
+    }
+    g->d_out = g->d_base + off_out;
+    g->d_units = reinterpret_cast<int32_t *>(g->d_base + off_units);
+    const size_t desc_bytes = round256(n_pieces_bound * sizeof(BatchCopyDesc)) + round256(g->tickets * 8);
+    if (desc_bytes > g->h_desc_bytes) {
+        if (g->h_desc) (void)hipHostFree(g->h_desc);
+        g->h_desc = nullptr;
+        g->h_desc_bytes = 0;
+        void *h = nullptr;
+        if (hipHostMalloc(&h, desc_bytes + desc_bytes / 4, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return SYMACCEL_ERR_OOM;
+        }
+        g->h_desc = static_cast<char *>(h);
+        g->h_desc_bytes = desc_bytes + desc_bytes / 4;
+    }
+    for (hipEvent_t *e : {&g->ev_in[0], &g->ev_in[1], &g->ev_k[0], &g->ev_k[1], &g->done})
+        if (!*e) SYM_GPU(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return SYMACCEL_OK;
 }
 
 // the kernels of one chunk: chains [c0, c0 + nc), submissions [t0, t0 + nt)
@@ -243,50 +304,83 @@ int launch_chunk(symaccel_batcher *b, Group *g, size_t c0, size_t nc, size_t t0,
     }
 }
 
-// Everything of a closed group: chunked copies in, kernels, copies out; `done` is recorded behind the last copy out.
+size_t pieces_of(size_t bytes) { return (bytes + kBatchCopyPiece - 1) / kBatchCopyPiece; }
+
+void add_pieces(BatchCopyDesc *&w, const char *src, char *dst, size_t bytes) {
+    for (size_t o = 0; o < bytes; o += kBatchCopyPiece) {
+        w->src = src + o;
+        w->dst = dst + o;
+        w->bytes = (uint32_t)std::min(kBatchCopyPiece, bytes - o);
+        w->pad = 0;
+        ++w;
+    }
+}
+
+// Everything of a closed group: per chunk of submissions ONE gather launch (slots -> HBM, the kernels' chain-major layout), the
+// synthesis kernel, ONE scatter launch (HBM -> slots); `done` is recorded behind the last scatter.
 int launch_group_inner(symaccel_batcher *b, Group *g) {
     symaccel_ctx *ctx = b->ctx;
     const PlaneSizes &ps = g->ps;
     if (!ctx->stage_in) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_in));
     if (!ctx->stage_out) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_out));
     hipStream_t s_in = ctx->stage_in, s_out = ctx->stage_out;
-    const size_t per_chain = in_bytes_per_chain(ps);
-    // ~1/6 of the group per chunk, 2 .. 32 MiB of input: long enough copies for the link, enough chunks for the overlap
-    size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)2 << 20, g->chains * per_chain / 6));
-    size_t chunk_chains = std::max<size_t>(1, chunk_bytes / std::max<size_t>(1, per_chain));
-    // (MP3_DECODE: the unit_chains of every submission are relative to the first chain of the chunk it falls into)
+    // an upper bound of the copy pieces: every plane of every submission, rounded up
+    size_t bound = 0;
+    for (uint32_t id : g->ticket_ids) {
+        const Ticket &t = b->tickets[id];
+        for (int i = 0; i < ps.n_in; ++i) bound += pieces_of(ps.in[i] * (ps.in_per_ticket[i] ? 1 : t.n_chains));
+        for (int i = 0; i < ps.n_state; ++i) bound += 2 * pieces_of(ps.state[i] * t.n_chains);
+        bound += pieces_of(ps.out * t.n_chains);
+    }
+    bound += g->tickets + 8;  // (the unit list's pieces, one per chunk at most)
+    SYM_TRY(group_device(b, g, bound));
+    BatchCopyDesc *descs = reinterpret_cast<BatchCopyDesc *>(g->h_desc);
+    int32_t *h_units = reinterpret_cast<int32_t *>(g->h_desc + round256(bound * sizeof(BatchCopyDesc)));
+    BatchCopyDesc *w = descs;
+    const size_t per_chain = std::max<size_t>(1, in_bytes_per_chain(ps));
+    // ~1/6 of the group per chunk, 2 .. 32 MiB of input: long enough launches for the link, enough chunks for the overlap
+    const size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)2 << 20, g->chains * per_chain / 6));
+    const size_t chunk_chains = std::max<size_t>(1, chunk_bytes / per_chain);
     size_t t0 = 0, k = 0;
     while (t0 < g->tickets) {
-        const size_t c0 = g->ticket_first[t0];
+        const size_t c0 = b->tickets[g->ticket_ids[t0]].first_chain;
         size_t t1 = t0, nc = 0;
-        while (t1 < g->tickets && (nc == 0 || nc + g->ticket_chains[t1] <= chunk_chains)) nc += g->ticket_chains[t1++];
+        while (t1 < g->tickets && (nc == 0 || nc + b->tickets[g->ticket_ids[t1]].n_chains <= chunk_chains)) nc += b->tickets[g->ticket_ids[t1++]].n_chains;
         const size_t nt = t1 - t0;
         const int e = (int)(k & 1);
-        if (g->kind == SYMACCEL_BATCH_MP3_DECODE) {
-            for (size_t t = t0; t < t1; ++t) {
-                const int32_t rel = (int32_t)(g->ticket_first[t] - c0);
-                g->h_units[2 * t] = rel;
-                g->h_units[2 * t + 1] = g->ticket_chains[t] == 2 ? rel + 1 : -1;
+        // ---- gather: the submissions' planes into the chain-major device arrays
+        BatchCopyDesc *g0 = w;
+        for (size_t ti = t0; ti < t1; ++ti) {
+            const Ticket &t = b->tickets[g->ticket_ids[ti]];
+            const SlotLayout l = slot_layout(ps, t.n_chains);
+            for (int i = 0; i < ps.n_in; ++i)
+                add_pieces(w, t.slot + l.in[i], g->d_in[i] + (ps.in_per_ticket[i] ? ti : (size_t)t.first_chain) * ps.in[i], l.in_bytes[i]);
+            for (int i = 0; i < ps.n_state; ++i)
+                add_pieces(w, t.slot + l.state[i], g->d_state_in[i] + (size_t)t.first_chain * ps.state[i], l.state_bytes[i]);
+            if (g->kind == SYMACCEL_BATCH_MP3_DECODE) {  // (unit_chains are relative to the first chain of the chunk the submission falls into)
+                const int32_t rel = (int32_t)(t.first_chain - c0);
+                h_units[2 * ti] = rel;
+                h_units[2 * ti + 1] = t.n_chains == 2 ? rel + 1 : -1;
             }
-            SYM_GPU(ctx, hipMemcpyAsync(g->d_units + 2 * t0, g->h_units + 2 * t0, nt * 8, hipMemcpyHostToDevice, s_in));
         }
-        for (int i = 0; i < ps.n_in; ++i) {
-            const size_t first = ps.in_per_ticket[i] ? t0 : c0, n = ps.in_per_ticket[i] ? nt : nc;
-            if (ps.in[i] * n)
-                SYM_GPU(ctx, hipMemcpyAsync(g->d_in[i] + first * ps.in[i], g->h_in[i] + first * ps.in[i], ps.in[i] * n, hipMemcpyHostToDevice, s_in));
-        }
-        for (int i = 0; i < ps.n_state; ++i)
-            SYM_GPU(ctx, hipMemcpyAsync(g->d_state_in[i] + c0 * ps.state[i], g->h_state[i] + c0 * ps.state[i], ps.state[i] * nc,
-                                        hipMemcpyHostToDevice, s_in));
+        if (g->kind == SYMACCEL_BATCH_MP3_DECODE)
+            add_pieces(w, reinterpret_cast<const char *>(h_units + 2 * t0), reinterpret_cast<char *>(g->d_units + 2 * t0), nt * 8);
+        SYM_TRY(launch_batch_copy(ctx, s_in, g0, (size_t)(w - g0)));
         SYM_GPU(ctx, hipEventRecord(g->ev_in[e], s_in));
         SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, g->ev_in[e], 0));
         SYM_TRY(launch_chunk(b, g, c0, nc, t0, nt));
         SYM_GPU(ctx, hipEventRecord(g->ev_k[e], ctx->stream));
         SYM_GPU(ctx, hipStreamWaitEvent(s_out, g->ev_k[e], 0));
-        SYM_GPU(ctx, hipMemcpyAsync(g->h_out + c0 * ps.out, g->d_out + c0 * ps.out, ps.out * nc, hipMemcpyDeviceToHost, s_out));
-        for (int i = 0; i < ps.n_state; ++i)
-            SYM_GPU(ctx, hipMemcpyAsync(g->h_state[i] + c0 * ps.state[i], g->d_state_out[i] + c0 * ps.state[i], ps.state[i] * nc,
-                                        hipMemcpyDeviceToHost, s_out));
+        // ---- scatter: PCM and the state after the batch back into the submissions' slots
+        BatchCopyDesc *s0 = w;
+        for (size_t ti = t0; ti < t1; ++ti) {
+            const Ticket &t = b->tickets[g->ticket_ids[ti]];
+            const SlotLayout l = slot_layout(ps, t.n_chains);
+            add_pieces(w, g->d_out + (size_t)t.first_chain * ps.out, t.slot + l.out, l.out_bytes);
+            for (int i = 0; i < ps.n_state; ++i)
+                add_pieces(w, g->d_state_out[i] + (size_t)t.first_chain * ps.state[i], t.slot + l.state[i], l.state_bytes[i]);
+        }
+        SYM_TRY(launch_batch_copy(ctx, s_out, s0, (size_t)(w - s0)));
         b->stats.chunks += 1;
         t0 = t1;
         ++k;
@@ -306,15 +400,15 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
         DeviceGuard dev(b->ctx);
         st = dev.ok() ? launch_group_inner(b, g) : dev.status();
         if (st != SYMACCEL_OK) {
-            // a launch that failed half way: nothing of this group may still be in flight when its staging memory is reused, and the
+            // a launch that failed half way: nothing of this group may still be in flight when its slots are reused, and the
             // copy-out stream does not follow what the other two were left with -- drain all three (error path only)
             b->last_error = b->ctx->last_error;
             if (b->ctx->stage_in) (void)hipStreamSynchronize(b->ctx->stage_in);
             if (b->ctx->stream) (void)hipStreamSynchronize(b->ctx->stream);
             if (b->ctx->stage_out) (void)hipStreamSynchronize(b->ctx->stage_out);
         }
-        // `done` sits behind the last copy out, which follows the last kernel, which follows the last copy in
-        if (dev.ok() && b->ctx->stage_out) (void)hipEventRecord(g->done, b->ctx->stage_out);
+        // `done` sits behind the last scatter, which follows the last kernel, which follows the last gather
+        if (dev.ok() && b->ctx->stage_out && g->done) (void)hipEventRecord(g->done, b->ctx->stage_out);
     }
     g->status = st;
     g->state = GroupState::Launched;
@@ -330,38 +424,21 @@ Group *open_group(symaccel_batcher *b, int kind, int param, size_t units, const 
     for (auto &up : b->groups) {
         Group *g = up.get();
         if (g->state == GroupState::Open && g->kind == kind && g->param == param && g->units == units) return g;
-        if (g->state == GroupState::Free) {
-            const bool fits = g->kind == kind && g->units == units;
-            if (fits && !(spare && spare->kind == kind && spare->units == units && spare->cap_chains >= g->cap_chains)) spare = g;
-            if (!fits && !spare && b->groups.size() >= 8) spare = g;  // a pool of eight shapes: beyond that the stalest shape is re-cut
-        }
+        if (g->state == GroupState::Free && (!spare || g->d_bytes > spare->d_bytes)) spare = g;  // (the one with the most device memory)
     }
-    const size_t per_chain = std::max<size_t>(1, in_bytes_per_chain(ps));
-    const size_t want = std::max<size_t>(n_chains, std::max<size_t>(2, b->flush_bytes / per_chain));
     if (!spare) {
         b->groups.emplace_back(new Group());
         spare = b->groups.back().get();
     }
     Group *g = spare;
-    if (!(g->kind == kind && g->units == units && g->cap_chains >= want)) {
-        g->kind = kind;
-        g->units = units;
-        g->ps = ps;
-        b->stats.staging_bytes -= std::min<uint64_t>(b->stats.staging_bytes, g->h_bytes);
-        g->h_bytes = 0;
-        DeviceGuard dev(b->ctx);
-        *st = dev.ok() ? group_alloc(b, g, want) : dev.status();
-        if (*st != SYMACCEL_OK) {
-            g->kind = 0;
-            g->cap_chains = 0;
-            return nullptr;
-        }
-        b->stats.staging_bytes += g->h_bytes;
-    }
+    g->kind = kind;
+    g->units = units;
+    g->ps = ps;
     g->param = param;
+    // what a group takes before it is launched unasked: flush_bytes of input
+    g->cap_chains = std::max<size_t>(n_chains, std::max<size_t>(2, b->flush_bytes / std::max<size_t>(1, in_bytes_per_chain(ps))));
     g->chains = g->tickets = g->uncommitted = g->live = 0;
-    g->ticket_first.clear();
-    g->ticket_chains.clear();
+    g->ticket_ids.clear();
     g->status = SYMACCEL_OK;
     g->state = GroupState::Open;
     return g;
@@ -375,18 +452,18 @@ Ticket *find_ticket(symaccel_batcher *b, uint64_t id) {
 }
 
 void fill_slot(const Group *g, const Ticket *t, symaccel_batch_slot *slot) {
-    const PlaneSizes &ps = g->ps;
+    const SlotLayout l = slot_layout(g->ps, t->n_chains);
     std::memset(slot, 0, sizeof(*slot));
-    for (int i = 0; i < ps.n_in; ++i) {
-        slot->input[i] = g->h_in[i] + (ps.in_per_ticket[i] ? (size_t)t->ordinal : (size_t)t->first_chain) * ps.in[i];
-        slot->input_bytes[i] = ps.in[i] * (ps.in_per_ticket[i] ? 1 : t->n_chains);
+    for (int i = 0; i < g->ps.n_in; ++i) {
+        slot->input[i] = t->slot + l.in[i];
+        slot->input_bytes[i] = l.in_bytes[i];
     }
-    for (int i = 0; i < ps.n_state; ++i) {
-        slot->state[i] = g->h_state[i] + (size_t)t->first_chain * ps.state[i];
-        slot->state_bytes[i] = ps.state[i] * t->n_chains;
+    for (int i = 0; i < g->ps.n_state; ++i) {
+        slot->state[i] = t->slot + l.state[i];
+        slot->state_bytes[i] = l.state_bytes[i];
     }
-    slot->out = g->h_out + (size_t)t->first_chain * ps.out;
-    slot->out_bytes = ps.out * t->n_chains;
+    slot->out = t->slot + l.out;
+    slot->out_bytes = l.out_bytes;
 }
 
 }  // namespace
@@ -413,6 +490,7 @@ int symaccel_batcher_destroy(symaccel_batcher *b) {
         if (b->ctx->stream) (void)hipStreamSynchronize(b->ctx->stream);
         if (b->ctx->stage_out) (void)hipStreamSynchronize(b->ctx->stage_out);
         for (auto &g : b->groups) group_free(g.get());
+        for (auto &sl : b->slabs) (void)hipHostFree(sl.base);
     }
     delete b;
     return SYMACCEL_OK;
@@ -442,6 +520,13 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
         idx = (uint32_t)b->tickets.size();
         b->tickets.emplace_back();
     }
+    const SlotLayout lay = slot_layout(ps, n_chains);
+    char *mem = nullptr;
+    st = slot_alloc(b, lay.bytes, &mem);
+    if (st != SYMACCEL_OK) {
+        b->free_tickets.push_back(idx);
+        return st;
+    }
     Ticket *t = &b->tickets[idx];
     const uint32_t gen = t->gen + 1;
     *t = Ticket();
@@ -451,8 +536,9 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
     t->n_chains = (uint32_t)n_chains;
     t->ordinal = (uint32_t)g->tickets;
     t->live = true;
-    g->ticket_first.push_back(t->first_chain);
-    g->ticket_chains.push_back(t->n_chains);
+    t->slot = mem;
+    t->slot_bytes = lay.bytes;
+    g->ticket_ids.push_back(idx);
     g->chains += n_chains;
     g->tickets += 1;
     g->uncommitted += 1;
@@ -482,6 +568,19 @@ int symaccel_batcher_flush(symaccel_batcher *b) {
     std::unique_lock<std::mutex> lock(b->mu);
     for (size_t i = 0; i < b->groups.size(); ++i)  // (index loop: flush_group drops the lock while it waits for commits)
         if (b->groups[i]->state == GroupState::Open && b->groups[i]->tickets) flush_group(b, b->groups[i].get(), lock);
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_hint(symaccel_batcher *b) {
+    if (!b) return SYMACCEL_ERR_INVALID_ARG;
+    std::unique_lock<std::mutex> lock(b->mu);
+    // "results will be wanted soon": whatever is worth a launch of its own goes now, so that the copies and the kernels run while
+    // the callers are still busy with their current batches; a group below that size waits for more submissions (or for a waiter)
+    const size_t worth = std::min<size_t>((size_t)4 << 20, b->flush_bytes / 8);
+    for (size_t i = 0; i < b->groups.size(); ++i) {
+        Group *g = b->groups[i].get();
+        if (g->state == GroupState::Open && g->tickets && g->chains * in_bytes_per_chain(g->ps) >= worth) flush_group(b, g, lock);
+    }
     return SYMACCEL_OK;
 }
 
@@ -523,21 +622,30 @@ int symaccel_batcher_release(symaccel_batcher *b, uint64_t ticket) {
         g->uncommitted -= 1;
         if (g->uncommitted == 0) b->cv.notify_all();
     }
+    // The slot goes back to the pool -- but the group's copies may still be reading or writing it (a release without a wait, or
+    // before the launch): the group is launched if it has not been, and drained, first.  (The common order -- wait, read, release --
+    // finds the event signalled.)
+    if (g->state == GroupState::Open) flush_group(b, g, lock);
+    b->cv.wait(lock, [&] { return g->state == GroupState::Launched; });
+    t = find_ticket(b, ticket);  // (the table may have grown while the lock was dropped)
+    if (!t) return SYMACCEL_ERR_INVALID_ARG;
+    if (g->tickets && g->done) {
+        hipEvent_t done = g->done;
+        lock.unlock();
+        {
+            DeviceGuard dev(b->ctx);
+            if (dev.ok()) (void)hipEventSynchronize(done);
+        }
+        lock.lock();
+        t = find_ticket(b, ticket);
+        if (!t) return SYMACCEL_ERR_INVALID_ARG;
+    }
+    slot_free(b, t->slot, t->slot_bytes);
+    t->slot = nullptr;
     t->live = false;
     b->free_tickets.push_back((uint32_t)(ticket & 0xffffffffu));
     g->live -= 1;
-    if (g->live == 0) {
-        if (g->state == GroupState::Open) flush_group(b, g, lock);  // (its submissions were all abandoned: still a defined state)
-        b->cv.wait(lock, [&] { return g->state == GroupState::Launched; });
-        if (g->live == 0 && g->state == GroupState::Launched) {
-            // released without a wait (or after one): either way nothing of the group may be in flight when it is reused
-            if (g->tickets && g->done) {
-                DeviceGuard dev(b->ctx);
-                if (dev.ok()) (void)hipEventSynchronize(g->done);
-            }
-            g->state = GroupState::Free;
-        }
-    }
+    if (g->live == 0 && g->state == GroupState::Launched) g->state = GroupState::Free;
     return SYMACCEL_OK;
 }
 

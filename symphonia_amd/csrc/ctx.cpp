@@ -1337,7 +1337,7 @@ int symaccel_probe_copy_device(symaccel_ctx *ctx, const void *d_src, void *d_dst
                                uint32_t flags) {
     if (!ctx) return SYMACCEL_ERR_INVALID_ARG;
     if (bytes == 0) return SYMACCEL_OK;
-    if (!d_src || !d_dst || bytes % 4096 != 0 || ((uintptr_t)d_src | (uintptr_t)d_dst) % 16 != 0 || flags > 31u || ((flags >> 1) & 3u) == 3u)
+    if (!d_src || !d_dst || bytes % 4096 != 0 || ((uintptr_t)d_src | (uintptr_t)d_dst) % 16 != 0 || flags > 63u || ((flags >> 1) & 3u) == 3u)
         return SYMACCEL_ERR_INVALID_ARG;
     const uintptr_t a = (uintptr_t)d_src, b = (uintptr_t)d_dst;
     if (a < b + bytes && b < a + bytes) return SYMACCEL_ERR_INVALID_ARG;  // overlapping buffers

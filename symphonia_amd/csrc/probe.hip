@@ -22,7 +22,9 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const float4 *__restric
 // MODE 0 copy, 1 read only (the values feed a compare that never holds), 2 write only.  GROUP 1: a wavefront streams `per_wave`
 // consecutive frames; GROUP 4: the four wavefronts of a workgroup share 4 * per_wave consecutive frames and take them
 // round-robin (wave j: frames j, j + 4, ...), so that a workgroup's accesses of one step are 16 KiB contiguous; GROUP 8 / 16: the same
-// over the wavefronts of two / four neighbouring workgroups (32 / 64 KiB per step).
+// over the wavefronts of two / four neighbouring workgroups (32 / 64 KiB per step).  GROUP -4: the workgroup walk over a WINDOW-MAJOR
+// layout, [step][workgroup][4 frames] instead of [workgroup][step][4 frames]: the grid-wide footprint of one step is ONE contiguous
+// window (resident workgroups x 16 KiB) instead of as many 16 KiB pieces a segment apart -- the layout question of VERDICT r4 item 4b.
 template <bool NT, int MODE, int GROUP>
 __global__ __launch_bounds__(256) void probe_copy_frames_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t frames,
                                                                 unsigned per_wave) {
@@ -30,7 +32,9 @@ __global__ __launch_bounds__(256) void probe_copy_frames_kernel(const float4 *__
     const unsigned lane = threadIdx.x & 63u;
     float acc = 0.0f;
     for (unsigned f = 0; f < per_wave; ++f) {
-        const size_t fr = GROUP == 1 ? wave * per_wave + f : ((wave / GROUP) * per_wave + f) * GROUP + wave % GROUP;
+        const size_t fr = GROUP == 1    ? wave * per_wave + f
+                          : GROUP == -4 ? ((size_t)f * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)
+                                        : ((wave / GROUP) * per_wave + f) * GROUP + wave % GROUP;
         if (fr >= frames) break;
         const float4 *s = in + fr * 256;
         float4 *d = out + fr * 256;
@@ -56,6 +60,8 @@ __global__ __launch_bounds__(256) void probe_copy_frames_kernel(const float4 *__
 int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, unsigned frames_per_wavefront, unsigned flags) {
     const bool nt = (flags & 1u) != 0;
     const unsigned mode = (flags >> 1) & 3u, group = (flags & 24u) == 24u ? 16u : ((flags & 16u) ? 8u : ((flags & 8u) ? 4u : 1u));
+    const bool window = (flags & 32u) != 0;  // (with the workgroup walk, group 4, plain copy)
+    if (window && (group != 4 || mode != 0 || frames_per_wavefront == 0)) return SYMACCEL_ERR_INVALID_ARG;
     const float4 *in = static_cast<const float4 *>(d_src);
     float4 *out = static_cast<float4 *>(d_dst);
     if (frames_per_wavefront == 0) {
@@ -74,7 +80,9 @@ int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t 
     hipLaunchKernelGGL((probe_copy_frames_kernel<NT, MODE, GROUP>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, in, out, frames, frames_per_wavefront)
 #define SYM_PROBE_G(NT, MODE) do { if (group == 16) SYM_PROBE(NT, MODE, 16); else if (group == 8) SYM_PROBE(NT, MODE, 8); else if (group == 4) SYM_PROBE(NT, MODE, 4); else SYM_PROBE(NT, MODE, 1); } while (0)
 #define SYM_PROBE_M(NT) do { if (mode == 0) SYM_PROBE_G(NT, 0); else if (mode == 1) SYM_PROBE_G(NT, 1); else SYM_PROBE_G(NT, 2); } while (0)
-        if (nt) SYM_PROBE_M(true); else SYM_PROBE_M(false);
+        if (window) {
+            if (nt) SYM_PROBE(true, 0, -4); else SYM_PROBE(false, 0, -4);
+        } else if (nt) SYM_PROBE_M(true); else SYM_PROBE_M(false);
 #undef SYM_PROBE_M
 #undef SYM_PROBE_G
 #undef SYM_PROBE

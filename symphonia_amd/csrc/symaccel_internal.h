@@ -278,6 +278,14 @@ int launch_tns_status(symaccel_ctx *ctx, const symaccel_aac_tns_filter *d_filter
 int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
                         const int32_t *d_coeffs, size_t n_blocks, size_t blocksize, const uint8_t *d_pair_mode = nullptr,
                         uint32_t out_shift = 0);
+// batch_copy.hip: one piece (<= kBatchCopyPiece bytes) per workgroup, host (page-locked) <-> device in either direction
+struct BatchCopyDesc {
+    const void *src;
+    void *dst;
+    uint32_t bytes, pad;
+};
+constexpr size_t kBatchCopyPiece = 16384;
+int launch_batch_copy(symaccel_ctx *ctx, hipStream_t stream, const BatchCopyDesc *descs, size_t n);
 int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, unsigned frames_per_wavefront, unsigned flags);
 int launch_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *d_mode, int32_t *d_ch0, int32_t *d_ch1,
                             size_t n_pairs, size_t blocksize, uint32_t out_shift);

@@ -699,8 +699,9 @@ int launch_vorbis(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const float *d_sp
                             SYM_VORBIS_WAVE2;
     // long blocks of 8192 samples: the workgroup-cooperative kernel (vorbis_wg.hip), two workgroups resident per CU.  (SYM_VORBIS_WG 2
     // sends the 4096-sample pairs there as well: measured slower than the one-wavefront-per-block form, 2.0 against 2.2 TB/s -- only
-    // two of its four wavefronts have a sub-transform to do.  The 4096 / 8192 pair would need both block routines in one kernel.)
-    const bool wg_path = wave2_path && !(bs0_exp == 12 && bs1_exp == 13) && ((bs1_exp == 13 && SYM_VORBIS_WG) || (bs1_exp == 12 && SYM_VORBIS_WG == 2));
+    // two of its four wavefronts have a sub-transform to do.  The 4096 / 8192 pair runs BOTH cooperative block routines in one
+    // instantiation, <FUSED, 13, 2>: 142 VGPRs, no scratch, three workgroups per CU.)
+    const bool wg_path = wave2_path && ((bs1_exp == 13 && SYM_VORBIS_WG) || (bs1_exp == 12 && SYM_VORBIS_WG == 2));
     const unsigned seg = choose_segment(ctx, n_chains, nb, wg_path ? (SYM_VORBIS_WG_SHARED ? 3 : 2) : (wave2_path && bs1_exp <= 10 ? 12 : (wave2_path && bs1_exp == 13 ? 6 : ((wave_path || wave2_path) ? 8 : (bs1_exp > 11 ? 2 : 8)))), 1, 1, 1);
     const size_t segs = (nb + seg - 1) / seg;
     const size_t grid = n_chains * segs;

@@ -704,18 +704,30 @@ int launch_vorbis_wave2(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *
         SYM_VW2_MODES(SYM_VW2_11);
 #undef SYM_VW2_11
     } else {
-        // the big-block instantiations: by long size and by whether the short size is big as well
+        // the big-block instantiations: by long size and by whether the short size is big as well.  Long blocks of 8192 samples belong
+        // to vorbis_synth_wg_kernel (vorbis_wg.hip) in the product build: the one-wavefront-per-block instantiations for them -- 256
+        // VGPRs + AGPR spills, one wavefront per SIMD, 0.13 of the roofline for the 4096 / 8192 pair -- exist in the SYM_VORBIS_WG = 0
+        // development build only (the A/B partner).
         const int big0 = bs0_exp <= 11 ? 0 : (bs0_exp == 12 ? 2 : 4);
+#if SYM_VORBIS_WG
+#define SYM_VW2_13(FUSED) return SYMACCEL_ERR_UNSUPPORTED
+#else
+#define SYM_VW2_13(FUSED)                                        \
+    do {                                                         \
+        if (big0 == 0) SYM_VW2_LAUNCH3(FUSED, 13, 0);            \
+        else if (big0 == 2) SYM_VW2_LAUNCH3(FUSED, 13, 2);       \
+        else SYM_VW2_LAUNCH3(FUSED, 13, 4);                      \
+    } while (0)
+#endif
 #define SYM_VW2_BIG(FUSED)                                                                      \
     do {                                                                                        \
         if (bs1_exp == 12) {                                                                    \
             if (big0 == 0) SYM_VW2_LAUNCH3(FUSED, 12, 0); else SYM_VW2_LAUNCH3(FUSED, 12, 2);   \
-        } else if (big0 == 0) SYM_VW2_LAUNCH3(FUSED, 13, 0);                                    \
-        else if (big0 == 2) SYM_VW2_LAUNCH3(FUSED, 13, 2);                                      \
-        else SYM_VW2_LAUNCH3(FUSED, 13, 4);                                                     \
+        } else SYM_VW2_13(FUSED);                                                               \
     } while (0)
         SYM_VW2_MODES(SYM_VW2_BIG);
 #undef SYM_VW2_BIG
+#undef SYM_VW2_13
     }
 #undef SYM_VW2_MODES
 #undef SYM_VW2_LAUNCH

@@ -540,9 +540,8 @@ int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_
                      const float *win_long, const float *d_spectra, const float *d_residue, size_t spec_stride, const uint8_t *d_block_flag,
                      const int32_t *d_prev_in, int32_t *d_prev_out, const float *d_overlap_in, float *d_overlap_out, float *d_pcm,
                      size_t pcm_stride, size_t n_chains, unsigned nb, unsigned seg, int floor_mode) {
-    // (the 4096 / 8192 pair would need both cooperative block routines in one kernel: 256 VGPRs and scratch -- it stays on
-    // vorbis_synth_wave2_kernel, launch_vorbis in vorbis.hip)
-    if ((bs1_exp != 12 && bs1_exp != 13) || (bs0_exp == 12 && bs1_exp == 13)) return SYMACCEL_ERR_INVALID_ARG;
+    // (the 4096 / 8192 pair: both cooperative block routines in one instantiation, BIG0 = 2 under MAXE1 = 13)
+    if (bs1_exp != 12 && bs1_exp != 13) return SYMACCEL_ERR_INVALID_ARG;
 #if SYM_VORBIS_WG != 2
     if (bs1_exp == 12) return SYMACCEL_ERR_INVALID_ARG;  // (those instantiations exist in the SYM_VORBIS_WG = 2 build only)
 #endif
@@ -564,6 +563,7 @@ int launch_vorbis_wg(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const cpx *tw_
         if (bs1_exp == 12) {                                                                  \
             SYM_VWG_12(FUSED);                                                                \
         } else if (big0 == 0) SYM_VWG_LAUNCH(FUSED, 13, 0);                                   \
+        else if (big0 == 2) SYM_VWG_LAUNCH(FUSED, 13, 2);                                     \
         else SYM_VWG_LAUNCH(FUSED, 13, 4);                                                    \
     } while (0)
     if (floor_mode == 2) SYM_VWG_BIG(2); else if (d_residue) SYM_VWG_BIG(1); else SYM_VWG_BIG(0);

@@ -289,7 +289,7 @@ def test_mp3_config3_sampled(ctx):
 
 # ------------------------------------------------------------------------------------------ Vorbis
 
-@pytest.mark.parametrize("bs0e,bs1e,seg", [(8, 11, 5), (6, 6, 2), (6, 13, 3), (7, 12, 1000), (11, 11, 4)])
+@pytest.mark.parametrize("bs0e,bs1e,seg", [(8, 11, 5), (6, 6, 2), (6, 13, 3), (7, 12, 1000), (11, 11, 4), (12, 13, 3), (12, 13, 1000)])
 def test_vorbis_parity(ctx, bs0e, bs1e, seg):
     from test_emu_codecs import vorbis_case
     from symphonia_amd import VorbisDsp
@@ -323,7 +323,7 @@ def test_vorbis_wave_paths(ctx, seed, nb, p_long, tail_short, seg):
     assert np.array_equal(host(d_prev), want[2])
 
 
-@pytest.mark.parametrize("bs0e,bs1e,nb,p_long", [(10, 13, 36, 0.7), (6, 13, 60, 0.4), (13, 13, 20, 1.0), (9, 12, 48, 0.7)])
+@pytest.mark.parametrize("bs0e,bs1e,nb,p_long", [(10, 13, 36, 0.7), (6, 13, 60, 0.4), (13, 13, 20, 1.0), (9, 12, 48, 0.7), (12, 13, 40, 0.5)])
 def test_vorbis_big_blocks_under_load(ctx, bs0e, bs1e, nb, p_long):
     """Long blocks of 8192 samples (the workgroup-cooperative kernel: four wavefronts per block, LDS exchange between them) and 4096
     samples with the whole chip busy: 256 chains = 4 distinct chains x 64 copies, several segments each.  Every copy must equal its

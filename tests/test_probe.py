@@ -8,7 +8,7 @@ from symphonia_amd import SymaccelError, _ffi
 
 
 def _modes():
-    return [(0, 0), (0, 1), (1, 1), (3, 0), (64, 1), (2, 9), (5, 8), (2, 17), (1, 25), (3, 24)]
+    return [(0, 0), (0, 1), (1, 1), (3, 0), (64, 1), (2, 9), (5, 8), (2, 17), (1, 25), (3, 24), (2, 41), (1, 40), (7, 41)]
 
 
 def test_emu_probe_copy(emu_ctx):

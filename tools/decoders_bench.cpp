@@ -1,0 +1,231 @@
+// Trait-level throughput: S streams decoded packet by packet through codecs::LookaheadDecoder (include/symaccel.hpp, the compiled
+// twin of the Rust shim's decoders), host memory in -> host memory out, the way a transcoding server drives
+// AudioDecoder::decode_ref (symphonia-core/src/codecs/audio.rs:279-297): T worker threads, every thread owns S / T streams and
+// calls decode() on them round-robin.  Two modes:
+//   batcher     every decoder submits to ONE process-wide symaccel_batcher (csrc/batcher.cpp): one launch per group of streams
+//   per-stream  every decoder batches its own look-ahead (one small call per stream and batch; the context is shared, so the
+//               calls are serialised by a mutex -- the context is externally synchronised)
+// The packets are pre-parsed synthetic spectra (what the CPU front end hands over); the "demuxer + parser" of a stream is a
+// peek that copies the next packet out of a small pool (a parser writes its output somewhere too).  Nothing here links the
+// oracle: bench.py times the CPU port beside this with its own harness.  One JSON line on stdout.
+//
+//   decoders_bench --codec aac|mp3|mp3h --streams S --lookahead L --packets P --threads T [--per-stream] [--flush-mb M]
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "symaccel.hpp"
+
+using namespace symphonia_accel;
+using namespace symphonia_accel::codecs;
+using Clock = std::chrono::steady_clock;
+
+namespace {
+
+struct Args {
+    std::string codec = "aac";
+    size_t streams = 64, lookahead = 64, packets = 512, threads = 1, flush_mb = 0, warm = 0;
+    bool per_stream = false;
+};
+
+constexpr size_t kPool = 32;
+
+template <class Codec>
+std::vector<typename Codec::Packet> make_pool(unsigned seed);
+
+template <>
+std::vector<AacLc::Packet> make_pool<AacLc>(unsigned seed) {
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nd(0.0f, 50.0f);
+    std::vector<AacLc::Packet> pool(kPool);
+    for (auto &p : pool) {
+        p.coeffs.resize(2 * 1024);
+        for (size_t i = 0; i < 2048; ++i) p.coeffs[i] = (i % 1024) < 672 ? nd(rng) : 0.0f;
+        p.side.assign(2, SYMACCEL_AAC_SIDE(0u, 1u, 1u));  // ONLY_LONG, KBD
+    }
+    return pool;
+}
+
+template <>
+std::vector<Mp3::Packet> make_pool<Mp3>(unsigned seed) {
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nd(0.0f, 0.1f);
+    std::vector<Mp3::Packet> pool(kPool);
+    for (auto &p : pool) {
+        p.xr.resize(2 * 2 * 576);
+        for (auto &v : p.xr) v = nd(rng);
+        p.side.assign(4, symaccel_mp3_side{0, 0, 576});
+    }
+    return pool;
+}
+
+template <>
+std::vector<Mp3Huffman::Packet> make_pool<Mp3Huffman>(unsigned seed) {
+    std::mt19937 rng(seed);
+    std::vector<Mp3Huffman::Packet> pool(kPool);
+    for (auto &p : pool) {
+        p.quant.resize(2 * 2 * 576);
+        for (auto &v : p.quant) v = (int16_t)((int)(rng() % 81) - 40);
+        p.rq.resize(4);
+        for (auto &r : p.rq) {
+            std::memset(&r, 0, sizeof r);
+            r.global_gain = 150;
+            r.rzero = 576;
+            for (int s = 0; s < 39; ++s) r.scalefacs[s] = (uint8_t)(rng() % 4);
+        }
+        p.stereo.resize(2);
+        for (auto &s : p.stereo) {
+            std::memset(&s, 0, sizeof s);
+            s.flags = SYMACCEL_MP3_ST_MID_SIDE | SYMACCEL_MP3_ST_MPEG1;
+            s.rzero0 = s.rzero1 = 576;
+        }
+        p.side.assign(4, symaccel_mp3_side{0, 0, 576});
+    }
+    return pool;
+}
+
+template <class Codec>
+typename Codec::Params params();
+template <>
+AacLc::Params params<AacLc>() { return AacLc::Params{2}; }
+template <>
+Mp3::Params params<Mp3>() { return Mp3::Params{2, 2, 0}; }
+template <>
+Mp3Huffman::Params params<Mp3Huffman>() { return Mp3Huffman::Params{2, 2, 0}; }
+
+template <class Codec>
+int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t bytes_in_per_packet) {
+    using Packet = typename Codec::Packet;
+    using Decoder = LookaheadDecoder<Codec>;
+    Context ctx(0);
+    std::unique_ptr<Batcher> batcher;
+    if (!a.per_stream) batcher.reset(new Batcher(ctx, a.flush_mb << 20));
+    const std::vector<Packet> pool = make_pool<Codec>(17);
+    struct Stream {
+        size_t cursor = 0, limit = 0, salt = 0;
+        std::unique_ptr<Decoder> dec;
+    };
+    std::vector<std::unique_ptr<Stream>> streams(a.streams);
+    const size_t total = a.warm + a.packets;
+    for (size_t s = 0; s < a.streams; ++s) {
+        streams[s].reset(new Stream());
+        Stream *st = streams[s].get();
+        st->salt = s * 7;
+        st->limit = total;
+        auto peek = [st, &pool]() -> std::optional<Packet> {
+            if (st->cursor >= st->limit) return std::nullopt;
+            Packet p = pool[(st->cursor + st->salt) % kPool];  // (the copy a parser's output costs)
+            p.ts = st->cursor++;
+            return p;
+        };
+        if (batcher)
+            st->dec.reset(new Decoder(*batcher, params<Codec>(), a.lookahead, peek));
+        else
+            st->dec.reset(new Decoder(ctx, params<Codec>(), a.lookahead, peek));
+    }
+    std::mutex ctx_mu;  // per-stream mode: one context, externally synchronised
+    std::atomic<size_t> failures{0};
+    std::atomic<uint64_t> checksum{0};
+    // What decode() is handed: in the warm-up the parsed packet in full (a cold decoder transforms it at once); afterwards only its
+    // identity -- the trait's packet carries the COMPRESSED bytes, and a packet the look-ahead has already parsed is not parsed
+    // again (a decoder that did need the content here fails with "packet shape" and is counted in `failures`).
+    auto phase = [&](size_t first, size_t count, bool full) {
+        std::vector<std::thread> ths;
+        const size_t T = std::min(a.threads, a.streams);
+        for (size_t t = 0; t < T; ++t)
+            ths.emplace_back([&, t]() {
+                uint64_t acc = 0;
+                try {
+                    for (size_t i = first; i < first + count; ++i)
+                        for (size_t s = t; s < a.streams; s += T) {
+                            Stream &st = *streams[s];
+                            Packet p;
+                            if (full) p = pool[(i + st.salt) % kPool];
+                            p.ts = i;
+                            if (st.cursor <= i) st.cursor = i + 1;
+                            if (batcher) {
+                                const auto &buf = st.dec->decode(p);
+                                uint32_t w;
+                                std::memcpy(&w, buf.planes[0] + (i % 1024 % buf.frames), 4);  // (touch the result)
+                                acc += w;
+                            } else {
+                                std::lock_guard<std::mutex> lock(ctx_mu);
+                                const auto &buf = st.dec->decode(p);
+                                uint32_t w;
+                                std::memcpy(&w, buf.planes[0] + (i % 1024 % buf.frames), 4);
+                                acc += w;
+                            }
+                        }
+                } catch (const std::exception &e) {
+                    std::fprintf(stderr, "decode failed: %s\n", e.what());
+                    failures += 1;
+                }
+                checksum += acc;
+            });
+        for (auto &th : ths) th.join();
+    };
+    if (a.warm) phase(0, a.warm, true);
+    symaccel_batcher_stats s0{};
+    if (batcher) s0 = batcher->stats();
+    const auto t0 = Clock::now();
+    phase(a.warm, a.packets, !batcher);  // (a per-stream decoder transforms the packet it is handed when its batch is used up)
+    const double secs = std::chrono::duration<double>(Clock::now() - t0).count();
+    symaccel_batcher_stats s1{};
+    if (batcher) s1 = batcher->stats();
+    size_t batches = 0;
+    for (auto &st : streams) batches += st->dec->batches_run();
+    streams.clear();
+    const double n = (double)a.streams * (double)a.packets;
+    std::printf("{\"codec\": \"%s\", \"mode\": \"%s\", \"streams\": %zu, \"lookahead\": %zu, \"threads\": %zu, \"packets\": %.0f, \"seconds\": %.6f, "
+                "\"packets_per_s\": %.1f, \"frames_per_packet\": %zu, \"host_bytes_in_per_packet\": %zu, \"host_bytes_out_per_packet\": %zu, "
+                "\"GBps_each_way\": [%.3f, %.3f], \"decoder_batches\": %zu, \"launches\": %llu, \"kernel_launches\": %llu, \"max_chains_per_launch\": %llu, "
+                "\"staging_bytes\": %llu, \"failures\": %zu, \"checksum\": %llu}\n",
+                codec_name, batcher ? "batcher" : "per-stream", a.streams, a.lookahead, std::min(a.threads, a.streams), n, secs, n / secs, frames_per_packet,
+                bytes_in_per_packet, frames_per_packet * 2 * 4, n * bytes_in_per_packet / secs / 1e9, n * frames_per_packet * 8 / secs / 1e9, batches,
+                (unsigned long long)(s1.launches - s0.launches), (unsigned long long)(s1.chunks - s0.chunks),
+                (unsigned long long)s1.max_chains_per_launch, (unsigned long long)s1.staging_bytes, failures.load(),
+                (unsigned long long)checksum.load());
+    return failures.load() ? 1 : 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Args a;
+    for (int i = 1; i < argc; ++i) {
+        const std::string k = argv[i];
+        auto val = [&]() -> size_t { return i + 1 < argc ? (size_t)std::strtoull(argv[++i], nullptr, 10) : 0; };
+        if (k == "--codec" && i + 1 < argc) a.codec = argv[++i];
+        else if (k == "--streams") a.streams = val();
+        else if (k == "--lookahead") a.lookahead = val();
+        else if (k == "--packets") a.packets = val();
+        else if (k == "--threads") a.threads = val();
+        else if (k == "--flush-mb") a.flush_mb = val();
+        else if (k == "--warm") a.warm = val();
+        else if (k == "--per-stream") a.per_stream = true;
+        else {
+            std::fprintf(stderr, "unknown argument %s\n", k.c_str());
+            return 2;
+        }
+    }
+    if (!a.streams || !a.lookahead || !a.packets || !a.threads) return 2;
+    if (!a.warm) a.warm = 2 * a.lookahead;  // past the cold start (every stream's first batch is a launch of its own) and the pool's growth
+    try {
+        if (a.codec == "aac") return run<AacLc>(a, "aac", 1024, 2 * 1024 * 4 + 2);
+        if (a.codec == "mp3") return run<Mp3>(a, "mp3", 1152, 4 * 576 * 4 + 16);
+        if (a.codec == "mp3h") return run<Mp3Huffman>(a, "mp3h", 1152, 4 * 576 * 2 + 4 * 52 + 2 * 48 + 16);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "decoders_bench: %s\n", e.what());
+        return 1;
+    }
+    std::fprintf(stderr, "unknown codec %s\n", a.codec.c_str());
+    return 2;
+}
