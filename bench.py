@@ -1351,6 +1351,14 @@ def main():
             out["exchange_c_api"] = exchange_c
         if world == 1 and args.workload == "aac" and not args.no_host_path and not emulate:
             out["host_to_host"] = host_to_host_aac(sa, ctx, torch, result, step.input, units)
+            try:  # BASELINE config 3 the same way: f32 spectra against the entropy decoder's int16 samples (half the bytes in)
+                out["host_to_host_mp3"] = host_to_host_mp3(sa, ctx, torch, 128, 2048, 131072)
+            except Exception as e:  # noqa: BLE001
+                out["host_to_host_mp3"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:  # the trait-level figure: S streams through decode() and the cross-stream batcher (short form: S = 256)
+                out["decoders"] = decoders_workload(quick=True)
+            except Exception as e:  # noqa: BLE001
+                out["decoders"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and args.workload == "mp3" and not args.no_host_path and not emulate:
             try:
                 out["host_to_host"] = host_to_host_mp3(sa, ctx, torch, int(step.input.shape[0]), int(step.input.shape[1]), units)

@@ -1,6 +1,7 @@
 //! Safe ownership of a `symaccel_ctx` and of page-locked batch buffers.
 use std::ffi::CStr;
 use std::ptr;
+use std::sync::{Arc, Mutex};
 
 use symphonia_core::errors::{Error, Result};
 
@@ -60,6 +61,52 @@ impl Drop for Context {
     fn drop(&mut self) {
         // SAFETY: created by symaccel_ctx_create, destroyed once.
         unsafe { ffi::symaccel_ctx_destroy(self.raw) }
+    }
+}
+
+/// The process-wide cross-stream batcher (csrc/batcher.cpp): ONE context and one `symaccel_batcher` shared by every pooled
+/// decoder of the process.  A decoder cannot see its siblings (codecs/audio.rs:279-297, registry.rs:330-341); the pool is where
+/// their look-ahead batches meet and go to the device in one launch.  The batcher is thread-safe; the pool's context is driven
+/// through the batcher only.
+pub struct Pool {
+    batcher: *mut ffi::SymaccelBatcher,
+    ctx: Context, // (declared after `batcher`: Drop destroys the batcher first, then the field drops the context)
+}
+
+unsafe impl Send for Pool {}
+unsafe impl Sync for Pool {}
+
+static POOL: Mutex<Option<Arc<Pool>>> = Mutex::new(None);
+
+impl Pool {
+    /// The shared pool, created on first use (device 0, the library's default flush size).
+    pub fn shared() -> Result<Arc<Pool>> {
+        let mut slot = POOL.lock().expect("pool poisoned");
+        if let Some(pool) = slot.as_ref() {
+            return Ok(pool.clone());
+        }
+        let ctx = Context::new(0)?;
+        let mut batcher = ptr::null_mut();
+        // SAFETY: valid context, valid out-pointer.
+        check(unsafe { ffi::symaccel_batcher_create(ctx.raw(), 0, &mut batcher) }, ctx.raw())?;
+        let pool = Arc::new(Pool { batcher, ctx });
+        *slot = Some(pool.clone());
+        Ok(pool)
+    }
+
+    pub(crate) fn raw(&self) -> *mut ffi::SymaccelBatcher {
+        self.batcher
+    }
+
+    pub(crate) fn ctx_raw(&self) -> *mut ffi::SymaccelCtx {
+        self.ctx.raw()
+    }
+}
+
+impl Drop for Pool {
+    fn drop(&mut self) {
+        // SAFETY: created by symaccel_batcher_create, destroyed once, before its context.
+        unsafe { ffi::symaccel_batcher_destroy(self.batcher) };
     }
 }
 

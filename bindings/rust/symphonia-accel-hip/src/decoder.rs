@@ -29,8 +29,8 @@ macro_rules! hip_decoder {
 
         impl symphonia_core::codecs::audio::AudioDecoder for $name {
             fn reset(&mut self) {
+                self.la.reset_with(&mut self.batch);  // (a batch still with the cross-stream batcher is given up first)
                 $crate::lookahead::BatchCodec::reset_state(&mut self.batch);
-                self.la.reset();
             }
 
             fn codec_info(&self) -> &symphonia_core::codecs::CodecInfo {

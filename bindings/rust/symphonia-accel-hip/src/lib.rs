@@ -38,7 +38,7 @@ mod vorbis;
 pub use aac::{AacFrontEnd, HipAacDecoder, ParsedAac};
 pub use alac::{AlacFrontEnd, HipAlacDecoder, ParsedAlac};
 pub use decoder::DecoderBatch;
-pub use ctx::{Context, Pinned};
+pub use ctx::{Context, Pinned, Pool};
 pub use flac::{FlacFrontEnd, HipFlacDecoder, ParsedFlac};
 pub use lookahead::{find_reader, BatchCodec, Lookahead, LookaheadReader, PacketKey, Shared, SharedHandle, TrackQueue};
 pub use mpa::{HipMpaDecoder, MpaFrontEnd, ParsedMpa};

@@ -18,7 +18,7 @@
 use std::collections::{HashMap, VecDeque};
 use std::sync::{Arc, Mutex, Weak};
 
-use symphonia_core::errors::Result;
+use symphonia_core::errors::{unsupported_error, Result};
 use symphonia_core::formats::{Attachment, FormatInfo, FormatReader, MediaInfo, SeekMode, SeekTo, SeekedTo, Track};
 use symphonia_core::io::MediaSourceStream;
 use symphonia_core::meta::{ChapterGroup, Metadata};
@@ -208,6 +208,29 @@ pub trait BatchCodec {
     fn reset_state(&mut self);
     /// Clear the `AudioBuffer` (the trait demands it on error, codecs/audio.rs:278).
     fn clear(&mut self);
+
+    // ---- the cross-stream batcher (csrc/batcher.cpp, `symaccel_batcher_*`; the C++ twin: LookaheadDecoder's second constructor).
+    // A decoder cannot see its siblings (decode_ref gets one packet of one track, codecs/audio.rs:279-297), so N decoders batching
+    // their own look-ahead are N small launches.  A codec that is `pooled()` hands its batches to the process-wide batcher instead:
+    // `submit` returns at once, `collect` blocks until the batch is done -- and whatever the decoders of the OTHER streams have
+    // submitted meanwhile went to the device in the same launch.  The defaults describe a codec without a batcher.
+    /// Does this codec submit to the shared batcher?
+    fn pooled(&self) -> bool {
+        false
+    }
+    /// Hand `batch` (the packets that follow the ones already transformed) to the batcher; the state it starts from is the state
+    /// the previous batch left.  Its PCM and the state after it arrive with `collect`.
+    fn submit(&mut self, _batch: &[Self::Parsed]) -> Result<()> {
+        unsupported_error("codec has no batcher")
+    }
+    /// Wait for the submitted batch: `publish` now serves ITS packets.
+    fn collect(&mut self) -> Result<()> {
+        unsupported_error("codec has no batcher")
+    }
+    /// The submitted batch will be wanted soon (a quarter of the current one is left).
+    fn hint(&mut self) {}
+    /// Drop the submitted batch unseen (reset, discontinuity): its results are never looked at, the carried state stays.
+    fn abandon(&mut self) {}
 }
 
 /// Batching state shared by the five decoders.
@@ -219,11 +242,26 @@ pub struct Lookahead<P> {
     max_batch: usize,
     /// the reader this decoder's packets come from, once found
     reader: Option<SharedHandle>,
+    /// a pooled codec's NEXT batch, parsed (and, if `next_live`, submitted) while the current one is still being handed out
+    next_parsed: Vec<P>,
+    next_ready: Vec<i64>,
+    next_live: bool,
+    hinted: bool,
 }
 
 impl<P> Lookahead<P> {
     pub fn new(max_batch: usize) -> Self {
-        Lookahead { parsed: Vec::new(), ready: Vec::new(), head: 0, max_batch: max_batch.max(1), reader: None }
+        Lookahead {
+            parsed: Vec::new(),
+            ready: Vec::new(),
+            head: 0,
+            max_batch: max_batch.max(1),
+            reader: None,
+            next_parsed: Vec::new(),
+            next_ready: Vec::new(),
+            next_live: false,
+            hinted: false,
+        }
     }
 
     /// `AudioDecoder::reset` (audio.rs:252-257): nothing pre-computed survives.
@@ -231,6 +269,26 @@ impl<P> Lookahead<P> {
         self.parsed.clear();
         self.ready.clear();
         self.head = 0;
+        self.next_parsed.clear();
+        self.next_ready.clear();
+        // (a batch that is still with the batcher is dropped by `drop_next`, which needs the codec: decode / reset_with do that first)
+        self.next_live = false;
+        self.hinted = false;
+    }
+
+    /// `AudioDecoder::reset` for a pooled codec: the batch submitted ahead is given up before the state is zeroed.
+    pub fn reset_with<C: BatchCodec<Parsed = P>>(&mut self, codec: &mut C) {
+        self.drop_next(codec);
+        self.reset();
+    }
+
+    fn drop_next<C: BatchCodec<Parsed = P>>(&mut self, codec: &mut C) {
+        if self.next_live {
+            codec.abandon();
+        }
+        self.next_live = false;
+        self.next_parsed.clear();
+        self.next_ready.clear();
     }
 
     /// Batches transformed so far would be a counter in the C++ twin; here: packets waiting in the current batch.
@@ -247,26 +305,108 @@ impl<P> Lookahead<P> {
             // the end of the batch.  Every codec on this path has a one-packet memory (the delay line / overlap / V FIFO after
             // a packet depend on that packet's input alone), so replaying the last returned packet rebuilds exactly that
             // state (include/symaccel.hpp, LookaheadDecoder::decode, does the same).
+            self.drop_next(codec);
             let replay = if self.head >= 1 { Some(self.head - 1) } else { None };
             if let Some(i) = replay {
                 if let Err(e) = codec.transform(&self.parsed[i..i + 1]) {
                     codec.clear();
-                    self.reset();
+                    self.reset_with(codec);
                     return Err(e);
                 }
             }
             self.reset();
         }
         if self.head >= self.ready.len() {
-            if let Err(e) = self.fill(codec, packet) {
-                codec.clear();
-                self.reset();
-                return Err(e);
+            let taken = if !self.next_ready.is_empty() && self.next_ready[0] == packet.pts.get() {
+                // the batch prepared ahead starts with this packet: collect it (or, if it could not be submitted, transform it now)
+                let r = if self.next_live { codec.collect() } else { codec.transform(&self.next_parsed) };
+                self.next_live = false;
+                match r {
+                    Ok(()) => {
+                        std::mem::swap(&mut self.parsed, &mut self.next_parsed);
+                        std::mem::swap(&mut self.ready, &mut self.next_ready);
+                        self.next_parsed.clear();
+                        self.next_ready.clear();
+                        self.head = 0;
+                        true
+                    }
+                    Err(e) => {
+                        codec.clear();
+                        self.reset_with(codec);
+                        return Err(e);
+                    }
+                }
+            }
+            else {
+                // (prepared for packets the caller then skipped: dropped unseen -- the carried state is still the one the last
+                // returned packet left, because the current batch was handed out to its end)
+                self.drop_next(codec);
+                false
+            };
+            if !taken {
+                if let Err(e) = self.fill(codec, packet) {
+                    codec.clear();
+                    self.reset_with(codec);
+                    return Err(e);
+                }
             }
         }
         codec.publish(self.head);
         self.head += 1;
+        if codec.pooled() {
+            // half of the batch handed out: the next one is parsed and submitted (the decoders of the other streams do the same
+            // around now); a quarter left: whatever is pending goes to the device while the rest is consumed
+            let left = self.ready.len() - self.head;
+            if self.next_ready.is_empty() && 2 * left <= self.ready.len() {
+                self.submit_ahead(codec, packet, left);
+            }
+            if self.next_live && !self.hinted && 4 * left <= self.ready.len() {
+                self.hinted = true;
+                codec.hint();
+            }
+        }
         Ok(())
+    }
+
+    /// Parse the packets that FOLLOW the current batch (the reader's queue holds what follows `packet`: first the `left` packets
+    /// of the current batch that have not been handed out yet, then the new ones) and submit them.  Nothing here fails the call:
+    /// a corrupt packet ends the batch (it fails at its own decode_ref), a failed submit leaves the parsed batch to be transformed
+    /// by the call that needs it.
+    fn submit_ahead<C: BatchCodec<Parsed = P>>(&mut self, codec: &mut C, packet: &PacketRef<'_>, left: usize) {
+        let Some(reader) = self.reader.clone() else { return };
+        let mut parsed = Vec::with_capacity(self.max_batch);
+        let mut ids = Vec::with_capacity(self.max_batch);
+        {
+            let shared = reader.lock().expect("look-ahead state poisoned");
+            let Some(q) = shared.tracks.get(&packet.track_id) else { return };
+            if q.last_out != Some(PacketKey::of(packet)) || q.packets.len() <= left {
+                return;
+            }
+            // the queue must continue the current batch exactly (the parser is stateful: no gaps, no repeats)
+            let mut i = 0;
+            for p in q.packets.iter().take(left) {
+                if p.pts.get() != self.ready[self.head + i] {
+                    return;
+                }
+                i += 1;
+            }
+            for p in q.packets.iter().skip(left).take(self.max_batch) {
+                match codec.parse(&p.as_packet_ref()) {
+                    Ok(x) => {
+                        parsed.push(x);
+                        ids.push(p.pts.get());
+                    }
+                    Err(_) => break,
+                }
+            }
+        }
+        if parsed.is_empty() {
+            return;
+        }
+        self.next_live = codec.submit(&parsed).is_ok();
+        self.next_parsed = parsed;
+        self.next_ready = ids;
+        self.hinted = false;
     }
 
     fn fill<C: BatchCodec<Parsed = P>>(&mut self, codec: &mut C, packet: &PacketRef<'_>) -> Result<()> {

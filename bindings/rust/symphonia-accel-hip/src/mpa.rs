@@ -15,7 +15,7 @@ use symphonia_core::errors::{decode_error, unsupported_error, Result};
 use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
-use crate::ctx::{check, Context, Pinned};
+use crate::ctx::{check, Context, Pinned, Pool};
 use crate::decoder::DecoderBatch;
 use crate::ffi;
 use crate::lookahead::{BatchCodec, Lookahead};
@@ -290,6 +290,11 @@ pub struct MpaBatch {
     st: Vec<ffi::SymaccelMp3Stereo>,  //   [granule of the batch] (the one channel pair of a stereo stream)
     first_granule: Vec<usize>,        // per packet of the batch: index of its first granule; one extra entry = total
     trims: Vec<(usize, usize)>,       // per packet of the batch
+    // the cross-stream batcher: the batch submitted ahead (its PCM and state land in `pcm` / `overlap` / `vvec` / `vfront` at collect)
+    pool: Option<Arc<Pool>>,
+    ticket: Option<u64>,
+    next_first_granule: Vec<usize>,
+    next_trims: Vec<(usize, usize)>,
     gapless: bool,
     buf: AudioBuffer<f32>,
 }
@@ -376,17 +381,101 @@ impl BatchCodec for MpaBatch {
     fn clear(&mut self) {
         self.buf.clear();
     }
+
+    fn pooled(&self) -> bool {
+        self.pool.is_some()
+    }
+
+    /// `symaccel_batcher_submit_mp3_decode`: the stream's next batch goes to the process-wide batcher (one stream = one submission
+    /// of 1 or 2 chains); the inputs are copied out of the staging buffers before the call returns, the PCM and the state after the
+    /// batch are written by `collect`.
+    fn submit(&mut self, batch: &[ParsedMpa]) -> Result<()> {
+        let Some(pool) = self.pool.clone() else {
+            return unsupported_error("mp3: no batcher");
+        };
+        if batch.is_empty() || !batch.iter().all(|p| p.fused.is_some()) || self.ticket.is_some() {
+            return unsupported_error("mp3: the batcher takes the entropy decoder's integers, one batch at a time");
+        }
+        self.next_first_granule.clear();
+        self.next_trims.clear();
+        let mut total = 0usize;
+        for p in batch {
+            self.next_first_granule.push(total);
+            self.next_trims.push(p.trim);
+            total += p.n_granules;
+        }
+        self.next_first_granule.push(total);
+        let first = self.next_first_granule.clone();
+        self.gather_fused(batch, total, &first);
+        let mut ticket = 0u64;
+        // SAFETY: the staging buffers cover nch * total (* 576) elements (sized for max_batch frames of two granules) and are copied
+        // before the call returns; the state arrays and `pcm` stay where they are until `collect` / `abandon` (fields of self).
+        check(
+            unsafe {
+                ffi::symaccel_batcher_submit_mp3_decode(
+                    pool.raw(),
+                    self.quant.as_slice().as_ptr(),
+                    self.rq.as_ptr(),
+                    self.st.as_ptr(),
+                    self.side.as_ptr(),
+                    self.front.sample_rate_idx(),
+                    self.overlap.as_mut_ptr(),
+                    self.vvec.as_mut_ptr(),
+                    self.vfront.as_mut_ptr(),
+                    self.pcm.as_mut_slice().as_mut_ptr(),
+                    self.nch,
+                    total,
+                    &mut ticket,
+                )
+            },
+            pool.ctx_raw(),
+        )?;
+        self.ticket = Some(ticket);
+        Ok(())
+    }
+
+    fn collect(&mut self) -> Result<()> {
+        let (Some(pool), Some(ticket)) = (self.pool.clone(), self.ticket.take()) else {
+            return unsupported_error("mp3: nothing was submitted");
+        };
+        // SAFETY: a live ticket of this pool's batcher; the pointers given to submit are fields of self.
+        check(unsafe { ffi::symaccel_batcher_collect(pool.raw(), ticket) }, pool.ctx_raw())?;
+        std::mem::swap(&mut self.first_granule, &mut self.next_first_granule);
+        std::mem::swap(&mut self.trims, &mut self.next_trims);
+        Ok(())
+    }
+
+    fn hint(&mut self) {
+        if let Some(pool) = &self.pool {
+            // SAFETY: a live batcher.
+            unsafe { ffi::symaccel_batcher_hint(pool.raw()) };
+        }
+    }
+
+    fn abandon(&mut self) {
+        if let (Some(pool), Some(ticket)) = (self.pool.clone(), self.ticket.take()) {
+            // SAFETY: a live ticket; nothing is written to the state or the PCM (the submission is released without a copy-out).
+            unsafe { ffi::symaccel_batcher_abandon(pool.raw(), ticket) };
+        }
+    }
+}
+
+impl Drop for MpaBatch {
+    fn drop(&mut self) {
+        BatchCodec::abandon(self); // (a batch still with the batcher points at this struct's buffers)
+    }
 }
 
 impl MpaBatch {
     /// layer3/mod.rs:421-477 for the whole batch in one call: requantize, stereo and the synthesis tail on the device from the
     /// entropy decoder's integers (2 bytes per line in, 4 bytes per sample out).
-    fn transform_fused(&mut self, batch: &[ParsedMpa], total: usize) -> Result<()> {
+    /// The fused batch in the chain-major staging layout (`first`: index of every packet's first granule).
+    fn gather_fused(&mut self, batch: &[ParsedMpa], total: usize, first: &[usize]) {
         let zero_st = ffi::SymaccelMp3Stereo { flags: 0, block_type: 0, is_mixed: 0, reserved: 0, rzero0: 0, rzero1: 0, scalefacs1: [0; 39], pad: 0 };
         for (i, p) in batch.iter().enumerate() {
             let Some(f) = &p.fused else { continue };
             for g in 0..p.n_granules {
-                let at = self.first_granule[i] + g;
+                let at = first[i] + g;
                 for c in 0..self.nch {
                     let dst = c * total + at;
                     let src = (g * self.nch + c) * 576;
@@ -397,6 +486,11 @@ impl MpaBatch {
                 self.st[at] = if self.nch == 2 { f.st[g] } else { zero_st };
             }
         }
+    }
+
+    fn transform_fused(&mut self, batch: &[ParsedMpa], total: usize) -> Result<()> {
+        let first = self.first_granule.clone();
+        self.gather_fused(batch, total, &first);
         let pair: [i32; 2] = [0, 1];
         let n_pairs = if self.nch == 2 { 1 } else { 0 };
         // SAFETY: every buffer covers nch * total (* 576) elements and st covers `total` records (sized for max_batch frames of
@@ -444,6 +538,22 @@ crate::hip_decoder!(
 
 impl HipMpaDecoder {
     pub fn try_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn MpaFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, None)
+    }
+
+    /// The same decoder submitting to the process-wide cross-stream batcher (`Pool::shared()`): with many streams open, the
+    /// batches of all of them go to the device in one launch (csrc/batcher.cpp).
+    pub fn try_new_pooled(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn MpaFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, Some(Pool::shared()?))
+    }
+
+    fn try_new_with_pool(
+        params: &AudioCodecParameters,
+        opts: &AudioDecoderOptions,
+        front: Box<dyn MpaFrontEnd>,
+        max_batch: usize,
+        pool: Option<Arc<Pool>>,
+    ) -> Result<Self> {
         let (Some(rate), Some(channels)) = (params.sample_rate, params.channels.clone()) else {
             return unsupported_error("mp3: sample rate and channels are required");
         };
@@ -470,6 +580,10 @@ impl HipMpaDecoder {
                 st: vec![ffi::SymaccelMp3Stereo { flags: 0, block_type: 0, is_mixed: 0, reserved: 0, rzero0: 0, rzero1: 0, scalefacs1: [0; 39], pad: 0 }; granules],
                 first_granule: Vec::with_capacity(max_batch + 1),
                 trims: Vec::with_capacity(max_batch),
+                pool,
+                ticket: None,
+                next_first_granule: Vec::with_capacity(max_batch + 1),
+                next_trims: Vec::with_capacity(max_batch),
                 gapless: opts.gapless,
                 buf: AudioBuffer::new(AudioSpec::new(rate, channels), 1152),
             },

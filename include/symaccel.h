@@ -666,7 +666,21 @@ int symaccel_batcher_wait(symaccel_batcher *b, uint64_t ticket, symaccel_batch_s
 int symaccel_batcher_release(symaccel_batcher *b, uint64_t ticket);
 int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_chains, size_t units_per_chain,
                             const void **input, void **state_io, void *out, uint64_t *ticket); /* input[4], state_io[3] */
+/* submit() with the argument lists of the entry points the kinds stand for (symaccel_aac_synth, symaccel_mp3_synth,
+ * symaccel_mp3_decode_pipelined for one stream: n_chains 1, or 2 = one channel pair with st_desc[granule]; st_desc may be NULL for 1) */
+int symaccel_batcher_submit_aac_synth(symaccel_batcher *b, const float *coeffs, const uint8_t *side, float *delay_io, float *pcm,
+                                      size_t n_chains, size_t frames_per_chain, uint64_t *ticket);
+int symaccel_batcher_submit_mp3_synth(symaccel_batcher *b, const float *xr, const symaccel_mp3_side *side, int sample_rate_idx,
+                                      float *overlap_io, float *vvec_io, int32_t *vfront_io, float *pcm, size_t n_chains,
+                                      size_t granules_per_chain, uint64_t *ticket);
+int symaccel_batcher_submit_mp3_decode(symaccel_batcher *b, const int16_t *quant, const symaccel_mp3_requant *rq_desc,
+                                       const symaccel_mp3_stereo *st_desc, const symaccel_mp3_side *side, int sample_rate_idx,
+                                       float *overlap_io, float *vvec_io, int32_t *vfront_io, float *pcm, size_t n_chains,
+                                       size_t granules_per_chain, uint64_t *ticket);
+/* wait + copy the PCM and the state after the batch into the `*_io` / `pcm` pointers given to submit + release */
 int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket);
+/* give up a submission (seek, reset): wait until nothing of it is in flight, write nothing, release */
+int symaccel_batcher_abandon(symaccel_batcher *b, uint64_t ticket);
 /* launch everything pending now (nobody has to wait for it) */
 int symaccel_batcher_flush(symaccel_batcher *b);
 /* "results will be wanted soon": launch the pending groups that are worth a launch of their own (4 MiB of input, or flush_bytes / 8),

@@ -689,6 +689,28 @@ int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_c
     return symaccel_batcher_commit(b, id);
 }
 
+int symaccel_batcher_submit_aac_synth(symaccel_batcher *b, const float *coeffs, const uint8_t *side, float *delay_io, float *pcm, size_t n_chains,
+                                      size_t frames_per_chain, uint64_t *ticket) {
+    const void *in[4] = {coeffs, side, nullptr, nullptr};
+    void *st[3] = {delay_io, nullptr, nullptr};
+    return symaccel_batcher_submit(b, SYMACCEL_BATCH_AAC_SYNTH, 0, n_chains, frames_per_chain, in, st, pcm, ticket);
+}
+
+int symaccel_batcher_submit_mp3_synth(symaccel_batcher *b, const float *xr, const symaccel_mp3_side *side, int sample_rate_idx, float *overlap_io,
+                                      float *vvec_io, int32_t *vfront_io, float *pcm, size_t n_chains, size_t granules_per_chain, uint64_t *ticket) {
+    const void *in[4] = {xr, side, nullptr, nullptr};
+    void *st[3] = {overlap_io, vvec_io, vfront_io};
+    return symaccel_batcher_submit(b, SYMACCEL_BATCH_MP3_SYNTH, sample_rate_idx, n_chains, granules_per_chain, in, st, pcm, ticket);
+}
+
+int symaccel_batcher_submit_mp3_decode(symaccel_batcher *b, const int16_t *quant, const symaccel_mp3_requant *rq_desc, const symaccel_mp3_stereo *st_desc,
+                                       const symaccel_mp3_side *side, int sample_rate_idx, float *overlap_io, float *vvec_io, int32_t *vfront_io,
+                                       float *pcm, size_t n_chains, size_t granules_per_chain, uint64_t *ticket) {
+    const void *in[4] = {quant, rq_desc, side, st_desc};
+    void *st[3] = {overlap_io, vvec_io, vfront_io};
+    return symaccel_batcher_submit(b, SYMACCEL_BATCH_MP3_DECODE, sample_rate_idx, n_chains, granules_per_chain, in, st, pcm, ticket);
+}
+
 int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket) {
     if (!b) return SYMACCEL_ERR_INVALID_ARG;
     symaccel_batch_slot slot;
@@ -708,6 +730,11 @@ int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket) {
     }
     const int rel = symaccel_batcher_release(b, ticket);
     return st != SYMACCEL_OK ? st : rel;
+}
+
+int symaccel_batcher_abandon(symaccel_batcher *b, uint64_t ticket) {
+    if (!b) return SYMACCEL_ERR_INVALID_ARG;
+    return symaccel_batcher_release(b, ticket);  // (release drains the ticket's group before the slot goes back)
 }
 
 int symaccel_batcher_get_stats(symaccel_batcher *b, symaccel_batcher_stats *out) {

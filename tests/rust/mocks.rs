@@ -11,11 +11,41 @@ pub struct MockCodec {
     pub batch_sizes: Vec<i64>,
     pub parses: i64,
     pub fail_transform_in: i64,
+    // the cross-stream batcher form (BatchCodec::pooled / submit / collect / hint / abandon)
+    pub pool: bool,
+    pub submitted: Vec<i64>,
+    pub in_flight: bool,
+    pub submits: i64,
+    pub collects: i64,
+    pub hints: i64,
+    pub abandons: i64,
+    pub fail_submit_in: i64,
 }
 
 impl MockCodec {
     pub fn new() -> Self {
-        MockCodec { state: 0, batch_out: Vec::new(), buffer: None, batch_sizes: Vec::new(), parses: 0, fail_transform_in: -1 }
+        MockCodec {
+            state: 0,
+            batch_out: Vec::new(),
+            buffer: None,
+            batch_sizes: Vec::new(),
+            parses: 0,
+            fail_transform_in: -1,
+            pool: false,
+            submitted: Vec::new(),
+            in_flight: false,
+            submits: 0,
+            collects: 0,
+            hints: 0,
+            abandons: 0,
+            fail_submit_in: -1,
+        }
+    }
+
+    pub fn new_pooled() -> Self {
+        let mut c = MockCodec::new();
+        c.pool = true;
+        c
     }
 }
 
@@ -57,6 +87,52 @@ impl BatchCodec for MockCodec {
 
     fn clear(&mut self) {
         self.buffer = None;
+    }
+
+    fn pooled(&self) -> bool {
+        self.pool
+    }
+
+    fn submit(&mut self, batch: &[i64]) -> Result<()> {
+        if self.in_flight {
+            return Err(Error::IoError("mock: one batch at a time"));
+        }
+        if self.fail_submit_in == 0 {
+            self.fail_submit_in = -1;
+            return Err(Error::IoError("mock: submit failed"));
+        }
+        if self.fail_submit_in > 0 {
+            self.fail_submit_in -= 1;
+        }
+        self.submitted.clear();
+        for v in batch.iter() {
+            self.submitted.push(*v);
+        }
+        self.in_flight = true;
+        self.submits += 1;
+        Ok(())
+    }
+
+    fn collect(&mut self) -> Result<()> {
+        if !self.in_flight {
+            return Err(Error::IoError("mock: nothing submitted"));
+        }
+        self.in_flight = false;
+        self.collects += 1;
+        let batch = self.submitted.clone();
+        self.transform(&batch)
+    }
+
+    fn hint(&mut self) {
+        self.hints += 1;
+    }
+
+    fn abandon(&mut self) {
+        if self.in_flight {
+            self.abandons += 1;
+        }
+        self.in_flight = false;
+        self.submitted.clear();
     }
 }
 

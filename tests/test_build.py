@@ -16,7 +16,7 @@ F32_FUSED = re.compile(r"\b(v_fma_f32|v_fmac_f32|v_mac_f32|v_mad_f32|v_pk_fma_f3
                        r"v_mad_legacy_f32|v_mac_legacy_f32|v_dot2c?_f32\w*)\b")
 F64_FUSED = re.compile(r"\b(v_fma_f64|v_fmac_f64)\b")
 SOURCES = ["aac.hip", "aac_tools.hip", "mp3.hip", "mp3_requant.hip", "mp3_stereo.hip", "mpa_polyphase.hip", "vorbis.hip", "vorbis_wave.hip", "vorbis_wave2.hip", "vorbis_wg.hip",
-           "imdct_generic.hip", "imdct_big.hip", "flac.hip", "alac.hip", "state_copy.hip", "probe.hip"]
+           "imdct_generic.hip", "imdct_big.hip", "flac.hip", "alac.hip", "state_copy.hip", "batch_copy.hip", "probe.hip"]
 
 
 import sys
@@ -42,7 +42,7 @@ def kernels(text):
 
 # Kernels with no f32 signal arithmetic at all: the only FMAs they may contain belong to the compiler's expansion of
 # integer and IEEE float DIVISION (index math, the floor-1 DDA reciprocal), which is correctly rounded by construction.
-INDEX_MATH_ONLY = re.compile(r"floor1|offsets|deinterleave|flac_|alac_|state_copy|mp3_requantize_kernel")
+INDEX_MATH_ONLY = re.compile(r"floor1|offsets|deinterleave|flac_|alac_|state_copy|batch_copy|mp3_requantize_kernel")
 
 
 def test_no_f32_fma_in_any_synthesis_kernel(asm):
@@ -95,10 +95,11 @@ def test_mp3_build_variants_fit_three_waves_per_simd(variant):
 
 
 def test_vorbis_wg_kernel_fits_three_workgroups_per_cu():
-    """vorbis_synth_wg_kernel (8192-sample blocks): exchange and group work areas inside the staging area -- at most 168 VGPRs and a
-    third of the CU's 160 KiB of LDS, no scratch; the round-3 layout (SYMACCEL_TUNE_VORBIS_WG_SHARED=0) stays buildable."""
+    """vorbis_synth_wg_kernel (8192-sample blocks, the 4096 / 8192 pair with BOTH cooperative block routines included): exchange and
+    group work areas inside the staging area -- at most 168 VGPRs and a third of the CU's 160 KiB of LDS, no scratch; the round-3
+    layout (SYMACCEL_TUNE_VORBIS_WG_SHARED=0) stays buildable."""
     res = kernel_resources(device_asm("vorbis_wg.hip", []))
-    assert len(res) == 6
+    assert len(res) == 9  # FUSED 0 / 1 / 2 x short blocks <= 2048 / 4096 / 8192 samples
     for name, r in res.items():
         assert r["ScratchSize"] == 0 and r["NumVgprs"] <= 168 and 3 * r["LDSByteSize"] <= 160 * 1024, (name, r)
     old = kernel_resources(device_asm("vorbis_wg.hip", ["-DSYM_VORBIS_WG_SHARED=0"]))

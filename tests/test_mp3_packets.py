@@ -236,6 +236,49 @@ def test_look_ahead_batches_and_reset(trees):
         assert st == st_r == "ok" and np.array_equal(bits(got), bits(want_r)), i
 
 
+def test_two_pooled_decoders_share_the_cross_stream_batcher(trees):
+    """`HipMpaDecoder::try_new_pooled`: two streams behind look-ahead readers, decoded alternately like a server's worker would.  The
+    batches after each stream's first go through symaccel_batcher_submit_mp3_decode / _collect of the process-wide `Pool` (one
+    batcher for both decoders), and every packet's PCM still equals the reference decoder's bit for bit."""
+    mpeg1, n, batch = sized((True, 10, 4), (True, 7, 2))
+    per_frame = 1152 if mpeg1 else 576
+    streams = [stream(8, n, "joint", mpeg1, 0), stream(9, n, "stereo", mpeg1, 0)]
+    want = []
+    for s, packets in streams:
+        ref = Harness(None, reference=True, mp3_tree=trees[0])
+        ref_dec = cpu_decoder(ref, s)
+        want.append([ref.decode("MpaDecoder", ref_dec, ref.packet(pk, i * per_frame))[1] for i, (pk, _) in enumerate(packets)])
+    h = shim(trees[1])
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    decs, readers = [], []
+    for k, (s, packets) in enumerate(streams):
+        p = h.params("CODEC_ID_MP3", s.rate, s.nch)
+        front = h.it.call("mpa_front_end", p, h.opts())
+        r = h.it.call("HipMpaDecoder::try_new_pooled", p, h.opts(), front.f["0"], usize(batch))
+        assert r.variant == "Ok", r
+        decs.append(r.f["0"])
+        pk = I.Arr([h.packet(d, i * per_frame, track=1 + k, owned=True) for i, (d, _) in enumerate(packets)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(3 * batch)))
+    for i in range(n):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            pkt = r.f["0"].f["0"]
+            st, got = h.decode("HipMpaDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", pkt))
+            assert st == "ok" and np.array_equal(bits(got), bits(want[k][i])), (k, i)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1                                     # one pool for both decoders
+    assert calls.count("symaccel_batcher_submit_mp3_decode") >= 2 * ((n - batch) // batch)   # every batch after the first: submitted ahead
+    assert calls.count("symaccel_batcher_collect") >= calls.count("symaccel_batcher_submit_mp3_decode") - 2
+    assert calls.count("symaccel_mp3_decode_pipelined") == 2                                 # each stream's cold start only
+    # a seek + reset with a batch in flight: given up, then everything again from packet 0
+    h.it.call_method("LookaheadReader", "seek", readers[0], I.Int(0, "i64"), usize(0))
+    h.it.call_method("HipMpaDecoder", "reset", decs[0])
+    for i in range(3):
+        r = h.it.call_method("LookaheadReader", "next_packet", readers[0])
+        st, got = h.decode("HipMpaDecoder", decs[0], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+        assert st == "ok" and np.array_equal(bits(got), bits(want[0][i])), i
+
+
 def test_seek_into_the_middle_of_the_stream_and_reset(trees):
     """A seek that lands on a packet whose main data reaches BACK into earlier packets (main_data_begin > 0), followed by reset():
     the reference rebuilds its whole state, bit reservoir included (decoder.rs:149-152), so the granules that would have started

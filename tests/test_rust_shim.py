@@ -329,8 +329,8 @@ class Rig:
         reader = self.it.call("LookaheadReader::new", inner, usize(depth))
         return reader, reader.f["inner"]  # (`inner` was moved into the reader: the interpreter's move is a copy)
 
-    def decoder(self, max_batch):
-        return self.it.call("MockCodec::new"), self.it.call("Lookahead::new", usize(max_batch))
+    def decoder(self, max_batch, pooled=False):
+        return self.it.call("MockCodec::new_pooled" if pooled else "MockCodec::new"), self.it.call("Lookahead::new", usize(max_batch))
 
     def next_packet(self, reader):
         r = self.it.call_method("LookaheadReader", "next_packet", reader)
@@ -551,6 +551,84 @@ def test_a_failing_inner_reader_loses_no_packet_at_any_depth(rig):
             if st == "eof":
                 break
         assert seen == [1, 2, 3, 4, 5, 6, "err", 7, 8, 9, 10, "eof"], (depth, seen)
+
+
+# ---- the cross-stream batcher form of the same decoder (BatchCodec::pooled / submit / collect / hint / abandon): the next batch is
+# parsed and submitted while the current one is still being handed out; what the application sees does not change
+
+def test_pooled_decode_is_frame_by_frame_and_submits_ahead(rig):
+    values = [3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8, 9, 7, 9, 3, 2, 3, 8, 4, 6]
+    reader, inner = rig.reader(rig.packets(values), depth=12)
+    codec, la = rig.decoder(4, pooled=True)
+    ref = FrameByFrame()
+    for i, v in enumerate(values):
+        st, p = rig.next_packet(reader)
+        assert st == "ok"
+        assert rig.decode(la, codec, p) == ref.decode(v)
+        if i == 1:  # half of the first batch of four handed out: the next four are with the batcher already
+            assert codec.f["submits"].v == 1 and codec.f["in_flight"] is True and codec.f["parses"].v == 8
+        if i == 2:  # a quarter left: the hint
+            assert codec.f["hints"].v == 1
+    assert rig.next_packet(reader)[0] == "eof"
+    assert codec.f["parses"].v == len(values)                       # every packet parsed exactly once, in order
+    assert rig.batch_sizes(codec) == [4, 4, 4, 4, 4, 1]              # the first by transform, the others collected
+    assert codec.f["submits"].v == 5 and codec.f["collects"].v == 5 and codec.f["abandons"].v == 0 and codec.f["in_flight"] is False
+
+
+def test_pooled_reset_after_a_seek_gives_up_the_submitted_batch(rig):
+    values = list(range(1, 25))
+    reader, inner = rig.reader(rig.packets(values), depth=12)
+    codec, la = rig.decoder(4, pooled=True)
+    ref = FrameByFrame()
+    for _ in range(7):
+        st, p = rig.next_packet(reader)
+        assert rig.decode(la, codec, p) == ref.decode(p.f["data"].a[0].v)
+    assert codec.f["in_flight"] is True
+    # seek: the application seeks the reader and resets the decoder (hip_decoder!'s reset: reset_with, then reset_state)
+    rig.it.call_method("LookaheadReader", "seek", reader, i64(0), usize(15))
+    rig.it.call_method("Lookahead", "reset_with", la, codec)
+    rig.it.call_method("MockCodec", "reset_state", codec)
+    ref.reset()
+    assert codec.f["abandons"].v == 1 and codec.f["in_flight"] is False
+    while True:
+        st, p = rig.next_packet(reader)
+        if st == "eof":
+            break
+        assert rig.decode(la, codec, p) == ref.decode(p.f["data"].a[0].v)
+
+
+def test_pooled_discontinuity_and_corrupt_packets(rig):
+    values = list(range(1, 31))
+    packets = rig.packets(values)
+    packets[13] = rig.it.call("corrupt_packet", u32(1), i64(130))  # inside a batch that is parsed AHEAD
+    reader, inner = rig.reader(packets, depth=12)
+    codec, la = rig.decoder(4, pooled=True)
+    ref = FrameByFrame()
+    got = []
+    for i in range(len(values)):
+        st, p = rig.next_packet(reader)
+        assert st == "ok"
+        if i in (5, 6):  # the application drops two packets without reset(): both decoders carry their state on
+            continue
+        r = rig.decode(la, codec, p)
+        if i == 13:
+            assert r == "DecodeError"  # fails at its own decode_ref, nothing before it was lost
+            continue
+        assert r == ref.decode(values[i]), i
+        got.append(i)
+    assert got == [i for i in range(30) if i not in (5, 6, 13)]
+
+
+def test_pooled_submit_failure_falls_back_to_the_synchronous_transform(rig):
+    values = list(range(1, 14))
+    reader, inner = rig.reader(rig.packets(values), depth=12)
+    codec, la = rig.decoder(4, pooled=True)
+    codec.f["fail_submit_in"] = I.Int(1, "i64")  # the second submit fails (a device error at submit time)
+    ref = FrameByFrame()
+    for v in values:
+        st, p = rig.next_packet(reader)
+        assert rig.decode(la, codec, p) == ref.decode(v)
+    assert codec.f["parses"].v == len(values)  # the batch that could not be submitted was kept and transformed when needed
 
 
 def test_registry_has_no_fall_through_and_the_shim_delegates(rig):

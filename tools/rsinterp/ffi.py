@@ -157,6 +157,9 @@ class Bridge:
         self.it, self.dll = it, C.CDLL(dll._name)
         rest, self.decls = parse_extern_block(sys_rs_text)
         it.load_source(rest, 'symaccel_sys.rs')
+        # symaccel_batcher_submit_* return before the library writes the `*_io` / `pcm` arrays (symaccel_batcher_collect does): the
+        # marshalled arrays of a submission are kept, keyed by its ticket, and copied back into the interpreter's values at collect
+        self.deferred = {}
         self.calls = []  # (name) log, for the tests
         self.scalars = []  # per call: (name, {parameter: value}) for the integer arguments passed by value
         for name in self.decls:
@@ -285,6 +288,14 @@ class Bridge:
         self.calls.append(name)
         self.scalars.append((name, {pn: int(c.value) for (pn, pt), c in zip(params, cargs) if hasattr(c, 'value') and isinstance(c.value, int) and not pt.startswith('*')}))
         r = fn(*cargs)
+        if name.startswith('symaccel_batcher_submit_') and int(r) == 0:
+            ticket = [arr for kind, dst, arr, dt, extra in after if kind == 'scalar'][-1]
+            self.deferred[int(ticket[0])] = ([a for a in after if a[0] == 'seq'], keep)
+            after = [a for a in after if a[0] != 'seq']
+        if name in ('symaccel_batcher_collect', 'symaccel_batcher_abandon'):
+            held = self.deferred.pop(int(cargs[1].value), None)
+            if held and name.endswith('collect') and int(r) == 0:
+                after = after + held[0]
         for kind, dst, arr, dt, extra in after:
             if kind == 'seq':
                 a, o, n = I.seq_view(dst)

@@ -1126,6 +1126,8 @@ class Interp:
             return True
         if k == 'ptuple':
             dv = deref(v)
+            if dv is UNIT and not pat[1]:
+                return True  # `()` against the unit value (`Ok(()) => ..`)
             if not isinstance(dv, tuple):
                 raise InterpError('tuple pattern against %r' % (dv,))
             pats = pat[1]
