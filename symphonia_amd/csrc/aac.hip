@@ -2,13 +2,17 @@
 // 8x128, symphonia-core/src/dsp/mdct.rs:67-146) + window + overlap-add, batched over chains.
 //
 // MI355X mapping (DESIGN.md "aac_synth"):
-//  * one 64-lane wavefront walks a SEGMENT of consecutive frames of one chain; the 1024-sample
-//    delay line stays in 16 VGPRs/lane between frames, so HBM traffic is the algorithmic
-//    4 KiB in + 4 KiB out per channel-frame (+ one halo frame re-read per segment: segments
-//    start by recomputing the previous frame's delay, which depends only on that frame's input);
-//  * a workgroup is four such wavefronts that share only the LDS-resident tables (Imdct twiddles,
-//    KBD and sine long windows, 12 KiB); they never synchronise with each other after start-up --
-//    each wavefront orders its own LDS traffic with wave-local fences;
+//  * a WORKGROUP of four wavefronts walks a SEGMENT of consecutive frames of one chain, four consecutive
+//    frames per step (wave j: frame t0 + 4 i + j: 16 KiB contiguous in, 16 KiB out); a frame's delay
+//    line depends on that frame's input alone, so the four transforms of a step are independent: each
+//    wavefront parks the delay line it produces in an LDS slot, the workgroup meets at an LDS-only
+//    barrier, each wavefront adds its predecessor's slot and stores the PCM, a second barrier frees
+//    the slots -- two barriers per step and channel.  HBM traffic is the algorithmic 4 KiB in +
+//    4 KiB out per channel-frame (+ one halo frame re-read per segment: segments start by
+//    recomputing the previous frame's delay).  (The wavefront walk this replaced -- one wavefront per
+//    segment, delay line in 16 VGPRs, no barriers after start-up -- is csrc/experiments/aac_wave_walk.h.)
+//  * the wavefronts share the LDS-resident tables (Imdct twiddles, KBD and sine windows, 13 KiB) and
+//    order their own LDS traffic inside a transform with wave-local fences;
 //  * the 512-point complex FFT is three radix-8 register passes (stages 1-3, 4-6, 7-9 of the
 //    reference's radix-2 DIT graph -- identical operands and roundings, only the schedule differs)
 //    with conflict-free LDS transposes between them whose addresses are lane base + immediate;
@@ -160,6 +164,7 @@ struct AacJsArgs {
     const int32_t *pair_chains;         // [pair][2]: the left and the right chain
     const symaccel_aac_js_frame *desc;  // [pair][frame]
     AacBandMaps maps;                   // line / 4 -> scale-factor band (long / short windows)
+    unsigned n_chains;                  // chains of the batch: the bound of pair_chains[]
 };
 
 template <bool JS>
@@ -190,6 +195,9 @@ __global__ __launch_bounds__(256, SYM_AAC_MIN_WAVES) void aac_synth_quad_kernel(
     const unsigned unit = blockIdx.x / segs_per_chain, seg = blockIdx.x % segs_per_chain;
     // the chain of channel 0 (the only one of the plain instantiation) and of channel 1
     const unsigned chain = JS ? (unsigned)js.pair_chains[2 * unit] : unit, chain1 = JS ? (unsigned)js.pair_chains[2 * unit + 1] : unit;
+    if constexpr (JS) {
+        if (chain >= js.n_chains || chain1 >= js.n_chains || chain == chain1) return;  // (device-resident indices are bounded, not trusted)
+    }
     const long t_begin = (long)seg * seg_steps * 4;
     const long t_end = t_begin + (long)seg_steps * 4 < (long)frames_per_chain ? t_begin + (long)seg_steps * 4 : (long)frames_per_chain;
     const long n_steps = (t_end - t_begin + 3) / 4;
@@ -449,9 +457,11 @@ __global__ __launch_bounds__(256, SYM_AAC_MIN_WAVES) void aac_synth_quad_kernel(
 
 // The per-chain index of a batch with channel pairs: .x = the partner chain, or -1 (after the memset) for a chain outside every
 // pair -- what tells the plain instantiation which chains are not its own.
-__global__ void aac_js_index_kernel(const int32_t *__restrict__ pair_chains, unsigned n_pairs, int2 *__restrict__ chain_index) {
+__global__ void aac_js_index_kernel(const int32_t *__restrict__ pair_chains, unsigned n_pairs, unsigned n_chains, int2 *__restrict__ chain_index) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2 * n_pairs) chain_index[pair_chains[i]] = make_int2(pair_chains[i ^ 1u], (int)i);
+    // (pair_chains lives in device memory: an index outside the batch must not become a write outside the scratch)
+    if (i < 2 * n_pairs && (unsigned)pair_chains[i] < n_chains && (unsigned)pair_chains[i ^ 1u] < n_chains)
+        chain_index[pair_chains[i]] = make_int2(pair_chains[i ^ 1u], (int)i);
 }
 
 }  // namespace
@@ -471,7 +481,7 @@ int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, 
         const size_t segs = (steps_per_chain + seg_steps - 1) / seg_steps;
         const size_t grid = n_chains * segs;
         if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-        AacJsArgs js{nullptr, nullptr, nullptr, AacBandMaps{}};
+        AacJsArgs js{nullptr, nullptr, nullptr, AacBandMaps{}, (unsigned)n_chains};
         if (n_pairs == 0 || !maps) {
             hipLaunchKernelGGL(aac_synth_quad_kernel<false>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->dev, d_coeffs, d_side,
                                d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, seg_steps, (unsigned)segs, js);
@@ -481,9 +491,9 @@ int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, 
             int2 *chain_index = reinterpret_cast<int2 *>(d_js_scratch);
             SYM_GPU(ctx, hipMemsetAsync(chain_index, 0xff, n_chains * sizeof(int2), ctx->stream));  // partner -1: not part of a pair
             hipLaunchKernelGGL(aac_js_index_kernel, dim3((unsigned)((2 * n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, d_pair_chains,
-                               (unsigned)n_pairs, chain_index);
+                               (unsigned)n_pairs, (unsigned)n_chains, chain_index);
             SYM_GPU(ctx, hipGetLastError());
-            js = AacJsArgs{chain_index, d_pair_chains, d_js_desc, *maps};
+            js = AacJsArgs{chain_index, d_pair_chains, d_js_desc, *maps, (unsigned)n_chains};
             // the pairs: a workgroup per (pair, segment) -- half as many walks as chains, so the segments are chosen for n_pairs walks
             unsigned pseg_steps;
             if (ctx->segment > 0) pseg_steps = (unsigned)((ctx->segment + 3) / 4);

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * WGW) SYM_MP3_WAVES_ATTR(FUSED) void mp3_synth_
     float *__restrict__ overlap_out, float *__restrict__ vvec_out, int32_t *__restrict__ vfront_out,
     float *__restrict__ pcm, float *__restrict__ sink, unsigned n_chains, unsigned granules_per_chain, unsigned seg_len,
     unsigned segs_per_chain, const int16_t *__restrict__ quant, const symaccel_mp3_requant *__restrict__ rq_desc,
-    const symaccel_mp3_stereo *__restrict__ st_desc, const int32_t *__restrict__ pair_chains, SfbEdges edges) {
+    const symaccel_mp3_stereo *__restrict__ st_desc, const int32_t *__restrict__ pair_chains, SfbEdges edges, unsigned chain_bound) {
     constexpr int kWgWaves = WGW;  // (shadows the file-level constant: wavefronts per workgroup of THIS instantiation)
     constexpr int kWaveFloatsT = kWaveFloats + (FUSED ? kFrontWaveFloats : 0);
     __shared__ __attribute__((aligned(16))) float lds_tab[kTabFloats + (FUSED ? kFrontTabFloats : 0)];
@@ -443,10 +443,12 @@ __global__ __launch_bounds__(64 * WGW) SYM_MP3_WAVES_ATTR(FUSED) void mp3_synth_
     const unsigned unit = in_range ? item / segs_per_chain : 0, seg = in_range ? item % segs_per_chain : 0;
     int fchain = 0;
     if (FUSED && in_range) fchain = pair_chains[2 * unit + (unsigned)half];  // -1: a mono stream's missing second channel
+    if (FUSED && fchain >= (int)chain_bound) fchain = -1;  // (unit_chains lives in device memory: an index outside the batch is skipped, not followed)
     const bool live = in_range && fchain >= 0;
     const unsigned chain = FUSED ? (live ? (unsigned)fchain : 0u) : unit;
     bool pair_live = false;  // both channels present: joint stereo can apply
-    if (FUSED) pair_live = in_range && pair_chains[2 * unit] >= 0 && pair_chains[2 * unit + 1] >= 0;
+    if (FUSED) pair_live = in_range && pair_chains[2 * unit] >= 0 && pair_chains[2 * unit + 1] >= 0 && pair_chains[2 * unit] < (int)chain_bound &&
+                           pair_chains[2 * unit + 1] < (int)chain_bound;
     const unsigned g_begin = seg * seg_len;
     const unsigned g_end = live ? min(g_begin + seg_len, granules_per_chain) : g_begin;
     const VMapX vm = vmapx(hl);
@@ -942,7 +944,7 @@ int launch_mp3(symaccel_ctx *ctx, const float *d_xr, const symaccel_mp3_side *d_
                        d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out, d_vfront_out, d_pcm,
                        static_cast<float *>(sink), (unsigned)n_chains, (unsigned)granules_per_chain, seg, (unsigned)segs,
                        (const int16_t *)nullptr, (const symaccel_mp3_requant *)nullptr, (const symaccel_mp3_stereo *)nullptr,
-                       (const int32_t *)nullptr, SfbEdges{});
+                       (const int32_t *)nullptr, SfbEdges{}, (unsigned)n_chains);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }
@@ -968,7 +970,8 @@ int launch_mp3_decode(symaccel_ctx *ctx, const int16_t *d_quant, const symaccel_
     const SfbEdges e = make_sfb_edges(host_tables(), sr);
     hipLaunchKernelGGL((mp3_synth_kernel<kFw, true>), dim3((unsigned)grid), dim3(64 * kFw), 0, ctx->stream, ctx->dev, (const float *)nullptr, d_side,
                        sr, d_overlap_in, d_vvec_in, d_vfront_in, d_overlap_out, d_vvec_out, d_vfront_out, d_pcm, static_cast<float *>(sink),
-                       (unsigned)n_pairs, (unsigned)granules_per_chain, seg, (unsigned)segs, d_quant, d_rq_desc, d_st_desc, d_pair_chains, e);
+                       (unsigned)n_pairs, (unsigned)granules_per_chain, seg, (unsigned)segs, d_quant, d_rq_desc, d_st_desc, d_pair_chains, e,
+                       (unsigned)n_chains);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 #else

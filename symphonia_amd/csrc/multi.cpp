@@ -39,7 +39,9 @@ std::once_flag g_rccl_once;
 symaccel_transport g_transport_slots[2]{};
 std::atomic<const symaccel_transport *> g_transport_ptr{nullptr};  // null: RCCL
 #define g_have_transport (g_transport_ptr.load(std::memory_order_acquire) != nullptr)
-#define g_transport (*g_transport_ptr.load(std::memory_order_acquire))
+// (every use loads the pointer ONCE into a local: a concurrent symaccel_multi_set_transport(NULL) between a check and a second load
+// would be a null dereference)
+inline const symaccel_transport *transport_now() { return g_transport_ptr.load(std::memory_order_acquire); }
 
 void load_rccl() {
     const char *names[] = {std::getenv("SYMACCEL_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -80,22 +82,22 @@ int rccl_fail(symaccel_ctx *ctx, int rc, const char *where) {
 
 // one peer-to-peer transfer through the transport in force
 int xfer_send(symaccel_ctx *ctx, const void *buf, size_t bytes, int peer, void *comm, hipStream_t stream) {
-    if (g_have_transport) return g_transport.send(buf, bytes, peer, comm, (void *)stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+    if (const symaccel_transport *t = transport_now()) return t->send(buf, bytes, peer, comm, (void *)stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
     const int rc = rccl()->Send(buf, bytes, 0, peer, comm, stream);
     return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclSend");
 }
 int xfer_recv(symaccel_ctx *ctx, void *buf, size_t bytes, int peer, void *comm, hipStream_t stream) {
-    if (g_have_transport) return g_transport.recv(buf, bytes, peer, comm, (void *)stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
+    if (const symaccel_transport *t = transport_now()) return t->recv(buf, bytes, peer, comm, (void *)stream) == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE;
     const int rc = rccl()->Recv(buf, bytes, 0, peer, comm, stream);
     return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclRecv");
 }
 int group_start(symaccel_ctx *ctx) {
-    if (g_have_transport) return g_transport.group_start ? (g_transport.group_start() == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE) : SYMACCEL_OK;
+    if (const symaccel_transport *t = transport_now()) return t->group_start ? (t->group_start() == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE) : SYMACCEL_OK;
     const int rc = rccl()->GroupStart();
     return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclGroupStart");
 }
 int group_end(symaccel_ctx *ctx) {
-    if (g_have_transport) return g_transport.group_end ? (g_transport.group_end() == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE) : SYMACCEL_OK;
+    if (const symaccel_transport *t = transport_now()) return t->group_end ? (t->group_end() == 0 ? SYMACCEL_OK : SYMACCEL_ERR_DEVICE) : SYMACCEL_OK;
     const int rc = rccl()->GroupEnd();
     return rc == 0 ? SYMACCEL_OK : rccl_fail(ctx, rc, "ncclGroupEnd");
 }
@@ -276,24 +278,25 @@ int symaccel_exchange_pipelined(symaccel_ctx *ctx, void *comm, int world, int ra
     // the transfer stream starts behind whatever the caller queued on the context's stream (the buffers' producers)
     SYM_GPU(ctx, hipEventRecord(ev_start, ctx->stream));
     SYM_GPU(ctx, hipStreamWaitEvent(xs, ev_start, 0));
+    // (from here on every failure is an assignment to `st` and a break: each exit goes through the ev_done join below)
+    auto gpu = [&](hipError_t e, const char *what) -> int { return e == hipSuccess ? SYMACCEL_OK : ctx_fail(ctx, e, what); };
     auto scatter = [&](int c) -> int {
-        SYM_TRY(exchange_chunk(ctx, comm, world, rank, root, all_in, mine_in, n_streams, in_bytes_per_stream, n_chunks, c, false, xs));
-        SYM_GPU(ctx, hipEventRecord(ev_in[c & 1], xs));
-        return SYMACCEL_OK;
+        const int s = exchange_chunk(ctx, comm, world, rank, root, all_in, mine_in, n_streams, in_bytes_per_stream, n_chunks, c, false, xs);
+        return s != SYMACCEL_OK ? s : gpu(hipEventRecord(ev_in[c & 1], xs), "hipEventRecord(scatter)");
     };
     int st = scatter(0);
     for (int c = 0; c < n_chunks && st == SYMACCEL_OK; ++c) {
         if (c + 1 < n_chunks) st = scatter(c + 1);
         if (st != SYMACCEL_OK) break;
-        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, ev_in[c & 1], 0));
+        if ((st = gpu(hipStreamWaitEvent(ctx->stream, ev_in[c & 1], 0), "hipStreamWaitEvent(scatter)")) != SYMACCEL_OK) break;
         const Slice mc = chunk_of(mine.count, n_chunks, c);
         if (mc.count && step(user, mc.first, mc.count) != 0) {
             ctx->last_error = "symaccel_exchange_pipelined: the step callback failed";
             st = SYMACCEL_ERR_DEVICE;
             break;
         }
-        SYM_GPU(ctx, hipEventRecord(ev_k[c & 1], ctx->stream));
-        SYM_GPU(ctx, hipStreamWaitEvent(xs, ev_k[c & 1], 0));
+        if ((st = gpu(hipEventRecord(ev_k[c & 1], ctx->stream), "hipEventRecord(step)")) != SYMACCEL_OK) break;
+        if ((st = gpu(hipStreamWaitEvent(xs, ev_k[c & 1], 0), "hipStreamWaitEvent(step)")) != SYMACCEL_OK) break;
         st = exchange_chunk(ctx, comm, world, rank, root, all_out, mine_out, n_streams, out_bytes_per_stream, n_chunks, c, true, xs);
     }
     // whoever synchronises the context's stream afterwards has the gathered result (also after an error: nothing stays in flight

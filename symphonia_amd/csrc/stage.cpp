@@ -394,8 +394,10 @@ int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, con
     SYM_TRY(pp.commit());
     // (the requantised spectra exist in registers and LDS only: csrc/mp3.hip mp3_front)
     SYM_GPU(ctx, hipMemcpy(d_pairs, units.data(), n_units * 8, hipMemcpyHostToDevice));  // (`units` is a local: a blocking copy)
-    for (int b = 0; b < 2; ++b)  // the records of mono units are zero (no joint-stereo flag): rows [n_pairs, n_units) at stride cg here,
-        SYM_GPU(ctx, hipMemsetAsync(d_st[b], 0, n_units * cg * sizeof(symaccel_mp3_stereo), pp.s_in));  // re-zeroed at stride ng for a short last chunk
+    // The stereo records of mono units are never INTERPRETED: the kernel masks the joint-stereo flags of a unit whose second chain is
+    // -1 (`pair_live`, csrc/mp3.hip), whatever rows [n_pairs, n_units) hold.  They are zeroed all the same, so that what the kernel
+    // loads there is defined memory.
+    for (int b = 0; b < 2; ++b) SYM_GPU(ctx, hipMemsetAsync(d_st[b], 0, n_units * cg * sizeof(symaccel_mp3_stereo), pp.s_in));
     SYM_GPU(ctx, hipMemcpyAsync(d_ov[0], h_overlap_io, n_chains * 2304, hipMemcpyHostToDevice, ctx->stream));
     SYM_GPU(ctx, hipMemcpyAsync(d_vv[0], h_vvec_io, n_chains * 4096, hipMemcpyHostToDevice, ctx->stream));
     SYM_GPU(ctx, hipMemcpyAsync(d_vf[0], h_vfront_io, n_chains * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -417,7 +419,7 @@ int symaccel_mp3_decode_pipelined(symaccel_ctx *ctx, const int16_t *h_quant, con
                               ng * sizeof(symaccel_mp3_stereo), n_pairs, hipMemcpyHostToDevice, pp.s_in));
         SYM_TRY(copy_rows(ctx, d_side[b], ng * 4, h_side + g0, granules_per_chain * 4, ng * 4, n_chains, hipMemcpyHostToDevice, pp.s_in));
         if (n_units > n_pairs && ng != cg)  // a short last chunk: the kernel indexes st_desc with stride ng, so the mono units' rows move
-            SYM_GPU(ctx, hipMemsetAsync(d_st[b] + n_pairs * ng, 0, (n_units - n_pairs) * ng * sizeof(symaccel_mp3_stereo), pp.s_in));
+            SYM_GPU(ctx, hipMemsetAsync(d_st[b] + n_pairs * ng, 0, (n_units - n_pairs) * ng * sizeof(symaccel_mp3_stereo), pp.s_in));  // (defined, not needed: see above)
         SYM_GPU(ctx, hipEventRecord(pp.ev_in[b], pp.s_in));
         SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, pp.ev_in[b], 0));
         // requantize, joint stereo and the synthesis tail (layer3/mod.rs:421-477) in one kernel
