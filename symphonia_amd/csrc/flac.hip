@@ -77,7 +77,9 @@ __device__ __forceinline__ int32_t flac_shifted(double acc_plus_magic, int shift
     return (int32_t)(uint32_t)((((uint64_t)hi << 32) | lo) >> (shift & 31));
 #endif
 }
-template <int TAPS>
+// ALL: every sample of the tile is predicted in every lane (the tile lies behind the warm-up samples of the wavefront's highest
+// order): no per-lane predicate and no divergent branch per step.  The one or two tiles in front of that take the general form.
+template <int TAPS, bool ALL = false>
 __device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&c)[32], int32_t *row, int col0,
                                                 int first_pred, int n_valid, int shift, uint32_t wasted) {
     int32_t xs[4];
@@ -89,7 +91,7 @@ __device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&
         }
         if (u < n_valid) {
             int32_t x = xs[u & 3];
-            if (col0 + u >= first_pred) {
+            if (ALL || col0 + u >= first_pred) {
                 constexpr int P = TAPS >= 8 ? SYM_FLAC_PARTS : 1;
                 double part[P];
 #pragma unroll
@@ -210,12 +212,14 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
             int32_t *row = tile + lane * kStride;
             const int first_pred = (int)p.order - (int)t0;  // column index of the first predicted sample
             if constexpr (F64) {
-                if (p.max_order <= 4)
-                    lpc_steps32_f64<4>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
+                if (t0 < p.max_order)  // a tile that still holds warm-up samples of some lane: all 32 taps (zero beyond a lane's order), predicated
+                    lpc_steps32_f64<32, false>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
+                else if (p.max_order <= 4)
+                    lpc_steps32_f64<4, true>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
                 else if (p.max_order <= 12)
-                    lpc_steps32_f64<12>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
+                    lpc_steps32_f64<12, true>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
                 else
-                    lpc_steps32_f64<32>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
+                    lpc_steps32_f64<32, true>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
             } else {
                 if (p.max_order <= 4)
                     lpc_steps32<4>(h, c, row, 0, first_pred, (int)cols, p.shift, p.wasted);

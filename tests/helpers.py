@@ -178,6 +178,56 @@ def flac_extreme_case(seed, big_coeffs):
     return buf, kind, order, shift, coeffs
 
 
+def flac_carrier_case(seed, carrier):
+    """64 blocks (one wavefront) of full-range i32 samples whose coefficient magnitudes sum to values around 2^16, with blocks 0..3
+    exactly on the bounds an exact 16-bit integer carrier of the sum has (`dot2`: every |c| <= 32767, sum <= 65533; `dot2x2`: the
+    tap pairs of even and of odd index each within 65533; `f64`: one step outside both).  Round 5 built that carrier on
+    v_dot2_i32_i16 and measured it slower than the FP64 FMA path (the instruction issues at half rate on gfx950:
+    profiles/r05e_*, HISTORY); the cases stay as extra coverage of the exact-sum arithmetic at awkward magnitudes."""
+    rng = np.random.default_rng(seed)
+    nb, blocksize = 64, 131
+    buf = rng.integers(-(1 << 31), 1 << 31, (nb, blocksize)).astype(np.int32)
+    buf[0, :50] = -(1 << 31)           # hi = -32768, lo' = -32768 throughout the history
+    buf[1, :50] = (1 << 31) - 1        # hi = 32767, lo' = 32767
+    buf[2, :50] = 0xffff               # hi = 0, lo' = 32767
+    buf[3, :50] = -65536               # hi = -1, lo' = -32768
+    kind = np.full(nb, 2, np.uint8)
+    order = rng.integers(1, 33, nb).astype(np.uint8)
+    order[:6] = 32
+    shift = rng.integers(0, 32, nb).astype(np.uint8)
+    shift[:6] = (0, 31, 15, 16, 1, 30)
+    coeffs = np.zeros((nb, 32), np.int64)
+    for b in range(nb):  # random signs, magnitudes scaled to a random total below the carrier's bound
+        mag = rng.random(32) ** 3
+        total = int(rng.integers(1, 65534)) if carrier == "dot2" else int(rng.integers(65534, 131067))
+        if carrier == "dot2":
+            m = np.floor(mag / mag.sum() * total)
+        else:  # each half of the tap pairs gets its own budget
+            m = np.zeros(32)
+            for h in (0, 1):
+                idx = [j for j in range(32) if (j >> 1) & 1 == h]
+                part = mag[idx]
+                m[idx] = np.floor(part / part.sum() * min(65533, total // 2 + (0 if h else total % 2)))
+        m = np.minimum(m, 32767)
+        coeffs[b] = (m * rng.choice([-1, 1], 32)).astype(np.int64)
+    if carrier == "dot2":
+        coeffs[0] = 0; coeffs[0, :2] = (32767, 32766)                      # sum 65533, all positive: the accumulators' largest value
+        coeffs[1] = 0; coeffs[1, :2] = (-32767, -32766)                    # ... and smallest
+        coeffs[2] = 0; coeffs[2, [0, 1, 31]] = (32767, -32765, 1)          # an odd coefficient sum (the folded constant's half)
+        coeffs[3] = np.where(np.arange(32) % 2 == 0, 2047, -2047); coeffs[3, 0] = 2047 + 29  # 65533 spread over all 32 taps
+    elif carrier == "dot2x2":
+        coeffs[0] = 0; coeffs[0, [0, 1, 2, 3]] = (32767, 32766, 32767, 32766)        # both halves at 65533
+        coeffs[1] = 0; coeffs[1, [0, 1, 2, 3]] = (-32767, -32766, -32767, -32766)
+        coeffs[2] = 0; coeffs[2, [4, 5, 6, 7]] = (32767, -32766, -32767, 32765)
+        coeffs[3] = np.where(np.arange(32) % 2 == 0, 4095, -4095); coeffs[3, [0, 2]] += 13  # 16 * 4095 + 13 = 65533 per half
+    else:  # "f64": one step outside the dot2 carriers
+        coeffs[0] = 0; coeffs[0, 0] = 32768                                 # does not fit a signed half
+        coeffs[1] = 0; coeffs[1, [0, 1]] = (32767, 32767)                   # a half at 65534
+        coeffs[2] = 0; coeffs[2, 3] = -32768
+        coeffs[3] = 0; coeffs[3, [2, 3, 6, 7]] = (32767, 32767, 1, 0)       # the odd-index half at 65535
+    return buf, kind, order, shift, coeffs.astype(np.int32)
+
+
 def floor1_case(rng):
     """A random floor-1 configuration and y rows: (x_list, multiplier, n, ys).  Post positions are spread or clustered
     (runs of adjacent x: one-line segments), y values up to 255 whatever the range (what a non-conforming but accepted

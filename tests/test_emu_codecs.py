@@ -5,7 +5,7 @@ import pytest
 
 import oracle
 from emu_lib import emu_ctx  # noqa: F401
-from helpers import bit_equal, flac_extreme_case
+from helpers import bit_equal, flac_carrier_case, flac_extreme_case
 from symphonia_amd import FlacPredictor, Mp3Synthesis, VorbisDsp, flac_desc, mp3_side
 from symphonia_amd.backend import FLAC_FIXED, FLAC_LPC, FLAC_VERBATIM
 
@@ -305,6 +305,16 @@ def test_emu_flac_extreme_ranges(emu_ctx, big_coeffs):
     got = FlacPredictor(emu_ctx).restore(buf, flac_desc(kind, order, shift, 0 * shift), coeffs)
     want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, 0 * shift), coeffs)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("carrier", ["dot2", "dot2x2", "f64"])
+def test_emu_flac_carriers_at_their_edges(emu_ctx, carrier):
+    """Full-range samples with coefficient sets whose magnitudes sum to about 2^16 (helpers.flac_carrier_case): the reference's i64
+    arithmetic bit for bit."""
+    buf, kind, order, shift, coeffs = flac_carrier_case(31, carrier)
+    got = FlacPredictor(emu_ctx).restore(buf, flac_desc(kind, order, shift, 0 * shift), coeffs)
+    want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, 0 * shift), coeffs)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
 
 
 @pytest.mark.parametrize("blocksize,nb", [(64, 64), (100, 70), (192, 6), (31, 130)])

@@ -592,6 +592,20 @@ def test_flac_extreme_ranges(ctx, big_coeffs):
     assert np.array_equal(host(d), want)
 
 
+@pytest.mark.parametrize("carrier", ["dot2", "dot2x2", "f64"])
+def test_flac_carriers_at_their_edges(ctx, carrier):
+    """Coefficient sets whose magnitudes sum to about 2^16, full-range i32 samples (helpers.flac_carrier_case): the reference's
+    exact i64 sum, bit for bit."""
+    from helpers import flac_carrier_case
+    from symphonia_amd import FlacPredictor, flac_desc
+    for seed in (41, 42):
+        buf, kind, order, shift, coeffs = flac_carrier_case(seed, carrier)
+        d = dev(buf)
+        FlacPredictor(ctx).restore(d, dev(flac_desc(kind, order, shift, 0 * shift).view(np.uint8).reshape(-1, 4)), dev(coeffs))
+        want = oracle.flac_restore(buf, oracle.flac_desc(kind, order, shift, 0 * shift), coeffs)
+        assert np.array_equal(host(d), want), (seed, np.argwhere(host(d) != want)[:5])
+
+
 @pytest.mark.parametrize("blocksize,nb", [(4096, 256), (1000, 130), (33, 64)])
 def test_flac_restore_stereo_fused(ctx, blocksize, nb):
     """symaccel_flac_restore_stereo_device == restore, decorrelate, shift (decoder.rs:199-242)."""
