@@ -338,8 +338,10 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
     int32_t *h_units = reinterpret_cast<int32_t *>(g->h_desc + round256(bound * sizeof(BatchCopyDesc)));
     BatchCopyDesc *w = descs;
     const size_t per_chain = std::max<size_t>(1, in_bytes_per_chain(ps));
-    // ~1/6 of the group per chunk, 2 .. 32 MiB of input: long enough launches for the link, enough chunks for the overlap
-    const size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)2 << 20, g->chains * per_chain / 6));
+    // a third of the group per chunk, 8 .. 32 MiB of input: a chunk costs three launches and two event hops (~40 us), which 2 MiB
+    // chunks (44 us on the link) did not amortise -- 22.7 GB/s each way at look-ahead 64 against 37.9 at 256 (profiles/r05c_*);
+    // consecutive GROUPS overlap on the three streams anyway, so a small group is one chunk
+    const size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)8 << 20, g->chains * per_chain / 3));
     const size_t chunk_chains = std::max<size_t>(1, chunk_bytes / per_chain);
     size_t t0 = 0, k = 0;
     while (t0 < g->tickets) {

@@ -44,3 +44,26 @@ def test_lookahead_decoder_on_the_gpu():
     exe = build(against_emu=False)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_decoders_bench_harness_on_the_emulation_build():
+    """tools/decoders_bench.cpp (what `bench.py --workload decoders` runs on the GPU): S streams through LookaheadDecoder + one
+    Batcher on several caller threads, and the same decoders batching per stream -- control flow and bookkeeping on the emulation
+    library (its numbers mean nothing): no failed decode, every stream's batches accounted for, the batcher coalesced."""
+    import json
+    import build_emu
+    so = build_emu.build()
+    BUILD.mkdir(exist_ok=True)
+    exe = BUILD / "decoders_bench_emu"
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", str(ROOT / "include"), str(ROOT / "tools" / "decoders_bench.cpp"), "-o", str(exe),
+                    "-L", str(so.parent), "-lsymaccel_emu", "-Wl,-rpath," + str(so.parent), "-pthread"], check=True)
+    for codec, extra in (("aac", []), ("mp3h", []), ("mp3", ["--per-stream"])):
+        r = subprocess.run([str(exe), "--codec", codec, "--streams", "6", "--lookahead", "4", "--packets", "12", "--threads", "3"] + extra,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["failures"] == 0 and d["packets"] == 72 and d["streams"] == 6 and d["threads"] == 3
+        if extra:
+            assert d["mode"] == "per-stream" and d["launches"] == 0
+        else:
+            assert d["mode"] == "batcher" and 0 < d["launches"] < d["decoder_batches"]
