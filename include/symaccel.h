@@ -624,7 +624,13 @@ int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uin
  *   SYMACCEL_BATCH_MP3_DECODE  symaccel_mp3_decode_pipelined for ONE stream (n_chains = 1, or 2 = one channel pair):
  *                              in = { quant[chain][unit][576] i16, rq_desc[chain][unit], side[chain][unit], st_desc[unit] (one row
  *                              per SUBMISSION; ignored for n_chains = 1) }; state / out / param as MP3_SYNTH
- * `units_per_chain` = frames (AAC) / granules (MP3) per chain.  Two forms:
+ *   SYMACCEL_BATCH_VORBIS_SYNTH symaccel_vorbis_synth with every chain's planes at their largest, so that submissions of one
+ *                              block-size pair and block count share a launch whatever their block flags:
+ *                              in = { spectra[chain][unit * bs1 / 2] f32 (the chain's packed spectrum at the front), block_flag[chain][unit] };
+ *                              state = { prev_flag[chain] i32, overlap[chain][bs1 / 2] }; out = pcm[chain][unit * bs1 / 2] (the chain's
+ *                              packed PCM at the front: spec_stride = pcm_stride = unit * bs1 / 2); param = bs0_exp | bs1_exp << 8.
+ *                              Only the lines / samples the flags account for cross the link.
+ * `units_per_chain` = frames (AAC) / granules (MP3) / blocks (Vorbis) per chain.  Two forms:
  *   zero-copy:  reserve() hands out a slot of page-locked staging memory (the front end writes its output straight into the DMA
  *               source), commit() says it is filled, wait() blocks until slot.out / slot.state hold the PCM and the state AFTER
  *               the batch, release() gives the slot back.  Commit a reservation before waiting for anything on the same thread.
@@ -636,6 +642,7 @@ int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uin
 #define SYMACCEL_BATCH_AAC_SYNTH 1
 #define SYMACCEL_BATCH_MP3_SYNTH 2
 #define SYMACCEL_BATCH_MP3_DECODE 3
+#define SYMACCEL_BATCH_VORBIS_SYNTH 4
 typedef struct symaccel_batcher symaccel_batcher;
 typedef struct symaccel_batch_slot {
     void *input[4];
@@ -677,6 +684,9 @@ int symaccel_batcher_submit_mp3_decode(symaccel_batcher *b, const int16_t *quant
                                        const symaccel_mp3_stereo *st_desc, const symaccel_mp3_side *side, int sample_rate_idx,
                                        float *overlap_io, float *vvec_io, int32_t *vfront_io, float *pcm, size_t n_chains,
                                        size_t granules_per_chain, uint64_t *ticket);
+int symaccel_batcher_submit_vorbis_synth(symaccel_batcher *b, int bs0_exp, int bs1_exp, const float *spectra, const uint8_t *block_flag,
+                                         int32_t *prev_flag_io, float *overlap_io, float *pcm, size_t n_chains, size_t blocks_per_chain,
+                                         uint64_t *ticket); /* spectra / pcm: [chain][blocks_per_chain * bs1 / 2], packed at the front */
 /* wait + copy the PCM and the state after the batch into the `*_io` / `pcm` pointers given to submit + release */
 int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket);
 /* give up a submission (seek, reset): wait until nothing of it is in flight, write nothing, release */
@@ -687,7 +697,7 @@ int symaccel_batcher_flush(symaccel_batcher *b);
  * leave smaller ones to grow -- what a decoder calls when a quarter of its current batch is left */
 int symaccel_batcher_hint(symaccel_batcher *b);
 /* bytes per chain of every plane of a kind (per submission for MP3_DECODE's input[3]); unused planes 0 */
-int symaccel_batcher_plane_bytes(int kind, size_t units_per_chain, size_t *input_bytes, size_t *state_bytes, size_t *out_bytes); /* [4], [3] */
+int symaccel_batcher_plane_bytes(int kind, int param, size_t units_per_chain, size_t *input_bytes, size_t *state_bytes, size_t *out_bytes); /* [4], [3] */
 int symaccel_batcher_get_stats(symaccel_batcher *b, symaccel_batcher_stats *out);
 
 /* ------------------------------------------------------------------------- multi-GPU */

@@ -483,8 +483,8 @@ struct FinalizeResult {  // codecs/audio.rs:230-236
 // batcher instead of being transformed by a call of their own, and the next batch is submitted early -- as soon as half of the
 // current one has been handed out -- so that by the time this stream needs it, the decoders of the other streams have submitted
 // theirs and one launch (one PCIe round trip) serves all of them.  The returned planes then point into the batcher's page-locked
-// result slot (valid, like every buffer of the trait, until the next &mut call).  Codecs without a batch kind (Vorbis, FLAC)
-// ignore the batcher and keep batching per stream.
+// result slot (valid, like every buffer of the trait, until the next &mut call).  Codecs without a batch kind (FLAC) ignore the batcher and keep batching
+// per stream.
 template <class Codec>
 class LookaheadDecoder {
 public:
@@ -945,7 +945,6 @@ struct Vorbis {
     };
     explicit Vorbis(const Params &p)
         : nch_(p.channels), e0_(p.bs0_exp), e1_(p.bs1_exp), prev_(p.channels, -1), overlap_(p.channels * ((std::size_t)1 << (p.bs1_exp - 1)), 0.0f) {}
-    static constexpr int kBatchKind = 0;  // (packed, per-stream block sizes: batches per stream)
     static std::uint64_t id(const Packet &p) { return p.ts; }
     std::size_t channels() const { return nch_; }
     std::size_t packet_frames(std::size_t i) const { return emits_[i] ? off_[i + 1] - off_[i] : 0; }
@@ -956,8 +955,56 @@ struct Vorbis {
     }
     void decode_batch(Context &ctx, const std::vector<Packet> &batch, std::vector<float> &pcm) {
         const std::size_t k = batch.size();
+        std::size_t lines = 0, samples = 0;
+        layout(batch, &lines, &samples);
+        stride_ = samples;
+        in_.resize(nch_ * lines);
+        flags_.resize(nch_ * k);
+        pcm.assign(nch_ * samples, 0.0f);
+        gather(batch, in_.data(), lines, flags_.data());
+        check(symaccel_vorbis_synth(ctx.raw(), e0_, e1_, in_.data(), lines, flags_.data(), prev_.data(), overlap_.data(), pcm.data(), samples,
+                                    nch_, k),
+              ctx.raw());
+    }
+    // the cross-stream batcher's view: every chain's planes at their largest (k * bs1 / 2), the packed data at the front -- so that
+    // streams with different block flags share a launch (SYMACCEL_BATCH_VORBIS_SYNTH)
+    static constexpr int kBatchKind = SYMACCEL_BATCH_VORBIS_SYNTH;
+    int batch_param() const { return e0_ | (e1_ << 8); }
+    std::size_t units_per_packet() const { return 1; }
+    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
+        const std::size_t k = batch.size(), cap = k << (e1_ - 1);
+        // (the batch being handed out keeps its offsets until this one is collected: the submitted batch's layout waits in next_*)
+        std::vector<std::size_t> cur_off, cur_spec;
+        std::vector<bool> cur_emits;
+        cur_off.swap(off_);
+        cur_spec.swap(spec_off_);
+        cur_emits.swap(emits_);
+        std::size_t lines = 0, samples = 0;
+        layout(batch, &lines, &samples);
+        gather(batch, static_cast<float *>(slot.input[0]), cap, static_cast<std::uint8_t *>(slot.input[1]));
+        next_off_.swap(off_);
+        next_emits_.swap(emits_);
+        next_stride_ = cap;
+        off_.swap(cur_off);
+        spec_off_.swap(cur_spec);
+        emits_.swap(cur_emits);
+        std::memcpy(slot.state[0], prev_.data(), prev_.size() * sizeof(std::int32_t));
+        std::memcpy(slot.state[1], overlap_.data(), overlap_.size() * sizeof(float));
+    }
+    void take_state(const symaccel_batch_slot &slot) {
+        std::memcpy(prev_.data(), slot.state[0], prev_.size() * sizeof(std::int32_t));
+        std::memcpy(overlap_.data(), slot.state[1], overlap_.size() * sizeof(float));
+        off_.swap(next_off_);
+        emits_.swap(next_emits_);
+        stride_ = next_stride_;
+    }
+
+private:
+    // packed offsets of the batch's blocks inside a chain: spec_off_[i] lines, off_[i] samples (a first block owns n / 2 untouched slots)
+    void layout(const std::vector<Packet> &batch, std::size_t *lines_out, std::size_t *samples_out) {
+        const std::size_t k = batch.size();
         const std::size_t bs[2] = {(std::size_t)1 << e0_, (std::size_t)1 << e1_};
-        std::vector<std::size_t> spec_off(k);
+        spec_off_.assign(k, 0);
         off_.assign(k + 1, 0);
         emits_.assign(k, false);
         std::size_t lines = 0, samples = 0;
@@ -965,39 +1012,36 @@ struct Vorbis {
         for (std::size_t i = 0; i < k; ++i) {
             const std::size_t n = bs[batch[i].long_block ? 1 : 0];
             if (batch[i].spectra.size() != nch_ * n / 2) throw std::invalid_argument("Vorbis: packet shape");
-            spec_off[i] = lines;
+            spec_off_[i] = lines;
             off_[i] = samples;
             emits_[i] = prev >= 0;
             lines += n / 2;
-            samples += prev >= 0 ? (bs[prev] + n) / 4 : n / 2;  // a first block owns n / 2 untouched slots
+            samples += prev >= 0 ? (bs[prev] + n) / 4 : n / 2;
             prev = batch[i].long_block ? 1 : 0;
         }
         off_[k] = samples;
-        stride_ = samples;
-        in_.resize(nch_ * lines);
-        flags_.resize(nch_ * k);
-        pcm.assign(nch_ * samples, 0.0f);
+        *lines_out = lines;
+        *samples_out = samples;
+    }
+    void gather(const std::vector<Packet> &batch, float *in, std::size_t spec_stride, std::uint8_t *flags) const {
+        const std::size_t k = batch.size();
+        const std::size_t bs[2] = {(std::size_t)1 << e0_, (std::size_t)1 << e1_};
         for (std::size_t i = 0; i < k; ++i) {
             const std::size_t half = bs[batch[i].long_block ? 1 : 0] / 2;
             for (std::size_t c = 0; c < nch_; ++c) {
-                std::copy_n(batch[i].spectra.data() + c * half, half, in_.data() + c * lines + spec_off[i]);
-                flags_[c * k + i] = batch[i].long_block ? 1 : 0;
+                std::copy_n(batch[i].spectra.data() + c * half, half, in + c * spec_stride + spec_off_[i]);
+                flags[c * k + i] = batch[i].long_block ? 1 : 0;
             }
         }
-        check(symaccel_vorbis_synth(ctx.raw(), e0_, e1_, in_.data(), lines, flags_.data(), prev_.data(), overlap_.data(), pcm.data(), samples,
-                                    nch_, k),
-              ctx.raw());
     }
-
-private:
     std::size_t nch_;
     int e0_, e1_;
     std::vector<std::int32_t> prev_;
     std::vector<float> overlap_, in_;
     std::vector<std::uint8_t> flags_;
-    std::vector<std::size_t> off_;
-    std::vector<bool> emits_;
-    std::size_t stride_ = 0;
+    std::vector<std::size_t> off_, spec_off_, next_off_;
+    std::vector<bool> emits_, next_emits_;
+    std::size_t stride_ = 0, next_stride_ = 0;
 };
 
 // FLAC: one packet = one frame = one subframe per channel.  What the CPU side (frame / subframe headers, Rice decode:

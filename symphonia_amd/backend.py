@@ -753,7 +753,7 @@ class PinnedBuffer:
             self.ptr = None
 
 
-BATCH_AAC_SYNTH, BATCH_MP3_SYNTH, BATCH_MP3_DECODE = 1, 2, 3
+BATCH_AAC_SYNTH, BATCH_MP3_SYNTH, BATCH_MP3_DECODE, BATCH_VORBIS_SYNTH = 1, 2, 3, 4
 
 
 class BatchSlot(C.Structure):

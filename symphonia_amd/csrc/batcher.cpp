@@ -45,9 +45,22 @@ struct PlaneSizes {
     int n_in = 0, n_state = 0;
 };
 
-bool plane_sizes(int kind, size_t units, PlaneSizes *ps) {
+bool plane_sizes(int kind, int param, size_t units, PlaneSizes *ps) {
     *ps = PlaneSizes();
     switch (kind) {
+    case SYMACCEL_BATCH_VORBIS_SYNTH: {  // symaccel_vorbis_synth with every chain's planes at their largest: spectra, flags | prev, overlap | pcm
+        const int e0 = param & 255, e1 = (param >> 8) & 255;
+        if (e0 < 6 || e1 > 13 || e0 > e1 || (param >> 16)) return false;  // (the block sizes a Vorbis stream can have, lib.rs:404-406)
+        const size_t half = (size_t)1 << (e1 - 1);
+        ps->n_in = 2;
+        ps->in[0] = units * half * 4;  // a block has at most bs1 / 2 lines ...
+        ps->in[1] = units;
+        ps->n_state = 2;
+        ps->state[0] = 4;
+        ps->state[1] = half * 4;
+        ps->out = units * half * 4;    // ... and yields at most bs1 / 2 samples
+        return true;
+    }
     case SYMACCEL_BATCH_AAC_SYNTH:  // symaccel_aac_synth: coeffs, side | delay | pcm
         ps->n_in = 2;
         ps->in[0] = units * 4096;
@@ -299,9 +312,31 @@ int launch_chunk(symaccel_batcher *b, Group *g, size_t c0, size_t nc, size_t t0,
                                  (const symaccel_mp3_stereo *)in(3), nt, (const symaccel_mp3_side *)in(2), g->param, (const float *)si(0),
                                  (const float *)si(1), (const int32_t *)si(2), (float *)so(0), (float *)so(1), (int32_t *)so(2), (float *)out, nc,
                                  g->units);
+    case SYMACCEL_BATCH_VORBIS_SYNTH: {
+        const int e0 = g->param & 255, e1 = (g->param >> 8) & 255;
+        const size_t cap = g->units << (e1 - 1);  // floats per chain of the spectrum and the PCM planes
+        return symaccel_vorbis_synth_pp_device(ctx, e0, e1, (const float *)in(0), nullptr, cap, (const uint8_t *)in(1), (const int32_t *)si(0),
+                                               (int32_t *)so(0), (const float *)si(1), (float *)so(1), (float *)out, cap, nc, g->units);
+    }
     default:
         return SYMACCEL_ERR_INVALID_ARG;
     }
+}
+
+// Vorbis: how much of a chain's spectrum / PCM plane its blocks fill (lines of the packed spectrum; samples of the packed PCM:
+// lib.rs:303 -- a block yields (prev_n + n) / 4, the first block after a reset keeps n / 2 slots): only that much crosses the link
+void vorbis_used(const uint8_t *flags, size_t nb, int32_t prev, int e0, int e1, size_t *lines, size_t *samples) {
+    const size_t bs[2] = {(size_t)1 << e0, (size_t)1 << e1};
+    size_t l = 0, s = 0;
+    int p = prev < 0 ? -1 : (prev ? 1 : 0);
+    for (size_t i = 0; i < nb; ++i) {
+        const int f = flags[i] ? 1 : 0;
+        l += bs[f] / 2;
+        s += p >= 0 ? (bs[p] + bs[f]) / 4 : bs[f] / 2;
+        p = f;
+    }
+    *lines = l;
+    *samples = s;
 }
 
 size_t pieces_of(size_t bytes) { return (bytes + kBatchCopyPiece - 1) / kBatchCopyPiece; }
@@ -333,6 +368,7 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
         bound += pieces_of(ps.out * t.n_chains);
     }
     bound += g->tickets + 8;  // (the unit list's pieces, one per chunk at most)
+    if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH) bound += 2 * g->chains;  // (spectra and PCM go chain by chain, each rounded up)
     SYM_TRY(group_device(b, g, bound));
     BatchCopyDesc *descs = reinterpret_cast<BatchCopyDesc *>(g->h_desc);
     int32_t *h_units = reinterpret_cast<int32_t *>(g->h_desc + round256(bound * sizeof(BatchCopyDesc)));
@@ -355,8 +391,18 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
         for (size_t ti = t0; ti < t1; ++ti) {
             const Ticket &t = b->tickets[g->ticket_ids[ti]];
             const SlotLayout l = slot_layout(ps, t.n_chains);
-            for (int i = 0; i < ps.n_in; ++i)
+            for (int i = 0; i < ps.n_in; ++i) {
+                if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH && i == 0) {  // the packed spectrum: what the chain's blocks fill, not the plane
+                    for (size_t c = 0; c < t.n_chains; ++c) {
+                        size_t lines, samples;
+                        vorbis_used(reinterpret_cast<const uint8_t *>(t.slot + l.in[1]) + c * g->units, g->units,
+                                    reinterpret_cast<const int32_t *>(t.slot + l.state[0])[c], g->param & 255, (g->param >> 8) & 255, &lines, &samples);
+                        add_pieces(w, t.slot + l.in[0] + c * ps.in[0], g->d_in[0] + ((size_t)t.first_chain + c) * ps.in[0], lines * 4);
+                    }
+                    continue;
+                }
                 add_pieces(w, t.slot + l.in[i], g->d_in[i] + (ps.in_per_ticket[i] ? ti : (size_t)t.first_chain) * ps.in[i], l.in_bytes[i]);
+            }
             for (int i = 0; i < ps.n_state; ++i)
                 add_pieces(w, t.slot + l.state[i], g->d_state_in[i] + (size_t)t.first_chain * ps.state[i], l.state_bytes[i]);
             if (g->kind == SYMACCEL_BATCH_MP3_DECODE) {  // (unit_chains are relative to the first chain of the chunk the submission falls into)
@@ -378,7 +424,18 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
         for (size_t ti = t0; ti < t1; ++ti) {
             const Ticket &t = b->tickets[g->ticket_ids[ti]];
             const SlotLayout l = slot_layout(ps, t.n_chains);
-            add_pieces(w, g->d_out + (size_t)t.first_chain * ps.out, t.slot + l.out, l.out_bytes);
+            if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH) {
+                // (the state planes of the slot still hold the state BEFORE the batch here: the scatter that overwrites them is the
+                // one being built)
+                for (size_t c = 0; c < t.n_chains; ++c) {
+                    size_t lines, samples;
+                    vorbis_used(reinterpret_cast<const uint8_t *>(t.slot + l.in[1]) + c * g->units, g->units,
+                                reinterpret_cast<const int32_t *>(t.slot + l.state[0])[c], g->param & 255, (g->param >> 8) & 255, &lines, &samples);
+                    add_pieces(w, g->d_out + ((size_t)t.first_chain + c) * ps.out, t.slot + l.out + c * ps.out, samples * 4);
+                }
+            } else {
+                add_pieces(w, g->d_out + (size_t)t.first_chain * ps.out, t.slot + l.out, l.out_bytes);
+            }
             for (int i = 0; i < ps.n_state; ++i)
                 add_pieces(w, g->d_state_out[i] + (size_t)t.first_chain * ps.state[i], t.slot + l.state[i], l.state_bytes[i]);
         }
@@ -502,9 +559,9 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
                              uint64_t *ticket) {
     if (!b || !slot || !ticket || n_chains == 0 || units_per_chain == 0 || n_chains > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     PlaneSizes ps;
-    if (!plane_sizes(kind, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
     if (kind == SYMACCEL_BATCH_AAC_SYNTH) param = 0;
-    if (kind != SYMACCEL_BATCH_AAC_SYNTH && (param < 0 || param > 8)) return SYMACCEL_ERR_INVALID_ARG;  // sample_rate_idx
+    if (!plane_sizes(kind, param, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
+    if ((kind == SYMACCEL_BATCH_MP3_SYNTH || kind == SYMACCEL_BATCH_MP3_DECODE) && (param < 0 || param > 8)) return SYMACCEL_ERR_INVALID_ARG;  // sample_rate_idx
     if (kind == SYMACCEL_BATCH_MP3_DECODE && n_chains > 2) return SYMACCEL_ERR_INVALID_ARG;            // one stream per submission
     std::unique_lock<std::mutex> lock(b->mu);
     int st = SYMACCEL_OK;
@@ -651,9 +708,9 @@ int symaccel_batcher_release(symaccel_batcher *b, uint64_t ticket) {
     return SYMACCEL_OK;
 }
 
-int symaccel_batcher_plane_bytes(int kind, size_t units_per_chain, size_t *in_bytes, size_t *state_bytes, size_t *out_bytes) {
+int symaccel_batcher_plane_bytes(int kind, int param, size_t units_per_chain, size_t *in_bytes, size_t *state_bytes, size_t *out_bytes) {
     PlaneSizes ps;
-    if (!plane_sizes(kind, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
+    if (!plane_sizes(kind, param, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
     for (int i = 0; i < kMaxIn; ++i)
         if (in_bytes) in_bytes[i] = ps.in[i];
     for (int i = 0; i < kMaxState; ++i)
@@ -666,7 +723,7 @@ int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_c
                             void **state_io, void *out, uint64_t *ticket) {
     if (!b || !in || !state_io || !out || !ticket) return SYMACCEL_ERR_INVALID_ARG;
     PlaneSizes ps;
-    if (!plane_sizes(kind, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
+    if (!plane_sizes(kind, kind == SYMACCEL_BATCH_AAC_SYNTH ? 0 : param, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
     for (int i = 0; i < ps.n_in; ++i)
         if (!in[i] && !(kind == SYMACCEL_BATCH_MP3_DECODE && i == 3 && n_chains == 1)) return SYMACCEL_ERR_INVALID_ARG;
     for (int i = 0; i < ps.n_state; ++i)
@@ -711,6 +768,15 @@ int symaccel_batcher_submit_mp3_decode(symaccel_batcher *b, const int16_t *quant
     const void *in[4] = {quant, rq_desc, side, st_desc};
     void *st[3] = {overlap_io, vvec_io, vfront_io};
     return symaccel_batcher_submit(b, SYMACCEL_BATCH_MP3_DECODE, sample_rate_idx, n_chains, granules_per_chain, in, st, pcm, ticket);
+}
+
+int symaccel_batcher_submit_vorbis_synth(symaccel_batcher *b, int bs0_exp, int bs1_exp, const float *spectra, const uint8_t *block_flag,
+                                         int32_t *prev_flag_io, float *overlap_io, float *pcm, size_t n_chains, size_t blocks_per_chain,
+                                         uint64_t *ticket) {
+    if (bs0_exp < 0 || bs0_exp > 255 || bs1_exp < 0 || bs1_exp > 255) return SYMACCEL_ERR_INVALID_ARG;
+    const void *in[4] = {spectra, block_flag, nullptr, nullptr};
+    void *st[3] = {prev_flag_io, overlap_io, nullptr};
+    return symaccel_batcher_submit(b, SYMACCEL_BATCH_VORBIS_SYNTH, bs0_exp | (bs1_exp << 8), n_chains, blocks_per_chain, in, st, pcm, ticket);
 }
 
 int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket) {

@@ -240,7 +240,7 @@ static void test_mp3_huffman(Context &ctx, size_t lookahead, Batcher *batcher = 
 }
 
 // ---- Vorbis: mixed block sizes, a variable number of frames per packet (none for the first block after a reset)
-static void test_vorbis(Context &ctx, size_t lookahead, int e0, int e1) {
+static void test_vorbis(Context &ctx, size_t lookahead, int e0, int e1, Batcher *batcher = nullptr) {
     const size_t nch = 2, n = 37;
     const size_t bs[2] = {(size_t)1 << e0, (size_t)1 << e1};
     std::mt19937 rng(100 + (unsigned)lookahead + (unsigned)e1);
@@ -253,10 +253,14 @@ static void test_vorbis(Context &ctx, size_t lookahead, int e0, int e1) {
         for (auto &v : track[i].spectra) v = nd(rng);
     }
     size_t cursor = 0;
-    LookaheadDecoder<Vorbis> dec(ctx, Vorbis::Params{nch, e0, e1}, lookahead, [&]() -> std::optional<Vorbis::Packet> {
+    auto peek = [&]() -> std::optional<Vorbis::Packet> {
         if (cursor >= track.size()) return std::nullopt;
         return track[cursor++];
-    });
+    };
+    std::optional<LookaheadDecoder<Vorbis>> holder;
+    if (batcher) holder.emplace(*batcher, Vorbis::Params{nch, e0, e1}, lookahead, peek);
+    else holder.emplace(ctx, Vorbis::Params{nch, e0, e1}, lookahead, peek);
+    LookaheadDecoder<Vorbis> &dec = *holder;
     // the frame-by-frame decoder: one oracle call per packet and channel, state carried like DspChannel does
     std::vector<int32_t> prev(nch, -1);
     std::vector<float> ov(nch * bs[1] / 2, 0.0f);
@@ -408,6 +412,9 @@ int main(int argc, char **argv) {
         for (size_t k : {size_t(1), size_t(4), size_t(9), size_t(64)}) test_aac(ctx, k, &batcher);
         for (size_t k : {size_t(1), size_t(3), size_t(8)}) test_mp3(ctx, k, &batcher);
         for (size_t k : {size_t(1), size_t(6)}) test_mp3_huffman(ctx, k, &batcher);
+        for (size_t k : {size_t(1), size_t(5), size_t(16)}) test_vorbis(ctx, k, 8, 11, &batcher);
+        test_vorbis(ctx, 6, 6, 9, &batcher);
+        test_vorbis(ctx, 4, 12, 13, &batcher);
     }
     test_cross_stream(ctx, 1, 8);
     test_cross_stream(ctx, 7, 8);

@@ -11,7 +11,7 @@ import pytest
 import oracle
 from emu_lib import emu_ctx  # noqa: F401
 from helpers import bit_equal
-from symphonia_amd import BATCH_AAC_SYNTH, BATCH_MP3_DECODE, BATCH_MP3_SYNTH, Batcher, mp3_side
+from symphonia_amd import BATCH_AAC_SYNTH, BATCH_MP3_DECODE, BATCH_MP3_SYNTH, BATCH_VORBIS_SYNTH, Batcher, mp3_side
 from test_staging import aac_case
 
 F = np.float32
@@ -148,6 +148,48 @@ def test_emu_mp3_decode_streams(emu_ctx):
     run_mp3_decode(emu_ctx)
 
 
+def run_vorbis(ctx, bs0e, bs1e, n_streams=5, nb=11):
+    """Streams with DIFFERENT block flags (different packed lengths) in one launch: every chain's planes at their largest,
+    nb * bs1 / 2, the packed data at the front; expectation = the oracle on each stream's own strides."""
+    from test_emu_codecs import vorbis_case
+    b = Batcher(ctx, 0)
+    half = (1 << bs1e) // 2
+    cap = nb * half
+    subs = []
+    for s in range(n_streams):
+        rng = np.random.default_rng(700 + s)
+        nch = 1 + (s % 3)
+        flags, prev, spectra, overlap, pcm_stride = vorbis_case(rng, bs0e, bs1e, nch, nb, p_long=(0.1, 0.5, 0.9)[s % 3])
+        want = oracle.vorbis_synth(bs0e, bs1e, spectra, flags, prev, overlap, pcm_stride)
+        lay = oracle.vorbis_layout(bs0e, bs1e, flags, prev)
+        spec = np.zeros((nch, cap), F)
+        spec[:, :spectra.shape[1]] = spectra
+        pcm = np.full((nch, cap), np.nan, F)
+        pv, ov = prev.copy(), overlap.copy()
+        t = b.submit(BATCH_VORBIS_SYNTH, bs0e | (bs1e << 8), [spec, np.ascontiguousarray(flags)], [pv, ov], pcm.reshape(nch, nb, half))
+        subs.append((t, pcm, pv, ov, want, lay, prev, flags, pcm_stride))
+    assert b.stats()["pending"] == n_streams
+    for t, pcm, pv, ov, want, lay, prev, flags, pcm_stride in subs:
+        b.collect(t)
+        for c in range(pcm.shape[0]):
+            # the samples the chain's blocks emit (a first block after a reset owns slots nothing writes: lib.rs:298-303)
+            start = int(lay[1][c, 1]) if prev[c] < 0 else 0
+            end = int(lay[1][c, -1])
+            assert bit_equal(pcm[c, start:end], np.asarray(want[0])[c, start:end]), c
+        assert bit_equal(ov, np.asarray(want[1])) and np.array_equal(pv, np.asarray(want[2]))
+    assert b.stats()["launches"] == 1
+    with pytest.raises(Exception):
+        b.reserve(BATCH_VORBIS_SYNTH, 5 | (11 << 8), 1, 4)   # 32-sample blocks do not exist
+    with pytest.raises(Exception):
+        b.reserve(BATCH_VORBIS_SYNTH, 11 | (8 << 8), 1, 4)   # bs0 > bs1
+    b.close()
+
+
+@pytest.mark.parametrize("bs0e,bs1e", [(8, 11), (6, 9)])
+def test_emu_vorbis_streams_with_different_flags_share_a_launch(emu_ctx, bs0e, bs1e):
+    run_vorbis(emu_ctx, bs0e, bs1e)
+
+
 def run_zero_copy(ctx):
     b = Batcher(ctx, 0)
     cases = [aac_case(2, 4, 90 + i) for i in range(3)]
@@ -251,6 +293,8 @@ def test_gpu_batcher_aac_streams(gpu_ctx):
 def test_gpu_batcher_mp3_and_zero_copy_and_threads(gpu_ctx):
     run_mp3_synth(gpu_ctx)
     run_mp3_decode(gpu_ctx, 7, 12)
+    for pair in ((8, 11), (7, 10), (12, 13)):
+        run_vorbis(gpu_ctx, *pair, n_streams=9, nb=14)
     run_zero_copy(gpu_ctx)
     run_threads(gpu_ctx, 6, 4)
 

@@ -9,7 +9,7 @@
 // peek that copies the next packet out of a small pool (a parser writes its output somewhere too).  Nothing here links the
 // oracle: bench.py times the CPU port beside this with its own harness.  One JSON line on stdout.
 //
-//   decoders_bench --codec aac|mp3|mp3h --streams S --lookahead L --packets P --threads T [--per-stream] [--flush-mb M]
+//   decoders_bench --codec aac|mp3|mp3h|vorbis --streams S --lookahead L --packets P --threads T [--per-stream] [--flush-mb M]
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -92,6 +92,19 @@ std::vector<Mp3Huffman::Packet> make_pool<Mp3Huffman>(unsigned seed) {
     return pool;
 }
 
+template <>
+std::vector<Vorbis::Packet> make_pool<Vorbis>(unsigned seed) {  // BASELINE config 4's shape: 8 channels, 2048 / 256 mixed, mostly long blocks
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nd(0.0f, 0.25f);
+    std::vector<Vorbis::Packet> pool(kPool);
+    for (auto &p : pool) {
+        p.long_block = rng() % 10 != 0;
+        p.spectra.resize(8 * (p.long_block ? 1024 : 128));
+        for (auto &v : p.spectra) v = nd(rng);
+    }
+    return pool;
+}
+
 template <class Codec>
 typename Codec::Params params();
 template <>
@@ -100,6 +113,8 @@ template <>
 Mp3::Params params<Mp3>() { return Mp3::Params{2, 2, 0}; }
 template <>
 Mp3Huffman::Params params<Mp3Huffman>() { return Mp3Huffman::Params{2, 2, 0}; }
+template <>
+Vorbis::Params params<Vorbis>() { return Vorbis::Params{8, 8, 11}; }
 
 template <class Codec>
 int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t bytes_in_per_packet) {
@@ -154,13 +169,14 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
                             if (batcher) {
                                 const auto &buf = st.dec->decode(p);
                                 uint32_t w;
-                                std::memcpy(&w, buf.planes[0] + (i % 1024 % buf.frames), 4);  // (touch the result)
+                                if (buf.frames) std::memcpy(&w, buf.planes[0] + (i % 1024 % buf.frames), 4);  // (touch the result)
+                                else w = 0;
                                 acc += w;
                             } else {
                                 std::lock_guard<std::mutex> lock(ctx_mu);
                                 const auto &buf = st.dec->decode(p);
-                                uint32_t w;
-                                std::memcpy(&w, buf.planes[0] + (i % 1024 % buf.frames), 4);
+                                uint32_t w = 0;
+                                if (buf.frames) std::memcpy(&w, buf.planes[0] + (i % 1024 % buf.frames), 4);
                                 acc += w;
                             }
                         }
@@ -189,7 +205,8 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
                 "\"GBps_each_way\": [%.3f, %.3f], \"decoder_batches\": %zu, \"launches\": %llu, \"kernel_launches\": %llu, \"max_chains_per_launch\": %llu, "
                 "\"staging_bytes\": %llu, \"failures\": %zu, \"checksum\": %llu}\n",
                 codec_name, batcher ? "batcher" : "per-stream", a.streams, a.lookahead, std::min(a.threads, a.streams), n, secs, n / secs, frames_per_packet,
-                bytes_in_per_packet, frames_per_packet * 2 * 4, n * bytes_in_per_packet / secs / 1e9, n * frames_per_packet * 8 / secs / 1e9, batches,
+                bytes_in_per_packet, frames_per_packet * params<Codec>().channels * 4, n * bytes_in_per_packet / secs / 1e9,
+                n * frames_per_packet * params<Codec>().channels * 4 / secs / 1e9, batches,
                 (unsigned long long)(s1.launches - s0.launches), (unsigned long long)(s1.chunks - s0.chunks),
                 (unsigned long long)s1.max_chains_per_launch, (unsigned long long)s1.staging_bytes, failures.load(),
                 (unsigned long long)checksum.load());
@@ -222,6 +239,8 @@ int main(int argc, char **argv) {
         if (a.codec == "aac") return run<AacLc>(a, "aac", 1024, 2 * 1024 * 4 + 2);
         if (a.codec == "mp3") return run<Mp3>(a, "mp3", 1152, 4 * 576 * 4 + 16);
         if (a.codec == "mp3h") return run<Mp3Huffman>(a, "mp3h", 1152, 4 * 576 * 2 + 4 * 52 + 2 * 48 + 16);
+        // (Vorbis: 8 channels, nine blocks in ten long -- the per-packet figures are those of a long block after a long block)
+        if (a.codec == "vorbis") return run<Vorbis>(a, "vorbis", 1024, 8 * 1024 * 4);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "decoders_bench: %s\n", e.what());
         return 1;
