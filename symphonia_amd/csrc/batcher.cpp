@@ -23,6 +23,7 @@
 // batcher only (the context itself is externally synchronised, include/symaccel.h "Thread safety").
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -180,6 +181,7 @@ struct symaccel_batcher {
     std::vector<uint32_t> free_tickets;
     symaccel_batcher_stats stats{};
     std::string last_error;
+    size_t hint_bytes = 0;  // what a group must hold for a hint to launch it
     // page-locked slot memory: slabs, carved into slots by size; a released slot goes to the free list of its size (the shapes of a
     // running service repeat: in the steady state nothing is allocated)
     struct Slab {
@@ -536,6 +538,9 @@ int symaccel_batcher_create(symaccel_ctx *ctx, size_t flush_bytes, symaccel_batc
     if (!b) return SYMACCEL_ERR_OOM;
     b->ctx = ctx;
     b->flush_bytes = flush_bytes ? flush_bytes : (size_t)64 << 20;
+    b->hint_bytes = std::min<size_t>((size_t)4 << 20, b->flush_bytes / 8);
+    if (const char *e = std::getenv("SYMACCEL_BATCHER_HINT_MB"))  // development knob (tools/gpu_r5g.sh): the hint threshold in MiB
+        if (std::atoi(e) > 0) b->hint_bytes = (size_t)std::atoi(e) << 20;
     *out = b;
     return SYMACCEL_OK;
 }
@@ -635,7 +640,7 @@ int symaccel_batcher_hint(symaccel_batcher *b) {
     std::unique_lock<std::mutex> lock(b->mu);
     // "results will be wanted soon": whatever is worth a launch of its own goes now, so that the copies and the kernels run while
     // the callers are still busy with their current batches; a group below that size waits for more submissions (or for a waiter)
-    const size_t worth = std::min<size_t>((size_t)4 << 20, b->flush_bytes / 8);
+    const size_t worth = b->hint_bytes;
     for (size_t i = 0; i < b->groups.size(); ++i) {
         Group *g = b->groups[i].get();
         if (g->state == GroupState::Open && g->tickets && g->chains * in_bytes_per_chain(g->ps) >= worth) flush_group(b, g, lock);
