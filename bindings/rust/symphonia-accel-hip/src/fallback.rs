@@ -13,6 +13,12 @@ use symphonia_core::codecs::registry::{AudioDecoderFactoryFn, CodecRegistry};
 use symphonia_core::errors::{Error, Result};
 
 /// Per codec id: `Some(factory)` = the decoder that was in force when this crate registered above it, `None` = there was none.
+///
+/// Process-wide BY CONSTRUCTION: `try_registry_new(params, opts)` (codecs/registry.rs:34-44) is not told which registry is
+/// asking, so the table cannot be keyed by registry.  An application that holds several registries with DIFFERENT decoders
+/// below this crate for the same codec gets the first one's decoder as the fall-back in all of them; registering this crate
+/// in one registry only (or building those registries from the same base set, the common case:
+/// `symphonia::default::get_codecs()`) avoids it.
 static BELOW: Mutex<Option<HashMap<AudioCodecId, Option<AudioDecoderFactoryFn>>>> = Mutex::new(None);
 
 /// Record what `registry` answers for `ids` right now (call before registering above it).  The FIRST lookup wins, also when
