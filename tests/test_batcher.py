@@ -319,3 +319,89 @@ def test_gpu_batcher_large_group_is_chunked(gpu_ctx):
     assert st["launches"] == 1 and st["chunks"] >= 3 and st["max_chains_per_launch"] == 512 and st["staging_bytes"] <= 3 * (64 << 20)
     assert bit_equal(pcm.reshape(-1, nfr, 1024), np.asarray(want_pcm)) and bit_equal(got_delay.reshape(-1, 1024), np.asarray(want_delay))
     b.close()
+
+
+def run_fuzz(ctx, seed, rounds=4, n_threads=3):
+    """Random traffic: threads submitting AAC / MP3 / Vorbis batches of random shapes in random order, collecting in random order,
+    abandoning some -- every collected result equals the oracle's, nothing is lost, the pool is quiet at the end."""
+    from test_emu_codecs import mp3_case, vorbis_case
+    b = Batcher(ctx, int(np.random.default_rng(seed).choice([0, 96 << 10, 1 << 20])))
+    errors, done = [], []
+    lock = threading.Lock()
+
+    def work(tid):
+        rng = np.random.default_rng(seed * 100 + tid)
+        try:
+            for r in range(rounds):
+                subs = []
+                for _ in range(int(rng.integers(1, 5))):
+                    kind = int(rng.choice([BATCH_AAC_SYNTH, BATCH_MP3_SYNTH, BATCH_VORBIS_SYNTH]))
+                    nch, units = int(rng.integers(1, 4)), int(rng.choice([1, 2, 3, 5, 8]))
+                    if kind == BATCH_AAC_SYNTH:
+                        coeffs, side, delay = aac_case(nch, units, int(rng.integers(1 << 30)))
+                        want = oracle.aac_synth(coeffs, side, delay)
+                        pcm, st = np.zeros((nch, units, 1024), F), [delay.copy()]
+                        t = b.submit(kind, 0, [coeffs, side], st, pcm)
+                        check = lambda pcm=pcm, st=st, want=want: bit_equal(pcm, want[0]) and bit_equal(st[0], want[1])
+                    elif kind == BATCH_MP3_SYNTH:
+                        xr, bt, mx, rz = mp3_case(rng, nch, units)
+                        ov, vv = rng.standard_normal((nch, 576)).astype(F), rng.standard_normal((nch, 1024)).astype(F)
+                        vf = rng.integers(0, 16, nch).astype(np.int32)
+                        sr = int(rng.integers(0, 9))
+                        want = oracle.mp3_synth(xr, oracle.mp3_side(bt, mx, rz), sr, ov, vv, vf)
+                        pcm, st = np.zeros(xr.shape, F), [ov.copy(), vv.copy(), vf.copy()]
+                        t = b.submit(kind, sr, [xr, np.ascontiguousarray(mp3_side(bt, mx, rz))], st, pcm)
+                        check = lambda pcm=pcm, st=st, want=want: (bit_equal(pcm, np.asarray(want[0])) and bit_equal(st[0], np.asarray(want[1]))
+                                                                   and bit_equal(st[1], np.asarray(want[2])) and np.array_equal(st[2], np.asarray(want[3])))
+                    else:
+                        e0, e1 = [(8, 11), (6, 9), (7, 10)][int(rng.integers(0, 3))]
+                        half = (1 << e1) // 2
+                        flags, prev, spectra, overlap, pcm_stride = vorbis_case(rng, e0, e1, nch, units, p_long=float(rng.random()))
+                        want = oracle.vorbis_synth(e0, e1, spectra, flags, prev, overlap, pcm_stride)
+                        lay = oracle.vorbis_layout(e0, e1, flags, prev)
+                        spec = np.zeros((nch, units * half), F)
+                        spec[:, :spectra.shape[1]] = spectra
+                        pcm, st = np.zeros((nch, units, half), F), [prev.copy(), overlap.copy()]
+                        t = b.submit(kind, e0 | (e1 << 8), [spec, np.ascontiguousarray(flags)], st, pcm)
+
+                        def check(pcm=pcm, st=st, want=want, lay=lay, prev=prev, nch=nch):
+                            flat = pcm.reshape(nch, -1)
+                            ok = bit_equal(st[1], np.asarray(want[1])) and np.array_equal(st[0], np.asarray(want[2]))
+                            for c in range(nch):
+                                a = int(lay[1][c, 1]) if prev[c] < 0 else 0
+                                ok = ok and bit_equal(flat[c, a:int(lay[1][c, -1])], np.asarray(want[0])[c, a:int(lay[1][c, -1])])
+                            return ok
+                    subs.append((t, check, kind))
+                order = rng.permutation(len(subs))
+                for i in order:
+                    t, check, kind = subs[i]
+                    if rng.random() < 0.15:
+                        ctx.lib.check(b.dll.symaccel_batcher_abandon(b.handle, t), ctx.handle)
+                        continue
+                    b.collect(t)
+                    if not check():
+                        errors.append((tid, r, kind))
+                    with lock:
+                        done.append(t)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors[:5]
+    st = b.stats()
+    assert st["pending"] == 0 and st["launches"] > 0 and len(done) > 0
+    b.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_emu_batcher_fuzz(emu_ctx, seed):
+    run_fuzz(emu_ctx, seed, rounds=2, n_threads=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_gpu_batcher_fuzz(gpu_ctx, seed):
+    run_fuzz(gpu_ctx, seed, rounds=6, n_threads=6)
