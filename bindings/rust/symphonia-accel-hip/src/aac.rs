@@ -15,7 +15,7 @@ use symphonia_core::errors::{decode_error, unsupported_error, Result};
 use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
-use crate::ctx::{check, Context, Pinned};
+use crate::ctx::{check, Context, Pinned, Pool};
 use crate::ffi;
 use crate::lookahead::{BatchCodec, Lookahead};
 
@@ -224,6 +224,10 @@ struct AacBatch {
     // that passes the library's checks and that no descriptor refers to)
     swb_long: Vec<u16>,
     swb_short: Vec<u16>,
+    // the cross-stream batcher: the batch submitted ahead (its PCM and delay lines land in `pcm` / `delay` at collect)
+    pool: Option<Arc<Pool>>,
+    ticket: Option<u64>,
+    next_batch_len: usize,
     buf: AudioBuffer<f32>,
 }
 
@@ -236,13 +240,7 @@ impl BatchCodec for AacBatch {
 
     fn transform(&mut self, batch: &[ParsedAac]) -> Result<()> {
         let k = batch.len();
-        for (i, p) in batch.iter().enumerate() {
-            for c in 0..self.nch {
-                let dst = (c * k + i) * 1024;
-                self.coeffs.as_mut_slice()[dst..dst + 1024].copy_from_slice(&p.coeffs[c * 1024..(c + 1) * 1024]);
-                self.side[c * k + i] = p.side[c];
-            }
-        }
+        self.gather(batch);
         self.batch_len = k;
         if k > 0 && batch.iter().all(|p| p.fused.is_some()) {
             return self.transform_fused(batch);
@@ -283,12 +281,117 @@ impl BatchCodec for AacBatch {
     fn clear(&mut self) {
         self.buf.clear();
     }
+
+    fn pooled(&self) -> bool {
+        self.pool.is_some()
+    }
+
+    /// `symaccel_batcher_submit_aac_decode`: the stream's next batch -- coded spectra, joint-stereo descriptors, TNS filters -- goes
+    /// to the process-wide batcher; the inputs are copied before the call returns, PCM and delay lines are written by `collect`.
+    fn submit(&mut self, batch: &[ParsedAac]) -> Result<()> {
+        let Some(pool) = self.pool.clone() else {
+            return unsupported_error("aac: no batcher");
+        };
+        if batch.is_empty() || !batch.iter().all(|p| p.fused.is_some()) || self.ticket.is_some() {
+            return unsupported_error("aac: the batcher takes the spectrum decoder's output, one batch at a time");
+        }
+        let k = batch.len();
+        self.gather(batch);
+        let (pair_chains, desc, tns) = self.describe(batch);
+        let n_pairs = pair_chains.len() / 2;
+        let mut bands: i32 = -1;
+        // SAFETY: the tables hold one entry more than the count passed; `bands` is a valid out-pointer.
+        check(
+            unsafe {
+                ffi::symaccel_batcher_aac_bands(
+                    pool.raw(),
+                    self.swb_long.as_ptr(),
+                    (self.swb_long.len() - 1) as i32,
+                    self.swb_short.as_ptr(),
+                    (self.swb_short.len() - 1) as i32,
+                    &mut bands,
+                )
+            },
+            pool.ctx_raw(),
+        )?;
+        let mut ticket = 0u64;
+        // SAFETY: coeffs / side cover nch * k (* 1024) elements, desc n_pairs * k records; they are copied before the call returns.
+        // `delay` and `pcm` are fields of self and stay where they are until `collect` / `abandon`.
+        check(
+            unsafe {
+                ffi::symaccel_batcher_submit_aac_decode(
+                    pool.raw(),
+                    bands,
+                    self.coeffs.as_slice().as_ptr(),
+                    self.side.as_ptr(),
+                    if n_pairs > 0 { pair_chains.as_ptr() } else { std::ptr::null() },
+                    if n_pairs > 0 { desc.as_ptr() } else { std::ptr::null() },
+                    n_pairs,
+                    if tns.is_empty() { std::ptr::null() } else { tns.as_ptr() },
+                    tns.len(),
+                    self.delay.as_mut_ptr(),
+                    self.pcm.as_mut_slice().as_mut_ptr(),
+                    self.nch,
+                    k,
+                    &mut ticket,
+                )
+            },
+            pool.ctx_raw(),
+        )?;
+        self.ticket = Some(ticket);
+        self.next_batch_len = k;
+        Ok(())
+    }
+
+    fn collect(&mut self) -> Result<()> {
+        let (Some(pool), Some(ticket)) = (self.pool.clone(), self.ticket.take()) else {
+            return unsupported_error("aac: nothing was submitted");
+        };
+        // SAFETY: a live ticket of this pool's batcher; the pointers given to submit are fields of self.
+        check(unsafe { ffi::symaccel_batcher_collect(pool.raw(), ticket) }, pool.ctx_raw())?;
+        self.batch_len = self.next_batch_len;
+        Ok(())
+    }
+
+    fn hint(&mut self) {
+        if let Some(pool) = &self.pool {
+            // SAFETY: a live batcher.
+            unsafe { ffi::symaccel_batcher_hint(pool.raw()) };
+        }
+    }
+
+    fn abandon(&mut self) {
+        if let (Some(pool), Some(ticket)) = (self.pool.clone(), self.ticket.take()) {
+            // SAFETY: a live ticket; nothing is written to the delay lines or the PCM.
+            unsafe { ffi::symaccel_batcher_abandon(pool.raw(), ticket) };
+        }
+    }
+}
+
+impl Drop for AacBatch {
+    fn drop(&mut self) {
+        BatchCodec::abandon(self); // (a batch still with the batcher points at this struct's buffers)
+    }
 }
 
 impl AacBatch {
+    /// The batch's coefficients and side bytes in the chain-major staging layout ([channel][packet of the batch]).
+    fn gather(&mut self, batch: &[ParsedAac]) {
+        let k = batch.len();
+        for (i, p) in batch.iter().enumerate() {
+            for c in 0..self.nch {
+                let dst = (c * k + i) * 1024;
+                self.coeffs.as_mut_slice()[dst..dst + 1024].copy_from_slice(&p.coeffs[c * 1024..(c + 1) * 1024]);
+                self.side[c * k + i] = p.side[c];
+            }
+        }
+    }
+
     /// cpe.rs:110-157 + ics/mod.rs:456-468 for the whole batch in one call: joint stereo, TNS and Dsp::synth on the device from
     /// the spectrum decoder's coefficients (already staged in `coeffs` / `side` by `transform`).
-    fn transform_fused(&mut self, batch: &[ParsedAac]) -> Result<()> {
+    /// What the fused entry points take beside the spectra: the channel pairs that are jointly coded anywhere in the batch, their
+    /// descriptors ([pair][packet]) and the TNS filters of the batch (frame = channel * k + packet).
+    fn describe(&mut self, batch: &[ParsedAac]) -> (Vec<i32>, Vec<ffi::SymaccelAacJsFrame>, Vec<ffi::SymaccelAacTnsFilter>) {
         let k = batch.len();
         // the channel pairs that are jointly coded anywhere in the batch (a stream's element layout is fixed: aac/mod.rs:121-129)
         let mut lefts: Vec<usize> = Vec::new();
@@ -329,6 +432,14 @@ impl AacBatch {
                 tns.push(t);
             }
         }
+        (pair_chains, desc, tns)
+    }
+
+    /// cpe.rs:110-157 + ics/mod.rs:456-468 for the whole batch in one call (the coefficients are already staged by `transform`).
+    fn transform_fused(&mut self, batch: &[ParsedAac]) -> Result<()> {
+        let k = batch.len();
+        let (pair_chains, desc, tns) = self.describe(batch);
+        let n_pairs = pair_chains.len() / 2;
         // SAFETY: coeffs / side / pcm cover nch * k (* 1024) elements, delay nch * 1024, desc n_pairs * k records, the swb tables
         // one entry more than the count passed; null is passed for an empty list.  The call returns after the PCM is in `pcm`.
         check(
@@ -366,7 +477,23 @@ pub struct HipAacDecoder {
 }
 
 impl HipAacDecoder {
-    pub fn try_new(_params: &AudioCodecParameters, _opts: &AudioDecoderOptions, front: Box<dyn AacFrontEnd>, max_batch: usize) -> Result<Self> {
+    pub fn try_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn AacFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, None)
+    }
+
+    /// The same decoder submitting to the process-wide cross-stream batcher (`Pool::shared()`, `SYMACCEL_BATCH_AAC_DECODE`): with
+    /// many streams open, joint stereo, TNS and synthesis of all of them run in one launch (csrc/batcher.cpp).
+    pub fn try_new_pooled(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn AacFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, Some(Pool::shared()?))
+    }
+
+    fn try_new_with_pool(
+        _params: &AudioCodecParameters,
+        _opts: &AudioDecoderOptions,
+        front: Box<dyn AacFrontEnd>,
+        max_batch: usize,
+        pool: Option<Arc<Pool>>,
+    ) -> Result<Self> {
         let params = front.params().clone();
         let (Some(rate), Some(channels)) = (params.sample_rate, params.channels.clone()) else {
             return unsupported_error("aac: sample rate and channels are required");
@@ -387,6 +514,9 @@ impl HipAacDecoder {
                 batch_len: 0,
                 swb_long: vec![0, 1024],
                 swb_short: vec![0, 128],
+                pool,
+                ticket: None,
+                next_batch_len: 0,
                 buf: AudioBuffer::new(AudioSpec::new(rate, channels), 1024),
             },
             la: Lookahead::new(max_batch),
@@ -396,8 +526,8 @@ impl HipAacDecoder {
 
 impl AudioDecoder for HipAacDecoder {
     fn reset(&mut self) {
+        self.la.reset_with(&mut self.batch); // (a batch still with the cross-stream batcher is given up first)
         self.batch.reset_state();
-        self.la.reset();
     }
 
     fn codec_info(&self) -> &CodecInfo {

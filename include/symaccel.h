@@ -630,6 +630,15 @@ int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uin
  *                              state = { prev_flag[chain] i32, overlap[chain][bs1 / 2] }; out = pcm[chain][unit * bs1 / 2] (the chain's
  *                              packed PCM at the front: spec_stride = pcm_stride = unit * bs1 / 2); param = bs0_exp | bs1_exp << 8.
  *                              Only the lines / samples the flags account for cross the link.
+ *   SYMACCEL_BATCH_AAC_DECODE  symaccel_aac_decode_pipelined for ONE stream (its n_chains channels, any number of them paired):
+ *                              in = { coeffs, side as AAC_SYNTH, blob[chain] }; state / out as AAC_SYNTH; param = the index
+ *                              symaccel_batcher_aac_bands() gave the stream's scale-factor-band tables.  The blob (every chain
+ *                              contributes 64 + units * (322 + 8 * 92) bytes to ONE contiguous region of the submission) holds
+ *                              { u32 n_pairs, n_tns, 0, 0 }, pair_chains[n_pairs][2] i32 (chains of the submission), padded to 16
+ *                              bytes, js_desc[n_pairs][unit] (644 B each), padded to 16 bytes, tns[n_tns] (92 B each, frame = chain *
+ *                              units + frame inside the submission): symaccel_batcher_submit_aac_decode() writes it.  Per launch the
+ *                              pair frames that carry TNS get their joint stereo decoded by a list pass, the filters of the whole
+ *                              group run, and ONE walk synthesises every stream of the group (cpe.rs:110-157, ics/mod.rs:449-468).
  * `units_per_chain` = frames (AAC) / granules (MP3) / blocks (Vorbis) per chain.  Two forms:
  *   zero-copy:  reserve() hands out a slot of page-locked staging memory (the front end writes its output straight into the DMA
  *               source), commit() says it is filled, wait() blocks until slot.out / slot.state hold the PCM and the state AFTER
@@ -643,6 +652,7 @@ int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uin
 #define SYMACCEL_BATCH_MP3_SYNTH 2
 #define SYMACCEL_BATCH_MP3_DECODE 3
 #define SYMACCEL_BATCH_VORBIS_SYNTH 4
+#define SYMACCEL_BATCH_AAC_DECODE 5
 typedef struct symaccel_batcher symaccel_batcher;
 typedef struct symaccel_batch_slot {
     void *input[4];
@@ -684,6 +694,14 @@ int symaccel_batcher_submit_mp3_decode(symaccel_batcher *b, const int16_t *quant
                                        const symaccel_mp3_stereo *st_desc, const symaccel_mp3_side *side, int sample_rate_idx,
                                        float *overlap_io, float *vvec_io, int32_t *vfront_io, float *pcm, size_t n_chains,
                                        size_t granules_per_chain, uint64_t *ticket);
+/* Register the scale-factor-band offset tables AAC_DECODE submissions refer to (as symaccel_aac_joint_stereo_device takes them: n + 1
+ * offsets each): the same tables give the same index; at most 64 distinct ones per batcher.  The index is the submissions' `param`. */
+int symaccel_batcher_aac_bands(symaccel_batcher *b, const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short, int n_swb_short,
+                               int *bands);
+int symaccel_batcher_submit_aac_decode(symaccel_batcher *b, int bands, const float *coeffs, const uint8_t *side,
+                                       const int32_t *pair_chains, const symaccel_aac_js_frame *js_desc, size_t n_pairs,
+                                       const symaccel_aac_tns_filter *tns, size_t n_tns, float *delay_io, float *pcm, size_t n_chains,
+                                       size_t frames_per_chain, uint64_t *ticket);
 int symaccel_batcher_submit_vorbis_synth(symaccel_batcher *b, int bs0_exp, int bs1_exp, const float *spectra, const uint8_t *block_flag,
                                          int32_t *prev_flag_io, float *overlap_io, float *pcm, size_t n_chains, size_t blocks_per_chain,
                                          uint64_t *ticket); /* spectra / pcm: [chain][blocks_per_chain * bs1 / 2], packed at the front */

@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "symaccel_aac_joint_stereo_list_device", "symaccel_aac_decode_pipelined", "symaccel_vorbis_decode",
     "symaccel_batcher_create", "symaccel_batcher_destroy", "symaccel_batcher_reserve", "symaccel_batcher_commit", "symaccel_batcher_wait",
     "symaccel_batcher_release", "symaccel_batcher_submit", "symaccel_batcher_collect", "symaccel_batcher_abandon",
-    "symaccel_batcher_submit_aac_synth", "symaccel_batcher_submit_mp3_synth", "symaccel_batcher_submit_mp3_decode", "symaccel_batcher_submit_vorbis_synth", "symaccel_batcher_flush", "symaccel_batcher_hint", "symaccel_batcher_plane_bytes",
+    "symaccel_batcher_submit_aac_synth", "symaccel_batcher_submit_mp3_synth", "symaccel_batcher_submit_mp3_decode", "symaccel_batcher_submit_vorbis_synth", "symaccel_batcher_aac_bands", "symaccel_batcher_submit_aac_decode", "symaccel_batcher_flush", "symaccel_batcher_hint", "symaccel_batcher_plane_bytes",
     "symaccel_batcher_get_stats",
 ]
 
@@ -140,6 +140,8 @@ class Library:
         d.symaccel_batcher_flush.argtypes = [_vp]
         d.symaccel_batcher_hint.argtypes = [_vp]
         d.symaccel_batcher_plane_bytes.argtypes = [_i, _i, _sz, _vp, _vp, _vp]
+        d.symaccel_batcher_aac_bands.argtypes = [_vp, _vp, _i, _vp, _i, C.POINTER(_i)]
+        d.symaccel_batcher_submit_aac_decode.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _sz, C.POINTER(C.c_uint64)]
         d.symaccel_batcher_submit_vorbis_synth.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _sz, C.POINTER(C.c_uint64)]
         d.symaccel_batcher_get_stats.argtypes = [_vp, _vp]
         d.symaccel_aac_decode_pipelined.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp, _sz, _sz, _sz]

@@ -753,7 +753,7 @@ class PinnedBuffer:
             self.ptr = None
 
 
-BATCH_AAC_SYNTH, BATCH_MP3_SYNTH, BATCH_MP3_DECODE, BATCH_VORBIS_SYNTH = 1, 2, 3, 4
+BATCH_AAC_SYNTH, BATCH_MP3_SYNTH, BATCH_MP3_DECODE, BATCH_VORBIS_SYNTH, BATCH_AAC_DECODE = 1, 2, 3, 4, 5
 
 
 class BatchSlot(C.Structure):
@@ -821,6 +821,28 @@ class Batcher:
 
     def collect(self, ticket):
         self._check(self.dll.symaccel_batcher_collect(self.handle, int(ticket)))
+
+    def aac_bands(self, swb_long, swb_short):
+        """register a stream's scale-factor-band offset tables (n + 1 offsets each): the `bands` index of submit_aac_decode"""
+        lo, sh = np.ascontiguousarray(swb_long, np.uint16), np.ascontiguousarray(swb_short, np.uint16)
+        out = C.c_int(-1)
+        self._check(self.dll.symaccel_batcher_aac_bands(self.handle, lo.ctypes.data, len(lo) - 1, sh.ctypes.data, len(sh) - 1, C.byref(out)))
+        return int(out.value)
+
+    def submit_aac_decode(self, bands, coeffs, side, pairs, js_desc, tns, delay_io, pcm):
+        """symaccel_batcher_submit_aac_decode: one stream's batch as symaccel_aac_decode_pipelined takes it (pairs [n][2] i32 or None,
+        js_desc [pair][frame] records or None, tns filters or None); delay_io / pcm are written by collect()"""
+        n_chains, frames = int(coeffs.shape[0]), int(coeffs.shape[1])
+        n_pairs = 0 if pairs is None else len(pairs)
+        n_tns = 0 if tns is None else len(tns)
+        keep = [np.ascontiguousarray(pairs, np.int32) if n_pairs else None, np.ascontiguousarray(js_desc) if n_pairs else None,
+                np.ascontiguousarray(tns) if n_tns else None]
+        t = C.c_uint64()
+        self._check(self.dll.symaccel_batcher_submit_aac_decode(
+            self.handle, int(bands), coeffs.ctypes.data, side.ctypes.data, keep[0].ctypes.data if n_pairs else None,
+            keep[1].ctypes.data if n_pairs else None, n_pairs, keep[2].ctypes.data if n_tns else None, n_tns, delay_io.ctypes.data,
+            pcm.ctypes.data, n_chains, frames, C.byref(t)))
+        return int(t.value)
 
     def reserve(self, kind, param, n_chains, units):
         slot, t = BatchSlot(), C.c_uint64()

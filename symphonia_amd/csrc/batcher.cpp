@@ -49,6 +49,17 @@ struct PlaneSizes {
 bool plane_sizes(int kind, int param, size_t units, PlaneSizes *ps) {
     *ps = PlaneSizes();
     switch (kind) {
+    case SYMACCEL_BATCH_AAC_DECODE:  // symaccel_aac_decode_pipelined for one stream: coeffs, side, the stream's descriptor blob | delay | pcm
+        ps->n_in = 3;
+        ps->in[0] = units * 4096;
+        ps->in[1] = units;
+        // the blob (aac_blob_*): header + pair list + joint-stereo rows (at most one pair per two chains) + TNS filters (at most
+        // eight per channel-frame: one per window of an EIGHT_SHORT frame), sized per chain so that it scales with the stream
+        ps->in[2] = 64 + units * (sizeof(symaccel_aac_js_frame) / 2 + 8 * sizeof(symaccel_aac_tns_filter));
+        ps->n_state = 1;
+        ps->state[0] = 4096;
+        ps->out = units * 4096;
+        return true;
     case SYMACCEL_BATCH_VORBIS_SYNTH: {  // symaccel_vorbis_synth with every chain's planes at their largest: spectra, flags | prev, overlap | pcm
         const int e0 = param & 255, e1 = (param >> 8) & 255;
         if (e0 < 6 || e1 > 13 || e0 > e1 || (param >> 16)) return false;  // (the block sizes a Vorbis stream can have, lib.rs:404-406)
@@ -132,6 +143,17 @@ SlotLayout slot_layout(const PlaneSizes &ps, size_t n_chains) {
     return l;
 }
 
+// The descriptor blob of an AAC_DECODE submission (plane in[2], n_chains * ps.in[2] bytes): what symaccel_aac_decode_pipelined takes
+// beside the spectra -- [AacBlobHeader][pair_chains: n_pairs x 2 i32, chains of THIS submission][js rows: n_pairs x units x 644 B]
+// [TNS filters: n_tns x 92 B, frame = chain * units + frame inside this submission]
+struct AacBlobHeader {
+    uint32_t n_pairs, n_tns, pad[2];
+};
+inline size_t aac_blob_pairs(size_t) { return sizeof(AacBlobHeader); }
+inline size_t aac_blob_js(size_t n_pairs) { return sizeof(AacBlobHeader) + ((n_pairs * 8 + 15) & ~(size_t)15); }
+inline size_t aac_blob_tns(size_t n_pairs, size_t units) { return aac_blob_js(n_pairs) + ((n_pairs * units * sizeof(symaccel_aac_js_frame) + 15) & ~(size_t)15); }
+inline size_t aac_blob_bytes(size_t n_pairs, size_t units, size_t n_tns) { return aac_blob_tns(n_pairs, units) + n_tns * sizeof(symaccel_aac_tns_filter); }
+
 struct Group;
 
 struct Ticket {
@@ -163,6 +185,17 @@ struct Group {
     size_t d_bytes = 0;
     char *d_in[kMaxIn] = {}, *d_state_in[kMaxState] = {}, *d_state_out[kMaxState] = {}, *d_out = nullptr;
     int32_t *d_units = nullptr;  // MP3_DECODE: unit_chains of every chunk, relative to the chunk's first chain
+    // AAC_DECODE: the group's pair list, joint-stereo rows, TNS filters, the pair frames that carry TNS, the walk's chain index
+    int32_t *d_aac_pairs = nullptr;
+    symaccel_aac_js_frame *d_aac_js = nullptr;
+    symaccel_aac_tns_filter *d_aac_tns = nullptr;
+    uint32_t *d_aac_pf = nullptr;
+    void *d_aac_index = nullptr;
+    size_t aac_pairs = 0, aac_tns = 0;  // totals of the group (counted when it is launched)
+    struct {                             // ... and of the chunk being launched: first pair / filter / TNS pair frame and their counts
+        size_t p0, np, f0, nf, q0, nq;
+    } aac_chunk{};
+    bool bad_blob = false;               // a submission's descriptor blob did not add up: the group's tickets fail with INVALID_ARG
     // page-locked: the copy descriptors of the launch (read by batch_copy_kernel straight from here) and the unit list
     char *h_desc = nullptr;
     size_t h_desc_bytes = 0;
@@ -190,6 +223,13 @@ struct symaccel_batcher {
     };
     std::vector<Slab> slabs;
     std::vector<std::pair<size_t, std::vector<char *>>> free_slots;
+    // AAC_DECODE: the scale-factor-band tables a stream's joint-stereo descriptors refer to, registered once per stream shape
+    // (symaccel_batcher_aac_bands); a submission names its table by index (`param`), which is part of the group key
+    struct Bands {
+        std::vector<uint16_t> swb_long, swb_short;
+        AacBandMaps maps;
+    };
+    std::vector<Bands> bands;
 };
 
 namespace {
@@ -261,6 +301,19 @@ int group_device(symaccel_batcher *b, Group *g, size_t n_pieces_bound) {
     total += round256(ps.out * g->chains);
     off_units = total;
     total += round256(g->tickets * 8);
+    size_t off_ap = 0, off_aj = 0, off_at = 0, off_af = 0, off_ai = 0;
+    if (g->kind == SYMACCEL_BATCH_AAC_DECODE) {
+        off_ap = total;
+        total += round256(std::max<size_t>(1, g->aac_pairs) * 8);
+        off_aj = total;
+        total += round256(std::max<size_t>(1, g->aac_pairs) * g->units * sizeof(symaccel_aac_js_frame));
+        off_at = total;
+        total += round256(std::max<size_t>(1, g->aac_tns) * sizeof(symaccel_aac_tns_filter));
+        off_af = total;
+        total += round256(std::max<size_t>(1, g->aac_tns) * 4);
+        off_ai = total;
+        total += round256(aac_js_scratch_bytes(g->chains, g->aac_pairs, g->units));
+    }
     if (total > g->d_bytes) {
         if (g->d_base) SYM_GPU(ctx, hipFree(g->d_base));
         g->d_base = nullptr;
@@ -277,7 +330,17 @@ int group_device(symaccel_batcher *b, Group *g, size_t n_pieces_bound) {
     }
     g->d_out = g->d_base + off_out;
     g->d_units = reinterpret_cast<int32_t *>(g->d_base + off_units);
-    const size_t desc_bytes = round256(n_pieces_bound * sizeof(BatchCopyDesc)) + round256(g->tickets * 8);
+    if (g->kind == SYMACCEL_BATCH_AAC_DECODE) {
+        g->d_aac_pairs = reinterpret_cast<int32_t *>(g->d_base + off_ap);
+        g->d_aac_js = reinterpret_cast<symaccel_aac_js_frame *>(g->d_base + off_aj);
+        g->d_aac_tns = reinterpret_cast<symaccel_aac_tns_filter *>(g->d_base + off_at);
+        g->d_aac_pf = reinterpret_cast<uint32_t *>(g->d_base + off_af);
+        g->d_aac_index = g->d_base + off_ai;
+    }
+    // (behind the descriptors: the MP3 unit list, or AAC_DECODE's rebased pair list, TNS filters and TNS pair frames)
+    const size_t desc_bytes = round256(n_pieces_bound * sizeof(BatchCopyDesc)) + round256(g->tickets * 8) +
+                              (g->kind == SYMACCEL_BATCH_AAC_DECODE ? round256(g->aac_pairs * 8) + round256(g->aac_tns * sizeof(symaccel_aac_tns_filter)) +
+                                                                          round256(g->aac_tns * 4) : 0);
     if (desc_bytes > g->h_desc_bytes) {
         if (g->h_desc) (void)hipHostFree(g->h_desc);
         g->h_desc = nullptr;
@@ -314,6 +377,22 @@ int launch_chunk(symaccel_batcher *b, Group *g, size_t c0, size_t nc, size_t t0,
                                  (const symaccel_mp3_stereo *)in(3), nt, (const symaccel_mp3_side *)in(2), g->param, (const float *)si(0),
                                  (const float *)si(1), (const int32_t *)si(2), (float *)so(0), (float *)so(1), (int32_t *)so(2), (float *)out, nc,
                                  g->units);
+    case SYMACCEL_BATCH_AAC_DECODE: {
+        // symaccel_aac_decode_pipelined's kernel sequence (csrc/stage.cpp) on the chunk: the pair frames that carry TNS get their joint
+        // stereo decoded in place (a list pass), the filters run, ONE walk decodes the joint stereo of every other frame on load
+        if (g->param < 0 || (size_t)g->param >= b->bands.size()) return SYMACCEL_ERR_INVALID_ARG;
+        const AacBandMaps &maps = b->bands[(size_t)g->param].maps;
+        const auto &ch = g->aac_chunk;
+        const int32_t *pairs = g->d_aac_pairs + 2 * ch.p0;
+        symaccel_aac_js_frame *js = g->d_aac_js + ch.p0 * g->units;
+        if (ch.nq) {
+            SYM_TRY(launch_aac_joint_stereo(ctx, maps, (float *)in(0), g->units, pairs, js, ch.np, g->d_aac_pf + ch.q0, ch.nq));
+            SYM_TRY(launch_aac_js_consume(ctx, js, g->d_aac_pf + ch.q0, ch.nq, ch.np * g->units));
+        }
+        if (ch.nf) SYM_TRY(launch_aac_tns(ctx, (float *)in(0), nc * g->units, g->d_aac_tns + ch.f0, ch.nf));
+        return launch_aac(ctx, (const float *)in(0), (const uint8_t *)in(1), (const float *)si(0), (float *)so(0), (float *)out, nc, g->units,
+                          ch.np ? &maps : nullptr, pairs, js, ch.np, g->d_aac_index);
+    }
     case SYMACCEL_BATCH_VORBIS_SYNTH: {
         const int e0 = g->param & 255, e1 = (g->param >> 8) & 255;
         const size_t cap = g->units << (e1 - 1);  // floats per chain of the spectrum and the PCM planes
@@ -371,9 +450,30 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
     }
     bound += g->tickets + 8;  // (the unit list's pieces, one per chunk at most)
     if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH) bound += 2 * g->chains;  // (spectra and PCM go chain by chain, each rounded up)
+    g->aac_pairs = g->aac_tns = 0;
+    g->bad_blob = false;
+    if (g->kind == SYMACCEL_BATCH_AAC_DECODE) {
+        // what the submissions' blobs announce (a blob that does not fit its plane is read as "nothing": the group fails afterwards)
+        for (uint32_t id : g->ticket_ids) {
+            Ticket &t = b->tickets[id];
+            AacBlobHeader *h = reinterpret_cast<AacBlobHeader *>(t.slot + slot_layout(ps, t.n_chains).in[2]);
+            if (2 * (size_t)h->n_pairs > t.n_chains || aac_blob_bytes(h->n_pairs, g->units, h->n_tns) > ps.in[2] * t.n_chains) {
+                g->bad_blob = true;
+                h->n_pairs = h->n_tns = 0;
+            }
+            g->aac_pairs += h->n_pairs;
+            g->aac_tns += h->n_tns;
+        }
+        bound += 3 * g->tickets + 8;  // (pair list, filters, TNS pair frames: one piece list each per chunk)
+    }
     SYM_TRY(group_device(b, g, bound));
     BatchCopyDesc *descs = reinterpret_cast<BatchCopyDesc *>(g->h_desc);
     int32_t *h_units = reinterpret_cast<int32_t *>(g->h_desc + round256(bound * sizeof(BatchCopyDesc)));
+    // AAC_DECODE: the group's pair list, filters and TNS pair frames with the indices the chunk's kernels want, built here
+    int32_t *h_pairs = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h_units) + round256(g->tickets * 8));
+    symaccel_aac_tns_filter *h_tns = reinterpret_cast<symaccel_aac_tns_filter *>(reinterpret_cast<char *>(h_pairs) + round256(g->aac_pairs * 8));
+    uint32_t *h_pf = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(h_tns) + round256(g->aac_tns * sizeof(symaccel_aac_tns_filter)));
+    size_t aac_p = 0, aac_f = 0, aac_q = 0;  // pairs / filters / TNS pair frames placed so far
     BatchCopyDesc *w = descs;
     const size_t per_chain = std::max<size_t>(1, in_bytes_per_chain(ps));
     // a third of the group per chunk, 8 .. 32 MiB of input: a chunk costs three launches and two event hops (~40 us), which 2 MiB
@@ -390,10 +490,49 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
         const int e = (int)(k & 1);
         // ---- gather: the submissions' planes into the chain-major device arrays
         BatchCopyDesc *g0 = w;
+        const size_t chunk_p0 = aac_p, chunk_f0 = aac_f, chunk_q0 = aac_q;
         for (size_t ti = t0; ti < t1; ++ti) {
             const Ticket &t = b->tickets[g->ticket_ids[ti]];
             const SlotLayout l = slot_layout(ps, t.n_chains);
             for (int i = 0; i < ps.n_in; ++i) {
+                if (g->kind == SYMACCEL_BATCH_AAC_DECODE && i == 2) {
+                    // the blob is taken apart: joint-stereo rows go as they are, the pair list and the filters are re-based to the
+                    // chunk (chain index relative to the chunk's first chain, pair index relative to its first pair)
+                    const char *blob = t.slot + l.in[2];
+                    const AacBlobHeader *h = reinterpret_cast<const AacBlobHeader *>(blob);
+                    const int32_t rel = (int32_t)(t.first_chain - c0);
+                    const int32_t *pc = reinterpret_cast<const int32_t *>(blob + aac_blob_pairs(h->n_pairs));
+                    std::vector<int32_t> pair_of(t.n_chains, -1);
+                    size_t good_pairs = 0;
+                    for (uint32_t q = 0; q < h->n_pairs; ++q) {
+                        const int32_t a = pc[2 * q], bb = pc[2 * q + 1];
+                        if (a < 0 || bb < 0 || (size_t)a >= t.n_chains || (size_t)bb >= t.n_chains || a == bb || pair_of[(size_t)a] >= 0 || pair_of[(size_t)bb] >= 0) {
+                            g->bad_blob = true;  // (the pair keeps its place -- the js rows are laid out by pair -- as an inert self-less entry)
+                            h_pairs[2 * (aac_p + q)] = rel;
+                            h_pairs[2 * (aac_p + q) + 1] = rel;
+                            continue;
+                        }
+                        pair_of[(size_t)a] = pair_of[(size_t)bb] = (int32_t)q;
+                        h_pairs[2 * (aac_p + q)] = rel + a;
+                        h_pairs[2 * (aac_p + q) + 1] = rel + bb;
+                        ++good_pairs;
+                    }
+                    (void)good_pairs;
+                    add_pieces(w, blob + aac_blob_js(h->n_pairs), reinterpret_cast<char *>(g->d_aac_js + aac_p * g->units),
+                               (size_t)h->n_pairs * g->units * sizeof(symaccel_aac_js_frame));
+                    const symaccel_aac_tns_filter *tf = reinterpret_cast<const symaccel_aac_tns_filter *>(blob + aac_blob_tns(h->n_pairs, g->units));
+                    for (uint32_t q = 0; q < h->n_tns; ++q) {
+                        symaccel_aac_tns_filter f = tf[q];
+                        const size_t chain = f.frame / g->units, frame = f.frame % g->units;
+                        if (chain >= t.n_chains) f.frame = 0xffffffffu;  // (what symaccel_aac_tns_device skips)
+                        else f.frame = (uint32_t)(((size_t)rel + chain) * g->units + frame);
+                        h_tns[aac_f++] = f;
+                        if (chain < t.n_chains && pair_of[chain] >= 0)  // a pair frame with TNS: joint stereo first, in place (list pass)
+                            h_pf[aac_q++] = (uint32_t)((aac_p - chunk_p0 + (size_t)pair_of[chain]) * g->units + frame);
+                    }
+                    aac_p += h->n_pairs;
+                    continue;
+                }
                 if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH && i == 0) {  // the packed spectrum: what the chain's blocks fill, not the plane
                     for (size_t c = 0; c < t.n_chains; ++c) {
                         size_t lines, samples;
@@ -415,6 +554,16 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
         }
         if (g->kind == SYMACCEL_BATCH_MP3_DECODE)
             add_pieces(w, reinterpret_cast<const char *>(h_units + 2 * t0), reinterpret_cast<char *>(g->d_units + 2 * t0), nt * 8);
+        if (g->kind == SYMACCEL_BATCH_AAC_DECODE) {
+            // (a pair frame listed twice -- both channels carry filters -- would be decoded twice: the list is made unique)
+            std::sort(h_pf + chunk_q0, h_pf + aac_q);
+            aac_q = (size_t)(std::unique(h_pf + chunk_q0, h_pf + aac_q) - h_pf);
+            g->aac_chunk = {chunk_p0, aac_p - chunk_p0, chunk_f0, aac_f - chunk_f0, chunk_q0, aac_q - chunk_q0};
+            add_pieces(w, reinterpret_cast<const char *>(h_pairs + 2 * chunk_p0), reinterpret_cast<char *>(g->d_aac_pairs + 2 * chunk_p0), (aac_p - chunk_p0) * 8);
+            add_pieces(w, reinterpret_cast<const char *>(h_tns + chunk_f0), reinterpret_cast<char *>(g->d_aac_tns + chunk_f0),
+                       (aac_f - chunk_f0) * sizeof(symaccel_aac_tns_filter));
+            add_pieces(w, reinterpret_cast<const char *>(h_pf + chunk_q0), reinterpret_cast<char *>(g->d_aac_pf + chunk_q0), (aac_q - chunk_q0) * 4);
+        }
         SYM_TRY(launch_batch_copy(ctx, s_in, g0, (size_t)(w - g0)));
         SYM_GPU(ctx, hipEventRecord(g->ev_in[e], s_in));
         SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, g->ev_in[e], 0));
@@ -471,7 +620,7 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
         // `done` sits behind the last scatter, which follows the last kernel, which follows the last gather
         if (dev.ok() && b->ctx->stage_out && g->done) (void)hipEventRecord(g->done, b->ctx->stage_out);
     }
-    g->status = st;
+    g->status = st != SYMACCEL_OK ? st : (g->bad_blob ? SYMACCEL_ERR_INVALID_ARG : SYMACCEL_OK);
     g->state = GroupState::Launched;
     b->stats.launches += 1;
     b->stats.chains_launched += g->chains;
@@ -568,6 +717,10 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
     if (!plane_sizes(kind, param, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
     if ((kind == SYMACCEL_BATCH_MP3_SYNTH || kind == SYMACCEL_BATCH_MP3_DECODE) && (param < 0 || param > 8)) return SYMACCEL_ERR_INVALID_ARG;  // sample_rate_idx
     if (kind == SYMACCEL_BATCH_MP3_DECODE && n_chains > 2) return SYMACCEL_ERR_INVALID_ARG;            // one stream per submission
+    if (kind == SYMACCEL_BATCH_AAC_DECODE) {
+        std::unique_lock<std::mutex> peek(b->mu);
+        if (param < 0 || (size_t)param >= b->bands.size()) return SYMACCEL_ERR_INVALID_ARG;  // (symaccel_batcher_aac_bands first)
+    }
     std::unique_lock<std::mutex> lock(b->mu);
     int st = SYMACCEL_OK;
     Group *g = open_group(b, kind, param, units_per_chain, ps, n_chains, &st);
@@ -727,6 +880,7 @@ int symaccel_batcher_plane_bytes(int kind, int param, size_t units_per_chain, si
 int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_chains, size_t units_per_chain, const void **in,
                             void **state_io, void *out, uint64_t *ticket) {
     if (!b || !in || !state_io || !out || !ticket) return SYMACCEL_ERR_INVALID_ARG;
+    if (kind == SYMACCEL_BATCH_AAC_DECODE) return SYMACCEL_ERR_INVALID_ARG;  // (symaccel_batcher_submit_aac_decode writes the blob)
     PlaneSizes ps;
     if (!plane_sizes(kind, kind == SYMACCEL_BATCH_AAC_SYNTH ? 0 : param, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
     for (int i = 0; i < ps.n_in; ++i)
@@ -773,6 +927,64 @@ int symaccel_batcher_submit_mp3_decode(symaccel_batcher *b, const int16_t *quant
     const void *in[4] = {quant, rq_desc, side, st_desc};
     void *st[3] = {overlap_io, vvec_io, vfront_io};
     return symaccel_batcher_submit(b, SYMACCEL_BATCH_MP3_DECODE, sample_rate_idx, n_chains, granules_per_chain, in, st, pcm, ticket);
+}
+
+int symaccel_batcher_aac_bands(symaccel_batcher *b, const uint16_t *swb_long, int n_swb_long, const uint16_t *swb_short, int n_swb_short, int *bands) {
+    if (!b || !bands || !swb_long || !swb_short || n_swb_long < 1 || n_swb_short < 1 || n_swb_long > 63 || n_swb_short > 15) return SYMACCEL_ERR_INVALID_ARG;
+    symaccel_batcher::Bands nb;
+    if (!aac_band_maps(swb_long, n_swb_long, swb_short, n_swb_short, &nb.maps)) return SYMACCEL_ERR_INVALID_ARG;
+    nb.swb_long.assign(swb_long, swb_long + n_swb_long + 1);
+    nb.swb_short.assign(swb_short, swb_short + n_swb_short + 1);
+    std::unique_lock<std::mutex> lock(b->mu);
+    for (size_t i = 0; i < b->bands.size(); ++i)
+        if (b->bands[i].swb_long == nb.swb_long && b->bands[i].swb_short == nb.swb_short) {
+            *bands = (int)i;
+            return SYMACCEL_OK;
+        }
+    if (b->bands.size() >= 64) return SYMACCEL_ERR_UNSUPPORTED;
+    b->bands.push_back(std::move(nb));
+    *bands = (int)b->bands.size() - 1;
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_submit_aac_decode(symaccel_batcher *b, int bands, const float *coeffs, const uint8_t *side, const int32_t *pair_chains,
+                                       const symaccel_aac_js_frame *js_desc, size_t n_pairs, const symaccel_aac_tns_filter *tns, size_t n_tns,
+                                       float *delay_io, float *pcm, size_t n_chains, size_t frames_per_chain, uint64_t *ticket) {
+    if (!b || !coeffs || !side || !delay_io || !pcm || !ticket || n_chains == 0 || frames_per_chain == 0) return SYMACCEL_ERR_INVALID_ARG;
+    if ((n_pairs && (!pair_chains || !js_desc)) || (n_tns && !tns) || 2 * n_pairs > n_chains) return SYMACCEL_ERR_INVALID_ARG;
+    {  // every chain in at most one pair, inside the submission (what symaccel_aac_decode_pipelined checks)
+        std::vector<uint8_t> seen(n_chains, 0);
+        for (size_t i = 0; i < 2 * n_pairs; ++i) {
+            const int32_t c = pair_chains[i];
+            if (c < 0 || (size_t)c >= n_chains || seen[(size_t)c]) return SYMACCEL_ERR_INVALID_ARG;
+            seen[(size_t)c] = 1;
+        }
+    }
+    PlaneSizes ps;
+    if (!plane_sizes(SYMACCEL_BATCH_AAC_DECODE, bands, frames_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
+    if (aac_blob_bytes(n_pairs, frames_per_chain, n_tns) > ps.in[2] * n_chains) return SYMACCEL_ERR_INVALID_ARG;  // (more than 8 filters per channel-frame)
+    symaccel_batch_slot slot;
+    uint64_t id = 0;
+    SYM_TRY(symaccel_batcher_reserve(b, SYMACCEL_BATCH_AAC_DECODE, bands, n_chains, frames_per_chain, &slot, &id));
+    std::memcpy(slot.input[0], coeffs, slot.input_bytes[0]);
+    std::memcpy(slot.input[1], side, slot.input_bytes[1]);
+    char *blob = static_cast<char *>(slot.input[2]);
+    AacBlobHeader h{(uint32_t)n_pairs, (uint32_t)n_tns, {0, 0}};
+    std::memcpy(blob, &h, sizeof h);
+    if (n_pairs) {
+        std::memcpy(blob + aac_blob_pairs(n_pairs), pair_chains, n_pairs * 8);
+        std::memcpy(blob + aac_blob_js(n_pairs), js_desc, n_pairs * frames_per_chain * sizeof(symaccel_aac_js_frame));
+    }
+    if (n_tns) std::memcpy(blob + aac_blob_tns(n_pairs, frames_per_chain), tns, n_tns * sizeof(symaccel_aac_tns_filter));
+    std::memcpy(slot.state[0], delay_io, slot.state_bytes[0]);
+    {
+        std::unique_lock<std::mutex> lock(b->mu);
+        Ticket *t = find_ticket(b, id);
+        t->user_state[0] = delay_io;
+        t->user_out = pcm;
+    }
+    *ticket = id;
+    return symaccel_batcher_commit(b, id);
 }
 
 int symaccel_batcher_submit_vorbis_synth(symaccel_batcher *b, int bs0_exp, int bs1_exp, const float *spectra, const uint8_t *block_flag,

@@ -213,6 +213,45 @@ def test_look_ahead_batches_and_reset(trees):
         assert st == "ok" and np.array_equal(bits(got), bits(again[i])), i
 
 
+def test_two_pooled_decoders_share_the_cross_stream_batcher(trees):
+    """`HipAacDecoder::try_new_pooled`: two AAC-LC streams (joint stereo, intensity, TNS, all window sequences) behind look-ahead readers,
+    decoded alternately.  The batches after each stream's first go through symaccel_batcher_submit_aac_decode / _collect of ONE
+    process-wide pool -- joint stereo, TNS and synthesis of both streams in the same launches -- and every packet's PCM equals the
+    reference decoder's bit for bit."""
+    nch = 2
+    n, batch = sized((10, 4), (6, 2))
+    streams = [[p for p, _ in stream(6, n, nch)], [p for p, _ in stream(2, n, nch)]]
+    want = []
+    for packets in streams:
+        ref = Harness(None, reference=True, aac_tree=trees[0])
+        ref_dec = cpu_decoder(ref, nch)
+        want.append([ref.decode("AacDecoder", ref_dec, ref.packet(pk, i * 1024))[1] for i, pk in enumerate(packets)])
+    from emu_lib import emu_library
+    h = Harness(emu_library().dll, reference=True, aac_tree=trees[1])
+    h.it.load_file(ROOT / "tests" / "rust" / "registry_stubs.rs")
+    h.load_shim("lib.rs", "ctx.rs", "decoder.rs", "lookahead.rs", "fallback.rs", "aac.rs", "frontends.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    decs, readers = [], []
+    for k, packets in enumerate(streams):
+        p = h.params("CODEC_ID_AAC", 44100, nch)
+        front = h.it.call("aac_front_end", p, h.opts())
+        assert front.variant == "Ok", front
+        r = h.it.call("HipAacDecoder::try_new_pooled", p, h.opts(), front.f["0"], usize(batch))
+        assert r.variant == "Ok", r
+        decs.append(h.f32_buffers(r.f["0"]))
+        pk = I.Arr([h.packet(d, i * 1024, track=1 + k, owned=True) for i, d in enumerate(packets)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(3 * batch)))
+    for i in range(n):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            st, got = h.decode("HipAacDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            assert st == "ok" and np.array_equal(bits(got), bits(want[k][i])), (k, i)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1
+    assert calls.count("symaccel_batcher_submit_aac_decode") >= 2 * ((n - batch) // batch)
+    assert calls.count("symaccel_aac_decode_pipelined") == 2  # each stream's cold start only
+
+
 def test_seek_into_the_middle_of_the_stream_and_reset(trees):
     """reset() after a seek must reach the reference decoder inside the front end (`AacFrontEnd::reset`): its pairs remember the
     window shape of the frame parsed last (ics/mod.rs:229-232 forgets it) -- and the front end parsed AHEAD of what the caller had been

@@ -190,6 +190,47 @@ def test_emu_vorbis_streams_with_different_flags_share_a_launch(emu_ctx, bs0e, b
     run_vorbis(emu_ctx, bs0e, bs1e)
 
 
+def run_aac_decode(ctx, n_streams=5, frames=7, seed0=900):
+    """symaccel_aac_decode_pipelined's work for many streams in ONE launch: every stream its own channel count, pairs (in any chain
+    order), joint-stereo descriptors and TNS filters; expectation = the reference's order per stream (joint stereo, TNS, Dsp::synth:
+    tests/test_aac_js_fused.py decode_case).  The pair frames with TNS take the list pass, every other frame the fused walk."""
+    import test_aac_tools as T
+    from test_aac_js_fused import decode_case
+    b = Batcher(ctx, 0)
+    bands = b.aac_bands(T.SWB_LONG, T.SWB_SHORT)
+    assert b.aac_bands(T.SWB_LONG, T.SWB_SHORT) == bands  # the same tables: the same index
+    subs = []
+    shapes = [(1, 0, 0.3), (2, 1, 0.5), (0, 2, 0.4), (3, 0, 0.0), (1, 1, 1.0), (0, 1, 0.0), (2, 0, 0.7)]
+    for s in range(n_streams):
+        n_pairs, extra, p_tns = shapes[s % len(shapes)]
+        coeffs, side, delay, pairs, desc, filt, want_pcm, want_delay = decode_case(seed0 + s, n_pairs, extra, frames, p_tns)
+        pcm, d = np.zeros_like(coeffs), delay.copy()
+        before = coeffs.copy()
+        t = b.submit_aac_decode(bands, coeffs, side, pairs if n_pairs else None, desc if n_pairs else None, filt if len(filt) else None, d, pcm)
+        assert bit_equal(coeffs, before)
+        subs.append((t, pcm, d, want_pcm, want_delay))
+    assert b.stats()["pending"] == n_streams
+    for t, pcm, d, want_pcm, want_delay in subs:
+        b.collect(t)
+        assert bit_equal(pcm, want_pcm) and bit_equal(d, want_delay)
+    assert b.stats()["launches"] == 1
+    # what the typed entry refuses: a chain in two pairs, a pair outside the stream, tables that were never registered
+    coeffs, side, delay, pairs, desc, filt, _, _ = decode_case(1, 1, 0, frames, 0.5)
+    pcm = np.zeros_like(coeffs)
+    with pytest.raises(Exception):
+        b.submit_aac_decode(bands, coeffs, side, np.array([[0, 1], [1, 0]], np.int32), np.zeros((2, frames), desc.dtype), None, delay.copy(), pcm)
+    with pytest.raises(Exception):
+        b.submit_aac_decode(bands, coeffs, side, np.array([[0, 2]], np.int32), desc, None, delay.copy(), pcm)
+    with pytest.raises(Exception):
+        b.submit_aac_decode(bands + 7, coeffs, side, None, None, None, delay.copy(), pcm)
+    assert b.stats()["pending"] == 0
+    b.close()
+
+
+def test_emu_aac_decode_streams_share_a_launch(emu_ctx):
+    run_aac_decode(emu_ctx)
+
+
 def run_zero_copy(ctx):
     b = Batcher(ctx, 0)
     cases = [aac_case(2, 4, 90 + i) for i in range(3)]
@@ -295,6 +336,8 @@ def test_gpu_batcher_mp3_and_zero_copy_and_threads(gpu_ctx):
     run_mp3_decode(gpu_ctx, 7, 12)
     for pair in ((8, 11), (7, 10), (12, 13)):
         run_vorbis(gpu_ctx, *pair, n_streams=9, nb=14)
+    run_aac_decode(gpu_ctx, n_streams=14, frames=33, seed0=1200)
+    run_aac_decode(gpu_ctx, n_streams=40, frames=9, seed0=1300)
     run_zero_copy(gpu_ctx)
     run_threads(gpu_ctx, 6, 4)
 
