@@ -482,9 +482,12 @@ __device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const cp
     wave_sync();
     bitrev8(z);
     fft8_regs(z);  // -> a_w[8*rev3(c) + r] = element (B = w, j = rev3(c), k = r)
+    // (the exchange in the T1M layout: T1's is conflict-free only for the 512-point transform's lane order -- here the sixteen lanes
+    // of a store hold two windows x eight j, whose T1 addresses fall on the same banks four at a time: 128 + 16 LDS cycles per
+    // exchange against 32 + 16, tools/vorbis_lds_model.py)
     {
         const int j = (int)rev_bits((unsigned)c, 3);
-        c32 *wp = lds + lds_t1_lane_w(w, j);
+        c32 *wp = lds + lds_t1m_lane_w(w, j);
 #pragma unroll
         for (int r = 0; r < 8; ++r) wp[lds_t1_inst_w(r)] = z[r];
     }
@@ -492,7 +495,7 @@ __device__ __forceinline__ void imdct_short_wave(int lane, float *ldsf, const cp
     {
         const c32 *rp = lds + lds_t1_lane_r(w, c);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = rp[lds_t1_inst_r(j)];
+        for (int j = 0; j < 8; ++j) z[j] = rp[lds_t1m_inst_r(j)];
     }
     pass2_regs(z, lt);  // 64-point FFT done: z[j] = Z_w[8j + k], k = c
     wave_sync();
