@@ -947,6 +947,8 @@ def decoders_workload(quick=False, seconds_cpu=3.0, lookahead=64):
         out["mp3_int16_S256"] = run("mp3h", 256, max(1, min(256, cores)))
         out["mp3_f32_S256"] = run("mp3", 256, max(1, min(256, cores)))
         out["vorbis_8ch_S64"] = run("vorbis", 64, max(1, min(64, cores)))  # (BASELINE config 4's shape: 8 channels, 2048 / 256)
+        # AAC one stage earlier: coded spectra + joint-stereo descriptors + TNS filters (30 % of the frames) -> PCM
+        out["aac_coded_S256"] = run("aacd", 256, max(1, min(256, cores)))
         in0 = rng.standard_normal((16, 32, 1024)).astype(np.float32)
         in0[:, :, 672:] = 0.0
         in1 = np.full((16, 32), oracle.aac_side(0, 1, 1), np.uint8)

@@ -500,6 +500,7 @@ public:
     LookaheadDecoder(Batcher &batcher, const typename Codec::Params &params, std::size_t lookahead, Peek peek)
         : ctx_(batcher.context()), codec_(params), lookahead_(lookahead < 1 ? 1 : lookahead), peek_(std::move(peek)),
           batcher_(Codec::kBatchKind ? &batcher : nullptr) {
+        if (batcher_) codec_.attach(batcher);  // (what a codec registers with the batcher once: AacLcCoded's band tables)
         reset();
     }
     ~LookaheadDecoder() { drop_tickets(); }
@@ -741,6 +742,7 @@ struct AacLc {
     }
     // the cross-stream batcher's view of the same batch (LookaheadDecoder's second constructor)
     static constexpr int kBatchKind = SYMACCEL_BATCH_AAC_SYNTH;
+    void attach(Batcher &) {}
     int batch_param() const { return 0; }
     std::size_t units_per_packet() const { return 1; }
     void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
@@ -763,6 +765,117 @@ private:
     std::size_t nch_;
     std::vector<float> delay_, in_;
     std::vector<std::uint8_t> side_;
+};
+
+// AAC-LC one stage earlier: what the spectrum decoder produces (cpe.rs:110-157 and ics/mod.rs:449-468 still to come) -- the
+// coefficients as decoded (mid / side or intensity coded where the descriptors say so), per jointly coded channel pair its
+// descriptor, and the TNS filters of the packet; joint stereo, TNS and Dsp::synth run on the device (symaccel_aac_decode_pipelined,
+// or SYMACCEL_BATCH_AAC_DECODE through the batcher: the pair frames with TNS take a list pass, the filters run, one walk synthesises).
+struct AacLcCoded {
+    using Sample = float;
+    struct Params {
+        std::size_t channels = 2;
+        std::vector<std::uint16_t> swb_long, swb_short;  // the stream's scale-factor-band offsets (n + 1 values each)
+    };
+    struct Packet {
+        std::uint64_t ts = 0;
+        std::vector<float> coeffs;                                       // [channel][1024]
+        std::vector<std::uint8_t> side;                                  // [channel]
+        std::vector<std::pair<std::size_t, symaccel_aac_js_frame>> joint;  // (left channel of the pair, its descriptor)
+        std::vector<symaccel_aac_tns_filter> tns;                        // frame = channel
+    };
+    explicit AacLcCoded(const Params &p) : nch_(p.channels), swb_long_(p.swb_long), swb_short_(p.swb_short), delay_(p.channels * 1024, 0.0f) {
+        if (swb_long_.size() < 2 || swb_short_.size() < 2) throw std::invalid_argument("AacLcCoded: band tables");
+    }
+    static std::uint64_t id(const Packet &p) { return p.ts; }
+    std::size_t channels() const { return nch_; }
+    std::size_t packet_frames(std::size_t) const { return 1024; }
+    std::size_t plane_offset(std::size_t c, std::size_t i, std::size_t k) const { return (c * k + i) * 1024; }
+    void reset_state() { std::fill(delay_.begin(), delay_.end(), 0.0f); }
+    void decode_batch(Context &ctx, const std::vector<Packet> &batch, std::vector<float> &pcm) {
+        const std::size_t k = batch.size();
+        in_.resize(nch_ * k * 1024);
+        side_.resize(nch_ * k);
+        pcm.resize(nch_ * k * 1024);
+        describe(batch, in_.data(), side_.data());
+        const std::size_t n_pairs = pairs_.size() / 2;
+        check(symaccel_aac_decode_pipelined(ctx.raw(), in_.data(), side_.data(), n_pairs ? pairs_.data() : nullptr, n_pairs ? js_.data() : nullptr,
+                                            n_pairs, swb_long_.data(), (int)swb_long_.size() - 1, swb_short_.data(), (int)swb_short_.size() - 1,
+                                            tns_.empty() ? nullptr : tns_.data(), tns_.size(), delay_.data(), pcm.data(), nch_, k, 0),
+              ctx.raw());
+    }
+    static constexpr int kBatchKind = SYMACCEL_BATCH_AAC_DECODE;
+    void attach(Batcher &b) {
+        check(symaccel_batcher_aac_bands(b.raw(), swb_long_.data(), (int)swb_long_.size() - 1, swb_short_.data(), (int)swb_short_.size() - 1, &bands_),
+              b.context().raw());
+    }
+    int batch_param() const { return bands_; }
+    std::size_t units_per_packet() const { return 1; }
+    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
+        const std::size_t k = batch.size();
+        describe(batch, static_cast<float *>(slot.input[0]), static_cast<std::uint8_t *>(slot.input[1]));
+        // the descriptor blob (include/symaccel.h, SYMACCEL_BATCH_AAC_DECODE): header, pair list, js rows, filters, 16-byte aligned parts
+        const std::size_t n_pairs = pairs_.size() / 2;
+        const std::size_t off_js = 16 + ((n_pairs * 8 + 15) & ~(std::size_t)15);
+        const std::size_t off_tns = off_js + ((n_pairs * k * sizeof(symaccel_aac_js_frame) + 15) & ~(std::size_t)15);
+        if (off_tns + tns_.size() * sizeof(symaccel_aac_tns_filter) > slot.input_bytes[2]) throw std::invalid_argument("AacLcCoded: more than 8 TNS filters per channel-frame");
+        char *blob = static_cast<char *>(slot.input[2]);
+        const std::uint32_t header[4] = {(std::uint32_t)n_pairs, (std::uint32_t)tns_.size(), 0u, 0u};
+        std::memcpy(blob, header, 16);
+        if (n_pairs) {
+            std::memcpy(blob + 16, pairs_.data(), n_pairs * 8);
+            std::memcpy(blob + off_js, js_.data(), n_pairs * k * sizeof(symaccel_aac_js_frame));
+        }
+        if (!tns_.empty()) std::memcpy(blob + off_tns, tns_.data(), tns_.size() * sizeof(symaccel_aac_tns_filter));
+        std::memcpy(slot.state[0], delay_.data(), delay_.size() * sizeof(float));
+    }
+    void take_state(const symaccel_batch_slot &slot) { std::memcpy(delay_.data(), slot.state[0], delay_.size() * sizeof(float)); }
+
+private:
+    // the batch in the entry points' terms: chain-major spectra + side bytes, the pairs coded jointly anywhere in the batch, their
+    // descriptors [pair][packet] (a packet in which a pair is not jointly coded gets the empty descriptor), the filters re-based
+    void describe(const std::vector<Packet> &batch, float *in, std::uint8_t *side) {
+        const std::size_t k = batch.size();
+        std::vector<std::size_t> lefts;
+        for (std::size_t i = 0; i < k; ++i) {
+            const Packet &p = batch[i];
+            if (p.coeffs.size() != nch_ * 1024 || p.side.size() != nch_) throw std::invalid_argument("AacLcCoded: packet shape");
+            for (std::size_t c = 0; c < nch_; ++c) {
+                std::copy_n(p.coeffs.data() + c * 1024, 1024, in + (c * k + i) * 1024);
+                side[c * k + i] = p.side[c];
+            }
+            for (const auto &j : p.joint)
+                if (j.first + 1 < nch_ && std::find(lefts.begin(), lefts.end(), j.first) == lefts.end()) lefts.push_back(j.first);
+        }
+        std::sort(lefts.begin(), lefts.end());
+        pairs_.clear();
+        for (std::size_t l : lefts) {
+            pairs_.push_back((std::int32_t)l);
+            pairs_.push_back((std::int32_t)l + 1);
+        }
+        symaccel_aac_js_frame none{};
+        none.num_windows = 1;
+        js_.assign(lefts.size() * k, none);
+        tns_.clear();
+        for (std::size_t i = 0; i < k; ++i) {
+            for (const auto &j : batch[i].joint) {
+                const auto it = std::find(lefts.begin(), lefts.end(), j.first);
+                if (it != lefts.end()) js_[(std::size_t)(it - lefts.begin()) * k + i] = j.second;
+            }
+            for (symaccel_aac_tns_filter f : batch[i].tns) {
+                f.frame = (std::uint32_t)((std::size_t)f.frame * k + i);  // [channel][packet of the batch]
+                tns_.push_back(f);
+            }
+        }
+    }
+    std::size_t nch_;
+    std::vector<std::uint16_t> swb_long_, swb_short_;
+    std::vector<float> delay_, in_;
+    std::vector<std::uint8_t> side_;
+    std::vector<std::int32_t> pairs_;
+    std::vector<symaccel_aac_js_frame> js_;
+    std::vector<symaccel_aac_tns_filter> tns_;
+    int bands_ = -1;
 };
 
 // MPEG-1/2 Layer III: one packet = one frame = `granules` granules of 576 frames per channel (2 for MPEG-1, 1 for
@@ -803,6 +916,7 @@ struct Mp3 {
               ctx.raw());
     }
     static constexpr int kBatchKind = SYMACCEL_BATCH_MP3_SYNTH;
+    void attach(Batcher &) {}
     int batch_param() const { return sr_; }
     std::size_t units_per_packet() const { return ngr_; }
     void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
@@ -883,6 +997,7 @@ struct Mp3Huffman {
     }
 
     static constexpr int kBatchKind = SYMACCEL_BATCH_MP3_DECODE;  // one stream per submission: exactly what this codec is
+    void attach(Batcher &) {}
     int batch_param() const { return sr_; }
     std::size_t units_per_packet() const { return ngr_; }
     void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
@@ -969,6 +1084,7 @@ struct Vorbis {
     // the cross-stream batcher's view: every chain's planes at their largest (k * bs1 / 2), the packed data at the front -- so that
     // streams with different block flags share a launch (SYMACCEL_BATCH_VORBIS_SYNTH)
     static constexpr int kBatchKind = SYMACCEL_BATCH_VORBIS_SYNTH;
+    void attach(Batcher &) {}
     int batch_param() const { return e0_ | (e1_ << 8); }
     std::size_t units_per_packet() const { return 1; }
     void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
@@ -1069,6 +1185,7 @@ struct Flac {
         if (p.channels == 0 || p.bits_per_sample == 0 || p.bits_per_sample > 32) throw std::invalid_argument("Flac: parameters");
     }
     static constexpr int kBatchKind = 0;  // (block sizes differ from stream to stream: batches per stream)
+    void attach(Batcher &) {}
     static std::uint64_t id(const Packet &p) { return p.ts; }
     std::size_t channels() const { return nch_; }
     std::size_t packet_frames(std::size_t i) const { return lens_[i]; }

@@ -343,6 +343,102 @@ static void test_flac(Context &ctx, size_t lookahead, size_t nch, uint32_t bps) 
     }
 }
 
+// ---- AAC-LC one stage earlier: coded spectra + joint-stereo descriptors + TNS filters in, the device decodes, filters and synthesises
+static const uint16_t kSwbLong[] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216,
+                                    240, 264, 292, 320, 352, 384, 416, 448, 480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800, 832, 864, 896,
+                                    928, 1024};
+static const uint16_t kSwbShort[] = {0, 4, 8, 12, 16, 20, 28, 36, 44, 56, 68, 80, 96, 112, 128};
+
+static void test_aac_coded(Context &ctx, size_t lookahead, Batcher *batcher = nullptr) {
+    const size_t nch = 3, n = 29;  // channels 0 / 1 a pair, channel 2 on its own
+    std::mt19937 rng(77 + (unsigned)lookahead);
+    std::normal_distribution<float> nd(0.0f, 40.0f);
+    std::uniform_real_distribution<float> ud(-0.4f, 0.4f);
+    std::vector<AacLcCoded::Packet> track(n);
+    int cur = 0, prev_shape = 1;
+    for (size_t i = 0; i < n; ++i) {
+        AacLcCoded::Packet &p = track[i];
+        cur = (cur == 0 || cur == 3) ? ((rng() % 4 == 0) ? 1 : 0) : ((rng() % 2) ? 2 : 3);
+        const int shape = (int)(rng() % 2);
+        p.ts = 3000 + 1024 * i;
+        p.coeffs.resize(nch * 1024);
+        for (auto &v : p.coeffs) v = nd(rng);
+        p.side.assign(nch, SYMACCEL_AAC_SIDE((unsigned)cur, (unsigned)shape, (unsigned)prev_shape));
+        prev_shape = shape;
+        const bool is_short = cur == 2;
+        if (rng() % 4 != 0) {  // the pair is jointly coded in three packets of four
+            symaccel_aac_js_frame d;
+            std::memset(&d, 0, sizeof d);
+            d.num_windows = is_short ? 8 : 1;
+            d.max_sfb = (uint8_t)(is_short ? 1 + rng() % 14 : 1 + rng() % 49);
+            for (int s = 0; s < 128; ++s) {
+                d.mode[s] = (uint8_t)(rng() % 3);
+                d.scale[s] = ud(rng) * 4.0f;
+            }
+            p.joint.emplace_back(0, d);
+        }
+        for (size_t c = 0; c < nch; ++c) {
+            if (rng() % 3) continue;  // TNS on a third of the channel-frames
+            const int windows = is_short ? 1 + (int)(rng() % 3) : 1;
+            for (int k = 0; k < windows; ++k) {
+                symaccel_aac_tns_filter f;
+                std::memset(&f, 0, sizeof f);
+                const int w = is_short ? (int)(rng() % 8) : 0, span = is_short ? 128 : 1024;
+                int a = (int)(rng() % span), b2 = (int)(rng() % span);
+                if (a > b2) std::swap(a, b2);
+                if (a == b2) b2 = a + 1;
+                bool clash = false;  // (the filters of one frame cover disjoint ranges, tns.rs:163-166: one per window here)
+                for (const auto &g : p.tns) clash = clash || (g.frame == c && g.start / 128 == (unsigned)w && is_short);
+                if (clash) continue;
+                f.frame = (uint32_t)c;
+                f.start = (uint16_t)(128 * w + a);
+                f.end = (uint16_t)(128 * w + b2);
+                f.order = (uint8_t)(1 + rng() % (is_short ? 7 : 12));
+                f.direction = (uint8_t)(rng() % 2);
+                for (int q = 0; q < f.order; ++q) f.lpc[q] = ud(rng);
+                p.tns.push_back(f);
+            }
+        }
+    }
+    AacLcCoded::Params params;
+    params.channels = nch;
+    params.swb_long.assign(kSwbLong, kSwbLong + sizeof kSwbLong / sizeof kSwbLong[0]);
+    params.swb_short.assign(kSwbShort, kSwbShort + sizeof kSwbShort / sizeof kSwbShort[0]);
+    size_t cursor = 0;
+    auto peek = [&]() -> std::optional<AacLcCoded::Packet> {
+        if (cursor >= track.size()) return std::nullopt;
+        return track[cursor++];
+    };
+    std::optional<LookaheadDecoder<AacLcCoded>> holder;
+    if (batcher) holder.emplace(*batcher, params, lookahead, peek);
+    else holder.emplace(ctx, params, lookahead, peek);
+    LookaheadDecoder<AacLcCoded> &dec = *holder;
+    // the frame-by-frame decoder: joint stereo on the pair (cpe.rs:110-157), then per channel TNS and Dsp::synth (ics/mod.rs:449-468)
+    std::vector<float> delay(nch * 1024, 0.0f);
+    auto step = [&](size_t i) {
+        if (cursor <= i) cursor = i + 1;
+        const AudioBufferRef &buf = dec.decode(track[i]);
+        const AacLcCoded::Packet &p = track[i];
+        std::vector<float> x = p.coeffs;
+        for (const auto &j : p.joint)
+            so_aac_joint_stereo(x.data() + j.first * 1024, x.data() + (j.first + 1) * 1024, j.second.num_windows, j.second.max_sfb,
+                                j.second.num_windows == 1 ? kSwbLong : kSwbShort, j.second.mode, j.second.scale);
+        for (const auto &f : p.tns) so_aac_tns_filter(x.data() + f.frame * 1024, f.start, f.end, f.order, f.direction, f.lpc);
+        for (size_t c = 0; c < nch; ++c) {
+            float want[1024];
+            so_aac_synth_batch(x.data() + c * 1024, &p.side[c], delay.data() + c * 1024, want, 1, 1);
+            EXPECT(same_bits(buf.planes[c], want, 1024), "AAC (coded spectra in) K=%zu packet %zu channel %zu differs from the frame-by-frame decoder", lookahead, i, c);
+        }
+    };
+    for (size_t i = 0; i < 13; ++i) step(i);
+    dec.reset();  // seek
+    std::fill(delay.begin(), delay.end(), 0.0f);
+    cursor = 17;
+    for (size_t i = 17; i < 22; ++i) step(i);
+    cursor = 24;  // packets dropped without reset()
+    for (size_t i = 24; i < n; ++i) step(i);
+}
+
 // ---- many streams, one batcher: S AAC decoders called round-robin like a server's worker would; every buffer equals the
 // frame-by-frame decoder's, and the batcher ran far fewer launches than the decoders ran batches
 static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead) {
@@ -402,6 +498,7 @@ int main(int argc, char **argv) {
     for (size_t k : {size_t(1), size_t(4), size_t(9), size_t(64)}) test_aac(ctx, k);
     for (size_t k : {size_t(1), size_t(3), size_t(8)}) test_mp3(ctx, k);
     for (size_t k : {size_t(1), size_t(6)}) test_mp3_huffman(ctx, k);
+    for (size_t k : {size_t(1), size_t(4), size_t(11)}) test_aac_coded(ctx, k);
     for (size_t k : {size_t(1), size_t(5), size_t(16)}) test_vorbis(ctx, k, 8, 11);
     test_vorbis(ctx, 6, 6, 9);
     for (size_t k : {size_t(1), size_t(4), size_t(32)}) test_flac(ctx, k, 2, 16);
@@ -412,6 +509,7 @@ int main(int argc, char **argv) {
         for (size_t k : {size_t(1), size_t(4), size_t(9), size_t(64)}) test_aac(ctx, k, &batcher);
         for (size_t k : {size_t(1), size_t(3), size_t(8)}) test_mp3(ctx, k, &batcher);
         for (size_t k : {size_t(1), size_t(6)}) test_mp3_huffman(ctx, k, &batcher);
+        for (size_t k : {size_t(1), size_t(4), size_t(11)}) test_aac_coded(ctx, k, &batcher);
         for (size_t k : {size_t(1), size_t(5), size_t(16)}) test_vorbis(ctx, k, 8, 11, &batcher);
         test_vorbis(ctx, 6, 6, 9, &batcher);
         test_vorbis(ctx, 4, 12, 13, &batcher);

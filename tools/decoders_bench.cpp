@@ -9,7 +9,7 @@
 // peek that copies the next packet out of a small pool (a parser writes its output somewhere too).  Nothing here links the
 // oracle: bench.py times the CPU port beside this with its own harness.  One JSON line on stdout.
 //
-//   decoders_bench --codec aac|mp3|mp3h|vorbis --streams S --lookahead L --packets P --threads T [--per-stream] [--flush-mb M]
+//   decoders_bench --codec aac|aacd|mp3|mp3h|vorbis --streams S --lookahead L --packets P --threads T [--per-stream] [--flush-mb M]
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -105,8 +105,55 @@ std::vector<Vorbis::Packet> make_pool<Vorbis>(unsigned seed) {  // BASELINE conf
     return pool;
 }
 
+static const uint16_t kSwbLong[] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216,
+                                    240, 264, 292, 320, 352, 384, 416, 448, 480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800, 832, 864, 896,
+                                    928, 1024};
+static const uint16_t kSwbShort[] = {0, 4, 8, 12, 16, 20, 28, 36, 44, 56, 68, 80, 96, 112, 128};
+
+template <>
+std::vector<AacLcCoded::Packet> make_pool<AacLcCoded>(unsigned seed) {  // long blocks, the pair mid/side- or intensity-coded, TNS on 30 % of the frames
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nd(0.0f, 50.0f);
+    std::vector<AacLcCoded::Packet> pool(kPool);
+    for (auto &p : pool) {
+        p.coeffs.resize(2 * 1024);
+        for (size_t i = 0; i < 2048; ++i) p.coeffs[i] = (i % 1024) < 672 ? nd(rng) : 0.0f;
+        p.side.assign(2, SYMACCEL_AAC_SIDE(0u, 1u, 1u));
+        symaccel_aac_js_frame d;
+        std::memset(&d, 0, sizeof d);
+        d.num_windows = 1;
+        d.max_sfb = 40;
+        for (int s = 0; s < 128; ++s) {
+            const unsigned r = rng() % 10;
+            d.mode[s] = (uint8_t)(r < 6 ? SYMACCEL_AAC_JS_MS : (r < 8 ? SYMACCEL_AAC_JS_INTENSITY : 0));
+            d.scale[s] = 0.5f;
+        }
+        p.joint.emplace_back(0, d);
+        for (uint32_t c = 0; c < 2; ++c)
+            if (rng() % 10 < 3) {
+                symaccel_aac_tns_filter f;
+                std::memset(&f, 0, sizeof f);
+                f.frame = c;
+                f.start = 160;
+                f.end = 672;
+                f.order = 10;
+                for (int q = 0; q < 10; ++q) f.lpc[q] = 0.05f * (float)((int)(rng() % 9) - 4);
+                p.tns.push_back(f);
+            }
+    }
+    return pool;
+}
+
 template <class Codec>
 typename Codec::Params params();
+template <>
+AacLcCoded::Params params<AacLcCoded>() {
+    AacLcCoded::Params p;
+    p.channels = 2;
+    p.swb_long.assign(kSwbLong, kSwbLong + sizeof kSwbLong / sizeof kSwbLong[0]);
+    p.swb_short.assign(kSwbShort, kSwbShort + sizeof kSwbShort / sizeof kSwbShort[0]);
+    return p;
+}
 template <>
 AacLc::Params params<AacLc>() { return AacLc::Params{2}; }
 template <>
@@ -237,6 +284,7 @@ int main(int argc, char **argv) {
     if (!a.warm) a.warm = 2 * a.lookahead;  // past the cold start (every stream's first batch is a launch of its own) and the pool's growth
     try {
         if (a.codec == "aac") return run<AacLc>(a, "aac", 1024, 2 * 1024 * 4 + 2);
+        if (a.codec == "aacd") return run<AacLcCoded>(a, "aacd", 1024, 2 * 1024 * 4 + 2 + 644 + 55);  // (+ 0.6 TNS filters of 92 B)
         if (a.codec == "mp3") return run<Mp3>(a, "mp3", 1152, 4 * 576 * 4 + 16);
         if (a.codec == "mp3h") return run<Mp3Huffman>(a, "mp3h", 1152, 4 * 576 * 2 + 4 * 52 + 2 * 48 + 16);
         // (Vorbis: 8 channels, nine blocks in ten long -- the per-packet figures are those of a long block after a long block)
