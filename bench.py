@@ -959,8 +959,15 @@ def decoders_workload(quick=False, seconds_cpu=3.0, lookahead=64):
     best = max((r for r in out["sweep"] if "error" not in r["gpu_batcher"]), key=lambda r: r["gpu_batcher"]["packets_per_s"], default=None)
     if best:
         out["best"] = {"streams": best["streams"], "packets_per_s": best["gpu_batcher"]["packets_per_s"], "gpu_over_cpu": best["gpu_over_cpu"]}
-        over = [r["streams"] for r in out["sweep"] if r["gpu_over_cpu"] and r["gpu_over_cpu"] > 1.0]
-        out["gpu_overtakes_cpu_port_from_streams"] = min(over) if over else None
+        if not quick:  # (the full sweep only: where the batcher stays ahead of the CPU port on the same number of threads from there on)
+            ahead = None
+            for r in reversed(out["sweep"]):
+                if r["gpu_over_cpu"] and r["gpu_over_cpu"] > 1.0:
+                    ahead = r["streams"]
+                else:
+                    break
+            out["gpu_ahead_of_cpu_port_from_streams"] = ahead
+            out["gpu_over_cpu_by_streams"] = {str(r["streams"]): r["gpu_over_cpu"] for r in out["sweep"]}
     out["note"] = ("packets/s through decode(): one packet = one AAC-LC stereo frame (2 x 1024 lines in, 2 x 1024 samples out, f32); the CPU port "
                    "runs native (-O3 -march=native) frame by frame on the same number of threads")
     return out
