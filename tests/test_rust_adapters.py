@@ -127,6 +127,45 @@ def test_aac_adapter_batches_behind_a_lookahead_reader(make_dll):
     assert front.f["parses"].v == nfr
 
 
+@pytest.mark.parametrize("make_dll", LIBS)
+def test_two_pooled_aac_adapters_share_the_batcher(make_dll):
+    """`HipAacDecoder::try_new_pooled` over scripted front ends that hand on the spectrum decoder's form (`ParsedAac::fused`): two
+    decoders behind look-ahead readers, decoded alternately -- the batches after each stream's first go through
+    symaccel_batcher_submit_aac_decode / _collect of ONE `Pool` (here and, in the gpu twin, on the MI355X), same PCM."""
+    h = harness(make_dll, "aac.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    f = np.load(FIX / "aac.npz")
+    swb_long = I.Arr([I.Int(v, "u16") for v in (0, 4, 8, 16, 32, 64, 128, 256, 512, 1024)], True)
+    swb_short = I.Arr([I.Int(v, "u16") for v in (0, 4, 8, 16, 32, 64, 128)], True)
+    decs, readers, wants = [], [], []
+    for k, walk in enumerate(("c", "d")):
+        coeffs, want, sd = f32(f["coeffs_" + walk]), f32(f["pcm_" + walk]), f["side_" + walk]
+        nch, nfr = coeffs.shape[0], coeffs.shape[1]
+        side = np.repeat(oracle.aac_side(sd[:, 0], sd[:, 1], sd[:, 2])[:, None], nch, axis=1)
+        fused = lambda: I.some(I.Struct("FusedAac", {"joint": I.Arr([], True), "tns": I.Arr([], True), "swb_long": swb_long,  # noqa: E731
+                                                     "swb_short": swb_short}))
+        script = I.Arr([I.Struct("ParsedAac", {"coeffs": f32_vec(coeffs[:, t]), "side": u8_vec(side[t]), "fused": fused()}) for t in range(nfr)], True)
+        params = h.params("CODEC_ID_AAC", 48000, nch)
+        front = I.Struct("ScriptedAacFront", {"params": params, "nch": usize(nch), "script": script, "parses": usize(0), "resets": usize(0)})
+        r = h.it.call("HipAacDecoder::try_new_pooled", params, h.opts(), front, usize(4))
+        assert r.variant == "Ok", r
+        decs.append(r.f["0"])
+        packets = I.Arr([h.packet(key(t), 1024 * t, track=3 + k, owned=True) for t in range(nfr)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", packets), usize(12)))
+        wants.append(want)
+    nfr = min(w.shape[1] for w in wants)
+    for t in range(nfr):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            st, got = h.decode("HipAacDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            assert st == "ok"
+            if t >= 1:
+                assert same(got, wants[k][:, t]), (k, t)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1 and calls.count("symaccel_batcher_submit_aac_decode") >= 2 * ((nfr - 4) // 4)
+    assert calls.count("symaccel_batcher_collect") >= calls.count("symaccel_batcher_submit_aac_decode") - 2
+
+
 # ------------------------------------------------------------------------------------------------ MP3
 
 @pytest.mark.parametrize("make_dll", LIBS)
