@@ -908,10 +908,10 @@ def decoders_workload(quick=False, seconds_cpu=3.0, lookahead=64):
     packets = 256 if quick else 512
     out = {"harness": "tools/decoders_bench.cpp (g++, links libsymaccel.so only)", "lookahead": lookahead, "cores": cores, "sweep": []}
 
-    def run(codec, streams, threads, per_stream=False, pk=packets, reps=3):
+    def run(codec, streams, threads, per_stream=False, pk=packets, reps=3, la=None):
         """the harness `reps` times (a fresh process each: its own context, pool and warm-up); the run with the MEDIAN rate is the one
         reported, every rate is kept beside it (`runs_packets_per_s`: threads meeting a shared pipeline scatter by +-20 %)"""
-        cmd = [str(exe), "--codec", codec, "--streams", str(streams), "--lookahead", str(lookahead), "--packets", str(pk), "--threads", str(threads)]
+        cmd = [str(exe), "--codec", codec, "--streams", str(streams), "--lookahead", str(la or lookahead), "--packets", str(pk), "--threads", str(threads)]
         if per_stream:
             cmd.append("--per-stream")
         lines = []
@@ -944,6 +944,14 @@ def decoders_workload(quick=False, seconds_cpu=3.0, lookahead=64):
         out["sweep"].append(row)
         log("decoders: S = %d done" % s_)
     if not quick:
+        # the same sweep at the Rust shim's default look-ahead (DEFAULT_LOOKAHEAD = 256 packets): a batch is a fixed ~150 us of
+        # latency whatever its size, so few streams gain the most from longer batches
+        out["sweep_lookahead_256"] = []
+        for s_ in (1, 4, 16, 64, 256):
+            t_ = max(1, min(s_, cores))
+            g = run("aac", s_, t_, pk=1024 if s_ <= 64 else 512, la=256)
+            out["sweep_lookahead_256"].append({"streams": s_, "threads": t_, "gpu_batcher": g, "cpu_port_packets_per_s": cpu_cache[t_],
+                                               "gpu_over_cpu": (g.get("packets_per_s", 0.0) / cpu_cache[t_]) if "error" not in g else None})
         out["mp3_int16_S256"] = run("mp3h", 256, max(1, min(256, cores)))
         out["mp3_f32_S256"] = run("mp3", 256, max(1, min(256, cores)))
         out["vorbis_8ch_S64"] = run("vorbis", 64, max(1, min(64, cores)))  # (BASELINE config 4's shape: 8 channels, 2048 / 256)
