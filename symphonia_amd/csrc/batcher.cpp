@@ -503,7 +503,6 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
                     const int32_t rel = (int32_t)(t.first_chain - c0);
                     const int32_t *pc = reinterpret_cast<const int32_t *>(blob + aac_blob_pairs(h->n_pairs));
                     std::vector<int32_t> pair_of(t.n_chains, -1);
-                    size_t good_pairs = 0;
                     for (uint32_t q = 0; q < h->n_pairs; ++q) {
                         const int32_t a = pc[2 * q], bb = pc[2 * q + 1];
                         if (a < 0 || bb < 0 || (size_t)a >= t.n_chains || (size_t)bb >= t.n_chains || a == bb || pair_of[(size_t)a] >= 0 || pair_of[(size_t)bb] >= 0) {
@@ -515,9 +514,7 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
                         pair_of[(size_t)a] = pair_of[(size_t)bb] = (int32_t)q;
                         h_pairs[2 * (aac_p + q)] = rel + a;
                         h_pairs[2 * (aac_p + q) + 1] = rel + bb;
-                        ++good_pairs;
                     }
-                    (void)good_pairs;
                     add_pieces(w, blob + aac_blob_js(h->n_pairs), reinterpret_cast<char *>(g->d_aac_js + aac_p * g->units),
                                (size_t)h->n_pairs * g->units * sizeof(symaccel_aac_js_frame));
                     const symaccel_aac_tns_filter *tf = reinterpret_cast<const symaccel_aac_tns_filter *>(blob + aac_blob_tns(h->n_pairs, g->units));
