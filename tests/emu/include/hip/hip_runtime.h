@@ -5,9 +5,9 @@
 // It is NOT part of the product: libsymaccel.so is only ever built by hipcc for gfx950
 // (symphonia_amd/build.py) and has no CPU path.  Nothing under symphonia_amd/ includes this.
 //
-// Model: one OS thread per work-item of a workgroup, workgroups run one after another,
-// __syncthreads() is a real barrier, `__shared__` is function-scope static storage, and the
-// cross-lane builtins the kernels use are emulated through a per-workgroup exchange buffer.
+// Model: the work-items of a workgroup are fibers of the launching host thread (emu_rt.cpp), workgroups
+// run one after another, __syncthreads() is a real barrier, `__shared__` is function-scope static
+// storage, and the cross-lane builtins the kernels use are emulated through a per-workgroup exchange buffer.
 #pragma once
 
 #include <pthread.h>
@@ -101,8 +101,8 @@ namespace emu {
 struct Idx { unsigned x, y, z; };
 extern thread_local Idx t_threadIdx, t_blockIdx;
 extern Idx g_blockDim, g_gridDim;
-extern pthread_barrier_t g_barrier;
-extern pthread_barrier_t g_wave_barrier[32];
+void wave_barrier();       // rendezvous of the calling work-item's wavefront (the work-items of it that have not returned)
+void workgroup_barrier();  //                ... of its workgroup
 extern uint32_t g_exchange[1024];
 void launch(dim3 grid, dim3 block, const std::function<void()> &body);
 }  // namespace emu
@@ -113,7 +113,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body);
 #define gridDim (emu::g_gridDim)
 static const int warpSize = 64;
 
-static inline void __syncthreads() { pthread_barrier_wait(&emu::g_barrier); }
+static inline void __syncthreads() { emu::workgroup_barrier(); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
@@ -126,11 +126,8 @@ static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); re
 #define __builtin_amdgcn_fence(order, ...) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
 // A real rendezvous of the wavefront's work-items: the hardware runs them in lock step, the emulation
-// runs them as threads, so every point where the kernel relies on lock step must synchronise.
-static inline void __builtin_amdgcn_wave_barrier() {
-    unsigned linear = emu::t_threadIdx.x + emu::g_blockDim.x * (emu::t_threadIdx.y + emu::g_blockDim.y * emu::t_threadIdx.z);
-    pthread_barrier_wait(&emu::g_wave_barrier[linear >> 6]);
-}
+// runs them one after the other, so every point where the kernel relies on lock step must synchronise.
+static inline void __builtin_amdgcn_wave_barrier() { emu::wave_barrier(); }
 static inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 // LDS-DMA load (global_load_lds): lane L's `size` bytes land at the wave-uniform LDS base + offset + L * size.  Done at
 // the point of issue here; on the GPU it lands some time before the kernel's vmcnt wait -- a kernel that still reads the
