@@ -1,5 +1,5 @@
 """TEST-ONLY: compile the product's .hip/.cpp sources with g++ against the stand-in HIP header
-(tests/emu/include) into tests/emu/libsymaccel_emu.so, so kernel logic can run on CPU threads.
+(tests/emu/include) into tests/emu/libsymaccel_emu.so, so kernel logic can run on the CPU (emu_rt.cpp).
 The product library (symphonia_amd/libsymaccel.so) is never built this way."""
 import os
 import subprocess
@@ -27,7 +27,7 @@ def needs_build(out=None):
 
 def tuned():
     """The allow-listed SYMACCEL_TUNE_* knobs of the product build (symphonia_amd/build.py), so a kernel variant can be
-    parity-tested on CPU threads before it is taken to the GPU.  A tuned emulation build has its own output path."""
+    parity-tested on the CPU before it is taken to the GPU.  A tuned emulation build has its own output path."""
     sys.path.insert(0, str(ROOT))
     from symphonia_amd.build import tuning_defines
     return list(tuning_defines())
