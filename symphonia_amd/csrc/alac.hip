@@ -39,6 +39,22 @@ __device__ __forceinline__ int32_t tap_mul(int32_t a, int32_t b) {
     if constexpr (M24) return __mul24(a, b);
     else return wrap_mul(a, b);
 }
+// a * b + c (wrapping): v_mad_i32_i24 in the narrow form -- one instruction of the multiplies' cost class instead of a multiply
+// and an add (tools/ubench/valu_int.hip: 1.85 ns per wave-instruction on a SIMD for v_mul_i32_i24, v_mad_i32_i24, v_mul_lo_u32 and
+// every other three-operand / compare / select instruction, 1.05 ns for add, sub, xor, and, shifts)
+template <bool M24>
+__device__ __forceinline__ int32_t tap_mad(int32_t a, int32_t b, int32_t c) {
+    if constexpr (M24) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        int32_t r;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+#else
+        return (int32_t)((uint32_t)__mul24(a, b) + (uint32_t)c);
+#endif
+    }
+    else return (int32_t)((uint32_t)wrap_mul(a, b) + (uint32_t)c);
+}
 // signum(v) = median(v, -1, 1): ONE instruction.  Written as `v > 1 ? 1 : (v < -1 ? -1 : v)` or as max(min(v, 1), -1), hipcc
 // emits two compares and two selects for it -- a sixth of the adaptive update's instructions.
 __device__ __forceinline__ int32_t signum_i32(int32_t v) {
@@ -93,9 +109,17 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
 #pragma unroll
                 for (int k = 2; k <= TAPS; ++k) past0 = L.order == (unsigned)k ? L.h[k] : past0;
             }
-            int32_t sum = 0;
+            // the taps' differences h[k] - past0: the prediction multiplies them, the update (narrow form) reads them again
+            int32_t dk[TAPS];
 #pragma unroll
-            for (int k = 0; k < TAPS; ++k) sum = wrap_add(sum, tap_mul<M24>(L.c[k], wrap_sub(L.h[k], past0)));
+            for (int k = 0; k < TAPS; ++k) dk[k] = wrap_sub(L.h[k], past0);
+            int32_t sum = 0, sum1 = 0;  // (two chains of multiply-adds; wrapping sums re-associate)
+#pragma unroll
+            for (int k = 0; k < TAPS; k += 2) {
+                sum = tap_mad<M24>(L.c[k], dk[k], sum);
+                if (k + 1 < TAPS) sum1 = tap_mad<M24>(L.c[k + 1], dk[k + 1], sum1);
+            }
+            sum = wrap_add(sum, sum1);
             const int32_t val = wrap_add(sum, (int32_t)((1u << L.shift) >> 1)) >> L.shift;
             x = clip_msbs(wrap_add(wrap_add(x, past0), val), L.clip);
             // sign-LMS update (lib.rs:224-260): from the oldest sample (coefficient order-1) to the newest, until the
@@ -115,15 +139,22 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
             const int32_t pm = res > 0 ? 0 : -1;      // 0: the residual is positive, -1: negative (zero: never active)
             int32_t act = res != 0 ? -1 : 0;
 #pragma unroll
+            //  * the instruction mix (round 5, tools/ubench/valu_int.hip): a multiply, a multiply-add, a compare or a select costs 1.75 x
+            //    an add / xor / shift on the SIMD, so +-|v| >> shift is what the reference writes -- (sign * val) >> shift, ONE multiply by
+            //    the signed direction, which the coefficient needs anyway -- instead of the five cheap operations of a branch-free abs,
+            //    and the residual takes its tap as a multiply-add.  In the narrow form val = past0 - sample is -dk[k] with no wrap (the
+            //    differences fit 24 bits), so the update works on dk[k] with the signs folded; the full-width form keeps val as the
+            //    reference computes it (past0 - sample wraps to the same sign as sample - past0 at -2^31).
             for (int k = TAPS - 1; k >= 0; --k) {
                 const int32_t nk = (int32_t)L.order - k;                                   // (1 + j); <= 0 beyond the order
-                int32_t v = wrap_sub(past0, L.h[k]);
+                int32_t v = M24 ? dk[k] : wrap_sub(past0, L.h[k]);                         // narrow: -val; full width: val
                 if constexpr (!FULL) v &= wrap_sub(0, nk) >> 31;                           // 0 beyond the lane's order
-                const int32_t m2 = pm ^ (v >> 31);                                         // v and the residual differ in sign
-                const int32_t step = wrap_sub(v ^ m2, m2) >> L.shift;                      // (+-sign(v) * v) >> shift = +-|v| >> shift
-                const int32_t sg = signum_i32(v);
-                L.c[k] = wrap_sub(L.c[k], wrap_sub(sg ^ pm, pm) & act);                    // c -= +-sign, while still active (as AND + v_mad_i32_i24: 4 % slower)
-                res = wrap_sub(res, tap_mul<M24>(nk, step));                               // the residual after this tap
+                // narrow: pm ? -sign(-val) : sign(-val) = minus the direction below; full width: pm ? -sign(val) : sign(val)
+                const int32_t dir = wrap_sub(signum_i32(v) ^ pm, pm);
+                const int32_t step = tap_mul<M24>(dir, v) >> L.shift;                      // (+-sign * val) >> shift = +-|val| >> shift (the two minus signs of the narrow form cancel)
+                if constexpr (M24) L.c[k] = wrap_add(L.c[k], dir & act);                   // c -= +-sign, while still active
+                else L.c[k] = wrap_sub(L.c[k], dir & act);
+                res = tap_mad<M24>(wrap_sub(0, nk), step, res);                            // the residual after this tap
                 act = (res ^ pm) > pm ? act : 0;                                           // > 0 resp. < 0: still on the residual's side
             }
         }

@@ -1,0 +1,111 @@
+// Micro-benchmark (development tool): what the integer VALU instructions of the ALAC / FLAC kernels cost on gfx950, in the SIMD's time per
+// wave-instruction at 1..4 wavefronts per SIMD (eight independent chains per wavefront, so no dependency stalls).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/build/valu_int tools/ubench/valu_int.hip && tools/ubench/build/valu_int
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#define REP8(x) x x x x x x x x
+#define OPS8(op, tail) \
+    REP8(asm volatile(op " %0, %0" tail "\n" op " %1, %1" tail "\n" op " %2, %2" tail "\n" op " %3, %3" tail "\n" op " %4, %4" tail "\n" op " %5, %5" tail "\n" op " %6, %6" tail "\n" op " %7, %7" tail \
+                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "vcc");)
+
+template <int KIND>
+__global__ void k(int *out, int iters, int seed) {
+    const int s = seed + threadIdx.x;
+    int a0 = s, a1 = s + 1, a2 = s + 2, a3 = s + 3, a4 = s + 4, a5 = s + 5, a6 = s + 6, a7 = s + 7, c = 3, d = s ^ 5;
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (KIND == 0) { OPS8("v_sub_u32", ", %8") }
+        else if constexpr (KIND == 1) { OPS8("v_xor_b32", ", %8") }
+        else if constexpr (KIND == 2) { OPS8("v_mul_i32_i24", ", %8") }
+        else if constexpr (KIND == 3) { OPS8("v_mad_i32_i24", ", %8, %9") }
+        else if constexpr (KIND == 4) { OPS8("v_mul_lo_u32", ", %8") }
+        else if constexpr (KIND == 5) { OPS8("v_med3_i32", ", %8, %9") }
+        else if constexpr (KIND == 6) { OPS8("v_add3_u32", ", %8, %9") }
+        else if constexpr (KIND == 7) { OPS8("v_lshl_add_u32", ", %8, %9") }
+        else if constexpr (KIND == 8) { OPS8("v_ashrrev_i32", ", %8") }
+        else if constexpr (KIND == 9) { OPS8("v_cndmask_b32", ", %8, vcc") }
+        else if constexpr (KIND == 10) { OPS8("v_bfi_b32", ", %8, %9") }
+        else if constexpr (KIND == 11) { OPS8("v_mad_u32_u24", ", %8, %9") }
+        else if constexpr (KIND == 12) { OPS8("v_xad_u32", ", %8, %9") }
+        else if constexpr (KIND == 13) { OPS8("v_sub_u32", ", 7") }
+        else if constexpr (KIND == 14) { OPS8("v_add_f32", ", %8") }
+        else if constexpr (KIND == 15) { OPS8("v_and_or_b32", ", %8, %9") }
+        else if constexpr (KIND == 16) { OPS8("v_mad_i32_i24", ", 5, %9") }
+        else if constexpr (KIND == 17) {  // the mask in an SGPR pair that nothing in the loop writes
+            REP8(asm volatile("v_cndmask_b32 %0, %0, %8, s[20:21]\n v_cndmask_b32 %1, %1, %8, s[20:21]\n v_cndmask_b32 %2, %2, %8, s[20:21]\n v_cndmask_b32 %3, %3, %8, s[20:21]\n"
+                              "v_cndmask_b32 %4, %4, %8, s[20:21]\n v_cndmask_b32 %5, %5, %8, s[20:21]\n v_cndmask_b32 %6, %6, %8, s[20:21]\n v_cndmask_b32 %7, %7, %8, s[20:21]"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "s20", "s21");)
+        } else if constexpr (KIND == 18) {  // compare into vcc, select on vcc (the compiler's usual pair): 16 instructions per block
+            REP8(asm volatile("v_cmp_gt_i32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %9, vcc\n v_cmp_gt_i32 vcc, %1, %8\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_gt_i32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %9, vcc\n v_cmp_gt_i32 vcc, %3, %8\n v_cndmask_b32 %3, %3, %9, vcc\n"
+                              "v_cmp_gt_i32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %9, vcc\n v_cmp_gt_i32 vcc, %5, %8\n v_cndmask_b32 %5, %5, %9, vcc\n v_cmp_gt_i32 vcc, %6, %8\n v_cndmask_b32 %6, %6, %9, vcc\n v_cmp_gt_i32 vcc, %7, %8\n v_cndmask_b32 %7, %7, %9, vcc"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "vcc");)
+        } else if constexpr (KIND == 19) {  // compare into an SGPR pair, select on it, the pairs interleaved two apart as a scheduler would
+            REP8(asm volatile("v_cmp_gt_i32 s[20:21], %0, %8\n v_cmp_gt_i32 s[22:23], %1, %8\n v_cndmask_b32 %0, %0, %9, s[20:21]\n v_cndmask_b32 %1, %1, %9, s[22:23]\n v_cmp_gt_i32 s[24:25], %2, %8\n v_cmp_gt_i32 s[26:27], %3, %8\n v_cndmask_b32 %2, %2, %9, s[24:25]\n v_cndmask_b32 %3, %3, %9, s[26:27]\n"
+                              "v_cmp_gt_i32 s[20:21], %4, %8\n v_cmp_gt_i32 s[22:23], %5, %8\n v_cndmask_b32 %4, %4, %9, s[20:21]\n v_cndmask_b32 %5, %5, %9, s[22:23]\n v_cmp_gt_i32 s[24:25], %6, %8\n v_cmp_gt_i32 s[26:27], %7, %8\n v_cndmask_b32 %6, %6, %9, s[24:25]\n v_cndmask_b32 %7, %7, %9, s[26:27]"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
+        } else if constexpr (KIND == 20) {  // compares only
+            REP8(asm volatile("v_cmp_gt_i32 s[20:21], %0, %8\n v_cmp_gt_i32 s[22:23], %1, %8\n v_cmp_gt_i32 s[24:25], %2, %8\n v_cmp_gt_i32 s[26:27], %3, %8\n v_cmp_gt_i32 s[20:21], %4, %8\n v_cmp_gt_i32 s[22:23], %5, %8\n v_cmp_gt_i32 s[24:25], %6, %8\n v_cmp_gt_i32 s[26:27], %7, %8"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
+        } else if constexpr (KIND == 21) {  // compare (vcc, VOPC encoding) only
+            REP8(asm volatile("v_cmp_gt_i32 vcc, %0, %8\n v_cmp_gt_i32 vcc, %1, %8\n v_cmp_gt_i32 vcc, %2, %8\n v_cmp_gt_i32 vcc, %3, %8\n v_cmp_gt_i32 vcc, %4, %8\n v_cmp_gt_i32 vcc, %5, %8\n v_cmp_gt_i32 vcc, %6, %8\n v_cmp_gt_i32 vcc, %7, %8"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "vcc");)
+        } else { OPS8("v_and_b32", ", %8") }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+template <int KIND>
+void run(const char *name, int *d_out, int cus) {
+    const int iters = 20000;
+    printf("%-28s", name);
+    for (int wps : {1, 2, 3, 4}) {
+        const int blocks = cus * wps;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("  %d w/SIMD: %.2f ns", wps, ms * 1e6 / ((double)iters * 64 * wps));
+    }
+    printf("   (SIMD time per wave-instruction)\n");
+}
+
+int main() {
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    printf("%s: %d CUs, nominal %.2f GHz\n", p.name, p.multiProcessorCount, p.clockRate / 1e6);
+    int *d;
+    hipMalloc(&d, 256 * 4 * 256 * 16 * sizeof(int));
+    const int cus = p.multiProcessorCount;
+    run<14>("v_add_f32 (for scale)", d, cus);
+    run<0>("v_sub_u32", d, cus);
+    run<13>("v_sub_u32 inline const", d, cus);
+    run<1>("v_xor_b32", d, cus);
+    run<8>("v_ashrrev_i32", d, cus);
+    run<9>("v_cndmask_b32 vcc", d, cus);
+    run<2>("v_mul_i32_i24", d, cus);
+    run<3>("v_mad_i32_i24", d, cus);
+    run<16>("v_mad_i32_i24 inline const", d, cus);
+    run<11>("v_mad_u32_u24", d, cus);
+    run<4>("v_mul_lo_u32", d, cus);
+    run<5>("v_med3_i32", d, cus);
+    run<6>("v_add3_u32", d, cus);
+    run<7>("v_lshl_add_u32", d, cus);
+    run<10>("v_bfi_b32", d, cus);
+    run<12>("v_xad_u32", d, cus);
+    run<15>("v_and_or_b32", d, cus);
+    run<17>("v_cndmask_b32 s[20:21]", d, cus);
+    run<18>("v_cmp vcc + v_cndmask (x2)", d, cus);
+    run<19>("v_cmp sgpr + v_cndmask (x2)", d, cus);
+    run<20>("v_cmp_gt_i32 sgpr pair", d, cus);
+    run<21>("v_cmp_gt_i32 vcc", d, cus);
+    run<22>("v_and_b32", d, cus);
+    return 0;
+}
