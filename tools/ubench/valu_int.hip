@@ -51,7 +51,20 @@ __global__ void k(int *out, int iters, int seed) {
         } else if constexpr (KIND == 21) {  // compare (vcc, VOPC encoding) only
             REP8(asm volatile("v_cmp_gt_i32 vcc, %0, %8\n v_cmp_gt_i32 vcc, %1, %8\n v_cmp_gt_i32 vcc, %2, %8\n v_cmp_gt_i32 vcc, %3, %8\n v_cmp_gt_i32 vcc, %4, %8\n v_cmp_gt_i32 vcc, %5, %8\n v_cmp_gt_i32 vcc, %6, %8\n v_cmp_gt_i32 vcc, %7, %8"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d) : "vcc");)
-        } else { OPS8("v_and_b32", ", %8") }
+        } else if constexpr (KIND == 22) { OPS8("v_and_b32", ", %8") }
+        else if constexpr (KIND == 23) { OPS8("v_cvt_f32_i32", "") }
+        else if constexpr (KIND == 24) { OPS8("v_cvt_i32_f32", "") }
+        else if constexpr (KIND == 25) { OPS8("v_mul_f32", ", %8") }
+        else if constexpr (KIND == 26) { OPS8("v_max_i32", ", %8") }
+        else if constexpr (KIND == 27) { OPS8("v_lshlrev_b32", ", 3") }
+        else if constexpr (KIND == 28) { OPS8("v_mul_hi_u32", ", %8") }
+        else if constexpr (KIND == 29) { OPS8("v_ffbh_u32", "") }
+        else if constexpr (KIND == 30) { OPS8("v_cvt_f32_ubyte0", "") }
+        else if constexpr (KIND == 31) { OPS8("v_rcp_f32", "") }
+        else if constexpr (KIND == 32) { OPS8("v_floor_f32", "") }
+        else if constexpr (KIND == 33) { OPS8("v_trunc_f32", "") }
+        else if constexpr (KIND == 34) { OPS8("v_fma_f64", "") }
+        else { OPS8("v_perm_b32", ", %8, %9") }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
@@ -107,5 +120,17 @@ int main() {
     run<20>("v_cmp_gt_i32 sgpr pair", d, cus);
     run<21>("v_cmp_gt_i32 vcc", d, cus);
     run<22>("v_and_b32", d, cus);
+    run<23>("v_cvt_f32_i32", d, cus);
+    run<24>("v_cvt_i32_f32", d, cus);
+    run<25>("v_mul_f32", d, cus);
+    run<26>("v_max_i32", d, cus);
+    run<27>("v_lshlrev_b32 const", d, cus);
+    run<28>("v_mul_hi_u32", d, cus);
+    run<29>("v_ffbh_u32", d, cus);
+    run<30>("v_cvt_f32_ubyte0", d, cus);
+    run<31>("v_rcp_f32", d, cus);
+    run<32>("v_floor_f32", d, cus);
+    run<33>("v_trunc_f32", d, cus);
+    run<35>("v_perm_b32", d, cus);
     return 0;
 }
