@@ -69,6 +69,89 @@ __global__ void k(int *out, int iters, int seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
+// 64-bit accumulators: the FLAC sum's candidates
+template <int KIND>
+__global__ void k64(long long *out, int iters, int seed, int big) {
+    const int s = seed + threadIdx.x;
+    long long a0 = s, a1 = s + 1, a2 = s + 2, a3 = s + 3;
+    double f0 = s, f1 = s + 1, f2 = s + 2, f3 = s + 3, fc = 1.0000001, fd = 0.5;
+    double g[16];
+    int gi[16];
+    for (int i = 0; i < 16; ++i) { g[i] = 1.0 + 1e-9 * (s + i); gi[i] = 0x1234567 * (i + 1) + s; }
+    int c = big ? 0x12345678 + s : 3, d = big ? (int)0x7edcba98 - s : s ^ 5;
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (KIND == 0) {
+            REP8(asm volatile("v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %1, vcc, %4, %5, %1\n v_mad_i64_i32 %2, vcc, %4, %5, %2\n v_mad_i64_i32 %3, vcc, %4, %5, %3\n"
+                              "v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %1, vcc, %4, %5, %1\n v_mad_i64_i32 %2, vcc, %4, %5, %2\n v_mad_i64_i32 %3, vcc, %4, %5, %3"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "vcc");)
+        } else if constexpr (KIND == 1) {
+            REP8(asm volatile("v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %1, %4, %5, %1\n v_fma_f64 %2, %4, %5, %2\n v_fma_f64 %3, %4, %5, %3\n"
+                              "v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %1, %4, %5, %1\n v_fma_f64 %2, %4, %5, %2\n v_fma_f64 %3, %4, %5, %3"
+                              : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fc), "v"(fd));)
+        } else if constexpr (KIND == 2) {
+            REP8(asm volatile("v_add_f64 %0, %4, %0\n v_add_f64 %1, %4, %1\n v_add_f64 %2, %4, %2\n v_add_f64 %3, %4, %3\n"
+                              "v_add_f64 %0, %5, %0\n v_add_f64 %1, %5, %1\n v_add_f64 %2, %5, %2\n v_add_f64 %3, %5, %3"
+                              : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fc), "v"(fd));)
+        } else if constexpr (KIND == 3) {
+            REP8(asm volatile("v_cvt_f64_i32 %0, %4\n v_cvt_f64_i32 %1, %5\n v_cvt_f64_i32 %2, %4\n v_cvt_f64_i32 %3, %5\n"
+                              "v_cvt_f64_i32 %0, %5\n v_cvt_f64_i32 %1, %4\n v_cvt_f64_i32 %2, %5\n v_cvt_f64_i32 %3, %4"
+                              : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(c), "v"(d));)
+        } else if constexpr (KIND == 5) {  // ONE dependent chain per wavefront
+            REP8(asm volatile("v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n"
+                              "v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "vcc");)
+        } else if constexpr (KIND == 6) {  // two chains
+            REP8(asm volatile("v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %1, vcc, %4, %5, %1\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %1, vcc, %4, %5, %1\n"
+                              "v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %1, vcc, %4, %5, %1\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %1, vcc, %4, %5, %1"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "vcc");)
+        } else if constexpr (KIND == 7) {  // one dependent FP64 FMA chain
+            REP8(asm volatile("v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n"
+                              "v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0"
+                              : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fc), "v"(fd));)
+        } else if constexpr (KIND == 8) {  // two FP64 FMA chains
+            REP8(asm volatile("v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %1, %4, %5, %1\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %1, %4, %5, %1\n"
+                              "v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %1, %4, %5, %1\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %1, %4, %5, %1"
+                              : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fc), "v"(fd));)
+        } else if constexpr (KIND == 9) {  // one FP64 FMA chain, eight DIFFERENT operand pairs (16 more VGPR pairs read per block)
+            REP8(asm volatile("v_fma_f64 %0, %1, %9, %0\n v_fma_f64 %0, %2, %10, %0\n v_fma_f64 %0, %3, %11, %0\n v_fma_f64 %0, %4, %12, %0\n"
+                              "v_fma_f64 %0, %5, %13, %0\n v_fma_f64 %0, %6, %14, %0\n v_fma_f64 %0, %7, %15, %0\n v_fma_f64 %0, %8, %16, %0"
+                              : "+v"(f0) : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]),
+                                "v"(g[8]), "v"(g[9]), "v"(g[10]), "v"(g[11]), "v"(g[12]), "v"(g[13]), "v"(g[14]), "v"(g[15]));)
+        } else if constexpr (KIND == 10) {  // the same with v_mad_i64_i32 (sixteen 32-bit operands)
+            REP8(asm volatile("v_mad_i64_i32 %0, vcc, %1, %9, %0\n v_mad_i64_i32 %0, vcc, %2, %10, %0\n v_mad_i64_i32 %0, vcc, %3, %11, %0\n v_mad_i64_i32 %0, vcc, %4, %12, %0\n"
+                              "v_mad_i64_i32 %0, vcc, %5, %13, %0\n v_mad_i64_i32 %0, vcc, %6, %14, %0\n v_mad_i64_i32 %0, vcc, %7, %15, %0\n v_mad_i64_i32 %0, vcc, %8, %16, %0"
+                              : "+v"(a0) : "v"(gi[0]), "v"(gi[1]), "v"(gi[2]), "v"(gi[3]), "v"(gi[4]), "v"(gi[5]), "v"(gi[6]), "v"(gi[7]),
+                                "v"(gi[8]), "v"(gi[9]), "v"(gi[10]), "v"(gi[11]), "v"(gi[12]), "v"(gi[13]), "v"(gi[14]), "v"(gi[15]) : "vcc");)
+        } else {
+            REP8(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n"
+                              "v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "vcc");)
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (long long)(f0 + f1 + f2 + f3);
+}
+
+template <int KIND>
+void run64(const char *name, long long *d_out, int cus, int big = 0) {
+    const int iters = 20000;
+    printf("%-28s", name);
+    for (int wps : {1, 2, 3, 4}) {
+        const int blocks = cus * wps;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipLaunchKernelGGL(k64<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1, big);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k64<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1, big);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("  %d w/SIMD: %.2f ns", wps, ms * 1e6 / ((double)iters * 64 * wps));
+    }
+    printf("   (SIMD time per wave-instruction)\n");
+}
+
 template <int KIND>
 void run(const char *name, int *d_out, int cus) {
     const int iters = 20000;
@@ -132,5 +215,20 @@ int main() {
     run<32>("v_floor_f32", d, cus);
     run<33>("v_trunc_f32", d, cus);
     run<35>("v_perm_b32", d, cus);
+    long long *d64;
+    hipMalloc(&d64, 256 * 4 * 256 * 16 * sizeof(long long));
+    run64<0>("v_mad_i64_i32 small operands", d64, cus);
+    run64<0>("v_mad_i64_i32 31-bit operands", d64, cus, 1);
+    run64<4>("v_mad_u64_u32 31-bit operands", d64, cus, 1);
+    run64<4>("v_mad_u64_u32", d64, cus);
+    run64<5>("v_mad_i64_i32 ONE chain", d64, cus, 1);
+    run64<6>("v_mad_i64_i32 two chains", d64, cus, 1);
+    run64<7>("v_fma_f64 ONE chain", d64, cus);
+    run64<9>("v_fma_f64 chain, 16 operands", d64, cus);
+    run64<10>("v_mad_i64_i32 chain, 16 oper.", d64, cus);
+    run64<8>("v_fma_f64 two chains", d64, cus);
+    run64<1>("v_fma_f64", d64, cus);
+    run64<2>("v_add_f64", d64, cus);
+    run64<3>("v_cvt_f64_i32", d64, cus);
     return 0;
 }
