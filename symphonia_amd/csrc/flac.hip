@@ -39,8 +39,22 @@ __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)
             int32_t x = xs[u & 3];
             if (col0 + u >= first_pred) {
                 int64_t acc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+                // v_mad_i64_i32 with its carry-out named as vcc: hipcc picks an SGPR pair for it, and in that form the instruction costs
+                // 9 - 18 ns instead of 1.85 (config 5 forced through this kernel: 19.8 ms, 9.4 ms with vcc; profiles/HISTORY.md round 5).
+                // Four taps per statement: every statement that clobbers vcc is followed by an s_nop.
+                static_assert(TAPS % 4 == 0, "groups of four taps");
+#pragma unroll
+                for (int j = 0; j < TAPS; j += 4)
+                    asm("v_mad_i64_i32 %0, vcc, %1, %5, %0\n\tv_mad_i64_i32 %0, vcc, %2, %6, %0\n\tv_mad_i64_i32 %0, vcc, %3, %7, %0\n\tv_mad_i64_i32 %0, vcc, %4, %8, %0"
+                        : "+v"(acc)
+                        : "v"(c[j]), "v"(c[j + 1]), "v"(c[j + 2]), "v"(c[j + 3]), "v"(h[(u + 31 - j) & 31]), "v"(h[(u + 30 - j) & 31]),
+                          "v"(h[(u + 29 - j) & 31]), "v"(h[(u + 28 - j) & 31])
+                        : "vcc");
+#else
 #pragma unroll
                 for (int j = 0; j < TAPS; ++j) acc += (int64_t)c[j] * (int64_t)h[(u + 31 - j) & 31];
+#endif
                 x = wrap_add(x, (int32_t)(acc >> shift));
             }
             h[u & 31] = x;
@@ -53,8 +67,8 @@ __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)
 // The same recurrence with the dot product carried by the FP64 FMA pipe, which is exact here:
 // sum |c_j| < 2^20 (checked per wavefront; a valid stream has <= 32 coefficients of qlp precision <= 15 bits,
 // decoder.rs:467-471) and |s| <= 2^31, so every partial sum is below 2^51 in magnitude (2^53 with the offset below):
-// no FMA ever rounds and the sum is the exact integer whatever the association.  v_mad_i64_i32 is a
-// slower instruction on CDNA4 than v_fma_f64.
+// no FMA ever rounds and the sum is the exact integer whatever the association.  (v_mad_i64_i32 issues at the
+// same rate -- tools/ubench/valu_int.hip -- but the kernel built on it is not faster: 8.7 - 9.4 ms against 8.3 for config 5.)
 // (acc >> shift) as i32 without leaving the integer domain: the sum is started from 2^52 + 2^51 instead of 0, so the f64
 // that comes out is 2^52 + (2^51 + acc), whose 52 mantissa bits ARE the integer 2^51 + acc (|acc| < 2^51 because a lane only
 // takes this path when the magnitudes of its coefficients sum to less than 2^20, load_params).  Its low word is acc mod 2^32,
