@@ -53,7 +53,15 @@ __device__ __forceinline__ int32_t tap_mad(int32_t a, int32_t b, int32_t c) {
         return (int32_t)((uint32_t)__mul24(a, b) + (uint32_t)c);
 #endif
     }
-    else return (int32_t)((uint32_t)wrap_mul(a, b) + (uint32_t)c);
+    else {
+        // v_mul_lo_u32 + v_add_u32, kept apart: fused, hipcc emits v_mad_u64_u32 with an SGPR pair as carry-out, which costs 9 - 18 ns
+        // on this part (profiles/HISTORY.md round 5, FLAC on v_mad_i64_i32)
+        int32_t m = wrap_mul(a, b);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(m));
+#endif
+        return (int32_t)((uint32_t)m + (uint32_t)c);
+    }
 }
 // signum(v) = median(v, -1, 1): ONE instruction.  Written as `v > 1 ? 1 : (v < -1 ? -1 : v)` or as max(min(v, 1), -1), hipcc
 // emits two compares and two selects for it -- a sixth of the adaptive update's instructions.
