@@ -54,8 +54,8 @@ __device__ __forceinline__ int32_t tap_mad(int32_t a, int32_t b, int32_t c) {
 #endif
     }
     else {
-        // v_mul_lo_u32 + v_add_u32, kept apart: fused, hipcc emits v_mad_u64_u32 with an SGPR pair as carry-out, which costs 9 - 18 ns
-        // on this part (profiles/HISTORY.md round 5, FLAC on v_mad_i64_i32)
+        // v_mul_lo_u32 + v_add_u32, kept apart: fused, hipcc emits chains of v_mad_u64_u32, the form that ran the FLAC integer kernel
+        // 2 - 4 x slower than the same sum issued from asm statements (profiles/HISTORY.md round 5)
         int32_t m = wrap_mul(a, b);
 #if defined(__HIP_DEVICE_COMPILE__)
         asm("" : "+v"(m));

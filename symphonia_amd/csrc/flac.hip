@@ -40,9 +40,10 @@ __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)
             if (col0 + u >= first_pred) {
                 int64_t acc = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-                // v_mad_i64_i32 with its carry-out named as vcc: hipcc picks an SGPR pair for it, and in that form the instruction costs
-                // 9 - 18 ns instead of 1.85 (config 5 forced through this kernel: 19.8 ms, 9.4 ms with vcc; profiles/HISTORY.md round 5).
-                // Four taps per statement: every statement that clobbers vcc is followed by an s_nop.
+                // v_mad_i64_i32 issued from asm statements, four taps each: the sequence hipcc emits for the plain C++ sum -- the same 32
+                // dependent instructions back to back, carry-out in an SGPR pair -- ran config 5 through this kernel in 19.8 ms, this form
+                // in 9.4 (with vcc or an SGPR pair as carry-out alike).  Not explained: in isolation (tools/ubench/valu_int.hip) every
+                // variant of the instruction issues in 1.85 ns (profiles/HISTORY.md round 5).
                 static_assert(TAPS % 4 == 0, "groups of four taps");
 #pragma unroll
                 for (int j = 0; j < TAPS; j += 4)

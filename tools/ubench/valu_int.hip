@@ -122,6 +122,36 @@ __global__ void k64(long long *out, int iters, int seed, int big) {
                               "v_mad_i64_i32 %0, vcc, %5, %13, %0\n v_mad_i64_i32 %0, vcc, %6, %14, %0\n v_mad_i64_i32 %0, vcc, %7, %15, %0\n v_mad_i64_i32 %0, vcc, %8, %16, %0"
                               : "+v"(a0) : "v"(gi[0]), "v"(gi[1]), "v"(gi[2]), "v"(gi[3]), "v"(gi[4]), "v"(gi[5]), "v"(gi[6]), "v"(gi[7]),
                                 "v"(gi[8]), "v"(gi[9]), "v"(gi[10]), "v"(gi[11]), "v"(gi[12]), "v"(gi[13]), "v"(gi[14]), "v"(gi[15]) : "vcc");)
+        } else if constexpr (KIND == 11) {  // the carry-out in an SGPR pair (what hipcc emits) instead of vcc
+            REP8(asm volatile("v_mad_i64_i32 %0, s[20:21], %4, %5, %0\n v_mad_i64_i32 %1, s[20:21], %4, %5, %1\n v_mad_i64_i32 %2, s[20:21], %4, %5, %2\n v_mad_i64_i32 %3, s[20:21], %4, %5, %3\n"
+                              "v_mad_i64_i32 %0, s[20:21], %4, %5, %0\n v_mad_i64_i32 %1, s[20:21], %4, %5, %1\n v_mad_i64_i32 %2, s[20:21], %4, %5, %2\n v_mad_i64_i32 %3, s[20:21], %4, %5, %3"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "s20", "s21");)
+        } else if constexpr (KIND == 12) {  // ... and ONE chain of them
+            REP8(asm volatile("v_mad_i64_i32 %0, s[20:21], %4, %5, %0\n v_mad_i64_i32 %0, s[20:21], %4, %5, %0\n v_mad_i64_i32 %0, s[20:21], %4, %5, %0\n v_mad_i64_i32 %0, s[20:21], %4, %5, %0\n"
+                              "v_mad_i64_i32 %0, s[20:21], %4, %5, %0\n v_mad_i64_i32 %0, s[20:21], %4, %5, %0\n v_mad_i64_i32 %0, s[20:21], %4, %5, %0\n v_mad_i64_i32 %0, s[20:21], %4, %5, %0"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "s20", "s21");)
+        } else if constexpr (KIND == 13) {  // 64-bit add as the compiler writes it: add_co + addc_co through an SGPR pair (x4 = 8 instructions)
+            REP8(asm volatile("v_add_co_u32 %0, s[20:21], %0, %2\n v_addc_co_u32 %1, s[20:21], %1, %3, s[20:21]\n v_add_co_u32 %0, s[20:21], %0, %2\n v_addc_co_u32 %1, s[20:21], %1, %3, s[20:21]\n"
+                              "v_add_co_u32 %0, s[20:21], %0, %2\n v_addc_co_u32 %1, s[20:21], %1, %3, s[20:21]\n v_add_co_u32 %0, s[20:21], %0, %2\n v_addc_co_u32 %1, s[20:21], %1, %3, s[20:21]"
+                              : "+v"(c), "+v"(d) : "v"(gi[0]), "v"(gi[1]) : "s20", "s21");)
+        } else if constexpr (KIND == 14) {  // ... through vcc
+            REP8(asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc\n v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc\n"
+                              "v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc\n v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %3, vcc"
+                              : "+v"(c), "+v"(d) : "v"(gi[0]), "v"(gi[1]) : "vcc");)
+        } else if constexpr (KIND == 15) {  // v_lshl_add_u64 (no carry-out)
+            REP8(asm volatile("v_lshl_add_u64 %0, %0, 0, %4\n v_lshl_add_u64 %1, %1, 0, %4\n v_lshl_add_u64 %2, %2, 0, %4\n v_lshl_add_u64 %3, %3, 0, %4\n"
+                              "v_lshl_add_u64 %0, %0, 0, %4\n v_lshl_add_u64 %1, %1, 0, %4\n v_lshl_add_u64 %2, %2, 0, %4\n v_lshl_add_u64 %3, %3, 0, %4"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a0));)
+        } else if constexpr (KIND == 16) {  // 64 dependent multiply-adds in ONE asm statement: nothing between them
+            asm volatile("v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "vcc");
+        } else if constexpr (KIND == 17) {  // ... with an s_nop 0 after every fourth
+            asm volatile("v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %0, vcc, %4, %5, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(d) : "vcc");
+        } else if constexpr (KIND == 18) {  // 64 dependent FP64 FMAs in one statement
+            asm volatile("v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fc), "v"(fd));
+        } else if constexpr (KIND == 19) {  // ... with an s_nop 0 after every fourth
+            asm volatile("v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n s_nop 0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0\n v_fma_f64 %0, %4, %5, %0" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fc), "v"(fd));
+        } else if constexpr (KIND == 20) {  // v_fmac_f64 (the VOP2 form the compiler picks), 64 dependent
+            asm volatile("v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5\n v_fmac_f64 %0, %4, %5" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fc), "v"(fd));
         } else {
             REP8(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n"
                               "v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3"
@@ -132,8 +162,7 @@ __global__ void k64(long long *out, int iters, int seed, int big) {
 }
 
 template <int KIND>
-void run64(const char *name, long long *d_out, int cus, int big = 0) {
-    const int iters = 20000;
+void run64(const char *name, long long *d_out, int cus, int big = 0, int iters = 20000) {
     printf("%-28s", name);
     for (int wps : {1, 2, 3, 4}) {
         const int blocks = cus * wps;
@@ -221,6 +250,18 @@ int main() {
     run64<0>("v_mad_i64_i32 31-bit operands", d64, cus, 1);
     run64<4>("v_mad_u64_u32 31-bit operands", d64, cus, 1);
     run64<4>("v_mad_u64_u32", d64, cus);
+    run64<11>("v_mad_i64_i32 -> s[20:21]", d64, cus, 1);
+    run64<12>("... ONE chain -> s[20:21]", d64, cus, 1);
+    run64<13>("add_co+addc_co via s[20:21]", d64, cus, 1);
+    run64<14>("add_co+addc_co via vcc", d64, cus, 1);
+    run64<15>("v_lshl_add_u64", d64, cus, 1);
+    run64<16>("mad_i64 x64 dep., 30 ms kernels", d64, cus, 1, 250000);
+    run64<18>("fma_f64 x64 dep., 30 ms kernels", d64, cus, 0, 250000);
+    run64<16>("mad_i64 x64 dependent, 1 stmt", d64, cus, 1);
+    run64<17>("... s_nop after every 4th", d64, cus, 1);
+    run64<18>("fma_f64 x64 dependent, 1 stmt", d64, cus);
+    run64<19>("... s_nop after every 4th", d64, cus);
+    run64<20>("fmac_f64 x64 dependent", d64, cus);
     run64<5>("v_mad_i64_i32 ONE chain", d64, cus, 1);
     run64<6>("v_mad_i64_i32 two chains", d64, cus, 1);
     run64<7>("v_fma_f64 ONE chain", d64, cus);
