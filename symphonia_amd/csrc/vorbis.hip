@@ -376,6 +376,16 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// byte `sel` of `old` replaced by the f32 value converted to 0 .. 255 (v_cvt_pk_u8_f32; the values it is given are exact integers)
+__device__ __forceinline__ uint32_t cvt_pk_u8(float v, int sel, uint32_t old) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, (uint32_t)sel, old);
+#else
+    const float cl = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+    return (old & ~(255u << (8 * sel))) | ((uint32_t)cl << (8 * sel));
+#endif
+}
+
 struct Floor1Setup {  // per floor configuration, derived on the host like the setup parser does (floor.rs:540-555)
     // Everything a loop iteration needs sits at an address that depends on the loop counter only: the scalar loads of
     // several iterations go out together instead of lo -> x[lo] chains of dependent round trips.
@@ -589,8 +599,14 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
             int32_t adx = (int32_t)segx[k1 * kF1Stride + b] - (int32_t)xk;
             adx = adx > 0 ? adx : 1;
             const float fadx = (float)adx;
-            segc[k] = make_uint4(xk | ((uint32_t)y0 << 18), __float_as_uint((float)dy / fadx),
-                                 __float_as_uint((dy < 0 ? -0.5f : 0.5f) / fadx), 0u);
+            // MODE 2 (bytes out): x0 and y0 as floats -- the line's arithmetic stays in f32 (exact: small integers) and ends in
+            // v_cvt_pk_u8_f32, which converts and places the byte in one instruction
+            if constexpr (MODE == 2)
+                segc[k] = make_uint4(__float_as_uint((float)xk), __float_as_uint((float)dy / fadx),
+                                     __float_as_uint((dy < 0 ? -0.5f : 0.5f) / fadx), __float_as_uint((float)y0));
+            else
+                segc[k] = make_uint4(xk | ((uint32_t)y0 << 18), __float_as_uint((float)dy / fadx),
+                                     __float_as_uint((dy < 0 ? -0.5f : 0.5f) / fadx), 0u);
         }
         wave_sync_lds();
         int carry = 1;  // segment (index + 1) in force before the current pass; x = 0 always starts segment 0
@@ -626,6 +642,15 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
             }
             float res[4][4];
             uint32_t ybytes[4] = {0u, 0u, 0u, 0u};
+            float xf[4][4];  // MODE 2: the lines' x as floats (one conversion per group, exact increments)
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xf[j][0] = (float)xb[j];
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) xf[j][q] = xf[j][0] + (float)q;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int seg_id = (below[j] && before[j] > carry) ? before[j] : carry;  // (index + 1) of the segment
@@ -635,12 +660,20 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
                     const int v = (int)((m[j] >> (8 * q)) & 255u);
                     seg_id = v > seg_id ? v : seg_id;
                     const uint4 c = segc[seg_id - 1];
-                    const int32_t t = (int32_t)(xb[j] + (uint32_t)q) - (int32_t)(c.x & 0xffffu);
-                    const int32_t steps = (int32_t)((float)t * __uint_as_float(c.y) + __uint_as_float(c.z));
-                    int32_t y4 = (int32_t)(c.x >> 16) + (steps << 2);  // byte offset of the table entry (y0 sits at bit 18)
-                    y4 = y4 < 0 ? 0 : (y4 > 1020 ? 1020 : y4);        // (in range for every rendered x; guards the lanes past the list)
-                    if constexpr (MODE == 2) ybytes[j] |= (uint32_t)(y4 >> 2) << (8 * q);
-                    else res[j][q] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dbl) + y4);
+                    if constexpr (MODE == 2) {
+                        // the same closed form on the f32 side: t = x - x0 as a difference of two exactly represented integers, the
+                        // truncation as v_trunc_f32, y0 + steps as an f32 add of small integers; y is in 0 .. 255 for every rendered x
+                        // (lanes past the list convert garbage, saturated by the instruction, and do not store)
+                        const float tf = xf[j][q] - __uint_as_float(c.x);
+                        const float yf = __uint_as_float(c.w) + __builtin_truncf(tf * __uint_as_float(c.y) + __uint_as_float(c.z));
+                        ybytes[j] = cvt_pk_u8(yf, q, ybytes[j]);
+                    } else {
+                        const int32_t t = (int32_t)(xb[j] + (uint32_t)q) - (int32_t)(c.x & 0xffffu);
+                        const int32_t steps = (int32_t)((float)t * __uint_as_float(c.y) + __uint_as_float(c.z));
+                        int32_t y4 = (int32_t)(c.x >> 16) + (steps << 2);  // byte offset of the table entry (y0 sits at bit 18)
+                        y4 = y4 < 0 ? 0 : (y4 > 1020 ? 1020 : y4);        // (in range for every rendered x; guards the lanes past the list)
+                        res[j][q] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dbl) + y4);
+                    }
                 }
             }
 #pragma unroll
