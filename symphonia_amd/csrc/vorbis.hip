@@ -386,6 +386,35 @@ __device__ __forceinline__ uint32_t cvt_pk_u8(float v, int sel, uint32_t old) {
 #endif
 }
 
+// Across the wavefront: excl = the maximum of v over the LOWER lanes (0 in lane 0), total = the maximum over all lanes.  Six DPP
+// steps (within rows of 16 lanes, then the rows' last lanes broadcast to the rows above), one lane shift and one v_readlane -- the
+// values are unsigned, 0 is the identity.
+__device__ __forceinline__ void wave_prefix_max(uint32_t v, uint32_t &excl, uint32_t &total) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int s = (int)v;
+#define SYM_DPP_MAX(ctrl, rows) s = max(s, __builtin_amdgcn_update_dpp(s, s, ctrl, rows, 0xf, true))  // (lanes without a source: 0 or s itself)
+    SYM_DPP_MAX(0x111, 0xf);  // row_shr:1
+    SYM_DPP_MAX(0x112, 0xf);  // row_shr:2
+    SYM_DPP_MAX(0x114, 0xf);  // row_shr:4
+    SYM_DPP_MAX(0x118, 0xf);  // row_shr:8
+    SYM_DPP_MAX(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    SYM_DPP_MAX(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef SYM_DPP_MAX
+    excl = (uint32_t)__builtin_amdgcn_update_dpp(0, s, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    total = (uint32_t)__builtin_amdgcn_readlane(s, 63);
+#else
+    const unsigned lane = threadIdx.x & 63u;
+    int s = (int)v;
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(s, d);
+        if (lane >= d) s = s > t ? s : t;
+    }
+    const int e = __shfl_up(s, 1);
+    excl = lane ? (uint32_t)e : 0u;
+    total = (uint32_t)__shfl(s, 63);
+#endif
+}
+
 struct Floor1Setup {  // per floor configuration, derived on the host like the setup parser does (floor.rs:540-555)
     // Everything a loop iteration needs sits at an address that depends on the loop counter only: the scalar loads of
     // several iterations go out together instead of lo -> x[lo] chains of dependent round trips.
@@ -626,19 +655,13 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
                 }
                 m[j] = xb[j] < n ? *reinterpret_cast<const uint32_t *>(mark + xb[j]) : 0u;
             }
-            // the segment in force just before a lane's first x: the highest mark below it.  Marks grow with x, so that is
-            // the last mark of the nearest lower lane that holds one (a ballot and one lane read, no scan), or else the
-            // highest mark of the groups before
-            int before[4], last[4];
-            unsigned long long below[4];
+            // the segment in force just before a lane's first x: the highest mark below it -- marks grow with x, so that is the
+            // maximum over the lower lanes (a prefix maximum across the wavefront), or else the highest mark of the groups before
+            uint32_t before[4], last[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int mine = (int)max(max(m[j] & 255u, (m[j] >> 8) & 255u), max((m[j] >> 16) & 255u, m[j] >> 24));
-                const unsigned long long holders = __ballot(mine != 0);
-                below[j] = holders & ((1ull << lane) - 1ull);
-                before[j] = __shfl(mine, below[j] ? 63 - __builtin_clzll(below[j]) : lane);
-                last[j] = __shfl(mine, holders ? 63 - __builtin_clzll(holders) : 0);
-                last[j] = holders ? last[j] : 0;
+                const uint32_t mine = max(max(m[j] & 255u, (m[j] >> 8) & 255u), max((m[j] >> 16) & 255u, m[j] >> 24));
+                wave_prefix_max(mine, before[j], last[j]);
             }
             float res[4][4];
             uint32_t ybytes[4] = {0u, 0u, 0u, 0u};
@@ -653,8 +676,8 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int seg_id = (below[j] && before[j] > carry) ? before[j] : carry;  // (index + 1) of the segment
-                carry = last[j] > carry ? last[j] : carry;
+                int seg_id = (int)before[j] > carry ? (int)before[j] : carry;  // (index + 1) of the segment
+                carry = (int)last[j] > carry ? (int)last[j] : carry;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int v = (int)((m[j] >> (8 * q)) & 255u);
