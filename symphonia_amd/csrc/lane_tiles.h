@@ -90,22 +90,43 @@ __device__ __forceinline__ int32_t flac_decorrelated(unsigned mode, bool is_ch1,
     }
     return (int32_t)((uint32_t)v << out_shift);
 }
-// Tile write-back with the decorrelation fused in: every lane reads its row and the pair's other row from LDS.
+// Both channels of one restored sample pair at once, without a branch: the four modes as three 0 / -1 masks of the pair's mode.
+// (Written per row with `if (mode == ...)`, hipcc built a tree of divergent branches per SAMPLE -- a dozen scalar and branch
+// instructions each, four samples per row segment; round 5.)  a / b = channel 0 / 1 as decoded; decoder.rs:32-82.
+__device__ __forceinline__ void flac_decorrelate_pair(int32_t a, int32_t b, int32_t is1, int32_t is2, int32_t is3, uint32_t out_shift,
+                                                      int32_t &o0, int32_t &o1) {
+    const uint32_t ua = (uint32_t)a, ub = (uint32_t)b;
+    const uint32_t d = ua - ub;                                         // left/side: right = left - side
+    const uint32_t l0 = ua + (ub & (uint32_t)is3);                      // right/side: left = side + right; else channel 0 as it is
+    const uint32_t l1 = ub ^ ((ub ^ d) & (uint32_t)is1);                // left/side: channel 1 = left - side; else as it is
+    const uint32_t mid = (ua << 1) | (ub & 1u);                         // mid/side (decoder.rs:60-72)
+    const uint32_t h0 = (uint32_t)((int32_t)(mid + ub) >> 1), h1 = (uint32_t)((int32_t)(mid - ub) >> 1);
+    o0 = (int32_t)((l0 ^ ((l0 ^ h0) & (uint32_t)is2)) << out_shift);
+    o1 = (int32_t)((l1 ^ ((l1 ^ h1) & (uint32_t)is2)) << out_shift);
+}
+// Tile write-back with the decorrelation fused in: a lane takes four columns of BOTH rows of a pair (32 pairs per tile: four
+// rounds of eight pairs x eight column groups), so each restored sample is read from LDS once and the pair's arithmetic is shared.
 // `row_mode[r]` = mode of the pair row r belongs to.
 __device__ __forceinline__ void tile_store_decorrelate_fast(int32_t *__restrict__ buf, const int32_t *tile,
                                                             const uint8_t *row_mode, uint32_t out_shift, size_t blk0,
                                                             unsigned blocksize, unsigned t0, int lane) {
-    const int q = lane & 7, rsub = lane >> 3;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int r = 8 * k + rsub;
-        const int4 own = *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q);
-        const int4 oth = *reinterpret_cast<const int4 *>(tile + (r ^ 1) * kStride + 4 * q);
-        const unsigned m = row_mode[r];
-        const bool c1 = (r & 1) != 0;
-        st_stream(reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q),
-                  make_int4(flac_decorrelated(m, c1, own.x, oth.x, out_shift), flac_decorrelated(m, c1, own.y, oth.y, out_shift),
-                            flac_decorrelated(m, c1, own.z, oth.z, out_shift), flac_decorrelated(m, c1, own.w, oth.w, out_shift)));
+    const int q = lane & 7, psub = lane >> 3;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {  // (not unrolled: the FP64 kernel has no register to spare for two rounds in flight)
+        const int r0 = 2 * (8 * k + psub);
+        const int4 a = *reinterpret_cast<const int4 *>(tile + r0 * kStride + 4 * q);
+        const int4 b = *reinterpret_cast<const int4 *>(tile + (r0 + 1) * kStride + 4 * q);
+        const int32_t m = (int32_t)row_mode[r0];
+        // mode == k as 0 / -1: (m ^ k) - 1 is negative only for m == k (m is 0 .. 3)
+        const int32_t is1 = ((m ^ 1) - 1) >> 31, is2 = ((m ^ 2) - 1) >> 31, is3 = ((m ^ 3) - 1) >> 31;
+        int4 o0, o1;
+        flac_decorrelate_pair(a.x, b.x, is1, is2, is3, out_shift, o0.x, o1.x);
+        flac_decorrelate_pair(a.y, b.y, is1, is2, is3, out_shift, o0.y, o1.y);
+        flac_decorrelate_pair(a.z, b.z, is1, is2, is3, out_shift, o0.z, o1.z);
+        flac_decorrelate_pair(a.w, b.w, is1, is2, is3, out_shift, o0.w, o1.w);
+        int32_t *dst = buf + (blk0 + (size_t)r0) * blocksize + t0 + 4u * (unsigned)q;
+        st_stream(reinterpret_cast<int4 *>(dst), o0);
+        st_stream(reinterpret_cast<int4 *>(dst + blocksize), o1);
     }
 }
 __device__ __forceinline__ void tile_store_decorrelate_slow(int32_t *__restrict__ buf, const int32_t *tile,
