@@ -212,18 +212,32 @@ __device__ __forceinline__ void alac_store_mixed(int32_t *__restrict__ buf, cons
                                                  const uint8_t *row_shift, size_t blk0, size_t n_blocks, unsigned blocksize,
                                                  unsigned t0, unsigned cols, int lane, bool fast) {
     if (fast) {
-        const int q = lane & 7, rsub = lane >> 3;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = 8 * k + rsub;
-            const int4 own = *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q);
-            const int4 oth = *reinterpret_cast<const int4 *>(tile + (r ^ 1) * kStride + 4 * q);
-            const int32_t w = row_weight[r];
-            const uint32_t sh = row_shift[r];
-            const bool c1 = (r & 1) != 0;
-            *reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q) =
-                make_int4(alac_mixed(w, sh, c1, own.x, oth.x), alac_mixed(w, sh, c1, own.y, oth.y),
-                          alac_mixed(w, sh, c1, own.z, oth.z), alac_mixed(w, sh, c1, own.w, oth.w));
+        // a lane takes four columns of BOTH rows of a pair (32 pairs per tile: four rounds of eight pairs x eight column groups): every
+        // predicted sample is read from LDS once, the product is shared, and "weight == 0 leaves the pair alone" is a mask, not the
+        // per-sample divergent branch `alac_mixed` compiles to
+        const int q = lane & 7, psub = lane >> 3;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const int r0 = 2 * (8 * k + psub);
+            const int4 a = *reinterpret_cast<const int4 *>(tile + r0 * kStride + 4 * q);
+            const int4 b = *reinterpret_cast<const int4 *>(tile + (r0 + 1) * kStride + 4 * q);
+            const int32_t w = row_weight[r0];
+            const uint32_t sh = row_shift[r0];
+            const uint32_t wz = w == 0 ? 0xffffffffu : 0u;
+            auto mix = [&](int32_t s0, int32_t s1, int32_t &o0, int32_t &o1) {
+                const uint32_t t = (uint32_t)(wrap_mul(s1, w) >> sh);          // lib.rs:664-671
+                o0 = (int32_t)((uint32_t)s0 + (((uint32_t)s1 - t) & ~wz));      // s0 + s1 - t, or s0
+                const uint32_t x = (uint32_t)s0 - t;                            // (s0 + s1 - t) - s1
+                o1 = (int32_t)(x ^ ((x ^ (uint32_t)s1) & wz));                 // ... or s1
+            };
+            int4 o0, o1;
+            mix(a.x, b.x, o0.x, o1.x);
+            mix(a.y, b.y, o0.y, o1.y);
+            mix(a.z, b.z, o0.z, o1.z);
+            mix(a.w, b.w, o0.w, o1.w);
+            int32_t *dst = buf + (blk0 + (size_t)r0) * blocksize + t0 + 4u * (unsigned)q;
+            *reinterpret_cast<int4 *>(dst) = o0;
+            *reinterpret_cast<int4 *>(dst + blocksize) = o1;
         }
     } else {
         const int c = lane & 31, rsub = lane >> 5;
