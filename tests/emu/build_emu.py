@@ -34,6 +34,14 @@ def tuned():
 
 
 def build(force=False):
+    """Build if needed; safe to call from several processes at once (pytest -n: the workers share the object directory)."""
+    import fcntl
+    with open(HERE / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force=False):
     defines = tuned()
     if defines:
         tag = "_".join(d[2:].replace("=", "") for d in defines)
