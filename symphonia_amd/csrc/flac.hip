@@ -210,19 +210,30 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
     TilePrefetch pre;
 #pragma unroll
     for (int k = 0; k < 8; ++k) pre.v[k] = make_int4(0, 0, 0, 0);
+    // Order of a round (gfx950 counts vector loads and stores with ONE in-order counter): recurrence over tile t -- tile t + 1 from its
+    // prefetch registers into the other LDS tile -- loads of tile t + 2 issued -- tile t written back.  The wait for a tile's loads then
+    // sits where nothing younger than those loads is in flight: they and the previous tile's stores were issued a whole recurrence
+    // earlier.  (Until round 5 the write-back came first, and the wait in front of the next tile's LDS commit -- vmcnt(7) .. vmcnt(0)
+    // at the loop's back edge -- also waited for the stores just issued: the write latency was exposed once per tile.)
+    auto fetch_tile = [&](unsigned t) {  // tile t: prefetch registers (or, ragged, global memory) -> LDS; then the loads of tile t + 1
+        const unsigned t0 = t * kCols;
+        const unsigned cols = min((unsigned)kCols, blocksize - t0);
+        int32_t *tile = tiles + (t & 1u) * kTileWords;
+        if (aligned && cols == (unsigned)kCols)
+            tile_commit(pre, tile, lane);
+        else
+            tile_fetch_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+        if (aligned && t0 + 2u * kCols <= blocksize)  // the tile after it is a full one
+            tile_issue_loads(buf, pre, blk0, blocksize, t0 + kCols, lane);
+    };
     if (aligned && blocksize >= (unsigned)kCols) tile_issue_loads(buf, pre, blk0, blocksize, 0, lane);
+    if (n_tiles > 0) fetch_tile(0);
+    wave_sync();
     for (unsigned t = 0; t < n_tiles; ++t) {
         const unsigned t0 = t * kCols;
         const unsigned cols = min((unsigned)kCols, blocksize - t0);
         const bool fast = aligned && cols == (unsigned)kCols;
         int32_t *tile = tiles + (t & 1u) * kTileWords;
-        if (fast)
-            tile_commit(pre, tile, lane);
-        else
-            tile_fetch_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
-        wave_sync();
-        if (aligned && t0 + 2u * kCols <= blocksize)  // the next tile is a full one: fetch it while this one computes
-            tile_issue_loads(buf, pre, blk0, blocksize, t0 + kCols, lane);
         if (have) {
             int32_t *row = tile + lane * kStride;
             const int first_pred = (int)p.order - (int)t0;  // column index of the first predicted sample
@@ -244,7 +255,8 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
                     lpc_steps32<32>(h, c, row, 0, first_pred, (int)cols, p.shift, p.wasted);
             }
         }
-        wave_sync();
+        wave_sync();  // tile t is complete
+        if (t + 1 < n_tiles) fetch_tile(t + 1);
         if constexpr (DECOR) {
             if (fast)
                 tile_store_decorrelate_fast(buf, tile, row_mode, out_shift, blk0, blocksize, t0, lane);
@@ -256,7 +268,7 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
             else
                 tile_store_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
         }
-        // no barrier here: the next round writes the OTHER LDS tile, and its barrier orders these reads
+        wave_sync();  // tile t + 1 is in place for every lane; tile t has been read: the round after next may overwrite it
     }
 }
 
