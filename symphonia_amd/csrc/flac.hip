@@ -25,7 +25,8 @@ namespace {
 
 // 32 recurrence steps with statically indexed circular history: before step u the most recent
 // sample sits in h[(u + 31) & 31].  Integer path: any coefficient magnitude.
-template <int TAPS>
+// ALL: as in lpc_steps32_f64 -- every sample of the tile is predicted in every lane, no per-step predicate.
+template <int TAPS, bool ALL = false>
 __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)[32], int32_t *row, int col0,
                                             int first_pred, int n_valid, uint32_t shift, uint32_t wasted) {
     int32_t xs[4];
@@ -37,7 +38,7 @@ __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)
         }
         if (u < n_valid) {
             int32_t x = xs[u & 3];
-            if (col0 + u >= first_pred) {
+            if (ALL || col0 + u >= first_pred) {
                 int64_t acc = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
                 // v_mad_i64_i32 issued from asm statements, four taps each: the sequence hipcc emits for the plain C++ sum -- the same 32
@@ -247,7 +248,9 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
                 else
                     lpc_steps32_f64<32, true>(h, c, row, 0, first_pred, (int)cols, (int)p.shift, p.wasted);
             } else {
-                if (p.max_order <= 4)
+                if (t0 >= p.max_order && p.max_order > 12)  // behind every lane's warm-up samples (config 5 through this kernel: 8.27 -> 7.98 ms)
+                    lpc_steps32<32, true>(h, c, row, 0, first_pred, (int)cols, p.shift, p.wasted);
+                else if (p.max_order <= 4)
                     lpc_steps32<4>(h, c, row, 0, first_pred, (int)cols, p.shift, p.wasted);
                 else if (p.max_order <= 12)
                     lpc_steps32<12>(h, c, row, 0, first_pred, (int)cols, p.shift, p.wasted);
