@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SYMACCEL_ABI_VERSION 6 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device, vorbis floor_y; 5: aac_decode_pipelined, aac_joint_stereo_list, vorbis_decode; 6: batcher */
+#define SYMACCEL_ABI_VERSION 7 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device, vorbis floor_y; 5: aac_decode_pipelined, aac_joint_stereo_list, vorbis_decode; 6: batcher; 7: batch kinds for Vorbis from posts, FLAC and ALAC (symaccel_batch_slot has six input planes), lanes, per-ticket status */
 
 typedef enum symaccel_status {
     SYMACCEL_OK = 0,
@@ -639,7 +639,26 @@ int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uin
  *                              units + frame inside the submission): symaccel_batcher_submit_aac_decode() writes it.  Per launch the
  *                              pair frames that carry TNS get their joint stereo decoded by a list pass, the filters of the whole
  *                              group run, and ONE walk synthesises every stream of the group (cpe.rs:110-157, ics/mod.rs:449-468).
- * `units_per_chain` = frames (AAC) / granules (MP3) / blocks (Vorbis) per chain.  Two forms:
+ *   SYMACCEL_BATCH_VORBIS_DECODE symaccel_vorbis_decode for ONE stream (n_chains = its channels): residue + floor-1 posts + coupling steps in,
+ *                              PCM out (lib.rs:250-331) -- inverse coupling, the floor curves as one byte per line, the dot product in the
+ *                              synthesis kernel's load path.  in = { residue[chain][unit * bs1 / 2] f32 (packed at the front, zeros for
+ *                              a do-not-decode channel), block_flag[chain][unit], floor[chain][unit] u8 (the index
+ *                              symaccel_batcher_vorbis_floor() gave the configuration, or SYMACCEL_VORBIS_FLOOR_UNUSED),
+ *                              posts[chain][unit][65] u32, coupling blob (ONE per submission: first[unit + 1] u32 padded to 16 bytes, then
+ *                              the (magnitude, angle) channel byte pairs of block b at [first[b], first[b + 1]); room for max(8, n_chains *
+ *                              (n_chains - 1)) steps per block on average, SYMACCEL_ERR_INVALID_ARG from submit beyond) }; state / out as
+ *                              VORBIS_SYNTH; param = bs0_exp | bs1_exp << 8 | n_chains << 16, so that streams of one block-size pair,
+ *                              channel count and block count share a launch whatever their flags, floors and coupling
+ *   SYMACCEL_BATCH_FLAC_RESTORE symaccel_flac_restore across streams: a chain is ONE SUBFRAME, units_per_chain = the block size (words per
+ *                              subframe slot; shorter blocks zero-padded), so submissions of any number of frames share a launch:
+ *                              in = { buf[chain][unit] i32 (warm-up samples + residuals; the RESULT overwrites it: slot.out == slot.input[0]),
+ *                              desc[chain] (symaccel_flac_desc), coeffs[chain][32] i32 }; no state; param = 0.  With param = 0x100 | out_shift
+ *                              the chains are channel pairs (2p, 2p + 1), in[3] = pair_mode[chain / 2] u8, and the decorrelation and the
+ *                              left-justification happen in the same kernel (symaccel_flac_restore_stereo_device, decoder.rs:199-242)
+ *   SYMACCEL_BATCH_ALAC_PREDICT symaccel_alac_predict across streams, the same shape: in = { buf[chain][unit] i32 (in place), desc[chain]
+ *                              (symaccel_alac_desc), coeffs[chain][32] }; param = 0.  With param = 0x100: in[3] = pair_weight[chain / 2] i32,
+ *                              in[4] = pair_shift[chain / 2] u8 (symaccel_alac_predict_stereo_device, lib.rs:541-560)
+ * `units_per_chain` = frames (AAC) / granules (MP3) / blocks (Vorbis) / words (FLAC, ALAC) per chain.  Two forms:
  *   zero-copy:  reserve() hands out a slot of page-locked staging memory (the front end writes its output straight into the DMA
  *               source), commit() says it is filled, wait() blocks until slot.out / slot.state hold the PCM and the state AFTER
  *               the batch, release() gives the slot back.  Commit a reservation before waiting for anything on the same thread.
@@ -647,18 +666,27 @@ int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uin
  *               pointers given to submit() + release.  The `in` planes are free again when submit() returns; `state_io` and `out`
  *               must stay valid until collect().
  * A stream submits batch n + 1 only after batch n was collected (the state it starts from).  Thread-safe; the context is driven
- * through the batcher only while one exists.  A failed launch fails every ticket of its group with the same status. */
+ * through the batcher only while one exists.  Status is kept PER TICKET: a submission whose own descriptors do not add up (a
+ * malformed AAC blob, a FLAC order above the block size, floor1_Y values above 511 ...) runs as an empty description and fails
+ * alone with the status the per-stream entry point would have returned; a reservation released before commit() runs as zeros;
+ * only a device error fails every ticket of the launch.  A group that closes is enqueued on one of the batcher's LANES (a context
+ * of its own -- kernel stream, scratch, tables -- plus two copy streams; lane 0 is the caller's context) without the batcher's
+ * mutex: other threads keep submitting and collecting meanwhile, and the gather of one group overlaps the scatter of another. */
 #define SYMACCEL_BATCH_AAC_SYNTH 1
 #define SYMACCEL_BATCH_MP3_SYNTH 2
 #define SYMACCEL_BATCH_MP3_DECODE 3
 #define SYMACCEL_BATCH_VORBIS_SYNTH 4
 #define SYMACCEL_BATCH_AAC_DECODE 5
+#define SYMACCEL_BATCH_VORBIS_DECODE 6
+#define SYMACCEL_BATCH_FLAC_RESTORE 7
+#define SYMACCEL_BATCH_ALAC_PREDICT 8
+#define SYMACCEL_BATCH_MAX_INPUTS 6
 typedef struct symaccel_batcher symaccel_batcher;
 typedef struct symaccel_batch_slot {
-    void *input[4];
+    void *input[6]; /* SYMACCEL_BATCH_MAX_INPUTS */
     void *state[3];
-    void *out;
-    size_t input_bytes[4]; /* sizes of this submission's planes */
+    void *out; /* FLAC / ALAC: == input[0] (in place) */
+    size_t input_bytes[6]; /* sizes of this submission's planes */
     size_t state_bytes[3];
     size_t out_bytes;
 } symaccel_batch_slot;
@@ -670,11 +698,22 @@ typedef struct symaccel_batcher_stats {
     uint64_t max_chains_per_launch;
     uint64_t staging_bytes;         /* page-locked memory held */
     uint64_t pending;               /* submissions not yet launched */
+    uint64_t failed_tickets;        /* submissions that came back with a status of their own (or of a failed launch) */
+    uint64_t lanes;                 /* pipelines in use (contexts + copy-stream pairs) */
+    uint64_t mutex_wait_ns;         /* time callers spent blocked on the batcher's mutex, summed over threads ... */
+    uint64_t mutex_contended;       /* ... and how many acquisitions found it taken */
+    uint64_t launch_host_ns;        /* host time spent building copy descriptors and enqueueing launches (outside the mutex) */
+    uint64_t lane_wait_ns;          /* time launchers waited for their lane (another group being enqueued on it) */
 } symaccel_batcher_stats;
 /* flush_bytes: input bytes of one group after which it is launched without anybody waiting (0 = 64 MiB); also sizes the
  * staging memory of a group (input + output + state, page-locked, pooled and reused). */
 int symaccel_batcher_create(symaccel_ctx *ctx, size_t flush_bytes, symaccel_batcher **out);
 int symaccel_batcher_destroy(symaccel_batcher *b);
+/* lanes: how many pipelines closing groups are dealt to (1..8, 0 = leave as is; default 2 -- lanes beyond the first are contexts the
+ * batcher creates on first use); hint_bytes: what a pending group must hold for symaccel_batcher_hint() to launch it (0 = leave as is) */
+int symaccel_batcher_configure(symaccel_batcher *b, int lanes, size_t hint_bytes);
+/* the text of the last device error a launch or a wait of this batcher met ("" if none), copied under the batcher's mutex */
+int symaccel_batcher_last_error(symaccel_batcher *b, char *buf, size_t capacity);
 int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_chains, size_t units_per_chain,
                              symaccel_batch_slot *slot, uint64_t *ticket);
 int symaccel_batcher_commit(symaccel_batcher *b, uint64_t ticket);
@@ -682,7 +721,7 @@ int symaccel_batcher_commit(symaccel_batcher *b, uint64_t ticket);
 int symaccel_batcher_wait(symaccel_batcher *b, uint64_t ticket, symaccel_batch_slot *slot);
 int symaccel_batcher_release(symaccel_batcher *b, uint64_t ticket);
 int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_chains, size_t units_per_chain,
-                            const void **input, void **state_io, void *out, uint64_t *ticket); /* input[4], state_io[3] */
+                            const void **input, void **state_io, void *out, uint64_t *ticket); /* input[6], state_io[3] */
 /* submit() with the argument lists of the entry points the kinds stand for (symaccel_aac_synth, symaccel_mp3_synth,
  * symaccel_mp3_decode_pipelined for one stream: n_chains 1, or 2 = one channel pair with st_desc[granule]; st_desc may be NULL for 1) */
 int symaccel_batcher_submit_aac_synth(symaccel_batcher *b, const float *coeffs, const uint8_t *side, float *delay_io, float *pcm,
@@ -705,6 +744,23 @@ int symaccel_batcher_submit_aac_decode(symaccel_batcher *b, int bands, const flo
 int symaccel_batcher_submit_vorbis_synth(symaccel_batcher *b, int bs0_exp, int bs1_exp, const float *spectra, const uint8_t *block_flag,
                                          int32_t *prev_flag_io, float *overlap_io, float *pcm, size_t n_chains, size_t blocks_per_chain,
                                          uint64_t *ticket); /* spectra / pcm: [chain][blocks_per_chain * bs1 / 2], packed at the front */
+/* Register a floor-1 configuration VORBIS_DECODE submissions refer to (floor.rs:510-555: multiplier, x list in bitstream order): the
+ * same configuration gives the same index; at most 255 distinct ones per batcher (SYMACCEL_ERR_UNSUPPORTED beyond: such a stream
+ * keeps batching per stream through symaccel_vorbis_decode). */
+int symaccel_batcher_vorbis_floor(symaccel_batcher *b, const symaccel_vorbis_floor1_cfg *cfg, int *index);
+/* symaccel_vorbis_decode's argument list for ONE stream (posts_stride 65; `floor` holds symaccel_batcher_vorbis_floor() indices) */
+int symaccel_batcher_submit_vorbis_decode(symaccel_batcher *b, int bs0_exp, int bs1_exp, const float *residue, const uint8_t *block_flag,
+                                          const uint8_t *floor, const uint32_t *posts, const uint8_t *coupling,
+                                          const uint32_t *coupling_first, int32_t *prev_flag_io, float *overlap_io, float *pcm,
+                                          size_t n_chains, size_t blocks_per_chain, uint64_t *ticket);
+/* symaccel_flac_restore (pair_mode NULL, out_shift 0) / symaccel_flac_restore_stereo_device (pair_mode[n_blocks / 2]) for the subframes
+ * of one stream's batch; collect() writes the result over buf_io */
+int symaccel_batcher_submit_flac_restore(symaccel_batcher *b, int32_t *buf_io, const symaccel_flac_desc *desc, const int32_t *coeffs,
+                                         const uint8_t *pair_mode, uint32_t out_shift, size_t n_blocks, size_t blocksize, uint64_t *ticket);
+/* symaccel_alac_predict (pair_weight / pair_shift NULL) / symaccel_alac_predict_stereo_device for one stream's batch, in place */
+int symaccel_batcher_submit_alac_predict(symaccel_batcher *b, int32_t *buf_io, const symaccel_alac_desc *desc, const int32_t *coeffs,
+                                         const int32_t *pair_weight, const uint8_t *pair_shift, size_t n_blocks, size_t blocksize,
+                                         uint64_t *ticket);
 /* wait + copy the PCM and the state after the batch into the `*_io` / `pcm` pointers given to submit + release */
 int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket);
 /* give up a submission (seek, reset): wait until nothing of it is in flight, write nothing, release */
@@ -715,7 +771,7 @@ int symaccel_batcher_flush(symaccel_batcher *b);
  * leave smaller ones to grow -- what a decoder calls when a quarter of its current batch is left */
 int symaccel_batcher_hint(symaccel_batcher *b);
 /* bytes per chain of every plane of a kind (per submission for MP3_DECODE's input[3]); unused planes 0 */
-int symaccel_batcher_plane_bytes(int kind, int param, size_t units_per_chain, size_t *input_bytes, size_t *state_bytes, size_t *out_bytes); /* [4], [3] */
+int symaccel_batcher_plane_bytes(int kind, int param, size_t units_per_chain, size_t *input_bytes, size_t *state_bytes, size_t *out_bytes); /* [6], [3] */
 int symaccel_batcher_get_stats(symaccel_batcher *b, symaccel_batcher_stats *out);
 
 /* ------------------------------------------------------------------------- multi-GPU */

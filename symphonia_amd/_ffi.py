@@ -52,7 +52,8 @@ ABI_SYMBOLS = [
     "symaccel_batcher_create", "symaccel_batcher_destroy", "symaccel_batcher_reserve", "symaccel_batcher_commit", "symaccel_batcher_wait",
     "symaccel_batcher_release", "symaccel_batcher_submit", "symaccel_batcher_collect", "symaccel_batcher_abandon",
     "symaccel_batcher_submit_aac_synth", "symaccel_batcher_submit_mp3_synth", "symaccel_batcher_submit_mp3_decode", "symaccel_batcher_submit_vorbis_synth", "symaccel_batcher_aac_bands", "symaccel_batcher_submit_aac_decode", "symaccel_batcher_flush", "symaccel_batcher_hint", "symaccel_batcher_plane_bytes",
-    "symaccel_batcher_get_stats",
+    "symaccel_batcher_get_stats", "symaccel_batcher_configure", "symaccel_batcher_last_error", "symaccel_batcher_vorbis_floor",
+    "symaccel_batcher_submit_vorbis_decode", "symaccel_batcher_submit_flac_restore", "symaccel_batcher_submit_alac_predict",
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
@@ -144,6 +145,12 @@ class Library:
         d.symaccel_batcher_submit_aac_decode.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _sz, C.POINTER(C.c_uint64)]
         d.symaccel_batcher_submit_vorbis_synth.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _sz, C.POINTER(C.c_uint64)]
         d.symaccel_batcher_get_stats.argtypes = [_vp, _vp]
+        d.symaccel_batcher_configure.argtypes = [_vp, _i, _sz]
+        d.symaccel_batcher_last_error.argtypes = [_vp, _vp, _sz]
+        d.symaccel_batcher_vorbis_floor.argtypes = [_vp, _vp, C.POINTER(_i)]
+        d.symaccel_batcher_submit_vorbis_decode.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, C.POINTER(C.c_uint64)]
+        d.symaccel_batcher_submit_flac_restore.argtypes = [_vp, _vp, _vp, _vp, _vp, _u32, _sz, _sz, C.POINTER(C.c_uint64)]
+        d.symaccel_batcher_submit_alac_predict.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, C.POINTER(C.c_uint64)]
         d.symaccel_aac_decode_pipelined.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_mp3_stereo_device.argtypes = [_vp, _vp, _sz, _vp, _vp, _i, _sz]
         d.symaccel_mp3_requantize_stereo_device.argtypes = [_vp, _vp, _vp, _sz, _vp, _vp, _i, _vp, _sz]

@@ -754,17 +754,20 @@ class PinnedBuffer:
 
 
 BATCH_AAC_SYNTH, BATCH_MP3_SYNTH, BATCH_MP3_DECODE, BATCH_VORBIS_SYNTH, BATCH_AAC_DECODE = 1, 2, 3, 4, 5
+BATCH_VORBIS_DECODE, BATCH_FLAC_RESTORE, BATCH_ALAC_PREDICT = 6, 7, 8
+BATCH_MAX_INPUTS = 6
 
 
 class BatchSlot(C.Structure):
     """symaccel_batch_slot (include/symaccel.h)"""
-    _fields_ = [("input", C.c_void_p * 4), ("state", C.c_void_p * 3), ("out", C.c_void_p), ("input_bytes", C.c_size_t * 4),
+    _fields_ = [("input", C.c_void_p * 6), ("state", C.c_void_p * 3), ("out", C.c_void_p), ("input_bytes", C.c_size_t * 6),
                 ("state_bytes", C.c_size_t * 3), ("out_bytes", C.c_size_t)]
 
 
 class BatcherStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("submissions", "launches", "chunks", "chains_launched", "max_chains_per_launch", "staging_bytes",
-                                           "pending")]
+                                           "pending", "failed_tickets", "lanes", "mutex_wait_ns", "mutex_contended", "launch_host_ns",
+                                           "lane_wait_ns")]
 
 
 def _slot_view(ptr, nbytes, dtype, shape):
@@ -811,7 +814,7 @@ class Batcher:
         """inputs / states / out: C-contiguous numpy arrays ([chain][unit]... / [chain]...); the states are updated and `out` is
         filled by collect()."""
         n_chains, units = int(out.shape[0]), int(out.shape[1])
-        ins = (C.c_void_p * 4)(*[a.ctypes.data if a is not None else None for a in list(inputs) + [None] * (4 - len(inputs))])
+        ins = (C.c_void_p * 6)(*[a.ctypes.data if a is not None else None for a in list(inputs) + [None] * (6 - len(inputs))])
         sts = (C.c_void_p * 3)(*[a.ctypes.data for a in list(states)] + [None] * (3 - len(states)))
         for a in list(inputs) + list(states) + [out]:
             assert a is None or a.flags["C_CONTIGUOUS"]
@@ -842,6 +845,62 @@ class Batcher:
             self.handle, int(bands), coeffs.ctypes.data, side.ctypes.data, keep[0].ctypes.data if n_pairs else None,
             keep[1].ctypes.data if n_pairs else None, n_pairs, keep[2].ctypes.data if n_tns else None, n_tns, delay_io.ctypes.data,
             pcm.ctypes.data, n_chains, frames, C.byref(t)))
+        return int(t.value)
+
+    def configure(self, lanes=0, hint_bytes=0):
+        self._check(self.dll.symaccel_batcher_configure(self.handle, int(lanes), int(hint_bytes)))
+
+    def last_error(self):
+        buf = C.create_string_buffer(512)
+        self._check(self.dll.symaccel_batcher_last_error(self.handle, buf, 512))
+        return buf.value.decode(errors="replace")
+
+    def vorbis_floor(self, multiplier, x_list):
+        """register a floor-1 configuration (floor.rs:510-555): the index VORBIS_DECODE submissions put in their `floor` plane"""
+        cfg = np.zeros(1, VORBIS_FLOOR1_DTYPE)
+        cfg["multiplier"], cfg["n_posts"] = int(multiplier), len(x_list)
+        cfg["x_list"][0, :len(x_list)] = np.asarray(x_list, np.uint32)
+        out = C.c_int(-1)
+        self._check(self.dll.symaccel_batcher_vorbis_floor(self.handle, cfg.ctypes.data, C.byref(out)))
+        return int(out.value)
+
+    def submit_vorbis_decode(self, bs0_exp, bs1_exp, residue, flags, floor, posts, coupling, coupling_first, prev_flag_io, overlap_io, pcm):
+        """symaccel_batcher_submit_vorbis_decode: ONE stream's batch as symaccel_vorbis_decode takes it -- residue / pcm
+        [chain][blocks * bs1 / 2] f32 (packed at the front), flags / floor [chain][blocks] u8, posts [chain][blocks][65] u32,
+        coupling [steps][2] u8 (or None), coupling_first [blocks + 1] u32; prev_flag_io / overlap_io / pcm are written by collect()"""
+        n_chains, blocks = int(flags.shape[0]), int(flags.shape[1])
+        for a in (residue, flags, floor, posts, coupling_first, prev_flag_io, overlap_io, pcm):
+            assert a.flags["C_CONTIGUOUS"]
+        keep = np.ascontiguousarray(coupling, np.uint8) if coupling is not None and len(coupling) else None
+        t = C.c_uint64()
+        self._check(self.dll.symaccel_batcher_submit_vorbis_decode(
+            self.handle, int(bs0_exp), int(bs1_exp), residue.ctypes.data, flags.ctypes.data, floor.ctypes.data, posts.ctypes.data,
+            keep.ctypes.data if keep is not None else None, coupling_first.ctypes.data, prev_flag_io.ctypes.data, overlap_io.ctypes.data,
+            pcm.ctypes.data, n_chains, blocks, C.byref(t)))
+        return int(t.value)
+
+    def submit_flac_restore(self, buf_io, desc, coeffs, pair_mode=None, out_shift=0):
+        """symaccel_batcher_submit_flac_restore: buf_io [block][blocksize] i32 (in place at collect()), desc [block], coeffs [block][32];
+        pair_mode [block / 2] u8 selects the fused stereo form"""
+        n_blocks, blocksize = int(buf_io.shape[0]), int(buf_io.shape[1])
+        for a in (buf_io, desc, coeffs):
+            assert a.flags["C_CONTIGUOUS"]
+        t = C.c_uint64()
+        self._check(self.dll.symaccel_batcher_submit_flac_restore(
+            self.handle, buf_io.ctypes.data, desc.ctypes.data, coeffs.ctypes.data, pair_mode.ctypes.data if pair_mode is not None else None,
+            int(out_shift), n_blocks, blocksize, C.byref(t)))
+        return int(t.value)
+
+    def submit_alac_predict(self, buf_io, desc, coeffs, pair_weight=None, pair_shift=None):
+        """symaccel_batcher_submit_alac_predict: as submit_flac_restore; pair_weight [block / 2] i32 + pair_shift [block / 2] u8 select the
+        fused mid/side form"""
+        n_blocks, blocksize = int(buf_io.shape[0]), int(buf_io.shape[1])
+        for a in (buf_io, desc, coeffs):
+            assert a.flags["C_CONTIGUOUS"]
+        t = C.c_uint64()
+        self._check(self.dll.symaccel_batcher_submit_alac_predict(
+            self.handle, buf_io.ctypes.data, desc.ctypes.data, coeffs.ctypes.data, pair_weight.ctypes.data if pair_weight is not None else None,
+            pair_shift.ctypes.data if pair_shift is not None else None, n_blocks, blocksize, C.byref(t)))
         return int(t.value)
 
     def reserve(self, kind, param, n_chains, units):

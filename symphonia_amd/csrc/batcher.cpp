@@ -6,7 +6,7 @@
 // track, symphonia-core/src/codecs/audio.rs:279-297; the registry builds decoders from (params, opts) alone, registry.rs:330-341),
 // so the coalescing point is below the trait, here: decoders SUBMIT their batches to a batcher shared by the process and come
 // back for the result later; whatever is pending when somebody needs a result (or when `flush_bytes` of input have piled up)
-// goes to the device as ONE batch per (kind, units per chain) group -- the chains of every submission side by side in the
+// goes to the device as ONE batch per (kind, param, units per chain) group -- the chains of every submission side by side in the
 // chain-major layout the kernels already take, so nothing in the kernels knows about streams.
 //
 //   reserve()  -> a slot of page-locked staging memory the front end writes its spectra / samples / records into (no copy
@@ -16,12 +16,17 @@
 //                 group's results are in page-locked memory; slot.out / slot.state now hold PCM and the carried state
 //   release()  -> the slot may be reused
 //
-// A group is transferred and transformed in chunks of submissions: H2D(c + 1) || kernel(c) || D2H(c - 1) on the context's three
-// streams (the chunks are chains, which are independent: no carried state between chunks, unlike stage.cpp's frame-axis
-// chunks).  Groups are pooled: in the steady state nothing is allocated.  Thread-safe: submissions may come from any thread; a
-// flush waits for reservations of the group that are still being filled.  A context that has a batcher is driven through the
-// batcher only (the context itself is externally synchronised, include/symaccel.h "Thread safety").
+// A group is transferred and transformed in chunks of submissions: gather(c + 1) || kernel(c) || scatter(c - 1) on the three
+// streams of a LANE (the chunks are chains, which are independent: no carried state between chunks, unlike stage.cpp's
+// frame-axis chunks).  A lane is a context of its own (stream, scratch, tables) plus two copy streams and a mutex; a group that
+// closes is handed to the next lane and ENQUEUED OUTSIDE the batcher's mutex -- the threads of other streams keep reserving,
+// committing and collecting while one thread builds the copy descriptors and launches, and the gather of one group overlaps the
+// scatter of another on a different lane.  Groups are pooled: in the steady state nothing is allocated.  Thread-safe: submissions
+// may come from any thread; a flush waits for reservations of the group that are still being filled.  The status of a launch is
+// kept PER TICKET: a submission whose descriptors do not add up fails alone, its neighbours in the launch succeed.  A context that
+// has a batcher is driven through the batcher only (the context itself is externally synchronised, include/symaccel.h "Thread safety").
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -35,16 +40,25 @@ using namespace symaccel;
 
 namespace {
 
-constexpr int kMaxIn = 4, kMaxState = 3;
+constexpr int kMaxIn = 6, kMaxState = 3;  // (symaccel_batch_slot's input[] / state[])
+constexpr size_t kVorbisPosts = 65;      // floor1_Y values per channel-block in a VORBIS_DECODE submission (floor.rs:510-520)
 
-// what a kind's planes weigh: bytes per chain (per ticket for `in_per_ticket`) for `units` frames / granules per chain
+// what a kind's planes weigh: bytes per chain (per ticket for `in_per_ticket`, per `in_div` chains otherwise) for `units` frames /
+// granules / blocks / words per chain
 struct PlaneSizes {
-    size_t in[kMaxIn] = {0, 0, 0, 0};
-    bool in_per_ticket[kMaxIn] = {false, false, false, false};
+    size_t in[kMaxIn] = {0, 0, 0, 0, 0, 0};
+    bool in_per_ticket[kMaxIn] = {false, false, false, false, false, false};
+    bool in_host_only[kMaxIn] = {false, false, false, false, false, false};  // read by the host when the group is launched; never copied as it is
+    uint8_t in_div[kMaxIn] = {1, 1, 1, 1, 1, 1};                             // 2: one element per channel PAIR (chains 2p, 2p + 1)
     size_t state[kMaxState] = {0, 0, 0};
     size_t out = 0;
+    bool in_place = false;  // the result overwrites input[0] (FLAC / ALAC: the entry points they stand for work in place)
     int n_in = 0, n_state = 0;
 };
+
+// coupling steps a block may carry in a VORBIS_DECODE submission: every ordered channel pair once, at least 8 (a mapping may list up to
+// 256 steps, lib.rs:604-640 -- a stream with more than this per block keeps batching per stream through symaccel_vorbis_decode)
+inline size_t vorbis_max_steps(size_t nch) { return std::min<size_t>(256, std::max<size_t>(8, nch * (nch - 1))); }
 
 bool plane_sizes(int kind, int param, size_t units, PlaneSizes *ps) {
     *ps = PlaneSizes();
@@ -56,6 +70,7 @@ bool plane_sizes(int kind, int param, size_t units, PlaneSizes *ps) {
         // the blob (aac_blob_*): header + pair list + joint-stereo rows (at most one pair per two chains) + TNS filters (at most
         // eight per channel-frame: one per window of an EIGHT_SHORT frame), sized per chain so that it scales with the stream
         ps->in[2] = 64 + units * (sizeof(symaccel_aac_js_frame) / 2 + 8 * sizeof(symaccel_aac_tns_filter));
+        ps->in_host_only[2] = true;
         ps->n_state = 1;
         ps->state[0] = 4096;
         ps->out = units * 4096;
@@ -71,6 +86,27 @@ bool plane_sizes(int kind, int param, size_t units, PlaneSizes *ps) {
         ps->state[0] = 4;
         ps->state[1] = half * 4;
         ps->out = units * half * 4;    // ... and yields at most bs1 / 2 samples
+        return true;
+    }
+    case SYMACCEL_BATCH_VORBIS_DECODE: {  // symaccel_vorbis_decode for ONE stream: residue, flags, floor index, posts, coupling blob | prev, overlap | pcm
+        const int e0 = param & 255, e1 = (param >> 8) & 255, nch = (param >> 16) & 255;
+        if (e0 < 6 || e1 > 13 || e0 > e1 || nch < 1 || (param >> 24)) return false;
+        const size_t half = (size_t)1 << (e1 - 1);
+        ps->n_in = 5;
+        ps->in[0] = units * half * 4;
+        ps->in[1] = units;
+        ps->in[2] = units;  // floor configuration of every channel-block (symaccel_batcher_vorbis_floor's index), or ..._FLOOR_UNUSED
+        ps->in_host_only[2] = true;
+        ps->in[3] = units * kVorbisPosts * 4;
+        ps->in_host_only[3] = true;
+        // the coupling steps of the stream's blocks: first[units + 1] u32, padded to 16 bytes, then (magnitude, angle) byte pairs
+        ps->in[4] = (((units + 1) * 4 + 15) & ~(size_t)15) + units * 2 * vorbis_max_steps((size_t)nch);
+        ps->in_per_ticket[4] = true;
+        ps->in_host_only[4] = true;
+        ps->n_state = 2;
+        ps->state[0] = 4;
+        ps->state[1] = half * 4;
+        ps->out = units * half * 4;
         return true;
     }
     case SYMACCEL_BATCH_AAC_SYNTH:  // symaccel_aac_synth: coeffs, side | delay | pcm
@@ -104,6 +140,32 @@ bool plane_sizes(int kind, int param, size_t units, PlaneSizes *ps) {
         ps->state[2] = 4;
         ps->out = units * 2304;
         return true;
+    case SYMACCEL_BATCH_FLAC_RESTORE:  // symaccel_flac_restore(_stereo_device): buf (in place), desc, coeffs [, pair_mode]; units = block size
+        if (units > 65535 || (param & ~0x11f)) return false;  // frame.rs:58 (u16 block size); param = 0, or 0x100 | out_shift
+        ps->n_in = (param & 0x100) ? 4 : 3;
+        ps->in[0] = units * 4;
+        ps->in[1] = sizeof(symaccel_flac_desc);
+        ps->in[2] = 32 * 4;
+        if (param & 0x100) {
+            ps->in[3] = 1;
+            ps->in_div[3] = 2;
+        }
+        ps->in_place = true;
+        return true;
+    case SYMACCEL_BATCH_ALAC_PREDICT:  // symaccel_alac_predict(_stereo_device): buf (in place), desc, coeffs [, pair_weight, pair_shift]
+        if (units > 0x3fffffffu || (param & ~0x100)) return false;
+        ps->n_in = (param & 0x100) ? 5 : 3;
+        ps->in[0] = units * 4;
+        ps->in[1] = sizeof(symaccel_alac_desc);
+        ps->in[2] = 32 * 4;
+        if (param & 0x100) {
+            ps->in[3] = 4;
+            ps->in_div[3] = 2;
+            ps->in[4] = 1;
+            ps->in_div[4] = 2;
+        }
+        ps->in_place = true;
+        return true;
     default:
         return false;
     }
@@ -111,14 +173,18 @@ bool plane_sizes(int kind, int param, size_t units, PlaneSizes *ps) {
 
 size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+inline size_t plane_bytes(const PlaneSizes &ps, int i, size_t n_chains) {
+    return ps.in_per_ticket[i] ? ps.in[i] : ps.in[i] * (n_chains / ps.in_div[i]);
+}
+
 size_t in_bytes_per_chain(const PlaneSizes &ps) {
     size_t s = 0;
     for (int i = 0; i < ps.n_in; ++i)
-        if (!ps.in_per_ticket[i]) s += ps.in[i];
+        if (!ps.in_per_ticket[i]) s += ps.in[i] / ps.in_div[i];
     return s;
 }
 
-// a submission's page-locked slot: [in 0 | .. | state 0 | .. | out], every plane on a 256-byte boundary
+// a submission's page-locked slot: [in 0 | .. | state 0 | .. | out], every plane on a 256-byte boundary (in place: out IS in 0)
 struct SlotLayout {
     size_t in[kMaxIn] = {}, state[kMaxState] = {}, out = 0, bytes = 0;
     size_t in_bytes[kMaxIn] = {}, state_bytes[kMaxState] = {}, out_bytes = 0;
@@ -128,7 +194,7 @@ SlotLayout slot_layout(const PlaneSizes &ps, size_t n_chains) {
     size_t off = 0;
     for (int i = 0; i < ps.n_in; ++i) {
         l.in[i] = off;
-        l.in_bytes[i] = ps.in[i] * (ps.in_per_ticket[i] ? 1 : n_chains);
+        l.in_bytes[i] = plane_bytes(ps, i, n_chains);
         off += round256(l.in_bytes[i]);
     }
     for (int i = 0; i < ps.n_state; ++i) {
@@ -136,11 +202,26 @@ SlotLayout slot_layout(const PlaneSizes &ps, size_t n_chains) {
         l.state_bytes[i] = ps.state[i] * n_chains;
         off += round256(l.state_bytes[i]);
     }
-    l.out = off;
-    l.out_bytes = ps.out * n_chains;
-    off += round256(l.out_bytes);
+    if (ps.in_place) {
+        l.out = l.in[0];
+        l.out_bytes = l.in_bytes[0];
+    } else {
+        l.out = off;
+        l.out_bytes = ps.out * n_chains;
+        off += round256(l.out_bytes);
+    }
     l.bytes = off;
     return l;
+}
+
+// Slots are pooled by size CLASS, not by exact size: eight classes per octave (at most 12.5 % of padding), so the odd shapes of a
+// running service -- tail batches at the end of a stream, short look-ahead batches, MP3 granule totals -- reuse each other's memory
+// instead of each carving a slab of its own.
+size_t slot_class(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    size_t top = (size_t)1 << (63 - __builtin_clzll((unsigned long long)bytes));
+    const size_t step = top >> 3;
+    return (bytes + step - 1) & ~(step - 1);
 }
 
 // The descriptor blob of an AAC_DECODE submission (plane in[2], n_chains * ps.in[2] bytes): what symaccel_aac_decode_pipelined takes
@@ -154,6 +235,10 @@ inline size_t aac_blob_js(size_t n_pairs) { return sizeof(AacBlobHeader) + ((n_p
 inline size_t aac_blob_tns(size_t n_pairs, size_t units) { return aac_blob_js(n_pairs) + ((n_pairs * units * sizeof(symaccel_aac_js_frame) + 15) & ~(size_t)15); }
 inline size_t aac_blob_bytes(size_t n_pairs, size_t units, size_t n_tns) { return aac_blob_tns(n_pairs, units) + n_tns * sizeof(symaccel_aac_tns_filter); }
 
+// The coupling blob of a VORBIS_DECODE submission (plane in[4]): first[units + 1] u32 -- the steps of block b are
+// [first[b], first[b + 1]) --, padded to 16 bytes, then the steps as (magnitude channel, angle channel) byte pairs
+inline size_t vorbis_blob_steps(size_t units) { return ((units + 1) * 4 + 15) & ~(size_t)15; }
+
 struct Group;
 
 struct Ticket {
@@ -161,14 +246,25 @@ struct Ticket {
     uint32_t gen = 0;
     uint32_t first_chain = 0, n_chains = 0, ordinal = 0;
     bool live = false, committed = false;
-    char *slot = nullptr;  // page-locked, slot_layout(group's planes, n_chains)
-    size_t slot_bytes = 0;
+    int status = SYMACCEL_OK;  // of THIS submission, once its group is launched
+    char *slot = nullptr;      // page-locked, slot_layout(group's planes, n_chains)
+    size_t slot_bytes = 0;     // (the size class it was carved for)
     // copy form (symaccel_batcher_submit): where collect() puts the results
     void *user_state[kMaxState] = {nullptr, nullptr, nullptr};
     void *user_out = nullptr;
 };
 
-enum class GroupState { Free, Open, Closed, Launched };
+// what a launch needs of a submission: copied out of the ticket table when the group closes, because the launch runs outside the
+// batcher's mutex and the table may grow meanwhile
+struct TicketView {
+    char *slot = nullptr;
+    uint32_t first_chain = 0, n_chains = 0;
+    int status = SYMACCEL_OK;
+};
+
+enum class GroupState { Free, Open, Closed, Launching, Launched };
+
+struct Lane;
 
 // One launch: the submissions of one shape that were pending together.  Host side: the submissions' own slots.  Device side: one
 // allocation, cut at launch time (when the number of chains is known) and kept with the group object for the next launch it serves.
@@ -179,8 +275,10 @@ struct Group {
     size_t cap_chains = 0;  // reservations accepted before the group is launched and a fresh one opened
     size_t chains = 0, tickets = 0, uncommitted = 0, live = 0;
     GroupState state = GroupState::Free;
-    int status = SYMACCEL_OK;
+    int status = SYMACCEL_OK;          // of the launch as a whole (a device error fails every ticket)
     std::vector<uint32_t> ticket_ids;  // the submissions, in order (index into symaccel_batcher::tickets)
+    std::vector<TicketView> views;     // ... as the launch sees them
+    Lane *lane = nullptr;              // where it was (is being) enqueued
     char *d_base = nullptr;
     size_t d_bytes = 0;
     char *d_in[kMaxIn] = {}, *d_state_in[kMaxState] = {}, *d_state_out[kMaxState] = {}, *d_out = nullptr;
@@ -195,12 +293,38 @@ struct Group {
     struct {                             // ... and of the chunk being launched: first pair / filter / TNS pair frame and their counts
         size_t p0, np, f0, nf, q0, nq;
     } aac_chunk{};
-    bool bad_blob = false;               // a submission's descriptor blob did not add up: the group's tickets fail with INVALID_ARG
-    // page-locked: the copy descriptors of the launch (read by batch_copy_kernel straight from here) and the unit list
+    AacBandMaps aac_maps{};              // the band tables `param` names (copied when the group closes)
+    // VORBIS_DECODE: the byte plane of the floor curves, the floor1_Y rows and line offsets by (configuration, block size) class, the
+    // blocks' line offsets, the channel-blocks without a floor, the coupling steps
+    uint8_t *d_vb_plane = nullptr, *d_vb_kill = nullptr, *d_vb_steps = nullptr;
+    uint32_t *d_vb_ys = nullptr, *d_vb_offs = nullptr, *d_vb_boff = nullptr, *d_vb_first = nullptr;
+    size_t vb_steps = 0;                 // coupling steps of the group (counted when it is launched)
+    std::vector<symaccel_vorbis_floor1_cfg> vb_floors;  // the registered configurations (copied when the group closes)
+    struct VbClass {
+        uint32_t cfg, n2;
+        size_t ys0, offs0, count;
+    };
+    struct {
+        std::vector<VbClass> classes;
+        size_t boff0, kill0, first0, steps0, n_steps;
+        bool prepare;
+    } vb_chunk{};
+    // page-locked: the copy descriptors of the launch (read by batch_copy_kernel straight from here) and the lists built at launch
     char *h_desc = nullptr;
     size_t h_desc_bytes = 0;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, done = nullptr;
 };
+
+// One pipeline: a context (kernel stream, scratch, tables) and two copy streams.  Lane 0 is the caller's context; the others are the
+// batcher's own.  `mu` serialises the enqueues of a lane (a context is externally synchronised).
+struct Lane {
+    symaccel_ctx *ctx = nullptr;
+    bool owned = false;
+    std::mutex mu;
+};
+
+using Clock = std::chrono::steady_clock;
+inline uint64_t ns_since(Clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t0).count(); }
 
 }  // namespace
 
@@ -215,8 +339,10 @@ struct symaccel_batcher {
     symaccel_batcher_stats stats{};
     std::string last_error;
     size_t hint_bytes = 0;  // what a group must hold for a hint to launch it
-    // page-locked slot memory: slabs, carved into slots by size; a released slot goes to the free list of its size (the shapes of a
-    // running service repeat: in the steady state nothing is allocated)
+    std::vector<std::unique_ptr<Lane>> lanes;
+    size_t want_lanes = 2, next_lane = 0;
+    // page-locked slot memory: slabs, carved into slots by size class; a released slot goes to the free list of its class (the
+    // shapes of a running service repeat: in the steady state nothing is allocated)
     struct Slab {
         char *base;
         size_t bytes, used;
@@ -230,11 +356,26 @@ struct symaccel_batcher {
         AacBandMaps maps;
     };
     std::vector<Bands> bands;
+    // VORBIS_DECODE: the floor-1 configurations the submissions' floor planes index (symaccel_batcher_vorbis_floor)
+    std::vector<symaccel_vorbis_floor1_cfg> floors;
 };
 
 namespace {
 
 constexpr size_t kSlabBytes = (size_t)32 << 20;
+
+// (the batcher's mutex, with the time spent waiting for it on the books: symaccel_batcher_stats::mutex_wait_ns)
+struct Locked {
+    std::unique_lock<std::mutex> lock;
+    explicit Locked(symaccel_batcher *b) : lock(b->mu, std::defer_lock) {
+        if (!lock.try_lock()) {
+            const Clock::time_point t0 = Clock::now();
+            lock.lock();
+            b->stats.mutex_wait_ns += ns_since(t0);
+            b->stats.mutex_contended += 1;
+        }
+    }
+};
 
 int slot_alloc(symaccel_batcher *b, size_t bytes, char **out) {
     for (auto &cls : b->free_slots)
@@ -282,14 +423,40 @@ void group_free(Group *g) {
     g->h_desc = nullptr;
 }
 
+// Sizes of the lists a launch builds on the host (page-locked, behind the copy descriptors) and mirrors on the device
+struct ListSizes {
+    size_t units = 0;                                      // MP3_DECODE
+    size_t aac_pairs = 0, aac_tns = 0, aac_pf = 0;         // AAC_DECODE
+    size_t vb_boff = 0, vb_kill = 0, vb_first = 0, vb_steps = 0, vb_ys = 0, vb_offs = 0;  // VORBIS_DECODE
+};
+ListSizes list_sizes(const Group *g) {
+    ListSizes s;
+    s.units = round256(g->tickets * 8);
+    if (g->kind == SYMACCEL_BATCH_AAC_DECODE) {
+        s.aac_pairs = round256(std::max<size_t>(1, g->aac_pairs) * 8);
+        s.aac_tns = round256(std::max<size_t>(1, g->aac_tns) * sizeof(symaccel_aac_tns_filter));
+        s.aac_pf = round256(std::max<size_t>(1, g->aac_tns) * 4);
+    }
+    if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) {
+        s.vb_boff = round256(g->tickets * (g->units + 1) * 4);
+        s.vb_kill = round256(g->chains * g->units);
+        s.vb_first = round256((g->tickets * g->units + g->tickets + 1) * 4);  // (every chunk's list starts with a 0 of its own)
+        s.vb_steps = round256(std::max<size_t>(1, g->vb_steps) * 2);
+        s.vb_ys = round256(g->chains * g->units * kVorbisPosts * 4);
+        s.vb_offs = round256(g->chains * g->units * 4);
+    }
+    return s;
+}
+
 // the device side of a closed group: sized for the chains it holds, planes carved out; grown (never shrunk) across reuses
-int group_device(symaccel_batcher *b, Group *g, size_t n_pieces_bound) {
-    symaccel_ctx *ctx = b->ctx;
+int group_device(symaccel_ctx *ctx, Group *g, size_t n_pieces_bound) {
     const PlaneSizes &ps = g->ps;
-    size_t total = 0, off_in[kMaxIn], off_si[kMaxState], off_so[kMaxState], off_out, off_units;
+    const ListSizes ls = list_sizes(g);
+    size_t total = 0, off_in[kMaxIn] = {}, off_si[kMaxState], off_so[kMaxState], off_out = 0, off_units;
     for (int i = 0; i < ps.n_in; ++i) {
         off_in[i] = total;
-        total += round256(ps.in[i] * (ps.in_per_ticket[i] ? g->tickets : g->chains));
+        if (ps.in_host_only[i]) continue;
+        total += round256(ps.in_per_ticket[i] ? ps.in[i] * g->tickets : ps.in[i] * ((g->chains + ps.in_div[i] - 1) / ps.in_div[i]));
     }
     for (int i = 0; i < ps.n_state; ++i) {
         off_si[i] = total;
@@ -297,22 +464,41 @@ int group_device(symaccel_batcher *b, Group *g, size_t n_pieces_bound) {
         off_so[i] = total;
         total += round256(ps.state[i] * g->chains);
     }
-    off_out = total;
-    total += round256(ps.out * g->chains);
+    if (!ps.in_place) {
+        off_out = total;
+        total += round256(ps.out * g->chains);
+    }
     off_units = total;
-    total += round256(g->tickets * 8);
+    total += ls.units;
     size_t off_ap = 0, off_aj = 0, off_at = 0, off_af = 0, off_ai = 0;
     if (g->kind == SYMACCEL_BATCH_AAC_DECODE) {
         off_ap = total;
-        total += round256(std::max<size_t>(1, g->aac_pairs) * 8);
+        total += ls.aac_pairs;
         off_aj = total;
         total += round256(std::max<size_t>(1, g->aac_pairs) * g->units * sizeof(symaccel_aac_js_frame));
         off_at = total;
-        total += round256(std::max<size_t>(1, g->aac_tns) * sizeof(symaccel_aac_tns_filter));
+        total += ls.aac_tns;
         off_af = total;
-        total += round256(std::max<size_t>(1, g->aac_tns) * 4);
+        total += ls.aac_pf;
         off_ai = total;
         total += round256(aac_js_scratch_bytes(g->chains, g->aac_pairs, g->units));
+    }
+    size_t off_vp = 0, off_vy = 0, off_vo = 0, off_vb = 0, off_vk = 0, off_vf = 0, off_vs = 0;
+    if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) {
+        off_vp = total;
+        total += round256(g->chains * (g->units << (((g->param >> 8) & 255) - 1)));  // one byte per line
+        off_vy = total;
+        total += ls.vb_ys;
+        off_vo = total;
+        total += ls.vb_offs;
+        off_vb = total;
+        total += ls.vb_boff;
+        off_vk = total;
+        total += ls.vb_kill;
+        off_vf = total;
+        total += ls.vb_first;
+        off_vs = total;
+        total += ls.vb_steps;
     }
     if (total > g->d_bytes) {
         if (g->d_base) SYM_GPU(ctx, hipFree(g->d_base));
@@ -328,7 +514,7 @@ int group_device(symaccel_batcher *b, Group *g, size_t n_pieces_bound) {
         g->d_state_in[i] = g->d_base + off_si[i];
         g->d_state_out[i] = g->d_base + off_so[i];
     }
-    g->d_out = g->d_base + off_out;
+    g->d_out = ps.in_place ? g->d_in[0] : g->d_base + off_out;
     g->d_units = reinterpret_cast<int32_t *>(g->d_base + off_units);
     if (g->kind == SYMACCEL_BATCH_AAC_DECODE) {
         g->d_aac_pairs = reinterpret_cast<int32_t *>(g->d_base + off_ap);
@@ -337,10 +523,18 @@ int group_device(symaccel_batcher *b, Group *g, size_t n_pieces_bound) {
         g->d_aac_pf = reinterpret_cast<uint32_t *>(g->d_base + off_af);
         g->d_aac_index = g->d_base + off_ai;
     }
-    // (behind the descriptors: the MP3 unit list, or AAC_DECODE's rebased pair list, TNS filters and TNS pair frames)
-    const size_t desc_bytes = round256(n_pieces_bound * sizeof(BatchCopyDesc)) + round256(g->tickets * 8) +
-                              (g->kind == SYMACCEL_BATCH_AAC_DECODE ? round256(g->aac_pairs * 8) + round256(g->aac_tns * sizeof(symaccel_aac_tns_filter)) +
-                                                                          round256(g->aac_tns * 4) : 0);
+    if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) {
+        g->d_vb_plane = reinterpret_cast<uint8_t *>(g->d_base + off_vp);
+        g->d_vb_ys = reinterpret_cast<uint32_t *>(g->d_base + off_vy);
+        g->d_vb_offs = reinterpret_cast<uint32_t *>(g->d_base + off_vo);
+        g->d_vb_boff = reinterpret_cast<uint32_t *>(g->d_base + off_vb);
+        g->d_vb_kill = reinterpret_cast<uint8_t *>(g->d_base + off_vk);
+        g->d_vb_first = reinterpret_cast<uint32_t *>(g->d_base + off_vf);
+        g->d_vb_steps = reinterpret_cast<uint8_t *>(g->d_base + off_vs);
+    }
+    // (behind the descriptors: the lists of list_sizes())
+    const size_t desc_bytes = round256(n_pieces_bound * sizeof(BatchCopyDesc)) + ls.units + ls.aac_pairs + ls.aac_tns + ls.aac_pf + ls.vb_boff +
+                              ls.vb_kill + ls.vb_first + ls.vb_steps + ls.vb_ys + ls.vb_offs;
     if (desc_bytes > g->h_desc_bytes) {
         if (g->h_desc) (void)hipHostFree(g->h_desc);
         g->h_desc = nullptr;
@@ -359,13 +553,12 @@ int group_device(symaccel_batcher *b, Group *g, size_t n_pieces_bound) {
 }
 
 // the kernels of one chunk: chains [c0, c0 + nc), submissions [t0, t0 + nt)
-int launch_chunk(symaccel_batcher *b, Group *g, size_t c0, size_t nc, size_t t0, size_t nt) {
-    symaccel_ctx *ctx = b->ctx;
+int launch_chunk(symaccel_ctx *ctx, Group *g, size_t c0, size_t nc, size_t t0, size_t nt) {
     const PlaneSizes &ps = g->ps;
-    auto in = [&](int i) { return g->d_in[i] + (ps.in_per_ticket[i] ? t0 : c0) * ps.in[i]; };
+    auto in = [&](int i) { return g->d_in[i] + (ps.in_per_ticket[i] ? t0 * ps.in[i] : (c0 / ps.in_div[i]) * ps.in[i]); };
     auto si = [&](int i) { return g->d_state_in[i] + c0 * ps.state[i]; };
     auto so = [&](int i) { return g->d_state_out[i] + c0 * ps.state[i]; };
-    char *out = g->d_out + c0 * ps.out;
+    char *out = g->d_out + c0 * (ps.in_place ? ps.in[0] : ps.out);
     switch (g->kind) {
     case SYMACCEL_BATCH_AAC_SYNTH:
         return launch_aac(ctx, (const float *)in(0), (const uint8_t *)in(1), (const float *)si(0), (float *)so(0), (float *)out, nc, g->units);
@@ -380,8 +573,7 @@ int launch_chunk(symaccel_batcher *b, Group *g, size_t c0, size_t nc, size_t t0,
     case SYMACCEL_BATCH_AAC_DECODE: {
         // symaccel_aac_decode_pipelined's kernel sequence (csrc/stage.cpp) on the chunk: the pair frames that carry TNS get their joint
         // stereo decoded in place (a list pass), the filters run, ONE walk decodes the joint stereo of every other frame on load
-        if (g->param < 0 || (size_t)g->param >= b->bands.size()) return SYMACCEL_ERR_INVALID_ARG;
-        const AacBandMaps &maps = b->bands[(size_t)g->param].maps;
+        const AacBandMaps &maps = g->aac_maps;
         const auto &ch = g->aac_chunk;
         const int32_t *pairs = g->d_aac_pairs + 2 * ch.p0;
         symaccel_aac_js_frame *js = g->d_aac_js + ch.p0 * g->units;
@@ -399,6 +591,32 @@ int launch_chunk(symaccel_batcher *b, Group *g, size_t c0, size_t nc, size_t t0,
         return symaccel_vorbis_synth_pp_device(ctx, e0, e1, (const float *)in(0), nullptr, cap, (const uint8_t *)in(1), (const int32_t *)si(0),
                                                (int32_t *)so(0), (const float *)si(1), (float *)so(1), (float *)out, cap, nc, g->units);
     }
+    case SYMACCEL_BATCH_VORBIS_DECODE: {
+        // symaccel_vorbis_decode's kernel sequence (csrc/ctx.cpp) on the chunk: the coupling steps and the zero floors in place
+        // (lib.rs:250-278, 206-209), the floor curves as one byte per line -- one launch per (configuration, block size) class
+        // (floor.rs:568-653, 776-825) --, then the synthesis with table[y] * residue in its load path (lib.rs:282-292, dsp.rs:68-126)
+        const int e0 = g->param & 255, e1 = (g->param >> 8) & 255, nch = (g->param >> 16) & 255;
+        const size_t cap = g->units << (e1 - 1);
+        const auto &ch = g->vb_chunk;
+        uint8_t *plane = g->d_vb_plane + c0 * cap;
+        SYM_GPU(ctx, hipMemsetAsync(plane, 0, nc * cap, ctx->stream));
+        if (ch.prepare)
+            SYM_TRY(launch_vorbis_prepare(ctx, (float *)in(0), cap, (unsigned)nch, nt, g->units, g->d_vb_boff + ch.boff0, g->d_vb_steps + 2 * ch.steps0,
+                                          g->d_vb_first + ch.first0, g->d_vb_kill + ch.kill0));
+        for (const Group::VbClass &k : ch.classes) {
+            const symaccel_vorbis_floor1_cfg &cfg = g->vb_floors[k.cfg];
+            SYM_TRY(symaccel_vorbis_floor1_y_device(ctx, cfg.x_list, cfg.n_posts, cfg.multiplier, g->d_vb_ys + k.ys0, k.n2, g->d_vb_offs + k.offs0, plane,
+                                                    k.count));
+        }
+        return symaccel_vorbis_synth_fy_pp_device(ctx, e0, e1, plane, (const float *)in(0), cap, (const uint8_t *)in(1), (const int32_t *)si(0),
+                                                  (int32_t *)so(0), (const float *)si(1), (float *)so(1), (float *)out, cap, nc, g->units);
+    }
+    case SYMACCEL_BATCH_FLAC_RESTORE:  // decoder.rs:663-752 (+ :32-82, :239-242 with the pair modes)
+        return launch_flac_restore(ctx, (int32_t *)in(0), (const symaccel_flac_desc *)in(1), (const int32_t *)in(2), nc, g->units,
+                                   (g->param & 0x100) ? (const uint8_t *)in(3) : nullptr, (uint32_t)(g->param & 31));
+    case SYMACCEL_BATCH_ALAC_PREDICT:  // alac/lib.rs:165-264 (+ :664-671 with the pair parameters)
+        return launch_alac_predict(ctx, (int32_t *)in(0), (const symaccel_alac_desc *)in(1), (const int32_t *)in(2), nc, g->units,
+                                   (g->param & 0x100) ? (const int32_t *)in(3) : nullptr, (g->param & 0x100) ? (const uint8_t *)in(4) : nullptr);
     default:
         return SYMACCEL_ERR_INVALID_ARG;
     }
@@ -432,67 +650,180 @@ void add_pieces(BatchCopyDesc *&w, const char *src, char *dst, size_t bytes) {
     }
 }
 
+// ---- what a submission's descriptors say, judged alone (its neighbours in the launch are not failed for it)
+
+int check_aac_blob(const PlaneSizes &ps, size_t units, TicketView &v) {
+    AacBlobHeader *h = reinterpret_cast<AacBlobHeader *>(v.slot + slot_layout(ps, v.n_chains).in[2]);
+    if (2 * (size_t)h->n_pairs > v.n_chains || aac_blob_bytes(h->n_pairs, units, h->n_tns) > ps.in[2] * v.n_chains) return SYMACCEL_ERR_INVALID_ARG;
+    const int32_t *pc = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(h) + aac_blob_pairs(h->n_pairs));
+    std::vector<uint8_t> seen(v.n_chains, 0);
+    for (uint32_t q = 0; q < 2 * h->n_pairs; ++q) {
+        const int32_t c = pc[q];
+        if (c < 0 || (size_t)c >= v.n_chains || seen[(size_t)c]) return SYMACCEL_ERR_INVALID_ARG;
+        seen[(size_t)c] = 1;
+    }
+    return SYMACCEL_OK;
+}
+
+int check_flac(const PlaneSizes &ps, size_t units, int param, const TicketView &v) {
+    const SlotLayout l = slot_layout(ps, v.n_chains);
+    const symaccel_flac_desc *d = reinterpret_cast<const symaccel_flac_desc *>(v.slot + l.in[1]);
+    for (size_t c = 0; c < v.n_chains; ++c) {  // what symaccel_flac_restore checks (decoder.rs:361, 456-458, 506-508)
+        if (d[c].kind > SYMACCEL_FLAC_LPC || d[c].order > units || d[c].shift > 31 || d[c].wasted_bits > 31) return SYMACCEL_ERR_INVALID_ARG;
+        if (d[c].kind == SYMACCEL_FLAC_FIXED && d[c].order > 4) return SYMACCEL_ERR_INVALID_ARG;
+        if (d[c].kind == SYMACCEL_FLAC_LPC && (d[c].order < 1 || d[c].order > 32)) return SYMACCEL_ERR_INVALID_ARG;
+    }
+    if (param & 0x100) {
+        const uint8_t *pm = reinterpret_cast<const uint8_t *>(v.slot + l.in[3]);
+        for (size_t p = 0; p < v.n_chains / 2; ++p)
+            if (pm[p] > 3) return SYMACCEL_ERR_INVALID_ARG;
+    }
+    return SYMACCEL_OK;
+}
+
+int check_alac(const PlaneSizes &ps, int param, const TicketView &v) {
+    const SlotLayout l = slot_layout(ps, v.n_chains);
+    const symaccel_alac_desc *d = reinterpret_cast<const symaccel_alac_desc *>(v.slot + l.in[1]);
+    for (size_t c = 0; c < v.n_chains; ++c) {
+        if (d[c].mode > 0 && d[c].mode < 15) return SYMACCEL_ERR_DECODE;  // lib.rs:167-169, "alac: invalid mode" (symaccel_alac_block_status_device)
+        if (d[c].lpc_order > 31 || d[c].shift > 31 || d[c].bps < 1 || d[c].bps > 32) return SYMACCEL_ERR_INVALID_ARG;
+    }
+    if (param & 0x100) {
+        const uint8_t *sh = reinterpret_cast<const uint8_t *>(v.slot + l.in[4]);
+        for (size_t p = 0; p < v.n_chains / 2; ++p)
+            if (sh[p] > 31) return SYMACCEL_ERR_INVALID_ARG;  // lib.rs:555
+    }
+    return SYMACCEL_OK;
+}
+
+// a VORBIS_DECODE submission (what symaccel_vorbis_decode checks of a stream); *steps = its coupling steps
+int check_vorbis(const Group *g, const TicketView &v, size_t *steps) {
+    const PlaneSizes &ps = g->ps;
+    const size_t nb = g->units, nch = v.n_chains;
+    const SlotLayout l = slot_layout(ps, nch);
+    const uint8_t *flags = reinterpret_cast<const uint8_t *>(v.slot + l.in[1]);
+    const uint8_t *floor = reinterpret_cast<const uint8_t *>(v.slot + l.in[2]);
+    const uint32_t *posts = reinterpret_cast<const uint32_t *>(v.slot + l.in[3]);
+    const int32_t *prev = reinterpret_cast<const int32_t *>(v.slot + l.state[0]);
+    *steps = 0;
+    // the channels of a stream share their block flags and their previous flag (one mode per packet, lib.rs:170-178)
+    for (size_t c = 1; c < nch; ++c) {
+        if (prev[c] != prev[0]) return SYMACCEL_ERR_INVALID_ARG;
+        for (size_t b = 0; b < nb; ++b)
+            if ((flags[c * nb + b] != 0) != (flags[b] != 0)) return SYMACCEL_ERR_INVALID_ARG;
+    }
+    for (size_t cb = 0; cb < nch * nb; ++cb) {
+        const unsigned f = floor[cb];
+        if (f == SYMACCEL_VORBIS_FLOOR_UNUSED) continue;
+        if (f >= g->vb_floors.size()) return SYMACCEL_ERR_INVALID_ARG;
+        const uint32_t *y = posts + cb * kVorbisPosts;
+        for (unsigned i = 0; i < g->vb_floors[f].n_posts; ++i)
+            if (y[i] > 511u) return SYMACCEL_ERR_UNSUPPORTED;  // (symaccel_vorbis_floor1_status_device's domain)
+    }
+    const uint32_t *first = reinterpret_cast<const uint32_t *>(v.slot + l.in[4]);
+    const uint8_t *st = reinterpret_cast<const uint8_t *>(v.slot + l.in[4] + vorbis_blob_steps(nb));
+    if (first[0] != 0) return SYMACCEL_ERR_INVALID_ARG;
+    for (size_t b = 0; b < nb; ++b)
+        if (first[b + 1] < first[b]) return SYMACCEL_ERR_INVALID_ARG;
+    const size_t n = first[nb];
+    if (vorbis_blob_steps(nb) + 2 * n > ps.in[4]) return SYMACCEL_ERR_INVALID_ARG;
+    for (size_t s = 0; s < n; ++s)
+        if (st[2 * s] >= nch || st[2 * s + 1] >= nch || st[2 * s] == st[2 * s + 1]) return SYMACCEL_ERR_INVALID_ARG;  // lib.rs:253
+    *steps = n;
+    return SYMACCEL_OK;
+}
+
 // Everything of a closed group: per chunk of submissions ONE gather launch (slots -> HBM, the kernels' chain-major layout), the
-// synthesis kernel, ONE scatter launch (HBM -> slots); `done` is recorded behind the last scatter.
-int launch_group_inner(symaccel_batcher *b, Group *g) {
-    symaccel_ctx *ctx = b->ctx;
+// synthesis kernel(s), ONE scatter launch (HBM -> slots); `done` is recorded behind the last scatter.  Runs on `lane`, outside the
+// batcher's mutex: nothing of the batcher but the group itself (and the slots its views point at) is touched.
+int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks) {
+    symaccel_ctx *ctx = lane->ctx;
     const PlaneSizes &ps = g->ps;
     if (!ctx->stage_in) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_in));
     if (!ctx->stage_out) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_out));
     hipStream_t s_in = ctx->stage_in, s_out = ctx->stage_out;
+    std::vector<TicketView> &views = g->views;
     // an upper bound of the copy pieces: every plane of every submission, rounded up
     size_t bound = 0;
-    for (uint32_t id : g->ticket_ids) {
-        const Ticket &t = b->tickets[id];
-        for (int i = 0; i < ps.n_in; ++i) bound += pieces_of(ps.in[i] * (ps.in_per_ticket[i] ? 1 : t.n_chains));
-        for (int i = 0; i < ps.n_state; ++i) bound += 2 * pieces_of(ps.state[i] * t.n_chains);
-        bound += pieces_of(ps.out * t.n_chains);
+    for (const TicketView &v : views) {
+        for (int i = 0; i < ps.n_in; ++i)
+            if (!ps.in_host_only[i]) bound += pieces_of(plane_bytes(ps, i, v.n_chains));
+        for (int i = 0; i < ps.n_state; ++i) bound += 2 * pieces_of(ps.state[i] * v.n_chains);
+        bound += pieces_of((ps.in_place ? ps.in[0] : ps.out) * v.n_chains);
     }
     bound += g->tickets + 8;  // (the unit list's pieces, one per chunk at most)
-    if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH) bound += 2 * g->chains;  // (spectra and PCM go chain by chain, each rounded up)
+    if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH || g->kind == SYMACCEL_BATCH_VORBIS_DECODE) bound += 2 * g->chains;  // (spectra and PCM go chain by chain, each rounded up)
     g->aac_pairs = g->aac_tns = 0;
-    g->bad_blob = false;
+    g->vb_steps = 0;
+    // ---- the submissions' own descriptors, each judged alone: one that does not add up is neutralised (it runs as an empty
+    // description, its ticket fails) and the rest of the launch goes ahead
     if (g->kind == SYMACCEL_BATCH_AAC_DECODE) {
-        // what the submissions' blobs announce (a blob that does not fit its plane is read as "nothing": the group fails afterwards)
-        for (uint32_t id : g->ticket_ids) {
-            Ticket &t = b->tickets[id];
-            AacBlobHeader *h = reinterpret_cast<AacBlobHeader *>(t.slot + slot_layout(ps, t.n_chains).in[2]);
-            if (2 * (size_t)h->n_pairs > t.n_chains || aac_blob_bytes(h->n_pairs, g->units, h->n_tns) > ps.in[2] * t.n_chains) {
-                g->bad_blob = true;
-                h->n_pairs = h->n_tns = 0;
-            }
+        for (TicketView &v : views) {
+            AacBlobHeader *h = reinterpret_cast<AacBlobHeader *>(v.slot + slot_layout(ps, v.n_chains).in[2]);
+            v.status = check_aac_blob(ps, g->units, v);
+            if (v.status != SYMACCEL_OK) h->n_pairs = h->n_tns = 0;
             g->aac_pairs += h->n_pairs;
             g->aac_tns += h->n_tns;
         }
         bound += 3 * g->tickets + 8;  // (pair list, filters, TNS pair frames: one piece list each per chunk)
+        for (const TicketView &v : views) bound += pieces_of(ps.in[2] * v.n_chains);  // (the joint-stereo rows of the blob)
     }
-    SYM_TRY(group_device(b, g, bound));
+    if (g->kind == SYMACCEL_BATCH_FLAC_RESTORE)
+        for (TicketView &v : views) v.status = check_flac(ps, g->units, g->param, v);
+    if (g->kind == SYMACCEL_BATCH_ALAC_PREDICT)
+        for (TicketView &v : views) v.status = check_alac(ps, g->param, v);
+    if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) {
+        for (TicketView &v : views) {
+            size_t steps = 0;
+            v.status = check_vorbis(g, v, &steps);
+            g->vb_steps += steps;
+        }
+        const ListSizes ls = list_sizes(g);
+        bound += 6 * (g->tickets + 8) + pieces_of(ls.vb_boff) + pieces_of(ls.vb_kill) + pieces_of(ls.vb_first) + pieces_of(ls.vb_steps) + pieces_of(ls.vb_ys) +
+                 pieces_of(ls.vb_offs);
+    }
+    SYM_TRY(group_device(ctx, g, bound));
+    const ListSizes ls = list_sizes(g);
     BatchCopyDesc *descs = reinterpret_cast<BatchCopyDesc *>(g->h_desc);
-    int32_t *h_units = reinterpret_cast<int32_t *>(g->h_desc + round256(bound * sizeof(BatchCopyDesc)));
+    char *lists = g->h_desc + round256(bound * sizeof(BatchCopyDesc));
+    auto carve = [&](size_t bytes) {
+        char *p = lists;
+        lists += bytes;
+        return p;
+    };
+    int32_t *h_units = reinterpret_cast<int32_t *>(carve(ls.units));
     // AAC_DECODE: the group's pair list, filters and TNS pair frames with the indices the chunk's kernels want, built here
-    int32_t *h_pairs = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h_units) + round256(g->tickets * 8));
-    symaccel_aac_tns_filter *h_tns = reinterpret_cast<symaccel_aac_tns_filter *>(reinterpret_cast<char *>(h_pairs) + round256(g->aac_pairs * 8));
-    uint32_t *h_pf = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(h_tns) + round256(g->aac_tns * sizeof(symaccel_aac_tns_filter)));
+    int32_t *h_pairs = reinterpret_cast<int32_t *>(carve(ls.aac_pairs));
+    symaccel_aac_tns_filter *h_tns = reinterpret_cast<symaccel_aac_tns_filter *>(carve(ls.aac_tns));
+    uint32_t *h_pf = reinterpret_cast<uint32_t *>(carve(ls.aac_pf));
     size_t aac_p = 0, aac_f = 0, aac_q = 0;  // pairs / filters / TNS pair frames placed so far
+    // VORBIS_DECODE: line offsets of the blocks, channel-blocks without a floor, coupling steps, floor1_Y rows and line offsets by class
+    uint32_t *h_boff = reinterpret_cast<uint32_t *>(carve(ls.vb_boff));
+    uint8_t *h_kill = reinterpret_cast<uint8_t *>(carve(ls.vb_kill));
+    uint32_t *h_first = reinterpret_cast<uint32_t *>(carve(ls.vb_first));
+    uint8_t *h_steps = reinterpret_cast<uint8_t *>(carve(ls.vb_steps));
+    uint32_t *h_ys = reinterpret_cast<uint32_t *>(carve(ls.vb_ys));
+    uint32_t *h_offs = reinterpret_cast<uint32_t *>(carve(ls.vb_offs));
+    size_t vb_first_at = 0, vb_steps_at = 0, vb_ys_at = 0, vb_offs_at = 0;
     BatchCopyDesc *w = descs;
     const size_t per_chain = std::max<size_t>(1, in_bytes_per_chain(ps));
     // a third of the group per chunk, 8 .. 32 MiB of input: a chunk costs three launches and two event hops (~40 us), which 2 MiB
     // chunks (44 us on the link) did not amortise -- 22.7 GB/s each way at look-ahead 64 against 37.9 at 256 (profiles/r05c_*);
-    // consecutive GROUPS overlap on the three streams anyway, so a small group is one chunk
+    // consecutive GROUPS overlap on the lanes anyway, so a small group is one chunk
     const size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)8 << 20, g->chains * per_chain / 3));
     const size_t chunk_chains = std::max<size_t>(1, chunk_bytes / per_chain);
     size_t t0 = 0, k = 0;
     while (t0 < g->tickets) {
-        const size_t c0 = b->tickets[g->ticket_ids[t0]].first_chain;
+        const size_t c0 = views[t0].first_chain;
         size_t t1 = t0, nc = 0;
-        while (t1 < g->tickets && (nc == 0 || nc + b->tickets[g->ticket_ids[t1]].n_chains <= chunk_chains)) nc += b->tickets[g->ticket_ids[t1++]].n_chains;
+        while (t1 < g->tickets && (nc == 0 || nc + views[t1].n_chains <= chunk_chains)) nc += views[t1++].n_chains;
         const size_t nt = t1 - t0;
         const int e = (int)(k & 1);
         // ---- gather: the submissions' planes into the chain-major device arrays
         BatchCopyDesc *g0 = w;
         const size_t chunk_p0 = aac_p, chunk_f0 = aac_f, chunk_q0 = aac_q;
         for (size_t ti = t0; ti < t1; ++ti) {
-            const Ticket &t = b->tickets[g->ticket_ids[ti]];
+            const TicketView &t = views[ti];
             const SlotLayout l = slot_layout(ps, t.n_chains);
             for (int i = 0; i < ps.n_in; ++i) {
                 if (g->kind == SYMACCEL_BATCH_AAC_DECODE && i == 2) {
@@ -504,13 +835,7 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
                     const int32_t *pc = reinterpret_cast<const int32_t *>(blob + aac_blob_pairs(h->n_pairs));
                     std::vector<int32_t> pair_of(t.n_chains, -1);
                     for (uint32_t q = 0; q < h->n_pairs; ++q) {
-                        const int32_t a = pc[2 * q], bb = pc[2 * q + 1];
-                        if (a < 0 || bb < 0 || (size_t)a >= t.n_chains || (size_t)bb >= t.n_chains || a == bb || pair_of[(size_t)a] >= 0 || pair_of[(size_t)bb] >= 0) {
-                            g->bad_blob = true;  // (the pair keeps its place -- the js rows are laid out by pair -- as an inert self-less entry)
-                            h_pairs[2 * (aac_p + q)] = rel;
-                            h_pairs[2 * (aac_p + q) + 1] = rel;
-                            continue;
-                        }
+                        const int32_t a = pc[2 * q], bb = pc[2 * q + 1];  // (in range and distinct: check_aac_blob)
                         pair_of[(size_t)a] = pair_of[(size_t)bb] = (int32_t)q;
                         h_pairs[2 * (aac_p + q)] = rel + a;
                         h_pairs[2 * (aac_p + q) + 1] = rel + bb;
@@ -530,7 +855,9 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
                     aac_p += h->n_pairs;
                     continue;
                 }
-                if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH && i == 0) {  // the packed spectrum: what the chain's blocks fill, not the plane
+                if (ps.in_host_only[i]) continue;
+                if ((g->kind == SYMACCEL_BATCH_VORBIS_SYNTH || g->kind == SYMACCEL_BATCH_VORBIS_DECODE) && i == 0) {
+                    // the packed spectrum: what the chain's blocks fill, not the plane
                     for (size_t c = 0; c < t.n_chains; ++c) {
                         size_t lines, samples;
                         vorbis_used(reinterpret_cast<const uint8_t *>(t.slot + l.in[1]) + c * g->units, g->units,
@@ -539,7 +866,7 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
                     }
                     continue;
                 }
-                add_pieces(w, t.slot + l.in[i], g->d_in[i] + (ps.in_per_ticket[i] ? ti : (size_t)t.first_chain) * ps.in[i], l.in_bytes[i]);
+                add_pieces(w, t.slot + l.in[i], g->d_in[i] + (ps.in_per_ticket[i] ? ti : (size_t)t.first_chain / ps.in_div[i]) * ps.in[i], l.in_bytes[i]);
             }
             for (int i = 0; i < ps.n_state; ++i)
                 add_pieces(w, t.slot + l.state[i], g->d_state_in[i] + (size_t)t.first_chain * ps.state[i], l.state_bytes[i]);
@@ -561,18 +888,106 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
                        (aac_f - chunk_f0) * sizeof(symaccel_aac_tns_filter));
             add_pieces(w, reinterpret_cast<const char *>(h_pf + chunk_q0), reinterpret_cast<char *>(g->d_aac_pf + chunk_q0), (aac_q - chunk_q0) * 4);
         }
+        if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) {
+            // the chunk's streams in symaccel_vorbis_decode's terms: where every block's lines start, which channel-blocks have no
+            // floor, the coupling steps block by block, and per (floor configuration, block size) class the floor1_Y rows and the
+            // byte offsets of their lines in the chunk's plane
+            const int e0 = g->param & 255, e1 = (g->param >> 8) & 255;
+            const size_t nb = g->units, cap = nb << (e1 - 1), nch = (size_t)((g->param >> 16) & 255);
+            auto &ch = g->vb_chunk;
+            ch.classes.clear();
+            ch.boff0 = t0 * (nb + 1);
+            ch.kill0 = c0 * nb;
+            ch.first0 = vb_first_at;
+            ch.steps0 = vb_steps_at;
+            bool any_kill = false;
+            std::vector<uint32_t> count(512, 0);
+            h_first[vb_first_at] = 0;
+            for (size_t ti = t0; ti < t1; ++ti) {
+                const TicketView &t = views[ti];
+                const SlotLayout l = slot_layout(ps, t.n_chains);
+                const uint8_t *flags = reinterpret_cast<const uint8_t *>(t.slot + l.in[1]);
+                const uint8_t *floor = reinterpret_cast<const uint8_t *>(t.slot + l.in[2]);
+                uint32_t *boff = h_boff + ti * (nb + 1);
+                size_t lines = 0;
+                for (size_t b = 0; b < nb; ++b) {
+                    boff[b] = (uint32_t)lines;
+                    lines += (size_t)1 << ((flags[b] ? e1 : e0) - 1);
+                }
+                boff[nb] = (uint32_t)lines;
+                const bool ok = t.status == SYMACCEL_OK;
+                for (size_t c = 0; c < nch; ++c)
+                    for (size_t b = 0; b < nb; ++b) {
+                        const unsigned f = ok ? floor[c * nb + b] : SYMACCEL_VORBIS_FLOOR_UNUSED;
+                        const bool kill = f == SYMACCEL_VORBIS_FLOOR_UNUSED;
+                        h_kill[((size_t)t.first_chain + c) * nb + b] = kill ? 1 : 0;
+                        any_kill |= kill;
+                        if (!kill) count[2 * f + (flags[b] ? 1 : 0)] += 1;
+                    }
+                // the steps: block by block behind the chunk's list (a failed submission has none)
+                const uint32_t *first = reinterpret_cast<const uint32_t *>(t.slot + l.in[4]);
+                const uint8_t *st = reinterpret_cast<const uint8_t *>(t.slot + l.in[4] + vorbis_blob_steps(nb));
+                uint32_t *out_first = h_first + vb_first_at + (ti - t0) * nb;
+                const uint32_t base = out_first[0];
+                for (size_t b = 0; b < nb; ++b) out_first[b + 1] = base + (ok ? first[b + 1] : 0);
+                if (ok && first[nb]) std::memcpy(h_steps + 2 * (vb_steps_at + base), st, 2 * (size_t)first[nb]);
+            }
+            ch.n_steps = h_first[vb_first_at + nt * nb];
+            ch.prepare = ch.n_steps != 0 || any_kill;
+            // classes in (configuration, block size) order, their rows behind each other
+            std::vector<size_t> ys_at(512, 0), offs_at(512, 0);
+            for (size_t kc = 0; kc < 512; ++kc) {
+                if (!count[kc]) continue;
+                const symaccel_vorbis_floor1_cfg &cfg = g->vb_floors[kc / 2];
+                ys_at[kc] = vb_ys_at;
+                offs_at[kc] = vb_offs_at;
+                ch.classes.push_back({(uint32_t)(kc / 2), (uint32_t)1 << ((kc & 1 ? e1 : e0) - 1), vb_ys_at, vb_offs_at, count[kc]});
+                vb_ys_at += (size_t)count[kc] * cfg.n_posts;
+                vb_offs_at += count[kc];
+            }
+            const size_t ys_begin = ch.classes.empty() ? vb_ys_at : ch.classes.front().ys0, offs_begin = ch.classes.empty() ? vb_offs_at : ch.classes.front().offs0;
+            for (size_t ti = t0; ti < t1; ++ti) {
+                const TicketView &t = views[ti];
+                if (t.status != SYMACCEL_OK) continue;
+                const SlotLayout l = slot_layout(ps, t.n_chains);
+                const uint8_t *flags = reinterpret_cast<const uint8_t *>(t.slot + l.in[1]);
+                const uint8_t *floor = reinterpret_cast<const uint8_t *>(t.slot + l.in[2]);
+                const uint32_t *posts = reinterpret_cast<const uint32_t *>(t.slot + l.in[3]);
+                const uint32_t *boff = h_boff + ti * (nb + 1);
+                for (size_t c = 0; c < nch; ++c)
+                    for (size_t b = 0; b < nb; ++b) {
+                        const unsigned f = floor[c * nb + b];
+                        if (f == SYMACCEL_VORBIS_FLOOR_UNUSED) continue;
+                        const size_t kc = 2 * f + (flags[b] ? 1 : 0);
+                        const unsigned np = g->vb_floors[f].n_posts;
+                        std::memcpy(h_ys + ys_at[kc], posts + (c * nb + b) * kVorbisPosts, np * 4);
+                        ys_at[kc] += np;
+                        h_offs[offs_at[kc]++] = (uint32_t)(((size_t)t.first_chain - c0 + c) * cap + boff[b]);
+                    }
+            }
+            if (ch.prepare) {
+                add_pieces(w, reinterpret_cast<const char *>(h_boff + ch.boff0), reinterpret_cast<char *>(g->d_vb_boff + ch.boff0), nt * (nb + 1) * 4);
+                add_pieces(w, reinterpret_cast<const char *>(h_kill + ch.kill0), reinterpret_cast<char *>(g->d_vb_kill + ch.kill0), nc * nb);
+                add_pieces(w, reinterpret_cast<const char *>(h_first + ch.first0), reinterpret_cast<char *>(g->d_vb_first + ch.first0), (nt * nb + 1) * 4);
+                add_pieces(w, reinterpret_cast<const char *>(h_steps + 2 * ch.steps0), reinterpret_cast<char *>(g->d_vb_steps + 2 * ch.steps0), 2 * ch.n_steps);
+            }
+            add_pieces(w, reinterpret_cast<const char *>(h_ys + ys_begin), reinterpret_cast<char *>(g->d_vb_ys + ys_begin), (vb_ys_at - ys_begin) * 4);
+            add_pieces(w, reinterpret_cast<const char *>(h_offs + offs_begin), reinterpret_cast<char *>(g->d_vb_offs + offs_begin), (vb_offs_at - offs_begin) * 4);
+            vb_first_at += nt * nb + 1;
+            vb_steps_at += ch.n_steps;
+        }
         SYM_TRY(launch_batch_copy(ctx, s_in, g0, (size_t)(w - g0)));
         SYM_GPU(ctx, hipEventRecord(g->ev_in[e], s_in));
         SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, g->ev_in[e], 0));
-        SYM_TRY(launch_chunk(b, g, c0, nc, t0, nt));
+        SYM_TRY(launch_chunk(ctx, g, c0, nc, t0, nt));
         SYM_GPU(ctx, hipEventRecord(g->ev_k[e], ctx->stream));
         SYM_GPU(ctx, hipStreamWaitEvent(s_out, g->ev_k[e], 0));
         // ---- scatter: PCM and the state after the batch back into the submissions' slots
         BatchCopyDesc *s0 = w;
         for (size_t ti = t0; ti < t1; ++ti) {
-            const Ticket &t = b->tickets[g->ticket_ids[ti]];
+            const TicketView &t = views[ti];
             const SlotLayout l = slot_layout(ps, t.n_chains);
-            if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH) {
+            if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH || g->kind == SYMACCEL_BATCH_VORBIS_DECODE) {
                 // (the state planes of the slot still hold the state BEFORE the batch here: the scatter that overwrites them is the
                 // one being built)
                 for (size_t c = 0; c < t.n_chains; ++c) {
@@ -582,51 +997,108 @@ int launch_group_inner(symaccel_batcher *b, Group *g) {
                     add_pieces(w, g->d_out + ((size_t)t.first_chain + c) * ps.out, t.slot + l.out + c * ps.out, samples * 4);
                 }
             } else {
-                add_pieces(w, g->d_out + (size_t)t.first_chain * ps.out, t.slot + l.out, l.out_bytes);
+                add_pieces(w, g->d_out + (size_t)t.first_chain * (ps.in_place ? ps.in[0] : ps.out), t.slot + l.out, l.out_bytes);
             }
             for (int i = 0; i < ps.n_state; ++i)
                 add_pieces(w, g->d_state_out[i] + (size_t)t.first_chain * ps.state[i], t.slot + l.state[i], l.state_bytes[i]);
         }
         SYM_TRY(launch_batch_copy(ctx, s_out, s0, (size_t)(w - s0)));
-        b->stats.chunks += 1;
+        *n_chunks += 1;
         t0 = t1;
         ++k;
     }
     return SYMACCEL_OK;
 }
 
-// mu held.  Close the group, wait until every reservation of it is filled, launch.  On return the group is Launched (its status
-// says whether the launch worked) -- or somebody else has launched it meanwhile.
+// the lane a closing group goes to (mu held): round robin over the lanes that exist; the second and later ones are made on demand
+Lane *pick_lane(symaccel_batcher *b) {
+    if (b->lanes.empty()) {
+        b->lanes.emplace_back(new Lane());
+        b->lanes.back()->ctx = b->ctx;
+    }
+    const size_t want = std::max<size_t>(1, b->want_lanes);
+    const size_t idx = b->next_lane++ % want;
+    while (b->lanes.size() <= idx) {
+        symaccel_ctx *c = nullptr;
+        if (symaccel_ctx_create(b->ctx->device, &c) != SYMACCEL_OK) {  // (no second context: everything stays on the lanes there are)
+            b->want_lanes = b->lanes.size();
+            return b->lanes[idx % b->lanes.size()].get();
+        }
+        c->segment = b->ctx->segment;
+        b->lanes.emplace_back(new Lane());
+        b->lanes.back()->ctx = c;
+        b->lanes.back()->owned = true;
+    }
+    b->stats.lanes = b->lanes.size();
+    return b->lanes[idx].get();
+}
+
+// mu held.  Close the group, wait until every reservation of it is filled, enqueue it on a lane WITHOUT the mutex.  On return the
+// group is Launched (its status says whether the launch worked) -- or somebody else is launching / has launched it.
 void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lock) {
     if (g->state != GroupState::Open) return;
+    if (g->tickets == 0) {  // (opened and never filled: nothing to launch, nobody to release it)
+        g->state = GroupState::Free;
+        return;
+    }
     g->state = GroupState::Closed;
     b->cv.wait(lock, [&] { return g->uncommitted == 0; });
     if (g->state != GroupState::Closed) return;
     int st = SYMACCEL_OK;
+    uint64_t chunks = 0, host_ns = 0, lane_ns = 0;
+    std::string err;
     if (g->tickets) {
-        DeviceGuard dev(b->ctx);
-        st = dev.ok() ? launch_group_inner(b, g) : dev.status();
-        if (st != SYMACCEL_OK) {
-            // a launch that failed half way: nothing of this group may still be in flight when its slots are reused, and the
-            // copy-out stream does not follow what the other two were left with -- drain all three (error path only)
-            b->last_error = b->ctx->last_error;
-            if (b->ctx->stage_in) (void)hipStreamSynchronize(b->ctx->stage_in);
-            if (b->ctx->stream) (void)hipStreamSynchronize(b->ctx->stream);
-            if (b->ctx->stage_out) (void)hipStreamSynchronize(b->ctx->stage_out);
+        // what the launch needs of the batcher, copied while the mutex is still ours
+        g->views.resize(g->tickets);
+        for (size_t i = 0; i < g->tickets; ++i) {
+            const Ticket &t = b->tickets[g->ticket_ids[i]];
+            g->views[i] = TicketView{t.slot, t.first_chain, t.n_chains, SYMACCEL_OK};
         }
-        // `done` sits behind the last scatter, which follows the last kernel, which follows the last gather
-        if (dev.ok() && b->ctx->stage_out && g->done) (void)hipEventRecord(g->done, b->ctx->stage_out);
+        if (g->kind == SYMACCEL_BATCH_AAC_DECODE) g->aac_maps = b->bands[(size_t)g->param].maps;  // (the index was checked by reserve())
+        if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) g->vb_floors = b->floors;
+        Lane *lane = pick_lane(b);
+        g->lane = lane;
+        g->state = GroupState::Launching;
+        lock.unlock();
+        {
+            const Clock::time_point t0 = Clock::now();
+            std::unique_lock<std::mutex> lane_lock(lane->mu);
+            lane_ns = ns_since(t0);
+            const Clock::time_point t1 = Clock::now();
+            DeviceGuard dev(lane->ctx);
+            st = dev.ok() ? launch_group_inner(lane, g, &chunks) : dev.status();
+            if (st != SYMACCEL_OK) {
+                // a launch that failed half way: nothing of this group may still be in flight when its slots are reused, and the
+                // copy-out stream does not follow what the other two were left with -- drain all three (error path only)
+                err = lane->ctx->last_error;
+                if (lane->ctx->stage_in) (void)hipStreamSynchronize(lane->ctx->stage_in);
+                if (lane->ctx->stream) (void)hipStreamSynchronize(lane->ctx->stream);
+                if (lane->ctx->stage_out) (void)hipStreamSynchronize(lane->ctx->stage_out);
+            }
+            // `done` sits behind the last scatter, which follows the last kernel, which follows the last gather
+            if (dev.ok() && lane->ctx->stage_out && g->done) (void)hipEventRecord(g->done, lane->ctx->stage_out);
+            host_ns = ns_since(t1);
+        }
+        lock.lock();
+        if (st != SYMACCEL_OK) b->last_error = err;
+        for (size_t i = 0; i < g->tickets; ++i) {
+            Ticket &t = b->tickets[g->ticket_ids[i]];
+            t.status = st != SYMACCEL_OK ? st : g->views[i].status;
+            if (t.status != SYMACCEL_OK) b->stats.failed_tickets += 1;
+        }
     }
-    g->status = st != SYMACCEL_OK ? st : (g->bad_blob ? SYMACCEL_ERR_INVALID_ARG : SYMACCEL_OK);
+    g->status = st;
     g->state = GroupState::Launched;
     b->stats.launches += 1;
+    b->stats.chunks += chunks;
+    b->stats.launch_host_ns += host_ns;
+    b->stats.lane_wait_ns += lane_ns;
     b->stats.chains_launched += g->chains;
     b->stats.max_chains_per_launch = std::max<uint64_t>(b->stats.max_chains_per_launch, g->chains);
     b->cv.notify_all();
 }
 
-Group *open_group(symaccel_batcher *b, int kind, int param, size_t units, const PlaneSizes &ps, size_t n_chains, int *st) {
-    *st = SYMACCEL_OK;
+Group *open_group(symaccel_batcher *b, int kind, int param, size_t units, const PlaneSizes &ps, size_t n_chains) {
     Group *spare = nullptr;
     for (auto &up : b->groups) {
         Group *g = up.get();
@@ -673,6 +1145,21 @@ void fill_slot(const Group *g, const Ticket *t, symaccel_batch_slot *slot) {
     slot->out_bytes = l.out_bytes;
 }
 
+// wait for the `done` event of a launched group (no mutex held); a failure is the batcher's to remember
+int sync_done(symaccel_batcher *b, Group *g) {
+    if (!g->tickets || !g->done || !g->lane) return SYMACCEL_OK;
+    hipError_t e;
+    {
+        DeviceGuard dev(g->lane->ctx);
+        if (!dev.ok()) return dev.status();
+        e = hipEventSynchronize(g->done);
+    }
+    if (e == hipSuccess) return SYMACCEL_OK;
+    Locked l(b);
+    b->last_error = std::string("hipEventSynchronize(batch done): ") + hipGetErrorString(e);
+    return SYMACCEL_ERR_DEVICE;
+}
+
 }  // namespace
 
 extern "C" {
@@ -687,7 +1174,17 @@ int symaccel_batcher_create(symaccel_ctx *ctx, size_t flush_bytes, symaccel_batc
     b->hint_bytes = std::min<size_t>((size_t)4 << 20, b->flush_bytes / 8);
     if (const char *e = std::getenv("SYMACCEL_BATCHER_HINT_MB"))  // development knob (tools/gpu_r5g.sh): the hint threshold in MiB
         if (std::atoi(e) > 0) b->hint_bytes = (size_t)std::atoi(e) << 20;
+    if (const char *e = std::getenv("SYMACCEL_BATCHER_LANES"))  // development knob: the number of lanes (symaccel_batcher_configure)
+        if (std::atoi(e) > 0) b->want_lanes = std::min(8, std::atoi(e));
     *out = b;
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_configure(symaccel_batcher *b, int lanes, size_t hint_bytes) {
+    if (!b || lanes < 0 || lanes > 8) return SYMACCEL_ERR_INVALID_ARG;
+    Locked l(b);
+    if (lanes) b->want_lanes = (size_t)lanes;  // (lanes already made stay; fewer are used from now on)
+    if (hint_bytes) b->hint_bytes = hint_bytes;
     return SYMACCEL_OK;
 }
 
@@ -696,12 +1193,17 @@ int symaccel_batcher_destroy(symaccel_batcher *b) {
     {
         DeviceGuard dev(b->ctx);
         // nothing of ours may still be in flight when the staging memory goes
-        if (b->ctx->stage_in) (void)hipStreamSynchronize(b->ctx->stage_in);
-        if (b->ctx->stream) (void)hipStreamSynchronize(b->ctx->stream);
-        if (b->ctx->stage_out) (void)hipStreamSynchronize(b->ctx->stage_out);
+        for (auto &ln : b->lanes) {
+            std::unique_lock<std::mutex> lane_lock(ln->mu);
+            if (ln->ctx->stage_in) (void)hipStreamSynchronize(ln->ctx->stage_in);
+            if (ln->ctx->stream) (void)hipStreamSynchronize(ln->ctx->stream);
+            if (ln->ctx->stage_out) (void)hipStreamSynchronize(ln->ctx->stage_out);
+        }
         for (auto &g : b->groups) group_free(g.get());
         for (auto &sl : b->slabs) (void)hipHostFree(sl.base);
     }
+    for (auto &ln : b->lanes)
+        if (ln->owned) symaccel_ctx_destroy(ln->ctx);
     delete b;
     return SYMACCEL_OK;
 }
@@ -714,18 +1216,17 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
     if (!plane_sizes(kind, param, units_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
     if ((kind == SYMACCEL_BATCH_MP3_SYNTH || kind == SYMACCEL_BATCH_MP3_DECODE) && (param < 0 || param > 8)) return SYMACCEL_ERR_INVALID_ARG;  // sample_rate_idx
     if (kind == SYMACCEL_BATCH_MP3_DECODE && n_chains > 2) return SYMACCEL_ERR_INVALID_ARG;            // one stream per submission
-    if (kind == SYMACCEL_BATCH_AAC_DECODE) {
-        std::unique_lock<std::mutex> peek(b->mu);
-        if (param < 0 || (size_t)param >= b->bands.size()) return SYMACCEL_ERR_INVALID_ARG;  // (symaccel_batcher_aac_bands first)
-    }
-    std::unique_lock<std::mutex> lock(b->mu);
-    int st = SYMACCEL_OK;
-    Group *g = open_group(b, kind, param, units_per_chain, ps, n_chains, &st);
-    if (g && g->chains + n_chains > g->cap_chains) {  // full: it goes, a fresh one opens
+    if (kind == SYMACCEL_BATCH_VORBIS_DECODE && n_chains != (size_t)((param >> 16) & 255)) return SYMACCEL_ERR_INVALID_ARG;  // one stream per submission
+    for (int i = 0; i < ps.n_in; ++i)
+        if (ps.in_div[i] == 2 && (n_chains & 1)) return SYMACCEL_ERR_INVALID_ARG;  // channel pairs
+    Locked locked(b);
+    std::unique_lock<std::mutex> &lock = locked.lock;
+    if (kind == SYMACCEL_BATCH_AAC_DECODE && (param < 0 || (size_t)param >= b->bands.size())) return SYMACCEL_ERR_INVALID_ARG;  // (symaccel_batcher_aac_bands first)
+    Group *g = open_group(b, kind, param, units_per_chain, ps, n_chains);
+    while (g->chains + n_chains > g->cap_chains && g->tickets) {  // full: it goes, a fresh one opens (or one somebody else opened meanwhile)
         flush_group(b, g, lock);
-        g = open_group(b, kind, param, units_per_chain, ps, n_chains, &st);
+        g = open_group(b, kind, param, units_per_chain, ps, n_chains);
     }
-    if (!g) return st;
     uint32_t idx;
     if (!b->free_tickets.empty()) {
         idx = b->free_tickets.back();
@@ -735,10 +1236,12 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
         b->tickets.emplace_back();
     }
     const SlotLayout lay = slot_layout(ps, n_chains);
+    const size_t cls = slot_class(lay.bytes);
     char *mem = nullptr;
-    st = slot_alloc(b, lay.bytes, &mem);
+    const int st = slot_alloc(b, cls, &mem);
     if (st != SYMACCEL_OK) {
         b->free_tickets.push_back(idx);
+        if (g->tickets == 0) g->state = GroupState::Free;  // (opened for this reservation alone: nobody would ever launch it)
         return st;
     }
     Ticket *t = &b->tickets[idx];
@@ -751,7 +1254,7 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
     t->ordinal = (uint32_t)g->tickets;
     t->live = true;
     t->slot = mem;
-    t->slot_bytes = lay.bytes;
+    t->slot_bytes = cls;
     g->ticket_ids.push_back(idx);
     g->chains += n_chains;
     g->tickets += 1;
@@ -765,7 +1268,7 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
 
 int symaccel_batcher_commit(symaccel_batcher *b, uint64_t ticket) {
     if (!b) return SYMACCEL_ERR_INVALID_ARG;
-    std::unique_lock<std::mutex> lock(b->mu);
+    Locked locked(b);
     Ticket *t = find_ticket(b, ticket);
     if (!t || t->committed) return SYMACCEL_ERR_INVALID_ARG;
     t->committed = true;
@@ -773,27 +1276,27 @@ int symaccel_batcher_commit(symaccel_batcher *b, uint64_t ticket) {
     g->uncommitted -= 1;
     if (g->uncommitted == 0) b->cv.notify_all();
     // enough input has piled up: to the device, nobody has to ask
-    if (g->state == GroupState::Open && g->chains * in_bytes_per_chain(g->ps) >= b->flush_bytes) flush_group(b, g, lock);
+    if (g->state == GroupState::Open && g->chains * in_bytes_per_chain(g->ps) >= b->flush_bytes) flush_group(b, g, locked.lock);
     return SYMACCEL_OK;
 }
 
 int symaccel_batcher_flush(symaccel_batcher *b) {
     if (!b) return SYMACCEL_ERR_INVALID_ARG;
-    std::unique_lock<std::mutex> lock(b->mu);
-    for (size_t i = 0; i < b->groups.size(); ++i)  // (index loop: flush_group drops the lock while it waits for commits)
-        if (b->groups[i]->state == GroupState::Open && b->groups[i]->tickets) flush_group(b, b->groups[i].get(), lock);
+    Locked locked(b);
+    for (size_t i = 0; i < b->groups.size(); ++i)  // (index loop: flush_group drops the lock while it waits for commits and while it enqueues)
+        if (b->groups[i]->state == GroupState::Open && b->groups[i]->tickets) flush_group(b, b->groups[i].get(), locked.lock);
     return SYMACCEL_OK;
 }
 
 int symaccel_batcher_hint(symaccel_batcher *b) {
     if (!b) return SYMACCEL_ERR_INVALID_ARG;
-    std::unique_lock<std::mutex> lock(b->mu);
+    Locked locked(b);
     // "results will be wanted soon": whatever is worth a launch of its own goes now, so that the copies and the kernels run while
     // the callers are still busy with their current batches; a group below that size waits for more submissions (or for a waiter)
     const size_t worth = b->hint_bytes;
     for (size_t i = 0; i < b->groups.size(); ++i) {
         Group *g = b->groups[i].get();
-        if (g->state == GroupState::Open && g->tickets && g->chains * in_bytes_per_chain(g->ps) >= worth) flush_group(b, g, lock);
+        if (g->state == GroupState::Open && g->tickets && g->chains * in_bytes_per_chain(g->ps) >= worth) flush_group(b, g, locked.lock);
     }
     return SYMACCEL_OK;
 }
@@ -801,8 +1304,10 @@ int symaccel_batcher_hint(symaccel_batcher *b) {
 int symaccel_batcher_wait(symaccel_batcher *b, uint64_t ticket, symaccel_batch_slot *slot) {
     if (!b) return SYMACCEL_ERR_INVALID_ARG;
     Group *g;
+    int status;
     {
-        std::unique_lock<std::mutex> lock(b->mu);
+        Locked locked(b);
+        std::unique_lock<std::mutex> &lock = locked.lock;
         Ticket *t = find_ticket(b, ticket);
         if (!t || !t->committed) return SYMACCEL_ERR_INVALID_ARG;
         g = t->group;
@@ -814,46 +1319,52 @@ int symaccel_batcher_wait(symaccel_batcher *b, uint64_t ticket, symaccel_batch_s
                 if (b->groups[i]->state == GroupState::Open && b->groups[i]->tickets) flush_group(b, b->groups[i].get(), lock);
         }
         b->cv.wait(lock, [&] { return g->state == GroupState::Launched; });
-        if (slot) fill_slot(g, find_ticket(b, ticket), slot);
+        t = find_ticket(b, ticket);  // (the table may have grown while the lock was dropped)
+        if (!t) return SYMACCEL_ERR_INVALID_ARG;
+        if (slot) fill_slot(g, t, slot);
+        status = t->status;
     }
-    if (g->tickets && g->done) {
-        DeviceGuard dev(b->ctx);
-        if (!dev.ok()) return dev.status();
-        const hipError_t e = hipEventSynchronize(g->done);
-        if (e != hipSuccess) return ctx_fail(b->ctx, e, "hipEventSynchronize(batch done)");
-    }
-    return g->status;
+    const int st = sync_done(b, g);
+    return st != SYMACCEL_OK ? st : status;
 }
 
 int symaccel_batcher_release(symaccel_batcher *b, uint64_t ticket) {
     if (!b) return SYMACCEL_ERR_INVALID_ARG;
-    std::unique_lock<std::mutex> lock(b->mu);
+    Locked locked(b);
+    std::unique_lock<std::mutex> &lock = locked.lock;
     Ticket *t = find_ticket(b, ticket);
     if (!t) return SYMACCEL_ERR_INVALID_ARG;
     Group *g = t->group;
-    if (!t->committed) {  // abandoned before it was filled: the slot's content is whatever it is, nobody reads the result
-        t->committed = true;
-        g->uncommitted -= 1;
-        if (g->uncommitted == 0) b->cv.notify_all();
+    if (!t->committed) {
+        // abandoned before it was filled (a front end that threw half way): what the slot holds is whatever it is, and it will be
+        // launched with its group -- as an EMPTY description: every plane zeroed (no pairs, no filters, verbatim blocks, silence), so
+        // that the neighbours' launch never reads garbage descriptors.  Error path: the memset runs without the mutex (the group
+        // cannot be launched while this reservation is open).
+        char *mem = t->slot;
+        const size_t bytes = slot_layout(g->ps, t->n_chains).bytes;
+        lock.unlock();
+        std::memset(mem, 0, bytes);
+        lock.lock();
+        t = find_ticket(b, ticket);
+        if (!t) return SYMACCEL_ERR_INVALID_ARG;
+        if (!t->committed) {
+            t->committed = true;
+            g->uncommitted -= 1;
+            if (g->uncommitted == 0) b->cv.notify_all();
+        }
     }
     // The slot goes back to the pool -- but the group's copies may still be reading or writing it (a release without a wait, or
     // before the launch): the group is launched if it has not been, and drained, first.  (The common order -- wait, read, release --
     // finds the event signalled.)
     if (g->state == GroupState::Open) flush_group(b, g, lock);
     b->cv.wait(lock, [&] { return g->state == GroupState::Launched; });
+    if (g->tickets && g->done) {
+        lock.unlock();
+        (void)sync_done(b, g);
+        lock.lock();
+    }
     t = find_ticket(b, ticket);  // (the table may have grown while the lock was dropped)
     if (!t) return SYMACCEL_ERR_INVALID_ARG;
-    if (g->tickets && g->done) {
-        hipEvent_t done = g->done;
-        lock.unlock();
-        {
-            DeviceGuard dev(b->ctx);
-            if (dev.ok()) (void)hipEventSynchronize(done);
-        }
-        lock.lock();
-        t = find_ticket(b, ticket);
-        if (!t) return SYMACCEL_ERR_INVALID_ARG;
-    }
     slot_free(b, t->slot, t->slot_bytes);
     t->slot = nullptr;
     t->live = false;
@@ -870,7 +1381,7 @@ int symaccel_batcher_plane_bytes(int kind, int param, size_t units_per_chain, si
         if (in_bytes) in_bytes[i] = ps.in[i];
     for (int i = 0; i < kMaxState; ++i)
         if (state_bytes) state_bytes[i] = ps.state[i];
-    if (out_bytes) *out_bytes = ps.out;
+    if (out_bytes) *out_bytes = ps.in_place ? ps.in[0] : ps.out;
     return SYMACCEL_OK;
 }
 
@@ -895,7 +1406,7 @@ int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_c
     }
     for (int i = 0; i < ps.n_state; ++i) std::memcpy(slot.state[i], state_io[i], slot.state_bytes[i]);
     {
-        std::unique_lock<std::mutex> lock(b->mu);
+        Locked locked(b);
         Ticket *t = find_ticket(b, id);
         for (int i = 0; i < ps.n_state; ++i) t->user_state[i] = state_io[i];
         t->user_out = out;
@@ -906,14 +1417,14 @@ int symaccel_batcher_submit(symaccel_batcher *b, int kind, int param, size_t n_c
 
 int symaccel_batcher_submit_aac_synth(symaccel_batcher *b, const float *coeffs, const uint8_t *side, float *delay_io, float *pcm, size_t n_chains,
                                       size_t frames_per_chain, uint64_t *ticket) {
-    const void *in[4] = {coeffs, side, nullptr, nullptr};
+    const void *in[kMaxIn] = {coeffs, side, nullptr, nullptr, nullptr, nullptr};
     void *st[3] = {delay_io, nullptr, nullptr};
     return symaccel_batcher_submit(b, SYMACCEL_BATCH_AAC_SYNTH, 0, n_chains, frames_per_chain, in, st, pcm, ticket);
 }
 
 int symaccel_batcher_submit_mp3_synth(symaccel_batcher *b, const float *xr, const symaccel_mp3_side *side, int sample_rate_idx, float *overlap_io,
                                       float *vvec_io, int32_t *vfront_io, float *pcm, size_t n_chains, size_t granules_per_chain, uint64_t *ticket) {
-    const void *in[4] = {xr, side, nullptr, nullptr};
+    const void *in[kMaxIn] = {xr, side, nullptr, nullptr, nullptr, nullptr};
     void *st[3] = {overlap_io, vvec_io, vfront_io};
     return symaccel_batcher_submit(b, SYMACCEL_BATCH_MP3_SYNTH, sample_rate_idx, n_chains, granules_per_chain, in, st, pcm, ticket);
 }
@@ -921,7 +1432,7 @@ int symaccel_batcher_submit_mp3_synth(symaccel_batcher *b, const float *xr, cons
 int symaccel_batcher_submit_mp3_decode(symaccel_batcher *b, const int16_t *quant, const symaccel_mp3_requant *rq_desc, const symaccel_mp3_stereo *st_desc,
                                        const symaccel_mp3_side *side, int sample_rate_idx, float *overlap_io, float *vvec_io, int32_t *vfront_io,
                                        float *pcm, size_t n_chains, size_t granules_per_chain, uint64_t *ticket) {
-    const void *in[4] = {quant, rq_desc, side, st_desc};
+    const void *in[kMaxIn] = {quant, rq_desc, side, st_desc, nullptr, nullptr};
     void *st[3] = {overlap_io, vvec_io, vfront_io};
     return symaccel_batcher_submit(b, SYMACCEL_BATCH_MP3_DECODE, sample_rate_idx, n_chains, granules_per_chain, in, st, pcm, ticket);
 }
@@ -932,7 +1443,7 @@ int symaccel_batcher_aac_bands(symaccel_batcher *b, const uint16_t *swb_long, in
     if (!aac_band_maps(swb_long, n_swb_long, swb_short, n_swb_short, &nb.maps)) return SYMACCEL_ERR_INVALID_ARG;
     nb.swb_long.assign(swb_long, swb_long + n_swb_long + 1);
     nb.swb_short.assign(swb_short, swb_short + n_swb_short + 1);
-    std::unique_lock<std::mutex> lock(b->mu);
+    Locked locked(b);
     for (size_t i = 0; i < b->bands.size(); ++i)
         if (b->bands[i].swb_long == nb.swb_long && b->bands[i].swb_short == nb.swb_short) {
             *bands = (int)i;
@@ -975,7 +1486,7 @@ int symaccel_batcher_submit_aac_decode(symaccel_batcher *b, int bands, const flo
     if (n_tns) std::memcpy(blob + aac_blob_tns(n_pairs, frames_per_chain), tns, n_tns * sizeof(symaccel_aac_tns_filter));
     std::memcpy(slot.state[0], delay_io, slot.state_bytes[0]);
     {
-        std::unique_lock<std::mutex> lock(b->mu);
+        Locked locked(b);
         Ticket *t = find_ticket(b, id);
         t->user_state[0] = delay_io;
         t->user_out = pcm;
@@ -988,9 +1499,83 @@ int symaccel_batcher_submit_vorbis_synth(symaccel_batcher *b, int bs0_exp, int b
                                          int32_t *prev_flag_io, float *overlap_io, float *pcm, size_t n_chains, size_t blocks_per_chain,
                                          uint64_t *ticket) {
     if (bs0_exp < 0 || bs0_exp > 255 || bs1_exp < 0 || bs1_exp > 255) return SYMACCEL_ERR_INVALID_ARG;
-    const void *in[4] = {spectra, block_flag, nullptr, nullptr};
+    const void *in[kMaxIn] = {spectra, block_flag, nullptr, nullptr, nullptr, nullptr};
     void *st[3] = {prev_flag_io, overlap_io, nullptr};
     return symaccel_batcher_submit(b, SYMACCEL_BATCH_VORBIS_SYNTH, bs0_exp | (bs1_exp << 8), n_chains, blocks_per_chain, in, st, pcm, ticket);
+}
+
+int symaccel_batcher_vorbis_floor(symaccel_batcher *b, const symaccel_vorbis_floor1_cfg *cfg, int *index) {
+    if (!b || !cfg || !index) return SYMACCEL_ERR_INVALID_ARG;
+    if (cfg->n_posts < 2 || cfg->n_posts > kVorbisPosts || cfg->multiplier < 1 || cfg->multiplier > 4) return SYMACCEL_ERR_INVALID_ARG;
+    symaccel_vorbis_floor1_cfg c{};
+    c.multiplier = cfg->multiplier;
+    c.n_posts = cfg->n_posts;
+    for (unsigned i = 0; i < cfg->n_posts; ++i) {
+        if (cfg->x_list[i] > 0xffffu) return SYMACCEL_ERR_INVALID_ARG;  // floor1_X values have at most 15 bits (rangebits)
+        for (unsigned j = 0; j < i; ++j)
+            if (cfg->x_list[j] == cfg->x_list[i]) return SYMACCEL_ERR_INVALID_ARG;  // render_line divides by (x1 - x0)
+        c.x_list[i] = cfg->x_list[i];
+    }
+    Locked locked(b);
+    for (size_t i = 0; i < b->floors.size(); ++i)
+        if (std::memcmp(&b->floors[i], &c, sizeof c) == 0) {
+            *index = (int)i;
+            return SYMACCEL_OK;
+        }
+    if (b->floors.size() >= SYMACCEL_VORBIS_FLOOR_UNUSED) return SYMACCEL_ERR_UNSUPPORTED;
+    b->floors.push_back(c);
+    *index = (int)b->floors.size() - 1;
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_submit_vorbis_decode(symaccel_batcher *b, int bs0_exp, int bs1_exp, const float *residue, const uint8_t *block_flag,
+                                          const uint8_t *floor, const uint32_t *posts, const uint8_t *coupling, const uint32_t *coupling_first,
+                                          int32_t *prev_flag_io, float *overlap_io, float *pcm, size_t n_chains, size_t blocks_per_chain,
+                                          uint64_t *ticket) {
+    if (!b || !residue || !block_flag || !floor || !posts || !coupling_first || !prev_flag_io || !overlap_io || !pcm || !ticket) return SYMACCEL_ERR_INVALID_ARG;
+    if (bs0_exp < 0 || bs0_exp > 255 || bs1_exp < 0 || bs1_exp > 255 || n_chains == 0 || n_chains > 255 || blocks_per_chain == 0) return SYMACCEL_ERR_INVALID_ARG;
+    const int param = bs0_exp | (bs1_exp << 8) | ((int)n_chains << 16);
+    PlaneSizes ps;
+    if (!plane_sizes(SYMACCEL_BATCH_VORBIS_DECODE, param, blocks_per_chain, &ps)) return SYMACCEL_ERR_INVALID_ARG;
+    const size_t n_steps = coupling_first[blocks_per_chain];
+    if ((n_steps && !coupling) || vorbis_blob_steps(blocks_per_chain) + 2 * n_steps > ps.in[4]) return SYMACCEL_ERR_INVALID_ARG;
+    symaccel_batch_slot slot;
+    uint64_t id = 0;
+    SYM_TRY(symaccel_batcher_reserve(b, SYMACCEL_BATCH_VORBIS_DECODE, param, n_chains, blocks_per_chain, &slot, &id));
+    std::memcpy(slot.input[0], residue, slot.input_bytes[0]);
+    std::memcpy(slot.input[1], block_flag, slot.input_bytes[1]);
+    std::memcpy(slot.input[2], floor, slot.input_bytes[2]);
+    std::memcpy(slot.input[3], posts, slot.input_bytes[3]);
+    char *blob = static_cast<char *>(slot.input[4]);
+    std::memcpy(blob, coupling_first, (blocks_per_chain + 1) * 4);
+    if (n_steps) std::memcpy(blob + vorbis_blob_steps(blocks_per_chain), coupling, 2 * n_steps);
+    std::memcpy(slot.state[0], prev_flag_io, slot.state_bytes[0]);
+    std::memcpy(slot.state[1], overlap_io, slot.state_bytes[1]);
+    {
+        Locked locked(b);
+        Ticket *t = find_ticket(b, id);
+        t->user_state[0] = prev_flag_io;
+        t->user_state[1] = overlap_io;
+        t->user_out = pcm;
+    }
+    *ticket = id;
+    return symaccel_batcher_commit(b, id);
+}
+
+int symaccel_batcher_submit_flac_restore(symaccel_batcher *b, int32_t *buf_io, const symaccel_flac_desc *desc, const int32_t *coeffs,
+                                         const uint8_t *pair_mode, uint32_t out_shift, size_t n_blocks, size_t blocksize, uint64_t *ticket) {
+    if (out_shift > 31 || (!pair_mode && out_shift)) return SYMACCEL_ERR_INVALID_ARG;
+    const void *in[kMaxIn] = {buf_io, desc, coeffs, pair_mode, nullptr, nullptr};
+    void *st[3] = {nullptr, nullptr, nullptr};
+    return symaccel_batcher_submit(b, SYMACCEL_BATCH_FLAC_RESTORE, pair_mode ? (int)(0x100 | out_shift) : 0, n_blocks, blocksize, in, st, buf_io, ticket);
+}
+
+int symaccel_batcher_submit_alac_predict(symaccel_batcher *b, int32_t *buf_io, const symaccel_alac_desc *desc, const int32_t *coeffs,
+                                         const int32_t *pair_weight, const uint8_t *pair_shift, size_t n_blocks, size_t blocksize, uint64_t *ticket) {
+    if ((pair_weight == nullptr) != (pair_shift == nullptr)) return SYMACCEL_ERR_INVALID_ARG;
+    const void *in[kMaxIn] = {buf_io, desc, coeffs, pair_weight, pair_shift, nullptr};
+    void *st[3] = {nullptr, nullptr, nullptr};
+    return symaccel_batcher_submit(b, SYMACCEL_BATCH_ALAC_PREDICT, pair_weight ? 0x100 : 0, n_blocks, blocksize, in, st, buf_io, ticket);
 }
 
 int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket) {
@@ -998,7 +1583,7 @@ int symaccel_batcher_collect(symaccel_batcher *b, uint64_t ticket) {
     symaccel_batch_slot slot;
     void *user_state[kMaxState], *user_out;
     {
-        std::unique_lock<std::mutex> lock(b->mu);
+        Locked locked(b);
         Ticket *t = find_ticket(b, ticket);
         if (!t || !t->user_out) return SYMACCEL_ERR_INVALID_ARG;
         for (int i = 0; i < kMaxState; ++i) user_state[i] = t->user_state[i];
@@ -1021,12 +1606,21 @@ int symaccel_batcher_abandon(symaccel_batcher *b, uint64_t ticket) {
 
 int symaccel_batcher_get_stats(symaccel_batcher *b, symaccel_batcher_stats *out) {
     if (!b || !out) return SYMACCEL_ERR_INVALID_ARG;
-    std::unique_lock<std::mutex> lock(b->mu);
+    Locked locked(b);
     *out = b->stats;
     uint64_t pending = 0;
     for (auto &g : b->groups)
         if (g->state == GroupState::Open || g->state == GroupState::Closed) pending += g->tickets;
     out->pending = pending;
+    return SYMACCEL_OK;
+}
+
+int symaccel_batcher_last_error(symaccel_batcher *b, char *buf, size_t capacity) {
+    if (!b || !buf || capacity == 0) return SYMACCEL_ERR_INVALID_ARG;
+    Locked locked(b);
+    const size_t n = std::min(capacity - 1, b->last_error.size());
+    std::memcpy(buf, b->last_error.data(), n);
+    buf[n] = 0;
     return SYMACCEL_OK;
 }
 
