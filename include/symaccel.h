@@ -704,6 +704,11 @@ typedef struct symaccel_batcher_stats {
     uint64_t mutex_contended;       /* ... and how many acquisitions found it taken */
     uint64_t launch_host_ns;        /* host time spent building copy descriptors and enqueueing launches (outside the mutex) */
     uint64_t lane_wait_ns;          /* time launchers waited for their lane (another group being enqueued on it) */
+    uint64_t launch_api_ns;         /* the part of launch_host_ns spent inside HIP launch / event calls */
+    uint64_t group_allocs;          /* device / page-locked allocations made for launches (0 in the steady state) */
+    uint64_t flag_wait_ns;          /* time callers spent waiting for a launch's completion flag (device + link time they could not hide) */
+    uint64_t slots_peak;            /* most submissions alive at once (reserved and not yet released) */
+    uint64_t blocks;                /* device-side blocks in the pool (memory + descriptors + events; reused as soon as a launch completes) */
 } symaccel_batcher_stats;
 /* flush_bytes: input bytes of one group after which it is launched without anybody waiting (0 = 64 MiB); also sizes the
  * staging memory of a group (input + output + state, page-locked, pooled and reused). */

@@ -503,6 +503,23 @@ public:
         if (batcher_) codec_.attach(batcher);  // (what a codec registers with the batcher once: AacLcCoded's band tables)
         reset();
     }
+    // Zero-copy parse: a front end that can parse the demuxer's next packet STRAIGHT INTO the batcher's page-locked slot.  The batch
+    // length is fixed first -- `avail()` = the packets of this track the demuxer can see now --, the slot is reserved for it, and
+    // `parse_into(view, i)` parses the next packet into position i of the batch (`view`: the codec's BatchView, the destination of
+    // every plane in the chain-major layout) and returns its id; nullopt = no packet after all (the batch is re-packed shorter).
+    // Nothing is copied between the parser's output and the DMA source.  For codecs with `kDirect` (fixed-size units: AacLc, Mp3,
+    // Mp3Huffman); the Rust twin: `BatchCodec::reserve` / `commit` (bindings/rust/symphonia-accel-hip/src/lookahead.rs).
+    struct Direct {
+        std::function<std::size_t()> avail;
+        std::function<std::optional<std::uint64_t>(const typename Codec::BatchView &, std::size_t)> parse_into;
+    };
+    LookaheadDecoder(Batcher &batcher, const typename Codec::Params &params, std::size_t lookahead, Direct direct)
+        : ctx_(batcher.context()), codec_(params), lookahead_(lookahead < 1 ? 1 : lookahead), batcher_(&batcher), direct_(std::move(direct)) {
+        static_assert(Codec::kDirect, "this codec's batch layout depends on the packets' content: use the Peek form");
+        if (!direct_.avail || !direct_.parse_into) throw std::invalid_argument("LookaheadDecoder: direct source");
+        codec_.attach(batcher);
+        reset();
+    }
     ~LookaheadDecoder() { drop_tickets(); }
     LookaheadDecoder(const LookaheadDecoder &) = delete;
     LookaheadDecoder &operator=(const LookaheadDecoder &) = delete;
@@ -580,6 +597,13 @@ private:
         return batch;
     }
     void fill(const Packet &first) {
+        if (direct_.avail) {
+            if constexpr (Codec::kDirect) {
+                submit_direct(&first);
+                take_next();
+                return;
+            }
+        }
         std::vector<Packet> batch = gather(&first);
         if (batcher_) {
             if constexpr (Codec::kBatchKind != 0) {
@@ -637,8 +661,68 @@ private:
     }
     void submit_ahead() {
         // the state the next batch starts from is the one the current batch left: known since take_next() copied it out
+        if (direct_.avail) {
+            if constexpr (Codec::kDirect) {
+                submit_direct(nullptr);
+                return;
+            }
+        }
         std::vector<Packet> batch = gather(nullptr);
         if (!batch.empty()) submit(batch);
+    }
+    // the direct form of submit(): reserve for the packets the demuxer can see, parse them into the slot, commit
+    void submit_direct(const Packet *first) {
+        if constexpr (Codec::kDirect) {
+            const std::size_t head = first ? 1 : 0;
+            std::size_t k = head + std::min(lookahead_ - head, direct_.avail());
+            if (k == 0) return;
+            symaccel_batch_slot slot;
+            auto reserve = [&](std::size_t n, symaccel_batch_slot *sl, std::uint64_t *t) {
+                check(symaccel_batcher_reserve(batcher_->raw(), Codec::kBatchKind, codec_.batch_param(), codec_.channels(), n * codec_.units_per_packet(), sl, t),
+                      ctx_.raw());
+            };
+            reserve(k, &slot, &next_ticket_);
+            next_live_ = true;
+            next_ids_.clear();
+            try {
+                typename Codec::BatchView view = codec_.view(slot, k);
+                std::size_t j = 0;
+                if (first) {
+                    codec_.put(view, 0, *first);
+                    next_ids_.push_back(Codec::id(*first));
+                    j = 1;
+                }
+                for (; j < k; ++j) {
+                    const std::optional<std::uint64_t> id = direct_.parse_into(view, j);
+                    if (!id) break;
+                    next_ids_.push_back(*id);
+                }
+                if (j == 0) {  // nothing there after all
+                    symaccel_batcher_release(batcher_->raw(), next_ticket_);
+                    next_live_ = false;
+                    return;
+                }
+                if (j < k) {
+                    // fewer packets than the demuxer announced (a corrupt one ends the batch): the rows move to a slot of the right
+                    // shape -- units are part of the layout AND of the state the batch leaves -- and the long one goes back unused
+                    symaccel_batch_slot shorter;
+                    std::uint64_t t2 = 0;
+                    reserve(j, &shorter, &t2);
+                    typename Codec::BatchView to = codec_.view(shorter, j);
+                    for (std::size_t i = 0; i < j; ++i) codec_.put(to, i, codec_.extract(view, i));
+                    symaccel_batcher_release(batcher_->raw(), next_ticket_);
+                    next_ticket_ = t2;
+                    slot = shorter;
+                }
+                codec_.put_state(slot);
+            } catch (...) {
+                symaccel_batcher_release(batcher_->raw(), next_ticket_);
+                next_live_ = false;
+                throw;
+            }
+            check(symaccel_batcher_commit(batcher_->raw(), next_ticket_), ctx_.raw());
+            hinted_ = false;
+        }
     }
     void take_next() {
         if constexpr (Codec::kBatchKind != 0) {
@@ -700,6 +784,7 @@ private:
     std::size_t lookahead_;
     Peek peek_;
     Batcher *batcher_ = nullptr;
+    Direct direct_{};                        // (empty: the Peek form)
     std::vector<Sample> pcm_;                // [channel][packet of the batch][frames_per_packet]: planar per packet
     const Sample *pcm_base_ = nullptr;       // pcm_.data(), or the batcher's result slot of the current batch
     std::vector<std::uint64_t> ready_;       // ids of the batch's packets, in order
@@ -742,12 +827,43 @@ struct AacLc {
     }
     // the cross-stream batcher's view of the same batch (LookaheadDecoder's second constructor)
     static constexpr int kBatchKind = SYMACCEL_BATCH_AAC_SYNTH;
+    static constexpr bool kDirect = true;
     void attach(Batcher &) {}
     int batch_param() const { return 0; }
     std::size_t units_per_packet() const { return 1; }
+    // where packet i of a batch of k lies in a slot's planes (what a parser that writes straight into the slot needs: LookaheadDecoder::Direct)
+    struct BatchView {
+        float *coeffs = nullptr;
+        std::uint8_t *side = nullptr;
+        std::size_t k = 0, nch = 0;
+        float *coeffs_at(std::size_t c, std::size_t i) const { return coeffs + (c * k + i) * 1024; }
+        std::uint8_t &side_at(std::size_t c, std::size_t i) const { return side[c * k + i]; }
+    };
+    BatchView view(const symaccel_batch_slot &slot, std::size_t k) const {
+        return BatchView{static_cast<float *>(slot.input[0]), static_cast<std::uint8_t *>(slot.input[1]), k, nch_};
+    }
+    void put(const BatchView &v, std::size_t i, const Packet &p) const {
+        if (p.coeffs.size() != nch_ * 1024 || p.side.size() != nch_) throw std::invalid_argument("AacLc: packet shape");
+        for (std::size_t c = 0; c < nch_; ++c) {
+            std::copy_n(p.coeffs.data() + c * 1024, 1024, v.coeffs_at(c, i));
+            v.side_at(c, i) = p.side[c];
+        }
+    }
+    Packet extract(const BatchView &v, std::size_t i) const {
+        Packet p;
+        p.coeffs.resize(nch_ * 1024);
+        p.side.resize(nch_);
+        for (std::size_t c = 0; c < nch_; ++c) {
+            std::copy_n(v.coeffs_at(c, i), 1024, p.coeffs.data() + c * 1024);
+            p.side[c] = v.side_at(c, i);
+        }
+        return p;
+    }
+    void put_state(const symaccel_batch_slot &slot) const { std::memcpy(slot.state[0], delay_.data(), delay_.size() * sizeof(float)); }
     void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
-        gather(batch, static_cast<float *>(slot.input[0]), static_cast<std::uint8_t *>(slot.input[1]));
-        std::memcpy(slot.state[0], delay_.data(), delay_.size() * sizeof(float));
+        const BatchView v = view(slot, batch.size());
+        for (std::size_t i = 0; i < batch.size(); ++i) put(v, i, batch[i]);
+        put_state(slot);
     }
     void take_state(const symaccel_batch_slot &slot) { std::memcpy(delay_.data(), slot.state[0], delay_.size() * sizeof(float)); }
 
@@ -805,6 +921,8 @@ struct AacLcCoded {
               ctx.raw());
     }
     static constexpr int kBatchKind = SYMACCEL_BATCH_AAC_DECODE;
+    static constexpr bool kDirect = false;  // (the descriptor blob is assembled from the whole batch)
+    struct BatchView {};
     void attach(Batcher &b) {
         check(symaccel_batcher_aac_bands(b.raw(), swb_long_.data(), (int)swb_long_.size() - 1, swb_short_.data(), (int)swb_short_.size() - 1, &bands_),
               b.context().raw());
@@ -916,14 +1034,47 @@ struct Mp3 {
               ctx.raw());
     }
     static constexpr int kBatchKind = SYMACCEL_BATCH_MP3_SYNTH;
+    static constexpr bool kDirect = true;
     void attach(Batcher &) {}
     int batch_param() const { return sr_; }
     std::size_t units_per_packet() const { return ngr_; }
-    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
-        gather(batch, static_cast<float *>(slot.input[0]), static_cast<symaccel_mp3_side *>(slot.input[1]));
+    struct BatchView {  // granule gr of packet i of channel c is unit i * ngr + gr of chain c
+        float *xr = nullptr;
+        symaccel_mp3_side *side = nullptr;
+        std::size_t k = 0, nch = 0, ngr = 0;
+        std::size_t unit(std::size_t c, std::size_t i, std::size_t gr) const { return c * k * ngr + i * ngr + gr; }
+    };
+    BatchView view(const symaccel_batch_slot &slot, std::size_t k) const {
+        return BatchView{static_cast<float *>(slot.input[0]), static_cast<symaccel_mp3_side *>(slot.input[1]), k, nch_, ngr_};
+    }
+    void put(const BatchView &v, std::size_t i, const Packet &p) const {
+        if (p.xr.size() != ngr_ * nch_ * 576 || p.side.size() != ngr_ * nch_) throw std::invalid_argument("Mp3: packet shape");
+        for (std::size_t gr = 0; gr < ngr_; ++gr)
+            for (std::size_t c = 0; c < nch_; ++c) {
+                std::copy_n(p.xr.data() + (gr * nch_ + c) * 576, 576, v.xr + v.unit(c, i, gr) * 576);
+                v.side[v.unit(c, i, gr)] = p.side[gr * nch_ + c];
+            }
+    }
+    Packet extract(const BatchView &v, std::size_t i) const {
+        Packet p;
+        p.xr.resize(ngr_ * nch_ * 576);
+        p.side.resize(ngr_ * nch_);
+        for (std::size_t gr = 0; gr < ngr_; ++gr)
+            for (std::size_t c = 0; c < nch_; ++c) {
+                std::copy_n(v.xr + v.unit(c, i, gr) * 576, 576, p.xr.data() + (gr * nch_ + c) * 576);
+                p.side[gr * nch_ + c] = v.side[v.unit(c, i, gr)];
+            }
+        return p;
+    }
+    void put_state(const symaccel_batch_slot &slot) const {
         std::memcpy(slot.state[0], overlap_.data(), overlap_.size() * sizeof(float));
         std::memcpy(slot.state[1], vvec_.data(), vvec_.size() * sizeof(float));
         std::memcpy(slot.state[2], vfront_.data(), vfront_.size() * sizeof(std::int32_t));
+    }
+    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
+        const BatchView v = view(slot, batch.size());
+        for (std::size_t i = 0; i < batch.size(); ++i) put(v, i, batch[i]);
+        put_state(slot);
     }
     void take_state(const symaccel_batch_slot &slot) {
         std::memcpy(overlap_.data(), slot.state[0], overlap_.size() * sizeof(float));
@@ -997,16 +1148,62 @@ struct Mp3Huffman {
     }
 
     static constexpr int kBatchKind = SYMACCEL_BATCH_MP3_DECODE;  // one stream per submission: exactly what this codec is
+    static constexpr bool kDirect = true;
     void attach(Batcher &) {}
     int batch_param() const { return sr_; }
     std::size_t units_per_packet() const { return ngr_; }
-    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
-        gather(batch, static_cast<std::int16_t *>(slot.input[0]), static_cast<symaccel_mp3_requant *>(slot.input[1]),
-               static_cast<symaccel_mp3_side *>(slot.input[2]), static_cast<symaccel_mp3_stereo *>(slot.input[3]));
-        if (nch_ != 2) std::memset(slot.input[3], 0, slot.input_bytes[3]);
+    struct BatchView {  // granule gr of packet i of channel c is unit i * ngr + gr of chain c; the stereo records are per granule of the STREAM
+        std::int16_t *quant = nullptr;
+        symaccel_mp3_requant *rq = nullptr;
+        symaccel_mp3_side *side = nullptr;
+        symaccel_mp3_stereo *stereo = nullptr;
+        std::size_t k = 0, nch = 0, ngr = 0;
+        std::size_t unit(std::size_t c, std::size_t i, std::size_t gr) const { return c * k * ngr + i * ngr + gr; }
+    };
+    BatchView view(const symaccel_batch_slot &slot, std::size_t k) const {
+        return BatchView{static_cast<std::int16_t *>(slot.input[0]), static_cast<symaccel_mp3_requant *>(slot.input[1]),
+                         static_cast<symaccel_mp3_side *>(slot.input[2]), static_cast<symaccel_mp3_stereo *>(slot.input[3]), k, nch_, ngr_};
+    }
+    void put(const BatchView &v, std::size_t i, const Packet &p) const {
+        if (p.quant.size() != ngr_ * nch_ * 576 || p.rq.size() != ngr_ * nch_ || p.side.size() != ngr_ * nch_ || p.stereo.size() != (nch_ == 2 ? ngr_ : 0))
+            throw std::invalid_argument("Mp3Huffman: packet shape");
+        for (std::size_t gr = 0; gr < ngr_; ++gr) {
+            for (std::size_t c = 0; c < nch_; ++c) {
+                const std::size_t dst = v.unit(c, i, gr);
+                std::copy_n(p.quant.data() + (gr * nch_ + c) * 576, 576, v.quant + dst * 576);
+                v.rq[dst] = p.rq[gr * nch_ + c];
+                v.side[dst] = p.side[gr * nch_ + c];
+            }
+            if (nch_ == 2) v.stereo[i * ngr_ + gr] = p.stereo[gr];
+            else std::memset(&v.stereo[i * ngr_ + gr], 0, sizeof(symaccel_mp3_stereo));
+        }
+    }
+    Packet extract(const BatchView &v, std::size_t i) const {
+        Packet p;
+        p.quant.resize(ngr_ * nch_ * 576);
+        p.rq.resize(ngr_ * nch_);
+        p.side.resize(ngr_ * nch_);
+        p.stereo.resize(nch_ == 2 ? ngr_ : 0);
+        for (std::size_t gr = 0; gr < ngr_; ++gr) {
+            for (std::size_t c = 0; c < nch_; ++c) {
+                const std::size_t src = v.unit(c, i, gr);
+                std::copy_n(v.quant + src * 576, 576, p.quant.data() + (gr * nch_ + c) * 576);
+                p.rq[gr * nch_ + c] = v.rq[src];
+                p.side[gr * nch_ + c] = v.side[src];
+            }
+            if (nch_ == 2) p.stereo[gr] = v.stereo[i * ngr_ + gr];
+        }
+        return p;
+    }
+    void put_state(const symaccel_batch_slot &slot) const {
         std::memcpy(slot.state[0], overlap_.data(), overlap_.size() * sizeof(float));
         std::memcpy(slot.state[1], vvec_.data(), vvec_.size() * sizeof(float));
         std::memcpy(slot.state[2], vfront_.data(), vfront_.size() * sizeof(std::int32_t));
+    }
+    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
+        const BatchView v = view(slot, batch.size());
+        for (std::size_t i = 0; i < batch.size(); ++i) put(v, i, batch[i]);
+        put_state(slot);
     }
     void take_state(const symaccel_batch_slot &slot) {
         std::memcpy(overlap_.data(), slot.state[0], overlap_.size() * sizeof(float));
@@ -1084,6 +1281,8 @@ struct Vorbis {
     // the cross-stream batcher's view: every chain's planes at their largest (k * bs1 / 2), the packed data at the front -- so that
     // streams with different block flags share a launch (SYMACCEL_BATCH_VORBIS_SYNTH)
     static constexpr int kBatchKind = SYMACCEL_BATCH_VORBIS_SYNTH;
+    static constexpr bool kDirect = false;  // (the packed layout depends on every packet's block flag)
+    struct BatchView {};
     void attach(Batcher &) {}
     int batch_param() const { return e0_ | (e1_ << 8); }
     std::size_t units_per_packet() const { return 1; }
@@ -1185,6 +1384,8 @@ struct Flac {
         if (p.channels == 0 || p.bits_per_sample == 0 || p.bits_per_sample > 32) throw std::invalid_argument("Flac: parameters");
     }
     static constexpr int kBatchKind = 0;  // (block sizes differ from stream to stream: batches per stream)
+    static constexpr bool kDirect = false;
+    struct BatchView {};
     void attach(Batcher &) {}
     static std::uint64_t id(const Packet &p) { return p.ts; }
     std::size_t channels() const { return nch_; }

@@ -32,6 +32,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "symaccel_internal.h"
@@ -265,9 +266,29 @@ struct TicketView {
 enum class GroupState { Free, Open, Closed, Launching, Launched };
 
 struct Lane;
+struct Group;
 
-// One launch: the submissions of one shape that were pending together.  Host side: the submissions' own slots.  Device side: one
-// allocation, cut at launch time (when the number of chains is known) and kept with the group object for the next launch it serves.
+// The device side of a launch: one allocation (cut into the planes of whatever group is launched with it), the page-locked copy
+// descriptors and lists, the events of the chunk pipeline.  Blocks are POOLED apart from the groups: a group stays around until the
+// last of its submissions is released -- the decoders hold their current batch for as long as they hand it out -- but the device
+// memory is free again as soon as the scatter has finished, so a handful of blocks serve any number of groups in flight.
+struct Block {
+    char *d_base = nullptr;
+    size_t d_bytes = 0;
+    char *h_desc = nullptr;
+    size_t h_desc_bytes = 0;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr};
+    // completion: a word of page-locked memory the launch's last kernel writes its sequence number into (batch_flag_kernel); the
+    // numbers of a block only grow, so "flag >= seq" stays true for a launch that has finished however often the block is reused
+    uint64_t *h_flag = nullptr;
+    uint64_t seq = 0;
+    Group *owner = nullptr;  // the group whose launch is (or was last) using it; nullptr: never used or given back
+};
+
+inline uint64_t read_flag(const uint64_t *flag) { return __atomic_load_n(flag, __ATOMIC_ACQUIRE); }
+
+// One launch: the submissions of one shape that were pending together.  Host side: the submissions' own slots.  Device side: a
+// Block, cut at launch time (when the number of chains is known).
 struct Group {
     int kind = 0, param = 0;
     size_t units = 0;
@@ -279,8 +300,10 @@ struct Group {
     std::vector<uint32_t> ticket_ids;  // the submissions, in order (index into symaccel_batcher::tickets)
     std::vector<TicketView> views;     // ... as the launch sees them
     Lane *lane = nullptr;              // where it was (is being) enqueued
-    char *d_base = nullptr;
-    size_t d_bytes = 0;
+    Block *block = nullptr;            // its device side, until somebody has seen the launch complete
+    bool completed = false;            // its launch has been seen complete (or failed and was drained): nothing of it is in flight
+    const uint64_t *done_flag = nullptr;  // where its launch reports completion, and the number that means "this launch"
+    uint64_t done_seq = 0;
     char *d_in[kMaxIn] = {}, *d_state_in[kMaxState] = {}, *d_state_out[kMaxState] = {}, *d_out = nullptr;
     int32_t *d_units = nullptr;  // MP3_DECODE: unit_chains of every chunk, relative to the chunk's first chain
     // AAC_DECODE: the group's pair list, joint-stereo rows, TNS filters, the pair frames that carry TNS, the walk's chain index
@@ -309,10 +332,6 @@ struct Group {
         size_t boff0, kill0, first0, steps0, n_steps;
         bool prepare;
     } vb_chunk{};
-    // page-locked: the copy descriptors of the launch (read by batch_copy_kernel straight from here) and the lists built at launch
-    char *h_desc = nullptr;
-    size_t h_desc_bytes = 0;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, done = nullptr;
 };
 
 // One pipeline: a context (kernel stream, scratch, tables) and two copy streams.  Lane 0 is the caller's context; the others are the
@@ -341,6 +360,7 @@ struct symaccel_batcher {
     size_t hint_bytes = 0;  // what a group must hold for a hint to launch it
     std::vector<std::unique_ptr<Lane>> lanes;
     size_t want_lanes = 2, next_lane = 0;
+    std::vector<std::unique_ptr<Block>> blocks;
     // page-locked slot memory: slabs, carved into slots by size class; a released slot goes to the free list of its class (the
     // shapes of a running service repeat: in the steady state nothing is allocated)
     struct Slab {
@@ -348,6 +368,8 @@ struct symaccel_batcher {
         size_t bytes, used;
     };
     std::vector<Slab> slabs;
+    uint64_t slots_live = 0;
+    bool growing = false;  // a caller is page-locking a new slab (outside the mutex): the others wait for it instead of adding their own
     std::vector<std::pair<size_t, std::vector<char *>>> free_slots;
     // AAC_DECODE: the scale-factor-band tables a stream's joint-stereo descriptors refer to, registered once per stream shape
     // (symaccel_batcher_aac_bands); a submission names its table by index (`param`), which is part of the group key
@@ -377,31 +399,53 @@ struct Locked {
     }
 };
 
-int slot_alloc(symaccel_batcher *b, size_t bytes, char **out) {
-    for (auto &cls : b->free_slots)
-        if (cls.first == bytes && !cls.second.empty()) {
-            *out = cls.second.back();
-            cls.second.pop_back();
-            return SYMACCEL_OK;
+// mu held on entry and on return; DROPPED while a new slab is page-locked (hipHostMalloc of tens of MiB takes milliseconds: held, it
+// stalled every other caller -- 1.1 to 1.6 s of summed mutex wait in a 0.4 s run, profiles/r06c_decoders.jsonl).  Slabs double in
+// size up to 128 MiB, so a service that grows does so in a few steps.
+int slot_alloc(symaccel_batcher *b, std::unique_lock<std::mutex> &lock, size_t bytes, char **out) {
+    for (;;) {
+        for (auto &cls : b->free_slots)
+            if (cls.first == bytes && !cls.second.empty()) {
+                *out = cls.second.back();
+                cls.second.pop_back();
+                return SYMACCEL_OK;
+            }
+        for (auto &sl : b->slabs)
+            if (sl.bytes - sl.used >= bytes) {
+                *out = sl.base + sl.used;
+                sl.used += bytes;
+                return SYMACCEL_OK;
+            }
+        if (b->growing) {  // somebody is page-locking a slab right now: its memory will do for this caller too
+            b->cv.wait(lock, [&] { return !b->growing; });
+            continue;
         }
-    for (auto &sl : b->slabs)
-        if (sl.bytes - sl.used >= bytes) {
-            *out = sl.base + sl.used;
-            sl.used += bytes;
-            return SYMACCEL_OK;
+        static const size_t slab0 = [] {  // (test knob: the first slab's size in KiB)
+            const char *e = std::getenv("SYMACCEL_BATCHER_SLAB_KB");
+            return e && std::atol(e) > 0 ? (size_t)std::atol(e) << 10 : kSlabBytes;
+        }();
+        size_t want = slab0;
+        if (!b->slabs.empty()) want = std::min<size_t>(4 * slab0, 2 * b->slabs.back().bytes);
+        want = std::max(want, bytes);
+        void *h = nullptr;
+        b->growing = true;
+        lock.unlock();
+        int st = SYMACCEL_OK;
+        {
+            DeviceGuard dev(b->ctx);
+            if (!dev.ok()) st = dev.status();
+            else if (hipHostMalloc(&h, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                st = SYMACCEL_ERR_OOM;
+            }
         }
-    const size_t want = std::max(kSlabBytes, bytes);
-    void *h = nullptr;
-    DeviceGuard dev(b->ctx);
-    if (!dev.ok()) return dev.status();
-    if (hipHostMalloc(&h, want, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        return SYMACCEL_ERR_OOM;
+        lock.lock();
+        b->growing = false;
+        b->cv.notify_all();
+        if (st != SYMACCEL_OK) return st;
+        b->slabs.push_back({static_cast<char *>(h), want, 0});
+        b->stats.staging_bytes += want;
     }
-    b->slabs.push_back({static_cast<char *>(h), want, bytes});
-    b->stats.staging_bytes += want;
-    *out = static_cast<char *>(h);
-    return SYMACCEL_OK;
 }
 
 void slot_free(symaccel_batcher *b, char *p, size_t bytes) {
@@ -414,13 +458,15 @@ void slot_free(symaccel_batcher *b, char *p, size_t bytes) {
     b->free_slots.push_back({bytes, {p}});
 }
 
-void group_free(Group *g) {
-    if (g->d_base) (void)hipFree(g->d_base);
-    if (g->h_desc) (void)hipHostFree(g->h_desc);
-    for (hipEvent_t e : {g->ev_in[0], g->ev_in[1], g->ev_k[0], g->ev_k[1], g->done})
+void block_free(Block *k) {
+    if (k->d_base) (void)hipFree(k->d_base);
+    if (k->h_desc) (void)hipHostFree(k->h_desc);
+    for (hipEvent_t e : {k->ev_in[0], k->ev_in[1], k->ev_k[0], k->ev_k[1]})
         if (e) (void)hipEventDestroy(e);
-    g->d_base = nullptr;
-    g->h_desc = nullptr;
+    if (k->h_flag) (void)hipHostFree(k->h_flag);
+    k->h_flag = nullptr;
+    k->d_base = nullptr;
+    k->h_desc = nullptr;
 }
 
 // Sizes of the lists a launch builds on the host (page-locked, behind the copy descriptors) and mirrors on the device
@@ -449,8 +495,9 @@ ListSizes list_sizes(const Group *g) {
 }
 
 // the device side of a closed group: sized for the chains it holds, planes carved out; grown (never shrunk) across reuses
-int group_device(symaccel_ctx *ctx, Group *g, size_t n_pieces_bound) {
+int group_device(symaccel_ctx *ctx, Group *g, size_t n_pieces_bound, uint64_t *n_allocs) {
     const PlaneSizes &ps = g->ps;
+    Block *blk = g->block;
     const ListSizes ls = list_sizes(g);
     size_t total = 0, off_in[kMaxIn] = {}, off_si[kMaxState], off_so[kMaxState], off_out = 0, off_units;
     for (int i = 0; i < ps.n_in; ++i) {
@@ -500,54 +547,63 @@ int group_device(symaccel_ctx *ctx, Group *g, size_t n_pieces_bound) {
         off_vs = total;
         total += ls.vb_steps;
     }
-    if (total > g->d_bytes) {
-        if (g->d_base) SYM_GPU(ctx, hipFree(g->d_base));
-        g->d_base = nullptr;
-        g->d_bytes = 0;
+    // (hipFree waits for the whole device, hipMalloc is not cheap either: a group's memory is sized for what the group can hold at
+    // most -- cap_chains, i.e. flush_bytes of input -- the first time, so that groups of fewer submissions never have to grow later;
+    // measured before: 0.87 ms of host time per launch with four caller threads, profiles/r06b_decoders.jsonl)
+    const size_t scale_num = std::max(g->cap_chains, g->chains), scale_den = std::max<size_t>(1, g->chains);
+    if (total > blk->d_bytes) {
+        if (blk->d_base) SYM_GPU(ctx, hipFree(blk->d_base));
+        blk->d_base = nullptr;
+        blk->d_bytes = 0;
         void *d = nullptr;
-        SYM_TRY(ctx_alloc(ctx, &d, total + total / 4, false));
-        g->d_base = static_cast<char *>(d);
-        g->d_bytes = total + total / 4;
+        const size_t want = std::max(total + total / 4, (total / scale_den + 1) * scale_num + ((size_t)1 << 20));
+        SYM_TRY(ctx_alloc(ctx, &d, want, false));
+        blk->d_base = static_cast<char *>(d);
+        blk->d_bytes = want;
+        *n_allocs += 1;
     }
-    for (int i = 0; i < ps.n_in; ++i) g->d_in[i] = g->d_base + off_in[i];
+    char *const d_base = blk->d_base;
+    for (int i = 0; i < ps.n_in; ++i) g->d_in[i] = d_base + off_in[i];
     for (int i = 0; i < ps.n_state; ++i) {
-        g->d_state_in[i] = g->d_base + off_si[i];
-        g->d_state_out[i] = g->d_base + off_so[i];
+        g->d_state_in[i] = d_base + off_si[i];
+        g->d_state_out[i] = d_base + off_so[i];
     }
-    g->d_out = ps.in_place ? g->d_in[0] : g->d_base + off_out;
-    g->d_units = reinterpret_cast<int32_t *>(g->d_base + off_units);
+    g->d_out = ps.in_place ? g->d_in[0] : d_base + off_out;
+    g->d_units = reinterpret_cast<int32_t *>(d_base + off_units);
     if (g->kind == SYMACCEL_BATCH_AAC_DECODE) {
-        g->d_aac_pairs = reinterpret_cast<int32_t *>(g->d_base + off_ap);
-        g->d_aac_js = reinterpret_cast<symaccel_aac_js_frame *>(g->d_base + off_aj);
-        g->d_aac_tns = reinterpret_cast<symaccel_aac_tns_filter *>(g->d_base + off_at);
-        g->d_aac_pf = reinterpret_cast<uint32_t *>(g->d_base + off_af);
-        g->d_aac_index = g->d_base + off_ai;
+        g->d_aac_pairs = reinterpret_cast<int32_t *>(d_base + off_ap);
+        g->d_aac_js = reinterpret_cast<symaccel_aac_js_frame *>(d_base + off_aj);
+        g->d_aac_tns = reinterpret_cast<symaccel_aac_tns_filter *>(d_base + off_at);
+        g->d_aac_pf = reinterpret_cast<uint32_t *>(d_base + off_af);
+        g->d_aac_index = d_base + off_ai;
     }
     if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) {
-        g->d_vb_plane = reinterpret_cast<uint8_t *>(g->d_base + off_vp);
-        g->d_vb_ys = reinterpret_cast<uint32_t *>(g->d_base + off_vy);
-        g->d_vb_offs = reinterpret_cast<uint32_t *>(g->d_base + off_vo);
-        g->d_vb_boff = reinterpret_cast<uint32_t *>(g->d_base + off_vb);
-        g->d_vb_kill = reinterpret_cast<uint8_t *>(g->d_base + off_vk);
-        g->d_vb_first = reinterpret_cast<uint32_t *>(g->d_base + off_vf);
-        g->d_vb_steps = reinterpret_cast<uint8_t *>(g->d_base + off_vs);
+        g->d_vb_plane = reinterpret_cast<uint8_t *>(d_base + off_vp);
+        g->d_vb_ys = reinterpret_cast<uint32_t *>(d_base + off_vy);
+        g->d_vb_offs = reinterpret_cast<uint32_t *>(d_base + off_vo);
+        g->d_vb_boff = reinterpret_cast<uint32_t *>(d_base + off_vb);
+        g->d_vb_kill = reinterpret_cast<uint8_t *>(d_base + off_vk);
+        g->d_vb_first = reinterpret_cast<uint32_t *>(d_base + off_vf);
+        g->d_vb_steps = reinterpret_cast<uint8_t *>(d_base + off_vs);
     }
     // (behind the descriptors: the lists of list_sizes())
     const size_t desc_bytes = round256(n_pieces_bound * sizeof(BatchCopyDesc)) + ls.units + ls.aac_pairs + ls.aac_tns + ls.aac_pf + ls.vb_boff +
                               ls.vb_kill + ls.vb_first + ls.vb_steps + ls.vb_ys + ls.vb_offs;
-    if (desc_bytes > g->h_desc_bytes) {
-        if (g->h_desc) (void)hipHostFree(g->h_desc);
-        g->h_desc = nullptr;
-        g->h_desc_bytes = 0;
+    if (desc_bytes > blk->h_desc_bytes) {
+        if (blk->h_desc) (void)hipHostFree(blk->h_desc);
+        blk->h_desc = nullptr;
+        blk->h_desc_bytes = 0;
         void *h = nullptr;
-        if (hipHostMalloc(&h, desc_bytes + desc_bytes / 4, hipHostMallocDefault) != hipSuccess) {
+        const size_t want = std::max(desc_bytes + desc_bytes / 4, (desc_bytes / scale_den + 1) * scale_num + 65536);
+        if (hipHostMalloc(&h, want, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             return SYMACCEL_ERR_OOM;
         }
-        g->h_desc = static_cast<char *>(h);
-        g->h_desc_bytes = desc_bytes + desc_bytes / 4;
+        blk->h_desc = static_cast<char *>(h);
+        blk->h_desc_bytes = want;
+        *n_allocs += 1;
     }
-    for (hipEvent_t *e : {&g->ev_in[0], &g->ev_in[1], &g->ev_k[0], &g->ev_k[1], &g->done})
+    for (hipEvent_t *e : {&blk->ev_in[0], &blk->ev_in[1], &blk->ev_k[0], &blk->ev_k[1]})
         if (!*e) SYM_GPU(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     return SYMACCEL_OK;
 }
@@ -736,7 +792,7 @@ int check_vorbis(const Group *g, const TicketView &v, size_t *steps) {
 // Everything of a closed group: per chunk of submissions ONE gather launch (slots -> HBM, the kernels' chain-major layout), the
 // synthesis kernel(s), ONE scatter launch (HBM -> slots); `done` is recorded behind the last scatter.  Runs on `lane`, outside the
 // batcher's mutex: nothing of the batcher but the group itself (and the slots its views point at) is touched.
-int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks) {
+int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_ns, uint64_t *n_allocs) {
     symaccel_ctx *ctx = lane->ctx;
     const PlaneSizes &ps = g->ps;
     if (!ctx->stage_in) SYM_GPU(ctx, hipStreamCreate(&ctx->stage_in));
@@ -782,10 +838,11 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks) {
         bound += 6 * (g->tickets + 8) + pieces_of(ls.vb_boff) + pieces_of(ls.vb_kill) + pieces_of(ls.vb_first) + pieces_of(ls.vb_steps) + pieces_of(ls.vb_ys) +
                  pieces_of(ls.vb_offs);
     }
-    SYM_TRY(group_device(ctx, g, bound));
+    SYM_TRY(group_device(ctx, g, bound, n_allocs));
     const ListSizes ls = list_sizes(g);
-    BatchCopyDesc *descs = reinterpret_cast<BatchCopyDesc *>(g->h_desc);
-    char *lists = g->h_desc + round256(bound * sizeof(BatchCopyDesc));
+    Block *blk = g->block;
+    BatchCopyDesc *descs = reinterpret_cast<BatchCopyDesc *>(blk->h_desc);
+    char *lists = blk->h_desc + round256(bound * sizeof(BatchCopyDesc));
     auto carve = [&](size_t bytes) {
         char *p = lists;
         lists += bytes;
@@ -806,6 +863,24 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks) {
     uint32_t *h_offs = reinterpret_cast<uint32_t *>(carve(ls.vb_offs));
     size_t vb_first_at = 0, vb_steps_at = 0, vb_ys_at = 0, vb_offs_at = 0;
     BatchCopyDesc *w = descs;
+    // A bulk plane (a submission's spectra, its PCM) of `dma_bytes` or more goes through a copy ENGINE (hipMemcpyAsync on the lane's copy
+    // stream) instead of the piece list: the engines move large PCIe payloads, a kernel's 64-byte accesses pay a header per 64 bytes
+    // in both directions -- two kernels copying against each other reached 30 + 30 GB/s, the engines 44 + 44 (profiles/r06d_*).  The
+    // small planes of a chunk (records, state, lists) still share ONE gather / scatter launch.
+    struct Dma {
+        const char *src;
+        char *dst;
+        size_t bytes;
+    };
+    std::vector<Dma> dma;
+    static const size_t dma_bytes = [] {  // development knob: SYMACCEL_BATCH_DMA_KB (0 = everything through the copy kernels)
+        const char *e = std::getenv("SYMACCEL_BATCH_DMA_KB");
+        return e ? (size_t)std::atol(e) << 10 : (size_t)0;
+    }();
+    auto bulk = [&](const char *src, char *dst, size_t bytes) {
+        if (dma_bytes && bytes >= dma_bytes) dma.push_back({src, dst, bytes});
+        else add_pieces(w, src, dst, bytes);
+    };
     const size_t per_chain = std::max<size_t>(1, in_bytes_per_chain(ps));
     // a third of the group per chunk, 8 .. 32 MiB of input: a chunk costs three launches and two event hops (~40 us), which 2 MiB
     // chunks (44 us on the link) did not amortise -- 22.7 GB/s each way at look-ahead 64 against 37.9 at 256 (profiles/r05c_*);
@@ -862,11 +937,11 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks) {
                         size_t lines, samples;
                         vorbis_used(reinterpret_cast<const uint8_t *>(t.slot + l.in[1]) + c * g->units, g->units,
                                     reinterpret_cast<const int32_t *>(t.slot + l.state[0])[c], g->param & 255, (g->param >> 8) & 255, &lines, &samples);
-                        add_pieces(w, t.slot + l.in[0] + c * ps.in[0], g->d_in[0] + ((size_t)t.first_chain + c) * ps.in[0], lines * 4);
+                        bulk(t.slot + l.in[0] + c * ps.in[0], g->d_in[0] + ((size_t)t.first_chain + c) * ps.in[0], lines * 4);
                     }
                     continue;
                 }
-                add_pieces(w, t.slot + l.in[i], g->d_in[i] + (ps.in_per_ticket[i] ? ti : (size_t)t.first_chain / ps.in_div[i]) * ps.in[i], l.in_bytes[i]);
+                bulk(t.slot + l.in[i], g->d_in[i] + (ps.in_per_ticket[i] ? ti : (size_t)t.first_chain / ps.in_div[i]) * ps.in[i], l.in_bytes[i]);
             }
             for (int i = 0; i < ps.n_state; ++i)
                 add_pieces(w, t.slot + l.state[i], g->d_state_in[i] + (size_t)t.first_chain * ps.state[i], l.state_bytes[i]);
@@ -976,12 +1051,16 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks) {
             vb_first_at += nt * nb + 1;
             vb_steps_at += ch.n_steps;
         }
+        const Clock::time_point api0 = Clock::now();
+        for (const Dma &m : dma) SYM_GPU(ctx, hipMemcpyAsync(m.dst, m.src, m.bytes, hipMemcpyHostToDevice, s_in));
+        dma.clear();
         SYM_TRY(launch_batch_copy(ctx, s_in, g0, (size_t)(w - g0)));
-        SYM_GPU(ctx, hipEventRecord(g->ev_in[e], s_in));
-        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, g->ev_in[e], 0));
+        SYM_GPU(ctx, hipEventRecord(blk->ev_in[e], s_in));
+        SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, blk->ev_in[e], 0));
         SYM_TRY(launch_chunk(ctx, g, c0, nc, t0, nt));
-        SYM_GPU(ctx, hipEventRecord(g->ev_k[e], ctx->stream));
-        SYM_GPU(ctx, hipStreamWaitEvent(s_out, g->ev_k[e], 0));
+        SYM_GPU(ctx, hipEventRecord(blk->ev_k[e], ctx->stream));
+        SYM_GPU(ctx, hipStreamWaitEvent(s_out, blk->ev_k[e], 0));
+        *api_ns += ns_since(api0);
         // ---- scatter: PCM and the state after the batch back into the submissions' slots
         BatchCopyDesc *s0 = w;
         for (size_t ti = t0; ti < t1; ++ti) {
@@ -994,20 +1073,63 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks) {
                     size_t lines, samples;
                     vorbis_used(reinterpret_cast<const uint8_t *>(t.slot + l.in[1]) + c * g->units, g->units,
                                 reinterpret_cast<const int32_t *>(t.slot + l.state[0])[c], g->param & 255, (g->param >> 8) & 255, &lines, &samples);
-                    add_pieces(w, g->d_out + ((size_t)t.first_chain + c) * ps.out, t.slot + l.out + c * ps.out, samples * 4);
+                    bulk(g->d_out + ((size_t)t.first_chain + c) * ps.out, t.slot + l.out + c * ps.out, samples * 4);
                 }
             } else {
-                add_pieces(w, g->d_out + (size_t)t.first_chain * (ps.in_place ? ps.in[0] : ps.out), t.slot + l.out, l.out_bytes);
+                bulk(g->d_out + (size_t)t.first_chain * (ps.in_place ? ps.in[0] : ps.out), t.slot + l.out, l.out_bytes);
             }
             for (int i = 0; i < ps.n_state; ++i)
                 add_pieces(w, g->d_state_out[i] + (size_t)t.first_chain * ps.state[i], t.slot + l.state[i], l.state_bytes[i]);
         }
+        const Clock::time_point api1 = Clock::now();
+        for (const Dma &m : dma) SYM_GPU(ctx, hipMemcpyAsync(m.dst, m.src, m.bytes, hipMemcpyDeviceToHost, s_out));
+        dma.clear();
         SYM_TRY(launch_batch_copy(ctx, s_out, s0, (size_t)(w - s0)));
+        *api_ns += ns_since(api1);
         *n_chunks += 1;
         t0 = t1;
         ++k;
     }
     return SYMACCEL_OK;
+}
+
+// the device side of a closing group (mu held): a block nobody is using -- never used, given back, or whose last launch is seen
+// complete now (its owner then needs it no more) --, else a new one (its memory is allocated by the launch, outside the mutex)
+Block *pick_block(symaccel_batcher *b, Group *g) {
+    Block *found = nullptr;
+    for (auto &up : b->blocks) {
+        Block *k = up.get();
+        if (k->owner == nullptr) {
+            found = k;
+            break;
+        }
+        Group *o = k->owner;
+        if (o->state == GroupState::Launched && (o->completed || read_flag(k->h_flag) >= k->seq)) {  // (a read of host memory: no runtime call)
+            o->completed = true;
+            o->block = nullptr;
+            found = k;
+            break;
+        }
+    }
+    if (!found) {
+        void *h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        std::memset(h, 0, 64);
+        b->blocks.emplace_back(new Block());
+        found = b->blocks.back().get();
+        found->h_flag = static_cast<uint64_t *>(h);
+        b->stats.blocks = b->blocks.size();
+    }
+    found->owner = g;
+    found->seq += 1;
+    g->block = found;
+    g->completed = false;
+    g->done_flag = found->h_flag;
+    g->done_seq = found->seq;
+    return found;
 }
 
 // the lane a closing group goes to (mu held): round robin over the lanes that exist; the second and later ones are made on demand
@@ -1045,7 +1167,7 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
     b->cv.wait(lock, [&] { return g->uncommitted == 0; });
     if (g->state != GroupState::Closed) return;
     int st = SYMACCEL_OK;
-    uint64_t chunks = 0, host_ns = 0, lane_ns = 0;
+    uint64_t chunks = 0, host_ns = 0, lane_ns = 0, api_ns = 0, allocs = 0;
     std::string err;
     if (g->tickets) {
         // what the launch needs of the batcher, copied while the mutex is still ours
@@ -1058,6 +1180,14 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
         if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) g->vb_floors = b->floors;
         Lane *lane = pick_lane(b);
         g->lane = lane;
+        if (!pick_block(b, g)) {  // (no page-locked word for a new block's completion flag)
+            for (size_t i = 0; i < g->tickets; ++i) b->tickets[g->ticket_ids[i]].status = SYMACCEL_ERR_OOM;
+            g->status = SYMACCEL_ERR_OOM;
+            g->completed = true;
+            g->state = GroupState::Launched;
+            b->cv.notify_all();
+            return;
+        }
         g->state = GroupState::Launching;
         lock.unlock();
         {
@@ -1066,7 +1196,7 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
             lane_ns = ns_since(t0);
             const Clock::time_point t1 = Clock::now();
             DeviceGuard dev(lane->ctx);
-            st = dev.ok() ? launch_group_inner(lane, g, &chunks) : dev.status();
+            st = dev.ok() ? launch_group_inner(lane, g, &chunks, &api_ns, &allocs) : dev.status();
             if (st != SYMACCEL_OK) {
                 // a launch that failed half way: nothing of this group may still be in flight when its slots are reused, and the
                 // copy-out stream does not follow what the other two were left with -- drain all three (error path only)
@@ -1075,12 +1205,19 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
                 if (lane->ctx->stream) (void)hipStreamSynchronize(lane->ctx->stream);
                 if (lane->ctx->stage_out) (void)hipStreamSynchronize(lane->ctx->stage_out);
             }
-            // `done` sits behind the last scatter, which follows the last kernel, which follows the last gather
-            if (dev.ok() && lane->ctx->stage_out && g->done) (void)hipEventRecord(g->done, lane->ctx->stage_out);
+            // the completion flag is written behind the last scatter, which follows the last kernel, which follows the last gather
+            if (st == SYMACCEL_OK) st = launch_batch_flag(lane->ctx, lane->ctx->stage_out, g->block->h_flag, g->done_seq);
+            if (st != SYMACCEL_OK && err.empty()) {
+                err = lane->ctx->last_error;
+                if (lane->ctx->stage_out) (void)hipStreamSynchronize(lane->ctx->stage_out);
+            }
             host_ns = ns_since(t1);
         }
         lock.lock();
-        if (st != SYMACCEL_OK) b->last_error = err;
+        if (st != SYMACCEL_OK) {
+            b->last_error = err;
+            g->completed = true;  // (the lane's streams were drained)
+        }
         for (size_t i = 0; i < g->tickets; ++i) {
             Ticket &t = b->tickets[g->ticket_ids[i]];
             t.status = st != SYMACCEL_OK ? st : g->views[i].status;
@@ -1092,6 +1229,8 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
     b->stats.launches += 1;
     b->stats.chunks += chunks;
     b->stats.launch_host_ns += host_ns;
+    b->stats.launch_api_ns += api_ns;
+    b->stats.group_allocs += allocs;
     b->stats.lane_wait_ns += lane_ns;
     b->stats.chains_launched += g->chains;
     b->stats.max_chains_per_launch = std::max<uint64_t>(b->stats.max_chains_per_launch, g->chains);
@@ -1103,7 +1242,7 @@ Group *open_group(symaccel_batcher *b, int kind, int param, size_t units, const 
     for (auto &up : b->groups) {
         Group *g = up.get();
         if (g->state == GroupState::Open && g->kind == kind && g->param == param && g->units == units) return g;
-        if (g->state == GroupState::Free && (!spare || g->d_bytes > spare->d_bytes)) spare = g;  // (the one with the most device memory)
+        if (g->state == GroupState::Free && !spare) spare = g;
     }
     if (!spare) {
         b->groups.emplace_back(new Group());
@@ -1119,6 +1258,9 @@ Group *open_group(symaccel_batcher *b, int kind, int param, size_t units, const 
     g->chains = g->tickets = g->uncommitted = g->live = 0;
     g->ticket_ids.clear();
     g->status = SYMACCEL_OK;
+    g->block = nullptr;
+    g->completed = false;
+    g->lane = nullptr;
     g->state = GroupState::Open;
     return g;
 }
@@ -1145,19 +1287,40 @@ void fill_slot(const Group *g, const Ticket *t, symaccel_batch_slot *slot) {
     slot->out_bytes = l.out_bytes;
 }
 
-// wait for the `done` event of a launched group (no mutex held); a failure is the batcher's to remember
+// Wait until nothing of a launched group is in flight (no mutex held).  The launch's last kernel writes the group's sequence number
+// into a word of page-locked memory: the waiter reads that word -- spinning briefly, then yielding, then sleeping in steps of 20 us
+// -- and calls nothing in the runtime.  A word that never arrives (a hung or lost device) is a device error after `kFlagTimeout`.
+constexpr double kFlagTimeout = 60.0;
 int sync_done(symaccel_batcher *b, Group *g) {
-    if (!g->tickets || !g->done || !g->lane) return SYMACCEL_OK;
-    hipError_t e;
+    const uint64_t *flag;
+    uint64_t seq;
     {
-        DeviceGuard dev(g->lane->ctx);
-        if (!dev.ok()) return dev.status();
-        e = hipEventSynchronize(g->done);
+        Locked l(b);
+        if (!g->tickets || g->completed || !g->done_flag) return SYMACCEL_OK;
+        flag = g->done_flag;
+        seq = g->done_seq;
     }
-    if (e == hipSuccess) return SYMACCEL_OK;
+    const Clock::time_point t0 = Clock::now();
+    for (unsigned spins = 0; read_flag(flag) < seq; ++spins) {
+        if (spins < 2000) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        } else if (spins < 4000) {
+            std::this_thread::yield();
+        } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if ((spins & 1023) == 0 && std::chrono::duration<double>(Clock::now() - t0).count() > kFlagTimeout) {
+                Locked l(b);
+                b->last_error = "the completion flag of a batch never arrived";
+                return SYMACCEL_ERR_DEVICE;
+            }
+        }
+    }
     Locked l(b);
-    b->last_error = std::string("hipEventSynchronize(batch done): ") + hipGetErrorString(e);
-    return SYMACCEL_ERR_DEVICE;
+    g->completed = true;
+    b->stats.flag_wait_ns += ns_since(t0);
+    return SYMACCEL_OK;
 }
 
 }  // namespace
@@ -1199,7 +1362,7 @@ int symaccel_batcher_destroy(symaccel_batcher *b) {
             if (ln->ctx->stream) (void)hipStreamSynchronize(ln->ctx->stream);
             if (ln->ctx->stage_out) (void)hipStreamSynchronize(ln->ctx->stage_out);
         }
-        for (auto &g : b->groups) group_free(g.get());
+        for (auto &k : b->blocks) block_free(k.get());
         for (auto &sl : b->slabs) (void)hipHostFree(sl.base);
     }
     for (auto &ln : b->lanes)
@@ -1222,6 +1385,11 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
     Locked locked(b);
     std::unique_lock<std::mutex> &lock = locked.lock;
     if (kind == SYMACCEL_BATCH_AAC_DECODE && (param < 0 || (size_t)param >= b->bands.size())) return SYMACCEL_ERR_INVALID_ARG;  // (symaccel_batcher_aac_bands first)
+    // the slot first: page-locking a new slab drops the mutex, and the group must be chosen in one piece with the reservation
+    const SlotLayout lay = slot_layout(ps, n_chains);
+    const size_t cls = slot_class(lay.bytes);
+    char *mem = nullptr;
+    SYM_TRY(slot_alloc(b, lock, cls, &mem));
     Group *g = open_group(b, kind, param, units_per_chain, ps, n_chains);
     while (g->chains + n_chains > g->cap_chains && g->tickets) {  // full: it goes, a fresh one opens (or one somebody else opened meanwhile)
         flush_group(b, g, lock);
@@ -1234,15 +1402,6 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
     } else {
         idx = (uint32_t)b->tickets.size();
         b->tickets.emplace_back();
-    }
-    const SlotLayout lay = slot_layout(ps, n_chains);
-    const size_t cls = slot_class(lay.bytes);
-    char *mem = nullptr;
-    const int st = slot_alloc(b, cls, &mem);
-    if (st != SYMACCEL_OK) {
-        b->free_tickets.push_back(idx);
-        if (g->tickets == 0) g->state = GroupState::Free;  // (opened for this reservation alone: nobody would ever launch it)
-        return st;
     }
     Ticket *t = &b->tickets[idx];
     const uint32_t gen = t->gen + 1;
@@ -1261,6 +1420,8 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
     g->uncommitted += 1;
     g->live += 1;
     b->stats.submissions += 1;
+    b->slots_live += 1;
+    b->stats.slots_peak = std::max<uint64_t>(b->stats.slots_peak, b->slots_live);
     fill_slot(g, t, slot);
     *ticket = ((uint64_t)gen << 32) | idx;
     return SYMACCEL_OK;
@@ -1358,7 +1519,7 @@ int symaccel_batcher_release(symaccel_batcher *b, uint64_t ticket) {
     // finds the event signalled.)
     if (g->state == GroupState::Open) flush_group(b, g, lock);
     b->cv.wait(lock, [&] { return g->state == GroupState::Launched; });
-    if (g->tickets && g->done) {
+    if (g->tickets && !g->completed) {
         lock.unlock();
         (void)sync_done(b, g);
         lock.lock();
@@ -1366,11 +1527,17 @@ int symaccel_batcher_release(symaccel_batcher *b, uint64_t ticket) {
     t = find_ticket(b, ticket);  // (the table may have grown while the lock was dropped)
     if (!t) return SYMACCEL_ERR_INVALID_ARG;
     slot_free(b, t->slot, t->slot_bytes);
+    b->slots_live -= 1;
     t->slot = nullptr;
     t->live = false;
     b->free_tickets.push_back((uint32_t)(ticket & 0xffffffffu));
     g->live -= 1;
-    if (g->live == 0 && g->state == GroupState::Launched) g->state = GroupState::Free;
+    if (g->live == 0 && g->state == GroupState::Launched) {
+        // (every submission was drained before it was released: the launch is complete, its block serves the next one)
+        if (g->block && g->block->owner == g) g->block->owner = nullptr;
+        g->block = nullptr;
+        g->state = GroupState::Free;
+    }
     return SYMACCEL_OK;
 }
 

@@ -441,7 +441,7 @@ static void test_aac_coded(Context &ctx, size_t lookahead, Batcher *batcher = nu
 
 // ---- many streams, one batcher: S AAC decoders called round-robin like a server's worker would; every buffer equals the
 // frame-by-frame decoder's, and the batcher ran far fewer launches than the decoders ran batches
-static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead) {
+static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead, bool direct = false) {
     const size_t n = 37;
     Batcher batcher(ctx);
     struct Stream {
@@ -456,10 +456,29 @@ static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead) 
         Stream *st = streams.back().get();
         st->nch = 1 + s % 2;
         st->track = aac_track(n, st->nch, 900 + (unsigned)s);
-        st->dec.reset(new LookaheadDecoder<AacLc>(batcher, AacLc::Params{st->nch}, lookahead, [st]() -> std::optional<AacLc::Packet> {
-            if (st->cursor >= st->track.size()) return std::nullopt;
-            return st->track[st->cursor++];
-        }));
+        if (direct) {
+            // zero-copy parse (LookaheadDecoder::Direct): the "parser" writes packet by packet into the batcher's slot.  Every third
+            // stream's demuxer announces three packets more than it has: those batches end short and are re-packed.
+            LookaheadDecoder<AacLc>::Direct d;
+            const size_t lie = s % 3 == 2 ? 3 : 0;
+            d.avail = [st, lie]() { return st->track.size() - std::min(st->track.size(), st->cursor) + lie; };
+            d.parse_into = [st](const AacLc::BatchView &v, size_t i) -> std::optional<std::uint64_t> {
+                if (st->cursor >= st->track.size()) return std::nullopt;
+                const AacLc::Packet &p = st->track[st->cursor];
+                for (size_t c = 0; c < st->nch; ++c) {
+                    std::memcpy(v.coeffs_at(c, i), p.coeffs.data() + c * 1024, 4096);
+                    v.side_at(c, i) = p.side[c];
+                }
+                ++st->cursor;
+                return p.ts;
+            };
+            st->dec.reset(new LookaheadDecoder<AacLc>(batcher, AacLc::Params{st->nch}, lookahead, d));
+        } else {
+            st->dec.reset(new LookaheadDecoder<AacLc>(batcher, AacLc::Params{st->nch}, lookahead, [st]() -> std::optional<AacLc::Packet> {
+                if (st->cursor >= st->track.size()) return std::nullopt;
+                return st->track[st->cursor++];
+            }));
+        }
         st->ref.reset(new AacOracle(st->nch));
     }
     size_t batches = 0;
@@ -478,7 +497,7 @@ static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead) 
     if (lookahead >= 4 && n_streams >= 4)
         EXPECT(stats.launches * 2 <= stats.submissions, "the batcher did not coalesce: %llu launches for %llu submissions", (unsigned long long)stats.launches,
                (unsigned long long)stats.submissions);
-    std::printf("cross-stream S=%zu K=%zu: %llu submissions in %llu launches (largest: %llu chains)\n", n_streams, lookahead,
+    std::printf("cross-stream%s S=%zu K=%zu: %llu submissions in %llu launches (largest: %llu chains)\n", direct ? " (direct)" : "", n_streams, lookahead,
                 (unsigned long long)stats.submissions, (unsigned long long)stats.launches, (unsigned long long)stats.max_chains_per_launch);
     streams.clear();  // (decoders release their tickets before the batcher goes)
 }
@@ -517,6 +536,8 @@ int main(int argc, char **argv) {
     test_cross_stream(ctx, 1, 8);
     test_cross_stream(ctx, 7, 8);
     test_cross_stream(ctx, 16, 3);
+    test_cross_stream(ctx, 7, 8, true);
+    test_cross_stream(ctx, 16, 5, true);
     if (g_failures == 0) std::printf("all checks passed\n");
     return g_failures ? 1 : 0;
 }

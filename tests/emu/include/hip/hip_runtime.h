@@ -91,6 +91,7 @@ static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
@@ -124,6 +125,8 @@ static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
 static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
 #define __builtin_amdgcn_fence(order, ...) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
 // A real rendezvous of the wavefront's work-items: the hardware runs them in lock step, the emulation
 // runs them one after the other, so every point where the kernel relies on lock step must synchronise.

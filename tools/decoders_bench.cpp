@@ -9,7 +9,7 @@
 // peek that copies the next packet out of a small pool (a parser writes its output somewhere too).  Nothing here links the
 // oracle: bench.py times the CPU port beside this with its own harness.  One JSON line on stdout.
 //
-//   decoders_bench --codec aac|aacd|mp3|mp3h|vorbis --streams S --lookahead L --packets P --threads T [--per-stream] [--flush-mb M]
+//   decoders_bench --codec aac|aacd|mp3|mp3h|vorbis --streams S --lookahead L --packets P --threads T [--per-stream] [--direct] [--in-phase] [--flush-mb M] [--lanes N]
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -32,8 +32,8 @@ namespace {
 
 struct Args {
     std::string codec = "aac";
-    size_t streams = 64, lookahead = 64, packets = 512, threads = 1, flush_mb = 0, warm = 0;
-    bool per_stream = false;
+    size_t streams = 64, lookahead = 64, packets = 512, threads = 1, flush_mb = 0, warm = 0, lanes = 0;
+    bool per_stream = false, direct = false, in_phase = false;
 };
 
 constexpr size_t kPool = 32;
@@ -144,6 +144,38 @@ std::vector<AacLcCoded::Packet> make_pool<AacLcCoded>(unsigned seed) {  // long 
     return pool;
 }
 
+// --direct: the "parser" writes the next packet straight into the batcher's slot (LookaheadDecoder::Direct) -- one copy of the
+// parsed packet (pool -> slot) instead of two (pool -> Packet -> slot)
+template <class Codec>
+void parse_into(const typename Codec::BatchView &, std::size_t, const typename Codec::Packet &) {}
+template <>
+void parse_into<AacLc>(const AacLc::BatchView &v, std::size_t i, const AacLc::Packet &p) {
+    for (size_t c = 0; c < v.nch; ++c) {
+        std::memcpy(v.coeffs_at(c, i), p.coeffs.data() + c * 1024, 4096);
+        v.side_at(c, i) = p.side[c];
+    }
+}
+template <>
+void parse_into<Mp3>(const Mp3::BatchView &v, std::size_t i, const Mp3::Packet &p) {
+    for (size_t gr = 0; gr < v.ngr; ++gr)
+        for (size_t c = 0; c < v.nch; ++c) {
+            std::memcpy(v.xr + v.unit(c, i, gr) * 576, p.xr.data() + (gr * v.nch + c) * 576, 2304);
+            v.side[v.unit(c, i, gr)] = p.side[gr * v.nch + c];
+        }
+}
+template <>
+void parse_into<Mp3Huffman>(const Mp3Huffman::BatchView &v, std::size_t i, const Mp3Huffman::Packet &p) {
+    for (size_t gr = 0; gr < v.ngr; ++gr) {
+        for (size_t c = 0; c < v.nch; ++c) {
+            const size_t dst = v.unit(c, i, gr);
+            std::memcpy(v.quant + dst * 576, p.quant.data() + (gr * v.nch + c) * 576, 1152);
+            v.rq[dst] = p.rq[gr * v.nch + c];
+            v.side[dst] = p.side[gr * v.nch + c];
+        }
+        v.stereo[i * v.ngr + gr] = p.stereo[gr];
+    }
+}
+
 template <class Codec>
 typename Codec::Params params();
 template <>
@@ -170,9 +202,10 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
     Context ctx(0);
     std::unique_ptr<Batcher> batcher;
     if (!a.per_stream) batcher.reset(new Batcher(ctx, a.flush_mb << 20));
+    if (batcher && a.lanes) check(symaccel_batcher_configure(batcher->raw(), (int)a.lanes, 0), ctx.raw());
     const std::vector<Packet> pool = make_pool<Codec>(17);
     struct Stream {
-        size_t cursor = 0, limit = 0, salt = 0;
+        size_t cursor = 0, limit = 0, salt = 0, pos = 0, lead = 0;
         std::unique_ptr<Decoder> dec;
     };
     std::vector<std::unique_ptr<Stream>> streams(a.streams);
@@ -181,14 +214,31 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
         streams[s].reset(new Stream());
         Stream *st = streams[s].get();
         st->salt = s * 7;
-        st->limit = total;
+        // streams do not start together in a service: stream s of a thread's S / T streams is (s / T) * L / (S / T) packets ahead of the
+        // first, so that the batches of a thread's streams end at different times (--in-phase: every stream at the same packet)
+        const size_t per_thread = std::max<size_t>(1, (a.streams + std::min(a.threads, a.streams) - 1) / std::min(a.threads, a.streams));
+        st->lead = a.in_phase ? 0 : (s / std::min(a.threads, a.streams)) * a.lookahead / per_thread;
+        st->limit = total + st->lead + 2 * a.lookahead;  // (no stream ends inside the timed region: a tail batch is a shape of its own)
         auto peek = [st, &pool]() -> std::optional<Packet> {
             if (st->cursor >= st->limit) return std::nullopt;
             Packet p = pool[(st->cursor + st->salt) % kPool];  // (the copy a parser's output costs)
             p.ts = st->cursor++;
             return p;
         };
-        if (batcher)
+        if (batcher && a.direct) {
+            if constexpr (Codec::kDirect) {
+                typename Decoder::Direct d;
+                d.avail = [st]() { return st->limit - std::min(st->limit, st->cursor); };
+                d.parse_into = [st, &pool](const typename Codec::BatchView &v, size_t i) -> std::optional<uint64_t> {
+                    if (st->cursor >= st->limit) return std::nullopt;
+                    parse_into<Codec>(v, i, pool[(st->cursor + st->salt) % kPool]);
+                    return st->cursor++;
+                };
+                st->dec.reset(new Decoder(*batcher, params<Codec>(), a.lookahead, d));
+            } else {
+                throw std::invalid_argument("--direct: this codec's layout depends on the packets (use the peek form)");
+            }
+        } else if (batcher)
             st->dec.reset(new Decoder(*batcher, params<Codec>(), a.lookahead, peek));
         else
             st->dec.reset(new Decoder(ctx, params<Codec>(), a.lookahead, peek));
@@ -199,16 +249,18 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
     // What decode() is handed: in the warm-up the parsed packet in full (a cold decoder transforms it at once); afterwards only its
     // identity -- the trait's packet carries the COMPRESSED bytes, and a packet the look-ahead has already parsed is not parsed
     // again (a decoder that did need the content here fails with "packet shape" and is counted in `failures`).
-    auto phase = [&](size_t first, size_t count, bool full) {
+    auto phase = [&](size_t first, size_t count, bool full, bool lead) {
         std::vector<std::thread> ths;
         const size_t T = std::min(a.threads, a.streams);
         for (size_t t = 0; t < T; ++t)
             ths.emplace_back([&, t]() {
                 uint64_t acc = 0;
                 try {
-                    for (size_t i = first; i < first + count; ++i)
+                    for (size_t step = first; step < first + count + (lead ? a.lookahead : 0); ++step)
                         for (size_t s = t; s < a.streams; s += T) {
                             Stream &st = *streams[s];
+                            if (lead && step >= first + count + st.lead) continue;  // (the warm-up runs stream s `lead` packets further)
+                            const size_t i = st.pos++;
                             Packet p;
                             if (full) p = pool[(i + st.salt) % kPool];
                             p.ts = i;
@@ -235,11 +287,11 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
             });
         for (auto &th : ths) th.join();
     };
-    if (a.warm) phase(0, a.warm, true);
+    if (a.warm) phase(0, a.warm, true, true);
     symaccel_batcher_stats s0{};
     if (batcher) s0 = batcher->stats();
     const auto t0 = Clock::now();
-    phase(a.warm, a.packets, !batcher);  // (a per-stream decoder transforms the packet it is handed when its batch is used up)
+    phase(a.warm, a.packets, !batcher, false);  // (a per-stream decoder transforms the packet it is handed when its batch is used up)
     const double secs = std::chrono::duration<double>(Clock::now() - t0).count();
     symaccel_batcher_stats s1{};
     if (batcher) s1 = batcher->stats();
@@ -247,15 +299,20 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
     for (auto &st : streams) batches += st->dec->batches_run();
     streams.clear();
     const double n = (double)a.streams * (double)a.packets;
-    std::printf("{\"codec\": \"%s\", \"mode\": \"%s\", \"streams\": %zu, \"lookahead\": %zu, \"threads\": %zu, \"packets\": %.0f, \"seconds\": %.6f, "
+    std::printf("{\"codec\": \"%s\", \"mode\": \"%s\", \"direct\": %s, \"in_phase\": %s, \"streams\": %zu, \"lookahead\": %zu, \"threads\": %zu, \"packets\": %.0f, \"seconds\": %.6f, "
                 "\"packets_per_s\": %.1f, \"frames_per_packet\": %zu, \"host_bytes_in_per_packet\": %zu, \"host_bytes_out_per_packet\": %zu, "
                 "\"GBps_each_way\": [%.3f, %.3f], \"decoder_batches\": %zu, \"launches\": %llu, \"kernel_launches\": %llu, \"max_chains_per_launch\": %llu, "
-                "\"staging_bytes\": %llu, \"failures\": %zu, \"checksum\": %llu}\n",
-                codec_name, batcher ? "batcher" : "per-stream", a.streams, a.lookahead, std::min(a.threads, a.streams), n, secs, n / secs, frames_per_packet,
+                "\"staging_bytes\": %llu, \"staging_grew_bytes\": %llu, \"slots_peak\": [%llu, %llu], \"lanes\": %llu, \"mutex_wait_ms\": %.3f, \"mutex_contended\": %llu, \"launch_host_ms\": %.3f, \"launch_api_ms\": %.3f, \"lane_wait_ms\": %.3f, \"group_allocs\": %llu, \"blocks\": %llu, \"flag_wait_ms\": %.3f, "
+                "\"failed_tickets\": %llu, \"failures\": %zu, \"checksum\": %llu}\n",
+                codec_name, batcher ? "batcher" : "per-stream", a.direct ? "true" : "false", a.in_phase ? "true" : "false", a.streams, a.lookahead, std::min(a.threads, a.streams), n, secs, n / secs, frames_per_packet,
                 bytes_in_per_packet, frames_per_packet * params<Codec>().channels * 4, n * bytes_in_per_packet / secs / 1e9,
                 n * frames_per_packet * params<Codec>().channels * 4 / secs / 1e9, batches,
                 (unsigned long long)(s1.launches - s0.launches), (unsigned long long)(s1.chunks - s0.chunks),
-                (unsigned long long)s1.max_chains_per_launch, (unsigned long long)s1.staging_bytes, failures.load(),
+                (unsigned long long)s1.max_chains_per_launch, (unsigned long long)s1.staging_bytes, (unsigned long long)(s1.staging_bytes - s0.staging_bytes), (unsigned long long)s0.slots_peak, (unsigned long long)s1.slots_peak, (unsigned long long)s1.lanes,
+                (double)(s1.mutex_wait_ns - s0.mutex_wait_ns) / 1e6, (unsigned long long)(s1.mutex_contended - s0.mutex_contended),
+                (double)(s1.launch_host_ns - s0.launch_host_ns) / 1e6, (double)(s1.launch_api_ns - s0.launch_api_ns) / 1e6,
+                (double)(s1.lane_wait_ns - s0.lane_wait_ns) / 1e6, (unsigned long long)(s1.group_allocs - s0.group_allocs), (unsigned long long)s1.blocks, (double)(s1.flag_wait_ns - s0.flag_wait_ns) / 1e6,
+                (unsigned long long)(s1.failed_tickets - s0.failed_tickets), failures.load(),
                 (unsigned long long)checksum.load());
     return failures.load() ? 1 : 0;
 }
@@ -274,14 +331,17 @@ int main(int argc, char **argv) {
         else if (k == "--threads") a.threads = val();
         else if (k == "--flush-mb") a.flush_mb = val();
         else if (k == "--warm") a.warm = val();
+        else if (k == "--lanes") a.lanes = val();
         else if (k == "--per-stream") a.per_stream = true;
+        else if (k == "--direct") a.direct = true;
+        else if (k == "--in-phase") a.in_phase = true;
         else {
             std::fprintf(stderr, "unknown argument %s\n", k.c_str());
             return 2;
         }
     }
     if (!a.streams || !a.lookahead || !a.packets || !a.threads) return 2;
-    if (!a.warm) a.warm = 2 * a.lookahead;  // past the cold start (every stream's first batch is a launch of its own) and the pool's growth
+    if (!a.warm) a.warm = 4 * a.lookahead;  // past the cold start (every stream's first batch is a launch of its own) and the pool's growth
     try {
         if (a.codec == "aac") return run<AacLc>(a, "aac", 1024, 2 * 1024 * 4 + 2);
         if (a.codec == "aacd") return run<AacLcCoded>(a, "aacd", 1024, 2 * 1024 * 4 + 2 + 644 + 55);  // (+ 0.6 TNS filters of 92 B)
