@@ -487,7 +487,7 @@ impl HipAacDecoder {
         Self::try_new_with_pool(params, opts, front, max_batch, Some(Pool::shared()?))
     }
 
-    fn try_new_with_pool(
+    pub fn try_new_with_pool(
         _params: &AudioCodecParameters,
         _opts: &AudioDecoderOptions,
         front: Box<dyn AacFrontEnd>,
@@ -555,8 +555,15 @@ impl AudioDecoder for HipAacDecoder {
 
 impl RegisterableAudioDecoder for HipAacDecoder {
     fn try_registry_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions) -> Result<Box<dyn AudioDecoder>> {
-        // no front end, no device, no memory: the decoder that was registered below this one takes the track
-        match crate::frontends::aac_front_end(params, opts).and_then(|front| HipAacDecoder::try_new(params, opts, front, crate::DEFAULT_LOOKAHEAD)) {
+        // The registry builds every decoder from (params, opts) alone (codecs/registry.rs:330-341): the decoders it builds find each
+        // other in the process-wide `Pool` -- their look-ahead batches go to the device in common launches (csrc/batcher.cpp).  Only
+        // when the pool cannot be created does a decoder batch on its own.
+        // No front end, no device, no memory: the decoder that was registered below this one takes the track.
+        let built = crate::frontends::aac_front_end(params, opts).and_then(|front| match Pool::shared() {
+            Ok(pool) => HipAacDecoder::try_new_with_pool(params, opts, front, crate::DEFAULT_LOOKAHEAD, Some(pool)),
+            Err(_) => HipAacDecoder::try_new(params, opts, front, crate::DEFAULT_LOOKAHEAD),
+        });
+        match built {
             Ok(decoder) => Ok(Box::new(decoder)),
             Err(e) => crate::fallback::make(params, opts, e),
         }

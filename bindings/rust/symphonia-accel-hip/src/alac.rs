@@ -13,7 +13,7 @@ use symphonia_core::errors::{decode_error, unsupported_error, Result};
 use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
-use crate::ctx::{check, Context, Pinned};
+use crate::ctx::{check, BatchSlot, Context, Pinned, Pool};
 use crate::decoder::DecoderBatch;
 use crate::ffi;
 use crate::lookahead::{BatchCodec, Lookahead};
@@ -190,6 +190,16 @@ pub struct AlacBatch {
     pairs: Vec<Vec<AlacPair>>,
     tails: Vec<Vec<AlacTail>>,
     shifts: Vec<u32>,
+    // the cross-stream batcher (SYMACCEL_BATCH_ALAC_PREDICT: a chain is an element channel, units = the stream's frame length): `cur`
+    // holds the batch being handed out -- what follows the predictor is applied in place in the page-locked slot --, `next` the one
+    // submitted ahead
+    pool: Option<Arc<Pool>>,
+    cur: Option<BatchSlot>,
+    next: Option<BatchSlot>,
+    next_lens: Vec<usize>,
+    next_pairs: Vec<Vec<AlacPair>>,
+    next_tails: Vec<Vec<AlacTail>>,
+    next_shifts: Vec<u32>,
     buf: AudioBuffer<i32>,
 }
 
@@ -205,6 +215,10 @@ impl BatchCodec for AlacBatch {
     }
 
     fn transform(&mut self, batch: &[ParsedAlac]) -> Result<()> {
+        // (a batch that came through the batcher is done with: this one is published from `words`)
+        if let (Some(pool), Some(old)) = (self.pool.clone(), self.cur.take()) {
+            pool.release(old);
+        }
         // Packets may differ in length (the last one of a stream): every element channel gets a slot of the batch's longest
         // packet, zero-padded -- predicting the padding is harmless, it is never read back.
         let k = batch.len();
@@ -244,7 +258,11 @@ impl BatchCodec for AlacBatch {
         let n = self.lens[i];
         self.buf.clear();
         self.buf.render_uninit(Some(n));
-        let words = self.words.as_mut_slice();
+        // the predicted element channels: in the batcher's slot (in place: the result plane IS input plane 0), or in this decoder's buffer
+        let words: &mut [i32] = match &mut self.cur {
+            Some(slot) => slot.input::<i32>(0),
+            None => self.words.as_mut_slice(),
+        };
         let base = i * self.nch * self.stride;
         // what follows the predictor, in the decoder's order (lib.rs:541-598, 409-414), on this packet's slots
         for pair in &self.pairs[i] {
@@ -287,6 +305,110 @@ impl BatchCodec for AlacBatch {
     fn clear(&mut self) {
         self.buf.clear();
     }
+
+    fn pooled(&self) -> bool {
+        self.pool.is_some()
+    }
+
+    /// The stream's next batch goes to the process-wide batcher: residuals, predictors and coefficients are written straight into a
+    /// page-locked slot; the device predicts in place, in one launch with the other streams' batches.
+    fn submit(&mut self, batch: &[ParsedAlac]) -> Result<()> {
+        let Some(pool) = self.pool.clone() else {
+            return unsupported_error("alac: no batcher");
+        };
+        if batch.is_empty() || self.next.is_some() {
+            return unsupported_error("alac: one batch at a time");
+        }
+        let (k, nch) = (batch.len(), self.nch);
+        let stride = self.front.max_frames(); // (the same for every batch of the stream: the group key)
+        if stride == 0 {
+            return unsupported_error("alac: empty packets");
+        }
+        let mut slot = pool.reserve(ffi::SYMACCEL_BATCH_ALAC_PREDICT as i32, 0, k * nch, stride)?;
+        {
+            let words = slot.input::<i32>(0);
+            for (i, p) in batch.iter().enumerate() {
+                for c in 0..nch {
+                    let at = (i * nch + c) * stride;
+                    words[at..at + p.frames].copy_from_slice(&p.words[c * p.frames..(c + 1) * p.frames]);
+                    words[at + p.frames..at + stride].fill(0);
+                }
+            }
+        }
+        {
+            let desc = slot.input::<ffi::SymaccelAlacDesc>(1);
+            for (i, p) in batch.iter().enumerate() {
+                for c in 0..nch {
+                    desc[i * nch + c] = p.desc[c];
+                }
+            }
+        }
+        {
+            let coeffs = slot.input::<i32>(2);
+            for (i, p) in batch.iter().enumerate() {
+                for c in 0..nch {
+                    coeffs[(i * nch + c) * 32..(i * nch + c + 1) * 32].copy_from_slice(&p.coeffs[c * 32..(c + 1) * 32]);
+                }
+            }
+        }
+        self.next_lens.clear();
+        self.next_pairs.clear();
+        self.next_tails.clear();
+        self.next_shifts.clear();
+        for p in batch {
+            self.next_lens.push(p.frames);
+            self.next_pairs.push(p.pairs.clone());
+            self.next_tails.push(p.tails.clone());
+            self.next_shifts.push(p.out_shift);
+        }
+        if let Err(e) = pool.commit(&mut slot) {
+            pool.release(slot);
+            return Err(e);
+        }
+        self.next = Some(slot);
+        Ok(())
+    }
+
+    fn collect(&mut self) -> Result<()> {
+        let (Some(pool), Some(mut slot)) = (self.pool.clone(), self.next.take()) else {
+            return unsupported_error("alac: nothing was submitted");
+        };
+        if let Err(e) = pool.wait(&mut slot) {
+            pool.release(slot);
+            return Err(e);
+        }
+        if let Some(old) = self.cur.take() {
+            pool.release(old);
+        }
+        self.cur = Some(slot);
+        self.stride = self.front.max_frames();
+        std::mem::swap(&mut self.lens, &mut self.next_lens);
+        std::mem::swap(&mut self.pairs, &mut self.next_pairs);
+        std::mem::swap(&mut self.tails, &mut self.next_tails);
+        std::mem::swap(&mut self.shifts, &mut self.next_shifts);
+        Ok(())
+    }
+
+    fn hint(&mut self) {
+        if let Some(pool) = &self.pool {
+            pool.hint();
+        }
+    }
+
+    fn abandon(&mut self) {
+        if let (Some(pool), Some(slot)) = (self.pool.clone(), self.next.take()) {
+            pool.release(slot);
+        }
+    }
+}
+
+impl Drop for AlacBatch {
+    fn drop(&mut self) {
+        BatchCodec::abandon(self);
+        if let (Some(pool), Some(slot)) = (self.pool.clone(), self.cur.take()) {
+            pool.release(slot);
+        }
+    }
 }
 
 impl DecoderBatch for AlacBatch {
@@ -305,7 +427,23 @@ crate::hip_decoder!(
 );
 
 impl HipAlacDecoder {
-    pub fn try_new(_params: &AudioCodecParameters, _opts: &AudioDecoderOptions, front: Box<dyn AlacFrontEnd>, max_batch: usize) -> Result<Self> {
+    pub fn try_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn AlacFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, None)
+    }
+
+    /// The same decoder submitting to the process-wide cross-stream batcher (`Pool::shared()`): the element channels of every open
+    /// ALAC stream with this frame length are predicted in one launch (csrc/batcher.cpp, SYMACCEL_BATCH_ALAC_PREDICT).
+    pub fn try_new_pooled(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn AlacFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, Some(Pool::shared()?))
+    }
+
+    pub fn try_new_with_pool(
+        _params: &AudioCodecParameters,
+        _opts: &AudioDecoderOptions,
+        front: Box<dyn AlacFrontEnd>,
+        max_batch: usize,
+        pool: Option<Arc<Pool>>,
+    ) -> Result<Self> {
         let params = front.params().clone();
         let (Some(rate), Some(channels)) = (params.sample_rate, params.channels.clone()) else {
             return unsupported_error("alac: sample rate and channels are required");
@@ -327,6 +465,13 @@ impl HipAlacDecoder {
                 pairs: Vec::with_capacity(max_batch),
                 tails: Vec::with_capacity(max_batch),
                 shifts: Vec::with_capacity(max_batch),
+                pool,
+                cur: None,
+                next: None,
+                next_lens: Vec::with_capacity(max_batch),
+                next_pairs: Vec::with_capacity(max_batch),
+                next_tails: Vec::with_capacity(max_batch),
+                next_shifts: Vec::with_capacity(max_batch),
                 buf: AudioBuffer::new(AudioSpec::new(rate, channels), max_frames),
             },
             la: Lookahead::new(max_batch),

@@ -103,6 +103,127 @@ impl Pool {
     }
 }
 
+/// A reservation with the cross-stream batcher (`symaccel_batcher_reserve`): a slot of page-locked staging memory the front end's
+/// output is written STRAIGHT into -- the planes of the entry point the batch kind stands for, chain-major over this submission's
+/// chains (include/symaccel.h, "cross-stream batcher") -- and the ticket that names it.  `Pool::commit` says it is filled,
+/// `Pool::wait` blocks until `out` / `state` hold the PCM and the state after the batch (whatever the decoders of the OTHER streams
+/// had pending went to the device in the same launch), `Pool::release` gives the slot back.  Nothing is copied between the parser's
+/// output and the DMA source, and nothing between the DMA target and `AudioBuffer`'s planes but `publish`'s own plane copies.
+pub struct BatchSlot {
+    raw: ffi::SymaccelBatchSlot,
+    ticket: u64,
+    committed: bool,
+}
+
+// SAFETY: the slot's planes are owned by this reservation until `Pool::release`; the batcher itself is thread-safe.
+unsafe impl Send for BatchSlot {}
+unsafe impl Sync for BatchSlot {}
+
+impl BatchSlot {
+    /// Plane `i` of the submission's input as elements of `T` (the kind's layout: f32 spectra, u8 flags, #[repr(C)] records ...).
+    pub fn input<T: Copy>(&mut self, i: usize) -> &mut [T] {
+        // SAFETY: the batcher handed out `input_bytes[i]` bytes at `input[i]`, 256-byte aligned, exclusively ours until release.
+        unsafe { std::slice::from_raw_parts_mut(self.raw.input[i] as *mut T, self.raw.input_bytes[i] / std::mem::size_of::<T>()) }
+    }
+
+    /// State plane `i`: the state the batch starts from (written before `commit`), the state it left (after `wait`).
+    pub fn state<T: Copy>(&mut self, i: usize) -> &mut [T] {
+        // SAFETY: as `input`.
+        unsafe { std::slice::from_raw_parts_mut(self.raw.state[i] as *mut T, self.raw.state_bytes[i] / std::mem::size_of::<T>()) }
+    }
+
+    /// The result plane (after `wait`).  FLAC / ALAC work in place: it is input plane 0.
+    pub fn out<T: Copy>(&self) -> &[T] {
+        // SAFETY: as `input`; written by the device before `wait` returned.
+        unsafe { std::slice::from_raw_parts(self.raw.out as *const T, self.raw.out_bytes / std::mem::size_of::<T>()) }
+    }
+
+    pub fn is_committed(&self) -> bool {
+        self.committed
+    }
+}
+
+impl Pool {
+    /// `symaccel_batcher_reserve`: a slot for `n_chains` chains of `units` frames / granules / blocks / words each.
+    pub fn reserve(&self, kind: i32, param: i32, n_chains: usize, units: usize) -> Result<BatchSlot> {
+        let mut raw = ffi::SymaccelBatchSlot {
+            input: [ptr::null_mut(); 6],
+            state: [ptr::null_mut(); 3],
+            out: ptr::null_mut(),
+            input_bytes: [0; 6],
+            state_bytes: [0; 3],
+            out_bytes: 0,
+        };
+        let mut ticket = 0u64;
+        // SAFETY: a live batcher, valid out-pointers.
+        check(unsafe { ffi::symaccel_batcher_reserve(self.batcher, kind, param, n_chains, units, &mut raw, &mut ticket) }, self.ctx.raw())?;
+        Ok(BatchSlot { raw, ticket, committed: false })
+    }
+
+    /// The slot is filled: it goes to the device with the next launch of its group.
+    pub fn commit(&self, slot: &mut BatchSlot) -> Result<()> {
+        // SAFETY: a live ticket of this batcher.
+        check(unsafe { ffi::symaccel_batcher_commit(self.batcher, slot.ticket) }, self.ctx.raw())?;
+        slot.committed = true;
+        Ok(())
+    }
+
+    /// Block until the submission's results are in its slot.  The status is this submission's own: a batch whose descriptors do
+    /// not add up fails alone, the neighbours of its launch do not (include/symaccel.h, "Status is kept PER TICKET").
+    pub fn wait(&self, slot: &mut BatchSlot) -> Result<()> {
+        // SAFETY: a live, committed ticket; the slot record is filled in again with the same pointers.
+        check(unsafe { ffi::symaccel_batcher_wait(self.batcher, slot.ticket, &mut slot.raw) }, self.ctx.raw())
+    }
+
+    /// Give the slot back (a reservation that was never committed runs as zeros with its group; nobody looks at the result).
+    pub fn release(&self, slot: BatchSlot) {
+        // SAFETY: a live ticket; the batcher drains whatever of it is in flight before the memory is reused.
+        unsafe { ffi::symaccel_batcher_release(self.batcher, slot.ticket) };
+    }
+
+    /// "Results will be wanted soon": pending groups worth a launch of their own go to the device now.
+    pub fn hint(&self) {
+        // SAFETY: a live batcher.
+        unsafe { ffi::symaccel_batcher_hint(self.batcher) };
+    }
+
+    /// `symaccel_batcher_get_stats`: submissions, launches, what the callers waited for (mutex, lanes, completion flags).
+    pub fn stats(&self) -> Result<ffi::SymaccelBatcherStats> {
+        let mut s = ffi::SymaccelBatcherStats {
+            submissions: 0,
+            launches: 0,
+            chunks: 0,
+            chains_launched: 0,
+            max_chains_per_launch: 0,
+            staging_bytes: 0,
+            pending: 0,
+            failed_tickets: 0,
+            lanes: 0,
+            mutex_wait_ns: 0,
+            mutex_contended: 0,
+            launch_host_ns: 0,
+            lane_wait_ns: 0,
+            launch_api_ns: 0,
+            group_allocs: 0,
+            flag_wait_ns: 0,
+            slots_peak: 0,
+            blocks: 0,
+        };
+        // SAFETY: a live batcher, a valid out-pointer.
+        check(unsafe { ffi::symaccel_batcher_get_stats(self.batcher, &mut s) }, self.ctx.raw())?;
+        Ok(s)
+    }
+
+    /// Register a floor-1 configuration of a Vorbis stream's setup header; the index goes into the `floor` plane of the stream's
+    /// `SYMACCEL_BATCH_VORBIS_DECODE` submissions.  The same configuration gives the same index in every stream.
+    pub fn vorbis_floor(&self, cfg: &ffi::SymaccelVorbisFloor1Cfg) -> Result<u8> {
+        let mut index: i32 = -1;
+        // SAFETY: a live batcher, a valid record, a valid out-pointer.
+        check(unsafe { ffi::symaccel_batcher_vorbis_floor(self.batcher, cfg, &mut index) }, self.ctx.raw())?;
+        Ok(index as u8)
+    }
+}
+
 impl Drop for Pool {
     fn drop(&mut self) {
         // SAFETY: created by symaccel_batcher_create, destroyed once, before its context.

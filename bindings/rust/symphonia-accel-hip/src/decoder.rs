@@ -65,8 +65,15 @@ macro_rules! hip_decoder {
                 params: &symphonia_core::codecs::audio::AudioCodecParameters,
                 opts: &symphonia_core::codecs::audio::AudioDecoderOptions,
             ) -> symphonia_core::errors::Result<Box<dyn symphonia_core::codecs::audio::AudioDecoder>> {
-                // no front end, no device, no memory: the decoder that was registered below this one takes the track
-                match $front_end(params, opts).and_then(|front| Self::try_new(params, opts, front, $crate::DEFAULT_LOOKAHEAD)) {
+                // The registry builds every decoder from (params, opts) alone (codecs/registry.rs:330-341): the decoders it builds
+                // find each other in the process-wide `Pool` -- their look-ahead batches go to the device in common launches
+                // (csrc/batcher.cpp).  Only when the pool cannot be created does a decoder batch on its own.
+                // No front end, no device, no memory: the decoder that was registered below this one takes the track.
+                let built = $front_end(params, opts).and_then(|front| match $crate::ctx::Pool::shared() {
+                    Ok(pool) => Self::try_new_with_pool(params, opts, front, $crate::DEFAULT_LOOKAHEAD, Some(pool)),
+                    Err(_) => Self::try_new(params, opts, front, $crate::DEFAULT_LOOKAHEAD),
+                });
+                match built {
                     Ok(decoder) => Ok(Box::new(decoder)),
                     Err(e) => $crate::fallback::make(params, opts, e),
                 }

@@ -11,7 +11,7 @@ use symphonia_core::errors::{decode_error, unsupported_error, Result};
 use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
-use crate::ctx::{check, Context, Pinned};
+use crate::ctx::{check, BatchSlot, Context, Pinned, Pool};
 use crate::decoder::DecoderBatch;
 use crate::ffi;
 use crate::lookahead::{BatchCodec, Lookahead};
@@ -167,6 +167,15 @@ pub struct FlacBatch {
     lens: Vec<usize>,                   // block size of each packet of the batch
     modes: Vec<u8>,
     shifts: Vec<u32>,
+    // the cross-stream batcher (SYMACCEL_BATCH_FLAC_RESTORE: a chain is a subframe, units = the stream's maximum block size, so the
+    // batches of every FLAC stream with that block size share launches whatever their lengths): `cur` holds the batch being handed
+    // out -- its restored words are read where the device left them, in the page-locked slot --, `next` the one submitted ahead
+    pool: Option<Arc<Pool>>,
+    cur: Option<BatchSlot>,
+    next: Option<BatchSlot>,
+    next_lens: Vec<usize>,
+    next_modes: Vec<u8>,
+    next_shifts: Vec<u32>,
     buf: AudioBuffer<i32>,
 }
 
@@ -182,6 +191,10 @@ impl BatchCodec for FlacBatch {
     }
 
     fn transform(&mut self, batch: &[ParsedFlac]) -> Result<()> {
+        // (a batch that came through the batcher is done with: this one is published from `words`)
+        if let (Some(pool), Some(old)) = (self.pool.clone(), self.cur.take()) {
+            pool.release(old);
+        }
         // Block sizes may differ (the last frame of a stream, variable-block-size streams): every subframe gets a slot
         // of the batch's largest block size, zero-padded -- predicting the padding is harmless, it is never read back.
         let k = batch.len();
@@ -216,7 +229,11 @@ impl BatchCodec for FlacBatch {
         let n = self.lens[i];
         self.buf.clear();
         self.buf.render_uninit(Some(n));
-        let words = self.words.as_slice();
+        // the restored subframes: in the batcher's slot (zero-copy: the device wrote them there), or in this decoder's own buffer
+        let words: &[i32] = match &self.cur {
+            Some(slot) => slot.out::<i32>(),
+            None => self.words.as_slice(),
+        };
         let base = i * self.nch * self.stride;
         // decorrelation + left-justification of ONE frame is 2 * blocksize operations: done here on the copy out (the
         // batched device form, symaccel_flac_restore_stereo_device, is for callers that keep the PCM on the GPU)
@@ -252,6 +269,104 @@ impl BatchCodec for FlacBatch {
     fn clear(&mut self) {
         self.buf.clear();
     }
+
+    fn pooled(&self) -> bool {
+        self.pool.is_some()
+    }
+
+    /// The stream's next batch goes to the process-wide batcher: the subframes are written straight into a page-locked slot
+    /// (`Pool::reserve` -> fill -> `commit`); the device restores them in place, in one launch with the other streams' batches.
+    fn submit(&mut self, batch: &[ParsedFlac]) -> Result<()> {
+        let Some(pool) = self.pool.clone() else {
+            return unsupported_error("flac: no batcher");
+        };
+        if batch.is_empty() || self.next.is_some() {
+            return unsupported_error("flac: one batch at a time");
+        }
+        let (k, nch) = (batch.len(), self.nch);
+        let stride = self.front.max_blocksize(); // (the same for every batch of the stream: the group key)
+        let mut slot = pool.reserve(ffi::SYMACCEL_BATCH_FLAC_RESTORE as i32, 0, k * nch, stride)?;
+        self.next_lens.clear();
+        self.next_modes.clear();
+        self.next_shifts.clear();
+        {
+            let words = slot.input::<i32>(0);
+            for (i, p) in batch.iter().enumerate() {
+                for c in 0..nch {
+                    let at = (i * nch + c) * stride;
+                    words[at..at + p.blocksize].copy_from_slice(&p.words[c * p.blocksize..(c + 1) * p.blocksize]);
+                    words[at + p.blocksize..at + stride].fill(0);
+                }
+            }
+        }
+        {
+            let desc = slot.input::<ffi::SymaccelFlacDesc>(1);
+            for (i, p) in batch.iter().enumerate() {
+                for c in 0..nch {
+                    desc[i * nch + c] = p.desc[c];
+                }
+            }
+        }
+        {
+            let coeffs = slot.input::<i32>(2);
+            for (i, p) in batch.iter().enumerate() {
+                for c in 0..nch {
+                    coeffs[(i * nch + c) * 32..(i * nch + c + 1) * 32].copy_from_slice(&p.coeffs[c * 32..(c + 1) * 32]);
+                }
+            }
+        }
+        for p in batch {
+            self.next_lens.push(p.blocksize);
+            self.next_modes.push(if nch == 2 { p.pair_mode } else { 0 });
+            self.next_shifts.push(p.out_shift);
+        }
+        if let Err(e) = pool.commit(&mut slot) {
+            pool.release(slot);
+            return Err(e);
+        }
+        self.next = Some(slot);
+        Ok(())
+    }
+
+    fn collect(&mut self) -> Result<()> {
+        let (Some(pool), Some(mut slot)) = (self.pool.clone(), self.next.take()) else {
+            return unsupported_error("flac: nothing was submitted");
+        };
+        if let Err(e) = pool.wait(&mut slot) {
+            pool.release(slot);
+            return Err(e);
+        }
+        if let Some(old) = self.cur.take() {
+            pool.release(old);
+        }
+        self.cur = Some(slot);
+        self.stride = self.front.max_blocksize();
+        std::mem::swap(&mut self.lens, &mut self.next_lens);
+        std::mem::swap(&mut self.modes, &mut self.next_modes);
+        std::mem::swap(&mut self.shifts, &mut self.next_shifts);
+        Ok(())
+    }
+
+    fn hint(&mut self) {
+        if let Some(pool) = &self.pool {
+            pool.hint();
+        }
+    }
+
+    fn abandon(&mut self) {
+        if let (Some(pool), Some(slot)) = (self.pool.clone(), self.next.take()) {
+            pool.release(slot);
+        }
+    }
+}
+
+impl Drop for FlacBatch {
+    fn drop(&mut self) {
+        BatchCodec::abandon(self);
+        if let (Some(pool), Some(slot)) = (self.pool.clone(), self.cur.take()) {
+            pool.release(slot);
+        }
+    }
 }
 
 impl DecoderBatch for FlacBatch {
@@ -270,7 +385,23 @@ crate::hip_decoder!(
 );
 
 impl HipFlacDecoder {
-    pub fn try_new(_params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn FlacFrontEnd>, max_batch: usize) -> Result<Self> {
+    pub fn try_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn FlacFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, None)
+    }
+
+    /// The same decoder submitting to the process-wide cross-stream batcher (`Pool::shared()`): with many streams open, the
+    /// subframes of all of them are restored in one launch (csrc/batcher.cpp, SYMACCEL_BATCH_FLAC_RESTORE).
+    pub fn try_new_pooled(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn FlacFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, Some(Pool::shared()?))
+    }
+
+    pub fn try_new_with_pool(
+        _params: &AudioCodecParameters,
+        opts: &AudioDecoderOptions,
+        front: Box<dyn FlacFrontEnd>,
+        max_batch: usize,
+        pool: Option<Arc<Pool>>,
+    ) -> Result<Self> {
         if opts.verify {
             // the MD5 of STREAMINFO is computed over the decoded audio inside the reference's decoder; here the caller verifies
             return unsupported_error("flac: verification is not available with the batched predictors");
@@ -295,6 +426,12 @@ impl HipFlacDecoder {
                 lens: Vec::with_capacity(max_batch),
                 modes: Vec::with_capacity(max_batch),
                 shifts: Vec::with_capacity(max_batch),
+                pool,
+                cur: None,
+                next: None,
+                next_lens: Vec::with_capacity(max_batch),
+                next_modes: Vec::with_capacity(max_batch),
+                next_shifts: Vec::with_capacity(max_batch),
                 buf: AudioBuffer::new(AudioSpec::new(rate, channels), max_bs),
             },
             la: Lookahead::new(max_batch),

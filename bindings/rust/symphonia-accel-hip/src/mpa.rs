@@ -15,7 +15,7 @@ use symphonia_core::errors::{decode_error, unsupported_error, Result};
 use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
-use crate::ctx::{check, Context, Pinned, Pool};
+use crate::ctx::{check, BatchSlot, Context, Pinned, Pool};
 use crate::decoder::DecoderBatch;
 use crate::ffi;
 use crate::lookahead::{BatchCodec, Lookahead};
@@ -290,9 +290,12 @@ pub struct MpaBatch {
     st: Vec<ffi::SymaccelMp3Stereo>,  //   [granule of the batch] (the one channel pair of a stereo stream)
     first_granule: Vec<usize>,        // per packet of the batch: index of its first granule; one extra entry = total
     trims: Vec<(usize, usize)>,       // per packet of the batch
-    // the cross-stream batcher: the batch submitted ahead (its PCM and state land in `pcm` / `overlap` / `vvec` / `vfront` at collect)
+    // the cross-stream batcher (SYMACCEL_BATCH_MP3_DECODE, one stream per submission): `cur` holds the batch being handed out -- its PCM
+    // is read where the device left it, in the page-locked slot --, `next` the one submitted ahead (its state lands in `overlap` /
+    // `vvec` / `vfront` at collect)
     pool: Option<Arc<Pool>>,
-    ticket: Option<u64>,
+    cur: Option<BatchSlot>,
+    next: Option<BatchSlot>,
     next_first_granule: Vec<usize>,
     next_trims: Vec<(usize, usize)>,
     gapless: bool,
@@ -307,6 +310,10 @@ impl BatchCodec for MpaBatch {
     }
 
     fn transform(&mut self, batch: &[ParsedMpa]) -> Result<()> {
+        // (a batch that came through the batcher is done with: this one is published from `pcm`)
+        if let (Some(pool), Some(old)) = (self.pool.clone(), self.cur.take()) {
+            pool.release(old);
+        }
         self.first_granule.clear();
         self.trims.clear();
         let mut total = 0usize;
@@ -357,10 +364,15 @@ impl BatchCodec for MpaBatch {
         let frames = (g1 - g0) * 576;
         self.buf.clear();
         self.buf.render_uninit(Some(frames));
+        // the batch's PCM: in the batcher's slot (zero-copy: the device wrote it there), or in this decoder's own buffer
+        let pcm: &[f32] = match &self.cur {
+            Some(slot) => slot.out::<f32>(),
+            None => self.pcm.as_slice(),
+        };
         for c in 0..self.nch {
             let src = (c * total + g0) * 576;
             if let Some(plane) = self.buf.plane_mut(c) {
-                plane[..frames].copy_from_slice(&self.pcm.as_slice()[src..src + frames]);
+                plane[..frames].copy_from_slice(&pcm[src..src + frames]);
             }
         }
         if self.gapless {
@@ -386,14 +398,14 @@ impl BatchCodec for MpaBatch {
         self.pool.is_some()
     }
 
-    /// `symaccel_batcher_submit_mp3_decode`: the stream's next batch goes to the process-wide batcher (one stream = one submission
-    /// of 1 or 2 chains); the inputs are copied out of the staging buffers before the call returns, the PCM and the state after the
-    /// batch are written by `collect`.
+    /// The stream's next batch goes to the process-wide batcher (one stream = one submission of 1 or 2 chains): the Huffman samples and
+    /// the side records are written straight into a page-locked slot (`Pool::reserve` -> fill -> `commit`); requantize, stereo and the
+    /// synthesis tail run in one launch with the other streams' batches (layer3/mod.rs:421-477).
     fn submit(&mut self, batch: &[ParsedMpa]) -> Result<()> {
         let Some(pool) = self.pool.clone() else {
             return unsupported_error("mp3: no batcher");
         };
-        if batch.is_empty() || !batch.iter().all(|p| p.fused.is_some()) || self.ticket.is_some() {
+        if batch.is_empty() || !batch.iter().all(|p| p.fused.is_some()) || self.next.is_some() {
             return unsupported_error("mp3: the batcher takes the entropy decoder's integers, one batch at a time");
         }
         self.next_first_granule.clear();
@@ -405,41 +417,81 @@ impl BatchCodec for MpaBatch {
             total += p.n_granules;
         }
         self.next_first_granule.push(total);
-        let first = self.next_first_granule.clone();
-        self.gather_fused(batch, total, &first);
-        let mut ticket = 0u64;
-        // SAFETY: the staging buffers cover nch * total (* 576) elements (sized for max_batch frames of two granules) and are copied
-        // before the call returns; the state arrays and `pcm` stay where they are until `collect` / `abandon` (fields of self).
-        check(
-            unsafe {
-                ffi::symaccel_batcher_submit_mp3_decode(
-                    pool.raw(),
-                    self.quant.as_slice().as_ptr(),
-                    self.rq.as_ptr(),
-                    self.st.as_ptr(),
-                    self.side.as_ptr(),
-                    self.front.sample_rate_idx(),
-                    self.overlap.as_mut_ptr(),
-                    self.vvec.as_mut_ptr(),
-                    self.vfront.as_mut_ptr(),
-                    self.pcm.as_mut_slice().as_mut_ptr(),
-                    self.nch,
-                    total,
-                    &mut ticket,
-                )
-            },
-            pool.ctx_raw(),
-        )?;
-        self.ticket = Some(ticket);
+        let nch = self.nch;
+        let mut slot = pool.reserve(ffi::SYMACCEL_BATCH_MP3_DECODE as i32, self.front.sample_rate_idx(), nch, total)?;
+        {
+            // [channel][granule of the batch][576] Huffman samples
+            let quant = slot.input::<i16>(0);
+            for (i, p) in batch.iter().enumerate() {
+                let Some(f) = &p.fused else { continue };
+                for g in 0..p.n_granules {
+                    for c in 0..nch {
+                        let dst = (c * total + self.next_first_granule[i] + g) * 576;
+                        let src = (g * nch + c) * 576;
+                        quant[dst..dst + 576].copy_from_slice(&f.quant[src..src + 576]);
+                    }
+                }
+            }
+        }
+        {
+            let rq = slot.input::<ffi::SymaccelMp3Requant>(1);
+            for (i, p) in batch.iter().enumerate() {
+                let Some(f) = &p.fused else { continue };
+                for g in 0..p.n_granules {
+                    for c in 0..nch {
+                        rq[c * total + self.next_first_granule[i] + g] = f.rq[g * nch + c];
+                    }
+                }
+            }
+        }
+        {
+            let side = slot.input::<ffi::SymaccelMp3Side>(2);
+            for (i, p) in batch.iter().enumerate() {
+                for g in 0..p.n_granules {
+                    for c in 0..nch {
+                        side[c * total + self.next_first_granule[i] + g] = p.side[g * nch + c];
+                    }
+                }
+            }
+        }
+        {
+            // one joint-stereo record per granule of the STREAM (all zeros for a mono stream)
+            let zero_st = ffi::SymaccelMp3Stereo { flags: 0, block_type: 0, is_mixed: 0, reserved: 0, rzero0: 0, rzero1: 0, scalefacs1: [0; 39], pad: 0 };
+            let st = slot.input::<ffi::SymaccelMp3Stereo>(3);
+            for (i, p) in batch.iter().enumerate() {
+                let Some(f) = &p.fused else { continue };
+                for g in 0..p.n_granules {
+                    st[self.next_first_granule[i] + g] = if nch == 2 { f.st[g] } else { zero_st };
+                }
+            }
+        }
+        slot.state::<f32>(0).copy_from_slice(&self.overlap);
+        slot.state::<f32>(1).copy_from_slice(&self.vvec);
+        slot.state::<i32>(2).copy_from_slice(&self.vfront);
+        if let Err(e) = pool.commit(&mut slot) {
+            pool.release(slot);
+            return Err(e);
+        }
+        self.next = Some(slot);
         Ok(())
     }
 
     fn collect(&mut self) -> Result<()> {
-        let (Some(pool), Some(ticket)) = (self.pool.clone(), self.ticket.take()) else {
+        let (Some(pool), Some(mut slot)) = (self.pool.clone(), self.next.take()) else {
             return unsupported_error("mp3: nothing was submitted");
         };
-        // SAFETY: a live ticket of this pool's batcher; the pointers given to submit are fields of self.
-        check(unsafe { ffi::symaccel_batcher_collect(pool.raw(), ticket) }, pool.ctx_raw())?;
+        if let Err(e) = pool.wait(&mut slot) {
+            pool.release(slot);
+            return Err(e);
+        }
+        // the state after the batch; the PCM stays where it is
+        self.overlap.copy_from_slice(slot.state::<f32>(0));
+        self.vvec.copy_from_slice(slot.state::<f32>(1));
+        self.vfront.copy_from_slice(slot.state::<i32>(2));
+        if let Some(old) = self.cur.take() {
+            pool.release(old);
+        }
+        self.cur = Some(slot);
         std::mem::swap(&mut self.first_granule, &mut self.next_first_granule);
         std::mem::swap(&mut self.trims, &mut self.next_trims);
         Ok(())
@@ -447,22 +499,23 @@ impl BatchCodec for MpaBatch {
 
     fn hint(&mut self) {
         if let Some(pool) = &self.pool {
-            // SAFETY: a live batcher.
-            unsafe { ffi::symaccel_batcher_hint(pool.raw()) };
+            pool.hint();
         }
     }
 
     fn abandon(&mut self) {
-        if let (Some(pool), Some(ticket)) = (self.pool.clone(), self.ticket.take()) {
-            // SAFETY: a live ticket; nothing is written to the state or the PCM (the submission is released without a copy-out).
-            unsafe { ffi::symaccel_batcher_abandon(pool.raw(), ticket) };
+        if let (Some(pool), Some(slot)) = (self.pool.clone(), self.next.take()) {
+            pool.release(slot);
         }
     }
 }
 
 impl Drop for MpaBatch {
     fn drop(&mut self) {
-        BatchCodec::abandon(self); // (a batch still with the batcher points at this struct's buffers)
+        BatchCodec::abandon(self);
+        if let (Some(pool), Some(slot)) = (self.pool.clone(), self.cur.take()) {
+            pool.release(slot);
+        }
     }
 }
 
@@ -547,7 +600,7 @@ impl HipMpaDecoder {
         Self::try_new_with_pool(params, opts, front, max_batch, Some(Pool::shared()?))
     }
 
-    fn try_new_with_pool(
+    pub fn try_new_with_pool(
         params: &AudioCodecParameters,
         opts: &AudioDecoderOptions,
         front: Box<dyn MpaFrontEnd>,
@@ -581,7 +634,8 @@ impl HipMpaDecoder {
                 first_granule: Vec::with_capacity(max_batch + 1),
                 trims: Vec::with_capacity(max_batch),
                 pool,
-                ticket: None,
+                cur: None,
+                next: None,
                 next_first_granule: Vec::with_capacity(max_batch + 1),
                 next_trims: Vec::with_capacity(max_batch),
                 gapless: opts.gapless,

@@ -14,7 +14,7 @@ use symphonia_core::errors::{decode_error, unsupported_error, Result};
 use symphonia_core::packet::PacketRef;
 use symphonia_core::support_audio_codec;
 
-use crate::ctx::{check, Context, Pinned};
+use crate::ctx::{check, BatchSlot, Context, Pinned, Pool};
 use crate::decoder::DecoderBatch;
 use crate::ffi;
 use crate::lookahead::{BatchCodec, Lookahead};
@@ -237,6 +237,18 @@ pub struct VorbisBatch {
     floors: Vec<ffi::SymaccelVorbisFloor1Cfg>, // the fused form: the stream's floor-1 configurations,
     floor: Vec<u8>,           //   [channel][packet] floor index or SYMACCEL_VORBIS_FLOOR_UNUSED,
     posts: Vec<u32>,          //   [channel][packet][POSTS]
+    // the cross-stream batcher (SYMACCEL_BATCH_VORBIS_DECODE for a front end that hands on residue + posts, SYMACCEL_BATCH_VORBIS_SYNTH for
+    // one that hands on spectra): every chain's planes at their largest -- max_batch x bs1 / 2 --, the packed data at the front, so that
+    // streams with different block flags share a launch.  `cur` holds the batch being handed out (its PCM is read where the device left
+    // it), `next` the one submitted ahead; `floor_index` = what the batcher calls this stream's floor configurations.
+    pool: Option<Arc<Pool>>,
+    cur: Option<BatchSlot>,
+    next: Option<BatchSlot>,
+    floor_index: Vec<u8>,
+    next_pcm_off: Vec<usize>,
+    next_emits: Vec<bool>,
+    next_trims: Vec<(usize, usize)>,
+    next_stride: usize,
     buf: AudioBuffer<f32>,
 }
 
@@ -248,6 +260,10 @@ impl BatchCodec for VorbisBatch {
     }
 
     fn transform(&mut self, batch: &[ParsedVorbis]) -> Result<()> {
+        // (a batch that came through the batcher is done with: this one is published from `pcm`)
+        if let (Some(pool), Some(old)) = (self.pool.clone(), self.cur.take()) {
+            pool.release(old);
+        }
         let k = batch.len();
         // the packed layout of include/symaccel.h ("Vorbis"): block b owns n_b / 2 lines and (prev_n + n_b) / 4 samples;
         // a first block without a previous one owns n_b / 2 sample slots and leaves them untouched
@@ -308,10 +324,15 @@ impl BatchCodec for VorbisBatch {
         let frames = if self.emits[i] { self.pcm_off[i + 1] - self.pcm_off[i] } else { 0 };
         self.buf.clear();
         self.buf.render_uninit(Some(frames));
+        // the batch's PCM: in the batcher's slot (zero-copy: the device wrote it there), or in this decoder's own buffer
+        let pcm: &[f32] = match &self.cur {
+            Some(slot) => slot.out::<f32>(),
+            None => self.pcm.as_slice(),
+        };
         for c in 0..self.nch {
             let src = c * self.pcm_stride + self.pcm_off[i];
             if let Some(plane) = self.buf.plane_mut(c) {
-                plane[..frames].copy_from_slice(&self.pcm.as_slice()[src..src + frames]);
+                plane[..frames].copy_from_slice(&pcm[src..src + frames]);
             }
         }
         // lib.rs:333-342 (gapless): the first packet after a reset is silenced (`emits`), every other one is trimmed
@@ -329,6 +350,165 @@ impl BatchCodec for VorbisBatch {
 
     fn clear(&mut self) {
         self.buf.clear();
+    }
+
+    fn pooled(&self) -> bool {
+        self.pool.is_some()
+    }
+
+    /// The stream's next batch goes to the process-wide batcher: residue (or spectra), flags, floor indices, posts and the coupling steps
+    /// are written straight into a page-locked slot; coupling, floor curves, dot product and synthesis run in one launch with the other
+    /// streams' batches (lib.rs:250-331).
+    fn submit(&mut self, batch: &[ParsedVorbis]) -> Result<()> {
+        let Some(pool) = self.pool.clone() else {
+            return unsupported_error("vorbis: no batcher");
+        };
+        if batch.is_empty() || self.next.is_some() {
+            return unsupported_error("vorbis: one batch at a time");
+        }
+        let (k, nch) = (batch.len(), self.nch);
+        let fused = batch.iter().all(|p| p.fused.is_some());
+        if !fused && batch.iter().any(|p| p.fused.is_some()) {
+            return unsupported_error("vorbis: a batch is all residue + posts, or all spectra");
+        }
+        let (bs0_exp, bs1_exp) = self.front.block_exps();
+        let cap = k * self.bs[1] / 2; // a chain's spectrum / PCM plane at its largest
+        // the packed layout of the batch inside a chain (as `transform`)
+        let mut prev: i32 = self.prev_flag[0];
+        let (mut lines, mut samples) = (0usize, 0usize);
+        let mut spec_off = Vec::with_capacity(k);
+        self.next_pcm_off.clear();
+        self.next_emits.clear();
+        self.next_trims.clear();
+        for p in batch {
+            let n = self.bs[p.long_block as usize];
+            spec_off.push(lines);
+            self.next_pcm_off.push(samples);
+            self.next_emits.push(prev >= 0);
+            self.next_trims.push(p.trim);
+            lines += n / 2;
+            samples += if prev >= 0 { (self.bs[prev as usize] + n) / 4 } else { n / 2 };
+            prev = p.long_block as i32;
+        }
+        self.next_pcm_off.push(samples);
+        self.next_stride = cap;
+        let (kind, param) = if fused {
+            (ffi::SYMACCEL_BATCH_VORBIS_DECODE as i32, bs0_exp | (bs1_exp << 8) | ((nch as i32) << 16))
+        }
+        else {
+            (ffi::SYMACCEL_BATCH_VORBIS_SYNTH as i32, bs0_exp | (bs1_exp << 8))
+        };
+        let mut slot = pool.reserve(kind, param, nch, k)?;
+        {
+            let spectra = slot.input::<f32>(0);
+            for (i, p) in batch.iter().enumerate() {
+                let half = self.bs[p.long_block as usize] / 2;
+                for c in 0..nch {
+                    let dst = c * cap + spec_off[i];
+                    spectra[dst..dst + half].copy_from_slice(&p.spectra[c * half..(c + 1) * half]);
+                }
+            }
+        }
+        {
+            let flags = slot.input::<u8>(1);
+            for (i, p) in batch.iter().enumerate() {
+                for c in 0..nch {
+                    flags[c * k + i] = p.long_block as u8;
+                }
+            }
+        }
+        if fused {
+            let mut steps: Vec<u8> = Vec::new();
+            let mut first: Vec<u32> = Vec::with_capacity(k + 1);
+            first.push(0);
+            {
+                let floor = slot.input::<u8>(2);
+                for (i, p) in batch.iter().enumerate() {
+                    let Some(f) = &p.fused else { continue };
+                    for c in 0..nch {
+                        // (the stream's floor numbers become the batcher's: registered when the decoder was built)
+                        let local = f.floor[c] as usize;
+                        floor[c * k + i] = if local < self.floor_index.len() { self.floor_index[local] } else { ffi::SYMACCEL_VORBIS_FLOOR_UNUSED as u8 };
+                    }
+                    steps.extend_from_slice(&f.coupling);
+                    first.push((steps.len() / 2) as u32);
+                }
+            }
+            {
+                let posts = slot.input::<u32>(3);
+                for (i, p) in batch.iter().enumerate() {
+                    let Some(f) = &p.fused else { continue };
+                    for c in 0..nch {
+                        let dst = (c * k + i) * POSTS;
+                        posts[dst..dst + POSTS].copy_from_slice(&f.posts[c * POSTS..(c + 1) * POSTS]);
+                    }
+                }
+            }
+            {
+                // the coupling blob: first[k + 1] u32 (little endian), padded to 16 bytes, then the (magnitude, angle) pairs
+                let blob = slot.input::<u8>(4);
+                let steps_at = ((k + 1) * 4 + 15) & !15;
+                if steps_at + steps.len() > blob.len() {
+                    pool.release(slot);
+                    return unsupported_error("vorbis: more coupling steps than a batcher submission holds");
+                }
+                for (b, v) in first.iter().enumerate() {
+                    blob[4 * b..4 * b + 4].copy_from_slice(&v.to_le_bytes());
+                }
+                blob[steps_at..steps_at + steps.len()].copy_from_slice(&steps);
+            }
+        }
+        slot.state::<i32>(0).copy_from_slice(&self.prev_flag);
+        slot.state::<f32>(1).copy_from_slice(&self.overlap);
+        if let Err(e) = pool.commit(&mut slot) {
+            pool.release(slot);
+            return Err(e);
+        }
+        self.next = Some(slot);
+        Ok(())
+    }
+
+    fn collect(&mut self) -> Result<()> {
+        let (Some(pool), Some(mut slot)) = (self.pool.clone(), self.next.take()) else {
+            return unsupported_error("vorbis: nothing was submitted");
+        };
+        if let Err(e) = pool.wait(&mut slot) {
+            pool.release(slot);
+            return Err(e);
+        }
+        // the lapping state after the batch; the PCM stays where it is
+        self.prev_flag.copy_from_slice(slot.state::<i32>(0));
+        self.overlap.copy_from_slice(slot.state::<f32>(1));
+        if let Some(old) = self.cur.take() {
+            pool.release(old);
+        }
+        self.cur = Some(slot);
+        self.pcm_stride = self.next_stride;
+        std::mem::swap(&mut self.pcm_off, &mut self.next_pcm_off);
+        std::mem::swap(&mut self.emits, &mut self.next_emits);
+        std::mem::swap(&mut self.trims, &mut self.next_trims);
+        Ok(())
+    }
+
+    fn hint(&mut self) {
+        if let Some(pool) = &self.pool {
+            pool.hint();
+        }
+    }
+
+    fn abandon(&mut self) {
+        if let (Some(pool), Some(slot)) = (self.pool.clone(), self.next.take()) {
+            pool.release(slot);
+        }
+    }
+}
+
+impl Drop for VorbisBatch {
+    fn drop(&mut self) {
+        BatchCodec::abandon(self);
+        if let (Some(pool), Some(slot)) = (self.pool.clone(), self.cur.take()) {
+            pool.release(slot);
+        }
     }
 }
 
@@ -401,6 +581,22 @@ crate::hip_decoder!(
 
 impl HipVorbisDecoder {
     pub fn try_new(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn VorbisFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, None)
+    }
+
+    /// The same decoder submitting to the process-wide cross-stream batcher (`Pool::shared()`): the batches of every open Vorbis stream
+    /// with these block sizes and this channel count go to the device in one launch (csrc/batcher.cpp, SYMACCEL_BATCH_VORBIS_DECODE).
+    pub fn try_new_pooled(params: &AudioCodecParameters, opts: &AudioDecoderOptions, front: Box<dyn VorbisFrontEnd>, max_batch: usize) -> Result<Self> {
+        Self::try_new_with_pool(params, opts, front, max_batch, Some(Pool::shared()?))
+    }
+
+    pub fn try_new_with_pool(
+        params: &AudioCodecParameters,
+        opts: &AudioDecoderOptions,
+        front: Box<dyn VorbisFrontEnd>,
+        max_batch: usize,
+        pool: Option<Arc<Pool>>,
+    ) -> Result<Self> {
         if !opts.gapless {
             // Without gapless support the reference returns the first block after a reset windowed against silence
             // (lib.rs:316-331 with an all-zero overlap); the batched call does not compute that half block.  The decoder
@@ -415,6 +611,25 @@ impl HipVorbisDecoder {
         let (bs0_exp, bs1_exp) = front.block_exps();
         let bs = [1usize << bs0_exp, 1usize << bs1_exp];
         let floors = front.floors();
+        // the stream's floor-1 configurations under the batcher's numbers (a setup entry that is no floor 1 has no posts to render: unused);
+        // a batcher that has no room for them (255 distinct configurations) leaves this stream batching on its own
+        let mut pool = pool;
+        let mut floor_index: Vec<u8> = Vec::with_capacity(floors.len());
+        if let Some(p) = pool.clone() {
+            for cfg in floors.iter() {
+                if cfg.n_posts < 2 {
+                    floor_index.push(ffi::SYMACCEL_VORBIS_FLOOR_UNUSED as u8);
+                    continue;
+                }
+                match p.vorbis_floor(cfg) {
+                    Ok(index) => floor_index.push(index),
+                    Err(_) => {
+                        pool = None;
+                        break;
+                    }
+                }
+            }
+        }
         Ok(HipVorbisDecoder {
             params: params.clone(),
             batch: VorbisBatch {
@@ -435,6 +650,14 @@ impl HipVorbisDecoder {
                 floors,
                 floor: vec![0; nch * max_batch],
                 posts: vec![0; nch * max_batch * POSTS],
+                pool,
+                cur: None,
+                next: None,
+                floor_index,
+                next_pcm_off: Vec::with_capacity(max_batch + 1),
+                next_emits: Vec::with_capacity(max_batch),
+                next_trims: Vec::with_capacity(max_batch),
+                next_stride: 0,
                 buf: AudioBuffer::new(AudioSpec::new(rate, channels), bs[1] / 2),
             },
             la: Lookahead::new(max_batch),

@@ -632,7 +632,8 @@ int symaccel_alac_mid_side(symaccel_ctx *ctx, const int32_t *h_weight, const uin
  *                              Only the lines / samples the flags account for cross the link.
  *   SYMACCEL_BATCH_AAC_DECODE  symaccel_aac_decode_pipelined for ONE stream (its n_chains channels, any number of them paired):
  *                              in = { coeffs, side as AAC_SYNTH, blob[chain] }; state / out as AAC_SYNTH; param = the index
- *                              symaccel_batcher_aac_bands() gave the stream's scale-factor-band tables.  The blob (every chain
+ *                              symaccel_batcher_aac_bands() gave the stream's scale-factor-band tables (-1: the submission has no
+ *                              jointly coded pair and reads no table -- it shares launches with streams of any table).  The blob (every chain
  *                              contributes 64 + units * (322 + 8 * 92) bytes to ONE contiguous region of the submission) holds
  *                              { u32 n_pairs, n_tns, 0, 0 }, pair_chains[n_pairs][2] i32 (chains of the submission), padded to 16
  *                              bytes, js_desc[n_pairs][unit] (644 B each), padded to 16 bytes, tns[n_tns] (92 B each, frame = chain *

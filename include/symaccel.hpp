@@ -483,8 +483,7 @@ struct FinalizeResult {  // codecs/audio.rs:230-236
 // batcher instead of being transformed by a call of their own, and the next batch is submitted early -- as soon as half of the
 // current one has been handed out -- so that by the time this stream needs it, the decoders of the other streams have submitted
 // theirs and one launch (one PCIe round trip) serves all of them.  The returned planes then point into the batcher's page-locked
-// result slot (valid, like every buffer of the trait, until the next &mut call).  Codecs without a batch kind (FLAC) ignore the batcher and keep batching
-// per stream.
+// result slot (valid, like every buffer of the trait, until the next &mut call).
 template <class Codec>
 class LookaheadDecoder {
 public:
@@ -624,8 +623,8 @@ private:
     void submit(const std::vector<Packet> &batch) {
         if constexpr (Codec::kBatchKind != 0) {
             symaccel_batch_slot slot;
-            check(symaccel_batcher_reserve(batcher_->raw(), Codec::kBatchKind, codec_.batch_param(), codec_.channels(),
-                                           batch.size() * codec_.units_per_packet(), &slot, &next_ticket_),
+            check(symaccel_batcher_reserve(batcher_->raw(), Codec::kBatchKind, codec_.batch_param(), codec_.batch_chains(batch.size()),
+                                           codec_.batch_units(batch.size()), &slot, &next_ticket_),
                   ctx_.raw());
             next_live_ = true;
             try {
@@ -678,7 +677,7 @@ private:
             if (k == 0) return;
             symaccel_batch_slot slot;
             auto reserve = [&](std::size_t n, symaccel_batch_slot *sl, std::uint64_t *t) {
-                check(symaccel_batcher_reserve(batcher_->raw(), Codec::kBatchKind, codec_.batch_param(), codec_.channels(), n * codec_.units_per_packet(), sl, t),
+                check(symaccel_batcher_reserve(batcher_->raw(), Codec::kBatchKind, codec_.batch_param(), codec_.batch_chains(n), codec_.batch_units(n), sl, t),
                       ctx_.raw());
             };
             reserve(k, &slot, &next_ticket_);
@@ -831,6 +830,8 @@ struct AacLc {
     void attach(Batcher &) {}
     int batch_param() const { return 0; }
     std::size_t units_per_packet() const { return 1; }
+    std::size_t batch_chains(std::size_t) const { return nch_; }  // a submission of k packets: nch chains of k units
+    std::size_t batch_units(std::size_t k) const { return k; }
     // where packet i of a batch of k lies in a slot's planes (what a parser that writes straight into the slot needs: LookaheadDecoder::Direct)
     struct BatchView {
         float *coeffs = nullptr;
@@ -929,6 +930,8 @@ struct AacLcCoded {
     }
     int batch_param() const { return bands_; }
     std::size_t units_per_packet() const { return 1; }
+    std::size_t batch_chains(std::size_t) const { return nch_; }  // a submission of k packets: nch chains of k units
+    std::size_t batch_units(std::size_t k) const { return k; }
     void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
         const std::size_t k = batch.size();
         describe(batch, static_cast<float *>(slot.input[0]), static_cast<std::uint8_t *>(slot.input[1]));
@@ -1038,6 +1041,8 @@ struct Mp3 {
     void attach(Batcher &) {}
     int batch_param() const { return sr_; }
     std::size_t units_per_packet() const { return ngr_; }
+    std::size_t batch_chains(std::size_t) const { return nch_; }
+    std::size_t batch_units(std::size_t k) const { return k * ngr_; }
     struct BatchView {  // granule gr of packet i of channel c is unit i * ngr + gr of chain c
         float *xr = nullptr;
         symaccel_mp3_side *side = nullptr;
@@ -1152,6 +1157,8 @@ struct Mp3Huffman {
     void attach(Batcher &) {}
     int batch_param() const { return sr_; }
     std::size_t units_per_packet() const { return ngr_; }
+    std::size_t batch_chains(std::size_t) const { return nch_; }
+    std::size_t batch_units(std::size_t k) const { return k * ngr_; }
     struct BatchView {  // granule gr of packet i of channel c is unit i * ngr + gr of chain c; the stereo records are per granule of the STREAM
         std::int16_t *quant = nullptr;
         symaccel_mp3_requant *rq = nullptr;
@@ -1286,6 +1293,8 @@ struct Vorbis {
     void attach(Batcher &) {}
     int batch_param() const { return e0_ | (e1_ << 8); }
     std::size_t units_per_packet() const { return 1; }
+    std::size_t batch_chains(std::size_t) const { return nch_; }  // a submission of k packets: nch chains of k units
+    std::size_t batch_units(std::size_t k) const { return k; }
     void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
         const std::size_t k = batch.size(), cap = k << (e1_ - 1);
         // (the batch being handed out keeps its offsets until this one is collected: the submitted batch's layout waits in next_*)
@@ -1371,6 +1380,7 @@ struct Flac {
     struct Params {
         std::size_t channels = 2;
         std::uint32_t bits_per_sample = 16;
+        std::size_t max_blocksize = 4096;  // STREAMINFO's maximum block size: the slot every subframe gets with the batcher
     };
     struct Packet {
         std::uint64_t ts = 0;
@@ -1380,13 +1390,51 @@ struct Flac {
         std::vector<std::int32_t> coeffs;       // [channel][32], reference order (decoder.rs:716-752)
         std::uint8_t pair_mode = 0;             // 0 independent, 1 left/side, 2 mid/side, 3 right/side (two-channel frames)
     };
-    explicit Flac(const Params &p) : nch_(p.channels), shift_(32u - p.bits_per_sample) {
-        if (p.channels == 0 || p.bits_per_sample == 0 || p.bits_per_sample > 32) throw std::invalid_argument("Flac: parameters");
+    explicit Flac(const Params &p) : nch_(p.channels), shift_(32u - p.bits_per_sample), max_bs_(p.max_blocksize) {
+        if (p.channels == 0 || p.bits_per_sample == 0 || p.bits_per_sample > 32 || p.max_blocksize == 0 || p.max_blocksize > 65535)
+            throw std::invalid_argument("Flac: parameters");
     }
-    static constexpr int kBatchKind = 0;  // (block sizes differ from stream to stream: batches per stream)
+    // With the batcher (SYMACCEL_BATCH_FLAC_RESTORE) a chain is ONE SUBFRAME and the unit count is the stream's maximum block size, so
+    // the batches of every FLAC stream with that block size share launches whatever their lengths; a two-channel stream takes the
+    // fused form (param 0x100 | shift: decorrelation and left-justification in the restore kernel's write-back, decoder.rs:199-242),
+    // every other layout the plain one with the shift on the host.
+    static constexpr int kBatchKind = SYMACCEL_BATCH_FLAC_RESTORE;
     static constexpr bool kDirect = false;
     struct BatchView {};
     void attach(Batcher &) {}
+    int batch_param() const { return nch_ == 2 ? (int)(0x100u | shift_) : 0; }
+    std::size_t batch_chains(std::size_t k) const { return k * nch_; }
+    std::size_t batch_units(std::size_t) const { return max_bs_; }
+    void fill_slot(const std::vector<Packet> &batch, const symaccel_batch_slot &slot) {
+        const std::size_t k = batch.size();
+        std::int32_t *words = static_cast<std::int32_t *>(slot.input[0]);
+        symaccel_flac_desc *desc = static_cast<symaccel_flac_desc *>(slot.input[1]);
+        std::int32_t *coeffs = static_cast<std::int32_t *>(slot.input[2]);
+        next_lens_.assign(k, 0);
+        for (std::size_t i = 0; i < k; ++i) {
+            const Packet &p = batch[i];
+            if (p.blocksize == 0 || p.blocksize > max_bs_ || p.words.size() != nch_ * p.blocksize || p.desc.size() != nch_ || p.coeffs.size() != nch_ * 32 ||
+                p.pair_mode > 3 || (p.pair_mode != 0 && nch_ != 2))
+                throw std::invalid_argument("Flac: packet shape");
+            next_lens_[i] = p.blocksize;
+            for (std::size_t c = 0; c < nch_; ++c) {
+                std::int32_t *row = words + (i * nch_ + c) * max_bs_;
+                std::copy_n(p.words.data() + c * p.blocksize, p.blocksize, row);
+                std::fill(row + p.blocksize, row + max_bs_, 0);  // (restoring the padding is harmless: it is never published)
+                desc[i * nch_ + c] = p.desc[c];
+                std::copy_n(p.coeffs.data() + c * 32, 32, coeffs + (i * nch_ + c) * 32);
+            }
+            if (nch_ == 2) static_cast<std::uint8_t *>(slot.input[3])[i] = p.pair_mode;
+        }
+    }
+    void take_state(const symaccel_batch_slot &slot) {
+        lens_.swap(next_lens_);
+        stride_ = max_bs_;
+        if (nch_ != 2) {  // decoder.rs:239-242 (the two-channel form did it on the device)
+            std::int32_t *words = static_cast<std::int32_t *>(slot.out);
+            for (std::size_t i = 0; i < slot.out_bytes / 4; ++i) words[i] = (std::int32_t)((std::uint32_t)words[i] << shift_);
+        }
+    }
     static std::uint64_t id(const Packet &p) { return p.ts; }
     std::size_t channels() const { return nch_; }
     std::size_t packet_frames(std::size_t i) const { return lens_[i]; }
@@ -1440,8 +1488,9 @@ struct Flac {
 private:
     std::size_t nch_;
     std::uint32_t shift_;
+    std::size_t max_bs_;
     std::size_t stride_ = 0;
-    std::vector<std::size_t> lens_;
+    std::vector<std::size_t> lens_, next_lens_;
     std::vector<symaccel_flac_desc> desc_;
     std::vector<std::int32_t> coeffs_, ch0_, ch1_;
     std::vector<std::uint8_t> modes_;

@@ -817,6 +817,7 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
         for (TicketView &v : views) {
             AacBlobHeader *h = reinterpret_cast<AacBlobHeader *>(v.slot + slot_layout(ps, v.n_chains).in[2]);
             v.status = check_aac_blob(ps, g->units, v);
+            if (v.status == SYMACCEL_OK && h->n_pairs && g->param < 0) v.status = SYMACCEL_ERR_INVALID_ARG;  // (pairs need a band table)
             if (v.status != SYMACCEL_OK) h->n_pairs = h->n_tns = 0;
             g->aac_pairs += h->n_pairs;
             g->aac_tns += h->n_tns;
@@ -1176,7 +1177,7 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
             const Ticket &t = b->tickets[g->ticket_ids[i]];
             g->views[i] = TicketView{t.slot, t.first_chain, t.n_chains, SYMACCEL_OK};
         }
-        if (g->kind == SYMACCEL_BATCH_AAC_DECODE) g->aac_maps = b->bands[(size_t)g->param].maps;  // (the index was checked by reserve())
+        if (g->kind == SYMACCEL_BATCH_AAC_DECODE && g->param >= 0) g->aac_maps = b->bands[(size_t)g->param].maps;  // (the index was checked by reserve())
         if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) g->vb_floors = b->floors;
         Lane *lane = pick_lane(b);
         g->lane = lane;
@@ -1241,7 +1242,15 @@ Group *open_group(symaccel_batcher *b, int kind, int param, size_t units, const 
     Group *spare = nullptr;
     for (auto &up : b->groups) {
         Group *g = up.get();
-        if (g->state == GroupState::Open && g->kind == kind && g->param == param && g->units == units) return g;
+        if (g->state == GroupState::Open && g->kind == kind && g->units == units) {
+            if (g->param == param) return g;
+            // AAC_DECODE: a submission without jointly coded pairs (param -1) reads no band table: it rides with whatever table the
+            // group has, and a group that so far holds only such submissions takes the table of the first one that does need it
+            if (kind == SYMACCEL_BATCH_AAC_DECODE && (param == -1 || g->param == -1)) {
+                if (g->param == -1) g->param = param;
+                return g;
+            }
+        }
         if (g->state == GroupState::Free && !spare) spare = g;
     }
     if (!spare) {
@@ -1384,7 +1393,7 @@ int symaccel_batcher_reserve(symaccel_batcher *b, int kind, int param, size_t n_
         if (ps.in_div[i] == 2 && (n_chains & 1)) return SYMACCEL_ERR_INVALID_ARG;  // channel pairs
     Locked locked(b);
     std::unique_lock<std::mutex> &lock = locked.lock;
-    if (kind == SYMACCEL_BATCH_AAC_DECODE && (param < 0 || (size_t)param >= b->bands.size())) return SYMACCEL_ERR_INVALID_ARG;  // (symaccel_batcher_aac_bands first)
+    if (kind == SYMACCEL_BATCH_AAC_DECODE && param != -1 && (param < 0 || (size_t)param >= b->bands.size())) return SYMACCEL_ERR_INVALID_ARG;  // (symaccel_batcher_aac_bands first; -1: no pairs, no table)
     // the slot first: page-locking a new slab drops the mutex, and the group must be chosen in one piece with the reservation
     const SlotLayout lay = slot_layout(ps, n_chains);
     const size_t cls = slot_class(lay.bytes);
@@ -1640,7 +1649,12 @@ int symaccel_batcher_submit_aac_decode(symaccel_batcher *b, int bands, const flo
     if (aac_blob_bytes(n_pairs, frames_per_chain, n_tns) > ps.in[2] * n_chains) return SYMACCEL_ERR_INVALID_ARG;  // (more than 8 filters per channel-frame)
     symaccel_batch_slot slot;
     uint64_t id = 0;
-    SYM_TRY(symaccel_batcher_reserve(b, SYMACCEL_BATCH_AAC_DECODE, bands, n_chains, frames_per_chain, &slot, &id));
+    {
+        Locked locked(b);
+        if (bands != -1 && (bands < 0 || (size_t)bands >= b->bands.size())) return SYMACCEL_ERR_INVALID_ARG;  // (tables that were never registered)
+    }
+    // (a batch without a jointly coded pair reads no band table: it shares a launch with streams of any table)
+    SYM_TRY(symaccel_batcher_reserve(b, SYMACCEL_BATCH_AAC_DECODE, n_pairs ? bands : -1, n_chains, frames_per_chain, &slot, &id));
     std::memcpy(slot.input[0], coeffs, slot.input_bytes[0]);
     std::memcpy(slot.input[1], side, slot.input_bytes[1]);
     char *blob = static_cast<char *>(slot.input[2]);

@@ -289,7 +289,7 @@ static void test_vorbis(Context &ctx, size_t lookahead, int e0, int e1, Batcher 
 }
 
 // ---- FLAC: integer samples, no carried state, block sizes that differ from packet to packet
-static void test_flac(Context &ctx, size_t lookahead, size_t nch, uint32_t bps) {
+static void test_flac(Context &ctx, size_t lookahead, size_t nch, uint32_t bps, Batcher *batcher = nullptr) {
     const size_t n = 23;
     std::mt19937 rng(77 + (unsigned)lookahead + (unsigned)nch);
     std::vector<Flac::Packet> track(n);
@@ -313,10 +313,13 @@ static void test_flac(Context &ctx, size_t lookahead, size_t nch, uint32_t bps) 
         }
     }
     size_t cursor = 0;
-    LookaheadDecoder<Flac> dec(ctx, Flac::Params{nch, bps}, lookahead, [&]() -> std::optional<Flac::Packet> {
+    auto peek = [&]() -> std::optional<Flac::Packet> {
         if (cursor >= track.size()) return std::nullopt;
         return track[cursor++];
-    });
+    };
+    std::unique_ptr<LookaheadDecoder<Flac>> holder(batcher ? new LookaheadDecoder<Flac>(*batcher, Flac::Params{nch, bps, 4096}, lookahead, peek)
+                                                           : new LookaheadDecoder<Flac>(ctx, Flac::Params{nch, bps, 4096}, lookahead, peek));
+    LookaheadDecoder<Flac> &dec = *holder;
     for (size_t i = 0; i < n; ++i) {
         if (i == 9) {  // seek
             dec.reset();
@@ -532,6 +535,9 @@ int main(int argc, char **argv) {
         for (size_t k : {size_t(1), size_t(5), size_t(16)}) test_vorbis(ctx, k, 8, 11, &batcher);
         test_vorbis(ctx, 6, 6, 9, &batcher);
         test_vorbis(ctx, 4, 12, 13, &batcher);
+        for (size_t k : {size_t(1), size_t(4), size_t(32)}) test_flac(ctx, k, 2, 16, &batcher);  // (the fused stereo form)
+        test_flac(ctx, 5, 1, 24, &batcher);
+        test_flac(ctx, 7, 3, 20, &batcher);
     }
     test_cross_stream(ctx, 1, 8);
     test_cross_stream(ctx, 7, 8);

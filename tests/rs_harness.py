@@ -269,3 +269,33 @@ class Harness:
             else:
                 rows.append(np.array([np.float32(x) if not isinstance(x, I.Int) else np.float32(x.v) for x in vals], np.float32))
         return np.stack(rows) if rows else np.zeros((0, 0))
+
+
+def registry_round_trip(h, decoder_type, params_list, opts=None):
+    """`register` -> `make_audio_decoder` for every entry of params_list, the way an application gets its decoders
+    (symphonia-core/src/codecs/registry.rs:252-269, 330-341): `register_one::<decoder_type>` (what lib.rs `register()` does for each
+    of the five decoder types) enters the type at Tier::Preferred, the registry's factory -- `try_registry_new`, from (params, opts)
+    alone -- builds the decoders.  Returns the decoders; the harness must have lib.rs, fallback.rs and the codec's adapter loaded."""
+    it = h.it
+    it.load_file(ROOT / "tests" / "rust" / "registry_generic.rs")
+    it.load_source("pub fn register_under_test(registry: &mut CodecRegistry) { register_one::<%s>(registry, true); }" % decoder_type, "register_under_test.rs")
+    reg = it.call("CodecRegistry::new")
+    it.call("register_under_test", reg)
+    decs = []
+    for p in params_list:
+        r = it.call_method("CodecRegistry", "make_registered_audio_decoder", reg, p, opts if opts is not None else h.opts())
+        assert r.variant == "Ok", r
+        dec = I.deref(r.f["0"])
+        assert isinstance(dec, I.Struct) and dec.name == decoder_type, dec
+        decs.append(dec)
+    return decs
+
+
+def pool_stats(h):
+    """symaccel_batcher_get_stats of the process-wide Pool the interpreted crate created (ctx.rs `Pool::shared` / `Pool::stats`)"""
+    pool = h.it.call("Pool::shared")
+    assert pool.variant == "Ok", pool
+    arc = pool.f["0"]
+    r = h.it.call_method("Pool", "stats", arc.v if hasattr(arc, "v") else arc)
+    assert r.variant == "Ok", r
+    return {k: int(v.v) for k, v in r.f["0"].f.items()}

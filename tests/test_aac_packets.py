@@ -288,3 +288,40 @@ def test_seek_into_the_middle_of_the_stream_and_reset(trees):
     assert [st for st, _ in got] == [st for st, _ in want]
     for i, ((st, a), (_, b)) in enumerate(zip(got, want)):
         assert (np.array_equal(bits(a), bits(b)) if st == "ok" else a == b), (k + i, st)
+
+
+def test_decoders_built_by_the_registry_share_the_cross_stream_batcher(trees):
+    """What an application gets: `register()` enters HipAacDecoder at Tier::Preferred, `make_audio_decoder(params, opts)` builds every decoder
+    from (params, opts) alone (codecs/registry.rs:34-44, 252-269, 330-341) -- and the decoders so built find each other in the
+    process-wide `Pool`: two streams behind look-ahead readers, decoded alternately, every packet's PCM the reference decoder's bit for
+    bit, their batches in common launches (symaccel_batcher_get_stats)."""
+    from emu_lib import emu_library
+    from rs_harness import pool_stats, registry_round_trip
+    nch = 2
+    n, depth = sized((10, 6), (6, 4))
+    streams = [[p for p, _ in stream(6, n, nch)], [p for p, _ in stream(2, n, nch)]]
+    want = []
+    for packets in streams:
+        ref = Harness(None, reference=True, aac_tree=trees[0])
+        ref_dec = cpu_decoder(ref, nch)
+        want.append([ref.decode("AacDecoder", ref_dec, ref.packet(pk, i * 1024))[1] for i, pk in enumerate(packets)])
+    h = Harness(emu_library().dll, reference=True, aac_tree=trees[1])
+    h.it.load_file(ROOT / "tests" / "rust" / "registry_stubs.rs")
+    h.load_shim("lib.rs", "ctx.rs", "decoder.rs", "lookahead.rs", "fallback.rs", "aac.rs", "frontends.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    p = h.params("CODEC_ID_AAC", 44100, nch)
+    decs = [h.f32_buffers(d) for d in registry_round_trip(h, "HipAacDecoder", [p, p])]
+    readers = []
+    for k, packets in enumerate(streams):
+        pk = I.Arr([h.packet(d, i * 1024, track=1 + k, owned=True) for i, d in enumerate(packets)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(depth)))
+    for i in range(n):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            st, got = h.decode("HipAacDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            assert st == "ok" and np.array_equal(bits(got), bits(want[k][i])), (k, i)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1 and calls.count("symaccel_batcher_submit_aac_decode") >= 2
+    assert calls.count("symaccel_aac_decode_pipelined") == 2  # each stream's cold start only
+    stats = pool_stats(h)
+    assert stats["submissions"] >= 2 and stats["launches"] < stats["submissions"] and stats["failed_tickets"] == 0, stats

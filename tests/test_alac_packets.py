@@ -182,3 +182,35 @@ def test_look_ahead_batches_and_reset(trees):
     h.it.call_method("HipAlacDecoder", "reset", dec)
     for i, (st, got) in zip(range(2, 6), run(2, 4)):
         assert st == "ok" and np.array_equal(got, left_justified(pcm[i], depth)), i
+
+
+def test_decoders_built_by_the_registry_share_the_cross_stream_batcher(trees):
+    """What an application gets: `register()` enters HipAlacDecoder at Tier::Preferred, `make_audio_decoder(params, opts)` builds every decoder
+    from (params, opts) alone (codecs/registry.rs:34-44, 252-269, 330-341) -- and the decoders so built find each other in the
+    process-wide `Pool`: two streams behind look-ahead readers, decoded alternately, every packet's PCM the reference decoder's bit for
+    bit, their batches in common launches (symaccel_batcher_get_stats)."""
+    from emu_lib import emu_library
+    from rs_harness import pool_stats, registry_round_trip
+    nch, depth, frame_length = 2, 16, 128
+    n, reader_depth = sized((12, 6), (8, 4))
+    streams = [stream(31 + k, n, nch, depth, frame_length) for k in range(2)]
+    h = Harness(emu_library().dll, reference=True, alac_tree=trees[1])
+    h.it.load_file(ROOT / "tests" / "rust" / "registry_stubs.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    h.load_shim("lib.rs", "ctx.rs", "decoder.rs", "lookahead.rs", "fallback.rs", "alac.rs", "frontends.rs")
+    p = h.params("CODEC_ID_ALAC", extra=W.cookie(frame_length, depth, nch))
+    decs = registry_round_trip(h, "HipAlacDecoder", [p, p])
+    readers = []
+    for k, (packets, _) in enumerate(streams):
+        pk = I.Arr([h.packet(d, i * frame_length, track=1 + k, owned=True) for i, d in enumerate(packets)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(reader_depth)))
+    for i in range(n):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            st, got = h.decode("HipAlacDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            assert st == "ok" and np.array_equal(got, left_justified(streams[k][1][i], depth)), (k, i)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1 and calls.count("symaccel_batcher_reserve") >= 2
+    assert calls.count("symaccel_alac_predict") == 2  # each stream's cold start only
+    stats = pool_stats(h)
+    assert stats["submissions"] >= 2 and stats["launches"] < stats["submissions"] and stats["failed_tickets"] == 0, stats

@@ -177,3 +177,35 @@ def test_look_ahead_batches_and_reset(trees):
     h.it.call_method("HipFlacDecoder", "reset", dec)
     for i, (st, got) in zip(range(3, 7), run(3, 4)):
         assert st == "ok" and np.array_equal(got, want[i]), i
+
+
+def test_decoders_built_by_the_registry_share_the_cross_stream_batcher(trees):
+    """What an application gets: `register()` enters HipFlacDecoder at Tier::Preferred, `make_audio_decoder(params, opts)` builds every
+    decoder from (params, opts) alone (codecs/registry.rs:34-44, 252-269, 330-341) -- and the decoders so built find each other in the
+    process-wide `Pool`: two streams behind look-ahead readers, decoded alternately, every packet's PCM the reference decoder's, their
+    batches in common launches (symaccel_batcher_get_stats), written straight into the batcher's page-locked slots."""
+    from emu_lib import emu_library
+    from rs_harness import pool_stats, registry_round_trip
+    nch, bps, blocksize = 2, 16, 192
+    n, depth = sized((12, 6), (8, 4))
+    streams = [W.random_stream(21 + k, n, nch, bps, blocksize) for k in range(2)]
+    h = Harness(emu_library().dll, reference=True, flac_tree=trees[1])
+    h.it.load_file(ROOT / "tests" / "rust" / "registry_stubs.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    h.load_shim("lib.rs", "ctx.rs", "decoder.rs", "lookahead.rs", "fallback.rs", "flac.rs", "frontends.rs")
+    p = h.params("CODEC_ID_FLAC", extra=streaminfo(blocksize, 44100, nch, bps))
+    decs = registry_round_trip(h, "HipFlacDecoder", [p, p])
+    readers = []
+    for k, (frames, _) in enumerate(streams):
+        pk = I.Arr([h.packet(fr, i * blocksize, track=1 + k, owned=True) for i, fr in enumerate(frames)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(depth)))
+    for i in range(n):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            st, got = h.decode("HipFlacDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            assert st == "ok" and np.array_equal(got, left_justified(streams[k][1][i], bps)), (k, i)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1 and calls.count("symaccel_batcher_reserve") >= 2
+    assert calls.count("symaccel_flac_restore") == 2  # each stream's cold start only: every later batch went through the batcher
+    stats = pool_stats(h)
+    assert stats["submissions"] >= 2 and stats["launches"] < stats["submissions"] and stats["failed_tickets"] == 0, stats

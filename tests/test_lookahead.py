@@ -58,7 +58,7 @@ def test_decoders_bench_harness_on_the_emulation_build():
     subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", str(ROOT / "include"), str(ROOT / "tools" / "decoders_bench.cpp"), "-o", str(exe),
                     "-L", str(so.parent), "-lsymaccel_emu", "-Wl,-rpath," + str(so.parent), "-pthread"], check=True)
     for codec, extra in (("aac", []), ("aacd", []), ("mp3h", []), ("vorbis", []), ("mp3", ["--per-stream"]), ("aac", ["--direct"]), ("mp3h", ["--direct", "--in-phase"]),
-                         ("mp3", ["--direct"])):
+                         ("mp3", ["--direct"]), ("flac", [])):
         r = subprocess.run([str(exe), "--codec", codec, "--streams", "6", "--lookahead", "4", "--packets", "12", "--threads", "3"] + extra,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -238,8 +238,8 @@ def test_look_ahead_batches_and_reset(trees):
 
 def test_two_pooled_decoders_share_the_cross_stream_batcher(trees):
     """`HipMpaDecoder::try_new_pooled`: two streams behind look-ahead readers, decoded alternately like a server's worker would.  The
-    batches after each stream's first go through symaccel_batcher_submit_mp3_decode / _collect of the process-wide `Pool` (one
-    batcher for both decoders), and every packet's PCM still equals the reference decoder's bit for bit."""
+    batches after each stream's first go through `Pool::reserve` / `commit` / `wait` / `release` of the process-wide `Pool` (one
+    batcher for both decoders; the Huffman samples are written straight into its page-locked slots), and every packet's PCM still equals the reference decoder's bit for bit."""
     mpeg1, n, batch = sized((True, 10, 4), (True, 7, 2))
     per_frame = 1152 if mpeg1 else 576
     streams = [stream(8, n, "joint", mpeg1, 0), stream(9, n, "stereo", mpeg1, 0)]
@@ -267,8 +267,10 @@ def test_two_pooled_decoders_share_the_cross_stream_batcher(trees):
             assert st == "ok" and np.array_equal(bits(got), bits(want[k][i])), (k, i)
     calls = h.bridge.calls
     assert calls.count("symaccel_batcher_create") == 1                                     # one pool for both decoders
-    assert calls.count("symaccel_batcher_submit_mp3_decode") >= 2 * ((n - batch) // batch)   # every batch after the first: submitted ahead
-    assert calls.count("symaccel_batcher_collect") >= calls.count("symaccel_batcher_submit_mp3_decode") - 2
+    assert calls.count("symaccel_batcher_reserve") >= 2 * ((n - batch) // batch)             # every batch after the first: submitted ahead,
+    assert calls.count("symaccel_batcher_commit") == calls.count("symaccel_batcher_reserve")  # written straight into the batcher's slots
+    assert calls.count("symaccel_batcher_wait") >= calls.count("symaccel_batcher_reserve") - 2
+    assert "symaccel_batcher_submit_mp3_decode" not in calls and "symaccel_batcher_collect" not in calls
     assert calls.count("symaccel_mp3_decode_pipelined") == 2                                 # each stream's cold start only
     # a seek + reset with a batch in flight: given up, then everything again from packet 0
     h.it.call_method("LookaheadReader", "seek", readers[0], I.Int(0, "i64"), usize(0))
@@ -317,3 +319,36 @@ def test_seek_into_the_middle_of_the_stream_and_reset(trees):
     assert [st for st, _ in got] == [st for st, _ in want]
     for i, ((st, a), (_, b)) in enumerate(zip(got, want)):
         assert (np.array_equal(bits(a), bits(b)) if st == "ok" else a == b), (k + i, st)
+
+
+def test_decoders_built_by_the_registry_share_the_cross_stream_batcher(trees):
+    """What an application gets: `register()` enters HipMpaDecoder at Tier::Preferred, `make_audio_decoder(params, opts)` builds every decoder
+    from (params, opts) alone (codecs/registry.rs:34-44, 252-269, 330-341) -- and the decoders so built find each other in the
+    process-wide `Pool`: two streams behind look-ahead readers, decoded alternately, every packet's PCM the reference decoder's bit for
+    bit, their batches in common launches (symaccel_batcher_get_stats)."""
+    from rs_harness import pool_stats, registry_round_trip
+    mpeg1, n, depth = sized((True, 10, 6), (True, 7, 4))
+    per_frame = 1152
+    streams = [stream(8, n, "joint", mpeg1, 0), stream(9, n, "stereo", mpeg1, 0)]
+    want = []
+    for s, packets in streams:
+        ref = Harness(None, reference=True, mp3_tree=trees[0])
+        ref_dec = cpu_decoder(ref, s)
+        want.append([ref.decode("MpaDecoder", ref_dec, ref.packet(pk, i * per_frame))[1] for i, (pk, _) in enumerate(packets)])
+    h = shim(trees[1])
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    decs = registry_round_trip(h, "HipMpaDecoder", [h.params("CODEC_ID_MP3", s.rate, s.nch) for s, _ in streams])
+    readers = []
+    for k, (s, packets) in enumerate(streams):
+        pk = I.Arr([h.packet(d, i * per_frame, track=1 + k, owned=True) for i, (d, _) in enumerate(packets)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(depth)))
+    for i in range(n):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            st, got = h.decode("HipMpaDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            assert st == "ok" and np.array_equal(bits(got), bits(want[k][i])), (k, i)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1 and calls.count("symaccel_batcher_reserve") >= 2
+    assert calls.count("symaccel_mp3_decode_pipelined") == 2  # each stream's cold start only
+    stats = pool_stats(h)
+    assert stats["submissions"] >= 2 and stats["launches"] < stats["submissions"] and stats["failed_tickets"] == 0, stats

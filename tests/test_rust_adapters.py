@@ -56,9 +56,23 @@ def key(i):
     return bytes([i % 256, i // 256])
 
 
+def wrap32(v):
+    return ((np.asarray(v, np.int64) + (1 << 31)) % (1 << 32)) - (1 << 31)
+
+
 def same(got, want):
     got, want = np.asarray(got), np.asarray(want)
     return got.shape == want.shape and bool(np.array_equal(got, want)) and not np.isnan(got.astype(np.float64)).any()
+
+
+def batcher_stats(h):
+    """symaccel_batcher_get_stats of the process-wide Pool the interpreted crate created (ctx.rs `Pool::shared` / `Pool::stats`)"""
+    pool = h.it.call("Pool::shared")
+    assert pool.variant == "Ok", pool
+    arc = pool.f["0"]
+    r = h.it.call_method("Pool", "stats", arc.v if hasattr(arc, "v") else arc)
+    assert r.variant == "Ok", r
+    return {k: int(v.v) for k, v in r.f["0"].f.items()}
 
 
 # ------------------------------------------------------------------------------------------------ AAC
@@ -253,18 +267,66 @@ def test_vorbis_adapter_publishes_the_fixture_pcm(make_dll, pair, max_batch):
     assert "symaccel_vorbis_synth" in h.bridge.calls
 
 
+@pytest.mark.parametrize("make_dll", LIBS)
+def test_two_pooled_vorbis_adapters_share_the_batcher(make_dll):
+    """`HipVorbisDecoder::try_new_pooled` over scripted front ends that hand on finished spectra (SYMACCEL_BATCH_VORBIS_SYNTH): two streams
+    of one block-size pair with DIFFERENT block flags behind look-ahead readers; the batches after each stream's first are written into
+    page-locked slots of ONE `Pool` (planes at their largest, packed data at the front) and the PCM is published from the slot."""
+    h = harness(make_dll, "vorbis.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    f = np.load(FIX / "vorbis.npz")
+    b0, b1 = 8, 11
+    k = "synth_%d_%d_" % (b0, b1)
+    flags0, prev0 = f[k + "flags"], int(f[k + "prev_flag"][0])
+    spectra0 = f32(f[k + "spectra"])
+    nch = spectra0.shape[0]
+    so0, _ = oracle.vorbis_layout(b0, b1, np.tile(flags0, (nch, 1)), np.full(nch, prev0))
+    decs, readers, wants, layouts = [], [], [], []
+    for s in range(2):
+        # stream 1: the fixture's blocks in reverse order (other flags at every position); expectation = the oracle from a reset state
+        order = list(range(flags0.size)) if s == 0 else list(range(flags0.size))[::-1]
+        flags = flags0[order]
+        blocks = [spectra0[:, so0[0, b]:so0[0, b + 1]] for b in order]
+        packed = np.ascontiguousarray(np.concatenate(blocks, axis=1))
+        fl = np.tile(flags, (nch, 1))
+        prev = np.full(nch, -1, np.int32)
+        so, po = oracle.vorbis_layout(b0, b1, fl, prev)
+        want = oracle.vorbis_synth(b0, b1, packed, fl, prev, np.zeros((nch, 1 << (b1 - 1)), np.float32), int(po[0, -1] + 3) & ~3)[0]
+        script = I.Arr([I.Struct("ParsedVorbis", {"trim": (usize(0), usize(0)), "long_block": bool(flags[b]), "spectra": f32_vec(blocks[b]),
+                                                   "fused": I.NONE}) for b in range(flags.size)], True)
+        front = I.Struct("ScriptedVorbisFront", {"nch": usize(nch), "bs0_exp": I.Int(b0, "i32"), "bs1_exp": I.Int(b1, "i32"), "script": script,
+                                                  "parses": usize(0), "resets": usize(0)})
+        r = h.it.call("HipVorbisDecoder::try_new_pooled", h.params("CODEC_ID_VORBIS", 44100, nch), h.opts(gapless=True), front, usize(3))
+        assert r.variant == "Ok", r
+        decs.append(r.f["0"])
+        packets = I.Arr([h.packet(key(t), 1000 * t, track=9 + s, owned=True) for t in range(flags.size)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", packets), usize(9)))
+        wants.append(np.asarray(want))
+        layouts.append(po)
+    for b in range(flags0.size):
+        for s in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[s])
+            st, got = h.decode("HipVorbisDecoder", decs[s], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            assert st == "ok"
+            if b == 0:
+                assert got.size == 0
+                continue
+            po = layouts[s]
+            ref = wants[s][:, po[0, b]:po[0, b + 1]]
+            assert got.shape == ref.shape and same(got, ref), (s, b)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1 and calls.count("symaccel_batcher_reserve") >= 4
+    assert "symaccel_batcher_collect" not in calls
+    stats = batcher_stats(h)
+    assert stats["launches"] < stats["submissions"] and stats["failed_tickets"] == 0, stats
+
+
 # ------------------------------------------------------------------------------------------------ FLAC
 
-@pytest.mark.parametrize("make_dll", LIBS)
-@pytest.mark.parametrize("bps,blocksize,max_batch", [(16, 192, 4), (24, 576, 1), (16, 60, 8)])
-def test_flac_adapter_restores_the_pcm(make_dll, bps, blocksize, max_batch):
-    """every subframe type, wasted bits and channel assignment through FlacBatch::transform / publish: the descriptors and
-    residuals are what the reference's parser would leave behind its seam (tests/flac_writer.py computes them while it
-    encodes), the PCM must come back exactly -- the encoder identity, the same criterion as config 5's"""
+def flac_script(rng, bps, blocksize, nfr, nch=2):
+    """what the reference's parser would leave behind its seam for `nfr` frames (tests/flac_writer.py computes it while it encodes):
+    (ParsedFlac script, the PCM per frame [channel][blocksize])"""
     import flac_writer as W
-    h = harness(make_dll, "flac.rs")
-    rng = np.random.default_rng(bps + blocksize)
-    nfr, nch = 9, 2
     script, pcm = [], []
     for t in range(nfr):
         chans = [rng.integers(-(1 << (bps - 2)), 1 << (bps - 2), blocksize) for _ in range(nch)]
@@ -297,6 +359,20 @@ def test_flac_adapter_restores_the_pcm(make_dll, bps, blocksize, max_batch):
         script.append(I.Struct("ParsedFlac", {"blocksize": usize(blocksize), "words": i32_vec(np.array(words)), "desc": I.Arr(descs, True),
                                                "coeffs": i32_vec(coeffs), "pair_mode": I.Int(mode, "u8"), "out_shift": I.Int(32 - bps, "u32")}))
         pcm.append(np.stack(chans))
+    return script, pcm
+
+
+
+@pytest.mark.parametrize("make_dll", LIBS)
+@pytest.mark.parametrize("bps,blocksize,max_batch", [(16, 192, 4), (24, 576, 1), (16, 60, 8)])
+def test_flac_adapter_restores_the_pcm(make_dll, bps, blocksize, max_batch):
+    """every subframe type, wasted bits and channel assignment through FlacBatch::transform / publish: the descriptors and
+    residuals are what the reference's parser would leave behind its seam (tests/flac_writer.py computes them while it
+    encodes), the PCM must come back exactly -- the encoder identity, the same criterion as config 5's"""
+    h = harness(make_dll, "flac.rs")
+    rng = np.random.default_rng(bps + blocksize)
+    nfr, nch = 9, 2
+    script, pcm = flac_script(rng, bps, blocksize, nfr, nch)
     params = h.params("CODEC_ID_FLAC", 44100, nch, bps=bps)
     front = I.Struct("ScriptedFlacFront", {"params": params, "nch": usize(nch), "max_bs": usize(blocksize), "script": I.Arr(script, True),
                                             "parses": usize(0)})
@@ -315,21 +391,48 @@ def test_flac_adapter_restores_the_pcm(make_dll, bps, blocksize, max_batch):
     assert "symaccel_flac_restore" in h.bridge.calls
 
 
+@pytest.mark.parametrize("make_dll", LIBS)
+def test_two_pooled_flac_adapters_share_the_batcher(make_dll):
+    """`HipFlacDecoder::try_new_pooled`: two streams (16 and 24 bit, the same maximum block size) behind look-ahead readers, decoded
+    alternately.  The batches after each stream's first are written straight into page-locked slots of ONE `Pool`
+    (`Pool::reserve` / `commit` / `wait` / `release`: SYMACCEL_BATCH_FLAC_RESTORE) and published from there; every packet's PCM is
+    the encoder's input, the two streams' subframes went to the device in common launches."""
+    h = harness(make_dll, "flac.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    blocksize, nfr = 96, 13
+    decs, readers, wants, shifts = [], [], [], []
+    for k, bps in enumerate((16, 24)):
+        rng = np.random.default_rng(700 + bps)
+        script, pcm = flac_script(rng, bps, blocksize, nfr)
+        params = h.params("CODEC_ID_FLAC", 44100, 2, bps=bps)
+        front = I.Struct("ScriptedFlacFront", {"params": params, "nch": usize(2), "max_bs": usize(blocksize), "script": I.Arr(script, True),
+                                                "parses": usize(0)})
+        r = h.it.call("HipFlacDecoder::try_new_pooled", params, h.opts(), front, usize(4))
+        assert r.variant == "Ok", r
+        decs.append(r.f["0"])
+        packets = I.Arr([h.packet(key(t), blocksize * t, track=5 + k, owned=True) for t in range(nfr)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", packets), usize(12)))
+        wants.append(pcm)
+        shifts.append(32 - bps)
+    for t in range(nfr):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            st, got = h.decode("HipFlacDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            want = wrap32(wants[k][t].astype(np.int64) << shifts[k])
+            assert st == "ok" and np.array_equal(got, want), (k, t)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1 and calls.count("symaccel_batcher_reserve") >= 4
+    assert calls.count("symaccel_batcher_wait") >= calls.count("symaccel_batcher_reserve") - 2
+    assert "symaccel_batcher_submit" not in calls and "symaccel_batcher_collect" not in calls  # zero-copy: no staging copies
+    stats = batcher_stats(h)
+    assert stats["launches"] < stats["submissions"], stats  # the two streams' batches shared launches
+
+
 # ------------------------------------------------------------------------------------------------ ALAC
 
-def wrap32(v):
-    return ((np.asarray(v, np.int64) + (1 << 31)) % (1 << 32)) - (1 << 31)
-
-
-@pytest.mark.parametrize("make_dll", LIBS)
-@pytest.mark.parametrize("depth,frames,max_batch", [(16, 160, 4), (24, 352, 1), (20, 64, 8)])
-def test_alac_adapter_restores_the_pcm(make_dll, depth, frames, max_batch):
-    """compressed and uncompressed elements, both predictor modes, orders up to 31, mid-side pairs, separately coded low bits and the
-    final left-justification through AlacBatch::transform / publish: the device predicts (symaccel_alac_predict), the adapter does
-    what follows on the copy out, in the decoder's order (symphonia-codec-alac/src/lib.rs:541-598, 409-414)"""
-    h = harness(make_dll, "alac.rs")
-    rng = np.random.default_rng(depth * 1000 + frames)
-    npk, nch = 9, 2
+def alac_script(rng, depth, frames, npk, nch=2):
+    """`npk` packets as the reference's parser leaves them behind its seam (residuals, predictors, pairs, low bits) and the PCM they
+    decode to [packet][channel][frames], left-justified"""
     script, want = [], []
     for t in range(npk):
         n = frames if t != npk - 1 else frames - 37  # the last packet of a stream is short
@@ -376,6 +479,19 @@ def test_alac_adapter_restores_the_pcm(make_dll, depth, frames, max_batch):
                                                "coeffs": i32_vec(coeffs), "pairs": I.Arr(pairs, True), "tails": I.Arr(tails, True),
                                                "out_shift": I.Int(32 - depth, "u32")}))
         want.append(wrap32(np.stack([wrap32(p) for p in planes]) << (32 - depth)))
+    return script, want
+
+
+@pytest.mark.parametrize("make_dll", LIBS)
+@pytest.mark.parametrize("depth,frames,max_batch", [(16, 160, 4), (24, 352, 1), (20, 64, 8)])
+def test_alac_adapter_restores_the_pcm(make_dll, depth, frames, max_batch):
+    """compressed and uncompressed elements, both predictor modes, orders up to 31, mid-side pairs, separately coded low bits and the
+    final left-justification through AlacBatch::transform / publish: the device predicts (symaccel_alac_predict), the adapter does
+    what follows on the copy out, in the decoder's order (symphonia-codec-alac/src/lib.rs:541-598, 409-414)"""
+    h = harness(make_dll, "alac.rs")
+    rng = np.random.default_rng(depth * 1000 + frames)
+    npk, nch = 9, 2
+    script, want = alac_script(rng, depth, frames, npk, nch)
     params = h.params("CODEC_ID_ALAC", 44100, nch, bps=depth)
     front = I.Struct("ScriptedAlacFront", {"params": params, "nch": usize(nch), "max_frames": usize(frames), "script": I.Arr(script, True),
                                             "parses": usize(0)})
@@ -391,6 +507,58 @@ def test_alac_adapter_restores_the_pcm(make_dll, depth, frames, max_batch):
     st, got = h.decode("HipAlacDecoder", dec, h.packet(key(2), 0))
     assert st == "ok" and np.array_equal(got, want[2])
     assert "symaccel_alac_predict" in h.bridge.calls
+
+
+@pytest.mark.parametrize("make_dll", LIBS)
+def test_two_pooled_alac_adapters_share_the_batcher(make_dll):
+    """`HipAlacDecoder::try_new_pooled`: two streams (16 and 24 bit, the same frame length) behind look-ahead readers, decoded
+    alternately; after each stream's first batch the element channels are written into page-locked slots of ONE `Pool`
+    (SYMACCEL_BATCH_ALAC_PREDICT), predicted in common launches, and what follows the predictor (mid/side, low bits,
+    left-justification) is applied in place in the slot at publish time."""
+    h = harness(make_dll, "alac.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    frames, npk = 160, 13
+    decs, readers, wants = [], [], []
+    for k, depth in enumerate((16, 24)):
+        script, want = alac_script(np.random.default_rng(900 + depth), depth, frames, npk)
+        params = h.params("CODEC_ID_ALAC", 44100, 2, bps=depth)
+        front = I.Struct("ScriptedAlacFront", {"params": params, "nch": usize(2), "max_frames": usize(frames), "script": I.Arr(script, True),
+                                                "parses": usize(0)})
+        r = h.it.call("HipAlacDecoder::try_new_pooled", params, h.opts(), front, usize(4))
+        assert r.variant == "Ok", r
+        decs.append(r.f["0"])
+        packets = I.Arr([h.packet(key(t), frames * t, track=7 + k, owned=True) for t in range(npk)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", packets), usize(12)))
+        wants.append(want)
+    for t in range(npk):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            st, got = h.decode("HipAlacDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            assert st == "ok" and np.array_equal(got, wants[k][t]), (k, t)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1 and calls.count("symaccel_batcher_reserve") >= 4
+    assert "symaccel_batcher_submit" not in calls and "symaccel_batcher_collect" not in calls
+    stats = batcher_stats(h)
+    assert stats["launches"] < stats["submissions"] and stats["failed_tickets"] == 0, stats
+
+
+def test_register_enters_all_five_decoders_at_the_preferred_tier():
+    """lib.rs `register()` EXECUTED: every decoder type of the crate is entered for its codec at Tier::Preferred through
+    `register_audio_decoder_at_tier::<D>` (codecs/registry.rs:252-269), above whatever the registry held (remembered: fallback.rs)"""
+    h = Harness(emu_dll())
+    h.load_shim("lib.rs", "ctx.rs", "decoder.rs", "lookahead.rs", "fallback.rs", "aac.rs", "mpa.rs", "vorbis.rs", "flac.rs", "alac.rs", "frontends.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "registry_generic.rs")
+    reg = h.it.call("CodecRegistry::new")
+    h.it.call("register", reg)
+    pref = I.Enum("Tier", "Preferred")
+    for cid in ("CODEC_ID_AAC", "CODEC_ID_MP3", "CODEC_ID_VORBIS", "CODEC_ID_FLAC", "CODEC_ID_ALAC"):
+        codec = h.it.resolve_value([cid], I.Env(), None)
+        r = h.it.call_method("CodecRegistry", "get_audio_decoder_at_tier", reg, pref, codec)
+        assert r.variant == "Some", cid
+        assert h.it.call("factory_below", codec).variant == "None"  # (nothing was registered below in this registry)
+    # a second register() on the same registry changes nothing (and cannot record the crate's own factories: fallback.rs)
+    h.it.call("register", reg)
+    assert h.it.call("factory_below", h.it.resolve_value(["CODEC_ID_FLAC"], I.Env(), None)).variant == "None"
 
 
 def test_the_ffi_bridge_leaves_the_bindings_ctypes_declarations_alone():

@@ -199,3 +199,42 @@ def test_look_ahead_batches_and_reset(trees):
     for i, ((st, got), want_r) in enumerate(zip(run(0, 3), again)):
         assert st == "ok" and got.shape == want_r.shape and np.array_equal(bits(got), bits(want_r)), i
     assert again[0].shape[1] == 0
+
+
+def test_decoders_built_by_the_registry_share_the_cross_stream_batcher(trees):
+    """What an application gets: `register()` enters HipVorbisDecoder at Tier::Preferred, `make_audio_decoder(params, opts)` builds every decoder
+    from (params, opts) alone (codecs/registry.rs:34-44, 252-269, 330-341) -- and the decoders so built find each other in the
+    process-wide `Pool`: two streams behind look-ahead readers, decoded alternately, every packet's PCM the reference decoder's bit for
+    bit, their batches in common launches (symaccel_batcher_get_stats)."""
+    from emu_lib import emu_library
+    from rs_harness import pool_stats, registry_round_trip
+    n, depth = sized((12, 6), (8, 4))
+    # two streams of one shape (block sizes, channels) from different seeds: their own codebooks, floors and packets
+    streams = [stream(11, n, 2, 6, 9, (2, 1), True), stream(12, n, 2, 6, 9, (1, 2), True)]
+    want = []
+    for s, packets in streams:
+        ref = Harness(None, reference=True, vorbis_tree=trees[0])
+        ref_dec = cpu_decoder(ref, s)
+        want.append([ref.decode("VorbisDecoder", ref_dec, ref.packet(pk, 0))[1] for pk, _ in packets])
+    h = Harness(emu_library().dll, reference=True, vorbis_tree=trees[1])
+    h.it.load_file(ROOT / "tests" / "rust" / "registry_stubs.rs")
+    h.it.load_file(ROOT / "tests" / "rust" / "mocks.rs")
+    h.load_shim("lib.rs", "ctx.rs", "decoder.rs", "lookahead.rs", "fallback.rs", "vorbis.rs", "frontends.rs")
+    decs = registry_round_trip(h, "HipVorbisDecoder", [h.params("CODEC_ID_VORBIS", 44100, s.nch, extra=s.extra_data()) for s, _ in streams])
+    readers = []
+    for k, (s, packets) in enumerate(streams):
+        pk = I.Arr([h.packet(d, i, track=1 + k, owned=True) for i, (d, _) in enumerate(packets)], True)
+        readers.append(h.it.call("LookaheadReader::new", h.it.call("MockReader::new", pk), usize(depth)))
+    for i in range(n):
+        for k in range(2):
+            r = h.it.call_method("LookaheadReader", "next_packet", readers[k])
+            st, got = h.decode("HipVorbisDecoder", decs[k], h.it.call_method("Packet", "as_packet_ref", r.f["0"].f["0"]))
+            assert st == "ok" and got.shape == want[k][i].shape and np.array_equal(bits(got), bits(want[k][i])), (k, i)
+    calls = h.bridge.calls
+    assert calls.count("symaccel_batcher_create") == 1 and calls.count("symaccel_batcher_reserve") >= 2
+    assert calls.count("symaccel_batcher_vorbis_floor") >= 2           # every stream's floor configurations are the batcher's
+    assert calls.count("symaccel_vorbis_decode") == 2                   # each stream's cold start only: residue + posts in, PCM out
+    kinds = [a["kind"] for name, a in h.bridge.scalars if name == "symaccel_batcher_reserve"]
+    assert kinds and all(kd == 6 for kd in kinds), kinds               # SYMACCEL_BATCH_VORBIS_DECODE: coupling, floors and synthesis on the device
+    stats = pool_stats(h)
+    assert stats["submissions"] >= 2 and stats["launches"] < stats["submissions"] and stats["failed_tickets"] == 0, stats

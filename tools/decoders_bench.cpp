@@ -9,7 +9,7 @@
 // peek that copies the next packet out of a small pool (a parser writes its output somewhere too).  Nothing here links the
 // oracle: bench.py times the CPU port beside this with its own harness.  One JSON line on stdout.
 //
-//   decoders_bench --codec aac|aacd|mp3|mp3h|vorbis --streams S --lookahead L --packets P --threads T [--per-stream] [--direct] [--in-phase] [--flush-mb M] [--lanes N]
+//   decoders_bench --codec aac|aacd|mp3|mp3h|vorbis|flac --streams S --lookahead L --packets P --threads T [--per-stream] [--direct] [--in-phase] [--flush-mb M] [--lanes N]
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -105,6 +105,22 @@ std::vector<Vorbis::Packet> make_pool<Vorbis>(unsigned seed) {  // BASELINE conf
     return pool;
 }
 
+template <>
+std::vector<Flac::Packet> make_pool<Flac>(unsigned seed) {  // BASELINE config 5's shape per packet: two subframes of 4096 samples, LPC order 32, 24 bits
+    std::mt19937 rng(seed);
+    std::vector<Flac::Packet> pool(kPool);
+    for (auto &p : pool) {
+        p.blocksize = 4096;
+        p.words.resize(2 * 4096);
+        for (auto &v : p.words) v = (int32_t)(rng() % 2001) - 1000;
+        p.desc.assign(2, symaccel_flac_desc{SYMACCEL_FLAC_LPC, 32, 12, 0});
+        p.coeffs.resize(2 * 32);
+        for (auto &c : p.coeffs) c = (int32_t)(rng() % 401) - 200;
+        p.pair_mode = (uint8_t)(rng() % 4);
+    }
+    return pool;
+}
+
 static const uint16_t kSwbLong[] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216,
                                     240, 264, 292, 320, 352, 384, 416, 448, 480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800, 832, 864, 896,
                                     928, 1024};
@@ -194,6 +210,8 @@ template <>
 Mp3Huffman::Params params<Mp3Huffman>() { return Mp3Huffman::Params{2, 2, 0}; }
 template <>
 Vorbis::Params params<Vorbis>() { return Vorbis::Params{8, 8, 11}; }
+template <>
+Flac::Params params<Flac>() { return Flac::Params{2, 24, 4096}; }
 
 template <class Codec>
 int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t bytes_in_per_packet) {
@@ -349,6 +367,7 @@ int main(int argc, char **argv) {
         if (a.codec == "mp3h") return run<Mp3Huffman>(a, "mp3h", 1152, 4 * 576 * 2 + 4 * 52 + 2 * 48 + 16);
         // (Vorbis: 8 channels, nine blocks in ten long -- the per-packet figures are those of a long block after a long block)
         if (a.codec == "vorbis") return run<Vorbis>(a, "vorbis", 1024, 8 * 1024 * 4);
+        if (a.codec == "flac") return run<Flac>(a, "flac", 4096, 2 * 4096 * 4 + 2 * 132 + 1);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "decoders_bench: %s\n", e.what());
         return 1;

@@ -10,6 +10,11 @@ What the crate does with raw pointers is little, and all of it is modelled by va
   slice::from_raw_parts(_mut)(ptr, n)   a slice over the first n elements
   v.as_ptr() / v.as_mut_ptr()           the Vec / slice itself (interp.builtin_method)
   CStr::from_ptr(p)                     the Python str a `*const c_char` result was turned into
+  pointers INSIDE a struct the library fills in (symaccel_batch_slot: the planes of a reservation with the cross-stream batcher)
+                                        are REAL addresses: `CPtr`.  `p as *mut T` gives the address an element type,
+                                        slice::from_raw_parts(_mut) over it is a slice whose storage is the C memory itself (`MemList`):
+                                        what the crate writes there is what libsymaccel's copy kernels read -- the zero-copy path of
+                                        ctx.rs `BatchSlot` is executed, not modelled
 
 A call of a bound function marshals every pointer argument into a numpy array of the element type the DECLARATION in
 bindings/rust/symaccel_sys.rs gives it (scalars, or #[repr(C)] structs as structured dtypes), calls the C function, and copies
@@ -90,9 +95,88 @@ class RawMem:
         raise I.InterpError('no method %s on a raw pointer' % name)
 
 
+class CPtr:
+    """a real address inside memory libsymaccel owns (a plane of a symaccel_batch_slot), with the element type the crate cast it to"""
+
+    def __init__(self, bridge, addr, elem='c_void'):
+        self.bridge, self.addr, self.elem = bridge, int(addr), elem
+
+    def __repr__(self):
+        return 'CPtr(%#x as *%s)' % (self.addr, self.elem)
+
+    def rs_ptr_cast(self, elem):
+        return CPtr(self.bridge, self.addr, elem)
+
+    def rs_method(self, it, name, args):
+        if name == 'is_null':
+            return self.addr == 0
+        if name in ('add', 'offset'):
+            return CPtr(self.bridge, self.addr + int(I.deref(args[0]).v) * self.bridge.dtype(self.elem).itemsize, self.elem)
+        if name in ('cast', 'cast_mut', 'cast_const'):
+            return self
+        if name in ('read', 'write'):
+            mem = MemList(self.bridge, self.addr, self.elem, 1)
+            if name == 'read':
+                return mem[0]
+            mem[0] = args[0]
+            return I.UNIT
+        raise I.InterpError('no method %s on a raw pointer' % name)
+
+
+class MemList:
+    """list-like storage of a Slice over C memory: element reads and writes go to the memory itself"""
+
+    def __init__(self, bridge, addr, elem, n):
+        self.bridge, self.elem, self.n = bridge, elem, n
+        self.dt = bridge.dtype(elem)
+        self.like = I.Struct(elem.split('::')[-1], {}) if self.dt.names else None
+        self.arr = np.frombuffer((C.c_char * (n * self.dt.itemsize)).from_address(addr), dtype=self.dt) if n else np.zeros(0, self.dt)
+
+    def __len__(self):
+        return self.n
+
+    def _get(self, i):
+        return self.bridge.from_np(self.arr[i], self.dt, self.like)
+
+    def _set(self, i, v):
+        self.arr[i] = self.bridge.to_np(I.deref(v), self.dt)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._get(j) for j in range(*i.indices(self.n))]
+        if i < 0 or i >= self.n:
+            raise I.RustPanic('index out of bounds: the len is %d but the index is %d' % (self.n, i))
+        return self._get(i)
+
+    def __setitem__(self, i, v):
+        if isinstance(i, slice):
+            idx = range(*i.indices(self.n))
+            v = list(v)
+            if len(v) != len(idx):
+                raise I.InterpError('a slice over C memory cannot change its length')
+            if v and not self.dt.names and all(isinstance(x, (I.Int, float, np.floating, int)) for x in v):  # the common case in one go
+                self.arr[idx.start:idx.stop:idx.step] = np.array([x.v if isinstance(x, I.Int) else x for x in v]).astype(self.dt)
+                return
+            for j, x in zip(idx, v):
+                self._set(j, x)
+            return
+        if i < 0 or i >= self.n:
+            raise I.RustPanic('index out of bounds: the len is %d but the index is %d' % (self.n, i))
+        self._set(i, v)
+
+    def __iter__(self):
+        return (self._get(i) for i in range(self.n))
+
+
 def from_raw_parts(ptr, n, mut):
     ptr = I.deref(ptr)
     n = int(I.deref(n).v)
+    if isinstance(ptr, CPtr):
+        if ptr.elem.split('::')[-1] == 'c_void':
+            raise I.InterpError('slice::from_raw_parts over an untyped pointer: cast it first')
+        if ptr.addr == 0 and n:
+            raise I.RustPanic('slice::from_raw_parts over a null pointer')
+        return I.Slice(MemList(ptr.bridge, ptr.addr, ptr.elem, n), 0, n, mut)
     if isinstance(ptr, RawMem):
         ptr.need(ptr.off + n)
         return I.Slice(ptr.arr.a, ptr.off, n, mut)
@@ -160,6 +244,9 @@ class Bridge:
         # symaccel_batcher_submit_* return before the library writes the `*_io` / `pcm` arrays (symaccel_batcher_collect does): the
         # marshalled arrays of a submission are kept, keyed by its ticket, and copied back into the interpreter's values at collect
         self.deferred = {}
+        self.ptr_fields = set()  # (struct, field) pairs that hold addresses
+        self.word_fields = {}    # (struct, field) -> 'usize' / 'isize'
+        it.size_of_struct = lambda name: self.dtype(name).itemsize  # std::mem::size_of::<T>() of a #[repr(C)] record
         self.calls = []  # (name) log, for the tests
         self.scalars = []  # per call: (name, {parameter: value}) for the integer arguments passed by value
         for name in self.decls:
@@ -178,9 +265,18 @@ class Bridge:
         fields = []
         for fname, fty in item[3]:
             fields.append((fname,) + self.field_dtype(fty))
+            inner = fty
+            while inner[0] == 'tarray':
+                inner = inner[1]
+            if inner[0] == 'tptr':
+                self.ptr_fields.add((base, fname))
+            elif inner[0] == 'tpath' and inner[1][-1] in ('usize', 'isize'):
+                self.word_fields[(base, fname)] = inner[1][-1]  # (u64 / i64 on the wire; `usize` to the crate)
         return np.dtype(fields)
 
     def field_dtype(self, fty):
+        if fty[0] == 'tptr':  # an address (symaccel_batch_slot's planes)
+            return (np.dtype(np.uint64),)
         if fty[0] == 'tarray':
             n = int(self.it.ev(fty[2], I.Env()).v) if not isinstance(fty[2], int) else fty[2]
             inner = self.field_dtype(fty[1])
@@ -197,6 +293,10 @@ class Bridge:
             return tuple(out)
         if isinstance(v, I.Int):
             return v.v
+        if isinstance(v, CPtr):
+            return v.addr
+        if isinstance(v, (Null, Handle)):
+            return getattr(v, 'p', 0) or 0
         if v is I.UNINIT or v is None:
             return 0
         if isinstance(v, (bool, np.bool_)):
@@ -216,13 +316,22 @@ class Bridge:
     def from_np(self, x, dt, like):
         if dt.names:
             f = {}
+            sname = like.name if isinstance(like, I.Struct) else '?'
             for fname in dt.names:
                 sub = dt.fields[fname][0]
-                if sub.shape:
-                    f[fname] = I.Arr([self.from_np(y, sub.base, None) for y in np.asarray(x[fname]).reshape(-1)])
+                ptr = (sname, fname) in self.ptr_fields
+                word = self.word_fields.get((sname, fname))
+                if ptr:
+                    conv = lambda y: CPtr(self, int(y)) if int(y) else NULL  # noqa: E731
+                elif word:
+                    conv = lambda y, _w=word: I.Int(int(y), _w)  # noqa: E731
                 else:
-                    f[fname] = self.from_np(x[fname], sub, None)
-            return I.Struct(like.name if isinstance(like, I.Struct) else '?', f)
+                    conv = lambda y, _b=sub.base if sub.shape else sub: self.from_np(y, _b, None)  # noqa: E731
+                if sub.shape:
+                    f[fname] = I.Arr([conv(y) for y in np.asarray(x[fname]).reshape(-1)])
+                else:
+                    f[fname] = conv(x[fname])
+            return I.Struct(sname, f)
         if dt.kind == 'f':
             return I.F32(x) if dt.itemsize == 4 else float(x)
         name = {v: k for k, v in SCALARS.items() if k[0] in 'iu' and k not in ('usize', 'isize')}.get(dt.type, 'i32')
@@ -268,6 +377,11 @@ class Bridge:
                 cargs.append(arr.ctypes.data_as(C.c_void_p))
                 if mut:
                     after.append(('scalar', v, arr, dt, x))
+            elif isinstance(x, I.Struct):  # `&record` for a `*const Record` parameter
+                dt = self.dtype(elem)
+                arr = np.array([self.to_np(x, dt)], dtype=dt)
+                keep.append(arr)
+                cargs.append(arr.ctypes.data_as(C.c_void_p))
             else:
                 if isinstance(x, RawMem):
                     x = I.Slice(x.arr.a, x.off, len(x.arr.a) - x.off, True)

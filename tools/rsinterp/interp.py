@@ -1712,6 +1712,12 @@ class Interp:
     def e_cast(self, e, env):
         v = deref(self.ev(e[1], env))
         ty = e[2]
+        if ty[0] == 'tptr' and hasattr(v, 'rs_ptr_cast'):  # a real address (rsinterp/ffi.py CPtr): the cast names its element type
+            inner = ty[1]
+            name = self.type_name(inner)
+            if name in env.generics and isinstance(env.generics[name], tuple) and env.generics[name][0] == 'tpath':
+                name = env.generics[name][1][-1]
+            return v.rs_ptr_cast(name)
         if ty[0] != 'tpath':
             return v
         name = ty[1][-1]
@@ -1963,10 +1969,16 @@ class Interp:
             if segs[-1] == 'size_of' and gargs and not args:  # std::mem::size_of::<T>() of a primitive
                 tn = self.type_name(gargs[0][1]) if isinstance(gargs[0], tuple) and gargs[0][0] == 'gtype' else None
                 tn = env.generics.get(tn, tn) if getattr(env, 'generics', None) else tn
+                if isinstance(tn, tuple) and tn[0] == 'tpath':  # a type parameter bound by a turbofish (`slot.input::<f32>(0)`)
+                    tn = tn[1][-1]
+                if not isinstance(tn, str):
+                    tn = None
                 if tn in INT_BITS:
                     return Int(INT_BITS[tn] // 8, 'usize')
                 if tn in FLOAT_TYPES:
                     return Int(4 if tn == 'f32' else 8, 'usize')
+                if isinstance(tn, str) and tn in self.types and self.types[tn][0] == 'struct' and getattr(self, 'size_of_struct', None):
+                    return Int(self.size_of_struct(tn), 'usize')  # a #[repr(C)] record of the FFI (rsinterp/ffi.py)
                 # a type parameter inferred from a declared type the interpreter does not track (Pinned<T>::new): memory
                 # is modelled by value (rsinterp/ffi.py RawMem), so a byte count only has to be positive
                 return Int(1, 'usize')
