@@ -174,6 +174,14 @@ bool plane_sizes(int kind, int param, size_t units, PlaneSizes *ps) {
 
 size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// What a launch costs is not the same for every kind: the FLAC / ALAC kernels walk a block's recurrence with ONE lane (4096 samples at
+// ~120 ns each: half a millisecond whatever the launch holds), so their groups are worth launching only when they are large -- four
+// times the input of the transform kinds before a group goes unasked, and a hint launches nothing below `flush_bytes`
+// (measured: 0.39 -> 0.74 M packets/s of 4096-sample stereo frames at 256 streams, profiles/r06k_decoders.jsonl).
+inline bool serial_kind(int kind) { return kind == SYMACCEL_BATCH_FLAC_RESTORE || kind == SYMACCEL_BATCH_ALAC_PREDICT; }
+inline size_t flush_threshold(size_t flush_bytes, int kind) { return serial_kind(kind) ? 4 * flush_bytes : flush_bytes; }
+inline size_t hint_threshold(size_t hint_bytes, size_t flush_bytes, int kind) { return serial_kind(kind) ? std::max(hint_bytes, 2 * flush_bytes) : hint_bytes; }
+
 inline size_t plane_bytes(const PlaneSizes &ps, int i, size_t n_chains) {
     return ps.in_per_ticket[i] ? ps.in[i] : ps.in[i] * (n_chains / ps.in_div[i]);
 }
@@ -1263,7 +1271,7 @@ Group *open_group(symaccel_batcher *b, int kind, int param, size_t units, const 
     g->ps = ps;
     g->param = param;
     // what a group takes before it is launched unasked: flush_bytes of input
-    g->cap_chains = std::max<size_t>(n_chains, std::max<size_t>(2, b->flush_bytes / std::max<size_t>(1, in_bytes_per_chain(ps))));
+    g->cap_chains = std::max<size_t>(n_chains, std::max<size_t>(2, flush_threshold(b->flush_bytes, kind) / std::max<size_t>(1, in_bytes_per_chain(ps))));
     g->chains = g->tickets = g->uncommitted = g->live = 0;
     g->ticket_ids.clear();
     g->status = SYMACCEL_OK;
@@ -1446,7 +1454,7 @@ int symaccel_batcher_commit(symaccel_batcher *b, uint64_t ticket) {
     g->uncommitted -= 1;
     if (g->uncommitted == 0) b->cv.notify_all();
     // enough input has piled up: to the device, nobody has to ask
-    if (g->state == GroupState::Open && g->chains * in_bytes_per_chain(g->ps) >= b->flush_bytes) flush_group(b, g, locked.lock);
+    if (g->state == GroupState::Open && g->chains * in_bytes_per_chain(g->ps) >= flush_threshold(b->flush_bytes, g->kind)) flush_group(b, g, locked.lock);
     return SYMACCEL_OK;
 }
 
@@ -1463,9 +1471,9 @@ int symaccel_batcher_hint(symaccel_batcher *b) {
     Locked locked(b);
     // "results will be wanted soon": whatever is worth a launch of its own goes now, so that the copies and the kernels run while
     // the callers are still busy with their current batches; a group below that size waits for more submissions (or for a waiter)
-    const size_t worth = b->hint_bytes;
     for (size_t i = 0; i < b->groups.size(); ++i) {
         Group *g = b->groups[i].get();
+        const size_t worth = hint_threshold(b->hint_bytes, b->flush_bytes, g->kind);
         if (g->state == GroupState::Open && g->tickets && g->chains * in_bytes_per_chain(g->ps) >= worth) flush_group(b, g, locked.lock);
     }
     return SYMACCEL_OK;
