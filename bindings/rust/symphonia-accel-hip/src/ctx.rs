@@ -144,6 +144,22 @@ impl BatchSlot {
 }
 
 impl Pool {
+    /// `check` for calls into the batcher: a device error's text is the BATCHER's (`symaccel_batcher_last_error`, copied under its
+    /// mutex) -- the shared context's own error string may be written by another thread's launch at any time.
+    fn check(&self, status: i32) -> Result<()> {
+        if status >= 0 || status == ffi::SYMACCEL_ERR_INVALID_ARG || status == ffi::SYMACCEL_ERR_UNSUPPORTED || status == ffi::SYMACCEL_ERR_DECODE {
+            return check(status, ptr::null());
+        }
+        let mut text = [0 as core::ffi::c_char; 256];
+        // SAFETY: a live batcher; `text` has room for 256 bytes including the terminator the library writes.
+        unsafe { ffi::symaccel_batcher_last_error(self.batcher, text.as_mut_ptr(), text.len()) };
+        // SAFETY: NUL-terminated by the library (or all zeros).
+        let detail = unsafe { CStr::from_ptr(text.as_ptr()) }.to_string_lossy().into_owned();
+        // SAFETY: symaccel_strerror returns a pointer to a static NUL-terminated string.
+        let msg = unsafe { CStr::from_ptr(ffi::symaccel_strerror(status)) }.to_str().unwrap_or("symaccel: error");
+        Err(Error::IoError(std::io::Error::other(format!("{msg}: {detail}"))))
+    }
+
     /// `symaccel_batcher_reserve`: a slot for `n_chains` chains of `units` frames / granules / blocks / words each.
     pub fn reserve(&self, kind: i32, param: i32, n_chains: usize, units: usize) -> Result<BatchSlot> {
         let mut raw = ffi::SymaccelBatchSlot {
@@ -156,14 +172,14 @@ impl Pool {
         };
         let mut ticket = 0u64;
         // SAFETY: a live batcher, valid out-pointers.
-        check(unsafe { ffi::symaccel_batcher_reserve(self.batcher, kind, param, n_chains, units, &mut raw, &mut ticket) }, self.ctx.raw())?;
+        self.check(unsafe { ffi::symaccel_batcher_reserve(self.batcher, kind, param, n_chains, units, &mut raw, &mut ticket) })?;
         Ok(BatchSlot { raw, ticket, committed: false })
     }
 
     /// The slot is filled: it goes to the device with the next launch of its group.
     pub fn commit(&self, slot: &mut BatchSlot) -> Result<()> {
         // SAFETY: a live ticket of this batcher.
-        check(unsafe { ffi::symaccel_batcher_commit(self.batcher, slot.ticket) }, self.ctx.raw())?;
+        self.check(unsafe { ffi::symaccel_batcher_commit(self.batcher, slot.ticket) })?;
         slot.committed = true;
         Ok(())
     }
@@ -172,7 +188,7 @@ impl Pool {
     /// not add up fails alone, the neighbours of its launch do not (include/symaccel.h, "Status is kept PER TICKET").
     pub fn wait(&self, slot: &mut BatchSlot) -> Result<()> {
         // SAFETY: a live, committed ticket; the slot record is filled in again with the same pointers.
-        check(unsafe { ffi::symaccel_batcher_wait(self.batcher, slot.ticket, &mut slot.raw) }, self.ctx.raw())
+        self.check(unsafe { ffi::symaccel_batcher_wait(self.batcher, slot.ticket, &mut slot.raw) })
     }
 
     /// Give the slot back (a reservation that was never committed runs as zeros with its group; nobody looks at the result).
@@ -210,7 +226,7 @@ impl Pool {
             blocks: 0,
         };
         // SAFETY: a live batcher, a valid out-pointer.
-        check(unsafe { ffi::symaccel_batcher_get_stats(self.batcher, &mut s) }, self.ctx.raw())?;
+        self.check(unsafe { ffi::symaccel_batcher_get_stats(self.batcher, &mut s) })?;
         Ok(s)
     }
 
@@ -219,7 +235,7 @@ impl Pool {
     pub fn vorbis_floor(&self, cfg: &ffi::SymaccelVorbisFloor1Cfg) -> Result<u8> {
         let mut index: i32 = -1;
         // SAFETY: a live batcher, a valid record, a valid out-pointer.
-        check(unsafe { ffi::symaccel_batcher_vorbis_floor(self.batcher, cfg, &mut index) }, self.ctx.raw())?;
+        self.check(unsafe { ffi::symaccel_batcher_vorbis_floor(self.batcher, cfg, &mut index) })?;
         Ok(index as u8)
     }
 }

@@ -12,6 +12,7 @@ if str(ROOT) not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / at round end)")
     config.addinivalue_line("markers", "localref: needs /root/reference (build container only)")
+    config.addinivalue_line("markers", "sanitize: the host C++ under ASan + UBSan / TSan on the emulation build (CPU only; part of the default CPU suite)")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -75,5 +75,46 @@ def _build(force=False):
     return out
 
 
+HOST_SOURCES = ["tables.cpp", "ctx.cpp", "host_tools.cpp", "stage.cpp", "batcher.cpp", "multi.cpp"]
+SANITIZERS = {"asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"],
+              "tsan": ["-fsanitize=thread", "-fno-omit-frame-pointer"]}
+
+
+def build_sanitized(kind):
+    """The emulation library with the HOST C++ of the product (ctx / stage / batcher / multi / host_tools / tables) compiled under a
+    sanitizer (`asan`: AddressSanitizer + UndefinedBehaviorSanitizer; `tsan`: ThreadSanitizer).  The kernels and the emulation runtime
+    switch stacks by hand (emu_rt.cpp: work-items are fibers) and stay uninstrumented: what is checked is the code that holds locks,
+    owns memory and talks to the runtime.  -> tests/emu/build/<kind>/libsymaccel_emu_<kind>.so"""
+    import fcntl
+    flags = SANITIZERS[kind]
+    with open(HERE / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        objdir = HERE / "build" / kind
+        out = objdir / ("libsymaccel_emu_%s.so" % kind)
+        if out.exists() and not needs_build(out):
+            return out
+        objdir.mkdir(exist_ok=True, parents=True)
+        procs, objs = [], []
+        for src in SOURCES + ["../../tests/emu/emu_rt.cpp"]:
+            path = (CSRC / src).resolve()
+            obj = objdir / (path.name.replace(".", "_") + ".o")
+            extra = flags + ["-g"] if src in HOST_SOURCES else []
+            cmd = ["g++", "-x", "c++", *FLAGS, *extra, "-I", str(HERE / "include"), "-I", str(CSRC), "-c", str(path), "-o", str(obj)]
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            objs.append(str(obj))
+        bad = False
+        for src, p in procs:
+            log, _ = p.communicate()
+            if p.returncode != 0:
+                bad = True
+                sys.stderr.write("==== %s ====\n%s\n" % (src, log.decode(errors="replace")[-6000:]))
+        if bad:
+            raise RuntimeError("sanitized emulation build failed")
+        tmp = out.with_suffix(".so.%d.tmp" % os.getpid())
+        subprocess.run(["g++", "-shared", "-pthread", *flags, "-o", str(tmp), *objs], check=True)
+        os.replace(tmp, out)
+        return out
+
+
 if __name__ == "__main__":
-    print(build(force=True))
+    print(build_sanitized(sys.argv[1]) if len(sys.argv) > 1 else build(force=True))

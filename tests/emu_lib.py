@@ -13,9 +13,13 @@ _lib = None
 def emu_library():
     global _lib
     if _lib is None:
+        import os
         import build_emu
         from symphonia_amd import Library
-        _lib = Library(build_emu.build())
+        # SYMACCEL_EMU_SANITIZED=asan|tsan: the build whose host C++ is compiled under a sanitizer (tests/test_sanitizers.py runs the
+        # batcher suites that way, with the sanitizer's runtime pre-loaded into the interpreter)
+        kind = os.environ.get("SYMACCEL_EMU_SANITIZED", "")
+        _lib = Library(build_emu.build_sanitized(kind) if kind else build_emu.build())
     return _lib
 
 
