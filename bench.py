@@ -197,6 +197,99 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d) from mid/side- and intensity-coded spectra (60 %% / 20 %% of the bands): %s"
                         % (frames, nch, nfr, "joint stereo on load in the synthesis kernel" if name == "aacjs" else "joint-stereo kernel in place, then synthesis"),
             "channel_frames": nch * nfr}, "aac_synth_quad_kernel<true>" if name == "aacjs" else "aac_joint_stereo_kernel + aac_synth_quad_kernel", pcm
+    if name == "aactns":
+        # config 2 as a REAL joint-stereo stream with temporal noise shaping looks: coded spectra + the pairs' stereo maps + TNS filters
+        # -> PCM, the device-resident kernel sequence of symaccel_aac_decode_pipelined / SYMACCEL_BATCH_AAC_DECODE (ics/mod.rs:449-468,
+        # cpe.rs:110-157, ics/tns.rs:149-199): a LIST pass decodes the joint stereo of the pair frames that carry a filter in place,
+        # the filters run (one lane per filter: the recurrence is serial along the spectrum), then ONE walk decodes the joint stereo
+        # of every other frame on load and synthesises all of them.  30 % of the channel frames carry one order-12 filter over
+        # lines 160..672; 60 % / 20 % of the bands mid/side / intensity.  The list pass and the filters work in place, so the
+        # spectra drift from step to step (timing only, like aacjs2); `verify` runs the sequence once on a pristine copy.
+        nch, nfr = max(2, int(128 * scale)) & ~1, (6 if emulate else 1024)
+        coeffs = torch.randn((nch, nfr, 1024), generator=g, device=dev, dtype=torch.float32)
+        coeffs *= torch.exp2(torch.randint(-8, 13, (nch, nfr, 64), generator=g, device=dev).float()).repeat_interleave(16, dim=2)
+        coeffs[:, :, 672:] = 0.0
+        pristine = coeffs.clone()
+        side = torch.full((nch, nfr), int(sa.aac_side(0, 1, 1)), dtype=torch.uint8, device=dev)
+        swb_long = [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216, 240, 264, 292, 320,
+                    352, 384, 416, 448, 480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800, 832, 864, 896, 928, 1024]
+        swb_short = [0, 4, 8, 12, 16, 20, 28, 36, 44, 56, 68, 80, 96, 112, 128]
+        rng = np.random.default_rng(seed)
+        n_pairs = nch // 2
+        desc = np.zeros((n_pairs, nfr), sa.AAC_JS_DTYPE)
+        desc["num_windows"], desc["max_sfb"] = 1, 40
+        desc["mode"] = rng.choice([0, 1, 1, 1, 1, 1, 1, 2, 2, 0], (n_pairs, nfr, 128)).astype(np.uint8)
+        desc["scale"] = (rng.standard_normal((n_pairs, nfr, 128)) * 0.5).astype(np.float32)
+        has = rng.random((nch, nfr)) < 0.30
+        cf = np.argwhere(has)
+        filt = np.zeros(len(cf), sa.AAC_TNS_DTYPE)
+        filt["frame"] = (cf[:, 0] * nfr + cf[:, 1]).astype(np.uint32)
+        filt["start"], filt["end"], filt["order"] = 160, 672, 12
+        filt["direction"] = rng.integers(0, 2, len(cf)).astype(np.uint8)
+        filt["lpc"][:, :12] = (rng.integers(-4, 5, (len(cf), 12)) * 0.05 * 0.8 ** np.arange(12)).astype(np.float32)
+        filt = filt[rng.permutation(len(filt))]
+        pair_has = has[0::2] | has[1::2]                                   # pair p = chains (2p, 2p + 1)
+        pf = np.flatnonzero(pair_has.ravel()).astype(np.uint32)            # pair * nfr + frame
+        desc_walk = desc.copy()
+        desc_walk["mode"][pair_has] = 0                                    # what the list pass leaves for the walk (launch_aac_js_consume)
+        d_desc = torch.from_numpy(desc.view(np.uint8).reshape(n_pairs, nfr, 644)).to(dev)
+        d_desc_walk = torch.from_numpy(desc_walk.view(np.uint8).reshape(n_pairs, nfr, 644)).to(dev)
+        d_filt = torch.from_numpy(filt.view(np.uint8).reshape(-1, 92)).to(dev)
+        d_pf = torch.from_numpy(pf.view(np.int32)).to(dev)
+        pairs = np.arange(nch, dtype=np.int32).reshape(n_pairs, 2)
+        d_pairs = torch.from_numpy(pairs).to(dev)
+        delay = [torch.zeros((nch, 1024), device=dev, dtype=torch.float32) for _ in range(2)]
+        pcm = torch.empty_like(coeffs)
+        tools = sa.AacSpectralTools(ctx, swb_long, swb_short)
+
+        def sequence(x, d_in, d_out):
+            tools.joint_stereo_list(x, d_pairs, d_desc, d_pf)
+            tools.tns(x, d_filt, len(filt))
+            tools.synth_joint_stereo(x, side, d_in, d_pairs, d_desc_walk, pcm, delay_out=d_out)
+
+        def step():
+            sequence(coeffs, delay[0], delay[1])
+            delay.reverse()
+        step.input = coeffs
+
+        def verify():
+            import oracle
+            x = pristine.clone()
+            sequence(x, torch.zeros_like(delay[0]), delay[1])
+            sync_dev()
+            bad = checked = 0
+            vr = verify_rng()
+            picked = sorted({0, n_pairs - 1, int(vr.integers(0, n_pairs))})
+            for p_ in picked:
+                l, r = int(pairs[p_, 0]), int(pairs[p_, 1])
+                a = int(vr.integers(0, max(1, nfr - 24)))
+                for fr in (slice(0, min(nfr, 16)), slice(a, min(nfr, a + 16))):
+                    f0 = max(0, fr.start - 1)  # (one frame of halo: the delay line of a frame depends on the previous frame's input alone)
+                    cl, cr = pristine[l, f0:fr.stop].cpu().numpy(), pristine[r, f0:fr.stop].cpu().numpy()
+                    dl, dr = cl.copy(), cr.copy()
+                    for i in range(cl.shape[0]):
+                        f = f0 + i
+                        dl[i], dr[i] = oracle.aac_joint_stereo(cl[i], cr[i], 1, 40, swb_long, desc[p_, f]["mode"], desc[p_, f]["scale"])
+                        for ch, buf in ((l, dl), (r, dr)):
+                            for q in filt[filt["frame"] == ch * nfr + f]:
+                                buf[i] = oracle.aac_tns_filter(buf[i], int(q["start"]), int(q["end"]), int(q["order"]), int(q["direction"]), q["lpc"][:int(q["order"])])
+                    want, _ = oracle.aac_synth(np.stack([dl, dr]), side[[l, r], f0:fr.stop].cpu().numpy(), np.zeros((2, 1024), np.float32))
+                    got = pcm[[l, r], fr].cpu().numpy()
+                    bad += int((got != want[:, fr.start - f0:]).sum())
+                    checked += got.size
+            if bad:
+                raise RuntimeError("bench: the aactns batch differs from the oracle in %d of %d sampled samples" % (bad, checked))
+            return {"checker": "oracle/symoracle.c (joint stereo, TNS, then Dsp::synth), outside the timed region, on a pristine copy of the spectra",
+                    "pairs": picked, "seed": VERIFY_SEED, "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
+        step.verify = verify
+        frames = nch * nfr // 2
+        bytes_alg = nch * nfr * 8192 + n_pairs * nfr * 644 + len(filt) * 92
+        return step, frames, "frames", bytes_alg, {
+            "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d) from mid/side- and intensity-coded spectra (60 %% / 20 %% of the bands) with "
+                        "one order-12 TNS filter on 30 %% of the channel frames (%d filters, %d of %d pair frames take the list pass): joint-stereo list pass, "
+                        "filters, one walk" % (frames, nch, nfr, len(filt), len(pf), n_pairs * nfr),
+            "channel_frames": nch * nfr, "tns_filters": int(len(filt)), "tns_pair_frames": int(len(pf))}, \
+            "aac_joint_stereo_kernel (list) + aac_tns_kernel + aac_synth_quad_kernel<true>", pcm
     if name in ("mp3q", "mp3q2"):
         # config 3 from what the ENTROPY DECODER produces: int16 Huffman samples + the 52-byte requantize record per granule-channel
         # + one 48-byte joint-stereo record per granule of a pair, every stream a mid/side pair, long blocks.
@@ -592,6 +685,13 @@ def sample_clocks(step, sync):
         return None
 
 
+VERIFY_SEED = None  # per-run seed of the verification samples (main() draws it; printed in the line as `verified.seed`)
+
+
+def verify_rng():
+    return np.random.default_rng(VERIFY_SEED if VERIFY_SEED is not None else 0)
+
+
 def verify_sampled_chains(name, step, torch, sync):
     """Tie the timed batch to a verified result: one more step of THE SAME batch (outside every timed region) from a zero
     carried state, then sampled chains x frame windows of its output compared bit for bit with the oracle (the checker,
@@ -610,8 +710,13 @@ def verify_sampled_chains(name, step, torch, sync):
     nch, nfr = int(coeffs.shape[0]), int(coeffs.shape[1])
     pcm = step.verify_step()
     sync()
-    chains = sorted({0, nch // 2 - 1, nch // 2, nch - 1})
+    # the fixed samples (the chain's start, the 256-frame workgroup-walk boundary, a segment boundary, the chain's end of the first,
+    # the middle two and the last chain) + chains and windows nobody chose: drawn from the run's seed, which the line prints
+    rng = verify_rng()
+    chains = sorted({0, nch // 2 - 1, nch // 2, nch - 1} | {int(c) for c in rng.integers(0, nch, 3)})
     wins = [(a, min(b, nfr)) for a, b in ((0, 24), (60, 70), (250, 262), (nfr - 12, nfr)) if a < nfr and a >= 0]
+    for a in rng.integers(0, max(1, nfr - 16), 3):
+        wins.append((int(a), min(int(a) + 12, nfr)))
     checked, bad = 0, 0
     for c in chains:
         for a, b in wins:
@@ -629,7 +734,7 @@ def verify_sampled_chains(name, step, torch, sync):
     if bad:
         raise RuntimeError("bench: the timed %s batch differs from the oracle in %d of %d sampled samples" % (name, bad, checked))
     return {"checker": "oracle/symoracle.c (CPU restatement), outside the timed region", "chains": chains, "frame_windows": wins,
-            "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
+            "seed": VERIFY_SEED, "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
 
 
 def verify_vorbis_chains(name, step, torch, sync):
@@ -642,7 +747,7 @@ def verify_vorbis_chains(name, step, torch, sync):
     sync()
     flags = v["flags"]
     nch = flags.shape[0]
-    chains = sorted({0, nch - 1})
+    chains = sorted({0, nch - 1} | {int(verify_rng().integers(0, nch))})  # first, last, and one the run's seed picks
     checked, bad = 0, 0
     for c in chains:
         if "classes" in v:
@@ -667,7 +772,7 @@ def verify_vorbis_chains(name, step, torch, sync):
     if bad:
         raise RuntimeError("bench: the timed %s batch differs from the oracle in %d of %d sampled samples" % (name, bad, checked))
     return {"checker": "oracle/symoracle.c (CPU restatement), outside the timed region", "chains": chains, "frame_windows": "whole chains",
-            "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
+            "seed": VERIFY_SEED, "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
 
 
 def workload_input(name, step):
@@ -1053,9 +1158,10 @@ def device_identity(torch, local_rank, emulate):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=256,
+                    help="timed steps (default 256: a 0.2 ms step gives a timed region of ~50 ms, long enough for an outside clock to see)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2", "vorbisf", "vorbisf2", "aacjs", "aacjs2", "decoders"])
+    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2", "vorbisf", "vorbisf2", "aacjs", "aacjs2", "aactns", "decoders"])
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1083,7 +1189,11 @@ def main():
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: run the control flow on CPU tensors through the CPU emulation build of the kernels "
                          "(tests/emu) with gloo; its numbers mean nothing")
+    ap.add_argument("--verify-seed", type=int, default=None,
+                    help="seed of the chains / windows the `verified` blocks sample beside the fixed ones (default: drawn per run, printed in the line)")
     args = ap.parse_args()
+    global VERIFY_SEED
+    VERIFY_SEED = args.verify_seed if args.verify_seed is not None else int.from_bytes(os.urandom(4), "little")
     if args.selftest_multi:
         from symphonia_amd.selftest import multi_selftest
         print(json.dumps({"selftest_multi": multi_selftest(args.selftest_multi)}), flush=True)
@@ -1302,7 +1412,8 @@ def main():
                              ("aac_mix_0.05", "aac", 0.05), ("aac_mix_0.25", "aac", 0.25), ("mp3_mix_0.06", "mp3", 0.06),
                              ("mp3_int16_one_kernel", "mp3q", 0.0), ("mp3_int16_two_kernels", "mp3q2", 0.0),
                              ("vorbis_posts_byte_plane", "vorbisf", 0.0), ("vorbis_posts_f32_spectrum", "vorbisf2", 0.0),
-                             ("aac_joint_stereo_on_load", "aacjs", 0.0), ("aac_joint_stereo_two_kernels", "aacjs2", 0.0)):
+                             ("aac_joint_stereo_on_load", "aacjs", 0.0), ("aac_joint_stereo_two_kernels", "aacjs2", 0.0),
+                             ("aac_tns_0.30", "aactns", 0.0)):
             try:
                 stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, mixw, emulate)
                 nw, ww = (8, 2) if w in ("flac", "alac") else (20, 3)  # (a few milliseconds each for the short ones)
@@ -1379,6 +1490,10 @@ def main():
             if tr and tr["algorithmic_bytes_per_launch"] == alg_bytes:
                 out["roofline"]["traffic"] = tr["bytes_per_launch"]
                 out["roofline"]["traffic_source"] = tr["source"] + " (a committed rocprofv3 PMC measurement of this command, not taken in this run)"
+                # which library the counters were taken on, against the one this line ran: a kernel changed since then is flagged
+                have = (ctx.lib.build_flags() or {}).get("source_sha256")
+                out["roofline"]["traffic_source_sha256"] = tr.get("source_sha256")
+                out["roofline"]["traffic_is_of_this_library"] = bool(have and tr.get("source_sha256") == have)
         except (OSError, ValueError, KeyError):
             pass
         if clocks:
@@ -1430,7 +1545,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not emulate:
             # (the int16 MP3 lines are timed against the same CPU restatement as config 3: its synthesis tail; the CPU side of
             # requantize + stereo is a few per cent of that)
-            out["cpu_baseline"] = cpu_baseline({"mp3q": "mp3", "mp3q2": "mp3", "vorbisf": "vorbis", "vorbisf2": "vorbis", "aacjs": "aac", "aacjs2": "aac"}.get(args.workload, args.workload))
+            out["cpu_baseline"] = cpu_baseline({"mp3q": "mp3", "mp3q2": "mp3", "vorbisf": "vorbis", "vorbisf2": "vorbis", "aacjs": "aac", "aacjs2": "aac", "aactns": "aac"}.get(args.workload, args.workload))
         print(json.dumps(out), flush=True)
     if hung:
         os._exit(0)  # a leg is still stuck in a collective: the line is out, do not wait for it

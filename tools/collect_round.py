@@ -75,6 +75,8 @@ def main(tag, traffic_only=False):
             traffic[w] = {"kernel": KERNELS[w], "fetch_size_kb_raw": pm["FETCH_SIZE"], "write_size_kb": pm["WRITE_SIZE"],
                           "bytes_per_launch": int(round((2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024)),
                           "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+                          # (the library the counters were taken on: bench.py flags a line whose library differs)
+                          "source_sha256": ((bench.get("library") or {}).get("build") or {}).get("source_sha256"),
                           "source": "profiles/%s_%s_rocprofv3.txt" % (tag, w)}
             print(w, "traffic / algorithmic = %.4f" % (traffic[w]["bytes_per_launch"] / traffic[w]["algorithmic_bytes_per_launch"]))
     (prof / "hbm_traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
