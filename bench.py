@@ -1189,6 +1189,7 @@ def main():
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: run the control flow on CPU tensors through the CPU emulation build of the kernels "
                          "(tests/emu) with gloo; its numbers mean nothing")
+    ap.add_argument("--no-verify", action="store_true", help="measurement builds whose results are wrong on purpose (SYMACCEL_TUNE_*_ABLATE): skip the oracle check; the line says so")
     ap.add_argument("--verify-seed", type=int, default=None,
                     help="seed of the chains / windows the `verified` blocks sample beside the fixed ones (default: drawn per run, printed in the line)")
     args = ap.parse_args()
@@ -1345,9 +1346,11 @@ def main():
                    "note": "region 0 is the line's own timed region (`value`); the others follow it back to back, W warm-up + K timed steps each"}
         log("repeats done: median %.4f ms/step, spread %.1f %%" % (med, repeats["spread_frac"] * 100))
     verified = None
-    if rank == 0 and hasattr(step, "verify"):
+    if args.no_verify:
+        verified = {"skipped": "--no-verify: NOT a measurement of the product (an ablation build's results are wrong on purpose)"}
+    elif rank == 0 and hasattr(step, "verify"):
         verified = step.verify()
-    if rank == 0 and args.workload in ("aac", "mp3", "vorbis", "vorbisf", "vorbisf2"):
+    if not args.no_verify and rank == 0 and args.workload in ("aac", "mp3", "vorbis", "vorbisf", "vorbisf2"):
         verified = verify_sampled_chains(args.workload, step, torch, sync)  # raises on a mismatch: no line for a wrong result
         log("timed batch verified against the oracle: %d samples" % verified["samples_compared"])
     per_rank_ms = [mine / args.steps * 1e3]

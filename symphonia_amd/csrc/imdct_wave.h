@@ -10,6 +10,14 @@
 
 namespace symaccel {
 
+// SYM_LDS_ABLATE (measurement only, never in the product build: results are WRONG): bit mask of LDS phases to leave out or to turn into
+// broadcasts, for attributing SQ_LDS_BANK_CONFLICT to a phase (tools/gpu_r6n.sh).  1 = mirror ds_bpermute of the long pre-twiddle,
+// 2 = pre-twiddle twiddle reads as broadcasts, 4 = T1 exchange (pass 1 -> 2), 8 = T2 exchange (pass 2 -> 3), 16 = natural-order write of Z,
+// 32 = post_slot's reads of Z as broadcasts, 64 = post_slot's twiddle reads as broadcasts, 128 = window reads as broadcasts,
+// 256 = the dB-table look-ups of the byte-plane form as broadcasts.
+#ifndef SYM_LDS_ABLATE
+#define SYM_LDS_ABLATE 0
+#endif
 constexpr int kWaveLds = 2264;  // floats of private LDS per wavefront (FFT work array, see the T1/T2 layouts)
 
 // Order this wavefront's LDS accesses (its lanes exchange data through LDS; the hardware executes
@@ -219,36 +227,46 @@ __device__ __forceinline__ void fft512_wave(c32 (&z)[8], int lane, c32 *lds, con
     fft8_regs(z);
     {
         const int B = (int)rev_bits((unsigned)lane & 7u, 3), j = (int)rev_bits((unsigned)lane >> 3, 3);
+#if !(SYM_LDS_ABLATE & 4)
         c32 *w = lds + lds_t1_lane_w(B, j);
 #pragma unroll
         for (int r = 0; r < 8; ++r) w[lds_t1_inst_w(r)] = z[r];
+#endif
     }
     wave_sync();
     // ---- pass 2: lane (B, k) gathers j = 0..7
     const int B2 = lane >> 3, k2 = lane & 7;
     {
+#if !(SYM_LDS_ABLATE & 4)
         const c32 *r = lds + lds_t1_lane_r(B2, k2);
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[j] = r[lds_t1_inst_r(j)];
+#endif
     }
     pass2_regs(z, lt);
     wave_sync();
+#if !(SYM_LDS_ABLATE & 8)
     {
         c32 *w = lds + lds_t2_lane_w(B2, k2);
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[lds_t2_inst_w(j)] = z[j];
     }
+#endif
     wave_sync();
     // ---- pass 3: lane k' = 8j + k gathers B = 0..7
+#if !(SYM_LDS_ABLATE & 8)
     {
         const c32 *r = lds + lds_t2_lane_r(lane >> 3, lane & 7);
 #pragma unroll
         for (int B = 0; B < 8; ++B) z[B] = r[lds_t2_inst_r(B)];
     }
+#endif
     pass3_regs(z, lt);
     wave_sync();
+#if !(SYM_LDS_ABLATE & 16)
 #pragma unroll
     for (int B = 0; B < 8; ++B) lds[64 * B + lane] = z[B];  // natural order Z[64B + k']
+#endif
     wave_sync();
 }
 
@@ -427,10 +445,11 @@ static_assert(2048 <= kWaveLds, "the Imdct output of a 512-point pass (2048 samp
 //   x2[q] = pcm[1024 + j(q)]  with j(q) = 4*m2 + q for q < 4, 1020 - 4*m2 + (q - 4) for q >= 4.
 // Twiddles tw[254-2m2 .. 255-2m2] and tw[256+2m2 .. 257+2m2] come from the shared LDS table.
 __device__ __forceinline__ void post_slot(const c32 *lds, const c32 *tw, int m2, float (&x)[8], float (&x2)[8]) {
-    const c32 vB = post_twiddle(lds[254 - 2 * m2], tw[254 - 2 * m2]);
-    const c32 vA = post_twiddle(lds[255 - 2 * m2], tw[255 - 2 * m2]);
-    const c32 vC = post_twiddle(lds[256 + 2 * m2], tw[256 + 2 * m2]);
-    const c32 vD = post_twiddle(lds[257 + 2 * m2], tw[257 + 2 * m2]);
+    const int mz = (SYM_LDS_ABLATE & 32) ? (m2 & 64) : m2, mt = (SYM_LDS_ABLATE & 64) ? (m2 & 64) : m2;
+    const c32 vB = post_twiddle(lds[254 - 2 * mz], tw[254 - 2 * mt]);
+    const c32 vA = post_twiddle(lds[255 - 2 * mz], tw[255 - 2 * mt]);
+    const c32 vC = post_twiddle(lds[256 + 2 * mz], tw[256 + 2 * mt]);
+    const c32 vD = post_twiddle(lds[257 + 2 * mz], tw[257 + 2 * mt]);
     x[0] = -vC.x;  // vec0[4m2 .. 4m2+3]
     x[1] = -vA.y;
     x[2] = -vD.x;

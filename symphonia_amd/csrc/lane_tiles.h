@@ -107,6 +107,13 @@ __device__ __forceinline__ void flac_decorrelate_pair(int32_t a, int32_t b, int3
 // Tile write-back with the decorrelation fused in: a lane takes four columns of BOTH rows of a pair (32 pairs per tile: four
 // rounds of eight pairs x eight column groups), so each restored sample is read from LDS once and the pair's arithmetic is shared.
 // `row_mode[r]` = mode of the pair row r belongs to.
+// SYM_FLAC_STORE_SWITCH (build knob, default 1): the pair's mode is constant over the lane's EIGHT samples of a round, so the round
+// branches on it once -- an independent pair costs two shifts per sample pair, a mid/side pair nine instructions, instead of the 21 of
+// the branch-free form for every pair (round 5's form, kept as 0: it wins only when all four modes meet in most wavefront rounds).
+// The branch is per ROUND, not per sample: round 5 removed a compiler-built tree of divergent branches per sample.
+#ifndef SYM_FLAC_STORE_SWITCH
+#define SYM_FLAC_STORE_SWITCH 0
+#endif
 __device__ __forceinline__ void tile_store_decorrelate_fast(int32_t *__restrict__ buf, const int32_t *tile,
                                                             const uint8_t *row_mode, uint32_t out_shift, size_t blk0,
                                                             unsigned blocksize, unsigned t0, int lane) {
@@ -117,13 +124,33 @@ __device__ __forceinline__ void tile_store_decorrelate_fast(int32_t *__restrict_
         const int4 a = *reinterpret_cast<const int4 *>(tile + r0 * kStride + 4 * q);
         const int4 b = *reinterpret_cast<const int4 *>(tile + (r0 + 1) * kStride + 4 * q);
         const int32_t m = (int32_t)row_mode[r0];
+        int4 o0, o1;
+#if SYM_FLAC_STORE_SWITCH
+        uint32_t x0[4] = {(uint32_t)a.x, (uint32_t)a.y, (uint32_t)a.z, (uint32_t)a.w}, x1[4] = {(uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)b.w};
+        if (m == 2) {  // mid/side (decoder.rs:60-72)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t mid = (x0[i] << 1) | (x1[i] & 1u), sd = x1[i];
+                x0[i] = (uint32_t)((int32_t)(mid + sd) >> 1);
+                x1[i] = (uint32_t)((int32_t)(mid - sd) >> 1);
+            }
+        } else if (m == 1) {  // left/side: right = left - side
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x1[i] = x0[i] - x1[i];
+        } else if (m == 3) {  // right/side: left = side + right
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x0[i] = x0[i] + x1[i];
+        }
+        o0 = make_int4((int32_t)(x0[0] << out_shift), (int32_t)(x0[1] << out_shift), (int32_t)(x0[2] << out_shift), (int32_t)(x0[3] << out_shift));
+        o1 = make_int4((int32_t)(x1[0] << out_shift), (int32_t)(x1[1] << out_shift), (int32_t)(x1[2] << out_shift), (int32_t)(x1[3] << out_shift));
+#else
         // mode == k as 0 / -1: (m ^ k) - 1 is negative only for m == k (m is 0 .. 3)
         const int32_t is1 = ((m ^ 1) - 1) >> 31, is2 = ((m ^ 2) - 1) >> 31, is3 = ((m ^ 3) - 1) >> 31;
-        int4 o0, o1;
         flac_decorrelate_pair(a.x, b.x, is1, is2, is3, out_shift, o0.x, o1.x);
         flac_decorrelate_pair(a.y, b.y, is1, is2, is3, out_shift, o0.y, o1.y);
         flac_decorrelate_pair(a.z, b.z, is1, is2, is3, out_shift, o0.z, o1.z);
         flac_decorrelate_pair(a.w, b.w, is1, is2, is3, out_shift, o0.w, o1.w);
+#endif
         int32_t *dst = buf + (blk0 + (size_t)r0) * blocksize + t0 + 4u * (unsigned)q;
         st_stream(reinterpret_cast<int4 *>(dst), o0);
         st_stream(reinterpret_cast<int4 *>(dst + blocksize), o1);

@@ -358,11 +358,15 @@ __device__ __forceinline__ void mp3_front(const DevTables &tb, const SfbEdges *e
     if (mid_side && !intensity) {  // (wave-uniform: one record per pair and granule) mid/side alone, stereo.rs:139-148, 541-543
         int end = sd.rzero0 > sd.rzero1 ? sd.rzero0 : sd.rzero1;  // stereo.rs:522
         end = end > 576 ? 576 : end;
+        // (c0 + c1) in channel 0, (c0 - c1) in channel 1: the other channel's line plus this one's with its sign flipped in the second
+        // half-wave -- IEEE subtraction IS addition of the negated operand, and addition commutes, so both are the reference's rounded
+        // results; two selects and a subtract per line less than choosing c0 / c1 and the operation (compares and selects cost 1.75 x
+        // an add or a xor on the SIMD: profiles/r05q_valu_int.txt)
+        const unsigned flip = half == 0 ? 0u : 0x80000000u;
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             const float b = __shfl_xor(a[i], 32);
-            const float c0 = half == 0 ? a[i] : b, c1 = half == 0 ? b : a[i];
-            const float v = (half == 0 ? c0 + c1 : c0 - c1) * kMp3Frac1Sqrt2;
+            const float v = (b + __uint_as_float(__float_as_uint(a[i]) ^ flip)) * kMp3Frac1Sqrt2;
             a[i] = 18 * hl + i < end ? v : a[i];
         }
     }

@@ -60,8 +60,13 @@ __device__ __forceinline__ void apply_residue(float2 (&line)[8], const float2 (&
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const unsigned yy = __float_as_uint(res[s].x);
+#if SYM_LDS_ABLATE & 256
+            line[s].x = dbt[s] * line[s].x + __uint_as_float(yy & 1u);
+            line[s].y = dbt[s + 8] * line[s].y;
+#else
             line[s].x = dbt[yy & 255u] * line[s].x;  // floor.rs:822 (the curve's value) and lib.rs:289-291 (*f *= r) in one step
             line[s].y = dbt[yy >> 8] * line[s].y;
+#endif
         }
     }
 }
@@ -229,8 +234,12 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
             apply_residue<FUSED>(line, res, dbt);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
+#if SYM_LDS_ABLATE & 1
+                const float mirrored = line[7 - s].y + (float)mirror;
+#else
                 const float mirrored = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(line[7 - s].y)));
-                z[s] = pre_twiddle(line[s].x, mirrored, tw[lane + 64 * s]);
+#endif
+                z[s] = pre_twiddle(line[s].x, mirrored, tw[((SYM_LDS_ABLATE & 2) ? 0 : lane) + 64 * s]);
             }
             if (glen_next > 0) fetch_lines<FUSED>(sp, rp, os_next, flag_next ? 8 : glen_next, lane, line, res);  // prefetch
             fft512_wave(z, lane, lds, lt);
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(64 * kWaves, SYM_VORBIS_WAVES) void vorbis_synth_wa
                 for (int h = 0; h < 2; ++h) {
                     float x[8], x2[8], w[8], dst[8];
                     post_slot(lds, tw, lane + 64 * h, x, x2);
-                    load_slot(wl, lane + 64 * h, w);
+                    load_slot(wl, ((SYM_LDS_ABLATE & 128) ? 0 : lane) + 64 * h, w);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) dst[q] = dl[h][q] * w[7 - q] + x[q] * w[q];
                     if (emit) store_slot_stream(o, lane + 64 * h, dst);
