@@ -1046,16 +1046,23 @@ def decoders_workload(quick=False, seconds_cpu=3.0, lookahead=64):
     def timed_packets(la, streams):
         return max(512, 16 * la)
     packets = timed_packets(lookahead, 256)
-    out = {"harness": "tools/decoders_bench.cpp (g++, links libsymaccel.so only)", "lookahead": lookahead, "cores": cores, "sweep": [],
+    out = {"harness": "tools/decoders_bench.cpp (g++, links libsymaccel.so only)", "decoders_built_by": "CodecRegistry::make_audio_decoder (--via-registry)", "lookahead": lookahead, "cores": cores, "sweep": [],
            "timed_packets_per_stream": {"lookahead_%d" % lookahead: packets, "lookahead_256": timed_packets(256, 256),
                                         "note": "after a warm-up of two batches per stream; >= 16 batches timed"}}
 
     def run(codec, streams, threads, per_stream=False, pk=packets, reps=3, la=None):
         """the harness `reps` times (a fresh process each: its own context, pool and warm-up); the run with the MEDIAN rate is the one
-        reported, every rate is kept beside it (`runs_packets_per_s`: threads meeting a shared pipeline scatter by +-20 %)"""
+        reported, every rate is kept beside it (`runs_packets_per_s`: threads meeting a shared pipeline scatter by +-20 %).
+        The pooled decoders are built the way the registry builds them -- `--via-registry`: CodecRegistry::make_audio_decoder is handed
+        (params, options) and the packet source, no batcher (registry.rs:330-341; the Rust shim's try_registry_new) -- and, where the
+        codec's batch layout allows it, parse straight into the batcher's slot (`--direct`)."""
         cmd = [str(exe), "--codec", codec, "--streams", str(streams), "--lookahead", str(la or lookahead), "--packets", str(pk), "--threads", str(threads)]
         if per_stream:
             cmd.append("--per-stream")
+        else:
+            cmd.append("--via-registry")
+            if codec in ("aac", "mp3", "mp3h"):
+                cmd.append("--direct")
         lines = []
         for _ in range(reps):
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
@@ -1099,6 +1106,7 @@ def decoders_workload(quick=False, seconds_cpu=3.0, lookahead=64):
         out["vorbis_8ch_S64"] = run("vorbis", 64, max(1, min(64, cores)))  # (BASELINE config 4's shape: 8 channels, 2048 / 256)
         # AAC one stage earlier: coded spectra + joint-stereo descriptors + TNS filters (30 % of the frames) -> PCM
         out["aac_coded_S256"] = run("aacd", 256, max(1, min(256, cores)))
+        out["flac_S256"] = run("flac", 256, max(1, min(256, cores)))  # (stereo, 24 bit, 4096-sample blocks: one packet = one block)
         in0 = rng.standard_normal((16, 32, 1024)).astype(np.float32)
         in0[:, :, 672:] = 0.0
         in1 = np.full((16, 32), oracle.aac_side(0, 1, 1), np.uint8)
@@ -1537,7 +1545,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["host_to_host_mp3"] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:  # the trait-level figure: S streams through decode() and the cross-stream batcher (short form: S = 256)
-                out["decoders"] = decoders_workload(quick=True)
+                out["decoders"] = decoders_workload(quick=True, lookahead=256)  # (the Rust shim's DEFAULT_LOOKAHEAD)
             except Exception as e:  # noqa: BLE001
                 out["decoders"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and args.workload == "mp3" and not args.no_host_path and not emulate:

@@ -29,11 +29,15 @@
 #include <complex>
 #include <functional>
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <optional>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <utility>
 #include <cstring>
+#include <typeindex>
 #include <vector>
 
 #include "symaccel.h"
@@ -96,6 +100,30 @@ public:
         symaccel_batcher_stats s{};
         check(symaccel_batcher_get_stats(b_, &s), ctx_.raw());
         return s;
+    }
+    // The process-wide batcher (the Rust shim's Pool::shared(), bindings/rust/symphonia-accel-hip/src/ctx.rs): device 0, the library's
+    // default flush size, created on first use and never destroyed (decoders of any thread may hold it until the process ends).  This is
+    // what a factory that sees (params, options) alone -- CodecRegistry::make_audio_decoder below, registry.rs:330-341 -- builds through.
+    // Throws what Context / Batcher construction throws (no device: Error{IoError}); a failed first attempt is not retried.
+    static Batcher &shared() {
+        static std::once_flag once;
+        static Batcher *inst = nullptr;
+        static std::string failure;
+        std::call_once(once, [] {
+            try {
+                auto *ctx = new Context(0);
+                try {
+                    inst = new Batcher(*ctx, 0);
+                } catch (...) {
+                    delete ctx;
+                    throw;
+                }
+            } catch (const std::exception &e) {
+                failure = e.what();
+            }
+        });
+        if (!inst) throw Error(Error::Kind::IoError, SYMACCEL_ERR_DEVICE, "shared batcher: " + failure);
+        return *inst;
     }
 
 private:
@@ -1495,6 +1523,59 @@ private:
     std::vector<std::int32_t> coeffs_, ch0_, ch1_;
     std::vector<std::uint8_t> modes_;
 };
+
+// CodecRegistry (symphonia-core/src/codecs/registry.rs:220-341).  The reference's registry maps a codec id to a factory that is handed
+// (params, options) and NOTHING ELSE -- `RegisterableAudioDecoder::try_registry_new` (registry.rs:34-44) -- so a decoder it builds cannot
+// be told about its siblings: the factories here find the process-wide batcher themselves (`Batcher::shared()`), exactly as the Rust shim's
+// `try_registry_new` goes through `Pool::shared()` (decoder.rs, aac.rs).  `register_audio_decoder` = registry.rs:252-269,
+// `make_audio_decoder` = registry.rs:330-341 (`Error::Unsupported("core (codec): unsupported codec")` for an id nobody registered).
+// The packet source stands where the reference has the FormatReader the decoder is read behind (LookaheadReader in the shim).
+struct AudioDecoderOptions {  // codecs/audio.rs:208-222 (`verify`) + the look-ahead of this backend (the shim's DEFAULT_LOOKAHEAD = 256)
+    bool verify = false;
+    std::size_t lookahead = 256;
+};
+
+class CodecRegistry {
+public:
+    template <class Codec>
+    void register_audio_decoder() {
+        ids_.insert(std::type_index(typeid(Codec)));
+    }
+    template <class Codec>
+    bool is_registered() const {
+        return ids_.count(std::type_index(typeid(Codec))) != 0;
+    }
+    template <class Codec>
+    std::unique_ptr<LookaheadDecoder<Codec>> make_audio_decoder(const typename Codec::Params &params, const AudioDecoderOptions &opts,
+                                                                typename LookaheadDecoder<Codec>::Peek peek) const {
+        require<Codec>();
+        return std::make_unique<LookaheadDecoder<Codec>>(Batcher::shared(), params, opts.lookahead, std::move(peek));
+    }
+    // (zero-copy parse, for the codecs with kDirect)
+    template <class Codec>
+    std::unique_ptr<LookaheadDecoder<Codec>> make_audio_decoder(const typename Codec::Params &params, const AudioDecoderOptions &opts,
+                                                                typename LookaheadDecoder<Codec>::Direct direct) const {
+        require<Codec>();
+        return std::make_unique<LookaheadDecoder<Codec>>(Batcher::shared(), params, opts.lookahead, std::move(direct));
+    }
+
+private:
+    template <class Codec>
+    void require() const {
+        if (!is_registered<Codec>()) throw Error(Error::Kind::Unsupported, SYMACCEL_ERR_UNSUPPORTED, "core (codec): unsupported codec");
+    }
+    std::set<std::type_index> ids_;
+};
+
+// symphonia::default::register_enabled_codecs' counterpart for this backend (the shim's `register()`): every codec of the twin
+inline void register_enabled_codecs(CodecRegistry &registry) {
+    registry.register_audio_decoder<AacLc>();
+    registry.register_audio_decoder<AacLcCoded>();
+    registry.register_audio_decoder<Mp3>();
+    registry.register_audio_decoder<Mp3Huffman>();
+    registry.register_audio_decoder<Vorbis>();
+    registry.register_audio_decoder<Flac>();
+}
 
 }  // namespace codecs
 

@@ -29,7 +29,7 @@ SOURCES = ["tables.cpp", "ctx.cpp", "host_tools.cpp", "stage.cpp", "batcher.cpp"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-missing-braces"]
-TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_VARIANT", "NT", "MP3_WAVES", "MP3_VARIANT", "MP3_WG_WAVES", "MP3_FUSED_WAVES", "MP3_FUSED_WG_WAVES", "VORBIS_WAVES", "ALAC_SMALL_WAVES", "FLAC_PARTS", "MP3_SLOT_GROUP", "MP3_PACKED", "MP3_PAIR_GROUP", "AAC_ABLATE", "AAC_SINK", "AAC_CLOCK", "AAC_QUAD", "MULTI_WAVE", "VORBIS_WAVE2", "VORBIS_WG", "VORBIS_WG_SHARED", "ST_POLICY", "PACKED_C32", "WG4096_ABLATE", "FLAC_STORE_SWITCH", "ALAC_ONE_LAUNCH", "MP3_FRONT", "LDS_ABLATE")
+TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_VARIANT", "NT", "MP3_WAVES", "MP3_VARIANT", "MP3_WG_WAVES", "MP3_FUSED_WAVES", "MP3_FUSED_WG_WAVES", "VORBIS_WAVES", "ALAC_SMALL_WAVES", "FLAC_PARTS", "MP3_SLOT_GROUP", "MP3_PACKED", "MP3_PAIR_GROUP", "AAC_ABLATE", "AAC_SINK", "AAC_CLOCK", "AAC_QUAD", "MULTI_WAVE", "VORBIS_WAVE2", "VORBIS_WG", "VORBIS_WG_SHARED", "ST_POLICY", "PACKED_C32", "WG4096_ABLATE", "FLAC_STORE_SWITCH", "ALAC_ONE_LAUNCH", "MP3_FRONT", "LDS_ABLATE", "F1_ABLATE", "F1_WAVES")
 TUNE_PREFIX = "SYMACCEL_TUNE_"
 
 

@@ -432,8 +432,16 @@ struct Floor1Setup {  // per floor configuration, derived on the host like the s
 // Measured (profiles/r02zb_floor1_ab.txt): a wavefront per 16 or 32 blocks doing everything itself spends as many
 // instructions in the post chain as in the render, and the kernel is bound by instruction issue and dependent latency, not
 // by HBM.
+// SYM_F1_ABLATE (measurement only, never in the product build: results are WRONG): 1 = no post chain (synthesis_step1), 2 = no point
+// lists (two points per block), 4 = no render pass, 8 = no segment tables / maps.  profiles/r06o_floor1_phases.txt
+#ifndef SYM_F1_ABLATE
+#define SYM_F1_ABLATE 0
+#endif
 constexpr int kF1B = 64;                 // channel-blocks per workgroup
-constexpr int kF1Waves = 4;              // wavefronts per workgroup
+#ifndef SYM_F1_WAVES
+#define SYM_F1_WAVES 4
+#endif
+constexpr int kF1Waves = SYM_F1_WAVES;   // wavefronts per workgroup
 constexpr int kF1Stride = kF1B + 1;      // LDS row stride of the per-block lists [entry][block]: conflict-free both ways
 
 // MODE 0: the curve (f32) -> floor_out[block][n];  1: curve * residue -> floor_out (the dot product of lib.rs:282-292);
@@ -466,15 +474,16 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
     uint8_t *mark = overlay + wave * kPerWave + 67 * 16;  // ... and its segment-start map
     const size_t blk0 = (size_t)blockIdx.x * kF1B;
     const int nb = (int)(count - blk0 < (size_t)kF1B ? count - blk0 : (size_t)kF1B);
-    dbl[tid] = db[tid];
+    if (tid < 256) dbl[tid] = db[tid];
     // the y rows of the 64 blocks are contiguous: coalesced load by the whole workgroup, transposed into LDS
     {
         const uint32_t *src = yv + blk0 * (size_t)n_posts;
         const int total = nb * n_posts;
         // element e = block * n_posts + post; (block, post) advance by 256 elements without a division per element
-        const int dq = 256 / n_posts, dr = 256 % n_posts;
+        constexpr int kT = 64 * kF1Waves;
+        const int dq = kT / n_posts, dr = kT % n_posts;
         int blk = tid / n_posts, post = tid % n_posts;
-        for (int e = tid; e < total; e += 256) {
+        for (int e = tid; e < total; e += kT) {
             segx[post * kF1Stride + blk] = (uint16_t)src[e];
             post += dr;
             blk += dq + (post >= n_posts ? 1 : 0);
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
         uint32_t pn_next = st.nb[2];
         float ratio_next = st.ratio[2], half_next = st.half[2];
         int32_t val_next = (int32_t)segx[2 * kF1Stride + lane];
-        for (int i = 2; i < n_posts; ++i) {
+        for (int i = 2; i < ((SYM_F1_ABLATE & 1) ? 3 : n_posts); ++i) {
             const uint32_t pn = pn_next;
             const int32_t val = val_next;
             const float ratio = ratio_next, half = half_next;
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
         int32_t hy = 0;
         // (the reads do not depend on the list being built: unrolled, their latencies overlap)
 #pragma unroll 4
-        for (int k = 1; k < n_posts; ++k) {
+        for (int k = 1; k < ((SYM_F1_ABLATE & 2) ? 2 : n_posts); ++k) {
             const uint32_t po = st.ord[k];
             const int i = (int)(po & 255u);
             int32_t py = fy[i * kF1B + lane] * multiplier;
@@ -605,8 +614,10 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
         // multiply per line, the reference's `*f *= r` -- so the curve itself never goes to HBM (residue may be `out`)
         const float *rin = DOT ? residue + line0 : nullptr;
         // segment-start map: mark[x_k] = k + 1 for the points with x_k < n (x values are distinct)
+#if !(SYM_F1_ABLATE & 8)
         for (uint32_t i = (uint32_t)lane; i < (n + 3u) / 4u; i += 64) reinterpret_cast<uint32_t *>(mark)[i] = 0u;
         wave_sync_lds();
+#endif
         // ... and the constants of segment k (point k to point k + 1), one lane per segment.  The integer DDA of render_line
         // (floor.rs:785-825: y += base every x, one more step of sign(dy) whenever err overflows adx) has the closed form
         //     y(x) = y0 + sign(dy) * floor(|dy| * t / adx),   t = x - x0 < adx
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
         // 65535), but only their first n <= 4096 lines are rendered: the value is below 255 * 4096 / adx there, the three
         // roundings move it by less than 3 * 255 * 4096 * 2^-24 / adx = 0.19 / adx < 0.5 / adx -- exact again; the same
         // program walks (4096 < adx <= 65535, |dy| <= 255, t < 4096) (every adx with SYM_SLOW_TESTS=1, every 16th otherwise).
-        for (int k = lane; k <= nsb; k += 64) {
+        for (int k = lane; k <= ((SYM_F1_ABLATE & 8) ? -1 : nsb); k += 64) {
             const int k1 = k + 1 <= nsb ? k + 1 : k;
             const uint32_t xk = segx[k * kF1Stride + b];
             if (xk < n) mark[xk] = (uint8_t)(k + 1);
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
         // instruction writes 1 KiB without a gap (16 consecutive x per lane left every 64-byte unit of a store three quarters
         // empty: four times the write requests).  The pass is straight-line code -- every LDS round trip (map, lane reads,
         // table, dB values) is issued for all four groups before the first result is needed.
-        for (uint32_t p0 = 0; p0 < n; p0 += 1024) {
+        for (uint32_t p0 = 0; p0 < ((SYM_F1_ABLATE & 4) ? 0u : n); p0 += 1024) {
             uint32_t xb[4], m[4];
             float4 rr[4];  // the lines' residue, requested now: the render hides the latency
 #pragma unroll

@@ -444,9 +444,25 @@ static void test_aac_coded(Context &ctx, size_t lookahead, Batcher *batcher = nu
 
 // ---- many streams, one batcher: S AAC decoders called round-robin like a server's worker would; every buffer equals the
 // frame-by-frame decoder's, and the batcher ran far fewer launches than the decoders ran batches
-static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead, bool direct = false) {
+// via_registry: the decoders come from CodecRegistry::make_audio_decoder (registry.rs:330-341), which is handed (params, options) and the
+// packet source alone; they must still meet in ONE batcher -- the process-wide one -- and share launches
+static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead, bool direct = false, bool via_registry = false) {
     const size_t n = 37;
-    Batcher batcher(ctx);
+    std::unique_ptr<Batcher> own;
+    if (!via_registry) own.reset(new Batcher(ctx));
+    Batcher &batcher = via_registry ? Batcher::shared() : *own;
+    const symaccel_batcher_stats before = batcher.stats();
+    CodecRegistry registry;
+    if (via_registry) {
+        try {
+            registry.make_audio_decoder<AacLc>(AacLc::Params{2}, AudioDecoderOptions{}, LookaheadDecoder<AacLc>::Peek([]() -> std::optional<AacLc::Packet> { return std::nullopt; }));
+            EXPECT(false, "an empty registry made a decoder");
+        } catch (const Error &e) {
+            EXPECT(e.kind == Error::Kind::Unsupported, "empty registry: wrong error kind");
+        }
+        register_enabled_codecs(registry);
+        EXPECT(registry.is_registered<AacLc>() && registry.is_registered<Flac>(), "register_enabled_codecs");
+    }
     struct Stream {
         std::vector<AacLc::Packet> track;
         size_t cursor = 0, nch = 2;
@@ -475,12 +491,19 @@ static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead, 
                 ++st->cursor;
                 return p.ts;
             };
-            st->dec.reset(new LookaheadDecoder<AacLc>(batcher, AacLc::Params{st->nch}, lookahead, d));
+            if (via_registry)
+                st->dec = registry.make_audio_decoder<AacLc>(AacLc::Params{st->nch}, AudioDecoderOptions{false, lookahead}, d);
+            else
+                st->dec.reset(new LookaheadDecoder<AacLc>(batcher, AacLc::Params{st->nch}, lookahead, d));
         } else {
-            st->dec.reset(new LookaheadDecoder<AacLc>(batcher, AacLc::Params{st->nch}, lookahead, [st]() -> std::optional<AacLc::Packet> {
+            LookaheadDecoder<AacLc>::Peek peek = [st]() -> std::optional<AacLc::Packet> {
                 if (st->cursor >= st->track.size()) return std::nullopt;
                 return st->track[st->cursor++];
-            }));
+            };
+            if (via_registry)
+                st->dec = registry.make_audio_decoder<AacLc>(AacLc::Params{st->nch}, AudioDecoderOptions{false, lookahead}, peek);
+            else
+                st->dec.reset(new LookaheadDecoder<AacLc>(batcher, AacLc::Params{st->nch}, lookahead, peek));
         }
         st->ref.reset(new AacOracle(st->nch));
     }
@@ -495,12 +518,14 @@ static void test_cross_stream(Context &ctx, size_t n_streams, size_t lookahead, 
                 EXPECT(same_bits(buf.planes[c], want.data() + c * 1024, 1024), "cross-stream S=%zu K=%zu packet %zu differs", n_streams, lookahead, i);
         }
     for (auto &up : streams) batches += up->dec->batches_run();
-    const symaccel_batcher_stats stats = batcher.stats();
+    symaccel_batcher_stats stats = batcher.stats();
+    stats.submissions -= before.submissions;  // (the shared batcher lives across tests)
+    stats.launches -= before.launches;
     EXPECT(stats.submissions >= batches, "submissions %llu < batches %zu", (unsigned long long)stats.submissions, batches);
     if (lookahead >= 4 && n_streams >= 4)
         EXPECT(stats.launches * 2 <= stats.submissions, "the batcher did not coalesce: %llu launches for %llu submissions", (unsigned long long)stats.launches,
                (unsigned long long)stats.submissions);
-    std::printf("cross-stream%s S=%zu K=%zu: %llu submissions in %llu launches (largest: %llu chains)\n", direct ? " (direct)" : "", n_streams, lookahead,
+    std::printf("cross-stream%s%s S=%zu K=%zu: %llu submissions in %llu launches (largest: %llu chains)\n", direct ? " (direct)" : "", via_registry ? " (registry)" : "", n_streams, lookahead,
                 (unsigned long long)stats.submissions, (unsigned long long)stats.launches, (unsigned long long)stats.max_chains_per_launch);
     streams.clear();  // (decoders release their tickets before the batcher goes)
 }
@@ -544,6 +569,8 @@ int main(int argc, char **argv) {
     test_cross_stream(ctx, 16, 3);
     test_cross_stream(ctx, 7, 8, true);
     test_cross_stream(ctx, 16, 5, true);
+    test_cross_stream(ctx, 7, 8, false, true);
+    test_cross_stream(ctx, 16, 5, true, true);
     if (g_failures == 0) std::printf("all checks passed\n");
     return g_failures ? 1 : 0;
 }

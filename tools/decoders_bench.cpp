@@ -9,7 +9,7 @@
 // peek that copies the next packet out of a small pool (a parser writes its output somewhere too).  Nothing here links the
 // oracle: bench.py times the CPU port beside this with its own harness.  One JSON line on stdout.
 //
-//   decoders_bench --codec aac|aacd|mp3|mp3h|vorbis|flac --streams S --lookahead L --packets P --threads T [--per-stream] [--direct] [--in-phase] [--flush-mb M] [--lanes N]
+//   decoders_bench --codec aac|aacd|mp3|mp3h|vorbis|flac --streams S --lookahead L --packets P --threads T [--per-stream] [--direct] [--in-phase] [--flush-mb M] [--lanes N] [--via-registry]
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -33,7 +33,7 @@ namespace {
 struct Args {
     std::string codec = "aac";
     size_t streams = 64, lookahead = 64, packets = 512, threads = 1, flush_mb = 0, warm = 0, lanes = 0;
-    bool per_stream = false, direct = false, in_phase = false;
+    bool per_stream = false, direct = false, in_phase = false, via_registry = false;
 };
 
 constexpr size_t kPool = 32;
@@ -217,9 +217,26 @@ template <class Codec>
 int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t bytes_in_per_packet) {
     using Packet = typename Codec::Packet;
     using Decoder = LookaheadDecoder<Codec>;
-    Context ctx(0);
-    std::unique_ptr<Batcher> batcher;
-    if (!a.per_stream) batcher.reset(new Batcher(ctx, a.flush_mb << 20));
+    // --via-registry: the decoders come from CodecRegistry::make_audio_decoder, which is handed (params, options) and the packet source
+    // and nothing else (registry.rs:330-341) -- no Batcher is passed anywhere: the factory finds the process-wide one, as the Rust shim's
+    // try_registry_new does.  The harness looks at Batcher::shared() itself only to read the statistics (and for --lanes / --flush-mb).
+    std::unique_ptr<Context> own_ctx;
+    std::unique_ptr<Batcher> own_batcher;
+    Batcher *batcher = nullptr;
+    CodecRegistry registry;
+    if (a.via_registry) {
+        if (a.per_stream) throw std::invalid_argument("--via-registry builds pooled decoders: not with --per-stream");
+        register_enabled_codecs(registry);
+        if (a.flush_mb) throw std::invalid_argument("--via-registry: the shared batcher has the library's flush size");
+        batcher = &Batcher::shared();
+    } else {
+        own_ctx.reset(new Context(0));
+        if (!a.per_stream) {
+            own_batcher.reset(new Batcher(*own_ctx, a.flush_mb << 20));
+            batcher = own_batcher.get();
+        }
+    }
+    Context &ctx = a.via_registry ? batcher->context() : *own_ctx;
     if (batcher && a.lanes) check(symaccel_batcher_configure(batcher->raw(), (int)a.lanes, 0), ctx.raw());
     const std::vector<Packet> pool = make_pool<Codec>(17);
     struct Stream {
@@ -252,11 +269,16 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
                     parse_into<Codec>(v, i, pool[(st->cursor + st->salt) % kPool]);
                     return st->cursor++;
                 };
-                st->dec.reset(new Decoder(*batcher, params<Codec>(), a.lookahead, d));
+                if (a.via_registry)
+                    st->dec = registry.make_audio_decoder<Codec>(params<Codec>(), AudioDecoderOptions{false, a.lookahead}, d);
+                else
+                    st->dec.reset(new Decoder(*batcher, params<Codec>(), a.lookahead, d));
             } else {
                 throw std::invalid_argument("--direct: this codec's layout depends on the packets (use the peek form)");
             }
-        } else if (batcher)
+        } else if (a.via_registry)
+            st->dec = registry.make_audio_decoder<Codec>(params<Codec>(), AudioDecoderOptions{false, a.lookahead}, peek);
+        else if (batcher)
             st->dec.reset(new Decoder(*batcher, params<Codec>(), a.lookahead, peek));
         else
             st->dec.reset(new Decoder(ctx, params<Codec>(), a.lookahead, peek));
@@ -322,7 +344,7 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
                 "\"GBps_each_way\": [%.3f, %.3f], \"decoder_batches\": %zu, \"launches\": %llu, \"kernel_launches\": %llu, \"max_chains_per_launch\": %llu, "
                 "\"staging_bytes\": %llu, \"staging_grew_bytes\": %llu, \"slots_peak\": [%llu, %llu], \"lanes\": %llu, \"mutex_wait_ms\": %.3f, \"mutex_contended\": %llu, \"launch_host_ms\": %.3f, \"launch_api_ms\": %.3f, \"lane_wait_ms\": %.3f, \"group_allocs\": %llu, \"blocks\": %llu, \"flag_wait_ms\": %.3f, "
                 "\"failed_tickets\": %llu, \"failures\": %zu, \"checksum\": %llu}\n",
-                codec_name, batcher ? "batcher" : "per-stream", a.direct ? "true" : "false", a.in_phase ? "true" : "false", a.streams, a.lookahead, std::min(a.threads, a.streams), n, secs, n / secs, frames_per_packet,
+                codec_name, a.via_registry ? "registry" : (batcher ? "batcher" : "per-stream"), a.direct ? "true" : "false", a.in_phase ? "true" : "false", a.streams, a.lookahead, std::min(a.threads, a.streams), n, secs, n / secs, frames_per_packet,
                 bytes_in_per_packet, frames_per_packet * params<Codec>().channels * 4, n * bytes_in_per_packet / secs / 1e9,
                 n * frames_per_packet * params<Codec>().channels * 4 / secs / 1e9, batches,
                 (unsigned long long)(s1.launches - s0.launches), (unsigned long long)(s1.chunks - s0.chunks),
@@ -353,6 +375,7 @@ int main(int argc, char **argv) {
         else if (k == "--per-stream") a.per_stream = true;
         else if (k == "--direct") a.direct = true;
         else if (k == "--in-phase") a.in_phase = true;
+        else if (k == "--via-registry") a.via_registry = true;
         else {
             std::fprintf(stderr, "unknown argument %s\n", k.c_str());
             return 2;
