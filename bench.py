@@ -425,10 +425,10 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
         pcm = torch.zeros((nch, pcm_stride), device=dev)
 
         def step():
-            for xs, mult, ys, n, offs, cnt in classes:
-                if name == "vorbisf":
-                    v.floor1(xs, mult, ys, n, None, cnt, y_plane=plane, line_offsets=offs)
-                else:
+            if name == "vorbisf":  # (both block-size classes in one launch)
+                v.floor1_y_jobs([(xs, mult, ys, n, offs, cnt) for xs, mult, ys, n, offs, cnt in classes], plane)
+            else:
+                for xs, mult, ys, n, offs, cnt in classes:
                     v.floor1(xs, mult, ys, n, spectrum, cnt, residue=residue, line_offsets=offs)
             if name == "vorbisf":
                 v.synth_floor_y(plane, residue, d_flags, prev[0], overlap[0], pcm_stride, pcm, state_out=(prev[1], overlap[1]))
@@ -442,7 +442,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             "workload": "Vorbis 2048/256, 8 ch, %d blocks (%d chains x %d) from floor-1 posts + residue: %s" % (
                 nch * nb // 8, nch, nb, "byte plane of dB-table indices, multiplied in the synthesis load path" if name == "vorbisf" else
                 "curve x residue as an f32 spectrum, then synthesis"),
-            "channel_blocks": nch * nb}, "vorbis_floor1_kernel x2 + vorbis_synth_wave_kernel", pcm
+            "channel_blocks": nch * nb}, ("vorbis_floor1_pair_kernel + vorbis_synth_wave_kernel" if name == "vorbisf" else "vorbis_floor1_kernel x2 + vorbis_synth_wave_kernel"), pcm
     if name == "flac":
         nb, bs = max(2, int(1048576 * scale) & ~1), 4096  # config 5: 1 M subframe blocks of 4096 samples = 16 GiB, in place
         buf, desc, co, pair_mode, _ = flac_config5(torch, nb, bs, seed, dev)

@@ -506,6 +506,19 @@ int symaccel_vorbis_floor1_dot_at_device(symaccel_ctx *ctx, const uint32_t *x_li
 int symaccel_vorbis_floor1_y_device(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier,
                                     const uint32_t *d_y, uint32_t n, const uint32_t *d_line_offsets, uint8_t *d_floor_y,
                                     size_t count);
+/* Several such renders into ONE plane -- the block-size classes of a floor, the floors of a stream (vorbis/lib.rs:206-232 picks a floor
+ * per channel and block) -- as jobs of one call: two jobs share a launch (their workgroups fill each other's last round).  The jobs' lines
+ * must not overlap; each job's fields are symaccel_vorbis_floor1_y_device's arguments; jobs with count 0 are skipped; every job is
+ * checked before anything is launched. */
+typedef struct symaccel_vorbis_floor1_job {
+    const uint32_t *x_list;
+    int n_posts, multiplier;
+    const uint32_t *d_y;
+    uint32_t n;
+    const uint32_t *d_line_offsets;
+    size_t count;
+} symaccel_vorbis_floor1_job;
+int symaccel_vorbis_floor1_y_jobs_device(symaccel_ctx *ctx, const symaccel_vorbis_floor1_job *jobs, size_t n_jobs, uint8_t *d_floor_y);
 /* Per-block status of the y rows (d_status[count] int8): 0, or SYMACCEL_ERR_UNSUPPORTED for a block with a value above
  * 511.  floor1_Y values are codebook entry numbers (floor.rs:698-712) that a conforming stream keeps below the floor's
  * range (<= 256); the reference computes whatever a larger value implies in i32.  Up to 511 the kernels above reproduce

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "symaccel_mp3_requantize_device", "symaccel_mp3_requantize", "symaccel_mp3_stereo_device", "symaccel_mp3_requantize_stereo_device",
     "symaccel_vorbis_synth_device", "symaccel_vorbis_synth_fr_device", "symaccel_vorbis_synth", "symaccel_vorbis_inverse_coupling_device",
     "symaccel_vorbis_dot_product_device", "symaccel_vorbis_deinterleave2_device",
-    "symaccel_vorbis_floor1_device", "symaccel_vorbis_floor1_dot_device", "symaccel_vorbis_floor1_y_device", "symaccel_vorbis_floor1_dot_at_device",
+    "symaccel_vorbis_floor1_device", "symaccel_vorbis_floor1_dot_device", "symaccel_vorbis_floor1_y_device", "symaccel_vorbis_floor1_dot_at_device", "symaccel_vorbis_floor1_y_jobs_device",
     "symaccel_vorbis_synth_fy_pp_device", "symaccel_vorbis_synth_fy_device", "symaccel_flac_restore_device", "symaccel_flac_restore", "symaccel_flac_restore_stereo_device",
     "symaccel_flac_decorrelate_device", "symaccel_flac_decorrelate", "symaccel_alac_predict_device",
     "symaccel_alac_predict", "symaccel_alac_predict_stereo_device", "symaccel_alac_mid_side_device", "symaccel_alac_mid_side", "symaccel_table_f32", "symaccel_imdct_twiddles",
@@ -57,6 +57,11 @@ ABI_SYMBOLS = [
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
+
+
+class VorbisFloor1Job(C.Structure):  # symaccel_vorbis_floor1_job
+    _fields_ = [("x_list", C.c_void_p), ("n_posts", C.c_int), ("multiplier", C.c_int), ("d_y", C.c_void_p), ("n", C.c_uint32),
+                ("d_line_offsets", C.c_void_p), ("count", C.c_size_t)]
 
 
 class SymaccelError(RuntimeError):
@@ -166,6 +171,7 @@ class Library:
         d.symaccel_vorbis_floor1_device.argtypes = [_vp, _vp, _i, _i, _vp, _u32, _vp, _sz]
         d.symaccel_vorbis_floor1_dot_device.argtypes = [_vp, _vp, _i, _i, _vp, C.c_uint32, _vp, _vp, _sz]
         d.symaccel_vorbis_floor1_y_device.argtypes = [_vp, _vp, _i, _i, _vp, C.c_uint32, _vp, _vp, _sz]
+        d.symaccel_vorbis_floor1_y_jobs_device.argtypes = [_vp, _vp, _sz, _vp]
         d.symaccel_vorbis_floor1_dot_at_device.argtypes = [_vp, _vp, _i, _i, _vp, C.c_uint32, _vp, _vp, _vp, _sz]
         d.symaccel_vorbis_synth_fy_pp_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_vorbis_synth_fy_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]

@@ -561,6 +561,20 @@ class VorbisDsp:
                            int(n), _ptr(residue), _ptr(floor), int(count))
 
 
+    def floor1_y_jobs(self, jobs, y_plane):
+        """several floor1(..., y_plane=...) renders into ONE plane, two per launch (symaccel_vorbis_floor1_y_jobs_device):
+        jobs = [(x_list, multiplier, y, n, line_offsets or None, count)]; the jobs' lines must not overlap."""
+        from ._ffi import VorbisFloor1Job
+        arr = (VorbisFloor1Job * max(1, len(jobs)))()
+        keep = []
+        for k, (x_list, multiplier, y, n, line_offsets, count) in enumerate(jobs):
+            xl = _np(x_list, np.uint32)
+            keep.append(xl)
+            arr[k] = VorbisFloor1Job(_ptr(xl), xl.size, int(multiplier), _ptr(y), int(n),
+                                     _ptr(line_offsets) if line_offsets is not None else None, int(count))
+        self.ctx._call(self.ctx.lib.dll.symaccel_vorbis_floor1_y_jobs_device, arr, len(jobs), _ptr(y_plane))
+
+
 FLAC_DESC_DTYPE = np.dtype([("kind", np.uint8), ("order", np.uint8), ("shift", np.uint8), ("wasted_bits", np.uint8)])
 FLAC_VERBATIM, FLAC_FIXED, FLAC_LPC = 0, 1, 2
 

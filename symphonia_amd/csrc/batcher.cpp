@@ -657,7 +657,7 @@ int launch_chunk(symaccel_ctx *ctx, Group *g, size_t c0, size_t nc, size_t t0, s
     }
     case SYMACCEL_BATCH_VORBIS_DECODE: {
         // symaccel_vorbis_decode's kernel sequence (csrc/ctx.cpp) on the chunk: the coupling steps and the zero floors in place
-        // (lib.rs:250-278, 206-209), the floor curves as one byte per line -- one launch per (configuration, block size) class
+        // (lib.rs:250-278, 206-209), the floor curves as one byte per line -- the (configuration, block size) classes two per launch
         // (floor.rs:568-653, 776-825) --, then the synthesis with table[y] * residue in its load path (lib.rs:282-292, dsp.rs:68-126)
         const int e0 = g->param & 255, e1 = (g->param >> 8) & 255, nch = (g->param >> 16) & 255;
         const size_t cap = g->units << (e1 - 1);
@@ -667,10 +667,14 @@ int launch_chunk(symaccel_ctx *ctx, Group *g, size_t c0, size_t nc, size_t t0, s
         if (ch.prepare)
             SYM_TRY(launch_vorbis_prepare(ctx, (float *)in(0), cap, (unsigned)nch, nt, g->units, g->d_vb_boff + ch.boff0, g->d_vb_steps + 2 * ch.steps0,
                                           g->d_vb_first + ch.first0, g->d_vb_kill + ch.kill0));
-        for (const Group::VbClass &k : ch.classes) {
-            const symaccel_vorbis_floor1_cfg &cfg = g->vb_floors[k.cfg];
-            SYM_TRY(symaccel_vorbis_floor1_y_device(ctx, cfg.x_list, cfg.n_posts, cfg.multiplier, g->d_vb_ys + k.ys0, k.n2, g->d_vb_offs + k.offs0, plane,
-                                                    k.count));
+        {
+            std::vector<symaccel_vorbis_floor1_job> jobs;  // two classes per launch
+            jobs.reserve(ch.classes.size());
+            for (const Group::VbClass &k : ch.classes) {
+                const symaccel_vorbis_floor1_cfg &cfg = g->vb_floors[k.cfg];
+                jobs.push_back(symaccel_vorbis_floor1_job{cfg.x_list, cfg.n_posts, cfg.multiplier, g->d_vb_ys + k.ys0, k.n2, g->d_vb_offs + k.offs0, k.count});
+            }
+            SYM_TRY(symaccel_vorbis_floor1_y_jobs_device(ctx, jobs.data(), jobs.size(), plane));
         }
         return symaccel_vorbis_synth_fy_pp_device(ctx, e0, e1, plane, (const float *)in(0), cap, (const uint8_t *)in(1), (const int32_t *)si(0),
                                                   (int32_t *)so(0), (const float *)si(1), (float *)so(1), (float *)out, cap, nc, g->units);

@@ -849,9 +849,10 @@ int symaccel_vorbis_decode(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const fl
         SYM_TRY(launch_vorbis_prepare(ctx, (float *)res.p, spec_stride, (unsigned)cps, n_streams, nb, (const uint32_t *)d_off.p,
                                       (const uint8_t *)d_steps.p, (const uint32_t *)d_first.p, (const uint8_t *)d_kill.p));
     }
-    // floor.rs:568-653 + 776-825 as one byte per line, one launch per class
+    // floor.rs:568-653 + 776-825 as one byte per line: the (floor, class) pairs are jobs, two per launch
     std::vector<DevBuf> keep;
     keep.reserve(4 * n_floors);
+    std::vector<symaccel_vorbis_floor1_job> jobs;
     for (size_t k = 0; k < 2 * n_floors; ++k) {
         if (offs[k].empty()) continue;
         const symaccel_vorbis_floor1_cfg &cfg = h_floors[k / 2];
@@ -862,9 +863,9 @@ int symaccel_vorbis_decode(symaccel_ctx *ctx, int bs0_exp, int bs1_exp, const fl
         DevBuf &dof = keep.back();
         SYM_TRY(dof.from_host(offs[k].data(), offs[k].size() * 4));
         const uint32_t n2 = (uint32_t)1 << ((k & 1 ? bs1_exp : bs0_exp) - 1);
-        SYM_TRY(symaccel_vorbis_floor1_y_device(ctx, cfg.x_list, cfg.n_posts, cfg.multiplier, (const uint32_t *)dy.p, n2,
-                                                (const uint32_t *)dof.p, (uint8_t *)plane.p, offs[k].size()));
+        jobs.push_back(symaccel_vorbis_floor1_job{cfg.x_list, cfg.n_posts, cfg.multiplier, (const uint32_t *)dy.p, n2, (const uint32_t *)dof.p, offs[k].size()});
     }
+    SYM_TRY(symaccel_vorbis_floor1_y_jobs_device(ctx, jobs.data(), jobs.size(), (uint8_t *)plane.p));
     // lib.rs:282-292 (one rounded multiply per line, in the load path) + dsp.rs:68-126
     SYM_TRY(symaccel_vorbis_synth_fy_device(ctx, bs0_exp, bs1_exp, (const uint8_t *)plane.p, (const float *)res.p, spec_stride,
                                             (const uint8_t *)bf.p, (int32_t *)pf.p, (float *)ov.p, (float *)pcm.p, pcm_stride, n_chains, nb));
@@ -907,17 +908,11 @@ int symaccel_vorbis_deinterleave2_device(symaccel_ctx *ctx, const float *d_type2
     return launch_vorbis_deinterleave(ctx, d_type2, d_planar, n_ch, n2, count);
 }
 
-static int vorbis_floor1(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier, const uint32_t *d_y, uint32_t n,
-                         float *d_floor, size_t count, const float *d_residue, uint8_t *d_floor_y = nullptr,
-                         const uint32_t *d_line_offs = nullptr) {
-    if (!ctx || n_posts < 2 || n_posts > 65 || multiplier < 1 || multiplier > 4) return SYMACCEL_ERR_INVALID_ARG;
-    if (count == 0 || n == 0) return SYMACCEL_OK;
-    if (!x_list || !d_y || (!d_floor && !d_floor_y)) return SYMACCEL_ERR_INVALID_ARG;
-    DeviceGuard dev(ctx);
-    if (!dev.ok()) return dev.status();
-    // Setup-time derivations the reference does once per floor (floor.rs:540-555, 748-773):
-    // neighbours of every post and the x-sorted visiting order.
-    uint32_t setup[65 * 4] = {0};  // x | low neighbour | high neighbour | sort order
+// Setup-time derivations the reference does once per floor (floor.rs:540-555, 748-773): neighbours of every post and the x-sorted
+// visiting order; with the argument checks every floor-1 entry point shares.  setup[65 * 4]: x | low neighbour | high neighbour | sort order
+static int vorbis_floor1_setup(const uint32_t *x_list, int n_posts, int multiplier, uint32_t n, uint32_t *setup) {
+    if (n_posts < 2 || n_posts > 65 || multiplier < 1 || multiplier > 4 || !x_list) return SYMACCEL_ERR_INVALID_ARG;
+    std::memset(setup, 0, 65 * 4 * sizeof(uint32_t));
     for (int x = 0; x < n_posts; ++x) {
         uint32_t bound = x_list[x], low = 0, high = 0xffffffffu, rl = 0, rh = 0;
         for (int i = 0; i < x; ++i) {
@@ -941,6 +936,19 @@ static int vorbis_floor1(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts,
     for (int i = 0; i < n_posts; ++i)
         if (x_list[i] > 0xffffu) return SYMACCEL_ERR_INVALID_ARG;  // floor1_X values have at most 15 bits (rangebits)
     if (n > 4096u || (n & 15u)) return SYMACCEL_ERR_INVALID_ARG;  // n = blocksize / 2, blocksize = 2^6 .. 2^13 (lib.rs:404-406)
+    return SYMACCEL_OK;
+}
+
+static int vorbis_floor1(symaccel_ctx *ctx, const uint32_t *x_list, int n_posts, int multiplier, const uint32_t *d_y, uint32_t n,
+                         float *d_floor, size_t count, const float *d_residue, uint8_t *d_floor_y = nullptr,
+                         const uint32_t *d_line_offs = nullptr) {
+    if (!ctx || n_posts < 2 || n_posts > 65 || multiplier < 1 || multiplier > 4) return SYMACCEL_ERR_INVALID_ARG;
+    if (count == 0 || n == 0) return SYMACCEL_OK;
+    if (!x_list || !d_y || (!d_floor && !d_floor_y)) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    uint32_t setup[65 * 4];
+    SYM_TRY(vorbis_floor1_setup(x_list, n_posts, multiplier, n, setup));
     // the derived tables travel as a kernel argument: no staging copy, no stream synchronisation
     return launch_vorbis_floor1(ctx, setup, n_posts, multiplier, d_y, n, d_floor, count, d_residue, d_floor_y, d_line_offs);
 }
@@ -964,6 +972,41 @@ int symaccel_vorbis_floor1_y_device(symaccel_ctx *ctx, const uint32_t *x_list, i
                                     uint32_t n, const uint32_t *d_line_offsets, uint8_t *d_floor_y, size_t count) {
     if (count != 0 && n != 0 && (!d_floor_y || ((uintptr_t)d_floor_y & 3u))) return SYMACCEL_ERR_INVALID_ARG;
     return vorbis_floor1(ctx, x_list, n_posts, multiplier, d_y, n, nullptr, count, nullptr, d_floor_y, d_line_offsets);
+}
+
+int symaccel_vorbis_floor1_y_jobs_device(symaccel_ctx *ctx, const symaccel_vorbis_floor1_job *jobs, size_t n_jobs, uint8_t *d_floor_y) {
+    if (!ctx || (n_jobs && !jobs)) return SYMACCEL_ERR_INVALID_ARG;
+    // every job is checked before anything is launched
+    std::vector<const symaccel_vorbis_floor1_job *> live;
+    for (size_t k = 0; k < n_jobs; ++k) {
+        const symaccel_vorbis_floor1_job &j = jobs[k];
+        if (j.n_posts < 2 || j.n_posts > 65 || j.multiplier < 1 || j.multiplier > 4) return SYMACCEL_ERR_INVALID_ARG;
+        if (j.count == 0 || j.n == 0) continue;
+        if (!j.x_list || !j.d_y || !d_floor_y || ((uintptr_t)d_floor_y & 3u)) return SYMACCEL_ERR_INVALID_ARG;
+        live.push_back(&j);
+    }
+    if (live.empty()) return SYMACCEL_OK;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    std::vector<uint32_t> setups(live.size() * 65 * 4);
+    for (size_t k = 0; k < live.size(); ++k)
+        SYM_TRY(vorbis_floor1_setup(live[k]->x_list, live[k]->n_posts, live[k]->multiplier, live[k]->n, setups.data() + k * 65 * 4));
+    size_t k = 0;
+    for (; k + 1 < live.size(); k += 2) {  // two jobs per grid
+        const symaccel_vorbis_floor1_job &a = *live[k], &b = *live[k + 1];
+        const uint32_t *const su[2] = {setups.data() + k * 65 * 4, setups.data() + (k + 1) * 65 * 4};
+        const int np[2] = {a.n_posts, b.n_posts}, mu[2] = {a.multiplier, b.multiplier};
+        const uint32_t *const dy[2] = {a.d_y, b.d_y};
+        const uint32_t nn[2] = {a.n, b.n};
+        const size_t cn[2] = {a.count, b.count};
+        const uint32_t *const lo[2] = {a.d_line_offsets, b.d_line_offsets};
+        SYM_TRY(launch_vorbis_floor1_pair(ctx, su, np, mu, dy, nn, cn, lo, d_floor_y));
+    }
+    if (k < live.size()) {
+        const symaccel_vorbis_floor1_job &a = *live[k];
+        SYM_TRY(launch_vorbis_floor1(ctx, setups.data() + k * 65 * 4, a.n_posts, a.multiplier, a.d_y, a.n, nullptr, a.count, nullptr, d_floor_y, a.d_line_offsets));
+    }
+    return SYMACCEL_OK;
 }
 
 // ---- FLAC ---------------------------------------------------------------------------------

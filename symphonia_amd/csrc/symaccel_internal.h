@@ -245,6 +245,9 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
 int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier,
                          const uint32_t *d_y, uint32_t n, float *d_floor, size_t count, const float *d_residue = nullptr,
                          uint8_t *d_floor_y = nullptr, const uint32_t *d_line_offs = nullptr);
+int launch_vorbis_floor1_pair(symaccel_ctx *ctx, const uint32_t *const h_setup[2], const int n_posts[2], const int multiplier[2],
+                              const uint32_t *const d_y[2], const uint32_t n[2], const size_t count[2], const uint32_t *const d_line_offs[2],
+                              uint8_t *d_floor_y);
 int launch_aac_joint_stereo(symaccel_ctx *ctx, const AacBandMaps &maps, float *d_coeffs, size_t frames_per_chain,
                             const int32_t *d_pair_chains, const symaccel_aac_js_frame *d_desc, size_t n_pairs,
                             const uint32_t *d_list = nullptr, size_t n_list = 0);

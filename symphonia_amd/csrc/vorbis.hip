@@ -450,11 +450,9 @@ constexpr int kF1Stride = kF1B + 1;      // LDS row stride of the per-block list
 //         curve; the synthesis kernels look the table up as they load the residue (symaccel_vorbis_synth_fy_*): 1 B / line
 //         written here and read there instead of 4 + 4 + 4 B / line for a multiplied spectrum.
 template <int MODE, int NMAX>
-__global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setup st, int n_posts, int multiplier,
-                                                                      const uint32_t *__restrict__ yv, uint32_t n,
-                                                                      float *floor_out, const float *__restrict__ db,
-                                                                      size_t count, const float *residue,
-                                                                      const uint32_t *__restrict__ line_offs) {
+__device__ __forceinline__ void floor1_workgroup(const Floor1Setup &st, int n_posts, int multiplier, const uint32_t *__restrict__ yv, uint32_t n,
+                                                 float *floor_out, const float *__restrict__ db, size_t count, const float *residue,
+                                                 const uint32_t *__restrict__ line_offs, unsigned wg) {
     constexpr bool DOT = MODE == 1;
     // LDS per workgroup: 13 KiB of point lists + 8.2 KiB (n <= 1024; 20 KiB otherwise) that first hold final_y and then, per
     // wavefront, a segment table and a segment-start map (n bytes): 22.6 KiB, seven workgroups per CU
@@ -472,7 +470,7 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
     // the render's: constants of the segments of the block being rendered (x0 | 4 y0 << 16, +-|dy| / adx, +-0.5 / adx) ...
     uint4 *segc = reinterpret_cast<uint4 *>(overlay + wave * kPerWave);
     uint8_t *mark = overlay + wave * kPerWave + 67 * 16;  // ... and its segment-start map
-    const size_t blk0 = (size_t)blockIdx.x * kF1B;
+    const size_t blk0 = (size_t)wg * kF1B;
     const int nb = (int)(count - blk0 < (size_t)kF1B ? count - blk0 : (size_t)kF1B);
     if (tid < 256) dbl[tid] = db[tid];
     // the y rows of the 64 blocks are contiguous: coalesced load by the whole workgroup, transposed into LDS
@@ -725,6 +723,40 @@ __global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setu
     }
 }
 
+template <int MODE, int NMAX>
+__global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_kernel(Floor1Setup st, int n_posts, int multiplier,
+                                                                      const uint32_t *__restrict__ yv, uint32_t n,
+                                                                      float *floor_out, const float *__restrict__ db,
+                                                                      size_t count, const float *residue,
+                                                                      const uint32_t *__restrict__ line_offs) {
+    floor1_workgroup<MODE, NMAX>(st, n_posts, multiplier, yv, n, floor_out, db, count, residue, line_offs, blockIdx.x);
+}
+
+// Two floor-1 jobs in ONE grid (byte form): the block-size classes of a stream's floor -- or two floors -- are independent renders into
+// the same plane, and as two launches the second waits for the first's last, partly filled round of workgroups (a launch of 3078
+// workgroups is 1.7 rounds of the 1792 resident ones).  Workgroups below job[0].grid belong to the first job; everything a workgroup
+// reads from its job is wave-uniform (scalar loads from the kernel-argument segment at a selected offset).
+struct Floor1Job {
+    Floor1Setup st;
+    const uint32_t *yv;
+    const uint32_t *line_offs;
+    size_t count;
+    uint32_t n;
+    int n_posts, multiplier;
+    unsigned grid;
+};
+struct Floor1Jobs {
+    Floor1Job job[2];
+};
+template <int NMAX>
+__global__ __launch_bounds__(64 * kF1Waves) void vorbis_floor1_pair_kernel(Floor1Jobs jobs, uint8_t *plane, const float *__restrict__ db) {
+    const unsigned g0 = jobs.job[0].grid;
+    const bool second = blockIdx.x >= g0;
+    const Floor1Job &j = jobs.job[second ? 1 : 0];
+    floor1_workgroup<2, NMAX>(j.st, j.n_posts, j.multiplier, j.yv, j.n, reinterpret_cast<float *>(plane), db, j.count, nullptr, j.line_offs,
+                              second ? blockIdx.x - g0 : blockIdx.x);
+}
+
 int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -846,12 +878,7 @@ int launch_vorbis_deinterleave(symaccel_ctx *ctx, const float *d_type2, float *d
     return SYMACCEL_OK;
 }
 
-int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier, const uint32_t *d_y,
-                         uint32_t n, float *d_floor, size_t count, const float *d_residue, uint8_t *d_floor_y,
-                         const uint32_t *d_line_offs) {
-    const size_t grid = (count + kF1B - 1) / kF1B;
-    if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    Floor1Setup st{};  // passed by value: the kernel reads it with scalar loads (wave-uniform indices)
+static void floor1_derive(Floor1Setup &st, const uint32_t *h_setup, int n_posts) {
     for (int k = 0; k < n_posts; ++k) {
         const uint32_t i = h_setup[195 + k] & 255u;
         st.ord[k] = i | (h_setup[i] & 0xffffu) << 16;
@@ -866,6 +893,15 @@ int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts
         st.half[i] = 0.5f / fadx;
         st.wide[i] = ((h_setup[i] - h_setup[lo]) & 0xffffu) | (uint32_t)(adx > 0 ? adx : 1) << 16;  // (x[i] - x[lo]) | adx << 16
     }
+}
+
+int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts, int multiplier, const uint32_t *d_y,
+                         uint32_t n, float *d_floor, size_t count, const float *d_residue, uint8_t *d_floor_y,
+                         const uint32_t *d_line_offs) {
+    const size_t grid = (count + kF1B - 1) / kF1B;
+    if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    Floor1Setup st{};  // passed by value: the kernel reads it with scalar loads (wave-uniform indices)
+    floor1_derive(st, h_setup, n_posts);
     // instantiated per block class: the segment-start map is n bytes of LDS, and LDS is what bounds the resident wavefronts
 #define SYM_F1_LAUNCH(MODE, NMAX)                                                                                                    \
     hipLaunchKernelGGL((vorbis_floor1_kernel<MODE, NMAX>), dim3((unsigned)grid), dim3(64 * kF1Waves), 0, ctx->stream, st, n_posts, multiplier, d_y, \
@@ -878,6 +914,33 @@ int launch_vorbis_floor1(symaccel_ctx *ctx, const uint32_t *h_setup, int n_posts
         if (n <= 1024) SYM_F1_LAUNCH(0, 1024); else SYM_F1_LAUNCH(0, 4096);
     }
 #undef SYM_F1_LAUNCH
+    SYM_GPU(ctx, hipGetLastError());
+    return SYMACCEL_OK;
+}
+
+int launch_vorbis_floor1_pair(symaccel_ctx *ctx, const uint32_t *const h_setup[2], const int n_posts[2], const int multiplier[2],
+                              const uint32_t *const d_y[2], const uint32_t n[2], const size_t count[2], const uint32_t *const d_line_offs[2],
+                              uint8_t *d_floor_y) {
+    Floor1Jobs jobs{};
+    size_t grid = 0;
+    for (int k = 0; k < 2; ++k) {
+        Floor1Job &j = jobs.job[k];
+        floor1_derive(j.st, h_setup[k], n_posts[k]);
+        j.yv = d_y[k];
+        j.line_offs = d_line_offs[k];
+        j.count = count[k];
+        j.n = n[k];
+        j.n_posts = n_posts[k];
+        j.multiplier = multiplier[k];
+        const size_t g = (count[k] + kF1B - 1) / kF1B;
+        if (g > 0x3fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+        j.grid = (unsigned)g;
+        grid += g;
+    }
+    if (n[0] <= 1024 && n[1] <= 1024)
+        hipLaunchKernelGGL((vorbis_floor1_pair_kernel<1024>), dim3((unsigned)grid), dim3(64 * kF1Waves), 0, ctx->stream, jobs, d_floor_y, ctx->dev.vorbis_floor1_db);
+    else
+        hipLaunchKernelGGL((vorbis_floor1_pair_kernel<4096>), dim3((unsigned)grid), dim3(64 * kF1Waves), 0, ctx->stream, jobs, d_floor_y, ctx->dev.vorbis_floor1_db);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

@@ -165,7 +165,7 @@ def test_bench_line_carries_the_other_workloads():
     ow = d["other_workloads"]
     assert set(ow) == {"mp3", "vorbis", "flac", "alac", "aac_mix_0.05", "aac_mix_0.25", "mp3_mix_0.06", "mp3_int16_one_kernel", "mp3_int16_two_kernels",
                        "vorbis_posts_byte_plane", "vorbis_posts_f32_spectrum",
-                       "aac_joint_stereo_on_load", "aac_joint_stereo_two_kernels"}
+                       "aac_joint_stereo_on_load", "aac_joint_stereo_two_kernels", "aac_tns_0.30"}
     for name, line in ow.items():
         assert "error" not in line, (name, line)
         assert line["steps"] == (8 if name in ("flac", "alac") else 20) and line["value"] > 0 and line["algorithmic_bytes_per_launch"] > 0

@@ -56,6 +56,51 @@ def test_emu_floor1_y_plane(emu_ctx):
     check_floor1_y(emu_ctx, lambda a: a, lambda a: a)
 
 
+def check_floor1_y_jobs(ctx, to_dev, to_host):
+    """symaccel_vorbis_floor1_y_jobs_device: several (floor, block size) renders into one plane, two per launch, == one call each ==
+    the oracle; an empty job is skipped; a malformed job fails the call before anything is written"""
+    from symphonia_amd import SymaccelError
+    rng = np.random.default_rng(707)
+    v = VorbisDsp(ctx, 8, 11)
+    db = db_table()
+    for shapes in (((1024, 40, 2, 130), (128, 12, 2, 70)), ((1024, 30, 1, 5), (2048, 65, 1, 9), (64, 4, 3, 200)), ((128, 9, 4, 1),),
+                   ((256, 20, 2, 0), (512, 33, 1, 66), (4096, 50, 2, 3), (128, 2, 1, 65))):
+        jobs, want, base = [], [], 16
+        for n, n_posts, mult, count in shapes:
+            xs, ys = floor_case(rng, n, n_posts, mult, max(count, 1), 0.25)
+            ys = ys[:count]
+            offs = (rng.permutation(max(count, 1))[:count].astype(np.uint32) * np.uint32(n + 16) + np.uint32(base))
+            base += (max(count, 1)) * (n + 16) + 32
+            jobs.append((xs, mult, to_dev(ys) if count else None, n, to_dev(offs) if count else None, count))
+            want.append((n, offs, [oracle.vorbis_floor1(xs, y, mult, n) for y in ys]))
+        plane = to_dev(np.full(base + 64, 0x5A, np.uint8))
+        v.floor1_y_jobs(jobs, plane)
+        got = to_host(plane)
+        seen = np.zeros(got.size, bool)
+        for n, offs, curves in want:
+            for o, c in zip(offs, curves):
+                assert bit_equal(db[got[o:o + n]], c), (shapes, n, o)
+                seen[o:o + n] = True
+        assert np.all(got[~seen] == 0x5A), shapes
+        # == one call per job
+        single = to_dev(np.full(base + 64, 0x5A, np.uint8))
+        for xs, mult, ys, n, offs, count in jobs:
+            if count:
+                v.floor1(xs, mult, ys, n, None, count, y_plane=single, line_offsets=offs)
+        assert np.array_equal(to_host(single), got)
+    # the second job's x list has a repeated value (render_line would divide by zero): nothing is launched
+    xs, ys = floor_case(rng, 128, 6, 1, 3, 0.0)
+    plane = to_dev(np.full(3 * 128, 0x5A, np.uint8))
+    with pytest.raises(SymaccelError):
+        v.floor1_y_jobs([(xs, 1, to_dev(ys), 128, None, 3), ([0, 128, 7, 7, 9, 11], 1, to_dev(ys), 128, None, 3)], plane)
+    ctx.sync()
+    assert np.all(to_host(plane) == 0x5A)
+
+
+def test_emu_floor1_y_jobs(emu_ctx):
+    check_floor1_y_jobs(emu_ctx, lambda a: a, lambda a: a)
+
+
 def fy_case(rng, bs0e, bs1e, nch, nb):
     from test_emu_codecs import vorbis_case
     flags, prev, residue, overlap, pcm_stride = vorbis_case(rng, bs0e, bs1e, nch, nb)
@@ -170,6 +215,11 @@ def gpu():
 @pytest.mark.gpu
 def test_gpu_floor1_y_plane(gpu):
     check_floor1_y(*gpu)
+
+
+@pytest.mark.gpu
+def test_gpu_floor1_y_jobs(gpu):
+    check_floor1_y_jobs(*gpu)
 
 
 @pytest.mark.gpu

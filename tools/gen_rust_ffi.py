@@ -69,8 +69,10 @@ def parse(text):
                 continue
             ctype, names = decl.rsplit(" ", 1)[0], decl[len(decl.rsplit(" ", 1)[0]) + 1:]
             # `uint16_t rzero0, rzero1` / `uint8_t scalefacs[39]`
-            first, *rest = [n.strip() for n in (decl.split(" ", 1)[1]).split(",")]
-            ctype = decl.split(" ", 1)[0]
+            toks = decl.split(" ")
+            nt = 2 if toks[0] == "const" else 1  # `const uint32_t *x_list`
+            first, *rest = [n.strip() for n in " ".join(toks[nt:]).split(",")]
+            ctype = " ".join(toks[:nt])
             for n in [first] + rest:
                 ft = ctype
                 while n.startswith("*"):  # `void *in[4]`: a pointer field
