@@ -224,6 +224,11 @@ impl Pool {
             flag_wait_ns: 0,
             slots_peak: 0,
             blocks: 0,
+            commit_to_launch_ns: 0,
+            waits: 0,
+            waits_blocked: 0,
+            launch_to_done_ns: 0,
+            launches_timed: 0,
         };
         // SAFETY: a live batcher, a valid out-pointer.
         self.check(unsafe { ffi::symaccel_batcher_get_stats(self.batcher, &mut s) })?;

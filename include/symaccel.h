@@ -723,6 +723,9 @@ typedef struct symaccel_batcher_stats {
     uint64_t flag_wait_ns;          /* time callers spent waiting for a launch's completion flag (device + link time they could not hide) */
     uint64_t slots_peak;            /* most submissions alive at once (reserved and not yet released) */
     uint64_t blocks;                /* device-side blocks in the pool (memory + descriptors + events; reused as soon as a launch completes) */
+    uint64_t commit_to_launch_ns;   /* summed over submissions: commit -> the closing of their group (how long they sat pending) */
+    uint64_t waits, waits_blocked;  /* waits on a completion word; those that found it not yet written */
+    uint64_t launch_to_done_ns, launches_timed; /* for launches somebody had to wait for: enqueue finished -> completion seen, summed; how many */
 } symaccel_batcher_stats;
 /* flush_bytes: input bytes of one group after which it is launched without anybody waiting (0 = 64 MiB); also sizes the
  * staging memory of a group (input + output + state, page-locked, pooled and reused). */

@@ -781,7 +781,7 @@ class BatchSlot(C.Structure):
 class BatcherStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("submissions", "launches", "chunks", "chains_launched", "max_chains_per_launch", "staging_bytes",
                                            "pending", "failed_tickets", "lanes", "mutex_wait_ns", "mutex_contended", "launch_host_ns",
-                                           "lane_wait_ns", "launch_api_ns", "group_allocs", "flag_wait_ns", "slots_peak", "blocks")]
+                                           "lane_wait_ns", "launch_api_ns", "group_allocs", "flag_wait_ns", "slots_peak", "blocks", "commit_to_launch_ns", "waits", "waits_blocked", "launch_to_done_ns", "launches_timed")]
 
 
 def _slot_view(ptr, nbytes, dtype, shape):

@@ -18,7 +18,8 @@ namespace {
 // A capped grid walks the piece list: the link needs about a hundred KiB in flight (50 GB/s x 2 us), not the 32 MiB a grid of one
 // workgroup per piece keeps resident -- such a grid fills every wave slot of the device with workgroups that wait for PCIe, and the
 // scatter and the synthesis kernel of the neighbouring chunk (other streams) queue behind it instead of running beside it.
-template <bool NT>
+// (DIR -- 0 = gather, host to device; 1 = scatter -- changes nothing in the code: it names the two directions apart in a kernel trace)
+template <bool NT, int DIR>
 __global__ __launch_bounds__(256) void batch_copy_kernel(const BatchCopyDesc *__restrict__ descs, unsigned n_pieces) {
   for (unsigned piece = blockIdx.x; piece < n_pieces; piece += gridDim.x) {
     const BatchCopyDesc d = descs[piece];
@@ -80,7 +81,7 @@ int launch_batch_flag(symaccel_ctx *ctx, hipStream_t stream, uint64_t *h_flag, u
     return SYMACCEL_OK;
 }
 
-int launch_batch_copy(symaccel_ctx *ctx, hipStream_t stream, const BatchCopyDesc *descs, size_t n) {
+int launch_batch_copy(symaccel_ctx *ctx, hipStream_t stream, const BatchCopyDesc *descs, size_t n, bool scatter) {
     if (n == 0) return SYMACCEL_OK;
     if (n > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     static const unsigned cap = [] {  // development knob: workgroups per copy launch (0 = one per piece, as rounds 5 had it)
@@ -92,8 +93,10 @@ int launch_batch_copy(symaccel_ctx *ctx, hipStream_t stream, const BatchCopyDesc
         const char *e = std::getenv("SYMACCEL_BATCH_COPY_NT");
         return e && std::atoi(e) != 0;
     }();
-    if (nt) hipLaunchKernelGGL(batch_copy_kernel<true>, dim3(grid), dim3(256), 0, stream, descs, (unsigned)n);
-    else hipLaunchKernelGGL(batch_copy_kernel<false>, dim3(grid), dim3(256), 0, stream, descs, (unsigned)n);
+    if (nt && scatter) hipLaunchKernelGGL((batch_copy_kernel<true, 1>), dim3(grid), dim3(256), 0, stream, descs, (unsigned)n);
+    else if (nt) hipLaunchKernelGGL((batch_copy_kernel<true, 0>), dim3(grid), dim3(256), 0, stream, descs, (unsigned)n);
+    else if (scatter) hipLaunchKernelGGL((batch_copy_kernel<false, 1>), dim3(grid), dim3(256), 0, stream, descs, (unsigned)n);
+    else hipLaunchKernelGGL((batch_copy_kernel<false, 0>), dim3(grid), dim3(256), 0, stream, descs, (unsigned)n);
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
 }

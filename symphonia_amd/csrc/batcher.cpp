@@ -250,11 +250,14 @@ inline size_t vorbis_blob_steps(size_t units) { return ((units + 1) * 4 + 15) & 
 
 struct Group;
 
+using Clock = std::chrono::steady_clock;
+
 struct Ticket {
     Group *group = nullptr;
     uint32_t gen = 0;
     uint32_t first_chain = 0, n_chains = 0, ordinal = 0;
     bool live = false, committed = false;
+    Clock::time_point committed_at{};
     int status = SYMACCEL_OK;  // of THIS submission, once its group is launched
     char *slot = nullptr;      // page-locked, slot_layout(group's planes, n_chains)
     size_t slot_bytes = 0;     // (the size class it was carved for)
@@ -303,6 +306,7 @@ struct Group {
     PlaneSizes ps;
     size_t cap_chains = 0;  // reservations accepted before the group is launched and a fresh one opened
     size_t chains = 0, tickets = 0, uncommitted = 0, live = 0;
+    Clock::time_point launched_at{};  // (enqueued: statistics)
     GroupState state = GroupState::Free;
     int status = SYMACCEL_OK;          // of the launch as a whole (a device error fails every ticket)
     std::vector<uint32_t> ticket_ids;  // the submissions, in order (index into symaccel_batcher::tickets)
@@ -350,7 +354,6 @@ struct Lane {
     std::mutex mu;
 };
 
-using Clock = std::chrono::steady_clock;
 inline uint64_t ns_since(Clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t0).count(); }
 
 }  // namespace
@@ -898,7 +901,18 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
     // a third of the group per chunk, 8 .. 32 MiB of input: a chunk costs three launches and two event hops (~40 us), which 2 MiB
     // chunks (44 us on the link) did not amortise -- 22.7 GB/s each way at look-ahead 64 against 37.9 at 256 (profiles/r05c_*);
     // consecutive GROUPS overlap on the lanes anyway, so a small group is one chunk
-    const size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)8 << 20, g->chains * per_chain / 3));
+    // (development knobs: SYMACCEL_BATCH_CHUNKS = chunks a full group is cut into, SYMACCEL_BATCH_CHUNK_MIN_KB = the smallest chunk)
+    static const size_t chunk_div = [] {
+        const char *e = std::getenv("SYMACCEL_BATCH_CHUNKS");
+        const long v = e ? std::atol(e) : 3;
+        return (size_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
+    static const size_t chunk_min = [] {
+        const char *e = std::getenv("SYMACCEL_BATCH_CHUNK_MIN_KB");
+        const long v = e ? std::atol(e) : 8192;
+        return (size_t)(v < 64 ? 64 : v) << 10;
+    }();
+    const size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>(chunk_min, g->chains * per_chain / chunk_div));
     const size_t chunk_chains = std::max<size_t>(1, chunk_bytes / per_chain);
     size_t t0 = 0, k = 0;
     while (t0 < g->tickets) {
@@ -1067,7 +1081,7 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
         const Clock::time_point api0 = Clock::now();
         for (const Dma &m : dma) SYM_GPU(ctx, hipMemcpyAsync(m.dst, m.src, m.bytes, hipMemcpyHostToDevice, s_in));
         dma.clear();
-        SYM_TRY(launch_batch_copy(ctx, s_in, g0, (size_t)(w - g0)));
+        SYM_TRY(launch_batch_copy(ctx, s_in, g0, (size_t)(w - g0), false));
         SYM_GPU(ctx, hipEventRecord(blk->ev_in[e], s_in));
         SYM_GPU(ctx, hipStreamWaitEvent(ctx->stream, blk->ev_in[e], 0));
         SYM_TRY(launch_chunk(ctx, g, c0, nc, t0, nt));
@@ -1097,7 +1111,7 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
         const Clock::time_point api1 = Clock::now();
         for (const Dma &m : dma) SYM_GPU(ctx, hipMemcpyAsync(m.dst, m.src, m.bytes, hipMemcpyDeviceToHost, s_out));
         dma.clear();
-        SYM_TRY(launch_batch_copy(ctx, s_out, s0, (size_t)(w - s0)));
+        SYM_TRY(launch_batch_copy(ctx, s_out, s0, (size_t)(w - s0), true));
         *api_ns += ns_since(api1);
         *n_chunks += 1;
         t0 = t1;
@@ -1185,9 +1199,11 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
     if (g->tickets) {
         // what the launch needs of the batcher, copied while the mutex is still ours
         g->views.resize(g->tickets);
+        const Clock::time_point closing = Clock::now();
         for (size_t i = 0; i < g->tickets; ++i) {
             const Ticket &t = b->tickets[g->ticket_ids[i]];
             g->views[i] = TicketView{t.slot, t.first_chain, t.n_chains, SYMACCEL_OK};
+            if (t.committed_at != Clock::time_point{}) b->stats.commit_to_launch_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(closing - t.committed_at).count();
         }
         if (g->kind == SYMACCEL_BATCH_AAC_DECODE && g->param >= 0) g->aac_maps = b->bands[(size_t)g->param].maps;  // (the index was checked by reserve())
         if (g->kind == SYMACCEL_BATCH_VORBIS_DECODE) g->vb_floors = b->floors;
@@ -1239,6 +1255,7 @@ void flush_group(symaccel_batcher *b, Group *g, std::unique_lock<std::mutex> &lo
     }
     g->status = st;
     g->state = GroupState::Launched;
+    g->launched_at = Clock::now();
     b->stats.launches += 1;
     b->stats.chunks += chunks;
     b->stats.launch_host_ns += host_ns;
@@ -1312,6 +1329,7 @@ void fill_slot(const Group *g, const Ticket *t, symaccel_batch_slot *slot) {
 // into a word of page-locked memory: the waiter reads that word -- spinning briefly, then yielding, then sleeping in steps of 20 us
 // -- and calls nothing in the runtime.  A word that never arrives (a hung or lost device) is a device error after `kFlagTimeout`.
 constexpr double kFlagTimeout = 60.0;
+
 int sync_done(symaccel_batcher *b, Group *g) {
     const uint64_t *flag;
     uint64_t seq;
@@ -1339,8 +1357,14 @@ int sync_done(symaccel_batcher *b, Group *g) {
         }
     }
     Locked l(b);
+    const uint64_t waited = ns_since(t0);
+    b->stats.waits += 1;
+    if (waited > 2000) {  // (the word was not there yet)
+        b->stats.waits_blocked += 1;
+        if (!g->completed) b->stats.launch_to_done_ns += ns_since(g->launched_at), b->stats.launches_timed += 1;  // (first to see it: enqueue -> completion seen)
+    }
     g->completed = true;
-    b->stats.flag_wait_ns += ns_since(t0);
+    b->stats.flag_wait_ns += waited;
     return SYMACCEL_OK;
 }
 
@@ -1454,6 +1478,7 @@ int symaccel_batcher_commit(symaccel_batcher *b, uint64_t ticket) {
     Ticket *t = find_ticket(b, ticket);
     if (!t || t->committed) return SYMACCEL_ERR_INVALID_ARG;
     t->committed = true;
+    t->committed_at = Clock::now();
     Group *g = t->group;
     g->uncommitted -= 1;
     if (g->uncommitted == 0) b->cv.notify_all();

@@ -288,7 +288,7 @@ struct BatchCopyDesc {
     uint32_t bytes, pad;
 };
 constexpr size_t kBatchCopyPiece = 16384;
-int launch_batch_copy(symaccel_ctx *ctx, hipStream_t stream, const BatchCopyDesc *descs, size_t n);
+int launch_batch_copy(symaccel_ctx *ctx, hipStream_t stream, const BatchCopyDesc *descs, size_t n, bool scatter);
 int launch_batch_flag(symaccel_ctx *ctx, hipStream_t stream, uint64_t *h_flag, uint64_t seq);  // (h_flag: page-locked host memory)
 int launch_probe_copy(symaccel_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, unsigned frames_per_wavefront, unsigned flags);
 int launch_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *d_mode, int32_t *d_ch0, int32_t *d_ch1,

@@ -342,7 +342,7 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
     std::printf("{\"codec\": \"%s\", \"mode\": \"%s\", \"direct\": %s, \"in_phase\": %s, \"streams\": %zu, \"lookahead\": %zu, \"threads\": %zu, \"packets\": %.0f, \"seconds\": %.6f, "
                 "\"packets_per_s\": %.1f, \"frames_per_packet\": %zu, \"host_bytes_in_per_packet\": %zu, \"host_bytes_out_per_packet\": %zu, "
                 "\"GBps_each_way\": [%.3f, %.3f], \"decoder_batches\": %zu, \"launches\": %llu, \"kernel_launches\": %llu, \"max_chains_per_launch\": %llu, "
-                "\"staging_bytes\": %llu, \"staging_grew_bytes\": %llu, \"slots_peak\": [%llu, %llu], \"lanes\": %llu, \"mutex_wait_ms\": %.3f, \"mutex_contended\": %llu, \"launch_host_ms\": %.3f, \"launch_api_ms\": %.3f, \"lane_wait_ms\": %.3f, \"group_allocs\": %llu, \"blocks\": %llu, \"flag_wait_ms\": %.3f, "
+                "\"staging_bytes\": %llu, \"staging_grew_bytes\": %llu, \"slots_peak\": [%llu, %llu], \"lanes\": %llu, \"mutex_wait_ms\": %.3f, \"mutex_contended\": %llu, \"launch_host_ms\": %.3f, \"launch_api_ms\": %.3f, \"lane_wait_ms\": %.3f, \"group_allocs\": %llu, \"blocks\": %llu, \"flag_wait_ms\": %.3f, \"commit_to_launch_ms_per_submission\": %.3f, \"waits\": %llu, \"waits_blocked\": %llu, \"launch_to_done_ms\": %.3f, "
                 "\"failed_tickets\": %llu, \"failures\": %zu, \"checksum\": %llu}\n",
                 codec_name, a.via_registry ? "registry" : (batcher ? "batcher" : "per-stream"), a.direct ? "true" : "false", a.in_phase ? "true" : "false", a.streams, a.lookahead, std::min(a.threads, a.streams), n, secs, n / secs, frames_per_packet,
                 bytes_in_per_packet, frames_per_packet * params<Codec>().channels * 4, n * bytes_in_per_packet / secs / 1e9,
@@ -351,7 +351,7 @@ int run(const Args &a, const char *codec_name, size_t frames_per_packet, size_t 
                 (unsigned long long)s1.max_chains_per_launch, (unsigned long long)s1.staging_bytes, (unsigned long long)(s1.staging_bytes - s0.staging_bytes), (unsigned long long)s0.slots_peak, (unsigned long long)s1.slots_peak, (unsigned long long)s1.lanes,
                 (double)(s1.mutex_wait_ns - s0.mutex_wait_ns) / 1e6, (unsigned long long)(s1.mutex_contended - s0.mutex_contended),
                 (double)(s1.launch_host_ns - s0.launch_host_ns) / 1e6, (double)(s1.launch_api_ns - s0.launch_api_ns) / 1e6,
-                (double)(s1.lane_wait_ns - s0.lane_wait_ns) / 1e6, (unsigned long long)(s1.group_allocs - s0.group_allocs), (unsigned long long)s1.blocks, (double)(s1.flag_wait_ns - s0.flag_wait_ns) / 1e6,
+                (double)(s1.lane_wait_ns - s0.lane_wait_ns) / 1e6, (unsigned long long)(s1.group_allocs - s0.group_allocs), (unsigned long long)s1.blocks, (double)(s1.flag_wait_ns - s0.flag_wait_ns) / 1e6, (double)(s1.commit_to_launch_ns - s0.commit_to_launch_ns) / 1e6 / (double)std::max<uint64_t>(1, s1.submissions - s0.submissions), (unsigned long long)(s1.waits - s0.waits), (unsigned long long)(s1.waits_blocked - s0.waits_blocked), (double)(s1.launch_to_done_ns - s0.launch_to_done_ns) / 1e6 / (double)std::max<uint64_t>(1, s1.launches_timed - s0.launches_timed),
                 (unsigned long long)(s1.failed_tickets - s0.failed_tickets), failures.load(),
                 (unsigned long long)checksum.load());
     return failures.load() ? 1 : 0;

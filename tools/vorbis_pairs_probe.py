@@ -59,5 +59,8 @@ def run(e0, e1, p_ll=0.9, p_ss=0.7):
 PAIRS = ((8, 11), (7, 10), (9, 12), (6, 9), (8, 10), (10, 13), (11, 11))
 if len(sys.argv) > 1:  # python tools/vorbis_pairs_probe.py 7,10 9,12
     PAIRS = tuple(tuple(int(x) for x in a.split(",")) for a in sys.argv[1:])
+import os
+MIX = [tuple(float(x) for x in m.split(",")) for m in os.environ.get("PAIRS_MIX", "0.9,0.7").split(";")]  # PAIRS_MIX="0.9,0.7;1,0;0,1": (p_ll, p_ss) ...
 for e0, e1 in PAIRS:
-    run(e0, e1)
+    for p_ll, p_ss in MIX:
+        run(e0, e1, p_ll, p_ss)
