@@ -1079,6 +1079,23 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
             vb_steps_at += ch.n_steps;
         }
         const Clock::time_point api0 = Clock::now();
+        // SYMACCEL_BATCH_FAKE_MIRROR (measurement only: the results are WRONG): the chunk's engine copies as ONE copy from a page-locked
+        // dummy -- what a group's bulk plane would cost the link if the submissions' slots were carved from a contiguous mirror of the
+        // device layout (profiles/r06y_fake_mirror.jsonl)
+        static const bool fake_mirror = [] { const char *e = std::getenv("SYMACCEL_BATCH_FAKE_MIRROR"); return e && std::atoi(e) != 0; }();
+        static char *fake_host = nullptr;
+        constexpr size_t kFakeBytes = (size_t)160 << 20;
+        if (fake_mirror && !dma.empty()) {
+            static std::mutex fake_mu;
+            std::lock_guard<std::mutex> fl(fake_mu);
+            if (!fake_host) SYM_GPU(ctx, hipHostMalloc(reinterpret_cast<void **>(&fake_host), 2 * kFakeBytes, hipHostMallocDefault));
+        }
+        if (fake_mirror && !dma.empty()) {
+            size_t total = 0;
+            for (const Dma &m : dma) total += m.bytes;
+            SYM_GPU(ctx, hipMemcpyAsync(dma[0].dst, fake_host, std::min(total, kFakeBytes), hipMemcpyHostToDevice, s_in));
+            dma.clear();
+        }
         for (const Dma &m : dma) SYM_GPU(ctx, hipMemcpyAsync(m.dst, m.src, m.bytes, hipMemcpyHostToDevice, s_in));
         dma.clear();
         SYM_TRY(launch_batch_copy(ctx, s_in, g0, (size_t)(w - g0), false));
@@ -1109,6 +1126,12 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
                 add_pieces(w, g->d_state_out[i] + (size_t)t.first_chain * ps.state[i], t.slot + l.state[i], l.state_bytes[i]);
         }
         const Clock::time_point api1 = Clock::now();
+        if (fake_mirror && !dma.empty()) {
+            size_t total = 0;
+            for (const Dma &m : dma) total += m.bytes;
+            SYM_GPU(ctx, hipMemcpyAsync(fake_host + kFakeBytes, dma[0].src, std::min(total, kFakeBytes), hipMemcpyDeviceToHost, s_out));
+            dma.clear();
+        }
         for (const Dma &m : dma) SYM_GPU(ctx, hipMemcpyAsync(m.dst, m.src, m.bytes, hipMemcpyDeviceToHost, s_out));
         dma.clear();
         SYM_TRY(launch_batch_copy(ctx, s_out, s0, (size_t)(w - s0), true));
