@@ -225,9 +225,14 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
         filt = np.zeros(len(cf), sa.AAC_TNS_DTYPE)
         filt["frame"] = (cf[:, 0] * nfr + cf[:, 1]).astype(np.uint32)
         filt["start"], filt["end"], filt["order"] = 160, 672, 12
+        if os.environ.get("SYM_BENCH_TNS_RANGE") == "staggered":  # (measurement: 512-line ranges at 32 different offsets -- is the pass bound by every filter
+            st = 16 * rng.integers(0, 32, len(cf))                 # touching the same offset of its 4 KiB frame at the same time?  Not verified: the spectra are
+            filt["start"], filt["end"] = st, st + 512              # zero from line 672 on and the walk's joint-stereo bands assume it)
         filt["direction"] = rng.integers(0, 2, len(cf)).astype(np.uint8)
         filt["lpc"][:, :12] = (rng.integers(-4, 5, (len(cf), 12)) * 0.05 * 0.8 ** np.arange(12)).astype(np.float32)
-        filt = filt[rng.permutation(len(filt))]
+        tns_order = os.environ.get("SYM_BENCH_TNS_ORDER", "shuffled")  # "stream": chain-major, frames ascending -- what a decoder hands over
+        if tns_order != "stream":
+            filt = filt[rng.permutation(len(filt))]
         pair_has = has[0::2] | has[1::2]                                   # pair p = chains (2p, 2p + 1)
         pf = np.flatnonzero(pair_has.ravel()).astype(np.uint32)            # pair * nfr + frame
         desc_walk = desc.copy()
@@ -288,7 +293,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             "workload": "AAC-LC 48 kHz stereo, %d long-block frames (%d chains x %d) from mid/side- and intensity-coded spectra (60 %% / 20 %% of the bands) with "
                         "one order-12 TNS filter on 30 %% of the channel frames (%d filters, %d of %d pair frames take the list pass): joint-stereo list pass, "
                         "filters, one walk" % (frames, nch, nfr, len(filt), len(pf), n_pairs * nfr),
-            "channel_frames": nch * nfr, "tns_filters": int(len(filt)), "tns_pair_frames": int(len(pf))}, \
+            "channel_frames": nch * nfr, "tns_filters": int(len(filt)), "tns_filter_order": tns_order, "tns_pair_frames": int(len(pf))}, \
             "aac_joint_stereo_kernel (list) + aac_tns_kernel + aac_synth_quad_kernel<true>", pcm
     if name in ("mp3q", "mp3q2"):
         # config 3 from what the ENTROPY DECODER produces: int16 Huffman samples + the 52-byte requantize record per granule-channel

@@ -29,7 +29,11 @@ SOURCES = ["tables.cpp", "ctx.cpp", "host_tools.cpp", "stage.cpp", "batcher.cpp"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-missing-braces"]
-TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_VARIANT", "NT", "MP3_WAVES", "MP3_VARIANT", "MP3_WG_WAVES", "MP3_FUSED_WAVES", "MP3_FUSED_WG_WAVES", "VORBIS_WAVES", "ALAC_SMALL_WAVES", "FLAC_PARTS", "MP3_SLOT_GROUP", "MP3_PACKED", "MP3_PAIR_GROUP", "AAC_ABLATE", "AAC_SINK", "AAC_CLOCK", "AAC_QUAD", "MULTI_WAVE", "VORBIS_WAVE2", "VORBIS_WG", "VORBIS_WG_SHARED", "ST_POLICY", "PACKED_C32", "WG4096_ABLATE", "FLAC_STORE_SWITCH", "ALAC_ONE_LAUNCH", "MP3_FRONT", "LDS_ABLATE", "F1_ABLATE", "F1_WAVES")
+# Per-source additions.  aac_tools.hip: the TNS filters are chains of dependent packed instructions, and a packed instruction that reads the
+# result of the instruction right before it costs a wait state (s_nop): the default scheduler puts every multiply directly in front of its
+# subtraction (mul, nop, sub per tap), the ILP strategy interleaves the next tap's multiply (1239 -> 150 s_nop in aac_tns_pair_kernel<12, true>).
+SOURCE_FLAGS = {"aac_tools.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}  # (an AMDGPU option: the host pass ignores it; -misched=gcn-iterative-ilp crashes the x86 side)
+TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_VARIANT", "NT", "MP3_WAVES", "MP3_VARIANT", "MP3_WG_WAVES", "MP3_FUSED_WAVES", "MP3_FUSED_WG_WAVES", "VORBIS_WAVES", "ALAC_SMALL_WAVES", "FLAC_PARTS", "MP3_SLOT_GROUP", "MP3_PACKED", "MP3_PAIR_GROUP", "AAC_ABLATE", "AAC_SINK", "AAC_CLOCK", "AAC_QUAD", "MULTI_WAVE", "VORBIS_WAVE2", "VORBIS_WG", "VORBIS_WG_SHARED", "ST_POLICY", "PACKED_C32", "WG4096_ABLATE", "FLAC_STORE_SWITCH", "ALAC_ONE_LAUNCH", "MP3_FRONT", "LDS_ABLATE", "F1_ABLATE", "F1_WAVES", "TNS_AHEAD", "TNS_ABLATE")
 TUNE_PREFIX = "SYMACCEL_TUNE_"
 
 
@@ -64,7 +68,7 @@ def flags_record(defines):
     for p in source_files():
         h.update(p.name.encode())
         h.update(p.read_bytes())
-    return {"arch": ARCH, "flags": [f for f in FLAGS if f != str(CSRC)], "tuning": list(defines), "sources": SOURCES,
+    return {"arch": ARCH, "flags": [f for f in FLAGS if f != str(CSRC)], "source_flags": SOURCE_FLAGS, "tuning": list(defines), "sources": SOURCES,
             "source_sha256": h.hexdigest()}
 
 
@@ -114,7 +118,7 @@ def build(force=False, verbose=False, save_temps=False):
             objs.append(str(HERE / "build" / (src.replace(".", "_") + ".o")))
             continue
         obj = objdir / (src.replace(".", "_") + ".o")
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-x", "hip", *FLAGS, *defines, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-x", "hip", *FLAGS, *SOURCE_FLAGS.get(src, []), *defines, "-c", str(CSRC / src), "-o", str(obj)]
         if save_temps:
             cmd += ["-save-temps=obj"]
         if verbose:

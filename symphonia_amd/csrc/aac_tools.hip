@@ -17,6 +17,8 @@
 // profiles/r02n_tns_alac_ab.txt, profiles/r02zc_tns_ab.txt.)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "symaccel_internal.h"
 
 namespace symaccel {
@@ -68,6 +70,8 @@ __global__ void aac_js_consume_kernel(symaccel_aac_js_frame *__restrict__ desc, 
 
 constexpr int kTnsMaxOrder = 20;  // TNS_MAX_ORDER, tns.rs:22
 constexpr int kTnsGroup = 16;     // lines per lane and round
+constexpr int kTnsSinkSlots = 256;  // wavefront slots of the sink buffer the small pass aims its idle pieces at
+static_assert((size_t)kTnsSinkSlots * 64 * 2 * kTnsGroup * sizeof(float) <= kSinkBytes, "sink slots");
 
 // One lane's filter: where it walks and what it multiplies by.
 struct TnsLane {
@@ -264,35 +268,278 @@ __device__ __forceinline__ void tns_walk(float *coeffs, const TnsLane &L, const 
     }
 }
 
-// One kernel per tap class (TAPS = 4, 8, 12, 20), all launched over the same grid: a wavefront runs in the kernel of its
-// highest order and leaves the others at once.  As ONE kernel the five walks shared a register allocation -- that of the
-// largest -- and the ring of groups in flight did not fit two wavefronts per SIMD.
-template <int TAPS>
-__global__ __launch_bounds__(64) void aac_tns_kernel(float *__restrict__ coeffs, unsigned n_frames,
-                                                     const symaccel_aac_tns_filter *__restrict__ filters, unsigned n_filters) {
-    const unsigned idx = blockIdx.x * 64u + threadIdx.x;
-    // the wavefront's class first: only the order bytes (one 4-byte word per filter)
-    int order = 0;
-    bool valid = false;
-    if (idx < n_filters) {
-        const symaccel_aac_tns_filter &f = filters[idx];
-        const int start = f.start, end = f.end;
-        valid = f.frame < n_frames && start < end && end <= 1024 && f.order >= 1 && f.order <= kTnsMaxOrder;
-        order = valid ? (int)f.order : 0;
+// ---- two filters per lane (round 6).  The filter pass runs below one wavefront per SIMD (39 k filters of a 131 072-frame batch
+// are 616 wavefronts for 1024 SIMDs) and a wavefront issues one instruction per ~4.9 cycles whatever it is: what bounds the
+// pass is the NUMBER of instructions a wavefront issues per line, 3 per tap (multiply, mask, subtract).  With two filters per
+// lane every tap is one v_pk_mul_f32 and one v_pk_add_f32 (neg) for BOTH -- the same IEEE multiply and subtract per
+// component, so the same bits -- and when every filter of the wavefront has the class's full order (the common case: AAC-LC
+// long windows, order 12) the mask disappears as well: 2 instructions per tap and line PAIR instead of 6.
+typedef float v2f __attribute__((vector_size(8)));  // (GCC / clang vector extension: the emulation build is g++)
+#ifndef SYM_TNS_ABLATE
+#define SYM_TNS_ABLATE 0
+#endif
+#ifndef SYM_TNS_AHEAD
+#define SYM_TNS_AHEAD 2  // groups in flight behind the current one in a small pass (build-time tuning knob)
+#endif
+
+// MODE 0: the groups that hold a range's first TAPS lines; 1: steady state, orders below TAPS present (mask on the product);
+// 2: steady state, every filter of the wavefront has order == TAPS.
+// (Forming the products of line m + 1 between the subtractions of line m -- they only need lines up to m - 1 -- would also remove the wait
+// state a packed instruction costs when it reads the result of the instruction right before it: mul, nop, sub per tap today.  The compiler
+// sinks every product back to its use, and an empty asm that pins it costs the same wait state at its boundary; not kept.)
+template <int TAPS, int MODE>
+__device__ __forceinline__ void tns_lines16_2(v2f (&cur)[kTnsGroup], v2f (&h)[TAPS], const v2f (&lpc)[TAPS], const unsigned (&mask)[2][TAPS],
+                                              int order0, int order1, int m0) {
+#pragma unroll
+    for (int k = 0; k < kTnsGroup; ++k) {
+        v2f acc = cur[k];
+        const int m = m0 + k;
+        const int lim0 = order0 < m ? order0 : m, lim1 = order1 < m ? order1 : m;
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) {
+            v2f term = h[j] * lpc[j];
+            if constexpr (MODE == 0) term = v2f{j < lim0 ? term[0] : 0.0f, j < lim1 ? term[1] : 0.0f};
+            else if constexpr (MODE == 1)
+                term = v2f{__uint_as_float(__float_as_uint(term[0]) & mask[0][j]), __uint_as_float(__float_as_uint(term[1]) & mask[1][j])};
+            acc = acc - term;
+        }
+        cur[k] = acc;
+#pragma unroll
+        for (int j = TAPS - 1; j >= 1; --j) h[j] = h[j - 1];
+        h[0] = acc;
     }
-    int max_order = order;
+}
+
+// The walk of tns_walk with two filters per lane: the lines of both move as there (quads, 64-byte requests), the arithmetic is packed.
+// FULL: every filter of the wavefront has order == TAPS (an instantiation of its own: the masks of the other cost 2 x TAPS registers)
+template <int TAPS, bool FULL>
+__device__ __forceinline__ void tns_walk2(float *coeffs, const TnsLane &L0, const TnsLane &L1, const float (&lpc0)[TAPS], const float (&lpc1)[TAPS],
+                                          int max_len, int lane) {
+    const TnsQuad Q0 = tns_quad(L0, coeffs), Q1 = tns_quad(L1, coeffs);
+    v2f lpc[TAPS], h[TAPS];
+    unsigned mask[2][TAPS];
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+        lpc[j] = v2f{lpc0[j], lpc1[j]};
+        h[j] = v2f{0.0f, 0.0f};
+        mask[0][j] = j < L0.order ? 0xffffffffu : 0u;
+        mask[1][j] = j < L1.order ? 0xffffffffu : 0u;
+    }
+    TnsRaw raw0[2], raw1[2];
+    float c0[kTnsGroup], c1[kTnsGroup];
+#pragma unroll
+    for (int k = 0; k < kTnsGroup; ++k) c0[k] = c1[k] = 0.0f;
+    tns_request(coeffs, Q0, lane, 0, raw0[0]);
+    tns_request(coeffs, Q1, lane, 0, raw1[0]);
+    for (int m0 = 0; m0 < max_len; m0 += 2 * kTnsGroup) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int m = m0 + r * kTnsGroup;
+            if (m < max_len) {  // (wave-uniform)
+                tns_request(coeffs, Q0, lane, m + kTnsGroup, raw0[r ^ 1]);
+                tns_request(coeffs, Q1, lane, m + kTnsGroup, raw1[r ^ 1]);
+                tns_take(L0, raw0[r], lane, m, c0);
+                tns_take(L1, raw1[r], lane, m, c1);
+                v2f cur[kTnsGroup];
+#pragma unroll
+                for (int k = 0; k < kTnsGroup; ++k) cur[k] = v2f{c0[k], c1[k]};
+                if (m < TAPS)  // (wave-uniform) the groups that contain a range's first TAPS lines
+                    tns_lines16_2<TAPS, 0>(cur, h, lpc, mask, L0.order, L1.order, m);
+                else
+                    tns_lines16_2<TAPS, FULL ? 2 : 1>(cur, h, lpc, mask, L0.order, L1.order, m);
+#pragma unroll
+                for (int k = 0; k < kTnsGroup; ++k) {
+                    c0[k] = cur[k][0];
+                    c1[k] = cur[k][1];
+                }
+                tns_store(coeffs, L0, Q0, lane, m, c0);
+                tns_store(coeffs, L1, Q1, lane, m, c1);
+            }
+        }
+    }
+}
+
+// ---- the SMALL pass (below ~two wavefronts per SIMD: 39 k filters of a 131 072-frame batch are 308 wavefronts of 128 filters for 1024
+// SIMDs).  Nothing is bound by the L2 or by HBM then: the pass takes as long as ONE wavefront needs for its own filters.  Two things
+// differ from the walks above:
+//  * every lane moves its own filters' lines, four 16-byte pieces per group (64 separate requests per instruction: fine at this
+//    occupancy, too slow at 2048 wavefronts -- profiles/r02z_tns_sq_counters.txt); no quad exchange (two 4 x 4 transposes per group
+//    and filter in DPP moves and selects);
+//  * the round is STRAIGHT-LINE code: every piece is loaded and stored unconditionally -- a piece that lies outside its range (or belongs
+//    to a lane whose group is ragged / unaligned) reads coeffs[0..3] and writes a per-lane slot of the context's sink buffer.  gfx950
+//    counts vector loads and stores with ONE in-order counter: with the ragged path's loads and the stores inside per-lane branches the
+//    compiler cannot know how many follow a prefetch and waited with vmcnt(0) in every round -- for the loads it had just issued and the
+//    stores of the round before, a memory round trip per sixteen lines whatever the number of groups requested ahead.  The ragged path
+//    (a length that is not a multiple of four lines, an unaligned range: no swb table produces either) sits behind ONE wave-uniform branch.
+// Measured on 39 424 order-12 filters of 512 lines (profiles/r06z6 .. r06z11): one filter per lane with the quad exchange (round 5) 94 us;
+// two per lane, packed, quad exchange 97 (90 with the ILP scheduling strategy, build.py); lane by lane 83; straight-line 70; ILP strategy
+// 68.  By ablation the arithmetic alone takes 40 us and the movement alone 69; the SQ counters say 19.6 k VALU instructions per wavefront
+// (58 % of its cycles; 384 of a round's 614 are the packed taps) and a quarter of its cycles waiting.  An exchange through LDS (a quad
+// moves 64 contiguous bytes, four ds_write_b128 + four ds_read_b128 per group instead of the DPP transposes) measured slower, 76 us.
+// End of a ragged section: everything in flight is waited for HERE, inside the wave-uniform branch.  Without it the compiler merges "an
+// unknown number of loads / stores may be pending" into the straight-line path at the join and waits with vmcnt(0) there.
+__device__ __forceinline__ void tns_slow_path_drain() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding: vmcnt [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8])
+#endif
+}
+struct TnsPieces {
+    const float *base;  // lowest address of the group's 64 bytes
+    bool whole[4];      // piece q (lines 4 q .. 4 q + 3 of the group, ascending ADDRESSES) moves as one 16-byte access
+    bool slow;          // the lane moves this group line by line
+};
+__device__ __forceinline__ TnsPieces tns_pieces(const TnsLane &L, int m) {
+    TnsPieces P;
+    const int left = L.len - m;  // lines of the range from m on
+    P.slow = left > 0 && (!L.aligned || (left < kTnsGroup && (left & 3) != 0));
+    P.base = L.down ? L.x - (m + kTnsGroup - 1) : L.x + m;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // ascending addresses: an upward filter's piece q holds lines 4 q .. 4 q + 3, a downward one's lines 12 - 4 q .. 15 - 4 q
+        const int last = L.down ? kTnsGroup - 4 * q : 4 * q + 4;  // the piece is whole when the group has that many lines
+        P.whole[q] = L.aligned && !P.slow && left >= last;
+    }
+    return P;
+}
+
+template <int TAPS, bool FULL>
+__device__ __forceinline__ void tns_walk2_direct(float *coeffs, float *sink_lane, const TnsLane &L0, const TnsLane &L1, const float (&lpc0)[TAPS],
+                                                 const float (&lpc1)[TAPS], int max_len) {
+    v2f lpc[TAPS], h[TAPS];
+    unsigned mask[2][TAPS];
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+        lpc[j] = v2f{lpc0[j], lpc1[j]};
+        h[j] = v2f{0.0f, 0.0f};
+        mask[0][j] = j < L0.order ? 0xffffffffu : 0u;
+        mask[1][j] = j < L1.order ? 0xffffffffu : 0u;
+    }
+    auto request = [&](const TnsLane &L, int m, TnsRaw &raw) {
+        const TnsPieces P = tns_pieces(L, m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw.e[q] = *reinterpret_cast<const uint4 *>(P.whole[q] ? P.base + 4 * q : coeffs);
+    };
+    auto take = [&](const TnsLane &L, const TnsRaw &raw, float (&v)[kTnsGroup]) {  // (pieces that are not whole: never stored)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint4 up = raw.e[p], dn = raw.e[3 - p];
+            v[4 * p + 0] = __uint_as_float(L.down ? dn.w : up.x);
+            v[4 * p + 1] = __uint_as_float(L.down ? dn.z : up.y);
+            v[4 * p + 2] = __uint_as_float(L.down ? dn.y : up.z);
+            v[4 * p + 3] = __uint_as_float(L.down ? dn.x : up.w);
+        }
+    };
+    auto store = [&](const TnsLane &L, const TnsPieces &P, float *sink16, const float (&v)[kTnsGroup]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = 3 - q;
+            const uint4 e = L.down ? make_uint4(__float_as_uint(v[4 * p + 3]), __float_as_uint(v[4 * p + 2]), __float_as_uint(v[4 * p + 1]), __float_as_uint(v[4 * p]))
+                                   : make_uint4(__float_as_uint(v[4 * q]), __float_as_uint(v[4 * q + 1]), __float_as_uint(v[4 * q + 2]), __float_as_uint(v[4 * q + 3]));
+            *reinterpret_cast<uint4 *>(P.whole[q] ? const_cast<float *>(P.base) + 4 * q : sink16 + 4 * q) = e;
+        }
+    };
+    // kAhead groups of sixteen lines are in flight behind the one being filtered (a ring of kAhead + 1 register groups, the round loop
+    // unrolled by as many so that every index is static)
+    constexpr int kAhead = SYM_TNS_AHEAD, kRing = kAhead + 1;
+    TnsRaw raw0[kRing], raw1[kRing];
+    float c0[kTnsGroup], c1[kTnsGroup];
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) {
+        request(L0, a * kTnsGroup, raw0[a]);
+        request(L1, a * kTnsGroup, raw1[a]);
+    }
+    for (int m0 = 0; m0 < max_len; m0 += kRing * kTnsGroup) {
+#pragma unroll
+        for (int r = 0; r < kRing; ++r) {
+            const int m = m0 + r * kTnsGroup;
+            if (m < max_len) {  // (wave-uniform)
+#if SYM_TNS_ABLATE == 2  // (measurement build, results wrong on purpose: only the first groups are loaded, only the last group is stored)
+                if (m == 0) {
+#endif
+                request(L0, m + kAhead * kTnsGroup, raw0[(r + kAhead) % kRing]);
+                request(L1, m + kAhead * kTnsGroup, raw1[(r + kAhead) % kRing]);
+#if SYM_TNS_ABLATE == 2
+                }
+#endif
+                const TnsPieces P0 = tns_pieces(L0, m), P1 = tns_pieces(L1, m);
+                take(L0, raw0[r], c0);
+                take(L1, raw1[r], c1);
+                const bool any_slow = __any(P0.slow || P1.slow) != 0;
+                if (any_slow) {  // (wave-uniform; rare)
+                    if (P0.slow) {
+#pragma unroll
+                        for (int k = 0; k < kTnsGroup; ++k)
+                            if (m + k < L0.len) c0[k] = L0.x[L0.down ? -(long)(m + k) : (long)(m + k)];
+                    }
+                    if (P1.slow) {
+#pragma unroll
+                        for (int k = 0; k < kTnsGroup; ++k)
+                            if (m + k < L1.len) c1[k] = L1.x[L1.down ? -(long)(m + k) : (long)(m + k)];
+                    }
+                    tns_slow_path_drain();
+                }
+                v2f cur[kTnsGroup];
+#pragma unroll
+                for (int k = 0; k < kTnsGroup; ++k) cur[k] = v2f{c0[k], c1[k]};
+#if SYM_TNS_ABLATE != 1  // (measurement build, results wrong on purpose: the lines pass through unfiltered)
+                if (m < TAPS)  // (wave-uniform) the groups that contain a range's first TAPS lines
+                    tns_lines16_2<TAPS, 0>(cur, h, lpc, mask, L0.order, L1.order, m);
+                else
+                    tns_lines16_2<TAPS, FULL ? 2 : 1>(cur, h, lpc, mask, L0.order, L1.order, m);
+#endif
+#pragma unroll
+                for (int k = 0; k < kTnsGroup; ++k) {
+                    c0[k] = cur[k][0];
+                    c1[k] = cur[k][1];
+                }
+#if SYM_TNS_ABLATE == 2
+                if (m + kTnsGroup >= max_len) {
+#endif
+                store(L0, P0, sink_lane, c0);
+                store(L1, P1, sink_lane + kTnsGroup, c1);
+#if SYM_TNS_ABLATE == 2
+                }
+#endif
+                if (any_slow) {
+                    if (P0.slow) {
+#pragma unroll
+                        for (int k = 0; k < kTnsGroup; ++k)
+                            if (m + k < L0.len) L0.x[L0.down ? -(long)(m + k) : (long)(m + k)] = c0[k];
+                    }
+                    if (P1.slow) {
+#pragma unroll
+                        for (int k = 0; k < kTnsGroup; ++k)
+                            if (m + k < L1.len) L1.x[L1.down ? -(long)(m + k) : (long)(m + k)] = c1[k];
+                    }
+                    tns_slow_path_drain();
+                }
+            }
+        }
+    }
+}
+
+// Whether filter idx is one the pass runs, and its order (0 otherwise)
+__device__ __forceinline__ int tns_filter_order(const symaccel_aac_tns_filter *filters, unsigned idx, unsigned n_filters, unsigned n_frames) {
+    if (idx >= n_filters) return 0;
+    const symaccel_aac_tns_filter &f = filters[idx];
+    const int start = f.start, end = f.end;
+    const bool valid = f.frame < n_frames && start < end && end <= 1024 && f.order >= 1 && f.order <= kTnsMaxOrder;
+    return valid ? (int)f.order : 0;
+}
+__device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-        const int b = __shfl_xor(max_order, m);
-        max_order = b > max_order ? b : max_order;
+        const int b = __shfl_xor(v, m);
+        v = b > v ? b : v;
     }
-    constexpr int kLower = TAPS == 20 ? 12 : TAPS - 4;  // this kernel's orders: kLower < max_order <= TAPS
-    if (max_order <= kLower || max_order > TAPS) return;
+    return v;
+}
+template <int TAPS>
+__device__ __forceinline__ TnsLane tns_lane(float *coeffs, const symaccel_aac_tns_filter *filters, unsigned idx, int order, float (&lpc)[TAPS]) {
     TnsLane L{coeffs, 0, 0, false, false};
-    float lpc[TAPS];
 #pragma unroll
     for (int j = 0; j < TAPS; ++j) lpc[j] = 0.0f;
-    if (valid) {
+    if (order > 0) {
         const symaccel_aac_tns_filter &f = filters[idx];
         const int start = f.start, end = f.end;
         L.order = order;
@@ -303,12 +550,55 @@ __global__ __launch_bounds__(64) void aac_tns_kernel(float *__restrict__ coeffs,
 #pragma unroll
         for (int j = 0; j < TAPS; ++j) lpc[j] = f.lpc[j];
     }
-    int max_len = L.len;  // wave-uniform bound: the longest range among the wavefront's filters
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const int a = __shfl_xor(max_len, m);
-        max_len = a > max_len ? a : max_len;
+    return L;
+}
+
+// A wavefront takes a BLOCK of 128 consecutive filters of the flat list, filters b + lane and b + 64 + lane on lane `lane`.
+// One kernel per tap class (TAPS = 4, 8, 12: aac_tns_pair_kernel; 20: aac_tns_kernel, one filter per lane -- forty packed
+// coefficient and history registers more than the pair form has room for), all launched over the same blocks: a wavefront runs
+// in the kernel of its block's highest order and leaves the others at once.  As ONE kernel the walks shared a register
+// allocation -- that of the largest -- and the ring of groups in flight did not fit two wavefronts per SIMD.
+template <int TAPS, bool DIRECT>
+__global__ __launch_bounds__(64) void aac_tns_pair_kernel(float *__restrict__ coeffs, unsigned n_frames,
+                                                          const symaccel_aac_tns_filter *__restrict__ filters, unsigned n_filters, float *__restrict__ sink) {
+    const unsigned idx0 = blockIdx.x * 128u + threadIdx.x, idx1 = idx0 + 64u;
+    // the block's class first: only the order bytes (one 4-byte word per filter)
+    const int order0 = tns_filter_order(filters, idx0, n_filters, n_frames), order1 = tns_filter_order(filters, idx1, n_filters, n_frames);
+    const int max_order = wave_max(order0 > order1 ? order0 : order1);
+    constexpr int kLower = TAPS - 4;  // this kernel's orders: kLower < max_order <= TAPS
+    if (max_order <= kLower || max_order > TAPS) return;
+    const bool all_full = wave_max(((order0 != 0 && order0 != TAPS) || (order1 != 0 && order1 != TAPS)) ? 1 : 0) == 0;
+    float lpc0[TAPS], lpc1[TAPS];
+    const TnsLane L0 = tns_lane<TAPS>(coeffs, filters, idx0, order0, lpc0), L1 = tns_lane<TAPS>(coeffs, filters, idx1, order1, lpc1);
+    const int max_len = wave_max(L0.len > L1.len ? L0.len : L1.len);  // wave-uniform bound: the longest range among the block's filters
+    if constexpr (DIRECT) {
+        // the lane's 128 bytes of the sink (symaccel_internal.h: kSinkBytes, never read), a slot of 8 KiB per wavefront
+        float *sink_lane = sink + (size_t)(blockIdx.x % (unsigned)kTnsSinkSlots) * (64 * 2 * kTnsGroup) + threadIdx.x * (2 * kTnsGroup);
+        if (all_full)  // (wave-uniform)
+            tns_walk2_direct<TAPS, true>(coeffs, sink_lane, L0, L1, lpc0, lpc1, max_len);
+        else
+            tns_walk2_direct<TAPS, false>(coeffs, sink_lane, L0, L1, lpc0, lpc1, max_len);
+    } else {
+        if (all_full)  // (wave-uniform)
+            tns_walk2<TAPS, true>(coeffs, L0, L1, lpc0, lpc1, max_len, (int)threadIdx.x);
+        else
+            tns_walk2<TAPS, false>(coeffs, L0, L1, lpc0, lpc1, max_len, (int)threadIdx.x);
     }
+}
+
+// Orders 13..20 (one filter per lane; the class is still the 128-filter block's: the lane looks at its sibling's order too)
+template <int TAPS>
+__global__ __launch_bounds__(64) void aac_tns_kernel(float *__restrict__ coeffs, unsigned n_frames,
+                                                     const symaccel_aac_tns_filter *__restrict__ filters, unsigned n_filters) {
+    const unsigned idx = blockIdx.x * 64u + threadIdx.x;
+    const int order = tns_filter_order(filters, idx, n_filters, n_frames), sibling = tns_filter_order(filters, idx ^ 64u, n_filters, n_frames);
+    const int max_order = wave_max(order > sibling ? order : sibling);
+    constexpr int kLower = 12;  // this kernel's orders: kLower < max_order <= TAPS
+    static_assert(TAPS == kTnsMaxOrder, "the one-filter-per-lane form is the last class");
+    if (max_order <= kLower || max_order > TAPS) return;
+    float lpc[TAPS];
+    const TnsLane L = tns_lane<TAPS>(coeffs, filters, idx, order, lpc);
+    const int max_len = wave_max(L.len);  // wave-uniform bound: the longest range among the wavefront's filters
     tns_walk<TAPS>(coeffs, L, lpc, max_len, (int)threadIdx.x);
 }
 
@@ -338,14 +628,28 @@ int launch_aac_js_consume(symaccel_ctx *ctx, symaccel_aac_js_frame *d_desc, cons
 
 int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
                    size_t n_filters) {
-    const size_t grid = (n_filters + 63) / 64;
-    if (n_frames > 0xffffffffu || n_filters > 0xffffffffu || grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-#define SYM_TNS_LAUNCH(TAPS) \
-    hipLaunchKernelGGL(aac_tns_kernel<TAPS>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_coeffs, (unsigned)n_frames, d_filters, (unsigned)n_filters)
-    SYM_TNS_LAUNCH(12);  // (AAC-LC long windows: the common class first)
-    SYM_TNS_LAUNCH(8);
-    SYM_TNS_LAUNCH(4);
-    SYM_TNS_LAUNCH(20);
+    const size_t blocks = (n_filters + 127) / 128;  // blocks of 128 filters: one wavefront each in the pair kernels, two in the last class
+    if (n_frames > 0xffffffffu || n_filters > 0xffffffffu || 2 * blocks > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_filters == 0) return SYMACCEL_OK;
+#define SYM_TNS_LAUNCH(KERNEL, GRID, ...) \
+    hipLaunchKernelGGL((KERNEL), dim3((unsigned)(GRID)), dim3(64), 0, ctx->stream, d_coeffs, (unsigned)n_frames, d_filters, (unsigned)n_filters, ##__VA_ARGS__)
+    // below two wavefronts per SIMD the lanes move their lines themselves (tns_walk2_direct); development knob: SYMACCEL_TNS_DIRECT = 0 / 1
+    const char *direct_env = std::getenv("SYMACCEL_TNS_DIRECT");  // (read per launch: the tests run both forms in one process)
+    const int direct_knob = direct_env ? std::atoi(direct_env) : -1;
+    const bool direct = direct_knob >= 0 ? direct_knob != 0 : blocks <= (size_t)8 * (size_t)ctx->n_cus;
+    void *sink = nullptr;
+    if (direct) SYM_TRY(ctx_sink(ctx, &sink));
+    float *fsink = static_cast<float *>(sink);
+    if (direct) {
+        SYM_TNS_LAUNCH((aac_tns_pair_kernel<12, true>), blocks, fsink);  // (AAC-LC long windows: the common class first)
+        SYM_TNS_LAUNCH((aac_tns_pair_kernel<8, true>), blocks, fsink);
+        SYM_TNS_LAUNCH((aac_tns_pair_kernel<4, true>), blocks, fsink);
+    } else {
+        SYM_TNS_LAUNCH((aac_tns_pair_kernel<12, false>), blocks, fsink);
+        SYM_TNS_LAUNCH((aac_tns_pair_kernel<8, false>), blocks, fsink);
+        SYM_TNS_LAUNCH((aac_tns_pair_kernel<4, false>), blocks, fsink);
+    }
+    SYM_TNS_LAUNCH((aac_tns_kernel<20>), 2 * blocks);
 #undef SYM_TNS_LAUNCH
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;

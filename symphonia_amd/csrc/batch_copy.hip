@@ -84,10 +84,14 @@ int launch_batch_flag(symaccel_ctx *ctx, hipStream_t stream, uint64_t *h_flag, u
 int launch_batch_copy(symaccel_ctx *ctx, hipStream_t stream, const BatchCopyDesc *descs, size_t n, bool scatter) {
     if (n == 0) return SYMACCEL_OK;
     if (n > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-    static const unsigned cap = [] {  // development knob: workgroups per copy launch (0 = one per piece, as rounds 5 had it)
-        const char *e = std::getenv("SYMACCEL_BATCH_COPY_WGS");
-        return e ? (unsigned)std::atoi(e) : 256u;
-    }();
+    // workgroups per copy launch.  64: the link needs few -- a copy kernel that fills the device keeps the synthesis kernel and the copy of
+    // the other direction waiting for compute units (256 -> 64: AAC behind the trait 3.96 -> 4.3-4.45 M packets/s at S = 256, 32 and 96 are
+    // both slower; profiles/r06z4_big_groups.jsonl, r06z5_copy_grid.jsonl).  Development knobs: SYMACCEL_BATCH_COPY_WGS (both directions;
+    // 0 = one workgroup per piece, as round 5 had it), SYMACCEL_BATCH_COPY_WGS_G / _S (gather / scatter alone)
+    static const unsigned caps[2] = {
+        [] { const char *e = std::getenv("SYMACCEL_BATCH_COPY_WGS_G"); if (!e) e = std::getenv("SYMACCEL_BATCH_COPY_WGS"); return e ? (unsigned)std::atoi(e) : 64u; }(),
+        [] { const char *e = std::getenv("SYMACCEL_BATCH_COPY_WGS_S"); if (!e) e = std::getenv("SYMACCEL_BATCH_COPY_WGS"); return e ? (unsigned)std::atoi(e) : 64u; }()};
+    const unsigned cap = caps[scatter ? 1 : 0];
     const unsigned grid = cap ? (unsigned)std::min<size_t>(n, cap) : (unsigned)n;
     static const bool nt = [] {  // development knob: non-temporal accesses
         const char *e = std::getenv("SYMACCEL_BATCH_COPY_NT");

@@ -899,13 +899,14 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
         else add_pieces(w, src, dst, bytes);
     };
     const size_t per_chain = std::max<size_t>(1, in_bytes_per_chain(ps));
-    // a third of the group per chunk, 8 .. 32 MiB of input: a chunk costs three launches and two event hops (~40 us), which 2 MiB
+    // half of the group per chunk, 8 .. 32 MiB of input: a chunk costs three launches and two event hops (~40 us), which 2 MiB
     // chunks (44 us on the link) did not amortise -- 22.7 GB/s each way at look-ahead 64 against 37.9 at 256 (profiles/r05c_*);
-    // consecutive GROUPS overlap on the lanes anyway, so a small group is one chunk
+    // consecutive GROUPS overlap on the lanes anyway, so a small group is one chunk (one or two chunks measure the same, three or
+    // six are slower: profiles/r06z4_big_groups.jsonl, r06z5_copy_grid.jsonl)
     // (development knobs: SYMACCEL_BATCH_CHUNKS = chunks a full group is cut into, SYMACCEL_BATCH_CHUNK_MIN_KB = the smallest chunk)
     static const size_t chunk_div = [] {
         const char *e = std::getenv("SYMACCEL_BATCH_CHUNKS");
-        const long v = e ? std::atol(e) : 3;
+        const long v = e ? std::atol(e) : 2;
         return (size_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     static const size_t chunk_min = [] {

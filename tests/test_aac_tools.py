@@ -11,7 +11,7 @@ from scipy.signal import lfilter
 
 import oracle
 from emu_lib import emu_ctx  # noqa: F401
-from helpers import bit_equal
+from helpers import bit_equal, equal_mod_nan
 
 # swb offsets of the 44.1 / 48 kHz tables (ISO/IEC 14496-3 Tables 4.138, 4.139): what ICS get_bands() returns there
 SWB_LONG = [0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80, 88, 96, 108, 120, 132, 144, 160, 176, 196, 216,
@@ -193,9 +193,11 @@ def test_emu_tns_unaligned_ranges(emu_ctx):
     assert bit_equal(got, want)
 
 
-def tns_case_ragged(rng, n_frames):
+def tns_case_ragged(rng, n_frames, orders=(1, 20)):
     """One filter per frame over an arbitrary range (any start, any length, both directions, every order): quads of
-    lanes then mix ranges whose groups are aligned, unaligned, ragged or already finished."""
+    lanes then mix ranges whose groups are aligned, unaligned, ragged or already finished.  `orders`: the range the orders are
+    drawn from -- a block of 128 filters runs in the kernel of its HIGHEST order (two filters per lane up to order 12; with
+    (12, 12) the form without masks)."""
     from symphonia_amd import AAC_TNS_DTYPE
     coeffs = (rng.standard_normal((n_frames, 1024)) * np.exp2(rng.integers(-6, 8, (n_frames, 1)))).astype(np.float32)
     filt = np.zeros(n_frames, AAC_TNS_DTYPE)
@@ -213,15 +215,39 @@ def tns_case_ragged(rng, n_frames):
         else:            # whole multiples of sixteen lines
             lo = 16 * int(rng.integers(0, 32))
             hi = lo + 16 * int(rng.integers(1, (1024 - lo) // 16 + 1))
-        order = int(rng.integers(1, 21))
+        order = int(rng.integers(orders[0], orders[1] + 1))
         filt[k] = (k, lo, hi, order, int(rng.integers(0, 2)), 0, tns_lpc(rng, order, coef_res=bool(rng.integers(0, 2))))
     return coeffs, filt[rng.permutation(n_frames)]
 
 
-@pytest.mark.parametrize("seed,n_frames", [(3, 64), (4, 130), (5, 7)])
-def test_emu_tns_ragged_quads(emu_ctx, seed, n_frames):
+TNS_ORDER_CLASSES = [(1, 4), (4, 4), (3, 8), (8, 8), (5, 12), (12, 12), (9, 16)]
+
+
+@pytest.mark.parametrize("direct", ["0", "1"])
+@pytest.mark.parametrize("seed,n_frames", [(3, 64), (4, 130), (5, 7), (6, 300)])
+def test_emu_tns_ragged_quads(emu_ctx, seed, n_frames, direct, monkeypatch):
+    """both ways a group's lines move (SYMACCEL_TNS_DIRECT: the quad exchange of a large pass, lane by lane in a small one)"""
     from symphonia_amd import AacSpectralTools
+    monkeypatch.setenv("SYMACCEL_TNS_DIRECT", direct)
     coeffs, filt = tns_case_ragged(np.random.default_rng(seed), n_frames)
+    want = tns_reference(coeffs, filt, n_frames)
+    got = coeffs.copy()
+    AacSpectralTools(emu_ctx, SWB_LONG, SWB_SHORT).tns(got, filt)
+    assert bit_equal(got, want)
+
+
+@pytest.mark.parametrize("direct", ["0", "1"])
+@pytest.mark.parametrize("orders", TNS_ORDER_CLASSES)
+def test_emu_tns_order_classes(emu_ctx, orders, direct, monkeypatch):
+    """every tap class of the pass, with and without orders below the class's (the masked and the unmasked steady state), some
+    filters skipped (order 0, a frame outside the batch)"""
+    from symphonia_amd import AacSpectralTools
+    monkeypatch.setenv("SYMACCEL_TNS_DIRECT", direct)
+    n_frames = 200
+    coeffs, filt = tns_case_ragged(np.random.default_rng(100 + orders[0] + 20 * orders[1]), n_frames, orders)
+    filt[5]["order"] = 0
+    filt[77]["frame"] = n_frames + 1
+    filt[150]["start"], filt[150]["end"] = 8, 8
     want = tns_reference(coeffs, filt, n_frames)
     got = coeffs.copy()
     AacSpectralTools(emu_ctx, SWB_LONG, SWB_SHORT).tns(got, filt)
@@ -287,12 +313,14 @@ def test_gpu_aac_tools():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("direct", ["0", "1"])
 @pytest.mark.parametrize("seed,n_frames", [(13, 64), (14, 1000), (15, 333)])
-def test_gpu_tns_ragged_quads(seed, n_frames):
+def test_gpu_tns_ragged_quads(seed, n_frames, direct, monkeypatch):
     import torch
     from symphonia_amd import AacSpectralTools, Context
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible")
+    monkeypatch.setenv("SYMACCEL_TNS_DIRECT", direct)
     coeffs, filt = tns_case_ragged(np.random.default_rng(seed), n_frames)
     want = tns_reference(coeffs, filt, n_frames)
     with Context(0) as ctx:
@@ -300,3 +328,27 @@ def test_gpu_tns_ragged_quads(seed, n_frames):
         AacSpectralTools(ctx, SWB_LONG, SWB_SHORT).tns(d, torch.from_numpy(filt.view(np.uint8).reshape(-1, 92)).cuda())
         ctx.sync()
         assert bit_equal(d.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direct", ["0", "1"])
+@pytest.mark.parametrize("orders", TNS_ORDER_CLASSES)
+def test_gpu_tns_order_classes(orders, direct, monkeypatch):
+    import torch
+    from symphonia_amd import AacSpectralTools, Context
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    monkeypatch.setenv("SYMACCEL_TNS_DIRECT", direct)
+    n_frames = 1500
+    coeffs, filt = tns_case_ragged(np.random.default_rng(200 + orders[0] + 20 * orders[1]), n_frames, orders)
+    filt[5]["order"] = 0
+    filt[77]["frame"] = n_frames + 1
+    # non-finite and signed-zero lines: a tap that does not apply subtracts +0.0, the others are the reference's rounded operations
+    coeffs[3, 100:140] = [np.inf, -np.inf, np.nan, -0.0] * 10
+    coeffs[9, :64] = -0.0
+    want = tns_reference(coeffs, filt, n_frames)
+    with Context(0) as ctx:
+        d = torch.from_numpy(coeffs).cuda()
+        AacSpectralTools(ctx, SWB_LONG, SWB_SHORT).tns(d, torch.from_numpy(filt.view(np.uint8).reshape(-1, 92)).cuda())
+        ctx.sync()
+        assert equal_mod_nan(d.cpu().numpy(), want)
