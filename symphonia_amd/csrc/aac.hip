@@ -488,11 +488,16 @@ int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, 
         } else {
             // scratch: chain_index[n_chains] int2
             if (n_pairs * frames_per_chain > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
-            int2 *chain_index = reinterpret_cast<int2 *>(d_js_scratch);
-            SYM_GPU(ctx, hipMemsetAsync(chain_index, 0xff, n_chains * sizeof(int2), ctx->stream));  // partner -1: not part of a pair
-            hipLaunchKernelGGL(aac_js_index_kernel, dim3((unsigned)((2 * n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, d_pair_chains,
-                               (unsigned)n_pairs, (unsigned)n_chains, chain_index);
-            SYM_GPU(ctx, hipGetLastError());
+            // the per-chain index is what the PLAIN instantiation skips paired chains by: built only when there are chains outside the pairs
+            // (a batch of stereo streams has none -- the memset and the index kernel were two launches, ~9 us of a 0.26 ms step)
+            const bool unpaired = 2 * n_pairs < n_chains;
+            int2 *chain_index = unpaired ? reinterpret_cast<int2 *>(d_js_scratch) : nullptr;
+            if (unpaired) {
+                SYM_GPU(ctx, hipMemsetAsync(chain_index, 0xff, n_chains * sizeof(int2), ctx->stream));  // partner -1: not part of a pair
+                hipLaunchKernelGGL(aac_js_index_kernel, dim3((unsigned)((2 * n_pairs + 255) / 256)), dim3(256), 0, ctx->stream, d_pair_chains,
+                                   (unsigned)n_pairs, (unsigned)n_chains, chain_index);
+                SYM_GPU(ctx, hipGetLastError());
+            }
             js = AacJsArgs{chain_index, d_pair_chains, d_js_desc, *maps, (unsigned)n_chains};
             // the pairs: a workgroup per (pair, segment) -- half as many walks as chains, so the segments are chosen for n_pairs walks
             unsigned pseg_steps;
@@ -504,7 +509,7 @@ int launch_aac(symaccel_ctx *ctx, const float *d_coeffs, const uint8_t *d_side, 
             hipLaunchKernelGGL(aac_synth_quad_kernel<true>, dim3((unsigned)(n_pairs * psegs)), dim3(256), 0, ctx->stream, ctx->dev, d_coeffs, d_side,
                                d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, pseg_steps, (unsigned)psegs, js);
             SYM_GPU(ctx, hipGetLastError());
-            if (2 * n_pairs < n_chains)  // the chains outside every pair: the plain walk over all chains, paired ones return at once
+            if (unpaired)  // the chains outside every pair: the plain walk over all chains, paired ones return at once
                 hipLaunchKernelGGL(aac_synth_quad_kernel<false>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->dev, d_coeffs, d_side,
                                    d_delay_in, d_delay_out, d_pcm, (unsigned)frames_per_chain, seg_steps, (unsigned)segs, js);
         }

@@ -559,14 +559,8 @@ __device__ __forceinline__ TnsLane tns_lane(float *coeffs, const symaccel_aac_tn
 // in the kernel of its block's highest order and leaves the others at once.  As ONE kernel the walks shared a register
 // allocation -- that of the largest -- and the ring of groups in flight did not fit two wavefronts per SIMD.
 template <int TAPS, bool DIRECT>
-__global__ __launch_bounds__(64) void aac_tns_pair_kernel(float *__restrict__ coeffs, unsigned n_frames,
-                                                          const symaccel_aac_tns_filter *__restrict__ filters, unsigned n_filters, float *__restrict__ sink) {
-    const unsigned idx0 = blockIdx.x * 128u + threadIdx.x, idx1 = idx0 + 64u;
-    // the block's class first: only the order bytes (one 4-byte word per filter)
-    const int order0 = tns_filter_order(filters, idx0, n_filters, n_frames), order1 = tns_filter_order(filters, idx1, n_filters, n_frames);
-    const int max_order = wave_max(order0 > order1 ? order0 : order1);
-    constexpr int kLower = TAPS - 4;  // this kernel's orders: kLower < max_order <= TAPS
-    if (max_order <= kLower || max_order > TAPS) return;
+__device__ __forceinline__ void tns_pair_block(float *coeffs, const symaccel_aac_tns_filter *filters, float *sink, unsigned idx0, unsigned idx1, int order0,
+                                               int order1) {
     const bool all_full = wave_max(((order0 != 0 && order0 != TAPS) || (order1 != 0 && order1 != TAPS)) ? 1 : 0) == 0;
     float lpc0[TAPS], lpc1[TAPS];
     const TnsLane L0 = tns_lane<TAPS>(coeffs, filters, idx0, order0, lpc0), L1 = tns_lane<TAPS>(coeffs, filters, idx1, order1, lpc1);
@@ -584,6 +578,21 @@ __global__ __launch_bounds__(64) void aac_tns_pair_kernel(float *__restrict__ co
         else
             tns_walk2<TAPS, false>(coeffs, L0, L1, lpc0, lpc1, max_len, (int)threadIdx.x);
     }
+}
+
+// Orders 1..12, two filters per lane: ONE launch for the three tap classes (4, 8, 12) -- their walks need 195 .. 227 registers each, so the
+// shared allocation costs nothing, and a class of its own was a launch (~3-5 us of stream time) that most batches leave at once.
+template <bool DIRECT>
+__global__ __launch_bounds__(64) void aac_tns_pair_kernel(float *__restrict__ coeffs, unsigned n_frames,
+                                                          const symaccel_aac_tns_filter *__restrict__ filters, unsigned n_filters, float *__restrict__ sink) {
+    const unsigned idx0 = blockIdx.x * 128u + threadIdx.x, idx1 = idx0 + 64u;
+    // the block's class first: only the order bytes (one 4-byte word per filter)
+    const int order0 = tns_filter_order(filters, idx0, n_filters, n_frames), order1 = tns_filter_order(filters, idx1, n_filters, n_frames);
+    const int max_order = wave_max(order0 > order1 ? order0 : order1);  // (wave-uniform)
+    if (max_order == 0 || max_order > 12) return;  // (nothing to run; or the last class: aac_tns_kernel<20>)
+    if (max_order > 8) tns_pair_block<12, DIRECT>(coeffs, filters, sink, idx0, idx1, order0, order1);
+    else if (max_order > 4) tns_pair_block<8, DIRECT>(coeffs, filters, sink, idx0, idx1, order0, order1);
+    else tns_pair_block<4, DIRECT>(coeffs, filters, sink, idx0, idx1, order0, order1);
 }
 
 // Orders 13..20 (one filter per lane; the class is still the 128-filter block's: the lane looks at its sibling's order too)
@@ -640,15 +649,8 @@ int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const sy
     void *sink = nullptr;
     if (direct) SYM_TRY(ctx_sink(ctx, &sink));
     float *fsink = static_cast<float *>(sink);
-    if (direct) {
-        SYM_TNS_LAUNCH((aac_tns_pair_kernel<12, true>), blocks, fsink);  // (AAC-LC long windows: the common class first)
-        SYM_TNS_LAUNCH((aac_tns_pair_kernel<8, true>), blocks, fsink);
-        SYM_TNS_LAUNCH((aac_tns_pair_kernel<4, true>), blocks, fsink);
-    } else {
-        SYM_TNS_LAUNCH((aac_tns_pair_kernel<12, false>), blocks, fsink);
-        SYM_TNS_LAUNCH((aac_tns_pair_kernel<8, false>), blocks, fsink);
-        SYM_TNS_LAUNCH((aac_tns_pair_kernel<4, false>), blocks, fsink);
-    }
+    if (direct) SYM_TNS_LAUNCH((aac_tns_pair_kernel<true>), blocks, fsink);
+    else SYM_TNS_LAUNCH((aac_tns_pair_kernel<false>), blocks, fsink);
     SYM_TNS_LAUNCH((aac_tns_kernel<20>), 2 * blocks);
 #undef SYM_TNS_LAUNCH
     SYM_GPU(ctx, hipGetLastError());
