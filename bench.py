@@ -294,7 +294,7 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
                         "one order-12 TNS filter on 30 %% of the channel frames (%d filters, %d of %d pair frames take the list pass): joint-stereo list pass, "
                         "filters, one walk" % (frames, nch, nfr, len(filt), len(pf), n_pairs * nfr),
             "channel_frames": nch * nfr, "tns_filters": int(len(filt)), "tns_filter_order": tns_order, "tns_pair_frames": int(len(pf))}, \
-            "aac_joint_stereo_kernel (list) + aac_tns_kernel + aac_synth_quad_kernel<true>", pcm
+            "aac_joint_stereo_kernel (list) + aac_tns_kernel<true> + aac_synth_quad_kernel<true>", pcm
     if name in ("mp3q", "mp3q2"):
         # config 3 from what the ENTROPY DECODER produces: int16 Huffman samples + the 52-byte requantize record per granule-channel
         # + one 48-byte joint-stereo record per granule of a pair, every stream a mid/side pair, long blocks.

@@ -553,62 +553,54 @@ __device__ __forceinline__ TnsLane tns_lane(float *coeffs, const symaccel_aac_tn
     return L;
 }
 
-// A wavefront takes a BLOCK of 128 consecutive filters of the flat list, filters b + lane and b + 64 + lane on lane `lane`.
-// One kernel per tap class (TAPS = 4, 8, 12: aac_tns_pair_kernel; 20: aac_tns_kernel, one filter per lane -- forty packed
-// coefficient and history registers more than the pair form has room for), all launched over the same blocks: a wavefront runs
-// in the kernel of its block's highest order and leaves the others at once.  As ONE kernel the walks shared a register
-// allocation -- that of the largest -- and the ring of groups in flight did not fit two wavefronts per SIMD.
+// A block of 128 consecutive filters of the flat list on ONE wavefront, filters b + lane and b + 64 + lane on lane `lane`, with the tap count
+// of the block's class (its highest order rounded up to 4, 8 or 12) as a compile-time constant.
 template <int TAPS, bool DIRECT>
 __device__ __forceinline__ void tns_pair_block(float *coeffs, const symaccel_aac_tns_filter *filters, float *sink, unsigned idx0, unsigned idx1, int order0,
-                                               int order1) {
+                                               int order1, int lane) {
     const bool all_full = wave_max(((order0 != 0 && order0 != TAPS) || (order1 != 0 && order1 != TAPS)) ? 1 : 0) == 0;
     float lpc0[TAPS], lpc1[TAPS];
     const TnsLane L0 = tns_lane<TAPS>(coeffs, filters, idx0, order0, lpc0), L1 = tns_lane<TAPS>(coeffs, filters, idx1, order1, lpc1);
     const int max_len = wave_max(L0.len > L1.len ? L0.len : L1.len);  // wave-uniform bound: the longest range among the block's filters
     if constexpr (DIRECT) {
         // the lane's 128 bytes of the sink (symaccel_internal.h: kSinkBytes, never read), a slot of 8 KiB per wavefront
-        float *sink_lane = sink + (size_t)(blockIdx.x % (unsigned)kTnsSinkSlots) * (64 * 2 * kTnsGroup) + threadIdx.x * (2 * kTnsGroup);
+        float *sink_lane = sink + (size_t)(blockIdx.x % (unsigned)kTnsSinkSlots) * (64 * 2 * kTnsGroup) + lane * (2 * kTnsGroup);
         if (all_full)  // (wave-uniform)
             tns_walk2_direct<TAPS, true>(coeffs, sink_lane, L0, L1, lpc0, lpc1, max_len);
         else
             tns_walk2_direct<TAPS, false>(coeffs, sink_lane, L0, L1, lpc0, lpc1, max_len);
     } else {
         if (all_full)  // (wave-uniform)
-            tns_walk2<TAPS, true>(coeffs, L0, L1, lpc0, lpc1, max_len, (int)threadIdx.x);
+            tns_walk2<TAPS, true>(coeffs, L0, L1, lpc0, lpc1, max_len, lane);
         else
-            tns_walk2<TAPS, false>(coeffs, L0, L1, lpc0, lpc1, max_len, (int)threadIdx.x);
+            tns_walk2<TAPS, false>(coeffs, L0, L1, lpc0, lpc1, max_len, lane);
     }
 }
 
-// Orders 1..12, two filters per lane: ONE launch for the three tap classes (4, 8, 12) -- their walks need 195 .. 227 registers each, so the
-// shared allocation costs nothing, and a class of its own was a launch (~3-5 us of stream time) that most batches leave at once.
+// ONE launch for every tap class: a workgroup of two wavefronts takes a block of 128 filters.
+//  * orders up to 12: wavefront 0 alone, two filters per lane, the tap count a compile-time constant of the block's class (4, 8 or 12: the
+//    walks need 195 .. 227 registers each, so the shared allocation costs nothing); wavefront 1 leaves at once;
+//  * orders 13 .. 20: both wavefronts, one filter per lane (forty packed coefficient and history registers more than the pair form has room for).
+// A kernel per class (rounds 2 .. 5) was a launch each -- 3-5 us of stream time that most batches leave at once.
 template <bool DIRECT>
-__global__ __launch_bounds__(64) void aac_tns_pair_kernel(float *__restrict__ coeffs, unsigned n_frames,
-                                                          const symaccel_aac_tns_filter *__restrict__ filters, unsigned n_filters, float *__restrict__ sink) {
-    const unsigned idx0 = blockIdx.x * 128u + threadIdx.x, idx1 = idx0 + 64u;
+__global__ __launch_bounds__(128) void aac_tns_kernel(float *__restrict__ coeffs, unsigned n_frames, const symaccel_aac_tns_filter *__restrict__ filters,
+                                                      unsigned n_filters, float *__restrict__ sink) {
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned idx0 = blockIdx.x * 128u + lane, idx1 = idx0 + 64u;
     // the block's class first: only the order bytes (one 4-byte word per filter)
     const int order0 = tns_filter_order(filters, idx0, n_filters, n_frames), order1 = tns_filter_order(filters, idx1, n_filters, n_frames);
-    const int max_order = wave_max(order0 > order1 ? order0 : order1);  // (wave-uniform)
-    if (max_order == 0 || max_order > 12) return;  // (nothing to run; or the last class: aac_tns_kernel<20>)
-    if (max_order > 8) tns_pair_block<12, DIRECT>(coeffs, filters, sink, idx0, idx1, order0, order1);
-    else if (max_order > 4) tns_pair_block<8, DIRECT>(coeffs, filters, sink, idx0, idx1, order0, order1);
-    else tns_pair_block<4, DIRECT>(coeffs, filters, sink, idx0, idx1, order0, order1);
-}
-
-// Orders 13..20 (one filter per lane; the class is still the 128-filter block's: the lane looks at its sibling's order too)
-template <int TAPS>
-__global__ __launch_bounds__(64) void aac_tns_kernel(float *__restrict__ coeffs, unsigned n_frames,
-                                                     const symaccel_aac_tns_filter *__restrict__ filters, unsigned n_filters) {
-    const unsigned idx = blockIdx.x * 64u + threadIdx.x;
-    const int order = tns_filter_order(filters, idx, n_filters, n_frames), sibling = tns_filter_order(filters, idx ^ 64u, n_filters, n_frames);
-    const int max_order = wave_max(order > sibling ? order : sibling);
-    constexpr int kLower = 12;  // this kernel's orders: kLower < max_order <= TAPS
-    static_assert(TAPS == kTnsMaxOrder, "the one-filter-per-lane form is the last class");
-    if (max_order <= kLower || max_order > TAPS) return;
-    float lpc[TAPS];
-    const TnsLane L = tns_lane<TAPS>(coeffs, filters, idx, order, lpc);
-    const int max_len = wave_max(L.len);  // wave-uniform bound: the longest range among the wavefront's filters
-    tns_walk<TAPS>(coeffs, L, lpc, max_len, (int)threadIdx.x);
+    const int max_order = wave_max(order0 > order1 ? order0 : order1);  // (the same in both wavefronts)
+    if (max_order == 0) return;
+    if (max_order > 12) {
+        float lpc[kTnsMaxOrder];
+        const TnsLane L = tns_lane<kTnsMaxOrder>(coeffs, filters, wave ? idx1 : idx0, wave ? order1 : order0, lpc);
+        tns_walk<kTnsMaxOrder>(coeffs, L, lpc, wave_max(L.len), (int)lane);
+        return;
+    }
+    if (wave != 0) return;
+    if (max_order > 8) tns_pair_block<12, DIRECT>(coeffs, filters, sink, idx0, idx1, order0, order1, (int)lane);
+    else if (max_order > 4) tns_pair_block<8, DIRECT>(coeffs, filters, sink, idx0, idx1, order0, order1, (int)lane);
+    else tns_pair_block<4, DIRECT>(coeffs, filters, sink, idx0, idx1, order0, order1, (int)lane);
 }
 
 }  // namespace
@@ -637,11 +629,11 @@ int launch_aac_js_consume(symaccel_ctx *ctx, symaccel_aac_js_frame *d_desc, cons
 
 int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const symaccel_aac_tns_filter *d_filters,
                    size_t n_filters) {
-    const size_t blocks = (n_filters + 127) / 128;  // blocks of 128 filters: one wavefront each in the pair kernels, two in the last class
-    if (n_frames > 0xffffffffu || n_filters > 0xffffffffu || 2 * blocks > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    const size_t blocks = (n_filters + 127) / 128;  // blocks of 128 filters: a workgroup each
+    if (n_frames > 0xffffffffu || n_filters > 0xffffffffu || blocks > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     if (n_filters == 0) return SYMACCEL_OK;
-#define SYM_TNS_LAUNCH(KERNEL, GRID, ...) \
-    hipLaunchKernelGGL((KERNEL), dim3((unsigned)(GRID)), dim3(64), 0, ctx->stream, d_coeffs, (unsigned)n_frames, d_filters, (unsigned)n_filters, ##__VA_ARGS__)
+#define SYM_TNS_LAUNCH(KERNEL) \
+    hipLaunchKernelGGL((KERNEL), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, d_coeffs, (unsigned)n_frames, d_filters, (unsigned)n_filters, fsink)
     // below two wavefronts per SIMD the lanes move their lines themselves (tns_walk2_direct); development knob: SYMACCEL_TNS_DIRECT = 0 / 1
     const char *direct_env = std::getenv("SYMACCEL_TNS_DIRECT");  // (read per launch: the tests run both forms in one process)
     const int direct_knob = direct_env ? std::atoi(direct_env) : -1;
@@ -649,9 +641,8 @@ int launch_aac_tns(symaccel_ctx *ctx, float *d_coeffs, size_t n_frames, const sy
     void *sink = nullptr;
     if (direct) SYM_TRY(ctx_sink(ctx, &sink));
     float *fsink = static_cast<float *>(sink);
-    if (direct) SYM_TNS_LAUNCH((aac_tns_pair_kernel<true>), blocks, fsink);
-    else SYM_TNS_LAUNCH((aac_tns_pair_kernel<false>), blocks, fsink);
-    SYM_TNS_LAUNCH((aac_tns_kernel<20>), 2 * blocks);
+    if (direct) SYM_TNS_LAUNCH(aac_tns_kernel<true>);
+    else SYM_TNS_LAUNCH(aac_tns_kernel<false>);
 #undef SYM_TNS_LAUNCH
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;
