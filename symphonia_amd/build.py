@@ -32,7 +32,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-f
 # Per-source additions.  aac_tools.hip: the TNS filters are chains of dependent packed instructions, and a packed instruction that reads the
 # result of the instruction right before it costs a wait state (s_nop): the default scheduler puts every multiply directly in front of its
 # subtraction (mul, nop, sub per tap), the ILP strategy interleaves the next tap's multiply (1239 -> 150 s_nop in aac_tns_pair_kernel<12, true>).
-SOURCE_FLAGS = {"aac_tools.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}  # (an AMDGPU option: the host pass ignores it; -misched=gcn-iterative-ilp crashes the x86 side)
+# mp3.hip / alac.hip / flac.hip: measured on the GPU against the default strategy (profiles/r06z13_ilp_ab.txt): MP3 int16 -> PCM 0.428 -> 0.403 ms,
+# ALAC 3.04 -> 3.00, FLAC 7.75 -> 7.71, MP3 config 3 equal; vorbis_wave.hip spills under it (68 B of scratch) and vorbis.hip gains nothing: not these.
+_ILP = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+SOURCE_FLAGS = {"aac_tools.hip": _ILP, "mp3.hip": _ILP, "alac.hip": _ILP, "flac.hip": _ILP}  # (an AMDGPU option: the host pass ignores it; -misched=gcn-iterative-ilp crashes the x86 side)
 TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_VARIANT", "NT", "MP3_WAVES", "MP3_VARIANT", "MP3_WG_WAVES", "MP3_FUSED_WAVES", "MP3_FUSED_WG_WAVES", "VORBIS_WAVES", "ALAC_SMALL_WAVES", "FLAC_PARTS", "MP3_SLOT_GROUP", "MP3_PACKED", "MP3_PAIR_GROUP", "AAC_ABLATE", "AAC_SINK", "AAC_CLOCK", "AAC_QUAD", "MULTI_WAVE", "VORBIS_WAVE2", "VORBIS_WG", "VORBIS_WG_SHARED", "ST_POLICY", "PACKED_C32", "WG4096_ABLATE", "FLAC_STORE_SWITCH", "ALAC_ONE_LAUNCH", "MP3_FRONT", "LDS_ABLATE", "F1_ABLATE", "F1_WAVES", "TNS_AHEAD", "TNS_ABLATE")
 TUNE_PREFIX = "SYMACCEL_TUNE_"
 
@@ -44,10 +47,25 @@ def hipcc():
     return exe
 
 
+def tuned_source_flags(env=None):
+    """SYMACCEL_TUNE_ILP=<a.hip,b.hip>: the ILP scheduling strategy for more sources than SOURCE_FLAGS names (development A/B: a tuned side build)."""
+    env = os.environ if env is None else env
+    names = [n for n in env.get(TUNE_PREFIX + "ILP", "").split(",") if n]
+    for n in names:
+        if n not in SOURCES:
+            raise ValueError("%sILP names %r, not one of the sources" % (TUNE_PREFIX, n))
+    out = {k: list(v) for k, v in SOURCE_FLAGS.items()}
+    for n in names:
+        out[n] = ["-mllvm", "-amdgpu-sched-strategy=" + env.get(TUNE_PREFIX + "SCHED", "iterative-ilp")]  # (SYMACCEL_TUNE_SCHED: another strategy for the A/B)
+    return out
+
+
 def tuning_defines(env=None):
     """-DSYM_<NAME>=<int> for every allow-listed SYMACCEL_TUNE_<NAME> in the environment."""
     env = os.environ if env is None else env
     out = []
+    if env.get(TUNE_PREFIX + "ILP"):
+        out.append("-DSYM_TUNED_ILP_SOURCES=1")  # (names no macro of the sources: it only marks the build as a tuned one, see tuned_source_flags)
     for name in TUNING_KNOBS:
         v = env.get(TUNE_PREFIX + name)
         if v is None:
@@ -68,7 +86,7 @@ def flags_record(defines):
     for p in source_files():
         h.update(p.name.encode())
         h.update(p.read_bytes())
-    return {"arch": ARCH, "flags": [f for f in FLAGS if f != str(CSRC)], "source_flags": SOURCE_FLAGS, "tuning": list(defines), "sources": SOURCES,
+    return {"arch": ARCH, "flags": [f for f in FLAGS if f != str(CSRC)], "source_flags": tuned_source_flags(), "tuning": list(defines), "sources": SOURCES,
             "source_sha256": h.hexdigest()}
 
 
@@ -118,7 +136,7 @@ def build(force=False, verbose=False, save_temps=False):
             objs.append(str(HERE / "build" / (src.replace(".", "_") + ".o")))
             continue
         obj = objdir / (src.replace(".", "_") + ".o")
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-x", "hip", *FLAGS, *SOURCE_FLAGS.get(src, []), *defines, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-x", "hip", *FLAGS, *tuned_source_flags().get(src, []), *defines, "-c", str(CSRC / src), "-o", str(obj)]
         if save_temps:
             cmd += ["-save-temps=obj"]
         if verbose:

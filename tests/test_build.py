@@ -87,7 +87,8 @@ def test_aac_three_wave_variant_fits_its_register_budget():
 def test_mp3_build_variants_fit_three_waves_per_simd(variant):
     """The measured-and-documented MP3 variants (float4 PCM stores through an LDS tile; two granules in
     flight) stay buildable at the same occupancy, without scratch or fused multiply-adds."""
-    text = device_asm("mp3.hip", ["-DSYM_MP3_VARIANT=%d" % variant, "-DSYM_MP3_PACKED=0"])  # (round-2 variants, as measured then)
+    # (round-2 variants, as measured then: the default scheduling strategy -- under the product's ILP strategy they spill 28 bytes)
+    text = device_asm("mp3.hip", ["-DSYM_MP3_VARIANT=%d" % variant, "-DSYM_MP3_PACKED=0"], source_flags=[])
     (r,) = kernel_resources(text).values()
     assert r["ScratchSize"] == 0 and r["NumVgprs"] <= 168 and r["Occupancy"] == 3, r
     assert 3 * 4 * r["LDSByteSize"] <= 160 * 1024 * (4 if variant == 2 else 1)  # variant 2: four wavefronts per workgroup
