@@ -344,7 +344,8 @@ def test_gpu_batcher_mp3_and_zero_copy_and_threads(gpu_ctx):
 
 @pytest.mark.gpu
 def test_gpu_batcher_large_group_is_chunked(gpu_ctx):
-    """512 chains x 16 frames = 32 MiB of spectra in one group: three overlapped chunks, same bits as one symaccel_aac_synth call"""
+    """512 chains x 16 frames = 32 MiB of spectra in one group: two overlapped chunks (round 6: half a full group per chunk, three measured
+    slower -- profiles/r06z5_copy_grid.jsonl), same bits as one symaccel_aac_synth call"""
     from symphonia_amd import AacDsp
     rng = np.random.default_rng(3)
     n_streams, nfr = 256, 16
@@ -359,7 +360,7 @@ def test_gpu_batcher_large_group_is_chunked(gpu_ctx):
     for t in tickets:
         b.collect(t)
     st = b.stats()
-    assert st["launches"] == 1 and st["chunks"] >= 3 and st["max_chains_per_launch"] == 512 and st["staging_bytes"] <= 3 * (64 << 20)
+    assert st["launches"] == 1 and st["chunks"] >= 2 and st["max_chains_per_launch"] == 512 and st["staging_bytes"] <= 3 * (64 << 20)
     assert bit_equal(pcm.reshape(-1, nfr, 1024), np.asarray(want_pcm)) and bit_equal(got_delay.reshape(-1, 1024), np.asarray(want_delay))
     b.close()
 
