@@ -169,28 +169,37 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
                 dsp.synth(coeffs, side, delay[0], pcm, delay_out=delay[1])
             delay.reverse()
         step.input = coeffs
-        if name == "aacjs":
-            def verify():
-                import oracle
-                z = torch.zeros_like(delay[0])
+        pristine = coeffs.clone() if name == "aacjs2" else coeffs  # (aacjs2 decodes in place: its check runs on a copy of the coded spectra)
+
+        def verify():
+            import oracle
+            z = torch.zeros_like(delay[0])
+            if name == "aacjs":
                 tools.synth_joint_stereo(coeffs, side, z, d_pairs, d_desc, pcm, delay_out=delay[1])
-                bad = checked = 0
-                for p_ in sorted({0, n_pairs - 1}):
-                    l, r = int(pairs[p_, 0]), int(pairs[p_, 1])
-                    fr = slice(0, min(nfr, 24))
-                    cl, cr = coeffs[l, fr].cpu().numpy(), coeffs[r, fr].cpu().numpy()
-                    dl, dr = cl.copy(), cr.copy()
-                    for f in range(cl.shape[0]):
-                        dl[f], dr[f] = oracle.aac_joint_stereo(cl[f], cr[f], 1, 40, swb_long, desc[p_, f]["mode"], desc[p_, f]["scale"])
-                    want, _ = oracle.aac_synth(np.stack([dl, dr]), side[[l, r], fr].cpu().numpy(), np.zeros((2, 1024), np.float32))
-                    got = pcm[[l, r], fr].cpu().numpy()
-                    bad += int((got != want).sum())
-                    checked += got.size
-                if bad:
-                    raise RuntimeError("bench: the aacjs batch differs from the oracle in %d of %d sampled samples" % (bad, checked))
-                return {"checker": "oracle/symoracle.c (joint stereo, then Dsp::synth), outside the timed region", "pairs": sorted({0, n_pairs - 1}),
-                        "frame_windows": [[0, min(nfr, 24)]], "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
-            step.verify = verify
+            else:
+                x = pristine.clone()
+                tools.joint_stereo(x, d_pairs, d_desc)
+                dsp.synth(x, side, z, pcm, delay_out=delay[1])
+                del x
+            sync_dev()
+            bad = checked = 0
+            for p_ in sorted({0, n_pairs - 1}):
+                l, r = int(pairs[p_, 0]), int(pairs[p_, 1])
+                fr = slice(0, min(nfr, 24))
+                cl, cr = pristine[l, fr].cpu().numpy(), pristine[r, fr].cpu().numpy()
+                dl, dr = cl.copy(), cr.copy()
+                for f in range(cl.shape[0]):
+                    dl[f], dr[f] = oracle.aac_joint_stereo(cl[f], cr[f], 1, 40, swb_long, desc[p_, f]["mode"], desc[p_, f]["scale"])
+                want, _ = oracle.aac_synth(np.stack([dl, dr]), side[[l, r], fr].cpu().numpy(), np.zeros((2, 1024), np.float32))
+                got = pcm[[l, r], fr].cpu().numpy()
+                bad += int((got != want).sum())
+                checked += got.size
+            if bad:
+                raise RuntimeError("bench: the %s batch differs from the oracle in %d of %d sampled samples" % (name, bad, checked))
+            return {"checker": "oracle/symoracle.c (joint stereo, then Dsp::synth), outside the timed region" + ("" if name == "aacjs" else ", on a pristine copy of the spectra"),
+                    "pairs": sorted({0, n_pairs - 1}), "frame_windows": [[0, min(nfr, 24)]], "samples_compared": checked, "mismatches": bad,
+                    "criterion": "bit-identical f32 (value comparison)"}
+        step.verify = verify
         frames = nch * nfr // 2
         bytes_alg = nch * nfr * 8192 + n_pairs * nfr * 644
         return step, frames, "frames", bytes_alg, {
@@ -318,46 +327,47 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
         pcm = torch.empty((nch, ngr, 576), device=dev, dtype=torch.float32)
         syn = sa.Mp3Synthesis(ctx, 0)
         if name == "mp3q":
-            def step():
-                syn.decode(q, d_rq, d_units, d_st, side, stt[0][0], stt[0][1], stt[0][2], pcm, state_out=stt[1])
-                stt.reverse()
+            def run_from(s0, s1):
+                syn.decode(q, d_rq, d_units, d_st, side, s0[0], s0[1], s0[2], pcm, state_out=s1)
             kernel = "mp3_synth_kernel<4, true>"
-
-            def verify():
-                """the timed batch itself, from a zero state: sampled streams x the first granules against the oracle chain requantize ->
-                stereo -> synthesis (layer3/mod.rs:421-477)"""
-                import oracle
-                z = [torch.zeros_like(t) for t in stt[0]]
-                syn.decode(q, d_rq, d_units, d_st, side, z[0], z[1], z[2], pcm, state_out=stt[1])
-                sync_dev()
-                bad = checked = 0
-                gw = min(ngr, 24)
-                picked = sorted({0, nch // 2 - 1})
-                for u in picked:
-                    c0, c1 = int(units[u, 0]), int(units[u, 1])
-                    qs = q[[c0, c1], :gw].cpu().numpy()
-                    xr_ = oracle.mp3_requantize(qs.reshape(-1, 576), np.ascontiguousarray(rq[[c0, c1], :gw]).reshape(-1), 0).reshape(2, gw, 576)
-                    for gi in range(gw):
-                        xr_[0, gi], xr_[1, gi] = oracle.mp3_stereo(xr_[0, gi], xr_[1, gi], st[u, gi], 0)
-                    want = oracle.mp3_synth(xr_, np.ascontiguousarray(side_np[[c0, c1], :gw]).view(np.uint8).reshape(2, gw, 4), 0, np.zeros((2, 576), np.float32),
-                                            np.zeros((2, 1024), np.float32), np.zeros(2, np.int32))[0]
-                    got = pcm[[c0, c1], :gw].cpu().numpy()
-                    bad += int((got != want).sum())
-                    checked += got.size
-                if bad:
-                    raise RuntimeError("bench: the mp3q batch differs from the oracle in %d of %d sampled samples" % (bad, checked))
-                return {"checker": "oracle/symoracle.c (requantize, stereo, then the synthesis tail), outside the timed region", "streams": picked,
-                        "granule_windows": [[0, gw]], "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
-            step.verify = verify
         else:
             xr = torch.empty((nch, ngr, 576), device=dev, dtype=torch.float32)
             ste = sa.Mp3Stereo(ctx, 0)
 
-            def step():
+            def run_from(s0, s1):
                 ste.requantize_stereo(q, d_rq, d_units, d_st, xr)
-                syn.synth(xr, side, stt[0][0], stt[0][1], stt[0][2], pcm, state_out=stt[1])
-                stt.reverse()
+                syn.synth(xr, side, s0[0], s0[1], s0[2], pcm, state_out=s1)
             kernel = "mp3_stereo_kernel<true> + mp3_synth_kernel<1, false>"
+
+        def step():
+            run_from(stt[0], stt[1])
+            stt.reverse()
+
+        def verify():
+            """the timed batch itself, from a zero state: sampled streams x the first granules against the oracle chain requantize ->
+            stereo -> synthesis (layer3/mod.rs:421-477)"""
+            import oracle
+            run_from([torch.zeros_like(t) for t in stt[0]], stt[1])
+            sync_dev()
+            bad = checked = 0
+            gw = min(ngr, 24)
+            picked = sorted({0, nch // 2 - 1})
+            for u in picked:
+                c0, c1 = int(units[u, 0]), int(units[u, 1])
+                qs = q[[c0, c1], :gw].cpu().numpy()
+                xr_ = oracle.mp3_requantize(qs.reshape(-1, 576), np.ascontiguousarray(rq[[c0, c1], :gw]).reshape(-1), 0).reshape(2, gw, 576)
+                for gi in range(gw):
+                    xr_[0, gi], xr_[1, gi] = oracle.mp3_stereo(xr_[0, gi], xr_[1, gi], st[u, gi], 0)
+                want = oracle.mp3_synth(xr_, np.ascontiguousarray(side_np[[c0, c1], :gw]).view(np.uint8).reshape(2, gw, 4), 0, np.zeros((2, 576), np.float32),
+                                        np.zeros((2, 1024), np.float32), np.zeros(2, np.int32))[0]
+                got = pcm[[c0, c1], :gw].cpu().numpy()
+                bad += int((got != want).sum())
+                checked += got.size
+            if bad:
+                raise RuntimeError("bench: the %s batch differs from the oracle in %d of %d sampled samples" % (name, bad, checked))
+            return {"checker": "oracle/symoracle.c (requantize, stereo, then the synthesis tail), outside the timed region", "streams": picked,
+                    "granule_windows": [[0, gw]], "samples_compared": checked, "mismatches": bad, "criterion": "bit-identical f32 (value comparison)"}
+        step.verify = verify
         step.input = q
         granules = nch * ngr // 2
         per_gc = 1152 + 52 + 24 + 4 + 2304  # samples + requantize record + half a stereo record + side word in, PCM out
