@@ -15,6 +15,9 @@
 
 // (the attribute's argument is an expression of a template parameter: hidden from the host-only emulation build, whose
 // compiler does not know the attribute and cannot parse that)
+#ifndef SYM_ALAC_UPDATE
+#define SYM_ALAC_UPDATE 1  // 0: the round-5 sign-LMS update in the narrow form too (A/B); 1: the residual carried as -|res| (alac_step)
+#endif
 #ifndef SYM_ALAC_SMALL_WAVES
 #define SYM_ALAC_SMALL_WAVES 3  // wavefronts per SIMD of the orders-<=-8 instantiations (build-time tuning knob)
 #endif
@@ -74,6 +77,16 @@ __device__ __forceinline__ int32_t signum_i32(int32_t v) {
     return v > 1 ? 1 : (v < -1 ? -1 : v);
 #endif
 }
+// |a - b| + c on unsigned operands: one instruction
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return (a > b ? a - b : b - a) + c;
+#endif
+}
 // clip_msbs (lib.rs:659-661)
 __device__ __forceinline__ int32_t clip_msbs(int32_t v, uint32_t num) { return (int32_t)((uint32_t)v << num) >> num; }
 
@@ -86,6 +99,7 @@ struct AlacLane {
     int32_t h[NC == 32 ? 32 : NC + 1];  // shift register of the latest outputs: h[k] = out[i - 1 - k]
     int32_t p1_prev;    // previous output of the first (order-1) pass of the double predictor (lib.rs:185-189)
     unsigned order, shift, clip;
+    uint32_t ceil_mask;  // 2^shift - 1 (the sign-LMS update of the narrow form)
     bool enabled, twice;
 };
 
@@ -94,6 +108,9 @@ struct AlacLane {
 // STEADY: every lane of the wavefront is enabled and past its warm-up samples (i > order): no per-sample conditions.
 template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false>
 __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigned i, int32_t past_far) {
+    // SYM_ALAC_UPDATE == 2 (narrow form): the history registers hold the outputs with the sign bit flipped, i.e. in unsigned order, so that
+    // |h[k] - past0| + rounding is ONE v_sad_u32 on them (the bias cancels in every difference)
+    constexpr uint32_t HB = (M24 && SYM_ALAC_UPDATE == 2) ? 0x80000000u : 0u;
     if (STEADY || L.enabled) {
         // first pass of the double predictor: out[i] = clip(out[i] + out[i-1]) over the whole block
         if constexpr (STEADY) {
@@ -104,12 +121,12 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
         }
         L.p1_prev = x;
         if (!STEADY && i >= 1 && i <= L.order) {
-            x = clip_msbs(wrap_add(x, L.h[0]), L.clip);  // warm-up samples (lib.rs:196-198)
+            x = clip_msbs(wrap_add(x, (int32_t)((uint32_t)L.h[0] ^ HB)), L.clip);  // warm-up samples (lib.rs:196-198)
         } else if (STEADY || i > L.order) {
             int32_t res = x;
             int32_t past0;
             if constexpr (NC == 32) {
-                past0 = L.order == 1 ? L.h[1] : (L.order == 2 ? L.h[2] : past_far);
+                past0 = L.order == 1 ? L.h[1] : (L.order == 2 ? L.h[2] : (int32_t)((uint32_t)past_far ^ HB));
             } else if constexpr (FULL) {
                 past0 = L.h[TAPS];
             } else {
@@ -129,7 +146,7 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
             }
             sum = wrap_add(sum, sum1);
             const int32_t val = wrap_add(sum, (int32_t)((1u << L.shift) >> 1)) >> L.shift;
-            x = clip_msbs(wrap_add(wrap_add(x, past0), val), L.clip);
+            x = clip_msbs(wrap_add(wrap_add(x, (int32_t)((uint32_t)past0 ^ HB)), val), L.clip);
             // sign-LMS update (lib.rs:224-260): from the oldest sample (coefficient order-1) to the newest, until the
             // residual reaches or crosses zero (the reference's `break`, here a per-lane predicate).
             // Shape of the code (it decides the kernel's speed; one lane per block means every predicate is per lane):
@@ -151,6 +168,36 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
             //    differences fit 24 bits), so the update works on dk[k] with the signs folded; the full-width form keeps val as the
             //    reference computes it (past0 - sample wraps to the same sign as sample - past0 at -2^31).
             //    (Taking the sign AFTER a conditional negate -- xor, sub, median instead of median, negate, select -- measured equal: 3.00 against 2.98 ms.)
+            if constexpr (M24 && SYM_ALAC_UPDATE != 0) {
+                // Round 6, narrow form only.  The serial part of a tap was xor + compare + select ("still on the residual's side") and the
+                // direction cost xor + sub per tap; both disappear when the residual is carried as Q = -|res|:
+                //  * res > 0: every tap subtracts (1 + j) * (|val| >> shift) >= 0 and the lane stays active while res > 0;
+                //    res < 0: every tap subtracts (1 + j) * ((-|val|) >> shift) <= 0, active while res < 0.  With
+                //    a_k = |val| >> shift resp. -((-|val|) >> shift) = (|val| + 2^shift - 1) >> shift (an arithmetic shift floors, so the
+                //    negative case is a ceiling) both are Q += (1 + j) * a_k, active while Q < 0: the test is the sign bit (ashr + and).
+                //    No wrap: |val| < 2^23 (narrow) and 1 + j <= 32, so a still-active Q (< 0) moves by less than 2^28 per tap -- and
+                //    once inactive the mask is 0 for good, whatever Q does afterwards.
+                //  * the coefficient moves by signum(-val) * (res > 0 ? 1 : -1) while active: ONE multiply-add with the mask that already
+                //    carries the direction (+-1, or 0 once inactive).
+                // |val| is signum(v) * v (one multiply of the 1.8 ns class; the signum is needed for the coefficient anyway).
+                const int32_t s = res >> 31;                                               // -1: negative residual
+                int32_t Q = wrap_sub(s, res ^ s);                                          // -|res|
+                int32_t actdir = (s | 1) & (Q >> 31);                                      // +1 / -1 while active, 0 for res == 0
+                const uint32_t rnd = (uint32_t)s & L.ceil_mask;                            // 2^shift - 1 for a negative residual: the ceiling
+#pragma unroll
+                for (int k = TAPS - 1; k >= 0; --k) {
+                    const int32_t nk = (int32_t)L.order - k;                               // (1 + j); <= 0 beyond the order
+                    int32_t v = dk[k];                                                     // -val
+                    if constexpr (!FULL) v &= wrap_sub(0, nk) >> 31;                       // 0 beyond the lane's order: a_k = 0, no move
+                    const int32_t sg = signum_i32(v);
+                    uint32_t a;
+                    if constexpr (HB != 0 && FULL) a = sad_u32((uint32_t)L.h[k], (uint32_t)past0, rnd) >> L.shift;
+                    else a = ((uint32_t)__mul24(sg, v) + rnd) >> L.shift;                  // |val| >> shift, resp. its ceiling
+                    L.c[k] = tap_mad<true>(sg, actdir, L.c[k]);
+                    Q = tap_mad<true>(nk, (int32_t)a, Q);
+                    actdir &= Q >> 31;
+                }
+            } else {
             const int32_t pm = res > 0 ? 0 : -1;      // 0: the residual is positive, -1: negative (zero: never active)
             int32_t act = res != 0 ? -1 : 0;
 #pragma unroll
@@ -166,11 +213,12 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
                 res = tap_mad<M24>(wrap_sub(0, nk), step, res);                            // the residual after this tap
                 act = (res ^ pm) > pm ? act : 0;                                           // > 0 resp. < 0: still on the residual's side
             }
+            }
         }
     }
 #pragma unroll
     for (int k = (NC == 32 ? TAPS - 1 : TAPS); k >= 1; --k) L.h[k] = L.h[k - 1];
-    L.h[0] = x;
+    L.h[0] = (int32_t)((uint32_t)x ^ HB);
     return x;
 }
 
@@ -321,15 +369,17 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
 #pragma unroll
     for (int j = 0; j < NC; ++j) L.c[j] = 0;
 #pragma unroll
-    for (int j = 0; j < (NC == 32 ? 32 : NC + 1); ++j) L.h[j] = 0;
+    for (int j = 0; j < (NC == 32 ? 32 : NC + 1); ++j) L.h[j] = (M24 && SYM_ALAC_UPDATE == 2) ? (int32_t)0x80000000u : 0;  // (zero, in the history's representation)
     L.p1_prev = 0;
     L.order = L.shift = L.clip = 0;
+    L.ceil_mask = 0;
     L.enabled = L.twice = false;
     if (have) {
         const symaccel_alac_desc d = desc[my];
         const bool valid_mode = d.mode == 0 || d.mode >= 15;  // lib.rs:167-169 (mode is a 4-bit field)
         L.order = d.lpc_order > 31u ? 31u : d.lpc_order;
         L.shift = d.shift & 31u;
+        L.ceil_mask = (1u << L.shift) - 1u;
         L.clip = 32u - (d.bps < 1u ? 1u : (d.bps > 32u ? 32u : d.bps));
         L.enabled = valid_mode && L.order != 0;                // lib.rs:173-175
         L.twice = L.order == 31 || d.mode == 15;               // lib.rs:185

@@ -182,6 +182,38 @@ def test_emu_alac_24_bit_multiply_bound(emu_ctx, blocksize):
     assert np.array_equal(got, want)
 
 
+def narrow_update_case(seed, nb, bs, hi_order):
+    """The narrow form's sign-LMS update at its edges (alac.hip, alac_step: the residual carried as -|res|): every shift 0 .. 31 (the
+    ceiling of the negative case adds 2^shift - 1), residuals of 0, +-1, i32::MIN / MAX, small ones that cross zero after a tap or two,
+    outputs on both ends of the channel's range so that |val| reaches 2^bps - 1."""
+    rng = np.random.default_rng(seed)
+    bps = rng.integers(16, 24, nb).astype(np.uint8)
+    buf = rng.integers(-40, 41, (nb, bs)).astype(np.int32)
+    kind = rng.integers(0, 6, (nb, bs))
+    buf[kind == 0] = 0
+    buf[kind == 1] = rng.choice([-(1 << 31), (1 << 31) - 1, -(1 << 31) + 1, 1, -1], int((kind == 1).sum()))
+    big = rng.integers(-(1 << 22), 1 << 22, (nb, bs))
+    buf[kind == 2] = big[kind == 2]
+    buf[:, 0] = rng.integers(-(1 << 22), 1 << 22, nb)
+    order = rng.integers(1, hi_order + 1, nb).astype(np.uint8)
+    shift = (np.arange(nb) % 32).astype(np.uint8)
+    mode = rng.choice([0, 15], nb).astype(np.uint8)
+    coeffs = rng.integers(-(1 << 12), 1 << 12, (nb, 32)).astype(np.int32)
+    coeffs[::3] = rng.integers(-(1 << 22) + 1, 1 << 22, (len(coeffs[::3]), 32))
+    return buf, mode, order, shift, bps, coeffs
+
+
+@pytest.mark.parametrize("hi_order,uniform", [(8, True), (8, False), (4, False), (31, False)])
+def test_emu_alac_narrow_update_edges(emu_ctx, hi_order, uniform):
+    from symphonia_amd import AlacPredictor, alac_desc
+    buf, mode, order, shift, bps, coeffs = narrow_update_case(40 + hi_order, 192, 150, hi_order)
+    if uniform:
+        order[:] = hi_order
+    want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
+    got = AlacPredictor(emu_ctx).predict(buf, alac_desc(mode, order, shift, bps), coeffs)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("blocksize,nb", [(64, 64), (100, 70), (31, 130)])
 def test_emu_alac_predict_stereo_fused(emu_ctx, blocksize, nb):
     """predict with decorrelate_mid_side fused into the write-back == predict, then decorrelate_mid_side."""
@@ -285,6 +317,26 @@ def test_gpu_alac_24_bit_multiply_bound(blocksize):
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible")
     buf, mode, order, shift, bps, coeffs = narrow_case(1000 + blocksize, blocksize)
+    want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
+    with Context(0) as ctx:
+        ctx.use_torch_stream()
+        d = torch.from_numpy(buf.copy()).cuda()
+        desc = torch.from_numpy(alac_desc(mode, order, shift, bps).view(np.uint8).reshape(-1, 4)).cuda()
+        AlacPredictor(ctx).predict(d, desc, torch.from_numpy(coeffs).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hi_order,uniform", [(8, True), (8, False), (4, False), (31, False)])
+def test_gpu_alac_narrow_update_edges(hi_order, uniform):
+    import torch
+    from symphonia_amd import AlacPredictor, Context, alac_desc
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    buf, mode, order, shift, bps, coeffs = narrow_update_case(140 + hi_order, 1024, 1000, hi_order)
+    if uniform:
+        order[:] = hi_order
     want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
     with Context(0) as ctx:
         ctx.use_torch_stream()
