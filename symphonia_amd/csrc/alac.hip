@@ -100,13 +100,25 @@ struct AlacLane {
     int32_t p1_prev;    // previous output of the first (order-1) pass of the double predictor (lib.rs:185-189)
     unsigned order, shift, clip;
     uint32_t ceil_mask;  // 2^shift - 1 (the sign-LMS update of the narrow form)
+    uint32_t half;       // (1 << shift) >> 1: the prediction's rounding term (lib.rs:219)
     bool enabled, twice;
+    bool any_twice;  // wave-uniform: some block of the wavefront runs the double predictor (lib.rs:185)
 };
+
+// clip_msbs to the lane's bit depth.  Narrow form (bps <= 23): sign-extending the low bps bits is ONE v_bfe_i32 (the field's width is a
+// 5-bit operand, so a 32-bit channel cannot take this form) instead of a shift pair.
+template <bool M24, int NC>
+__device__ __forceinline__ int32_t clip_bits(int32_t v, const AlacLane<NC> &L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (M24) return __builtin_amdgcn_sbfe(v, 0u, 32u - L.clip);
+#endif
+    return clip_msbs(v, L.clip);
+}
 
 // One sample.  `past_far` = out[i - order - 1] as read back from LDS (valid for order >= 3).
 // FULL: every lane's order equals TAPS (wave-uniform), so no tap needs neutralising.
 // STEADY: every lane of the wavefront is enabled and past its warm-up samples (i > order): no per-sample conditions.
-template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false>
+template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false, bool TW = true>
 __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigned i, int32_t past_far) {
     // SYM_ALAC_UPDATE == 2 (narrow form): the history registers hold the outputs with the sign bit flipped, i.e. in unsigned order, so that
     // |h[k] - past0| + rounding is ONE v_sad_u32 on them (the bias cancels in every difference)
@@ -114,8 +126,10 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
     if (STEADY || L.enabled) {
         // first pass of the double predictor: out[i] = clip(out[i] + out[i-1]) over the whole block
         if constexpr (STEADY) {
-            const int32_t x2 = clip_msbs(wrap_add(x, L.p1_prev), L.clip);
-            x = L.twice ? x2 : x;
+            if constexpr (TW) {  // (TW = false: no block of the wavefront runs the double predictor -- order 31 / mode 15 is rare)
+                const int32_t x2 = clip_bits<M24>(wrap_add(x, L.p1_prev), L);
+                x = L.twice ? x2 : x;
+            }
         } else {
             if (L.twice && i >= 1) x = clip_msbs(wrap_add(x, L.p1_prev), L.clip);
         }
@@ -138,15 +152,15 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
             int32_t dk[TAPS];
 #pragma unroll
             for (int k = 0; k < TAPS; ++k) dk[k] = wrap_sub(L.h[k], past0);
-            int32_t sum = 0, sum1 = 0;  // (two chains of multiply-adds; wrapping sums re-associate)
+            int32_t sum = (int32_t)L.half, sum1 = 0;  // (two chains of multiply-adds; wrapping sums re-associate: the rounding term leads one)
 #pragma unroll
             for (int k = 0; k < TAPS; k += 2) {
                 sum = tap_mad<M24>(L.c[k], dk[k], sum);
                 if (k + 1 < TAPS) sum1 = tap_mad<M24>(L.c[k + 1], dk[k + 1], sum1);
             }
             sum = wrap_add(sum, sum1);
-            const int32_t val = wrap_add(sum, (int32_t)((1u << L.shift) >> 1)) >> L.shift;
-            x = clip_msbs(wrap_add(wrap_add(x, (int32_t)((uint32_t)past0 ^ HB)), val), L.clip);
+            const int32_t val = sum >> L.shift;
+            x = clip_bits<M24>(wrap_add(wrap_add(x, (int32_t)((uint32_t)past0 ^ HB)), val), L);
             // sign-LMS update (lib.rs:224-260): from the oldest sample (coefficient order-1) to the newest, until the
             // residual reaches or crosses zero (the reference's `break`, here a per-lane predicate).
             // Shape of the code (it decides the kernel's speed; one lane per block means every predicate is per lane):
@@ -225,7 +239,7 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
 // 32 samples of one tile.  `row` = this tile's LDS row of the lane, `prev_row` = the previous tile's (still intact in
 // the other LDS buffer); t0 = absolute index of column 0.  Rows are written back four samples at a time, so anything
 // older than three samples can be read back from LDS: that is where out[i - order - 1] comes from for order >= 3.
-template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false>
+template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false, bool TW = true>
 __device__ __forceinline__ void alac_steps32(AlacLane<NC> &L, int32_t *row, const int32_t *prev_row, unsigned t0, int n_valid) {
 #pragma unroll 1
     for (int u0 = 0; u0 < 32; u0 += 4) {
@@ -240,7 +254,7 @@ __device__ __forceinline__ void alac_steps32(AlacLane<NC> &L, int32_t *row, cons
                     const int idx = u - (int)L.order - 1;
                     far = idx >= 0 ? row[idx >= 0 ? idx : 0] : prev_row[32 + (idx < -32 ? -32 : idx)];
                 }
-                xs[q] = alac_step<TAPS, M24, FULL, NC, STEADY>(L, xs[q], t0 + (unsigned)u, far);
+                xs[q] = alac_step<TAPS, M24, FULL, NC, STEADY, TW>(L, xs[q], t0 + (unsigned)u, far);
             }
         }
         *reinterpret_cast<int4 *>(row + u0) = make_int4(xs[0], xs[1], xs[2], xs[3]);
@@ -373,6 +387,7 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
     L.p1_prev = 0;
     L.order = L.shift = L.clip = 0;
     L.ceil_mask = 0;
+    L.half = 0;
     L.enabled = L.twice = false;
     if (have) {
         const symaccel_alac_desc d = desc[my];
@@ -380,6 +395,7 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
         L.order = d.lpc_order > 31u ? 31u : d.lpc_order;
         L.shift = d.shift & 31u;
         L.ceil_mask = (1u << L.shift) - 1u;
+        L.half = (1u << L.shift) >> 1;
         L.clip = 32u - (d.bps < 1u ? 1u : (d.bps > 32u ? 32u : d.bps));
         L.enabled = valid_mode && L.order != 0;                // lib.rs:173-175
         L.twice = L.order == 31 || d.mode == 15;               // lib.rs:185
@@ -393,6 +409,7 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
             L.c[4 * j + 3] = (unsigned)(4 * j + 3) < L.order ? v.w : 0;
         }
     }
+    L.any_twice = __any(L.enabled && L.twice) != 0;
     const unsigned max_order = wave_max(L.enabled ? L.order : 0u);
     const bool full8 = __all(!have || !L.enabled || L.order == 8u) != 0 && max_order == 8u;
     const bool steady_ok = __all(!have || L.enabled) != 0;  // (with full8: past sample 8 no lane has a per-sample condition left)
@@ -423,7 +440,8 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
             const bool steady = steady_ok && cols == (unsigned)kCols && t0 > max_order;
             if constexpr (SMALL) {
                 if (full8) {  // the common stream: every block of the wavefront has order 8
-                    if (steady) alac_steps32<8, M24, true, 8, true>(L, row, prow, t0, (int)cols);
+                    if (steady && !L.any_twice) alac_steps32<8, M24, true, 8, true, false>(L, row, prow, t0, (int)cols);
+                    else if (steady) alac_steps32<8, M24, true, 8, true>(L, row, prow, t0, (int)cols);
                     else alac_steps32<8, M24, true>(L, row, prow, t0, (int)cols);
                 } else if (max_order <= 4) {
                     if (steady) alac_steps32<4, M24, false, 8, true>(L, row, prow, t0, (int)cols);

@@ -203,12 +203,14 @@ def narrow_update_case(seed, nb, bs, hi_order):
     return buf, mode, order, shift, bps, coeffs
 
 
-@pytest.mark.parametrize("hi_order,uniform", [(8, True), (8, False), (4, False), (31, False)])
+@pytest.mark.parametrize("hi_order,uniform", [(8, 1), (8, 2), (8, 0), (4, 0), (31, 0)])
 def test_emu_alac_narrow_update_edges(emu_ctx, hi_order, uniform):
     from symphonia_amd import AlacPredictor, alac_desc
     buf, mode, order, shift, bps, coeffs = narrow_update_case(40 + hi_order, 192, 150, hi_order)
     if uniform:
         order[:] = hi_order
+    if uniform == 2:  # no block runs the double predictor: the instantiation without that pass
+        mode[:] = 0
     want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
     got = AlacPredictor(emu_ctx).predict(buf, alac_desc(mode, order, shift, bps), coeffs)
     assert np.array_equal(got, want)
@@ -328,7 +330,7 @@ def test_gpu_alac_24_bit_multiply_bound(blocksize):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hi_order,uniform", [(8, True), (8, False), (4, False), (31, False)])
+@pytest.mark.parametrize("hi_order,uniform", [(8, 1), (8, 2), (8, 0), (4, 0), (31, 0)])
 def test_gpu_alac_narrow_update_edges(hi_order, uniform):
     import torch
     from symphonia_amd import AlacPredictor, Context, alac_desc
@@ -337,6 +339,8 @@ def test_gpu_alac_narrow_update_edges(hi_order, uniform):
     buf, mode, order, shift, bps, coeffs = narrow_update_case(140 + hi_order, 1024, 1000, hi_order)
     if uniform:
         order[:] = hi_order
+    if uniform == 2:
+        mode[:] = 0
     want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
     with Context(0) as ctx:
         ctx.use_torch_stream()
