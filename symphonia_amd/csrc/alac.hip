@@ -118,7 +118,7 @@ __device__ __forceinline__ int32_t clip_bits(int32_t v, const AlacLane<NC> &L) {
 // One sample.  `past_far` = out[i - order - 1] as read back from LDS (valid for order >= 3).
 // FULL: every lane's order equals TAPS (wave-uniform), so no tap needs neutralising.
 // STEADY: every lane of the wavefront is enabled and past its warm-up samples (i > order): no per-sample conditions.
-template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false, bool TW = true>
+template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false, bool TW = true, bool QF = false>
 __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigned i, int32_t past_far) {
     // SYM_ALAC_UPDATE == 2 (narrow form): the history registers hold the outputs with the sign bit flipped, i.e. in unsigned order, so that
     // |h[k] - past0| + rounding is ONE v_sad_u32 on them (the bias cancels in every difference)
@@ -182,8 +182,8 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
             //    differences fit 24 bits), so the update works on dk[k] with the signs folded; the full-width form keeps val as the
             //    reference computes it (past0 - sample wraps to the same sign as sample - past0 at -2^31).
             //    (Taking the sign AFTER a conditional negate -- xor, sub, median instead of median, negate, select -- measured equal: 3.00 against 2.98 ms.)
-            if constexpr (M24 && SYM_ALAC_UPDATE != 0) {
-                // Round 6, narrow form only.  The serial part of a tap was xor + compare + select ("still on the residual's side") and the
+            if constexpr ((M24 && SYM_ALAC_UPDATE != 0) || QF) {
+                // Round 6, narrow form (and the "mid" wavefronts of the wide form: QF, below).  The serial part of a tap was xor + compare + select ("still on the residual's side") and the
                 // direction cost xor + sub per tap; both disappear when the residual is carried as Q = -|res|:
                 //  * res > 0: every tap subtracts (1 + j) * (|val| >> shift) >= 0 and the lane stays active while res > 0;
                 //    res < 0: every tap subtracts (1 + j) * ((-|val|) >> shift) <= 0, active while res < 0.  With
@@ -194,21 +194,27 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
                 //  * the coefficient moves by signum(-val) * (res > 0 ? 1 : -1) while active: ONE multiply-add with the mask that already
                 //    carries the direction (+-1, or 0 once inactive).
                 // |val| is signum(v) * v (one multiply of the 1.8 ns class; the signum is needed for the coefficient anyway).
+                // QF (wide form, orders <= 8): the same carried residual for wavefronts whose blocks are "mid" (alac_narrow_kernel: outputs of at
+                // most 26 bits, so |val| < 2^27 and (1 + j) * a_k < 2^30 -- an active Q cannot wrap); |val| is max(v, -v) there (v does not fit a
+                // 24-bit multiply), the prediction keeps its full 32-bit multiplies.  Both forms compute the reference's update bit for bit, so
+                // a block may change between them from tile to tile (only full steady tiles take this one).
                 const int32_t s = res >> 31;                                               // -1: negative residual
                 int32_t Q = wrap_sub(s, res ^ s);                                          // -|res|
                 int32_t actdir = (s | 1) & (Q >> 31);                                      // +1 / -1 while active, 0 for res == 0
                 const uint32_t rnd = (uint32_t)s & L.ceil_mask;                            // 2^shift - 1 for a negative residual: the ceiling
 #pragma unroll
                 for (int k = TAPS - 1; k >= 0; --k) {
-                    const int32_t nk = (int32_t)L.order - k;                               // (1 + j); <= 0 beyond the order
+                    const int32_t nk = FULL ? TAPS - k : (int32_t)L.order - k;             // (1 + j); <= 0 beyond the order
                     int32_t v = dk[k];                                                     // -val
                     if constexpr (!FULL) v &= wrap_sub(0, nk) >> 31;                       // 0 beyond the lane's order: a_k = 0, no move
                     const int32_t sg = signum_i32(v);
                     uint32_t a;
                     if constexpr (HB != 0 && FULL) a = sad_u32((uint32_t)L.h[k], (uint32_t)past0, rnd) >> L.shift;
+                    else if constexpr (!M24) a = ((uint32_t)max(v, wrap_sub(0, v)) + rnd) >> L.shift;
                     else a = ((uint32_t)__mul24(sg, v) + rnd) >> L.shift;                  // |val| >> shift, resp. its ceiling
                     L.c[k] = tap_mad<true>(sg, actdir, L.c[k]);
-                    Q = tap_mad<true>(nk, (int32_t)a, Q);
+                    if constexpr (!M24) Q = wrap_add(Q, wrap_mul(nk, (int32_t)a));         // (FULL: 1 + j is a literal -- shifts and adds)
+                    else Q = tap_mad<true>(nk, (int32_t)a, Q);
                     actdir &= Q >> 31;
                 }
             } else {
@@ -239,7 +245,7 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
 // 32 samples of one tile.  `row` = this tile's LDS row of the lane, `prev_row` = the previous tile's (still intact in
 // the other LDS buffer); t0 = absolute index of column 0.  Rows are written back four samples at a time, so anything
 // older than three samples can be read back from LDS: that is where out[i - order - 1] comes from for order >= 3.
-template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false, bool TW = true>
+template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false, bool TW = true, bool QF = false>
 __device__ __forceinline__ void alac_steps32(AlacLane<NC> &L, int32_t *row, const int32_t *prev_row, unsigned t0, int n_valid) {
 #pragma unroll 1
     for (int u0 = 0; u0 < 32; u0 += 4) {
@@ -254,7 +260,7 @@ __device__ __forceinline__ void alac_steps32(AlacLane<NC> &L, int32_t *row, cons
                     const int idx = u - (int)L.order - 1;
                     far = idx >= 0 ? row[idx >= 0 ? idx : 0] : prev_row[32 + (idx < -32 ? -32 : idx)];
                 }
-                xs[q] = alac_step<TAPS, M24, FULL, NC, STEADY, TW>(L, xs[q], t0 + (unsigned)u, far);
+                xs[q] = alac_step<TAPS, M24, FULL, NC, STEADY, TW, QF>(L, xs[q], t0 + (unsigned)u, far);
             }
         }
         *reinterpret_cast<int4 *>(row + u0) = make_int4(xs[0], xs[1], xs[2], xs[3]);
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(64) void alac_narrow_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ coeffs, size_t n_blocks, unsigned blocksize,
                                                          uint8_t *__restrict__ narrow_flag) {
     const size_t my = (size_t)blockIdx.x * kRows + threadIdx.x;
-    bool narrow = true, small = true;  // small: order <= 8 (the register-only instantiation, AlacLane<8>)
+    bool narrow = true, small = true, mid = true;  // small: order <= 8 (the register-only instantiation, AlacLane<8>); mid: see alac_step, QF
     if (my < n_blocks) {
         const symaccel_alac_desc d = desc[my];
         const unsigned order = d.lpc_order > 31u ? 31u : d.lpc_order;
@@ -337,6 +343,7 @@ __global__ __launch_bounds__(64) void alac_narrow_kernel(const int32_t *__restri
             const unsigned bps = d.bps < 1u ? 1u : (d.bps > 32u ? 32u : d.bps);
             const int32_t first = buf[my * (size_t)blocksize];
             narrow = bps <= 23u && blocksize <= (1u << 21) && first >= -(1 << 22) && first < (1 << 22);
+            mid = bps <= 26u && first >= -(1 << 25) && first < (1 << 25);
             const int4 *cp = reinterpret_cast<const int4 *>(coeffs + my * 32);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -348,8 +355,8 @@ __global__ __launch_bounds__(64) void alac_narrow_kernel(const int32_t *__restri
             }
         }
     }
-    const bool all = __all(narrow) != 0, all_small = __all(small) != 0;
-    if (threadIdx.x == 0) narrow_flag[blockIdx.x] = (uint8_t)((all ? 1 : 0) | (all_small ? 2 : 0));
+    const bool all = __all(narrow) != 0, all_small = __all(small) != 0, all_mid = __all(mid) != 0;
+    if (threadIdx.x == 0) narrow_flag[blockIdx.x] = (uint8_t)((all ? 1 : 0) | (all_small ? 2 : 0) | (all_mid ? 4 : 0));
 }
 
 // M24: the instantiation for wavefronts whose blocks are all "narrow" (see there); SMALL: for wavefronts whose orders are
@@ -362,10 +369,9 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
     int32_t *__restrict__ buf, const symaccel_alac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
     size_t n_blocks, unsigned blocksize, const int32_t *__restrict__ pair_weight, const uint8_t *__restrict__ pair_shift,
     const uint8_t *__restrict__ narrow_flag) {
-    {
-        const unsigned f = narrow_flag[blockIdx.x];  // alac_narrow_kernel
-        if (((f & 1u) != 0) != M24 || ((f & 2u) != 0) != SMALL) return;  // another instantiation's wavefront
-    }
+    const unsigned wave_class = narrow_flag[blockIdx.x];  // alac_narrow_kernel
+    if (((wave_class & 1u) != 0) != M24 || ((wave_class & 2u) != 0) != SMALL) return;  // another instantiation's wavefront
+    const bool mid = (wave_class & 4u) != 0;
     constexpr int NC = SMALL ? 8 : 32;
     __shared__ __attribute__((aligned(16))) int32_t tiles[(SMALL ? 1 : 2) * kTileWords];
     __shared__ int32_t row_weight[kRows];
@@ -440,7 +446,8 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
             const bool steady = steady_ok && cols == (unsigned)kCols && t0 > max_order;
             if constexpr (SMALL) {
                 if (full8) {  // the common stream: every block of the wavefront has order 8
-                    if (steady && !L.any_twice) alac_steps32<8, M24, true, 8, true, false>(L, row, prow, t0, (int)cols);
+                    // (wide form: the instantiation without the double-predictor pass is the "mid" one, QF; other wavefronts take the general steady form)
+                    if (steady && !L.any_twice && (M24 || mid)) alac_steps32<8, M24, true, 8, true, false, !M24>(L, row, prow, t0, (int)cols);
                     else if (steady) alac_steps32<8, M24, true, 8, true>(L, row, prow, t0, (int)cols);
                     else alac_steps32<8, M24, true>(L, row, prow, t0, (int)cols);
                 } else if (max_order <= 4) {

@@ -216,6 +216,37 @@ def test_emu_alac_narrow_update_edges(emu_ctx, hi_order, uniform):
     assert np.array_equal(got, want)
 
 
+def wide_update_case(seed, nb, bs):
+    """The wide form's carried-residual update (alac_step, QF): wavefronts of order-8 blocks without the double predictor whose channels have
+    24 .. 26 bits ("mid": the instantiation under test), next to wavefronts just outside the bound (27 .. 32 bits, or a first sample beyond
+    +-2^25), which must take the general form.  Every shift, residuals at the i32 limits, outputs at both ends of the range."""
+    rng = np.random.default_rng(seed)
+    group = np.arange(nb) // 64
+    bps = np.where(group % 3 == 2, rng.integers(27, 33, nb), rng.integers(24, 27, nb)).astype(np.uint8)
+    buf = rng.integers(-40, 41, (nb, bs)).astype(np.int32)
+    kind = rng.integers(0, 6, (nb, bs))
+    buf[kind == 0] = 0
+    buf[kind == 1] = rng.choice([-(1 << 31), (1 << 31) - 1, -(1 << 31) + 1, 1, -1], int((kind == 1).sum()))
+    big = rng.integers(-(1 << 25), 1 << 25, (nb, bs))
+    buf[kind == 2] = big[kind == 2]
+    buf[:, 0] = rng.integers(-(1 << 25), 1 << 25, nb)
+    buf[group % 3 == 1, 0] = rng.choice([-(1 << 25), (1 << 25) - 1, -(1 << 25) - 1, 1 << 25, -(1 << 31), (1 << 31) - 1], int((group % 3 == 1).sum()))
+    order = np.full(nb, 8, np.uint8)
+    shift = (np.arange(nb) % 32).astype(np.uint8)
+    mode = np.zeros(nb, np.uint8)
+    coeffs = rng.integers(-(1 << 15), 1 << 15, (nb, 32)).astype(np.int32)
+    coeffs[::3] = rng.integers(-(1 << 31), (1 << 31) - 1, (len(coeffs[::3]), 32))
+    return buf, mode, order, shift, bps, coeffs
+
+
+def test_emu_alac_wide_update_edges(emu_ctx):
+    from symphonia_amd import AlacPredictor, alac_desc
+    buf, mode, order, shift, bps, coeffs = wide_update_case(77, 384, 170)
+    want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
+    got = AlacPredictor(emu_ctx).predict(buf, alac_desc(mode, order, shift, bps), coeffs)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("blocksize,nb", [(64, 64), (100, 70), (31, 130)])
 def test_emu_alac_predict_stereo_fused(emu_ctx, blocksize, nb):
     """predict with decorrelate_mid_side fused into the write-back == predict, then decorrelate_mid_side."""
@@ -341,6 +372,23 @@ def test_gpu_alac_narrow_update_edges(hi_order, uniform):
         order[:] = hi_order
     if uniform == 2:
         mode[:] = 0
+    want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
+    with Context(0) as ctx:
+        ctx.use_torch_stream()
+        d = torch.from_numpy(buf.copy()).cuda()
+        desc = torch.from_numpy(alac_desc(mode, order, shift, bps).view(np.uint8).reshape(-1, 4)).cuda()
+        AlacPredictor(ctx).predict(d, desc, torch.from_numpy(coeffs).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_gpu_alac_wide_update_edges():
+    import torch
+    from symphonia_amd import AlacPredictor, Context, alac_desc
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    buf, mode, order, shift, bps, coeffs = wide_update_case(177, 1536, 1000)
     want = oracle.alac_predict(buf, oracle.alac_desc(mode, order, shift, bps), coeffs)
     with Context(0) as ctx:
         ctx.use_torch_stream()
