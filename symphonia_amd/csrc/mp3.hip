@@ -162,6 +162,9 @@ __device__ __forceinline__ void fetch_granule(const float *granule, int hl, floa
     line[4] = ld_stream(src + 128 + (hl & 15));  // lanes 16..31 re-read float4 128..143 (same cache lines) and ignore it
 }
 
+#ifndef SYM_MP3_FRONT
+#define SYM_MP3_FRONT 0  // bit 0: requantize on packed pairs + SDWA addresses, bit 1: mid/side through v_permlane32_swap (round 6: see pk_abs_clamp_i16; measured, not faster); 0: the round-5 form
+#endif
 #ifndef SYM_MP3_PACKED
 #define SYM_MP3_PACKED 1
 #endif
@@ -218,6 +221,7 @@ constexpr int kSinkSlots = 256;
 // SIMD) per CU.
 constexpr int kFrontPow = 8208;                         // POW43 (8207 entries, padded)
 constexpr int kFrontMapFloats = 4 * 576 / 4;            // the four line -> band maps of this sample rate (bytes)
+constexpr int kMapShift = (SYM_MP3_FRONT & 1) ? 2 : 0;            // the maps in LDS hold 4 x band (a byte offset into the scale table): see SYM_MP3_FRONT
 constexpr int kP2MinE = kMp3Pow2abMinE, kP2Len = kMp3Pow2abLen;
 constexpr int kFrontEdgeFloats = (sizeof(SfbEdges) + 3) / 4;  // the band edge tables (the intensity walk reads them through a pointer)
 constexpr int kFrontTabFloats = kFrontPow + kFrontMapFloats + kP2Len + kFrontEdgeFloats;
@@ -230,6 +234,74 @@ constexpr int kFwKl = kFwAct + 40;
 constexpr int kFwKr = kFwKl + 40;
 constexpr int kFrontWaveFloats = kFwKr + 40;
 static_assert(sizeof(symaccel_mp3_requant) == 52 && sizeof(symaccel_mp3_stereo) == 48, "records are fetched as 13 / 12 dwords");
+
+// Round 6.  With two wavefronts per SIMD the fused kernel is bound by how many instructions a wavefront can issue (one per ~4.9 cycles, whatever
+// the instruction: tools/ubench/valu_clock.hip), so the front is written for the NUMBER of instructions per line:
+//  * |sample| and its clamp to POW43's last entry on the PACKED 16-bit pairs as the entropy decoder stores them (v_pk_sub_i16, v_pk_max_i16,
+//    v_pk_min_u16: three instructions per two lines instead of six; -32768 stays -32768, i.e. 32768 unsigned, and clamps like every |sample| > 8206);
+//  * the POW43 address (4 x magnitude) straight from a half of the packed word (v_lshlrev_b32_sdwa, src1_sel:WORD_n): no unpacking at all -- the
+//    sign of an odd line is bit 31 of the raw word, of an even line bit 31 of the word shifted up;
+//  * the band maps sit in LDS pre-multiplied by four, so a line's scale address is ONE v_add_u32_sdwa with a byte select;
+//  * the rzero partition (literal +0.0, requantize.rs:117-147) is applied to the finished line;
+//  * mid/side (stereo.rs:139-148): v_permlane32_swap_b32 puts channel 0's lines 2k / 2k + 1 into one register (low / high half-wave) and channel
+//    1's into another: one add, one subtract, two multiplies and a second swap per TWO lines and both channels, instead of a ds_bpermute, a sign
+//    flip, an add and a multiply per line -- the same IEEE operations on the same operands (c0 + c1 commutes, c0 - c1 is c0 + (-c1));
+//  * no select behind mid/side when the stereo record's bound is not below either channel's rzero (what a front end that fills both records from
+//    one granule always produces): the lines behind the bound are +0.0 in both channels and (0 + 0) k = (0 - 0) k = +0.0.
+__device__ __forceinline__ uint32_t pk_abs_clamp_i16(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t n, m;
+    asm("v_pk_sub_i16 %0, 0, %1" : "=v"(n) : "v"(w));
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(m) : "v"(n), "v"(w));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(0x200e200eu));
+    return m;
+#else
+    auto one = [](uint32_t h) {
+        const int v = (int)(int16_t)(uint16_t)h;
+        const uint32_t a = (uint32_t)(v < 0 ? -v : v) & 0xffffu;  // (-32768: 32768)
+        return a > 8206u ? 8206u : a;
+    };
+    return one(w & 0xffffu) | (one(w >> 16) << 16);
+#endif
+}
+// 4 x (half `hi` of a packed pair of u16)
+template <int HI>
+__device__ __forceinline__ uint32_t pk_half_times4(uint32_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    if constexpr (HI) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(m));
+    else asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(m));
+    return r;
+#else
+    return ((HI ? m >> 16 : m) & 0xffffu) << 2;
+#endif
+}
+// base + byte B (0 / 1) of w
+template <int B, typename A>
+__device__ __forceinline__ A add_byte(A base, uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    A r;
+    if constexpr (B) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(base), "v"(w));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(base), "v"(w));
+    return r;
+#else
+    return base + ((w >> (8 * B)) & 0xffu);
+#endif
+}
+// x.hi <-> y.lo (lanes 32..63 of x with lanes 0..31 of y)
+__device__ __forceinline__ void half_wave_swap(float &x, float &y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]);
+    y = __uint_as_float(r[1]);
+#else
+    const float xo = __shfl_xor(x, 32), yo = __shfl_xor(y, 32);
+    const bool low = (threadIdx.x & 32u) == 0;
+    const float nx = low ? x : yo, ny = low ? xo : y;
+    x = nx;
+    y = ny;
+#endif
+}
 
 // The exponent A - B of mp3_slot_scale (mp3_requant.h; requantize.rs:260-352) of scale slot `slot` (< kMp3Unscaled), without a
 // memory table: the pre-emphasis values of ISO/IEC 11172-3 Table B.6 are two bits per band in a constant.
@@ -282,7 +354,7 @@ __device__ __attribute__((noinline)) void mp3_front_intensity(const float *is_ra
         unsigned long long mine = 0ull;
 #pragma unroll
         for (int i = 0; i < 18; ++i)
-            if (c1[i] != 0.0f) mine |= 1ull << bmap[i];
+            if (c1[i] != 0.0f) mine |= 1ull << (bmap[i] >> kMapShift);
         if ((unsigned)mine) atomicOr(&nzw[0], (unsigned)mine);
         if ((unsigned)(mine >> 32)) atomicOr(&nzw[1], (unsigned)(mine >> 32));
     }
@@ -293,7 +365,7 @@ __device__ __attribute__((noinline)) void mp3_front_intensity(const float *is_ra
     wave_sync();
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
-        mp3_stereo_apply(c0[i], c1[i], 18 * hl + i, plan.bound, mid_side, true, bmap[i], act, kl, kr);
+        mp3_stereo_apply(c0[i], c1[i], 18 * hl + i, plan.bound, mid_side, true, bmap[i] >> kMapShift, act, kl, kr);
         tiles[576 * half + 18 * hl + i] = half == 0 ? c0[i] : c1[i];
     }
 }
@@ -330,6 +402,40 @@ __device__ __forceinline__ void mp3_front(const DevTables &tb, const SfbEdges *e
     // compiler turns `cond ? table[i] : 0` into a branch per line with the LDS round trip inside it -- 54 dependent round trips
     // per granule.  Here the index is made harmless instead (a zeroed sample reads POW43[0] = +0.0), the 18 + 9 + 18 reads
     // of a phase are independent of each other, and the sign is OR-ed in (POW43 >= 0).
+#if SYM_MP3_FRONT & 1
+    float a[18];
+    {
+        unsigned sm[9];  // the lane's 18 bytes of 4 x slot, two per 16-bit read (18 hl is even)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sm[k] = reinterpret_cast<const uint16_t *>(smap)[k];
+        const char *pow_b = reinterpret_cast<const char *>(pow43_lo);
+        // the scale table's address as the 32-bit LDS address it is: base + byte select is then the whole address computation of a line's scale
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) const float *lds_cfp;
+        const uint32_t scale_addr = (uint32_t)(uintptr_t)(lds_cfp)scale;
+#define SYM_FRONT_SCALE(off) (*(lds_cfp)(uintptr_t)(off))
+#else
+        const uintptr_t scale_addr = reinterpret_cast<uintptr_t>(scale);
+#define SYM_FRONT_SCALE(off) (*reinterpret_cast<const float *>(off))
+#endif
+        float pw[18], sc[18];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const uint32_t m = pk_abs_clamp_i16(qw[k]);
+            pw[2 * k] = *reinterpret_cast<const float *>(pow_b + pk_half_times4<0>(m));
+            pw[2 * k + 1] = *reinterpret_cast<const float *>(pow_b + pk_half_times4<1>(m));
+            sc[2 * k] = SYM_FRONT_SCALE(add_byte<0>(scale_addr, sm[k]));
+            sc[2 * k + 1] = SYM_FRONT_SCALE(add_byte<1>(scale_addr, sm[k]));
+        }
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const uint32_t w = qw[i >> 1];
+            const uint32_t sign_src = (i & 1) ? w : w << 16;  // little endian: the even sample is the low half
+            const float v = __uint_as_float((sign_src & 0x80000000u) | __float_as_uint(pw[i])) * sc[i];
+            a[i] = 18 * hl + i < rz ? v : 0.0f;                // the rzero partition: literal +0.0 (requantize.rs:117-147)
+        }
+    }
+#else
     int mag[18];
     unsigned sgn[18];
 #pragma unroll
@@ -353,6 +459,7 @@ __device__ __forceinline__ void mp3_front(const DevTables &tb, const SfbEdges *e
         const float sc = scale[(sm[i >> 1] >> (8 * (i & 1))) & 255u];
         a[i] = __uint_as_float(__float_as_uint(pw[i]) | sgn[i]) * sc;
     }
+#endif
     // ---- joint stereo (both half-waves hold the same lines of their channel)
     const bool mid_side = pair_live && (sd.flags & SYMACCEL_MP3_ST_MID_SIDE), intensity = pair_live && (sd.flags & SYMACCEL_MP3_ST_INTENSITY);
     if (mid_side && !intensity) {  // (wave-uniform: one record per pair and granule) mid/side alone, stereo.rs:139-148, 541-543
@@ -362,6 +469,33 @@ __device__ __forceinline__ void mp3_front(const DevTables &tb, const SfbEdges *e
         // half-wave -- IEEE subtraction IS addition of the negated operand, and addition commutes, so both are the reference's rounded
         // results; two selects and a subtract per line less than choosing c0 / c1 and the operation (compares and selects cost 1.75 x
         // an add or a xor on the SIMD: profiles/r05q_valu_int.txt)
+#if SYM_MP3_FRONT & 2
+        // (see SYM_MP3_FRONT) `plain`: nothing non-zero at or behind the bound in either channel -- wave-uniform, both records are in LDS
+        const uint32_t rz_a = reinterpret_cast<const symaccel_mp3_requant *>(fw + kFwRq)->rzero;
+        const uint32_t rz_b = reinterpret_cast<const symaccel_mp3_requant *>(reinterpret_cast<const uint32_t *>(fw + kFwRq) + 14)->rzero;
+        const bool plain = (int)(rz_a > 576u ? 576u : rz_a) <= end && (int)(rz_b > 576u ? 576u : rz_b) <= end;
+        if (plain) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float x = a[2 * k], y = a[2 * k + 1];
+                half_wave_swap(x, y);  // x: channel 0's lines 2k | 2k + 1, y: channel 1's
+                float sum = (x + y) * kMp3Frac1Sqrt2, dif = (x - y) * kMp3Frac1Sqrt2;
+                half_wave_swap(sum, dif);  // sum: line 2k as channel 0 | channel 1 want it, dif: line 2k + 1
+                a[2 * k] = sum;
+                a[2 * k + 1] = dif;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float x = a[2 * k], y = a[2 * k + 1];
+                half_wave_swap(x, y);
+                float sum = (x + y) * kMp3Frac1Sqrt2, dif = (x - y) * kMp3Frac1Sqrt2;
+                half_wave_swap(sum, dif);
+                a[2 * k] = 18 * hl + 2 * k < end ? sum : a[2 * k];
+                a[2 * k + 1] = 18 * hl + 2 * k + 1 < end ? dif : a[2 * k + 1];
+            }
+        }
+#else
         const unsigned flip = half == 0 ? 0u : 0x80000000u;
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
@@ -369,6 +503,7 @@ __device__ __forceinline__ void mp3_front(const DevTables &tb, const SfbEdges *e
             const float v = (b + __uint_as_float(__float_as_uint(a[i]) ^ flip)) * kMp3Frac1Sqrt2;
             a[i] = 18 * hl + i < end ? v : a[i];
         }
+#endif
     }
     float2 *t2 = reinterpret_cast<float2 *>(tile + 18 * hl);  // 72 B lane stride: conflict-free b64
 #pragma unroll
@@ -434,7 +569,7 @@ __global__ __launch_bounds__(64 * WGW) SYM_MP3_WAVES_ATTR(FUSED) void mp3_synth_
     if (FUSED) {
         for (int i = (int)threadIdx.x; i < 8207; i += 64 * kWgWaves) pow43_lo[i] = tb.mp3_pow43[i];
         const uint32_t *msrc = reinterpret_cast<const uint32_t *>(tb.mp3_band_map + (size_t)sr * 4 * 576);
-        for (int i = (int)threadIdx.x; i < kFrontMapFloats; i += 64 * kWgWaves) reinterpret_cast<uint32_t *>(front_maps)[i] = msrc[i];
+        for (int i = (int)threadIdx.x; i < kFrontMapFloats; i += 64 * kWgWaves) reinterpret_cast<uint32_t *>(front_maps)[i] = msrc[i] << kMapShift;  // (bands < 64: no carry between bytes)
         for (int i = (int)threadIdx.x; i < kP2Len; i += 64 * kWgWaves) p2_lo[i] = tb.mp3_pow2ab[i];
         if (threadIdx.x == 0) *e_lds = edges;
     }

@@ -440,6 +440,63 @@ def test_emu_mp3_decode_device(emu_ctx, sr, n_pairs, granules, with_mono, seg):
     run_decode_device(emu_ctx, lambda a: np.array(a, copy=True, order="C"), lambda a: a, sr, n_pairs, granules, with_mono, seg)
 
 
+def run_decode_device_loose_records(ctx, dev, host, sr, n_pairs, granules, seed):
+    """The stereo record's rzero0 / rzero1 need not equal the requantize records' rzero (they are separate arguments of the C ABI): with a
+    bound BELOW a channel's rzero the lines from the bound on keep their requantised values (stereo.rs:522-543 on the record's own numbers) --
+    the fused front's select path; a front end that fills both from one granule never takes it."""
+    from symphonia_amd import Mp3Synthesis
+    q, rd, pairs, sd, side, ov, vv, vf, _ = decode_pipelined_case(300 + seed + sr, sr, n_pairs, granules, True)
+    rng = np.random.default_rng(seed)
+    sd = sd.copy()
+    q = q.copy()
+    for p, (c0, c1) in enumerate(pairs):
+        for g in range(granules):
+            r = rng.random()
+            if r < 0.5:
+                sd["rzero0"][p, g] = rng.integers(0, int(rd["rzero"][c0, g]) + 1)
+                sd["rzero1"][p, g] = rng.integers(0, int(rd["rzero"][c1, g]) + 1)
+            elif r < 0.7:
+                sd["rzero0"][p, g], sd["rzero1"][p, g] = 576, 0
+    q[:, :, 5::41] = rng.choice(np.array([-8206, 8206, 8205, -1, 0], np.int16), q[:, :, 5::41].shape)  # (the domain's edge: linbits escapes end at 8206)
+    chains = q.shape[0]
+    xr = oracle.mp3_requantize(q, rd, sr).reshape(chains, granules, 576)
+    for p, (c0, c1) in enumerate(pairs):
+        for g in range(granules):
+            xr[c0, g], xr[c1, g] = oracle.mp3_stereo(xr[c0, g], xr[c1, g], sd[p, g], sr)
+    side = oracle.mp3_side(rd["block_type"], rd["is_mixed"], np.full(rd.shape, 576))  # (the synthesis sees every line)
+    want = oracle.mp3_synth(xr, side, sr, ov, vv, vf)
+    units = units_of(pairs, chains)
+    sdu = np.zeros((len(units), granules), oracle.MP3_STEREO_DTYPE)
+    sdu[: len(pairs)] = sd
+    as_bytes = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(a.shape + (-1,))  # noqa: E731
+    d_ov, d_vv, d_vf = dev(ov), dev(vv), dev(vf)
+    pcm = dev(np.zeros((chains, granules, 576), F))
+    Mp3Synthesis(ctx, sr).decode(dev(q), dev(as_bytes(rd)), dev(units), dev(as_bytes(sdu)), dev(as_bytes(np.ascontiguousarray(side))), d_ov, d_vv,
+                                 d_vf, pcm)
+    assert bit_equal(host(pcm), want[0])
+    assert bit_equal(host(d_ov), want[1]) and bit_equal(host(d_vv), want[2]) and np.array_equal(host(d_vf), want[3])
+
+
+@pytest.mark.parametrize("sr,n_pairs,granules", [(0, 3, 8), (5, 2, 5)])
+def test_emu_mp3_decode_device_loose_records(emu_ctx, sr, n_pairs, granules):
+    run_decode_device_loose_records(emu_ctx, lambda a: np.array(a, copy=True, order="C"), lambda a: a, sr, n_pairs, granules, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,n_pairs,granules", [(0, 17, 30), (5, 40, 12)])
+def test_gpu_mp3_decode_device_loose_records(sr, n_pairs, granules):
+    import torch
+    from symphonia_amd import Context
+    ctx = Context(0)
+    ctx.use_torch_stream()
+
+    def host(t):
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+    run_decode_device_loose_records(ctx, lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda(), host, sr, n_pairs, granules, 2)
+    ctx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("sr,n_pairs,granules,with_mono,seg", [(0, 9, 40, True, 0), (8, 5, 33, False, 7), (3, 33, 17, True, 2), (0, 1, 1, False, 0),
                                                                 (5, 70, 24, True, 0)])
