@@ -26,6 +26,12 @@ namespace {
 // 32 recurrence steps with statically indexed circular history: before step u the most recent
 // sample sits in h[(u + 31) & 31].  Integer path: any coefficient magnitude.
 // ALL: as in lpc_steps32_f64 -- every sample of the tile is predicted in every lane, no per-step predicate.
+// The ORDER of the taps in the chain (round 6 experiment; the sum is exact whatever the association).  Newest sample first -- the order the sum is written in --
+// makes the first FMA of sample u + 1 wait for the last instruction of sample u; oldest first, only the LAST FMA of a sample needs its predecessor.  If the
+// kernel were bound by the latency of the dependent chain this (and SYM_FLAC_GROUP below) would show; it does not: 32 v_fmac_f64 cost a SIMD ~3.6 ns each.
+#ifndef SYM_FLAC_OLDEST_FIRST
+#define SYM_FLAC_OLDEST_FIRST 0  // (measured equal, 7.67-7.71 ms both ways: hipcc keeps a sample's chain together in either order and two wavefronts per SIMD cover it -- profiles/r06zz12_flac_order_ab.txt)
+#endif
 template <int TAPS, bool ALL = false>
 __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)[32], int32_t *row, int col0,
                                             int first_pred, int n_valid, uint32_t shift, uint32_t wasted) {
@@ -47,12 +53,16 @@ __device__ __forceinline__ void lpc_steps32(int32_t (&h)[32], const int32_t (&c)
                 // variant of the instruction issues in 1.85 ns (profiles/HISTORY.md round 5).
                 static_assert(TAPS % 4 == 0, "groups of four taps");
 #pragma unroll
-                for (int j = 0; j < TAPS; j += 4)
+                for (int jj = 0; jj < TAPS; jj += 4) {
+                    // (SYM_FLAC_OLDEST_FIRST, see there: the groups from the oldest samples to the newest, and inside a group too)
+                    const int j = SYM_FLAC_OLDEST_FIRST ? TAPS - 4 - jj : jj;
+                    constexpr int R = SYM_FLAC_OLDEST_FIRST ? 3 : 0;  // tap j + (R ^ k) is the k-th of the group
                     asm("v_mad_i64_i32 %0, vcc, %1, %5, %0\n\tv_mad_i64_i32 %0, vcc, %2, %6, %0\n\tv_mad_i64_i32 %0, vcc, %3, %7, %0\n\tv_mad_i64_i32 %0, vcc, %4, %8, %0"
                         : "+v"(acc)
-                        : "v"(c[j]), "v"(c[j + 1]), "v"(c[j + 2]), "v"(c[j + 3]), "v"(h[(u + 31 - j) & 31]), "v"(h[(u + 30 - j) & 31]),
-                          "v"(h[(u + 29 - j) & 31]), "v"(h[(u + 28 - j) & 31])
+                        : "v"(c[j + (R ^ 0)]), "v"(c[j + (R ^ 1)]), "v"(c[j + (R ^ 2)]), "v"(c[j + (R ^ 3)]), "v"(h[(u + 31 - j - (R ^ 0)) & 31]),
+                          "v"(h[(u + 31 - j - (R ^ 1)) & 31]), "v"(h[(u + 31 - j - (R ^ 2)) & 31]), "v"(h[(u + 31 - j - (R ^ 3)) & 31])
                         : "vcc");
+                }
 #else
 #pragma unroll
                 for (int j = 0; j < TAPS; ++j) acc += (int64_t)c[j] * (int64_t)h[(u + 31 - j) & 31];
@@ -95,9 +105,54 @@ __device__ __forceinline__ int32_t flac_shifted(double acc_plus_magic, int shift
 }
 // ALL: every sample of the tile is predicted in every lane (the tile lies behind the warm-up samples of the wavefront's highest
 // order): no per-lane predicate and no divergent branch per step.  The one or two tiles in front of that take the general form.
+// SYM_FLAC_GROUP (round 6): G consecutive samples' sums in flight at once.  Sample n + q needs the outputs n + q - 1 - j for tap j: every tap j >= q reads samples
+// from before the group, so the G chains run their taps TAPS - 1 .. q interleaved (G independent accumulators: a dependent v_fmac_f64 issues only every ~17 cycles,
+// two wavefronts per SIMD cover two of those, hipcc's schedulers keep a sample's chain together whatever the tap order), then the group finishes in order: sample n,
+// its output into the q taps the later chains still miss, sample n + 1, ...  The sums are exact whatever their association (see above): same bits.
+#ifndef SYM_FLAC_GROUP
+#define SYM_FLAC_GROUP 1  // (measured: 4 -> 7.92 ms, 2 -> 8.0, 1 -> 7.70 for config 5: the kernel is bound by the FP64 pipe itself, not by the chain's latency -- profiles/r06zz13_flac_group_ab.txt)
+#endif
+template <int TAPS>
+__device__ __forceinline__ void lpc_steps32_f64_grouped(double (&h)[32], const double (&c)[32], int32_t *row, int col0, int shift, uint32_t wasted) {
+    constexpr int G = SYM_FLAC_GROUP;
+    static_assert(TAPS >= G && 4 % G == 0, "group of 1, 2 or 4 samples");
+#pragma unroll
+    for (int u0 = 0; u0 < 32; u0 += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(row + col0 + u0);
+        int32_t xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int g0 = 0; g0 < 4; g0 += G) {
+            const int ub = u0 + g0;  // first sample of the group
+            double acc[G];
+#pragma unroll
+            for (int q = 0; q < G; ++q) acc[q] = kFlacMagic;
+#pragma unroll
+            for (int j = TAPS - 1; j >= 0; --j) {
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    if (j >= q) acc[q] = __builtin_fma(c[j], h[(ub + q + 31 - j) & 31], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const int32_t x = wrap_add(xs[g0 + q], flac_shifted(acc[q], shift));
+                const double xd = (double)x;
+                h[(ub + q) & 31] = xd;
+                xs[g0 + q] = (int32_t)((uint32_t)x << wasted);  // samples_shl (decoder.rs:403-409)
+#pragma unroll
+                for (int r = q + 1; r < G; ++r) acc[r] = __builtin_fma(c[r - q - 1], xd, acc[r]);  // tap r - q - 1 of sample ub + r reads sample ub + q
+            }
+        }
+        *reinterpret_cast<int4 *>(row + col0 + u0) = make_int4(xs[0], xs[1], xs[2], xs[3]);
+    }
+}
+
 template <int TAPS, bool ALL = false>
 __device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&c)[32], int32_t *row, int col0,
                                                 int first_pred, int n_valid, int shift, uint32_t wasted) {
+    if constexpr (ALL && SYM_FLAC_GROUP > 1 && TAPS >= SYM_FLAC_GROUP) {
+        lpc_steps32_f64_grouped<TAPS>(h, c, row, col0, shift, wasted);
+        return;
+    }
     int32_t xs[4];
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
@@ -113,7 +168,10 @@ __device__ __forceinline__ void lpc_steps32_f64(double (&h)[32], const double (&
 #pragma unroll
                 for (int q = 0; q < P; ++q) part[q] = q == 0 ? kFlacMagic : 0.0;
 #pragma unroll
-                for (int j = 0; j < TAPS; ++j) part[j % P] = __builtin_fma(c[j], h[(u + 31 - j) & 31], part[j % P]);
+                for (int jj = 0; jj < TAPS; ++jj) {
+                    const int j = SYM_FLAC_OLDEST_FIRST ? TAPS - 1 - jj : jj;
+                    part[j % P] = __builtin_fma(c[j], h[(u + 31 - j) & 31], part[j % P]);
+                }
                 double acc = part[0];
                 if constexpr (P == 4) acc = (part[0] + part[1]) + (part[2] + part[3]);
                 if constexpr (P == 2) acc = part[0] + part[1];
