@@ -122,8 +122,9 @@ def test_alac_has_both_multiply_forms(asm):
     for name, body in bodies.items():
         n24, nlo = len(re.findall(r"v_m(?:ul|ad)_i32_i24", body)), len(re.findall(r"v_mul_lo_u32", body))
         # (the few v_mul_lo_u32 of the 24-bit form are address arithmetic and the mid/side weight of the fused store)
-        assert (n24 > 100 and nlo < 60) or (nlo > 100 and n24 == 0), (name, n24, nlo)
-        fast += n24 > 100
+        # (and the few 24-bit multiply-adds of the wide form are the coefficient moves of its carried-residual update: signum x direction mask, alac_step QF)
+        assert (n24 > 100 and nlo < 60) or (nlo > 100 and n24 < nlo // 3), (name, n24, nlo)
+        fast += nlo < 60
     assert fast == 4
     res = kernel_resources(text)
     small = [r for n, r in res.items() if "alac_predict_kernel" in n and n.split("alac_predict_kernel")[1].startswith("ILb") and "ELb1EEE" in n]
