@@ -152,13 +152,21 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
             int32_t dk[TAPS];
 #pragma unroll
             for (int k = 0; k < TAPS; ++k) dk[k] = wrap_sub(L.h[k], past0);
-            int32_t sum = (int32_t)L.half, sum1 = 0;  // (two chains of multiply-adds; wrapping sums re-associate: the rounding term leads one)
+            int32_t sum = (int32_t)L.half;  // (the rounding term leads the sum)
+            if constexpr (M24 && TAPS <= 8) {
+                // one chain, from the oldest sample to the newest (wrapping sums re-associate): the join of two chains is an instruction, and the newest
+                // difference -- the one that waits for the previous sample -- comes last
 #pragma unroll
-            for (int k = 0; k < TAPS; k += 2) {
-                sum = tap_mad<M24>(L.c[k], dk[k], sum);
-                if (k + 1 < TAPS) sum1 = tap_mad<M24>(L.c[k + 1], dk[k + 1], sum1);
+                for (int k = TAPS - 1; k >= 0; --k) sum = tap_mad<M24>(L.c[k], dk[k], sum);
+            } else {
+                int32_t sum1 = 0;  // (two chains of multiply-adds)
+#pragma unroll
+                for (int k = 0; k < TAPS; k += 2) {
+                    sum = tap_mad<M24>(L.c[k], dk[k], sum);
+                    if (k + 1 < TAPS) sum1 = tap_mad<M24>(L.c[k + 1], dk[k + 1], sum1);
+                }
+                sum = wrap_add(sum, sum1);
             }
-            sum = wrap_add(sum, sum1);
             const int32_t val = sum >> L.shift;
             x = clip_bits<M24>(wrap_add(wrap_add(x, (int32_t)((uint32_t)past0 ^ HB)), val), L);
             // sign-LMS update (lib.rs:224-260): from the oldest sample (coefficient order-1) to the newest, until the
@@ -200,7 +208,7 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
                 // a block may change between them from tile to tile (only full steady tiles take this one).
                 const int32_t s = res >> 31;                                               // -1: negative residual
                 int32_t Q = wrap_sub(s, res ^ s);                                          // -|res|
-                int32_t actdir = (s | 1) & (Q >> 31);                                      // +1 / -1 while active, 0 for res == 0
+                int32_t actdir = signum_i32(res);                                          // +1 / -1 while active, 0 for res == 0 (one v_med3_i32)
                 const uint32_t rnd = (uint32_t)s & L.ceil_mask;                            // 2^shift - 1 for a negative residual: the ceiling
 #pragma unroll
                 for (int k = TAPS - 1; k >= 0; --k) {
