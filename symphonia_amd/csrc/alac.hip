@@ -18,6 +18,9 @@
 #ifndef SYM_ALAC_UPDATE
 #define SYM_ALAC_UPDATE 1  // 0: the round-5 sign-LMS update in the narrow form too (A/B); 1: the residual carried as -|res| (alac_step)
 #endif
+#ifndef SYM_ALAC_UNROLL
+#define SYM_ALAC_UNROLL 2  // groups of four samples per iteration of the hot instantiation's tile loop (measured: 1 -> 2.378 ms, 2 -> 2.33, 4 -> 2.32; 8 crashes hipcc's register allocator)
+#endif
 #ifndef SYM_ALAC_SMALL_WAVES
 #define SYM_ALAC_SMALL_WAVES 3  // wavefronts per SIMD of the orders-<=-8 instantiations (build-time tuning knob)
 #endif
@@ -255,7 +258,11 @@ __device__ __forceinline__ int32_t alac_step(AlacLane<NC> &L, int32_t x, unsigne
 // older than three samples can be read back from LDS: that is where out[i - order - 1] comes from for order >= 3.
 template <int TAPS, bool M24, bool FULL, int NC, bool STEADY = false, bool TW = true, bool QF = false>
 __device__ __forceinline__ void alac_steps32(AlacLane<NC> &L, int32_t *row, const int32_t *prev_row, unsigned t0, int n_valid) {
-#pragma unroll 1
+    // (the hot instantiation -- steady, every lane at the wavefront's order, no double predictor -- unrolled SYM_ALAC_UNROLL groups deep: the nine history
+    // registers rotate by four per group, which hipcc resolves with register copies at the loop's back edge; the other instantiations stay rolled for the
+    // instruction cache)
+    constexpr int kUnroll = (STEADY && FULL && !TW && NC == 8) ? SYM_ALAC_UNROLL : 1;
+#pragma unroll kUnroll
     for (int u0 = 0; u0 < 32; u0 += 4) {
         const int4 v = *reinterpret_cast<const int4 *>(row + u0);
         int32_t xs[4] = {v.x, v.y, v.z, v.w};
