@@ -437,6 +437,9 @@ struct Floor1Setup {  // per floor configuration, derived on the host like the s
 #ifndef SYM_F1_ABLATE
 #define SYM_F1_ABLATE 0
 #endif
+#ifndef SYM_F1_LANE16
+#define SYM_F1_LANE16 1  // the byte render with sixteen consecutive lines per lane (floor1_workgroup, MODE 2); 0: four groups of four lines 256 apart, as the f32 forms
+#endif
 constexpr int kF1B = 64;                 // channel-blocks per workgroup
 #ifndef SYM_F1_WAVES
 #define SYM_F1_WAVES 4
@@ -652,6 +655,55 @@ __device__ __forceinline__ void floor1_workgroup(const Floor1Setup &st, int n_po
         // instruction writes 1 KiB without a gap (16 consecutive x per lane left every 64-byte unit of a store three quarters
         // empty: four times the write requests).  The pass is straight-line code -- every LDS round trip (map, lane reads,
         // table, dB values) is issued for all four groups before the first result is needed.
+#if SYM_F1_LANE16
+        if constexpr (MODE == 2) {
+            // Bytes out: lane l renders the SIXTEEN consecutive lines p0 + 16 l .. + 15 of a pass -- 16 bytes per lane, so a store instruction still writes 1 KiB without a
+            // gap (the four-lines-per-group layout below exists for the f32 forms, where 16 consecutive lines per lane are 64 bytes) -- with ONE prefix maximum across the
+            // wavefront, one 16-byte read of the segment-start map and one 16-byte store per 16 lines instead of four of each; the segment in force runs on through the
+            // lane's lines.  (`aligned16`: wave-uniform; a packed layout whose block offsets are not multiples of 16 takes four 4-byte stores.)
+            const bool aligned16 = ((reinterpret_cast<uintptr_t>(yout)) & 15u) == 0;
+            for (uint32_t p0 = 0; p0 < ((SYM_F1_ABLATE & 4) ? 0u : n); p0 += 1024) {
+                const uint32_t x0 = p0 + 16u * (uint32_t)lane;  // (n is a multiple of 16)
+                const bool live = x0 < n;
+                uint32_t m[4] = {0u, 0u, 0u, 0u};
+                if (live) {
+                    const uint4 mm = *reinterpret_cast<const uint4 *>(mark + x0);
+                    m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+                }
+                uint32_t mine = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine = max(mine, max(max(m[j] & 255u, (m[j] >> 8) & 255u), max((m[j] >> 16) & 255u, m[j] >> 24)));
+                uint32_t before, last;
+                wave_prefix_max(mine, before, last);
+                int seg_id = (int)before > carry ? (int)before : carry;  // (index + 1) of the segment in force in front of the lane's first line
+                carry = (int)last > carry ? (int)last : carry;
+                const float xf0 = (float)x0;
+                uint32_t yb[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int v = (int)((m[j] >> (8 * q)) & 255u);
+                        seg_id = v > seg_id ? v : seg_id;
+                        const uint4 c = segc[seg_id - 1];
+                        const float tf = (xf0 + (float)(4 * j + q)) - __uint_as_float(c.x);
+                        const float yf = __uint_as_float(c.w) + __builtin_truncf(tf * __uint_as_float(c.y) + __uint_as_float(c.z));
+                        yb[j] = cvt_pk_u8(yf, q, yb[j]);
+                    }
+                }
+                if (live) {
+                    if (aligned16) {
+                        *reinterpret_cast<uint4 *>(yout + x0) = make_uint4(yb[0], yb[1], yb[2], yb[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t *>(yout + x0 + 4u * (uint32_t)j) = yb[j];
+                    }
+                }
+            }
+            wave_sync_lds();  // the next block's segment-start map overwrites this one's
+            continue;
+        }
+#endif
         for (uint32_t p0 = 0; p0 < ((SYM_F1_ABLATE & 4) ? 0u : n); p0 += 1024) {
             uint32_t xb[4], m[4];
             float4 rr[4];  // the lines' residue, requested now: the render hides the latency
