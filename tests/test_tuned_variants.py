@@ -21,6 +21,12 @@ CASES = [
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "18"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_FLAC_PARTS": "4"}, "tests/test_emu_codecs.py", "emu_flac"),
+    # round 6: the knobs of the last session's A/Bs (profiles/r06zz3 .. r06zz17)
+    ({"SYMACCEL_TUNE_FLAC_GROUP": "4", "SYMACCEL_TUNE_FLAC_OLDEST_FIRST": "1"}, "tests/test_emu_codecs.py", "emu_flac"),
+    ({"SYMACCEL_TUNE_ALAC_UPDATE": "0"}, "tests/test_alac.py", "emu"),
+    ({"SYMACCEL_TUNE_ALAC_UPDATE": "2", "SYMACCEL_TUNE_ALAC_UNROLL": "1"}, "tests/test_alac.py", "emu"),
+    ({"SYMACCEL_TUNE_MP3_FRONT": "3"}, "tests/test_mp3_stereo.py", "emu_mp3_decode_device or emu_requantize_stereo_fused or emu_mp3_decode_pipelined"),
+    ({"SYMACCEL_TUNE_F1_LANE16": "0"}, "tests/test_vorbis_floor_y.py", "emu"),
     ({"SYMACCEL_TUNE_VORBIS_WG": "0"}, "tests/test_emu_codecs.py", "register_pass_kernel_pairs"),
     ({"SYMACCEL_TUNE_VORBIS_WG": "2"}, "tests/test_emu_codecs.py", "register_pass_kernel_pairs or emu_vorbis_synth"),
 ]
