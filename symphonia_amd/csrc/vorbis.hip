@@ -9,6 +9,7 @@
 // into an LDS PCM tile, overlap-add against the previous block's right half kept in LDS, coalesced
 // PCM store.  Segments start with a one-block halo that only rebuilds the overlap.
 // Roofline: HBM-bound: 4*(n/2) B in + 4*(prev_n + n)/4 B out per channel-block.
+#include <type_traits>
 #include "fft_lds.h"
 
 namespace symaccel {
@@ -438,7 +439,7 @@ struct Floor1Setup {  // per floor configuration, derived on the host like the s
 #define SYM_F1_ABLATE 0
 #endif
 #ifndef SYM_F1_LANE16
-#define SYM_F1_LANE16 1  // the byte render with sixteen consecutive lines per lane (floor1_workgroup, MODE 2); 0: four groups of four lines 256 apart, as the f32 forms
+#define SYM_F1_LANE16 1  // the byte render with consecutive lines per lane (floor1_workgroup, MODE 2): sixteen, four for blocks of <= 256 lines; 2: sixteen for every size; 0: four groups of four lines 256 apart, as the f32 forms
 #endif
 constexpr int kF1B = 64;                 // channel-blocks per workgroup
 #ifndef SYM_F1_WAVES
@@ -662,44 +663,62 @@ __device__ __forceinline__ void floor1_workgroup(const Floor1Setup &st, int n_po
             // wavefront, one 16-byte read of the segment-start map and one 16-byte store per 16 lines instead of four of each; the segment in force runs on through the
             // lane's lines.  (`aligned16`: wave-uniform; a packed layout whose block offsets are not multiples of 16 takes four 4-byte stores.)
             const bool aligned16 = ((reinterpret_cast<uintptr_t>(yout)) & 15u) == 0;
-            for (uint32_t p0 = 0; p0 < ((SYM_F1_ABLATE & 4) ? 0u : n); p0 += 1024) {
-                const uint32_t x0 = p0 + 16u * (uint32_t)lane;  // (n is a multiple of 16)
-                const bool live = x0 < n;
-                uint32_t m[4] = {0u, 0u, 0u, 0u};
-                if (live) {
-                    const uint4 mm = *reinterpret_cast<const uint4 *>(mark + x0);
-                    m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
-                }
-                uint32_t mine = 0;
+            // W = words of four lines per lane and pass: 4 (sixteen lines, passes of 1024) -- or 1 for blocks of at most 256 lines (the short blocks of a stream:
+            // a 128-line block keeps 32 lanes busy for four lines each instead of 8 lanes for sixteen; a quarter of the pass's instructions)
+            auto render_bytes = [&](auto w_tag) {
+                constexpr int W = decltype(w_tag)::value;
+                for (uint32_t p0 = 0; p0 < ((SYM_F1_ABLATE & 4) ? 0u : n); p0 += 256u * (uint32_t)W) {
+                    const uint32_t x0 = p0 + 4u * (uint32_t)W * (uint32_t)lane;  // (n is a multiple of 16)
+                    const bool live = x0 < n;
+                    uint32_t m[W];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mine = max(mine, max(max(m[j] & 255u, (m[j] >> 8) & 255u), max((m[j] >> 16) & 255u, m[j] >> 24)));
-                uint32_t before, last;
-                wave_prefix_max(mine, before, last);
-                int seg_id = (int)before > carry ? (int)before : carry;  // (index + 1) of the segment in force in front of the lane's first line
-                carry = (int)last > carry ? (int)last : carry;
-                const float xf0 = (float)x0;
-                uint32_t yb[4] = {0u, 0u, 0u, 0u};
+                    for (int j = 0; j < W; ++j) m[j] = 0u;
+                    if (live) {
+                        if constexpr (W == 4) {
+                            const uint4 mm = *reinterpret_cast<const uint4 *>(mark + x0);
+                            m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+                        } else {
+                            m[0] = *reinterpret_cast<const uint32_t *>(mark + x0);
+                        }
+                    }
+                    uint32_t mine = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < W; ++j) mine = max(mine, max(max(m[j] & 255u, (m[j] >> 8) & 255u), max((m[j] >> 16) & 255u, m[j] >> 24)));
+                    uint32_t before, last;
+                    wave_prefix_max(mine, before, last);
+                    int seg_id = (int)before > carry ? (int)before : carry;  // (index + 1) of the segment in force in front of the lane's first line
+                    carry = (int)last > carry ? (int)last : carry;
+                    const float xf0 = (float)x0;
+                    uint32_t yb[W];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int v = (int)((m[j] >> (8 * q)) & 255u);
-                        seg_id = v > seg_id ? v : seg_id;
-                        const uint4 c = segc[seg_id - 1];
-                        const float tf = (xf0 + (float)(4 * j + q)) - __uint_as_float(c.x);
-                        const float yf = __uint_as_float(c.w) + __builtin_truncf(tf * __uint_as_float(c.y) + __uint_as_float(c.z));
-                        yb[j] = cvt_pk_u8(yf, q, yb[j]);
+                    for (int j = 0; j < W; ++j) {
+                        yb[j] = 0u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int v = (int)((m[j] >> (8 * q)) & 255u);
+                            seg_id = v > seg_id ? v : seg_id;
+                            const uint4 c = segc[seg_id - 1];
+                            const float tf = (xf0 + (float)(4 * j + q)) - __uint_as_float(c.x);
+                            const float yf = __uint_as_float(c.w) + __builtin_truncf(tf * __uint_as_float(c.y) + __uint_as_float(c.z));
+                            yb[j] = cvt_pk_u8(yf, q, yb[j]);
+                        }
+                    }
+                    if (live) {
+                        if constexpr (W == 4) {
+                            if (aligned16) {
+                                *reinterpret_cast<uint4 *>(yout + x0) = make_uint4(yb[0], yb[1], yb[2], yb[3]);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t *>(yout + x0 + 4u * (uint32_t)j) = yb[j];
+                            }
+                        } else {
+                            *reinterpret_cast<uint32_t *>(yout + x0) = yb[0];
+                        }
                     }
                 }
-                if (live) {
-                    if (aligned16) {
-                        *reinterpret_cast<uint4 *>(yout + x0) = make_uint4(yb[0], yb[1], yb[2], yb[3]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t *>(yout + x0 + 4u * (uint32_t)j) = yb[j];
-                    }
-                }
-            }
+            };
+            if (SYM_F1_LANE16 == 1 && n <= 256u) render_bytes(std::integral_constant<int, 1>{});  // (wave-uniform; SYM_F1_LANE16 = 2: sixteen lines per lane for every block size)
+            else render_bytes(std::integral_constant<int, 4>{});
             wave_sync_lds();  // the next block's segment-start map overwrites this one's
             continue;
         }
