@@ -115,7 +115,7 @@ def test_emu_alac_uniform_small_orders(emu_ctx):
     """Whole wavefronts of order <= 4 / <= 8 take the short-tap specialisations."""
     from symphonia_amd import AlacPredictor, alac_desc
     rng = np.random.default_rng(3)
-    for hi in (4, 8, 16):
+    for hi in (4, 6, 8, 16):  # (6: the six-tap steady tiles between eight-tap first / last ones)
         nb, bs = 64, 96
         buf = rng.integers(-(1 << 14), 1 << 14, (nb, bs)).astype(np.int32)
         order = rng.integers(1, hi + 1, nb).astype(np.uint8)
@@ -203,7 +203,7 @@ def narrow_update_case(seed, nb, bs, hi_order):
     return buf, mode, order, shift, bps, coeffs
 
 
-@pytest.mark.parametrize("hi_order,uniform", [(8, 1), (8, 2), (8, 0), (4, 0), (31, 0)])
+@pytest.mark.parametrize("hi_order,uniform", [(8, 1), (8, 2), (8, 0), (6, 0), (6, 2), (4, 0), (31, 0)])
 def test_emu_alac_narrow_update_edges(emu_ctx, hi_order, uniform):
     from symphonia_amd import AlacPredictor, alac_desc
     buf, mode, order, shift, bps, coeffs = narrow_update_case(40 + hi_order, 192, 150, hi_order)
@@ -361,7 +361,7 @@ def test_gpu_alac_24_bit_multiply_bound(blocksize):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hi_order,uniform", [(8, 1), (8, 2), (8, 0), (4, 0), (31, 0)])
+@pytest.mark.parametrize("hi_order,uniform", [(8, 1), (8, 2), (8, 0), (6, 0), (6, 2), (4, 0), (31, 0)])
 def test_gpu_alac_narrow_update_edges(hi_order, uniform):
     import torch
     from symphonia_amd import AlacPredictor, Context, alac_desc
