@@ -471,7 +471,8 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
                 } else if (max_order <= 6 && steady) {
                     // orders up to 6 (what ffmpeg's encoder writes: 4 .. 6 per frame, so a wavefront of blocks from many streams is mixed): six taps in the steady
                     // tiles; the first and the ragged last tile take the eight-tap form below (taps beyond a lane's order are neutral there: same results)
-                    alac_steps32<6, M24, false, 8, true>(L, row, prow, t0, (int)cols);
+                    if (!L.any_twice) alac_steps32<6, M24, false, 8, true, false>(L, row, prow, t0, (int)cols);
+                    else alac_steps32<6, M24, false, 8, true>(L, row, prow, t0, (int)cols);
                 } else {
                     if (steady) alac_steps32<8, M24, false, 8, true>(L, row, prow, t0, (int)cols);
                     else alac_steps32<8, M24, false>(L, row, prow, t0, (int)cols);
