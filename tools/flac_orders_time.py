@@ -16,7 +16,8 @@ def main():
     import oracle
     ctx = sa.Context()
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    nb, bs = 524288, 4096
+    nb = 524288
+    bs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096  # (row stride in samples: 4096 = 16 KiB, a power of two)
     rng = np.random.default_rng(9)
     for name, orders, bits in (("uniform 32, 24 bit", np.full(nb, 32), 24), ("uniform 12, 16 bit", np.full(nb, 12), 16), ("6..12 mixed, 16 bit", rng.integers(6, 13, nb), 16),
                                ("uniform 8, 16 bit", np.full(nb, 8), 16), ("1..8 mixed, 16 bit", rng.integers(1, 9, nb), 16), ("fixed 0..4, 16 bit", None, 16)):
@@ -38,7 +39,7 @@ def main():
         before = buf[rows].cpu().numpy()
         fp.restore(buf, desc, co)
         torch.cuda.synchronize()
-        bad = int((buf[rows].cpu().numpy() != oracle.flac_restore(before, desc_np[rows], co_np[rows])).sum())
+        bad = int((buf[rows].cpu().numpy() != oracle.flac_restore(before, oracle.flac_desc(kind[rows], od[rows], np.full(len(rows), 11), np.zeros(len(rows))), co_np[rows])).sum())
         for _ in range(3):
             fp.restore(buf, desc, co)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,7 +49,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 8
-        print(json.dumps({"case": name, "ms_per_launch": round(ms, 4), "frac_of_8TBps": round(nb * bs * 8 / (ms * 1e-3) / 8e12, 4), "mismatches_vs_oracle": bad}), flush=True)
+        print(json.dumps({"blocksize": bs, "case": name, "ms_per_launch": round(ms, 4), "frac_of_8TBps": round(nb * bs * 8 / (ms * 1e-3) / 8e12, 4), "mismatches_vs_oracle": bad}), flush=True)
         del buf
 
 
