@@ -458,16 +458,28 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
                 nch * nb // 8, nch, nb, "byte plane of dB-table indices, multiplied in the synthesis load path" if name == "vorbisf" else
                 "curve x residue as an f32 spectrum, then synthesis"),
             "channel_blocks": nch * nb}, ("vorbis_floor1_pair_kernel + vorbis_synth_wave_kernel" if name == "vorbisf" else "vorbis_floor1_kernel x2 + vorbis_synth_wave_kernel"), pcm
-    if name == "flac":
+    if name in ("flac", "flacp"):
         nb, bs = max(2, int(1048576 * scale) & ~1), 4096  # config 5: 1 M subframe blocks of 4096 samples = 16 GiB, in place
         buf, desc, co, pair_mode, _ = flac_config5(torch, nb, bs, seed, dev)
         fp = sa.FlacPredictor(ctx)
+        # "flacp": the same batch with its rows at the pitch symaccel_row_stride() recommends (4608 words: rows 18 KiB apart instead
+        # of 16 KiB) through symaccel_flac_restore_strided_device -- the layout a caller that owns the plane (the batcher) uses
+        padded = name == "flacp"
+        if padded:
+            pitch = int(os.environ.get("SYM_BENCH_PITCH", "0")) or int(ctx.lib.dll.symaccel_row_stride(bs))  # (development: the sweep of profiles/r06zz33_*)
+            wide = torch.full((nb, pitch), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+            wide[:, :bs] = buf
+            del buf
+            buf = wide
 
         def step():
             # In place, so every step after the first predicts over the previous step's output.  That is still one full
             # pass of the recurrence + decorrelation over the batch: the kernel has no data-dependent control flow (the
             # f64 / i64 path is chosen from the coefficients alone) and the arithmetic wraps, so every pass costs the same.
-            fp.restore_stereo(buf, desc, co, pair_mode, 8)
+            if padded:
+                fp.restore_strided(buf, desc, co, bs, pair_mode, 8)
+            else:
+                fp.restore_stereo(buf, desc, co, pair_mode, 8)
 
         def verify():
             """one more pass over the batch (outside every timed region): sampled channel pairs, their words saved in front of it,
@@ -475,11 +487,13 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
             import oracle
             pairs = sorted({0, min(1, nb // 2 - 1), max(0, nb // 4 - 1), nb // 4, nb // 2 - 1})
             rows = [r for p_ in pairs for r in (2 * p_, 2 * p_ + 1)]
-            before = buf[rows].cpu().numpy()
+            before = buf[rows][:, :bs].cpu().numpy()
             step()
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
-            got = buf[rows].cpu().numpy()
+            got = buf[rows][:, :bs].cpu().numpy()
+            if padded and not bool((buf[rows][:, bs:] == 0x5A5A5A5A).all()):
+                raise RuntimeError("bench: the FLAC kernel wrote into the padding of its rows")
             want = oracle.flac_restore(before, desc[rows].cpu().numpy(), co[rows].cpu().numpy())
             pm = pair_mode[pairs].cpu().numpy()
             for k in range(len(pairs)):
@@ -494,27 +508,36 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
         return step, nb, "blocks", nb * bs * 8, {
             "workload": "FLAC 24-bit 192 kHz, LPC order 32 (15-bit quantised coefficients of random AR models, shift 10..14), "
                         "%d subframe blocks of 4096 samples, half the channel pairs mid/side (side channel 25 bits), "
-                        "restore + decorrelate + left-justify fused, in place" % nb, "samples": nb * bs}, "flac_restore_f64_kernel", buf
-    if name == "alac":
+                        "restore + decorrelate + left-justify fused, in place%s" % (
+                            nb, ", rows %d words apart (symaccel_row_stride)" % buf.shape[1] if padded else ""), "samples": nb * bs}, "flac_restore_f64_kernel", buf
+    if name in ("alac", "alacp"):
         nb, bs = max(1, int(262144 * scale)), 4096  # 16-bit ALAC frames of 4096 samples, adaptive predictor of order 8
-        buf = torch.randint(-(1 << 9), 1 << 9, (nb, bs), generator=g, device=dev, dtype=torch.int32)
+        padded = name == "alacp"  # (as "flacp")
+        pitch = (int(os.environ.get("SYM_BENCH_PITCH", "0")) or int(ctx.lib.dll.symaccel_row_stride(bs))) if padded else bs
+        buf = torch.full((nb, pitch), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+        buf[:, :bs] = torch.randint(-(1 << 9), 1 << 9, (nb, bs), generator=g, device=dev, dtype=torch.int32)
         desc_np = sa.alac_desc(np.zeros(nb), np.full(nb, 8), np.full(nb, 9), np.full(nb, 16))
         desc = torch.from_numpy(desc_np.view(np.uint8).reshape(nb, 4)).to(dev)
         co = torch.randint(-200, 200, (nb, 32), generator=g, device=dev, dtype=torch.int32)
         ap = sa.AlacPredictor(ctx)
 
         def step():
-            ap.predict(buf, desc, co)  # in place, like the FLAC workload: every pass costs the same
+            if padded:
+                ap.predict_strided(buf, desc, co, bs)
+            else:
+                ap.predict(buf, desc, co)  # in place, like the FLAC workload: every pass costs the same
 
         def verify():
             """as for FLAC: sampled blocks of one more pass against the oracle's predictor on the words saved in front of it"""
             import oracle
             rows = sorted({0, min(1, nb - 1), min(63, nb - 1), min(64, nb - 1), nb // 2, nb - 1})
-            before = buf[rows].cpu().numpy()
+            before = buf[rows][:, :bs].cpu().numpy()
             step()
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
-            got = buf[rows].cpu().numpy()
+            got = buf[rows][:, :bs].cpu().numpy()
+            if padded and not bool((buf[rows][:, bs:] == 0x5A5A5A5A).all()):
+                raise RuntimeError("bench: the ALAC kernel wrote into the padding of its rows")
             want = oracle.alac_predict(before, desc_np[rows], co[rows].cpu().numpy())
             bad = int((got != want).sum())
             if bad:
@@ -523,7 +546,8 @@ def make_workload(name, torch, ctx, seed, scale=1.0, mix=0.0, emulate=False):
                     "samples_compared": int(got.size), "mismatches": bad, "criterion": "bit-identical i32"}
         step.verify = verify
         return step, nb, "blocks", nb * bs * 8, {
-            "workload": "ALAC 16-bit, adaptive LPC order 8 (shift 9), %d element-channel blocks of 4096 samples, in place" % nb,
+            "workload": "ALAC 16-bit, adaptive LPC order 8 (shift 9), %d element-channel blocks of 4096 samples, in place%s" % (
+                nb, ", rows %d words apart (symaccel_row_stride)" % pitch if padded else ""),
             "samples": nb * bs}, "alac_predict_kernel", buf
     raise ValueError(name)
 
@@ -1184,7 +1208,7 @@ def main():
     ap.add_argument("--steps", type=int, default=256,
                     help="timed steps (default 256: a 0.2 ms step gives a timed region of ~50 ms, long enough for an outside clock to see)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "mp3q2", "vorbisf", "vorbisf2", "aacjs", "aacjs2", "aactns", "decoders"])
+    ap.add_argument("--workload", default="aac", choices=["aac", "mp3", "vorbis", "flac", "alac", "flacp", "alacp", "mp3q", "mp3q2", "vorbisf", "vorbisf2", "aacjs", "aacjs2", "aactns", "decoders"])
     ap.add_argument("--segment", type=int, default=0, help="frames per wavefront segment (0 = library default)")
     ap.add_argument("--scale", type=float, default=1.0, help="batch size multiplier (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1435,6 +1459,7 @@ def main():
         # LONG_STOP run, random window shapes) and MP3 with Start -> Short.. -> End runs (a quarter of them mixed) and random
         # rzero: SURVEY 8d's correctness mixes, timed
         for key, w, mixw in (("mp3", "mp3", 0.0), ("vorbis", "vorbis", 0.0), ("flac", "flac", 0.0), ("alac", "alac", 0.0),
+                             ("flac_padded_rows", "flacp", 0.0), ("alac_padded_rows", "alacp", 0.0),
                              ("aac_mix_0.05", "aac", 0.05), ("aac_mix_0.25", "aac", 0.25), ("mp3_mix_0.06", "mp3", 0.06),
                              ("mp3_int16_one_kernel", "mp3q", 0.0), ("mp3_int16_two_kernels", "mp3q2", 0.0),
                              ("vorbis_posts_byte_plane", "vorbisf", 0.0), ("vorbis_posts_f32_spectrum", "vorbisf2", 0.0),
@@ -1442,7 +1467,7 @@ def main():
                              ("aac_tns_0.30", "aactns", 0.0)):
             try:
                 stw, unitsw, unitw, bytesw, cfgw, kernelw, resw = make_workload(w, torch, ctx, 4321, args.scale, mixw, emulate)
-                nw, ww = (8, 2) if w in ("flac", "alac") else (20, 3)  # (a few milliseconds each for the short ones)
+                nw, ww = (8, 2) if w in ("flac", "alac", "flacp", "alacp") else (20, 3)  # (a few milliseconds each for the short ones)
                 ew, lw, _ = timed(stw, nw, ww, spin)
                 others[key] = {"value": unitsw * nw / ew, "unit": unitw + "/s", "ms_per_step": ew / nw * 1e3, "steps": nw, "warmup": ww,
                                "kernel": kernelw, "kernel_ms": lw * 1e3, "algorithmic_bytes_per_launch": bytesw,
@@ -1496,7 +1521,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "i32/i64" if args.workload == "flac" else ("i32" if args.workload == "alac" else "f32"),
+            "dtype": "i32/i64" if args.workload in ("flac", "flacp") else ("i32" if args.workload in ("alac", "alacp") else "f32"),
             "data": "synthetic",
             "config": dict(config, parallelism="chains sharded per GPU, no data-path collective", segment=args.segment or "auto"),
             "ranks": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
@@ -1539,10 +1564,11 @@ def main():
                                                     "headline kernel's pattern: `frac_of_same_pattern_copy`); `peak` stays the HBM3E spec")
         if others:
             out["other_workloads"] = others
-        if args.workload == "alac":
+        if args.workload in ("alac", "alacp"):
             out["roofline"]["note"] = "integer-ALU bound (adaptive predictor, ~13 x order operations per sample), not HBM"
-        if args.workload == "flac":
-            out["roofline"]["note"] = "FP64-FMA-issue bound (32 exact FMAs per 8 B), not HBM (DESIGN.md 4.5)"
+        if args.workload in ("flac", "flacp"):
+            out["roofline"]["note"] = ("one lane per block: bound by how the 64 row segments of a wavefront's tile spread over the HBM channels -- rows 16 KiB apart "
+                                       "0.57, rows at symaccel_row_stride() 0.66 (--workload flacp) -- with the FP64 work (32 exact FMAs per 8 B) underneath (DESIGN.md 4.5)")
         if gather:
             out["collective"] = gather
         if exchange:
@@ -1571,7 +1597,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not emulate:
             # (the int16 MP3 lines are timed against the same CPU restatement as config 3: its synthesis tail; the CPU side of
             # requantize + stereo is a few per cent of that)
-            out["cpu_baseline"] = cpu_baseline({"mp3q": "mp3", "mp3q2": "mp3", "vorbisf": "vorbis", "vorbisf2": "vorbis", "aacjs": "aac", "aacjs2": "aac", "aactns": "aac"}.get(args.workload, args.workload))
+            out["cpu_baseline"] = cpu_baseline({"mp3q": "mp3", "mp3q2": "mp3", "vorbisf": "vorbis", "vorbisf2": "vorbis", "aacjs": "aac", "aacjs2": "aac", "aactns": "aac", "flacp": "flac", "alacp": "alac"}.get(args.workload, args.workload))
         print(json.dumps(out), flush=True)
     if hung:
         os._exit(0)  # a leg is still stuck in a collective: the line is out, do not wait for it

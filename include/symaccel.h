@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SYMACCEL_ABI_VERSION 7 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device, vorbis floor_y; 5: aac_decode_pipelined, aac_joint_stereo_list, vorbis_decode; 6: batcher; 7: batch kinds for Vorbis from posts, FLAC and ALAC (symaccel_batch_slot has six input planes), lanes, per-ticket status */
+#define SYMACCEL_ABI_VERSION 8 /* 2: *_pp_device entry points, per-block status arrays, lookahead staging; 3: multi-GPU, probe; 4: mp3_decode_*device, vorbis floor_y; 5: aac_decode_pipelined, aac_joint_stereo_list, vorbis_decode; 6: batcher; 7: batch kinds for Vorbis from posts, FLAC and ALAC (symaccel_batch_slot has six input planes), lanes, per-ticket status; 8: *_strided_device (padded row pitch for the FLAC / ALAC planes), symaccel_row_stride */
 
 typedef enum symaccel_status {
     SYMACCEL_OK = 0,
@@ -576,6 +576,22 @@ int symaccel_flac_block_status_device(symaccel_ctx *ctx, const symaccel_flac_des
 int symaccel_flac_restore_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
                                         const int32_t *d_coeffs, const uint8_t *d_pair_mode, uint32_t out_shift,
                                         size_t n_blocks, size_t blocksize);
+/* The same restore over rows `stride` words apart (ABI 8): buf[block][stride] i32, the first `blocksize` words of a row are the
+ * subframe, the rest is padding the kernels neither read nor write.  stride >= blocksize (0 = blocksize: rows back to back);
+ * a multiple of 4 keeps the 16-byte tile path.  d_pair_mode NULL = symaccel_flac_restore_device, else the fused stereo form
+ * (n_blocks even).  Why it exists: one LANE owns a subframe, so a wavefront moves 64 row segments of 128 B per tile, one per
+ * row; with rows 4, 8, 16 or 32 KiB apart (4096 samples = 16 KiB, the block size of nearly every FLAC stream) those 64
+ * segments fall on a fraction of the HBM channels and the kernel is bound by that instead of its arithmetic (FLAC row).
+ * A caller that owns the layout -- the batcher's device planes, a shim that decodes residuals straight into a batch buffer --
+ * asks symaccel_row_stride() for the pitch.  The reference has no such notion: its buffers are one Vec<i32> per channel
+ * (decoder.rs:199-242), i.e. every row already lives at an unrelated address. */
+int symaccel_flac_restore_strided_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
+                                         const int32_t *d_coeffs, const uint8_t *d_pair_mode, uint32_t out_shift,
+                                         size_t n_blocks, size_t blocksize, size_t stride);
+/* The row pitch (in i32 words, a multiple of 4, >= blocksize) the lane-per-block kernels (FLAC restore, ALAC predict) run
+ * fastest at for blocks of `blocksize` samples: blocksize rounded up to 4, plus an eighth of the row when it is 1024 samples or more and
+ * a multiple of 512 (4096 -> 4608: config 5's batch goes from 0.57 to 0.66 of the HBM peak).  Pure arithmetic, no context. */
+size_t symaccel_row_stride(size_t blocksize);
 /* decorrelate_{left_side,mid_side,right_side} (decoder.rs:32-82) then `<< out_shift`
  * (decoder.rs:239-242, out_shift = 32 - bits_per_sample, 0 = none) over n_pairs channel pairs:
  * mode[pair] in {0 independent, 1 left/side, 2 mid/side, 3 right/side}; ch0/ch1[pair][blocksize]. */
@@ -612,6 +628,11 @@ int symaccel_alac_block_status_device(symaccel_ctx *ctx, const symaccel_alac_des
 int symaccel_alac_predict_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc,
                                         const int32_t *d_coeffs, const int32_t *d_pair_weight,
                                         const uint8_t *d_pair_shift, size_t n_blocks, size_t blocksize);
+/* predict over rows `stride` words apart (ABI 8; see symaccel_flac_restore_strided_device): d_pair_weight / d_pair_shift NULL =
+ * symaccel_alac_predict_device, else the fused mid/side form (n_blocks even). */
+int symaccel_alac_predict_strided_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc,
+                                         const int32_t *d_coeffs, const int32_t *d_pair_weight, const uint8_t *d_pair_shift,
+                                         size_t n_blocks, size_t blocksize, size_t stride);
 /* decorrelate_mid_side (lib.rs:664-671) over n_pairs channel pairs: weight[pair] (0 = pair left alone, lib.rs:552),
  * shift[pair] (<= 31, lib.rs:555); ch0/ch1[pair][blocksize]. */
 int symaccel_alac_mid_side_device(symaccel_ctx *ctx, const int32_t *d_weight, const uint8_t *d_shift,

@@ -54,6 +54,7 @@ ABI_SYMBOLS = [
     "symaccel_batcher_submit_aac_synth", "symaccel_batcher_submit_mp3_synth", "symaccel_batcher_submit_mp3_decode", "symaccel_batcher_submit_vorbis_synth", "symaccel_batcher_aac_bands", "symaccel_batcher_submit_aac_decode", "symaccel_batcher_flush", "symaccel_batcher_hint", "symaccel_batcher_plane_bytes",
     "symaccel_batcher_get_stats", "symaccel_batcher_configure", "symaccel_batcher_last_error", "symaccel_batcher_vorbis_floor",
     "symaccel_batcher_submit_vorbis_decode", "symaccel_batcher_submit_flac_restore", "symaccel_batcher_submit_alac_predict",
+    "symaccel_flac_restore_strided_device", "symaccel_alac_predict_strided_device", "symaccel_row_stride",
 ]
 
 _vp, _sz, _i, _d, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
@@ -177,6 +178,10 @@ class Library:
         d.symaccel_vorbis_synth_fy_device.argtypes = [_vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
         d.symaccel_flac_restore_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_flac_restore_stereo_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _u32, _sz, _sz]
+        d.symaccel_flac_restore_strided_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _u32, _sz, _sz, _sz]
+        d.symaccel_alac_predict_strided_device.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz]
+        d.symaccel_row_stride.argtypes = [_sz]
+        d.symaccel_row_stride.restype = _sz
         d.symaccel_flac_restore.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]
         d.symaccel_flac_decorrelate_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz, _u32]
         d.symaccel_alac_predict_device.argtypes = [_vp, _vp, _vp, _vp, _sz, _sz]

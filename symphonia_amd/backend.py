@@ -618,6 +618,14 @@ class FlacPredictor:
                        _ptr(pair_mode), int(out_shift), nb, bs)
         return buf
 
+    def restore_strided(self, buf, desc, coeffs, blocksize, pair_mode=None, out_shift=0):
+        """restore() / restore_stereo() over padded rows: buf[n_blocks, stride] i32 on the device, the first `blocksize` words of a
+        row are the subframe (symaccel_flac_restore_strided_device).  In place; the padding is neither read nor written."""
+        nb, stride = int(buf.shape[0]), int(buf.shape[1])
+        self.ctx._call(self.ctx.lib.dll.symaccel_flac_restore_strided_device, _ptr(buf), _ptr(desc), _ptr(coeffs),
+                       _ptr(pair_mode) if pair_mode is not None else None, int(out_shift), nb, int(blocksize), stride)
+        return buf
+
     def decorrelate(self, mode, ch0, ch1, blocksize, out_shift=0):
         n_pairs = (ch0.numel() if _is_torch(ch0) else ch0.size) // int(blocksize)
         self.ctx._call(self.ctx.lib.dll.symaccel_flac_decorrelate_device, _ptr(mode), _ptr(ch0), _ptr(ch1), n_pairs,
@@ -660,6 +668,15 @@ class AlacPredictor:
         nb, bs = int(buf.shape[0]), int(buf.shape[1])
         self.ctx._call(self.ctx.lib.dll.symaccel_alac_predict_stereo_device, _ptr(buf), _ptr(desc), _ptr(coeffs),
                        _ptr(pair_weight), _ptr(pair_shift), nb, bs)
+        return buf
+
+    def predict_strided(self, buf, desc, coeffs, blocksize, pair_weight=None, pair_shift=None):
+        """predict() / predict_stereo() over padded rows: buf[n_blocks, stride] i32 on the device
+        (symaccel_alac_predict_strided_device).  In place."""
+        nb, stride = int(buf.shape[0]), int(buf.shape[1])
+        self.ctx._call(self.ctx.lib.dll.symaccel_alac_predict_strided_device, _ptr(buf), _ptr(desc), _ptr(coeffs),
+                       _ptr(pair_weight) if pair_weight is not None else None,
+                       _ptr(pair_shift) if pair_shift is not None else None, nb, int(blocksize), stride)
         return buf
 
     def mid_side(self, weight, shift, ch0, ch1):

@@ -36,7 +36,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I", str(CSRC), "-ffp-contract=off", "-f
 # ALAC 3.04 -> 3.00, FLAC 7.75 -> 7.71, MP3 config 3 equal; vorbis_wave.hip spills under it (68 B of scratch) and vorbis.hip gains nothing: not these.
 _ILP = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 SOURCE_FLAGS = {"aac_tools.hip": _ILP, "mp3.hip": _ILP, "alac.hip": _ILP, "flac.hip": _ILP}  # (an AMDGPU option: the host pass ignores it; -misched=gcn-iterative-ilp crashes the x86 side)
-TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_VARIANT", "NT", "MP3_WAVES", "MP3_VARIANT", "MP3_WG_WAVES", "MP3_FUSED_WAVES", "MP3_FUSED_WG_WAVES", "VORBIS_WAVES", "ALAC_SMALL_WAVES", "FLAC_PARTS", "MP3_SLOT_GROUP", "MP3_PACKED", "MP3_PAIR_GROUP", "AAC_ABLATE", "AAC_SINK", "AAC_CLOCK", "AAC_QUAD", "MULTI_WAVE", "VORBIS_WAVE2", "VORBIS_WG", "VORBIS_WG_SHARED", "ST_POLICY", "PACKED_C32", "WG4096_ABLATE", "FLAC_STORE_SWITCH", "ALAC_ONE_LAUNCH", "MP3_FRONT", "LDS_ABLATE", "F1_ABLATE", "F1_WAVES", "TNS_AHEAD", "TNS_ABLATE", "ALAC_UPDATE", "FLAC_OLDEST_FIRST", "FLAC_GROUP", "ALAC_UNROLL", "F1_LANE16")
+TUNING_KNOBS = ("AAC_MIN_WAVES", "AAC_PREFETCH", "AAC_VARIANT", "NT", "MP3_WAVES", "MP3_VARIANT", "MP3_WG_WAVES", "MP3_FUSED_WAVES", "MP3_FUSED_WG_WAVES", "VORBIS_WAVES", "ALAC_SMALL_WAVES", "FLAC_PARTS", "MP3_SLOT_GROUP", "MP3_PACKED", "MP3_PAIR_GROUP", "AAC_ABLATE", "AAC_SINK", "AAC_CLOCK", "AAC_QUAD", "MULTI_WAVE", "VORBIS_WAVE2", "VORBIS_WG", "VORBIS_WG_SHARED", "ST_POLICY", "PACKED_C32", "WG4096_ABLATE", "FLAC_STORE_SWITCH", "ALAC_ONE_LAUNCH", "MP3_FRONT", "LDS_ABLATE", "F1_ABLATE", "F1_WAVES", "TNS_AHEAD", "TNS_ABLATE", "ALAC_UPDATE", "FLAC_OLDEST_FIRST", "FLAC_GROUP", "ALAC_UNROLL", "F1_LANE16", "FLAC_WAVES")
 TUNE_PREFIX = "SYMACCEL_TUNE_"
 
 

@@ -292,7 +292,7 @@ __device__ __forceinline__ int32_t alac_mixed(int32_t weight, uint32_t shift, bo
     return is_ch1 ? wrap_sub(o0, s1) : o0;
 }
 __device__ __forceinline__ void alac_store_mixed(int32_t *__restrict__ buf, const int32_t *tile, const int32_t *row_weight,
-                                                 const uint8_t *row_shift, size_t blk0, size_t n_blocks, unsigned blocksize,
+                                                 const uint8_t *row_shift, size_t blk0, size_t n_blocks, unsigned stride,
                                                  unsigned t0, unsigned cols, int lane, bool fast) {
     if (fast) {
         // a lane takes four columns of BOTH rows of a pair (32 pairs per tile: four rounds of eight pairs x eight column groups): every
@@ -318,16 +318,16 @@ __device__ __forceinline__ void alac_store_mixed(int32_t *__restrict__ buf, cons
             mix(a.y, b.y, o0.y, o1.y);
             mix(a.z, b.z, o0.z, o1.z);
             mix(a.w, b.w, o0.w, o1.w);
-            int32_t *dst = buf + (blk0 + (size_t)r0) * blocksize + t0 + 4u * (unsigned)q;
+            int32_t *dst = buf + (blk0 + (size_t)r0) * stride + t0 + 4u * (unsigned)q;
             *reinterpret_cast<int4 *>(dst) = o0;
-            *reinterpret_cast<int4 *>(dst + blocksize) = o1;
+            *reinterpret_cast<int4 *>(dst + stride) = o1;
         }
     } else {
         const int c = lane & 31, rsub = lane >> 5;
 #pragma unroll 4
         for (int r = rsub; r < kRows; r += 2) {
             if (blk0 + (size_t)r < n_blocks && (unsigned)c < cols)
-                buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)c] =
+                buf[(blk0 + (size_t)r) * stride + t0 + (unsigned)c] =
                     alac_mixed(row_weight[r], row_shift[r], (r & 1) != 0, tile[r * kStride + c], tile[(r ^ 1) * kStride + c]);
         }
     }
@@ -345,7 +345,7 @@ __device__ __forceinline__ void alac_store_mixed(int32_t *__restrict__ buf, cons
 // Anything else (24-bit channels -- 25 bits on a side channel --, a caller's arbitrary i32 data) takes the full 32-bit
 // multiply.  One flag per wavefront of 64 blocks, computed BEFORE the in-place prediction touches the buffer.
 __global__ __launch_bounds__(64) void alac_narrow_kernel(const int32_t *__restrict__ buf, const symaccel_alac_desc *__restrict__ desc,
-                                                         const int32_t *__restrict__ coeffs, size_t n_blocks, unsigned blocksize,
+                                                         const int32_t *__restrict__ coeffs, size_t n_blocks, unsigned blocksize, unsigned stride,
                                                          uint8_t *__restrict__ narrow_flag) {
     const size_t my = (size_t)blockIdx.x * kRows + threadIdx.x;
     bool narrow = true, small = true, mid = true;  // small: order <= 8 (the register-only instantiation, AlacLane<8>); mid: see alac_step, QF
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64) void alac_narrow_kernel(const int32_t *__restri
         if (enabled) {
             small = order <= 8u;
             const unsigned bps = d.bps < 1u ? 1u : (d.bps > 32u ? 32u : d.bps);
-            const int32_t first = buf[my * (size_t)blocksize];
+            const int32_t first = buf[my * (size_t)stride];
             narrow = bps <= 23u && blocksize <= (1u << 21) && first >= -(1 << 22) && first < (1 << 22);
             mid = bps <= 26u && first >= -(1 << 25) && first < (1 << 25);
             const int4 *cp = reinterpret_cast<const int4 *>(coeffs + my * 32);
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(64) void alac_narrow_kernel(const int32_t *__restri
 template <bool MIX, bool M24, bool SMALL>
 __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES : 2) void alac_predict_kernel(
     int32_t *__restrict__ buf, const symaccel_alac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
-    size_t n_blocks, unsigned blocksize, const int32_t *__restrict__ pair_weight, const uint8_t *__restrict__ pair_shift,
-    const uint8_t *__restrict__ narrow_flag) {
+    size_t n_blocks, unsigned blocksize, unsigned stride, const int32_t *__restrict__ pair_weight,
+    const uint8_t *__restrict__ pair_shift, const uint8_t *__restrict__ narrow_flag) {
     const unsigned wave_class = narrow_flag[blockIdx.x];  // alac_narrow_kernel
     if (((wave_class & 1u) != 0) != M24 || ((wave_class & 2u) != 0) != SMALL) return;  // another instantiation's wavefront
     const bool mid = (wave_class & 4u) != 0;
@@ -435,12 +435,12 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
     const bool full8 = __all(!have || !L.enabled || L.order == 8u) != 0 && max_order == 8u;
     const bool steady_ok = __all(!have || L.enabled) != 0;  // (with full8: past sample 8 no lane has a per-sample condition left)
 
-    const bool aligned = (blocksize & 3u) == 0 && blk0 + kRows <= n_blocks;
+    const bool aligned = (stride & 3u) == 0 && blk0 + kRows <= n_blocks;  // rows `stride` words apart (>= blocksize)
     const unsigned n_tiles = (blocksize + kCols - 1) / kCols;
     TilePrefetch pre;
 #pragma unroll
     for (int k = 0; k < 8; ++k) pre.v[k] = make_int4(0, 0, 0, 0);
-    if (aligned && blocksize >= (unsigned)kCols) tile_issue_loads(buf, pre, blk0, blocksize, 0, lane);
+    if (aligned && blocksize >= (unsigned)kCols) tile_issue_loads(buf, pre, blk0, stride, 0, lane);
     for (unsigned t = 0; t < n_tiles; ++t) {
         const unsigned t0 = t * kCols;
         const unsigned cols = min((unsigned)kCols, blocksize - t0);
@@ -451,9 +451,9 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
         if (fast)
             tile_commit(pre, tile, lane);
         else
-            tile_fetch_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+            tile_fetch_slow(buf, tile, blk0, n_blocks, stride, t0, cols, lane);
         wave_sync();
-        if (aligned && t0 + 2u * kCols <= blocksize) tile_issue_loads(buf, pre, blk0, blocksize, t0 + kCols, lane);
+        if (aligned && t0 + 2u * kCols <= blocksize) tile_issue_loads(buf, pre, blk0, stride, t0 + kCols, lane);
         if (have) {
             int32_t *row = tile + lane * kStride;
             const int32_t *prow = prev_tile + lane * kStride;
@@ -488,12 +488,12 @@ __global__ __launch_bounds__(64) SYM_ALAC_OCCUPANCY(SMALL ? SYM_ALAC_SMALL_WAVES
         }
         wave_sync();
         if constexpr (MIX) {
-            alac_store_mixed(buf, tile, row_weight, row_shift, blk0, n_blocks, blocksize, t0, cols, lane, fast);
+            alac_store_mixed(buf, tile, row_weight, row_shift, blk0, n_blocks, stride, t0, cols, lane, fast);
         } else {
             if (fast)
-                tile_store_fast(buf, tile, blk0, blocksize, t0, lane);
+                tile_store_fast(buf, tile, blk0, stride, t0, lane);
             else
-                tile_store_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+                tile_store_slow(buf, tile, blk0, n_blocks, stride, t0, cols, lane);
         }
     }
 }
@@ -516,7 +516,9 @@ __global__ void alac_mid_side_kernel(const int32_t *__restrict__ weight, const u
 }  // namespace
 
 int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc, const int32_t *d_coeffs,
-                        size_t n_blocks, size_t blocksize, const int32_t *d_pair_weight, const uint8_t *d_pair_shift) {
+                        size_t n_blocks, size_t blocksize, const int32_t *d_pair_weight, const uint8_t *d_pair_shift, size_t stride) {
+    if (stride == 0) stride = blocksize;  // rows back to back
+    if (stride < blocksize || stride > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
     const size_t grid = (n_blocks + kRows - 1) / kRows;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     // one byte per wavefront: 24-bit multiplies are exact for its 64 blocks.  A buffer of its own: the context's shared scratch
@@ -534,11 +536,11 @@ int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_d
     }
     void *flags = ctx->alac_flags;
     hipLaunchKernelGGL(alac_narrow_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
-                       (unsigned)blocksize, (uint8_t *)flags);
+                       (unsigned)blocksize, (unsigned)stride, (uint8_t *)flags);
     // four launches over the same grid, one per (24-bit multiplies, orders <= 8) class: each wavefront runs in exactly one
 #define SYM_ALAC_LAUNCH(MIX, M24, SMALL)                                                                                     \
     hipLaunchKernelGGL((alac_predict_kernel<MIX, M24, SMALL>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_buf, d_desc, \
-                       d_coeffs, n_blocks, (unsigned)blocksize, d_pair_weight, d_pair_shift, (const uint8_t *)flags)
+                       d_coeffs, n_blocks, (unsigned)blocksize, (unsigned)stride, d_pair_weight, d_pair_shift, (const uint8_t *)flags)
     if (d_pair_weight) {
         SYM_ALAC_LAUNCH(true, true, true);
         SYM_ALAC_LAUNCH(true, true, false);

@@ -317,6 +317,7 @@ struct Group {
     const uint64_t *done_flag = nullptr;  // where its launch reports completion, and the number that means "this launch"
     uint64_t done_seq = 0;
     char *d_in[kMaxIn] = {}, *d_state_in[kMaxState] = {}, *d_state_out[kMaxState] = {}, *d_out = nullptr;
+    size_t row_pitch = 0;  // FLAC_RESTORE / ALAC_PREDICT: bytes between the chains (rows) of d_in[0] when the device plane is padded (symaccel_row_stride), 0 = rows back to back
     int32_t *d_units = nullptr;  // MP3_DECODE: unit_chains of every chunk, relative to the chunk's first chain
     // AAC_DECODE: the group's pair list, joint-stereo rows, TNS filters, the pair frames that carry TNS, the walk's chain index
     int32_t *d_aac_pairs = nullptr;
@@ -515,7 +516,7 @@ int group_device(symaccel_ctx *ctx, Group *g, size_t n_pieces_bound, uint64_t *n
     for (int i = 0; i < ps.n_in; ++i) {
         off_in[i] = total;
         if (ps.in_host_only[i]) continue;
-        total += round256(ps.in_per_ticket[i] ? ps.in[i] * g->tickets : ps.in[i] * ((g->chains + ps.in_div[i] - 1) / ps.in_div[i]));
+        total += round256(ps.in_per_ticket[i] ? ps.in[i] * g->tickets : (i == 0 && g->row_pitch ? g->row_pitch : ps.in[i]) * ((g->chains + ps.in_div[i] - 1) / ps.in_div[i]));
     }
     for (int i = 0; i < ps.n_state; ++i) {
         off_si[i] = total;
@@ -623,7 +624,7 @@ int group_device(symaccel_ctx *ctx, Group *g, size_t n_pieces_bound, uint64_t *n
 // the kernels of one chunk: chains [c0, c0 + nc), submissions [t0, t0 + nt)
 int launch_chunk(symaccel_ctx *ctx, Group *g, size_t c0, size_t nc, size_t t0, size_t nt) {
     const PlaneSizes &ps = g->ps;
-    auto in = [&](int i) { return g->d_in[i] + (ps.in_per_ticket[i] ? t0 * ps.in[i] : (c0 / ps.in_div[i]) * ps.in[i]); };
+    auto in = [&](int i) { return g->d_in[i] + (ps.in_per_ticket[i] ? t0 * ps.in[i] : (c0 / ps.in_div[i]) * (i == 0 && g->row_pitch ? g->row_pitch : ps.in[i])); };
     auto si = [&](int i) { return g->d_state_in[i] + c0 * ps.state[i]; };
     auto so = [&](int i) { return g->d_state_out[i] + c0 * ps.state[i]; };
     char *out = g->d_out + c0 * (ps.in_place ? ps.in[0] : ps.out);
@@ -685,10 +686,10 @@ int launch_chunk(symaccel_ctx *ctx, Group *g, size_t c0, size_t nc, size_t t0, s
     }
     case SYMACCEL_BATCH_FLAC_RESTORE:  // decoder.rs:663-752 (+ :32-82, :239-242 with the pair modes)
         return launch_flac_restore(ctx, (int32_t *)in(0), (const symaccel_flac_desc *)in(1), (const int32_t *)in(2), nc, g->units,
-                                   (g->param & 0x100) ? (const uint8_t *)in(3) : nullptr, (uint32_t)(g->param & 31));
+                                   (g->param & 0x100) ? (const uint8_t *)in(3) : nullptr, (uint32_t)(g->param & 31), g->row_pitch / 4);
     case SYMACCEL_BATCH_ALAC_PREDICT:  // alac/lib.rs:165-264 (+ :664-671 with the pair parameters)
         return launch_alac_predict(ctx, (int32_t *)in(0), (const symaccel_alac_desc *)in(1), (const int32_t *)in(2), nc, g->units,
-                                   (g->param & 0x100) ? (const int32_t *)in(3) : nullptr, (g->param & 0x100) ? (const uint8_t *)in(4) : nullptr);
+                                   (g->param & 0x100) ? (const int32_t *)in(3) : nullptr, (g->param & 0x100) ? (const uint8_t *)in(4) : nullptr, g->row_pitch / 4);
     default:
         return SYMACCEL_ERR_INVALID_ARG;
     }
@@ -824,6 +825,18 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
         bound += pieces_of((ps.in_place ? ps.in[0] : ps.out) * v.n_chains);
     }
     bound += g->tickets + 8;  // (the unit list's pieces, one per chunk at most)
+    // FLAC / ALAC: the device plane's rows at the pitch the lane-per-block kernels run fastest at (symaccel_row_stride: rows a multiple of 2 KiB apart -- the
+    // 4096-sample blocks of nearly every stream -- put a wavefront's 64 row segments on a fraction of the HBM channels); the slots stay compact, the
+    // gather / scatter go row by row (development knob: SYMACCEL_BATCH_ROW_PAD=0 keeps the rows back to back)
+    static const bool row_pad = [] {
+        const char *e = std::getenv("SYMACCEL_BATCH_ROW_PAD");
+        return !e || std::atol(e) != 0;
+    }();
+    g->row_pitch = 0;
+    if (serial_kind(g->kind) && row_pad && symaccel_row_stride(g->units) * 4 != ps.in[0]) {
+        g->row_pitch = symaccel_row_stride(g->units) * 4;
+        bound += 2 * g->chains;  // (each row rounded up)
+    }
     if (g->kind == SYMACCEL_BATCH_VORBIS_SYNTH || g->kind == SYMACCEL_BATCH_VORBIS_DECODE) bound += 2 * g->chains;  // (spectra and PCM go chain by chain, each rounded up)
     g->aac_pairs = g->aac_tns = 0;
     g->vb_steps = 0;
@@ -968,6 +981,10 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
                                     reinterpret_cast<const int32_t *>(t.slot + l.state[0])[c], g->param & 255, (g->param >> 8) & 255, &lines, &samples);
                         bulk(t.slot + l.in[0] + c * ps.in[0], g->d_in[0] + ((size_t)t.first_chain + c) * ps.in[0], lines * 4);
                     }
+                    continue;
+                }
+                if (i == 0 && g->row_pitch) {  // compact rows of the slot -> padded rows of the device plane
+                    for (size_t c = 0; c < t.n_chains; ++c) bulk(t.slot + l.in[0] + c * ps.in[0], g->d_in[0] + ((size_t)t.first_chain + c) * g->row_pitch, ps.in[0]);
                     continue;
                 }
                 bulk(t.slot + l.in[i], g->d_in[i] + (ps.in_per_ticket[i] ? ti : (size_t)t.first_chain / ps.in_div[i]) * ps.in[i], l.in_bytes[i]);
@@ -1121,6 +1138,8 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
                                 reinterpret_cast<const int32_t *>(t.slot + l.state[0])[c], g->param & 255, (g->param >> 8) & 255, &lines, &samples);
                     bulk(g->d_out + ((size_t)t.first_chain + c) * ps.out, t.slot + l.out + c * ps.out, samples * 4);
                 }
+            } else if (g->row_pitch) {  // (in place: d_out is d_in[0], padded rows)
+                for (size_t c = 0; c < t.n_chains; ++c) bulk(g->d_out + ((size_t)t.first_chain + c) * g->row_pitch, t.slot + l.out + c * ps.in[0], ps.in[0]);
             } else {
                 bulk(g->d_out + (size_t)t.first_chain * (ps.in_place ? ps.in[0] : ps.out), t.slot + l.out, l.out_bytes);
             }

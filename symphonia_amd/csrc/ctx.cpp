@@ -1057,6 +1057,29 @@ int symaccel_flac_restore_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const
     return launch_flac_restore(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize, d_pair_mode, out_shift);
 }
 
+int symaccel_flac_restore_strided_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
+                                         const int32_t *d_coeffs, const uint8_t *d_pair_mode, uint32_t out_shift, size_t n_blocks,
+                                         size_t blocksize, size_t stride) {
+    if (stride == 0) stride = blocksize;
+    if (!ctx || blocksize > 65535 || stride < blocksize || stride > 0xffffffffu || out_shift > 31) return SYMACCEL_ERR_INVALID_ARG;
+    if (d_pair_mode && (n_blocks & 1)) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!d_buf || !d_desc || !d_coeffs) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_flac_restore(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize, d_pair_mode, d_pair_mode ? out_shift : 0, stride);
+}
+
+// Rows 4, 8, 16 or 32 KiB apart put the 64 row segments (128 B each) a wavefront moves per tile on a fraction of the HBM channels: the FLAC kernel runs 4096-sample
+// blocks at 0.57 of the HBM peak with rows back to back, 0.63 with 256 B of padding, 0.66 with 2 KiB, 0.67-0.68 with 2.5-3 KiB, 0.67 with 4 or 8 KiB (128 B: 0.53,
+// 64 B, which breaks the 128-byte alignment of the segments: 0.42); 1024-sample blocks 0.49 -> 0.62, 2048 0.51 -> 0.64, 8192 0.54 -> 0.67 with an eighth of a row
+// (profiles/r06zz30_stride_sweep.txt, r06zz31_stride_sweep.txt; ALAC: 0.386 -> 0.42).  An eighth of the row keeps the pitch an odd multiple of a power of two.
+size_t symaccel_row_stride(size_t blocksize) {
+    size_t s = (blocksize + 3) & ~(size_t)3;
+    if (s >= 1024 && (s % 512) == 0) s += s / kRowPadDiv;
+    return s;
+}
+
 int symaccel_flac_decorrelate(symaccel_ctx *ctx, const uint8_t *h_mode, int32_t *h_ch0, int32_t *h_ch1, size_t n_pairs,
                               size_t blocksize, uint32_t out_shift) {
     if (!ctx || out_shift > 31) return SYMACCEL_ERR_INVALID_ARG;
@@ -1299,6 +1322,19 @@ int symaccel_alac_predict_stereo_device(symaccel_ctx *ctx, int32_t *d_buf, const
     DeviceGuard dev(ctx);
     if (!dev.ok()) return dev.status();
     return launch_alac_predict(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize, d_pair_weight, d_pair_shift);
+}
+
+int symaccel_alac_predict_strided_device(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc,
+                                         const int32_t *d_coeffs, const int32_t *d_pair_weight, const uint8_t *d_pair_shift,
+                                         size_t n_blocks, size_t blocksize, size_t stride) {
+    if (stride == 0) stride = blocksize;
+    if (!ctx || blocksize > 0xffffffffu || stride < blocksize || stride > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
+    if ((d_pair_weight != nullptr) != (d_pair_shift != nullptr) || (d_pair_weight && (n_blocks & 1))) return SYMACCEL_ERR_INVALID_ARG;
+    if (n_blocks == 0 || blocksize == 0) return SYMACCEL_OK;
+    if (!d_buf || !d_desc || !d_coeffs) return SYMACCEL_ERR_INVALID_ARG;
+    DeviceGuard dev(ctx);
+    if (!dev.ok()) return dev.status();
+    return launch_alac_predict(ctx, d_buf, d_desc, d_coeffs, n_blocks, blocksize, d_pair_weight, d_pair_shift, stride);
 }
 
 int symaccel_alac_predict(symaccel_ctx *ctx, int32_t *h_buf, const symaccel_alac_desc *h_desc, const int32_t *h_coeffs,

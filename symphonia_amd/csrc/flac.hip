@@ -246,8 +246,8 @@ __device__ __forceinline__ void load_params(LaneParams &p, const symaccel_flac_d
 template <bool F64, bool DECOR>
 __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc,
                                                   const int32_t *__restrict__ coeffs, size_t n_blocks,
-                                                  unsigned blocksize, int32_t *tiles, const uint8_t *__restrict__ pair_mode,
-                                                  uint32_t out_shift, uint8_t *row_mode) {
+                                                  unsigned blocksize, unsigned stride, int32_t *tiles,
+                                                  const uint8_t *__restrict__ pair_mode, uint32_t out_shift, uint8_t *row_mode) {
     const int lane = (int)threadIdx.x;
     const size_t blk0 = (size_t)blockIdx.x * kRows;
     const size_t my = blk0 + (size_t)lane;
@@ -264,7 +264,7 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
         c[j] = (T)p.c[j];
         h[j] = (T)0;
     }
-    const bool aligned = (blocksize & 3u) == 0 && blk0 + kRows <= n_blocks;
+    const bool aligned = (stride & 3u) == 0 && blk0 + kRows <= n_blocks;  // rows `stride` words apart (>= blocksize): 16-byte aligned rows
     const unsigned n_tiles = (blocksize + kCols - 1) / kCols;
     TilePrefetch pre;
 #pragma unroll
@@ -281,11 +281,11 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
         if (aligned && cols == (unsigned)kCols)
             tile_commit(pre, tile, lane);
         else
-            tile_fetch_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+            tile_fetch_slow(buf, tile, blk0, n_blocks, stride, t0, cols, lane);
         if (aligned && t0 + 2u * kCols <= blocksize)  // the tile after it is a full one
-            tile_issue_loads(buf, pre, blk0, blocksize, t0 + kCols, lane);
+            tile_issue_loads(buf, pre, blk0, stride, t0 + kCols, lane);
     };
-    if (aligned && blocksize >= (unsigned)kCols) tile_issue_loads(buf, pre, blk0, blocksize, 0, lane);
+    if (aligned && blocksize >= (unsigned)kCols) tile_issue_loads(buf, pre, blk0, stride, 0, lane);
     if (n_tiles > 0) fetch_tile(0);
     wave_sync();
     for (unsigned t = 0; t < n_tiles; ++t) {
@@ -320,35 +320,39 @@ __device__ __forceinline__ void flac_restore_body(int32_t *__restrict__ buf, con
         if (t + 1 < n_tiles) fetch_tile(t + 1);
         if constexpr (DECOR) {
             if (fast)
-                tile_store_decorrelate_fast(buf, tile, row_mode, out_shift, blk0, blocksize, t0, lane);
+                tile_store_decorrelate_fast(buf, tile, row_mode, out_shift, blk0, stride, t0, lane);
             else
-                tile_store_decorrelate_slow(buf, tile, row_mode, out_shift, blk0, n_blocks, blocksize, t0, cols, lane);
+                tile_store_decorrelate_slow(buf, tile, row_mode, out_shift, blk0, n_blocks, stride, t0, cols, lane);
         } else {
             if (fast)
-                tile_store_fast(buf, tile, blk0, blocksize, t0, lane);
+                tile_store_fast(buf, tile, blk0, stride, t0, lane);
             else
-                tile_store_slow(buf, tile, blk0, n_blocks, blocksize, t0, cols, lane);
+                tile_store_slow(buf, tile, blk0, n_blocks, stride, t0, cols, lane);
         }
         wave_sync();  // tile t + 1 is in place for every lane; tile t has been read: the round after next may overwrite it
     }
 }
 
+// (build knob for the A/B on padded rows -- with rows 16 KiB apart three wavefronts per SIMD never moved the time, the row pitch was the bound)
+#ifndef SYM_FLAC_WAVES
+#define SYM_FLAC_WAVES 2
+#endif
 template <bool DECOR>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void flac_restore_f64_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SYM_FLAC_WAVES, SYM_FLAC_WAVES))) void flac_restore_f64_kernel(
     int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
-    size_t n_blocks, unsigned blocksize, const uint8_t *__restrict__ pair_mode, uint32_t out_shift) {
+    size_t n_blocks, unsigned blocksize, unsigned stride, const uint8_t *__restrict__ pair_mode, uint32_t out_shift) {
     __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
     __shared__ uint8_t row_mode[kRows];
-    flac_restore_body<true, DECOR>(buf, desc, coeffs, n_blocks, blocksize, tiles, pair_mode, out_shift, row_mode);
+    flac_restore_body<true, DECOR>(buf, desc, coeffs, n_blocks, blocksize, stride, tiles, pair_mode, out_shift, row_mode);
 }
 
 template <bool DECOR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void flac_restore_i64_kernel(
     int32_t *__restrict__ buf, const symaccel_flac_desc *__restrict__ desc, const int32_t *__restrict__ coeffs,
-    size_t n_blocks, unsigned blocksize, const uint8_t *__restrict__ pair_mode, uint32_t out_shift) {
+    size_t n_blocks, unsigned blocksize, unsigned stride, const uint8_t *__restrict__ pair_mode, uint32_t out_shift) {
     __shared__ __attribute__((aligned(16))) int32_t tiles[2 * kTileWords];
     __shared__ uint8_t row_mode[kRows];
-    flac_restore_body<false, DECOR>(buf, desc, coeffs, n_blocks, blocksize, tiles, pair_mode, out_shift, row_mode);
+    flac_restore_body<false, DECOR>(buf, desc, coeffs, n_blocks, blocksize, stride, tiles, pair_mode, out_shift, row_mode);
 }
 
 // decoder.rs:32-82 + :239-242
@@ -377,20 +381,22 @@ __global__ void flac_decorrelate_kernel(const uint8_t *__restrict__ mode, int32_
 }  // namespace
 
 int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc, const int32_t *d_coeffs,
-                        size_t n_blocks, size_t blocksize, const uint8_t *d_pair_mode, uint32_t out_shift) {
+                        size_t n_blocks, size_t blocksize, const uint8_t *d_pair_mode, uint32_t out_shift, size_t stride) {
+    if (stride == 0) stride = blocksize;  // rows back to back
+    if (stride < blocksize || stride > 0xffffffffu) return SYMACCEL_ERR_INVALID_ARG;
     const size_t grid = (n_blocks + kRows - 1) / kRows;
     if (grid > 0x7fffffffu) return SYMACCEL_ERR_INVALID_ARG;
     const dim3 g((unsigned)grid), b(64);
     if (d_pair_mode) {
         hipLaunchKernelGGL(flac_restore_f64_kernel<true>, g, b, 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
-                           (unsigned)blocksize, d_pair_mode, out_shift);
+                           (unsigned)blocksize, (unsigned)stride, d_pair_mode, out_shift);
         hipLaunchKernelGGL(flac_restore_i64_kernel<true>, g, b, 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
-                           (unsigned)blocksize, d_pair_mode, out_shift);
+                           (unsigned)blocksize, (unsigned)stride, d_pair_mode, out_shift);
     } else {
         hipLaunchKernelGGL(flac_restore_f64_kernel<false>, g, b, 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
-                           (unsigned)blocksize, d_pair_mode, out_shift);
+                           (unsigned)blocksize, (unsigned)stride, d_pair_mode, out_shift);
         hipLaunchKernelGGL(flac_restore_i64_kernel<false>, g, b, 0, ctx->stream, d_buf, d_desc, d_coeffs, n_blocks,
-                           (unsigned)blocksize, d_pair_mode, out_shift);
+                           (unsigned)blocksize, (unsigned)stride, d_pair_mode, out_shift);
     }
     SYM_GPU(ctx, hipGetLastError());
     return SYMACCEL_OK;

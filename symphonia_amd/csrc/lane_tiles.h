@@ -24,12 +24,12 @@ struct TilePrefetch {
     int4 v[8];
 };
 __device__ __forceinline__ void tile_issue_loads(const int32_t *__restrict__ buf, TilePrefetch &p, size_t blk0,
-                                                 unsigned blocksize, unsigned t0, int lane) {
+                                                 unsigned stride, unsigned t0, int lane) {
     const int q = lane & 7, rsub = lane >> 3;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = 8 * k + rsub;
-        p.v[k] = ld_stream(reinterpret_cast<const int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q));
+        p.v[k] = ld_stream(reinterpret_cast<const int4 *>(buf + (blk0 + (size_t)r) * stride + t0 + 4u * (unsigned)q));
     }
 }
 __device__ __forceinline__ void tile_commit(const TilePrefetch &p, int32_t *tile, int lane) {
@@ -38,18 +38,18 @@ __device__ __forceinline__ void tile_commit(const TilePrefetch &p, int32_t *tile
     for (int k = 0; k < 8; ++k) *reinterpret_cast<int4 *>(tile + (8 * k + rsub) * kStride + 4 * q) = p.v[k];
 }
 __device__ __forceinline__ void tile_store_fast(int32_t *__restrict__ buf, const int32_t *tile, size_t blk0,
-                                                unsigned blocksize, unsigned t0, int lane) {
+                                                unsigned stride, unsigned t0, int lane) {
     const int q = lane & 7, rsub = lane >> 3;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = 8 * k + rsub;
-        st_stream(reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * blocksize + t0 + 4u * (unsigned)q),
+        st_stream(reinterpret_cast<int4 *>(buf + (blk0 + (size_t)r) * stride + t0 + 4u * (unsigned)q),
                   *reinterpret_cast<const int4 *>(tile + r * kStride + 4 * q));
     }
 }
 // Ragged tiles (last columns of a block size that is not a multiple of 32, unaligned rows, last subframes).
 __device__ __forceinline__ void tile_fetch_slow(const int32_t *__restrict__ buf, int32_t *tile, size_t blk0, size_t n_blocks,
-                                                unsigned blocksize, unsigned t0, unsigned cols, int lane) {
+                                                unsigned stride, unsigned t0, unsigned cols, int lane) {
     const int c = lane & 31, rsub = lane >> 5;
 #pragma unroll 1
     for (int r0 = 0; r0 < kRows; r0 += 16) {
@@ -57,19 +57,19 @@ __device__ __forceinline__ void tile_fetch_slow(const int32_t *__restrict__ buf,
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const size_t b = blk0 + (size_t)(r0 + 2 * k + rsub);
-            v[k] = (b < n_blocks && (unsigned)c < cols) ? buf[b * blocksize + t0 + (unsigned)c] : 0;
+            v[k] = (b < n_blocks && (unsigned)c < cols) ? buf[b * stride + t0 + (unsigned)c] : 0;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) tile[(r0 + 2 * k + rsub) * kStride + c] = v[k];
     }
 }
 __device__ __forceinline__ void tile_store_slow(int32_t *__restrict__ buf, const int32_t *tile, size_t blk0, size_t n_blocks,
-                                                unsigned blocksize, unsigned t0, unsigned cols, int lane) {
+                                                unsigned stride, unsigned t0, unsigned cols, int lane) {
     const int c = lane & 31, rsub = lane >> 5;
 #pragma unroll 4
     for (int r = rsub; r < kRows; r += 2) {
         if (blk0 + (size_t)r < n_blocks && (unsigned)c < cols)
-            buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)c] = tile[r * kStride + c];
+            buf[(blk0 + (size_t)r) * stride + t0 + (unsigned)c] = tile[r * kStride + c];
     }
 }
 
@@ -111,12 +111,14 @@ __device__ __forceinline__ void flac_decorrelate_pair(int32_t a, int32_t b, int3
 // branches on it once -- an independent pair costs two shifts per sample pair, a mid/side pair nine instructions, instead of the 21 of
 // the branch-free form for every pair (round 5's form, kept as 0: it wins only when all four modes meet in most wavefront rounds).
 // The branch is per ROUND, not per sample: round 5 removed a compiler-built tree of divergent branches per sample.
+// Measured: with rows 16 KiB apart both forms take the same 7.65 ms for config 5 (the row pitch was the bound: profiles/r06l..); on rows at
+// symaccel_row_stride() the switch is 1.2 % ahead, 6.89 against 6.975 ms, twice in alternation (profiles/r06zz33_flac_variants_ab.txt) -- default since.
 #ifndef SYM_FLAC_STORE_SWITCH
-#define SYM_FLAC_STORE_SWITCH 0
+#define SYM_FLAC_STORE_SWITCH 1
 #endif
 __device__ __forceinline__ void tile_store_decorrelate_fast(int32_t *__restrict__ buf, const int32_t *tile,
                                                             const uint8_t *row_mode, uint32_t out_shift, size_t blk0,
-                                                            unsigned blocksize, unsigned t0, int lane) {
+                                                            unsigned stride, unsigned t0, int lane) {
     const int q = lane & 7, psub = lane >> 3;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {  // (not unrolled: the FP64 kernel has no register to spare for two rounds in flight)
@@ -151,20 +153,20 @@ __device__ __forceinline__ void tile_store_decorrelate_fast(int32_t *__restrict_
         flac_decorrelate_pair(a.z, b.z, is1, is2, is3, out_shift, o0.z, o1.z);
         flac_decorrelate_pair(a.w, b.w, is1, is2, is3, out_shift, o0.w, o1.w);
 #endif
-        int32_t *dst = buf + (blk0 + (size_t)r0) * blocksize + t0 + 4u * (unsigned)q;
+        int32_t *dst = buf + (blk0 + (size_t)r0) * stride + t0 + 4u * (unsigned)q;
         st_stream(reinterpret_cast<int4 *>(dst), o0);
-        st_stream(reinterpret_cast<int4 *>(dst + blocksize), o1);
+        st_stream(reinterpret_cast<int4 *>(dst + stride), o1);
     }
 }
 __device__ __forceinline__ void tile_store_decorrelate_slow(int32_t *__restrict__ buf, const int32_t *tile,
                                                             const uint8_t *row_mode, uint32_t out_shift, size_t blk0,
-                                                            size_t n_blocks, unsigned blocksize, unsigned t0, unsigned cols,
+                                                            size_t n_blocks, unsigned stride, unsigned t0, unsigned cols,
                                                             int lane) {
     const int c = lane & 31, rsub = lane >> 5;
 #pragma unroll 4
     for (int r = rsub; r < kRows; r += 2) {
         if (blk0 + (size_t)r < n_blocks && (unsigned)c < cols)
-            buf[(blk0 + (size_t)r) * blocksize + t0 + (unsigned)c] =
+            buf[(blk0 + (size_t)r) * stride + t0 + (unsigned)c] =
                 flac_decorrelated(row_mode[r], (r & 1) != 0, tile[r * kStride + c], tile[(r ^ 1) * kStride + c], out_shift);
     }
 }

@@ -269,7 +269,7 @@ int launch_mpa_polyphase(symaccel_ctx *ctx, int n_frames, const float *d_in, con
                          size_t packets_per_chain);
 int launch_alac_predict(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_alac_desc *d_desc, const int32_t *d_coeffs,
                         size_t n_blocks, size_t blocksize, const int32_t *d_pair_weight = nullptr,
-                        const uint8_t *d_pair_shift = nullptr);
+                        const uint8_t *d_pair_shift = nullptr, size_t stride = 0 /* words between rows; 0 = blocksize */);
 int launch_alac_mid_side(symaccel_ctx *ctx, const int32_t *d_weight, const uint8_t *d_shift, int32_t *d_ch0, int32_t *d_ch1,
                          size_t n_pairs, size_t blocksize);
 int launch_state_copy(symaccel_ctx *ctx, void *dst0, const void *src0, size_t bytes0, void *dst1, const void *src1,
@@ -278,9 +278,12 @@ int launch_flac_status(symaccel_ctx *ctx, const symaccel_flac_desc *d_desc, size
 int launch_alac_status(symaccel_ctx *ctx, const symaccel_alac_desc *d_desc, size_t n, int8_t *d_status);
 int launch_floor1_status(symaccel_ctx *ctx, const uint32_t *d_y, size_t count, int n_posts, int8_t *d_status);
 int launch_tns_status(symaccel_ctx *ctx, const symaccel_aac_tns_filter *d_filters, size_t n, size_t n_frames, int8_t *d_status);
+// symaccel_row_stride() pads rows that are a multiple of 2 KiB long (1024 samples and more) by this fraction of the row; the sweeps behind it:
+// profiles/r06zz30_stride_sweep.txt, r06zz31_stride_sweep.txt
+constexpr size_t kRowPadDiv = 8;
 int launch_flac_restore(symaccel_ctx *ctx, int32_t *d_buf, const symaccel_flac_desc *d_desc,
                         const int32_t *d_coeffs, size_t n_blocks, size_t blocksize, const uint8_t *d_pair_mode = nullptr,
-                        uint32_t out_shift = 0);
+                        uint32_t out_shift = 0, size_t stride = 0 /* words between rows; 0 = blocksize */);
 // batch_copy.hip: one piece (<= kBatchCopyPiece bytes) per workgroup, host (page-locked) <-> device in either direction
 struct BatchCopyDesc {
     const void *src;

@@ -35,7 +35,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(lib):
     for name in declared_symbols():
         assert hasattr(lib.dll, name), name
-    assert lib.dll.symaccel_abi_version() == 7
+    assert lib.dll.symaccel_abi_version() == 8
 
 
 def test_strerror_is_static_text(lib):

@@ -172,6 +172,13 @@ def test_emu_flac_streams_share_a_launch(emu_ctx):
     run_flac(emu_ctx)
 
 
+def test_emu_flac_streams_padded_device_rows(emu_ctx):
+    """1024-sample blocks: the group's device plane has its rows at symaccel_row_stride(1024) = 1152 words (gather / scatter row by row),
+    the slots stay compact; the same streams with SYMACCEL_BATCH_ROW_PAD=0 would take the compact plane -- both bit-equal to the oracle"""
+    assert emu_ctx.lib.dll.symaccel_row_stride(1024) == 1152
+    run_flac(emu_ctx, 1024)
+
+
 def alac_stream(rng, nb, blocksize):
     from test_alac import alac_case
     buf, mode, order, shift, bps, coeffs = alac_case(int(rng.integers(1 << 30)), nb, blocksize)
@@ -221,6 +228,10 @@ def run_alac(ctx, blocksize=100):
 
 def test_emu_alac_streams_share_a_launch(emu_ctx):
     run_alac(emu_ctx)
+
+
+def test_emu_alac_streams_padded_device_rows(emu_ctx):
+    run_alac(emu_ctx, 1024)
 
 
 # ------------------------------------------------------------------------------------------------ per-ticket status, lanes
@@ -343,6 +354,8 @@ def test_gpu_new_kinds_and_ticket_status(gpu_ctx):
     run_flac(gpu_ctx, 4096)
     run_alac(gpu_ctx, 100)
     run_alac(gpu_ctx, 4096)
+    run_flac(gpu_ctx, 1024)
+    run_alac(gpu_ctx, 2048)
     run_bad_aac_blob(gpu_ctx)
     run_lanes(gpu_ctx, 1, 6, 4)
     run_lanes(gpu_ctx, 3, 6, 4)

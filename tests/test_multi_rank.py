@@ -163,12 +163,12 @@ def test_bench_line_carries_the_other_workloads():
     r, d = _bench(["--emulate", "--scale", "0.0001", "--steps", "2", "--warmup", "1"], timeout=600)
     assert r.returncode == 0 and d is not None, r.stderr[-3000:]
     ow = d["other_workloads"]
-    assert set(ow) == {"mp3", "vorbis", "flac", "alac", "aac_mix_0.05", "aac_mix_0.25", "mp3_mix_0.06", "mp3_int16_one_kernel", "mp3_int16_two_kernels",
+    assert set(ow) == {"mp3", "vorbis", "flac", "alac", "flac_padded_rows", "alac_padded_rows", "aac_mix_0.05", "aac_mix_0.25", "mp3_mix_0.06", "mp3_int16_one_kernel", "mp3_int16_two_kernels",
                        "vorbis_posts_byte_plane", "vorbis_posts_f32_spectrum",
                        "aac_joint_stereo_on_load", "aac_joint_stereo_two_kernels", "aac_tns_0.30"}
     for name, line in ow.items():
         assert "error" not in line, (name, line)
-        assert line["steps"] == (8 if name in ("flac", "alac") else 20) and line["value"] > 0 and line["algorithmic_bytes_per_launch"] > 0
+        assert line["steps"] == (8 if name in ("flac", "alac", "flac_padded_rows", "alac_padded_rows") else 20) and line["value"] > 0 and line["algorithmic_bytes_per_launch"] > 0
         if name.startswith(("aac", "mp3", "vorbis", "flac", "alac")) and "int16" not in name and "two_kernels" not in name:  # the timed batch itself is compared with the oracle (sampled chains / blocks), mixes included
             assert line["verified"]["mismatches"] == 0 and line["verified"]["samples_compared"] > 0
         if "mix" in name:
@@ -176,3 +176,4 @@ def test_bench_line_carries_the_other_workloads():
         assert abs(line["roofline_frac"] - line["algorithmic_bytes_per_launch"] / (line["kernel_ms"] / 1e3) / 1e9 / 8000.0) < 1e-9
     assert d["verified"]["mismatches"] == 0 and d["schema"] == 5 and "protocol" in d and (d.get("repeats") is None or d["repeats"]["regions"] >= 5)
     assert ow["flac"]["kernel"] == "flac_restore_f64_kernel" and ow["mp3"]["kernel"] == "mp3_synth_kernel"
+    assert "rows 4608 words apart" in ow["flac_padded_rows"]["workload"] and "rows 4608 words apart" in ow["alac_padded_rows"]["workload"]

@@ -20,7 +20,7 @@ CASES = [
     ({"SYMACCEL_TUNE_MP3_PACKED": "0", "SYMACCEL_TUNE_MP3_PAIR_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "1"}, "tests/test_emu_codecs.py", "emu_mp3"),
     ({"SYMACCEL_TUNE_MP3_SLOT_GROUP": "18"}, "tests/test_emu_codecs.py", "emu_mp3"),
-    ({"SYMACCEL_TUNE_FLAC_PARTS": "4"}, "tests/test_emu_codecs.py", "emu_flac"),
+    ({"SYMACCEL_TUNE_FLAC_PARTS": "4", "SYMACCEL_TUNE_FLAC_STORE_SWITCH": "0"}, "tests/test_emu_codecs.py tests/test_row_stride.py", "emu_flac"),
     # round 6: the knobs of the last session's A/Bs (profiles/r06zz3 .. r06zz17), several per build (one emulation library each)
     ({"SYMACCEL_TUNE_FLAC_GROUP": "4", "SYMACCEL_TUNE_FLAC_OLDEST_FIRST": "1", "SYMACCEL_TUNE_ALAC_UPDATE": "0", "SYMACCEL_TUNE_MP3_FRONT": "3",
       "SYMACCEL_TUNE_F1_LANE16": "0"}, "tests/test_emu_codecs.py tests/test_alac.py tests/test_mp3_stereo.py tests/test_vorbis_floor_y.py",

@@ -81,7 +81,7 @@ def parse(text):
                 fields.append((am.group(1), ft, int(am.group(2))) if am else (n, ft, None))
         structs.append((m.group(3), fields))
     funcs = []
-    for m in re.finditer(r"^(int|void|const char \*)\s*(symaccel_\w+)\(([^;{]*?)\);", text, flags=re.S | re.M):
+    for m in re.finditer(r"^(int|void|size_t|const char \*)\s*(symaccel_\w+)\(([^;{]*?)\);", text, flags=re.S | re.M):
         params = []
         body = " ".join(m.group(3).split())
         if body not in ("void", ""):
@@ -127,7 +127,7 @@ def generate():
     out += ['#[link(name = "symaccel")]', 'unsafe extern "C" {']
     for name, ret, params in funcs:
         args = ", ".join("%s: %s" % (pn, rust_type(pt)) for pn, pt in params)
-        rret = {"int": " -> i32", "void": "", "const char *": " -> *const core::ffi::c_char"}[ret]
+        rret = {"int": " -> i32", "void": "", "size_t": " -> usize", "const char *": " -> *const core::ffi::c_char"}[ret]
         out.append("    pub fn %s(%s)%s;" % (name, args, rret))
     out += ["}", ""]
     return "\n".join(out), structs, funcs
