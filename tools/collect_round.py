@@ -20,7 +20,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tools"))
 import rocpd_summary  # noqa: E402
 
-WORKLOADS = ["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "vorbisf", "aacjs", "aactns"]
+WORKLOADS = ["aac", "mp3", "vorbis", "flac", "alac", "mp3q", "vorbisf", "aacjs", "aactns", "flacp", "alacp"]
 
 
 def pmc_avg(db, kernel, counter):
@@ -33,7 +33,7 @@ def pmc_avg(db, kernel, counter):
 KERNELS = {"aac": "aac_synth_quad_kernel", "mp3": "mp3_synth_kernel", "vorbis": "vorbis_synth_wave_kernel",
            "flac": "flac_restore_f64_kernel", "mp3q": "mp3_synth_kernel<4, true>", "vorbisf": "vorbis_synth_wave_kernel<2>", "aacjs": "aac_synth_quad_kernel<true>", "aactns": "aac_synth_quad_kernel<true>",
            # (four instantiations are launched per step and three return at once: count the one the workload's wavefronts run in)
-           "alac": "alac_predict_kernel<false, true, true>"}
+           "alac": "alac_predict_kernel<false, true, true>", "flacp": "flac_restore_f64_kernel", "alacp": "alac_predict_kernel<false, true, true>"}
 
 
 def bench_line(path):
