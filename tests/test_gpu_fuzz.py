@@ -159,6 +159,31 @@ def test_fuzz_flac_alac(ctx, it):
 
 
 @pytest.mark.parametrize("it", range(ITERS))
+def test_fuzz_flac_alac_strided(ctx, it):
+    """the strided entry points (ABI 8) at random pitches -- the recommended one, aligned and unaligned pads, none --, plain and fused stereo:
+    rows == the oracle on the compact rows, the padding untouched"""
+    from symphonia_amd import AlacPredictor, FlacPredictor, alac_desc, flac_desc
+    from test_alac import alac_case
+    from test_row_stride import alac_want, check, flac_case, flac_want, padded
+    rng = np.random.default_rng(9000 + it)
+    nb = int(rng.choice([2, 62, 64, 66, 130, 258]))
+    bs = int(rng.choice([1, 31, 32, 33, 100, 576, 1024, 1152, 2048, 4096]))
+    stride = int(rng.choice([bs, ctx.lib.dll.symaccel_row_stride(bs), bs + 1, bs + 4, bs + 64, bs + int(rng.integers(1, 200))]))
+    fused = bool(rng.integers(0, 2))
+    buf, kind, order, shift, wasted, coeffs, mode = flac_case(9100 + it, nb, bs)
+    d = dev(padded(buf, stride))
+    FlacPredictor(ctx).restore_strided(d, dev(flac_desc(kind, order, shift, wasted).view(np.uint8).reshape(nb, 4)), dev(coeffs), bs,
+                                       pair_mode=dev(mode) if fused else None, out_shift=8 if fused else 0)
+    check(host(d), flac_want(buf, kind, order, shift, wasted, coeffs, mode if fused else None, 8), bs)
+    res, amode, aorder, ashift, bps, acoef = alac_case(9200 + it, nb, bs)
+    weight, msh = rng.integers(-3, 4, nb // 2).astype(np.int32), rng.integers(0, 32, nb // 2).astype(np.uint8)
+    d = dev(padded(res, stride))
+    AlacPredictor(ctx).predict_strided(d, dev(alac_desc(amode, aorder, ashift, bps).view(np.uint8).reshape(nb, 4)), dev(acoef), bs,
+                                       dev(weight) if fused else None, dev(msh) if fused else None)
+    check(host(d), alac_want(res, amode, aorder, ashift, bps, acoef, weight if fused else None, msh if fused else None), bs)
+
+
+@pytest.mark.parametrize("it", range(ITERS))
 def test_fuzz_mp3_front(ctx, it):
     """requantize (+ stereo, separately and fused) for random shapes / sample rates."""
     from symphonia_amd import Mp3Requantize, Mp3Stereo
