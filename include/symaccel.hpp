@@ -426,6 +426,16 @@ inline void restore_batch(Context &ctx, std::int32_t *buf, const symaccel_flac_d
                           std::size_t n_blocks, std::size_t blocksize) {
     check(symaccel_flac_restore(ctx.raw(), buf, desc, coeffs, n_blocks, blocksize), ctx.raw());
 }
+// A caller that owns a device batch plane (as the Batcher does for its FLAC / ALAC groups) gives its rows this pitch, in words: rows a power-of-two number of KiB
+// apart -- 4096-sample blocks back to back -- alias on the HBM channels (symaccel_row_stride, include/symaccel.h; the reference has no counterpart: one Vec<i32>
+// per channel, decoder.rs:199-242).  The device form over such a plane: the first `blocksize` words of a row are the subframe, the padding is left alone;
+// d_pair_mode null = restore only, else restore + decorrelate + `<< out_shift` (decoder.rs:199-242 in one pass).
+inline std::size_t row_stride(std::size_t blocksize) { return symaccel_row_stride(blocksize); }
+inline void restore_strided_device(Context &ctx, std::int32_t *d_buf, const symaccel_flac_desc *d_desc, const std::int32_t *d_coeffs,
+                                   const std::uint8_t *d_pair_mode, std::uint32_t out_shift, std::size_t n_blocks, std::size_t blocksize,
+                                   std::size_t stride) {
+    check(symaccel_flac_restore_strided_device(ctx.raw(), d_buf, d_desc, d_coeffs, d_pair_mode, out_shift, n_blocks, blocksize, stride), ctx.raw());
+}
 namespace detail {
 inline void decorrelate(Context &ctx, std::uint8_t mode, std::int32_t *ch0, std::int32_t *ch1, std::size_t len) {
     check(symaccel_flac_decorrelate(ctx.raw(), &mode, ch0, ch1, 1, len, 0), ctx.raw());
@@ -466,6 +476,13 @@ struct ElementChannel {
 inline void predict_batch(Context &ctx, std::int32_t *buf, const symaccel_alac_desc *desc, const std::int32_t *coeffs,
                           std::size_t n_blocks, std::size_t blocksize) {
     check(symaccel_alac_predict(ctx.raw(), buf, desc, coeffs, n_blocks, blocksize), ctx.raw());
+}
+// predict over a device plane whose rows are `stride` words apart (flac::row_stride); d_pair_weight / d_pair_shift null = predict only, else with
+// decorrelate_mid_side fused (lib.rs:541-560)
+inline void predict_strided_device(Context &ctx, std::int32_t *d_buf, const symaccel_alac_desc *d_desc, const std::int32_t *d_coeffs,
+                                   const std::int32_t *d_pair_weight, const std::uint8_t *d_pair_shift, std::size_t n_blocks,
+                                   std::size_t blocksize, std::size_t stride) {
+    check(symaccel_alac_predict_strided_device(ctx.raw(), d_buf, d_desc, d_coeffs, d_pair_weight, d_pair_shift, n_blocks, blocksize, stride), ctx.raw());
 }
 // decorrelate_mid_side(out0, out1, weight, shift) (lib.rs:664-671)
 inline void decorrelate_mid_side(Context &ctx, std::int32_t *out0, std::int32_t *out1, std::size_t len, std::int32_t weight,

@@ -222,6 +222,7 @@ static void verify_flac(Context &ctx) {  // decode_linear / decode_fixed_linear 
         so_flac_fixed_predict((int)order, ref.data(), ref.size());
         EXPECT(buf == ref, "fixed_predict order %zu", order);
     }
+    EXPECT(flac::row_stride(4096) == 4608 && flac::row_stride(4000) == 4000 && flac::row_stride(1023) == 1152, "row_stride");
     std::vector<std::int32_t> a(777), b(777), ra, rb;
     for (auto &v : a) v = (std::int32_t)rng();
     for (auto &v : b) v = (std::int32_t)rng();
