@@ -825,7 +825,7 @@ int launch_group_inner(Lane *lane, Group *g, uint64_t *n_chunks, uint64_t *api_n
         bound += pieces_of((ps.in_place ? ps.in[0] : ps.out) * v.n_chains);
     }
     bound += g->tickets + 8;  // (the unit list's pieces, one per chunk at most)
-    // FLAC / ALAC: the device plane's rows at the pitch the lane-per-block kernels run fastest at (symaccel_row_stride: rows a multiple of 2 KiB apart -- the
+    // FLAC / ALAC: the device plane's rows at the pitch the lane-per-block kernels run fastest at (symaccel_row_stride: rows 4 / 8 / 16 / 32 KiB apart -- the
     // 4096-sample blocks of nearly every stream -- put a wavefront's 64 row segments on a fraction of the HBM channels); the slots stay compact, the
     // gather / scatter go row by row (development knob: SYMACCEL_BATCH_ROW_PAD=0 keeps the rows back to back)
     static const bool row_pad = [] {

@@ -1073,7 +1073,8 @@ int symaccel_flac_restore_strided_device(symaccel_ctx *ctx, int32_t *d_buf, cons
 // Rows 4, 8, 16 or 32 KiB apart put the 64 row segments (128 B each) a wavefront moves per tile on a fraction of the HBM channels: the FLAC kernel runs 4096-sample
 // blocks at 0.57 of the HBM peak with rows back to back, 0.63 with 256 B of padding, 0.66 with 2 KiB, 0.67-0.68 with 2.5-3 KiB, 0.67 with 4 or 8 KiB (128 B: 0.53,
 // 64 B, which breaks the 128-byte alignment of the segments: 0.42); 1024-sample blocks 0.49 -> 0.62, 2048 0.51 -> 0.64, 8192 0.54 -> 0.67 with an eighth of a row
-// (profiles/r06zz30_stride_sweep.txt, r06zz31_stride_sweep.txt; ALAC: 0.386 -> 0.42).  An eighth of the row keeps the pitch an odd multiple of a power of two.
+// (profiles/r06zz30_stride_sweep.txt, r06zz31_stride_sweep.txt; ALAC: 0.386 -> 0.42).  What spreads the segments is where a row STARTS modulo 16 KiB:
+// dealing a wavefront rows that are 80 KiB apart in the compact plane changes nothing (profiles/r06zz34_interleave_ab.txt); an eighth of the row steps the starts by 2 KiB (4096-sample rows).
 size_t symaccel_row_stride(size_t blocksize) {
     size_t s = (blocksize + 3) & ~(size_t)3;
     if (s >= 1024 && (s % 512) == 0) s += s / kRowPadDiv;
