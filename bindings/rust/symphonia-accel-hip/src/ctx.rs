@@ -77,15 +77,29 @@ unsafe impl Send for Pool {}
 unsafe impl Sync for Pool {}
 
 static POOL: Mutex<Option<Arc<Pool>>> = Mutex::new(None);
+static POOL_DEVICE: Mutex<i32> = Mutex::new(0);
 
 impl Pool {
-    /// The shared pool, created on first use (device 0, the library's default flush size).
+    /// The device the shared pool is created on (default 0).  One process per GPU: a launcher that does not narrow the visible
+    /// devices per rank calls this with the local rank BEFORE `register()` / the first decoder; once the pool exists it stays
+    /// where it is and the call returns `false`.
+    pub fn set_device(device: i32) -> bool {
+        let slot = POOL.lock().expect("pool poisoned");
+        if slot.is_some() {
+            return false;
+        }
+        *POOL_DEVICE.lock().expect("pool poisoned") = device;
+        true
+    }
+
+    /// The shared pool, created on first use (the device of `set_device`, the library's default flush size).
     pub fn shared() -> Result<Arc<Pool>> {
         let mut slot = POOL.lock().expect("pool poisoned");
         if let Some(pool) = slot.as_ref() {
             return Ok(pool.clone());
         }
-        let ctx = Context::new(0)?;
+        let device = *POOL_DEVICE.lock().expect("pool poisoned");
+        let ctx = Context::new(device)?;
         let mut batcher = ptr::null_mut();
         // SAFETY: valid context, valid out-pointer.
         check(unsafe { ffi::symaccel_batcher_create(ctx.raw(), 0, &mut batcher) }, ctx.raw())?;

@@ -542,6 +542,18 @@ def test_two_pooled_alac_adapters_share_the_batcher(make_dll):
     assert stats["launches"] < stats["submissions"] and stats["failed_tickets"] == 0, stats
 
 
+def test_pool_set_device_only_before_the_pool_exists():
+    """ctx.rs `Pool::set_device`: one process per GPU picks the shared pool's device before the first decoder; the context is created
+    on THAT device (symaccel_ctx_create's first argument), and once the pool exists the call is refused"""
+    h = harness(emu_dll, "aac.rs")
+    assert h.it.call("Pool::set_device", I.Int(0, "i32")) is True
+    n0 = h.bridge.calls.count("symaccel_ctx_create")
+    assert h.it.call("Pool::shared").variant == "Ok"
+    assert h.bridge.calls.count("symaccel_ctx_create") == n0 + 1 and h.bridge.calls.count("symaccel_batcher_create") == 1
+    assert h.it.call("Pool::set_device", I.Int(1, "i32")) is False
+    assert h.it.call("Pool::shared").variant == "Ok" and h.bridge.calls.count("symaccel_batcher_create") == 1
+
+
 def test_register_enters_all_five_decoders_at_the_preferred_tier():
     """lib.rs `register()` EXECUTED: every decoder type of the crate is entered for its codec at Tier::Preferred through
     `register_audio_decoder_at_tier::<D>` (codecs/registry.rs:252-269), above whatever the registry held (remembered: fallback.rs)"""
